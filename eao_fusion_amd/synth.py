@@ -1,0 +1,166 @@
+"""Deterministic synthetic workloads.  There is no dataset in the reference tree
+(data/rgb_full_demo.txt is an index of file names only), so every benchmark/parity input is generated here.
+
+frames  : config 2 -- 640x480 u8 "rectangle world" images, seed 1000+f
+hamming : config 3 -- 1000x32-byte descriptor sets, seed 2000 (+ planted variant, seed 2001)
+ba      : config 4 -- 24 cameras (4 fixed + 20 free) x 3000 points, stereo observations, seed 3000
+pose    : PoseOptimization problem (one frame, N matched map points)
+"""
+import numpy as np
+
+# reference camera (ros_test/config/TUM3.yaml:8-11,25)
+FX, FY, CX, CY, BF = 535.4, 539.2, 320.1, 247.6, 40.0
+
+
+def synth_frame(seed, w=640, h=480, n_rect=400, n_small=1000):
+    """"Rectangle world": background 96; n_rect large (20..w/2 x 20..h/2) then n_small small (3..23 px)
+    axis-aligned rectangles with uniform origins and intensity U[0,255] painted in order (clipped at the
+    image edge); 3x3 box blur; additive integer noise U[-3,3]; clamp.  Returns (h, w) uint8.
+    Defaults give ~3000 FAST corners at threshold 20 on level 0 (every per-level quota over-subscribed,
+    so the quad-tree distribution is exercised); n_rect=40, n_small=0 is the low-texture variant that
+    drives cells into the minThFAST retry."""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 96, dtype=np.int32)
+    n = n_rect + n_small
+    x0 = rng.integers(0, w, n)
+    y0 = rng.integers(0, h, n)
+    bw = np.concatenate([rng.integers(20, max(w // 2, 21), n_rect), rng.integers(3, 24, n_small)])
+    bh = np.concatenate([rng.integers(20, max(h // 2, 21), n_rect), rng.integers(3, 24, n_small)])
+    val = rng.integers(0, 256, n)
+    for i in range(n):
+        img[y0[i]:y0[i] + bh[i], x0[i]:x0[i] + bw[i]] = val[i]
+    pad = np.pad(img, 1, mode="edge")
+    acc = np.zeros_like(img)
+    for dy in range(3):
+        for dx in range(3):
+            acc += pad[dy:dy + h, dx:dx + w]
+    img = (acc + 4) // 9
+    img = img + rng.integers(-3, 4, size=(h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_frames(batch, seed0=1000, w=640, h=480, n_rect=400, n_small=1000):
+    return np.stack([synth_frame(seed0 + f, w, h, n_rect, n_small) for f in range(batch)])
+
+
+def synth_descriptors(n=1000, seed=2000):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    return a, b
+
+
+def synth_descriptors_planted(n=1000, seed=2001, flip=0.08):
+    """B = permuted A with each bit flipped w.p. `flip` so ratio-test paths fire."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    perm = rng.permutation(n)
+    bits = np.unpackbits(a[perm], axis=1)
+    bits ^= (rng.random(bits.shape) < flip).astype(np.uint8)
+    return a, np.packbits(bits, axis=1), perm
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_frac=0.05, mono_frac=0.0):
+    """Local-BA window.  Cameras on a 1 m arc facing a common volume; ids 0..n_fixed-1 fixed.
+    Point i is observed by m_i = 2 + (i mod 7) cameras (i*7919 + j) mod n_cams.
+    Returns a dict of float32/int32 arrays shaped as the C-ABI wants them (eao_ba_problem):
+      poses   (n_cams, 4, 4) f32 Tcw   (perturbed for free cameras)
+      fixed   (n_cams,) u8
+      points  (n_points, 3) f32 (perturbed)
+      edge_point, edge_cam (E,) i32 ; obs (E,3) f32 (u, v, ur; ur<0 = monocular) ; inv_sigma2 (E,) f32
+      plus ground truth: poses_gt, points_gt
+    Edge order = for each point (index order), its observations in ascending camera id (the reference iterates
+    a std::map<KeyFrame*,size_t>, i.e. pointer order; ascending id is this build's deterministic stand-in)."""
+    rng = np.random.default_rng(seed)
+    n_cams = n_free + n_fixed
+    pts = np.empty((n_points, 3))
+    pts[:, 0] = rng.uniform(-2.0, 2.0, n_points)
+    pts[:, 1] = rng.uniform(-1.5, 1.5, n_points)
+    pts[:, 2] = rng.uniform(2.0, 5.0, n_points)
+    poses = np.zeros((n_cams, 4, 4))
+    for c in range(n_cams):
+        t = c / max(n_cams - 1, 1) - 0.5            # camera centres along a 1 m arc
+        centre = np.array([t, 0.05 * np.sin(6 * t), 0.1 * t * t])
+        Rwc = _rot(0.02 * np.sin(3 * t), -0.15 * t, 0.01 * t)   # look roughly at the volume centre
+        Rcw = Rwc.T
+        poses[c, :3, :3] = Rcw
+        poses[c, :3, 3] = -Rcw @ centre
+        poses[c, 3, 3] = 1
+    e_pt, e_cam = [], []
+    for i in range(n_points):
+        m = 2 + (i % 7)
+        cams = sorted({(i * 7919 + j) % n_cams for j in range(m)})
+        for c in cams:
+            e_pt.append(i)
+            e_cam.append(c)
+    e_pt = np.array(e_pt, dtype=np.int32)
+    e_cam = np.array(e_cam, dtype=np.int32)
+    E = len(e_pt)
+    octave = rng.integers(0, 8, size=E)
+    inv_sigma2 = (np.float32(1.0) / (np.float32(1.2) ** (2 * octave)).astype(np.float32)).astype(np.float32)
+    Xc = np.einsum("eij,ej->ei", poses[e_cam, :3, :3], pts[e_pt]) + poses[e_cam, :3, 3]
+    u = FX * Xc[:, 0] / Xc[:, 2] + CX
+    v = FY * Xc[:, 1] / Xc[:, 2] + CY
+    noise = rng.normal(0.0, 1.0, size=(E, 3)) * (sigma * 1.2 ** octave)[:, None]
+    out = rng.random(E) < outlier_frac
+    noise[out, :2] += rng.uniform(10, 30, size=(int(out.sum()), 2)) * rng.choice([-1, 1], size=(int(out.sum()), 2))
+    ur = u - BF / Xc[:, 2]
+    obs = np.stack([u + noise[:, 0], v + noise[:, 1], ur + noise[:, 0] + 0.3 * noise[:, 2]], axis=1)
+    mono = rng.random(E) < mono_frac
+    obs[mono, 2] = -1.0
+    fixed = np.zeros(n_cams, dtype=np.uint8)
+    fixed[:n_fixed] = 1
+    poses_init = poses.copy()
+    for c in range(n_fixed, n_cams):
+        d = _rot(*(rng.normal(0, np.deg2rad(0.5), 3)))
+        poses_init[c, :3, :3] = d @ poses[c, :3, :3]
+        poses_init[c, :3, 3] = d @ poses[c, :3, 3] + rng.normal(0, 0.01, 3)
+    pts_init = pts + rng.normal(0, 0.02, size=pts.shape)
+    return dict(
+        poses=poses_init.astype(np.float32), fixed=fixed, points=pts_init.astype(np.float32),
+        edge_point=e_pt, edge_cam=e_cam, obs=obs.astype(np.float32), inv_sigma2=inv_sigma2,
+        poses_gt=poses.astype(np.float32), points_gt=pts.astype(np.float32),
+        fx=np.float32(FX), fy=np.float32(FY), cx=np.float32(CX), cy=np.float32(CY), bf=np.float32(BF),
+    )
+
+
+def synth_pose(n=1000, seed=4000, sigma=1.0, outlier_frac=0.1, mono_frac=0.3):
+    """PoseOptimization problem: one camera, n matched map points (world xyz f32), observations
+    (u, v, ur) with ur<0 for monocular matches, octave-dependent inv_sigma2, initial pose perturbed."""
+    rng = np.random.default_rng(seed)
+    pts = np.empty((n, 3))
+    pts[:, 0] = rng.uniform(-2.0, 2.0, n)
+    pts[:, 1] = rng.uniform(-1.5, 1.5, n)
+    pts[:, 2] = rng.uniform(2.0, 6.0, n)
+    Rcw = _rot(0.03, -0.05, 0.02)
+    tcw = np.array([0.1, -0.05, 0.2])
+    Xc = pts @ Rcw.T + tcw
+    octave = rng.integers(0, 8, size=n)
+    inv_sigma2 = (np.float32(1.0) / (np.float32(1.2) ** (2 * octave)).astype(np.float32)).astype(np.float32)
+    u = FX * Xc[:, 0] / Xc[:, 2] + CX
+    v = FY * Xc[:, 1] / Xc[:, 2] + CY
+    ur = u - BF / Xc[:, 2]
+    noise = rng.normal(0, 1.0, size=(n, 3)) * (sigma * 1.2 ** octave)[:, None]
+    out = rng.random(n) < outlier_frac
+    noise[out, :2] += rng.uniform(10, 40, size=(int(out.sum()), 2)) * rng.choice([-1, 1], size=(int(out.sum()), 2))
+    obs = np.stack([u + noise[:, 0], v + noise[:, 1], ur + noise[:, 0] + 0.3 * noise[:, 2]], axis=1)
+    mono = rng.random(n) < mono_frac
+    obs[mono, 2] = -1.0
+    T = np.eye(4)
+    d = _rot(*(rng.normal(0, np.deg2rad(1.0), 3)))
+    T[:3, :3] = d @ Rcw
+    T[:3, 3] = d @ tcw + rng.normal(0, 0.03, 3)
+    Tgt = np.eye(4)
+    Tgt[:3, :3] = Rcw
+    Tgt[:3, 3] = tcw
+    return dict(Tcw=T.astype(np.float32), Tcw_gt=Tgt.astype(np.float32), points=pts.astype(np.float32),
+                obs=obs.astype(np.float32), inv_sigma2=inv_sigma2,
+                fx=np.float32(FX), fy=np.float32(FY), cx=np.float32(CX), cy=np.float32(CY), bf=np.float32(BF))

@@ -1,0 +1,239 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from the
+product package (eao_fusion_amd never imports this module).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+class Trace(C.Structure):
+    _fields_ = [("n", C.c_int32), ("lam", C.c_double * 64), ("chi2", C.c_double * 64), ("trials", C.c_int32 * 64)]
+
+    def to_dict(self):
+        n = self.n
+        return dict(lam=np.array(self.lam[:n]), chi2=np.array(self.chi2[:n]), trials=np.array(self.trials[:n]))
+
+
+class PoseProblem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("Tcw", C.c_void_p), ("Xw", C.c_void_p), ("obs", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("bf", C.c_float)]
+
+
+class BAProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("cam_Tcw", C.c_void_p), ("cam_fixed", C.c_void_p), ("points", C.c_void_p),
+                ("edge_cam", C.c_void_p), ("edge_point", C.c_void_p), ("edge_obs", C.c_void_p),
+                ("edge_inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("bf", C.c_float), ("its_first", C.c_int32), ("its_second", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_orb_create.restype = C.c_void_p
+        L.orc_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_orb_destroy.argtypes = [C.c_void_p]
+        L.orc_orb_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_orb_result.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_orb_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_orb_level_dims.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_orb_level_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_orb_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_orb_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_gaussian_taps.argtypes = [C.c_void_p]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_orb_pattern.restype = C.POINTER(C.c_int8)
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_hamming_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_hamming_best2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_pose_optimization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_local_ba.argtypes = [C.c_void_p] * 9
+        L.orc_ba_edge_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_double] * 5 + [C.c_void_p] * 3
+        L.orc_se3_oplus.argtypes = [C.c_void_p] * 3
+        L.orc_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
+        L.orc_Tcw_to_cam7.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+class OrbOracle:
+    """CPU restatement of ORBextractor (reference include/ORBextractor.h:45-111)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.h = self.L.orc_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+    def __del__(self):
+        try:
+            self.L.orc_orb_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        quota = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.orc_orb_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(quota), _p(umax))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        n = self.L.orc_orb_run(self.h, _p(img), w, h, w)
+        if n < 0:
+            raise ValueError("unsupported image geometry")
+        kps = np.zeros(n, KP_DTYPE)
+        desc = np.zeros((n, 32), np.uint8)
+        self.L.orc_orb_result(self.h, _p(kps), _p(desc), n)
+        return kps, desc
+
+    def level_dims(self, level):
+        w, h = C.c_int(), C.c_int()
+        self.L.orc_orb_level_dims(self.h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_image(self, level, blurred=False):
+        w, h = self.level_dims(level)
+        out = np.zeros((h, w), np.uint8)
+        n = self.L.orc_orb_level_image(self.h, level, 1 if blurred else 0, _p(out))
+        return out if n else None
+
+    def level_candidates(self, level):
+        n = self.L.orc_orb_level_candidates(self.h, level, None, 0)
+        out = np.zeros((n, 3), np.float32)
+        self.L.orc_orb_level_candidates(self.h, level, _p(out), n)
+        return out
+
+    def level_keypoints(self, level):
+        n = self.L.orc_orb_level_keypoints(self.h, level, None, 0)
+        out = np.zeros(n, KP_DTYPE)
+        self.L.orc_orb_level_keypoints(self.h, level, _p(out), n)
+        return out
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], _p(out), dw, dh)
+    return out
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    out = np.zeros_like(src)
+    lib().orc_gaussian_blur7(_p(src), src.shape[1], src.shape[0], _p(out))
+    return out
+
+
+def fast(img, th):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros((cap, 3), np.float32)
+    n = lib().orc_fast(_p(img), img.shape[1], img.shape[0], th, _p(out), cap)
+    return out[:n]
+
+
+def distribute(xyr, min_x, max_x, min_y, max_y, N):
+    xyr = np.ascontiguousarray(xyr, np.float32)
+    sel = np.zeros(len(xyr) + 8, np.int32)
+    n = lib().orc_distribute(_p(xyr), len(xyr), min_x, max_x, min_y, max_y, N, _p(sel), len(sel))
+    return sel[:n]
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_matrix(A, B):
+    A = np.ascontiguousarray(A, np.uint8)
+    B = np.ascontiguousarray(B, np.uint8)
+    D = np.zeros((len(A), len(B)), np.uint16)
+    lib().orc_hamming_matrix(_p(A), len(A), _p(B), len(B), _p(D))
+    return D
+
+
+def hamming_best2(A, B, mask=None):
+    A = np.ascontiguousarray(A, np.uint8)
+    B = np.ascontiguousarray(B, np.uint8)
+    out = np.zeros((len(A), 4), np.int32)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8)
+    lib().orc_hamming_best2(_p(A), len(A), _p(B), len(B), _p(mask), _p(out))
+    return out
+
+
+def pose_optimization(prob):
+    """prob: dict from eao_fusion_amd.synth.synth_pose (Tcw, points, obs, inv_sigma2, fx..bf)."""
+    Tcw = np.ascontiguousarray(prob["Tcw"], np.float32)
+    Xw = np.ascontiguousarray(prob["points"], np.float32)
+    obs = np.ascontiguousarray(prob["obs"], np.float32)
+    inv = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+    n = len(Xw)
+    P = PoseProblem(n, _p(Tcw), _p(Xw), _p(obs), _p(inv), prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
+    T_out = np.zeros((4, 4), np.float32)
+    outl = np.zeros(max(n, 1), np.uint8)
+    pose_d = np.zeros(7)
+    tr = Trace()
+    ninl = lib().orc_pose_optimization(C.byref(P), _p(T_out), _p(outl), _p(pose_d), C.byref(tr))
+    return dict(Tcw=T_out, outlier=outl[:n], n_inliers=ninl, pose_d=pose_d, trace=tr.to_dict())
+
+
+def local_ba(prob, its=(5, 10), stop=None):
+    cams = np.ascontiguousarray(prob["poses"], np.float32)
+    fixed = np.ascontiguousarray(prob["fixed"], np.uint8)
+    pts = np.ascontiguousarray(prob["points"], np.float32)
+    ec = np.ascontiguousarray(prob["edge_cam"], np.int32)
+    ep = np.ascontiguousarray(prob["edge_point"], np.int32)
+    obs = np.ascontiguousarray(prob["obs"], np.float32)
+    inv = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+    P = BAProblem(len(cams), len(pts), len(ec), _p(cams), _p(fixed), _p(pts), _p(ec), _p(ep), _p(obs), _p(inv),
+                  prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], its[0], its[1])
+    cams_out = np.zeros_like(cams)
+    pts_out = np.zeros_like(pts)
+    outl = np.zeros(max(len(ec), 1), np.uint8)
+    cams_d = np.zeros((len(cams), 7))
+    pts_d = np.zeros((len(pts), 3))
+    iters = np.zeros(2, np.int32)
+    tr = Trace()
+    stop_p = None
+    if stop is not None:
+        stop_arr = np.array([1 if stop else 0], np.uint8)
+        stop_p = _p(stop_arr)
+    rc = lib().orc_local_ba(C.byref(P), stop_p, _p(cams_out), _p(pts_out), _p(outl), _p(cams_d), _p(pts_d), _p(iters), C.byref(tr))
+    return dict(poses=cams_out, points=pts_out, edge_outlier=outl[:len(ec)], cams_d=cams_d, points_d=pts_d,
+                iters=iters, trace=tr.to_dict(), aborted=bool(rc))

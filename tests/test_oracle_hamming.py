@@ -1,0 +1,42 @@
+"""Pins for the Hamming oracle (reference src/ORBmatcher.cc:1649-1665)."""
+import numpy as np
+
+from eao_fusion_amd import synth
+
+
+def test_swar_equals_popcount(oracle):
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, size=(500, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, size=(500, 32), dtype=np.uint8)
+    for i in range(500):
+        ref = int(np.unpackbits(a[i] ^ b[i]).sum())
+        assert oracle.descriptor_distance(a[i], b[i]) == ref
+    z = np.zeros(32, np.uint8)
+    o = np.full(32, 255, np.uint8)
+    assert oracle.descriptor_distance(z, z) == 0
+    assert oracle.descriptor_distance(z, o) == 256
+    for bit in range(256):  # every single-bit difference counts once
+        v = np.zeros(32, np.uint8)
+        v[bit // 8] = 1 << (bit % 8)
+        assert oracle.descriptor_distance(z, v) == 1
+
+
+def test_matrix_and_best2(oracle):
+    a, b, perm = synth.synth_descriptors_planted(200)
+    D = oracle.hamming_matrix(a, b)
+    ref = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(D, ref)
+    b2 = oracle.hamming_best2(a, b)
+    inv = np.argsort(perm)
+    assert (b2[:, 2] == inv).mean() > 0.99          # planted partner is the nearest neighbour
+    for i in range(200):
+        order = np.argsort(D[i], kind="stable")    # first index wins ties
+        assert b2[i, 0] == D[i, order[0]] and b2[i, 2] == order[0]
+        assert b2[i, 1] == D[i, order[1]]
+    mask = np.zeros((200, 200), np.uint8)
+    mask[:, ::3] = 1
+    b2m = oracle.hamming_best2(a, b, mask)
+    Dm = np.where(mask > 0, D.astype(np.int32), 1000)
+    assert np.array_equal(b2m[:, 0], Dm.min(axis=1))
+    empty = oracle.hamming_best2(a[:3], b, np.zeros((3, 200), np.uint8))
+    assert np.array_equal(empty[:, :3], np.array([[256, 256, -1]] * 3))
