@@ -82,9 +82,9 @@ def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_
     rng = np.random.default_rng(seed)
     n_cams = n_free + n_fixed
     pts = np.empty((n_points, 3))
-    pts[:, 0] = rng.uniform(-2.0, 2.0, n_points)
-    pts[:, 1] = rng.uniform(-1.5, 1.5, n_points)
     pts[:, 2] = rng.uniform(2.0, 5.0, n_points)
+    pts[:, 0] = rng.uniform(-0.3, 0.3, n_points) * pts[:, 2]   # inside every camera's frustum
+    pts[:, 1] = rng.uniform(-0.25, 0.25, n_points) * pts[:, 2]
     poses = np.zeros((n_cams, 4, 4))
     for c in range(n_cams):
         t = c / max(n_cams - 1, 1) - 0.5            # camera centres along a 1 m arc
@@ -114,6 +114,7 @@ def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_
     noise[out, :2] += rng.uniform(10, 30, size=(int(out.sum()), 2)) * rng.choice([-1, 1], size=(int(out.sum()), 2))
     ur = u - BF / Xc[:, 2]
     obs = np.stack([u + noise[:, 0], v + noise[:, 1], ur + noise[:, 0] + 0.3 * noise[:, 2]], axis=1)
+    obs[:, 2] = np.maximum(obs[:, 2], 0.0)      # ur < 0 is the reference's "monocular" marker
     mono = rng.random(E) < mono_frac
     obs[mono, 2] = -1.0
     fixed = np.zeros(n_cams, dtype=np.uint8)
@@ -137,9 +138,9 @@ def synth_pose(n=1000, seed=4000, sigma=1.0, outlier_frac=0.1, mono_frac=0.3):
     (u, v, ur) with ur<0 for monocular matches, octave-dependent inv_sigma2, initial pose perturbed."""
     rng = np.random.default_rng(seed)
     pts = np.empty((n, 3))
-    pts[:, 0] = rng.uniform(-2.0, 2.0, n)
-    pts[:, 1] = rng.uniform(-1.5, 1.5, n)
     pts[:, 2] = rng.uniform(2.0, 6.0, n)
+    pts[:, 0] = rng.uniform(-0.45, 0.45, n) * pts[:, 2]
+    pts[:, 1] = rng.uniform(-0.35, 0.35, n) * pts[:, 2]
     Rcw = _rot(0.03, -0.05, 0.02)
     tcw = np.array([0.1, -0.05, 0.2])
     Xc = pts @ Rcw.T + tcw
@@ -152,6 +153,7 @@ def synth_pose(n=1000, seed=4000, sigma=1.0, outlier_frac=0.1, mono_frac=0.3):
     out = rng.random(n) < outlier_frac
     noise[out, :2] += rng.uniform(10, 40, size=(int(out.sum()), 2)) * rng.choice([-1, 1], size=(int(out.sum()), 2))
     obs = np.stack([u + noise[:, 0], v + noise[:, 1], ur + noise[:, 0] + 0.3 * noise[:, 2]], axis=1)
+    obs[:, 2] = np.maximum(obs[:, 2], 0.0)
     mono = rng.random(n) < mono_frac
     obs[mono, 2] = -1.0
     T = np.eye(4)

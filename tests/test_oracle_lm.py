@@ -8,7 +8,8 @@ import pytest
 
 from eao_fusion_amd import synth
 
-FX, FY, CX, CY, BF = 535.4, 539.2, 320.1, 247.6, 40.0
+# intrinsics cross the boundary as float32 (Optimizer.cc:858-898): use the promoted values
+FX, FY, CX, CY, BF = (float(np.float32(v)) for v in (535.4, 539.2, 320.1, 247.6, 40.0))
 
 
 def _edge_eval(L, cam7, pt, obs, stereo):
