@@ -1,0 +1,104 @@
+"""ctypes binding of libeaofusion_hip.so (the C-ABI in include/eao_fusion.h).
+
+The library is the product; this module only loads it.  There is no CPU fallback anywhere in this package:
+if the shared object is missing or no MI355X is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libeaofusion_hip.so")
+
+EAO_OK, EAO_ERR_INVALID, EAO_ERR_NO_DEVICE, EAO_ERR_CAPACITY, EAO_ERR_INTERNAL = 0, -1, -2, -3, -4
+
+
+class EaoError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("eao status %d: %s" % (status, msg))
+        self.status = status
+
+
+class OrbCfg(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class PoseProblem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("Tcw", C.c_void_p), ("Xw", C.c_void_p), ("obs", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("bf", C.c_float)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("Tcw", C.c_float * 16), ("outlier", C.c_void_p), ("n_inliers", C.c_int32),
+                ("lm_iterations", C.c_int32)]
+
+
+class BAProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("cam_Tcw", C.c_void_p), ("cam_fixed", C.c_void_p), ("points", C.c_void_p),
+                ("edge_cam", C.c_void_p), ("edge_point", C.c_void_p), ("edge_obs", C.c_void_p),
+                ("edge_inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("bf", C.c_float), ("its_first", C.c_int32), ("its_second", C.c_int32)]
+
+
+class BAResult(C.Structure):
+    _fields_ = [("cam_Tcw", C.c_void_p), ("points", C.c_void_p), ("edge_outlier", C.c_void_p),
+                ("iters", C.c_int32 * 2), ("aborted", C.c_int32), ("chi2", C.c_double * 2)]
+
+
+# every symbol include/eao_fusion.h declares: (restype, argtypes)
+_P = C.c_void_p
+_I = C.c_int32
+SYMBOLS = {
+    "eao_last_error": (C.c_char_p, []),
+    "eao_device_check": (_I, []),
+    "eao_version": (C.c_char_p, []),
+    "eao_orb_create": (_I, [C.POINTER(OrbCfg), C.POINTER(_P)]),
+    "eao_orb_destroy": (None, [_P]),
+    "eao_orb_tables": (_I, [_P, _P, _P, _P, _P, _P]),
+    "eao_orb_max_keypoints": (_I, [_P, _I, _I, C.POINTER(_I)]),
+    "eao_orb_extract": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, C.POINTER(_I)]),
+    "eao_orb_extract_batch": (_I, [_P, _P, _I, _I, _I, C.c_int64, _I, _P, _P, _I, _P]),
+    "eao_orb_extract_batch_device": (_I, [_P, _P, _I, _I, _I, C.c_int64, _I, _P, _P, _I, _P, _P]),
+    "eao_orb_level": (_I, [_P, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
+    "eao_orb_level_candidates": (_I, [_P, _I, _I, _P, _I, C.POINTER(_I)]),
+    "eao_orb_set_profiling": (_I, [_P, _I]),
+    "eao_orb_last_timing": (_I, [_P, _P]),
+    "eao_hamming_matrix": (_I, [_P, _I, _P, _I, _P]),
+    "eao_hamming_best2": (_I, [_P, _I, _P, _I, _P, _P]),
+    "eao_hamming_matrix_device": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "eao_hamming_best2_device": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
+    "eao_pose_optimization": (_I, [C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
+    "eao_local_ba": (_I, [C.POINTER(BAProblem), _P, C.POINTER(BAResult)]),
+    "eao_last_lm_trace": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),
+    "eao_last_lm_timing": (_I, [C.POINTER(C.c_float), C.POINTER(_I)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object (after torch, if torch is in the process, so that both resolve the same
+    libamdhip64.so.7 -- see DESIGN.md 'process model')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError = ABI drift, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != EAO_OK:
+        raise EaoError(status, load().eao_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data

@@ -1,0 +1,57 @@
+// common.h -- error plumbing shared by the HIP translation units of libeaofusion_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/eao_fusion.h"
+
+namespace eao {
+
+void set_error(const char* fmt, ...);
+
+#define EAO_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            eao::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return EAO_ERR_NO_DEVICE;                                                                   \
+        }                                                                                               \
+    } while (0)
+
+#define EAO_REQUIRE(cond, ...)           \
+    do {                                 \
+        if (!(cond)) {                   \
+            eao::set_error(__VA_ARGS__); \
+            return EAO_ERR_INVALID;      \
+        }                                \
+    } while (0)
+
+// Fails loudly (EAO_ERR_NO_DEVICE) when no HIP device can run gfx950 code objects.  There is no CPU fallback.
+eao_status require_device();
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    // grow-only allocation
+    eao_status reserve(size_t count) {
+        if (count <= n) return EAO_OK;
+        release();
+        EAO_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return EAO_OK;
+    }
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace eao

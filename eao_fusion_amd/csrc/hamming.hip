@@ -1,0 +1,159 @@
+// hamming.hip -- 256-bit Hamming distances for MI355X (gfx950).
+//
+// Stands behind ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1649-1665) and the candidate loops of
+// the Search* routines (e.g. :83-115, :1402-1426): the distances are exact integers, v_xor + v_bcnt per 32-bit
+// word.  Two products:
+//   k_hamming_matrix  full na x nb uint16 matrix; write-bound (2 B per pair): each lane keeps two B descriptors in
+//                     registers and streams 32-row A tiles from LDS, storing packed u32 (256 B per wave store)
+//   k_hamming_best2   per A row the two smallest (distance, column) under lexicographic order == the result of
+//                     upstream's sequential "if d<best ... else if d<second" scan; one wavefront per row, lane-
+//                     local two-smallest then a 6-step xor-shuffle merge
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int dist8(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+constexpr int kRowsPerBlock = 32;
+
+__global__ __launch_bounds__(128) void k_hamming_matrix(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,
+                                                        unsigned short* __restrict__ D) {
+    __shared__ uint4 sa[kRowsPerBlock * 2];
+    const int pair = blockIdx.z;
+    A += (long long)pair * na * 2;
+    B += (long long)pair * nb * 2;
+    D += (long long)pair * na * nb;
+    const int i0 = blockIdx.y * kRowsPerBlock;
+    const int j0 = (blockIdx.x * 128 + threadIdx.x) * 2;
+    if (threadIdx.x < kRowsPerBlock * 2) {
+        const int r = i0 + (threadIdx.x >> 1);
+        sa[threadIdx.x] = r < na ? A[(long long)r * 2 + (threadIdx.x & 1)] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (j0 >= nb) return;
+    const bool two = j0 + 1 < nb;
+    const uint4 b00 = B[(long long)j0 * 2], b01 = B[(long long)j0 * 2 + 1];
+    const uint4 b10 = two ? B[(long long)j0 * 2 + 2] : b00, b11 = two ? B[(long long)j0 * 2 + 3] : b01;
+    const int rows = min(kRowsPerBlock, na - i0);
+    const bool aligned = two && ((nb & 1) == 0);
+    for (int r = 0; r < rows; r++) {
+        const uint4 a0 = sa[2 * r], a1 = sa[2 * r + 1];
+        const unsigned d0 = dist8(a0, a1, b00, b01), d1 = dist8(a0, a1, b10, b11);
+        unsigned short* o = D + (long long)(i0 + r) * nb + j0;
+        if (aligned) *reinterpret_cast<unsigned*>(o) = d0 | (d1 << 16);
+        else { o[0] = (unsigned short)d0; if (two) o[1] = (unsigned short)d1; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hamming_best2(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,
+                                                       const uint8_t* __restrict__ mask, eao_best2* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pair = blockIdx.y;
+    const int i = blockIdx.x * 4 + wv;
+    if (i >= na) return;
+    A += (long long)pair * na * 2;
+    B += (long long)pair * nb * 2;
+    const uint4 a0 = A[(long long)i * 2], a1 = A[(long long)i * 2 + 1];
+    const uint8_t* m = mask ? mask + ((long long)pair * na + i) * nb : nullptr;
+    const unsigned none = (256u << 20) | 0xFFFFFu;
+    unsigned k1 = none, k2 = none;
+    for (int j = lane; j < nb; j += 64) {
+        if (m && !m[j]) continue;
+        const unsigned d = dist8(a0, a1, B[(long long)j * 2], B[(long long)j * 2 + 1]);
+        const unsigned key = (d << 20) | (unsigned)j;
+        if (key < k1) { k2 = k1; k1 = key; }
+        else if (key < k2) k2 = key;
+    }
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+        const unsigned o1 = __shfl_xor(k1, dlt), o2 = __shfl_xor(k2, dlt);
+        const unsigned n1 = min(k1, o1);
+        const unsigned n2 = min(max(k1, o1), min(k2, o2));
+        k1 = n1; k2 = n2;
+    }
+    if (lane == 0) {
+        eao_best2 r;
+        r.best = (int)(k1 >> 20);
+        r.second = (int)(k2 >> 20);
+        r.idx = k1 == none ? -1 : (int)(k1 & 0xFFFFF);
+        r.idx2 = k2 == none ? -1 : (int)(k2 & 0xFFFFF);
+        out[(long long)pair * na + i] = r;
+    }
+}
+
+struct Scratch {
+    eao::DevBuf<uint8_t> a, b, mask;
+    eao::DevBuf<unsigned short> d;
+    eao::DevBuf<eao_best2> best;
+};
+thread_local Scratch g_scr;
+
+}  // namespace
+
+extern "C" {
+
+eao_status eao_hamming_matrix_device(const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb, int32_t pairs,
+                                     uint16_t* d_D, void* stream) {
+    EAO_REQUIRE(d_A && d_B && d_D && na > 0 && nb > 0 && pairs > 0, "bad argument");
+    EAO_REQUIRE(((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_B & 15) == 0 && ((uintptr_t)d_D & 3) == 0, "descriptor arrays must be 16-byte aligned");
+    eao_status st = eao::require_device();
+    if (st) return st;
+    dim3 grid(eao::cdiv(nb, 256), eao::cdiv(na, kRowsPerBlock), pairs);
+    hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(128), 0, (hipStream_t)stream, (const uint4*)d_A, na, (const uint4*)d_B, nb, d_D);
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
+
+eao_status eao_hamming_best2_device(const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb, int32_t pairs,
+                                    const uint8_t* d_mask, eao_best2* d_out, void* stream) {
+    EAO_REQUIRE(d_A && d_B && d_out && na > 0 && nb > 0 && pairs > 0, "bad argument");
+    EAO_REQUIRE(nb < (1 << 20), "nb must be below 2^20");
+    EAO_REQUIRE(((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_B & 15) == 0, "descriptor arrays must be 16-byte aligned");
+    eao_status st = eao::require_device();
+    if (st) return st;
+    hipLaunchKernelGGL(k_hamming_best2, dim3(eao::cdiv(na, 4), pairs), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_A, na,
+                       (const uint4*)d_B, nb, d_mask, d_out);
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
+
+eao_status eao_hamming_matrix(const uint8_t* A, int32_t na, const uint8_t* B, int32_t nb, uint16_t* D) {
+    EAO_REQUIRE(A && B && D && na > 0 && nb > 0, "bad argument");
+    eao_status st = eao::require_device();
+    if (st) return st;
+    Scratch& s = g_scr;
+    if ((st = s.a.reserve((size_t)na * 32))) return st;
+    if ((st = s.b.reserve((size_t)nb * 32))) return st;
+    if ((st = s.d.reserve((size_t)na * nb))) return st;
+    EAO_HIP(hipMemcpy(s.a.p, A, (size_t)na * 32, hipMemcpyHostToDevice));
+    EAO_HIP(hipMemcpy(s.b.p, B, (size_t)nb * 32, hipMemcpyHostToDevice));
+    if ((st = eao_hamming_matrix_device(s.a.p, na, s.b.p, nb, 1, s.d.p, nullptr))) return st;
+    EAO_HIP(hipMemcpy(D, s.d.p, (size_t)na * nb * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return EAO_OK;
+}
+
+eao_status eao_hamming_best2(const uint8_t* A, int32_t na, const uint8_t* B, int32_t nb, const uint8_t* mask, eao_best2* out) {
+    EAO_REQUIRE(A && B && out && na > 0 && nb > 0, "bad argument");
+    eao_status st = eao::require_device();
+    if (st) return st;
+    Scratch& s = g_scr;
+    if ((st = s.a.reserve((size_t)na * 32))) return st;
+    if ((st = s.b.reserve((size_t)nb * 32))) return st;
+    if ((st = s.best.reserve((size_t)na))) return st;
+    EAO_HIP(hipMemcpy(s.a.p, A, (size_t)na * 32, hipMemcpyHostToDevice));
+    EAO_HIP(hipMemcpy(s.b.p, B, (size_t)nb * 32, hipMemcpyHostToDevice));
+    const uint8_t* dm = nullptr;
+    if (mask) {
+        if ((st = s.mask.reserve((size_t)na * nb))) return st;
+        EAO_HIP(hipMemcpy(s.mask.p, mask, (size_t)na * nb, hipMemcpyHostToDevice));
+        dm = s.mask.p;
+    }
+    if ((st = eao_hamming_best2_device(s.a.p, na, s.b.p, nb, 1, dm, s.best.p, nullptr))) return st;
+    EAO_HIP(hipMemcpy(out, s.best.p, (size_t)na * sizeof(eao_best2), hipMemcpyDeviceToHost));
+    return EAO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1081 @@
+// orb.hip -- ORB extraction for MI355X (gfx950): pyramid, per-cell FAST-9/16 + NMS, quad-tree keypoint
+// distribution, intensity-centroid orientation, 7x7 Gaussian, 256-bit steered BRIEF.
+//
+// Stands behind ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:45-111, src/ORBextractor.cc:410-470,
+// 765-853, 1043-1132).  Nothing here is translated from the reference: the work is re-decomposed for a
+// 64-wide-wavefront machine and batched over frames so that one launch covers every level of every frame:
+//
+//   k_resize          level l from level l-1, 11-bit fixed-point bilinear, 4 px per lane, coalesced u32 stores
+//   k_fast_cells      one workgroup per FAST cell: LDS-staged pixel tile, branch-free arc score per pixel
+//                     (min3/max3 sliding windows), LDS NMS that is blind across the cell seam (as upstream's
+//                     per-cell cv::FAST calls are), wave-scan compaction in row-major order, minThFAST retry
+//   k_quadtree        one workgroup per (frame, level): level-synchronous restatement of DistributeOctTree --
+//                     the std::list order is reproduced by prefix sums, the (size, pointer) sort by a rank
+//   k_blur7           separable 7x7 fixed-point Gaussian, LDS tile with reflect-101 halo
+//   k_orient_describe one wavefront per keypoint: integer moments reduced across lanes, fastAtan2, 256 point
+//                     pairs (4 per lane) packed into the descriptor with 4 wave ballots
+//
+// Float semantics: this file is compiled with -ffp-contract=off (see Makefile): the reference's float
+// expressions are rounded op by op.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxLevels = 16;
+constexpr int kEdge = 19;
+constexpr int kMinBorder = kEdge - 3;  // 16
+constexpr int kTile = 72;              // max FAST sub-image edge (cell <= 60 px + 6)
+constexpr int kTested = kTile - 6;     // 66
+constexpr int kMaxIni = 16;
+
+__constant__ signed char c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+struct LevelGeom {
+    int w, h, pitch, off;      // level image; off = byte offset inside one frame's pyramid block
+    int cellBase, nCells;      // FAST cells of this level inside the per-frame cell table
+    int quota;                 // mnFeaturesPerLevel
+    int nIni, boxH;            // initial quad-tree nodes; maxBorderY - minBorderY
+    float hX;
+    int listCap;               // node-list / keypoint capacity of this level
+    int kpBase;                // first keypoint slot of this level inside a frame
+    int candBase, candCap;     // candidate scratch of this level inside a frame
+    int tabBase;               // resize coefficient tables (ints): xofs[w] xalpha[w] yofs[h] ybeta[h]
+    int tileBase, tilesX;      // blur tiles (64 x 16) of this level
+    int scaledPatch;
+    float scale;
+};
+
+struct Geom {
+    int nlevels, W, H;
+    int totalCells, cellCap;
+    int totalKpCap, totalCandCap, totalTiles;
+    int pyrFrameBytes;
+    int iniTh, minTh;
+    int scanCap;               // LDS scan workspace entries for k_quadtree
+    int umax[16];
+    LevelGeom L[kMaxLevels];
+};
+
+struct CellDesc {
+    short level, x0, y0, sw, sh, offX, offY, pad;
+};
+
+struct ImgSrc {  // level-0 source (caller's frames) + internal pyramid
+    const uint8_t* img0;
+    int pitch0;
+    long long fs0;
+    uint8_t* pyr;
+};
+
+__device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const ImgSrc& s, int l, int f, int* pitch) {
+    if (l == 0) {
+        *pitch = s.pitch0;
+        return s.img0 + (long long)f * s.fs0;
+    }
+    *pitch = g->L[l].pitch;
+    return s.pyr + (long long)f * g->pyrFrameBytes + g->L[l].off;
+}
+
+// ---------------------------------------------------------------------------------------------- resize
+__global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, const int* __restrict__ tab, ImgSrc s, int l) {
+    const LevelGeom D = g->L[l];
+    const LevelGeom S = g->L[l - 1];
+    const int f = blockIdx.z;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (dy >= D.h || dx0 >= D.w) return;
+    int spitch;
+    const uint8_t* src = level_ptr(g, s, l - 1, f, &spitch);
+    uint8_t* dst = s.pyr + (long long)f * g->pyrFrameBytes + D.off;
+    const int* xofs = tab + D.tabBase;
+    const int* xal = xofs + D.w;
+    const int* yofs = xal + D.w;
+    const int* ybe = yofs + D.h;
+    const int sy = yofs[dy];
+    const int bb = ybe[dy];
+    const int b0 = (short)(bb & 0xFFFF), b1 = (short)(bb >> 16);
+    const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+    const uint8_t* r0 = src + (long long)sy0 * spitch;
+    const uint8_t* r1 = src + (long long)sy1 * spitch;
+    unsigned packed = 0;
+    int nvalid = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = dx0 + i;
+        if (dx < D.w) {
+            const int sx = xofs[dx];
+            const int aa = xal[dx];
+            const int a0 = (short)(aa & 0xFFFF), a1 = (short)(aa >> 16);
+            const int sx1 = min(sx + 1, S.w - 1);
+            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            packed |= (unsigned)v << (8 * i);
+            nvalid++;
+        }
+    }
+    uint8_t* o = dst + (long long)dy * D.pitch + dx0;
+    if (nvalid == 4) {
+        *reinterpret_cast<unsigned*>(o) = packed;
+    } else {
+        for (int i = 0; i < nvalid; i++) o[i] = (uint8_t)(packed >> (8 * i));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- FAST
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// A = max over the sixteen 9-arcs of min(v - ring) and of min(ring - v): the pixel is a FAST-9 corner at
+// threshold t iff A > t, and its OpenCV corner score is A - 1.
+__device__ __forceinline__ int fast_arc_value(const uint8_t* p) {
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * kTile];          d[1] = v - p[3 * kTile + 1];   d[2] = v - p[2 * kTile + 2];
+    d[3] = v - p[kTile + 3];          d[4] = v - p[3];               d[5] = v - p[-kTile + 3];
+    d[6] = v - p[-2 * kTile + 2];     d[7] = v - p[-3 * kTile + 1];  d[8] = v - p[-3 * kTile];
+    d[9] = v - p[-3 * kTile - 1];     d[10] = v - p[-2 * kTile - 2]; d[11] = v - p[-kTile - 3];
+    d[12] = v - p[-3];                d[13] = v - p[kTile - 3];      d[14] = v - p[2 * kTile - 2];
+    d[15] = v - p[3 * kTile - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    }
+    int dark = -256, bright = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        dark = max(dark, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+        bright = min(bright, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+    }
+    return max(dark, -bright);
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const Geom* __restrict__ g, const CellDesc* __restrict__ cells, ImgSrc s,
+                                                    unsigned* __restrict__ cellcand, int* __restrict__ cellcnt) {
+    __shared__ uint8_t tile[kTile * kTile];
+    __shared__ short arc[kTested * kTested];
+    __shared__ uint8_t sc[(kTested + 2) * (kTested + 2)];
+    __shared__ int wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int cell = blockIdx.x, f = blockIdx.y;
+    const CellDesc c = cells[cell];
+    int pitch;
+    const uint8_t* src = level_ptr(g, s, c.level, f, &pitch);
+    const int sw = c.sw, sh = c.sh, tw = sw - 6, th_ = sh - 6;
+    const long long slot = (long long)f * g->totalCells + cell;
+    if (tw <= 0 || th_ <= 0) {
+        if (t == 0) cellcnt[slot] = 0;
+        return;
+    }
+    for (int i = t; i < sw * sh; i += 256) {
+        const int y = i / sw, x = i - y * sw;
+        tile[y * kTile + x] = src[(long long)(c.y0 + y) * pitch + c.x0 + x];
+    }
+    __syncthreads();
+    const int n = tw * th_;
+    for (int i = t; i < n; i += 256) {
+        const int y = i / tw, x = i - y * tw;
+        arc[i] = (short)fast_arc_value(&tile[(y + 3) * kTile + x + 3]);
+    }
+    __syncthreads();
+    const int rw = tw + 2;
+    const int ppt = (n + 255) / 256;           // <= 18, contiguous pixels per thread => row-major output order
+    const int beg = min(t * ppt, n), end = min(beg + ppt, n);
+    for (int pass = 0; pass < 2; pass++) {
+        const int th = min(max(pass ? g->minTh : g->iniTh, 0), 255);
+        for (int i = t; i < rw * (th_ + 2); i += 256) {
+            const int yy = i / rw - 1, xx = i - (yy + 1) * rw - 1;
+            int v = 0;
+            if (yy >= 0 && yy < th_ && xx >= 0 && xx < tw) {
+                const int a = arc[yy * tw + xx];
+                v = (a > th) ? a - 1 : 0;
+            }
+            sc[i] = (uint8_t)v;
+        }
+        __syncthreads();
+        unsigned keep = 0;
+        for (int i = beg; i < end; i++) {
+            const int y = i / tw, x = i - y * tw;
+            if (arc[i] > th) {
+                const uint8_t* q = &sc[(y + 1) * rw + x + 1];
+                const int v = q[0];
+                const int m = max(max3i(q[-rw - 1], q[-rw], q[-rw + 1]), max(max(q[-1], q[1]), max3i(q[rw - 1], q[rw], q[rw + 1])));
+                if (v > m) keep |= 1u << (i - beg);
+            }
+        }
+        const int cnt = __popc(keep);
+        int incl = cnt;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int o = __shfl_up(incl, dlt);
+            if (lane >= dlt) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; w++) base += wsum[w];
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (total > 0 || pass == 1) {
+            int pos = base + incl - cnt;
+            unsigned* out = cellcand + slot * g->cellCap;
+            for (int i = beg; i < end; i++) {
+                if (keep & (1u << (i - beg))) {
+                    const int y = i / tw, x = i - y * tw;
+                    const unsigned X = (unsigned)(x + 3 + c.offX), Y = (unsigned)(y + 3 + c.offY);
+                    if (pos < g->cellCap) out[pos] = X | (Y << 12) | ((unsigned)(arc[i] - 1) << 24);
+                    pos++;
+                }
+            }
+            if (t == 0) cellcnt[slot] = min(total, g->cellCap);
+            return;  // uniform: `total` is the same in every thread
+        }
+        __syncthreads();  // before sc/wsum are rewritten by the minThFAST pass
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- quad-tree
+// In-place exclusive scan of a[0..n) by the whole 256-thread block; returns the total.  Caller guarantees a[]
+// is fully written and visible (barrier) before the call; the function ends with a barrier.
+__device__ int block_excl_scan(int* a, int n, int* wtmp) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = (n + 255) / 256;
+    const int b = min(t * per, n), e = min(b + per, n);
+    int ssum = 0;
+    for (int i = b; i < e; i++) ssum += a[i];
+    int v = ssum;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int o = __shfl_up(v, dlt);
+        if (lane >= dlt) v += o;
+    }
+    __syncthreads();  // protect wtmp from the previous call's readers
+    if (lane == 63) wtmp[wv] = v;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; w++) woff += wtmp[w];
+    const int total = wtmp[0] + wtmp[1] + wtmp[2] + wtmp[3];
+    int run = woff + v - ssum;
+    for (int i = b; i < e; i++) {
+        const int x = a[i];
+        a[i] = run;
+        run += x;
+    }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ int quadrant(unsigned key, short4 bx) {
+    const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
+    const int mx = bx.x + ((bx.z - bx.x + 1) >> 1);   // UL.x + ceil((UR.x-UL.x)/2)
+    const int my = bx.y + ((bx.w - bx.y + 1) >> 1);
+    return (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+}
+
+// One workgroup per (level, frame).  List entries are (box, count, creation rank); `nodeof[k]` is the list
+// position of candidate k's node.  Every pass (a) histograms children of all multi-key nodes, (b) picks the set
+// of nodes that upstream would split in this pass and their processing order, (c) lays out the new list exactly
+// as upstream's push_front/erase sequence would leave it.
+__global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
+                                                  const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
+                                                  unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
+                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int wtmp[4];
+    __shared__ int sh_S, sh_phase, sh_done, sh_rstar, sh_nexp;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int l = blockIdx.x, f = blockIdx.y;
+    const LevelGeom L = g->L[l];
+    const int LC = L.listCap, N = L.quota;
+    // ---- LDS carve-up
+    short4* box0 = reinterpret_cast<short4*>(smem);
+    short4* box1 = box0 + LC;
+    int* cnt0 = reinterpret_cast<int*>(box1 + LC);
+    int* cnt1 = cnt0 + LC;
+    int* crk0 = cnt1 + LC;
+    int* crk1 = crk0 + LC;
+    int* childcnt = crk1 + LC;          // 4 per entry
+    int* childpos = childcnt + 4 * LC;  // 4 per entry
+    int* newpos = childpos + 4 * LC;
+    int* order = newpos + LC;
+    int* vlist = order + LC;
+    int* procRank = vlist + LC;
+    int* scanB = procRank + LC;
+    int* scanA = scanB + LC;            // g->scanCap entries (>= LC and >= nCells)
+
+    unsigned* keys = cand + (long long)f * g->totalCandCap + L.candBase;
+    unsigned short* nof = nodeof + (long long)f * g->totalCandCap + L.candBase;
+
+    // ---- gather this level's candidates in upstream order: cells row-major, corners row-major inside a cell
+    const long long cslot = (long long)f * g->totalCells + L.cellBase;
+    for (int i = t; i < L.nCells; i += 256) scanA[i] = cellcnt[cslot + i];
+    __syncthreads();
+    const int M = block_excl_scan(scanA, L.nCells, wtmp);
+    for (int c = wv; c < L.nCells; c += 4) {
+        const int n = cellcnt[cslot + c], o = scanA[c];
+        const unsigned* srcc = cellcand + (cslot + c) * g->cellCap;
+        for (int j = lane; j < n; j += 64) keys[o + j] = srcc[j];
+    }
+    if (t == 0) candcnt[f * g->nlevels + l] = M;
+    __syncthreads();
+    if (M == 0) {
+        if (t == 0) levelcnt[f * g->nlevels + l] = 0;
+        return;
+    }
+    // ---- initial nodes
+    const int nIni = L.nIni;
+    if (t < nIni) {
+        box0[t] = make_short4((short)(int)(L.hX * (float)t), 0, (short)(int)(L.hX * (float)(t + 1)), (short)L.boxH);
+        cnt0[t] = 0;
+        crk0[t] = t;
+    }
+    __syncthreads();
+    for (int k = t; k < M; k += 256) {
+        const int ini = min((int)((float)(keys[k] & 0xFFF) / L.hX), nIni - 1);
+        atomicAdd(&cnt0[ini], 1);
+        nof[k] = (unsigned short)ini;
+    }
+    __syncthreads();
+    if (t == 0) {  // drop empty initial nodes (nIni <= 16)
+        int S = 0;
+        for (int i = 0; i < nIni; i++) {
+            newpos[i] = S;
+            if (cnt0[i] > 0) { box0[S] = box0[i]; cnt0[S] = cnt0[i]; crk0[S] = S; S++; }
+        }
+        sh_S = S; sh_phase = 0; sh_done = 0;
+    }
+    __syncthreads();
+    if (nIni > 1) {
+        for (int k = t; k < M; k += 256) nof[k] = (unsigned short)newpos[nof[k]];
+        __syncthreads();
+    }
+
+    short4* box = box0; short4* nbox = box1;
+    int* cnt = cnt0; int* ncnt = cnt1;
+    int* crk = crk0; int* ncrk = crk1;
+    for (int iter = 0; iter < 64 && !sh_done; iter++) {
+        const int S = sh_S, phase = sh_phase;
+        // (1) multi-key entries in list order
+        for (int i = t; i < S; i += 256) {
+            scanA[i] = cnt[i] > 1 ? 1 : 0;
+            procRank[i] = -1;
+            childcnt[4 * i] = 0; childcnt[4 * i + 1] = 0; childcnt[4 * i + 2] = 0; childcnt[4 * i + 3] = 0;
+        }
+        if (t == 0) { sh_rstar = 0x7FFFFFFF; sh_nexp = 0; }
+        __syncthreads();
+        const int nCand = block_excl_scan(scanA, S, wtmp);
+        for (int i = t; i < S; i += 256)
+            if (cnt[i] > 1) vlist[scanA[i]] = i;
+        // (2) child histograms of every candidate
+        for (int k = t; k < M; k += 256) {
+            const int nd = nof[k];
+            if (cnt[nd] > 1) atomicAdd(&childcnt[4 * nd + quadrant(keys[k], box[nd])], 1);
+        }
+        __syncthreads();
+        // (3) processing order: list order (full pass) or (size, creation rank) descending (careful pass)
+        if (phase == 0) {
+            for (int j = t; j < nCand; j += 256) order[j] = vlist[j];
+        } else {
+            for (int j = t; j < nCand; j += 256) {
+                const int me = vlist[j], ms = cnt[me], mr = crk[me];
+                int r = 0;
+                for (int u = 0; u < nCand; u++) {
+                    const int o = vlist[u], os = cnt[o], orr = crk[o];
+                    r += (os > ms) || (os == ms && orr > mr);
+                }
+                order[r] = me;
+            }
+        }
+        __syncthreads();
+        // (4) growth prefix in processing order; the careful pass stops at the first prefix reaching N
+        for (int r = t; r < nCand; r += 256) {
+            const int i = order[r];
+            scanA[r] = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
+        }
+        __syncthreads();
+        block_excl_scan(scanA, nCand, wtmp);
+        if (phase == 1) {
+            for (int r = t; r < nCand; r += 256) {
+                const int i = order[r];
+                const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
+                if (S + scanA[r] + ne - (r + 1) >= N) atomicMin(&sh_rstar, r);
+            }
+        }
+        __syncthreads();
+        const int nProc = (phase == 1 && sh_rstar != 0x7FFFFFFF) ? sh_rstar + 1 : nCand;
+        int totalChildren = 0;
+        if (nProc > 0) {
+            const int i = order[nProc - 1];
+            totalChildren = scanA[nProc - 1] + (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
+        }
+        for (int r = t; r < nProc; r += 256) procRank[order[r]] = r;
+        __syncthreads();
+        for (int i = t; i < S; i += 256) scanB[i] = procRank[i] < 0 ? 1 : 0;
+        __syncthreads();
+        block_excl_scan(scanB, S, wtmp);
+        // (5) new list: children of the LAST processed node first (each as n4,n3,n2,n1), untouched entries after
+        int myexp = 0;
+        for (int i = t; i < S; i += 256) {
+            const int r = procRank[i];
+            if (r < 0) {
+                const int p = totalChildren + scanB[i];
+                newpos[i] = p;
+                nbox[p] = box[i]; ncnt[p] = cnt[i]; ncrk[p] = crk[i];
+            } else {
+                const short4 b = box[i];
+                const short mx = (short)(b.x + ((b.z - b.x + 1) >> 1)), my = (short)(b.y + ((b.w - b.y + 1) >> 1));
+                const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
+                int p = totalChildren - (scanA[r] + ne);
+                for (int q = 3; q >= 0; q--) {
+                    const int c = childcnt[4 * i + q];
+                    if (c > 0) {
+                        short4 nb;
+                        nb.x = (q & 1) ? mx : b.x; nb.z = (q & 1) ? b.z : mx;
+                        nb.y = (q & 2) ? my : b.y; nb.w = (q & 2) ? b.w : my;
+                        nbox[p] = nb; ncnt[p] = c; ncrk[p] = 4 * r + q;
+                        childpos[4 * i + q] = p;
+                        p++;
+                        myexp += c > 1;
+                    }
+                }
+            }
+        }
+        if (myexp) atomicAdd(&sh_nexp, myexp);
+        __syncthreads();
+        // (6) re-home the candidates
+        for (int k = t; k < M; k += 256) {
+            const int nd = nof[k];
+            nof[k] = (unsigned short)(procRank[nd] >= 0 ? childpos[4 * nd + quadrant(keys[k], box[nd])] : newpos[nd]);
+        }
+        // (7) upstream's termination tests (src/ORBextractor.cc:660-737)
+        if (t == 0) {
+            const int S2 = totalChildren + S - nProc;
+            sh_S = S2;
+            if (S2 >= N || S2 == S) sh_done = 1;
+            else if (phase == 0 && S2 + 3 * sh_nexp > N) sh_phase = 1;
+        }
+        __syncthreads();
+        short4* tb = box; box = nbox; nbox = tb;
+        int* ti = cnt; cnt = ncnt; ncnt = ti;
+        ti = crk; crk = ncrk; ncrk = ti;
+    }
+    // ---- best response per node, first candidate wins ties (strict '>' at src/ORBextractor.cc:752)
+    const int S = sh_S;
+    unsigned* best = reinterpret_cast<unsigned*>(scanB);
+    for (int i = t; i < S; i += 256) best[i] = 0;
+    __syncthreads();
+    for (int k = t; k < M; k += 256) atomicMax(&best[nof[k]], ((keys[k] >> 24) << 20) | (0xFFFFFu - (unsigned)k));
+    __syncthreads();
+    unsigned* out = levelkps + (long long)f * g->totalKpCap + L.kpBase;
+    for (int i = t; i < S; i += 256) {
+        const unsigned k = 0xFFFFFu - (best[i] & 0xFFFFFu);
+        out[i] = keys[k];
+    }
+    if (t == 0) levelcnt[f * g->nlevels + l] = S;
+}
+
+// ---------------------------------------------------------------------------------------------- blur
+__device__ __forceinline__ int reflect101(int p, int len) {
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur,
+                                               const int* __restrict__ levelcnt) {
+    __shared__ uint8_t in[22][72];
+    __shared__ unsigned short hb[22][64];
+    const int t = threadIdx.x, f = blockIdx.y;
+    int l = 0;
+    while (l + 1 < g->nlevels && (int)blockIdx.x >= g->L[l + 1].tileBase) l++;
+    if (levelcnt[f * g->nlevels + l] == 0) return;  // upstream skips levels without keypoints (:1081-1082)
+    const LevelGeom L = g->L[l];
+    const int tile = blockIdx.x - L.tileBase;
+    const int x0 = (tile % L.tilesX) * 64, y0 = (tile / L.tilesX) * 16;
+    int pitch;
+    const uint8_t* src = level_ptr(g, s, l, f, &pitch);
+    for (int i = t; i < 22 * 70; i += 256) {
+        const int ry = i / 70, rx = i - ry * 70;
+        const int sy = reflect101(y0 - 3 + ry, L.h), sx = reflect101(x0 - 3 + rx, L.w);
+        in[ry][rx] = src[(long long)sy * pitch + sx];
+    }
+    __syncthreads();
+    // taps round(k*256) of getGaussianKernel(7, 2): 18 34 49 55 49 34 18 (host-verified at handle creation)
+    for (int i = t; i < 22 * 64; i += 256) {
+        const int ry = i >> 6, x = i & 63;
+        const uint8_t* p = &in[ry][x];
+        hb[ry][x] = (unsigned short)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    }
+    __syncthreads();
+    const int tx = t & 63, ty = t >> 6;
+    uint8_t* dst = blur + (long long)f * g->pyrFrameBytes + L.off;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int yy = ty * 4 + r, y = y0 + yy, x = x0 + tx;
+        if (y < L.h && x < L.w) {
+            const int sv = 18 * (hb[yy][tx] + hb[yy + 6][tx]) + 34 * (hb[yy + 1][tx] + hb[yy + 5][tx]) +
+                           49 * (hb[yy + 2][tx] + hb[yy + 4][tx]) + 55 * hb[yy + 3][tx];
+            dst[(long long)y * L.pitch + x] = (uint8_t)min((sv + 32768) >> 16, 255);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- orientation + rBRIEF
+// sin/cos of a float angle in [0, 2*pi], evaluated in double (Cody-Waite reduction by pi/2 + the classic
+// minimax kernels) and rounded to float: plain +,-,* only, so results do not depend on a device libm.
+__device__ __forceinline__ void sincos_f32_via_f64(float angle, float* sn, float* cs) {
+    const double x = (double)angle;
+    const int k = (int)(x * 0.63661977236758134308 + 0.5);
+    const double kd = (double)k;
+    const double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double sr = r + r * z * ps;
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double cr = 1.0 - 0.5 * z + z * z * pc;
+    double sv, cv;
+    switch (k & 3) {
+        case 0: sv = sr; cv = cr; break;
+        case 1: sv = cr; cv = -sr; break;
+        case 2: sv = -sr; cv = -cr; break;
+        default: sv = -cr; cv = sr; break;
+    }
+    *sn = (float)sv;
+    *cs = (float)cv;
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict__ g, ImgSrc s, const uint8_t* __restrict__ blur,
+                                                         const unsigned* __restrict__ levelkps, const int* __restrict__ levelcnt,
+                                                         eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                         int* __restrict__ nout, int cap) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = blockIdx.y;
+    int j = blockIdx.x * 4 + wv;   // compact output index inside the frame
+    const int jout = j;
+    int l = -1, total = 0;
+    for (int q = 0; q < g->nlevels; q++) {
+        const int c = levelcnt[f * g->nlevels + q];
+        if (l < 0) {
+            if (j < c) l = q; else j -= c;
+        }
+        total += c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
+    if (l < 0 || jout >= cap) return;
+    const LevelGeom L = g->L[l];
+    const unsigned key = levelkps[(long long)f * g->totalKpCap + L.kpBase + j];
+    const int cx = (int)(key & 0xFFF) + kMinBorder, cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
+    int pitch;
+    const uint8_t* img = level_ptr(g, s, l, f, &pitch);
+    // intensity centroid over the radius-15 disc: lanes 0..30 / 32..62 take column u, the halves split the rows
+    const int u = (lane & 31) - 15, half = lane >> 5;
+    int m10 = 0, m01 = 0;
+    if (u <= 15) {
+        const uint8_t* c0 = img + (long long)cy * pitch + cx + u;
+        const int au = u < 0 ? -u : u;
+        const int v0 = half ? 1 : -15, v1 = half ? 15 : 0;
+        for (int v = v0; v <= v1; v++) {
+            const int av = v < 0 ? -v : v;
+            if (au <= g->umax[av]) {
+                const int val = c0[(long long)v * pitch];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+        m10 += __shfl_xor(m10, dlt);
+        m01 += __shfl_xor(m01, dlt);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // steered BRIEF on the blurred level
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    sincos_f32_via_f64(angle * factorPI, &b, &a);
+    const uint8_t* bc = blur + (long long)f * g->pyrFrameBytes + L.off + (long long)cy * L.pitch + cx;
+    unsigned long long words[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = (lane + 64 * k) * 4;
+        const float xa = (float)c_pattern[p], ya = (float)c_pattern[p + 1];
+        const float xb = (float)c_pattern[p + 2], yb = (float)c_pattern[p + 3];
+        const int ra = __float2int_rn(xa * b + ya * a), ca = __float2int_rn(xa * a - ya * b);
+        const int rb = __float2int_rn(xb * b + yb * a), cb = __float2int_rn(xb * a - yb * b);
+        const int t0 = bc[(long long)ra * L.pitch + ca], t1 = bc[(long long)rb * L.pitch + cb];
+        words[k] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((long long)f * cap + jout) * 32);
+        d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+        eao_keypoint kp;
+        const float fxp = (float)cx, fyp = (float)cy;
+        kp.x = l ? fxp * L.scale : fxp;
+        kp.y = l ? fyp * L.scale : fyp;
+        kp.size = (float)L.scaledPatch;
+        kp.angle = angle;
+        kp.response = (float)(key >> 24);
+        kp.octave = l;
+        kp.class_id = -1;
+        kps[(long long)f * cap + jout] = kp;
+    }
+}
+
+// unpack (x, y, response) of the gathered FAST candidates for the stage tap
+__global__ void k_unpack_cand(const unsigned* __restrict__ keys, int n, float* __restrict__ xyr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const unsigned k = keys[i];
+        xyr[3 * i] = (float)(k & 0xFFF);
+        xyr[3 * i + 1] = (float)((k >> 12) & 0xFFF);
+        xyr[3 * i + 2] = (float)(k >> 24);
+    }
+}
+
+inline int cv_round(double v) { return (int)std::lrint(v); }
+
+}  // namespace
+
+// ================================================================================================= host
+struct eao_orb {
+    eao_orb_cfg cfg;
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> quota;
+    int umax[16];
+    // geometry of the current (W, H)
+    Geom geom;
+    bool geomValid = false;
+    int batchCap = 0;
+    std::vector<CellDesc> cells;
+    std::vector<int> tab;
+    size_t quadLds = 0;
+    // device state
+    hipStream_t stream = nullptr;
+    eao::DevBuf<Geom> d_geom;
+    eao::DevBuf<CellDesc> d_cells;
+    eao::DevBuf<int> d_tab;
+    eao::DevBuf<uint8_t> d_pyr, d_blur, d_in;
+    eao::DevBuf<unsigned> d_cellcand, d_cand, d_levelkps;
+    eao::DevBuf<unsigned short> d_nodeof;
+    eao::DevBuf<int> d_cellcnt, d_levelcnt, d_candcnt, d_nout;
+    eao::DevBuf<eao_keypoint> d_kps;
+    eao::DevBuf<uint8_t> d_desc;
+    eao::DevBuf<float> d_xyr;
+    // last call (for stage taps)
+    ImgSrc lastSrc{};
+    int lastBatch = 0;
+    bool profiling = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool evValid = false;
+};
+
+namespace {
+
+eao_status build_geometry(eao_orb* h, int W, int H) {
+    const eao_orb_cfg& c = h->cfg;
+    Geom& g = h->geom;
+    std::memset(&g, 0, sizeof(g));
+    g.nlevels = c.nlevels; g.W = W; g.H = H;
+    g.iniTh = c.ini_th_fast; g.minTh = c.min_th_fast;
+    for (int i = 0; i < 16; i++) g.umax[i] = h->umax[i];
+    h->cells.clear();
+    h->tab.clear();
+    int off = 0, kpBase = 0, candBase = 0, tileBase = 0, maxCell = 0, scanCap = 0, maxList = 0;
+    // first pass: level sizes and the largest FAST cell (fixes cellCap)
+    for (int l = 0; l < c.nlevels; l++) {
+        LevelGeom& L = g.L[l];
+        const float s = h->invScale[l];
+        L.w = cv_round((float)W * s);   // reference src/ORBextractor.cc:1111-1112
+        L.h = cv_round((float)H * s);
+        EAO_REQUIRE(L.w < 4096 && L.h < 4096, "level %d is %dx%d: coordinates are packed in 12 bits", l, L.w, L.h);
+        const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+        const float width = (float)(maxBX - kMinBorder), height = (float)(maxBY - kMinBorder);
+        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        EAO_REQUIRE(nCols >= 1 && nRows >= 1, "level %d (%dx%d) is smaller than one 30 px FAST cell plus borders", l, L.w, L.h);
+        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+        EAO_REQUIRE(wCell + 6 <= kTile && hCell + 6 <= kTile, "FAST cell %dx%d exceeds the LDS tile", wCell, hCell);
+        maxCell = std::max(maxCell, ((wCell + 1) / 2) * ((hCell + 1) / 2));
+    }
+    g.cellCap = maxCell;  // 3x3 NMS with strict '>' keeps at most one corner per 2x2 block
+    for (int l = 0; l < c.nlevels; l++) {
+        LevelGeom& L = g.L[l];
+        L.pitch = (L.w + 63) & ~63;
+        L.off = off;
+        off += ((L.pitch * L.h) + 255) & ~255;
+        const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+        const float width = (float)(maxBX - kMinBorder), height = (float)(maxBY - kMinBorder);
+        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+        L.cellBase = (int)h->cells.size();
+        for (int i = 0; i < nRows; i++) {   // reference src/ORBextractor.cc:789-806
+            const float iniY = (float)(kMinBorder + i * hCell);
+            float maxY = iniY + hCell + 6;
+            if (iniY >= maxBY - 3) continue;
+            if (maxY > maxBY) maxY = (float)maxBY;
+            for (int j = 0; j < nCols; j++) {
+                const float iniX = (float)(kMinBorder + j * wCell);
+                float maxX = iniX + wCell + 6;
+                if (iniX >= maxBX - 6) continue;
+                if (maxX > maxBX) maxX = (float)maxBX;
+                CellDesc cd;
+                cd.level = (short)l; cd.x0 = (short)iniX; cd.y0 = (short)iniY;
+                cd.sw = (short)((int)maxX - (int)iniX); cd.sh = (short)((int)maxY - (int)iniY);
+                cd.offX = (short)(j * wCell); cd.offY = (short)(i * hCell); cd.pad = 0;
+                h->cells.push_back(cd);
+            }
+        }
+        L.nCells = (int)h->cells.size() - L.cellBase;
+        L.quota = h->quota[l];
+        L.boxH = maxBY - kMinBorder;
+        L.nIni = (int)std::round((float)(maxBX - kMinBorder) / (float)(maxBY - kMinBorder));  // :543
+        EAO_REQUIRE(L.nIni >= 1 && L.nIni <= kMaxIni, "level %d aspect ratio gives %d initial quad-tree nodes (supported 1..%d)", l, L.nIni, kMaxIni);
+        L.hX = (float)(maxBX - kMinBorder) / (float)L.nIni;
+        L.listCap = std::max(L.quota + 3, 4 * L.nIni) + 1;
+        EAO_REQUIRE(L.listCap < 65535, "quota too large");
+        L.kpBase = kpBase; kpBase += L.listCap;
+        L.candBase = candBase; L.candCap = L.nCells * g.cellCap; candBase += L.candCap;
+        EAO_REQUIRE(L.candCap < (1 << 20), "level %d can hold %d FAST candidates; the quad-tree packs indices in 20 bits", l, L.candCap);
+        L.tilesX = eao::cdiv(L.w, 64);
+        L.tileBase = tileBase; tileBase += L.tilesX * eao::cdiv(L.h, 16);
+        L.scale = h->scale[l];
+        L.scaledPatch = (int)(31 * h->scale[l]);
+        scanCap = std::max(scanCap, std::max(L.listCap, L.nCells));
+        maxList = std::max(maxList, L.listCap);
+        // resize tables (OpenCV 3.3.x resize INTER_LINEAR u8 coefficients), built in double/float on the host
+        L.tabBase = (int)h->tab.size();
+        if (l > 0) {
+            const LevelGeom& S = g.L[l - 1];
+            const double sx_ = 1. / ((double)L.w / S.w), sy_ = 1. / ((double)L.h / S.h);
+            std::vector<int> xofs(L.w), xal(L.w), yofs(L.h), ybe(L.h);
+            for (int dx = 0; dx < L.w; dx++) {
+                float fx = (float)((dx + 0.5) * sx_ - 0.5);
+                int sx = (int)std::floor(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+                const int a0 = std::min(std::max(cv_round((1.f - fx) * 2048.f), -32768), 32767);
+                const int a1 = std::min(std::max(cv_round(fx * 2048.f), -32768), 32767);
+                xofs[dx] = sx;
+                xal[dx] = (a0 & 0xFFFF) | (a1 << 16);
+            }
+            for (int dy = 0; dy < L.h; dy++) {
+                float fy = (float)((dy + 0.5) * sy_ - 0.5);
+                int sy = (int)std::floor(fy);
+                fy -= sy;
+                const int b0 = std::min(std::max(cv_round((1.f - fy) * 2048.f), -32768), 32767);
+                const int b1 = std::min(std::max(cv_round(fy * 2048.f), -32768), 32767);
+                yofs[dy] = sy;
+                ybe[dy] = (b0 & 0xFFFF) | (b1 << 16);
+            }
+            h->tab.insert(h->tab.end(), xofs.begin(), xofs.end());
+            h->tab.insert(h->tab.end(), xal.begin(), xal.end());
+            h->tab.insert(h->tab.end(), yofs.begin(), yofs.end());
+            h->tab.insert(h->tab.end(), ybe.begin(), ybe.end());
+        }
+    }
+    if (h->tab.empty()) h->tab.push_back(0);
+    g.totalCells = (int)h->cells.size();
+    g.totalKpCap = kpBase;
+    g.totalCandCap = candBase;
+    g.totalTiles = tileBase;
+    g.pyrFrameBytes = off;
+    g.scanCap = scanCap;
+    // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
+    h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (size_t)scanCap * sizeof(int);
+    EAO_REQUIRE(h->quadLds <= 150 * 1024, "nfeatures too large: quad-tree needs %zu bytes of LDS", h->quadLds);
+    // the blur kernel hard-codes the taps; make sure the published construction gives them
+    {
+        float cf[7]; double sum = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3; cf[i] = (float)std::exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
+        const int expect[7] = {18, 34, 49, 55, 49, 34, 18};
+        for (int i = 0; i < 7; i++)
+            if (cv_round((double)(float)(cf[i] * (1. / sum)) * 256.0) != expect[i]) { eao::set_error("gaussian taps mismatch"); return EAO_ERR_INTERNAL; }
+    }
+    { eao_status st = h->d_geom.reserve(1); if (st) return st; }
+    EAO_HIP(hipMemcpyAsync(h->d_geom.p, &g, sizeof(Geom), hipMemcpyHostToDevice, h->stream));
+    { eao_status st = h->d_cells.reserve(h->cells.size()); if (st) return st; }
+    EAO_HIP(hipMemcpyAsync(h->d_cells.p, h->cells.data(), h->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice, h->stream));
+    { eao_status st = h->d_tab.reserve(h->tab.size()); if (st) return st; }
+    EAO_HIP(hipMemcpyAsync(h->d_tab.p, h->tab.data(), h->tab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
+    h->geomValid = true;
+    h->batchCap = 0;
+    return EAO_OK;
+}
+
+eao_status ensure(eao_orb* h, int W, int H, int batch) {
+    eao_status st = eao::require_device();
+    if (st) return st;
+    if (!h->stream) EAO_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (!h->geomValid || h->geom.W != W || h->geom.H != H) {
+        st = build_geometry(h, W, H);
+        if (st) return st;
+    }
+    if (batch > h->batchCap) {
+        const Geom& g = h->geom;
+        const size_t B = batch;
+#define RES(buf, cnt) do { st = h->buf.reserve(cnt); if (st) return st; } while (0)
+        RES(d_pyr, B * g.pyrFrameBytes);
+        RES(d_blur, B * g.pyrFrameBytes);
+        RES(d_cellcand, B * (size_t)g.totalCells * g.cellCap);
+        RES(d_cellcnt, B * g.totalCells);
+        RES(d_cand, B * (size_t)g.totalCandCap);
+        RES(d_nodeof, B * (size_t)g.totalCandCap);
+        RES(d_levelkps, B * (size_t)g.totalKpCap);
+        RES(d_levelcnt, B * g.nlevels);
+        RES(d_candcnt, B * g.nlevels);
+#undef RES
+        h->batchCap = batch;
+    }
+    return EAO_OK;
+}
+
+// enqueue the whole pipeline for `batch` frames; level 0 is read from `src` (device memory)
+eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, int batch, eao_keypoint* d_kps,
+                   uint8_t* d_desc, int cap, int* d_n, hipStream_t st) {
+    const Geom& g = h->geom;
+    ImgSrc s;
+    s.img0 = d_img; s.pitch0 = pitch0; s.fs0 = fs0; s.pyr = h->d_pyr.p;
+    h->lastSrc = s; h->lastBatch = batch;
+    const bool prof = h->profiling;
+    if (prof) {
+        for (int i = 0; i < 6; i++) if (!h->ev[i]) EAO_HIP(hipEventCreate(&h->ev[i]));
+        EAO_HIP(hipEventRecord(h->ev[0], st));
+    }
+    for (int l = 1; l < g.nlevels; l++) {
+        dim3 grid(eao::cdiv(g.L[l].w, 256), eao::cdiv(g.L[l].h, 4), batch), block(64, 4);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, st, h->d_geom.p, h->d_tab.p, s, l);
+    }
+    if (prof) EAO_HIP(hipEventRecord(h->ev[1], st));
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, batch), dim3(256), 0, st, h->d_geom.p, h->d_cells.p, s,
+                       h->d_cellcand.p, h->d_cellcnt.p);
+    if (prof) EAO_HIP(hipEventRecord(h->ev[2], st));
+    hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, batch), dim3(256), h->quadLds, st, h->d_geom.p, h->d_cellcand.p,
+                       h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p);
+    if (prof) EAO_HIP(hipEventRecord(h->ev[3], st));
+    hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, batch), dim3(256), 0, st, h->d_geom.p, s, h->d_blur.p, h->d_levelcnt.p);
+    if (prof) EAO_HIP(hipEventRecord(h->ev[4], st));
+    hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), batch), dim3(256), 0, st, h->d_geom.p, s,
+                       h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap);
+    if (prof) {
+        EAO_HIP(hipEventRecord(h->ev[5], st));
+        h->evValid = true;
+    }
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+eao_status eao_orb_create(const eao_orb_cfg* cfg, eao_orb** out) {
+    EAO_REQUIRE(cfg && out, "null argument");
+    EAO_REQUIRE(cfg->nlevels >= 1 && cfg->nlevels <= kMaxLevels, "nlevels must be in 1..%d", kMaxLevels);
+    EAO_REQUIRE(cfg->nfeatures >= 1 && cfg->scale_factor > 1.0f, "need nfeatures >= 1 and scale_factor > 1");
+    eao_status st = eao::require_device();
+    if (st) return st;
+    eao_orb* h = new eao_orb();
+    h->cfg = *cfg;
+    const int nl = cfg->nlevels;
+    const double scaleFactor = cfg->scale_factor;  // the reference keeps this member as a double (include/ORBextractor.h:97)
+    h->scale.resize(nl); h->sigma2.resize(nl); h->invScale.resize(nl); h->invSigma2.resize(nl); h->quota.resize(nl);
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) {
+        h->scale[i] = (float)(h->scale[i - 1] * scaleFactor);
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < nl; i++) {
+        h->invScale[i] = 1.0f / h->scale[i];
+        h->invSigma2[i] = 1.0f / h->sigma2[i];
+    }
+    const float factor = (float)(1.0f / scaleFactor);
+    float desired = cfg->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        h->quota[l] = cv_round(desired);
+        sum += h->quota[l];
+        desired *= factor;
+    }
+    h->quota[nl - 1] = std::max(cfg->nfeatures - sum, 0);
+    {   // end of each row of the radius-15 disc (reference src/ORBextractor.cc:455-469)
+        const int vmax = (int)std::floor(15 * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(15 * std::sqrt(2.f) / 2);
+        for (int v = 0; v <= vmax; ++v) h->umax[v] = cv_round(std::sqrt(225.0 - v * v));
+        for (int v = 15, v0 = 0; v >= vmin; --v) {
+            while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+            h->umax[v] = v0;
+            ++v0;
+        }
+    }
+    *out = h;
+    return EAO_OK;
+}
+
+void eao_orb_destroy(eao_orb* h) {
+    if (!h) return;
+    for (int i = 0; i < 6; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+}
+
+eao_status eao_orb_tables(const eao_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* fpl) {
+    EAO_REQUIRE(h, "null handle");
+    for (int i = 0; i < h->cfg.nlevels; i++) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->invScale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->invSigma2[i];
+        if (fpl) fpl[i] = h->quota[i];
+    }
+    return EAO_OK;
+}
+
+eao_status eao_orb_max_keypoints(eao_orb* h, int32_t width, int32_t height, int32_t* cap) {
+    EAO_REQUIRE(h && cap, "null argument");
+    eao_status st = ensure(h, width, height, 0);
+    if (st) return st;
+    *cap = h->geom.totalKpCap;
+    return EAO_OK;
+}
+
+eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_t width, int32_t height, int32_t stride,
+                                        int64_t frame_stride, int32_t batch, eao_keypoint* d_kps, uint8_t* d_desc, int32_t cap,
+                                        int32_t* d_n, void* stream) {
+    EAO_REQUIRE(h && d_img && d_kps && d_desc && d_n, "null argument");
+    EAO_REQUIRE(width > 0 && height > 0 && stride >= width && batch >= 1, "bad image geometry");
+    eao_status st = ensure(h, width, height, batch);
+    if (st) return st;
+    if (cap < h->geom.totalKpCap) {
+        eao::set_error("cap %d < eao_orb_max_keypoints %d", cap, h->geom.totalKpCap);
+        return EAO_ERR_CAPACITY;
+    }
+    return enqueue(h, d_img, stride, frame_stride, batch, d_kps, d_desc, cap, d_n, stream ? (hipStream_t)stream : h->stream);
+}
+
+eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, int64_t frame_stride,
+                                 int32_t batch, eao_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n) {
+    EAO_REQUIRE(h && n, "null argument");
+    if (!img || width <= 0 || height <= 0) {  // empty image: outputs untouched (reference :1046-1047)
+        for (int f = 0; f < std::max(batch, 0); f++) n[f] = 0;
+        return EAO_OK;
+    }
+    EAO_REQUIRE(kps && desc && stride >= width && batch >= 1, "bad argument");
+    eao_status st = ensure(h, width, height, batch);
+    if (st) return st;
+    const Geom& g = h->geom;
+    if (cap < g.totalKpCap) {
+        eao::set_error("cap %d < eao_orb_max_keypoints %d", cap, g.totalKpCap);
+        return EAO_ERR_CAPACITY;
+    }
+    const size_t B = batch;
+    if ((st = h->d_in.reserve(B * (size_t)g.L[0].pitch * height))) return st;
+    if ((st = h->d_kps.reserve(B * (size_t)cap))) return st;
+    if ((st = h->d_desc.reserve(B * (size_t)cap * 32))) return st;
+    if ((st = h->d_nout.reserve(B))) return st;
+    const long long fs0 = (long long)g.L[0].pitch * height;
+    for (int f = 0; f < batch; f++)
+        EAO_HIP(hipMemcpy2DAsync(h->d_in.p + f * fs0, g.L[0].pitch, img + (long long)f * frame_stride, stride, width, height,
+                                 hipMemcpyHostToDevice, h->stream));
+    st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, batch, h->d_kps.p, h->d_desc.p, cap, h->d_nout.p, h->stream);
+    if (st) return st;
+    EAO_HIP(hipMemcpyAsync(n, h->d_nout.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    EAO_HIP(hipMemcpyAsync(kps, h->d_kps.p, B * cap * sizeof(eao_keypoint), hipMemcpyDeviceToHost, h->stream));
+    EAO_HIP(hipMemcpyAsync(desc, h->d_desc.p, B * (size_t)cap * 32, hipMemcpyDeviceToHost, h->stream));
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    return EAO_OK;
+}
+
+eao_status eao_orb_extract(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, eao_keypoint* kps,
+                           uint8_t* desc, int32_t cap, int32_t* n) {
+    return eao_orb_extract_batch(h, img, width, height, stride, 0, 1, kps, desc, cap, n);
+}
+
+eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which, int32_t* w, int32_t* hgt, uint8_t* dst) {
+    EAO_REQUIRE(h && h->geomValid && h->lastBatch > 0, "no extraction has run on this handle");
+    EAO_REQUIRE(frame >= 0 && frame < h->lastBatch && level >= 0 && level < h->geom.nlevels, "frame/level out of range");
+    const LevelGeom& L = h->geom.L[level];
+    if (w) *w = L.w;
+    if (hgt) *hgt = L.h;
+    if (!dst) return EAO_OK;
+    const uint8_t* src;
+    int pitch;
+    if (which == 0 && level == 0) {
+        src = h->lastSrc.img0 + (long long)frame * h->lastSrc.fs0;
+        pitch = h->lastSrc.pitch0;
+    } else {
+        src = (which ? h->d_blur.p : h->d_pyr.p) + (long long)frame * h->geom.pyrFrameBytes + L.off;
+        pitch = L.pitch;
+    }
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(hipMemcpy2D(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return EAO_OK;
+}
+
+eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, float* xyr, int32_t cap, int32_t* n) {
+    EAO_REQUIRE(h && n && h->geomValid && h->lastBatch > 0, "no extraction has run on this handle");
+    EAO_REQUIRE(frame >= 0 && frame < h->lastBatch && level >= 0 && level < h->geom.nlevels, "frame/level out of range");
+    const Geom& g = h->geom;
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    int cnt = 0;
+    EAO_HIP(hipMemcpy(&cnt, h->d_candcnt.p + frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n = cnt;
+    if (!xyr || cnt == 0) return EAO_OK;
+    const int m = std::min(cnt, cap);
+    eao_status st = h->d_xyr.reserve((size_t)m * 3);
+    if (st) return st;
+    hipLaunchKernelGGL(k_unpack_cand, dim3(eao::cdiv(m, 256)), dim3(256), 0, h->stream,
+                       h->d_cand.p + (long long)frame * g.totalCandCap + g.L[level].candBase, m, h->d_xyr.p);
+    EAO_HIP(hipMemcpyAsync(xyr, h->d_xyr.p, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    return EAO_OK;
+}
+
+eao_status eao_orb_set_profiling(eao_orb* h, int32_t on) {
+    EAO_REQUIRE(h, "null handle");
+    h->profiling = on != 0;
+    h->evValid = false;
+    return EAO_OK;
+}
+
+eao_status eao_orb_last_timing(eao_orb* h, float ms[6]) {
+    EAO_REQUIRE(h && ms && h->evValid, "profiling was not enabled for the last call");
+    EAO_HIP(hipEventSynchronize(h->ev[5]));
+    for (int i = 0; i < 5; i++) EAO_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    EAO_HIP(hipEventElapsedTime(&ms[5], h->ev[0], h->ev[5]));
+    return EAO_OK;
+}
+
+}  // extern "C"

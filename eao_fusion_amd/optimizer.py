@@ -1,0 +1,72 @@
+"""Optimizer -- PoseOptimization / LocalBundleAdjustment over flattened problems (reference
+include/Optimizer.h:55-56, src/Optimizer.cc:325-673,675-1138); compute is eao_pose_optimization /
+eao_local_ba in libeaofusion_hip.so."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _trace():
+    L = _lib.load()
+    lam = np.zeros(128)
+    chi = np.zeros(128)
+    tr = np.zeros(128, np.int32)
+    n = C.c_int32()
+    _lib.check(L.eao_last_lm_trace(_lib.ptr(lam), _lib.ptr(chi), _lib.ptr(tr), 128, C.byref(n)))
+    return dict(lam=lam[:n.value], chi2=chi[:n.value], trials=tr[:n.value])
+
+
+def _timing():
+    ms, lin = C.c_float(), C.c_int32()
+    if _lib.load().eao_last_lm_timing(C.byref(ms), C.byref(lin)) != 0:
+        return None
+    return dict(device_ms=ms.value, linearizations=lin.value)
+
+
+class Optimizer:
+    @staticmethod
+    def PoseOptimization(prob):
+        """prob: Tcw (4,4) f32, points (n,3) f32, obs (n,3) f32 [u, v, ur (<0 = mono)], inv_sigma2 (n,), fx..bf.
+        Returns dict(Tcw, outlier, n_inliers) -- n_inliers is the reference's return value."""
+        Tcw = np.ascontiguousarray(prob["Tcw"], np.float32)
+        Xw = np.ascontiguousarray(prob["points"], np.float32)
+        obs = np.ascontiguousarray(prob["obs"], np.float32)
+        inv = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+        n = len(Xw)
+        outl = np.zeros(max(n, 1), np.uint8)
+        P = _lib.PoseProblem(n, _lib.ptr(Tcw), _lib.ptr(Xw), _lib.ptr(obs), _lib.ptr(inv), prob["fx"], prob["fy"],
+                             prob["cx"], prob["cy"], prob["bf"])
+        R = _lib.PoseResult()
+        R.outlier = _lib.ptr(outl)
+        _lib.check(_lib.load().eao_pose_optimization(C.byref(P), C.byref(R)))
+        return dict(Tcw=np.array(R.Tcw, np.float32).reshape(4, 4), outlier=outl[:n], n_inliers=R.n_inliers,
+                    lm_iterations=R.lm_iterations, trace=_trace(), timing=_timing())
+
+    @staticmethod
+    def LocalBundleAdjustment(prob, stop=None, its=(5, 10)):
+        """prob: poses (n_cams,4,4) f32, fixed (n_cams,) u8, points (n_points,3) f32, edge_cam, edge_point (E,) i32,
+        obs (E,3) f32, inv_sigma2 (E,) f32, fx..bf.  stop: optional np.uint8[1] polled between LM iterations."""
+        cams = np.ascontiguousarray(prob["poses"], np.float32)
+        fixed = np.ascontiguousarray(prob["fixed"], np.uint8)
+        pts = np.ascontiguousarray(prob["points"], np.float32)
+        ec = np.ascontiguousarray(prob["edge_cam"], np.int32)
+        ep = np.ascontiguousarray(prob["edge_point"], np.int32)
+        obs = np.ascontiguousarray(prob["obs"], np.float32)
+        inv = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+        P = _lib.BAProblem(len(cams), len(pts), len(ec), _lib.ptr(cams), _lib.ptr(fixed), _lib.ptr(pts), _lib.ptr(ec),
+                           _lib.ptr(ep), _lib.ptr(obs), _lib.ptr(inv), prob["fx"], prob["fy"], prob["cx"], prob["cy"],
+                           prob["bf"], its[0], its[1])
+        cams_out = np.zeros_like(cams)
+        pts_out = np.zeros_like(pts)
+        outl = np.zeros(max(len(ec), 1), np.uint8)
+        R = _lib.BAResult()
+        R.cam_Tcw, R.points, R.edge_outlier = _lib.ptr(cams_out), _lib.ptr(pts_out), _lib.ptr(outl)
+        stop_p = None
+        if stop is not None:
+            stop = np.ascontiguousarray(stop, np.uint8)
+            stop_p = _lib.ptr(stop)
+        _lib.check(_lib.load().eao_local_ba(C.byref(P), stop_p, C.byref(R)))
+        return dict(poses=cams_out, points=pts_out, edge_outlier=outl[:len(ec)], iters=np.array(R.iters[:]),
+                    aborted=bool(R.aborted), chi2=np.array(R.chi2[:]), trace=_trace(), timing=_timing())

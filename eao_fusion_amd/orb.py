@@ -1,0 +1,120 @@
+"""ORBextractor -- same constructor arguments, call semantics and getters as the reference class
+(reference include/ORBextractor.h:45-111); compute is eao_orb_* in libeaofusion_hip.so."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])  # cv::KeyPoint, 28 bytes
+
+EDGE_THRESHOLD = 19
+
+
+class ORBextractor:
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST):
+        self._L = _lib.load()
+        self.nfeatures, self.scaleFactor, self.nlevels = int(nfeatures), float(scaleFactor), int(nlevels)
+        self.iniThFAST, self.minThFAST = int(iniThFAST), int(minThFAST)
+        cfg = _lib.OrbCfg(self.nfeatures, self.scaleFactor, self.nlevels, self.iniThFAST, self.minThFAST)
+        self._h = C.c_void_p()
+        _lib.check(self._L.eao_orb_create(C.byref(cfg), C.byref(self._h)))
+        n = self.nlevels
+        self._scale, self._inv, self._s2, self._is2 = (np.zeros(n, np.float32) for _ in range(4))
+        self._quota = np.zeros(n, np.int32)
+        _lib.check(self._L.eao_orb_tables(self._h, _lib.ptr(self._scale), _lib.ptr(self._inv), _lib.ptr(self._s2),
+                                         _lib.ptr(self._is2), _lib.ptr(self._quota)))
+        self._last_shape = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.eao_orb_destroy(self._h)
+        except Exception:
+            pass
+
+    # --- reference getters (include/ORBextractor.h:63-83)
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return self.scaleFactor
+
+    def GetScaleFactors(self):
+        return self._scale.copy()
+
+    def GetInverseScaleFactors(self):
+        return self._inv.copy()
+
+    def GetScaleSigmaSquares(self):
+        return self._s2.copy()
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._is2.copy()
+
+    @property
+    def mnFeaturesPerLevel(self):
+        return self._quota.copy()
+
+    def max_keypoints(self, width, height):
+        cap = C.c_int32()
+        _lib.check(self._L.eao_orb_max_keypoints(self._h, width, height, C.byref(cap)))
+        return cap.value
+
+    # --- operator()(image, mask, keypoints, descriptors): mask is ignored upstream too (include/ORBextractor.h:58)
+    def __call__(self, image, mask=None):
+        if image is None or image.size == 0:
+            return None, None  # reference returns without touching its outputs (src/ORBextractor.cc:1046-1047)
+        kps, desc = self.extract_batch(image[None])
+        return kps[0], desc[0]
+
+    def extract_batch(self, images):
+        """images: (B, H, W) uint8.  Returns per-frame lists of (keypoints, descriptors)."""
+        images = np.ascontiguousarray(images)
+        assert images.dtype == np.uint8 and images.ndim == 3, "CV_8UC1 images expected (reference asserts the same)"
+        B, H, W = images.shape
+        cap = self.max_keypoints(W, H)
+        kps = np.zeros((B, cap), KP_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        _lib.check(self._L.eao_orb_extract_batch(self._h, _lib.ptr(images), W, H, W, H * W, B, _lib.ptr(kps), _lib.ptr(desc),
+                                                cap, _lib.ptr(n)))
+        self._last_shape = (B, H, W)
+        return [kps[f, :n[f]] for f in range(B)], [desc[f, :n[f]] for f in range(B)]
+
+    def extract_batch_device(self, d_img, width, height, stride, frame_stride, batch, d_kps, d_desc, cap, d_n, stream=0):
+        """Device-resident variant: all pointers are integers (HBM addresses), asynchronous on `stream`."""
+        _lib.check(self._L.eao_orb_extract_batch_device(self._h, d_img, width, height, stride, frame_stride, batch, d_kps,
+                                                       d_desc, cap, d_n, stream))
+        self._last_shape = (batch, height, width)
+
+    def set_profiling(self, on):
+        _lib.check(self._L.eao_orb_set_profiling(self._h, 1 if on else 0))
+
+    def last_timing(self):
+        ms = (C.c_float * 6)()
+        _lib.check(self._L.eao_orb_last_timing(self._h, ms))
+        return dict(zip(("pyramid", "fast", "quadtree", "blur", "orient_describe", "total"), list(ms)))
+
+    # --- stage taps
+    def level_image(self, level, frame=0, blurred=False):
+        w, h = C.c_int32(), C.c_int32()
+        _lib.check(self._L.eao_orb_level(self._h, frame, level, 1 if blurred else 0, C.byref(w), C.byref(h), None))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _lib.check(self._L.eao_orb_level(self._h, frame, level, 1 if blurred else 0, None, None, _lib.ptr(out)))
+        return out
+
+    def level_candidates(self, level, frame=0):
+        n = C.c_int32()
+        _lib.check(self._L.eao_orb_level_candidates(self._h, frame, level, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 3), np.float32)
+        if n.value:
+            _lib.check(self._L.eao_orb_level_candidates(self._h, frame, level, _lib.ptr(out), n.value, C.byref(n)))
+        return out
+
+    @property
+    def mvImagePyramid(self):
+        """Level images of frame 0 of the last call with the reference's 19 px BORDER_REFLECT_101 frame
+        (src/ORBextractor.cc:1113-1128); the hot path itself never reads the border."""
+        return [np.pad(self.level_image(l), EDGE_THRESHOLD, mode="reflect") for l in range(self.nlevels)]

@@ -1,0 +1,198 @@
+/* eao_fusion.h -- C-ABI of libeaofusion_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for EAO-Fusion's ORB front-end + local-BA hot path.  The reference has no FFI/plugin
+ * layer: its boundary is the C++ class surface ORB_SLAM2::{ORBextractor, ORBmatcher, Optimizer}.  The
+ * header-only adapters in include/eaofusion/ keep those signatures and call the functions below; every
+ * entry point cites the reference interface it stands behind.  Plain pointers and sizes only -- no C++,
+ * OpenCV, Eigen or torch types cross this ABI.
+ *
+ * Conventions
+ *  - every function returns eao_status (0 = ok, < 0 = error) and never throws; eao_last_error() gives the
+ *    thread-local message of the last failure.
+ *  - the caller allocates all outputs; the library owns device memory inside handles.
+ *  - "_device" variants take pointers that are already resident in HBM and a hipStream_t passed as void*
+ *    (NULL = the handle's own stream); they enqueue work and do NOT synchronise.
+ *  - a handle is single-threaded (one HIP stream each); distinct handles are independent; the stateless
+ *    functions are thread-safe.
+ *  - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *    EAO_ERR_NO_DEVICE.
+ */
+#ifndef EAO_FUSION_H_
+#define EAO_FUSION_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t eao_status;
+enum {
+    EAO_OK = 0,
+    EAO_ERR_INVALID = -1,    /* bad argument / unsupported geometry */
+    EAO_ERR_NO_DEVICE = -2,  /* no HIP device or HIP runtime failure */
+    EAO_ERR_CAPACITY = -3,   /* caller-provided output capacity too small */
+    EAO_ERR_INTERNAL = -4
+};
+
+const char* eao_last_error(void);
+/* 0 when a gfx950-class device is usable by this process, else EAO_ERR_NO_DEVICE (never initialises a context
+ * beyond hipGetDeviceCount / hipGetDeviceProperties). */
+eao_status eao_device_check(void);
+const char* eao_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ORB extraction -- replaces ORB_SLAM2::ORBextractor
+ *   ctor        reference include/ORBextractor.h:52-53, src/ORBextractor.cc:410-470
+ *   operator()  reference include/ORBextractor.h:60-62, src/ORBextractor.cc:1043-1105
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct eao_orb eao_orb; /* opaque handle */
+
+typedef struct {
+    int32_t nfeatures;   /* ORBextractor.nFeatures  */
+    float scale_factor;  /* ORBextractor.scaleFactor */
+    int32_t nlevels;     /* ORBextractor.nLevels (1..16) */
+    int32_t ini_th_fast; /* ORBextractor.iniThFAST */
+    int32_t min_th_fast; /* ORBextractor.minThFAST */
+} eao_orb_cfg;
+
+/* cv::KeyPoint POD mirror (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} eao_keypoint;
+
+eao_status eao_orb_create(const eao_orb_cfg* cfg, eao_orb** out);
+void eao_orb_destroy(eao_orb* h);
+
+/* scale tables exposed by the reference getters (include/ORBextractor.h:63-83); arrays of nlevels floats/ints,
+ * any pointer may be NULL */
+eao_status eao_orb_tables(const eao_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                          int32_t* features_per_level);
+
+/* Upper bound on keypoints returned per frame of the given size (the quad-tree can return a few more than
+ * nfeatures: it stops at the first list size >= quota).  Use it to size kps/desc. */
+eao_status eao_orb_max_keypoints(eao_orb* h, int32_t width, int32_t height, int32_t* cap);
+
+/* One frame from host memory, synchronous: operator()(image, mask, keypoints, descriptors).
+ * img: 8-bit single channel, `stride` bytes per row.  kps/desc: capacity `cap` keypoints (desc = cap*32 bytes).
+ * *n receives the number of keypoints.  Empty image (img NULL or w/h <= 0) => *n = 0, outputs untouched
+ * (reference src/ORBextractor.cc:1046-1047). */
+eao_status eao_orb_extract(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride,
+                           eao_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n);
+
+/* Batch of `batch` same-sized frames from host memory, synchronous.  Frame f starts at img + f*frame_stride.
+ * kps: batch*cap entries, desc: batch*cap*32 bytes, n: batch counts. */
+eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride,
+                                 int64_t frame_stride, int32_t batch, eao_keypoint* kps, uint8_t* desc, int32_t cap,
+                                 int32_t* n);
+
+/* Same, all pointers device-resident (HBM), asynchronous on `stream`.  d_n: batch int32 on the device. */
+eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_t width, int32_t height,
+                                        int32_t stride, int64_t frame_stride, int32_t batch, eao_keypoint* d_kps,
+                                        uint8_t* d_desc, int32_t cap, int32_t* d_n, void* stream);
+
+/* Pyramid level of frame `frame` of the LAST extract call, copied to host (tight rows, w*h bytes): backs the
+ * public member ORBextractor::mvImagePyramid (include/ORBextractor.h:85).  which = 0 level image, 1 = its
+ * 7x7 Gaussian-blurred copy.  Either of w/h/dst may be NULL to query sizes only. */
+eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which, int32_t* w, int32_t* hgt, uint8_t* dst);
+
+/* Stage taps for parity tests (device -> host copies of intermediate products of the LAST extract call).
+ * candidates: FAST corners of (frame, level) in reference order before the quad-tree, as (x, y, response)
+ * float triples relative to the (16,16) level border origin; returns the count in *n (cap in triples). */
+eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, float* xyr, int32_t cap, int32_t* n);
+
+/* HIP-event timing of the kernels of the last *_device / extract call, in milliseconds, in pipeline order:
+ * [0] pyramid  [1] fast  [2] quadtree  [3] blur  [4] orient+describe  [5] whole pipeline.  Requires
+ * eao_orb_set_profiling(h, 1) before the call; blocks until the events have completed. */
+eao_status eao_orb_set_profiling(eao_orb* h, int32_t on);
+eao_status eao_orb_last_timing(eao_orb* h, float ms[6]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hamming matching -- replaces ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1649-1665) and
+ * the candidate loops of the Search* routines (e.g. :83-115, :1402-1426)
+ * ------------------------------------------------------------------------------------------------ */
+/* D[i*nb + j] = popcount(A_i xor B_j), A: na x 32 bytes, B: nb x 32 bytes (host pointers, synchronous) */
+eao_status eao_hamming_matrix(const uint8_t* A, int32_t na, const uint8_t* B, int32_t nb, uint16_t* D);
+
+typedef struct {
+    int32_t best;    /* smallest distance, 256 if no candidate */
+    int32_t second;  /* second smallest (reference bestDist2), 256 if none */
+    int32_t idx;     /* column of best, -1 if none; first column wins ties (strict '<' upstream) */
+    int32_t idx2;    /* column of second, -1 if none */
+} eao_best2;
+/* per row of A the best two over the columns j with mask[i*nb + j] != 0 (mask NULL = all) */
+eao_status eao_hamming_best2(const uint8_t* A, int32_t na, const uint8_t* B, int32_t nb, const uint8_t* mask,
+                             eao_best2* out);
+
+/* device-resident variants; `pairs` independent (A,B) problems laid out back to back (pair p: A + p*na*32, ...) */
+eao_status eao_hamming_matrix_device(const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb, int32_t pairs,
+                                     uint16_t* d_D, void* stream);
+eao_status eao_hamming_best2_device(const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb, int32_t pairs,
+                                    const uint8_t* d_mask, eao_best2* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer::PoseOptimization(Frame*) -- reference include/Optimizer.h:56, src/Optimizer.cc:325-673
+ * (point/stereo edges; plane edges src/Optimizer.cc:456-535 are not part of this entry point)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n;               /* matched map points (pFrame->mvpMapPoints[i] != NULL), in index order */
+    const float* Tcw;        /* 16 floats, row-major 4x4: pFrame->mTcw */
+    const float* Xw;         /* n*3: MapPoint::GetWorldPos() */
+    const float* obs;        /* n*3: mvKeysUn[i].pt.x, .pt.y, mvuRight[i]  (mvuRight < 0 => monocular edge) */
+    const float* inv_sigma2; /* n: mvInvLevelSigma2[mvKeysUn[i].octave] */
+    float fx, fy, cx, cy, bf;
+} eao_pose_problem;
+
+typedef struct {
+    float Tcw[16];      /* optimised pose as Converter::toCvMat would deliver it */
+    uint8_t* outlier;   /* n flags: pFrame->mvbOutlier (caller-allocated) */
+    int32_t n_inliers;  /* return value of PoseOptimization: nInitialCorrespondences - nBad */
+    int32_t lm_iterations; /* outer LM iterations executed over the 4 rounds */
+} eao_pose_result;
+
+eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*) -- reference include/Optimizer.h:55,
+ * src/Optimizer.cc:675-1138.  The adapter flattens the local window: cameras in ascending KeyFrame::mnId
+ * (free = lLocalKeyFrames, fixed = lFixedCameras or mnId == 0), points in ascending MapPoint::mnId, edges
+ * in insertion order.  At most one edge per (camera, point).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_cams, n_points, n_edges;
+    const float* cam_Tcw;         /* n_cams*16 */
+    const uint8_t* cam_fixed;     /* n_cams */
+    const float* points;          /* n_points*3 */
+    const int32_t* edge_cam;      /* n_edges */
+    const int32_t* edge_point;    /* n_edges */
+    const float* edge_obs;        /* n_edges*3: u, v, ur (ur < 0 => monocular) */
+    const float* edge_inv_sigma2; /* n_edges */
+    float fx, fy, cx, cy, bf;
+    int32_t its_first, its_second; /* 5 and 10 upstream (src/Optimizer.cc:966,1027) */
+} eao_ba_problem;
+
+typedef struct {
+    float* cam_Tcw;        /* n_cams*16 out */
+    float* points;         /* n_points*3 out */
+    uint8_t* edge_outlier; /* n_edges: observation to erase (chi2 > 5.991/7.815 or depth <= 0), src/Optimizer.cc:1040-1068 */
+    int32_t iters[2];      /* outer LM iterations executed in the two passes */
+    int32_t aborted;       /* 1 when *stop was set on entry (src/Optimizer.cc:961-963): outputs = inputs */
+    double chi2[2];        /* robust chi2 after each pass */
+} eao_ba_result;
+
+/* stop may be NULL; it is polled on the host between LM iterations like g2o's forceStopFlag */
+eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r);
+
+/* LM trace of the last eao_local_ba / eao_pose_optimization call made by this thread (for parity tests):
+ * up to cap entries of (lambda after the iteration, robust chi2, trials). Returns the count in *n. */
+eao_status eao_last_lm_trace(double* lambda, double* chi2, int32_t* trials, int32_t cap, int32_t* n);
+
+/* HIP-event time (ms) spent in device work by the last eao_local_ba / eao_pose_optimization on this thread,
+ * and the number of linearisations (buildSystem calls) it made. */
+eao_status eao_last_lm_timing(float* device_ms, int32_t* linearizations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAO_FUSION_H_ */
