@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the ORB front-end + local-BA hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one batch of synthetic input, inputs already resident in HBM:
+  * ORB extraction of BASELINE.json configs[1]: 64 synthetic 640x480 frames, nFeatures 1000, 8 levels   -> `value`
+  * inside the same timed step, on the same stream: Hamming best-2 matching of consecutive frames'
+    descriptor sets is NOT included in `value` (reported under "extra").
+Local BA (configs[3], 20 KF x 3000 MP) and Hamming (configs[2]) are measured after the timed region and reported
+under "extra" -- the combined BASELINE metric has two halves; `value` is its first half (ORB kpts/s), the BA half
+is extra.ba_residual_blocks_per_s.
+
+Multi-GPU: frames are independent units => each rank extracts its own 64-frame shard (weak scaling, no data-path
+collective); the only collectives are the timing barrier/max and one all_gather of the per-frame keypoint counts
+(RCCL), which is outside the timed region.
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# algorithmic bytes per frame of each stage at 640x480 / 8 levels (DESIGN.md "roofline accounting")
+LEVELS = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+PX = [w * h for w, h in LEVELS]
+BYTES_PYRAMID = sum(PX[:-1]) + sum(PX[1:])      # read levels 0..6, write levels 1..7
+BYTES_FAST = sum(PX)                            # every level read once (+ 4 B per candidate, added at run time)
+BYTES_BLUR = 2 * sum(PX)                        # read + write every level
+BYTES_PER_KP = 749 + 512 + 32 + 28              # IC disc + BRIEF samples + descriptor + keypoint record
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import eao_fusion_amd as E  # after torch: one libamdhip64 in the process
+    from eao_fusion_amd import synth
+
+    B, W, H = args.batch, 640, 480
+    frames = synth.synth_frames(B, seed0=1000 + rank * B, w=W, h=H)
+    d_img = torch.from_numpy(frames).to(dev)
+    ext = E.ORBextractor(1000, 1.2, 8, 20, 7)
+    cap = ext.max_keypoints(W, H)
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ext.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, B, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                 d_n.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ext.set_profiling(True)          # HIP events between the kernels, on the stream they run on
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    stage_ms = ext.last_timing()
+    ext.set_profiling(False)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    kp_step = d_n.to(torch.int64).sum().reshape(1)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kp_step, op=dist.ReduceOp.SUM)
+    elapsed = float(elapsed.item())
+    kp_total_step = int(kp_step.item())
+    value = kp_total_step * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (largest average HIP-event duration over the timed steps)
+    n_host = d_n.cpu().numpy()
+    kp_rank = int(n_host.sum())
+    n_cand = 0
+    try:
+        n_cand = sum(len(ext.level_candidates(l, 0)) for l in range(8)) * B  # frame 0 as the estimate
+    except Exception:
+        pass
+    stage_bytes = {
+        "pyramid": B * BYTES_PYRAMID,
+        "fast": B * BYTES_FAST + 4 * n_cand,
+        "quadtree": 8 * n_cand + 4 * kp_rank,     # candidate words gathered (read+write) + selected keypoints
+        "blur": B * BYTES_BLUR,
+        "orient_describe": kp_rank * BYTES_PER_KP,
+    }
+    dom = max(stage_bytes, key=lambda k: stage_ms[k])
+    achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": int(stage_bytes[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
+                "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                "pipeline_GBps": round(sum(stage_bytes.values()) / (stage_ms["total"] * 1e-3) / 1e9, 2)}
+
+    extra = {}
+    cpu_baseline = None
+    if rank == 0:
+        if not args.no_extra:
+            extra = measure_extra(E, synth, torch, dev)
+        if not args.no_cpu_baseline:
+            cpu_baseline, cpu_extra = measure_cpu(frames, synth, extra)
+            extra.update(cpu_extra)
+    if world > 1:
+        # the batched-sequence config gathers every rank's per-frame keypoint counts over RCCL (outside the timed region)
+        gathered = [torch.zeros_like(d_n) for _ in range(world)]
+        dist.all_gather(gathered, d_n)
+        extra["allgather_frames"] = int(sum(g.numel() for g in gathered))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        out = {
+            "metric": "ORB kpts/s (640x480, 1k feat) + local-BA residuals/s (20 KF x 3k pts)",
+            "value": round(value, 1), "unit": "kpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "ORBextractor FAST+rBRIEF, 640x480, 8-level pyramid, nFeatures 1000, batch=%d synthetic frames per GPU (BASELINE configs[1])" % B,
+                       "frames_per_step": B * world, "keypoints_per_step": kp_total_step, "parallelism": "frames sharded per GPU, no data-path collective"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
+        }
+        print(json.dumps(out))
+
+
+def measure_extra(E, synth, torch, dev):
+    """Hamming (configs[2]) and local BA (configs[3]) on GPU 0, outside the timed region."""
+    extra = {}
+    L = E.load()
+    try:
+        a, b = synth.synth_descriptors(1000, 2000)
+        pairs = 64
+        dA = torch.from_numpy(np.tile(a, (pairs, 1, 1))).to(dev)
+        dB = torch.from_numpy(np.tile(b, (pairs, 1, 1))).to(dev)
+        dD = torch.zeros((pairs, 1000, 1000), dtype=torch.int16, device=dev)
+        dO = torch.zeros((pairs, 1000, 4), dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        for mode in ("matrix", "best2"):
+            def run():
+                if mode == "matrix":
+                    E._lib.check(L.eao_hamming_matrix_device(dA.data_ptr(), 1000, dB.data_ptr(), 1000, pairs, dD.data_ptr(), st))
+                else:
+                    E._lib.check(L.eao_hamming_best2_device(dA.data_ptr(), 1000, dB.data_ptr(), 1000, pairs, None, dO.data_ptr(), st))
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reps = 20
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            byts = pairs * (2_064_000 if mode == "matrix" else 72_000)
+            extra["hamming_%s" % mode] = {"pair_distances_per_s": round(pairs * 1e6 / (ms * 1e-3), 1), "ms_per_launch": round(ms, 4),
+                                          "pairs_per_launch": pairs, "achieved_GBps": round(byts / (ms * 1e-3) / 1e9, 2),
+                                          "frac_hbm": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    except Exception as ex:  # noqa: BLE001
+        extra["hamming_error"] = repr(ex)
+    try:
+        p = synth.synth_ba()
+        E.Optimizer.LocalBundleAdjustment(p)  # warm-up (allocations, code load)
+        t0 = time.perf_counter()
+        reps = 5
+        lin = 0
+        dev_ms = 0.0
+        for _ in range(reps):
+            r = E.Optimizer.LocalBundleAdjustment(p)
+            lin += r["timing"]["linearizations"]
+            dev_ms += r["timing"]["device_ms"]
+        wall = (time.perf_counter() - t0) / reps
+        E_ = len(p["edge_cam"])
+        extra["ba"] = {"workload": "LocalBundleAdjustment 20 free + 4 fixed KF x 3000 MP, E=%d stereo edges, 5+10 LM its (BASELINE configs[3])" % E_,
+                       "ms_per_lba_wall": round(wall * 1e3, 3), "ms_per_lba_device": round(dev_ms / reps, 3),
+                       "linearizations_per_lba": lin / reps,
+                       "ba_residual_blocks_per_s": round(E_ * (lin / reps) / wall, 1),
+                       "ba_scalar_residuals_per_s": round(3 * E_ * (lin / reps) / wall, 1),
+                       "achieved_GBps": round((lin / reps) * (E_ * 520 + 3000 * 360) / wall / 1e9, 3), "iters": [int(x) for x in r["iters"]]}
+        pp = synth.synth_pose()
+        E.Optimizer.PoseOptimization(pp)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            E.Optimizer.PoseOptimization(pp)
+        extra["pose_optimization_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+    except Exception as ex:  # noqa: BLE001
+        extra["ba_error"] = repr(ex)
+    return extra
+
+
+def measure_cpu(frames, synth, extra):
+    """CPU baseline = the oracle ("port" of the reference arithmetic, g++ -O3 -march=native), 1 thread, on a bounded
+    sample of the SAME workload, timed on this box's host cores."""
+    from oracle import oracle as O
+    O.build()
+    orc = O.OrbOracle(1000, 1.2, 8, 20, 7)
+    orc.extract(frames[0])  # warm
+    budget, nk, nf = 12.0, 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget and nf < 4 * len(frames):
+        k, _ = orc.extract(frames[nf % len(frames)])
+        nk += len(k)
+        nf += 1
+    dt = time.perf_counter() - t0
+    cpu = {"value": round(nk / dt, 1), "unit": "kpts/s", "cores": 1, "kind": "port",
+           "sample": "%d of the benchmark's synthetic 640x480 frames through oracle/orb_cpu.cpp (1 thread, %.1f s)" % (nf, dt),
+           "ms_per_frame": round(dt / nf * 1e3, 2), "host_cpus": os.cpu_count()}
+    ex = {}
+    try:
+        p = synth.synth_ba()
+        O.local_ba(p)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 5.0:
+            r = O.local_ba(p)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        lin = int(r["trace"]["trials"].sum()) if len(r["trace"]["trials"]) else 0  # error passes; linearisations = outer its
+        outer = int(r["iters"].sum())
+        ex["cpu_ba"] = {"ms_per_lba": round(dt * 1e3, 3), "ba_residual_blocks_per_s": round(len(p["edge_cam"]) * outer / dt, 1),
+                        "cores": 1, "kind": "port", "sample": "%d x oracle/lm_cpu.cpp LocalBundleAdjustment on the same window" % reps,
+                        "lm_trials": lin}
+        a, b = synth.synth_descriptors(1000, 2000)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 3.0:
+            O.hamming_matrix(a, b)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        ex["cpu_hamming_matrix"] = {"pair_distances_per_s": round(1e6 / dt, 1), "cores": 1, "kind": "port"}
+    except Exception as e:  # noqa: BLE001
+        ex["cpu_extra_error"] = repr(e)
+    return cpu, ex
+
+
+if __name__ == "__main__":
+    main()

@@ -697,8 +697,8 @@ struct eao_orb {
     ImgSrc lastSrc{};
     int lastBatch = 0;
     bool profiling = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool evValid = false;
+    std::vector<hipEvent_t> evs;   // 6 events per profiled call, averaged by eao_orb_last_timing
+    size_t evUsed = 0;
 };
 
 namespace {
@@ -871,29 +871,33 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
     s.img0 = d_img; s.pitch0 = pitch0; s.fs0 = fs0; s.pyr = h->d_pyr.p;
     h->lastSrc = s; h->lastBatch = batch;
     const bool prof = h->profiling;
+    hipEvent_t* ev = nullptr;
     if (prof) {
-        for (int i = 0; i < 6; i++) if (!h->ev[i]) EAO_HIP(hipEventCreate(&h->ev[i]));
-        EAO_HIP(hipEventRecord(h->ev[0], st));
+        if (h->evUsed + 6 > h->evs.size()) {
+            const size_t old = h->evs.size();
+            h->evs.resize(old + 6 * 16, nullptr);
+            for (size_t i = old; i < h->evs.size(); i++) EAO_HIP(hipEventCreate(&h->evs[i]));
+        }
+        ev = &h->evs[h->evUsed];
+        h->evUsed += 6;
+        EAO_HIP(hipEventRecord(ev[0], st));
     }
     for (int l = 1; l < g.nlevels; l++) {
         dim3 grid(eao::cdiv(g.L[l].w, 256), eao::cdiv(g.L[l].h, 4), batch), block(64, 4);
         hipLaunchKernelGGL(k_resize, grid, block, 0, st, h->d_geom.p, h->d_tab.p, s, l);
     }
-    if (prof) EAO_HIP(hipEventRecord(h->ev[1], st));
+    if (prof) EAO_HIP(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, batch), dim3(256), 0, st, h->d_geom.p, h->d_cells.p, s,
                        h->d_cellcand.p, h->d_cellcnt.p);
-    if (prof) EAO_HIP(hipEventRecord(h->ev[2], st));
+    if (prof) EAO_HIP(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, batch), dim3(256), h->quadLds, st, h->d_geom.p, h->d_cellcand.p,
                        h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p);
-    if (prof) EAO_HIP(hipEventRecord(h->ev[3], st));
+    if (prof) EAO_HIP(hipEventRecord(ev[3], st));
     hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, batch), dim3(256), 0, st, h->d_geom.p, s, h->d_blur.p, h->d_levelcnt.p);
-    if (prof) EAO_HIP(hipEventRecord(h->ev[4], st));
+    if (prof) EAO_HIP(hipEventRecord(ev[4], st));
     hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), batch), dim3(256), 0, st, h->d_geom.p, s,
                        h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap);
-    if (prof) {
-        EAO_HIP(hipEventRecord(h->ev[5], st));
-        h->evValid = true;
-    }
+    if (prof) EAO_HIP(hipEventRecord(ev[5], st));
     EAO_HIP(hipGetLastError());
     return EAO_OK;
 }
@@ -946,7 +950,7 @@ eao_status eao_orb_create(const eao_orb_cfg* cfg, eao_orb** out) {
 
 void eao_orb_destroy(eao_orb* h) {
     if (!h) return;
-    for (int i = 0; i < 6; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
 }
@@ -1066,15 +1070,24 @@ eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, fl
 eao_status eao_orb_set_profiling(eao_orb* h, int32_t on) {
     EAO_REQUIRE(h, "null handle");
     h->profiling = on != 0;
-    h->evValid = false;
+    h->evUsed = 0;
     return EAO_OK;
 }
 
 eao_status eao_orb_last_timing(eao_orb* h, float ms[6]) {
-    EAO_REQUIRE(h && ms && h->evValid, "profiling was not enabled for the last call");
-    EAO_HIP(hipEventSynchronize(h->ev[5]));
-    for (int i = 0; i < 5; i++) EAO_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
-    EAO_HIP(hipEventElapsedTime(&ms[5], h->ev[0], h->ev[5]));
+    EAO_REQUIRE(h && ms && h->evUsed >= 6, "no profiled call since eao_orb_set_profiling(h, 1)");
+    const size_t calls = h->evUsed / 6;
+    EAO_HIP(hipEventSynchronize(h->evs[h->evUsed - 1]));
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t c = 0; c < calls; c++) {
+        hipEvent_t* ev = &h->evs[c * 6];
+        float t;
+        for (int i = 0; i < 5; i++) { EAO_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1])); acc[i] += t; }
+        EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[5]));
+        acc[5] += t;
+    }
+    for (int i = 0; i < 6; i++) ms[i] = (float)(acc[i] / calls);
+    h->evUsed = 0;
     return EAO_OK;
 }
 

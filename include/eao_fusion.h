@@ -102,9 +102,10 @@ eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which
  * float triples relative to the (16,16) level border origin; returns the count in *n (cap in triples). */
 eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, float* xyr, int32_t cap, int32_t* n);
 
-/* HIP-event timing of the kernels of the last *_device / extract call, in milliseconds, in pipeline order:
- * [0] pyramid  [1] fast  [2] quadtree  [3] blur  [4] orient+describe  [5] whole pipeline.  Requires
- * eao_orb_set_profiling(h, 1) before the call; blocks until the events have completed. */
+/* HIP-event timing of the pipeline stages, in milliseconds, in pipeline order:
+ * [0] pyramid  [1] fast  [2] quadtree  [3] blur  [4] orient+describe  [5] whole pipeline,
+ * AVERAGED over every extract call made since eao_orb_set_profiling(h, 1) (events are recorded on the stream the
+ * kernels run on); reading blocks until the events have completed and restarts the average. */
 eao_status eao_orb_set_profiling(eao_orb* h, int32_t on);
 eao_status eao_orb_last_timing(eao_orb* h, float ms[6]);
 
