@@ -8,14 +8,14 @@
 //
 //  PoseOptimization  : ONE persistent 1024-thread workgroup runs all 4 rounds x <=10 LM iterations x <=10
 //                      trials on the device (no host round trip): per-edge 2x6/3x6 Jacobians in registers,
-//                      fixed-order shuffle/LDS reductions of the 28 accumulators, 6x6 pivoted LDLT by lane 0.
+//                      fixed-order shuffle/LDS reductions of the 28 accumulators, 6x6 LDLT by lane 0.
 //  LocalBundleAdjustment : multi-workgroup kernels per LM trial, all reductions in a fixed order
 //      k_ba_linearize   role A (one thread per map point): residual Jacobians, Hll/bl, per-edge 6x3 Hpl blocks
 //                       role B (one workgroup per free camera): Hpp/bp by a fixed-order tree over its edges
-//      k_ba_point_prep  (Hll + lambda I)^-1 (3x3 cofactor inverse), Dinv*bl, Y = Hpl*Dinv per edge
-//      k_ba_schur       one workgroup per (free camera, edge chunk): thread (i2,r,c) accumulates its element of
-//                       -sum_l Y_{i1,l} Hpl_{i2,l}^T through a dense point x camera edge table (no atomics)
-//      k_ba_solve       120x120 (6*nFree) LDLT in LDS by one workgroup, pose update exp(dx)*T
+//      k_ba_schur       one workgroup per (free camera, edge chunk): stages Y = Hpl (Hll+lambda I)^-1 in LDS, then thread
+//                       (i2,r,c) accumulates its element of -sum_l Y_{i1,l} Hpl_{i2,l}^T through a dense point x camera
+//                       edge table (no atomics, fixed order)
+//      k_ba_solve       6*nFree square blocked LDLT in LDS (1024 threads, 6-row panels), pose update exp(dx)*T
 //      k_ba_backsub     per point: x_l = Dinv (bl - Hpl^T x_p), new point, residuals + robust chi2 at the trial state
 //      k_ba_decide      fixed-order sums, rho, lambda / nu update; status lands in pinned host memory
 //  Blocks are 6x6 / 6x3 / 3x3: no MFMA shape fits; everything is fp64 VALU + LDS and the path is
@@ -25,6 +25,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -44,19 +45,21 @@ __host__ __device__ inline Quat quat_from_matrix(const double m[9]) {
         q.w = 0.5 * t;
         t = 0.5 / t;
         q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
-    } else {
-        int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
-        double v[3];
-        v[i] = 0.5 * t;
+    } else if (m[0] >= m[4] && m[0] >= m[8]) {   // i = 0 (Eigen picks the largest diagonal; ties go to the lower index)
+        t = sqrt(m[0] - m[4] - m[8] + 1.0);
+        q.x = 0.5 * t;
         t = 0.5 / t;
-        q.w = (m[k * 3 + j] - m[j * 3 + k]) * t;
-        v[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-        v[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
-        q.x = v[0]; q.y = v[1]; q.z = v[2];
+        q.w = (m[7] - m[5]) * t; q.y = (m[3] + m[1]) * t; q.z = (m[6] + m[2]) * t;
+    } else if (m[4] > m[0] && m[4] >= m[8]) {    // i = 1
+        t = sqrt(m[4] - m[8] - m[0] + 1.0);
+        q.y = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (m[2] - m[6]) * t; q.z = (m[7] + m[5]) * t; q.x = (m[1] + m[3]) * t;
+    } else {                                        // i = 2
+        t = sqrt(m[8] - m[0] - m[4] + 1.0);
+        q.z = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (m[3] - m[1]) * t; q.x = (m[2] + m[6]) * t; q.y = (m[5] + m[7]) * t;
     }
     return q;
 }
@@ -145,6 +148,14 @@ inline void se3_to_Tcw_f32(const SE3& s, float* T) {  // Converter::toCvMat(SE3Q
     T[15] = 1.f;
 }
 
+// 1/x by v_rcp_f64 + two Newton steps (~1 ulp): the solver's pivots and the projection denominators
+__device__ inline double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 __device__ inline void huber(double e, double delta, double& rho0, double& rho1) {
     const double dsqr = delta * delta;
     if (e <= dsqr) { rho0 = e; rho1 = 1.; }
@@ -173,42 +184,45 @@ __device__ inline void block_sum(double (&v)[NV], double* lds /* (NT/64)*NV */, 
     __syncthreads();
 }
 
-// pivoted LDLT solve (largest |diagonal| pivot), n = 6; mirrors Eigen::LDLT as g2o's dense solver uses it
-__device__ inline bool ldlt6_pivot_solve(const double* Ain, const double* b, double* x) {
-    constexpr int n = 6;
-    double A[36], d[6], y[6];
-    int perm[6];
-    for (int i = 0; i < 36; i++) A[i] = Ain[i];
-    for (int i = 0; i < n; i++) perm[i] = i;
+// 6x6 LDLT solve of the damped pose system.  g2o's dense solver (solvers/linear_solver_dense.h:104-112) uses Eigen's
+// diagonally pivoted LDLT and reports failure when the matrix is not positive; an unpivoted factorisation has the same
+// inertia (Sylvester), hence the same success/failure decision, and the same solution up to rounding -- and it keeps
+// every index static (registers, no scratch).
+__device__ inline bool ldlt6_solve(const double* A, const double* b, double* x) {
+    double a[6][6], inv[6], y[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) a[r][c] = A[r * 6 + c];
     bool positive = true;
-    for (int k = 0; k < n; k++) {
-        int p = k;
-        double big = fabs(A[k * n + k]);
-        for (int i = k + 1; i < n; i++) if (fabs(A[i * n + i]) > big) { big = fabs(A[i * n + i]); p = i; }
-        if (p != k) {
-            for (int j = 0; j < n; j++) { const double tmp = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = tmp; }
-            for (int i = 0; i < n; i++) { const double tmp = A[i * n + k]; A[i * n + k] = A[i * n + p]; A[i * n + p] = tmp; }
-            const int tp = perm[k]; perm[k] = perm[p]; perm[p] = tp;
-        }
-        const double dk = A[k * n + k];
-        d[k] = dk;
-        if (!(dk > 0)) positive = false;
-        if (dk == 0) continue;
-        for (int i = k + 1; i < n; i++) {
-            const double l = A[i * n + k] / dk;
-            for (int j = k + 1; j <= i; j++) { A[i * n + j] -= l * A[k * n + j]; A[j * n + i] = A[i * n + j]; }
-            A[i * n + k] = l;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const double d = a[r][r];
+        if (!(d > 0)) positive = false;
+        inv[r] = 1.0 / d;
+#pragma unroll
+        for (int i = r + 1; i < 6; i++) {
+            const double l = a[r][i] * inv[r];
+#pragma unroll
+            for (int c = i; c < 6; c++) a[i][c] -= l * a[r][c];
+            a[i][r] = l;          // keep the multiplier below the diagonal
         }
     }
     if (!positive) return false;
-    for (int i = 0; i < n; i++) y[i] = b[perm[i]];
-    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) y[i] -= A[i * n + j] * y[j];
-    double dmax = 0;
-    for (int i = 0; i < n; i++) dmax = fmax(dmax, fabs(d[i]));
-    const double tol = fmax(dmax * DBL_EPSILON, 1.0 / DBL_MAX);
-    for (int i = 0; i < n; i++) y[i] = (fabs(d[i]) > tol) ? y[i] / d[i] : 0.0;
-    for (int i = n - 1; i >= 0; i--) for (int j = i + 1; j < n; j++) y[i] -= A[j * n + i] * y[j];
-    for (int i = 0; i < n; i++) x[perm[i]] = y[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= a[i][k] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double v = y[i] * inv[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v -= a[k][i] * x[k];
+        x[i] = v;
+    }
     return true;
 }
 
@@ -229,7 +243,7 @@ struct PoseDev {
     double* trace;       // 3 * 64: lambda, chi2, trials
 };
 
-constexpr int kPoseThreads = 1024;
+constexpr int kPoseThreads = 512;
 
 __device__ inline void pose_edge_error(const PoseDev& P, const SE3& est, int i, bool stereo) {
     double p[3];
@@ -302,20 +316,25 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
                     J[0][3] = -invz * c.fx; J[0][4] = 0; J[0][5] = X * invz2 * c.fx;
                     J[1][0] = (1 + Y * Y * invz2) * c.fy; J[1][1] = -X * Y * invz2 * c.fy; J[1][2] = -X * invz * c.fy;
                     J[1][3] = 0; J[1][4] = -invz * c.fy; J[1][5] = Y * invz2 * c.fy;
-                    J[2][0] = J[0][0] - c.bf * Y * invz2; J[2][1] = J[0][1] + c.bf * X * invz2; J[2][2] = J[0][2];
-                    J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - c.bf * invz2;
-                    const int D = stereo ? 3 : 2;
+                    if (stereo) {
+                        J[2][0] = J[0][0] - c.bf * Y * invz2; J[2][1] = J[0][1] + c.bf * X * invz2; J[2][2] = J[0][2];
+                        J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - c.bf * invz2;
+                    } else {   // monocular edge: a zero third row keeps every loop static (registers, no scratch)
+#pragma unroll
+                        for (int a = 0; a < 6; a++) J[2][a] = 0;
+                    }
                     const double info = P.info[i], wi = w * info;
+                    const double e0 = info * P.err[3 * i], e1 = info * P.err[3 * i + 1], e2 = info * P.err[3 * i + 2];
                     int q = 0;
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
-                        double sb = 0;
-                        for (int k = 0; k < D; k++) sb += J[k][a] * (info * P.err[3 * i + k]);
+                        double sb = J[0][a] * e0 + J[1][a] * e1;
+                        sb += J[2][a] * e2;
                         acc[21 + a] -= w * sb;
 #pragma unroll
                         for (int b = a; b < 6; b++) {
-                            double hh = 0;
-                            for (int k = 0; k < D; k++) hh += J[k][a] * wi * J[k][b];
+                            double hh = J[0][a] * wi * J[0][b] + J[1][a] * wi * J[1][b];
+                            hh += J[2][a] * wi * J[2][b];
                             acc[q++] += hh;
                         }
                     }
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
                             for (int b2 = a; b2 < 6; b2++) { A[a * 6 + b2] = sums[q]; A[b2 * 6 + a] = sums[q]; q++; }
                         for (int a = 0; a < 6; a++) { A[a * 7] += s_lambda; b[a] = sums[21 + a]; }
                         double x[6] = {0, 0, 0, 0, 0, 0};
-                        s_ok = ldlt6_pivot_solve(A, b, x) ? 1 : 0;
+                        s_ok = ldlt6_solve(A, b, x) ? 1 : 0;
                         for (int a = 0; a < 6; a++) s_x[a] = x[a];
                         s_est = se3_mul(se3_exp(x), s_est);
                     }
@@ -457,10 +476,9 @@ struct BADev {
     double* Hll;            // nL*9
     double* bl;             // nL*3
     double* Hpl;            // E*18 (pose row block 6x3) for active edges with a free camera
-    double* Y;              // E*18  Hpl * Dinv
-    double* Dinv;           // nL*9
-    double* db;             // nL*3  Dinv*bl
     double* slab;           // chunks * nFree * (nFree*36 + 6): partial Schur rows
+    double* solveScratch;   // n*(n+1)+... doubles when the Schur system does not fit in LDS, else null
+    long long* dbg;         // optional phase stamps of k_ba_solve (diagnostic builds of the harness only)
     double* xp;             // nFree*6
     double* xl;             // nL*3
     double* partChi;        // nL (robust chi2 of the point's edges at the last evaluated state)
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
             const int e = P.ptEdges[k];
             const unsigned char fl = P.eflag[e];
             const bool stereo = fl & 1;
-            const int D = stereo ? 3 : 2;
+            constexpr int D = 3;   // monocular edges carry a zero third row / residual: static loops, no scratch
             double A[3][3], B[3][6];
             ba_jacobians(P.cam, stereo, P.cams[P.ecam[e]], &P.pts[3 * pt], A, B);
             const double* er = &P.err[3 * e];
@@ -614,7 +632,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
             const int e = P.camEdges[k];
             const unsigned char fl = P.eflag[e];
             const bool stereo = fl & 1;
-            const int D = stereo ? 3 : 2;
+            constexpr int D = 3;
             double A[3][3], B[3][6];
             ba_jacobians(P.cam, stereo, T, &P.pts[3 * P.ept[e]], A, B);
             const double* er = &P.err[3 * e];
@@ -659,144 +677,263 @@ __global__ __launch_bounds__(256) void k_ba_lambda_init(BADev P) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_ba_point_prep(BADev P) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= P.nL) return;
-    const double lambda = P.lm[0];
+// (Hll + lambda I)^-1 by cofactors / determinant, as Eigen's fixed-size 3x3 inverse() (block_solver.hpp:392)
+__device__ inline void dinv3(const double* Hll, double lambda, double Di[9]) {
     double A[9];
-    for (int i = 0; i < 9; i++) A[i] = P.Hll[(size_t)l * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) A[i] = Hll[i];
     A[0] += lambda; A[4] += lambda; A[8] += lambda;
-    // Eigen fixed-size 3x3 inverse (cofactors / determinant)
     const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
     const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
     const double id = 1.0 / det;
-    double Di[9];
     Di[0] = c00 * id; Di[1] = (A[2] * A[7] - A[1] * A[8]) * id; Di[2] = (A[1] * A[5] - A[2] * A[4]) * id;
     Di[3] = c01 * id; Di[4] = (A[0] * A[8] - A[2] * A[6]) * id; Di[5] = (A[2] * A[3] - A[0] * A[5]) * id;
     Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-    for (int i = 0; i < 9; i++) P.Dinv[(size_t)l * 9 + i] = Di[i];
-    const double* bl = &P.bl[(size_t)l * 3];
-    for (int i = 0; i < 3; i++) P.db[(size_t)l * 3 + i] = Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2];
-    for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
-        const int e = P.ptEdges[k];
-        if (P.camIdx[P.ecam[e]] < 0) continue;
-        const double* Bi = &P.Hpl[(size_t)e * 18];
-        double* Yo = &P.Y[(size_t)e * 18];
-        for (int r = 0; r < 6; r++)
-            for (int c = 0; c < 3; c++) Yo[r * 3 + c] = Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c];
-    }
 }
 
-// grid (nFree, chunks), 256 threads striding over the nFree*36 + 6 outputs of one partial row:
-//   S(i1, i2) = -sum_l Y(i1,l) Hpl(i2,l)^T   and   coeff(i1) = sum_l Hpl(i1,l) db_l
+// grid (nFree, chunks).  The block stages its chunk of camera i1's edges in LDS -- Y = Hpl * Dinv (18 doubles), Dinv*bl
+// (3) and the point's row of the (point x camera) edge table -- then 256 threads stride over the nFree*36 + 6 outputs:
+//   S(i1, i2) = -sum_l Y(i1,l) Hpl(i2,l)^T   and   coeff(i1) = sum_l Hpl(i1,l) (Dinv bl)_l
 // Every output is accumulated by ONE thread over the chunk's edges in list order: no atomics, reproducible.
+constexpr int kSchurMaxEdges = 128;   // edges staged per pass
+constexpr int kSchurMaxFree = 64;     // free keyframes per window (table row stride in LDS)
+constexpr int kSchurMaxOut = (kSchurMaxFree * 36 + 6 + 255) / 256;
 __global__ __launch_bounds__(256) void k_ba_schur(BADev P) {
+    __shared__ double sY[kSchurMaxEdges * 18];
+    __shared__ double sDb[kSchurMaxEdges * 3];
+    __shared__ int sTab[kSchurMaxEdges * kSchurMaxFree];
+    __shared__ int sE[kSchurMaxEdges];
     const int i1 = blockIdx.x, chunk = blockIdx.y;
     const int nF = P.nFree, rowLen = nF * 36 + 6;
     const int beg = P.camStart[i1], end = P.camStart[i1 + 1];
     const int per = (end - beg + P.chunks - 1) / P.chunks;
-    const int b0 = min(beg + chunk * per, end), e0 = min(b0 + per, end);
-    for (int t = threadIdx.x; t < rowLen; t += 256) {
-        double acc = 0;
-        if (t < nF * 36) {
-            const int i2 = t / 36, r = (t % 36) / 6, c = t % 6;
-            if (i2 >= i1) {
-                for (int k = b0; k < e0; k++) {
-                    const int e = P.camEdges[k];
-                    const int l = P.ptIdx[P.ept[e]];
-                    const int e2 = P.table[(size_t)l * nF + i2];
-                    if (e2 < 0) continue;
-                    const double* Yv = &P.Y[(size_t)e * 18 + r * 3];
-                    const double* Bj = &P.Hpl[(size_t)e2 * 18 + c * 3];
-                    acc -= Yv[0] * Bj[0] + Yv[1] * Bj[1] + Yv[2] * Bj[2];
+    const int b0 = min(beg + chunk * per, end), total = min(per, end - b0);
+    const double lambda = P.lm[0];
+    double acc[kSchurMaxOut];
+#pragma unroll
+    for (int o = 0; o < kSchurMaxOut; o++) acc[o] = 0;
+    for (int base = 0; base < total; base += kSchurMaxEdges) {
+        const int cnt = min(kSchurMaxEdges, total - base);
+        for (int k = threadIdx.x; k < cnt; k += 256) {
+            const int e = P.camEdges[b0 + base + k];
+            const int l = P.ptIdx[P.ept[e]];
+            double Di[9];
+            dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
+            const double* bl = &P.bl[(size_t)l * 3];
+            const double* Bi = &P.Hpl[(size_t)e * 18];
+#pragma unroll
+            for (int i = 0; i < 3; i++) sDb[k * 3 + i] = Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) sY[k * 18 + r * 3 + c] = Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c];
+            sE[k] = e;
+        }
+        for (int idx = threadIdx.x; idx < cnt * nF; idx += 256) {
+            const int k = idx / nF, i2 = idx - k * nF;
+            const int l = P.ptIdx[P.ept[P.camEdges[b0 + base + k]]];
+            sTab[k * kSchurMaxFree + i2] = P.table[(size_t)l * nF + i2];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < kSchurMaxOut; o++) {
+            const int t = threadIdx.x + o * 256;
+            if (t >= rowLen) break;
+            double a = acc[o];
+            if (t < nF * 36) {
+                const int i2 = t / 36, r = (t % 36) / 6, c = t % 6;
+                if (i2 >= i1) {
+#pragma unroll 4
+                    for (int k = 0; k < cnt; k++) {
+                        const int e2 = sTab[k * kSchurMaxFree + i2];
+                        if (e2 < 0) continue;
+                        const double* Yv = &sY[k * 18 + r * 3];
+                        const double* Bj = &P.Hpl[(size_t)e2 * 18 + c * 3];
+                        a -= Yv[0] * Bj[0] + Yv[1] * Bj[1] + Yv[2] * Bj[2];
+                    }
+                }
+            } else {
+                const int r = t - nF * 36;
+                for (int k = 0; k < cnt; k++) {
+                    const double* Bi = &P.Hpl[(size_t)sE[k] * 18 + r * 3];
+                    a += Bi[0] * sDb[k * 3] + Bi[1] * sDb[k * 3 + 1] + Bi[2] * sDb[k * 3 + 2];
                 }
             }
-        } else {
-            const int r = t - nF * 36;
-            for (int k = b0; k < e0; k++) {
-                const int e = P.camEdges[k];
-                const int l = P.ptIdx[P.ept[e]];
-                const double* Bi = &P.Hpl[(size_t)e * 18 + r * 3];
-                const double* d = &P.db[(size_t)l * 3];
-                acc += Bi[0] * d[0] + Bi[1] * d[1] + Bi[2] * d[2];
-            }
+            acc[o] = a;
         }
-        P.slab[((size_t)chunk * nF + i1) * rowLen + t] = acc;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 0; o < kSchurMaxOut; o++) {
+        const int t = threadIdx.x + o * 256;
+        if (t < rowLen) P.slab[((size_t)chunk * nF + i1) * rowLen + t] = acc[o];
     }
 }
 
-// One workgroup: assemble Hschur = Hpp + lambda I + sum of slabs (upper triangle) in LDS, right-looking LDLT with the
-// right-hand side carried as an extra column (no pivoting; fails on a zero pivot like SimplicialLDLT), column-oriented
-// back substitution, then exp(dx) * T for the free cameras (trial state).  n = 6*nFree <= 192.
-constexpr int kSolveThreads = 256;
+// One 1024-thread workgroup: assemble Hschur = Hpp + lambda I + sum of slabs (upper triangle) in LDS, blocked
+// right-looking LDLT (6-row panels; the right-hand side rides along as an extra column; no pivoting, a zero pivot fails
+// like SimplicialLDLT), blocked back substitution, then exp(dx) * T for the free cameras.  n = 6*nFree <= 192.
+// The trailing update subtracts the six panel terms one after the other, i.e. exactly the scalar algorithm's operation order.
+constexpr int kSolveThreads = 1024;
+constexpr int kChunks = 8;                      // partial Schur rows per free camera (fixed: the assembly loop is unrolled)
+// IN_LDS = true: the system lives in LDS (up to 22 free keyframes); false: in L2-resident global scratch.  Two
+// instantiations so that each uses its own address space (a runtime-selected pointer would degrade to flat loads).
+template <bool IN_LDS>
 __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveOk) {
     extern __shared__ double sm[];
     const int nF = P.nFree, n = nF * 6, rowLen = nF * 36 + 6, t = threadIdx.x;
-    double* S = sm;                   // n*n row-major, upper triangle used
-    double* y = S + (size_t)n * n;    // n
-    double* xv = y + n;               // n
+    const int ld = n + 1;                       // column n of every row = right-hand side
+    double* S;                                  // n * ld
+    double* M;                                  // 6 * ld   multipliers of the current panel
+    if (IN_LDS) { S = sm; M = sm + (size_t)n * ld; }
+    else { S = P.solveScratch; M = sm; }
+    double* xv = M + (size_t)6 * ld;            // n   (LDS in both variants)
+    double* rd = xv + n;                        // n reciprocal pivots
     __shared__ int s_fail;
     const double lambda = P.lm[0];
     if (t == 0) s_fail = 0;
+    if (P.dbg && t == 0) { P.dbg[0] = clock64(); P.dbg[1] = wall_clock64(); }
     for (int idx = t; idx < n * n; idx += kSolveThreads) {
-        const int row = idx / n, col = idx % n;
-        const int i1 = row / 6, r = row % 6, i2 = col / 6, c = col % 6;
+        const int row = idx / n, col = idx - row * n;
+        const int i1 = row / 6, r = row - i1 * 6, i2 = col / 6, c = col - i2 * 6;
         double v = 0;
         if (i2 >= i1) {
+            double part[kChunks];
+#pragma unroll
+            for (int ch = 0; ch < kChunks; ch++) part[ch] = P.slab[((size_t)ch * nF + i1) * rowLen + i2 * 36 + r * 6 + c];
             if (i1 == i2) v = P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
-            for (int ch = 0; ch < P.chunks; ch++) v += P.slab[((size_t)ch * nF + i1) * rowLen + i2 * 36 + r * 6 + c];
+#pragma unroll
+            for (int ch = 0; ch < kChunks; ch++) v += part[ch];
         }
-        S[idx] = v;
+        S[(size_t)row * ld + col] = v;
     }
     for (int row = t; row < n; row += kSolveThreads) {
-        const int i1 = row / 6, r = row % 6;
+        const int i1 = row / 6, r = row - i1 * 6;
         double co = 0;
         for (int ch = 0; ch < P.chunks; ch++) co += P.slab[((size_t)ch * nF + i1) * rowLen + nF * 36 + r];
-        y[row] = P.bp[row] - co;
+        S[(size_t)row * ld + n] = P.bp[row] - co;
         xv[row] = 0;
     }
     __syncthreads();
-    for (int j = 0; j < n; j++) {
-        const double dj = S[(size_t)j * n + j];
-        if (dj == 0.0 || !isfinite(dj)) { if (t == 0) s_fail = 1; }
-        __syncthreads();
-        if (s_fail) break;
-        const double inv = 1.0 / dj;
-        const int m = n - j - 1;
-        // trailing update S(i,k) -= l_i * S(j,k), l_i = S(j,i)/d_j, for j < i <= k; the rhs is column "n"
-        for (int idx = t; idx < m * m; idx += kSolveThreads) {
-            const int a = idx / m, b = idx - a * m;
-            if (b >= a) {
-                const int i = j + 1 + a, k = j + 1 + b;
-                S[(size_t)i * n + k] -= (S[(size_t)j * n + i] * inv) * S[(size_t)j * n + k];
+    if (P.dbg && t == 0) { P.dbg[2] = clock64(); P.dbg[3] = wall_clock64(); }
+    for (int jb = 0; jb < nF; jb++) {
+        const int j = jb * 6;
+        // ---- panel: the thread owning column k (j <= k <= n) factorises the 6x6 diagonal block redundantly in registers
+        //      and retires its own column of the six panel rows; the other waves only take part in the barriers
+        const int k = j + t;
+        const bool active = k <= n;
+        double col[6], invd[6], l[6][6], a[6][6];
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) a[r][c] = (c >= r) ? S[(size_t)(j + r) * ld + j + c] : 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double dr = a[r][r];
+                if (dr == 0.0 || !isfinite(dr)) bad = true;
+                invd[r] = frcp(dr);
+#pragma unroll
+                for (int i = r + 1; i < 6; i++) {
+                    l[i][r] = a[r][i] * invd[r];
+#pragma unroll
+                    for (int c = i; c < 6; c++) a[i][c] -= l[i][r] * a[r][c];
+                }
+            }
+            if (bad) s_fail = 1;
+#pragma unroll
+            for (int r = 0; r < 6; r++) col[r] = S[(size_t)(j + r) * ld + k];
+        }
+        __syncthreads();           // every column has read the untouched diagonal block before anyone rewrites it
+        if (active) {
+            if (k >= j + 6) {
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int i = r + 1; i < 6; i++) col[i] -= l[i][r] * col[r];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    S[(size_t)(j + r) * ld + k] = col[r];
+                    if (k < n) M[(size_t)r * ld + k] = col[r] * invd[r];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    if (c == k - j) {
+#pragma unroll
+                        for (int r = 0; r <= c; r++) S[(size_t)(j + r) * ld + k] = a[r][c];
+                        rd[k] = invd[c];     // reciprocal pivot, reused by the back substitution
+                    }
             }
         }
-        for (int a = t; a < m; a += kSolveThreads) y[j + 1 + a] -= (S[(size_t)j * n + j + 1 + a] * inv) * y[j];
+        __syncthreads();
+        if (s_fail) break;
+        // ---- trailing update of rows i >= j+6: S(i,k) -= sum_r M(r,i) * S(j+r,k), r = 0..5 in order, k >= i (k == n: rhs)
+        {
+            const int tx = t & 31, ty = t >> 5;
+            for (int i = j + 6 + ty; i < n; i += 32) {
+                const double m0 = M[i], m1 = M[ld + i], m2 = M[2 * ld + i], m3 = M[3 * ld + i], m4 = M[4 * ld + i], m5 = M[5 * ld + i];
+                for (int kk = j + 6 + tx; kk <= n; kk += 32) {
+                    if (kk < i) continue;
+                    double v = S[(size_t)i * ld + kk];
+                    v -= m0 * S[(size_t)j * ld + kk];
+                    v -= m1 * S[(size_t)(j + 1) * ld + kk];
+                    v -= m2 * S[(size_t)(j + 2) * ld + kk];
+                    v -= m3 * S[(size_t)(j + 3) * ld + kk];
+                    v -= m4 * S[(size_t)(j + 4) * ld + kk];
+                    v -= m5 * S[(size_t)(j + 5) * ld + kk];
+                    S[(size_t)i * ld + kk] = v;
+                }
+            }
+        }
         __syncthreads();
     }
+    if (P.dbg && t == 0) { P.dbg[4] = clock64(); P.dbg[5] = wall_clock64(); }
     if (!s_fail) {
-        // x_i = (y_i - sum_{k>i} S(i,k) x_k) / d_i, column-oriented: once x_i is known every row k < i retires it
-        for (int i = n - 1; i >= 0; i--) {
-            const double xi = y[i] / S[(size_t)i * n + i];
-            if (t == 0) xv[i] = xi;
-            for (int k = t; k < i; k += kSolveThreads) y[k] -= S[(size_t)k * n + i] * xi;
+        // ---- back substitution by 6-row blocks: x_i = (y_i - sum_{k>i} U(i,k) x_k) / d_i; only the threads that own a
+        //      row above the block (and wave 0, which publishes x) solve the 6x6 triangle
+        for (int jb = nF - 1; jb >= 0; jb--) {
+            const int j = jb * 6;
+            const bool need = t < j || t < 6;
+            double x[6];
+            if (need) {
+#pragma unroll
+                for (int r = 5; r >= 0; r--) {
+                    double v = S[(size_t)(j + r) * ld + n];
+#pragma unroll
+                    for (int c = r + 1; c < 6; c++) v -= S[(size_t)(j + r) * ld + j + c] * x[c];
+                    x[r] = v * rd[j + r];
+                }
+#pragma unroll
+                for (int r = 0; r < 6; r++) if (t == r) xv[j + r] = x[r];
+            }
+            __syncthreads();                    // all reads of the rhs column done before rows above are updated
+            if (t < j) {
+                double v = S[(size_t)t * ld + n];
+#pragma unroll
+                for (int c = 0; c < 6; c++) v -= S[(size_t)t * ld + j + c] * x[c];
+                S[(size_t)t * ld + n] = v;
+            }
             __syncthreads();
         }
     }
     __syncthreads();
+    if (P.dbg && t == 0) { P.dbg[6] = clock64(); P.dbg[7] = wall_clock64(); }
     for (int i = t; i < n; i += kSolveThreads) P.xp[i] = xv[i];
     // trial cameras: exp(dx) * T for the free ones, copy for the others
     for (int c = t; c < P.nCams; c += kSolveThreads) {
         const int ci = P.camIdx[c];
         if (ci >= 0) {
             double u[6];
-            for (int k = 0; k < 6; k++) u[k] = xv[ci * 6 + k];
+            for (int q = 0; q < 6; q++) u[q] = xv[ci * 6 + q];
             P.camsT[c] = se3_mul(se3_exp(u), P.cams[c]);
         } else {
             P.camsT[c] = P.cams[c];
         }
     }
     if (t == 0) *solveOk = s_fail ? 0 : 1;
+    if (P.dbg && t == 0) { P.dbg[8] = clock64(); P.dbg[9] = wall_clock64(); }
 }
 
 // per landmark: x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 at the trial state; scale partial
@@ -819,7 +956,8 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
             cl[c] += s;
         }
     }
-    const double* Di = &P.Dinv[(size_t)l * 9];
+    double Di[9];
+    dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
     double xl[3], np[3];
     for (int i = 0; i < 3; i++) {
         xl[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
@@ -851,10 +989,13 @@ __global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, 
     __shared__ double red[4], out1;
     const double tempSum = ordered_sum(P.partChi, P.nL, red, &out1);
     const double scaleL = ordered_sum(P.partScale, P.nL, red, &out1);
+    __shared__ double s_xp[kSchurMaxFree * 6], s_bp[kSchurMaxFree * 6];
+    for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { s_xp[i] = P.xp[i]; s_bp[i] = P.bp[i]; }
+    __syncthreads();
     if (threadIdx.x == 0) {
         const double lambda = P.lm[0];
         double scale = 0;
-        for (int i = 0; i < P.nFree * 6; i++) scale += P.xp[i] * (lambda * P.xp[i] + P.bp[i]);
+        for (int i = 0; i < P.nFree * 6; i++) scale += s_xp[i] * (lambda * s_xp[i] + s_bp[i]);
         scale += scaleL;
         const int ok2 = *solveOk;
         double tempChi = tempSum;
@@ -1050,11 +1191,14 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         hinfo[e] = p->edge_inv_sigma2[e];
         hflag[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | 4);
     }
-    const int nFmax = nC, chunks = 8;
-    EAO_REQUIRE(nFmax * 6 <= 192, "at most 32 free keyframes per window (dense Schur system is LDS resident)");
+    const int nFmax = nC, chunks = kChunks;
+    int nFreeIn = 0;
+    for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
+    EAO_REQUIRE(nFreeIn <= kSchurMaxFree, "at most %d free keyframes per window in this build (got %d)", kSchurMaxFree, nFreeIn);
     const size_t rowLenMax = (size_t)nFmax * 36 + 6;
     size_t need = 0;
-    need += (size_t)E * (3 + 1 + 3 + 18 + 18) * 8 + (size_t)E * (4 + 4 + 4 + 4 + 2);
+    need += (size_t)E * (3 + 1 + 3 + 18) * 8 + (size_t)E * (4 + 4 + 4 + 4 + 2);
+    need += ((size_t)(nC * 6 + 6) * (nC * 6 + 1) + 8) * 8;
     need += (size_t)nP * (3 + 3 + 9 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 12 + (size_t)nP * nFmax * 4;
     need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16) + chunks * nFmax * rowLenMax * 8;
     need += 64 * 256;
@@ -1076,13 +1220,15 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     D.err = a.take<double>((size_t)E * 3);
     D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
     D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
-    D.Hpl = a.take<double>((size_t)E * 18); D.Y = a.take<double>((size_t)E * 18);
-    D.Dinv = a.take<double>((size_t)nP * 9); D.db = a.take<double>((size_t)nP * 3);
+    D.Hpl = a.take<double>((size_t)E * 18);
+    double* dsolveScratch = a.take<double>((size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 1) + 8);
     D.slab = a.take<double>(chunks * nFmax * rowLenMax);
     D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
     D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
     D.lm = a.take<double>(8);
     int* dsolveOk = a.take<int>(4);
+    long long* ddbg = a.take<long long>(16);
+    D.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
     EAO_REQUIRE(a.off <= a.cap, "internal: arena overflow");
     D.obs = dobs; D.info = dinfo; D.ecam = decam; D.ept = dept; D.eflag = dflag;
     D.camIdx = dcamIdx; D.ptIdx = dptIdx; D.actCam = dactCam; D.actPt = dactPt;
@@ -1151,8 +1297,15 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         const int nF = D.nFree, nL = D.nL;
         if (nF + nL == 0) return EAO_OK;   // "_ivMap.size() == 0": nothing to optimise
         const int ptBlocks = eao::cdiv(std::max(nL, 1), 256);
-        const size_t solveLds = ((size_t)(nF * 6) * (nF * 6) + 2 * (size_t)nF * 6) * sizeof(double);
-        EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+        size_t solveLds = ((size_t)(nF * 6 + 6) * (nF * 6 + 1) + 2 * (size_t)nF * 6) * sizeof(double);
+        if (solveLds > 150 * 1024) {   // system too large for LDS: S lives in (L2-resident) global scratch, M/xv stay in LDS
+            D.solveScratch = dsolveScratch;
+            solveLds = ((size_t)6 * (nF * 6 + 1) + 2 * (size_t)nF * 6) * sizeof(double);
+        } else {
+            D.solveScratch = nullptr;
+        }
+        const bool solveInLds = D.solveScratch == nullptr;
+        if (solveInLds) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
         bool needErrors = true, ok = true;
         double currentChi = 0;
         int nBad = 0;
@@ -1171,9 +1324,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
             int qmax = 0;
             double rho = 0;
             do {
-                if (nL) hipLaunchKernelGGL(k_ba_point_prep, dim3(ptBlocks), dim3(256), 0, s, D);
                 if (nF) hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(256), 0, s, D);
-                hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
+                if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
+                else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
                 if (nL) hipLaunchKernelGGL(k_ba_backsub, dim3(ptBlocks), dim3(256), 0, s, D);
                 hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq);
                 if ((st = wait_status(seq))) return st;
@@ -1229,6 +1382,12 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
     EAO_HIP(hipEventElapsedTime(&g_trace.deviceMs, c.ev0, c.ev1));
+    if (D.dbg) {
+        long long st[16];
+        EAO_HIP(hipMemcpy(st, D.dbg, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
+                st[2] - st[0], st[4] - st[2], st[6] - st[4], st[8] - st[6], st[3] - st[1], st[5] - st[3], st[7] - st[5], st[9] - st[7]);
+    }
     write_out();
     return EAO_OK;
 }
