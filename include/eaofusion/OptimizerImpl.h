@@ -1,0 +1,177 @@
+// OptimizerImpl.h -- Optimizer::PoseOptimization / Optimizer::LocalBundleAdjustment on top of the C-ABI.
+//
+// The reference functions (src/Optimizer.cc:325-673, 675-1138) walk the SLAM object graph, build a g2o graph,
+// optimise, and write back.  Here the walk and the write-back stay on the host, restated over the SAME member
+// names of the reference's Frame / KeyFrame / MapPoint / Map classes (so the templates instantiate against the
+// real classes in a checkout -- see INTEGRATION.md), and the optimisation is one call into libeaofusion_hip.so.
+//
+//   // src/Optimizer_hip.cc in an EAO-Fusion checkout (replaces the two function bodies in src/Optimizer.cc):
+//   #include "Optimizer.h"            // reference header, unchanged
+//   #include <eaofusion/OptimizerImpl.h>
+//   int  ORB_SLAM2::Optimizer::PoseOptimization(Frame* f) { return eaofusion::PoseOptimization<MapPoint>(f); }
+//   void ORB_SLAM2::Optimizer::LocalBundleAdjustment(KeyFrame* kf, bool* stop, Map* m) { eaofusion::LocalBundleAdjustment<MapPoint>(kf, stop, m); }
+//
+// Not covered yet (DESIGN.md "what comes next"): the plane edges PoseOptimization adds when PEAC
+// planes are associated (src/Optimizer.cc:456-535); frames with mnPlaneNum > 0 are optimised on their point edges only.
+#pragma once
+
+#include <algorithm>
+#include <list>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../eao_fusion.h"
+#include "cv_compat.h"
+
+namespace eaofusion {
+
+inline void check(eao_status st, const char* what) {
+    if (st != EAO_OK) throw std::runtime_error(std::string(what) + ": " + eao_last_error());
+}
+
+// ---- Optimizer::PoseOptimization(Frame*) --------------------------------------------------------------------
+template <class MapPointT, class FrameT>
+int PoseOptimization(FrameT* pFrame) {
+    const int N = pFrame->N;
+    std::vector<int> slot;            // frame index of every correspondence, ascending
+    std::vector<float> Xw, obs, inv;
+    {
+        std::unique_lock<std::mutex> lock(MapPointT::mGlobalMutex);
+        for (int i = 0; i < N; i++) {
+            MapPointT* pMP = pFrame->mvpMapPoints[i];
+            if (!pMP) continue;
+            pFrame->mvbOutlier[i] = false;
+            const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
+            const cv::Mat P = pMP->GetWorldPos();
+            slot.push_back(i);
+            Xw.push_back(P.template at<float>(0)); Xw.push_back(P.template at<float>(1)); Xw.push_back(P.template at<float>(2));
+            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(pFrame->mvuRight[i]);   // < 0 => monocular edge
+            inv.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
+        }
+    }
+    const int n = (int)slot.size();
+    if (n < 3) return 0;   // pose untouched, as upstream
+    cv::Mat Tcw = pFrame->mTcw;
+    float T[16];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[r * 4 + c] = Tcw.template at<float>(r, c);
+    eao_pose_problem P = {n, T, Xw.data(), obs.data(), inv.data(), pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf};
+    std::vector<uint8_t> outl(n);
+    eao_pose_result R;
+    R.outlier = outl.data();
+    check(eao_pose_optimization(&P, &R), "eao_pose_optimization");
+    for (int k = 0; k < n; k++) pFrame->mvbOutlier[slot[k]] = outl[k] != 0;
+    cv::Mat pose(4, 4, CV_32F);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[r * 4 + c];
+    pFrame->SetPose(pose);
+    return R.n_inliers;
+}
+
+// ---- Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*) ------------------------------------------------
+template <class MapPointT, class KeyFrameT, class MapT>
+void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
+    // the local window: this keyframe + its covisible ones; every map point they see; every other observer is fixed
+    std::list<KeyFrameT*> localKFs;
+    localKFs.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    for (KeyFrameT* n : pKF->GetVectorCovisibleKeyFrames()) {
+        n->mnBALocalForKF = pKF->mnId;
+        if (!n->isBad()) localKFs.push_back(n);
+    }
+    std::list<MapPointT*> localMPs;
+    for (KeyFrameT* kf : localKFs)
+        for (MapPointT* mp : kf->GetMapPointMatches())
+            if (mp && !mp->isBad() && mp->mnBALocalForKF != pKF->mnId) {
+                localMPs.push_back(mp);
+                mp->mnBALocalForKF = pKF->mnId;
+            }
+    std::list<KeyFrameT*> fixedKFs;
+    for (MapPointT* mp : localMPs) {
+        const std::map<KeyFrameT*, size_t> seenBy = mp->GetObservations();
+        for (const auto& ob : seenBy) {
+            KeyFrameT* kf = ob.first;
+            if (kf->mnBALocalForKF != pKF->mnId && kf->mnBAFixedForKF != pKF->mnId) {
+                kf->mnBAFixedForKF = pKF->mnId;
+                if (!kf->isBad()) fixedKFs.push_back(kf);
+            }
+        }
+    }
+    // flatten: cameras / points in ascending mnId (= g2o's vertex order), edges in the reference's insertion order
+    struct CamRec { KeyFrameT* kf; bool fixed; };
+    std::vector<CamRec> cams;
+    for (KeyFrameT* kf : localKFs) cams.push_back({kf, kf->mnId == 0});
+    for (KeyFrameT* kf : fixedKFs) cams.push_back({kf, true});
+    std::sort(cams.begin(), cams.end(), [](const CamRec& a, const CamRec& b) { return a.kf->mnId < b.kf->mnId; });
+    std::map<KeyFrameT*, int> camIndex;
+    for (size_t i = 0; i < cams.size(); i++) camIndex[cams[i].kf] = (int)i;
+    std::vector<MapPointT*> pts(localMPs.begin(), localMPs.end());
+    std::sort(pts.begin(), pts.end(), [](MapPointT* a, MapPointT* b) { return a->mnId < b->mnId; });
+    std::map<MapPointT*, int> ptIndex;
+    for (size_t i = 0; i < pts.size(); i++) ptIndex[pts[i]] = (int)i;
+
+    std::vector<float> camT(cams.size() * 16), xyz(pts.size() * 3), obs, inv;
+    std::vector<uint8_t> camFixed(cams.size());
+    std::vector<int32_t> eCam, ePt;
+    std::vector<KeyFrameT*> eKF;
+    std::vector<MapPointT*> eMP;
+    for (size_t i = 0; i < cams.size(); i++) {
+        const cv::Mat T = cams[i].kf->GetPose();
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) camT[i * 16 + r * 4 + c] = T.template at<float>(r, c);
+        camFixed[i] = cams[i].fixed ? 1 : 0;
+    }
+    for (size_t i = 0; i < pts.size(); i++) {
+        const cv::Mat P = pts[i]->GetWorldPos();
+        for (int k = 0; k < 3; k++) xyz[i * 3 + k] = P.template at<float>(k);
+    }
+    float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy, bf = pKF->mbf;
+    for (MapPointT* mp : localMPs) {
+        const std::map<KeyFrameT*, size_t> seenBy = mp->GetObservations();
+        for (const auto& ob : seenBy) {
+            KeyFrameT* kf = ob.first;
+            if (kf->isBad()) continue;
+            auto ci = camIndex.find(kf);
+            if (ci == camIndex.end()) continue;   // upstream would dereference a null vertex here
+            const cv::KeyPoint& kpUn = kf->mvKeysUn[ob.second];
+            eCam.push_back(ci->second); ePt.push_back(ptIndex[mp]);
+            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(kf->mvuRight[ob.second]);
+            inv.push_back(kf->mvInvLevelSigma2[kpUn.octave]);
+            eKF.push_back(kf); eMP.push_back(mp);
+        }
+    }
+    if (pbStopFlag && *pbStopFlag) return;
+    eao_ba_problem P;
+    P.n_cams = (int)cams.size(); P.n_points = (int)pts.size(); P.n_edges = (int)eCam.size();
+    P.cam_Tcw = camT.data(); P.cam_fixed = camFixed.data(); P.points = xyz.data();
+    P.edge_cam = eCam.data(); P.edge_point = ePt.data(); P.edge_obs = obs.data(); P.edge_inv_sigma2 = inv.data();
+    P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy; P.bf = bf; P.its_first = 5; P.its_second = 10;
+    std::vector<float> camOut(camT.size()), xyzOut(xyz.size());
+    std::vector<uint8_t> erase(std::max<size_t>(eCam.size(), 1));
+    eao_ba_result R;
+    R.cam_Tcw = camOut.data(); R.points = xyzOut.data(); R.edge_outlier = erase.data();
+    static_assert(sizeof(bool) == 1, "bool* abort flag is polled as a byte");
+    check(eao_local_ba(&P, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), &R), "eao_local_ba");
+    if (R.aborted) return;
+
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+    for (size_t e = 0; e < eCam.size(); e++) {
+        if (!erase[e] || eMP[e]->isBad()) continue;
+        eKF[e]->EraseMapPointMatch(eMP[e]);
+        eMP[e]->EraseObservation(eKF[e]);
+    }
+    for (size_t i = 0; i < cams.size(); i++) {
+        if (cams[i].kf->mnBALocalForKF != pKF->mnId) continue;   // only local keyframes are written back
+        cv::Mat pose(4, 4, CV_32F);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = camOut[i * 16 + r * 4 + c];
+        cams[i].kf->SetPose(pose);
+    }
+    for (size_t i = 0; i < pts.size(); i++) {
+        cv::Mat pos(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) pos.template at<float>(k) = xyzOut[i * 3 + k];
+        pts[i]->SetWorldPos(pos);
+        pts[i]->UpdateNormalAndDepth();
+    }
+}
+
+}  // namespace eaofusion

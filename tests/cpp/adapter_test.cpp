@@ -1,0 +1,178 @@
+// adapter_test.cpp -- drives the header-only drop-in adapters (include/eaofusion/*.h) the way Tracking.cc /
+// LocalMapping.cc drive the reference classes, against small stand-ins of the reference's Frame / KeyFrame /
+// MapPoint / Map (same member names the adapters touch).  Built and run by tests/test_gpu_adapters.py.
+//   adapter_test <problem.bin> <result.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include <eaofusion/ORBextractor.h>
+#include <eaofusion/ORBmatcher.h>
+#include <eaofusion/OptimizerImpl.h>
+
+struct KeyFrame;
+struct MapPoint {
+    static std::mutex mGlobalMutex;
+    long unsigned int mnId = 0, mnBALocalForKF = ~0ul;
+    cv::Mat pos;
+    std::map<KeyFrame*, size_t> observations;
+    int normalUpdates = 0;
+    bool isBad() { return false; }
+    cv::Mat GetWorldPos() { return pos.clone(); }
+    void SetWorldPos(const cv::Mat& p) { pos = p.clone(); }
+    std::map<KeyFrame*, size_t> GetObservations() { return observations; }
+    void EraseObservation(KeyFrame* kf) { observations.erase(kf); }
+    void UpdateNormalAndDepth() { normalUpdates++; }
+};
+std::mutex MapPoint::mGlobalMutex;
+
+struct KeyFrame {
+    long unsigned int mnId = 0, mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul;
+    float fx, fy, cx, cy, mbf;
+    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<float> mvuRight, mvInvLevelSigma2;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<KeyFrame*> covisible;
+    cv::Mat Tcw;
+    int erased = 0;
+    bool isBad() { return false; }
+    cv::Mat GetPose() { return Tcw.clone(); }
+    void SetPose(const cv::Mat& T) { Tcw = T.clone(); }
+    std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return covisible; }
+    std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    void EraseMapPointMatch(MapPoint* mp) {
+        for (auto& p : mvpMapPoints) if (p == mp) { p = nullptr; erased++; }
+    }
+};
+struct Map { std::mutex mMutexMapUpdate; };
+struct Frame {
+    int N = 0;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<float> mvuRight, mvInvLevelSigma2;
+    std::vector<bool> mvbOutlier;
+    cv::Mat mTcw;
+    float fx, fy, cx, cy, mbf;
+    void SetPose(cv::Mat T) { mTcw = T.clone(); }
+};
+
+template <typename T> static void rd(std::ifstream& f, T* p, size_t n) { f.read(reinterpret_cast<char*>(p), n * sizeof(T)); }
+template <typename T> static void wr(std::ofstream& f, const T* p, size_t n) { f.write(reinterpret_cast<const char*>(p), n * sizeof(T)); }
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    std::ifstream in(argv[1], std::ios::binary);
+    std::ofstream out(argv[2], std::ios::binary);
+    // ---------------------------------------------------------------- ORBextractor, as Frame::ExtractORB calls it
+    int32_t H, W;
+    rd(in, &H, 1); rd(in, &W, 1);
+    cv::Mat img(H, W, CV_8UC1);
+    rd(in, img.data, (size_t)H * W);
+    ORB_SLAM2::ORBextractor extractor(1000, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> keys;
+    cv::Mat descriptors;
+    extractor(img, cv::Mat(), keys, descriptors);
+    int32_t nk = (int32_t)keys.size();
+    wr(out, &nk, 1);
+    wr(out, keys.data(), keys.size());
+    for (int i = 0; i < nk; i++) wr(out, descriptors.ptr(i), 32);
+    int32_t pyr0[3] = {extractor.mvImagePyramid[0].rows, extractor.mvImagePyramid[0].cols, (int32_t)extractor.mvImagePyramid[7].cols};
+    wr(out, pyr0, 3);
+    int32_t dd = ORB_SLAM2::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1));
+    wr(out, &dd, 1);
+    cv::Mat empty;
+    std::vector<cv::KeyPoint> untouched(3);
+    extractor(empty, cv::Mat(), untouched, descriptors);   // empty image: outputs untouched
+    int32_t stillThree = (int32_t)untouched.size();
+    wr(out, &stillThree, 1);
+    // ---------------------------------------------------------------- Optimizer::PoseOptimization(Frame*)
+    int32_t n;
+    rd(in, &n, 1);
+    Frame F;
+    F.N = n + 5;   // a few keypoints without a map point
+    F.mTcw = cv::Mat(4, 4, CV_32F);
+    rd(in, F.mTcw.ptr<float>(0), 16);
+    std::vector<float> Xw(n * 3), obs(n * 3), inv(n);
+    rd(in, Xw.data(), Xw.size()); rd(in, obs.data(), obs.size()); rd(in, inv.data(), inv.size());
+    float K[5];
+    rd(in, K, 5);
+    F.fx = K[0]; F.fy = K[1]; F.cx = K[2]; F.cy = K[3]; F.mbf = K[4];
+    std::vector<MapPoint> poseMPs(n);
+    F.mvpMapPoints.assign(F.N, nullptr); F.mvKeysUn.resize(F.N); F.mvuRight.assign(F.N, -1.f); F.mvbOutlier.assign(F.N, true);
+    F.mvInvLevelSigma2.assign(n, 0.f);   // one table entry per correspondence keeps the exact float of the problem file
+    for (int i = 0; i < n; i++) {
+        poseMPs[i].pos = cv::Mat(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) poseMPs[i].pos.at<float>(k) = Xw[3 * i + k];
+        F.mvpMapPoints[i] = &poseMPs[i];
+        F.mvKeysUn[i].pt.x = obs[3 * i]; F.mvKeysUn[i].pt.y = obs[3 * i + 1]; F.mvuRight[i] = obs[3 * i + 2];
+        F.mvKeysUn[i].octave = i;
+        F.mvInvLevelSigma2[i] = inv[i];
+    }
+    int32_t inliers = eaofusion::PoseOptimization<MapPoint>(&F);
+    wr(out, &inliers, 1);
+    wr(out, F.mTcw.ptr<float>(0), 16);
+    std::vector<uint8_t> ofl(n);
+    for (int i = 0; i < n; i++) ofl[i] = F.mvbOutlier[i];
+    wr(out, ofl.data(), n);
+    // ---------------------------------------------------------------- Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*)
+    int32_t dims[3];
+    rd(in, dims, 3);
+    const int nc = dims[0], np = dims[1], ne = dims[2];
+    std::vector<float> camT(nc * 16), pts(np * 3), eobs(ne * 3), einv(ne);
+    std::vector<uint8_t> fixed(nc);
+    std::vector<int32_t> ecam(ne), ept(ne);
+    rd(in, camT.data(), camT.size()); rd(in, fixed.data(), nc); rd(in, pts.data(), pts.size());
+    rd(in, ecam.data(), ne); rd(in, ept.data(), ne); rd(in, eobs.data(), eobs.size()); rd(in, einv.data(), ne);
+    rd(in, K, 5);
+    std::vector<KeyFrame> kfs(nc);     // contiguous: pointer order == camera order, like the generator's edge order
+    std::vector<MapPoint> mps(np);
+    int firstFree = -1;
+    for (int c = 0; c < nc; c++) {
+        kfs[c].mnId = c;               // camera 0 is fixed by the mnId == 0 rule, other fixed ones by not being covisible
+        kfs[c].fx = K[0]; kfs[c].fy = K[1]; kfs[c].cx = K[2]; kfs[c].cy = K[3]; kfs[c].mbf = K[4];
+        kfs[c].Tcw = cv::Mat(4, 4, CV_32F);
+        for (int k = 0; k < 16; k++) kfs[c].Tcw.ptr<float>(0)[k] = camT[c * 16 + k];
+        kfs[c].mvInvLevelSigma2.assign(ne ? 1 : 1, 0.f);
+        if (!fixed[c] && firstFree < 0) firstFree = c;
+    }
+    for (int p = 0; p < np; p++) {
+        mps[p].mnId = p;
+        mps[p].pos = cv::Mat(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) mps[p].pos.at<float>(k) = pts[3 * p + k];
+    }
+    for (int e = 0; e < ne; e++) {
+        KeyFrame& kf = kfs[ecam[e]];
+        const size_t idx = kf.mvKeysUn.size();
+        cv::KeyPoint kp;
+        kp.pt.x = eobs[3 * e]; kp.pt.y = eobs[3 * e + 1];
+        kp.octave = (int)kf.mvInvLevelSigma2.size();      // one table entry per observation keeps the exact float
+        kf.mvInvLevelSigma2.push_back(einv[e]);
+        kf.mvKeysUn.push_back(kp);
+        kf.mvuRight.push_back(eobs[3 * e + 2]);
+        kf.mvpMapPoints.push_back(&mps[ept[e]]);
+        mps[ept[e]].observations[&kf] = idx;
+    }
+    KeyFrame* cur = &kfs[firstFree];
+    for (int c = 0; c < nc; c++) if (!fixed[c] && c != firstFree) cur->covisible.push_back(&kfs[c]);
+    Map map;
+    bool stop = false;
+    eaofusion::LocalBundleAdjustment<MapPoint>(cur, &stop, &map);
+    for (int c = 0; c < nc; c++) wr(out, kfs[c].Tcw.ptr<float>(0), 16);
+    for (int p = 0; p < np; p++) wr(out, mps[p].pos.ptr<float>(0), 3);
+    int32_t erased = 0, normals = 0;
+    for (int c = 0; c < nc; c++) erased += kfs[c].erased;
+    for (int p = 0; p < np; p++) normals += mps[p].normalUpdates;
+    wr(out, &erased, 1); wr(out, &normals, 1);
+    bool stopNow = true;                                  // abort flag set on entry: silent return, nothing written back
+    std::vector<float> before(16);
+    for (int k = 0; k < 16; k++) before[k] = cur->Tcw.ptr<float>(0)[k];
+    eaofusion::LocalBundleAdjustment<MapPoint>(cur, &stopNow, &map);
+    int32_t same = 1;
+    for (int k = 0; k < 16; k++) same &= (before[k] == cur->Tcw.ptr<float>(0)[k]);
+    wr(out, &same, 1);
+    printf("adapter_test ok: %d keypoints, %d pose inliers, %d observations erased\n", nk, inliers, erased);
+    return 0;
+}
