@@ -64,10 +64,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import eao_fusion_amd as E  # after torch: one libamdhip64 in the process
-    from eao_fusion_amd import synth
+    from eao_fusion_amd import shard, synth
 
     B, W, H = args.batch, 640, 480
-    frames = synth.synth_frames(B, seed0=1000 + rank * B, w=W, h=H)
+    n_frames = B * world                                   # weak scaling: 64 frames per GPU
+    lo, hi = shard.frame_shard(n_frames, rank, world)      # contiguous shard of the sequence owned by this rank
+    assert hi - lo == B
+    frames = np.stack([synth.synth_frame(1000 + f, W, H) for f in range(lo, hi)])
     d_img = torch.from_numpy(frames).to(dev)
     ext = E.ORBextractor(1000, 1.2, 8, 20, 7)
     cap = ext.max_keypoints(W, H)
@@ -98,14 +101,9 @@ def main():
     t1 = time.perf_counter()
     stage_ms = ext.last_timing()
     ext.set_profiling(False)
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    kp_step = d_n.to(torch.int64).sum().reshape(1)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kp_step, op=dist.ReduceOp.SUM)
-    elapsed = float(elapsed.item())
-    kp_total_step = int(kp_step.item())
-    value = kp_total_step * args.steps / elapsed
+    # whole-job throughput: SUM of the units of all ranks / MAX of the elapsed times (RCCL all_reduce when N > 1)
+    value, kp_all_steps, elapsed = shard.aggregate_throughput(int(d_n.to(torch.int64).sum().item()) * args.steps, t1 - t0, device=dev)
+    kp_total_step = int(round(kp_all_steps / args.steps))
 
     # ---- roofline of the dominant kernel (largest average HIP-event duration over the timed steps)
     n_host = d_n.cpu().numpy()
@@ -140,9 +138,9 @@ def main():
             extra.update(cpu_extra)
     if world > 1:
         # the batched-sequence config gathers every rank's per-frame keypoint counts over RCCL (outside the timed region)
-        gathered = [torch.zeros_like(d_n) for _ in range(world)]
-        dist.all_gather(gathered, d_n)
-        extra["allgather_frames"] = int(sum(g.numel() for g in gathered))
+        all_counts = shard.gather_frame_counts(d_n, n_frames, device=dev)
+        extra["allgather_frames"] = int(all_counts.numel())
+        extra["allgather_keypoints"] = int(all_counts.sum().item())
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

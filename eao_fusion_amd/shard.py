@@ -1,0 +1,64 @@
+"""Frame / BA-window sharding across the GPUs of one node.
+
+The hot path has no data-path collective: frames are independent units (contiguous shards, so the consecutive-frame
+matcher needs one halo frame per shard boundary) and BA windows are independent problems (round robin).  The only
+collectives are the timing barrier / max-reduce and one all_gather of per-frame results at the end, over
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def frame_shard(n_frames, rank, world):
+    """Contiguous shard [lo, hi) of frame indices owned by `rank`; the first n_frames % world ranks get one more."""
+    base, rem = divmod(n_frames, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def frame_owner(f, n_frames, world):
+    for r in range(world):
+        lo, hi = frame_shard(n_frames, r, world)
+        if lo <= f < hi:
+            return r
+    raise IndexError(f)
+
+
+def halo_frame(rank, n_frames, world):
+    """Index of the frame the matcher of `rank` needs from its left neighbour (pair (f-1, f) is owned by f's shard)."""
+    lo, hi = frame_shard(n_frames, rank, world)
+    return lo - 1 if lo > 0 and hi > lo else None
+
+
+def window_owner(w, world):
+    return w % world
+
+
+def gather_frame_counts(local_counts, n_frames, device=None):
+    """all_gather of the per-frame keypoint counts of every shard (shards may differ by one frame => padded).
+    Returns a tensor of n_frames counts in global frame order, identical on every rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    local_counts = torch.as_tensor(local_counts, dtype=torch.int32, device=device)
+    if world == 1:
+        return local_counts.clone()
+    cap = (n_frames + world - 1) // world
+    pad = torch.full((cap,), -1, dtype=torch.int32, device=local_counts.device)
+    pad[:local_counts.numel()] = local_counts
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = []
+    for r in range(world):
+        lo, hi = frame_shard(n_frames, r, world)
+        out.append(parts[r][:hi - lo])
+    assert rank < world
+    return torch.cat(out)
+
+
+def aggregate_throughput(units_local, seconds_local, device=None):
+    """Whole-job throughput: all ranks' units / the slowest rank's time (bench.py contract)."""
+    u = torch.tensor([float(units_local)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(seconds_local)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(u.item()) / float(t.item()), float(u.item()), float(t.item())
