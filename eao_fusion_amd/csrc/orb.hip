@@ -5,13 +5,15 @@
 // 765-853, 1043-1132).  Nothing here is translated from the reference: the work is re-decomposed for a
 // 64-wide-wavefront machine and batched over frames so that one launch covers every level of every frame:
 //
-//   k_resize          level l from level l-1, 11-bit fixed-point bilinear, 4 px per lane, coalesced u32 stores
-//   k_fast_cells      one workgroup per FAST cell: LDS-staged pixel tile, branch-free arc score per pixel
-//                     (min3/max3 sliding windows), LDS NMS that is blind across the cell seam (as upstream's
-//                     per-cell cv::FAST calls are), wave-scan compaction in row-major order, minThFAST retry
+//   k_resize          level l from level l-1, 11-bit fixed-point bilinear, 4 px per lane: three aligned u32 loads per
+//                     source row + v_alignbyte extraction, packed u32 stores
+//   k_fast_cells      one WAVEFRONT per FAST cell: LDS-staged pixel tile (aligned u32 loads), compass pre-test with
+//                     ballot compaction, branch-free arc score of the survivors (min3/max3 sliding windows), LDS NMS
+//                     that is blind across the cell seam (as upstream's per-cell cv::FAST calls are), ballot-scan
+//                     emission in row-major order, minThFAST retry
 //   k_quadtree        one workgroup per (frame, level): level-synchronous restatement of DistributeOctTree --
 //                     the std::list order is reproduced by prefix sums, the (size, pointer) sort by a rank
-//   k_blur7           separable 7x7 fixed-point Gaussian, LDS tile with reflect-101 halo
+//   k_blur7           separable 7x7 fixed-point Gaussian: 4 px per lane, aligned u32 loads, 7-row register window
 //   k_orient_describe one wavefront per keypoint: integer moments reduced across lanes, fastAtan2, 256 point
 //                     pairs (4 per lane) packed into the descriptor with 4 wave ballots
 //
@@ -30,7 +32,8 @@ constexpr int kMaxLevels = 16;
 constexpr int kEdge = 19;
 constexpr int kMinBorder = kEdge - 3;  // 16
 constexpr int kTile = 72;              // max FAST sub-image edge (cell <= 60 px + 6)
-constexpr int kTested = kTile - 6;     // 66
+// (tested region of a cell = sub-image minus the 3 px FAST margin on every side: at most 66 x 66)
+constexpr int kTileStride = 80;        // LDS row stride of the tile: 72 + up to 3 bytes of alignment phase, multiple of 4
 constexpr int kMaxIni = 16;
 
 __constant__ signed char c_pattern[1024] = {
@@ -46,8 +49,8 @@ struct LevelGeom {
     int listCap;               // node-list / keypoint capacity of this level
     int kpBase;                // first keypoint slot of this level inside a frame
     int candBase, candCap;     // candidate scratch of this level inside a frame
-    int tabBase;               // resize coefficient tables (ints): xofs[w] xalpha[w] yofs[h] ybeta[h]
-    int tileBase, tilesX;      // blur tiles (64 x 16) of this level
+    int tabBase;               // resize coefficient tables (int2): (xofs, xalpha)[w] then (yofs, ybeta)[h]
+    int tileBase, tilesX;      // blur tiles (256 x 64) of this level
     int scaledPatch;
     float scale;
 };
@@ -59,6 +62,7 @@ struct Geom {
     int pyrFrameBytes;
     int iniTh, minTh;
     int scanCap;               // LDS scan workspace entries for k_quadtree
+    int fastMaxTested, fastTileBytes, fastLdsBytes;   // k_fast_cells dynamic LDS carve-up
     int umax[16];
     LevelGeom L[kMaxLevels];
 };
@@ -84,6 +88,15 @@ __device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const ImgSrc&
 }
 
 // ---------------------------------------------------------------------------------------------- resize
+// Source bytes S[sx], S[sx+1] of the four output pixels of a lane all lie inside three aligned words of the source
+// row (scale factors up to 2): three u32 loads + v_alignbyte extraction instead of eight byte loads.
+__device__ __forceinline__ unsigned pair_at(unsigned w0, unsigned w1, unsigned w2, int o) {
+    const int k = o >> 2;
+    const unsigned lo = k == 0 ? w0 : (k == 1 ? w1 : w2);
+    const unsigned hi = k == 0 ? w1 : w2;
+    return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));   // bits 0-7: S[sx], bits 8-15: S[sx+1]
+}
+
 __global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, const int* __restrict__ tab, ImgSrc s, int l) {
     const LevelGeom D = g->L[l];
     const LevelGeom S = g->L[l - 1];
@@ -94,32 +107,48 @@ __global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, cons
     int spitch;
     const uint8_t* src = level_ptr(g, s, l - 1, f, &spitch);
     uint8_t* dst = s.pyr + (long long)f * g->pyrFrameBytes + D.off;
-    const int* xofs = tab + D.tabBase;
-    const int* xal = xofs + D.w;
-    const int* yofs = xal + D.w;
-    const int* ybe = yofs + D.h;
-    const int sy = yofs[dy];
-    const int bb = ybe[dy];
-    const int b0 = (short)(bb & 0xFFFF), b1 = (short)(bb >> 16);
-    const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+    const int2* xt = reinterpret_cast<const int2*>(tab + D.tabBase);   // (xofs, alpha0 | alpha1 << 16) per output column
+    const int2* yt = xt + D.w;                                          // (yofs, beta0 | beta1 << 16) per output row
+    const int2 yy = yt[dy];
+    const int b0 = (short)(yy.y & 0xFFFF), b1 = (short)(yy.y >> 16);
+    const int sy0 = min(max(yy.x, 0), S.h - 1), sy1 = min(max(yy.x + 1, 0), S.h - 1);
     const uint8_t* r0 = src + (long long)sy0 * spitch;
     const uint8_t* r1 = src + (long long)sy1 * spitch;
-    unsigned packed = 0;
-    int nvalid = 0;
+    int sx[4], aa[4];
+    const int nvalid = min(4, D.w - dx0);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int dx = dx0 + i;
-        if (dx < D.w) {
-            const int sx = xofs[dx];
-            const int aa = xal[dx];
-            const int a0 = (short)(aa & 0xFFFF), a1 = (short)(aa >> 16);
-            const int sx1 = min(sx + 1, S.w - 1);
-            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+        const int2 e = xt[min(dx0 + i, D.w - 1)];
+        sx[i] = e.x; aa[i] = e.y;
+    }
+    const int wb = sx[0] >> 2, wmax = (S.w - 1) >> 2;
+    const bool fast = ((((uintptr_t)src | (uintptr_t)spitch) & 3) == 0) && (sx[3] + 1 - 4 * wb < 12);
+    unsigned packed = 0;
+    if (fast) {
+        const unsigned* q0 = reinterpret_cast<const unsigned*>(r0);
+        const unsigned* q1 = reinterpret_cast<const unsigned*>(r1);
+        const int i0 = wb, i1 = min(wb + 1, wmax), i2 = min(wb + 2, wmax);
+        const unsigned a0 = q0[i0], a1 = q0[i1], a2 = q0[i2];
+        const unsigned c0 = q1[i0], c1 = q1[i1], c2 = q1[i2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int o = sx[i] - 4 * wb;
+            const unsigned pa = pair_at(a0, a1, a2, o), pc = pair_at(c0, c1, c2, o);
+            const int w0 = (short)(aa[i] & 0xFFFF), w1 = (short)(aa[i] >> 16);
+            const int h0 = (int)(pa & 0xFF) * w0 + (int)((pa >> 8) & 0xFF) * w1;
+            const int h1 = (int)(pc & 0xFF) * w0 + (int)((pc >> 8) & 0xFF) * w1;
             int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            packed |= (unsigned)v << (8 * i);
-            nvalid++;
+            packed |= (unsigned)min(max(v, 0), 255) << (8 * i);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int w0 = (short)(aa[i] & 0xFFFF), w1 = (short)(aa[i] >> 16);
+            const int sx1 = min(sx[i] + 1, S.w - 1);
+            const int h0 = r0[sx[i]] * w0 + r0[sx1] * w1;
+            const int h1 = r1[sx[i]] * w0 + r1[sx1] * w1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (unsigned)min(max(v, 0), 255) << (8 * i);
         }
     }
     uint8_t* o = dst + (long long)dy * D.pitch + dx0;
@@ -137,14 +166,15 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // A = max over the sixteen 9-arcs of min(v - ring) and of min(ring - v): the pixel is a FAST-9 corner at
 // threshold t iff A > t, and its OpenCV corner score is A - 1.
 __device__ __forceinline__ int fast_arc_value(const uint8_t* p) {
+    constexpr int T = kTileStride;
     const int v = p[0];
     int d[16];
-    d[0] = v - p[3 * kTile];          d[1] = v - p[3 * kTile + 1];   d[2] = v - p[2 * kTile + 2];
-    d[3] = v - p[kTile + 3];          d[4] = v - p[3];               d[5] = v - p[-kTile + 3];
-    d[6] = v - p[-2 * kTile + 2];     d[7] = v - p[-3 * kTile + 1];  d[8] = v - p[-3 * kTile];
-    d[9] = v - p[-3 * kTile - 1];     d[10] = v - p[-2 * kTile - 2]; d[11] = v - p[-kTile - 3];
-    d[12] = v - p[-3];                d[13] = v - p[kTile - 3];      d[14] = v - p[2 * kTile - 2];
-    d[15] = v - p[3 * kTile - 1];
+    d[0] = v - p[3 * T];          d[1] = v - p[3 * T + 1];   d[2] = v - p[2 * T + 2];
+    d[3] = v - p[T + 3];          d[4] = v - p[3];           d[5] = v - p[-T + 3];
+    d[6] = v - p[-2 * T + 2];     d[7] = v - p[-3 * T + 1];  d[8] = v - p[-3 * T];
+    d[9] = v - p[-3 * T - 1];     d[10] = v - p[-2 * T - 2]; d[11] = v - p[-T - 3];
+    d[12] = v - p[-3];            d[13] = v - p[T - 3];      d[14] = v - p[2 * T - 2];
+    d[15] = v - p[3 * T - 1];
     int lo3[16], hi3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -160,41 +190,90 @@ __device__ __forceinline__ int fast_arc_value(const uint8_t* p) {
     return max(dark, -bright);
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const Geom* __restrict__ g, const CellDesc* __restrict__ cells, ImgSrc s,
-                                                    unsigned* __restrict__ cellcand, int* __restrict__ cellcnt) {
-    __shared__ uint8_t tile[kTile * kTile];
-    __shared__ short arc[kTested * kTested];
-    __shared__ uint8_t sc[(kTested + 2) * (kTested + 2)];
-    __shared__ int wsum[4];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+// Any 9 contiguous ring positions contain at least two of the compass positions 0, 4, 8, 12: a pixel can only be a
+// corner at threshold t if two compass pixels are darker than v - t or two are brighter than v + t.
+__device__ __forceinline__ bool fast_quick_pass(const uint8_t* p, int t) {
+    constexpr int T = kTileStride;
+    const int v = p[0];
+    const int d0 = v - p[3 * T], d4 = v - p[3], d8 = v - p[-3 * T], d12 = v - p[-3];
+    const int dark = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
+    const int bright = (-d0 > t) + (-d4 > t) + (-d8 > t) + (-d12 > t);
+    return dark >= 2 || bright >= 2;
+}
+
+// ONE WAVEFRONT per FAST cell (64-thread workgroups): no cross-wave barriers, LDS sized by the largest cell of the
+// current geometry (8 KB at 640x480 => the 32-waves/CU limit, not LDS, bounds residency).
+//   1. stage the sub-image with aligned u32 loads (the tile keeps the source's alignment phase)
+//   2. pass A: compass test at the lower threshold, survivors compacted into a work list (ballot + popcount)
+//   3. pass B: exact arc value of the survivors
+//   4. score map + 3x3 strict NMS in LDS (blind across the cell seam, like upstream's per-cell cv::FAST calls);
+//      corners leave in row-major order through a ballot scan; an empty cell retries at minThFAST
+__global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, const CellDesc* __restrict__ cells, ImgSrc s,
+                                                   unsigned* __restrict__ cellcand, int* __restrict__ cellcnt) {
+    extern __shared__ __align__(16) uint8_t fsm[];
+    const int lane = threadIdx.x;
     const int cell = blockIdx.x, f = blockIdx.y;
     const CellDesc c = cells[cell];
+    const int maxT = g->fastMaxTested;                 // max tested pixels of any cell
+    uint8_t* tile = fsm;                                // fastTileBytes
+    short* arc = reinterpret_cast<short*>(fsm + g->fastTileBytes);
+    unsigned short* worklist = reinterpret_cast<unsigned short*>(arc + maxT);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(worklist + maxT);   // (tw+2)*(th+2) <= fastScBytes
     int pitch;
     const uint8_t* src = level_ptr(g, s, c.level, f, &pitch);
     const int sw = c.sw, sh = c.sh, tw = sw - 6, th_ = sh - 6;
     const long long slot = (long long)f * g->totalCells + cell;
     if (tw <= 0 || th_ <= 0) {
-        if (t == 0) cellcnt[slot] = 0;
+        if (lane == 0) cellcnt[slot] = 0;
         return;
     }
-    for (int i = t; i < sw * sh; i += 256) {
-        const int y = i / sw, x = i - y * sw;
-        tile[y * kTile + x] = src[(long long)(c.y0 + y) * pitch + c.x0 + x];
+    // i / d for 0 <= i < 8192, 1 <= d <= 80 without an integer divide: (i + 0.5) / d is at least 0.5/80 away from an
+    // integer, the float product is off by < 1e-4, so truncation is exact
+#define QDIV(i, inv) ((int)(((float)(i) + 0.5f) * (inv)))
+    const float invTw = 1.0f / (float)tw, invRw = 1.0f / (float)(tw + 2), invSw = 1.0f / (float)sw;
+    const int x0a = c.x0 & ~3, ph = c.x0 - x0a;
+    if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
+        const int nw = (c.x0 + sw + 3 - x0a) >> 2;   // words per row
+        const float invNw = 1.0f / (float)nw;
+        for (int i = lane; i < nw * sh; i += 64) {
+            const int y = QDIV(i, invNw), xw = i - y * nw;
+            *reinterpret_cast<unsigned*>(&tile[y * kTileStride + 4 * xw]) =
+                *reinterpret_cast<const unsigned*>(src + (long long)(c.y0 + y) * pitch + x0a + 4 * xw);
+        }
+    } else {
+        for (int i = lane; i < sw * sh; i += 64) {
+            const int y = QDIV(i, invSw), x = i - y * sw;
+            tile[y * kTileStride + x + ph] = src[(long long)(c.y0 + y) * pitch + c.x0 + x];
+        }
     }
     __syncthreads();
     const int n = tw * th_;
-    for (int i = t; i < n; i += 256) {
-        const int y = i / tw, x = i - y * tw;
-        arc[i] = (short)fast_arc_value(&tile[(y + 3) * kTile + x + 3]);
+    const int thLow = min(max(min(g->iniTh, g->minTh), 0), 255);
+    int nwork = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool pass = false;
+        if (i < n) {
+            const int y = QDIV(i, invTw), x = i - y * tw;
+            pass = fast_quick_pass(&tile[(y + 3) * kTileStride + x + 3 + ph], thLow);
+            if (!pass) arc[i] = 0;   // arc value <= thLow: never a corner at either threshold
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) worklist[nwork + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)i;
+        nwork += __popcll(m);
+    }
+    __syncthreads();
+    for (int k = lane; k < nwork; k += 64) {
+        const int i = worklist[k];
+        const int y = QDIV(i, invTw), x = i - y * tw;
+        arc[i] = (short)fast_arc_value(&tile[(y + 3) * kTileStride + x + 3 + ph]);
     }
     __syncthreads();
     const int rw = tw + 2;
-    const int ppt = (n + 255) / 256;           // <= 18, contiguous pixels per thread => row-major output order
-    const int beg = min(t * ppt, n), end = min(beg + ppt, n);
     for (int pass = 0; pass < 2; pass++) {
         const int th = min(max(pass ? g->minTh : g->iniTh, 0), 255);
-        for (int i = t; i < rw * (th_ + 2); i += 256) {
-            const int yy = i / rw - 1, xx = i - (yy + 1) * rw - 1;
+        for (int i = lane; i < rw * (th_ + 2); i += 64) {
+            const int yy = QDIV(i, invRw) - 1, xx = i - (yy + 1) * rw - 1;
             int v = 0;
             if (yy >= 0 && yy < th_ && xx >= 0 && xx < tw) {
                 const int a = arc[yy * tw + xx];
@@ -203,44 +282,44 @@ __global__ __launch_bounds__(256) void k_fast_cells(const Geom* __restrict__ g, 
             sc[i] = (uint8_t)v;
         }
         __syncthreads();
-        unsigned keep = 0;
-        for (int i = beg; i < end; i++) {
-            const int y = i / tw, x = i - y * tw;
-            if (arc[i] > th) {
-                const uint8_t* q = &sc[(y + 1) * rw + x + 1];
-                const int v = q[0];
-                const int m = max(max3i(q[-rw - 1], q[-rw], q[-rw + 1]), max(max(q[-1], q[1]), max3i(q[rw - 1], q[rw], q[rw + 1])));
-                if (v > m) keep |= 1u << (i - beg);
-            }
-        }
-        const int cnt = __popc(keep);
-        int incl = cnt;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const int o = __shfl_up(incl, dlt);
-            if (lane >= dlt) incl += o;
-        }
-        if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wv; w++) base += wsum[w];
-        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (total > 0 || pass == 1) {
-            int pos = base + incl - cnt;
-            unsigned* out = cellcand + slot * g->cellCap;
-            for (int i = beg; i < end; i++) {
-                if (keep & (1u << (i - beg))) {
-                    const int y = i / tw, x = i - y * tw;
-                    const unsigned X = (unsigned)(x + 3 + c.offX), Y = (unsigned)(y + 3 + c.offY);
-                    if (pos < g->cellCap) out[pos] = X | (Y << 12) | ((unsigned)(arc[i] - 1) << 24);
-                    pos++;
+        // two sweeps over the pixels in row-major order: count, then (if the cell is not empty) emit
+        int total = 0;
+        unsigned* out = cellcand + slot * g->cellCap;
+        for (int sweep = 0; sweep < 2; sweep++) {
+            int run = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                bool keep = false;
+                int y = 0, x = 0, a = 0;
+                if (i < n) {
+                    a = arc[i];
+                    if (a > th) {
+                        y = QDIV(i, invTw); x = i - y * tw;
+                        const uint8_t* q = &sc[(y + 1) * rw + x + 1];
+                        const int v = q[0];
+                        const int m = max(max3i(q[-rw - 1], q[-rw], q[-rw + 1]), max(max(q[-1], q[1]), max3i(q[rw - 1], q[rw], q[rw + 1])));
+                        keep = v > m;
+                    }
                 }
+                const unsigned long long m = __ballot(keep);
+                if (sweep == 1 && keep) {
+                    const int pos = run + __popcll(m & ((1ull << lane) - 1));
+                    if (pos < g->cellCap) out[pos] = (unsigned)(x + 3 + c.offX) | ((unsigned)(y + 3 + c.offY) << 12) | ((unsigned)(a - 1) << 24);
+                }
+                run += __popcll(m);
             }
-            if (t == 0) cellcnt[slot] = min(total, g->cellCap);
-            return;  // uniform: `total` is the same in every thread
+            if (sweep == 0) {
+                total = run;
+                if (total == 0) break;
+            }
         }
-        __syncthreads();  // before sc/wsum are rewritten by the minThFAST pass
+        if (total > 0 || pass == 1) {
+            if (lane == 0) cellcnt[slot] = min(total, g->cellCap);
+            return;
+        }
+        __syncthreads();  // before sc is rewritten by the minThFAST pass
     }
+#undef QDIV
 }
 
 // ---------------------------------------------------------------------------------------------- quad-tree
@@ -489,41 +568,67 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur,
-                                               const int* __restrict__ levelcnt) {
-    __shared__ uint8_t in[22][72];
-    __shared__ unsigned short hb[22][64];
-    const int t = threadIdx.x, f = blockIdx.y;
+// Tile = 256 px (64 lanes x 4 px) wide, 64 rows (4 waves x 16 rows) high.  Each lane streams down its 4-px column
+// strip: per source row three aligned u32 loads (12 bytes cover x-3..x+6), a horizontal 7-tap pass in registers, a
+// 7-deep register window of row results and the vertical pass; one packed u32 store per row.  No LDS; edge lanes
+// (window crossing the image border, or an unaligned caller buffer) take a byte-wise reflect-101 path.
+constexpr int kBlurRows = 16;   // output rows per wave
+__device__ __forceinline__ void blur_hpass(const uint8_t* __restrict__ row, int x4, int w, bool fast, unsigned hres[4]) {
+    unsigned p[10];
+    if (fast) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(row + x4);
+        const unsigned w0 = q[-1], w1 = q[0], w2 = q[1];
+        p[0] = (w0 >> 8) & 0xFF; p[1] = (w0 >> 16) & 0xFF; p[2] = w0 >> 24;
+        p[3] = w1 & 0xFF; p[4] = (w1 >> 8) & 0xFF; p[5] = (w1 >> 16) & 0xFF; p[6] = w1 >> 24;
+        p[7] = w2 & 0xFF; p[8] = (w2 >> 8) & 0xFF; p[9] = (w2 >> 16) & 0xFF;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 10; k++) p[k] = row[reflect101(x4 - 3 + k, w)];
+    }
+    // taps round(k*256) of getGaussianKernel(7, 2): 18 34 49 55 49 34 18 (host-verified at handle creation)
+#pragma unroll
+    for (int i = 0; i < 4; i++) hres[i] = 18u * (p[i] + p[i + 6]) + 34u * (p[i + 1] + p[i + 5]) + 49u * (p[i + 2] + p[i + 4]) + 55u * p[i + 3];
+}
+
+__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
     int l = 0;
     while (l + 1 < g->nlevels && (int)blockIdx.x >= g->L[l + 1].tileBase) l++;
-    if (levelcnt[f * g->nlevels + l] == 0) return;  // upstream skips levels without keypoints (:1081-1082)
+    // (upstream blurs only levels that hold keypoints, :1081-1082; blurring all of them changes no output and removes
+    //  the dependency on the quad-tree, so this kernel can overlap it)
     const LevelGeom L = g->L[l];
     const int tile = blockIdx.x - L.tileBase;
-    const int x0 = (tile % L.tilesX) * 64, y0 = (tile / L.tilesX) * 16;
+    const int x4 = (tile % L.tilesX) * 256 + lane * 4;
+    const int y0 = (tile / L.tilesX) * (4 * kBlurRows) + wv * kBlurRows;
+    if (x4 >= L.w || y0 >= L.h) return;
     int pitch;
     const uint8_t* src = level_ptr(g, s, l, f, &pitch);
-    for (int i = t; i < 22 * 70; i += 256) {
-        const int ry = i / 70, rx = i - ry * 70;
-        const int sy = reflect101(y0 - 3 + ry, L.h), sx = reflect101(x0 - 3 + rx, L.w);
-        in[ry][rx] = src[(long long)sy * pitch + sx];
-    }
-    __syncthreads();
-    // taps round(k*256) of getGaussianKernel(7, 2): 18 34 49 55 49 34 18 (host-verified at handle creation)
-    for (int i = t; i < 22 * 64; i += 256) {
-        const int ry = i >> 6, x = i & 63;
-        const uint8_t* p = &in[ry][x];
-        hb[ry][x] = (unsigned short)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
-    }
-    __syncthreads();
-    const int tx = t & 63, ty = t >> 6;
+    const bool aligned = (((uintptr_t)src | (uintptr_t)pitch) & 3) == 0;
+    const bool fast = aligned && x4 >= 4 && x4 + 7 < L.w;
     uint8_t* dst = blur + (long long)f * g->pyrFrameBytes + L.off;
+    unsigned win[7][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int yy = ty * 4 + r, y = y0 + yy, x = x0 + tx;
-        if (y < L.h && x < L.w) {
-            const int sv = 18 * (hb[yy][tx] + hb[yy + 6][tx]) + 34 * (hb[yy + 1][tx] + hb[yy + 5][tx]) +
-                           49 * (hb[yy + 2][tx] + hb[yy + 4][tx]) + 55 * hb[yy + 3][tx];
-            dst[(long long)y * L.pitch + x] = (uint8_t)min((sv + 32768) >> 16, 255);
+    for (int r = 0; r < kBlurRows + 6; r++) {
+        const int sy = reflect101(y0 - 3 + r, L.h);
+        unsigned hr[4];
+        blur_hpass(src + (long long)sy * pitch, x4, L.w, fast, hr);
+#pragma unroll
+        for (int i = 0; i < 4; i++) win[r % 7][i] = hr[i];
+        if (r >= 6) {
+            const int y = y0 + r - 6;
+            if (y < L.h) {
+                unsigned packed = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    // rows r-6 .. r of the window hold taps 0..6
+                    const unsigned sv = 18u * (win[(r - 6) % 7][i] + win[r % 7][i]) + 34u * (win[(r - 5) % 7][i] + win[(r - 1) % 7][i]) +
+                                        49u * (win[(r - 4) % 7][i] + win[(r - 2) % 7][i]) + 55u * win[(r - 3) % 7][i];
+                    packed |= min((sv + 32768u) >> 16, 255u) << (8 * i);
+                }
+                uint8_t* o = dst + (long long)y * L.pitch + x4;
+                if (x4 + 3 < L.w) *reinterpret_cast<unsigned*>(o) = packed;
+                else for (int i = 0; x4 + i < L.w; i++) o[i] = (uint8_t)(packed >> (8 * i));
+            }
         }
     }
 }
@@ -603,12 +708,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     const int u = (lane & 31) - 15, half = lane >> 5;
     int m10 = 0, m01 = 0;
     if (u <= 15) {
+        // rows v = -15..0 (lower half-wave) / 1..15 (upper); end of each row of the radius-15 disc = kUmax[|v|]
+        // (the table of reference src/ORBextractor.cc:455-469, verified against the computed one at handle creation)
+        constexpr int kUmax[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
         const uint8_t* c0 = img + (long long)cy * pitch + cx + u;
         const int au = u < 0 ? -u : u;
-        const int v0 = half ? 1 : -15, v1 = half ? 15 : 0;
-        for (int v = v0; v <= v1; v++) {
-            const int av = v < 0 ? -v : v;
-            if (au <= g->umax[av]) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int v = half ? k + 1 : k - 15;
+            const int um = half ? kUmax[k + 1] : kUmax[15 - k];
+            if (au <= um) {
                 const int val = c0[(long long)v * pitch];
                 m10 += u * val;
                 m01 += v * val;
@@ -683,6 +792,8 @@ struct eao_orb {
     size_t quadLds = 0;
     // device state
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;          // the blur runs here, concurrently with FAST + quad-tree
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
     eao::DevBuf<int> d_tab;
@@ -697,7 +808,7 @@ struct eao_orb {
     ImgSrc lastSrc{};
     int lastBatch = 0;
     bool profiling = false;
-    std::vector<hipEvent_t> evs;   // 6 events per profiled call, averaged by eao_orb_last_timing
+    std::vector<hipEvent_t> evs;   // 8 events per profiled call, averaged by eao_orb_last_timing
     size_t evUsed = 0;
 };
 
@@ -712,7 +823,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     for (int i = 0; i < 16; i++) g.umax[i] = h->umax[i];
     h->cells.clear();
     h->tab.clear();
-    int off = 0, kpBase = 0, candBase = 0, tileBase = 0, maxCell = 0, scanCap = 0, maxList = 0;
+    int off = 0, kpBase = 0, candBase = 0, tileBase = 0, maxCell = 0, scanCap = 0, maxList = 0, maxSw = 0, maxSh = 0;
     // first pass: level sizes and the largest FAST cell (fixes cellCap)
     for (int l = 0; l < c.nlevels; l++) {
         LevelGeom& L = g.L[l];
@@ -753,6 +864,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
                 cd.level = (short)l; cd.x0 = (short)iniX; cd.y0 = (short)iniY;
                 cd.sw = (short)((int)maxX - (int)iniX); cd.sh = (short)((int)maxY - (int)iniY);
                 cd.offX = (short)(j * wCell); cd.offY = (short)(i * hCell); cd.pad = 0;
+                maxSw = std::max(maxSw, (int)cd.sw); maxSh = std::max(maxSh, (int)cd.sh);
                 h->cells.push_back(cd);
             }
         }
@@ -767,8 +879,8 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         L.kpBase = kpBase; kpBase += L.listCap;
         L.candBase = candBase; L.candCap = L.nCells * g.cellCap; candBase += L.candCap;
         EAO_REQUIRE(L.candCap < (1 << 20), "level %d can hold %d FAST candidates; the quad-tree packs indices in 20 bits", l, L.candCap);
-        L.tilesX = eao::cdiv(L.w, 64);
-        L.tileBase = tileBase; tileBase += L.tilesX * eao::cdiv(L.h, 16);
+        L.tilesX = eao::cdiv(L.w, 256);
+        L.tileBase = tileBase; tileBase += L.tilesX * eao::cdiv(L.h, 4 * kBlurRows);
         L.scale = h->scale[l];
         L.scaledPatch = (int)(31 * h->scale[l]);
         scanCap = std::max(scanCap, std::max(L.listCap, L.nCells));
@@ -778,7 +890,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         if (l > 0) {
             const LevelGeom& S = g.L[l - 1];
             const double sx_ = 1. / ((double)L.w / S.w), sy_ = 1. / ((double)L.h / S.h);
-            std::vector<int> xofs(L.w), xal(L.w), yofs(L.h), ybe(L.h);
+            std::vector<int> xt(2 * (size_t)L.w), yt(2 * (size_t)L.h);
             for (int dx = 0; dx < L.w; dx++) {
                 float fx = (float)((dx + 0.5) * sx_ - 0.5);
                 int sx = (int)std::floor(fx);
@@ -787,8 +899,8 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
                 if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
                 const int a0 = std::min(std::max(cv_round((1.f - fx) * 2048.f), -32768), 32767);
                 const int a1 = std::min(std::max(cv_round(fx * 2048.f), -32768), 32767);
-                xofs[dx] = sx;
-                xal[dx] = (a0 & 0xFFFF) | (a1 << 16);
+                xt[2 * dx] = sx;
+                xt[2 * dx + 1] = (a0 & 0xFFFF) | (a1 << 16);
             }
             for (int dy = 0; dy < L.h; dy++) {
                 float fy = (float)((dy + 0.5) * sy_ - 0.5);
@@ -796,13 +908,11 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
                 fy -= sy;
                 const int b0 = std::min(std::max(cv_round((1.f - fy) * 2048.f), -32768), 32767);
                 const int b1 = std::min(std::max(cv_round(fy * 2048.f), -32768), 32767);
-                yofs[dy] = sy;
-                ybe[dy] = (b0 & 0xFFFF) | (b1 << 16);
+                yt[2 * dy] = sy;
+                yt[2 * dy + 1] = (b0 & 0xFFFF) | (b1 << 16);
             }
-            h->tab.insert(h->tab.end(), xofs.begin(), xofs.end());
-            h->tab.insert(h->tab.end(), xal.begin(), xal.end());
-            h->tab.insert(h->tab.end(), yofs.begin(), yofs.end());
-            h->tab.insert(h->tab.end(), ybe.begin(), ybe.end());
+            h->tab.insert(h->tab.end(), xt.begin(), xt.end());
+            h->tab.insert(h->tab.end(), yt.begin(), yt.end());
         }
     }
     if (h->tab.empty()) h->tab.push_back(0);
@@ -812,6 +922,9 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     g.totalTiles = tileBase;
     g.pyrFrameBytes = off;
     g.scanCap = scanCap;
+    g.fastMaxTested = std::max(1, (maxSw - 6) * (maxSh - 6));
+    g.fastTileBytes = ((maxSh * kTileStride) + 15) & ~15;
+    g.fastLdsBytes = g.fastTileBytes + g.fastMaxTested * 4 + (((maxSw - 4) * (maxSh - 4)) + 15 & ~15);
     // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
     h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (size_t)scanCap * sizeof(int);
     EAO_REQUIRE(h->quadLds <= 150 * 1024, "nfeatures too large: quad-tree needs %zu bytes of LDS", h->quadLds);
@@ -839,7 +952,12 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
 eao_status ensure(eao_orb* h, int W, int H, int batch) {
     eao_status st = eao::require_device();
     if (st) return st;
-    if (!h->stream) EAO_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (!h->stream) {
+        EAO_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        EAO_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        EAO_HIP(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+        EAO_HIP(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
+    }
     if (!h->geomValid || h->geom.W != W || h->geom.H != H) {
         st = build_geometry(h, W, H);
         if (st) return st;
@@ -873,13 +991,13 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
     const bool prof = h->profiling;
     hipEvent_t* ev = nullptr;
     if (prof) {
-        if (h->evUsed + 6 > h->evs.size()) {
+        if (h->evUsed + 8 > h->evs.size()) {
             const size_t old = h->evs.size();
-            h->evs.resize(old + 6 * 16, nullptr);
+            h->evs.resize(old + 8 * 16, nullptr);
             for (size_t i = old; i < h->evs.size(); i++) EAO_HIP(hipEventCreate(&h->evs[i]));
         }
         ev = &h->evs[h->evUsed];
-        h->evUsed += 6;
+        h->evUsed += 8;
         EAO_HIP(hipEventRecord(ev[0], st));
     }
     for (int l = 1; l < g.nlevels; l++) {
@@ -887,13 +1005,21 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
         hipLaunchKernelGGL(k_resize, grid, block, 0, st, h->d_geom.p, h->d_tab.p, s, l);
     }
     if (prof) EAO_HIP(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, batch), dim3(256), 0, st, h->d_geom.p, h->d_cells.p, s,
+    // fork: the 7x7 blur only needs the pyramid, so it runs on the side stream while FAST and the quad-tree (both
+    // latency-bound, far from filling the chip) run on the main one; join before orientation + description
+    EAO_HIP(hipEventRecord(h->evFork, st));
+    EAO_HIP(hipStreamWaitEvent(h->side, h->evFork, 0));
+    if (prof) EAO_HIP(hipEventRecord(ev[6], h->side));
+    hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, batch), dim3(256), 0, h->side, h->d_geom.p, s, h->d_blur.p);
+    if (prof) EAO_HIP(hipEventRecord(ev[7], h->side));
+    EAO_HIP(hipEventRecord(h->evJoin, h->side));
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, batch), dim3(64), g.fastLdsBytes, st, h->d_geom.p, h->d_cells.p, s,
                        h->d_cellcand.p, h->d_cellcnt.p);
     if (prof) EAO_HIP(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, batch), dim3(256), h->quadLds, st, h->d_geom.p, h->d_cellcand.p,
                        h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p);
     if (prof) EAO_HIP(hipEventRecord(ev[3], st));
-    hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, batch), dim3(256), 0, st, h->d_geom.p, s, h->d_blur.p, h->d_levelcnt.p);
+    EAO_HIP(hipStreamWaitEvent(st, h->evJoin, 0));
     if (prof) EAO_HIP(hipEventRecord(ev[4], st));
     hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), batch), dim3(256), 0, st, h->d_geom.p, s,
                        h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap);
@@ -944,6 +1070,11 @@ eao_status eao_orb_create(const eao_orb_cfg* cfg, eao_orb** out) {
             ++v0;
         }
     }
+    {
+        const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+        for (int i = 0; i < 16; i++)
+            if (h->umax[i] != expect[i]) { delete h; eao::set_error("umax table mismatch"); return EAO_ERR_INTERNAL; }
+    }
     *out = h;
     return EAO_OK;
 }
@@ -952,6 +1083,9 @@ void eao_orb_destroy(eao_orb* h) {
     if (!h) return;
     for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     delete h;
 }
 
@@ -1075,16 +1209,19 @@ eao_status eao_orb_set_profiling(eao_orb* h, int32_t on) {
 }
 
 eao_status eao_orb_last_timing(eao_orb* h, float ms[6]) {
-    EAO_REQUIRE(h && ms && h->evUsed >= 6, "no profiled call since eao_orb_set_profiling(h, 1)");
-    const size_t calls = h->evUsed / 6;
-    EAO_HIP(hipEventSynchronize(h->evs[h->evUsed - 1]));
+    EAO_REQUIRE(h && ms && h->evUsed >= 8, "no profiled call since eao_orb_set_profiling(h, 1)");
+    const size_t calls = h->evUsed / 8;
+    EAO_HIP(hipEventSynchronize(h->evs[h->evUsed - 3]));   // ev[5] of the last call
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (size_t c = 0; c < calls; c++) {
-        hipEvent_t* ev = &h->evs[c * 6];
+        hipEvent_t* ev = &h->evs[c * 8];
         float t;
-        for (int i = 0; i < 5; i++) { EAO_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1])); acc[i] += t; }
-        EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[5]));
-        acc[5] += t;
+        EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[1])); acc[0] += t;   // pyramid
+        EAO_HIP(hipEventElapsedTime(&t, ev[1], ev[2])); acc[1] += t;   // FAST (the blur overlaps it on the side stream)
+        EAO_HIP(hipEventElapsedTime(&t, ev[2], ev[3])); acc[2] += t;   // quad-tree
+        EAO_HIP(hipEventElapsedTime(&t, ev[6], ev[7])); acc[3] += t;   // blur, side stream
+        EAO_HIP(hipEventElapsedTime(&t, ev[4], ev[5])); acc[4] += t;   // orientation + description
+        EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[5])); acc[5] += t;
     }
     for (int i = 0; i < 6; i++) ms[i] = (float)(acc[i] / calls);
     h->evUsed = 0;
