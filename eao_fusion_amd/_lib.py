@@ -65,6 +65,7 @@ SYMBOLS = {
     "eao_orb_level_candidates": (_I, [_P, _I, _I, _P, _I, C.POINTER(_I)]),
     "eao_orb_set_profiling": (_I, [_P, _I]),
     "eao_orb_last_timing": (_I, [_P, _P]),
+    "eao_orb_lanes": (_I, [_I]),
     "eao_hamming_matrix": (_I, [_P, _I, _P, _I, _P]),
     "eao_hamming_best2": (_I, [_P, _I, _P, _I, _P, _P]),
     "eao_hamming_matrix_device": (_I, [_P, _I, _P, _I, _I, _P, _P]),

@@ -21,6 +21,7 @@
 // expressions are rounded op by op.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -97,10 +98,10 @@ __device__ __forceinline__ unsigned pair_at(unsigned w0, unsigned w1, unsigned w
     return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));   // bits 0-7: S[sx], bits 8-15: S[sx+1]
 }
 
-__global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, const int* __restrict__ tab, ImgSrc s, int l) {
+__global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, const int* __restrict__ tab, ImgSrc s, int l, int f0) {
     const LevelGeom D = g->L[l];
     const LevelGeom S = g->L[l - 1];
-    const int f = blockIdx.z;
+    const int f = blockIdx.z + f0;
     const int dy = blockIdx.y * 4 + threadIdx.y;
     const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     if (dy >= D.h || dx0 >= D.w) return;
@@ -202,23 +203,24 @@ __device__ __forceinline__ bool fast_quick_pass(const uint8_t* p, int t) {
 }
 
 // ONE WAVEFRONT per FAST cell (64-thread workgroups): no cross-wave barriers, LDS sized by the largest cell of the
-// current geometry (8 KB at 640x480 => the 32-waves/CU limit, not LDS, bounds residency).
-//   1. stage the sub-image with aligned u32 loads (the tile keeps the source's alignment phase)
-//   2. pass A: compass test at the lower threshold, survivors compacted into a work list (ballot + popcount)
-//   3. pass B: exact arc value of the survivors
-//   4. score map + 3x3 strict NMS in LDS (blind across the cell seam, like upstream's per-cell cv::FAST calls);
-//      corners leave in row-major order through a ballot scan; an empty cell retries at minThFAST
+// current geometry.  Per threshold (iniThFAST, then minThFAST only if the cell stayed empty, as upstream :809-816):
+//   1. compass test of every pixel, survivors compacted into a work list (ballot + popcount keeps row-major order)
+//   2. exact arc value of the survivors; corners (arc > th) write their score into an LDS score map that is zero
+//      everywhere else and are appended to a corner list (again order-preserving)
+//   3. 3x3 strict NMS of the listed corners against the score map (blind across the cell seam, like upstream's
+//      per-cell cv::FAST calls); kept corners leave in row-major order through a ballot scan
 __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, const CellDesc* __restrict__ cells, ImgSrc s,
-                                                   unsigned* __restrict__ cellcand, int* __restrict__ cellcnt) {
+                                                   unsigned* __restrict__ cellcand, int* __restrict__ cellcnt, int f0) {
     extern __shared__ __align__(16) uint8_t fsm[];
     const int lane = threadIdx.x;
-    const int cell = blockIdx.x, f = blockIdx.y;
+    const int cell = blockIdx.x, f = blockIdx.y + f0;
     const CellDesc c = cells[cell];
     const int maxT = g->fastMaxTested;                 // max tested pixels of any cell
     uint8_t* tile = fsm;                                // fastTileBytes
-    short* arc = reinterpret_cast<short*>(fsm + g->fastTileBytes);
-    unsigned short* worklist = reinterpret_cast<unsigned short*>(arc + maxT);
-    uint8_t* sc = reinterpret_cast<uint8_t*>(worklist + maxT);   // (tw+2)*(th+2) <= fastScBytes
+    unsigned short* worklist = reinterpret_cast<unsigned short*>(fsm + g->fastTileBytes);
+    unsigned short* corners = worklist + maxT;
+    unsigned* sc4 = reinterpret_cast<unsigned*>(corners + maxT + (maxT & 1));   // score map (tw+2) x (th+2) bytes, word aligned
+    uint8_t* sc = reinterpret_cast<uint8_t*>(sc4);
     int pitch;
     const uint8_t* src = level_ptr(g, s, c.level, f, &pitch);
     const int sw = c.sw, sh = c.sh, tw = sw - 6, th_ = sh - 6;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     // i / d for 0 <= i < 8192, 1 <= d <= 80 without an integer divide: (i + 0.5) / d is at least 0.5/80 away from an
     // integer, the float product is off by < 1e-4, so truncation is exact
 #define QDIV(i, inv) ((int)(((float)(i) + 0.5f) * (inv)))
-    const float invTw = 1.0f / (float)tw, invRw = 1.0f / (float)(tw + 2), invSw = 1.0f / (float)sw;
+    const float invTw = 1.0f / (float)tw, invSw = 1.0f / (float)sw;
     const int x0a = c.x0 & ~3, ph = c.x0 - x0a;
     if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
         const int nw = (c.x0 + sw + 3 - x0a) >> 2;   // words per row
@@ -246,78 +248,70 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
             tile[y * kTileStride + x + ph] = src[(long long)(c.y0 + y) * pitch + c.x0 + x];
         }
     }
-    __syncthreads();
-    const int n = tw * th_;
-    const int thLow = min(max(min(g->iniTh, g->minTh), 0), 255);
-    int nwork = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        bool pass = false;
-        if (i < n) {
-            const int y = QDIV(i, invTw), x = i - y * tw;
-            pass = fast_quick_pass(&tile[(y + 3) * kTileStride + x + 3 + ph], thLow);
-            if (!pass) arc[i] = 0;   // arc value <= thLow: never a corner at either threshold
-        }
-        const unsigned long long m = __ballot(pass);
-        if (pass) worklist[nwork + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)i;
-        nwork += __popcll(m);
-    }
-    __syncthreads();
-    for (int k = lane; k < nwork; k += 64) {
-        const int i = worklist[k];
-        const int y = QDIV(i, invTw), x = i - y * tw;
-        arc[i] = (short)fast_arc_value(&tile[(y + 3) * kTileStride + x + 3 + ph]);
-    }
-    __syncthreads();
-    const int rw = tw + 2;
+    const int n = tw * th_, rw = tw + 2;
+    const int scWords = (rw * (th_ + 2) + 3) >> 2;
+    unsigned* out = cellcand + slot * g->cellCap;
     for (int pass = 0; pass < 2; pass++) {
         const int th = min(max(pass ? g->minTh : g->iniTh, 0), 255);
-        for (int i = lane; i < rw * (th_ + 2); i += 64) {
-            const int yy = QDIV(i, invRw) - 1, xx = i - (yy + 1) * rw - 1;
-            int v = 0;
-            if (yy >= 0 && yy < th_ && xx >= 0 && xx < tw) {
-                const int a = arc[yy * tw + xx];
-                v = (a > th) ? a - 1 : 0;
+        for (int i = lane; i < scWords; i += 64) sc4[i] = 0;
+        __syncthreads();   // tile staged (first pass) / previous pass done with sc
+        // ---- 1. compass test
+        int nwork = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            bool pass1 = false;
+            if (i < n) {
+                const int y = QDIV(i, invTw), x = i - y * tw;
+                pass1 = fast_quick_pass(&tile[(y + 3) * kTileStride + x + 3 + ph], th);
             }
-            sc[i] = (uint8_t)v;
+            const unsigned long long m = __ballot(pass1);
+            if (pass1) worklist[nwork + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)i;
+            nwork += __popcll(m);
         }
         __syncthreads();
-        // two sweeps over the pixels in row-major order: count, then (if the cell is not empty) emit
+        // ---- 2. exact arc value of the survivors; corners go to the score map and the corner list
+        int ncorner = 0;
+        for (int k0 = 0; k0 < nwork; k0 += 64) {
+            const int k = k0 + lane;
+            bool corner = false;
+            int i = 0;
+            if (k < nwork) {
+                i = worklist[k];
+                const int y = QDIV(i, invTw), x = i - y * tw;
+                const int a = fast_arc_value(&tile[(y + 3) * kTileStride + x + 3 + ph]);
+                corner = a > th;
+                if (corner) sc[(y + 1) * rw + x + 1] = (uint8_t)(a - 1);
+            }
+            const unsigned long long m = __ballot(corner);
+            if (corner) corners[ncorner + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)i;
+            ncorner += __popcll(m);
+        }
+        __syncthreads();
+        // ---- 3. NMS + ordered emission
         int total = 0;
-        unsigned* out = cellcand + slot * g->cellCap;
-        for (int sweep = 0; sweep < 2; sweep++) {
-            int run = 0;
-            for (int i0 = 0; i0 < n; i0 += 64) {
-                const int i = i0 + lane;
-                bool keep = false;
-                int y = 0, x = 0, a = 0;
-                if (i < n) {
-                    a = arc[i];
-                    if (a > th) {
-                        y = QDIV(i, invTw); x = i - y * tw;
-                        const uint8_t* q = &sc[(y + 1) * rw + x + 1];
-                        const int v = q[0];
-                        const int m = max(max3i(q[-rw - 1], q[-rw], q[-rw + 1]), max(max(q[-1], q[1]), max3i(q[rw - 1], q[rw], q[rw + 1])));
-                        keep = v > m;
-                    }
-                }
-                const unsigned long long m = __ballot(keep);
-                if (sweep == 1 && keep) {
-                    const int pos = run + __popcll(m & ((1ull << lane) - 1));
-                    if (pos < g->cellCap) out[pos] = (unsigned)(x + 3 + c.offX) | ((unsigned)(y + 3 + c.offY) << 12) | ((unsigned)(a - 1) << 24);
-                }
-                run += __popcll(m);
+        for (int k0 = 0; k0 < ncorner; k0 += 64) {
+            const int k = k0 + lane;
+            bool keep = false;
+            int x = 0, y = 0, v = 0;
+            if (k < ncorner) {
+                const int i = corners[k];
+                y = QDIV(i, invTw); x = i - y * tw;
+                const uint8_t* q = &sc[(y + 1) * rw + x + 1];
+                v = q[0];
+                const int m = max(max3i(q[-rw - 1], q[-rw], q[-rw + 1]), max(max(q[-1], q[1]), max3i(q[rw - 1], q[rw], q[rw + 1])));
+                keep = v > m;
             }
-            if (sweep == 0) {
-                total = run;
-                if (total == 0) break;
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = total + __popcll(m & ((1ull << lane) - 1));
+                if (pos < g->cellCap) out[pos] = (unsigned)(x + 3 + c.offX) | ((unsigned)(y + 3 + c.offY) << 12) | ((unsigned)v << 24);
             }
+            total += __popcll(m);
         }
         if (total > 0 || pass == 1) {
             if (lane == 0) cellcnt[slot] = min(total, g->cellCap);
             return;
         }
-        __syncthreads();  // before sc is rewritten by the minThFAST pass
     }
 #undef QDIV
 }
@@ -367,12 +361,12 @@ __device__ __forceinline__ int quadrant(unsigned key, short4 bx) {
 __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
                                                   const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
                                                   unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
-                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt) {
+                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int wtmp[4];
     __shared__ int sh_S, sh_phase, sh_done, sh_rstar, sh_nexp;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int l = blockIdx.x, f = blockIdx.y;
+    const int l = blockIdx.x, f = blockIdx.y + f0;
     const LevelGeom L = g->L[l];
     const int LC = L.listCap, N = L.quota;
     // ---- LDS carve-up
@@ -590,8 +584,8 @@ __device__ __forceinline__ void blur_hpass(const uint8_t* __restrict__ row, int 
     for (int i = 0; i < 4; i++) hres[i] = 18u * (p[i] + p[i + 6]) + 34u * (p[i + 1] + p[i + 5]) + 49u * (p[i + 2] + p[i + 4]) + 55u * p[i + 3];
 }
 
-__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
+__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur, int f0) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y + f0;
     int l = 0;
     while (l + 1 < g->nlevels && (int)blockIdx.x >= g->L[l + 1].tileBase) l++;
     // (upstream blurs only levels that hold keypoints, :1081-1082; blurring all of them changes no output and removes
@@ -684,9 +678,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict__ g, ImgSrc s, const uint8_t* __restrict__ blur,
                                                          const unsigned* __restrict__ levelkps, const int* __restrict__ levelcnt,
                                                          eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                         int* __restrict__ nout, int cap) {
+                                                         int* __restrict__ nout, int cap, int f0) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int f = blockIdx.y;
+    const int f = blockIdx.y + f0;
     int j = blockIdx.x * 4 + wv;   // compact output index inside the frame
     const int jout = j;
     int l = -1, total = 0;
@@ -778,6 +772,13 @@ inline int cv_round(double v) { return (int)std::lrint(v); }
 }  // namespace
 
 // ================================================================================================= host
+struct GraphKey {
+    const void* img; int pitch0; long long fs0; int batch; void* kps; void* desc; int cap; void* n; int lanes;
+    bool operator==(const GraphKey& o) const {
+        return img == o.img && pitch0 == o.pitch0 && fs0 == o.fs0 && batch == o.batch && kps == o.kps && desc == o.desc && cap == o.cap && n == o.n && lanes == o.lanes;
+    }
+};
+
 struct eao_orb {
     eao_orb_cfg cfg;
     std::vector<float> scale, invScale, sigma2, invSigma2;
@@ -792,8 +793,11 @@ struct eao_orb {
     size_t quadLds = 0;
     // device state
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;          // the blur runs here, concurrently with FAST + quad-tree
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // up to kLanes sub-batches can run as independent pipelines, each on its own (main, side) stream pair
+    // (EAO_ORB_LANES, default 1: see the measurement note at enqueue())
+    static constexpr int kLanes = 4;
+    hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
+    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
     eao::DevBuf<int> d_tab;
@@ -808,7 +812,9 @@ struct eao_orb {
     ImgSrc lastSrc{};
     int lastBatch = 0;
     bool profiling = false;
-    std::vector<hipEvent_t> evs;   // 8 events per profiled call, averaged by eao_orb_last_timing
+    hipGraphExec_t graphExec = nullptr;
+    GraphKey graphKey = {};
+    std::vector<hipEvent_t> evs;   // 9 events per profiled call, averaged by eao_orb_last_timing
     size_t evUsed = 0;
 };
 
@@ -924,7 +930,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     g.scanCap = scanCap;
     g.fastMaxTested = std::max(1, (maxSw - 6) * (maxSh - 6));
     g.fastTileBytes = ((maxSh * kTileStride) + 15) & ~15;
-    g.fastLdsBytes = g.fastTileBytes + g.fastMaxTested * 4 + (((maxSw - 4) * (maxSh - 4)) + 15 & ~15);
+    g.fastLdsBytes = g.fastTileBytes + (g.fastMaxTested + 1) * 4 + ((((maxSw - 4) * (maxSh - 4)) + 15) & ~15);
     // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
     h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (size_t)scanCap * sizeof(int);
     EAO_REQUIRE(h->quadLds <= 150 * 1024, "nfeatures too large: quad-tree needs %zu bytes of LDS", h->quadLds);
@@ -946,6 +952,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
     h->geomValid = true;
     h->batchCap = 0;
+    if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
     return EAO_OK;
 }
 
@@ -954,9 +961,14 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
     if (st) return st;
     if (!h->stream) {
         EAO_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        EAO_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        EAO_HIP(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
-        EAO_HIP(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
+        EAO_HIP(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
+        for (int i = 0; i < eao_orb::kLanes; i++) {
+            EAO_HIP(hipStreamCreateWithFlags(&h->laneMain[i], hipStreamNonBlocking));
+            EAO_HIP(hipStreamCreateWithFlags(&h->laneSide[i], hipStreamNonBlocking));
+            EAO_HIP(hipEventCreateWithFlags(&h->evFork[i], hipEventDisableTiming));
+            EAO_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
+            EAO_HIP(hipEventCreateWithFlags(&h->evDone[i], hipEventDisableTiming));
+        }
     }
     if (!h->geomValid || h->geom.W != W || h->geom.H != H) {
         st = build_geometry(h, W, H);
@@ -977,13 +989,14 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
         RES(d_candcnt, B * g.nlevels);
 #undef RES
         h->batchCap = batch;
+        if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }   // buffers moved
     }
     return EAO_OK;
 }
 
 // enqueue the whole pipeline for `batch` frames; level 0 is read from `src` (device memory)
-eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, int batch, eao_keypoint* d_kps,
-                   uint8_t* d_desc, int cap, int* d_n, hipStream_t st) {
+eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, int batch, eao_keypoint* d_kps,
+                          uint8_t* d_desc, int cap, int* d_n, hipStream_t st, int lanes) {
     const Geom& g = h->geom;
     ImgSrc s;
     s.img0 = d_img; s.pitch0 = pitch0; s.fs0 = fs0; s.pyr = h->d_pyr.p;
@@ -991,40 +1004,80 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
     const bool prof = h->profiling;
     hipEvent_t* ev = nullptr;
     if (prof) {
-        if (h->evUsed + 8 > h->evs.size()) {
+        if (h->evUsed + 9 > h->evs.size()) {
             const size_t old = h->evs.size();
-            h->evs.resize(old + 8 * 16, nullptr);
+            h->evs.resize(old + 9 * 16, nullptr);
             for (size_t i = old; i < h->evs.size(); i++) EAO_HIP(hipEventCreate(&h->evs[i]));
         }
         ev = &h->evs[h->evUsed];
-        h->evUsed += 8;
+        h->evUsed += 9;
         EAO_HIP(hipEventRecord(ev[0], st));
     }
-    for (int l = 1; l < g.nlevels; l++) {
-        dim3 grid(eao::cdiv(g.L[l].w, 256), eao::cdiv(g.L[l].h, 4), batch), block(64, 4);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, st, h->d_geom.p, h->d_tab.p, s, l);
+    // split the batch into up to kLanes contiguous slices; slice i runs pyramid -> {FAST -> quad-tree | blur} ->
+    // orientation + description on its own stream pair.  Profiling events bracket the stages of slice 0.
+    lanes = std::max(1, std::min(std::min(eao_orb::kLanes, batch), lanes));
+    EAO_HIP(hipEventRecord(h->evStart, st));
+    for (int i = 0; i < lanes; i++) {
+        const int f0 = (int)((long long)batch * i / lanes), f1 = (int)((long long)batch * (i + 1) / lanes), nb = f1 - f0;
+        hipStream_t ms = h->laneMain[i], ss = h->laneSide[i];
+        const bool pe = prof && i == 0;
+        EAO_HIP(hipStreamWaitEvent(ms, h->evStart, 0));
+        for (int l = 1; l < g.nlevels; l++) {
+            dim3 grid(eao::cdiv(g.L[l].w, 256), eao::cdiv(g.L[l].h, 4), nb), block(64, 4);
+            hipLaunchKernelGGL(k_resize, grid, block, 0, ms, h->d_geom.p, h->d_tab.p, s, l, f0);
+        }
+        if (pe) EAO_HIP(hipEventRecord(ev[1], ms));
+        EAO_HIP(hipEventRecord(h->evFork[i], ms));
+        EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
+        if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
+        hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0);
+        if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
+        EAO_HIP(hipEventRecord(h->evJoin[i], ss));
+        hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nb), dim3(64), g.fastLdsBytes, ms, h->d_geom.p, h->d_cells.p, s,
+                           h->d_cellcand.p, h->d_cellcnt.p, f0);
+        if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
+        hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nb), dim3(256), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
+                           h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0);
+        if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
+        EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
+        if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
+        hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
+                           h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0);
+        if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
+        EAO_HIP(hipEventRecord(h->evDone[i], ms));
+        EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
     }
-    if (prof) EAO_HIP(hipEventRecord(ev[1], st));
-    // fork: the 7x7 blur only needs the pyramid, so it runs on the side stream while FAST and the quad-tree (both
-    // latency-bound, far from filling the chip) run on the main one; join before orientation + description
-    EAO_HIP(hipEventRecord(h->evFork, st));
-    EAO_HIP(hipStreamWaitEvent(h->side, h->evFork, 0));
-    if (prof) EAO_HIP(hipEventRecord(ev[6], h->side));
-    hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, batch), dim3(256), 0, h->side, h->d_geom.p, s, h->d_blur.p);
-    if (prof) EAO_HIP(hipEventRecord(ev[7], h->side));
-    EAO_HIP(hipEventRecord(h->evJoin, h->side));
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, batch), dim3(64), g.fastLdsBytes, st, h->d_geom.p, h->d_cells.p, s,
-                       h->d_cellcand.p, h->d_cellcnt.p);
-    if (prof) EAO_HIP(hipEventRecord(ev[2], st));
-    hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, batch), dim3(256), h->quadLds, st, h->d_geom.p, h->d_cellcand.p,
-                       h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p);
-    if (prof) EAO_HIP(hipEventRecord(ev[3], st));
-    EAO_HIP(hipStreamWaitEvent(st, h->evJoin, 0));
-    if (prof) EAO_HIP(hipEventRecord(ev[4], st));
-    hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), batch), dim3(256), 0, st, h->d_geom.p, s,
-                       h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap);
-    if (prof) EAO_HIP(hipEventRecord(ev[5], st));
+    if (prof) EAO_HIP(hipEventRecord(ev[8], st));
     EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
+
+
+// Optional (EAO_ORB_GRAPH=1): capture the launch sequence of one batch into a hipGraph per argument set and replay it.
+// Measured on MI355X (tools/dbg_lanes.py): replay 0.736 ms vs direct launches 0.742 ms per 64-frame batch, and cutting
+// the batch into 2 / 4 concurrent lanes (EAO_ORB_LANES) is SLOWER (0.75 / 0.94 ms): the kernels are throughput-bound,
+// not latency-bound, so the defaults are one lane and direct launches.  (Graph replay also crashes inside the HIP 7.0
+// runtime bundled with PyTorch 2.10; it works with the ROCm 7.2 runtime.)  Profiled calls always bypass the graph.
+eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, int batch, eao_keypoint* d_kps,
+                   uint8_t* d_desc, int cap, int* d_n, hipStream_t st) {
+    static const int envLanes = getenv("EAO_ORB_LANES") ? atoi(getenv("EAO_ORB_LANES")) : 1;
+    static const bool envGraph = getenv("EAO_ORB_GRAPH") && atoi(getenv("EAO_ORB_GRAPH")) != 0;
+    if (h->profiling || !envGraph) return enqueue_direct(h, d_img, pitch0, fs0, batch, d_kps, d_desc, cap, d_n, st, envLanes);
+    const GraphKey key = {d_img, pitch0, fs0, batch, d_kps, d_desc, cap, d_n, envLanes};
+    if (!h->graphExec || !(h->graphKey == key)) {
+        if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
+        hipGraph_t graph = nullptr;
+        EAO_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        const eao_status st2 = enqueue_direct(h, d_img, pitch0, fs0, batch, d_kps, d_desc, cap, d_n, h->stream, envLanes);
+        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (st2) { if (graph) (void)hipGraphDestroy(graph); return st2; }
+        if (e != hipSuccess) { eao::set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return EAO_ERR_NO_DEVICE; }
+        EAO_HIP(hipGraphInstantiate(&h->graphExec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        h->graphKey = key;
+    }
+    h->lastBatch = batch;
+    EAO_HIP(hipGraphLaunch(h->graphExec, st));
     return EAO_OK;
 }
 
@@ -1083,9 +1136,15 @@ void eao_orb_destroy(eao_orb* h) {
     if (!h) return;
     for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
-    if (h->evFork) (void)hipEventDestroy(h->evFork);
-    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    for (int i = 0; i < eao_orb::kLanes; i++) {
+        if (h->laneMain[i]) { (void)hipStreamSynchronize(h->laneMain[i]); (void)hipStreamDestroy(h->laneMain[i]); }
+        if (h->laneSide[i]) { (void)hipStreamSynchronize(h->laneSide[i]); (void)hipStreamDestroy(h->laneSide[i]); }
+        if (h->evFork[i]) (void)hipEventDestroy(h->evFork[i]);
+        if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
+        if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
+    }
+    if (h->evStart) (void)hipEventDestroy(h->evStart);
+    if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
     delete h;
 }
 
@@ -1177,7 +1236,7 @@ eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which
         src = (which ? h->d_blur.p : h->d_pyr.p) + (long long)frame * h->geom.pyrFrameBytes + L.off;
         pitch = L.pitch;
     }
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(hipDeviceSynchronize());   // the last extraction may have run on a caller-provided stream
     EAO_HIP(hipMemcpy2D(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
     return EAO_OK;
 }
@@ -1186,7 +1245,7 @@ eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, fl
     EAO_REQUIRE(h && n && h->geomValid && h->lastBatch > 0, "no extraction has run on this handle");
     EAO_REQUIRE(frame >= 0 && frame < h->lastBatch && level >= 0 && level < h->geom.nlevels, "frame/level out of range");
     const Geom& g = h->geom;
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(hipDeviceSynchronize());
     int cnt = 0;
     EAO_HIP(hipMemcpy(&cnt, h->d_candcnt.p + frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
     *n = cnt;
@@ -1201,6 +1260,8 @@ eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, fl
     return EAO_OK;
 }
 
+int32_t eao_orb_lanes(int32_t batch) { return batch < eao_orb::kLanes ? (batch > 0 ? batch : 1) : eao_orb::kLanes; }
+
 eao_status eao_orb_set_profiling(eao_orb* h, int32_t on) {
     EAO_REQUIRE(h, "null handle");
     h->profiling = on != 0;
@@ -1209,19 +1270,20 @@ eao_status eao_orb_set_profiling(eao_orb* h, int32_t on) {
 }
 
 eao_status eao_orb_last_timing(eao_orb* h, float ms[6]) {
-    EAO_REQUIRE(h && ms && h->evUsed >= 8, "no profiled call since eao_orb_set_profiling(h, 1)");
-    const size_t calls = h->evUsed / 8;
-    EAO_HIP(hipEventSynchronize(h->evs[h->evUsed - 3]));   // ev[5] of the last call
+    EAO_REQUIRE(h && ms && h->evUsed >= 9, "no profiled call since eao_orb_set_profiling(h, 1)");
+    const size_t calls = h->evUsed / 9;
+    EAO_HIP(hipEventSynchronize(h->evs[h->evUsed - 1]));   // ev[8] of the last call
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (size_t c = 0; c < calls; c++) {
-        hipEvent_t* ev = &h->evs[c * 8];
+        hipEvent_t* ev = &h->evs[c * 9];
         float t;
+        // stage intervals of slice 0 (one of the concurrently running sub-batches)
         EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[1])); acc[0] += t;   // pyramid
-        EAO_HIP(hipEventElapsedTime(&t, ev[1], ev[2])); acc[1] += t;   // FAST (the blur overlaps it on the side stream)
+        EAO_HIP(hipEventElapsedTime(&t, ev[1], ev[2])); acc[1] += t;   // FAST
         EAO_HIP(hipEventElapsedTime(&t, ev[2], ev[3])); acc[2] += t;   // quad-tree
         EAO_HIP(hipEventElapsedTime(&t, ev[6], ev[7])); acc[3] += t;   // blur, side stream
         EAO_HIP(hipEventElapsedTime(&t, ev[4], ev[5])); acc[4] += t;   // orientation + description
-        EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[5])); acc[5] += t;
+        EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[8])); acc[5] += t;   // whole batch
     }
     for (int i = 0; i < 6; i++) ms[i] = (float)(acc[i] / calls);
     h->evUsed = 0;

@@ -106,9 +106,11 @@ eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, fl
  * [0] pyramid  [1] fast  [2] quadtree  [3] blur  [4] orient+describe  [5] whole pipeline,
  * AVERAGED over every extract call made since eao_orb_set_profiling(h, 1) (events are recorded on the stream the
  * kernels run on); reading blocks until the events have completed and restarts the average.  The blur runs on a side
- * stream concurrently with FAST + quad-tree, so the stage times may add up to more than [5]. */
+ * stream concurrently with FAST + quad-tree, so the stage times may add up to more than [5].
+ * eao_orb_lanes() returns the maximum number of concurrent slices a batch can be cut into (EAO_ORB_LANES, default 1). */
 eao_status eao_orb_set_profiling(eao_orb* h, int32_t on);
 eao_status eao_orb_last_timing(eao_orb* h, float ms[6]);
+int32_t eao_orb_lanes(int32_t batch);
 
 /* ------------------------------------------------------------------------------------------------
  * Hamming matching -- replaces ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1649-1665) and
