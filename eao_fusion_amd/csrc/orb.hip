@@ -317,11 +317,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
 }
 
 // ---------------------------------------------------------------------------------------------- quad-tree
-// In-place exclusive scan of a[0..n) by the whole 256-thread block; returns the total.  Caller guarantees a[]
+constexpr int kQT = 256;   // threads per quad-tree workgroup (the candidate passes scale with it; 2 workgroups fit a CU)
+// In-place exclusive scan of a[0..n) by the whole kQT-thread block; returns the total.  Caller guarantees a[]
 // is fully written and visible (barrier) before the call; the function ends with a barrier.
 __device__ int block_excl_scan(int* a, int n, int* wtmp) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int per = (n + 255) / 256;
+    const int per = (n + kQT - 1) / kQT;
     const int b = min(t * per, n), e = min(b + per, n);
     int ssum = 0;
     for (int i = b; i < e; i++) ssum += a[i];
@@ -334,9 +335,13 @@ __device__ int block_excl_scan(int* a, int n, int* wtmp) {
     __syncthreads();  // protect wtmp from the previous call's readers
     if (lane == 63) wtmp[wv] = v;
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wv; w++) woff += wtmp[w];
-    const int total = wtmp[0] + wtmp[1] + wtmp[2] + wtmp[3];
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kQT / 64; w++) {
+        const int x = wtmp[w];
+        if (w < wv) woff += x;
+        total += x;
+    }
     int run = woff + v - ssum;
     for (int i = b; i < e; i++) {
         const int x = a[i];
@@ -358,12 +363,12 @@ __device__ __forceinline__ int quadrant(unsigned key, short4 bx) {
 // position of candidate k's node.  Every pass (a) histograms children of all multi-key nodes, (b) picks the set
 // of nodes that upstream would split in this pass and their processing order, (c) lays out the new list exactly
 // as upstream's push_front/erase sequence would leave it.
-__global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
+__global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
                                                   const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
                                                   unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
                                                   int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int wtmp[4];
+    __shared__ int wtmp[kQT / 64];
     __shared__ int sh_S, sh_phase, sh_done, sh_rstar, sh_nexp;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int l = blockIdx.x, f = blockIdx.y + f0;
@@ -390,10 +395,10 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
 
     // ---- gather this level's candidates in upstream order: cells row-major, corners row-major inside a cell
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
-    for (int i = t; i < L.nCells; i += 256) scanA[i] = cellcnt[cslot + i];
+    for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
     __syncthreads();
     const int M = block_excl_scan(scanA, L.nCells, wtmp);
-    for (int c = wv; c < L.nCells; c += 4) {
+    for (int c = wv; c < L.nCells; c += kQT / 64) {
         const int n = cellcnt[cslot + c], o = scanA[c];
         const unsigned* srcc = cellcand + (cslot + c) * g->cellCap;
         for (int j = lane; j < n; j += 64) keys[o + j] = srcc[j];
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
         crk0[t] = t;
     }
     __syncthreads();
-    for (int k = t; k < M; k += 256) {
+    for (int k = t; k < M; k += kQT) {
         const int ini = min((int)((float)(keys[k] & 0xFFF) / L.hX), nIni - 1);
         atomicAdd(&cnt0[ini], 1);
         nof[k] = (unsigned short)ini;
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
     }
     __syncthreads();
     if (nIni > 1) {
-        for (int k = t; k < M; k += 256) nof[k] = (unsigned short)newpos[nof[k]];
+        for (int k = t; k < M; k += kQT) nof[k] = (unsigned short)newpos[nof[k]];
         __syncthreads();
     }
 
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
     for (int iter = 0; iter < 64 && !sh_done; iter++) {
         const int S = sh_S, phase = sh_phase;
         // (1) multi-key entries in list order
-        for (int i = t; i < S; i += 256) {
+        for (int i = t; i < S; i += kQT) {
             scanA[i] = cnt[i] > 1 ? 1 : 0;
             procRank[i] = -1;
             childcnt[4 * i] = 0; childcnt[4 * i + 1] = 0; childcnt[4 * i + 2] = 0; childcnt[4 * i + 3] = 0;
@@ -446,19 +451,19 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
         if (t == 0) { sh_rstar = 0x7FFFFFFF; sh_nexp = 0; }
         __syncthreads();
         const int nCand = block_excl_scan(scanA, S, wtmp);
-        for (int i = t; i < S; i += 256)
+        for (int i = t; i < S; i += kQT)
             if (cnt[i] > 1) vlist[scanA[i]] = i;
         // (2) child histograms of every candidate
-        for (int k = t; k < M; k += 256) {
+        for (int k = t; k < M; k += kQT) {
             const int nd = nof[k];
             if (cnt[nd] > 1) atomicAdd(&childcnt[4 * nd + quadrant(keys[k], box[nd])], 1);
         }
         __syncthreads();
         // (3) processing order: list order (full pass) or (size, creation rank) descending (careful pass)
         if (phase == 0) {
-            for (int j = t; j < nCand; j += 256) order[j] = vlist[j];
+            for (int j = t; j < nCand; j += kQT) order[j] = vlist[j];
         } else {
-            for (int j = t; j < nCand; j += 256) {
+            for (int j = t; j < nCand; j += kQT) {
                 const int me = vlist[j], ms = cnt[me], mr = crk[me];
                 int r = 0;
                 for (int u = 0; u < nCand; u++) {
@@ -470,14 +475,14 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
         }
         __syncthreads();
         // (4) growth prefix in processing order; the careful pass stops at the first prefix reaching N
-        for (int r = t; r < nCand; r += 256) {
+        for (int r = t; r < nCand; r += kQT) {
             const int i = order[r];
             scanA[r] = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
         }
         __syncthreads();
         block_excl_scan(scanA, nCand, wtmp);
         if (phase == 1) {
-            for (int r = t; r < nCand; r += 256) {
+            for (int r = t; r < nCand; r += kQT) {
                 const int i = order[r];
                 const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
                 if (S + scanA[r] + ne - (r + 1) >= N) atomicMin(&sh_rstar, r);
@@ -490,14 +495,14 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
             const int i = order[nProc - 1];
             totalChildren = scanA[nProc - 1] + (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
         }
-        for (int r = t; r < nProc; r += 256) procRank[order[r]] = r;
+        for (int r = t; r < nProc; r += kQT) procRank[order[r]] = r;
         __syncthreads();
-        for (int i = t; i < S; i += 256) scanB[i] = procRank[i] < 0 ? 1 : 0;
+        for (int i = t; i < S; i += kQT) scanB[i] = procRank[i] < 0 ? 1 : 0;
         __syncthreads();
         block_excl_scan(scanB, S, wtmp);
         // (5) new list: children of the LAST processed node first (each as n4,n3,n2,n1), untouched entries after
         int myexp = 0;
-        for (int i = t; i < S; i += 256) {
+        for (int i = t; i < S; i += kQT) {
             const int r = procRank[i];
             if (r < 0) {
                 const int p = totalChildren + scanB[i];
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
         if (myexp) atomicAdd(&sh_nexp, myexp);
         __syncthreads();
         // (6) re-home the candidates
-        for (int k = t; k < M; k += 256) {
+        for (int k = t; k < M; k += kQT) {
             const int nd = nof[k];
             nof[k] = (unsigned short)(procRank[nd] >= 0 ? childpos[4 * nd + quadrant(keys[k], box[nd])] : newpos[nd]);
         }
@@ -544,12 +549,12 @@ __global__ __launch_bounds__(256) void k_quadtree(const Geom* __restrict__ g, co
     // ---- best response per node, first candidate wins ties (strict '>' at src/ORBextractor.cc:752)
     const int S = sh_S;
     unsigned* best = reinterpret_cast<unsigned*>(scanB);
-    for (int i = t; i < S; i += 256) best[i] = 0;
+    for (int i = t; i < S; i += kQT) best[i] = 0;
     __syncthreads();
-    for (int k = t; k < M; k += 256) atomicMax(&best[nof[k]], ((keys[k] >> 24) << 20) | (0xFFFFFu - (unsigned)k));
+    for (int k = t; k < M; k += kQT) atomicMax(&best[nof[k]], ((keys[k] >> 24) << 20) | (0xFFFFFu - (unsigned)k));
     __syncthreads();
     unsigned* out = levelkps + (long long)f * g->totalKpCap + L.kpBase;
-    for (int i = t; i < S; i += 256) {
+    for (int i = t; i < S; i += kQT) {
         const unsigned k = 0xFFFFFu - (best[i] & 0xFFFFFu);
         out[i] = keys[k];
     }
@@ -1036,7 +1041,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nb), dim3(64), g.fastLdsBytes, ms, h->d_geom.p, h->d_cells.p, s,
                            h->d_cellcand.p, h->d_cellcnt.p, f0);
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
-        hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nb), dim3(256), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
+        hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nb), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
                            h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0);
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
