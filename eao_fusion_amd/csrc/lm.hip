@@ -464,11 +464,10 @@ struct BADev {
     const int* camStart;    // nFree+1 CSR by free camera block
     const int* camEdges;
     const int* table;       // nL * nFree: active edge id of (point, free camera) or -1
-    // state
-    SE3* cams;              // current
-    double* pts;
-    SE3* camsT;             // trial
-    double* ptsT;
+    // state: two buffers; ctl[1] says which one holds the current estimate, the other receives the trial
+    SE3* camsBuf[2];
+    double* ptsBuf[2];
+    int* ctl;               // [0] halt  [1] current buffer  [2] iterations done  [3] status  [4] nBad
     double* err;            // E*3, last computed
     // system
     double* Hpp;            // nFree*36
@@ -487,10 +486,21 @@ struct BADev {
     int chunks;
 };
 
+enum { kCtlHalt = 0, kCtlCur = 1, kCtlIters = 2, kCtlStatus = 3, kCtlNBad = 4 };
+enum { kStRunning = 0, kStTakeover = 1, kStTerminate = 2 };
+
 struct BAStatus {            // pinned host memory, written by k_ba_decide / k_ba_chi_init
     double lambda, rho, chi, tempChi;
-    int accepted, solveOk, seq, pad;
+    int accepted, solveOk, seq, cur;
+    int iters, status, nBad, ntrace;
+    double trLambda[32], trChi[32];
+    int trTrials[32];
 };
+
+__device__ __forceinline__ const SE3* cur_cams(const BADev& P) { return P.camsBuf[P.ctl[kCtlCur]]; }
+__device__ __forceinline__ const double* cur_pts(const BADev& P) { return P.ptsBuf[P.ctl[kCtlCur]]; }
+__device__ __forceinline__ SE3* trial_cams(const BADev& P) { return P.camsBuf[P.ctl[kCtlCur] ^ 1]; }
+__device__ __forceinline__ double* trial_pts(const BADev& P) { return P.ptsBuf[P.ctl[kCtlCur] ^ 1]; }
 
 __device__ inline void ba_project(const Cam& c, bool stereo, const double p[3], double r[3]) {
     if (!stereo) {
@@ -541,15 +551,17 @@ __device__ inline void ba_jacobians(const Cam& c, bool stereo, const SE3& T, con
 // residuals + robust chi2 of every active edge at the CURRENT state (start of an optimize() call)
 __global__ __launch_bounds__(256) void k_ba_errors(BADev P) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= P.nL) return;
+    if (l >= P.nL || P.ctl[kCtlHalt]) return;
     const int pt = P.actPt[l];
+    const SE3* cams = cur_cams(P);
+    const double* pts = cur_pts(P);
     double chi = 0;
     for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
         const int e = P.ptEdges[k];
         const unsigned char fl = P.eflag[e];
         const bool stereo = fl & 1;
         double p[3], r[3];
-        se3_map(P.cams[P.ecam[e]], &P.pts[3 * pt], p);
+        se3_map(cams[P.ecam[e]], &pts[3 * pt], p);
         ba_project(P.cam, stereo, p, r);
         double* er = &P.err[3 * e];
         er[0] = P.obs[3 * e] - r[0]; er[1] = P.obs[3 * e + 1] - r[1]; er[2] = stereo ? P.obs[3 * e + 2] - r[2] : 0;
@@ -573,10 +585,12 @@ __device__ inline double ordered_sum(const double* part, int n, double* red, dou
 
 __global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int seq) {
     __shared__ double red[4], out1;
+    if (P.ctl[kCtlHalt]) return;
     const double chi = ordered_sum(P.partChi, P.nL, red, &out1);
     if (threadIdx.x == 0) {
         P.lm[2] = chi;
         st->chi = chi; st->tempChi = chi; st->accepted = 1; st->solveOk = 1; st->rho = 0; st->lambda = P.lm[0];
+        st->cur = P.ctl[kCtlCur];
         __threadfence_system();
         st->seq = seq;
     }
@@ -585,6 +599,9 @@ __global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int 
 // role A: blocks [0, ptBlocks): one thread per landmark.  role B: blocks [ptBlocks, ptBlocks + nFree): one block per free camera.
 __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
     __shared__ double red[4 * 27], sums[27];
+    if (P.ctl[kCtlHalt]) return;
+    const SE3* cams = cur_cams(P);
+    const double* pts = cur_pts(P);
     if ((int)blockIdx.x < ptBlocks) {
         const int l = blockIdx.x * 256 + threadIdx.x;
         if (l >= P.nL) return;
@@ -596,7 +613,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
             const bool stereo = fl & 1;
             constexpr int D = 3;   // monocular edges carry a zero third row / residual: static loops, no scratch
             double A[3][3], B[3][6];
-            ba_jacobians(P.cam, stereo, P.cams[P.ecam[e]], &P.pts[3 * pt], A, B);
+            ba_jacobians(P.cam, stereo, cams[P.ecam[e]], &pts[3 * pt], A, B);
             const double* er = &P.err[3 * e];
             const double info = P.info[e];
             double w = 1.0, r0;
@@ -621,7 +638,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
     } else {
         const int ci = blockIdx.x - ptBlocks;
         const int cam = P.actCam[ci];
-        const SE3 T = P.cams[cam];
+        const SE3 T = cams[cam];
         double acc[27];
 #pragma unroll
         for (int k = 0; k < 27; k++) acc[k] = 0;
@@ -634,7 +651,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
             const bool stereo = fl & 1;
             constexpr int D = 3;
             double A[3][3], B[3][6];
-            ba_jacobians(P.cam, stereo, T, &P.pts[3 * P.ept[e]], A, B);
+            ba_jacobians(P.cam, stereo, T, &pts[3 * P.ept[e]], A, B);
             const double* er = &P.err[3 * e];
             const double info = P.info[e];
             double w = 1.0, r0;
@@ -665,6 +682,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
 // lambda_0 = 1e-5 * max |diag| over every active vertex (optimization_algorithm_levenberg.cpp:166-180)
 __global__ __launch_bounds__(256) void k_ba_lambda_init(BADev P) {
     __shared__ double red[4];
+    if (P.ctl[kCtlHalt]) return;
     double m = 0;
     for (int i = threadIdx.x; i < P.nFree * 6; i += 256) m = fmax(m, fabs(P.Hpp[(size_t)(i / 6) * 36 + (i % 6) * 7]));
     for (int i = threadIdx.x; i < P.nL * 3; i += 256) m = fmax(m, fabs(P.Hll[(size_t)(i / 3) * 9 + (i % 3) * 4]));
@@ -703,6 +721,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BADev P) {
     __shared__ double sDb[kSchurMaxEdges * 3];
     __shared__ int sTab[kSchurMaxEdges * kSchurMaxFree];
     __shared__ int sE[kSchurMaxEdges];
+    if (P.ctl[kCtlHalt]) return;
     const int i1 = blockIdx.x, chunk = blockIdx.y;
     const int nF = P.nFree, rowLen = nF * 36 + 6;
     const int beg = P.camStart[i1], end = P.camStart[i1 + 1];
@@ -790,6 +809,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveO
     double* xv = M + (size_t)6 * ld;            // n   (LDS in both variants)
     double* rd = xv + n;                        // n reciprocal pivots
     __shared__ int s_fail;
+    if (P.ctl[kCtlHalt]) return;
     const double lambda = P.lm[0];
     if (t == 0) s_fail = 0;
     if (P.dbg && t == 0) { P.dbg[0] = clock64(); P.dbg[1] = wall_clock64(); }
@@ -922,14 +942,16 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveO
     if (P.dbg && t == 0) { P.dbg[6] = clock64(); P.dbg[7] = wall_clock64(); }
     for (int i = t; i < n; i += kSolveThreads) P.xp[i] = xv[i];
     // trial cameras: exp(dx) * T for the free ones, copy for the others
+    const SE3* cams = cur_cams(P);
+    SE3* camsT = trial_cams(P);
     for (int c = t; c < P.nCams; c += kSolveThreads) {
         const int ci = P.camIdx[c];
         if (ci >= 0) {
             double u[6];
             for (int q = 0; q < 6; q++) u[q] = xv[ci * 6 + q];
-            P.camsT[c] = se3_mul(se3_exp(u), P.cams[c]);
+            camsT[c] = se3_mul(se3_exp(u), cams[c]);
         } else {
-            P.camsT[c] = P.cams[c];
+            camsT[c] = cams[c];
         }
     }
     if (t == 0) *solveOk = s_fail ? 0 : 1;
@@ -939,8 +961,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveO
 // per landmark: x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 at the trial state; scale partial
 __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
     const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= P.nL) return;
+    if (l >= P.nL || P.ctl[kCtlHalt]) return;
     const int pt = P.actPt[l];
+    const double* pts = cur_pts(P);
+    double* ptsT = trial_pts(P);
+    const SE3* camsT = trial_cams(P);
     const double lambda = P.lm[0];
     const double* bl = &P.bl[(size_t)l * 3];
     double cl[3] = {bl[0], bl[1], bl[2]};
@@ -962,8 +987,8 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
     for (int i = 0; i < 3; i++) {
         xl[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
         P.xl[(size_t)l * 3 + i] = xl[i];
-        np[i] = P.pts[3 * pt + i] + xl[i];
-        P.ptsT[3 * pt + i] = np[i];
+        np[i] = pts[3 * pt + i] + xl[i];
+        ptsT[3 * pt + i] = np[i];
     }
     double chi = 0;
     for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
@@ -971,7 +996,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
         const unsigned char fl = P.eflag[e];
         const bool stereo = fl & 1;
         double p[3], r[3];
-        se3_map(P.camsT[P.ecam[e]], np, p);
+        se3_map(camsT[P.ecam[e]], np, p);
         ba_project(P.cam, stereo, p, r);
         double* er = &P.err[3 * e];
         er[0] = P.obs[3 * e] - r[0]; er[1] = P.obs[3 * e + 1] - r[1]; er[2] = stereo ? P.obs[3 * e + 2] - r[2] : 0;
@@ -984,12 +1009,17 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
     P.partScale[l] = xl[0] * (lambda * xl[0] + bl[0]) + xl[1] * (lambda * xl[1] + bl[1]) + xl[2] * (lambda * xl[2] + bl[2]);
 }
 
-// rho, accept / reject, lambda & nu update (optimization_algorithm_levenberg.cpp:118-147); one 256-thread block
-__global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, BAStatus* st, int seq) {
+// rho, accept / reject, lambda & nu update (optimization_algorithm_levenberg.cpp:118-147); one 256-thread block.
+// bulk = 1: the host has enqueued every remaining iteration of this optimize() call back to back (one trial each).  A
+// clean iteration -- first trial accepted -- is finished right here (trace entry, iteration count, the "3 bad
+// iterations" stop); anything else (rejected trial, rho == 0 or NaN) raises the halt flag so that the kernels still in
+// the stream do nothing, and the host takes that iteration over trial by trial.
+__global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, BAStatus* st, int seq, int bulk) {
     __shared__ double red[4], out1;
+    __shared__ double s_xp[kSchurMaxFree * 6], s_bp[kSchurMaxFree * 6];
+    if (P.ctl[kCtlHalt]) return;
     const double tempSum = ordered_sum(P.partChi, P.nL, red, &out1);
     const double scaleL = ordered_sum(P.partScale, P.nL, red, &out1);
-    __shared__ double s_xp[kSchurMaxFree * 6], s_bp[kSchurMaxFree * 6];
     for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { s_xp[i] = P.xp[i]; s_bp[i] = P.bp[i]; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1012,11 +1042,29 @@ __global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, 
             P.lm[1] = 2;
             P.lm[2] = tempChi;
             accepted = 1;
+            P.ctl[kCtlCur] ^= 1;            // discardTop(): the trial buffer becomes the estimate
         } else {
             P.lm[0] = lambda * P.lm[1];
             P.lm[1] *= 2;
         }
+        int status = kStRunning;
+        if (bulk) {
+            if (accepted) {
+                const int k = P.ctl[kCtlIters];
+                if (k < 32) { st->trLambda[k] = P.lm[0]; st->trChi[k] = tempChi; st->trTrials[k] = 1; }
+                P.ctl[kCtlIters] = k + 1;
+                int nb = P.ctl[kCtlNBad];
+                if ((currentChi - tempChi) * 1e3 < currentChi) nb++; else nb = 0;
+                P.ctl[kCtlNBad] = nb;
+                if (nb >= 3) { status = kStTerminate; P.ctl[kCtlHalt] = 1; }
+            } else {
+                status = kStTakeover;
+                P.ctl[kCtlHalt] = 1;
+            }
+            P.ctl[kCtlStatus] = status;
+        }
         st->lambda = P.lm[0]; st->rho = rho; st->chi = P.lm[2]; st->tempChi = tempChi; st->accepted = accepted; st->solveOk = ok2;
+        st->cur = P.ctl[kCtlCur]; st->iters = P.ctl[kCtlIters]; st->status = status; st->nBad = P.ctl[kCtlNBad];
         __threadfence_system();
         st->seq = seq;
     }
@@ -1029,7 +1077,7 @@ __global__ void k_ba_classify(BADev P, unsigned char* out, int nEdges, const uns
     const bool stereo = eflagAll[e] & 1;
     const double c2 = ba_chi2(&P.err[3 * e], P.info[e], stereo);
     double p[3];
-    se3_map(P.cams[P.ecam[e]], &P.pts[3 * P.ept[e]], p);
+    se3_map(cur_cams(P)[P.ecam[e]], &cur_pts(P)[3 * P.ept[e]], p);
     out[e] = (c2 > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) ? 1 : 0;
 }
 
@@ -1227,6 +1275,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
     D.lm = a.take<double>(8);
     int* dsolveOk = a.take<int>(4);
+    int* dctl = a.take<int>(8);
     long long* ddbg = a.take<long long>(16);
     D.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
     EAO_REQUIRE(a.off <= a.cap, "internal: arena overflow");
@@ -1242,7 +1291,8 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     EAO_HIP(hipMemcpyAsync(dcams, hcams.data(), nC * sizeof(SE3), hipMemcpyHostToDevice, s));
     EAO_HIP(hipMemcpyAsync(dpts, hpts.data(), hpts.size() * 8, hipMemcpyHostToDevice, s));
     EAO_HIP(hipMemsetAsync(D.err, 0, (size_t)E * 24, s));
-    D.cams = dcams; D.pts = dpts; D.camsT = dcamsT; D.ptsT = dptsT;
+    D.camsBuf[0] = dcams; D.camsBuf[1] = dcamsT; D.ptsBuf[0] = dpts; D.ptsBuf[1] = dptsT;
+    D.ctl = dctl;
 
     std::vector<int> camIdx(nC), ptIdx(nP), actCam, actPt, ptStart, ptEdges, camStart, camEdges, table;
     int seq = c.status->seq;
@@ -1292,6 +1342,15 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         return EAO_OK;
     };
     // ---- SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve per iteration
+    int curHost = 0;     // host mirror of ctl[kCtlCur]
+    auto set_ctl = [&](int halt, int iters, int nBad) -> eao_status {
+        const int v[5] = {halt, curHost, iters, kStRunning, nBad};
+        EAO_HIP(hipMemcpyAsync(D.ctl, v, sizeof(v), hipMemcpyHostToDevice, s));
+        return EAO_OK;
+    };
+    // ---- SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve per iteration.
+    // Iterations are enqueued in bulk (one trial each, no host round trip); the device finishes clean iterations itself
+    // and halts the stream on anything else, which the host then replays trial by trial like g2o's do/while.
     auto optimize = [&](int iterations, int* itersDone, double* chiOut) -> eao_status {
         *itersDone = 0;
         const int nF = D.nFree, nL = D.nL;
@@ -1306,50 +1365,64 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         }
         const bool solveInLds = D.solveScratch == nullptr;
         if (solveInLds) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+        auto enqueue_trial = [&](int bulk) {
+            if (nF) hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(256), 0, s, D);
+            if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
+            else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
+            if (nL) hipLaunchKernelGGL(k_ba_backsub, dim3(ptBlocks), dim3(256), 0, s, D);
+            hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq, bulk);
+        };
         bool needErrors = true, ok = true;
         double currentChi = 0;
-        int nBad = 0;
-        for (int it = 0; it < iterations && !(stop && *stop) && ok; it++) {
+        int nBad = 0, done = 0;
+        while (done < iterations && !(stop && *stop) && ok) {
+            // ---- bulk segment: every remaining iteration, one trial each
+            if ((st = set_ctl(0, done, nBad))) return st;
             if (needErrors) {   // computeActiveErrors + activeRobustChi2 (otherwise the accepted trial already left them)
                 if (nL) hipLaunchKernelGGL(k_ba_errors, dim3(ptBlocks), dim3(256), 0, s, D);
                 hipLaunchKernelGGL(k_ba_chi_init, dim3(1), dim3(256), 0, s, D, c.status, ++seq);
-                if ((st = wait_status(seq))) return st;
-                currentChi = c.status->chi;
                 needErrors = false;
             }
-            const double iniChi = currentChi;
-            hipLaunchKernelGGL(k_ba_linearize, dim3(ptBlocks + nF), dim3(256), 0, s, D, ptBlocks);
+            for (int it = done; it < iterations; it++) {
+                hipLaunchKernelGGL(k_ba_linearize, dim3(ptBlocks + nF), dim3(256), 0, s, D, ptBlocks);
+                if (it == 0) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);
+                enqueue_trial(1);
+            }
+            EAO_HIP(hipStreamSynchronize(s));
+            const BAStatus& S = *c.status;
+            for (int k = done; k < S.iters && k < 32; k++) {
+                g_trace.lambda.push_back(S.trLambda[k]); g_trace.chi2.push_back(S.trChi[k]); g_trace.trials.push_back(S.trTrials[k]);
+            }
+            g_trace.linearizations += S.iters - done;
+            done = S.iters; nBad = S.nBad; curHost = S.cur; currentChi = S.chi;
+            if (S.status == kStTerminate) { ok = false; break; }
+            if (S.status != kStTakeover) break;           // all requested iterations done
+            // ---- host takeover of iteration `done`: its first trial was rejected (or rho == 0 / NaN)
             g_trace.linearizations++;
-            if (it == 0) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);
-            int qmax = 0;
-            double rho = 0;
-            do {
-                if (nF) hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(256), 0, s, D);
-                if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
-                else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
-                if (nL) hipLaunchKernelGGL(k_ba_backsub, dim3(ptBlocks), dim3(256), 0, s, D);
-                hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq);
+            const double iniChi = S.chi;
+            double rho = S.rho;
+            int qmax = 1;
+            bool accepted = S.accepted != 0;
+            while (rho < 0 && qmax < 10 && !(stop && *stop)) {
+                if ((st = set_ctl(0, done, nBad))) return st;
+                enqueue_trial(0);
                 if ((st = wait_status(seq))) return st;
-                rho = c.status->rho;
-                if (c.status->accepted) {   // discardTop(): the trial state becomes the estimate
-                    std::swap(D.cams, D.camsT);
-                    std::swap(D.pts, D.ptsT);
-                    currentChi = c.status->chi;
-                } else {
-                    needErrors = true;      // pop(): residuals now belong to the rejected state
-                }
+                rho = c.status->rho; accepted = c.status->accepted != 0; curHost = c.status->cur;
+                if (accepted) currentChi = c.status->chi;
                 qmax++;
-            } while (rho < 0 && qmax < 10 && !(stop && *stop));
-            if (c.status->accepted) needErrors = false;
+            }
+            needErrors = !accepted;             // pop(): residuals belong to the rejected state
             g_trace.lambda.push_back(c.status->lambda); g_trace.chi2.push_back(currentChi); g_trace.trials.push_back(qmax);
-            ++*itersDone;
+            done++;
             if (qmax == 10 || rho == 0) { ok = false; break; }
             if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
             if (nBad >= 3) ok = false;
         }
+        *itersDone = done;
         *chiOut = currentChi;
         return EAO_OK;
     };
+    { const int v0[8] = {0, 0, 0, 0, 0, 0, 0, 0}; EAO_HIP(hipMemcpyAsync(dctl, v0, sizeof(v0), hipMemcpyHostToDevice, s)); }
     // a point that no active edge reaches keeps its value in BOTH state buffers
     EAO_HIP(hipMemcpyAsync(dptsT, dpts, hpts.size() * 8, hipMemcpyDeviceToDevice, s));
     EAO_HIP(hipMemcpyAsync(dcamsT, dcams, nC * sizeof(SE3), hipMemcpyDeviceToDevice, s));
@@ -1367,8 +1440,8 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
             hflag[e] &= ~4;
         }
         // the two state buffers must agree on vertices that drop out of the active set
-        EAO_HIP(hipMemcpyAsync(D.ptsT, D.pts, hpts.size() * 8, hipMemcpyDeviceToDevice, s));
-        EAO_HIP(hipMemcpyAsync(D.camsT, D.cams, nC * sizeof(SE3), hipMemcpyDeviceToDevice, s));
+        EAO_HIP(hipMemcpyAsync(D.ptsBuf[curHost ^ 1], D.ptsBuf[curHost], hpts.size() * 8, hipMemcpyDeviceToDevice, s));
+        EAO_HIP(hipMemcpyAsync(D.camsBuf[curHost ^ 1], D.camsBuf[curHost], nC * sizeof(SE3), hipMemcpyDeviceToDevice, s));
         if ((st = build_structure())) return st;
         if ((st = optimize(p->its_second, &r->iters[1], &r->chi2[1]))) return st;
     }
@@ -1376,8 +1449,8 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, dflag);
         EAO_HIP(hipMemcpyAsync(r->edge_outlier, dcls, E, hipMemcpyDeviceToHost, s));
     }
-    EAO_HIP(hipMemcpyAsync(hcams.data(), D.cams, nC * sizeof(SE3), hipMemcpyDeviceToHost, s));
-    EAO_HIP(hipMemcpyAsync(hpts.data(), D.pts, hpts.size() * 8, hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipMemcpyAsync(hcams.data(), D.camsBuf[curHost], nC * sizeof(SE3), hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipMemcpyAsync(hpts.data(), D.ptsBuf[curHost], hpts.size() * 8, hipMemcpyDeviceToHost, s));
     EAO_HIP(hipEventRecord(c.ev1, s));
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
