@@ -148,7 +148,7 @@ inline void se3_to_Tcw_f32(const SE3& s, float* T) {  // Converter::toCvMat(SE3Q
     T[15] = 1.f;
 }
 
-// 1/x by v_rcp_f64 + two Newton steps (~1 ulp): the solver's pivots and the projection denominators
+// 1/x by v_rcp_f64 + two Newton steps (~1 ulp): the solver's pivots
 __device__ inline double frcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
@@ -163,6 +163,14 @@ __device__ inline void huber(double e, double delta, double& rho0, double& rho1)
 }
 
 struct Cam { double fx, fy, cx, cy, bf; float bf_f; double deltaMono, deltaStereo; };
+
+// sum over the 8 lanes of an aligned lane group (fixed xor tree => reproducible); every lane gets the result
+__device__ __forceinline__ double group8_sum(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
 
 // ---- block-wide fixed-order sum of NV doubles per thread; result valid in thread 0 (and in `out` LDS after a barrier)
 template <int NV, int NT>
@@ -476,6 +484,7 @@ struct BADev {
     double* bl;             // nL*3
     double* Hpl;            // E*18 (pose row block 6x3) for active edges with a free camera
     double* slab;           // chunks * nFree * (nFree*36 + 6): partial Schur rows
+    double* sys;            // n*(n+1): assembled Schur system (upper triangle + rhs column)
     double* solveScratch;   // n*(n+1)+... doubles when the Schur system does not fit in LDS, else null
     long long* dbg;         // optional phase stamps of k_ba_solve (diagnostic builds of the harness only)
     double* xp;             // nFree*6
@@ -549,14 +558,18 @@ __device__ inline void ba_jacobians(const Cam& c, bool stereo, const SE3& T, con
 }
 
 // residuals + robust chi2 of every active edge at the CURRENT state (start of an optimize() call)
+// Eight lanes per landmark, one edge per lane (points with more than 8 active edges loop): the per-point sums are
+// 3-step xor trees inside the lane group.
 __global__ __launch_bounds__(256) void k_ba_errors(BADev P) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= P.nL || P.ctl[kCtlHalt]) return;
-    const int pt = P.actPt[l];
+    const int l = (blockIdx.x * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+    if (P.ctl[kCtlHalt]) return;
+    const bool live = l < P.nL;
+    const int pt = live ? P.actPt[l] : 0;
     const SE3* cams = cur_cams(P);
     const double* pts = cur_pts(P);
+    const int beg = live ? P.ptStart[l] : 0, end = live ? P.ptStart[l + 1] : 0;
     double chi = 0;
-    for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
+    for (int k = beg + slot; k < end; k += 8) {
         const int e = P.ptEdges[k];
         const unsigned char fl = P.eflag[e];
         const bool stereo = fl & 1;
@@ -570,7 +583,8 @@ __global__ __launch_bounds__(256) void k_ba_errors(BADev P) {
         if (fl & 4) huber(c2, stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
         chi += r0;
     }
-    P.partChi[l] = chi;
+    chi = group8_sum(chi);
+    if (live && slot == 0) P.partChi[l] = chi;
 }
 
 // fixed-order sum of part[0..n) by one 256-thread block
@@ -603,11 +617,13 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
     const SE3* cams = cur_cams(P);
     const double* pts = cur_pts(P);
     if ((int)blockIdx.x < ptBlocks) {
-        const int l = blockIdx.x * 256 + threadIdx.x;
-        if (l >= P.nL) return;
-        const int pt = P.actPt[l];
-        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-        for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
+        // role A: eight lanes per landmark, one edge per lane; Hll / bl are xor-tree sums over the lane group
+        const int l = (blockIdx.x * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+        const bool live = l < P.nL;
+        const int pt = live ? P.actPt[l] : 0;
+        const int beg = live ? P.ptStart[l] : 0, end = live ? P.ptStart[l + 1] : 0;
+        double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};   // upper triangle 00 01 02 11 12 22
+        for (int k = beg + slot; k < end; k += 8) {
             const int e = P.ptEdges[k];
             const unsigned char fl = P.eflag[e];
             const bool stereo = fl & 1;
@@ -621,20 +637,33 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
             const double wi = w * info;
             double omr[3];
             for (int r = 0; r < 3; r++) omr[r] = w * (-(info * er[r]));
+            int q = 0;
+#pragma unroll
             for (int i = 0; i < 3; i++) {
-                double s = 0;
-                for (int r = 0; r < D; r++) s += A[r][i] * omr[r];
-                b[i] += s;
-                for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi * A[r][j]; H[i * 3 + j] += h; }
+                double sb = 0;
+#pragma unroll
+                for (int r = 0; r < D; r++) sb += A[r][i] * omr[r];
+                b[i] += sb;
+#pragma unroll
+                for (int j = i; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi * A[r][j]; H[q++] += h; }
             }
             if (P.camIdx[P.ecam[e]] >= 0) {
                 double* Hx = &P.Hpl[(size_t)e * 18];
+#pragma unroll
                 for (int i = 0; i < 6; i++)
+#pragma unroll
                     for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi * A[r][j]; Hx[i * 3 + j] = h; }
             }
         }
-        for (int i = 0; i < 9; i++) P.Hll[(size_t)l * 9 + i] = H[i];
-        for (int i = 0; i < 3; i++) P.bl[(size_t)l * 3 + i] = b[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) H[i] = group8_sum(H[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) b[i] = group8_sum(b[i]);
+        if (live && slot == 0) {
+            double* Ho = &P.Hll[(size_t)l * 9];
+            Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
+            for (int i = 0; i < 3; i++) P.bl[(size_t)l * 3 + i] = b[i];
+        }
     } else {
         const int ci = blockIdx.x - ptBlocks;
         const int cam = P.actCam[ci];
@@ -713,6 +742,7 @@ __device__ inline void dinv3(const double* Hll, double lambda, double Di[9]) {
 // (3) and the point's row of the (point x camera) edge table -- then 256 threads stride over the nFree*36 + 6 outputs:
 //   S(i1, i2) = -sum_l Y(i1,l) Hpl(i2,l)^T   and   coeff(i1) = sum_l Hpl(i1,l) (Dinv bl)_l
 // Every output is accumulated by ONE thread over the chunk's edges in list order: no atomics, reproducible.
+constexpr int kChunks = 8;             // partial Schur rows per free camera (fixed: the reduction loop is unrolled)
 constexpr int kSchurMaxEdges = 128;   // edges staged per pass
 constexpr int kSchurMaxFree = 64;     // free keyframes per window (table row stride in LDS)
 constexpr int kSchurMaxOut = (kSchurMaxFree * 36 + 6 + 255) / 256;
@@ -762,13 +792,23 @@ __global__ __launch_bounds__(256) void k_ba_schur(BADev P) {
             if (t < nF * 36) {
                 const int i2 = t / 36, r = (t % 36) / 6, c = t % 6;
                 if (i2 >= i1) {
-#pragma unroll 4
-                    for (int k = 0; k < cnt; k++) {
-                        const int e2 = sTab[k * kSchurMaxFree + i2];
-                        if (e2 < 0) continue;
-                        const double* Yv = &sY[k * 18 + r * 3];
-                        const double* Bj = &P.Hpl[(size_t)e2 * 18 + c * 3];
-                        a -= Yv[0] * Bj[0] + Yv[1] * Bj[1] + Yv[2] * Bj[2];
+                    for (int k0 = 0; k0 < cnt; k0 += 8) {   // eight gathered 6x3 rows in flight
+                        double b0[8], b1[8], b2[8];
+                        bool has[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int e2 = (k0 + u < cnt) ? sTab[(k0 + u) * kSchurMaxFree + i2] : -1;
+                            has[u] = e2 >= 0;
+                            const double* Bj = &P.Hpl[(size_t)(has[u] ? e2 : 0) * 18 + c * 3];
+                            b0[u] = Bj[0]; b1[u] = Bj[1]; b2[u] = Bj[2];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            if (has[u]) {
+                                const double* Yv = &sY[(k0 + u) * 18 + r * 3];
+                                a -= Yv[0] * b0[u] + Yv[1] * b1[u] + Yv[2] * b2[u];
+                            }
+                        }
                     }
                 }
             } else {
@@ -782,26 +822,66 @@ __global__ __launch_bounds__(256) void k_ba_schur(BADev P) {
         }
         __syncthreads();
     }
+    // partial slab of this chunk: dense n x n row-major (upper blocks) followed by the n coefficients, so that the
+    // assembly in k_ba_solve reads it fully coalesced
+    const int n = nF * 6;
+    double* slab = P.slab + (size_t)chunk * ((size_t)n * n + n);
 #pragma unroll
     for (int o = 0; o < kSchurMaxOut; o++) {
         const int t = threadIdx.x + o * 256;
-        if (t < rowLen) P.slab[((size_t)chunk * nF + i1) * rowLen + t] = acc[o];
+        if (t < nF * 36) {
+            const int i2 = t / 36, r = (t % 36) / 6, c = t % 6;
+            if (i2 >= i1) slab[(size_t)(i1 * 6 + r) * n + i2 * 6 + c] = acc[o];
+        } else if (t < rowLen) {
+            slab[(size_t)n * n + i1 * 6 + (t - nF * 36)] = acc[o];
+        }
     }
 }
 
-// One 1024-thread workgroup: assemble Hschur = Hpp + lambda I + sum of slabs (upper triangle) in LDS, blocked
+// Sum the kChunks partial slabs in chunk order, add Hpp + lambda I and the right-hand side: one dense n x (n+1) system
+// (upper triangle) in global memory.  Many workgroups: a single CU can only pull ~10 B/clk from L2, so letting the
+// solver's lone workgroup read all slabs itself cost 16 us.
+__global__ __launch_bounds__(256) void k_ba_reduce_slabs(BADev P) {
+    if (P.ctl[kCtlHalt]) return;
+    const int nF = P.nFree, n = nF * 6, ld = n + 1;
+    const size_t slabStride = (size_t)n * n + n;
+    const double lambda = P.lm[0];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * ld) return;
+    const int row = idx / ld, col = idx - row * ld;
+    double v = 0;
+    if (col == n) {
+        double co = 0;
+#pragma unroll
+        for (int ch = 0; ch < kChunks; ch++) co += P.slab[ch * slabStride + (size_t)n * n + row];
+        v = P.bp[row] - co;
+    } else {
+        const int i1 = row / 6, r = row - i1 * 6, i2 = col / 6, c = col - i2 * 6;
+        if (i2 >= i1) {
+            double part[kChunks];
+#pragma unroll
+            for (int ch = 0; ch < kChunks; ch++) part[ch] = P.slab[ch * slabStride + (size_t)row * n + col];
+            if (i1 == i2) v = P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+#pragma unroll
+            for (int ch = 0; ch < kChunks; ch++) v += part[ch];
+        }
+    }
+    P.sys[idx] = v;
+}
+
+// One 512-thread workgroup: assemble Hschur = Hpp + lambda I + sum of slabs (upper triangle) in LDS, blocked
 // right-looking LDLT (6-row panels; the right-hand side rides along as an extra column; no pivoting, a zero pivot fails
 // like SimplicialLDLT), blocked back substitution, then exp(dx) * T for the free cameras.  n = 6*nFree <= 192.
 // The trailing update subtracts the six panel terms one after the other, i.e. exactly the scalar algorithm's operation order.
-constexpr int kSolveThreads = 1024;
-constexpr int kChunks = 8;                      // partial Schur rows per free camera (fixed: the assembly loop is unrolled)
+constexpr int kSolveThreads = 512;   // 8 waves: 256 VGPRs per lane keep the panel's 6x6 working set out of scratch
 // IN_LDS = true: the system lives in LDS (up to 22 free keyframes); false: in L2-resident global scratch.  Two
 // instantiations so that each uses its own address space (a runtime-selected pointer would degrade to flat loads).
 template <bool IN_LDS>
 __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveOk) {
     extern __shared__ double sm[];
-    const int nF = P.nFree, n = nF * 6, rowLen = nF * 36 + 6, t = threadIdx.x;
-    const int ld = n + 1;                       // column n of every row = right-hand side
+    const int nF = P.nFree, n = nF * 6, t = threadIdx.x;
+    const int ld = ((n + 32) & ~31) + 1;        // row stride: >= n + 1 (column n = right-hand side) and == 1 (mod 32) doubles, so a
+                                                // column walk (one row per lane) touches every LDS bank exactly once
     double* S;                                  // n * ld
     double* M;                                  // 6 * ld   multipliers of the current panel
     if (IN_LDS) { S = sm; M = sm + (size_t)n * ld; }
@@ -810,34 +890,20 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveO
     double* rd = xv + n;                        // n reciprocal pivots
     __shared__ int s_fail;
     if (P.ctl[kCtlHalt]) return;
-    const double lambda = P.lm[0];
     if (t == 0) s_fail = 0;
     if (P.dbg && t == 0) { P.dbg[0] = clock64(); P.dbg[1] = wall_clock64(); }
-    for (int idx = t; idx < n * n; idx += kSolveThreads) {
-        const int row = idx / n, col = idx - row * n;
-        const int i1 = row / 6, r = row - i1 * 6, i2 = col / 6, c = col - i2 * 6;
-        double v = 0;
-        if (i2 >= i1) {
-            double part[kChunks];
-#pragma unroll
-            for (int ch = 0; ch < kChunks; ch++) part[ch] = P.slab[((size_t)ch * nF + i1) * rowLen + i2 * 36 + r * 6 + c];
-            if (i1 == i2) v = P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
-#pragma unroll
-            for (int ch = 0; ch < kChunks; ch++) v += part[ch];
-        }
-        S[(size_t)row * ld + col] = v;
+    // the assembled system (k_ba_reduce_slabs): n x (n+1) row-major, upper triangle + right-hand side column
+    for (int idx = t; idx < n * (n + 1); idx += kSolveThreads) {
+        const int row = idx / (n + 1), col = idx - row * (n + 1);
+        S[(size_t)row * ld + col] = P.sys[idx];
     }
-    for (int row = t; row < n; row += kSolveThreads) {
-        const int i1 = row / 6, r = row - i1 * 6;
-        double co = 0;
-        for (int ch = 0; ch < P.chunks; ch++) co += P.slab[((size_t)ch * nF + i1) * rowLen + nF * 36 + r];
-        S[(size_t)row * ld + n] = P.bp[row] - co;
-        xv[row] = 0;
-    }
+    for (int row = t; row < n; row += kSolveThreads) xv[row] = 0;
     __syncthreads();
     if (P.dbg && t == 0) { P.dbg[2] = clock64(); P.dbg[3] = wall_clock64(); }
+    long long accPanel = 0, accTrail = 0, tStamp = 0;
     for (int jb = 0; jb < nF; jb++) {
         const int j = jb * 6;
+        if (P.dbg && t == 0) tStamp = clock64();
         // ---- panel: the thread owning column k (j <= k <= n) factorises the 6x6 diagonal block redundantly in registers
         //      and retires its own column of the six panel rows; the other waves only take part in the barriers
         const int k = j + t;
@@ -888,28 +954,36 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveO
             }
         }
         __syncthreads();
+        if (P.dbg && t == 0) { const long long now = clock64(); accPanel += now - tStamp; tStamp = now; }
         if (s_fail) break;
-        // ---- trailing update of rows i >= j+6: S(i,k) -= sum_r M(r,i) * S(j+r,k), r = 0..5 in order, k >= i (k == n: rhs)
+        // ---- trailing update of rows i >= j+6: S(i,k) -= sum_r M(r,i) * S(j+r,k), r = 0..5 in order, k >= i (k == n: rhs).
+        //      Measured alternatives on MI355X (cycles of this phase summed over the 20 steps of a 120x120 system):
+        //        element per thread, 32-wide column strips (this code)            64 k
+        //        row per lane, panel values as LDS broadcast reads, 4 columns in flight   99 k
+        //        v_mfma_f64_16x16x4_f64 on 16x16 tiles, two tiles in flight per wave      81 k  (one tile: 95 k)
+        //      One workgroup alone on a CU cannot hide the ~64-cycle f64 MFMA / LDS latencies; the plain version wins.
         {
             const int tx = t & 31, ty = t >> 5;
-            for (int i = j + 6 + ty; i < n; i += 32) {
+            for (int i = j + 6 + ty; i < n; i += kSolveThreads / 32) {
                 const double m0 = M[i], m1 = M[ld + i], m2 = M[2 * ld + i], m3 = M[3 * ld + i], m4 = M[4 * ld + i], m5 = M[5 * ld + i];
-                for (int kk = j + 6 + tx; kk <= n; kk += 32) {
-                    if (kk < i) continue;
+                const int base = j + 6 + tx;
+                const int kfirst = i > base ? base + (((i - base + 31) >> 5) << 5) : base;
+                for (int kk = kfirst; kk <= n; kk += 32) {
                     double v = S[(size_t)i * ld + kk];
-                    v -= m0 * S[(size_t)j * ld + kk];
-                    v -= m1 * S[(size_t)(j + 1) * ld + kk];
-                    v -= m2 * S[(size_t)(j + 2) * ld + kk];
-                    v -= m3 * S[(size_t)(j + 3) * ld + kk];
-                    v -= m4 * S[(size_t)(j + 4) * ld + kk];
-                    v -= m5 * S[(size_t)(j + 5) * ld + kk];
+                    v = fma(-m0, S[(size_t)j * ld + kk], v);
+                    v = fma(-m1, S[(size_t)(j + 1) * ld + kk], v);
+                    v = fma(-m2, S[(size_t)(j + 2) * ld + kk], v);
+                    v = fma(-m3, S[(size_t)(j + 3) * ld + kk], v);
+                    v = fma(-m4, S[(size_t)(j + 4) * ld + kk], v);
+                    v = fma(-m5, S[(size_t)(j + 5) * ld + kk], v);
                     S[(size_t)i * ld + kk] = v;
                 }
             }
         }
         __syncthreads();
+        if (P.dbg && t == 0) accTrail += clock64() - tStamp;
     }
-    if (P.dbg && t == 0) { P.dbg[4] = clock64(); P.dbg[5] = wall_clock64(); }
+    if (P.dbg && t == 0) { P.dbg[4] = clock64(); P.dbg[5] = wall_clock64(); P.dbg[10] = accPanel; P.dbg[11] = accTrail; }
     if (!s_fail) {
         // ---- back substitution by 6-row blocks: x_i = (y_i - sum_{k>i} U(i,k) x_k) / d_i; only the threads that own a
         //      row above the block (and wave 0, which publishes x) solve the 6x6 triangle
@@ -958,40 +1032,49 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveO
     if (P.dbg && t == 0) { P.dbg[8] = clock64(); P.dbg[9] = wall_clock64(); }
 }
 
-// per landmark: x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 at the trial state; scale partial
+// per landmark (eight lanes, one edge per lane): x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 of
+// its edges at the trial state; scale partial
 __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= P.nL || P.ctl[kCtlHalt]) return;
-    const int pt = P.actPt[l];
+    const int l = (blockIdx.x * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+    if (P.ctl[kCtlHalt]) return;
+    const bool live = l < P.nL;
+    const int pt = live ? P.actPt[l] : 0;
     const double* pts = cur_pts(P);
     double* ptsT = trial_pts(P);
     const SE3* camsT = trial_cams(P);
     const double lambda = P.lm[0];
-    const double* bl = &P.bl[(size_t)l * 3];
-    double cl[3] = {bl[0], bl[1], bl[2]};
-    for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
+    const int beg = live ? P.ptStart[l] : 0, end = live ? P.ptStart[l + 1] : 0;
+    double cl[3] = {0, 0, 0};
+    for (int k = beg + slot; k < end; k += 8) {
         const int e = P.ptEdges[k];
         const int ci = P.camIdx[P.ecam[e]];
         if (ci < 0) continue;
         const double* Bi = &P.Hpl[(size_t)e * 18];
         const double* x = &P.xp[ci * 6];
+#pragma unroll
         for (int c = 0; c < 3; c++) {
-            double s = 0;
-            for (int r = 0; r < 6; r++) s += Bi[r * 3 + c] * (-x[r]);
-            cl[c] += s;
+            double sacc = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) sacc += Bi[r * 3 + c] * (-x[r]);
+            cl[c] += sacc;
         }
     }
-    double Di[9];
-    dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
-    double xl[3], np[3];
+    double bl[3] = {0, 0, 0}, Di[9], xl[3], np[3];
+    if (live) {
+        bl[0] = P.bl[(size_t)l * 3]; bl[1] = P.bl[(size_t)l * 3 + 1]; bl[2] = P.bl[(size_t)l * 3 + 2];
+        dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
+    } else {
+        for (int i = 0; i < 9; i++) Di[i] = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) cl[c] = bl[c] + group8_sum(cl[c]);
+#pragma unroll
     for (int i = 0; i < 3; i++) {
         xl[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
-        P.xl[(size_t)l * 3 + i] = xl[i];
-        np[i] = pts[3 * pt + i] + xl[i];
-        ptsT[3 * pt + i] = np[i];
+        np[i] = (live ? pts[3 * pt + i] : 0.0) + xl[i];
     }
     double chi = 0;
-    for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
+    for (int k = beg + slot; k < end; k += 8) {
         const int e = P.ptEdges[k];
         const unsigned char fl = P.eflag[e];
         const bool stereo = fl & 1;
@@ -1005,8 +1088,12 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
         if (fl & 4) huber(c2, stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
         chi += r0;
     }
-    P.partChi[l] = chi;
-    P.partScale[l] = xl[0] * (lambda * xl[0] + bl[0]) + xl[1] * (lambda * xl[1] + bl[1]) + xl[2] * (lambda * xl[2] + bl[2]);
+    chi = group8_sum(chi);
+    if (live && slot == 0) {
+        for (int i = 0; i < 3; i++) { P.xl[(size_t)l * 3 + i] = xl[i]; ptsT[3 * pt + i] = np[i]; }
+        P.partChi[l] = chi;
+        P.partScale[l] = xl[0] * (lambda * xl[0] + bl[0]) + xl[1] * (lambda * xl[1] + bl[1]) + xl[2] * (lambda * xl[2] + bl[2]);
+    }
 }
 
 // rho, accept / reject, lambda & nu update (optimization_algorithm_levenberg.cpp:118-147); one 256-thread block.
@@ -1243,12 +1330,11 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     int nFreeIn = 0;
     for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
     EAO_REQUIRE(nFreeIn <= kSchurMaxFree, "at most %d free keyframes per window in this build (got %d)", kSchurMaxFree, nFreeIn);
-    const size_t rowLenMax = (size_t)nFmax * 36 + 6;
     size_t need = 0;
     need += (size_t)E * (3 + 1 + 3 + 18) * 8 + (size_t)E * (4 + 4 + 4 + 4 + 2);
-    need += ((size_t)(nC * 6 + 6) * (nC * 6 + 1) + 8) * 8;
+    need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
     need += (size_t)nP * (3 + 3 + 9 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 12 + (size_t)nP * nFmax * 4;
-    need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16) + chunks * nFmax * rowLenMax * 8;
+    need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16) + (size_t)chunks * ((size_t)nFmax * 6 * nFmax * 6 + nFmax * 6) * 8;
     need += 64 * 256;
     if ((st = c.bytes.reserve(need))) return st;
     Arena a{c.bytes.p, c.bytes.n};
@@ -1269,8 +1355,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
     D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
     D.Hpl = a.take<double>((size_t)E * 18);
-    double* dsolveScratch = a.take<double>((size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 1) + 8);
-    D.slab = a.take<double>(chunks * nFmax * rowLenMax);
+    double* dsolveScratch = a.take<double>((size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
+    D.sys = a.take<double>((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1) + 8);
+    D.slab = a.take<double>((size_t)chunks * ((size_t)nFmax * 6 * nFmax * 6 + nFmax * 6));
     D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
     D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
     D.lm = a.take<double>(8);
@@ -1355,18 +1442,22 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         *itersDone = 0;
         const int nF = D.nFree, nL = D.nL;
         if (nF + nL == 0) return EAO_OK;   // "_ivMap.size() == 0": nothing to optimise
-        const int ptBlocks = eao::cdiv(std::max(nL, 1), 256);
-        size_t solveLds = ((size_t)(nF * 6 + 6) * (nF * 6 + 1) + 2 * (size_t)nF * 6) * sizeof(double);
+        const int ptBlocks = eao::cdiv(std::max(nL, 1) * 8, 256);   // eight lanes per landmark
+        const size_t ldHost = (size_t)((nF * 6 + 32) & ~31) + 1;
+        size_t solveLds = ((size_t)(nF * 6 + 6) * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
         if (solveLds > 150 * 1024) {   // system too large for LDS: S lives in (L2-resident) global scratch, M/xv stay in LDS
             D.solveScratch = dsolveScratch;
-            solveLds = ((size_t)6 * (nF * 6 + 1) + 2 * (size_t)nF * 6) * sizeof(double);
+            solveLds = ((size_t)6 * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
         } else {
             D.solveScratch = nullptr;
         }
         const bool solveInLds = D.solveScratch == nullptr;
         if (solveInLds) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
         auto enqueue_trial = [&](int bulk) {
-            if (nF) hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(256), 0, s, D);
+            if (nF) {
+                hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(256), 0, s, D);
+                hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, D);
+            }
             if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
             else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
             if (nL) hipLaunchKernelGGL(k_ba_backsub, dim3(ptBlocks), dim3(256), 0, s, D);
@@ -1458,8 +1549,8 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     if (D.dbg) {
         long long st[16];
         EAO_HIP(hipMemcpy(st, D.dbg, sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
-                st[2] - st[0], st[4] - st[2], st[6] - st[4], st[8] - st[6], st[3] - st[1], st[5] - st[3], st[7] - st[5], st[9] - st[7]);
+        fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
+                st[2] - st[0], st[4] - st[2], st[10], st[11], st[6] - st[4], st[8] - st[6], st[3] - st[1], st[5] - st[3], st[7] - st[5], st[9] - st[7]);
     }
     write_out();
     return EAO_OK;
