@@ -1182,10 +1182,13 @@ struct LMContext {  // per-thread device workspace, grow-only
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     BAStatus* status = nullptr;   // pinned + mapped
+    unsigned char* pin = nullptr; // pinned host mirror of the input part of the arena: ONE H2D copy per upload
+    size_t pinCap = 0;
     eao::DevBuf<unsigned char> bytes;
     size_t used = 0;
     ~LMContext() {
         if (status) (void)hipHostFree(status);
+        if (pin) (void)hipHostFree(pin);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1318,14 +1321,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     }
     for (int e = 0; e < E; e++)
         EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nP, "edge %d out of range", e);
-    // ---- static problem data
-    std::vector<double> hobs((size_t)E * 3), hinfo(E);
+    // ---- static problem data: edge flags (bit0 stereo, bit1 inactive, bit2 robust kernel present)
     std::vector<unsigned char> hflag(E);
-    for (int e = 0; e < E; e++) {
-        for (int k = 0; k < 3; k++) hobs[3 * e + k] = p->edge_obs[3 * e + k];
-        hinfo[e] = p->edge_inv_sigma2[e];
-        hflag[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | 4);
-    }
+    for (int e = 0; e < E; e++) hflag[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | 4);
     const int nFmax = nC, chunks = kChunks;
     int nFreeIn = 0;
     for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
@@ -1343,14 +1341,22 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     D.nCams = nC; D.nPts = nP; D.nEdges = E; D.chunks = chunks;
     D.cam.fx = p->fx; D.cam.fy = p->fy; D.cam.cx = p->cx; D.cam.cy = p->cy; D.cam.bf = p->bf; D.cam.bf_f = p->bf;
     D.cam.deltaMono = (float)std::sqrt(5.991); D.cam.deltaStereo = (float)std::sqrt(7.815);
+    // region A (static problem) and region B (active structure) come first and are mirrored in pinned host memory
+    const size_t offA0 = a.off;
     double* dobs = a.take<double>((size_t)E * 3); double* dinfo = a.take<double>(E);
     int* decam = a.take<int>(E); int* dept = a.take<int>(E);
-    unsigned char* dflag = a.take<unsigned char>(E); unsigned char* dcls = a.take<unsigned char>(E);
+    SE3* dcams = a.take<SE3>(nC);
+    double* dpts = a.take<double>((size_t)nP * 3);
+    const size_t offA1 = (a.off + 255) & ~(size_t)255;
+    unsigned char* dflag = a.take<unsigned char>(E);
+    const size_t offB0 = (size_t)(dflag - a.base);
     int* dcamIdx = a.take<int>(nC); int* dptIdx = a.take<int>(nP); int* dactCam = a.take<int>(nC); int* dactPt = a.take<int>(nP);
     int* dptStart = a.take<int>(nP + 1); int* dptEdges = a.take<int>(E); int* dcamStart = a.take<int>(nC + 1); int* dcamEdges = a.take<int>(E);
     int* dtable = a.take<int>((size_t)nP * nFmax);
-    SE3* dcams = a.take<SE3>(nC); SE3* dcamsT = a.take<SE3>(nC);
-    double* dpts = a.take<double>((size_t)nP * 3); double* dptsT = a.take<double>((size_t)nP * 3);
+    const size_t offB1 = (a.off + 255) & ~(size_t)255;
+    unsigned char* dcls = a.take<unsigned char>(E);
+    SE3* dcamsT = a.take<SE3>(nC);
+    double* dptsT = a.take<double>((size_t)nP * 3);
     D.err = a.take<double>((size_t)E * 3);
     D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
     D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
@@ -1371,36 +1377,50 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     D.ptStart = dptStart; D.ptEdges = dptEdges; D.camStart = dcamStart; D.camEdges = dcamEdges; D.table = dtable;
     hipStream_t s = c.stream;
     EAO_HIP(hipEventRecord(c.ev0, s));
-    EAO_HIP(hipMemcpyAsync(dobs, hobs.data(), hobs.size() * 8, hipMemcpyHostToDevice, s));
-    EAO_HIP(hipMemcpyAsync(dinfo, hinfo.data(), hinfo.size() * 8, hipMemcpyHostToDevice, s));
-    EAO_HIP(hipMemcpyAsync(decam, p->edge_cam, (size_t)E * 4, hipMemcpyHostToDevice, s));
-    EAO_HIP(hipMemcpyAsync(dept, p->edge_point, (size_t)E * 4, hipMemcpyHostToDevice, s));
-    EAO_HIP(hipMemcpyAsync(dcams, hcams.data(), nC * sizeof(SE3), hipMemcpyHostToDevice, s));
-    EAO_HIP(hipMemcpyAsync(dpts, hpts.data(), hpts.size() * 8, hipMemcpyHostToDevice, s));
+    if (c.pinCap < offB1) {
+        if (c.pin) (void)hipHostFree(c.pin);
+        c.pin = nullptr; c.pinCap = 0;
+        EAO_HIP(hipHostMalloc((void**)&c.pin, offB1 + (offB1 >> 2), hipHostMallocDefault));
+        c.pinCap = offB1 + (offB1 >> 2);
+    }
+    auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
+    {   // float32 -> double exactly as Converter / Eigen would promote them, straight into the pinned mirror
+        double* ho = (double*)hostp(dobs); double* hi = (double*)hostp(dinfo);
+        for (size_t k = 0; k < (size_t)E * 3; k++) ho[k] = p->edge_obs[k];
+        for (int e = 0; e < E; e++) hi[e] = p->edge_inv_sigma2[e];
+        std::memcpy(hostp(decam), p->edge_cam, (size_t)E * 4);
+        std::memcpy(hostp(dept), p->edge_point, (size_t)E * 4);
+        std::memcpy(hostp(dcams), hcams.data(), nC * sizeof(SE3));
+        std::memcpy(hostp(dpts), hpts.data(), hpts.size() * 8);
+    }
+    EAO_HIP(hipMemcpyAsync(a.base + offA0, c.pin + offA0, offA1 - offA0, hipMemcpyHostToDevice, s));
     EAO_HIP(hipMemsetAsync(D.err, 0, (size_t)E * 24, s));
     D.camsBuf[0] = dcams; D.camsBuf[1] = dcamsT; D.ptsBuf[0] = dpts; D.ptsBuf[1] = dptsT;
     D.ctl = dctl;
 
-    std::vector<int> camIdx(nC), ptIdx(nP), actCam, actPt, ptStart, ptEdges, camStart, camEdges, table;
     int seq = c.status->seq;
-    // ---- (re)build the active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
+    // ---- (re)build the active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping.
+    //      Built directly in the pinned mirror of region B, uploaded with one copy.
     auto build_structure = [&]() -> eao_status {
+        int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
+        int* actCam = (int*)hostp(dactCam); int* actPt = (int*)hostp(dactPt);
+        int* ptStart = (int*)hostp(dptStart); int* ptEdges = (int*)hostp(dptEdges);
+        int* camStart = (int*)hostp(dcamStart); int* camEdges = (int*)hostp(dcamEdges);
+        int* table = (int*)hostp(dtable);
         std::vector<int> camCnt(nC, 0), ptCnt(nP, 0);
         for (int e = 0; e < E; e++) if (!(hflag[e] & 2)) { camCnt[p->edge_cam[e]]++; ptCnt[p->edge_point[e]]++; }
-        actCam.clear(); actPt.clear();
         int nF = 0, nL = 0;
-        for (int i = 0; i < nC; i++) { camIdx[i] = -1; if (camCnt[i] && !p->cam_fixed[i]) { camIdx[i] = nF++; actCam.push_back(i); } }
-        for (int i = 0; i < nP; i++) { ptIdx[i] = -1; if (ptCnt[i]) { ptIdx[i] = nL++; actPt.push_back(i); } }
-        ptStart.assign(nL + 1, 0); camStart.assign(nF + 1, 0);
+        for (int i = 0; i < nC; i++) { camIdx[i] = -1; if (camCnt[i] && !p->cam_fixed[i]) { actCam[nF] = i; camIdx[i] = nF++; } }
+        for (int i = 0; i < nP; i++) { ptIdx[i] = -1; if (ptCnt[i]) { actPt[nL] = i; ptIdx[i] = nL++; } }
+        std::fill(ptStart, ptStart + nL + 1, 0); std::fill(camStart, camStart + nF + 1, 0);
         for (int e = 0; e < E; e++) if (!(hflag[e] & 2)) {
             ptStart[ptIdx[p->edge_point[e]] + 1]++;
             if (camIdx[p->edge_cam[e]] >= 0) camStart[camIdx[p->edge_cam[e]] + 1]++;
         }
         for (int i = 0; i < nL; i++) ptStart[i + 1] += ptStart[i];
         for (int i = 0; i < nF; i++) camStart[i + 1] += camStart[i];
-        ptEdges.assign(std::max(ptStart[nL], 1), 0); camEdges.assign(std::max(camStart[nF], 1), 0);
-        table.assign(std::max((size_t)nL * nF, (size_t)1), -1);
-        std::vector<int> pf(ptStart.begin(), ptStart.end() - 1), cf(camStart.begin(), camStart.end() - 1);
+        std::fill(table, table + (size_t)nL * nF, -1);
+        std::vector<int> pf(ptStart, ptStart + nL), cf(camStart, camStart + nF);
         for (int e = 0; e < E; e++) if (!(hflag[e] & 2)) {
             const int l = ptIdx[p->edge_point[e]], ci = camIdx[p->edge_cam[e]];
             ptEdges[pf[l]++] = e;
@@ -1411,16 +1431,8 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
             }
         }
         D.nFree = nF; D.nL = nL;
-        EAO_HIP(hipMemcpyAsync(dflag, hflag.data(), E, hipMemcpyHostToDevice, s));
-        EAO_HIP(hipMemcpyAsync(dcamIdx, camIdx.data(), nC * 4, hipMemcpyHostToDevice, s));
-        EAO_HIP(hipMemcpyAsync(dptIdx, ptIdx.data(), (size_t)nP * 4, hipMemcpyHostToDevice, s));
-        if (nF) EAO_HIP(hipMemcpyAsync(dactCam, actCam.data(), nF * 4, hipMemcpyHostToDevice, s));
-        if (nL) EAO_HIP(hipMemcpyAsync(dactPt, actPt.data(), (size_t)nL * 4, hipMemcpyHostToDevice, s));
-        EAO_HIP(hipMemcpyAsync(dptStart, ptStart.data(), (size_t)(nL + 1) * 4, hipMemcpyHostToDevice, s));
-        EAO_HIP(hipMemcpyAsync(dptEdges, ptEdges.data(), ptEdges.size() * 4, hipMemcpyHostToDevice, s));
-        EAO_HIP(hipMemcpyAsync(dcamStart, camStart.data(), (size_t)(nF + 1) * 4, hipMemcpyHostToDevice, s));
-        EAO_HIP(hipMemcpyAsync(dcamEdges, camEdges.data(), camEdges.size() * 4, hipMemcpyHostToDevice, s));
-        EAO_HIP(hipMemcpyAsync(dtable, table.data(), table.size() * 4, hipMemcpyHostToDevice, s));
+        std::memcpy(hostp(dflag), hflag.data(), E);
+        EAO_HIP(hipMemcpyAsync(a.base + offB0, c.pin + offB0, offB1 - offB0, hipMemcpyHostToDevice, s));
         return EAO_OK;
     };
     auto wait_status = [&](int want) -> eao_status {
