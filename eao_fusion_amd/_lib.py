@@ -23,6 +23,14 @@ class OrbCfg(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p), ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p),
+                ("u_right", C.c_void_p), ("descriptors", C.c_void_p), ("occupied", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("grid_cols", C.c_int32), ("grid_rows", C.c_int32),
+                ("scale_factors", C.c_void_p), ("nlevels", C.c_int32)]
+
+
 class PoseProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("Tcw", C.c_void_p), ("Xw", C.c_void_p), ("obs", C.c_void_p),
                 ("inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
@@ -70,6 +78,8 @@ SYMBOLS = {
     "eao_hamming_best2": (_I, [_P, _I, _P, _I, _P, _P]),
     "eao_hamming_matrix_device": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "eao_hamming_best2_device": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
+    "eao_search_by_projection_points": (_I, [C.POINTER(FrameView), _I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, C.POINTER(_I)]),
+    "eao_search_by_projection_frames": (_I, [C.POINTER(FrameView), _P, _P, _I, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P, C.POINTER(_I)]),
     "eao_pose_optimization": (_I, [C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
     "eao_local_ba": (_I, [C.POINTER(BAProblem), _P, C.POINTER(BAResult)]),
     "eao_last_lm_trace": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),

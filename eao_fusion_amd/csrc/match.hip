@@ -1,0 +1,362 @@
+// match.hip -- guided ORB matching for MI355X (gfx950): the two per-frame SearchByProjection variants.
+//
+// Stands behind ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:45-129)
+// and ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (:1328-1472), with
+// Frame::GetFeaturesInArea / PosInGrid (src/Frame.cc:696-761) as the candidate generator.
+//
+// Upstream is greedy over queries (a keypoint claimed by an earlier query is skipped by later ones), so only the
+// candidate generation + Hamming distances are data parallel:
+//   k_match_candidates  one wavefront per query walks the frame's keypoints in GRID ORDER (cell column-major, then
+//                       insertion order -- the order upstream's nested cell loops visit them), applies the cell-range,
+//                       level, window and stereo gates with the reference's float expressions, computes the 256-bit
+//                       Hamming distance of the survivors and appends (index, distance) through ballot compaction, so
+//                       every query's list is already in upstream's candidate order.  Two sweeps (count, reserve a
+//                       segment with one atomic, fill) keep the output compact.
+// The host part of this file replays the assignment loops over those lists exactly as upstream runs them.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct Query {
+    float x, y, r;            // window centre and half-size
+    int minLevel, maxLevel;   // GetFeaturesInArea level gate (maxLevel < 0: open)
+    float urRef, urTol;       // stereo gate: |urRef - uRight| > urTol rejects (only for keypoints with uRight > 0)
+    int active;
+};
+
+struct FrameDev {
+    int n, nOrdered;
+    const float* kx; const float* ky; const int* oct; const float* ur;
+    const uint4* desc;        // n x 2
+    const int* order;         // keypoint indices in grid order
+    const unsigned short* cellx; const unsigned short* celly;   // per ordered entry
+    float minX, minY, invW, invH;
+    int cols, rows;
+};
+
+__device__ __forceinline__ int dist256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// out: packed (distance << 16 | keypoint index); segStart/segCount per query; cursor = global fill position
+__global__ __launch_bounds__(256) void k_match_candidates(FrameDev F, const Query* __restrict__ q, const uint4* __restrict__ qdesc, int nq,
+                                                          unsigned* __restrict__ out, int outCap, int* __restrict__ segStart,
+                                                          int* __restrict__ segCount, int* __restrict__ cursor) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const Query Q = q[qi];
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+    bool any = Q.active != 0;
+    if (any) {   // Frame::GetFeaturesInArea, src/Frame.cc:701-717 (float expressions kept as written upstream)
+        x0 = max(0, (int)floorf((Q.x - F.minX - Q.r) * F.invW));
+        x1 = min(F.cols - 1, (int)ceilf((Q.x - F.minX + Q.r) * F.invW));
+        y0 = max(0, (int)floorf((Q.y - F.minY - Q.r) * F.invH));
+        y1 = min(F.rows - 1, (int)ceilf((Q.y - F.minY + Q.r) * F.invH));
+        if (x0 >= F.cols || x1 < 0 || y0 >= F.rows || y1 < 0) any = false;
+    }
+    const bool checkLevels = (Q.minLevel > 0) || (Q.maxLevel >= 0);
+    const uint4 d0 = qdesc[2 * qi], d1 = qdesc[2 * qi + 1];
+    int base = 0, total = 0;
+    for (int sweep = 0; sweep < 2; sweep++) {
+        int run = 0;
+        if (any) {
+            for (int o0 = 0; o0 < F.nOrdered; o0 += 64) {
+                const int o = o0 + lane;
+                bool pass = false;
+                int i = 0;
+                if (o < F.nOrdered) {
+                    const int cx = F.cellx[o], cy = F.celly[o];
+                    if (cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1) {
+                        i = F.order[o];
+                        const int oc = F.oct[i];
+                        bool ok = true;
+                        if (checkLevels) {
+                            if (oc < Q.minLevel) ok = false;
+                            if (Q.maxLevel >= 0 && oc > Q.maxLevel) ok = false;
+                        }
+                        if (ok) {
+                            const float dx = F.kx[i] - Q.x, dy = F.ky[i] - Q.y;
+                            ok = fabsf(dx) < Q.r && fabsf(dy) < Q.r;
+                        }
+                        if (ok) {
+                            const float u = F.ur[i];
+                            if (u > 0 && fabsf(Q.urRef - u) > Q.urTol) ok = false;
+                        }
+                        pass = ok;
+                    }
+                }
+                const unsigned long long m = __ballot(pass);
+                if (sweep == 1 && pass) {
+                    const int pos = base + run + __popcll(m & ((1ull << lane) - 1));
+                    if (pos < outCap) out[pos] = ((unsigned)dist256(d0, d1, F.desc[2 * i], F.desc[2 * i + 1]) << 16) | (unsigned)i;
+                }
+                run += __popcll(m);
+            }
+        }
+        if (sweep == 0) {
+            total = run;
+            if (lane == 0) {
+                base = total ? atomicAdd(cursor, total) : 0;
+                segStart[qi] = base;
+                segCount[qi] = total;
+            }
+            base = __shfl(base, 0);
+            if (total == 0) break;
+        }
+    }
+}
+
+struct Ctx {   // per-thread workspace, grow-only
+    hipStream_t stream = nullptr;
+    eao::DevBuf<unsigned char> dev;
+    std::vector<unsigned char> host;
+    eao::DevBuf<unsigned> out;
+    eao::DevBuf<int> meta;   // segStart[nq], segCount[nq], cursor
+    ~Ctx() { if (stream) (void)hipStreamDestroy(stream); }
+};
+thread_local Ctx g_ctx;
+
+struct Lists {
+    std::vector<int> start, count;
+    std::vector<unsigned> items;
+};
+
+// uploads the frame + queries, runs the candidate kernel, downloads the compact lists
+eao_status build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L) {
+    Ctx& c = g_ctx;
+    eao_status st = eao::require_device();
+    if (st) return st;
+    if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    const int n = F->n, nq = (int)q.size();
+    L.start.assign(nq, 0); L.count.assign(nq, 0); L.items.clear();
+    if (n == 0 || nq == 0) return EAO_OK;
+    EAO_REQUIRE(n < 65536, "at most 65535 keypoints per frame (indices are packed in 16 bits)");
+    // grid order: PosInGrid (src/Frame.cc:751-761) then cell column-major, insertion (= index) order inside a cell
+    struct Ord { int cx, cy, i; };
+    std::vector<Ord> ord;
+    ord.reserve(n);
+    for (int i = 0; i < n; i++) {
+        const int px = (int)std::round((F->kp_x[i] - F->min_x) * F->grid_inv_w);
+        const int py = (int)std::round((F->kp_y[i] - F->min_y) * F->grid_inv_h);
+        if (px < 0 || px >= F->grid_cols || py < 0 || py >= F->grid_rows) continue;
+        ord.push_back({px, py, i});
+    }
+    std::sort(ord.begin(), ord.end(), [](const Ord& a, const Ord& b) {
+        return a.cx != b.cx ? a.cx < b.cx : (a.cy != b.cy ? a.cy < b.cy : a.i < b.i);
+    });
+    const int no = (int)ord.size();
+    // one staging block: kx ky ur (float n) | oct (int n) | order (int no) | cellx celly (u16 no) | desc (32 n) | queries | qdesc
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    const size_t oKx = off; off = al(off + 4 * (size_t)n);
+    const size_t oKy = off; off = al(off + 4 * (size_t)n);
+    const size_t oUr = off; off = al(off + 4 * (size_t)n);
+    const size_t oOc = off; off = al(off + 4 * (size_t)n);
+    const size_t oOr = off; off = al(off + 4 * (size_t)std::max(no, 1));
+    const size_t oCx = off; off = al(off + 2 * (size_t)std::max(no, 1));
+    const size_t oCy = off; off = al(off + 2 * (size_t)std::max(no, 1));
+    const size_t oDe = off; off = al(off + 32 * (size_t)n);
+    const size_t oQ = off; off = al(off + sizeof(Query) * (size_t)nq);
+    const size_t oQd = off; off = al(off + 32 * (size_t)nq);
+    c.host.resize(off);
+    unsigned char* hb = c.host.data();
+    std::memcpy(hb + oKx, F->kp_x, 4 * (size_t)n); std::memcpy(hb + oKy, F->kp_y, 4 * (size_t)n);
+    std::memcpy(hb + oUr, F->u_right, 4 * (size_t)n); std::memcpy(hb + oOc, F->kp_octave, 4 * (size_t)n);
+    for (int k = 0; k < no; k++) {
+        ((int*)(hb + oOr))[k] = ord[k].i;
+        ((unsigned short*)(hb + oCx))[k] = (unsigned short)ord[k].cx;
+        ((unsigned short*)(hb + oCy))[k] = (unsigned short)ord[k].cy;
+    }
+    std::memcpy(hb + oDe, F->descriptors, 32 * (size_t)n);
+    std::memcpy(hb + oQ, q.data(), sizeof(Query) * (size_t)nq);
+    std::memcpy(hb + oQd, qdesc, 32 * (size_t)nq);
+    if ((st = c.dev.reserve(off))) return st;
+    const size_t outCap = (size_t)nq * std::max(no, 1);
+    if ((st = c.out.reserve(outCap))) return st;
+    if ((st = c.meta.reserve(2 * (size_t)nq + 1))) return st;
+    hipStream_t s = c.stream;
+    EAO_HIP(hipMemcpyAsync(c.dev.p, hb, off, hipMemcpyHostToDevice, s));
+    EAO_HIP(hipMemsetAsync(c.meta.p + 2 * (size_t)nq, 0, sizeof(int), s));
+    FrameDev D;
+    D.n = n; D.nOrdered = no;
+    D.kx = (const float*)(c.dev.p + oKx); D.ky = (const float*)(c.dev.p + oKy); D.ur = (const float*)(c.dev.p + oUr);
+    D.oct = (const int*)(c.dev.p + oOc); D.order = (const int*)(c.dev.p + oOr);
+    D.cellx = (const unsigned short*)(c.dev.p + oCx); D.celly = (const unsigned short*)(c.dev.p + oCy);
+    D.desc = (const uint4*)(c.dev.p + oDe);
+    D.minX = F->min_x; D.minY = F->min_y; D.invW = F->grid_inv_w; D.invH = F->grid_inv_h; D.cols = F->grid_cols; D.rows = F->grid_rows;
+    hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, (const Query*)(c.dev.p + oQ),
+                       (const uint4*)(c.dev.p + oQd), nq, c.out.p, (int)std::min(outCap, (size_t)0x7FFFFFFF), c.meta.p, c.meta.p + nq,
+                       c.meta.p + 2 * (size_t)nq);
+    std::vector<int> meta(2 * (size_t)nq + 1);
+    EAO_HIP(hipMemcpyAsync(meta.data(), c.meta.p, meta.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(hipGetLastError());
+    const int totalItems = meta[2 * (size_t)nq];
+    L.items.resize(std::max(totalItems, 0));
+    if (totalItems > 0) EAO_HIP(hipMemcpy(L.items.data(), c.out.p, (size_t)totalItems * sizeof(unsigned), hipMemcpyDeviceToHost));
+    for (int k = 0; k < nq; k++) { L.start[k] = meta[k]; L.count[k] = meta[nq + k]; }
+    return EAO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+eao_status eao_search_by_projection_points(const eao_frame_view* F, int32_t n_mp, const float* proj_x, const float* proj_y,
+                                           const float* proj_xr, const float* view_cos, const int32_t* pred_level,
+                                           const uint8_t* mp_desc, const uint8_t* skip, float th, float nnratio,
+                                           int32_t* match_kp, int32_t* nmatches) {
+    EAO_REQUIRE(F && match_kp && nmatches && n_mp >= 0, "null argument");
+    EAO_REQUIRE(n_mp == 0 || (proj_x && proj_y && proj_xr && view_cos && pred_level && mp_desc), "null map-point arrays");
+    EAO_REQUIRE(F->n == 0 || (F->kp_x && F->kp_y && F->kp_octave && F->u_right && F->descriptors && F->scale_factors), "incomplete frame view");
+    const bool bFactor = th != 1.0;
+    std::vector<Query> q(n_mp);
+    std::vector<float> rs(n_mp, 0.f);
+    for (int m = 0; m < n_mp; m++) {
+        Query& Q = q[m];
+        Q.active = !(skip && skip[m]);
+        const int lvl = pred_level[m];
+        if (Q.active) EAO_REQUIRE(lvl >= 0 && lvl < F->nlevels, "map point %d: predicted level %d out of range", m, lvl);
+        float r = view_cos[m] > 0.998 ? 2.5f : 4.0f;          // RadiusByViewingCos, :131-137
+        if (bFactor) r *= th;
+        rs[m] = Q.active ? r * F->scale_factors[lvl] : 0.f;
+        Q.x = proj_x[m]; Q.y = proj_y[m]; Q.r = rs[m];
+        Q.minLevel = lvl - 1; Q.maxLevel = lvl;
+        Q.urRef = proj_xr[m]; Q.urTol = rs[m];
+    }
+    Lists L;
+    eao_status st = build_lists(F, q, mp_desc, L);
+    if (st) return st;
+    std::vector<uint8_t> occ(F->n, 0);
+    if (F->occupied) std::memcpy(occ.data(), F->occupied, F->n);
+    int nm = 0;
+    for (int m = 0; m < n_mp; m++) {   // upstream's loop, :51-126
+        match_kp[m] = -1;
+        if (!q[m].active || L.count[m] == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        const unsigned* it = &L.items[L.start[m]];
+        for (int k = 0; k < L.count[m]; k++) {
+            const int i = (int)(it[k] & 0xFFFF), d = (int)(it[k] >> 16);
+            if (occ[i]) continue;
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = F->kp_octave[i]; bestIdx = i; }
+            else if (d < bestDist2) { bestLevel2 = F->kp_octave[i]; bestDist2 = d; }
+        }
+        if (bestDist <= 100) {   // TH_HIGH
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            match_kp[m] = bestIdx;
+            occ[bestIdx] = 1;
+            nm++;
+        }
+    }
+    *nmatches = nm;
+    return EAO_OK;
+}
+
+eao_status eao_search_by_projection_frames(const eao_frame_view* C, const float* Tcw, const float* Tlw, int32_t n_last,
+                                           const uint8_t* valid, const float* Xw, const uint8_t* mp_desc, const int32_t* last_octave,
+                                           const float* last_angle, float fx, float fy, float cx, float cy, float mbf, float mb,
+                                           float th, int32_t mono, int32_t check_orientation, int32_t* cur_match, int32_t* nmatches) {
+    EAO_REQUIRE(C && Tcw && Tlw && cur_match && nmatches && n_last >= 0, "null argument");
+    EAO_REQUIRE(n_last == 0 || (valid && Xw && mp_desc && last_octave && last_angle), "null last-frame arrays");
+    EAO_REQUIRE(C->n == 0 || (C->kp_x && C->kp_y && C->kp_octave && C->kp_angle && C->u_right && C->descriptors && C->scale_factors), "incomplete frame view");
+    for (int i = 0; i < C->n; i++) cur_match[i] = -1;
+    // relative motion along the optical axis decides the level window (:1343-1347); float matrices, double accumulation
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++) {
+        double sacc = 0;
+        for (int k = 0; k < 3; k++) sacc += (double)(-Tcw[k * 4 + i]) * (double)Tcw[k * 4 + 3];
+        twc[i] = (float)sacc;
+    }
+    for (int i = 0; i < 3; i++) {
+        double sacc = 0;
+        for (int k = 0; k < 3; k++) sacc += (double)Tlw[i * 4 + k] * (double)twc[k];
+        tlc[i] = (float)(sacc + (double)Tlw[i * 4 + 3]);
+    }
+    const bool bForward = tlc[2] > mb && !mono;
+    const bool bBackward = -tlc[2] > mb && !mono;
+    std::vector<Query> q(n_last);
+    for (int i = 0; i < n_last; i++) {
+        Query& Q = q[i];
+        Q.active = 0; Q.x = Q.y = Q.r = 0; Q.minLevel = 0; Q.maxLevel = -1; Q.urRef = 0; Q.urTol = 0;
+        if (!valid[i]) continue;
+        float xc3[3];
+        for (int r = 0; r < 3; r++) {
+            double sacc = 0;
+            for (int k = 0; k < 3; k++) sacc += (double)Tcw[r * 4 + k] * (double)Xw[3 * i + k];
+            xc3[r] = (float)(sacc + (double)Tcw[r * 4 + 3]);
+        }
+        const float invzc = (float)(1.0 / xc3[2]);
+        if (invzc < 0) continue;
+        const float u = fx * xc3[0] * invzc + cx, v = fy * xc3[1] * invzc + cy;
+        if (u < C->min_x || u > C->max_x) continue;
+        if (v < C->min_y || v > C->max_y) continue;
+        const int oct = last_octave[i];
+        EAO_REQUIRE(oct >= 0 && oct < C->nlevels, "last-frame keypoint %d: octave %d out of range", i, oct);
+        const float radius = th * C->scale_factors[oct];
+        Q.active = 1; Q.x = u; Q.y = v; Q.r = radius;
+        if (bForward) { Q.minLevel = oct; Q.maxLevel = -1; }
+        else if (bBackward) { Q.minLevel = 0; Q.maxLevel = oct; }
+        else { Q.minLevel = oct - 1; Q.maxLevel = oct + 1; }
+        Q.urRef = u - mbf * invzc; Q.urTol = radius;
+    }
+    Lists L;
+    eao_status st = build_lists(C, q, mp_desc, L);
+    if (st) return st;
+    std::vector<uint8_t> occ(C->n, 0);
+    if (C->occupied) std::memcpy(occ.data(), C->occupied, C->n);
+    constexpr int HISTO = 30;                      // HISTO_LENGTH
+    std::vector<int> rotHist[HISTO];
+    const float factor = HISTO / 360.0f;          // this fork's histogram factor for this routine (:1337)
+    int nm = 0;
+    for (int i = 0; i < n_last; i++) {
+        if (!q[i].active || L.count[i] == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        const unsigned* it = &L.items[L.start[i]];
+        for (int k = 0; k < L.count[i]; k++) {
+            const int i2 = (int)(it[k] & 0xFFFF), d = (int)(it[k] >> 16);
+            if (occ[i2]) continue;
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= 100) {
+            cur_match[bestIdx2] = i;
+            occ[bestIdx2] = 1;
+            nm++;
+            if (check_orientation) {
+                float rot = last_angle[i] - C->kp_angle[bestIdx2];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO) bin = 0;
+                if (bin >= 0 && bin < HISTO) rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {   // keep the three fullest bins (ComputeThreeMaxima, :1603-1644)
+        int top[3] = {0, 0, 0}, ind[3] = {-1, -1, -1};
+        for (int b = 0; b < HISTO; b++) {
+            const int pop = (int)rotHist[b].size();
+            for (int rk = 0; rk < 3; rk++)
+                if (pop > top[rk]) {
+                    for (int z = 2; z > rk; z--) { top[z] = top[z - 1]; ind[z] = ind[z - 1]; }
+                    top[rk] = pop; ind[rk] = b;
+                    break;
+                }
+        }
+        const float floor10 = 0.1f * (float)top[0];
+        if (top[1] < floor10) { ind[1] = -1; ind[2] = -1; }
+        else if (top[2] < floor10) ind[2] = -1;
+        for (int b = 0; b < HISTO; b++)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (int k : rotHist[b]) { cur_match[k] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return EAO_OK;
+}
+
+}  // extern "C"

@@ -37,7 +37,7 @@ constexpr int kTile = 72;              // max FAST sub-image edge (cell <= 60 px
 constexpr int kTileStride = 80;        // LDS row stride of the tile: 72 + up to 3 bytes of alignment phase, multiple of 4
 constexpr int kMaxIni = 16;
 
-__constant__ signed char c_pattern[1024] = {
+__constant__ __align__(16) signed char c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 
@@ -686,6 +686,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
                                                          int* __restrict__ nout, int cap, int f0) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int f = blockIdx.y + f0;
+    // the lane's four test pairs (xa, ya, xb, yb as int8) depend on nothing: fetch them first, under the other loads
+    unsigned pat[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const unsigned*>(c_pattern)[lane + 64 * k];
     int j = blockIdx.x * 4 + wv;   // compact output index inside the frame
     const int jout = j;
     int l = -1, total = 0;
@@ -737,9 +741,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     unsigned long long words[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int p = (lane + 64 * k) * 4;
-        const float xa = (float)c_pattern[p], ya = (float)c_pattern[p + 1];
-        const float xb = (float)c_pattern[p + 2], yb = (float)c_pattern[p + 3];
+        const float xa = (float)(signed char)(pat[k] & 0xFF), ya = (float)(signed char)((pat[k] >> 8) & 0xFF);
+        const float xb = (float)(signed char)((pat[k] >> 16) & 0xFF), yb = (float)(signed char)(pat[k] >> 24);
         const int ra = __float2int_rn(xa * b + ya * a), ca = __float2int_rn(xa * a - ya * b);
         const int rb = __float2int_rn(xb * b + yb * a), cb = __float2int_rn(xb * a - yb * b);
         const int t0 = bc[(long long)ra * L.pitch + ca], t1 = bc[(long long)rb * L.pitch + cb];

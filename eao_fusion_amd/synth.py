@@ -166,3 +166,51 @@ def synth_pose(n=1000, seed=4000, sigma=1.0, outlier_frac=0.1, mono_frac=0.3):
     return dict(Tcw=T.astype(np.float32), Tcw_gt=Tgt.astype(np.float32), points=pts.astype(np.float32),
                 obs=obs.astype(np.float32), inv_sigma2=inv_sigma2,
                 fx=np.float32(FX), fy=np.float32(FY), cx=np.float32(CX), cy=np.float32(CY), bf=np.float32(BF))
+
+
+def synth_tracking(n=1000, seed=7000, flip=0.06, moved=0.03, mono_frac=0.3, occupied_frac=0.05):
+    """A tracked frame pair for the guided matchers (SearchByProjection): `n` map points seen by the LAST frame, the
+    CURRENT frame sees them from a slightly moved pose at noisy pixel positions (plus 10% clutter keypoints), each
+    with the last descriptor corrupted by `flip` bit noise.  Returns (cur, last, mps): the frame view of the
+    current frame, the last-frame arrays, and the in-view map-point arrays (TrackLocalMap query form)."""
+    rng = np.random.default_rng(seed)
+    scale = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)])).astype(np.float32)
+    Xw = np.empty((n, 3))
+    Xw[:, 2] = rng.uniform(2.0, 6.0, n)
+    Xw[:, 0] = rng.uniform(-0.5, 0.5, n) * Xw[:, 2]
+    Xw[:, 1] = rng.uniform(-0.4, 0.4, n) * Xw[:, 2]
+    Tl = np.eye(4)
+    Tc = np.eye(4)
+    Tc[:3, :3] = _rot(0.01, -0.015, 0.005)
+    Tc[:3, 3] = [0.02, -0.01, -moved]
+    Tl32, Tc32 = Tl.astype(np.float32), Tc.astype(np.float32)
+    Xc = Xw @ Tc[:3, :3].T + Tc[:3, 3]
+    u = FX * Xc[:, 0] / Xc[:, 2] + CX
+    v = FY * Xc[:, 1] / Xc[:, 2] + CY
+    octave = rng.integers(0, 8, n).astype(np.int32)
+    desc_last = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    angle_last = rng.uniform(0, 360, n).astype(np.float32)
+    n_clutter = n // 10
+    N = n + n_clutter
+    perm = rng.permutation(N)
+    kx = np.concatenate([u + rng.normal(0, 1.5, n) * scale[octave], rng.uniform(0, 640, n_clutter)])
+    ky = np.concatenate([v + rng.normal(0, 1.5, n) * scale[octave], rng.uniform(0, 480, n_clutter)])
+    koct = np.concatenate([np.clip(octave + rng.integers(-1, 2, n), 0, 7), rng.integers(0, 8, n_clutter)]).astype(np.int32)
+    bits = np.unpackbits(desc_last, axis=1) ^ (rng.random((n, 256)) < flip).astype(np.uint8)
+    kdesc = np.concatenate([np.packbits(bits, axis=1), rng.integers(0, 256, (n_clutter, 32), dtype=np.uint8)])
+    kang = np.concatenate([(angle_last + 12.0 + rng.normal(0, 3, n)) % 360, rng.uniform(0, 360, n_clutter)]).astype(np.float32)
+    ur_true = np.concatenate([u - BF / Xc[:, 2] + rng.normal(0, 1.0, n), rng.uniform(0, 600, n_clutter)])
+    mono = rng.random(N) < mono_frac
+    ur = np.where(mono, -1.0, np.maximum(ur_true, 0.5))
+    occ = (rng.random(N) < occupied_frac).astype(np.uint8)
+    cur = dict(kp_x=kx[perm].astype(np.float32), kp_y=ky[perm].astype(np.float32), kp_octave=koct[perm], kp_angle=kang[perm],
+               u_right=ur[perm].astype(np.float32), descriptors=np.ascontiguousarray(kdesc[perm]), occupied=occ[perm],
+               min_x=np.float32(0), min_y=np.float32(0), max_x=np.float32(640), max_y=np.float32(480), scale_factors=scale,
+               Tcw=Tc32, fx=np.float32(FX), fy=np.float32(FY), cx=np.float32(CX), cy=np.float32(CY), mbf=np.float32(BF),
+               mb=np.float32(BF / FX))
+    valid = (rng.random(n) < 0.9).astype(np.uint8)
+    last = dict(Tcw=Tl32, valid=valid, Xw=Xw.astype(np.float32), descriptors=desc_last, octave=octave, angle=angle_last)
+    view_cos = np.where(rng.random(n) < 0.5, 0.9995, 0.97).astype(np.float32)
+    mps = dict(proj_x=u.astype(np.float32), proj_y=v.astype(np.float32), proj_xr=(u - BF / Xc[:, 2]).astype(np.float32),
+               view_cos=view_cos, level=octave, descriptors=desc_last, skip=(rng.random(n) < 0.1).astype(np.uint8))
+    return cur, last, mps

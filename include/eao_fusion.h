@@ -136,6 +136,53 @@ eao_status eao_hamming_best2_device(const uint8_t* d_A, int32_t na, const uint8_
                                     const uint8_t* d_mask, eao_best2* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Guided matching -- ORBmatcher::SearchByProjection, the two per-frame tracking variants
+ *   (Frame&, const vector<MapPoint*>&, th)          reference src/ORBmatcher.cc:45-129   (TrackLocalMap)
+ *   (Frame& Cur, const Frame& Last, th, bMono)      reference src/ORBmatcher.cc:1328-1472 (TrackWithMotionModel)
+ * with Frame::GetFeaturesInArea / PosInGrid (src/Frame.cc:696-761) as the candidate generator.  The device builds,
+ * for every query, the candidate list (keypoint index, Hamming distance) in the reference's candidate ORDER (grid cell
+ * column-major, then insertion order) with every geometric / level / stereo gate applied; the greedy assignment
+ * ("skip keypoints that already hold a map point", best / second-best, ratio test, rotation histogram) is replayed
+ * on the host inside the library, query by query, exactly as upstream's loops run.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n;                   /* Frame::N */
+    const float* kp_x;           /* mvKeysUn[i].pt.x */
+    const float* kp_y;
+    const int32_t* kp_octave;    /* mvKeysUn[i].octave */
+    const float* kp_angle;       /* mvKeysUn[i].angle (rotation histogram) */
+    const float* u_right;        /* mvuRight[i] */
+    const uint8_t* descriptors;  /* mDescriptors: n x 32 */
+    const uint8_t* occupied;     /* n: mvpMapPoints[i] != NULL && Observations() > 0 on entry (may be NULL = none) */
+    float min_x, min_y, max_x, max_y;   /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    float grid_inv_w, grid_inv_h;       /* mfGridElementWidthInv, mfGridElementHeightInv */
+    int32_t grid_cols, grid_rows;       /* FRAME_GRID_COLS, FRAME_GRID_ROWS (64 x 48 upstream) */
+    const float* scale_factors;         /* mvScaleFactors */
+    int32_t nlevels;
+} eao_frame_view;
+
+/* SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th): map points that are in view.
+ * Per map point: mTrackProjX/Y/XR, mTrackViewCos, mnTrackScaleLevel, GetDescriptor(), and skip[i] != 0 where upstream
+ * `continue`s (!mbTrackInView || isBad()).  match_kp[i] receives the keypoint index the point was assigned to or -1;
+ * the return value of the reference is *nmatches.  A keypoint assigned during the call counts as occupied afterwards
+ * (upstream: F.mvpMapPoints[idx]->Observations() > 0 for a point of the local map). */
+eao_status eao_search_by_projection_points(const eao_frame_view* F, int32_t n_mp, const float* proj_x, const float* proj_y,
+                                           const float* proj_xr, const float* view_cos, const int32_t* pred_level,
+                                           const uint8_t* mp_desc, const uint8_t* skip, float th, float nnratio,
+                                           int32_t* match_kp, int32_t* nmatches);
+
+/* SearchByProjection(Frame& Cur, const Frame& Last, th, bMono).  Per last-frame keypoint i: valid[i] != 0 where
+ * LastFrame.mvpMapPoints[i] != NULL && !mvbOutlier[i]; Xw = GetWorldPos(); mp_desc = GetDescriptor(); last_octave =
+ * LastFrame.mvKeys[i].octave; last_angle = LastFrame.mvKeysUn[i].angle.  Tcw_cur / Tcw_last: 16 floats row-major.
+ * cur_match[k] (Cur->n entries) receives the last-frame index assigned to current keypoint k or -1 (after the rotation
+ * consistency filter when check_orientation != 0). */
+eao_status eao_search_by_projection_frames(const eao_frame_view* Cur, const float* Tcw_cur, const float* Tcw_last,
+                                           int32_t n_last, const uint8_t* valid, const float* Xw, const uint8_t* mp_desc,
+                                           const int32_t* last_octave, const float* last_angle, float fx, float fy, float cx,
+                                           float cy, float mbf, float mb, float th, int32_t mono, int32_t check_orientation,
+                                           int32_t* cur_match, int32_t* nmatches);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer::PoseOptimization(Frame*) -- reference include/Optimizer.h:56, src/Optimizer.cc:325-673
  * (point/stereo edges; plane edges src/Optimizer.cc:456-535 are not part of this entry point)
  * ------------------------------------------------------------------------------------------------ */

@@ -79,6 +79,8 @@ def lib():
         L.orc_se3_oplus.argtypes = [C.c_void_p] * 3
         L.orc_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
         L.orc_Tcw_to_cam7.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_search_by_projection_points.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_void_p]
+        L.orc_search_by_projection_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 7 + [C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -237,3 +239,56 @@ def local_ba(prob, its=(5, 10), stop=None):
     rc = lib().orc_local_ba(C.byref(P), stop_p, _p(cams_out), _p(pts_out), _p(outl), _p(cams_d), _p(pts_d), _p(iters), C.byref(tr))
     return dict(poses=cams_out, points=pts_out, edge_outlier=outl[:len(ec)], cams_d=cams_d, points_d=pts_d,
                 iters=iters, trace=tr.to_dict(), aborted=bool(rc))
+
+
+class FrameView(C.Structure):   # same layout as eao_frame_view
+    _fields_ = [("n", C.c_int32), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p), ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p),
+                ("u_right", C.c_void_p), ("descriptors", C.c_void_p), ("occupied", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("grid_cols", C.c_int32), ("grid_rows", C.c_int32),
+                ("scale_factors", C.c_void_p), ("nlevels", C.c_int32)]
+
+
+def _frame_view(frame):
+    keep = {}
+    for k, dt in (("kp_x", np.float32), ("kp_y", np.float32), ("kp_octave", np.int32), ("kp_angle", np.float32),
+                  ("u_right", np.float32), ("descriptors", np.uint8), ("scale_factors", np.float32)):
+        keep[k] = np.ascontiguousarray(frame[k], dt)
+    occ = frame.get("occupied")
+    keep["occupied"] = None if occ is None else np.ascontiguousarray(occ, np.uint8)
+    cols, rows = int(frame.get("grid_cols", 64)), int(frame.get("grid_rows", 48))
+    inv_w = np.float32(cols) / np.float32(np.float32(frame["max_x"]) - np.float32(frame["min_x"]))
+    inv_h = np.float32(rows) / np.float32(np.float32(frame["max_y"]) - np.float32(frame["min_y"]))
+    v = FrameView(len(keep["kp_x"]), _p(keep["kp_x"]), _p(keep["kp_y"]), _p(keep["kp_octave"]), _p(keep["kp_angle"]), _p(keep["u_right"]),
+                  _p(keep["descriptors"]), _p(keep["occupied"]), frame["min_x"], frame["min_y"], frame["max_x"], frame["max_y"],
+                  inv_w, inv_h, cols, rows, _p(keep["scale_factors"]), len(keep["scale_factors"]))
+    return v, keep
+
+
+def search_by_projection_points(frame, mps, th, nnratio):
+    v, keep = _frame_view(frame)
+    a = {k: np.ascontiguousarray(mps[k], np.float32) for k in ("proj_x", "proj_y", "proj_xr", "view_cos")}
+    lvl = np.ascontiguousarray(mps["level"], np.int32)
+    desc = np.ascontiguousarray(mps["descriptors"], np.uint8)
+    skip = mps.get("skip")
+    skip = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+    out = np.full(len(lvl), -1, np.int32)
+    nm = lib().orc_search_by_projection_points(C.byref(v), len(lvl), _p(a["proj_x"]), _p(a["proj_y"]), _p(a["proj_xr"]), _p(a["view_cos"]),
+                                               _p(lvl), _p(desc), _p(skip), th, nnratio, _p(out))
+    return nm, out
+
+
+def search_by_projection_frames(cur, last, th, mono, check_orientation=True):
+    v, keep = _frame_view(cur)
+    Tc = np.ascontiguousarray(cur["Tcw"], np.float32)
+    Tl = np.ascontiguousarray(last["Tcw"], np.float32)
+    valid = np.ascontiguousarray(last["valid"], np.uint8)
+    Xw = np.ascontiguousarray(last["Xw"], np.float32)
+    desc = np.ascontiguousarray(last["descriptors"], np.uint8)
+    octv = np.ascontiguousarray(last["octave"], np.int32)
+    ang = np.ascontiguousarray(last["angle"], np.float32)
+    out = np.full(v.n, -1, np.int32)
+    nm = lib().orc_search_by_projection_frames(C.byref(v), _p(Tc), _p(Tl), len(valid), _p(valid), _p(Xw), _p(desc), _p(octv), _p(ang),
+                                               cur["fx"], cur["fy"], cur["cx"], cur["cy"], cur["mbf"], cur["mb"], th, 1 if mono else 0,
+                                               1 if check_orientation else 0, _p(out))
+    return nm, out
