@@ -17,6 +17,14 @@ struct KeyFrame;
 struct MapPoint {
     static std::mutex mGlobalMutex;
     long unsigned int mnId = 0, mnBALocalForKF = ~0ul;
+    // tracking members read by ORBmatcher::SearchByProjection
+    bool mbTrackInView = true;
+    int mnTrackScaleLevel = 0;
+    float mTrackViewCos = 1.f, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
+    cv::Mat descriptor;
+    int nObs = 1;
+    cv::Mat GetDescriptor() { return descriptor.clone(); }
+    int Observations() { return nObs; }
     cv::Mat pos;
     std::map<KeyFrame*, size_t> observations;
     int normalUpdates = 0;
@@ -50,6 +58,11 @@ struct KeyFrame {
 struct Map { std::mutex mMutexMapUpdate; };
 struct Frame {
     int N = 0;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+    std::vector<cv::KeyPoint> mvKeys;
+    cv::Mat mDescriptors;
+    std::vector<float> mvScaleFactors;
+    float mb = 0;
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<float> mvuRight, mvInvLevelSigma2;
@@ -58,6 +71,9 @@ struct Frame {
     float fx, fy, cx, cy, mbf;
     void SetPose(cv::Mat T) { mTcw = T.clone(); }
 };
+
+float Frame::mnMinX = 0, Frame::mnMaxX = 640, Frame::mnMinY = 0, Frame::mnMaxY = 480;
+float Frame::mfGridElementWidthInv = 64.f / 640.f, Frame::mfGridElementHeightInv = 48.f / 480.f;
 
 template <typename T> static void rd(std::ifstream& f, T* p, size_t n) { f.read(reinterpret_cast<char*>(p), n * sizeof(T)); }
 template <typename T> static void wr(std::ofstream& f, const T* p, size_t n) { f.write(reinterpret_cast<const char*>(p), n * sizeof(T)); }
@@ -88,6 +104,26 @@ int main(int argc, char** argv) {
     extractor(empty, cv::Mat(), untouched, descriptors);   // empty image: outputs untouched
     int32_t stillThree = (int32_t)untouched.size();
     wr(out, &stillThree, 1);
+    // ---------------------------------------------------------------- ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)
+    {
+        Frame TF;                                   // the extracted keypoints ARE the frame; each becomes a map point to re-find
+        TF.N = nk; TF.mvKeysUn = keys; TF.mvKeys = keys; TF.mDescriptors = descriptors.clone();
+        TF.mvuRight.assign(nk, -1.f); TF.mvpMapPoints.assign(nk, nullptr); TF.mvbOutlier.assign(nk, false);
+        TF.mvScaleFactors = extractor.GetScaleFactors();
+        std::vector<MapPoint> tmps(nk);
+        std::vector<MapPoint*> vp;
+        for (int i = 0; i < nk; i++) {
+            tmps[i].mTrackProjX = keys[i].pt.x + 0.5f; tmps[i].mTrackProjY = keys[i].pt.y - 0.5f; tmps[i].mTrackProjXR = -1.f;
+            tmps[i].mnTrackScaleLevel = keys[i].octave; tmps[i].mTrackViewCos = 0.9999f;
+            tmps[i].descriptor = descriptors.row(i).clone();
+            vp.push_back(&tmps[i]);
+        }
+        ORB_SLAM2::ORBmatcher matcher(0.8f, true);
+        int32_t nm = matcher.SearchByProjection(TF, vp, 1.0f);
+        int32_t selfHits = 0;
+        for (int i = 0; i < nk; i++) selfHits += (TF.mvpMapPoints[i] == &tmps[i]);
+        wr(out, &nm, 1); wr(out, &selfHits, 1);
+    }
     // ---------------------------------------------------------------- Optimizer::PoseOptimization(Frame*)
     int32_t n;
     rd(in, &n, 1);

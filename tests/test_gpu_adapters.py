@@ -59,6 +59,9 @@ def test_cpp_adapters_end_to_end(tmp_path):
     assert list(pyr) == [480, 640, 179]               # mvImagePyramid[l] is the w x h view (border lives around it)
     assert dd == int(np.unpackbits(desc[0] ^ desc[1]).sum())
     assert untouched == 3
+    # ---- ORBmatcher::SearchByProjection over the extractor's own keypoints: (almost) every point re-finds itself
+    nm, self_hits = (int(x) for x in take(np.int32, 2))
+    assert nm > 0.9 * nk and self_hits > 0.9 * nm
     # ---- PoseOptimization
     inl = int(take(np.int32, 1)[0])
     Tcw = take(np.float32, 16).reshape(4, 4)
