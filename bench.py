@@ -127,8 +127,18 @@ def main():
     }
     dom = max(stage_bytes, key=lambda k: stage_ms[k])
     achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of
+    # this same command; profiles/r01_pmc_traffic.json explains the calibration) -- per launch, like `achieved`
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pmc.get("batch") == B and dom in pmc["kernels"]:
+            k = pmc["kernels"][dom]
+            traffic = int(k["hbm_bytes_per_launch"]) * int(k.get("launches_per_step", 1))
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(stage_bytes[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                 "pipeline_GBps": round(sum(stage_bytes.values()) / (stage_ms["total"] * 1e-3) / 1e9, 2)}
@@ -214,6 +224,17 @@ def measure_extra(E, synth, torch, dev):
                        "ba_residual_blocks_per_s": round(E_ * (lin / reps) / wall, 1),
                        "ba_scalar_residuals_per_s": round(3 * E_ * (lin / reps) / wall, 1),
                        "achieved_GBps": round((lin / reps) * (E_ * 520 + 3000 * 360) / wall / 1e9, 3), "iters": [int(x) for x in r["iters"]]}
+        # guided matching of one tracked frame (the two SearchByProjection variants of the tracking loop)
+        curf, lastf, mpsf = synth.synth_tracking()
+        mt = E.ORBmatcher(0.8, True)
+        mt.SearchByProjectionPoints(curf, mpsf, 1.0)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            nm1, _m = mt.SearchByProjectionPoints(curf, mpsf, 1.0)
+            nm2, _m = mt.SearchByProjectionFrames(curf, lastf, 7.0, False)
+        extra["guided_matching"] = {"ms_per_frame_both_searches": round((time.perf_counter() - t0) / 20 * 1e3, 3),
+                                    "matches": [int(nm1), int(nm2)], "keypoints": int(len(curf["kp_x"])),
+                                    "note": "host buffers in/out, includes H2D/D2H and the host replay of the greedy assignment"}
         pp = synth.synth_pose()
         E.Optimizer.PoseOptimization(pp)
         t0 = time.perf_counter()
@@ -265,6 +286,21 @@ def measure_cpu(frames, synth, extra):
             reps += 1
         dt = (time.perf_counter() - t0) / reps
         ex["cpu_hamming_matrix"] = {"pair_distances_per_s": round(1e6 / dt, 1), "cores": 1, "kind": "port"}
+        curf, lastf, mpsf = synth.synth_tracking()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            O.search_by_projection_points(curf, mpsf, 1.0, 0.8)
+            O.search_by_projection_frames(curf, lastf, 7.0, False, True)
+            reps += 1
+        ex["cpu_guided_matching"] = {"ms_per_frame_both_searches": round((time.perf_counter() - t0) / reps * 1e3, 3), "cores": 1, "kind": "port"}
+        pp = synth.synth_pose()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            O.pose_optimization(pp)
+            reps += 1
+        ex["cpu_pose_optimization_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
     except Exception as e:  # noqa: BLE001
         ex["cpu_extra_error"] = repr(e)
     return cpu, ex
