@@ -6,21 +6,25 @@
 // core/block_solver.hpp:354-604, types/types_six_dof_expmap.cpp, types/se3quat.h).  g2o's object graph is
 // not reproduced; the maths is re-decomposed for the GPU:
 //
-//  PoseOptimization  : ONE persistent 1024-thread workgroup runs all 4 rounds x <=10 LM iterations x <=10
+//  PoseOptimization  : ONE persistent 512-thread workgroup runs all 4 rounds x <=10 LM iterations x <=10
 //                      trials on the device (no host round trip): per-edge 2x6/3x6 Jacobians in registers,
 //                      fixed-order shuffle/LDS reductions of the 28 accumulators, 6x6 LDLT by lane 0.
 //  LocalBundleAdjustment : multi-workgroup kernels per LM trial, all reductions in a fixed order
-//      k_ba_linearize   role A (one thread per map point): residual Jacobians, Hll/bl, per-edge 6x3 Hpl blocks
-//                       role B (one workgroup per free camera): Hpp/bp by a fixed-order tree over its edges
+//      k_ba_linearize   role A (eight lanes per map point, one edge per lane): residual Jacobians, Hll/bl, per-edge 6x3
+//                       Hpl blocks; role B (one workgroup per free camera): Hpp/bp by a fixed-order tree over its edges
 //      k_ba_schur       one workgroup per (free camera, edge chunk): stages Y = Hpl (Hll+lambda I)^-1 in LDS, then thread
 //                       (i2,r,c) accumulates its element of -sum_l Y_{i1,l} Hpl_{i2,l}^T through a dense point x camera
 //                       edge table (no atomics, fixed order)
-//      k_ba_solve       6*nFree square blocked LDLT in LDS (1024 threads, 6-row panels), pose update exp(dx)*T
+//      k_ba_reduce_*    sums the partial Schur slabs (many workgroups: one CU alone pulls too little from L2)
+//      k_ba_solve_tiles the 6*nFree square system as register-resident 16x16 tiles: LDL^T in 4-column panels, trailing
+//                       update by v_mfma_f64_16x16x4_f64 (the ONE GEMM-shaped piece of the path), forward substitution
+//                       folded in as an extra matrix row, single-wave back substitution, pose update exp(dx)*T.
+//                       k_ba_solve (LDS / global scratch, 6-row panels, VALU) covers windows of more than 30 free keyframes
 //      k_ba_backsub     per point: x_l = Dinv (bl - Hpl^T x_p), new point, residuals + robust chi2 at the trial state
 //      k_ba_decide      fixed-order sums, rho, lambda / nu update; status lands in pinned host memory
-//  Blocks are 6x6 / 6x3 / 3x3: no MFMA shape fits; everything is fp64 VALU + LDS and the path is
-//  latency/bandwidth bound.  The host only sequences trials (one sync per trial) and polls the abort flag
-//  between iterations like g2o's forceStopFlag.
+//  The Jacobian blocks are 6x6 / 6x3 / 3x3 (no MFMA shape fits): fp64 VALU + LDS, latency/bandwidth bound.  LM state
+//  and control flow live on the device: the host enqueues all iterations of an optimize() call in bulk, syncs once, and
+//  replays an iteration trial by trial only when its first trial was rejected.
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
@@ -149,6 +153,11 @@ inline void se3_to_Tcw_f32(const SE3& s, float* T) {  // Converter::toCvMat(SE3Q
 }
 
 // 1/x by v_rcp_f64 + two Newton steps (~1 ulp): the solver's pivots
+// one Newton step on v_rcp_f64: ~2^-46 relative error (the hardware seed carries single-precision accuracy)
+__device__ inline double frcp1(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
 __device__ inline double frcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
@@ -1032,6 +1041,247 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveO
     if (P.dbg && t == 0) { P.dbg[8] = clock64(); P.dbg[9] = wall_clock64(); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile-resident solver (up to kTileMaxFree free keyframes): the dense Schur system sits in REGISTERS as 16x16 accumulator
+// tiles of v_mfma_f64_16x16x4_f64 (lower-triangle tiles, dealt round-robin to the 16 waves; lane l of a tile holds rows
+// (l>>4)+4*reg, column l&15), with the right-hand side as one extra matrix row so that the forward substitution is part
+// of the factorisation.  Right-looking LDL^T without pivoting in panels of FOUR columns (= the k extent of the MFMA):
+//   export   the tile column under the panel writes its four columns to LDS                           -> barrier
+//   panel    one thread per remaining row: factor the 4x4 diagonal block (redundantly, 10 broadcast reads), solve its
+//            row  w = a L_kk^-T,  l = w D^-1;  publish w and l (zero for finished rows), archive l    -> barrier
+//   update   every live tile: C -= W_tile L_tile^T, ONE MFMA, operands = one LDS double per lane each
+// Measured on MI355X a lone wave issues one fp64 VALU instruction per 8 cycles whatever the dependences, so the cost
+// of a step is its instruction count on the longest wave: ~90 for the panel thread, ~10 per tile for the update.
+// L is archived row-packed in LDS; the back substitution L^T x = z walks it bottom-up in blocks of four.
+constexpr int kTileMaxFree = 30;
+constexpr int kTileThreads = 1024;
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct TileGeom { int n, n4, R, Tr, Tc, nTiles; };
+__host__ __device__ inline TileGeom tile_geom(int nF) {
+    TileGeom g;
+    g.n = nF * 6; g.n4 = (g.n + 3) & ~3; g.R = g.n4 + 1;
+    g.Tr = (g.R + 15) >> 4; g.Tc = (g.n4 + 15) >> 4;
+    g.nTiles = g.Tc * g.Tr - g.Tc * (g.Tc - 1) / 2;      // column tj holds tile rows tj .. Tr-1
+    return g;
+}
+__host__ __device__ inline void tile_of(const TileGeom& g, int idx, int& ti, int& tj) {
+    int j = 0, off = 0;
+    while (idx >= off + (g.Tr - j)) { off += g.Tr - j; j++; }
+    tj = j; ti = j + (idx - off);
+}
+// L archive: row r (r = n4 is the right-hand side, i.e. z) starts at r (r - 1) / 2 + 4 r: r entries + 4 slack so that
+// the panel threads store their four values unconditionally
+__host__ __device__ inline int tile_lrow(int r) { return r * (r - 1) / 2 + 4 * r; }
+__host__ inline size_t tile_solver_lds(int nF) {
+    const TileGeom g = tile_geom(nF);
+    return ((size_t)((tile_lrow(g.n4 + 1) + 1) & ~1) + 3 * (size_t)g.Tr * 16 * 4 + (size_t)g.n4 + 8) * sizeof(double);
+}
+
+// Sum the partial slabs straight into the solver's register layout: [tile][reg][lane].
+__global__ __launch_bounds__(256) void k_ba_reduce_tiles(BADev P) {
+    if (P.ctl[kCtlHalt]) return;
+    const TileGeom g = tile_geom(P.nFree);
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= g.nTiles * 256) return;
+    const int idx = o >> 8, reg = (o >> 6) & 3, lane = o & 63;
+    int ti, tj;
+    tile_of(g, idx, ti, tj);
+    const int row = ti * 16 + (lane >> 4) + 4 * reg, col = tj * 16 + (lane & 15);
+    const int n = g.n;
+    const size_t slabStride = (size_t)n * n + n;
+    double v = 0;
+    if (row < n) {
+        if (col <= row) {
+            double part[kChunks];
+#pragma unroll
+            for (int ch = 0; ch < kChunks; ch++) part[ch] = P.slab[ch * slabStride + (size_t)col * n + row];   // stored upper (col,row)
+            const int bi = row / 6;
+            if (bi == col / 6) v = P.Hpp[(size_t)bi * 36 + (col - bi * 6) * 6 + (row - bi * 6)] + (row == col ? P.lm[0] : 0.0);
+#pragma unroll
+            for (int ch = 0; ch < kChunks; ch++) v += part[ch];
+        }
+    } else if (row < g.n4) {
+        v = (col == row) ? 1.0 : 0.0;                       // identity padding up to a multiple of four
+    } else if (row == g.n4 && col < n) {
+        double co = 0;
+#pragma unroll
+        for (int ch = 0; ch < kChunks; ch++) co += P.slab[ch * slabStride + (size_t)n * n + col];
+        v = P.bp[col] - co;
+    }
+    P.sys[o] = v;
+}
+
+template <int TPW>
+__global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(BADev P, int* solveOk) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int s_fail;
+    if (P.ctl[kCtlHalt]) return;
+    const TileGeom g = tile_geom(P.nFree);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: tile tests become scalar branches
+    constexpr int NW = kTileThreads / 64;
+    const int rowsPad = g.Tr * 16;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    double* Lall = sm;                                          // tile_lrow(): rows 0 .. n4 (row n4 = z)
+    double* sP = Lall + ((tile_lrow(g.n4 + 1) + 1) & ~1);       // [rowsPad][4] exported panel (16-byte aligned rows)
+    double* sW = sP + (size_t)rowsPad * 4;                      // [rowsPad][4]
+    double* sL = sW + (size_t)rowsPad * 4;                      // [rowsPad][4]
+    double* sx = sL + (size_t)rowsPad * 4;                      // n4
+    const bool stamp = P.dbg && t == 0;
+    long long acc0 = 0, acc1 = 0, acc2 = 0, ts = 0;
+    if (stamp) { P.dbg[0] = clock64(); P.dbg[1] = wall_clock64(); }
+    if (t == 0) s_fail = 0;
+    v4d c[TPW];
+    int tJ[TPW], aOff[TPW], bOff[TPW], eOff[TPW];
+    const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+    for (int q = 0; q < TPW; q++) {
+        const int idx = wave + NW * q;
+        int ti = 0, tj = 0;
+        tJ[q] = -1;
+        c[q] = v4d{0, 0, 0, 0};
+        if (idx < g.nTiles) {
+            tile_of(g, idx, ti, tj);
+            tJ[q] = tj;
+            const double* src = P.sys + (size_t)idx * 256 + lane;
+            c[q] = v4d{src[0], src[64], src[128], src[192]};
+        }
+        aOff[q] = (ti * 16 + lc) * 4 + lr;       // MFMA operands: W(row of the tile), L(column of the tile)
+        bOff[q] = (tj * 16 + lc) * 4 + lr;
+        eOff[q] = (ti * 16 + lr) * 4 + lc;       // export: element (row lr + 4 reg, column lc)
+    }
+    for (int q = t; q < rowsPad * 4; q += kTileThreads) { sW[q] = 0; sL[q] = 0; sP[q] = 0; }
+    // panel role: thread t owns matrix row t (row n4 = right-hand side) for the whole factorisation
+    const bool hasRow = t <= g.n4;
+    const v2d* myP = (const v2d*)(sP + t * 4);
+    v2d* myW = (v2d*)(sW + t * 4);
+    v2d* myL = (v2d*)(sL + t * 4);
+    double* myArch = Lall + tile_lrow(hasRow ? t : 0);
+    __syncthreads();
+    if (stamp) { P.dbg[2] = clock64(); P.dbg[3] = wall_clock64(); }
+    for (int kc = 0; kc < g.n4; kc += 4) {
+        const int tk = kc >> 4, co = kc & 15;
+        if (stamp) ts = clock64();
+        // ---- export the four panel columns of the tile column under the panel (all 16 rows of each tile: rows above
+        //      the panel land in slots nobody reads)
+        if (lc >= co && lc < co + 4) {
+#pragma unroll
+            for (int q = 0; q < TPW; q++) {
+                if (tJ[q] == tk) {
+                    double* dst = sP + eOff[q] - co;
+                    dst[0] = c[q][0]; dst[16] = c[q][1]; dst[32] = c[q][2]; dst[48] = c[q][3];
+                }
+            }
+        }
+        __syncthreads();
+        if (stamp) { const long long now = clock64(); acc0 += now - ts; ts = now; }
+        // ---- panel: one thread per remaining row.  The four diagonal rows run the same row solve: it reproduces their
+        //      L entries left of the diagonal; what they publish in sW / sL only ever reaches matrix entries of finished
+        //      rows and columns, which are never read again.  A zero pivot leaves Inf / NaN that reach x (checked there).
+        if (hasRow && t >= kc) {
+            const v2d* dg = (const v2d*)(sP + kc * 4);
+            const double d00 = dg[0].x;
+            const v2d r1 = dg[2], r2a = dg[4], r2b = dg[5], r3a = dg[6], r3b = dg[7];
+            const v2d pa = myP[0], pb = myP[1];
+            const double d10 = r1.x, d11 = r1.y, d20 = r2a.x, d21 = r2a.y, d22 = r2b.x, d30 = r3a.x, d31 = r3a.y, d32 = r3b.x, d33 = r3b.y;
+            const double i0 = frcp1(d00);
+            const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+            const double e11 = fma(-l10, d10, d11), e21 = fma(-l20, d10, d21), e31 = fma(-l30, d10, d31);
+            const double e22 = fma(-l20, d20, d22), e32 = fma(-l30, d20, d32), e33 = fma(-l30, d30, d33);
+            const double i1 = frcp1(e11);
+            const double l21 = e21 * i1, l31 = e31 * i1;
+            const double f22 = fma(-l21, e21, e22), f32 = fma(-l31, e21, e32), f33 = fma(-l31, e31, e33);
+            const double i2 = frcp1(f22);
+            const double l32 = f32 * i2;
+            const double h33 = fma(-l32, f32, f33);
+            const double i3 = frcp1(h33);
+            const double w0 = pa.x;
+            const double w1 = fma(-w0, l10, pa.y);
+            const double w2 = fma(-w1, l21, fma(-w0, l20, pb.x));
+            const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, pb.y)));
+            const double m0 = w0 * i0, m1 = w1 * i1, m2 = w2 * i2, m3 = w3 * i3;
+            myW[0] = v2d{w0, w1}; myW[1] = v2d{w2, w3};
+            myL[0] = v2d{m0, m1}; myL[1] = v2d{m2, m3};
+            double* dst = myArch + kc;
+            dst[0] = m0; dst[1] = m1; dst[2] = m2; dst[3] = m3;
+        }
+        __syncthreads();
+        if (stamp) { const long long now = clock64(); acc1 += now - ts; ts = now; }
+        // ---- trailing update: tiles whose columns reach past the panel; operands first, then the MFMAs back to back
+        const int tkNext = (kc + 4) >> 4;
+        double av[TPW], bv[TPW];
+#pragma unroll
+        for (int q = 0; q < TPW; q++) { av[q] = -sW[aOff[q]]; bv[q] = sL[bOff[q]]; }
+#pragma unroll
+        for (int q = 0; q < TPW; q++)
+            if (tJ[q] >= tkNext) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c[q], 0, 0, 0);
+        if (stamp) acc2 += clock64() - ts;
+    }
+    if (stamp) { P.dbg[4] = clock64(); P.dbg[5] = wall_clock64(); P.dbg[10] = acc0; P.dbg[11] = acc1; P.dbg[12] = acc2; }
+    __syncthreads();
+    // ---- L^T x = z bottom-up by ONE wave, no barriers: lane l keeps z(l), z(l + 64), z(l + 128) in registers; x(r) is
+    //      broadcast with a readlane, row r - 1 of L is fetched from LDS while row r is applied.  The products run over
+    //      whole registers: entries at and right of the diagonal only disturb z values that were consumed already.
+    if (wave == 0) {
+        const double* zrow = Lall + tile_lrow(g.n4);
+        double z0 = zrow[lane], z1 = zrow[lane + 64], z2 = zrow[lane + 128];   // slack + following arrays keep this in bounds
+        const double* lrow = Lall + tile_lrow(g.n4 - 1) + lane;
+        double p0 = lrow[0], p1 = lrow[64], p2 = lrow[128];
+        auto bcast = [](double v, int src) {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+        };
+        int r = g.n4 - 1;
+        for (; r >= 128; r--) {
+            const double c0 = p0, c1 = p1, c2 = p2;
+            lrow -= r + 3;                         // tile_lrow(r) - tile_lrow(r - 1)
+            p0 = lrow[0]; p1 = lrow[64]; p2 = lrow[128];
+            const double xr = bcast(z2, r - 128);
+            sx[r] = xr;
+            z0 = fma(-c0, xr, z0); z1 = fma(-c1, xr, z1); z2 = fma(-c2, xr, z2);
+        }
+        for (; r >= 64; r--) {
+            const double c0 = p0, c1 = p1;
+            lrow -= r + 3;
+            p0 = lrow[0]; p1 = lrow[64];
+            const double xr = bcast(z1, r - 64);
+            sx[r] = xr;
+            z0 = fma(-c0, xr, z0); z1 = fma(-c1, xr, z1);
+        }
+        for (; r >= 0; r--) {
+            const double c0 = p0;
+            if (r > 0) { lrow -= r + 3; p0 = lrow[0]; }
+            const double xr = bcast(z0, r);
+            sx[r] = xr;
+            z0 = fma(-c0, xr, z0);
+        }
+    }
+    __syncthreads();
+    if (stamp) { P.dbg[6] = clock64(); P.dbg[7] = wall_clock64(); }
+    bool bad = false;
+    for (int q = t; q < g.n; q += kTileThreads) { const double v = sx[q]; P.xp[q] = v; bad |= !isfinite(v); }
+    if (bad) s_fail = 1;
+    __syncthreads();
+    const bool failed = s_fail != 0;
+    if (failed) {   // like a failed SimplicialLDLT: the step is void
+        for (int q = t; q < g.n; q += kTileThreads) { sx[q] = 0; P.xp[q] = 0; }
+        __syncthreads();
+    }
+    const SE3* cams = cur_cams(P);
+    SE3* camsT = trial_cams(P);
+    for (int cI = t; cI < P.nCams; cI += kTileThreads) {
+        const int ci = P.camIdx[cI];
+        if (ci >= 0) {
+            double u[6];
+            for (int q = 0; q < 6; q++) u[q] = sx[ci * 6 + q];
+            camsT[cI] = se3_mul(se3_exp(u), cams[cI]);
+        } else {
+            camsT[cI] = cams[cI];
+        }
+    }
+    if (t == 0) *solveOk = failed ? 0 : 1;
+    if (stamp) { P.dbg[8] = clock64(); P.dbg[9] = wall_clock64(); }
+}
+
 // per landmark (eight lanes, one edge per lane): x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 of
 // its edges at the trial state; scale partial
 __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
@@ -1362,7 +1612,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
     D.Hpl = a.take<double>((size_t)E * 18);
     double* dsolveScratch = a.take<double>((size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
-    D.sys = a.take<double>((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1) + 8);
+    D.sys = a.take<double>(std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
     D.slab = a.take<double>((size_t)chunks * ((size_t)nFmax * 6 * nFmax * 6 + nFmax * 6));
     D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
     D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
@@ -1464,13 +1714,27 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
             D.solveScratch = nullptr;
         }
         const bool solveInLds = D.solveScratch == nullptr;
-        if (solveInLds) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+        // solver choice: register tiles + MFMA up to kTileMaxFree free keyframes, else the LDS / global-scratch solver
+        static const char* solverEnv = getenv("EAO_BA_SOLVER");   // A/B switch for the profiling harness: tiles | lds
+        const bool wantLds = solverEnv && !strcmp(solverEnv, "lds");
+        const bool solveTiles = nF > 0 && nF <= kTileMaxFree && !wantLds;
+        const TileGeom tg = tile_geom(std::max(nF, 1));
+        const size_t tileLds = tile_solver_lds(std::max(nF, 1));
+        const bool tiles3 = tg.nTiles <= 3 * (kTileThreads / 64);
+        if (solveTiles) {
+            if (tiles3) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve_tiles<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileLds));
+            else EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve_tiles<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileLds));
+        }
+        if (solveInLds && !solveTiles) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
         auto enqueue_trial = [&](int bulk) {
             if (nF) {
                 hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(256), 0, s, D);
-                hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, D);
+                if (solveTiles) hipLaunchKernelGGL(k_ba_reduce_tiles, dim3(tg.nTiles), dim3(256), 0, s, D);
+                else hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, D);
             }
-            if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
+            if (solveTiles && tiles3) hipLaunchKernelGGL(k_ba_solve_tiles<3>, dim3(1), dim3(kTileThreads), tileLds, s, D, dsolveOk);
+            else if (solveTiles) hipLaunchKernelGGL(k_ba_solve_tiles<5>, dim3(1), dim3(kTileThreads), tileLds, s, D, dsolveOk);
+            else if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
             else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
             if (nL) hipLaunchKernelGGL(k_ba_backsub, dim3(ptBlocks), dim3(256), 0, s, D);
             hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq, bulk);
@@ -1561,8 +1825,8 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     if (D.dbg) {
         long long st[16];
         EAO_HIP(hipMemcpy(st, D.dbg, sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
-                st[2] - st[0], st[4] - st[2], st[10], st[11], st[6] - st[4], st[8] - st[6], st[3] - st[1], st[5] - st[3], st[7] - st[5], st[9] - st[7]);
+        fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld / %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
+                st[2] - st[0], st[4] - st[2], st[10], st[11], st[12], st[6] - st[4], st[8] - st[6], st[3] - st[1], st[5] - st[3], st[7] - st[5], st[9] - st[7]);
     }
     write_out();
     return EAO_OK;
