@@ -466,21 +466,22 @@ struct BADev {
     int nCams, nPts, nEdges, nFree, nL;   // nFree / nL: active free cameras / active points of the current pass
     Cam cam;
     // problem (device)
-    const double* obs;      // E*3
-    const double* info;     // E
+    const float* obs;       // E*3 as handed over (promoted to double where used, exactly like Converter / Eigen)
+    const float* info;      // E
     const int* ecam;        // E
     const int* ept;         // E
-    const unsigned char* eflag;  // bit0 stereo, bit1 inactive (level 1), bit2 robust
+    unsigned char* eflag;   // bit0 stereo, bit1 inactive (level 1: set on the device by the outlier pass), bit2 robust
     const int* camIdx;      // nCams -> free block index or -1
     const int* ptIdx;       // nPts  -> landmark block index or -1
     const int* actCam;      // nFree -> camera
     const int* actPt;       // nL    -> point
-    // adjacency of the ACTIVE edges
+    // adjacency of the edges that were active when the window was set up; kernels skip edges whose bit1 was set since
     const int* ptStart;     // nL+1   CSR by landmark block: all active edges of the point, insertion order
     const int* ptEdges;
     const int* camStart;    // nFree+1 CSR by free camera block
     const int* camEdges;
-    const int* table;       // nL * nFree: active edge id of (point, free camera) or -1
+    int* camEdgeL;          // landmark block of each camEdges entry (resolved by k_ba_prepare)
+    int* table;             // nL * nFree: edge id of (point, free camera) or -1 (built and maintained on the device)
     // state: two buffers; ctl[1] says which one holds the current estimate, the other receives the trial
     SE3* camsBuf[2];
     double* ptsBuf[2];
@@ -581,6 +582,7 @@ __global__ __launch_bounds__(256) void k_ba_errors(BADev P) {
     for (int k = beg + slot; k < end; k += 8) {
         const int e = P.ptEdges[k];
         const unsigned char fl = P.eflag[e];
+        if (fl & 2) continue;
         const bool stereo = fl & 1;
         double p[3], r[3];
         se3_map(cams[P.ecam[e]], &pts[3 * pt], p);
@@ -635,6 +637,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
         for (int k = beg + slot; k < end; k += 8) {
             const int e = P.ptEdges[k];
             const unsigned char fl = P.eflag[e];
+            if (fl & 2) continue;
             const bool stereo = fl & 1;
             constexpr int D = 3;   // monocular edges carry a zero third row / residual: static loops, no scratch
             double A[3][3], B[3][6];
@@ -686,6 +689,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
         for (int k = b0; k < e0; k++) {
             const int e = P.camEdges[k];
             const unsigned char fl = P.eflag[e];
+            if (fl & 2) continue;
             const bool stereo = fl & 1;
             constexpr int D = 3;
             double A[3][3], B[3][6];
@@ -747,22 +751,30 @@ __device__ inline void dinv3(const double* Hll, double lambda, double Di[9]) {
     Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
-// grid (nFree, chunks).  The block stages its chunk of camera i1's edges in LDS -- Y = Hpl * Dinv (18 doubles), Dinv*bl
-// (3) and the point's row of the (point x camera) edge table -- then 256 threads stride over the nFree*36 + 6 outputs:
-//   S(i1, i2) = -sum_l Y(i1,l) Hpl(i2,l)^T   and   coeff(i1) = sum_l Hpl(i1,l) (Dinv bl)_l
+// grid (nFree, chunks), one workgroup per (free camera i1, chunk of its edge list).  Everything the accumulation needs is
+// staged in LDS first, with every global load of a batch in flight at once (the previous version gathered the other
+// cameras' Hpl rows inside the accumulation loop: a chain of dependent L2 round trips, 30 us):
+//   stage 1  thread per edge: Dinv of its point, Y = Hpl Dinv (18 doubles), Dinv bl (3)
+//   stage 2  thread per (edge, camera i2, 16-byte piece): the point's row of the (point x camera) edge table, then the
+//            6x3 block Hpl(i2, point) of every co-observing free camera
+//   stage 3  thread per output:  S(i1, i2)[r][c] -= sum_k Y_k[r][:] . Hpl(i2, k)[c][:]   and   coeff(i1) += Hpl(i1,k) (Dinv bl)_k
 // Every output is accumulated by ONE thread over the chunk's edges in list order: no atomics, reproducible.
-constexpr int kChunks = 8;             // partial Schur rows per free camera (fixed: the reduction loop is unrolled)
-constexpr int kSchurMaxEdges = 128;   // edges staged per pass
-constexpr int kSchurMaxFree = 64;     // free keyframes per window (table row stride in LDS)
-constexpr int kSchurMaxOut = (kSchurMaxFree * 36 + 6 + 255) / 256;
-__global__ __launch_bounds__(256) void k_ba_schur(BADev P) {
-    __shared__ double sY[kSchurMaxEdges * 18];
-    __shared__ double sDb[kSchurMaxEdges * 3];
-    __shared__ int sTab[kSchurMaxEdges * kSchurMaxFree];
-    __shared__ int sE[kSchurMaxEdges];
+constexpr int kChunks = 12;            // partial Schur rows per free camera (fixed: the reduction loop is unrolled);
+                                       // 20 keyframes x 12 chunks = 240 workgroups: one round on 256 CUs
+constexpr int kSchurSlots = 640;       // (edge, camera) blocks staged per batch: 90 KB
+constexpr int kSchurMaxFree = 64;      // free keyframes per window
+constexpr int kSchurThreads = 1024;
+constexpr int kSchurMaxOut = (kSchurMaxFree * 36 + 6 + kSchurThreads - 1) / kSchurThreads;
+__global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P) {
+    extern __shared__ __attribute__((aligned(16))) double schurLds[];
     if (P.ctl[kCtlHalt]) return;
-    const int i1 = blockIdx.x, chunk = blockIdx.y;
+    const int i1 = blockIdx.x, chunk = blockIdx.y, t = threadIdx.x;
     const int nF = P.nFree, rowLen = nF * 36 + 6;
+    const int EB = kSchurSlots / nF;                          // edges per batch
+    double* sB = schurLds;                                   // [EB * nF][18]
+    double* sY = sB + (size_t)kSchurSlots * 18;              // [EB][18]
+    double* sDb = sY + (size_t)EB * 18;                      // [EB][3]
+    int* sTab = (int*)(sDb + (size_t)EB * 3);                // [EB * nF]
     const int beg = P.camStart[i1], end = P.camStart[i1 + 1];
     const int per = (end - beg + P.chunks - 1) / P.chunks;
     const int b0 = min(beg + chunk * per, end), total = min(per, end - b0);
@@ -770,60 +782,55 @@ __global__ __launch_bounds__(256) void k_ba_schur(BADev P) {
     double acc[kSchurMaxOut];
 #pragma unroll
     for (int o = 0; o < kSchurMaxOut; o++) acc[o] = 0;
-    for (int base = 0; base < total; base += kSchurMaxEdges) {
-        const int cnt = min(kSchurMaxEdges, total - base);
-        for (int k = threadIdx.x; k < cnt; k += 256) {
-            const int e = P.camEdges[b0 + base + k];
-            const int l = P.ptIdx[P.ept[e]];
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    for (int base = 0; base < total; base += EB) {
+        const int cnt = min(EB, total - base);
+        // stages 1 and 2 share one barrier: the landmark of every list entry was resolved when the window was set up
+        // (camEdgeL), so the table rows and the co-observers' blocks do not wait for stage 1
+        for (int idx = t; idx < cnt * nF * 9; idx += kSchurThreads) {
+            const int slot = idx / 9, piece = idx - slot * 9;
+            const int k = slot / nF, i2 = slot - k * nF;
+            const int e2 = P.table[(size_t)P.camEdgeL[b0 + base + k] * nF + i2];
+            if (piece == 0) sTab[slot] = e2;
+            if (e2 >= 0) ((v2d*)(sB + (size_t)slot * 18))[piece] = ((const v2d*)(P.Hpl + (size_t)e2 * 18))[piece];
+        }
+        if (t < cnt) {
+            const int e = P.camEdges[b0 + base + t];
+            const int l = P.camEdgeL[b0 + base + t];
+            const bool on = !(P.eflag[e] & 2);     // a deactivated edge stays in the list with a zero contribution
             double Di[9];
             dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
             const double* bl = &P.bl[(size_t)l * 3];
             const double* Bi = &P.Hpl[(size_t)e * 18];
 #pragma unroll
-            for (int i = 0; i < 3; i++) sDb[k * 3 + i] = Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2];
+            for (int i = 0; i < 3; i++) sDb[t * 3 + i] = on ? Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2] : 0.0;
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) sY[k * 18 + r * 3 + c] = Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c];
-            sE[k] = e;
-        }
-        for (int idx = threadIdx.x; idx < cnt * nF; idx += 256) {
-            const int k = idx / nF, i2 = idx - k * nF;
-            const int l = P.ptIdx[P.ept[P.camEdges[b0 + base + k]]];
-            sTab[k * kSchurMaxFree + i2] = P.table[(size_t)l * nF + i2];
+                for (int c = 0; c < 3; c++) sY[t * 18 + r * 3 + c] = on ? Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c] : 0.0;
         }
         __syncthreads();
 #pragma unroll
         for (int o = 0; o < kSchurMaxOut; o++) {
-            const int t = threadIdx.x + o * 256;
-            if (t >= rowLen) break;
+            const int q = t + o * kSchurThreads;
+            if (q >= rowLen) break;
             double a = acc[o];
-            if (t < nF * 36) {
-                const int i2 = t / 36, r = (t % 36) / 6, c = t % 6;
+            if (q < nF * 36) {
+                const int i2 = q / 36, r = (q % 36) / 6, c = q % 6;
                 if (i2 >= i1) {
-                    for (int k0 = 0; k0 < cnt; k0 += 8) {   // eight gathered 6x3 rows in flight
-                        double b0[8], b1[8], b2[8];
-                        bool has[8];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const int e2 = (k0 + u < cnt) ? sTab[(k0 + u) * kSchurMaxFree + i2] : -1;
-                            has[u] = e2 >= 0;
-                            const double* Bj = &P.Hpl[(size_t)(has[u] ? e2 : 0) * 18 + c * 3];
-                            b0[u] = Bj[0]; b1[u] = Bj[1]; b2[u] = Bj[2];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            if (has[u]) {
-                                const double* Yv = &sY[(k0 + u) * 18 + r * 3];
-                                a -= Yv[0] * b0[u] + Yv[1] * b1[u] + Yv[2] * b2[u];
-                            }
+                    for (int k = 0; k < cnt; k++) {
+                        const int slot = k * nF + i2;
+                        if (sTab[slot] >= 0) {
+                            const double* Yv = &sY[k * 18 + r * 3];
+                            const double* Bj = &sB[(size_t)slot * 18 + c * 3];
+                            a -= Yv[0] * Bj[0] + Yv[1] * Bj[1] + Yv[2] * Bj[2];
                         }
                     }
                 }
             } else {
-                const int r = t - nF * 36;
+                const int r = q - nF * 36;
                 for (int k = 0; k < cnt; k++) {
-                    const double* Bi = &P.Hpl[(size_t)sE[k] * 18 + r * 3];
+                    const double* Bi = &sB[(size_t)(k * nF + i1) * 18 + r * 3];
                     a += Bi[0] * sDb[k * 3] + Bi[1] * sDb[k * 3 + 1] + Bi[2] * sDb[k * 3 + 2];
                 }
             }
@@ -831,20 +838,23 @@ __global__ __launch_bounds__(256) void k_ba_schur(BADev P) {
         }
         __syncthreads();
     }
-    // partial slab of this chunk: dense n x n row-major (upper blocks) followed by the n coefficients, so that the
-    // assembly in k_ba_solve reads it fully coalesced
+    // partial slab of this chunk: dense n x n row-major (upper blocks) followed by the n coefficients
     const int n = nF * 6;
     double* slab = P.slab + (size_t)chunk * ((size_t)n * n + n);
 #pragma unroll
     for (int o = 0; o < kSchurMaxOut; o++) {
-        const int t = threadIdx.x + o * 256;
-        if (t < nF * 36) {
-            const int i2 = t / 36, r = (t % 36) / 6, c = t % 6;
+        const int q = t + o * kSchurThreads;
+        if (q < nF * 36) {
+            const int i2 = q / 36, r = (q % 36) / 6, c = q % 6;
             if (i2 >= i1) slab[(size_t)(i1 * 6 + r) * n + i2 * 6 + c] = acc[o];
-        } else if (t < rowLen) {
-            slab[(size_t)n * n + i1 * 6 + (t - nF * 36)] = acc[o];
+        } else if (q < rowLen) {
+            slab[(size_t)n * n + i1 * 6 + (q - nF * 36)] = acc[o];
         }
     }
+}
+__host__ inline size_t schur_lds_bytes(int nF) {
+    const int EB = kSchurSlots / std::max(nF, 1);
+    return ((size_t)kSchurSlots * 18 + (size_t)EB * 21) * sizeof(double) + ((size_t)EB * nF) * sizeof(int) + 16;
 }
 
 // Sum the kChunks partial slabs in chunk order, add Hpp + lambda I and the right-hand side: one dense n x (n+1) system
@@ -1298,7 +1308,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
     for (int k = beg + slot; k < end; k += 8) {
         const int e = P.ptEdges[k];
         const int ci = P.camIdx[P.ecam[e]];
-        if (ci < 0) continue;
+        if (ci < 0 || (P.eflag[e] & 2)) continue;
         const double* Bi = &P.Hpl[(size_t)e * 18];
         const double* x = &P.xp[ci * 6];
 #pragma unroll
@@ -1327,6 +1337,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
     for (int k = beg + slot; k < end; k += 8) {
         const int e = P.ptEdges[k];
         const unsigned char fl = P.eflag[e];
+        if (fl & 2) continue;              // level-1 edges keep the residual they last computed
         const bool stereo = fl & 1;
         double p[3], r[3];
         se3_map(camsT[P.ecam[e]], np, p);
@@ -1407,18 +1418,62 @@ __global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, 
     }
 }
 
-// per edge: chi2 (of the stored residual) > threshold or non-positive depth at the current state
-__global__ void k_ba_classify(BADev P, unsigned char* out, int nEdges, const unsigned char* eflagAll) {
+// per edge: chi2 (of the stored residual) > threshold or non-positive depth at the current state.  update = 1 is the
+// outlier pass between the two optimize() calls (src/Optimizer.cc:978-1008): flagged edges go to level 1 (bit1) and every
+// edge loses its robust kernel (bit2) -- on the device, so the window's structure is never rebuilt.
+__global__ void k_ba_classify(BADev P, unsigned char* out, int nEdges, int update) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nEdges) return;
-    const bool stereo = eflagAll[e] & 1;
+    const unsigned char fl = P.eflag[e];
+    const bool stereo = fl & 1;
     const double c2 = ba_chi2(&P.err[3 * e], P.info[e], stereo);
     double p[3];
     se3_map(cur_cams(P)[P.ecam[e]], &cur_pts(P)[3 * P.ept[e]], p);
-    out[e] = (c2 > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) ? 1 : 0;
+    const unsigned char bad = (c2 > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) ? 1 : 0;
+    out[e] = bad;
+    if (update) {
+        if (e == 0) {   // fresh control block for the second optimize() (the current-buffer index carries over)
+            P.ctl[kCtlHalt] = 0; P.ctl[kCtlIters] = 0; P.ctl[kCtlStatus] = kStRunning; P.ctl[kCtlNBad] = 0;
+        }
+        P.eflag[e] = (unsigned char)((fl | (bad ? 2 : 0)) & ~4);
+        const int l = P.ptIdx[P.ept[e]], ci = P.camIdx[P.ecam[e]];
+        if (bad && l >= 0 && ci >= 0) P.table[(size_t)l * P.nFree + ci] = -1;
+    }
 }
 
-// ============================================================================================ host side
+// Device-side part of the set-up: the dense (point x free camera) edge table from the point adjacency, and the second
+// copy of the state (a vertex no active edge reaches keeps its value in BOTH buffers).
+__global__ __launch_bounds__(256) void k_ba_prepare(BADev P) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < P.nL * P.nFree) {
+        const int l = idx / P.nFree, ci = idx - l * P.nFree;
+        int found = -1;
+        for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
+            const int e = P.ptEdges[k];
+            if (P.camIdx[P.ecam[e]] == ci) found = e;
+        }
+        P.table[idx] = found;
+    }
+    if (idx < P.nPts * 3) P.ptsBuf[1][idx] = P.ptsBuf[0][idx];
+    if (idx < P.nCams) P.camsBuf[1][idx] = P.camsBuf[0][idx];
+    if (idx < P.camStart[P.nFree]) P.camEdgeL[idx] = P.ptIdx[P.ept[P.camEdges[idx]]];
+}
+
+// Results straight into pinned host memory: final state + the per-edge outlier flags.
+__global__ __launch_bounds__(256) void k_ba_finish(BADev P, SE3* outCams, double* outPts, unsigned char* outCls) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < P.nCams) outCams[idx] = cur_cams(P)[idx];
+    if (idx < P.nPts * 3) outPts[idx] = cur_pts(P)[idx];
+    if (idx < P.nEdges) {
+        const int e = idx;
+        const bool stereo = P.eflag[e] & 1;
+        const double c2 = ba_chi2(&P.err[3 * e], P.info[e], stereo);
+        double p[3];
+        se3_map(cur_cams(P)[P.ecam[e]], &cur_pts(P)[3 * P.ept[e]], p);
+        outCls[e] = (c2 > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) ? 1 : 0;
+    }
+}
+
 struct LMTraceHost {
     std::vector<double> lambda, chi2;
     std::vector<int> trials;
@@ -1434,11 +1489,15 @@ struct LMContext {  // per-thread device workspace, grow-only
     BAStatus* status = nullptr;   // pinned + mapped
     unsigned char* pin = nullptr; // pinned host mirror of the input part of the arena: ONE H2D copy per upload
     size_t pinCap = 0;
+    unsigned char* pinOut = nullptr;   // pinned results, written by k_ba_finish
+    size_t pinOutCap = 0;
     eao::DevBuf<unsigned char> bytes;
+    std::vector<int> scratch;     // host counters of the structure build (kept to avoid per-call allocation)
     size_t used = 0;
     ~LMContext() {
         if (status) (void)hipHostFree(status);
         if (pin) (void)hipHostFree(pin);
+        if (pinOut) (void)hipHostFree(pinOut);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1555,35 +1614,25 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     g_trace.clear();
     const int nC = p->n_cams, nP = p->n_points, E = p->n_edges;
     r->iters[0] = r->iters[1] = 0; r->aborted = 0; r->chi2[0] = r->chi2[1] = 0;
-    if (E) std::memset(r->edge_outlier, 0, E);
-    std::vector<SE3> hcams(nC);
-    for (int i = 0; i < nC; i++) hcams[i] = se3_from_Tcw_f32(p->cam_Tcw + 16 * i);
-    std::vector<double> hpts((size_t)nP * 3);
-    for (size_t i = 0; i < hpts.size(); i++) hpts[i] = p->points[i];
-    auto write_out = [&]() {
-        for (int i = 0; i < nC; i++) se3_to_Tcw_f32(hcams[i], r->cam_Tcw + 16 * i);
-        for (size_t i = 0; i < hpts.size(); i++) r->points[i] = (float)hpts[i];
-    };
-    if (stop && *stop) {  // src/Optimizer.cc:961-963
+    if (stop && *stop) {  // src/Optimizer.cc:961-963: nothing is optimised; poses go through the same SE3 round trip
         r->aborted = 1;
-        write_out();
+        for (int i = 0; i < nC; i++) se3_to_Tcw_f32(se3_from_Tcw_f32(p->cam_Tcw + 16 * i), r->cam_Tcw + 16 * i);
+        for (size_t i = 0; i < (size_t)nP * 3; i++) r->points[i] = p->points[i];
+        if (E) std::memset(r->edge_outlier, 0, E);
         return EAO_OK;
     }
     for (int e = 0; e < E; e++)
         EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nP, "edge %d out of range", e);
-    // ---- static problem data: edge flags (bit0 stereo, bit1 inactive, bit2 robust kernel present)
-    std::vector<unsigned char> hflag(E);
-    for (int e = 0; e < E; e++) hflag[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | 4);
-    const int nFmax = nC, chunks = kChunks;
+    const int chunks = kChunks;
     int nFreeIn = 0;
     for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
     EAO_REQUIRE(nFreeIn <= kSchurMaxFree, "at most %d free keyframes per window in this build (got %d)", kSchurMaxFree, nFreeIn);
     size_t need = 0;
-    need += (size_t)E * (3 + 1 + 3 + 18) * 8 + (size_t)E * (4 + 4 + 4 + 4 + 2);
+    need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 1 + 24 + 18 * 8);
     need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
-    need += (size_t)nP * (3 + 3 + 9 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 12 + (size_t)nP * nFmax * 4;
-    need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16) + (size_t)chunks * ((size_t)nFmax * 6 * nFmax * 6 + nFmax * 6) * 8;
-    need += 64 * 256;
+    need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
+    need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16) + (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
+    need += 96 * 256;
     if ((st = c.bytes.reserve(need))) return st;
     Arena a{c.bytes.p, c.bytes.n};
     BADev D;
@@ -1591,19 +1640,21 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     D.nCams = nC; D.nPts = nP; D.nEdges = E; D.chunks = chunks;
     D.cam.fx = p->fx; D.cam.fy = p->fy; D.cam.cx = p->cx; D.cam.cy = p->cy; D.cam.bf = p->bf; D.cam.bf_f = p->bf;
     D.cam.deltaMono = (float)std::sqrt(5.991); D.cam.deltaStereo = (float)std::sqrt(7.815);
-    // region A (static problem) and region B (active structure) come first and are mirrored in pinned host memory
-    const size_t offA0 = a.off;
-    double* dobs = a.take<double>((size_t)E * 3); double* dinfo = a.take<double>(E);
+    // ---- the uploaded part of the arena (problem, initial state, adjacency, zeroed control block) is mirrored in pinned
+    //      host memory: filled in place, sent with ONE copy
+    const size_t off0 = a.off;
+    float* dobs = a.take<float>((size_t)E * 3); float* dinfo = a.take<float>(E);
     int* decam = a.take<int>(E); int* dept = a.take<int>(E);
     SE3* dcams = a.take<SE3>(nC);
     double* dpts = a.take<double>((size_t)nP * 3);
-    const size_t offA1 = (a.off + 255) & ~(size_t)255;
     unsigned char* dflag = a.take<unsigned char>(E);
-    const size_t offB0 = (size_t)(dflag - a.base);
     int* dcamIdx = a.take<int>(nC); int* dptIdx = a.take<int>(nP); int* dactCam = a.take<int>(nC); int* dactPt = a.take<int>(nP);
     int* dptStart = a.take<int>(nP + 1); int* dptEdges = a.take<int>(E); int* dcamStart = a.take<int>(nC + 1); int* dcamEdges = a.take<int>(E);
-    int* dtable = a.take<int>((size_t)nP * nFmax);
-    const size_t offB1 = (a.off + 255) & ~(size_t)255;
+    int* dctl = a.take<int>(8);
+    const size_t off1 = (a.off + 255) & ~(size_t)255;
+    // ---- device-only part
+    int* dtable = a.take<int>((size_t)nP * nC);
+    D.camEdgeL = a.take<int>(E);
     unsigned char* dcls = a.take<unsigned char>(E);
     SE3* dcamsT = a.take<SE3>(nC);
     double* dptsT = a.take<double>((size_t)nP * 3);
@@ -1613,78 +1664,86 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     D.Hpl = a.take<double>((size_t)E * 18);
     double* dsolveScratch = a.take<double>((size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
     D.sys = a.take<double>(std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
-    D.slab = a.take<double>((size_t)chunks * ((size_t)nFmax * 6 * nFmax * 6 + nFmax * 6));
+    D.slab = a.take<double>((size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
     D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
     D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
     D.lm = a.take<double>(8);
     int* dsolveOk = a.take<int>(4);
-    int* dctl = a.take<int>(8);
     long long* ddbg = a.take<long long>(16);
     D.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
     EAO_REQUIRE(a.off <= a.cap, "internal: arena overflow");
     D.obs = dobs; D.info = dinfo; D.ecam = decam; D.ept = dept; D.eflag = dflag;
     D.camIdx = dcamIdx; D.ptIdx = dptIdx; D.actCam = dactCam; D.actPt = dactPt;
     D.ptStart = dptStart; D.ptEdges = dptEdges; D.camStart = dcamStart; D.camEdges = dcamEdges; D.table = dtable;
-    hipStream_t s = c.stream;
-    EAO_HIP(hipEventRecord(c.ev0, s));
-    if (c.pinCap < offB1) {
-        if (c.pin) (void)hipHostFree(c.pin);
-        c.pin = nullptr; c.pinCap = 0;
-        EAO_HIP(hipHostMalloc((void**)&c.pin, offB1 + (offB1 >> 2), hipHostMallocDefault));
-        c.pinCap = offB1 + (offB1 >> 2);
-    }
-    auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
-    {   // float32 -> double exactly as Converter / Eigen would promote them, straight into the pinned mirror
-        double* ho = (double*)hostp(dobs); double* hi = (double*)hostp(dinfo);
-        for (size_t k = 0; k < (size_t)E * 3; k++) ho[k] = p->edge_obs[k];
-        for (int e = 0; e < E; e++) hi[e] = p->edge_inv_sigma2[e];
-        std::memcpy(hostp(decam), p->edge_cam, (size_t)E * 4);
-        std::memcpy(hostp(dept), p->edge_point, (size_t)E * 4);
-        std::memcpy(hostp(dcams), hcams.data(), nC * sizeof(SE3));
-        std::memcpy(hostp(dpts), hpts.data(), hpts.size() * 8);
-    }
-    EAO_HIP(hipMemcpyAsync(a.base + offA0, c.pin + offA0, offA1 - offA0, hipMemcpyHostToDevice, s));
-    EAO_HIP(hipMemsetAsync(D.err, 0, (size_t)E * 24, s));
     D.camsBuf[0] = dcams; D.camsBuf[1] = dcamsT; D.ptsBuf[0] = dpts; D.ptsBuf[1] = dptsT;
     D.ctl = dctl;
-
+    hipStream_t s = c.stream;
+    if (c.pinCap < off1) {
+        if (c.pin) (void)hipHostFree(c.pin);
+        c.pin = nullptr; c.pinCap = 0;
+        EAO_HIP(hipHostMalloc((void**)&c.pin, off1 + (off1 >> 2), hipHostMallocDefault));
+        c.pinCap = off1 + (off1 >> 2);
+    }
+    const size_t outBytes = (size_t)nC * sizeof(SE3) + (size_t)nP * 24 + (size_t)E + 64;
+    if (c.pinOutCap < outBytes) {
+        if (c.pinOut) (void)hipHostFree(c.pinOut);
+        c.pinOut = nullptr; c.pinOutCap = 0;
+        EAO_HIP(hipHostMalloc((void**)&c.pinOut, outBytes + (outBytes >> 2), hipHostMallocMapped));
+        c.pinOutCap = outBytes + (outBytes >> 2);
+    }
+    SE3* outCams = (SE3*)c.pinOut;
+    double* outPts = (double*)(c.pinOut + (((size_t)nC * sizeof(SE3) + 15) & ~(size_t)15));
+    unsigned char* outCls = (unsigned char*)(outPts + (size_t)nP * 3);
+    auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
     int seq = c.status->seq;
-    // ---- (re)build the active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping.
-    //      Built directly in the pinned mirror of region B, uploaded with one copy.
-    auto build_structure = [&]() -> eao_status {
+    {
+        std::memcpy(hostp(dobs), p->edge_obs, (size_t)E * 12);
+        std::memcpy(hostp(dinfo), p->edge_inv_sigma2, (size_t)E * 4);
+        std::memcpy(hostp(decam), p->edge_cam, (size_t)E * 4);
+        std::memcpy(hostp(dept), p->edge_point, (size_t)E * 4);
+        SE3* hc = (SE3*)hostp(dcams);
+        for (int i = 0; i < nC; i++) hc[i] = se3_from_Tcw_f32(p->cam_Tcw + 16 * i);
+        double* hp = (double*)hostp(dpts);
+        for (size_t i = 0; i < (size_t)nP * 3; i++) hp[i] = p->points[i];
+        // edge flags: bit0 stereo, bit2 robust kernel present (bit1 = level 1 is only ever set on the device)
+        unsigned char* hf = (unsigned char*)hostp(dflag);
+        for (int e = 0; e < E; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | 4);
+        std::memset(hostp(dctl), 0, 8 * sizeof(int));
+        // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
         int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
         int* actCam = (int*)hostp(dactCam); int* actPt = (int*)hostp(dactPt);
         int* ptStart = (int*)hostp(dptStart); int* ptEdges = (int*)hostp(dptEdges);
         int* camStart = (int*)hostp(dcamStart); int* camEdges = (int*)hostp(dcamEdges);
-        int* table = (int*)hostp(dtable);
-        std::vector<int> camCnt(nC, 0), ptCnt(nP, 0);
-        for (int e = 0; e < E; e++) if (!(hflag[e] & 2)) { camCnt[p->edge_cam[e]]++; ptCnt[p->edge_point[e]]++; }
+        std::vector<int>& cnt = c.scratch;
+        cnt.assign((size_t)nC + nP, 0);
+        int* camCnt = cnt.data(); int* ptCnt = camCnt + nC;
+        for (int e = 0; e < E; e++) { camCnt[p->edge_cam[e]]++; ptCnt[p->edge_point[e]]++; }
         int nF = 0, nL = 0;
         for (int i = 0; i < nC; i++) { camIdx[i] = -1; if (camCnt[i] && !p->cam_fixed[i]) { actCam[nF] = i; camIdx[i] = nF++; } }
-        for (int i = 0; i < nP; i++) { ptIdx[i] = -1; if (ptCnt[i]) { actPt[nL] = i; ptIdx[i] = nL++; } }
-        std::fill(ptStart, ptStart + nL + 1, 0); std::fill(camStart, camStart + nF + 1, 0);
-        for (int e = 0; e < E; e++) if (!(hflag[e] & 2)) {
-            ptStart[ptIdx[p->edge_point[e]] + 1]++;
-            if (camIdx[p->edge_cam[e]] >= 0) camStart[camIdx[p->edge_cam[e]] + 1]++;
+        ptStart[0] = 0;
+        for (int i = 0; i < nP; i++) { ptIdx[i] = -1; if (ptCnt[i]) { actPt[nL] = i; ptIdx[i] = nL; ptStart[nL + 1] = ptStart[nL] + ptCnt[i]; nL++; } }
+        camStart[0] = 0;
+        for (int i = 0; i < nF; i++) camStart[i + 1] = camStart[i] + camCnt[actCam[i]];
+        for (int i = 0; i < nL; i++) ptCnt[actPt[i]] = ptStart[i];         // counters become fill cursors
+        for (int i = 0; i < nF; i++) camCnt[actCam[i]] = camStart[i];
+        for (int e = 0; e < E; e++) {
+            const int cam = p->edge_cam[e];
+            ptEdges[ptCnt[p->edge_point[e]]++] = e;
+            if (camIdx[cam] >= 0) camEdges[camCnt[cam]++] = e;
         }
-        for (int i = 0; i < nL; i++) ptStart[i + 1] += ptStart[i];
-        for (int i = 0; i < nF; i++) camStart[i + 1] += camStart[i];
-        std::fill(table, table + (size_t)nL * nF, -1);
-        std::vector<int> pf(ptStart, ptStart + nL), cf(camStart, camStart + nF);
-        for (int e = 0; e < E; e++) if (!(hflag[e] & 2)) {
-            const int l = ptIdx[p->edge_point[e]], ci = camIdx[p->edge_cam[e]];
-            ptEdges[pf[l]++] = e;
-            if (ci >= 0) {
-                camEdges[cf[ci]++] = e;
-                if (table[(size_t)l * nF + ci] >= 0) { eao::set_error("two edges join camera %d and point %d", p->edge_cam[e], p->edge_point[e]); return EAO_ERR_INVALID; }
-                table[(size_t)l * nF + ci] = e;
+        // one edge per (camera, point) pair: the device's edge table has one slot per pair
+        for (int i = 0; i < nC; i++) camCnt[i] = -1;                        // now: last point seen with this camera
+        for (int l = 0; l < nL; l++)
+            for (int k = ptStart[l]; k < ptStart[l + 1]; k++) {
+                const int cam = p->edge_cam[ptEdges[k]];
+                if (camCnt[cam] == l) { eao::set_error("two edges join camera %d and point %d", cam, actPt[l]); return EAO_ERR_INVALID; }
+                camCnt[cam] = l;
             }
-        }
         D.nFree = nF; D.nL = nL;
-        std::memcpy(hostp(dflag), hflag.data(), E);
-        EAO_HIP(hipMemcpyAsync(a.base + offB0, c.pin + offB0, offB1 - offB0, hipMemcpyHostToDevice, s));
-        return EAO_OK;
-    };
+    }
+    EAO_HIP(hipEventRecord(c.ev0, s));
+    EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(D.nL * D.nFree, nP * 3), nC), E), 256)), dim3(256), 0, s, D);
     auto wait_status = [&](int want) -> eao_status {
         EAO_HIP(hipStreamSynchronize(s));
         if (c.status->seq != want) { eao::set_error("LM status hand-off out of sequence"); return EAO_ERR_INTERNAL; }
@@ -1726,9 +1785,11 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
             else EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve_tiles<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileLds));
         }
         if (solveInLds && !solveTiles) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
+        const size_t schurLds = schur_lds_bytes(nF);
+        if (nF) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         auto enqueue_trial = [&](int bulk) {
             if (nF) {
-                hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(256), 0, s, D);
+                hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(kSchurThreads), schurLds, s, D);
                 if (solveTiles) hipLaunchKernelGGL(k_ba_reduce_tiles, dim3(tg.nTiles), dim3(256), 0, s, D);
                 else hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, D);
             }
@@ -1743,8 +1804,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         double currentChi = 0;
         int nBad = 0, done = 0;
         while (done < iterations && !(stop && *stop) && ok) {
-            // ---- bulk segment: every remaining iteration, one trial each
-            if ((st = set_ctl(0, done, nBad))) return st;
+            // ---- bulk segment: every remaining iteration, one trial each.  The control block is clean at the start of an
+            //      optimize() call (zeros from the upload / reset by the outlier pass); after a takeover it is rewritten.
+            if (done > 0 && (st = set_ctl(0, done, nBad))) return st;
             if (needErrors) {   // computeActiveErrors + activeRobustChi2 (otherwise the accepted trial already left them)
                 if (nL) hipLaunchKernelGGL(k_ba_errors, dim3(ptBlocks), dim3(256), 0, s, D);
                 hipLaunchKernelGGL(k_ba_chi_init, dim3(1), dim3(256), 0, s, D, c.status, ++seq);
@@ -1789,35 +1851,17 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         *chiOut = currentChi;
         return EAO_OK;
     };
-    { const int v0[8] = {0, 0, 0, 0, 0, 0, 0, 0}; EAO_HIP(hipMemcpyAsync(dctl, v0, sizeof(v0), hipMemcpyHostToDevice, s)); }
-    // a point that no active edge reaches keeps its value in BOTH state buffers
-    EAO_HIP(hipMemcpyAsync(dptsT, dpts, hpts.size() * 8, hipMemcpyDeviceToDevice, s));
-    EAO_HIP(hipMemcpyAsync(dcamsT, dcams, nC * sizeof(SE3), hipMemcpyDeviceToDevice, s));
-    if ((st = build_structure())) return st;
     if ((st = optimize(p->its_first, &r->iters[0], &r->chi2[0]))) return st;
     const bool doMore = !(stop && *stop);
-    std::vector<unsigned char> cls(std::max(E, 1));
     if (doMore && E) {
-        // outlier pass (src/Optimizer.cc:978-1008): chi2 of the residual each edge last computed + depth test
-        hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, dflag);
-        EAO_HIP(hipMemcpyAsync(cls.data(), dcls, E, hipMemcpyDeviceToHost, s));
-        EAO_HIP(hipStreamSynchronize(s));
-        for (int e = 0; e < E; e++) {
-            if (cls[e]) hflag[e] |= 2;
-            hflag[e] &= ~4;
-        }
-        // the two state buffers must agree on vertices that drop out of the active set
-        EAO_HIP(hipMemcpyAsync(D.ptsBuf[curHost ^ 1], D.ptsBuf[curHost], hpts.size() * 8, hipMemcpyDeviceToDevice, s));
-        EAO_HIP(hipMemcpyAsync(D.camsBuf[curHost ^ 1], D.camsBuf[curHost], nC * sizeof(SE3), hipMemcpyDeviceToDevice, s));
-        if ((st = build_structure())) return st;
+        // outlier pass (src/Optimizer.cc:978-1008): chi2 of the residual each edge last computed + depth test.  g2o's
+        // initializeOptimization(0) would now drop the level-1 edges (and vertices left without edges) from the active
+        // set; here they stay in the lists with zero weight, which leaves every sum -- and a vertex without edges --
+        // unchanged, and saves the host round trip of rebuilding and re-uploading the structure.
+        hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
         if ((st = optimize(p->its_second, &r->iters[1], &r->chi2[1]))) return st;
     }
-    if (E) {
-        hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, dflag);
-        EAO_HIP(hipMemcpyAsync(r->edge_outlier, dcls, E, hipMemcpyDeviceToHost, s));
-    }
-    EAO_HIP(hipMemcpyAsync(hcams.data(), D.camsBuf[curHost], nC * sizeof(SE3), hipMemcpyDeviceToHost, s));
-    EAO_HIP(hipMemcpyAsync(hpts.data(), D.ptsBuf[curHost], hpts.size() * 8, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(E, nP * 3), nC), 256)), dim3(256), 0, s, D, outCams, outPts, outCls);
     EAO_HIP(hipEventRecord(c.ev1, s));
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
@@ -1828,7 +1872,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld / %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
                 st[2] - st[0], st[4] - st[2], st[10], st[11], st[12], st[6] - st[4], st[8] - st[6], st[3] - st[1], st[5] - st[3], st[7] - st[5], st[9] - st[7]);
     }
-    write_out();
+    for (int i = 0; i < nC; i++) se3_to_Tcw_f32(outCams[i], r->cam_Tcw + 16 * i);
+    for (size_t i = 0; i < (size_t)nP * 3; i++) r->points[i] = (float)outPts[i];
+    if (E) std::memcpy(r->edge_outlier, outCls, E);
     return EAO_OK;
 }
 

@@ -5,6 +5,7 @@ tag=${1:-ba}
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o $tag -- python3 tools/dbg_ba.py > gpurun_out/prof_$tag.log 2>&1
 tail -1 gpurun_out/prof_$tag.log
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
+python3 tools/ba_timeline.py $(find gpurun_out/prof_$tag -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
