@@ -752,29 +752,31 @@ __device__ inline void dinv3(const double* Hll, double lambda, double Di[9]) {
 }
 
 // grid (nFree, chunks), one workgroup per (free camera i1, chunk of its edge list).  Everything the accumulation needs is
-// staged in LDS first, with every global load of a batch in flight at once (the previous version gathered the other
+// staged in LDS first, with every global load of a batch in flight at once (the first version gathered the other
 // cameras' Hpl rows inside the accumulation loop: a chain of dependent L2 round trips, 30 us):
-//   stage 1  thread per edge: Dinv of its point, Y = Hpl Dinv (18 doubles), Dinv bl (3)
-//   stage 2  thread per (edge, camera i2, 16-byte piece): the point's row of the (point x camera) edge table, then the
-//            6x3 block Hpl(i2, point) of every co-observing free camera
-//   stage 3  thread per output:  S(i1, i2)[r][c] -= sum_k Y_k[r][:] . Hpl(i2, k)[c][:]   and   coeff(i1) += Hpl(i1,k) (Dinv bl)_k
-// Every output is accumulated by ONE thread over the chunk's edges in list order: no atomics, reproducible.
+//   stage    thread per (edge k, camera i2) slot: the point's entry of the (point x camera) edge table, then the 6x3
+//            block Hpl(i2, point) as nine 16-byte loads in flight, and bit k of the hit mask of i2;
+//            the LAST cnt threads, one per edge: Dinv of its point, Y = Hpl Dinv (18 doubles), Dinv bl (3)
+//   sums     thread per output, walking the set bits of its camera's hit mask:
+//            S(i1, i2)[r][c] -= sum_k Y_k[r][:] . Hpl(i2, k)[c][:]   and   coeff(i1) += Hpl(i1,k) (Dinv bl)_k
+// Every output is accumulated by ONE thread over the chunk's edges in list order: no atomics on data, reproducible.
 constexpr int kChunks = 12;            // partial Schur rows per free camera (fixed: the reduction loop is unrolled);
                                        // 20 keyframes x 12 chunks = 240 workgroups: one round on 256 CUs
 constexpr int kSchurSlots = 640;       // (edge, camera) blocks staged per batch: 90 KB
 constexpr int kSchurMaxFree = 64;      // free keyframes per window
 constexpr int kSchurThreads = 1024;
 constexpr int kSchurMaxOut = (kSchurMaxFree * 36 + 6 + kSchurThreads - 1) / kSchurThreads;
+__host__ __device__ inline int schur_batch_edges(int nF) { return min(32, kSchurSlots / max(nF, 1)); }   // 32: one hit-mask word
 __global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P) {
     extern __shared__ __attribute__((aligned(16))) double schurLds[];
     if (P.ctl[kCtlHalt]) return;
     const int i1 = blockIdx.x, chunk = blockIdx.y, t = threadIdx.x;
     const int nF = P.nFree, rowLen = nF * 36 + 6;
-    const int EB = kSchurSlots / nF;                          // edges per batch
+    const int EB = schur_batch_edges(nF);
     double* sB = schurLds;                                   // [EB * nF][18]
     double* sY = sB + (size_t)kSchurSlots * 18;              // [EB][18]
     double* sDb = sY + (size_t)EB * 18;                      // [EB][3]
-    int* sTab = (int*)(sDb + (size_t)EB * 3);                // [EB * nF]
+    unsigned* sMask = (unsigned*)(sDb + (size_t)EB * 3);     // [2][nF] hit masks over the batch's edges, by batch parity
     const int beg = P.camStart[i1], end = P.camStart[i1 + 1];
     const int per = (end - beg + P.chunks - 1) / P.chunks;
     const int b0 = min(beg + chunk * per, end), total = min(per, end - b0);
@@ -783,33 +785,43 @@ __global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P) {
 #pragma unroll
     for (int o = 0; o < kSchurMaxOut; o++) acc[o] = 0;
     typedef double v2d __attribute__((ext_vector_type(2)));
-    for (int base = 0; base < total; base += EB) {
+    if (t < 2 * nF) sMask[t] = 0;
+    __syncthreads();
+    const int sk = t / nF, si2 = t - sk * nF;                 // this thread's slot
+    int par = 0;
+    for (int base = 0; base < total; base += EB, par ^= 1) {
         const int cnt = min(EB, total - base);
-        // stages 1 and 2 share one barrier: the landmark of every list entry was resolved when the window was set up
-        // (camEdgeL), so the table rows and the co-observers' blocks do not wait for stage 1
-        for (int idx = t; idx < cnt * nF * 9; idx += kSchurThreads) {
-            const int slot = idx / 9, piece = idx - slot * 9;
-            const int k = slot / nF, i2 = slot - k * nF;
-            const int e2 = P.table[(size_t)P.camEdgeL[b0 + base + k] * nF + i2];
-            if (piece == 0) sTab[slot] = e2;
-            if (e2 >= 0) ((v2d*)(sB + (size_t)slot * 18))[piece] = ((const v2d*)(P.Hpl + (size_t)e2 * 18))[piece];
+        if (sk < cnt) {
+            const int e2 = P.table[(size_t)P.camEdgeL[b0 + base + sk] * nF + si2];
+            if (e2 >= 0) {
+                const v2d* src = (const v2d*)(P.Hpl + (size_t)e2 * 18);
+                v2d v[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) v[i] = src[i];
+                v2d* dst = (v2d*)(sB + (size_t)t * 18);
+#pragma unroll
+                for (int i = 0; i < 9; i++) dst[i] = v[i];
+                atomicOr(&sMask[par * nF + si2], 1u << sk);
+            }
         }
-        if (t < cnt) {
-            const int e = P.camEdges[b0 + base + t];
-            const int l = P.camEdgeL[b0 + base + t];
+        const int yk = t - (kSchurThreads - cnt);
+        if (yk >= 0) {
+            const int e = P.camEdges[b0 + base + yk];
+            const int l = P.camEdgeL[b0 + base + yk];
             const bool on = !(P.eflag[e] & 2);     // a deactivated edge stays in the list with a zero contribution
             double Di[9];
             dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
             const double* bl = &P.bl[(size_t)l * 3];
             const double* Bi = &P.Hpl[(size_t)e * 18];
 #pragma unroll
-            for (int i = 0; i < 3; i++) sDb[t * 3 + i] = on ? Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2] : 0.0;
+            for (int i = 0; i < 3; i++) sDb[yk * 3 + i] = on ? Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2] : 0.0;
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) sY[t * 18 + r * 3 + c] = on ? Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c] : 0.0;
+                for (int c = 0; c < 3; c++) sY[yk * 18 + r * 3 + c] = on ? Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c] : 0.0;
         }
         __syncthreads();
+        if (t < nF) sMask[(par ^ 1) * nF + t] = 0;            // the other parity's masks were last read before this barrier
 #pragma unroll
         for (int o = 0; o < kSchurMaxOut; o++) {
             const int q = t + o * kSchurThreads;
@@ -818,18 +830,21 @@ __global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P) {
             if (q < nF * 36) {
                 const int i2 = q / 36, r = (q % 36) / 6, c = q % 6;
                 if (i2 >= i1) {
-                    for (int k = 0; k < cnt; k++) {
-                        const int slot = k * nF + i2;
-                        if (sTab[slot] >= 0) {
-                            const double* Yv = &sY[k * 18 + r * 3];
-                            const double* Bj = &sB[(size_t)slot * 18 + c * 3];
-                            a -= Yv[0] * Bj[0] + Yv[1] * Bj[1] + Yv[2] * Bj[2];
-                        }
+                    unsigned m = sMask[par * nF + i2];
+                    while (m) {
+                        const int k = __builtin_ctz(m);
+                        m &= m - 1;
+                        const double* Yv = &sY[k * 18 + r * 3];
+                        const double* Bj = &sB[(size_t)(k * nF + i2) * 18 + c * 3];
+                        a -= Yv[0] * Bj[0] + Yv[1] * Bj[1] + Yv[2] * Bj[2];
                     }
                 }
             } else {
                 const int r = q - nF * 36;
-                for (int k = 0; k < cnt; k++) {
+                unsigned m = sMask[par * nF + i1];          // the camera's own edges: every list entry that is still active
+                while (m) {
+                    const int k = __builtin_ctz(m);
+                    m &= m - 1;
                     const double* Bi = &sB[(size_t)(k * nF + i1) * 18 + r * 3];
                     a += Bi[0] * sDb[k * 3] + Bi[1] * sDb[k * 3 + 1] + Bi[2] * sDb[k * 3 + 2];
                 }
@@ -853,8 +868,8 @@ __global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P) {
     }
 }
 __host__ inline size_t schur_lds_bytes(int nF) {
-    const int EB = kSchurSlots / std::max(nF, 1);
-    return ((size_t)kSchurSlots * 18 + (size_t)EB * 21) * sizeof(double) + ((size_t)EB * nF) * sizeof(int) + 16;
+    const int EB = schur_batch_edges(nF);
+    return ((size_t)kSchurSlots * 18 + (size_t)EB * 21) * sizeof(double) + ((size_t)2 * nF) * sizeof(int) + 16;
 }
 
 // Sum the kChunks partial slabs in chunk order, add Hpp + lambda I and the right-hand side: one dense n x (n+1) system
@@ -1292,6 +1307,67 @@ __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(BADev P, int* s
     if (stamp) { P.dbg[8] = clock64(); P.dbg[9] = wall_clock64(); }
 }
 
+// rho, accept / reject, lambda & nu update (optimization_algorithm_levenberg.cpp:118-147) by one 256-thread block.
+// bulk = 1: the host has enqueued every remaining iteration of this optimize() call back to back (one trial each).  A
+// clean iteration -- first trial accepted -- is finished right here (trace entry, iteration count, the "3 bad
+// iterations" stop); anything else (rejected trial, rho == 0 or NaN) raises the halt flag so that the kernels still in
+// the stream do nothing, and the host takes that iteration over trial by trial.  The status block is pinned host memory;
+// the host reads it after a stream synchronisation, so no fence is needed.
+__device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BAStatus* st, int seq, int bulk) {
+    __shared__ double red[4], out1;
+    __shared__ double s_term[kSchurMaxFree * 6];
+    const double tempSum = ordered_sum(P.partChi, P.nL, red, &out1);
+    const double scaleL = ordered_sum(P.partScale, P.nL, red, &out1);
+    const double lambda = P.lm[0];
+    for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { const double x = P.xp[i]; s_term[i] = x * (lambda * x + P.bp[i]); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double scale = 0;
+        for (int i = 0; i < P.nFree * 6; i++) scale += s_term[i];
+        scale += scaleL;
+        const int ok2 = *solveOk;
+        double tempChi = tempSum;
+        if (!ok2) tempChi = DBL_MAX;
+        const double currentChi = P.lm[2];
+        double rho = currentChi - tempChi;
+        scale += 1e-3;
+        rho /= scale;
+        int accepted = 0;
+        if (rho > 0 && isfinite(tempChi)) {
+            const double y = 2 * rho - 1;
+            double alpha = 1. - y * y * y;
+            alpha = fmin(alpha, 2. / 3.);
+            P.lm[0] = lambda * fmax(1. / 3., alpha);
+            P.lm[1] = 2;
+            P.lm[2] = tempChi;
+            accepted = 1;
+            P.ctl[kCtlCur] ^= 1;            // discardTop(): the trial buffer becomes the estimate
+        } else {
+            P.lm[0] = lambda * P.lm[1];
+            P.lm[1] *= 2;
+        }
+        int status = kStRunning;
+        if (bulk) {
+            if (accepted) {
+                const int k = P.ctl[kCtlIters];
+                if (k < 32) { st->trLambda[k] = P.lm[0]; st->trChi[k] = tempChi; st->trTrials[k] = 1; }
+                P.ctl[kCtlIters] = k + 1;
+                int nb = P.ctl[kCtlNBad];
+                if ((currentChi - tempChi) * 1e3 < currentChi) nb++; else nb = 0;
+                P.ctl[kCtlNBad] = nb;
+                if (nb >= 3) { status = kStTerminate; P.ctl[kCtlHalt] = 1; }
+            } else {
+                status = kStTakeover;
+                P.ctl[kCtlHalt] = 1;
+            }
+            P.ctl[kCtlStatus] = status;
+        }
+        st->lambda = P.lm[0]; st->rho = rho; st->chi = P.lm[2]; st->tempChi = tempChi; st->accepted = accepted; st->solveOk = ok2;
+        st->cur = P.ctl[kCtlCur]; st->iters = P.ctl[kCtlIters]; st->status = status; st->nBad = P.ctl[kCtlNBad];
+        st->seq = seq;
+    }
+}
+
 // per landmark (eight lanes, one edge per lane): x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 of
 // its edges at the trial state; scale partial
 __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
@@ -1357,65 +1433,11 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
     }
 }
 
-// rho, accept / reject, lambda & nu update (optimization_algorithm_levenberg.cpp:118-147); one 256-thread block.
-// bulk = 1: the host has enqueued every remaining iteration of this optimize() call back to back (one trial each).  A
-// clean iteration -- first trial accepted -- is finished right here (trace entry, iteration count, the "3 bad
-// iterations" stop); anything else (rejected trial, rho == 0 or NaN) raises the halt flag so that the kernels still in
-// the stream do nothing, and the host takes that iteration over trial by trial.
+// One block.  (Folding this into k_ba_backsub behind a last-block ticket was measured: the agent-scope fences every
+// block then needs cost more (23 us for the pair) than the launch they save (6 + 9 us).)
 __global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, BAStatus* st, int seq, int bulk) {
-    __shared__ double red[4], out1;
-    __shared__ double s_xp[kSchurMaxFree * 6], s_bp[kSchurMaxFree * 6];
     if (P.ctl[kCtlHalt]) return;
-    const double tempSum = ordered_sum(P.partChi, P.nL, red, &out1);
-    const double scaleL = ordered_sum(P.partScale, P.nL, red, &out1);
-    for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { s_xp[i] = P.xp[i]; s_bp[i] = P.bp[i]; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double lambda = P.lm[0];
-        double scale = 0;
-        for (int i = 0; i < P.nFree * 6; i++) scale += s_xp[i] * (lambda * s_xp[i] + s_bp[i]);
-        scale += scaleL;
-        const int ok2 = *solveOk;
-        double tempChi = tempSum;
-        if (!ok2) tempChi = DBL_MAX;
-        const double currentChi = P.lm[2];
-        double rho = currentChi - tempChi;
-        scale += 1e-3;
-        rho /= scale;
-        int accepted = 0;
-        if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - pow((2 * rho - 1), 3);
-            alpha = fmin(alpha, 2. / 3.);
-            P.lm[0] = lambda * fmax(1. / 3., alpha);
-            P.lm[1] = 2;
-            P.lm[2] = tempChi;
-            accepted = 1;
-            P.ctl[kCtlCur] ^= 1;            // discardTop(): the trial buffer becomes the estimate
-        } else {
-            P.lm[0] = lambda * P.lm[1];
-            P.lm[1] *= 2;
-        }
-        int status = kStRunning;
-        if (bulk) {
-            if (accepted) {
-                const int k = P.ctl[kCtlIters];
-                if (k < 32) { st->trLambda[k] = P.lm[0]; st->trChi[k] = tempChi; st->trTrials[k] = 1; }
-                P.ctl[kCtlIters] = k + 1;
-                int nb = P.ctl[kCtlNBad];
-                if ((currentChi - tempChi) * 1e3 < currentChi) nb++; else nb = 0;
-                P.ctl[kCtlNBad] = nb;
-                if (nb >= 3) { status = kStTerminate; P.ctl[kCtlHalt] = 1; }
-            } else {
-                status = kStTakeover;
-                P.ctl[kCtlHalt] = 1;
-            }
-            P.ctl[kCtlStatus] = status;
-        }
-        st->lambda = P.lm[0]; st->rho = rho; st->chi = P.lm[2]; st->tempChi = tempChi; st->accepted = accepted; st->solveOk = ok2;
-        st->cur = P.ctl[kCtlCur]; st->iters = P.ctl[kCtlIters]; st->status = status; st->nBad = P.ctl[kCtlNBad];
-        __threadfence_system();
-        st->seq = seq;
-    }
+    ba_decide_block(P, solveOk, st, seq, bulk);
 }
 
 // per edge: chi2 (of the stored residual) > threshold or non-positive depth at the current state.  update = 1 is the
