@@ -621,15 +621,27 @@ __global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int 
     }
 }
 
-// role A: blocks [0, ptBlocks): one thread per landmark.  role B: blocks [ptBlocks, ptBlocks + nFree): one block per free camera.
-__global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
-    __shared__ double red[4 * 27], sums[27];
+// role A: blocks [0, ptBlocks): eight lanes per landmark.  role B: blocks [ptBlocks, ptBlocks + nFree): one block per free
+// camera, one edge per thread; the 27 sums (21 of Hpp's upper triangle + 6 of bp) go through LDS in a fixed order: lane
+// quads first (DPP), then 27 x 8 column threads over 32 quad leaders each, then the last 8.  (Sixty-four-lane shuffle
+// trees for the 27 values cost 6.4 us here; this costs about one.)
+constexpr int kLinThreads = 1024;
+__device__ __forceinline__ double quad_sum(double v) {   // sum over the four lanes of a quad, same value in all four
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += o;
+    lo = __double2loint(v); hi = __double2hiint(v);
+    o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));          // quad_perm [2,3,0,1]
+    return v + o;
+}
+__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlocks) {
+    __shared__ double red[(kLinThreads / 4) * 27], part[8 * 27];
     if (P.ctl[kCtlHalt]) return;
     const SE3* cams = cur_cams(P);
     const double* pts = cur_pts(P);
     if ((int)blockIdx.x < ptBlocks) {
         // role A: eight lanes per landmark, one edge per lane; Hll / bl are xor-tree sums over the lane group
-        const int l = (blockIdx.x * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+        const int l = (blockIdx.x * kLinThreads + threadIdx.x) >> 3, slot = threadIdx.x & 7;
         const bool live = l < P.nL;
         const int pt = live ? P.actPt[l] : 0;
         const int beg = live ? P.ptStart[l] : 0, end = live ? P.ptStart[l + 1] : 0;
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
 #pragma unroll
         for (int k = 0; k < 27; k++) acc[k] = 0;
         const int beg = P.camStart[ci], end = P.camStart[ci + 1];
-        const int per = (end - beg + 255) / 256;
+        const int per = (end - beg + kLinThreads - 1) / kLinThreads;
         const int b0 = min(beg + (int)threadIdx.x * per, end), e0 = min(b0 + per, end);
         for (int k = b0; k < e0; k++) {
             const int e = P.camEdges[k];
@@ -711,8 +723,31 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev P, int ptBlocks) {
                 for (int j = i; j < 6; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi * B[r][j]; acc[q++] += h; }
             }
         }
-        block_sum<27, 256>(acc, red, sums);
+        // fixed-order reduction of the 27 accumulators over the block
+#pragma unroll
+        for (int q = 0; q < 27; q++) acc[q] = quad_sum(acc[q]);
+        if ((threadIdx.x & 3) == 0) {
+            double* dst = red + (threadIdx.x >> 2) * 27;
+#pragma unroll
+            for (int q = 0; q < 27; q++) dst[q] = acc[q];
+        }
+        __syncthreads();
+        constexpr int kSeg = kLinThreads / 4 / 8;       // quad leaders per column thread
+        if (threadIdx.x < 27 * 8) {
+            const int q = threadIdx.x % 27, seg = threadIdx.x / 27;
+            double sacc = 0;
+            for (int j = 0; j < kSeg; j++) sacc += red[(seg * kSeg + j) * 27 + q];
+            part[seg * 27 + q] = sacc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 27) {
+            double sacc = 0;
+            for (int seg = 0; seg < 8; seg++) sacc += part[seg * 27 + threadIdx.x];
+            part[threadIdx.x] = sacc;                  // only this thread reads or writes these eight slots
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
+            const double* sums = part;
             int q = 0;
             for (int i = 0; i < 6; i++)
                 for (int j = i; j < 6; j++) { P.Hpp[(size_t)ci * 36 + i * 6 + j] = sums[q]; P.Hpp[(size_t)ci * 36 + j * 6 + i] = sums[q]; q++; }
@@ -1786,6 +1821,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         const int nF = D.nFree, nL = D.nL;
         if (nF + nL == 0) return EAO_OK;   // "_ivMap.size() == 0": nothing to optimise
         const int ptBlocks = eao::cdiv(std::max(nL, 1) * 8, 256);   // eight lanes per landmark
+        const int linBlocks = eao::cdiv(std::max(nL, 1) * 8, kLinThreads);
         const size_t ldHost = (size_t)((nF * 6 + 32) & ~31) + 1;
         size_t solveLds = ((size_t)(nF * 6 + 6) * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
         if (solveLds > 150 * 1024) {   // system too large for LDS: S lives in (L2-resident) global scratch, M/xv stay in LDS
@@ -1835,7 +1871,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
                 needErrors = false;
             }
             for (int it = done; it < iterations; it++) {
-                hipLaunchKernelGGL(k_ba_linearize, dim3(ptBlocks + nF), dim3(256), 0, s, D, ptBlocks);
+                hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks);
                 if (it == 0) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);
                 enqueue_trial(1);
             }
