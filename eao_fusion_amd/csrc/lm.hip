@@ -37,6 +37,19 @@
 
 namespace {
 
+// 1/x: v_rcp_f64 + two Newton steps on the device (~1 ulp, a third of the instructions of an IEEE division), a plain
+// division in host code
+__host__ __device__ inline double recip(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+
 // ============================================================================================ SE3 helpers
 struct Quat { double x, y, z, w; };
 struct SE3 { Quat r; double t[3]; };
@@ -47,30 +60,30 @@ __host__ __device__ inline Quat quat_from_matrix(const double m[9]) {
     if (t > 0) {
         t = sqrt(t + 1.0);
         q.w = 0.5 * t;
-        t = 0.5 / t;
+        t = 0.5 * recip(t);
         q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
     } else if (m[0] >= m[4] && m[0] >= m[8]) {   // i = 0 (Eigen picks the largest diagonal; ties go to the lower index)
         t = sqrt(m[0] - m[4] - m[8] + 1.0);
         q.x = 0.5 * t;
-        t = 0.5 / t;
+        t = 0.5 * recip(t);
         q.w = (m[7] - m[5]) * t; q.y = (m[3] + m[1]) * t; q.z = (m[6] + m[2]) * t;
     } else if (m[4] > m[0] && m[4] >= m[8]) {    // i = 1
         t = sqrt(m[4] - m[8] - m[0] + 1.0);
         q.y = 0.5 * t;
-        t = 0.5 / t;
+        t = 0.5 * recip(t);
         q.w = (m[2] - m[6]) * t; q.z = (m[7] + m[5]) * t; q.x = (m[1] + m[3]) * t;
     } else {                                        // i = 2
         t = sqrt(m[8] - m[0] - m[4] + 1.0);
         q.z = 0.5 * t;
-        t = 0.5 / t;
+        t = 0.5 * recip(t);
         q.w = (m[3] - m[1]) * t; q.x = (m[2] + m[6]) * t; q.y = (m[5] + m[7]) * t;
     }
     return q;
 }
 __host__ __device__ inline void quat_normalize_pos(Quat& q) {
     if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
-    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+    const double in = recip(sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w));
+    q.x *= in; q.y *= in; q.z *= in; q.w *= in;
 }
 __host__ __device__ inline Quat quat_mul(const Quat& a, const Quat& b) {
     Quat r;
@@ -110,8 +123,9 @@ __host__ __device__ inline SE3 se3_exp(const double u[6]) {  // (omega, upsilon)
     if (theta < 0.00001) {
         for (int i = 0; i < 9; i++) { const double id = (i % 4 == 0) ? 1.0 : 0.0; R[i] = id + Om[i] + Om2[i]; V[i] = R[i]; }
     } else {
-        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
-        const double c = (theta - sin(theta)) / (theta * theta * theta);
+        const double st = sin(theta), ct = cos(theta), it = recip(theta), it2 = it * it;
+        const double a = st * it, b = (1 - ct) * it2;
+        const double c = (theta - st) * (it2 * it);
         for (int i = 0; i < 9; i++) {
             const double id = (i % 4 == 0) ? 1.0 : 0.0;
             R[i] = id + a * Om[i] + b * Om2[i];
@@ -182,6 +196,44 @@ __device__ __forceinline__ double group8_sum(double v) {
 }
 
 // ---- block-wide fixed-order sum of NV doubles per thread; result valid in thread 0 (and in `out` LDS after a barrier)
+__device__ __forceinline__ double quad_sum(double v) {   // sum over the four lanes of a quad, same value in all four
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += o;
+    lo = __double2loint(v); hi = __double2hiint(v);
+    o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));          // quad_perm [2,3,0,1]
+    return v + o;
+}
+// Fixed-order sum of NV accumulators over a block of NT threads through LDS: lane quads first (DPP), then NV x 8 column
+// threads over NT/32 quad leaders each, then the last 8.  red: (NT/4)*NV doubles, part: 8*NV doubles; the totals land in
+// part[0 .. NV).  (A 64-lane shuffle tree per value costs ~230 cycles per value; this is ~10x cheaper for NV ~ 28.)
+template <int NV, int NT>
+__device__ inline void block_sum_lds(double (&acc)[NV], double* red, double* part) {
+    static_assert(NV * 8 <= NT, "column threads");
+#pragma unroll
+    for (int q = 0; q < NV; q++) acc[q] = quad_sum(acc[q]);
+    if ((threadIdx.x & 3) == 0) {
+        double* dst = red + (threadIdx.x >> 2) * NV;
+#pragma unroll
+        for (int q = 0; q < NV; q++) dst[q] = acc[q];
+    }
+    __syncthreads();
+    constexpr int kSeg = NT / 4 / 8;
+    if (threadIdx.x < NV * 8) {
+        const int q = threadIdx.x % NV, seg = threadIdx.x / NV;
+        double sacc = 0;
+        for (int j = 0; j < kSeg; j++) sacc += red[(seg * kSeg + j) * NV + q];
+        part[seg * NV + q] = sacc;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double sacc = 0;
+        for (int seg = 0; seg < 8; seg++) sacc += part[seg * NV + threadIdx.x];
+        part[threadIdx.x] = sacc;                  // only this thread reads or writes these eight slots
+    }
+    __syncthreads();
+}
+
 template <int NV, int NT>
 __device__ inline void block_sum(double (&v)[NV], double* lds /* (NT/64)*NV */, double* out /* NV */) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -216,12 +268,12 @@ __device__ inline bool ldlt6_solve(const double* A, const double* b, double* x) 
     for (int r = 0; r < 6; r++) {
         const double d = a[r][r];
         if (!(d > 0)) positive = false;
-        inv[r] = 1.0 / d;
+        inv[r] = recip(d);
 #pragma unroll
         for (int i = r + 1; i < 6; i++) {
             const double l = a[r][i] * inv[r];
 #pragma unroll
-            for (int c = i; c < 6; c++) a[i][c] -= l * a[r][c];
+            for (int c = i; c < 6; c++) a[i][c] = fma(-l, a[r][c], a[i][c]);
             a[i][r] = l;          // keep the multiplier below the diagonal
         }
     }
@@ -230,14 +282,14 @@ __device__ inline bool ldlt6_solve(const double* A, const double* b, double* x) 
     for (int i = 0; i < 6; i++) {
         double v = b[i];
 #pragma unroll
-        for (int k = 0; k < i; k++) v -= a[i][k] * y[k];
+        for (int k = 0; k < i; k++) v = fma(-a[i][k], y[k], v);
         y[i] = v;
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
         double v = y[i] * inv[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; k++) v -= a[k][i] * x[k];
+        for (int k = i + 1; k < 6; k++) v = fma(-a[k][i], x[k], v);
         x[i] = v;
     }
     return true;
@@ -258,6 +310,7 @@ struct PoseDev {
     SE3* Tout;
     int* result;         // [0] nBad of the last round, [1] LM iterations, [2] trace count
     double* trace;       // 3 * 64: lambda, chi2, trials
+    long long* dbg;      // optional phase stamps (diagnostic runs of the harness only)
 };
 
 constexpr int kPoseThreads = 512;
@@ -285,9 +338,244 @@ __device__ inline double pose_edge_chi2(const PoseDev& P, int i, bool stereo) {
     return s;
 }
 
+// Register-resident variant: thread t owns edges t, t + 512, ... (EPT of them) for the whole call -- point, observation,
+// information, flags and the last computed residual (g2o's _error) never leave its registers, so the ~50 passes over the
+// edges of one PoseOptimization are free of memory latency (the memory variant spent a third of its time waiting on L2).
+template <int EPT>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
-    __shared__ double red[(kPoseThreads / 64) * 28];
-    __shared__ double sums[28];
+    __shared__ double red[(kPoseThreads / 4) * 28];
+    __shared__ double sums[8 * 28];
+    __shared__ SE3 s_est, s_backup;
+    __shared__ double s_x[6];
+    __shared__ double s_lambda, s_ni, s_rho, s_cur, s_tmp;
+    __shared__ int s_ok, s_flag, s_nbad, s_ntrace, s_iters, s_active;
+    const int t = threadIdx.x, n = P.n;
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    const Cam c = P.cam;
+    double eX[EPT][3], eO[EPT][3], eI[EPT], eE[EPT][3];
+    unsigned char eF[EPT], eOut[EPT];
+    bool eLive[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int i = t + k * kPoseThreads;
+        eLive[k] = i < n;
+        const int j = eLive[k] ? i : 0;
+#pragma unroll
+        for (int d = 0; d < 3; d++) { eX[k][d] = P.Xw[3 * j + d]; eO[k][d] = P.obs[3 * j + d]; eE[k][d] = 0; }
+        eI[k] = P.info[j];
+        eF[k] = eLive[k] ? P.flags[j] : (unsigned char)2;     // a slot without an edge behaves like a level-1 edge
+        eOut[k] = 0;
+    }
+    auto edge_error = [&](const SE3& T, int k) {
+        const bool stereo = eF[k] & 1;
+        double p[3];
+        se3_map(T, eX[k], p);
+        if (!stereo) {
+            eE[k][0] = eO[k][0] - (p[0] / p[2] * c.fx + c.cx);
+            eE[k][1] = eO[k][1] - (p[1] / p[2] * c.fy + c.cy);
+            eE[k][2] = 0;
+        } else {
+            const float invz = (float)(1.0 / p[2]);  // types_six_dof_expmap.cpp:335-342 ("const float invz")
+            const double r0 = p[0] * invz * c.fx + c.cx;
+            const double r1 = p[1] * invz * c.fy + c.cy;
+            const double r2 = r0 - c.bf * invz;
+            eE[k][0] = eO[k][0] - r0; eE[k][1] = eO[k][1] - r1; eE[k][2] = eO[k][2] - r2;
+        }
+    };
+    auto edge_chi2 = [&](int k) {
+        const double w = eI[k];
+        double s2 = eE[k][0] * (w * eE[k][0]) + eE[k][1] * (w * eE[k][1]);
+        if (eF[k] & 1) s2 += eE[k][2] * (w * eE[k][2]);
+        return s2;
+    };
+    if (t == 0) { s_ntrace = 0; s_iters = 0; s_est = P.T0; }
+    const bool stamp = P.dbg && t == 0;
+    long long pa[6] = {0, 0, 0, 0, 0, 0}, pts = 0;
+    auto lap = [&](int slot) { if (stamp) { const long long now = clock64(); pa[slot] += now - pts; pts = now; } };
+    __syncthreads();
+    for (int round = 0; round < 4; round++) {
+        if (t == 0) { s_est = P.T0; s_active = 0; }
+        __syncthreads();
+        {   // any level-0 edge?  (g2o: optimize() returns -1 when the index mapping is empty)
+            int any = 0;
+#pragma unroll
+            for (int k = 0; k < EPT; k++) any |= !(eF[k] & 2);
+            if (any) s_active = 1;
+        }
+        __syncthreads();
+        const int active = s_active;
+        if (active) {
+            bool ok = true;
+            for (int it = 0; it < 10 && ok; it++) {
+                // ---- computeActiveErrors + activeRobustChi2 + buildSystem at the current estimate
+                if (stamp) pts = clock64();
+                const SE3 est = s_est;
+                double acc[28];
+#pragma unroll
+                for (int q = 0; q < 28; q++) acc[q] = 0;
+#pragma unroll
+                for (int k = 0; k < EPT; k++) {
+                    const unsigned char fl = eF[k];
+                    if (fl & 2) continue;
+                    const bool stereo = fl & 1;
+                    edge_error(est, k);
+                    const double c2 = edge_chi2(k);
+                    double w = 1.0, r0 = c2;
+                    if (fl & 4) huber(c2, stereo ? c.deltaStereo : c.deltaMono, r0, w);
+                    acc[27] += r0;
+                    double p[3];
+                    se3_map(est, eX[k], p);
+                    const double X = p[0], Y = p[1], invz = 1.0 / p[2], invz2 = invz * invz;
+                    double J[3][6];
+                    J[0][0] = X * Y * invz2 * c.fx; J[0][1] = -(1 + (X * X * invz2)) * c.fx; J[0][2] = Y * invz * c.fx;
+                    J[0][3] = -invz * c.fx; J[0][4] = 0; J[0][5] = X * invz2 * c.fx;
+                    J[1][0] = (1 + Y * Y * invz2) * c.fy; J[1][1] = -X * Y * invz2 * c.fy; J[1][2] = -X * invz * c.fy;
+                    J[1][3] = 0; J[1][4] = -invz * c.fy; J[1][5] = Y * invz2 * c.fy;
+                    if (stereo) {
+                        J[2][0] = J[0][0] - c.bf * Y * invz2; J[2][1] = J[0][1] + c.bf * X * invz2; J[2][2] = J[0][2];
+                        J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - c.bf * invz2;
+                    } else {   // monocular edge: a zero third row keeps every loop static (registers, no scratch)
+#pragma unroll
+                        for (int a = 0; a < 6; a++) J[2][a] = 0;
+                    }
+                    const double info = eI[k], wi = w * info;
+                    const double e0 = info * eE[k][0], e1 = info * eE[k][1], e2 = info * eE[k][2];
+                    int q = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+                        double sb = J[0][a] * e0 + J[1][a] * e1;
+                        sb += J[2][a] * e2;
+                        acc[21 + a] -= w * sb;
+#pragma unroll
+                        for (int b = a; b < 6; b++) {
+                            double hh = J[0][a] * wi * J[0][b] + J[1][a] * wi * J[1][b];
+                            hh += J[2][a] * wi * J[2][b];
+                            acc[q++] += hh;
+                        }
+                    }
+                }
+                lap(0);
+                block_sum_lds<28, kPoseThreads>(acc, red, sums);
+                lap(1);
+                if (t == 0) {
+                    s_cur = sums[27];
+                    if (it == 0) {
+                        double md = 0;
+                        int q = 0;
+                        for (int a = 0; a < 6; a++) { md = fmax(md, fabs(sums[q])); q += 6 - a; }
+                        s_lambda = 1e-5 * md;
+                        s_ni = 2;
+                        s_nbad = 0;
+                    }
+                }
+                __syncthreads();
+                const double iniChi = s_cur;
+                int qmax = 0;
+                double rho = 0;
+                do {
+                    if (stamp) pts = clock64();
+                    if (t == 0) {
+                        s_backup = s_est;
+                        double A[36], b[6];
+                        int q = 0;
+                        for (int a = 0; a < 6; a++)
+                            for (int b2 = a; b2 < 6; b2++) { A[a * 6 + b2] = sums[q]; A[b2 * 6 + a] = sums[q]; q++; }
+                        for (int a = 0; a < 6; a++) { A[a * 7] += s_lambda; b[a] = sums[21 + a]; }
+                        double x[6] = {0, 0, 0, 0, 0, 0};
+                        s_ok = ldlt6_solve(A, b, x) ? 1 : 0;
+                        for (int a = 0; a < 6; a++) s_x[a] = x[a];
+                        s_est = se3_mul(se3_exp(x), s_est);
+                    }
+                    __syncthreads();
+                    lap(2);
+                    const SE3 tr = s_est;
+                    double chi[1] = {0};
+#pragma unroll
+                    for (int k = 0; k < EPT; k++) {
+                        const unsigned char fl = eF[k];
+                        if (fl & 2) continue;
+                        edge_error(tr, k);
+                        const double c2 = edge_chi2(k);
+                        double w, r0 = c2;
+                        if (fl & 4) huber(c2, (fl & 1) ? c.deltaStereo : c.deltaMono, r0, w);
+                        chi[0] += r0;
+                    }
+                    lap(3);
+                    block_sum<1, kPoseThreads>(chi, red, &s_tmp);
+                    lap(4);
+                    if (t == 0) {
+                        double tempChi = s_tmp;
+                        if (!s_ok) tempChi = DBL_MAX;
+                        double r = s_cur - tempChi;
+                        double scale = 0;
+                        for (int a = 0; a < 6; a++) scale += s_x[a] * (s_lambda * s_x[a] + sums[21 + a]);
+                        scale += 1e-3;
+                        r /= scale;
+                        if (r > 0 && isfinite(tempChi)) {
+                            const double y = 2 * r - 1;
+                            double alpha = 1. - y * y * y;
+                            alpha = fmin(alpha, 2. / 3.);
+                            s_lambda *= fmax(1. / 3., alpha);
+                            s_ni = 2;
+                            s_cur = tempChi;
+                        } else {
+                            s_lambda *= s_ni;
+                            s_ni *= 2;
+                            s_est = s_backup;
+                        }
+                        s_rho = r;
+                    }
+                    __syncthreads();
+                    lap(5);
+                    rho = s_rho;
+                    qmax++;
+                } while (rho < 0 && qmax < 10);
+                if (t == 0) {
+                    if (s_ntrace < 64) { P.trace[s_ntrace] = s_lambda; P.trace[64 + s_ntrace] = s_cur; P.trace[128 + s_ntrace] = qmax; s_ntrace++; }
+                    s_iters++;
+                    int term = (qmax == 10 || rho == 0) ? 1 : 0;
+                    if (!term) {
+                        if ((iniChi - s_cur) * 1e3 < iniChi) s_nbad++; else s_nbad = 0;
+                        if (s_nbad >= 3) term = 1;
+                    }
+                    s_flag = term;
+                }
+                __syncthreads();
+                ok = !s_flag;
+            }
+        }
+        // ---- inlier / outlier classification of every edge (src/Optimizer.cc:554-621)
+        const SE3 est = s_est;
+        double nb[1] = {0};
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            if (!eLive[k]) continue;
+            unsigned char fl = eF[k];
+            const bool stereo = fl & 1;
+            if (eOut[k]) edge_error(est, k);
+            const float c2 = (float)edge_chi2(k);
+            if (c2 > (stereo ? chi2Stereo : chi2Mono)) { eOut[k] = 1; fl |= 2; nb[0] += 1; }
+            else { eOut[k] = 0; fl &= ~2; }
+            if (!stereo) fl &= ~4;            // mono: kernel removed after every round
+            else if (round == 2) fl &= ~4;    // stereo: at it == 2
+            eF[k] = fl;
+        }
+        block_sum<1, kPoseThreads>(nb, red, &s_tmp);
+        if (t == 0) P.result[0] = (int)s_tmp;
+        __syncthreads();
+        if (n < 10) break;
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; k++)
+        if (eLive[k]) P.outlier[t + k * kPoseThreads] = eOut[k];
+    if (t == 0) { *P.Tout = s_est; P.result[1] = s_iters; P.result[2] = s_ntrace; }
+    if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
+}
+
+// Generic variant: edges stay in global memory (frames with more than 4 * kPoseThreads correspondences).
+__global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev P) {
+    __shared__ double red[(kPoseThreads / 4) * 28];
+    __shared__ double sums[8 * 28];
     __shared__ SE3 s_est, s_backup;
     __shared__ double s_x[6];
     __shared__ double s_lambda, s_ni, s_rho, s_cur, s_tmp;
@@ -356,7 +644,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
                         }
                     }
                 }
-                block_sum<28, kPoseThreads>(acc, red, sums);
+                block_sum_lds<28, kPoseThreads>(acc, red, sums);
                 if (t == 0) {
                     s_cur = sums[27];
                     if (it == 0) {
@@ -373,7 +661,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
                 int qmax = 0;
                 double rho = 0;
                 do {
-                    if (t == 0) {
+                        if (t == 0) {
                         s_backup = s_est;
                         double A[36], b[6];
                         int q = 0;
@@ -408,7 +696,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
                         scale += 1e-3;
                         r /= scale;
                         if (r > 0 && isfinite(tempChi)) {
-                            double alpha = 1. - pow((2 * r - 1), 3);
+                            const double y = 2 * r - 1;
+                            double alpha = 1. - y * y * y;
                             alpha = fmin(alpha, 2. / 3.);
                             s_lambda *= fmax(1. / 3., alpha);
                             s_ni = 2;
@@ -626,14 +915,6 @@ __global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int 
 // quads first (DPP), then 27 x 8 column threads over 32 quad leaders each, then the last 8.  (Sixty-four-lane shuffle
 // trees for the 27 values cost 6.4 us here; this costs about one.)
 constexpr int kLinThreads = 1024;
-__device__ __forceinline__ double quad_sum(double v) {   // sum over the four lanes of a quad, same value in all four
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    double o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += o;
-    lo = __double2loint(v); hi = __double2hiint(v);
-    o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));          // quad_perm [2,3,0,1]
-    return v + o;
-}
 __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlocks) {
     __shared__ double red[(kLinThreads / 4) * 27], part[8 * 27];
     if (P.ctl[kCtlHalt]) return;
@@ -723,29 +1004,7 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
                 for (int j = i; j < 6; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi * B[r][j]; acc[q++] += h; }
             }
         }
-        // fixed-order reduction of the 27 accumulators over the block
-#pragma unroll
-        for (int q = 0; q < 27; q++) acc[q] = quad_sum(acc[q]);
-        if ((threadIdx.x & 3) == 0) {
-            double* dst = red + (threadIdx.x >> 2) * 27;
-#pragma unroll
-            for (int q = 0; q < 27; q++) dst[q] = acc[q];
-        }
-        __syncthreads();
-        constexpr int kSeg = kLinThreads / 4 / 8;       // quad leaders per column thread
-        if (threadIdx.x < 27 * 8) {
-            const int q = threadIdx.x % 27, seg = threadIdx.x / 27;
-            double sacc = 0;
-            for (int j = 0; j < kSeg; j++) sacc += red[(seg * kSeg + j) * 27 + q];
-            part[seg * 27 + q] = sacc;
-        }
-        __syncthreads();
-        if (threadIdx.x < 27) {
-            double sacc = 0;
-            for (int seg = 0; seg < 8; seg++) sacc += part[seg * 27 + threadIdx.x];
-            part[threadIdx.x] = sacc;                  // only this thread reads or writes these eight slots
-        }
-        __syncthreads();
+        block_sum_lds<27, kLinThreads>(acc, red, part);
         if (threadIdx.x == 0) {
             const double* sums = part;
             int q = 0;
@@ -1607,50 +1866,72 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
         r->n_inliers = 0;
         return EAO_OK;
     }
-    // host staging: float32 -> double exactly as Converter / Eigen would promote them
-    std::vector<double> hXw((size_t)n * 3), hobs((size_t)n * 3), hinfo(n);
-    std::vector<unsigned char> hflags(n);
-    for (int i = 0; i < n; i++) {
-        for (int k = 0; k < 3; k++) { hXw[3 * i + k] = p->Xw[3 * i + k]; hobs[3 * i + k] = p->obs[3 * i + k]; }
-        hinfo[i] = p->inv_sigma2[i];
-        hflags[i] = (unsigned char)((!(p->obs[3 * i + 2] < 0) ? 1 : 0) | 4);
-    }
-    const size_t need = (size_t)n * (3 + 3 + 1 + 3) * 8 + (size_t)n * 2 + 192 * 8 + sizeof(SE3) + 64 + 16 * 256;
+    // inputs are staged in the pinned mirror of the arena (float32 -> double exactly as Converter / Eigen would promote
+    // them) and sent with ONE copy; the results come back through pinned memory the kernel writes directly
+    const size_t need = (size_t)n * (3 + 3 + 1 + 3) * 8 + (size_t)n * 2 + 32 * 256;
     if ((st = c.bytes.reserve(need))) return st;
     Arena a{c.bytes.p, c.bytes.n};
+    const size_t off0 = a.off;
     double* dXw = a.take<double>((size_t)n * 3);
     double* dobs = a.take<double>((size_t)n * 3);
     double* dinfo = a.take<double>(n);
-    double* derr = a.take<double>((size_t)n * 3);
     unsigned char* dflags = a.take<unsigned char>(n);
-    unsigned char* doutl = a.take<unsigned char>(n);
-    double* dtrace = a.take<double>(192);
-    SE3* dT = a.take<SE3>(1);
-    int* dres = a.take<int>(4);
-    EAO_HIP(hipMemcpyAsync(dXw, hXw.data(), hXw.size() * 8, hipMemcpyHostToDevice, c.stream));
-    EAO_HIP(hipMemcpyAsync(dobs, hobs.data(), hobs.size() * 8, hipMemcpyHostToDevice, c.stream));
-    EAO_HIP(hipMemcpyAsync(dinfo, hinfo.data(), hinfo.size() * 8, hipMemcpyHostToDevice, c.stream));
-    EAO_HIP(hipMemcpyAsync(dflags, hflags.data(), n, hipMemcpyHostToDevice, c.stream));
-    EAO_HIP(hipMemsetAsync(doutl, 0, n, c.stream));
-    EAO_HIP(hipMemsetAsync(derr, 0, (size_t)n * 24, c.stream));
+    const size_t off1 = (a.off + 255) & ~(size_t)255;
+    double* derr = a.take<double>((size_t)n * 3);
+    long long* ddbg = a.take<long long>(8);
+    if (c.pinCap < off1) {
+        if (c.pin) (void)hipHostFree(c.pin);
+        c.pin = nullptr; c.pinCap = 0;
+        EAO_HIP(hipHostMalloc((void**)&c.pin, off1 + (off1 >> 2), hipHostMallocDefault));
+        c.pinCap = off1 + (off1 >> 2);
+    }
+    const size_t outBytes = sizeof(SE3) + 16 + 192 * 8 + 16 + (size_t)n + 64;
+    if (c.pinOutCap < outBytes) {
+        if (c.pinOut) (void)hipHostFree(c.pinOut);
+        c.pinOut = nullptr; c.pinOutCap = 0;
+        EAO_HIP(hipHostMalloc((void**)&c.pinOut, outBytes + (outBytes >> 2), hipHostMallocMapped));
+        c.pinOutCap = outBytes + (outBytes >> 2);
+    }
+    SE3* oT = (SE3*)c.pinOut;
+    double* otrace = (double*)(c.pinOut + ((sizeof(SE3) + 15) & ~(size_t)15));
+    int* ores = (int*)(otrace + 192);
+    unsigned char* ooutl = (unsigned char*)(ores + 4);
+    std::memset(ooutl, 0, n);     // the memory variant of the kernel reads the flags before it first writes them
+    ores[0] = ores[1] = ores[2] = 0;
+    auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
+    {
+        double* hX = (double*)hostp(dXw); double* hO = (double*)hostp(dobs); double* hI = (double*)hostp(dinfo);
+        unsigned char* hF = (unsigned char*)hostp(dflags);
+        for (int i = 0; i < n; i++) {
+            for (int k = 0; k < 3; k++) { hX[3 * i + k] = p->Xw[3 * i + k]; hO[3 * i + k] = p->obs[3 * i + k]; }
+            hI[i] = p->inv_sigma2[i];
+            hF[i] = (unsigned char)((!(p->obs[3 * i + 2] < 0) ? 1 : 0) | 4);
+        }
+    }
+    EAO_HIP(hipEventRecord(c.ev0, c.stream));
+    EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
     PoseDev P;
-    P.n = n; P.Xw = dXw; P.obs = dobs; P.info = dinfo; P.err = derr; P.flags = dflags; P.outlier = doutl;
+    P.n = n; P.Xw = dXw; P.obs = dobs; P.info = dinfo; P.err = derr; P.flags = dflags; P.outlier = ooutl;
     P.T0 = se3_from_Tcw_f32(p->Tcw);
     P.cam.fx = p->fx; P.cam.fy = p->fy; P.cam.cx = p->cx; P.cam.cy = p->cy; P.cam.bf = p->bf; P.cam.bf_f = p->bf;
     P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
-    P.Tout = dT; P.result = dres; P.trace = dtrace;
-    EAO_HIP(hipEventRecord(c.ev0, c.stream));
-    hipLaunchKernelGGL(k_pose_optimization, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
+    P.Tout = oT; P.result = ores; P.trace = otrace;
+    P.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
+    if (n <= 2 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<2>, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
+    else if (n <= 4 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<4>, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
+    else hipLaunchKernelGGL(k_pose_optimization_mem, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
     EAO_HIP(hipEventRecord(c.ev1, c.stream));
-    SE3 Tout;
-    int res[4] = {0, 0, 0, 0};
-    double trace[192];
-    EAO_HIP(hipMemcpyAsync(&Tout, dT, sizeof(SE3), hipMemcpyDeviceToHost, c.stream));
-    EAO_HIP(hipMemcpyAsync(res, dres, sizeof(res), hipMemcpyDeviceToHost, c.stream));
-    EAO_HIP(hipMemcpyAsync(trace, dtrace, sizeof(trace), hipMemcpyDeviceToHost, c.stream));
-    EAO_HIP(hipMemcpyAsync(r->outlier, doutl, n, hipMemcpyDeviceToHost, c.stream));
     EAO_HIP(hipStreamSynchronize(c.stream));
     EAO_HIP(hipGetLastError());
+    const SE3 Tout = *oT;
+    const int* res = ores;
+    const double* trace = otrace;
+    std::memcpy(r->outlier, ooutl, n);
+    if (P.dbg) {
+        long long st[8];
+        EAO_HIP(hipMemcpy(st, P.dbg, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[eao pose stamps] linearize %lld sum28 %lld solve %lld errors %lld sum1 %lld decide %lld shader-cycles\n", st[0], st[1], st[2], st[3], st[4], st[5]);
+    }
     se3_to_Tcw_f32(Tout, r->Tcw);
     r->n_inliers = n - res[0];
     r->lm_iterations = res[1];

@@ -83,7 +83,9 @@ def test_local_ba_rejects_duplicate_edges(gpu):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(n=300, sigma=0.0, outlier_frac=0.0), dict(n=50, seed=4001, mono_frac=1.0),
-                                dict(n=2000, seed=4002, mono_frac=0.0), dict(n=8, seed=4003)])
+                                dict(n=2000, seed=4002, mono_frac=0.0), dict(n=8, seed=4003),
+                                # 2 and 4 register-resident edges per thread, and the global-memory variant beyond 2048
+                                dict(n=1024, seed=4004), dict(n=1025, seed=4005), dict(n=2600, seed=4006)])
 def test_pose_optimization_parity(gpu, oracle, kw):
     p = synth.synth_pose(**kw)
     r = gpu.Optimizer.PoseOptimization(p)
