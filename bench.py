@@ -224,6 +224,23 @@ def measure_extra(E, synth, torch, dev):
                        "ba_residual_blocks_per_s": round(E_ * (lin / reps) / wall, 1),
                        "ba_scalar_residuals_per_s": round(3 * E_ * (lin / reps) / wall, 1),
                        "achieved_GBps": round((lin / reps) * (E_ * 520 + 3000 * 360) / wall / 1e9, 3), "iters": [int(x) for x in r["iters"]]}
+        # independent windows from several host threads (one HIP stream and arena per thread): the single-window kernels
+        # leave most CUs idle, so windows overlap -- the throughput figure for BASELINE configs[4]'s per-window local BA
+        import threading
+        nth, wreps = 8, 6
+        def _work():
+            for _ in range(wreps):
+                E.Optimizer.LocalBundleAdjustment(p)
+        ths = [threading.Thread(target=_work) for _ in range(nth)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dtw = time.perf_counter() - t0
+        extra["ba"]["concurrent_windows"] = {"host_threads": nth, "windows_per_s": round(nth * wreps / dtw, 1),
+                                             "ms_per_window": round(dtw * 1e3 / (nth * wreps), 3),
+                                             "ba_residual_blocks_per_s": round(E_ * (lin / reps) * nth * wreps / dtw, 1)}
         # guided matching of one tracked frame (the two SearchByProjection variants of the tracking loop)
         curf, lastf, mpsf = synth.synth_tracking()
         mt = E.ORBmatcher(0.8, True)

@@ -28,7 +28,8 @@ class FrameView(C.Structure):
                 ("u_right", C.c_void_p), ("descriptors", C.c_void_p), ("occupied", C.c_void_p),
                 ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
                 ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("grid_cols", C.c_int32), ("grid_rows", C.c_int32),
-                ("scale_factors", C.c_void_p), ("nlevels", C.c_int32)]
+                ("scale_factors", C.c_void_p), ("nlevels", C.c_int32),
+                ("log_scale_factor", C.c_float), ("level_sigma2", C.c_void_p), ("inv_level_sigma2", C.c_void_p)]
 
 
 class PoseProblem(C.Structure):
@@ -80,6 +81,9 @@ SYMBOLS = {
     "eao_hamming_best2_device": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
     "eao_search_by_projection_points": (_I, [C.POINTER(FrameView), _I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, C.POINTER(_I)]),
     "eao_search_by_projection_frames": (_I, [C.POINTER(FrameView), _P, _P, _I, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P, C.POINTER(_I)]),
+    # the remaining guided searches: argument lists live in search.py (SEARCH_ARGTYPES), bound there
+    "eao_search_by_projection_sim3": None, "eao_search_by_projection_kf": None, "eao_search_by_bow": None,
+    "eao_search_for_triangulation": None, "eao_search_for_initialization": None, "eao_fuse_search": None, "eao_search_by_sim3": None,
     "eao_pose_optimization": (_I, [C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
     "eao_local_ba": (_I, [C.POINTER(BAProblem), _P, C.POINTER(BAResult)]),
     "eao_last_lm_trace": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),
@@ -98,10 +102,10 @@ def load():
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, sig in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError = ABI drift, fail loudly
-            fn.restype = res
-            fn.argtypes = args
+            if sig is not None:
+                fn.restype, fn.argtypes = sig
         _lib = L
     return _lib
 

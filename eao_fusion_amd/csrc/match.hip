@@ -19,15 +19,12 @@
 #include <vector>
 
 #include "common.h"
+#include "match_internal.h"
+
+using eao::match::Query;
+using eao::match::Lists;
 
 namespace {
-
-struct Query {
-    float x, y, r;            // window centre and half-size
-    int minLevel, maxLevel;   // GetFeaturesInArea level gate (maxLevel < 0: open)
-    float urRef, urTol;       // stereo gate: |urRef - uRight| > urTol rejects (only for keypoints with uRight > 0)
-    int active;
-};
 
 struct FrameDev {
     int n, nOrdered;
@@ -123,13 +120,10 @@ struct Ctx {   // per-thread workspace, grow-only
 };
 thread_local Ctx g_ctx;
 
-struct Lists {
-    std::vector<int> start, count;
-    std::vector<unsigned> items;
-};
+}  // namespace
 
 // uploads the frame + queries, runs the candidate kernel, downloads the compact lists
-eao_status build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L) {
+eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L) {
     Ctx& c = g_ctx;
     eao_status st = eao::require_device();
     if (st) return st;
@@ -205,7 +199,48 @@ eao_status build_lists(const eao_frame_view* F, const std::vector<Query>& q, con
     return EAO_OK;
 }
 
+namespace {
+
+__global__ __launch_bounds__(256) void k_pair_distances(const uint4* __restrict__ A, const uint4* __restrict__ B, const int2* __restrict__ pairs,
+                                                        int n, unsigned short* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int2 p = pairs[k];
+    out[k] = (unsigned short)dist256(A[2 * p.x], A[2 * p.x + 1], B[2 * p.y], B[2 * p.y + 1]);
+}
+
 }  // namespace
+
+eao_status eao::match::pair_distances(const uint8_t* descA, int nA, const uint8_t* descB, int nB, const std::vector<int>& ia,
+                                      const std::vector<int>& ib, std::vector<unsigned short>& dist) {
+    Ctx& c = g_ctx;
+    eao_status st = eao::require_device();
+    if (st) return st;
+    if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    const size_t np = ia.size();
+    dist.assign(np, 0);
+    if (np == 0) return EAO_OK;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    const size_t oA = off; off = al(off + 32 * (size_t)nA);
+    const size_t oB = off; off = al(off + 32 * (size_t)nB);
+    const size_t oP = off; off = al(off + 8 * np);
+    const size_t oD = off; off = al(off + 2 * np);
+    c.host.resize(off);
+    unsigned char* hb = c.host.data();
+    std::memcpy(hb + oA, descA, 32 * (size_t)nA);
+    std::memcpy(hb + oB, descB, 32 * (size_t)nB);
+    for (size_t k = 0; k < np; k++) { ((int*)(hb + oP))[2 * k] = ia[k]; ((int*)(hb + oP))[2 * k + 1] = ib[k]; }
+    if ((st = c.dev.reserve(off))) return st;
+    hipStream_t s = c.stream;
+    EAO_HIP(hipMemcpyAsync(c.dev.p, hb, oD, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pair_distances, dim3(eao::cdiv((int)np, 256)), dim3(256), 0, s, (const uint4*)(c.dev.p + oA), (const uint4*)(c.dev.p + oB),
+                       (const int2*)(c.dev.p + oP), (int)np, (unsigned short*)(c.dev.p + oD));
+    EAO_HIP(hipMemcpyAsync(dist.data(), c.dev.p + oD, 2 * np, hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
 
 extern "C" {
 

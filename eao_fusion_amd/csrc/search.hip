@@ -1,0 +1,532 @@
+// search.hip -- the remaining guided searches of the reference matcher for MI355X (gfx950), host side.
+//
+// Stands behind (include/eao_fusion.h cites each entry point):
+//   SearchByProjection(KeyFrame*, Scw, ...)            src/ORBmatcher.cc:290-403     eao_search_by_projection_sim3
+//   SearchByProjection(Frame&, KeyFrame*, set, ...)     src/ORBmatcher.cc:1474-1601   eao_search_by_projection_kf
+//   SearchByBoW (KF-Frame, KF-KF)                       src/ORBmatcher.cc:159-288, 522-655   eao_search_by_bow
+//   SearchForTriangulation (+ CheckDistEpipolarLine)    src/ORBmatcher.cc:657-823, 140-157   eao_search_for_triangulation
+//   SearchForInitialization                             src/ORBmatcher.cc:405-520     eao_search_for_initialization
+//   Fuse (both overloads, search half)                  src/ORBmatcher.cc:825-975, 977-1100  eao_fuse_search
+//   SearchBySim3                                        src/ORBmatcher.cc:1102-1326   eao_search_by_sim3
+// Division of labour, as for the two per-frame searches in match.hip: the data-parallel part -- every candidate of every
+// query inside its grid window (or vocabulary bucket) with its 256-bit Hamming distance, in upstream's visiting order --
+// runs on the GPU (k_match_candidates / k_pair_distances); the per-query geometry (a dozen float operations that must
+// round exactly like the cv::Mat expressions upstream) and the order-dependent selection loops are replayed on the host
+// over those lists.  cv::Mat float semantics used throughout: A*x (+b) accumulates in double and rounds once; cv::norm
+// and Mat::dot accumulate in double; scalar * matrix is an element-wise float product; PredictScale is float logf/ceilf.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "match_internal.h"
+
+using eao::match::Lists;
+using eao::match::Query;
+
+namespace {
+
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;
+
+void affine3(const float* A, const float* x, const float* b, float alpha, float* y) {
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)A[r * 3 + k] * (double)x[k];
+        y[r] = (float)((double)alpha * s + (b ? (double)b[r] : 0.0));
+    }
+}
+float norm3(const float* v) { return (float)std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); }
+double dot3(const float* a, const float* b) { return (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]; }
+// MapPoint::PredictScale (src/MapPoint.cc:385-394): this fork does not clamp the level
+int predict_scale(float maxDistance, float currentDist, float logScaleFactor) {
+    const float ratio = maxDistance / currentDist;
+    return (int)std::ceil(std::log(ratio) / logScaleFactor);
+}
+bool in_image(const eao_frame_view* K, float x, float y) {   // KeyFrame::IsInImage, src/KeyFrame.cc:649-652
+    return x >= K->min_x && x < K->max_x && y >= K->min_y && y < K->max_y;
+}
+void split_pose(const float* T, float* R, float* t) {
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = T[r * 4 + c]; t[r] = T[r * 4 + 3]; }
+}
+void camera_centre(const float* R, const float* t, float* O) {   // -R^T t
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)R[k * 3 + i] * (double)t[k];
+        O[i] = (float)(-s);
+    }
+}
+void decompose_sim3(const float* S, float* Rcw, float* tcw, float* Ow) {   // src/ORBmatcher.cc:298-303
+    const float scw = (float)std::sqrt((double)S[0] * S[0] + (double)S[1] * S[1] + (double)S[2] * S[2]);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = S[r * 4 + c] / scw;
+        tcw[r] = S[r * 4 + 3] / scw;
+    }
+    camera_centre(Rcw, tcw, Ow);
+}
+
+struct RotHist {    // rotation-consistency histogram + ComputeThreeMaxima (src/ORBmatcher.cc:1603-1644)
+    std::vector<int> bin[HISTO_LENGTH];
+    float factor;
+    explicit RotHist(float f) : factor(f) {}
+    void add(float a1, float a2, int payload) {
+        float rot = a1 - a2;
+        if (rot < 0.0) rot += 360.0f;
+        int b = (int)std::round(rot * factor);
+        if (b == HISTO_LENGTH) b = 0;
+        bin[b].push_back(payload);
+    }
+    template <typename Fn>
+    void reject_minor(Fn&& drop) const {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int s = (int)bin[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int v : bin[i]) drop(v);
+    }
+};
+
+Query window(float u, float v, float r, int minLevel, int maxLevel) {
+    Query q;
+    q.x = u; q.y = v; q.r = r; q.minLevel = minLevel; q.maxLevel = maxLevel;
+    q.urRef = 0.f; q.urTol = INFINITY; q.active = 1;
+    return q;
+}
+Query inactive() { Query q = window(0, 0, 0, -1, -1); q.active = 0; return q; }
+
+bool points_ok(const eao_map_points* P, bool needNormal) {
+    return P && P->n >= 0 && (P->n == 0 || (P->active && P->Xw && P->min_dist_inv && P->max_dist_inv && P->max_dist && P->desc &&
+                                            (!needNormal || P->normal)));
+}
+bool view_ok(const eao_frame_view* F) {
+    return F && F->n >= 0 && (F->n == 0 || (F->kp_x && F->kp_y && F->kp_octave && F->kp_angle && F->u_right && F->descriptors)) &&
+           F->scale_factors && F->nlevels > 0 && F->grid_cols > 0 && F->grid_rows > 0;
+}
+
+// projection of one map point with the range / viewing-angle tests shared by SearchByProjection(KF, Scw), both Fuse
+// overloads: returns false where upstream `continue`s
+struct Shot { float u, v, invz, dist; int level; };
+bool shoot(const eao_frame_view* K, const float* Rcw, const float* tcw, const float* Ow, float fx, float fy, float cx, float cy,
+           const eao_map_points* P, int i, bool invzInDouble, Shot& s) {
+    const float* Xw = P->Xw + 3 * i;
+    float pc[3];
+    affine3(Rcw, Xw, tcw, 1.f, pc);
+    if (pc[2] < 0.0f) return false;
+    s.invz = invzInDouble ? (float)(1.0 / pc[2]) : 1 / pc[2];
+    const float x = pc[0] * s.invz, y = pc[1] * s.invz;
+    s.u = fx * x + cx; s.v = fy * y + cy;
+    if (!in_image(K, s.u, s.v)) return false;
+    const float PO[3] = {Xw[0] - Ow[0], Xw[1] - Ow[1], Xw[2] - Ow[2]};
+    s.dist = norm3(PO);
+    if (s.dist < P->min_dist_inv[i] || s.dist > P->max_dist_inv[i]) return false;
+    if (dot3(PO, P->normal + 3 * i) < 0.5 * s.dist) return false;
+    s.level = predict_scale(P->max_dist[i], s.dist, K->log_scale_factor);
+    return s.level >= 0 && s.level < K->nlevels;   // upstream would index mvScaleFactors out of range otherwise
+}
+
+// merge walk over two feature vectors (std::map iteration + lower_bound, src/ORBmatcher.cc:175-262)
+template <typename Fn>
+void for_common_nodes(const eao_feature_vector* f1, const eao_feature_vector* f2, Fn&& fn) {
+    int a = 0, b = 0;
+    while (a < f1->n_nodes && b < f2->n_nodes) {
+        if (f1->node_id[a] == f2->node_id[b]) { fn(a, b); a++; b++; }
+        else if (f1->node_id[a] < f2->node_id[b]) { while (a < f1->n_nodes && f1->node_id[a] < f2->node_id[b]) a++; }
+        else { while (b < f2->n_nodes && f2->node_id[b] < f1->node_id[a]) b++; }
+    }
+}
+bool fv_ok(const eao_feature_vector* f, int n) {
+    if (!f || f->n_nodes < 0) return false;
+    if (f->n_nodes == 0) return true;
+    if (!f->node_id || !f->node_start || !f->index) return false;
+    for (int k = 0; k < f->n_nodes; k++) {
+        if (k && f->node_id[k] <= f->node_id[k - 1]) return false;
+        if (f->node_start[k + 1] < f->node_start[k]) return false;
+    }
+    for (int p = f->node_start[0]; p < f->node_start[f->n_nodes]; p++)
+        if ((int)f->index[p] >= n) return false;
+    return f->node_start[0] == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+eao_status eao_search_by_projection_sim3(const eao_frame_view* KF, const float* Scw, float fx, float fy, float cx, float cy,
+                                         const eao_map_points* pts, int32_t th, int32_t* kp_match, int32_t* nmatches) {
+    EAO_REQUIRE(view_ok(KF) && Scw && points_ok(pts, true) && kp_match && nmatches, "bad argument");
+    float Rcw[9], tcw[3], Ow[3];
+    decompose_sim3(Scw, Rcw, tcw, Ow);
+    const int n = pts->n;
+    std::vector<Query> q(n, inactive());
+    std::vector<int> level(n, 0);
+    for (int i = 0; i < n; i++) {
+        if (!pts->active[i]) continue;
+        Shot s;
+        if (!shoot(KF, Rcw, tcw, Ow, fx, fy, cx, cy, pts, i, false, s)) continue;
+        level[i] = s.level;
+        q[i] = window(s.u, s.v, th * KF->scale_factors[s.level], -1, -1);
+    }
+    Lists L;
+    eao_status st = eao::match::build_lists(KF, q, pts->desc, L);
+    if (st) return st;
+    std::vector<uint8_t> occ(KF->n, 0);
+    if (KF->occupied) std::memcpy(occ.data(), KF->occupied, KF->n);
+    for (int k = 0; k < KF->n; k++) kp_match[k] = -1;
+    int nm = 0;
+    for (int i = 0; i < n; i++) {
+        if (!q[i].active || L.count[i] == 0) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < L.count[i]; c++) {
+            const unsigned it = L.items[L.start[i] + c];
+            const int k = (int)(it & 0xFFFF), d = (int)(it >> 16);
+            if (occ[k]) continue;
+            const int kl = KF->kp_octave[k];
+            if (kl < level[i] - 1 || kl > level[i]) continue;
+            if (d < bestDist) { bestDist = d; bestIdx = k; }
+        }
+        if (bestDist <= TH_LOW) { kp_match[bestIdx] = i; occ[bestIdx] = 1; nm++; }
+    }
+    *nmatches = nm;
+    return EAO_OK;
+}
+
+eao_status eao_search_by_projection_kf(const eao_frame_view* Cur, const float* Tcw, float fx, float fy, float cx, float cy,
+                                       const eao_map_points* pts, const float* kf_angle, float th, int32_t orb_dist,
+                                       int32_t check_orientation, int32_t* cur_match, int32_t* nmatches) {
+    EAO_REQUIRE(view_ok(Cur) && Tcw && points_ok(pts, false) && cur_match && nmatches && (pts->n == 0 || kf_angle), "bad argument");
+    float Rcw[9], tcw[3], Ow[3];
+    split_pose(Tcw, Rcw, tcw);
+    camera_centre(Rcw, tcw, Ow);
+    const int n = pts->n;
+    std::vector<Query> q(n, inactive());
+    for (int i = 0; i < n; i++) {
+        if (!pts->active[i]) continue;
+        const float* Xw = pts->Xw + 3 * i;
+        float xc[3];
+        affine3(Rcw, Xw, tcw, 1.f, xc);
+        const float invzc = (float)(1.0 / xc[2]);
+        const float u = fx * xc[0] * invzc + cx, v = fy * xc[1] * invzc + cy;
+        if (u < Cur->min_x || u > Cur->max_x) continue;
+        if (v < Cur->min_y || v > Cur->max_y) continue;
+        const float PO[3] = {Xw[0] - Ow[0], Xw[1] - Ow[1], Xw[2] - Ow[2]};
+        const float dist3D = norm3(PO);
+        if (dist3D < pts->min_dist_inv[i] || dist3D > pts->max_dist_inv[i]) continue;
+        const int lvl = predict_scale(pts->max_dist[i], dist3D, Cur->log_scale_factor);
+        if (lvl < 0 || lvl >= Cur->nlevels) continue;
+        q[i] = window(u, v, th * Cur->scale_factors[lvl], lvl - 1, lvl + 1);
+    }
+    Lists L;
+    eao_status st = eao::match::build_lists(Cur, q, pts->desc, L);
+    if (st) return st;
+    std::vector<uint8_t> occ(Cur->n, 0);
+    if (Cur->occupied) std::memcpy(occ.data(), Cur->occupied, Cur->n);
+    for (int k = 0; k < Cur->n; k++) cur_match[k] = -1;
+    RotHist hist(1.0f / HISTO_LENGTH);
+    int nm = 0;
+    for (int i = 0; i < n; i++) {
+        if (!q[i].active || L.count[i] == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < L.count[i]; c++) {
+            const unsigned it = L.items[L.start[i] + c];
+            const int k = (int)(it & 0xFFFF), d = (int)(it >> 16);
+            if (occ[k]) continue;
+            if (d < bestDist) { bestDist = d; bestIdx2 = k; }
+        }
+        if (bestDist <= orb_dist) {
+            cur_match[bestIdx2] = i; occ[bestIdx2] = 1; nm++;
+            if (check_orientation) hist.add(kf_angle[i], Cur->kp_angle[bestIdx2], bestIdx2);
+        }
+    }
+    if (check_orientation) hist.reject_minor([&](int k) { cur_match[k] = -1; nm--; });
+    *nmatches = nm;
+    return EAO_OK;
+}
+
+eao_status eao_search_by_bow(int32_t mode, int32_t n1, const uint8_t* desc1, const float* angle1, const uint8_t* valid1,
+                             const eao_feature_vector* fv1, int32_t n2, const uint8_t* desc2, const float* angle2,
+                             const uint8_t* valid2, const eao_feature_vector* fv2, float nnratio, int32_t check_orientation,
+                             int32_t* match12, int32_t* nmatches) {
+    EAO_REQUIRE((mode == 0 || mode == 1) && n1 >= 0 && n2 >= 0 && match12 && nmatches, "bad argument");
+    EAO_REQUIRE(n1 == 0 || (desc1 && angle1 && valid1), "side 1 arrays missing");
+    EAO_REQUIRE(n2 == 0 || (desc2 && angle2 && (mode == 0 || valid2)), "side 2 arrays missing");
+    EAO_REQUIRE(fv_ok(fv1, n1) && fv_ok(fv2, n2), "malformed feature vector");
+    // every (query, candidate) pair of the common nodes, in visiting order
+    std::vector<int> ia, ib;
+    for_common_nodes(fv1, fv2, [&](int a, int b) {
+        for (int p = fv1->node_start[a]; p < fv1->node_start[a + 1]; p++) {
+            const int idx1 = (int)fv1->index[p];
+            if (!valid1[idx1]) continue;
+            for (int qx = fv2->node_start[b]; qx < fv2->node_start[b + 1]; qx++) {
+                const int idx2 = (int)fv2->index[qx];
+                if (mode == 1 && !valid2[idx2]) continue;
+                ia.push_back(idx1); ib.push_back(idx2);
+            }
+        }
+    });
+    std::vector<unsigned short> dist;
+    eao_status st = eao::match::pair_distances(desc1, n1, desc2, n2, ia, ib, dist);
+    if (st) return st;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<uint8_t> taken2(n2, 0);
+    RotHist hist(1.0f / HISTO_LENGTH);
+    int nm = 0;
+    size_t cur = 0;
+    for_common_nodes(fv1, fv2, [&](int a, int b) {
+        for (int p = fv1->node_start[a]; p < fv1->node_start[a + 1]; p++) {
+            const int idx1 = (int)fv1->index[p];
+            if (!valid1[idx1]) continue;
+            int best1 = 256, bestIdx2 = -1, best2 = 256;
+            for (int qx = fv2->node_start[b]; qx < fv2->node_start[b + 1]; qx++) {
+                const int idx2 = (int)fv2->index[qx];
+                if (mode == 1 && !valid2[idx2]) continue;
+                const int d = dist[cur++];
+                if (taken2[idx2]) continue;
+                if (d < best1) { best2 = best1; best1 = d; bestIdx2 = idx2; }
+                else if (d < best2) { best2 = d; }
+            }
+            const bool close = mode == 0 ? best1 <= TH_LOW : best1 < TH_LOW;
+            if (close && (float)best1 < nnratio * (float)best2) {
+                match12[idx1] = bestIdx2;
+                taken2[bestIdx2] = 1;
+                if (check_orientation) hist.add(angle1[idx1], angle2[bestIdx2], idx1);
+                nm++;
+            }
+        }
+    });
+    if (check_orientation) hist.reject_minor([&](int k) { match12[k] = -1; nm--; });
+    *nmatches = nm;
+    return EAO_OK;
+}
+
+eao_status eao_search_for_triangulation(const eao_frame_view* K1, const eao_feature_vector* fv1, const eao_frame_view* K2,
+                                        const eao_feature_vector* fv2, const float* F12, float ex, float ey,
+                                        int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
+    EAO_REQUIRE(view_ok(K1) && view_ok(K2) && F12 && match12 && nmatches && K2->level_sigma2, "bad argument");
+    EAO_REQUIRE(fv_ok(fv1, K1->n) && fv_ok(fv2, K2->n), "malformed feature vector");
+    auto skip1 = [&](int i) { return (K1->occupied && K1->occupied[i]) || (only_stereo && !(K1->u_right[i] >= 0)); };
+    auto skip2 = [&](int j) { return (K2->occupied && K2->occupied[j]) || (only_stereo && !(K2->u_right[j] >= 0)); };
+    std::vector<int> ia, ib;
+    for_common_nodes(fv1, fv2, [&](int a, int b) {
+        for (int p = fv1->node_start[a]; p < fv1->node_start[a + 1]; p++) {
+            const int idx1 = (int)fv1->index[p];
+            if (skip1(idx1)) continue;
+            for (int qx = fv2->node_start[b]; qx < fv2->node_start[b + 1]; qx++) {
+                const int idx2 = (int)fv2->index[qx];
+                if (skip2(idx2)) continue;
+                ia.push_back(idx1); ib.push_back(idx2);
+            }
+        }
+    });
+    std::vector<unsigned short> dist;
+    eao_status st = eao::match::pair_distances(K1->descriptors, K1->n, K2->descriptors, K2->n, ia, ib, dist);
+    if (st) return st;
+    for (int i = 0; i < K1->n; i++) match12[i] = -1;
+    RotHist hist(1.0f / HISTO_LENGTH);
+    int nm = 0;
+    size_t cur = 0;
+    for_common_nodes(fv1, fv2, [&](int a, int b) {
+        for (int p = fv1->node_start[a]; p < fv1->node_start[a + 1]; p++) {
+            const int idx1 = (int)fv1->index[p];
+            if (skip1(idx1)) continue;
+            const bool stereo1 = K1->u_right[idx1] >= 0;
+            const float x1 = K1->kp_x[idx1], y1 = K1->kp_y[idx1];
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int qx = fv2->node_start[b]; qx < fv2->node_start[b + 1]; qx++) {
+                const int idx2 = (int)fv2->index[qx];
+                if (skip2(idx2)) continue;          // upstream never sets vbMatched2, so side 2 is never consumed
+                const int d = dist[cur++];
+                if (d > TH_LOW || d > bestDist) continue;
+                const bool stereo2 = K2->u_right[idx2] >= 0;
+                const float x2 = K2->kp_x[idx2], y2 = K2->kp_y[idx2];
+                const int oct2 = K2->kp_octave[idx2];
+                if (!stereo1 && !stereo2) {
+                    const float dex = ex - x2, dey = ey - y2;
+                    if (dex * dex + dey * dey < 100 * K2->scale_factors[oct2]) continue;
+                }
+                // CheckDistEpipolarLine (src/ORBmatcher.cc:140-157)
+                const float la = x1 * F12[0] + y1 * F12[3] + F12[6];
+                const float lb = x1 * F12[1] + y1 * F12[4] + F12[7];
+                const float lc = x1 * F12[2] + y1 * F12[5] + F12[8];
+                const float num = la * x2 + lb * y2 + lc;
+                const float den = la * la + lb * lb;
+                if (den == 0) continue;
+                const float dsqr = num * num / den;
+                if (dsqr < 3.84 * K2->level_sigma2[oct2]) { bestIdx2 = idx2; bestDist = d; }
+            }
+            if (bestIdx2 >= 0) {
+                match12[idx1] = bestIdx2;
+                nm++;
+                if (check_orientation) hist.add(K1->kp_angle[idx1], K2->kp_angle[bestIdx2], idx1);
+            }
+        }
+    });
+    if (check_orientation) hist.reject_minor([&](int k) { match12[k] = -1; nm--; });
+    *nmatches = nm;
+    return EAO_OK;
+}
+
+eao_status eao_search_for_initialization(int32_t n1, const int32_t* octave1, const float* angle1, const uint8_t* desc1,
+                                         const eao_frame_view* F2, float* prev_matched, int32_t window_size, float nnratio,
+                                         int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
+    EAO_REQUIRE(n1 >= 0 && view_ok(F2) && match12 && nmatches && (n1 == 0 || (octave1 && angle1 && desc1 && prev_matched)), "bad argument");
+    std::vector<Query> q(n1, inactive());
+    for (int i = 0; i < n1; i++) {
+        if (octave1[i] > 0) continue;
+        q[i] = window(prev_matched[2 * i], prev_matched[2 * i + 1], (float)window_size, octave1[i], octave1[i]);
+    }
+    Lists L;
+    eao_status st = eao::match::build_lists(F2, q, desc1, L);
+    if (st) return st;
+    int nm = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    RotHist hist(1.0f / HISTO_LENGTH);
+    std::vector<int> matchedDistance(F2->n, INT_MAX), matches21(F2->n, -1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (!q[i1].active || L.count[i1] == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < L.count[i1]; c++) {
+            const unsigned it = L.items[L.start[i1] + c];
+            const int i2 = (int)(it & 0xFFFF), d = (int)(it >> 16);
+            if (matchedDistance[i2] <= d) continue;
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
+            else if (d < bestDist2) { bestDist2 = d; }
+        }
+        if (bestDist <= TH_LOW && bestDist < (float)bestDist2 * nnratio) {
+            if (matches21[bestIdx2] >= 0) { match12[matches21[bestIdx2]] = -1; nm--; }
+            match12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matchedDistance[bestIdx2] = bestDist;
+            nm++;
+            if (check_orientation) hist.add(angle1[i1], F2->kp_angle[bestIdx2], i1);
+        }
+    }
+    if (check_orientation) hist.reject_minor([&](int k) { if (match12[k] >= 0) { match12[k] = -1; nm--; } });
+    for (int i1 = 0; i1 < n1; i1++)
+        if (match12[i1] >= 0) { prev_matched[2 * i1] = F2->kp_x[match12[i1]]; prev_matched[2 * i1 + 1] = F2->kp_y[match12[i1]]; }
+    *nmatches = nm;
+    return EAO_OK;
+}
+
+eao_status eao_fuse_search(const eao_frame_view* KF, int32_t use_sim3, const float* pose, float fx, float fy, float cx, float cy,
+                           float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused) {
+    EAO_REQUIRE(view_ok(KF) && pose && points_ok(pts, true) && best_kp && nfused && (use_sim3 || KF->inv_level_sigma2), "bad argument");
+    float Rcw[9], tcw[3], Ow[3];
+    if (use_sim3) decompose_sim3(pose, Rcw, tcw, Ow);
+    else { std::memcpy(Rcw, pose, 36); std::memcpy(tcw, pose + 9, 12); std::memcpy(Ow, pose + 12, 12); }
+    const int n = pts->n;
+    std::vector<Query> q(n, inactive());
+    std::vector<Shot> shot(n);
+    for (int i = 0; i < n; i++) {
+        best_kp[i] = -1;
+        if (!pts->active[i]) continue;
+        if (!shoot(KF, Rcw, tcw, Ow, fx, fy, cx, cy, pts, i, use_sim3 != 0, shot[i])) continue;
+        q[i] = window(shot[i].u, shot[i].v, th * KF->scale_factors[shot[i].level], -1, -1);
+    }
+    Lists L;
+    eao_status st = eao::match::build_lists(KF, q, pts->desc, L);
+    if (st) return st;
+    int nf = 0;
+    for (int i = 0; i < n; i++) {
+        if (!q[i].active || L.count[i] == 0) continue;
+        const Shot& s = shot[i];
+        const float ur = s.u - bf * s.invz;
+        int bestDist = use_sim3 ? INT_MAX : 256, bestIdx = -1;
+        for (int c = 0; c < L.count[i]; c++) {
+            const unsigned it = L.items[L.start[i] + c];
+            const int k = (int)(it & 0xFFFF), d = (int)(it >> 16);
+            const int kl = KF->kp_octave[k];
+            if (kl < s.level - 1 || kl > s.level) continue;
+            if (!use_sim3) {   // reprojection gates of the pose overload (src/ORBmatcher.cc:915-941)
+                const float exx = s.u - KF->kp_x[k], eyy = s.v - KF->kp_y[k];
+                if (KF->u_right[k] >= 0) {
+                    const float er = ur - KF->u_right[k];
+                    const float e2 = exx * exx + eyy * eyy + er * er;
+                    if (e2 * KF->inv_level_sigma2[kl] > 7.8) continue;
+                } else {
+                    const float e2 = exx * exx + eyy * eyy;
+                    if (e2 * KF->inv_level_sigma2[kl] > 5.99) continue;
+                }
+            }
+            if (d < bestDist) { bestDist = d; bestIdx = k; }
+        }
+        if (bestDist <= TH_LOW) { best_kp[i] = bestIdx; nf++; }
+    }
+    *nfused = nf;
+    return EAO_OK;
+}
+
+eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const eao_map_points* pts1, const eao_frame_view* K2,
+                              const float* T2w, const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12,
+                              const float* R12, const float* t12, float th, int32_t* match12, int32_t* nfound) {
+    EAO_REQUIRE(view_ok(K1) && view_ok(K2) && T1w && T2w && points_ok(pts1, false) && points_ok(pts2, false) && R12 && t12 && match12 && nfound,
+                "bad argument");
+    float R1w[9], t1w[3], R2w[9], t2w[3];
+    split_pose(T1w, R1w, t1w);
+    split_pose(T2w, R2w, t2w);
+    float sR12[9], sR21[9], t21[3];
+    const float is12 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { sR12[r * 3 + c] = s12 * R12[r * 3 + c]; sR21[r * 3 + c] = is12 * R12[c * 3 + r]; }
+    affine3(sR21, t12, nullptr, -1.f, t21);
+    auto one_way = [&](const eao_map_points* P, const float* Rw, const float* tw, const float* sR, const float* t,
+                       const eao_frame_view* K, std::vector<int>& out) -> eao_status {
+        const int n = P->n;
+        std::vector<Query> q(n, inactive());
+        std::vector<int> level(n, 0);
+        for (int i = 0; i < n; i++) {
+            if (!P->active[i]) continue;
+            float pa[3], pb[3];
+            affine3(Rw, P->Xw + 3 * i, tw, 1.f, pa);
+            affine3(sR, pa, t, 1.f, pb);
+            if (pb[2] < 0.0) continue;
+            const float invz = (float)(1.0 / pb[2]);
+            const float x = pb[0] * invz, y = pb[1] * invz;
+            const float u = fx * x + cx, v = fy * y + cy;
+            if (!in_image(K, u, v)) continue;
+            const float dist3D = norm3(pb);
+            if (dist3D < P->min_dist_inv[i] || dist3D > P->max_dist_inv[i]) continue;
+            const int lvl = predict_scale(P->max_dist[i], dist3D, K->log_scale_factor);
+            if (lvl < 0 || lvl >= K->nlevels) continue;
+            level[i] = lvl;
+            q[i] = window(u, v, th * K->scale_factors[lvl], -1, -1);
+        }
+        Lists L;
+        eao_status st = eao::match::build_lists(K, q, P->desc, L);
+        if (st) return st;
+        out.assign(n, -1);
+        for (int i = 0; i < n; i++) {
+            if (!q[i].active) continue;
+            int bestDist = INT_MAX, bestIdx = -1;
+            for (int c = 0; c < L.count[i]; c++) {
+                const unsigned it = L.items[L.start[i] + c];
+                const int k = (int)(it & 0xFFFF), d = (int)(it >> 16);
+                if (K->kp_octave[k] < level[i] - 1 || K->kp_octave[k] > level[i]) continue;
+                if (d < bestDist) { bestDist = d; bestIdx = k; }
+            }
+            if (bestDist <= TH_HIGH) out[i] = bestIdx;
+        }
+        return EAO_OK;
+    };
+    std::vector<int> m1, m2;
+    eao_status st = one_way(pts1, R1w, t1w, sR21, t21, K2, m1);
+    if (st) return st;
+    if ((st = one_way(pts2, R2w, t2w, sR12, t12, K1, m2))) return st;
+    int nf = 0;
+    for (int i1 = 0; i1 < pts1->n; i1++) {
+        match12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && idx2 < pts2->n && m2[idx2] == i1) { match12[i1] = idx2; nf++; }
+    }
+    *nfound = nf;
+    return EAO_OK;
+}
+
+}  // extern "C"

@@ -60,7 +60,7 @@ def make_frame_view(frame, view_cls=None):
     v = cls(len(keep["kp_x"]), _lib.ptr(keep["kp_x"]), _lib.ptr(keep["kp_y"]), _lib.ptr(keep["kp_octave"]), _lib.ptr(keep["kp_angle"]),
             _lib.ptr(keep["u_right"]), _lib.ptr(keep["descriptors"]), _lib.ptr(keep["occupied"]),
             frame["min_x"], frame["min_y"], frame["max_x"], frame["max_y"], inv_w, inv_h, cols, rows,
-            _lib.ptr(keep["scale_factors"]), len(keep["scale_factors"]))
+            _lib.ptr(keep["scale_factors"]), len(keep["scale_factors"]), 0.0, None, None)
     return v, keep
 
 

@@ -214,3 +214,98 @@ def synth_tracking(n=1000, seed=7000, flip=0.06, moved=0.03, mono_frac=0.3, occu
     mps = dict(proj_x=u.astype(np.float32), proj_y=v.astype(np.float32), proj_xr=(u - BF / Xc[:, 2]).astype(np.float32),
                view_cos=view_cos, level=octave, descriptors=desc_last, skip=(rng.random(n) < 0.1).astype(np.uint8))
     return cur, last, mps
+
+
+def synth_search_scene(n=800, seed=8000, flip=0.05, clutter=0.15, mono_frac=0.3, n_nodes=60):
+    """Two keyframes K1 / K2 (frame views with grid bounds, level sigmas, log scale factor) observing `n` map points from
+    two poses, for the remaining guided searches (SearchByBoW, SearchForTriangulation, SearchForInitialization, Fuse,
+    SearchBySim3, the loop / relocalisation SearchByProjection variants).
+    Returns a dict:
+      K1, K2     frame dicts; keypoint k < n of K1 observes map point perm1[k] (-1 = clutter), likewise K2 / perm2
+      T1w, T2w   4x4 float32 poses;  K = (fx, fy, cx, cy), bf
+      points     map-point arrays (active, Xw, normal, min/max distance invariance, max_dist, descriptors)
+      mp1, mp2   per keypoint: index of its map point or -1
+      fv1, fv2   DBoW2-like feature vectors (node = map point id mod n_nodes for inliers, with 10 % reassigned)
+      F12, ex, ey fundamental matrix (x1' F12 x2 = 0 convention of the reference) and the epipole in image 2
+      Scw        sim3 of K2's pose with scale 1.03 (float32 4x4)"""
+    rng = np.random.default_rng(seed)
+    nlev = 8
+    scale = np.cumprod(np.concatenate([[1.0], np.full(nlev - 1, 1.2)])).astype(np.float32)
+    sigma2 = (scale * scale).astype(np.float32)
+    inv_sigma2 = (np.float32(1.0) / sigma2).astype(np.float32)
+    logsf = np.float32(np.log(np.float32(1.2)))
+    Xw = np.empty((n, 3))
+    Xw[:, 2] = rng.uniform(2.5, 6.0, n)
+    Xw[:, 0] = rng.uniform(-0.45, 0.45, n) * Xw[:, 2]
+    Xw[:, 1] = rng.uniform(-0.35, 0.35, n) * Xw[:, 2]
+    T1 = np.eye(4)
+    T2 = np.eye(4)
+    T2[:3, :3] = _rot(0.02, -0.05, 0.01)
+    T2[:3, 3] = [-0.25, 0.03, 0.05]
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    level = rng.integers(0, nlev - 1, n).astype(np.int32)
+    angle0 = rng.uniform(0, 360, n)
+
+    def observe(T, rot_off, seed_off):
+        r = np.random.default_rng(seed + seed_off)
+        Xc = Xw @ T[:3, :3].T + T[:3, 3]
+        u = FX * Xc[:, 0] / Xc[:, 2] + CX
+        v = FY * Xc[:, 1] / Xc[:, 2] + CY
+        nc = int(n * clutter)
+        N = n + nc
+        oct_ = np.concatenate([np.clip(level + r.integers(-1, 2, n), 0, nlev - 1), r.integers(0, nlev, nc)]).astype(np.int32)
+        kx = np.concatenate([u + r.normal(0, 0.8, n) * scale[oct_[:n]], r.uniform(0, 640, nc)])
+        ky = np.concatenate([v + r.normal(0, 0.8, n) * scale[oct_[:n]], r.uniform(0, 480, nc)])
+        bits = np.unpackbits(desc, axis=1) ^ (r.random((n, 256)) < flip).astype(np.uint8)
+        kd = np.concatenate([np.packbits(bits, axis=1), r.integers(0, 256, (nc, 32), dtype=np.uint8)])
+        ka = np.concatenate([(angle0 + rot_off + r.normal(0, 3, n)) % 360, r.uniform(0, 360, nc)]).astype(np.float32)
+        ur = np.concatenate([u - BF / Xc[:, 2] + r.normal(0, 0.5, n), r.uniform(0, 600, nc)])
+        mono = r.random(N) < mono_frac
+        ur = np.where(mono, -1.0, np.maximum(ur, 0.5))
+        mp = np.concatenate([np.arange(n), np.full(nc, -1)]).astype(np.int32)
+        inside = (kx > 1) & (kx < 639) & (ky > 1) & (ky < 479)
+        mp = np.where(inside, mp, -1)
+        perm = r.permutation(N)
+        node = np.where(mp >= 0, mp % n_nodes, r.integers(0, n_nodes, N))
+        node = np.where(r.random(N) < 0.1, r.integers(0, n_nodes, N), node)[perm]
+        frame = dict(kp_x=kx[perm].astype(np.float32), kp_y=ky[perm].astype(np.float32), kp_octave=oct_[perm], kp_angle=ka[perm],
+                     u_right=ur[perm].astype(np.float32), descriptors=np.ascontiguousarray(kd[perm]),
+                     min_x=np.float32(0), min_y=np.float32(0), max_x=np.float32(640), max_y=np.float32(480), scale_factors=scale,
+                     log_scale_factor=logsf, level_sigma2=sigma2, inv_level_sigma2=inv_sigma2)
+        ids = np.unique(node)
+        start, index = [0], []
+        for nid in ids:   # keypoints of a node in ascending index order (DBoW2 appends them in feature order)
+            idx = np.nonzero(node == nid)[0]
+            index.extend(idx.tolist())
+            start.append(len(index))
+        fv = dict(node_id=ids.astype(np.uint32), node_start=np.asarray(start, np.int32), index=np.asarray(index, np.uint32))
+        return frame, mp[perm], fv
+
+    K1, mp1, fv1 = observe(T1, 0.0, 1)
+    K2, mp2, fv2 = observe(T2, 15.0, 2)
+    # MapPoint::UpdateNormalAndDepth (src/MapPoint.cc:330-370) with K1 as the reference keyframe
+    O1 = -T1[:3, :3].T @ T1[:3, 3]
+    O2 = -T2[:3, :3].T @ T2[:3, 3]
+    n1 = Xw - O1
+    n2 = Xw - O2
+    normal = n1 / np.linalg.norm(n1, axis=1, keepdims=True) + n2 / np.linalg.norm(n2, axis=1, keepdims=True)
+    normal /= 2.0
+    dist = np.linalg.norm(n1, axis=1).astype(np.float32)
+    max_dist = (dist * scale[level]).astype(np.float32)
+    min_dist = (max_dist / scale[nlev - 1]).astype(np.float32)
+    points = dict(active=(rng.random(n) < 0.92).astype(np.uint8), Xw=Xw.astype(np.float32), normal=normal.astype(np.float32),
+                  min_dist_inv=(np.float32(0.8) * min_dist).astype(np.float32), max_dist_inv=(np.float32(1.2) * max_dist).astype(np.float32),
+                  max_dist=max_dist, descriptors=desc)
+    # F12 = K^-T [t12]x R12 K^-1 (LocalMapping::ComputeF12, src/LocalMapping.cc): x1' F12 x2 = 0
+    R12 = T1[:3, :3] @ T2[:3, :3].T
+    t12 = -R12 @ T2[:3, 3] + T1[:3, 3]
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    Km = np.array([[FX, 0, CX], [0, FY, CY], [0, 0, 1.0]])
+    F12 = np.linalg.inv(Km).T @ tx @ R12 @ np.linalg.inv(Km)
+    C2 = T2[:3, :3] @ O1 + T2[:3, 3]
+    ex, ey = FX * C2[0] / C2[2] + CX, FY * C2[1] / C2[2] + CY
+    Scw = T2.copy()
+    Scw[:3, :] *= 1.03
+    return dict(K1=K1, K2=K2, T1w=T1.astype(np.float32), T2w=T2.astype(np.float32), K=(np.float32(FX), np.float32(FY), np.float32(CX), np.float32(CY)),
+                bf=np.float32(BF), points=points, mp1=mp1, mp2=mp2, fv1=fv1, fv2=fv2, F12=F12.astype(np.float32), ex=np.float32(ex),
+                ey=np.float32(ey), Scw=Scw.astype(np.float32), R12=R12.astype(np.float32), t12=t12.astype(np.float32))

@@ -159,6 +159,10 @@ typedef struct {
     int32_t grid_cols, grid_rows;       /* FRAME_GRID_COLS, FRAME_GRID_ROWS (64 x 48 upstream) */
     const float* scale_factors;         /* mvScaleFactors */
     int32_t nlevels;
+    /* only read by the entry points that say so (may be 0 / NULL otherwise) */
+    float log_scale_factor;             /* mfLogScaleFactor */
+    const float* level_sigma2;          /* mvLevelSigma2 */
+    const float* inv_level_sigma2;      /* mvInvLevelSigma2 */
 } eao_frame_view;
 
 /* SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th): map points that are in view.
@@ -181,6 +185,84 @@ eao_status eao_search_by_projection_frames(const eao_frame_view* Cur, const floa
                                            const int32_t* last_octave, const float* last_angle, float fx, float fy, float cx,
                                            float cy, float mbf, float mb, float th, int32_t mono, int32_t check_orientation,
                                            int32_t* cur_match, int32_t* nmatches);
+
+/* Map points as plain arrays (what the remaining searches read through MapPoint's accessors). */
+typedef struct {
+    int32_t n;
+    const uint8_t* active;        /* n: 0 where upstream `continue`s before looking at the point (NULL pointer, isBad(),
+                                     member of the caller's "already found" set, IsInKeyFrame(pKF), ...) */
+    const float* Xw;              /* n*3  GetWorldPos() */
+    const float* normal;          /* n*3  GetNormal()  (NULL for the searches that have no viewing-angle test) */
+    const float* min_dist_inv;    /* n    GetMinDistanceInvariance() */
+    const float* max_dist_inv;    /* n    GetMaxDistanceInvariance() */
+    const float* max_dist;        /* n    mfMaxDistance, the numerator of PredictScale (src/MapPoint.cc:385-394) */
+    const uint8_t* desc;          /* n*32 GetDescriptor() */
+} eao_map_points;
+
+/* DBoW2::FeatureVector of one frame: nodes in ascending id, each with its keypoint indices (std::map order). */
+typedef struct {
+    int32_t n_nodes;
+    const uint32_t* node_id;      /* n_nodes, strictly ascending */
+    const int32_t* node_start;    /* n_nodes + 1 offsets into index */
+    const uint32_t* index;        /* keypoint indices, in the order of the node's vector */
+} eao_feature_vector;
+
+/* a13  SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th)
+ * -- src/ORBmatcher.cc:290-403 (loop detection).  KF->occupied[k] != 0 where vpMatched[k] != NULL on entry; active[i] = 0
+ * for bad points and members of spAlreadyFound.  Reads KF->log_scale_factor.  kp_match[k] receives the index of the point
+ * assigned to keypoint k during the call, or -1. */
+eao_status eao_search_by_projection_sim3(const eao_frame_view* KF, const float* Scw, float fx, float fy, float cx, float cy,
+                                         const eao_map_points* pts, int32_t th, int32_t* kp_match, int32_t* nmatches);
+
+/* a13  SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * -- src/ORBmatcher.cc:1474-1601 (relocalisation).  pts = pKF->GetMapPointMatches() (active[i] = 0 for NULL, bad or already
+ * found), kf_angle[i] = pKF->mvKeysUn[i].angle; Cur->occupied = CurrentFrame.mvpMapPoints[k] != NULL.  cur_match[k]
+ * receives the map-point index assigned to current keypoint k or -1 (after the rotation filter, whose histogram factor
+ * is 1/HISTO_LENGTH here, :1486). */
+eao_status eao_search_by_projection_kf(const eao_frame_view* Cur, const float* Tcw, float fx, float fy, float cx, float cy,
+                                       const eao_map_points* pts, const float* kf_angle, float th, int32_t orb_dist,
+                                       int32_t check_orientation, int32_t* cur_match, int32_t* nmatches);
+
+/* a14  SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) -- src/ORBmatcher.cc:159-288 (mode 0) and
+ *      SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) -- :522-655 (mode 1).
+ * Side 1 is the keyframe whose map points drive the search: valid1[i] != 0 where its map point exists and is not bad.
+ * mode 0: side 2 is the frame; a frame keypoint taken during the call is skipped afterwards; accept best <= TH_LOW.
+ * mode 1: valid2[j] != 0 where pKF2's map point exists and is not bad; accept best < TH_LOW.
+ * Both: best < nnratio * second.  match12[i] receives the side-2 index matched to side-1 keypoint i or -1. */
+eao_status eao_search_by_bow(int32_t mode, int32_t n1, const uint8_t* desc1, const float* angle1, const uint8_t* valid1,
+                             const eao_feature_vector* fv1, int32_t n2, const uint8_t* desc2, const float* angle2,
+                             const uint8_t* valid2, const eao_feature_vector* fv2, float nnratio, int32_t check_orientation,
+                             int32_t* match12, int32_t* nmatches);
+
+/* a15  SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) -- src/ORBmatcher.cc:657-823, with
+ * CheckDistEpipolarLine :140-157.  K1 / K2: keypoints (kp_x, kp_y, kp_octave, kp_angle, u_right, descriptors;
+ * occupied[k] != 0 where the keyframe already has a map point at k); K2->level_sigma2 and K2->scale_factors are read.
+ * F12: 9 floats row-major; (ex, ey) the epipole in image 2 (:663-670).  match12[i] = index in K2 or -1. */
+eao_status eao_search_for_triangulation(const eao_frame_view* K1, const eao_feature_vector* fv1, const eao_frame_view* K2,
+                                        const eao_feature_vector* fv2, const float* F12, float ex, float ey,
+                                        int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches);
+
+/* a15  SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) -- src/ORBmatcher.cc:405-520.
+ * F1: n1 keypoints (octave, angle, descriptors); prev_matched: n1 x 2 floats, updated in place like vbPrevMatched. */
+eao_status eao_search_for_initialization(int32_t n1, const int32_t* octave1, const float* angle1, const uint8_t* desc1,
+                                         const eao_frame_view* F2, float* prev_matched, int32_t window, float nnratio,
+                                         int32_t check_orientation, int32_t* match12, int32_t* nmatches);
+
+/* a15  the search half of Fuse(KeyFrame*, const vector<MapPoint*>&, th) -- src/ORBmatcher.cc:825-975 (use_sim3 = 0:
+ * pose = Rcw (9) | tcw (3) | Ow (3) as 15 floats; reads KF->inv_level_sigma2 and the stereo / monocular chi2 gates) and of
+ * Fuse(KeyFrame*, cv::Mat Scw, vpPoints, th, vpReplacePoint) -- :977-1100 (use_sim3 = 1: pose = Scw, 16 floats).
+ * best_kp[i] receives the keypoint the point would be fused into (best distance <= TH_LOW) or -1; replacing or adding the
+ * observation is the caller's part (it mutates the map), in index order, re-checking isBad() as upstream would. */
+eao_status eao_fuse_search(const eao_frame_view* KF, int32_t use_sim3, const float* pose, float fx, float fy, float cx, float cy,
+                           float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused);
+
+/* a15  SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) -- src/ORBmatcher.cc:1102-1326.  pts1 / pts2: the map
+ * points of the two keyframes by keypoint index (active = exists, not bad, not already matched); T1w / T2w: 16 floats.
+ * match12[i] = keypoint of KF2 whose map point agrees in both directions, or -1 (already matched entries are not touched
+ * by the caller). */
+eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const eao_map_points* pts1, const eao_frame_view* K2,
+                              const float* T2w, const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12,
+                              const float* R12, const float* t12, float th, int32_t* match12, int32_t* nfound);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer::PoseOptimization(Frame*) -- reference include/Optimizer.h:56, src/Optimizer.cc:325-673

@@ -25,6 +25,7 @@ struct FrameView {   // same layout as eao_frame_view (include/eao_fusion.h)
     float min_x, min_y, max_x, max_y, grid_inv_w, grid_inv_h;
     int32_t grid_cols, grid_rows;
     const float* scale_factors; int32_t nlevels;
+    float log_scale_factor; const float* level_sigma2; const float* inv_level_sigma2;   // unused here
 };
 
 int dist256(const uint8_t* a, const uint8_t* b) {

@@ -246,7 +246,8 @@ class FrameView(C.Structure):   # same layout as eao_frame_view
                 ("u_right", C.c_void_p), ("descriptors", C.c_void_p), ("occupied", C.c_void_p),
                 ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
                 ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("grid_cols", C.c_int32), ("grid_rows", C.c_int32),
-                ("scale_factors", C.c_void_p), ("nlevels", C.c_int32)]
+                ("scale_factors", C.c_void_p), ("nlevels", C.c_int32),
+                ("log_scale_factor", C.c_float), ("level_sigma2", C.c_void_p), ("inv_level_sigma2", C.c_void_p)]
 
 
 def _frame_view(frame):
@@ -261,7 +262,7 @@ def _frame_view(frame):
     inv_h = np.float32(rows) / np.float32(np.float32(frame["max_y"]) - np.float32(frame["min_y"]))
     v = FrameView(len(keep["kp_x"]), _p(keep["kp_x"]), _p(keep["kp_y"]), _p(keep["kp_octave"]), _p(keep["kp_angle"]), _p(keep["u_right"]),
                   _p(keep["descriptors"]), _p(keep["occupied"]), frame["min_x"], frame["min_y"], frame["max_x"], frame["max_y"],
-                  inv_w, inv_h, cols, rows, _p(keep["scale_factors"]), len(keep["scale_factors"]))
+                  inv_w, inv_h, cols, rows, _p(keep["scale_factors"]), len(keep["scale_factors"]), 0.0, None, None)
     return v, keep
 
 

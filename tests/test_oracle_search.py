@@ -1,0 +1,439 @@
+"""CPU: the oracle's restatement of the remaining guided searches (oracle/search_cpu.cpp) against an independent replay
+written here from the reference text (src/ORBmatcher.cc:140-1326,1474-1601): candidates come from a brute-force scan of
+the gridded keypoints in grid order instead of the cell walk, distances from numpy bit counts, geometry from explicit
+float32 / float64 scalar arithmetic."""
+import math
+
+import numpy as np
+import pytest
+
+from eao_fusion_amd import search, synth
+
+F32 = np.float32
+TH_LOW, TH_HIGH, HISTO = 50, 100, 30
+
+
+@pytest.fixture(scope="module")
+def orc(oracle):
+    return search.Binding(oracle.lib(), "orc_")
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return synth.synth_search_scene(n=220, seed=8100, n_nodes=25)
+
+
+def ham(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+class Gridded:
+    def __init__(self, fr):
+        self.fr = fr
+        cols, rows = 64, 48
+        self.inv_w = F32(cols) / F32(F32(fr["max_x"]) - F32(fr["min_x"]))
+        self.inv_h = F32(rows) / F32(F32(fr["max_y"]) - F32(fr["min_y"]))
+        order = []
+        for i in range(len(fr["kp_x"])):
+            px = int(np.round(F32(F32(fr["kp_x"][i]) - F32(fr["min_x"])) * self.inv_w))
+            py = int(np.round(F32(F32(fr["kp_y"][i]) - F32(fr["min_y"])) * self.inv_h))
+            if 0 <= px < cols and 0 <= py < rows:
+                order.append((px, py, i))
+        order.sort()
+        self.order = [i for _, _, i in order]
+
+    def area(self, x, y, r, lo, hi):
+        fr, out = self.fr, []
+        x, y, r = F32(x), F32(y), F32(r)
+        check = lo > 0 or hi >= 0
+        for i in self.order:
+            o = int(fr["kp_octave"][i])
+            if check and (o < lo or (hi >= 0 and o > hi)):
+                continue
+            if abs(F32(fr["kp_x"][i]) - x) < r and abs(F32(fr["kp_y"][i]) - y) < r:
+                out.append(i)
+        return out
+
+
+def affine(A, x, b=None, alpha=1.0):
+    out = []
+    for r in range(3):
+        s = float(A[r][0]) * float(x[0]) + float(A[r][1]) * float(x[1]) + float(A[r][2]) * float(x[2])
+        out.append(F32(alpha * s + (float(b[r]) if b is not None else 0.0)))
+    return out
+
+
+def norm3(v):
+    return F32(math.sqrt(float(v[0]) * float(v[0]) + float(v[1]) * float(v[1]) + float(v[2]) * float(v[2])))
+
+
+def predict(maxd, d, lsf):
+    return int(np.ceil(np.log(F32(maxd) / F32(d)) / F32(lsf)))
+
+
+def decompose(S):
+    scw = F32(math.sqrt(float(S[0][0]) ** 2 + float(S[0][1]) ** 2 + float(S[0][2]) ** 2))
+    R = [[F32(S[r][c]) / scw for c in range(3)] for r in range(3)]
+    t = [F32(S[r][3]) / scw for r in range(3)]
+    Ow = [F32(-(float(R[0][i]) * float(t[0]) + float(R[1][i]) * float(t[1]) + float(R[2][i]) * float(t[2]))) for i in range(3)]
+    return R, t, Ow
+
+
+def in_image(fr, u, v):
+    return fr["min_x"] <= u < fr["max_x"] and fr["min_y"] <= v < fr["max_y"]
+
+
+def rot_filter(hist, drop):
+    sizes = [len(h) for h in hist]
+    m1 = m2 = m3 = 0
+    i1 = i2 = i3 = -1
+    for i, s in enumerate(sizes):
+        if s > m1:
+            m3, m2, m1, i3, i2, i1 = m2, m1, s, i2, i1, i
+        elif s > m2:
+            m3, m2, i3, i2 = m2, s, i2, i
+        elif s > m3:
+            m3, i3 = s, i
+    if m2 < F32(0.1) * F32(m1):
+        i2 = i3 = -1
+    elif m3 < F32(0.1) * F32(m1):
+        i3 = -1
+    for i, h in enumerate(hist):
+        if i not in (i1, i2, i3):
+            for v in h:
+                drop(v)
+
+
+def rbin(a1, a2, factor=F32(1.0) / F32(HISTO)):
+    rot = F32(a1) - F32(a2)
+    if rot < 0:
+        rot = rot + F32(360.0)
+    b = int(np.round(rot * factor))
+    return 0 if b == HISTO else b
+
+
+def shoot(fr, R, t, Ow, K, P, i, invz_double):
+    fx, fy, cx, cy = K
+    Xw = P["Xw"][i]
+    pc = affine(R, Xw, t)
+    if pc[2] < 0:
+        return None
+    invz = F32(1.0 / float(pc[2])) if invz_double else F32(1) / pc[2]
+    u, v = fx * (pc[0] * invz) + cx, fy * (pc[1] * invz) + cy
+    if not in_image(fr, u, v):
+        return None
+    PO = [F32(Xw[k]) - Ow[k] for k in range(3)]
+    dist = norm3(PO)
+    if dist < P["min_dist_inv"][i] or dist > P["max_dist_inv"][i]:
+        return None
+    nrm = P["normal"][i]
+    if float(PO[0]) * float(nrm[0]) + float(PO[1]) * float(nrm[1]) + float(PO[2]) * float(nrm[2]) < 0.5 * float(dist):
+        return None
+    lvl = predict(P["max_dist"][i], dist, fr["log_scale_factor"])
+    if not 0 <= lvl < len(fr["scale_factors"]):
+        return None
+    return u, v, invz, dist, lvl
+
+
+def test_search_by_projection_sim3(orc, scene):
+    kf = dict(scene["K2"])
+    kf["occupied"] = (np.arange(len(kf["kp_x"])) % 13 == 0).astype(np.uint8)
+    P = scene["points"]
+    n_o, got = orc.search_by_projection_sim3(kf, scene["Scw"], scene["K"], P, 10)
+    g = Gridded(kf)
+    R, t, Ow = decompose(scene["Scw"])
+    occ = kf["occupied"].copy()
+    exp = np.full(len(kf["kp_x"]), -1, np.int32)
+    for i in range(len(P["active"])):
+        if not P["active"][i]:
+            continue
+        s = shoot(kf, R, t, Ow, scene["K"], P, i, False)
+        if s is None:
+            continue
+        u, v, _, _, lvl = s
+        best, bi = 256, -1
+        for k in g.area(u, v, F32(10) * kf["scale_factors"][lvl], -1, -1):
+            if occ[k] or not (lvl - 1 <= kf["kp_octave"][k] <= lvl):
+                continue
+            d = ham(P["descriptors"][i], kf["descriptors"][k])
+            if d < best:
+                best, bi = d, k
+        if best <= TH_LOW:
+            exp[bi] = i
+            occ[bi] = 1
+    assert np.array_equal(got, exp) and n_o == int((exp >= 0).sum()) and n_o > 20
+
+
+def test_search_by_projection_kf(orc, scene):
+    cur = dict(scene["K2"])
+    cur["occupied"] = (np.arange(len(cur["kp_x"])) % 11 == 0).astype(np.uint8)
+    P = scene["points"]
+    ang = ((np.arange(len(P["active"])) * 37) % 360).astype(np.float32)
+    for check in (False, True):
+        n_o, got = orc.search_by_projection_kf(cur, scene["T2w"], scene["K"], P, ang, 15, 90, check)
+        g = Gridded(cur)
+        T = scene["T2w"]
+        R = [list(T[r][:3]) for r in range(3)]
+        t = [T[r][3] for r in range(3)]
+        Ow = [F32(-(float(R[0][i]) * float(t[0]) + float(R[1][i]) * float(t[1]) + float(R[2][i]) * float(t[2]))) for i in range(3)]
+        fx, fy, cx, cy = scene["K"]
+        occ = cur["occupied"].copy()
+        exp = np.full(len(cur["kp_x"]), -1, np.int32)
+        hist = [[] for _ in range(HISTO)]
+        for i in range(len(P["active"])):
+            if not P["active"][i]:
+                continue
+            xc = affine(R, P["Xw"][i], t)
+            invz = F32(1.0 / float(xc[2]))
+            u, v = fx * xc[0] * invz + cx, fy * xc[1] * invz + cy
+            if u < cur["min_x"] or u > cur["max_x"] or v < cur["min_y"] or v > cur["max_y"]:
+                continue
+            d3 = norm3([F32(P["Xw"][i][k]) - Ow[k] for k in range(3)])
+            if d3 < P["min_dist_inv"][i] or d3 > P["max_dist_inv"][i]:
+                continue
+            lvl = predict(P["max_dist"][i], d3, cur["log_scale_factor"])
+            if not 0 <= lvl < 8:
+                continue
+            best, bi = 256, -1
+            for k in g.area(u, v, F32(15) * cur["scale_factors"][lvl], lvl - 1, lvl + 1):
+                if occ[k]:
+                    continue
+                d = ham(P["descriptors"][i], cur["descriptors"][k])
+                if d < best:
+                    best, bi = d, k
+            if best <= 90:
+                exp[bi] = i
+                occ[bi] = 1
+                hist[rbin(ang[i], cur["kp_angle"][bi])].append(bi)
+        if check:
+            rot_filter(hist, lambda k: exp.__setitem__(k, -1))
+        assert np.array_equal(got, exp) and n_o == int((exp >= 0).sum())
+
+
+def _sides(scene):
+    def side(K, mp, fv):
+        return dict(descriptors=K["descriptors"], angle=K["kp_angle"], valid=(mp >= 0).astype(np.uint8), fv=fv)
+    return side(scene["K1"], scene["mp1"], scene["fv1"]), side(scene["K2"], scene["mp2"], scene["fv2"])
+
+
+def _common(f1, f2):
+    ids2 = {int(n): j for j, n in enumerate(f2["node_id"])}
+    for a, n in enumerate(f1["node_id"]):
+        if int(n) in ids2:
+            b = ids2[int(n)]
+            yield (f1["index"][f1["node_start"][a]:f1["node_start"][a + 1]], f2["index"][f2["node_start"][b]:f2["node_start"][b + 1]])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_search_by_bow(orc, scene, mode):
+    s1, s2 = _sides(scene)
+    ratio = 0.75
+    n_o, got = orc.search_by_bow(mode, s1, s2, ratio, True)
+    exp = np.full(len(s1["descriptors"]), -1, np.int32)
+    taken = np.zeros(len(s2["descriptors"]), bool)
+    hist = [[] for _ in range(HISTO)]
+    for b1, b2 in _common(s1["fv"], s2["fv"]):
+        for i1 in b1:
+            if not s1["valid"][i1]:
+                continue
+            d1 = d2 = 256
+            j1 = -1
+            for i2 in b2:
+                if taken[i2] or (mode == 1 and not s2["valid"][i2]):
+                    continue
+                d = ham(s1["descriptors"][i1], s2["descriptors"][i2])
+                if d < d1:
+                    d2, d1, j1 = d1, d, i2
+                elif d < d2:
+                    d2 = d
+            close = d1 <= TH_LOW if mode == 0 else d1 < TH_LOW
+            if close and F32(d1) < F32(ratio) * F32(d2):
+                exp[i1] = j1
+                taken[j1] = True
+                hist[rbin(s1["angle"][i1], s2["angle"][j1])].append(i1)
+    rot_filter(hist, lambda k: exp.__setitem__(k, -1))
+    assert np.array_equal(got, exp) and n_o == int((exp >= 0).sum()) and n_o > 20
+
+
+@pytest.mark.parametrize("only_stereo", [0, 1])
+def test_search_for_triangulation(orc, scene, only_stereo):
+    k1, k2 = dict(scene["K1"]), dict(scene["K2"])
+    k1["occupied"] = ((scene["mp1"] >= 0) & (np.arange(len(scene["mp1"])) % 2 == 0)).astype(np.uint8)
+    k2["occupied"] = ((scene["mp2"] >= 0) & (np.arange(len(scene["mp2"])) % 3 == 0)).astype(np.uint8)
+    F, ex, ey = scene["F12"], scene["ex"], scene["ey"]
+    n_o, got = orc.search_for_triangulation(k1, scene["fv1"], k2, scene["fv2"], F, ex, ey, only_stereo, True)
+    exp = np.full(len(k1["kp_x"]), -1, np.int32)
+    hist = [[] for _ in range(HISTO)]
+    for b1, b2 in _common(scene["fv1"], scene["fv2"]):
+        for i1 in b1:
+            st1 = k1["u_right"][i1] >= 0
+            if k1["occupied"][i1] or (only_stereo and not st1):
+                continue
+            best, bi = TH_LOW, -1
+            x1, y1 = k1["kp_x"][i1], k1["kp_y"][i1]
+            for i2 in b2:
+                st2 = k2["u_right"][i2] >= 0
+                if k2["occupied"][i2] or (only_stereo and not st2):
+                    continue
+                d = ham(k1["descriptors"][i1], k2["descriptors"][i2])
+                if d > TH_LOW or d > best:
+                    continue
+                x2, y2, o2 = k2["kp_x"][i2], k2["kp_y"][i2], k2["kp_octave"][i2]
+                if not st1 and not st2:
+                    dx, dy = ex - x2, ey - y2
+                    if dx * dx + dy * dy < F32(100) * k2["scale_factors"][o2]:
+                        continue
+                a = x1 * F[0][0] + y1 * F[1][0] + F[2][0]
+                b = x1 * F[0][1] + y1 * F[1][1] + F[2][1]
+                c = x1 * F[0][2] + y1 * F[1][2] + F[2][2]
+                num = a * x2 + b * y2 + c
+                den = a * a + b * b
+                if den == 0:
+                    continue
+                if float(num * num / den) < 3.84 * float(k2["level_sigma2"][o2]):
+                    best, bi = d, i2
+            if bi >= 0:
+                exp[i1] = bi
+                hist[rbin(k1["kp_angle"][i1], k2["kp_angle"][bi])].append(i1)
+    rot_filter(hist, lambda k: exp.__setitem__(k, -1))
+    assert np.array_equal(got, exp) and n_o == int((exp >= 0).sum())
+    if not only_stereo:
+        assert n_o > 5
+
+
+def test_search_for_initialization(orc, scene):
+    f1, f2 = scene["K1"], scene["K2"]
+    pm = np.stack([f1["kp_x"], f1["kp_y"]], 1)
+    n_o, got, pm_out = orc.search_for_initialization(f1, f2, pm, 100, 0.9, True)
+    g = Gridded(f2)
+    exp = np.full(len(f1["kp_x"]), -1, np.int32)
+    mdist = np.full(len(f2["kp_x"]), 2 ** 31 - 1, np.int64)
+    m21 = np.full(len(f2["kp_x"]), -1, np.int32)
+    hist = [[] for _ in range(HISTO)]
+    for i1 in range(len(f1["kp_x"])):
+        if f1["kp_octave"][i1] > 0:
+            continue
+        b1 = b2 = 2 ** 31 - 1
+        bi = -1
+        for i2 in g.area(pm[i1][0], pm[i1][1], 100, 0, 0):
+            d = ham(f1["descriptors"][i1], f2["descriptors"][i2])
+            if mdist[i2] <= d:
+                continue
+            if d < b1:
+                b2, b1, bi = b1, d, i2
+            elif d < b2:
+                b2 = d
+        if b1 <= TH_LOW and b1 < F32(b2) * F32(0.9):
+            if m21[bi] >= 0:
+                exp[m21[bi]] = -1
+            exp[i1], m21[bi], mdist[bi] = bi, i1, b1
+            hist[rbin(f1["kp_angle"][i1], f2["kp_angle"][bi])].append(i1)
+    rot_filter(hist, lambda k: exp.__setitem__(k, -1))
+    assert np.array_equal(got, exp) and n_o == int((exp >= 0).sum()) and n_o > 3
+    m = exp >= 0
+    assert np.array_equal(pm_out[m], np.stack([f2["kp_x"][exp[m]], f2["kp_y"][exp[m]]], 1)) and np.array_equal(pm_out[~m], pm[~m])
+
+
+@pytest.mark.parametrize("use_sim3", [0, 1])
+def test_fuse_search(orc, scene, use_sim3):
+    kf, P, K = scene["K2"], scene["points"], scene["K"]
+    th = 3.0
+    if use_sim3:
+        pose = scene["Scw"]
+        R, t, Ow = decompose(pose)
+    else:
+        T = scene["T2w"].astype(np.float64)
+        Rm, tm = T[:3, :3], T[:3, 3]
+        pose = np.concatenate([Rm.ravel(), tm, -Rm.T @ tm]).astype(np.float32)
+        R = [list(pose[3 * r:3 * r + 3]) for r in range(3)]
+        t, Ow = list(pose[9:12]), list(pose[12:15])
+    n_o, got = orc.fuse_search(kf, use_sim3, pose, K, scene["bf"], P, th)
+    g = Gridded(kf)
+    exp = np.full(len(P["active"]), -1, np.int32)
+    for i in range(len(P["active"])):
+        if not P["active"][i]:
+            continue
+        s = shoot(kf, R, t, Ow, K, P, i, bool(use_sim3))
+        if s is None:
+            continue
+        u, v, invz, _, lvl = s
+        ur = u - scene["bf"] * invz
+        best, bi = (2 ** 31 - 1 if use_sim3 else 256), -1
+        for k in g.area(u, v, F32(th) * kf["scale_factors"][lvl], -1, -1):
+            kl = int(kf["kp_octave"][k])
+            if not (lvl - 1 <= kl <= lvl):
+                continue
+            if not use_sim3:
+                ex_, ey_ = u - kf["kp_x"][k], v - kf["kp_y"][k]
+                if kf["u_right"][k] >= 0:
+                    er = ur - kf["u_right"][k]
+                    if float((ex_ * ex_ + ey_ * ey_ + er * er) * kf["inv_level_sigma2"][kl]) > 7.8:
+                        continue
+                elif float((ex_ * ex_ + ey_ * ey_) * kf["inv_level_sigma2"][kl]) > 5.99:
+                    continue
+            d = ham(P["descriptors"][i], kf["descriptors"][k])
+            if d < best:
+                best, bi = d, k
+        if best <= TH_LOW:
+            exp[i] = bi
+    assert np.array_equal(got, exp) and n_o == int((exp >= 0).sum()) and n_o > 20
+
+
+def _pts_of(scene, mp):
+    P = scene["points"]
+    idx = np.maximum(mp, 0)
+    d = {k: np.ascontiguousarray(P[k][idx]) for k in ("Xw", "normal", "min_dist_inv", "max_dist_inv", "max_dist", "descriptors")}
+    d["active"] = ((mp >= 0) & (P["active"][idx] > 0)).astype(np.uint8)
+    return d
+
+
+def test_search_by_sim3(orc, scene):
+    K1, K2, K = scene["K1"], scene["K2"], scene["K"]
+    P1, P2 = _pts_of(scene, scene["mp1"]), _pts_of(scene, scene["mp2"])
+    s12, R12, t12, th = F32(1.0), scene["R12"], scene["t12"], 7.5
+    n_o, got = orc.search_by_sim3(K1, scene["T1w"], P1, K2, scene["T2w"], P2, K, s12, R12, t12, th)
+    is12 = F32(1.0 / float(s12))
+    sR12 = [[s12 * R12[r][c] for c in range(3)] for r in range(3)]
+    sR21 = [[is12 * R12[c][r] for c in range(3)] for r in range(3)]
+    t21 = affine(sR21, t12, None, -1.0)
+
+    def one_way(P, T, sR, t, Kf):
+        g = Gridded(Kf)
+        Rw = [list(T[r][:3]) for r in range(3)]
+        tw = [T[r][3] for r in range(3)]
+        out = np.full(len(P["active"]), -1, np.int32)
+        fx, fy, cx, cy = K
+        for i in range(len(P["active"])):
+            if not P["active"][i]:
+                continue
+            pb = affine(sR, affine(Rw, P["Xw"][i], tw), t)
+            if pb[2] < 0:
+                continue
+            invz = F32(1.0 / float(pb[2]))
+            u, v = fx * (pb[0] * invz) + cx, fy * (pb[1] * invz) + cy
+            if not in_image(Kf, u, v):
+                continue
+            d3 = norm3(pb)
+            if d3 < P["min_dist_inv"][i] or d3 > P["max_dist_inv"][i]:
+                continue
+            lvl = predict(P["max_dist"][i], d3, Kf["log_scale_factor"])
+            if not 0 <= lvl < 8:
+                continue
+            best, bi = 2 ** 31 - 1, -1
+            for k in g.area(u, v, F32(th) * Kf["scale_factors"][lvl], -1, -1):
+                if not (lvl - 1 <= Kf["kp_octave"][k] <= lvl):
+                    continue
+                d = ham(P["descriptors"][i], Kf["descriptors"][k])
+                if d < best:
+                    best, bi = d, k
+            if best <= TH_HIGH:
+                out[i] = bi
+        return out
+
+    m1 = one_way(P1, scene["T1w"], sR21, t21, K2)
+    m2 = one_way(P2, scene["T2w"], sR12, list(t12), K1)
+    exp = np.full(len(m1), -1, np.int32)
+    for i1, i2 in enumerate(m1):
+        if i2 >= 0 and i2 < len(m2) and m2[i2] == i1:
+            exp[i1] = i2
+    assert np.array_equal(got, exp) and n_o == int((exp >= 0).sum()) and n_o > 20
