@@ -295,7 +295,7 @@ def synth_search_scene(n=800, seed=8000, flip=0.05, clutter=0.15, mono_frac=0.3,
     min_dist = (max_dist / scale[nlev - 1]).astype(np.float32)
     points = dict(active=(rng.random(n) < 0.92).astype(np.uint8), Xw=Xw.astype(np.float32), normal=normal.astype(np.float32),
                   min_dist_inv=(np.float32(0.8) * min_dist).astype(np.float32), max_dist_inv=(np.float32(1.2) * max_dist).astype(np.float32),
-                  max_dist=max_dist, descriptors=desc)
+                  max_dist=max_dist, min_dist=min_dist, descriptors=desc)
     # F12 = K^-T [t12]x R12 K^-1 (LocalMapping::ComputeF12, src/LocalMapping.cc): x1' F12 x2 = 0
     R12 = T1[:3, :3] @ T2[:3, :3].T
     t12 = -R12 @ T2[:3, 3] + T1[:3, 3]

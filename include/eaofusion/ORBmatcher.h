@@ -6,13 +6,19 @@
 // const Frame& Last, th, bMono) (candidate lists + distances on the GPU, the greedy assignment replayed inside the
 // library), and the batched primitive the remaining Search* routines are built from: best-two Hamming search of a set
 // of query descriptors against a set of train descriptors under a candidate mask, with the reference's tie order.
-// The other eight Search*/Fuse routines (BoW, triangulation, Sim3, fuse) are the next row of the scope table.
+// The remaining searches (BoW x2, triangulation, initialisation, Sim3, loop / relocalisation projection, Fuse x2) are
+// templates further down: they flatten what upstream reads through the KeyFrame / MapPoint accessors, call the library
+// (candidates + distances on the GPU, upstream's selection loops replayed in order) and apply the result the way upstream
+// does -- including the map mutations of Fuse, which stay on the caller's side of the C-ABI.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
 #include <cstring>
+#include <map>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../eao_fusion.h"
@@ -102,6 +108,256 @@ public:
         return nm;
     }
 
+
+    // =====================================================================================================================
+    // The remaining guided searches.  KeyFrameT / FrameT / MapPointT are the reference classes (same member names as
+    // src/ORBmatcher.cc uses); feature vectors are DBoW2::FeatureVector, i.e. std::map<unsigned, std::vector<unsigned>>.
+
+    // reference :290-403 (LoopClosing::ComputeSim3 / DetectLoop)
+    template <class KeyFrameT, class MapPointT>
+    int SearchByProjection(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints, std::vector<MapPointT*>& vpMatched, int th) {
+        std::set<MapPointT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+        spAlreadyFound.erase(static_cast<MapPointT*>(NULL));
+        PointArrays pa;
+        const eao_map_points mp = gather(vpPoints, pa, [&](MapPointT* p) { return !p->isBad() && !spAlreadyFound.count(p); });
+        FrameArrays fa;
+        eao_frame_view v = kfview(*pKF, fa);
+        for (int k = 0; k < v.n; k++) fa.occ[k] = vpMatched[k] ? 1 : 0;
+        float S[16];
+        mat44(Scw, S);
+        std::vector<int32_t> km(v.n, -1);
+        int nm = 0;
+        check(eao_search_by_projection_sim3(&v, S, pKF->fx, pKF->fy, pKF->cx, pKF->cy, &mp, th, km.data(), &nm), "eao_search_by_projection_sim3");
+        for (int k = 0; k < v.n; k++) if (km[k] >= 0) vpMatched[k] = vpPoints[km[k]];
+        return nm;
+    }
+
+    // reference :1474-1601 (Tracking::Relocalization)
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*>& sAlreadyFound, const float th, const int ORBdist) {
+        const std::vector<MapPointT*> vpMPs = pKF->GetMapPointMatches();
+        PointArrays pa;
+        const eao_map_points mp = gather(vpMPs, pa, [&](MapPointT* p) { return p && !p->isBad() && !sAlreadyFound.count(p); });
+        std::vector<float> ang(vpMPs.size());
+        for (size_t i = 0; i < vpMPs.size(); i++) ang[i] = pKF->mvKeysUn[i].angle;
+        FrameArrays fa;
+        eao_frame_view v = view(CurrentFrame, fa);
+        for (int k = 0; k < v.n; k++) fa.occ[k] = CurrentFrame.mvpMapPoints[k] ? 1 : 0;
+        v.log_scale_factor = CurrentFrame.mfLogScaleFactor;
+        float T[16];
+        mat44(CurrentFrame.mTcw, T);
+        std::vector<int32_t> cm(v.n, -1);
+        int nm = 0;
+        check(eao_search_by_projection_kf(&v, T, CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, &mp, ang.data(), th, ORBdist,
+                                          mbCheckOrientation ? 1 : 0, cm.data(), &nm), "eao_search_by_projection_kf");
+        for (int k = 0; k < v.n; k++) if (cm[k] >= 0) CurrentFrame.mvpMapPoints[k] = vpMPs[cm[k]];
+        return nm;
+    }
+
+    // reference :159-288 (Tracking::TrackReferenceKeyFrame, Relocalization)
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches) {
+        const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+        vpMapPointMatches = std::vector<MapPointT*>(F.N, static_cast<MapPointT*>(NULL));
+        const int n1 = (int)vpMapPointsKF.size(), n2 = F.N;
+        std::vector<uint8_t> valid1(n1), d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+        std::vector<float> a1(n1), a2(n2);
+        for (int i = 0; i < n1; i++) {
+            valid1[i] = (vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad()) ? 1 : 0;
+            a1[i] = pKF->mvKeysUn[i].angle;
+            std::memcpy(&d1[(size_t)i * 32], pKF->mDescriptors.ptr(i), 32);
+        }
+        for (int j = 0; j < n2; j++) { a2[j] = F.mvKeys[j].angle; std::memcpy(&d2[(size_t)j * 32], F.mDescriptors.ptr(j), 32); }
+        FeatVecArrays f1, f2;
+        const eao_feature_vector fv1 = flatten(pKF->mFeatVec, f1), fv2 = flatten(F.mFeatVec, f2);
+        std::vector<int32_t> m12(n1, -1);
+        int nm = 0;
+        check(eao_search_by_bow(0, n1, d1.data(), a1.data(), valid1.data(), &fv1, n2, d2.data(), a2.data(), nullptr, &fv2, mfNNratio,
+                                mbCheckOrientation ? 1 : 0, m12.data(), &nm), "eao_search_by_bow");
+        for (int i = 0; i < n1; i++) if (m12[i] >= 0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
+        return nm;
+    }
+
+    // reference :522-655 (LoopClosing::ComputeSim3)
+    template <class KeyFrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12) {
+        const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+        vpMatches12 = std::vector<MapPointT*>(n1, static_cast<MapPointT*>(NULL));
+        std::vector<uint8_t> v1(n1), v2(n2), d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+        std::vector<float> a1(n1), a2(n2);
+        for (int i = 0; i < n1; i++) {
+            v1[i] = (vpMapPoints1[i] && !vpMapPoints1[i]->isBad()) ? 1 : 0;
+            a1[i] = pKF1->mvKeysUn[i].angle;
+            std::memcpy(&d1[(size_t)i * 32], pKF1->mDescriptors.ptr(i), 32);
+        }
+        for (int j = 0; j < n2; j++) {
+            v2[j] = (vpMapPoints2[j] && !vpMapPoints2[j]->isBad()) ? 1 : 0;
+            a2[j] = pKF2->mvKeysUn[j].angle;
+            std::memcpy(&d2[(size_t)j * 32], pKF2->mDescriptors.ptr(j), 32);
+        }
+        FeatVecArrays f1, f2;
+        const eao_feature_vector fv1 = flatten(pKF1->mFeatVec, f1), fv2 = flatten(pKF2->mFeatVec, f2);
+        std::vector<int32_t> m12(n1, -1);
+        int nm = 0;
+        check(eao_search_by_bow(1, n1, d1.data(), a1.data(), v1.data(), &fv1, n2, d2.data(), a2.data(), v2.data(), &fv2, mfNNratio,
+                                mbCheckOrientation ? 1 : 0, m12.data(), &nm), "eao_search_by_bow");
+        for (int i = 0; i < n1; i++) if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];
+        return nm;
+    }
+
+    // reference :657-823 (LocalMapping::CreateNewMapPoints)
+    template <class KeyFrameT>
+    int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                               const bool bOnlyStereo) {
+        // epipole in the second image (:663-670): C2 = R2w * Cw + t2w with cv::gemm's double accumulation
+        const cv::Mat Cw = pKF1->GetCameraCenter(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+        float C2[3];
+        for (int r = 0; r < 3; r++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += (double)R2w.template at<float>(r, k) * (double)Cw.template at<float>(k);
+            C2[r] = (float)(acc + (double)t2w.template at<float>(r));
+        }
+        const float invz = 1.0f / C2[2];
+        const float ex = pKF2->fx * C2[0] * invz + pKF2->cx, ey = pKF2->fy * C2[1] * invz + pKF2->cy;
+        FrameArrays fa1, fa2;
+        eao_frame_view v1 = kfview(*pKF1, fa1), v2 = kfview(*pKF2, fa2);
+        for (int k = 0; k < v1.n; k++) fa1.occ[k] = pKF1->GetMapPoint(k) ? 1 : 0;
+        for (int k = 0; k < v2.n; k++) fa2.occ[k] = pKF2->GetMapPoint(k) ? 1 : 0;
+        FeatVecArrays f1, f2;
+        const eao_feature_vector fv1 = flatten(pKF1->mFeatVec, f1), fv2 = flatten(pKF2->mFeatVec, f2);
+        float Fm[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Fm[r * 3 + c] = F12.template at<float>(r, c);
+        std::vector<int32_t> m12(v1.n, -1);
+        int nm = 0;
+        check(eao_search_for_triangulation(&v1, &fv1, &v2, &fv2, Fm, ex, ey, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, m12.data(), &nm),
+              "eao_search_for_triangulation");
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(nm);
+        for (size_t i = 0; i < m12.size(); i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+        return nm;
+    }
+
+    // reference :405-520 (Tracking::MonocularInitialization)
+    template <class FrameT>
+    int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10) {
+        const int n1 = (int)F1.mvKeysUn.size();
+        std::vector<int32_t> oct(n1), m12(n1, -1);
+        std::vector<float> ang(n1), pm((size_t)n1 * 2);
+        std::vector<uint8_t> d1((size_t)n1 * 32);
+        for (int i = 0; i < n1; i++) {
+            oct[i] = F1.mvKeysUn[i].octave; ang[i] = F1.mvKeysUn[i].angle;
+            pm[2 * i] = vbPrevMatched[i].x; pm[2 * i + 1] = vbPrevMatched[i].y;
+            std::memcpy(&d1[(size_t)i * 32], F1.mDescriptors.ptr(i), 32);
+        }
+        FrameArrays fa;
+        const eao_frame_view v2 = view(F2, fa);
+        int nm = 0;
+        check(eao_search_for_initialization(n1, oct.data(), ang.data(), d1.data(), &v2, pm.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                            m12.data(), &nm), "eao_search_for_initialization");
+        vnMatches12.assign(m12.begin(), m12.end());
+        for (int i = 0; i < n1; i++) { vbPrevMatched[i].x = pm[2 * i]; vbPrevMatched[i].y = pm[2 * i + 1]; }
+        return nm;
+    }
+
+    // reference :825-975 (LocalMapping::SearchInNeighbors).  The search runs for all points first; replacing / adding
+    // observations then happens in index order exactly as upstream interleaves it, re-checking the entry conditions a
+    // previous replacement may have changed.
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0) {
+        PointArrays pa;
+        const eao_map_points mp = gather(vpMapPoints, pa, [&](MapPointT* p) { return p && !p->isBad() && !p->IsInKeyFrame(pKF); });
+        FrameArrays fa;
+        const eao_frame_view v = kfview(*pKF, fa);
+        const cv::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
+        float pose[15];
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pose[r * 3 + c] = Rcw.template at<float>(r, c); pose[9 + r] = tcw.template at<float>(r); pose[12 + r] = Ow.template at<float>(r); }
+        std::vector<int32_t> best(vpMapPoints.size(), -1);
+        int n = 0;
+        check(eao_fuse_search(&v, 0, pose, pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, &mp, th, best.data(), &n), "eao_fuse_search");
+        int nFused = 0;
+        for (size_t i = 0; i < vpMapPoints.size(); i++) {
+            if (best[i] < 0) continue;
+            MapPointT* pMP = vpMapPoints[i];
+            if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+            MapPointT* pMPinKF = pKF->GetMapPoint(best[i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, best[i]);
+                pKF->AddMapPoint(pMP, best[i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    // reference :977-1100 (LoopClosing::SearchAndFuse)
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints, float th, std::vector<MapPointT*>& vpReplacePoint) {
+        const std::set<MapPointT*> spAlreadyFound = pKF->GetMapPoints();
+        PointArrays pa;
+        const eao_map_points mp = gather(vpPoints, pa, [&](MapPointT* p) { return !p->isBad() && !spAlreadyFound.count(p); });
+        FrameArrays fa;
+        const eao_frame_view v = kfview(*pKF, fa);
+        float S[16];
+        mat44(Scw, S);
+        std::vector<int32_t> best(vpPoints.size(), -1);
+        int n = 0;
+        check(eao_fuse_search(&v, 1, S, pKF->fx, pKF->fy, pKF->cx, pKF->cy, 0.f, &mp, th, best.data(), &n), "eao_fuse_search");
+        int nFused = 0;
+        for (size_t i = 0; i < vpPoints.size(); i++) {
+            if (best[i] < 0) continue;
+            MapPointT* pMP = vpPoints[i];
+            MapPointT* pMPinKF = pKF->GetMapPoint(best[i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
+            } else {
+                pMP->AddObservation(pKF, best[i]);
+                pKF->AddMapPoint(pMP, best[i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    // reference :1102-1326 (LoopClosing::ComputeSim3)
+    template <class KeyFrameT, class MapPointT>
+    int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                     const cv::Mat& t12, const float th) {
+        const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+        std::vector<bool> already1(N1, false), already2(N2, false);
+        for (int i = 0; i < N1; i++) {
+            MapPointT* pMP = vpMatches12[i];
+            if (pMP) {
+                already1[i] = true;
+                const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+                if (idx2 >= 0 && idx2 < N2) already2[idx2] = true;
+            }
+        }
+        PointArrays pa1, pa2;
+        int cursor = 0;
+        const eao_map_points mp1 = gather(vpMapPoints1, pa1, [&](MapPointT* p) { const int i = cursor++; return p && !already1[i] && !p->isBad(); });
+        cursor = 0;
+        const eao_map_points mp2 = gather(vpMapPoints2, pa2, [&](MapPointT* p) { const int i = cursor++; return p && !already2[i] && !p->isBad(); });
+        FrameArrays fa1, fa2;
+        const eao_frame_view v1 = kfview(*pKF1, fa1), v2 = kfview(*pKF2, fa2);
+        float T1[16], T2[16], R[9], t[3];
+        pose44(pKF1->GetRotation(), pKF1->GetTranslation(), T1);
+        pose44(pKF2->GetRotation(), pKF2->GetTranslation(), T2);
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = R12.template at<float>(r, c); t[r] = t12.template at<float>(r); }
+        std::vector<int32_t> m12(N1, -1);
+        int nf = 0;
+        check(eao_search_by_sim3(&v1, T1, &mp1, &v2, T2, &mp2, pKF1->fx, pKF1->fy, pKF1->cx, pKF1->cy, s12, R, t, th, m12.data(), &nf),
+              "eao_search_by_sim3");
+        for (int i = 0; i < N1; i++) if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];
+        return nf;
+    }
+
     static const int TH_LOW;
     static const int TH_HIGH;
     static const int HISTO_LENGTH;
@@ -129,7 +385,80 @@ public:
     }
 
 protected:
-    struct FrameArrays { std::vector<float> x, y, ang, ur, sf; std::vector<int32_t> oct; std::vector<uint8_t> occ, desc; };
+    struct FrameArrays { std::vector<float> x, y, ang, ur, sf, s2, is2; std::vector<int32_t> oct; std::vector<uint8_t> occ, desc; };
+    struct PointArrays { std::vector<uint8_t> active, desc; std::vector<float> Xw, normal, dmin, dmax, draw; };
+    struct FeatVecArrays { std::vector<uint32_t> id, index; std::vector<int32_t> start; };
+    // mfMaxDistance is what PredictScale divides (src/MapPoint.cc:385-394); upstream exposes it only through
+    // GetMaxDistanceInvariance() = 1.2f * mfMaxDistance, which does not round-trip in float.  A derived class may name
+    // the protected member of its base, and the resulting pointer-to-member applies to any MapPoint: an exact read
+    // without touching MapPoint.h.  (A one-line public accessor in MapPoint.h is the alternative.)
+    template <class MapPointT>
+    struct MaxDistance : MapPointT {
+        static float of(MapPointT* p) { return p->*(&MaxDistance::mfMaxDistance); }
+    };
+    // flatten the map points the searches read; active(p) evaluates upstream's entry conditions IN INDEX ORDER
+    template <class MapPointT, class Pred>
+    static eao_map_points gather(const std::vector<MapPointT*>& pts, PointArrays& a, Pred&& active) {
+        const size_t n = pts.size();
+        a.active.assign(n, 0); a.desc.assign(n * 32, 0); a.Xw.assign(n * 3, 0.f); a.normal.assign(n * 3, 0.f);
+        a.dmin.assign(n, 0.f); a.dmax.assign(n, 0.f); a.draw.assign(n, 0.f);
+        for (size_t i = 0; i < n; i++) {
+            MapPointT* p = pts[i];
+            if (!active(p)) continue;
+            a.active[i] = 1;
+            const cv::Mat X = p->GetWorldPos(), Nn = p->GetNormal(), d = p->GetDescriptor();
+            for (int k = 0; k < 3; k++) { a.Xw[i * 3 + k] = X.template at<float>(k); a.normal[i * 3 + k] = Nn.template at<float>(k); }
+            a.dmin[i] = p->GetMinDistanceInvariance(); a.dmax[i] = p->GetMaxDistanceInvariance(); a.draw[i] = MaxDistance<MapPointT>::of(p);
+            std::memcpy(&a.desc[i * 32], d.ptr(0), 32);
+        }
+        eao_map_points m;
+        m.n = (int32_t)n; m.active = a.active.data(); m.Xw = a.Xw.data(); m.normal = a.normal.data(); m.min_dist_inv = a.dmin.data();
+        m.max_dist_inv = a.dmax.data(); m.max_dist = a.draw.data(); m.desc = a.desc.data();
+        return m;
+    }
+    template <class FeatVecT>
+    static eao_feature_vector flatten(const FeatVecT& fv, FeatVecArrays& a) {
+        a.id.clear(); a.index.clear(); a.start.assign(1, 0);
+        for (typename FeatVecT::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+            a.id.push_back((uint32_t)it->first);
+            for (size_t k = 0; k < it->second.size(); k++) a.index.push_back((uint32_t)it->second[k]);
+            a.start.push_back((int32_t)a.index.size());
+        }
+        eao_feature_vector f;
+        f.n_nodes = (int32_t)a.id.size(); f.node_id = a.id.data(); f.node_start = a.start.data(); f.index = a.index.data();
+        return f;
+    }
+    static void mat44(const cv::Mat& M, float* out) {
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[r * 4 + c] = M.at<float>(r, c);
+    }
+    static void pose44(const cv::Mat& R, const cv::Mat& t, float* out) {
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) out[r * 4 + c] = R.at<float>(r, c); out[r * 4 + 3] = t.at<float>(r); }
+        out[12] = out[13] = out[14] = 0.f; out[15] = 1.f;
+    }
+    // KeyFrame flavour of view(): per-keyframe grid bounds (const members, include/KeyFrame.h:193-194,255-262), no
+    // occupancy (each search defines its own), level sigmas and the log scale factor
+    template <class KeyFrameT>
+    static eao_frame_view kfview(KeyFrameT& K, FrameArrays& a) {
+        const int N = K.N;
+        a.x.resize(N); a.y.resize(N); a.ang.resize(N); a.ur.resize(N); a.oct.resize(N); a.occ.assign(N, 0); a.desc.resize((size_t)N * 32);
+        for (int i = 0; i < N; i++) {
+            a.x[i] = K.mvKeysUn[i].pt.x; a.y[i] = K.mvKeysUn[i].pt.y; a.ang[i] = K.mvKeysUn[i].angle; a.oct[i] = K.mvKeysUn[i].octave;
+            a.ur[i] = K.mvuRight[i];
+            std::memcpy(&a.desc[(size_t)i * 32], K.mDescriptors.ptr(i), 32);
+        }
+        a.sf.assign(K.mvScaleFactors.begin(), K.mvScaleFactors.end());
+        a.s2.assign(K.mvLevelSigma2.begin(), K.mvLevelSigma2.end());
+        a.is2.assign(K.mvInvLevelSigma2.begin(), K.mvInvLevelSigma2.end());
+        eao_frame_view v;
+        v.n = N; v.kp_x = a.x.data(); v.kp_y = a.y.data(); v.kp_octave = a.oct.data(); v.kp_angle = a.ang.data(); v.u_right = a.ur.data();
+        v.descriptors = a.desc.data(); v.occupied = a.occ.data();
+        v.min_x = K.mnMinX; v.min_y = K.mnMinY; v.max_x = K.mnMaxX; v.max_y = K.mnMaxY;
+        v.grid_inv_w = K.mfGridElementWidthInv; v.grid_inv_h = K.mfGridElementHeightInv;
+        v.grid_cols = K.mnGridCols; v.grid_rows = K.mnGridRows;
+        v.scale_factors = a.sf.data(); v.nlevels = (int)a.sf.size();
+        v.log_scale_factor = K.mfLogScaleFactor; v.level_sigma2 = a.s2.data(); v.inv_level_sigma2 = a.is2.data();
+        return v;
+    }
     // flatten the members of Frame the searches read (src/ORBmatcher.cc, src/Frame.cc:696-761) into an eao_frame_view
     template <class FrameT>
     static eao_frame_view view(FrameT& F, FrameArrays& a) {
@@ -149,6 +478,7 @@ protected:
         v.grid_inv_w = FrameT::mfGridElementWidthInv; v.grid_inv_h = FrameT::mfGridElementHeightInv;
         v.grid_cols = 64; v.grid_rows = 48;   // FRAME_GRID_COLS / FRAME_GRID_ROWS (include/Frame.h:89-90)
         v.scale_factors = a.sf.data(); v.nlevels = (int)a.sf.size();
+        v.log_scale_factor = 0.f; v.level_sigma2 = nullptr; v.inv_level_sigma2 = nullptr;
         return v;
     }
     static void check(eao_status st, const char* what) {

@@ -86,3 +86,129 @@ def test_cpp_adapters_end_to_end(tmp_path):
     assert erased > 0
     f = bp["fixed"].astype(bool)
     assert np.array_equal(poses[f], bp["poses"][f])    # fixed keyframes are never written back
+
+
+def test_cpp_search_adapters(tmp_path):
+    """The remaining ORBmatcher templates (BoW x2, triangulation, initialisation, projection loop / relocalisation, Sim3,
+    Fuse x2) over mock KeyFrame / Frame / MapPoint classes must reproduce what the C-ABI returns for the same data."""
+    import torch  # noqa: F401
+    from eao_fusion_amd import search
+    exe = str(tmp_path / "search_adapter_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DEAOFUSION_FORCE_CV_COMPAT", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "search_adapter_test.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "eao_fusion_amd"), "-leaofusion_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "eao_fusion_amd"), "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    sc = synth.synth_search_scene(n=500, seed=8200)
+    K1, K2, P = sc["K1"], sc["K2"], sc["points"]
+    mp1, mp2 = sc["mp1"], sc["mp2"]
+    scene = str(tmp_path / "scene.bin")
+    with open(scene, "wb") as f:
+        for K, mp, fv in ((K1, mp1, sc["fv1"]), (K2, mp2, sc["fv2"])):
+            f.write(struct.pack("<i", len(K["kp_x"])))
+            for k in ("kp_x", "kp_y", "kp_angle", "u_right"):
+                f.write(np.ascontiguousarray(K[k], np.float32).tobytes())
+            f.write(np.ascontiguousarray(K["kp_octave"], np.int32).tobytes()); f.write(np.ascontiguousarray(mp, np.int32).tobytes())
+            f.write(np.ascontiguousarray(K["descriptors"], np.uint8).tobytes())
+            f.write(struct.pack("<i", len(fv["node_id"])))
+            f.write(fv["node_id"].astype(np.uint32).tobytes()); f.write(fv["node_start"].astype(np.int32).tobytes()); f.write(fv["index"].astype(np.uint32).tobytes())
+        f.write(struct.pack("<i", len(P["active"])))
+        f.write(P["active"].astype(np.uint8).tobytes())
+        for k in ("Xw", "normal", "min_dist", "max_dist"):
+            f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
+        f.write(np.ascontiguousarray(P["descriptors"], np.uint8).tobytes())
+        f.write(sc["T1w"].tobytes()); f.write(sc["T2w"].tobytes()); f.write(np.array(sc["K"], np.float32).tobytes())
+        f.write(struct.pack("<f", float(sc["bf"])))
+        f.write(sc["F12"].tobytes()); f.write(sc["Scw"].tobytes()); f.write(sc["R12"].tobytes()); f.write(sc["t12"].tobytes())
+        f.write(K1["scale_factors"].tobytes()); f.write(K1["level_sigma2"].tobytes()); f.write(K1["inv_level_sigma2"].tobytes())
+        f.write(struct.pack("<f", float(K1["log_scale_factor"])))
+    res = str(tmp_path / "search_result.bin")
+    out = subprocess.run([exe, scene, res], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    buf = open(res, "rb").read()
+    off = 0
+
+    def take(dtype, n):
+        nonlocal off
+        a = np.frombuffer(buf, dtype=dtype, count=n, offset=off)
+        off += a.nbytes
+        return a
+
+    def take_table():
+        n = int(take(np.int32, 1)[0])
+        return take(np.int32, n)
+
+    g = search.product()
+    act = P["active"].astype(bool)
+    v1 = ((mp1 >= 0) & act[np.maximum(mp1, 0)]).astype(np.uint8)
+    v2 = ((mp2 >= 0) & act[np.maximum(mp2, 0)]).astype(np.uint8)
+    s1 = dict(descriptors=K1["descriptors"], angle=K1["kp_angle"], valid=v1, fv=sc["fv1"])
+    s2 = dict(descriptors=K2["descriptors"], angle=K2["kp_angle"], valid=v2, fv=sc["fv2"])
+    # 1. SearchByBoW(KF, KF)
+    n = int(take(np.int32, 1)[0]); tab = take_table()
+    en, m12 = g.search_by_bow(1, s1, s2, 0.75, True)
+    assert n == en and np.array_equal(tab, np.where(m12 >= 0, mp2[np.maximum(m12, 0)], -1)) and n > 10
+    # 2. SearchByBoW(KF, Frame)
+    n = int(take(np.int32, 1)[0]); tab = take_table()
+    en, m12 = g.search_by_bow(0, s1, s2, 0.75, True)
+    exp = np.full(len(K2["kp_x"]), -1, np.int32)
+    exp[m12[m12 >= 0]] = mp1[m12 >= 0]
+    assert n == en and np.array_equal(tab, exp)
+    # 3. SearchForTriangulation
+    k1, k2 = dict(K1), dict(K2)
+    k1["occupied"] = ((mp1 >= 0) & (np.arange(len(mp1)) % 2 == 0)).astype(np.uint8)
+    k2["occupied"] = ((mp2 >= 0) & (np.arange(len(mp2)) % 3 == 0)).astype(np.uint8)
+    n = int(take(np.int32, 1)[0]); tab = take(np.int32, len(mp1))
+    en, m12 = g.search_for_triangulation(k1, sc["fv1"], k2, sc["fv2"], sc["F12"], sc["ex"], sc["ey"], 0, True)
+    assert n == en and np.array_equal(tab, m12)
+    # 4. SearchForInitialization
+    pm = np.stack([K1["kp_x"], K1["kp_y"]], 1)
+    n = int(take(np.int32, 1)[0]); tab = take(np.int32, len(mp1)); pm_cpp = take(np.float32, 2 * len(mp1)).reshape(-1, 2)
+    en, m12, pm_out = g.search_for_initialization(K1, K2, pm, 100, 0.9, True)
+    assert n == en and np.array_equal(tab, m12) and np.array_equal(pm_cpp, pm_out)
+    # 5. SearchByProjection(KF, Scw, ...)
+    kf = dict(K2)
+    kf["occupied"] = (np.arange(len(mp2)) % 13 == 0).astype(np.uint8)
+    pts = dict(P)
+    a5 = P["active"].copy(); a5[0] = 0
+    pts["active"] = a5
+    n = int(take(np.int32, 1)[0]); tab = take_table()
+    en, km = g.search_by_projection_sim3(kf, sc["Scw"], sc["K"], pts, 10)
+    assert n == en and np.array_equal(tab, km) and n > 10
+    # 6. SearchByProjection(Frame, KF, found, th, ORBdist)
+    idx1 = np.maximum(mp1, 0)
+    pk = {k: np.ascontiguousarray(P[k][idx1]) for k in ("Xw", "normal", "min_dist_inv", "max_dist_inv", "max_dist", "descriptors")}
+    pk["active"] = ((mp1 >= 0) & act[idx1] & (idx1 % 17 != 0)).astype(np.uint8)
+    n = int(take(np.int32, 1)[0]); tab = take_table()
+    en, cm = g.search_by_projection_kf(K2, sc["T2w"], sc["K"], pk, K1["kp_angle"], 15.0, 100, True)
+    assert n == en and np.array_equal(tab, np.where(cm >= 0, mp1[np.maximum(cm, 0)], -1))
+    # 7. SearchBySim3
+    idx2 = np.maximum(mp2, 0)
+    p1 = dict(pk); p1["active"] = v1
+    p2 = {k: np.ascontiguousarray(P[k][idx2]) for k in ("Xw", "normal", "min_dist_inv", "max_dist_inv", "max_dist", "descriptors")}
+    p2["active"] = v2
+    n = int(take(np.int32, 1)[0]); tab = take_table()
+    en, m12 = g.search_by_sim3(K1, sc["T1w"], p1, K2, sc["T2w"], p2, sc["K"], 1.0, sc["R12"], sc["t12"], 7.5)
+    assert n == en and np.array_equal(tab, np.where(m12 >= 0, mp2[np.maximum(m12, 0)], -1)) and n > 10
+    # 8. Fuse(KF, Scw, ...) into an empty keyframe: the first point to reach a keypoint is added, later ones replace
+    n = int(take(np.int32, 1)[0]); tab = take(np.int32, len(act))
+    en, best = g.fuse_search(K2, 1, sc["Scw"], sc["K"], 0.0, P, 3.0)
+    exp = np.full(len(act), -1, np.int32)
+    seen = set()
+    for i, b in enumerate(best):
+        if b >= 0 and int(b) not in seen:
+            exp[i] = b
+            seen.add(int(b))
+    assert n == en and np.array_equal(tab, exp) and n > 10
+    # 9. Fuse(KF, points, th): every hit on a keypoint that already has a point replaces, the others add
+    T = sc["T2w"].astype(np.float64)
+    pose = np.concatenate([T[:3, :3].ravel(), T[:3, 3], -T[:3, :3].T @ T[:3, 3]]).astype(np.float32)
+    n, replaced, added = (int(x) for x in take(np.int32, 3))
+    en, best = g.fuse_search(K2, 0, pose, sc["K"], sc["bf"], P, 3.0)
+    slot = mp2 >= 0
+    slot = slot.copy()
+    e_add = 0
+    for b in best:
+        if b >= 0 and not slot[b]:
+            slot[b] = True
+            e_add += 1
+    assert n == en and added == e_add and replaced == en - e_add and n > 10
