@@ -35,12 +35,13 @@ class FrameView(C.Structure):
 class PoseProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("Tcw", C.c_void_p), ("Xw", C.c_void_p), ("obs", C.c_void_p),
                 ("inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
-                ("cy", C.c_float), ("bf", C.c_float)]
+                ("cy", C.c_float), ("bf", C.c_float),
+                ("n_planes", C.c_int32), ("plane_world", C.c_void_p), ("plane_obs", C.c_void_p), ("plane_seen", C.c_void_p)]
 
 
 class PoseResult(C.Structure):
     _fields_ = [("Tcw", C.c_float * 16), ("outlier", C.c_void_p), ("n_inliers", C.c_int32),
-                ("lm_iterations", C.c_int32)]
+                ("lm_iterations", C.c_int32), ("plane_outlier", C.c_void_p)]
 
 
 class BAProblem(C.Structure):

@@ -295,6 +295,45 @@ __device__ inline bool ldlt6_solve(const double* A, const double* b, double* x) 
     return true;
 }
 
+// ------------------------------------------------------------------ planes (src/g2oAddition/Plane3D.h, EdgePlane.h)
+// Plane3D keeps (n, -d) normalised with a non-negative fourth coefficient; the edge's error is (azimuth, elevation,
+// distance) of the measured plane in the frame that rotates the predicted plane's normal onto +x.
+__host__ __device__ inline void plane_normalize(double c[4]) {                 // Plane3D::normalize
+    const double n = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const double s = 1. / n;
+    for (int k = 0; k < 4; k++) c[k] = c[k] * s;
+    if (c[3] < 0.0) for (int k = 0; k < 4; k++) c[k] = -c[k];
+}
+inline void plane_from_f32(const float* v, double c[4]) {                      // Converter::toPlane3D, src/Converter.cc:215-225
+    for (int k = 0; k < 4; k++) c[k] = v[k];
+    if (v[3] < 0.0) for (int k = 0; k < 4; k++) c[k] = -c[k];
+    plane_normalize(c);
+}
+__device__ inline void plane_error(const SE3& T, const double* world, const double* meas, double err[3]) {   // EdgePlane::computeError
+    double R[9];
+    quat_to_matrix(T.r, R);
+    double v2[4];
+#pragma unroll
+    for (int r = 0; r < 3; r++) v2[r] = R[r * 3] * world[0] + R[r * 3 + 1] * world[1] + R[r * 3 + 2] * world[2];
+    v2[3] = world[3] - (T.t[0] * v2[0] + T.t[1] * v2[1] + T.t[2] * v2[2]);
+    if (v2[3] < 0.0) { v2[0] = -v2[0]; v2[1] = -v2[1]; v2[2] = -v2[2]; v2[3] = -v2[3]; }
+    plane_normalize(v2);
+    // Plane3D::rotation: AngleAxis(azimuth, Z) * AngleAxis(-elevation, Y) as a quaternion product
+    const double az = atan2(v2[1], v2[0]);
+    const double el = atan2(v2[2], sqrt(v2[0] * v2[0] + v2[1] * v2[1]));
+    const double ha = 0.5 * az, hb = 0.5 * (-el);
+    const Quat qa{0, 0, sin(ha) * 1.0, cos(ha)}, qb{0, sin(hb) * 1.0, 0, cos(hb)};
+    double Rn[9];
+    quat_to_matrix(quat_mul(qa, qb), Rn);
+    double n[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) n[r] = Rn[r] * meas[0] + Rn[3 + r] * meas[1] + Rn[6 + r] * meas[2];   // rotation^T * normal
+    err[0] = atan2(n[1], n[0]);
+    err[1] = atan2(n[2], sqrt(n[0] * n[0] + n[1] * n[1]));
+    err[2] = (-v2[3]) - (-meas[3]);
+}
+constexpr int kPoseMaxPlanes = 32;
+
 // ============================================================================================ PoseOptimization
 struct PoseDev {
     int n;
@@ -311,6 +350,11 @@ struct PoseDev {
     int* result;         // [0] nBad of the last round, [1] LM iterations, [2] trace count
     double* trace;       // 3 * 64: lambda, chi2, trials
     long long* dbg;      // optional phase stamps (diagnostic runs of the harness only)
+    // plane edges: nPlanes x { world[4], meas[4], infoAngle, infoDistance } doubles; flags as for the points
+    int nPlanes;
+    const double* planes;
+    unsigned char* planeOutlier;
+    double deltaPlane;
 };
 
 constexpr int kPoseThreads = 512;
@@ -349,6 +393,12 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
     __shared__ double s_x[6];
     __shared__ double s_lambda, s_ni, s_rho, s_cur, s_tmp;
     __shared__ int s_ok, s_flag, s_nbad, s_ntrace, s_iters, s_active;
+    // plane edges: thread 13 p + v evaluates plane p at the pose perturbed along variant v (0: none, 1 + 2d / 2 + 2d: +-1e-9
+    // along dimension d) -- g2o's central-difference Jacobian (core/base_binary_edge.hpp:131-205); thread p owns the edge
+    __shared__ double s_pvar[kPoseMaxPlanes * 13 * 3];
+    __shared__ double s_perr[kPoseMaxPlanes * 3];          // the edge's _error (last computed)
+    __shared__ unsigned char s_pflag[kPoseMaxPlanes], s_pout[kPoseMaxPlanes];
+    const int M = P.nPlanes;
     const int t = threadIdx.x, n = P.n;
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
     const Cam c = P.cam;
@@ -389,6 +439,12 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
         return s2;
     };
     if (t == 0) { s_ntrace = 0; s_iters = 0; s_est = P.T0; }
+    if (t < M) { s_pflag[t] = 4; s_pout[t] = 0; s_perr[3 * t] = s_perr[3 * t + 1] = s_perr[3 * t + 2] = 0; }
+    auto plane_chi2 = [&](int p) {
+        const double* pl = P.planes + 10 * p;
+        const double* e = s_perr + 3 * p;
+        return e[0] * (pl[8] * e[0]) + e[1] * (pl[8] * e[1]) + e[2] * (pl[9] * e[2]);
+    };
     const bool stamp = P.dbg && t == 0;
     long long pa[6] = {0, 0, 0, 0, 0, 0}, pts = 0;
     auto lap = [&](int slot) { if (stamp) { const long long now = clock64(); pa[slot] += now - pts; pts = now; } };
@@ -400,6 +456,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
             int any = 0;
 #pragma unroll
             for (int k = 0; k < EPT; k++) any |= !(eF[k] & 2);
+            if (t < M) any |= !(s_pflag[t] & 2);
             if (any) s_active = 1;
         }
         __syncthreads();
@@ -454,6 +511,53 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
                         }
                     }
                 }
+                if (M) {
+                    if (t < 13 * M) {
+                        const int p = t / 13, v = t - 13 * p;
+                        if (!(s_pflag[p] & 2)) {
+                            SE3 Tp = est;
+                            if (v) {
+                                double add[6] = {0, 0, 0, 0, 0, 0};
+                                const int d = (v - 1) >> 1;
+                                const double step = ((v - 1) & 1) ? -1e-9 : 1e-9;
+#pragma unroll
+                                for (int q = 0; q < 6; q++) if (q == d) add[q] = step;
+                                Tp = se3_mul(se3_exp(add), est);
+                            }
+                            plane_error(Tp, P.planes + 10 * p, P.planes + 10 * p + 4, &s_pvar[(p * 13 + v) * 3]);
+                        }
+                    }
+                    __syncthreads();
+                    if (t < M && !(s_pflag[t] & 2)) {
+                        const double* pl = P.planes + 10 * t;
+                        const double* pv = &s_pvar[t * 13 * 3];
+                        s_perr[3 * t] = pv[0]; s_perr[3 * t + 1] = pv[1]; s_perr[3 * t + 2] = pv[2];
+                        const double scalar = 1.0 / (2 * 1e-9);
+                        double J[3][6];
+#pragma unroll
+                        for (int d = 0; d < 6; d++)
+#pragma unroll
+                            for (int r = 0; r < 3; r++) J[r][d] = scalar * (pv[(1 + 2 * d) * 3 + r] - pv[(2 + 2 * d) * 3 + r]);
+                        const double c2 = plane_chi2(t);
+                        double w = 1.0, r0 = c2;
+                        if (s_pflag[t] & 4) huber(c2, P.deltaPlane, r0, w);
+                        acc[27] += r0;
+                        const double info[3] = {pl[8], pl[8], pl[9]};
+                        int q = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+                            double sb = J[0][a] * (info[0] * pv[0]) + J[1][a] * (info[1] * pv[1]);
+                            sb += J[2][a] * (info[2] * pv[2]);
+                            acc[21 + a] -= w * sb;
+#pragma unroll
+                            for (int b = a; b < 6; b++) {
+                                double hh = J[0][a] * (w * info[0]) * J[0][b] + J[1][a] * (w * info[1]) * J[1][b];
+                                hh += J[2][a] * (w * info[2]) * J[2][b];
+                                acc[q++] += hh;
+                            }
+                        }
+                    }
+                }
                 lap(0);
                 block_sum_lds<28, kPoseThreads>(acc, red, sums);
                 lap(1);
@@ -498,6 +602,13 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
                         const double c2 = edge_chi2(k);
                         double w, r0 = c2;
                         if (fl & 4) huber(c2, (fl & 1) ? c.deltaStereo : c.deltaMono, r0, w);
+                        chi[0] += r0;
+                    }
+                    if (t < M && !(s_pflag[t] & 2)) {
+                        plane_error(tr, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
+                        const double c2 = plane_chi2(t);
+                        double w, r0 = c2;
+                        if (s_pflag[t] & 4) huber(c2, P.deltaPlane, r0, w);
                         chi[0] += r0;
                     }
                     lap(3);
@@ -560,14 +671,24 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
             else if (round == 2) fl &= ~4;    // stereo: at it == 2
             eF[k] = fl;
         }
+        if (t < M) {   // src/Optimizer.cc:626-658
+            unsigned char fl = s_pflag[t];
+            if (s_pout[t]) plane_error(est, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
+            const float c2 = (float)plane_chi2(t);
+            if (c2 > 300.0) { s_pout[t] = 1; fl |= 2; nb[0] += 1; }
+            else { s_pout[t] = 0; fl &= ~2; }
+            if (round == 2) fl &= ~4;
+            s_pflag[t] = fl;
+        }
         block_sum<1, kPoseThreads>(nb, red, &s_tmp);
         if (t == 0) P.result[0] = (int)s_tmp;
         __syncthreads();
-        if (n < 10) break;
+        if (n + M < 10) break;
     }
 #pragma unroll
     for (int k = 0; k < EPT; k++)
         if (eLive[k]) P.outlier[t + k * kPoseThreads] = eOut[k];
+    if (t < M) P.planeOutlier[t] = s_pout[t];
     if (t == 0) { *P.Tout = s_est; P.result[1] = s_iters; P.result[2] = s_ntrace; }
     if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
 }
@@ -1854,6 +1975,10 @@ extern "C" {
 eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) {
     EAO_REQUIRE(p && r, "null argument");
     EAO_REQUIRE(p->n >= 0 && p->Tcw && (p->n == 0 || (p->Xw && p->obs && p->inv_sigma2 && r->outlier)), "bad problem");
+    const int M = p->n_planes;
+    EAO_REQUIRE(M >= 0 && M <= kPoseMaxPlanes, "at most %d plane edges (got %d)", kPoseMaxPlanes, M);
+    EAO_REQUIRE(M == 0 || (p->plane_world && p->plane_obs && p->plane_seen && r->plane_outlier), "plane arrays missing");
+    EAO_REQUIRE(M == 0 || p->n <= 4 * kPoseThreads, "plane edges are supported for up to %d point correspondences", 4 * kPoseThreads);
     LMContext& c = g_ctx;
     eao_status st = ctx_init(c);
     if (st) return st;
@@ -1868,7 +1993,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     }
     // inputs are staged in the pinned mirror of the arena (float32 -> double exactly as Converter / Eigen would promote
     // them) and sent with ONE copy; the results come back through pinned memory the kernel writes directly
-    const size_t need = (size_t)n * (3 + 3 + 1 + 3) * 8 + (size_t)n * 2 + 32 * 256;
+    const size_t need = (size_t)n * (3 + 3 + 1 + 3) * 8 + (size_t)n * 2 + 40 * 256;
     if ((st = c.bytes.reserve(need))) return st;
     Arena a{c.bytes.p, c.bytes.n};
     const size_t off0 = a.off;
@@ -1876,6 +2001,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     double* dobs = a.take<double>((size_t)n * 3);
     double* dinfo = a.take<double>(n);
     unsigned char* dflags = a.take<unsigned char>(n);
+    double* dplanes = a.take<double>((size_t)kPoseMaxPlanes * 10);
     const size_t off1 = (a.off + 255) & ~(size_t)255;
     double* derr = a.take<double>((size_t)n * 3);
     long long* ddbg = a.take<long long>(8);
@@ -1885,7 +2011,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
         EAO_HIP(hipHostMalloc((void**)&c.pin, off1 + (off1 >> 2), hipHostMallocDefault));
         c.pinCap = off1 + (off1 >> 2);
     }
-    const size_t outBytes = sizeof(SE3) + 16 + 192 * 8 + 16 + (size_t)n + 64;
+    const size_t outBytes = sizeof(SE3) + 16 + 192 * 8 + 16 + (size_t)n + 64 + kPoseMaxPlanes;
     if (c.pinOutCap < outBytes) {
         if (c.pinOut) (void)hipHostFree(c.pinOut);
         c.pinOut = nullptr; c.pinOutCap = 0;
@@ -1895,7 +2021,9 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     SE3* oT = (SE3*)c.pinOut;
     double* otrace = (double*)(c.pinOut + ((sizeof(SE3) + 15) & ~(size_t)15));
     int* ores = (int*)(otrace + 192);
-    unsigned char* ooutl = (unsigned char*)(ores + 4);
+    unsigned char* opl = (unsigned char*)(ores + 4);          // kPoseMaxPlanes plane flags, then the point flags
+    unsigned char* ooutl = opl + kPoseMaxPlanes;
+    std::memset(opl, 0, kPoseMaxPlanes);
     std::memset(ooutl, 0, n);     // the memory variant of the kernel reads the flags before it first writes them
     ores[0] = ores[1] = ores[2] = 0;
     auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
@@ -1907,6 +2035,15 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
             hI[i] = p->inv_sigma2[i];
             hF[i] = (unsigned char)((!(p->obs[3 * i + 2] < 0) ? 1 : 0) | 4);
         }
+        // planes: normalised world / measured coefficients and the two information values (src/Optimizer.cc:464-465, 503-516)
+        double* hP = (double*)hostp(dplanes);
+        const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0;
+        for (int i = 0; i < M; i++) {
+            plane_from_f32(p->plane_world + 4 * i, hP + 10 * i);
+            plane_from_f32(p->plane_obs + 4 * i, hP + 10 * i + 4);
+            const double f = p->plane_seen[i] ? 1.0 : 2.0;
+            hP[10 * i + 8] = f * angleInfo; hP[10 * i + 9] = f * disInfo;
+        }
     }
     EAO_HIP(hipEventRecord(c.ev0, c.stream));
     EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
@@ -1916,6 +2053,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     P.cam.fx = p->fx; P.cam.fy = p->fy; P.cam.cx = p->cx; P.cam.cy = p->cy; P.cam.bf = p->bf; P.cam.bf_f = p->bf;
     P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
     P.Tout = oT; P.result = ores; P.trace = otrace;
+    P.nPlanes = M; P.planes = dplanes; P.planeOutlier = opl; P.deltaPlane = (float)std::sqrt(300.0);
     P.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
     if (n <= 2 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<2>, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
     else if (n <= 4 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<4>, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
@@ -1927,13 +2065,14 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     const int* res = ores;
     const double* trace = otrace;
     std::memcpy(r->outlier, ooutl, n);
+    if (M) std::memcpy(r->plane_outlier, opl, M);
     if (P.dbg) {
         long long st[8];
         EAO_HIP(hipMemcpy(st, P.dbg, sizeof(st), hipMemcpyDeviceToHost));
         fprintf(stderr, "[eao pose stamps] linearize %lld sum28 %lld solve %lld errors %lld sum1 %lld decide %lld shader-cycles\n", st[0], st[1], st[2], st[3], st[4], st[5]);
     }
     se3_to_Tcw_f32(Tout, r->Tcw);
-    r->n_inliers = n - res[0];
+    r->n_inliers = n + M - res[0];
     r->lm_iterations = res[1];
     for (int k = 0; k < res[2] && k < 64; k++) {
         g_trace.lambda.push_back(trace[k]); g_trace.chi2.push_back(trace[64 + k]); g_trace.trials.push_back((int)trace[128 + k]);

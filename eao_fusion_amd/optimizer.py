@@ -28,21 +28,32 @@ def _timing():
 class Optimizer:
     @staticmethod
     def PoseOptimization(prob):
-        """prob: Tcw (4,4) f32, points (n,3) f32, obs (n,3) f32 [u, v, ur (<0 = mono)], inv_sigma2 (n,), fx..bf.
-        Returns dict(Tcw, outlier, n_inliers) -- n_inliers is the reference's return value."""
+        """prob: Tcw (4,4) f32, points (n,3) f32, obs (n,3) f32 [u, v, ur (<0 = mono)], inv_sigma2 (n,), fx..bf, optional
+        plane_world / plane_obs (m,4) f32 + plane_seen (m,) u8 (the plane edges of src/Optimizer.cc:456-535).
+        Returns dict(Tcw, outlier, [plane_outlier,] n_inliers) -- n_inliers is the reference's return value."""
         Tcw = np.ascontiguousarray(prob["Tcw"], np.float32)
         Xw = np.ascontiguousarray(prob["points"], np.float32)
         obs = np.ascontiguousarray(prob["obs"], np.float32)
         inv = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
         n = len(Xw)
         outl = np.zeros(max(n, 1), np.uint8)
+        pw = prob.get("plane_world")
+        m = 0 if pw is None else len(pw)
+        pw = None if pw is None else np.ascontiguousarray(pw, np.float32)
+        po = None if pw is None else np.ascontiguousarray(prob["plane_obs"], np.float32)
+        ps = None if pw is None else np.ascontiguousarray(prob["plane_seen"], np.uint8)
+        pout = np.zeros(max(m, 1), np.uint8)
         P = _lib.PoseProblem(n, _lib.ptr(Tcw), _lib.ptr(Xw), _lib.ptr(obs), _lib.ptr(inv), prob["fx"], prob["fy"],
-                             prob["cx"], prob["cy"], prob["bf"])
+                             prob["cx"], prob["cy"], prob["bf"], m, _lib.ptr(pw), _lib.ptr(po), _lib.ptr(ps))
         R = _lib.PoseResult()
         R.outlier = _lib.ptr(outl)
+        R.plane_outlier = _lib.ptr(pout)
         _lib.check(_lib.load().eao_pose_optimization(C.byref(P), C.byref(R)))
-        return dict(Tcw=np.array(R.Tcw, np.float32).reshape(4, 4), outlier=outl[:n], n_inliers=R.n_inliers,
-                    lm_iterations=R.lm_iterations, trace=_trace(), timing=_timing())
+        out = dict(Tcw=np.array(R.Tcw, np.float32).reshape(4, 4), outlier=outl[:n], n_inliers=R.n_inliers,
+                   lm_iterations=R.lm_iterations, trace=_trace(), timing=_timing())
+        if m:
+            out["plane_outlier"] = pout[:m]
+        return out
 
     @staticmethod
     def LocalBundleAdjustment(prob, stop=None, its=(5, 10)):

@@ -133,9 +133,12 @@ def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_
     )
 
 
-def synth_pose(n=1000, seed=4000, sigma=1.0, outlier_frac=0.1, mono_frac=0.3):
+def synth_pose(n=1000, seed=4000, sigma=1.0, outlier_frac=0.1, mono_frac=0.3, n_planes=0, plane_noise=0.002):
     """PoseOptimization problem: one camera, n matched map points (world xyz f32), observations
-    (u, v, ur) with ur<0 for monocular matches, octave-dependent inv_sigma2, initial pose perturbed."""
+    (u, v, ur) with ur<0 for monocular matches, octave-dependent inv_sigma2, initial pose perturbed.
+    n_planes > 0 adds associated map planes (src/Optimizer.cc:456-535): plane_world (n_planes,4) = (normal, -distance) in
+    the world, plane_obs the same plane seen from the true pose plus noise (the last plane is a gross outlier when
+    n_planes >= 3), plane_seen (MapPlane::mbSeen)."""
     rng = np.random.default_rng(seed)
     pts = np.empty((n, 3))
     pts[:, 2] = rng.uniform(2.0, 6.0, n)
@@ -163,9 +166,25 @@ def synth_pose(n=1000, seed=4000, sigma=1.0, outlier_frac=0.1, mono_frac=0.3):
     Tgt = np.eye(4)
     Tgt[:3, :3] = Rcw
     Tgt[:3, 3] = tcw
-    return dict(Tcw=T.astype(np.float32), Tcw_gt=Tgt.astype(np.float32), points=pts.astype(np.float32),
+    prob = dict(Tcw=T.astype(np.float32), Tcw_gt=Tgt.astype(np.float32), points=pts.astype(np.float32),
                 obs=obs.astype(np.float32), inv_sigma2=inv_sigma2,
                 fx=np.float32(FX), fy=np.float32(FY), cx=np.float32(CX), cy=np.float32(CY), bf=np.float32(BF))
+    if n_planes:
+        nw = rng.normal(0, 1, (n_planes, 3))
+        nw /= np.linalg.norm(nw, axis=1, keepdims=True)
+        dw = rng.uniform(1.0, 4.0, n_planes)
+        world = np.concatenate([nw, -dw[:, None]], 1)
+        nc = nw @ Rcw.T                                       # local plane: (R n, c3 - t . R n)
+        local = np.concatenate([nc, (world[:, 3] - nc @ tcw)[:, None]], 1)
+        local[:, :3] += rng.normal(0, plane_noise, (n_planes, 3))
+        local[:, 3] += rng.normal(0, plane_noise, n_planes)
+        if n_planes >= 3:
+            local[-1, :3] = _rot(0.5, 0.4, 0.0) @ local[-1, :3]
+            local[-1, 3] += 0.8
+        local *= rng.uniform(0.5, 2.0, (n_planes, 1)) * rng.choice([-1.0, 1.0], (n_planes, 1))   # un-normalised, either sign
+        prob.update(plane_world=world.astype(np.float32), plane_obs=local.astype(np.float32),
+                    plane_seen=(rng.random(n_planes) < 0.6).astype(np.uint8))
+    return prob
 
 
 def synth_tracking(n=1000, seed=7000, flip=0.06, moved=0.03, mono_frac=0.3, occupied_frac=0.05):

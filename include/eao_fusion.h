@@ -266,7 +266,7 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer::PoseOptimization(Frame*) -- reference include/Optimizer.h:56, src/Optimizer.cc:325-673
- * (point/stereo edges; plane edges src/Optimizer.cc:456-535 are not part of this entry point)
+ * (point / stereo edges and the plane edges of src/Optimizer.cc:456-535)
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t n;               /* matched map points (pFrame->mvpMapPoints[i] != NULL), in index order */
@@ -275,6 +275,12 @@ typedef struct {
     const float* obs;        /* n*3: mvKeysUn[i].pt.x, .pt.y, mvuRight[i]  (mvuRight < 0 => monocular edge) */
     const float* inv_sigma2; /* n: mvInvLevelSigma2[mvKeysUn[i].octave] */
     float fx, fy, cx, cy, bf;
+    /* plane edges (src/Optimizer.cc:456-535, 626-658; src/g2oAddition/EdgePlane.h, Plane3D.h): one per associated map
+     * plane (pFrame->mvpMapPlanes[i] != NULL), in index order; n_planes = 0 and NULL pointers when there are none */
+    int32_t n_planes;           /* at most 32 */
+    const float* plane_world;   /* n_planes*4: MapPlane::GetWorldPos() */
+    const float* plane_obs;     /* n_planes*4: pFrame->mvPlaneCoefficients[i] */
+    const uint8_t* plane_seen;  /* n_planes:   MapPlane::mbSeen (unseen planes get twice the information) */
 } eao_pose_problem;
 
 typedef struct {
@@ -282,6 +288,7 @@ typedef struct {
     uint8_t* outlier;   /* n flags: pFrame->mvbOutlier (caller-allocated) */
     int32_t n_inliers;  /* return value of PoseOptimization: nInitialCorrespondences - nBad */
     int32_t lm_iterations; /* outer LM iterations executed over the 4 rounds */
+    uint8_t* plane_outlier; /* n_planes flags: pFrame->mvbPlaneOutlier (caller-allocated; may be NULL when n_planes = 0) */
 } eao_pose_result;
 
 eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r);

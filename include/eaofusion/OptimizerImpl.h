@@ -11,8 +11,9 @@
 //   int  ORB_SLAM2::Optimizer::PoseOptimization(Frame* f) { return eaofusion::PoseOptimization<MapPoint>(f); }
 //   void ORB_SLAM2::Optimizer::LocalBundleAdjustment(KeyFrame* kf, bool* stop, Map* m) { eaofusion::LocalBundleAdjustment<MapPoint>(kf, stop, m); }
 //
-// Not covered yet (DESIGN.md "what comes next"): the plane edges PoseOptimization adds when PEAC
-// planes are associated (src/Optimizer.cc:456-535); frames with mnPlaneNum > 0 are optimised on their point edges only.
+// The plane edges PoseOptimization adds when PEAC planes are associated (src/Optimizer.cc:456-535, 626-658) are part
+// of the call: the template reads Frame::mnPlaneNum / mvpMapPlanes / mvPlaneCoefficients / mvbPlaneOutlier and
+// MapPlane::GetWorldPos() / mbSeen / mGlobalMutex when the Frame class has them (upstream's does).
 #pragma once
 
 #include <algorithm>
@@ -21,6 +22,8 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../eao_fusion.h"
@@ -31,6 +34,37 @@ namespace eaofusion {
 inline void check(eao_status st, const char* what) {
     if (st != EAO_OK) throw std::runtime_error(std::string(what) + ": " + eao_last_error());
 }
+
+// Frame classes with associated map planes (upstream's include/Frame.h: mnPlaneNum, mvpMapPlanes, ...)
+template <class F, class = void> struct has_planes : std::false_type {};
+template <class F> struct has_planes<F, decltype(void(std::declval<F&>().mnPlaneNum), void(std::declval<F&>().mvpMapPlanes))> : std::true_type {};
+
+struct PlaneEdges { std::vector<int> slot; std::vector<float> world, obs; std::vector<uint8_t> seen; };
+// src/Optimizer.cc:456-535: one edge per associated map plane, in index order (under MapPlane::mGlobalMutex)
+template <class FrameT>
+typename std::enable_if<has_planes<FrameT>::value>::type collect_planes(FrameT* pFrame, PlaneEdges& pe) {
+    typedef typename std::remove_pointer<typename std::decay<decltype(pFrame->mvpMapPlanes[0])>::type>::type MapPlaneT;
+    std::unique_lock<std::mutex> lock(MapPlaneT::mGlobalMutex);
+    const int M = pFrame->mnPlaneNum;
+    for (int i = 0; i < M; ++i) {
+        MapPlaneT* pMP = pFrame->mvpMapPlanes[i];
+        if (!pMP) continue;
+        pFrame->mvbPlaneOutlier[i] = false;
+        const cv::Mat w = pMP->GetWorldPos();
+        const cv::Mat& c = pFrame->mvPlaneCoefficients[i];
+        pe.slot.push_back(i);
+        for (int k = 0; k < 4; k++) { pe.world.push_back(w.template at<float>(k, 0)); pe.obs.push_back(c.template at<float>(k, 0)); }
+        pe.seen.push_back(pMP->mbSeen ? 1 : 0);
+    }
+}
+template <class FrameT>
+typename std::enable_if<!has_planes<FrameT>::value>::type collect_planes(FrameT*, PlaneEdges&) {}
+template <class FrameT>
+typename std::enable_if<has_planes<FrameT>::value>::type store_planes(FrameT* pFrame, const PlaneEdges& pe, const std::vector<uint8_t>& out) {
+    for (size_t k = 0; k < pe.slot.size(); k++) pFrame->mvbPlaneOutlier[pe.slot[k]] = out[k] != 0;
+}
+template <class FrameT>
+typename std::enable_if<!has_planes<FrameT>::value>::type store_planes(FrameT*, const PlaneEdges&, const std::vector<uint8_t>&) {}
 
 // ---- Optimizer::PoseOptimization(Frame*) --------------------------------------------------------------------
 template <class MapPointT, class FrameT>
@@ -57,12 +91,18 @@ int PoseOptimization(FrameT* pFrame) {
     cv::Mat Tcw = pFrame->mTcw;
     float T[16];
     for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[r * 4 + c] = Tcw.template at<float>(r, c);
-    eao_pose_problem P = {n, T, Xw.data(), obs.data(), inv.data(), pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf};
-    std::vector<uint8_t> outl(n);
+    PlaneEdges pe;                    // added after the "< 3 correspondences" test, as upstream (:453-456)
+    collect_planes(pFrame, pe);
+    const int M = (int)pe.slot.size();
+    eao_pose_problem P = {n, T, Xw.data(), obs.data(), inv.data(), pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf,
+                          M, pe.world.data(), pe.obs.data(), pe.seen.data()};
+    std::vector<uint8_t> outl(n), pout(M ? M : 1);
     eao_pose_result R;
     R.outlier = outl.data();
+    R.plane_outlier = pout.data();
     check(eao_pose_optimization(&P, &R), "eao_pose_optimization");
     for (int k = 0; k < n; k++) pFrame->mvbOutlier[slot[k]] = outl[k] != 0;
+    store_planes(pFrame, pe, pout);
     cv::Mat pose(4, 4, CV_32F);
     for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[r * 4 + c];
     pFrame->SetPose(pose);

@@ -293,6 +293,50 @@ struct LM {
 };
 
 // ------------------------------------------------------------------ PoseOptimization (unary edges)
+// ------------------------------------------------------------------ planes (src/g2oAddition/Plane3D.h, EdgePlane.h)
+// Plane3D keeps (n, -d) normalised with a non-negative fourth coefficient; ominus returns (azimuth, elevation, distance)
+// of the measured plane in the frame that rotates this plane's normal onto +x.
+void plane_normalize(double c[4]) {                       // Plane3D::normalize, Plane3D.h:125-130
+    const double n = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const double s = 1. / n;
+    for (int k = 0; k < 4; k++) c[k] = c[k] * s;
+    if (c[3] < 0.0) for (int k = 0; k < 4; k++) c[k] = -c[k];
+}
+void plane_from_f32(const float* v, double c[4]) {         // Converter::toPlane3D, src/Converter.cc:215-225
+    for (int k = 0; k < 4; k++) c[k] = v[k];
+    if (v[3] < 0.0) for (int k = 0; k < 4; k++) c[k] = -c[k];
+    plane_normalize(c);
+}
+void plane_rotation(const double v[3], double R[9]) {      // Plane3D::rotation, Plane3D.h:65-71: AngleAxis(az, Z) * AngleAxis(-el, Y)
+    const double az = std::atan2(v[1], v[0]);
+    const double el = std::atan2(v[2], std::sqrt(v[0] * v[0] + v[1] * v[1]));
+    const double ha = 0.5 * az, hb = 0.5 * (-el);
+    const Quat a{0, 0, std::sin(ha) * 1.0, std::cos(ha)}, b{0, std::sin(hb) * 1.0, 0, std::cos(hb)};
+    quat_to_matrix(quat_mul(a, b), R);
+}
+void plane_error(const SE3& T, const double world[4], const double meas[4], double err[3]) {   // EdgePlane::computeError
+    double R[9];
+    quat_to_matrix(T.r, R);
+    double v2[4];
+    for (int r = 0; r < 3; r++) v2[r] = R[r * 3] * world[0] + R[r * 3 + 1] * world[1] + R[r * 3 + 2] * world[2];
+    v2[3] = world[3] - (T.t[0] * v2[0] + T.t[1] * v2[1] + T.t[2] * v2[2]);
+    if (v2[3] < 0.0) for (int k = 0; k < 4; k++) v2[k] = -v2[k];
+    plane_normalize(v2);                                   // Plane3D(v2)
+    double Rn[9];
+    plane_rotation(v2, Rn);
+    double n[3];
+    for (int r = 0; r < 3; r++) n[r] = Rn[r] * meas[0] + Rn[3 + r] * meas[1] + Rn[6 + r] * meas[2];   // rotation^T * normal
+    err[0] = std::atan2(n[1], n[0]);
+    err[1] = std::atan2(n[2], std::sqrt(n[0] * n[0] + n[1] * n[1]));
+    err[2] = (-v2[3]) - (-meas[3]);
+}
+struct PlaneEdge {
+    double world[4], meas[4], infoA, infoD;
+    int level = 0;
+    bool robust = true;
+    double err[3] = {0, 0, 0};
+};
+
 struct PoseEdge {
     double Xw[3], obs[3], info;
     bool stereo;
@@ -306,8 +350,13 @@ struct PoseProblem : Problem {
     std::vector<PoseEdge> edges;
     double fx, fy, cx, cy, bf;
     double deltaMono, deltaStereo;  // float sqrt() results promoted (Optimizer.cc:361-362)
+    std::vector<PlaneEdge> planes;  // EdgePlane against fixed plane vertices (src/Optimizer.cc:456-535), after the point edges
+    double deltaPlane = 0;
     double H[36], b[6], x[6];
 
+    static double chi2(const PlaneEdge& e) {
+        return e.err[0] * (e.infoA * e.err[0]) + e.err[1] * (e.infoA * e.err[1]) + e.err[2] * (e.infoD * e.err[2]);
+    }
     void edgeError(PoseEdge& e) const {
         double p[3];
         se3_map(est, e.Xw, p);
@@ -329,14 +378,27 @@ struct PoseProblem : Problem {
         if (e.stereo) s += e.err[2] * (e.info * e.err[2]);
         return s;
     }
-    bool hasActive() const override { for (auto& e : edges) if (e.level == 0) return true; return false; }
-    void computeActiveErrors() override { for (auto& e : edges) if (e.level == 0) edgeError(e); }
+    bool hasActive() const override {
+        for (auto& e : edges) if (e.level == 0) return true;
+        for (auto& e : planes) if (e.level == 0) return true;
+        return false;
+    }
+    void computeActiveErrors() override {
+        for (auto& e : edges) if (e.level == 0) edgeError(e);
+        for (auto& e : planes) if (e.level == 0) plane_error(est, e.world, e.meas, e.err);
+    }
     double activeRobustChi2() const override {
         double chi = 0;
         for (auto& e : edges) {
             if (e.level != 0) continue;
             double c = chi2(e);
             if (e.robust) { double d = e.stereo ? deltaStereo : deltaMono, r0, r1; huber(c, d, d * d, r0, r1); chi += r0; }
+            else chi += c;
+        }
+        for (auto& e : planes) {
+            if (e.level != 0) continue;
+            double c = chi2(e);
+            if (e.robust) { double r0, r1; huber(c, deltaPlane, deltaPlane * deltaPlane, r0, r1); chi += r0; }
             else chi += c;
         }
         return chi;
@@ -370,6 +432,34 @@ struct PoseProblem : Problem {
                 for (int j = 0; j < 6; j++) {
                     double h = 0;
                     for (int k = 0; k < D; k++) h += J[k][i] * wi * J[k][j];
+                    H[i * 6 + j] += h;
+                }
+            }
+        }
+        // plane edges: g2o's numeric Jacobian with respect to the pose (central differences, delta = 1e-9,
+        // core/base_binary_edge.hpp:131-205); the plane vertex is fixed
+        for (auto& e : planes) {
+            if (e.level != 0) continue;
+            const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+            double J[3][6];
+            for (int d = 0; d < 6; d++) {
+                double add[6] = {0, 0, 0, 0, 0, 0}, ep[3], em[3];
+                add[d] = delta;
+                plane_error(se3_mul(se3_exp(add), est), e.world, e.meas, ep);
+                add[d] = -delta;
+                plane_error(se3_mul(se3_exp(add), est), e.world, e.meas, em);
+                for (int k = 0; k < 3; k++) J[k][d] = scalar * (ep[k] - em[k]);
+            }
+            double w = 1.0;
+            if (e.robust) { double r0; huber(chi2(e), deltaPlane, deltaPlane * deltaPlane, r0, w); }
+            const double info[3] = {e.infoA, e.infoA, e.infoD};
+            for (int i = 0; i < 6; i++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += J[k][i] * (info[k] * e.err[k]);
+                b[i] -= w * s;
+                for (int j = 0; j < 6; j++) {
+                    double h = 0;
+                    for (int k = 0; k < 3; k++) h += J[k][i] * (w * info[k]) * J[k][j];
                     H[i * 6 + j] += h;
                 }
             }
@@ -629,8 +719,12 @@ struct orc_pose_problem {
 };
 struct orc_trace { int32_t n; double lambda[64]; double chi2[64]; int32_t trials[64]; };
 
-// returns nInitialCorrespondences - nBad; Tcw_out float[16]; outlier[n]; pose_d = final (qx,qy,qz,qw,tx,ty,tz) in fp64
-int orc_pose_optimization(const orc_pose_problem* P, float* Tcw_out, uint8_t* outlier, double* pose_d, orc_trace* trace) {
+// returns nInitialCorrespondences - nBad; Tcw_out float[16]; outlier[n]; pose_d = final (qx,qy,qz,qw,tx,ty,tz) in fp64.
+// Planes (src/Optimizer.cc:456-535, 626-658): plane_world / plane_obs 4 floats each (MapPlane::GetWorldPos(),
+// Frame::mvPlaneCoefficients[i]), plane_seen[i] = MapPlane::mbSeen, plane_outlier[i] = Frame::mvbPlaneOutlier[i] on return.
+int orc_pose_optimization_planes(const orc_pose_problem* P, int n_planes, const float* plane_world, const float* plane_obs,
+                                 const uint8_t* plane_seen, float* Tcw_out, uint8_t* outlier, uint8_t* plane_outlier, double* pose_d,
+                                 orc_trace* trace) {
     const int n = P->n;
     PoseProblem pb;
     pb.fx = P->fx; pb.fy = P->fy; pb.cx = P->cx; pb.cy = P->cy; pb.bf = P->bf;
@@ -644,7 +738,19 @@ int orc_pose_optimization(const orc_pose_problem* P, float* Tcw_out, uint8_t* ou
         outlier[i] = 0;
     }
     if (trace) trace->n = 0;
-    if (n < 3) { std::memcpy(Tcw_out, P->Tcw, 16 * sizeof(float)); return 0; }
+    if (n < 3) { std::memcpy(Tcw_out, P->Tcw, 16 * sizeof(float)); return 0; }   // checked BEFORE the planes are added (:453-454)
+    const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0, planeChi = 300;
+    pb.deltaPlane = (float)std::sqrt(planeChi);
+    pb.planes.resize(n_planes);
+    for (int i = 0; i < n_planes; i++) {
+        PlaneEdge& e = pb.planes[i];
+        plane_from_f32(plane_world + 4 * i, e.world);
+        plane_from_f32(plane_obs + 4 * i, e.meas);
+        const double f = plane_seen[i] ? 1.0 : 2.0;
+        e.infoA = f * angleInfo; e.infoD = f * disInfo;
+        plane_outlier[i] = 0;
+    }
+    const int nInitial = n + n_planes;
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
     int nBad = 0;
     pb.est = se3_from_Tcw_f32(P->Tcw);
@@ -666,12 +772,23 @@ int orc_pose_optimization(const orc_pose_problem* P, float* Tcw_out, uint8_t* ou
             if (!e.stereo) e.robust = false;             // mono: kernel dropped after every round (:584-586)
             else if (it == 2) e.robust = false;          // stereo: at it == 2 (:620-621)
         }
-        if (n < 10) break;
+        for (int i = 0; i < n_planes; i++) {             // :626-658
+            PlaneEdge& e = pb.planes[i];
+            if (plane_outlier[i]) plane_error(pb.est, e.world, e.meas, e.err);
+            const float c = (float)PoseProblem::chi2(e);
+            if (c > planeChi) { plane_outlier[i] = 1; e.level = 1; nBad++; }
+            else { e.level = 0; plane_outlier[i] = 0; }
+            if (it == 2) e.robust = false;
+        }
+        if (nInitial < 10) break;
     }
     se3_to_Tcw_f32(pb.est, Tcw_out);
     if (pose_d) { pose_d[0] = pb.est.r.x; pose_d[1] = pb.est.r.y; pose_d[2] = pb.est.r.z; pose_d[3] = pb.est.r.w;
                   pose_d[4] = pb.est.t[0]; pose_d[5] = pb.est.t[1]; pose_d[6] = pb.est.t[2]; }
-    return n - nBad;
+    return nInitial - nBad;
+}
+int orc_pose_optimization(const orc_pose_problem* P, float* Tcw_out, uint8_t* outlier, double* pose_d, orc_trace* trace) {
+    return orc_pose_optimization_planes(P, 0, nullptr, nullptr, nullptr, Tcw_out, outlier, nullptr, pose_d, trace);
 }
 
 struct orc_ba_problem {

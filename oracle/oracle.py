@@ -211,8 +211,19 @@ def pose_optimization(prob):
     outl = np.zeros(max(n, 1), np.uint8)
     pose_d = np.zeros(7)
     tr = Trace()
-    ninl = lib().orc_pose_optimization(C.byref(P), _p(T_out), _p(outl), _p(pose_d), C.byref(tr))
-    return dict(Tcw=T_out, outlier=outl[:n], n_inliers=ninl, pose_d=pose_d, trace=tr.to_dict())
+    pw = prob.get("plane_world")
+    if pw is None:
+        ninl = lib().orc_pose_optimization(C.byref(P), _p(T_out), _p(outl), _p(pose_d), C.byref(tr))
+        return dict(Tcw=T_out, outlier=outl[:n], n_inliers=ninl, pose_d=pose_d, trace=tr.to_dict())
+    pw = np.ascontiguousarray(pw, np.float32)
+    po = np.ascontiguousarray(prob["plane_obs"], np.float32)
+    ps = np.ascontiguousarray(prob["plane_seen"], np.uint8)
+    pout = np.zeros(max(len(pw), 1), np.uint8)
+    fn = lib().orc_pose_optimization_planes
+    fn.restype = C.c_int
+    ninl = fn(C.byref(P), C.c_int(len(pw)), C.c_void_p(_p(pw)), C.c_void_p(_p(po)), C.c_void_p(_p(ps)), C.c_void_p(_p(T_out)),
+              C.c_void_p(_p(outl)), C.c_void_p(_p(pout)), C.c_void_p(_p(pose_d)), C.byref(tr))
+    return dict(Tcw=T_out, outlier=outl[:n], plane_outlier=pout[:len(pw)], n_inliers=ninl, pose_d=pose_d, trace=tr.to_dict())
 
 
 def local_ba(prob, its=(5, 10), stop=None):

@@ -56,6 +56,13 @@ struct KeyFrame {
     }
 };
 struct Map { std::mutex mMutexMapUpdate; };
+struct MapPlane {
+    static std::mutex mGlobalMutex;
+    cv::Mat world;
+    bool mbSeen = false;
+    cv::Mat GetWorldPos() { return world.clone(); }
+};
+std::mutex MapPlane::mGlobalMutex;
 struct Frame {
     int N = 0;
     static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
@@ -70,6 +77,11 @@ struct Frame {
     cv::Mat mTcw;
     float fx, fy, cx, cy, mbf;
     void SetPose(cv::Mat T) { mTcw = T.clone(); }
+    // associated map planes (upstream include/Frame.h)
+    int mnPlaneNum = 0;
+    std::vector<MapPlane*> mvpMapPlanes;
+    std::vector<cv::Mat> mvPlaneCoefficients;
+    std::vector<bool> mvbPlaneOutlier;
 };
 
 float Frame::mnMinX = 0, Frame::mnMaxX = 640, Frame::mnMinY = 0, Frame::mnMaxY = 480;
@@ -147,8 +159,28 @@ int main(int argc, char** argv) {
         F.mvKeysUn[i].octave = i;
         F.mvInvLevelSigma2[i] = inv[i];
     }
+    // planes: m associated + one empty slot in front
+    int32_t m;
+    rd(in, &m, 1);
+    std::vector<float> pworld(m * 4), pobs(m * 4);
+    std::vector<uint8_t> pseen(m);
+    rd(in, pworld.data(), pworld.size()); rd(in, pobs.data(), pobs.size()); rd(in, pseen.data(), m);
+    std::vector<MapPlane> planes(m);
+    F.mnPlaneNum = m + 1;
+    F.mvpMapPlanes.assign(m + 1, nullptr); F.mvPlaneCoefficients.assign(m + 1, cv::Mat(4, 1, CV_32F)); F.mvbPlaneOutlier.assign(m + 1, true);
+    for (int i = 0; i < m; i++) {
+        planes[i].world = cv::Mat(4, 1, CV_32F);
+        cv::Mat c(4, 1, CV_32F);
+        for (int k = 0; k < 4; k++) { planes[i].world.at<float>(k, 0) = pworld[4 * i + k]; c.at<float>(k, 0) = pobs[4 * i + k]; }
+        planes[i].mbSeen = pseen[i] != 0;
+        F.mvpMapPlanes[i + 1] = &planes[i];
+        F.mvPlaneCoefficients[i + 1] = c;
+    }
     int32_t inliers = eaofusion::PoseOptimization<MapPoint>(&F);
     wr(out, &inliers, 1);
+    std::vector<uint8_t> pfl(m + 1);
+    for (int i = 0; i <= m; i++) pfl[i] = F.mvbPlaneOutlier[i];
+    wr(out, pfl.data(), m + 1);
     wr(out, F.mTcw.ptr<float>(0), 16);
     std::vector<uint8_t> ofl(n);
     for (int i = 0; i < n; i++) ofl[i] = F.mvbOutlier[i];

@@ -22,7 +22,7 @@ def test_cpp_adapters_end_to_end(tmp_path):
                            "-L", os.path.join(ROOT, "eao_fusion_amd"), "-leaofusion_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "eao_fusion_amd"), "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
     img = synth.synth_frame(1234)
-    pp = synth.synth_pose(n=400, seed=4100)
+    pp = synth.synth_pose(n=400, seed=4100, n_planes=4)
     bp = synth.synth_ba(n_free=6, n_fixed=3, n_points=400, seed=3100, mono_frac=0.2)
     prob = str(tmp_path / "problem.bin")
     with open(prob, "wb") as f:
@@ -31,6 +31,8 @@ def test_cpp_adapters_end_to_end(tmp_path):
         for k in ("Tcw", "points", "obs", "inv_sigma2"):
             f.write(np.ascontiguousarray(pp[k], np.float32).tobytes())
         f.write(np.array([pp[k] for k in ("fx", "fy", "cx", "cy", "bf")], np.float32).tobytes())
+        f.write(struct.pack("<i", len(pp["plane_world"])))
+        f.write(pp["plane_world"].tobytes()); f.write(pp["plane_obs"].tobytes()); f.write(pp["plane_seen"].tobytes())
         f.write(struct.pack("<iii", len(bp["poses"]), len(bp["points"]), len(bp["edge_cam"])))
         f.write(bp["poses"].tobytes()); f.write(bp["fixed"].tobytes()); f.write(bp["points"].tobytes())
         f.write(bp["edge_cam"].tobytes()); f.write(bp["edge_point"].tobytes()); f.write(bp["obs"].tobytes()); f.write(bp["inv_sigma2"].tobytes())
@@ -64,10 +66,12 @@ def test_cpp_adapters_end_to_end(tmp_path):
     assert nm > 0.9 * nk and self_hits > 0.9 * nm
     # ---- PoseOptimization
     inl = int(take(np.int32, 1)[0])
+    pfl = take(np.uint8, len(pp["plane_world"]) + 1)
     Tcw = take(np.float32, 16).reshape(4, 4)
     outl = take(np.uint8, len(pp["points"]))
     r = E.Optimizer.PoseOptimization(pp)
     assert inl == r["n_inliers"] and np.array_equal(outl, r["outlier"]) and np.array_equal(Tcw, r["Tcw"])
+    assert pfl[0] == 1 and np.array_equal(pfl[1:], r["plane_outlier"])      # the empty plane slot keeps its flag
     # ---- LocalBundleAdjustment (edge insertion order differs from the flat problem => rounding-level differences only)
     nc, npnt = len(bp["poses"]), len(bp["points"])
     poses = take(np.float32, nc * 16).reshape(nc, 4, 4)

@@ -96,6 +96,22 @@ def test_pose_optimization_parity(gpu, oracle, kw):
     _check_updates(r["Tcw"], o["Tcw"], p["Tcw"], "Tcw")
 
 
+@pytest.mark.parametrize("kw", [dict(n=300, seed=4200, n_planes=6), dict(n=12, seed=4201, n_planes=5, sigma=0.5, outlier_frac=0.0),
+                                dict(n=1500, seed=4202, n_planes=32), dict(n=40, seed=4203, n_planes=1, mono_frac=1.0)])
+def test_pose_optimization_with_planes(gpu, oracle, kw):
+    """Plane edges (src/Optimizer.cc:456-535): same inlier / outlier tables as the oracle, pose update within 1e-4.  The
+    Jacobian of these edges is g2o's central difference with delta = 1e-9, i.e. it carries ~1e-7 of rounding noise in
+    any implementation."""
+    p = synth.synth_pose(**kw)
+    r = gpu.Optimizer.PoseOptimization(p)
+    o = oracle.pose_optimization(p)
+    assert r["n_inliers"] == o["n_inliers"]
+    assert np.array_equal(r["outlier"], o["outlier"]) and np.array_equal(r["plane_outlier"], o["plane_outlier"])
+    _check_updates(r["Tcw"], o["Tcw"], p["Tcw"], "Tcw")
+    if kw["n_planes"] >= 3:
+        assert r["plane_outlier"][-1] == 1 and r["plane_outlier"][:-1].sum() == 0
+
+
 def test_pose_optimization_too_few_points(gpu):
     p = synth.synth_pose(n=2)
     r = gpu.Optimizer.PoseOptimization(p)
