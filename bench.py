@@ -151,6 +151,26 @@ def main():
         if not args.no_cpu_baseline:
             cpu_baseline, cpu_extra = measure_cpu(frames, synth, extra)
             extra.update(cpu_extra)
+    # ---- BASELINE configs[4] (batched sequence), outside the timed region: consecutive-frame matching inside the shard (one
+    #      halo frame from the previous rank) and this rank's share of the local-BA windows (window w -> rank w mod N)
+    seq = {}
+    if not args.no_extra:
+        halo_desc, halo_n = shard.exchange_halo(d_desc[B - 1], int(n_host[B - 1]), device=dev)   # symmetric collective: every rank calls it
+        seq_local = [0.0, 0.0, 0.0, 0.0]      # frame pairs, seconds matching, residual blocks, seconds BA
+        try:
+            seq_local = measure_sequence(E, synth, shard, torch, dev, rank, world, d_desc, n_host, halo_desc, halo_n)
+        except Exception as ex:  # noqa: BLE001
+            seq["error_rank%d" % rank] = repr(ex)
+        tsr = torch.tensor(seq_local, dtype=torch.float64, device=dev)
+        tmax = tsr.clone()
+        if world > 1:
+            dist.all_reduce(tsr, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        pairs, blocks = float(tsr[0].item()), float(tsr[2].item())
+        t_match, t_ba = float(tmax[1].item()), float(tmax[3].item())
+        seq.update({"frame_pairs": int(pairs), "frame_pairs_per_s": round(pairs / t_match, 1) if t_match > 0 else None,
+                    "ba_windows": 25, "ba_residual_blocks_per_s": round(blocks / t_ba, 1) if t_ba > 0 else None,
+                    "note": "consecutive-frame brute-force matching (best-2 Hamming) per shard with one halo frame; 25 LBA windows, window w on rank w mod N"})
     if world > 1:
         # the batched-sequence config gathers every rank's per-frame keypoint counts over RCCL (outside the timed region)
         all_counts = shard.gather_frame_counts(d_n, n_frames, device=dev)
@@ -158,6 +178,8 @@ def main():
         extra["allgather_keypoints"] = int(all_counts.sum().item())
         dist.barrier()
         dist.destroy_process_group()
+    if seq:
+        extra["sequence"] = seq
     if rank == 0:
         out = {
             "metric": "ORB kpts/s (640x480, 1k feat) + local-BA residuals/s (20 KF x 3k pts)",
@@ -169,6 +191,32 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }
         print(json.dumps(out))
+
+
+def measure_sequence(E, synth, shard, torch, dev, rank, world, d_desc, n_host, halo_desc, halo_n):
+    """This rank's share of the batched-sequence work.  Returns [pairs, s, residual blocks, s]."""
+    L = E.load()
+    B = d_desc.shape[0]
+    st = torch.cuda.current_stream().cuda_stream
+    d_out = torch.zeros((int(n_host.max()) + 1, 4), dtype=torch.int32, device=dev)
+    jobs = [(d_desc[f - 1], int(n_host[f - 1]), d_desc[f], int(n_host[f])) for f in range(1, B)]
+    if halo_desc is not None:
+        jobs.insert(0, (halo_desc, halo_n, d_desc[0], int(n_host[0])))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, na, b, nb in jobs:
+        if na and nb:
+            E._lib.check(L.eao_hamming_best2_device(a.data_ptr(), na, b.data_ptr(), nb, 1, None, d_out.data_ptr(), st))
+    torch.cuda.synchronize()
+    t_match = time.perf_counter() - t0
+    blocks, t_ba = 0.0, 0.0
+    for w in shard.window_shard(25, rank, world):
+        p = synth.synth_ba(seed=6000 + w)
+        t0 = time.perf_counter()
+        r = E.Optimizer.LocalBundleAdjustment(p)
+        t_ba += time.perf_counter() - t0
+        blocks += len(p["edge_cam"]) * r["timing"]["linearizations"]
+    return [float(len(jobs)), t_match, blocks, t_ba]
 
 
 def measure_extra(E, synth, torch, dev):

@@ -110,12 +110,32 @@ __global__ __launch_bounds__(256) void k_match_candidates(FrameDev F, const Quer
     }
 }
 
+struct PinBuf {   // grow-only pinned host buffer (device-visible: kernels write results straight into it)
+    unsigned char* p = nullptr;
+    size_t n = 0;
+    eao_status reserve(size_t need) {
+        if (need <= n) return EAO_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; n = 0;
+        const size_t cap = need + (need >> 2) + 4096;
+        EAO_HIP(hipHostMalloc((void**)&p, cap, hipHostMallocMapped));
+        n = cap;
+        return EAO_OK;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+struct HostView {   // what the old std::vector staging offered
+    PinBuf buf;
+    eao_status resize(size_t n) { return buf.reserve(n); }
+    unsigned char* data() { return buf.p; }
+};
 struct Ctx {   // per-thread workspace, grow-only
     hipStream_t stream = nullptr;
     eao::DevBuf<unsigned char> dev;
-    std::vector<unsigned char> host;
-    eao::DevBuf<unsigned> out;
-    eao::DevBuf<int> meta;   // segStart[nq], segCount[nq], cursor
+    HostView host;           // pinned staging of everything uploaded: ONE asynchronous H2D copy per call
+    PinBuf out;              // candidate items, written by the kernel over PCIe (zero-copy), read after the stream sync
+    eao::DevBuf<int> metaDev; // segStart[nq], segCount[nq], cursor (device: the cursor is an atomic)
+    PinBuf meta;             // their pinned copy (asynchronous D2H in the same stream)
     ~Ctx() { if (stream) (void)hipStreamDestroy(stream); }
 };
 thread_local Ctx g_ctx;
@@ -159,7 +179,7 @@ eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Qu
     const size_t oDe = off; off = al(off + 32 * (size_t)n);
     const size_t oQ = off; off = al(off + sizeof(Query) * (size_t)nq);
     const size_t oQd = off; off = al(off + 32 * (size_t)nq);
-    c.host.resize(off);
+    if ((st = c.host.resize(off))) return st;
     unsigned char* hb = c.host.data();
     std::memcpy(hb + oKx, F->kp_x, 4 * (size_t)n); std::memcpy(hb + oKy, F->kp_y, 4 * (size_t)n);
     std::memcpy(hb + oUr, F->u_right, 4 * (size_t)n); std::memcpy(hb + oOc, F->kp_octave, 4 * (size_t)n);
@@ -173,11 +193,13 @@ eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Qu
     std::memcpy(hb + oQd, qdesc, 32 * (size_t)nq);
     if ((st = c.dev.reserve(off))) return st;
     const size_t outCap = (size_t)nq * std::max(no, 1);
-    if ((st = c.out.reserve(outCap))) return st;
-    if ((st = c.meta.reserve(2 * (size_t)nq + 1))) return st;
+    if ((st = c.out.reserve(outCap * sizeof(unsigned)))) return st;
+    if ((st = c.meta.reserve((2 * (size_t)nq + 1) * sizeof(int)))) return st;
+    if ((st = c.metaDev.reserve(2 * (size_t)nq + 1))) return st;
     hipStream_t s = c.stream;
     EAO_HIP(hipMemcpyAsync(c.dev.p, hb, off, hipMemcpyHostToDevice, s));
-    EAO_HIP(hipMemsetAsync(c.meta.p + 2 * (size_t)nq, 0, sizeof(int), s));
+    EAO_HIP(hipMemsetAsync(c.metaDev.p + 2 * (size_t)nq, 0, sizeof(int), s));   // cursor
+    int* meta = (int*)c.meta.p;
     FrameDev D;
     D.n = n; D.nOrdered = no;
     D.kx = (const float*)(c.dev.p + oKx); D.ky = (const float*)(c.dev.p + oKy); D.ur = (const float*)(c.dev.p + oUr);
@@ -186,15 +208,13 @@ eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Qu
     D.desc = (const uint4*)(c.dev.p + oDe);
     D.minX = F->min_x; D.minY = F->min_y; D.invW = F->grid_inv_w; D.invH = F->grid_inv_h; D.cols = F->grid_cols; D.rows = F->grid_rows;
     hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, (const Query*)(c.dev.p + oQ),
-                       (const uint4*)(c.dev.p + oQd), nq, c.out.p, (int)std::min(outCap, (size_t)0x7FFFFFFF), c.meta.p, c.meta.p + nq,
-                       c.meta.p + 2 * (size_t)nq);
-    std::vector<int> meta(2 * (size_t)nq + 1);
-    EAO_HIP(hipMemcpyAsync(meta.data(), c.meta.p, meta.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+                       (const uint4*)(c.dev.p + oQd), nq, (unsigned*)c.out.p, (int)std::min(outCap, (size_t)0x7FFFFFFF), c.metaDev.p,
+                       c.metaDev.p + nq, c.metaDev.p + 2 * (size_t)nq);
+    EAO_HIP(hipMemcpyAsync(meta, c.metaDev.p, (2 * (size_t)nq + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
     const int totalItems = meta[2 * (size_t)nq];
-    L.items.resize(std::max(totalItems, 0));
-    if (totalItems > 0) EAO_HIP(hipMemcpy(L.items.data(), c.out.p, (size_t)totalItems * sizeof(unsigned), hipMemcpyDeviceToHost));
+    L.items.assign((const unsigned*)c.out.p, (const unsigned*)c.out.p + std::max(totalItems, 0));
     for (int k = 0; k < nq; k++) { L.start[k] = meta[k]; L.count[k] = meta[nq + k]; }
     return EAO_OK;
 }
@@ -226,7 +246,7 @@ eao_status eao::match::pair_distances(const uint8_t* descA, int nA, const uint8_
     const size_t oB = off; off = al(off + 32 * (size_t)nB);
     const size_t oP = off; off = al(off + 8 * np);
     const size_t oD = off; off = al(off + 2 * np);
-    c.host.resize(off);
+    if ((st = c.host.resize(off))) return st;
     unsigned char* hb = c.host.data();
     std::memcpy(hb + oA, descA, 32 * (size_t)nA);
     std::memcpy(hb + oB, descB, 32 * (size_t)nB);
@@ -234,11 +254,12 @@ eao_status eao::match::pair_distances(const uint8_t* descA, int nA, const uint8_
     if ((st = c.dev.reserve(off))) return st;
     hipStream_t s = c.stream;
     EAO_HIP(hipMemcpyAsync(c.dev.p, hb, oD, hipMemcpyHostToDevice, s));
+    if ((st = c.out.reserve(2 * np))) return st;
     hipLaunchKernelGGL(k_pair_distances, dim3(eao::cdiv((int)np, 256)), dim3(256), 0, s, (const uint4*)(c.dev.p + oA), (const uint4*)(c.dev.p + oB),
-                       (const int2*)(c.dev.p + oP), (int)np, (unsigned short*)(c.dev.p + oD));
-    EAO_HIP(hipMemcpyAsync(dist.data(), c.dev.p + oD, 2 * np, hipMemcpyDeviceToHost, s));
+                       (const int2*)(c.dev.p + oP), (int)np, (unsigned short*)c.out.p);
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
+    std::memcpy(dist.data(), c.out.p, 2 * np);
     return EAO_OK;
 }
 

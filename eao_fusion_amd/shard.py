@@ -62,3 +62,26 @@ def aggregate_throughput(units_local, seconds_local, device=None):
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(u.item()) / float(t.item()), float(u.item()), float(t.item())
+
+
+def window_shard(n_windows, rank, world):
+    """BA windows are independent problems: window w belongs to rank w mod world."""
+    return list(range(rank, n_windows, world))
+
+
+def exchange_halo(last_desc, last_count, device=None):
+    """The consecutive-frame matcher of a shard needs the last frame of the previous shard: every rank contributes the
+    descriptors (cap, 32) u8 and keypoint count of its LAST frame to one all_gather and picks the entry of rank - 1.
+    Returns (desc, count) of the halo frame, or (None, 0) on rank 0 / a single rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return None, 0
+    cnt = torch.tensor([int(last_count)], dtype=torch.int32, device=device)
+    descs = [torch.empty_like(last_desc) for _ in range(world)]
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(descs, last_desc.contiguous())
+    dist.all_gather(cnts, cnt)
+    if rank == 0:
+        return None, 0
+    return descs[rank - 1], int(cnts[rank - 1].item())

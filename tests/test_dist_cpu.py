@@ -32,8 +32,12 @@ def _worker(rank, world, port, n_frames, q):
     local = [1000 + (f * 7) % 13 for f in range(lo, hi)]          # stand-in for per-frame keypoint counts
     allc = shard.gather_frame_counts(local, n_frames)
     thr, units, secs = shard.aggregate_throughput(sum(local), 0.5 + 0.25 * rank)
+    # halo exchange of the consecutive-frame matcher: each rank's last frame goes to the next rank
+    last = torch.full((5, 32), 10 * rank + 1, dtype=torch.uint8)
+    hd, hn = shard.exchange_halo(last, 3 + rank)
+    halo = None if hd is None else (int(hd[0, 0]), hn)
     dist.barrier()
-    q.put((rank, allc.tolist(), thr, units, secs))
+    q.put((rank, allc.tolist(), thr, units, secs, halo, shard.window_shard(25, rank, world)))
     dist.destroy_process_group()
 
 
@@ -53,7 +57,9 @@ def test_two_rank_gather_and_throughput(n_frames):
         p.join(timeout=60)
         assert p.exitcode == 0
     expect = [1000 + (f * 7) % 13 for f in range(n_frames)]
-    for rank, allc, thr, units, secs in res:
+    for rank, allc, thr, units, secs, halo, windows in res:
         assert allc == expect                      # every rank sees every frame, in global order
         assert units == sum(expect) and secs == 0.75   # SUM of units, MAX of time
         assert thr == pytest.approx(sum(expect) / 0.75)
+        assert halo == (None if rank == 0 else (1, 3))  # rank 1 receives rank 0's last frame (value 1, 3 keypoints)
+        assert windows == list(range(rank, 25, 2))
