@@ -1024,6 +1024,7 @@ __global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int 
     const double chi = ordered_sum(P.partChi, P.nL, red, &out1);
     if (threadIdx.x == 0) {
         P.lm[2] = chi;
+        P.lm[3] = 0;          // max |diagonal| accumulator of the first linearisation (lambda_0)
         st->chi = chi; st->tempChi = chi; st->accepted = 1; st->solveOk = 1; st->rho = 0; st->lambda = P.lm[0];
         st->cur = P.ctl[kCtlCur];
         __threadfence_system();
@@ -1036,8 +1037,12 @@ __global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int 
 // quads first (DPP), then 27 x 8 column threads over 32 quad leaders each, then the last 8.  (Sixty-four-lane shuffle
 // trees for the 27 values cost 6.4 us here; this costs about one.)
 constexpr int kLinThreads = 1024;
-__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlocks) {
+// first = 1 on the first linearisation of an optimize() call: the largest |diagonal entry| of Hpp / Hll (lambda_0 = 1e-5 x
+// that, optimization_algorithm_levenberg.cpp:166-180) is accumulated with one atomic max per workgroup -- a max does not
+// depend on the order, and non-negative doubles order like their bit patterns.
+__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlocks, int first) {
     __shared__ double red[(kLinThreads / 4) * 27], part[8 * 27];
+    __shared__ double s_wmax[kLinThreads / 64];
     if (P.ctl[kCtlHalt]) return;
     const SE3* cams = cur_cams(P);
     const double* pts = cur_pts(P);
@@ -1090,6 +1095,16 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
             Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
             for (int i = 0; i < 3; i++) P.bl[(size_t)l * 3 + i] = b[i];
         }
+        if (first) {
+            double m = (live && slot == 0) ? fmax(fmax(fabs(H[0]), fabs(H[3])), fabs(H[5])) : 0.0;
+            for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_down(m, d));
+            if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < kLinThreads / 64; w++) m = fmax(m, s_wmax[w]);
+                atomicMax((unsigned long long*)&P.lm[3], (unsigned long long)__double_as_longlong(m));
+            }
+        }
     } else {
         const int ci = blockIdx.x - ptBlocks;
         const int cam = P.actCam[ci];
@@ -1132,6 +1147,12 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
             for (int i = 0; i < 6; i++)
                 for (int j = i; j < 6; j++) { P.Hpp[(size_t)ci * 36 + i * 6 + j] = sums[q]; P.Hpp[(size_t)ci * 36 + j * 6 + i] = sums[q]; q++; }
             for (int i = 0; i < 6; i++) P.bp[(size_t)ci * 6 + i] = sums[21 + i];
+            if (first) {
+                double m = 0;
+                q = 0;
+                for (int i = 0; i < 6; i++) { m = fmax(m, fabs(sums[q])); q += 6 - i; }
+                atomicMax((unsigned long long*)&P.lm[3], (unsigned long long)__double_as_longlong(m));
+            }
         }
     }
 }
@@ -1182,7 +1203,7 @@ constexpr int kSchurMaxFree = 64;      // free keyframes per window
 constexpr int kSchurThreads = 1024;
 constexpr int kSchurMaxOut = (kSchurMaxFree * 36 + 6 + kSchurThreads - 1) / kSchurThreads;
 __host__ __device__ inline int schur_batch_edges(int nF) { return min(32, kSchurSlots / max(nF, 1)); }   // 32: one hit-mask word
-__global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P) {
+__global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P, int first) {
     extern __shared__ __attribute__((aligned(16))) double schurLds[];
     if (P.ctl[kCtlHalt]) return;
     const int i1 = blockIdx.x, chunk = blockIdx.y, t = threadIdx.x;
@@ -1195,7 +1216,10 @@ __global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P) {
     const int beg = P.camStart[i1], end = P.camStart[i1 + 1];
     const int per = (end - beg + P.chunks - 1) / P.chunks;
     const int b0 = min(beg + chunk * per, end), total = min(per, end - b0);
-    const double lambda = P.lm[0];
+    // first trial of an optimize() call: lambda_0 from the maximum the linearisation just accumulated; workgroup (0,0)
+    // publishes it for the kernels that follow in the stream
+    const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
+    if (first && i1 == 0 && chunk == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
     double acc[kSchurMaxOut];
 #pragma unroll
     for (int o = 0; o < kSchurMaxOut; o++) acc[o] = 0;
@@ -2265,9 +2289,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         if (solveInLds && !solveTiles) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
         const size_t schurLds = schur_lds_bytes(nF);
         if (nF) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
-        auto enqueue_trial = [&](int bulk) {
+        auto enqueue_trial = [&](int bulk, bool firstTrial = false) {
             if (nF) {
-                hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(kSchurThreads), schurLds, s, D);
+                hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(kSchurThreads), schurLds, s, D, firstTrial ? 1 : 0);
                 if (solveTiles) hipLaunchKernelGGL(k_ba_reduce_tiles, dim3(tg.nTiles), dim3(256), 0, s, D);
                 else hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, D);
             }
@@ -2291,9 +2315,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
                 needErrors = false;
             }
             for (int it = done; it < iterations; it++) {
-                hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks);
-                if (it == 0) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);
-                enqueue_trial(1);
+                hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0);
+                if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);   // no Schur kernel to do it
+                enqueue_trial(1, it == 0 && nF);
             }
             EAO_HIP(hipStreamSynchronize(s));
             const BAStatus& S = *c.status;
