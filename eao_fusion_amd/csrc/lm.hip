@@ -915,15 +915,17 @@ struct BADev {
     int chunks;
 };
 
-enum { kCtlHalt = 0, kCtlCur = 1, kCtlIters = 2, kCtlStatus = 3, kCtlNBad = 4 };
-enum { kStRunning = 0, kStTakeover = 1, kStTerminate = 2 };
+enum { kCtlHalt = 0, kCtlCur = 1, kCtlIters = 2, kCtlStatus = 3, kCtlNBad = 4, kCtlPhase = 5, kCtlAnyActive = 6 };   // phase: 0 / 1 = first / second optimize()
+enum { kStRunning = 0, kStTakeover = 1, kStTerminate = 2, kStEmpty = 3 };   // empty: no level-0 edge left (g2o's optimize() returns -1)
 
+struct BAPhase { double lambda, rho, chi; int accepted, cur, iters, status, nBad, touched; };
 struct BAStatus {            // pinned host memory, written by k_ba_decide / k_ba_chi_init
     double lambda, rho, chi, tempChi;
     int accepted, solveOk, seq, cur;
     int iters, status, nBad, ntrace;
-    double trLambda[32], trChi[32];
+    double trLambda[32], trChi[32];   // [16 * phase + iteration]
     int trTrials[32];
+    BAPhase ph[2];           // where each optimize() stood after its last decision (both calls may run in ONE enqueue)
 };
 
 __device__ __forceinline__ const SE3* cur_cams(const BADev& P) { return P.camsBuf[P.ctl[kCtlCur]]; }
@@ -1021,12 +1023,24 @@ __device__ inline double ordered_sum(const double* part, int n, double* red, dou
 __global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int seq) {
     __shared__ double red[4], out1;
     if (P.ctl[kCtlHalt]) return;
+    if (P.ctl[kCtlPhase] == 1 && !P.ctl[kCtlAnyActive]) {   // initializeOptimization(0) found nothing: optimize() returns -1
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            P.ctl[kCtlHalt] = 1; P.ctl[kCtlStatus] = kStEmpty;
+            st->ph[1].status = kStEmpty; st->ph[1].iters = 0; st->ph[1].cur = P.ctl[kCtlCur]; st->ph[1].chi = 0; st->ph[1].touched = 1;
+            st->status = kStEmpty; st->seq = seq;
+        }
+        return;
+    }
     const double chi = ordered_sum(P.partChi, P.nL, red, &out1);
     if (threadIdx.x == 0) {
         P.lm[2] = chi;
         P.lm[3] = 0;          // max |diagonal| accumulator of the first linearisation (lambda_0)
         st->chi = chi; st->tempChi = chi; st->accepted = 1; st->solveOk = 1; st->rho = 0; st->lambda = P.lm[0];
         st->cur = P.ctl[kCtlCur];
+        BAPhase& ph = st->ph[P.ctl[kCtlPhase] & 1];
+        ph.chi = chi; ph.cur = P.ctl[kCtlCur]; ph.iters = P.ctl[kCtlIters]; ph.status = kStRunning; ph.nBad = P.ctl[kCtlNBad]; ph.accepted = 1;
+        ph.rho = 0; ph.touched = 1;
         __threadfence_system();
         st->seq = seq;
     }
@@ -1789,7 +1803,8 @@ __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BASta
         if (bulk) {
             if (accepted) {
                 const int k = P.ctl[kCtlIters];
-                if (k < 32) { st->trLambda[k] = P.lm[0]; st->trChi[k] = tempChi; st->trTrials[k] = 1; }
+                const int slot = 16 * (P.ctl[kCtlPhase] & 1) + k;
+                if (k < 16) { st->trLambda[slot] = P.lm[0]; st->trChi[slot] = tempChi; st->trTrials[slot] = 1; }
                 P.ctl[kCtlIters] = k + 1;
                 int nb = P.ctl[kCtlNBad];
                 if ((currentChi - tempChi) * 1e3 < currentChi) nb++; else nb = 0;
@@ -1803,6 +1818,9 @@ __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BASta
         }
         st->lambda = P.lm[0]; st->rho = rho; st->chi = P.lm[2]; st->tempChi = tempChi; st->accepted = accepted; st->solveOk = ok2;
         st->cur = P.ctl[kCtlCur]; st->iters = P.ctl[kCtlIters]; st->status = status; st->nBad = P.ctl[kCtlNBad];
+        BAPhase& ph = st->ph[P.ctl[kCtlPhase] & 1];
+        ph.lambda = P.lm[0]; ph.rho = rho; ph.chi = P.lm[2]; ph.accepted = accepted; ph.cur = P.ctl[kCtlCur]; ph.iters = P.ctl[kCtlIters];
+        ph.status = status; ph.nBad = P.ctl[kCtlNBad]; ph.touched = 1;
         st->seq = seq;
     }
 }
@@ -1885,6 +1903,8 @@ __global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, 
 __global__ void k_ba_classify(BADev P, unsigned char* out, int nEdges, int update) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nEdges) return;
+    // enqueued speculatively behind the first optimize(): a pending host takeover freezes the rest of the stream
+    if (update && P.ctl[kCtlStatus] == kStTakeover) return;
     const unsigned char fl = P.eflag[e];
     const bool stereo = fl & 1;
     const double c2 = ba_chi2(&P.err[3 * e], P.info[e], stereo);
@@ -1893,10 +1913,12 @@ __global__ void k_ba_classify(BADev P, unsigned char* out, int nEdges, int updat
     const unsigned char bad = (c2 > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) ? 1 : 0;
     out[e] = bad;
     if (update) {
-        if (e == 0) {   // fresh control block for the second optimize() (the current-buffer index carries over)
-            P.ctl[kCtlHalt] = 0; P.ctl[kCtlIters] = 0; P.ctl[kCtlStatus] = kStRunning; P.ctl[kCtlNBad] = 0;
+        if (e == 0) {   // fresh control block for the second optimize() (the current-buffer index carries over); a first
+                        // call that stopped early ("3 bad iterations") left the halt flag up -- it ends here
+            P.ctl[kCtlHalt] = 0; P.ctl[kCtlIters] = 0; P.ctl[kCtlNBad] = 0; P.ctl[kCtlPhase] = 1;
         }
         P.eflag[e] = (unsigned char)((fl | (bad ? 2 : 0)) & ~4);
+        if (!bad && !(fl & 2)) P.ctl[kCtlAnyActive] = 1;     // somebody survives: the second optimize() has something to do
         const int l = P.ptIdx[P.ept[e]], ci = P.camIdx[P.ecam[e]];
         if (bad && l >= 0 && ci >= 0) P.table[(size_t)l * P.nFree + ci] = -1;
     }
@@ -2260,7 +2282,8 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     // ---- SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve per iteration.
     // Iterations are enqueued in bulk (one trial each, no host round trip); the device finishes clean iterations itself
     // and halts the stream on anything else, which the host then replays trial by trial like g2o's do/while.
-    auto optimize = [&](int iterations, int* itersDone, double* chiOut) -> eao_status {
+    // resume: the first bulk segment of this call was already enqueued (and has finished) -- start from its outcome
+    auto optimize = [&](int phase, int iterations, int* itersDone, double* chiOut, const BAPhase* resume) -> eao_status {
         *itersDone = 0;
         const int nF = D.nFree, nL = D.nL;
         if (nF + nL == 0) return EAO_OK;   // "_ivMap.size() == 0": nothing to optimise
@@ -2302,30 +2325,39 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
             if (nL) hipLaunchKernelGGL(k_ba_backsub, dim3(ptBlocks), dim3(256), 0, s, D);
             hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq, bulk);
         };
-        bool needErrors = true, ok = true;
-        double currentChi = 0;
-        int nBad = 0, done = 0;
-        while (done < iterations && !(stop && *stop) && ok) {
-            // ---- bulk segment: every remaining iteration, one trial each.  The control block is clean at the start of an
-            //      optimize() call (zeros from the upload / reset by the outlier pass); after a takeover it is rewritten.
-            if (done > 0 && (st = set_ctl(0, done, nBad))) return st;
-            if (needErrors) {   // computeActiveErrors + activeRobustChi2 (otherwise the accepted trial already left them)
+        auto enqueue_bulk = [&](int from, int to, bool withErrors) {
+            if (withErrors) {   // computeActiveErrors + activeRobustChi2 (otherwise the accepted trial already left them)
                 if (nL) hipLaunchKernelGGL(k_ba_errors, dim3(ptBlocks), dim3(256), 0, s, D);
                 hipLaunchKernelGGL(k_ba_chi_init, dim3(1), dim3(256), 0, s, D, c.status, ++seq);
-                needErrors = false;
             }
-            for (int it = done; it < iterations; it++) {
+            for (int it = from; it < to; it++) {
                 hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0);
                 if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);   // no Schur kernel to do it
                 enqueue_trial(1, it == 0 && nF);
             }
-            EAO_HIP(hipStreamSynchronize(s));
-            const BAStatus& S = *c.status;
-            for (int k = done; k < S.iters && k < 32; k++) {
-                g_trace.lambda.push_back(S.trLambda[k]); g_trace.chi2.push_back(S.trChi[k]); g_trace.trials.push_back(S.trTrials[k]);
+        };
+        if (phase < 0) { enqueue_bulk(0, iterations, true); return EAO_OK; }   // enqueue only (speculative chaining)
+        bool needErrors = true, ok = true;
+        double currentChi = 0;
+        int nBad = 0, done = 0;
+        while (done < iterations && !(stop && *stop && !resume) && ok) {
+            if (!resume) {
+                // ---- bulk segment: every remaining iteration, one trial each.  The control block is clean at the start of
+                //      an optimize() call (zeros from the upload / reset by the outlier pass); after a takeover it is rewritten.
+                if (done > 0 && (st = set_ctl(0, done, nBad))) return st;
+                enqueue_bulk(done, iterations, needErrors);
+                needErrors = false;
+                EAO_HIP(hipStreamSynchronize(s));
+            }
+            const BAPhase S = resume ? *resume : c.status->ph[phase];
+            resume = nullptr;
+            for (int k = done; k < S.iters && k < 16; k++) {
+                g_trace.lambda.push_back(c.status->trLambda[16 * phase + k]); g_trace.chi2.push_back(c.status->trChi[16 * phase + k]);
+                g_trace.trials.push_back(c.status->trTrials[16 * phase + k]);
             }
             g_trace.linearizations += S.iters - done;
             done = S.iters; nBad = S.nBad; curHost = S.cur; currentChi = S.chi;
+            if (S.status == kStEmpty) { done = -1; break; }
             if (S.status == kStTerminate) { ok = false; break; }
             if (S.status != kStTakeover) break;           // all requested iterations done
             // ---- host takeover of iteration `done`: its first trial was rejected (or rho == 0 / NaN)
@@ -2353,16 +2385,41 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         *chiOut = currentChi;
         return EAO_OK;
     };
-    if ((st = optimize(p->its_first, &r->iters[0], &r->chi2[0]))) return st;
-    const bool doMore = !(stop && *stop);
+    // Both optimize() calls of the reference, the outlier pass between them and the result copy go into the stream in ONE
+    // enqueue; the host synchronises once.  A rejected LM trial freezes the stream behind it (halt flag + the takeover
+    // check of the outlier pass), and the host then continues from where the device stopped, call by call as before.
+    // The abort flag is read before and after: the whole call takes less time than one g2o iteration on the CPU.
+    c.status->ph[0].touched = c.status->ph[1].touched = 0;
+    const bool chained = E > 0 && (D.nFree + D.nL) > 0;
+    if (chained) {
+        int dummyI; double dummyD;
+        if ((st = optimize(-1, p->its_first, &dummyI, &dummyD, nullptr))) return st;
+        hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
+        if ((st = optimize(-1, p->its_second, &dummyI, &dummyD, nullptr))) return st;
+        hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(E, nP * 3), nC), 256)), dim3(256), 0, s, D, outCams, outPts, outCls);
+        EAO_HIP(hipStreamSynchronize(s));
+    }
+    const BAPhase A = c.status->ph[0], B = c.status->ph[1];
+    if ((st = optimize(0, p->its_first, &r->iters[0], &r->chi2[0], chained ? &A : nullptr))) return st;
+    const bool firstClean = chained && A.status != kStTakeover;
+    const bool doMore = firstClean || !(stop && *stop);
+    bool redo = !chained;
     if (doMore && E) {
         // outlier pass (src/Optimizer.cc:978-1008): chi2 of the residual each edge last computed + depth test.  g2o's
         // initializeOptimization(0) would now drop the level-1 edges (and vertices left without edges) from the active
         // set; here they stay in the lists with zero weight, which leaves every sum -- and a vertex without edges --
         // unchanged, and saves the host round trip of rebuilding and re-uploading the structure.
-        hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
-        if ((st = optimize(p->its_second, &r->iters[1], &r->chi2[1]))) return st;
+        if (firstClean) {
+            if (B.status == kStTakeover) redo = true;
+            if ((st = optimize(1, p->its_second, &r->iters[1], &r->chi2[1], &B))) return st;
+        } else {
+            redo = true;
+            if ((st = set_ctl(0, 0, 0))) return st;            // the frozen stream left "takeover" in the control block
+            hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
+            if ((st = optimize(1, p->its_second, &r->iters[1], &r->chi2[1], nullptr))) return st;
+        }
     }
+    if (redo)
     hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(E, nP * 3), nC), 256)), dim3(256), 0, s, D, outCams, outPts, outCls);
     EAO_HIP(hipEventRecord(c.ev1, s));
     EAO_HIP(hipStreamSynchronize(s));

@@ -68,7 +68,8 @@ def _rot(rx, ry, rz):
     return Rz @ Ry @ Rx
 
 
-def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_frac=0.05, mono_frac=0.0):
+def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_frac=0.05, mono_frac=0.0,
+             rot_noise_deg=0.5, trans_noise=0.01, point_noise=0.02):
     """Local-BA window.  Cameras on a 1 m arc facing a common volume; ids 0..n_fixed-1 fixed.
     Point i is observed by m_i = 2 + (i mod 7) cameras (i*7919 + j) mod n_cams.
     Returns a dict of float32/int32 arrays shaped as the C-ABI wants them (eao_ba_problem):
@@ -121,10 +122,10 @@ def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_
     fixed[:n_fixed] = 1
     poses_init = poses.copy()
     for c in range(n_fixed, n_cams):
-        d = _rot(*(rng.normal(0, np.deg2rad(0.5), 3)))
+        d = _rot(*(rng.normal(0, np.deg2rad(rot_noise_deg), 3)))
         poses_init[c, :3, :3] = d @ poses[c, :3, :3]
-        poses_init[c, :3, 3] = d @ poses[c, :3, 3] + rng.normal(0, 0.01, 3)
-    pts_init = pts + rng.normal(0, 0.02, size=pts.shape)
+        poses_init[c, :3, 3] = d @ poses[c, :3, 3] + rng.normal(0, trans_noise, 3)
+    pts_init = pts + rng.normal(0, point_noise, size=pts.shape)
     return dict(
         poses=poses_init.astype(np.float32), fixed=fixed, points=pts_init.astype(np.float32),
         edge_point=e_pt, edge_cam=e_cam, obs=obs.astype(np.float32), inv_sigma2=inv_sigma2,

@@ -17,7 +17,7 @@ def gpu():
     return E
 
 
-def _check_trace(r, o):
+def _check_trace(r, o, rel=1e-6):
     """LM control flow must match wherever it is well-conditioned: once chi2 stalls at the float32 noise floor
     (relative improvement < 1e-6) rho = (chi_old - chi_new)/scale is rounding noise and accept/reject is a coin flip
     in ANY implementation, so only the well-conditioned prefix of each optimize() call is compared."""
@@ -30,7 +30,7 @@ def _check_trace(r, o):
         if stalled or c < 1e-6:
             break
         assert tg["trials"][k] == to["trials"][k], "trials differ at LM iteration %d" % k
-        assert tg["chi2"][k] == pytest.approx(c, rel=1e-6), "chi2 differs at LM iteration %d" % k
+        assert tg["chi2"][k] == pytest.approx(c, rel=rel), "chi2 differs at LM iteration %d" % k
         assert tg["lam"][k] == pytest.approx(to["lam"][k], rel=2e-3), "lambda differs at LM iteration %d" % k
         prev = c
 
@@ -62,6 +62,24 @@ def test_local_ba_parity(gpu, oracle, kw):
     assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
     f = p["fixed"].astype(bool)
     assert np.array_equal(r["poses"][f], o["poses"][f])
+
+
+@pytest.mark.parametrize("seed", [3030, 3031, 3034, 3035, 3043, 3044, 3046, 3049, 3051, 3052, 3054, 3057])
+def test_local_ba_rejected_trials(gpu, oracle, seed):
+    """Far-off starts (25 degrees, 0.8 m, 1 m on the points): LM trials get rejected in the first and / or the second
+    optimize() -- the stream freezes and the host replays the iteration trial by trial (up to the 10-trial limit) -- and
+    in some windows every edge ends up an outlier, so the second optimize() has nothing to do (g2o returns -1).  Two fixed
+    cameras keep the scale observable: with one, the damped system is singular along the gauge and no two
+    implementations agree on the step.  (Seeds whose first iterations are chaotic -- points flipping behind cameras, chi2
+    around 1e6 -- amplify rounding beyond any tolerance; 3040, 3045 and 3059 are such cases and are left out.)"""
+    p = synth.synth_ba(n_free=5, n_fixed=2, n_points=200, seed=seed, rot_noise_deg=25, trans_noise=0.8, point_noise=1.0, mono_frac=0.7)
+    r = gpu.Optimizer.LocalBundleAdjustment(p)
+    o = oracle.local_ba(p)
+    assert list(r["iters"]) == list(o["iters"])
+    _check_trace(r, o, rel=1e-4)      # monocular-only windows this far from the optimum are ill-conditioned: rounding differences grow
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
 
 
 def test_local_ba_abort_flag(gpu):
