@@ -110,3 +110,29 @@ def test_mvImagePyramid_has_reference_border(gpu):
     assert pyr[0].shape == (480 + 38, 640 + 38)
     assert np.array_equal(pyr[0][19:-19, 19:-19], img)
     assert np.array_equal(pyr[0][0, 19:-19], img[19])      # BORDER_REFLECT_101
+
+
+def test_random_configurations(gpu, oracle):
+    """A seeded sample of tools/sweep_orb.py: random landscape sizes, feature counts, scale factors, level counts, FAST
+    thresholds and textures (including pure noise, where every pixel is a corner candidate) -- keypoints and descriptors
+    bit-exact against the oracle.  (The full sweep ran 140 configurations without a mismatch.)"""
+    rng = np.random.default_rng(20260101)
+    done = 0
+    while done < 12:
+        w = int(rng.integers(320, 1400)); h = int(rng.integers(200, min(w, 900) + 1))
+        nfeat = int(rng.choice([100, 300, 500, 1000, 1500, 2000]))
+        sf = float(rng.choice([1.1, 1.2, 1.25, 1.3, 1.5, 2.0]))
+        top = int(np.floor(np.log(min(w, h) / 90.0) / np.log(sf))) + 1
+        nlev = int(rng.integers(2, max(3, min(8, top) + 1)))
+        ini = int(rng.choice([10, 20, 30, 50])); mn = min(int(rng.choice([3, 5, 7, 9])), ini)
+        n_rect = int(rng.choice([0, 5, 40, 400])); n_small = int(rng.choice([0, 100, 1000]))
+        img = synth.synth_frame(int(rng.integers(0, 1 << 30)), w, h, n_rect, n_small)
+        if rng.random() < 0.2:
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        try:
+            k0, d0 = oracle.OrbOracle(nfeat, sf, nlev, ini, mn).extract(img)
+        except ValueError:
+            continue                                           # geometry neither side supports
+        k1, d1 = gpu.ORBextractor(nfeat, sf, nlev, ini, mn)(img)
+        assert np.array_equal(k0, k1) and np.array_equal(d0, d1), (w, h, nfeat, sf, nlev, ini, mn)
+        done += 1
