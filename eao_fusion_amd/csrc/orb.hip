@@ -211,7 +211,8 @@ __device__ __forceinline__ bool fast_quick_pass(const uint8_t* p, int t) {
 //   3. 3x3 strict NMS of the listed corners against the score map (blind across the cell seam, like upstream's
 //      per-cell cv::FAST calls); kept corners leave in row-major order through a ballot scan
 __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, const CellDesc* __restrict__ cells, ImgSrc s,
-                                                   unsigned* __restrict__ cellcand, int* __restrict__ cellcnt, int f0) {
+                                                   unsigned* __restrict__ cellcand, int* __restrict__ cellcnt, int f0, int cellFirst,
+                                                   int cellEnd) {
     extern __shared__ __align__(16) uint8_t fsm[];
     const int lane = threadIdx.x;
     // Workgroup -> cell placement.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), so with
@@ -226,8 +227,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
         const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
         cell = ((bslot / kFastXcdRun) * 8 + xcd) * kFastXcdRun + bslot % kFastXcdRun;
     }
+    cell += cellFirst;                                  // the launch covers cells [cellFirst, cellEnd)
     const int f = blockIdx.y + f0;
-    if (cell >= g->totalCells) return;
+    if (cell >= cellEnd) return;
     const CellDesc c = cells[cell];
     const int maxT = g->fastMaxTested;                 // max tested pixels of any cell
     uint8_t* tile = fsm;                                // fastTileBytes
@@ -819,7 +821,7 @@ struct eao_orb {
     // (EAO_ORB_LANES, default 1: see the measurement note at enqueue())
     static constexpr int kLanes = 4;
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
-    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {};
+    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
     eao::DevBuf<int> d_tab;
@@ -988,6 +990,7 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
             EAO_HIP(hipStreamCreateWithFlags(&h->laneMain[i], hipStreamNonBlocking));
             EAO_HIP(hipStreamCreateWithFlags(&h->laneSide[i], hipStreamNonBlocking));
             EAO_HIP(hipEventCreateWithFlags(&h->evFork[i], hipEventDisableTiming));
+            EAO_HIP(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evDone[i], hipEventDisableTiming));
         }
@@ -1044,6 +1047,20 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         hipStream_t ms = h->laneMain[i], ss = h->laneSide[i];
         const bool pe = prof && i == 0;
         EAO_HIP(hipStreamWaitEvent(ms, h->evStart, 0));
+        // Level 0 IS the input image: its FAST cells (a third of all cells) do not wait for the pyramid.  Outside profiling
+        // runs they start on the side stream at once and overlap the seven resize launches; the side stream then goes on
+        // with the blur as before.  (Profiling runs keep the stages sequential so that each is timed alone.)
+        const int cells0 = g.L[0].nCells;
+        const bool early0 = !prof && g.nlevels > 1 && g.L[0].cellBase == 0 && cells0 < g.totalCells;
+        auto fast = [&](hipStream_t str, int first, int end) {
+            hipLaunchKernelGGL(k_fast_cells, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
+                               h->d_cellcand.p, h->d_cellcnt.p, f0, first, end);
+        };
+        if (early0) {
+            EAO_HIP(hipStreamWaitEvent(ss, h->evStart, 0));
+            fast(ss, 0, cells0);
+            EAO_HIP(hipEventRecord(h->evFast0[i], ss));
+        }
         for (int l = 1; l < g.nlevels; l++) {
             dim3 grid(eao::cdiv(g.L[l].w, 256), eao::cdiv(g.L[l].h, 4), nb), block(64, 4);
             hipLaunchKernelGGL(k_resize, grid, block, 0, ms, h->d_geom.p, h->d_tab.p, s, l, f0);
@@ -1055,8 +1072,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0);
         if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
         EAO_HIP(hipEventRecord(h->evJoin[i], ss));
-        hipLaunchKernelGGL(k_fast_cells, dim3(128 * ((g.totalCells + 127) / 128), nb), dim3(64), g.fastLdsBytes, ms, h->d_geom.p, h->d_cells.p, s,
-                           h->d_cellcand.p, h->d_cellcnt.p, f0);
+        if (early0) {
+            fast(ms, cells0, g.totalCells);
+            EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
+        } else {
+            fast(ms, 0, g.totalCells);
+        }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
         hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nb), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
                            h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0);
@@ -1162,6 +1183,7 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->laneMain[i]) { (void)hipStreamSynchronize(h->laneMain[i]); (void)hipStreamDestroy(h->laneMain[i]); }
         if (h->laneSide[i]) { (void)hipStreamSynchronize(h->laneSide[i]); (void)hipStreamDestroy(h->laneSide[i]); }
         if (h->evFork[i]) (void)hipEventDestroy(h->evFork[i]);
+        if (h->evFast0[i]) (void)hipEventDestroy(h->evFast0[i]);
         if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
