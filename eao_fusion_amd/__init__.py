@@ -6,5 +6,5 @@ libeaofusion_hip.so (hand-written HIP kernels for gfx950) through the C-ABI in i
 """
 from ._lib import EaoError, load  # noqa: F401
 from .orb import KP_DTYPE, ORBextractor  # noqa: F401
-from .matcher import ORBmatcher, hamming_best2, hamming_matrix  # noqa: F401
+from .matcher import ORBmatcher, distinctive_descriptors, hamming_best2, hamming_matrix  # noqa: F401
 from .optimizer import Optimizer  # noqa: F401

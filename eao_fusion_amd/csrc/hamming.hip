@@ -93,6 +93,65 @@ thread_local Scratch g_scr;
 
 }  // namespace
 
+namespace {
+
+// One wavefront per (set, row): the row's Hamming distances to every member of its set (itself included) go into a
+// 257-bin LDS histogram (LDS atomics: counts do not depend on the order), the median is the bin where the running count
+// passes (int)(0.5 (N - 1)), and the set's winner is an atomicMin over (median << 20 | row): least median, first row.
+__global__ __launch_bounds__(256) void k_distinct_rows(const uint4* __restrict__ desc, const int* __restrict__ setStart,
+                                                       const int* __restrict__ rowSet, int total, unsigned* __restrict__ key) {
+    __shared__ unsigned hist[4][264];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    unsigned* h = hist[wv];
+    for (int b = lane; b < 264; b += 64) h[b] = 0;
+    __syncthreads();
+    const bool live = row < total;
+    const int s = live ? rowSet[row] : 0;
+    const int beg = setStart[s], end = setStart[s + 1], N = end - beg;
+    if (live) {
+        const uint4 a0 = desc[2 * row], a1 = desc[2 * row + 1];
+        for (int j = beg + lane; j < end; j += 64) {
+            const uint4 b0 = desc[2 * j], b1 = desc[2 * j + 1];
+            const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                          __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+            atomicAdd(&h[d], 1u);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const int k = (int)(0.5 * (N - 1));      // index of the median in the sorted row (src/MapPoint.cc:294)
+        // exclusive prefix over the 257 bins, five bins per lane (lanes own consecutive bins)
+        unsigned mine[5], run = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) { const int b = lane * 5 + q; mine[q] = b < 257 ? h[b] : 0; run += mine[q]; }
+        unsigned incl = run;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) { const unsigned o = __shfl_up(incl, dlt); if (lane >= dlt) incl += o; }
+        unsigned before = incl - run;
+        int med = 0x7FFFFFFF;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            if (med == 0x7FFFFFFF && mine[q] && before + mine[q] > (unsigned)k) med = lane * 5 + q;
+            before += mine[q];
+        }
+        // the lane holding the smallest qualifying bin
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) med = min(med, __shfl_down(med, dlt));
+        if (lane == 0) atomicMin(&key[s], ((unsigned)med << 20) | (unsigned)(row - beg));
+    }
+}
+
+struct DistinctScratch {
+    hipStream_t stream = nullptr;
+    eao::DevBuf<int> start, rowset;
+    eao::DevBuf<unsigned char> desc;
+    eao::DevBuf<unsigned> key;
+    ~DistinctScratch() { if (stream) (void)hipStreamDestroy(stream); }
+};
+thread_local DistinctScratch g_distinct;
+
+}  // namespace
+
 extern "C" {
 
 eao_status eao_hamming_matrix_device(const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb, int32_t pairs,
@@ -153,6 +212,40 @@ eao_status eao_hamming_best2(const uint8_t* A, int32_t na, const uint8_t* B, int
     }
     if ((st = eao_hamming_best2_device(s.a.p, na, s.b.p, nb, 1, dm, s.best.p, nullptr))) return st;
     EAO_HIP(hipMemcpy(out, s.best.p, (size_t)na * sizeof(eao_best2), hipMemcpyDeviceToHost));
+    return EAO_OK;
+}
+
+
+/* MapPoint::ComputeDistinctiveDescriptors, batched (see include/eao_fusion.h) */
+eao_status eao_distinctive_descriptors(int32_t n_sets, const int32_t* set_start, const uint8_t* desc, int32_t* best) {
+    EAO_REQUIRE(n_sets >= 0 && (n_sets == 0 || (set_start && best)), "null argument");
+    eao_status st = eao::require_device();
+    if (st) return st;
+    if (n_sets == 0) return EAO_OK;
+    const int total = set_start[n_sets];
+    EAO_REQUIRE(set_start[0] == 0 && total >= 0 && (total == 0 || desc), "bad set table");
+    for (int s2 = 0; s2 < n_sets; s2++) EAO_REQUIRE(set_start[s2 + 1] >= set_start[s2], "set table not ascending");
+    DistinctScratch& c = g_distinct;
+    if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if ((st = c.start.reserve((size_t)n_sets + 1))) return st;
+    if ((st = c.desc.reserve(std::max((size_t)total, (size_t)1) * 32))) return st;
+    if ((st = c.rowset.reserve(std::max(total, 1)))) return st;
+    if ((st = c.key.reserve(n_sets))) return st;
+    std::vector<int> rowset(std::max(total, 1));
+    for (int s2 = 0; s2 < n_sets; s2++)
+        for (int k = set_start[s2]; k < set_start[s2 + 1]; k++) rowset[k] = s2;
+    EAO_HIP(hipMemcpyAsync(c.start.p, set_start, ((size_t)n_sets + 1) * sizeof(int), hipMemcpyHostToDevice, c.stream));
+    if (total) {
+        EAO_HIP(hipMemcpyAsync(c.desc.p, desc, (size_t)total * 32, hipMemcpyHostToDevice, c.stream));
+        EAO_HIP(hipMemcpyAsync(c.rowset.p, rowset.data(), (size_t)total * sizeof(int), hipMemcpyHostToDevice, c.stream));
+    }
+    EAO_HIP(hipMemsetAsync(c.key.p, 0xFF, (size_t)n_sets * sizeof(unsigned), c.stream));
+    if (total) hipLaunchKernelGGL(k_distinct_rows, dim3(eao::cdiv(total, 4)), dim3(256), 0, c.stream, (const uint4*)c.desc.p, c.start.p, c.rowset.p, total, c.key.p);
+    std::vector<unsigned> key(n_sets);
+    EAO_HIP(hipMemcpyAsync(key.data(), c.key.p, (size_t)n_sets * sizeof(unsigned), hipMemcpyDeviceToHost, c.stream));
+    EAO_HIP(hipStreamSynchronize(c.stream));
+    EAO_HIP(hipGetLastError());
+    for (int s2 = 0; s2 < n_sets; s2++) best[s2] = key[s2] == 0xFFFFFFFFu ? -1 : (int)(key[s2] & 0xFFFFF);
     return EAO_OK;
 }
 

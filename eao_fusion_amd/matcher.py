@@ -28,6 +28,19 @@ def hamming_best2(A, B, mask=None):
     return out
 
 
+def distinctive_descriptors(sets):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307) for a batch of map points: `sets` is a list of
+    (N_s, 32) uint8 arrays (the descriptors of the keyframes observing each point).  Returns the index of the chosen
+    descriptor inside each set (-1 for an empty set)."""
+    start = np.zeros(len(sets) + 1, np.int32)
+    for i, d in enumerate(sets):
+        start[i + 1] = start[i] + len(d)
+    desc = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint8).reshape(-1, 32) for d in sets]) if len(sets) else np.zeros((0, 32), np.uint8))
+    best = np.full(len(sets), -1, np.int32)
+    _lib.check(_lib.load().eao_distinctive_descriptors(len(sets), _lib.ptr(start), _lib.ptr(desc), _lib.ptr(best)))
+    return best
+
+
 class ORBmatcher:
     TH_LOW = 50
     TH_HIGH = 100

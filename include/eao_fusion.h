@@ -264,6 +264,13 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
                               const float* T2w, const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12,
                               const float* R12, const float* t12, float th, int32_t* match12, int32_t* nfound);
 
+/* f4  MapPoint::ComputeDistinctiveDescriptors() -- src/MapPoint.cc:242-307, batched over map points.  Set s holds the
+ * descriptors of the (non-bad) keyframes observing point s, in std::map<KeyFrame*, size_t> iteration order:
+ * desc[32 * k] for set_start[s] <= k < set_start[s + 1].  best[s] receives the position inside the set of the descriptor
+ * with the least median Hamming distance to the others (median = sorted[(int)(0.5 * (N - 1))], the distance to itself
+ * included; first index wins ties), or -1 for an empty set. */
+eao_status eao_distinctive_descriptors(int32_t n_sets, const int32_t* set_start, const uint8_t* desc, int32_t* best);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimizer::PoseOptimization(Frame*) -- reference include/Optimizer.h:56, src/Optimizer.cc:325-673
  * (point / stereo edges and the plane edges of src/Optimizer.cc:456-535)

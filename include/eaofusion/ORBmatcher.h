@@ -358,6 +358,29 @@ public:
         return nf;
     }
 
+    // reference src/MapPoint.cc:242-307 (MapPoint::ComputeDistinctiveDescriptors), for one map point or a batch: returns,
+    // per point, the row of `descriptors[s]` (the observing keyframes' descriptors in std::map order, bad keyframes
+    // skipped) with the least median distance to the rest, or -1 for an empty set.  The body of
+    // MapPoint::ComputeDistinctiveDescriptors becomes: gather vDescriptors as upstream, then
+    //   mDescriptor = vDescriptors[ORBmatcher::DistinctiveDescriptor(vDescriptors)].clone();
+    static std::vector<int> DistinctiveDescriptors(const std::vector<std::vector<cv::Mat> >& descriptors) {
+        std::vector<int32_t> start(descriptors.size() + 1, 0), best(descriptors.size(), -1);
+        std::vector<uint8_t> flat;
+        for (size_t s = 0; s < descriptors.size(); s++) {
+            for (size_t k = 0; k < descriptors[s].size(); k++) {
+                const unsigned char* d = descriptors[s][k].ptr(0);
+                flat.insert(flat.end(), d, d + 32);
+            }
+            start[s + 1] = (int32_t)(flat.size() / 32);
+        }
+        if (!descriptors.empty())
+            check(eao_distinctive_descriptors((int32_t)descriptors.size(), start.data(), flat.data(), best.data()), "eao_distinctive_descriptors");
+        return std::vector<int>(best.begin(), best.end());
+    }
+    static int DistinctiveDescriptor(const std::vector<cv::Mat>& vDescriptors) {
+        return DistinctiveDescriptors(std::vector<std::vector<cv::Mat> >(1, vDescriptors))[0];
+    }
+
     static const int TH_LOW;
     static const int TH_HIGH;
     static const int HISTO_LENGTH;

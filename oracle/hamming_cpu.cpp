@@ -6,6 +6,9 @@
 // Pinned by: exhaustive agreement with __builtin_popcount in tests/test_oracle_hamming.py, plus the
 // all-zero / all-one known answers (0 and 256).  PARITY otherwise UNPINNED (no upstream fixtures exist).
 #include <cstdint>
+#include <vector>
+#include <climits>
+#include <algorithm>
 #include <cstring>
 
 namespace {
@@ -54,4 +57,33 @@ void orc_hamming_best2(const uint8_t* A, int na, const uint8_t* B, int nb, const
     }
 }
 
+
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307) for a batch of map points: per set the N x N distance
+// table, each row sorted, median = sorted[(int)(0.5 * (N - 1))], least median wins (strict <, so the first index).
+void orc_distinctive_descriptors(int n_sets, const int32_t* set_start, const uint8_t* desc, int32_t* best) {
+    for (int s = 0; s < n_sets; s++) {
+        const int beg = set_start[s], N = set_start[s + 1] - beg;
+        best[s] = -1;
+        if (N <= 0) continue;
+        std::vector<int> D((size_t)N * N);
+        for (int i = 0; i < N; i++) {
+            D[(size_t)i * N + i] = 0;
+            for (int j = i + 1; j < N; j++) {
+                uint32_t a[8], b[8];
+                std::memcpy(a, desc + 32 * (size_t)(beg + i), 32); std::memcpy(b, desc + 32 * (size_t)(beg + j), 32);
+                int d = 0;
+                for (int w = 0; w < 8; w++) d += __builtin_popcount(a[w] ^ b[w]);
+                D[(size_t)i * N + j] = d; D[(size_t)j * N + i] = d;
+            }
+        }
+        int bestMedian = INT_MAX, bestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            std::vector<int> v(D.begin() + (size_t)i * N, D.begin() + (size_t)(i + 1) * N);
+            std::sort(v.begin(), v.end());
+            const int median = v[(size_t)(0.5 * (N - 1))];
+            if (median < bestMedian) { bestMedian = median; bestIdx = i; }
+        }
+        best[s] = bestIdx;
+    }
+}
 }  // extern "C"

@@ -304,3 +304,15 @@ def search_by_projection_frames(cur, last, th, mono, check_orientation=True):
                                                cur["fx"], cur["fy"], cur["cx"], cur["cy"], cur["mbf"], cur["mb"], th, 1 if mono else 0,
                                                1 if check_orientation else 0, _p(out))
     return nm, out
+
+
+def distinctive_descriptors(sets):
+    start = np.zeros(len(sets) + 1, np.int32)
+    for i, d in enumerate(sets):
+        start[i + 1] = start[i] + len(d)
+    desc = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint8).reshape(-1, 32) for d in sets]) if len(sets) else np.zeros((0, 32), np.uint8))
+    best = np.full(len(sets), -1, np.int32)
+    fn = lib().orc_distinctive_descriptors
+    fn.restype = None
+    fn(C.c_int(len(sets)), C.c_void_p(_p(start)), C.c_void_p(_p(desc)), C.c_void_p(_p(best)))
+    return best

@@ -232,6 +232,16 @@ int main(int argc, char** argv) {
         for (auto& p : store) if (p.replacedBy) replaced++;
         wr(out, &n, 1); wr(out, &replaced, 1); wr(out, &addedN, 1);
     }
+    // 10. MapPoint::ComputeDistinctiveDescriptors over the observations of each map point (K1 and K2 keypoints)
+    {
+        std::vector<std::vector<cv::Mat> > sets(np);
+        for (int k = 0; k < r1.n; k++) if (r1.mp[k] >= 0) sets[r1.mp[k]].push_back(K1.mDescriptors.row(k));
+        for (int k = 0; k < r2.n; k++) if (r2.mp[k] >= 0) sets[r2.mp[k]].push_back(K2.mDescriptors.row(k));
+        sets[0].clear();
+        const std::vector<int> best = ORBmatcher::DistinctiveDescriptors(sets);
+        std::vector<int32_t> b32(best.begin(), best.end());
+        wr(out, b32.data(), b32.size());
+    }
     printf("search_adapter_test ok\n");
     return 0;
 }

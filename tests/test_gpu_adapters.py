@@ -96,6 +96,7 @@ def test_cpp_search_adapters(tmp_path):
     """The remaining ORBmatcher templates (BoW x2, triangulation, initialisation, projection loop / relocalisation, Sim3,
     Fuse x2) over mock KeyFrame / Frame / MapPoint classes must reproduce what the C-ABI returns for the same data."""
     import torch  # noqa: F401
+    import eao_fusion_amd as E
     from eao_fusion_amd import search
     exe = str(tmp_path / "search_adapter_test")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-DEAOFUSION_FORCE_CV_COMPAT", "-I", os.path.join(ROOT, "include"),
@@ -216,3 +217,15 @@ def test_cpp_search_adapters(tmp_path):
             slot[b] = True
             e_add += 1
     assert n == en and added == e_add and replaced == en - e_add and n > 10
+    # 10. ComputeDistinctiveDescriptors: each point observed by (at most) one keypoint of K1 and one of K2
+    tab = take(np.int32, len(act))
+    sets = [[] for _ in range(len(act))]
+    for k, m in enumerate(mp1):
+        if m >= 0:
+            sets[m].append(K1["descriptors"][k])
+    for k, m in enumerate(mp2):
+        if m >= 0:
+            sets[m].append(K2["descriptors"][k])
+    sets[0] = []
+    exp = E.distinctive_descriptors([np.array(x, np.uint8).reshape(-1, 32) for x in sets])
+    assert np.array_equal(tab, exp) and exp[0] == -1

@@ -40,3 +40,17 @@ def test_descriptor_distance_known_answers(gpu):
     m = gpu.ORBmatcher(0.6, True)
     assert m.DescriptorDistance(z, z) == 0 and m.DescriptorDistance(z, o) == 256
     assert (m.TH_LOW, m.TH_HIGH, m.HISTO_LENGTH) == (50, 100, 30)
+
+
+def test_distinctive_descriptors(gpu, oracle):
+    rng = np.random.default_rng(78)
+    sets = []
+    for n in list(rng.integers(0, 40, 300)) + [1, 64, 65, 257, 300]:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = np.tile(base, (int(n), 1))
+        if n:
+            flips = (rng.random((int(n), 256)) < rng.uniform(0.0, 0.3, (int(n), 1))).astype(np.uint8)
+            d = np.packbits(np.unpackbits(d, axis=1) ^ flips, axis=1)
+        sets.append(d)
+    assert np.array_equal(gpu.distinctive_descriptors(sets), oracle.distinctive_descriptors(sets))
+    assert len(gpu.distinctive_descriptors([])) == 0

@@ -40,3 +40,25 @@ def test_matrix_and_best2(oracle):
     assert np.array_equal(b2m[:, 0], Dm.min(axis=1))
     empty = oracle.hamming_best2(a[:3], b, np.zeros((3, 200), np.uint8))
     assert np.array_equal(empty[:, :3], np.array([[256, 256, -1]] * 3))
+
+
+def test_distinctive_descriptors_known_answers(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307) against a numpy re-derivation."""
+    rng = np.random.default_rng(77)
+    sets = []
+    for n in [1, 2, 3, 4, 7, 8, 20, 65, 130, 0]:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = np.tile(base, (n, 1))
+        if n:
+            flips = (rng.random((n, 256)) < rng.uniform(0.02, 0.3, (n, 1))).astype(np.uint8)
+            d = np.packbits(np.unpackbits(d, axis=1) ^ flips, axis=1)
+        sets.append(d)
+    got = oracle.distinctive_descriptors(sets)
+    for d, g in zip(sets, got):
+        n = len(d)
+        if n == 0:
+            assert g == -1
+            continue
+        D = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(axis=2)
+        med = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
+        assert g == int(np.argmin(med))        # argmin returns the first minimum, like the strict '<' upstream
