@@ -1,0 +1,65 @@
+"""Thread safety of the C-ABI as the header states it: every entry point keeps its device workspace per host thread (one
+HIP stream + arena each), an ORB handle belongs to one thread.  Four threads hammer different entry points at once; every
+result must equal the single-threaded one."""
+import threading
+
+import numpy as np
+import pytest
+
+from eao_fusion_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_entry_points():
+    import torch  # noqa: F401
+    import eao_fusion_amd as E
+    from eao_fusion_amd import search
+    assert E.load().eao_device_check() == 0
+    img = synth.synth_frame(1002)
+    ba = synth.synth_ba(n_free=6, n_fixed=2, n_points=400, seed=3100)
+    pose = synth.synth_pose(n=500, seed=4100, n_planes=3)
+    cur, last, mps = synth.synth_tracking(n=600, seed=7100)
+    a, b = synth.synth_descriptors(300, 2100)
+    sc = synth.synth_search_scene(n=300, seed=8300)
+    s1 = dict(descriptors=sc["K1"]["descriptors"], angle=sc["K1"]["kp_angle"], valid=(sc["mp1"] >= 0).astype(np.uint8), fv=sc["fv1"])
+    s2 = dict(descriptors=sc["K2"]["descriptors"], angle=sc["K2"]["kp_angle"], valid=(sc["mp2"] >= 0).astype(np.uint8), fv=sc["fv2"])
+
+    def job_orb():
+        k, d = E.ORBextractor(1000, 1.2, 8, 20, 7)(img)
+        return k.tobytes() + d.tobytes()
+
+    def job_ba():
+        r = E.Optimizer.LocalBundleAdjustment(ba)
+        return r["poses"].tobytes() + r["points"].tobytes() + r["edge_outlier"].tobytes()
+
+    def job_pose():
+        r = E.Optimizer.PoseOptimization(pose)
+        return r["Tcw"].tobytes() + r["outlier"].tobytes() + r["plane_outlier"].tobytes()
+
+    def job_match():
+        m = E.ORBmatcher(0.8, True)
+        n1, m1 = m.SearchByProjectionPoints(cur, mps, 1.0)
+        n2, m2 = m.SearchByProjectionFrames(cur, last, 7.0, False)
+        n3, m3 = search.product().search_by_bow(1, s1, s2, 0.75, True)
+        return m1.tobytes() + m2.tobytes() + m3.tobytes() + E.hamming_best2(a, b).tobytes()
+
+    jobs = [job_orb, job_ba, job_pose, job_match]
+    expect = [j() for j in jobs]
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(6):
+                j = (i + rep) % len(jobs)
+                if jobs[j]() != expect[j]:
+                    errors.append("thread %d: job %s differs on repetition %d" % (i, jobs[j].__name__, rep))
+        except Exception as ex:  # noqa: BLE001
+            errors.append("thread %d: %r" % (i, ex))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
