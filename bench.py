@@ -143,14 +143,8 @@ def main():
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                 "pipeline_GBps": round(sum(stage_bytes.values()) / (stage_ms["total"] * 1e-3) / 1e9, 2)}
 
-    extra = {}
-    cpu_baseline = None
-    if rank == 0:
-        if not args.no_extra:
-            extra = measure_extra(E, synth, torch, dev)
-        if not args.no_cpu_baseline:
-            cpu_baseline, cpu_extra = measure_cpu(frames, synth, extra)
-            extra.update(cpu_extra)
+    # every collective first (all ranks), the rank-0-only measurements afterwards: no rank waits inside RCCL for minutes
+    gathered = {}
     # ---- BASELINE configs[4] (batched sequence), outside the timed region: consecutive-frame matching inside the shard (one
     #      halo frame from the previous rank) and this rank's share of the local-BA windows (window w -> rank w mod N)
     seq = {}
@@ -174,10 +168,18 @@ def main():
     if world > 1:
         # the batched-sequence config gathers every rank's per-frame keypoint counts over RCCL (outside the timed region)
         all_counts = shard.gather_frame_counts(d_n, n_frames, device=dev)
-        extra["allgather_frames"] = int(all_counts.numel())
-        extra["allgather_keypoints"] = int(all_counts.sum().item())
+        gathered = {"allgather_frames": int(all_counts.numel()), "allgather_keypoints": int(all_counts.sum().item())}
         dist.barrier()
         dist.destroy_process_group()
+    extra = {}
+    cpu_baseline = None
+    if rank == 0:
+        if not args.no_extra:
+            extra = measure_extra(E, synth, torch, dev)
+        if not args.no_cpu_baseline:
+            cpu_baseline, cpu_extra = measure_cpu(frames, synth, extra)
+            extra.update(cpu_extra)
+    extra.update(gathered)
     if seq:
         extra["sequence"] = seq
     if rank == 0:
