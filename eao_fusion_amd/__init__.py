@@ -5,6 +5,6 @@ flavour that drops into Tracking.cc / LocalMapping.cc lives in include/eaofusion
 libeaofusion_hip.so (hand-written HIP kernels for gfx950) through the C-ABI in include/eao_fusion.h.
 """
 from ._lib import EaoError, load  # noqa: F401
-from .orb import KP_DTYPE, ORBextractor  # noqa: F401
+from .orb import KP_DTYPE, ORBextractor, compute_stereo_matches  # noqa: F401
 from .matcher import ORBmatcher, distinctive_descriptors, hamming_best2, hamming_matrix  # noqa: F401
 from .optimizer import Optimizer  # noqa: F401

@@ -86,6 +86,7 @@ SYMBOLS = {
     "eao_search_by_projection_sim3": None, "eao_search_by_projection_kf": None, "eao_search_by_bow": None,
     "eao_search_for_triangulation": None, "eao_search_for_initialization": None, "eao_fuse_search": None, "eao_search_by_sim3": None,
     "eao_distinctive_descriptors": (_I, [_I, _P, _P, _P]),
+    "eao_compute_stereo_matches": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, C.c_float, C.c_float, _P, _P]),
     "eao_pose_optimization": (_I, [C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
     "eao_local_ba": (_I, [C.POINTER(BAProblem), _P, C.POINTER(BAResult)]),
     "eao_last_lm_trace": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),

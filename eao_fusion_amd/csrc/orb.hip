@@ -803,6 +803,116 @@ struct GraphKey {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------- stereo matching
+// Frame::ComputeStereoMatches (src/Frame.cc:841-1013): one wavefront per left keypoint.
+//   1. descriptor search over the right keypoints whose row band (kp.y +- 2 scale[octave]) contains the left row, octave
+//      within +-1, uR in [uL - maxD, uL + 3]: best Hamming distance below TH_HIGH, lowest index on ties (upstream walks
+//      its per-row lists in index order);
+//   2. 11x11 L1 patch correlation on the pyramid level of the left keypoint for the 11 shifts incR = -5 .. 5 (both patches
+//      minus their centre pixel: integer arithmetic, exact), parabola through the best shift, disparity, depth.
+// mvImagePyramid's 19-px reflect-101 border is not materialised on the device; the patch reads mirror the coordinate.
+struct StereoArgs {
+    int nl, nr, frame;
+    const eao_keypoint* kl; const eao_keypoint* kr;
+    const uint4* dl; const uint4* dr;
+    const float* scale; const float* invScale;
+    float mb, mbf;
+    float* uRight; float* depth; int* sad;
+};
+__device__ __forceinline__ int px_reflect(const uint8_t* img, int pitch, int w, int h, int x, int y) {
+    x = x < 0 ? -x : (x >= w ? 2 * w - 2 - x : x);
+    y = y < 0 ? -y : (y >= h ? 2 * h - 2 - y : y);
+    return img[(long long)y * pitch + x];
+}
+__global__ __launch_bounds__(256) void k_stereo_match(const Geom* __restrict__ g, ImgSrc sl, ImgSrc sr, StereoArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= A.nl) return;
+    const eao_keypoint kpL = A.kl[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int row = (int)vL;                         // vRowIndices[vL]: float -> index truncation
+    const float minZ = A.mb, minD = -3, maxD = A.mbf / minZ;
+    const float minU = uL - maxD, maxU = uL - minD;
+    float outU = -1.0f, outD = -1.0f;
+    int outS = -1;
+    if (!(maxU < 0)) {
+        const uint4 a0 = A.dl[2 * iL], a1 = A.dl[2 * iL + 1];
+        unsigned best = 0xFFFFFFFFu;                 // (distance << 16 | right index), smallest wins
+        for (int iR = lane; iR < A.nr; iR += 64) {
+            const eao_keypoint kr = A.kr[iR];
+            const float r = 2.0f * A.scale[kr.octave];
+            const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
+            if (row < minr || row > maxr) continue;
+            if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
+            if (!(kr.x >= minU && kr.x <= maxU)) continue;
+            const uint4 b0 = A.dr[2 * iR], b1 = A.dr[2 * iR + 1];
+            const unsigned d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                               __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+            best = min(best, (d << 16) | (unsigned)iR);
+        }
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, dlt));
+        const int bestDist = (int)(best >> 16);
+        if (best != 0xFFFFFFFFu && bestDist < 100) {           // ORBmatcher::TH_HIGH
+            const int bestIdxR = (int)(best & 0xFFFF);
+            const float uR0 = A.kr[bestIdxR].x;
+            const float sf = A.invScale[levelL];
+            const int suL = (int)roundf(uL * sf), svL = (int)roundf(vL * sf), suR0 = (int)roundf(uR0 * sf);
+            const int w = 5, Lw = 5;
+            int pl, pr;
+            const uint8_t* imgL = level_ptr(g, sl, levelL, A.frame, &pl);
+            const uint8_t* imgR = level_ptr(g, sr, levelL, A.frame, &pr);
+            const int lw = g->L[levelL].w, lh = g->L[levelL].h;
+            const float iniu = (float)(suR0 + Lw - w), endu = (float)(suR0 + Lw + w + 1);
+            if (!(iniu < 0 || endu >= (float)lw)) {
+                const int cL = px_reflect(imgL, pl, lw, lh, suL, svL);
+                // this lane's two patch pixels (121 = 64 + 57)
+                int dL0 = 0, dL1 = 0, px0x = 0, px0y = 0, px1x = 0, px1y = 0;
+                const bool has1 = lane + 64 < 121;
+                px0y = lane / 11; px0x = lane - px0y * 11;
+                dL0 = px_reflect(imgL, pl, lw, lh, suL - w + px0x, svL - w + px0y) - cL;
+                if (has1) {
+                    px1y = (lane + 64) / 11; px1x = lane + 64 - px1y * 11;
+                    dL1 = px_reflect(imgL, pl, lw, lh, suL - w + px1x, svL - w + px1y) - cL;
+                }
+                int dists[11];
+                int bestSad = 0x7FFFFFFF, bestinc = 0;
+#pragma unroll
+                for (int inc = -5; inc <= 5; inc++) {
+                    const int cR = px_reflect(imgR, pr, lw, lh, suR0 + inc, svL);
+                    int sacc = abs(dL0 - (px_reflect(imgR, pr, lw, lh, suR0 + inc - w + px0x, svL - w + px0y) - cR));
+                    if (has1) sacc += abs(dL1 - (px_reflect(imgR, pr, lw, lh, suR0 + inc - w + px1x, svL - w + px1y) - cR));
+                    for (int dlt = 32; dlt >= 1; dlt >>= 1) sacc += __shfl_xor(sacc, dlt);
+                    dists[inc + 5] = sacc;
+                    if (sacc < bestSad) { bestSad = sacc; bestinc = inc; }
+                }
+                if (!(bestinc == -Lw || bestinc == Lw)) {
+                    float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+                    for (int k = 0; k < 11; k++) {
+                        if (k == Lw + bestinc - 1) dist1 = (float)dists[k];
+                        if (k == Lw + bestinc) dist2 = (float)dists[k];
+                        if (k == Lw + bestinc + 1) dist3 = (float)dists[k];
+                    }
+                    const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+                    if (!(deltaR < -1 || deltaR > 1)) {
+                        float bestuR = A.scale[levelL] * ((float)suR0 + (float)bestinc + deltaR);
+                        float disparity = uL - bestuR;
+                        if (disparity >= 0 && disparity < maxD) {
+                            if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                            outD = A.mbf / disparity;
+                            outU = bestuR;
+                            outS = bestSad;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { A.uRight[iL] = outU; A.depth[iL] = outD; A.sad[iL] = outS; }
+}
+
 struct eao_orb {
     eao_orb_cfg cfg;
     std::vector<float> scale, invScale, sigma2, invSigma2;
@@ -832,6 +942,7 @@ struct eao_orb {
     eao::DevBuf<eao_keypoint> d_kps;
     eao::DevBuf<uint8_t> d_desc;
     eao::DevBuf<float> d_xyr;
+    eao::DevBuf<unsigned char> d_stereo;   // staging of eao_compute_stereo_matches
     // last call (for stage taps)
     ImgSrc lastSrc{};
     int lastBatch = 0;
@@ -1331,6 +1442,72 @@ eao_status eao_orb_last_timing(eao_orb* h, float ms[6]) {
     }
     for (int i = 0; i < 6; i++) ms[i] = (float)(acc[i] / calls);
     h->evUsed = 0;
+    return EAO_OK;
+}
+
+
+eao_status eao_compute_stereo_matches(eao_orb* left, eao_orb* right, int32_t frame, int32_t nl, const eao_keypoint* kps_l,
+                                      const uint8_t* desc_l, int32_t nr, const eao_keypoint* kps_r, const uint8_t* desc_r,
+                                      float mb, float mbf, float* u_right, float* depth) {
+    EAO_REQUIRE(left && right && left->geomValid && right->geomValid && left->lastBatch > 0 && right->lastBatch > 0,
+                "both extractors must have run on the stereo pair");
+    EAO_REQUIRE(frame >= 0 && frame < left->lastBatch && frame < right->lastBatch, "frame out of range");
+    const Geom& g = left->geom;
+    EAO_REQUIRE(g.nlevels == right->geom.nlevels && g.L[0].w == right->geom.L[0].w && g.L[0].h == right->geom.L[0].h &&
+                left->cfg.scale_factor == right->cfg.scale_factor, "the two extractors must share image size and pyramid");
+    EAO_REQUIRE(nl >= 0 && nr >= 0 && nr < 65536 && (nl == 0 || (kps_l && desc_l && u_right && depth)) && (nr == 0 || (kps_r && desc_r)), "bad argument");
+    for (int i = 0; i < nl; i++) {
+        u_right[i] = -1.0f; depth[i] = -1.0f;
+        EAO_REQUIRE(kps_l[i].octave >= 0 && kps_l[i].octave < g.nlevels, "left keypoint %d: octave out of range", i);
+    }
+    for (int i = 0; i < nr; i++) EAO_REQUIRE(kps_r[i].octave >= 0 && kps_r[i].octave < g.nlevels, "right keypoint %d: octave out of range", i);
+    if (nl == 0 || nr == 0) return EAO_OK;
+    EAO_HIP(hipDeviceSynchronize());   // the extractions may have run on caller-provided streams
+    eao::DevBuf<unsigned char>& buf = left->d_stereo;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    const size_t oKl = off; off = al(off + sizeof(eao_keypoint) * (size_t)nl);
+    const size_t oKr = off; off = al(off + sizeof(eao_keypoint) * (size_t)nr);
+    const size_t oDl = off; off = al(off + 32 * (size_t)nl);
+    const size_t oDr = off; off = al(off + 32 * (size_t)nr);
+    const size_t oSc = off; off = al(off + 8 * (size_t)g.nlevels);
+    const size_t oOut = off; off = al(off + 12 * (size_t)nl);
+    eao_status st = buf.reserve(off);
+    if (st) return st;
+    hipStream_t s = left->stream;
+    EAO_HIP(hipMemcpyAsync(buf.p + oKl, kps_l, sizeof(eao_keypoint) * (size_t)nl, hipMemcpyHostToDevice, s));
+    EAO_HIP(hipMemcpyAsync(buf.p + oKr, kps_r, sizeof(eao_keypoint) * (size_t)nr, hipMemcpyHostToDevice, s));
+    EAO_HIP(hipMemcpyAsync(buf.p + oDl, desc_l, 32 * (size_t)nl, hipMemcpyHostToDevice, s));
+    EAO_HIP(hipMemcpyAsync(buf.p + oDr, desc_r, 32 * (size_t)nr, hipMemcpyHostToDevice, s));
+    std::vector<float> sc(2 * (size_t)g.nlevels);
+    for (int l = 0; l < g.nlevels; l++) { sc[l] = left->scale[l]; sc[g.nlevels + l] = left->invScale[l]; }
+    EAO_HIP(hipMemcpyAsync(buf.p + oSc, sc.data(), 8 * (size_t)g.nlevels, hipMemcpyHostToDevice, s));
+    StereoArgs A;
+    A.nl = nl; A.nr = nr; A.frame = frame;
+    A.kl = (const eao_keypoint*)(buf.p + oKl); A.kr = (const eao_keypoint*)(buf.p + oKr);
+    A.dl = (const uint4*)(buf.p + oDl); A.dr = (const uint4*)(buf.p + oDr);
+    A.scale = (const float*)(buf.p + oSc); A.invScale = A.scale + g.nlevels;
+    A.mb = mb; A.mbf = mbf;
+    A.uRight = (float*)(buf.p + oOut); A.depth = A.uRight + nl; A.sad = (int*)(A.depth + nl);
+    hipLaunchKernelGGL(k_stereo_match, dim3(eao::cdiv(nl, 4)), dim3(256), 0, s, left->d_geom.p, left->lastSrc, right->lastSrc, A);
+    std::vector<int> sad(nl);
+    EAO_HIP(hipMemcpyAsync(u_right, A.uRight, 4 * (size_t)nl, hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipMemcpyAsync(depth, A.depth, 4 * (size_t)nl, hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipMemcpyAsync(sad.data(), A.sad, 4 * (size_t)nl, hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(hipGetLastError());
+    // median-based rejection (src/Frame.cc:995-1012)
+    std::vector<std::pair<int, int> > vDistIdx;
+    for (int i = 0; i < nl; i++) if (sad[i] >= 0) vDistIdx.push_back(std::make_pair(sad[i], i));
+    if (!vDistIdx.empty()) {
+        std::sort(vDistIdx.begin(), vDistIdx.end());
+        const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+            if (vDistIdx[i].first < thDist) break;
+            u_right[vDistIdx[i].second] = -1; depth[vDistIdx[i].second] = -1;
+        }
+    }
     return EAO_OK;
 }
 

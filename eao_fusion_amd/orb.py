@@ -118,3 +118,18 @@ class ORBextractor:
         """Level images of frame 0 of the last call with the reference's 19 px BORDER_REFLECT_101 frame
         (src/ORBextractor.cc:1113-1128); the hot path itself never reads the border."""
         return [np.pad(self.level_image(l), EDGE_THRESHOLD, mode="reflect") for l in range(self.nlevels)]
+
+
+def compute_stereo_matches(ext_left, ext_right, kps_l, desc_l, kps_r, desc_r, mb, mbf, frame=0):
+    """Frame::ComputeStereoMatches (reference src/Frame.cc:841-1013) on the pyramids the two extractors still hold on the
+    device after extracting the stereo pair.  kps_*: KP_DTYPE arrays (mvKeys / mvKeysRight), desc_*: (n, 32) uint8.
+    Returns (u_right, depth), float32 arrays with -1 where there is no match."""
+    kl = np.ascontiguousarray(kps_l, KP_DTYPE)
+    kr = np.ascontiguousarray(kps_r, KP_DTYPE)
+    dl = np.ascontiguousarray(desc_l, np.uint8)
+    dr = np.ascontiguousarray(desc_r, np.uint8)
+    ur = np.full(len(kl), -1, np.float32)
+    dp = np.full(len(kl), -1, np.float32)
+    _lib.check(_lib.load().eao_compute_stereo_matches(ext_left._h, ext_right._h, int(frame), len(kl), _lib.ptr(kl), _lib.ptr(dl),
+                                                      len(kr), _lib.ptr(kr), _lib.ptr(dr), float(mb), float(mbf), _lib.ptr(ur), _lib.ptr(dp)))
+    return ur, dp

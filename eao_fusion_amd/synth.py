@@ -329,3 +329,21 @@ def synth_search_scene(n=800, seed=8000, flip=0.05, clutter=0.15, mono_frac=0.3,
     return dict(K1=K1, K2=K2, T1w=T1.astype(np.float32), T2w=T2.astype(np.float32), K=(np.float32(FX), np.float32(FY), np.float32(CX), np.float32(CY)),
                 bf=np.float32(BF), points=points, mp1=mp1, mp2=mp2, fv1=fv1, fv2=fv2, F12=F12.astype(np.float32), ex=np.float32(ex),
                 ey=np.float32(ey), Scw=Scw.astype(np.float32), R12=R12.astype(np.float32), t12=t12.astype(np.float32))
+
+
+def synth_stereo_pair(seed=9000, w=640, h=480, n_planes=6):
+    """A rectified stereo pair from the rectangle world: the right image is the left one re-sampled with a piecewise
+    constant disparity (horizontal bands of 4 .. 40 px, i.e. fronto-parallel planes at different depths) plus independent
+    sensor noise.  Returns (left, right) uint8 images."""
+    rng = np.random.default_rng(seed)
+    left = synth_frame(seed, w, h).astype(np.int32)
+    right = np.empty_like(left)
+    edges = np.sort(rng.integers(0, h, n_planes - 1))
+    bands = np.concatenate([[0], edges, [h]])
+    for b in range(n_planes):
+        d = int(rng.integers(4, 41))
+        y0, y1 = bands[b], bands[b + 1]
+        right[y0:y1, :w - d] = left[y0:y1, d:]          # a point at column u in the left image sits at u - d in the right one
+        right[y0:y1, w - d:] = left[y0:y1, w - 1:w]
+    right = right + rng.integers(-2, 3, size=right.shape)
+    return left.astype(np.uint8), np.clip(right, 0, 255).astype(np.uint8)

@@ -264,6 +264,15 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
                               const float* T2w, const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12,
                               const float* R12, const float* t12, float th, int32_t* match12, int32_t* nfound);
 
+/* f4  Frame::ComputeStereoMatches() -- src/Frame.cc:841-1013.  `left` / `right` are the two extractor handles
+ * (mpORBextractorLeft / Right) right after they extracted the stereo pair: the image pyramids of frame `frame` of their
+ * last batch are still on the device and are read in place (the 19-px reflect-101 border of mvImagePyramid is evaluated
+ * on the fly).  kps / desc: mvKeys + mDescriptors and mvKeysRight + mDescriptorsRight.  mb, mbf: Frame::mb, mbf.
+ * u_right[i] / depth[i] receive mvuRight / mvDepth (-1 = no match), after the median-based outlier rejection. */
+eao_status eao_compute_stereo_matches(eao_orb* left, eao_orb* right, int32_t frame, int32_t nl, const eao_keypoint* kps_l,
+                                      const uint8_t* desc_l, int32_t nr, const eao_keypoint* kps_r, const uint8_t* desc_r,
+                                      float mb, float mbf, float* u_right, float* depth);
+
 /* f4  MapPoint::ComputeDistinctiveDescriptors() -- src/MapPoint.cc:242-307, batched over map points.  Set s holds the
  * descriptors of the (non-bad) keyframes observing point s, in std::map<KeyFrame*, size_t> iteration order:
  * desc[32 * k] for set_start[s] <= k < set_start[s + 1].  best[s] receives the position inside the set of the descriptor

@@ -113,6 +113,10 @@ protected:
     std::vector<int> mnFeaturesPerLevel;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 
+public:
+    // the library handle (its image pyramid of the last extraction stays on the device: eaofusion::ComputeStereoMatches)
+    eao_orb* handle() const { return h_; }
+
 private:
     eao_orb* h_ = nullptr;
     std::vector<eao_keypoint> kp_;
@@ -120,5 +124,28 @@ private:
 };
 
 }  // namespace ORB_SLAM2
+
+namespace eaofusion {
+
+// Frame::ComputeStereoMatches() -- reference src/Frame.cc:841-1013.  The body of the member becomes
+//   eaofusion::ComputeStereoMatches(*this);
+// right after the two extractors ran on the stereo pair (as upstream: Frame's stereo constructor, src/Frame.cc:113-125):
+// their pyramids are read in place on the device.  Members used: N, mvKeys, mvKeysRight, mDescriptors, mDescriptorsRight,
+// mpORBextractorLeft / Right, mb, mbf, mvuRight, mvDepth.
+template <class FrameT>
+void ComputeStereoMatches(FrameT& F) {
+    static_assert(sizeof(cv::KeyPoint) == sizeof(eao_keypoint), "cv::KeyPoint is the 28-byte POD the C-ABI mirrors");
+    const int N = F.N, Nr = (int)F.mvKeysRight.size();
+    F.mvuRight = std::vector<float>(N, -1.0f);
+    F.mvDepth = std::vector<float>(N, -1.0f);
+    if (N == 0 || Nr == 0) return;
+    const eao_status st = eao_compute_stereo_matches(F.mpORBextractorLeft->handle(), F.mpORBextractorRight->handle(), 0, N,
+                                                     reinterpret_cast<const eao_keypoint*>(F.mvKeys.data()), F.mDescriptors.ptr(0), Nr,
+                                                     reinterpret_cast<const eao_keypoint*>(F.mvKeysRight.data()), F.mDescriptorsRight.ptr(0),
+                                                     F.mb, F.mbf, F.mvuRight.data(), F.mvDepth.data());
+    if (st != EAO_OK) throw std::runtime_error(std::string("eao_compute_stereo_matches: ") + eao_last_error());
+}
+
+}  // namespace eaofusion
 
 #endif  // ORBEXTRACTOR_H

@@ -316,3 +316,18 @@ def distinctive_descriptors(sets):
     fn.restype = None
     fn(C.c_int(len(sets)), C.c_void_p(_p(start)), C.c_void_p(_p(desc)), C.c_void_p(_p(best)))
     return best
+
+
+def stereo_matches(orc_left, orc_right, kps_l, desc_l, kps_r, desc_r, mb, mbf):
+    """Frame::ComputeStereoMatches over two OrbOracle instances that just extracted the stereo pair."""
+    kl = np.ascontiguousarray(kps_l, KP_DTYPE)
+    kr = np.ascontiguousarray(kps_r, KP_DTYPE)
+    dl = np.ascontiguousarray(desc_l, np.uint8)
+    dr = np.ascontiguousarray(desc_r, np.uint8)
+    ur = np.full(len(kl), -1, np.float32)
+    dp = np.full(len(kl), -1, np.float32)
+    fn = lib().orc_stereo_matches
+    fn.restype = C.c_int
+    fn(C.c_void_p(orc_left.h), C.c_void_p(orc_right.h), C.c_int(len(kl)), C.c_void_p(_p(kl)), C.c_void_p(_p(dl)), C.c_int(len(kr)),
+       C.c_void_p(_p(kr)), C.c_void_p(_p(dr)), C.c_float(mb), C.c_float(mbf), C.c_void_p(_p(ur)), C.c_void_p(_p(dp)))
+    return ur, dp

@@ -25,6 +25,7 @@
 //  * DistributeOctTree sorts (size, node*) pairs (:684): ties on size are broken by heap address upstream;
 //    here by node creation sequence (later-created node compares greater).
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -627,3 +628,112 @@ int orc_distribute(const float* xyr, int n, int minX, int maxX, int minY, int ma
 const int8_t* orc_orb_pattern() { return kPattern; }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- stereo matching
+// Frame::ComputeStereoMatches (src/Frame.cc:841-1013) over the pyramids of two extractors that just ran on the stereo
+// pair.  mvImagePyramid[l] is a view into a buffer with a 19-px BORDER_REFLECT_101 frame (src/ORBextractor.cc:1113-1128):
+// patch reads that leave the level are answered with the mirrored pixel.  The patches minus their centre pixel and their
+// L1 distance are integers, hence exact in float.
+namespace {
+int refl_px(const Image& im, int x, int y) {
+    x = x < 0 ? -x : (x >= im.w ? 2 * im.w - 2 - x : x);
+    y = y < 0 ? -y : (y >= im.h ? 2 * im.h - 2 - y : y);
+    return im.row(y)[x];
+}
+}  // namespace
+
+extern "C" int orc_stereo_matches(void* hl, void* hr, int nl, const void* kpsL28, const uint8_t* descL, int nr, const void* kpsR28,
+                                  const uint8_t* descR, float mb, float mbf, float* uRight, float* depth) {
+    const Extractor* L = (const Extractor*)hl;
+    const Extractor* R = (const Extractor*)hr;
+    struct KP { float x, y, size, angle, response; int32_t octave, class_id; };
+    const KP* kl = (const KP*)kpsL28;
+    const KP* kr = (const KP*)kpsR28;
+    for (int i = 0; i < nl; i++) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    const int nRows = L->pyr[0].h;
+    std::vector<std::vector<size_t>> vRowIndices(nRows);
+    for (int iR = 0; iR < nr; iR++) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * L->scale[kr[iR].octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);
+    }
+    const float minZ = mb, minD = -3, maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < nl; iL++) {
+        const KP& kpL = kl[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y, uL = kpL.x;
+        if ((int)vL < 0 || (int)vL >= nRows) continue;
+        const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = 100;   // ORBmatcher::TH_HIGH
+        size_t bestIdxR = 0;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            if (kr[iR].octave < levelL - 1 || kr[iR].octave > levelL + 1) continue;
+            const float uR = kr[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                uint32_t a[8], b[8];
+                std::memcpy(a, descL + 32 * (size_t)iL, 32); std::memcpy(b, descR + 32 * iR, 32);
+                int dist = 0;
+                for (int w = 0; w < 8; w++) dist += __builtin_popcount(a[w] ^ b[w]);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < 100) {
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = L->invScale[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5;
+            const Image& imL = L->pyr[kpL.octave];
+            const Image& imR = R->pyr[kpL.octave];
+            float IL[11][11];
+            const float cL = (float)refl_px(imL, (int)scaleduL, (int)scaledvL);
+            for (int py = 0; py < 11; py++)
+                for (int px = 0; px < 11; px++) IL[py][px] = (float)refl_px(imL, (int)(scaleduL - w) + px, (int)(scaledvL - w) + py) - cL;
+            int bestDistSad = INT_MAX, bestincR = 0;
+            const int Lw = 5;
+            std::vector<float> vDists(2 * Lw + 1);
+            const float iniu = scaleduR0 + Lw - w, endu = scaleduR0 + Lw + w + 1;
+            if (iniu < 0 || endu >= imR.w) continue;
+            for (int incR = -Lw; incR <= +Lw; incR++) {
+                const float cR = (float)refl_px(imR, (int)(scaleduR0 + incR), (int)scaledvL);
+                float dist = 0;
+                for (int py = 0; py < 11; py++)
+                    for (int px = 0; px < 11; px++)
+                        dist += std::fabs(IL[py][px] - ((float)refl_px(imR, (int)(scaleduR0 + incR - w) + px, (int)(scaledvL - w) + py) - cR));
+                if (dist < bestDistSad) { bestDistSad = (int)dist; bestincR = incR; }
+                vDists[Lw + incR] = dist;
+            }
+            if (bestincR == -Lw || bestincR == Lw) continue;
+            const float dist1 = vDists[Lw + bestincR - 1], dist2 = vDists[Lw + bestincR], dist3 = vDists[Lw + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = L->scale[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= 0 && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                depth[iL] = mbf / disparity;
+                uRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistSad, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0;
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        uRight[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+    }
+    return (int)vDistIdx.size();
+}

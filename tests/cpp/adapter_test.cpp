@@ -241,6 +241,30 @@ int main(int argc, char** argv) {
     int32_t same = 1;
     for (int k = 0; k < 16; k++) same &= (before[k] == cur->Tcw.ptr<float>(0)[k]);
     wr(out, &same, 1);
+    // ---------------------------------------------------------------- Frame::ComputeStereoMatches over two extractors
+    {
+        int32_t sw = 0, sh = 0;
+        rd(in, &sw, 1); rd(in, &sh, 1);
+        cv::Mat imL(sh, sw, CV_8U), imR(sh, sw, CV_8U);
+        rd(in, imL.ptr(0), (size_t)sw * sh); rd(in, imR.ptr(0), (size_t)sw * sh);
+        struct StereoFrame {
+            int N = 0;
+            std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
+            cv::Mat mDescriptors, mDescriptorsRight;
+            ORB_SLAM2::ORBextractor* mpORBextractorLeft = nullptr; ORB_SLAM2::ORBextractor* mpORBextractorRight = nullptr;
+            float mb = 0, mbf = 0;
+            std::vector<float> mvuRight, mvDepth;
+        } SF;
+        ORB_SLAM2::ORBextractor exL(1000, 1.2f, 8, 20, 7), exR(1000, 1.2f, 8, 20, 7);
+        exL(imL, cv::Mat(), SF.mvKeys, SF.mDescriptors);
+        exR(imR, cv::Mat(), SF.mvKeysRight, SF.mDescriptorsRight);
+        SF.N = (int)SF.mvKeys.size();
+        SF.mpORBextractorLeft = &exL; SF.mpORBextractorRight = &exR;
+        SF.mbf = 40.0f; SF.mb = 40.0f / 535.4f;
+        eaofusion::ComputeStereoMatches(SF);
+        const int32_t ns = SF.N;
+        wr(out, &ns, 1); wr(out, SF.mvuRight.data(), ns); wr(out, SF.mvDepth.data(), ns);
+    }
     printf("adapter_test ok: %d keypoints, %d pose inliers, %d observations erased\n", nk, inliers, erased);
     return 0;
 }

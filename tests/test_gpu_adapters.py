@@ -37,6 +37,8 @@ def test_cpp_adapters_end_to_end(tmp_path):
         f.write(bp["poses"].tobytes()); f.write(bp["fixed"].tobytes()); f.write(bp["points"].tobytes())
         f.write(bp["edge_cam"].tobytes()); f.write(bp["edge_point"].tobytes()); f.write(bp["obs"].tobytes()); f.write(bp["inv_sigma2"].tobytes())
         f.write(np.array([bp[k] for k in ("fx", "fy", "cx", "cy", "bf")], np.float32).tobytes())
+        sl, sr = synth.synth_stereo_pair(9000)
+        f.write(struct.pack("<ii", sl.shape[1], sl.shape[0])); f.write(sl.tobytes()); f.write(sr.tobytes())
     res = str(tmp_path / "result.bin")
     out = subprocess.run([exe, prob, res], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -90,6 +92,14 @@ def test_cpp_adapters_end_to_end(tmp_path):
     assert erased > 0
     f = bp["fixed"].astype(bool)
     assert np.array_equal(poses[f], bp["poses"][f])    # fixed keyframes are never written back
+    # ---- Frame::ComputeStereoMatches through the two ORBextractor adapters
+    ns = int(take(np.int32, 1)[0])
+    ur_cpp, dp_cpp = take(np.float32, ns), take(np.float32, ns)
+    el, er = E.ORBextractor(1000, 1.2, 8, 20, 7), E.ORBextractor(1000, 1.2, 8, 20, 7)
+    skl, sdl = el(sl)
+    skr, sdr = er(sr)
+    ur, dp = E.compute_stereo_matches(el, er, skl, sdl, skr, sdr, np.float32(40.0) / np.float32(535.4), np.float32(40.0))
+    assert ns == len(skl) and np.array_equal(ur_cpp, ur) and np.array_equal(dp_cpp, dp) and (ur >= 0).sum() > 100
 
 
 def test_cpp_search_adapters(tmp_path):

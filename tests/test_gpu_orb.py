@@ -136,3 +136,26 @@ def test_random_configurations(gpu, oracle):
         k1, d1 = gpu.ORBextractor(nfeat, sf, nlev, ini, mn)(img)
         assert np.array_equal(k0, k1) and np.array_equal(d0, d1), (w, h, nfeat, sf, nlev, ini, mn)
         done += 1
+
+
+@pytest.mark.parametrize("seed,cfg", [(9000, (1000, 1.2, 8, 20, 7)), (9001, (2000, 1.2, 8, 20, 7)), (9002, (800, 1.3, 5, 20, 7))])
+def test_compute_stereo_matches(gpu, oracle, seed, cfg):
+    """Frame::ComputeStereoMatches (src/Frame.cc:841-1013) on the device-resident pyramids of the two extractors:
+    mvuRight / mvDepth bit-exact against the oracle, and most keypoints recover their band's disparity."""
+    left, right = synth.synth_stereo_pair(seed)
+    el, er = gpu.ORBextractor(*cfg), gpu.ORBextractor(*cfg)
+    kl, dl = el(left)
+    kr, dr = er(right)
+    ol, orr = oracle.OrbOracle(*cfg), oracle.OrbOracle(*cfg)
+    okl, odl = ol.extract(left)
+    okr, odr = orr.extract(right)
+    assert np.array_equal(kl, okl) and np.array_equal(kr, okr)
+    bf = np.float32(40.0)
+    mb = np.float32(40.0 / 535.4)
+    ur, dp = gpu.compute_stereo_matches(el, er, kl, dl, kr, dr, mb, bf)
+    our, odp = oracle.stereo_matches(ol, orr, okl, odl, okr, odr, mb, bf)
+    assert np.array_equal(ur, our) and np.array_equal(dp, odp)
+    m = ur >= 0
+    assert m.sum() > 0.3 * len(kl)
+    disp = kl["x"][m] - ur[m]
+    assert np.all(disp >= 0) and np.all(disp < bf / mb) and np.median(np.abs(disp - np.round(disp))) < 0.35

@@ -193,3 +193,83 @@ def test_low_texture_uses_min_threshold(oracle):
     kps, _ = e.extract(img)
     assert len(kps) > 50
     assert kps["response"].min() < 20  # a response below iniThFAST can only come from the minThFAST retry
+
+
+def test_stereo_matches_against_independent_replay(oracle):
+    """Frame::ComputeStereoMatches (src/Frame.cc:841-1013): the oracle against a replay written here from the reference
+    text over the oracle's own pyramid levels (numpy patches padded with reflect-101, float32 arithmetic)."""
+    from eao_fusion_amd import synth
+    left, right = synth.synth_stereo_pair(9100, 400, 300, 4)
+    cfg = (400, 1.2, 4, 20, 7)
+    ol, orr = oracle.OrbOracle(*cfg), oracle.OrbOracle(*cfg)
+    kl, dl = ol.extract(left)
+    kr, dr = orr.extract(right)
+    F = np.float32
+    bf, mb = F(40.0), F(40.0 / 535.4)
+    got_u, got_d = oracle.stereo_matches(ol, orr, kl, dl, kr, dr, mb, bf)
+    tab = ol.tables()
+    scale, inv = tab["scale"], tab["inv_scale"]
+    pad = 19
+    pyrL = [np.pad(ol.level_image(l).astype(np.float32), pad, mode="reflect") for l in range(4)]
+    pyrR = [np.pad(orr.level_image(l).astype(np.float32), pad, mode="reflect") for l in range(4)]
+    n_rows = left.shape[0]
+    rows = [[] for _ in range(n_rows)]
+    for i in range(len(kr)):
+        r = F(2.0) * scale[kr["octave"][i]]
+        for yi in range(int(np.floor(kr["y"][i] - r)), int(np.ceil(kr["y"][i] + r)) + 1):
+            if 0 <= yi < n_rows:
+                rows[yi].append(i)
+    maxD = bf / mb
+    exp_u = np.full(len(kl), -1, np.float32)
+    exp_d = np.full(len(kl), -1, np.float32)
+    dist_idx = []
+    for iL in range(len(kl)):
+        lvl, uL, vL = int(kl["octave"][iL]), kl["x"][iL], kl["y"][iL]
+        cands = rows[int(vL)]
+        minU, maxU = uL - maxD, uL + F(3)
+        if not cands or maxU < 0:
+            continue
+        best, bi = 100, 0
+        for iR in cands:
+            if abs(int(kr["octave"][iR]) - lvl) > 1 or not (minU <= kr["x"][iR] <= maxU):
+                continue
+            d = int(np.unpackbits(dl[iL] ^ dr[iR]).sum())
+            if d < best:
+                best, bi = d, iR
+        if best >= 100:
+            continue
+        sf = inv[lvl]
+        rnd = lambda v: int(np.floor(abs(v) + F(0.5)) * np.sign(v))          # C round(): half away from zero
+        su, sv, sr0 = rnd(uL * sf), rnd(vL * sf), rnd(kr["x"][bi] * sf)
+        w = 5
+        if sr0 + 5 - w < 0 or sr0 + 5 + w + 1 >= pyrR[lvl].shape[1] - 2 * pad:
+            continue
+        IL = pyrL[lvl][pad + sv - w:pad + sv + w + 1, pad + su - w:pad + su + w + 1]
+        IL = IL - IL[w, w]
+        dists = []
+        for inc in range(-5, 6):
+            IR = pyrR[lvl][pad + sv - w:pad + sv + w + 1, pad + sr0 + inc - w:pad + sr0 + inc + w + 1]
+            dists.append(F(np.abs(IL - (IR - IR[w, w])).sum()))
+        binc = int(np.argmin(dists)) - 5                                      # first minimum, like the strict '<'
+        if binc in (-5, 5):
+            continue
+        d1, d2, d3 = dists[5 + binc - 1], dists[5 + binc], dists[5 + binc + 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = (d1 - d3) / (F(2.0) * (d1 + d3 - F(2.0) * d2))
+        if not (-1 <= delta <= 1):
+            continue
+        bu = scale[lvl] * (F(sr0) + F(binc) + delta)
+        disp = uL - bu
+        if 0 <= disp < maxD:
+            if disp <= 0:
+                disp, bu = F(0.01), uL - F(0.01)
+            exp_d[iL], exp_u[iL] = bf / disp, bu
+            dist_idx.append((int(dists[5 + binc]), iL))
+    dist_idx.sort()
+    th = F(1.5) * F(1.4) * F(dist_idx[len(dist_idx) // 2][0])
+    for d, i in reversed(dist_idx):
+        if d < th:
+            break
+        exp_u[i] = exp_d[i] = -1
+    assert (exp_u >= 0).sum() > 50
+    assert np.array_equal(got_u, exp_u) and np.array_equal(got_d, exp_d)
