@@ -891,6 +891,8 @@ struct BADev {
     const int* camStart;    // nFree+1 CSR by free camera block
     const int* camEdges;
     int* camEdgeL;          // landmark block of each camEdges entry (resolved by k_ba_prepare)
+    int* pairCnt;           // per camera pair (i1 <= i2): number of landmarks both observe ...
+    int* pairPts;           // ... and their landmark blocks, ascending, nL slots per pair (k_ba_pairs)
     int* table;             // nL * nFree: edge id of (point, free camera) or -1 (built and maintained on the device)
     // state: two buffers; ctl[1] says which one holds the current estimate, the other receives the trial
     SE3* camsBuf[2];
@@ -1556,6 +1558,119 @@ __host__ inline size_t tile_solver_lds(int nF) {
     return ((size_t)((tile_lrow(g.n4 + 1) + 1) & ~1) + 3 * (size_t)g.Tr * 16 * 4 + (size_t)g.n4 + 8) * sizeof(double);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pair-owned Schur assembly for the tile solver.  Instead of partial rows per (camera, edge chunk) that a second kernel has to
+// sum, ONE workgroup owns the 6x6 block S(i1, i2) of a camera pair i1 <= i2 (and, for i1 == i2, the camera's six right-hand
+// side entries): its threads split the ascending list of landmarks both cameras observe, each thread accumulates
+//   -Y(i1,l) Hpl(i2,l)^T  with  Y = Hpl(i1,l) (Hll_l + lambda I)^-1     (+ Hpl(i1,l) (Hll_l + lambda I)^-1 bl_l for the rhs)
+// over its landmarks in order, a fixed-order LDS reduction adds the threads, and the block goes straight into the solver's
+// register-tile layout (Hpp + lambda I added on the diagonal).  No slabs, no reduction launch, no atomics on data.
+__host__ __device__ inline int pair_index(int i1, int i2, int nF) { return i1 * nF - i1 * (i1 - 1) / 2 + (i2 - i1); }   // i1 <= i2
+constexpr int kPairThreads = 512;
+
+// landmark lists of the camera pairs (once per window; the outlier pass only clears table entries, which the assembly re-checks)
+__global__ __launch_bounds__(256) void k_ba_pairs(BADev P) {
+    __shared__ int s_base;
+    const int nF = P.nFree, t = threadIdx.x, lane = t & 63;
+    int i1 = 0, rem = blockIdx.x;
+    while (rem >= nF - i1) { rem -= nF - i1; i1++; }
+    const int i2 = i1 + rem;
+    int* out = P.pairPts + (size_t)blockIdx.x * P.nL;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int l0 = 0; l0 < P.nL; l0 += 256) {
+        const int l = l0 + t;
+        const bool hit = l < P.nL && P.table[(size_t)l * nF + i1] >= 0 && P.table[(size_t)l * nF + i2] >= 0;
+        // ordered compaction: waves in order, lanes in order
+        __shared__ int s_w[4];
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_w[t >> 6] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < (t >> 6); w++) off += s_w[w];
+        if (hit) out[off + __popcll(m & ((1ull << lane) - 1))] = l;
+        __syncthreads();
+        if (t == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (t == 0) P.pairCnt[blockIdx.x] = s_base;
+}
+
+// zero / identity background of the tile system (entries no pair block owns never change during a window)
+__global__ __launch_bounds__(256) void k_ba_tiles_init(BADev P) {
+    const TileGeom g = tile_geom(P.nFree);
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= g.nTiles * 256) return;
+    const int idx = o >> 8, reg = (o >> 6) & 3, lane = o & 63;
+    int ti, tj;
+    tile_of(g, idx, ti, tj);
+    const int row = ti * 16 + (lane >> 4) + 4 * reg, col = tj * 16 + (lane & 15);
+    P.sys[o] = (row >= g.n && row < g.n4 && col == row) ? 1.0 : 0.0;
+}
+
+__device__ __forceinline__ void tile_store(const BADev& P, const TileGeom& g, int row, int col, double v) {   // col <= row
+    const int ti = row >> 4, tj = col >> 4;
+    const int tileIdx = tj * g.Tr - tj * (tj - 1) / 2 + (ti - tj);
+    const int rr = row & 15, cc = col & 15;
+    P.sys[(size_t)tileIdx * 256 + (rr >> 2) * 64 + (rr & 3) * 16 + cc] = v;
+}
+
+__global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(BADev P, int first) {
+    __shared__ double red[(kPairThreads / 4) * 42], part[8 * 42];
+    if (P.ctl[kCtlHalt]) return;
+    const int nF = P.nFree, t = threadIdx.x;
+    int i1 = 0, rem = blockIdx.x;
+    while (rem >= nF - i1) { rem -= nF - i1; i1++; }
+    const int i2 = i1 + rem;
+    const bool diag = i1 == i2;
+    const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
+    if (first && blockIdx.x == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
+    const int cnt = P.pairCnt[blockIdx.x];
+    const int* pts = P.pairPts + (size_t)blockIdx.x * P.nL;
+    double acc[42];
+#pragma unroll
+    for (int q = 0; q < 42; q++) acc[q] = 0;
+    for (int k = t; k < cnt; k += kPairThreads) {
+        const int l = pts[k];
+        const int e1 = P.table[(size_t)l * nF + i1], e2 = P.table[(size_t)l * nF + i2];
+        if (e1 < 0 || e2 < 0) continue;                      // deactivated by the outlier pass
+        double Di[9];
+        dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
+        const double* B1 = &P.Hpl[(size_t)e1 * 18];
+        const double* B2 = &P.Hpl[(size_t)e2 * 18];
+        double b2[18];
+#pragma unroll
+        for (int q = 0; q < 18; q++) b2[q] = B2[q];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const double h0 = B1[r * 3], h1 = B1[r * 3 + 1], h2 = B1[r * 3 + 2];
+            const double y0 = h0 * Di[0] + h1 * Di[3] + h2 * Di[6];
+            const double y1 = h0 * Di[1] + h1 * Di[4] + h2 * Di[7];
+            const double y2 = h0 * Di[2] + h1 * Di[5] + h2 * Di[8];
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[r * 6 + c] -= y0 * b2[c * 3] + y1 * b2[c * 3 + 1] + y2 * b2[c * 3 + 2];
+            if (diag) {
+                const double* bl = &P.bl[(size_t)l * 3];
+                acc[36 + r] += y0 * bl[0] + y1 * bl[1] + y2 * bl[2];     // Hpl (Dinv bl), row r
+            }
+        }
+    }
+    block_sum_lds<42, kPairThreads>(acc, red, part);
+    const TileGeom g = tile_geom(nF);
+    if (t < 36) {
+        const int r = t / 6, c = t - r * 6;
+        if (!diag) {
+            tile_store(P, g, i2 * 6 + c, i1 * 6 + r, part[t]);        // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
+        } else if (c >= r) {
+            const double v = part[t] + P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+            tile_store(P, g, i1 * 6 + c, i1 * 6 + r, v);              // the upper-triangle value, mirrored into the lower tile
+        }
+    } else if (t < 42 && diag) {
+        const int r = t - 36;
+        tile_store(P, g, g.n4, i1 * 6 + r, P.bp[i1 * 6 + r] - part[t]);   // right-hand side row
+    }
+}
+
 // Sum the partial slabs straight into the solver's register layout: [tile][reg][lane].
 __global__ __launch_bounds__(256) void k_ba_reduce_tiles(BADev P) {
     if (P.ctl[kCtlHalt]) return;
@@ -2156,6 +2271,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
     need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16) + (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
     need += 96 * 256;
+    need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * 4;   // landmark lists of the camera pairs
     if ((st = c.bytes.reserve(need))) return st;
     Arena a{c.bytes.p, c.bytes.n};
     BADev D;
@@ -2178,6 +2294,10 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     // ---- device-only part
     int* dtable = a.take<int>((size_t)nP * nC);
     D.camEdgeL = a.take<int>(E);
+    const bool pairPath = nFreeIn > 0 && nFreeIn <= kTileMaxFree && !(getenv("EAO_BA_SOLVER") && !strcmp(getenv("EAO_BA_SOLVER"), "lds")) && !getenv("EAO_BA_SLABS");
+    const int nPairsMax = nFreeIn * (nFreeIn + 1) / 2;
+    D.pairCnt = a.take<int>(std::max(nPairsMax, 1));
+    D.pairPts = a.take<int>(pairPath ? (size_t)nPairsMax * std::max(nP, 1) : 1);
     unsigned char* dcls = a.take<unsigned char>(E);
     SE3* dcamsT = a.take<SE3>(nC);
     double* dptsT = a.take<double>((size_t)nP * 3);
@@ -2267,6 +2387,11 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     EAO_HIP(hipEventRecord(c.ev0, s));
     EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(D.nL * D.nFree, nP * 3), nC), E), 256)), dim3(256), 0, s, D);
+    const bool usePairs = pairPath && D.nFree > 0 && D.nL > 0;
+    if (usePairs) {
+        hipLaunchKernelGGL(k_ba_pairs, dim3(D.nFree * (D.nFree + 1) / 2), dim3(256), 0, s, D);
+        hipLaunchKernelGGL(k_ba_tiles_init, dim3(tile_geom(D.nFree).nTiles), dim3(256), 0, s, D);
+    }
     auto wait_status = [&](int want) -> eao_status {
         EAO_HIP(hipStreamSynchronize(s));
         if (c.status->seq != want) { eao::set_error("LM status hand-off out of sequence"); return EAO_ERR_INTERNAL; }
@@ -2313,7 +2438,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         const size_t schurLds = schur_lds_bytes(nF);
         if (nF) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         auto enqueue_trial = [&](int bulk, bool firstTrial = false) {
-            if (nF) {
+            if (nF && usePairs && solveTiles) {
+                hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2), dim3(kPairThreads), 0, s, D, firstTrial ? 1 : 0);
+            } else if (nF) {
                 hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(kSchurThreads), schurLds, s, D, firstTrial ? 1 : 0);
                 if (solveTiles) hipLaunchKernelGGL(k_ba_reduce_tiles, dim3(tg.nTiles), dim3(256), 0, s, D);
                 else hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, D);
