@@ -123,7 +123,9 @@ __host__ __device__ inline SE3 se3_exp(const double u[6]) {  // (omega, upsilon)
     if (theta < 0.00001) {
         for (int i = 0; i < 9; i++) { const double id = (i % 4 == 0) ? 1.0 : 0.0; R[i] = id + Om[i] + Om2[i]; V[i] = R[i]; }
     } else {
-        const double st = sin(theta), ct = cos(theta), it = recip(theta), it2 = it * it;
+        double st, ct;
+        sincos(theta, &st, &ct);                // one range reduction for both
+        const double it = recip(theta), it2 = it * it;
         const double a = st * it, b = (1 - ct) * it2;
         const double c = (theta - st) * (it2 * it);
         for (int i = 0; i < 9; i++) {
