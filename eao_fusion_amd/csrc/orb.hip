@@ -13,7 +13,8 @@
 //                     emission in row-major order, minThFAST retry
 //   k_quadtree        one workgroup per (frame, level): level-synchronous restatement of DistributeOctTree --
 //                     the std::list order is reproduced by prefix sums, the (size, pointer) sort by a rank
-//   k_blur7           separable 7x7 fixed-point Gaussian: 4 px per lane, aligned u32 loads, 7-row register window
+//   k_blur7           separable 7x7 fixed-point Gaussian: 4 px per lane, one dwordx3 per source row, v_dot4_u32_u8
+//                     horizontal and v_dot2_u32_u16 vertical passes, window of row pairs in registers
 //   k_orient_describe one wavefront per keypoint: integer moments reduced across lanes, fastAtan2, 256 point
 //                     pairs (4 per lane) packed into the descriptor with 4 wave ballots
 //
@@ -52,7 +53,7 @@ struct LevelGeom {
     int kpBase;                // first keypoint slot of this level inside a frame
     int candBase, candCap;     // candidate scratch of this level inside a frame
     int tabBase;               // resize coefficient tables (int2): (xofs, xalpha)[w] then (yofs, ybeta)[h]
-    int tileBase, tilesX;      // blur tiles (256 x 64) of this level
+    int tileBase, tilesX;      // blur: first workgroup of this level, 128-px strips per row of strips
     int scaledPatch;
     float scale;
 };
@@ -64,6 +65,7 @@ struct Geom {
     int pyrFrameBytes;
     int iniTh, minTh;
     int scanCap;               // LDS scan workspace entries for k_quadtree
+    int qtLdsCand, qtKeysOff;  // k_quadtree: candidates (key + node index) that fit in LDS, byte offset of the keys
     int fastMaxTested, fastTileBytes, fastLdsBytes;   // k_fast_cells dynamic LDS carve-up
     int umax[16];
     LevelGeom L[kMaxLevels];
@@ -91,73 +93,98 @@ __device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const ImgSrc&
 
 // ---------------------------------------------------------------------------------------------- resize
 // Source bytes S[sx], S[sx+1] of the four output pixels of a lane all lie inside three aligned words of the source
-// row (scale factors up to 2): three u32 loads + v_alignbyte extraction instead of eight byte loads.
-__device__ __forceinline__ unsigned pair_at(unsigned w0, unsigned w1, unsigned w2, int o) {
-    const int k = o >> 2;
-    const unsigned lo = k == 0 ? w0 : (k == 1 ? w1 : w2);
-    const unsigned hi = k == 0 ? w1 : w2;
-    return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));   // bits 0-7: S[sx], bits 8-15: S[sx+1]
+// row (scale factors up to 2): three u32 loads per source row; one v_perm_b32 per pixel lifts its byte pair into two
+// 16-bit halves, v_dot2_u32_u16 applies the column weights and v_mul_hi_u32 the row weights (all weights are >= 0 and
+// sum to 2048, so the result needs no clamp).  A lane produces 4 px of kResizeRows output rows: the column set-up
+// (table loads, selectors) is shared between the rows.
+constexpr int kResizeRows = 8;
+__device__ __forceinline__ unsigned udot2w(unsigned a, unsigned b) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), 0u, false);
 }
 
 __global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, const int* __restrict__ tab, ImgSrc s, int l, int f0) {
     const LevelGeom D = g->L[l];
     const LevelGeom S = g->L[l - 1];
     const int f = blockIdx.z + f0;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
+    const int dyb = (blockIdx.y * 4 + threadIdx.y) * kResizeRows;
     const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (dy >= D.h || dx0 >= D.w) return;
+    if (dyb >= D.h || dx0 >= D.w) return;
     int spitch;
     const uint8_t* src = level_ptr(g, s, l - 1, f, &spitch);
     uint8_t* dst = s.pyr + (long long)f * g->pyrFrameBytes + D.off;
     const int2* xt = reinterpret_cast<const int2*>(tab + D.tabBase);   // (xofs, alpha0 | alpha1 << 16) per output column
     const int2* yt = xt + D.w;                                          // (yofs, beta0 | beta1 << 16) per output row
-    const int2 yy = yt[dy];
-    const int b0 = (short)(yy.y & 0xFFFF), b1 = (short)(yy.y >> 16);
-    const int sy0 = min(max(yy.x, 0), S.h - 1), sy1 = min(max(yy.x + 1, 0), S.h - 1);
-    const uint8_t* r0 = src + (long long)sy0 * spitch;
-    const uint8_t* r1 = src + (long long)sy1 * spitch;
-    int sx[4], aa[4];
-    const int nvalid = min(4, D.w - dx0);
+    int sx[4];
+    unsigned aa[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int2 e = xt[min(dx0 + i, D.w - 1)];
-        sx[i] = e.x; aa[i] = e.y;
+        sx[i] = e.x; aa[i] = (unsigned)e.y;
     }
     const int wb = sx[0] >> 2, wmax = (S.w - 1) >> 2;
     const bool fast = ((((uintptr_t)src | (uintptr_t)spitch) & 3) == 0) && (sx[3] + 1 - 4 * wb < 12);
-    unsigned packed = 0;
     if (fast) {
-        const unsigned* q0 = reinterpret_cast<const unsigned*>(r0);
-        const unsigned* q1 = reinterpret_cast<const unsigned*>(r1);
-        const int i0 = wb, i1 = min(wb + 1, wmax), i2 = min(wb + 2, wmax);
-        const unsigned a0 = q0[i0], a1 = q0[i1], a2 = q0[i2];
-        const unsigned c0 = q1[i0], c1 = q1[i1], c2 = q1[i2];
+        const int i0 = 4 * wb, i1 = 4 * min(wb + 1, wmax), i2 = 4 * min(wb + 2, wmax);
+        unsigned sel[4];
+        bool up[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int o = sx[i] - 4 * wb;
-            const unsigned pa = pair_at(a0, a1, a2, o), pc = pair_at(c0, c1, c2, o);
-            const int w0 = (short)(aa[i] & 0xFFFF), w1 = (short)(aa[i] >> 16);
-            const int h0 = (int)(pa & 0xFF) * w0 + (int)((pa >> 8) & 0xFF) * w1;
-            const int h1 = (int)(pc & 0xFF) * w0 + (int)((pc >> 8) & 0xFF) * w1;
-            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (unsigned)min(max(v, 0), 255) << (8 * i);
+            const int o = sx[i] - 4 * wb;          // 0 .. 10: bytes o, o+1 of the 12 loaded
+            up[i] = o >= 4;                        // pair lives in words (1, 2) instead of (0, 1)
+            const unsigned oo = (unsigned)(up[i] ? o - 4 : o);
+            sel[i] = oo | ((oo + 1) << 16) | 0x0c000c00u;   // v_perm: (S[sx], 0, S[sx+1], 0)
         }
-    } else {
+        // All loads of the lane's rows are issued before any arithmetic (rows past the image repeat the last one: same
+        // bytes to the same address), so a wave pays the memory latency once, not once per row.
+        unsigned raw[kResizeRows][6], B0[kResizeRows], B1[kResizeRows];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int w0 = (short)(aa[i] & 0xFFFF), w1 = (short)(aa[i] >> 16);
-            const int sx1 = min(sx[i] + 1, S.w - 1);
-            const int h0 = r0[sx[i]] * w0 + r0[sx1] * w1;
-            const int h1 = r1[sx[i]] * w0 + r1[sx1] * w1;
-            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (unsigned)min(max(v, 0), 255) << (8 * i);
+        for (int r = 0; r < kResizeRows; r++) {
+            const int2 yy = yt[min(dyb + r, D.h - 1)];
+            B0[r] = (unsigned)yy.y << 16; B1[r] = (unsigned)yy.y & 0xFFFF0000u;   // beta << 16
+            const int sy0 = min(max(yy.x, 0), S.h - 1), sy1 = min(max(yy.x + 1, 0), S.h - 1);
+            const uint8_t* r0 = src + __umul24(sy0, spitch);
+            const uint8_t* r1 = src + __umul24(sy1, spitch);
+            raw[r][0] = *reinterpret_cast<const unsigned*>(r0 + i0); raw[r][1] = *reinterpret_cast<const unsigned*>(r0 + i1);
+            raw[r][2] = *reinterpret_cast<const unsigned*>(r0 + i2); raw[r][3] = *reinterpret_cast<const unsigned*>(r1 + i0);
+            raw[r][4] = *reinterpret_cast<const unsigned*>(r1 + i1); raw[r][5] = *reinterpret_cast<const unsigned*>(r1 + i2);
         }
-    }
-    uint8_t* o = dst + (long long)dy * D.pitch + dx0;
-    if (nvalid == 4) {
-        *reinterpret_cast<unsigned*>(o) = packed;
+#pragma unroll
+        for (int r = 0; r < kResizeRows; r++) {
+            const int dy = min(dyb + r, D.h - 1);
+            unsigned packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned pa = __builtin_amdgcn_perm(up[i] ? raw[r][2] : raw[r][1], up[i] ? raw[r][1] : raw[r][0], sel[i]);
+                const unsigned pc = __builtin_amdgcn_perm(up[i] ? raw[r][5] : raw[r][4], up[i] ? raw[r][4] : raw[r][3], sel[i]);
+                const unsigned h0 = udot2w(pa, aa[i]), h1 = udot2w(pc, aa[i]);
+                // ((beta0 * (h0 >> 4)) >> 16) + ((beta1 * (h1 >> 4)) >> 16), rounded: OpenCV's 11-bit fixed-point VResizeLinear
+                const unsigned v = (__umulhi(B0[r], h0 >> 4) + __umulhi(B1[r], h1 >> 4) + 2) >> 2;
+                packed |= min(v, 255u) << (8 * i);
+            }
+            // (the level's pitch is a multiple of 64: the tail of the last word lands in padding)
+            *reinterpret_cast<unsigned*>(dst + __umul24(dy, D.pitch) + dx0) = packed;
+        }
     } else {
-        for (int i = 0; i < nvalid; i++) o[i] = (uint8_t)(packed >> (8 * i));
+        const int nvalid = min(4, D.w - dx0);
+        for (int r = 0; r < kResizeRows; r++) {
+            const int dy = dyb + r;
+            if (dy >= D.h) break;
+            const int2 yy = yt[dy];
+            const int b0 = (short)(yy.y & 0xFFFF), b1 = (short)(yy.y >> 16);
+            const int sy0 = min(max(yy.x, 0), S.h - 1), sy1 = min(max(yy.x + 1, 0), S.h - 1);
+            const uint8_t* r0 = src + (long long)sy0 * spitch;
+            const uint8_t* r1 = src + (long long)sy1 * spitch;
+            uint8_t* o = dst + (long long)dy * D.pitch + dx0;
+            for (int i = 0; i < nvalid; i++) {
+                const int w0 = (short)(aa[i] & 0xFFFF), w1 = (short)(aa[i] >> 16);
+                const int sx1 = min(sx[i] + 1, S.w - 1);
+                const int h0 = r0[sx[i]] * w0 + r0[sx1] * w1;
+                const int h1 = r1[sx[i]] * w0 + r1[sx1] * w1;
+                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                o[i] = (uint8_t)min(max(v, 0), 255);
+            }
+        }
     }
 }
 
@@ -379,15 +406,24 @@ __device__ __forceinline__ int quadrant(unsigned key, short4 bx) {
 // position of candidate k's node.  Every pass (a) histograms children of all multi-key nodes, (b) picks the set
 // of nodes that upstream would split in this pass and their processing order, (c) lays out the new list exactly
 // as upstream's push_front/erase sequence would leave it.
-__global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
-                                                  const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
-                                                  unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
-                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int wtmp[kQT / 64];
-    __shared__ int sh_S, sh_phase, sh_done, sh_rstar, sh_nexp;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int l = blockIdx.x, f = blockIdx.y + f0;
+struct QtArgs {
+    const Geom* g; const unsigned* cellcand; const int* cellcnt; unsigned* levelkps; int* levelcnt; int f, l, M;
+    long long* dbg;
+    unsigned* candOut;   // global copy of the gathered candidates (read back by eao_orb_level_candidates)
+};
+
+// The candidate keys and their node index live in LDS when the level's M candidates fit the launch's LDS budget
+// (g->qtLdsCand; always at the default 1000-feature settings), else in the global scratch arrays: the body is inlined
+// once per placement.
+template <class KeyPtr, class NofPtr>
+__device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* smem, int* wtmp, int* shv, KeyPtr keys, NofPtr nof) {
+    const Geom* __restrict__ g = A.g;
+    int& sh_S = shv[0]; int& sh_phase = shv[1]; int& sh_done = shv[2]; int& sh_rstar = shv[3]; int& sh_nexp = shv[4];
+    long long* dbg = A.dbg;
+    long long dacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dlast = clock64();
+#define QSTAMP(i) do { if (dbg) { const long long now_ = clock64(); dacc[i] += now_ - dlast; dlast = now_; } } while (0)
+    const int t = threadIdx.x;
+    const int l = A.l, f = A.f, M = A.M;
     const LevelGeom L = g->L[l];
     const int LC = L.listCap, N = L.quota;
     // ---- LDS carve-up
@@ -404,27 +440,24 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
     int* vlist = order + LC;
     int* procRank = vlist + LC;
     int* scanB = procRank + LC;
-    int* scanA = scanB + LC;            // g->scanCap entries (>= LC and >= nCells)
+    int* scanA = scanB + LC;            // g->scanCap entries (>= LC and >= nCells); holds the exclusive cell prefix on entry
 
-    unsigned* keys = cand + (long long)f * g->totalCandCap + L.candBase;
-    unsigned short* nof = nodeof + (long long)f * g->totalCandCap + L.candBase;
-
-    // ---- gather this level's candidates in upstream order: cells row-major, corners row-major inside a cell
+    // ---- gather this level's candidates in upstream order: cells row-major, corners row-major inside a cell.  One
+    // thread per cell, four independent loads in flight (a cell holds a handful of corners).
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
-    for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
-    __syncthreads();
-    const int M = block_excl_scan(scanA, L.nCells, wtmp);
-    for (int c = wv; c < L.nCells; c += kQT / 64) {
-        const int n = cellcnt[cslot + c], o = scanA[c];
-        const unsigned* srcc = cellcand + (cslot + c) * g->cellCap;
-        for (int j = lane; j < n; j += 64) keys[o + j] = srcc[j];
+    for (int c = t; c < L.nCells; c += kQT) {
+        const int o = scanA[c], n = (c + 1 < L.nCells ? scanA[c + 1] : M) - o;
+        const unsigned* srcc = A.cellcand + (cslot + c) * g->cellCap;
+        for (int j0 = 0; j0 < n; j0 += 4) {
+            unsigned v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = srcc[min(j0 + u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (j0 + u < n) { keys[o + j0 + u] = v[u]; A.candOut[o + j0 + u] = v[u]; }
+        }
     }
-    if (t == 0) candcnt[f * g->nlevels + l] = M;
     __syncthreads();
-    if (M == 0) {
-        if (t == 0) levelcnt[f * g->nlevels + l] = 0;
-        return;
-    }
     // ---- initial nodes
     const int nIni = L.nIni;
     if (t < nIni) {
@@ -433,10 +466,17 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
         crk0[t] = t;
     }
     __syncthreads();
-    for (int k = t; k < M; k += kQT) {
-        const int ini = min((int)((float)(keys[k] & 0xFFF) / L.hX), nIni - 1);
-        atomicAdd(&cnt0[ini], 1);
-        nof[k] = (unsigned short)ini;
+    for (int k0 = 0; k0 < M; k0 += kQT) {   // (every candidate lands in one of <= 16 nodes: count by ballot, not by 3000 atomics on one word)
+        const int k = k0 + t;
+        int ini = -1;
+        if (k < M) {
+            ini = min((int)((float)(keys[k] & 0xFFF) / L.hX), nIni - 1);
+            nof[k] = (unsigned short)ini;
+        }
+        for (int i = 0; i < nIni; i++) {
+            const unsigned long long m = __ballot(ini == i);
+            if (m && (t & 63) == 0) atomicAdd(&cnt0[i], __popcll(m));
+        }
     }
     __syncthreads();
     if (t == 0) {  // drop empty initial nodes (nIni <= 16)
@@ -453,6 +493,8 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
         __syncthreads();
     }
 
+    QSTAMP(0);
+    int diters = 0;
     short4* box = box0; short4* nbox = box1;
     int* cnt = cnt0; int* ncnt = cnt1;
     int* crk = crk0; int* ncrk = crk1;
@@ -467,6 +509,7 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
         if (t == 0) { sh_rstar = 0x7FFFFFFF; sh_nexp = 0; }
         __syncthreads();
         const int nCand = block_excl_scan(scanA, S, wtmp);
+        QSTAMP(1);
         for (int i = t; i < S; i += kQT)
             if (cnt[i] > 1) vlist[scanA[i]] = i;
         // (2) child histograms of every candidate
@@ -475,21 +518,28 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
             if (cnt[nd] > 1) atomicAdd(&childcnt[4 * nd + quadrant(keys[k], box[nd])], 1);
         }
         __syncthreads();
+        QSTAMP(2);
         // (3) processing order: list order (full pass) or (size, creation rank) descending (careful pass)
         if (phase == 0) {
             for (int j = t; j < nCand; j += kQT) order[j] = vlist[j];
         } else {
+            // rank by (size, creation rank) descending: the two sort fields are first laid out densely (newpos / scanB
+            // are free here) so that the counting loop reads independent, broadcast LDS words
+            for (int j = t; j < nCand; j += kQT) { const int me = vlist[j]; newpos[j] = cnt[me]; scanB[j] = crk[me]; }
+            __syncthreads();
             for (int j = t; j < nCand; j += kQT) {
-                const int me = vlist[j], ms = cnt[me], mr = crk[me];
+                const int ms = newpos[j], mr = scanB[j];
                 int r = 0;
+#pragma unroll 8
                 for (int u = 0; u < nCand; u++) {
-                    const int o = vlist[u], os = cnt[o], orr = crk[o];
+                    const int os = newpos[u], orr = scanB[u];
                     r += (os > ms) || (os == ms && orr > mr);
                 }
-                order[r] = me;
+                order[r] = vlist[j];
             }
         }
         __syncthreads();
+        QSTAMP(3);
         // (4) growth prefix in processing order; the careful pass stops at the first prefix reaching N
         for (int r = t; r < nCand; r += kQT) {
             const int i = order[r];
@@ -505,6 +555,7 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
             }
         }
         __syncthreads();
+        QSTAMP(4);
         const int nProc = (phase == 1 && sh_rstar != 0x7FFFFFFF) ? sh_rstar + 1 : nCand;
         int totalChildren = 0;
         if (nProc > 0) {
@@ -516,6 +567,7 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
         for (int i = t; i < S; i += kQT) scanB[i] = procRank[i] < 0 ? 1 : 0;
         __syncthreads();
         block_excl_scan(scanB, S, wtmp);
+        QSTAMP(5);
         // (5) new list: children of the LAST processed node first (each as n4,n3,n2,n1), untouched entries after
         int myexp = 0;
         for (int i = t; i < S; i += kQT) {
@@ -545,6 +597,7 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
         }
         if (myexp) atomicAdd(&sh_nexp, myexp);
         __syncthreads();
+        QSTAMP(6);
         // (6) re-home the candidates
         for (int k = t; k < M; k += kQT) {
             const int nd = nof[k];
@@ -558,6 +611,8 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
             else if (phase == 0 && S2 + 3 * sh_nexp > N) sh_phase = 1;
         }
         __syncthreads();
+        QSTAMP(7);
+        diters++;
         short4* tb = box; box = nbox; nbox = tb;
         int* ti = cnt; cnt = ncnt; ncnt = ti;
         ti = crk; crk = ncrk; ncrk = ti;
@@ -569,12 +624,48 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
     __syncthreads();
     for (int k = t; k < M; k += kQT) atomicMax(&best[nof[k]], ((keys[k] >> 24) << 20) | (0xFFFFFu - (unsigned)k));
     __syncthreads();
-    unsigned* out = levelkps + (long long)f * g->totalKpCap + L.kpBase;
+    unsigned* out = A.levelkps + (long long)f * g->totalKpCap + L.kpBase;
     for (int i = t; i < S; i += kQT) {
         const unsigned k = 0xFFFFFu - (best[i] & 0xFFFFFu);
         out[i] = keys[k];
     }
-    if (t == 0) levelcnt[f * g->nlevels + l] = S;
+    if (t == 0) A.levelcnt[f * g->nlevels + l] = S;
+    QSTAMP(8);
+    if (dbg && t == 0 && A.dbg) {
+        long long* o = dbg + 16 * l;
+        for (int i = 0; i < 9; i++) o[i] = dacc[i];
+        o[9] = diters; o[10] = M; o[11] = S;
+    }
+#undef QSTAMP
+}
+
+__global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
+                                                  const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
+                                                  unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
+                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0, long long* dbg) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int wtmp[kQT / 64];
+    __shared__ int shv[8];
+    const int t = threadIdx.x;
+    const int l = blockIdx.x, f = blockIdx.y + f0;
+    const LevelGeom L = g->L[l];
+    int* scanA = reinterpret_cast<int*>(smem + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)));
+    const long long cslot = (long long)f * g->totalCells + L.cellBase;
+    for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
+    __syncthreads();
+    const int M = block_excl_scan(scanA, L.nCells, wtmp);
+    if (t == 0) candcnt[f * g->nlevels + l] = M;
+    if (M == 0) {
+        if (t == 0) levelcnt[f * g->nlevels + l] = 0;
+        return;
+    }
+    QtArgs A = {g, cellcand, cellcnt, levelkps, levelcnt, f, l, M, (dbg && f == f0) ? dbg : nullptr, cand + (long long)f * g->totalCandCap + L.candBase};
+    if (M <= g->qtLdsCand) {
+        unsigned* keysL = reinterpret_cast<unsigned*>(smem + g->qtKeysOff);
+        quadtree_body(A, smem, wtmp, shv, keysL, reinterpret_cast<unsigned short*>(keysL + g->qtLdsCand));
+    } else {
+        quadtree_body(A, smem, wtmp, shv, cand + (long long)f * g->totalCandCap + L.candBase, nodeof + (long long)f * g->totalCandCap + L.candBase);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- blur
@@ -583,69 +674,152 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-// Tile = 256 px (64 lanes x 4 px) wide, 64 rows (4 waves x 16 rows) high.  Each lane streams down its 4-px column
-// strip: per source row three aligned u32 loads (12 bytes cover x-3..x+6), a horizontal 7-tap pass in registers, a
-// 7-deep register window of row results and the vertical pass; one packed u32 store per row.  No LDS; edge lanes
-// (window crossing the image border, or an unaligned caller buffer) take a byte-wise reflect-101 path.
-constexpr int kBlurRows = 16;   // output rows per wave
-__device__ __forceinline__ void blur_hpass(const uint8_t* __restrict__ row, int x4, int w, bool fast, unsigned hres[4]) {
-    unsigned p[10];
-    if (fast) {
-        const unsigned* q = reinterpret_cast<const unsigned*>(row + x4);
-        const unsigned w0 = q[-1], w1 = q[0], w2 = q[1];
-        p[0] = (w0 >> 8) & 0xFF; p[1] = (w0 >> 16) & 0xFF; p[2] = w0 >> 24;
-        p[3] = w1 & 0xFF; p[4] = (w1 >> 8) & 0xFF; p[5] = (w1 >> 16) & 0xFF; p[6] = w1 >> 24;
-        p[7] = w2 & 0xFF; p[8] = (w2 >> 8) & 0xFF; p[9] = (w2 >> 16) & 0xFF;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 10; k++) p[k] = row[reflect101(x4 - 3 + k, w)];
-    }
-    // taps round(k*256) of getGaussianKernel(7, 2): 18 34 49 55 49 34 18 (host-verified at handle creation)
-#pragma unroll
-    for (int i = 0; i < 4; i++) hres[i] = 18u * (p[i] + p[i + 6]) + 34u * (p[i + 1] + p[i + 5]) + 49u * (p[i + 2] + p[i + 4]) + 55u * p[i + 3];
+// Strip = 128 px (32 lanes x 4 px) wide, 16 rows high; a workgroup of 8 half-waves takes 8 consecutive strips of a level
+// (x fastest), so only the last workgroup of a level and strips hanging over the right / bottom edge idle lanes.
+// Per source row a lane loads the three aligned words around its 4 pixels (one dwordx3), the horizontal pass is two
+// v_dot4_u32_u8 per pixel on v_alignbyte windows, two rows of 16-bit results are paired in one register and the
+// vertical pass is four v_dot2_u32_u16 per pixel on a 4-deep window of row pairs; one packed store per row.  No LDS.
+// Borders: in waves that touch the left / right image edge each lane carries three v_perm selectors (built once) that
+// rebuild the reflect-101 window from the words it could load in bounds; rows reflect through their index.  An
+// unaligned caller image (level 0 only) takes a byte-wise variant of the same loop.
+constexpr int kBlurRows = 16;    // output rows per strip
+constexpr int kBlurSegW = 128;   // strip width
+constexpr int kBlurStripsPerWg = 8;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned udot2(unsigned a, unsigned b, unsigned c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
-__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur, int f0) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y + f0;
+struct BlurEdge {   // per-lane reconstruction of the 12-byte window x4-4 .. x4+7 (MODE 1)
+    int off0;       // byte offset (inside the row) of the first loaded word
+    bool left;      // window pools: W1, W2 come from (L0, L1) instead of (L1, L2)
+    unsigned selA, selB, selC;
+};
+
+__device__ __forceinline__ BlurEdge blur_edge(int x4, int w) {
+    BlurEdge e;
+    const int wi = x4 >> 2, wmax = (w - 1) >> 2;
+    const int wi0 = min(max(wi - 1, 0), wmax - 2);
+    e.off0 = 4 * wi0;
+    e.left = wi == 0;
+    e.selA = e.selB = e.selC = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        int x = min(max(x4 - 4 + k, -3), w + 2);     // (bytes further out carry a zero tap or feed pixels beyond the row)
+        x = x < 0 ? -x : x;
+        x = min(x, 2 * w - 2 - x);                   // reflect-101, one fold is enough here
+        const int m = min(max(x - 4 * wi0, 0), 11);  // loaded byte holding logical byte k
+        if (k < 4) e.selA |= (unsigned)min(m, 7) << (8 * k);
+        else {
+            const unsigned q = (unsigned)min(max(e.left ? m : m - 4, 0), 7) << (8 * (k & 3));
+            if (k < 8) e.selB |= q; else e.selC |= q;
+        }
+    }
+    return e;
+}
+
+// MODE 0: interior wave (every lane's window is inside the row); 1: wave touching a border; 2: byte-wise loads
+template <int MODE>
+__device__ __forceinline__ void blur_load(const uint8_t* __restrict__ row, int x4, int w, const BlurEdge& e, unsigned L[3]) {
+    if (MODE == 0) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(row + x4 - 4);
+        L[0] = q[0]; L[1] = q[1]; L[2] = q[2];
+    } else if (MODE == 1) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(row + e.off0);
+        L[0] = q[0]; L[1] = q[1]; L[2] = q[2];
+    } else {
+        L[0] = L[1] = L[2] = 0;
+#pragma unroll
+        for (int k = 1; k < 11; k++) L[k >> 2] |= (unsigned)row[reflect101(x4 - 4 + k, w)] << (8 * (k & 3));
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void blur_hpass(const unsigned L[3], const BlurEdge& e, unsigned hres[4]) {
+    unsigned W0 = L[0], W1 = L[1], W2 = L[2];
+    if (MODE == 1) {
+        const unsigned a = e.left ? L[0] : L[1], b = e.left ? L[1] : L[2];
+        W0 = __builtin_amdgcn_perm(L[1], L[0], e.selA);
+        W1 = __builtin_amdgcn_perm(b, a, e.selB);
+        W2 = __builtin_amdgcn_perm(b, a, e.selC);
+    }
+    // taps round(k*256) of getGaussianKernel(7, 2): 18 34 49 55 49 34 18 (host-verified at handle creation)
+    constexpr unsigned T0 = 18u | 34u << 8 | 49u << 16 | 55u << 24, T1 = 49u | 34u << 8 | 18u << 16;
+    hres[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 1), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 1), T1, 0, false), false);
+    hres[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 2), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 2), T1, 0, false), false);
+    hres[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 3), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 3), T1, 0, false), false);
+    hres[3] = __builtin_amdgcn_udot4(W1, T0, __builtin_amdgcn_udot4(W2, T1, 0, false), false);
+}
+
+// The loop is branch-free (rows below the image land in the padding rows every level of the blur buffer carries), so
+// the loads of the next row pairs are issued before the arithmetic of the current one.
+template <int MODE>
+__device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int pitch, uint8_t* __restrict__ dst, int dpitch, int x4, int y0, int w, int h) {
+    BlurEdge e = {};
+    if (MODE == 1) e = blur_edge(x4, w);
+    constexpr int NP = (kBlurRows + 6) / 2;   // source row pairs
+    constexpr int PF = MODE == 2 ? 1 : 3;     // row pairs in flight
+    unsigned raw[NP][2][3];
+    auto fetch = [&](int m) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            int t = y0 - 3 + 2 * m + q;
+            t = t < 0 ? -t : t;
+            t = min(t, 2 * h - 2 - t);
+            blur_load<MODE>(src + __umul24(t, pitch), x4, w, e, raw[m][q]);
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < PF; m++) fetch(m);
+    unsigned P[4][4];   // P[m & 3][i] = horizontal results of source rows 2m (low half) and 2m+1 (high half), pixel i
+#pragma unroll
+    for (int m = 0; m < NP; m++) {
+        if (m + PF < NP) fetch(m + PF);
+        unsigned hr[2][4];
+        blur_hpass<MODE>(raw[m][0], e, hr[0]);
+        blur_hpass<MODE>(raw[m][1], e, hr[1]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) P[m & 3][i] = hr[0][i] | (hr[1][i] << 16);
+        if (m >= 3) {
+            // even output row 2(m-3): source rows 2(m-3) .. 2m hold taps 0..6; odd row 2(m-3)+1: rows 2(m-3)+1 .. 2m+1
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const unsigned K0 = q ? 18u << 16 : (18u | 34u << 16), K1 = q ? (34u | 49u << 16) : (49u | 55u << 16),
+                               K2 = q ? (55u | 49u << 16) : (49u | 34u << 16), K3 = q ? (34u | 18u << 16) : 18u;
+                unsigned sv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    sv[i] = udot2(P[(m - 3) & 3][i], K0, udot2(P[(m - 2) & 3][i], K1, udot2(P[(m - 1) & 3][i], K2, udot2(P[m & 3][i], K3, 32768u))));
+                // (sv >> 16) saturated to 255, four to a word
+                const u16x2 lim = {255, 255};
+                const u16x2 pa = __builtin_elementwise_min(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(sv[1], sv[0], 0x07060302u)), lim);
+                const u16x2 pb = __builtin_elementwise_min(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(sv[3], sv[2], 0x07060302u)), lim);
+                const unsigned packed = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, pb), __builtin_bit_cast(unsigned, pa), 0x06040200u);
+                const int y = y0 + 2 * (m - 3) + q;
+                // (pitch is a multiple of 64 and the level holds a multiple of kBlurRows rows: tails land in padding)
+                *reinterpret_cast<unsigned*>(dst + __umul24(y, dpitch) + x4) = packed;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur, int f0, int src0Aligned) {
+    const int lane = threadIdx.x & 31, f = blockIdx.y + f0;
     int l = 0;
     while (l + 1 < g->nlevels && (int)blockIdx.x >= g->L[l + 1].tileBase) l++;
     // (upstream blurs only levels that hold keypoints, :1081-1082; blurring all of them changes no output and removes
     //  the dependency on the quad-tree, so this kernel can overlap it)
     const LevelGeom L = g->L[l];
-    const int tile = blockIdx.x - L.tileBase;
-    const int x4 = (tile % L.tilesX) * 256 + lane * 4;
-    const int y0 = (tile / L.tilesX) * (4 * kBlurRows) + wv * kBlurRows;
+    const int strip = ((int)blockIdx.x - L.tileBase) * kBlurStripsPerWg + (int)(threadIdx.x >> 5);
+    const int x4 = (strip % L.tilesX) * kBlurSegW + lane * 4;
+    const int y0 = (strip / L.tilesX) * kBlurRows;
     if (x4 >= L.w || y0 >= L.h) return;
     int pitch;
     const uint8_t* src = level_ptr(g, s, l, f, &pitch);
-    const bool aligned = (((uintptr_t)src | (uintptr_t)pitch) & 3) == 0;
-    const bool fast = aligned && x4 >= 4 && x4 + 7 < L.w;
     uint8_t* dst = blur + (long long)f * g->pyrFrameBytes + L.off;
-    unsigned win[7][4];
-#pragma unroll
-    for (int r = 0; r < kBlurRows + 6; r++) {
-        const int sy = reflect101(y0 - 3 + r, L.h);
-        unsigned hr[4];
-        blur_hpass(src + (long long)sy * pitch, x4, L.w, fast, hr);
-#pragma unroll
-        for (int i = 0; i < 4; i++) win[r % 7][i] = hr[i];
-        if (r >= 6) {
-            const int y = y0 + r - 6;
-            if (y < L.h) {
-                unsigned packed = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    // rows r-6 .. r of the window hold taps 0..6
-                    const unsigned sv = 18u * (win[(r - 6) % 7][i] + win[r % 7][i]) + 34u * (win[(r - 5) % 7][i] + win[(r - 1) % 7][i]) +
-                                        49u * (win[(r - 4) % 7][i] + win[(r - 2) % 7][i]) + 55u * win[(r - 3) % 7][i];
-                    packed |= min((sv + 32768u) >> 16, 255u) << (8 * i);
-                }
-                uint8_t* o = dst + (long long)y * L.pitch + x4;
-                if (x4 + 3 < L.w) *reinterpret_cast<unsigned*>(o) = packed;
-                else for (int i = 0; x4 + i < L.w; i++) o[i] = (uint8_t)(packed >> (8 * i));
-            }
-        }
-    }
+    if (l == 0 && !src0Aligned) blur_strip<2>(src, pitch, dst, L.pitch, x4, y0, L.w, L.h);
+    else if (__any(x4 < 4 || x4 + 7 > L.w)) blur_strip<1>(src, pitch, dst, L.pitch, x4, y0, L.w, L.h);
+    else blur_strip<0>(src, pitch, dst, L.pitch, x4, y0, L.w, L.h);
 }
 
 // ---------------------------------------------------------------------------------------------- orientation + rBRIEF
@@ -947,6 +1121,7 @@ struct eao_orb {
     ImgSrc lastSrc{};
     int lastBatch = 0;
     bool profiling = false;
+    long long* d_dbg = nullptr;   // EAO_DEBUG_STAMPS: per-level phase cycles of k_quadtree (diagnostic runs only)
     hipGraphExec_t graphExec = nullptr;
     GraphKey graphKey = {};
     std::vector<hipEvent_t> evs;   // 9 events per profiled call, averaged by eao_orb_last_timing
@@ -985,7 +1160,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         LevelGeom& L = g.L[l];
         L.pitch = (L.w + 63) & ~63;
         L.off = off;
-        off += ((L.pitch * L.h) + 255) & ~255;
+        off += ((L.pitch * ((L.h + kBlurRows - 1) / kBlurRows * kBlurRows)) + 255) & ~255;   // (padding rows: see k_blur7)
         const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
         const float width = (float)(maxBX - kMinBorder), height = (float)(maxBY - kMinBorder);
         const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
@@ -1020,8 +1195,8 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         L.kpBase = kpBase; kpBase += L.listCap;
         L.candBase = candBase; L.candCap = L.nCells * g.cellCap; candBase += L.candCap;
         EAO_REQUIRE(L.candCap < (1 << 20), "level %d can hold %d FAST candidates; the quad-tree packs indices in 20 bits", l, L.candCap);
-        L.tilesX = eao::cdiv(L.w, 256);
-        L.tileBase = tileBase; tileBase += L.tilesX * eao::cdiv(L.h, 4 * kBlurRows);
+        L.tilesX = eao::cdiv(L.w, kBlurSegW);
+        L.tileBase = tileBase; tileBase += eao::cdiv(L.tilesX * eao::cdiv(L.h, kBlurRows), kBlurStripsPerWg);
         L.scale = h->scale[l];
         L.scaledPatch = (int)(31 * h->scale[l]);
         scanCap = std::max(scanCap, std::max(L.listCap, L.nCells));
@@ -1069,6 +1244,11 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
     h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (size_t)scanCap * sizeof(int);
     EAO_REQUIRE(h->quadLds <= 150 * 1024, "nfeatures too large: quad-tree needs %zu bytes of LDS", h->quadLds);
+    // candidate keys (4 B) + node indices (2 B) in LDS while two workgroups still fit a CU
+    h->quadLds = (h->quadLds + 15) & ~(size_t)15;
+    g.qtKeysOff = (int)h->quadLds;
+    g.qtLdsCand = (int)std::min<size_t>(8192, h->quadLds < 76 * 1024 ? (76 * 1024 - h->quadLds) / 6 : 0) & ~7;
+    h->quadLds += (size_t)g.qtLdsCand * 6;
     // the blur kernel hard-codes the taps; make sure the published construction gives them
     {
         float cf[7]; double sum = 0;
@@ -1105,6 +1285,10 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
             EAO_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evDone[i], hipEventDisableTiming));
         }
+    }
+    if (!h->d_dbg && getenv("EAO_DEBUG_STAMPS")) {
+        EAO_HIP(hipMalloc(&h->d_dbg, 16 * kMaxLevels * sizeof(long long)));
+        EAO_HIP(hipMemset(h->d_dbg, 0, 16 * kMaxLevels * sizeof(long long)));
     }
     if (!h->geomValid || h->geom.W != W || h->geom.H != H) {
         st = build_geometry(h, W, H);
@@ -1173,16 +1357,19 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             EAO_HIP(hipEventRecord(h->evFast0[i], ss));
         }
         for (int l = 1; l < g.nlevels; l++) {
-            dim3 grid(eao::cdiv(g.L[l].w, 256), eao::cdiv(g.L[l].h, 4), nb), block(64, 4);
+            dim3 grid(eao::cdiv(g.L[l].w, 256), eao::cdiv(g.L[l].h, 4 * kResizeRows), nb), block(64, 4);
             hipLaunchKernelGGL(k_resize, grid, block, 0, ms, h->d_geom.p, h->d_tab.p, s, l, f0);
         }
         if (pe) EAO_HIP(hipEventRecord(ev[1], ms));
         EAO_HIP(hipEventRecord(h->evFork[i], ms));
         EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
         if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
-        hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0);
+        // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
+        const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
         if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
         EAO_HIP(hipEventRecord(h->evJoin[i], ss));
+        if (prof) EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));   // profiled calls: the blur runs alone, then FAST
         if (early0) {
             fast(ms, cells0, g.totalCells);
             EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
@@ -1191,7 +1378,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
         hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nb), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
-                           h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0);
+                           h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg);
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
         if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
@@ -1442,6 +1629,15 @@ eao_status eao_orb_last_timing(eao_orb* h, float ms[6]) {
     }
     for (int i = 0; i < 6; i++) ms[i] = (float)(acc[i] / calls);
     h->evUsed = 0;
+    if (h->d_dbg) {
+        long long st[16 * kMaxLevels];
+        EAO_HIP(hipMemcpy(st, h->d_dbg, sizeof(st), hipMemcpyDeviceToHost));
+        for (int l = 0; l < h->geom.nlevels; l++) {
+            const long long* o = st + 16 * l;
+            fprintf(stderr, "[eao quadtree stamps] level %d: M %lld S %lld passes %lld | setup %lld | multi-scan %lld hist %lld order %lld growth %lld rank %lld newlist %lld rehome %lld tail %lld | final %lld cycles\n",
+                    l, o[10], o[11], o[9], o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], 0LL, o[8]);
+        }
+    }
     return EAO_OK;
 }
 

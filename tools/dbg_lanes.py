@@ -14,10 +14,11 @@ def dmalloc(n):
 d_img=dmalloc(imgs.nbytes); hip.hipMemcpy(d_img, imgs.ctypes.data, imgs.nbytes, 1)
 d_k=dmalloc(B*cap*28); d_d=dmalloc(B*cap*32); d_n=dmalloc(B*4)
 def step(): _lib.check(L.eao_orb_extract_batch_device(ext._h, d_img, W,H,W,W*H,B,d_k,d_d,cap,d_n,None))
+if os.environ.get('EAO_DBG_PROF'): ext.set_profiling(True)   # stages run one after the other
 for _ in range(3): step()
 hip.hipDeviceSynchronize()
 t=time.perf_counter()
-K=30
+K=int(os.environ.get("EAO_DBG_STEPS", "30"))
 for _ in range(K): step()
 hip.hipDeviceSynchronize()
 print("lanes", os.environ.get("EAO_ORB_LANES"), "graph", os.environ.get("EAO_ORB_GRAPH"), "ms/step %.4f" % ((time.perf_counter()-t)/K*1e3))
