@@ -52,7 +52,6 @@ struct LevelGeom {
     int listCap;               // node-list / keypoint capacity of this level
     int kpBase;                // first keypoint slot of this level inside a frame
     int candBase, candCap;     // candidate scratch of this level inside a frame
-    int tabBase;               // resize coefficient tables (int2): (xofs, xalpha)[w] then (yofs, ybeta)[h]
     int tileBase, tilesX;      // blur: first workgroup of this level, 128-px strips per row of strips
     int scaledPatch;
     float scale;
@@ -96,32 +95,52 @@ __device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const ImgSrc&
 // row (scale factors up to 2): three u32 loads per source row; one v_perm_b32 per pixel lifts its byte pair into two
 // 16-bit halves, v_dot2_u32_u16 applies the column weights and v_mul_hi_u32 the row weights (all weights are >= 0 and
 // sum to 2048, so the result needs no clamp).  A lane produces 4 px of kResizeRows output rows: the column set-up
-// (table loads, selectors) is shared between the rows.
-constexpr int kResizeRows = 8;
+// (coefficients, selectors) is shared between the rows.
+constexpr int kResizeRows = 4;
 __device__ __forceinline__ unsigned udot2w(unsigned a, unsigned b) {
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), 0u, false);
 }
 
-__global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, const int* __restrict__ tab, ImgSrc s, int l, int f0) {
-    const LevelGeom D = g->L[l];
-    const LevelGeom S = g->L[l - 1];
+// Everything the kernel needs about the two levels travels in the kernel arguments and the bilinear coefficients are
+// computed in the kernel (the same float / double expressions OpenCV 3.3.x evaluates on the host: (float)((d + 0.5) *
+// inv_scale - 0.5), floor, cvRound(w * 2048)), so a wave's only dependent memory accesses are its image loads: the
+// seven launches of the pyramid chain are latency-, not bandwidth-bound.
+struct ResizeLevel { int w, h, pitch, off; };
+struct ResizeArgs {
+    ResizeLevel D, S;
+    double invX, invY;       // 1 / (D.w / S.w), 1 / (D.h / S.h)
+    int srcIsInput;          // level l-1 is the caller's image
+    int pyrFrameBytes;
+};
+
+__device__ __forceinline__ void resize_coef(int d, double inv, int slimit, bool clampHi, int* ofs, unsigned* wpair) {
+    float fr = (float)(((double)d + 0.5) * inv - 0.5);
+    int o = (int)floorf(fr);
+    fr -= (float)o;
+    if (clampHi) {   // columns only (rows are clamped at the load, with their weights kept)
+        if (o < 0) { fr = 0; o = 0; }
+        if (o >= slimit - 1) { fr = 0; o = slimit - 1; }
+    }
+    const int w0 = min(max(__float2int_rn((1.f - fr) * 2048.f), -32768), 32767);
+    const int w1 = min(max(__float2int_rn(fr * 2048.f), -32768), 32767);
+    *ofs = o;
+    *wpair = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
+}
+
+__global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) {
+    const ResizeLevel D = A.D, S = A.S;
     const int f = blockIdx.z + f0;
     const int dyb = (blockIdx.y * 4 + threadIdx.y) * kResizeRows;
     const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     if (dyb >= D.h || dx0 >= D.w) return;
-    int spitch;
-    const uint8_t* src = level_ptr(g, s, l - 1, f, &spitch);
-    uint8_t* dst = s.pyr + (long long)f * g->pyrFrameBytes + D.off;
-    const int2* xt = reinterpret_cast<const int2*>(tab + D.tabBase);   // (xofs, alpha0 | alpha1 << 16) per output column
-    const int2* yt = xt + D.w;                                          // (yofs, beta0 | beta1 << 16) per output row
+    const int spitch = A.srcIsInput ? s.pitch0 : S.pitch;
+    const uint8_t* src = A.srcIsInput ? s.img0 + (long long)f * s.fs0 : s.pyr + (long long)f * A.pyrFrameBytes + S.off;
+    uint8_t* dst = s.pyr + (long long)f * A.pyrFrameBytes + D.off;
     int sx[4];
     unsigned aa[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int2 e = xt[min(dx0 + i, D.w - 1)];
-        sx[i] = e.x; aa[i] = (unsigned)e.y;
-    }
+    for (int i = 0; i < 4; i++) resize_coef(min(dx0 + i, D.w - 1), A.invX, S.w, true, &sx[i], &aa[i]);
     const int wb = sx[0] >> 2, wmax = (S.w - 1) >> 2;
     const bool fast = ((((uintptr_t)src | (uintptr_t)spitch) & 3) == 0) && (sx[3] + 1 - 4 * wb < 12);
     if (fast) {
@@ -140,9 +159,10 @@ __global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, cons
         unsigned raw[kResizeRows][6], B0[kResizeRows], B1[kResizeRows];
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
-            const int2 yy = yt[min(dyb + r, D.h - 1)];
-            B0[r] = (unsigned)yy.y << 16; B1[r] = (unsigned)yy.y & 0xFFFF0000u;   // beta << 16
-            const int sy0 = min(max(yy.x, 0), S.h - 1), sy1 = min(max(yy.x + 1, 0), S.h - 1);
+            int yo; unsigned yw;
+            resize_coef(min(dyb + r, D.h - 1), A.invY, S.h, false, &yo, &yw);
+            B0[r] = yw << 16; B1[r] = yw & 0xFFFF0000u;   // beta << 16
+            const int sy0 = min(max(yo, 0), S.h - 1), sy1 = min(max(yo + 1, 0), S.h - 1);
             const uint8_t* r0 = src + __umul24(sy0, spitch);
             const uint8_t* r1 = src + __umul24(sy1, spitch);
             raw[r][0] = *reinterpret_cast<const unsigned*>(r0 + i0); raw[r][1] = *reinterpret_cast<const unsigned*>(r0 + i1);
@@ -170,9 +190,10 @@ __global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, cons
         for (int r = 0; r < kResizeRows; r++) {
             const int dy = dyb + r;
             if (dy >= D.h) break;
-            const int2 yy = yt[dy];
-            const int b0 = (short)(yy.y & 0xFFFF), b1 = (short)(yy.y >> 16);
-            const int sy0 = min(max(yy.x, 0), S.h - 1), sy1 = min(max(yy.x + 1, 0), S.h - 1);
+            int yo; unsigned yw;
+            resize_coef(dy, A.invY, S.h, false, &yo, &yw);
+            const int b0 = (short)(yw & 0xFFFF), b1 = (short)(yw >> 16);
+            const int sy0 = min(max(yo, 0), S.h - 1), sy1 = min(max(yo + 1, 0), S.h - 1);
             const uint8_t* r0 = src + (long long)sy0 * spitch;
             const uint8_t* r1 = src + (long long)sy1 * spitch;
             uint8_t* o = dst + (long long)dy * D.pitch + dx0;
@@ -873,7 +894,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict__ g, ImgSrc s, const uint8_t* __restrict__ blur,
                                                          const unsigned* __restrict__ levelkps, const int* __restrict__ levelcnt,
                                                          eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                         int* __restrict__ nout, int cap, int f0) {
+                                                         int* __restrict__ nout, int cap, int f0, int nlevels) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int f = blockIdx.y + f0;
     // the lane's four test pairs (xa, ya, xb, yb as int8) depend on nothing: fetch them first, under the other loads
@@ -882,21 +903,39 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const unsigned*>(c_pattern)[lane + 64 * k];
     int j = blockIdx.x * 4 + wv;   // compact output index inside the frame
     const int jout = j;
-    int l = -1, total = 0;
-    for (int q = 0; q < g->nlevels; q++) {
-        const int c = levelcnt[f * g->nlevels + q];
-        if (l < 0) {
-            if (j < c) l = q; else j -= c;
-        }
-        total += c;
+    // level of compact index j: lane q holds the count of level q (one vector load instead of nlevels dependent scalar
+    // loads), an inclusive wave scan gives the level boundaries
+    const int myc = lane < nlevels ? levelcnt[f * nlevels + lane] : 0;
+    int incl = myc;
+#pragma unroll
+    for (int dlt = 1; dlt < kMaxLevels; dlt <<= 1) {
+        const int o = __shfl_up(incl, dlt);
+        if (lane >= dlt) incl += o;
     }
+    const int total = __shfl(incl, kMaxLevels - 1);
+    const unsigned long long below = __ballot(lane < nlevels && incl <= j);   // levels that end at or before j
+    const int l = __popcll(below);
     if (blockIdx.x == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
-    if (l < 0 || jout >= cap) return;
+    if (l >= nlevels || jout >= cap) return;
+    j -= l ? __shfl(incl, l - 1) : 0;
     const LevelGeom L = g->L[l];
     const unsigned key = levelkps[(long long)f * g->totalKpCap + L.kpBase + j];
     const int cx = (int)(key & 0xFFF) + kMinBorder, cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
     int pitch;
     const uint8_t* img = level_ptr(g, s, l, f, &pitch);
+    // The 256 test pairs, rotated, stay inside radius 18.4 of the keypoint (|pattern| <= sqrt(338)): the 37 x 37 window of
+    // the blurred level is staged in LDS with aligned word loads (6 per lane, issued before the moment loads) and the
+    // 512 scattered byte reads of the wave go to LDS instead of the texture path.
+    constexpr int kPR = 18, kPW = 10;   // window radius; words per staged row (37 + up to 3 bytes of alignment)
+    __shared__ unsigned patch[4][(2 * kPR + 1) * kPW];
+    const int ph = (cx - kPR) & 3;
+    const uint8_t* bw = blur + (long long)f * g->pyrFrameBytes + L.off + (cy - kPR) * L.pitch + (cx - kPR - ph);
+    unsigned pw[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int i = min(lane + 64 * k, (2 * kPR + 1) * kPW - 1), r = (i * 6554) >> 16;   // i / 10
+        pw[k] = *reinterpret_cast<const unsigned*>(bw + r * L.pitch + 4 * (i - r * kPW));
+    }
     // intensity centroid over the radius-15 disc: lanes 0..30 / 32..62 take column u, the halves split the rows
     const int u = (lane & 31) - 15, half = lane >> 5;
     int m10 = 0, m01 = 0;
@@ -927,7 +966,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     sincos_f32_via_f64(angle * factorPI, &b, &a);
-    const uint8_t* bc = blur + (long long)f * g->pyrFrameBytes + L.off + (long long)cy * L.pitch + cx;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        if (lane + 64 * k < (2 * kPR + 1) * kPW) patch[wv][lane + 64 * k] = pw[k];
+    __builtin_amdgcn_wave_barrier();   // (one wave per keypoint: LDS writes of a wave are ordered before its later reads)
+    const uint8_t* bc = reinterpret_cast<const uint8_t*>(patch[wv]) + kPR * (4 * kPW) + kPR + ph;
     unsigned long long words[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -935,7 +978,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
         const float xb = (float)(signed char)((pat[k] >> 16) & 0xFF), yb = (float)(signed char)(pat[k] >> 24);
         const int ra = __float2int_rn(xa * b + ya * a), ca = __float2int_rn(xa * a - ya * b);
         const int rb = __float2int_rn(xb * b + yb * a), cb = __float2int_rn(xb * a - yb * b);
-        const int t0 = bc[(long long)ra * L.pitch + ca], t1 = bc[(long long)rb * L.pitch + cb];
+        const int t0 = bc[ra * (4 * kPW) + ca], t1 = bc[rb * (4 * kPW) + cb];
         words[k] = __ballot(t0 < t1);
     }
     if (lane == 0) {
@@ -1097,7 +1140,6 @@ struct eao_orb {
     bool geomValid = false;
     int batchCap = 0;
     std::vector<CellDesc> cells;
-    std::vector<int> tab;
     size_t quadLds = 0;
     // device state
     hipStream_t stream = nullptr;
@@ -1105,10 +1147,9 @@ struct eao_orb {
     // (EAO_ORB_LANES, default 1: see the measurement note at enqueue())
     static constexpr int kLanes = 4;
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
-    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {};
+    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
-    eao::DevBuf<int> d_tab;
     eao::DevBuf<uint8_t> d_pyr, d_blur, d_in;
     eao::DevBuf<unsigned> d_cellcand, d_cand, d_levelkps;
     eao::DevBuf<unsigned short> d_nodeof;
@@ -1138,7 +1179,6 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     g.iniTh = c.ini_th_fast; g.minTh = c.min_th_fast;
     for (int i = 0; i < 16; i++) g.umax[i] = h->umax[i];
     h->cells.clear();
-    h->tab.clear();
     int off = 0, kpBase = 0, candBase = 0, tileBase = 0, maxCell = 0, scanCap = 0, maxList = 0, maxSw = 0, maxSh = 0;
     // first pass: level sizes and the largest FAST cell (fixes cellCap)
     for (int l = 0; l < c.nlevels; l++) {
@@ -1201,37 +1241,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         L.scaledPatch = (int)(31 * h->scale[l]);
         scanCap = std::max(scanCap, std::max(L.listCap, L.nCells));
         maxList = std::max(maxList, L.listCap);
-        // resize tables (OpenCV 3.3.x resize INTER_LINEAR u8 coefficients), built in double/float on the host
-        L.tabBase = (int)h->tab.size();
-        if (l > 0) {
-            const LevelGeom& S = g.L[l - 1];
-            const double sx_ = 1. / ((double)L.w / S.w), sy_ = 1. / ((double)L.h / S.h);
-            std::vector<int> xt(2 * (size_t)L.w), yt(2 * (size_t)L.h);
-            for (int dx = 0; dx < L.w; dx++) {
-                float fx = (float)((dx + 0.5) * sx_ - 0.5);
-                int sx = (int)std::floor(fx);
-                fx -= sx;
-                if (sx < 0) { fx = 0; sx = 0; }
-                if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
-                const int a0 = std::min(std::max(cv_round((1.f - fx) * 2048.f), -32768), 32767);
-                const int a1 = std::min(std::max(cv_round(fx * 2048.f), -32768), 32767);
-                xt[2 * dx] = sx;
-                xt[2 * dx + 1] = (a0 & 0xFFFF) | (a1 << 16);
-            }
-            for (int dy = 0; dy < L.h; dy++) {
-                float fy = (float)((dy + 0.5) * sy_ - 0.5);
-                int sy = (int)std::floor(fy);
-                fy -= sy;
-                const int b0 = std::min(std::max(cv_round((1.f - fy) * 2048.f), -32768), 32767);
-                const int b1 = std::min(std::max(cv_round(fy * 2048.f), -32768), 32767);
-                yt[2 * dy] = sy;
-                yt[2 * dy + 1] = (b0 & 0xFFFF) | (b1 << 16);
-            }
-            h->tab.insert(h->tab.end(), xt.begin(), xt.end());
-            h->tab.insert(h->tab.end(), yt.begin(), yt.end());
-        }
     }
-    if (h->tab.empty()) h->tab.push_back(0);
     g.totalCells = (int)h->cells.size();
     g.totalKpCap = kpBase;
     g.totalCandCap = candBase;
@@ -1261,8 +1271,6 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     EAO_HIP(hipMemcpyAsync(h->d_geom.p, &g, sizeof(Geom), hipMemcpyHostToDevice, h->stream));
     { eao_status st = h->d_cells.reserve(h->cells.size()); if (st) return st; }
     EAO_HIP(hipMemcpyAsync(h->d_cells.p, h->cells.data(), h->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice, h->stream));
-    { eao_status st = h->d_tab.reserve(h->tab.size()); if (st) return st; }
-    EAO_HIP(hipMemcpyAsync(h->d_tab.p, h->tab.data(), h->tab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     EAO_HIP(hipStreamSynchronize(h->stream));
     EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
     h->geomValid = true;
@@ -1282,6 +1290,7 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
             EAO_HIP(hipStreamCreateWithFlags(&h->laneSide[i], hipStreamNonBlocking));
             EAO_HIP(hipEventCreateWithFlags(&h->evFork[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
+            EAO_HIP(hipEventCreateWithFlags(&h->evMid[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evDone[i], hipEventDisableTiming));
         }
@@ -1351,30 +1360,50 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             hipLaunchKernelGGL(k_fast_cells, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
                                h->d_cellcand.p, h->d_cellcnt.p, f0, first, end);
         };
+        // Schedule of a (non-profiled) batch -- FAST and the blur are both VALU-bound, the quad-tree leaves the machine
+        // almost idle, so the blur runs beside the quad-tree, not beside FAST:
+        //   main:  resize 1..n-1 -> FAST(levels >= mid) -> quad-tree -> orientation + description
+        //   side:  FAST(level 0) [-> FAST(levels 1..mid-1) once they exist] -> (all FAST done) blur
+        static const int envMid = getenv("EAO_ORB_MID") ? atoi(getenv("EAO_ORB_MID")) : 0;
+        const int mid = early0 && envMid >= 2 && envMid < g.nlevels ? envMid : 0;
+        // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
+        const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         if (early0) {
             EAO_HIP(hipStreamWaitEvent(ss, h->evStart, 0));
             fast(ss, 0, cells0);
-            EAO_HIP(hipEventRecord(h->evFast0[i], ss));
         }
         for (int l = 1; l < g.nlevels; l++) {
             dim3 grid(eao::cdiv(g.L[l].w, 256), eao::cdiv(g.L[l].h, 4 * kResizeRows), nb), block(64, 4);
-            hipLaunchKernelGGL(k_resize, grid, block, 0, ms, h->d_geom.p, h->d_tab.p, s, l, f0);
+            ResizeArgs ra;
+            ra.D = {g.L[l].w, g.L[l].h, g.L[l].pitch, g.L[l].off};
+            ra.S = {g.L[l - 1].w, g.L[l - 1].h, g.L[l - 1].pitch, g.L[l - 1].off};
+            ra.invX = 1. / ((double)g.L[l].w / g.L[l - 1].w); ra.invY = 1. / ((double)g.L[l].h / g.L[l - 1].h);
+            ra.srcIsInput = l == 1; ra.pyrFrameBytes = g.pyrFrameBytes;
+            hipLaunchKernelGGL(k_resize, grid, block, 0, ms, ra, s, f0);
+            if (l == mid - 1) {
+                EAO_HIP(hipEventRecord(h->evMid[i], ms));
+                EAO_HIP(hipStreamWaitEvent(ss, h->evMid[i], 0));
+                fast(ss, cells0, g.L[mid].cellBase);
+            }
         }
+        if (early0) EAO_HIP(hipEventRecord(h->evFast0[i], ss));   // the side stream's share of FAST
         if (pe) EAO_HIP(hipEventRecord(ev[1], ms));
-        EAO_HIP(hipEventRecord(h->evFork[i], ms));
-        EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
-        if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
-        // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
-        const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
-        hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
-        if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
-        EAO_HIP(hipEventRecord(h->evJoin[i], ss));
-        if (prof) EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));   // profiled calls: the blur runs alone, then FAST
-        if (early0) {
-            fast(ms, cells0, g.totalCells);
-            EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
-        } else {
+        if (prof) {   // profiled calls: every stage alone -- blur, then FAST
+            EAO_HIP(hipEventRecord(h->evFork[i], ms));
+            EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
+            EAO_HIP(hipEventRecord(ev[6], ss));
+            hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
+            EAO_HIP(hipEventRecord(ev[7], ss));
+            EAO_HIP(hipEventRecord(h->evJoin[i], ss));
+            EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
             fast(ms, 0, g.totalCells);
+        } else {
+            fast(ms, early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
+            EAO_HIP(hipEventRecord(h->evFork[i], ms));            // the pyramid and the main stream's FAST are done
+            EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
+            hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
+            EAO_HIP(hipEventRecord(h->evJoin[i], ss));
+            if (early0) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
         }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
         hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nb), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
@@ -1383,7 +1412,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
         if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
         hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
-                           h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0);
+                           h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels);
         if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
         EAO_HIP(hipEventRecord(h->evDone[i], ms));
         EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
@@ -1482,6 +1511,7 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->laneSide[i]) { (void)hipStreamSynchronize(h->laneSide[i]); (void)hipStreamDestroy(h->laneSide[i]); }
         if (h->evFork[i]) (void)hipEventDestroy(h->evFork[i]);
         if (h->evFast0[i]) (void)hipEventDestroy(h->evFast0[i]);
+        if (h->evMid[i]) (void)hipEventDestroy(h->evMid[i]);
         if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }

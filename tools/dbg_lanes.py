@@ -20,5 +20,7 @@ hip.hipDeviceSynchronize()
 t=time.perf_counter()
 K=int(os.environ.get("EAO_DBG_STEPS", "30"))
 for _ in range(K): step()
+t_enq=time.perf_counter()-t
 hip.hipDeviceSynchronize()
+print('host enqueue ms/step %.4f' % (t_enq/K*1e3))
 print("lanes", os.environ.get("EAO_ORB_LANES"), "graph", os.environ.get("EAO_ORB_GRAPH"), "ms/step %.4f" % ((time.perf_counter()-t)/K*1e3))
