@@ -896,13 +896,22 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
                                                          eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                          int* __restrict__ nout, int cap, int f0, int nlevels) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int f = blockIdx.y + f0;
     // the lane's four test pairs (xa, ya, xb, yb as int8) depend on nothing: fetch them first, under the other loads
     unsigned pat[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const unsigned*>(c_pattern)[lane + 64 * k];
-    int j = blockIdx.x * 4 + wv;   // compact output index inside the frame
+    // Workgroups are dealt round-robin over the 8 XCDs and every XCD has its own L2: with the plain (blockIdx.y = frame)
+    // order the patches of one frame are pulled into all eight L2s.  When the batch is a multiple of 8, frame f is served
+    // by XCD f % 8 only (speed only: any placement gives the same results).
+    int bx = blockIdx.x, fy = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const unsigned b = blockIdx.x + gridDim.x * blockIdx.y, xcd = b & 7, slot = b >> 3;
+        fy = (int)(xcd + 8 * (slot / gridDim.x));
+        bx = (int)(slot % gridDim.x);
+    }
+    int j = bx * 4 + wv;   // compact output index inside the frame
     const int jout = j;
+    const int f = fy + f0;
     // level of compact index j: lane q holds the count of level q (one vector load instead of nlevels dependent scalar
     // loads), an inclusive wave scan gives the level boundaries
     const int myc = lane < nlevels ? levelcnt[f * nlevels + lane] : 0;
@@ -915,7 +924,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     const int total = __shfl(incl, kMaxLevels - 1);
     const unsigned long long below = __ballot(lane < nlevels && incl <= j);   // levels that end at or before j
     const int l = __popcll(below);
-    if (blockIdx.x == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
+    if (bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
     if (l >= nlevels || jout >= cap) return;
     j -= l ? __shfl(incl, l - 1) : 0;
     const LevelGeom L = g->L[l];
@@ -936,6 +945,31 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
         const int i = min(lane + 64 * k, (2 * kPR + 1) * kPW - 1), r = (i * 6554) >> 16;   // i / 10
         pw[k] = *reinterpret_cast<const unsigned*>(bw + r * L.pitch + 4 * (i - r * kPW));
     }
+    // the 31 x 31 window of the (unblurred) level for the intensity centroid goes through LDS the same way: 5 aligned word
+    // loads per lane instead of 16 byte loads
+    constexpr int kMR = 15, kMW = 9;    // 31 + up to 3 bytes of alignment = 9 words per row
+    __shared__ unsigned mpatch[4][(2 * kMR + 1) * kMW];
+    const bool imgAligned = ((((uintptr_t)img | (uintptr_t)pitch) & 3) == 0);   // (an unaligned caller image: byte loads)
+    const int mph = (cx - kMR) & 3;
+    if (imgAligned) {
+        const uint8_t* mw = img + (cy - kMR) * pitch + (cx - kMR - mph);
+        unsigned mv[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = min(lane + 64 * k, (2 * kMR + 1) * kMW - 1), r = (i * 7282) >> 16;   // i / 9
+            mv[k] = *reinterpret_cast<const unsigned*>(mw + r * pitch + 4 * (i - r * kMW));
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (lane + 64 * k < (2 * kMR + 1) * kMW) mpatch[wv][lane + 64 * k] = mv[k];
+    } else {
+        uint8_t* mb = reinterpret_cast<uint8_t*>(mpatch[wv]);
+        for (int i = lane; i < (2 * kMR + 1) * (2 * kMR + 1); i += 64) {
+            const int r = i / (2 * kMR + 1), c = i - r * (2 * kMR + 1);
+            mb[r * (4 * kMW) + c + mph] = img[(long long)(cy - kMR + r) * pitch + cx - kMR + c];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
     // intensity centroid over the radius-15 disc: lanes 0..30 / 32..62 take column u, the halves split the rows
     const int u = (lane & 31) - 15, half = lane >> 5;
     int m10 = 0, m01 = 0;
@@ -943,14 +977,14 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
         // rows v = -15..0 (lower half-wave) / 1..15 (upper); end of each row of the radius-15 disc = kUmax[|v|]
         // (the table of reference src/ORBextractor.cc:455-469, verified against the computed one at handle creation)
         constexpr int kUmax[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
-        const uint8_t* c0 = img + (long long)cy * pitch + cx + u;
+        const uint8_t* c0 = reinterpret_cast<const uint8_t*>(mpatch[wv]) + kMR * (4 * kMW) + kMR + mph + u;
         const int au = u < 0 ? -u : u;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int v = half ? k + 1 : k - 15;
             const int um = half ? kUmax[k + 1] : kUmax[15 - k];
             if (au <= um) {
-                const int val = c0[(long long)v * pitch];
+                const int val = c0[v * (4 * kMW)];
                 m10 += u * val;
                 m01 += v * val;
             }
