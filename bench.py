@@ -134,7 +134,7 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if pmc.get("batch") == B and dom in pmc["kernels"]:
             k = pmc["kernels"][dom]
-            traffic = int(k["hbm_bytes_per_launch"]) * int(k.get("launches_per_step", 1))
+            traffic = int(k["hbm_bytes_per_step"])   # all launches of the stage in one step (the pyramid is 7, FAST 1 or 2)
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

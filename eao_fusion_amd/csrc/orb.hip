@@ -319,18 +319,69 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
         const int th = min(max(pass ? g->minTh : g->iniTh, 0), 255);
         for (int i = lane; i < scWords; i += 64) sc4[i] = 0;
         __syncthreads();   // tile staged (first pass) / previous pass done with sc
-        // ---- 1. compass test
+        // ---- 1. compass test, four horizontally adjacent pixels per lane: five pairs of aligned LDS words (centre, left,
+        // right, up, down) shifted into place with v_alignbyte, bytes widened to 16-bit pairs (even / odd pixels) with
+        // v_perm, and per pair the SECOND largest and SECOND smallest of the four differences v - p from a 6-operation
+        // packed min / max network: two compass pixels are darker than v - th iff the second largest difference exceeds th,
+        // two are brighter than v + th iff the second smallest is below -th.  Survivors keep row-major order: a lane's
+        // four pixels are consecutive, and the lanes' counts are prefixed with one ballot per pixel slot.
         int nwork = 0;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            bool pass1 = false;
-            if (i < n) {
-                const int y = QDIV(i, invTw), x = i - y * tw;
-                pass1 = fast_quick_pass(&tile[(y + 3) * kTileStride + x + 3 + ph], th);
+        {
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            const int G = (tw + 3) >> 2, items = G * th_;
+            const float invG = 1.0f / (float)G;
+            const int a0 = 3 + ph;                       // byte offset of the first centre pixel inside its 16-byte window
+            const int shC = a0 & 3, wC = a0 >> 2;        // centre / up / down: words wC, wC+1 shifted by shC
+            const int shR = (a0 + 3) & 3, wR = (a0 + 3) >> 2;
+            const unsigned* t32 = reinterpret_cast<const unsigned*>(tile);
+            const short thS = (short)th;
+            const s16x2 TH = {thS, thS}, ZERO = {0, 0};
+            for (int it0 = 0; it0 < items; it0 += 64) {
+                const int it = min(it0 + lane, items - 1);
+                const int y = QDIV(it, invG), xg = it - y * G;
+                const int wbase = (y * kTileStride >> 2) + xg;          // word index of (row y, byte 4 xg): the UP row
+                const int wmid = wbase + 3 * (kTileStride >> 2), wdn = wbase + 6 * (kTileStride >> 2);
+                const unsigned C = __builtin_amdgcn_alignbyte(t32[wmid + wC + 1], t32[wmid + wC], (unsigned)shC);
+                const unsigned U = __builtin_amdgcn_alignbyte(t32[wbase + wC + 1], t32[wbase + wC], (unsigned)shC);
+                const unsigned D = __builtin_amdgcn_alignbyte(t32[wdn + wC + 1], t32[wdn + wC], (unsigned)shC);
+                const unsigned Lf = __builtin_amdgcn_alignbyte(t32[wmid + 1], t32[wmid], (unsigned)ph);
+                const unsigned R = __builtin_amdgcn_alignbyte(t32[wmid + wR + 1], t32[wmid + wR], (unsigned)shR);
+                unsigned fl[2];
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    const unsigned sel = par ? 0x0c030c01u : 0x0c020c00u;   // (pixel 1, pixel 3) / (pixel 0, pixel 2) as 16-bit halves
+                    const s16x2 v = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, C, sel));
+                    const s16x2 d0 = v - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, U, sel));
+                    const s16x2 d1 = v - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, D, sel));
+                    const s16x2 d2 = v - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Lf, sel));
+                    const s16x2 d3 = v - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, R, sel));
+                    const s16x2 t1 = __builtin_elementwise_min(__builtin_elementwise_max(d0, d1), __builtin_elementwise_max(d2, d3));
+                    const s16x2 t2 = __builtin_elementwise_max(__builtin_elementwise_min(d0, d1), __builtin_elementwise_min(d2, d3));
+                    const s16x2 s2 = __builtin_elementwise_max(t1, t2), s3 = __builtin_elementwise_min(t1, t2);
+                    const s16x2 m = __builtin_elementwise_max(s2, ZERO - s3);
+                    fl[par] = __builtin_bit_cast(unsigned, TH - m);           // sign bit of a half set <=> that pixel passes
+                }
+                const int x0 = 4 * xg, i0 = y * tw + x0;
+                // 4-bit pass mask of the lane (pixels beyond the row end / lanes beyond the last item masked off)
+                unsigned m4 = ((fl[0] >> 15) & 1u) | ((fl[1] >> 14) & 2u) | ((fl[0] >> 29) & 4u) | ((fl[1] >> 28) & 8u);
+                const int nv = it0 + lane < items ? tw - x0 : 0;
+                m4 &= (1u << min(nv, 4)) - 1u;
+                // survivors of the lower lanes: the lane counts (0..4) are prefixed bit plane by bit plane
+                const unsigned c = __popc(m4);
+                const unsigned long long b0 = __ballot(c & 1u), b1 = __ballot(c & 2u), b2 = __ballot(c & 4u);
+                const unsigned long long below = (1ull << lane) - 1;
+                int pos = nwork + __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+                // branch-free stores: a pixel that failed writes to a scratch slot (corners[] is not in use yet)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned bit = (m4 >> j) & 1u;
+                    unsigned short* dstp = bit ? &worklist[pos] : &corners[0];
+                    *dstp = (unsigned short)(i0 + j);
+                    pos += (int)bit;
+                }
+                const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+                nwork += tot;
             }
-            const unsigned long long m = __ballot(pass1);
-            if (pass1) worklist[nwork + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)i;
-            nwork += __popcll(m);
         }
         __syncthreads();
         // ---- 2. exact arc value of the survivors; corners go to the score map and the corner list
@@ -1047,6 +1098,7 @@ inline int cv_round(double v) { return (int)std::lrint(v); }
 }  // namespace
 
 // ================================================================================================= host
+constexpr size_t kProfEvents = 10;
 struct GraphKey {
     const void* img; int pitch0; long long fs0; int batch; void* kps; void* desc; int cap; void* n; int lanes;
     bool operator==(const GraphKey& o) const {
@@ -1199,7 +1251,7 @@ struct eao_orb {
     long long* d_dbg = nullptr;   // EAO_DEBUG_STAMPS: per-level phase cycles of k_quadtree (diagnostic runs only)
     hipGraphExec_t graphExec = nullptr;
     GraphKey graphKey = {};
-    std::vector<hipEvent_t> evs;   // 9 events per profiled call, averaged by eao_orb_last_timing
+    std::vector<hipEvent_t> evs;   // kProfEvents events per profiled call, averaged by eao_orb_last_timing
     size_t evUsed = 0;
 };
 
@@ -1367,13 +1419,13 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     const bool prof = h->profiling;
     hipEvent_t* ev = nullptr;
     if (prof) {
-        if (h->evUsed + 9 > h->evs.size()) {
+        if (h->evUsed + kProfEvents > h->evs.size()) {
             const size_t old = h->evs.size();
-            h->evs.resize(old + 9 * 16, nullptr);
+            h->evs.resize(old + kProfEvents * 16, nullptr);
             for (size_t i = old; i < h->evs.size(); i++) EAO_HIP(hipEventCreate(&h->evs[i]));
         }
         ev = &h->evs[h->evUsed];
-        h->evUsed += 9;
+        h->evUsed += kProfEvents;
         EAO_HIP(hipEventRecord(ev[0], st));
     }
     // split the batch into up to kLanes contiguous slices; slice i runs pyramid -> {FAST -> quad-tree | blur} ->
@@ -1425,11 +1477,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         if (prof) {   // profiled calls: every stage alone -- blur, then FAST
             EAO_HIP(hipEventRecord(h->evFork[i], ms));
             EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
-            EAO_HIP(hipEventRecord(ev[6], ss));
+            if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
             hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
-            EAO_HIP(hipEventRecord(ev[7], ss));
+            if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
             EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
+            if (pe) EAO_HIP(hipEventRecord(ev[9], ms));
             fast(ms, 0, g.totalCells);
         } else {
             fast(ms, early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
@@ -1676,16 +1729,16 @@ eao_status eao_orb_set_profiling(eao_orb* h, int32_t on) {
 }
 
 eao_status eao_orb_last_timing(eao_orb* h, float ms[6]) {
-    EAO_REQUIRE(h && ms && h->evUsed >= 9, "no profiled call since eao_orb_set_profiling(h, 1)");
-    const size_t calls = h->evUsed / 9;
-    EAO_HIP(hipEventSynchronize(h->evs[h->evUsed - 1]));   // ev[8] of the last call
+    EAO_REQUIRE(h && ms && h->evUsed >= kProfEvents, "no profiled call since eao_orb_set_profiling(h, 1)");
+    const size_t calls = h->evUsed / kProfEvents;
+    EAO_HIP(hipEventSynchronize(h->evs[h->evUsed - kProfEvents + 8]));   // ev[8] of the last call
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (size_t c = 0; c < calls; c++) {
-        hipEvent_t* ev = &h->evs[c * 9];
+        hipEvent_t* ev = &h->evs[c * kProfEvents];
         float t;
         // stage intervals of slice 0 (one of the concurrently running sub-batches)
         EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[1])); acc[0] += t;   // pyramid
-        EAO_HIP(hipEventElapsedTime(&t, ev[1], ev[2])); acc[1] += t;   // FAST
+        EAO_HIP(hipEventElapsedTime(&t, ev[9], ev[2])); acc[1] += t;   // FAST (after the blur of a profiled call)
         EAO_HIP(hipEventElapsedTime(&t, ev[2], ev[3])); acc[2] += t;   // quad-tree
         EAO_HIP(hipEventElapsedTime(&t, ev[6], ev[7])); acc[3] += t;   // blur, side stream
         EAO_HIP(hipEventElapsedTime(&t, ev[4], ev[5])); acc[4] += t;   // orientation + description
