@@ -1884,17 +1884,20 @@ __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(BADev P, int* s
 // the stream do nothing, and the host takes that iteration over trial by trial.  The status block is pinned host memory;
 // the host reads it after a stream synchronisation, so no fence is needed.
 __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BAStatus* st, int seq, int bulk) {
-    __shared__ double red[4], out1;
-    __shared__ double s_term[kSchurMaxFree * 6];
-    const double tempSum = ordered_sum(P.partChi, P.nL, red, &out1);
-    const double scaleL = ordered_sum(P.partScale, P.nL, red, &out1);
+    // the three sums of the decision (robust chi2 at the trial state, the landmark and the camera part of the gain
+    // denominator) go through ONE fixed-order block reduction; every load of a thread is issued before its first add
+    __shared__ double red[3 * 4], out3[3];
     const double lambda = P.lm[0];
-    for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { const double x = P.xp[i]; s_term[i] = x * (lambda * x + P.bp[i]); }
-    __syncthreads();
+    double v[3] = {0, 0, 0};
+    {
+#pragma unroll 4
+        for (int i = threadIdx.x; i < P.nL; i += 256) { v[0] += P.partChi[i]; v[1] += P.partScale[i]; }
+        for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { const double x = P.xp[i]; v[2] += x * (lambda * x + P.bp[i]); }
+    }
+    block_sum<3, 256>(v, red, out3);
     if (threadIdx.x == 0) {
-        double scale = 0;
-        for (int i = 0; i < P.nFree * 6; i++) scale += s_term[i];
-        scale += scaleL;
+        const double tempSum = out3[0];
+        double scale = out3[2] + out3[1];
         const int ok2 = *solveOk;
         double tempChi = tempSum;
         if (!ok2) tempChi = DBL_MAX;
