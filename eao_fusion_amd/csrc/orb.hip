@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
             tile[y * kTileStride + x + ph] = src[(long long)(c.y0 + y) * pitch + c.x0 + x];
         }
     }
-    const int n = tw * th_, rw = tw + 2;
+    const int rw = tw + 2;
     const int scWords = (rw * (th_ + 2) + 3) >> 2;
     unsigned* out = cellcand + slot * g->cellCap;
     for (int pass = 0; pass < 2; pass++) {

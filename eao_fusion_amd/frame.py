@@ -1,0 +1,113 @@
+"""ctypes mirror of the Frame glue either side of the matcher (include/eao_fusion.h, row f1): eao_frame_is_in_frustum,
+eao_assign_features_to_grid, eao_compute_stereo_from_rgbd -- reference src/Frame.cc:597-614, 638-695, 751-761, 1016-1037.
+
+`Binding(lib, prefix, check)` binds the wrappers to any shared object exporting `<prefix>...` entry points: the product
+('eao_', struct arguments, status codes) or a library with the oracle's flat argument lists ('orc_')."""
+import ctypes as C
+
+import numpy as np
+
+from .search import MapPoints, map_points
+
+_P = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+
+
+class FrustumFrame(C.Structure):
+    _fields_ = [("Tcw", _F * 16), ("Ow", _F * 3), ("fx", _F), ("fy", _F), ("cx", _F), ("cy", _F), ("mbf", _F),
+                ("min_x", _F), ("max_x", _F), ("min_y", _F), ("max_y", _F), ("log_scale_factor", _F)]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class Binding:
+    def __init__(self, lib, prefix, check=None):
+        self.lib, self.prefix, self.check = lib, prefix, check
+        if check:   # product
+            lib.eao_frame_is_in_frustum.restype = _I
+            lib.eao_frame_is_in_frustum.argtypes = [C.POINTER(FrustumFrame), C.POINTER(MapPoints), _F] + [_P] * 6
+            lib.eao_assign_features_to_grid.restype = _I
+            lib.eao_assign_features_to_grid.argtypes = [_I, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P]
+            lib.eao_compute_stereo_from_rgbd.restype = _I
+            lib.eao_compute_stereo_from_rgbd.argtypes = [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]
+        else:       # oracle: flat argument lists
+            lib.orc_is_in_frustum.restype = _I
+            lib.orc_is_in_frustum.argtypes = [_I] + [_P] * 8 + [_F] * 11 + [_P] * 6
+            lib.orc_assign_features_to_grid.restype = _I
+            lib.orc_assign_features_to_grid.argtypes = [_I, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P]
+            lib.orc_stereo_from_rgbd.restype = _I
+            lib.orc_stereo_from_rgbd.argtypes = [_I, _P, _P, _P, _P, _I, _F, _P, _P]
+
+    def is_in_frustum(self, frame, pts, viewing_cos_limit=0.5):
+        """frame: Tcw (4x4 f32), Ow (3), fx, fy, cx, cy, mbf, min_x, max_x, min_y, max_y, log_scale_factor.
+        pts: Xw, normal, min_dist_inv, max_dist_inv, max_dist (+ active / descriptors, unread).
+        Returns dict(in_view, proj_x, proj_y, proj_xr, view_cos, pred_level); entries of points out of view are -1 / 0."""
+        m, keep = map_points(pts)
+        n = m.n
+        out = dict(in_view=np.zeros(n, np.uint8), proj_x=np.full(n, -1, np.float32), proj_y=np.full(n, -1, np.float32),
+                   proj_xr=np.full(n, -1, np.float32), view_cos=np.zeros(n, np.float32), pred_level=np.full(n, -1, np.int32))
+        T = np.ascontiguousarray(frame["Tcw"], np.float32).reshape(4, 4)
+        Ow = np.ascontiguousarray(frame["Ow"], np.float32)
+        sc = [float(frame[k]) for k in ("fx", "fy", "cx", "cy", "mbf", "min_x", "max_x", "min_y", "max_y", "log_scale_factor")]
+        outs = [_p(out[k]) for k in ("in_view", "proj_x", "proj_y", "proj_xr", "view_cos", "pred_level")]
+        if self.check:
+            F = FrustumFrame()
+            F.Tcw[:] = T.ravel().tolist(); F.Ow[:] = Ow.tolist()
+            (F.fx, F.fy, F.cx, F.cy, F.mbf, F.min_x, F.max_x, F.min_y, F.max_y, F.log_scale_factor) = sc
+            self.check(self.lib.eao_frame_is_in_frustum(C.byref(F), C.byref(m), float(viewing_cos_limit), *outs))
+        else:
+            R = np.ascontiguousarray(T[:3, :3]); t = np.ascontiguousarray(T[:3, 3])
+            self.lib.orc_is_in_frustum(n, _p(keep["Xw"]), _p(keep["normal"]), _p(keep["min_dist_inv"]), _p(keep["max_dist_inv"]),
+                                       _p(keep["max_dist"]), _p(R), _p(t), _p(Ow), *sc, float(viewing_cos_limit), *outs)
+        return out
+
+    def assign_features_to_grid(self, kp_x, kp_y, min_x, min_y, max_x, max_y, cols=64, rows=48):
+        """Returns (cell_start [cols*rows+1], items): mGrid[ix][iy] = items[cell_start[ix*rows+iy] : cell_start[ix*rows+iy+1]]."""
+        kx, ky = np.ascontiguousarray(kp_x, np.float32), np.ascontiguousarray(kp_y, np.float32)
+        inv_w = np.float32(cols) / np.float32(np.float32(max_x) - np.float32(min_x))     # mfGridElementWidthInv, src/Frame.cc:258-259
+        inv_h = np.float32(rows) / np.float32(np.float32(max_y) - np.float32(min_y))
+        start = np.zeros(cols * rows + 1, np.int32)
+        items = np.full(max(len(kx), 1), -1, np.int32)
+        fn = getattr(self.lib, self.prefix + "assign_features_to_grid")
+        st = fn(len(kx), _p(kx), _p(ky), float(min_x), float(min_y), float(inv_w), float(inv_h), cols, rows, _p(start), _p(items))
+        if self.check:
+            self.check(st)
+        return start, items[:start[-1]]
+
+    def compute_stereo_from_rgbd(self, kp_x, kp_y, kpu_x, depth, mbf):
+        """depth: (H, W) float32 image.  Returns (mvuRight, mvDepth)."""
+        kx, ky, ku = (np.ascontiguousarray(a, np.float32) for a in (kp_x, kp_y, kpu_x))
+        d = np.ascontiguousarray(depth, np.float32)
+        ur, dz = np.zeros(len(kx), np.float32), np.zeros(len(kx), np.float32)
+        if self.check:
+            self.check(self.lib.eao_compute_stereo_from_rgbd(len(kx), _p(kx), _p(ky), _p(ku), _p(d), d.shape[1], d.shape[0], d.shape[1], 0,
+                                                             float(mbf), _p(ur), _p(dz)))
+        else:
+            self.lib.orc_stereo_from_rgbd(len(kx), _p(kx), _p(ky), _p(ku), _p(d), d.shape[1], float(mbf), _p(ur), _p(dz))
+        return ur, dz
+
+
+_product = None
+
+
+def product():
+    global _product
+    if _product is None:
+        from . import _lib
+        _product = Binding(_lib.load(), "eao_", _lib.check)
+    return _product
+
+
+def is_in_frustum(frame, pts, viewing_cos_limit=0.5):
+    return product().is_in_frustum(frame, pts, viewing_cos_limit)
+
+
+def assign_features_to_grid(kp_x, kp_y, min_x, min_y, max_x, max_y, cols=64, rows=48):
+    return product().assign_features_to_grid(kp_x, kp_y, min_x, min_y, max_x, max_y, cols, rows)
+
+
+def compute_stereo_from_rgbd(kp_x, kp_y, kpu_x, depth, mbf):
+    return product().compute_stereo_from_rgbd(kp_x, kp_y, kpu_x, depth, mbf)

@@ -264,6 +264,42 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
                               const float* T2w, const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12,
                               const float* R12, const float* t12, float th, int32_t* match12, int32_t* nfound);
 
+/* ---- f1  Frame glue either side of the matcher ------------------------------------------------------------------ */
+
+/* What Frame::isInFrustum reads of the frame: mTcw (16 floats row-major: mRcw, mtcw), mOw, the static intrinsics and image
+ * bounds (fx, fy, cx, cy, mbf, mnMinX .. mnMaxY) and mfLogScaleFactor. */
+typedef struct {
+    float Tcw[16];
+    float Ow[3];
+    float fx, fy, cx, cy, mbf;
+    float min_x, max_x, min_y, max_y;
+    float log_scale_factor;
+} eao_frustum_frame;
+
+/* Frame::isInFrustum(MapPoint*, viewingCosLimit) -- src/Frame.cc:638-695 -- for every point of pts, i.e. the projection
+ * loop of Tracking::SearchLocalPoints (src/Tracking.cc:2612-2626; the caller keeps its own skip rules: mnLastFrameSeen,
+ * isBad()).  pts: Xw, normal, min_dist_inv / max_dist_inv (Get{Min,Max}DistanceInvariance()), max_dist (mfMaxDistance, the
+ * numerator of MapPoint::PredictScale, src/MapPoint.cc:385-394 -- not clamped in this fork); active and desc are not read.
+ * in_view[i] = the return value = mbTrackInView; proj_x / proj_y / proj_xr / view_cos / pred_level receive mTrackProjX,
+ * mTrackProjY, mTrackProjXR, mTrackViewCos, mnTrackScaleLevel where in_view[i] = 1 and keep the caller's values elsewhere
+ * (upstream leaves those members untouched).  The outputs are exactly the inputs of eao_search_by_projection_points. */
+eao_status eao_frame_is_in_frustum(const eao_frustum_frame* F, const eao_map_points* pts, float viewing_cos_limit, uint8_t* in_view,
+                                   float* proj_x, float* proj_y, float* proj_xr, float* view_cos, int32_t* pred_level);
+
+/* Frame::AssignFeaturesToGrid() with PosInGrid -- src/Frame.cc:597-614, 751-761 -- over mvKeysUn.  mGrid comes back as a CSR:
+ * cell c = ix * rows + iy is mGrid[ix][iy]; cell_start has cols * rows + 1 entries; items[cell_start[c] .. cell_start[c+1])
+ * are the keypoint indices of the cell in push_back (= ascending) order.  items needs room for n entries. */
+eao_status eao_assign_features_to_grid(int32_t n, const float* kp_x, const float* kp_y, float min_x, float min_y, float grid_inv_w,
+                                       float grid_inv_h, int32_t cols, int32_t rows, int32_t* cell_start, int32_t* items);
+
+/* Frame::ComputeStereoFromRGBD(imDepth) -- src/Frame.cc:1016-1037.  kp_x / kp_y: mvKeys[i].pt (distorted), kpu_x:
+ * mvKeysUn[i].pt.x; depth: the CV_32F depth image (`pitch` floats per row), a host pointer or, with depth_on_device != 0,
+ * a device pointer (a depth map that is already resident).  u_right / out_depth receive mvuRight / mvDepth (-1 where the
+ * depth is not positive). */
+eao_status eao_compute_stereo_from_rgbd(int32_t n, const float* kp_x, const float* kp_y, const float* kpu_x, const float* depth,
+                                        int32_t width, int32_t height, int32_t pitch, int32_t depth_on_device, float mbf,
+                                        float* u_right, float* out_depth);
+
 /* f4  Frame::ComputeStereoMatches() -- src/Frame.cc:841-1013.  `left` / `right` are the two extractor handles
  * (mpORBextractorLeft / Right) right after they extracted the stereo pair: the image pyramids of frame `frame` of their
  * last batch are still on the device and are read in place (the 19-px reflect-101 border of mvImagePyramid is evaluated

@@ -1,0 +1,123 @@
+// include/eaofusion/Frame.h -- drop-in bodies for the Frame glue either side of the matcher, over
+// libeaofusion_hip.so (include/eao_fusion.h).  Each template replaces the body of one reference member function:
+//
+//   Tracking::SearchLocalPoints, projection loop      src/Tracking.cc:2612-2626   ->  eaofusion::IsInFrustum(frame, points, 0.5f, skip)
+//     (Frame::isInFrustum                             src/Frame.cc:638-695)
+//   Frame::AssignFeaturesToGrid                       src/Frame.cc:597-614        ->  eaofusion::AssignFeaturesToGrid(*this)
+//   Frame::ComputeStereoFromRGBD                      src/Frame.cc:1016-1037      ->  eaofusion::ComputeStereoFromRGBD(*this, imDepth)
+//
+// The templates only name members the reference's Frame / MapPoint already have (mRcw, mtcw, mOw, fx .. mbf, mnMinX ..,
+// mfLogScaleFactor, mGrid, mvKeys, mvKeysUn, mvuRight, mvDepth; GetWorldPos, GetNormal, Get{Min,Max}DistanceInvariance,
+// mbTrackInView, mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos).  Nothing here is copied from the reference.
+#ifndef EAOFUSION_FRAME_H
+#define EAOFUSION_FRAME_H
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../eao_fusion.h"
+#include "cv_compat.h"
+
+namespace eaofusion {
+namespace detail {
+// mfMaxDistance is what MapPoint::PredictScale divides (src/MapPoint.cc:385-394); upstream exposes it only through
+// GetMaxDistanceInvariance() = 1.2f * mfMaxDistance, which does not round-trip in float.  A derived class may name the
+// protected member of its base and the resulting pointer-to-member applies to any MapPoint: an exact read without touching
+// MapPoint.h.
+template <class MapPointT>
+struct MaxDistanceOf : MapPointT {
+    static float get(MapPointT* p) { return p->*(&MaxDistanceOf::mfMaxDistance); }
+};
+inline void check(eao_status st, const char* what) {
+    if (st != EAO_OK) throw std::runtime_error(std::string(what) + ": " + eao_last_error());
+}
+}  // namespace detail
+
+// for (pMP : vpMPs) if (!skip(pMP)) if (F.isInFrustum(pMP, viewingCosLimit)) nToMatch++;   returns nToMatch.
+// skip(pMP) holds the caller's own `continue`s (src/Tracking.cc:2615-2618: mnLastFrameSeen == mCurrentFrame.mnId, isBad()).
+// Every visited point gets mbTrackInView; points in view also get mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos.
+template <class FrameT, class MapPointT, class Skip>
+int IsInFrustum(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewingCosLimit, Skip&& skip) {
+    std::vector<int> idx;
+    idx.reserve(vpMPs.size());
+    for (size_t i = 0; i < vpMPs.size(); i++)
+        if (!skip(vpMPs[i])) idx.push_back((int)i);
+    const int n = (int)idx.size();
+    if (n == 0) return 0;
+    std::vector<float> Xw(3 * (size_t)n), nrm(3 * (size_t)n), dmin(n), dmax(n), draw(n);
+    for (int k = 0; k < n; k++) {
+        MapPointT* p = vpMPs[idx[k]];
+        const cv::Mat P = p->GetWorldPos(), Pn = p->GetNormal();
+        for (int a = 0; a < 3; a++) { Xw[3 * (size_t)k + a] = P.template at<float>(a); nrm[3 * (size_t)k + a] = Pn.template at<float>(a); }
+        dmin[k] = p->GetMinDistanceInvariance(); dmax[k] = p->GetMaxDistanceInvariance(); draw[k] = detail::MaxDistanceOf<MapPointT>::get(p);
+    }
+    eao_frustum_frame fr;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) fr.Tcw[4 * r + c] = F.mRcw.template at<float>(r, c);
+        fr.Tcw[4 * r + 3] = F.mtcw.template at<float>(r);
+        fr.Tcw[12 + r] = 0.f;
+        fr.Ow[r] = F.mOw.template at<float>(r);
+    }
+    fr.Tcw[15] = 1.f;
+    fr.fx = FrameT::fx; fr.fy = FrameT::fy; fr.cx = FrameT::cx; fr.cy = FrameT::cy; fr.mbf = F.mbf;
+    fr.min_x = FrameT::mnMinX; fr.max_x = FrameT::mnMaxX; fr.min_y = FrameT::mnMinY; fr.max_y = FrameT::mnMaxY;
+    fr.log_scale_factor = F.mfLogScaleFactor;
+    eao_map_points mp;
+    std::memset(&mp, 0, sizeof(mp));
+    mp.n = n; mp.Xw = Xw.data(); mp.normal = nrm.data(); mp.min_dist_inv = dmin.data(); mp.max_dist_inv = dmax.data(); mp.max_dist = draw.data();
+    std::vector<uint8_t> in(n, 0);
+    std::vector<float> u(n, 0.f), v(n, 0.f), ur(n, 0.f), vc(n, 0.f);
+    std::vector<int32_t> lvl(n, 0);
+    detail::check(eao_frame_is_in_frustum(&fr, &mp, viewingCosLimit, in.data(), u.data(), v.data(), ur.data(), vc.data(), lvl.data()),
+                  "eao_frame_is_in_frustum");
+    int nToMatch = 0;
+    for (int k = 0; k < n; k++) {
+        MapPointT* p = vpMPs[idx[k]];
+        p->mbTrackInView = in[k] != 0;
+        if (!in[k]) continue;
+        p->mTrackProjX = u[k]; p->mTrackProjXR = ur[k]; p->mTrackProjY = v[k];
+        p->mnTrackScaleLevel = lvl[k]; p->mTrackViewCos = vc[k];
+        nToMatch++;
+    }
+    return nToMatch;
+}
+
+// fills F.mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS] from F.mvKeysUn (the reserve() of upstream is an allocation hint only)
+template <class FrameT>
+void AssignFeaturesToGrid(FrameT& F) {
+    typedef typename std::remove_reference<decltype(F.mGrid)>::type GridT;
+    const int cols = (int)std::extent<GridT, 0>::value, rows = (int)std::extent<GridT, 1>::value;
+    const int N = F.N;
+    std::vector<float> x(N), y(N);
+    for (int i = 0; i < N; i++) { x[i] = F.mvKeysUn[i].pt.x; y[i] = F.mvKeysUn[i].pt.y; }
+    std::vector<int32_t> start((size_t)cols * rows + 1, 0), items(N > 0 ? N : 1, 0);
+    detail::check(eao_assign_features_to_grid(N, x.data(), y.data(), FrameT::mnMinX, FrameT::mnMinY, FrameT::mfGridElementWidthInv,
+                                              FrameT::mfGridElementHeightInv, cols, rows, start.data(), items.data()),
+                  "eao_assign_features_to_grid");
+    for (int i = 0; i < cols; i++)
+        for (int j = 0; j < rows; j++) {
+            const size_t c = (size_t)i * rows + j;
+            F.mGrid[i][j].assign(items.begin() + start[c], items.begin() + start[c + 1]);
+        }
+}
+
+// imDepth: CV_32F, as Tracking::GrabImageRGBD hands it over after the depth-factor conversion
+template <class FrameT>
+void ComputeStereoFromRGBD(FrameT& F, const cv::Mat& imDepth) {
+    const int N = F.N;
+    F.mvuRight = std::vector<float>(N, -1.0f);
+    F.mvDepth = std::vector<float>(N, -1.0f);
+    if (N == 0) return;
+    std::vector<float> x(N), y(N), xu(N);
+    for (int i = 0; i < N; i++) { x[i] = F.mvKeys[i].pt.x; y[i] = F.mvKeys[i].pt.y; xu[i] = F.mvKeysUn[i].pt.x; }
+    detail::check(eao_compute_stereo_from_rgbd(N, x.data(), y.data(), xu.data(), reinterpret_cast<const float*>(imDepth.data), imDepth.cols,
+                                               imDepth.rows, (int)(imDepth.step / sizeof(float)), 0, F.mbf, F.mvuRight.data(), F.mvDepth.data()),
+                  "eao_compute_stereo_from_rgbd");
+}
+
+}  // namespace eaofusion
+
+#endif  // EAOFUSION_FRAME_H

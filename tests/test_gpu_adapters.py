@@ -239,3 +239,17 @@ def test_cpp_search_adapters(tmp_path):
     sets[0] = []
     exp = E.distinctive_descriptors([np.array(x, np.uint8).reshape(-1, 32) for x in sets])
     assert np.array_equal(tab, exp) and exp[0] == -1
+
+
+def test_cpp_frame_adapters(tmp_path):
+    """include/eaofusion/Frame.h (IsInFrustum over a local map with upstream's skip rules, AssignFeaturesToGrid into
+    mGrid[64][48], ComputeStereoFromRGBD) over mock Frame / MapPoint classes: the C++ test restates the reference loops
+    (src/Frame.cc:597-614, 638-695, 1016-1037) and exits non-zero on any difference."""
+    exe = str(tmp_path / "frame_adapter_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DEAOFUSION_FORCE_CV_COMPAT", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "frame_adapter_test.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "eao_fusion_amd"), "-leaofusion_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "eao_fusion_amd"), "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "in view" in out.stderr and "inside the grid" in out.stderr
