@@ -927,8 +927,8 @@ struct BAStatus {            // pinned host memory, written by k_ba_decide / k_b
     double lambda, rho, chi, tempChi;
     int accepted, solveOk, seq, cur;
     int iters, status, nBad, ntrace;
-    double trLambda[32], trChi[32];   // [16 * phase + iteration]
-    int trTrials[32];
+    double trLambda[64], trChi[64];   // [32 * phase + iteration]
+    int trTrials[64];
     BAPhase ph[2];           // where each optimize() stood after its last decision (both calls may run in ONE enqueue)
 };
 
@@ -1923,8 +1923,8 @@ __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BASta
         if (bulk) {
             if (accepted) {
                 const int k = P.ctl[kCtlIters];
-                const int slot = 16 * (P.ctl[kCtlPhase] & 1) + k;
-                if (k < 16) { st->trLambda[slot] = P.lm[0]; st->trChi[slot] = tempChi; st->trTrials[slot] = 1; }
+                const int slot = 32 * (P.ctl[kCtlPhase] & 1) + k;
+                if (k < 32) { st->trLambda[slot] = P.lm[0]; st->trChi[slot] = tempChi; st->trTrials[slot] = 1; }
                 P.ctl[kCtlIters] = k + 1;
                 int nb = P.ctl[kCtlNBad];
                 if ((currentChi - tempChi) * 1e3 < currentChi) nb++; else nb = 0;
@@ -2248,8 +2248,11 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     return EAO_OK;
 }
 
-eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r) {
-    EAO_REQUIRE(p && r && r->cam_Tcw && r->points && (p->n_edges == 0 || r->edge_outlier), "null argument");
+// mode 0: Optimizer::LocalBundleAdjustment (two passes with the outlier pass between them, Huber kernels in the first).
+// mode 1: Optimizer::BundleAdjustment over keyframes and map points (src/Optimizer.cc:55-323): ONE optimize(its_first) call,
+//         Huber kernels only when `robust`, delta_mono = sqrt(5.99) (:94), no outlier pass, no observation is erased.
+static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r, int mode, int robust) {
+    EAO_REQUIRE(p && r && r->cam_Tcw && r->points && (p->n_edges == 0 || r->edge_outlier || mode == 1), "null argument");
     EAO_REQUIRE(p->n_cams > 0 && p->n_points >= 0 && p->n_edges >= 0, "bad sizes");
     LMContext& c = g_ctx;
     eao_status st = ctx_init(c);
@@ -2261,7 +2264,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         r->aborted = 1;
         for (int i = 0; i < nC; i++) se3_to_Tcw_f32(se3_from_Tcw_f32(p->cam_Tcw + 16 * i), r->cam_Tcw + 16 * i);
         for (size_t i = 0; i < (size_t)nP * 3; i++) r->points[i] = p->points[i];
-        if (E) std::memset(r->edge_outlier, 0, E);
+        if (E && r->edge_outlier) std::memset(r->edge_outlier, 0, E);
         return EAO_OK;
     }
     for (int e = 0; e < E; e++)
@@ -2283,7 +2286,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     std::memset(&D, 0, sizeof(D));
     D.nCams = nC; D.nPts = nP; D.nEdges = E; D.chunks = chunks;
     D.cam.fx = p->fx; D.cam.fy = p->fy; D.cam.cx = p->cx; D.cam.cy = p->cy; D.cam.bf = p->bf; D.cam.bf_f = p->bf;
-    D.cam.deltaMono = (float)std::sqrt(5.991); D.cam.deltaStereo = (float)std::sqrt(7.815);
+    D.cam.deltaMono = (float)std::sqrt(mode == 1 ? 5.99 : 5.991); D.cam.deltaStereo = (float)std::sqrt(7.815);
     // ---- the uploaded part of the arena (problem, initial state, adjacency, zeroed control block) is mirrored in pinned
     //      host memory: filled in place, sent with ONE copy
     const size_t off0 = a.off;
@@ -2355,7 +2358,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
         for (size_t i = 0; i < (size_t)nP * 3; i++) hp[i] = p->points[i];
         // edge flags: bit0 stereo, bit2 robust kernel present (bit1 = level 1 is only ever set on the device)
         unsigned char* hf = (unsigned char*)hostp(dflag);
-        for (int e = 0; e < E; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | 4);
+        for (int e = 0; e < E; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | (robust ? 4 : 0));
         std::memset(hostp(dctl), 0, 8 * sizeof(int));
         // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
         int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
@@ -2483,9 +2486,9 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
             }
             const BAPhase S = resume ? *resume : c.status->ph[phase];
             resume = nullptr;
-            for (int k = done; k < S.iters && k < 16; k++) {
-                g_trace.lambda.push_back(c.status->trLambda[16 * phase + k]); g_trace.chi2.push_back(c.status->trChi[16 * phase + k]);
-                g_trace.trials.push_back(c.status->trTrials[16 * phase + k]);
+            for (int k = done; k < S.iters && k < 32; k++) {
+                g_trace.lambda.push_back(c.status->trLambda[32 * phase + k]); g_trace.chi2.push_back(c.status->trChi[32 * phase + k]);
+                g_trace.trials.push_back(c.status->trTrials[32 * phase + k]);
             }
             g_trace.linearizations += S.iters - done;
             done = S.iters; nBad = S.nBad; curHost = S.cur; currentChi = S.chi;
@@ -2526,16 +2529,18 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     if (chained) {
         int dummyI; double dummyD;
         if ((st = optimize(-1, p->its_first, &dummyI, &dummyD, nullptr))) return st;
-        hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
-        if ((st = optimize(-1, p->its_second, &dummyI, &dummyD, nullptr))) return st;
+        if (mode == 0) {
+            hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
+            if ((st = optimize(-1, p->its_second, &dummyI, &dummyD, nullptr))) return st;
+        }
         hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(E, nP * 3), nC), 256)), dim3(256), 0, s, D, outCams, outPts, outCls);
         EAO_HIP(hipStreamSynchronize(s));
     }
     const BAPhase A = c.status->ph[0], B = c.status->ph[1];
     if ((st = optimize(0, p->its_first, &r->iters[0], &r->chi2[0], chained ? &A : nullptr))) return st;
     const bool firstClean = chained && A.status != kStTakeover;
-    const bool doMore = firstClean || !(stop && *stop);
-    bool redo = !chained;
+    const bool doMore = mode == 0 && (firstClean || !(stop && *stop));
+    bool redo = !chained || (mode == 1 && !firstClean);
     if (doMore && E) {
         // outlier pass (src/Optimizer.cc:978-1008): chi2 of the residual each edge last computed + depth test.  g2o's
         // initializeOptimization(0) would now drop the level-1 edges (and vertices left without edges) from the active
@@ -2565,8 +2570,17 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
     }
     for (int i = 0; i < nC; i++) se3_to_Tcw_f32(outCams[i], r->cam_Tcw + 16 * i);
     for (size_t i = 0; i < (size_t)nP * 3; i++) r->points[i] = (float)outPts[i];
-    if (E) std::memcpy(r->edge_outlier, outCls, E);
+    if (E && r->edge_outlier) {
+        if (mode == 0) std::memcpy(r->edge_outlier, outCls, E);
+        else std::memset(r->edge_outlier, 0, E);
+    }
     return EAO_OK;
+}
+
+eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r) { return ba_run(p, stop, r, 0, 1); }
+
+eao_status eao_bundle_adjustment(const eao_ba_problem* p, int32_t robust, const volatile uint8_t* stop, eao_ba_result* r) {
+    return ba_run(p, stop, r, 1, robust != 0);
 }
 
 eao_status eao_last_lm_trace(double* lambda, double* chi2, int32_t* trials, int32_t cap, int32_t* n) {

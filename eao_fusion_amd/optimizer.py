@@ -56,7 +56,7 @@ class Optimizer:
         return out
 
     @staticmethod
-    def LocalBundleAdjustment(prob, stop=None, its=(5, 10)):
+    def LocalBundleAdjustment(prob, stop=None, its=(5, 10), gba=None):
         """prob: poses (n_cams,4,4) f32, fixed (n_cams,) u8, points (n_points,3) f32, edge_cam, edge_point (E,) i32,
         obs (E,3) f32, inv_sigma2 (E,) f32, fx..bf.  stop: optional np.uint8[1] polled between LM iterations."""
         cams = np.ascontiguousarray(prob["poses"], np.float32)
@@ -78,6 +78,16 @@ class Optimizer:
         if stop is not None:
             stop = np.ascontiguousarray(stop, np.uint8)
             stop_p = _lib.ptr(stop)
-        _lib.check(_lib.load().eao_local_ba(C.byref(P), stop_p, C.byref(R)))
+        if gba is None:
+            _lib.check(_lib.load().eao_local_ba(C.byref(P), stop_p, C.byref(R)))
+        else:
+            _lib.check(_lib.load().eao_bundle_adjustment(C.byref(P), 1 if gba else 0, stop_p, C.byref(R)))
         return dict(poses=cams_out, points=pts_out, edge_outlier=outl[:len(ec)], iters=np.array(R.iters[:]),
                     aborted=bool(R.aborted), chi2=np.array(R.chi2[:]), trace=_trace(), timing=_timing())
+
+    @staticmethod
+    def BundleAdjustment(prob, nIterations=5, stop=None, bRobust=True):
+        """Optimizer::BundleAdjustment over keyframes and map points (reference src/Optimizer.cc:55-323): one
+        optimize(nIterations) call, Huber kernels only when bRobust, nothing is erased.  prob as for LocalBundleAdjustment
+        (fixed[i] = 1 for the keyframe with mnId == 0)."""
+        return Optimizer.LocalBundleAdjustment(prob, stop, (int(nIterations), 0), gba=bool(bRobust))

@@ -376,6 +376,15 @@ typedef struct {
 /* stop may be NULL; it is polled on the host between LM iterations like g2o's forceStopFlag */
 eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r);
 
+/* f3 (first step)  Optimizer::BundleAdjustment(vpKFs, vpMP, vpMPl, nIterations, pbStopFlag, nLoopKF, bRobust) --
+ * src/Optimizer.cc:55-323 -- over keyframes and map points: the same flattening as eao_local_ba (cameras in ascending
+ * mnId with cam_fixed = (mnId == 0), points in ascending mnId, points without an edge simply stay where they are),
+ * ONE optimize(p->its_first) call (its_second is ignored), Huber kernels (delta sqrt(5.99) / sqrt(7.815), :94-95) only
+ * when robust != 0, no outlier pass: r->edge_outlier may be NULL and comes back all zero, r->iters[1] = 0.
+ * Not covered: the MapPlane vertices / EdgePlane edges of :203-252 (a map with planes is refused by the adapter) and maps
+ * beyond the single-workgroup solvers (more than 64 free keyframes: refused with an error). */
+eao_status eao_bundle_adjustment(const eao_ba_problem* p, int32_t robust, const volatile uint8_t* stop, eao_ba_result* r);
+
 /* LM trace of the last eao_local_ba / eao_pose_optimization call made by this thread (for parity tests):
  * up to cap entries of (lambda after the iteration, robust chi2, trials). Returns the count in *n. */
 eao_status eao_last_lm_trace(double* lambda, double* chi2, int32_t* trials, int32_t cap, int32_t* n);

@@ -214,4 +214,95 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
     }
 }
 
+// ---- Optimizer::BundleAdjustment(vpKFs, vpMP, vpMPl, nIterations, pbStopFlag, nLoopKF, bRobust) ------------------
+// reference src/Optimizer.cc:55-323 over keyframes and map points.  The MapPlane vertices / EdgePlane edges of :203-252
+// are not covered by the library yet: a map that holds a (non-bad) plane is refused instead of being optimised without it.
+template <class MapPointT, class KeyFrameT, class MapPlaneT>
+void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<MapPointT*>& vpMP, const std::vector<MapPlaneT*>& vpMPl,
+                      int nIterations = 5, bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true) {
+    for (MapPlaneT* pl : vpMPl)
+        if (pl && !pl->isBad()) throw std::runtime_error("eaofusion::BundleAdjustment: map planes are not supported by eao_bundle_adjustment yet");
+    // cameras / points in ascending mnId (g2o's vertex order); edges in upstream's insertion order (vpMP order, then the
+    // observation map's order)
+    std::vector<KeyFrameT*> cams;
+    for (KeyFrameT* kf : vpKFs) if (!kf->isBad()) cams.push_back(kf);
+    std::sort(cams.begin(), cams.end(), [](KeyFrameT* a, KeyFrameT* b) { return a->mnId < b->mnId; });
+    if (cams.empty()) return;
+    std::map<KeyFrameT*, int> camIndex;
+    for (size_t i = 0; i < cams.size(); i++) camIndex[cams[i]] = (int)i;
+    std::vector<MapPointT*> pts;
+    for (MapPointT* mp : vpMP) if (!mp->isBad()) pts.push_back(mp);
+    std::sort(pts.begin(), pts.end(), [](MapPointT* a, MapPointT* b) { return a->mnId < b->mnId; });
+    std::map<MapPointT*, int> ptIndex;
+    for (size_t i = 0; i < pts.size(); i++) ptIndex[pts[i]] = (int)i;
+    std::vector<float> camT(cams.size() * 16), xyz(pts.size() * 3), obs, inv;
+    std::vector<uint8_t> camFixed(cams.size()), included(pts.size(), 0);
+    std::vector<int32_t> eCam, ePt;
+    for (size_t i = 0; i < cams.size(); i++) {
+        const cv::Mat T = cams[i]->GetPose();
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) camT[i * 16 + r * 4 + c] = T.template at<float>(r, c);
+        camFixed[i] = cams[i]->mnId == 0 ? 1 : 0;                       // :91
+    }
+    for (size_t i = 0; i < pts.size(); i++) {
+        const cv::Mat P = pts[i]->GetWorldPos();
+        for (int k = 0; k < 3; k++) xyz[i * 3 + k] = P.template at<float>(k);
+    }
+    for (MapPointT* mp : vpMP) {
+        if (mp->isBad()) continue;
+        const std::map<KeyFrameT*, size_t> seenBy = mp->GetObservations();
+        for (const auto& ob : seenBy) {
+            KeyFrameT* kf = ob.first;
+            if (kf->isBad()) continue;                                  // :124
+            auto ci = camIndex.find(kf);
+            if (ci == camIndex.end()) continue;                         // a keyframe outside vpKFs: upstream has no vertex for it
+            const cv::KeyPoint& kpUn = kf->mvKeysUn[ob.second];
+            eCam.push_back(ci->second); ePt.push_back(ptIndex[mp]);
+            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(kf->mvuRight[ob.second]);
+            inv.push_back(kf->mvInvLevelSigma2[kpUn.octave]);
+            included[ptIndex[mp]] = 1;                                  // nEdges != 0, :193-201
+        }
+    }
+    eao_ba_problem P;
+    P.n_cams = (int)cams.size(); P.n_points = (int)pts.size(); P.n_edges = (int)eCam.size();
+    P.cam_Tcw = camT.data(); P.cam_fixed = camFixed.data(); P.points = xyz.data();
+    P.edge_cam = eCam.data(); P.edge_point = ePt.data(); P.edge_obs = obs.data(); P.edge_inv_sigma2 = inv.data();
+    P.fx = cams[0]->fx; P.fy = cams[0]->fy; P.cx = cams[0]->cx; P.cy = cams[0]->cy; P.bf = cams[0]->mbf;
+    P.its_first = nIterations; P.its_second = 0;
+    std::vector<float> camOut(camT.size()), xyzOut(xyz.size());
+    eao_ba_result R;
+    R.cam_Tcw = camOut.data(); R.points = xyzOut.data(); R.edge_outlier = nullptr;
+    static_assert(sizeof(bool) == 1, "bool* abort flag is polled as a byte");
+    check(eao_bundle_adjustment(&P, bRobust ? 1 : 0, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), &R), "eao_bundle_adjustment");
+    for (size_t i = 0; i < cams.size(); i++) {                          // :258-275
+        cv::Mat T(4, 4, CV_32F);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.template at<float>(r, c) = camOut[i * 16 + r * 4 + c];
+        if (nLoopKF == 0) {
+            cams[i]->SetPose(T);
+        } else {
+            cams[i]->mTcwGBA.create(4, 4, CV_32F);
+            T.copyTo(cams[i]->mTcwGBA);
+            cams[i]->mnBAGlobalForKF = nLoopKF;
+        }
+    }
+    for (size_t i = 0; i < pts.size(); i++) {                           // :277-300
+        if (!included[i]) continue;
+        cv::Mat X(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) X.template at<float>(k) = xyzOut[i * 3 + k];
+        if (nLoopKF == 0) {
+            pts[i]->SetWorldPos(X);
+            pts[i]->UpdateNormalAndDepth();
+        } else {
+            pts[i]->mPosGBA.create(3, 1, CV_32F);
+            X.copyTo(pts[i]->mPosGBA);
+            pts[i]->mnBAGlobalForKF = nLoopKF;
+        }
+    }
+}
+
+// Optimizer::GlobalBundleAdjustemnt(Map*, nIterations, pbStopFlag, nLoopKF, bRobust) -- src/Optimizer.cc:47-53
+template <class MapPointT, class MapT>
+void GlobalBundleAdjustemnt(MapT* pMap, int nIterations = 5, bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true) {
+    BundleAdjustment<MapPointT>(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), pMap->GetAllMapPlanes(), nIterations, pbStopFlag, nLoopKF, bRobust);
+}
+
 }  // namespace eaofusion

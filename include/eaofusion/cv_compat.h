@@ -71,6 +71,7 @@ public:
         for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * elemSize());
         return m;
     }
+    void copyTo(Mat& dst) const { dst = clone(); }
     static Mat zeros(int r, int c, int type) { Mat m(r, c, type); std::memset(m.data, 0, (size_t)r * m.step); return m; }
     static Mat eye(int r, int c, int type) {
         Mat m = zeros(r, c, type);

@@ -869,6 +869,46 @@ int orc_local_ba(const orc_ba_problem* P, const volatile bool* stop, float* cam_
     return 0;
 }
 
+// Optimizer::BundleAdjustment over keyframes and map points (src/Optimizer.cc:55-323; the MapPlane vertices of :203-252 are
+// not restated): every edge robust iff bRobust with delta sqrt(5.99) / sqrt(7.815) (:94-95), ONE initializeOptimization() +
+// optimize(iterations) (:254-255), estimates written back (:258-300).  A map point without an edge is removed from the graph
+// (:193-201) and keeps its position.  Same outputs as orc_local_ba (iters[1] = 0).
+int orc_bundle_adjustment(const orc_ba_problem* P, int32_t iterations, int32_t robust, const volatile bool* stop, float* cam_Tcw_out,
+                          float* points_out, double* cams_d, double* points_d, int32_t* iters, orc_trace* trace) {
+    BAProblem pb;
+    pb.fx = P->fx; pb.fy = P->fy; pb.cx = P->cx; pb.cy = P->cy; pb.bf = P->bf; pb.bf_f = P->bf;
+    pb.deltaMono = (float)std::sqrt(5.99); pb.deltaStereo = (float)std::sqrt(7.815);
+    pb.cams.resize(P->n_cams); pb.camFixed.assign(P->cam_fixed, P->cam_fixed + P->n_cams);
+    for (int c = 0; c < P->n_cams; c++) pb.cams[c] = se3_from_Tcw_f32(P->cam_Tcw + 16 * c);
+    pb.pts.resize((size_t)P->n_points * 3);
+    for (size_t i = 0; i < pb.pts.size(); i++) pb.pts[i] = P->points[i];
+    pb.edges.resize(P->n_edges);
+    for (int k = 0; k < P->n_edges; k++) {
+        BAEdge& e = pb.edges[k];
+        e.cam = P->edge_cam[k]; e.pt = P->edge_point[k];
+        for (int j = 0; j < 3; j++) e.obs[j] = P->edge_obs[3 * k + j];
+        e.stereo = !(P->edge_obs[3 * k + 2] < 0);
+        e.info = P->edge_inv_sigma2[k];
+        e.robust = robust != 0;
+    }
+    if (trace) trace->n = 0;
+    if (iters) { iters[0] = iters[1] = 0; }
+    pb.initialize();
+    LM lm; LMTrace tr;
+    const int it = lm.optimize(pb, iterations, stop, &tr);
+    if (iters) iters[0] = it;
+    if (trace) for (size_t k = 0; k < tr.lambda.size() && trace->n < 64; k++) {
+        trace->lambda[trace->n] = tr.lambda[k]; trace->chi2[trace->n] = tr.chi2[k]; trace->trials[trace->n] = tr.trials[k]; trace->n++;
+    }
+    for (int c = 0; c < P->n_cams; c++) {
+        se3_to_Tcw_f32(pb.cams[c], cam_Tcw_out + 16 * c);
+        if (cams_d) { double* d = cams_d + 7 * c; d[0] = pb.cams[c].r.x; d[1] = pb.cams[c].r.y; d[2] = pb.cams[c].r.z; d[3] = pb.cams[c].r.w;
+                      d[4] = pb.cams[c].t[0]; d[5] = pb.cams[c].t[1]; d[6] = pb.cams[c].t[2]; }
+    }
+    for (size_t i = 0; i < pb.pts.size(); i++) { points_out[i] = (float)pb.pts[i]; if (points_d) points_d[i] = pb.pts[i]; }
+    return 0;
+}
+
 // ---- known-answer hooks for tests -------------------------------------------------------------
 // residual of one binary edge at (Tcw given as quaternion+translation fp64, point fp64)
 void orc_ba_edge_eval(const double* cam7, const double* pt3, const double* obs3, int stereo,

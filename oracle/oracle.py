@@ -75,6 +75,8 @@ def lib():
         L.orc_hamming_best2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_pose_optimization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_local_ba.argtypes = [C.c_void_p] * 9
+        L.orc_bundle_adjustment.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
+        L.orc_bundle_adjustment.restype = C.c_int
         L.orc_ba_edge_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_double] * 5 + [C.c_void_p] * 3
         L.orc_se3_oplus.argtypes = [C.c_void_p] * 3
         L.orc_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
@@ -250,6 +252,30 @@ def local_ba(prob, its=(5, 10), stop=None):
     rc = lib().orc_local_ba(C.byref(P), stop_p, _p(cams_out), _p(pts_out), _p(outl), _p(cams_d), _p(pts_d), _p(iters), C.byref(tr))
     return dict(poses=cams_out, points=pts_out, edge_outlier=outl[:len(ec)], cams_d=cams_d, points_d=pts_d,
                 iters=iters, trace=tr.to_dict(), aborted=bool(rc))
+
+
+def bundle_adjustment(prob, iterations=5, robust=True, stop=None):
+    """Optimizer::BundleAdjustment over keyframes and map points (oracle/lm_cpu.cpp: orc_bundle_adjustment)"""
+    cams = np.ascontiguousarray(prob["poses"], np.float32)
+    fixed = np.ascontiguousarray(prob["fixed"], np.uint8)
+    pts = np.ascontiguousarray(prob["points"], np.float32)
+    ec = np.ascontiguousarray(prob["edge_cam"], np.int32)
+    ep = np.ascontiguousarray(prob["edge_point"], np.int32)
+    obs = np.ascontiguousarray(prob["obs"], np.float32)
+    inv = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+    P = BAProblem(len(cams), len(pts), len(ec), _p(cams), _p(fixed), _p(pts), _p(ec), _p(ep), _p(obs), _p(inv),
+                  prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], iterations, 0)
+    cams_out, pts_out = np.zeros_like(cams), np.zeros_like(pts)
+    cams_d, pts_d = np.zeros((len(cams), 7)), np.zeros((len(pts), 3))
+    iters = np.zeros(2, np.int32)
+    tr = Trace()
+    stop_p = None
+    if stop is not None:
+        stop_arr = np.array([1 if stop else 0], np.uint8)
+        stop_p = _p(stop_arr)
+    lib().orc_bundle_adjustment(C.byref(P), int(iterations), 1 if robust else 0, stop_p, _p(cams_out), _p(pts_out), _p(cams_d), _p(pts_d),
+                                _p(iters), C.byref(tr))
+    return dict(poses=cams_out, points=pts_out, cams_d=cams_d, points_d=pts_d, iters=iters, trace=tr.to_dict())
 
 
 class FrameView(C.Structure):   # same layout as eao_frame_view

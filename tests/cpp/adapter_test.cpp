@@ -28,6 +28,8 @@ struct MapPoint {
     cv::Mat pos;
     std::map<KeyFrame*, size_t> observations;
     int normalUpdates = 0;
+    cv::Mat mPosGBA;                       // Optimizer::BundleAdjustment with nLoopKF != 0
+    long unsigned int mnBAGlobalForKF = 0;
     bool isBad() { return false; }
     cv::Mat GetWorldPos() { return pos.clone(); }
     void SetWorldPos(const cv::Mat& p) { pos = p.clone(); }
@@ -44,7 +46,8 @@ struct KeyFrame {
     std::vector<float> mvuRight, mvInvLevelSigma2;
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<KeyFrame*> covisible;
-    cv::Mat Tcw;
+    cv::Mat Tcw, mTcwGBA;
+    long unsigned int mnBAGlobalForKF = 0;
     int erased = 0;
     bool isBad() { return false; }
     cv::Mat GetPose() { return Tcw.clone(); }
@@ -59,7 +62,8 @@ struct Map { std::mutex mMutexMapUpdate; };
 struct MapPlane {
     static std::mutex mGlobalMutex;
     cv::Mat world;
-    bool mbSeen = false;
+    bool mbSeen = false, bad = false;
+    bool isBad() { return bad; }
     cv::Mat GetWorldPos() { return world.clone(); }
 };
 std::mutex MapPlane::mGlobalMutex;
@@ -264,6 +268,65 @@ int main(int argc, char** argv) {
         eaofusion::ComputeStereoMatches(SF);
         const int32_t ns = SF.N;
         wr(out, &ns, 1); wr(out, SF.mvuRight.data(), ns); wr(out, SF.mvDepth.data(), ns);
+    }
+    // ---------------------------------------------------------------- Optimizer::BundleAdjustment (keyframes + map points)
+    {
+        auto build = [&](std::vector<KeyFrame>& gk, std::vector<MapPoint>& gm) {
+            gk.assign(nc, KeyFrame()); gm.assign(np, MapPoint());
+            for (int c = 0; c < nc; c++) {
+                gk[c].mnId = c;
+                gk[c].fx = K[0]; gk[c].fy = K[1]; gk[c].cx = K[2]; gk[c].cy = K[3]; gk[c].mbf = K[4];
+                gk[c].Tcw = cv::Mat(4, 4, CV_32F);
+                for (int k = 0; k < 16; k++) gk[c].Tcw.ptr<float>(0)[k] = camT[c * 16 + k];
+                gk[c].mvInvLevelSigma2.assign(1, 0.f);
+            }
+            for (int p = 0; p < np; p++) {
+                gm[p].mnId = p;
+                gm[p].pos = cv::Mat(3, 1, CV_32F);
+                for (int k = 0; k < 3; k++) gm[p].pos.at<float>(k) = pts[3 * p + k];
+            }
+            for (int e = 0; e < ne; e++) {
+                KeyFrame& kf = gk[ecam[e]];
+                const size_t idx = kf.mvKeysUn.size();
+                cv::KeyPoint kp;
+                kp.pt.x = eobs[3 * e]; kp.pt.y = eobs[3 * e + 1];
+                kp.octave = (int)kf.mvInvLevelSigma2.size();
+                kf.mvInvLevelSigma2.push_back(einv[e]);
+                kf.mvKeysUn.push_back(kp);
+                kf.mvuRight.push_back(eobs[3 * e + 2]);
+                kf.mvpMapPoints.push_back(&gm[ept[e]]);
+                gm[ept[e]].observations[&kf] = idx;
+            }
+        };
+        std::vector<KeyFrame> gk; std::vector<MapPoint> gm;
+        build(gk, gm);
+        std::vector<KeyFrame*> vk; std::vector<MapPoint*> vm; std::vector<MapPlane*> vpl;
+        for (int c = nc - 1; c >= 0; c--) vk.push_back(&gk[c]);      // any order: the template sorts by mnId
+        for (int p = 0; p < np; p++) vm.push_back(&gm[p]);
+        MapPlane deadPlane; deadPlane.bad = true; vpl.push_back(&deadPlane);   // a bad plane is skipped (:205-206)
+        eaofusion::BundleAdjustment(vk, vm, vpl, 10, nullptr, 0, false);       // nLoopKF == 0: SetPose / SetWorldPos
+        for (int c = 0; c < nc; c++) wr(out, gk[c].Tcw.ptr<float>(0), 16);
+        for (int p = 0; p < np; p++) wr(out, gm[p].pos.ptr<float>(0), 3);
+        int32_t normalsG = 0;
+        for (int p = 0; p < np; p++) normalsG += gm[p].normalUpdates;
+        wr(out, &normalsG, 1);
+        build(gk, gm);
+        vk.clear(); vm.clear();
+        for (int c = 0; c < nc; c++) vk.push_back(&gk[c]);
+        for (int p = 0; p < np; p++) vm.push_back(&gm[p]);
+        eaofusion::BundleAdjustment(vk, vm, vpl, 10, nullptr, 7, false);       // loop closing: results parked in mTcwGBA / mPosGBA
+        int32_t parked = 1;
+        for (int c = 0; c < nc; c++) {
+            parked &= gk[c].mnBAGlobalForKF == 7 && !gk[c].mTcwGBA.empty();
+            for (int k = 0; k < 16; k++) parked &= gk[c].Tcw.ptr<float>(0)[k] == camT[c * 16 + k];   // poses themselves untouched
+            wr(out, gk[c].mTcwGBA.ptr<float>(0), 16);
+        }
+        for (int p = 0; p < np; p++) parked &= gm[p].normalUpdates == 0 && (gm[p].observations.empty() || (gm[p].mnBAGlobalForKF == 7 && !gm[p].mPosGBA.empty()));
+        wr(out, &parked, 1);
+        MapPlane livePlane; vpl.push_back(&livePlane);
+        int32_t refused = 0;
+        try { eaofusion::BundleAdjustment(vk, vm, vpl, 10, nullptr, 0, false); } catch (const std::runtime_error&) { refused = 1; }
+        wr(out, &refused, 1);
     }
     printf("adapter_test ok: %d keypoints, %d pose inliers, %d observations erased\n", nk, inliers, erased);
     return 0;

@@ -100,6 +100,19 @@ def test_cpp_adapters_end_to_end(tmp_path):
     skr, sdr = er(sr)
     ur, dp = E.compute_stereo_matches(el, er, skl, sdl, skr, sdr, np.float32(40.0) / np.float32(535.4), np.float32(40.0))
     assert ns == len(skl) and np.array_equal(ur_cpp, ur) and np.array_equal(dp_cpp, dp) and (ur >= 0).sum() > 100
+    # ---- Optimizer::BundleAdjustment (keyframes + map points): only keyframe 0 is fixed, one optimize(10), no Huber kernels
+    gposes = take(np.float32, nc * 16).reshape(nc, 4, 4)
+    gpts = take(np.float32, npnt * 3).reshape(npnt, 3)
+    normals_g = int(take(np.int32, 1)[0])
+    parked_poses = take(np.float32, nc * 16).reshape(nc, 4, 4)
+    parked, refused = (int(x) for x in take(np.int32, 2))
+    gp = dict(bp)
+    gp["fixed"] = (np.arange(nc) == 0).astype(np.uint8)
+    rg = E.Optimizer.BundleAdjustment(gp, 10, bRobust=False)
+    assert rg["iters"][0] >= 3
+    assert np.allclose(gposes, rg["poses"], rtol=0, atol=2e-6) and np.allclose(gpts, rg["points"], rtol=0, atol=2e-5)
+    assert np.array_equal(gposes[0], bp["poses"][0]) and normals_g == npnt
+    assert np.array_equal(parked_poses, gposes) and parked == 1 and refused == 1
 
 
 def test_cpp_search_adapters(tmp_path):

@@ -134,3 +134,33 @@ def test_pose_optimization_too_few_points(gpu):
     p = synth.synth_pose(n=2)
     r = gpu.Optimizer.PoseOptimization(p)
     assert r["n_inliers"] == 0 and np.array_equal(r["Tcw"], p["Tcw"])   # src/Optimizer.cc:453-454
+
+
+@pytest.mark.parametrize("kw,its,robust", [(dict(n_free=11, n_fixed=1, n_points=800, seed=5100), 10, False),
+                                           (dict(n_free=5, n_fixed=1, n_points=300, seed=5101, mono_frac=0.3), 20, True),
+                                           (dict(n_free=2, n_fixed=1, n_points=150, seed=5103, outlier_frac=0.0), 20, True),
+                                           # beyond the register-tile solver (30 free keyframes): the LDS / global-scratch solver
+                                           (dict(n_free=40, n_fixed=1, n_points=2000, seed=5102), 10, False)])
+def test_bundle_adjustment_parity(gpu, oracle, kw, its, robust):
+    """Optimizer::BundleAdjustment over keyframes and map points (src/Optimizer.cc:55-323): keyframe 0 fixed, ONE
+    optimize(nIterations), Huber kernels only when bRobust, nothing is erased, a point without observations stays put."""
+    p = synth.synth_ba(**kw)
+    orphan = np.array([[0.1, 0.2, 3.0], [-0.4, 0.1, 4.0]], np.float32)
+    p["points"] = np.concatenate([p["points"], orphan])          # two map points nobody observes (removed from the graph, :193-201)
+    r = gpu.Optimizer.BundleAdjustment(p, its, bRobust=robust)
+    o = oracle.bundle_adjustment(p, its, robust)
+    assert list(r["iters"]) == [int(o["iters"][0]), 0] and r["iters"][0] >= 3
+    _check_trace(r, o)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    assert np.array_equal(r["points"][-2:], orphan) and not r["edge_outlier"].any()
+    assert np.array_equal(r["poses"][0], o["poses"][0])
+
+
+def test_bundle_adjustment_limits(gpu):
+    p = synth.synth_ba(n_free=70, n_fixed=1, n_points=400, seed=5104)
+    with pytest.raises(gpu.EaoError):            # more free keyframes than the single-workgroup solvers take: refused, not approximated
+        gpu.Optimizer.BundleAdjustment(p, 10, bRobust=False)
+    p = synth.synth_ba(n_free=4, n_fixed=1, n_points=100, seed=5105)
+    r = gpu.Optimizer.BundleAdjustment(p, 10, stop=np.array([1], np.uint8))
+    assert r["aborted"] and np.array_equal(r["points"], p["points"])

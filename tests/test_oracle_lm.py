@@ -140,3 +140,25 @@ def test_pose_outlier_classification_consistent(oracle):
     assert 0.05 < r["outlier"].mean() < 0.3
     assert np.abs(r["Tcw"] - p["Tcw_gt"]).max() < 5e-3
     assert oracle.pose_optimization({**p, "points": p["points"][:2], "obs": p["obs"][:2], "inv_sigma2": p["inv_sigma2"][:2]})["n_inliers"] == 0
+
+
+def test_bundle_adjustment_restatement(oracle):
+    """oracle/lm_cpu.cpp: orc_bundle_adjustment (src/Optimizer.cc:55-323 over keyframes and map points): zero noise reaches
+    the ground truth with keyframe 0 alone fixed; it is the first pass of the local-BA restatement when the kernels and
+    the Huber width agree (no outliers: every residual far below sqrt(5.99)); unobserved points do not move; robust
+    kernels change the result when there are outliers."""
+    p = synth.synth_ba(n_free=7, n_fixed=1, n_points=300, sigma=0.0, outlier_frac=0.0)
+    r = oracle.bundle_adjustment(p, 10, robust=False)
+    assert np.abs(r["poses"] - p["poses_gt"]).max() < 3e-4 and r["iters"][0] >= 3 and r["iters"][1] == 0
+    p2 = synth.synth_ba(n_free=5, n_fixed=1, n_points=200, seed=3111, sigma=0.3, outlier_frac=0.0)
+    a = oracle.bundle_adjustment(p2, 5, robust=True)
+    b = oracle.local_ba(p2, its=(5, 0))
+    assert np.abs(a["poses"] - b["poses"]).max() < 1e-5 and np.array_equal(a["iters"][:1], b["iters"][:1])
+    p3 = synth.synth_ba(n_free=5, n_fixed=1, n_points=200, seed=3112, outlier_frac=0.1)
+    p3["points"] = np.concatenate([p3["points"], np.array([[0.5, 0.5, 3.5]], np.float32)])
+    rr, rn = oracle.bundle_adjustment(p3, 10, robust=True), oracle.bundle_adjustment(p3, 10, robust=False)
+    assert np.array_equal(rr["points"][-1], p3["points"][-1]) and np.array_equal(rn["points"][-1], p3["points"][-1])
+    assert np.abs(rr["poses"] - rn["poses"]).max() > 1e-4
+    err_r = np.abs(rr["poses"] - p3["poses_gt"]).max()
+    err_n = np.abs(rn["poses"] - p3["poses_gt"]).max()
+    assert err_r < err_n                                  # the Huber kernels are what keeps 10 % outliers from dragging the poses
