@@ -12,7 +12,7 @@ Local BA (configs[3], 20 KF x 3000 MP) and Hamming (configs[2]) are measured aft
 under "extra" -- the combined BASELINE metric has two halves; `value` is its first half (ORB kpts/s), the BA half
 is extra.ba_residual_blocks_per_s.
 
-Multi-GPU: frames are independent units => each rank extracts its own 64-frame shard (weak scaling, no data-path
+Multi-GPU: frames are independent units => each rank extracts its own B-frame shard (--batch, default 256) (weak scaling, no data-path
 collective); the only collectives are the timing barrier/max and one all_gather of the per-frame keypoint counts
 (RCCL), which is outside the timed region.
 
@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -67,7 +67,7 @@ def main():
     from eao_fusion_amd import shard, synth
 
     B, W, H = args.batch, 640, 480
-    n_frames = B * world                                   # weak scaling: 64 frames per GPU
+    n_frames = B * world                                   # weak scaling: B frames per GPU
     lo, hi = shard.frame_shard(n_frames, rank, world)      # contiguous shard of the sequence owned by this rank
     assert hi - lo == B
     frames = np.stack([synth.synth_frame(1000 + f, W, H) for f in range(lo, hi)])

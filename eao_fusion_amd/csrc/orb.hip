@@ -1343,7 +1343,8 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     // candidate keys (4 B) + node indices (2 B) in LDS while two workgroups still fit a CU
     h->quadLds = (h->quadLds + 15) & ~(size_t)15;
     g.qtKeysOff = (int)h->quadLds;
-    g.qtLdsCand = (int)std::min<size_t>(8192, h->quadLds < 76 * 1024 ? (76 * 1024 - h->quadLds) / 6 : 0) & ~7;
+    static const size_t kQtLdsCand = getenv("EAO_QT_LDS_CAND") ? (size_t)atoi(getenv("EAO_QT_LDS_CAND")) : 8192;
+    g.qtLdsCand = (int)std::min<size_t>(kQtLdsCand, h->quadLds < 76 * 1024 ? (76 * 1024 - h->quadLds) / 6 : 0) & ~7;
     h->quadLds += (size_t)g.qtLdsCand * 6;
     // the blur kernel hard-codes the taps; make sure the published construction gives them
     {

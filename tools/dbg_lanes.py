@@ -6,7 +6,7 @@ from eao_fusion_amd import synth, _lib
 L=_lib.load()
 hip=C.CDLL("libamdhip64.so.7")
 hip.hipMalloc.argtypes=[C.c_void_p,C.c_size_t]; hip.hipMemcpy.argtypes=[C.c_void_p,C.c_void_p,C.c_size_t,C.c_int]
-imgs = synth.synth_frames(64)
+imgs = synth.synth_frames(int(os.environ.get("EAO_DBG_BATCH", "64")))
 ext = E.ORBextractor(1000,1.2,8,20,7)
 B,H,W=imgs.shape; cap=ext.max_keypoints(W,H)
 def dmalloc(n):

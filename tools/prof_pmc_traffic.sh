@@ -26,10 +26,10 @@ stage = {"pyramid": "k_resize", "fast": "k_fast_cells", "blur": "k_blur7", "quad
 # launches of the kernel per bench step (profiled + timed steps of the run: 1 warmup + 3 steps + 3 profiled calls ...): derive from blur (1 per step)
 steps = raw["k_blur7"]["launches_fetch"]
 out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 3 --warmup 1 "
-                "--no-cpu-baseline --no-extra; per-launch averages at batch 64, bytes = KiB counter * 1024.  RAW counters: the guide's x2 FETCH_SIZE "
+                "--no-cpu-baseline --no-extra; bytes = KiB counter * 1024.  RAW counters: the guide's x2 FETCH_SIZE "
                 "correction is calibrated for 16-B-per-lane streaming reads; these kernels read 4 or 12 B per lane, which is uncalibrated -- "
-                "self-check: k_blur7 reads and writes 60.8 MB algorithmically (64 x 950 532 px; + halo rows on the read side, + pitch padding on the write side).",
-       "batch": 64, "kernels": {}}
+                "self-check: k_blur7 reads and writes 243 MB algorithmically (256 x 950 532 px; + halo rows on the read side, + pitch padding on the write side).",
+       "batch": 256, "kernels": {}}
 for st, k in stage.items():
     r = raw[k]
     f, w = r["fetch_KiB_per_launch"] * 1024, r["write_KiB_per_launch"] * 1024
