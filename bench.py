@@ -308,6 +308,50 @@ def measure_extra(E, synth, torch, dev):
         for _ in range(20):
             E.Optimizer.PoseOptimization(pp)
         extra["pose_optimization_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+        # the tracking step of independent frames (both guided searches + PoseOptimization) from several host threads: the
+        # per-frame kernels are latency-bound single-workgroup work, frames of a batched sequence overlap on the device
+        treps = 10
+        def _track():
+            m2 = E.ORBmatcher(0.8, True)
+            for _ in range(treps):
+                m2.SearchByProjectionPoints(curf, mpsf, 1.0)
+                m2.SearchByProjectionFrames(curf, lastf, 7.0, False)
+                E.Optimizer.PoseOptimization(pp)
+        _track()
+        ths = [threading.Thread(target=_track) for _ in range(nth)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dtt = time.perf_counter() - t0
+        extra["tracking_concurrent"] = {"host_threads": nth, "frames_per_s": round(nth * treps / dtt, 1),
+                                        "ms_per_frame": round(dtt * 1e3 / (nth * treps), 3),
+                                        "note": "per frame: SearchByProjection(points) + SearchByProjection(frames) + PoseOptimization, host buffers in/out"}
+        # the Frame glue (isInFrustum over a 20 000-point local map) and a small-map BundleAdjustment (12 KF, 10 its)
+        from eao_fusion_amd import frame as FR
+        rng = np.random.default_rng(11)
+        nmp = 20000
+        X = rng.uniform([-8, -5, -2], [8, 5, 14], (nmp, 3)).astype(np.float32)
+        nv = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+        dd = np.linalg.norm(X, axis=1).astype(np.float32)
+        mpts = dict(active=np.ones(nmp, np.uint8), Xw=X, normal=nv, min_dist_inv=dd * 0.5, max_dist_inv=dd * 2.0, max_dist=dd * 2.5,
+                    descriptors=np.zeros((nmp, 32), np.uint8))
+        ffr = dict(Tcw=np.eye(4, dtype=np.float32), Ow=np.zeros(3, np.float32), fx=517.3, fy=516.5, cx=318.6, cy=255.3, mbf=40.0, min_x=0,
+                   max_x=640, min_y=0, max_y=480, log_scale_factor=float(np.log(np.float32(1.2))))
+        FR.is_in_frustum(ffr, mpts, 0.5)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            rr = FR.is_in_frustum(ffr, mpts, 0.5)
+        extra["is_in_frustum"] = {"map_points": nmp, "in_view": int(rr["in_view"].sum()), "ms_per_call": round((time.perf_counter() - t0) / 20 * 1e3, 3),
+                                  "note": "host buffers in/out (0.6 MB up, 0.4 MB down)"}
+        gp = synth.synth_ba(n_free=11, n_fixed=1, n_points=2000, seed=5100)
+        E.Optimizer.BundleAdjustment(gp, 10, bRobust=False)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            rg = E.Optimizer.BundleAdjustment(gp, 10, bRobust=False)
+        extra["bundle_adjustment"] = {"workload": "BundleAdjustment 11 free + 1 fixed KF x 2000 MP, E=%d, 10 its, no robust kernel" % len(gp["edge_cam"]),
+                                      "ms_per_call": round((time.perf_counter() - t0) / 5 * 1e3, 3), "iters": int(rg["iters"][0])}
     except Exception as ex:  # noqa: BLE001
         extra["ba_error"] = repr(ex)
     return extra
@@ -391,6 +435,13 @@ def measure_cpu(frames, synth, extra):
             O.pose_optimization(pp)
             reps += 1
         ex["cpu_pose_optimization_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+        gp = synth.synth_ba(n_free=11, n_fixed=1, n_points=2000, seed=5100)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            O.bundle_adjustment(gp, 10, False)
+            reps += 1
+        ex["cpu_bundle_adjustment_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
     except Exception as e:  # noqa: BLE001
         ex["cpu_extra_error"] = repr(e)
     return cpu, ex
