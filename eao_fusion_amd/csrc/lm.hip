@@ -1050,6 +1050,74 @@ __global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int 
     }
 }
 
+// The decision is a pure function of the previous LM state and three sums (BADecision); committing it writes the next LM
+// state.  It runs either in k_ba_decide (state updated in place) or, for every trial but the last of a bulk segment, at the
+// head of the NEXT trial's k_ba_linearize: every workgroup of that kernel derives the same decision from the OLD control
+// block (which nobody writes during the kernel), workgroup 0 commits it into the OTHER control block, and the rest of
+// the trial reads that one -- one launch less per trial, no inter-workgroup synchronisation.
+struct BADecision {
+    double lambda, nu, chi, rho, tempChi, currentChi;
+    int accepted, cur, iters, nBad, halt, status, ok2;
+};
+__device__ inline BADecision ba_decision(const double* lmOld, const int* ctlOld, double tempSum, double scale, int ok2, int bulk) {
+    BADecision d;
+    const double lambda = lmOld[0];
+    d.ok2 = ok2;
+    d.tempChi = ok2 ? tempSum : DBL_MAX;
+    d.currentChi = lmOld[2];
+    double rho = d.currentChi - d.tempChi;
+    scale += 1e-3;
+    rho /= scale;
+    d.rho = rho;
+    d.cur = ctlOld[kCtlCur]; d.iters = ctlOld[kCtlIters]; d.nBad = ctlOld[kCtlNBad]; d.halt = ctlOld[kCtlHalt];
+    d.chi = d.currentChi;
+    d.accepted = 0;
+    if (rho > 0 && isfinite(d.tempChi)) {
+        const double y = 2 * rho - 1;
+        double alpha = 1. - y * y * y;
+        alpha = fmin(alpha, 2. / 3.);
+        d.lambda = lambda * fmax(1. / 3., alpha);
+        d.nu = 2;
+        d.chi = d.tempChi;
+        d.accepted = 1;
+        d.cur ^= 1;                         // discardTop(): the trial buffer becomes the estimate
+    } else {
+        d.lambda = lambda * lmOld[1];
+        d.nu = lmOld[1] * 2;
+    }
+    d.status = kStRunning;
+    if (bulk) {
+        if (d.accepted) {
+            d.iters += 1;
+            if ((d.currentChi - d.tempChi) * 1e3 < d.currentChi) d.nBad++; else d.nBad = 0;
+            if (d.nBad >= 3) { d.status = kStTerminate; d.halt = 1; }
+        } else {
+            d.status = kStTakeover;
+            d.halt = 1;
+        }
+    }
+    return d;
+}
+// one thread; lm / ctl may be the old blocks themselves (in place) or the other pair
+__device__ inline void ba_commit(const BADecision& d, const double* lmOld, const int* ctlOld, double* lm, int* ctl, BAStatus* st, int seq, int bulk) {
+    const int phase = ctlOld[kCtlPhase] & 1;
+    const int itersOld = ctlOld[kCtlIters], statusOld = ctlOld[kCtlStatus], anyActive = ctlOld[kCtlAnyActive], phaseRaw = ctlOld[kCtlPhase];
+    const double maxDiag = lmOld[3];
+    lm[0] = d.lambda; lm[1] = d.nu; lm[2] = d.chi; lm[3] = maxDiag;
+    ctl[kCtlHalt] = d.halt; ctl[kCtlCur] = d.cur; ctl[kCtlIters] = d.iters; ctl[kCtlNBad] = d.nBad;
+    ctl[kCtlStatus] = bulk ? d.status : statusOld; ctl[kCtlPhase] = phaseRaw; ctl[kCtlAnyActive] = anyActive;
+    if (bulk && d.accepted && itersOld < 32) {
+        const int slot = 32 * phase + itersOld;
+        st->trLambda[slot] = d.lambda; st->trChi[slot] = d.tempChi; st->trTrials[slot] = 1;
+    }
+    st->lambda = d.lambda; st->rho = d.rho; st->chi = d.chi; st->tempChi = d.tempChi; st->accepted = d.accepted; st->solveOk = d.ok2;
+    st->cur = d.cur; st->iters = d.iters; st->status = d.status; st->nBad = d.nBad;
+    BAPhase& ph = st->ph[phase];
+    ph.lambda = d.lambda; ph.rho = d.rho; ph.chi = d.chi; ph.accepted = d.accepted; ph.cur = d.cur; ph.iters = d.iters;
+    ph.status = d.status; ph.nBad = d.nBad; ph.touched = 1;
+    st->seq = seq;
+}
+
 // role A: blocks [0, ptBlocks): eight lanes per landmark.  role B: blocks [ptBlocks, ptBlocks + nFree): one block per free
 // camera, one edge per thread; the 27 sums (21 of Hpp's upper triangle + 6 of bp) go through LDS in a fixed order: lane
 // quads first (DPP), then 27 x 8 column threads over 32 quad leaders each, then the last 8.  (Sixty-four-lane shuffle
@@ -1058,12 +1126,33 @@ constexpr int kLinThreads = 1024;
 // first = 1 on the first linearisation of an optimize() call: the largest |diagonal entry| of Hpp / Hll (lambda_0 = 1e-5 x
 // that, optimization_algorithm_levenberg.cpp:166-180) is accumulated with one atomic max per workgroup -- a max does not
 // depend on the order, and non-negative doubles order like their bit patterns.
-__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlocks, int first) {
+// ctlOld != nullptr: the previous trial's decision has not been taken yet (bulk segment): see BADecision.  P.ctl / P.lm
+// are then the blocks this trial runs on (written by workgroup 0 here), ctlOld / lmOld the ones the previous trial ran on.
+__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlocks, int first, const int* ctlOld, const double* lmOld,
+                                                              const int* solveOk, BAStatus* st, int seq) {
     __shared__ double red[(kLinThreads / 4) * 27], part[8 * 27];
     __shared__ double s_wmax[kLinThreads / 64];
-    if (P.ctl[kCtlHalt]) return;
-    const SE3* cams = cur_cams(P);
-    const double* pts = cur_pts(P);
+    int cur;
+    if (ctlOld) {
+        if (ctlOld[kCtlHalt]) {   // frozen stream: hand the control block on unchanged
+            if (blockIdx.x == 0 && threadIdx.x < 8) { P.ctl[threadIdx.x] = ctlOld[threadIdx.x]; P.lm[threadIdx.x] = lmOld[threadIdx.x]; }
+            return;
+        }
+        double v[2] = {0, 0};
+#pragma unroll 3
+        for (int i = threadIdx.x; i < P.nL; i += kLinThreads) { v[0] += P.partChi[i]; v[1] += P.partScale[i]; }
+        block_sum<2, kLinThreads>(v, red, part);
+        const BADecision d = ba_decision(lmOld, ctlOld, part[0], lmOld[4] + part[1], *solveOk, 1);   // the same in every workgroup
+        __syncthreads();   // (red / part are reused below)
+        if (blockIdx.x == 0 && threadIdx.x == 0) ba_commit(d, lmOld, ctlOld, P.lm, P.ctl, st, seq, 1);
+        if (d.halt) return;
+        cur = d.cur;
+    } else {
+        if (P.ctl[kCtlHalt]) return;
+        cur = P.ctl[kCtlCur];
+    }
+    const SE3* cams = P.camsBuf[cur];
+    const double* pts = P.ptsBuf[cur];
     if ((int)blockIdx.x < ptBlocks) {
         // role A: eight lanes per landmark, one edge per lane; Hll / bl are xor-tree sums over the lane group
         const int l = (blockIdx.x * kLinThreads + threadIdx.x) >> 3, slot = threadIdx.x & 7;
@@ -1882,66 +1971,17 @@ __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(BADev P, int* s
 // clean iteration -- first trial accepted -- is finished right here (trace entry, iteration count, the "3 bad
 // iterations" stop); anything else (rejected trial, rho == 0 or NaN) raises the halt flag so that the kernels still in
 // the stream do nothing, and the host takes that iteration over trial by trial.  The status block is pinned host memory;
-// the host reads it after a stream synchronisation, so no fence is needed.
+// the host reads it after a stream synchronisation, so no fence is needed.  (The camera part of the gain denominator,
+// sum x (lambda x + b), is left in lm[4] by k_ba_backsub: the next linearisation overwrites b.)
 __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BAStatus* st, int seq, int bulk) {
-    // the three sums of the decision (robust chi2 at the trial state, the landmark and the camera part of the gain
-    // denominator) go through ONE fixed-order block reduction; every load of a thread is issued before its first add
-    __shared__ double red[3 * 4], out3[3];
-    const double lambda = P.lm[0];
-    double v[3] = {0, 0, 0};
-    {
+    __shared__ double red[2 * 4], out2[2];
+    double v[2] = {0, 0};
 #pragma unroll 4
-        for (int i = threadIdx.x; i < P.nL; i += 256) { v[0] += P.partChi[i]; v[1] += P.partScale[i]; }
-        for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { const double x = P.xp[i]; v[2] += x * (lambda * x + P.bp[i]); }
-    }
-    block_sum<3, 256>(v, red, out3);
+    for (int i = threadIdx.x; i < P.nL; i += 256) { v[0] += P.partChi[i]; v[1] += P.partScale[i]; }
+    block_sum<2, 256>(v, red, out2);
     if (threadIdx.x == 0) {
-        const double tempSum = out3[0];
-        double scale = out3[2] + out3[1];
-        const int ok2 = *solveOk;
-        double tempChi = tempSum;
-        if (!ok2) tempChi = DBL_MAX;
-        const double currentChi = P.lm[2];
-        double rho = currentChi - tempChi;
-        scale += 1e-3;
-        rho /= scale;
-        int accepted = 0;
-        if (rho > 0 && isfinite(tempChi)) {
-            const double y = 2 * rho - 1;
-            double alpha = 1. - y * y * y;
-            alpha = fmin(alpha, 2. / 3.);
-            P.lm[0] = lambda * fmax(1. / 3., alpha);
-            P.lm[1] = 2;
-            P.lm[2] = tempChi;
-            accepted = 1;
-            P.ctl[kCtlCur] ^= 1;            // discardTop(): the trial buffer becomes the estimate
-        } else {
-            P.lm[0] = lambda * P.lm[1];
-            P.lm[1] *= 2;
-        }
-        int status = kStRunning;
-        if (bulk) {
-            if (accepted) {
-                const int k = P.ctl[kCtlIters];
-                const int slot = 32 * (P.ctl[kCtlPhase] & 1) + k;
-                if (k < 32) { st->trLambda[slot] = P.lm[0]; st->trChi[slot] = tempChi; st->trTrials[slot] = 1; }
-                P.ctl[kCtlIters] = k + 1;
-                int nb = P.ctl[kCtlNBad];
-                if ((currentChi - tempChi) * 1e3 < currentChi) nb++; else nb = 0;
-                P.ctl[kCtlNBad] = nb;
-                if (nb >= 3) { status = kStTerminate; P.ctl[kCtlHalt] = 1; }
-            } else {
-                status = kStTakeover;
-                P.ctl[kCtlHalt] = 1;
-            }
-            P.ctl[kCtlStatus] = status;
-        }
-        st->lambda = P.lm[0]; st->rho = rho; st->chi = P.lm[2]; st->tempChi = tempChi; st->accepted = accepted; st->solveOk = ok2;
-        st->cur = P.ctl[kCtlCur]; st->iters = P.ctl[kCtlIters]; st->status = status; st->nBad = P.ctl[kCtlNBad];
-        BAPhase& ph = st->ph[P.ctl[kCtlPhase] & 1];
-        ph.lambda = P.lm[0]; ph.rho = rho; ph.chi = P.lm[2]; ph.accepted = accepted; ph.cur = P.ctl[kCtlCur]; ph.iters = P.ctl[kCtlIters];
-        ph.status = status; ph.nBad = P.ctl[kCtlNBad]; ph.touched = 1;
-        st->seq = seq;
+        const BADecision d = ba_decision(P.lm, P.ctl, out2[0], P.lm[4] + out2[1], *solveOk, bulk);
+        ba_commit(d, P.lm, P.ctl, P.lm, P.ctl, st, seq, bulk);
     }
 }
 
@@ -2008,13 +2048,25 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
         P.partChi[l] = chi;
         P.partScale[l] = xl[0] * (lambda * xl[0] + bl[0]) + xl[1] * (lambda * xl[1] + bl[1]) + xl[2] * (lambda * xl[2] + bl[2]);
     }
+    if (blockIdx.x == 0) {   // camera part of the gain denominator, sum x (lambda x + b), for the decision (fixed order)
+        __shared__ double red[4], out1;
+        double v[1] = {0};
+        for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { const double x = P.xp[i]; v[0] += x * (lambda * x + P.bp[i]); }
+        block_sum<1, 256>(v, red, &out1);
+        if (threadIdx.x == 0) P.lm[4] = out1;
+    }
 }
 
 // One block.  (Folding this into k_ba_backsub behind a last-block ticket was measured: the agent-scope fences every
 // block then needs cost more (23 us for the pair) than the launch they save (6 + 9 us).)
-__global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, BAStatus* st, int seq, int bulk) {
-    if (P.ctl[kCtlHalt]) return;
-    ba_decide_block(P, solveOk, st, seq, bulk);
+// ctl0 / lm0: the canonical control blocks.  The last trial of a bulk segment may have run on the other pair (see
+// BADecision); whatever happened, the state is back in the canonical pair when this kernel ends.
+__global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, BAStatus* st, int seq, int bulk, int* ctl0, double* lm0) {
+    if (!P.ctl[kCtlHalt]) ba_decide_block(P, solveOk, st, seq, bulk);
+    if (P.ctl != ctl0) {
+        __syncthreads();
+        if (threadIdx.x < 8) { ctl0[threadIdx.x] = P.ctl[threadIdx.x]; lm0[threadIdx.x] = P.lm[threadIdx.x]; }
+    }
 }
 
 // per edge: chi2 (of the stored residual) > threshold or non-positive depth at the current state.  update = 1 is the
@@ -2297,7 +2349,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     unsigned char* dflag = a.take<unsigned char>(E);
     int* dcamIdx = a.take<int>(nC); int* dptIdx = a.take<int>(nP); int* dactCam = a.take<int>(nC); int* dactPt = a.take<int>(nP);
     int* dptStart = a.take<int>(nP + 1); int* dptEdges = a.take<int>(E); int* dcamStart = a.take<int>(nC + 1); int* dcamEdges = a.take<int>(E);
-    int* dctl = a.take<int>(8);
+    int* dctl = a.take<int>(16);   // two control blocks: see BADecision
     const size_t off1 = (a.off + 255) & ~(size_t)255;
     // ---- device-only part
     int* dtable = a.take<int>((size_t)nP * nC);
@@ -2318,7 +2370,8 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     D.slab = a.take<double>((size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
     D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
     D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
-    D.lm = a.take<double>(8);
+    D.lm = a.take<double>(16);
+    double* const dlm0 = D.lm;
     int* dsolveOk = a.take<int>(4);
     long long* ddbg = a.take<long long>(16);
     D.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
@@ -2359,7 +2412,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         // edge flags: bit0 stereo, bit2 robust kernel present (bit1 = level 1 is only ever set on the device)
         unsigned char* hf = (unsigned char*)hostp(dflag);
         for (int e = 0; e < E; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | (robust ? 4 : 0));
-        std::memset(hostp(dctl), 0, 8 * sizeof(int));
+        std::memset(hostp(dctl), 0, 16 * sizeof(int));
         // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
         int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
         int* actCam = (int*)hostp(dactCam); int* actPt = (int*)hostp(dactPt);
@@ -2445,7 +2498,9 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         if (solveInLds && !solveTiles) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
         const size_t schurLds = schur_lds_bytes(nF);
         if (nF) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
-        auto enqueue_trial = [&](int bulk, bool firstTrial = false) {
+        int* const ctl0 = dctl; double* const lm0 = dlm0;
+        auto use_pair = [&](int k) { D.ctl = ctl0 + 8 * k; D.lm = lm0 + 8 * k; };
+        auto enqueue_trial = [&](int bulk, bool firstTrial = false, bool withDecide = true) {
             if (nF && usePairs && solveTiles) {
                 hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2), dim3(kPairThreads), 0, s, D, firstTrial ? 1 : 0);
             } else if (nF) {
@@ -2458,18 +2513,33 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
             else if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
             else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
             if (nL) hipLaunchKernelGGL(k_ba_backsub, dim3(ptBlocks), dim3(256), 0, s, D);
-            hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq, bulk);
+            if (withDecide) hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq, bulk, ctl0, lm0);
         };
         auto enqueue_bulk = [&](int from, int to, bool withErrors) {
+            use_pair(0);
             if (withErrors) {   // computeActiveErrors + activeRobustChi2 (otherwise the accepted trial already left them)
                 if (nL) hipLaunchKernelGGL(k_ba_errors, dim3(ptBlocks), dim3(256), 0, s, D);
                 hipLaunchKernelGGL(k_ba_chi_init, dim3(1), dim3(256), 0, s, D, c.status, ++seq);
             }
+            // every trial but the last leaves its accept / reject decision to the head of the next linearisation, which
+            // runs on the other control block (BADecision); the last one is decided by k_ba_decide, which also brings the
+            // state back to the canonical block
+            int par = 0;
             for (int it = from; it < to; it++) {
-                hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0);
+                if (it == from) {
+                    hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0,
+                                       (const int*)nullptr, (const double*)nullptr, (const int*)dsolveOk, c.status, 0);
+                } else {
+                    const int* ctlOld = D.ctl; const double* lmOld = D.lm;
+                    par ^= 1;
+                    use_pair(par);
+                    hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, 0, ctlOld, lmOld,
+                                       (const int*)dsolveOk, c.status, ++seq);
+                }
                 if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);   // no Schur kernel to do it
-                enqueue_trial(1, it == 0 && nF);
+                enqueue_trial(1, it == 0 && nF, it == to - 1);
             }
+            use_pair(0);
         };
         if (phase < 0) { enqueue_bulk(0, iterations, true); return EAO_OK; }   // enqueue only (speculative chaining)
         bool needErrors = true, ok = true;

@@ -494,7 +494,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
     long long* dbg = A.dbg;
     long long dacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dlast = clock64();
 #define QSTAMP(i) do { if (dbg) { const long long now_ = clock64(); dacc[i] += now_ - dlast; dlast = now_; } } while (0)
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
     const int l = A.l, f = A.f, M = A.M;
     const LevelGeom L = g->L[l];
     const int LC = L.listCap, N = L.quota;
@@ -585,9 +585,24 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
         for (int i = t; i < S; i += kQT)
             if (cnt[i] > 1) vlist[scanA[i]] = i;
         // (2) child histograms of every candidate
-        for (int k = t; k < M; k += kQT) {
-            const int nd = nof[k];
-            if (cnt[nd] > 1) atomicAdd(&childcnt[4 * nd + quadrant(keys[k], box[nd])], 1);
+        // The candidates are in spatial order (cells row-major, corners row-major inside a cell), so neighbouring lanes mostly
+        // hit the same (node, quadrant) bin: one LDS atomic per RUN of equal bins in the wave instead of one per candidate
+        // (while the tree is shallow, thousands of atomics would otherwise queue on a handful of words).
+        for (int k0 = 0; k0 < M; k0 += kQT) {
+            const int k = k0 + t;
+            int bin = -1;
+            if (k < M) {
+                const int nd = nof[k];
+                if (cnt[nd] > 1) bin = 4 * nd + quadrant(keys[k], box[nd]);
+            }
+            const int prev = __shfl_up(bin, 1);
+            const bool head = lane == 0 || bin != prev;
+            const unsigned long long hm = __ballot(head);
+            if (head && bin >= 0) {
+                const unsigned long long rest = lane == 63 ? 0ull : (hm >> (lane + 1));
+                const int run = rest ? __ffsll((long long)rest) : 64 - lane;
+                atomicAdd(&childcnt[bin], run);
+            }
         }
         __syncthreads();
         QSTAMP(2);
