@@ -159,3 +159,43 @@ def test_compute_stereo_matches(gpu, oracle, seed, cfg):
     assert m.sum() > 0.3 * len(kl)
     disp = kl["x"][m] - ur[m]
     assert np.all(disp >= 0) and np.all(disp < bf / mb) and np.median(np.abs(disp - np.round(disp))) < 0.35
+
+
+@pytest.mark.parametrize("w,h,pad,shift", [(487, 360, 0, 0), (640, 480, 3, 0), (642, 400, 2, 1), (640, 480, 0, 0)])
+def test_device_api_unaligned_frames(gpu, oracle, w, h, pad, shift):
+    """eao_orb_extract_batch_device reads the caller's frames in place: odd widths / pitches and a base pointer that is not
+    4-byte aligned take the byte-wise variants of the resize, FAST staging, blur and orientation loads; the result must not
+    depend on the layout (3 frames, bit-exact against the oracle; the aligned case runs through the same entry point)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")          # the runtime the library itself is linked against (no torch in this module)
+    hip.hipMalloc.argtypes = [C.c_void_p, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+    B = 3
+    frames = np.stack([synth.synth_frame(4200 + f, w, h) for f in range(B)])
+    pitch = w + pad
+    host = np.zeros(B * h * pitch + 8, np.uint8)
+    host[shift:shift + B * h * pitch].reshape(B, h, pitch)[:, :, :w] = frames
+    d_img = dmalloc(host.nbytes)
+    assert hip.hipMemcpy(d_img, host.ctypes.data, host.nbytes, 1) == 0
+    ext = gpu.ORBextractor(1000, 1.2, 8, 20, 7)
+    cap = ext.max_keypoints(w, h)
+    d_k, d_d, d_n = dmalloc(B * cap * 28), dmalloc(B * cap * 32), dmalloc(B * 4)
+    ext.extract_batch_device(d_img.value + shift, w, h, pitch, h * pitch, B, d_k.value, d_d.value, cap, d_n.value, None)
+    assert hip.hipDeviceSynchronize() == 0
+    n = np.zeros(B, np.int32)
+    kps = np.zeros((B, cap), gpu.KP_DTYPE)
+    desc = np.zeros((B, cap, 32), np.uint8)
+    assert hip.hipMemcpy(n.ctypes.data, d_n, n.nbytes, 2) == 0 and hip.hipMemcpy(kps.ctypes.data, d_k, kps.nbytes, 2) == 0
+    assert hip.hipMemcpy(desc.ctypes.data, d_d, desc.nbytes, 2) == 0
+    for p_ in (d_img, d_k, d_d, d_n):
+        hip.hipFree(p_)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    for f in range(B):
+        k0, d0 = orc.extract(frames[f])
+        assert n[f] == len(k0) and np.array_equal(kps[f, :n[f]], k0) and np.array_equal(desc[f, :n[f]], d0), (f, w, h, pad, shift)
