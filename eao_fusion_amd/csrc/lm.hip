@@ -917,6 +917,15 @@ struct BADev {
     double* partScale;      // nL
     double* lm;             // [0] lambda [1] ni [2] currentChi [3] maxdiag
     int chunks;
+    // map-scale path (k_bal_*): dense lower-triangular system in HBM, panel workspace, factored diagonal blocks, pair CSR
+    double* big;            // RP * RP
+    double* bigW;           // RP * 32: w = a L_kk^-T of the current panel
+    double* bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks
+    int* bigFail;
+    const int* lpStart;     // nPairsNZ + 1
+    const int* lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
+    const int* lpPts;       // landmark blocks of each pair, ascending
+    int nPairsNZ;
 };
 
 enum { kCtlHalt = 0, kCtlCur = 1, kCtlIters = 2, kCtlStatus = 3, kCtlNBad = 4, kCtlPhase = 5, kCtlAnyActive = 6 };   // phase: 0 / 1 = first / second optimize()
@@ -1966,6 +1975,244 @@ __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(BADev P, int* s
     if (stamp) { P.dbg[8] = clock64(); P.dbg[9] = wall_clock64(); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Map-scale path (more than kSchurMaxFree free keyframes: Optimizer::BundleAdjustment / GlobalBundleAdjustemnt over a whole
+// map, src/Optimizer.cc:47-323, and oversized local windows).  The reduced camera system no longer fits one workgroup, so
+// it lives in HBM as a dense lower triangle and is factorised by the whole chip:
+//   layout   S: RP x RP doubles, row-major, only col <= row is meaningful.  Rows / columns 0..n-1 = the 6 nFree pose
+//            unknowns, n..N-1 = identity padding up to a multiple of the panel width, row N = the right-hand side (so the
+//            forward substitution is part of the factorisation, as in the tile solver), RP = N + 1 rounded up to the
+//            64-wide update tiles.  Anything above the diagonal or beyond row N is scratch nobody reads.
+//   assembly k_bal_schur_pairs: ONE WAVEFRONT per camera pair (i1 <= i2) that shares at least one landmark -- the pair
+//            lists come from the host as a CSR (counting sort over the landmarks' observer lists, ascending landmark
+//            order); the 6x6 block -Sum Y(i1,l) Hpl(i2,l)^T (+ Hpp + lambda I and the right-hand side on diagonal pairs)
+//            is reduced through LDS in lane order and stored straight into S.  Pairs without a common landmark stay zero
+//            from the memset that precedes every trial (the factorisation fills in place).
+//   factor   right-looking LDL^T without pivoting in panels of 32 columns, two launches per panel:
+//            k_bal_panel   every workgroup factors the 32 x 32 diagonal block redundantly in LDS (32 steps, one barrier
+//                          each), then one thread per row below solves  w = a L_kk^-T  (496 FMAs on registers, L_kk as LDS
+//                          broadcast reads), keeps w for the update and stores l = w D^-1 in place;
+//            k_bal_update  64 x 64 tiles of the trailing lower triangle, C -= W L^T over the 32 panel columns, 4 x 4
+//                          outputs per thread from transposed LDS tiles.
+//   solve    k_bal_backsolve: one 1024-thread workgroup walks L^T x = z bottom-up in blocks of 32 (column sums over the
+//            rows below split across the 32 waves, the 32 x 32 triangle by shuffles in wave 0), then exp(dx) * T.
+// A zero or non-finite pivot fails the trial like SimplicialLDLT (`bigFail`).
+constexpr int kBigMaxFree = 2048;
+constexpr int kBigNB = 32;
+struct BigGeom { int n, N, RP; };
+__host__ __device__ inline BigGeom big_geom(int nF) {
+    BigGeom g;
+    g.n = nF * 6; g.N = (g.n + kBigNB - 1) / kBigNB * kBigNB; g.RP = (g.N + 1 + 63) & ~63;
+    return g;
+}
+
+__global__ __launch_bounds__(64) void k_bal_schur_pairs(BADev P, int first) {
+    __shared__ double red[64 * 43];
+    if (P.ctl[kCtlHalt]) return;
+    const int nF = P.nFree, t = threadIdx.x;
+    const BigGeom g = big_geom(nF);
+    const size_t ld = g.RP;
+    const int i1 = P.lpPair[2 * blockIdx.x], i2 = P.lpPair[2 * blockIdx.x + 1];
+    const bool diag = i1 == i2;
+    const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
+    if (blockIdx.x == 0) {
+        if (first && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
+        if (t == 0) *P.bigFail = 0;
+        for (int r = g.n + t; r < g.N; r += 64) P.big[(size_t)r * ld + r] = 1.0;     // identity padding
+    }
+    const int beg = P.lpStart[blockIdx.x], cnt = P.lpStart[blockIdx.x + 1] - beg;
+    double acc[42];
+#pragma unroll
+    for (int q = 0; q < 42; q++) acc[q] = 0;
+    for (int k = t; k < cnt; k += 64) {
+        const int l = P.lpPts[beg + k];
+        const int e1 = P.table[(size_t)l * nF + i1], e2 = P.table[(size_t)l * nF + i2];
+        if (e1 < 0 || e2 < 0) continue;                      // deactivated by the outlier pass
+        double Di[9];
+        dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
+        const double* B1 = &P.Hpl[(size_t)e1 * 18];
+        const double* B2 = &P.Hpl[(size_t)e2 * 18];
+        double b2[18];
+#pragma unroll
+        for (int q = 0; q < 18; q++) b2[q] = B2[q];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const double h0 = B1[r * 3], h1 = B1[r * 3 + 1], h2 = B1[r * 3 + 2];
+            const double y0 = h0 * Di[0] + h1 * Di[3] + h2 * Di[6];
+            const double y1 = h0 * Di[1] + h1 * Di[4] + h2 * Di[7];
+            const double y2 = h0 * Di[2] + h1 * Di[5] + h2 * Di[8];
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[r * 6 + c] -= y0 * b2[c * 3] + y1 * b2[c * 3 + 1] + y2 * b2[c * 3 + 2];
+            if (diag) {
+                const double* bl = &P.bl[(size_t)l * 3];
+                acc[36 + r] += y0 * bl[0] + y1 * bl[1] + y2 * bl[2];
+            }
+        }
+    }
+    const int act = min(cnt, 64);
+    if (t < act) {
+#pragma unroll
+        for (int q = 0; q < 42; q++) red[t * 43 + q] = acc[q];
+    }
+    __syncthreads();
+    if (t >= 42) return;
+    double s = 0;
+    for (int j = 0; j < act; j++) s += red[j * 43 + t];
+    if (t < 36) {
+        const int r = t / 6, c = t - r * 6;
+        if (!diag) P.big[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = s;        // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
+        else if (c >= r) P.big[(size_t)(i1 * 6 + c) * ld + i1 * 6 + r] = s + P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+    } else if (diag) {
+        const int r = t - 36;
+        P.big[(size_t)g.N * ld + i1 * 6 + r] = P.bp[i1 * 6 + r] - s;         // right-hand side row
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bal_panel(BADev P, int kb) {
+    __shared__ double a[kBigNB][kBigNB + 1];
+    __shared__ double invd[kBigNB];
+    __shared__ int s_bad;
+    if (P.ctl[kCtlHalt]) return;
+    const BigGeom g = big_geom(P.nFree);
+    const size_t ld = g.RP;
+    const int k0 = kb * kBigNB, t = threadIdx.x;
+    double* S = P.big;
+    for (int idx = t; idx < kBigNB * kBigNB; idx += 256) {
+        const int i = idx >> 5, j = idx & 31;
+        a[i][j] = j <= i ? S[(size_t)(k0 + i) * ld + k0 + j] : 0.0;
+    }
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    {
+        const int i = t >> 3, jg = t & 7;
+        for (int p = 0; p < kBigNB; p++) {
+            const double d = a[p][p];
+            const double id = 1.0 / d;
+            if (t == 0) { invd[p] = id; if (d == 0.0 || !isfinite(d)) s_bad = 1; }
+            if (i > p) {
+                const double lip = a[i][p] * id;
+                for (int j = jg; j <= i; j += 8)
+                    if (j > p) a[i][j] = fma(-lip, a[j][p], a[i][j]);
+            }
+            __syncthreads();
+        }
+        for (int j = jg; j < i; j += 8) a[i][j] *= invd[j];       // unit lower L_kk
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB;
+        for (int idx = t; idx < kBigNB * kBigNB; idx += 256) {
+            const int i = idx >> 5, j = idx & 31;
+            Ld[idx] = j < i ? a[i][j] : (j == i ? 1.0 : 0.0);
+        }
+        if (t == 0 && s_bad) *P.bigFail = 1;
+    }
+    const int row = k0 + kBigNB + blockIdx.x * 256 + t;
+    if (row > g.N) return;
+    double w[kBigNB];
+    double* src = S + (size_t)row * ld + k0;
+#pragma unroll
+    for (int c = 0; c < kBigNB; c++) w[c] = src[c];
+#pragma unroll
+    for (int c = 1; c < kBigNB; c++) {
+#pragma unroll
+        for (int q = 0; q < c; q++) w[c] = fma(-w[q], a[c][q], w[c]);
+    }
+    double* wd = P.bigW + (size_t)row * kBigNB;
+#pragma unroll
+    for (int c = 0; c < kBigNB; c++) { wd[c] = w[c]; src[c] = w[c] * invd[c]; }
+}
+
+__global__ __launch_bounds__(256) void k_bal_update(BADev P, int kb) {
+    __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
+    __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
+    if (P.ctl[kCtlHalt]) return;
+    const BigGeom g = big_geom(P.nFree);
+    const size_t ld = g.RP;
+    const int k0 = kb * kBigNB, t = threadIdx.x;
+    const int tj0 = (k0 + kBigNB) >> 6;
+    const int tj = tj0 + blockIdx.x, ti = tj0 + blockIdx.y;
+    if (ti < tj) return;
+    const int r0 = ti * 64, c0 = tj * 64;
+    double* S = P.big;
+    for (int idx = t; idx < 64 * kBigNB; idx += 256) {
+        const int r = idx >> 5, k = idx & 31;
+        Wt[k][r] = P.bigW[(size_t)(r0 + r) * kBigNB + k];
+        Lt[k][r] = (c0 + r >= k0 + kBigNB) ? S[(size_t)(c0 + r) * ld + k0 + k] : 0.0;    // columns of the panel itself are final
+    }
+    __syncthreads();
+    const int tx = t & 15, ty = t >> 4;
+    double c[4][4];
+    double* C = S + (size_t)(r0 + ty * 4) * ld + c0 + tx * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[i][j] = C[(size_t)i * ld + j];
+#pragma unroll 8
+    for (int k = 0; k < kBigNB; k++) {
+        double wv[4], lv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { wv[i] = Wt[k][ty * 4 + i]; lv[i] = Lt[k][tx * 4 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) c[i][j] = fma(-wv[i], lv[j], c[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) C[(size_t)i * ld + j] = c[i][j];
+}
+
+constexpr int kBigSolveThreads = 1024;
+__global__ __launch_bounds__(kBigSolveThreads) void k_bal_backsolve(BADev P, int* solveOk) {
+    extern __shared__ double xs[];     // N
+    __shared__ double part[kBigSolveThreads / 32][kBigNB + 1];
+    if (P.ctl[kCtlHalt]) return;
+    const BigGeom g = big_geom(P.nFree);
+    const size_t ld = g.RP;
+    const int n = g.n, N = g.N, t = threadIdx.x;
+    const double* S = P.big;
+    const int c = t & 31, ri = t >> 5;
+    for (int kb = N / kBigNB - 1; kb >= 0; kb--) {
+        const int k0 = kb * kBigNB;
+        double acc = 0;
+        for (int i = k0 + kBigNB + ri; i < n; i += kBigSolveThreads / 32) acc = fma(S[(size_t)i * ld + k0 + c], xs[i], acc);
+        part[ri][c] = acc;
+        __syncthreads();
+        if (t < 64) {
+            double s = 0;
+            for (int r = 0; r < kBigSolveThreads / 32; r++) s += part[r][c];
+            double v = S[(size_t)N * ld + k0 + c] - s;
+            const double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB;
+            double lc[kBigNB];
+#pragma unroll
+            for (int q = 0; q < kBigNB; q++) lc[q] = Ld[q * kBigNB + c];       // column c of L_kk
+#pragma unroll
+            for (int q = kBigNB - 1; q >= 0; q--) {
+                const double xq = __shfl(v, q);
+                if (c < q) v = fma(-lc[q], xq, v);
+            }
+            if (t < 32) xs[k0 + t] = v;
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < n; i += kBigSolveThreads) P.xp[i] = xs[i];
+    const SE3* cams = cur_cams(P);
+    SE3* camsT = trial_cams(P);
+    for (int cI = t; cI < P.nCams; cI += kBigSolveThreads) {
+        const int ci = P.camIdx[cI];
+        if (ci >= 0) {
+            double u[6];
+            for (int q = 0; q < 6; q++) u[q] = xs[ci * 6 + q];
+            camsT[cI] = se3_mul(se3_exp(u), cams[cI]);
+        } else {
+            camsT[cI] = cams[cI];
+        }
+    }
+    if (t == 0) *solveOk = *P.bigFail ? 0 : 1;
+}
+
 // rho, accept / reject, lambda & nu update (optimization_algorithm_levenberg.cpp:118-147) by one 256-thread block.
 // bulk = 1: the host has enqueued every remaining iteration of this optimize() call back to back (one trial each).  A
 // clean iteration -- first trial accepted -- is finished right here (trace entry, iteration count, the "3 bad
@@ -2324,14 +2571,35 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     const int chunks = kChunks;
     int nFreeIn = 0;
     for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
-    EAO_REQUIRE(nFreeIn <= kSchurMaxFree, "at most %d free keyframes per window in this build (got %d)", kSchurMaxFree, nFreeIn);
+    EAO_REQUIRE(nFreeIn <= kBigMaxFree, "at most %d free keyframes in this build (got %d)", kBigMaxFree, nFreeIn);
+    // more free keyframes than the single-workgroup solvers take (or EAO_BA_SOLVER=big, the harness's A/B switch): the
+    // map-scale path, dense system in HBM factorised by the whole chip (k_bal_*)
+    const char* solverEnv0 = getenv("EAO_BA_SOLVER");
+    const bool bigPath = nFreeIn > kSchurMaxFree || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
+    const BigGeom bg = big_geom(std::max(nFreeIn, 1));
+    size_t lpEntries = 0, lpPairsMax = 0;
+    if (bigPath) {   // sizes of the pair CSR: sum over the points of m (m + 1) / 2, m = observers among the free keyframes
+        std::vector<int>& fc = c.scratch;
+        fc.assign((size_t)nP, 0);
+        for (int e = 0; e < E; e++) if (!p->cam_fixed[p->edge_cam[e]]) fc[p->edge_point[e]]++;
+        for (int i = 0; i < nP; i++) lpEntries += (size_t)fc[i] * (fc[i] + 1) / 2;
+        lpPairsMax = std::min(lpEntries, (size_t)nFreeIn * (nFreeIn + 1) / 2);
+        EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
+    }
     size_t need = 0;
-    need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 1 + 24 + 18 * 8);
-    need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
+    need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
     need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
-    need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16) + (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
-    need += 96 * 256;
-    need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * 4;   // landmark lists of the camera pairs
+    need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
+    need += 128 * 256;
+    if (bigPath) {
+        need += ((size_t)bg.RP * bg.RP + (size_t)bg.RP * kBigNB + (size_t)bg.N * kBigNB) * 8;
+        need += (lpEntries + 3 * lpPairsMax + 8) * 4;
+    } else {
+        need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
+        need += (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
+        need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * 4;   // landmark lists of the camera pairs
+        need += (size_t)nC * (nC + 1) / 2 * 4;
+    }
     if ((st = c.bytes.reserve(need))) return st;
     Arena a{c.bytes.p, c.bytes.n};
     BADev D;
@@ -2350,13 +2618,16 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     int* dcamIdx = a.take<int>(nC); int* dptIdx = a.take<int>(nP); int* dactCam = a.take<int>(nC); int* dactPt = a.take<int>(nP);
     int* dptStart = a.take<int>(nP + 1); int* dptEdges = a.take<int>(E); int* dcamStart = a.take<int>(nC + 1); int* dcamEdges = a.take<int>(E);
     int* dctl = a.take<int>(16);   // two control blocks: see BADecision
+    int* dlpStart = a.take<int>(bigPath ? lpPairsMax + 1 : 1);
+    int* dlpPair = a.take<int>(bigPath ? 2 * lpPairsMax : 1);
+    int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
     const size_t off1 = (a.off + 255) & ~(size_t)255;
     // ---- device-only part
     int* dtable = a.take<int>((size_t)nP * nC);
     D.camEdgeL = a.take<int>(E);
-    const bool pairPath = nFreeIn > 0 && nFreeIn <= kTileMaxFree && !(getenv("EAO_BA_SOLVER") && !strcmp(getenv("EAO_BA_SOLVER"), "lds")) && !getenv("EAO_BA_SLABS");
+    const bool pairPath = !bigPath && nFreeIn > 0 && nFreeIn <= kTileMaxFree && !(getenv("EAO_BA_SOLVER") && !strcmp(getenv("EAO_BA_SOLVER"), "lds")) && !getenv("EAO_BA_SLABS");
     const int nPairsMax = nFreeIn * (nFreeIn + 1) / 2;
-    D.pairCnt = a.take<int>(std::max(nPairsMax, 1));
+    D.pairCnt = a.take<int>(bigPath ? 1 : std::max(nPairsMax, 1));
     D.pairPts = a.take<int>(pairPath ? (size_t)nPairsMax * std::max(nP, 1) : 1);
     unsigned char* dcls = a.take<unsigned char>(E);
     SE3* dcamsT = a.take<SE3>(nC);
@@ -2365,9 +2636,14 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
     D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
     D.Hpl = a.take<double>((size_t)E * 18);
-    double* dsolveScratch = a.take<double>((size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
-    D.sys = a.take<double>(std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
-    D.slab = a.take<double>((size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
+    double* dsolveScratch = a.take<double>(bigPath ? 8 : (size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
+    D.sys = a.take<double>(bigPath ? 8 : std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
+    D.slab = a.take<double>(bigPath ? 8 : (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
+    D.big = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
+    D.bigW = a.take<double>(bigPath ? (size_t)bg.RP * kBigNB : 8);
+    D.bigDiag = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
+    D.bigFail = a.take<int>(4);
+    D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpPts = dlpPts;
     D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
     D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
     D.lm = a.take<double>(16);
@@ -2444,10 +2720,41 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
                 camCnt[cam] = l;
             }
         D.nFree = nF; D.nL = nL;
+        if (bigPath && nF > 0) {
+            // covisibility CSR: for every camera pair (i1 <= i2) sharing a landmark, the landmark blocks in ascending order
+            // (counting sort over the landmarks' observer lists; the diagonal pairs carry each camera's own landmarks)
+            int* lpStart = (int*)hostp(dlpStart); int* lpPair = (int*)hostp(dlpPair); int* lpPts = (int*)hostp(dlpPts);
+            static thread_local std::vector<int> pcnt, obs;
+            pcnt.assign((size_t)nF * (nF + 1) / 2, 0);
+            auto each_pair = [&](auto&& fn) {
+                for (int l = 0; l < nL; l++) {
+                    obs.clear();
+                    for (int k = ptStart[l]; k < ptStart[l + 1]; k++) { const int ci = camIdx[p->edge_cam[ptEdges[k]]]; if (ci >= 0) obs.push_back(ci); }
+                    for (size_t u = 0; u < obs.size(); u++)
+                        for (size_t v = u; v < obs.size(); v++) fn(pair_index(std::min(obs[u], obs[v]), std::max(obs[u], obs[v]), nF), l);
+                }
+            };
+            each_pair([&](int pi, int) { pcnt[pi]++; });
+            int nz = 0, run = 0, pi = 0;
+            for (int i1 = 0; i1 < nF; i1++)
+                for (int i2 = i1; i2 < nF; i2++, pi++) {
+                    const int cnt0 = pcnt[pi];
+                    if (!cnt0) { pcnt[pi] = -1; continue; }
+                    lpPair[2 * nz] = i1; lpPair[2 * nz + 1] = i2; lpStart[nz] = run;
+                    pcnt[pi] = nz;            // the pair's slot; lpStart[slot] doubles as the fill cursor below
+                    run += cnt0; nz++;
+                }
+            lpStart[nz] = run;
+            each_pair([&](int pi2, int l) { lpPts[lpStart[pcnt[pi2]]++] = l; });
+            for (int k = nz; k > 0; k--) lpStart[k] = lpStart[k - 1];   // cursors ended at the next pair's start: shift back
+            lpStart[0] = 0;
+            D.nPairsNZ = nz;
+        }
     }
     EAO_HIP(hipEventRecord(c.ev0, s));
     EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(D.nL * D.nFree, nP * 3), nC), E), 256)), dim3(256), 0, s, D);
+    if (bigPath) EAO_HIP(hipMemsetAsync(D.bigW, 0, (size_t)bg.RP * kBigNB * sizeof(double), s));
     const bool usePairs = pairPath && D.nFree > 0 && D.nL > 0;
     if (usePairs) {
         hipLaunchKernelGGL(k_ba_pairs, dim3(D.nFree * (D.nFree + 1) / 2), dim3(256), 0, s, D);
@@ -2487,7 +2794,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         // solver choice: register tiles + MFMA up to kTileMaxFree free keyframes, else the LDS / global-scratch solver
         static const char* solverEnv = getenv("EAO_BA_SOLVER");   // A/B switch for the profiling harness: tiles | lds
         const bool wantLds = solverEnv && !strcmp(solverEnv, "lds");
-        const bool solveTiles = nF > 0 && nF <= kTileMaxFree && !wantLds;
+        const bool solveTiles = !bigPath && nF > 0 && nF <= kTileMaxFree && !wantLds;
         const TileGeom tg = tile_geom(std::max(nF, 1));
         const size_t tileLds = tile_solver_lds(std::max(nF, 1));
         const bool tiles3 = tg.nTiles <= 3 * (kTileThreads / 64);
@@ -2496,19 +2803,32 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
             else EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve_tiles<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileLds));
         }
         if (solveInLds && !solveTiles) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
-        const size_t schurLds = schur_lds_bytes(nF);
-        if (nF) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+        const size_t schurLds = bigPath ? 0 : schur_lds_bytes(nF);
+        if (nF && !bigPath) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+        const BigGeom gB = big_geom(std::max(nF, 1));
+        if (bigPath) EAO_HIP(hipFuncSetAttribute((const void*)k_bal_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(gB.N * sizeof(double))));
         int* const ctl0 = dctl; double* const lm0 = dlm0;
         auto use_pair = [&](int k) { D.ctl = ctl0 + 8 * k; D.lm = lm0 + 8 * k; };
         auto enqueue_trial = [&](int bulk, bool firstTrial = false, bool withDecide = true) {
-            if (nF && usePairs && solveTiles) {
+            if (nF && bigPath) {
+                (void)hipMemsetAsync(D.big, 0, (size_t)gB.RP * gB.RP * sizeof(double), s);
+                hipLaunchKernelGGL(k_bal_schur_pairs, dim3(D.nPairsNZ), dim3(64), 0, s, D, firstTrial ? 1 : 0);
+                const int nbk = gB.N / kBigNB, nT = gB.RP / 64;
+                for (int kb = 0; kb < nbk; kb++) {
+                    hipLaunchKernelGGL(k_bal_panel, dim3(eao::cdiv(gB.N - kb * kBigNB - kBigNB + 1, 256)), dim3(256), 0, s, D, kb);
+                    const int tj0 = (kb * kBigNB + kBigNB) >> 6;
+                    if (kb + 1 < nbk) hipLaunchKernelGGL(k_bal_update, dim3(nT - tj0, nT - tj0), dim3(256), 0, s, D, kb);
+                }
+                hipLaunchKernelGGL(k_bal_backsolve, dim3(1), dim3(kBigSolveThreads), gB.N * sizeof(double), s, D, dsolveOk);
+            } else if (nF && usePairs && solveTiles) {
                 hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2), dim3(kPairThreads), 0, s, D, firstTrial ? 1 : 0);
             } else if (nF) {
                 hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(kSchurThreads), schurLds, s, D, firstTrial ? 1 : 0);
                 if (solveTiles) hipLaunchKernelGGL(k_ba_reduce_tiles, dim3(tg.nTiles), dim3(256), 0, s, D);
                 else hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, D);
             }
-            if (solveTiles && tiles3) hipLaunchKernelGGL(k_ba_solve_tiles<3>, dim3(1), dim3(kTileThreads), tileLds, s, D, dsolveOk);
+            if (bigPath) {}
+            else if (solveTiles && tiles3) hipLaunchKernelGGL(k_ba_solve_tiles<3>, dim3(1), dim3(kTileThreads), tileLds, s, D, dsolveOk);
             else if (solveTiles) hipLaunchKernelGGL(k_ba_solve_tiles<5>, dim3(1), dim3(kTileThreads), tileLds, s, D, dsolveOk);
             else if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
             else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);

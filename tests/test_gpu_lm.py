@@ -157,9 +157,62 @@ def test_bundle_adjustment_parity(gpu, oracle, kw, its, robust):
     assert np.array_equal(r["poses"][0], o["poses"][0])
 
 
+@pytest.mark.parametrize("kw,its,robust", [(dict(n_free=80, n_fixed=1, n_points=3000, seed=5200), 10, False),        # n = 480: no padding
+                                           (dict(n_free=131, n_fixed=2, n_points=6000, seed=5201, mono_frac=0.3), 12, True),   # n = 786 -> N = 800
+                                           (dict(n_free=67, n_fixed=1, n_points=900, seed=5202, outlier_frac=0.0), 8, True)])
+def test_bundle_adjustment_map_scale(gpu, oracle, kw, its, robust):
+    """More free keyframes than one workgroup factorises: the map-scale path (pair CSR from the host, dense lower
+    triangle in HBM, panel / update LDL^T across the chip, k_bal_* in csrc/lm.hip) against the same oracle."""
+    p = synth.synth_ba(**kw)
+    r = gpu.Optimizer.BundleAdjustment(p, its, bRobust=robust)
+    o = oracle.bundle_adjustment(p, its, robust)
+    assert list(r["iters"]) == [int(o["iters"][0]), 0] and r["iters"][0] >= 3
+    _check_trace(r, o)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    f = p["fixed"].astype(bool)
+    assert np.array_equal(r["poses"][f], o["poses"][f])
+
+
+@pytest.mark.parametrize("kw", [dict(n_free=11, n_fixed=1, n_points=800, seed=5100), dict(n_free=3, n_fixed=1, n_points=150, seed=5203),
+                                dict(n_free=34, n_fixed=2, n_points=1500, seed=3005)])
+def test_map_scale_path_on_small_windows(gpu, oracle, kw, monkeypatch):
+    """EAO_BA_SOLVER=big forces the map-scale kernels onto windows the single-workgroup solvers would take (n = 66, 18 and
+    204 unknowns: identity padding up to the 32-column panels, a single panel, odd tile counts): same results as the oracle,
+    for BundleAdjustment and for both passes of LocalBundleAdjustment."""
+    monkeypatch.setenv("EAO_BA_SOLVER", "big")
+    p = synth.synth_ba(**kw)
+    r = gpu.Optimizer.BundleAdjustment(p, 10, bRobust=True)
+    o = oracle.bundle_adjustment(p, 10, True)
+    assert list(r["iters"]) == [int(o["iters"][0]), 0]
+    _check_trace(r, o)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    r = gpu.Optimizer.LocalBundleAdjustment(p)
+    o = oracle.local_ba(p)
+    assert list(r["iters"]) == list(o["iters"])
+    _check_trace(r, o)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
+
+
+def test_local_ba_oversized_window(gpu, oracle):
+    """A local window with more than 64 free keyframes goes through the map-scale path too (both optimize() passes, the
+    outlier pass between them deactivating edges in the pair lists)."""
+    p = synth.synth_ba(n_free=70, n_fixed=3, n_points=2500, seed=5204)
+    r = gpu.Optimizer.LocalBundleAdjustment(p)
+    o = oracle.local_ba(p)
+    assert list(r["iters"]) == list(o["iters"])
+    _check_trace(r, o)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
+
+
 def test_bundle_adjustment_limits(gpu):
-    p = synth.synth_ba(n_free=70, n_fixed=1, n_points=400, seed=5104)
-    with pytest.raises(gpu.EaoError):            # more free keyframes than the single-workgroup solvers take: refused, not approximated
+    p = synth.synth_ba(n_free=2049, n_fixed=1, n_points=60, seed=5104)
+    with pytest.raises(gpu.EaoError):            # beyond the map-scale path's 2048 free keyframes: refused, not approximated
         gpu.Optimizer.BundleAdjustment(p, 10, bRobust=False)
     p = synth.synth_ba(n_free=4, n_fixed=1, n_points=100, seed=5105)
     r = gpu.Optimizer.BundleAdjustment(p, 10, stop=np.array([1], np.uint8))
