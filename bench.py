@@ -371,6 +371,17 @@ def measure_extra(E, synth, torch, dev):
             rg = E.Optimizer.BundleAdjustment(gp, 10, bRobust=False)
         extra["bundle_adjustment"] = {"workload": "BundleAdjustment 11 free + 1 fixed KF x 2000 MP, E=%d, 10 its, no robust kernel" % len(gp["edge_cam"]),
                                       "ms_per_call": round((time.perf_counter() - t0) / 5 * 1e3, 3), "iters": int(rg["iters"][0])}
+        # map scale: more free keyframes than one workgroup factorises -> dense Schur system in HBM, panel / update LDL^T
+        gm = synth.synth_ba(n_free=200, n_fixed=1, n_points=20000, seed=5300)
+        E.Optimizer.BundleAdjustment(gm, 10, bRobust=False)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rm = E.Optimizer.BundleAdjustment(gm, 10, bRobust=False)
+        dtm = (time.perf_counter() - t0) / 3
+        trials = int(np.sum(rm["trace"]["trials"]))
+        extra["bundle_adjustment_map_scale"] = {"workload": "BundleAdjustment 200 free + 1 fixed KF x 20000 MP, E=%d, 10 its (1200 x 1200 reduced camera system)" % len(gm["edge_cam"]),
+                                                "ms_per_call": round(dtm * 1e3, 3), "iters": int(rm["iters"][0]), "lm_trials": trials,
+                                                "ba_residual_blocks_per_s": round(len(gm["edge_cam"]) * int(rm["iters"][0]) / dtm, 1)}
     except Exception as ex:  # noqa: BLE001
         extra["ba_error"] = repr(ex)
     return extra
@@ -461,6 +472,10 @@ def measure_cpu(frames, synth, extra):
             O.bundle_adjustment(gp, 10, False)
             reps += 1
         ex["cpu_bundle_adjustment_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+        gm = synth.synth_ba(n_free=200, n_fixed=1, n_points=20000, seed=5300)
+        t0 = time.perf_counter()
+        O.bundle_adjustment(gm, 10, False)
+        ex["cpu_bundle_adjustment_map_scale_ms"] = round((time.perf_counter() - t0) * 1e3, 1)   # (dense LDL^T on the CPU; g2o's sparse solver would be faster)
     except Exception as e:  # noqa: BLE001
         ex["cpu_extra_error"] = repr(e)
     return cpu, ex

@@ -52,6 +52,11 @@ class BAProblem(C.Structure):
                 ("cy", C.c_float), ("bf", C.c_float), ("its_first", C.c_int32), ("its_second", C.c_int32)]
 
 
+class BAPlanes(C.Structure):   # eao_ba_planes
+    _fields_ = [("n_planes", C.c_int32), ("plane_world", C.c_void_p), ("n_pedges", C.c_int32), ("pedge_plane", C.c_void_p),
+                ("pedge_cam", C.c_void_p), ("pedge_obs", C.c_void_p)]
+
+
 class BAResult(C.Structure):
     _fields_ = [("cam_Tcw", C.c_void_p), ("points", C.c_void_p), ("edge_outlier", C.c_void_p),
                 ("iters", C.c_int32 * 2), ("aborted", C.c_int32), ("chi2", C.c_double * 2)]
@@ -92,6 +97,7 @@ SYMBOLS = {
     "eao_pose_optimization": (_I, [C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
     "eao_local_ba": (_I, [C.POINTER(BAProblem), _P, C.POINTER(BAResult)]),
     "eao_bundle_adjustment": (_I, [C.POINTER(BAProblem), _I, _P, C.POINTER(BAResult)]),
+    "eao_bundle_adjustment_planes": (_I, [C.POINTER(BAProblem), C.POINTER(BAPlanes), _I, _P, C.POINTER(BAResult), _P]),
     "eao_last_lm_trace": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),
     "eao_last_lm_timing": (_I, [C.POINTER(C.c_float), C.POINTER(_I)]),
 }

@@ -311,6 +311,26 @@ inline void plane_from_f32(const float* v, double c[4]) {                      /
     if (v[3] < 0.0) for (int k = 0; k < 4; k++) c[k] = -c[k];
     plane_normalize(c);
 }
+// Plane3D::rotation: AngleAxis(azimuth, Z) * AngleAxis(-elevation, Y) as a quaternion product
+__device__ inline void plane_rotation(const double* v, double Rn[9]) {
+    const double az = atan2(v[1], v[0]);
+    const double el = atan2(v[2], sqrt(v[0] * v[0] + v[1] * v[1]));
+    const double ha = 0.5 * az, hb = 0.5 * (-el);
+    const Quat qa{0, 0, sin(ha) * 1.0, cos(ha)}, qb{0, sin(hb) * 1.0, 0, cos(hb)};
+    quat_to_matrix(quat_mul(qa, qb), Rn);
+}
+// Plane3D::oplus (VertexPlane::oplusImpl, src/g2oAddition/Plane3D.h:73-89, VertexPlane.h:35-38)
+__device__ inline void plane_oplus(const double* c, const double* v, double out[4]) {
+    const double sn = sin(v[1]), cs = cos(v[1]);
+    const double n[3] = {cs * cos(v[0]), cs * sin(v[0]), sn};
+    double R[9];
+    plane_rotation(c, R);
+    const double d = (-c[3]) + v[2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) out[r] = R[r * 3] * n[0] + R[r * 3 + 1] * n[1] + R[r * 3 + 2] * n[2];
+    out[3] = -d;
+    plane_normalize(out);
+}
 __device__ inline void plane_error(const SE3& T, const double* world, const double* meas, double err[3]) {   // EdgePlane::computeError
     double R[9];
     quat_to_matrix(T.r, R);
@@ -320,13 +340,8 @@ __device__ inline void plane_error(const SE3& T, const double* world, const doub
     v2[3] = world[3] - (T.t[0] * v2[0] + T.t[1] * v2[1] + T.t[2] * v2[2]);
     if (v2[3] < 0.0) { v2[0] = -v2[0]; v2[1] = -v2[1]; v2[2] = -v2[2]; v2[3] = -v2[3]; }
     plane_normalize(v2);
-    // Plane3D::rotation: AngleAxis(azimuth, Z) * AngleAxis(-elevation, Y) as a quaternion product
-    const double az = atan2(v2[1], v2[0]);
-    const double el = atan2(v2[2], sqrt(v2[0] * v2[0] + v2[1] * v2[1]));
-    const double ha = 0.5 * az, hb = 0.5 * (-el);
-    const Quat qa{0, 0, sin(ha) * 1.0, cos(ha)}, qb{0, sin(hb) * 1.0, 0, cos(hb)};
     double Rn[9];
-    quat_to_matrix(quat_mul(qa, qb), Rn);
+    plane_rotation(v2, Rn);
     double n[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) n[r] = Rn[r] * meas[0] + Rn[3 + r] * meas[1] + Rn[6 + r] * meas[2];   // rotation^T * normal
@@ -917,6 +932,12 @@ struct BADev {
     double* partScale;      // nL
     double* lm;             // [0] lambda [1] ni [2] currentChi [3] maxdiag
     int chunks;
+    // MapPlane vertices / EdgePlane edges of Optimizer::BundleAdjustment (src/Optimizer.cc:203-252): landmarks nPtsOnly.. are
+    // planes (4 coefficients each, two state buffers like the points), edges nEdgesPt.. are plane edges (eflag bit3)
+    int nPtsOnly, nEdgesPt;
+    double* plBuf[2];
+    const double* pmeas;    // 4 per plane edge: the measured plane, normalised
+    double deltaPlane, infoAngle, infoDist;
     // map-scale path (k_bal_*): dense lower-triangular system in HBM, panel workspace, factored diagonal blocks, pair CSR
     double* big;            // RP * RP
     double* bigW;           // RP * 32: w = a L_kk^-T of the current panel
@@ -992,9 +1013,36 @@ __device__ inline void ba_jacobians(const Cam& c, bool stereo, const SE3& T, con
     }
 }
 
+__device__ inline double plane_chi2(const BADev& P, const double* e) {
+    return e[0] * (P.infoAngle * e[0]) + e[1] * (P.infoAngle * e[1]) + e[2] * (P.infoDist * e[2]);
+}
+// g2o's numeric Jacobians of an EdgePlane (central differences, delta = 1e-9, core/base_binary_edge.hpp:131-205):
+// with respect to the plane vertex (VertexPlane::oplusImpl) ...
+__device__ inline void plane_jac_plane(const SE3& T, const double* pl, const double* meas, double A[3][3]) {
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        double add[3] = {0, 0, 0}, q[4], ep[3], em[3];
+        add[d] = delta;  plane_oplus(pl, add, q); plane_error(T, q, meas, ep);
+        add[d] = -delta; plane_oplus(pl, add, q); plane_error(T, q, meas, em);
+        for (int k = 0; k < 3; k++) A[k][d] = scalar * (ep[k] - em[k]);
+    }
+}
+// ... and with respect to the keyframe (exp(delta) * T)
+__device__ inline void plane_jac_pose(const SE3& T, const double* pl, const double* meas, double B[3][6]) {
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    for (int d = 0; d < 6; d++) {
+        double add[6] = {0, 0, 0, 0, 0, 0}, ep[3], em[3];
+        add[d] = delta;  plane_error(se3_mul(se3_exp(add), T), pl, meas, ep);
+        add[d] = -delta; plane_error(se3_mul(se3_exp(add), T), pl, meas, em);
+        for (int k = 0; k < 3; k++) B[k][d] = scalar * (ep[k] - em[k]);
+    }
+}
+
 // residuals + robust chi2 of every active edge at the CURRENT state (start of an optimize() call)
 // Eight lanes per landmark, one edge per lane (points with more than 8 active edges loop): the per-point sums are
 // 3-step xor trees inside the lane group.
+template <bool PL>
 __global__ __launch_bounds__(256) void k_ba_errors(BADev P) {
     const int l = (blockIdx.x * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
     if (P.ctl[kCtlHalt]) return;
@@ -1009,10 +1057,18 @@ __global__ __launch_bounds__(256) void k_ba_errors(BADev P) {
         const unsigned char fl = P.eflag[e];
         if (fl & 2) continue;
         const bool stereo = fl & 1;
+        double* er = &P.err[3 * e];
+        if (PL && (fl & 8)) {
+            plane_error(cams[P.ecam[e]], &P.plBuf[P.ctl[kCtlCur]][4 * (pt - P.nPtsOnly)], &P.pmeas[4 * (e - P.nEdgesPt)], er);
+            const double c2 = plane_chi2(P, er);
+            double r0 = c2, w;
+            if (fl & 4) huber(c2, P.deltaPlane, r0, w);
+            chi += r0;
+            continue;
+        }
         double p[3], r[3];
         se3_map(cams[P.ecam[e]], &pts[3 * pt], p);
         ba_project(P.cam, stereo, p, r);
-        double* er = &P.err[3 * e];
         er[0] = P.obs[3 * e] - r[0]; er[1] = P.obs[3 * e + 1] - r[1]; er[2] = stereo ? P.obs[3 * e + 2] - r[2] : 0;
         const double c2 = ba_chi2(er, P.info[e], stereo);
         double r0 = c2, w;
@@ -1137,6 +1193,7 @@ constexpr int kLinThreads = 1024;
 // depend on the order, and non-negative doubles order like their bit patterns.
 // ctlOld != nullptr: the previous trial's decision has not been taken yet (bulk segment): see BADecision.  P.ctl / P.lm
 // are then the blocks this trial runs on (written by workgroup 0 here), ctlOld / lmOld the ones the previous trial ran on.
+template <bool PL>
 __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlocks, int first, const int* ctlOld, const double* lmOld,
                                                               const int* solveOk, BAStatus* st, int seq) {
     __shared__ double red[(kLinThreads / 4) * 27], part[8 * 27];
@@ -1176,14 +1233,24 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
             const bool stereo = fl & 1;
             constexpr int D = 3;   // monocular edges carry a zero third row / residual: static loops, no scratch
             double A[3][3], B[3][6];
-            ba_jacobians(P.cam, stereo, cams[P.ecam[e]], &pts[3 * pt], A, B);
             const double* er = &P.err[3 * e];
-            const double info = P.info[e];
+            double info = P.info[e], info2 = info;     // rows 0, 1 / row 2 of the (diagonal) information matrix
             double w = 1.0, r0;
-            if (fl & 4) huber(ba_chi2(er, info, stereo), stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
-            const double wi = w * info;
+            const bool camFree = P.camIdx[P.ecam[e]] >= 0;
+            if (PL && (fl & 8)) {
+                const double* pl = &P.plBuf[cur][4 * (pt - P.nPtsOnly)];
+                const double* meas = &P.pmeas[4 * (e - P.nEdgesPt)];
+                plane_jac_plane(cams[P.ecam[e]], pl, meas, A);
+                if (camFree) plane_jac_pose(cams[P.ecam[e]], pl, meas, B);
+                info = P.infoAngle; info2 = P.infoDist;
+                if (fl & 4) huber(plane_chi2(P, er), P.deltaPlane, r0, w);
+            } else {
+                ba_jacobians(P.cam, stereo, cams[P.ecam[e]], &pts[3 * pt], A, B);
+                if (fl & 4) huber(ba_chi2(er, info, stereo), stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
+            }
+            const double wi[3] = {w * info, w * info, PL ? w * info2 : w * info};
             double omr[3];
-            for (int r = 0; r < 3; r++) omr[r] = w * (-(info * er[r]));
+            for (int r = 0; r < 3; r++) omr[r] = w * (-((PL && r == 2 ? info2 : info) * er[r]));
             int q = 0;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
@@ -1192,14 +1259,14 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
                 for (int r = 0; r < D; r++) sb += A[r][i] * omr[r];
                 b[i] += sb;
 #pragma unroll
-                for (int j = i; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi * A[r][j]; H[q++] += h; }
+                for (int j = i; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi[r] * A[r][j]; H[q++] += h; }
             }
-            if (P.camIdx[P.ecam[e]] >= 0) {
+            if (camFree) {
                 double* Hx = &P.Hpl[(size_t)e * 18];
 #pragma unroll
                 for (int i = 0; i < 6; i++)
 #pragma unroll
-                    for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi * A[r][j]; Hx[i * 3 + j] = h; }
+                    for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; Hx[i * 3 + j] = h; }
             }
         }
 #pragma unroll
@@ -1238,14 +1305,20 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
             const bool stereo = fl & 1;
             constexpr int D = 3;
             double A[3][3], B[3][6];
-            ba_jacobians(P.cam, stereo, T, &pts[3 * P.ept[e]], A, B);
             const double* er = &P.err[3 * e];
-            const double info = P.info[e];
+            double info = P.info[e], info2 = info;
             double w = 1.0, r0;
-            if (fl & 4) huber(ba_chi2(er, info, stereo), stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
-            const double wi = w * info;
+            if (PL && (fl & 8)) {
+                plane_jac_pose(T, &P.plBuf[cur][4 * (P.ept[e] - P.nPtsOnly)], &P.pmeas[4 * (e - P.nEdgesPt)], B);
+                info = P.infoAngle; info2 = P.infoDist;
+                if (fl & 4) huber(plane_chi2(P, er), P.deltaPlane, r0, w);
+            } else {
+                ba_jacobians(P.cam, stereo, T, &pts[3 * P.ept[e]], A, B);
+                if (fl & 4) huber(ba_chi2(er, info, stereo), stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
+            }
+            const double wi[3] = {w * info, w * info, PL ? w * info2 : w * info};
             double omr[3];
-            for (int r = 0; r < 3; r++) omr[r] = w * (-(info * er[r]));
+            for (int r = 0; r < 3; r++) omr[r] = w * (-((PL && r == 2 ? info2 : info) * er[r]));
             int q = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -1253,7 +1326,7 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
                 for (int r = 0; r < D; r++) s += B[r][i] * omr[r];
                 acc[21 + i] += s;
 #pragma unroll
-                for (int j = i; j < 6; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi * B[r][j]; acc[q++] += h; }
+                for (int j = i; j < 6; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * B[r][j]; acc[q++] += h; }
             }
         }
         block_sum_lds<27, kLinThreads>(acc, red, part);
@@ -1989,13 +2062,12 @@ __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(BADev P, int* s
 //            is reduced through LDS in lane order and stored straight into S.  Pairs without a common landmark stay zero
 //            from the memset that precedes every trial (the factorisation fills in place).
 //   factor   right-looking LDL^T without pivoting in panels of 32 columns, two launches per panel:
-//            k_bal_panel   every workgroup factors the 32 x 32 diagonal block redundantly in LDS (32 steps, one barrier
-//                          each), then one thread per row below solves  w = a L_kk^-T  (496 FMAs on registers, L_kk as LDS
-//                          broadcast reads), keeps w for the update and stores l = w D^-1 in place;
+//            k_bal_panel   one thread per row below the diagonal block solves  w = a L_kk^-T  (496 FMAs on registers, the
+//                          factored L_kk as LDS broadcast reads), keeps w for the update and stores l = w D^-1 in place;
 //            k_bal_update  64 x 64 tiles of the trailing lower triangle, C -= W L^T over the 32 panel columns, 4 x 4
-//                          outputs per thread from transposed LDS tiles.
-//   solve    k_bal_backsolve: one 1024-thread workgroup walks L^T x = z bottom-up in blocks of 32 (column sums over the
-//            rows below split across the 32 waves, the 32 x 32 triangle by shuffles in wave 0), then exp(dx) * T.
+//                          outputs per thread from transposed LDS tiles; the tile holding the NEXT diagonal block factors
+//                          it on the spot (32 steps, one barrier each), off the critical path of the other tiles.
+//   solve    k_bal_backsolve: L^T x = z bottom-up in super-blocks of 256 columns, one launch each (see there), then exp(dx) * T.
 // A zero or non-finite pivot fails the trial like SimplicialLDLT (`bigFail`).
 constexpr int kBigMaxFree = 2048;
 constexpr int kBigNB = 32;
@@ -2068,46 +2140,65 @@ __global__ __launch_bounds__(64) void k_bal_schur_pairs(BADev P, int first) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_bal_panel(BADev P, int kb) {
-    __shared__ double a[kBigNB][kBigNB + 1];
-    __shared__ double invd[kBigNB];
-    __shared__ int s_bad;
+// LDL^T of a 32 x 32 block by ONE wavefront without LDS or barriers: lane i (and its mirror i + 32) holds row i in
+// registers (columns <= i meaningful).  Step p broadcasts the pivot and the un-normalised column p with v_readlane --
+// every index is a compile-time constant, so the rows stay in registers -- and every lane updates its row; what the lanes
+// compute above the diagonal is never read.  On return row[j] = L(i, j) for j < i and lane i's row[i] = 1 / d_i.
+// (The first version did the 32 steps with 256 threads on an LDS copy, one barrier per step: 18 us per block.)
+__device__ __forceinline__ double bal_readlane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ inline bool bal_factor_diag_wave(double (&row)[kBigNB]) {
+    const int lane = threadIdx.x & 31;
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < kBigNB; p++) {
+        const double d = bal_readlane(row[p], p);
+        bad |= (d == 0.0 || !isfinite(d));
+        const double id = frcp(d);
+        const double lip = row[p] * id;
+#pragma unroll
+        for (int j = p + 1; j < kBigNB; j++) row[j] = fma(-lip, bal_readlane(row[p], j), row[j]);
+        row[p] = lane == p ? id : lip;
+    }
+    return bad;
+}
+// the factored block as the panel / back-substitution kernels read it: unit-lower L below the diagonal, 1 / d ON it
+__device__ inline void bal_store_diag_wave(const BADev& P, int kb, const double (&row)[kBigNB], bool bad) {
+    const int lane = threadIdx.x & 63;
+    if (lane < kBigNB) {
+        double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB + lane * kBigNB;
+#pragma unroll
+        for (int j = 0; j < kBigNB; j++) Ld[j] = j <= lane ? row[j] : 0.0;
+    }
+    if (lane == 0 && bad) *P.bigFail = 1;
+}
+
+// first diagonal block of a trial (the following ones are factored by the update kernel of the panel before them)
+__global__ __launch_bounds__(64) void k_bal_diag0(BADev P) {
+    if (P.ctl[kCtlHalt]) return;
+    const size_t ld = big_geom(P.nFree).RP;
+    const int i = threadIdx.x & 31;
+    double row[kBigNB];
+#pragma unroll
+    for (int j = 0; j < kBigNB; j++) row[j] = P.big[(size_t)i * ld + j];
+    const bool bad = bal_factor_diag_wave(row);
+    bal_store_diag_wave(P, 0, row, bad);
+}
+
+// one thread per row below the panel's diagonal block (single-wave workgroups: the rows are independent and a wave's
+// speed does not depend on its neighbours, so more, smaller workgroups only spread the rows over more CUs)
+__global__ __launch_bounds__(64) void k_bal_panel(BADev P, int kb) {
+    __shared__ __attribute__((aligned(16))) double a[kBigNB][kBigNB];
     if (P.ctl[kCtlHalt]) return;
     const BigGeom g = big_geom(P.nFree);
     const size_t ld = g.RP;
     const int k0 = kb * kBigNB, t = threadIdx.x;
     double* S = P.big;
-    for (int idx = t; idx < kBigNB * kBigNB; idx += 256) {
-        const int i = idx >> 5, j = idx & 31;
-        a[i][j] = j <= i ? S[(size_t)(k0 + i) * ld + k0 + j] : 0.0;
-    }
-    if (t == 0) s_bad = 0;
+    const double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB;
+    for (int idx = t; idx < kBigNB * kBigNB; idx += 64) a[idx >> 5][idx & 31] = Ld[idx];
     __syncthreads();
-    {
-        const int i = t >> 3, jg = t & 7;
-        for (int p = 0; p < kBigNB; p++) {
-            const double d = a[p][p];
-            const double id = 1.0 / d;
-            if (t == 0) { invd[p] = id; if (d == 0.0 || !isfinite(d)) s_bad = 1; }
-            if (i > p) {
-                const double lip = a[i][p] * id;
-                for (int j = jg; j <= i; j += 8)
-                    if (j > p) a[i][j] = fma(-lip, a[j][p], a[i][j]);
-            }
-            __syncthreads();
-        }
-        for (int j = jg; j < i; j += 8) a[i][j] *= invd[j];       // unit lower L_kk
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) {
-        double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB;
-        for (int idx = t; idx < kBigNB * kBigNB; idx += 256) {
-            const int i = idx >> 5, j = idx & 31;
-            Ld[idx] = j < i ? a[i][j] : (j == i ? 1.0 : 0.0);
-        }
-        if (t == 0 && s_bad) *P.bigFail = 1;
-    }
-    const int row = k0 + kBigNB + blockIdx.x * 256 + t;
+    const int row = k0 + kBigNB + blockIdx.x * 64 + t;
     if (row > g.N) return;
     double w[kBigNB];
     double* src = S + (size_t)row * ld + k0;
@@ -2120,12 +2211,13 @@ __global__ __launch_bounds__(256) void k_bal_panel(BADev P, int kb) {
     }
     double* wd = P.bigW + (size_t)row * kBigNB;
 #pragma unroll
-    for (int c = 0; c < kBigNB; c++) { wd[c] = w[c]; src[c] = w[c] * invd[c]; }
+    for (int c = 0; c < kBigNB; c++) { wd[c] = w[c]; src[c] = w[c] * a[c][c]; }
 }
 
 __global__ __launch_bounds__(256) void k_bal_update(BADev P, int kb) {
     __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
+    __shared__ double da[kBigNB][kBigNB + 1];
     if (P.ctl[kCtlHalt]) return;
     const BigGeom g = big_geom(P.nFree);
     const size_t ld = g.RP;
@@ -2162,49 +2254,107 @@ __global__ __launch_bounds__(256) void k_bal_update(BADev P, int kb) {
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) C[(size_t)i * ld + j] = c[i][j];
+    // look-ahead: the tile that holds the NEXT panel's diagonal block (the first one dispatched) factors it right away, so
+    // the next panel kernel starts from a finished L_kk instead of every one of its workgroups repeating the 32 steps
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        const int o = k0 + kBigNB - c0;            // 0 or 32: offset of the block inside this tile
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = ty * 4 + i - o, cc = tx * 4 + j - o;
+                if (r >= 0 && r < kBigNB && cc >= 0 && cc < kBigNB) da[r][cc] = c[i][j];
+            }
+        __syncthreads();
+        if (t < 64) {
+            double row[kBigNB];
+#pragma unroll
+            for (int j = 0; j < kBigNB; j++) row[j] = da[t & 31][j];
+            const bool bad = bal_factor_diag_wave(row);
+            bal_store_diag_wave(P, kb + 1, row, bad);
+        }
+    }
 }
 
-constexpr int kBigSolveThreads = 1024;
-__global__ __launch_bounds__(kBigSolveThreads) void k_bal_backsolve(BADev P, int* solveOk) {
-    extern __shared__ double xs[];     // N
-    __shared__ double part[kBigSolveThreads / 32][kBigNB + 1];
+// Back substitution L^T x = z in super-blocks of 256 columns, one launch each, bottom-up.  Every workgroup solves the
+// super-block's own triangle redundantly (8 blocks of 32: column sums over the rows already solved split across the
+// waves, the 32 x 32 triangle by shuffles in wave 0), then removes the super-block's contribution from ITS 64 columns of z
+// to the left: z_j -= sum_i L(i, j) x_i.  L is read once, by as many workgroups as there are column chunks; the last launch
+// (super-block 0) also applies exp(dx) * T.
+constexpr int kBigSB = 256;
+__global__ __launch_bounds__(256) void k_bal_backsolve(BADev P, int J, int* solveOk) {
+    __shared__ double xl[kBigSB];      // z of the super-block on entry, x on exit
+    __shared__ double part2[4][64];
     if (P.ctl[kCtlHalt]) return;
     const BigGeom g = big_geom(P.nFree);
     const size_t ld = g.RP;
     const int n = g.n, N = g.N, t = threadIdx.x;
-    const double* S = P.big;
-    const int c = t & 31, ri = t >> 5;
-    for (int kb = N / kBigNB - 1; kb >= 0; kb--) {
-        const int k0 = kb * kBigNB;
-        double acc = 0;
-        for (int i = k0 + kBigNB + ri; i < n; i += kBigSolveThreads / 32) acc = fma(S[(size_t)i * ld + k0 + c], xs[i], acc);
-        part[ri][c] = acc;
-        __syncthreads();
+    double* S = P.big;
+    const int J0 = J * kBigSB, w = min(kBigSB, N - J0);
+    double* z = S + (size_t)N * ld;
+    if (t < w) xl[t] = z[J0 + t];
+    // the super-block's triangle, right-looking: the top block is solved by wave 0 (column c of L_kk in registers, the
+    // solved entries handed down by v_readlane), then every thread owning a column to the left removes the block's 32 rows
+    // from its z entry -- the 32 loads of a thread are independent of x, so they are in flight before the chain ends
+    for (int b = w / kBigNB - 1; b >= 0; b--) {
+        const int cb = J0 + b * kBigNB;
+        double lrow[kBigNB];
+        const bool left = t < b * kBigNB;
+        if (left) {
+#pragma unroll
+            for (int i = 0; i < kBigNB; i++) lrow[i] = S[(size_t)(cb + i) * ld + J0 + t];
+        }
+        __syncthreads();                 // xl[] of this block is final (initial load / previous block's updates)
         if (t < 64) {
-            double s = 0;
-            for (int r = 0; r < kBigSolveThreads / 32; r++) s += part[r][c];
-            double v = S[(size_t)N * ld + k0 + c] - s;
-            const double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB;
+            const int c = t & 31;
+            double v = xl[b * kBigNB + c];
+            const double* Ld = P.bigDiag + (size_t)(cb / kBigNB) * kBigNB * kBigNB;
             double lc[kBigNB];
 #pragma unroll
             for (int q = 0; q < kBigNB; q++) lc[q] = Ld[q * kBigNB + c];       // column c of L_kk
 #pragma unroll
-            for (int q = kBigNB - 1; q >= 0; q--) {
-                const double xq = __shfl(v, q);
-                if (c < q) v = fma(-lc[q], xq, v);
+            for (int q = kBigNB - 1; q >= 1; q--) {
+                const double xq = bal_readlane(v, q);
+                v = c < q ? fma(-lc[q], xq, v) : v;
             }
-            if (t < 32) xs[k0 + t] = v;
+            if (t < 32) xl[b * kBigNB + t] = v;
         }
         __syncthreads();
+        if (left) {
+            double acc = 0;
+#pragma unroll
+            for (int i = 0; i < kBigNB; i++) acc = fma(lrow[i], xl[b * kBigNB + i], acc);
+            xl[t] -= acc;
+        }
     }
-    for (int i = t; i < n; i += kBigSolveThreads) P.xp[i] = xs[i];
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = t; i < w; i += 256) if (J0 + i < n) P.xp[J0 + i] = xl[i];
+    if (J > 0) {
+        // this workgroup's 64 columns to the left of the super-block
+        const int j = blockIdx.x * 64 + (t & 63), rg = t >> 6;
+        double acc = 0;
+        for (int i0 = rg; i0 < w; i0 += 32) {      // (w is a multiple of 32) eight independent loads in flight
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = S[(size_t)(J0 + i0 + 4 * u) * ld + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = fma(v[u], xl[i0 + 4 * u], acc);
+        }
+        part2[rg][t & 63] = acc;
+        __syncthreads();
+        if (rg == 0) z[j] -= (part2[0][t] + part2[1][t]) + (part2[2][t] + part2[3][t]);
+        return;
+    }
+    __threadfence();
+    __syncthreads();
     const SE3* cams = cur_cams(P);
     SE3* camsT = trial_cams(P);
-    for (int cI = t; cI < P.nCams; cI += kBigSolveThreads) {
+    for (int cI = t; cI < P.nCams; cI += 256) {
         const int ci = P.camIdx[cI];
         if (ci >= 0) {
             double u[6];
-            for (int q = 0; q < 6; q++) u[q] = xs[ci * 6 + q];
+            for (int q = 0; q < 6; q++) u[q] = P.xp[ci * 6 + q];
             camsT[cI] = se3_mul(se3_exp(u), cams[cI]);
         } else {
             camsT[cI] = cams[cI];
@@ -2234,6 +2384,7 @@ __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BASta
 
 // per landmark (eight lanes, one edge per lane): x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 of
 // its edges at the trial state; scale partial
+template <bool PL>
 __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
     const int l = (blockIdx.x * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
     if (P.ctl[kCtlHalt]) return;
@@ -2273,16 +2424,27 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
         xl[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
         np[i] = (live ? pts[3 * pt + i] : 0.0) + xl[i];
     }
+    const bool isPl = PL && live && pt >= P.nPtsOnly;
+    double npl[4] = {1, 0, 0, 0};
+    if (isPl) plane_oplus(&P.plBuf[P.ctl[kCtlCur]][4 * (pt - P.nPtsOnly)], xl, npl);      // VertexPlane::oplusImpl
     double chi = 0;
     for (int k = beg + slot; k < end; k += 8) {
         const int e = P.ptEdges[k];
         const unsigned char fl = P.eflag[e];
         if (fl & 2) continue;              // level-1 edges keep the residual they last computed
         const bool stereo = fl & 1;
+        double* er = &P.err[3 * e];
+        if (isPl) {
+            plane_error(camsT[P.ecam[e]], npl, &P.pmeas[4 * (e - P.nEdgesPt)], er);
+            const double c2 = plane_chi2(P, er);
+            double r0 = c2, w;
+            if (fl & 4) huber(c2, P.deltaPlane, r0, w);
+            chi += r0;
+            continue;
+        }
         double p[3], r[3];
         se3_map(camsT[P.ecam[e]], np, p);
         ba_project(P.cam, stereo, p, r);
-        double* er = &P.err[3 * e];
         er[0] = P.obs[3 * e] - r[0]; er[1] = P.obs[3 * e + 1] - r[1]; er[2] = stereo ? P.obs[3 * e + 2] - r[2] : 0;
         const double c2 = ba_chi2(er, P.info[e], stereo);
         double r0 = c2, w;
@@ -2290,6 +2452,10 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
         chi += r0;
     }
     chi = group8_sum(chi);
+    if (isPl && slot == 0) {
+        double* plT = &P.plBuf[P.ctl[kCtlCur] ^ 1][4 * (pt - P.nPtsOnly)];
+        for (int i = 0; i < 4; i++) plT[i] = npl[i];
+    }
     if (live && slot == 0) {
         for (int i = 0; i < 3; i++) { P.xl[(size_t)l * 3 + i] = xl[i]; ptsT[3 * pt + i] = np[i]; }
         P.partChi[l] = chi;
@@ -2325,6 +2491,7 @@ __global__ void k_ba_classify(BADev P, unsigned char* out, int nEdges, int updat
     // enqueued speculatively behind the first optimize(): a pending host takeover freezes the rest of the stream
     if (update && P.ctl[kCtlStatus] == kStTakeover) return;
     const unsigned char fl = P.eflag[e];
+    if (fl & 8) { out[e] = 0; return; }      // (EdgePlane edges only exist in BundleAdjustment, which has no outlier pass)
     const bool stereo = fl & 1;
     const double c2 = ba_chi2(&P.err[3 * e], P.info[e], stereo);
     double p[3];
@@ -2357,16 +2524,18 @@ __global__ __launch_bounds__(256) void k_ba_prepare(BADev P) {
         P.table[idx] = found;
     }
     if (idx < P.nPts * 3) P.ptsBuf[1][idx] = P.ptsBuf[0][idx];
+    if (idx < (P.nPts - P.nPtsOnly) * 4) P.plBuf[1][idx] = P.plBuf[0][idx];
     if (idx < P.nCams) P.camsBuf[1][idx] = P.camsBuf[0][idx];
     if (idx < P.camStart[P.nFree]) P.camEdgeL[idx] = P.ptIdx[P.ept[P.camEdges[idx]]];
 }
 
 // Results straight into pinned host memory: final state + the per-edge outlier flags.
-__global__ __launch_bounds__(256) void k_ba_finish(BADev P, SE3* outCams, double* outPts, unsigned char* outCls) {
+__global__ __launch_bounds__(256) void k_ba_finish(BADev P, SE3* outCams, double* outPts, unsigned char* outCls, double* outPlanes) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < P.nCams) outCams[idx] = cur_cams(P)[idx];
-    if (idx < P.nPts * 3) outPts[idx] = cur_pts(P)[idx];
-    if (idx < P.nEdges) {
+    if (idx < P.nPtsOnly * 3) outPts[idx] = cur_pts(P)[idx];
+    if (idx < (P.nPts - P.nPtsOnly) * 4) outPlanes[idx] = P.plBuf[P.ctl[kCtlCur]][idx];
+    if (idx < P.nEdgesPt) {
         const int e = idx;
         const bool stereo = P.eflag[e] & 1;
         const double c2 = ba_chi2(&P.err[3 * e], P.info[e], stereo);
@@ -2550,24 +2719,36 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
 // mode 0: Optimizer::LocalBundleAdjustment (two passes with the outlier pass between them, Huber kernels in the first).
 // mode 1: Optimizer::BundleAdjustment over keyframes and map points (src/Optimizer.cc:55-323): ONE optimize(its_first) call,
 //         Huber kernels only when `robust`, delta_mono = sqrt(5.99) (:94), no outlier pass, no observation is erased.
-static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r, int mode, int robust) {
+//         With `pl`: the MapPlane vertices / EdgePlane edges of :203-252 ride along as landmarks nPo.. / edges Ept.. .
+static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r, int mode, int robust,
+                         const eao_ba_planes* pl = nullptr, float* planes_out = nullptr) {
     EAO_REQUIRE(p && r && r->cam_Tcw && r->points && (p->n_edges == 0 || r->edge_outlier || mode == 1), "null argument");
     EAO_REQUIRE(p->n_cams > 0 && p->n_points >= 0 && p->n_edges >= 0, "bad sizes");
+    if (pl && pl->n_planes <= 0) pl = nullptr;
+    EAO_REQUIRE(!pl || (mode == 1 && pl->plane_world && planes_out && pl->n_pedges >= 0 && (pl->n_pedges == 0 || (pl->pedge_plane && pl->pedge_cam && pl->pedge_obs))),
+                "bad plane arguments");
     LMContext& c = g_ctx;
     eao_status st = ctx_init(c);
     if (st) return st;
     g_trace.clear();
-    const int nC = p->n_cams, nP = p->n_points, E = p->n_edges;
+    const int nPo = p->n_points, nPl = pl ? pl->n_planes : 0, Ept = p->n_edges, Epl = pl ? pl->n_pedges : 0;
+    const int nC = p->n_cams, nP = nPo + nPl, E = Ept + Epl;          // landmarks = points then planes, edges = point edges then plane edges
+    const bool hasPl = nPl > 0;
+    auto edge_cam = [&](int e) { return e < Ept ? p->edge_cam[e] : pl->pedge_cam[e - Ept]; };
+    auto edge_lm = [&](int e) { return e < Ept ? p->edge_point[e] : nPo + pl->pedge_plane[e - Ept]; };
     r->iters[0] = r->iters[1] = 0; r->aborted = 0; r->chi2[0] = r->chi2[1] = 0;
     if (stop && *stop) {  // src/Optimizer.cc:961-963: nothing is optimised; poses go through the same SE3 round trip
         r->aborted = 1;
         for (int i = 0; i < nC; i++) se3_to_Tcw_f32(se3_from_Tcw_f32(p->cam_Tcw + 16 * i), r->cam_Tcw + 16 * i);
-        for (size_t i = 0; i < (size_t)nP * 3; i++) r->points[i] = p->points[i];
-        if (E && r->edge_outlier) std::memset(r->edge_outlier, 0, E);
+        for (size_t i = 0; i < (size_t)nPo * 3; i++) r->points[i] = p->points[i];
+        for (int i = 0; i < nPl; i++) { double c4[4]; plane_from_f32(pl->plane_world + 4 * i, c4); for (int k = 0; k < 4; k++) planes_out[4 * i + k] = (float)c4[k]; }
+        if (Ept && r->edge_outlier) std::memset(r->edge_outlier, 0, Ept);
         return EAO_OK;
     }
-    for (int e = 0; e < E; e++)
-        EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nP, "edge %d out of range", e);
+    for (int e = 0; e < Ept; e++)
+        EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nPo, "edge %d out of range", e);
+    for (int e = 0; e < Epl; e++)
+        EAO_REQUIRE(pl->pedge_cam[e] >= 0 && pl->pedge_cam[e] < nC && pl->pedge_plane[e] >= 0 && pl->pedge_plane[e] < nPl, "plane edge %d out of range", e);
     const int chunks = kChunks;
     int nFreeIn = 0;
     for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
@@ -2581,7 +2762,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     if (bigPath) {   // sizes of the pair CSR: sum over the points of m (m + 1) / 2, m = observers among the free keyframes
         std::vector<int>& fc = c.scratch;
         fc.assign((size_t)nP, 0);
-        for (int e = 0; e < E; e++) if (!p->cam_fixed[p->edge_cam[e]]) fc[p->edge_point[e]]++;
+        for (int e = 0; e < E; e++) if (!p->cam_fixed[edge_cam(e)]) fc[edge_lm(e)]++;
         for (int i = 0; i < nP; i++) lpEntries += (size_t)fc[i] * (fc[i] + 1) / 2;
         lpPairsMax = std::min(lpEntries, (size_t)nFreeIn * (nFreeIn + 1) / 2);
         EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
@@ -2590,7 +2771,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
     need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
     need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
-    need += 128 * 256;
+    need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8;
     if (bigPath) {
         need += ((size_t)bg.RP * bg.RP + (size_t)bg.RP * kBigNB + (size_t)bg.N * kBigNB) * 8;
         need += (lpEntries + 3 * lpPairsMax + 8) * 4;
@@ -2621,6 +2802,8 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     int* dlpStart = a.take<int>(bigPath ? lpPairsMax + 1 : 1);
     int* dlpPair = a.take<int>(bigPath ? 2 * lpPairsMax : 1);
     int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
+    double* dpl0 = a.take<double>((size_t)nPl * 4 + 1);
+    double* dpmeas = a.take<double>((size_t)Epl * 4 + 1);
     const size_t off1 = (a.off + 255) & ~(size_t)255;
     // ---- device-only part
     int* dtable = a.take<int>((size_t)nP * nC);
@@ -2632,6 +2815,9 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     unsigned char* dcls = a.take<unsigned char>(E);
     SE3* dcamsT = a.take<SE3>(nC);
     double* dptsT = a.take<double>((size_t)nP * 3);
+    D.plBuf[0] = dpl0; D.plBuf[1] = a.take<double>((size_t)nPl * 4 + 1); D.pmeas = dpmeas;
+    D.nPtsOnly = nPo; D.nEdgesPt = Ept;
+    D.deltaPlane = (float)std::sqrt(300.0); D.infoAngle = 3282.8 / (1.0 * 1.0); D.infoDist = 100.0 * 100.0;   // src/Optimizer.cc:203-208
     D.err = a.take<double>((size_t)E * 3);
     D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
     D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
@@ -2664,7 +2850,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         EAO_HIP(hipHostMalloc((void**)&c.pin, off1 + (off1 >> 2), hipHostMallocDefault));
         c.pinCap = off1 + (off1 >> 2);
     }
-    const size_t outBytes = (size_t)nC * sizeof(SE3) + (size_t)nP * 24 + (size_t)E + 64;
+    const size_t outBytes = (size_t)nC * sizeof(SE3) + (size_t)nP * 24 + (size_t)nPl * 32 + (((size_t)E + 15) & ~(size_t)15) + 64;
     if (c.pinOutCap < outBytes) {
         if (c.pinOut) (void)hipHostFree(c.pinOut);
         c.pinOut = nullptr; c.pinOutCap = 0;
@@ -2673,21 +2859,33 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     }
     SE3* outCams = (SE3*)c.pinOut;
     double* outPts = (double*)(c.pinOut + (((size_t)nC * sizeof(SE3) + 15) & ~(size_t)15));
-    unsigned char* outCls = (unsigned char*)(outPts + (size_t)nP * 3);
+    double* outPlanes = outPts + (size_t)nP * 3;
+    unsigned char* outCls = (unsigned char*)(outPlanes + (size_t)nPl * 4);
     auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
     int seq = c.status->seq;
     {
-        std::memcpy(hostp(dobs), p->edge_obs, (size_t)E * 12);
-        std::memcpy(hostp(dinfo), p->edge_inv_sigma2, (size_t)E * 4);
-        std::memcpy(hostp(decam), p->edge_cam, (size_t)E * 4);
-        std::memcpy(hostp(dept), p->edge_point, (size_t)E * 4);
+        std::memcpy(hostp(dobs), p->edge_obs, (size_t)Ept * 12);
+        std::memcpy(hostp(dinfo), p->edge_inv_sigma2, (size_t)Ept * 4);
+        std::memcpy(hostp(decam), p->edge_cam, (size_t)Ept * 4);
+        std::memcpy(hostp(dept), p->edge_point, (size_t)Ept * 4);
+        if (hasPl) {
+            std::memset(hostp(dobs) + (size_t)Ept * 12, 0, (size_t)Epl * 12);
+            std::memset(hostp(dinfo) + (size_t)Ept * 4, 0, (size_t)Epl * 4);
+            int* hc2 = (int*)hostp(decam); int* hp2 = (int*)hostp(dept);
+            for (int e = Ept; e < E; e++) { hc2[e] = edge_cam(e); hp2[e] = edge_lm(e); }
+            double* hpl = (double*)hostp(dpl0); double* hpm = (double*)hostp(dpmeas);
+            for (int i = 0; i < nPl; i++) plane_from_f32(pl->plane_world + 4 * i, hpl + 4 * i);          // Converter::toPlane3D (:217)
+            for (int e = 0; e < Epl; e++) plane_from_f32(pl->pedge_obs + 4 * e, hpm + 4 * e);           // (:239)
+        }
         SE3* hc = (SE3*)hostp(dcams);
         for (int i = 0; i < nC; i++) hc[i] = se3_from_Tcw_f32(p->cam_Tcw + 16 * i);
         double* hp = (double*)hostp(dpts);
-        for (size_t i = 0; i < (size_t)nP * 3; i++) hp[i] = p->points[i];
+        for (size_t i = 0; i < (size_t)nPo * 3; i++) hp[i] = p->points[i];
+        for (size_t i = (size_t)nPo * 3; i < (size_t)nP * 3; i++) hp[i] = 0;
         // edge flags: bit0 stereo, bit2 robust kernel present (bit1 = level 1 is only ever set on the device)
         unsigned char* hf = (unsigned char*)hostp(dflag);
-        for (int e = 0; e < E; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | (robust ? 4 : 0));
+        for (int e = 0; e < Ept; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | (robust ? 4 : 0));
+        for (int e = Ept; e < E; e++) hf[e] = 8 | 4;      // EdgePlane: always a Huber kernel (:246-248)
         std::memset(hostp(dctl), 0, 16 * sizeof(int));
         // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
         int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
@@ -2697,7 +2895,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         std::vector<int>& cnt = c.scratch;
         cnt.assign((size_t)nC + nP, 0);
         int* camCnt = cnt.data(); int* ptCnt = camCnt + nC;
-        for (int e = 0; e < E; e++) { camCnt[p->edge_cam[e]]++; ptCnt[p->edge_point[e]]++; }
+        for (int e = 0; e < E; e++) { camCnt[edge_cam(e)]++; ptCnt[edge_lm(e)]++; }
         int nF = 0, nL = 0;
         for (int i = 0; i < nC; i++) { camIdx[i] = -1; if (camCnt[i] && !p->cam_fixed[i]) { actCam[nF] = i; camIdx[i] = nF++; } }
         ptStart[0] = 0;
@@ -2707,15 +2905,15 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         for (int i = 0; i < nL; i++) ptCnt[actPt[i]] = ptStart[i];         // counters become fill cursors
         for (int i = 0; i < nF; i++) camCnt[actCam[i]] = camStart[i];
         for (int e = 0; e < E; e++) {
-            const int cam = p->edge_cam[e];
-            ptEdges[ptCnt[p->edge_point[e]]++] = e;
+            const int cam = edge_cam(e);
+            ptEdges[ptCnt[edge_lm(e)]++] = e;
             if (camIdx[cam] >= 0) camEdges[camCnt[cam]++] = e;
         }
         // one edge per (camera, point) pair: the device's edge table has one slot per pair
         for (int i = 0; i < nC; i++) camCnt[i] = -1;                        // now: last point seen with this camera
         for (int l = 0; l < nL; l++)
             for (int k = ptStart[l]; k < ptStart[l + 1]; k++) {
-                const int cam = p->edge_cam[ptEdges[k]];
+                const int cam = edge_cam(ptEdges[k]);
                 if (camCnt[cam] == l) { eao::set_error("two edges join camera %d and point %d", cam, actPt[l]); return EAO_ERR_INVALID; }
                 camCnt[cam] = l;
             }
@@ -2729,7 +2927,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
             auto each_pair = [&](auto&& fn) {
                 for (int l = 0; l < nL; l++) {
                     obs.clear();
-                    for (int k = ptStart[l]; k < ptStart[l + 1]; k++) { const int ci = camIdx[p->edge_cam[ptEdges[k]]]; if (ci >= 0) obs.push_back(ci); }
+                    for (int k = ptStart[l]; k < ptStart[l + 1]; k++) { const int ci = camIdx[edge_cam(ptEdges[k])]; if (ci >= 0) obs.push_back(ci); }
                     for (size_t u = 0; u < obs.size(); u++)
                         for (size_t v = u; v < obs.size(); v++) fn(pair_index(std::min(obs[u], obs[v]), std::max(obs[u], obs[v]), nF), l);
                 }
@@ -2753,7 +2951,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     }
     EAO_HIP(hipEventRecord(c.ev0, s));
     EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(D.nL * D.nFree, nP * 3), nC), E), 256)), dim3(256), 0, s, D);
+    hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(D.nL * D.nFree, nP * 3), nC), E), nPl * 4), 256)), dim3(256), 0, s, D);
     if (bigPath) EAO_HIP(hipMemsetAsync(D.bigW, 0, (size_t)bg.RP * kBigNB * sizeof(double), s));
     const bool usePairs = pairPath && D.nFree > 0 && D.nL > 0;
     if (usePairs) {
@@ -2806,7 +3004,6 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         const size_t schurLds = bigPath ? 0 : schur_lds_bytes(nF);
         if (nF && !bigPath) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         const BigGeom gB = big_geom(std::max(nF, 1));
-        if (bigPath) EAO_HIP(hipFuncSetAttribute((const void*)k_bal_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(gB.N * sizeof(double))));
         int* const ctl0 = dctl; double* const lm0 = dlm0;
         auto use_pair = [&](int k) { D.ctl = ctl0 + 8 * k; D.lm = lm0 + 8 * k; };
         auto enqueue_trial = [&](int bulk, bool firstTrial = false, bool withDecide = true) {
@@ -2814,12 +3011,14 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
                 (void)hipMemsetAsync(D.big, 0, (size_t)gB.RP * gB.RP * sizeof(double), s);
                 hipLaunchKernelGGL(k_bal_schur_pairs, dim3(D.nPairsNZ), dim3(64), 0, s, D, firstTrial ? 1 : 0);
                 const int nbk = gB.N / kBigNB, nT = gB.RP / 64;
+                hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, D);
                 for (int kb = 0; kb < nbk; kb++) {
-                    hipLaunchKernelGGL(k_bal_panel, dim3(eao::cdiv(gB.N - kb * kBigNB - kBigNB + 1, 256)), dim3(256), 0, s, D, kb);
+                    hipLaunchKernelGGL(k_bal_panel, dim3(eao::cdiv(gB.N - kb * kBigNB - kBigNB + 1, 64)), dim3(64), 0, s, D, kb);
                     const int tj0 = (kb * kBigNB + kBigNB) >> 6;
                     if (kb + 1 < nbk) hipLaunchKernelGGL(k_bal_update, dim3(nT - tj0, nT - tj0), dim3(256), 0, s, D, kb);
                 }
-                hipLaunchKernelGGL(k_bal_backsolve, dim3(1), dim3(kBigSolveThreads), gB.N * sizeof(double), s, D, dsolveOk);
+                for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
+                    hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), 0, s, D, J, dsolveOk);
             } else if (nF && usePairs && solveTiles) {
                 hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2), dim3(kPairThreads), 0, s, D, firstTrial ? 1 : 0);
             } else if (nF) {
@@ -2832,13 +3031,15 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
             else if (solveTiles) hipLaunchKernelGGL(k_ba_solve_tiles<5>, dim3(1), dim3(kTileThreads), tileLds, s, D, dsolveOk);
             else if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
             else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
-            if (nL) hipLaunchKernelGGL(k_ba_backsub, dim3(ptBlocks), dim3(256), 0, s, D);
+            if (nL && hasPl) hipLaunchKernelGGL(k_ba_backsub<true>, dim3(ptBlocks), dim3(256), 0, s, D);
+            else if (nL) hipLaunchKernelGGL(k_ba_backsub<false>, dim3(ptBlocks), dim3(256), 0, s, D);
             if (withDecide) hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq, bulk, ctl0, lm0);
         };
         auto enqueue_bulk = [&](int from, int to, bool withErrors) {
             use_pair(0);
             if (withErrors) {   // computeActiveErrors + activeRobustChi2 (otherwise the accepted trial already left them)
-                if (nL) hipLaunchKernelGGL(k_ba_errors, dim3(ptBlocks), dim3(256), 0, s, D);
+                if (nL && hasPl) hipLaunchKernelGGL(k_ba_errors<true>, dim3(ptBlocks), dim3(256), 0, s, D);
+                else if (nL) hipLaunchKernelGGL(k_ba_errors<false>, dim3(ptBlocks), dim3(256), 0, s, D);
                 hipLaunchKernelGGL(k_ba_chi_init, dim3(1), dim3(256), 0, s, D, c.status, ++seq);
             }
             // every trial but the last leaves its accept / reject decision to the head of the next linearisation, which
@@ -2847,14 +3048,19 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
             int par = 0;
             for (int it = from; it < to; it++) {
                 if (it == from) {
-                    hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0,
-                                       (const int*)nullptr, (const double*)nullptr, (const int*)dsolveOk, c.status, 0);
+                    if (hasPl) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0,
+                                                  (const int*)nullptr, (const double*)nullptr, (const int*)dsolveOk, c.status, 0);
+                    else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0,
+                                            (const int*)nullptr, (const double*)nullptr, (const int*)dsolveOk, c.status, 0);
                 } else {
                     const int* ctlOld = D.ctl; const double* lmOld = D.lm;
                     par ^= 1;
                     use_pair(par);
-                    hipLaunchKernelGGL(k_ba_linearize, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, 0, ctlOld, lmOld,
-                                       (const int*)dsolveOk, c.status, ++seq);
+                    ++seq;
+                    if (hasPl) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, 0, ctlOld, lmOld,
+                                                  (const int*)dsolveOk, c.status, seq);
+                    else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, 0, ctlOld, lmOld,
+                                            (const int*)dsolveOk, c.status, seq);
                 }
                 if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);   // no Schur kernel to do it
                 enqueue_trial(1, it == 0 && nF, it == to - 1);
@@ -2923,7 +3129,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
             hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
             if ((st = optimize(-1, p->its_second, &dummyI, &dummyD, nullptr))) return st;
         }
-        hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(E, nP * 3), nC), 256)), dim3(256), 0, s, D, outCams, outPts, outCls);
+        hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(std::max(E, nP * 3), nC), nPl * 4), 256)), dim3(256), 0, s, D, outCams, outPts, outCls, outPlanes);
         EAO_HIP(hipStreamSynchronize(s));
     }
     const BAPhase A = c.status->ph[0], B = c.status->ph[1];
@@ -2947,7 +3153,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         }
     }
     if (redo)
-    hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(E, nP * 3), nC), 256)), dim3(256), 0, s, D, outCams, outPts, outCls);
+    hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(std::max(E, nP * 3), nC), nPl * 4), 256)), dim3(256), 0, s, D, outCams, outPts, outCls, outPlanes);
     EAO_HIP(hipEventRecord(c.ev1, s));
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
@@ -2959,10 +3165,11 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
                 st[2] - st[0], st[4] - st[2], st[10], st[11], st[12], st[6] - st[4], st[8] - st[6], st[3] - st[1], st[5] - st[3], st[7] - st[5], st[9] - st[7]);
     }
     for (int i = 0; i < nC; i++) se3_to_Tcw_f32(outCams[i], r->cam_Tcw + 16 * i);
-    for (size_t i = 0; i < (size_t)nP * 3; i++) r->points[i] = (float)outPts[i];
-    if (E && r->edge_outlier) {
-        if (mode == 0) std::memcpy(r->edge_outlier, outCls, E);
-        else std::memset(r->edge_outlier, 0, E);
+    for (size_t i = 0; i < (size_t)nPo * 3; i++) r->points[i] = (float)outPts[i];
+    for (size_t i = 0; i < (size_t)nPl * 4; i++) planes_out[i] = (float)outPlanes[i];           // Converter::toCvMat(Plane3D)
+    if (Ept && r->edge_outlier) {
+        if (mode == 0) std::memcpy(r->edge_outlier, outCls, Ept);
+        else std::memset(r->edge_outlier, 0, Ept);
     }
     return EAO_OK;
 }
@@ -2971,6 +3178,11 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
 
 eao_status eao_bundle_adjustment(const eao_ba_problem* p, int32_t robust, const volatile uint8_t* stop, eao_ba_result* r) {
     return ba_run(p, stop, r, 1, robust != 0);
+}
+
+eao_status eao_bundle_adjustment_planes(const eao_ba_problem* p, const eao_ba_planes* planes, int32_t robust, const volatile uint8_t* stop,
+                                        eao_ba_result* r, float* planes_out) {
+    return ba_run(p, stop, r, 1, robust != 0, planes, planes_out);
 }
 
 eao_status eao_last_lm_trace(double* lambda, double* chi2, int32_t* trials, int32_t cap, int32_t* n) {

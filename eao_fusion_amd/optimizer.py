@@ -78,16 +78,29 @@ class Optimizer:
         if stop is not None:
             stop = np.ascontiguousarray(stop, np.uint8)
             stop_p = _lib.ptr(stop)
+        planes_out = None
         if gba is None:
             _lib.check(_lib.load().eao_local_ba(C.byref(P), stop_p, C.byref(R)))
+        elif prob.get("planes") is not None and len(prob["planes"]):
+            pw = np.ascontiguousarray(prob["planes"], np.float32)
+            pp = np.ascontiguousarray(prob["pedge_plane"], np.int32)
+            pc = np.ascontiguousarray(prob["pedge_cam"], np.int32)
+            po = np.ascontiguousarray(prob["pedge_obs"], np.float32)
+            PL = _lib.BAPlanes(len(pw), _lib.ptr(pw), len(pp), _lib.ptr(pp), _lib.ptr(pc), _lib.ptr(po))
+            planes_out = np.zeros_like(pw)
+            _lib.check(_lib.load().eao_bundle_adjustment_planes(C.byref(P), C.byref(PL), 1 if gba else 0, stop_p, C.byref(R), _lib.ptr(planes_out)))
         else:
             _lib.check(_lib.load().eao_bundle_adjustment(C.byref(P), 1 if gba else 0, stop_p, C.byref(R)))
-        return dict(poses=cams_out, points=pts_out, edge_outlier=outl[:len(ec)], iters=np.array(R.iters[:]),
-                    aborted=bool(R.aborted), chi2=np.array(R.chi2[:]), trace=_trace(), timing=_timing())
+        out = dict(poses=cams_out, points=pts_out, edge_outlier=outl[:len(ec)], iters=np.array(R.iters[:]),
+                   aborted=bool(R.aborted), chi2=np.array(R.chi2[:]), trace=_trace(), timing=_timing())
+        if planes_out is not None:
+            out["planes"] = planes_out
+        return out
 
     @staticmethod
     def BundleAdjustment(prob, nIterations=5, stop=None, bRobust=True):
         """Optimizer::BundleAdjustment over keyframes and map points (reference src/Optimizer.cc:55-323): one
         optimize(nIterations) call, Huber kernels only when bRobust, nothing is erased.  prob as for LocalBundleAdjustment
-        (fixed[i] = 1 for the keyframe with mnId == 0)."""
+        (fixed[i] = 1 for the keyframe with mnId == 0); optional planes (m,4) f32 + pedge_plane / pedge_cam (Ep,) i32 + pedge_obs
+        (Ep,4) f32: the MapPlane vertices and EdgePlane edges of :203-252 (eao_bundle_adjustment_planes)."""
         return Optimizer.LocalBundleAdjustment(prob, stop, (int(nIterations), 0), gba=bool(bRobust))

@@ -347,3 +347,50 @@ def synth_stereo_pair(seed=9000, w=640, h=480, n_planes=6):
         right[y0:y1, w - d:] = left[y0:y1, w - 1:w]
     right = right + rng.integers(-2, 3, size=right.shape)
     return left.astype(np.uint8), np.clip(right, 0, 255).astype(np.uint8)
+
+
+def add_ba_planes(prob, n_planes=5, seed=7000, angle_noise_deg=0.3, dist_noise=0.01, init_angle_deg=2.0, init_dist=0.03, outlier_edges=1):
+    """Map planes for Optimizer::BundleAdjustment (reference src/Optimizer.cc:203-252) on top of a synth_ba problem: n_planes
+    world planes (n, c) with n . X + c = 0 (Plane3D coefficients, c >= 0), each observed by a contiguous run of cameras;
+    an observation is the plane in the camera frame (R n, c - t . R n; sign so that the fourth coefficient is >= 0) with a
+    little noise on the normal and the distance, float32 like KeyFrame::mvPlaneCoefficients.  The initial world planes are
+    the true ones turned by init_angle_deg and shifted by init_dist.  `outlier_edges` observations get a grossly wrong
+    normal (the Huber kernel of every plane edge must take them)."""
+    rng = np.random.default_rng(seed)
+    poses = prob["poses_gt"].astype(np.float64)
+    n_cams = len(poses)
+
+    def unit(v):
+        return v / np.linalg.norm(v)
+
+    def canon(c):
+        c = c / np.linalg.norm(c[:3])
+        return -c if c[3] < 0 else c
+
+    def turn(n, deg):
+        axis = unit(np.cross(n, rng.normal(size=3)))
+        a = np.deg2rad(deg)
+        return unit(n * np.cos(a) + np.cross(axis, n) * np.sin(a))
+
+    gt, init, pe_pl, pe_cam, pe_obs = [], [], [], [], []
+    for i in range(n_planes):
+        n = unit(rng.normal(size=3) + np.array([0.0, 0.0, 1.5]))
+        c = rng.uniform(2.0, 5.0)
+        w = canon(np.concatenate([n, [c]]))
+        gt.append(w)
+        init.append(canon(np.concatenate([turn(w[:3], init_angle_deg * rng.uniform(0.5, 1.0)), [w[3] + rng.uniform(-init_dist, init_dist)]])))
+        m = int(rng.integers(max(2, n_cams // 3), n_cams + 1))
+        first = int(rng.integers(0, n_cams - m + 1))
+        for cam in range(first, first + m):
+            R, t = poses[cam, :3, :3], poses[cam, :3, 3]
+            nl = R @ w[:3]
+            loc = canon(np.concatenate([nl, [w[3] - t @ nl]]))
+            meas = canon(np.concatenate([turn(loc[:3], angle_noise_deg * rng.uniform(0.0, 1.0)), [loc[3] + rng.normal(0.0, dist_noise)]]))
+            pe_pl.append(i); pe_cam.append(cam); pe_obs.append(meas)
+    pe_obs = np.array(pe_obs)
+    for k in rng.choice(len(pe_obs), size=min(outlier_edges, len(pe_obs)), replace=False):
+        pe_obs[k] = canon(np.concatenate([turn(pe_obs[k][:3], 25.0), [pe_obs[k][3] + 0.4]]))
+    out = dict(prob)
+    out.update(planes=np.array(init, np.float32), planes_gt=np.array(gt, np.float32), pedge_plane=np.array(pe_pl, np.int32),
+               pedge_cam=np.array(pe_cam, np.int32), pedge_obs=pe_obs.astype(np.float32))
+    return out

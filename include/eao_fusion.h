@@ -376,14 +376,30 @@ typedef struct {
 /* stop may be NULL; it is polled on the host between LM iterations like g2o's forceStopFlag */
 eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r);
 
-/* f3 (first step)  Optimizer::BundleAdjustment(vpKFs, vpMP, vpMPl, nIterations, pbStopFlag, nLoopKF, bRobust) --
- * src/Optimizer.cc:55-323 -- over keyframes and map points: the same flattening as eao_local_ba (cameras in ascending
- * mnId with cam_fixed = (mnId == 0), points in ascending mnId, points without an edge simply stay where they are),
+/* f3  Optimizer::BundleAdjustment(vpKFs, vpMP, vpMPl, nIterations, pbStopFlag, nLoopKF, bRobust) --
+ * src/Optimizer.cc:55-323: the same flattening as eao_local_ba (cameras in ascending mnId with
+ * cam_fixed = (mnId == 0), points in ascending mnId, points without an edge simply stay where they are),
  * ONE optimize(p->its_first) call (its_second is ignored), Huber kernels (delta sqrt(5.99) / sqrt(7.815), :94-95) only
  * when robust != 0, no outlier pass: r->edge_outlier may be NULL and comes back all zero, r->iters[1] = 0.
- * Not covered: the MapPlane vertices / EdgePlane edges of :203-252 (a map with planes is refused by the adapter) and maps
- * beyond the single-workgroup solvers (more than 64 free keyframes: refused with an error). */
+ * Up to 64 free keyframes run on the single-workgroup solvers of eao_local_ba; beyond that (whole maps after a loop
+ * closure, up to 2048 free keyframes) the reduced camera system is a dense lower triangle in HBM factorised by the whole
+ * chip (csrc/lm.hip, k_bal_*); oversized windows of eao_local_ba take the same path. */
 eao_status eao_bundle_adjustment(const eao_ba_problem* p, int32_t robust, const volatile uint8_t* stop, eao_ba_result* r);
+
+/* The MapPlane vertices / EdgePlane edges of the same function (src/Optimizer.cc:203-252; src/g2oAddition/VertexPlane.h,
+ * EdgePlane.h, Plane3D.h): every non-bad map plane is a marginalised 3-dof vertex (Plane3D::oplus), every observation by
+ * a keyframe of the graph an edge with information diag(3282.8, 3282.8, 1e4), ALWAYS a Huber kernel (delta sqrt(300))
+ * and g2o's numeric Jacobians on both vertices.  planes == NULL or n_planes == 0: same as eao_bundle_adjustment. */
+typedef struct {
+    int32_t n_planes;
+    const float* plane_world;     /* n_planes*4: MapPlane::GetWorldPos() */
+    int32_t n_pedges;
+    const int32_t* pedge_plane;   /* n_pedges: index into plane_world */
+    const int32_t* pedge_cam;     /* n_pedges: index into p->cam_Tcw */
+    const float* pedge_obs;       /* n_pedges*4: KeyFrame::mvPlaneCoefficients[observation index] */
+} eao_ba_planes;
+eao_status eao_bundle_adjustment_planes(const eao_ba_problem* p, const eao_ba_planes* planes, int32_t robust, const volatile uint8_t* stop,
+                                        eao_ba_result* r, float* planes_out /* n_planes*4: Converter::toCvMat(vPlane->estimate()) */);
 
 /* LM trace of the last eao_local_ba / eao_pose_optimization call made by this thread (for parity tests):
  * up to cap entries of (lambda after the iteration, robust chi2, trials). Returns the count in *n. */

@@ -330,6 +330,17 @@ void plane_error(const SE3& T, const double world[4], const double meas[4], doub
     err[1] = std::atan2(n[2], std::sqrt(n[0] * n[0] + n[1] * n[1]));
     err[2] = (-v2[3]) - (-meas[3]);
 }
+void plane_oplus(const double c[4], const double v[3], double out[4]) {   // Plane3D::oplus, Plane3D.h:73-89 (VertexPlane::oplusImpl)
+    const double az = v[0], el = v[1];
+    const double sn = std::sin(el), cs = std::cos(el);
+    const double n[3] = {cs * std::cos(az), cs * std::sin(az), sn};
+    double R[9];
+    plane_rotation(c, R);
+    const double d = (-c[3]) + v[2];
+    for (int r = 0; r < 3; r++) out[r] = R[r * 3] * n[0] + R[r * 3 + 1] * n[1] + R[r * 3 + 2] * n[2];
+    out[3] = -d;
+    plane_normalize(out);
+}
 struct PlaneEdge {
     double world[4], meas[4], infoA, infoD;
     int level = 0;
@@ -490,12 +501,18 @@ struct BAEdge {
     int level = 0;
     bool robust = true;
     double err[3] = {0, 0, 0};
+    // EdgePlane (src/g2oAddition/EdgePlane.h) between a VertexPlane and a keyframe: `pt` is then a landmark id beyond the
+    // points (point count + plane index), `meas` the measured plane, `info3` the diagonal of its information matrix
+    bool plane = false;
+    double meas[4] = {0, 0, 0, 0}, info3[3] = {0, 0, 0};
 };
 
 struct BAProblem : Problem {
     std::vector<SE3> cams, camsBackup;
     std::vector<uint8_t> camFixed;
     std::vector<double> pts, ptsBackup;  // 3 per point
+    std::vector<double> planes, planesBackup;   // 4 per MapPlane vertex (marginalised 3-dof landmarks after the points)
+    double deltaPlane = 0;
     std::vector<BAEdge> edges;
     double fx, fy, cx, cy, bf;
     float bf_f;
@@ -510,7 +527,7 @@ struct BAProblem : Problem {
 
     // SparseOptimizer::initializeOptimization(level) + buildIndexMapping
     void initialize() {
-        const int nc = (int)cams.size(), np = (int)pts.size() / 3;
+        const int nc = (int)cams.size(), np = (int)pts.size() / 3 + (int)planes.size() / 4;
         std::vector<int> camCnt(nc, 0), ptCnt(np, 0);
         activeEdges.clear();
         for (int k = 0; k < (int)edges.size(); k++) {
@@ -545,7 +562,9 @@ struct BAProblem : Problem {
             r[2] = r[0] - (double)(bf_f * invz);        // "const float &bf": float * float product
         }
     }
+    const double* planeOf(const BAEdge& e) const { return &planes[4 * (size_t)(e.pt - (int)pts.size() / 3)]; }
     void edgeError(BAEdge& e) const {
+        if (e.plane) { plane_error(cams[e.cam], planeOf(e), e.meas, e.err); return; }
         double p[3], r[3];
         se3_map(cams[e.cam], &pts[3 * e.pt], p);
         project(e, p, r);
@@ -557,6 +576,7 @@ struct BAProblem : Problem {
         return p[2] > 0.0;
     }
     static double chi2(const BAEdge& e) {
+        if (e.plane) return e.err[0] * (e.info3[0] * e.err[0]) + e.err[1] * (e.info3[1] * e.err[1]) + e.err[2] * (e.info3[2] * e.err[2]);
         double s = e.err[0] * (e.info * e.err[0]) + e.err[1] * (e.info * e.err[1]);
         if (e.stereo) s += e.err[2] * (e.info * e.err[2]);
         return s;
@@ -567,13 +587,34 @@ struct BAProblem : Problem {
         for (int k : activeEdges) {
             const BAEdge& e = edges[k];
             double c = chi2(e);
-            if (e.robust) { double d = e.stereo ? deltaStereo : deltaMono, r0, r1; huber(c, d, d * d, r0, r1); chi += r0; }
+            if (e.robust) { double d = e.plane ? deltaPlane : e.stereo ? deltaStereo : deltaMono, r0, r1; huber(c, d, d * d, r0, r1); chi += r0; }
             else chi += c;
         }
         return chi;
     }
     // Jacobians: A (D x 3, point) and B (D x 6, pose)
     void jacobians(const BAEdge& e, double A[3][3], double B[3][6]) const {
+        if (e.plane) {
+            // g2o's numeric Jacobians (central differences, delta = 1e-9, core/base_binary_edge.hpp:131-205): vertex 0 =
+            // the plane (VertexPlane::oplusImpl), vertex 1 = the keyframe (exp(delta) * T); a fixed keyframe is skipped
+            const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+            const double* pl = planeOf(e);
+            for (int d = 0; d < 3; d++) {
+                double add[3] = {0, 0, 0}, q[4], ep[3], em[3];
+                add[d] = delta;  plane_oplus(pl, add, q); plane_error(cams[e.cam], q, e.meas, ep);
+                add[d] = -delta; plane_oplus(pl, add, q); plane_error(cams[e.cam], q, e.meas, em);
+                for (int k = 0; k < 3; k++) A[k][d] = scalar * (ep[k] - em[k]);
+            }
+            for (int d = 0; d < 6; d++) {
+                double add[6] = {0, 0, 0, 0, 0, 0}, ep[3] = {0, 0, 0}, em[3] = {0, 0, 0};
+                if (!camFixed[e.cam]) {
+                    add[d] = delta;  plane_error(se3_mul(se3_exp(add), cams[e.cam]), pl, e.meas, ep);
+                    add[d] = -delta; plane_error(se3_mul(se3_exp(add), cams[e.cam]), pl, e.meas, em);
+                }
+                for (int k = 0; k < 3; k++) B[k][d] = scalar * (ep[k] - em[k]);
+            }
+            return;
+        }
         double p[3], R[9];
         se3_map(cams[e.cam], &pts[3 * e.pt], p);
         quat_to_matrix(cams[e.cam].r, R);
@@ -609,19 +650,20 @@ struct BAProblem : Problem {
             BAEdge& e = edges[k];
             double A[3][3], B[3][6];
             jacobians(e, A, B);
-            const int D = e.stereo ? 3 : 2;
+            const int D = (e.stereo || e.plane) ? 3 : 2;
             double w = 1.0;
-            if (e.robust) { double d = e.stereo ? deltaStereo : deltaMono, r0; huber(chi2(e), d, d * d, r0, w); }
-            const double wi = w * e.info;
+            if (e.robust) { double d = e.plane ? deltaPlane : e.stereo ? deltaStereo : deltaMono, r0; huber(chi2(e), d, d * d, r0, w); }
+            const double inf[3] = {e.plane ? e.info3[0] : e.info, e.plane ? e.info3[1] : e.info, e.plane ? e.info3[2] : e.info};
+            const double wi[3] = {w * inf[0], w * inf[1], w * inf[2]};
             double omr[3];  // rho' * (-Omega e)
-            for (int r = 0; r < D; r++) omr[r] = w * (-(e.info * e.err[r]));
+            for (int r = 0; r < D; r++) omr[r] = w * (-(inf[r] * e.err[r]));
             const int li = ptIdx[e.pt], pi = camIdx[e.cam];
             double* bl = &bvec[(size_t)nP * 6 + (size_t)li * 3];
             double* Hl = &Hll[(size_t)li * 9];
             for (int i = 0; i < 3; i++) {
                 double s = 0; for (int r = 0; r < D; r++) s += A[r][i] * omr[r];
                 bl[i] += s;
-                for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi * A[r][j]; Hl[i * 3 + j] += h; }
+                for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi[r] * A[r][j]; Hl[i * 3 + j] += h; }
             }
             if (pi >= 0) {
                 double* bp = &bvec[(size_t)pi * 6];
@@ -630,8 +672,8 @@ struct BAProblem : Problem {
                 for (int i = 0; i < 6; i++) {
                     double s = 0; for (int r = 0; r < D; r++) s += B[r][i] * omr[r];
                     bp[i] += s;
-                    for (int j = 0; j < 6; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi * B[r][j]; Hp[i * 6 + j] += h; }
-                    for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi * A[r][j]; Hx[i * 3 + j] = h; }
+                    for (int j = 0; j < 6; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * B[r][j]; Hp[i * 6 + j] += h; }
+                    for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; Hx[i * 3 + j] = h; }
                 }
             }
         }
@@ -695,12 +737,17 @@ struct BAProblem : Problem {
         return true;
     }
     double computeScale(double lambda) const override { double s = 0; for (size_t j = 0; j < x.size(); j++) s += x[j] * (lambda * x[j] + bvec[j]); return s; }
-    void push() override { camsBackup = cams; ptsBackup = pts; }
-    void pop() override { cams = camsBackup; pts = ptsBackup; }
+    void push() override { camsBackup = cams; ptsBackup = pts; planesBackup = planes; }
+    void pop() override { cams = camsBackup; pts = ptsBackup; planes = planesBackup; }
     void discardTop() override {}
     void applyUpdate() override {
         for (int p = 0; p < nP; p++) { int c = activeCams[p]; cams[c] = se3_mul(se3_exp(&x[(size_t)p * 6]), cams[c]); }
-        for (int l = 0; l < nL; l++) { int q = activePts[l]; for (int i = 0; i < 3; i++) pts[3 * q + i] += x[(size_t)nP * 6 + l * 3 + i]; }
+        const int npo = (int)pts.size() / 3;
+        for (int l = 0; l < nL; l++) {
+            const int q = activePts[l];
+            if (q < npo) { for (int i = 0; i < 3; i++) pts[3 * q + i] += x[(size_t)nP * 6 + l * 3 + i]; }
+            else { double out[4]; plane_oplus(&planes[4 * (size_t)(q - npo)], &x[(size_t)nP * 6 + l * 3], out); for (int i = 0; i < 4; i++) planes[4 * (size_t)(q - npo) + i] = out[i]; }
+        }
     }
 };
 
@@ -869,12 +916,16 @@ int orc_local_ba(const orc_ba_problem* P, const volatile bool* stop, float* cam_
     return 0;
 }
 
-// Optimizer::BundleAdjustment over keyframes and map points (src/Optimizer.cc:55-323; the MapPlane vertices of :203-252 are
-// not restated): every edge robust iff bRobust with delta sqrt(5.99) / sqrt(7.815) (:94-95), ONE initializeOptimization() +
+// Optimizer::BundleAdjustment over keyframes, map points and map planes (src/Optimizer.cc:55-323): every point edge robust iff bRobust with delta sqrt(5.99) / sqrt(7.815) (:94-95), ONE initializeOptimization() +
 // optimize(iterations) (:254-255), estimates written back (:258-300).  A map point without an edge is removed from the graph
 // (:193-201) and keeps its position.  Same outputs as orc_local_ba (iters[1] = 0).
-int orc_bundle_adjustment(const orc_ba_problem* P, int32_t iterations, int32_t robust, const volatile bool* stop, float* cam_Tcw_out,
-                          float* points_out, double* cams_d, double* points_d, int32_t* iters, orc_trace* trace) {
+// Planes (:203-252): n_planes MapPlane vertices (plane_world 4 floats each, MapPlane::GetWorldPos()), marginalised 3-dof landmarks
+// with ids beyond the points; n_pedges EdgePlane edges (plane index, camera, measured coefficients KeyFrame::mvPlaneCoefficients[.]),
+// information diag(3282.8, 3282.8, 1e4), ALWAYS a Huber kernel with delta sqrt(300), numeric Jacobians on both vertices.  An edge
+// whose keyframe is not in the graph is skipped by the caller (:234-235).  planes_out: 4 floats per plane (Converter::toCvMat(Plane3D)).
+struct orc_ba_planes { int32_t n_planes; const float* plane_world; int32_t n_pedges; const int32_t* pedge_plane; const int32_t* pedge_cam; const float* pedge_obs; };
+int orc_bundle_adjustment_planes(const orc_ba_problem* P, const orc_ba_planes* PL, int32_t iterations, int32_t robust, const volatile bool* stop,
+                                 float* cam_Tcw_out, float* points_out, float* planes_out, double* cams_d, double* points_d, int32_t* iters, orc_trace* trace) {
     BAProblem pb;
     pb.fx = P->fx; pb.fy = P->fy; pb.cx = P->cx; pb.cy = P->cy; pb.bf = P->bf; pb.bf_f = P->bf;
     pb.deltaMono = (float)std::sqrt(5.99); pb.deltaStereo = (float)std::sqrt(7.815);
@@ -891,6 +942,20 @@ int orc_bundle_adjustment(const orc_ba_problem* P, int32_t iterations, int32_t r
         e.info = P->edge_inv_sigma2[k];
         e.robust = robust != 0;
     }
+    if (PL && PL->n_planes > 0) {
+        pb.deltaPlane = (float)std::sqrt(300.0);
+        pb.planes.resize((size_t)PL->n_planes * 4);
+        for (int i = 0; i < PL->n_planes; i++) plane_from_f32(PL->plane_world + 4 * i, &pb.planes[4 * (size_t)i]);
+        const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0;
+        for (int k = 0; k < PL->n_pedges; k++) {
+            BAEdge e;
+            e.cam = PL->pedge_cam[k]; e.pt = P->n_points + PL->pedge_plane[k];
+            e.plane = true; e.stereo = false; e.info = 0; e.robust = true;
+            plane_from_f32(PL->pedge_obs + 4 * k, e.meas);
+            e.info3[0] = angleInfo; e.info3[1] = angleInfo; e.info3[2] = disInfo;
+            pb.edges.push_back(e);
+        }
+    }
     if (trace) trace->n = 0;
     if (iters) { iters[0] = iters[1] = 0; }
     pb.initialize();
@@ -906,7 +971,12 @@ int orc_bundle_adjustment(const orc_ba_problem* P, int32_t iterations, int32_t r
                       d[4] = pb.cams[c].t[0]; d[5] = pb.cams[c].t[1]; d[6] = pb.cams[c].t[2]; }
     }
     for (size_t i = 0; i < pb.pts.size(); i++) { points_out[i] = (float)pb.pts[i]; if (points_d) points_d[i] = pb.pts[i]; }
+    if (planes_out) for (size_t i = 0; i < pb.planes.size(); i++) planes_out[i] = (float)pb.planes[i];
     return 0;
+}
+int orc_bundle_adjustment(const orc_ba_problem* P, int32_t iterations, int32_t robust, const volatile bool* stop, float* cam_Tcw_out,
+                          float* points_out, double* cams_d, double* points_d, int32_t* iters, orc_trace* trace) {
+    return orc_bundle_adjustment_planes(P, nullptr, iterations, robust, stop, cam_Tcw_out, points_out, nullptr, cams_d, points_d, iters, trace);
 }
 
 // ---- known-answer hooks for tests -------------------------------------------------------------
@@ -932,6 +1002,12 @@ void orc_se3_oplus(const double* cam7, const double* upd6, double* out7) {
     out7[0] = r.r.x; out7[1] = r.r.y; out7[2] = r.r.z; out7[3] = r.r.w; out7[4] = r.t[0]; out7[5] = r.t[1]; out7[6] = r.t[2];
 }
 void orc_huber(double e, double delta, double* rho2) { huber(e, delta, delta * delta, rho2[0], rho2[1]); }
+// Plane3D::oplus / EdgePlane::computeError on raw coefficients (cam7 = qx qy qz qw tx ty tz)
+void orc_plane_oplus(const double* c4, const double* v3, double* out4) { plane_oplus(c4, v3, out4); }
+void orc_plane_error(const double* cam7, const double* world4, const double* meas4, double* err3) {
+    SE3 T; T.r = Quat{cam7[0], cam7[1], cam7[2], cam7[3]}; T.t[0] = cam7[4]; T.t[1] = cam7[5]; T.t[2] = cam7[6];
+    plane_error(T, world4, meas4, err3);
+}
 void orc_Tcw_to_cam7(const float* T, double* out7) {
     SE3 s = se3_from_Tcw_f32(T);
     out7[0] = s.r.x; out7[1] = s.r.y; out7[2] = s.r.z; out7[3] = s.r.w; out7[4] = s.t[0]; out7[5] = s.t[1]; out7[6] = s.t[2];

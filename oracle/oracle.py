@@ -43,6 +43,11 @@ class BAProblem(C.Structure):
                 ("cy", C.c_float), ("bf", C.c_float), ("its_first", C.c_int32), ("its_second", C.c_int32)]
 
 
+class BAPlanes(C.Structure):   # orc_ba_planes
+    _fields_ = [("n_planes", C.c_int32), ("plane_world", C.c_void_p), ("n_pedges", C.c_int32), ("pedge_plane", C.c_void_p),
+                ("pedge_cam", C.c_void_p), ("pedge_obs", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -77,6 +82,8 @@ def lib():
         L.orc_local_ba.argtypes = [C.c_void_p] * 9
         L.orc_bundle_adjustment.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
         L.orc_bundle_adjustment.restype = C.c_int
+        L.orc_bundle_adjustment_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        L.orc_bundle_adjustment_planes.restype = C.c_int
         L.orc_ba_edge_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_double] * 5 + [C.c_void_p] * 3
         L.orc_se3_oplus.argtypes = [C.c_void_p] * 3
         L.orc_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
@@ -273,6 +280,16 @@ def bundle_adjustment(prob, iterations=5, robust=True, stop=None):
     if stop is not None:
         stop_arr = np.array([1 if stop else 0], np.uint8)
         stop_p = _p(stop_arr)
+    if prob.get("planes") is not None and len(prob["planes"]):
+        pw = np.ascontiguousarray(prob["planes"], np.float32)
+        pp = np.ascontiguousarray(prob["pedge_plane"], np.int32)
+        pc = np.ascontiguousarray(prob["pedge_cam"], np.int32)
+        po = np.ascontiguousarray(prob["pedge_obs"], np.float32)
+        PL = BAPlanes(len(pw), _p(pw), len(pp), _p(pp), _p(pc), _p(po))
+        planes_out = np.zeros_like(pw)
+        lib().orc_bundle_adjustment_planes(C.byref(P), C.byref(PL), int(iterations), 1 if robust else 0, stop_p, _p(cams_out), _p(pts_out), _p(planes_out),
+           _p(cams_d), _p(pts_d), _p(iters), C.byref(tr))
+        return dict(poses=cams_out, points=pts_out, planes=planes_out, cams_d=cams_d, points_d=pts_d, iters=iters, trace=tr.to_dict())
     lib().orc_bundle_adjustment(C.byref(P), int(iterations), 1 if robust else 0, stop_p, _p(cams_out), _p(pts_out), _p(cams_d), _p(pts_d),
                                 _p(iters), C.byref(tr))
     return dict(poses=cams_out, points=pts_out, cams_d=cams_d, points_d=pts_d, iters=iters, trace=tr.to_dict())

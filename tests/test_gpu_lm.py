@@ -210,6 +210,31 @@ def test_local_ba_oversized_window(gpu, oracle):
     assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
 
 
+@pytest.mark.parametrize("kw,pk,its,robust", [(dict(n_free=8, n_fixed=1, n_points=500, seed=5400), dict(n_planes=4), 10, True),
+                                              (dict(n_free=5, n_fixed=2, n_points=200, seed=5402, mono_frac=0.5), dict(n_planes=1, seed=7002, outlier_edges=0), 10, False),
+                                              # beyond the register-tile solver, and on the map-scale path
+                                              (dict(n_free=40, n_fixed=1, n_points=2000, seed=5403), dict(n_planes=6, seed=7003, outlier_edges=3), 10, True),
+                                              (dict(n_free=90, n_fixed=1, n_points=3000, seed=5404), dict(n_planes=8, seed=7004, outlier_edges=4), 10, False)])
+def test_bundle_adjustment_with_planes(gpu, oracle, kw, pk, its, robust):
+    """The MapPlane vertices / EdgePlane edges of Optimizer::BundleAdjustment (src/Optimizer.cc:203-252): marginalised 3-dof
+    plane landmarks (Plane3D::oplus), information diag(3282.8, 3282.8, 1e4), always a Huber kernel, g2o's central-difference
+    Jacobians (delta = 1e-9, i.e. ~1e-7 of rounding noise in any implementation) on both vertices."""
+    p = synth.add_ba_planes(synth.synth_ba(**kw), **pk)
+    r = gpu.Optimizer.BundleAdjustment(p, its, bRobust=robust)
+    o = oracle.bundle_adjustment(p, its, robust)
+    assert list(r["iters"]) == [int(o["iters"][0]), 0] and r["iters"][0] >= 3
+    _check_trace(r, o, rel=1e-5)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    _check_updates(r["planes"], o["planes"], p["planes"], "planes")
+    assert np.abs(r["planes"] - p["planes"]).max() > 1e-3            # the planes did move
+    f = p["fixed"].astype(bool)
+    assert np.array_equal(r["poses"][f], o["poses"][f])
+    # aborted before the first iteration: planes come back normalised, nothing else changes
+    ra = gpu.Optimizer.BundleAdjustment(p, its, stop=np.array([1], np.uint8), bRobust=robust)
+    assert ra["aborted"] and np.allclose(ra["planes"], p["planes"], atol=1e-6) and np.array_equal(ra["points"], p["points"])
+
+
 def test_bundle_adjustment_limits(gpu):
     p = synth.synth_ba(n_free=2049, n_fixed=1, n_points=60, seed=5104)
     with pytest.raises(gpu.EaoError):            # beyond the map-scale path's 2048 free keyframes: refused, not approximated
