@@ -215,13 +215,13 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
 }
 
 // ---- Optimizer::BundleAdjustment(vpKFs, vpMP, vpMPl, nIterations, pbStopFlag, nLoopKF, bRobust) ------------------
-// reference src/Optimizer.cc:55-323 over keyframes and map points.  The MapPlane vertices / EdgePlane edges of :203-252
-// are not covered by the library yet: a map that holds a (non-bad) plane is refused instead of being optimised without it.
+// reference src/Optimizer.cc:55-323 over keyframes, map points and map planes: every non-bad MapPlane becomes a plane
+// landmark, every observation of it by a (non-bad) keyframe of vpKFs an EdgePlane (:203-252, eao_bundle_adjustment_planes).
+// (Upstream looks the keyframe of a plane observation up by id without the `mnId > maxKFid` guard of the point edges: an
+// observation by a keyframe outside vpKFs could there land on a map-point vertex -- undefined behaviour; here it is skipped.)
 template <class MapPointT, class KeyFrameT, class MapPlaneT>
 void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<MapPointT*>& vpMP, const std::vector<MapPlaneT*>& vpMPl,
                       int nIterations = 5, bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true) {
-    for (MapPlaneT* pl : vpMPl)
-        if (pl && !pl->isBad()) throw std::runtime_error("eaofusion::BundleAdjustment: map planes are not supported by eao_bundle_adjustment yet");
     // cameras / points in ascending mnId (g2o's vertex order); edges in upstream's insertion order (vpMP order, then the
     // observation map's order)
     std::vector<KeyFrameT*> cams;
@@ -262,17 +262,41 @@ void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<Ma
             included[ptIndex[mp]] = 1;                                  // nEdges != 0, :193-201
         }
     }
+    // map planes (:210-252), in ascending mnId like their vertex ids
+    std::vector<MapPlaneT*> planes;
+    for (MapPlaneT* pl : vpMPl) if (pl && !pl->isBad()) planes.push_back(pl);
+    std::sort(planes.begin(), planes.end(), [](MapPlaneT* a, MapPlaneT* b) { return a->mnId < b->mnId; });
+    std::vector<float> plWorld(planes.size() * 4), plObs;
+    std::vector<int32_t> plEdgePlane, plEdgeCam;
+    for (size_t i = 0; i < planes.size(); i++) {
+        const cv::Mat W = planes[i]->GetWorldPos();
+        for (int k = 0; k < 4; k++) plWorld[i * 4 + k] = W.template at<float>(k);
+        const auto seenBy = planes[i]->GetObservations();           // map<KeyFrame*, int>
+        for (const auto& ob : seenBy) {
+            KeyFrameT* kf = ob.first;
+            if (kf->isBad()) continue;                                  // :231
+            auto ci = camIndex.find(kf);
+            if (ci == camIndex.end()) continue;                         // optimizer.vertex(pKFi->mnId) == NULL, :234-235
+            const cv::Mat& c = kf->mvPlaneCoefficients[ob.second];
+            plEdgePlane.push_back((int32_t)i); plEdgeCam.push_back(ci->second);
+            for (int k = 0; k < 4; k++) plObs.push_back(c.template at<float>(k));
+        }
+    }
     eao_ba_problem P;
     P.n_cams = (int)cams.size(); P.n_points = (int)pts.size(); P.n_edges = (int)eCam.size();
     P.cam_Tcw = camT.data(); P.cam_fixed = camFixed.data(); P.points = xyz.data();
     P.edge_cam = eCam.data(); P.edge_point = ePt.data(); P.edge_obs = obs.data(); P.edge_inv_sigma2 = inv.data();
     P.fx = cams[0]->fx; P.fy = cams[0]->fy; P.cx = cams[0]->cx; P.cy = cams[0]->cy; P.bf = cams[0]->mbf;
     P.its_first = nIterations; P.its_second = 0;
-    std::vector<float> camOut(camT.size()), xyzOut(xyz.size());
+    eao_ba_planes PL;
+    PL.n_planes = (int)planes.size(); PL.plane_world = plWorld.data(); PL.n_pedges = (int)plEdgeCam.size();
+    PL.pedge_plane = plEdgePlane.data(); PL.pedge_cam = plEdgeCam.data(); PL.pedge_obs = plObs.data();
+    std::vector<float> camOut(camT.size()), xyzOut(xyz.size()), plOut(plWorld.size());
     eao_ba_result R;
     R.cam_Tcw = camOut.data(); R.points = xyzOut.data(); R.edge_outlier = nullptr;
     static_assert(sizeof(bool) == 1, "bool* abort flag is polled as a byte");
-    check(eao_bundle_adjustment(&P, bRobust ? 1 : 0, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), &R), "eao_bundle_adjustment");
+    check(eao_bundle_adjustment_planes(&P, planes.empty() ? nullptr : &PL, bRobust ? 1 : 0, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), &R,
+                                       plOut.data()), "eao_bundle_adjustment_planes");
     for (size_t i = 0; i < cams.size(); i++) {                          // :258-275
         cv::Mat T(4, 4, CV_32F);
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.template at<float>(r, c) = camOut[i * 16 + r * 4 + c];
@@ -295,6 +319,17 @@ void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<Ma
             pts[i]->mPosGBA.create(3, 1, CV_32F);
             X.copyTo(pts[i]->mPosGBA);
             pts[i]->mnBAGlobalForKF = nLoopKF;
+        }
+    }
+    for (size_t i = 0; i < planes.size(); i++) {                        // :303-322
+        cv::Mat C4(4, 1, CV_32F);
+        for (int k = 0; k < 4; k++) C4.template at<float>(k) = plOut[i * 4 + k];
+        if (nLoopKF == 0) {
+            planes[i]->SetWorldPos(C4);
+        } else {
+            planes[i]->mPosGBA.create(4, 1, CV_32F);
+            C4.copyTo(planes[i]->mPosGBA);
+            planes[i]->mnBAGlobalForKF = nLoopKF;
         }
     }
 }

@@ -47,6 +47,7 @@ struct KeyFrame {
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<KeyFrame*> covisible;
     cv::Mat Tcw, mTcwGBA;
+    std::vector<cv::Mat> mvPlaneCoefficients;   // upstream include/KeyFrame.h:261
     long unsigned int mnBAGlobalForKF = 0;
     int erased = 0;
     bool isBad() { return false; }
@@ -65,6 +66,12 @@ struct MapPlane {
     bool mbSeen = false, bad = false;
     bool isBad() { return bad; }
     cv::Mat GetWorldPos() { return world.clone(); }
+    // Optimizer::BundleAdjustment (upstream include/MapPlane.h:32-66)
+    long unsigned int mnId = 0, mnBAGlobalForKF = 0;
+    std::map<KeyFrame*, int> observations;
+    cv::Mat mPosGBA;
+    std::map<KeyFrame*, int> GetObservations() { return observations; }
+    void SetWorldPos(const cv::Mat& p) { world = p.clone(); }
 };
 std::mutex MapPlane::mGlobalMutex;
 struct Frame {
@@ -323,10 +330,35 @@ int main(int argc, char** argv) {
         }
         for (int p = 0; p < np; p++) parked &= gm[p].normalUpdates == 0 && (gm[p].observations.empty() || (gm[p].mnBAGlobalForKF == 7 && !gm[p].mPosGBA.empty()));
         wr(out, &parked, 1);
-        MapPlane livePlane; vpl.push_back(&livePlane);
-        int32_t refused = 0;
-        try { eaofusion::BundleAdjustment(vk, vm, vpl, 10, nullptr, 0, false); } catch (const std::runtime_error&) { refused = 1; }
-        wr(out, &refused, 1);
+        // a live map plane seen by every keyframe: measured coefficients = the plane in each camera frame (from the initial
+        // poses) with a small deterministic disturbance; the test replays the same data through the C-ABI mirror
+        build(gk, gm);
+        vk.clear(); vm.clear();
+        for (int c = 0; c < nc; c++) vk.push_back(&gk[c]);
+        for (int p = 0; p < np; p++) vm.push_back(&gm[p]);
+        MapPlane livePlane; livePlane.mnId = 3;
+        livePlane.world = cv::Mat(4, 1, CV_32F);
+        const float w4[4] = {0.12f, -0.2f, 0.97f, 3.4f};
+        for (int k = 0; k < 4; k++) livePlane.world.at<float>(k) = w4[k];
+        std::vector<float> plobs;
+        for (int c = 0; c < nc; c++) {
+            const float* T = &camT[c * 16];
+            float nl[3], d;
+            for (int r = 0; r < 3; r++) nl[r] = T[r * 4] * w4[0] + T[r * 4 + 1] * w4[1] + T[r * 4 + 2] * w4[2];
+            d = w4[3] - (T[3] * nl[0] + T[7] * nl[1] + T[11] * nl[2]);
+            cv::Mat m(4, 1, CV_32F);
+            m.at<float>(0) = nl[0] + 0.004f * (float)((c % 3) - 1); m.at<float>(1) = nl[1] - 0.003f * (float)(c % 2); m.at<float>(2) = nl[2];
+            m.at<float>(3) = d + 0.01f * (float)((c % 5) - 2);
+            gk[c].mvPlaneCoefficients.assign(2, cv::Mat());
+            gk[c].mvPlaneCoefficients[1] = m;
+            livePlane.observations[&gk[c]] = 1;
+            for (int k = 0; k < 4; k++) plobs.push_back(m.at<float>(k));
+        }
+        vpl.push_back(&livePlane);
+        eaofusion::BundleAdjustment(vk, vm, vpl, 10, nullptr, 0, true);
+        wr(out, plobs.data(), plobs.size());
+        for (int c = 0; c < nc; c++) wr(out, gk[c].Tcw.ptr<float>(0), 16);
+        wr(out, livePlane.world.ptr<float>(0), 4);
     }
     printf("adapter_test ok: %d keypoints, %d pose inliers, %d observations erased\n", nk, inliers, erased);
     return 0;

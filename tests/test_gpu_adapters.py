@@ -105,14 +105,28 @@ def test_cpp_adapters_end_to_end(tmp_path):
     gpts = take(np.float32, npnt * 3).reshape(npnt, 3)
     normals_g = int(take(np.int32, 1)[0])
     parked_poses = take(np.float32, nc * 16).reshape(nc, 4, 4)
-    parked, refused = (int(x) for x in take(np.int32, 2))
+    parked = int(take(np.int32, 1)[0])
+    plobs = take(np.float32, nc * 4).reshape(nc, 4)
+    plposes = take(np.float32, nc * 16).reshape(nc, 4, 4)
+    plworld = take(np.float32, 4)
     gp = dict(bp)
     gp["fixed"] = (np.arange(nc) == 0).astype(np.uint8)
     rg = E.Optimizer.BundleAdjustment(gp, 10, bRobust=False)
     assert rg["iters"][0] >= 3
     assert np.allclose(gposes, rg["poses"], rtol=0, atol=2e-6) and np.allclose(gpts, rg["points"], rtol=0, atol=2e-5)
     assert np.array_equal(gposes[0], bp["poses"][0]) and normals_g == npnt
-    assert np.array_equal(parked_poses, gposes) and parked == 1 and refused == 1
+    assert np.array_equal(parked_poses, gposes) and parked == 1
+    # ... and with a live MapPlane seen by every keyframe (src/Optimizer.cc:203-252): the template's flattening = this one
+    gq = dict(gp)
+    gq.update(planes=np.array([[0.12, -0.2, 0.97, 3.4]], np.float32), pedge_plane=np.zeros(nc, np.int32), pedge_cam=np.arange(nc, dtype=np.int32), pedge_obs=plobs)
+    rq = E.Optimizer.BundleAdjustment(gq, 10, bRobust=True)
+    assert np.allclose(plposes, rq["poses"], rtol=0, atol=2e-6) and np.allclose(plworld, rq["planes"][0], rtol=0, atol=2e-6)
+    assert np.abs(rq["planes"][0] - _normalized_plane(gq["planes"][0])).max() > 1e-3 and np.abs(rq["poses"] - rg["poses"]).max() > 1e-5
+
+
+def _normalized_plane(c):
+    c = c.astype(np.float64) / np.linalg.norm(c[:3].astype(np.float64))
+    return (-c if c[3] < 0 else c).astype(np.float32)
 
 
 def test_cpp_search_adapters(tmp_path):
