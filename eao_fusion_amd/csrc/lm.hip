@@ -940,7 +940,7 @@ struct BADev {
     double deltaPlane, infoAngle, infoDist;
     // map-scale path (k_bal_*): dense lower-triangular system in HBM, panel workspace, factored diagonal blocks, pair CSR
     double* big;            // RP * RP
-    double* bigW;           // RP * 32: w = a L_kk^-T of the current panel
+    double* bigL;           // RP * RP: the factor L (rows below each panel's diagonal block), row N = z
     double* bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks
     int* bigFail;
     const int* lpStart;     // nPairsNZ + 1
@@ -2061,7 +2061,7 @@ __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(BADev P, int* s
 //            order); the 6x6 block -Sum Y(i1,l) Hpl(i2,l)^T (+ Hpp + lambda I and the right-hand side on diagonal pairs)
 //            is reduced through LDS in lane order and stored straight into S.  Pairs without a common landmark stay zero
 //            from the memset that precedes every trial (the factorisation fills in place).
-//   factor   right-looking LDL^T without pivoting in panels of 32 columns, two launches per panel:
+//   factor   right-looking LDL^T without pivoting in panels of 32 columns, ONE launch per panel (k_bal_step; it started as two):
 //            k_bal_panel   one thread per row below the diagonal block solves  w = a L_kk^-T  (496 FMAs on registers, the
 //                          factored L_kk as LDS broadcast reads), keeps w for the update and stores l = w D^-1 in place;
 //            k_bal_update  64 x 64 tiles of the trailing lower triangle, C -= W L^T over the 32 panel columns, 4 x 4
@@ -2078,8 +2078,9 @@ __host__ __device__ inline BigGeom big_geom(int nF) {
     return g;
 }
 
-__global__ __launch_bounds__(64) void k_bal_schur_pairs(BADev P, int first) {
-    __shared__ double red[64 * 43];
+constexpr int kBigPairThreads = 512;   // (block_sum_lds needs 8 column threads per value)
+__global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(BADev P, int first) {
+    __shared__ double red[(kBigPairThreads / 4) * 42], part[8 * 42];
     if (P.ctl[kCtlHalt]) return;
     const int nF = P.nFree, t = threadIdx.x;
     const BigGeom g = big_geom(nF);
@@ -2090,13 +2091,13 @@ __global__ __launch_bounds__(64) void k_bal_schur_pairs(BADev P, int first) {
     if (blockIdx.x == 0) {
         if (first && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
         if (t == 0) *P.bigFail = 0;
-        for (int r = g.n + t; r < g.N; r += 64) P.big[(size_t)r * ld + r] = 1.0;     // identity padding
+        for (int r = g.n + t; r < g.N; r += kBigPairThreads) P.big[(size_t)r * ld + r] = 1.0;     // identity padding
     }
     const int beg = P.lpStart[blockIdx.x], cnt = P.lpStart[blockIdx.x + 1] - beg;
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; q++) acc[q] = 0;
-    for (int k = t; k < cnt; k += 64) {
+    for (int k = t; k < cnt; k += kBigPairThreads) {
         const int l = P.lpPts[beg + k];
         const int e1 = P.table[(size_t)l * nF + i1], e2 = P.table[(size_t)l * nF + i2];
         if (e1 < 0 || e2 < 0) continue;                      // deactivated by the outlier pass
@@ -2121,15 +2122,9 @@ __global__ __launch_bounds__(64) void k_bal_schur_pairs(BADev P, int first) {
             }
         }
     }
-    const int act = min(cnt, 64);
-    if (t < act) {
-#pragma unroll
-        for (int q = 0; q < 42; q++) red[t * 43 + q] = acc[q];
-    }
-    __syncthreads();
+    block_sum_lds<42, kBigPairThreads>(acc, red, part);
     if (t >= 42) return;
-    double s = 0;
-    for (int j = 0; j < act; j++) s += red[j * 43 + t];
+    const double s = part[t];
     if (t < 36) {
         const int r = t / 6, c = t - r * 6;
         if (!diag) P.big[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = s;        // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
@@ -2186,37 +2181,18 @@ __global__ __launch_bounds__(64) void k_bal_diag0(BADev P) {
     bal_store_diag_wave(P, 0, row, bad);
 }
 
-// one thread per row below the panel's diagonal block (single-wave workgroups: the rows are independent and a wave's
-// speed does not depend on its neighbours, so more, smaller workgroups only spread the rows over more CUs)
-__global__ __launch_bounds__(64) void k_bal_panel(BADev P, int kb) {
-    __shared__ __attribute__((aligned(16))) double a[kBigNB][kBigNB];
-    if (P.ctl[kCtlHalt]) return;
-    const BigGeom g = big_geom(P.nFree);
-    const size_t ld = g.RP;
-    const int k0 = kb * kBigNB, t = threadIdx.x;
-    double* S = P.big;
-    const double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB;
-    for (int idx = t; idx < kBigNB * kBigNB; idx += 64) a[idx >> 5][idx & 31] = Ld[idx];
-    __syncthreads();
-    const int row = k0 + kBigNB + blockIdx.x * 64 + t;
-    if (row > g.N) return;
-    double w[kBigNB];
-    double* src = S + (size_t)row * ld + k0;
-#pragma unroll
-    for (int c = 0; c < kBigNB; c++) w[c] = src[c];
-#pragma unroll
-    for (int c = 1; c < kBigNB; c++) {
-#pragma unroll
-        for (int q = 0; q < c; q++) w[c] = fma(-w[q], a[c][q], w[c]);
-    }
-    double* wd = P.bigW + (size_t)row * kBigNB;
-#pragma unroll
-    for (int c = 0; c < kBigNB; c++) { wd[c] = w[c]; src[c] = w[c] * a[c][c]; }
-}
-
-__global__ __launch_bounds__(256) void k_bal_update(BADev P, int kb) {
+// One launch per 32-column panel: every 64 x 64 tile of the trailing lower triangle first solves the panel rows it needs ITSELF
+// -- 64 rows of its tile row (w = a L_kk^-T, kept as W) and 64 of its tile column (l = w D^-1) on 128 threads, 496 FMAs each on
+// registers against the factored diagonal block in LDS; a row is solved by every tile that uses it, which costs no wall time --
+// then C -= W L^T (4 x 4 outputs per thread from transposed LDS tiles).  The first tile column archives l in `bigL` (the
+// factor proper: the working matrix keeps its stale panel columns, nobody reads them again, so there is no race between a
+// tile that still reads a and one that would overwrite it with l).  The tile that holds the NEXT diagonal block factors it on
+// the spot (one wavefront, see above), so the next launch starts from a finished L_kk.  The first version ran the row solves
+// as a launch of their own: two dependent launches per panel instead of one (12 + 13 us at 40 free keyframes).
+__global__ __launch_bounds__(256) void k_bal_step(BADev P, int kb, int last) {
     __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
+    __shared__ __attribute__((aligned(16))) double a[kBigNB][kBigNB];
     __shared__ double da[kBigNB][kBigNB + 1];
     if (P.ctl[kCtlHalt]) return;
     const BigGeom g = big_geom(P.nFree);
@@ -2227,12 +2203,19 @@ __global__ __launch_bounds__(256) void k_bal_update(BADev P, int kb) {
     if (ti < tj) return;
     const int r0 = ti * 64, c0 = tj * 64;
     double* S = P.big;
-    for (int idx = t; idx < 64 * kBigNB; idx += 256) {
-        const int r = idx >> 5, k = idx & 31;
-        Wt[k][r] = P.bigW[(size_t)(r0 + r) * kBigNB + k];
-        Lt[k][r] = (c0 + r >= k0 + kBigNB) ? S[(size_t)(c0 + r) * ld + k0 + k] : 0.0;    // columns of the panel itself are final
+    // panel rows of this tile: threads 0..63 the tile's rows (W), 64..127 its columns (L)
+    const bool roleW = t < 64;
+    const int prow = roleW ? r0 + t : c0 + (t - 64);
+    const bool act = t < 128 && prow >= k0 + kBigNB && prow <= g.N;      // rows of the panel itself / beyond the system: zero
+    double w[kBigNB];
+    if (act) {
+        const double* src = S + (size_t)prow * ld + k0;
+#pragma unroll
+        for (int c = 0; c < kBigNB; c++) w[c] = src[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < kBigNB; c++) w[c] = 0.0;
     }
-    __syncthreads();
     const int tx = t & 15, ty = t >> 4;
     double c[4][4];
     double* C = S + (size_t)(r0 + ty * 4) * ld + c0 + tx * 4;
@@ -2240,6 +2223,33 @@ __global__ __launch_bounds__(256) void k_bal_update(BADev P, int kb) {
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) c[i][j] = C[(size_t)i * ld + j];
+    {
+        const double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB;
+        for (int idx = t; idx < kBigNB * kBigNB; idx += 256) a[idx >> 5][idx & 31] = Ld[idx];
+    }
+    __syncthreads();
+    if (t < 128) {
+        if (act) {
+#pragma unroll
+            for (int cc = 1; cc < kBigNB; cc++) {
+#pragma unroll
+                for (int q = 0; q < cc; q++) w[cc] = fma(-w[q], a[cc][q], w[cc]);
+            }
+        }
+        if (roleW) {
+#pragma unroll
+            for (int k = 0; k < kBigNB; k++) Wt[k][t] = w[k];
+            if (blockIdx.x == 0 && act) {
+                double* ldst = P.bigL + (size_t)prow * ld + k0;
+#pragma unroll
+                for (int k = 0; k < kBigNB; k++) ldst[k] = w[k] * a[k][k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kBigNB; k++) Lt[k][t - 64] = w[k] * a[k][k];
+        }
+    }
+    __syncthreads();
 #pragma unroll 8
     for (int k = 0; k < kBigNB; k++) {
         double wv[4], lv[4];
@@ -2254,9 +2264,8 @@ __global__ __launch_bounds__(256) void k_bal_update(BADev P, int kb) {
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) C[(size_t)i * ld + j] = c[i][j];
-    // look-ahead: the tile that holds the NEXT panel's diagonal block (the first one dispatched) factors it right away, so
-    // the next panel kernel starts from a finished L_kk instead of every one of its workgroups repeating the 32 steps
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    // look-ahead: the tile that holds the NEXT panel's diagonal block (the first one dispatched) factors it right away
+    if (!last && blockIdx.x == 0 && blockIdx.y == 0) {
         const int o = k0 + kBigNB - c0;            // 0 or 32: offset of the block inside this tile
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -2289,7 +2298,7 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(BADev P, int J, int* solv
     const BigGeom g = big_geom(P.nFree);
     const size_t ld = g.RP;
     const int n = g.n, N = g.N, t = threadIdx.x;
-    double* S = P.big;
+    double* S = P.bigL;            // the archived factor (rows below each panel's diagonal block, z = row N)
     const int J0 = J * kBigSB, w = min(kBigSB, N - J0);
     double* z = S + (size_t)N * ld;
     if (t < w) xl[t] = z[J0 + t];
@@ -2756,7 +2765,11 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     // more free keyframes than the single-workgroup solvers take (or EAO_BA_SOLVER=big, the harness's A/B switch): the
     // map-scale path, dense system in HBM factorised by the whole chip (k_bal_*)
     const char* solverEnv0 = getenv("EAO_BA_SOLVER");
-    const bool bigPath = nFreeIn > kSchurMaxFree || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
+    // (measured, LocalBundleAdjustment wall time, tools/dbg_ba_sizes.py: the LDS / global-scratch single-workgroup solver with
+    //  the slab assembly takes 5.8 ms at 31 free keyframes and 29 ms at 64, the map-scale path 3.6 and 6.9 ms -- so everything
+    //  beyond the register-tile solver goes there; EAO_BA_SOLVER=lds keeps the old path reachable up to 64 for A/B runs)
+    const bool wantLds0 = solverEnv0 && !strcmp(solverEnv0, "lds") && nFreeIn <= kSchurMaxFree;
+    const bool bigPath = (nFreeIn > kTileMaxFree && !wantLds0) || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
     const BigGeom bg = big_geom(std::max(nFreeIn, 1));
     size_t lpEntries = 0, lpPairsMax = 0;
     if (bigPath) {   // sizes of the pair CSR: sum over the points of m (m + 1) / 2, m = observers among the free keyframes
@@ -2773,7 +2786,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
     need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8;
     if (bigPath) {
-        need += ((size_t)bg.RP * bg.RP + (size_t)bg.RP * kBigNB + (size_t)bg.N * kBigNB) * 8;
+        need += (2 * (size_t)bg.RP * bg.RP + (size_t)bg.N * kBigNB) * 8;
         need += (lpEntries + 3 * lpPairsMax + 8) * 4;
     } else {
         need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
@@ -2826,7 +2839,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     D.sys = a.take<double>(bigPath ? 8 : std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
     D.slab = a.take<double>(bigPath ? 8 : (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
     D.big = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
-    D.bigW = a.take<double>(bigPath ? (size_t)bg.RP * kBigNB : 8);
+    D.bigL = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
     D.bigDiag = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
     D.bigFail = a.take<int>(4);
     D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpPts = dlpPts;
@@ -2952,7 +2965,6 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     EAO_HIP(hipEventRecord(c.ev0, s));
     EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(D.nL * D.nFree, nP * 3), nC), E), nPl * 4), 256)), dim3(256), 0, s, D);
-    if (bigPath) EAO_HIP(hipMemsetAsync(D.bigW, 0, (size_t)bg.RP * kBigNB * sizeof(double), s));
     const bool usePairs = pairPath && D.nFree > 0 && D.nL > 0;
     if (usePairs) {
         hipLaunchKernelGGL(k_ba_pairs, dim3(D.nFree * (D.nFree + 1) / 2), dim3(256), 0, s, D);
@@ -3009,13 +3021,12 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         auto enqueue_trial = [&](int bulk, bool firstTrial = false, bool withDecide = true) {
             if (nF && bigPath) {
                 (void)hipMemsetAsync(D.big, 0, (size_t)gB.RP * gB.RP * sizeof(double), s);
-                hipLaunchKernelGGL(k_bal_schur_pairs, dim3(D.nPairsNZ), dim3(64), 0, s, D, firstTrial ? 1 : 0);
+                hipLaunchKernelGGL(k_bal_schur_pairs, dim3(D.nPairsNZ), dim3(kBigPairThreads), 0, s, D, firstTrial ? 1 : 0);
                 const int nbk = gB.N / kBigNB, nT = gB.RP / 64;
                 hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, D);
                 for (int kb = 0; kb < nbk; kb++) {
-                    hipLaunchKernelGGL(k_bal_panel, dim3(eao::cdiv(gB.N - kb * kBigNB - kBigNB + 1, 64)), dim3(64), 0, s, D, kb);
                     const int tj0 = (kb * kBigNB + kBigNB) >> 6;
-                    if (kb + 1 < nbk) hipLaunchKernelGGL(k_bal_update, dim3(nT - tj0, nT - tj0), dim3(256), 0, s, D, kb);
+                    hipLaunchKernelGGL(k_bal_step, dim3(nT - tj0, nT - tj0), dim3(256), 0, s, D, kb, kb + 1 == nbk ? 1 : 0);
                 }
                 for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
                     hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), 0, s, D, J, dsolveOk);
