@@ -371,6 +371,20 @@ def measure_extra(E, synth, torch, dev):
             rg = E.Optimizer.BundleAdjustment(gp, 10, bRobust=False)
         extra["bundle_adjustment"] = {"workload": "BundleAdjustment 11 free + 1 fixed KF x 2000 MP, E=%d, 10 its, no robust kernel" % len(gp["edge_cam"]),
                                       "ms_per_call": round((time.perf_counter() - t0) / 5 * 1e3, 3), "iters": int(rg["iters"][0])}
+        # what Tracking.cc sees through the unchanged call signature: ONE 640x480 frame per ORBextractor::operator() call, host
+        # image in, host keypoints / descriptors out (H2D + the latency-bound kernel chain + D2H)
+        ext1 = E.ORBextractor(1000, 1.2, 8, 20, 7)
+        one = synth.synth_frames(1, seed0=1000)
+        for _ in range(3):
+            ext1.extract_batch(one)
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            k1, _d1 = ext1.extract_batch(one)
+            ts.append(time.perf_counter() - t0)
+        extra["orb_single_frame_host_api"] = {"ms_per_frame": round(min(ts) * 1e3, 4), "keypoints": int(len(k1[0])),
+                                              "note": "eao_orb_extract_batch, batch 1, pageable host buffers in and out (min of 30 calls)"}
+        del ext1
         # map scale: more free keyframes than one workgroup factorises -> dense Schur system in HBM, panel / update LDL^T
         gm = synth.synth_ba(n_free=200, n_fixed=1, n_points=20000, seed=5300)
         E.Optimizer.BundleAdjustment(gm, 10, bRobust=False)
