@@ -741,7 +741,9 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
     __shared__ int wtmp[kQT / 64];
     __shared__ int shv[8];
     const int t = threadIdx.x;
-    const int l = blockIdx.x, f = blockIdx.y + f0;
+    // level-major dispatch (frames fastest): the long level-0 workgroups of EVERY frame start first and the short top levels
+    // fill the gaps behind them -- with the levels of a frame dispatched together the last frames' level 0 was the tail
+    const int l = blockIdx.y, f = blockIdx.x + f0;
     const LevelGeom L = g->L[l];
     int* scanA = reinterpret_cast<int*>(smem + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)));
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
@@ -1518,7 +1520,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             if (early0) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
         }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
-        hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nb), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
+        hipLaunchKernelGGL(k_quadtree, dim3(nb, g.nlevels), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
                            h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg);
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
