@@ -1367,7 +1367,12 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     // candidate keys (4 B) + node indices (2 B) in LDS while two workgroups still fit a CU
     h->quadLds = (h->quadLds + 15) & ~(size_t)15;
     g.qtKeysOff = (int)h->quadLds;
-    static const size_t kQtLdsCand = getenv("EAO_QT_LDS_CAND") ? (size_t)atoi(getenv("EAO_QT_LDS_CAND")) : 8192;
+    // Capacity: about four candidates per requested feature (the 640 x 480 benchmark frames leave ~3100 candidates on level 0
+    // for 1000 features; a level that holds more falls back to the global arrays).  With the level-major dispatch the
+    // smaller footprint pays: three workgroups per CU instead of two -- k_quadtree alone 210 -> 169 us at batch 256 (8192 ->
+    // 4096 candidates; 3200: 143 us, but then the blur beside it is the longer of the two).
+    static const size_t kQtLdsCandEnv = getenv("EAO_QT_LDS_CAND") ? (size_t)atoi(getenv("EAO_QT_LDS_CAND")) : 0;
+    const size_t kQtLdsCand = kQtLdsCandEnv ? kQtLdsCandEnv : std::min<size_t>(8192, std::max<size_t>(2048, ((size_t)h->cfg.nfeatures * 4 + 63) & ~(size_t)63));
     g.qtLdsCand = (int)std::min<size_t>(kQtLdsCand, h->quadLds < 76 * 1024 ? (76 * 1024 - h->quadLds) / 6 : 0) & ~7;
     h->quadLds += (size_t)g.qtLdsCand * 6;
     // the blur kernel hard-codes the taps; make sure the published construction gives them
