@@ -1479,8 +1479,11 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         // Schedule of a (non-profiled) batch -- FAST and the blur are both VALU-bound, the quad-tree leaves the machine
         // almost idle, so the blur runs beside the quad-tree, not beside FAST:
         //   main:  resize 1..n-1 -> FAST(levels >= mid) -> quad-tree -> orientation + description
-        //   side:  FAST(level 0) [-> FAST(levels 1..mid-1) once they exist] -> (all FAST done) blur
-        static const int envMid = getenv("EAO_ORB_MID") ? atoi(getenv("EAO_ORB_MID")) : 0;
+        //   side:  FAST(level 0) -> FAST(levels 1..mid-1) once they exist -> (all FAST done) blur
+        // mid = 3: FAST of levels 1 and 2 joins level 0 on the side stream as soon as they exist, beside the rest of the pyramid
+        // chain, whose small launches leave the machine idle (measured, ms per step, mid 0 / 3: batch 32 0.296 / 0.296, 64
+        // 0.420 / 0.417, 128 0.717 / 0.706, 256 1.339 / 1.314; mid 4 = 1.314, mid 5 = 1.352).  EAO_ORB_MID=0 switches it off.
+        static const int envMid = getenv("EAO_ORB_MID") ? atoi(getenv("EAO_ORB_MID")) : 3;
         const int mid = early0 && envMid >= 2 && envMid < g.nlevels ? envMid : 0;
         // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
