@@ -1483,8 +1483,10 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         // mid = 3: FAST of levels 1 and 2 joins level 0 on the side stream as soon as they exist, beside the rest of the pyramid
         // chain, whose small launches leave the machine idle (measured, ms per step, mid 0 / 3: batch 32 0.296 / 0.296, 64
         // 0.420 / 0.417, 128 0.717 / 0.706, 256 1.339 / 1.314; mid 4 = 1.314, mid 5 = 1.352).  EAO_ORB_MID=0 switches it off.
-        static const int envMid = getenv("EAO_ORB_MID") ? atoi(getenv("EAO_ORB_MID")) : 3;
-        const int mid = early0 && envMid >= 2 && envMid < g.nlevels ? envMid : 0;
+        // A single frame pays for the extra launch and event instead: 0.220 vs 0.211 ms per call -- small batches keep mid = 0.
+        static const int envMid = getenv("EAO_ORB_MID") ? atoi(getenv("EAO_ORB_MID")) : -1;
+        const int wantMid = envMid >= 0 ? envMid : (nb >= 48 ? 3 : 0);
+        const int mid = early0 && wantMid >= 2 && wantMid < g.nlevels ? wantMid : 0;
         // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         if (early0) {
