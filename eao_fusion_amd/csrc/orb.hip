@@ -265,6 +265,10 @@ __device__ __forceinline__ bool fast_quick_pass(const uint8_t* p, int t) {
 //      everywhere else and are appended to a corner list (again order-preserving)
 //   3. 3x3 strict NMS of the listed corners against the score map (blind across the cell seam, like upstream's
 //      per-cell cv::FAST calls); kept corners leave in row-major order through a ballot scan
+// WHOLE = true: the launch covers every cell of the frames (profiled calls, single-level pyramids); false: one share of the
+// overlapped schedule.  Same code -- the parameter only gives the two kinds of launch different names in a rocprofv3 summary,
+// so that the whole-stage duration bench.py reports can be read off the `k_fast_cells<true>` row directly.
+template <bool WHOLE>
 __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, const CellDesc* __restrict__ cells, ImgSrc s,
                                                    unsigned* __restrict__ cellcand, int* __restrict__ cellcnt, int f0, int cellFirst,
                                                    int cellEnd) {
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     // The kernel is VALU/LDS-bound, not fabric-bound, and the XCD-aware orders cost more in load balance (level-0 cells
     // are the heavy ones) than the saved re-fetches return, so the plain order stays the default.  Speed only, never results.
     int cell = blockIdx.x;
-    if (kFastXcdRun > 0) {
+    if constexpr (kFastXcdRun > 0) {
         const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
         cell = ((bslot / kFastXcdRun) * 8 + xcd) * kFastXcdRun + bslot % kFastXcdRun;
     }
@@ -1473,8 +1477,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         const int cells0 = g.L[0].nCells;
         const bool early0 = !prof && g.nlevels > 1 && g.L[0].cellBase == 0 && cells0 < g.totalCells;
         auto fast = [&](hipStream_t str, int first, int end) {
-            hipLaunchKernelGGL(k_fast_cells, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
-                               h->d_cellcand.p, h->d_cellcnt.p, f0, first, end);
+            if (first == 0 && end == g.totalCells)
+                hipLaunchKernelGGL(k_fast_cells<true>, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
+                                   h->d_cellcand.p, h->d_cellcnt.p, f0, first, end);
+            else
+                hipLaunchKernelGGL(k_fast_cells<false>, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
+                                   h->d_cellcand.p, h->d_cellcnt.p, f0, first, end);
         };
         // Schedule of a (non-profiled) batch -- FAST and the blur are both VALU-bound, the quad-tree leaves the machine
         // almost idle, so the blur runs beside the quad-tree, not beside FAST:

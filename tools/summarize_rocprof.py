@@ -7,7 +7,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(k_[A-Za-z0-9_]+)", name)
+    m = re.search(r"(k_[A-Za-z0-9_]+(?:<[A-Za-z0-9_, ]+>)?)", name)
     return m.group(1) if m else name.split("(")[0][-60:]
 
 
