@@ -132,11 +132,12 @@ __device__ __forceinline__ void resize_coef(int d, double inv, int slimit, bool 
 
 __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) {
     const ResizeLevel D = A.D, S = A.S;
+    const int bxi = blockIdx.x;
     const int f = blockIdx.z + f0;
     // work items = (group of kResizeRows output rows) x (4-pixel group), dealt to the lanes in one flat sequence: with a
     // 256-pixel-wide block per row group the levels whose width is just above a multiple of 256 left up to half of the
     // lanes idle (257 px -> two blocks; measured 240 -> 181 us for the seven launches of a 256-frame batch)
-    const int item = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;
+    const int item = bxi * 256 + threadIdx.y * 64 + threadIdx.x;
     const int rg = (int)(((float)item + 0.5f) * A.invG);
     const int dyb = rg * kResizeRows;
     const int dx0 = (item - rg * A.G) * 4;
@@ -271,7 +272,7 @@ __device__ __forceinline__ bool fast_quick_pass(const uint8_t* p, int t) {
 template <bool WHOLE>
 __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, const CellDesc* __restrict__ cells, ImgSrc s,
                                                    unsigned* __restrict__ cellcand, int* __restrict__ cellcnt, int f0, int cellFirst,
-                                                   int cellEnd) {
+                                                   int cellEnd, int frameAffinity) {
     extern __shared__ __align__(16) uint8_t fsm[];
     const int lane = threadIdx.x;
     // Workgroup -> cell placement.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), so with
@@ -279,15 +280,23 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     // on MI355X, 64-frame batch (rocprofv3 --pmc FETCH_SIZE, per launch):   plain        134 MB   0.200 ms
     //    runs of 16 consecutive cells per XCD in rotation (kFastXcdRun = 16)               39 MB   0.228 ms
     //    one contiguous eighth of the cell table per XCD                                   30 MB   0.248 ms
-    // The kernel is VALU/LDS-bound, not fabric-bound, and the XCD-aware orders cost more in load balance (level-0 cells
-    // are the heavy ones) than the saved re-fetches return, so the plain order stays the default.  Speed only, never results.
-    int cell = blockIdx.x;
+    // The kernel is VALU/LDS-bound, not fabric-bound, and those cell orders cost more in load balance (level-0 cells are the
+    // heavy ones) than the saved re-fetches return.  What does pay is FRAME affinity (below): frame f is served by XCD f % 8
+    // only, every XCD walks its frames' cells in table order, so a cache line is fetched into one L2 and the load stays
+    // balanced by construction -- 256-frame batch: FAST alone 0.540 -> 0.532 ms, the scheduled step 1.338 -> 1.301 ms (the
+    // resize running beside FAST gets the fabric).  Speed only, never results.  EAO_FAST_AFFINITY=0 switches it off.
+    int cell = blockIdx.x, fy = blockIdx.y;
     if constexpr (kFastXcdRun > 0) {
         const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
         cell = ((bslot / kFastXcdRun) * 8 + xcd) * kFastXcdRun + bslot % kFastXcdRun;
     }
+    if (frameAffinity) {   // frame f on XCD f % 8 (batches that are a multiple of 8): all cells of a frame share one L2
+        const unsigned b = blockIdx.x + gridDim.x * blockIdx.y, xcd = b & 7, slot = b >> 3;
+        fy = (int)(xcd + 8 * (slot / gridDim.x));
+        cell = (int)(slot % gridDim.x);
+    }
     cell += cellFirst;                                  // the launch covers cells [cellFirst, cellEnd)
-    const int f = blockIdx.y + f0;
+    const int f = fy + f0;
     if (cell >= cellEnd) return;
     const CellDesc c = cells[cell];
     const int maxT = g->fastMaxTested;                 // max tested pixels of any cell
@@ -904,13 +913,16 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
 }
 
 __global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur, int f0, int src0Aligned) {
+    // (frame -> XCD affinity as in k_fast_cells was measured here and in k_resize: 0.152 vs 0.149 ms and 0.199 vs 0.194 ms at
+    //  batch 256 -- neither kernel re-reads enough across workgroups for it to matter; plain order kept)
     const int lane = threadIdx.x & 31, f = blockIdx.y + f0;
+    const int bxi = blockIdx.x;
     int l = 0;
-    while (l + 1 < g->nlevels && (int)blockIdx.x >= g->L[l + 1].tileBase) l++;
+    while (l + 1 < g->nlevels && bxi >= g->L[l + 1].tileBase) l++;
     // (upstream blurs only levels that hold keypoints, :1081-1082; blurring all of them changes no output and removes
     //  the dependency on the quad-tree, so this kernel can overlap it)
     const LevelGeom L = g->L[l];
-    const int strip = ((int)blockIdx.x - L.tileBase) * kBlurStripsPerWg + (int)(threadIdx.x >> 5);
+    const int strip = (bxi - L.tileBase) * kBlurStripsPerWg + (int)(threadIdx.x >> 5);
     const int x4 = (strip % L.tilesX) * kBlurSegW + lane * 4;
     const int y0 = (strip / L.tilesX) * kBlurRows;
     if (x4 >= L.w || y0 >= L.h) return;
@@ -1477,12 +1489,14 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         const int cells0 = g.L[0].nCells;
         const bool early0 = !prof && g.nlevels > 1 && g.L[0].cellBase == 0 && cells0 < g.totalCells;
         auto fast = [&](hipStream_t str, int first, int end) {
+            static const int envAff = getenv("EAO_FAST_AFFINITY") ? atoi(getenv("EAO_FAST_AFFINITY")) : 1;
+            const int aff = envAff && (nb & 7) == 0 ? 1 : 0;
             if (first == 0 && end == g.totalCells)
                 hipLaunchKernelGGL(k_fast_cells<true>, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
-                                   h->d_cellcand.p, h->d_cellcnt.p, f0, first, end);
+                                   h->d_cellcand.p, h->d_cellcnt.p, f0, first, end, aff);
             else
                 hipLaunchKernelGGL(k_fast_cells<false>, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
-                                   h->d_cellcand.p, h->d_cellcnt.p, f0, first, end);
+                                   h->d_cellcand.p, h->d_cellcnt.p, f0, first, end, aff);
         };
         // Schedule of a (non-profiled) batch -- FAST and the blur are both VALU-bound, the quad-tree leaves the machine
         // almost idle, so the blur runs beside the quad-tree, not beside FAST:
