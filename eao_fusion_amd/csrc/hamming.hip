@@ -48,6 +48,40 @@ __global__ __launch_bounds__(128) void k_hamming_matrix(const uint4* __restrict_
     }
 }
 
+// Eight B descriptors per lane (64 VGPRs) and ONE 16-byte store per row and lane: a wave writes 1 KB per store instruction
+// instead of 256 B -- the matrix is write-bound, and the wider stores are what the memory system wants (1000 x 1000 x 64
+// pairs: 52 -> 47 us, 2.5 -> 2.8 TB/s; the 16 v_xor / v_bcnt per distance are then about as long as the writes).  Needs nb % 8 == 0 and a 16-byte aligned D; everything else takes k_hamming_matrix.
+constexpr int kRowsPerBlock8 = 16;
+__global__ __launch_bounds__(128) void k_hamming_matrix8(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,
+                                                         unsigned short* __restrict__ D) {
+    __shared__ uint4 sa[kRowsPerBlock8 * 2];
+    const int pair = blockIdx.z;
+    A += (long long)pair * na * 2;
+    B += (long long)pair * nb * 2;
+    D += (long long)pair * na * nb;
+    const int i0 = blockIdx.y * kRowsPerBlock8;
+    const int j0 = (blockIdx.x * 128 + threadIdx.x) * 8;
+    if (threadIdx.x < kRowsPerBlock8 * 2) {
+        const int r = i0 + (threadIdx.x >> 1);
+        sa[threadIdx.x] = r < na ? A[(long long)r * 2 + (threadIdx.x & 1)] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (j0 >= nb) return;
+    uint4 b[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = B[(long long)j0 * 2 + k];
+    const int rows = min(kRowsPerBlock8, na - i0);
+    for (int r = 0; r < rows; r++) {
+        const uint4 a0 = sa[2 * r], a1 = sa[2 * r + 1];
+        unsigned d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = dist8(a0, a1, b[2 * k], b[2 * k + 1]);
+        uint4 o;
+        o.x = d[0] | (d[1] << 16); o.y = d[2] | (d[3] << 16); o.z = d[4] | (d[5] << 16); o.w = d[6] | (d[7] << 16);
+        *reinterpret_cast<uint4*>(D + (long long)(i0 + r) * nb + j0) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_hamming_best2(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,
                                                        const uint8_t* __restrict__ mask, eao_best2* __restrict__ out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -160,8 +194,13 @@ eao_status eao_hamming_matrix_device(const uint8_t* d_A, int32_t na, const uint8
     EAO_REQUIRE(((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_B & 15) == 0 && ((uintptr_t)d_D & 3) == 0, "descriptor arrays must be 16-byte aligned");
     eao_status st = eao::require_device();
     if (st) return st;
-    dim3 grid(eao::cdiv(nb, 256), eao::cdiv(na, kRowsPerBlock), pairs);
-    hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(128), 0, (hipStream_t)stream, (const uint4*)d_A, na, (const uint4*)d_B, nb, d_D);
+    if ((nb & 7) == 0 && ((uintptr_t)d_D & 15) == 0 && !getenv("EAO_HAMMING_NARROW")) {
+        dim3 grid8(eao::cdiv(nb, 1024), eao::cdiv(na, kRowsPerBlock8), pairs);
+        hipLaunchKernelGGL(k_hamming_matrix8, grid8, dim3(128), 0, (hipStream_t)stream, (const uint4*)d_A, na, (const uint4*)d_B, nb, d_D);
+    } else {
+        dim3 grid(eao::cdiv(nb, 256), eao::cdiv(na, kRowsPerBlock), pairs);
+        hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(128), 0, (hipStream_t)stream, (const uint4*)d_A, na, (const uint4*)d_B, nb, d_D);
+    }
     EAO_HIP(hipGetLastError());
     return EAO_OK;
 }
