@@ -118,6 +118,60 @@ __global__ __launch_bounds__(256) void k_hamming_best2(const uint4* __restrict__
     }
 }
 
+// The same result for SIXTEEN A rows per wavefront (no mask): a lane loads each of its B descriptors once and tests it
+// against the sixteen rows (LDS broadcast reads), keeping sixteen lane-local (best, second) pairs in registers.  One row per
+// wave made every wave pull all of B through L1 / L2 -- 32 bytes per distance, 2 GB per 1000 x 1000 x 64 launch; this is 2 bytes.
+constexpr int kB2Rows = 16;
+__global__ __launch_bounds__(256) void k_hamming_best2_rows(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,
+                                                            eao_best2* __restrict__ out) {
+    __shared__ uint4 sa[4][kB2Rows * 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pair = blockIdx.y;
+    const int i0 = (blockIdx.x * 4 + wv) * kB2Rows;
+    if (i0 >= na) return;
+    A += (long long)pair * na * 2;
+    B += (long long)pair * nb * 2;
+    if (lane < kB2Rows * 2) {
+        const int r = i0 + (lane >> 1);
+        sa[wv][lane] = r < na ? A[(long long)r * 2 + (lane & 1)] : make_uint4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned none = (256u << 20) | 0xFFFFFu;
+    unsigned k1[kB2Rows], k2[kB2Rows];
+#pragma unroll
+    for (int r = 0; r < kB2Rows; r++) { k1[r] = none; k2[r] = none; }
+    for (int j = lane; j < nb; j += 64) {
+        const uint4 b0 = B[(long long)j * 2], b1 = B[(long long)j * 2 + 1];
+#pragma unroll
+        for (int r = 0; r < kB2Rows; r++) {
+            const unsigned d = dist8(sa[wv][2 * r], sa[wv][2 * r + 1], b0, b1);
+            const unsigned key = (d << 20) | (unsigned)j;
+            const unsigned lo = min(key, k1[r]);
+            k2[r] = min(max(key, k1[r]), k2[r]);
+            k1[r] = lo;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kB2Rows; r++) {
+        unsigned a1 = k1[r], a2 = k2[r];
+#pragma unroll
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            const unsigned o1 = __shfl_xor(a1, dlt), o2 = __shfl_xor(a2, dlt);
+            const unsigned n1 = min(a1, o1);
+            const unsigned n2 = min(max(a1, o1), min(a2, o2));
+            a1 = n1; a2 = n2;
+        }
+        if (lane == r && i0 + r < na) {
+            eao_best2 res;
+            res.best = (int)(a1 >> 20);
+            res.second = (int)(a2 >> 20);
+            res.idx = a1 == none ? -1 : (int)(a1 & 0xFFFFF);
+            res.idx2 = a2 == none ? -1 : (int)(a2 & 0xFFFFF);
+            out[(long long)pair * na + i0 + r] = res;
+        }
+    }
+}
+
 struct Scratch {
     eao::DevBuf<uint8_t> a, b, mask;
     eao::DevBuf<unsigned short> d;
@@ -212,8 +266,12 @@ eao_status eao_hamming_best2_device(const uint8_t* d_A, int32_t na, const uint8_
     EAO_REQUIRE(((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_B & 15) == 0, "descriptor arrays must be 16-byte aligned");
     eao_status st = eao::require_device();
     if (st) return st;
-    hipLaunchKernelGGL(k_hamming_best2, dim3(eao::cdiv(na, 4), pairs), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_A, na,
-                       (const uint4*)d_B, nb, d_mask, d_out);
+    if (!d_mask && na >= 256 && !getenv("EAO_HAMMING_NARROW"))     // (few rows: one row per wave fills the chip better)
+        hipLaunchKernelGGL(k_hamming_best2_rows, dim3(eao::cdiv(na, 4 * kB2Rows), pairs), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_A, na,
+                           (const uint4*)d_B, nb, d_out);
+    else
+        hipLaunchKernelGGL(k_hamming_best2, dim3(eao::cdiv(na, 4), pairs), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_A, na,
+                           (const uint4*)d_B, nb, d_mask, d_out);
     EAO_HIP(hipGetLastError());
     return EAO_OK;
 }

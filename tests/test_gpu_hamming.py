@@ -14,7 +14,7 @@ def gpu():
     return E
 
 
-@pytest.mark.parametrize("na,nb", [(1000, 1000), (1, 1), (37, 129), (64, 255), (513, 2)])
+@pytest.mark.parametrize("na,nb", [(1000, 1000), (1, 1), (37, 129), (64, 255), (513, 2), (33, 1024), (17, 8), (250, 1008)])
 def test_matrix_bit_exact(gpu, oracle, na, nb):
     rng = np.random.default_rng(na * 7 + nb)
     A = rng.integers(0, 256, (na, 32), dtype=np.uint8)
@@ -32,6 +32,18 @@ def test_best2_bit_exact_with_ties_and_mask(gpu, oracle):
     mask = (rng.random((300, 1000)) < 0.05).astype(np.uint8)
     mask[5] = 0                                   # a row without candidates
     assert np.array_equal(gpu.hamming_best2(a[:300], b, mask), oracle.hamming_best2(a[:300], b, mask))
+
+
+@pytest.mark.parametrize("na,nb", [(256, 1), (257, 63), (1000, 1000), (271, 130), (4096, 70)])
+def test_best2_sixteen_rows_per_wave(gpu, oracle, na, nb):
+    """From 256 unmasked rows on, a wavefront takes sixteen A rows at once (k_hamming_best2_rows): ragged last groups, fewer
+    than two candidates, heavy ties (B drawn from 5 distinct descriptors: the first column must win)."""
+    rng = np.random.default_rng(na * 13 + nb)
+    A = rng.integers(0, 256, (na, 32), dtype=np.uint8)
+    B = rng.integers(0, 256, (5, 32), dtype=np.uint8)[rng.integers(0, 5, nb)]
+    assert np.array_equal(gpu.hamming_best2(A, B), oracle.hamming_best2(A, B))
+    B2 = rng.integers(0, 256, (nb, 32), dtype=np.uint8)
+    assert np.array_equal(gpu.hamming_best2(A, B2), oracle.hamming_best2(A, B2))
 
 
 def test_descriptor_distance_known_answers(gpu):

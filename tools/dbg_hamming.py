@@ -21,3 +21,14 @@ print("matrix: %.4f ms per launch, %.0f GB/s (%.1f %% of 8 TB/s)" % (ms, pairs *
 ref = ((dA[0, :8].cpu().numpy()[:, None, :] ^ dB[0].cpu().numpy()[None, :, :]))
 ref = np.unpackbits(ref, axis=2).sum(2)
 assert np.array_equal(ref, dD[0, :8].cpu().numpy()), "mismatch"
+
+import ctypes as C
+dO = torch.empty((pairs, 1000, 4), dtype=torch.int32, device="cuda")
+def run2(): E._lib.check(L.eao_hamming_best2_device(dA.data_ptr(), 1000, dB.data_ptr(), 1000, pairs, None, dO.data_ptr(), st))
+for _ in range(5): run2()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(50): run2()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 50
+print("best2: %.4f ms per launch, %.0f G distances/s" % (ms, pairs * 1e6 / ms / 1e6))
