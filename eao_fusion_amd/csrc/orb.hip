@@ -986,7 +986,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
                                                          const unsigned* __restrict__ levelkps, const int* __restrict__ levelcnt,
                                                          eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                          int* __restrict__ nout, int cap, int f0, int nlevels) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the compiler then KNOWS that the keypoint -- index, key, position, level --
+    //  is wave-uniform, keeps it in SGPRs, loads it with scalar loads and addresses the two windows as SGPR base + 32-bit
+    //  lane offset instead of per-lane 64-bit pointer arithmetic)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the lane's four test pairs (xa, ya, xb, yb as int8) depend on nothing: fetch them first, under the other loads
     unsigned pat[4];
 #pragma unroll
@@ -1012,12 +1015,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
         const int o = __shfl_up(incl, dlt);
         if (lane >= dlt) incl += o;
     }
-    const int total = __shfl(incl, kMaxLevels - 1);
+    const int total = __builtin_amdgcn_readlane(incl, kMaxLevels - 1);
     const unsigned long long below = __ballot(lane < nlevels && incl <= j);   // levels that end at or before j
     const int l = __popcll(below);
     if (bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
     if (l >= nlevels || jout >= cap) return;
-    j -= l ? __shfl(incl, l - 1) : 0;
+    j -= l ? __builtin_amdgcn_readlane(incl, l - 1) : 0;
     const LevelGeom L = g->L[l];
     const unsigned key = levelkps[(long long)f * g->totalKpCap + L.kpBase + j];
     const int cx = (int)(key & 0xFFF) + kMinBorder, cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
@@ -1034,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const int i = min(lane + 64 * k, (2 * kPR + 1) * kPW - 1), r = (i * 6554) >> 16;   // i / 10
-        pw[k] = *reinterpret_cast<const unsigned*>(bw + r * L.pitch + 4 * (i - r * kPW));
+        pw[k] = *reinterpret_cast<const unsigned*>(bw + (unsigned)(r * L.pitch + 4 * (i - r * kPW)));
     }
     // the 31 x 31 window of the (unblurred) level for the intensity centroid goes through LDS the same way: 5 aligned word
     // loads per lane instead of 16 byte loads
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int i = min(lane + 64 * k, (2 * kMR + 1) * kMW - 1), r = (i * 7282) >> 16;   // i / 9
-            mv[k] = *reinterpret_cast<const unsigned*>(mw + r * pitch + 4 * (i - r * kMW));
+            mv[k] = *reinterpret_cast<const unsigned*>(mw + (unsigned)(r * pitch + 4 * (i - r * kMW)));
         }
 #pragma unroll
         for (int k = 0; k < 5; k++)
@@ -1074,11 +1077,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
         for (int k = 0; k < 16; k++) {
             const int v = half ? k + 1 : k - 15;
             const int um = half ? kUmax[k + 1] : kUmax[15 - k];
-            if (au <= um) {
-                const int val = c0[v * (4 * kMW)];
-                m10 += u * val;
-                m01 += v * val;
-            }
+            // (branch-free: the window holds every (u, v) with |u|, |v| <= 15, pixels outside the disc count as zero)
+            const int val = au <= um ? (int)c0[v * (4 * kMW)] : 0;
+            m10 += u * val;
+            m01 += v * val;
         }
     }
 #pragma unroll
