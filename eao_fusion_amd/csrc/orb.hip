@@ -171,11 +171,10 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
             resize_coef(min(dyb + r, D.h - 1), A.invY, S.h, false, &yo, &yw);
             B0[r] = yw << 16; B1[r] = yw & 0xFFFF0000u;   // beta << 16
             const int sy0 = min(max(yo, 0), S.h - 1), sy1 = min(max(yo + 1, 0), S.h - 1);
-            const uint8_t* r0 = src + __umul24(sy0, spitch);
-            const uint8_t* r1 = src + __umul24(sy1, spitch);
-            raw[r][0] = *reinterpret_cast<const unsigned*>(r0 + i0); raw[r][1] = *reinterpret_cast<const unsigned*>(r0 + i1);
-            raw[r][2] = *reinterpret_cast<const unsigned*>(r0 + i2); raw[r][3] = *reinterpret_cast<const unsigned*>(r1 + i0);
-            raw[r][4] = *reinterpret_cast<const unsigned*>(r1 + i1); raw[r][5] = *reinterpret_cast<const unsigned*>(r1 + i2);
+            const unsigned r0 = __umul24(sy0, spitch), r1 = __umul24(sy1, spitch);   // 32-bit lane offsets from the wave-uniform base
+            raw[r][0] = *reinterpret_cast<const unsigned*>(src + (r0 + i0)); raw[r][1] = *reinterpret_cast<const unsigned*>(src + (r0 + i1));
+            raw[r][2] = *reinterpret_cast<const unsigned*>(src + (r0 + i2)); raw[r][3] = *reinterpret_cast<const unsigned*>(src + (r1 + i0));
+            raw[r][4] = *reinterpret_cast<const unsigned*>(src + (r1 + i1)); raw[r][5] = *reinterpret_cast<const unsigned*>(src + (r1 + i2));
         }
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
                 packed |= min(v, 255u) << (8 * i);
             }
             // (the level's pitch is a multiple of 64: the tail of the last word lands in padding)
-            *reinterpret_cast<unsigned*>(dst + __umul24(dy, D.pitch) + dx0) = packed;
+            *reinterpret_cast<unsigned*>(dst + (unsigned)(__umul24(dy, D.pitch) + dx0)) = packed;
         }
     } else {
         const int nvalid = min(4, D.w - dx0);
@@ -829,12 +828,14 @@ __device__ __forceinline__ BlurEdge blur_edge(int x4, int w) {
 
 // MODE 0: interior wave (every lane's window is inside the row); 1: wave touching a border; 2: byte-wise loads
 template <int MODE>
-__device__ __forceinline__ void blur_load(const uint8_t* __restrict__ row, int x4, int w, const BlurEdge& e, unsigned L[3]) {
+__device__ __forceinline__ void blur_load(const uint8_t* __restrict__ base, unsigned rowOff, int x4, int w, const BlurEdge& e, unsigned L[3]) {
+    // (base is wave-uniform, the row and column enter as ONE 32-bit lane offset: SGPR-base addressing, no 64-bit VALU adds)
+    const uint8_t* row = base + rowOff;
     if (MODE == 0) {
-        const unsigned* q = reinterpret_cast<const unsigned*>(row + x4 - 4);
+        const unsigned* q = reinterpret_cast<const unsigned*>(base + (rowOff + (unsigned)(x4 - 4)));
         L[0] = q[0]; L[1] = q[1]; L[2] = q[2];
     } else if (MODE == 1) {
-        const unsigned* q = reinterpret_cast<const unsigned*>(row + e.off0);
+        const unsigned* q = reinterpret_cast<const unsigned*>(base + (rowOff + (unsigned)e.off0));
         L[0] = q[0]; L[1] = q[1]; L[2] = q[2];
     } else {
         L[0] = L[1] = L[2] = 0;
@@ -875,7 +876,7 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
             int t = y0 - 3 + 2 * m + q;
             t = t < 0 ? -t : t;
             t = min(t, 2 * h - 2 - t);
-            blur_load<MODE>(src + __umul24(t, pitch), x4, w, e, raw[m][q]);
+            blur_load<MODE>(src, __umul24(t, pitch), x4, w, e, raw[m][q]);
         }
     };
 #pragma unroll
@@ -906,7 +907,7 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
                 const unsigned packed = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, pb), __builtin_bit_cast(unsigned, pa), 0x06040200u);
                 const int y = y0 + 2 * (m - 3) + q;
                 // (pitch is a multiple of 64 and the level holds a multiple of kBlurRows rows: tails land in padding)
-                *reinterpret_cast<unsigned*>(dst + __umul24(y, dpitch) + x4) = packed;
+                *reinterpret_cast<unsigned*>(dst + (unsigned)(__umul24(y, dpitch) + x4)) = packed;
             }
         }
     }
