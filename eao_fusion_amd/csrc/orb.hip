@@ -315,15 +315,23 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     // i / d for 0 <= i < 8192, 1 <= d <= 80 without an integer divide: (i + 0.5) / d is at least 0.5/80 away from an
     // integer, the float product is off by < 1e-4, so truncation is exact
 #define QDIV(i, inv) ((int)(((float)(i) + 0.5f) * (inv)))
-    const float invTw = 1.0f / (float)tw, invSw = 1.0f / (float)sw;
+    // (v_rcp_f32 is good to 1 ulp, far inside the 1e-4 the truncation argument needs; an IEEE division costs ten instructions)
+    const float invTw = __builtin_amdgcn_rcpf((float)tw), invSw = __builtin_amdgcn_rcpf((float)sw);
     const int x0a = c.x0 & ~3, ph = c.x0 - x0a;
     if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
         const int nw = (c.x0 + sw + 3 - x0a) >> 2;   // words per row
-        const float invNw = 1.0f / (float)nw;
+        const float invNw = __builtin_amdgcn_rcpf((float)nw);
+        // the lane's words are 64 apart in the row-major word sequence of the tile: (row, word) advance by (64 / nw, 64 % nw)
+        // with a carry, so one division per lane serves the whole loop and the addresses are running 32-bit offsets
+        int y = QDIV(lane, invNw), xw = lane - y * nw;
+        const int q = QDIV(64, invNw), rem = 64 - q * nw;
+        unsigned goff = (unsigned)((c.y0 + y) * pitch + x0a + 4 * xw), loff = (unsigned)(y * kTileStride + 4 * xw);
+        const unsigned gstep = (unsigned)(q * pitch + 4 * rem), lstep = (unsigned)(q * kTileStride + 4 * rem);
+        const unsigned gwrap = (unsigned)(pitch - 4 * nw), lwrap = (unsigned)(kTileStride - 4 * nw);
         for (int i = lane; i < nw * sh; i += 64) {
-            const int y = QDIV(i, invNw), xw = i - y * nw;
-            *reinterpret_cast<unsigned*>(&tile[y * kTileStride + 4 * xw]) =
-                *reinterpret_cast<const unsigned*>(src + (long long)(c.y0 + y) * pitch + x0a + 4 * xw);
+            *reinterpret_cast<unsigned*>(&tile[loff]) = *reinterpret_cast<const unsigned*>(src + goff);
+            xw += rem; goff += gstep; loff += lstep;
+            if (xw >= nw) { xw -= nw; goff += gwrap; loff += lwrap; }
         }
     } else {
         for (int i = lane; i < sw * sh; i += 64) {
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
         {
             typedef short s16x2 __attribute__((ext_vector_type(2)));
             const int G = (tw + 3) >> 2, items = G * th_;
-            const float invG = 1.0f / (float)G;
+            const float invG = __builtin_amdgcn_rcpf((float)G);
             const int a0 = 3 + ph;                       // byte offset of the first centre pixel inside its 16-byte window
             const int shC = a0 & 3, wC = a0 >> 2;        // centre / up / down: words wC, wC+1 shifted by shC
             const int shR = (a0 + 3) & 3, wR = (a0 + 3) >> 2;
