@@ -943,6 +943,18 @@ __global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSr
     else blur_strip<0>(src, pitch, dst, L.pitch, x4, y0, L.w, L.h);
 }
 
+// Sum over the 64 lanes on the VALU (DPP: two quad permutes, half-row and row mirrors, then the row broadcasts 15 / 31), the
+// total read from lane 63 into an SGPR: six v_add with DPP + one v_readlane instead of six ds_bpermute round trips.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: every lane of a row holds the row sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // ---------------------------------------------------------------------------------------------- orientation + rBRIEF
 // sin/cos of a float angle in [0, 2*pi], evaluated in double (Cody-Waite reduction by pi/2 + the classic
 // minimax kernels) and rounded to float: plain +,-,* only, so results do not depend on a device libm.
@@ -1015,21 +1027,18 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     int j = bx * 4 + wv;   // compact output index inside the frame
     const int jout = j;
     const int f = fy + f0;
-    // level of compact index j: lane q holds the count of level q (one vector load instead of nlevels dependent scalar
-    // loads), an inclusive wave scan gives the level boundaries
-    const int myc = lane < nlevels ? levelcnt[f * nlevels + lane] : 0;
-    int incl = myc;
+    // level of compact index j: the level counts are wave-uniform -- independent scalar loads and a running sum on the
+    // scalar unit (the first version scanned them across lanes: four ds_bpermute round trips before anything else could start)
+    int total = 0, l = 0, lbase = 0;
 #pragma unroll
-    for (int dlt = 1; dlt < kMaxLevels; dlt <<= 1) {
-        const int o = __shfl_up(incl, dlt);
-        if (lane >= dlt) incl += o;
+    for (int q = 0; q < kMaxLevels; q++) {
+        const int cq = q < nlevels ? levelcnt[f * nlevels + q] : 0;
+        total += cq;
+        if (q < nlevels && total <= j) { l = q + 1; lbase = total; }   // levels that end at or before j
     }
-    const int total = __builtin_amdgcn_readlane(incl, kMaxLevels - 1);
-    const unsigned long long below = __ballot(lane < nlevels && incl <= j);   // levels that end at or before j
-    const int l = __popcll(below);
     if (bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
     if (l >= nlevels || jout >= cap) return;
-    j -= l ? __builtin_amdgcn_readlane(incl, l - 1) : 0;
+    j -= lbase;
     const LevelGeom L = g->L[l];
     const unsigned key = levelkps[(long long)f * g->totalKpCap + L.kpBase + j];
     const int cx = (int)(key & 0xFFF) + kMinBorder, cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
@@ -1092,11 +1101,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
             m01 += v * val;
         }
     }
-#pragma unroll
-    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-        m10 += __shfl_xor(m10, dlt);
-        m01 += __shfl_xor(m01, dlt);
-    }
+    m10 = wave_sum_i32(m10);
+    m01 = wave_sum_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // steered BRIEF on the blurred level
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
