@@ -381,7 +381,7 @@ eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, e
  * cam_fixed = (mnId == 0), points in ascending mnId, points without an edge simply stay where they are),
  * ONE optimize(p->its_first) call (its_second is ignored), Huber kernels (delta sqrt(5.99) / sqrt(7.815), :94-95) only
  * when robust != 0, no outlier pass: r->edge_outlier may be NULL and comes back all zero, r->iters[1] = 0.
- * Up to 64 free keyframes run on the single-workgroup solvers of eao_local_ba; beyond that (whole maps after a loop
+ * Up to 30 free keyframes run on the register-tile solver of eao_local_ba; beyond that (whole maps after a loop
  * closure, up to 2048 free keyframes) the reduced camera system is a dense lower triangle in HBM factorised by the whole
  * chip (csrc/lm.hip, k_bal_*); oversized windows of eao_local_ba take the same path. */
 eao_status eao_bundle_adjustment(const eao_ba_problem* p, int32_t robust, const volatile uint8_t* stop, eao_ba_result* r);
