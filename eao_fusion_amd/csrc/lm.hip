@@ -2876,6 +2876,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     unsigned char* outCls = (unsigned char*)(outPlanes + (size_t)nPl * 4);
     auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
     int seq = c.status->seq;
+    size_t offSplit = off0;
     {
         std::memcpy(hostp(dobs), p->edge_obs, (size_t)Ept * 12);
         std::memcpy(hostp(dinfo), p->edge_inv_sigma2, (size_t)Ept * 4);
@@ -2900,6 +2901,11 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         for (int e = 0; e < Ept; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | (robust ? 4 : 0));
         for (int e = Ept; e < E; e++) hf[e] = 8 | 4;      // EdgePlane: always a Huber kernel (:246-248)
         std::memset(hostp(dctl), 0, 16 * sizeof(int));
+        // The problem itself (observations, indices, initial state, flags) is on its way to the device while the host builds
+        // the active structure below; the structure follows in a second copy.
+        offSplit = (size_t)((unsigned char*)dcamIdx - a.base) & ~(size_t)255;
+        EAO_HIP(hipEventRecord(c.ev0, s));
+        EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, offSplit - off0, hipMemcpyHostToDevice, s));
         // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
         int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
         int* actCam = (int*)hostp(dactCam); int* actPt = (int*)hostp(dactPt);
@@ -2962,8 +2968,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
             D.nPairsNZ = nz;
         }
     }
-    EAO_HIP(hipEventRecord(c.ev0, s));
-    EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, s));
+    EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(D.nL * D.nFree, nP * 3), nC), E), nPl * 4), 256)), dim3(256), 0, s, D);
     const bool usePairs = pairPath && D.nFree > 0 && D.nL > 0;
     if (usePairs) {
