@@ -82,6 +82,21 @@ def test_local_ba_rejected_trials(gpu, oracle, seed):
     assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
 
 
+@pytest.mark.parametrize("seed", [3030, 3034, 3043, 3051])
+def test_rejected_trials_on_the_map_scale_path(gpu, oracle, seed, monkeypatch):
+    """The same far-off windows through the map-scale kernels (EAO_BA_SOLVER=big): rejected trials freeze the stream, the
+    host replays them one by one with the dense factorisation, a failed / empty second pass is reported like g2o's."""
+    monkeypatch.setenv("EAO_BA_SOLVER", "big")
+    p = synth.synth_ba(n_free=5, n_fixed=2, n_points=200, seed=seed, rot_noise_deg=25, trans_noise=0.8, point_noise=1.0, mono_frac=0.7)
+    r = gpu.Optimizer.LocalBundleAdjustment(p)
+    o = oracle.local_ba(p)
+    assert list(r["iters"]) == list(o["iters"])
+    _check_trace(r, o, rel=1e-4)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
+
+
 def test_local_ba_abort_flag(gpu):
     p = synth.synth_ba(n_free=5, n_fixed=2, n_points=200)
     r = gpu.Optimizer.LocalBundleAdjustment(p, stop=np.array([1], np.uint8))
