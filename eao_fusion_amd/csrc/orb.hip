@@ -756,14 +756,14 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
 __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
                                                   const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
                                                   unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
-                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0, long long* dbg) {
+                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0, long long* dbg, int l0) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int wtmp[kQT / 64];
     __shared__ int shv[8];
     const int t = threadIdx.x;
     // level-major dispatch (frames fastest): the long level-0 workgroups of EVERY frame start first and the short top levels
     // fill the gaps behind them -- with the levels of a frame dispatched together the last frames' level 0 was the tail
-    const int l = blockIdx.y, f = blockIdx.x + f0;
+    const int l = blockIdx.y + l0, f = blockIdx.x + f0;   // the launch covers levels l0 .. l0 + gridDim.y - 1
     const LevelGeom L = g->L[l];
     int* scanA = reinterpret_cast<int*>(smem + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)));
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
@@ -1526,6 +1526,8 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         static const int envMid = getenv("EAO_ORB_MID") ? atoi(getenv("EAO_ORB_MID")) : -1;
         const int wantMid = envMid >= 0 ? envMid : (nb >= 48 ? 3 : 0);
         const int mid = early0 && wantMid >= 2 && wantMid < g.nlevels ? wantMid : 0;
+        static const int envQtEarly = getenv("EAO_ORB_QT_EARLY") ? atoi(getenv("EAO_ORB_QT_EARLY")) : 0;
+        const bool qtEarly = mid > 0 && envQtEarly != 0;
         // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         if (early0) {
@@ -1546,9 +1548,14 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 EAO_HIP(hipEventRecord(h->evMid[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evMid[i], 0));
                 fast(ss, cells0, g.L[mid].cellBase);
+                // EAO_ORB_QT_EARLY=1: their quad-trees right behind, beside the main stream's FAST of the upper levels instead of
+                // beside the blur afterwards.  Measured and NOT kept: 1.258 vs 1.226 ms per step -- the quad-tree workgroups'
+                // 42 KB of LDS each take the occupancy FAST needs.
+                if (qtEarly) hipLaunchKernelGGL(k_quadtree, dim3(nb, mid), dim3(kQT), h->quadLds, ss, h->d_geom.p, h->d_cellcand.p,
+                                   h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, 0);
             }
         }
-        if (early0) EAO_HIP(hipEventRecord(h->evFast0[i], ss));   // the side stream's share of FAST
+        if (early0) EAO_HIP(hipEventRecord(h->evFast0[i], ss));   // the side stream's share of FAST (and of the quad-trees)
         if (pe) EAO_HIP(hipEventRecord(ev[1], ms));
         if (prof) {   // profiled calls: every stage alone -- blur, then FAST
             EAO_HIP(hipEventRecord(h->evFork[i], ms));
@@ -1566,11 +1573,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
             hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
-            if (early0) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
+            if (early0 && !qtEarly) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
         }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
-        hipLaunchKernelGGL(k_quadtree, dim3(nb, g.nlevels), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
-                           h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg);
+        hipLaunchKernelGGL(k_quadtree, dim3(nb, g.nlevels - (qtEarly ? mid : 0)), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
+                           h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, qtEarly ? mid : 0);
+        if (early0 && qtEarly) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));   // the lower levels' quad-trees ran on the side stream
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
         if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
