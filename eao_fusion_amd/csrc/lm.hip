@@ -236,15 +236,31 @@ __device__ inline void block_sum_lds(double (&acc)[NV], double* red, double* par
     __syncthreads();
 }
 
+// Sum over the 64 lanes of a wave on the VALU: DPP quad permutes, half-row and row mirrors, then the row broadcasts 15 / 31;
+// the total ends up in lane 63.  (A shuffle tree is six dependent ds_bpermute round trips per value: the single-value sums
+// on the LM kernels' critical paths cost ~4.5 k cycles each that way.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64_lane63(double v) {
+    v = dpp_add_f64<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    v = dpp_add_f64<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    v = dpp_add_f64<0x141, 0xF>(v);    // row_half_mirror
+    v = dpp_add_f64<0x140, 0xF>(v);    // row_mirror: every lane of a row holds the row sum
+    v = dpp_add_f64<0x142, 0xA>(v);    // row_bcast15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xC>(v);    // row_bcast31 into rows 2 and 3
+    return v;
+}
 template <int NV, int NT>
 __device__ inline void block_sum(double (&v)[NV], double* lds /* (NT/64)*NV */, double* out /* NV */) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        double x = v[k];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_down(x, d);
-        if (lane == 0) lds[wv * NV + k] = x;
+        const double x = wave_sum_f64_lane63(v[k]);
+        if (lane == 63) lds[wv * NV + k] = x;
     }
     __syncthreads();
     if (threadIdx.x < NV) {
