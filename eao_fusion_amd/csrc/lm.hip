@@ -189,11 +189,20 @@ __device__ inline void huber(double e, double delta, double& rho0, double& rho1)
 
 struct Cam { double fx, fy, cx, cy, bf; float bf_f; double deltaMono, deltaStereo; };
 
-// sum over the 8 lanes of an aligned lane group (fixed xor tree => reproducible); every lane gets the result
+// v + (v of the lane a DPP control selects): the building block of the cross-lane sums below -- VALU only, no LDS round trip
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+// sum over the 8 lanes of an aligned lane group; every lane gets the result.  The same tree as xor-shuffles by 1, 2, 4
+// (pairs, quads, then the mirrored quad of the other half), so the sums are bit-identical to those -- but each step is a
+// DPP add instead of a ds_bpermute round trip (66 of them per k_ba_linearize before).
 __device__ __forceinline__ double group8_sum(double v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
+    v = dpp_add_f64<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]: lane ^ 1
+    v = dpp_add_f64<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]: lane ^ 2
+    v = dpp_add_f64<0x141, 0xF>(v);    // row_half_mirror: lane i <-> 7 - i of its 8-lane half, i.e. the other quad's sum
     return v;
 }
 
@@ -239,12 +248,6 @@ __device__ inline void block_sum_lds(double (&acc)[NV], double* red, double* par
 // Sum over the 64 lanes of a wave on the VALU: DPP quad permutes, half-row and row mirrors, then the row broadcasts 15 / 31;
 // the total ends up in lane 63.  (A shuffle tree is six dependent ds_bpermute round trips per value: the single-value sums
 // on the LM kernels' critical paths cost ~4.5 k cycles each that way.)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
-    return v + __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double wave_sum_f64_lane63(double v) {
     v = dpp_add_f64<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
     v = dpp_add_f64<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
