@@ -28,8 +28,8 @@ steps = raw["k_blur7"]["launches_fetch"]
 out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 3 --warmup 1 "
                 "--no-cpu-baseline --no-extra; bytes = KiB counter * 1024.  RAW counters: the guide's x2 FETCH_SIZE "
                 "correction is calibrated for 16-B-per-lane streaming reads; these kernels read 4 or 12 B per lane, which is uncalibrated -- "
-                "self-check: k_blur7 reads and writes 243 MB algorithmically (256 x 950 532 px; + halo rows on the read side, + pitch padding on the write side).",
-       "batch": 256, "kernels": {}}
+                "self-check: k_blur7 reads and writes 243 MB algorithmically (batch x 950 532 px; + halo rows on the read side, + pitch padding on the write side).",
+       "batch": int(__import__("os").environ.get("EAO_PMC_BATCH", "64")), "kernels": {}}
 for st, k in stage.items():
     r = raw[k]
     f, w = r["fetch_KiB_per_launch"] * 1024, r["write_KiB_per_launch"] * 1024
