@@ -1526,8 +1526,8 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         static const int envMid = getenv("EAO_ORB_MID") ? atoi(getenv("EAO_ORB_MID")) : -1;
         const int wantMid = envMid >= 0 ? envMid : (nb >= 48 ? 3 : 0);
         const int mid = early0 && wantMid >= 2 && wantMid < g.nlevels ? wantMid : 0;
-        static const int envQtEarly = getenv("EAO_ORB_QT_EARLY") ? atoi(getenv("EAO_ORB_QT_EARLY")) : 0;
-        const bool qtEarly = mid > 0 && envQtEarly != 0;
+        static const int envQtEarly = getenv("EAO_ORB_QT_EARLY") ? atoi(getenv("EAO_ORB_QT_EARLY")) : -1;
+        const bool qtEarly = mid > 0 && (envQtEarly >= 0 ? envQtEarly != 0 : nb <= 96);
         // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         if (early0) {
@@ -1548,9 +1548,11 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 EAO_HIP(hipEventRecord(h->evMid[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evMid[i], 0));
                 fast(ss, cells0, g.L[mid].cellBase);
-                // EAO_ORB_QT_EARLY=1: their quad-trees right behind, beside the main stream's FAST of the upper levels instead of
-                // beside the blur afterwards.  Measured and NOT kept: 1.258 vs 1.226 ms per step -- the quad-tree workgroups'
-                // 42 KB of LDS each take the occupancy FAST needs.
+                // ... and, up to 96 frames, their quad-trees right behind, beside the main stream's FAST of the upper levels
+                // instead of beside the blur afterwards: a quad-tree launch lasts as long as its level-0 workgroup (~60 us), and
+                // at these batches that is the long pole of the last-but-one segment (64 frames: 0.403 -> 0.390 ms per step).
+                // At 256 frames it is slower (1.258 vs 1.226 ms: 768 workgroups with 42 KB of LDS each take the occupancy FAST
+                // needs), so large batches keep all eight levels after FAST.  EAO_ORB_QT_EARLY=0 / 1 overrides.
                 if (qtEarly) hipLaunchKernelGGL(k_quadtree, dim3(nb, mid), dim3(kQT), h->quadLds, ss, h->d_geom.p, h->d_cellcand.p,
                                    h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, 0);
             }
