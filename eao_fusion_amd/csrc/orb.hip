@@ -468,12 +468,15 @@ __device__ int block_excl_scan(int* a, int n, int* wtmp) {
     const int b = min(t * per, n), e = min(b + per, n);
     int ssum = 0;
     for (int i = b; i < e; i++) ssum += a[i];
+    // inclusive scan over the wave on the VALU (DPP row shifts inside the rows of 16, then the row broadcasts 15 / 31) instead
+    // of six ds_bpermute round trips: the quad-tree calls this scan some thirty times per level, each on its critical path
     int v = ssum;
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        const int o = __shfl_up(v, dlt);
-        if (lane >= dlt) v += o;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2 and 3
     __syncthreads();  // protect wtmp from the previous call's readers
     if (lane == 63) wtmp[wv] = v;
     __syncthreads();

@@ -8,7 +8,7 @@ nkf = int(os.environ.get("EAO_DBG_KF", "200")); npts = int(os.environ.get("EAO_D
 t = time.perf_counter(); p = synth.synth_ba(n_free=nkf, n_fixed=1, n_points=npts, seed=5300); print("synth %.1f s, E = %d" % (time.perf_counter() - t, len(p["edge_cam"])), flush=True)
 for k in range(3):
     t = time.perf_counter(); r = E.Optimizer.BundleAdjustment(p, its, bRobust=False); dt = time.perf_counter() - t
-    print("GBA %d KF x %d MP: %.2f ms wall, iters %s, trials %s" % (nkf, npts, dt * 1e3, list(r["iters"]), list(r["trace"]["trials"])), flush=True)
+    print("GBA %d KF x %d MP: %.2f ms wall (device %.2f ms), iters %s, trials %s" % (nkf, npts, dt * 1e3, r["timing"]["device_ms"], list(r["iters"]), list(r["trace"]["trials"])), flush=True)
 if os.environ.get("EAO_DBG_ORACLE"):
     from oracle import oracle as O
     t = time.perf_counter(); o = O.bundle_adjustment(p, its, False); dt = time.perf_counter() - t
