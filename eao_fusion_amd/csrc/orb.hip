@@ -959,6 +959,10 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// end of each row of the radius-15 disc by |v| (the table of reference src/ORBextractor.cc:455-469, verified against the
+// computed one at handle creation); [16] closes the upper half-wave's sixteenth step (there is no row 16)
+constexpr int kUmaxTab[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
+
 // ---------------------------------------------------------------------------------------------- orientation + rBRIEF
 // sin/cos of a float angle in [0, 2*pi], evaluated in double (Cody-Waite reduction by pi/2 + the classic
 // minimax kernels) and rounded to float: plain +,-,* only, so results do not depend on a device libm.
@@ -1090,20 +1094,27 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     const int u = (lane & 31) - 15, half = lane >> 5;
     int m10 = 0, m01 = 0;
     if (u <= 15) {
-        // rows v = -15..0 (lower half-wave) / 1..15 (upper); end of each row of the radius-15 disc = kUmax[|v|]
-        // (the table of reference src/ORBextractor.cc:455-469, verified against the computed one at handle creation)
-        constexpr int kUmax[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
+        // rows v = -15..0 (lower half-wave) / 1..15 (upper); end of each row of the radius-15 disc = kUmaxTab[|v|]
         const uint8_t* c0 = reinterpret_cast<const uint8_t*>(mpatch[wv]) + kMR * (4 * kMW) + kMR + mph + u;
         const int au = u < 0 ? -u : u;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
+        // One row per step and half-wave; the row ends come into the code as IMMEDIATES (template constants).  Written as a
+        // loop over a constexpr table the compiler selected between two table ADDRESSES and loaded the bound from constant
+        // memory -- a dependent global load (plus s_waitcnt vmcnt(0)) in every one of the sixteen steps: 85 of the kernel's
+        // 300 us.  Pixels outside the disc count as zero (the window holds every (u, v) with |u|, |v| <= 15).
+        auto row = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int umLo = kUmaxTab[15 - k], umHi = kUmaxTab[k + 1];
             const int v = half ? k + 1 : k - 15;
-            const int um = half ? kUmax[k + 1] : kUmax[15 - k];
-            // (branch-free: the window holds every (u, v) with |u|, |v| <= 15, pixels outside the disc count as zero)
-            const int val = au <= um ? (int)c0[v * (4 * kMW)] : 0;
+            const int um = half ? umHi : umLo;
+            const int pix = c0[v * (4 * kMW)];
+            const int val = au <= um ? pix : 0;
             m10 += u * val;
             m01 += v * val;
-        }
+        };
+#define EAO_ROW(K) row(std::integral_constant<int, K>{});
+        EAO_ROW(0) EAO_ROW(1) EAO_ROW(2) EAO_ROW(3) EAO_ROW(4) EAO_ROW(5) EAO_ROW(6) EAO_ROW(7)
+        EAO_ROW(8) EAO_ROW(9) EAO_ROW(10) EAO_ROW(11) EAO_ROW(12) EAO_ROW(13) EAO_ROW(14) EAO_ROW(15)
+#undef EAO_ROW
     }
     m10 = wave_sum_i32(m10);
     m01 = wave_sum_i32(m01);
