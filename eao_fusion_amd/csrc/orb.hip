@@ -341,9 +341,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     }
     const int rw = tw + 2;
     const int scWords = (rw * (th_ + 2) + 3) >> 2;
-    unsigned* out = cellcand + slot * g->cellCap;
+    // (the geometry fields the loops need, read ONCE: the compiler re-loads g->x after every store it cannot tell apart)
+    const int cellCap = g->cellCap, thIni = g->iniTh, thMin = g->minTh;
+    unsigned* out = cellcand + slot * cellCap;
     for (int pass = 0; pass < 2; pass++) {
-        const int th = min(max(pass ? g->minTh : g->iniTh, 0), 255);
+        const int th = min(max(pass ? thMin : thIni, 0), 255);
         for (int i = lane; i < scWords; i += 64) sc4[i] = 0;
         __syncthreads();   // tile staged (first pass) / previous pass done with sc
         // ---- 1. compass test, four horizontally adjacent pixels per lane: five pairs of aligned LDS words (centre, left,
@@ -446,12 +448,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
             const unsigned long long m = __ballot(keep);
             if (keep) {
                 const int pos = total + __popcll(m & ((1ull << lane) - 1));
-                if (pos < g->cellCap) out[pos] = (unsigned)(x + 3 + c.offX) | ((unsigned)(y + 3 + c.offY) << 12) | ((unsigned)v << 24);
+                if (pos < cellCap) out[pos] = (unsigned)(x + 3 + c.offX) | ((unsigned)(y + 3 + c.offY) << 12) | ((unsigned)v << 24);
             }
             total += __popcll(m);
         }
         if (total > 0 || pass == 1) {
-            if (lane == 0) cellcnt[slot] = min(total, g->cellCap);
+            if (lane == 0) cellcnt[slot] = min(total, cellCap);
             return;
         }
     }
