@@ -2312,6 +2312,7 @@ __global__ __launch_bounds__(256) void k_bal_step(BADev P, int kb, int last) {
 constexpr int kBigSB = 256;
 __global__ __launch_bounds__(256) void k_bal_backsolve(BADev P, int J, int* solveOk) {
     __shared__ double xl[kBigSB];      // z of the super-block on entry, x on exit
+    extern __shared__ double sdiag[];  // (kBigSB / 32) x 32 x 32: the factored diagonal blocks of the super-block
     __shared__ double part2[4][64];
     if (P.ctl[kCtlHalt]) return;
     const BigGeom g = big_geom(P.nFree);
@@ -2321,25 +2322,32 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(BADev P, int J, int* solv
     const int J0 = J * kBigSB, w = min(kBigSB, N - J0);
     double* z = S + (size_t)N * ld;
     if (t < w) xl[t] = z[J0 + t];
+    {   // the super-block's (up to eight) factored diagonal blocks: 64 KB of LDS, every load of a thread in flight at once
+        const double* Ld0 = P.bigDiag + (size_t)(J0 / kBigNB) * kBigNB * kBigNB;
+        const int cnt = (w / kBigNB) * kBigNB * kBigNB;
+        for (int i = t; i < cnt; i += 256) sdiag[i] = Ld0[i];
+    }
     // the super-block's triangle, right-looking: the top block is solved by wave 0 (column c of L_kk in registers, the
     // solved entries handed down by v_readlane), then every thread owning a column to the left removes the block's 32 rows
     // from its z entry -- the 32 loads of a thread are independent of x, so they are in flight before the chain ends
-    for (int b = w / kBigNB - 1; b >= 0; b--) {
-        const int cb = J0 + b * kBigNB;
-        double lrow[kBigNB];
-        const bool left = t < b * kBigNB;
-        if (left) {
+    // the rows a thread needs for block b - 1 are fetched while block b is being solved (two register buffers, A / B)
+    auto fetch = [&](int b, double (&dst)[kBigNB]) {
+        if (b >= 0 && t < b * kBigNB) {
+            const int cb = J0 + b * kBigNB;
 #pragma unroll
-            for (int i = 0; i < kBigNB; i++) lrow[i] = S[(size_t)(cb + i) * ld + J0 + t];
+            for (int i = 0; i < kBigNB; i++) dst[i] = S[(size_t)(cb + i) * ld + J0 + t];
         }
+    };
+    auto do_block = [&](int b, double (&cur)[kBigNB], double (&nxt)[kBigNB]) {
+        fetch(b - 1, nxt);
         __syncthreads();                 // xl[] of this block is final (initial load / previous block's updates)
         if (t < 64) {
             const int c = t & 31;
             double v = xl[b * kBigNB + c];
-            const double* Ld = P.bigDiag + (size_t)(cb / kBigNB) * kBigNB * kBigNB;
+            const double* Ld = sdiag + (size_t)b * kBigNB * kBigNB;
             double lc[kBigNB];
 #pragma unroll
-            for (int q = 0; q < kBigNB; q++) lc[q] = Ld[q * kBigNB + c];       // column c of L_kk
+            for (int q = 0; q < kBigNB; q++) lc[q] = Ld[q * kBigNB + c];       // column c of L_kk (LDS)
 #pragma unroll
             for (int q = kBigNB - 1; q >= 1; q--) {
                 const double xq = bal_readlane(v, q);
@@ -2348,11 +2356,20 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(BADev P, int J, int* solv
             if (t < 32) xl[b * kBigNB + t] = v;
         }
         __syncthreads();
-        if (left) {
+        if (t < b * kBigNB) {
             double acc = 0;
 #pragma unroll
-            for (int i = 0; i < kBigNB; i++) acc = fma(lrow[i], xl[b * kBigNB + i], acc);
+            for (int i = 0; i < kBigNB; i++) acc = fma(cur[i], xl[b * kBigNB + i], acc);
             xl[t] -= acc;
+        }
+    };
+    {
+        double rowA[kBigNB], rowB[kBigNB];
+        const int top = w / kBigNB - 1;
+        fetch(top, rowA);
+        for (int b = top; b >= 0; b -= 2) {
+            do_block(b, rowA, rowB);
+            if (b - 1 >= 0) do_block(b - 1, rowB, rowA);
         }
     }
     __syncthreads();
@@ -3040,6 +3057,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         const size_t schurLds = bigPath ? 0 : schur_lds_bytes(nF);
         if (nF && !bigPath) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         const BigGeom gB = big_geom(std::max(nF, 1));
+        if (bigPath) EAO_HIP(hipFuncSetAttribute((const void*)k_bal_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double))));
         int* const ctl0 = dctl; double* const lm0 = dlm0;
         auto use_pair = [&](int k) { D.ctl = ctl0 + 8 * k; D.lm = lm0 + 8 * k; };
         auto enqueue_trial = [&](int bulk, bool firstTrial = false, bool withDecide = true) {
@@ -3053,7 +3071,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
                     hipLaunchKernelGGL(k_bal_step, dim3(nT - tj0, nT - tj0), dim3(256), 0, s, D, kb, kb + 1 == nbk ? 1 : 0);
                 }
                 for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
-                    hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), 0, s, D, J, dsolveOk);
+                    hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, D, J, dsolveOk);
             } else if (nF && usePairs && solveTiles) {
                 hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2), dim3(kPairThreads), 0, s, D, firstTrial ? 1 : 0);
             } else if (nF) {
