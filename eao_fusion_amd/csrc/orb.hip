@@ -396,10 +396,17 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
                 const int nv = it0 + lane < items ? tw - x0 : 0;
                 m4 &= (1u << min(nv, 4)) - 1u;
                 // survivors of the lower lanes: the lane counts (0..4) are prefixed bit plane by bit plane
-                const unsigned c = __popc(m4);
-                const unsigned long long b0 = __ballot(c & 1u), b1 = __ballot(c & 2u), b2 = __ballot(c & 4u);
-                const unsigned long long below = (1ull << lane) - 1;
-                int pos = nwork + __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+                // (an inclusive DPP scan of the lane counts: row shifts inside the rows of 16, then the row broadcasts 15 / 31 --
+                //  six VALU adds; the first version prefixed the counts bit plane by bit plane with three ballots)
+                const int c = (int)__popc(m4);
+                int incl = c;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1 and 3
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2 and 3
+                int pos = nwork + incl - c;
                 // branch-free stores: a pixel that failed writes to a scratch slot (corners[] is not in use yet)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -408,8 +415,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
                     *dstp = (unsigned short)(i0 + j);
                     pos += (int)bit;
                 }
-                const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-                nwork += tot;
+                nwork += __builtin_amdgcn_readlane(incl, 63);
             }
         }
         __syncthreads();
