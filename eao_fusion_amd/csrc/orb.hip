@@ -1603,7 +1603,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
         hipLaunchKernelGGL(k_quadtree, dim3(nb, g.nlevels - (qtEarly ? mid : 0)), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
                            h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, qtEarly ? mid : 0);
-        if (early0 && qtEarly) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));   // the lower levels' quad-trees ran on the side stream
+        // (the lower levels' quad-trees ran on the side stream, ahead of the blur: the wait for evJoin below covers them)
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
         if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
