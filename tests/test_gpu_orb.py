@@ -86,18 +86,20 @@ def test_empty_and_flat_images(gpu, oracle):
         ext(np.zeros((40, 40), np.uint8))                        # smaller than one FAST cell: loud error
 
 
-def test_full_batch64_properties(gpu, oracle):
-    """BASELINE configs[1] size (64 frames): determinism across calls + spot parity on 3 frames."""
-    imgs = synth.synth_frames(64)
+@pytest.mark.parametrize("B", [64, 104])
+def test_full_batch64_properties(gpu, oracle, B):
+    """BASELINE configs[1] size (64 frames: side-stream FAST of levels 0-2 with their quad-trees behind, frame -> XCD affinity)
+    and a batch beyond 96 frames (all quad-trees after FAST): determinism across calls + spot parity on 3 frames."""
+    imgs = synth.synth_frames(B)
     ext = gpu.ORBextractor(1000, 1.2, 8, 20, 7)
     k1, d1 = ext.extract_batch(imgs)
     k2, d2 = ext.extract_batch(imgs)
     orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
-    for f in range(64):
+    for f in range(B):
         assert np.array_equal(k1[f], k2[f]) and np.array_equal(d1[f], d2[f])
         assert 1000 <= len(k1[f]) <= 1016
         assert np.all(np.diff(k1[f]["octave"]) >= 0)
-    for f in (0, 31, 63):
+    for f in (0, 31, B - 1):
         okps, odesc = orc.extract(imgs[f])
         assert np.array_equal(k1[f], okps) and np.array_equal(d1[f], odesc)
 
