@@ -51,15 +51,27 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the N-rank launch and the collectives on the CPU (gloo, stand-in payloads, no HIP call, no timing)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` as typed: start one rank per GPU under torch.distributed.run as a CHILD process and pass its
+        # output and return code through.  Nothing in this process has touched HIP or torch.cuda yet (and it never execs).
+        sys.exit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under torch.distributed.run "
+                 "--nproc-per-node N)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -196,6 +208,70 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }
         print(json.dumps(out))
+
+
+def self_launch(n):
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """CPU rehearsal of the multi-rank plumbing (gloo): shard arithmetic, halo exchange, the s8(e) all-gathers of
+    (keypoints, descriptors) and of per-window BA results, the throughput reduction.  Payloads are stand-ins derived from the
+    frame / window index (so that every rank can check what it received); no extraction, no timing, `value` is null."""
+    import torch
+    import torch.distributed as dist
+    from eao_fusion_amd import shard
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    B, cap = args.batch, 16
+    n_frames = B * world
+    lo, hi = shard.frame_shard(n_frames, rank, world)
+
+    def rec(f):      # stand-in (keypoints, descriptors, count) of frame f
+        g = torch.Generator().manual_seed(7000 + f)
+        return (torch.randint(0, 256, (cap, 28), dtype=torch.uint8, generator=g), torch.randint(0, 256, (cap, 32), dtype=torch.uint8, generator=g),
+                3 + f % (cap - 3))
+    mine = [rec(f) for f in range(lo, hi)]
+    kps, desc = torch.stack([m[0] for m in mine]), torch.stack([m[1] for m in mine])
+    cnt = torch.tensor([m[2] for m in mine], dtype=torch.int32)
+    hk, hd, hn = shard.exchange_halo_frame(kps[-1], desc[-1], int(cnt[-1]))
+    ok = True
+    if rank > 0:
+        ek, ed, en = rec(lo - 1)
+        ok &= bool(torch.equal(hk, ek) and torch.equal(hd, ed) and hn == en)
+    K, D, Cn = shard.gather_frame_results(kps, desc, cnt, n_frames)
+    for f in (0, n_frames // 2, n_frames - 1):
+        ek, ed, en = rec(f)
+        ok &= bool(torch.equal(K[f], ek) and torch.equal(D[f], ed) and int(Cn[f]) == en)
+    nwin = 25
+    ws = shard.window_shard(nwin, rank, world)
+    cams = torch.stack([torch.full((24, 16), float(w)) for w in ws]) if ws else torch.zeros((0, 24, 16))
+    pts = torch.stack([torch.full((30, 3), float(-w)) for w in ws]) if ws else torch.zeros((0, 30, 3))
+    AC, AP = shard.gather_window_results(cams, pts, nwin)
+    ok &= all(float(AC[w, 0, 0]) == w and float(AP[w, 0, 0]) == -w for w in range(nwin))
+    thr, units, secs = shard.aggregate_throughput(int(cnt.sum()), 1.0 + rank)
+    ok &= secs == float(world) and units == float(Cn.sum())
+    flag = torch.tensor([1 if ok else 0])
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "ORB kpts/s (640x480, 1k feat) + local-BA residuals/s (20 KF x 3k pts)", "value": None, "unit": "kpts/s",
+                          "n_gpus": world, "dry_run": True, "collectives_ok": bool(flag.item()), "frames": n_frames, "ba_windows": nwin,
+                          "note": "CPU rehearsal of the launcher and the collectives (gloo); nothing was measured"}))
+    return 0 if flag.item() else 1
 
 
 def measure_sequence(E, synth, shard, torch, dev, rank, world, d_desc, n_host, halo_desc, halo_n):
@@ -526,4 +602,4 @@ def measure_cpu(frames, synth, extra):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,8 +1,7 @@
 """ctypes mirror of the Frame glue either side of the matcher (include/eao_fusion.h, row f1): eao_frame_is_in_frustum,
 eao_assign_features_to_grid, eao_compute_stereo_from_rgbd -- reference src/Frame.cc:597-614, 638-695, 751-761, 1016-1037.
 
-`Binding(lib, prefix, check)` binds the wrappers to any shared object exporting `<prefix>...` entry points: the product
-('eao_', struct arguments, status codes) or a library with the oracle's flat argument lists ('orc_')."""
+`Binding(lib, check)` binds the wrappers to libeaofusion_hip.so (see product() below)."""
 import ctypes as C
 
 import numpy as np
@@ -24,22 +23,29 @@ def _p(a):
 
 
 class Binding:
-    def __init__(self, lib, prefix, check=None):
-        self.lib, self.prefix, self.check = lib, prefix, check
-        if check:   # product
-            lib.eao_frame_is_in_frustum.restype = _I
-            lib.eao_frame_is_in_frustum.argtypes = [C.POINTER(FrustumFrame), C.POINTER(MapPoints), _F] + [_P] * 6
-            lib.eao_assign_features_to_grid.restype = _I
-            lib.eao_assign_features_to_grid.argtypes = [_I, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P]
-            lib.eao_compute_stereo_from_rgbd.restype = _I
-            lib.eao_compute_stereo_from_rgbd.argtypes = [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]
-        else:       # oracle: flat argument lists
-            lib.orc_is_in_frustum.restype = _I
-            lib.orc_is_in_frustum.argtypes = [_I] + [_P] * 8 + [_F] * 11 + [_P] * 6
-            lib.orc_assign_features_to_grid.restype = _I
-            lib.orc_assign_features_to_grid.argtypes = [_I, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P]
-            lib.orc_stereo_from_rgbd.restype = _I
-            lib.orc_stereo_from_rgbd.argtypes = [_I, _P, _P, _P, _P, _I, _F, _P, _P]
+    """The Frame glue bound to libeaofusion_hip.so.  The three `_raw_*` methods are the only places that touch the library;
+    the test suite derives its checker binding from this class by overriding exactly those."""
+
+    def __init__(self, lib, check):
+        self.lib, self.check = lib, check
+        lib.eao_frame_is_in_frustum.restype = _I
+        lib.eao_frame_is_in_frustum.argtypes = [C.POINTER(FrustumFrame), C.POINTER(MapPoints), _F] + [_P] * 6
+        lib.eao_assign_features_to_grid.restype = _I
+        lib.eao_assign_features_to_grid.argtypes = [_I, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P]
+        lib.eao_compute_stereo_from_rgbd.restype = _I
+        lib.eao_compute_stereo_from_rgbd.argtypes = [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]
+
+    def _raw_is_in_frustum(self, m, keep, T, Ow, sc, limit, outs):
+        F = FrustumFrame()
+        F.Tcw[:] = T.ravel().tolist(); F.Ow[:] = Ow.tolist()
+        (F.fx, F.fy, F.cx, F.cy, F.mbf, F.min_x, F.max_x, F.min_y, F.max_y, F.log_scale_factor) = sc
+        self.check(self.lib.eao_frame_is_in_frustum(C.byref(F), C.byref(m), limit, *outs))
+
+    def _raw_assign(self, n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows, start, items):
+        self.check(self.lib.eao_assign_features_to_grid(n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows, start, items))
+
+    def _raw_rgbd(self, n, kx, ky, ku, d, w, h, mbf, ur, dz):
+        self.check(self.lib.eao_compute_stereo_from_rgbd(n, kx, ky, ku, d, w, h, w, 0, mbf, ur, dz))
 
     def is_in_frustum(self, frame, pts, viewing_cos_limit=0.5):
         """frame: Tcw (4x4 f32), Ow (3), fx, fy, cx, cy, mbf, min_x, max_x, min_y, max_y, log_scale_factor.
@@ -53,15 +59,7 @@ class Binding:
         Ow = np.ascontiguousarray(frame["Ow"], np.float32)
         sc = [float(frame[k]) for k in ("fx", "fy", "cx", "cy", "mbf", "min_x", "max_x", "min_y", "max_y", "log_scale_factor")]
         outs = [_p(out[k]) for k in ("in_view", "proj_x", "proj_y", "proj_xr", "view_cos", "pred_level")]
-        if self.check:
-            F = FrustumFrame()
-            F.Tcw[:] = T.ravel().tolist(); F.Ow[:] = Ow.tolist()
-            (F.fx, F.fy, F.cx, F.cy, F.mbf, F.min_x, F.max_x, F.min_y, F.max_y, F.log_scale_factor) = sc
-            self.check(self.lib.eao_frame_is_in_frustum(C.byref(F), C.byref(m), float(viewing_cos_limit), *outs))
-        else:
-            R = np.ascontiguousarray(T[:3, :3]); t = np.ascontiguousarray(T[:3, 3])
-            self.lib.orc_is_in_frustum(n, _p(keep["Xw"]), _p(keep["normal"]), _p(keep["min_dist_inv"]), _p(keep["max_dist_inv"]),
-                                       _p(keep["max_dist"]), _p(R), _p(t), _p(Ow), *sc, float(viewing_cos_limit), *outs)
+        self._raw_is_in_frustum(m, keep, T, Ow, sc, float(viewing_cos_limit), outs)
         return out
 
     def assign_features_to_grid(self, kp_x, kp_y, min_x, min_y, max_x, max_y, cols=64, rows=48):
@@ -71,10 +69,7 @@ class Binding:
         inv_h = np.float32(rows) / np.float32(np.float32(max_y) - np.float32(min_y))
         start = np.zeros(cols * rows + 1, np.int32)
         items = np.full(max(len(kx), 1), -1, np.int32)
-        fn = getattr(self.lib, self.prefix + "assign_features_to_grid")
-        st = fn(len(kx), _p(kx), _p(ky), float(min_x), float(min_y), float(inv_w), float(inv_h), cols, rows, _p(start), _p(items))
-        if self.check:
-            self.check(st)
+        self._raw_assign(len(kx), _p(kx), _p(ky), float(min_x), float(min_y), float(inv_w), float(inv_h), cols, rows, _p(start), _p(items))
         return start, items[:start[-1]]
 
     def compute_stereo_from_rgbd(self, kp_x, kp_y, kpu_x, depth, mbf):
@@ -82,11 +77,7 @@ class Binding:
         kx, ky, ku = (np.ascontiguousarray(a, np.float32) for a in (kp_x, kp_y, kpu_x))
         d = np.ascontiguousarray(depth, np.float32)
         ur, dz = np.zeros(len(kx), np.float32), np.zeros(len(kx), np.float32)
-        if self.check:
-            self.check(self.lib.eao_compute_stereo_from_rgbd(len(kx), _p(kx), _p(ky), _p(ku), _p(d), d.shape[1], d.shape[0], d.shape[1], 0,
-                                                             float(mbf), _p(ur), _p(dz)))
-        else:
-            self.lib.orc_stereo_from_rgbd(len(kx), _p(kx), _p(ky), _p(ku), _p(d), d.shape[1], float(mbf), _p(ur), _p(dz))
+        self._raw_rgbd(len(kx), _p(kx), _p(ky), _p(ku), _p(d), d.shape[1], d.shape[0], float(mbf), _p(ur), _p(dz))
         return ur, dz
 
 
@@ -97,7 +88,7 @@ def product():
     global _product
     if _product is None:
         from . import _lib
-        _product = Binding(_lib.load(), "eao_", _lib.check)
+        _product = Binding(_lib.load(), _lib.check)
     return _product
 
 

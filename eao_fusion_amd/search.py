@@ -7,8 +7,7 @@ Data conventions (dicts of numpy arrays):
           max_x, max_y, scale_factors (f32), optional log_scale_factor, level_sigma2, inv_level_sigma2
   points  active (u8), Xw (n,3), optional normal (n,3), min_dist_inv, max_dist_inv, max_dist (f32), descriptors (n,32)
   fv      node_id (u32, ascending), node_start (i32, n_nodes+1), index (u32)
-`Binding(lib, prefix, check)` binds the same wrappers to any shared object exporting `<prefix>search_...` with the C-ABI's
-struct layouts; the product binds its own library below."""
+`Binding(lib, check)` binds the wrappers to libeaofusion_hip.so (see product() below)."""
 import ctypes as C
 
 import numpy as np
@@ -87,23 +86,22 @@ SEARCH_ARGTYPES = {   # argument types after which every function takes (int32* 
 
 
 class Binding:
-    """The seven searches bound to one shared object.  product: prefix 'eao_', functions return a status and write the
-    count through the last pointer; oracle: prefix 'orc_', functions return the count and take no count pointer."""
+    """The seven searches bound to libeaofusion_hip.so: every function returns a status and writes the match count through its
+    last pointer.  (The test suite derives its checker binding from this class; nothing in this package
+    knows about it.)"""
+    prefix = "eao_"
 
-    def __init__(self, lib, prefix, check=None):
-        self.lib, self.prefix, self.check = lib, prefix, check
+    def __init__(self, lib, check):
+        self.lib, self.check = lib, check
         for name, args in SEARCH_ARGTYPES.items():
-            fn = getattr(lib, prefix + name)
+            fn = getattr(lib, self.prefix + name)
             fn.restype = _I
-            fn.argtypes = args + [_P] + ([C.POINTER(_I)] if check else [])
+            fn.argtypes = args + [_P, C.POINTER(_I)]
 
     def _call(self, name, args, out):
-        fn = getattr(self.lib, self.prefix + name)
-        if self.check:
-            n = _I(0)
-            self.check(fn(*args, _p(out), C.byref(n)))
-            return int(n.value), out
-        return int(fn(*args, _p(out))), out
+        n = _I(0)
+        self.check(getattr(self.lib, self.prefix + name)(*args, _p(out), C.byref(n)))
+        return int(n.value), out
 
     def search_by_projection_sim3(self, kf, Scw, K, pts, th):
         v, k1 = frame_view(kf)
@@ -180,5 +178,5 @@ def product():
     global _binding
     if _binding is None:
         from . import _lib
-        _binding = Binding(_lib.load(), "eao_", _lib.check)
+        _binding = Binding(_lib.load(), _lib.check)
     return _binding

@@ -16,7 +16,7 @@ def both(oracle):
     import torch  # noqa: F401  (first, so that the library resolves the same HIP runtime)
     import eao_fusion_amd as E
     assert E.load().eao_device_check() == 0, E.load().eao_last_error()
-    return F.product(), F.Binding(oracle.lib(), "orc_"), E
+    return F.product(), oracle.frame_binding(), E
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(n=1200, seed=8001, flip=0.09, mono_frac=0.6), dict(n=300, seed=8002, clutter=0.5, n_nodes=12)])

@@ -9,7 +9,7 @@ from eao_fusion_amd import synth
 
 @pytest.fixture(scope="module")
 def orc(oracle):
-    return F.Binding(oracle.lib(), "orc_")
+    return oracle.frame_binding()
 
 
 def frustum_frame(scene, which="T2w"):

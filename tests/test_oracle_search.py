@@ -15,7 +15,7 @@ TH_LOW, TH_HIGH, HISTO = 50, 100, 30
 
 @pytest.fixture(scope="module")
 def orc(oracle):
-    return search.Binding(oracle.lib(), "orc_")
+    return oracle.search_binding()
 
 
 @pytest.fixture(scope="module")
