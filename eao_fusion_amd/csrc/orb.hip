@@ -35,7 +35,7 @@ constexpr int kEdge = 19;
 constexpr int kMinBorder = kEdge - 3;  // 16
 constexpr int kTile = 72;              // max FAST sub-image edge (cell <= 60 px + 6)
 // (tested region of a cell = sub-image minus the 3 px FAST margin on every side: at most 66 x 66)
-constexpr int kTileStride = 80;        // LDS row stride of the tile: 72 + up to 3 bytes of alignment phase, multiple of 4
+constexpr int kTileStrideWide = 80;    // LDS row stride of the widest tile: 72 + up to 3 bytes of alignment phase, multiple of 4
 constexpr int kMaxIni = 16;
 constexpr int kFastXcdRun = 0;         // 0 = plain workgroup -> cell order (see k_fast_cells)
 
@@ -65,7 +65,7 @@ struct Geom {
     int iniTh, minTh;
     int scanCap;               // LDS scan workspace entries for k_quadtree
     int qtLdsCand, qtKeysOff;  // k_quadtree: candidates (key + node index) that fit in LDS, byte offset of the keys
-    int fastMaxTested, fastTileBytes, fastLdsBytes;   // k_fast_cells dynamic LDS carve-up
+    int fastMaxTested, fastTileBytes, fastLdsBytes, fastStride;   // k_fast_cells dynamic LDS carve-up
     int umax[16];
     LevelGeom L[kMaxLevels];
 };
@@ -220,55 +220,64 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-// A = max over the sixteen 9-arcs of min(v - ring) and of min(ring - v): the pixel is a FAST-9 corner at
-// threshold t iff A > t, and its OpenCV corner score is A - 1.
-__device__ __forceinline__ int fast_arc_value(const uint8_t* p) {
-    constexpr int T = kTileStride;
-    const int v = p[0];
-    int d[16];
-    d[0] = v - p[3 * T];          d[1] = v - p[3 * T + 1];   d[2] = v - p[2 * T + 2];
-    d[3] = v - p[T + 3];          d[4] = v - p[3];           d[5] = v - p[-T + 3];
-    d[6] = v - p[-2 * T + 2];     d[7] = v - p[-3 * T + 1];  d[8] = v - p[-3 * T];
-    d[9] = v - p[-3 * T - 1];     d[10] = v - p[-2 * T - 2]; d[11] = v - p[-T - 3];
-    d[12] = v - p[-3];            d[13] = v - p[T - 3];      d[14] = v - p[2 * T - 2];
-    d[15] = v - p[3 * T - 1];
-    int lo3[16], hi3[16];
+// Arc value of ONE polarity.  With d_k = v - p_k the pixel is a FAST-9 corner at threshold t iff
+//   A = max( max_arcs min_{k in arc} d_k ,  max_arcs min_{k in arc} -d_k ) > t          (OpenCV's corner score is A - 1)
+// and min / max commute with the subtraction: the dark term is v - min_arcs max_{k in arc} p_k, the bright term the same
+// expression on the complemented bytes 255 - p (= p ^ 0xFF), 255 - v.  Two 9-arcs of a 16-ring overlap, so at most one of
+// the two terms is positive and a corner's score is the positive one: a lane evaluates the polarity `s` (0 = dark, 0xFF =
+// bright) its candidate test allows -- 16 xor + 16 + 16 max3 + 8 min3 -- instead of both (the first version: 16 differences,
+// 32 min3 / max3 for the triples and 64 for the arcs).  Pixels whose candidate test allows both polarities go through the
+// bright one in a second, short pass (see k_fast_cells).
+template <int T>
+__device__ __forceinline__ int fast_arc_polar(const uint8_t* p, unsigned s, int* centre) {
+    unsigned q[16];
+    q[0] = p[3 * T];          q[1] = p[3 * T + 1];   q[2] = p[2 * T + 2];
+    q[3] = p[T + 3];          q[4] = p[3];           q[5] = p[-T + 3];
+    q[6] = p[-2 * T + 2];     q[7] = p[-3 * T + 1];  q[8] = p[-3 * T];
+    q[9] = p[-3 * T - 1];     q[10] = p[-2 * T - 2]; q[11] = p[-T - 3];
+    q[12] = p[-3];            q[13] = p[T - 3];      q[14] = p[2 * T - 2];
+    q[15] = p[3 * T - 1];
+    *centre = p[0];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    }
-    int dark = -256, bright = 256;
+    for (int k = 0; k < 16; k++) q[k] ^= s;
+    int hi3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        dark = max(dark, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-        bright = min(bright, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
-    }
-    return max(dark, -bright);
+    for (int k = 0; k < 16; k++) hi3[k] = max3i((int)q[k], (int)q[(k + 1) & 15], (int)q[(k + 2) & 15]);
+    int w9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w9[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+    const int m = min3i(min3i(min3i(w9[0], w9[1], w9[2]), min3i(w9[3], w9[4], w9[5]), min3i(w9[6], w9[7], w9[8])),
+                        min3i(min3i(w9[9], w9[10], w9[11]), min3i(w9[12], w9[13], w9[14]), w9[15]), 255);
+    return (int)((unsigned)*centre ^ s) - m;
 }
 
-// Any 9 contiguous ring positions contain at least two of the compass positions 0, 4, 8, 12: a pixel can only be a
-// corner at threshold t if two compass pixels are darker than v - t or two are brighter than v + t.
-__device__ __forceinline__ bool fast_quick_pass(const uint8_t* p, int t) {
-    constexpr int T = kTileStride;
-    const int v = p[0];
-    const int d0 = v - p[3 * T], d4 = v - p[3], d8 = v - p[-3 * T], d12 = v - p[-3];
-    const int dark = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
-    const int bright = (-d0 > t) + (-d4 > t) + (-d8 > t) + (-d12 > t);
-    return dark >= 2 || bright >= 2;
+// A 9-arc of the 16-ring holds at least one pixel of every opposite pair (its complement is 7 contiguous positions): a
+// pixel can only be a dark corner at threshold t if (p0 or p8) and (p4 or p12) are below v - t, a bright one if one of each
+// pair is above v + t (positions 0 / 8 = three rows down / up, 4 / 12 = three columns right / left).  On the benchmark
+// frames 15.6 % of the level-0 pixels pass (18.7 % passed the first version's "two of the four compass pixels" test).
+template <int T>
+__device__ __forceinline__ void fast_candidate(const uint8_t* p, int v, int t, bool* dark, bool* bright) {
+    const int dn = p[3 * T], up = p[-3 * T], rt = p[3], lf = p[-3];
+    *dark = max(min(dn, up), min(rt, lf)) < v - t;
+    *bright = min(max(dn, up), max(rt, lf)) > v + t;
 }
 
 // ONE WAVEFRONT per FAST cell (64-thread workgroups): no cross-wave barriers, LDS sized by the largest cell of the
 // current geometry.  Per threshold (iniThFAST, then minThFAST only if the cell stayed empty, as upstream :809-816):
-//   1. compass test of every pixel, survivors compacted into a work list (ballot + popcount keeps row-major order)
-//   2. exact arc value of the survivors; corners (arc > th) write their score into an LDS score map that is zero
-//      everywhere else and are appended to a corner list (again order-preserving)
-//   3. 3x3 strict NMS of the listed corners against the score map (blind across the cell seam, like upstream's
-//      per-cell cv::FAST calls); kept corners leave in row-major order through a ballot scan
+//   1. candidate test of every pixel, four per lane on packed 16-bit halves; survivors are compacted into a work list in
+//      row-major order (DPP scan of the lane counts, positions of a lane's survivors from a 16-entry LDS table)
+//   2. arc value of the survivors in the polarity their candidate test allows; corners (arc > th) write their score into an
+//      LDS score map that is zero everywhere else.  2b: the few survivors that could be either polarity and were no dark
+//      corner are evaluated as bright ones
+//   3. the work list again: survivors with a non-zero score take the 3x3 strict NMS against the score map (blind across
+//      the cell seam, like upstream's per-cell cv::FAST calls); kept corners leave in row-major order through a ballot scan
 // WHOLE = true: the launch covers every cell of the frames (profiled calls, single-level pyramids); false: one share of the
 // overlapped schedule.  Same code -- the parameter only gives the two kinds of launch different names in a rocprofv3 summary,
 // so that the whole-stage duration bench.py reports can be read off the `k_fast_cells<true>` row directly.
-template <bool WHOLE>
+// kTileStride = LDS row stride of the pixel tile: 48 bytes when every cell of the geometry is at most 45 px wide (the default
+// 30-px cells are 37..43), 80 otherwise -- with the narrow tile and the shared list buffer a cell takes 6 KB of LDS instead
+// of 9.7 KB, i.e. 6.5 instead of 4 resident wavefronts per SIMD for a kernel whose waves spend 3/4 of their life waiting.
+template <bool WHOLE, int kTileStride>
 __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, const CellDesc* __restrict__ cells, ImgSrc s,
                                                    unsigned* __restrict__ cellcand, int* __restrict__ cellcnt, int f0, int cellFirst,
                                                    int cellEnd, int frameAffinity) {
@@ -301,9 +310,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     const int maxT = g->fastMaxTested;                 // max tested pixels of any cell
     uint8_t* tile = fsm;                                // fastTileBytes
     unsigned short* worklist = reinterpret_cast<unsigned short*>(fsm + g->fastTileBytes);
-    unsigned short* corners = worklist + maxT;
-    unsigned* sc4 = reinterpret_cast<unsigned*>(corners + maxT + (maxT & 1));   // score map (tw+2) x (th+2) bytes, word aligned
+    // (survivors that wait for their bright evaluation are stacked downwards from the end of the same buffer)
+    unsigned* sc4 = reinterpret_cast<unsigned*>(worklist + maxT + (maxT & 1));   // score map (tw+2) x (th+2) bytes, word aligned
     uint8_t* sc = reinterpret_cast<uint8_t*>(sc4);
+    unsigned* lut = reinterpret_cast<unsigned*>(fsm + g->fastLdsBytes - 64);        // 16 words
     int pitch;
     const uint8_t* src = level_ptr(g, s, c.level, f, &pitch);
     const int sw = c.sw, sh = c.sh, tw = sw - 6, th_ = sh - 6;
@@ -312,11 +322,18 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
         if (lane == 0) cellcnt[slot] = 0;
         return;
     }
+    if (lane < 16) {   // pixel positions of a word's survivors, one per byte, lowest first (index bits 0..3 = pixels 1, 0, 3, 2)
+        unsigned e = 0, n = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (lane & (1 << (j ^ 1))) { e |= (unsigned)j << (8 * n); n++; }
+        lut[lane] = e;
+    }
     // i / d for 0 <= i < 8192, 1 <= d <= 80 without an integer divide: (i + 0.5) / d is at least 0.5/80 away from an
     // integer, the float product is off by < 1e-4, so truncation is exact
 #define QDIV(i, inv) ((int)(((float)(i) + 0.5f) * (inv)))
     // (v_rcp_f32 is good to 1 ulp, far inside the 1e-4 the truncation argument needs; an IEEE division costs ten instructions)
-    const float invTw = __builtin_amdgcn_rcpf((float)tw), invSw = __builtin_amdgcn_rcpf((float)sw);
+    const float invSw = __builtin_amdgcn_rcpf((float)sw);
     const int x0a = c.x0 & ~3, ph = c.x0 - x0a;
     if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
         const int nw = (c.x0 + sw + 3 - x0a) >> 2;   // words per row
@@ -348,115 +365,152 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
         const int th = min(max(pass ? thMin : thIni, 0), 255);
         for (int i = lane; i < scWords; i += 64) sc4[i] = 0;
         __syncthreads();   // tile staged (first pass) / previous pass done with sc
-        // ---- 1. compass test, four horizontally adjacent pixels per lane: five pairs of aligned LDS words (centre, left,
-        // right, up, down) shifted into place with v_alignbyte, bytes widened to 16-bit pairs (even / odd pixels) with
-        // v_perm, and per pair the SECOND largest and SECOND smallest of the four differences v - p from a 6-operation
-        // packed min / max network: two compass pixels are darker than v - th iff the second largest difference exceeds th,
-        // two are brighter than v + th iff the second smallest is below -th.  Survivors keep row-major order: a lane's
-        // four pixels are consecutive, and the lanes' counts are prefixed with one ballot per pixel slot.
+        // ---- 1. candidate test, EIGHT horizontally adjacent pixels per lane (two words): aligned LDS words of the rows three
+        // up, three down and of the centre row (left / centre / right windows) shifted into place with v_alignbyte, bytes
+        // widened to 16-bit pairs (even / odd pixels) with v_perm; on the raw bytes the test reads
+        // max(min(up, down), min(left, right)) < v - th  (dark)  or  min(max(up, down), max(left, right)) > v + th  (bright):
+        // six packed min / max and two packed subtractions whose sign bits are the answer.  Survivors keep row-major order: a
+        // lane's eight pixels are consecutive, the lanes' counts are prefixed with a DPP scan, and the positions of a word's
+        // survivors come from a 16-entry table.  Work-list entry = y << 7 | x (tested-region coordinates, both < 72).
         int nwork = 0;
         {
             typedef short s16x2 __attribute__((ext_vector_type(2)));
-            const int G = (tw + 3) >> 2, items = G * th_;
+            const int G = (tw + 7) >> 3, items = G * th_;
             const float invG = __builtin_amdgcn_rcpf((float)G);
-            const int a0 = 3 + ph;                       // byte offset of the first centre pixel inside its 16-byte window
-            const int shC = a0 & 3, wC = a0 >> 2;        // centre / up / down: words wC, wC+1 shifted by shC
+            const int a0 = 3 + ph;                       // byte offset of the first centre pixel inside its window
+            const int shC = a0 & 3, wC = a0 >> 2;        // centre / up / down: words wC .. wC+2 shifted by shC
             const int shR = (a0 + 3) & 3, wR = (a0 + 3) >> 2;
             const unsigned* t32 = reinterpret_cast<const unsigned*>(tile);
             const short thS = (short)th;
-            const s16x2 TH = {thS, thS}, ZERO = {0, 0};
+            const s16x2 TH = {thS, thS};
             for (int it0 = 0; it0 < items; it0 += 64) {
                 const int it = min(it0 + lane, items - 1);
-                const int y = QDIV(it, invG), xg = it - y * G;
-                const int wbase = (y * kTileStride >> 2) + xg;          // word index of (row y, byte 4 xg): the UP row
-                const int wmid = wbase + 3 * (kTileStride >> 2), wdn = wbase + 6 * (kTileStride >> 2);
-                const unsigned C = __builtin_amdgcn_alignbyte(t32[wmid + wC + 1], t32[wmid + wC], (unsigned)shC);
-                const unsigned U = __builtin_amdgcn_alignbyte(t32[wbase + wC + 1], t32[wbase + wC], (unsigned)shC);
-                const unsigned D = __builtin_amdgcn_alignbyte(t32[wdn + wC + 1], t32[wdn + wC], (unsigned)shC);
-                const unsigned Lf = __builtin_amdgcn_alignbyte(t32[wmid + 1], t32[wmid], (unsigned)ph);
-                const unsigned R = __builtin_amdgcn_alignbyte(t32[wmid + wR + 1], t32[wmid + wR], (unsigned)shR);
-                unsigned fl[2];
+                const int y = QDIV(it, invG), xg = it - (int)__umul24(y, G);
+                const unsigned* tu = t32 + ((int)__umul24(y, kTileStride >> 2) + 2 * xg);   // (row y, byte 8 xg): the UP row
+                const unsigned* tm = tu + 3 * (kTileStride >> 2);
+                const unsigned* td = tu + 6 * (kTileStride >> 2);
+                const unsigned u0 = tu[wC], u1 = tu[wC + 1], u2 = tu[wC + 2];
+                const unsigned d0 = td[wC], d1 = td[wC + 1], d2 = td[wC + 2];
+                const unsigned c0 = tm[wC], c1 = tm[wC + 1], c2 = tm[wC + 2];
+                const unsigned l0 = tm[0], l1 = tm[1], l2 = tm[2];
+                const unsigned r0 = tm[wR], r1 = tm[wR + 1], r2 = tm[wR + 2];
+                unsigned m8 = 0;
 #pragma unroll
-                for (int par = 0; par < 2; par++) {
-                    const unsigned sel = par ? 0x0c030c01u : 0x0c020c00u;   // (pixel 1, pixel 3) / (pixel 0, pixel 2) as 16-bit halves
-                    const s16x2 v = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, C, sel));
-                    const s16x2 d0 = v - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, U, sel));
-                    const s16x2 d1 = v - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, D, sel));
-                    const s16x2 d2 = v - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Lf, sel));
-                    const s16x2 d3 = v - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, R, sel));
-                    const s16x2 t1 = __builtin_elementwise_min(__builtin_elementwise_max(d0, d1), __builtin_elementwise_max(d2, d3));
-                    const s16x2 t2 = __builtin_elementwise_max(__builtin_elementwise_min(d0, d1), __builtin_elementwise_min(d2, d3));
-                    const s16x2 s2 = __builtin_elementwise_max(t1, t2), s3 = __builtin_elementwise_min(t1, t2);
-                    const s16x2 m = __builtin_elementwise_max(s2, ZERO - s3);
-                    fl[par] = __builtin_bit_cast(unsigned, TH - m);           // sign bit of a half set <=> that pixel passes
+                for (int w = 0; w < 2; w++) {
+                    const unsigned C = __builtin_amdgcn_alignbyte(w ? c2 : c1, w ? c1 : c0, (unsigned)shC);
+                    const unsigned U = __builtin_amdgcn_alignbyte(w ? u2 : u1, w ? u1 : u0, (unsigned)shC);
+                    const unsigned D = __builtin_amdgcn_alignbyte(w ? d2 : d1, w ? d1 : d0, (unsigned)shC);
+                    const unsigned Lf = __builtin_amdgcn_alignbyte(w ? l2 : l1, w ? l1 : l0, (unsigned)ph);
+                    const unsigned R = __builtin_amdgcn_alignbyte(w ? r2 : r1, w ? r1 : r0, (unsigned)shR);
+                    unsigned fl[2];
+#pragma unroll
+                    for (int par = 0; par < 2; par++) {
+                        const unsigned sel = par ? 0x0c030c01u : 0x0c020c00u;   // (pixel 1, pixel 3) / (pixel 0, pixel 2) as 16-bit halves
+                        const s16x2 v = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, C, sel));
+                        const s16x2 pu = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, U, sel));
+                        const s16x2 pd = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, D, sel));
+                        const s16x2 pl = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Lf, sel));
+                        const s16x2 pr = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, R, sel));
+                        const s16x2 dk = __builtin_elementwise_max(__builtin_elementwise_min(pu, pd), __builtin_elementwise_min(pl, pr));
+                        const s16x2 br = __builtin_elementwise_min(__builtin_elementwise_max(pu, pd), __builtin_elementwise_max(pl, pr));
+                        // sign bit of a half set <=> dk < v - th  or  br > v + th
+                        fl[par] = __builtin_bit_cast(unsigned, dk - (v - TH)) | __builtin_bit_cast(unsigned, (v + TH) - br);
+                    }
+                    // signs: pixel 0 -> bit 15, pixel 1 -> 14, pixel 2 -> 31, pixel 3 -> 30; table index bits 0..3 = pixels 1, 0, 3, 2
+                    const unsigned cw = (fl[0] & 0x80008000u) | ((fl[1] >> 1) & 0x40004000u);
+                    const unsigned m4 = ((cw >> 14) & 3u) | ((cw >> 28) & 0xCu);
+                    m8 |= m4 << (4 * w);
                 }
-                const int x0 = 4 * xg, i0 = y * tw + x0;
-                // 4-bit pass mask of the lane (pixels beyond the row end / lanes beyond the last item masked off)
-                unsigned m4 = ((fl[0] >> 15) & 1u) | ((fl[1] >> 14) & 2u) | ((fl[0] >> 29) & 4u) | ((fl[1] >> 28) & 8u);
+                const int x0 = 8 * xg;
+                // pixels beyond the row end / lanes beyond the last item masked off (mask bit order as above)
                 const int nv = it0 + lane < items ? tw - x0 : 0;
-                m4 &= (1u << min(nv, 4)) - 1u;
-                // survivors of the lower lanes: the lane counts (0..4) are prefixed bit plane by bit plane
-                // (an inclusive DPP scan of the lane counts: row shifts inside the rows of 16, then the row broadcasts 15 / 31 --
-                //  six VALU adds; the first version prefixed the counts bit plane by bit plane with three ballots)
-                const int c = (int)__popc(m4);
-                int incl = c;
+                {
+                    const unsigned okpx = (1u << min(max(nv, 0), 8)) - 1u;               // bit k = pixel k is a tested pixel
+                    const unsigned sw1 = ((okpx & 0x55u) << 1) | ((okpx >> 1) & 0x55u);  // swap neighbours: table bit order
+                    m8 &= sw1;
+                }
+                const unsigned mlo = m8 & 15u, mhi = m8 >> 4;
+                const int cl = (int)__popc(mlo), cnt = (int)__popc(m8);
+                // survivors of the lower lanes: an inclusive DPP scan of the lane counts (row shifts inside the rows of 16, then
+                // the row broadcasts 15 / 31 -- six VALU adds)
+                int incl = cnt;
                 incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
                 incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
                 incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
                 incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
                 incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1 and 3
                 incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2 and 3
-                int pos = nwork + incl - c;
-                // branch-free stores: a pixel that failed writes to a scratch slot (corners[] is not in use yet)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const unsigned bit = (m4 >> j) & 1u;
-                    unsigned short* dstp = bit ? &worklist[pos] : &corners[0];
-                    *dstp = (unsigned short)(i0 + j);
-                    pos += (int)bit;
-                }
+                unsigned short* dst = worklist + (nwork + incl - cnt);
+                const unsigned e0 = lut[mlo], e1 = lut[mhi];      // byte k = position of the word's k-th survivor
+                const int i0 = (y << 7) + x0;
+                if (cl > 0) dst[0] = (unsigned short)(i0 + (int)(e0 & 0xFF));
+                if (cl > 1) dst[1] = (unsigned short)(i0 + (int)((e0 >> 8) & 0xFF));
+                if (cl > 2) dst[2] = (unsigned short)(i0 + (int)((e0 >> 16) & 0xFF));
+                if (cl > 3) dst[3] = (unsigned short)(i0 + 3);
+                dst += cl;
+                const int ch = cnt - cl;
+                if (ch > 0) dst[0] = (unsigned short)(i0 + 4 + (int)(e1 & 0xFF));
+                if (ch > 1) dst[1] = (unsigned short)(i0 + 4 + (int)((e1 >> 8) & 0xFF));
+                if (ch > 2) dst[2] = (unsigned short)(i0 + 4 + (int)((e1 >> 16) & 0xFF));
+                if (ch > 3) dst[3] = (unsigned short)(i0 + 7);
                 nwork += __builtin_amdgcn_readlane(incl, 63);
             }
         }
         __syncthreads();
-        // ---- 2. exact arc value of the survivors; corners go to the score map and the corner list
-        int ncorner = 0;
+        // ---- 2. arc value of the survivors in one polarity; corners go to the score map
+        int nsecond = 0;
         for (int k0 = 0; k0 < nwork; k0 += 64) {
             const int k = k0 + lane;
-            bool corner = false;
-            int i = 0;
-            if (k < nwork) {
-                i = worklist[k];
-                const int y = QDIV(i, invTw), x = i - y * tw;
-                const int a = fast_arc_value(&tile[(y + 3) * kTileStride + x + 3 + ph]);
-                corner = a > th;
-                if (corner) sc[(y + 1) * rw + x + 1] = (uint8_t)(a - 1);
+            const bool live = k < nwork;
+            const int i = worklist[min(k, nwork - 1)];
+            const int y = i >> 7, x = i & 127;
+            const uint8_t* p = &tile[__umul24(y + 3, kTileStride) + x + 3 + ph];
+            bool dk, br;
+            fast_candidate<kTileStride>(p, p[0], th, &dk, &br);
+            int v;
+            const int a = fast_arc_polar<kTileStride>(p, dk ? 0u : 0xFFu, &v);
+            const bool corner = live && a > th;
+            if (corner) sc[__umul24(y + 1, rw) + x + 1] = (uint8_t)(a - 1);
+            const bool again = live && dk && br && !corner;     // could still be a bright corner
+            const unsigned long long m = __ballot(again);
+            if (m) {
+                const int n2 = (int)__popcll(m);
+                if (nwork + nsecond + n2 <= maxT) {
+                    if (again) worklist[maxT - 1 - (nsecond + (int)__popcll(m & ((1ull << lane) - 1)))] = (unsigned short)i;
+                    nsecond += n2;
+                } else {   // (no room left behind the work list -- a cell of pure noise: the bright evaluation right here)
+                    const int a2 = fast_arc_polar<kTileStride>(p, 0xFFu, &v);
+                    if (again && a2 > th) sc[__umul24(y + 1, rw) + x + 1] = (uint8_t)(a2 - 1);
+                }
             }
-            const unsigned long long m = __ballot(corner);
-            if (corner) corners[ncorner + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)i;
-            ncorner += __popcll(m);
+        }
+        for (int k0 = 0; k0 < nsecond; k0 += 64) {
+            const int k = k0 + lane;
+            const int i = worklist[maxT - 1 - min(k, nsecond - 1)];
+            const int y = i >> 7, x = i & 127;
+            int v;
+            const int a = fast_arc_polar<kTileStride>(&tile[__umul24(y + 3, kTileStride) + x + 3 + ph], 0xFFu, &v);
+            if (k < nsecond && a > th) sc[__umul24(y + 1, rw) + x + 1] = (uint8_t)(a - 1);
         }
         __syncthreads();
-        // ---- 3. NMS + ordered emission
+        // ---- 3. NMS + ordered emission (a corner of score 0 is never kept: 0 > max(...) cannot hold, upstream the same)
         int total = 0;
-        for (int k0 = 0; k0 < ncorner; k0 += 64) {
+        for (int k0 = 0; k0 < nwork; k0 += 64) {
             const int k = k0 + lane;
-            bool keep = false;
-            int x = 0, y = 0, v = 0;
-            if (k < ncorner) {
-                const int i = corners[k];
-                y = QDIV(i, invTw); x = i - y * tw;
-                const uint8_t* q = &sc[(y + 1) * rw + x + 1];
-                v = q[0];
-                const int m = max(max3i(q[-rw - 1], q[-rw], q[-rw + 1]), max(max(q[-1], q[1]), max3i(q[rw - 1], q[rw], q[rw + 1])));
-                keep = v > m;
-            }
-            const unsigned long long m = __ballot(keep);
+            const int i = worklist[min(k, nwork - 1)];
+            const int y = i >> 7, x = i & 127;
+            const uint8_t* q = &sc[__umul24(y + 1, rw) + x + 1];
+            const int v = q[0];
+            const unsigned long long cm = __ballot(k < nwork && v > 0);
+            if (cm == 0) continue;
+            const int m = max(max3i(q[-rw - 1], q[-rw], q[-rw + 1]), max(max(q[-1], q[1]), max3i(q[rw - 1], q[rw], q[rw + 1])));
+            const bool keep = k < nwork && v > m;
+            const unsigned long long km = __ballot(keep);
             if (keep) {
-                const int pos = total + __popcll(m & ((1ull << lane) - 1));
+                const int pos = total + __popcll(km & ((1ull << lane) - 1));
                 if (pos < cellCap) out[pos] = (unsigned)(x + 3 + c.offX) | ((unsigned)(y + 3 + c.offY) << 12) | ((unsigned)v << 24);
             }
-            total += __popcll(m);
+            total += __popcll(km);
         }
         if (total > 0 || pass == 1) {
             if (lane == 0) cellcnt[slot] = min(total, cellCap);
@@ -1415,8 +1469,10 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     g.pyrFrameBytes = off;
     g.scanCap = scanCap;
     g.fastMaxTested = std::max(1, (maxSw - 6) * (maxSh - 6));
-    g.fastTileBytes = ((maxSh * kTileStride) + 15) & ~15;
-    g.fastLdsBytes = g.fastTileBytes + (g.fastMaxTested + 1) * 4 + ((((maxSw - 4) * (maxSh - 4)) + 15) & ~15);
+    // tile | work list u16[maxT] (+ the second list, stacked from its end) | score map | 16-word survivor-position table
+    g.fastStride = maxSw + 3 <= 48 ? 48 : kTileStrideWide;
+    g.fastTileBytes = ((maxSh * g.fastStride) + 15) & ~15;
+    g.fastLdsBytes = g.fastTileBytes + (((g.fastMaxTested + 1) * 2 + 3) & ~3) + ((((maxSw - 4) * (maxSh - 4)) + 15) & ~15) + 64;
     // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
     h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (size_t)scanCap * sizeof(int);
     EAO_REQUIRE(h->quadLds <= 150 * 1024, "nfeatures too large: quad-tree needs %zu bytes of LDS", h->quadLds);
@@ -1531,12 +1587,11 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         auto fast = [&](hipStream_t str, int first, int end) {
             static const int envAff = getenv("EAO_FAST_AFFINITY") ? atoi(getenv("EAO_FAST_AFFINITY")) : 1;
             const int aff = envAff && (nb & 7) == 0 ? 1 : 0;
-            if (first == 0 && end == g.totalCells)
-                hipLaunchKernelGGL(k_fast_cells<true>, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
-                                   h->d_cellcand.p, h->d_cellcnt.p, f0, first, end, aff);
-            else
-                hipLaunchKernelGGL(k_fast_cells<false>, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
-                                   h->d_cellcand.p, h->d_cellcnt.p, f0, first, end, aff);
+            const bool whole = first == 0 && end == g.totalCells, narrow = g.fastStride == 48;
+            auto* kern = whole ? (narrow ? k_fast_cells<true, 48> : k_fast_cells<true, kTileStrideWide>)
+                               : (narrow ? k_fast_cells<false, 48> : k_fast_cells<false, kTileStrideWide>);
+            hipLaunchKernelGGL(kern, dim3(128 * ((end - first + 127) / 128), nb), dim3(64), g.fastLdsBytes, str, h->d_geom.p, h->d_cells.p, s,
+                               h->d_cellcand.p, h->d_cellcnt.p, f0, first, end, aff);
         };
         // Schedule of a (non-profiled) batch -- FAST and the blur are both VALU-bound, the quad-tree leaves the machine
         // almost idle, so the blur runs beside the quad-tree, not beside FAST:
