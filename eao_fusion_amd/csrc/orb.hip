@@ -240,14 +240,18 @@ __device__ __forceinline__ int fast_arc_polar(const uint8_t* p, unsigned s, int*
     *centre = p[0];
 #pragma unroll
     for (int k = 0; k < 16; k++) q[k] ^= s;
-    int hi3[16];
+    // (v_max3 / v_min3 spelled out: left to itself the compiler re-associates the 32 three-input maxima into 24 + 15 two-input ones)
+    auto mx3 = [](unsigned a, unsigned b, unsigned c) { unsigned r; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+    auto mn3 = [](unsigned a, unsigned b, unsigned c) { unsigned r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+    unsigned hi3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) hi3[k] = max3i((int)q[k], (int)q[(k + 1) & 15], (int)q[(k + 2) & 15]);
-    int w9[16];
+    for (int k = 0; k < 16; k++) hi3[k] = mx3(q[k], q[(k + 1) & 15], q[(k + 2) & 15]);
+    unsigned w9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) w9[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
-    const int m = min3i(min3i(min3i(w9[0], w9[1], w9[2]), min3i(w9[3], w9[4], w9[5]), min3i(w9[6], w9[7], w9[8])),
-                        min3i(min3i(w9[9], w9[10], w9[11]), min3i(w9[12], w9[13], w9[14]), w9[15]), 255);
+    for (int k = 0; k < 16; k++) w9[k] = mx3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+    const unsigned m5 = mn3(w9[12], w9[13], w9[14]);
+    const unsigned ma = mn3(mn3(w9[0], w9[1], w9[2]), mn3(w9[3], w9[4], w9[5]), mn3(w9[6], w9[7], w9[8]));
+    const int m = (int)mn3(ma, mn3(w9[9], w9[10], w9[11]), min(m5, w9[15]));
     return (int)((unsigned)*centre ^ s) - m;
 }
 
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     uint8_t* tile = fsm;                                // fastTileBytes
     unsigned short* worklist = reinterpret_cast<unsigned short*>(fsm + g->fastTileBytes);
     // (survivors that wait for their bright evaluation are stacked downwards from the end of the same buffer)
-    unsigned* sc4 = reinterpret_cast<unsigned*>(worklist + maxT + (maxT & 1));   // score map (tw+2) x (th+2) bytes, word aligned
+    unsigned* sc4 = reinterpret_cast<unsigned*>(fsm + g->fastTileBytes + ((2 * maxT + 15) & ~15));   // score map (tw+2) x (th+2) bytes, 16-byte aligned
     uint8_t* sc = reinterpret_cast<uint8_t*>(sc4);
     unsigned* lut = reinterpret_cast<unsigned*>(fsm + g->fastLdsBytes - 64);        // 16 words
     int pitch;
@@ -336,19 +340,21 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     const float invSw = __builtin_amdgcn_rcpf((float)sw);
     const int x0a = c.x0 & ~3, ph = c.x0 - x0a;
     if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
-        const int nw = (c.x0 + sw + 3 - x0a) >> 2;   // words per row
-        const float invNw = __builtin_amdgcn_rcpf((float)nw);
-        // the lane's words are 64 apart in the row-major word sequence of the tile: (row, word) advance by (64 / nw, 64 % nw)
+        const int np = (c.x0 + sw + 7 - x0a) >> 3;   // word PAIRS per row (the odd word of a row lands in the row's padding)
+        const float invNp = __builtin_amdgcn_rcpf((float)np);
+        // the lane's pairs are 64 apart in the row-major pair sequence of the tile: (row, pair) advance by (64 / np, 64 % np)
         // with a carry, so one division per lane serves the whole loop and the addresses are running 32-bit offsets
-        int y = QDIV(lane, invNw), xw = lane - y * nw;
-        const int q = QDIV(64, invNw), rem = 64 - q * nw;
-        unsigned goff = (unsigned)((c.y0 + y) * pitch + x0a + 4 * xw), loff = (unsigned)(y * kTileStride + 4 * xw);
-        const unsigned gstep = (unsigned)(q * pitch + 4 * rem), lstep = (unsigned)(q * kTileStride + 4 * rem);
-        const unsigned gwrap = (unsigned)(pitch - 4 * nw), lwrap = (unsigned)(kTileStride - 4 * nw);
-        for (int i = lane; i < nw * sh; i += 64) {
-            *reinterpret_cast<unsigned*>(&tile[loff]) = *reinterpret_cast<const unsigned*>(src + goff);
+        int y = QDIV(lane, invNp), xw = lane - y * np;
+        const int q = QDIV(64, invNp), rem = 64 - q * np;
+        unsigned goff = (unsigned)((c.y0 + y) * pitch + x0a + 8 * xw), loff = (unsigned)(y * kTileStride + 8 * xw);
+        const unsigned gstep = (unsigned)(q * pitch + 8 * rem), lstep = (unsigned)(q * kTileStride + 8 * rem);
+        const unsigned gwrap = (unsigned)(pitch - 8 * np), lwrap = (unsigned)(kTileStride - 8 * np);
+        for (int i = lane; i < np * sh; i += 64) {
+            const unsigned w0 = *reinterpret_cast<const unsigned*>(src + goff), w1 = *reinterpret_cast<const unsigned*>(src + goff + 4);
+            *reinterpret_cast<unsigned*>(&tile[loff]) = w0;
+            *reinterpret_cast<unsigned*>(&tile[loff + 4]) = w1;
             xw += rem; goff += gstep; loff += lstep;
-            if (xw >= nw) { xw -= nw; goff += gwrap; loff += lwrap; }
+            if (xw >= np) { xw -= np; goff += gwrap; loff += lwrap; }
         }
     } else {
         for (int i = lane; i < sw * sh; i += 64) {
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     unsigned* out = cellcand + slot * cellCap;
     for (int pass = 0; pass < 2; pass++) {
         const int th = min(max(pass ? thMin : thIni, 0), 255);
-        for (int i = lane; i < scWords; i += 64) sc4[i] = 0;
+        for (int i = lane; i < ((scWords + 3) >> 2); i += 64) reinterpret_cast<uint4*>(sc4)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();   // tile staged (first pass) / previous pass done with sc
         // ---- 1. candidate test, EIGHT horizontally adjacent pixels per lane (two words): aligned LDS words of the rows three
         // up, three down and of the centre row (left / centre / right windows) shifted into place with v_alignbyte, bytes
@@ -1472,7 +1478,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     // tile | work list u16[maxT] (+ the second list, stacked from its end) | score map | 16-word survivor-position table
     g.fastStride = maxSw + 3 <= 48 ? 48 : kTileStrideWide;
     g.fastTileBytes = ((maxSh * g.fastStride) + 15) & ~15;
-    g.fastLdsBytes = g.fastTileBytes + (((g.fastMaxTested + 1) * 2 + 3) & ~3) + ((((maxSw - 4) * (maxSh - 4)) + 15) & ~15) + 64;
+    g.fastLdsBytes = g.fastTileBytes + ((2 * g.fastMaxTested + 15) & ~15) + ((((maxSw - 4) * (maxSh - 4)) + 15) & ~15) + 64;
     // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
     h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (size_t)scanCap * sizeof(int);
     EAO_REQUIRE(h->quadLds <= 150 * 1024, "nfeatures too large: quad-tree needs %zu bytes of LDS", h->quadLds);
