@@ -96,6 +96,7 @@ SYMBOLS = {
     "eao_compute_stereo_matches": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, C.c_float, C.c_float, _P, _P]),
     "eao_pose_optimization": (_I, [C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
     "eao_local_ba": (_I, [C.POINTER(BAProblem), _P, C.POINTER(BAResult)]),
+    "eao_local_ba_batch": (_I, [C.POINTER(BAProblem), _I, _P, C.POINTER(BAResult)]),
     "eao_bundle_adjustment": (_I, [C.POINTER(BAProblem), _I, _P, C.POINTER(BAResult)]),
     "eao_bundle_adjustment_planes": (_I, [C.POINTER(BAProblem), C.POINTER(BAPlanes), _I, _P, C.POINTER(BAResult), _P]),
     "eao_last_lm_trace": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),

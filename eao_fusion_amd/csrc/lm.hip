@@ -33,6 +33,11 @@
 #include <cstring>
 #include <vector>
 
+#include <atomic>
+#include <memory>
+#include <string>
+#include <thread>
+
 #include "common.h"
 
 namespace {
@@ -218,9 +223,9 @@ __device__ __forceinline__ double quad_sum(double v) {   // sum over the four la
 // Fixed-order sum of NV accumulators over a block of NT threads through LDS: lane quads first (DPP), then NV x 8 column
 // threads over NT/32 quad leaders each, then the last 8.  red: (NT/4)*NV doubles, part: 8*NV doubles; the totals land in
 // part[0 .. NV).  (A 64-lane shuffle tree per value costs ~230 cycles per value; this is ~10x cheaper for NV ~ 28.)
-template <int NV, int NT>
+template <int NV, int NT, int SEGS = 8>
 __device__ inline void block_sum_lds(double (&acc)[NV], double* red, double* part) {
-    static_assert(NV * 8 <= NT, "column threads");
+    static_assert(NV * SEGS <= NT && SEGS <= 8 && (NT / 4) % SEGS == 0, "column threads");
 #pragma unroll
     for (int q = 0; q < NV; q++) acc[q] = quad_sum(acc[q]);
     if ((threadIdx.x & 3) == 0) {
@@ -229,8 +234,8 @@ __device__ inline void block_sum_lds(double (&acc)[NV], double* red, double* par
         for (int q = 0; q < NV; q++) dst[q] = acc[q];
     }
     __syncthreads();
-    constexpr int kSeg = NT / 4 / 8;
-    if (threadIdx.x < NV * 8) {
+    constexpr int kSeg = NT / 4 / SEGS;
+    if (threadIdx.x < NV * SEGS) {
         const int q = threadIdx.x % NV, seg = threadIdx.x / NV;
         double sacc = 0;
         for (int j = 0; j < kSeg; j++) sacc += red[(seg * kSeg + j) * NV + q];
@@ -239,7 +244,7 @@ __device__ inline void block_sum_lds(double (&acc)[NV], double* red, double* par
     __syncthreads();
     if (threadIdx.x < NV) {
         double sacc = 0;
-        for (int seg = 0; seg < 8; seg++) sacc += part[seg * NV + threadIdx.x];
+        for (int seg = 0; seg < SEGS; seg++) sacc += part[seg * NV + threadIdx.x];
         part[threadIdx.x] = sacc;                  // only this thread reads or writes these eight slots
     }
     __syncthreads();
@@ -966,7 +971,37 @@ struct BADev {
     const int* lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
     const int* lpPts;       // landmark blocks of each pair, ascending
     int nPairsNZ;
+    // per-window addresses every kernel finds HERE (the kernels take an array of windows and blockIdx.z, see BA_WIN)
+    int* ctl0;              // the two control blocks (8 ints each); a launch runs on ctl0 + 8 * par
+    double* lm0;            // the two LM blocks (8 doubles each)
+    int* solveOk;
+    struct BAStatus* status;   // pinned host memory
+    unsigned char* cls;     // E: outlier table of the pass between the two optimize() calls
+    SE3* outCams; double* outPts; unsigned char* outCls; double* outPlanes;   // pinned results (k_ba_finish)
 };
+
+// Every BA kernel takes the device array of window records: workgroup (x, y, z) works on window z, on the control / LM block
+// pair `wpar` of that window (BADecision).  The array holds TWO records per window that differ only in ctl / lm (pair 0 and
+// pair 1), so a kernel reads its record in place -- uniform, read-only loads on the scalar unit, exactly like kernel
+// arguments (a local copy with the two pointers patched went through scratch memory: 1.17 -> 2.2 ms per window).  A single
+// window is a batch of one.
+// Batches pin every window to one XCD (speed only, any placement gives the same results): workgroups are dealt round-robin
+// over the 8 XCDs in dispatch order, so with the plain (x = block, z = window) numbering the ~5 MB a window keeps re-reading
+// (Hpl blocks, residuals, the edge table) would be pulled into all eight L2s -- 25 windows are then fabric-bound (the pair
+// assembly alone moved 350 MB per launch).  Window w is served by XCD w % 8 only; the launch pads grid.z to a multiple of 8.
+// wpar = block pair | number of windows << 8;  bx = this workgroup's block index inside its window.
+#define BA_WIN(P)                                                                                                   \
+    unsigned bx = blockIdx.x, wz_ = blockIdx.z;                                                                     \
+    {                                                                                                               \
+        const unsigned nz_ = (unsigned)wpar >> 8;                                                                   \
+        if (nz_ > 1) {                                                                                              \
+            const unsigned b_ = blockIdx.x + gridDim.x * blockIdx.z, s_ = b_ >> 3;                                  \
+            wz_ = (b_ & 7) + 8 * (s_ / gridDim.x);                                                                  \
+            bx = s_ % gridDim.x;                                                                                    \
+            if (wz_ >= nz_) return;                                                                                 \
+        }                                                                                                           \
+    }                                                                                                               \
+    const BADev& P = W[2 * wz_ + (wpar & 1)]
 
 enum { kCtlHalt = 0, kCtlCur = 1, kCtlIters = 2, kCtlStatus = 3, kCtlNBad = 4, kCtlPhase = 5, kCtlAnyActive = 6 };   // phase: 0 / 1 = first / second optimize()
 enum { kStRunning = 0, kStTakeover = 1, kStTerminate = 2, kStEmpty = 3 };   // empty: no level-0 edge left (g2o's optimize() returns -1)
@@ -1062,8 +1097,9 @@ __device__ inline void plane_jac_pose(const SE3& T, const double* pl, const doub
 // Eight lanes per landmark, one edge per lane (points with more than 8 active edges loop): the per-point sums are
 // 3-step xor trees inside the lane group.
 template <bool PL>
-__global__ __launch_bounds__(256) void k_ba_errors(BADev P) {
-    const int l = (blockIdx.x * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+__global__ __launch_bounds__(256) void k_ba_errors(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    const int l = (bx * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
     if (P.ctl[kCtlHalt]) return;
     const bool live = l < P.nL;
     const int pt = live ? P.actPt[l] : 0;
@@ -1108,7 +1144,9 @@ __device__ inline double ordered_sum(const double* part, int n, double* red, dou
     return *out1;
 }
 
-__global__ __launch_bounds__(256) void k_ba_chi_init(BADev P, BAStatus* st, int seq) {
+__global__ __launch_bounds__(256) void k_ba_chi_init(const BADev* __restrict__ W, int wpar, int seq) {
+    BA_WIN(P);
+    BAStatus* const st = P.status;
     __shared__ double red[4], out1;
     if (P.ctl[kCtlHalt]) return;
     if (P.ctl[kCtlPhase] == 1 && !P.ctl[kCtlAnyActive]) {   // initializeOptimization(0) found nothing: optimize() returns -1
@@ -1213,14 +1251,19 @@ constexpr int kLinThreads = 1024;
 // ctlOld != nullptr: the previous trial's decision has not been taken yet (bulk segment): see BADecision.  P.ctl / P.lm
 // are then the blocks this trial runs on (written by workgroup 0 here), ctlOld / lmOld the ones the previous trial ran on.
 template <bool PL>
-__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlocks, int first, const int* ctlOld, const double* lmOld,
-                                                              const int* solveOk, BAStatus* st, int seq) {
+__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(const BADev* __restrict__ W, int wpar, int ptBlocks, int first, int parOld, int seq) {
+    BA_WIN(P);
+    const int* const ctlOld = parOld >= 0 ? P.ctl0 + 8 * parOld : nullptr;
+    const double* const lmOld = parOld >= 0 ? P.lm0 + 8 * parOld : nullptr;
+    const int* const solveOk = P.solveOk;
+    BAStatus* const st = P.status;
+    if ((int)bx >= ptBlocks + P.nFree) return;      // (a batch is launched with the largest window's grid)
     __shared__ double red[(kLinThreads / 4) * 27], part[8 * 27];
     __shared__ double s_wmax[kLinThreads / 64];
     int cur;
     if (ctlOld) {
         if (ctlOld[kCtlHalt]) {   // frozen stream: hand the control block on unchanged
-            if (blockIdx.x == 0 && threadIdx.x < 8) { P.ctl[threadIdx.x] = ctlOld[threadIdx.x]; P.lm[threadIdx.x] = lmOld[threadIdx.x]; }
+            if (bx == 0 && threadIdx.x < 8) { P.ctl[threadIdx.x] = ctlOld[threadIdx.x]; P.lm[threadIdx.x] = lmOld[threadIdx.x]; }
             return;
         }
         double v[2] = {0, 0};
@@ -1229,7 +1272,7 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
         block_sum<2, kLinThreads>(v, red, part);
         const BADecision d = ba_decision(lmOld, ctlOld, part[0], lmOld[4] + part[1], *solveOk, 1);   // the same in every workgroup
         __syncthreads();   // (red / part are reused below)
-        if (blockIdx.x == 0 && threadIdx.x == 0) ba_commit(d, lmOld, ctlOld, P.lm, P.ctl, st, seq, 1);
+        if (bx == 0 && threadIdx.x == 0) ba_commit(d, lmOld, ctlOld, P.lm, P.ctl, st, seq, 1);
         if (d.halt) return;
         cur = d.cur;
     } else {
@@ -1238,9 +1281,9 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
     }
     const SE3* cams = P.camsBuf[cur];
     const double* pts = P.ptsBuf[cur];
-    if ((int)blockIdx.x < ptBlocks) {
+    if ((int)bx < ptBlocks) {
         // role A: eight lanes per landmark, one edge per lane; Hll / bl are xor-tree sums over the lane group
-        const int l = (blockIdx.x * kLinThreads + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+        const int l = (bx * kLinThreads + threadIdx.x) >> 3, slot = threadIdx.x & 7;
         const bool live = l < P.nL;
         const int pt = live ? P.actPt[l] : 0;
         const int beg = live ? P.ptStart[l] : 0, end = live ? P.ptStart[l + 1] : 0;
@@ -1308,7 +1351,7 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
             }
         }
     } else {
-        const int ci = blockIdx.x - ptBlocks;
+        const int ci = bx - ptBlocks;
         const int cam = P.actCam[ci];
         const SE3 T = cams[cam];
         double acc[27];
@@ -1366,7 +1409,8 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(BADev P, int ptBlo
 }
 
 // lambda_0 = 1e-5 * max |diag| over every active vertex (optimization_algorithm_levenberg.cpp:166-180)
-__global__ __launch_bounds__(256) void k_ba_lambda_init(BADev P) {
+__global__ __launch_bounds__(256) void k_ba_lambda_init(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
     __shared__ double red[4];
     if (P.ctl[kCtlHalt]) return;
     double m = 0;
@@ -1411,10 +1455,11 @@ constexpr int kSchurMaxFree = 64;      // free keyframes per window
 constexpr int kSchurThreads = 1024;
 constexpr int kSchurMaxOut = (kSchurMaxFree * 36 + 6 + kSchurThreads - 1) / kSchurThreads;
 __host__ __device__ inline int schur_batch_edges(int nF) { return min(32, kSchurSlots / max(nF, 1)); }   // 32: one hit-mask word
-__global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BADev P, int first) {
+__global__ __launch_bounds__(kSchurThreads) void k_ba_schur(const BADev* __restrict__ W, int wpar, int first) {
+    BA_WIN(P);
     extern __shared__ __attribute__((aligned(16))) double schurLds[];
     if (P.ctl[kCtlHalt]) return;
-    const int i1 = blockIdx.x, chunk = blockIdx.y, t = threadIdx.x;
+    const int i1 = bx, chunk = blockIdx.y, t = threadIdx.x;
     const int nF = P.nFree, rowLen = nF * 36 + 6;
     const int EB = schur_batch_edges(nF);
     double* sB = schurLds;                                   // [EB * nF][18]
@@ -1522,12 +1567,13 @@ __host__ inline size_t schur_lds_bytes(int nF) {
 // Sum the kChunks partial slabs in chunk order, add Hpp + lambda I and the right-hand side: one dense n x (n+1) system
 // (upper triangle) in global memory.  Many workgroups: a single CU can only pull ~10 B/clk from L2, so letting the
 // solver's lone workgroup read all slabs itself cost 16 us.
-__global__ __launch_bounds__(256) void k_ba_reduce_slabs(BADev P) {
+__global__ __launch_bounds__(256) void k_ba_reduce_slabs(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
     if (P.ctl[kCtlHalt]) return;
     const int nF = P.nFree, n = nF * 6, ld = n + 1;
     const size_t slabStride = (size_t)n * n + n;
     const double lambda = P.lm[0];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = bx * 256 + threadIdx.x;
     if (idx >= n * ld) return;
     const int row = idx / ld, col = idx - row * ld;
     double v = 0;
@@ -1558,7 +1604,9 @@ constexpr int kSolveThreads = 512;   // 8 waves: 256 VGPRs per lane keep the pan
 // IN_LDS = true: the system lives in LDS (up to 22 free keyframes); false: in L2-resident global scratch.  Two
 // instantiations so that each uses its own address space (a runtime-selected pointer would degrade to flat loads).
 template <bool IN_LDS>
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BADev P, int* solveOk) {
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    int* const solveOk = P.solveOk;
     extern __shared__ double sm[];
     const int nF = P.nFree, n = nF * 6, t = threadIdx.x;
     const int ld = ((n + 32) & ~31) + 1;        // row stride: >= n + 1 (column n = right-hand side) and == 1 (mod 32) doubles, so a
@@ -1761,13 +1809,15 @@ __host__ __device__ inline int pair_index(int i1, int i2, int nF) { return i1 * 
 constexpr int kPairThreads = 512;    // 1024 threads (one landmark per thread on the diagonal pairs) spill the 42 accumulators: 36.6 us vs 13.5
 
 // landmark lists of the camera pairs (once per window; the outlier pass only clears table entries, which the assembly re-checks)
-__global__ __launch_bounds__(256) void k_ba_pairs(BADev P) {
+__global__ __launch_bounds__(256) void k_ba_pairs(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    if ((int)bx >= P.nFree * (P.nFree + 1) / 2) return;
     __shared__ int s_base;
     const int nF = P.nFree, t = threadIdx.x, lane = t & 63;
-    int i1 = 0, rem = blockIdx.x;
+    int i1 = 0, rem = bx;
     while (rem >= nF - i1) { rem -= nF - i1; i1++; }
     const int i2 = i1 + rem;
-    int* out = P.pairPts + (size_t)blockIdx.x * P.nL;
+    int* out = P.pairPts + (size_t)bx * P.nL;
     if (t == 0) s_base = 0;
     __syncthreads();
     for (int l0 = 0; l0 < P.nL; l0 += 256) {
@@ -1785,13 +1835,14 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BADev P) {
         if (t == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
     }
-    if (t == 0) P.pairCnt[blockIdx.x] = s_base;
+    if (t == 0) P.pairCnt[bx] = s_base;
 }
 
 // zero / identity background of the tile system (entries no pair block owns never change during a window)
-__global__ __launch_bounds__(256) void k_ba_tiles_init(BADev P) {
+__global__ __launch_bounds__(256) void k_ba_tiles_init(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
     const TileGeom g = tile_geom(P.nFree);
-    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int o = bx * 256 + threadIdx.x;
     if (o >= g.nTiles * 256) return;
     const int idx = o >> 8, reg = (o >> 6) & 3, lane = o & 63;
     int ti, tj;
@@ -1807,18 +1858,22 @@ __device__ __forceinline__ void tile_store(const BADev& P, const TileGeom& g, in
     P.sys[(size_t)tileIdx * 256 + (rr >> 2) * 64 + (rr & 3) * 16 + cc] = v;
 }
 
-__global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(BADev P, int first) {
+// (a) ONE window: one thread per landmark, 512 threads -- the 210 workgroups of a 20-keyframe window have the chip to
+//     themselves, so the 194 VGPRs (two waves per SIMD) of 42 accumulators per thread cost nothing and the launch is as
+//     short as its slowest workgroup (13.8 us).
+__global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(const BADev* __restrict__ W, int wpar, int first) {
+    BA_WIN(P);
     __shared__ double red[(kPairThreads / 4) * 42], part[8 * 42];
     if (P.ctl[kCtlHalt]) return;
     const int nF = P.nFree, t = threadIdx.x;
-    int i1 = 0, rem = blockIdx.x;
+    int i1 = 0, rem = bx;
     while (rem >= nF - i1) { rem -= nF - i1; i1++; }
     const int i2 = i1 + rem;
     const bool diag = i1 == i2;
     const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
-    if (first && blockIdx.x == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
-    const int cnt = P.pairCnt[blockIdx.x];
-    const int* pts = P.pairPts + (size_t)blockIdx.x * P.nL;
+    if (first && bx == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
+    const int cnt = P.pairCnt[bx];
+    const int* pts = P.pairPts + (size_t)bx * P.nL;
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; q++) acc[q] = 0;
@@ -1863,11 +1918,101 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(BADev P, int fi
     }
 }
 
+// (b) A BATCH of windows (5 250 workgroups for 25 windows) is bound by workgroup latency x rounds: two threads per landmark
+//     (thread t < NT / 2 accumulates rows 0..2 of the pair's 6x6 block and of its right-hand side, thread t + NT / 2 rows
+//     3..5: 21 accumulators, 128 VGPRs) in 256-thread workgroups, four of which fit a CU instead of two.  Measured, 25
+//     windows per launch: (a) 152 us, (a) with 256 threads 106 us, two threads per landmark in 512-thread workgroups 112 us,
+//     this 58 us; staging the operands through LDS with cooperative loads 156 us, pinning windows to XCDs no change.
+constexpr int kPairThreadsB = 256;
+__global__ __launch_bounds__(kPairThreadsB, 4) void k_ba_schur_pairs_b(const BADev* __restrict__ W, int wpar, int first) {
+    BA_WIN(P);
+    if ((int)bx >= P.nFree * (P.nFree + 1) / 2) return;
+    constexpr int NT = kPairThreadsB, kHalf = NT / 2, kLeaders = NT / 4;     // quad leaders: the first kLeaders / 2 belong to rows 0..2
+    __shared__ double red[kLeaders * 21], part[4 * 42];
+    if (P.ctl[kCtlHalt]) return;
+    const int nF = P.nFree, t = threadIdx.x;
+    int i1 = 0, rem = bx;
+    while (rem >= nF - i1) { rem -= nF - i1; i1++; }
+    const int i2 = i1 + rem;
+    const bool diag = i1 == i2;
+    const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
+    if (first && bx == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
+    const int cnt = P.pairCnt[bx];
+    const int* pts = P.pairPts + (size_t)bx * P.nL;
+    const int half = t >= kHalf ? 1 : 0;
+    double acc[21];
+#pragma unroll
+    for (int q = 0; q < 21; q++) acc[q] = 0;
+    for (int k = t - half * kHalf; k < cnt; k += kHalf) {
+        const int l = pts[k];
+        const int e1 = P.table[(size_t)l * nF + i1], e2 = P.table[(size_t)l * nF + i2];
+        if (e1 < 0 || e2 < 0) continue;                      // deactivated by the outlier pass
+        double Di[9];
+        dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
+        const double* B1 = &P.Hpl[(size_t)e1 * 18 + 9 * half];
+        const double* B2 = &P.Hpl[(size_t)e2 * 18];
+        double b2[18];
+#pragma unroll
+        for (int q = 0; q < 18; q++) b2[q] = B2[q];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const double h0 = B1[r * 3], h1 = B1[r * 3 + 1], h2 = B1[r * 3 + 2];
+            const double y0 = h0 * Di[0] + h1 * Di[3] + h2 * Di[6];
+            const double y1 = h0 * Di[1] + h1 * Di[4] + h2 * Di[7];
+            const double y2 = h0 * Di[2] + h1 * Di[5] + h2 * Di[8];
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[r * 6 + c] -= y0 * b2[c * 3] + y1 * b2[c * 3 + 1] + y2 * b2[c * 3 + 2];
+            if (diag) {
+                const double* bl = &P.bl[(size_t)l * 3];
+                acc[18 + r] += y0 * bl[0] + y1 * bl[1] + y2 * bl[2];     // Hpl (Dinv bl), row 3 half + r
+            }
+        }
+    }
+    // fixed-order sum: lane quads (DPP), then 42 x 4 column threads over a quarter of their half's quad leaders each, then
+    // the last four.  Value q < 18: S[3 half + q / 6][q % 6]; q = 18..20: right-hand side row 3 half + q - 18.
+#pragma unroll
+    for (int q = 0; q < 21; q++) acc[q] = quad_sum(acc[q]);
+    if ((t & 3) == 0) {
+        double* dst = red + (t >> 2) * 21;
+#pragma unroll
+        for (int q = 0; q < 21; q++) dst[q] = acc[q];
+    }
+    __syncthreads();
+    if (t < 42 * 4) {
+        const int v = t % 42, seg = t / 42, h = v >= 21 ? 1 : 0, q = v - 21 * h;
+        constexpr int kSeg = kLeaders / 2 / 4;
+        const double* src = red + (size_t)(h * (kLeaders / 2) + seg * kSeg) * 21 + q;
+        double sacc = 0;
+        for (int j = 0; j < kSeg; j++) sacc += src[j * 21];
+        part[seg * 42 + v] = sacc;
+    }
+    __syncthreads();
+    double tot = 0;
+    if (t < 42) tot = ((part[t] + part[42 + t]) + part[84 + t]) + part[126 + t];
+    const TileGeom g = tile_geom(nF);
+    if (t < 42) {
+        const int h = t >= 21 ? 1 : 0, q = t - 21 * h;
+        if (q < 18) {
+            const int r = 3 * h + q / 6, c = q % 6;
+            if (!diag) {
+                tile_store(P, g, i2 * 6 + c, i1 * 6 + r, tot);            // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
+            } else if (c >= r) {
+                const double v = tot + P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+                tile_store(P, g, i1 * 6 + c, i1 * 6 + r, v);              // the upper-triangle value, mirrored into the lower tile
+            }
+        } else if (diag) {
+            const int r = 3 * h + q - 18;
+            tile_store(P, g, g.n4, i1 * 6 + r, P.bp[i1 * 6 + r] - tot);   // right-hand side row
+        }
+    }
+}
+
 // Sum the partial slabs straight into the solver's register layout: [tile][reg][lane].
-__global__ __launch_bounds__(256) void k_ba_reduce_tiles(BADev P) {
+__global__ __launch_bounds__(256) void k_ba_reduce_tiles(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
     if (P.ctl[kCtlHalt]) return;
     const TileGeom g = tile_geom(P.nFree);
-    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int o = bx * 256 + threadIdx.x;
     if (o >= g.nTiles * 256) return;
     const int idx = o >> 8, reg = (o >> 6) & 3, lane = o & 63;
     int ti, tj;
@@ -1898,7 +2043,9 @@ __global__ __launch_bounds__(256) void k_ba_reduce_tiles(BADev P) {
 }
 
 template <int TPW>
-__global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(BADev P, int* solveOk) {
+__global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    int* const solveOk = P.solveOk;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int s_fail;
     if (P.ctl[kCtlHalt]) return;
@@ -2098,21 +2245,22 @@ __host__ __device__ inline BigGeom big_geom(int nF) {
 }
 
 constexpr int kBigPairThreads = 512;   // (block_sum_lds needs 8 column threads per value)
-__global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(BADev P, int first) {
+__global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(const BADev* __restrict__ W, int wpar, int first) {
+    BA_WIN(P);
     __shared__ double red[(kBigPairThreads / 4) * 42], part[8 * 42];
     if (P.ctl[kCtlHalt]) return;
     const int nF = P.nFree, t = threadIdx.x;
     const BigGeom g = big_geom(nF);
     const size_t ld = g.RP;
-    const int i1 = P.lpPair[2 * blockIdx.x], i2 = P.lpPair[2 * blockIdx.x + 1];
+    const int i1 = P.lpPair[2 * bx], i2 = P.lpPair[2 * bx + 1];
     const bool diag = i1 == i2;
     const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
         if (first && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
         if (t == 0) *P.bigFail = 0;
         for (int r = g.n + t; r < g.N; r += kBigPairThreads) P.big[(size_t)r * ld + r] = 1.0;     // identity padding
     }
-    const int beg = P.lpStart[blockIdx.x], cnt = P.lpStart[blockIdx.x + 1] - beg;
+    const int beg = P.lpStart[bx], cnt = P.lpStart[bx + 1] - beg;
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; q++) acc[q] = 0;
@@ -2189,7 +2337,8 @@ __device__ inline void bal_store_diag_wave(const BADev& P, int kb, const double 
 }
 
 // first diagonal block of a trial (the following ones are factored by the update kernel of the panel before them)
-__global__ __launch_bounds__(64) void k_bal_diag0(BADev P) {
+__global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
     if (P.ctl[kCtlHalt]) return;
     const size_t ld = big_geom(P.nFree).RP;
     const int i = threadIdx.x & 31;
@@ -2208,7 +2357,8 @@ __global__ __launch_bounds__(64) void k_bal_diag0(BADev P) {
 // tile that still reads a and one that would overwrite it with l).  The tile that holds the NEXT diagonal block factors it on
 // the spot (one wavefront, see above), so the next launch starts from a finished L_kk.  The first version ran the row solves
 // as a launch of their own: two dependent launches per panel instead of one (12 + 13 us at 40 free keyframes).
-__global__ __launch_bounds__(256) void k_bal_step(BADev P, int kb, int last) {
+__global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, int wpar, int kb, int last) {
+    BA_WIN(P);
     __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double a[kBigNB][kBigNB];
@@ -2218,7 +2368,7 @@ __global__ __launch_bounds__(256) void k_bal_step(BADev P, int kb, int last) {
     const size_t ld = g.RP;
     const int k0 = kb * kBigNB, t = threadIdx.x;
     const int tj0 = (k0 + kBigNB) >> 6;
-    const int tj = tj0 + blockIdx.x, ti = tj0 + blockIdx.y;
+    const int tj = tj0 + bx, ti = tj0 + blockIdx.y;
     if (ti < tj) return;
     const int r0 = ti * 64, c0 = tj * 64;
     double* S = P.big;
@@ -2258,7 +2408,7 @@ __global__ __launch_bounds__(256) void k_bal_step(BADev P, int kb, int last) {
         if (roleW) {
 #pragma unroll
             for (int k = 0; k < kBigNB; k++) Wt[k][t] = w[k];
-            if (blockIdx.x == 0 && act) {
+            if (bx == 0 && act) {
                 double* ldst = P.bigL + (size_t)prow * ld + k0;
 #pragma unroll
                 for (int k = 0; k < kBigNB; k++) ldst[k] = w[k] * a[k][k];
@@ -2284,7 +2434,7 @@ __global__ __launch_bounds__(256) void k_bal_step(BADev P, int kb, int last) {
 #pragma unroll
         for (int j = 0; j < 4; j++) C[(size_t)i * ld + j] = c[i][j];
     // look-ahead: the tile that holds the NEXT panel's diagonal block (the first one dispatched) factors it right away
-    if (!last && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (!last && bx == 0 && blockIdx.y == 0) {
         const int o = k0 + kBigNB - c0;            // 0 or 32: offset of the block inside this tile
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -2310,7 +2460,9 @@ __global__ __launch_bounds__(256) void k_bal_step(BADev P, int kb, int last) {
 // to the left: z_j -= sum_i L(i, j) x_i.  L is read once, by as many workgroups as there are column chunks; the last launch
 // (super-block 0) also applies exp(dx) * T.
 constexpr int kBigSB = 256;
-__global__ __launch_bounds__(256) void k_bal_backsolve(BADev P, int J, int* solveOk) {
+__global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__ W, int wpar, int J) {
+    BA_WIN(P);
+    int* const solveOk = P.solveOk;
     __shared__ double xl[kBigSB];      // z of the super-block on entry, x on exit
     extern __shared__ double sdiag[];  // (kBigSB / 32) x 32 x 32: the factored diagonal blocks of the super-block
     __shared__ double part2[4][64];
@@ -2373,11 +2525,11 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(BADev P, int J, int* solv
         }
     }
     __syncthreads();
-    if (blockIdx.x == 0)
+    if (bx == 0)
         for (int i = t; i < w; i += 256) if (J0 + i < n) P.xp[J0 + i] = xl[i];
     if (J > 0) {
         // this workgroup's 64 columns to the left of the super-block
-        const int j = blockIdx.x * 64 + (t & 63), rg = t >> 6;
+        const int j = bx * 64 + (t & 63), rg = t >> 6;
         double acc = 0;
         for (int i0 = rg; i0 < w; i0 += 32) {      // (w is a multiple of 32) eight independent loads in flight
             double v[8];
@@ -2430,8 +2582,9 @@ __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BASta
 // per landmark (eight lanes, one edge per lane): x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 of
 // its edges at the trial state; scale partial
 template <bool PL>
-__global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
-    const int l = (blockIdx.x * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+__global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    const int l = (bx * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
     if (P.ctl[kCtlHalt]) return;
     const bool live = l < P.nL;
     const int pt = live ? P.actPt[l] : 0;
@@ -2506,7 +2659,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
         P.partChi[l] = chi;
         P.partScale[l] = xl[0] * (lambda * xl[0] + bl[0]) + xl[1] * (lambda * xl[1] + bl[1]) + xl[2] * (lambda * xl[2] + bl[2]);
     }
-    if (blockIdx.x == 0) {   // camera part of the gain denominator, sum x (lambda x + b), for the decision (fixed order)
+    if (bx == 0) {   // camera part of the gain denominator, sum x (lambda x + b), for the decision (fixed order)
         __shared__ double red[4], out1;
         double v[1] = {0};
         for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { const double x = P.xp[i]; v[0] += x * (lambda * x + P.bp[i]); }
@@ -2519,7 +2672,12 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev P) {
 // block then needs cost more (23 us for the pair) than the launch they save (6 + 9 us).)
 // ctl0 / lm0: the canonical control blocks.  The last trial of a bulk segment may have run on the other pair (see
 // BADecision); whatever happened, the state is back in the canonical pair when this kernel ends.
-__global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, BAStatus* st, int seq, int bulk, int* ctl0, double* lm0) {
+__global__ __launch_bounds__(256) void k_ba_decide(const BADev* __restrict__ W, int wpar, int seq, int bulk) {
+    BA_WIN(P);
+    const int* const solveOk = P.solveOk;
+    BAStatus* const st = P.status;
+    int* const ctl0 = P.ctl0;
+    double* const lm0 = P.lm0;
     if (!P.ctl[kCtlHalt]) ba_decide_block(P, solveOk, st, seq, bulk);
     if (P.ctl != ctl0) {
         __syncthreads();
@@ -2530,8 +2688,11 @@ __global__ __launch_bounds__(256) void k_ba_decide(BADev P, const int* solveOk, 
 // per edge: chi2 (of the stored residual) > threshold or non-positive depth at the current state.  update = 1 is the
 // outlier pass between the two optimize() calls (src/Optimizer.cc:978-1008): flagged edges go to level 1 (bit1) and every
 // edge loses its robust kernel (bit2) -- on the device, so the window's structure is never rebuilt.
-__global__ void k_ba_classify(BADev P, unsigned char* out, int nEdges, int update) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_ba_classify(const BADev* __restrict__ W, int wpar, int update) {
+    BA_WIN(P);
+    unsigned char* const out = P.cls;
+    const int nEdges = P.nEdges;
+    const int e = bx * blockDim.x + threadIdx.x;
     if (e >= nEdges) return;
     // enqueued speculatively behind the first optimize(): a pending host takeover freezes the rest of the stream
     if (update && P.ctl[kCtlStatus] == kStTakeover) return;
@@ -2557,8 +2718,9 @@ __global__ void k_ba_classify(BADev P, unsigned char* out, int nEdges, int updat
 
 // Device-side part of the set-up: the dense (point x free camera) edge table from the point adjacency, and the second
 // copy of the state (a vertex no active edge reaches keeps its value in BOTH buffers).
-__global__ __launch_bounds__(256) void k_ba_prepare(BADev P) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_ba_prepare(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    const int idx = bx * 256 + threadIdx.x;
     if (idx < P.nL * P.nFree) {
         const int l = idx / P.nFree, ci = idx - l * P.nFree;
         int found = -1;
@@ -2575,8 +2737,10 @@ __global__ __launch_bounds__(256) void k_ba_prepare(BADev P) {
 }
 
 // Results straight into pinned host memory: final state + the per-edge outlier flags.
-__global__ __launch_bounds__(256) void k_ba_finish(BADev P, SE3* outCams, double* outPts, unsigned char* outCls, double* outPlanes) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_ba_finish(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    SE3* const outCams = P.outCams; double* const outPts = P.outPts; unsigned char* const outCls = P.outCls; double* const outPlanes = P.outPlanes;
+    const int idx = bx * 256 + threadIdx.x;
     if (idx < P.nCams) outCams[idx] = cur_cams(P)[idx];
     if (idx < P.nPtsOnly * 3) outPts[idx] = cur_pts(P)[idx];
     if (idx < (P.nPts - P.nPtsOnly) * 4) outPlanes[idx] = P.plBuf[P.ctl[kCtlCur]][idx];
@@ -2621,13 +2785,15 @@ struct LMContext {  // per-thread device workspace, grow-only
 };
 thread_local LMContext g_ctx;
 
-eao_status ctx_init(LMContext& c) {
+eao_status ctx_init(LMContext& c, bool ownStream = true) {
     eao_status st = eao::require_device();
     if (st) return st;
-    if (!c.stream) {
+    if (ownStream && !c.stream) {
         EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         EAO_HIP(hipEventCreate(&c.ev0));
         EAO_HIP(hipEventCreate(&c.ev1));
+    }
+    if (!c.status) {
         EAO_HIP(hipHostMalloc((void**)&c.status, sizeof(BAStatus), hipHostMallocMapped));
         std::memset(c.status, 0, sizeof(BAStatus));
     }
@@ -2765,362 +2931,442 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
 // mode 1: Optimizer::BundleAdjustment over keyframes and map points (src/Optimizer.cc:55-323): ONE optimize(its_first) call,
 //         Huber kernels only when `robust`, delta_mono = sqrt(5.99) (:94), no outlier pass, no observation is erased.
 //         With `pl`: the MapPlane vertices / EdgePlane edges of :203-252 ride along as landmarks nPo.. / edges Ept.. .
-static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r, int mode, int robust,
-                         const eao_ba_planes* pl = nullptr, float* planes_out = nullptr) {
-    EAO_REQUIRE(p && r && r->cam_Tcw && r->points && (p->n_edges == 0 || r->edge_outlier || mode == 1), "null argument");
-    EAO_REQUIRE(p->n_cams > 0 && p->n_points >= 0 && p->n_edges >= 0, "bad sizes");
-    if (pl && pl->n_planes <= 0) pl = nullptr;
-    EAO_REQUIRE(!pl || (mode == 1 && pl->plane_world && planes_out && pl->n_pedges >= 0 && (pl->n_pedges == 0 || (pl->pedge_plane && pl->pedge_cam && pl->pedge_obs))),
-                "bad plane arguments");
-    LMContext& c = g_ctx;
-    eao_status st = ctx_init(c);
-    if (st) return st;
-    g_trace.clear();
-    const int nPo = p->n_points, nPl = pl ? pl->n_planes : 0, Ept = p->n_edges, Epl = pl ? pl->n_pedges : 0;
-    const int nC = p->n_cams, nP = nPo + nPl, E = Ept + Epl;          // landmarks = points then planes, edges = point edges then plane edges
-    const bool hasPl = nPl > 0;
-    auto edge_cam = [&](int e) { return e < Ept ? p->edge_cam[e] : pl->pedge_cam[e - Ept]; };
-    auto edge_lm = [&](int e) { return e < Ept ? p->edge_point[e] : nPo + pl->pedge_plane[e - Ept]; };
-    r->iters[0] = r->iters[1] = 0; r->aborted = 0; r->chi2[0] = r->chi2[1] = 0;
-    if (stop && *stop) {  // src/Optimizer.cc:961-963: nothing is optimised; poses go through the same SE3 round trip
-        r->aborted = 1;
-        for (int i = 0; i < nC; i++) se3_to_Tcw_f32(se3_from_Tcw_f32(p->cam_Tcw + 16 * i), r->cam_Tcw + 16 * i);
-        for (size_t i = 0; i < (size_t)nPo * 3; i++) r->points[i] = p->points[i];
-        for (int i = 0; i < nPl; i++) { double c4[4]; plane_from_f32(pl->plane_world + 4 * i, c4); for (int k = 0; k < 4; k++) planes_out[4 * i + k] = (float)c4[k]; }
-        if (Ept && r->edge_outlier) std::memset(r->edge_outlier, 0, Ept);
-        return EAO_OK;
+}  // extern "C"
+
+namespace {
+
+// Launch geometry of one window -- or, field by field, the largest of a batch (every kernel guards its own window's sizes).
+struct BADims {
+    int nF = 0, nL = 0, nP = 0, nC = 0, E = 0, nPl = 0;
+    bool hasPl = false, bigPath = false, usePairs = false, solveTiles = false, tiles3 = true, solveInLds = true;
+    size_t tileLds = 0, solveLds = 0, schurLds = 0;
+    int nPairsNZ = 0;          // map-scale path (never batched)
+    double* big = nullptr;     // "
+    BigGeom gB{};
+    int chunks = kChunks;
+    void merge(const BADims& o) {
+        nF = std::max(nF, o.nF); nL = std::max(nL, o.nL); nP = std::max(nP, o.nP); nC = std::max(nC, o.nC); E = std::max(E, o.E);
+        tiles3 = tiles3 && o.tiles3; tileLds = std::max(tileLds, o.tileLds);
     }
-    for (int e = 0; e < Ept; e++)
-        EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nPo, "edge %d out of range", e);
-    for (int e = 0; e < Epl; e++)
-        EAO_REQUIRE(pl->pedge_cam[e] >= 0 && pl->pedge_cam[e] < nC && pl->pedge_plane[e] >= 0 && pl->pedge_plane[e] < nPl, "plane edge %d out of range", e);
-    const int chunks = kChunks;
-    int nFreeIn = 0;
-    for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
-    EAO_REQUIRE(nFreeIn <= kBigMaxFree, "at most %d free keyframes in this build (got %d)", kBigMaxFree, nFreeIn);
-    // more free keyframes than the single-workgroup solvers take (or EAO_BA_SOLVER=big, the harness's A/B switch): the
-    // map-scale path, dense system in HBM factorised by the whole chip (k_bal_*)
-    const char* solverEnv0 = getenv("EAO_BA_SOLVER");
-    // (measured, LocalBundleAdjustment wall time, tools/dbg_ba_sizes.py: the LDS / global-scratch single-workgroup solver with
-    //  the slab assembly takes 5.8 ms at 31 free keyframes and 29 ms at 64, the map-scale path 3.6 and 6.9 ms -- so everything
-    //  beyond the register-tile solver goes there; EAO_BA_SOLVER=lds keeps the old path reachable up to 64 for A/B runs)
-    const bool wantLds0 = solverEnv0 && !strcmp(solverEnv0, "lds") && nFreeIn <= kSchurMaxFree;
-    const bool bigPath = (nFreeIn > kTileMaxFree && !wantLds0) || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
-    const BigGeom bg = big_geom(std::max(nFreeIn, 1));
-    size_t lpEntries = 0, lpPairsMax = 0;
-    if (bigPath) {   // sizes of the pair CSR: sum over the points of m (m + 1) / 2, m = observers among the free keyframes
-        std::vector<int>& fc = c.scratch;
-        fc.assign((size_t)nP, 0);
-        for (int e = 0; e < E; e++) if (!p->cam_fixed[edge_cam(e)]) fc[edge_lm(e)]++;
-        for (int i = 0; i < nP; i++) lpEntries += (size_t)fc[i] * (fc[i] + 1) / 2;
-        lpPairsMax = std::min(lpEntries, (size_t)nFreeIn * (nFreeIn + 1) / 2);
-        EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
-    }
-    size_t need = 0;
-    need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
-    need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
-    need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
-    need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8;
-    if (bigPath) {
-        need += (2 * (size_t)bg.RP * bg.RP + (size_t)bg.N * kBigNB) * 8;
-        need += (lpEntries + 3 * lpPairsMax + 8) * 4;
-    } else {
-        need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
-        need += (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
-        need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * 4;   // landmark lists of the camera pairs
-        need += (size_t)nC * (nC + 1) / 2 * 4;
-    }
-    if ((st = c.bytes.reserve(need))) return st;
-    Arena a{c.bytes.p, c.bytes.n};
-    BADev D;
-    std::memset(&D, 0, sizeof(D));
-    D.nCams = nC; D.nPts = nP; D.nEdges = E; D.chunks = chunks;
-    D.cam.fx = p->fx; D.cam.fy = p->fy; D.cam.cx = p->cx; D.cam.cy = p->cy; D.cam.bf = p->bf; D.cam.bf_f = p->bf;
-    D.cam.deltaMono = (float)std::sqrt(mode == 1 ? 5.99 : 5.991); D.cam.deltaStereo = (float)std::sqrt(7.815);
-    // ---- the uploaded part of the arena (problem, initial state, adjacency, zeroed control block) is mirrored in pinned
-    //      host memory: filled in place, sent with ONE copy
-    const size_t off0 = a.off;
-    float* dobs = a.take<float>((size_t)E * 3); float* dinfo = a.take<float>(E);
-    int* decam = a.take<int>(E); int* dept = a.take<int>(E);
-    SE3* dcams = a.take<SE3>(nC);
-    double* dpts = a.take<double>((size_t)nP * 3);
-    unsigned char* dflag = a.take<unsigned char>(E);
-    int* dcamIdx = a.take<int>(nC); int* dptIdx = a.take<int>(nP); int* dactCam = a.take<int>(nC); int* dactPt = a.take<int>(nP);
-    int* dptStart = a.take<int>(nP + 1); int* dptEdges = a.take<int>(E); int* dcamStart = a.take<int>(nC + 1); int* dcamEdges = a.take<int>(E);
-    int* dctl = a.take<int>(16);   // two control blocks: see BADecision
-    int* dlpStart = a.take<int>(bigPath ? lpPairsMax + 1 : 1);
-    int* dlpPair = a.take<int>(bigPath ? 2 * lpPairsMax : 1);
-    int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
-    double* dpl0 = a.take<double>((size_t)nPl * 4 + 1);
-    double* dpmeas = a.take<double>((size_t)Epl * 4 + 1);
-    const size_t off1 = (a.off + 255) & ~(size_t)255;
-    // ---- device-only part
-    int* dtable = a.take<int>((size_t)nP * nC);
-    D.camEdgeL = a.take<int>(E);
-    const bool pairPath = !bigPath && nFreeIn > 0 && nFreeIn <= kTileMaxFree && !(getenv("EAO_BA_SOLVER") && !strcmp(getenv("EAO_BA_SOLVER"), "lds")) && !getenv("EAO_BA_SLABS");
-    const int nPairsMax = nFreeIn * (nFreeIn + 1) / 2;
-    D.pairCnt = a.take<int>(bigPath ? 1 : std::max(nPairsMax, 1));
-    D.pairPts = a.take<int>(pairPath ? (size_t)nPairsMax * std::max(nP, 1) : 1);
-    unsigned char* dcls = a.take<unsigned char>(E);
-    SE3* dcamsT = a.take<SE3>(nC);
-    double* dptsT = a.take<double>((size_t)nP * 3);
-    D.plBuf[0] = dpl0; D.plBuf[1] = a.take<double>((size_t)nPl * 4 + 1); D.pmeas = dpmeas;
-    D.nPtsOnly = nPo; D.nEdgesPt = Ept;
-    D.deltaPlane = (float)std::sqrt(300.0); D.infoAngle = 3282.8 / (1.0 * 1.0); D.infoDist = 100.0 * 100.0;   // src/Optimizer.cc:203-208
-    D.err = a.take<double>((size_t)E * 3);
-    D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
-    D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
-    D.Hpl = a.take<double>((size_t)E * 18);
-    double* dsolveScratch = a.take<double>(bigPath ? 8 : (size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
-    D.sys = a.take<double>(bigPath ? 8 : std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
-    D.slab = a.take<double>(bigPath ? 8 : (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
-    D.big = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
-    D.bigL = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
-    D.bigDiag = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
-    D.bigFail = a.take<int>(4);
-    D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpPts = dlpPts;
-    D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
-    D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
-    D.lm = a.take<double>(16);
-    double* const dlm0 = D.lm;
-    int* dsolveOk = a.take<int>(4);
-    long long* ddbg = a.take<long long>(16);
-    D.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
-    EAO_REQUIRE(a.off <= a.cap, "internal: arena overflow");
-    D.obs = dobs; D.info = dinfo; D.ecam = decam; D.ept = dept; D.eflag = dflag;
-    D.camIdx = dcamIdx; D.ptIdx = dptIdx; D.actCam = dactCam; D.actPt = dactPt;
-    D.ptStart = dptStart; D.ptEdges = dptEdges; D.camStart = dcamStart; D.camEdges = dcamEdges; D.table = dtable;
-    D.camsBuf[0] = dcams; D.camsBuf[1] = dcamsT; D.ptsBuf[0] = dpts; D.ptsBuf[1] = dptsT;
-    D.ctl = dctl;
-    hipStream_t s = c.stream;
-    if (c.pinCap < off1) {
-        if (c.pin) (void)hipHostFree(c.pin);
-        c.pin = nullptr; c.pinCap = 0;
-        EAO_HIP(hipHostMalloc((void**)&c.pin, off1 + (off1 >> 2), hipHostMallocDefault));
-        c.pinCap = off1 + (off1 >> 2);
-    }
-    const size_t outBytes = (size_t)nC * sizeof(SE3) + (size_t)nP * 24 + (size_t)nPl * 32 + (((size_t)E + 15) & ~(size_t)15) + 64;
-    if (c.pinOutCap < outBytes) {
-        if (c.pinOut) (void)hipHostFree(c.pinOut);
-        c.pinOut = nullptr; c.pinOutCap = 0;
-        EAO_HIP(hipHostMalloc((void**)&c.pinOut, outBytes + (outBytes >> 2), hipHostMallocMapped));
-        c.pinOutCap = outBytes + (outBytes >> 2);
-    }
-    SE3* outCams = (SE3*)c.pinOut;
-    double* outPts = (double*)(c.pinOut + (((size_t)nC * sizeof(SE3) + 15) & ~(size_t)15));
-    double* outPlanes = outPts + (size_t)nP * 3;
-    unsigned char* outCls = (unsigned char*)(outPlanes + (size_t)nPl * 4);
-    auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
-    int seq = c.status->seq;
-    size_t offSplit = off0;
-    {
-        std::memcpy(hostp(dobs), p->edge_obs, (size_t)Ept * 12);
-        std::memcpy(hostp(dinfo), p->edge_inv_sigma2, (size_t)Ept * 4);
-        std::memcpy(hostp(decam), p->edge_cam, (size_t)Ept * 4);
-        std::memcpy(hostp(dept), p->edge_point, (size_t)Ept * 4);
-        if (hasPl) {
-            std::memset(hostp(dobs) + (size_t)Ept * 12, 0, (size_t)Epl * 12);
-            std::memset(hostp(dinfo) + (size_t)Ept * 4, 0, (size_t)Epl * 4);
-            int* hc2 = (int*)hostp(decam); int* hp2 = (int*)hostp(dept);
-            for (int e = Ept; e < E; e++) { hc2[e] = edge_cam(e); hp2[e] = edge_lm(e); }
-            double* hpl = (double*)hostp(dpl0); double* hpm = (double*)hostp(dpmeas);
-            for (int i = 0; i < nPl; i++) plane_from_f32(pl->plane_world + 4 * i, hpl + 4 * i);          // Converter::toPlane3D (:217)
-            for (int e = 0; e < Epl; e++) plane_from_f32(pl->pedge_obs + 4 * e, hpm + 4 * e);           // (:239)
-        }
-        SE3* hc = (SE3*)hostp(dcams);
-        for (int i = 0; i < nC; i++) hc[i] = se3_from_Tcw_f32(p->cam_Tcw + 16 * i);
-        double* hp = (double*)hostp(dpts);
-        for (size_t i = 0; i < (size_t)nPo * 3; i++) hp[i] = p->points[i];
-        for (size_t i = (size_t)nPo * 3; i < (size_t)nP * 3; i++) hp[i] = 0;
-        // edge flags: bit0 stereo, bit2 robust kernel present (bit1 = level 1 is only ever set on the device)
-        unsigned char* hf = (unsigned char*)hostp(dflag);
-        for (int e = 0; e < Ept; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | (robust ? 4 : 0));
-        for (int e = Ept; e < E; e++) hf[e] = 8 | 4;      // EdgePlane: always a Huber kernel (:246-248)
-        std::memset(hostp(dctl), 0, 16 * sizeof(int));
-        // The problem itself (observations, indices, initial state, flags) is on its way to the device while the host builds
-        // the active structure below; the structure follows in a second copy.
-        offSplit = (size_t)((unsigned char*)dcamIdx - a.base) & ~(size_t)255;
-        EAO_HIP(hipEventRecord(c.ev0, s));
-        EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, offSplit - off0, hipMemcpyHostToDevice, s));
-        // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
-        int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
-        int* actCam = (int*)hostp(dactCam); int* actPt = (int*)hostp(dactPt);
-        int* ptStart = (int*)hostp(dptStart); int* ptEdges = (int*)hostp(dptEdges);
-        int* camStart = (int*)hostp(dcamStart); int* camEdges = (int*)hostp(dcamEdges);
-        std::vector<int>& cnt = c.scratch;
-        cnt.assign((size_t)nC + nP, 0);
-        int* camCnt = cnt.data(); int* ptCnt = camCnt + nC;
-        for (int e = 0; e < E; e++) { camCnt[edge_cam(e)]++; ptCnt[edge_lm(e)]++; }
-        int nF = 0, nL = 0;
-        for (int i = 0; i < nC; i++) { camIdx[i] = -1; if (camCnt[i] && !p->cam_fixed[i]) { actCam[nF] = i; camIdx[i] = nF++; } }
-        ptStart[0] = 0;
-        for (int i = 0; i < nP; i++) { ptIdx[i] = -1; if (ptCnt[i]) { actPt[nL] = i; ptIdx[i] = nL; ptStart[nL + 1] = ptStart[nL] + ptCnt[i]; nL++; } }
-        camStart[0] = 0;
-        for (int i = 0; i < nF; i++) camStart[i + 1] = camStart[i] + camCnt[actCam[i]];
-        for (int i = 0; i < nL; i++) ptCnt[actPt[i]] = ptStart[i];         // counters become fill cursors
-        for (int i = 0; i < nF; i++) camCnt[actCam[i]] = camStart[i];
-        for (int e = 0; e < E; e++) {
-            const int cam = edge_cam(e);
-            ptEdges[ptCnt[edge_lm(e)]++] = e;
-            if (camIdx[cam] >= 0) camEdges[camCnt[cam]++] = e;
-        }
-        // one edge per (camera, point) pair: the device's edge table has one slot per pair
-        for (int i = 0; i < nC; i++) camCnt[i] = -1;                        // now: last point seen with this camera
-        for (int l = 0; l < nL; l++)
-            for (int k = ptStart[l]; k < ptStart[l + 1]; k++) {
-                const int cam = edge_cam(ptEdges[k]);
-                if (camCnt[cam] == l) { eao::set_error("two edges join camera %d and point %d", cam, actPt[l]); return EAO_ERR_INVALID; }
-                camCnt[cam] = l;
+};
+
+// Where launches go: `nz` windows (device array W) on one stream.  Every kernel of the LM engine is launched from here, with
+// the window as grid.z -- a single window is a batch of one.
+struct BALaunch {
+    const BADev* W = nullptr;
+    int nz = 1;
+    BADims d;
+    hipStream_t s = nullptr;
+    int seq = 0;
+    eao_status attributes() const {
+        // (per-function, process-wide state: only ever raised -- two threads or two windows of different sizes must not lower
+        //  each other's limit between the set and the launch)
+        auto raise = [](const void* fn, std::atomic<int>& cur, size_t want) -> eao_status {
+            int have = cur.load();
+            while ((int)want > have) {
+                EAO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+                if (cur.compare_exchange_weak(have, (int)want)) break;
             }
-        D.nFree = nF; D.nL = nL;
-        if (bigPath && nF > 0) {
-            // covisibility CSR: for every camera pair (i1 <= i2) sharing a landmark, the landmark blocks in ascending order
-            // (counting sort over the landmarks' observer lists; the diagonal pairs carry each camera's own landmarks)
-            int* lpStart = (int*)hostp(dlpStart); int* lpPair = (int*)hostp(dlpPair); int* lpPts = (int*)hostp(dlpPts);
-            static thread_local std::vector<int> pcnt, obs;
-            pcnt.assign((size_t)nF * (nF + 1) / 2, 0);
-            auto each_pair = [&](auto&& fn) {
-                for (int l = 0; l < nL; l++) {
-                    obs.clear();
-                    for (int k = ptStart[l]; k < ptStart[l + 1]; k++) { const int ci = camIdx[edge_cam(ptEdges[k])]; if (ci >= 0) obs.push_back(ci); }
-                    for (size_t u = 0; u < obs.size(); u++)
-                        for (size_t v = u; v < obs.size(); v++) fn(pair_index(std::min(obs[u], obs[v]), std::max(obs[u], obs[v]), nF), l);
-                }
-            };
-            each_pair([&](int pi, int) { pcnt[pi]++; });
-            int nz = 0, run = 0, pi = 0;
-            for (int i1 = 0; i1 < nF; i1++)
-                for (int i2 = i1; i2 < nF; i2++, pi++) {
-                    const int cnt0 = pcnt[pi];
-                    if (!cnt0) { pcnt[pi] = -1; continue; }
-                    lpPair[2 * nz] = i1; lpPair[2 * nz + 1] = i2; lpStart[nz] = run;
-                    pcnt[pi] = nz;            // the pair's slot; lpStart[slot] doubles as the fill cursor below
-                    run += cnt0; nz++;
-                }
-            lpStart[nz] = run;
-            each_pair([&](int pi2, int l) { lpPts[lpStart[pcnt[pi2]]++] = l; });
-            for (int k = nz; k > 0; k--) lpStart[k] = lpStart[k - 1];   // cursors ended at the next pair's start: shift back
-            lpStart[0] = 0;
-            D.nPairsNZ = nz;
+            return EAO_OK;
+        };
+        static std::atomic<int> aT3{0}, aT5{0}, aSolve{0}, aSchur{0}, aBack{0};
+        eao_status st;
+        if (d.solveTiles) {
+            if (d.tiles3) { if ((st = raise((const void*)k_ba_solve_tiles<3>, aT3, d.tileLds))) return st; }
+            else if ((st = raise((const void*)k_ba_solve_tiles<5>, aT5, d.tileLds))) return st;
+        }
+        if (d.solveInLds && !d.solveTiles && !d.bigPath) { if ((st = raise((const void*)k_ba_solve<true>, aSolve, d.solveLds))) return st; }
+        if (d.nF && !d.bigPath) { if ((st = raise((const void*)k_ba_schur, aSchur, d.schurLds))) return st; }
+        if (d.bigPath) { if ((st = raise((const void*)k_bal_backsolve, aBack, (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double)))) return st; }
+        return EAO_OK;
+    }
+    int wp(int par) const { return par | (nz > 1 ? nz << 8 : 0); }      // kernel argument: block pair | windows << 8 (BA_WIN)
+    unsigned gz() const { return nz > 1 ? (unsigned)((nz + 7) & ~7) : 1u; }   // windows are dealt to the XCDs: grid.z padded to 8
+    int ptBlocks() const { return eao::cdiv(std::max(d.nL, 1) * 8, 256); }       // eight lanes per landmark
+    int linBlocks() const { return eao::cdiv(std::max(d.nL, 1) * 8, kLinThreads); }
+    void setup() const {      // device-side part of the set-up (once per window)
+        hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(d.nL * d.nF, d.nP * 3), d.nC), d.E), d.nPl * 4), 256), 1, gz()), dim3(256), 0, s, W, wp(0));
+        if (d.usePairs) {
+            hipLaunchKernelGGL(k_ba_pairs, dim3(d.nF * (d.nF + 1) / 2, 1, gz()), dim3(256), 0, s, W, wp(0));
+            hipLaunchKernelGGL(k_ba_tiles_init, dim3(tile_geom(d.nF).nTiles, 1, gz()), dim3(256), 0, s, W, wp(0));
         }
     }
-    EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(D.nL * D.nFree, nP * 3), nC), E), nPl * 4), 256)), dim3(256), 0, s, D);
-    const bool usePairs = pairPath && D.nFree > 0 && D.nL > 0;
-    if (usePairs) {
-        hipLaunchKernelGGL(k_ba_pairs, dim3(D.nFree * (D.nFree + 1) / 2), dim3(256), 0, s, D);
-        hipLaunchKernelGGL(k_ba_tiles_init, dim3(tile_geom(D.nFree).nTiles), dim3(256), 0, s, D);
+    // one LM trial behind a linearisation: Schur assembly, solve, back substitution + residuals, (decision)
+    void trial(int par, int bulk, bool firstTrial, bool withDecide) {
+        const int nF = d.nF, nL = d.nL;
+        const TileGeom tg = tile_geom(std::max(nF, 1));
+        if (nF && d.bigPath) {
+            const BigGeom gB = d.gB;
+            (void)hipMemsetAsync(d.big, 0, (size_t)gB.RP * gB.RP * sizeof(double), s);
+            hipLaunchKernelGGL(k_bal_schur_pairs, dim3(d.nPairsNZ), dim3(kBigPairThreads), 0, s, W, wp(par), firstTrial ? 1 : 0);
+            const int nbk = gB.N / kBigNB, nT = gB.RP / 64;
+            hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, W, wp(par));
+            for (int kb = 0; kb < nbk; kb++) {
+                const int tj0 = (kb * kBigNB + kBigNB) >> 6;
+                hipLaunchKernelGGL(k_bal_step, dim3(nT - tj0, nT - tj0), dim3(256), 0, s, W, wp(par), kb, kb + 1 == nbk ? 1 : 0);
+            }
+            for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
+                hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, W, wp(par), J);
+        } else if (nF && d.usePairs && d.solveTiles) {
+            if (nz > 1) hipLaunchKernelGGL(k_ba_schur_pairs_b, dim3(nF * (nF + 1) / 2, 1, gz()), dim3(kPairThreadsB), 0, s, W, wp(par), firstTrial ? 1 : 0);
+            else hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2, 1, 1), dim3(kPairThreads), 0, s, W, wp(par), firstTrial ? 1 : 0);
+        } else if (nF) {
+            hipLaunchKernelGGL(k_ba_schur, dim3(nF, d.chunks), dim3(kSchurThreads), d.schurLds, s, W, wp(par), firstTrial ? 1 : 0);
+            if (d.solveTiles) hipLaunchKernelGGL(k_ba_reduce_tiles, dim3(tg.nTiles), dim3(256), 0, s, W, wp(par));
+            else hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, W, wp(par));
+        }
+        if (d.bigPath) {}
+        else if (d.solveTiles && d.tiles3) hipLaunchKernelGGL(k_ba_solve_tiles<3>, dim3(1, 1, gz()), dim3(kTileThreads), d.tileLds, s, W, wp(par));
+        else if (d.solveTiles) hipLaunchKernelGGL(k_ba_solve_tiles<5>, dim3(1, 1, gz()), dim3(kTileThreads), d.tileLds, s, W, wp(par));
+        else if (d.solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), d.solveLds, s, W, wp(par));
+        else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), d.solveLds, s, W, wp(par));
+        if (nL && d.hasPl) hipLaunchKernelGGL(k_ba_backsub<true>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par));
+        else if (nL) hipLaunchKernelGGL(k_ba_backsub<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par));
+        if (withDecide) hipLaunchKernelGGL(k_ba_decide, dim3(1, 1, gz()), dim3(256), 0, s, W, wp(par), ++seq, bulk);
     }
-    auto wait_status = [&](int want) -> eao_status {
-        EAO_HIP(hipStreamSynchronize(s));
-        if (c.status->seq != want) { eao::set_error("LM status hand-off out of sequence"); return EAO_ERR_INTERNAL; }
-        return EAO_OK;
-    };
-    // ---- SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve per iteration
-    int curHost = 0;     // host mirror of ctl[kCtlCur]
-    auto set_ctl = [&](int halt, int iters, int nBad) -> eao_status {
-        const int v[5] = {halt, curHost, iters, kStRunning, nBad};
-        EAO_HIP(hipMemcpyAsync(D.ctl, v, sizeof(v), hipMemcpyHostToDevice, s));
-        return EAO_OK;
-    };
-    // ---- SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve per iteration.
-    // Iterations are enqueued in bulk (one trial each, no host round trip); the device finishes clean iterations itself
-    // and halts the stream on anything else, which the host then replays trial by trial like g2o's do/while.
-    // resume: the first bulk segment of this call was already enqueued (and has finished) -- start from its outcome
-    auto optimize = [&](int phase, int iterations, int* itersDone, double* chiOut, const BAPhase* resume) -> eao_status {
-        *itersDone = 0;
+    // iterations [from, to) of an optimize() call, one trial each, no host round trip
+    void bulk(int from, int to, bool withErrors) {
+        const int nF = d.nF, nL = d.nL, lb = linBlocks();
+        if (withErrors) {   // computeActiveErrors + activeRobustChi2 (otherwise the accepted trial already left them)
+            if (nL && d.hasPl) hipLaunchKernelGGL(k_ba_errors<true>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(0));
+            else if (nL) hipLaunchKernelGGL(k_ba_errors<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(0));
+            hipLaunchKernelGGL(k_ba_chi_init, dim3(1, 1, gz()), dim3(256), 0, s, W, wp(0), ++seq);
+        }
+        // every trial but the last leaves its accept / reject decision to the head of the next linearisation, which
+        // runs on the other control block (BADecision); the last one is decided by k_ba_decide, which also brings the
+        // state back to the canonical block
+        int par = 0;
+        for (int it = from; it < to; it++) {
+            int parOld = -1, sq = 0;
+            if (it != from) { parOld = par; par ^= 1; sq = ++seq; }
+            if (d.hasPl) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, parOld, sq);
+            else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, parOld, sq);
+            if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, W, wp(par));   // no Schur kernel to do it
+            trial(par, 1, it == 0 && nF, it == to - 1);
+        }
+    }
+    void classify() const { hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(std::max(d.E, 1), 256), 1, gz()), dim3(256), 0, s, W, wp(0), 1); }
+    void finish() const {
+        hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(std::max(std::max(d.E, d.nP * 3), d.nC), d.nPl * 4), 1), 256), 1, gz()), dim3(256), 0, s, W, wp(0));
+    }
+    // Both optimize() calls of the reference, the outlier pass between them and the result copy in ONE enqueue.  A rejected LM
+    // trial freezes the rest of ITS window's work (halt flag + the takeover check of the outlier pass); the host then
+    // continues that window from where the device stopped.
+    void chain(int mode, int itsFirst, int itsSecond) {
+        bulk(0, itsFirst, true);
+        if (mode == 0) { classify(); bulk(0, itsSecond, true); }
+        finish();
+    }
+};
+
+// One window in flight: LocalBundleAdjustment / BundleAdjustment of one problem on one context (device arena + pinned mirrors).
+struct BAJob {
+    const eao_ba_problem* p = nullptr; const volatile uint8_t* stop = nullptr; eao_ba_result* r = nullptr;
+    int mode = 0, robust = 1; const eao_ba_planes* pl = nullptr; float* planes_out = nullptr;
+    LMContext* c = nullptr; LMTraceHost* tr = nullptr;
+    int nPo = 0, nPl = 0, Ept = 0, Epl = 0, nC = 0, nP = 0, E = 0;
+    bool hasPl = false, trivial = false, chained = false;
+    BADev D; BADev* dW = nullptr;
+    BALaunch L;
+    int curHost = 0;
+    SE3* outCams = nullptr; double* outPts = nullptr; double* outPlanes = nullptr; unsigned char* outCls = nullptr;
+
+    void write_records(BADev* dst) const {      // the two records of this window (see BA_WIN)
+        dst[0] = D; dst[0].ctl = D.ctl0; dst[0].lm = D.lm0;
+        dst[1] = D; dst[1].ctl = D.ctl0 + 8; dst[1].lm = D.lm0 + 8;
+    }
+    bool batchable() const { return !trivial && chained && L.d.usePairs && L.d.solveTiles && !hasPl && !L.d.bigPath && D.nFree > 0 && D.nL > 0 && mode == 0; }
+
+    // validation, arena, pinned mirror, upload (two copies on `s`), active structure.  No kernel is launched here.
+    eao_status prepare(hipStream_t s) {
+        EAO_REQUIRE(p && r && r->cam_Tcw && r->points && (p->n_edges == 0 || r->edge_outlier || mode == 1), "null argument");
+        EAO_REQUIRE(p->n_cams > 0 && p->n_points >= 0 && p->n_edges >= 0, "bad sizes");
+        if (pl && pl->n_planes <= 0) pl = nullptr;
+        EAO_REQUIRE(!pl || (mode == 1 && pl->plane_world && planes_out && pl->n_pedges >= 0 && (pl->n_pedges == 0 || (pl->pedge_plane && pl->pedge_cam && pl->pedge_obs))),
+                    "bad plane arguments");
+        LMContext& c = *this->c;
+        eao_status st;
+        tr->clear();
+        nPo = p->n_points; nPl = pl ? pl->n_planes : 0; Ept = p->n_edges; Epl = pl ? pl->n_pedges : 0;
+        nC = p->n_cams; nP = nPo + nPl; E = Ept + Epl;          // landmarks = points then planes, edges = point edges then plane edges
+        hasPl = nPl > 0;
+        const eao_ba_problem* p = this->p; const eao_ba_planes* pl = this->pl;
+        const int nPo = this->nPo, Ept = this->Ept;
+        auto edge_cam = [=](int e) { return e < Ept ? p->edge_cam[e] : pl->pedge_cam[e - Ept]; };
+        auto edge_lm = [=](int e) { return e < Ept ? p->edge_point[e] : nPo + pl->pedge_plane[e - Ept]; };
+        r->iters[0] = r->iters[1] = 0; r->aborted = 0; r->chi2[0] = r->chi2[1] = 0;
+        if (stop && *stop) {  // src/Optimizer.cc:961-963: nothing is optimised; poses go through the same SE3 round trip
+            r->aborted = 1;
+            for (int i = 0; i < nC; i++) se3_to_Tcw_f32(se3_from_Tcw_f32(p->cam_Tcw + 16 * i), r->cam_Tcw + 16 * i);
+            for (size_t i = 0; i < (size_t)nPo * 3; i++) r->points[i] = p->points[i];
+            for (int i = 0; i < nPl; i++) { double c4[4]; plane_from_f32(pl->plane_world + 4 * i, c4); for (int k = 0; k < 4; k++) planes_out[4 * i + k] = (float)c4[k]; }
+            if (Ept && r->edge_outlier) std::memset(r->edge_outlier, 0, Ept);
+            trivial = true;
+            return EAO_OK;
+        }
+        for (int e = 0; e < Ept; e++)
+            EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nPo, "edge %d out of range", e);
+        for (int e = 0; e < Epl; e++)
+            EAO_REQUIRE(pl->pedge_cam[e] >= 0 && pl->pedge_cam[e] < nC && pl->pedge_plane[e] >= 0 && pl->pedge_plane[e] < nPl, "plane edge %d out of range", e);
+        const int chunks = kChunks;
+        int nFreeIn = 0;
+        for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
+        EAO_REQUIRE(nFreeIn <= kBigMaxFree, "at most %d free keyframes in this build (got %d)", kBigMaxFree, nFreeIn);
+        // more free keyframes than the single-workgroup solvers take (or EAO_BA_SOLVER=big, the harness's A/B switch): the
+        // map-scale path, dense system in HBM factorised by the whole chip (k_bal_*)
+        static const char* solverEnv0 = getenv("EAO_BA_SOLVER");
+        // (measured, LocalBundleAdjustment wall time, tools/dbg_ba_sizes.py: the LDS / global-scratch single-workgroup solver with
+        //  the slab assembly takes 5.8 ms at 31 free keyframes and 29 ms at 64, the map-scale path 3.6 and 6.9 ms -- so everything
+        //  beyond the register-tile solver goes there; EAO_BA_SOLVER=lds keeps the old path reachable up to 64 for A/B runs)
+        const bool wantLds0 = solverEnv0 && !strcmp(solverEnv0, "lds") && nFreeIn <= kSchurMaxFree;
+        const bool bigPath = (nFreeIn > kTileMaxFree && !wantLds0) || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
+        const BigGeom bg = big_geom(std::max(nFreeIn, 1));
+        size_t lpEntries = 0, lpPairsMax = 0;
+        if (bigPath) {   // sizes of the pair CSR: sum over the points of m (m + 1) / 2, m = observers among the free keyframes
+            std::vector<int>& fc = c.scratch;
+            fc.assign((size_t)nP, 0);
+            for (int e = 0; e < E; e++) if (!p->cam_fixed[edge_cam(e)]) fc[edge_lm(e)]++;
+            for (int i = 0; i < nP; i++) lpEntries += (size_t)fc[i] * (fc[i] + 1) / 2;
+            lpPairsMax = std::min(lpEntries, (size_t)nFreeIn * (nFreeIn + 1) / 2);
+            EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
+        }
+        size_t need = 0;
+        need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
+        need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
+        need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
+        need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev);
+        if (bigPath) {
+            need += (2 * (size_t)bg.RP * bg.RP + (size_t)bg.N * kBigNB) * 8;
+            need += (lpEntries + 3 * lpPairsMax + 8) * 4;
+        } else {
+            need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
+            need += (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
+            need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * 4;   // landmark lists of the camera pairs
+            need += (size_t)nC * (nC + 1) / 2 * 4;
+        }
+        if ((st = c.bytes.reserve(need))) return st;
+        Arena a{c.bytes.p, c.bytes.n};
+        std::memset(&D, 0, sizeof(D));
+        D.nCams = nC; D.nPts = nP; D.nEdges = E; D.chunks = chunks;
+        D.cam.fx = p->fx; D.cam.fy = p->fy; D.cam.cx = p->cx; D.cam.cy = p->cy; D.cam.bf = p->bf; D.cam.bf_f = p->bf;
+        D.cam.deltaMono = (float)std::sqrt(mode == 1 ? 5.99 : 5.991); D.cam.deltaStereo = (float)std::sqrt(7.815);
+        // ---- the uploaded part of the arena (problem, initial state, adjacency, zeroed control block, the window record
+        //      itself) is mirrored in pinned host memory: filled in place, sent with two copies
+        const size_t off0 = a.off;
+        float* dobs = a.take<float>((size_t)E * 3); float* dinfo = a.take<float>(E);
+        int* decam = a.take<int>(E); int* dept = a.take<int>(E);
+        SE3* dcams = a.take<SE3>(nC);
+        double* dpts = a.take<double>((size_t)nP * 3);
+        unsigned char* dflag = a.take<unsigned char>(E);
+        int* dcamIdx = a.take<int>(nC); int* dptIdx = a.take<int>(nP); int* dactCam = a.take<int>(nC); int* dactPt = a.take<int>(nP);
+        int* dptStart = a.take<int>(nP + 1); int* dptEdges = a.take<int>(E); int* dcamStart = a.take<int>(nC + 1); int* dcamEdges = a.take<int>(E);
+        int* dctl = a.take<int>(16);   // two control blocks: see BADecision
+        int* dlpStart = a.take<int>(bigPath ? lpPairsMax + 1 : 1);
+        int* dlpPair = a.take<int>(bigPath ? 2 * lpPairsMax : 1);
+        int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
+        double* dpl0 = a.take<double>((size_t)nPl * 4 + 1);
+        double* dpmeas = a.take<double>((size_t)Epl * 4 + 1);
+        dW = a.take<BADev>(2);
+        const size_t off1 = (a.off + 255) & ~(size_t)255;
+        // ---- device-only part
+        int* dtable = a.take<int>((size_t)nP * nC);
+        D.camEdgeL = a.take<int>(E);
+        const bool pairPath = !bigPath && nFreeIn > 0 && nFreeIn <= kTileMaxFree && !(solverEnv0 && !strcmp(solverEnv0, "lds")) && !getenv("EAO_BA_SLABS");
+        const int nPairsMax = nFreeIn * (nFreeIn + 1) / 2;
+        D.pairCnt = a.take<int>(bigPath ? 1 : std::max(nPairsMax, 1));
+        D.pairPts = a.take<int>(pairPath ? (size_t)nPairsMax * std::max(nP, 1) : 1);
+        D.cls = a.take<unsigned char>(E);
+        SE3* dcamsT = a.take<SE3>(nC);
+        double* dptsT = a.take<double>((size_t)nP * 3);
+        D.plBuf[0] = dpl0; D.plBuf[1] = a.take<double>((size_t)nPl * 4 + 1); D.pmeas = dpmeas;
+        D.nPtsOnly = nPo; D.nEdgesPt = Ept;
+        D.deltaPlane = (float)std::sqrt(300.0); D.infoAngle = 3282.8 / (1.0 * 1.0); D.infoDist = 100.0 * 100.0;   // src/Optimizer.cc:203-208
+        D.err = a.take<double>((size_t)E * 3);
+        D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
+        D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
+        D.Hpl = a.take<double>((size_t)E * 18);
+        double* dsolveScratch = a.take<double>(bigPath ? 8 : (size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
+        D.sys = a.take<double>(bigPath ? 8 : std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
+        D.slab = a.take<double>(bigPath ? 8 : (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
+        D.big = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
+        D.bigL = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
+        D.bigDiag = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
+        D.bigFail = a.take<int>(4);
+        D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpPts = dlpPts;
+        D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
+        D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
+        D.lm0 = a.take<double>(16);
+        D.solveOk = a.take<int>(4);
+        long long* ddbg = a.take<long long>(16);
+        D.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
+        EAO_REQUIRE(a.off <= a.cap, "internal: arena overflow");
+        D.obs = dobs; D.info = dinfo; D.ecam = decam; D.ept = dept; D.eflag = dflag;
+        D.camIdx = dcamIdx; D.ptIdx = dptIdx; D.actCam = dactCam; D.actPt = dactPt;
+        D.ptStart = dptStart; D.ptEdges = dptEdges; D.camStart = dcamStart; D.camEdges = dcamEdges; D.table = dtable;
+        D.camsBuf[0] = dcams; D.camsBuf[1] = dcamsT; D.ptsBuf[0] = dpts; D.ptsBuf[1] = dptsT;
+        D.ctl0 = dctl; D.ctl = dctl; D.lm = D.lm0;
+        D.status = c.status;
+        if (c.pinCap < off1) {
+            if (c.pin) (void)hipHostFree(c.pin);
+            c.pin = nullptr; c.pinCap = 0;
+            EAO_HIP(hipHostMalloc((void**)&c.pin, off1 + (off1 >> 2), hipHostMallocDefault));
+            c.pinCap = off1 + (off1 >> 2);
+        }
+        const size_t outBytes = (size_t)nC * sizeof(SE3) + (size_t)nP * 24 + (size_t)nPl * 32 + (((size_t)E + 15) & ~(size_t)15) + 64;
+        if (c.pinOutCap < outBytes) {
+            if (c.pinOut) (void)hipHostFree(c.pinOut);
+            c.pinOut = nullptr; c.pinOutCap = 0;
+            EAO_HIP(hipHostMalloc((void**)&c.pinOut, outBytes + (outBytes >> 2), hipHostMallocMapped));
+            c.pinOutCap = outBytes + (outBytes >> 2);
+        }
+        outCams = (SE3*)c.pinOut;
+        outPts = (double*)(c.pinOut + (((size_t)nC * sizeof(SE3) + 15) & ~(size_t)15));
+        outPlanes = outPts + (size_t)nP * 3;
+        outCls = (unsigned char*)(outPlanes + (size_t)nPl * 4);
+        D.outCams = outCams; D.outPts = outPts; D.outPlanes = outPlanes; D.outCls = outCls;
+        auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
+        size_t offSplit = off0;
+        {
+            std::memcpy(hostp(dobs), p->edge_obs, (size_t)Ept * 12);
+            std::memcpy(hostp(dinfo), p->edge_inv_sigma2, (size_t)Ept * 4);
+            std::memcpy(hostp(decam), p->edge_cam, (size_t)Ept * 4);
+            std::memcpy(hostp(dept), p->edge_point, (size_t)Ept * 4);
+            if (hasPl) {
+                std::memset(hostp(dobs) + (size_t)Ept * 12, 0, (size_t)Epl * 12);
+                std::memset(hostp(dinfo) + (size_t)Ept * 4, 0, (size_t)Epl * 4);
+                int* hc2 = (int*)hostp(decam); int* hp2 = (int*)hostp(dept);
+                for (int e = Ept; e < E; e++) { hc2[e] = edge_cam(e); hp2[e] = edge_lm(e); }
+                double* hpl = (double*)hostp(dpl0); double* hpm = (double*)hostp(dpmeas);
+                for (int i = 0; i < nPl; i++) plane_from_f32(pl->plane_world + 4 * i, hpl + 4 * i);          // Converter::toPlane3D (:217)
+                for (int e = 0; e < Epl; e++) plane_from_f32(pl->pedge_obs + 4 * e, hpm + 4 * e);           // (:239)
+            }
+            SE3* hc = (SE3*)hostp(dcams);
+            for (int i = 0; i < nC; i++) hc[i] = se3_from_Tcw_f32(p->cam_Tcw + 16 * i);
+            double* hp = (double*)hostp(dpts);
+            for (size_t i = 0; i < (size_t)nPo * 3; i++) hp[i] = p->points[i];
+            for (size_t i = (size_t)nPo * 3; i < (size_t)nP * 3; i++) hp[i] = 0;
+            // edge flags: bit0 stereo, bit2 robust kernel present (bit1 = level 1 is only ever set on the device)
+            unsigned char* hf = (unsigned char*)hostp(dflag);
+            for (int e = 0; e < Ept; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | (robust ? 4 : 0));
+            for (int e = Ept; e < E; e++) hf[e] = 8 | 4;      // EdgePlane: always a Huber kernel (:246-248)
+            std::memset(hostp(dctl), 0, 16 * sizeof(int));
+            // The problem itself (observations, indices, initial state, flags) is on its way to the device while the host builds
+            // the active structure below; the structure follows in a second copy.
+            offSplit = (size_t)((unsigned char*)dcamIdx - a.base) & ~(size_t)255;
+            EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, offSplit - off0, hipMemcpyHostToDevice, s));
+            // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
+            int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
+            int* actCam = (int*)hostp(dactCam); int* actPt = (int*)hostp(dactPt);
+            int* ptStart = (int*)hostp(dptStart); int* ptEdges = (int*)hostp(dptEdges);
+            int* camStart = (int*)hostp(dcamStart); int* camEdges = (int*)hostp(dcamEdges);
+            std::vector<int>& cnt = c.scratch;
+            cnt.assign((size_t)nC + nP, 0);
+            int* camCnt = cnt.data(); int* ptCnt = camCnt + nC;
+            for (int e = 0; e < E; e++) { camCnt[edge_cam(e)]++; ptCnt[edge_lm(e)]++; }
+            int nF = 0, nL = 0;
+            for (int i = 0; i < nC; i++) { camIdx[i] = -1; if (camCnt[i] && !p->cam_fixed[i]) { actCam[nF] = i; camIdx[i] = nF++; } }
+            ptStart[0] = 0;
+            for (int i = 0; i < nP; i++) { ptIdx[i] = -1; if (ptCnt[i]) { actPt[nL] = i; ptIdx[i] = nL; ptStart[nL + 1] = ptStart[nL] + ptCnt[i]; nL++; } }
+            camStart[0] = 0;
+            for (int i = 0; i < nF; i++) camStart[i + 1] = camStart[i] + camCnt[actCam[i]];
+            for (int i = 0; i < nL; i++) ptCnt[actPt[i]] = ptStart[i];         // counters become fill cursors
+            for (int i = 0; i < nF; i++) camCnt[actCam[i]] = camStart[i];
+            for (int e = 0; e < E; e++) {
+                const int cam = edge_cam(e);
+                ptEdges[ptCnt[edge_lm(e)]++] = e;
+                if (camIdx[cam] >= 0) camEdges[camCnt[cam]++] = e;
+            }
+            // one edge per (camera, point) pair: the device's edge table has one slot per pair
+            for (int i = 0; i < nC; i++) camCnt[i] = -1;                        // now: last point seen with this camera
+            for (int l = 0; l < nL; l++)
+                for (int k = ptStart[l]; k < ptStart[l + 1]; k++) {
+                    const int cam = edge_cam(ptEdges[k]);
+                    if (camCnt[cam] == l) { eao::set_error("two edges join camera %d and point %d", cam, actPt[l]); return EAO_ERR_INVALID; }
+                    camCnt[cam] = l;
+                }
+            D.nFree = nF; D.nL = nL;
+            if (bigPath && nF > 0) {
+                // covisibility CSR: for every camera pair (i1 <= i2) sharing a landmark, the landmark blocks in ascending order
+                // (counting sort over the landmarks' observer lists; the diagonal pairs carry each camera's own landmarks)
+                int* lpStart = (int*)hostp(dlpStart); int* lpPair = (int*)hostp(dlpPair); int* lpPts = (int*)hostp(dlpPts);
+                static thread_local std::vector<int> pcnt, obs;
+                pcnt.assign((size_t)nF * (nF + 1) / 2, 0);
+                auto each_pair = [&](auto&& fn) {
+                    for (int l = 0; l < nL; l++) {
+                        obs.clear();
+                        for (int k = ptStart[l]; k < ptStart[l + 1]; k++) { const int ci = camIdx[edge_cam(ptEdges[k])]; if (ci >= 0) obs.push_back(ci); }
+                        for (size_t u = 0; u < obs.size(); u++)
+                            for (size_t v = u; v < obs.size(); v++) fn(pair_index(std::min(obs[u], obs[v]), std::max(obs[u], obs[v]), nF), l);
+                    }
+                };
+                each_pair([&](int pi, int) { pcnt[pi]++; });
+                int nz = 0, run = 0, pi = 0;
+                for (int i1 = 0; i1 < nF; i1++)
+                    for (int i2 = i1; i2 < nF; i2++, pi++) {
+                        const int cnt0 = pcnt[pi];
+                        if (!cnt0) { pcnt[pi] = -1; continue; }
+                        lpPair[2 * nz] = i1; lpPair[2 * nz + 1] = i2; lpStart[nz] = run;
+                        pcnt[pi] = nz;            // the pair's slot; lpStart[slot] doubles as the fill cursor below
+                        run += cnt0; nz++;
+                    }
+                lpStart[nz] = run;
+                each_pair([&](int pi2, int l) { lpPts[lpStart[pcnt[pi2]]++] = l; });
+                for (int k = nz; k > 0; k--) lpStart[k] = lpStart[k - 1];   // cursors ended at the next pair's start: shift back
+                lpStart[0] = 0;
+                D.nPairsNZ = nz;
+            }
+        }
+        // ---- launch geometry and solver choice of this window
         const int nF = D.nFree, nL = D.nL;
-        if (nF + nL == 0) return EAO_OK;   // "_ivMap.size() == 0": nothing to optimise
-        const int ptBlocks = eao::cdiv(std::max(nL, 1) * 8, 256);   // eight lanes per landmark
-        const int linBlocks = eao::cdiv(std::max(nL, 1) * 8, kLinThreads);
+        BADims& d = L.d;
+        d = BADims();
+        d.nF = nF; d.nL = nL; d.nP = nP; d.nC = nC; d.E = E; d.nPl = nPl; d.hasPl = hasPl; d.bigPath = bigPath; d.chunks = chunks;
+        d.usePairs = pairPath && nF > 0 && nL > 0;
         const size_t ldHost = (size_t)((nF * 6 + 32) & ~31) + 1;
-        size_t solveLds = ((size_t)(nF * 6 + 6) * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
-        if (solveLds > 150 * 1024) {   // system too large for LDS: S lives in (L2-resident) global scratch, M/xv stay in LDS
+        d.solveLds = ((size_t)(nF * 6 + 6) * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
+        if (d.solveLds > 150 * 1024) {   // system too large for LDS: S lives in (L2-resident) global scratch, M/xv stay in LDS
             D.solveScratch = dsolveScratch;
-            solveLds = ((size_t)6 * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
+            d.solveLds = ((size_t)6 * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
         } else {
             D.solveScratch = nullptr;
         }
-        const bool solveInLds = D.solveScratch == nullptr;
+        d.solveInLds = D.solveScratch == nullptr;
         // solver choice: register tiles + MFMA up to kTileMaxFree free keyframes, else the LDS / global-scratch solver
-        static const char* solverEnv = getenv("EAO_BA_SOLVER");   // A/B switch for the profiling harness: tiles | lds
-        const bool wantLds = solverEnv && !strcmp(solverEnv, "lds");
-        const bool solveTiles = !bigPath && nF > 0 && nF <= kTileMaxFree && !wantLds;
-        const TileGeom tg = tile_geom(std::max(nF, 1));
-        const size_t tileLds = tile_solver_lds(std::max(nF, 1));
-        const bool tiles3 = tg.nTiles <= 3 * (kTileThreads / 64);
-        if (solveTiles) {
-            if (tiles3) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve_tiles<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileLds));
-            else EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve_tiles<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tileLds));
-        }
-        if (solveInLds && !solveTiles) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLds));
-        const size_t schurLds = bigPath ? 0 : schur_lds_bytes(nF);
-        if (nF && !bigPath) EAO_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
-        const BigGeom gB = big_geom(std::max(nF, 1));
-        if (bigPath) EAO_HIP(hipFuncSetAttribute((const void*)k_bal_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double))));
-        int* const ctl0 = dctl; double* const lm0 = dlm0;
-        auto use_pair = [&](int k) { D.ctl = ctl0 + 8 * k; D.lm = lm0 + 8 * k; };
-        auto enqueue_trial = [&](int bulk, bool firstTrial = false, bool withDecide = true) {
-            if (nF && bigPath) {
-                (void)hipMemsetAsync(D.big, 0, (size_t)gB.RP * gB.RP * sizeof(double), s);
-                hipLaunchKernelGGL(k_bal_schur_pairs, dim3(D.nPairsNZ), dim3(kBigPairThreads), 0, s, D, firstTrial ? 1 : 0);
-                const int nbk = gB.N / kBigNB, nT = gB.RP / 64;
-                hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, D);
-                for (int kb = 0; kb < nbk; kb++) {
-                    const int tj0 = (kb * kBigNB + kBigNB) >> 6;
-                    hipLaunchKernelGGL(k_bal_step, dim3(nT - tj0, nT - tj0), dim3(256), 0, s, D, kb, kb + 1 == nbk ? 1 : 0);
-                }
-                for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
-                    hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, D, J, dsolveOk);
-            } else if (nF && usePairs && solveTiles) {
-                hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2), dim3(kPairThreads), 0, s, D, firstTrial ? 1 : 0);
-            } else if (nF) {
-                hipLaunchKernelGGL(k_ba_schur, dim3(nF, chunks), dim3(kSchurThreads), schurLds, s, D, firstTrial ? 1 : 0);
-                if (solveTiles) hipLaunchKernelGGL(k_ba_reduce_tiles, dim3(tg.nTiles), dim3(256), 0, s, D);
-                else hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, D);
-            }
-            if (bigPath) {}
-            else if (solveTiles && tiles3) hipLaunchKernelGGL(k_ba_solve_tiles<3>, dim3(1), dim3(kTileThreads), tileLds, s, D, dsolveOk);
-            else if (solveTiles) hipLaunchKernelGGL(k_ba_solve_tiles<5>, dim3(1), dim3(kTileThreads), tileLds, s, D, dsolveOk);
-            else if (solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
-            else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), solveLds, s, D, dsolveOk);
-            if (nL && hasPl) hipLaunchKernelGGL(k_ba_backsub<true>, dim3(ptBlocks), dim3(256), 0, s, D);
-            else if (nL) hipLaunchKernelGGL(k_ba_backsub<false>, dim3(ptBlocks), dim3(256), 0, s, D);
-            if (withDecide) hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D, dsolveOk, c.status, ++seq, bulk, ctl0, lm0);
-        };
-        auto enqueue_bulk = [&](int from, int to, bool withErrors) {
-            use_pair(0);
-            if (withErrors) {   // computeActiveErrors + activeRobustChi2 (otherwise the accepted trial already left them)
-                if (nL && hasPl) hipLaunchKernelGGL(k_ba_errors<true>, dim3(ptBlocks), dim3(256), 0, s, D);
-                else if (nL) hipLaunchKernelGGL(k_ba_errors<false>, dim3(ptBlocks), dim3(256), 0, s, D);
-                hipLaunchKernelGGL(k_ba_chi_init, dim3(1), dim3(256), 0, s, D, c.status, ++seq);
-            }
-            // every trial but the last leaves its accept / reject decision to the head of the next linearisation, which
-            // runs on the other control block (BADecision); the last one is decided by k_ba_decide, which also brings the
-            // state back to the canonical block
-            int par = 0;
-            for (int it = from; it < to; it++) {
-                if (it == from) {
-                    if (hasPl) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0,
-                                                  (const int*)nullptr, (const double*)nullptr, (const int*)dsolveOk, c.status, 0);
-                    else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, it == 0 ? 1 : 0,
-                                            (const int*)nullptr, (const double*)nullptr, (const int*)dsolveOk, c.status, 0);
-                } else {
-                    const int* ctlOld = D.ctl; const double* lmOld = D.lm;
-                    par ^= 1;
-                    use_pair(par);
-                    ++seq;
-                    if (hasPl) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, 0, ctlOld, lmOld,
-                                                  (const int*)dsolveOk, c.status, seq);
-                    else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(linBlocks + nF), dim3(kLinThreads), 0, s, D, linBlocks, 0, ctlOld, lmOld,
-                                            (const int*)dsolveOk, c.status, seq);
-                }
-                if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, D);   // no Schur kernel to do it
-                enqueue_trial(1, it == 0 && nF, it == to - 1);
-            }
-            use_pair(0);
-        };
-        if (phase < 0) { enqueue_bulk(0, iterations, true); return EAO_OK; }   // enqueue only (speculative chaining)
+        const bool wantLds = solverEnv0 && !strcmp(solverEnv0, "lds");
+        d.solveTiles = !bigPath && nF > 0 && nF <= kTileMaxFree && !wantLds;
+        d.tileLds = tile_solver_lds(std::max(nF, 1));
+        d.tiles3 = tile_geom(std::max(nF, 1)).nTiles <= 3 * (kTileThreads / 64);
+        d.schurLds = bigPath ? 0 : schur_lds_bytes(nF);
+        d.gB = big_geom(std::max(nF, 1));
+        d.nPairsNZ = D.nPairsNZ; d.big = D.big;
+        // the window record itself travels with the structure
+        write_records((BADev*)hostp(dW));
+        EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));
+        L.W = dW; L.nz = 1; L.s = s; L.seq = c.status->seq;
+        c.status->ph[0].touched = c.status->ph[1].touched = 0;
+        chained = E > 0 && (nF + nL) > 0;
+        return EAO_OK;
+    }
+
+    eao_status wait_status(int want) {
+        EAO_HIP(hipStreamSynchronize(L.s));
+        if (c->status->seq != want) { eao::set_error("LM status hand-off out of sequence"); return EAO_ERR_INTERNAL; }
+        return EAO_OK;
+    }
+    eao_status set_ctl(int halt, int iters, int nBad) {
+        const int v[5] = {halt, curHost, iters, kStRunning, nBad};
+        EAO_HIP(hipMemcpyAsync(D.ctl0, v, sizeof(v), hipMemcpyHostToDevice, L.s));
+        return EAO_OK;
+    }
+    // ---- SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve per iteration.
+    // Iterations are enqueued in bulk (one trial each, no host round trip); the device finishes clean iterations itself
+    // and halts the window on anything else, which the host then replays trial by trial like g2o's do/while.
+    // resume: the first bulk segment of this call was already enqueued (and has finished) -- start from its outcome
+    eao_status optimize(int phase, int iterations, int* itersDone, double* chiOut, const BAPhase* resume) {
+        *itersDone = 0;
+        LMContext& c = *this->c;
+        eao_status st;
+        if (D.nFree + D.nL == 0) return EAO_OK;   // "_ivMap.size() == 0": nothing to optimise
         bool needErrors = true, ok = true;
         double currentChi = 0;
         int nBad = 0, done = 0;
@@ -3129,37 +3375,37 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
                 // ---- bulk segment: every remaining iteration, one trial each.  The control block is clean at the start of
                 //      an optimize() call (zeros from the upload / reset by the outlier pass); after a takeover it is rewritten.
                 if (done > 0 && (st = set_ctl(0, done, nBad))) return st;
-                enqueue_bulk(done, iterations, needErrors);
+                L.bulk(done, iterations, needErrors);
                 needErrors = false;
-                EAO_HIP(hipStreamSynchronize(s));
+                EAO_HIP(hipStreamSynchronize(L.s));
             }
             const BAPhase S = resume ? *resume : c.status->ph[phase];
             resume = nullptr;
             for (int k = done; k < S.iters && k < 32; k++) {
-                g_trace.lambda.push_back(c.status->trLambda[32 * phase + k]); g_trace.chi2.push_back(c.status->trChi[32 * phase + k]);
-                g_trace.trials.push_back(c.status->trTrials[32 * phase + k]);
+                tr->lambda.push_back(c.status->trLambda[32 * phase + k]); tr->chi2.push_back(c.status->trChi[32 * phase + k]);
+                tr->trials.push_back(c.status->trTrials[32 * phase + k]);
             }
-            g_trace.linearizations += S.iters - done;
+            tr->linearizations += S.iters - done;
             done = S.iters; nBad = S.nBad; curHost = S.cur; currentChi = S.chi;
             if (S.status == kStEmpty) { done = -1; break; }
             if (S.status == kStTerminate) { ok = false; break; }
             if (S.status != kStTakeover) break;           // all requested iterations done
             // ---- host takeover of iteration `done`: its first trial was rejected (or rho == 0 / NaN)
-            g_trace.linearizations++;
+            tr->linearizations++;
             const double iniChi = S.chi;
             double rho = S.rho;
             int qmax = 1;
             bool accepted = S.accepted != 0;
             while (rho < 0 && qmax < 10 && !(stop && *stop)) {
                 if ((st = set_ctl(0, done, nBad))) return st;
-                enqueue_trial(0);
-                if ((st = wait_status(seq))) return st;
+                L.trial(0, 0, false, true);
+                if ((st = wait_status(L.seq))) return st;
                 rho = c.status->rho; accepted = c.status->accepted != 0; curHost = c.status->cur;
                 if (accepted) currentChi = c.status->chi;
                 qmax++;
             }
             needErrors = !accepted;             // pop(): residuals belong to the rejected state
-            g_trace.lambda.push_back(c.status->lambda); g_trace.chi2.push_back(currentChi); g_trace.trials.push_back(qmax);
+            tr->lambda.push_back(c.status->lambda); tr->chi2.push_back(currentChi); tr->trials.push_back(qmax);
             done++;
             if (qmax == 10 || rho == 0) { ok = false; break; }
             if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
@@ -3168,66 +3414,215 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
         *itersDone = done;
         *chiOut = currentChi;
         return EAO_OK;
-    };
-    // Both optimize() calls of the reference, the outlier pass between them and the result copy go into the stream in ONE
-    // enqueue; the host synchronises once.  A rejected LM trial freezes the stream behind it (halt flag + the takeover
-    // check of the outlier pass), and the host then continues from where the device stopped, call by call as before.
-    // The abort flag is read before and after: the whole call takes less time than one g2o iteration on the CPU.
-    c.status->ph[0].touched = c.status->ph[1].touched = 0;
-    const bool chained = E > 0 && (D.nFree + D.nL) > 0;
-    if (chained) {
-        int dummyI; double dummyD;
-        if ((st = optimize(-1, p->its_first, &dummyI, &dummyD, nullptr))) return st;
-        if (mode == 0) {
-            hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
-            if ((st = optimize(-1, p->its_second, &dummyI, &dummyD, nullptr))) return st;
-        }
-        hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(std::max(E, nP * 3), nC), nPl * 4), 256)), dim3(256), 0, s, D, outCams, outPts, outCls, outPlanes);
-        EAO_HIP(hipStreamSynchronize(s));
     }
-    const BAPhase A = c.status->ph[0], B = c.status->ph[1];
-    if ((st = optimize(0, p->its_first, &r->iters[0], &r->chi2[0], chained ? &A : nullptr))) return st;
-    const bool firstClean = chained && A.status != kStTakeover;
-    const bool doMore = mode == 0 && (firstClean || !(stop && *stop));
-    bool redo = !chained || (mode == 1 && !firstClean);
-    if (doMore && E) {
-        // outlier pass (src/Optimizer.cc:978-1008): chi2 of the residual each edge last computed + depth test.  g2o's
-        // initializeOptimization(0) would now drop the level-1 edges (and vertices left without edges) from the active
-        // set; here they stay in the lists with zero weight, which leaves every sum -- and a vertex without edges --
-        // unchanged, and saves the host round trip of rebuilding and re-uploading the structure.
-        if (firstClean) {
-            if (B.status == kStTakeover) redo = true;
-            if ((st = optimize(1, p->its_second, &r->iters[1], &r->chi2[1], &B))) return st;
-        } else {
-            redo = true;
-            if ((st = set_ctl(0, 0, 0))) return st;            // the frozen stream left "takeover" in the control block
-            hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(E, 256)), dim3(256), 0, s, D, dcls, E, 1);
-            if ((st = optimize(1, p->its_second, &r->iters[1], &r->chi2[1], nullptr))) return st;
+
+    // After the chained enqueue (own or as part of a batch) has finished: takeovers, results.  The abort flag is read before
+    // and after: a clean window takes less time than one g2o iteration on the CPU.
+    eao_status complete() {
+        LMContext& c = *this->c;
+        eao_status st;
+        hipStream_t s = L.s;
+        const BAPhase A = c.status->ph[0], B = c.status->ph[1];
+        if ((st = optimize(0, p->its_first, &r->iters[0], &r->chi2[0], chained ? &A : nullptr))) return st;
+        const bool firstClean = chained && A.status != kStTakeover;
+        const bool doMore = mode == 0 && (firstClean || !(stop && *stop));
+        bool redo = !chained || (mode == 1 && !firstClean);
+        if (doMore && E) {
+            // outlier pass (src/Optimizer.cc:978-1008): chi2 of the residual each edge last computed + depth test.  g2o's
+            // initializeOptimization(0) would now drop the level-1 edges (and vertices left without edges) from the active
+            // set; here they stay in the lists with zero weight, which leaves every sum -- and a vertex without edges --
+            // unchanged, and saves the host round trip of rebuilding and re-uploading the structure.
+            if (firstClean) {
+                if (B.status == kStTakeover) redo = true;
+                if ((st = optimize(1, p->its_second, &r->iters[1], &r->chi2[1], &B))) return st;
+            } else {
+                redo = true;
+                if ((st = set_ctl(0, 0, 0))) return st;            // the frozen window left "takeover" in the control block
+                L.classify();
+                if ((st = optimize(1, p->its_second, &r->iters[1], &r->chi2[1], nullptr))) return st;
+            }
         }
+        if (redo) {
+            L.finish();
+            EAO_HIP(hipStreamSynchronize(s));
+        }
+        EAO_HIP(hipGetLastError());
+        if (D.dbg) {
+            long long stt[16];
+            EAO_HIP(hipMemcpy(stt, D.dbg, sizeof(stt), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld / %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
+                    stt[2] - stt[0], stt[4] - stt[2], stt[10], stt[11], stt[12], stt[6] - stt[4], stt[8] - stt[6], stt[3] - stt[1], stt[5] - stt[3], stt[7] - stt[5], stt[9] - stt[7]);
+        }
+        for (int i = 0; i < nC; i++) se3_to_Tcw_f32(outCams[i], r->cam_Tcw + 16 * i);
+        for (size_t i = 0; i < (size_t)nPo * 3; i++) r->points[i] = (float)outPts[i];
+        for (size_t i = 0; i < (size_t)nPl * 4; i++) planes_out[i] = (float)outPlanes[i];           // Converter::toCvMat(Plane3D)
+        if (Ept && r->edge_outlier) {
+            if (mode == 0) std::memcpy(r->edge_outlier, outCls, Ept);
+            else std::memset(r->edge_outlier, 0, Ept);
+        }
+        return EAO_OK;
     }
-    if (redo)
-    hipLaunchKernelGGL(k_ba_finish, dim3(eao::cdiv(std::max(std::max(std::max(E, nP * 3), nC), nPl * 4), 256)), dim3(256), 0, s, D, outCams, outPts, outCls, outPlanes);
-    EAO_HIP(hipEventRecord(c.ev1, s));
-    EAO_HIP(hipStreamSynchronize(s));
-    EAO_HIP(hipGetLastError());
+};
+
+}  // namespace
+
+static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r, int mode, int robust,
+                         const eao_ba_planes* pl = nullptr, float* planes_out = nullptr) {
+    LMContext& c = g_ctx;
+    eao_status st = ctx_init(c);
+    if (st) return st;
+    BAJob j;
+    j.p = p; j.stop = stop; j.r = r; j.mode = mode; j.robust = robust; j.pl = pl; j.planes_out = planes_out; j.c = &c; j.tr = &g_trace;
+    EAO_HIP(hipEventRecord(c.ev0, c.stream));
+    if ((st = j.prepare(c.stream))) return st;
+    if (j.trivial) return EAO_OK;
+    if ((st = j.L.attributes())) return st;
+    j.L.setup();
+    if (j.chained) {
+        j.L.chain(mode, p->its_first, p->its_second);
+        EAO_HIP(hipStreamSynchronize(c.stream));
+    }
+    if ((st = j.complete())) return st;
+    EAO_HIP(hipEventRecord(c.ev1, c.stream));
+    EAO_HIP(hipStreamSynchronize(c.stream));
     EAO_HIP(hipEventElapsedTime(&g_trace.deviceMs, c.ev0, c.ev1));
-    if (D.dbg) {
-        long long st[16];
-        EAO_HIP(hipMemcpy(st, D.dbg, sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld / %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
-                st[2] - st[0], st[4] - st[2], st[10], st[11], st[12], st[6] - st[4], st[8] - st[6], st[3] - st[1], st[5] - st[3], st[7] - st[5], st[9] - st[7]);
-    }
-    for (int i = 0; i < nC; i++) se3_to_Tcw_f32(outCams[i], r->cam_Tcw + 16 * i);
-    for (size_t i = 0; i < (size_t)nPo * 3; i++) r->points[i] = (float)outPts[i];
-    for (size_t i = 0; i < (size_t)nPl * 4; i++) planes_out[i] = (float)outPlanes[i];           // Converter::toCvMat(Plane3D)
-    if (Ept && r->edge_outlier) {
-        if (mode == 0) std::memcpy(r->edge_outlier, outCls, Ept);
-        else std::memset(r->edge_outlier, 0, Ept);
-    }
     return EAO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LocalBundleAdjustment of MANY independent windows (the batched-sequence configuration: 25 windows of 20 keyframes): the
+// window is the z dimension of every launch.  Each window owns a context (arena, pinned mirrors, status block); the
+// host-side set-up of the windows runs on a few host threads; ONE chained enqueue serves them all; a window whose LM
+// rejected a trial freezes by itself (its halt flag) and is finished by the host afterwards exactly like a single call.
+namespace {
+struct BABatchPool {
+    std::vector<std::unique_ptr<LMContext>> ctx;
+    std::vector<LMTraceHost> trace;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    BADev* hW = nullptr; size_t hWCap = 0;      // pinned mirror of the window array
+    eao::DevBuf<BADev> dW;
+    ~BABatchPool() {
+        if (hW) (void)hipHostFree(hW);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+thread_local BABatchPool g_batch;
+}  // namespace
+
+extern "C" {
+
 eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r) { return ba_run(p, stop, r, 0, 1); }
+
+eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const volatile uint8_t* stop, eao_ba_result* results) {
+    EAO_REQUIRE(n >= 0 && (n == 0 || (problems && results)), "null argument");
+    if (n == 0) return EAO_OK;
+    eao_status st = eao::require_device();
+    if (st) return st;
+    BABatchPool& B = g_batch;
+    if (!B.stream) {
+        EAO_HIP(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+        EAO_HIP(hipEventCreate(&B.ev0));
+        EAO_HIP(hipEventCreate(&B.ev1));
+    }
+    while ((int)B.ctx.size() < n) B.ctx.emplace_back(new LMContext());
+    if ((int)B.trace.size() < n) B.trace.resize(n);
+    for (int w = 0; w < n; w++)
+        if ((st = ctx_init(*B.ctx[w], false))) return st;
+    if (B.hWCap < (size_t)n * 2) {
+        if (B.hW) (void)hipHostFree(B.hW);
+        B.hW = nullptr; B.hWCap = 0;
+        EAO_HIP(hipHostMalloc((void**)&B.hW, (size_t)n * 2 * sizeof(BADev), hipHostMallocDefault));
+        B.hWCap = (size_t)n * 2;
+    }
+    if ((st = B.dW.reserve((size_t)n * 2))) return st;
+    g_trace.clear();
+    std::vector<BAJob> jobs(n);
+    for (int w = 0; w < n; w++) {
+        BAJob& j = jobs[w];
+        j.p = &problems[w]; j.stop = stop; j.r = &results[w]; j.mode = 0; j.robust = 1; j.c = B.ctx[w].get(); j.tr = &B.trace[w];
+        j.c->status->seq = 0;        // every window of the batch sees the same hand-off sequence numbers
+    }
+    static const bool envTiming = getenv("EAO_BA_BATCH_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    EAO_HIP(hipEventRecord(B.ev0, B.stream));
+    // ---- host-side set-up of the windows (validation, pinned mirror, active structure, two uploads each) on a few host
+    //      threads: it is ~0.1 ms of memcpy and counting per window, which would otherwise be most of the call
+    static const int envThreads = getenv("EAO_BA_BATCH_THREADS") ? atoi(getenv("EAO_BA_BATCH_THREADS")) : 0;
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nThreads = std::max(1, std::min(n, envThreads > 0 ? envThreads : std::min(8, std::max(1, hw / 2))));
+    std::vector<eao_status> stw(n, EAO_OK);
+    std::vector<std::string> errw(n);
+    int dev = 0;
+    EAO_HIP(hipGetDevice(&dev));
+    auto work = [&](int t) {
+        if (t > 0) (void)hipSetDevice(dev);
+        for (int w = t; w < n; w += nThreads) {
+            stw[w] = jobs[w].prepare(B.stream);
+            if (stw[w]) errw[w] = eao_last_error();
+        }
+    };
+    if (nThreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nThreads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (int w = 0; w < n; w++)
+        if (stw[w]) { eao::set_error("window %d: %s", w, errw[w].c_str()); (void)hipStreamSynchronize(B.stream); return stw[w]; }
+    // ---- the windows that share the batched enqueue (tile-solver path, something to optimise); the others -- windows
+    //      beyond 30 free keyframes, empty ones -- follow one by one on the same stream
+    const double msPrepare = since(tp0);
+    std::vector<int> inBatch;
+    BALaunch LB;
+    LB.s = B.stream; LB.W = B.dW.p; LB.seq = 0;
+    for (int w = 0; w < n; w++) {
+        BAJob& j = jobs[w];
+        if (!j.batchable() || j.p->its_first != jobs[inBatch.empty() ? w : inBatch[0]].p->its_first ||
+            j.p->its_second != jobs[inBatch.empty() ? w : inBatch[0]].p->its_second) continue;
+        if (inBatch.empty()) LB.d = j.L.d; else LB.d.merge(j.L.d);
+        j.write_records(B.hW + 2 * inBatch.size());
+        inBatch.push_back(w);
+    }
+    std::vector<char> batched(n, 0);
+    if (!inBatch.empty()) {
+        LB.nz = (int)inBatch.size();
+        EAO_HIP(hipMemcpyAsync(B.dW.p, B.hW, (size_t)LB.nz * 2 * sizeof(BADev), hipMemcpyHostToDevice, B.stream));
+        if ((st = LB.attributes())) return st;
+        LB.setup();
+        LB.chain(0, jobs[inBatch[0]].p->its_first, jobs[inBatch[0]].p->its_second);
+        for (int w : inBatch) batched[w] = 1;
+    }
+    for (int w = 0; w < n; w++) {
+        BAJob& j = jobs[w];
+        if (batched[w] || j.trivial) continue;
+        if ((st = j.L.attributes())) return st;
+        j.L.setup();
+        if (j.chained) j.L.chain(0, j.p->its_first, j.p->its_second);
+    }
+    const double msEnqueue = since(tp0);
+    EAO_HIP(hipStreamSynchronize(B.stream));
+    const double msSync = since(tp0);
+    EAO_HIP(hipGetLastError());
+    for (int w = 0; w < n; w++) {
+        BAJob& j = jobs[w];
+        if (j.trivial) continue;
+        if (batched[w]) j.L.seq = LB.seq;
+        if ((st = j.complete())) { const std::string m = eao_last_error(); eao::set_error("window %d: %s", w, m.c_str()); return st; }
+        g_trace.linearizations += j.tr->linearizations;
+    }
+    EAO_HIP(hipEventRecord(B.ev1, B.stream));
+    EAO_HIP(hipStreamSynchronize(B.stream));
+    EAO_HIP(hipEventElapsedTime(&g_trace.deviceMs, B.ev0, B.ev1));
+    if (envTiming)
+        fprintf(stderr, "[eao_local_ba_batch] %d windows (%d batched, %d host threads): set-up + uploads enqueued %.3f ms, launches enqueued %.3f, device done %.3f, results out %.3f\n",
+                n, (int)inBatch.size(), nThreads, msPrepare, msEnqueue, msSync, since(tp0));
+    return EAO_OK;
+}
 
 eao_status eao_bundle_adjustment(const eao_ba_problem* p, int32_t robust, const volatile uint8_t* stop, eao_ba_result* r) {
     return ba_run(p, stop, r, 1, robust != 0);

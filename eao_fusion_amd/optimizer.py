@@ -98,6 +98,39 @@ class Optimizer:
         return out
 
     @staticmethod
+    def pack_batch(probs, its=(5, 10)):
+        """The argument arrays of eao_local_ba_batch for a list of windows (kept alive by the returned object)."""
+        n = len(probs)
+        P, R = (_lib.BAProblem * n)(), (_lib.BAResult * n)()
+        keep, outs = [], []
+        for w, prob in enumerate(probs):
+            cams = np.ascontiguousarray(prob["poses"], np.float32); fixed = np.ascontiguousarray(prob["fixed"], np.uint8)
+            pts = np.ascontiguousarray(prob["points"], np.float32); ec = np.ascontiguousarray(prob["edge_cam"], np.int32)
+            ep = np.ascontiguousarray(prob["edge_point"], np.int32); obs = np.ascontiguousarray(prob["obs"], np.float32)
+            inv = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+            P[w] = _lib.BAProblem(len(cams), len(pts), len(ec), _lib.ptr(cams), _lib.ptr(fixed), _lib.ptr(pts), _lib.ptr(ec), _lib.ptr(ep),
+                                  _lib.ptr(obs), _lib.ptr(inv), prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], its[0], its[1])
+            co, po, ol = np.zeros_like(cams), np.zeros_like(pts), np.zeros(max(len(ec), 1), np.uint8)
+            R[w].cam_Tcw, R[w].points, R[w].edge_outlier = _lib.ptr(co), _lib.ptr(po), _lib.ptr(ol)
+            keep.append((cams, fixed, pts, ec, ep, obs, inv))
+            outs.append((co, po, ol, len(ec)))
+        return dict(P=P, R=R, n=n, keep=keep, outs=outs)
+
+    @staticmethod
+    def LocalBundleAdjustmentBatch(probs, stop=None, its=(5, 10), packed=None):
+        """n independent windows through ONE eao_local_ba_batch call (the window is a grid dimension of every launch).
+        Returns a list of result dicts shaped like LocalBundleAdjustment's (without the per-window LM trace)."""
+        pk = packed or Optimizer.pack_batch(probs, its)
+        stop_p = None
+        if stop is not None:
+            stop = np.ascontiguousarray(stop, np.uint8)
+            stop_p = _lib.ptr(stop)
+        _lib.check(_lib.load().eao_local_ba_batch(pk["P"], pk["n"], stop_p, pk["R"]))
+        tm = _timing()
+        return [dict(poses=co, points=po, edge_outlier=ol[:ne], iters=np.array(pk["R"][w].iters[:]), aborted=bool(pk["R"][w].aborted),
+                     chi2=np.array(pk["R"][w].chi2[:]), timing=tm) for w, (co, po, ol, ne) in enumerate(pk["outs"])]
+
+    @staticmethod
     def BundleAdjustment(prob, nIterations=5, stop=None, bRobust=True):
         """Optimizer::BundleAdjustment over keyframes and map points (reference src/Optimizer.cc:55-323): one
         optimize(nIterations) call, Huber kernels only when bRobust, nothing is erased.  prob as for LocalBundleAdjustment

@@ -376,6 +376,14 @@ typedef struct {
 /* stop may be NULL; it is polled on the host between LM iterations like g2o's forceStopFlag */
 eao_status eao_local_ba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r);
 
+/* The same call for n INDEPENDENT windows at once (BASELINE configs[4]: the 25 local-BA windows of a batched sequence; in
+ * a live system: the windows of several maps / agents).  Every window is exactly one eao_local_ba call -- same inputs, same
+ * outputs, same LM schedule (src/Optimizer.cc:675-1138 per window; independence per SURVEY.md s8e) -- but the window is the
+ * z dimension of every kernel launch, so one enqueue serves them all.  Windows the batched path does not take (more than 30
+ * free keyframes, nothing to optimise) run one after the other inside the same call.  `stop` is shared by all windows.
+ * eao_last_lm_timing then reports the device time of the whole batch and the linearisations summed over the windows. */
+eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const volatile uint8_t* stop, eao_ba_result* results);
+
 /* f3  Optimizer::BundleAdjustment(vpKFs, vpMP, vpMPl, nIterations, pbStopFlag, nLoopKF, bRobust) --
  * src/Optimizer.cc:55-323: the same flattening as eao_local_ba (cameras in ascending mnId with
  * cam_fixed = (mnId == 0), points in ascending mnId, points without an edge simply stay where they are),

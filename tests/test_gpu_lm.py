@@ -257,3 +257,67 @@ def test_bundle_adjustment_limits(gpu):
     p = synth.synth_ba(n_free=4, n_fixed=1, n_points=100, seed=5105)
     r = gpu.Optimizer.BundleAdjustment(p, 10, stop=np.array([1], np.uint8))
     assert r["aborted"] and np.array_equal(r["points"], p["points"])
+
+
+def _same_result(a, b):
+    return (np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"]) and
+            np.array_equal(a["edge_outlier"], b["edge_outlier"]) and list(a["iters"]) == list(b["iters"]) and
+            np.array_equal(a["chi2"], b["chi2"]))
+
+
+def _close_result(a, b, p):
+    """Same LM schedule and outlier table; poses / points within the parity bar of the UPDATE (the batched Schur assembly adds
+    its landmarks in another order than the single-window kernel: rounding-level differences only)."""
+    assert list(a["iters"]) == list(b["iters"]) and np.array_equal(a["edge_outlier"], b["edge_outlier"])
+    _check_updates(a["poses"], b["poses"], p["poses"], "poses")
+    _check_updates(a["points"], b["points"], p["points"], "points")
+    assert np.allclose(a["chi2"], b["chi2"], rtol=1e-4)
+
+
+def test_local_ba_batch_equals_single_calls(gpu):
+    """eao_local_ba_batch: the window is the z dimension of every launch.  Every window must come out as its own
+    eao_local_ba call does -- clean windows, windows of different sizes in one batch, windows whose LM rejects trials (they
+    freeze inside the batch and the host finishes them), a window beyond the tile solver (runs on its own inside the call)
+    -- and the batch itself must be deterministic and independent of its composition and order.  A batch of ONE window
+    runs the single-window kernels: bit-identical."""
+    probs = [synth.synth_ba(seed=6000 + w) for w in range(5)]
+    probs += [synth.synth_ba(n_free=5, n_fixed=2, n_points=300, seed=6100), synth.synth_ba(n_free=7, n_fixed=2, n_points=400, seed=6101),
+              synth.synth_ba(n_free=30, n_fixed=3, n_points=1500, seed=6102)]
+    probs += [synth.synth_ba(n_free=5, n_fixed=2, n_points=200, seed=sd, rot_noise_deg=25, trans_noise=0.8, point_noise=1.0, mono_frac=0.7)
+              for sd in (3030, 3034, 3046)]
+    probs += [synth.synth_ba(n_free=34, n_fixed=2, n_points=1500, seed=6103)]
+    single = [gpu.Optimizer.LocalBundleAdjustment(p) for p in probs]
+    batch = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
+    assert len(batch) == len(probs)
+    for w, (a, b) in enumerate(zip(single, batch)):
+        _close_result(b, a, probs[w])
+    assert _same_result(single[-1], batch[-1])          # (the 34-keyframe window ran on its own inside the call)
+    again = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
+    assert all(_same_result(a, b) for a, b in zip(batch, again)), "eao_local_ba_batch is not deterministic"
+    # order and batch composition do not matter
+    rev = gpu.Optimizer.LocalBundleAdjustmentBatch(probs[::-1])[::-1]
+    assert all(_same_result(a, b) for a, b in zip(batch, rev))
+    sub = gpu.Optimizer.LocalBundleAdjustmentBatch(probs[2:7])
+    assert all(_same_result(a, b) for a, b in zip(batch[2:7], sub))
+    one = gpu.Optimizer.LocalBundleAdjustmentBatch(probs[:1])
+    assert _same_result(one[0], single[0])
+
+
+def test_local_ba_batch_parity_configs4(gpu, oracle):
+    """The 25 windows of BASELINE configs[4] (seeds 6000 + w) in one call; windows 0 and 24 against the fp64 oracle."""
+    probs = [synth.synth_ba(seed=6000 + w) for w in range(25)]
+    res = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
+    for w in (0, 24):
+        o = oracle.local_ba(probs[w])
+        assert list(res[w]["iters"]) == list(o["iters"])
+        _check_updates(res[w]["poses"], o["poses"], probs[w]["poses"], "poses of window %d" % w)
+        _check_updates(res[w]["points"], o["points"], probs[w]["points"], "points of window %d" % w)
+        assert np.array_equal(res[w]["edge_outlier"], o["edge_outlier"])
+
+
+def test_local_ba_batch_stop_and_empty(gpu):
+    probs = [synth.synth_ba(n_free=5, n_fixed=2, n_points=300, seed=6200 + w) for w in range(3)]
+    res = gpu.Optimizer.LocalBundleAdjustmentBatch(probs, stop=np.array([1], np.uint8))
+    for p, r in zip(probs, res):
+        assert r["aborted"] and np.array_equal(r["points"], p["points"]) and not r["edge_outlier"].any()
+    assert gpu.Optimizer.LocalBundleAdjustmentBatch([]) == []
