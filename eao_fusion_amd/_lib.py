@@ -85,6 +85,7 @@ SYMBOLS = {
     "eao_hamming_best2": (_I, [_P, _I, _P, _I, _P, _P]),
     "eao_hamming_matrix_device": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "eao_hamming_best2_device": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
+    "eao_hamming_best2_sequence_device": (_I, [_P, _I, _P, _I, _P, _I, _P, _P]),
     "eao_search_by_projection_points": (_I, [C.POINTER(FrameView), _I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, C.POINTER(_I)]),
     "eao_search_by_projection_frames": (_I, [C.POINTER(FrameView), _P, _P, _I, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P, C.POINTER(_I)]),
     # the remaining guided searches: argument lists live in search.py (SEARCH_ARGTYPES), bound there

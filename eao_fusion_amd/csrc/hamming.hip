@@ -172,6 +172,61 @@ __global__ __launch_bounds__(256) void k_hamming_best2_rows(const uint4* __restr
     }
 }
 
+// Consecutive-frame matcher of a device-resident batch (the batched-sequence configuration): pair f = (frame f - 1, frame f)
+// of one descriptor block [batch][cap][32], keypoint counts read ON THE DEVICE (the extractor's d_n) -- no host round trip
+// between extraction and matching.  Pair 0 takes the halo frame (the last frame of the previous shard) as its left side, or
+// is skipped when there is none.  Same sixteen-rows-per-wavefront scheme as k_hamming_best2_rows.
+__global__ __launch_bounds__(256) void k_hamming_best2_seq(const uint4* __restrict__ desc, int cap, const int* __restrict__ counts,
+                                                           const uint4* __restrict__ halo, int haloN, eao_best2* __restrict__ out) {
+    __shared__ uint4 sa[4][kB2Rows * 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = blockIdx.y;
+    const uint4* A = f ? desc + (long long)(f - 1) * cap * 2 : halo;
+    const int na = f ? min(counts[f - 1], cap) : haloN, nb = min(counts[f], cap);
+    const int i0 = (blockIdx.x * 4 + wv) * kB2Rows;
+    if (!A || i0 >= na) return;
+    const uint4* B = desc + (long long)f * cap * 2;
+    if (lane < kB2Rows * 2) {
+        const int r = i0 + (lane >> 1);
+        sa[wv][lane] = r < na ? A[(long long)r * 2 + (lane & 1)] : make_uint4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned none = (256u << 20) | 0xFFFFFu;
+    unsigned k1[kB2Rows], k2[kB2Rows];
+#pragma unroll
+    for (int r = 0; r < kB2Rows; r++) { k1[r] = none; k2[r] = none; }
+    for (int j = lane; j < nb; j += 64) {
+        const uint4 b0 = B[(long long)j * 2], b1 = B[(long long)j * 2 + 1];
+#pragma unroll
+        for (int r = 0; r < kB2Rows; r++) {
+            const unsigned d = dist8(sa[wv][2 * r], sa[wv][2 * r + 1], b0, b1);
+            const unsigned key = (d << 20) | (unsigned)j;
+            const unsigned lo = min(key, k1[r]);
+            k2[r] = min(max(key, k1[r]), k2[r]);
+            k1[r] = lo;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kB2Rows; r++) {
+        unsigned a1 = k1[r], a2 = k2[r];
+#pragma unroll
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            const unsigned o1 = __shfl_xor(a1, dlt), o2 = __shfl_xor(a2, dlt);
+            const unsigned n1 = min(a1, o1);
+            const unsigned n2 = min(max(a1, o1), min(a2, o2));
+            a1 = n1; a2 = n2;
+        }
+        if (lane == r && i0 + r < na) {
+            eao_best2 res;
+            res.best = (int)(a1 >> 20);
+            res.second = (int)(a2 >> 20);
+            res.idx = a1 == none ? -1 : (int)(a1 & 0xFFFFF);
+            res.idx2 = a2 == none ? -1 : (int)(a2 & 0xFFFFF);
+            out[(long long)f * cap + i0 + r] = res;
+        }
+    }
+}
+
 struct Scratch {
     eao::DevBuf<uint8_t> a, b, mask;
     eao::DevBuf<unsigned short> d;
@@ -272,6 +327,19 @@ eao_status eao_hamming_best2_device(const uint8_t* d_A, int32_t na, const uint8_
     else
         hipLaunchKernelGGL(k_hamming_best2, dim3(eao::cdiv(na, 4), pairs), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_A, na,
                            (const uint4*)d_B, nb, d_mask, d_out);
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
+
+eao_status eao_hamming_best2_sequence_device(const uint8_t* d_desc, int32_t cap, const int32_t* d_counts, int32_t batch,
+                                             const uint8_t* d_halo_desc, int32_t halo_n, eao_best2* d_out, void* stream) {
+    EAO_REQUIRE(d_desc && d_counts && d_out && cap > 0 && batch > 0 && halo_n >= 0 && (halo_n == 0 || d_halo_desc), "bad argument");
+    EAO_REQUIRE(cap < (1 << 20), "cap must be below 2^20");
+    EAO_REQUIRE(((uintptr_t)d_desc & 15) == 0 && ((uintptr_t)d_halo_desc & 15) == 0, "descriptor arrays must be 16-byte aligned");
+    eao_status st = eao::require_device();
+    if (st) return st;
+    hipLaunchKernelGGL(k_hamming_best2_seq, dim3(eao::cdiv(cap, 4 * kB2Rows), batch), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_desc, cap,
+                       d_counts, halo_n ? (const uint4*)d_halo_desc : nullptr, halo_n, d_out);
     EAO_HIP(hipGetLastError());
     return EAO_OK;
 }

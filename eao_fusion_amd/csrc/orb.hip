@@ -1373,6 +1373,8 @@ struct eao_orb {
     // (EAO_ORB_LANES, default 1: see the measurement note at enqueue())
     static constexpr int kLanes = 4;
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
+    hipEvent_t evLast = nullptr;   // end of the previous call on this handle (whatever stream it ran on)
+    bool evLastValid = false, capturing = false;
     hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
@@ -1519,6 +1521,7 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
     if (!h->stream) {
         EAO_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         EAO_HIP(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
+        EAO_HIP(hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming));
         for (int i = 0; i < eao_orb::kLanes; i++) {
             EAO_HIP(hipStreamCreateWithFlags(&h->laneMain[i], hipStreamNonBlocking));
             EAO_HIP(hipStreamCreateWithFlags(&h->laneSide[i], hipStreamNonBlocking));
@@ -1579,6 +1582,9 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     // split the batch into up to kLanes contiguous slices; slice i runs pyramid -> {FAST -> quad-tree | blur} ->
     // orientation + description on its own stream pair.  Profiling events bracket the stages of slice 0.
     lanes = std::max(1, std::min(std::min(eao_orb::kLanes, batch), lanes));
+    // the handle's pyramid / candidate scratch is shared by its calls: a call enqueued on another stream than the previous
+    // one waits for it (same stream: already ordered, the wait costs nothing)
+    if (h->evLastValid && !h->capturing) EAO_HIP(hipStreamWaitEvent(st, h->evLast, 0));
     EAO_HIP(hipEventRecord(h->evStart, st));
     for (int i = 0; i < lanes; i++) {
         const int f0 = (int)((long long)batch * i / lanes), f1 = (int)((long long)batch * (i + 1) / lanes), nb = f1 - f0;
@@ -1675,6 +1681,10 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
     }
     if (prof) EAO_HIP(hipEventRecord(ev[8], st));
+    if (!h->capturing) {
+        EAO_HIP(hipEventRecord(h->evLast, st));
+        h->evLastValid = true;
+    }
     EAO_HIP(hipGetLastError());
     return EAO_OK;
 }
@@ -1695,7 +1705,9 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
         if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
         hipGraph_t graph = nullptr;
         EAO_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->capturing = true;
         const eao_status st2 = enqueue_direct(h, d_img, pitch0, fs0, batch, d_kps, d_desc, cap, d_n, h->stream, envLanes);
+        h->capturing = false;
         const hipError_t e = hipStreamEndCapture(h->stream, &graph);
         if (st2) { if (graph) (void)hipGraphDestroy(graph); return st2; }
         if (e != hipSuccess) { eao::set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return EAO_ERR_NO_DEVICE; }
@@ -1773,6 +1785,7 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
     if (h->evStart) (void)hipEventDestroy(h->evStart);
+    if (h->evLast) (void)hipEventDestroy(h->evLast);
     if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
     delete h;
 }
@@ -1808,7 +1821,9 @@ eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_
         eao::set_error("cap %d < eao_orb_max_keypoints %d", cap, h->geom.totalKpCap);
         return EAO_ERR_CAPACITY;
     }
-    return enqueue(h, d_img, stride, frame_stride, batch, d_kps, d_desc, cap, d_n, stream ? (hipStream_t)stream : h->stream);
+    // exactly the caller's stream: NULL is the (legacy) null stream, as in the Hamming entry points -- torch's default stream
+    // among others; work the caller enqueues behind this call on that stream is ordered behind the extraction
+    return enqueue(h, d_img, stride, frame_stride, batch, d_kps, d_desc, cap, d_n, (hipStream_t)stream);
 }
 
 eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, int64_t frame_stride,

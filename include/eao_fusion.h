@@ -87,7 +87,10 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
                                  int64_t frame_stride, int32_t batch, eao_keypoint* kps, uint8_t* desc, int32_t cap,
                                  int32_t* n);
 
-/* Same, all pointers device-resident (HBM), asynchronous on `stream`.  d_n: batch int32 on the device. */
+/* Same, all pointers device-resident (HBM), asynchronous on `stream` (a hipStream_t; NULL = the null stream, exactly as the
+ * Hamming entry points read it): whatever the caller enqueues on that stream afterwards is ordered behind the extraction.
+ * Calls on one handle are serialised with each other even when they come in on different streams (they share the handle's
+ * pyramid and candidate scratch).  d_n: batch int32 on the device. */
 eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_t width, int32_t height,
                                         int32_t stride, int64_t frame_stride, int32_t batch, eao_keypoint* d_kps,
                                         uint8_t* d_desc, int32_t cap, int32_t* d_n, void* stream);
@@ -134,6 +137,16 @@ eao_status eao_hamming_matrix_device(const uint8_t* d_A, int32_t na, const uint8
                                      uint16_t* d_D, void* stream);
 eao_status eao_hamming_best2_device(const uint8_t* d_A, int32_t na, const uint8_t* d_B, int32_t nb, int32_t pairs,
                                     const uint8_t* d_mask, eao_best2* d_out, void* stream);
+
+/* The consecutive-frame matcher of a device-resident batch (BASELINE configs[4]): pair f = (frame f - 1,
+ * frame f) for every frame of the descriptor block d_desc [batch][cap][32] an eao_orb_extract_batch_device call left on
+ * the device, with the per-frame keypoint counts read ON THE DEVICE from d_counts (that call's d_n) -- no host round trip
+ * between extraction and matching.  Result of pair f, row i < count[f - 1]: d_out[f * cap + i] = the two nearest
+ * descriptors of frame f (same definition as eao_hamming_best2).  Pair 0 matches the halo frame (d_halo_desc, halo_n rows:
+ * the last frame of the previous shard) against frame 0, or is skipped when halo_n == 0.  Rows beyond a pair's count are
+ * not written. */
+eao_status eao_hamming_best2_sequence_device(const uint8_t* d_desc, int32_t cap, const int32_t* d_counts, int32_t batch,
+                                             const uint8_t* d_halo_desc, int32_t halo_n, eao_best2* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Guided matching -- ORBmatcher::SearchByProjection, the two per-frame tracking variants
