@@ -10,7 +10,8 @@ A "step" = one pass of the hot path over one batch of synthetic input, inputs al
     descriptor sets is NOT included in `value` (reported under "extra").
 Local BA (configs[3], 20 KF x 3000 MP) and Hamming (configs[2]) are measured after the timed region and reported
 under "extra" -- the combined BASELINE metric has two halves; `value` is its first half (ORB kpts/s), the BA half
-is extra.ba_residual_blocks_per_s.
+is extra.ba (one window, latency at the C-ABI) and extra.ba_batch (25 windows per call, residual blocks/s).
+`python bench.py --gpus N` (N > 1) starts its own torch.distributed.run child; extra.sequence is BASELINE configs[4].
 
 The default batch is the 64 frames configs[1] names; the pyramid chain and the quad-tree are latency-bound, so larger batches
 amortise them -- `extra.orb_batch256` carries the 256-frame figure of the same call.
@@ -33,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4   # wave instructions / s: 256 CUs x 4 SIMDs, one (integer / packed) VALU instruction per 4 cycles (tools/ubench/intops.hip)
 
 # algorithmic bytes per frame of each stage at 640x480 / 8 levels (DESIGN.md "roofline accounting")
 LEVELS = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
@@ -79,7 +81,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import eao_fusion_amd as E  # after torch: one libamdhip64 in the process
-    from eao_fusion_amd import shard, synth
+    from eao_fusion_amd import sequence, shard, synth
 
     B, W, H = args.batch, 640, 480
     n_frames = B * world                                   # weak scaling: B frames per GPU
@@ -87,16 +89,11 @@ def main():
     assert hi - lo == B
     frames = np.stack([synth.synth_frame(1000 + f, W, H) for f in range(lo, hi)])
     d_img = torch.from_numpy(frames).to(dev)
-    ext = E.ORBextractor(1000, 1.2, 8, 20, 7)
-    cap = ext.max_keypoints(W, H)
-    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    seq = sequence.SequenceShard(B, W, H, dev)             # the extractor + its device-resident outputs (also used by tests/test_gpu_sequence.py)
+    ext, cap, d_kps, d_desc, d_n = seq.ext, seq.cap, seq.d_kps, seq.d_desc, seq.d_n
 
     def step():
-        ext.extract_batch_device(d_img.data_ptr(), W, H, W, W * H, B, d_kps.data_ptr(), d_desc.data_ptr(), cap,
-                                 d_n.data_ptr(), stream)
+        seq.extract(d_img)
 
     def barrier():
         if world > 1:
@@ -142,50 +139,57 @@ def main():
     }
     dom = max(stage_bytes, key=lambda k: stage_ms[k])
     achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of
-    # this same command; profiles/r01_pmc_traffic.json explains the calibration) -- per launch, like `achieved`
-    traffic = None
+    # HBM traffic of the dominant kernel: FETCH_SIZE + WRITE_SIZE from the COMMITTED PMC passes of this same command (two
+    # separate rocprofv3 --pmc runs, profiles/r02_pmc_traffic.json) -- a recorded figure, not measured in this run.  FETCH_SIZE
+    # carries the guide's x2 (MI355X_MICROARCH.md, HBM): the blur's own byte count confirms it for these 4 / 12-byte-per-lane
+    # reads (22/16 halo rows x 60.8 MB = 83.6 MB expected, 2 x 42.9 MB counted).
+    traffic, traffic_note = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         if pmc.get("batch") == B and dom in pmc["kernels"]:
             k = pmc["kernels"][dom]
-            traffic = int(k["hbm_bytes_per_step"])   # all launches of the stage in one step (the pyramid is 7, FAST 1 or 2)
+            traffic = int(2 * k["fetch_bytes_per_step"] + k["write_bytes_per_step"])   # all launches of the stage in one step
+            traffic_note = "from the committed PMC passes (profiles/r02_pmc_traffic.json): 2 x FETCH_SIZE + WRITE_SIZE per step"
+    except Exception:
+        pass
+    # VALU roofline: wave instructions per launch (SQ_INSTS_VALU of the committed PMC pass, a property of the kernel and its
+    # input) / the launch duration measured in THIS run / the chip's issue rate (1024 SIMDs x one wave instruction per 4 cycles)
+    valu = {}
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+        kname = {"pyramid": "k_resize", "fast": "k_fast_cells", "quadtree": "k_quadtree", "blur": "k_blur7", "orient_describe": "k_orient_describe"}
+        if sq.get("batch") == B:
+            for st_, kn in kname.items():
+                if kn in sq["kernels"] and stage_ms.get(st_, 0) > 0:
+                    insts = sq["kernels"][kn]["SQ_INSTS_VALU"] * sq["kernels"][kn].get("launches_per_step", 1)
+                    valu[st_] = round(insts / (stage_ms[st_] * 1e-3) / VALU_PEAK_WAVE_INSTS, 4)
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": int(stage_bytes[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                "valu_frac": valu.get(dom), "valu_frac_by_stage": valu,
+                "valu_note": "SQ_INSTS_VALU per launch (committed PMC pass, profiles/r02_pmc_sq.json) / this run's launch time / 6.14e11 wave-instructions/s (1024 SIMDs, 2.4 GHz, 4 cycles each): the dominant kernel is instruction-bound, the HBM fraction is reported because the contract asks for it",
                 "pipeline_GBps": round(sum(stage_bytes.values()) / (stage_ms["total"] * 1e-3) / 1e9, 2)}
 
     # every collective first (all ranks), the rank-0-only measurements afterwards: no rank waits inside RCCL for minutes
     gathered = {}
     # ---- BASELINE configs[4] (batched sequence), outside the timed region: consecutive-frame matching inside the shard (one
-    #      halo frame from the previous rank) and this rank's share of the local-BA windows (window w -> rank w mod N)
-    seq = {}
+    #      halo frame from the previous rank), this rank's share of the 25 local-BA windows (window w -> rank w mod N) in ONE
+    #      eao_local_ba_batch call, and the s8(e) all-gather of every frame's (keypoints, descriptors) and every window's result
+    seqr = {}
     if not args.no_extra:
-        halo_desc, halo_n = shard.exchange_halo(d_desc[B - 1], int(n_host[B - 1]), device=dev)   # symmetric collective: every rank calls it
-        seq_local = [0.0, 0.0, 0.0, 0.0]      # frame pairs, seconds matching, residual blocks, seconds BA
         try:
-            seq_local = measure_sequence(E, synth, shard, torch, dev, rank, world, d_desc, n_host, halo_desc, halo_n)
+            seqr = measure_sequence(E, sequence, shard, torch, dist, dev, rank, world, seq, n_frames)
         except Exception as ex:  # noqa: BLE001
-            seq["error_rank%d" % rank] = repr(ex)
-        tsr = torch.tensor(seq_local, dtype=torch.float64, device=dev)
-        tmax = tsr.clone()
-        if world > 1:
-            dist.all_reduce(tsr, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        pairs, blocks = float(tsr[0].item()), float(tsr[2].item())
-        t_match, t_ba = float(tmax[1].item()), float(tmax[3].item())
-        seq.update({"frame_pairs": int(pairs), "frame_pairs_per_s": round(pairs / t_match, 1) if t_match > 0 else None,
-                    "ba_windows": 25, "ba_residual_blocks_per_s": round(blocks / t_ba, 1) if t_ba > 0 else None,
-                    "note": "consecutive-frame brute-force matching (best-2 Hamming) per shard with one halo frame; 25 LBA windows, window w on rank w mod N"})
+            seqr = {"error_rank%d" % rank: repr(ex)}
+            if world > 1:
+                raise
     if world > 1:
-        # the batched-sequence config gathers every rank's per-frame keypoint counts over RCCL (outside the timed region)
-        all_counts = shard.gather_frame_counts(d_n, n_frames, device=dev)
-        gathered = {"allgather_frames": int(all_counts.numel()), "allgather_keypoints": int(all_counts.sum().item())}
         dist.barrier()
         dist.destroy_process_group()
+    seq_out = seqr
     extra = {}
     cpu_baseline = None
     if rank == 0:
@@ -194,9 +198,8 @@ def main():
         if not args.no_cpu_baseline:
             cpu_baseline, cpu_extra = measure_cpu(frames, synth, extra)
             extra.update(cpu_extra)
-    extra.update(gathered)
-    if seq:
-        extra["sequence"] = seq
+    if seq_out:
+        extra["sequence"] = seq_out
     if rank == 0:
         out = {
             "metric": "ORB kpts/s (640x480, 1k feat) + local-BA residuals/s (20 KF x 3k pts)",
@@ -274,30 +277,71 @@ def dry_run(args, rank, world):
     return 0 if flag.item() else 1
 
 
-def measure_sequence(E, synth, shard, torch, dev, rank, world, d_desc, n_host, halo_desc, halo_n):
-    """This rank's share of the batched-sequence work.  Returns [pairs, s, residual blocks, s]."""
-    L = E.load()
-    B = d_desc.shape[0]
-    st = torch.cuda.current_stream().cuda_stream
-    d_out = torch.zeros((int(n_host.max()) + 1, 4), dtype=torch.int32, device=dev)
-    jobs = [(d_desc[f - 1], int(n_host[f - 1]), d_desc[f], int(n_host[f])) for f in range(1, B)]
-    if halo_desc is not None:
-        jobs.insert(0, (halo_desc, halo_n, d_desc[0], int(n_host[0])))
+def measure_sequence(E, sequence, shard, torch, dist, dev, rank, world, seq, n_frames):
+    """This rank's share of the batched-sequence work and the collectives around it.  Every rank
+    calls this (the collectives are symmetric); the returned dict is the same on every rank."""
+    B = seq.B
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    # halo: the last frame of the previous shard (RCCL all_gather of one frame's records per rank)
+    kl, dl, nl = seq.last_frame()
+    hk, hd, hn = shard.exchange_halo_frame(kl, dl, nl)
+    halo = (hd, hn) if hd is not None else (None, 0)
+    seq.match(*halo)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for a, na, b, nb in jobs:
-        if na and nb:
-            E._lib.check(L.eao_hamming_best2_device(a.data_ptr(), na, b.data_ptr(), nb, 1, None, d_out.data_ptr(), st))
+    e0, e1 = ev(), ev()
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        seq.match(*halo)
+    e1.record()
     torch.cuda.synchronize()
-    t_match = time.perf_counter() - t0
-    blocks, t_ba = 0.0, 0.0
-    for w in shard.window_shard(25, rank, world):
-        p = synth.synth_ba(seed=6000 + w)
+    t_match = e0.elapsed_time(e1) / reps * 1e-3
+    pairs = B - (0 if halo[0] is not None else 1)
+    # local BA: this rank's windows, packed once, ONE C-ABI call for all of them
+    ws = shard.window_shard(sequence.N_WINDOWS, rank, world)
+    probs = [sequence.window_problem(w) for w in ws]
+    blocks, t_ba, cams, pts = 0.0, 0.0, None, None
+    if probs:
+        pk = E.Optimizer.pack_batch(probs)
+        E.Optimizer.LocalBundleAdjustmentBatch(None, packed=pk)           # warm-up (contexts, arenas)
         t0 = time.perf_counter()
-        r = E.Optimizer.LocalBundleAdjustment(p)
-        t_ba += time.perf_counter() - t0
-        blocks += len(p["edge_cam"]) * r["timing"]["linearizations"]
-    return [float(len(jobs)), t_match, blocks, t_ba]
+        for _ in range(3):
+            res = E.Optimizer.LocalBundleAdjustmentBatch(None, packed=pk)
+        t_ba = (time.perf_counter() - t0) / 3
+        blocks = float(np.mean([len(p["edge_cam"]) for p in probs])) * res[0]["timing"]["linearizations"]
+        cams = torch.from_numpy(np.stack([r["poses"].reshape(-1, 16) for r in res])).to(dev)
+        pts = torch.from_numpy(np.stack([r["points"] for r in res])).to(dev)
+    else:
+        cams, pts = torch.zeros((0, 24, 16), device=dev), torch.zeros((0, 3000, 3), device=dev)
+    # s8(e): every rank ends with every frame's keypoints + descriptors and every window's poses + points
+    if world > 1:
+        dist.barrier()
+    shard.gather_frame_results(seq.d_kps, seq.d_desc, seq.d_n, n_frames)       # warm-up (allocations, RCCL channel set-up)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    K, D, Cn = shard.gather_frame_results(seq.d_kps, seq.d_desc, seq.d_n, n_frames)
+    AC, AP = shard.gather_window_results(cams, pts, sequence.N_WINDOWS)
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t0
+    ok = bool(torch.equal(K[rank * B:(rank + 1) * B], seq.d_kps) and torch.equal(Cn[rank * B:(rank + 1) * B], seq.d_n) and AC.shape[0] == sequence.N_WINDOWS)
+    tsr = torch.tensor([float(pairs), blocks, 1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([t_match, t_ba, t_gather], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tsr, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    pairs_all, blocks_all, ok_all = float(tsr[0]), float(tsr[1]), float(tsr[2]) == world
+    tm, tb, tg = float(tmax[0]), float(tmax[1]), float(tmax[2])
+    gbytes = int(K.numel() + D.numel() + 4 * Cn.numel() + 4 * AC.numel() + 4 * AP.numel())
+    return {"frames": n_frames, "frame_pairs": int(pairs_all), "frame_pairs_per_s": round(pairs_all / tm, 1) if tm > 0 else None,
+            "match_ms_per_shard": round(tm * 1e3, 4), "ba_windows": sequence.N_WINDOWS,
+            "ba_residual_blocks_per_s": round(blocks_all / tb, 1) if tb > 0 else None, "ba_ms_slowest_rank": round(tb * 1e3, 3),
+            "allgather_ms": round(tg * 1e3, 3), "allgather_bytes_per_rank_result": gbytes, "allgather_ok": ok_all,
+            "allgather_keypoints": int(Cn.sum().item()),
+            "note": "per shard: device-resident best-2 matching of consecutive frames (eao_hamming_best2_sequence_device, halo frame from the "
+                    "previous rank) and ONE eao_local_ba_batch call for the rank's windows (window w -> rank w mod N); then the s8(e) "
+                    "all-gather of (keypoints, descriptors) of every frame and of every window's poses + points"}
 
 
 def measure_extra(E, synth, torch, dev):
@@ -329,11 +373,78 @@ def measure_extra(E, synth, torch, dev):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             byts = pairs * (2_064_000 if mode == "matrix" else 72_000)
-            extra["hamming_%s" % mode] = {"pair_distances_per_s": round(pairs * 1e6 / (ms * 1e-3), 1), "ms_per_launch": round(ms, 4),
-                                          "pairs_per_launch": pairs, "achieved_GBps": round(byts / (ms * 1e-3) / 1e9, 2),
-                                          "frac_hbm": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            h = {"pair_distances_per_s": round(pairs * 1e6 / (ms * 1e-3), 1), "ms_per_launch": round(ms, 4), "pairs_per_launch": pairs,
+                 "achieved_GBps": round(byts / (ms * 1e-3) / 1e9, 2)}
+            # 16 v_xor + 16 v_bcnt (with accumulate) per 256-bit distance, per lane: what the VALU must issue at the very least
+            dist_per_s = pairs * 1e6 / (ms * 1e-3)
+            h["valu_frac_min"] = round(dist_per_s * 16 / 64 / VALU_PEAK_WAVE_INSTS, 4)
+            if mode == "matrix":
+                h["frac_hbm"] = round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)     # write-bound: 2 B per distance
+            else:
+                h["bound"] = "valu (72 KB of traffic per pair: an HBM fraction says nothing here)"
+            try:
+                sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+                kn = "k_hamming_matrix8" if mode == "matrix" else "k_hamming_best2_rows"
+                if kn in sq.get("kernels_extra", {}):
+                    h["valu_frac"] = round(sq["kernels_extra"][kn]["SQ_INSTS_VALU"] / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS, 4)
+            except Exception:
+                pass
+            extra["hamming_%s" % mode] = h
     except Exception as ex:  # noqa: BLE001
         extra["hamming_error"] = repr(ex)
+    try:
+        # measured stream-copy ceiling of this GPU: 1 GiB device-to-device copy, read + write counted
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        extra["stream_copy_GBps"] = round(2 * 5 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
+    except Exception as ex:  # noqa: BLE001
+        extra["stream_copy_error"] = repr(ex)
+    try:
+        # the ORB batch end to end through the host API: pageable host frames in, host keypoints + descriptors out (PCIe both ways);
+        # never `value`
+        ext_h = E.ORBextractor(1000, 1.2, 8, 20, 7)
+        fr64 = np.stack([synth.synth_frame(1000 + f, 640, 480) for f in range(64)])
+        for _ in range(2):
+            kk, _dd = ext_h.extract_batch(fr64)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            kk, _dd = ext_h.extract_batch(fr64)
+        dtp = (time.perf_counter() - t0) / 5
+        extra["orb_end_to_end_pcie"] = {"ms_per_64_frames": round(dtp * 1e3, 3), "kpts_per_s": round(sum(len(k) for k in kk) / dtp, 1),
+                                        "note": "eao_orb_extract_batch: H2D of 19.7 MB of frames + extraction + D2H of 64 x cap x 60 B, pageable host memory"}
+        del ext_h
+    except Exception as ex:  # noqa: BLE001
+        extra["orb_end_to_end_pcie_error"] = repr(ex)
+    try:
+        # the BA half of the metric as a THROUGHPUT: the 25 independent windows of BASELINE configs[4] in one eao_local_ba_batch
+        # call (the window is a grid dimension of every launch), timed at the C-ABI with the arguments packed once
+        from eao_fusion_amd import sequence as SQ
+        probs = [SQ.window_problem(w) for w in range(SQ.N_WINDOWS)]
+        pk = E.Optimizer.pack_batch(probs)
+        for _ in range(2):
+            E._lib.check(L.eao_local_ba_batch(pk["P"], pk["n"], None, pk["R"]))
+        t0 = time.perf_counter()
+        for _ in range(5):
+            E._lib.check(L.eao_local_ba_batch(pk["P"], pk["n"], None, pk["R"]))
+        dtb = (time.perf_counter() - t0) / 5
+        import ctypes as C2
+        dm2, li2 = C2.c_float(), C2.c_int32()
+        L.eao_last_lm_timing(C2.byref(dm2), C2.byref(li2))
+        Eavg = float(np.mean([len(p["edge_cam"]) for p in probs]))
+        extra["ba_batch"] = {"workload": "25 x LocalBundleAdjustment (20 free + 4 fixed KF x 3000 MP, 5+10 LM its), ONE eao_local_ba_batch call",
+                             "ms_per_call": round(dtb * 1e3, 3), "ms_per_window": round(dtb * 1e3 / len(probs), 4), "device_ms": round(dm2.value, 3),
+                             "ba_residual_blocks_per_s": round(Eavg * li2.value / dtb, 1), "ba_scalar_residuals_per_s": round(3 * Eavg * li2.value / dtb, 1),
+                             "linearizations": int(li2.value)}
+    except Exception as ex:  # noqa: BLE001
+        extra["ba_batch_error"] = repr(ex)
     try:
         p = synth.synth_ba()
         r = E.Optimizer.LocalBundleAdjustment(p)  # warm-up (allocations, code load)
