@@ -537,6 +537,41 @@ def measure_extra(E, synth, torch, dev):
         extra["tracking_concurrent"] = {"host_threads": nth, "frames_per_s": round(nth * treps / dtt, 1),
                                         "ms_per_frame": round(dtt * 1e3 / (nth * treps), 3),
                                         "note": "per frame: SearchByProjection(points) + SearchByProjection(frames) + PoseOptimization, host buffers in/out"}
+        # the same tracked frame with NOTHING returning to the host in between (row f1): ComputeStereoFromRGBD + grid ->
+        # isInFrustum over the local map -> SearchByProjection -> PoseOptimization chained on the device behind the extractor's
+        # outputs, one copy back (eao_tracker_track_local_map)
+        try:
+            from eao_fusion_amd.tracker import Tracker
+            curT, lastT, _ = synth.synth_tracking(n=1000, seed=7100, mono_frac=0.0, occupied_frac=0.0)
+            NT = len(curT["kp_x"])
+            kT = np.zeros(NT, E.orb.KP_DTYPE)
+            kT["x"], kT["y"] = np.clip(curT["kp_x"], 1, 638), np.clip(curT["kp_y"], 1, 478)
+            kT["angle"], kT["octave"] = curT["kp_angle"], curT["kp_octave"]
+            XwT = lastT["Xw"].astype(np.float64)
+            dT = np.linalg.norm(XwT, axis=1).astype(np.float32)
+            ptsT = dict(active=np.ones(len(XwT), np.uint8), Xw=lastT["Xw"], normal=(XwT / dT[:, None]).astype(np.float32), min_dist_inv=0.6 * dT,
+                        max_dist_inv=1.7 * dT, max_dist=(dT * np.float32(1.2) ** (lastT["octave"] - 0.5)).astype(np.float32), descriptors=lastT["descriptors"])
+            sfT = curT["scale_factors"]
+            trk = Tracker(curT["fx"], curT["fy"], curT["cx"], curT["cy"], curT["mbf"], (0.0, 640.0, 0.0, 480.0), sfT, (np.float32(1) / (sfT * sfT)).astype(np.float32),
+                          float(np.log(np.float32(1.2))), 2048, 2048)
+            trk.set_local_map(ptsT)
+            dk = torch.zeros((2048, 28), dtype=torch.uint8, device=dev); dk[:NT] = torch.from_numpy(kT.view(np.uint8).reshape(NT, 28)).to(dev)
+            dd = torch.zeros((2048, 32), dtype=torch.uint8, device=dev); dd[:NT] = torch.from_numpy(np.ascontiguousarray(curT["descriptors"])).to(dev)
+            dn = torch.tensor([NT], dtype=torch.int32, device=dev)
+            ddep = torch.full((480, 640), 3.0, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            stT = torch.cuda.current_stream().cuda_stream
+            for _ in range(3):
+                rT = trk.track_local_map(dk.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddep.data_ptr(), 640, 640, 480, curT["Tcw"], None, 3.0, 0.8, stT)
+            t0 = time.perf_counter()
+            for _ in range(30):
+                rT = trk.track_local_map(dk.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddep.data_ptr(), 640, 640, 480, curT["Tcw"], None, 3.0, 0.8, stT)
+            extra["tracking_frame_device_ms"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
+            extra["tracking_frame_device"] = {"keypoints": int(rT["n_keypoints"]), "map_points": len(XwT), "matches": int(rT["n_matches"]), "inliers": int(rT["n_inliers"]),
+                                              "note": "eao_tracker_track_local_map: RGB-D stereo + grid + isInFrustum + SearchByProjection(points) + PoseOptimization on the device, one D2H; "
+                                                      "PoseOptimization's single-workgroup LM (4 x 10 iterations) is ~0.27 ms of it"}
+        except Exception as ex:  # noqa: BLE001
+            extra["tracking_frame_device_error"] = repr(ex)
         # the Frame glue (isInFrustum over a 20 000-point local map) and a small-map BundleAdjustment (12 KF, 10 its)
         from eao_fusion_amd import frame as FR
         rng = np.random.default_rng(11)

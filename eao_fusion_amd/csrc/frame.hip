@@ -270,3 +270,24 @@ eao_status eao_compute_stereo_from_rgbd(int32_t n, const float* kp_x, const floa
 }
 
 }  // extern "C"
+
+// hook for the device-resident tracking chain (csrc/track.hip): the same kernel over arrays that already live on the device
+#include "chain_internal.h"
+eao_status eao::frame::enqueue_frustum_device(const FrustumDevArgs& a, hipStream_t s) {
+    if (a.n <= 0) return EAO_OK;
+    FrustumArgs A;
+    A.n = a.n;
+    A.Xw = a.Xw; A.normal = a.normal; A.minDist = a.minDist; A.maxDist = a.maxDist; A.maxDistNum = a.maxDistNum;
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) A.R[3 * r + k] = a.Tcw[4 * r + k];
+        A.t[r] = a.Tcw[4 * r + 3];
+        A.Ow[r] = a.Ow[r];
+    }
+    A.fx = a.fx; A.fy = a.fy; A.cx = a.cx; A.cy = a.cy; A.mbf = a.mbf;
+    A.minX = a.minX; A.maxX = a.maxX; A.minY = a.minY; A.maxY = a.maxY; A.logScale = a.logScale; A.cosLimit = a.cosLimit;
+    A.inView = a.inView; A.projX = a.projX; A.projY = a.projY; A.projXR = a.projXR; A.viewCos = a.viewCos; A.level = a.level;
+    hipLaunchKernelGGL(k_is_in_frustum, dim3(eao::cdiv(a.n, 256)), dim3(256), 0, s, A);
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
+

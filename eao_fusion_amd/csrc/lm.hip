@@ -378,6 +378,7 @@ constexpr int kPoseMaxPlanes = 32;
 // ============================================================================================ PoseOptimization
 struct PoseDev {
     int n;
+    const int* nDev;     // when set: the number of edges lives on the device (chained tracking: eao_tracker); n is then the capacity
     const double* Xw;    // n*3
     const double* obs;   // n*3
     const double* info;  // n
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
     __shared__ double s_perr[kPoseMaxPlanes * 3];          // the edge's _error (last computed)
     __shared__ unsigned char s_pflag[kPoseMaxPlanes], s_pout[kPoseMaxPlanes];
     const int M = P.nPlanes;
-    const int t = threadIdx.x, n = P.n;
+    const int t = threadIdx.x, n = P.nDev ? min(*P.nDev, P.n) : P.n;
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
     const Cam c = P.cam;
     double eX[EPT][3], eO[EPT][3], eI[EPT], eE[EPT][3];
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
     __shared__ double s_x[6];
     __shared__ double s_lambda, s_ni, s_rho, s_cur, s_tmp;
     __shared__ int s_ok, s_flag, s_nbad, s_ntrace, s_iters, s_active;
-    const int t = threadIdx.x, n = P.n;
+    const int t = threadIdx.x, n = P.nDev ? min(*P.nDev, P.n) : P.n;
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
     if (t == 0) { s_ntrace = 0; s_iters = 0; s_est = P.T0; }
     __syncthreads();
@@ -991,7 +992,7 @@ struct BADev {
 // assembly alone moved 350 MB per launch).  Window w is served by XCD w % 8 only; the launch pads grid.z to a multiple of 8.
 // wpar = block pair | number of windows << 8;  bx = this workgroup's block index inside its window.
 #define BA_WIN(P)                                                                                                   \
-    unsigned bx = blockIdx.x, wz_ = blockIdx.z;                                                                     \
+    unsigned bx = blockIdx.x, wz_ = blockIdx.z; (void)bx;                                                                  \
     {                                                                                                               \
         const unsigned nz_ = (unsigned)wpar >> 8;                                                                   \
         if (nz_ > 1) {                                                                                              \
@@ -2893,6 +2894,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     EAO_HIP(hipEventRecord(c.ev0, c.stream));
     EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
     PoseDev P;
+    P.nDev = nullptr;
     P.n = n; P.Xw = dXw; P.obs = dobs; P.info = dinfo; P.err = derr; P.flags = dflags; P.outlier = ooutl;
     P.T0 = se3_from_Tcw_f32(p->Tcw);
     P.cam.fx = p->fx; P.cam.fy = p->fy; P.cam.cx = p->cx; P.cam.cy = p->cy; P.cam.bf = p->bf; P.cam.bf_f = p->bf;
@@ -3652,3 +3654,32 @@ eao_status eao_last_lm_timing(float* device_ms, int32_t* linearizations) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Hooks for the device-resident tracking chain (csrc/track.hip): PoseOptimization over edges that a previous kernel left
+// on the device, their count included.
+#include "chain_internal.h"
+namespace eao {
+namespace lm {
+size_t pose_se3_bytes() { return sizeof(SE3); }
+void pose_se3_to_Tcw(const void* se3, float* T) { se3_to_Tcw_f32(*(const SE3*)se3, T); }
+eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
+    EAO_REQUIRE(a.cap > 0 && a.cap <= 4 * kPoseThreads, "the chained PoseOptimization takes up to %d edges", 4 * kPoseThreads);
+    PoseDev P;
+    std::memset(&P, 0, sizeof(P));
+    P.n = a.cap; P.nDev = a.nEdges;
+    P.Xw = a.Xw; P.obs = a.obs; P.info = a.info; P.err = a.err; P.flags = a.flags; P.outlier = a.outlier;
+    P.T0 = se3_from_Tcw_f32(a.Tcw0);
+    P.cam.fx = a.fx; P.cam.fy = a.fy; P.cam.cx = a.cx; P.cam.cy = a.cy; P.cam.bf = a.bf; P.cam.bf_f = a.bf;
+    P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
+    P.Tout = (SE3*)a.outSE3; P.result = a.outResult; P.trace = a.outTrace;
+    P.nPlanes = 0; P.planes = nullptr; P.planeOutlier = nullptr; P.deltaPlane = (float)std::sqrt(300.0);
+    P.dbg = nullptr;
+    if (a.cap <= 2 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<2>, dim3(1), dim3(kPoseThreads), 0, s, P);
+    else hipLaunchKernelGGL(k_pose_optimization<4>, dim3(1), dim3(kPoseThreads), 0, s, P);
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
+}  // namespace lm
+}  // namespace eao
+

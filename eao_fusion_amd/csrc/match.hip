@@ -28,6 +28,7 @@ namespace {
 
 struct FrameDev {
     int n, nOrdered;
+    const int* nOrderedDev;   // when set: the number of ordered entries lives on the device (chained tracking)
     const float* kx; const float* ky; const int* oct; const float* ur;
     const uint4* desc;        // n x 2
     const int* order;         // keypoint indices in grid order
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void k_match_candidates(FrameDev F, const Quer
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
     const Query Q = q[qi];
+    if (F.nOrderedDev) F.nOrdered = *F.nOrderedDev;
     int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
     bool any = Q.active != 0;
     if (any) {   // Frame::GetFeaturesInArea, src/Frame.cc:701-717 (float expressions kept as written upstream)
@@ -201,6 +203,7 @@ eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Qu
     EAO_HIP(hipMemsetAsync(c.metaDev.p + 2 * (size_t)nq, 0, sizeof(int), s));   // cursor
     int* meta = (int*)c.meta.p;
     FrameDev D;
+    D.nOrderedDev = nullptr;
     D.n = n; D.nOrdered = no;
     D.kx = (const float*)(c.dev.p + oKx); D.ky = (const float*)(c.dev.p + oKy); D.ur = (const float*)(c.dev.p + oUr);
     D.oct = (const int*)(c.dev.p + oOc); D.order = (const int*)(c.dev.p + oOr);
@@ -260,6 +263,21 @@ eao_status eao::match::pair_distances(const uint8_t* descA, int nA, const uint8_
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
     std::memcpy(dist.data(), c.out.p, 2 * np);
+    return EAO_OK;
+}
+
+#include "chain_internal.h"
+eao_status eao::match::enqueue_candidates_device(const FrameDevArgs& F, const Query* q, const uint8_t* qdesc, int nq, unsigned* out, int outCap,
+                                                 int* segStart, int* segCount, int* cursor, hipStream_t s) {
+    if (nq <= 0) return EAO_OK;
+    FrameDev D;
+    D.n = F.cap; D.nOrdered = 0; D.nOrderedDev = F.nOrdered;
+    D.kx = F.kx; D.ky = F.ky; D.oct = F.oct; D.ur = F.ur; D.desc = (const uint4*)F.desc;
+    D.order = F.order; D.cellx = F.cellx; D.celly = F.celly;
+    D.minX = F.minX; D.minY = F.minY; D.invW = F.invW; D.invH = F.invH; D.cols = F.cols; D.rows = F.rows;
+    EAO_HIP(hipMemsetAsync(cursor, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, q, (const uint4*)qdesc, nq, out, outCap, segStart, segCount, cursor);
+    EAO_HIP(hipGetLastError());
     return EAO_OK;
 }
 

@@ -1,0 +1,509 @@
+// track.hip -- the device-resident tracked frame (second half), MI355X (gfx950).
+//
+// Tracking::TrackLocalMap's data path -- Frame::ComputeStereoFromRGBD + AssignFeaturesToGrid on the extractor's output,
+// Frame::isInFrustum over the local map (Tracking::SearchLocalPoints), ORBmatcher::SearchByProjection(Frame&, local map
+// points, th) and Optimizer::PoseOptimization(&frame) -- reference src/Tracking.cc:1717-2231, 2587-2641; src/Frame.cc:
+// 599-614, 638-761, 1016-1037; src/ORBmatcher.cc:45-137; src/Optimizer.cc:325-673 -- chained on ONE stream over arrays
+// that never leave HBM: the keypoints, descriptors and keypoint count come straight from eao_orb_extract_batch_device, the
+// local map is uploaded when it changes, and one copy brings the pose, the matches and the outlier flags back.
+//
+//   k_track_frame    one workgroup: cv::KeyPoint records -> coordinate / octave / angle arrays, mvuRight / mvDepth from the
+//                    depth image, PosInGrid keys sorted in LDS -> the grid-order walk list k_match_candidates uses
+//   k_is_in_frustum  (frame.hip) one thread per local map point
+//   k_track_queries  search windows of the points in view (RadiusByViewingCos x th x scale factor of the predicted level)
+//   k_match_candidates (match.hip) candidate lists in upstream's order
+//   k_track_assign   upstream's greedy assignment (a keypoint taken by an earlier map point is skipped by later ones) WITHOUT
+//                    walking the map points one by one: rounds in which every undecided point decides from the final claims
+//                    so far, and becomes final when no earlier undecided point lists any keypoint its decision depends on
+//   k_track_edges    mvpMapPoints by keypoint (prior matches + new ones), the PoseOptimization edges in keypoint order
+//   k_pose_optimization (lm.hip) with the edge count read on the device
+//   k_track_finish   mvbOutlier by keypoint, everything the host needs in one block
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "chain_internal.h"
+#include "common.h"
+
+using eao::match::Query;
+
+struct eao_tracker {
+    eao_tracker_cfg cfg;
+    std::vector<float> scale, invSigma2;
+    int cap = 0, capMp = 0, nMp = 0, nCells = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t evIn = nullptr, evOut = nullptr;
+    eao::DevBuf<unsigned char> dev;
+    unsigned char* pin = nullptr;      // pinned staging: local map upload, prior matches in, result block out
+    size_t pinCap = 0;
+    // device slices (offsets into dev)
+    float *kx, *ky, *ang, *ur, *dz; int* oct; int* order; unsigned short *cellx, *celly; int* counts;   // counts: n, nOrdered, nEdges, nMatches, err
+    int* prior; int* kpMp; unsigned char* occ; unsigned char* kpOut;
+    float *mXw, *mNormal, *mMin, *mMax, *mNum; unsigned char* mDesc; unsigned char* mActive; unsigned char* mSkip;
+    unsigned char* inView; float *projX, *projY, *projXR, *viewCos; int* level;
+    Query* q; unsigned* lists; int *segStart, *segCount, *cursor; int* match;
+    double *eXw, *eObs, *eInfo, *eErr; unsigned char *eFlags, *eOutl; int* eKp;
+    float* dScale; float* dInvSigma2;
+    unsigned char* res;                // result block (device), resBytes
+    size_t resBytes = 0, listCap = 0;
+    ~eao_tracker() {
+        if (pin) (void)hipHostFree(pin);
+        if (evIn) (void)hipEventDestroy(evIn);
+        if (evOut) (void)hipEventDestroy(evOut);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+struct FrameArrays {
+    float *kx, *ky, *ang, *ur, *dz; int* oct; int* order; unsigned short *cellx, *celly; int* counts;
+    int* prior; int* kpMp; unsigned char* occ; unsigned char* mSkip;
+};
+
+constexpr int kFrameThreads = 1024;
+// ONE workgroup.  Frame::Frame's per-keypoint work for a distortion-free camera (mvKeysUn = mvKeys, as in the reference's
+// RGB-D configuration: ros_test/config/TUM3.yaml:13-16): ComputeStereoFromRGBD (src/Frame.cc:1016-1037) and
+// AssignFeaturesToGrid / PosInGrid (:599-614, 751-761).  The grid leaves as the walk list of k_match_candidates: keypoints in
+// (cell column, cell row, index) order = the order upstream's nested cell loops of GetFeaturesInArea visit them.
+__global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoint* __restrict__ kps, const int* __restrict__ nPtr, int cap,
+                                                               const float* __restrict__ depth, int pitch, int W, int H, float mbf,
+                                                               float minX, float minY, float invW, float invH, int cols, int rows, int npow2,
+                                                               int nMp, FrameArrays A) {
+    extern __shared__ unsigned tkeys[];
+    __shared__ int s_cnt;
+    const int t = threadIdx.x;
+    const int n = min(max(*nPtr, 0), cap);
+    if (t == 0) s_cnt = 0;
+    for (int m = t; m < nMp; m += kFrameThreads) A.mSkip[m] = 0;
+    __syncthreads();
+    for (int i = t; i < npow2; i += kFrameThreads) {
+        unsigned key = 0xFFFFFFFFu;
+        if (i < n) {
+            const eao_keypoint kp = kps[i];
+            A.kx[i] = kp.x; A.ky[i] = kp.y; A.ang[i] = kp.angle; A.oct[i] = kp.octave;
+            float ur = -1.0f, dz = -1.0f;
+            const int xi = (int)kp.x, yi = (int)kp.y;          // Mat::at<float>(float v, float u): truncation
+            if (depth && xi >= 0 && xi < W && yi >= 0 && yi < H) {
+                const float d = depth[(size_t)yi * pitch + xi];
+                if (d > 0) { dz = d; ur = kp.x - mbf / d; }
+            }
+            A.ur[i] = ur; A.dz[i] = dz;
+            const int px = (int)roundf((kp.x - minX) * invW);      // PosInGrid, src/Frame.cc:753-757
+            const int py = (int)roundf((kp.y - minY) * invH);
+            if (px >= 0 && px < cols && py >= 0 && py < rows) key = ((unsigned)(px * rows + py) << 16) | (unsigned)i;
+            // mvpMapPoints as the caller hands it over: a keypoint that already has a map point is occupied, and that map
+            // point is not searched again (Tracking::SearchLocalPoints: mnLastFrameSeen == frame id)
+            const int pm = A.prior ? A.prior[i] : -1;
+            A.kpMp[i] = pm;
+            A.occ[i] = pm >= 0 ? 1 : 0;
+            if (pm >= 0 && pm < nMp) A.mSkip[pm] = 1;
+        }
+        tkeys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < npow2; i += kFrameThreads) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned a = tkeys[i], b = tkeys[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { tkeys[i] = b; tkeys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int mine = 0;
+    for (int i = t; i < npow2; i += kFrameThreads) {
+        const unsigned key = tkeys[i];
+        if (key != 0xFFFFFFFFu) {
+            const int cell = (int)(key >> 16);
+            A.order[i] = (int)(key & 0xFFFFu);
+            A.cellx[i] = (unsigned short)(cell / rows);
+            A.celly[i] = (unsigned short)(cell % rows);
+            mine++;
+        }
+    }
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (t == 0) { A.counts[0] = n; A.counts[1] = s_cnt; A.counts[2] = 0; A.counts[3] = 0; A.counts[4] = 0; }
+}
+
+// ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th), src/ORBmatcher.cc:51-81: the window of every point in view
+__global__ __launch_bounds__(256) void k_track_queries(int nMp, const unsigned char* __restrict__ active, const unsigned char* __restrict__ skip,
+                                                       const unsigned char* __restrict__ inView, const float* __restrict__ projX,
+                                                       const float* __restrict__ projY, const float* __restrict__ projXR,
+                                                       const float* __restrict__ viewCos, const int* __restrict__ level,
+                                                       const float* __restrict__ scale, int nlevels, float th, Query* __restrict__ q,
+                                                       int* __restrict__ counts) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= nMp) return;
+    Query Q;
+    Q.active = (active[m] && inView[m] && !skip[m]) ? 1 : 0;
+    int lvl = Q.active ? level[m] : 0;
+    if (Q.active && (lvl < 0 || lvl >= nlevels)) { atomicOr(&counts[4], 1); Q.active = 0; lvl = 0; }   // (upstream would index out of range)
+    float r = (double)viewCos[m] > 0.998 ? 2.5f : 4.0f;          // RadiusByViewingCos, :131-137
+    if (th != 1.0f) r *= th;
+    const float rs = Q.active ? r * scale[lvl] : 0.f;
+    Q.x = projX[m]; Q.y = projY[m]; Q.r = rs;
+    Q.minLevel = lvl - 1; Q.maxLevel = lvl;
+    Q.urRef = projXR[m]; Q.urTol = rs;
+    q[m] = Q;
+}
+
+// Upstream walks the map points in index order; a keypoint assigned to an earlier point is skipped by every later one
+// (src/ORBmatcher.cc:87-89, 123).  A point's decision -- the two smallest (distance, list position) among its unoccupied
+// candidates, the TH_HIGH / ratio tests -- depends only on the occupancy of the candidates up to its second best.  Rounds:
+//   1. minq[k] = the smallest UNDECIDED point that lists keypoint k
+//   2. every undecided point m decides from the claims that are final so far; it becomes final iff minq[k] >= m for every
+//      keypoint its decision depended on (no earlier undecided point can still take one of them) -- the smallest undecided
+//      point always does, and a claim never lands in the list of an earlier undecided point, so final decisions are exactly
+//      upstream's
+// ONE workgroup; occupancy and minq in LDS.  Converges in a handful of rounds (overlaps are local).
+constexpr int kAssignThreads = 1024;
+__global__ __launch_bounds__(kAssignThreads) void k_track_assign(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
+                                                                 const int* __restrict__ segStart, const int* __restrict__ segCount,
+                                                                 const int* __restrict__ oct, unsigned char* __restrict__ occG, float nnratio,
+                                                                 int* __restrict__ match, int* __restrict__ counts) {
+    extern __shared__ int asm_[];
+    int* minq = asm_;                                           // cap
+    unsigned char* occ = reinterpret_cast<unsigned char*>(minq + cap);   // cap
+    __shared__ int s_left, s_nm;
+    const int t = threadIdx.x;
+    constexpr int PER = 4;                                      // map points per thread (capMp <= 4096)
+    int st_[PER], cn_[PER];
+    bool open[PER];
+    for (int i = t; i < cap; i += kAssignThreads) occ[i] = occG[i];
+    if (t == 0) s_nm = 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int m = t + u * kAssignThreads;
+        open[u] = false; st_[u] = 0; cn_[u] = 0;
+        if (m < nMp) {
+            match[m] = -1;
+            if (q[m].active && segCount[m] > 0) { open[u] = true; st_[u] = segStart[m]; cn_[u] = segCount[m]; }
+        }
+    }
+    __syncthreads();
+    for (int round = 0; round < 4096; round++) {
+        for (int i = t; i < cap; i += kAssignThreads) minq[i] = 0x7FFFFFFF;
+        if (t == 0) s_left = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (open[u]) {
+                const int m = t + u * kAssignThreads;
+                for (int k = 0; k < cn_[u]; k++) atomicMin(&minq[lists[st_[u] + k] & 0xFFFF], m);
+            }
+        __syncthreads();
+        int claim[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            claim[u] = -1;
+            if (!open[u]) continue;
+            const int m = t + u * kAssignThreads;
+            // upstream's scan over the candidates that are free (:83-115)
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int k = 0; k < cn_[u]; k++) {
+                const unsigned it = lists[st_[u] + k];
+                const int i = (int)(it & 0xFFFF), d = (int)(it >> 16);
+                if (occ[i]) continue;
+                if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = oct[i]; bestIdx = i; }
+                else if (d < bestDist2) { bestLevel2 = oct[i]; bestDist2 = d; }
+            }
+            // final? every candidate the decision looked at with an effect -- distance <= the second best (all of them when
+            // fewer than two are free) -- must not be listed by an earlier undecided point
+            bool fin = true;
+            for (int k = 0; k < cn_[u]; k++) {
+                const unsigned it = lists[st_[u] + k];
+                const int i = (int)(it & 0xFFFF), d = (int)(it >> 16);
+                if (d <= bestDist2 && minq[i] < m) { fin = false; break; }
+            }
+            if (!fin) continue;
+            open[u] = false;
+            if (bestDist <= 100) {   // TH_HIGH
+                if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                claim[u] = bestIdx;
+                match[m] = bestIdx;
+            }
+        }
+        __syncthreads();      // every decision of the round was taken from the same occupancy
+        int left = 0, nm = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            if (claim[u] >= 0) { occ[claim[u]] = 1; nm++; }
+            left += open[u] ? 1 : 0;
+        }
+        if (left) atomicAdd(&s_left, left);
+        if (nm) atomicAdd(&s_nm, nm);
+        __syncthreads();
+        if (s_left == 0) break;
+        __syncthreads();
+    }
+    for (int i = t; i < cap; i += kAssignThreads) occG[i] = occ[i];
+    if (t == 0) counts[3] = s_nm;
+}
+
+// mvpMapPoints by keypoint (the prior matches + this search's), and the edges of Optimizer::PoseOptimization in keypoint
+// order (src/Optimizer.cc:361-447): Xw, (u, v, uR), invSigma2 of the octave, stereo / robust flags.  ONE workgroup.
+struct EdgeArrays { double *Xw, *obs, *info; unsigned char* flags; int* eKp; };
+constexpr int kEdgeThreads = 1024;
+__global__ __launch_bounds__(kEdgeThreads) void k_track_edges(int nMp, int cap, const int* __restrict__ match, int* __restrict__ kpMp,
+                                                              const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ ur,
+                                                              const int* __restrict__ oct, const float* __restrict__ mXw,
+                                                              const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, int* __restrict__ counts) {
+    __shared__ int s_wsum[kEdgeThreads / 64], s_base;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int n = counts[0];
+    for (int m = t; m < nMp; m += kEdgeThreads) {
+        const int k = match[m];
+        if (k >= 0) kpMp[k] = m;          // (a keypoint is claimed by at most one point)
+    }
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += kEdgeThreads) {
+        const int k = k0 + t;
+        const int m = k < n ? kpMp[k] : -1;
+        const bool has = m >= 0;
+        const unsigned long long bal = __ballot(has);
+        if (lane == 0) s_wsum[wv] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wv; w++) off += s_wsum[w];
+        const int e = off + __popcll(bal & ((1ull << lane) - 1));
+        if (has && e < edgeCap) {
+            E.Xw[3 * e] = mXw[3 * m]; E.Xw[3 * e + 1] = mXw[3 * m + 1]; E.Xw[3 * e + 2] = mXw[3 * m + 2];
+            const float u_r = ur[k];
+            E.obs[3 * e] = kx[k]; E.obs[3 * e + 1] = ky[k]; E.obs[3 * e + 2] = u_r;
+            E.info[e] = invSigma2[oct[k]];
+            E.flags[e] = (unsigned char)((!(u_r < 0) ? 1 : 0) | 4);
+            E.eKp[e] = k;
+        }
+        __syncthreads();
+        if (t == 0) { int tot = 0; for (int w = 0; w < kEdgeThreads / 64; w++) tot += s_wsum[w]; s_base += tot; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (s_base > edgeCap) atomicOr(&counts[4], 2);
+        counts[2] = min(s_base, edgeCap);
+    }
+}
+
+// everything the host needs, in one block: [SE3 | result ints | counts | kpMp | kpOutlier | uRight | depth]
+__global__ __launch_bounds__(256) void k_track_finish(int cap, const int* __restrict__ counts, const int* __restrict__ kpMp, const int* __restrict__ eKp,
+                                                      const unsigned char* __restrict__ eOutl, const float* __restrict__ ur, const float* __restrict__ dz,
+                                                      int* __restrict__ oCounts, int* __restrict__ oKpMp, unsigned char* __restrict__ oOutl,
+                                                      float* __restrict__ oUr, float* __restrict__ oDz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 8) oCounts[i] = i < 5 ? counts[i] : 0;
+    if (i >= cap) return;
+    const int n = counts[0], ne = counts[2];
+    oKpMp[i] = i < n ? kpMp[i] : -1;
+    oUr[i] = i < n ? ur[i] : -1.f;
+    oDz[i] = i < n ? dz[i] : -1.f;
+    oOutl[i] = 0;
+    // (the scatter below runs over edges, i.e. other indices: a second launch-wide pass would need a grid sync -- instead
+    //  every thread looks its keypoint up among the edges by binary search: eKp is ascending)
+    if (i < n && kpMp[i] >= 0 && ne >= 3) {
+        int lo = 0, hi = ne;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (eKp[mid] < i) lo = mid + 1; else hi = mid; }
+        if (lo < ne && eKp[lo] == i) oOutl[i] = eOutl[lo];
+    }
+}
+
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
+    EAO_REQUIRE(cfg && out && cfg->scale_factors && cfg->inv_level_sigma2, "null argument");
+    EAO_REQUIRE(cfg->nlevels >= 1 && cfg->nlevels <= 64 && cfg->grid_cols > 0 && cfg->grid_rows > 0 && (long long)cfg->grid_cols * cfg->grid_rows < 65535, "bad geometry");
+    EAO_REQUIRE(cfg->max_keypoints >= 1 && cfg->max_keypoints <= 4096, "max_keypoints must be in 1..4096 (the grid sort runs in the LDS of one workgroup)");
+    EAO_REQUIRE(cfg->max_map_points >= 1 && cfg->max_map_points <= 4096, "max_map_points must be in 1..4096 (one assignment workgroup, four points per thread)");
+    EAO_REQUIRE(cfg->max_x > cfg->min_x && cfg->max_y > cfg->min_y, "empty image bounds");
+    eao_status st = eao::require_device();
+    if (st) return st;
+    eao_tracker* h = new eao_tracker();
+    h->cfg = *cfg;
+    h->scale.assign(cfg->scale_factors, cfg->scale_factors + cfg->nlevels);
+    h->invSigma2.assign(cfg->inv_level_sigma2, cfg->inv_level_sigma2 + cfg->nlevels);
+    h->cfg.scale_factors = nullptr; h->cfg.inv_level_sigma2 = nullptr;
+    h->cap = cfg->max_keypoints; h->capMp = cfg->max_map_points; h->nCells = cfg->grid_cols * cfg->grid_rows;
+    const size_t C = h->cap, M = h->capMp;
+    h->listCap = std::min<size_t>(C * M, (size_t)1 << 24);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = al256(off + bytes); return o; };
+    const size_t oKx = take(4 * C), oKy = take(4 * C), oAng = take(4 * C), oUr = take(4 * C), oDz = take(4 * C), oOct = take(4 * C), oOrd = take(4 * C),
+                 oCx = take(2 * C), oCy = take(2 * C), oCnt = take(64), oPrior = take(4 * C), oKpMp = take(4 * C), oOcc = take(C), oKpOut = take(C),
+                 oMX = take(12 * M), oMN = take(12 * M), oMMin = take(4 * M), oMMax = take(4 * M), oMNum = take(4 * M), oMD = take(32 * M), oMA = take(M),
+                 oMS = take(M), oIn = take(M), oPx = take(4 * M), oPy = take(4 * M), oPxr = take(4 * M), oVc = take(4 * M), oLv = take(4 * M),
+                 oQ = take(sizeof(Query) * M), oLists = take(4 * h->listCap), oSS = take(4 * M), oSC = take(4 * M), oCur = take(64), oMatch = take(4 * M),
+                 oEX = take(24 * C), oEO = take(24 * C), oEI = take(8 * C), oEE = take(24 * C), oEF = take(C), oEOu = take(C), oEK = take(4 * C),
+                 oSc = take(4 * 64), oIs = take(4 * 64);
+    const size_t se3 = al256(eao::lm::pose_se3_bytes());
+    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C);
+    const size_t oRes = take(h->resBytes);
+    if ((st = h->dev.reserve(off))) { delete h; return st; }
+    unsigned char* b = h->dev.p;
+    h->kx = (float*)(b + oKx); h->ky = (float*)(b + oKy); h->ang = (float*)(b + oAng); h->ur = (float*)(b + oUr); h->dz = (float*)(b + oDz);
+    h->oct = (int*)(b + oOct); h->order = (int*)(b + oOrd); h->cellx = (unsigned short*)(b + oCx); h->celly = (unsigned short*)(b + oCy);
+    h->counts = (int*)(b + oCnt); h->prior = (int*)(b + oPrior); h->kpMp = (int*)(b + oKpMp); h->occ = b + oOcc; h->kpOut = b + oKpOut;
+    h->mXw = (float*)(b + oMX); h->mNormal = (float*)(b + oMN); h->mMin = (float*)(b + oMMin); h->mMax = (float*)(b + oMMax); h->mNum = (float*)(b + oMNum);
+    h->mDesc = b + oMD; h->mActive = b + oMA; h->mSkip = b + oMS;
+    h->inView = b + oIn; h->projX = (float*)(b + oPx); h->projY = (float*)(b + oPy); h->projXR = (float*)(b + oPxr); h->viewCos = (float*)(b + oVc);
+    h->level = (int*)(b + oLv); h->q = (Query*)(b + oQ); h->lists = (unsigned*)(b + oLists); h->segStart = (int*)(b + oSS); h->segCount = (int*)(b + oSC);
+    h->cursor = (int*)(b + oCur); h->match = (int*)(b + oMatch);
+    h->eXw = (double*)(b + oEX); h->eObs = (double*)(b + oEO); h->eInfo = (double*)(b + oEI); h->eErr = (double*)(b + oEE); h->eFlags = b + oEF;
+    h->eOutl = b + oEOu; h->eKp = (int*)(b + oEK); h->dScale = (float*)(b + oSc); h->dInvSigma2 = (float*)(b + oIs);
+    h->res = b + oRes;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evOut, hipEventDisableTiming) != hipSuccess) { delete h; eao::set_error("stream / event creation failed"); return EAO_ERR_NO_DEVICE; }
+    h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C)) + 4096;
+    if (hipHostMalloc((void**)&h->pin, h->pinCap, hipHostMallocDefault) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
+    EAO_HIP(hipMemcpyAsync(h->dScale, h->scale.data(), 4 * (size_t)cfg->nlevels, hipMemcpyHostToDevice, h->stream));
+    EAO_HIP(hipMemcpyAsync(h->dInvSigma2, h->invSigma2.data(), 4 * (size_t)cfg->nlevels, hipMemcpyHostToDevice, h->stream));
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    *out = h;
+    return EAO_OK;
+}
+
+void eao_tracker_destroy(eao_tracker* h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+eao_status eao_tracker_set_local_map(eao_tracker* h, const eao_map_points* pts) {
+    EAO_REQUIRE(h && pts && pts->n >= 0 && pts->n <= h->capMp, "bad argument (at most %d map points)", h ? h->capMp : 0);
+    const int n = pts->n;
+    h->nMp = n;
+    if (n == 0) return EAO_OK;
+    EAO_REQUIRE(pts->active && pts->Xw && pts->normal && pts->min_dist_inv && pts->max_dist_inv && pts->max_dist && pts->desc, "incomplete map-point arrays");
+    const size_t M = n;
+    size_t off = 0;
+    auto put = [&](void* dst, const void* src, size_t bytes) -> eao_status {
+        std::memcpy(h->pin + off, src, bytes);
+        EAO_HIP(hipMemcpyAsync(dst, h->pin + off, bytes, hipMemcpyHostToDevice, h->stream));
+        off = al256(off + bytes);
+        return EAO_OK;
+    };
+    eao_status st;
+    EAO_HIP(hipStreamSynchronize(h->stream));      // the staging block may still feed the previous upload
+    if ((st = put(h->mXw, pts->Xw, 12 * M)) || (st = put(h->mNormal, pts->normal, 12 * M)) || (st = put(h->mMin, pts->min_dist_inv, 4 * M)) ||
+        (st = put(h->mMax, pts->max_dist_inv, 4 * M)) || (st = put(h->mNum, pts->max_dist, 4 * M)) || (st = put(h->mDesc, pts->desc, 32 * M)) ||
+        (st = put(h->mActive, pts->active, M))) return st;
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    return EAO_OK;
+}
+
+eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                       const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
+                                       const int32_t* prior_kp_map_point, float th, float nnratio, eao_track_result* out, void* stream) {
+    EAO_REQUIRE(h && d_kps && d_desc && d_n && Tcw_prior && out && out->kp_map_point && out->kp_outlier, "null argument");
+    EAO_REQUIRE(!d_depth || (depth_pitch >= width && width > 0 && height > 0), "bad depth image geometry");
+    EAO_REQUIRE(((uintptr_t)d_desc & 15) == 0, "descriptors must be 16-byte aligned");
+    const eao_tracker_cfg& c = h->cfg;
+    const int C = h->cap, nMp = h->nMp;
+    hipStream_t s = h->stream;
+    // ordered behind whatever produced the inputs on the caller's stream (the extraction)
+    EAO_HIP(hipEventRecord(h->evIn, (hipStream_t)stream));
+    EAO_HIP(hipStreamWaitEvent(s, h->evIn, 0));
+    if (prior_kp_map_point) {
+        std::memcpy(h->pin, prior_kp_map_point, 4 * (size_t)C);
+        EAO_HIP(hipMemcpyAsync(h->prior, h->pin, 4 * (size_t)C, hipMemcpyHostToDevice, s));
+    }
+    FrameArrays A;
+    A.kx = h->kx; A.ky = h->ky; A.ang = h->ang; A.ur = h->ur; A.dz = h->dz; A.oct = h->oct; A.order = h->order; A.cellx = h->cellx; A.celly = h->celly;
+    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = h->mSkip;
+    int npow2 = 64;
+    while (npow2 < C) npow2 <<= 1;
+    const float invW = (float)c.grid_cols / (c.max_x - c.min_x), invH = (float)c.grid_rows / (c.max_y - c.min_y);   // src/Frame.cc:258-259
+    hipLaunchKernelGGL(k_track_frame, dim3(1), dim3(kFrameThreads), (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth, depth_pitch, width, height, c.mbf,
+                       c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A);
+    eao_status st;
+    if (nMp > 0) {
+        eao::frame::FrustumDevArgs F;
+        F.n = nMp; F.Xw = h->mXw; F.normal = h->mNormal; F.minDist = h->mMin; F.maxDist = h->mMax; F.maxDistNum = h->mNum;
+        std::memcpy(F.Tcw, Tcw_prior, 64);
+        for (int i = 0; i < 3; i++) {   // mOw = -Rcw^T tcw (Frame::UpdatePoseMatrices, src/Frame.cc:630-636): float matrices, double accumulation
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += (double)Tcw_prior[4 * k + i] * (double)Tcw_prior[4 * k + 3];
+            F.Ow[i] = (float)(-acc);
+        }
+        F.fx = c.fx; F.fy = c.fy; F.cx = c.cx; F.cy = c.cy; F.mbf = c.mbf; F.minX = c.min_x; F.maxX = c.max_x; F.minY = c.min_y; F.maxY = c.max_y;
+        F.logScale = c.log_scale_factor; F.cosLimit = 0.5f;          // Tracking::SearchLocalPoints: isInFrustum(pMP, 0.5)
+        F.inView = h->inView; F.projX = h->projX; F.projY = h->projY; F.projXR = h->projXR; F.viewCos = h->viewCos; F.level = h->level;
+        if ((st = eao::frame::enqueue_frustum_device(F, s))) return st;
+        hipLaunchKernelGGL(k_track_queries, dim3(eao::cdiv(nMp, 256)), dim3(256), 0, s, nMp, h->mActive, h->mSkip, h->inView, h->projX, h->projY, h->projXR,
+                           h->viewCos, h->level, h->dScale, c.nlevels, th, h->q, h->counts);
+        eao::match::FrameDevArgs FD;
+        FD.cap = C; FD.nOrdered = h->counts + 1; FD.kx = h->kx; FD.ky = h->ky; FD.oct = h->oct; FD.ur = h->ur; FD.desc = d_desc;
+        FD.order = h->order; FD.cellx = h->cellx; FD.celly = h->celly;
+        FD.minX = c.min_x; FD.minY = c.min_y; FD.invW = invW; FD.invH = invH; FD.cols = c.grid_cols; FD.rows = c.grid_rows;
+        if ((st = eao::match::enqueue_candidates_device(FD, h->q, h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
+                                                        h->segCount, h->cursor, s))) return st;
+        hipLaunchKernelGGL(k_track_assign, dim3(1), dim3(kAssignThreads), (size_t)C * 5, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
+                           nnratio, h->match, h->counts);
+    }
+    EdgeArrays E;
+    E.Xw = h->eXw; E.obs = h->eObs; E.info = h->eInfo; E.flags = h->eFlags; E.eKp = h->eKp;
+    const int edgeCap = std::min(C, 2048);
+    hipLaunchKernelGGL(k_track_edges, dim3(1), dim3(kEdgeThreads), 0, s, nMp, C, h->match, h->kpMp, h->kx, h->ky, h->ur, h->oct, h->mXw, h->dInvSigma2, E,
+                       edgeCap, h->counts);
+    // result block layout
+    const size_t se3 = al256(eao::lm::pose_se3_bytes());
+    unsigned char* r = h->res;
+    size_t ro = 0;
+    void* rSE3 = r + ro; ro += se3;
+    int* rRes = (int*)(r + ro); ro += al256(16);
+    double* rTrace = (double*)(r + ro); ro += al256(192 * 8);
+    int* rCounts = (int*)(r + ro); ro += al256(32);
+    int* rKpMp = (int*)(r + ro); ro += al256(4 * (size_t)C);
+    unsigned char* rOutl = r + ro; ro += al256(C);
+    float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
+    float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
+    EAO_HIP(hipMemsetAsync(rRes, 0, 16, s));
+    EAO_HIP(hipMemsetAsync(h->eOutl, 0, C, s));
+    eao::lm::PoseChainArgs PA;
+    PA.nEdges = h->counts + 2; PA.cap = edgeCap;
+    PA.Xw = h->eXw; PA.obs = h->eObs; PA.info = h->eInfo; PA.flags = h->eFlags; PA.err = h->eErr; PA.outlier = h->eOutl;
+    std::memcpy(PA.Tcw0, Tcw_prior, 64);
+    PA.fx = c.fx; PA.fy = c.fy; PA.cx = c.cx; PA.cy = c.cy; PA.bf = c.mbf;
+    PA.outSE3 = rSE3; PA.outResult = rRes; PA.outTrace = rTrace;
+    if ((st = eao::lm::enqueue_pose_device(PA, s))) return st;
+    hipLaunchKernelGGL(k_track_finish, dim3(eao::cdiv(std::max(C, 8), 256)), dim3(256), 0, s, C, h->counts, h->kpMp, h->eKp, h->eOutl, h->ur, h->dz, rCounts,
+                       rKpMp, rOutl, rUr, rDz);
+    // ---- the ONE copy back
+    EAO_HIP(hipMemcpyAsync(h->pin, h->res, h->resBytes, hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(hipGetLastError());
+    const unsigned char* p = h->pin;
+    const int* oc = (const int*)(p + ((unsigned char*)rCounts - r));
+    const int n = oc[0], nEdges = oc[2];
+    EAO_REQUIRE(!(oc[4] & 1), "a map point in view has a predicted level outside the pyramid (upstream would index mvScaleFactors out of range)");
+    EAO_REQUIRE(!(oc[4] & 2), "more than %d correspondences: beyond the chained PoseOptimization's capacity", edgeCap);
+    out->n_keypoints = n; out->n_matches = oc[3]; out->n_edges = nEdges;
+    std::memcpy(out->kp_map_point, p + ((unsigned char*)rKpMp - r), 4 * (size_t)C);
+    if (out->kp_u_right) std::memcpy(out->kp_u_right, p + ((unsigned char*)rUr - r), 4 * (size_t)C);
+    if (out->kp_depth) std::memcpy(out->kp_depth, p + ((unsigned char*)rDz - r), 4 * (size_t)C);
+    if (nEdges < 3) {   // "if(nInitialCorrespondences<3) return 0" (src/Optimizer.cc:453-454): pose untouched
+        std::memcpy(out->Tcw, Tcw_prior, 64);
+        out->n_inliers = 0;
+        std::memset(out->kp_outlier, 0, C);
+    } else {
+        eao::lm::pose_se3_to_Tcw(p, out->Tcw);
+        const int* rr = (const int*)(p + ((unsigned char*)rRes - r));
+        out->n_inliers = nEdges - rr[0];
+        std::memcpy(out->kp_outlier, p + ((unsigned char*)rOutl - r), C);
+    }
+    // the caller's stream continues behind the chain (its inputs may be reused)
+    EAO_HIP(hipEventRecord(h->evOut, s));
+    EAO_HIP(hipStreamWaitEvent((hipStream_t)stream, h->evOut, 0));
+    return EAO_OK;
+}
+
+}  // extern "C"

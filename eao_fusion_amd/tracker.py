@@ -1,0 +1,77 @@
+"""ctypes mirror of the device-resident tracked frame (include/eao_fusion.h, row f1: eao_tracker_*): Tracking::TrackLocalMap's
+data path -- reference src/Tracking.cc:1717-2231, 2587-2641 -- chained on the device behind the extractor's outputs."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .search import MapPoints, map_points
+
+_P, _I, _F = C.c_void_p, C.c_int32, C.c_float
+
+
+class TrackerCfg(C.Structure):
+    _fields_ = [("fx", _F), ("fy", _F), ("cx", _F), ("cy", _F), ("mbf", _F), ("min_x", _F), ("max_x", _F), ("min_y", _F), ("max_y", _F),
+                ("grid_cols", _I), ("grid_rows", _I), ("nlevels", _I), ("scale_factors", _P), ("inv_level_sigma2", _P),
+                ("log_scale_factor", _F), ("max_keypoints", _I), ("max_map_points", _I)]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("Tcw", _F * 16), ("n_keypoints", _I), ("n_matches", _I), ("n_edges", _I), ("n_inliers", _I), ("kp_map_point", _P),
+                ("kp_outlier", _P), ("kp_u_right", _P), ("kp_depth", _P)]
+
+
+def _bind(L):
+    L.eao_tracker_create.restype = _I
+    L.eao_tracker_create.argtypes = [C.POINTER(TrackerCfg), C.POINTER(_P)]
+    L.eao_tracker_destroy.restype = None
+    L.eao_tracker_destroy.argtypes = [_P]
+    L.eao_tracker_set_local_map.restype = _I
+    L.eao_tracker_set_local_map.argtypes = [_P, C.POINTER(MapPoints)]
+    L.eao_tracker_track_local_map.restype = _I
+    L.eao_tracker_track_local_map.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, C.POINTER(TrackResult), _P]
+    return L
+
+
+class Tracker:
+    def __init__(self, fx, fy, cx, cy, mbf, bounds, scale_factors, inv_level_sigma2, log_scale_factor, max_keypoints, max_map_points,
+                 grid=(64, 48)):
+        self._L = _bind(_lib.load())
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        isg = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        cfg = TrackerCfg(fx, fy, cx, cy, mbf, bounds[0], bounds[1], bounds[2], bounds[3], grid[0], grid[1], len(sf), _lib.ptr(sf), _lib.ptr(isg),
+                         log_scale_factor, max_keypoints, max_map_points)
+        self._h = _P()
+        _lib.check(self._L.eao_tracker_create(C.byref(cfg), C.byref(self._h)))
+        self.cap = int(max_keypoints)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.eao_tracker_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_local_map(self, pts):
+        m, keep = map_points(pts)
+        _lib.check(self._L.eao_tracker_set_local_map(self._h, C.byref(m)))
+
+    def track_local_map(self, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_prior, prior=None, th=1.0, nnratio=0.8, stream=0):
+        """d_*: integers (HBM addresses).  Returns dict(Tcw, n_keypoints, n_matches, n_edges, n_inliers, kp_map_point, kp_outlier,
+        u_right, depth)."""
+        T = np.ascontiguousarray(Tcw_prior, np.float32).reshape(4, 4)
+        kpmp = np.full(self.cap, -1, np.int32)
+        outl = np.zeros(self.cap, np.uint8)
+        ur = np.zeros(self.cap, np.float32)
+        dz = np.zeros(self.cap, np.float32)
+        pr = None
+        if prior is not None:
+            pr = np.full(self.cap, -1, np.int32)
+            pr[:len(prior)] = np.asarray(prior, np.int32)
+        R = TrackResult()
+        R.kp_map_point, R.kp_outlier, R.kp_u_right, R.kp_depth = _lib.ptr(kpmp), _lib.ptr(outl), _lib.ptr(ur), _lib.ptr(dz)
+        _lib.check(self._L.eao_tracker_track_local_map(self._h, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, _lib.ptr(T), _lib.ptr(pr),
+                                                      th, nnratio, C.byref(R), stream))
+        n = R.n_keypoints
+        return dict(Tcw=np.array(R.Tcw, np.float32).reshape(4, 4), n_keypoints=n, n_matches=R.n_matches, n_edges=R.n_edges, n_inliers=R.n_inliers,
+                    kp_map_point=kpmp[:n], kp_outlier=outl[:n], u_right=ur[:n], depth=dz[:n])

@@ -430,6 +430,53 @@ eao_status eao_last_lm_trace(double* lambda, double* chi2, int32_t* trials, int3
  * and the number of linearisations (buildSystem calls) it made. */
 eao_status eao_last_lm_timing(float* device_ms, int32_t* linearizations);
 
+/* ---- f1, second half: the device-resident tracked frame ------------------------------------------------------------
+ * Tracking::TrackLocalMap's data path (reference src/Tracking.cc:1717-2231, 2587-2641) chained on the device: the
+ * extractor's device outputs of ONE frame go through Frame::ComputeStereoFromRGBD + AssignFeaturesToGrid (src/Frame.cc:
+ * 599-614, 751-761, 1016-1037), Frame::isInFrustum over the local map (:638-695; viewingCosLimit 0.5 as in
+ * Tracking::SearchLocalPoints), ORBmatcher::SearchByProjection(Frame&, local map points, th) (src/ORBmatcher.cc:45-137)
+ * and Optimizer::PoseOptimization (src/Optimizer.cc:325-673, point edges) without returning to the host in between; one
+ * copy brings back the pose, mvpMapPoints, mvbOutlier (and mvuRight / mvDepth).  Results are those of the host-hop calls
+ * eao_compute_stereo_from_rgbd -> eao_frame_is_in_frustum -> eao_search_by_projection_points -> eao_pose_optimization on
+ * the same data, bit for bit (tests/test_gpu_track.py).  Distortion-free camera (mvKeysUn = mvKeys), as the reference's
+ * RGB-D configuration (ros_test/config/TUM3.yaml:13-16). */
+typedef struct eao_tracker eao_tracker;
+typedef struct {
+    float fx, fy, cx, cy, mbf;                 /* Frame::fx .. mbf */
+    float min_x, max_x, min_y, max_y;          /* mnMinX .. mnMaxY */
+    int32_t grid_cols, grid_rows;              /* FRAME_GRID_COLS x FRAME_GRID_ROWS = 64 x 48 (include/Frame.h:89-90) */
+    int32_t nlevels;
+    const float* scale_factors;                /* nlevels: mvScaleFactors (copied) */
+    const float* inv_level_sigma2;             /* nlevels: mvInvLevelSigma2 (copied) */
+    float log_scale_factor;                    /* mfLogScaleFactor */
+    int32_t max_keypoints;                     /* per frame, <= 4096; >= eao_orb_max_keypoints of the extractor */
+    int32_t max_map_points;                    /* of a local map, <= 4096 */
+} eao_tracker_cfg;
+eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out);
+void eao_tracker_destroy(eao_tracker* h);
+/* The local map (Tracking::mvpLocalMapPoints) as plain arrays; uploaded once and kept in HBM until replaced.  active[i] = 0
+ * where upstream skips the point (isBad()). */
+eao_status eao_tracker_set_local_map(eao_tracker* h, const eao_map_points* pts);
+typedef struct {
+    float Tcw[16];            /* the optimised pose (the prior when fewer than 3 correspondences, src/Optimizer.cc:453-454) */
+    int32_t n_keypoints;      /* N of the frame */
+    int32_t n_matches;        /* return value of SearchByProjection */
+    int32_t n_edges;          /* nInitialCorrespondences of PoseOptimization */
+    int32_t n_inliers;        /* its return value */
+    int32_t* kp_map_point;    /* caller array [max_keypoints]: mvpMapPoints as map-point index or -1 */
+    uint8_t* kp_outlier;      /* caller array [max_keypoints]: mvbOutlier */
+    float* kp_u_right;        /* optional caller arrays [max_keypoints]: mvuRight, mvDepth (NULL: not copied) */
+    float* kp_depth;
+} eao_track_result;
+/* d_kps / d_desc / d_n: ONE frame's slice of the device outputs of eao_orb_extract_batch_device (d_n points at that frame's
+ * count); d_depth: the float depth image on the device (rows of depth_pitch floats) or NULL (monocular: mvuRight = -1);
+ * Tcw_prior: the pose the frame enters TrackLocalMap with; prior_kp_map_point: mvpMapPoints as it stands (host array
+ * [max_keypoints], NULL = none) -- those keypoints are occupied, their map points are not searched again, and they are
+ * edges of the pose optimisation.  `stream`: the stream the extraction was enqueued on (the chain waits for it). */
+eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                       const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
+                                       const int32_t* prior_kp_map_point, float th, float nnratio, eao_track_result* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,108 @@
+// include/eaofusion/DeviceTracker.h -- the device-resident tracked frame (second half) behind the reference's
+// own objects: Tracking::TrackLocalMap's data path (reference src/Tracking.cc:1717-2231, 2587-2641) with nothing returning to
+// the host between ORBextractor::operator() and the optimised pose.  Over libeaofusion_hip.so (eao_tracker_*, include/eao_fusion.h).
+//
+//   eaofusion::DeviceTracker trk(frame, maxKeypoints, maxMapPoints);      // once per camera (Frame statics: fx .. mbf, bounds, scale tables)
+//   trk.SetLocalMap(mvpLocalMapPoints);                                    // when Tracking::UpdateLocalMap changed the local map
+//   int nInliers = trk.TrackLocalMap(mCurrentFrame, d_kps, d_desc, d_n, d_depth, depthPitch, th, stream);
+//
+// TrackLocalMap replaces, for a distortion-free RGB-D / monocular camera, the sequence Frame::ComputeStereoFromRGBD +
+// AssignFeaturesToGrid (the part of the Frame constructor after the extractor) -> Tracking::SearchLocalPoints ->
+// Optimizer::PoseOptimization(&mCurrentFrame): it fills mvuRight, mvDepth, mvpMapPoints (new matches added to the ones the
+// frame already has), mvbOutlier and the pose exactly as those calls would.  Only members the reference's classes already have
+// are named.  Nothing here is copied from the reference.
+#ifndef EAOFUSION_DEVICE_TRACKER_H
+#define EAOFUSION_DEVICE_TRACKER_H
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../eao_fusion.h"
+#include "Frame.h"
+
+namespace eaofusion {
+
+class DeviceTracker {
+public:
+    template <class FrameT>
+    DeviceTracker(const FrameT& F, int maxKeypoints, int maxMapPoints) : cap_(maxKeypoints) {
+        eao_tracker_cfg c;
+        c.fx = F.fx; c.fy = F.fy; c.cx = F.cx; c.cy = F.cy; c.mbf = F.mbf;
+        c.min_x = F.mnMinX; c.max_x = F.mnMaxX; c.min_y = F.mnMinY; c.max_y = F.mnMaxY;
+        c.grid_cols = 64; c.grid_rows = 48;                       // FRAME_GRID_COLS / ROWS, include/Frame.h:89-90
+        c.nlevels = F.mnScaleLevels;
+        c.scale_factors = F.mvScaleFactors.data(); c.inv_level_sigma2 = F.mvInvLevelSigma2.data();
+        c.log_scale_factor = F.mfLogScaleFactor;
+        c.max_keypoints = maxKeypoints; c.max_map_points = maxMapPoints;
+        detail::check(eao_tracker_create(&c, &h_), "eao_tracker_create");
+    }
+    ~DeviceTracker() { eao_tracker_destroy(h_); }
+    DeviceTracker(const DeviceTracker&) = delete;
+    DeviceTracker& operator=(const DeviceTracker&) = delete;
+
+    // Tracking::mvpLocalMapPoints -> HBM (kept until the next call).  Bad points stay in the arrays with active = 0.
+    template <class MapPointT>
+    void SetLocalMap(const std::vector<MapPointT*>& vpMPs) {
+        const size_t n = vpMPs.size();
+        map_.assign(vpMPs.begin(), vpMPs.end());
+        std::vector<unsigned char> active(n);
+        std::vector<float> Xw(3 * n), nrm(3 * n), dmin(n), dmax(n), draw(n);
+        std::vector<unsigned char> desc(32 * n);
+        for (size_t i = 0; i < n; i++) {
+            MapPointT* p = vpMPs[i];
+            active[i] = (p && !p->isBad()) ? 1 : 0;
+            if (!active[i]) continue;
+            const cv::Mat P = p->GetWorldPos(), Pn = p->GetNormal(), D = p->GetDescriptor();
+            for (int a = 0; a < 3; a++) { Xw[3 * i + a] = P.template at<float>(a); nrm[3 * i + a] = Pn.template at<float>(a); }
+            dmin[i] = p->GetMinDistanceInvariance(); dmax[i] = p->GetMaxDistanceInvariance(); draw[i] = detail::MaxDistanceOf<MapPointT>::get(p);
+            std::memcpy(&desc[32 * i], D.template ptr<unsigned char>(0), 32);
+        }
+        eao_map_points mp;
+        mp.n = (int)n; mp.active = active.data(); mp.Xw = Xw.data(); mp.normal = nrm.data(); mp.min_dist_inv = dmin.data();
+        mp.max_dist_inv = dmax.data(); mp.max_dist = draw.data(); mp.desc = desc.data();
+        detail::check(eao_tracker_set_local_map(h_, &mp), "eao_tracker_set_local_map");
+    }
+
+    // d_kps / d_desc / d_n: this frame's slice of eao_orb_extract_batch_device's outputs (F.mvKeys / mDescriptors are their host
+    // copies, F.N = the count); d_depth: imDepth on the device or nullptr.  Returns Optimizer::PoseOptimization's return value.
+    template <class FrameT>
+    int TrackLocalMap(FrameT& F, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch,
+                      int width, int height, float th, float nnratio, void* stream) {
+        using MapPointT = typename std::remove_pointer<typename std::decay<decltype(F.mvpMapPoints[0])>::type>::type;
+        std::vector<int32_t> prior(cap_, -1), kpMp(cap_, -1);
+        std::vector<uint8_t> outl(cap_, 0);
+        std::vector<float> ur(cap_), dz(cap_);
+        for (int k = 0; k < F.N && k < cap_; k++)
+            if (F.mvpMapPoints[k]) {
+                for (size_t m = 0; m < map_.size(); m++)
+                    if (map_[m] == (void*)F.mvpMapPoints[k]) { prior[k] = (int32_t)m; break; }
+            }
+        float T[16];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) T[4 * r + c] = F.mTcw.template at<float>(r, c);
+        eao_track_result R;
+        R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data();
+        detail::check(eao_tracker_track_local_map(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, T, prior.data(), th, nnratio, &R, stream),
+                      "eao_tracker_track_local_map");
+        F.mvuRight.assign(ur.begin(), ur.begin() + R.n_keypoints);
+        F.mvDepth.assign(dz.begin(), dz.begin() + R.n_keypoints);
+        for (int k = 0; k < R.n_keypoints; k++) {
+            if (kpMp[k] >= 0 && !F.mvpMapPoints[k]) F.mvpMapPoints[k] = static_cast<MapPointT*>(map_[kpMp[k]]);
+            F.mvbOutlier[k] = outl[k] != 0;
+        }
+        cv::Mat pose(4, 4, CV_32F);
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[4 * r + c];
+        F.SetPose(pose);
+        return R.n_inliers;
+    }
+
+private:
+    eao_tracker* h_ = nullptr;
+    int cap_;
+    std::vector<void*> map_;
+};
+
+}  // namespace eaofusion
+#endif

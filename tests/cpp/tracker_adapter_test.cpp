@@ -1,0 +1,134 @@
+// Drives eaofusion::DeviceTracker (include/eaofusion/DeviceTracker.h) against stand-ins of the reference's Frame / MapPoint
+// and compares what it leaves in the frame -- mvuRight, mvDepth, mvpMapPoints, mvbOutlier, the pose -- with a direct call of
+// the C-ABI on the same arrays.  Device buffers come from the HIP runtime (this test is built with hipcc).
+// Exit code 0 = everything agrees.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include <eaofusion/DeviceTracker.h>
+
+struct MapPoint {
+    cv::Mat pos, normal, desc;
+    bool bad = false;
+    bool isBad() { return bad; }
+    cv::Mat GetWorldPos() { return pos.clone(); }
+    cv::Mat GetNormal() { return normal.clone(); }
+    cv::Mat GetDescriptor() { return desc.clone(); }
+    float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+    float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+    void SetDistances(float mn, float mx) { mfMinDistance = mn; mfMaxDistance = mx; }
+protected:
+    float mfMinDistance = 0, mfMaxDistance = 0;
+};
+
+struct Frame {
+    int N = 0;
+    static float fx, fy, cx, cy, mnMinX, mnMaxX, mnMinY, mnMaxY;
+    float mbf = 40.f, mfLogScaleFactor = std::log(1.2f);
+    int mnScaleLevels = 8;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2;
+    cv::Mat mTcw;
+    std::vector<cv::KeyPoint> mvKeys;
+    std::vector<float> mvuRight, mvDepth;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    void SetPose(cv::Mat T) { mTcw = T.clone(); }
+};
+float Frame::fx = 535.4f, Frame::fy = 539.2f, Frame::cx = 320.1f, Frame::cy = 247.6f;
+float Frame::mnMinX = 0.f, Frame::mnMaxX = 640.f, Frame::mnMinY = 0.f, Frame::mnMaxY = 480.f;
+
+static unsigned long long g_s = 88172645463325252ull;
+static double rnd() { g_s ^= g_s << 13; g_s ^= g_s >> 7; g_s ^= g_s << 17; return (double)(g_s >> 11) / 9007199254740992.0; }
+#define HIPCHK(x) do { if ((x) != hipSuccess) { fprintf(stderr, "HIP call failed: %s\n", #x); return 2; } } while (0)
+
+int main() {
+    const int M = 700, cap = 1024, W = 640, H = 480;
+    Frame F;
+    for (int l = 0; l < 8; l++) { F.mvScaleFactors.push_back(l ? F.mvScaleFactors[l - 1] * 1.2f : 1.0f); F.mvInvLevelSigma2.push_back(1.0f / (F.mvScaleFactors[l] * F.mvScaleFactors[l])); }
+    F.mTcw = cv::Mat::eye(4, 4, CV_32F);
+    F.mTcw.at<float>(0, 3) = 0.02f; F.mTcw.at<float>(2, 3) = -0.03f;
+    std::vector<MapPoint> pts(M);
+    std::vector<MapPoint*> local;
+    std::vector<float> depth((size_t)W * H, 0.f);
+    std::vector<unsigned char> desc;
+    for (int m = 0; m < M; m++) {
+        MapPoint& p = pts[m];
+        const float z = 2.f + 4.f * (float)rnd(), x = (float)(rnd() - 0.5) * z * 0.9f, y = (float)(rnd() - 0.5) * z * 0.7f;
+        p.pos = cv::Mat(3, 1, CV_32F); p.pos.at<float>(0) = x; p.pos.at<float>(1) = y; p.pos.at<float>(2) = z;
+        const float nrm = std::sqrt(x * x + y * y + z * z);
+        p.normal = cv::Mat(3, 1, CV_32F); p.normal.at<float>(0) = x / nrm; p.normal.at<float>(1) = y / nrm; p.normal.at<float>(2) = z / nrm;
+        const int oct = (int)(rnd() * 7.99);
+        p.SetDistances(0.7f * nrm, nrm * std::pow(1.2f, oct - 0.5f));
+        p.desc = cv::Mat(1, 32, CV_8U);
+        for (int b = 0; b < 32; b++) p.desc.at<unsigned char>(0, b) = (unsigned char)(rnd() * 256);
+        p.bad = rnd() < 0.03;
+        local.push_back(&p);
+        // the keypoint that observes it: projection + noise, the same descriptor with a few bits flipped
+        const float xc = x + 0.02f, zc = z - 0.03f;
+        const float u = Frame::fx * xc / zc + Frame::cx + (float)(rnd() - 0.5) * 2.f, v = Frame::fy * y / zc + Frame::cy + (float)(rnd() - 0.5) * 2.f;
+        if (u < 2 || u > W - 3 || v < 2 || v > H - 3) continue;
+        cv::KeyPoint kp(u, v, 31.f, (float)(rnd() * 360.0), 50.f, oct);
+        F.mvKeys.push_back(kp);
+        for (int b = 0; b < 32; b++) desc.push_back((unsigned char)(p.desc.at<unsigned char>(0, b) ^ (rnd() < 0.1 ? 1 << (int)(rnd() * 8) : 0)));
+        depth[(size_t)(int)v * W + (int)u] = rnd() < 0.2 ? 0.f : zc;
+    }
+    F.N = (int)F.mvKeys.size();
+    F.mvpMapPoints.assign(F.N, nullptr);
+    F.mvbOutlier.assign(F.N, false);
+    F.mvpMapPoints[3] = local[3 < M ? 3 : 0];        // a match the frame already carries
+    eao_keypoint* d_kps; uint8_t* d_desc; int32_t* d_n; float* d_depth;
+    HIPCHK(hipMalloc((void**)&d_kps, cap * sizeof(eao_keypoint))); HIPCHK(hipMalloc((void**)&d_desc, cap * 32)); HIPCHK(hipMalloc((void**)&d_n, 4));
+    HIPCHK(hipMalloc((void**)&d_depth, depth.size() * 4));
+    HIPCHK(hipMemset(d_kps, 0, cap * sizeof(eao_keypoint))); HIPCHK(hipMemset(d_desc, 0, cap * 32));
+    HIPCHK(hipMemcpy(d_kps, F.mvKeys.data(), (size_t)F.N * sizeof(eao_keypoint), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_desc, desc.data(), desc.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_n, &F.N, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_depth, depth.data(), depth.size() * 4, hipMemcpyHostToDevice));
+    Frame F2 = F;                                      // for the direct C-ABI call below
+    eaofusion::DeviceTracker trk(F, cap, 1024);
+    trk.SetLocalMap(local);
+    const int nIn = trk.TrackLocalMap(F, d_kps, d_desc, d_n, d_depth, W, W, H, 3.0f, 0.8f, nullptr);
+    // ---- the same through the C-ABI, arrays built by hand
+    eao_tracker_cfg c = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, F2.mbf, 0.f, 640.f, 0.f, 480.f, 64, 48, 8, F2.mvScaleFactors.data(), F2.mvInvLevelSigma2.data(),
+                         F2.mfLogScaleFactor, cap, 1024};
+    eao_tracker* h = nullptr;
+    if (eao_tracker_create(&c, &h) != EAO_OK) { fprintf(stderr, "%s\n", eao_last_error()); return 2; }
+    std::vector<unsigned char> act(M), dsc(32 * (size_t)M);
+    std::vector<float> Xw(3 * (size_t)M), nr(3 * (size_t)M), dmin(M), dmax(M), draw(M);
+    for (int m = 0; m < M; m++) {
+        act[m] = pts[m].bad ? 0 : 1;
+        for (int a = 0; a < 3; a++) { Xw[3 * m + a] = pts[m].pos.at<float>(a); nr[3 * m + a] = pts[m].normal.at<float>(a); }
+        dmin[m] = pts[m].GetMinDistanceInvariance(); dmax[m] = pts[m].GetMaxDistanceInvariance(); draw[m] = dmax[m] / 1.2f;
+        memcpy(&dsc[32 * (size_t)m], pts[m].desc.ptr<unsigned char>(0), 32);
+    }
+    // (mfMaxDistance itself: GetMaxDistanceInvariance() / 1.2f does not round-trip -- read it the way the adapter does)
+    for (int m = 0; m < M; m++) draw[m] = eaofusion::detail::MaxDistanceOf<MapPoint>::get(&pts[m]);
+    eao_map_points mp = {M, act.data(), Xw.data(), nr.data(), dmin.data(), dmax.data(), draw.data(), dsc.data()};
+    if (eao_tracker_set_local_map(h, &mp) != EAO_OK) { fprintf(stderr, "%s\n", eao_last_error()); return 2; }
+    std::vector<int32_t> prior(cap, -1), kpMp(cap, -1);
+    prior[3] = 3;
+    std::vector<uint8_t> outl(cap);
+    std::vector<float> ur(cap), dz(cap);
+    eao_track_result R;
+    R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data();
+    float T[16];
+    for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) T[4 * r + k] = F2.mTcw.at<float>(r, k);
+    if (eao_tracker_track_local_map(h, d_kps, d_desc, d_n, d_depth, W, W, H, T, prior.data(), 3.0f, 0.8f, &R, nullptr) != EAO_OK) { fprintf(stderr, "%s\n", eao_last_error()); return 2; }
+    eao_tracker_destroy(h);
+    int bad = 0, matched = 0;
+    if (nIn != R.n_inliers) { fprintf(stderr, "inliers %d vs %d\n", nIn, R.n_inliers); bad++; }
+    for (int k = 0; k < F.N; k++) {
+        MapPoint* want = kpMp[k] >= 0 ? &pts[kpMp[k]] : nullptr;
+        if (F.mvpMapPoints[k] != want) bad++;
+        if (F.mvbOutlier[k] != (outl[k] != 0)) bad++;
+        if (F.mvuRight[k] != ur[k] || F.mvDepth[k] != dz[k]) bad++;
+        matched += want ? 1 : 0;
+    }
+    for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) if (F.mTcw.at<float>(r, k) != R.Tcw[4 * r + k]) bad++;
+    fprintf(stderr, "%d keypoints, %d with a map point, %d inliers, %d disagreements\n", F.N, matched, nIn, bad);
+    return (bad == 0 && matched > 100 && nIn > 50) ? 0 : 1;
+}

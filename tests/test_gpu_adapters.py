@@ -280,3 +280,17 @@ def test_cpp_frame_adapters(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "in view" in out.stderr and "inside the grid" in out.stderr
+
+
+def test_cpp_device_tracker_adapter(tmp_path):
+    """include/eaofusion/DeviceTracker.h (row f1, second half) over mock Frame / MapPoint classes: the adapter's TrackLocalMap
+    leaves the frame exactly as a direct eao_tracker_track_local_map call on hand-built arrays does.  Built with hipcc: the test
+    owns the device buffers an extractor would hand over."""
+    exe = str(tmp_path / "tracker_adapter_test")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-DEAOFUSION_FORCE_CV_COMPAT", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "tracker_adapter_test.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "eao_fusion_amd"), "-leaofusion_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "eao_fusion_amd"), "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 disagreements" in out.stderr

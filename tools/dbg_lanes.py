@@ -13,7 +13,10 @@ def dmalloc(n):
     p=C.c_void_p(); assert hip.hipMalloc(C.byref(p), n)==0; return p
 d_img=dmalloc(imgs.nbytes); hip.hipMemcpy(d_img, imgs.ctypes.data, imgs.nbytes, 1)
 d_k=dmalloc(B*cap*28); d_d=dmalloc(B*cap*32); d_n=dmalloc(B*4)
-def step(): _lib.check(L.eao_orb_extract_batch_device(ext._h, d_img, W,H,W,W*H,B,d_k,d_d,cap,d_n,None))
+stream = None
+if os.environ.get("EAO_DBG_STREAM") == "own":      # a non-blocking stream of the caller's instead of the null stream
+    stream = C.c_void_p(); assert hip.hipStreamCreateWithFlags(C.byref(stream), 1) == 0
+def step(): _lib.check(L.eao_orb_extract_batch_device(ext._h, d_img, W,H,W,W*H,B,d_k,d_d,cap,d_n,stream))
 if os.environ.get('EAO_DBG_PROF'): ext.set_profiling(True)   # stages run one after the other
 for _ in range(3): step()
 hip.hipDeviceSynchronize()
