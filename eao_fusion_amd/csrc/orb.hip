@@ -130,6 +130,21 @@ __device__ __forceinline__ void resize_coef(int d, double inv, int slimit, bool 
     *wpair = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
 }
 
+// the same on the host (k_pyramid_fused reads tables built with it): lrintf rounds to nearest even like v_cvt_i32_f32
+inline void resize_coef_host(int d, double inv, int slimit, bool clampHi, int* ofs, unsigned* wpair) {
+    float fr = (float)(((double)d + 0.5) * inv - 0.5);
+    int o = (int)std::floor(fr);
+    fr -= (float)o;
+    if (clampHi) {
+        if (o < 0) { fr = 0; o = 0; }
+        if (o >= slimit - 1) { fr = 0; o = slimit - 1; }
+    }
+    const int w0 = std::min(std::max((int)std::lrintf((1.f - fr) * 2048.f), -32768), 32767);
+    const int w1 = std::min(std::max((int)std::lrintf(fr * 2048.f), -32768), 32767);
+    *ofs = o;
+    *wpair = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
+}
+
 __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) {
     const ResizeLevel D = A.D, S = A.S;
     const int bxi = blockIdx.x;
@@ -213,6 +228,181 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
                 o[i] = (uint8_t)min(max(v, 0), 255);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- fused pyramid
+// The whole pyramid of a frame in ONE launch.  Level l is a resize of level l - 1, so the seven launches of k_resize are a
+// dependent chain: 67 us for 100 MB at a 64-frame batch (latency, not bandwidth), 137 us with FAST running beside it.  Here a
+// workgroup owns a tile of level 1 and everything above it: per level the pixels whose TOP-LEFT source pixel it owns on the
+// level below (the boundaries follow from the source-offset function of the resize, so the owned ranges of the workgroups
+// tile every level exactly), plus the one-pixel right / bottom fringe the next level's interpolation reaches into, which it
+// recomputes instead of waiting for its neighbour.  The tiles of all levels live in LDS; only owned pixels go to HBM.
+// Same arithmetic as k_resize, pixel by pixel (OpenCV's 11-bit fixed point; the coefficients come from resize_coef).
+constexpr int kPyrTW = 128, kPyrTH = 32;      // the level-1 tile of a workgroup
+constexpr int kPyrThreads = 256;
+struct PyrLevel { int w, h, pitch, off; double invX, invY; int ldsOff, ldsW, ldsH; int coefXOff, coefYOff; };   // ldsW x ldsH: capacity of the level's tile
+struct PyrArgs {
+    int nlevels, tilesX, tilesY, pyrFrameBytes;
+    int coefOff;                      // LDS offset of the coefficient tables (xofs, xw, yofs, yw: 4 x coefCap ints)
+    int coefCap;
+    PyrLevel L[kMaxLevels];           // L[0]: the input image (ldsOff / ldsW / ldsH: its staged source region)
+    const int4* ranges;               // [level][tilesX + tilesY]: (own0, own1, req0, req1) of a tile column / tile row (device)
+    const int2* coefX;                // per level: (source offset, weight pair) of every column / row (device)
+    const int2* coefY;
+};
+// first destination index whose clamped source offset is >= bound (destinations 0 .. dn): the ownership boundary
+__host__ __device__ inline int pyr_src_ofs(int d, double inv, int sn) {
+    float fr = (float)(((double)d + 0.5) * inv - 0.5);
+    int o = (int)floorf(fr);
+    return o < 0 ? 0 : (o > sn - 1 ? sn - 1 : o);
+}
+__host__ __device__ inline int pyr_first_at_least(int bound, double inv, int sn, int dn) {
+    if (bound <= 0) return 0;
+    int d = (int)((double)bound / inv);          // estimate, then walk (the offset function is monotone)
+    d = d < 0 ? 0 : (d > dn ? dn : d);
+    while (d > 0 && pyr_src_ofs(d - 1, inv, sn) >= bound) d--;
+    while (d < dn && pyr_src_ofs(d, inv, sn) < bound) d++;
+    return d;
+}
+struct PyrRange { int x0, x1, y0, y1; };        // [x0, x1) x [y0, y1)
+__global__ __launch_bounds__(kPyrThreads) void k_pyramid_fused(PyrArgs A, ImgSrc s, int f0) {
+    extern __shared__ __align__(16) unsigned char psm[];
+    __shared__ PyrRange s_own[kMaxLevels], s_req[kMaxLevels];
+    const int t = threadIdx.x;
+    const int tx = blockIdx.x % A.tilesX, ty = blockIdx.x / A.tilesX, f = blockIdx.z + f0;
+    const int nl = A.nlevels;
+    // owned / required ranges of this tile, per level: separable in x and y and the same for every frame -- the host ran the
+    // range rules (pyr_first_at_least / pyr_src_ofs) once per tile column and tile row (PyrArgs::ranges); a thread deriving
+    // them here took 30 us of serial double arithmetic per workgroup
+    if (t < nl) {
+        const int4 rx = A.ranges[(size_t)t * (A.tilesX + A.tilesY) + tx], ry = A.ranges[(size_t)t * (A.tilesX + A.tilesY) + A.tilesX + ty];
+        s_own[t] = {rx.x, rx.y, ry.x, ry.y};
+        s_req[t] = {rx.z, rx.w, ry.z, ry.w};
+    }
+    __syncthreads();
+    // ---- stage the required region of the input image: aligned words when the image allows it (the tile's origin moves left
+    //      to the word boundary), bytes otherwise
+    int orgX0;       // image column of the staged tile's first byte
+    {
+        const PyrRange q = s_req[0];
+        const uint8_t* src = s.img0 + (long long)f * s.fs0;
+        const bool aligned = ((((uintptr_t)src | (uintptr_t)s.pitch0) & 3) == 0);
+        orgX0 = aligned ? (q.x0 & ~3) : q.x0;
+        const int rh = q.y1 - q.y0;
+        unsigned char* dst = psm + A.L[0].ldsOff;
+        const int ds = A.L[0].ldsW;
+        if (q.x1 > q.x0 && rh > 0) {
+            if (aligned) {
+                const int nwr = (q.x1 - orgX0 + 3) >> 2;
+                const float inv = __builtin_amdgcn_rcpf((float)nwr);
+                for (int i = t; i < nwr * rh; i += kPyrThreads) {
+                    const int y = (int)(((float)i + 0.5f) * inv), xw4 = i - y * nwr;
+                    *reinterpret_cast<unsigned*>(dst + y * ds + 4 * xw4) = *reinterpret_cast<const unsigned*>(src + (long long)(q.y0 + y) * s.pitch0 + orgX0 + 4 * xw4);
+                }
+            } else {
+                const int rw = q.x1 - q.x0;
+                const float inv = __builtin_amdgcn_rcpf((float)rw);
+                for (int i = t; i < rw * rh; i += kPyrThreads) {
+                    const int y = (int)(((float)i + 0.5f) * inv), x = i - y * rw;
+                    dst[y * ds + x] = src[(long long)(q.y0 + y) * s.pitch0 + q.x0 + x];
+                }
+            }
+        }
+    }
+    int* xofs = reinterpret_cast<int*>(psm + A.coefOff);
+    unsigned* xw = reinterpret_cast<unsigned*>(xofs + A.coefCap);
+    int* yofs = reinterpret_cast<int*>(xw + A.coefCap);
+    unsigned* yw = reinterpret_cast<unsigned*>(yofs + A.coefCap);
+    constexpr int RR = 2;     // output rows per work item (the column set-up is shared)
+    int srcOrg = orgX0;       // image column of the source tile's first byte
+    for (int l = 1; l < nl; l++) {
+        const PyrRange r = s_req[l], q = s_req[l - 1], own = s_own[l];
+        // the tile's first column is the word boundary at or left of the required range (pitches are multiples of 64), so
+        // that owned pixels leave as aligned words; the up to three extra columns are computed from whatever the source tile
+        // holds there and are never read (the next level's sources start at its required range) nor written to HBM
+        const int xa = r.x0 & ~3;
+        const int rw = r.x1 - xa, rh = r.y1 - r.y0;
+        __syncthreads();     // the source tile is complete; the coefficient tables of the previous level are no longer read
+        if (r.x1 <= r.x0 || rh <= 0) { srcOrg = xa; continue; }
+        const int sh = A.L[l - 1].h;
+        const int rw4 = (rw + 3) & ~3;
+        // bilinear coefficients of the level's columns and rows: built once per geometry by the host (the same float / double
+        // expressions, resize_coef) -- every workgroup evaluating them per level was a third of the kernel's instructions
+        const int2* cx = A.coefX + A.L[l].coefXOff;
+        const int2* cy = A.coefY + A.L[l].coefYOff;
+        for (int i = t; i < rw4; i += kPyrThreads) {   // (padded to a multiple of four with the last column)
+            const int2 cw = cx[min(xa + i, r.x1 - 1)];
+            xofs[i] = max(cw.x - srcOrg, 0); xw[i] = (unsigned)cw.y;
+        }
+        for (int i = t; i < rh; i += kPyrThreads) {
+            const int2 cw = cy[r.y0 + i];
+            const int yo = cw.x;
+            const int sy0 = min(max(yo, 0), sh - 1), sy1 = min(max(yo + 1, 0), sh - 1);
+            yofs[i] = (sy0 - q.y0) | ((sy1 - q.y0) << 16);
+            yw[i] = (unsigned)cw.y;
+        }
+        __syncthreads();
+        const unsigned* S32 = reinterpret_cast<const unsigned*>(psm + A.L[l - 1].ldsOff);
+        unsigned* D32 = reinterpret_cast<unsigned*>(psm + A.L[l].ldsOff);
+        const int ssw = A.L[l - 1].ldsW >> 2, dsw = A.L[l].ldsW >> 2;     // tile strides in words
+        uint8_t* gdst = s.pyr + (long long)f * A.pyrFrameBytes + A.L[l].off;
+        const int gp = A.L[l].pitch;
+        const int G = rw4 >> 2, items = G * ((rh + RR - 1) / RR);
+        const float invG = __builtin_amdgcn_rcpf((float)G);
+        for (int it = t; it < items; it += kPyrThreads) {
+            const int rg = (int)(((float)it + 0.5f) * invG), gx = it - rg * G, x = 4 * gx;
+            const int4 xo = *reinterpret_cast<const int4*>(&xofs[x]);
+            const uint4 xwv = *reinterpret_cast<const uint4*>(&xw[x]);
+            const int sxv[4] = {xo.x, xo.y, xo.z, xo.w};
+            const unsigned aa[4] = {xwv.x, xwv.y, xwv.z, xwv.w};
+            const int wb = sxv[0] >> 2;
+            // S[sx], S[sx + 1] of the four pixels lie inside three aligned words (scale factors up to 2, checked by the host)
+            unsigned sel[4];
+            bool up[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int o = min(sxv[i] - 4 * wb, 10);
+                up[i] = o >= 4;
+                const unsigned oo = (unsigned)(up[i] ? o - 4 : o);
+                sel[i] = oo | ((oo + 1) << 16) | 0x0c000c00u;   // v_perm: (S[sx], 0, S[sx+1], 0)
+            }
+            const int gx0 = xa + x;
+            const bool whole = gx0 >= own.x0 && gx0 + 4 <= own.x1;
+#pragma unroll
+            for (int rr = 0; rr < RR; rr++) {
+                const int y = rg * RR + rr, yc = min(y, rh - 1);
+                const int yy = yofs[yc];
+                const unsigned wy = yw[yc];
+                const unsigned B0 = wy << 16, B1 = wy & 0xFFFF0000u;
+                const unsigned* p0 = S32 + (yy & 0xFFFF) * ssw + wb;
+                const unsigned* p1 = S32 + (yy >> 16) * ssw + wb;
+                const unsigned a0 = p0[0], a1 = p0[1], a2 = p0[2], c0 = p1[0], c1 = p1[1], c2 = p1[2];
+                unsigned packed = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const unsigned pa = __builtin_amdgcn_perm(up[i] ? a2 : a1, up[i] ? a1 : a0, sel[i]);
+                    const unsigned pc = __builtin_amdgcn_perm(up[i] ? c2 : c1, up[i] ? c1 : c0, sel[i]);
+                    const unsigned h0 = udot2w(pa, aa[i]), h1 = udot2w(pc, aa[i]);
+                    const unsigned v = (__umulhi(B0, h0 >> 4) + __umulhi(B1, h1 >> 4) + 2) >> 2;
+                    packed |= min(v, 255u) << (8 * i);
+                }
+                if (y < rh) {
+                    D32[y * dsw + gx] = packed;
+                    const int gy = r.y0 + y;
+                    if (gy >= own.y0 && gy < own.y1) {
+                        uint8_t* o = gdst + gy * gp + gx0;
+                        if (whole) *reinterpret_cast<unsigned*>(o) = packed;
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if (gx0 + i >= own.x0 && gx0 + i < own.x1) o[i] = (uint8_t)(packed >> (8 * i));
+                        }
+                    }
+                }
+            }
+        }
+        srcOrg = xa;
     }
 }
 
@@ -1367,6 +1557,11 @@ struct eao_orb {
     int batchCap = 0;
     std::vector<CellDesc> cells;
     size_t quadLds = 0;
+    eao::DevBuf<int4> d_pyrRanges;
+    eao::DevBuf<int2> d_pyrCoef;
+    PyrArgs pyr;               // the fused pyramid launch of this geometry
+    size_t pyrLds = 0;
+    bool pyrFused = false;
     // device state
     hipStream_t stream = nullptr;
     // up to kLanes sub-batches can run as independent pipelines, each on its own (main, side) stream pair
@@ -1475,6 +1670,91 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     g.totalCandCap = candBase;
     g.totalTiles = tileBase;
     g.pyrFrameBytes = off;
+    // ---- fused pyramid: tile capacities by running the kernel's own range rules over every tile (host and device evaluate
+    //      the same float / double expressions; -ffp-contract=off on both sides)
+    {
+        PyrArgs& P = h->pyr;
+        std::memset(&P, 0, sizeof(P));
+        h->pyrFused = false;
+        static const bool envChain = getenv("EAO_ORB_PYRAMID") && !strcmp(getenv("EAO_ORB_PYRAMID"), "chain");
+        if (c.nlevels > 1 && !envChain) {
+            P.nlevels = c.nlevels; P.pyrFrameBytes = g.pyrFrameBytes;
+            for (int l = 0; l < c.nlevels; l++) {
+                P.L[l].w = g.L[l].w; P.L[l].h = g.L[l].h; P.L[l].pitch = g.L[l].pitch; P.L[l].off = g.L[l].off;
+                if (l) { P.L[l].invX = 1. / ((double)g.L[l].w / g.L[l - 1].w); P.L[l].invY = 1. / ((double)g.L[l].h / g.L[l - 1].h); }
+            }
+            P.tilesX = eao::cdiv(g.L[1].w, kPyrTW); P.tilesY = eao::cdiv(g.L[1].h, kPyrTH);
+            std::vector<int> capW(c.nlevels, 1), capH(c.nlevels, 1);
+            const int nT = P.tilesX + P.tilesY;
+            std::vector<int4> table((size_t)c.nlevels * nT, make_int4(0, 0, 0, 0));
+            auto axis = [&](int tiles, int T, bool isX, std::vector<int>& capv) {
+                for (int b = 0; b < tiles; b++) {
+                    const int col = isX ? b : P.tilesX + b;
+                    std::vector<int> o0(c.nlevels), o1(c.nlevels);
+                    int b0 = std::min(b * T, isX ? g.L[1].w : g.L[1].h), b1 = std::min((b + 1) * T, isX ? g.L[1].w : g.L[1].h);
+                    o0[1] = b0; o1[1] = b1;
+                    for (int l = 2; l < c.nlevels; l++) {
+                        const double inv = isX ? P.L[l].invX : P.L[l].invY;
+                        const int sn = isX ? g.L[l - 1].w : g.L[l - 1].h, dn = isX ? g.L[l].w : g.L[l].h;
+                        b0 = pyr_first_at_least(b0, inv, sn, dn); b1 = pyr_first_at_least(b1, inv, sn, dn);
+                        o0[l] = b0; o1[l] = b1;
+                    }
+                    int r0 = o0[c.nlevels - 1], r1 = o1[c.nlevels - 1];
+                    capv[c.nlevels - 1] = std::max(capv[c.nlevels - 1], r1 - r0);
+                    for (int l = 1; l < c.nlevels; l++) { table[(size_t)l * nT + col].x = o0[l]; table[(size_t)l * nT + col].y = o1[l]; }
+                    table[(size_t)(c.nlevels - 1) * nT + col].z = r0; table[(size_t)(c.nlevels - 1) * nT + col].w = r1;
+                    for (int l = c.nlevels - 1; l >= 1; l--) {
+                        int q0 = l > 1 ? o0[l - 1] : 0x7FFFFFFF, q1 = l > 1 ? o1[l - 1] : 0;
+                        if (r1 > r0) {
+                            const double inv = isX ? P.L[l].invX : P.L[l].invY;
+                            const int sn = isX ? g.L[l - 1].w : g.L[l - 1].h;
+                            q0 = std::min(q0, pyr_src_ofs(r0, inv, sn));
+                            q1 = std::max(q1, std::min(pyr_src_ofs(r1 - 1, inv, sn) + 1, sn - 1) + 1);
+                        }
+                        if (q0 > q1) q0 = q1 = 0;
+                        capv[l - 1] = std::max(capv[l - 1], q1 - q0);
+                        table[(size_t)(l - 1) * nT + col].z = q0; table[(size_t)(l - 1) * nT + col].w = q1;
+                        r0 = q0; r1 = q1;
+                    }
+                }
+            };
+            axis(P.tilesX, kPyrTW, true, capW);
+            axis(P.tilesY, kPyrTH, false, capH);
+            size_t lds = 0;
+            int coefCap = 1;
+            for (int l = 0; l < c.nlevels; l++) {
+                P.L[l].ldsW = ((capW[l] + 3) & ~3) + 16; P.L[l].ldsH = capH[l] + 1;     // (+ slack: staging origin, three-word reads past the last pixel)
+                P.L[l].ldsOff = (int)lds;
+                lds += ((size_t)P.L[l].ldsW * P.L[l].ldsH + 15) & ~(size_t)15;
+                coefCap = std::max(coefCap, std::max(capW[l], capH[l]));
+            }
+            coefCap = (coefCap + 7) & ~3;
+            P.coefOff = (int)lds; P.coefCap = coefCap;
+            lds += (size_t)coefCap * 16;
+            h->pyrLds = lds;
+            // (extreme level counts, and scale factors beyond 2 -- four pixels then read more than three source words -- keep
+            //  the chain of k_resize launches)
+            h->pyrFused = lds <= 64 * 1024 && h->cfg.scale_factor <= 2.0f;
+            for (int l = 1; l < c.nlevels; l++)
+                if (P.L[l].invX > 2.0 || P.L[l].invY > 2.0) h->pyrFused = false;
+            if (h->pyrFused) {
+                std::vector<int2> cxv, cyv;
+                for (int l = 1; l < c.nlevels; l++) {
+                    P.L[l].coefXOff = (int)cxv.size(); P.L[l].coefYOff = (int)cyv.size();
+                    for (int d = 0; d < g.L[l].w; d++) { int o; unsigned w2; resize_coef_host(d, P.L[l].invX, g.L[l - 1].w, true, &o, &w2); cxv.push_back(make_int2(o, (int)w2)); }
+                    for (int d = 0; d < g.L[l].h; d++) { int o; unsigned w2; resize_coef_host(d, P.L[l].invY, g.L[l - 1].h, false, &o, &w2); cyv.push_back(make_int2(o, (int)w2)); }
+                }
+                eao_status st2 = h->d_pyrRanges.reserve(table.size());
+                if (st2) return st2;
+                if ((st2 = h->d_pyrCoef.reserve(cxv.size() + cyv.size()))) return st2;
+                EAO_HIP(hipMemcpy(h->d_pyrRanges.p, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice));
+                EAO_HIP(hipMemcpy(h->d_pyrCoef.p, cxv.data(), cxv.size() * sizeof(int2), hipMemcpyHostToDevice));
+                EAO_HIP(hipMemcpy(h->d_pyrCoef.p + cxv.size(), cyv.data(), cyv.size() * sizeof(int2), hipMemcpyHostToDevice));
+                P.ranges = h->d_pyrRanges.p;
+                P.coefX = h->d_pyrCoef.p; P.coefY = h->d_pyrCoef.p + cxv.size();
+            }
+        }
+    }
     g.scanCap = scanCap;
     g.fastMaxTested = std::max(1, (maxSw - 6) * (maxSh - 6));
     // tile | work list u16[maxT] (+ the second list, stacked from its end) | score map | 16-word survivor-position table
@@ -1620,6 +1900,57 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         const bool qtEarly = mid > 0 && (envQtEarly >= 0 ? envQtEarly != 0 : nb <= 96);
         // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
+        auto quadtree = [&](hipStream_t str, int lFirst, int nLev) {
+            hipLaunchKernelGGL(k_quadtree, dim3(nb, nLev), dim3(kQT), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
+                               h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst);
+        };
+        // Measured (device-resident step, ms): batch 1: 0.117 fused vs 0.142 chain, 8: 0.136 / 0.160, 32: 0.231 / 0.235, 64: 0.353 /
+        // 0.309 -- small batches are bound by the chain of dependent launches, large ones by the VALU, where the fused kernel's
+        // recomputed fringes (+35 % pixels) and its seven barrier-separated levels per workgroup lose.  EAO_ORB_PYRAMID=fused
+        // forces it for any batch, =chain disables it.
+        static const bool envFused = getenv("EAO_ORB_PYRAMID") && !strcmp(getenv("EAO_ORB_PYRAMID"), "fused");
+        if (h->pyrFused && (envFused || nb <= 32)) {
+            // ---- the pyramid is ONE launch (k_pyramid_fused): no chain to hide things behind, so the schedule is simply
+            //   main:  pyramid -> FAST(levels >= 1) -> quad-trees(levels >= 1) ----------------------> orientation + description
+            //   side:  FAST(level 0) -> quad-tree(level 0, the longest) -> (pyramid done) blur --^
+            // (profiled calls: every stage alone, one after the other)
+            const dim3 pgrid(h->pyr.tilesX * h->pyr.tilesY, 1, nb);
+            if (prof) {
+                hipLaunchKernelGGL(k_pyramid_fused, pgrid, dim3(kPyrThreads), h->pyrLds, ms, h->pyr, s, f0);
+                if (pe) EAO_HIP(hipEventRecord(ev[1], ms));
+                EAO_HIP(hipEventRecord(h->evFork[i], ms));
+                EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
+                if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
+                hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
+                if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
+                EAO_HIP(hipEventRecord(h->evJoin[i], ss));
+                EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
+                if (pe) EAO_HIP(hipEventRecord(ev[9], ms));
+                fast(ms, 0, g.totalCells);
+                if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
+                quadtree(ms, 0, g.nlevels);
+                if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
+                if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
+            } else {
+                EAO_HIP(hipStreamWaitEvent(ss, h->evStart, 0));
+                fast(ss, 0, cells0);
+                quadtree(ss, 0, 1);
+                hipLaunchKernelGGL(k_pyramid_fused, pgrid, dim3(kPyrThreads), h->pyrLds, ms, h->pyr, s, f0);
+                EAO_HIP(hipEventRecord(h->evFork[i], ms));
+                EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
+                hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
+                EAO_HIP(hipEventRecord(h->evJoin[i], ss));
+                fast(ms, cells0, g.totalCells);
+                quadtree(ms, 1, g.nlevels - 1);
+                EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
+            }
+            hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
+                               h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels);
+            if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
+            EAO_HIP(hipEventRecord(h->evDone[i], ms));
+            EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
+            continue;
+        }
         if (early0) {
             EAO_HIP(hipStreamWaitEvent(ss, h->evStart, 0));
             fast(ss, 0, cells0);
