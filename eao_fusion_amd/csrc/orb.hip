@@ -21,6 +21,7 @@
 // Float semantics: this file is compiled with -ffp-contract=off (see Makefile): the reference's float
 // expressions are rounded op by op.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +54,7 @@ struct LevelGeom {
     int kpBase;                // first keypoint slot of this level inside a frame
     int candBase, candCap;     // candidate scratch of this level inside a frame
     int tileBase, tilesX;      // blur: first workgroup of this level, 128-px strips per row of strips
+    long long nodeOff;         // k_quadtree, global node lists: byte offset of this level inside a frame's workspace
     int scaledPatch;
     float scale;
 };
@@ -65,6 +67,8 @@ struct Geom {
     int iniTh, minTh;
     int scanCap;               // LDS scan workspace entries for k_quadtree
     int qtLdsCand, qtKeysOff;  // k_quadtree: candidates (key + node index) that fit in LDS, byte offset of the keys
+    int qtNodesGlobal;         // the node lists do not fit in LDS (thousands of features on one level): global workspace instead
+    long long qtNodeFrameBytes;
     int fastMaxTested, fastTileBytes, fastLdsBytes, fastStride;   // k_fast_cells dynamic LDS carve-up
     int umax[16];
     LevelGeom L[kMaxLevels];
@@ -1015,10 +1019,29 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
 #undef QSTAMP
 }
 
+__device__ __noinline__ void quadtree_global(const Geom* __restrict__ g, const unsigned* cellcand, const int* cellcnt, unsigned* cand, unsigned short* nodeof,
+                                             unsigned* levelkps, int* levelcnt, int* candcnt, int f, int l, unsigned char* base, long long* dbg, int* wtmp, int* shv) {
+    const int t = threadIdx.x;
+    const LevelGeom L = g->L[l];
+    int* scanA = reinterpret_cast<int*>(base + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)));
+    const long long cslot = (long long)f * g->totalCells + L.cellBase;
+    for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
+    __syncthreads();
+    const int M = block_excl_scan(scanA, L.nCells, wtmp);
+    if (t == 0) candcnt[f * g->nlevels + l] = M;
+    if (M == 0) {
+        if (t == 0) levelcnt[f * g->nlevels + l] = 0;
+        return;
+    }
+    QtArgs A = {g, cellcand, cellcnt, levelkps, levelcnt, f, l, M, dbg, cand + (long long)f * g->totalCandCap + L.candBase};
+    quadtree_body(A, base, wtmp, shv, cand + (long long)f * g->totalCandCap + L.candBase, nodeof + (long long)f * g->totalCandCap + L.candBase);
+}
+
 __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
                                                   const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
                                                   unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
-                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0, long long* dbg, int l0) {
+                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0, long long* dbg, int l0,
+                                                  unsigned char* __restrict__ qtnodes) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int wtmp[kQT / 64];
     __shared__ int shv[8];
@@ -1027,6 +1050,11 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
     // fill the gaps behind them -- with the levels of a frame dispatched together the last frames' level 0 was the tail
     const int l = blockIdx.y + l0, f = blockIdx.x + f0;   // the launch covers levels l0 .. l0 + gridDim.y - 1
     const LevelGeom L = g->L[l];
+    if (g->qtNodesGlobal) {   // node lists too large for LDS: the same algorithm over a global workspace (slower, never refused)
+        quadtree_global(g, cellcand, cellcnt, cand, nodeof, levelkps, levelcnt, candcnt, f, l, qtnodes + (long long)f * g->qtNodeFrameBytes + L.nodeOff,
+                        (dbg && f == f0) ? dbg : nullptr, wtmp, shv);
+        return;
+    }
     int* scanA = reinterpret_cast<int*>(smem + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)));
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
     for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
@@ -1576,6 +1604,7 @@ struct eao_orb {
     eao::DevBuf<uint8_t> d_pyr, d_blur, d_in;
     eao::DevBuf<unsigned> d_cellcand, d_cand, d_levelkps;
     eao::DevBuf<unsigned short> d_nodeof;
+    eao::DevBuf<unsigned char> d_qtnodes;   // global node lists (only when they do not fit in LDS)
     eao::DevBuf<int> d_cellcnt, d_levelcnt, d_candcnt, d_nout;
     eao::DevBuf<eao_keypoint> d_kps;
     eao::DevBuf<uint8_t> d_desc;
@@ -1763,7 +1792,17 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     g.fastLdsBytes = g.fastTileBytes + ((2 * g.fastMaxTested + 15) & ~15) + ((((maxSw - 4) * (maxSh - 4)) + 15) & ~15) + 64;
     // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
     h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (size_t)scanCap * sizeof(int);
-    EAO_REQUIRE(h->quadLds <= 150 * 1024, "nfeatures too large: quad-tree needs %zu bytes of LDS", h->quadLds);
+    g.qtNodesGlobal = 0; g.qtNodeFrameBytes = 0;
+    if (h->quadLds > 100 * 1024) {   // (thousands of features on one level: upstream takes any N, src/ORBextractor.cc:539)
+        g.qtNodesGlobal = 1;
+        long long noff = 0;
+        for (int l = 0; l < c.nlevels; l++) {
+            g.L[l].nodeOff = noff;
+            noff += (((long long)g.L[l].listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (long long)scanCap * sizeof(int)) + 255) & ~255LL;
+        }
+        g.qtNodeFrameBytes = noff;
+        h->quadLds = 0;
+    }
     // candidate keys (4 B) + node indices (2 B) in LDS while two workgroups still fit a CU
     h->quadLds = (h->quadLds + 15) & ~(size_t)15;
     g.qtKeysOff = (int)h->quadLds;
@@ -1775,6 +1814,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     const size_t kQtLdsCand = kQtLdsCandEnv ? kQtLdsCandEnv : std::min<size_t>(8192, std::max<size_t>(2048, ((size_t)h->cfg.nfeatures * 4 + 63) & ~(size_t)63));
     g.qtLdsCand = (int)std::min<size_t>(kQtLdsCand, h->quadLds < 76 * 1024 ? (76 * 1024 - h->quadLds) / 6 : 0) & ~7;
     h->quadLds += (size_t)g.qtLdsCand * 6;
+    if (g.qtNodesGlobal) { g.qtLdsCand = 0; h->quadLds = 0; }     // (everything in the global workspace)
     // the blur kernel hard-codes the taps; make sure the published construction gives them
     {
         float cf[7]; double sum = 0;
@@ -1788,7 +1828,14 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     { eao_status st = h->d_cells.reserve(h->cells.size()); if (st) return st; }
     EAO_HIP(hipMemcpyAsync(h->d_cells.p, h->cells.data(), h->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice, h->stream));
     EAO_HIP(hipStreamSynchronize(h->stream));
-    EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
+    {   // per-function, process-wide state: only ever raised (another handle with a larger nfeatures may be in use)
+        static std::atomic<int> cur{0};
+        int have = cur.load();
+        while ((int)h->quadLds > have) {
+            EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
+            if (cur.compare_exchange_weak(have, (int)h->quadLds)) break;
+        }
+    }
     h->geomValid = true;
     h->batchCap = 0;
     if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
@@ -1830,6 +1877,7 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
         RES(d_cellcnt, B * g.totalCells);
         RES(d_cand, B * (size_t)g.totalCandCap);
         RES(d_nodeof, B * (size_t)g.totalCandCap);
+        if (g.qtNodesGlobal) RES(d_qtnodes, B * (size_t)g.qtNodeFrameBytes);
         RES(d_levelkps, B * (size_t)g.totalKpCap);
         RES(d_levelcnt, B * g.nlevels);
         RES(d_candcnt, B * g.nlevels);
@@ -1902,7 +1950,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         auto quadtree = [&](hipStream_t str, int lFirst, int nLev) {
             hipLaunchKernelGGL(k_quadtree, dim3(nb, nLev), dim3(kQT), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
-                               h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst);
+                               h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst, h->d_qtnodes.p);
         };
         // Measured (device-resident step, ms): batch 1: 0.117 fused vs 0.142 chain, 8: 0.136 / 0.160, 32: 0.231 / 0.235, 64: 0.353 /
         // 0.309 -- small batches are bound by the chain of dependent launches, large ones by the VALU, where the fused kernel's
@@ -1975,7 +2023,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 // At 256 frames it is slower (1.258 vs 1.226 ms: 768 workgroups with 42 KB of LDS each take the occupancy FAST
                 // needs), so large batches keep all eight levels after FAST.  EAO_ORB_QT_EARLY=0 / 1 overrides.
                 if (qtEarly) hipLaunchKernelGGL(k_quadtree, dim3(nb, mid), dim3(kQT), h->quadLds, ss, h->d_geom.p, h->d_cellcand.p,
-                                   h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, 0);
+                                   h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, 0, h->d_qtnodes.p);
             }
         }
         if (early0) EAO_HIP(hipEventRecord(h->evFast0[i], ss));   // the side stream's share of FAST (and of the quad-trees)
@@ -2000,7 +2048,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
         hipLaunchKernelGGL(k_quadtree, dim3(nb, g.nlevels - (qtEarly ? mid : 0)), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
-                           h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, qtEarly ? mid : 0);
+                           h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, qtEarly ? mid : 0, h->d_qtnodes.p);
         // (the lower levels' quad-trees ran on the side stream, ahead of the blur: the wait for evJoin below covers them)
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));

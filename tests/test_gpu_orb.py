@@ -201,3 +201,15 @@ def test_device_api_unaligned_frames(gpu, oracle, w, h, pad, shift):
     for f in range(B):
         k0, d0 = orc.extract(frames[f])
         assert n[f] == len(k0) and np.array_equal(kps[f, :n[f]], k0) and np.array_equal(desc[f, :n[f]], d0), (f, w, h, pad, shift)
+
+
+@pytest.mark.parametrize("cfg", [(989, 353, 3000, 1.5, 2, 20, 3, 400, 1000), (714, 502, 3000, 2.0, 2, 50, 3, 40, 1000), (640, 480, 5000, 1.2, 3, 20, 7, 400, 1000)])
+def test_thousands_of_features_on_few_levels(gpu, oracle, cfg):
+    """Quotas whose quad-tree node lists do not fit in LDS (3000 features on two levels need 150+ KB): upstream's
+    DistributeOctTree takes any N (reference src/ORBextractor.cc:539) -- the same algorithm then runs over a global workspace."""
+    w, h, nfeat, sf, nlev, ini, mn, n_rect, n_small = cfg
+    img = synth.synth_frame(4242, w, h, n_rect, n_small)
+    k0, d0 = oracle.OrbOracle(nfeat, sf, nlev, ini, mn).extract(img)
+    k1, d1 = gpu.ORBextractor(nfeat, sf, nlev, ini, mn)(img)
+    assert len(k0) == len(k1) and len(k0) > 1000
+    assert np.array_equal(k0, k1) and np.array_equal(d0, d1)
