@@ -1,4 +1,7 @@
 // api_common.hip -- status/error plumbing and the device gate of the C-ABI (include/eao_fusion.h)
+#include <dlfcn.h>
+
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -46,6 +49,35 @@ eao_status require_device() {
     if (cached != EAO_OK) set_error("%s", cached_msg);
     return cached;
 }
+
+// roctx ranges around the stages of the hot path (SURVEY.md s5 "Tracing"): EAO_ROCTX=1 loads libroctx64 at the first range and
+// every later range shows up under `rocprofv3 --marker-trace`; without the variable a range is one predictable branch.
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)();
+roctx_push_t g_push = nullptr;
+roctx_pop_t g_pop = nullptr;
+bool roctx_ready() {
+    static std::once_flag once;
+    static bool on = false;
+    std::call_once(once, [] {
+        const char* e = getenv("EAO_ROCTX");
+        if (!e || !atoi(e)) return;
+        // rocprofv3 listens to the rocprofiler-sdk flavour of the library; roctracer's libroctx64 is the fallback (rocprof v1/v2)
+        void* lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        g_push = (roctx_push_t)dlsym(lib, "roctxRangePushA");
+        g_pop = (roctx_pop_t)dlsym(lib, "roctxRangePop");
+        on = g_push && g_pop;
+    });
+    return on;
+}
+}  // namespace
+void range_push(const char* name) { if (roctx_ready()) g_push(name); }
+void range_pop() { if (roctx_ready()) g_pop(); }
 
 }  // namespace eao
 

@@ -54,4 +54,14 @@ struct DevBuf {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// roctx range around a stage of the hot path (host side: the enqueue of its kernels); active only under EAO_ROCTX=1
+void range_push(const char* name);
+void range_pop();
+struct Range {
+    explicit Range(const char* name) { range_push(name); }
+    ~Range() { range_pop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
+
 }  // namespace eao

@@ -3055,6 +3055,7 @@ struct BALaunch {
     // trial freezes the rest of ITS window's work (halt flag + the takeover check of the outlier pass); the host then
     // continues that window from where the device stopped.
     void chain(int mode, int itsFirst, int itsSecond) {
+        eao::Range rg("lm: optimize x2 + outlier pass, enqueue");
         bulk(0, itsFirst, true);
         if (mode == 0) { classify(); bulk(0, itsSecond, true); }
         finish();
@@ -3067,7 +3068,7 @@ struct BAJob {
     int mode = 0, robust = 1; const eao_ba_planes* pl = nullptr; float* planes_out = nullptr;
     LMContext* c = nullptr; LMTraceHost* tr = nullptr;
     int nPo = 0, nPl = 0, Ept = 0, Epl = 0, nC = 0, nP = 0, E = 0;
-    bool hasPl = false, trivial = false, chained = false;
+    bool hasPl = false, trivial = false, chained = false, pollStop = false;
     BADev D; BADev* dW = nullptr;
     BALaunch L;
     int curHost = 0;
@@ -3081,6 +3082,7 @@ struct BAJob {
 
     // validation, arena, pinned mirror, upload (two copies on `s`), active structure.  No kernel is launched here.
     eao_status prepare(hipStream_t s) {
+        eao::Range rg("lm: window set-up + upload");
         EAO_REQUIRE(p && r && r->cam_Tcw && r->points && (p->n_edges == 0 || r->edge_outlier || mode == 1), "null argument");
         EAO_REQUIRE(p->n_cams > 0 && p->n_points >= 0 && p->n_edges >= 0, "bad sizes");
         if (pl && pl->n_planes <= 0) pl = nullptr;
@@ -3346,7 +3348,10 @@ struct BAJob {
         EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));
         L.W = dW; L.nz = 1; L.s = s; L.seq = c.status->seq;
         c.status->ph[0].touched = c.status->ph[1].touched = 0;
-        chained = E > 0 && (nF + nL) > 0;
+        // map-scale runs (tens of milliseconds) are NOT enqueued speculatively when the caller can abort them: optimize() then
+        // submits one LM iteration at a time and reads *stop in between, like g2o's forceStopFlag
+        pollStop = bigPath && stop != nullptr;
+        chained = E > 0 && (nF + nL) > 0 && !pollStop;
         return EAO_OK;
     }
 
@@ -3377,7 +3382,7 @@ struct BAJob {
                 // ---- bulk segment: every remaining iteration, one trial each.  The control block is clean at the start of
                 //      an optimize() call (zeros from the upload / reset by the outlier pass); after a takeover it is rewritten.
                 if (done > 0 && (st = set_ctl(0, done, nBad))) return st;
-                L.bulk(done, iterations, needErrors);
+                L.bulk(done, pollStop ? std::min(iterations, done + 1) : iterations, needErrors);
                 needErrors = false;
                 EAO_HIP(hipStreamSynchronize(L.s));
             }
@@ -3391,6 +3396,7 @@ struct BAJob {
             done = S.iters; nBad = S.nBad; curHost = S.cur; currentChi = S.chi;
             if (S.status == kStEmpty) { done = -1; break; }
             if (S.status == kStTerminate) { ok = false; break; }
+            if (S.status == kStRunning && done < iterations && pollStop) continue;   // next iteration (after a look at *stop)
             if (S.status != kStTakeover) break;           // all requested iterations done
             // ---- host takeover of iteration `done`: its first trial was rejected (or rho == 0 / NaN)
             tr->linearizations++;
@@ -3421,6 +3427,7 @@ struct BAJob {
     // After the chained enqueue (own or as part of a batch) has finished: takeovers, results.  The abort flag is read before
     // and after: a clean window takes less time than one g2o iteration on the CPU.
     eao_status complete() {
+        eao::Range rg("lm: takeovers + results");
         LMContext& c = *this->c;
         eao_status st;
         hipStream_t s = L.s;

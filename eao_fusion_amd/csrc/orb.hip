@@ -1892,6 +1892,7 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
 eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, int batch, eao_keypoint* d_kps,
                           uint8_t* d_desc, int cap, int* d_n, hipStream_t st, int lanes) {
     const Geom& g = h->geom;
+    eao::Range rAll("eao_orb_extract: enqueue");
     ImgSrc s;
     s.img0 = d_img; s.pitch0 = pitch0; s.fs0 = fs0; s.pyr = h->d_pyr.p;
     h->lastSrc = s; h->lastBatch = batch;
@@ -1925,6 +1926,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         const int cells0 = g.L[0].nCells;
         const bool early0 = !prof && g.nlevels > 1 && g.L[0].cellBase == 0 && cells0 < g.totalCells;
         auto fast = [&](hipStream_t str, int first, int end) {
+            eao::Range rg("orb: FAST cells");
             static const int envAff = getenv("EAO_FAST_AFFINITY") ? atoi(getenv("EAO_FAST_AFFINITY")) : 1;
             const int aff = envAff && (nb & 7) == 0 ? 1 : 0;
             const bool whole = first == 0 && end == g.totalCells, narrow = g.fastStride == 48;
@@ -1949,6 +1951,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         // word loads need a 4-byte aligned source whose rows can be read up to the next multiple of 4
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         auto quadtree = [&](hipStream_t str, int lFirst, int nLev) {
+            eao::Range rg("orb: quad-tree");
             hipLaunchKernelGGL(k_quadtree, dim3(nb, nLev), dim3(kQT), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
                                h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst, h->d_qtnodes.p);
         };
@@ -1964,12 +1967,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             // (profiled calls: every stage alone, one after the other)
             const dim3 pgrid(h->pyr.tilesX * h->pyr.tilesY, 1, nb);
             if (prof) {
-                hipLaunchKernelGGL(k_pyramid_fused, pgrid, dim3(kPyrThreads), h->pyrLds, ms, h->pyr, s, f0);
+                { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_pyramid_fused, pgrid, dim3(kPyrThreads), h->pyrLds, ms, h->pyr, s, f0); }
                 if (pe) EAO_HIP(hipEventRecord(ev[1], ms));
                 EAO_HIP(hipEventRecord(h->evFork[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
                 if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
-                hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
+                { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
                 if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
                 EAO_HIP(hipEventRecord(h->evJoin[i], ss));
                 EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
@@ -1983,17 +1986,17 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 EAO_HIP(hipStreamWaitEvent(ss, h->evStart, 0));
                 fast(ss, 0, cells0);
                 quadtree(ss, 0, 1);
-                hipLaunchKernelGGL(k_pyramid_fused, pgrid, dim3(kPyrThreads), h->pyrLds, ms, h->pyr, s, f0);
+                { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_pyramid_fused, pgrid, dim3(kPyrThreads), h->pyrLds, ms, h->pyr, s, f0); }
                 EAO_HIP(hipEventRecord(h->evFork[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
-                hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
+                { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
                 EAO_HIP(hipEventRecord(h->evJoin[i], ss));
                 fast(ms, cells0, g.totalCells);
                 quadtree(ms, 1, g.nlevels - 1);
                 EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
             }
-            hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
-                               h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels);
+            { eao::Range rg("orb: orientation + description"); hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
+                               h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels); }
             if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
             EAO_HIP(hipEventRecord(h->evDone[i], ms));
             EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
@@ -2012,7 +2015,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             ra.S = {g.L[l - 1].w, g.L[l - 1].h, g.L[l - 1].pitch, g.L[l - 1].off};
             ra.invX = 1. / ((double)g.L[l].w / g.L[l - 1].w); ra.invY = 1. / ((double)g.L[l].h / g.L[l - 1].h);
             ra.srcIsInput = l == 1; ra.pyrFrameBytes = g.pyrFrameBytes;
-            hipLaunchKernelGGL(k_resize, grid, block, 0, ms, ra, s, f0);
+            { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_resize, grid, block, 0, ms, ra, s, f0); }
             if (l == mid - 1) {
                 EAO_HIP(hipEventRecord(h->evMid[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evMid[i], 0));
@@ -2032,7 +2035,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             EAO_HIP(hipEventRecord(h->evFork[i], ms));
             EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
             if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
-            hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
+            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
             if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
             EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
@@ -2042,7 +2045,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             fast(ms, early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
             EAO_HIP(hipEventRecord(h->evFork[i], ms));            // the pyramid and the main stream's FAST are done
             EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
-            hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned);
+            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
             if (early0 && !qtEarly) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
         }
@@ -2053,8 +2056,8 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
         if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
-        hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
-                           h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels);
+        { eao::Range rg("orb: orientation + description"); hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
+                           h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels); }
         if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
         EAO_HIP(hipEventRecord(h->evDone[i], ms));
         EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));

@@ -406,6 +406,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     EAO_REQUIRE(h && d_kps && d_desc && d_n && Tcw_prior && out && out->kp_map_point && out->kp_outlier, "null argument");
     EAO_REQUIRE(!d_depth || (depth_pitch >= width && width > 0 && height > 0), "bad depth image geometry");
     EAO_REQUIRE(((uintptr_t)d_desc & 15) == 0, "descriptors must be 16-byte aligned");
+    eao::Range rg("track: frame -> frustum -> search -> pose");
     const eao_tracker_cfg& c = h->cfg;
     const int C = h->cap, nMp = h->nMp;
     hipStream_t s = h->stream;

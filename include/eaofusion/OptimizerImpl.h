@@ -173,6 +173,11 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
             if (kf->isBad()) continue;
             auto ci = camIndex.find(kf);
             if (ci == camIndex.end()) continue;   // upstream would dereference a null vertex here
+            // upstream copies the intrinsics into every edge from ITS keyframe (e->fx = pKFi->fx ..., src/Optimizer.cc:858-898); the
+            // C-ABI carries one set per window, which is what this fork's single-camera Frame / KeyFrame statics amount to --
+            // a window that mixes cameras is refused here rather than optimised with the wrong projection
+            if (kf->fx != fx || kf->fy != fy || kf->cx != cx || kf->cy != cy || kf->mbf != bf)
+                throw std::runtime_error("eaofusion::LocalBundleAdjustment: keyframes of the window do not share fx, fy, cx, cy, mbf");
             const cv::KeyPoint& kpUn = kf->mvKeysUn[ob.second];
             eCam.push_back(ci->second); ePt.push_back(ptIndex[mp]);
             obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(kf->mvuRight[ob.second]);

@@ -321,3 +321,15 @@ def test_local_ba_batch_stop_and_empty(gpu):
     for p, r in zip(probs, res):
         assert r["aborted"] and np.array_equal(r["points"], p["points"]) and not r["edge_outlier"].any()
     assert gpu.Optimizer.LocalBundleAdjustmentBatch([]) == []
+
+
+def test_map_scale_ba_with_an_abort_flag_that_is_never_raised(gpu):
+    """Map-scale runs poll *stop between LM iterations (one iteration per enqueue, like g2o's forceStopFlag) instead of
+    submitting the whole optimize() speculatively: an un-raised flag must not change a bit."""
+    p = synth.synth_ba(n_free=40, n_fixed=1, n_points=2500, seed=5400)
+    a = gpu.Optimizer.BundleAdjustment(p, 8, bRobust=True)
+    b = gpu.Optimizer.BundleAdjustment(p, 8, stop=np.zeros(1, np.uint8), bRobust=True)
+    assert list(a["iters"]) == list(b["iters"]) and np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"])
+    la = gpu.Optimizer.LocalBundleAdjustment(p)
+    lb = gpu.Optimizer.LocalBundleAdjustment(p, stop=np.zeros(1, np.uint8))
+    assert list(la["iters"]) == list(lb["iters"]) and np.array_equal(la["poses"], lb["poses"]) and np.array_equal(la["edge_outlier"], lb["edge_outlier"])
