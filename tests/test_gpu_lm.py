@@ -64,14 +64,16 @@ def test_local_ba_parity(gpu, oracle, kw):
     assert np.array_equal(r["poses"][f], o["poses"][f])
 
 
-@pytest.mark.parametrize("seed", [3030, 3031, 3034, 3035, 3043, 3044, 3046, 3049, 3051, 3052, 3054, 3057])
+@pytest.mark.parametrize("seed", [sd for sd in range(3030, 3060) if sd not in (3039, 3040, 3045)])
 def test_local_ba_rejected_trials(gpu, oracle, seed):
     """Far-off starts (25 degrees, 0.8 m, 1 m on the points): LM trials get rejected in the first and / or the second
     optimize() -- the stream freezes and the host replays the iteration trial by trial (up to the 10-trial limit) -- and
     in some windows every edge ends up an outlier, so the second optimize() has nothing to do (g2o returns -1).  Two fixed
     cameras keep the scale observable: with one, the damped system is singular along the gauge and no two
-    implementations agree on the step.  (Seeds whose first iterations are chaotic -- points flipping behind cameras, chi2
-    around 1e6 -- amplify rounding beyond any tolerance; 3040, 3045 and 3059 are such cases and are left out.)"""
+    implementations agree on the step.  All thirty seeds 3030..3059 of the family but three: on 3039, 3040 and 3045 the result
+    moves by 1.7e-3 / 3.7e-2 / 1.2e-3 of the update when the ORACLE's own inputs are perturbed by one float32 ulp (points
+    flipping behind cameras in the first iterations, chi2 around 1e6), and the GPU's distance to the oracle there (8.4e-4 /
+    1.2e-2 / 5.2e-4) is inside that band -- profiles/r02_lm_chaotic_seeds.txt, written by tools/lm_chaotic_seeds.py."""
     p = synth.synth_ba(n_free=5, n_fixed=2, n_points=200, seed=seed, rot_noise_deg=25, trans_noise=0.8, point_noise=1.0, mono_frac=0.7)
     r = gpu.Optimizer.LocalBundleAdjustment(p)
     o = oracle.local_ba(p)
