@@ -721,9 +721,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
 }
 
 // ---------------------------------------------------------------------------------------------- quad-tree
-constexpr int kQT = 256;   // threads per quad-tree workgroup (the candidate passes scale with it; 2 workgroups fit a CU)
+// Threads per quad-tree workgroup: a template parameter.  The candidate sweeps scale with it, the block scans and barriers get
+// dearer: 1024 threads are faster while the launch is latency-bound (one frame: device step 0.124 -> 0.105 ms, eight frames 0.143 ->
+// 0.129), 256 when many workgroups compete for the CUs (64 frames: 0.323 vs 0.339 ms).
+constexpr int kQTSmall = 1024, kQTLarge = 256;
 // In-place exclusive scan of a[0..n) by the whole kQT-thread block; returns the total.  Caller guarantees a[]
 // is fully written and visible (barrier) before the call; the function ends with a barrier.
+template <int kQT>
 __device__ int block_excl_scan(int* a, int n, int* wtmp) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int per = (n + kQT - 1) / kQT;
@@ -779,7 +783,7 @@ struct QtArgs {
 // The candidate keys and their node index live in LDS when the level's M candidates fit the launch's LDS budget
 // (g->qtLdsCand; always at the default 1000-feature settings), else in the global scratch arrays: the body is inlined
 // once per placement.
-template <class KeyPtr, class NofPtr>
+template <int kQT, class KeyPtr, class NofPtr>
 __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* smem, int* wtmp, int* shv, KeyPtr keys, NofPtr nof) {
     const Geom* __restrict__ g = A.g;
     int& sh_S = shv[0]; int& sh_phase = shv[1]; int& sh_done = shv[2]; int& sh_rstar = shv[3]; int& sh_nexp = shv[4];
@@ -873,7 +877,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
         }
         if (t == 0) { sh_rstar = 0x7FFFFFFF; sh_nexp = 0; }
         __syncthreads();
-        const int nCand = block_excl_scan(scanA, S, wtmp);
+        const int nCand = block_excl_scan<kQT>(scanA, S, wtmp);
         QSTAMP(1);
         for (int i = t; i < S; i += kQT)
             if (cnt[i] > 1) vlist[scanA[i]] = i;
@@ -926,7 +930,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
             scanA[r] = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
         }
         __syncthreads();
-        block_excl_scan(scanA, nCand, wtmp);
+        block_excl_scan<kQT>(scanA, nCand, wtmp);
         if (phase == 1) {
             for (int r = t; r < nCand; r += kQT) {
                 const int i = order[r];
@@ -946,7 +950,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
         __syncthreads();
         for (int i = t; i < S; i += kQT) scanB[i] = procRank[i] < 0 ? 1 : 0;
         __syncthreads();
-        block_excl_scan(scanB, S, wtmp);
+        block_excl_scan<kQT>(scanB, S, wtmp);
         QSTAMP(5);
         // (5) new list: children of the LAST processed node first (each as n4,n3,n2,n1), untouched entries after
         int myexp = 0;
@@ -1019,6 +1023,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
 #undef QSTAMP
 }
 
+template <int kQT>
 __device__ __noinline__ void quadtree_global(const Geom* __restrict__ g, const unsigned* cellcand, const int* cellcnt, unsigned* cand, unsigned short* nodeof,
                                              unsigned* levelkps, int* levelcnt, int* candcnt, int f, int l, unsigned char* base, long long* dbg, int* wtmp, int* shv) {
     const int t = threadIdx.x;
@@ -1027,16 +1032,17 @@ __device__ __noinline__ void quadtree_global(const Geom* __restrict__ g, const u
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
     for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
     __syncthreads();
-    const int M = block_excl_scan(scanA, L.nCells, wtmp);
+    const int M = block_excl_scan<kQT>(scanA, L.nCells, wtmp);
     if (t == 0) candcnt[f * g->nlevels + l] = M;
     if (M == 0) {
         if (t == 0) levelcnt[f * g->nlevels + l] = 0;
         return;
     }
     QtArgs A = {g, cellcand, cellcnt, levelkps, levelcnt, f, l, M, dbg, cand + (long long)f * g->totalCandCap + L.candBase};
-    quadtree_body(A, base, wtmp, shv, cand + (long long)f * g->totalCandCap + L.candBase, nodeof + (long long)f * g->totalCandCap + L.candBase);
+    quadtree_body<kQT>(A, base, wtmp, shv, cand + (long long)f * g->totalCandCap + L.candBase, nodeof + (long long)f * g->totalCandCap + L.candBase);
 }
 
+template <int kQT>
 __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
                                                   const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
                                                   unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
@@ -1051,7 +1057,7 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
     const int l = blockIdx.y + l0, f = blockIdx.x + f0;   // the launch covers levels l0 .. l0 + gridDim.y - 1
     const LevelGeom L = g->L[l];
     if (g->qtNodesGlobal) {   // node lists too large for LDS: the same algorithm over a global workspace (slower, never refused)
-        quadtree_global(g, cellcand, cellcnt, cand, nodeof, levelkps, levelcnt, candcnt, f, l, qtnodes + (long long)f * g->qtNodeFrameBytes + L.nodeOff,
+        quadtree_global<kQT>(g, cellcand, cellcnt, cand, nodeof, levelkps, levelcnt, candcnt, f, l, qtnodes + (long long)f * g->qtNodeFrameBytes + L.nodeOff,
                         (dbg && f == f0) ? dbg : nullptr, wtmp, shv);
         return;
     }
@@ -1059,7 +1065,7 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
     for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
     __syncthreads();
-    const int M = block_excl_scan(scanA, L.nCells, wtmp);
+    const int M = block_excl_scan<kQT>(scanA, L.nCells, wtmp);
     if (t == 0) candcnt[f * g->nlevels + l] = M;
     if (M == 0) {
         if (t == 0) levelcnt[f * g->nlevels + l] = 0;
@@ -1068,9 +1074,9 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
     QtArgs A = {g, cellcand, cellcnt, levelkps, levelcnt, f, l, M, (dbg && f == f0) ? dbg : nullptr, cand + (long long)f * g->totalCandCap + L.candBase};
     if (M <= g->qtLdsCand) {
         unsigned* keysL = reinterpret_cast<unsigned*>(smem + g->qtKeysOff);
-        quadtree_body(A, smem, wtmp, shv, keysL, reinterpret_cast<unsigned short*>(keysL + g->qtLdsCand));
+        quadtree_body<kQT>(A, smem, wtmp, shv, keysL, reinterpret_cast<unsigned short*>(keysL + g->qtLdsCand));
     } else {
-        quadtree_body(A, smem, wtmp, shv, cand + (long long)f * g->totalCandCap + L.candBase, nodeof + (long long)f * g->totalCandCap + L.candBase);
+        quadtree_body<kQT>(A, smem, wtmp, shv, cand + (long long)f * g->totalCandCap + L.candBase, nodeof + (long long)f * g->totalCandCap + L.candBase);
     }
 }
 
@@ -1832,7 +1838,8 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         static std::atomic<int> cur{0};
         int have = cur.load();
         while ((int)h->quadLds > have) {
-            EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
+            EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree<kQTSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
+            EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree<kQTLarge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
             if (cur.compare_exchange_weak(have, (int)h->quadLds)) break;
         }
     }
@@ -1952,7 +1959,9 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         auto quadtree = [&](hipStream_t str, int lFirst, int nLev) {
             eao::Range rg("orb: quad-tree");
-            hipLaunchKernelGGL(k_quadtree, dim3(nb, nLev), dim3(kQT), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
+            if (nb < 48) hipLaunchKernelGGL(k_quadtree<kQTSmall>, dim3(nb, nLev), dim3(kQTSmall), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
+                               h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst, h->d_qtnodes.p);
+            else hipLaunchKernelGGL(k_quadtree<kQTLarge>, dim3(nb, nLev), dim3(kQTLarge), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
                                h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst, h->d_qtnodes.p);
         };
         // Measured (device-resident step, ms): batch 1: 0.117 fused vs 0.142 chain, 8: 0.136 / 0.160, 32: 0.231 / 0.235, 64: 0.353 /
@@ -2025,8 +2034,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 // at these batches that is the long pole of the last-but-one segment (64 frames: 0.403 -> 0.390 ms per step).
                 // At 256 frames it is slower (1.258 vs 1.226 ms: 768 workgroups with 42 KB of LDS each take the occupancy FAST
                 // needs), so large batches keep all eight levels after FAST.  EAO_ORB_QT_EARLY=0 / 1 overrides.
-                if (qtEarly) hipLaunchKernelGGL(k_quadtree, dim3(nb, mid), dim3(kQT), h->quadLds, ss, h->d_geom.p, h->d_cellcand.p,
-                                   h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, 0, h->d_qtnodes.p);
+                if (qtEarly) quadtree(ss, 0, mid);
             }
         }
         if (early0) EAO_HIP(hipEventRecord(h->evFast0[i], ss));   // the side stream's share of FAST (and of the quad-trees)
@@ -2050,8 +2058,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             if (early0 && !qtEarly) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
         }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
-        hipLaunchKernelGGL(k_quadtree, dim3(nb, g.nlevels - (qtEarly ? mid : 0)), dim3(kQT), h->quadLds, ms, h->d_geom.p, h->d_cellcand.p,
-                           h->d_cellcnt.p, h->d_cand.p, h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, qtEarly ? mid : 0, h->d_qtnodes.p);
+        quadtree(ms, qtEarly ? mid : 0, g.nlevels - (qtEarly ? mid : 0));
         // (the lower levels' quad-trees ran on the side stream, ahead of the blur: the wait for evJoin below covers them)
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
