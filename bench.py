@@ -446,6 +446,19 @@ def measure_extra(E, synth, torch, dev):
     except Exception as ex:  # noqa: BLE001
         extra["ba_batch_error"] = repr(ex)
     try:
+        # PoseOptimization as a throughput: 256 frames (300 correspondences each) in ONE eao_pose_optimization_batch call
+        # (the Relocalization candidate loop / offline replays), host arrays in, host results out
+        pprobs = [synth.synth_pose(n=300, seed=7000 + k) for k in range(256)]
+        E.Optimizer.PoseOptimizationBatch(pprobs)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            E.Optimizer.PoseOptimizationBatch(pprobs)
+        dpb = (time.perf_counter() - t0) / 3
+        extra["pose_batch"] = {"workload": "256 x PoseOptimization (300 correspondences), ONE eao_pose_optimization_batch call",
+                               "ms_per_call": round(dpb * 1e3, 3), "us_per_frame": round(dpb * 1e6 / 256, 2), "frames_per_s": round(256 / dpb, 1)}
+    except Exception as ex:  # noqa: BLE001
+        extra["pose_batch_error"] = repr(ex)
+    try:
         p = synth.synth_ba()
         r = E.Optimizer.LocalBundleAdjustment(p)  # warm-up (allocations, code load)
         # timed AT THE C-ABI (the drop-in boundary): arguments prepared once, eao_local_ba called directly -- the Python mirror's

@@ -98,6 +98,7 @@ SYMBOLS = {
     "eao_distinctive_descriptors": (_I, [_I, _P, _P, _P]),
     "eao_compute_stereo_matches": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, C.c_float, C.c_float, _P, _P]),
     "eao_pose_optimization": (_I, [C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
+    "eao_pose_optimization_batch": (_I, [C.POINTER(PoseProblem), C.c_int32, C.POINTER(PoseResult)]),
     "eao_local_ba": (_I, [C.POINTER(BAProblem), _P, C.POINTER(BAResult)]),
     "eao_local_ba_batch": (_I, [C.POINTER(BAProblem), _I, _P, C.POINTER(BAResult)]),
     "eao_bundle_adjustment": (_I, [C.POINTER(BAProblem), _I, _P, C.POINTER(BAResult)]),

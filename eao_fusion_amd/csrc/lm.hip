@@ -428,7 +428,7 @@ __device__ inline double pose_edge_chi2(const PoseDev& P, int i, bool stereo) {
 // information, flags and the last computed residual (g2o's _error) never leave its registers, so the ~50 passes over the
 // edges of one PoseOptimization are free of memory latency (the memory variant spent a third of its time waiting on L2).
 template <int EPT>
-__global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
+__device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
     __shared__ double red[(kPoseThreads / 4) * 28];
     __shared__ double sums[8 * 28];
     __shared__ SE3 s_est, s_backup;
@@ -733,6 +733,13 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) {
     if (t < M) P.planeOutlier[t] = s_pout[t];
     if (t == 0) { *P.Tout = s_est; P.result[1] = s_iters; P.result[2] = s_ntrace; }
     if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
+}
+template <int EPT>
+__global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) { pose_lm_registers<EPT>(P); }
+// One workgroup per frame: eao_pose_optimization_batch (the record is read through scalar loads, never copied to registers).
+template <int EPT>
+__global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_batch(const PoseDev* __restrict__ W) {
+    pose_lm_registers<EPT>(W[blockIdx.x]);
 }
 
 // Generic variant: edges stay in global memory (frames with more than 4 * kPoseThreads correspondences).
@@ -2926,6 +2933,144 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     }
     g_trace.linearizations = res[1];
     EAO_HIP(hipEventElapsedTime(&g_trace.deviceMs, c.ev0, c.ev1));
+    return EAO_OK;
+}
+
+// Optimizer::PoseOptimization for `nb` frames at once -- the candidate loop of Tracking::Relocalization (src/Tracking.cc:2786-2940: every
+// candidate keyframe that passes PnP gets its own PoseOptimization) and offline replays.  One workgroup per frame, ONE upload,
+// ONE launch per register variant, ONE synchronisation; each frame's result is what eao_pose_optimization returns for it
+// (same kernel body, same reduction order).  Frames the one-workgroup register kernels do not take (more than
+// 4 * kPoseThreads correspondences) go through eao_pose_optimization one by one.
+eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, eao_pose_result* rs) {
+    EAO_REQUIRE(nb >= 0 && (nb == 0 || (ps && rs)), "bad batch");
+    if (nb == 0) return EAO_OK;
+    for (int b = 0; b < nb; b++) {
+        const eao_pose_problem* p = &ps[b];
+        const eao_pose_result* r = &rs[b];
+        EAO_REQUIRE(p->n >= 0 && p->Tcw && (p->n == 0 || (p->Xw && p->obs && p->inv_sigma2 && r->outlier)), "bad problem %d", b);
+        EAO_REQUIRE(p->n_planes >= 0 && p->n_planes <= kPoseMaxPlanes, "at most %d plane edges (problem %d has %d)", kPoseMaxPlanes, b, p->n_planes);
+        EAO_REQUIRE(p->n_planes == 0 || (p->plane_world && p->plane_obs && p->plane_seen && r->plane_outlier), "plane arrays missing (problem %d)", b);
+    }
+    LMContext& c = g_ctx;
+    eao_status st = ctx_init(c);
+    if (st) return st;
+    std::vector<int> grp[2], single;
+    for (int b = 0; b < nb; b++) {
+        const int n = ps[b].n;
+        for (int i = 0; i < n; i++) rs[b].outlier[i] = 0;
+        rs[b].lm_iterations = 0;
+        if (n < 3) { std::memcpy(rs[b].Tcw, ps[b].Tcw, 16 * sizeof(float)); rs[b].n_inliers = 0; }
+        else if (n > 4 * kPoseThreads) single.push_back(b);
+        else grp[n > 2 * kPoseThreads].push_back(b);
+    }
+    const int nk = (int)(grp[0].size() + grp[1].size());
+    if (nk) {
+        // arena: [records | per frame: Xw, obs, info, flags, planes] uploaded, then the per-frame residual scratch
+        struct Slot { int b; double *Xw, *obs, *info, *planes, *err; unsigned char* flags; size_t out; };
+        std::vector<Slot> slots;
+        size_t need = (size_t)nk * sizeof(PoseDev) + 512, outBytes = 0;
+        const size_t outFixed = ((sizeof(SE3) + 15) & ~(size_t)15) + 192 * 8 + 16 + kPoseMaxPlanes;
+        for (int g = 0; g < 2; g++)
+            for (int b : grp[g]) {
+                need += (size_t)ps[b].n * (3 + 3 + 1 + 3) * 8 + (size_t)ps[b].n + (size_t)kPoseMaxPlanes * 80 + 6 * 256;
+                outBytes += (outFixed + (size_t)ps[b].n + 63) & ~(size_t)63;
+            }
+        if ((st = c.bytes.reserve(need))) return st;
+        Arena a{c.bytes.p, c.bytes.n};
+        const size_t off0 = a.off;
+        PoseDev* dW = a.take<PoseDev>(nk);
+        for (int g = 0; g < 2; g++)
+            for (int b : grp[g]) {
+                Slot s{};
+                const int n = ps[b].n;
+                s.b = b;
+                s.Xw = a.take<double>((size_t)n * 3); s.obs = a.take<double>((size_t)n * 3); s.info = a.take<double>(n);
+                s.flags = a.take<unsigned char>(n); s.planes = a.take<double>((size_t)kPoseMaxPlanes * 10);
+                slots.push_back(s);
+            }
+        const size_t off1 = (a.off + 255) & ~(size_t)255;
+        for (Slot& s : slots) s.err = a.take<double>((size_t)ps[s.b].n * 3);
+        if (c.pinCap < off1) {
+            if (c.pin) (void)hipHostFree(c.pin);
+            c.pin = nullptr; c.pinCap = 0;
+            EAO_HIP(hipHostMalloc((void**)&c.pin, off1 + (off1 >> 2), hipHostMallocDefault));
+            c.pinCap = off1 + (off1 >> 2);
+        }
+        if (c.pinOutCap < outBytes) {
+            if (c.pinOut) (void)hipHostFree(c.pinOut);
+            c.pinOut = nullptr; c.pinOutCap = 0;
+            EAO_HIP(hipHostMalloc((void**)&c.pinOut, outBytes + (outBytes >> 2), hipHostMallocMapped));
+            c.pinOutCap = outBytes + (outBytes >> 2);
+        }
+        auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
+        PoseDev* hW = (PoseDev*)hostp(dW);
+        size_t oo = 0;
+        const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0;     // src/Optimizer.cc:464-465
+        for (size_t k = 0; k < slots.size(); k++) {
+            Slot& s = slots[k];
+            const eao_pose_problem* p = &ps[s.b];
+            const int n = p->n, M = p->n_planes;
+            s.out = oo;
+            oo += (outFixed + (size_t)n + 63) & ~(size_t)63;
+            unsigned char* o = c.pinOut + s.out;
+            double* otrace = (double*)(o + ((sizeof(SE3) + 15) & ~(size_t)15));
+            int* ores = (int*)(otrace + 192);
+            unsigned char* opl = (unsigned char*)(ores + 4);
+            std::memset(opl, 0, kPoseMaxPlanes + (size_t)n);
+            ores[0] = ores[1] = ores[2] = 0;
+            double* hX = (double*)hostp(s.Xw); double* hO = (double*)hostp(s.obs); double* hI = (double*)hostp(s.info);
+            unsigned char* hF = (unsigned char*)hostp(s.flags);
+            for (int i = 0; i < n; i++) {
+                for (int d = 0; d < 3; d++) { hX[3 * i + d] = p->Xw[3 * i + d]; hO[3 * i + d] = p->obs[3 * i + d]; }
+                hI[i] = p->inv_sigma2[i];
+                hF[i] = (unsigned char)((!(p->obs[3 * i + 2] < 0) ? 1 : 0) | 4);
+            }
+            double* hP = (double*)hostp(s.planes);
+            for (int i = 0; i < M; i++) {
+                plane_from_f32(p->plane_world + 4 * i, hP + 10 * i);
+                plane_from_f32(p->plane_obs + 4 * i, hP + 10 * i + 4);
+                const double f = p->plane_seen[i] ? 1.0 : 2.0;
+                hP[10 * i + 8] = f * angleInfo; hP[10 * i + 9] = f * disInfo;
+            }
+            PoseDev& P = hW[k];
+            std::memset((void*)&P, 0, sizeof(PoseDev));
+            P.nDev = nullptr;
+            P.n = n; P.Xw = s.Xw; P.obs = s.obs; P.info = s.info; P.err = s.err; P.flags = s.flags; P.outlier = opl + kPoseMaxPlanes;
+            P.T0 = se3_from_Tcw_f32(p->Tcw);
+            P.cam.fx = p->fx; P.cam.fy = p->fy; P.cam.cx = p->cx; P.cam.cy = p->cy; P.cam.bf = p->bf; P.cam.bf_f = p->bf;
+            P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
+            P.Tout = (SE3*)o; P.result = ores; P.trace = otrace;
+            P.nPlanes = M; P.planes = s.planes; P.planeOutlier = opl; P.deltaPlane = (float)std::sqrt(300.0);
+            P.dbg = nullptr;
+        }
+        g_trace.clear();
+        EAO_HIP(hipEventRecord(c.ev0, c.stream));
+        EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
+        if (!grp[0].empty())
+            hipLaunchKernelGGL(k_pose_optimization_batch<2>, dim3((unsigned)grp[0].size()), dim3(kPoseThreads), 0, c.stream, dW);
+        if (!grp[1].empty())
+            hipLaunchKernelGGL(k_pose_optimization_batch<4>, dim3((unsigned)grp[1].size()), dim3(kPoseThreads), 0, c.stream, dW + grp[0].size());
+        EAO_HIP(hipEventRecord(c.ev1, c.stream));
+        EAO_HIP(hipStreamSynchronize(c.stream));
+        EAO_HIP(hipGetLastError());
+        for (const Slot& s : slots) {
+            const eao_pose_problem* p = &ps[s.b];
+            eao_pose_result* r = &rs[s.b];
+            const unsigned char* o = c.pinOut + s.out;
+            const SE3 Tout = *(const SE3*)o;
+            const double* otrace = (const double*)(o + ((sizeof(SE3) + 15) & ~(size_t)15));
+            const int* ores = (const int*)(otrace + 192);
+            const unsigned char* opl = (const unsigned char*)(ores + 4);
+            std::memcpy(r->outlier, opl + kPoseMaxPlanes, p->n);
+            if (p->n_planes) std::memcpy(r->plane_outlier, opl, p->n_planes);
+            se3_to_Tcw_f32(Tout, r->Tcw);
+            r->n_inliers = p->n + p->n_planes - ores[0];
+            r->lm_iterations = ores[1];
+        }
+        EAO_HIP(hipEventElapsedTime(&g_trace.deviceMs, c.ev0, c.ev1));
+    }
+    for (int b : single)
+        if ((st = eao_pose_optimization(&ps[b], &rs[b]))) return st;
     return EAO_OK;
 }
 

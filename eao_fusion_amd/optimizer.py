@@ -56,6 +56,43 @@ class Optimizer:
         return out
 
     @staticmethod
+    def PoseOptimizationBatch(probs):
+        """One PoseOptimization per element of `probs` (the candidate loop of Tracking::Relocalization, src/Tracking.cc:2786-2940)
+        in a single eao_pose_optimization_batch call.  Returns a list of the dicts PoseOptimization returns."""
+        nb = len(probs)
+        Ps = (_lib.PoseProblem * max(nb, 1))()
+        Rs = (_lib.PoseResult * max(nb, 1))()
+        keep = []
+        for b, prob in enumerate(probs):
+            Tcw = np.ascontiguousarray(prob["Tcw"], np.float32)
+            Xw = np.ascontiguousarray(prob["points"], np.float32)
+            obs = np.ascontiguousarray(prob["obs"], np.float32)
+            inv = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+            n = len(Xw)
+            pw = prob.get("plane_world")
+            m = 0 if pw is None else len(pw)
+            pw = None if pw is None else np.ascontiguousarray(pw, np.float32)
+            po = None if pw is None else np.ascontiguousarray(prob["plane_obs"], np.float32)
+            ps = None if pw is None else np.ascontiguousarray(prob["plane_seen"], np.uint8)
+            outl = np.zeros(max(n, 1), np.uint8)
+            pout = np.zeros(max(m, 1), np.uint8)
+            Ps[b] = _lib.PoseProblem(n, _lib.ptr(Tcw), _lib.ptr(Xw), _lib.ptr(obs), _lib.ptr(inv), prob["fx"], prob["fy"],
+                                     prob["cx"], prob["cy"], prob["bf"], m, _lib.ptr(pw), _lib.ptr(po), _lib.ptr(ps))
+            Rs[b].outlier = _lib.ptr(outl)
+            Rs[b].plane_outlier = _lib.ptr(pout)
+            keep.append((Tcw, Xw, obs, inv, pw, po, ps, outl, pout, n, m))
+        _lib.check(_lib.load().eao_pose_optimization_batch(Ps, nb, Rs))
+        outs = []
+        for b in range(nb):
+            outl, pout, n, m = keep[b][7:]
+            out = dict(Tcw=np.array(Rs[b].Tcw, np.float32).reshape(4, 4), outlier=outl[:n], n_inliers=Rs[b].n_inliers,
+                       lm_iterations=Rs[b].lm_iterations)
+            if m:
+                out["plane_outlier"] = pout[:m]
+            outs.append(out)
+        return outs
+
+    @staticmethod
     def LocalBundleAdjustment(prob, stop=None, its=(5, 10), gba=None):
         """prob: poses (n_cams,4,4) f32, fixed (n_cams,) u8, points (n_points,3) f32, edge_cam, edge_point (E,) i32,
         obs (E,3) f32, inv_sigma2 (E,) f32, fx..bf.  stop: optional np.uint8[1] polled between LM iterations."""

@@ -358,6 +358,13 @@ typedef struct {
 
 eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r);
 
+/* `n` independent PoseOptimization problems in one call: the candidate loop of Tracking::Relocalization
+ * (reference src/Tracking.cc:2786-2940: the first Optimizer::PoseOptimization (:2885) of every candidate keyframe whose PnP converged)
+ * and offline replays.  One workgroup per frame, one upload, one launch, one synchronisation; results[i] is
+ * bit-identical to what eao_pose_optimization(&problems[i], &results[i]) returns.  Frames with more than 2048
+ * correspondences are run one by one through that entry point. */
+eao_status eao_pose_optimization_batch(const eao_pose_problem* problems, int32_t n, eao_pose_result* results);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*) -- reference include/Optimizer.h:55,
  * src/Optimizer.cc:675-1138.  The adapter flattens the local window: cameras in ascending KeyFrame::mnId

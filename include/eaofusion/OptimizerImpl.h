@@ -67,11 +67,21 @@ template <class FrameT>
 typename std::enable_if<!has_planes<FrameT>::value>::type store_planes(FrameT*, const PlaneEdges&, const std::vector<uint8_t>&) {}
 
 // ---- Optimizer::PoseOptimization(Frame*) --------------------------------------------------------------------
-template <class MapPointT, class FrameT>
-int PoseOptimization(FrameT* pFrame) {
-    const int N = pFrame->N;
+// The flattened problem of one frame and what is needed to write its result back.
+struct PoseJob {
     std::vector<int> slot;            // frame index of every correspondence, ascending
     std::vector<float> Xw, obs, inv;
+    float T[16];
+    PlaneEdges pe;
+    std::vector<uint8_t> outl, pout;
+    eao_pose_problem P;
+    eao_pose_result R;
+    int n = 0;
+};
+// src/Optimizer.cc:349-453 (vertices and edges) -- returns false when upstream would return 0 without optimising
+template <class MapPointT, class FrameT>
+bool gather_pose(FrameT* pFrame, PoseJob& j) {
+    const int N = pFrame->N;
     {
         std::unique_lock<std::mutex> lock(MapPointT::mGlobalMutex);
         for (int i = 0; i < N; i++) {
@@ -80,33 +90,63 @@ int PoseOptimization(FrameT* pFrame) {
             pFrame->mvbOutlier[i] = false;
             const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
             const cv::Mat P = pMP->GetWorldPos();
-            slot.push_back(i);
-            Xw.push_back(P.template at<float>(0)); Xw.push_back(P.template at<float>(1)); Xw.push_back(P.template at<float>(2));
-            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(pFrame->mvuRight[i]);   // < 0 => monocular edge
-            inv.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
+            j.slot.push_back(i);
+            j.Xw.push_back(P.template at<float>(0)); j.Xw.push_back(P.template at<float>(1)); j.Xw.push_back(P.template at<float>(2));
+            j.obs.push_back(kpUn.pt.x); j.obs.push_back(kpUn.pt.y); j.obs.push_back(pFrame->mvuRight[i]);   // < 0 => monocular edge
+            j.inv.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
         }
     }
-    const int n = (int)slot.size();
-    if (n < 3) return 0;   // pose untouched, as upstream
+    j.n = (int)j.slot.size();
+    if (j.n < 3) return false;   // pose untouched, as upstream
     cv::Mat Tcw = pFrame->mTcw;
-    float T[16];
-    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[r * 4 + c] = Tcw.template at<float>(r, c);
-    PlaneEdges pe;                    // added after the "< 3 correspondences" test, as upstream (:453-456)
-    collect_planes(pFrame, pe);
-    const int M = (int)pe.slot.size();
-    eao_pose_problem P = {n, T, Xw.data(), obs.data(), inv.data(), pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf,
-                          M, pe.world.data(), pe.obs.data(), pe.seen.data()};
-    std::vector<uint8_t> outl(n), pout(M ? M : 1);
-    eao_pose_result R;
-    R.outlier = outl.data();
-    R.plane_outlier = pout.data();
-    check(eao_pose_optimization(&P, &R), "eao_pose_optimization");
-    for (int k = 0; k < n; k++) pFrame->mvbOutlier[slot[k]] = outl[k] != 0;
-    store_planes(pFrame, pe, pout);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) j.T[r * 4 + c] = Tcw.template at<float>(r, c);
+    collect_planes(pFrame, j.pe);     // added after the "< 3 correspondences" test, as upstream (:453-456)
+    const int M = (int)j.pe.slot.size();
+    j.P = eao_pose_problem{j.n, j.T, j.Xw.data(), j.obs.data(), j.inv.data(), pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf,
+                           M, j.pe.world.data(), j.pe.obs.data(), j.pe.seen.data()};
+    j.outl.assign(j.n, 0);
+    j.pout.assign(M ? M : 1, 0);
+    j.R.outlier = j.outl.data();
+    j.R.plane_outlier = j.pout.data();
+    return true;
+}
+// src/Optimizer.cc:660-672 (outlier flags were written round by round upstream; the last round's are what remains)
+template <class FrameT>
+int store_pose(FrameT* pFrame, const PoseJob& j) {
+    for (int k = 0; k < j.n; k++) pFrame->mvbOutlier[j.slot[k]] = j.outl[k] != 0;
+    store_planes(pFrame, j.pe, j.pout);
     cv::Mat pose(4, 4, CV_32F);
-    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[r * 4 + c];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = j.R.Tcw[r * 4 + c];
     pFrame->SetPose(pose);
-    return R.n_inliers;
+    return j.R.n_inliers;
+}
+
+template <class MapPointT, class FrameT>
+int PoseOptimization(FrameT* pFrame) {
+    PoseJob j;
+    if (!gather_pose<MapPointT>(pFrame, j)) return 0;
+    check(eao_pose_optimization(&j.P, &j.R), "eao_pose_optimization");
+    return store_pose(pFrame, j);
+}
+
+// Several frames at once: the candidate loop of Tracking::Relocalization (src/Tracking.cc:2786-2940) keeps one Frame copy per
+// candidate keyframe and calls this once instead of PoseOptimization per candidate.  Element k of the result is what
+// PoseOptimization(frames[k]) returns; every frame is written back exactly as by that call.
+template <class MapPointT, class FrameT>
+std::vector<int> PoseOptimizationBatch(const std::vector<FrameT*>& frames) {
+    std::vector<PoseJob> jobs(frames.size());
+    std::vector<int> live, ret(frames.size(), 0);
+    for (size_t k = 0; k < frames.size(); k++)
+        if (gather_pose<MapPointT>(frames[k], jobs[k])) live.push_back((int)k);
+    std::vector<eao_pose_problem> P(live.size());
+    std::vector<eao_pose_result> R(live.size());
+    for (size_t q = 0; q < live.size(); q++) { P[q] = jobs[live[q]].P; R[q] = jobs[live[q]].R; }
+    check(eao_pose_optimization_batch(P.data(), (int32_t)live.size(), R.data()), "eao_pose_optimization_batch");
+    for (size_t q = 0; q < live.size(); q++) {
+        jobs[live[q]].R = R[q];
+        ret[live[q]] = store_pose(frames[live[q]], jobs[live[q]]);
+    }
+    return ret;
 }
 
 // ---- Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*) ------------------------------------------------

@@ -187,7 +187,19 @@ int main(int argc, char** argv) {
         F.mvpMapPlanes[i + 1] = &planes[i];
         F.mvPlaneCoefficients[i + 1] = c;
     }
+    Frame Fa = F, Fb = F;              // two more candidates with the same correspondences: PoseOptimizationBatch (Relocalization)
+    Fa.mTcw = F.mTcw.clone(); Fb.mTcw = F.mTcw.clone();
     int32_t inliers = eaofusion::PoseOptimization<MapPoint>(&F);
+    {
+        std::vector<Frame*> cands = {&Fa, &Fb};
+        const std::vector<int> got = eaofusion::PoseOptimizationBatch<MapPoint>(cands);
+        for (int q = 0; q < 2; q++) {
+            const Frame& G = *cands[q];
+            bool same = got[q] == inliers && G.mvbOutlier == F.mvbOutlier && G.mvbPlaneOutlier == F.mvbPlaneOutlier;
+            for (int k = 0; k < 16; k++) same = same && G.mTcw.ptr<float>(0)[k] == F.mTcw.ptr<float>(0)[k];
+            if (!same) { std::fprintf(stderr, "PoseOptimizationBatch: candidate %d differs from PoseOptimization\n", q); return 3; }
+        }
+    }
     wr(out, &inliers, 1);
     std::vector<uint8_t> pfl(m + 1);
     for (int i = 0; i <= m; i++) pfl[i] = F.mvbPlaneOutlier[i];

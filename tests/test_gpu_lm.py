@@ -147,6 +147,39 @@ def test_pose_optimization_with_planes(gpu, oracle, kw):
         assert r["plane_outlier"][-1] == 1 and r["plane_outlier"][:-1].sum() == 0
 
 
+def test_pose_optimization_batch_equals_single_calls(gpu):
+    """eao_pose_optimization_batch (one workgroup per frame -- the candidate loop of Tracking::Relocalization,
+    src/Tracking.cc:2786-2940): every frame's pose, outlier tables and return value are BIT-identical to its own
+    eao_pose_optimization call, whatever the batch's mix (2 / 4 register edges per thread, planes, mono-only, the
+    < 3 correspondences early-out, and a frame beyond 2048 correspondences that the batch hands to the single path)."""
+    kws = [dict(), dict(n=300, sigma=0.0, outlier_frac=0.0), dict(n=50, seed=4001, mono_frac=1.0), dict(n=2000, seed=4002, mono_frac=0.0),
+           dict(n=8, seed=4003), dict(n=1024, seed=4004), dict(n=1025, seed=4005), dict(n=2, seed=4007), dict(n=2600, seed=4006),
+           dict(n=300, seed=4200, n_planes=6), dict(n=1500, seed=4202, n_planes=32), dict(n=40, seed=4203, n_planes=1, mono_frac=1.0)]
+    kws += [dict(n=200 + 37 * k, seed=4300 + k) for k in range(20)]
+    probs = [synth.synth_pose(**kw) for kw in kws]
+    singles = [gpu.Optimizer.PoseOptimization(p) for p in probs]
+    for order in (list(range(len(probs))), list(reversed(range(len(probs))))):
+        outs = gpu.Optimizer.PoseOptimizationBatch([probs[i] for i in order])
+        for o, i in zip(outs, order):
+            s = singles[i]
+            assert o["n_inliers"] == s["n_inliers"] and o["lm_iterations"] == s["lm_iterations"], kws[i]
+            assert np.array_equal(o["outlier"], s["outlier"]), kws[i]
+            assert np.array_equal(o["Tcw"].view(np.uint32), s["Tcw"].view(np.uint32)), kws[i]
+            if "plane_outlier" in s:
+                assert np.array_equal(o["plane_outlier"], s["plane_outlier"])
+    assert gpu.Optimizer.PoseOptimizationBatch([]) == []
+
+
+def test_pose_optimization_batch_parity(gpu, oracle):
+    """The batch against the fp64 oracle directly (same bar as the single call)."""
+    probs = [synth.synth_pose(n=150 + 61 * k, seed=4400 + k, mono_frac=0.1 * (k % 5)) for k in range(12)]
+    outs = gpu.Optimizer.PoseOptimizationBatch(probs)
+    for p, r in zip(probs, outs):
+        o = oracle.pose_optimization(p)
+        assert r["n_inliers"] == o["n_inliers"] and np.array_equal(r["outlier"], o["outlier"])
+        _check_updates(r["Tcw"], o["Tcw"], p["Tcw"], "Tcw")
+
+
 def test_pose_optimization_too_few_points(gpu):
     p = synth.synth_pose(n=2)
     r = gpu.Optimizer.PoseOptimization(p)
