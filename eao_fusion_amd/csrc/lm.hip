@@ -997,14 +997,15 @@ struct BADev {
 // over the 8 XCDs in dispatch order, so with the plain (x = block, z = window) numbering the ~5 MB a window keeps re-reading
 // (Hpl blocks, residuals, the edge table) would be pulled into all eight L2s -- 25 windows are then fabric-bound (the pair
 // assembly alone moved 350 MB per launch).  Window w is served by XCD w % 8 only; the launch pads grid.z to a multiple of 8.
-// wpar = block pair | number of windows << 8;  bx = this workgroup's block index inside its window.
+// wpar = block pair | rot << 4 | number of windows << 8 (rot: XCD of the group's first window -- the groups of a batch run
+// concurrently and together should load the XCDs evenly);  bx = this workgroup's block index inside its window.
 #define BA_WIN(P)                                                                                                   \
     unsigned bx = blockIdx.x, wz_ = blockIdx.z; (void)bx;                                                                  \
     {                                                                                                               \
         const unsigned nz_ = (unsigned)wpar >> 8;                                                                   \
         if (nz_ > 1) {                                                                                              \
             const unsigned b_ = blockIdx.x + gridDim.x * blockIdx.z, s_ = b_ >> 3;                                  \
-            wz_ = (b_ & 7) + 8 * (s_ / gridDim.x);                                                                  \
+            wz_ = ((b_ - ((unsigned)wpar >> 4)) & 7) + 8 * (s_ / gridDim.x);      /* XCD x serves window (x - rot) mod 8 */  \
             bx = s_ % gridDim.x;                                                                                    \
             if (wz_ >= nz_) return;                                                                                 \
         }                                                                                                           \
@@ -1930,7 +1931,10 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(const BADev* __
 //     (thread t < NT / 2 accumulates rows 0..2 of the pair's 6x6 block and of its right-hand side, thread t + NT / 2 rows
 //     3..5: 21 accumulators, 128 VGPRs) in 256-thread workgroups, four of which fit a CU instead of two.  Measured, 25
 //     windows per launch: (a) 152 us, (a) with 256 threads 106 us, two threads per landmark in 512-thread workgroups 112 us,
-//     this 58 us; staging the operands through LDS with cooperative loads 156 us, pinning windows to XCDs no change.
+//     this 58 us; staging the operands through LDS with cooperative loads 156 us, pinning windows to XCDs no change; eight
+//     lanes per landmark (lane r owns row r: a wave load touches 8 cache lines instead of 64, but three times the load
+//     instructions) +12 us.  With the loop body removed the launch costs 19 us (5 250 workgroups: prologue, reduction, stores),
+//     with the index loads only the same -- the time is the 30 scattered 16-byte loads per landmark-thread.
 constexpr int kPairThreadsB = 256;
 __global__ __launch_bounds__(kPairThreadsB, 4) void k_ba_schur_pairs_b(const BADev* __restrict__ W, int wpar, int first) {
     BA_WIN(P);
@@ -3127,7 +3131,8 @@ struct BALaunch {
         if (d.bigPath) { if ((st = raise((const void*)k_bal_backsolve, aBack, (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double)))) return st; }
         return EAO_OK;
     }
-    int wp(int par) const { return par | (nz > 1 ? nz << 8 : 0); }      // kernel argument: block pair | windows << 8 (BA_WIN)
+    int rot = 0;               // XCD of window 0 (BA_WIN)
+    int wp(int par) const { return par | (nz > 1 ? (rot & 7) << 4 | nz << 8 : 0); }      // kernel argument (BA_WIN)
     unsigned gz() const { return nz > 1 ? (unsigned)((nz + 7) & ~7) : 1u; }   // windows are dealt to the XCDs: grid.z padded to 8
     int ptBlocks() const { return eao::cdiv(std::max(d.nL, 1) * 8, 256); }       // eight lanes per landmark
     int linBlocks() const { return eao::cdiv(std::max(d.nL, 1) * 8, kLinThreads); }
@@ -3654,16 +3659,21 @@ struct BABatchPool {
     std::vector<LMTraceHost> trace;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipStream_t> side;              // streams of the window groups beyond the first
+    std::vector<hipEvent_t> sideDone;
     BADev* hW = nullptr; size_t hWCap = 0;      // pinned mirror of the window array
     eao::DevBuf<BADev> dW;
     ~BABatchPool() {
         if (hW) (void)hipHostFree(hW);
+        for (hipEvent_t e : sideDone) (void)hipEventDestroy(e);
+        for (hipStream_t q : side) (void)hipStreamDestroy(q);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
 thread_local BABatchPool g_batch;
+constexpr int kBatchGroups = 4, kBatchGroupMin = 4;     // default number of window groups / fewest windows worth a group
 }  // namespace
 
 extern "C" {
@@ -3703,78 +3713,133 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     const auto tp0 = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     EAO_HIP(hipEventRecord(B.ev0, B.stream));
-    // ---- host-side set-up of the windows (validation, pinned mirror, active structure, two uploads each) on a few host
-    //      threads: it is ~0.1 ms of memcpy and counting per window, which would otherwise be most of the call
+    // ---- The windows are dealt to G groups (contiguous ranges).  A group is a chain of its own on its own stream: its
+    //      host-side set-up (validation, pinned mirror, active structure, two uploads per window: ~0.1 ms of memcpy and
+    //      counting each, on a few host threads), then ONE batched enqueue for its windows.  The first group's kernels start
+    //      while the others are still being set up, and a group's one-workgroup-per-window solver (a tenth of the chip) and
+    //      the tails of its other launches overlap the other groups' wide kernels.  More than four streams share hardware
+    //      queues on this runtime and serialise (measured: 5+ groups are 40 % slower than one).
     static const int envThreads = getenv("EAO_BA_BATCH_THREADS") ? atoi(getenv("EAO_BA_BATCH_THREADS")) : 0;
+    static const int envGroups = getenv("EAO_BA_BATCH_GROUPS") ? atoi(getenv("EAO_BA_BATCH_GROUPS")) : 0;
     const int hw = (int)std::thread::hardware_concurrency();
     const int nThreads = std::max(1, std::min(n, envThreads > 0 ? envThreads : std::min(8, std::max(1, hw / 2))));
-    std::vector<eao_status> stw(n, EAO_OK);
-    std::vector<std::string> errw(n);
+    const int G = std::max(1, std::min(std::min(envGroups > 0 ? envGroups : kBatchGroups, nThreads), n / kBatchGroupMin));
+    while ((int)B.side.size() < G - 1) {
+        hipStream_t q; hipEvent_t e;
+        EAO_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        EAO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        B.side.push_back(q); B.sideDone.push_back(e);
+    }
+    std::vector<eao_status> stw(n, EAO_OK), stg(G, EAO_OK);
+    std::vector<std::string> errw(n), errg(G);
+    std::vector<BALaunch> LG(G);
+    std::vector<int> groupOf(n, -1), nInGroup(G, 0);
+    std::vector<char> batched(n, 0);
+    std::vector<double> msPrep(G, 0.0), msEnq(G, 0.0), msDone(G, 0.0);
     int dev = 0;
     EAO_HIP(hipGetDevice(&dev));
-    auto work = [&](int t) {
-        if (t > 0) (void)hipSetDevice(dev);
+    // set-up: nThreads workers take the windows in order (window w's uploads go to its group's stream), so the first
+    // group is complete after one round; each group's leader then enqueues its chain while the workers carry on
+    std::vector<std::atomic<int>> prepared(G);
+    for (auto& a : prepared) a.store(0);
+    auto groupOfWindow = [&](int w) { int g = (int)(((long long)w * G) / n); while ((long long)n * (g + 1) / G <= w) g++; while ((long long)n * g / G > w) g--; return g; };
+    auto streamOf = [&](int g) { return g == 0 ? B.stream : B.side[g - 1]; };
+    auto worker = [&](int t) {
+        (void)hipSetDevice(dev);
         for (int w = t; w < n; w += nThreads) {
-            stw[w] = jobs[w].prepare(B.stream);
+            const int g = groupOfWindow(w);
+            stw[w] = jobs[w].prepare(streamOf(g));
             if (stw[w]) errw[w] = eao_last_error();
+            prepared[g].fetch_add(1, std::memory_order_release);
         }
     };
-    if (nThreads == 1) work(0);
-    else {
+    auto groupWork = [&](int g) {
+        (void)hipSetDevice(dev);
+        const int w0 = (int)((long long)n * g / G), w1 = (int)((long long)n * (g + 1) / G);
+        hipStream_t sg = streamOf(g);
+        while (prepared[g].load(std::memory_order_acquire) < w1 - w0) std::this_thread::yield();    // (the workers above)
+        msPrep[g] = since(tp0);
+        for (int w = w0; w < w1; w++)
+            if (stw[w]) return;
+        // the windows that share the batched enqueue (tile-solver path, something to optimise); the others -- windows beyond
+        // 30 free keyframes, empty ones -- follow one by one on the same stream
+        BALaunch& L = LG[g];
+        L.s = sg; L.W = B.dW.p + 2 * w0; L.seq = 0; L.rot = w0 & 7;
+        int first = -1, cnt = 0;
+        for (int w = w0; w < w1; w++) {
+            BAJob& j = jobs[w];
+            if (!j.batchable()) continue;
+            if (first >= 0 && (j.p->its_first != jobs[first].p->its_first || j.p->its_second != jobs[first].p->its_second)) continue;
+            if (first < 0) { first = w; L.d = j.L.d; } else L.d.merge(j.L.d);
+            j.write_records(B.hW + 2 * (w0 + cnt));
+            cnt++;
+            groupOf[w] = g; batched[w] = 1;
+        }
+        nInGroup[g] = cnt;
+        auto fail = [&](eao_status e) { stg[g] = e; errg[g] = eao_last_error(); };
+        if (cnt) {
+            L.nz = cnt;
+            if (hipMemcpyAsync(B.dW.p + 2 * w0, B.hW + 2 * w0, (size_t)cnt * 2 * sizeof(BADev), hipMemcpyHostToDevice, sg) != hipSuccess) {
+                eao::set_error("hipMemcpyAsync of the window records failed");
+                return fail(EAO_ERR_NO_DEVICE);
+            }
+            eao_status e = L.attributes();
+            if (e) return fail(e);
+            L.setup();
+            L.chain(0, jobs[first].p->its_first, jobs[first].p->its_second);
+        }
+        for (int w = w0; w < w1; w++) {
+            BAJob& j = jobs[w];
+            if (batched[w] || j.trivial) continue;
+            eao_status e = j.L.attributes();
+            if (e) return fail(e);
+            j.L.setup();
+            if (j.chained) j.L.chain(0, j.p->its_first, j.p->its_second);
+        }
+        msEnq[g] = since(tp0);
+        // results (and, for a window whose device-side run handed over to the host, the rest of its run) as soon as THIS
+        // group's stream has drained: only the last group's ~10 us per window are not hidden behind the other groups' kernels
+        if (g > 0 && hipEventRecord(B.sideDone[g - 1], sg) != hipSuccess) { eao::set_error("hipEventRecord failed"); return fail(EAO_ERR_NO_DEVICE); }
+        if (hipStreamSynchronize(sg) != hipSuccess) { eao::set_error("hipStreamSynchronize: %s", hipGetErrorString(hipGetLastError())); return fail(EAO_ERR_NO_DEVICE); }
+        msDone[g] = since(tp0);
+        for (int w = w0; w < w1; w++) {
+            BAJob& j = jobs[w];
+            if (j.trivial) continue;
+            if (batched[w]) j.L.seq = L.seq;
+            stw[w] = j.complete();
+            if (stw[w]) { errw[w] = eao_last_error(); return; }
+        }
+    };
+    {
         std::vector<std::thread> th;
-        for (int t = 1; t < nThreads; t++) th.emplace_back(work, t);
-        work(0);
+        for (int t = 0; t < nThreads; t++) th.emplace_back(worker, t);
+        for (int g = 1; g < G; g++) th.emplace_back(groupWork, g);
+        groupWork(0);
         for (auto& x : th) x.join();
     }
+    bool failed = false;
+    for (int w = 0; w < n; w++) failed = failed || stw[w];
+    for (int g = 0; g < G; g++) failed = failed || stg[g];
+    if (failed)
+        for (int g = 1; g < G; g++) (void)hipStreamSynchronize(B.side[g - 1]);
+    else
+        for (int g = 1; g < G; g++) EAO_HIP(hipStreamWaitEvent(B.stream, B.sideDone[g - 1], 0));   // (device time of the call: ev0 .. ev1)
     for (int w = 0; w < n; w++)
         if (stw[w]) { eao::set_error("window %d: %s", w, errw[w].c_str()); (void)hipStreamSynchronize(B.stream); return stw[w]; }
-    // ---- the windows that share the batched enqueue (tile-solver path, something to optimise); the others -- windows
-    //      beyond 30 free keyframes, empty ones -- follow one by one on the same stream
-    const double msPrepare = since(tp0);
-    std::vector<int> inBatch;
-    BALaunch LB;
-    LB.s = B.stream; LB.W = B.dW.p; LB.seq = 0;
-    for (int w = 0; w < n; w++) {
-        BAJob& j = jobs[w];
-        if (!j.batchable() || j.p->its_first != jobs[inBatch.empty() ? w : inBatch[0]].p->its_first ||
-            j.p->its_second != jobs[inBatch.empty() ? w : inBatch[0]].p->its_second) continue;
-        if (inBatch.empty()) LB.d = j.L.d; else LB.d.merge(j.L.d);
-        j.write_records(B.hW + 2 * inBatch.size());
-        inBatch.push_back(w);
-    }
-    std::vector<char> batched(n, 0);
-    if (!inBatch.empty()) {
-        LB.nz = (int)inBatch.size();
-        EAO_HIP(hipMemcpyAsync(B.dW.p, B.hW, (size_t)LB.nz * 2 * sizeof(BADev), hipMemcpyHostToDevice, B.stream));
-        if ((st = LB.attributes())) return st;
-        LB.setup();
-        LB.chain(0, jobs[inBatch[0]].p->its_first, jobs[inBatch[0]].p->its_second);
-        for (int w : inBatch) batched[w] = 1;
-    }
-    for (int w = 0; w < n; w++) {
-        BAJob& j = jobs[w];
-        if (batched[w] || j.trivial) continue;
-        if ((st = j.L.attributes())) return st;
-        j.L.setup();
-        if (j.chained) j.L.chain(0, j.p->its_first, j.p->its_second);
-    }
-    const double msEnqueue = since(tp0);
-    EAO_HIP(hipStreamSynchronize(B.stream));
-    const double msSync = since(tp0);
-    EAO_HIP(hipGetLastError());
-    for (int w = 0; w < n; w++) {
-        BAJob& j = jobs[w];
-        if (j.trivial) continue;
-        if (batched[w]) j.L.seq = LB.seq;
-        if ((st = j.complete())) { const std::string m = eao_last_error(); eao::set_error("window %d: %s", w, m.c_str()); return st; }
-        g_trace.linearizations += j.tr->linearizations;
-    }
+    for (int g = 0; g < G; g++)
+        if (stg[g]) { eao::set_error("%s", errg[g].c_str()); (void)hipStreamSynchronize(B.stream); return stg[g]; }
+    int nBatched = 0;
+    for (int g = 0; g < G; g++) nBatched += nInGroup[g];
+    const double msPrepare = *std::max_element(msPrep.begin(), msPrep.end());
+    const double msEnqueue = *std::max_element(msEnq.begin(), msEnq.end()), msSync = *std::max_element(msDone.begin(), msDone.end());
+    for (int w = 0; w < n; w++)
+        if (!jobs[w].trivial) g_trace.linearizations += jobs[w].tr->linearizations;
     EAO_HIP(hipEventRecord(B.ev1, B.stream));
     EAO_HIP(hipStreamSynchronize(B.stream));
     EAO_HIP(hipEventElapsedTime(&g_trace.deviceMs, B.ev0, B.ev1));
     if (envTiming)
         fprintf(stderr, "[eao_local_ba_batch] %d windows (%d batched, %d host threads): set-up + uploads enqueued %.3f ms, launches enqueued %.3f, device done %.3f, results out %.3f\n",
-                n, (int)inBatch.size(), nThreads, msPrepare, msEnqueue, msSync, since(tp0));
+                n, nBatched, nThreads, msPrepare, msEnqueue, msSync, since(tp0));
     return EAO_OK;
 }
 
