@@ -220,6 +220,18 @@ __device__ __forceinline__ double quad_sum(double v) {   // sum over the four la
     o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));          // quad_perm [2,3,0,1]
     return v + o;
 }
+// Sum over the eight lanes of a 16-lane DPP row that share this lane's parity (valid in lanes 0 and 1 of the row).
+__device__ __forceinline__ double row_half_sum(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += o;
+    lo = __double2loint(v); hi = __double2hiint(v);
+    o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x124, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x124, 0xF, 0xF, true));        // row_ror:4
+    v += o;
+    lo = __double2loint(v); hi = __double2hiint(v);
+    o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x128, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, true));        // row_ror:8
+    return v + o;
+}
 // Fixed-order sum of NV accumulators over a block of NT threads through LDS: lane quads first (DPP), then NV x 8 column
 // threads over NT/32 quad leaders each, then the last 8.  red: (NT/4)*NV doubles, part: 8*NV doubles; the totals land in
 // part[0 .. NV).  (A 64-lane shuffle tree per value costs ~230 cycles per value; this is ~10x cheaper for NV ~ 28.)
@@ -1928,19 +1940,24 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(const BADev* __
 }
 
 // (b) A BATCH of windows (5 250 workgroups for 25 windows) is bound by workgroup latency x rounds: two threads per landmark
-//     (thread t < NT / 2 accumulates rows 0..2 of the pair's 6x6 block and of its right-hand side, thread t + NT / 2 rows
-//     3..5: 21 accumulators, 128 VGPRs) in 256-thread workgroups, four of which fit a CU instead of two.  Measured, 25
+//     (ADJACENT lanes 2k / 2k + 1 accumulate rows 0..2 / 3..5 of the pair's 6x6 block and of its right-hand side: 21
+//     accumulators, 128 VGPRs) in 256-thread workgroups, four of which fit a CU instead of two.  The launch is bound by the
+//     texture-address unit walking the distinct cache lines of each scattered 16-byte load (about one line per cycle): with
+//     the two lanes of a landmark adjacent their Hll / Hpl(e2) loads share lines -- 32 lines per wave load instead of 64,
+//     -20 us per launch against the halves in separate waves.  Four lanes per landmark (3x3 sub-blocks, 16 lines per load but
+//     three passes per pair instead of two): +14 us.  One window: no difference to (a) at 256 / 512 / 1024 threads.  Measured, 25
 //     windows per launch: (a) 152 us, (a) with 256 threads 106 us, two threads per landmark in 512-thread workgroups 112 us,
 //     this 58 us; staging the operands through LDS with cooperative loads 156 us, pinning windows to XCDs no change; eight
 //     lanes per landmark (lane r owns row r: a wave load touches 8 cache lines instead of 64, but three times the load
 //     instructions) +12 us.  With the loop body removed the launch costs 19 us (5 250 workgroups: prologue, reduction, stores),
 //     with the index loads only the same -- the time is the 30 scattered 16-byte loads per landmark-thread.
 constexpr int kPairThreadsB = 256;
-__global__ __launch_bounds__(kPairThreadsB, 4) void k_ba_schur_pairs_b(const BADev* __restrict__ W, int wpar, int first) {
+template <int NT>
+__global__ __launch_bounds__(NT, 1024 / NT) void k_ba_schur_pairs_b(const BADev* __restrict__ W, int wpar, int first) {
     BA_WIN(P);
     if ((int)bx >= P.nFree * (P.nFree + 1) / 2) return;
-    constexpr int NT = kPairThreadsB, kHalf = NT / 2, kLeaders = NT / 4;     // quad leaders: the first kLeaders / 2 belong to rows 0..2
-    __shared__ double red[kLeaders * 21], part[4 * 42];
+    constexpr int kHalf = NT / 2, kRows = NT / 16;      // DPP rows of 16 lanes: lanes 0 / 1 of a row lead its two halves
+    __shared__ double red[2 * kRows * 21], part[4 * 42];
     if (P.ctl[kCtlHalt]) return;
     const int nF = P.nFree, t = threadIdx.x;
     int i1 = 0, rem = bx;
@@ -1951,11 +1968,11 @@ __global__ __launch_bounds__(kPairThreadsB, 4) void k_ba_schur_pairs_b(const BAD
     if (first && bx == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
     const int cnt = P.pairCnt[bx];
     const int* pts = P.pairPts + (size_t)bx * P.nL;
-    const int half = t >= kHalf ? 1 : 0;
+    const int half = t & 1;        // adjacent lanes share a landmark: their Hll / Hpl(e2) loads hit the same cache lines
     double acc[21];
 #pragma unroll
     for (int q = 0; q < 21; q++) acc[q] = 0;
-    for (int k = t - half * kHalf; k < cnt; k += kHalf) {
+    for (int k = t >> 1; k < cnt; k += kHalf) {
         const int l = pts[k];
         const int e1 = P.table[(size_t)l * nF + i1], e2 = P.table[(size_t)l * nF + i2];
         if (e1 < 0 || e2 < 0) continue;                      // deactivated by the outlier pass
@@ -1980,20 +1997,21 @@ __global__ __launch_bounds__(kPairThreadsB, 4) void k_ba_schur_pairs_b(const BAD
             }
         }
     }
-    // fixed-order sum: lane quads (DPP), then 42 x 4 column threads over a quarter of their half's quad leaders each, then
-    // the last four.  Value q < 18: S[3 half + q / 6][q % 6]; q = 18..20: right-hand side row 3 half + q - 18.
+    // fixed-order sum: the eight landmarks of a DPP row per half (lanes i, i+2 of a quad, then the row's four quads), then
+    // 42 x 4 column threads over a quarter of their half's row leaders each, then the last four.  Value q < 18:
+    // S[3 half + q / 6][q % 6]; q = 18..20: right-hand side row 3 half + q - 18.
 #pragma unroll
-    for (int q = 0; q < 21; q++) acc[q] = quad_sum(acc[q]);
-    if ((t & 3) == 0) {
-        double* dst = red + (t >> 2) * 21;
+    for (int q = 0; q < 21; q++) acc[q] = row_half_sum(acc[q]);
+    if ((t & 14) == 0) {
+        double* dst = red + (half * kRows + (t >> 4)) * 21;
 #pragma unroll
         for (int q = 0; q < 21; q++) dst[q] = acc[q];
     }
     __syncthreads();
     if (t < 42 * 4) {
         const int v = t % 42, seg = t / 42, h = v >= 21 ? 1 : 0, q = v - 21 * h;
-        constexpr int kSeg = kLeaders / 2 / 4;
-        const double* src = red + (size_t)(h * (kLeaders / 2) + seg * kSeg) * 21 + q;
+        constexpr int kSeg = kRows / 4;
+        const double* src = red + (size_t)(h * kRows + seg * kSeg) * 21 + q;
         double sacc = 0;
         for (int j = 0; j < kSeg; j++) sacc += src[j * 21];
         part[seg * 42 + v] = sacc;
@@ -3160,7 +3178,7 @@ struct BALaunch {
             for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
                 hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, W, wp(par), J);
         } else if (nF && d.usePairs && d.solveTiles) {
-            if (nz > 1) hipLaunchKernelGGL(k_ba_schur_pairs_b, dim3(nF * (nF + 1) / 2, 1, gz()), dim3(kPairThreadsB), 0, s, W, wp(par), firstTrial ? 1 : 0);
+            if (nz > 1) hipLaunchKernelGGL(k_ba_schur_pairs_b<kPairThreadsB>, dim3(nF * (nF + 1) / 2, 1, gz()), dim3(kPairThreadsB), 0, s, W, wp(par), firstTrial ? 1 : 0);
             else hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2, 1, 1), dim3(kPairThreads), 0, s, W, wp(par), firstTrial ? 1 : 0);
         } else if (nF) {
             hipLaunchKernelGGL(k_ba_schur, dim3(nF, d.chunks), dim3(kSchurThreads), d.schurLds, s, W, wp(par), firstTrial ? 1 : 0);
@@ -3812,7 +3830,8 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     };
     {
         std::vector<std::thread> th;
-        for (int t = 0; t < nThreads; t++) th.emplace_back(worker, t);
+        if (nThreads == 1 && G == 1) worker(0);          // (a batch of one: no thread is started)
+        else for (int t = 0; t < nThreads; t++) th.emplace_back(worker, t);
         for (int g = 1; g < G; g++) th.emplace_back(groupWork, g);
         groupWork(0);
         for (auto& x : th) x.join();
