@@ -969,6 +969,8 @@ struct BADev {
     double* slab;           // chunks * nFree * (nFree*36 + 6): partial Schur rows
     double* sys;            // n*(n+1): assembled Schur system (upper triangle + rhs column)
     double* solveScratch;   // n*(n+1)+... doubles when the Schur system does not fit in LDS, else null
+    int* doneCnt;           // workgroups of the running k_ba_backsub that have published their partial sums (zero between launches)
+    double* wgPart;         // their partial sums: 2 per workgroup
     long long* dbg;         // optional phase stamps of k_ba_solve (diagnostic builds of the harness only)
     double* xp;             // nFree*6
     double* xl;             // nL*3
@@ -1272,34 +1274,13 @@ constexpr int kLinThreads = 1024;
 // ctlOld != nullptr: the previous trial's decision has not been taken yet (bulk segment): see BADecision.  P.ctl / P.lm
 // are then the blocks this trial runs on (written by workgroup 0 here), ctlOld / lmOld the ones the previous trial ran on.
 template <bool PL>
-__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(const BADev* __restrict__ W, int wpar, int ptBlocks, int first, int parOld, int seq) {
+__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(const BADev* __restrict__ W, int wpar, int ptBlocks, int first) {
     BA_WIN(P);
-    const int* const ctlOld = parOld >= 0 ? P.ctl0 + 8 * parOld : nullptr;
-    const double* const lmOld = parOld >= 0 ? P.lm0 + 8 * parOld : nullptr;
-    const int* const solveOk = P.solveOk;
-    BAStatus* const st = P.status;
     if ((int)bx >= ptBlocks + P.nFree) return;      // (a batch is launched with the largest window's grid)
     __shared__ double red[(kLinThreads / 4) * 27], part[8 * 27];
     __shared__ double s_wmax[kLinThreads / 64];
-    int cur;
-    if (ctlOld) {
-        if (ctlOld[kCtlHalt]) {   // frozen stream: hand the control block on unchanged
-            if (bx == 0 && threadIdx.x < 8) { P.ctl[threadIdx.x] = ctlOld[threadIdx.x]; P.lm[threadIdx.x] = lmOld[threadIdx.x]; }
-            return;
-        }
-        double v[2] = {0, 0};
-#pragma unroll 3
-        for (int i = threadIdx.x; i < P.nL; i += kLinThreads) { v[0] += P.partChi[i]; v[1] += P.partScale[i]; }
-        block_sum<2, kLinThreads>(v, red, part);
-        const BADecision d = ba_decision(lmOld, ctlOld, part[0], lmOld[4] + part[1], *solveOk, 1);   // the same in every workgroup
-        __syncthreads();   // (red / part are reused below)
-        if (bx == 0 && threadIdx.x == 0) ba_commit(d, lmOld, ctlOld, P.lm, P.ctl, st, seq, 1);
-        if (d.halt) return;
-        cur = d.cur;
-    } else {
-        if (P.ctl[kCtlHalt]) return;
-        cur = P.ctl[kCtlCur];
-    }
+    if (P.ctl[kCtlHalt]) return;            // (the previous trial's decision is already in this control block: k_ba_backsub's last workgroup)
+    const int cur = P.ctl[kCtlCur];
     const SE3* cams = P.camsBuf[cur];
     const double* pts = P.ptsBuf[cur];
     if ((int)bx < ptBlocks) {
@@ -2612,10 +2593,15 @@ __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BASta
 // per landmark (eight lanes, one edge per lane): x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 of
 // its edges at the trial state; scale partial
 template <bool PL>
-__global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W, int wpar) {
+__global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W, int wpar, int decide, int seq) {
     BA_WIN(P);
     const int l = (bx * 256 + threadIdx.x) >> 3, slot = threadIdx.x & 7;
-    if (P.ctl[kCtlHalt]) return;
+    int* const ctlNext = P.ctl0 + 8 * ((wpar & 1) ^ 1);
+    double* const lmNext = P.lm0 + 8 * ((wpar & 1) ^ 1);
+    if (P.ctl[kCtlHalt]) {      // frozen stream: hand the control block on unchanged
+        if (decide && bx == 0 && threadIdx.x < 8) { ctlNext[threadIdx.x] = P.ctl[threadIdx.x]; lmNext[threadIdx.x] = P.lm[threadIdx.x]; }
+        return;
+    }
     const bool live = l < P.nL;
     const int pt = live ? P.actPt[l] : 0;
     const double* pts = cur_pts(P);
@@ -2684,22 +2670,58 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
         double* plT = &P.plBuf[P.ctl[kCtlCur] ^ 1][4 * (pt - P.nPtsOnly)];
         for (int i = 0; i < 4; i++) plT[i] = npl[i];
     }
+    double mine[2] = {0, 0};      // this landmark's terms of the trial chi2 and of the gain denominator (group leaders only)
     if (live && slot == 0) {
         for (int i = 0; i < 3; i++) { P.xl[(size_t)l * 3 + i] = xl[i]; ptsT[3 * pt + i] = np[i]; }
-        P.partChi[l] = chi;
-        P.partScale[l] = xl[0] * (lambda * xl[0] + bl[0]) + xl[1] * (lambda * xl[1] + bl[1]) + xl[2] * (lambda * xl[2] + bl[2]);
+        mine[0] = chi;
+        mine[1] = xl[0] * (lambda * xl[0] + bl[0]) + xl[1] * (lambda * xl[1] + bl[1]) + xl[2] * (lambda * xl[2] + bl[2]);
+        P.partChi[l] = mine[0];
+        P.partScale[l] = mine[1];
     }
+    __shared__ double red[8], out2[2];
     if (bx == 0) {   // camera part of the gain denominator, sum x (lambda x + b), for the decision (fixed order)
-        __shared__ double red[4], out1;
         double v[1] = {0};
         for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { const double x = P.xp[i]; v[0] += x * (lambda * x + P.bp[i]); }
-        block_sum<1, 256>(v, red, &out1);
-        if (threadIdx.x == 0) P.lm[4] = out1;
+        block_sum<1, 256>(v, red, &out2[0]);
+        if (threadIdx.x == 0) __hip_atomic_store(&P.lm[4], out2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!decide) return;
+    // The accept / reject decision of this trial, by the LAST workgroup of the window to get here (every other one has
+    // published its partial sums by then): the next linearisation finds it in the other control block.  Leaving it to the
+    // head of that launch instead -- every workgroup re-deriving it from the 2 nL partial sums -- cost each of its 1 100
+    // workgroups (25 windows) 2.6 - 4 us of an 8 - 9 us life.
+    // Memory model: a workgroup publishes ITS partial sums (wgPart) with agent-scope atomic stores (written through, no L2
+    // write-back needed -- a __threadfence() here is a buffer_wbl2 per workgroup and made the launch 3x slower), waits for
+    // them (workgroup-scope release = s_waitcnt) and then takes its ticket; the last workgroup reads the partial sums with
+    // agent-scope atomic loads (they bypass its CU's L1).  The same goes for the camera part in lm[4].
+    __shared__ int s_last;
+    __syncthreads();
+    block_sum<2, 256>(mine, red, out2);         // this workgroup's 32 landmarks, fixed order
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&P.wgPart[2 * bx], out2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&P.wgPart[2 * bx + 1], out2[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        s_last = __hip_atomic_fetch_add(P.doneCnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    double v[2] = {0, 0};
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        v[0] += __hip_atomic_load(&P.wgPart[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[1] += __hip_atomic_load(&P.wgPart[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    block_sum<2, 256>(v, red, out2);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(P.doneCnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double camPart = __hip_atomic_load(&P.lm[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const BADecision d = ba_decision(P.lm, P.ctl, out2[0], camPart + out2[1], *P.solveOk, 1);
+        ba_commit(d, P.lm, P.ctl, lmNext, ctlNext, P.status, seq, 1);
     }
 }
 
-// One block.  (Folding this into k_ba_backsub behind a last-block ticket was measured: the agent-scope fences every
-// block then needs cost more (23 us for the pair) than the launch they save (6 + 9 us).)
+// One block: the decision of the LAST trial of a bulk segment and of host-stepped trials (the others are decided by
+// k_ba_backsub's last workgroup).
 // ctl0 / lm0: the canonical control blocks.  The last trial of a bulk segment may have run on the other pair (see
 // BADecision); whatever happened, the state is back in the canonical pair when this kernel ends.
 __global__ __launch_bounds__(256) void k_ba_decide(const BADev* __restrict__ W, int wpar, int seq, int bulk) {
@@ -2764,6 +2786,7 @@ __global__ __launch_bounds__(256) void k_ba_prepare(const BADev* __restrict__ W,
     if (idx < (P.nPts - P.nPtsOnly) * 4) P.plBuf[1][idx] = P.plBuf[0][idx];
     if (idx < P.nCams) P.camsBuf[1][idx] = P.camsBuf[0][idx];
     if (idx < P.camStart[P.nFree]) P.camEdgeL[idx] = P.ptIdx[P.ept[P.camEdges[idx]]];
+    if (idx == 0) *P.doneCnt = 0;
 }
 
 // Results straight into pinned host memory: final state + the per-edge outlier flags.
@@ -3190,8 +3213,9 @@ struct BALaunch {
         else if (d.solveTiles) hipLaunchKernelGGL(k_ba_solve_tiles<5>, dim3(1, 1, gz()), dim3(kTileThreads), d.tileLds, s, W, wp(par));
         else if (d.solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), d.solveLds, s, W, wp(par));
         else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), d.solveLds, s, W, wp(par));
-        if (nL && d.hasPl) hipLaunchKernelGGL(k_ba_backsub<true>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par));
-        else if (nL) hipLaunchKernelGGL(k_ba_backsub<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par));
+        const int decideHere = bulk && !withDecide ? 1 : 0, sqHere = decideHere ? ++seq : 0;      // (see k_ba_backsub)
+        if (nL && d.hasPl) hipLaunchKernelGGL(k_ba_backsub<true>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par), decideHere, sqHere);
+        else if (nL) hipLaunchKernelGGL(k_ba_backsub<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par), decideHere, sqHere);
         if (withDecide) hipLaunchKernelGGL(k_ba_decide, dim3(1, 1, gz()), dim3(256), 0, s, W, wp(par), ++seq, bulk);
     }
     // iterations [from, to) of an optimize() call, one trial each, no host round trip
@@ -3202,17 +3226,16 @@ struct BALaunch {
             else if (nL) hipLaunchKernelGGL(k_ba_errors<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(0));
             hipLaunchKernelGGL(k_ba_chi_init, dim3(1, 1, gz()), dim3(256), 0, s, W, wp(0), ++seq);
         }
-        // every trial but the last leaves its accept / reject decision to the head of the next linearisation, which
-        // runs on the other control block (BADecision); the last one is decided by k_ba_decide, which also brings the
-        // state back to the canonical block
+        // every trial but the last is decided (accept / reject) by the last workgroup of its k_ba_backsub, into the other
+        // control block (BADecision), where the next linearisation finds it; the last one is decided by k_ba_decide, which
+        // also brings the state back to the canonical block
         int par = 0;
         for (int it = from; it < to; it++) {
-            int parOld = -1, sq = 0;
-            if (it != from) { parOld = par; par ^= 1; sq = ++seq; }
-            if (d.hasPl) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, parOld, sq);
-            else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, parOld, sq);
+            if (it != from && nL) par ^= 1;
+            if (d.hasPl) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0);
+            else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0);
             if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, W, wp(par));   // no Schur kernel to do it
-            trial(par, 1, it == 0 && nF, it == to - 1);
+            trial(par, 1, it == 0 && nF, it == to - 1 || !nL);      // (no landmark, no k_ba_backsub: k_ba_decide after every trial)
         }
     }
     void classify() const { hipLaunchKernelGGL(k_ba_classify, dim3(eao::cdiv(std::max(d.E, 1), 256), 1, gz()), dim3(256), 0, s, W, wp(0), 1); }
@@ -3306,7 +3329,7 @@ struct BAJob {
         need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
         need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
         need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
-        need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev);
+        need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
             need += (2 * (size_t)bg.RP * bg.RP + (size_t)bg.N * kBigNB) * 8;
             need += (lpEntries + 3 * lpPairsMax + 8) * 4;
@@ -3369,6 +3392,8 @@ struct BAJob {
         D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
         D.lm0 = a.take<double>(16);
         D.solveOk = a.take<int>(4);
+        D.doneCnt = a.take<int>(4);
+        D.wgPart = a.take<double>(2 * (size_t)eao::cdiv(std::max(nP, 1) * 8, 256) + 2);
         long long* ddbg = a.take<long long>(16);
         D.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
         EAO_REQUIRE(a.off <= a.cap, "internal: arena overflow");

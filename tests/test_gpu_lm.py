@@ -64,19 +64,38 @@ def test_local_ba_parity(gpu, oracle, kw):
     assert np.array_equal(r["poses"][f], o["poses"][f])
 
 
-@pytest.mark.parametrize("seed", [sd for sd in range(3030, 3060) if sd not in (3039, 3040, 3045)])
+# Seeds of the far-off family on which the ORACLE ITSELF moves by more than the parity bar (or changes its LM schedule) when
+# its inputs are perturbed by one float32 ulp: seed -> the larger of its pose / point displacement relative to the update
+# (profiles/r02_lm_chaotic_seeds.txt, written by tools/lm_chaotic_seeds.py; "B" columns).  No two implementations -- not
+# even two summation orders of one -- can be held to 1e-4 there.
+CHAOTIC_BAND = {3031: 2.2e-4, 3034: 1.8e-4, 3039: 1.7e-3, 3040: 3.7e-2, 3042: 1.9e-4, 3045: 1.2e-3, 3048: 2.5e-4, 3050: 1e-4, 3051: 2.8e-4,
+                3053: 4.7e-3, 3055: 1.2e-4, 3059: 1e-4}
+
+
+@pytest.mark.parametrize("seed", list(range(3030, 3060)))
 def test_local_ba_rejected_trials(gpu, oracle, seed):
     """Far-off starts (25 degrees, 0.8 m, 1 m on the points): LM trials get rejected in the first and / or the second
     optimize() -- the stream freezes and the host replays the iteration trial by trial (up to the 10-trial limit) -- and
     in some windows every edge ends up an outlier, so the second optimize() has nothing to do (g2o returns -1).  Two fixed
     cameras keep the scale observable: with one, the damped system is singular along the gauge and no two
-    implementations agree on the step.  All thirty seeds 3030..3059 of the family but three: on 3039, 3040 and 3045 the result
-    moves by 1.7e-3 / 3.7e-2 / 1.2e-3 of the update when the ORACLE's own inputs are perturbed by one float32 ulp (points
-    flipping behind cameras in the first iterations, chi2 around 1e6), and the GPU's distance to the oracle there (8.4e-4 /
-    1.2e-2 / 5.2e-4) is inside that band -- profiles/r02_lm_chaotic_seeds.txt, written by tools/lm_chaotic_seeds.py."""
+    implementations agree on the step.  All thirty seeds 3030..3059: full parity (LM schedule, trace, updates within 1e-4,
+    outlier table) on the 18 well-conditioned ones; on the 12 of CHAOTIC_BAND (points flipping behind cameras in the first
+    iterations, chi2 around 1e6 -- one ulp on the inputs moves the oracle's own result by the listed amount and on three
+    of them changes its iteration count) the result must be reproducible bit for bit and stay within four of the oracle's
+    own one-ulp bands."""
     p = synth.synth_ba(n_free=5, n_fixed=2, n_points=200, seed=seed, rot_noise_deg=25, trans_noise=0.8, point_noise=1.0, mono_frac=0.7)
     r = gpu.Optimizer.LocalBundleAdjustment(p)
     o = oracle.local_ba(p)
+    if seed in CHAOTIC_BAND:
+        r2 = gpu.Optimizer.LocalBundleAdjustment(p)
+        assert np.array_equal(r["poses"].view(np.uint32), r2["poses"].view(np.uint32)) and np.array_equal(r["points"].view(np.uint32), r2["points"].view(np.uint32))
+        assert list(r["iters"]) == list(r2["iters"]) and np.array_equal(r["edge_outlier"], r2["edge_outlier"])
+        bound = 4 * max(CHAOTIC_BAND[seed], REL)
+        for key in ("poses", "points"):
+            upd = max(np.abs(o[key].astype(np.float64) - p[key].astype(np.float64)).max(), 1e-6)
+            err = np.abs(r[key].astype(np.float64) - o[key].astype(np.float64)).max()
+            assert err <= bound * upd, "%s: |gpu-cpu| %.3e vs update %.3e (band %.1e)" % (key, err, upd, CHAOTIC_BAND[seed])
+        return
     assert list(r["iters"]) == list(o["iters"])
     _check_trace(r, o, rel=1e-4)      # monocular-only windows this far from the optimum are ill-conditioned: rounding differences grow
     _check_updates(r["poses"], o["poses"], p["poses"], "poses")
