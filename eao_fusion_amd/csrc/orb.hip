@@ -1604,6 +1604,7 @@ struct eao_orb {
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
     hipEvent_t evLast = nullptr;   // end of the previous call on this handle (whatever stream it ran on)
     bool evLastValid = false, capturing = false;
+    hipStream_t lastStream = nullptr;      // the stream of the previous call (evLast)
     hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
@@ -1920,13 +1921,17 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     lanes = std::max(1, std::min(std::min(eao_orb::kLanes, batch), lanes));
     // the handle's pyramid / candidate scratch is shared by its calls: a call enqueued on another stream than the previous
     // one waits for it (same stream: already ordered, the wait costs nothing)
-    if (h->evLastValid && !h->capturing) EAO_HIP(hipStreamWaitEvent(st, h->evLast, 0));
+    if (h->evLastValid && !h->capturing && h->lastStream != st) EAO_HIP(hipStreamWaitEvent(st, h->evLast, 0));
+    h->lastStream = st;
     EAO_HIP(hipEventRecord(h->evStart, st));
     for (int i = 0; i < lanes; i++) {
         const int f0 = (int)((long long)batch * i / lanes), f1 = (int)((long long)batch * (i + 1) / lanes), nb = f1 - f0;
-        hipStream_t ms = h->laneMain[i], ss = h->laneSide[i];
+        // One lane (the default): the main chain runs on the CALLER's stream itself -- no hand-over to a private stream and
+        // back, which put two cross-stream event hops (~25 us on PyTorch's bundled HIP 7.0 runtime) between consecutive calls.
+        const bool onCaller = lanes == 1;
+        hipStream_t ms = onCaller ? st : h->laneMain[i], ss = h->laneSide[i];
         const bool pe = prof && i == 0;
-        EAO_HIP(hipStreamWaitEvent(ms, h->evStart, 0));
+        if (!onCaller) EAO_HIP(hipStreamWaitEvent(ms, h->evStart, 0));
         // Level 0 IS the input image: its FAST cells (a third of all cells) do not wait for the pyramid.  Outside profiling
         // runs they start on the side stream at once and overlap the seven resize launches; the side stream then goes on
         // with the blur as before.  (Profiling runs keep the stages sequential so that each is timed alone.)
@@ -2007,8 +2012,10 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             { eao::Range rg("orb: orientation + description"); hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
                                h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels); }
             if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
-            EAO_HIP(hipEventRecord(h->evDone[i], ms));
-            EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
+            if (!onCaller) {
+                EAO_HIP(hipEventRecord(h->evDone[i], ms));
+                EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
+            }
             continue;
         }
         if (early0) {
@@ -2066,8 +2073,10 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         { eao::Range rg("orb: orientation + description"); hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
                            h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels); }
         if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
-        EAO_HIP(hipEventRecord(h->evDone[i], ms));
-        EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
+        if (!onCaller) {
+            EAO_HIP(hipEventRecord(h->evDone[i], ms));
+            EAO_HIP(hipStreamWaitEvent(st, h->evDone[i], 0));
+        }
     }
     if (prof) EAO_HIP(hipEventRecord(ev[8], st));
     if (!h->capturing) {
