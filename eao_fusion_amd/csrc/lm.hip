@@ -1267,25 +1267,25 @@ __device__ inline void ba_commit(const BADecision& d, const double* lmOld, const
 // camera, one edge per thread; the 27 sums (21 of Hpp's upper triangle + 6 of bp) go through LDS in a fixed order: lane
 // quads first (DPP), then 27 x 8 column threads over 32 quad leaders each, then the last 8.  (Sixty-four-lane shuffle
 // trees for the 27 values cost 6.4 us here; this costs about one.)
-constexpr int kLinThreads = 1024;
+constexpr int kLinThreads = 1024;      // (batches: 512- and 256-thread workgroups measured, no difference: 3.27 / 3.29 / 3.29 ms for 25 windows)
 // first = 1 on the first linearisation of an optimize() call: the largest |diagonal entry| of Hpp / Hll (lambda_0 = 1e-5 x
 // that, optimization_algorithm_levenberg.cpp:166-180) is accumulated with one atomic max per workgroup -- a max does not
 // depend on the order, and non-negative doubles order like their bit patterns.
 // ctlOld != nullptr: the previous trial's decision has not been taken yet (bulk segment): see BADecision.  P.ctl / P.lm
 // are then the blocks this trial runs on (written by workgroup 0 here), ctlOld / lmOld the ones the previous trial ran on.
-template <bool PL>
-__global__ __launch_bounds__(kLinThreads) void k_ba_linearize(const BADev* __restrict__ W, int wpar, int ptBlocks, int first) {
+template <bool PL, int NT>
+__global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W, int wpar, int ptBlocks, int first) {
     BA_WIN(P);
     if ((int)bx >= ptBlocks + P.nFree) return;      // (a batch is launched with the largest window's grid)
-    __shared__ double red[(kLinThreads / 4) * 27], part[8 * 27];
-    __shared__ double s_wmax[kLinThreads / 64];
+    __shared__ double red[(NT / 4) * 27], part[8 * 27];
+    __shared__ double s_wmax[NT / 64];
     if (P.ctl[kCtlHalt]) return;            // (the previous trial's decision is already in this control block: k_ba_backsub's last workgroup)
     const int cur = P.ctl[kCtlCur];
     const SE3* cams = P.camsBuf[cur];
     const double* pts = P.ptsBuf[cur];
     if ((int)bx < ptBlocks) {
         // role A: eight lanes per landmark, one edge per lane; Hll / bl are xor-tree sums over the lane group
-        const int l = (bx * kLinThreads + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+        const int l = (bx * NT + threadIdx.x) >> 3, slot = threadIdx.x & 7;
         const bool live = l < P.nL;
         const int pt = live ? P.actPt[l] : 0;
         const int beg = live ? P.ptStart[l] : 0, end = live ? P.ptStart[l + 1] : 0;
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(const BADev* __res
             if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = m;
             __syncthreads();
             if (threadIdx.x == 0) {
-                for (int w = 1; w < kLinThreads / 64; w++) m = fmax(m, s_wmax[w]);
+                for (int w = 1; w < NT / 64; w++) m = fmax(m, s_wmax[w]);
                 atomicMax((unsigned long long*)&P.lm[3], (unsigned long long)__double_as_longlong(m));
             }
         }
@@ -1360,9 +1360,7 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(const BADev* __res
 #pragma unroll
         for (int k = 0; k < 27; k++) acc[k] = 0;
         const int beg = P.camStart[ci], end = P.camStart[ci + 1];
-        const int per = (end - beg + kLinThreads - 1) / kLinThreads;
-        const int b0 = min(beg + (int)threadIdx.x * per, end), e0 = min(b0 + per, end);
-        for (int k = b0; k < e0; k++) {
+        for (int k = beg + (int)threadIdx.x; k < end; k += NT) {
             const int e = P.camEdges[k];
             const unsigned char fl = P.eflag[e];
             if (fl & 2) continue;
@@ -1393,7 +1391,7 @@ __global__ __launch_bounds__(kLinThreads) void k_ba_linearize(const BADev* __res
                 for (int j = i; j < 6; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * B[r][j]; acc[q++] += h; }
             }
         }
-        block_sum_lds<27, kLinThreads>(acc, red, part);
+        block_sum_lds<27, NT>(acc, red, part);
         if (threadIdx.x == 0) {
             const double* sums = part;
             int q = 0;
@@ -3232,8 +3230,8 @@ struct BALaunch {
         int par = 0;
         for (int it = from; it < to; it++) {
             if (it != from && nL) par ^= 1;
-            if (d.hasPl) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0);
-            else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0);
+            if (d.hasPl) hipLaunchKernelGGL((k_ba_linearize<true, kLinThreads>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0);
+            else hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0);
             if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, W, wp(par));   // no Schur kernel to do it
             trial(par, 1, it == 0 && nF, it == to - 1 || !nL);      // (no landmark, no k_ba_backsub: k_ba_decide after every trial)
         }
