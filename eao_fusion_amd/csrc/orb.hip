@@ -763,6 +763,30 @@ __device__ int block_excl_scan(int* a, int n, int* wtmp) {
     return total;
 }
 
+// The same exclusive scan by ONE wave, in place, without a workgroup barrier (the caller fences at wavefront scope).
+__device__ __forceinline__ int wave_excl_scan(int* a, int n, int lane) {
+    const int per = (n + 63) >> 6;
+    const int b = min(lane * per, n), e = min(b + per, n);
+    int ssum = 0;
+    for (int i = b; i < e; i++) ssum += a[i];
+    int v = ssum;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2 and 3
+    const int total = __builtin_amdgcn_readlane(v, 63);
+    int run = v - ssum;
+    for (int i = b; i < e; i++) {
+        const int x = a[i];
+        a[i] = run;
+        run += x;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    return total;
+}
+
 __device__ __forceinline__ int quadrant(unsigned key, short4 bx) {
     const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
     const int mx = bx.x + ((bx.z - bx.x + 1) >> 1);   // UL.x + ceil((UR.x-UL.x)/2)
@@ -803,6 +827,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
     int* crk1 = crk0 + LC;
     int* childcnt = crk1 + LC;          // 4 per entry
     int* childpos = childcnt + 4 * LC;  // 4 per entry
+    unsigned long long* rkey = reinterpret_cast<unsigned long long*>(childpos);   // sort keys of a careful pass (before childpos is filled)
     int* newpos = childpos + 4 * LC;
     int* order = newpos + LC;
     int* vlist = order + LC;
@@ -867,20 +892,33 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
     short4* box = box0; short4* nbox = box1;
     int* cnt = cnt0; int* ncnt = cnt1;
     int* crk = crk0; int* ncrk = crk1;
+    // Every pass: two sweeps over the M candidates by the whole workgroup (child histograms, re-homing) and, between them, the
+    // list logic over the S <= N nodes.  The list logic runs in WAVE 0 ALONE, wave-synchronously (DPP scans, wavefront-scope
+    // fences, no workgroup barrier): as a sequence of block-wide steps it was ~20 barriers per pass with a handful of
+    // instructions between them -- 43 k of level 0's 132 k cycles.  Four barriers per pass remain (six in a careful pass,
+    // whose O(n^2) ranking stays block-wide).
+#define QT_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+    const int wv = t >> 6;
     for (int iter = 0; iter < 64 && !sh_done; iter++) {
         const int S = sh_S, phase = sh_phase;
-        // (1) multi-key entries in list order
+        // (1) reset of the per-node scratch (everyone) ...
         for (int i = t; i < S; i += kQT) {
-            scanA[i] = cnt[i] > 1 ? 1 : 0;
             procRank[i] = -1;
             childcnt[4 * i] = 0; childcnt[4 * i + 1] = 0; childcnt[4 * i + 2] = 0; childcnt[4 * i + 3] = 0;
         }
         if (t == 0) { sh_rstar = 0x7FFFFFFF; sh_nexp = 0; }
         __syncthreads();
-        const int nCand = block_excl_scan<kQT>(scanA, S, wtmp);
+        // ... and the multi-key entries in list order (wave 0, beside the other waves' share of the histogram sweep)
+        int nCand = 0;
+        if (wv == 0) {
+            for (int i = lane; i < S; i += 64) scanA[i] = cnt[i] > 1 ? 1 : 0;
+            QT_WAVE_FENCE();
+            nCand = wave_excl_scan(scanA, S, lane);
+            for (int i = lane; i < S; i += 64)
+                if (cnt[i] > 1) vlist[scanA[i]] = i;
+            QT_WAVE_FENCE();
+        }
         QSTAMP(1);
-        for (int i = t; i < S; i += kQT)
-            if (cnt[i] > 1) vlist[scanA[i]] = i;
         // (2) child histograms of every candidate
         // The candidates are in spatial order (cells row-major, corners row-major inside a cell), so neighbouring lanes mostly
         // hit the same (node, quadrant) bin: one LDS atomic per RUN of equal bins in the wave instead of one per candidate
@@ -904,95 +942,110 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
         __syncthreads();
         QSTAMP(2);
         // (3) processing order: list order (full pass) or (size, creation rank) descending (careful pass)
-        if (phase == 0) {
-            for (int j = t; j < nCand; j += kQT) order[j] = vlist[j];
-        } else {
-            // rank by (size, creation rank) descending: the two sort fields are first laid out densely (newpos / scanB
-            // are free here) so that the counting loop reads independent, broadcast LDS words
-            for (int j = t; j < nCand; j += kQT) { const int me = vlist[j]; newpos[j] = cnt[me]; scanB[j] = crk[me]; }
-            __syncthreads();
-            for (int j = t; j < nCand; j += kQT) {
-                const int ms = newpos[j], mr = scanB[j];
-                int r = 0;
-#pragma unroll 8
-                for (int u = 0; u < nCand; u++) {
-                    const int os = newpos[u], orr = scanB[u];
-                    r += (os > ms) || (os == ms && orr > mr);
-                }
-                order[r] = vlist[j];
-            }
-        }
-        __syncthreads();
-        QSTAMP(3);
-        // (4) growth prefix in processing order; the careful pass stops at the first prefix reaching N
-        for (int r = t; r < nCand; r += kQT) {
-            const int i = order[r];
-            scanA[r] = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
-        }
-        __syncthreads();
-        block_excl_scan<kQT>(scanA, nCand, wtmp);
         if (phase == 1) {
-            for (int r = t; r < nCand; r += kQT) {
-                const int i = order[r];
-                const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
-                if (S + scanA[r] + ne - (r + 1) >= N) atomicMin(&sh_rstar, r);
+            // rank by (size, creation rank) descending, block-wide: the two sort fields are packed into one 64-bit key per node
+            // (size << 32 | creation rank; the pairs are unique) and laid out densely (childpos is free here, 8-byte aligned),
+            // so that the counting loop is one broadcast LDS read and one compare per node.  When there are fewer nodes than
+            // threads, 2 / 4 / ... adjacent lanes share a node's loop and add their counts with DPP shuffles.
+            if (wv == 0) {
+                for (int j = lane; j < nCand; j += 64) { const int me = vlist[j]; rkey[j] = ((unsigned long long)(unsigned)cnt[me] << 32) | (unsigned)crk[me]; }
+                if (lane == 0) sh_nexp = nCand;         // (nCand lives in wave 0's registers: hand it to the others; reset below)
             }
+            __syncthreads();
+            const int nC2 = sh_nexp;
+            int sl = 1;
+            while (2 * sl * nC2 <= kQT && sl < 16) sl *= 2;
+            for (int j0 = 0; j0 < nC2; j0 += kQT / sl) {
+                const int j = j0 + t / sl, part = t & (sl - 1);
+                int r = 0;
+                if (j < nC2) {
+                    const unsigned long long mk = rkey[j];
+#pragma unroll 8
+                    for (int u = part; u < nC2; u += sl) r += rkey[u] > mk;
+                }
+                for (int d = sl >> 1; d >= 1; d >>= 1) r += __shfl_xor(r, d);
+                if (j < nC2 && part == 0) order[r] = vlist[j];
+            }
+            __syncthreads();
+            if (t == 0) sh_nexp = 0;
         }
-        __syncthreads();
-        QSTAMP(4);
-        const int nProc = (phase == 1 && sh_rstar != 0x7FFFFFFF) ? sh_rstar + 1 : nCand;
-        int totalChildren = 0;
-        if (nProc > 0) {
-            const int i = order[nProc - 1];
-            totalChildren = scanA[nProc - 1] + (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
-        }
-        for (int r = t; r < nProc; r += kQT) procRank[order[r]] = r;
-        __syncthreads();
-        for (int i = t; i < S; i += kQT) scanB[i] = procRank[i] < 0 ? 1 : 0;
-        __syncthreads();
-        block_excl_scan<kQT>(scanB, S, wtmp);
-        QSTAMP(5);
-        // (5) new list: children of the LAST processed node first (each as n4,n3,n2,n1), untouched entries after
-        int myexp = 0;
-        for (int i = t; i < S; i += kQT) {
-            const int r = procRank[i];
-            if (r < 0) {
-                const int p = totalChildren + scanB[i];
-                newpos[i] = p;
-                nbox[p] = box[i]; ncnt[p] = cnt[i]; ncrk[p] = crk[i];
-            } else {
-                const short4 b = box[i];
-                const short mx = (short)(b.x + ((b.z - b.x + 1) >> 1)), my = (short)(b.y + ((b.w - b.y + 1) >> 1));
-                const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
-                int p = totalChildren - (scanA[r] + ne);
-                for (int q = 3; q >= 0; q--) {
-                    const int c = childcnt[4 * i + q];
-                    if (c > 0) {
-                        short4 nb;
-                        nb.x = (q & 1) ? mx : b.x; nb.z = (q & 1) ? b.z : mx;
-                        nb.y = (q & 2) ? my : b.y; nb.w = (q & 2) ? b.w : my;
-                        nbox[p] = nb; ncnt[p] = c; ncrk[p] = 4 * r + q;
-                        childpos[4 * i + q] = p;
-                        p++;
-                        myexp += c > 1;
+        QSTAMP(3);
+        if (wv == 0) {
+            if (phase == 0) {
+                for (int j = lane; j < nCand; j += 64) order[j] = vlist[j];
+                QT_WAVE_FENCE();
+            }
+            // (4) growth prefix in processing order; the careful pass stops at the first prefix reaching N
+            for (int r = lane; r < nCand; r += 64) {
+                const int i = order[r];
+                scanA[r] = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
+            }
+            QT_WAVE_FENCE();
+            wave_excl_scan(scanA, nCand, lane);
+            int rstar = 0x7FFFFFFF;
+            if (phase == 1) {
+                for (int r = lane; r < nCand; r += 64) {
+                    const int i = order[r];
+                    const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
+                    if (S + scanA[r] + ne - (r + 1) >= N) rstar = min(rstar, r);
+                }
+                for (int d = 32; d >= 1; d >>= 1) rstar = min(rstar, __shfl_xor(rstar, d));
+            }
+            QSTAMP(4);
+            const int nProc = (phase == 1 && rstar != 0x7FFFFFFF) ? rstar + 1 : nCand;
+            int totalChildren = 0;
+            if (nProc > 0) {
+                const int i = order[nProc - 1];
+                totalChildren = scanA[nProc - 1] + (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
+            }
+            for (int r = lane; r < nProc; r += 64) procRank[order[r]] = r;
+            QT_WAVE_FENCE();
+            for (int i = lane; i < S; i += 64) scanB[i] = procRank[i] < 0 ? 1 : 0;
+            QT_WAVE_FENCE();
+            wave_excl_scan(scanB, S, lane);
+            QSTAMP(5);
+            // (5) new list: children of the LAST processed node first (each as n4,n3,n2,n1), untouched entries after
+            int myexp = 0;
+            for (int i = lane; i < S; i += 64) {
+                const int r = procRank[i];
+                if (r < 0) {
+                    const int p = totalChildren + scanB[i];
+                    newpos[i] = p;
+                    nbox[p] = box[i]; ncnt[p] = cnt[i]; ncrk[p] = crk[i];
+                } else {
+                    const short4 b = box[i];
+                    const short mx = (short)(b.x + ((b.z - b.x + 1) >> 1)), my = (short)(b.y + ((b.w - b.y + 1) >> 1));
+                    const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
+                    int p = totalChildren - (scanA[r] + ne);
+                    for (int q = 3; q >= 0; q--) {
+                        const int c = childcnt[4 * i + q];
+                        if (c > 0) {
+                            short4 nb;
+                            nb.x = (q & 1) ? mx : b.x; nb.z = (q & 1) ? b.z : mx;
+                            nb.y = (q & 2) ? my : b.y; nb.w = (q & 2) ? b.w : my;
+                            nbox[p] = nb; ncnt[p] = c; ncrk[p] = 4 * r + q;
+                            childpos[4 * i + q] = p;
+                            p++;
+                            myexp += c > 1;
+                        }
                     }
                 }
             }
+            for (int d = 32; d >= 1; d >>= 1) myexp += __shfl_xor(myexp, d);
+            // (7) upstream's termination tests (src/ORBextractor.cc:660-737)
+            if (lane == 0) {
+                const int S2 = totalChildren + S - nProc;
+                sh_S = S2;
+                if (S2 >= N || S2 == S) sh_done = 1;
+                else if (phase == 0 && S2 + 3 * myexp > N) sh_phase = 1;
+            }
         }
-        if (myexp) atomicAdd(&sh_nexp, myexp);
         __syncthreads();
         QSTAMP(6);
         // (6) re-home the candidates
         for (int k = t; k < M; k += kQT) {
             const int nd = nof[k];
             nof[k] = (unsigned short)(procRank[nd] >= 0 ? childpos[4 * nd + quadrant(keys[k], box[nd])] : newpos[nd]);
-        }
-        // (7) upstream's termination tests (src/ORBextractor.cc:660-737)
-        if (t == 0) {
-            const int S2 = totalChildren + S - nProc;
-            sh_S = S2;
-            if (S2 >= N || S2 == S) sh_done = 1;
-            else if (phase == 0 && S2 + 3 * sh_nexp > N) sh_phase = 1;
         }
         __syncthreads();
         QSTAMP(7);
@@ -1001,6 +1054,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
         int* ti = cnt; cnt = ncnt; ncnt = ti;
         ti = crk; crk = ncrk; ncrk = ti;
     }
+#undef QT_WAVE_FENCE
     // ---- best response per node, first candidate wins ties (strict '>' at src/ORBextractor.cc:752)
     const int S = sh_S;
     unsigned* best = reinterpret_cast<unsigned*>(scanB);
