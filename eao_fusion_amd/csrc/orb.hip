@@ -727,6 +727,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
 constexpr int kQTSmall = 1024, kQTLarge = 256;
 // In-place exclusive scan of a[0..n) by the whole kQT-thread block; returns the total.  Caller guarantees a[]
 // is fully written and visible (barrier) before the call; the function ends with a barrier.
+constexpr int kQtNodeInts = 2 + 2 + 2 + 4 + 4 + 5;   // per list entry next to its two boxes: cnt, crk, mid (x2 each), childcnt, childpos (x4), five work arrays
 template <int kQT>
 __device__ int block_excl_scan(int* a, int n, int* wtmp) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -787,6 +788,14 @@ __device__ __forceinline__ int wave_excl_scan(int* a, int n, int lane) {
     return total;
 }
 
+constexpr unsigned kQtLeaf = 0xFFFFFFFFu;          // mid of an entry that holds one key (every key then maps to quadrant 0)
+__device__ __forceinline__ unsigned box_mid(short4 bx) {
+    return (unsigned)(bx.x + ((bx.z - bx.x + 1) >> 1)) | ((unsigned)(bx.y + ((bx.w - bx.y + 1) >> 1)) << 16);
+}
+__device__ __forceinline__ int quadrant_mid(unsigned key, unsigned mid) {
+    const unsigned x = key & 0xFFF, y = (key >> 12) & 0xFFF;
+    return (x < (mid & 0xFFFFu) ? 0 : 1) + (y < (mid >> 16) ? 0 : 2);
+}
 __device__ __forceinline__ int quadrant(unsigned key, short4 bx) {
     const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
     const int mx = bx.x + ((bx.z - bx.x + 1) >> 1);   // UL.x + ceil((UR.x-UL.x)/2)
@@ -825,7 +834,9 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
     int* cnt1 = cnt0 + LC;
     int* crk0 = cnt1 + LC;
     int* crk1 = crk0 + LC;
-    int* childcnt = crk1 + LC;          // 4 per entry
+    unsigned* mid0 = reinterpret_cast<unsigned*>(crk1 + LC);   // split point of a multi-key entry (mx | my << 16), kQtLeaf otherwise
+    unsigned* mid1 = mid0 + LC;
+    int* childcnt = reinterpret_cast<int*>(mid1 + LC);          // 4 per entry
     int* childpos = childcnt + 4 * LC;  // 4 per entry
     unsigned long long* rkey = reinterpret_cast<unsigned long long*>(childpos);   // sort keys of a careful pass (before childpos is filled)
     int* newpos = childpos + 4 * LC;
@@ -877,7 +888,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
         int S = 0;
         for (int i = 0; i < nIni; i++) {
             newpos[i] = S;
-            if (cnt0[i] > 0) { box0[S] = box0[i]; cnt0[S] = cnt0[i]; crk0[S] = S; S++; }
+            if (cnt0[i] > 0) { box0[S] = box0[i]; cnt0[S] = cnt0[i]; crk0[S] = S; mid0[S] = cnt0[i] > 1 ? box_mid(box0[i]) : kQtLeaf; S++; }
         }
         sh_S = S; sh_phase = 0; sh_done = 0;
     }
@@ -890,6 +901,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
     QSTAMP(0);
     int diters = 0;
     short4* box = box0; short4* nbox = box1;
+    unsigned* mid = mid0; unsigned* nmid = mid1;
     int* cnt = cnt0; int* ncnt = cnt1;
     int* crk = crk0; int* ncrk = crk1;
     // Every pass: two sweeps over the M candidates by the whole workgroup (child histograms, re-homing) and, between them, the
@@ -928,10 +940,11 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
             int bin = -1;
             if (k < M) {
                 const int nd = nof[k];
-                if (cnt[nd] > 1) bin = 4 * nd + quadrant(keys[k], box[nd]);
+                const unsigned md = mid[nd];
+                if (md != kQtLeaf) bin = 4 * nd + quadrant_mid(keys[k], md);
             }
-            const int prev = __shfl_up(bin, 1);
-            const bool head = lane == 0 || bin != prev;
+            const int prev = __builtin_amdgcn_update_dpp(-2, bin, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -2): VALU, not the LDS crossbar
+            const bool head = bin != prev;
             const unsigned long long hm = __ballot(head);
             if (head && bin >= 0) {
                 const unsigned long long rest = lane == 63 ? 0ull : (hm >> (lane + 1));
@@ -1010,8 +1023,8 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
                 const int r = procRank[i];
                 if (r < 0) {
                     const int p = totalChildren + scanB[i];
-                    newpos[i] = p;
-                    nbox[p] = box[i]; ncnt[p] = cnt[i]; ncrk[p] = crk[i];
+                    nbox[p] = box[i]; ncnt[p] = cnt[i]; ncrk[p] = crk[i]; nmid[p] = mid[i];
+                    childpos[4 * i] = p; childpos[4 * i + 1] = p; childpos[4 * i + 2] = p; childpos[4 * i + 3] = p;   // (every key of an untouched entry moves with it)
                 } else {
                     const short4 b = box[i];
                     const short mx = (short)(b.x + ((b.z - b.x + 1) >> 1)), my = (short)(b.y + ((b.w - b.y + 1) >> 1));
@@ -1023,7 +1036,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
                             short4 nb;
                             nb.x = (q & 1) ? mx : b.x; nb.z = (q & 1) ? b.z : mx;
                             nb.y = (q & 2) ? my : b.y; nb.w = (q & 2) ? b.w : my;
-                            nbox[p] = nb; ncnt[p] = c; ncrk[p] = 4 * r + q;
+                            nbox[p] = nb; ncnt[p] = c; ncrk[p] = 4 * r + q; nmid[p] = c > 1 ? box_mid(nb) : kQtLeaf;
                             childpos[4 * i + q] = p;
                             p++;
                             myexp += c > 1;
@@ -1045,12 +1058,13 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
         // (6) re-home the candidates
         for (int k = t; k < M; k += kQT) {
             const int nd = nof[k];
-            nof[k] = (unsigned short)(procRank[nd] >= 0 ? childpos[4 * nd + quadrant(keys[k], box[nd])] : newpos[nd]);
+            nof[k] = (unsigned short)childpos[4 * nd + quadrant_mid(keys[k], mid[nd])];
         }
         __syncthreads();
         QSTAMP(7);
         diters++;
         short4* tb = box; box = nbox; nbox = tb;
+        unsigned* tm = mid; mid = nmid; nmid = tm;
         int* ti = cnt; cnt = ncnt; ncnt = ti;
         ti = crk; crk = ncrk; ncrk = ti;
     }
@@ -1082,7 +1096,7 @@ __device__ __noinline__ void quadtree_global(const Geom* __restrict__ g, const u
                                              unsigned* levelkps, int* levelcnt, int* candcnt, int f, int l, unsigned char* base, long long* dbg, int* wtmp, int* shv) {
     const int t = threadIdx.x;
     const LevelGeom L = g->L[l];
-    int* scanA = reinterpret_cast<int*>(base + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)));
+    int* scanA = reinterpret_cast<int*>(base + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * kQtNodeInts));
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
     for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
     __syncthreads();
@@ -1115,7 +1129,7 @@ __global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, co
                         (dbg && f == f0) ? dbg : nullptr, wtmp, shv);
         return;
     }
-    int* scanA = reinterpret_cast<int*>(smem + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)));
+    int* scanA = reinterpret_cast<int*>(smem + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * kQtNodeInts));
     const long long cslot = (long long)f * g->totalCells + L.cellBase;
     for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
     __syncthreads();
@@ -1852,14 +1866,14 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     g.fastTileBytes = ((maxSh * g.fastStride) + 15) & ~15;
     g.fastLdsBytes = g.fastTileBytes + ((2 * g.fastMaxTested + 15) & ~15) + ((((maxSw - 4) * (maxSh - 4)) + 15) & ~15) + 64;
     // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
-    h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (size_t)scanCap * sizeof(int);
+    h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * kQtNodeInts) + (size_t)scanCap * sizeof(int);
     g.qtNodesGlobal = 0; g.qtNodeFrameBytes = 0;
     if (h->quadLds > 100 * 1024) {   // (thousands of features on one level: upstream takes any N, src/ORBextractor.cc:539)
         g.qtNodesGlobal = 1;
         long long noff = 0;
         for (int l = 0; l < c.nlevels; l++) {
             g.L[l].nodeOff = noff;
-            noff += (((long long)g.L[l].listCap * (2 * sizeof(short4) + sizeof(int) * (2 + 2 + 4 + 4 + 5)) + (long long)scanCap * sizeof(int)) + 255) & ~255LL;
+            noff += (((long long)g.L[l].listCap * (2 * sizeof(short4) + sizeof(int) * kQtNodeInts) + (long long)scanCap * sizeof(int)) + 255) & ~255LL;
         }
         g.qtNodeFrameBytes = noff;
         h->quadLds = 0;
