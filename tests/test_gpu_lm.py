@@ -17,7 +17,7 @@ def gpu():
     return E
 
 
-def _check_trace(r, o, rel=1e-6):
+def _check_trace(r, o, rel=1e-6, lam_rel=5e-4):
     """LM control flow must match wherever it is well-conditioned: once chi2 stalls at the float32 noise floor
     (relative improvement < 1e-6) rho = (chi_old - chi_new)/scale is rounding noise and accept/reject is a coin flip
     in ANY implementation, so only the well-conditioned prefix of each optimize() call is compared."""
@@ -31,7 +31,9 @@ def _check_trace(r, o, rel=1e-6):
             break
         assert tg["trials"][k] == to["trials"][k], "trials differ at LM iteration %d" % k
         assert tg["chi2"][k] == pytest.approx(c, rel=rel), "chi2 differs at LM iteration %d" % k
-        assert tg["lam"][k] == pytest.approx(to["lam"][k], rel=2e-3), "lambda differs at LM iteration %d" % k
+        # (profiles/r02_lm_trace_sensitivity.txt: GPU vs oracle <= 5.1e-5 on these problems, where one float32 ulp on the inputs moves the
+        #  ORACLE's own lambda by up to 8e-3 -- lambda is a function of rho, a ratio of small differences)
+        assert tg["lam"][k] == pytest.approx(to["lam"][k], rel=lam_rel), "lambda differs at LM iteration %d" % k
         prev = c
 
 
@@ -97,7 +99,7 @@ def test_local_ba_rejected_trials(gpu, oracle, seed):
             assert err <= bound * upd, "%s: |gpu-cpu| %.3e vs update %.3e (band %.1e)" % (key, err, upd, CHAOTIC_BAND[seed])
         return
     assert list(r["iters"]) == list(o["iters"])
-    _check_trace(r, o, rel=1e-4)      # monocular-only windows this far from the optimum are ill-conditioned: rounding differences grow
+    _check_trace(r, o, rel=1e-4, lam_rel=2e-3)      # monocular-only windows this far from the optimum are ill-conditioned: rounding differences grow
     _check_updates(r["poses"], o["poses"], p["poses"], "poses")
     _check_updates(r["points"], o["points"], p["points"], "points")
     assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
@@ -112,7 +114,7 @@ def test_rejected_trials_on_the_map_scale_path(gpu, oracle, seed, monkeypatch):
     r = gpu.Optimizer.LocalBundleAdjustment(p)
     o = oracle.local_ba(p)
     assert list(r["iters"]) == list(o["iters"])
-    _check_trace(r, o, rel=1e-4)
+    _check_trace(r, o, rel=1e-4, lam_rel=2e-3)
     _check_updates(r["poses"], o["poses"], p["poses"], "poses")
     _check_updates(r["points"], o["points"], p["points"], "points")
     assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
