@@ -11,7 +11,7 @@
  *    thread-local message of the last failure.
  *  - the caller allocates all outputs; the library owns device memory inside handles.
  *  - "_device" variants take pointers that are already resident in HBM and a hipStream_t passed as void*
- *    (NULL = the handle's own stream); they enqueue work and do NOT synchronise.
+ *    (NULL = the null stream); they enqueue work on that stream and do NOT synchronise.
  *  - a handle is single-threaded (one HIP stream each); distinct handles are independent; the stateless
  *    functions are thread-safe.
  *  - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
@@ -89,8 +89,10 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
 
 /* Same, all pointers device-resident (HBM), asynchronous on `stream` (a hipStream_t; NULL = the null stream, exactly as the
  * Hamming entry points read it): whatever the caller enqueues on that stream afterwards is ordered behind the extraction.
- * Calls on one handle are serialised with each other even when they come in on different streams (they share the handle's
- * pyramid and candidate scratch).  d_n: batch int32 on the device. */
+ * The main chain of the call's kernels is enqueued on `stream` ITSELF (a private side stream of the handle, forked from and
+ * joined back into it with events, carries the part that runs beside it), so consecutive calls on one stream follow each
+ * other without a cross-stream hop.  Calls on one handle are serialised with each other even when they come in on different
+ * streams (they share the handle's pyramid and candidate scratch).  d_n: batch int32 on the device. */
 eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_t width, int32_t height,
                                         int32_t stride, int64_t frame_stride, int32_t batch, eao_keypoint* d_kps,
                                         uint8_t* d_desc, int32_t cap, int32_t* d_n, void* stream);
