@@ -43,8 +43,9 @@ sq = {"_note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python3 bench.
 stage = {"k_resize": "k_resize", "k_fast_cells": "k_fast_cells<true, 48>", "k_quadtree": "k_quadtree", "k_blur7": "k_blur7", "k_orient_describe": "k_orient_describe"}
 lines = []
 for name, row in stage.items():
-    ra = a.get(row) or next((v for k, v in a.items() if k.startswith(name + "<true")), None) or a.get(name)
-    rb = b.get(row) or next((v for k, v in b.items() if k.startswith(name + "<true")), None) or b.get(name)
+    pick = lambda t: (t.get(row) or next((v for k, v in t.items() if k.startswith(name + "<true")), None) or t.get(name)
+                      or next((v for k, v in t.items() if k.startswith(name + "<")), None))      # (k_quadtree<256>: a template since round 2)
+    ra, rb = pick(a), pick(b)
     if not ra:
         continue
     d = {k: v for k, v in ra.items() if k != "launches"}
