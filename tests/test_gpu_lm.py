@@ -379,6 +379,23 @@ def test_local_ba_batch_stop_and_empty(gpu):
     assert gpu.Optimizer.LocalBundleAdjustmentBatch([]) == []
 
 
+def test_local_ba_batch_error_in_one_window_leaves_the_library_usable(gpu):
+    """A window that fails validation (two edges on one camera / point pair) fails the whole call loudly -- its group stops,
+    the other groups' streams are drained -- and the next call on the same thread is unaffected."""
+    probs = [synth.synth_ba(n_free=5, n_fixed=2, n_points=300, seed=6300 + w) for w in range(9)]
+    good = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
+    bad = dict(probs[5])
+    k = int(np.flatnonzero(bad["fixed"][bad["edge_cam"]] == 0)[-1])       # an edge of a free camera
+    for key in ("edge_cam", "edge_point", "obs", "inv_sigma2"):
+        bad[key] = np.concatenate([bad[key], bad[key][k:k + 1]])
+    with pytest.raises(gpu.EaoError):
+        gpu.Optimizer.LocalBundleAdjustmentBatch(probs[:5] + [bad] + probs[6:])
+    again = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
+    for a, b in zip(good, again):
+        assert np.array_equal(a["poses"].view(np.uint32), b["poses"].view(np.uint32)) and np.array_equal(a["points"].view(np.uint32), b["points"].view(np.uint32))
+        assert list(a["iters"]) == list(b["iters"])
+
+
 def test_map_scale_ba_with_an_abort_flag_that_is_never_raised(gpu):
     """Map-scale runs poll *stop between LM iterations (one iteration per enqueue, like g2o's forceStopFlag) instead of
     submitting the whole optimize() speculatively: an un-raised flag must not change a bit."""
