@@ -38,6 +38,7 @@ constexpr int kTile = 72;              // max FAST sub-image edge (cell <= 60 px
 // (tested region of a cell = sub-image minus the 3 px FAST margin on every side: at most 66 x 66)
 constexpr int kTileStrideWide = 80;    // LDS row stride of the widest tile: 72 + up to 3 bytes of alignment phase, multiple of 4
 constexpr int kMaxIni = 16;
+constexpr size_t kPinnedOutMax = 1 << 20;   // host-API calls whose results fit go through mapped pinned memory (eao_orb_extract_batch)
 constexpr int kFastXcdRun = 0;         // 0 = plain workgroup -> cell order (see k_fast_cells)
 
 __constant__ __align__(16) signed char c_pattern[1024] = {
@@ -1682,6 +1683,8 @@ struct eao_orb {
     eao::DevBuf<unsigned char> d_qtnodes;   // global node lists (only when they do not fit in LDS)
     eao::DevBuf<int> d_cellcnt, d_levelcnt, d_candcnt, d_nout;
     eao::DevBuf<eao_keypoint> d_kps;
+    unsigned char* pinOut = nullptr;       // mapped pinned host memory: results of small host-API calls land here directly
+    size_t pinOutCap = 0;
     eao::DevBuf<uint8_t> d_desc;
     eao::DevBuf<float> d_xyr;
     eao::DevBuf<unsigned char> d_stereo;   // staging of eao_compute_stereo_matches
@@ -2250,6 +2253,7 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
+    if (h->pinOut) (void)hipHostFree(h->pinOut);
     if (h->evStart) (void)hipEventDestroy(h->evStart);
     if (h->evLast) (void)hipEventDestroy(h->evLast);
     if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
@@ -2313,9 +2317,40 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
     if ((st = h->d_desc.reserve(B * (size_t)cap * 32))) return st;
     if ((st = h->d_nout.reserve(B))) return st;
     const long long fs0 = (long long)g.L[0].pitch * height;
-    for (int f = 0; f < batch; f++)
-        EAO_HIP(hipMemcpy2DAsync(h->d_in.p + f * fs0, g.L[0].pitch, img + (long long)f * frame_stride, stride, width, height,
-                                 hipMemcpyHostToDevice, h->stream));
+    if (stride == g.L[0].pitch && (batch == 1 || frame_stride == fs0)) {     // contiguous frames: one linear copy
+        EAO_HIP(hipMemcpyAsync(h->d_in.p, img, B * (size_t)fs0, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int f = 0; f < batch; f++)
+            EAO_HIP(hipMemcpy2DAsync(h->d_in.p + f * fs0, g.L[0].pitch, img + (long long)f * frame_stride, stride, width, height,
+                                     hipMemcpyHostToDevice, h->stream));
+    }
+    // Small calls (the per-frame latency path): the last kernel writes keypoints, descriptors and counts straight into mapped
+    // pinned host memory -- ~70 KB per frame over PCIe -- and the rows that exist are copied to the caller's (pageable) arrays
+    // after the one synchronisation: three pageable device-to-host copies (~15 us each) gone.  Large batches keep the DMA path.
+    const size_t outBytes = B * sizeof(int) + 64 + B * (size_t)cap * (sizeof(eao_keypoint) + 32);
+    static const bool envNoPinned = getenv("EAO_ORB_PINNED_OUT") && !atoi(getenv("EAO_ORB_PINNED_OUT"));      // (A/B switch)
+    if (outBytes <= kPinnedOutMax && !envNoPinned) {
+        if (h->pinOutCap < outBytes) {
+            if (h->pinOut) (void)hipHostFree(h->pinOut);
+            h->pinOut = nullptr; h->pinOutCap = 0;
+            EAO_HIP(hipHostMalloc((void**)&h->pinOut, outBytes, hipHostMallocMapped));
+            h->pinOutCap = outBytes;
+        }
+        unsigned char* dv = nullptr;
+        EAO_HIP(hipHostGetDevicePointer((void**)&dv, h->pinOut, 0));
+        const size_t offK = (B * sizeof(int) + 63) & ~(size_t)63, offD = offK + B * (size_t)cap * sizeof(eao_keypoint);
+        st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, batch, (eao_keypoint*)(dv + offK), dv + offD, cap, (int*)dv, h->stream);
+        if (st) return st;
+        EAO_HIP(hipStreamSynchronize(h->stream));
+        const int* hn = (const int*)h->pinOut;
+        for (int f = 0; f < batch; f++) {
+            const int nf = std::min(std::max(hn[f], 0), cap);
+            n[f] = nf;
+            std::memcpy(kps + (size_t)f * cap, h->pinOut + offK + (size_t)f * cap * sizeof(eao_keypoint), (size_t)nf * sizeof(eao_keypoint));
+            std::memcpy(desc + (size_t)f * cap * 32, h->pinOut + offD + (size_t)f * cap * 32, (size_t)nf * 32);
+        }
+        return EAO_OK;
+    }
     st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, batch, h->d_kps.p, h->d_desc.p, cap, h->d_nout.p, h->stream);
     if (st) return st;
     EAO_HIP(hipMemcpyAsync(n, h->d_nout.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
