@@ -1992,7 +1992,10 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     lanes = std::max(1, std::min(std::min(eao_orb::kLanes, batch), lanes));
     // the handle's pyramid / candidate scratch is shared by its calls: a call enqueued on another stream than the previous
     // one waits for it (same stream: already ordered, the wait costs nothing)
-    if (h->evLastValid && !h->capturing && h->lastStream != st) EAO_HIP(hipStreamWaitEvent(st, h->evLast, 0));
+    // (no event is recorded at the end of a call for this: an event record between two kernels of a stream costs ~5 us on this
+    //  runtime, every call would pay it, and consecutive calls on one handle almost always share their stream -- the rare
+    //  change of stream waits for the previous one on the host instead)
+    if (h->evLastValid && !h->capturing && h->lastStream != st) EAO_HIP(hipStreamSynchronize(h->lastStream));
     h->lastStream = st;
     EAO_HIP(hipEventRecord(h->evStart, st));
     for (int i = 0; i < lanes; i++) {
@@ -2151,7 +2154,6 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     }
     if (prof) EAO_HIP(hipEventRecord(ev[8], st));
     if (!h->capturing) {
-        EAO_HIP(hipEventRecord(h->evLast, st));
         h->evLastValid = true;
     }
     EAO_HIP(hipGetLastError());
