@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
     // work items = (group of kResizeRows output rows) x (4-pixel group), dealt to the lanes in one flat sequence: with a
     // 256-pixel-wide block per row group the levels whose width is just above a multiple of 256 left up to half of the
     // lanes idle (257 px -> two blocks; measured 240 -> 181 us for the seven launches of a 256-frame batch)
-    const int item = bxi * 256 + threadIdx.y * 64 + threadIdx.x;
+    const int item = (bxi * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x;
     const int rg = (int)(((float)item + 0.5f) * A.invG);
     const int dyb = rg * kResizeRows;
     const int dx0 = (item - rg * A.G) * 4;
@@ -2098,7 +2098,13 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         }
         for (int l = 1; l < g.nlevels; l++) {
             const int G4 = eao::cdiv(g.L[l].w, 4);
-            dim3 grid(eao::cdiv(G4 * eao::cdiv(g.L[l].h, kResizeRows), 256), 1, nb), block(64, 4);
+            // ONE-WAVE workgroups: the chain's small launches run beside FAST launches that fill every CU with one-wave workgroups;
+            // a 256-thread workgroup needs four wave slots free on ONE CU at the same moment and kept losing them to the next FAST
+            // wave -- levels 2 and 4 took 32 / 37 us instead of 9, and the pyramid was the critical path of the step up to 121 us
+            // (64 frames: 0.296 -> 0.279 ms per step; EAO_RESIZE_WAVES=4 restores the 256-thread workgroups)
+            static const int envRW = getenv("EAO_RESIZE_WAVES") ? atoi(getenv("EAO_RESIZE_WAVES")) : 1;
+            const int rw = envRW == 2 || envRW == 4 ? envRW : 1;
+            dim3 grid(eao::cdiv(G4 * eao::cdiv(g.L[l].h, kResizeRows), 64 * rw), 1, nb), block(64, rw);
             ResizeArgs ra;
             ra.G = G4; ra.invG = 1.0f / (float)G4;
             ra.D = {g.L[l].w, g.L[l].h, g.L[l].pitch, g.L[l].off};
