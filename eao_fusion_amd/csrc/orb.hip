@@ -2137,8 +2137,15 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             if (pe) EAO_HIP(hipEventRecord(ev[9], ms));
             fast(ms, 0, g.totalCells);
         } else {
+            // The blur's fork point is the END OF THE PYRAMID, not the end of the main stream's FAST: on the side stream the blur
+            // follows the quad-trees of the lower levels in stream order, which end when the main stream's FAST does, so the
+            // blur still runs beside the upper levels' quad-trees -- but without a cross-stream hand-over (~10 us) in front of
+            // it (64 frames: 0.2784 -> 0.2762 ms, 256 frames: 1.092 -> 1.071; measured the other way round before the resize
+            // launches became one-wave workgroups, when the pyramid ended 20 us later).  EAO_ORB_BLUR_EARLY=0 restores the old point.
+            static const int envBlurEarly = getenv("EAO_ORB_BLUR_EARLY") ? atoi(getenv("EAO_ORB_BLUR_EARLY")) : 1;
+            if (envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
             fast(ms, early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
-            EAO_HIP(hipEventRecord(h->evFork[i], ms));            // the pyramid and the main stream's FAST are done
+            if (!envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
             EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
             { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
