@@ -409,10 +409,10 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     eao::Range rg("track: frame -> frustum -> search -> pose");
     const eao_tracker_cfg& c = h->cfg;
     const int C = h->cap, nMp = h->nMp;
-    hipStream_t s = h->stream;
-    // ordered behind whatever produced the inputs on the caller's stream (the extraction)
-    EAO_HIP(hipEventRecord(h->evIn, (hipStream_t)stream));
-    EAO_HIP(hipStreamWaitEvent(s, h->evIn, 0));
+    // The chain runs on the CALLER's stream itself: it is ordered behind whatever produced the inputs there (the extraction)
+    // without an event hand-over to a private stream and back (~10 us each on this runtime).  The handle's own stream only
+    // carries the local-map uploads, which eao_tracker_set_local_map waits for.
+    hipStream_t s = (hipStream_t)stream;
     if (prior_kp_map_point) {
         std::memcpy(h->pin, prior_kp_map_point, 4 * (size_t)C);
         EAO_HIP(hipMemcpyAsync(h->prior, h->pin, 4 * (size_t)C, hipMemcpyHostToDevice, s));
@@ -501,9 +501,6 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
         out->n_inliers = nEdges - rr[0];
         std::memcpy(out->kp_outlier, p + ((unsigned char*)rOutl - r), C);
     }
-    // the caller's stream continues behind the chain (its inputs may be reused)
-    EAO_HIP(hipEventRecord(h->evOut, s));
-    EAO_HIP(hipStreamWaitEvent((hipStream_t)stream, h->evOut, 0));
     return EAO_OK;
 }
 

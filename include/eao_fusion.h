@@ -482,7 +482,8 @@ typedef struct {
  * count); d_depth: the float depth image on the device (rows of depth_pitch floats) or NULL (monocular: mvuRight = -1);
  * Tcw_prior: the pose the frame enters TrackLocalMap with; prior_kp_map_point: mvpMapPoints as it stands (host array
  * [max_keypoints], NULL = none) -- those keypoints are occupied, their map points are not searched again, and they are
- * edges of the pose optimisation.  `stream`: the stream the extraction was enqueued on (the chain waits for it). */
+ * edges of the pose optimisation.  `stream`: the stream the extraction was enqueued on -- the chain is enqueued on
+ * that stream itself (ordered behind the extraction without an event hand-over); the call returns when the results are on the host. */
 eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
                                        const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
                                        const int32_t* prior_kp_map_point, float th, float nnratio, eao_track_result* out, void* stream);
