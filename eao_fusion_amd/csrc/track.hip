@@ -44,10 +44,12 @@ struct eao_tracker {
     Query* q; unsigned* lists; int *segStart, *segCount, *cursor; int* match;
     double *eXw, *eObs, *eInfo, *eErr; unsigned char *eFlags, *eOutl; int* eKp;
     float* dScale; float* dInvSigma2;
-    unsigned char* res;                // result block (device), resBytes
+    unsigned char* res = nullptr;      // result block: device view of resPin, resBytes
+    unsigned char* resPin = nullptr;
     size_t resBytes = 0, listCap = 0;
     ~eao_tracker() {
         if (pin) (void)hipHostFree(pin);
+        if (resPin) (void)hipHostFree(resPin);
         if (evIn) (void)hipEventDestroy(evIn);
         if (evOut) (void)hipEventDestroy(evOut);
         if (stream) (void)hipStreamDestroy(stream);
@@ -346,7 +348,6 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
                  oSc = take(4 * 64), oIs = take(4 * 64);
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
     h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C);
-    const size_t oRes = take(h->resBytes);
     if ((st = h->dev.reserve(off))) { delete h; return st; }
     unsigned char* b = h->dev.p;
     h->kx = (float*)(b + oKx); h->ky = (float*)(b + oKy); h->ang = (float*)(b + oAng); h->ur = (float*)(b + oUr); h->dz = (float*)(b + oDz);
@@ -359,7 +360,11 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     h->cursor = (int*)(b + oCur); h->match = (int*)(b + oMatch);
     h->eXw = (double*)(b + oEX); h->eObs = (double*)(b + oEO); h->eInfo = (double*)(b + oEI); h->eErr = (double*)(b + oEE); h->eFlags = b + oEF;
     h->eOutl = b + oEOu; h->eKp = (int*)(b + oEK); h->dScale = (float*)(b + oSc); h->dInvSigma2 = (float*)(b + oIs);
-    h->res = b + oRes;
+    // the result block is MAPPED PINNED HOST memory: the last kernels of the chain write it over PCIe (~30 KB) and the host reads it
+    // after the one synchronisation -- no device-to-host copy behind the chain
+    if (hipHostMalloc((void**)&h->resPin, h->resBytes, hipHostMallocMapped) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
+    std::memset(h->resPin, 0, h->resBytes);
+    if (hipHostGetDevicePointer((void**)&h->res, h->resPin, 0) != hipSuccess) { delete h; eao::set_error("hipHostGetDevicePointer failed"); return EAO_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evOut, hipEventDisableTiming) != hipSuccess) { delete h; eao::set_error("stream / event creation failed"); return EAO_ERR_NO_DEVICE; }
     h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C)) + 4096;
@@ -467,7 +472,6 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     unsigned char* rOutl = r + ro; ro += al256(C);
     float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
-    EAO_HIP(hipMemsetAsync(rRes, 0, 16, s));
     EAO_HIP(hipMemsetAsync(h->eOutl, 0, C, s));
     eao::lm::PoseChainArgs PA;
     PA.nEdges = h->counts + 2; PA.cap = edgeCap;
@@ -478,11 +482,10 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     if ((st = eao::lm::enqueue_pose_device(PA, s))) return st;
     hipLaunchKernelGGL(k_track_finish, dim3(eao::cdiv(std::max(C, 8), 256)), dim3(256), 0, s, C, h->counts, h->kpMp, h->eKp, h->eOutl, h->ur, h->dz, rCounts,
                        rKpMp, rOutl, rUr, rDz);
-    // ---- the ONE copy back
-    EAO_HIP(hipMemcpyAsync(h->pin, h->res, h->resBytes, hipMemcpyDeviceToHost, s));
+    // ---- the results are in host memory when the stream has drained
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
-    const unsigned char* p = h->pin;
+    const unsigned char* p = h->resPin;
     const int* oc = (const int*)(p + ((unsigned char*)rCounts - r));
     const int n = oc[0], nEdges = oc[2];
     EAO_REQUIRE(!(oc[4] & 1), "a map point in view has a predicted level outside the pyramid (upstream would index mvScaleFactors out of range)");
