@@ -42,7 +42,7 @@ struct FrameDevArgs {             // a frame in the layout k_match_candidates wa
 // candidate lists of nq device-resident queries: out (packed distance << 16 | keypoint), segStart / segCount per query,
 // cursor (zeroed here)
 eao_status enqueue_candidates_device(const FrameDevArgs& F, const Query* q, const uint8_t* qdesc, int nq, unsigned* out, int outCap,
-                                     int* segStart, int* segCount, int* cursor, hipStream_t s);
+                                     int* segStart, int* segCount, int* cursor, hipStream_t s, bool cursorIsZero = false);
 }  // namespace match
 
 }  // namespace eao

@@ -268,14 +268,14 @@ eao_status eao::match::pair_distances(const uint8_t* descA, int nA, const uint8_
 
 #include "chain_internal.h"
 eao_status eao::match::enqueue_candidates_device(const FrameDevArgs& F, const Query* q, const uint8_t* qdesc, int nq, unsigned* out, int outCap,
-                                                 int* segStart, int* segCount, int* cursor, hipStream_t s) {
+                                                 int* segStart, int* segCount, int* cursor, hipStream_t s, bool cursorIsZero) {
     if (nq <= 0) return EAO_OK;
     FrameDev D;
     D.n = F.cap; D.nOrdered = 0; D.nOrderedDev = F.nOrdered;
     D.kx = F.kx; D.ky = F.ky; D.oct = F.oct; D.ur = F.ur; D.desc = (const uint4*)F.desc;
     D.order = F.order; D.cellx = F.cellx; D.celly = F.celly;
     D.minX = F.minX; D.minY = F.minY; D.invW = F.invW; D.invH = F.invH; D.cols = F.cols; D.rows = F.rows;
-    EAO_HIP(hipMemsetAsync(cursor, 0, sizeof(int), s));
+    if (!cursorIsZero) EAO_HIP(hipMemsetAsync(cursor, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, q, (const uint4*)qdesc, nq, out, outCap, segStart, segCount, cursor);
     EAO_HIP(hipGetLastError());
     return EAO_OK;

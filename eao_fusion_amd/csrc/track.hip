@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256) void k_track_queries(int nMp, const unsigned c
                                                        const float* __restrict__ projY, const float* __restrict__ projXR,
                                                        const float* __restrict__ viewCos, const int* __restrict__ level,
                                                        const float* __restrict__ scale, int nlevels, float th, Query* __restrict__ q,
-                                                       int* __restrict__ counts) {
+                                                       int* __restrict__ counts, int* __restrict__ cursor) {
     const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m == 0) *cursor = 0;             // k_match_candidates' list cursor (instead of a fill launch in front of it)
     if (m >= nMp) return;
     Query Q;
     Q.active = (active[m] && inView[m] && !skip[m]) ? 1 : 0;
@@ -255,10 +256,12 @@ constexpr int kEdgeThreads = 1024;
 __global__ __launch_bounds__(kEdgeThreads) void k_track_edges(int nMp, int cap, const int* __restrict__ match, int* __restrict__ kpMp,
                                                               const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ ur,
                                                               const int* __restrict__ oct, const float* __restrict__ mXw,
-                                                              const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, int* __restrict__ counts) {
+                                                              const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, int* __restrict__ counts,
+                                                              unsigned char* __restrict__ eOutl) {
     __shared__ int s_wsum[kEdgeThreads / 64], s_base;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int n = counts[0];
+    for (int k = t; k < cap; k += kEdgeThreads) eOutl[k] = 0;      // (instead of a fill launch in front of PoseOptimization)
     for (int m = t; m < nMp; m += kEdgeThreads) {
         const int k = match[m];
         if (k >= 0) kpMp[k] = m;          // (a keypoint is claimed by at most one point)
@@ -445,13 +448,13 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
         F.inView = h->inView; F.projX = h->projX; F.projY = h->projY; F.projXR = h->projXR; F.viewCos = h->viewCos; F.level = h->level;
         if ((st = eao::frame::enqueue_frustum_device(F, s))) return st;
         hipLaunchKernelGGL(k_track_queries, dim3(eao::cdiv(nMp, 256)), dim3(256), 0, s, nMp, h->mActive, h->mSkip, h->inView, h->projX, h->projY, h->projXR,
-                           h->viewCos, h->level, h->dScale, c.nlevels, th, h->q, h->counts);
+                           h->viewCos, h->level, h->dScale, c.nlevels, th, h->q, h->counts, h->cursor);
         eao::match::FrameDevArgs FD;
         FD.cap = C; FD.nOrdered = h->counts + 1; FD.kx = h->kx; FD.ky = h->ky; FD.oct = h->oct; FD.ur = h->ur; FD.desc = d_desc;
         FD.order = h->order; FD.cellx = h->cellx; FD.celly = h->celly;
         FD.minX = c.min_x; FD.minY = c.min_y; FD.invW = invW; FD.invH = invH; FD.cols = c.grid_cols; FD.rows = c.grid_rows;
         if ((st = eao::match::enqueue_candidates_device(FD, h->q, h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
-                                                        h->segCount, h->cursor, s))) return st;
+                                                        h->segCount, h->cursor, s, true))) return st;
         hipLaunchKernelGGL(k_track_assign, dim3(1), dim3(kAssignThreads), (size_t)C * 5, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
                            nnratio, h->match, h->counts);
     }
@@ -459,7 +462,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     E.Xw = h->eXw; E.obs = h->eObs; E.info = h->eInfo; E.flags = h->eFlags; E.eKp = h->eKp;
     const int edgeCap = std::min(C, 2048);
     hipLaunchKernelGGL(k_track_edges, dim3(1), dim3(kEdgeThreads), 0, s, nMp, C, h->match, h->kpMp, h->kx, h->ky, h->ur, h->oct, h->mXw, h->dInvSigma2, E,
-                       edgeCap, h->counts);
+                       edgeCap, h->counts, h->eOutl);
     // result block layout
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
     unsigned char* r = h->res;
@@ -472,7 +475,6 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     unsigned char* rOutl = r + ro; ro += al256(C);
     float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
-    EAO_HIP(hipMemsetAsync(h->eOutl, 0, C, s));
     eao::lm::PoseChainArgs PA;
     PA.nEdges = h->counts + 2; PA.cap = edgeCap;
     PA.Xw = h->eXw; PA.obs = h->eObs; PA.info = h->eInfo; PA.flags = h->eFlags; PA.err = h->eErr; PA.outlier = h->eOutl;
