@@ -2942,10 +2942,16 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
         }
     }
     EAO_HIP(hipEventRecord(c.ev0, c.stream));
-    EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
+    // The register variants read every input exactly once: they take it straight from the pinned mirror over PCIe (~60 KB) --
+    // an upload in front of the kernel is a copy-engine job plus a hand-over to the compute queue (~10 us).  The memory
+    // variant walks the edges in every LM pass and gets its copy.
+    static const bool envUpload = getenv("EAO_POSE_UPLOAD") && atoi(getenv("EAO_POSE_UPLOAD")) != 0;      // (A/B switch)
+    const bool zeroCopy = n <= 4 * kPoseThreads && M == 0 && !envUpload;      // (plane coefficients are re-read in every pass: uploaded)
+    if (!zeroCopy) EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
     PoseDev P;
     P.nDev = nullptr;
     P.n = n; P.Xw = dXw; P.obs = dobs; P.info = dinfo; P.err = derr; P.flags = dflags; P.outlier = ooutl;
+    if (zeroCopy) { P.Xw = (const double*)hostp(dXw); P.obs = (const double*)hostp(dobs); P.info = (const double*)hostp(dinfo); P.flags = (unsigned char*)hostp(dflags); }
     P.T0 = se3_from_Tcw_f32(p->Tcw);
     P.cam.fx = p->fx; P.cam.fy = p->fy; P.cam.cx = p->cx; P.cam.cy = p->cy; P.cam.bf = p->bf; P.cam.bf_f = p->bf;
     P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
@@ -3047,6 +3053,7 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
         }
         auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
         PoseDev* hW = (PoseDev*)hostp(dW);
+        const bool zeroCopy = false;       // (the single call reads its inputs from the pinned mirror; for a batch it was measured and makes no difference)
         size_t oo = 0;
         const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0;     // src/Optimizer.cc:464-465
         for (size_t k = 0; k < slots.size(); k++) {
@@ -3079,6 +3086,9 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
             std::memset((void*)&P, 0, sizeof(PoseDev));
             P.nDev = nullptr;
             P.n = n; P.Xw = s.Xw; P.obs = s.obs; P.info = s.info; P.err = s.err; P.flags = s.flags; P.outlier = opl + kPoseMaxPlanes;
+            if (zeroCopy) {     // (read once by the register kernels: straight from the pinned mirror, the transfer overlaps other frames' LM)
+                P.Xw = (const double*)hostp(s.Xw); P.obs = (const double*)hostp(s.obs); P.info = (const double*)hostp(s.info); P.flags = (unsigned char*)hostp(s.flags);
+            }
             P.T0 = se3_from_Tcw_f32(p->Tcw);
             P.cam.fx = p->fx; P.cam.fy = p->fy; P.cam.cx = p->cx; P.cam.cy = p->cy; P.cam.bf = p->bf; P.cam.bf_f = p->bf;
             P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
@@ -3088,11 +3098,13 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
         }
         g_trace.clear();
         EAO_HIP(hipEventRecord(c.ev0, c.stream));
-        EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
+        const PoseDev* kW = dW;
+        if (zeroCopy) kW = hW;          // (the records too)
+        else EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
         if (!grp[0].empty())
-            hipLaunchKernelGGL(k_pose_optimization_batch<2>, dim3((unsigned)grp[0].size()), dim3(kPoseThreads), 0, c.stream, dW);
+            hipLaunchKernelGGL(k_pose_optimization_batch<2>, dim3((unsigned)grp[0].size()), dim3(kPoseThreads), 0, c.stream, kW);
         if (!grp[1].empty())
-            hipLaunchKernelGGL(k_pose_optimization_batch<4>, dim3((unsigned)grp[1].size()), dim3(kPoseThreads), 0, c.stream, dW + grp[0].size());
+            hipLaunchKernelGGL(k_pose_optimization_batch<4>, dim3((unsigned)grp[1].size()), dim3(kPoseThreads), 0, c.stream, kW + grp[0].size());
         EAO_HIP(hipEventRecord(c.ev1, c.stream));
         EAO_HIP(hipStreamSynchronize(c.stream));
         EAO_HIP(hipGetLastError());
