@@ -822,8 +822,11 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
     const Geom* __restrict__ g = A.g;
     int& sh_S = shv[0]; int& sh_phase = shv[1]; int& sh_done = shv[2]; int& sh_rstar = shv[3]; int& sh_nexp = shv[4];
     long long* dbg = A.dbg;
-    long long dacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dlast = clock64();
-#define QSTAMP(i) do { if (dbg) { const long long now_ = clock64(); dacc[i] += now_ - dlast; dlast = now_; } } while (0)
+    // (phase stamps of diagnostic runs, thread 0 only, kept in LDS: as per-thread registers they cost 22 VGPRs of a kernel that
+    //  spills at 1024 threads)
+    __shared__ long long dacc[11];
+    if (dbg && threadIdx.x == 0) { for (int i = 0; i < 10; i++) dacc[i] = 0; dacc[10] = clock64(); }
+#define QSTAMP(i) do { if (dbg && threadIdx.x == 0) { const long long now_ = clock64(); dacc[i] += now_ - dacc[10]; dacc[10] = now_; } } while (0)
     const int t = threadIdx.x, lane = t & 63;
     const int l = A.l, f = A.f, M = A.M;
     const LevelGeom L = g->L[l];
