@@ -1115,7 +1115,7 @@ __device__ __noinline__ void quadtree_global(const Geom* __restrict__ g, const u
 }
 
 template <int kQT>
-__global__ __launch_bounds__(kQT) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
+__global__ __launch_bounds__(kQT, kQT == 256 ? 4 : 1) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
                                                   const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
                                                   unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
                                                   int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0, long long* dbg, int l0,
