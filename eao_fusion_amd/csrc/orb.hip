@@ -2041,7 +2041,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         auto quadtree = [&](hipStream_t str, int lFirst, int nLev) {
             eao::Range rg("orb: quad-tree");
-            if (nb < 48) hipLaunchKernelGGL(k_quadtree<kQTSmall>, dim3(nb, nLev), dim3(kQTSmall), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
+            if (nb < 36) hipLaunchKernelGGL(k_quadtree<kQTSmall>, dim3(nb, nLev), dim3(kQTSmall), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
                                h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst, h->d_qtnodes.p);
             else hipLaunchKernelGGL(k_quadtree<kQTLarge>, dim3(nb, nLev), dim3(kQTLarge), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
                                h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst, h->d_qtnodes.p);
