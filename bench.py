@@ -636,14 +636,14 @@ def measure_extra(E, synth, torch, dev):
 
             def step2():
                 ext2.extract_batch_device(d2.data_ptr(), 640, 480, 640, 640 * 480, B2, k2.data_ptr(), e2.data_ptr(), cap2, n2.data_ptr(), st2)
-            for _ in range(3):
+            for _ in range(20):           # (allocations on the first call, then the clocks: see SETTLE_STEPS)
                 step2()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(20):
+            for _ in range(30):
                 step2()
             torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t0) / 20
+            dt2 = (time.perf_counter() - t0) / 30
             extra["orb_batch256"] = {"ms_per_step": round(dt2 * 1e3, 4), "kpts_per_s": round(float(n2.sum().item()) / dt2, 1), "frames_per_step": B2}
             del ext2, d2, k2, e2, n2
         except Exception as ex:  # noqa: BLE001
