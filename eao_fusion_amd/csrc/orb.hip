@@ -1401,12 +1401,19 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     const int f = fy + f0;
     // level of compact index j: the level counts are wave-uniform -- independent scalar loads and a running sum on the
     // scalar unit (the first version scanned them across lanes: four ds_bpermute round trips before anything else could start)
-    int total = 0, l = 0, lbase = 0;
-#pragma unroll
-    for (int q = 0; q < kMaxLevels; q++) {
-        const int cq = q < nlevels ? levelcnt[f * nlevels + q] : 0;
-        total += cq;
-        if (q < nlevels && total <= j) { l = q + 1; lbase = total; }   // levels that end at or before j
+    // (lanes 0 .. nlevels-1 hold the level counts, an inclusive DPP scan inside the 16-lane row gives the level ends, a ballot
+    //  counts the levels that end at or before j: a dozen instructions.  As a scalar loop over the sixteen possible levels it
+    //  was ~90 SALU instructions per wave, in a kernel that issues as many scalar as vector instructions -- one scalar unit per CU)
+    int total, l, lbase;
+    {
+        int inc = lane < nlevels ? levelcnt[f * nlevels + lane] : 0;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);   // row_shr:1
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);   // row_shr:2
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);   // row_shr:4
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);   // row_shr:8
+        total = __builtin_amdgcn_readlane(inc, 15);
+        l = (int)__popcll(__ballot(lane < nlevels && inc <= j));                // levels that end at or before j
+        lbase = l > 0 ? __builtin_amdgcn_readlane(inc, min(l, kMaxLevels) - 1) : 0;
     }
     if (bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
     if (l >= nlevels || jout >= cap) return;
