@@ -762,9 +762,21 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
     __shared__ double s_x[6];
     __shared__ double s_lambda, s_ni, s_rho, s_cur, s_tmp;
     __shared__ int s_ok, s_flag, s_nbad, s_ntrace, s_iters, s_active;
+    // plane edges exactly as in the register variant: thread 13 p + v evaluates plane p at the pose perturbed along variant v
+    // (g2o's central-difference Jacobian, core/base_binary_edge.hpp:131-205); thread p owns the edge
+    __shared__ double s_pvar[kPoseMaxPlanes * 13 * 3];
+    __shared__ double s_perr[kPoseMaxPlanes * 3];
+    __shared__ unsigned char s_pflag[kPoseMaxPlanes], s_pout[kPoseMaxPlanes];
+    const int M = P.nPlanes;
     const int t = threadIdx.x, n = P.nDev ? min(*P.nDev, P.n) : P.n;
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
     if (t == 0) { s_ntrace = 0; s_iters = 0; s_est = P.T0; }
+    if (t < M) { s_pflag[t] = 4; s_pout[t] = 0; s_perr[3 * t] = s_perr[3 * t + 1] = s_perr[3 * t + 2] = 0; }
+    auto plane_chi2 = [&](int p) {
+        const double* pl = P.planes + 10 * p;
+        const double* e = s_perr + 3 * p;
+        return e[0] * (pl[8] * e[0]) + e[1] * (pl[8] * e[1]) + e[2] * (pl[9] * e[2]);
+    };
     __syncthreads();
     for (int round = 0; round < 4; round++) {
         if (t == 0) { s_est = P.T0; s_active = 0; }
@@ -772,6 +784,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
         {   // any level-0 edge?  (g2o: optimize() returns -1 when the index mapping is empty)
             int any = 0;
             for (int i = t; i < n; i += kPoseThreads) any |= !(P.flags[i] & 2);
+            if (t < M) any |= !(s_pflag[t] & 2);
             if (any) s_active = 1;
         }
         __syncthreads();
@@ -826,6 +839,53 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
                         }
                     }
                 }
+                if (M) {
+                    if (t < 13 * M) {
+                        const int p = t / 13, v = t - 13 * p;
+                        if (!(s_pflag[p] & 2)) {
+                            SE3 Tp = est;
+                            if (v) {
+                                double add[6] = {0, 0, 0, 0, 0, 0};
+                                const int d = (v - 1) >> 1;
+                                const double step = ((v - 1) & 1) ? -1e-9 : 1e-9;
+#pragma unroll
+                                for (int q = 0; q < 6; q++) if (q == d) add[q] = step;
+                                Tp = se3_mul(se3_exp(add), est);
+                            }
+                            plane_error(Tp, P.planes + 10 * p, P.planes + 10 * p + 4, &s_pvar[(p * 13 + v) * 3]);
+                        }
+                    }
+                    __syncthreads();
+                    if (t < M && !(s_pflag[t] & 2)) {
+                        const double* pl = P.planes + 10 * t;
+                        const double* pv = &s_pvar[t * 13 * 3];
+                        s_perr[3 * t] = pv[0]; s_perr[3 * t + 1] = pv[1]; s_perr[3 * t + 2] = pv[2];
+                        const double scalar = 1.0 / (2 * 1e-9);
+                        double J[3][6];
+#pragma unroll
+                        for (int d = 0; d < 6; d++)
+#pragma unroll
+                            for (int r = 0; r < 3; r++) J[r][d] = scalar * (pv[(1 + 2 * d) * 3 + r] - pv[(2 + 2 * d) * 3 + r]);
+                        const double c2 = plane_chi2(t);
+                        double w = 1.0, r0 = c2;
+                        if (s_pflag[t] & 4) huber(c2, P.deltaPlane, r0, w);
+                        acc[27] += r0;
+                        const double info[3] = {pl[8], pl[8], pl[9]};
+                        int q = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+                            double sb = J[0][a] * (info[0] * pv[0]) + J[1][a] * (info[1] * pv[1]);
+                            sb += J[2][a] * (info[2] * pv[2]);
+                            acc[21 + a] -= w * sb;
+#pragma unroll
+                            for (int b = a; b < 6; b++) {
+                                double hh = J[0][a] * (w * info[0]) * J[0][b] + J[1][a] * (w * info[1]) * J[1][b];
+                                hh += J[2][a] * (w * info[2]) * J[2][b];
+                                acc[q++] += hh;
+                            }
+                        }
+                    }
+                }
                 block_sum_lds<28, kPoseThreads>(acc, red, sums);
                 if (t == 0) {
                     s_cur = sums[27];
@@ -866,6 +926,13 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
                         const double c2 = pose_edge_chi2(P, i, stereo);
                         double w, r0 = c2;
                         if (fl & 4) huber(c2, stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
+                        chi[0] += r0;
+                    }
+                    if (t < M && !(s_pflag[t] & 2)) {
+                        plane_error(tr, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
+                        const double c2 = plane_chi2(t);
+                        double w, r0 = c2;
+                        if (s_pflag[t] & 4) huber(c2, P.deltaPlane, r0, w);
                         chi[0] += r0;
                     }
                     block_sum<1, kPoseThreads>(chi, red, &s_tmp);
@@ -924,11 +991,21 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
             else if (round == 2) fl &= ~4;    // stereo: at it == 2
             P.flags[i] = fl;
         }
+        if (t < M) {   // src/Optimizer.cc:626-658
+            unsigned char fl = s_pflag[t];
+            if (s_pout[t]) plane_error(est, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
+            const float c2 = (float)plane_chi2(t);
+            if (c2 > 300.0) { s_pout[t] = 1; fl |= 2; nb[0] += 1; }
+            else { s_pout[t] = 0; fl &= ~2; }
+            if (round == 2) fl &= ~4;
+            s_pflag[t] = fl;
+        }
         block_sum<1, kPoseThreads>(nb, red, &s_tmp);
         if (t == 0) P.result[0] = (int)s_tmp;
         __syncthreads();
-        if (n < 10) break;
+        if (n + M < 10) break;
     }
+    if (t < M) P.planeOutlier[t] = s_pout[t];
     if (t == 0) { *P.Tout = s_est; P.result[1] = s_iters; P.result[2] = s_ntrace; }
 }
 
@@ -2874,7 +2951,6 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     const int M = p->n_planes;
     EAO_REQUIRE(M >= 0 && M <= kPoseMaxPlanes, "at most %d plane edges (got %d)", kPoseMaxPlanes, M);
     EAO_REQUIRE(M == 0 || (p->plane_world && p->plane_obs && p->plane_seen && r->plane_outlier), "plane arrays missing");
-    EAO_REQUIRE(M == 0 || p->n <= 4 * kPoseThreads, "plane edges are supported for up to %d point correspondences", 4 * kPoseThreads);
     LMContext& c = g_ctx;
     eao_status st = ctx_init(c);
     if (st) return st;

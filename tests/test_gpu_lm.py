@@ -153,7 +153,9 @@ def test_pose_optimization_parity(gpu, oracle, kw):
 
 
 @pytest.mark.parametrize("kw", [dict(n=300, seed=4200, n_planes=6), dict(n=12, seed=4201, n_planes=5, sigma=0.5, outlier_frac=0.0),
-                                dict(n=1500, seed=4202, n_planes=32), dict(n=40, seed=4203, n_planes=1, mono_frac=1.0)])
+                                dict(n=1500, seed=4202, n_planes=32), dict(n=40, seed=4203, n_planes=1, mono_frac=1.0),
+                                # beyond 2048 correspondences: the global-memory variant of the kernel carries the plane edges too
+                                dict(n=2600, seed=4204, n_planes=6), dict(n=3000, seed=4205, n_planes=32, mono_frac=0.5)])
 def test_pose_optimization_with_planes(gpu, oracle, kw):
     """Plane edges (src/Optimizer.cc:456-535): same inlier / outlier tables as the oracle, pose update within 1e-4.  The
     Jacobian of these edges is g2o's central difference with delta = 1e-9, i.e. it carries ~1e-7 of rounding noise in
