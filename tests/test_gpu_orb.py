@@ -2,6 +2,7 @@
 Bar: bit-exact pyramid / blur / FAST candidates / keypoints / descriptors (BASELINE.json north_star)."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the library loads, so that both resolve the same HIP runtime)
 
 from eao_fusion_amd import synth
 
@@ -214,3 +215,30 @@ def test_thousands_of_features_on_few_levels(gpu, oracle, cfg):
     k1, d1 = gpu.ORBextractor(nfeat, sf, nlev, ini, mn)(img)
     assert len(k0) == len(k1) and len(k0) > 1000
     assert np.array_equal(k0, k1) and np.array_equal(d0, d1)
+
+
+def test_device_api_alternating_streams(gpu, oracle):
+    """One handle, consecutive device calls on DIFFERENT streams: the calls share the handle's pyramid and candidate scratch, so a
+    call on another stream than the previous one first waits for it (on the host).  Four calls alternating between two torch
+    streams, no synchronisation in between from the caller: every result equals the oracle's."""
+    imgs = synth.synth_frames(4, seed0=1300)
+    ext = gpu.ORBextractor(1000, 1.2, 8, 20, 7)
+    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    H, W = imgs.shape[1:]
+    cap = ext.max_keypoints(W, H)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    d_img = [torch.from_numpy(imgs[f:f + 1].copy()).cuda() for f in range(4)]
+    d_k = [torch.zeros((1, cap, 28), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    d_d = [torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    d_n = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    for f in range(4):
+        st = streams[f & 1]
+        ext.extract_batch_device(d_img[f].data_ptr(), W, H, W, W * H, 1, d_k[f].data_ptr(), d_d[f].data_ptr(), cap, d_n[f].data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    for f in range(4):
+        okps, odesc = orc.extract(imgs[f])
+        n = int(d_n[f].item())
+        assert n == len(okps)
+        assert np.array_equal(d_k[f].cpu().numpy()[0, :n].reshape(-1).view(gpu.KP_DTYPE), okps), "frame %d keypoints" % f
+        assert np.array_equal(d_d[f].cpu().numpy()[0, :n], odesc), "frame %d descriptors" % f
