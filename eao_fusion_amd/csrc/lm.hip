@@ -55,6 +55,32 @@ __host__ __device__ inline double recip(double x) {
 #endif
 }
 
+// Several IEEE divisions by ONE denominator.  The compiler's sequence per fp64 division is v_div_scale x 2, v_rcp_f64 (quarter
+// rate), four FMAs that refine the reciprocal, v_mul, v_fma, v_div_fmas, v_div_fixup: eleven instructions, seven of which
+// depend on the denominator alone.  DivBy<true> runs those once (rcp + 4 FMA) and spends mul + 2 FMA per quotient -- the same
+// operations on the same values, so the quotient is the SAME correctly rounded double, as long as v_div_scale would not have
+// rescaled and v_div_fixup would not have patched anything: plain_den() admits denominators of magnitude 2^-400 .. 2^400 (not
+// zero, NaN or infinite; depths in metres and their squares), the numerators are coordinates and products of coordinates
+// (a quotient in the denormal range or a -0 numerator's sign could differ -- neither reaches a result).  The Jacobians of
+// one BA edge divide 22 times by z or z^2 (types_six_dof_expmap.cpp:103-139,188-234 written out as upstream writes them):
+// 242 -> 76 instructions per edge and role.  DivBy<false> is the plain division, taken lane by lane for any other denominator.
+__device__ __forceinline__ bool plain_den(double d) { const double a = fabs(d); return a > 0x1p-400 && a < 0x1p400; }
+template <bool SHARED> struct DivBy {
+    double d, r;
+    __device__ __forceinline__ explicit DivBy(double den) : d(den), r(0) {
+        if (SHARED) {
+            r = __builtin_amdgcn_rcp(den);
+            r = fma(r, fma(-den, r, 1.0), r);
+            r = fma(r, fma(-den, r, 1.0), r);
+        }
+    }
+    __device__ __forceinline__ double operator()(double a) const {
+        if (!SHARED) return a / d;
+        const double q = a * r;
+        return fma(fma(-d, q, a), r, q);
+    }
+};
+
 // ============================================================================================ SE3 helpers
 struct Quat { double x, y, z, w; };
 struct SE3 { Quat r; double t[3]; };
@@ -1123,7 +1149,9 @@ __device__ __forceinline__ double* trial_pts(const BADev& P) { return P.ptsBuf[P
 
 __device__ inline void ba_project(const Cam& c, bool stereo, const double p[3], double r[3]) {
     if (!stereo) {
-        r[0] = p[0] / p[2] * c.fx + c.cx; r[1] = p[1] / p[2] * c.fy + c.cy; r[2] = 0;
+        if (plain_den(p[2])) { const DivBy<true> z(p[2]); r[0] = z(p[0]) * c.fx + c.cx; r[1] = z(p[1]) * c.fy + c.cy; }
+        else { r[0] = p[0] / p[2] * c.fx + c.cx; r[1] = p[1] / p[2] * c.fy + c.cy; }
+        r[2] = 0;
     } else {
         const float invz = (float)(1.0 / p[2]);   // types_six_dof_expmap.cpp:150-156
         r[0] = p[0] * invz * c.fx + c.cx;
@@ -1136,35 +1164,40 @@ __device__ inline double ba_chi2(const double* e, double info, bool stereo) {
     if (stereo) s += e[2] * (info * e[2]);
     return s;
 }
+template <bool SHARED>
+__device__ __forceinline__ void ba_jacobians_t(const Cam& c, bool stereo, const double R[9], double X, double Y, double Zd, double A[3][3], double B[3][6]) {
+    const DivBy<SHARED> Z(Zd), z2(Zd * Zd);      // "x / Z" is spelled Z(x) below; every expression keeps upstream's order of operations
+    if (!stereo) {
+        const double tmp[2][3] = {{c.fx, 0, Z(-X) * c.fx}, {0, c.fy, Z(-Y) * c.fy}};
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 3; j++)
+                A[i][j] = (Z(-1.) * tmp[i][0]) * R[j] + (Z(-1.) * tmp[i][1]) * R[3 + j] + (Z(-1.) * tmp[i][2]) * R[6 + j];
+        for (int j = 0; j < 3; j++) A[2][j] = 0;
+    } else {
+        for (int j = 0; j < 3; j++) {
+            A[0][j] = Z(-c.fx * R[j]) + z2(c.fx * X * R[6 + j]);
+            A[1][j] = Z(-c.fy * R[3 + j]) + z2(c.fy * Y * R[6 + j]);
+            A[2][j] = A[0][j] - z2(c.bf * R[6 + j]);
+        }
+    }
+    B[0][0] = z2(X * Y) * c.fx; B[0][1] = -(1 + (z2(X * X))) * c.fx; B[0][2] = Z(Y) * c.fx;
+    B[0][3] = Z(-1.) * c.fx; B[0][4] = 0; B[0][5] = z2(X) * c.fx;
+    B[1][0] = (1 + z2(Y * Y)) * c.fy; B[1][1] = z2(-X * Y) * c.fy; B[1][2] = Z(-X) * c.fy;
+    B[1][3] = 0; B[1][4] = Z(-1.) * c.fy; B[1][5] = z2(Y) * c.fy;
+    if (stereo) {
+        B[2][0] = B[0][0] - z2(c.bf * Y); B[2][1] = B[0][1] + z2(c.bf * X); B[2][2] = B[0][2];
+        B[2][3] = B[0][3]; B[2][4] = 0; B[2][5] = B[0][5] - z2(c.bf);
+    } else {
+        for (int j = 0; j < 6; j++) B[2][j] = 0;
+    }
+}
 // Jacobians wrt point (A, Dx3) and pose (B, Dx6): types_six_dof_expmap.cpp:103-139,188-234
 __device__ inline void ba_jacobians(const Cam& c, bool stereo, const SE3& T, const double* pw, double A[3][3], double B[3][6]) {
     double p[3], R[9];
     se3_map(T, pw, p);
     quat_to_matrix(T.r, R);
-    const double X = p[0], Y = p[1], Z = p[2], z2 = Z * Z;
-    if (!stereo) {
-        const double tmp[2][3] = {{c.fx, 0, -X / Z * c.fx}, {0, c.fy, -Y / Z * c.fy}};
-        for (int i = 0; i < 2; i++)
-            for (int j = 0; j < 3; j++)
-                A[i][j] = (-1. / Z * tmp[i][0]) * R[j] + (-1. / Z * tmp[i][1]) * R[3 + j] + (-1. / Z * tmp[i][2]) * R[6 + j];
-        for (int j = 0; j < 3; j++) A[2][j] = 0;
-    } else {
-        for (int j = 0; j < 3; j++) {
-            A[0][j] = -c.fx * R[j] / Z + c.fx * X * R[6 + j] / z2;
-            A[1][j] = -c.fy * R[3 + j] / Z + c.fy * Y * R[6 + j] / z2;
-            A[2][j] = A[0][j] - c.bf * R[6 + j] / z2;
-        }
-    }
-    B[0][0] = X * Y / z2 * c.fx; B[0][1] = -(1 + (X * X / z2)) * c.fx; B[0][2] = Y / Z * c.fx;
-    B[0][3] = -1. / Z * c.fx; B[0][4] = 0; B[0][5] = X / z2 * c.fx;
-    B[1][0] = (1 + Y * Y / z2) * c.fy; B[1][1] = -X * Y / z2 * c.fy; B[1][2] = -X / Z * c.fy;
-    B[1][3] = 0; B[1][4] = -1. / Z * c.fy; B[1][5] = Y / z2 * c.fy;
-    if (stereo) {
-        B[2][0] = B[0][0] - c.bf * Y / z2; B[2][1] = B[0][1] + c.bf * X / z2; B[2][2] = B[0][2];
-        B[2][3] = B[0][3]; B[2][4] = 0; B[2][5] = B[0][5] - c.bf / z2;
-    } else {
-        for (int j = 0; j < 6; j++) B[2][j] = 0;
-    }
+    if (plain_den(p[2]) && plain_den(p[2] * p[2])) ba_jacobians_t<true>(c, stereo, R, p[0], p[1], p[2], A, B);
+    else ba_jacobians_t<false>(c, stereo, R, p[0], p[1], p[2], A, B);
 }
 
 __device__ inline double plane_chi2(const BADev& P, const double* e) {
@@ -3066,6 +3099,11 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
 // ONE launch per register variant, ONE synchronisation; each frame's result is what eao_pose_optimization returns for it
 // (same kernel body, same reduction order).  Frames the one-workgroup register kernels do not take (more than
 // 4 * kPoseThreads correspondences) go through eao_pose_optimization one by one.
+// float -> double over one contiguous array (restrict-qualified and on its own, so that the host compiler vectorises it: the
+// interleaved per-correspondence loop it replaces ran scalar and was half of a 256-frame call's host time)
+static inline void widen(double* __restrict dst, const float* __restrict src, size_t n) {
+    for (size_t i = 0; i < n; i++) dst[i] = (double)src[i];
+}
 eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, eao_pose_result* rs) {
     EAO_REQUIRE(nb >= 0 && (nb == 0 || (ps && rs)), "bad batch");
     if (nb == 0) return EAO_OK;
@@ -3146,11 +3184,8 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
             ores[0] = ores[1] = ores[2] = 0;
             double* hX = (double*)hostp(s.Xw); double* hO = (double*)hostp(s.obs); double* hI = (double*)hostp(s.info);
             unsigned char* hF = (unsigned char*)hostp(s.flags);
-            for (int i = 0; i < n; i++) {
-                for (int d = 0; d < 3; d++) { hX[3 * i + d] = p->Xw[3 * i + d]; hO[3 * i + d] = p->obs[3 * i + d]; }
-                hI[i] = p->inv_sigma2[i];
-                hF[i] = (unsigned char)((!(p->obs[3 * i + 2] < 0) ? 1 : 0) | 4);
-            }
+            widen(hX, p->Xw, (size_t)n * 3); widen(hO, p->obs, (size_t)n * 3); widen(hI, p->inv_sigma2, n);
+            for (int i = 0; i < n; i++) hF[i] = (unsigned char)((!(p->obs[3 * i + 2] < 0) ? 1 : 0) | 4);
             double* hP = (double*)hostp(s.planes);
             for (int i = 0; i < M; i++) {
                 plane_from_f32(p->plane_world + 4 * i, hP + 10 * i);

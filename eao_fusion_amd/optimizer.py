@@ -56,9 +56,8 @@ class Optimizer:
         return out
 
     @staticmethod
-    def PoseOptimizationBatch(probs):
-        """One PoseOptimization per element of `probs` (the candidate loop of Tracking::Relocalization, src/Tracking.cc:2786-2940)
-        in a single eao_pose_optimization_batch call.  Returns a list of the dicts PoseOptimization returns."""
+    def pack_pose_batch(probs):
+        """The argument arrays of eao_pose_optimization_batch for a list of frames (kept alive by the returned object)."""
         nb = len(probs)
         Ps = (_lib.PoseProblem * max(nb, 1))()
         Rs = (_lib.PoseResult * max(nb, 1))()
@@ -81,7 +80,15 @@ class Optimizer:
             Rs[b].outlier = _lib.ptr(outl)
             Rs[b].plane_outlier = _lib.ptr(pout)
             keep.append((Tcw, Xw, obs, inv, pw, po, ps, outl, pout, n, m))
-        _lib.check(_lib.load().eao_pose_optimization_batch(Ps, nb, Rs))
+        return dict(P=Ps, R=Rs, n=nb, keep=keep)
+
+    @staticmethod
+    def PoseOptimizationBatch(probs, packed=None):
+        """One PoseOptimization per element of `probs` (the candidate loop of Tracking::Relocalization, src/Tracking.cc:2786-2940)
+        in a single eao_pose_optimization_batch call.  Returns a list of the dicts PoseOptimization returns."""
+        pk = packed or Optimizer.pack_pose_batch(probs)
+        nb, Rs, keep = pk["n"], pk["R"], pk["keep"]
+        _lib.check(_lib.load().eao_pose_optimization_batch(pk["P"], nb, Rs))
         outs = []
         for b in range(nb):
             outl, pout, n, m = keep[b][7:]
