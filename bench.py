@@ -554,6 +554,15 @@ def measure_extra(E, synth, torch, dev):
         for _ in range(20):
             E.Optimizer.PoseOptimization(pp)
         extra["pose_optimization_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+        # ... and at the C-ABI, the argument record built once (the figure above includes the Python mirror's array packing)
+        import ctypes as C3
+        pk1 = E.Optimizer.pack_pose_batch([pp])
+        tq = []
+        for _ in range(25):
+            t0 = time.perf_counter()
+            E._lib.check(L.eao_pose_optimization(C3.byref(pk1["P"][0]), C3.byref(pk1["R"][0])))
+            tq.append(time.perf_counter() - t0)
+        extra["pose_optimization_c_abi_ms"] = round(float(np.median(tq[5:])) * 1e3, 3)
         # the tracking step of independent frames (both guided searches + PoseOptimization) from several host threads: the
         # per-frame kernels are latency-bound single-workgroup work, frames of a batched sequence overlap on the device
         treps = 10
