@@ -414,26 +414,42 @@ __device__ inline void plane_error(const SE3& T, const double* world, const doub
 constexpr int kPoseMaxPlanes = 32;
 
 // ============================================================================================ PoseOptimization
+// A pointer member of a record that kernels read FROM MEMORY (the window records of the batched LM kernels).  A plain `T*`
+// loaded from memory is a generic pointer to the compiler, and every access through it becomes a FLAT instruction: it
+// takes the LDS path's counters as well, so the waits behind it are `vmcnt(0) lgkmcnt(0)` instead of counted ones, and it
+// cannot use the scalar-base addressing mode.  On the device the member is declared in the global address space (same
+// size and layout); converting it to `T*` is then a global -> generic cast the optimiser sees through, and the kernels'
+// accesses become GLOBAL instructions with no change at their use sites.  Only device / pinned buffers are ever stored here.
+template <typename T> struct GP {
+#ifdef __HIP_DEVICE_COMPILE__
+    __attribute__((address_space(1))) T* p;
+#else
+    T* p;
+#endif
+    __host__ __device__ __forceinline__ operator T*() const { return (T*)p; }
+    __host__ __device__ __forceinline__ GP& operator=(T* q) { p = (decltype(p))q; return *this; }
+};
+
 struct PoseDev {
     int n;
-    const int* nDev;     // when set: the number of edges lives on the device (chained tracking: eao_tracker); n is then the capacity
-    const double* Xw;    // n*3
-    const double* obs;   // n*3
-    const double* info;  // n
-    double* err;         // n*3 (last computed residual of each edge, g2o's _error)
-    unsigned char* flags;  // bit0 stereo, bit1 level (1 = excluded), bit2 robust kernel present
-    unsigned char* outlier;
+    GP<const int> nDev;     // when set: the number of edges lives on the device (chained tracking: eao_tracker); n is then the capacity
+    GP<const double> Xw;    // n*3
+    GP<const double> obs;   // n*3
+    GP<const double> info;  // n
+    GP<double> err;         // n*3 (last computed residual of each edge, g2o's _error)
+    GP<unsigned char> flags;  // bit0 stereo, bit1 level (1 = excluded), bit2 robust kernel present
+    GP<unsigned char> outlier;
     SE3 T0;
     Cam cam;
     // outputs
-    SE3* Tout;
-    int* result;         // [0] nBad of the last round, [1] LM iterations, [2] trace count
-    double* trace;       // 3 * 64: lambda, chi2, trials
-    long long* dbg;      // optional phase stamps (diagnostic runs of the harness only)
+    GP<SE3> Tout;
+    GP<int> result;         // [0] nBad of the last round, [1] LM iterations, [2] trace count
+    GP<double> trace;       // 3 * 64: lambda, chi2, trials
+    GP<long long> dbg;      // optional phase stamps (diagnostic runs of the harness only)
     // plane edges: nPlanes x { world[4], meas[4], infoAngle, infoDistance } doubles; flags as for the points
     int nPlanes;
-    const double* planes;
-    unsigned char* planeOutlier;
+    GP<const double> planes;
+    GP<unsigned char> planeOutlier;
     double deltaPlane;
 };
 
@@ -1040,69 +1056,72 @@ struct BADev {
     int nCams, nPts, nEdges, nFree, nL;   // nFree / nL: active free cameras / active points of the current pass
     Cam cam;
     // problem (device)
-    const float* obs;       // E*3 as handed over (promoted to double where used, exactly like Converter / Eigen)
-    const float* info;      // E
-    const int* ecam;        // E
-    const int* ept;         // E
-    unsigned char* eflag;   // bit0 stereo, bit1 inactive (level 1: set on the device by the outlier pass), bit2 robust
-    const int* camIdx;      // nCams -> free block index or -1
-    const int* ptIdx;       // nPts  -> landmark block index or -1
-    const int* actCam;      // nFree -> camera
-    const int* actPt;       // nL    -> point
+    GP<const float> obs;       // E*3 as handed over (promoted to double where used, exactly like Converter / Eigen)
+    GP<const float> info;      // E
+    GP<const int> ecam;        // E
+    GP<const int> ept;         // E
+    GP<unsigned char> eflag;   // bit0 stereo, bit1 inactive (level 1: set on the device by the outlier pass), bit2 robust
+    GP<const int> camIdx;      // nCams -> free block index or -1
+    GP<const int> ptIdx;       // nPts  -> landmark block index or -1
+    GP<const int> actCam;      // nFree -> camera
+    GP<const int> actPt;       // nL    -> point
     // adjacency of the edges that were active when the window was set up; kernels skip edges whose bit1 was set since
-    const int* ptStart;     // nL+1   CSR by landmark block: all active edges of the point, insertion order
-    const int* ptEdges;
-    const int* camStart;    // nFree+1 CSR by free camera block
-    const int* camEdges;
-    int* camEdgeL;          // landmark block of each camEdges entry (resolved by k_ba_prepare)
-    int* pairCnt;           // per camera pair (i1 <= i2): number of landmarks both observe ...
-    int* pairPts;           // ... and their landmark blocks, ascending, nL slots per pair (k_ba_pairs)
-    int* table;             // nL * nFree: edge id of (point, free camera) or -1 (built and maintained on the device)
+    GP<const int> ptStart;     // nL+1   CSR by landmark block: all active edges of the point, insertion order
+    GP<const int> ptEdges;
+    GP<const int> camStart;    // nFree+1 CSR by free camera block
+    GP<const int> camEdges;
+    GP<int> camEdgeL;          // landmark block of each camEdges entry (resolved by k_ba_prepare)
+    GP<int> pairCnt;           // per camera pair (i1 <= i2): number of landmarks both observe ...
+    GP<int> pairPts;           // ... and their landmark blocks, ascending, nL slots per pair (k_ba_pairs)
+    GP<int> table;             // nL * nFree: edge id of (point, free camera) or -1 (built and maintained on the device)
+    GP<int4> slot;             // nL * 8: {edge, camera, free-camera index, point | more-than-8-edges << 31} of the landmark's k-th edge, edge = -1
+                            // beyond its last one (k_ba_prepare): what the eight lanes of a landmark would otherwise chase through
+                            // ptStart -> ptEdges -> ecam -> camIdx, four dependent round trips at the head of every launch
     // state: two buffers; ctl[1] says which one holds the current estimate, the other receives the trial
-    SE3* camsBuf[2];
-    double* ptsBuf[2];
-    int* ctl;               // [0] halt  [1] current buffer  [2] iterations done  [3] status  [4] nBad
-    double* err;            // E*3, last computed
+    GP<SE3> camsBuf[2];
+    GP<double> ptsBuf[2];
+    GP<int> ctl;               // [0] halt  [1] current buffer  [2] iterations done  [3] status  [4] nBad
+    GP<double> err;            // E*3, last computed
     // system
-    double* Hpp;            // nFree*36
-    double* bp;             // nFree*6
-    double* Hll;            // nL*9
-    double* bl;             // nL*3
-    double* Hpl;            // E*18 (pose row block 6x3) for active edges with a free camera
-    double* slab;           // chunks * nFree * (nFree*36 + 6): partial Schur rows
-    double* sys;            // n*(n+1): assembled Schur system (upper triangle + rhs column)
-    double* solveScratch;   // n*(n+1)+... doubles when the Schur system does not fit in LDS, else null
-    int* doneCnt;           // workgroups of the running k_ba_backsub that have published their partial sums (zero between launches)
-    double* wgPart;         // their partial sums: 2 per workgroup
-    long long* dbg;         // optional phase stamps of k_ba_solve (diagnostic builds of the harness only)
-    double* xp;             // nFree*6
-    double* xl;             // nL*3
-    double* partChi;        // nL (robust chi2 of the point's edges at the last evaluated state)
-    double* partScale;      // nL
-    double* lm;             // [0] lambda [1] ni [2] currentChi [3] maxdiag
+    GP<double> Hpp;            // nFree*36
+    GP<double> bp;             // nFree*6
+    GP<double> Hll;            // nL*9
+    GP<double> bl;             // nL*3
+    GP<double> Hpl;            // E*18 (pose row block 6x3) for active edges with a free camera
+    GP<double> slab;           // chunks * nFree * (nFree*36 + 6): partial Schur rows
+    GP<double> sys;            // n*(n+1): assembled Schur system (upper triangle + rhs column)
+    GP<double> solveScratch;   // n*(n+1)+... doubles when the Schur system does not fit in LDS, else null
+    GP<int> doneCnt;           // workgroups of the running k_ba_backsub that have published their partial sums (zero between launches)
+    GP<double> wgPart;         // their partial sums: 2 per workgroup
+    GP<long long> dbg;         // optional phase stamps of k_ba_solve (diagnostic builds of the harness only)
+    GP<double> xp;             // nFree*6
+    GP<double> xl;             // nL*3
+    GP<double> partChi;        // nL (robust chi2 of the point's edges at the last evaluated state)
+    GP<double> partScale;      // nL
+    GP<double> lm;             // [0] lambda [1] ni [2] currentChi [3] maxdiag
     int chunks;
     // MapPlane vertices / EdgePlane edges of Optimizer::BundleAdjustment (src/Optimizer.cc:203-252): landmarks nPtsOnly.. are
     // planes (4 coefficients each, two state buffers like the points), edges nEdgesPt.. are plane edges (eflag bit3)
     int nPtsOnly, nEdgesPt;
-    double* plBuf[2];
-    const double* pmeas;    // 4 per plane edge: the measured plane, normalised
+    GP<double> plBuf[2];
+    GP<const double> pmeas;    // 4 per plane edge: the measured plane, normalised
     double deltaPlane, infoAngle, infoDist;
     // map-scale path (k_bal_*): dense lower-triangular system in HBM, panel workspace, factored diagonal blocks, pair CSR
-    double* big;            // RP * RP
-    double* bigL;           // RP * RP: the factor L (rows below each panel's diagonal block), row N = z
-    double* bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks
-    int* bigFail;
-    const int* lpStart;     // nPairsNZ + 1
-    const int* lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
-    const int* lpPts;       // landmark blocks of each pair, ascending
+    GP<double> big;            // RP * RP
+    GP<double> bigL;           // RP * RP: the factor L (rows below each panel's diagonal block), row N = z
+    GP<double> bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks
+    GP<int> bigFail;
+    GP<const int> lpStart;     // nPairsNZ + 1
+    GP<const int> lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
+    GP<const int> lpPts;       // landmark blocks of each pair, ascending
     int nPairsNZ;
     // per-window addresses every kernel finds HERE (the kernels take an array of windows and blockIdx.z, see BA_WIN)
-    int* ctl0;              // the two control blocks (8 ints each); a launch runs on ctl0 + 8 * par
-    double* lm0;            // the two LM blocks (8 doubles each)
-    int* solveOk;
-    struct BAStatus* status;   // pinned host memory
-    unsigned char* cls;     // E: outlier table of the pass between the two optimize() calls
-    SE3* outCams; double* outPts; unsigned char* outCls; double* outPlanes;   // pinned results (k_ba_finish)
+    GP<int> ctl0;              // the two control blocks (8 ints each); a launch runs on ctl0 + 8 * par
+    GP<double> lm0;            // the two LM blocks (8 doubles each)
+    GP<int> solveOk;
+    GP<struct BAStatus> status;   // pinned host memory
+    GP<unsigned char> cls;     // E: outlier table of the pass between the two optimize() calls
+    GP<SE3> outCams; GP<double> outPts; GP<unsigned char> outCls; GP<double> outPlanes;   // pinned results (k_ba_finish)
 };
 
 // Every BA kernel takes the device array of window records: workgroup (x, y, z) works on window z, on the control / LM block
@@ -1397,50 +1416,59 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
         // role A: eight lanes per landmark, one edge per lane; Hll / bl are xor-tree sums over the lane group
         const int l = (bx * NT + threadIdx.x) >> 3, slot = threadIdx.x & 7;
         const bool live = l < P.nL;
-        const int pt = live ? P.actPt[l] : 0;
-        const int beg = live ? P.ptStart[l] : 0, end = live ? P.ptStart[l + 1] : 0;
+        const int4 rec = live ? P.slot[(size_t)l * 8 + slot] : make_int4(-1, 0, -1, 0);    // the lane's first edge (see BADev::slot)
+        const int pt = rec.w & 0x7FFFFFFF;
+        const bool more = rec.w < 0;          // a landmark with more than eight edges walks its list as before
+        int e = rec.x, cam = rec.y, ci = rec.z;
+        int k = 0, end = 0;
+        if (more) { k = P.ptStart[l] + slot; end = P.ptStart[l + 1]; }
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};   // upper triangle 00 01 02 11 12 22
-        for (int k = beg + slot; k < end; k += 8) {
-            const int e = P.ptEdges[k];
+        while (e >= 0) {
             const unsigned char fl = P.eflag[e];
-            if (fl & 2) continue;
-            const bool stereo = fl & 1;
-            constexpr int D = 3;   // monocular edges carry a zero third row / residual: static loops, no scratch
-            double A[3][3], B[3][6];
-            const double* er = &P.err[3 * e];
-            double info = P.info[e], info2 = info;     // rows 0, 1 / row 2 of the (diagonal) information matrix
-            double w = 1.0, r0;
-            const bool camFree = P.camIdx[P.ecam[e]] >= 0;
-            if (PL && (fl & 8)) {
-                const double* pl = &P.plBuf[cur][4 * (pt - P.nPtsOnly)];
-                const double* meas = &P.pmeas[4 * (e - P.nEdgesPt)];
-                plane_jac_plane(cams[P.ecam[e]], pl, meas, A);
-                if (camFree) plane_jac_pose(cams[P.ecam[e]], pl, meas, B);
-                info = P.infoAngle; info2 = P.infoDist;
-                if (fl & 4) huber(plane_chi2(P, er), P.deltaPlane, r0, w);
-            } else {
-                ba_jacobians(P.cam, stereo, cams[P.ecam[e]], &pts[3 * pt], A, B);
-                if (fl & 4) huber(ba_chi2(er, info, stereo), stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
+            if (!(fl & 2)) {
+                const bool stereo = fl & 1;
+                constexpr int D = 3;   // monocular edges carry a zero third row / residual: static loops, no scratch
+                double A[3][3], B[3][6];
+                const double* er = &P.err[3 * e];
+                double info = P.info[e], info2 = info;     // rows 0, 1 / row 2 of the (diagonal) information matrix
+                double w = 1.0, r0;
+                const bool camFree = ci >= 0;
+                if (PL && (fl & 8)) {
+                    const double* pl = &P.plBuf[cur][4 * (pt - P.nPtsOnly)];
+                    const double* meas = &P.pmeas[4 * (e - P.nEdgesPt)];
+                    plane_jac_plane(cams[cam], pl, meas, A);
+                    if (camFree) plane_jac_pose(cams[cam], pl, meas, B);
+                    info = P.infoAngle; info2 = P.infoDist;
+                    if (fl & 4) huber(plane_chi2(P, er), P.deltaPlane, r0, w);
+                } else {
+                    ba_jacobians(P.cam, stereo, cams[cam], &pts[3 * pt], A, B);
+                    if (fl & 4) huber(ba_chi2(er, info, stereo), stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
+                }
+                const double wi[3] = {w * info, w * info, PL ? w * info2 : w * info};
+                double omr[3];
+                for (int r = 0; r < 3; r++) omr[r] = w * (-((PL && r == 2 ? info2 : info) * er[r]));
+                int q = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    double sb = 0;
+#pragma unroll
+                    for (int r = 0; r < D; r++) sb += A[r][i] * omr[r];
+                    b[i] += sb;
+#pragma unroll
+                    for (int j = i; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi[r] * A[r][j]; H[q++] += h; }
+                }
+                if (camFree) {
+                    double* Hx = &P.Hpl[(size_t)e * 18];
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; Hx[i * 3 + j] = h; }
+                }
             }
-            const double wi[3] = {w * info, w * info, PL ? w * info2 : w * info};
-            double omr[3];
-            for (int r = 0; r < 3; r++) omr[r] = w * (-((PL && r == 2 ? info2 : info) * er[r]));
-            int q = 0;
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                double sb = 0;
-#pragma unroll
-                for (int r = 0; r < D; r++) sb += A[r][i] * omr[r];
-                b[i] += sb;
-#pragma unroll
-                for (int j = i; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi[r] * A[r][j]; H[q++] += h; }
-            }
-            if (camFree) {
-                double* Hx = &P.Hpl[(size_t)e * 18];
-#pragma unroll
-                for (int i = 0; i < 6; i++)
-#pragma unroll
-                    for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; Hx[i * 3 + j] = h; }
+            e = -1;
+            if (more) {
+                k += 8;
+                if (k < end) { e = P.ptEdges[k]; cam = P.ecam[e]; ci = P.camIdx[cam]; }
             }
         }
 #pragma unroll
@@ -2809,7 +2837,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
         __hip_atomic_store(&P.wgPart[2 * bx], out2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&P.wgPart[2 * bx + 1], out2[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        s_last = __hip_atomic_fetch_add(P.doneCnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        s_last = __hip_atomic_fetch_add((int*)P.doneCnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
@@ -2821,7 +2849,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
     __syncthreads();
     block_sum<2, 256>(v, red, out2);
     if (threadIdx.x == 0) {
-        __hip_atomic_store(P.doneCnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((int*)P.doneCnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double camPart = __hip_atomic_load(&P.lm[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const BADecision d = ba_decision(P.lm, P.ctl, out2[0], camPart + out2[1], *P.solveOk, 1);
         ba_commit(d, P.lm, P.ctl, lmNext, ctlNext, P.status, seq, 1);
@@ -2889,6 +2917,12 @@ __global__ __launch_bounds__(256) void k_ba_prepare(const BADev* __restrict__ W,
             if (P.camIdx[P.ecam[e]] == ci) found = e;
         }
         P.table[idx] = found;
+    }
+    if (idx < P.nL * 8) {
+        const int l = idx >> 3, beg = P.ptStart[l], end = P.ptStart[l + 1], k = beg + (idx & 7);
+        int4 r = make_int4(-1, 0, -1, P.actPt[l] | (end - beg > 8 ? (int)0x80000000 : 0));
+        if (k < end) { r.x = P.ptEdges[k]; r.y = P.ecam[r.x]; r.z = P.camIdx[r.y]; }
+        P.slot[idx] = r;
     }
     if (idx < P.nPts * 3) P.ptsBuf[1][idx] = P.ptsBuf[0][idx];
     if (idx < (P.nPts - P.nPtsOnly) * 4) P.plBuf[1][idx] = P.plBuf[0][idx];
@@ -3299,7 +3333,7 @@ struct BALaunch {
     int ptBlocks() const { return eao::cdiv(std::max(d.nL, 1) * 8, 256); }       // eight lanes per landmark
     int linBlocks() const { return eao::cdiv(std::max(d.nL, 1) * 8, kLinThreads); }
     void setup() const {      // device-side part of the set-up (once per window)
-        hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(d.nL * d.nF, d.nP * 3), d.nC), d.E), d.nPl * 4), 256), 1, gz()), dim3(256), 0, s, W, wp(0));
+        hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(std::max(d.nL * d.nF, d.nL * 8), d.nP * 3), d.nC), d.E), d.nPl * 4), 256), 1, gz()), dim3(256), 0, s, W, wp(0));
         if (d.usePairs) {
             hipLaunchKernelGGL(k_ba_pairs, dim3(d.nF * (d.nF + 1) / 2, 1, gz()), dim3(256), 0, s, W, wp(0));
             hipLaunchKernelGGL(k_ba_tiles_init, dim3(tile_geom(d.nF).nTiles, 1, gz()), dim3(256), 0, s, W, wp(0));
@@ -3450,6 +3484,7 @@ struct BAJob {
         need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
         need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
         need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
+        need += (size_t)nP * 8 * sizeof(int4) + 256;
         need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
             need += (2 * (size_t)bg.RP * bg.RP + (size_t)bg.N * kBigNB) * 8;
@@ -3486,6 +3521,7 @@ struct BAJob {
         const size_t off1 = (a.off + 255) & ~(size_t)255;
         // ---- device-only part
         int* dtable = a.take<int>((size_t)nP * nC);
+        D.slot = a.take<int4>((size_t)std::max(nP, 1) * 8);
         D.camEdgeL = a.take<int>(E);
         const bool pairPath = !bigPath && nFreeIn > 0 && nFreeIn <= kTileMaxFree && !(solverEnv0 && !strcmp(solverEnv0, "lds")) && !getenv("EAO_BA_SLABS");
         const int nPairsMax = nFreeIn * (nFreeIn + 1) / 2;
