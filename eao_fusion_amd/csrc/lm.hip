@@ -2739,17 +2739,28 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
         return;
     }
     const bool live = l < P.nL;
-    const int pt = live ? P.actPt[l] : 0;
+    const int4 rec = live ? P.slot[(size_t)l * 8 + slot] : make_int4(-1, 0, -1, 0);      // the lane's first edge (BADev::slot)
+    const int pt = rec.w & 0x7FFFFFFF;
+    const bool more = rec.w < 0;                // more than eight edges: the lane walks on through the landmark's list
     const double* pts = cur_pts(P);
     double* ptsT = trial_pts(P);
     const SE3* camsT = trial_cams(P);
     const double lambda = P.lm[0];
-    const int beg = live ? P.ptStart[l] : 0, end = live ? P.ptStart[l + 1] : 0;
+    const int kFirst = more ? P.ptStart[l] + slot : 0, end = more ? P.ptStart[l + 1] : 0;
+    auto each_edge = [&](auto&& body) {         // body(edge, camera, free-camera index) for every edge of this lane
+        int e = rec.x, cam = rec.y, ci = rec.z, k = kFirst;
+        while (e >= 0) {
+            body(e, cam, ci);
+            e = -1;
+            if (more) {
+                k += 8;
+                if (k < end) { e = P.ptEdges[k]; cam = P.ecam[e]; ci = P.camIdx[cam]; }
+            }
+        }
+    };
     double cl[3] = {0, 0, 0};
-    for (int k = beg + slot; k < end; k += 8) {
-        const int e = P.ptEdges[k];
-        const int ci = P.camIdx[P.ecam[e]];
-        if (ci < 0 || (P.eflag[e] & 2)) continue;
+    each_edge([&](int e, int, int ci) {
+        if (ci < 0 || (P.eflag[e] & 2)) return;
         const double* Bi = &P.Hpl[(size_t)e * 18];
         const double* x = &P.xp[ci * 6];
 #pragma unroll
@@ -2759,7 +2770,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
             for (int r = 0; r < 6; r++) sacc += Bi[r * 3 + c] * (-x[r]);
             cl[c] += sacc;
         }
-    }
+    });
     double bl[3] = {0, 0, 0}, Di[9], xl[3], np[3];
     if (live) {
         bl[0] = P.bl[(size_t)l * 3]; bl[1] = P.bl[(size_t)l * 3 + 1]; bl[2] = P.bl[(size_t)l * 3 + 2];
@@ -2778,29 +2789,28 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
     double npl[4] = {1, 0, 0, 0};
     if (isPl) plane_oplus(&P.plBuf[P.ctl[kCtlCur]][4 * (pt - P.nPtsOnly)], xl, npl);      // VertexPlane::oplusImpl
     double chi = 0;
-    for (int k = beg + slot; k < end; k += 8) {
-        const int e = P.ptEdges[k];
+    each_edge([&](int e, int cam, int) {
         const unsigned char fl = P.eflag[e];
-        if (fl & 2) continue;              // level-1 edges keep the residual they last computed
+        if (fl & 2) return;                // level-1 edges keep the residual they last computed
         const bool stereo = fl & 1;
         double* er = &P.err[3 * e];
         if (isPl) {
-            plane_error(camsT[P.ecam[e]], npl, &P.pmeas[4 * (e - P.nEdgesPt)], er);
+            plane_error(camsT[cam], npl, &P.pmeas[4 * (e - P.nEdgesPt)], er);
             const double c2 = plane_chi2(P, er);
             double r0 = c2, w;
             if (fl & 4) huber(c2, P.deltaPlane, r0, w);
             chi += r0;
-            continue;
+            return;
         }
         double p[3], r[3];
-        se3_map(camsT[P.ecam[e]], np, p);
+        se3_map(camsT[cam], np, p);
         ba_project(P.cam, stereo, p, r);
         er[0] = P.obs[3 * e] - r[0]; er[1] = P.obs[3 * e + 1] - r[1]; er[2] = stereo ? P.obs[3 * e + 2] - r[2] : 0;
         const double c2 = ba_chi2(er, P.info[e], stereo);
         double r0 = c2, w;
         if (fl & 4) huber(c2, stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
         chi += r0;
-    }
+    });
     chi = group8_sum(chi);
     if (isPl && slot == 0) {
         double* plT = &P.plBuf[P.ctl[kCtlCur] ^ 1][4 * (pt - P.nPtsOnly)];
