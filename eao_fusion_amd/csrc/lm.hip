@@ -1396,7 +1396,9 @@ __device__ inline void ba_commit(const BADecision& d, const double* lmOld, const
 // camera, one edge per thread; the 27 sums (21 of Hpp's upper triangle + 6 of bp) go through LDS in a fixed order: lane
 // quads first (DPP), then 27 x 8 column threads over 32 quad leaders each, then the last 8.  (Sixty-four-lane shuffle
 // trees for the 27 values cost 6.4 us here; this costs about one.)
-constexpr int kLinThreads = 1024;      // (batches: 512- and 256-thread workgroups measured, no difference: 3.27 / 3.29 / 3.29 ms for 25 windows)
+constexpr int kLinThreads = 1024;      // (batches: 512- and 256-thread workgroups measured, no difference: 3.27 / 3.29 / 3.29 ms for 25 windows; again after
+                                       //  the flat -> global change: the launch alone 43.8 -> 37.6 us with 512, the four-group batch 2.94-2.98 ms either way,
+                                       //  one window 1.128 -> 1.143 ms -- and the role-B sum's tree depends on it, so ONE size serves both)
 // first = 1 on the first linearisation of an optimize() call: the largest |diagonal entry| of Hpp / Hll (lambda_0 = 1e-5 x
 // that, optimization_algorithm_levenberg.cpp:166-180) is accumulated with one atomic max per workgroup -- a max does not
 // depend on the order, and non-negative doubles order like their bit patterns.
