@@ -466,8 +466,8 @@ __device__ __forceinline__ void fast_candidate(const uint8_t* p, int v, int t, b
 //   1. candidate test of every pixel, four per lane on packed 16-bit halves; survivors are compacted into a work list in
 //      row-major order (DPP scan of the lane counts, positions of a lane's survivors from a 16-entry LDS table)
 //   2. arc value of the survivors in the polarity their candidate test allows; corners (arc > th) write their score into an
-//      LDS score map that is zero everywhere else.  2b: the few survivors that could be either polarity and were no dark
-//      corner are evaluated as bright ones
+//      LDS score map that is zero everywhere else.  The few survivors that could be either polarity and were no dark corner
+//      are appended to the list and evaluated as bright ones by later lanes of the same loop
 //   3. the work list again: survivors with a non-zero score take the 3x3 strict NMS against the score map (blind across
 //      the cell seam, like upstream's per-cell cv::FAST calls); kept corners leave in row-major order through a ballot scan
 // WHOLE = true: the launch covers every cell of the frames (profiled calls, single-level pyramids); false: one share of the
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     const int maxT = g->fastMaxTested;                 // max tested pixels of any cell
     uint8_t* tile = fsm;                                // fastTileBytes
     unsigned short* worklist = reinterpret_cast<unsigned short*>(fsm + g->fastTileBytes);
-    // (survivors that wait for their bright evaluation are stacked downwards from the end of the same buffer)
+    // (survivors that wait for their bright evaluation are appended behind the list, with bit 14 set)
     unsigned* sc4 = reinterpret_cast<unsigned*>(fsm + g->fastTileBytes + ((2 * maxT + 15) & ~15));   // score map (tw+2) x (th+2) bytes, 16-byte aligned
     uint8_t* sc = reinterpret_cast<uint8_t*>(sc4);
     unsigned* lut = reinterpret_cast<unsigned*>(fsm + g->fastLdsBytes - 64);        // 16 words
@@ -658,40 +658,40 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
             }
         }
         __syncthreads();
-        // ---- 2. arc value of the survivors in one polarity; corners go to the score map
+        // ---- 2. arc value of the survivors in one polarity; corners go to the score map.  A survivor whose candidate test allows
+        // both polarities and that is no dark corner is APPENDED to the work list with kSecond set and meets the bright
+        // evaluation in a later lane of the same loop -- normally one of the lanes the last 64-entry round leaves idle (a
+        // separate loop over these few entries was a whole extra round of the arc code per cell)
+        constexpr int kSecond = 0x4000;
         int nsecond = 0;
-        for (int k0 = 0; k0 < nwork; k0 += 64) {
+        for (int k0 = 0; k0 < nwork + nsecond;) {
+            const int nlist = nwork + nsecond;
             const int k = k0 + lane;
-            const bool live = k < nwork;
-            const int i = worklist[min(k, nwork - 1)];
+            const bool live = k < nlist;
+            const int ent = worklist[min(k, nlist - 1)];
+            const bool second = ent & kSecond;
+            const int i = ent & (kSecond - 1);
             const int y = i >> 7, x = i & 127;
             const uint8_t* p = &tile[__umul24(y + 3, kTileStride) + x + 3 + ph];
             bool dk, br;
             fast_candidate<kTileStride>(p, p[0], th, &dk, &br);
             int v;
-            const int a = fast_arc_polar<kTileStride>(p, dk ? 0u : 0xFFu, &v);
+            const int a = fast_arc_polar<kTileStride>(p, dk && !second ? 0u : 0xFFu, &v);
             const bool corner = live && a > th;
             if (corner) sc[__umul24(y + 1, rw) + x + 1] = (uint8_t)(a - 1);
-            const bool again = live && dk && br && !corner;     // could still be a bright corner
+            const bool again = live && !second && dk && br && !corner;     // could still be a bright corner
             const unsigned long long m = __ballot(again);
             if (m) {
                 const int n2 = (int)__popcll(m);
-                if (nwork + nsecond + n2 <= maxT) {
-                    if (again) worklist[maxT - 1 - (nsecond + (int)__popcll(m & ((1ull << lane) - 1)))] = (unsigned short)i;
+                if (nlist + n2 <= maxT) {
+                    if (again) worklist[nlist + (int)__popcll(m & ((1ull << lane) - 1))] = (unsigned short)(i | kSecond);
                     nsecond += n2;
                 } else {   // (no room left behind the work list -- a cell of pure noise: the bright evaluation right here)
                     const int a2 = fast_arc_polar<kTileStride>(p, 0xFFu, &v);
                     if (again && a2 > th) sc[__umul24(y + 1, rw) + x + 1] = (uint8_t)(a2 - 1);
                 }
             }
-        }
-        for (int k0 = 0; k0 < nsecond; k0 += 64) {
-            const int k = k0 + lane;
-            const int i = worklist[maxT - 1 - min(k, nsecond - 1)];
-            const int y = i >> 7, x = i & 127;
-            int v;
-            const int a = fast_arc_polar<kTileStride>(&tile[__umul24(y + 3, kTileStride) + x + 3 + ph], 0xFFu, &v);
-            if (k < nsecond && a > th) sc[__umul24(y + 1, rw) + x + 1] = (uint8_t)(a - 1);
+            k0 = min(k0 + 64, nlist);      // (entries appended by a partial round start right behind it)
         }
         __syncthreads();
         // ---- 3. NMS + ordered emission (a corner of score 0 is never kept: 0 > max(...) cannot hold, upstream the same)
