@@ -29,6 +29,63 @@ struct FrustumDevArgs {           // Frame::isInFrustum over device-resident map
     unsigned char* inView; float* projX; float* projY; float* projXR; float* viewCos; int* level;
 };
 eao_status enqueue_frustum_device(const FrustumDevArgs& a, hipStream_t s);
+
+// The kernel-side view of the same test, shared by k_is_in_frustum (csrc/frame.hip) and by the tracker's first launch
+// (csrc/track.hip), whose extra workgroups run it beside the single-workgroup frame set-up.
+struct FrustumArgs {
+    int n;
+    const float* Xw; const float* normal; const float* minDist; const float* maxDist; const float* maxDistNum;
+    float R[9], t[3], Ow[3];
+    float fx, fy, cx, cy, mbf, minX, maxX, minY, maxY, logScale, cosLimit;
+    unsigned char* inView; float* projX; float* projY; float* projXR; float* viewCos; int* level;
+};
+inline void fill_frustum_args(const FrustumDevArgs& a, FrustumArgs& A) {
+    A.n = a.n;
+    A.Xw = a.Xw; A.normal = a.normal; A.minDist = a.minDist; A.maxDist = a.maxDist; A.maxDistNum = a.maxDistNum;
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) A.R[3 * r + k] = a.Tcw[4 * r + k];
+        A.t[r] = a.Tcw[4 * r + 3];
+        A.Ow[r] = a.Ow[r];
+    }
+    A.fx = a.fx; A.fy = a.fy; A.cx = a.cx; A.cy = a.cy; A.mbf = a.mbf;
+    A.minX = a.minX; A.maxX = a.maxX; A.minY = a.minY; A.maxY = a.maxY; A.logScale = a.logScale; A.cosLimit = a.cosLimit;
+    A.inView = a.inView; A.projX = a.projX; A.projY = a.projY; A.projXR = a.projXR; A.viewCos = a.viewCos; A.level = a.level;
+}
+// reference src/Frame.cc:638-695 for map point i; the statements keep upstream's order (each early return of upstream is a `return` here)
+__device__ __forceinline__ void frustum_point(const FrustumArgs& A, int i) {
+    A.inView[i] = 0;
+    const float P0 = A.Xw[3 * i], P1 = A.Xw[3 * i + 1], P2 = A.Xw[3 * i + 2];
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double acc = (double)A.R[3 * r] * (double)P0 + (double)A.R[3 * r + 1] * (double)P1 + (double)A.R[3 * r + 2] * (double)P2;
+        Pc[r] = (float)(acc + (double)A.t[r]);
+    }
+    if (Pc[2] < 0.0f) return;
+    const float invz = 1.0f / Pc[2];
+    const float u = A.fx * Pc[0] * invz + A.cx;
+    const float v = A.fy * Pc[1] * invz + A.cy;
+    if (u < A.minX || u > A.maxX) return;
+    if (v < A.minY || v > A.maxY) return;
+    const float PO0 = P0 - A.Ow[0], PO1 = P1 - A.Ow[1], PO2 = P2 - A.Ow[2];
+    const float dist = (float)sqrt((double)PO0 * PO0 + (double)PO1 * PO1 + (double)PO2 * PO2);
+    if (dist < A.minDist[i] || dist > A.maxDist[i]) return;
+    const double dot = (double)PO0 * A.normal[3 * i] + (double)PO1 * A.normal[3 * i + 1] + (double)PO2 * A.normal[3 * i + 2];
+    const float viewCos = (float)(dot / (double)dist);
+    if (viewCos < A.cosLimit) return;
+    // MapPoint::PredictScale (src/MapPoint.cc:385-394): float log, float division, ceil.  The float logarithm is taken
+    // as the double logarithm rounded to float (correctly rounded but for ~2^-29 of the inputs; a host libm's logf may
+    // differ from that by one ulp on rare inputs, which only matters when the quotient sits on an integer).
+    const float ratio = A.maxDistNum[i] / dist;
+    const float lg = (float)log((double)ratio);
+    const int level = (int)ceilf(lg / A.logScale);
+    A.inView[i] = 1;
+    A.projX[i] = u;
+    A.projXR[i] = u - A.mbf * invz;
+    A.projY[i] = v;
+    A.level[i] = level;
+    A.viewCos[i] = viewCos;
+}
 }  // namespace frame
 
 namespace match {

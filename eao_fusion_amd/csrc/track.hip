@@ -7,15 +7,18 @@
 // that never leave HBM: the keypoints, descriptors and keypoint count come straight from eao_orb_extract_batch_device, the
 // local map is uploaded when it changes, and one copy brings the pose, the matches and the outlier flags back.
 //
-//   k_track_frame    one workgroup: cv::KeyPoint records -> coordinate / octave / angle arrays, mvuRight / mvDepth from the
-//                    depth image, PosInGrid keys sorted in LDS -> the grid-order walk list k_match_candidates uses
-//   k_is_in_frustum  (frame.hip) one thread per local map point
+// Six launches (eight until late in round 2: every launch of this latency chain costs its ~3 us gap):
+//   k_track_frame    workgroup 0: cv::KeyPoint records -> coordinate / octave / angle arrays, mvuRight / mvDepth from the
+//                    depth image, PosInGrid keys sorted in LDS -> the grid-order walk list k_match_candidates uses;
+//                    workgroups 1..: Frame::isInFrustum, one thread per local map point (frustum_point, chain_internal.h -- the
+//                    same code as frame.hip's k_is_in_frustum), beside it
 //   k_track_queries  search windows of the points in view (RadiusByViewingCos x th x scale factor of the predicted level)
 //   k_match_candidates (match.hip) candidate lists in upstream's order
-//   k_track_assign   upstream's greedy assignment (a keypoint taken by an earlier map point is skipped by later ones) WITHOUT
+//   k_track_assign_edges   one workgroup, two steps:
+//       assignment   upstream's greedy assignment (a keypoint taken by an earlier map point is skipped by later ones) WITHOUT
 //                    walking the map points one by one: rounds in which every undecided point decides from the final claims
 //                    so far, and becomes final when no earlier undecided point lists any keypoint its decision depends on
-//   k_track_edges    mvpMapPoints by keypoint (prior matches + new ones), the PoseOptimization edges in keypoint order
+//       edges        mvpMapPoints by keypoint (prior matches + new ones), the PoseOptimization edges in keypoint order
 //   k_pose_optimization (lm.hip) with the edge count read on the device
 //   k_track_finish   mvbOutlier by keypoint, everything the host needs in one block
 #include <cmath>
@@ -71,10 +74,17 @@ constexpr int kFrameThreads = 1024;
 __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoint* __restrict__ kps, const int* __restrict__ nPtr, int cap,
                                                                const float* __restrict__ depth, int pitch, int W, int H, float mbf,
                                                                float minX, float minY, float invW, float invH, int cols, int rows, int npow2,
-                                                               int nMp, FrameArrays A) {
+                                                               int nMp, FrameArrays A, eao::frame::FrustumArgs FA) {
     extern __shared__ unsigned tkeys[];
     __shared__ int s_cnt;
     const int t = threadIdx.x;
+    // Workgroups 1.. : Frame::isInFrustum over the local map points (independent of the keypoints) beside workgroup 0's frame
+    // set-up -- as a launch of its own it cost 4.5 us plus a launch gap in front of every tracked frame's searches
+    if (blockIdx.x > 0) {
+        const int m = ((int)blockIdx.x - 1) * kFrameThreads + t;
+        if (m < FA.n) eao::frame::frustum_point(FA, m);
+        return;
+    }
     const int n = min(max(*nPtr, 0), cap);
     if (t == 0) s_cnt = 0;
     for (int m = t; m < nMp; m += kFrameThreads) A.mSkip[m] = 0;
@@ -201,10 +211,10 @@ __global__ __launch_bounds__(256) void k_track_queries(int nMp, const unsigned c
 //      upstream's
 // ONE workgroup; occupancy and minq in LDS.  Converges in a handful of rounds (overlaps are local).
 constexpr int kAssignThreads = 1024;
-__global__ __launch_bounds__(kAssignThreads) void k_track_assign(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
-                                                                 const int* __restrict__ segStart, const int* __restrict__ segCount,
-                                                                 const int* __restrict__ oct, unsigned char* __restrict__ occG, float nnratio,
-                                                                 int* __restrict__ match, int* __restrict__ counts) {
+__device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
+                                                  const int* __restrict__ segStart, const int* __restrict__ segCount,
+                                                  const int* __restrict__ oct, unsigned char* occG, float nnratio,
+                                                  int* match, int* counts) {
     extern __shared__ int asm_[];
     int* minq = asm_;                                           // cap
     unsigned char* occ = reinterpret_cast<unsigned char*>(minq + cap);   // cap
@@ -288,11 +298,11 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign(int nMp, int ca
 // order (src/Optimizer.cc:361-447): Xw, (u, v, uR), invSigma2 of the octave, stereo / robust flags.  ONE workgroup.
 struct EdgeArrays { double *Xw, *obs, *info; unsigned char* flags; int* eKp; };
 constexpr int kEdgeThreads = 1024;
-__global__ __launch_bounds__(kEdgeThreads) void k_track_edges(int nMp, int cap, const int* __restrict__ match, int* __restrict__ kpMp,
-                                                              const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ ur,
-                                                              const int* __restrict__ oct, const float* __restrict__ mXw,
-                                                              const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, int* __restrict__ counts,
-                                                              unsigned char* __restrict__ eOutl) {
+__device__ __forceinline__ void track_edges_body(int nMp, int cap, const int* match, int* kpMp,
+                                                 const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ ur,
+                                                 const int* __restrict__ oct, const float* __restrict__ mXw,
+                                                 const float* __restrict__ invSigma2, const EdgeArrays& E, int edgeCap, int* counts,
+                                                 unsigned char* eOutl) {
     __shared__ int s_wsum[kEdgeThreads / 64], s_base;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int n = counts[0];
@@ -329,6 +339,22 @@ __global__ __launch_bounds__(kEdgeThreads) void k_track_edges(int nMp, int cap, 
         if (s_base > edgeCap) atomicOr(&counts[4], 2);
         counts[2] = min(s_base, edgeCap);
     }
+}
+
+// ONE launch for the greedy assignment and the edge list behind it (both are single-workgroup steps of 1024 threads; as two
+// launches the second one waited a launch gap for the first).  nMp = 0: no search ran, only the prior matches become edges.
+static_assert(kAssignThreads == kEdgeThreads, "one workgroup runs both steps");
+__global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
+                                                                       const int* __restrict__ segStart, const int* __restrict__ segCount,
+                                                                       const int* __restrict__ oct, unsigned char* occG, float nnratio, int* match, int* counts,
+                                                                       int* kpMp, const float* __restrict__ kx, const float* __restrict__ ky,
+                                                                       const float* __restrict__ ur, const float* __restrict__ mXw,
+                                                                       const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl) {
+    if (nMp > 0) {
+        track_assign_body(nMp, cap, q, lists, segStart, segCount, oct, occG, nnratio, match, counts);
+        __syncthreads();      // match[] is complete (and visible to the whole workgroup)
+    }
+    track_edges_body(nMp, cap, match, kpMp, kx, ky, ur, oct, mXw, invSigma2, E, edgeCap, counts, eOutl);
 }
 
 // everything the host needs, in one block: [SE3 | result ints | counts | kpMp | kpOutlier | uRight | depth]
@@ -466,9 +492,8 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     int npow2 = 64;
     while (npow2 < C) npow2 <<= 1;
     const float invW = (float)c.grid_cols / (c.max_x - c.min_x), invH = (float)c.grid_rows / (c.max_y - c.min_y);   // src/Frame.cc:258-259
-    hipLaunchKernelGGL(k_track_frame, dim3(1), dim3(kFrameThreads), (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth, depth_pitch, width, height, c.mbf,
-                       c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A);
-    eao_status st;
+    eao::frame::FrustumArgs FA;
+    std::memset(&FA, 0, sizeof(FA));
     if (nMp > 0) {
         eao::frame::FrustumDevArgs F;
         F.n = nMp; F.Xw = h->mXw; F.normal = h->mNormal; F.minDist = h->mMin; F.maxDist = h->mMax; F.maxDistNum = h->mNum;
@@ -481,7 +506,12 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
         F.fx = c.fx; F.fy = c.fy; F.cx = c.cx; F.cy = c.cy; F.mbf = c.mbf; F.minX = c.min_x; F.maxX = c.max_x; F.minY = c.min_y; F.maxY = c.max_y;
         F.logScale = c.log_scale_factor; F.cosLimit = 0.5f;          // Tracking::SearchLocalPoints: isInFrustum(pMP, 0.5)
         F.inView = h->inView; F.projX = h->projX; F.projY = h->projY; F.projXR = h->projXR; F.viewCos = h->viewCos; F.level = h->level;
-        if ((st = eao::frame::enqueue_frustum_device(F, s))) return st;
+        eao::frame::fill_frustum_args(F, FA);
+    }
+    hipLaunchKernelGGL(k_track_frame, dim3(1 + (nMp > 0 ? eao::cdiv(nMp, kFrameThreads) : 0)), dim3(kFrameThreads), (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth,
+                       depth_pitch, width, height, c.mbf, c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A, FA);
+    eao_status st;
+    if (nMp > 0) {
         hipLaunchKernelGGL(k_track_queries, dim3(eao::cdiv(nMp, 256)), dim3(256), 0, s, nMp, h->mActive, h->mSkip, h->inView, h->projX, h->projY, h->projXR,
                            h->viewCos, h->level, h->dScale, c.nlevels, th, h->q, h->counts, h->cursor);
         eao::match::FrameDevArgs FD;
@@ -490,14 +520,12 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
         FD.minX = c.min_x; FD.minY = c.min_y; FD.invW = invW; FD.invH = invH; FD.cols = c.grid_cols; FD.rows = c.grid_rows;
         if ((st = eao::match::enqueue_candidates_device(FD, h->q, h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
                                                         h->segCount, h->cursor, s, true))) return st;
-        hipLaunchKernelGGL(k_track_assign, dim3(1), dim3(kAssignThreads), (size_t)C * 5, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
-                           nnratio, h->match, h->counts);
     }
     EdgeArrays E;
     E.Xw = h->eXw; E.obs = h->eObs; E.info = h->eInfo; E.flags = h->eFlags; E.eKp = h->eKp;
     const int edgeCap = std::min(C, 2048);
-    hipLaunchKernelGGL(k_track_edges, dim3(1), dim3(kEdgeThreads), 0, s, nMp, C, h->match, h->kpMp, h->kx, h->ky, h->ur, h->oct, h->mXw, h->dInvSigma2, E,
-                       edgeCap, h->counts, h->eOutl);
+    hipLaunchKernelGGL(k_track_assign_edges, dim3(1), dim3(kAssignThreads), (size_t)C * 5, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
+                       nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->dInvSigma2, E, edgeCap, h->eOutl);
     // result block layout
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
     unsigned char* r = h->res;
