@@ -14,6 +14,7 @@ struct PoseChainArgs {            // every pointer is a device address (outSE3 /
     const double* Xw; const double* obs; const double* info; unsigned char* flags; double* err; unsigned char* outlier;
     float Tcw0[16]; float fx, fy, cx, cy, bf;
     void* outSE3; int* outResult; double* outTrace;
+    const int* scatterIdx; unsigned char* scatterOut;   // optional: the final outlier flag of edge e also goes to scatterOut[scatterIdx[e]] (mvbOutlier by keypoint)
 };
 size_t pose_se3_bytes();
 void pose_se3_to_Tcw(const void* se3, float* T);       // Converter::toCvMat(SE3Quat)

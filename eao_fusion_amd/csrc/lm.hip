@@ -451,6 +451,8 @@ struct PoseDev {
     GP<const double> planes;
     GP<unsigned char> planeOutlier;
     double deltaPlane;
+    GP<const int> scatterIdx;        // chained tracking: edge -> keypoint; the final outlier flags also land in scatterOut by keypoint
+    GP<unsigned char> scatterOut;    // (null otherwise)
 };
 
 constexpr int kPoseThreads = 512;
@@ -783,7 +785,10 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
     }
 #pragma unroll
     for (int k = 0; k < EPT; k++)
-        if (eLive[k]) P.outlier[t + k * kPoseThreads] = eOut[k];
+        if (eLive[k]) {
+            P.outlier[t + k * kPoseThreads] = eOut[k];
+            if (P.scatterOut) P.scatterOut[P.scatterIdx[t + k * kPoseThreads]] = eOut[k];
+        }
     if (t < M) P.planeOutlier[t] = s_pout[t];
     if (t == 0) { *P.Tout = s_est; P.result[1] = s_iters; P.result[2] = s_ntrace; }
     if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
@@ -3104,7 +3109,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     const bool zeroCopy = n <= 4 * kPoseThreads && M == 0 && !envUpload;      // (plane coefficients are re-read in every pass: uploaded)
     if (!zeroCopy) EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
     PoseDev P;
-    P.nDev = nullptr;
+    P.nDev = nullptr; P.scatterIdx = nullptr; P.scatterOut = nullptr;
     P.n = n; P.Xw = dXw; P.obs = dobs; P.info = dinfo; P.err = derr; P.flags = dflags; P.outlier = ooutl;
     if (zeroCopy) { P.Xw = (const double*)hostp(dXw); P.obs = (const double*)hostp(dobs); P.info = (const double*)hostp(dinfo); P.flags = (unsigned char*)hostp(dflags); }
     P.T0 = se3_from_Tcw_f32(p->Tcw);
@@ -4103,6 +4108,7 @@ eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
     P.cam.fx = a.fx; P.cam.fy = a.fy; P.cam.cx = a.cx; P.cam.cy = a.cy; P.cam.bf = a.bf; P.cam.bf_f = a.bf;
     P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
     P.Tout = (SE3*)a.outSE3; P.result = a.outResult; P.trace = a.outTrace;
+    P.scatterIdx = a.scatterIdx; P.scatterOut = a.scatterOut;
     P.nPlanes = 0; P.planes = nullptr; P.planeOutlier = nullptr; P.deltaPlane = (float)std::sqrt(300.0);
     P.dbg = nullptr;
     if (a.cap <= 2 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<2>, dim3(1), dim3(kPoseThreads), 0, s, P);

@@ -7,7 +7,7 @@
 // that never leave HBM: the keypoints, descriptors and keypoint count come straight from eao_orb_extract_batch_device, the
 // local map is uploaded when it changes, and one copy brings the pose, the matches and the outlier flags back.
 //
-// Six launches (eight until late in round 2: every launch of this latency chain costs its ~3 us gap):
+// Five launches (eight until late in round 2: every launch of this latency chain costs its ~3 us gap):
 //   k_track_frame    workgroup 0: cv::KeyPoint records -> coordinate / octave / angle arrays, mvuRight / mvDepth from the
 //                    depth image, PosInGrid keys sorted in LDS -> the grid-order walk list k_match_candidates uses;
 //                    workgroups 1..: Frame::isInFrustum, one thread per local map point (frustum_point, chain_internal.h -- the
@@ -20,7 +20,8 @@
 //                    so far, and becomes final when no earlier undecided point lists any keypoint its decision depends on
 //       edges        mvpMapPoints by keypoint (prior matches + new ones), the PoseOptimization edges in keypoint order
 //   k_pose_optimization (lm.hip) with the edge count read on the device
-//   k_track_finish   mvbOutlier by keypoint, everything the host needs in one block
+//                    (it also scatters mvbOutlier by keypoint into the result block; the rest of the block is written by the tail of
+//                    k_track_assign_edges -- a k_track_finish launch behind PoseOptimization until late in round 2)
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -297,6 +298,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
 // mvpMapPoints by keypoint (the prior matches + this search's), and the edges of Optimizer::PoseOptimization in keypoint
 // order (src/Optimizer.cc:361-447): Xw, (u, v, uR), invSigma2 of the octave, stereo / robust flags.  ONE workgroup.
 struct EdgeArrays { double *Xw, *obs, *info; unsigned char* flags; int* eKp; };
+struct ResultBlock { int* counts; int* kpMp; unsigned char* outl; float* ur; float* dz; };      // slices of the host-visible result block
 constexpr int kEdgeThreads = 1024;
 __device__ __forceinline__ void track_edges_body(int nMp, int cap, const int* match, int* kpMp,
                                                  const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ ur,
@@ -349,35 +351,27 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
                                                                        const int* __restrict__ oct, unsigned char* occG, float nnratio, int* match, int* counts,
                                                                        int* kpMp, const float* __restrict__ kx, const float* __restrict__ ky,
                                                                        const float* __restrict__ ur, const float* __restrict__ mXw,
-                                                                       const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl) {
+                                                                       const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl,
+                                                                       const float* __restrict__ dz, ResultBlock R) {
     if (nMp > 0) {
         track_assign_body(nMp, cap, q, lists, segStart, segCount, oct, occG, nnratio, match, counts);
         __syncthreads();      // match[] is complete (and visible to the whole workgroup)
     }
     track_edges_body(nMp, cap, match, kpMp, kx, ky, ur, oct, mXw, invSigma2, E, edgeCap, counts, eOutl);
+    __syncthreads();          // counts[2], kpMp[] are final
+    // everything the host needs except the pose and mvbOutlier, which PoseOptimization itself writes (by keypoint, through
+    // the edge -> keypoint table): the block lies in mapped host memory
+    const int t = threadIdx.x, n = counts[0];
+    if (t < 8) R.counts[t] = t < 5 ? counts[t] : 0;
+    for (int i = t; i < cap; i += kAssignThreads) {
+        R.kpMp[i] = i < n ? kpMp[i] : -1;
+        R.ur[i] = i < n ? ur[i] : -1.f;
+        R.dz[i] = i < n ? dz[i] : -1.f;
+        R.outl[i] = 0;
+    }
 }
 
 // everything the host needs, in one block: [SE3 | result ints | counts | kpMp | kpOutlier | uRight | depth]
-__global__ __launch_bounds__(256) void k_track_finish(int cap, const int* __restrict__ counts, const int* __restrict__ kpMp, const int* __restrict__ eKp,
-                                                      const unsigned char* __restrict__ eOutl, const float* __restrict__ ur, const float* __restrict__ dz,
-                                                      int* __restrict__ oCounts, int* __restrict__ oKpMp, unsigned char* __restrict__ oOutl,
-                                                      float* __restrict__ oUr, float* __restrict__ oDz) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < 8) oCounts[i] = i < 5 ? counts[i] : 0;
-    if (i >= cap) return;
-    const int n = counts[0], ne = counts[2];
-    oKpMp[i] = i < n ? kpMp[i] : -1;
-    oUr[i] = i < n ? ur[i] : -1.f;
-    oDz[i] = i < n ? dz[i] : -1.f;
-    oOutl[i] = 0;
-    // (the scatter below runs over edges, i.e. other indices: a second launch-wide pass would need a grid sync -- instead
-    //  every thread looks its keypoint up among the edges by binary search: eKp is ascending)
-    if (i < n && kpMp[i] >= 0 && ne >= 3) {
-        int lo = 0, hi = ne;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (eKp[mid] < i) lo = mid + 1; else hi = mid; }
-        if (lo < ne && eKp[lo] == i) oOutl[i] = eOutl[lo];
-    }
-}
 
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -524,8 +518,6 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     EdgeArrays E;
     E.Xw = h->eXw; E.obs = h->eObs; E.info = h->eInfo; E.flags = h->eFlags; E.eKp = h->eKp;
     const int edgeCap = std::min(C, 2048);
-    hipLaunchKernelGGL(k_track_assign_edges, dim3(1), dim3(kAssignThreads), (size_t)C * 5, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
-                       nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->dInvSigma2, E, edgeCap, h->eOutl);
     // result block layout
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
     unsigned char* r = h->res;
@@ -538,15 +530,17 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     unsigned char* rOutl = r + ro; ro += al256(C);
     float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
+    ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz};
+    hipLaunchKernelGGL(k_track_assign_edges, dim3(1), dim3(kAssignThreads), (size_t)C * 5, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
+                       nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz, RB);
     eao::lm::PoseChainArgs PA;
     PA.nEdges = h->counts + 2; PA.cap = edgeCap;
     PA.Xw = h->eXw; PA.obs = h->eObs; PA.info = h->eInfo; PA.flags = h->eFlags; PA.err = h->eErr; PA.outlier = h->eOutl;
     std::memcpy(PA.Tcw0, Tcw_prior, 64);
     PA.fx = c.fx; PA.fy = c.fy; PA.cx = c.cx; PA.cy = c.cy; PA.bf = c.mbf;
     PA.outSE3 = rSE3; PA.outResult = rRes; PA.outTrace = rTrace;
+    PA.scatterIdx = h->eKp; PA.scatterOut = rOutl;      // mvbOutlier by keypoint, straight into the result block
     if ((st = eao::lm::enqueue_pose_device(PA, s))) return st;
-    hipLaunchKernelGGL(k_track_finish, dim3(eao::cdiv(std::max(C, 8), 256)), dim3(256), 0, s, C, h->counts, h->kpMp, h->eKp, h->eOutl, h->ur, h->dz, rCounts,
-                       rKpMp, rOutl, rUr, rDz);
     // ---- the results are in host memory when the stream has drained
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
