@@ -659,6 +659,9 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
                 lap(0);
                 block_sum_lds<28, kPoseThreads>(acc, red, sums);
                 lap(1);
+                // (thread 0 alone carries the LM state from here to the end of the iteration: no barrier until its first trial
+                //  pose is ready -- one barrier per iteration and two per trial fewer than the step-by-step version)
+                double iniChi = 0;
                 if (t == 0) {
                     s_cur = sums[27];
                     if (it == 0) {
@@ -669,9 +672,8 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
                         s_ni = 2;
                         s_nbad = 0;
                     }
+                    iniChi = s_cur;
                 }
-                __syncthreads();
-                const double iniChi = s_cur;
                 int qmax = 0;
                 double rho = 0;
                 do {
@@ -710,10 +712,15 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
                         chi[0] += r0;
                     }
                     lap(3);
-                    block_sum<1, kPoseThreads>(chi, red, &s_tmp);
+                    {   // block_sum<1, kPoseThreads> with its second half (the sum over the waves, same order) left to thread 0 below
+                        const double x = wave_sum_f64_lane63(chi[0]);
+                        if ((t & 63) == 63) red[t >> 6] = x;
+                    }
+                    __syncthreads();
                     lap(4);
                     if (t == 0) {
-                        double tempChi = s_tmp;
+                        double tempChi = 0;
+                        for (int w = 0; w < kPoseThreads / 64; w++) tempChi += red[w];
                         if (!s_ok) tempChi = DBL_MAX;
                         double r = s_cur - tempChi;
                         double scale = 0;
@@ -733,23 +740,23 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
                             s_est = s_backup;
                         }
                         s_rho = r;
+                        const int q1 = qmax + 1;
+                        if (!(r < 0 && q1 < 10)) {      // the last trial of this iteration: close the iteration here
+                            if (s_ntrace < 64) { P.trace[s_ntrace] = s_lambda; P.trace[64 + s_ntrace] = s_cur; P.trace[128 + s_ntrace] = q1; s_ntrace++; }
+                            s_iters++;
+                            int term = (q1 == 10 || r == 0) ? 1 : 0;
+                            if (!term) {
+                                if ((iniChi - s_cur) * 1e3 < iniChi) s_nbad++; else s_nbad = 0;
+                                if (s_nbad >= 3) term = 1;
+                            }
+                            s_flag = term;
+                        }
                     }
                     __syncthreads();
                     lap(5);
                     rho = s_rho;
                     qmax++;
                 } while (rho < 0 && qmax < 10);
-                if (t == 0) {
-                    if (s_ntrace < 64) { P.trace[s_ntrace] = s_lambda; P.trace[64 + s_ntrace] = s_cur; P.trace[128 + s_ntrace] = qmax; s_ntrace++; }
-                    s_iters++;
-                    int term = (qmax == 10 || rho == 0) ? 1 : 0;
-                    if (!term) {
-                        if ((iniChi - s_cur) * 1e3 < iniChi) s_nbad++; else s_nbad = 0;
-                        if (s_nbad >= 3) term = 1;
-                    }
-                    s_flag = term;
-                }
-                __syncthreads();
                 ok = !s_flag;
             }
         }
