@@ -97,10 +97,21 @@ struct FrameDevArgs {             // a frame in the layout k_match_candidates wa
     const int* order; const unsigned short* cellx; const unsigned short* celly;
     float minX, minY, invW, invH; int cols, rows;
 };
+// When handed to enqueue_candidates_device, the wave of query m BUILDS the query itself -- the search window of local map point m
+// (Tracking::SearchLocalPoints / ORBmatcher::SearchByProjection, src/ORBmatcher.cc:45-137: RadiusByViewingCos x th x scale factor
+// of the predicted level) from the tracker's per-point arrays -- and stores it in qOut[m] for the assignment step; q is then unused.
+struct QueryBuild {
+    const unsigned char* active; const unsigned char* skip; const unsigned char* inView;
+    const float* projX; const float* projY; const float* projXR; const float* viewCos; const int* level; const float* scale;
+    int nlevels; float th;
+    int* errFlags;            // bit 0: a point in view has a predicted level outside the pyramid
+    Query* qOut;
+};
 // candidate lists of nq device-resident queries: out (packed distance << 16 | keypoint), segStart / segCount per query,
 // cursor (zeroed here)
 eao_status enqueue_candidates_device(const FrameDevArgs& F, const Query* q, const uint8_t* qdesc, int nq, unsigned* out, int outCap,
-                                     int* segStart, int* segCount, int* cursor, hipStream_t s, bool cursorIsZero = false);
+                                     int* segStart, int* segCount, int* cursor, hipStream_t s, bool cursorIsZero = false,
+                                     const QueryBuild* build = nullptr);
 }  // namespace match
 
 }  // namespace eao

@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "match_internal.h"
+#include "chain_internal.h"
 
 using eao::match::Query;
 using eao::match::Lists;
@@ -45,11 +46,26 @@ __device__ __forceinline__ int dist256(const uint4 a0, const uint4 a1, const uin
 // out: packed (distance << 16 | keypoint index); segStart/segCount per query; cursor = global fill position
 __global__ __launch_bounds__(256) void k_match_candidates(FrameDev F, const Query* __restrict__ q, const uint4* __restrict__ qdesc, int nq,
                                                           unsigned* __restrict__ out, int outCap, int* __restrict__ segStart,
-                                                          int* __restrict__ segCount, int* __restrict__ cursor) {
+                                                          int* __restrict__ segCount, int* __restrict__ cursor, eao::match::QueryBuild B) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
-    const Query Q = q[qi];
+    Query Q;
+    if (B.inView) {      // the tracker's chain: the window of local map point qi, built here (QueryBuild, chain_internal.h)
+        const int m = qi;
+        Q.active = (B.active[m] && B.inView[m] && !B.skip[m]) ? 1 : 0;
+        int lvl = Q.active ? B.level[m] : 0;
+        if (Q.active && (lvl < 0 || lvl >= B.nlevels)) { if (lane == 0) atomicOr(B.errFlags, 1); Q.active = 0; lvl = 0; }   // (upstream would index out of range)
+        float r = (double)B.viewCos[m] > 0.998 ? 2.5f : 4.0f;          // RadiusByViewingCos, :131-137
+        if (B.th != 1.0f) r *= B.th;
+        const float rs = Q.active ? r * B.scale[lvl] : 0.f;
+        Q.x = B.projX[m]; Q.y = B.projY[m]; Q.r = rs;
+        Q.minLevel = lvl - 1; Q.maxLevel = lvl;
+        Q.urRef = B.projXR[m]; Q.urTol = rs;
+        if (lane == 0) B.qOut[m] = Q;
+    } else {
+        Q = q[qi];
+    }
     if (F.nOrderedDev) F.nOrdered = *F.nOrderedDev;
     int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
     bool any = Q.active != 0;
@@ -212,7 +228,7 @@ eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Qu
     D.minX = F->min_x; D.minY = F->min_y; D.invW = F->grid_inv_w; D.invH = F->grid_inv_h; D.cols = F->grid_cols; D.rows = F->grid_rows;
     hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, (const Query*)(c.dev.p + oQ),
                        (const uint4*)(c.dev.p + oQd), nq, (unsigned*)c.out.p, (int)std::min(outCap, (size_t)0x7FFFFFFF), c.metaDev.p,
-                       c.metaDev.p + nq, c.metaDev.p + 2 * (size_t)nq);
+                       c.metaDev.p + nq, c.metaDev.p + 2 * (size_t)nq, eao::match::QueryBuild{});
     EAO_HIP(hipMemcpyAsync(meta, c.metaDev.p, (2 * (size_t)nq + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
@@ -268,7 +284,7 @@ eao_status eao::match::pair_distances(const uint8_t* descA, int nA, const uint8_
 
 #include "chain_internal.h"
 eao_status eao::match::enqueue_candidates_device(const FrameDevArgs& F, const Query* q, const uint8_t* qdesc, int nq, unsigned* out, int outCap,
-                                                 int* segStart, int* segCount, int* cursor, hipStream_t s, bool cursorIsZero) {
+                                                 int* segStart, int* segCount, int* cursor, hipStream_t s, bool cursorIsZero, const QueryBuild* build) {
     if (nq <= 0) return EAO_OK;
     FrameDev D;
     D.n = F.cap; D.nOrdered = 0; D.nOrderedDev = F.nOrdered;
@@ -276,7 +292,10 @@ eao_status eao::match::enqueue_candidates_device(const FrameDevArgs& F, const Qu
     D.order = F.order; D.cellx = F.cellx; D.celly = F.celly;
     D.minX = F.minX; D.minY = F.minY; D.invW = F.invW; D.invH = F.invH; D.cols = F.cols; D.rows = F.rows;
     if (!cursorIsZero) EAO_HIP(hipMemsetAsync(cursor, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, q, (const uint4*)qdesc, nq, out, outCap, segStart, segCount, cursor);
+    QueryBuild B;
+    std::memset(&B, 0, sizeof(B));
+    if (build) B = *build;
+    hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, q, (const uint4*)qdesc, nq, out, outCap, segStart, segCount, cursor, B);
     EAO_HIP(hipGetLastError());
     return EAO_OK;
 }

@@ -7,13 +7,14 @@
 // that never leave HBM: the keypoints, descriptors and keypoint count come straight from eao_orb_extract_batch_device, the
 // local map is uploaded when it changes, and one copy brings the pose, the matches and the outlier flags back.
 //
-// Five launches (eight until late in round 2: every launch of this latency chain costs its ~3 us gap):
+// Four launches (eight until late in round 2: every launch of this latency chain costs its ~3 us gap):
 //   k_track_frame    workgroup 0: cv::KeyPoint records -> coordinate / octave / angle arrays, mvuRight / mvDepth from the
 //                    depth image, PosInGrid keys sorted in LDS -> the grid-order walk list k_match_candidates uses;
 //                    workgroups 1..: Frame::isInFrustum, one thread per local map point (frustum_point, chain_internal.h -- the
 //                    same code as frame.hip's k_is_in_frustum), beside it
-//   k_track_queries  search windows of the points in view (RadiusByViewingCos x th x scale factor of the predicted level)
-//   k_match_candidates (match.hip) candidate lists in upstream's order
+//   k_match_candidates (match.hip) one wave per local map point: its search window (RadiusByViewingCos x th x scale factor of the
+//                    predicted level -- QueryBuild, chain_internal.h; a launch of its own until late in round 2), then its candidate
+//                    list in upstream's order
 //   k_track_assign_edges   one workgroup, two steps:
 //       assignment   upstream's greedy assignment (a keypoint taken by an earlier map point is skipped by later ones) WITHOUT
 //                    walking the map points one by one: rounds in which every undecided point decides from the final claims
@@ -65,6 +66,7 @@ namespace {
 struct FrameArrays {
     float *kx, *ky, *ang, *ur, *dz; int* oct; int* order; unsigned short *cellx, *celly; int* counts;
     int* prior; int* kpMp; unsigned char* occ; unsigned char* mSkip;
+    int* cursor;      // k_match_candidates' list cursor, zeroed here (instead of a fill launch in front of it)
 };
 
 constexpr int kFrameThreads = 1024;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
         return;
     }
     const int n = min(max(*nPtr, 0), cap);
-    if (t == 0) s_cnt = 0;
+    if (t == 0) { s_cnt = 0; *A.cursor = 0; }
     for (int m = t; m < nMp; m += kFrameThreads) A.mSkip[m] = 0;
     __syncthreads();
     for (int i = t; i < npow2; i += kFrameThreads) {
@@ -180,27 +182,6 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
 }
 
 // ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th), src/ORBmatcher.cc:51-81: the window of every point in view
-__global__ __launch_bounds__(256) void k_track_queries(int nMp, const unsigned char* __restrict__ active, const unsigned char* __restrict__ skip,
-                                                       const unsigned char* __restrict__ inView, const float* __restrict__ projX,
-                                                       const float* __restrict__ projY, const float* __restrict__ projXR,
-                                                       const float* __restrict__ viewCos, const int* __restrict__ level,
-                                                       const float* __restrict__ scale, int nlevels, float th, Query* __restrict__ q,
-                                                       int* __restrict__ counts, int* __restrict__ cursor) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m == 0) *cursor = 0;             // k_match_candidates' list cursor (instead of a fill launch in front of it)
-    if (m >= nMp) return;
-    Query Q;
-    Q.active = (active[m] && inView[m] && !skip[m]) ? 1 : 0;
-    int lvl = Q.active ? level[m] : 0;
-    if (Q.active && (lvl < 0 || lvl >= nlevels)) { atomicOr(&counts[4], 1); Q.active = 0; lvl = 0; }   // (upstream would index out of range)
-    float r = (double)viewCos[m] > 0.998 ? 2.5f : 4.0f;          // RadiusByViewingCos, :131-137
-    if (th != 1.0f) r *= th;
-    const float rs = Q.active ? r * scale[lvl] : 0.f;
-    Q.x = projX[m]; Q.y = projY[m]; Q.r = rs;
-    Q.minLevel = lvl - 1; Q.maxLevel = lvl;
-    Q.urRef = projXR[m]; Q.urTol = rs;
-    q[m] = Q;
-}
 
 // Upstream walks the map points in index order; a keypoint assigned to an earlier point is skipped by every later one
 // (src/ORBmatcher.cc:87-89, 123).  A point's decision -- the two smallest (distance, list position) among its unoccupied
@@ -482,7 +463,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     }
     FrameArrays A;
     A.kx = h->kx; A.ky = h->ky; A.ang = h->ang; A.ur = h->ur; A.dz = h->dz; A.oct = h->oct; A.order = h->order; A.cellx = h->cellx; A.celly = h->celly;
-    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = h->mSkip;
+    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = h->mSkip; A.cursor = h->cursor;
     int npow2 = 64;
     while (npow2 < C) npow2 <<= 1;
     const float invW = (float)c.grid_cols / (c.max_x - c.min_x), invH = (float)c.grid_rows / (c.max_y - c.min_y);   // src/Frame.cc:258-259
@@ -506,14 +487,16 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
                        depth_pitch, width, height, c.mbf, c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A, FA);
     eao_status st;
     if (nMp > 0) {
-        hipLaunchKernelGGL(k_track_queries, dim3(eao::cdiv(nMp, 256)), dim3(256), 0, s, nMp, h->mActive, h->mSkip, h->inView, h->projX, h->projY, h->projXR,
-                           h->viewCos, h->level, h->dScale, c.nlevels, th, h->q, h->counts, h->cursor);
+        // the search windows are built by the candidate kernel itself (one wave per map point), which leaves them in h->q for the assignment
+        eao::match::QueryBuild QB;
+        QB.active = h->mActive; QB.skip = h->mSkip; QB.inView = h->inView; QB.projX = h->projX; QB.projY = h->projY; QB.projXR = h->projXR;
+        QB.viewCos = h->viewCos; QB.level = h->level; QB.scale = h->dScale; QB.nlevels = c.nlevels; QB.th = th; QB.errFlags = h->counts + 4; QB.qOut = h->q;
         eao::match::FrameDevArgs FD;
         FD.cap = C; FD.nOrdered = h->counts + 1; FD.kx = h->kx; FD.ky = h->ky; FD.oct = h->oct; FD.ur = h->ur; FD.desc = d_desc;
         FD.order = h->order; FD.cellx = h->cellx; FD.celly = h->celly;
         FD.minX = c.min_x; FD.minY = c.min_y; FD.invW = invW; FD.invH = invH; FD.cols = c.grid_cols; FD.rows = c.grid_rows;
         if ((st = eao::match::enqueue_candidates_device(FD, h->q, h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
-                                                        h->segCount, h->cursor, s, true))) return st;
+                                                        h->segCount, h->cursor, s, true, &QB))) return st;
     }
     EdgeArrays E;
     E.Xw = h->eXw; E.obs = h->eObs; E.info = h->eInfo; E.flags = h->eFlags; E.eKp = h->eKp;
