@@ -7,7 +7,7 @@ python3 - <<'PY'
 import csv, glob, re
 f = glob.glob("gpurun_out/tr_track/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_track_finish" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_pose_optimization" in r["Kernel_Name"]]      # the last kernel of a tracked frame
 a, b = idx[-3] + 1, idx[-2] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b]:
