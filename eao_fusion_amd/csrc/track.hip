@@ -200,12 +200,13 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
     extern __shared__ int asm_[];
     int* minq = asm_;                                           // cap
     unsigned char* occ = reinterpret_cast<unsigned char*>(minq + cap);   // cap
+    unsigned char* octL = occ + cap;                            // cap: the keypoints' octaves (read per candidate in every round)
     __shared__ int s_left, s_nm;
     const int t = threadIdx.x;
     constexpr int PER = 4;                                      // map points per thread (capMp <= 4096)
     int st_[PER], cn_[PER];
     bool open[PER];
-    for (int i = t; i < cap; i += kAssignThreads) occ[i] = occG[i];
+    for (int i = t; i < cap; i += kAssignThreads) { occ[i] = occG[i]; octL[i] = (unsigned char)oct[i]; }
     if (t == 0) s_nm = 0;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
@@ -240,8 +241,8 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
                 const unsigned it = lists[st_[u] + k];
                 const int i = (int)(it & 0xFFFF), d = (int)(it >> 16);
                 if (occ[i]) continue;
-                if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = oct[i]; bestIdx = i; }
-                else if (d < bestDist2) { bestLevel2 = oct[i]; bestDist2 = d; }
+                if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = octL[i]; bestIdx = i; }
+                else if (d < bestDist2) { bestLevel2 = octL[i]; bestDist2 = d; }
             }
             // final? every candidate the decision looked at with an effect -- distance <= the second best (all of them when
             // fewer than two are free) -- must not be listed by an earlier undecided point
@@ -514,7 +515,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
     ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz};
-    hipLaunchKernelGGL(k_track_assign_edges, dim3(1), dim3(kAssignThreads), (size_t)C * 5, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
+    hipLaunchKernelGGL(k_track_assign_edges, dim3(1), dim3(kAssignThreads), (size_t)C * 6, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
                        nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz, RB);
     eao::lm::PoseChainArgs PA;
     PA.nEdges = h->counts + 2; PA.cap = edgeCap;
