@@ -96,6 +96,7 @@ struct FrameDevArgs {             // a frame in the layout k_match_candidates wa
     const float* kx; const float* ky; const int* oct; const float* ur; const uint8_t* desc;
     const int* order; const unsigned short* cellx; const unsigned short* celly;
     float minX, minY, invW, invH; int cols, rows;
+    const int* colStart;          // optional, cols + 1 entries: first ordered entry of every grid column (a query then walks its columns only)
 };
 // When handed to enqueue_candidates_device, the wave of query m BUILDS the query itself -- the search window of local map point m
 // (Tracking::SearchLocalPoints / ORBmatcher::SearchByProjection, src/ORBmatcher.cc:45-137: RadiusByViewingCos x th x scale factor

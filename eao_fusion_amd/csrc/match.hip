@@ -34,6 +34,8 @@ struct FrameDev {
     const uint4* desc;        // n x 2
     const int* order;         // keypoint indices in grid order
     const unsigned short* cellx; const unsigned short* celly;   // per ordered entry
+    const int* colStart;      // when set (cols + 1 entries): first ordered entry of every grid column -- the walk list is in (column, row,
+                              // index) order, so a query's candidates all lie in [colStart[x0], colStart[x1 + 1])
     float minX, minY, invW, invH;
     int cols, rows;
 };
@@ -79,14 +81,18 @@ __global__ __launch_bounds__(256) void k_match_candidates(FrameDev F, const Quer
     const bool checkLevels = (Q.minLevel > 0) || (Q.maxLevel >= 0);
     const uint4 d0 = qdesc[2 * qi], d1 = qdesc[2 * qi + 1];
     int base = 0, total = 0;
+    // (the tracker's chain hands the column starts over: a window of one or two grid columns then costs one round of the wave per
+    //  sweep instead of a walk over every keypoint of the frame -- 18 rounds for 1100 keypoints)
+    int oBeg = 0, oEnd = F.nOrdered;
+    if (any && F.colStart) { oBeg = F.colStart[x0]; oEnd = min(F.colStart[x1 + 1], F.nOrdered); }
     for (int sweep = 0; sweep < 2; sweep++) {
         int run = 0;
         if (any) {
-            for (int o0 = 0; o0 < F.nOrdered; o0 += 64) {
+            for (int o0 = oBeg; o0 < oEnd; o0 += 64) {
                 const int o = o0 + lane;
                 bool pass = false;
                 int i = 0;
-                if (o < F.nOrdered) {
+                if (o < oEnd) {
                     const int cx = F.cellx[o], cy = F.celly[o];
                     if (cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1) {
                         i = F.order[o];
@@ -223,7 +229,7 @@ eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Qu
     D.n = n; D.nOrdered = no;
     D.kx = (const float*)(c.dev.p + oKx); D.ky = (const float*)(c.dev.p + oKy); D.ur = (const float*)(c.dev.p + oUr);
     D.oct = (const int*)(c.dev.p + oOc); D.order = (const int*)(c.dev.p + oOr);
-    D.cellx = (const unsigned short*)(c.dev.p + oCx); D.celly = (const unsigned short*)(c.dev.p + oCy);
+    D.cellx = (const unsigned short*)(c.dev.p + oCx); D.celly = (const unsigned short*)(c.dev.p + oCy); D.colStart = nullptr;
     D.desc = (const uint4*)(c.dev.p + oDe);
     D.minX = F->min_x; D.minY = F->min_y; D.invW = F->grid_inv_w; D.invH = F->grid_inv_h; D.cols = F->grid_cols; D.rows = F->grid_rows;
     hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, (const Query*)(c.dev.p + oQ),
@@ -289,7 +295,7 @@ eao_status eao::match::enqueue_candidates_device(const FrameDevArgs& F, const Qu
     FrameDev D;
     D.n = F.cap; D.nOrdered = 0; D.nOrderedDev = F.nOrdered;
     D.kx = F.kx; D.ky = F.ky; D.oct = F.oct; D.ur = F.ur; D.desc = (const uint4*)F.desc;
-    D.order = F.order; D.cellx = F.cellx; D.celly = F.celly;
+    D.order = F.order; D.cellx = F.cellx; D.celly = F.celly; D.colStart = F.colStart;
     D.minX = F.minX; D.minY = F.minY; D.invW = F.invW; D.invH = F.invH; D.cols = F.cols; D.rows = F.rows;
     if (!cursorIsZero) EAO_HIP(hipMemsetAsync(cursor, 0, sizeof(int), s));
     QueryBuild B;

@@ -43,6 +43,7 @@ struct eao_tracker {
     size_t pinCap = 0;
     // device slices (offsets into dev)
     float *kx, *ky, *ang, *ur, *dz; int* oct; int* order; unsigned short *cellx, *celly; int* counts;   // counts: n, nOrdered, nEdges, nMatches, err
+    int* colStart = nullptr;
     int* prior; int* kpMp; unsigned char* occ; unsigned char* kpOut;
     float *mXw, *mNormal, *mMin, *mMax, *mNum; unsigned char* mDesc; unsigned char* mActive; unsigned char* mSkip;
     unsigned char* inView; float *projX, *projY, *projXR, *viewCos; int* level;
@@ -67,6 +68,7 @@ struct FrameArrays {
     float *kx, *ky, *ang, *ur, *dz; int* oct; int* order; unsigned short *cellx, *celly; int* counts;
     int* prior; int* kpMp; unsigned char* occ; unsigned char* mSkip;
     int* cursor;      // k_match_candidates' list cursor, zeroed here (instead of a fill launch in front of it)
+    int* colStart;    // cols + 1: first walk-list entry of every grid column
 };
 
 constexpr int kFrameThreads = 1024;
@@ -177,6 +179,14 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
         }
     }
     if (mine) atomicAdd(&s_cnt, mine);
+    // first walk-list entry of every grid column (binary search over the sorted keys; keys of keypoints outside the grid are
+    // 0xFFFFFFFF and sort behind every cell): a search window then walks its one or two columns, not the whole frame
+    for (int cI = t; cI <= cols; cI += kFrameThreads) {
+        const unsigned want = (unsigned)(cI * rows);
+        int lo = 0, hi = npow2;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((tkeys[mid] >> 16) < want) lo = mid + 1; else hi = mid; }
+        A.colStart[cI] = lo;
+    }
     __syncthreads();
     if (t == 0) { A.counts[0] = n; A.counts[1] = s_cnt; A.counts[2] = 0; A.counts[3] = 0; A.counts[4] = 0; }
 }
@@ -385,7 +395,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
                  oMS = take(M), oIn = take(M), oPx = take(4 * M), oPy = take(4 * M), oPxr = take(4 * M), oVc = take(4 * M), oLv = take(4 * M),
                  oQ = take(sizeof(Query) * M), oLists = take(4 * h->listCap), oSS = take(4 * M), oSC = take(4 * M), oCur = take(64), oMatch = take(4 * M),
                  oEX = take(24 * C), oEO = take(24 * C), oEI = take(8 * C), oEE = take(24 * C), oEF = take(C), oEOu = take(C), oEK = take(4 * C),
-                 oSc = take(4 * 64), oIs = take(4 * 64);
+                 oSc = take(4 * 64), oIs = take(4 * 64), oCol = take(4 * ((size_t)cfg->grid_cols + 1));
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
     h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C);
     if ((st = h->dev.reserve(off))) { delete h; return st; }
@@ -400,6 +410,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     h->cursor = (int*)(b + oCur); h->match = (int*)(b + oMatch);
     h->eXw = (double*)(b + oEX); h->eObs = (double*)(b + oEO); h->eInfo = (double*)(b + oEI); h->eErr = (double*)(b + oEE); h->eFlags = b + oEF;
     h->eOutl = b + oEOu; h->eKp = (int*)(b + oEK); h->dScale = (float*)(b + oSc); h->dInvSigma2 = (float*)(b + oIs);
+    h->colStart = (int*)(b + oCol);
     // the result block is MAPPED PINNED HOST memory: the last kernels of the chain write it over PCIe (~30 KB) and the host reads it
     // after the one synchronisation -- no device-to-host copy behind the chain
     if (hipHostMalloc((void**)&h->resPin, h->resBytes, hipHostMallocMapped) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
@@ -464,7 +475,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     }
     FrameArrays A;
     A.kx = h->kx; A.ky = h->ky; A.ang = h->ang; A.ur = h->ur; A.dz = h->dz; A.oct = h->oct; A.order = h->order; A.cellx = h->cellx; A.celly = h->celly;
-    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = h->mSkip; A.cursor = h->cursor;
+    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = h->mSkip; A.cursor = h->cursor; A.colStart = h->colStart;
     int npow2 = 64;
     while (npow2 < C) npow2 <<= 1;
     const float invW = (float)c.grid_cols / (c.max_x - c.min_x), invH = (float)c.grid_rows / (c.max_y - c.min_y);   // src/Frame.cc:258-259
@@ -494,7 +505,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
         QB.viewCos = h->viewCos; QB.level = h->level; QB.scale = h->dScale; QB.nlevels = c.nlevels; QB.th = th; QB.errFlags = h->counts + 4; QB.qOut = h->q;
         eao::match::FrameDevArgs FD;
         FD.cap = C; FD.nOrdered = h->counts + 1; FD.kx = h->kx; FD.ky = h->ky; FD.oct = h->oct; FD.ur = h->ur; FD.desc = d_desc;
-        FD.order = h->order; FD.cellx = h->cellx; FD.celly = h->celly;
+        FD.order = h->order; FD.cellx = h->cellx; FD.celly = h->celly; FD.colStart = h->colStart;
         FD.minX = c.min_x; FD.minY = c.min_y; FD.invW = invW; FD.invH = invH; FD.cols = c.grid_cols; FD.rows = c.grid_rows;
         if ((st = eao::match::enqueue_candidates_device(FD, h->q, h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
                                                         h->segCount, h->cursor, s, true, &QB))) return st;
