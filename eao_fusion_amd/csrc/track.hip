@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
 //      upstream's
 // ONE workgroup; occupancy and minq in LDS.  Converges in a handful of rounds (overlaps are local).
 constexpr int kAssignThreads = 1024;
+constexpr int kWalk = 4;              // candidate-list entries loaded together by the walks of the assignment step (8: no further gain)
 __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
                                                   const int* __restrict__ segStart, const int* __restrict__ segCount,
                                                   const int* __restrict__ oct, unsigned char* occG, float nnratio,
@@ -236,7 +237,16 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
         for (int u = 0; u < PER; u++)
             if (open[u]) {
                 const int m = t + u * kAssignThreads;
-                for (int k = 0; k < cn_[u]; k++) atomicMin(&minq[lists[st_[u] + k] & 0xFFFF], m);
+                // (the candidate lists are walked four entries at a time: four independent loads in flight instead of one
+                //  load latency per candidate -- these walks were 60 % of the kernel)
+                for (int k = 0; k < cn_[u]; k += kWalk) {
+                    unsigned itw[kWalk];
+#pragma unroll
+                    for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn_[u] ? lists[st_[u] + k + j] : 0u;
+#pragma unroll
+                    for (int j = 0; j < kWalk; j++)
+                        if (k + j < cn_[u]) atomicMin(&minq[itw[j] & 0xFFFF], m);
+                }
             }
         __syncthreads();
         int claim[PER];
@@ -247,20 +257,33 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
             const int m = t + u * kAssignThreads;
             // upstream's scan over the candidates that are free (:83-115)
             int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-            for (int k = 0; k < cn_[u]; k++) {
-                const unsigned it = lists[st_[u] + k];
-                const int i = (int)(it & 0xFFFF), d = (int)(it >> 16);
-                if (occ[i]) continue;
-                if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = octL[i]; bestIdx = i; }
-                else if (d < bestDist2) { bestLevel2 = octL[i]; bestDist2 = d; }
+            for (int k = 0; k < cn_[u]; k += kWalk) {
+                unsigned itw[kWalk];
+#pragma unroll
+                for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn_[u] ? lists[st_[u] + k + j] : 0u;
+#pragma unroll
+                for (int j = 0; j < kWalk; j++) {
+                    if (k + j >= cn_[u]) continue;
+                    const unsigned it = itw[j];
+                    const int i = (int)(it & 0xFFFF), d = (int)(it >> 16);
+                    if (occ[i]) continue;
+                    if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = octL[i]; bestIdx = i; }
+                    else if (d < bestDist2) { bestLevel2 = octL[i]; bestDist2 = d; }
+                }
             }
             // final? every candidate the decision looked at with an effect -- distance <= the second best (all of them when
             // fewer than two are free) -- must not be listed by an earlier undecided point
             bool fin = true;
-            for (int k = 0; k < cn_[u]; k++) {
-                const unsigned it = lists[st_[u] + k];
-                const int i = (int)(it & 0xFFFF), d = (int)(it >> 16);
-                if (d <= bestDist2 && minq[i] < m) { fin = false; break; }
+            for (int k = 0; k < cn_[u] && fin; k += kWalk) {
+                unsigned itw[kWalk];
+#pragma unroll
+                for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn_[u] ? lists[st_[u] + k + j] : 0u;
+#pragma unroll
+                for (int j = 0; j < kWalk; j++) {
+                    if (k + j >= cn_[u]) continue;
+                    const int i = (int)(itw[j] & 0xFFFF), d = (int)(itw[j] >> 16);
+                    if (d <= bestDist2 && minq[i] < m) fin = false;
+                }
             }
             if (!fin) continue;
             open[u] = false;
