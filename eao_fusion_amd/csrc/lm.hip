@@ -2089,22 +2089,28 @@ __global__ __launch_bounds__(NT, 1024 / NT) void k_ba_schur_pairs_b(const BADev*
     if ((int)bx >= P.nFree * (P.nFree + 1) / 2) return;
     constexpr int kHalf = NT / 2, kRows = NT / 16;      // DPP rows of 16 lanes: lanes 0 / 1 of a row lead its two halves
     __shared__ double red[2 * kRows * 21], part[4 * 42];
-    if (P.ctl[kCtlHalt]) return;
+    // The loads a workgroup needs first -- halt flag, lambda, the pair's landmark count and its first list entry -- are independent
+    // of each other: all four are issued before the halt flag is looked at, so a workgroup starts its first Hll / Hpl loads after
+    // three memory round trips instead of five (flag -> count -> list entry -> table -> blocks).
     const int nF = P.nFree, t = threadIdx.x;
+    const int halt = P.ctl[kCtlHalt];
+    const double lm0 = P.lm[0], lm3 = P.lm[3];
+    const int cnt = P.pairCnt[bx];
+    const int* pts = P.pairPts + (size_t)bx * P.nL;
+    const int lFirst = (t >> 1) < P.nL ? pts[t >> 1] : 0;      // (inside the pair's nL slots whatever cnt turns out to be)
+    if (halt) return;
     int i1 = 0, rem = bx;
     while (rem >= nF - i1) { rem -= nF - i1; i1++; }
     const int i2 = i1 + rem;
     const bool diag = i1 == i2;
-    const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
+    const double lambda = first ? 1e-5 * lm3 : lm0;
     if (first && bx == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
-    const int cnt = P.pairCnt[bx];
-    const int* pts = P.pairPts + (size_t)bx * P.nL;
     const int half = t & 1;        // adjacent lanes share a landmark: their Hll / Hpl(e2) loads hit the same cache lines
     double acc[21];
 #pragma unroll
     for (int q = 0; q < 21; q++) acc[q] = 0;
     for (int k = t >> 1; k < cnt; k += kHalf) {
-        const int l = pts[k];
+        const int l = k == (t >> 1) ? lFirst : pts[k];
         const int e1 = P.table[(size_t)l * nF + i1], e2 = P.table[(size_t)l * nF + i2];
         if (e1 < 0 || e2 < 0) continue;                      // deactivated by the outlier pass
         double Di[9];
