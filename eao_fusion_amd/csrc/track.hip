@@ -36,6 +36,7 @@ struct eao_tracker {
     eao_tracker_cfg cfg;
     std::vector<float> scale, invSigma2;
     int cap = 0, capMp = 0, nMp = 0, nCells = 0;
+    std::vector<unsigned char> hActive;      // host copy of the local map's active[]: prior matches are checked against it
     hipStream_t stream = nullptr;
     hipEvent_t evIn = nullptr, evOut = nullptr;
     eao::DevBuf<unsigned char> dev;
@@ -44,7 +45,7 @@ struct eao_tracker {
     // device slices (offsets into dev)
     float *kx, *ky, *ang, *ur, *dz; int* oct; int* order; unsigned short *cellx, *celly; int* counts;   // counts: n, nOrdered, nEdges, nMatches, err
     int* colStart = nullptr;
-    int* prior; int* kpMp; unsigned char* occ; unsigned char* kpOut;
+    int* prior; float* priorXw; int* kpMp; unsigned char* occ; unsigned char* kpOut;
     float *mXw, *mNormal, *mMin, *mMax, *mNum; unsigned char* mDesc; unsigned char* mActive; unsigned char* mSkip;
     unsigned char* inView; float *projX, *projY, *projXR, *viewCos; int* level;
     Query* q; unsigned* lists; int *segStart, *segCount, *cursor; int* match;
@@ -110,10 +111,12 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
             const int py = (int)roundf((kp.y - minY) * invH);
             if (px >= 0 && px < cols && py >= 0 && py < rows) key = ((unsigned)(px * rows + py) << 16) | (unsigned)i;
             // mvpMapPoints as the caller hands it over: a keypoint that already has a map point is occupied, and that map
-            // point is not searched again (Tracking::SearchLocalPoints: mnLastFrameSeen == frame id)
+            // point is not searched again (Tracking::SearchLocalPoints: mnLastFrameSeen == frame id).  The host entry point
+            // has validated the array: -1 (free), -2 (a map point outside the local map; its position travels in priorXw)
+            // or the index of an ACTIVE local map point
             const int pm = A.prior ? A.prior[i] : -1;
             A.kpMp[i] = pm;
-            A.occ[i] = pm >= 0 ? 1 : 0;
+            A.occ[i] = pm != -1 ? 1 : 0;
             if (pm >= 0 && pm < nMp) A.mSkip[pm] = 1;
         }
         tkeys[i] = key;
@@ -204,6 +207,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
 // ONE workgroup; occupancy and minq in LDS.  Converges in a handful of rounds (overlaps are local).
 constexpr int kAssignThreads = 1024;
 constexpr int kWalk = 4;              // candidate-list entries loaded together by the walks of the assignment step (8: no further gain)
+template <int PER>
 __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
                                                   const int* __restrict__ segStart, const int* __restrict__ segCount,
                                                   const int* __restrict__ oct, unsigned char* occG, float nnratio,
@@ -214,7 +218,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
     unsigned char* octL = occ + cap;                            // cap: the keypoints' octaves (read per candidate in every round)
     __shared__ int s_left, s_nm;
     const int t = threadIdx.x;
-    constexpr int PER = 4;                                      // map points per thread (capMp <= 4096)
+    // PER = map points per thread: 4, 8 or 16 (local maps of up to 4096 / 8192 / 16384 points)
     int st_[PER], cn_[PER];
     bool open[PER];
     for (int i = t; i < cap; i += kAssignThreads) { occ[i] = occG[i]; octL[i] = (unsigned char)oct[i]; }
@@ -313,11 +317,11 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
 // mvpMapPoints by keypoint (the prior matches + this search's), and the edges of Optimizer::PoseOptimization in keypoint
 // order (src/Optimizer.cc:361-447): Xw, (u, v, uR), invSigma2 of the octave, stereo / robust flags.  ONE workgroup.
 struct EdgeArrays { double *Xw, *obs, *info; unsigned char* flags; int* eKp; };
-struct ResultBlock { int* counts; int* kpMp; unsigned char* outl; float* ur; float* dz; };      // slices of the host-visible result block
+struct ResultBlock { int* counts; int* kpMp; unsigned char* outl; float* ur; float* dz; unsigned char* inView; };      // slices of the host-visible result block
 constexpr int kEdgeThreads = 1024;
 __device__ __forceinline__ void track_edges_body(int nMp, int cap, const int* match, int* kpMp,
                                                  const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ ur,
-                                                 const int* __restrict__ oct, const float* __restrict__ mXw,
+                                                 const int* __restrict__ oct, const float* __restrict__ mXw, const float* __restrict__ priorXw,
                                                  const float* __restrict__ invSigma2, const EdgeArrays& E, int edgeCap, int* counts,
                                                  unsigned char* eOutl) {
     __shared__ int s_wsum[kEdgeThreads / 64], s_base;
@@ -333,7 +337,7 @@ __device__ __forceinline__ void track_edges_body(int nMp, int cap, const int* ma
     for (int k0 = 0; k0 < n; k0 += kEdgeThreads) {
         const int k = k0 + t;
         const int m = k < n ? kpMp[k] : -1;
-        const bool has = m >= 0;
+        const bool has = m >= 0 || m == -2;       // -2: a prior match outside the local map (an edge all the same, :361-447)
         const unsigned long long bal = __ballot(has);
         if (lane == 0) s_wsum[wv] = __popcll(bal);
         __syncthreads();
@@ -341,7 +345,8 @@ __device__ __forceinline__ void track_edges_body(int nMp, int cap, const int* ma
         for (int w = 0; w < wv; w++) off += s_wsum[w];
         const int e = off + __popcll(bal & ((1ull << lane) - 1));
         if (has && e < edgeCap) {
-            E.Xw[3 * e] = mXw[3 * m]; E.Xw[3 * e + 1] = mXw[3 * m + 1]; E.Xw[3 * e + 2] = mXw[3 * m + 2];
+            const float* X = m >= 0 ? mXw + 3 * m : priorXw + 3 * k;
+            E.Xw[3 * e] = X[0]; E.Xw[3 * e + 1] = X[1]; E.Xw[3 * e + 2] = X[2];
             const float u_r = ur[k];
             E.obs[3 * e] = kx[k]; E.obs[3 * e + 1] = ky[k]; E.obs[3 * e + 2] = u_r;
             E.info[e] = invSigma2[oct[k]];
@@ -361,18 +366,19 @@ __device__ __forceinline__ void track_edges_body(int nMp, int cap, const int* ma
 // ONE launch for the greedy assignment and the edge list behind it (both are single-workgroup steps of 1024 threads; as two
 // launches the second one waited a launch gap for the first).  nMp = 0: no search ran, only the prior matches become edges.
 static_assert(kAssignThreads == kEdgeThreads, "one workgroup runs both steps");
+template <int PER>
 __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
                                                                        const int* __restrict__ segStart, const int* __restrict__ segCount,
                                                                        const int* __restrict__ oct, unsigned char* occG, float nnratio, int* match, int* counts,
                                                                        int* kpMp, const float* __restrict__ kx, const float* __restrict__ ky,
-                                                                       const float* __restrict__ ur, const float* __restrict__ mXw,
+                                                                       const float* __restrict__ ur, const float* __restrict__ mXw, const float* __restrict__ priorXw,
                                                                        const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl,
-                                                                       const float* __restrict__ dz, ResultBlock R) {
+                                                                       const float* __restrict__ dz, const unsigned char* __restrict__ inView, ResultBlock R) {
     if (nMp > 0) {
-        track_assign_body(nMp, cap, q, lists, segStart, segCount, oct, occG, nnratio, match, counts);
+        track_assign_body<PER>(nMp, cap, q, lists, segStart, segCount, oct, occG, nnratio, match, counts);
         __syncthreads();      // match[] is complete (and visible to the whole workgroup)
     }
-    track_edges_body(nMp, cap, match, kpMp, kx, ky, ur, oct, mXw, invSigma2, E, edgeCap, counts, eOutl);
+    track_edges_body(nMp, cap, match, kpMp, kx, ky, ur, oct, mXw, priorXw, invSigma2, E, edgeCap, counts, eOutl);
     __syncthreads();          // counts[2], kpMp[] are final
     // everything the host needs except the pose and mvbOutlier, which PoseOptimization itself writes (by keypoint, through
     // the edge -> keypoint table): the block lies in mapped host memory
@@ -384,6 +390,8 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
         R.dz[i] = i < n ? dz[i] : -1.f;
         R.outl[i] = 0;
     }
+    // Frame::isInFrustum(pMP, 0.5) of every local map point (workgroups 1.. of k_track_frame): the caller's visibility counters
+    for (int m = t; m < nMp; m += kAssignThreads) R.inView[m] = inView[m];
 }
 
 // everything the host needs, in one block: [SE3 | result ints | counts | kpMp | kpOutlier | uRight | depth]
@@ -398,7 +406,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     EAO_REQUIRE(cfg && out && cfg->scale_factors && cfg->inv_level_sigma2, "null argument");
     EAO_REQUIRE(cfg->nlevels >= 1 && cfg->nlevels <= 64 && cfg->grid_cols > 0 && cfg->grid_rows > 0 && (long long)cfg->grid_cols * cfg->grid_rows < 65535, "bad geometry");
     EAO_REQUIRE(cfg->max_keypoints >= 1 && cfg->max_keypoints <= 4096, "max_keypoints must be in 1..4096 (the grid sort runs in the LDS of one workgroup)");
-    EAO_REQUIRE(cfg->max_map_points >= 1 && cfg->max_map_points <= 4096, "max_map_points must be in 1..4096 (one assignment workgroup, four points per thread)");
+    EAO_REQUIRE(cfg->max_map_points >= 1 && cfg->max_map_points <= 16384, "max_map_points must be in 1..16384 (one assignment workgroup, up to sixteen points per thread)");
     EAO_REQUIRE(cfg->max_x > cfg->min_x && cfg->max_y > cfg->min_y, "empty image bounds");
     eao_status st = eao::require_device();
     if (st) return st;
@@ -413,19 +421,19 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = al256(off + bytes); return o; };
     const size_t oKx = take(4 * C), oKy = take(4 * C), oAng = take(4 * C), oUr = take(4 * C), oDz = take(4 * C), oOct = take(4 * C), oOrd = take(4 * C),
-                 oCx = take(2 * C), oCy = take(2 * C), oCnt = take(64), oPrior = take(4 * C), oKpMp = take(4 * C), oOcc = take(C), oKpOut = take(C),
+                 oCx = take(2 * C), oCy = take(2 * C), oCnt = take(64), oPrior = take(4 * C), oPriorX = take(12 * C), oKpMp = take(4 * C), oOcc = take(C), oKpOut = take(C),
                  oMX = take(12 * M), oMN = take(12 * M), oMMin = take(4 * M), oMMax = take(4 * M), oMNum = take(4 * M), oMD = take(32 * M), oMA = take(M),
                  oMS = take(M), oIn = take(M), oPx = take(4 * M), oPy = take(4 * M), oPxr = take(4 * M), oVc = take(4 * M), oLv = take(4 * M),
                  oQ = take(sizeof(Query) * M), oLists = take(4 * h->listCap), oSS = take(4 * M), oSC = take(4 * M), oCur = take(64), oMatch = take(4 * M),
                  oEX = take(24 * C), oEO = take(24 * C), oEI = take(8 * C), oEE = take(24 * C), oEF = take(C), oEOu = take(C), oEK = take(4 * C),
                  oSc = take(4 * 64), oIs = take(4 * 64), oCol = take(4 * ((size_t)cfg->grid_cols + 1));
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
-    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C);
+    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C) + al256(M);
     if ((st = h->dev.reserve(off))) { delete h; return st; }
     unsigned char* b = h->dev.p;
     h->kx = (float*)(b + oKx); h->ky = (float*)(b + oKy); h->ang = (float*)(b + oAng); h->ur = (float*)(b + oUr); h->dz = (float*)(b + oDz);
     h->oct = (int*)(b + oOct); h->order = (int*)(b + oOrd); h->cellx = (unsigned short*)(b + oCx); h->celly = (unsigned short*)(b + oCy);
-    h->counts = (int*)(b + oCnt); h->prior = (int*)(b + oPrior); h->kpMp = (int*)(b + oKpMp); h->occ = b + oOcc; h->kpOut = b + oKpOut;
+    h->counts = (int*)(b + oCnt); h->prior = (int*)(b + oPrior); h->priorXw = (float*)(b + oPriorX); h->kpMp = (int*)(b + oKpMp); h->occ = b + oOcc; h->kpOut = b + oKpOut;
     h->mXw = (float*)(b + oMX); h->mNormal = (float*)(b + oMN); h->mMin = (float*)(b + oMMin); h->mMax = (float*)(b + oMMax); h->mNum = (float*)(b + oMNum);
     h->mDesc = b + oMD; h->mActive = b + oMA; h->mSkip = b + oMS;
     h->inView = b + oIn; h->projX = (float*)(b + oPx); h->projY = (float*)(b + oPy); h->projXR = (float*)(b + oPxr); h->viewCos = (float*)(b + oVc);
@@ -441,7 +449,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     if (hipHostGetDevicePointer((void**)&h->res, h->resPin, 0) != hipSuccess) { delete h; eao::set_error("hipHostGetDevicePointer failed"); return EAO_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evOut, hipEventDisableTiming) != hipSuccess) { delete h; eao::set_error("stream / event creation failed"); return EAO_ERR_NO_DEVICE; }
-    h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C)) + 4096;
+    h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C) + al256(12 * C)) + 4096;
     if (hipHostMalloc((void**)&h->pin, h->pinCap, hipHostMallocDefault) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     EAO_HIP(hipMemcpyAsync(h->dScale, h->scale.data(), 4 * (size_t)cfg->nlevels, hipMemcpyHostToDevice, h->stream));
     EAO_HIP(hipMemcpyAsync(h->dInvSigma2, h->invSigma2.data(), 4 * (size_t)cfg->nlevels, hipMemcpyHostToDevice, h->stream));
@@ -460,9 +468,11 @@ eao_status eao_tracker_set_local_map(eao_tracker* h, const eao_map_points* pts) 
     EAO_REQUIRE(h && pts && pts->n >= 0 && pts->n <= h->capMp, "bad argument (at most %d map points)", h ? h->capMp : 0);
     const int n = pts->n;
     h->nMp = n;
+    h->hActive.clear();
     if (n == 0) return EAO_OK;
     EAO_REQUIRE(pts->active && pts->Xw && pts->normal && pts->min_dist_inv && pts->max_dist_inv && pts->max_dist && pts->desc, "incomplete map-point arrays");
     const size_t M = n;
+    h->hActive.assign(pts->active, pts->active + n);
     size_t off = 0;
     auto put = [&](void* dst, const void* src, size_t bytes) -> eao_status {
         std::memcpy(h->pin + off, src, bytes);
@@ -481,7 +491,8 @@ eao_status eao_tracker_set_local_map(eao_tracker* h, const eao_map_points* pts) 
 
 eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
                                        const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
-                                       const int32_t* prior_kp_map_point, float th, float nnratio, eao_track_result* out, void* stream) {
+                                       const int32_t* prior_kp_map_point, const float* prior_kp_Xw, float th, float nnratio, eao_track_result* out,
+                                       void* stream) {
     EAO_REQUIRE(h && d_kps && d_desc && d_n && Tcw_prior && out && out->kp_map_point && out->kp_outlier, "null argument");
     EAO_REQUIRE(!d_depth || (depth_pitch >= width && width > 0 && height > 0), "bad depth image geometry");
     EAO_REQUIRE(((uintptr_t)d_desc & 15) == 0, "descriptors must be 16-byte aligned");
@@ -493,8 +504,26 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     // carries the local-map uploads, which eao_tracker_set_local_map waits for.
     hipStream_t s = (hipStream_t)stream;
     if (prior_kp_map_point) {
-        std::memcpy(h->pin, prior_kp_map_point, 4 * (size_t)C);
+        // Validated HERE: the kernels index the local map with these values.  An index beyond the uploaded map (e.g. a stale table
+        // from before a smaller eao_tracker_set_local_map) is an error; a prior on an INACTIVE point is dropped -- the keypoint is free
+        // again, as upstream's "if(pMP->isBad()) *vit = NULL" (src/Tracking.cc:2596-2599); -2 = the keypoint's map point is not in the
+        // local map: it stays occupied and becomes a pose edge from prior_kp_Xw (PoseOptimization takes every mvpMapPoints entry)
+        int32_t* pr = reinterpret_cast<int32_t*>(h->pin);
+        bool outside = false;
+        for (int k = 0; k < C; k++) {
+            int32_t pm = prior_kp_map_point[k];
+            EAO_REQUIRE(pm >= -2 && pm < nMp, "prior_kp_map_point[%d] = %d names no point of the local map (%d points)", k, (int)pm, nMp);
+            if (pm >= 0 && !h->hActive[pm]) pm = -1;
+            outside = outside || pm == -2;
+            pr[k] = pm;
+        }
+        EAO_REQUIRE(!outside || prior_kp_Xw, "prior_kp_map_point holds -2 but prior_kp_Xw is NULL");
         EAO_HIP(hipMemcpyAsync(h->prior, h->pin, 4 * (size_t)C, hipMemcpyHostToDevice, s));
+        if (outside) {
+            unsigned char* px = h->pin + al256(4 * (size_t)C);
+            std::memcpy(px, prior_kp_Xw, 12 * (size_t)C);
+            EAO_HIP(hipMemcpyAsync(h->priorXw, px, 12 * (size_t)C, hipMemcpyHostToDevice, s));
+        }
     }
     FrameArrays A;
     A.kx = h->kx; A.ky = h->ky; A.ang = h->ang; A.ur = h->ur; A.dz = h->dz; A.oct = h->oct; A.order = h->order; A.cellx = h->cellx; A.celly = h->celly;
@@ -548,9 +577,16 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     unsigned char* rOutl = r + ro; ro += al256(C);
     float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
-    ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz};
-    hipLaunchKernelGGL(k_track_assign_edges, dim3(1), dim3(kAssignThreads), (size_t)C * 6, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
-                       nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz, RB);
+    unsigned char* rInView = r + ro; ro += al256((size_t)h->capMp);
+    ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz, rInView};
+    auto launch_assign = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), (size_t)C * 6, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
+                           nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
+                           h->inView, RB);
+    };
+    if (nMp <= 4 * kAssignThreads) launch_assign(k_track_assign_edges<4>);
+    else if (nMp <= 8 * kAssignThreads) launch_assign(k_track_assign_edges<8>);
+    else launch_assign(k_track_assign_edges<16>);
     eao::lm::PoseChainArgs PA;
     PA.nEdges = h->counts + 2; PA.cap = edgeCap;
     PA.Xw = h->eXw; PA.obs = h->eObs; PA.info = h->eInfo; PA.flags = h->eFlags; PA.err = h->eErr; PA.outlier = h->eOutl;
@@ -571,6 +607,10 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     std::memcpy(out->kp_map_point, p + ((unsigned char*)rKpMp - r), 4 * (size_t)C);
     if (out->kp_u_right) std::memcpy(out->kp_u_right, p + ((unsigned char*)rUr - r), 4 * (size_t)C);
     if (out->kp_depth) std::memcpy(out->kp_depth, p + ((unsigned char*)rDz - r), 4 * (size_t)C);
+    if (out->map_in_view && nMp > 0) {
+        const unsigned char* iv = p + ((unsigned char*)rInView - r);
+        for (int m = 0; m < nMp; m++) out->map_in_view[m] = (iv[m] && h->hActive[m]) ? 1 : 0;      // (an inactive point's arrays are stale)
+    }
     if (nEdges < 3) {   // "if(nInitialCorrespondences<3) return 0" (src/Optimizer.cc:453-454): pose untouched
         std::memcpy(out->Tcw, Tcw_prior, 64);
         out->n_inliers = 0;

@@ -18,7 +18,7 @@ class TrackerCfg(C.Structure):
 
 class TrackResult(C.Structure):
     _fields_ = [("Tcw", _F * 16), ("n_keypoints", _I), ("n_matches", _I), ("n_edges", _I), ("n_inliers", _I), ("kp_map_point", _P),
-                ("kp_outlier", _P), ("kp_u_right", _P), ("kp_depth", _P)]
+                ("kp_outlier", _P), ("kp_u_right", _P), ("kp_depth", _P), ("map_in_view", _P)]
 
 
 def _bind(L):
@@ -29,7 +29,7 @@ def _bind(L):
     L.eao_tracker_set_local_map.restype = _I
     L.eao_tracker_set_local_map.argtypes = [_P, C.POINTER(MapPoints)]
     L.eao_tracker_track_local_map.restype = _I
-    L.eao_tracker_track_local_map.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, C.POINTER(TrackResult), _P]
+    L.eao_tracker_track_local_map.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _F, C.POINTER(TrackResult), _P]
     return L
 
 
@@ -44,6 +44,8 @@ class Tracker:
         self._h = _P()
         _lib.check(self._L.eao_tracker_create(C.byref(cfg), C.byref(self._h)))
         self.cap = int(max_keypoints)
+        self.cap_mp = int(max_map_points)
+        self.n_mp = 0
 
     def __del__(self):
         try:
@@ -55,10 +57,11 @@ class Tracker:
     def set_local_map(self, pts):
         m, keep = map_points(pts)
         _lib.check(self._L.eao_tracker_set_local_map(self._h, C.byref(m)))
+        self.n_mp = int(m.n)
 
-    def track_local_map(self, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_prior, prior=None, th=1.0, nnratio=0.8, stream=0):
-        """d_*: integers (HBM addresses).  Returns dict(Tcw, n_keypoints, n_matches, n_edges, n_inliers, kp_map_point, kp_outlier,
-        u_right, depth)."""
+    def track_local_map(self, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_prior, prior=None, th=1.0, nnratio=0.8, stream=0, prior_Xw=None):
+        """d_*: integers (HBM addresses).  prior: per keypoint -1 / local-map index / -2 (map point outside the local map, position in
+        prior_Xw[k]).  Returns dict(Tcw, n_keypoints, n_matches, n_edges, n_inliers, kp_map_point, kp_outlier, u_right, depth, map_in_view)."""
         T = np.ascontiguousarray(Tcw_prior, np.float32).reshape(4, 4)
         kpmp = np.full(self.cap, -1, np.int32)
         outl = np.zeros(self.cap, np.uint8)
@@ -68,10 +71,16 @@ class Tracker:
         if prior is not None:
             pr = np.full(self.cap, -1, np.int32)
             pr[:len(prior)] = np.asarray(prior, np.int32)
+        px = None
+        if prior_Xw is not None:
+            px = np.zeros((self.cap, 3), np.float32)
+            px[:len(prior_Xw)] = np.asarray(prior_Xw, np.float32).reshape(-1, 3)
+        inview = np.zeros(self.cap_mp, np.uint8)
         R = TrackResult()
         R.kp_map_point, R.kp_outlier, R.kp_u_right, R.kp_depth = _lib.ptr(kpmp), _lib.ptr(outl), _lib.ptr(ur), _lib.ptr(dz)
+        R.map_in_view = _lib.ptr(inview)
         _lib.check(self._L.eao_tracker_track_local_map(self._h, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, _lib.ptr(T), _lib.ptr(pr),
-                                                      th, nnratio, C.byref(R), stream))
+                                                      _lib.ptr(px), th, nnratio, C.byref(R), stream))
         n = R.n_keypoints
         return dict(Tcw=np.array(R.Tcw, np.float32).reshape(4, 4), n_keypoints=n, n_matches=R.n_matches, n_edges=R.n_edges, n_inliers=R.n_inliers,
-                    kp_map_point=kpmp[:n], kp_outlier=outl[:n], u_right=ur[:n], depth=dz[:n])
+                    kp_map_point=kpmp[:n], kp_outlier=outl[:n], u_right=ur[:n], depth=dz[:n], map_in_view=inview[:self.n_mp])

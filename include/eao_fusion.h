@@ -460,7 +460,7 @@ typedef struct {
     const float* inv_level_sigma2;             /* nlevels: mvInvLevelSigma2 (copied) */
     float log_scale_factor;                    /* mfLogScaleFactor */
     int32_t max_keypoints;                     /* per frame, <= 4096; >= eao_orb_max_keypoints of the extractor */
-    int32_t max_map_points;                    /* of a local map, <= 4096 */
+    int32_t max_map_points;                    /* of a local map, <= 16384 */
 } eao_tracker_cfg;
 eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out);
 void eao_tracker_destroy(eao_tracker* h);
@@ -477,16 +477,26 @@ typedef struct {
     uint8_t* kp_outlier;      /* caller array [max_keypoints]: mvbOutlier */
     float* kp_u_right;        /* optional caller arrays [max_keypoints]: mvuRight, mvDepth (NULL: not copied) */
     float* kp_depth;
+    uint8_t* map_in_view;     /* optional caller array [max_map_points] (NULL: not copied): Frame::isInFrustum(pMP, 0.5) of every ACTIVE
+                               * local map point -- what Tracking::SearchLocalPoints needs for IncreaseVisible() (src/Tracking.cc:2621-2625);
+                               * the caller ignores the entries of points a prior match names (upstream never projects those) */
 } eao_track_result;
 /* d_kps / d_desc / d_n: ONE frame's slice of the device outputs of eao_orb_extract_batch_device (d_n points at that frame's
  * count); d_depth: the float depth image on the device (rows of depth_pitch floats) or NULL (monocular: mvuRight = -1);
  * Tcw_prior: the pose the frame enters TrackLocalMap with; prior_kp_map_point: mvpMapPoints as it stands (host array
  * [max_keypoints], NULL = none) -- those keypoints are occupied, their map points are not searched again, and they are
- * edges of the pose optimisation.  `stream`: the stream the extraction was enqueued on -- the chain is enqueued on
+ * edges of the pose optimisation.  Entries: -1 = no map point; m in [0, n) = point m of the local map -- if that point is
+ * inactive (isBad()) the prior is DROPPED and the keypoint is free, as upstream sets such an entry to NULL
+ * (src/Tracking.cc:2596-2599), and the returned kp_map_point shows it; -2 = a map point that is not in the local map
+ * (a temporal point of the RGB-D odometry, a point the local map lost): the keypoint stays occupied and its edge is built
+ * from prior_kp_Xw[3k..3k+2] (host array [3 * max_keypoints], may be NULL when no entry is -2), kp_map_point returns -2;
+ * anything else (an index >= n, e.g. a table older than the last eao_tracker_set_local_map) fails with EAO_ERR_INVALID before
+ * any kernel runs.  `stream`: the stream the extraction was enqueued on -- the chain is enqueued on
  * that stream itself (ordered behind the extraction without an event hand-over); the call returns when the results are on the host. */
 eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
                                        const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
-                                       const int32_t* prior_kp_map_point, float th, float nnratio, eao_track_result* out, void* stream);
+                                       const int32_t* prior_kp_map_point, const float* prior_kp_Xw, float th, float nnratio, eao_track_result* out,
+                                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,13 +9,15 @@
 // TrackLocalMap replaces, for a distortion-free RGB-D / monocular camera, the sequence Frame::ComputeStereoFromRGBD +
 // AssignFeaturesToGrid (the part of the Frame constructor after the extractor) -> Tracking::SearchLocalPoints ->
 // Optimizer::PoseOptimization(&mCurrentFrame): it fills mvuRight, mvDepth, mvpMapPoints (new matches added to the ones the
-// frame already has), mvbOutlier and the pose exactly as those calls would.  Only members the reference's classes already have
-// are named.  Nothing here is copied from the reference.
+// frame already has), mvbOutlier and the pose exactly as those calls would, and applies SearchLocalPoints' bookkeeping on the
+// map points (bad prior matches dropped, IncreaseVisible, mnLastFrameSeen, mbTrackInView).  Only members the reference's classes
+// already have are named.  Nothing here is copied from the reference.
 #ifndef EAOFUSION_DEVICE_TRACKER_H
 #define EAOFUSION_DEVICE_TRACKER_H
 
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../eao_fusion.h"
@@ -26,7 +28,7 @@ namespace eaofusion {
 class DeviceTracker {
 public:
     template <class FrameT>
-    DeviceTracker(const FrameT& F, int maxKeypoints, int maxMapPoints) : cap_(maxKeypoints) {
+    DeviceTracker(const FrameT& F, int maxKeypoints, int maxMapPoints) : cap_(maxKeypoints), capMp_(maxMapPoints) {
         eao_tracker_cfg c;
         c.fx = F.fx; c.fy = F.fy; c.cx = F.cx; c.cy = F.cy; c.mbf = F.mbf;
         c.min_x = F.mnMinX; c.max_x = F.mnMaxX; c.min_y = F.mnMinY; c.max_y = F.mnMaxY;
@@ -42,15 +44,21 @@ public:
     DeviceTracker& operator=(const DeviceTracker&) = delete;
 
     // Tracking::mvpLocalMapPoints -> HBM (kept until the next call).  Bad points stay in the arrays with active = 0.
+    // Returns false -- and leaves the previous map in place -- when the local map is larger than maxMapPoints (the handle's
+    // capacity, at most 16384): the caller then runs upstream's own SearchLocalPoints + PoseOptimization for this frame.
     template <class MapPointT>
-    void SetLocalMap(const std::vector<MapPointT*>& vpMPs) {
+    bool SetLocalMap(const std::vector<MapPointT*>& vpMPs) {
         const size_t n = vpMPs.size();
+        if ((int)n > capMp_) return false;
         map_.assign(vpMPs.begin(), vpMPs.end());
+        index_.clear();
+        index_.reserve(2 * n);
         std::vector<unsigned char> active(n);
         std::vector<float> Xw(3 * n), nrm(3 * n), dmin(n), dmax(n), draw(n);
         std::vector<unsigned char> desc(32 * n);
         for (size_t i = 0; i < n; i++) {
             MapPointT* p = vpMPs[i];
+            if (p) index_.emplace((void*)p, (int)i);          // (a point listed twice keeps its first slot, like upstream's first visit)
             active[i] = (p && !p->isBad()) ? 1 : 0;
             if (!active[i]) continue;
             const cv::Mat P = p->GetWorldPos(), Pn = p->GetNormal(), D = p->GetDescriptor();
@@ -62,29 +70,57 @@ public:
         mp.n = (int)n; mp.active = active.data(); mp.Xw = Xw.data(); mp.normal = nrm.data(); mp.min_dist_inv = dmin.data();
         mp.max_dist_inv = dmax.data(); mp.max_dist = draw.data(); mp.desc = desc.data();
         detail::check(eao_tracker_set_local_map(h_, &mp), "eao_tracker_set_local_map");
+        return true;
     }
 
     // d_kps / d_desc / d_n: this frame's slice of eao_orb_extract_batch_device's outputs (F.mvKeys / mDescriptors are their host
     // copies, F.N = the count); d_depth: imDepth on the device or nullptr.  Returns Optimizer::PoseOptimization's return value.
+    //
+    // Bookkeeping of Tracking::SearchLocalPoints (src/Tracking.cc:2590-2627), applied here exactly as upstream orders it:
+    //   * a prior match that isBad() is set to NULL first (:2596-2599) -- its keypoint is free for the search;
+    //   * every remaining prior match: IncreaseVisible(), mnLastFrameSeen = F.mnId, mbTrackInView = false (:2603-2607).  A prior
+    //     match that is not in the local map (a temporal RGB-D point, a point the local map dropped) stays in mvpMapPoints, keeps
+    //     its keypoint occupied and is an edge of the pose optimisation from its own GetWorldPos(), as upstream takes every
+    //     mvpMapPoints entry (src/Optimizer.cc:361-447);
+    //   * every other non-bad local point in the frustum: mbTrackInView = true, IncreaseVisible() (:2621-2625); out of it:
+    //     mbTrackInView = false.  (mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos stay on the device: only the matcher
+    //     reads them, and the matcher ran there.)
     template <class FrameT>
     int TrackLocalMap(FrameT& F, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch,
                       int width, int height, float th, float nnratio, void* stream) {
         using MapPointT = typename std::remove_pointer<typename std::decay<decltype(F.mvpMapPoints[0])>::type>::type;
         std::vector<int32_t> prior(cap_, -1), kpMp(cap_, -1);
-        std::vector<uint8_t> outl(cap_, 0);
-        std::vector<float> ur(cap_), dz(cap_);
-        for (int k = 0; k < F.N && k < cap_; k++)
-            if (F.mvpMapPoints[k]) {
-                for (size_t m = 0; m < map_.size(); m++)
-                    if (map_[m] == (void*)F.mvpMapPoints[k]) { prior[k] = (int32_t)m; break; }
-            }
+        std::vector<uint8_t> outl(cap_, 0), inView(map_.size() ? map_.size() : 1, 0);
+        std::vector<float> ur(cap_), dz(cap_), priorXw;
+        if (F.N > cap_) throw std::runtime_error("DeviceTracker: the frame has more keypoints than maxKeypoints");
+        for (int k = 0; k < F.N; k++) {
+            MapPointT* pMP = F.mvpMapPoints[k];
+            if (!pMP) continue;
+            if (pMP->isBad()) { F.mvpMapPoints[k] = static_cast<MapPointT*>(NULL); continue; }
+            pMP->IncreaseVisible();
+            pMP->mnLastFrameSeen = F.mnId;
+            pMP->mbTrackInView = false;
+            const auto it = index_.find((void*)pMP);
+            if (it != index_.end()) { prior[k] = it->second; continue; }
+            prior[k] = -2;
+            if (priorXw.empty()) priorXw.assign(3 * (size_t)cap_, 0.f);
+            const cv::Mat P = pMP->GetWorldPos();
+            for (int a = 0; a < 3; a++) priorXw[3 * (size_t)k + a] = P.template at<float>(a);
+        }
         float T[16];
         for (int r = 0; r < 4; r++)
             for (int c = 0; c < 4; c++) T[4 * r + c] = F.mTcw.template at<float>(r, c);
         eao_track_result R;
-        R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data();
-        detail::check(eao_tracker_track_local_map(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, T, prior.data(), th, nnratio, &R, stream),
+        R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data(); R.map_in_view = inView.data();
+        detail::check(eao_tracker_track_local_map(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, T, prior.data(),
+                                                  priorXw.empty() ? nullptr : priorXw.data(), th, nnratio, &R, stream),
                       "eao_tracker_track_local_map");
+        for (size_t m = 0; m < map_.size(); m++) {
+            MapPointT* pMP = static_cast<MapPointT*>(map_[m]);
+            if (!pMP || pMP->mnLastFrameSeen == F.mnId || pMP->isBad()) continue;      // upstream's two `continue`s, :2615-2618
+            pMP->mbTrackInView = inView[m] != 0;
+            if (inView[m]) pMP->IncreaseVisible();
+        }
         F.mvuRight.assign(ur.begin(), ur.begin() + R.n_keypoints);
         F.mvDepth.assign(dz.begin(), dz.begin() + R.n_keypoints);
         for (int k = 0; k < R.n_keypoints; k++) {
@@ -100,8 +136,9 @@ public:
 
 private:
     eao_tracker* h_ = nullptr;
-    int cap_;
+    int cap_, capMp_;
     std::vector<void*> map_;
+    std::unordered_map<void*, int> index_;      // map point -> slot of the uploaded local map (the prior-match lookup, O(1) per keypoint)
 };
 
 }  // namespace eaofusion

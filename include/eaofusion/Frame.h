@@ -6,7 +6,7 @@
 //   Frame::AssignFeaturesToGrid                       src/Frame.cc:597-614        ->  eaofusion::AssignFeaturesToGrid(*this)
 //   Frame::ComputeStereoFromRGBD                      src/Frame.cc:1016-1037      ->  eaofusion::ComputeStereoFromRGBD(*this, imDepth)
 //
-// The templates only name members the reference's Frame / MapPoint already have (mRcw, mtcw, mOw, fx .. mbf, mnMinX ..,
+// The templates only name members the reference's Frame / MapPoint already have (mTcw, GetCameraCenter(), fx .. mbf, mnMinX ..,
 // mfLogScaleFactor, mGrid, mvKeys, mvKeysUn, mvuRight, mvDepth; GetWorldPos, GetNormal, Get{Min,Max}DistanceInvariance,
 // mbTrackInView, mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos).  Nothing here is copied from the reference.
 #ifndef EAOFUSION_FRAME_H
@@ -38,9 +38,10 @@ inline void check(eao_status st, const char* what) {
 
 // for (pMP : vpMPs) if (!skip(pMP)) if (F.isInFrustum(pMP, viewingCosLimit)) nToMatch++;   returns nToMatch.
 // skip(pMP) holds the caller's own `continue`s (src/Tracking.cc:2615-2618: mnLastFrameSeen == mCurrentFrame.mnId, isBad()).
-// Every visited point gets mbTrackInView; points in view also get mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos.
-template <class FrameT, class MapPointT, class Skip>
-int IsInFrustum(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewingCosLimit, Skip&& skip) {
+// Every visited point gets mbTrackInView; points in view also get mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos, and
+// inView(pMP) is called for them in list order -- the place of upstream's pMP->IncreaseVisible() (src/Tracking.cc:2623).
+template <class FrameT, class MapPointT, class Skip, class InView>
+int IsInFrustum(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewingCosLimit, Skip&& skip, InView&& inView) {
     std::vector<int> idx;
     idx.reserve(vpMPs.size());
     for (size_t i = 0; i < vpMPs.size(); i++)
@@ -55,11 +56,13 @@ int IsInFrustum(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewingCo
         dmin[k] = p->GetMinDistanceInvariance(); dmax[k] = p->GetMaxDistanceInvariance(); draw[k] = detail::MaxDistanceOf<MapPointT>::get(p);
     }
     eao_frustum_frame fr;
+    // upstream's isInFrustum reads the private mRcw / mtcw / mOw; they are copies of blocks of the public mTcw
+    // (Frame::UpdatePoseMatrices, src/Frame.cc:624-636) and mOw is what the public GetCameraCenter() returns
+    const cv::Mat Ow = F.GetCameraCenter();
     for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) fr.Tcw[4 * r + c] = F.mRcw.template at<float>(r, c);
-        fr.Tcw[4 * r + 3] = F.mtcw.template at<float>(r);
+        for (int c = 0; c < 4; c++) fr.Tcw[4 * r + c] = F.mTcw.template at<float>(r, c);
         fr.Tcw[12 + r] = 0.f;
-        fr.Ow[r] = F.mOw.template at<float>(r);
+        fr.Ow[r] = Ow.template at<float>(r);
     }
     fr.Tcw[15] = 1.f;
     fr.fx = FrameT::fx; fr.fy = FrameT::fy; fr.cx = FrameT::cx; fr.cy = FrameT::cy; fr.mbf = F.mbf;
@@ -80,9 +83,14 @@ int IsInFrustum(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewingCo
         if (!in[k]) continue;
         p->mTrackProjX = u[k]; p->mTrackProjXR = ur[k]; p->mTrackProjY = v[k];
         p->mnTrackScaleLevel = lvl[k]; p->mTrackViewCos = vc[k];
+        inView(p);
         nToMatch++;
     }
     return nToMatch;
+}
+template <class FrameT, class MapPointT, class Skip>
+int IsInFrustum(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewingCosLimit, Skip&& skip) {
+    return IsInFrustum(F, vpMPs, viewingCosLimit, skip, [](MapPointT*) {});
 }
 
 // fills F.mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS] from F.mvKeysUn (the reserve() of upstream is an allocation hint only)

@@ -10,8 +10,12 @@
 // templates further down: they flatten what upstream reads through the KeyFrame / MapPoint accessors, call the library
 // (candidates + distances on the GPU, upstream's selection loops replayed in order) and apply the result the way upstream
 // does -- including the map mutations of Fuse, which stay on the caller's side of the C-ABI.
-#ifndef ORBMATCHER_H
-#define ORBMATCHER_H
+//
+// HOW IT IS BOUND: the reference header include/ORBmatcher.h stays as it is; src/ORBmatcher.cc leaves
+// the build and src/ORBmatcher_hip.cc (whole file in INTEGRATION.md) defines ORB_SLAM2::ORBmatcher's members as one-line
+// forwards to the class below.  Hence its own namespace and its own include guard: both headers are seen by that file.
+#ifndef EAOFUSION_ORBMATCHER_H
+#define EAOFUSION_ORBMATCHER_H
 
 #include <cstring>
 #include <map>
@@ -24,14 +28,17 @@
 #include "../eao_fusion.h"
 #include "cv_compat.h"
 
-namespace ORB_SLAM2 {
+namespace eaofusion {
 
 class ORBmatcher {
 public:
     ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
     // Computes the Hamming distance between two ORB descriptors (1 x 32 CV_8U each), reference :1649-1665.
-    // One pair per call costs a kernel launch; hot loops should use BestTwo / DistanceMatrix below.
+    // One pair per call is an upload, a kernel launch and a download (tens of microseconds):
+    // kept for completeness of the class surface only.  The reference's two outside callers are loops and are routed to
+    // the batched entry points instead -- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:281) to
+    // DistinctiveDescriptor() below, Frame::ComputeStereoMatches (src/Frame.cc:914) to eaofusion::ComputeStereoMatches.
     static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
         uint16_t d = 0;
         check(eao_hamming_matrix(a.ptr(0), 1, b.ptr(0), 1, &d), "eao_hamming_matrix");
@@ -53,8 +60,7 @@ public:
     }
 
     // ---- guided searches of the per-frame tracking loop.  Templates over the reference's Frame / MapPoint classes (same
-    //      member names as src/ORBmatcher.cc uses), so `ORBmatcher::SearchByProjection(F, vpMapPoints, th)` in Tracking.cc
-    //      resolves to these when src/ORBmatcher.cc's two bodies are removed.
+    //      member names as src/ORBmatcher.cc uses); src/ORBmatcher_hip.cc instantiates them with the reference's classes.
 
     // reference :45-129 (TrackLocalMap -> SearchLocalPoints)
     template <class FrameT, class MapPointT>
@@ -381,9 +387,10 @@ public:
         return DistinctiveDescriptors(std::vector<std::vector<cv::Mat> >(1, vDescriptors))[0];
     }
 
-    static const int TH_LOW;
-    static const int TH_HIGH;
-    static const int HISTO_LENGTH;
+    // reference src/ORBmatcher.cc:37-39
+    static constexpr int TH_LOW = 50;
+    static constexpr int TH_HIGH = 100;
+    static constexpr int HISTO_LENGTH = 30;
 
     // reference :1603-1644 (rotation-consistency histogram): indices of the three fullest bins, -1 when a bin is
     // below 10% of the fullest
@@ -511,10 +518,5 @@ protected:
     bool mbCheckOrientation;
 };
 
-// reference src/ORBmatcher.cc:37-39
-inline const int ORBmatcher::TH_HIGH = 100;
-inline const int ORBmatcher::TH_LOW = 50;
-inline const int ORBmatcher::HISTO_LENGTH = 30;
-
-}  // namespace ORB_SLAM2
-#endif  // ORBMATCHER_H
+}  // namespace eaofusion
+#endif  // EAOFUSION_ORBMATCHER_H

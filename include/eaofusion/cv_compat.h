@@ -52,7 +52,7 @@ public:
     unsigned char* data = nullptr;
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
-    Mat(int r, int c, int type, void* ext, size_t stp = 0) : rows(r), cols(c), type_(type), data((unsigned char*)ext) {
+    Mat(int r, int c, int type, void* ext, size_t stp = 0) : rows(r), cols(c), data((unsigned char*)ext), type_(type) {
         step = stp ? stp : (size_t)c * elemSize();
     }
     void create(int r, int c, int type) {

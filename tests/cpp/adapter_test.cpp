@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nk; i++) wr(out, descriptors.ptr(i), 32);
     int32_t pyr0[3] = {extractor.mvImagePyramid[0].rows, extractor.mvImagePyramid[0].cols, (int32_t)extractor.mvImagePyramid[7].cols};
     wr(out, pyr0, 3);
-    int32_t dd = ORB_SLAM2::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1));
+    int32_t dd = eaofusion::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1));
     wr(out, &dd, 1);
     cv::Mat empty;
     std::vector<cv::KeyPoint> untouched(3);
@@ -141,7 +141,7 @@ int main(int argc, char** argv) {
             tmps[i].descriptor = descriptors.row(i).clone();
             vp.push_back(&tmps[i]);
         }
-        ORB_SLAM2::ORBmatcher matcher(0.8f, true);
+        eaofusion::ORBmatcher matcher(0.8f, true);
         int32_t nm = matcher.SearchByProjection(TF, vp, 1.0f);
         int32_t selfHits = 0;
         for (int i = 0; i < nk; i++) selfHits += (TF.mvpMapPoints[i] == &tmps[i]);

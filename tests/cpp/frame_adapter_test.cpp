@@ -31,7 +31,8 @@ struct Frame {
     long mnId = 5;
     static float fx, fy, cx, cy, mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
     float mbf = 40.f, mfLogScaleFactor = std::log(1.2f);
-    cv::Mat mRcw, mtcw, mOw;
+    cv::Mat mRcw, mtcw, mOw, mTcw;
+    cv::Mat GetCameraCenter() { return mOw.clone(); }
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     std::vector<float> mvuRight, mvDepth;
     std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
@@ -52,6 +53,8 @@ int main() {
     const float R[9] = {std::cos(a), 0, std::sin(a), 0, 1, 0, -std::sin(a), 0, std::cos(a)}, t[3] = {0.1f, -0.05f, 0.3f};
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) F.mRcw.at<float>(r, c) = R[3 * r + c]; F.mtcw.at<float>(r) = t[r]; }
     for (int r = 0; r < 3; r++) { double s = 0; for (int k = 0; k < 3; k++) s += -(double)R[3 * k + r] * t[k]; F.mOw.at<float>(r) = (float)s; }
+    F.mTcw = cv::Mat::eye(4, 4, CV_32F);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) F.mTcw.at<float>(r, c) = R[3 * r + c]; F.mTcw.at<float>(r, 3) = t[r]; }
     // ---- 1. IsInFrustum over a local map
     const int np = 3000;
     std::vector<MapPoint> store(np);

@@ -1,0 +1,24 @@
+// Stand-in for the reference's include/Map.h (test infrastructure, see MapPoint.h here).
+#ifndef MAP_H
+#define MAP_H
+
+#include <mutex>
+#include <vector>
+
+#include "KeyFrame.h"
+#include "MapPlane.h"
+#include "MapPoint.h"
+
+namespace ORB_SLAM2 {
+class Map {
+public:
+    std::vector<KeyFrame*> GetAllKeyFrames() { return kfs; }
+    std::vector<MapPoint*> GetAllMapPoints() { return mps; }
+    std::vector<MapPlane*> GetAllMapPlanes() { return planes; }
+    std::mutex mMutexMapUpdate;
+    std::vector<KeyFrame*> kfs;
+    std::vector<MapPoint*> mps;
+    std::vector<MapPlane*> planes;
+};
+}  // namespace ORB_SLAM2
+#endif  // MAP_H

@@ -1,0 +1,340 @@
+// integration_snippets_test.cpp -- runs the code blocks of INTEGRATION.md.
+//
+// tests/test_integration_snippets.py extracts every block marked `<!-- snippet: path -->` from INTEGRATION.md into a scratch
+// directory laid out like a checkout (include/ORBextractor.h, src/*_hip.cc, src/*.inc) and compiles them, verbatim, together
+// with this driver against tests/cpp/integration/ref/ -- stand-ins that carry the reference headers' file names, include
+// guards, namespace and declarations.  Everything below therefore goes through the classes the REFERENCE declares
+// (ORB_SLAM2::ORBextractor / ORBmatcher / Optimizer / Frame / MapPoint / Tracking), whose members the snippets define, down
+// to libeaofusion_hip.so.  Exit code 0 = every check passed.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <vector>
+
+#include "Map.h"
+#include "Optimizer.h"
+#include "ORBmatcher.h"
+#include "Tracking.h"
+
+#include <eaofusion/Frame.h>
+#include <eaofusion/OptimizerImpl.h>
+
+namespace ORB_SLAM2 {
+float Frame::fx = 535.4f, Frame::fy = 539.2f, Frame::cx = 320.1f, Frame::cy = 247.6f, Frame::invfx = 1.f / 535.4f, Frame::invfy = 1.f / 539.2f;
+float Frame::mnMinX = 0.f, Frame::mnMaxX = 640.f, Frame::mnMinY = 0.f, Frame::mnMaxY = 480.f;
+float Frame::mfGridElementWidthInv = 64.f / 640.f, Frame::mfGridElementHeightInv = 48.f / 480.f;
+std::mutex MapPoint::mGlobalMutex;
+std::mutex MapPlane::mGlobalMutex;
+
+// upstream's function with its first loop as it is (src/Tracking.cc:2590-2610) and the INTEGRATION.md fragment behind it
+void Tracking::SearchLocalPoints() {
+    for (MapPoint*& pMP : mCurrentFrame.mvpMapPoints) {
+        if (!pMP) continue;
+        if (pMP->isBad()) { pMP = static_cast<MapPoint*>(NULL); continue; }
+        pMP->IncreaseVisible();
+        pMP->mnLastFrameSeen = mCurrentFrame.mnId;
+        pMP->mbTrackInView = false;
+    }
+#include "Tracking_SearchLocalPoints.inc"
+    nToMatchSeen = nToMatch;
+}
+// section 2b (compiled here; tests/cpp/tracker_adapter_test.cpp runs the same calls on device buffers)
+void Tracking::TrackLocalMapOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch,
+                                     int width, int height, void* stream) {
+#include "Tracking_TrackLocalMap.inc"
+}
+}  // namespace ORB_SLAM2
+
+using namespace ORB_SLAM2;
+
+static unsigned long long g_s = 0x9E3779B97F4A7C15ull;
+static double rnd() { g_s ^= g_s << 13; g_s ^= g_s >> 7; g_s ^= g_s << 17; return (double)(g_s >> 11) / 9007199254740992.0; }
+static int g_fail = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { std::fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); g_fail++; } } while (0)
+
+static cv::Mat synth_image(int W, int H, int shift) {       // rectangles on grey, as eao_fusion_amd/synth.py paints them (no blur)
+    cv::Mat img(H, W, CV_8UC1);
+    std::memset(img.data, 96, (size_t)W * H);
+    unsigned long long keep = g_s;
+    g_s = 0xD1B54A32D192ED03ull;
+    for (int r = 0; r < 400; r++) {
+        int x0 = (int)(rnd() * W) + shift, x1 = (int)(rnd() * W) + shift, y0 = (int)(rnd() * H), y1 = (int)(rnd() * H);
+        const unsigned char v = (unsigned char)(rnd() * 256);
+        if (x0 > x1) std::swap(x0, x1);
+        if (y0 > y1) std::swap(y0, y1);
+        for (int y = y0; y < y1; y++)
+            for (int x = std::max(x0, 0); x < std::min(x1, W); x++) img.at<unsigned char>(y, x) = v;
+    }
+    g_s = keep;
+    return img;
+}
+static int popcount256(const unsigned char* a, const unsigned char* b) {
+    int d = 0;
+    for (int k = 0; k < 32; k++) d += __builtin_popcount((unsigned)(a[k] ^ b[k]));
+    return d;
+}
+static cv::Mat col3(float x, float y, float z) { cv::Mat m(3, 1, CV_32F); m.at<float>(0) = x; m.at<float>(1) = y; m.at<float>(2) = z; return m; }
+static void scale_tables(std::vector<float>& sf, std::vector<float>& s2, std::vector<float>& is2) {
+    sf.assign(8, 1.f); s2.assign(8, 1.f); is2.assign(8, 1.f);
+    for (int l = 1; l < 8; l++) { sf[l] = sf[l - 1] * 1.2f; s2[l] = sf[l] * sf[l]; is2[l] = 1.f / s2[l]; }
+}
+static KeyFrame* keyframe_of(const Frame& F, unsigned long id) {
+    KeyFrame* K = new KeyFrame();
+    K->mnId = id; K->fx = Frame::fx; K->fy = Frame::fy; K->cx = Frame::cx; K->cy = Frame::cy; K->mbf = F.mbf;
+    K->N = F.N; K->mvKeysUn = F.mvKeysUn; K->mvuRight = F.mvuRight; K->mDescriptors = F.mDescriptors.clone();
+    K->mvScaleFactors = F.mvScaleFactors; K->mvLevelSigma2 = F.mvLevelSigma2; K->mvInvLevelSigma2 = F.mvInvLevelSigma2;
+    K->mfLogScaleFactor = F.mfLogScaleFactor; K->Tcw = F.mTcw.clone(); K->mvpMapPoints = F.mvpMapPoints; K->mFeatVec = F.mFeatVec;
+    return K;
+}
+
+int main() {
+    const int W = 640, H = 480;
+    // ------------------------------------------------------------------ row 1: ORBextractor through the replaced header
+    ORBextractor exL(1000, 1.2f, 8, 20, 7), exR(1000, 1.2f, 8, 20, 7);
+    cv::Mat imL = synth_image(W, H, 0), imR = synth_image(W, H, -14);     // right image = left shifted by a 14 px disparity
+    Frame F;
+    F.mpORBextractorLeft = &exL; F.mpORBextractorRight = &exR;
+    (*F.mpORBextractorLeft)(imL, cv::Mat(), F.mvKeys, F.mDescriptors);        // Frame::ExtractORB, src/Frame.cc:616-622
+    (*F.mpORBextractorRight)(imR, cv::Mat(), F.mvKeysRight, F.mDescriptorsRight);
+    F.N = (int)F.mvKeys.size();
+    F.mvKeysUn = F.mvKeys;
+    CHECK(F.N > 300 && (int)F.mvKeysRight.size() > 300, "ORBextractor: %d / %zu keypoints", F.N, F.mvKeysRight.size());
+    CHECK(exL.mvImagePyramid.size() == 8 && exL.mvImagePyramid[0].cols == W && exL.mvImagePyramid[0].rows == H, "mvImagePyramid");
+    scale_tables(F.mvScaleFactors, F.mvLevelSigma2, F.mvInvLevelSigma2);
+    F.mfLogScaleFactor = std::log(1.2f);
+    F.mbf = 40.f; F.mb = 40.f / Frame::fx;
+    F.mvpMapPoints.assign(F.N, nullptr); F.mvbOutlier.assign(F.N, false);
+    F.mnId = 7;
+    // ------------------------------------------------------------------ row 3b: Frame::ComputeStereoMatches (one call instead of a DescriptorDistance loop)
+    F.ComputeStereoMatches();
+    int nStereo = 0, nDisp14 = 0;
+    for (int i = 0; i < F.N; i++)
+        if (F.mvDepth[i] > 0) { nStereo++; nDisp14 += std::fabs((F.mvKeys[i].pt.x - F.mvuRight[i]) - 14.f) < 1.5f; }
+    CHECK(nStereo > F.N / 2 && nDisp14 > 0.9 * nStereo, "ComputeStereoMatches: %d matched, %d at the planted disparity", nStereo, nDisp14);
+    std::fprintf(stderr, "ComputeStereoMatches: %d of %d keypoints matched, %d at the planted disparity of 14 px\n", nStereo, F.N, nDisp14);
+    // ------------------------------------------------------------------ row 3c: ComputeStereoFromRGBD + AssignFeaturesToGrid
+    cv::Mat depth(H, W, CV_32F);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) depth.at<float>(y, x) = 3.0f + 0.001f * (float)((x * 7 + y * 3) % 100);
+    F.ComputeStereoFromRGBD(depth);
+    int nDepth = 0;
+    for (int i = 0; i < F.N; i++) nDepth += (F.mvDepth[i] >= 3.0f && F.mvDepth[i] < 3.1f && std::fabs(F.mvuRight[i] - (F.mvKeysUn[i].pt.x - F.mbf / F.mvDepth[i])) < 1e-4f);
+    CHECK(nDepth == F.N, "ComputeStereoFromRGBD: %d of %d", nDepth, F.N);
+    F.TestAssignFeaturesToGrid();
+    {
+        std::vector<int> seen(F.N, 0);
+        size_t total = 0;
+        for (int i = 0; i < FRAME_GRID_COLS; i++) for (int j = 0; j < FRAME_GRID_ROWS; j++) for (size_t k : F.mGrid[i][j]) { seen[k]++; total++; }
+        bool once = total == (size_t)F.N;
+        for (int v : seen) once = once && v == 1;
+        CHECK(once, "AssignFeaturesToGrid: %zu entries for %d keypoints", total, F.N);
+    }
+    // ------------------------------------------------------------------ the local map: every keypoint back-projected at its depth (camera = world)
+    std::vector<MapPoint*> local;
+    for (int i = 0; i < F.N; i++) {
+        const float z = F.mvDepth[i], x = (F.mvKeysUn[i].pt.x - Frame::cx) * z / Frame::fx, y = (F.mvKeysUn[i].pt.y - Frame::cy) * z / Frame::fy;
+        const float d = std::sqrt(x * x + y * y + z * z);
+        MapPoint* p = new MapPoint();
+        p->mnId = i;
+        // MapPoint::UpdateNormalAndDepth (src/MapPoint.cc:372-373) sets mfMaxDistance = dist * scale factor of the observing level; 5 % less
+        // here so that the level PredictScale returns from the moved camera stays the keypoint's (this fork does not clamp it)
+        const float dmax = 0.95f * d * F.mvScaleFactors[F.mvKeysUn[i].octave];
+        p->TestSet(col3(x, y, z), col3(x / d, y / d, z / d), F.mDescriptors.row(i), dmax / F.mvScaleFactors[7], dmax);
+        if (i % 29 == 0) p->TestSetBad(true);
+        local.push_back(p);
+    }
+    // ------------------------------------------------------------------ rows 3 / 3c: Tracking::SearchLocalPoints (fragment) -> ORBmatcher::SearchByProjection
+    Tracking T;
+    T.mCurrentFrame = F;
+    cv::Mat Tcw = cv::Mat::eye(4, 4, CV_32F);
+    Tcw.at<float>(0, 3) = 0.004f; Tcw.at<float>(1, 3) = -0.003f;        // a couple of pixels of motion
+    T.mCurrentFrame.SetPose(Tcw);
+    T.mvpLocalMapPoints = local;
+    T.mCurrentFrame.mvpMapPoints[5] = local[5]; T.mCurrentFrame.mvpMapPoints[29] = local[29];   // one prior match, one BAD prior match
+    T.SearchLocalPoints();
+    int nMatched = 0, nSelf = 0, nVis = 0;
+    for (int i = 0; i < F.N; i++) { nMatched += T.mCurrentFrame.mvpMapPoints[i] != nullptr; nSelf += T.mCurrentFrame.mvpMapPoints[i] == local[i]; nVis += local[i]->nVisible; }
+    CHECK(T.nToMatchSeen > 0.9 * F.N && nMatched > 0.85 * F.N && nSelf > 0.95 * nMatched, "SearchLocalPoints: %d in view, %d matched, %d to themselves", T.nToMatchSeen, nMatched, nSelf);
+    CHECK(T.mCurrentFrame.mvpMapPoints[29] == nullptr && nVis == T.nToMatchSeen + 1, "visibility bookkeeping: %d vs %d + 1", nVis, T.nToMatchSeen);
+    std::fprintf(stderr, "SearchLocalPoints: %d in view, %d matched (%d to the point they came from)\n", T.nToMatchSeen, nMatched, nSelf);
+    // ------------------------------------------------------------------ row 2: Optimizer::PoseOptimization through the reference's static
+    {
+        Frame& C = T.mCurrentFrame;
+        Frame direct = C;                                       // the template called directly on a copy must agree bit for bit
+        direct.mTcw = C.mTcw.clone();
+        const int inl = Optimizer::PoseOptimization(&C);
+        const int inl2 = eaofusion::PoseOptimization<MapPoint>(&direct);
+        bool same = inl == inl2 && C.mvbOutlier == direct.mvbOutlier;
+        for (int k = 0; k < 16; k++) same = same && C.mTcw.ptr<float>(0)[k] == direct.mTcw.ptr<float>(0)[k];
+        CHECK(same && inl > 0.8 * nMatched, "PoseOptimization: %d inliers (direct %d)", inl, inl2);
+        // the map was built with the camera at the origin: the optimum is the identity
+        CHECK(std::fabs(C.mTcw.at<float>(0, 3)) < 2e-3f && std::fabs(C.mTcw.at<float>(1, 3)) < 2e-3f, "PoseOptimization pose %g %g", C.mTcw.at<float>(0, 3), C.mTcw.at<float>(1, 3));
+        std::fprintf(stderr, "PoseOptimization: %d inliers, t = (%.5f, %.5f, %.5f)\n", inl, C.mTcw.at<float>(0, 3), C.mTcw.at<float>(1, 3), C.mTcw.at<float>(2, 3));
+    }
+    // ------------------------------------------------------------------ row 3: the other matcher forwards, each called once through ORB_SLAM2::ORBmatcher
+    {
+        Frame Last = T.mCurrentFrame, Cur = F;
+        Cur.SetPose(Last.mTcw);
+        Cur.mvpMapPoints.assign(Cur.N, nullptr);
+        ORBmatcher m9(0.9, true);
+        const int n1 = m9.SearchByProjection(Cur, Last, 7.f, false);                       // TrackWithMotionModel
+        CHECK(n1 > 0.8 * nMatched, "SearchByProjection(Cur, Last): %d", n1);
+        Frame F1 = F, F2 = F;
+        std::vector<cv::Point2f> prev(F1.N);
+        for (int i = 0; i < F1.N; i++) prev[i] = F1.mvKeysUn[i].pt;
+        std::vector<int> m12;
+        const int n2 = ORBmatcher(0.9, true).SearchForInitialization(F1, F2, prev, m12, 100);   // MonocularInitialization
+        int selfInit = 0;
+        for (int i = 0; i < F1.N; i++) selfInit += m12[i] == i;
+        CHECK(n2 > 0 && selfInit == n2, "SearchForInitialization: %d matches, %d to themselves", n2, selfInit);
+        // keyframe flavours: two keyframes that share the frame's keypoints; one vocabulary node per level as the feature vector
+        Frame FK = T.mCurrentFrame;
+        for (int i = 0; i < FK.N; i++) FK.mFeatVec[(unsigned)FK.mvKeysUn[i].octave].push_back((unsigned)i);
+        KeyFrame *K1 = keyframe_of(FK, 1), *K2 = keyframe_of(FK, 2);
+        for (int i = 0; i < FK.N; i++) if (K1->mvpMapPoints[i]) { K1->mvpMapPoints[i]->AddObservation(K1, i); K1->mvpMapPoints[i]->AddObservation(K2, i); }
+        std::vector<MapPoint*> vm;
+        const int n3 = ORBmatcher(0.75, true).SearchByBoW(K1, K2, vm);                     // LoopClosing::ComputeSim3
+        int agree = 0;
+        for (int i = 0; i < FK.N; i++) agree += vm[i] && vm[i] == K2->mvpMapPoints[i];
+        CHECK(n3 > 100 && agree == n3, "SearchByBoW(KF, KF): %d matches, %d consistent", n3, agree);
+        Frame FB = FK;
+        std::vector<MapPoint*> vb;
+        const int n4 = ORBmatcher(0.7, true).SearchByBoW(K1, FB, vb);                      // TrackReferenceKeyFrame
+        CHECK(n4 > 100, "SearchByBoW(KF, Frame): %d", n4);
+        Frame FR = F;
+        FR.SetPose(T.mCurrentFrame.mTcw);
+        FR.mvpMapPoints.assign(FR.N, nullptr);
+        const int n5 = ORBmatcher(0.9, true).SearchByProjection(FR, K1, std::set<MapPoint*>(), 10.f, 100);   // Relocalization
+        CHECK(n5 > 100, "SearchByProjection(Frame, KF, found): %d", n5);
+        std::vector<MapPoint*> matched(K2->N, static_cast<MapPoint*>(NULL));
+        std::vector<MapPoint*> good;
+        for (MapPoint* p : local) if (!p->isBad()) good.push_back(p);
+        const int n6 = ORBmatcher(0.75, true).SearchByProjection(K2, K2->GetPose(), good, matched, 10);      // loop detection
+        CHECK(n6 > 100, "SearchByProjection(KF, Scw): %d", n6);
+        std::vector<MapPoint*> v12(K1->N, static_cast<MapPoint*>(NULL));
+        cv::Mat R12 = cv::Mat::eye(3, 3, CV_32F), t12 = cv::Mat::zeros(3, 1, CV_32F);
+        const int n7 = ORBmatcher(0.75, true).SearchBySim3(K1, K2, v12, 1.0f, R12, t12, 7.5f);
+        CHECK(n7 > 100, "SearchBySim3: %d", n7);
+        KeyFrame* K3 = keyframe_of(FK, 3);
+        K3->mvpMapPoints.assign(K3->N, nullptr);
+        const int n8 = ORBmatcher(0.6, true).Fuse(K3, good, 3.0f);                          // SearchInNeighbors: everything is added
+        int added = 0;
+        for (MapPoint* p : K3->mvpMapPoints) added += p != nullptr;
+        CHECK(n8 > 100 && added > 100, "Fuse(KF, points): %d fused, %d added", n8, added);
+        std::vector<MapPoint*> repl(good.size(), static_cast<MapPoint*>(NULL));
+        KeyFrame* K4 = keyframe_of(FK, 4);
+        const int n9 = ORBmatcher(0.8, true).Fuse(K4, K4->GetPose(), good, 4.f, repl);      // SearchAndFuse
+        CHECK(n9 >= 0, "Fuse(KF, Scw): %d", n9);
+        KeyFrame *KA = keyframe_of(FK, 5), *KB = keyframe_of(FK, 6);
+        KA->mvpMapPoints.assign(KA->N, nullptr); KB->mvpMapPoints.assign(KB->N, nullptr);
+        cv::Mat TB = KB->Tcw.clone();
+        TB.at<float>(0, 3) += 0.1f;                                                          // a 10 cm baseline along x
+        KB->SetPose(TB);
+        cv::Mat F12 = cv::Mat::zeros(3, 3, CV_32F);                                          // F of a pure x translation: epipolar lines are rows
+        F12.at<float>(1, 2) = -1.f; F12.at<float>(2, 1) = 1.f;
+        std::vector<std::pair<size_t, size_t> > pairs;
+        const int n10 = ORBmatcher(0.6, false).SearchForTriangulation(KA, KB, F12, pairs, false);   // CreateNewMapPoints
+        CHECK(n10 == (int)pairs.size(), "SearchForTriangulation: %d vs %zu", n10, pairs.size());
+        std::fprintf(stderr, "matcher forwards: frames %d, init %d, BoW %d / %d, reloc %d, loop %d, sim3 %d, fuse %d / %d, triangulation %d\n", n1, n2, n3,
+                     n4, n5, n6, n7, n8, n9, n10);
+        CHECK(ORBmatcher::TH_HIGH == 100 && ORBmatcher::TH_LOW == 50 && ORBmatcher::HISTO_LENGTH == 30, "constants");
+    }
+    // ------------------------------------------------------------------ row 3b: MapPoint::ComputeDistinctiveDescriptors vs a brute-force median
+    {
+        int bad = 0, checked = 0;
+        std::vector<KeyFrame*> kfs;
+        for (int k = 0; k < 7; k++) {
+            KeyFrame* K = new KeyFrame();
+            K->mnId = 20 + k; K->N = 50; K->mDescriptors = cv::Mat(50, 32, CV_8U);
+            for (int i = 0; i < 50; i++) for (int b = 0; b < 32; b++) K->mDescriptors.at<unsigned char>(i, b) = (unsigned char)((i * 37 + b * 11) ^ (rnd() < 0.15 ? (int)(rnd() * 256) : 0));
+            kfs.push_back(K);
+        }
+        for (int i = 0; i < 50; i++) {
+            MapPoint p;
+            const int nobs = 1 + i % 7;
+            for (int k = 0; k < nobs; k++) p.AddObservation(kfs[(i + k) % 7], (size_t)((i * 3 + k) % 50));
+            p.ComputeDistinctiveDescriptors();
+            std::vector<const unsigned char*> rows;
+            for (const auto& ob : p.GetObservations()) rows.push_back(ob.first->mDescriptors.ptr((int)ob.second));
+            int bestMedian = 1 << 30, bestIdx = 0;
+            for (size_t a = 0; a < rows.size(); a++) {
+                std::vector<int> d;
+                for (size_t b = 0; b < rows.size(); b++) d.push_back(a == b ? 0 : popcount256(rows[a], rows[b]));
+                std::sort(d.begin(), d.end());
+                const int med = d[(size_t)(0.5 * (rows.size() - 1))];
+                if (med < bestMedian) { bestMedian = med; bestIdx = (int)a; }
+            }
+            const cv::Mat got = p.GetDescriptor();
+            bad += std::memcmp(got.ptr(0), rows[bestIdx], 32) != 0;
+            checked++;
+        }
+        CHECK(bad == 0, "ComputeDistinctiveDescriptors: %d of %d differ from the brute-force median", bad, checked);
+    }
+    // ------------------------------------------------------------------ rows 2 / 2b: LocalBundleAdjustment and GlobalBundleAdjustemnt
+    {
+        const int nc = 5, np = 300;
+        Map map;
+        std::vector<float> truth(np * 3);
+        for (int p = 0; p < np; p++) {
+            MapPoint* mp = new MapPoint();
+            mp->mnId = p;
+            truth[3 * p] = (float)(rnd() * 4 - 2); truth[3 * p + 1] = (float)(rnd() * 3 - 1.5); truth[3 * p + 2] = (float)(3 + rnd() * 3);
+            mp->SetWorldPos(col3(truth[3 * p] + 0.02f * (float)(rnd() - 0.5), truth[3 * p + 1] + 0.02f * (float)(rnd() - 0.5), truth[3 * p + 2] + 0.02f * (float)(rnd() - 0.5)));
+            map.mps.push_back(mp);
+        }
+        for (int c = 0; c < nc; c++) {
+            KeyFrame* K = new KeyFrame();
+            K->mnId = c; K->fx = Frame::fx; K->fy = Frame::fy; K->cx = Frame::cx; K->cy = Frame::cy; K->mbf = 40.f;
+            scale_tables(K->mvScaleFactors, K->mvLevelSigma2, K->mvInvLevelSigma2);
+            cv::Mat Tt = cv::Mat::eye(4, 4, CV_32F);
+            Tt.at<float>(0, 3) = -0.15f * (float)c;
+            for (int p = 0; p < np; p++) {
+                if ((p + c) % 4 == 0) continue;
+                const float X = truth[3 * p] + Tt.at<float>(0, 3), Y = truth[3 * p + 1], Z = truth[3 * p + 2];
+                cv::KeyPoint kp;
+                kp.pt.x = Frame::fx * X / Z + Frame::cx + (float)(rnd() - 0.5); kp.pt.y = Frame::fy * Y / Z + Frame::cy + (float)(rnd() - 0.5);
+                kp.octave = p % 4;
+                K->mvKeysUn.push_back(kp);
+                K->mvuRight.push_back(p % 5 == 0 ? -1.f : kp.pt.x - 40.f / Z);
+                K->mvpMapPoints.push_back(map.mps[p]);
+                map.mps[p]->AddObservation(K, K->mvKeysUn.size() - 1);
+            }
+            K->N = (int)K->mvKeysUn.size();
+            if (c) Tt.at<float>(0, 3) += 0.01f;      // free keyframes start a centimetre off
+            K->SetPose(Tt);
+            map.kfs.push_back(K);
+        }
+        KeyFrame* cur = map.kfs[nc - 1];
+        for (int c = 1; c < nc - 1; c++) cur->covisible.push_back(map.kfs[c]);
+        bool stop = false;
+        Optimizer::LocalBundleAdjustment(cur, &stop, &map);
+        double err = 0;
+        for (int c = 1; c < nc; c++) err = std::max(err, (double)std::fabs(map.kfs[c]->Tcw.at<float>(0, 3) + 0.15f * (float)c));
+        int normals = 0;
+        for (MapPoint* p : map.mps) normals += p->normalUpdates;
+        CHECK(err < 4e-3 && normals > 0.9 * np, "LocalBundleAdjustment: pose error %g, %d normal updates", err, normals);
+        Optimizer::GlobalBundleAdjustemnt(&map, 10, nullptr, 0, true);
+        double err2 = 0;
+        for (int c = 1; c < nc; c++) err2 = std::max(err2, (double)std::fabs(map.kfs[c]->Tcw.at<float>(0, 3) + 0.15f * (float)c));
+        CHECK(err2 < 4e-3, "GlobalBundleAdjustemnt: pose error %g", err2);
+        std::fprintf(stderr, "LocalBundleAdjustment: max |tx error| %.2e; GlobalBundleAdjustemnt: %.2e\n", err, err2);
+    }
+    // ------------------------------------------------------------------ the single-pair DescriptorDistance: correct, and what a call costs
+    {
+        int wrong = 0;
+        for (int i = 0; i + 1 < 40; i++)
+            wrong += ORBmatcher::DescriptorDistance(F.mDescriptors.row(i), F.mDescriptors.row(i + 1)) != popcount256(F.mDescriptors.ptr(i), F.mDescriptors.ptr(i + 1));
+        CHECK(wrong == 0, "DescriptorDistance: %d wrong", wrong);
+        const auto t0 = std::chrono::steady_clock::now();
+        int acc = 0;
+        for (int r = 0; r < 500; r++) acc += ORBmatcher::DescriptorDistance(F.mDescriptors.row(r % F.N), F.mDescriptors.row((r + 1) % F.N));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 500.0;
+        std::fprintf(stderr, "DescriptorDistance single pair: %.1f us per call (checksum %d)\n", us, acc);
+    }
+    if (g_fail) { std::fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
+    std::fprintf(stderr, "integration snippets: all checks passed\n");
+    return 0;
+}

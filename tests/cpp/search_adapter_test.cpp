@@ -10,7 +10,7 @@
 
 #include <eaofusion/ORBmatcher.h>
 
-using namespace ORB_SLAM2;
+using eaofusion::ORBmatcher;
 
 struct KeyFrame;
 struct MapPoint {

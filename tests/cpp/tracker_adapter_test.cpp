@@ -13,7 +13,10 @@
 
 struct MapPoint {
     cv::Mat pos, normal, desc;
-    bool bad = false;
+    bool bad = false, mbTrackInView = false;
+    int nVisible = 0;
+    long unsigned int mnLastFrameSeen = ~0ul;
+    void IncreaseVisible(int n = 1) { nVisible += n; }
     bool isBad() { return bad; }
     cv::Mat GetWorldPos() { return pos.clone(); }
     cv::Mat GetNormal() { return normal.clone(); }
@@ -27,6 +30,7 @@ protected:
 
 struct Frame {
     int N = 0;
+    long unsigned int mnId = 9;
     static float fx, fy, cx, cy, mnMinX, mnMaxX, mnMinY, mnMaxY;
     float mbf = 40.f, mfLogScaleFactor = std::log(1.2f);
     int mnScaleLevels = 8;
@@ -80,6 +84,20 @@ int main() {
     F.mvpMapPoints.assign(F.N, nullptr);
     F.mvbOutlier.assign(F.N, false);
     F.mvpMapPoints[3] = local[3 < M ? 3 : 0];        // a match the frame already carries
+    //  a prior match that has gone bad: upstream's SearchLocalPoints sets it to NULL and the keypoint is free again;
+    // and a prior match that is NOT in the local map: it stays, keeps its keypoint and is an edge of the pose optimisation
+    int badIdx = -1;
+    for (int m = 0; m < M && badIdx < 0; m++) if (pts[m].bad && m != 3) badIdx = m;
+    if (badIdx < 0) { fprintf(stderr, "no bad point in the scene\n"); return 2; }
+    F.mvpMapPoints[5] = local[badIdx];
+    MapPoint outsider;
+    {
+        const cv::KeyPoint& kp = F.mvKeys[7];
+        const float z = 3.5f, xc = (kp.pt.x - Frame::cx) * z / Frame::fx, yc = (kp.pt.y - Frame::cy) * z / Frame::fy;
+        outsider.pos = cv::Mat(3, 1, CV_32F); outsider.pos.at<float>(0) = xc - 0.02f; outsider.pos.at<float>(1) = yc; outsider.pos.at<float>(2) = z + 0.03f;
+        outsider.normal = outsider.pos.clone(); outsider.desc = cv::Mat(1, 32, CV_8U);
+    }
+    F.mvpMapPoints[7] = &outsider;
     eao_keypoint* d_kps; uint8_t* d_desc; int32_t* d_n; float* d_depth;
     HIPCHK(hipMalloc((void**)&d_kps, cap * sizeof(eao_keypoint))); HIPCHK(hipMalloc((void**)&d_desc, cap * 32)); HIPCHK(hipMalloc((void**)&d_n, 4));
     HIPCHK(hipMalloc((void**)&d_depth, depth.size() * 4));
@@ -90,7 +108,11 @@ int main() {
     HIPCHK(hipMemcpy(d_depth, depth.data(), depth.size() * 4, hipMemcpyHostToDevice));
     Frame F2 = F;                                      // for the direct C-ABI call below
     eaofusion::DeviceTracker trk(F, cap, 1024);
-    trk.SetLocalMap(local);
+    if (!trk.SetLocalMap(local)) { fprintf(stderr, "SetLocalMap refused %d points\n", M); return 2; }
+    {
+        std::vector<MapPoint*> tooMany(1025, local[0]);
+        if (trk.SetLocalMap(tooMany)) { fprintf(stderr, "SetLocalMap accepted a map beyond the handle's capacity\n"); return 2; }
+    }
     const int nIn = trk.TrackLocalMap(F, d_kps, d_desc, d_n, d_depth, W, W, H, 3.0f, 0.8f, nullptr);
     // ---- the same through the C-ABI, arrays built by hand
     eao_tracker_cfg c = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, F2.mbf, 0.f, 640.f, 0.f, 480.f, 64, 48, 8, F2.mvScaleFactors.data(), F2.mvInvLevelSigma2.data(),
@@ -111,18 +133,46 @@ int main() {
     if (eao_tracker_set_local_map(h, &mp) != EAO_OK) { fprintf(stderr, "%s\n", eao_last_error()); return 2; }
     std::vector<int32_t> prior(cap, -1), kpMp(cap, -1);
     prior[3] = 3;
+    prior[5] = badIdx;            // the library itself drops a prior on an inactive point
+    prior[7] = -2;                // outside the local map: position handed over
+    std::vector<float> priorXw(3 * (size_t)cap, 0.f);
+    for (int a = 0; a < 3; a++) priorXw[3 * 7 + a] = outsider.pos.at<float>(a);
+    std::vector<uint8_t> inView(1024, 0);
     std::vector<uint8_t> outl(cap);
     std::vector<float> ur(cap), dz(cap);
     eao_track_result R;
-    R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data();
+    R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data(); R.map_in_view = inView.data();
     float T[16];
     for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) T[4 * r + k] = F2.mTcw.at<float>(r, k);
-    if (eao_tracker_track_local_map(h, d_kps, d_desc, d_n, d_depth, W, W, H, T, prior.data(), 3.0f, 0.8f, &R, nullptr) != EAO_OK) { fprintf(stderr, "%s\n", eao_last_error()); return 2; }
+    if (eao_tracker_track_local_map(h, d_kps, d_desc, d_n, d_depth, W, W, H, T, prior.data(), priorXw.data(), 3.0f, 0.8f, &R, nullptr) != EAO_OK) { fprintf(stderr, "%s\n", eao_last_error()); return 2; }
+    {   // a stale prior table (an index beyond the uploaded map) is refused before any kernel runs
+        std::vector<int32_t> stale(prior);
+        stale[11] = M;
+        eao_track_result R2 = R;
+        std::vector<int32_t> k2(cap); std::vector<uint8_t> o2(cap);
+        R2.kp_map_point = k2.data(); R2.kp_outlier = o2.data(); R2.kp_u_right = nullptr; R2.kp_depth = nullptr; R2.map_in_view = nullptr;
+        if (eao_tracker_track_local_map(h, d_kps, d_desc, d_n, d_depth, W, W, H, T, stale.data(), priorXw.data(), 3.0f, 0.8f, &R2, nullptr) != EAO_ERR_INVALID) {
+            fprintf(stderr, "a prior index beyond the local map was accepted\n");
+            return 2;
+        }
+    }
     eao_tracker_destroy(h);
     int bad = 0, matched = 0;
     if (nIn != R.n_inliers) { fprintf(stderr, "inliers %d vs %d\n", nIn, R.n_inliers); bad++; }
+    // SearchLocalPoints' bookkeeping (src/Tracking.cc:2590-2627)
+    if (kpMp[5] == badIdx || F.mvpMapPoints[5] == local[badIdx]) { fprintf(stderr, "the bad prior match survived\n"); bad++; }
+    if (kpMp[7] != -2 || F.mvpMapPoints[7] != &outsider) { fprintf(stderr, "the prior match outside the local map was lost\n"); bad++; }
+    if (outsider.nVisible != 1 || outsider.mnLastFrameSeen != F.mnId || local[3]->nVisible != 1 || local[3]->mnLastFrameSeen != F.mnId) { fprintf(stderr, "prior-match bookkeeping\n"); bad++; }
+    if (local[badIdx]->nVisible != 0) { fprintf(stderr, "a bad point was counted visible\n"); bad++; }
+    int nView = 0;
+    for (int m = 0; m < M; m++) {
+        if (m == 3 || pts[m].bad) continue;
+        nView += inView[m];
+        if (pts[m].nVisible != (int)inView[m] || pts[m].mbTrackInView != (inView[m] != 0)) bad++;
+    }
+    if (nView < 100) { fprintf(stderr, "only %d points in view\n", nView); bad++; }
     for (int k = 0; k < F.N; k++) {
-        MapPoint* want = kpMp[k] >= 0 ? &pts[kpMp[k]] : nullptr;
+        MapPoint* want = kpMp[k] >= 0 ? &pts[kpMp[k]] : (kpMp[k] == -2 ? &outsider : nullptr);
         if (F.mvpMapPoints[k] != want) bad++;
         if (F.mvbOutlier[k] != (outl[k] != 0)) bad++;
         if (F.mvuRight[k] != ur[k] || F.mvDepth[k] != dz[k]) bad++;

@@ -1,6 +1,7 @@
 """Row f1, second half: the device-resident tracked frame.  eao_tracker_track_local_map chains ComputeStereoFromRGBD +
 AssignFeaturesToGrid -> isInFrustum over the local map -> SearchByProjection(points) -> PoseOptimization on the device behind
-the extractor's outputs; it must give, bit for bit, what the host-hop calls of the same C-ABI give on the same data."""
+the extractor's outputs; it must give what the CPU oracle gives for the same chain (integer tables bit for bit, the pose within the LM bound), and, bit for bit,
+what the host-hop calls of the same C-ABI give on the same data."""
 import numpy as np
 import pytest
 import torch
@@ -44,44 +45,221 @@ def _scene(seed, n=900, prior_frac=0.0, mono_frac=0.25):
     return cur, kps, np.ascontiguousarray(cur["descriptors"]), depth, pts, prior
 
 
-def _host_hop(E, cur, kps, desc, depth, pts, prior, th, nnratio):
-    from eao_fusion_amd import frame as FR
+class _ProductCalls:
+    """The host-hop calls of the product's C-ABI (each of them parity-tested against the oracle in its own test file)."""
+    def __init__(self, E):
+        from eao_fusion_amd import frame as FR
+        self.stereo, self.frustum = FR.compute_stereo_from_rgbd, FR.is_in_frustum
+        self.search = lambda frame, mps, th, nnratio: E.ORBmatcher(nnratio, True).SearchByProjectionPoints(frame, mps, th)
+        self.pose = E.Optimizer.PoseOptimization
+
+
+class _OracleCalls:
+    """The same four steps on the CPU oracle: oracle/frame_cpu.cpp (src/Frame.cc:638-695, 1016-1037), oracle/match_cpu.cpp
+    (src/ORBmatcher.cc:45-129), oracle/lm_cpu.cpp (src/Optimizer.cc:325-673) -- Tracking::TrackLocalMap's data path
+    (src/Tracking.cc:2233-2297, 2587-2641) chained on the host."""
+    def __init__(self, O):
+        fb = O.frame_binding()
+        self.stereo, self.frustum = fb.compute_stereo_from_rgbd, fb.is_in_frustum
+        self.search = O.search_by_projection_points
+        self.pose = O.pose_optimization
+
+
+def _chain(calls, cur, kps, desc, depth, pts, prior, th, nnratio, prior_Xw=None):
+    """Frame::ComputeStereoFromRGBD -> Tracking::SearchLocalPoints (prior matches on bad points dropped, isInFrustum over the
+    rest, SearchByProjection) -> Optimizer::PoseOptimization over every mvpMapPoints entry, step by step."""
     N, M = len(kps), len(pts["Xw"])
     kx, ky = np.ascontiguousarray(kps["x"]), np.ascontiguousarray(kps["y"])
-    ur, dz = FR.compute_stereo_from_rgbd(kx, ky, kx, depth, cur["mbf"])
+    ur, dz = calls.stereo(kx, ky, kx, depth, cur["mbf"])
     T = np.ascontiguousarray(cur["Tcw"], np.float32)
     Ow = (-(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))).astype(np.float32)
     logsf = float(np.log(np.float32(1.2)))
     fr = dict(Tcw=T, Ow=Ow, fx=cur["fx"], fy=cur["fy"], cx=cur["cx"], cy=cur["cy"], mbf=cur["mbf"], min_x=0.0, max_x=640.0, min_y=0.0, max_y=480.0,
               log_scale_factor=np.float32(logsf))
-    fo = FR.is_in_frustum(fr, pts, 0.5)
+    fo = calls.frustum(fr, pts, 0.5)
+    active = pts["active"].astype(bool)
     occupied = np.zeros(N, np.uint8)
-    skip = (~fo["in_view"].astype(bool)) | (~pts["active"].astype(bool))
+    skip = (~fo["in_view"].astype(bool)) | (~active)
     kp_mp = np.full(N, -1, np.int32)
     if prior is not None:
-        occupied[prior >= 0] = 1
-        skip[prior[prior >= 0]] = True
-        kp_mp[:] = prior
+        pr = np.array(prior, np.int32)
+        pr[(pr >= 0) & ~active[np.maximum(pr, 0)]] = -1        # "if(pMP->isBad()) *vit = NULL", src/Tracking.cc:2596-2599
+        occupied[pr != -1] = 1
+        skip[pr[pr >= 0]] = True                                # mnLastFrameSeen == mCurrentFrame.mnId, :2615-2616
+        kp_mp[:] = pr
     frame = dict(kp_x=kx, kp_y=ky, kp_octave=np.ascontiguousarray(kps["octave"]), kp_angle=np.ascontiguousarray(kps["angle"]), u_right=ur,
                  descriptors=desc, occupied=occupied, min_x=np.float32(0), min_y=np.float32(0), max_x=np.float32(640), max_y=np.float32(480),
                  scale_factors=cur["scale_factors"])
     lvl = np.where(skip, 0, fo["pred_level"]).astype(np.int32)
     mps = dict(proj_x=fo["proj_x"], proj_y=fo["proj_y"], proj_xr=fo["proj_xr"], view_cos=fo["view_cos"], level=lvl, descriptors=pts["descriptors"],
                skip=skip.astype(np.uint8))
-    nm, match = E.ORBmatcher(nnratio, True).SearchByProjectionPoints(frame, mps, th)
+    nm, match = calls.search(frame, mps, th, nnratio)
     for m in range(M):
         if match[m] >= 0:
             kp_mp[match[m]] = m
-    ks = np.nonzero(kp_mp >= 0)[0]
+    ks = np.nonzero(kp_mp != -1)[0]
     inv_sigma2 = (np.float32(1.0) / (cur["scale_factors"] * cur["scale_factors"])).astype(np.float32)
-    res = dict(n_matches=nm, kp_map_point=kp_mp, u_right=ur, depth=dz, n_edges=len(ks))
-    prob = dict(Tcw=T, points=pts["Xw"][kp_mp[ks]], obs=np.stack([kx[ks], ky[ks], ur[ks]], 1).astype(np.float32),
+    # what the caller's visibility counters need: isInFrustum of the points upstream projects (active, not named by a prior match)
+    projected = active.copy()
+    if prior is not None:
+        projected[kp_mp[(kp_mp >= 0) & (occupied == 1)]] = False
+    res = dict(n_matches=nm, kp_map_point=kp_mp, u_right=ur, depth=dz, n_edges=len(ks), in_view=fo["in_view"].astype(bool) & active, projected=projected)
+    Xe = np.zeros((len(ks), 3), np.float32)
+    inmap = kp_mp[ks] >= 0
+    Xe[inmap] = pts["Xw"][kp_mp[ks][inmap]]
+    if (~inmap).any():
+        Xe[~inmap] = np.asarray(prior_Xw, np.float32)[ks[~inmap]]
+    prob = dict(Tcw=T, points=Xe, obs=np.stack([kx[ks], ky[ks], ur[ks]], 1).astype(np.float32),
                 inv_sigma2=inv_sigma2[kps["octave"][ks]], fx=cur["fx"], fy=cur["fy"], cx=cur["cx"], cy=cur["cy"], bf=cur["mbf"])
-    r = E.Optimizer.PoseOptimization(prob)
+    if len(ks) < 3:
+        res.update(Tcw=T, n_inliers=0, kp_outlier=np.zeros(N, np.uint8))
+        return res
+    r = calls.pose(prob)
     outl = np.zeros(N, np.uint8)
     outl[ks] = r["outlier"]
     res.update(Tcw=r["Tcw"], n_inliers=r["n_inliers"], kp_outlier=outl)
     return res
+
+
+def _host_hop(E, cur, kps, desc, depth, pts, prior, th, nnratio):
+    return _chain(_ProductCalls(E), cur, kps, desc, depth, pts, prior, th, nnratio)
+
+
+def _device_buffers(kps, desc, depth, cap):
+    dev = torch.device("cuda")
+    N = len(kps)
+    d_kps = torch.zeros((cap, 28), dtype=torch.uint8, device=dev)
+    d_kps[:N] = torch.from_numpy(kps.view(np.uint8).reshape(N, 28)).to(dev)
+    d_desc = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
+    d_desc[:N] = torch.from_numpy(desc).to(dev)
+    d_n = torch.tensor([N], dtype=torch.int32, device=dev)
+    d_depth = torch.from_numpy(depth).to(dev)
+    torch.cuda.synchronize()
+    return d_kps, d_desc, d_n, d_depth
+
+
+def _tracker(cur, cap, cap_mp):
+    from eao_fusion_amd.tracker import Tracker
+    sf = cur["scale_factors"]
+    return Tracker(cur["fx"], cur["fy"], cur["cx"], cur["cy"], cur["mbf"], (0.0, 640.0, 0.0, 480.0), sf, (np.float32(1.0) / (sf * sf)).astype(np.float32),
+                   float(np.log(np.float32(1.2))), cap, cap_mp)
+
+
+def _pose_close(got, want, old):
+    """tests/test_gpu_lm.py's bound: 1e-4 of the update (+ two float32 ulps of the value: outputs are float32)."""
+    upd = max(np.abs(want.astype(np.float64) - old.astype(np.float64)).max(), 1e-6)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+    return err <= 1e-4 * upd + 2 * np.spacing(np.abs(want).max().astype(np.float32)), err, upd
+
+
+@pytest.mark.parametrize("case", [dict(seed=7100), dict(seed=7101, prior_frac=0.3), dict(seed=7102, th=3.0, mono_frac=0.6),
+                                  dict(seed=7103, n=300, prior_frac=0.1, nnratio=0.9), dict(seed=7104, n=1500, th=5.0),
+                                  dict(seed=7106, n=1200, prior_frac=0.2, th=3.0), dict(seed=7107, n=600, mono_frac=1.0)])
+def test_chained_device_path_equals_the_oracle_chain(case, oracle):
+    """the device chain against the ORACLE (not against other GPU calls): every integer table of the chain
+    -- mvuRight / mvDepth, the in-view flags, the greedy assignment, mvpMapPoints, the edge count, mvbOutlier, the inlier count --
+    bit for bit, the optimised pose within the LM bound (1e-4 of the update)."""
+    import eao_fusion_amd as E
+    assert E.load().eao_device_check() == 0, E.load().eao_last_error()
+    kw = dict(case)
+    th, nnratio = kw.pop("th", 1.0), kw.pop("nnratio", 0.8)
+    cur, kps, desc, depth, pts, prior = _scene(**kw)
+    want = _chain(_OracleCalls(oracle), cur, kps, desc, depth, pts, prior, th, nnratio)
+    N, cap = len(kps), 2048
+    trk = _tracker(cur, cap, 2048)
+    trk.set_local_map(pts)
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+    got = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], prior, th, nnratio,
+                              torch.cuda.current_stream().cuda_stream)
+    assert got["n_keypoints"] == N
+    assert np.array_equal(got["u_right"], want["u_right"]) and np.array_equal(got["depth"], want["depth"])
+    pj = want["projected"]
+    assert np.array_equal(got["map_in_view"].astype(bool)[pj], want["in_view"][pj]) and want["in_view"][pj].sum() > 50
+    assert got["n_matches"] == want["n_matches"] and want["n_matches"] > 50
+    assert np.array_equal(got["kp_map_point"], want["kp_map_point"])
+    assert got["n_edges"] == want["n_edges"]
+    assert got["n_inliers"] == want["n_inliers"]
+    assert np.array_equal(got["kp_outlier"], want["kp_outlier"])
+    ok, err, upd = _pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])
+    assert ok, "pose: |gpu - oracle| %.3e vs update %.3e" % (err, upd)
+
+
+def test_prior_matches_bad_and_outside_the_local_map(oracle):
+    """a prior match on an inactive (bad) point is dropped -- the keypoint is free again, as upstream's
+    SearchLocalPoints sets it to NULL; a prior match that is not in the local map (-2) keeps its keypoint and is an edge built
+    from the position handed over; an index beyond the uploaded map is refused before any kernel runs.  Against the oracle chain."""
+    import eao_fusion_amd as E
+    cur, kps, desc, depth, pts, prior = _scene(7110, n=800, prior_frac=0.2)
+    rng = np.random.default_rng(5)
+    N, M = len(kps), len(pts["Xw"])
+    inactive = np.nonzero(pts["active"] == 0)[0]
+    assert len(inactive) >= 5
+    free = np.nonzero(prior < 0)[0]
+    unused = np.setdiff1d(inactive, prior[prior >= 0])
+    prior[free[:3]] = unused[:3]                      # three keypoints matched to points that have gone bad
+    outside = free[3:23]                              # twenty keypoints matched to points the local map does not hold
+    prior[outside] = -2
+    prior_Xw = np.zeros((N, 3), np.float32)
+    T = cur["Tcw"].astype(np.float64)
+    z = rng.uniform(2.0, 5.0, len(outside))
+    Xc = np.stack([(kps["x"][outside] - cur["cx"]) * z / cur["fx"], (kps["y"][outside] - cur["cy"]) * z / cur["fy"], z], 1)
+    prior_Xw[outside] = ((Xc - T[:3, 3]) @ T[:3, :3]).astype(np.float32)
+    want = _chain(_OracleCalls(oracle), cur, kps, desc, depth, pts, prior, 3.0, 0.8, prior_Xw)
+    cap = 2048
+    trk = _tracker(cur, cap, 2048)
+    trk.set_local_map(pts)
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+    st = torch.cuda.current_stream().cuda_stream
+    got = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], prior, 3.0, 0.8, st, prior_Xw)
+    assert np.array_equal(got["kp_map_point"], want["kp_map_point"])
+    assert (got["kp_map_point"][outside] == -2).all() and not np.isin(got["kp_map_point"][free[:3]], unused[:3]).any()
+    assert got["n_matches"] == want["n_matches"] and got["n_edges"] == want["n_edges"] and got["n_inliers"] == want["n_inliers"]
+    assert np.array_equal(got["kp_outlier"], want["kp_outlier"])
+    ok, err, upd = _pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])
+    assert ok, "pose: |gpu - oracle| %.3e vs update %.3e" % (err, upd)
+    # -2 without positions, and a stale index, are refused
+    with pytest.raises(Exception, match="prior_kp_Xw"):
+        trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], prior, 3.0, 0.8, st)
+    stale = prior.copy()
+    stale[free[30]] = M
+    with pytest.raises(Exception, match="names no point of the local map"):
+        trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], stale, 3.0, 0.8, st, prior_Xw)
+    small = {k: (v[:M // 2] if isinstance(v, np.ndarray) else v) for k, v in pts.items()}
+    trk.set_local_map(small)                          # the map shrank: the old table now points beyond it
+    if (prior >= M // 2).any():
+        with pytest.raises(Exception, match="names no point of the local map"):
+            trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], prior, 3.0, 0.8, st, prior_Xw)
+
+
+def test_local_map_beyond_4096_points(oracle):
+    """upstream's mvpLocalMapPoints has no limit (80 local keyframes give 5-10 k points).  One assignment workgroup
+    now carries up to 16 points per thread: 6 000 and 12 000 local map points against the oracle chain."""
+    import eao_fusion_amd as E
+    for seed, big in ((7120, 6000), (7121, 12000)):
+        cur, kps, desc, depth, pts, prior = _scene(seed, n=1000)
+        rng = np.random.default_rng(seed)
+        M = len(pts["Xw"])
+        extra = big - M
+        # the extra points: around the scene (some in view, most not), random descriptors
+        Xe = rng.uniform([-8, -6, -2], [8, 6, 10], (extra, 3)).astype(np.float32)
+        de = np.maximum(np.linalg.norm(Xe, axis=1), 0.1).astype(np.float32)
+        more = dict(active=np.ones(extra, np.uint8), Xw=Xe, normal=(Xe / de[:, None]).astype(np.float32), min_dist_inv=(0.6 * de).astype(np.float32),
+                    max_dist_inv=(1.7 * de).astype(np.float32), max_dist=(de * np.float32(1.2) ** 3).astype(np.float32),
+                    descriptors=rng.integers(0, 256, (extra, 32), dtype=np.uint8))
+        order = rng.permutation(big)                   # the real points spread over the whole index range
+        allp = {k: np.ascontiguousarray(np.concatenate([pts[k], more[k]])[order]) for k in more}
+        want = _chain(_OracleCalls(oracle), cur, kps, desc, depth, allp, None, 3.0, 0.8)
+        cap = 2048
+        trk = _tracker(cur, cap, 16384)
+        trk.set_local_map(allp)
+        d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+        got = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], None, 3.0, 0.8,
+                                  torch.cuda.current_stream().cuda_stream)
+        assert got["n_matches"] == want["n_matches"] and want["n_matches"] > 300
+        assert np.array_equal(got["kp_map_point"], want["kp_map_point"]) and np.array_equal(got["kp_outlier"], want["kp_outlier"])
+        assert np.array_equal(got["map_in_view"].astype(bool), want["in_view"])
+        ok, err, upd = _pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])
+        assert ok, "pose: |gpu - oracle| %.3e vs update %.3e" % (err, upd)
 
 
 @pytest.mark.parametrize("case", [dict(seed=7100), dict(seed=7101, prior_frac=0.3), dict(seed=7102, th=3.0, mono_frac=0.6),
