@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "../../include/eao_fusion.h"
+#include "ref_constants.inc"   // GENERATED from the reference text (tools/gen_ref_constants.py): namespace refc
 
 namespace eao {
 

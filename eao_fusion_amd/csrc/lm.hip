@@ -498,7 +498,7 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
     __shared__ unsigned char s_pflag[kPoseMaxPlanes], s_pout[kPoseMaxPlanes];
     const int M = P.nPlanes;
     const int t = threadIdx.x, n = P.nDev ? min(*P.nDev, P.n) : P.n;
-    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    const float chi2Mono = refc::POSE_CHI2_MONO, chi2Stereo = refc::POSE_CHI2_STEREO;
     const Cam c = P.cam;
     double eX[EPT][3], eO[EPT][3], eI[EPT], eE[EPT][3];
     unsigned char eF[EPT], eOut[EPT];
@@ -547,7 +547,7 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
     long long pa[6] = {0, 0, 0, 0, 0, 0}, pts = 0;
     auto lap = [&](int slot) { if (stamp) { const long long now = clock64(); pa[slot] += now - pts; pts = now; } };
     __syncthreads();
-    for (int round = 0; round < 4; round++) {
+    for (int round = 0; round < refc::POSE_ROUNDS; round++) {
         if (t == 0) { s_est = P.T0; s_active = 0; }
         __syncthreads();
         {   // any level-0 edge?  (g2o: optimize() returns -1 when the index mapping is empty)
@@ -561,7 +561,7 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
         const int active = s_active;
         if (active) {
             bool ok = true;
-            for (int it = 0; it < 10 && ok; it++) {
+            for (int it = 0; it < refc::POSE_ITS && ok; it++) {
                 // ---- computeActiveErrors + activeRobustChi2 + buildSystem at the current estimate
                 if (stamp) pts = clock64();
                 const SE3 est = s_est;
@@ -668,7 +668,7 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
                         double md = 0;
                         int q = 0;
                         for (int a = 0; a < 6; a++) { md = fmax(md, fabs(sums[q])); q += 6 - a; }
-                        s_lambda = 1e-5 * md;
+                        s_lambda = refc::LM_TAU * md;
                         s_ni = 2;
                         s_nbad = 0;
                     }
@@ -741,10 +741,10 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
                         }
                         s_rho = r;
                         const int q1 = qmax + 1;
-                        if (!(r < 0 && q1 < 10)) {      // the last trial of this iteration: close the iteration here
+                        if (!(r < 0 && q1 < refc::LM_MAX_TRIALS)) {      // the last trial of this iteration: close the iteration here
                             if (s_ntrace < 64) { P.trace[s_ntrace] = s_lambda; P.trace[64 + s_ntrace] = s_cur; P.trace[128 + s_ntrace] = q1; s_ntrace++; }
                             s_iters++;
-                            int term = (q1 == 10 || r == 0) ? 1 : 0;
+                            int term = (q1 == refc::LM_MAX_TRIALS || r == 0) ? 1 : 0;
                             if (!term) {
                                 if ((iniChi - s_cur) * 1e3 < iniChi) s_nbad++; else s_nbad = 0;
                                 if (s_nbad >= 3) term = 1;
@@ -756,7 +756,7 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
                     lap(5);
                     rho = s_rho;
                     qmax++;
-                } while (rho < 0 && qmax < 10);
+                } while (rho < 0 && qmax < refc::LM_MAX_TRIALS);
                 ok = !s_flag;
             }
         }
@@ -773,16 +773,16 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
             if (c2 > (stereo ? chi2Stereo : chi2Mono)) { eOut[k] = 1; fl |= 2; nb[0] += 1; }
             else { eOut[k] = 0; fl &= ~2; }
             if (!stereo) fl &= ~4;            // mono: kernel removed after every round
-            else if (round == 2) fl &= ~4;    // stereo: at it == 2
+            else if (round == refc::POSE_UNROBUST_ROUND) fl &= ~4;    // stereo: at it == 2
             eF[k] = fl;
         }
         if (t < M) {   // src/Optimizer.cc:626-658
             unsigned char fl = s_pflag[t];
             if (s_pout[t]) plane_error(est, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
             const float c2 = (float)plane_chi2(t);
-            if (c2 > 300.0) { s_pout[t] = 1; fl |= 2; nb[0] += 1; }
+            if (c2 > refc::PLANE_CHI2) { s_pout[t] = 1; fl |= 2; nb[0] += 1; }
             else { s_pout[t] = 0; fl &= ~2; }
-            if (round == 2) fl &= ~4;
+            if (round == refc::POSE_UNROBUST_ROUND) fl &= ~4;
             s_pflag[t] = fl;
         }
         block_sum<1, kPoseThreads>(nb, red, &s_tmp);
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
     __shared__ unsigned char s_pflag[kPoseMaxPlanes], s_pout[kPoseMaxPlanes];
     const int M = P.nPlanes;
     const int t = threadIdx.x, n = P.nDev ? min(*P.nDev, P.n) : P.n;
-    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    const float chi2Mono = refc::POSE_CHI2_MONO, chi2Stereo = refc::POSE_CHI2_STEREO;
     if (t == 0) { s_ntrace = 0; s_iters = 0; s_est = P.T0; }
     if (t < M) { s_pflag[t] = 4; s_pout[t] = 0; s_perr[3 * t] = s_perr[3 * t + 1] = s_perr[3 * t + 2] = 0; }
     auto plane_chi2 = [&](int p) {
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
         return e[0] * (pl[8] * e[0]) + e[1] * (pl[8] * e[1]) + e[2] * (pl[9] * e[2]);
     };
     __syncthreads();
-    for (int round = 0; round < 4; round++) {
+    for (int round = 0; round < refc::POSE_ROUNDS; round++) {
         if (t == 0) { s_est = P.T0; s_active = 0; }
         __syncthreads();
         {   // any level-0 edge?  (g2o: optimize() returns -1 when the index mapping is empty)
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
         int lmNBad = 0;  // uniform copies of the LM state that only thread 0 updates live in LDS
         if (active) {
             bool ok = true;
-            for (int it = 0; it < 10 && ok; it++) {
+            for (int it = 0; it < refc::POSE_ITS && ok; it++) {
                 // ---- computeActiveErrors + activeRobustChi2 + buildSystem at the current estimate
                 const SE3 est = s_est;
                 double acc[28];
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
                         double md = 0;
                         int q = 0;
                         for (int a = 0; a < 6; a++) { md = fmax(md, fabs(sums[q])); q += 6 - a; }
-                        s_lambda = 1e-5 * md;
+                        s_lambda = refc::LM_TAU * md;
                         s_ni = 2;
                         s_nbad = 0;
                     }
@@ -1015,11 +1015,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
                     __syncthreads();
                     rho = s_rho;
                     qmax++;
-                } while (rho < 0 && qmax < 10);
+                } while (rho < 0 && qmax < refc::LM_MAX_TRIALS);
                 if (t == 0) {
                     if (s_ntrace < 64) { P.trace[s_ntrace] = s_lambda; P.trace[64 + s_ntrace] = s_cur; P.trace[128 + s_ntrace] = qmax; s_ntrace++; }
                     s_iters++;
-                    int term = (qmax == 10 || rho == 0) ? 1 : 0;
+                    int term = (qmax == refc::LM_MAX_TRIALS || rho == 0) ? 1 : 0;
                     if (!term) {
                         if ((iniChi - s_cur) * 1e3 < iniChi) s_nbad++; else s_nbad = 0;
                         if (s_nbad >= 3) term = 1;
@@ -1042,16 +1042,16 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_mem(PoseDev 
             if (c2 > (stereo ? chi2Stereo : chi2Mono)) { P.outlier[i] = 1; fl |= 2; nb[0] += 1; }
             else { P.outlier[i] = 0; fl &= ~2; }
             if (!stereo) fl &= ~4;            // mono: kernel removed after every round
-            else if (round == 2) fl &= ~4;    // stereo: at it == 2
+            else if (round == refc::POSE_UNROBUST_ROUND) fl &= ~4;    // stereo: at it == 2
             P.flags[i] = fl;
         }
         if (t < M) {   // src/Optimizer.cc:626-658
             unsigned char fl = s_pflag[t];
             if (s_pout[t]) plane_error(est, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
             const float c2 = (float)plane_chi2(t);
-            if (c2 > 300.0) { s_pout[t] = 1; fl |= 2; nb[0] += 1; }
+            if (c2 > refc::PLANE_CHI2) { s_pout[t] = 1; fl |= 2; nb[0] += 1; }
             else { s_pout[t] = 0; fl &= ~2; }
-            if (round == 2) fl &= ~4;
+            if (round == refc::POSE_UNROBUST_ROUND) fl &= ~4;
             s_pflag[t] = fl;
         }
         block_sum<1, kPoseThreads>(nb, red, &s_tmp);
@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(256) void k_ba_lambda_init(const BADev* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-        P.lm[0] = 1e-5 * m; P.lm[1] = 2; P.lm[3] = m;
+        P.lm[0] = refc::LM_TAU * m; P.lm[1] = refc::LM_NI; P.lm[3] = m;
     }
 }
 
@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_ba_schur(const BADev* __restr
     const int b0 = min(beg + chunk * per, end), total = min(per, end - b0);
     // first trial of an optimize() call: lambda_0 from the maximum the linearisation just accumulated; workgroup (0,0)
     // publishes it for the kernels that follow in the stream
-    const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
+    const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
     if (first && i1 == 0 && chunk == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
     double acc[kSchurMaxOut];
 #pragma unroll
@@ -2022,7 +2022,7 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(const BADev* __
     while (rem >= nF - i1) { rem -= nF - i1; i1++; }
     const int i2 = i1 + rem;
     const bool diag = i1 == i2;
-    const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
+    const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
     if (first && bx == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
     const int cnt = P.pairCnt[bx];
     const int* pts = P.pairPts + (size_t)bx * P.nL;
@@ -2103,7 +2103,7 @@ __global__ __launch_bounds__(NT, 1024 / NT) void k_ba_schur_pairs_b(const BADev*
     while (rem >= nF - i1) { rem -= nF - i1; i1++; }
     const int i2 = i1 + rem;
     const bool diag = i1 == i2;
-    const double lambda = first ? 1e-5 * lm3 : lm0;
+    const double lambda = first ? refc::LM_TAU * lm3 : lm0;
     if (first && bx == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
     const int half = t & 1;        // adjacent lanes share a landmark: their Hll / Hpl(e2) loads hit the same cache lines
     double acc[21];
@@ -2421,7 +2421,7 @@ __global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(const BADev
     const size_t ld = g.RP;
     const int i1 = P.lpPair[2 * bx], i2 = P.lpPair[2 * bx + 1];
     const bool diag = i1 == i2;
-    const double lambda = first ? 1e-5 * P.lm[3] : P.lm[0];
+    const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
     if (bx == 0) {
         if (first && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
         if (t == 0) *P.bigFail = 0;
@@ -2920,7 +2920,7 @@ __global__ void k_ba_classify(const BADev* __restrict__ W, int wpar, int update)
     const double c2 = ba_chi2(&P.err[3 * e], P.info[e], stereo);
     double p[3];
     se3_map(cur_cams(P)[P.ecam[e]], &cur_pts(P)[3 * P.ept[e]], p);
-    const unsigned char bad = (c2 > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) ? 1 : 0;
+    const unsigned char bad = (c2 > (stereo ? refc::LBA_CHI2_STEREO : refc::LBA_CHI2_MONO) || !(p[2] > 0.0)) ? 1 : 0;
     out[e] = bad;
     if (update) {
         if (e == 0) {   // fresh control block for the second optimize() (the current-buffer index carries over); a first
@@ -2975,7 +2975,7 @@ __global__ __launch_bounds__(256) void k_ba_finish(const BADev* __restrict__ W, 
         const double c2 = ba_chi2(&P.err[3 * e], P.info[e], stereo);
         double p[3];
         se3_map(cur_cams(P)[P.ecam[e]], &cur_pts(P)[3 * P.ept[e]], p);
-        outCls[e] = (c2 > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) ? 1 : 0;
+        outCls[e] = (c2 > (stereo ? refc::LBA_CHI2_STEREO : refc::LBA_CHI2_MONO) || !(p[2] > 0.0)) ? 1 : 0;
     }
 }
 
@@ -3106,7 +3106,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
         }
         // planes: normalised world / measured coefficients and the two information values (src/Optimizer.cc:464-465, 503-516)
         double* hP = (double*)hostp(dplanes);
-        const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0;
+        const double angleInfo = refc::PLANE_ANGLE_INFO / (1.0 * 1.0), disInfo = refc::PLANE_DIST_INFO_ROOT * refc::PLANE_DIST_INFO_ROOT;
         for (int i = 0; i < M; i++) {
             plane_from_f32(p->plane_world + 4 * i, hP + 10 * i);
             plane_from_f32(p->plane_obs + 4 * i, hP + 10 * i + 4);
@@ -3127,9 +3127,9 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     if (zeroCopy) { P.Xw = (const double*)hostp(dXw); P.obs = (const double*)hostp(dobs); P.info = (const double*)hostp(dinfo); P.flags = (unsigned char*)hostp(dflags); }
     P.T0 = se3_from_Tcw_f32(p->Tcw);
     P.cam.fx = p->fx; P.cam.fy = p->fy; P.cam.cx = p->cx; P.cam.cy = p->cy; P.cam.bf = p->bf; P.cam.bf_f = p->bf;
-    P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
+    P.cam.deltaMono = (float)std::sqrt(refc::POSE_HUBER2_MONO); P.cam.deltaStereo = (float)std::sqrt(refc::POSE_HUBER2_STEREO);
     P.Tout = oT; P.result = ores; P.trace = otrace;
-    P.nPlanes = M; P.planes = dplanes; P.planeOutlier = opl; P.deltaPlane = (float)std::sqrt(300.0);
+    P.nPlanes = M; P.planes = dplanes; P.planeOutlier = opl; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
     P.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
     if (n <= 2 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<2>, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
     else if (n <= 4 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<4>, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
@@ -3233,7 +3233,7 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
         PoseDev* hW = (PoseDev*)hostp(dW);
         const bool zeroCopy = false;       // (the single call reads its inputs from the pinned mirror; for a batch it was measured and makes no difference)
         size_t oo = 0;
-        const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0;     // src/Optimizer.cc:464-465
+        const double angleInfo = refc::PLANE_ANGLE_INFO / (1.0 * 1.0), disInfo = refc::PLANE_DIST_INFO_ROOT * refc::PLANE_DIST_INFO_ROOT;     // src/Optimizer.cc:464-465
         for (size_t k = 0; k < slots.size(); k++) {
             Slot& s = slots[k];
             const eao_pose_problem* p = &ps[s.b];
@@ -3266,9 +3266,9 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
             }
             P.T0 = se3_from_Tcw_f32(p->Tcw);
             P.cam.fx = p->fx; P.cam.fy = p->fy; P.cam.cx = p->cx; P.cam.cy = p->cy; P.cam.bf = p->bf; P.cam.bf_f = p->bf;
-            P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
+            P.cam.deltaMono = (float)std::sqrt(refc::POSE_HUBER2_MONO); P.cam.deltaStereo = (float)std::sqrt(refc::POSE_HUBER2_STEREO);
             P.Tout = (SE3*)o; P.result = ores; P.trace = otrace;
-            P.nPlanes = M; P.planes = s.planes; P.planeOutlier = opl; P.deltaPlane = (float)std::sqrt(300.0);
+            P.nPlanes = M; P.planes = s.planes; P.planeOutlier = opl; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
             P.dbg = nullptr;
         }
         g_trace.clear();
@@ -3530,7 +3530,8 @@ struct BAJob {
         std::memset(&D, 0, sizeof(D));
         D.nCams = nC; D.nPts = nP; D.nEdges = E; D.chunks = chunks;
         D.cam.fx = p->fx; D.cam.fy = p->fy; D.cam.cx = p->cx; D.cam.cy = p->cy; D.cam.bf = p->bf; D.cam.bf_f = p->bf;
-        D.cam.deltaMono = (float)std::sqrt(mode == 1 ? 5.99 : 5.991); D.cam.deltaStereo = (float)std::sqrt(7.815);
+        D.cam.deltaMono = (float)std::sqrt(mode == 1 ? refc::GBA_HUBER2_MONO : refc::LBA_HUBER2_MONO);
+        D.cam.deltaStereo = (float)std::sqrt(mode == 1 ? refc::GBA_HUBER2_STEREO : refc::LBA_HUBER2_STEREO);
         // ---- the uploaded part of the arena (problem, initial state, adjacency, zeroed control block, the window record
         //      itself) is mirrored in pinned host memory: filled in place, sent with two copies
         const size_t off0 = a.off;
@@ -3562,7 +3563,7 @@ struct BAJob {
         double* dptsT = a.take<double>((size_t)nP * 3);
         D.plBuf[0] = dpl0; D.plBuf[1] = a.take<double>((size_t)nPl * 4 + 1); D.pmeas = dpmeas;
         D.nPtsOnly = nPo; D.nEdgesPt = Ept;
-        D.deltaPlane = (float)std::sqrt(300.0); D.infoAngle = 3282.8 / (1.0 * 1.0); D.infoDist = 100.0 * 100.0;   // src/Optimizer.cc:203-208
+        D.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2); D.infoAngle = refc::PLANE_ANGLE_INFO / (1.0 * 1.0); D.infoDist = refc::PLANE_DIST_INFO_ROOT * refc::PLANE_DIST_INFO_ROOT;   // src/Optimizer.cc:203-208
         D.err = a.take<double>((size_t)E * 3);
         D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
         D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
@@ -3784,7 +3785,7 @@ struct BAJob {
             double rho = S.rho;
             int qmax = 1;
             bool accepted = S.accepted != 0;
-            while (rho < 0 && qmax < 10 && !(stop && *stop)) {
+            while (rho < 0 && qmax < refc::LM_MAX_TRIALS && !(stop && *stop)) {
                 if ((st = set_ctl(0, done, nBad))) return st;
                 L.trial(0, 0, false, true);
                 if ((st = wait_status(L.seq))) return st;
@@ -3795,7 +3796,7 @@ struct BAJob {
             needErrors = !accepted;             // pop(): residuals belong to the rejected state
             tr->lambda.push_back(c.status->lambda); tr->chi2.push_back(currentChi); tr->trials.push_back(qmax);
             done++;
-            if (qmax == 10 || rho == 0) { ok = false; break; }
+            if (qmax == refc::LM_MAX_TRIALS || rho == 0) { ok = false; break; }
             if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
             if (nBad >= 3) ok = false;
         }
@@ -4119,10 +4120,10 @@ eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
     P.Xw = a.Xw; P.obs = a.obs; P.info = a.info; P.err = a.err; P.flags = a.flags; P.outlier = a.outlier;
     P.T0 = se3_from_Tcw_f32(a.Tcw0);
     P.cam.fx = a.fx; P.cam.fy = a.fy; P.cam.cx = a.cx; P.cam.cy = a.cy; P.cam.bf = a.bf; P.cam.bf_f = a.bf;
-    P.cam.deltaMono = (float)std::sqrt(5.991); P.cam.deltaStereo = (float)std::sqrt(7.815);
+    P.cam.deltaMono = (float)std::sqrt(refc::POSE_HUBER2_MONO); P.cam.deltaStereo = (float)std::sqrt(refc::POSE_HUBER2_STEREO);
     P.Tout = (SE3*)a.outSE3; P.result = a.outResult; P.trace = a.outTrace;
     P.scatterIdx = a.scatterIdx; P.scatterOut = a.scatterOut;
-    P.nPlanes = 0; P.planes = nullptr; P.planeOutlier = nullptr; P.deltaPlane = (float)std::sqrt(300.0);
+    P.nPlanes = 0; P.planes = nullptr; P.planeOutlier = nullptr; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
     P.dbg = nullptr;
     if (a.cap <= 2 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<2>, dim3(1), dim3(kPoseThreads), 0, s, P);
     else hipLaunchKernelGGL(k_pose_optimization<4>, dim3(1), dim3(kPoseThreads), 0, s, P);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_match_candidates(FrameDev F, const Quer
         Q.active = (B.active[m] && B.inView[m] && !B.skip[m]) ? 1 : 0;
         int lvl = Q.active ? B.level[m] : 0;
         if (Q.active && (lvl < 0 || lvl >= B.nlevels)) { if (lane == 0) atomicOr(B.errFlags, 1); Q.active = 0; lvl = 0; }   // (upstream would index out of range)
-        float r = (double)B.viewCos[m] > 0.998 ? 2.5f : 4.0f;          // RadiusByViewingCos, :131-137
+        float r = (double)B.viewCos[m] > refc::VIEWCOS_NARROW ? refc::RADIUS_NARROW : refc::RADIUS_WIDE;          // RadiusByViewingCos, :131-137
         if (B.th != 1.0f) r *= B.th;
         const float rs = Q.active ? r * B.scale[lvl] : 0.f;
         Q.x = B.projX[m]; Q.y = B.projY[m]; Q.r = rs;
@@ -323,7 +323,7 @@ eao_status eao_search_by_projection_points(const eao_frame_view* F, int32_t n_mp
         Q.active = !(skip && skip[m]);
         const int lvl = pred_level[m];
         if (Q.active) EAO_REQUIRE(lvl >= 0 && lvl < F->nlevels, "map point %d: predicted level %d out of range", m, lvl);
-        float r = view_cos[m] > 0.998 ? 2.5f : 4.0f;          // RadiusByViewingCos, :131-137
+        float r = view_cos[m] > refc::VIEWCOS_NARROW ? refc::RADIUS_NARROW : refc::RADIUS_WIDE;          // RadiusByViewingCos, :131-137
         if (bFactor) r *= th;
         rs[m] = Q.active ? r * F->scale_factors[lvl] : 0.f;
         Q.x = proj_x[m]; Q.y = proj_y[m]; Q.r = rs[m];
@@ -347,7 +347,7 @@ eao_status eao_search_by_projection_points(const eao_frame_view* F, int32_t n_mp
             if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = F->kp_octave[i]; bestIdx = i; }
             else if (d < bestDist2) { bestLevel2 = F->kp_octave[i]; bestDist2 = d; }
         }
-        if (bestDist <= 100) {   // TH_HIGH
+        if (bestDist <= refc::TH_HIGH) {
             if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
             match_kp[m] = bestIdx;
             occ[bestIdx] = 1;
@@ -410,7 +410,7 @@ eao_status eao_search_by_projection_frames(const eao_frame_view* C, const float*
     if (st) return st;
     std::vector<uint8_t> occ(C->n, 0);
     if (C->occupied) std::memcpy(occ.data(), C->occupied, C->n);
-    constexpr int HISTO = 30;                      // HISTO_LENGTH
+    constexpr int HISTO = refc::HISTO_LENGTH;
     std::vector<int> rotHist[HISTO];
     const float factor = HISTO / 360.0f;          // this fork's histogram factor for this routine (:1337)
     int nm = 0;

@@ -32,7 +32,7 @@
 namespace {
 
 constexpr int kMaxLevels = 16;
-constexpr int kEdge = 19;
+constexpr int kEdge = refc::EDGE_THRESHOLD;
 constexpr int kMinBorder = kEdge - 3;  // 16
 constexpr int kTile = 72;              // max FAST sub-image edge (cell <= 60 px + 6)
 // (tested region of a cell = sub-image minus the 3 px FAST margin on every side: at most 66 x 66)
@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Geom* __restrict__ g
         }
         for (int dlt = 32; dlt >= 1; dlt >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, dlt));
         const int bestDist = (int)(best >> 16);
-        if (best != 0xFFFFFFFFu && bestDist < 100) {           // ORBmatcher::TH_HIGH
+        if (best != 0xFFFFFFFFu && bestDist < refc::TH_HIGH) {
             const int bestIdxR = (int)(best & 0xFFFF);
             const float uR0 = A.kr[bestIdxR].x;
             const float sf = A.invScale[levelL];
@@ -1681,9 +1681,8 @@ struct eao_orb {
     // (EAO_ORB_LANES, default 1: see the measurement note at enqueue())
     static constexpr int kLanes = 4;
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
-    hipEvent_t evLast = nullptr;   // end of the previous call on this handle (whatever stream it ran on)
-    bool evLastValid = false, capturing = false;
-    hipStream_t lastStream = nullptr;      // the stream of the previous call (evLast)
+    bool evLastValid = false, capturing = false;   // evLastValid: a call has been enqueued on lastStream
+    hipStream_t lastStream = nullptr;      // the stream of the previous call: compared, never dereferenced (its owner may have destroyed it)
     hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
@@ -1729,7 +1728,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         EAO_REQUIRE(L.w < 4096 && L.h < 4096, "level %d is %dx%d: coordinates are packed in 12 bits", l, L.w, L.h);
         const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
         const float width = (float)(maxBX - kMinBorder), height = (float)(maxBY - kMinBorder);
-        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        const int nCols = (int)(width / (float)refc::FAST_CELL), nRows = (int)(height / (float)refc::FAST_CELL);
         EAO_REQUIRE(nCols >= 1 && nRows >= 1, "level %d (%dx%d) is smaller than one 30 px FAST cell plus borders", l, L.w, L.h);
         const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
         EAO_REQUIRE(wCell + 6 <= kTile && hCell + 6 <= kTile, "FAST cell %dx%d exceeds the LDS tile", wCell, hCell);
@@ -1743,7 +1742,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         off += ((L.pitch * ((L.h + kBlurRows - 1) / kBlurRows * kBlurRows)) + 255) & ~255;   // (padding rows: see k_blur7)
         const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
         const float width = (float)(maxBX - kMinBorder), height = (float)(maxBY - kMinBorder);
-        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        const int nCols = (int)(width / (float)refc::FAST_CELL), nRows = (int)(height / (float)refc::FAST_CELL);
         const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
         L.cellBase = (int)h->cells.size();
         for (int i = 0; i < nRows; i++) {   // reference src/ORBextractor.cc:789-806
@@ -1778,7 +1777,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
         L.tilesX = eao::cdiv(L.w, kBlurSegW);
         L.tileBase = tileBase; tileBase += eao::cdiv(L.tilesX * eao::cdiv(L.h, kBlurRows), kBlurStripsPerWg);
         L.scale = h->scale[l];
-        L.scaledPatch = (int)(31 * h->scale[l]);
+        L.scaledPatch = (int)(refc::PATCH_SIZE * h->scale[l]);
         scanCap = std::max(scanCap, std::max(L.listCap, L.nCells));
         maxList = std::max(maxList, L.listCap);
     }
@@ -1937,7 +1936,6 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
     if (!h->stream) {
         EAO_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         EAO_HIP(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
-        EAO_HIP(hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming));
         for (int i = 0; i < eao_orb::kLanes; i++) {
             EAO_HIP(hipStreamCreateWithFlags(&h->laneMain[i], hipStreamNonBlocking));
             EAO_HIP(hipStreamCreateWithFlags(&h->laneSide[i], hipStreamNonBlocking));
@@ -2005,8 +2003,10 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     // (no event is recorded at the end of a call for this: an event record between two kernels of a stream costs ~5 us on this
     //  runtime, every call would pay it, and consecutive calls on one handle almost always share their stream -- the rare
     //  change of stream waits for the previous one on the host instead)
-    if (h->evLastValid && !h->capturing && h->lastStream != st) EAO_HIP(hipStreamSynchronize(h->lastStream));
-    h->lastStream = st;
+    //  (the previous stream may have been DESTROYED by its owner in the meantime -- a garbage-collected
+    //  torch.cuda.Stream -- so its handle is never touched again: the rare change of stream drains the device instead)
+    if (h->evLastValid && !h->capturing && h->lastStream != st) EAO_HIP(hipDeviceSynchronize());
+    if (!h->capturing) h->lastStream = st;
     EAO_HIP(hipEventRecord(h->evStart, st));
     for (int i = 0; i < lanes; i++) {
         const int f0 = (int)((long long)batch * i / lanes), f1 = (int)((long long)batch * (i + 1) / lanes), nb = f1 - f0;
@@ -2210,6 +2210,10 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
         h->graphKey = key;
     }
     h->lastBatch = batch;
+    // the same ordering rule as the direct path: the replayed launches use the handle's scratch
+    if (h->evLastValid && h->lastStream != st) EAO_HIP(hipDeviceSynchronize());
+    h->lastStream = st;
+    h->evLastValid = true;
     EAO_HIP(hipGraphLaunch(h->graphExec, st));
     return EAO_OK;
 }
@@ -2280,7 +2284,6 @@ void eao_orb_destroy(eao_orb* h) {
     }
     if (h->pinOut) (void)hipHostFree(h->pinOut);
     if (h->evStart) (void)hipEventDestroy(h->evStart);
-    if (h->evLast) (void)hipEventDestroy(h->evLast);
     if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
     delete h;
 }

@@ -28,7 +28,7 @@ using eao::match::Query;
 
 namespace {
 
-constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;
+constexpr int TH_HIGH = refc::TH_HIGH, TH_LOW = refc::TH_LOW, HISTO_LENGTH = refc::HISTO_LENGTH;
 
 void affine3(const float* A, const float* x, const float* b, float alpha, float* y) {
     for (int r = 0; r < 3; r++) {
@@ -359,7 +359,7 @@ eao_status eao_search_for_triangulation(const eao_frame_view* K1, const eao_feat
                 const float den = la * la + lb * lb;
                 if (den == 0) continue;
                 const float dsqr = num * num / den;
-                if (dsqr < 3.84 * K2->level_sigma2[oct2]) { bestIdx2 = idx2; bestDist = d; }
+                if (dsqr < refc::EPIPOLAR_CHI2 * K2->level_sigma2[oct2]) { bestIdx2 = idx2; bestDist = d; }
             }
             if (bestIdx2 >= 0) {
                 match12[idx1] = bestIdx2;
@@ -449,10 +449,10 @@ eao_status eao_fuse_search(const eao_frame_view* KF, int32_t use_sim3, const flo
                 if (KF->u_right[k] >= 0) {
                     const float er = ur - KF->u_right[k];
                     const float e2 = exx * exx + eyy * eyy + er * er;
-                    if (e2 * KF->inv_level_sigma2[kl] > 7.8) continue;
+                    if (e2 * KF->inv_level_sigma2[kl] > refc::FUSE_CHI2_STEREO) continue;
                 } else {
                     const float e2 = exx * exx + eyy * eyy;
-                    if (e2 * KF->inv_level_sigma2[kl] > 5.99) continue;
+                    if (e2 * KF->inv_level_sigma2[kl] > refc::FUSE_CHI2_MONO) continue;
                 }
             }
             if (d < bestDist) { bestDist = d; bestIdx = k; }

@@ -291,7 +291,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
             }
             if (!fin) continue;
             open[u] = false;
-            if (bestDist <= 100) {   // TH_HIGH
+            if (bestDist <= refc::TH_HIGH) {
                 if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
                 claim[u] = bestIdx;
                 match[m] = bestIdx;

@@ -92,8 +92,10 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
  * The main chain of the call's kernels is enqueued on `stream` ITSELF (a private side stream of the handle, forked from and
  * joined back into it with events, carries the part that runs beside it), so consecutive calls on one stream follow each
  * other without a cross-stream hop.  Calls on one handle are serialised with each other even when they come in on different
- * streams (they share the handle's pyramid and candidate scratch): a call on another stream than the previous one first waits,
- * on the host, for that previous call.  d_n: batch int32 on the device. */
+ * streams (they share the handle's pyramid and candidate scratch): a call on another stream than the previous one first drains
+ * the device on the host (hipDeviceSynchronize -- the previous stream's handle is never used again, so its owner is free to
+ * destroy it once its own work is done).  NULL is the legacy null stream (rounds 1 - 2a read NULL as "the handle's private
+ * stream"; callers that relied on that pass their own stream now).  d_n: batch int32 on the device. */
 eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_t width, int32_t height,
                                         int32_t stride, int64_t frame_stride, int32_t batch, eao_keypoint* d_kps,
                                         uint8_t* d_desc, int32_t cap, int32_t* d_n, void* stream);

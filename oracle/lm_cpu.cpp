@@ -28,6 +28,8 @@
 #include <limits>
 #include <vector>
 
+#include "ref_constants.inc"   // GENERATED from the reference text (tools/gen_ref_constants.py): namespace refc
+
 namespace {
 
 // ------------------------------------------------------------------ small fixed-size helpers
@@ -244,7 +246,7 @@ struct LM {
         double currentChi = P.activeRobustChi2(), tempChi = currentChi;
         const double iniChi = currentChi;
         P.buildSystem();
-        if (iteration == 0) { lambda = 1e-5 * P.maxDiagonal(); ni = 2; nBad = 0; }
+        if (iteration == 0) { lambda = refc::LM_TAU * P.maxDiagonal(); ni = refc::LM_NI; nBad = 0; }
         double rho = 0;
         int qmax = 0;
         do {
@@ -263,7 +265,7 @@ struct LM {
                 alpha = std::min(alpha, 2. / 3.);
                 double scaleFactor = std::max(1. / 3., alpha);
                 lambda *= scaleFactor;
-                ni = 2;
+                ni = refc::LM_NI;
                 currentChi = tempChi;
                 P.discardTop();
             } else {
@@ -272,9 +274,9 @@ struct LM {
                 P.pop();
             }
             qmax++;
-        } while (rho < 0 && qmax < 10 && !(stop && *stop));
+        } while (rho < 0 && qmax < refc::LM_MAX_TRIALS && !(stop && *stop));
         if (tr) { tr->lambda.push_back(lambda); tr->chi2.push_back(currentChi); tr->trials.push_back(qmax); }
-        if (qmax == 10 || rho == 0) return Terminate;
+        if (qmax == refc::LM_MAX_TRIALS || rho == 0) return Terminate;
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
         if (nBad >= 3) return Terminate;
         return OK;
@@ -775,7 +777,7 @@ int orc_pose_optimization_planes(const orc_pose_problem* P, int n_planes, const 
     const int n = P->n;
     PoseProblem pb;
     pb.fx = P->fx; pb.fy = P->fy; pb.cx = P->cx; pb.cy = P->cy; pb.bf = P->bf;
-    pb.deltaMono = (float)std::sqrt(5.991); pb.deltaStereo = (float)std::sqrt(7.815);
+    pb.deltaMono = (float)std::sqrt(refc::POSE_HUBER2_MONO); pb.deltaStereo = (float)std::sqrt(refc::POSE_HUBER2_STEREO);
     pb.edges.resize(n);
     for (int i = 0; i < n; i++) {
         PoseEdge& e = pb.edges[i];
@@ -786,7 +788,7 @@ int orc_pose_optimization_planes(const orc_pose_problem* P, int n_planes, const 
     }
     if (trace) trace->n = 0;
     if (n < 3) { std::memcpy(Tcw_out, P->Tcw, 16 * sizeof(float)); return 0; }   // checked BEFORE the planes are added (:453-454)
-    const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0, planeChi = 300;
+    const double angleInfo = refc::PLANE_ANGLE_INFO / (1.0 * 1.0), disInfo = refc::PLANE_DIST_INFO_ROOT * refc::PLANE_DIST_INFO_ROOT, planeChi = refc::PLANE_CHI2;
     pb.deltaPlane = (float)std::sqrt(planeChi);
     pb.planes.resize(n_planes);
     for (int i = 0; i < n_planes; i++) {
@@ -798,14 +800,14 @@ int orc_pose_optimization_planes(const orc_pose_problem* P, int n_planes, const 
         plane_outlier[i] = 0;
     }
     const int nInitial = n + n_planes;
-    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    const float chi2Mono = refc::POSE_CHI2_MONO, chi2Stereo = refc::POSE_CHI2_STEREO;
     int nBad = 0;
     pb.est = se3_from_Tcw_f32(P->Tcw);
-    for (int it = 0; it < 4; it++) {
+    for (int it = 0; it < refc::POSE_ROUNDS; it++) {
         pb.est = se3_from_Tcw_f32(P->Tcw);
         LM lm;
         LMTrace tr;
-        lm.optimize(pb, 10, nullptr, &tr);
+        lm.optimize(pb, refc::POSE_ITS, nullptr, &tr);
         if (trace) for (size_t k = 0; k < tr.lambda.size() && trace->n < 64; k++) {
             trace->lambda[trace->n] = tr.lambda[k]; trace->chi2[trace->n] = tr.chi2[k]; trace->trials[trace->n] = tr.trials[k]; trace->n++;
         }
@@ -817,7 +819,7 @@ int orc_pose_optimization_planes(const orc_pose_problem* P, int n_planes, const 
             if (c > (e.stereo ? chi2Stereo : chi2Mono)) { outlier[i] = 1; e.level = 1; nBad++; }
             else { outlier[i] = 0; e.level = 0; }
             if (!e.stereo) e.robust = false;             // mono: kernel dropped after every round (:584-586)
-            else if (it == 2) e.robust = false;          // stereo: at it == 2 (:620-621)
+            else if (it == refc::POSE_UNROBUST_ROUND) e.robust = false;          // stereo: at it == 2 (:620-621)
         }
         for (int i = 0; i < n_planes; i++) {             // :626-658
             PlaneEdge& e = pb.planes[i];
@@ -825,7 +827,7 @@ int orc_pose_optimization_planes(const orc_pose_problem* P, int n_planes, const 
             const float c = (float)PoseProblem::chi2(e);
             if (c > planeChi) { plane_outlier[i] = 1; e.level = 1; nBad++; }
             else { e.level = 0; plane_outlier[i] = 0; }
-            if (it == 2) e.robust = false;
+            if (it == refc::POSE_UNROBUST_ROUND) e.robust = false;
         }
         if (nInitial < 10) break;
     }
@@ -857,7 +859,7 @@ int orc_local_ba(const orc_ba_problem* P, const volatile bool* stop, float* cam_
                  uint8_t* edge_outlier, double* cams_d, double* points_d, int32_t* iters, orc_trace* trace) {
     BAProblem pb;
     pb.fx = P->fx; pb.fy = P->fy; pb.cx = P->cx; pb.cy = P->cy; pb.bf = P->bf; pb.bf_f = P->bf;
-    pb.deltaMono = (float)std::sqrt(5.991); pb.deltaStereo = (float)std::sqrt(7.815);
+    pb.deltaMono = (float)std::sqrt(refc::LBA_HUBER2_MONO); pb.deltaStereo = (float)std::sqrt(refc::LBA_HUBER2_STEREO);
     pb.cams.resize(P->n_cams); pb.camFixed.assign(P->cam_fixed, P->cam_fixed + P->n_cams);
     for (int c = 0; c < P->n_cams; c++) pb.cams[c] = se3_from_Tcw_f32(P->cam_Tcw + 16 * c);
     pb.pts.resize((size_t)P->n_points * 3);
@@ -897,7 +899,7 @@ int orc_local_ba(const orc_ba_problem* P, const volatile bool* stop, float* cam_
     bool doMore = !(stop && *stop);
     if (doMore) {
         for (BAEdge& e : pb.edges) {
-            const double th = e.stereo ? 7.815 : 5.991;
+            const double th = e.stereo ? refc::LBA_CHI2_STEREO : refc::LBA_CHI2_MONO;
             if (BAProblem::chi2(e) > th || !pb.depthPositive(e)) e.level = 1;
             e.robust = false;
         }
@@ -909,7 +911,7 @@ int orc_local_ba(const orc_ba_problem* P, const volatile bool* stop, float* cam_
     }
     for (int k = 0; k < P->n_edges; k++) {
         const BAEdge& e = pb.edges[k];
-        const double th = e.stereo ? 7.815 : 5.991;
+        const double th = e.stereo ? refc::LBA_CHI2_STEREO : refc::LBA_CHI2_MONO;
         edge_outlier[k] = (BAProblem::chi2(e) > th || !pb.depthPositive(e)) ? 1 : 0;
     }
     write_out();
@@ -928,7 +930,7 @@ int orc_bundle_adjustment_planes(const orc_ba_problem* P, const orc_ba_planes* P
                                  float* cam_Tcw_out, float* points_out, float* planes_out, double* cams_d, double* points_d, int32_t* iters, orc_trace* trace) {
     BAProblem pb;
     pb.fx = P->fx; pb.fy = P->fy; pb.cx = P->cx; pb.cy = P->cy; pb.bf = P->bf; pb.bf_f = P->bf;
-    pb.deltaMono = (float)std::sqrt(5.99); pb.deltaStereo = (float)std::sqrt(7.815);
+    pb.deltaMono = (float)std::sqrt(refc::GBA_HUBER2_MONO); pb.deltaStereo = (float)std::sqrt(refc::GBA_HUBER2_STEREO);
     pb.cams.resize(P->n_cams); pb.camFixed.assign(P->cam_fixed, P->cam_fixed + P->n_cams);
     for (int c = 0; c < P->n_cams; c++) pb.cams[c] = se3_from_Tcw_f32(P->cam_Tcw + 16 * c);
     pb.pts.resize((size_t)P->n_points * 3);
@@ -943,10 +945,10 @@ int orc_bundle_adjustment_planes(const orc_ba_problem* P, const orc_ba_planes* P
         e.robust = robust != 0;
     }
     if (PL && PL->n_planes > 0) {
-        pb.deltaPlane = (float)std::sqrt(300.0);
+        pb.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
         pb.planes.resize((size_t)PL->n_planes * 4);
         for (int i = 0; i < PL->n_planes; i++) plane_from_f32(PL->plane_world + 4 * i, &pb.planes[4 * (size_t)i]);
-        const double angleInfo = 3282.8 / (1.0 * 1.0), disInfo = 100.0 * 100.0;
+        const double angleInfo = refc::PLANE_ANGLE_INFO / (1.0 * 1.0), disInfo = refc::PLANE_DIST_INFO_ROOT * refc::PLANE_DIST_INFO_ROOT;
         for (int k = 0; k < PL->n_pedges; k++) {
             BAEdge e;
             e.cam = PL->pedge_cam[k]; e.pt = P->n_points + PL->pedge_plane[k];

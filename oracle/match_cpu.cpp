@@ -16,6 +16,8 @@
 #include <cstring>
 #include <vector>
 
+#include "ref_constants.inc"   // GENERATED from the reference text (tools/gen_ref_constants.py): namespace refc
+
 namespace {
 
 struct FrameView {   // same layout as eao_frame_view (include/eao_fusion.h)
@@ -88,7 +90,7 @@ int orc_search_by_projection_points(const FrameView* F, int n_mp, const float* p
         match_kp[m] = -1;
         if (skip && skip[m]) continue;
         const int lvl = pred_level[m];
-        float r = view_cos[m] > 0.998 ? 2.5f : 4.0f;
+        float r = view_cos[m] > refc::VIEWCOS_NARROW ? refc::RADIUS_NARROW : refc::RADIUS_WIDE;
         if (bFactor) r *= th;
         const float rs = r * F->scale_factors[lvl];
         const std::vector<int> idx = grid.area(proj_x[m], proj_y[m], rs, lvl - 1, lvl);
@@ -104,7 +106,7 @@ int orc_search_by_projection_points(const FrameView* F, int n_mp, const float* p
             if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = F->kp_octave[i]; bestIdx = i; }
             else if (d < bestDist2) { bestLevel2 = F->kp_octave[i]; bestDist2 = d; }
         }
-        if (bestDist <= 100) {
+        if (bestDist <= refc::TH_HIGH) {
             if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
             match_kp[m] = bestIdx;
             occ[bestIdx] = 1;
@@ -123,7 +125,7 @@ int orc_search_by_projection_frames(const FrameView* C, const float* Tcw, const 
     if (C->occupied) std::memcpy(occ.data(), C->occupied, C->n);
     for (int i = 0; i < C->n; i++) cur_match[i] = -1;
     int nmatches = 0;
-    const int HISTO = 30;
+    const int HISTO = refc::HISTO_LENGTH;
     std::vector<int> rotHist[HISTO];
     const float factor = HISTO / 360.0f;
     // twc = -Rcw^T tcw ; tlc = Rlw twc + tlw   (float matrices, double accumulation)
@@ -172,7 +174,7 @@ int orc_search_by_projection_frames(const FrameView* C, const float* Tcw, const 
             const int d = dist256(mp_desc + 32 * (size_t)i, C->descriptors + 32 * (size_t)i2);
             if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
         }
-        if (bestDist <= 100) {
+        if (bestDist <= refc::TH_HIGH) {
             cur_match[bestIdx2] = i;
             occ[bestIdx2] = 1;
             nmatches++;

@@ -32,11 +32,13 @@
 #include <list>
 #include <vector>
 
+#include "ref_constants.inc"   // GENERATED from the reference text (tools/gen_ref_constants.py): namespace refc
+
 namespace {
 
-constexpr int kPatch = 31;
-constexpr int kHalfPatch = 15;
-constexpr int kEdge = 19;
+constexpr int kPatch = refc::PATCH_SIZE;
+constexpr int kHalfPatch = refc::HALF_PATCH_SIZE;
+constexpr int kEdge = refc::EDGE_THRESHOLD;
 
 const int8_t kPattern[1024] = {
 #include "orb_pattern.inc"
@@ -471,7 +473,7 @@ struct Extractor {
         cands.assign(nlevels, {}); kps.assign(nlevels, {}); blurred.assign(nlevels, Image());
         if (!img || w <= 0 || h <= 0) return 0;
         compute_pyramid(img, w, h, stride);
-        const float W = 30;
+        const float W = refc::FAST_CELL;
         for (int l = 0; l < nlevels; l++) {
             const Image& im = pyr[l];
             const int minBX = kEdge - 3, minBY = minBX;
@@ -590,7 +592,8 @@ int orc_orb_level_candidates(void* h, int level, float* xyr, int cap) {
 int orc_orb_level_keypoints(void* h, int level, void* kps28, int cap) {
     Extractor* e = (Extractor*)h;
     int n = (int)e->kps[level].size();
-    std::memcpy(kps28, e->kps[level].data(), (size_t)std::min(n, cap) * sizeof(KeyPoint));
+    const int m = std::min(n, cap);
+    if (m > 0) std::memcpy(kps28, e->kps[level].data(), (size_t)m * sizeof(KeyPoint));   // (a count query passes a null destination: UBSan, r03)
     return n;
 }
 
@@ -671,7 +674,7 @@ extern "C" int orc_stereo_matches(void* hl, void* hr, int nl, const void* kpsL28
         if (vCandidates.empty()) continue;
         const float minU = uL - maxD, maxU = uL - minD;
         if (maxU < 0) continue;
-        int bestDist = 100;   // ORBmatcher::TH_HIGH
+        int bestDist = refc::TH_HIGH;   // ORBmatcher::TH_HIGH
         size_t bestIdxR = 0;
         for (size_t iC = 0; iC < vCandidates.size(); iC++) {
             const size_t iR = vCandidates[iC];
@@ -685,7 +688,7 @@ extern "C" int orc_stereo_matches(void* hl, void* hr, int nl, const void* kpsL28
                 if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
             }
         }
-        if (bestDist < 100) {
+        if (bestDist < refc::TH_HIGH) {
             const float uR0 = kr[bestIdxR].x;
             const float scaleFactor = L->invScale[kpL.octave];
             const float scaleduL = std::round(kpL.x * scaleFactor);

@@ -21,6 +21,8 @@
 #include <cstring>
 #include <vector>
 
+#include "ref_constants.inc"   // GENERATED from the reference text (tools/gen_ref_constants.py): namespace refc
+
 namespace {
 
 struct FrameView {   // same layout as eao_frame_view (include/eao_fusion.h)
@@ -135,7 +137,7 @@ int rot_bin(float a1, float a2, float factor, int L) {
     if (bin == L) bin = 0;
     return bin;
 }
-const int TH_HIGH = 100, TH_LOW = 50, HISTO = 30;
+const int TH_HIGH = refc::TH_HIGH, TH_LOW = refc::TH_LOW, HISTO = refc::HISTO_LENGTH;
 
 }  // namespace
 
@@ -321,7 +323,7 @@ int orc_search_for_triangulation(const FrameView* K1, const FeatVec* f1, const F
                     const float den = la * la + lb * lb;
                     if (den == 0) continue;
                     const float dsqr = num * num / den;
-                    if (dsqr < 3.84 * K2->level_sigma2[K2->kp_octave[idx2]]) { bestIdx2 = idx2; bestDist = d; }
+                    if (dsqr < refc::EPIPOLAR_CHI2 * K2->level_sigma2[K2->kp_octave[idx2]]) { bestIdx2 = idx2; bestDist = d; }
                 }
                 if (bestIdx2 >= 0) {
                     match12[idx1] = bestIdx2;
@@ -427,10 +429,10 @@ int orc_fuse_search(const FrameView* K, int use_sim3, const float* pose, float f
                 if (K->u_right[k] >= 0) {
                     const float er = ur - K->u_right[k];
                     const float e2 = exx * exx + eyy * eyy + er * er;
-                    if (e2 * K->inv_level_sigma2[kl] > 7.8) continue;
+                    if (e2 * K->inv_level_sigma2[kl] > refc::FUSE_CHI2_STEREO) continue;
                 } else {
                     const float e2 = exx * exx + eyy * eyy;
-                    if (e2 * K->inv_level_sigma2[kl] > 5.99) continue;
+                    if (e2 * K->inv_level_sigma2[kl] > refc::FUSE_CHI2_MONO) continue;
                 }
             }
             const int d = dist256(P->desc + 32 * (size_t)i, K->descriptors + 32 * (size_t)k);

@@ -72,6 +72,10 @@ def test_local_ba_parity(gpu, oracle, kw):
 # even two summation orders of one -- can be held to 1e-4 there.
 CHAOTIC_BAND = {3031: 2.2e-4, 3034: 1.8e-4, 3039: 1.7e-3, 3040: 3.7e-2, 3042: 1.9e-4, 3045: 1.2e-3, 3048: 2.5e-4, 3050: 1e-4, 3051: 2.8e-4,
                 3053: 4.7e-3, 3055: 1.2e-4, 3059: 1e-4}
+# ... of which the oracle's own LM schedule (iterations of the two optimize() calls, outlier table) changes under that perturbation:
+SCHEDULE_UNSTABLE = {3050, 3055, 3059}
+# ... and on which the GPU result actually leaves the 1e-4 bar ("G" columns of the same log; every other banded seed is still held to 1e-4):
+LEAVES_THE_BAR = {3039, 3040, 3045, 3059}
 
 
 @pytest.mark.parametrize("seed", list(range(3030, 3060)))
@@ -92,6 +96,17 @@ def test_local_ba_rejected_trials(gpu, oracle, seed):
         r2 = gpu.Optimizer.LocalBundleAdjustment(p)
         assert np.array_equal(r["poses"].view(np.uint32), r2["poses"].view(np.uint32)) and np.array_equal(r["points"].view(np.uint32), r2["points"].view(np.uint32))
         assert list(r["iters"]) == list(r2["iters"]) and np.array_equal(r["edge_outlier"], r2["edge_outlier"])
+        #  the band loosens the UPDATE bound only.  The LM schedule and the outlier table are still compared with the
+        # oracle wherever the oracle's own schedule survives the one-ulp perturbation (all but SCHEDULE_UNSTABLE) ...
+        if seed not in SCHEDULE_UNSTABLE:
+            assert list(r["iters"]) == list(o["iters"]), "LM schedule differs from the oracle's"
+            assert np.array_equal(r["edge_outlier"], o["edge_outlier"]), "outlier table differs from the oracle's"
+        # ... and a banded seed on which the GPU is in fact within the strict bar stays under the strict bar (the band is the
+        # ceiling for the seeds in LEAVES_THE_BAR only): a regression on one of the others is a finding, not noise
+        if seed not in LEAVES_THE_BAR:
+            _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+            _check_updates(r["points"], o["points"], p["points"], "points")
+            return
         bound = 4 * max(CHAOTIC_BAND[seed], REL)
         for key in ("poses", "points"):
             upd = max(np.abs(o[key].astype(np.float64) - p[key].astype(np.float64)).max(), 1e-6)

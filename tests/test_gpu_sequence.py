@@ -1,7 +1,7 @@
 """BASELINE configs[4]: the batched 512-frame sequence (ORB extraction + consecutive-frame matching + 25 local-BA windows)
 on ONE GPU, run as the eight 64-frame shards an 8-GPU job would own -- through the same shard code (eao_fusion_amd/shard.py,
 sequence.py), with the halo frame handed from shard to shard -- and as one unsharded run.  Sharding must not change a bit;
-frames {0, 63, 64, 511}, the shard-boundary pair (63, 64) and windows {0, 24} are checked against the CPU oracle."""
+ALL 512 frames, ALL 511 pairs (the seven shard-boundary pairs included) and ALL 25 windows are checked against the CPU oracle."""
 import numpy as np
 import pytest
 import torch
@@ -61,36 +61,51 @@ def test_sequence_is_deterministic(sequence):
     assert np.array_equal(again["ba_cams"], shards[3]["ba_cams"]) and np.array_equal(again["ba_points"], shards[3]["ba_points"])
 
 
-def test_spot_parity_against_the_oracle(sequence, oracle):
+def _oracle_extract_all(oracle, frames, workers=8):
+    """The CPU oracle over every frame (21 ms each, one OrbOracle per worker thread; ctypes calls release the GIL)."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    tl = threading.local()
+
+    def one(f):
+        if not hasattr(tl, "orc"):
+            tl.orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+        return tl.orc.extract(frames[f])
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(one, range(len(frames))))
+
+
+def test_full_parity_against_the_oracle(sequence, oracle):
+    """configs[4] in full, not as spots -- ALL 512 frames (keypoints + descriptors bit for bit), ALL 511
+    consecutive pairs (best / second-best tables, the seven shard-boundary pairs through the halo among them) and ALL 25
+    local-BA windows (iteration counts, outlier tables, updates within 1e-4) against the CPU oracle."""
     frames, shards, whole, S = sequence
+    from concurrent.futures import ThreadPoolExecutor
     from eao_fusion_amd.orb import KP_DTYPE
-    orc = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
-    ref = {}
-    for f in (0, 63, 64, 510, 511):
-        ref[f] = orc.extract(frames[f])
-    for f in (0, 63, 64, 511):
+    ref = _oracle_extract_all(oracle, frames)
+    for f in range(N_FRAMES):
         r, i = divmod(f, 64)
         n = int(shards[r]["n"][i])
         okps, odesc = ref[f]
-        assert n == len(okps)
+        assert n == len(okps), "keypoint count of frame %d" % f
         assert np.array_equal(shards[r]["kps"][i, :n].copy().view(KP_DTYPE).reshape(-1), okps), "keypoints of frame %d" % f
         assert np.array_equal(shards[r]["desc"][i, :n], odesc), "descriptors of frame %d" % f
-    # pairs (63, 64) -- across the shard boundary, through the halo -- and (510, 511)
-    for f in (64, 511):
+    with ThreadPoolExecutor(8) as ex:
+        wants = list(ex.map(lambda f: oracle.hamming_best2(ref[f - 1][1], ref[f][1]), range(1, N_FRAMES)))
+    for f in range(1, N_FRAMES):
         r, i = divmod(f, 64)
-        want = oracle.hamming_best2(ref[f - 1][1], ref[f][1])
         na = len(ref[f - 1][1])
-        got = shards[r]["match"][i, :na]
-        assert np.array_equal(got, want), "pair (%d, %d)" % (f - 1, f)
+        assert np.array_equal(shards[r]["match"][i, :na], wants[f - 1]), "pair (%d, %d)%s" % (f - 1, f, " -- across a shard boundary" if i == 0 else "")
         assert (shards[r]["match"][i, na:] == -1).all()
-    # windows 0 and 24 within 1e-4 of the oracle's update (BASELINE north_star)
-    for w in (0, 24):
-        p = S.window_problem(w)
-        o = oracle.local_ba(p)
+    probs = [S.window_problem(w) for w in range(S.N_WINDOWS)]
+    with ThreadPoolExecutor(8) as ex:
+        orcs = list(ex.map(oracle.local_ba, probs))
+    for w in range(S.N_WINDOWS):
+        p, o = probs[w], orcs[w]
         r = shard.window_owner(w, WORLD)
         k = shard.window_shard(S.N_WINDOWS, r, WORLD).index(w)
         res = shards[r]["ba_results"][k]
-        assert list(res["iters"]) == list(o["iters"]) and np.array_equal(res["edge_outlier"], o["edge_outlier"])
+        assert list(res["iters"]) == list(o["iters"]) and np.array_equal(res["edge_outlier"], o["edge_outlier"]), "window %d" % w
         for name, new_g, new_c, old in (("poses", res["poses"], o["poses"], p["poses"]), ("points", res["points"], o["points"], p["points"])):
             upd = np.abs(new_c.astype(np.float64) - old.astype(np.float64)).max()
             err = np.abs(new_g.astype(np.float64) - new_c.astype(np.float64)).max()

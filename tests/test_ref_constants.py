@@ -1,0 +1,107 @@
+"""The thresholds, chi2 gates, Huber deltas and iteration schedules of the hot path are DATA taken from the reference's text
+(tools/gen_ref_constants.py -> tests/golden/ref_constants.json + two generated .inc files), the way the rBRIEF pattern table is
+(VERDICT r2 next #2d).  Checked here: the fixture equals the reference text where it is present; both generated headers equal the
+fixture; oracle AND product consume the named constants (no stray literal copies in the kernels or the oracle); the adapters
+and the Python mirror carry the same numbers."""
+import json
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_constants.json")))["constants"]
+BY_NAME = {e["name"]: e for e in FIX}
+INC = {"product": os.path.join(ROOT, "eao_fusion_amd", "csrc", "ref_constants.inc"), "oracle": os.path.join(ROOT, "oracle", "ref_constants.inc")}
+
+
+def _parse_inc(path):
+    out = {}
+    for m in re.finditer(r"constexpr (int|float|double) (\w+) = ([^;]+);", open(path).read()):
+        lit = m.group(3).rstrip("f") if m.group(1) == "float" else m.group(3)
+        out[m.group(2)] = (m.group(1), float(lit))
+    return out
+
+
+def test_fixture_equals_reference_text_when_present():
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("the reference tree only exists in the build container")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_ref_constants as G
+    now = G.parse()
+    assert [(e["name"], e["literal"], e["where"]) for e in now] == [(e["name"], e["literal"], e["where"]) for e in FIX]
+
+
+@pytest.mark.parametrize("who", ["product", "oracle"])
+def test_generated_headers_equal_the_fixture(who):
+    got = _parse_inc(INC[who])
+    assert set(got) == set(BY_NAME)
+    for name, (ctype, val) in got.items():
+        assert ctype == BY_NAME[name]["type"] and val == pytest.approx(BY_NAME[name]["value"], rel=0, abs=0), name
+    assert open(INC["product"]).read().split("\n", 1)[1] == open(INC["oracle"]).read().split("\n", 1)[1]
+
+
+def _code_lines(path):
+    """source lines with // comments and /* */ blocks removed"""
+    s = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    return [re.sub(r"//.*", "", ln) for ln in s.split("\n")]
+
+
+CONSUMERS = {
+    "product": ["eao_fusion_amd/csrc/lm.hip", "eao_fusion_amd/csrc/match.hip", "eao_fusion_amd/csrc/search.hip", "eao_fusion_amd/csrc/track.hip",
+                "eao_fusion_amd/csrc/orb.hip", "eao_fusion_amd/csrc/chain_internal.h", "eao_fusion_amd/csrc/frame.hip", "eao_fusion_amd/csrc/hamming.hip"],
+    "oracle": ["oracle/lm_cpu.cpp", "oracle/match_cpu.cpp", "oracle/search_cpu.cpp", "oracle/orb_cpu.cpp", "oracle/frame_cpu.cpp"],
+}
+# literals that can only be one of the reference's constants (a bare 10 or 100 can be anything; these cannot)
+DISTINCT = [r"5\.991", r"7\.815", r"\b5\.99\b", r"\b7\.8\b", r"3282\.8", r"0\.998", r"\b3\.84\b", r"sqrt\(300", r"> 300\.0"]
+
+
+@pytest.mark.parametrize("who", ["product", "oracle"])
+def test_no_literal_copies_beside_the_generated_header(who):
+    for rel in CONSUMERS[who]:
+        for i, ln in enumerate(_code_lines(os.path.join(ROOT, rel))):
+            for rx in DISTINCT:
+                assert not re.search(rx, ln), "%s:%d carries a literal copy of a reference constant: %s" % (rel, i + 1, ln.strip())
+
+
+@pytest.mark.parametrize("who,rel,names", [
+    ("product", "eao_fusion_amd/csrc/lm.hip", ["POSE_CHI2_MONO", "POSE_CHI2_STEREO", "POSE_ROUNDS", "POSE_ITS", "POSE_UNROBUST_ROUND", "POSE_HUBER2_MONO", "POSE_HUBER2_STEREO",
+                                               "LBA_CHI2_MONO", "LBA_CHI2_STEREO", "LBA_HUBER2_MONO", "LBA_HUBER2_STEREO", "GBA_HUBER2_MONO", "GBA_HUBER2_STEREO",
+                                               "PLANE_CHI2", "PLANE_ANGLE_INFO", "PLANE_DIST_INFO_ROOT", "LM_TAU", "LM_MAX_TRIALS"]),
+    ("oracle", "oracle/lm_cpu.cpp", ["POSE_CHI2_MONO", "POSE_CHI2_STEREO", "POSE_ROUNDS", "POSE_ITS", "POSE_UNROBUST_ROUND", "POSE_HUBER2_MONO", "POSE_HUBER2_STEREO",
+                                     "LBA_CHI2_MONO", "LBA_CHI2_STEREO", "LBA_HUBER2_MONO", "LBA_HUBER2_STEREO", "GBA_HUBER2_MONO", "GBA_HUBER2_STEREO",
+                                     "PLANE_CHI2", "PLANE_ANGLE_INFO", "PLANE_DIST_INFO_ROOT", "LM_TAU", "LM_MAX_TRIALS", "LM_NI"]),
+    ("product", "eao_fusion_amd/csrc/match.hip", ["TH_HIGH", "HISTO_LENGTH", "VIEWCOS_NARROW", "RADIUS_NARROW", "RADIUS_WIDE"]),
+    ("oracle", "oracle/match_cpu.cpp", ["TH_HIGH", "HISTO_LENGTH", "VIEWCOS_NARROW", "RADIUS_NARROW", "RADIUS_WIDE"]),
+    ("product", "eao_fusion_amd/csrc/search.hip", ["TH_HIGH", "TH_LOW", "HISTO_LENGTH", "EPIPOLAR_CHI2", "FUSE_CHI2_MONO", "FUSE_CHI2_STEREO"]),
+    ("oracle", "oracle/search_cpu.cpp", ["TH_HIGH", "TH_LOW", "HISTO_LENGTH", "EPIPOLAR_CHI2", "FUSE_CHI2_MONO", "FUSE_CHI2_STEREO"]),
+    ("product", "eao_fusion_amd/csrc/track.hip", ["TH_HIGH"]),
+    ("product", "eao_fusion_amd/csrc/orb.hip", ["TH_HIGH", "EDGE_THRESHOLD", "FAST_CELL", "PATCH_SIZE"]),
+    ("oracle", "oracle/orb_cpu.cpp", ["TH_HIGH", "EDGE_THRESHOLD", "FAST_CELL", "PATCH_SIZE", "HALF_PATCH_SIZE"]),
+])
+def test_consumers_name_the_constants(who, rel, names):
+    code = "\n".join(_code_lines(os.path.join(ROOT, rel)))
+    for n in names:
+        assert re.search(r"\brefc::%s\b" % n, code), "%s does not use refc::%s" % (rel, n)
+    if who == "oracle":
+        assert '#include "ref_constants.inc"' in open(os.path.join(ROOT, rel)).read()
+    else:
+        assert '#include "ref_constants.inc"' in open(os.path.join(ROOT, "eao_fusion_amd", "csrc", "common.h")).read()
+
+
+def test_adapters_and_mirror_carry_the_same_numbers():
+    hdr = open(os.path.join(ROOT, "include", "eaofusion", "ORBmatcher.h")).read()
+    for n in ("TH_LOW", "TH_HIGH", "HISTO_LENGTH"):
+        m = re.search(r"static constexpr int %s = (\d+);" % n, hdr)
+        assert m and int(m.group(1)) == BY_NAME[n]["value"], n
+    opt = open(os.path.join(ROOT, "include", "eaofusion", "OptimizerImpl.h")).read()
+    m = re.search(r"P\.its_first = (\d+); P\.its_second = (\d+);", opt)
+    assert m and (int(m.group(1)), int(m.group(2))) == (BY_NAME["LBA_ITS_FIRST"]["value"], BY_NAME["LBA_ITS_SECOND"]["value"])
+    import inspect
+    from eao_fusion_amd import matcher, optimizer
+    from oracle import oracle as O
+    assert (matcher.ORBmatcher.TH_LOW, matcher.ORBmatcher.TH_HIGH, matcher.ORBmatcher.HISTO_LENGTH) == tuple(BY_NAME[n]["value"] for n in ("TH_LOW", "TH_HIGH", "HISTO_LENGTH"))
+    want = (BY_NAME["LBA_ITS_FIRST"]["value"], BY_NAME["LBA_ITS_SECOND"]["value"])
+    assert inspect.signature(optimizer.Optimizer.LocalBundleAdjustment).parameters["its"].default == want
+    assert inspect.signature(O.local_ba).parameters["its"].default == want

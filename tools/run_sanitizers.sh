@@ -1,0 +1,51 @@
+#!/bin/bash
+# CPU-side sanitizer pass (VERDICT r2 next #2e): the oracle (oracle/*.cpp) rebuilt with AddressSanitizer + UndefinedBehaviorSanitizer
+# and driven by the whole non-GPU suite (golden vectors, oracle self-checks, numpy re-derivations, 240 quad-tree replays ...), and
+# the C++ adapters + every INTEGRATION.md snippet compiled with the same flags and -Werror=... off (compile + link only: running
+# them needs the GPU, and GPU / host-in-GPU-process sanitizer runs are not available on this pool).
+# Usage: bash tools/run_sanitizers.sh   -> profiles/r03_sanitizers_cpu.txt
+set -u
+cd "$(dirname "$0")/.."
+OUT=profiles/r03_sanitizers_cpu.txt
+TMP=$(mktemp -d)
+SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1"
+{
+echo "== $(date -u +%Y-%m-%dT%H:%MZ)  g++ $(g++ -dumpversion), flags: $SAN"
+echo "== 1. oracle/*.cpp with ASan + UBSan"
+g++ $SAN -ffp-contract=off -std=c++17 -fPIC -Wall -Wextra -pthread -shared -o $TMP/liboracle_san.so oracle/orb_cpu.cpp oracle/hamming_cpu.cpp oracle/lm_cpu.cpp \
+    oracle/match_cpu.cpp oracle/search_cpu.cpp oracle/frame_cpu.cpp 2>&1 || { echo "BUILD FAILED"; exit 1; }
+echo "built $TMP/liboracle_san.so"
+echo "== 2. python -m pytest tests -m 'not gpu' against the instrumented oracle (halt_on_error: any report aborts the run)"
+# (-O1 without -march=native: integer tables must still match the golden vectors bit for bit, fp64 LM results within 1e-9)
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+EAO_ORACLE_LIB=$TMP/liboracle_san.so python -m pytest tests -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -15
+echo "pytest exit code: ${PIPESTATUS[0]}"
+echo "== 3. adapters + INTEGRATION.md snippets compiled with the sanitizer flags (compile + link)"
+python - <<PY
+import os, subprocess, sys
+sys.path.insert(0, "tests")
+import test_integration_snippets as T
+tree = "$TMP/checkout"
+found = T.extract(tree)
+units = sorted(os.path.join(tree, p) for p in found if p.endswith(".cc"))
+inc = ["-I", os.path.join(tree, "include"), "-I", os.path.join(tree, "src"), "-I", "tests/cpp/integration/ref", "-I", "include"]
+link = ["-L", "eao_fusion_amd", "-leaofusion_hip", "-Wl,-rpath,/opt/rocm/lib", "-pthread"]
+san = "$SAN".split()
+jobs = [("integration_snippets_test", ["tests/cpp/integration_snippets_test.cpp"] + units, inc)]
+for t in ("adapter_test", "search_adapter_test", "frame_adapter_test"):
+    jobs.append((t, ["tests/cpp/%s.cpp" % t], ["-I", "include"]))
+bad = 0
+for name, srcs, incs in jobs:
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-function", "-DEAOFUSION_FORCE_CV_COMPAT"] + san + incs + srcs + ["-o", "$TMP/" + name] + link,
+                       capture_output=True, text=True)
+    warn = [l for l in r.stderr.split("\n") if "warning:" in l or "error:" in l]
+    print("%-28s rc %d, %d diagnostics" % (name, r.returncode, len(warn)))
+    for l in warn[:20]:
+        print("   ", l)
+    bad += r.returncode != 0
+sys.exit(bad)
+PY
+echo "compile exit code: $?"
+} 2>&1 | tee $OUT
+rm -rf $TMP
