@@ -155,6 +155,31 @@ __host__ __device__ inline SE3 se3_exp(const double u[6]) {  // (omega, upsilon)
         for (int i = 0; i < 9; i++) { const double id = (i % 4 == 0) ? 1.0 : 0.0; R[i] = id + Om[i] + Om2[i]; V[i] = R[i]; }
     } else {
         double st, ct;
+#ifdef __HIP_DEVICE_COMPILE__
+        // LM steps are small rotations: below half a radian the Taylor polynomials to x^15 / x^16 are exact to the last bit or two
+        // (remainder < 2^-70) and cost 17 fused multiply-adds; the library's sincos (argument reduction, two kernels, ~150 fp64
+        // instructions on ONE wave while the workgroup waits) only runs for larger angles.
+        if (theta < 0.5) {
+            const double z = theta * theta;
+            double ps = -1.0 / 1307674368000.0;                     // -1/15!
+            ps = fma(ps, z, 1.0 / 6227020800.0);                    // +1/13!
+            ps = fma(ps, z, -1.0 / 39916800.0);                     // -1/11!
+            ps = fma(ps, z, 1.0 / 362880.0);                        // +1/9!
+            ps = fma(ps, z, -1.0 / 5040.0);                         // -1/7!
+            ps = fma(ps, z, 1.0 / 120.0);                           // +1/5!
+            ps = fma(ps, z, -1.0 / 6.0);                            // -1/3!
+            st = fma(theta * z, ps, theta);
+            double pc = 1.0 / 20922789888000.0;                     // +1/16!
+            pc = fma(pc, z, -1.0 / 87178291200.0);                  // -1/14!
+            pc = fma(pc, z, 1.0 / 479001600.0);                     // +1/12!
+            pc = fma(pc, z, -1.0 / 3628800.0);                      // -1/10!
+            pc = fma(pc, z, 1.0 / 40320.0);                         // +1/8!
+            pc = fma(pc, z, -1.0 / 720.0);                          // -1/6!
+            pc = fma(pc, z, 1.0 / 24.0);                            // +1/4!
+            pc = fma(pc, z, -0.5);                                  // -1/2!
+            ct = fma(pc, z, 1.0);
+        } else
+#endif
         sincos(theta, &st, &ct);                // one range reduction for both
         const double it = recip(theta), it2 = it * it;
         const double a = st * it, b = (1 - ct) * it2;
@@ -433,6 +458,7 @@ template <typename T> struct GP {
 struct PoseDev {
     int n;
     GP<const int> nDev;     // when set: the number of edges lives on the device (chained tracking: eao_tracker); n is then the capacity
+    int devLo, devHi;       // ... and this launch serves device counts in (devLo, devHi] only (the chain enqueues one launch per register variant)
     GP<const double> Xw;    // n*3
     GP<const double> obs;   // n*3
     GP<const double> info;  // n
@@ -480,24 +506,99 @@ __device__ inline double pose_edge_chi2(const PoseDev& P, int i, bool stereo) {
     return s;
 }
 
-// Register-resident variant: thread t owns edges t, t + 512, ... (EPT of them) for the whole call -- point, observation,
-// information, flags and the last computed residual (g2o's _error) never leave its registers, so the ~50 passes over the
-// edges of one PoseOptimization are free of memory latency (the memory variant spent a third of its time waiting on L2).
-template <int EPT>
-__device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
-    __shared__ double red[(kPoseThreads / 4) * 28];
-    __shared__ double sums[8 * 28];
-    __shared__ SE3 s_est, s_backup;
-    __shared__ double s_x[6];
-    __shared__ double s_lambda, s_ni, s_rho, s_cur, s_tmp;
-    __shared__ int s_ok, s_flag, s_nbad, s_ntrace, s_iters, s_active;
+// ---- sum of 32 per-lane doubles over the 64 lanes of a wave WITHOUT reducing every value through its own tree: in step s the lane
+// pairs (L, L ^ 2^s) split the values they still hold -- the lane whose bit s is clear keeps the lower half, its partner the upper
+// half, each adds what the other one held of its half -- so the live values halve every step (16 + 8 + 4 + 2 + 1 exchanges instead
+// of 6 x 32), and after five steps lane L holds ONE value: the sum, over the lanes that agree with L in bit 5, of value
+// bitrev5(L & 31); the sixth step adds the two halves of the wave.  Steps 0 / 1 are DPP quad permutes, the others ds_bpermute.
+// A fixed tree: the result does not depend on anything but the 64 x 32 inputs.
+__device__ __forceinline__ double dpp_quad_f64(double v, bool xor2) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return xor2 ? __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true))
+                : __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));
+}
+// H += w Omega J_r^T J_r (upper triangle, row-major in acc[0 .. 21)) and b -= J_r^T (w Omega e_r) (acc[21 .. 27)) for ONE Jacobian row whose
+// column ZERO is a structural zero; every index is a compile-time constant.
+template <int ZERO>
+__device__ __forceinline__ void pose_accumulate_row(double (&acc)[32], const double (&J)[6], double wi, double we) {
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        if (a == ZERO) continue;
+        const double wJ = wi * J[a];
+        acc[21 + a] = fma(-J[a], we, acc[21 + a]);
+#pragma unroll
+        for (int b = a; b < 6; b++) {
+            if (b == ZERO) continue;
+            const int q = a * 6 - a * (a - 1) / 2 + (b - a);
+            acc[q] = fma(wJ, J[b], acc[q]);
+        }
+    }
+}
+template <int M, int DIST>      // one halving step over ds_bpermute: M pairs (j, j + M), partner lane ^ DIST (every index a compile-time constant)
+__device__ __forceinline__ void transpose_sum_step(double (&v)[32], bool up) {
+#pragma unroll
+    for (int j = 0; j < M; j++) { const double keep = up ? v[j + M] : v[j], send = up ? v[j] : v[j + M]; v[j] = keep + __shfl_xor(send, DIST); }
+}
+__device__ __forceinline__ double wave_transpose_sum32(double (&v)[32]) {
+    const int lane = threadIdx.x & 63;
+    {
+        const bool up = lane & 1;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const double keep = up ? v[j + 16] : v[j], send = up ? v[j] : v[j + 16]; v[j] = keep + dpp_quad_f64(send, false); }
+    }
+    {
+        const bool up = lane & 2;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const double keep = up ? v[j + 8] : v[j], send = up ? v[j] : v[j + 8]; v[j] = keep + dpp_quad_f64(send, true); }
+    }
+    transpose_sum_step<4, 4>(v, lane & 4);
+    transpose_sum_step<2, 8>(v, lane & 8);
+    transpose_sum_step<1, 16>(v, lane & 16);
+    return v[0] + __shfl_xor(v[0], 32);
+}
+// which of the 32 values a lane holds after wave_transpose_sum32
+__device__ __forceinline__ int transpose_sum_index(int lane) {
+    return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+}
+__device__ __forceinline__ double lane_bcast_f64(double v, int src) {      // v of lane `src` in every lane (src wave-uniform)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// Optimizer::PoseOptimization in ONE workgroup of up to eight waves (round 3: rewritten around what the cycle stamps of round 2 showed
+// -- two thirds of an LM trial were serial sections and barrier hand-overs, and the kernel sat at 256 VGPRs with 500 bytes of scratch).
+//   * thread t owns edges t, t + NT, ... (EPT of them) for the whole call -- point, observation, information, flags and the last computed
+//     residual (g2o's _error) never leave its registers;
+//   * ONE pass per LM trial: evaluating the trial pose computes the residuals, the robust chi2 AND the Jacobians / H / b there (eval),
+//     so an accepted trial IS the next iteration's linear system (g2o recomputes exactly these values at the top of the next
+//     iteration from the same state, optimization_algorithm_levenberg.cpp:64-72) -- a rejected trial keeps the current system in LDS;
+//   * the 28 sums of a pass go through wave_transpose_sum32 (about 220 VALU instructions per wave instead of three barrier-separated
+//     LDS passes) and ONE barrier; wave 0 adds the per-wave totals, takes the accept / reject decision of the trial just evaluated,
+//     solves the next damped system, applies exp(dx) and publishes the next trial pose -- one serial section and two barriers per trial
+//     (seven sections and five barriers before);
+//   * the plane edges (rare: RGB-D frames with associated PEAC planes) live in a separate instantiation, so the common kernel does not
+//     carry their registers.
+// Same LM control flow as the round-2 kernel; the order of the 28 sums
+// differs (a tree over lanes and waves instead of quads / columns / segments).  The single call, the batch and the tracker chain
+// share this body, so they agree bit for bit.
+template <int EPT, bool PLANES>
+__device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
+    constexpr int kMaxWaves = kPoseThreads / 64;
+    __shared__ double red[kMaxWaves * 32];     // per-wave totals of a pass
+    __shared__ double s_sys[28];               // the linear system at the CURRENT estimate: H (upper triangle, 21), b (6), robust chi2
+    __shared__ SE3 s_pose;                     // the pose the next pass evaluates / the round's final estimate
+    __shared__ SE3 s_est;                      // the current (last accepted) estimate -- wave 0's, kept out of everybody's registers
+    __shared__ int s_ctrl;                     // 1: evaluate s_pose; 0: the round's LM is over
+    __shared__ double s_nb[kMaxWaves];
     // plane edges: thread 13 p + v evaluates plane p at the pose perturbed along variant v (0: none, 1 + 2d / 2 + 2d: +-1e-9
     // along dimension d) -- g2o's central-difference Jacobian (core/base_binary_edge.hpp:131-205); thread p owns the edge
-    __shared__ double s_pvar[kPoseMaxPlanes * 13 * 3];
-    __shared__ double s_perr[kPoseMaxPlanes * 3];          // the edge's _error (last computed)
-    __shared__ unsigned char s_pflag[kPoseMaxPlanes], s_pout[kPoseMaxPlanes];
-    const int M = P.nPlanes;
-    const int t = threadIdx.x, n = P.nDev ? min(*P.nDev, P.n) : P.n;
+    __shared__ double s_pvar[PLANES ? kPoseMaxPlanes * 13 * 3 : 1];
+    __shared__ double s_perr[PLANES ? kPoseMaxPlanes * 3 : 1];          // the edge's _error (last computed)
+    __shared__ unsigned char s_pflag[PLANES ? kPoseMaxPlanes : 1], s_pout[PLANES ? kPoseMaxPlanes : 1];
+    const int M = PLANES ? P.nPlanes : 0;
+    const int NT = blockDim.x, nw = NT >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n = P.nDev ? min(*P.nDev, P.n) : P.n;
+    if (P.nDev && (n <= P.devLo || n > P.devHi)) return;      // another variant's frame (workgroup-uniform)
     const float chi2Mono = refc::POSE_CHI2_MONO, chi2Stereo = refc::POSE_CHI2_STEREO;
     const Cam c = P.cam;
     double eX[EPT][3], eO[EPT][3], eI[EPT], eE[EPT][3];
@@ -505,7 +606,7 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
     bool eLive[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
-        const int i = t + k * kPoseThreads;
+        const int i = t + k * NT;
         eLive[k] = i < n;
         const int j = eLive[k] ? i : 0;
 #pragma unroll
@@ -514,18 +615,18 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
         eF[k] = eLive[k] ? P.flags[j] : (unsigned char)2;     // a slot without an edge behaves like a level-1 edge
         eOut[k] = 0;
     }
-    auto edge_error = [&](const SE3& T, int k) {
+    // residual of edge slot k at pose T (EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose::computeError); pc = T * Xw
+    auto edge_error = [&](const SE3& T, int k, double (&pc)[3]) {
         const bool stereo = eF[k] & 1;
-        double p[3];
-        se3_map(T, eX[k], p);
+        se3_map(T, eX[k], pc);
         if (!stereo) {
-            eE[k][0] = eO[k][0] - (p[0] / p[2] * c.fx + c.cx);
-            eE[k][1] = eO[k][1] - (p[1] / p[2] * c.fy + c.cy);
+            eE[k][0] = eO[k][0] - (pc[0] / pc[2] * c.fx + c.cx);
+            eE[k][1] = eO[k][1] - (pc[1] / pc[2] * c.fy + c.cy);
             eE[k][2] = 0;
         } else {
-            const float invz = (float)(1.0 / p[2]);  // types_six_dof_expmap.cpp:335-342 ("const float invz")
-            const double r0 = p[0] * invz * c.fx + c.cx;
-            const double r1 = p[1] * invz * c.fy + c.cy;
+            const float invz = (float)(1.0 / pc[2]);  // types_six_dof_expmap.cpp:335-342 ("const float invz")
+            const double r0 = pc[0] * invz * c.fx + c.cx;
+            const double r1 = pc[1] * invz * c.fy + c.cy;
             const double r2 = r0 - c.bf * invz;
             eE[k][0] = eO[k][0] - r0; eE[k][1] = eO[k][1] - r1; eE[k][2] = eO[k][2] - r2;
         }
@@ -536,97 +637,97 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
         if (eF[k] & 1) s2 += eE[k][2] * (w * eE[k][2]);
         return s2;
     };
-    if (t == 0) { s_ntrace = 0; s_iters = 0; s_est = P.T0; }
-    if (t < M) { s_pflag[t] = 4; s_pout[t] = 0; s_perr[3 * t] = s_perr[3 * t + 1] = s_perr[3 * t + 2] = 0; }
     auto plane_chi2 = [&](int p) {
         const double* pl = P.planes + 10 * p;
         const double* e = s_perr + 3 * p;
         return e[0] * (pl[8] * e[0]) + e[1] * (pl[8] * e[1]) + e[2] * (pl[9] * e[2]);
     };
+    if (PLANES && t < M) { s_pflag[t] = 4; s_pout[t] = 0; s_perr[3 * t] = s_perr[3 * t + 1] = s_perr[3 * t + 2] = 0; }
     const bool stamp = P.dbg && t == 0;
     long long pa[6] = {0, 0, 0, 0, 0, 0}, pts = 0;
     auto lap = [&](int slot) { if (stamp) { const long long now = clock64(); pa[slot] += now - pts; pts = now; } };
+    // LM state: meaningful in wave 0 only (wave-uniform there)
+    int ntrace = 0, iters = 0, npass = 0;
+    const bool wstamp = P.dbg && lane == 0;      // per-wave stamps of the call's SECOND pass: dbg[8 + 4 wave + {0: after (A), 1: after eval, 2: after the tree, 3: after (B)}]
     __syncthreads();
     for (int round = 0; round < refc::POSE_ROUNDS; round++) {
-        if (t == 0) { s_est = P.T0; s_active = 0; }
-        __syncthreads();
-        {   // any level-0 edge?  (g2o: optimize() returns -1 when the index mapping is empty)
-            int any = 0;
+        int any = 0;                                  // any level-0 edge?  (g2o: optimize() returns -1 when the index mapping is empty)
 #pragma unroll
-            for (int k = 0; k < EPT; k++) any |= !(eF[k] & 2);
-            if (t < M) any |= !(s_pflag[t] & 2);
-            if (any) s_active = 1;
-        }
-        __syncthreads();
-        const int active = s_active;
+        for (int k = 0; k < EPT; k++) any |= !(eF[k] & 2);
+        if (PLANES && t < M) any |= !(s_pflag[t] & 2);
+        if (t == 0) { s_est = P.T0; s_pose = P.T0; s_ctrl = 1; }      // every round restarts from the frame's pose (src/Optimizer.cc:547)
+        const int active = __syncthreads_or(any);
         if (active) {
-            bool ok = true;
-            for (int it = 0; it < refc::POSE_ITS && ok; it++) {
-                // ---- computeActiveErrors + activeRobustChi2 + buildSystem at the current estimate
+            // wave 0's view of the LM (all wave-uniform): phase 0 = the pass just evaluated the current estimate (the first
+            // linearisation of the round), phase 1 = it evaluated a trial
+            int phase = 0, it = 0, qmax = 0, nbad = 0, okSolve = 1;
+            double lambda = 0, ni = 2, curChi = 0, iniChi = 0;
+            double scaleTrial = 0;      // computeScale() of the trial under evaluation: sum x (lambda x + b), taken when x was solved
+            for (;;) {
+                __syncthreads();                                                             // (A) s_pose / s_ctrl are published
+                if (!s_ctrl) break;
                 if (stamp) pts = clock64();
-                const SE3 est = s_est;
-                double acc[28];
+                npass++;
+                if (wstamp && npass == 2) P.dbg[8 + 4 * wv] = clock64();
+                const SE3 T = s_pose;
+                // ---- computeActiveErrors + activeRobustChi2 + buildSystem at T
+                double acc[32];
 #pragma unroll
-                for (int q = 0; q < 28; q++) acc[q] = 0;
+                for (int q = 0; q < 32; q++) acc[q] = 0;
+                bool work = false;
 #pragma unroll
                 for (int k = 0; k < EPT; k++) {
                     const unsigned char fl = eF[k];
                     if (fl & 2) continue;
+                    work = true;
                     const bool stereo = fl & 1;
-                    edge_error(est, k);
+                    double p[3];
+                    edge_error(T, k, p);
                     const double c2 = edge_chi2(k);
                     double w = 1.0, r0 = c2;
                     if (fl & 4) huber(c2, stereo ? c.deltaStereo : c.deltaMono, r0, w);
                     acc[27] += r0;
-                    double p[3];
-                    se3_map(est, eX[k], p);
+                    // Jacobian rows of the edge (types_six_dof_expmap.cpp:103-139, 188-234), written out as upstream writes them.  Columns
+                    // 4 of rows 0 / 2 and 3 of row 1 are structural zeros: their products are left out of the sums below (adding +0.0
+                    // changes no bit of a sum), which takes a quarter of the pass's arithmetic away; each remaining product is
+                    // accumulated with ONE fused multiply-add (the kernel's 28 accumulators cost two thirds of the pass otherwise).
                     const double X = p[0], Y = p[1], invz = 1.0 / p[2], invz2 = invz * invz;
-                    double J[3][6];
-                    J[0][0] = X * Y * invz2 * c.fx; J[0][1] = -(1 + (X * X * invz2)) * c.fx; J[0][2] = Y * invz * c.fx;
-                    J[0][3] = -invz * c.fx; J[0][4] = 0; J[0][5] = X * invz2 * c.fx;
-                    J[1][0] = (1 + Y * Y * invz2) * c.fy; J[1][1] = -X * Y * invz2 * c.fy; J[1][2] = -X * invz * c.fy;
-                    J[1][3] = 0; J[1][4] = -invz * c.fy; J[1][5] = Y * invz2 * c.fy;
+                    double J0[6], J1[6], J2[6];
+                    J0[0] = X * Y * invz2 * c.fx; J0[1] = -(1 + (X * X * invz2)) * c.fx; J0[2] = Y * invz * c.fx;
+                    J0[3] = -invz * c.fx; J0[4] = 0; J0[5] = X * invz2 * c.fx;
+                    J1[0] = (1 + Y * Y * invz2) * c.fy; J1[1] = -X * Y * invz2 * c.fy; J1[2] = -X * invz * c.fy;
+                    J1[3] = 0; J1[4] = -invz * c.fy; J1[5] = Y * invz2 * c.fy;
                     if (stereo) {
-                        J[2][0] = J[0][0] - c.bf * Y * invz2; J[2][1] = J[0][1] + c.bf * X * invz2; J[2][2] = J[0][2];
-                        J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - c.bf * invz2;
+                        J2[0] = J0[0] - c.bf * Y * invz2; J2[1] = J0[1] + c.bf * X * invz2; J2[2] = J0[2];
+                        J2[3] = J0[3]; J2[4] = 0; J2[5] = J0[5] - c.bf * invz2;
                     } else {   // monocular edge: a zero third row keeps every loop static (registers, no scratch)
 #pragma unroll
-                        for (int a = 0; a < 6; a++) J[2][a] = 0;
+                        for (int a = 0; a < 6; a++) J2[a] = 0;
                     }
                     const double info = eI[k], wi = w * info;
-                    const double e0 = info * eE[k][0], e1 = info * eE[k][1], e2 = info * eE[k][2];
-                    int q = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) {
-                        double sb = J[0][a] * e0 + J[1][a] * e1;
-                        sb += J[2][a] * e2;
-                        acc[21 + a] -= w * sb;
-#pragma unroll
-                        for (int b = a; b < 6; b++) {
-                            double hh = J[0][a] * wi * J[0][b] + J[1][a] * wi * J[1][b];
-                            hh += J[2][a] * wi * J[2][b];
-                            acc[q++] += hh;
-                        }
-                    }
+                    pose_accumulate_row<4>(acc, J0, wi, w * (info * eE[k][0]));
+                    pose_accumulate_row<3>(acc, J1, wi, w * (info * eE[k][1]));
+                    pose_accumulate_row<4>(acc, J2, wi, w * (info * eE[k][2]));
                 }
-                if (M) {
+                if (PLANES && M) {
                     if (t < 13 * M) {
                         const int p = t / 13, v = t - 13 * p;
                         if (!(s_pflag[p] & 2)) {
-                            SE3 Tp = est;
+                            SE3 Tp = T;
                             if (v) {
                                 double add[6] = {0, 0, 0, 0, 0, 0};
                                 const int d = (v - 1) >> 1;
                                 const double step = ((v - 1) & 1) ? -1e-9 : 1e-9;
 #pragma unroll
                                 for (int q = 0; q < 6; q++) if (q == d) add[q] = step;
-                                Tp = se3_mul(se3_exp(add), est);
+                                Tp = se3_mul(se3_exp(add), T);
                             }
                             plane_error(Tp, P.planes + 10 * p, P.planes + 10 * p + 4, &s_pvar[(p * 13 + v) * 3]);
                         }
                     }
                     __syncthreads();
                     if (t < M && !(s_pflag[t] & 2)) {
+                        work = true;
                         const double* pl = P.planes + 10 * t;
                         const double* pv = &s_pvar[t * 13 * 3];
                         s_perr[3 * t] = pv[0]; s_perr[3 * t + 1] = pv[1]; s_perr[3 * t + 2] = pv[2];
@@ -657,155 +758,194 @@ __device__ __forceinline__ void pose_lm_registers(const PoseDev& P) {
                     }
                 }
                 lap(0);
-                block_sum_lds<28, kPoseThreads>(acc, red, sums);
+                if (wstamp && npass == 2) P.dbg[8 + 4 * wv + 1] = clock64();
+                // ---- the wave's 28 totals (a wave without a level-0 edge contributes zeros without walking the tree)
+                if (__any(work)) {
+                    const double tot = wave_transpose_sum32(acc);
+                    if (lane < 32) red[wv * 32 + transpose_sum_index(lane)] = tot;
+                } else if (lane < 32) red[wv * 32 + lane] = 0;
+                if (wstamp && npass == 2) P.dbg[8 + 4 * wv + 2] = clock64();
+                __syncthreads();                                                             // (B) red[] is complete
+                if (wstamp && npass == 2) P.dbg[8 + 4 * wv + 3] = clock64();
                 lap(1);
-                // (thread 0 alone carries the LM state from here to the end of the iteration: no barrier until its first trial
-                //  pose is ready -- one barrier per iteration and two per trial fewer than the step-by-step version)
-                double iniChi = 0;
-                if (t == 0) {
-                    s_cur = sums[27];
-                    if (it == 0) {
-                        double md = 0;
-                        int q = 0;
-                        for (int a = 0; a < 6; a++) { md = fmax(md, fabs(sums[q])); q += 6 - a; }
-                        s_lambda = refc::LM_TAU * md;
-                        s_ni = 2;
-                        s_nbad = 0;
-                    }
-                    iniChi = s_cur;
-                }
-                int qmax = 0;
-                double rho = 0;
-                do {
-                    if (stamp) pts = clock64();
-                    if (t == 0) {
-                        s_backup = s_est;
-                        double A[36], b[6];
-                        int q = 0;
-                        for (int a = 0; a < 6; a++)
-                            for (int b2 = a; b2 < 6; b2++) { A[a * 6 + b2] = sums[q]; A[b2 * 6 + a] = sums[q]; q++; }
-                        for (int a = 0; a < 6; a++) { A[a * 7] += s_lambda; b[a] = sums[21 + a]; }
-                        double x[6] = {0, 0, 0, 0, 0, 0};
-                        s_ok = ldlt6_solve(A, b, x) ? 1 : 0;
-                        for (int a = 0; a < 6; a++) s_x[a] = x[a];
-                        s_est = se3_mul(se3_exp(x), s_est);
-                    }
-                    __syncthreads();
-                    lap(2);
-                    const SE3 tr = s_est;
-                    double chi[1] = {0};
-#pragma unroll
-                    for (int k = 0; k < EPT; k++) {
-                        const unsigned char fl = eF[k];
-                        if (fl & 2) continue;
-                        edge_error(tr, k);
-                        const double c2 = edge_chi2(k);
-                        double w, r0 = c2;
-                        if (fl & 4) huber(c2, (fl & 1) ? c.deltaStereo : c.deltaMono, r0, w);
-                        chi[0] += r0;
-                    }
-                    if (t < M && !(s_pflag[t] & 2)) {
-                        plane_error(tr, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
-                        const double c2 = plane_chi2(t);
-                        double w, r0 = c2;
-                        if (s_pflag[t] & 4) huber(c2, P.deltaPlane, r0, w);
-                        chi[0] += r0;
-                    }
-                    lap(3);
-                    {   // block_sum<1, kPoseThreads> with its second half (the sum over the waves, same order) left to thread 0 below
-                        const double x = wave_sum_f64_lane63(chi[0]);
-                        if ((t & 63) == 63) red[t >> 6] = x;
-                    }
-                    __syncthreads();
-                    lap(4);
-                    if (t == 0) {
-                        double tempChi = 0;
-                        for (int w = 0; w < kPoseThreads / 64; w++) tempChi += red[w];
-                        if (!s_ok) tempChi = DBL_MAX;
-                        double r = s_cur - tempChi;
-                        double scale = 0;
-                        for (int a = 0; a < 6; a++) scale += s_x[a] * (s_lambda * s_x[a] + sums[21 + a]);
-                        scale += 1e-3;
-                        r /= scale;
+                if (wv == 0) {
+                    // ---- totals: lane q < 28 adds value q of the waves in wave order
+                    double tot = 0;
+                    if (lane < 28)
+                        for (int w = 0; w < nw; w++) tot += red[w * 32 + lane];
+                    const double chiT = lane_bcast_f64(tot, 27);
+                    bool solveNext = false, reinit = false, done = false;
+                    if (phase == 0) {
+                        if (lane < 28) s_sys[lane] = tot;
+                        curChi = chiT;
+                        iniChi = curChi;
+                        qmax = 0;
+                        solveNext = true;
+                    } else {
+                        // ---- the trial just evaluated: accept / reject (optimization_algorithm_levenberg.cpp:118-149)
+                        const double tempChi = okSolve ? chiT : DBL_MAX;
+                        double r = curChi - tempChi;
+                        r /= scaleTrial + 1e-3;
+                        bool accepted = false;
                         if (r > 0 && isfinite(tempChi)) {
                             const double y = 2 * r - 1;
                             double alpha = 1. - y * y * y;
                             alpha = fmin(alpha, 2. / 3.);
-                            s_lambda *= fmax(1. / 3., alpha);
-                            s_ni = 2;
-                            s_cur = tempChi;
+                            lambda *= fmax(1. / 3., alpha);
+                            ni = 2;
+                            curChi = tempChi;
+                            if (lane < 7) reinterpret_cast<double*>(&s_est)[lane] = reinterpret_cast<const double*>(&s_pose)[lane];   // est = trial
+                            if (lane < 28) s_sys[lane] = tot;      // the accepted trial's system is the next iteration's
+                            accepted = true;
                         } else {
-                            s_lambda *= s_ni;
-                            s_ni *= 2;
-                            s_est = s_backup;
+                            lambda *= ni;
+                            ni *= 2;
                         }
-                        s_rho = r;
-                        const int q1 = qmax + 1;
-                        if (!(r < 0 && q1 < refc::LM_MAX_TRIALS)) {      // the last trial of this iteration: close the iteration here
-                            if (s_ntrace < 64) { P.trace[s_ntrace] = s_lambda; P.trace[64 + s_ntrace] = s_cur; P.trace[128 + s_ntrace] = q1; s_ntrace++; }
-                            s_iters++;
-                            int term = (q1 == refc::LM_MAX_TRIALS || r == 0) ? 1 : 0;
+                        qmax++;
+                        if (r < 0 && qmax < refc::LM_MAX_TRIALS) solveNext = true;         // another trial of this iteration
+                        else {                                                            // the iteration closes here
+                            if (lane == 0 && ntrace < 64) { P.trace[ntrace] = lambda; P.trace[64 + ntrace] = curChi; P.trace[128 + ntrace] = qmax; }
+                            if (ntrace < 64) ntrace++;
+                            iters++;
+                            bool term = qmax == refc::LM_MAX_TRIALS || r == 0;
                             if (!term) {
-                                if ((iniChi - s_cur) * 1e3 < iniChi) s_nbad++; else s_nbad = 0;
-                                if (s_nbad >= 3) term = 1;
+                                if ((iniChi - curChi) * 1e3 < iniChi) nbad++; else nbad = 0;
+                                if (nbad >= 3) term = true;
                             }
-                            s_flag = term;
+                            it++;
+                            if (term || it >= refc::POSE_ITS) done = true;
+                            else if (!accepted) reinit = true;      // (only a NaN rho ends an iteration on a rejected trial without terminating:
+                                                                    //  g2o then recomputes errors and system at the restored estimate)
+                            else { iniChi = curChi; qmax = 0; solveNext = true; }
                         }
                     }
-                    __syncthreads();
-                    lap(5);
-                    rho = s_rho;
-                    qmax++;
-                } while (rho < 0 && qmax < refc::LM_MAX_TRIALS);
-                ok = !s_flag;
+                    if (solveNext) {
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");               // s_sys was written by the lanes of this wave
+                        double A[36], b[6];
+                        int q = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+#pragma unroll
+                            for (int b2 = a; b2 < 6; b2++) { const double h = s_sys[q]; A[a * 6 + b2] = h; A[b2 * 6 + a] = h; q++; }
+#pragma unroll
+                        for (int a = 0; a < 6; a++) b[a] = s_sys[21 + a];
+                        if (phase == 0 && it == 0) {      // lambda_0 = tau * max |diagonal| (:166-180), at the first iteration of every optimize()
+                            double md = 0;
+#pragma unroll
+                            for (int a = 0; a < 6; a++) md = fmax(md, fabs(A[a * 7]));
+                            lambda = refc::LM_TAU * md;
+                            ni = 2;
+                            nbad = 0;
+                        }
+#pragma unroll
+                        for (int a = 0; a < 6; a++) A[a * 7] += lambda;
+                        double x[6] = {0, 0, 0, 0, 0, 0};
+                        okSolve = ldlt6_solve(A, b, x) ? 1 : 0;
+                        scaleTrial = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) scaleTrial += x[a] * (lambda * x[a] + b[a]);
+                        const SE3 trial = se3_mul(se3_exp(x), s_est);
+                        phase = 1;
+                        if (lane == 0) { s_pose = trial; s_ctrl = 1; }
+                    } else if (reinit) {
+                        phase = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        if (lane < 7) reinterpret_cast<double*>(&s_pose)[lane] = reinterpret_cast<const double*>(&s_est)[lane];
+                        if (lane == 0) s_ctrl = 1;
+                    } else if (done) {
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        if (lane < 7) reinterpret_cast<double*>(&s_pose)[lane] = reinterpret_cast<const double*>(&s_est)[lane];
+                        if (lane == 0) s_ctrl = 0;
+                    }
+                    lap(2);
+                }
             }
         }
-        // ---- inlier / outlier classification of every edge (src/Optimizer.cc:554-621)
-        const SE3 est = s_est;
-        double nb[1] = {0};
+        // ---- inlier / outlier classification of every edge (src/Optimizer.cc:554-621) at the round's estimate
+        const SE3 fin = s_pose;
+        double nb = 0;
 #pragma unroll
         for (int k = 0; k < EPT; k++) {
             if (!eLive[k]) continue;
             unsigned char fl = eF[k];
             const bool stereo = fl & 1;
-            if (eOut[k]) edge_error(est, k);
+            if (eOut[k]) { double p[3]; edge_error(fin, k, p); }
             const float c2 = (float)edge_chi2(k);
-            if (c2 > (stereo ? chi2Stereo : chi2Mono)) { eOut[k] = 1; fl |= 2; nb[0] += 1; }
+            if (c2 > (stereo ? chi2Stereo : chi2Mono)) { eOut[k] = 1; fl |= 2; nb += 1; }
             else { eOut[k] = 0; fl &= ~2; }
             if (!stereo) fl &= ~4;            // mono: kernel removed after every round
             else if (round == refc::POSE_UNROBUST_ROUND) fl &= ~4;    // stereo: at it == 2
             eF[k] = fl;
         }
-        if (t < M) {   // src/Optimizer.cc:626-658
+        if (PLANES && t < M) {   // src/Optimizer.cc:626-658
             unsigned char fl = s_pflag[t];
-            if (s_pout[t]) plane_error(est, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
+            if (s_pout[t]) plane_error(fin, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
             const float c2 = (float)plane_chi2(t);
-            if (c2 > refc::PLANE_CHI2) { s_pout[t] = 1; fl |= 2; nb[0] += 1; }
+            if (c2 > refc::PLANE_CHI2) { s_pout[t] = 1; fl |= 2; nb += 1; }
             else { s_pout[t] = 0; fl &= ~2; }
             if (round == refc::POSE_UNROBUST_ROUND) fl &= ~4;
             s_pflag[t] = fl;
         }
-        block_sum<1, kPoseThreads>(nb, red, &s_tmp);
-        if (t == 0) P.result[0] = (int)s_tmp;
+        {
+            const double xs = wave_sum_f64_lane63(nb);
+            if (lane == 63) s_nb[wv] = xs;
+        }
         __syncthreads();
+        if (t == 0) {
+            double tot = 0;
+            for (int w = 0; w < nw; w++) tot += s_nb[w];
+            P.result[0] = (int)tot;
+            *P.Tout = fin;
+        }
         if (n + M < 10) break;
     }
 #pragma unroll
     for (int k = 0; k < EPT; k++)
         if (eLive[k]) {
-            P.outlier[t + k * kPoseThreads] = eOut[k];
-            if (P.scatterOut) P.scatterOut[P.scatterIdx[t + k * kPoseThreads]] = eOut[k];
+            P.outlier[t + k * NT] = eOut[k];
+            if (P.scatterOut) P.scatterOut[P.scatterIdx[t + k * NT]] = eOut[k];
         }
-    if (t < M) P.planeOutlier[t] = s_pout[t];
-    if (t == 0) { *P.Tout = s_est; P.result[1] = s_iters; P.result[2] = s_ntrace; }
+    if (PLANES && t < M) P.planeOutlier[t] = s_pout[t];
+    if (t == 0) { P.result[1] = iters; P.result[2] = ntrace; P.result[3] = npass; }
     if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
 }
-template <int EPT>
-__global__ __launch_bounds__(kPoseThreads) void k_pose_optimization(PoseDev P) { pose_lm_registers<EPT>(P); }
+// MAXT = the launch's thread count bound: the four-wave classes are compiled for ONE wave per SIMD, i.e. with the SIMD's whole
+// register file (256 VGPRs + 256 AGPRs) per wave -- what does not fit the VGPRs is parked in AGPRs, not in scratch memory.
+template <int EPT, bool PLANES, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_pose_optimization(PoseDev P) { pose_lm_fused<EPT, PLANES>(P); }
 // One workgroup per frame: eao_pose_optimization_batch (the record is read through scalar loads, never copied to registers).
-template <int EPT>
-__global__ __launch_bounds__(kPoseThreads) void k_pose_optimization_batch(const PoseDev* __restrict__ W) {
-    pose_lm_registers<EPT>(W[blockIdx.x]);
+template <int EPT, bool PLANES, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_pose_optimization_batch(const PoseDev* __restrict__ W) {
+    pose_lm_fused<EPT, PLANES>(W[blockIdx.x]);
+}
+// Launch geometry of the register kernels.  Measured (EAO_DEBUG_STAMPS, 1000 correspondences): an fp64 instruction occupies its SIMD
+// for ~8 cycles and two waves on one SIMD do not overlap -- so one wave per SIMD (four per workgroup) already saturates the CU's fp64
+// pipes, and every further wave only adds its own reduction tree.  Hence FOUR waves with up to four edges per thread for frames of
+// up to 1024 correspondences (edge i lives in thread i mod 256, slot i / 256), eight waves x four edges beyond.
+constexpr int kPoseWaves4 = 256;
+inline int pose_threads(int n) { return n <= 4 * kPoseWaves4 ? std::min(kPoseWaves4, std::max(64, (n + 63) / 64 * 64)) : kPoseThreads; }
+inline int pose_ept(int n) { return n <= kPoseWaves4 ? 1 : (n <= 2 * kPoseWaves4 ? 2 : 4); }
+inline int pose_class(int n) { return n <= kPoseWaves4 ? 0 : n <= 2 * kPoseWaves4 ? 1 : n <= 4 * kPoseWaves4 ? 2 : 3; }
+inline void launch_pose_registers(const PoseDev& P, int n, bool planes, hipStream_t s) {
+    static const bool env8 = getenv("EAO_POSE_WAVES") && atoi(getenv("EAO_POSE_WAVES")) == 8;      // A/B switch: eight waves, fewer edges per thread
+    if (env8 && !planes && n <= 4 * kPoseThreads) {
+        const dim3 b8(kPoseThreads);
+        if (n <= kPoseThreads) hipLaunchKernelGGL((k_pose_optimization<1, false, kPoseThreads>), dim3(1), b8, 0, s, P);
+        else if (n <= 2 * kPoseThreads) hipLaunchKernelGGL((k_pose_optimization<2, false, kPoseThreads>), dim3(1), b8, 0, s, P);
+        else hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseThreads>), dim3(1), b8, 0, s, P);
+        return;
+    }
+    const dim3 b(pose_threads(n));
+    switch (pose_class(n) + (planes ? 4 : 0)) {
+        case 0: hipLaunchKernelGGL((k_pose_optimization<1, false, kPoseWaves4>), dim3(1), b, 0, s, P); break;
+        case 1: hipLaunchKernelGGL((k_pose_optimization<2, false, kPoseWaves4>), dim3(1), b, 0, s, P); break;
+        case 2: hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseWaves4>), dim3(1), b, 0, s, P); break;
+        case 3: hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseThreads>), dim3(1), b, 0, s, P); break;
+        case 4: hipLaunchKernelGGL((k_pose_optimization<1, true, kPoseWaves4>), dim3(1), b, 0, s, P); break;
+        case 5: hipLaunchKernelGGL((k_pose_optimization<2, true, kPoseWaves4>), dim3(1), b, 0, s, P); break;
+        case 6: hipLaunchKernelGGL((k_pose_optimization<4, true, kPoseWaves4>), dim3(1), b, 0, s, P); break;
+        default: hipLaunchKernelGGL((k_pose_optimization<4, true, kPoseThreads>), dim3(1), b, 0, s, P); break;
+    }
 }
 
 // Generic variant: edges stay in global memory (frames with more than 4 * kPoseThreads correspondences).
@@ -3073,7 +3213,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     double* dplanes = a.take<double>((size_t)kPoseMaxPlanes * 10);
     const size_t off1 = (a.off + 255) & ~(size_t)255;
     double* derr = a.take<double>((size_t)n * 3);
-    long long* ddbg = a.take<long long>(8);
+    long long* ddbg = a.take<long long>(64);
     if (c.pinCap < off1) {
         if (c.pin) (void)hipHostFree(c.pin);
         c.pin = nullptr; c.pinCap = 0;
@@ -3094,7 +3234,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     unsigned char* ooutl = opl + kPoseMaxPlanes;
     std::memset(opl, 0, kPoseMaxPlanes);
     std::memset(ooutl, 0, n);     // the memory variant of the kernel reads the flags before it first writes them
-    ores[0] = ores[1] = ores[2] = 0;
+    ores[0] = ores[1] = ores[2] = ores[3] = 0;
     auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
     {
         double* hX = (double*)hostp(dXw); double* hO = (double*)hostp(dobs); double* hI = (double*)hostp(dinfo);
@@ -3131,9 +3271,8 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     P.Tout = oT; P.result = ores; P.trace = otrace;
     P.nPlanes = M; P.planes = dplanes; P.planeOutlier = opl; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
     P.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
-    if (n <= 2 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<2>, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
-    else if (n <= 4 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<4>, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
-    else hipLaunchKernelGGL(k_pose_optimization_mem, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
+    if (n > 4 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization_mem, dim3(1), dim3(kPoseThreads), 0, c.stream, P);
+    else launch_pose_registers(P, n, M > 0, c.stream);
     EAO_HIP(hipEventRecord(c.ev1, c.stream));
     EAO_HIP(hipStreamSynchronize(c.stream));
     EAO_HIP(hipGetLastError());
@@ -3143,9 +3282,13 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     std::memcpy(r->outlier, ooutl, n);
     if (M) std::memcpy(r->plane_outlier, opl, M);
     if (P.dbg) {
-        long long st[8];
+        long long st[64];
         EAO_HIP(hipMemcpy(st, P.dbg, sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[eao pose stamps] linearize %lld sum28 %lld solve %lld errors %lld sum1 %lld decide %lld shader-cycles\n", st[0], st[1], st[2], st[3], st[4], st[5]);
+        fprintf(stderr, "[eao pose stamps] eval %lld tree + barrier %lld decide + solve + exp %lld clock64 ticks over %d LM iterations, %d passes\n", st[0], st[1], st[2], res[1], res[3]);
+        const int nwv = (n <= 4 * kPoseWaves4 && !(getenv("EAO_POSE_WAVES") && atoi(getenv("EAO_POSE_WAVES")) == 8) ? pose_threads(n) : kPoseThreads) / 64;
+        for (int w = 0; w < nwv; w++)
+            fprintf(stderr, "[eao pose stamps]   pass 2, wave %d: starts %+lld, eval %lld, tree %lld, waits at (B) %lld\n", w, st[8 + 4 * w] - st[8], st[9 + 4 * w] - st[8 + 4 * w],
+                    st[10 + 4 * w] - st[9 + 4 * w], st[11 + 4 * w] - st[10 + 4 * w]);
     }
     se3_to_Tcw_f32(Tout, r->Tcw);
     r->n_inliers = n + M - res[0];
@@ -3181,23 +3324,24 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
     LMContext& c = g_ctx;
     eao_status st = ctx_init(c);
     if (st) return st;
-    std::vector<int> grp[2], single;
+    std::vector<int> grp[8], single;      // register kernels by geometry class (pose_class) x (plane edges or not)
     for (int b = 0; b < nb; b++) {
         const int n = ps[b].n;
         for (int i = 0; i < n; i++) rs[b].outlier[i] = 0;
         rs[b].lm_iterations = 0;
         if (n < 3) { std::memcpy(rs[b].Tcw, ps[b].Tcw, 16 * sizeof(float)); rs[b].n_inliers = 0; }
         else if (n > 4 * kPoseThreads) single.push_back(b);
-        else grp[n > 2 * kPoseThreads].push_back(b);
+        else grp[pose_class(n) + (ps[b].n_planes > 0 ? 4 : 0)].push_back(b);
     }
-    const int nk = (int)(grp[0].size() + grp[1].size());
+    int nk = 0;
+    for (int g = 0; g < 8; g++) nk += (int)grp[g].size();
     if (nk) {
         // arena: [records | per frame: Xw, obs, info, flags, planes] uploaded, then the per-frame residual scratch
         struct Slot { int b; double *Xw, *obs, *info, *planes, *err; unsigned char* flags; size_t out; };
         std::vector<Slot> slots;
         size_t need = (size_t)nk * sizeof(PoseDev) + 512, outBytes = 0;
         const size_t outFixed = ((sizeof(SE3) + 15) & ~(size_t)15) + 192 * 8 + 16 + kPoseMaxPlanes;
-        for (int g = 0; g < 2; g++)
+        for (int g = 0; g < 8; g++)
             for (int b : grp[g]) {
                 need += (size_t)ps[b].n * (3 + 3 + 1 + 3) * 8 + (size_t)ps[b].n + (size_t)kPoseMaxPlanes * 80 + 6 * 256;
                 outBytes += (outFixed + (size_t)ps[b].n + 63) & ~(size_t)63;
@@ -3206,7 +3350,7 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
         Arena a{c.bytes.p, c.bytes.n};
         const size_t off0 = a.off;
         PoseDev* dW = a.take<PoseDev>(nk);
-        for (int g = 0; g < 2; g++)
+        for (int g = 0; g < 8; g++)
             for (int b : grp[g]) {
                 Slot s{};
                 const int n = ps[b].n;
@@ -3245,7 +3389,7 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
             int* ores = (int*)(otrace + 192);
             unsigned char* opl = (unsigned char*)(ores + 4);
             std::memset(opl, 0, kPoseMaxPlanes + (size_t)n);
-            ores[0] = ores[1] = ores[2] = 0;
+            ores[0] = ores[1] = ores[2] = ores[3] = 0;
             double* hX = (double*)hostp(s.Xw); double* hO = (double*)hostp(s.obs); double* hI = (double*)hostp(s.info);
             unsigned char* hF = (unsigned char*)hostp(s.flags);
             widen(hX, p->Xw, (size_t)n * 3); widen(hO, p->obs, (size_t)n * 3); widen(hI, p->inv_sigma2, n);
@@ -3276,10 +3420,25 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
         const PoseDev* kW = dW;
         if (zeroCopy) kW = hW;          // (the records too)
         else EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
-        if (!grp[0].empty())
-            hipLaunchKernelGGL(k_pose_optimization_batch<2>, dim3((unsigned)grp[0].size()), dim3(kPoseThreads), 0, c.stream, kW);
-        if (!grp[1].empty())
-            hipLaunchKernelGGL(k_pose_optimization_batch<4>, dim3((unsigned)grp[1].size()), dim3(kPoseThreads), 0, c.stream, kW + grp[0].size());
+        {   // one launch per (geometry class, planes) group; the records lie group after group
+            size_t first = 0;
+            for (int g = 0; g < 8; g++) {
+                if (grp[g].empty()) continue;
+                const dim3 gr((unsigned)grp[g].size()), bl(g % 4 == 3 ? kPoseThreads : kPoseWaves4);
+                const PoseDev* w = kW + first;
+                switch (g) {
+                    case 0: hipLaunchKernelGGL((k_pose_optimization_batch<1, false, kPoseWaves4>), gr, bl, 0, c.stream, w); break;
+                    case 1: hipLaunchKernelGGL((k_pose_optimization_batch<2, false, kPoseWaves4>), gr, bl, 0, c.stream, w); break;
+                    case 2: hipLaunchKernelGGL((k_pose_optimization_batch<4, false, kPoseWaves4>), gr, bl, 0, c.stream, w); break;
+                    case 3: hipLaunchKernelGGL((k_pose_optimization_batch<4, false, kPoseThreads>), gr, bl, 0, c.stream, w); break;
+                    case 4: hipLaunchKernelGGL((k_pose_optimization_batch<1, true, kPoseWaves4>), gr, bl, 0, c.stream, w); break;
+                    case 5: hipLaunchKernelGGL((k_pose_optimization_batch<2, true, kPoseWaves4>), gr, bl, 0, c.stream, w); break;
+                    case 6: hipLaunchKernelGGL((k_pose_optimization_batch<4, true, kPoseWaves4>), gr, bl, 0, c.stream, w); break;
+                    default: hipLaunchKernelGGL((k_pose_optimization_batch<4, true, kPoseThreads>), gr, bl, 0, c.stream, w); break;
+                }
+                first += grp[g].size();
+            }
+        }
         EAO_HIP(hipEventRecord(c.ev1, c.stream));
         EAO_HIP(hipStreamSynchronize(c.stream));
         EAO_HIP(hipGetLastError());
@@ -4125,9 +4284,15 @@ eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
     P.scatterIdx = a.scatterIdx; P.scatterOut = a.scatterOut;
     P.nPlanes = 0; P.planes = nullptr; P.planeOutlier = nullptr; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
     P.dbg = nullptr;
-    if (a.cap <= 2 * kPoseThreads) hipLaunchKernelGGL(k_pose_optimization<2>, dim3(1), dim3(kPoseThreads), 0, s, P);
-    else hipLaunchKernelGGL(k_pose_optimization<4>, dim3(1), dim3(kPoseThreads), 0, s, P);
-    EAO_HIP(hipGetLastError());
+    // The edge count lives on the device: one launch per geometry class the capacity admits (four waves up to 1024 edges, eight
+    // beyond); each returns at its first instruction unless the frame's count falls in its range (a ~3 us launch, against running every
+    // frame as eight waves).  Waves without an edge leave a pass at once.
+    P.devLo = -1; P.devHi = std::min(a.cap, 4 * kPoseWaves4);
+    hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseWaves4>), dim3(1), dim3(kPoseWaves4), 0, s, P);
+    if (a.cap > 4 * kPoseWaves4) {
+        P.devLo = 4 * kPoseWaves4; P.devHi = a.cap;
+        hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseThreads>), dim3(1), dim3(kPoseThreads), 0, s, P);
+    }
     return EAO_OK;
 }
 }  // namespace lm

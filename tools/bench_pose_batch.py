@@ -4,7 +4,7 @@ records per call), and single calls."""
 import time
 import numpy as np
 import torch  # noqa: F401
-import eao_fusion_amd as E
+import sys; sys.path.insert(0, "."); import eao_fusion_amd as E
 from eao_fusion_amd import _lib, synth
 
 L = _lib.load()
