@@ -564,30 +564,80 @@ __device__ __forceinline__ double lane_bcast_f64(double v, int src) {      // v 
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-// Optimizer::PoseOptimization in ONE workgroup of up to eight waves (round 3: rewritten around what the cycle stamps of round 2 showed
-// -- two thirds of an LM trial were serial sections and barrier hand-overs, and the kernel sat at 256 VGPRs with 500 bytes of scratch).
+// exp(dx) * T for the LM's pose update (SE3Quat::exp, types/se3quat.h:223-259, then operator*), specialised for ONE wave computing it
+// while a workgroup waits: the rotation as the quaternion (sin(theta/2) / theta * omega, cos(theta/2)) -- what the rotation matrix
+// upstream builds and converts back (Eigen's Quaterniond(R)) represents, without the detour (R, trace branch, two square roots); the
+// V matrix as upstream writes it (I + b Omega + c Omega^2).  Differs from the matrix route by rounding (~1e-16); the composed quaternion
+// is normalised as upstream's operator* does.
+__device__ __forceinline__ SE3 se3_exp_mul(const double u[6], const SE3& T) {
+    const double w0 = u[0], w1 = u[1], w2 = u[2];
+    const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
+    const double theta = sqrt(th2);
+    double b, cc, sh_over, ch;      // (1 - cos) / theta^2, (theta - sin) / theta^3, sin(theta / 2) / theta, cos(theta / 2)
+    if (theta < 0.00001) {          // upstream's small-angle branch: R = I + Omega + Omega^2, V = R
+        b = 1.0; cc = 1.0;
+        // quaternion of I + Omega + Omega^2 to first order: (omega / 2, 1), normalised below like every result
+        sh_over = 0.5; ch = 1.0;
+    } else {
+        const double h = 0.5 * theta;
+        double sh, st, ct;
+        if (theta < 0.5) {          // Taylor polynomials on the half angle (remainder < 2^-80): 15 fused multiply-adds
+            const double z = h * h;
+            double ps = -1.0 / 1307674368000.0;
+            ps = fma(ps, z, 1.0 / 6227020800.0); ps = fma(ps, z, -1.0 / 39916800.0); ps = fma(ps, z, 1.0 / 362880.0);
+            ps = fma(ps, z, -1.0 / 5040.0); ps = fma(ps, z, 1.0 / 120.0); ps = fma(ps, z, -1.0 / 6.0);
+            sh = fma(h * z, ps, h);
+            double pc = 1.0 / 20922789888000.0;
+            pc = fma(pc, z, -1.0 / 87178291200.0); pc = fma(pc, z, 1.0 / 479001600.0); pc = fma(pc, z, -1.0 / 3628800.0);
+            pc = fma(pc, z, 1.0 / 40320.0); pc = fma(pc, z, -1.0 / 720.0); pc = fma(pc, z, 1.0 / 24.0); pc = fma(pc, z, -0.5);
+            ch = fma(pc, z, 1.0);
+        } else sincos(h, &sh, &ch);
+        st = 2.0 * sh * ch;                 // sin(theta), 1 - cos(theta) = 2 sin^2(theta / 2)
+        ct = 2.0 * sh * sh;
+        const double it = recip(theta), it2 = it * it;
+        b = ct * it2;
+        cc = (theta - st) * (it2 * it);
+        sh_over = sh * it;
+    }
+    SE3 e;
+    e.r.x = sh_over * w0; e.r.y = sh_over * w1; e.r.z = sh_over * w2; e.r.w = ch;
+    // V u = u + b (omega x u) + c omega x (omega x u)
+    const double ux = u[3], uy = u[4], uz = u[5];
+    const double c1x = w1 * uz - w2 * uy, c1y = w2 * ux - w0 * uz, c1z = w0 * uy - w1 * ux;
+    const double c2x = w1 * c1z - w2 * c1y, c2y = w2 * c1x - w0 * c1z, c2z = w0 * c1y - w1 * c1x;
+    e.t[0] = ux + b * c1x + cc * c2x; e.t[1] = uy + b * c1y + cc * c2y; e.t[2] = uz + b * c1z + cc * c2z;
+    return se3_mul(e, T);       // (normalises the product quaternion, sign w >= 0)
+}
+
+// Optimizer::PoseOptimization in ONE workgroup (round 3: rewritten around what the cycle stamps showed -- in round 2 two thirds of an LM
+// trial were serial sections and barrier hand-overs, and the kernel sat at 256 VGPRs with 500 bytes of scratch).
 //   * thread t owns edges t, t + NT, ... (EPT of them) for the whole call -- point, observation, information, flags and the last computed
 //     residual (g2o's _error) never leave its registers;
-//   * ONE pass per LM trial: evaluating the trial pose computes the residuals, the robust chi2 AND the Jacobians / H / b there (eval),
-//     so an accepted trial IS the next iteration's linear system (g2o recomputes exactly these values at the top of the next
-//     iteration from the same state, optimization_algorithm_levenberg.cpp:64-72) -- a rejected trial keeps the current system in LDS;
-//   * the 28 sums of a pass go through wave_transpose_sum32 (about 220 VALU instructions per wave instead of three barrier-separated
-//     LDS passes) and ONE barrier; wave 0 adds the per-wave totals, takes the accept / reject decision of the trial just evaluated,
-//     solves the next damped system, applies exp(dx) and publishes the next trial pose -- one serial section and two barriers per trial
-//     (seven sections and five barriers before);
-//   * the plane edges (rare: RGB-D frames with associated PEAC planes) live in a separate instantiation, so the common kernel does not
-//     carry their registers.
-// Same LM control flow as the round-2 kernel; the order of the 28 sums
-// differs (a tree over lanes and waves instead of quads / columns / segments).  The single call, the batch and the tracker chain
-// share this body, so they agree bit for bit.
+//   * an iteration's FIRST trial is evaluated by a HEAVY pass: residuals, robust chi2 AND the Jacobians / H / b at the trial pose, so an
+//     accepted first trial (the common case) IS the next iteration's linear system -- g2o recomputes exactly these values at the top of
+//     the next iteration from the same state (optimization_algorithm_levenberg.cpp:64-72);
+//   * after a rejected trial the next lambdas are known in advance (lambda *= ni, ni *= 2 while rho < 0, :143-145): up to FOUR retrials
+//     are solved side by side, one per wave, and evaluated together by one LIGHT pass (residuals + chi2 only, four poses per edge);
+//     the decisions are then taken in upstream's order and stop at the first accepted one (the run of rejections that closes every
+//     converged round costs three passes instead of nine).  An accepted retrial is followed by a heavy pass at its pose;
+//   * the 28 sums of a heavy pass go through wave_transpose_sum32 and ONE barrier; the control flow that follows (totals, accept / reject,
+//     LM bookkeeping) is replicated in every wave from the same LDS totals, so there is no broadcast of decisions -- two barriers per pass;
+//   * the plane edges (rare: RGB-D frames with associated PEAC planes) live in a separate instantiation.
+// Same LM control flow as the round-2 kernel; the order of the 28 sums differs (a tree over lanes and waves instead of quads / columns /
+// segments), products are accumulated with fused multiply-adds, and exp(dx) goes through the quaternion directly.  The single call, the
+// batch and the tracker chain share this body and the same edge -> (thread, slot) map, so they agree bit for bit.
+constexpr int kPoseCand = 4;      // retrials evaluated per light pass
 template <int EPT, bool PLANES>
 __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     constexpr int kMaxWaves = kPoseThreads / 64;
-    __shared__ double red[kMaxWaves * 32];     // per-wave totals of a pass
-    __shared__ double s_sys[28];               // the linear system at the CURRENT estimate: H (upper triangle, 21), b (6), robust chi2
-    __shared__ SE3 s_pose;                     // the pose the next pass evaluates / the round's final estimate
-    __shared__ SE3 s_est;                      // the current (last accepted) estimate -- wave 0's, kept out of everybody's registers
-    __shared__ int s_ctrl;                     // 1: evaluate s_pose; 0: the round's LM is over
+    __shared__ double red[kMaxWaves * 32];              // per-wave totals of a pass
+    __shared__ double s_sys[kMaxWaves][28];             // per wave: the linear system at the CURRENT estimate -- H (upper triangle, 21), b (6), chi2
+    __shared__ SE3 s_est[kMaxWaves];                    // per wave: the current (last accepted) estimate
+    // The candidate records are DOUBLE-BUFFERED by pass parity: a wave that has taken its decisions publishes the next pass's candidates
+    // while slower waves still read this pass's (nothing but barrier (A) separates the two)
+    __shared__ SE3 s_cpose[2][kPoseCand];               // the poses a pass evaluates
+    __shared__ double s_cscale[2][kPoseCand];           // computeScale() of each: sum x (lambda x + b)
+    __shared__ int s_cok[2][kPoseCand];                 // did its LDL^T succeed
     __shared__ double s_nb[kMaxWaves];
     // plane edges: thread 13 p + v evaluates plane p at the pose perturbed along variant v (0: none, 1 + 2d / 2 + 2d: +-1e-9
     // along dimension d) -- g2o's central-difference Jacobian (core/base_binary_edge.hpp:131-205); thread p owns the edge
@@ -615,19 +665,31 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
         eF[k] = eLive[k] ? P.flags[j] : (unsigned char)2;     // a slot without an edge behaves like a level-1 edge
         eOut[k] = 0;
     }
-    // residual of edge slot k at pose T (EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose::computeError); pc = T * Xw
-    auto edge_error = [&](const SE3& T, int k, double (&pc)[3]) {
+    // A pose as the kernel maps points with it: the rotation MATRIX of the unit quaternion and the translation, built once per pose and
+    // thread (20 instructions) instead of rotating every point through the quaternion product (30 per point; the two agree to rounding).
+    struct PoseRt { double R[9], t[3]; };
+    auto pose_rt = [&](const SE3& T) { PoseRt m; quat_to_matrix(T.r, m.R); m.t[0] = T.t[0]; m.t[1] = T.t[1]; m.t[2] = T.t[2]; return m; };
+    // residual of edge slot k at a pose (EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose::computeError); pc = T * Xw, invz = 1 / z.
+    // The quotients x / z, y / z (monocular edge) and 1 / z (stereo edge, Jacobians) share ONE refined reciprocal (DivBy: the same
+    // correctly rounded quotients as three IEEE divisions for every depth of magnitude 2^-400 .. 2^400, the plain divisions otherwise).
+    auto edge_error = [&](const PoseRt& m, int k, double (&pc)[3], double& invz) {
         const bool stereo = eF[k] & 1;
-        se3_map(T, eX[k], pc);
+        const double x = eX[k][0], y = eX[k][1], z = eX[k][2];
+        pc[0] = fma(m.R[2], z, fma(m.R[1], y, fma(m.R[0], x, m.t[0])));
+        pc[1] = fma(m.R[5], z, fma(m.R[4], y, fma(m.R[3], x, m.t[1])));
+        pc[2] = fma(m.R[8], z, fma(m.R[7], y, fma(m.R[6], x, m.t[2])));
+        double qx, qy;
+        if (plain_den(pc[2])) { const DivBy<true> Z(pc[2]); invz = Z(1.0); qx = Z(pc[0]); qy = Z(pc[1]); }
+        else { invz = 1.0 / pc[2]; qx = pc[0] / pc[2]; qy = pc[1] / pc[2]; }
         if (!stereo) {
-            eE[k][0] = eO[k][0] - (pc[0] / pc[2] * c.fx + c.cx);
-            eE[k][1] = eO[k][1] - (pc[1] / pc[2] * c.fy + c.cy);
+            eE[k][0] = eO[k][0] - (qx * c.fx + c.cx);
+            eE[k][1] = eO[k][1] - (qy * c.fy + c.cy);
             eE[k][2] = 0;
         } else {
-            const float invz = (float)(1.0 / pc[2]);  // types_six_dof_expmap.cpp:335-342 ("const float invz")
-            const double r0 = pc[0] * invz * c.fx + c.cx;
-            const double r1 = pc[1] * invz * c.fy + c.cy;
-            const double r2 = r0 - c.bf * invz;
+            const float invzf = (float)invz;  // types_six_dof_expmap.cpp:335-342 ("const float invz")
+            const double r0 = pc[0] * invzf * c.fx + c.cx;
+            const double r1 = pc[1] * invzf * c.fy + c.cy;
+            const double r2 = r0 - c.bf * invzf;
             eE[k][0] = eO[k][0] - r0; eE[k][1] = eO[k][1] - r1; eE[k][2] = eO[k][2] - r2;
         }
     };
@@ -646,147 +708,223 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     const bool stamp = P.dbg && t == 0;
     long long pa[6] = {0, 0, 0, 0, 0, 0}, pts = 0;
     auto lap = [&](int slot) { if (stamp) { const long long now = clock64(); pa[slot] += now - pts; pts = now; } };
-    // LM state: meaningful in wave 0 only (wave-uniform there)
-    int ntrace = 0, iters = 0, npass = 0;
-    const bool wstamp = P.dbg && lane == 0;      // per-wave stamps of the call's SECOND pass: dbg[8 + 4 wave + {0: after (A), 1: after eval, 2: after the tree, 3: after (B)}]
+    int ntrace = 0, iters = 0, npass = 0, nlight = 0;
+    int pb = 0;                                          // parity of the pass in flight (which candidate buffer it reads)
+    double* const mySys = s_sys[wv];
+    double* const myEst = reinterpret_cast<double*>(&s_est[wv]);
+    // solve (H + lambda I) x = b of THIS wave's copy of the system, x -> trial pose exp(x) * est, published as candidate `slot`
+    auto solve_candidate = [&](int buf, int slot, double lambda) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");               // mySys / myEst were written by lanes of this wave
+        double A[36], b[6];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b2 = a; b2 < 6; b2++) { const double h = mySys[q]; A[a * 6 + b2] = h; A[b2 * 6 + a] = h; q++; }
+#pragma unroll
+        for (int a = 0; a < 6; a++) { b[a] = mySys[21 + a]; A[a * 7] += lambda; }
+        double x[6] = {0, 0, 0, 0, 0, 0};
+        const int ok = ldlt6_solve(A, b, x) ? 1 : 0;
+        double sc = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) sc += x[a] * (lambda * x[a] + b[a]);
+        const SE3 trial = se3_exp_mul(x, s_est[wv]);
+        if (lane == 0) { s_cpose[buf][slot] = trial; s_cscale[buf][slot] = sc; s_cok[buf][slot] = ok; }
+    };
+    auto copy7 = [&](double* dst, const double* src) {      // an SE3 between LDS records, by seven lanes of the calling wave
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane < 7) dst[lane] = src[lane];
+    };
     __syncthreads();
     for (int round = 0; round < refc::POSE_ROUNDS; round++) {
         int any = 0;                                  // any level-0 edge?  (g2o: optimize() returns -1 when the index mapping is empty)
 #pragma unroll
         for (int k = 0; k < EPT; k++) any |= !(eF[k] & 2);
         if (PLANES && t < M) any |= !(s_pflag[t] & 2);
-        if (t == 0) { s_est = P.T0; s_pose = P.T0; s_ctrl = 1; }      // every round restarts from the frame's pose (src/Optimizer.cc:547)
-        const int active = __syncthreads_or(any);
+        if (lane == 0) { s_est[wv] = P.T0; if (wv == 0) s_cpose[pb][0] = P.T0; }      // every round restarts from the frame's pose (src/Optimizer.cc:547)
+        const int active = __syncthreads_or(any);                                       // (also barrier (A) of the round's first pass)
         if (active) {
-            // wave 0's view of the LM (all wave-uniform): phase 0 = the pass just evaluated the current estimate (the first
-            // linearisation of the round), phase 1 = it evaluated a trial
-            int phase = 0, it = 0, qmax = 0, nbad = 0, okSolve = 1;
+            // ---- the LM of this optimize() call.  Every wave carries the SAME state (wave-uniform registers), derived from the same LDS
+            //      totals by the same instructions; only the side effects (trace, result) are wave 0's.
+            enum { kInit = 0, kTrial1 = 1, kRetry = 2, kRefresh = 3 };
+            int phase = kInit, it = 0, qmax = 0, nbad = 0, nb = 1;      // nb: poses of the pass in flight
+            bool heavy = true;
             double lambda = 0, ni = 2, curChi = 0, iniChi = 0;
-            double scaleTrial = 0;      // computeScale() of the trial under evaluation: sum x (lambda x + b), taken when x was solved
-            for (;;) {
-                __syncthreads();                                                             // (A) s_pose / s_ctrl are published
-                if (!s_ctrl) break;
+            for (bool first = true;; first = false) {
+                if (!first) { __syncthreads(); pb ^= 1; }                                    // (A) the candidate poses are published
                 if (stamp) pts = clock64();
                 npass++;
-                if (wstamp && npass == 2) P.dbg[8 + 4 * wv] = clock64();
-                const SE3 T = s_pose;
-                // ---- computeActiveErrors + activeRobustChi2 + buildSystem at T
-                double acc[32];
+                double tot = 0;       // after the pass: lane q of every wave holds total q (heavy: 28 sums; light: chi2 of candidate q)
+                if (heavy) {
+                    const SE3 T = s_cpose[pb][0];
+                    const PoseRt Tm = pose_rt(T);
+                    // ---- computeActiveErrors + activeRobustChi2 + buildSystem at T
+                    double acc[32];
 #pragma unroll
-                for (int q = 0; q < 32; q++) acc[q] = 0;
-                bool work = false;
+                    for (int q = 0; q < 32; q++) acc[q] = 0;
+                    bool work = false;
 #pragma unroll
-                for (int k = 0; k < EPT; k++) {
-                    const unsigned char fl = eF[k];
-                    if (fl & 2) continue;
-                    work = true;
-                    const bool stereo = fl & 1;
-                    double p[3];
-                    edge_error(T, k, p);
-                    const double c2 = edge_chi2(k);
-                    double w = 1.0, r0 = c2;
-                    if (fl & 4) huber(c2, stereo ? c.deltaStereo : c.deltaMono, r0, w);
-                    acc[27] += r0;
-                    // Jacobian rows of the edge (types_six_dof_expmap.cpp:103-139, 188-234), written out as upstream writes them.  Columns
-                    // 4 of rows 0 / 2 and 3 of row 1 are structural zeros: their products are left out of the sums below (adding +0.0
-                    // changes no bit of a sum), which takes a quarter of the pass's arithmetic away; each remaining product is
-                    // accumulated with ONE fused multiply-add (the kernel's 28 accumulators cost two thirds of the pass otherwise).
-                    const double X = p[0], Y = p[1], invz = 1.0 / p[2], invz2 = invz * invz;
-                    double J0[6], J1[6], J2[6];
-                    J0[0] = X * Y * invz2 * c.fx; J0[1] = -(1 + (X * X * invz2)) * c.fx; J0[2] = Y * invz * c.fx;
-                    J0[3] = -invz * c.fx; J0[4] = 0; J0[5] = X * invz2 * c.fx;
-                    J1[0] = (1 + Y * Y * invz2) * c.fy; J1[1] = -X * Y * invz2 * c.fy; J1[2] = -X * invz * c.fy;
-                    J1[3] = 0; J1[4] = -invz * c.fy; J1[5] = Y * invz2 * c.fy;
-                    if (stereo) {
-                        J2[0] = J0[0] - c.bf * Y * invz2; J2[1] = J0[1] + c.bf * X * invz2; J2[2] = J0[2];
-                        J2[3] = J0[3]; J2[4] = 0; J2[5] = J0[5] - c.bf * invz2;
-                    } else {   // monocular edge: a zero third row keeps every loop static (registers, no scratch)
-#pragma unroll
-                        for (int a = 0; a < 6; a++) J2[a] = 0;
-                    }
-                    const double info = eI[k], wi = w * info;
-                    pose_accumulate_row<4>(acc, J0, wi, w * (info * eE[k][0]));
-                    pose_accumulate_row<3>(acc, J1, wi, w * (info * eE[k][1]));
-                    pose_accumulate_row<4>(acc, J2, wi, w * (info * eE[k][2]));
-                }
-                if (PLANES && M) {
-                    if (t < 13 * M) {
-                        const int p = t / 13, v = t - 13 * p;
-                        if (!(s_pflag[p] & 2)) {
-                            SE3 Tp = T;
-                            if (v) {
-                                double add[6] = {0, 0, 0, 0, 0, 0};
-                                const int d = (v - 1) >> 1;
-                                const double step = ((v - 1) & 1) ? -1e-9 : 1e-9;
-#pragma unroll
-                                for (int q = 0; q < 6; q++) if (q == d) add[q] = step;
-                                Tp = se3_mul(se3_exp(add), T);
-                            }
-                            plane_error(Tp, P.planes + 10 * p, P.planes + 10 * p + 4, &s_pvar[(p * 13 + v) * 3]);
-                        }
-                    }
-                    __syncthreads();
-                    if (t < M && !(s_pflag[t] & 2)) {
+                    for (int k = 0; k < EPT; k++) {
+                        const unsigned char fl = eF[k];
+                        if (fl & 2) continue;
                         work = true;
-                        const double* pl = P.planes + 10 * t;
-                        const double* pv = &s_pvar[t * 13 * 3];
-                        s_perr[3 * t] = pv[0]; s_perr[3 * t + 1] = pv[1]; s_perr[3 * t + 2] = pv[2];
-                        const double scalar = 1.0 / (2 * 1e-9);
-                        double J[3][6];
-#pragma unroll
-                        for (int d = 0; d < 6; d++)
-#pragma unroll
-                            for (int r = 0; r < 3; r++) J[r][d] = scalar * (pv[(1 + 2 * d) * 3 + r] - pv[(2 + 2 * d) * 3 + r]);
-                        const double c2 = plane_chi2(t);
+                        const bool stereo = fl & 1;
+                        double p[3], invz;
+                        edge_error(Tm, k, p, invz);
+                        const double c2 = edge_chi2(k);
                         double w = 1.0, r0 = c2;
-                        if (s_pflag[t] & 4) huber(c2, P.deltaPlane, r0, w);
+                        if (fl & 4) huber(c2, stereo ? c.deltaStereo : c.deltaMono, r0, w);
                         acc[27] += r0;
-                        const double info[3] = {pl[8], pl[8], pl[9]};
-                        int q = 0;
+                        // Jacobian rows of the edge (types_six_dof_expmap.cpp:103-139, 188-234), written out as upstream writes them.  Columns
+                        // 4 of rows 0 / 2 and 3 of row 1 are structural zeros: their products are left out of the sums below (adding +0.0
+                        // changes no bit of a sum), which takes a quarter of the pass's arithmetic away; each remaining product is
+                        // accumulated with ONE fused multiply-add (the 28 accumulators were two thirds of the pass).
+                        const double X = p[0], Y = p[1], invz2 = invz * invz;
+                        double J0[6], J1[6], J2[6];
+                        J0[0] = X * Y * invz2 * c.fx; J0[1] = -(1 + (X * X * invz2)) * c.fx; J0[2] = Y * invz * c.fx;
+                        J0[3] = -invz * c.fx; J0[4] = 0; J0[5] = X * invz2 * c.fx;
+                        J1[0] = (1 + Y * Y * invz2) * c.fy; J1[1] = -X * Y * invz2 * c.fy; J1[2] = -X * invz * c.fy;
+                        J1[3] = 0; J1[4] = -invz * c.fy; J1[5] = Y * invz2 * c.fy;
+                        if (stereo) {
+                            J2[0] = J0[0] - c.bf * Y * invz2; J2[1] = J0[1] + c.bf * X * invz2; J2[2] = J0[2];
+                            J2[3] = J0[3]; J2[4] = 0; J2[5] = J0[5] - c.bf * invz2;
+                        } else {   // monocular edge: a zero third row keeps every loop static (registers, no scratch)
 #pragma unroll
-                        for (int a = 0; a < 6; a++) {
-                            double sb = J[0][a] * (info[0] * pv[0]) + J[1][a] * (info[1] * pv[1]);
-                            sb += J[2][a] * (info[2] * pv[2]);
-                            acc[21 + a] -= w * sb;
+                            for (int a = 0; a < 6; a++) J2[a] = 0;
+                        }
+                        const double info = eI[k], wi = w * info;
+                        pose_accumulate_row<4>(acc, J0, wi, w * (info * eE[k][0]));
+                        pose_accumulate_row<3>(acc, J1, wi, w * (info * eE[k][1]));
+                        pose_accumulate_row<4>(acc, J2, wi, w * (info * eE[k][2]));
+                    }
+                    if (PLANES && M) {
+                        if (t < 13 * M) {
+                            const int p = t / 13, v = t - 13 * p;
+                            if (!(s_pflag[p] & 2)) {
+                                SE3 Tp = T;
+                                if (v) {
+                                    double add[6] = {0, 0, 0, 0, 0, 0};
+                                    const int d = (v - 1) >> 1;
+                                    const double step = ((v - 1) & 1) ? -1e-9 : 1e-9;
 #pragma unroll
-                            for (int b = a; b < 6; b++) {
-                                double hh = J[0][a] * (w * info[0]) * J[0][b] + J[1][a] * (w * info[1]) * J[1][b];
-                                hh += J[2][a] * (w * info[2]) * J[2][b];
-                                acc[q++] += hh;
+                                    for (int q = 0; q < 6; q++) if (q == d) add[q] = step;
+                                    Tp = se3_mul(se3_exp(add), T);
+                                }
+                                plane_error(Tp, P.planes + 10 * p, P.planes + 10 * p + 4, &s_pvar[(p * 13 + v) * 3]);
+                            }
+                        }
+                        __syncthreads();
+                        if (t < M && !(s_pflag[t] & 2)) {
+                            work = true;
+                            const double* pl = P.planes + 10 * t;
+                            const double* pv = &s_pvar[t * 13 * 3];
+                            s_perr[3 * t] = pv[0]; s_perr[3 * t + 1] = pv[1]; s_perr[3 * t + 2] = pv[2];
+                            const double scalar = 1.0 / (2 * 1e-9);
+                            double J[3][6];
+#pragma unroll
+                            for (int d = 0; d < 6; d++)
+#pragma unroll
+                                for (int r = 0; r < 3; r++) J[r][d] = scalar * (pv[(1 + 2 * d) * 3 + r] - pv[(2 + 2 * d) * 3 + r]);
+                            const double c2 = plane_chi2(t);
+                            double w = 1.0, r0 = c2;
+                            if (s_pflag[t] & 4) huber(c2, P.deltaPlane, r0, w);
+                            acc[27] += r0;
+                            const double info[3] = {pl[8], pl[8], pl[9]};
+                            int q = 0;
+#pragma unroll
+                            for (int a = 0; a < 6; a++) {
+                                double sb = J[0][a] * (info[0] * pv[0]) + J[1][a] * (info[1] * pv[1]);
+                                sb += J[2][a] * (info[2] * pv[2]);
+                                acc[21 + a] -= w * sb;
+#pragma unroll
+                                for (int b = a; b < 6; b++) {
+                                    double hh = J[0][a] * (w * info[0]) * J[0][b] + J[1][a] * (w * info[1]) * J[1][b];
+                                    hh += J[2][a] * (w * info[2]) * J[2][b];
+                                    acc[q++] += hh;
+                                }
                             }
                         }
                     }
+                    lap(0);
+                    // ---- the wave's 28 totals (a wave without a level-0 edge contributes zeros without walking the tree)
+                    if (__any(work)) {
+                        const double ws = wave_transpose_sum32(acc);
+                        if (lane < 32) red[wv * 32 + transpose_sum_index(lane)] = ws;
+                    } else if (lane < 32) red[wv * 32 + lane] = 0;
+                } else {
+                    // ---- LIGHT pass: the robust chi2 of up to four candidate poses (computeActiveErrors + activeRobustChi2 of each, in
+                    //      candidate order: the residuals every edge keeps are the LAST candidate's, as after upstream's last trial)
+                    nlight++;
+                    double chi[kPoseCand];
+#pragma unroll
+                    for (int cnd = 0; cnd < kPoseCand; cnd++) {
+                        chi[cnd] = 0;
+                        if (cnd >= nb) continue;
+                        const SE3 T = s_cpose[pb][cnd];
+                        const PoseRt Tm = pose_rt(T);
+#pragma unroll
+                        for (int k = 0; k < EPT; k++) {
+                            const unsigned char fl = eF[k];
+                            if (fl & 2) continue;
+                            double p[3], invz;
+                            edge_error(Tm, k, p, invz);
+                            const double c2 = edge_chi2(k);
+                            double w, r0 = c2;
+                            if (fl & 4) huber(c2, (fl & 1) ? c.deltaStereo : c.deltaMono, r0, w);
+                            chi[cnd] += r0;
+                        }
+                        if (PLANES && t < M && !(s_pflag[t] & 2)) {
+                            plane_error(T, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
+                            const double c2 = plane_chi2(t);
+                            double w, r0 = c2;
+                            if (s_pflag[t] & 4) huber(c2, P.deltaPlane, r0, w);
+                            chi[cnd] += r0;
+                        }
+                    }
+                    lap(0);
+#pragma unroll
+                    for (int cnd = 0; cnd < kPoseCand; cnd++) {
+                        if (cnd >= nb) continue;
+                        const double ws = wave_sum_f64_lane63(chi[cnd]);
+                        if (lane == 63) red[wv * 32 + cnd] = ws;
+                    }
                 }
-                lap(0);
-                if (wstamp && npass == 2) P.dbg[8 + 4 * wv + 1] = clock64();
-                // ---- the wave's 28 totals (a wave without a level-0 edge contributes zeros without walking the tree)
-                if (__any(work)) {
-                    const double tot = wave_transpose_sum32(acc);
-                    if (lane < 32) red[wv * 32 + transpose_sum_index(lane)] = tot;
-                } else if (lane < 32) red[wv * 32 + lane] = 0;
-                if (wstamp && npass == 2) P.dbg[8 + 4 * wv + 2] = clock64();
                 __syncthreads();                                                             // (B) red[] is complete
-                if (wstamp && npass == 2) P.dbg[8 + 4 * wv + 3] = clock64();
                 lap(1);
-                if (wv == 0) {
-                    // ---- totals: lane q < 28 adds value q of the waves in wave order
-                    double tot = 0;
-                    if (lane < 28)
-                        for (int w = 0; w < nw; w++) tot += red[w * 32 + lane];
-                    const double chiT = lane_bcast_f64(tot, 27);
-                    bool solveNext = false, reinit = false, done = false;
-                    if (phase == 0) {
-                        if (lane < 28) s_sys[lane] = tot;
-                        curChi = chiT;
-                        iniChi = curChi;
-                        qmax = 0;
-                        solveNext = true;
-                    } else {
-                        // ---- the trial just evaluated: accept / reject (optimization_algorithm_levenberg.cpp:118-149)
-                        const double tempChi = okSolve ? chiT : DBL_MAX;
-                        double r = curChi - tempChi;
-                        r /= scaleTrial + 1e-3;
-                        bool accepted = false;
+                // ---- totals: lane q adds value q of the waves in wave order (every wave does, for itself)
+                if (lane < 28)
+                    for (int w = 0; w < nw; w++) tot += red[w * 32 + lane];
+                bool solve1 = false, done = false, toInit = false, toRefresh = false;
+                int refreshFrom = 0;
+                if (phase == kInit) {
+                    // the pass linearised the current estimate (first pass of the round, after an accepted retrial, or g2o's recomputation
+                    // after an iteration that ended on a rejected trial)
+                    if (lane < 28) mySys[lane] = tot;
+                    curChi = lane_bcast_f64(tot, 27);
+                    if (it == 0) {      // lambda_0 = tau * max |diagonal| (:166-180), at the first iteration of every optimize()
+                        double md = 0;
+                        md = fmax(md, fabs(lane_bcast_f64(tot, 0))); md = fmax(md, fabs(lane_bcast_f64(tot, 6))); md = fmax(md, fabs(lane_bcast_f64(tot, 11)));
+                        md = fmax(md, fabs(lane_bcast_f64(tot, 15))); md = fmax(md, fabs(lane_bcast_f64(tot, 18))); md = fmax(md, fabs(lane_bcast_f64(tot, 20)));
+                        lambda = refc::LM_TAU * md;
+                        ni = 2;
+                        nbad = 0;
+                    }
+                    iniChi = curChi;
+                    qmax = 0;
+                    solve1 = true;
+                } else if (phase == kRefresh) {
+                    done = true;        // (the pass only restored the residuals of the trial the LM stopped on)
+                } else {
+                    // ---- decisions on the candidates just evaluated, in upstream's order (optimization_algorithm_levenberg.cpp:118-149)
+                    bool closed = false, accepted = false;
+                    double r = 0;
+                    int cnd = 0;
+                    for (; cnd < nb; cnd++) {
+                        const double chiT = lane_bcast_f64(tot, phase == kTrial1 ? 27 : cnd);
+                        const double tempChi = s_cok[pb][cnd] ? chiT : DBL_MAX;
+                        r = curChi - tempChi;
+                        r /= s_cscale[pb][cnd] + 1e-3;
+                        qmax++;
                         if (r > 0 && isfinite(tempChi)) {
                             const double y = 2 * r - 1;
                             double alpha = 1. - y * y * y;
@@ -794,84 +932,76 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                             lambda *= fmax(1. / 3., alpha);
                             ni = 2;
                             curChi = tempChi;
-                            if (lane < 7) reinterpret_cast<double*>(&s_est)[lane] = reinterpret_cast<const double*>(&s_pose)[lane];   // est = trial
-                            if (lane < 28) s_sys[lane] = tot;      // the accepted trial's system is the next iteration's
+                            copy7(myEst, reinterpret_cast<const double*>(&s_cpose[pb][cnd]));      // est = this trial
+                            if (phase == kTrial1 && lane < 28) mySys[lane] = tot;               // its system is the next iteration's
                             accepted = true;
-                        } else {
-                            lambda *= ni;
-                            ni *= 2;
+                            closed = true;
+                            break;
                         }
-                        qmax++;
-                        if (r < 0 && qmax < refc::LM_MAX_TRIALS) solveNext = true;         // another trial of this iteration
-                        else {                                                            // the iteration closes here
-                            if (lane == 0 && ntrace < 64) { P.trace[ntrace] = lambda; P.trace[64 + ntrace] = curChi; P.trace[128 + ntrace] = qmax; }
-                            if (ntrace < 64) ntrace++;
-                            iters++;
-                            bool term = qmax == refc::LM_MAX_TRIALS || r == 0;
-                            if (!term) {
-                                if ((iniChi - curChi) * 1e3 < iniChi) nbad++; else nbad = 0;
-                                if (nbad >= 3) term = true;
-                            }
-                            it++;
-                            if (term || it >= refc::POSE_ITS) done = true;
-                            else if (!accepted) reinit = true;      // (only a NaN rho ends an iteration on a rejected trial without terminating:
+                        lambda *= ni;
+                        ni *= 2;
+                        if (!(r < 0 && qmax < refc::LM_MAX_TRIALS)) { closed = true; break; }
+                    }
+                    if (!closed) {
+                        // every candidate was rejected with rho < 0 and trials remain: the next batch of retrials (their lambdas are known)
+                        phase = kRetry; heavy = false;
+                        nb = min(min(kPoseCand, nw), refc::LM_MAX_TRIALS - qmax);
+                        if (wv < nb) {
+                            double lc = lambda, nc = ni;
+                            for (int k = 0; k < wv; k++) { lc *= nc; nc *= 2; }
+                            solve_candidate(pb ^ 1, wv, lc);
+                        }
+                    } else {
+                        // ---- the iteration closes here
+                        if (wv == 0 && lane == 0 && ntrace < 64) { P.trace[ntrace] = lambda; P.trace[64 + ntrace] = curChi; P.trace[128 + ntrace] = qmax; }
+                        if (ntrace < 64) ntrace++;
+                        iters++;
+                        bool term = qmax == refc::LM_MAX_TRIALS || r == 0;
+                        if (!term) {
+                            if ((iniChi - curChi) * 1e3 < iniChi) nbad++; else nbad = 0;
+                            if (nbad >= 3) term = true;
+                        }
+                        it++;
+                        const bool stop = term || it >= refc::POSE_ITS;
+                        // the residuals the edges keep must be those of the LAST trial upstream evaluated: candidate `cnd` -- a light pass ends
+                        // on its last candidate, so a run that stops earlier WITHOUT continuing re-evaluates that one pose
+                        const bool stale = phase == kRetry && cnd < nb - 1;
+                        if (stop) {
+                            if (stale) { toRefresh = true; refreshFrom = cnd; }
+                            else done = true;
+                        } else if (!accepted) toInit = true;        // (only a NaN rho ends an iteration on a rejected trial without terminating:
                                                                     //  g2o then recomputes errors and system at the restored estimate)
-                            else { iniChi = curChi; qmax = 0; solveNext = true; }
-                        }
+                        else if (phase == kTrial1) { iniChi = curChi; qmax = 0; solve1 = true; }      // the heavy pass already linearised the new estimate
+                        else toInit = true;                         // an accepted retrial: linearise its pose
                     }
-                    if (solveNext) {
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");               // s_sys was written by the lanes of this wave
-                        double A[36], b[6];
-                        int q = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; a++)
-#pragma unroll
-                            for (int b2 = a; b2 < 6; b2++) { const double h = s_sys[q]; A[a * 6 + b2] = h; A[b2 * 6 + a] = h; q++; }
-#pragma unroll
-                        for (int a = 0; a < 6; a++) b[a] = s_sys[21 + a];
-                        if (phase == 0 && it == 0) {      // lambda_0 = tau * max |diagonal| (:166-180), at the first iteration of every optimize()
-                            double md = 0;
-#pragma unroll
-                            for (int a = 0; a < 6; a++) md = fmax(md, fabs(A[a * 7]));
-                            lambda = refc::LM_TAU * md;
-                            ni = 2;
-                            nbad = 0;
-                        }
-#pragma unroll
-                        for (int a = 0; a < 6; a++) A[a * 7] += lambda;
-                        double x[6] = {0, 0, 0, 0, 0, 0};
-                        okSolve = ldlt6_solve(A, b, x) ? 1 : 0;
-                        scaleTrial = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; a++) scaleTrial += x[a] * (lambda * x[a] + b[a]);
-                        const SE3 trial = se3_mul(se3_exp(x), s_est);
-                        phase = 1;
-                        if (lane == 0) { s_pose = trial; s_ctrl = 1; }
-                    } else if (reinit) {
-                        phase = 0;
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                        if (lane < 7) reinterpret_cast<double*>(&s_pose)[lane] = reinterpret_cast<const double*>(&s_est)[lane];
-                        if (lane == 0) s_ctrl = 1;
-                    } else if (done) {
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                        if (lane < 7) reinterpret_cast<double*>(&s_pose)[lane] = reinterpret_cast<const double*>(&s_est)[lane];
-                        if (lane == 0) s_ctrl = 0;
-                    }
-                    lap(2);
                 }
+                if (solve1) {
+                    phase = kTrial1; heavy = true; nb = 1;
+                    if (wv == 0) solve_candidate(pb ^ 1, 0, lambda);
+                } else if (toInit) {
+                    phase = kInit; heavy = true; nb = 1;
+                    if (wv == 0) copy7(reinterpret_cast<double*>(&s_cpose[pb ^ 1][0]), myEst);
+                } else if (toRefresh) {
+                    phase = kRefresh; heavy = false; nb = 1;
+                    if (wv == 0) copy7(reinterpret_cast<double*>(&s_cpose[pb ^ 1][0]), reinterpret_cast<const double*>(&s_cpose[pb][refreshFrom]));
+                }
+                lap(2);
+                if (done) break;
             }
         }
         // ---- inlier / outlier classification of every edge (src/Optimizer.cc:554-621) at the round's estimate
-        const SE3 fin = s_pose;
-        double nb = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const SE3 fin = s_est[wv];
+        const PoseRt finm = pose_rt(fin);
+        double nbo = 0;
 #pragma unroll
         for (int k = 0; k < EPT; k++) {
             if (!eLive[k]) continue;
             unsigned char fl = eF[k];
             const bool stereo = fl & 1;
-            if (eOut[k]) { double p[3]; edge_error(fin, k, p); }
+            if (eOut[k]) { double p[3], invz; edge_error(finm, k, p, invz); }
             const float c2 = (float)edge_chi2(k);
-            if (c2 > (stereo ? chi2Stereo : chi2Mono)) { eOut[k] = 1; fl |= 2; nb += 1; }
+            if (c2 > (stereo ? chi2Stereo : chi2Mono)) { eOut[k] = 1; fl |= 2; nbo += 1; }
             else { eOut[k] = 0; fl &= ~2; }
             if (!stereo) fl &= ~4;            // mono: kernel removed after every round
             else if (round == refc::POSE_UNROBUST_ROUND) fl &= ~4;    // stereo: at it == 2
@@ -881,20 +1011,20 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
             unsigned char fl = s_pflag[t];
             if (s_pout[t]) plane_error(fin, P.planes + 10 * t, P.planes + 10 * t + 4, &s_perr[3 * t]);
             const float c2 = (float)plane_chi2(t);
-            if (c2 > refc::PLANE_CHI2) { s_pout[t] = 1; fl |= 2; nb += 1; }
+            if (c2 > refc::PLANE_CHI2) { s_pout[t] = 1; fl |= 2; nbo += 1; }
             else { s_pout[t] = 0; fl &= ~2; }
             if (round == refc::POSE_UNROBUST_ROUND) fl &= ~4;
             s_pflag[t] = fl;
         }
         {
-            const double xs = wave_sum_f64_lane63(nb);
+            const double xs = wave_sum_f64_lane63(nbo);
             if (lane == 63) s_nb[wv] = xs;
         }
         __syncthreads();
         if (t == 0) {
-            double tot = 0;
-            for (int w = 0; w < nw; w++) tot += s_nb[w];
-            P.result[0] = (int)tot;
+            double totb = 0;
+            for (int w = 0; w < nw; w++) totb += s_nb[w];
+            P.result[0] = (int)totb;
             *P.Tout = fin;
         }
         if (n + M < 10) break;
@@ -906,7 +1036,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
             if (P.scatterOut) P.scatterOut[P.scatterIdx[t + k * NT]] = eOut[k];
         }
     if (PLANES && t < M) P.planeOutlier[t] = s_pout[t];
-    if (t == 0) { P.result[1] = iters; P.result[2] = ntrace; P.result[3] = npass; }
+    if (t == 0) { P.result[1] = iters; P.result[2] = ntrace; P.result[3] = npass | (nlight << 16); }
     if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
 }
 // MAXT = the launch's thread count bound: the four-wave classes are compiled for ONE wave per SIMD, i.e. with the SIMD's whole
@@ -3284,11 +3414,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     if (P.dbg) {
         long long st[64];
         EAO_HIP(hipMemcpy(st, P.dbg, sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[eao pose stamps] eval %lld tree + barrier %lld decide + solve + exp %lld clock64 ticks over %d LM iterations, %d passes\n", st[0], st[1], st[2], res[1], res[3]);
-        const int nwv = (n <= 4 * kPoseWaves4 && !(getenv("EAO_POSE_WAVES") && atoi(getenv("EAO_POSE_WAVES")) == 8) ? pose_threads(n) : kPoseThreads) / 64;
-        for (int w = 0; w < nwv; w++)
-            fprintf(stderr, "[eao pose stamps]   pass 2, wave %d: starts %+lld, eval %lld, tree %lld, waits at (B) %lld\n", w, st[8 + 4 * w] - st[8], st[9 + 4 * w] - st[8 + 4 * w],
-                    st[10 + 4 * w] - st[9 + 4 * w], st[11 + 4 * w] - st[10 + 4 * w]);
+        fprintf(stderr, "[eao pose stamps] eval %lld tree + barrier %lld decide + solve + exp %lld clock64 ticks over %d LM iterations, %d passes (%d of them light)\n", st[0], st[1], st[2], res[1], res[3] & 0xFFFF, res[3] >> 16);
     }
     se3_to_Tcw_f32(Tout, r->Tcw);
     r->n_inliers = n + M - res[0];
