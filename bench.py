@@ -35,7 +35,30 @@ sys.path.insert(0, ROOT)
 
 SETTLE_STEPS = 50       # untimed steps before the W warm-up steps (clock settling; see main())
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4   # wave instructions / s: 256 CUs x 4 SIMDs, one (integer / packed) VALU instruction per 4 cycles (tools/ubench/intops.hip)
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4   # wave instructions / s: 256 CUs x 4 SIMDs, one (integer / packed) VALU instruction per 4 cycles
+                                          # (tools/ubench/intops.hip; its output at 1 / 2 / 4 / 8 waves per SIMD: profiles/r03_ubench_intops.txt)
+
+
+def _profile(name):
+    """The newest committed profile file of that name (profiles/r03_<name>, else r02_<name>): recorded figures the line quotes."""
+    for tag in ("r03", "r02"):
+        f = os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
+        if os.path.exists(f):
+            return f
+    return None
+
+
+def _kernel_avg_us(csv_name, kernel_prefix):
+    """avg_us of the first row whose kernel starts with kernel_prefix in a committed rocprofv3 summary (tools/summarize_rocprof.py)."""
+    f = _profile(csv_name)
+    if not f:
+        return None, None
+    for ln in open(f):
+        if ln.startswith(kernel_prefix):
+            c = ln.strip().split(",")
+            # (template arguments contain commas: the numeric columns are the last six)
+            return float(c[-5]), os.path.relpath(f, ROOT)
+    return None, os.path.relpath(f, ROOT)
 
 # algorithmic bytes per frame of each stage at 640x480 / 8 levels (SURVEY.md s8d; DESIGN.md "roofline accounting")
 LEVELS = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
@@ -79,7 +102,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))      # a rank that never arrives fails the job instead of hanging it
+        # one line per rank on stderr: a first real N-rank run that dies in set-up says where
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl = "?"
+        print("[bench rank %d/%d] local_rank %d device %s (%s), RCCL %s, MASTER %s:%s" % (rank, world, local_rank, dev, torch.cuda.get_device_name(dev), rccl,
+              os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")), file=sys.stderr, flush=True)
 
     import eao_fusion_amd as E  # after torch: one libamdhip64 in the process
     from eao_fusion_amd import sequence, shard, synth
@@ -151,33 +182,45 @@ def main():
     # reads (22/16 halo rows x 60.8 MB = 83.6 MB expected, 2 x 42.9 MB counted).
     traffic, traffic_note = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pmc_file = _profile("pmc_traffic.json")
+        pmc = json.load(open(pmc_file))
         if pmc.get("batch") == B and dom in pmc["kernels"]:
             k = pmc["kernels"][dom]
             traffic = int(2 * k["fetch_bytes_per_step"] + k["write_bytes_per_step"])   # all launches of the stage in one step
-            traffic_note = "from the committed PMC passes (profiles/r02_pmc_traffic.json): 2 x FETCH_SIZE + WRITE_SIZE per step"
+            traffic_note = "from the committed PMC passes (%s): 2 x FETCH_SIZE + WRITE_SIZE per step" % os.path.relpath(pmc_file, ROOT)
     except Exception:
         pass
     # VALU roofline: wave instructions per launch (SQ_INSTS_VALU of the committed PMC pass, a property of the kernel and its
     # input) / the launch duration measured in THIS run / the chip's issue rate (1024 SIMDs x one wave instruction per 4 cycles)
-    valu = {}
+    valu, valu_insts, sq_file = {}, {}, _profile("pmc_sq.json")
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+        sq = json.load(open(sq_file))
         kname = {"pyramid": "k_resize", "fast": "k_fast_cells", "quadtree": "k_quadtree", "blur": "k_blur7", "orient_describe": "k_orient_describe"}
         if sq.get("batch") == B:
             for st_, kn in kname.items():
                 if kn in sq["kernels"] and stage_ms.get(st_, 0) > 0:
                     insts = sq["kernels"][kn]["SQ_INSTS_VALU"] * sq["kernels"][kn].get("launches_per_step", 1)
+                    valu_insts[st_] = insts
                     valu[st_] = round(insts / (stage_ms[st_] * 1e-3) / VALU_PEAK_WAVE_INSTS, 4)
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_note,
-                "algorithmic_bytes_per_launch": int(stage_bytes[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
-                "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-                "valu_frac": valu.get(dom), "valu_frac_by_stage": valu,
-                "valu_note": "SQ_INSTS_VALU per launch (committed PMC pass, profiles/r02_pmc_sq.json) / this run's launch time / 6.14e11 wave-instructions/s (1024 SIMDs, 2.4 GHz, 4 cycles each): the dominant kernel is instruction-bound, the HBM fraction is reported because the contract asks for it",
-                "pipeline_GBps": round(sum(stage_bytes.values()) / (stage_ms["total"] * 1e-3) / 1e9, 2)}
+    hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)}
+    common = {"kernel": dom, "traffic": traffic, "traffic_source": traffic_note,
+              "algorithmic_bytes_per_launch": int(stage_bytes[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
+              "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+              "valu_frac": valu.get(dom), "valu_frac_by_stage": valu,
+              "pipeline_GBps": round(sum(stage_bytes.values()) / (stage_ms["total"] * 1e-3) / 1e9, 2)}
+    if valu.get(dom) is not None:
+        # The dominant kernel is VALU-ISSUE-bound (integer / packed byte arithmetic, no MFMA shape): its roofline is the chip's
+        # wave-instruction rate; the HBM fraction the contract names is kept beside it under "hbm".
+        ginst = valu_insts[dom] / (stage_ms[dom] * 1e-3) / 1e9
+        roofline = dict({"bound": "valu", "achieved": round(ginst, 2), "peak": round(VALU_PEAK_WAVE_INSTS / 1e9, 1), "unit": "Gwave-inst/s",
+                         "frac": valu[dom], "hbm": hbm,
+                         "valu_note": "SQ_INSTS_VALU per launch (committed PMC pass, %s) / this run's launch time (HIP events on the kernel's stream) / 6.14e11 "
+                                      "wave-instructions/s (1024 SIMDs x 2.4 GHz / 4 cycles: profiles/r03_ubench_intops.txt); traffic = HBM bytes of the same "
+                                      "launch against algorithmic_bytes_per_launch" % os.path.relpath(sq_file, ROOT)}, **common)
+    else:
+        roofline = dict(dict({"bound": "hbm"}, **hbm), **common)
 
     # every collective first (all ranks), the rank-0-only measurements afterwards: no rank waits inside RCCL for minutes
     gathered = {}
@@ -205,8 +248,10 @@ def main():
             cpu_baseline, cpu_extra = measure_cpu(frames, synth, extra)
             extra.update(cpu_extra)
     if seq_out:
+        seq_out["ranks"] = world                 # the world size RCCL saw: an N-GPU run describes itself
         extra["sequence"] = seq_out
     if rank == 0:
+        roofline["ba"] = ba_roofline(extra)
         out = {
             "metric": "ORB kpts/s (640x480, 1k feat) + local-BA residuals/s (20 KF x 3k pts)",
             "value": round(value, 1), "unit": "kpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS,
@@ -217,6 +262,52 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }
         print(json.dumps(out))
+    if seq_out and seq_out.get("allgather_ok") is False:
+        print("[bench rank %d] the s8(e) all-gather returned payloads that differ from what the ranks sent" % rank, file=sys.stderr)
+        return 3
+    return 0
+
+
+def ba_roofline(extra):
+    """The BA half of the metric against the HBM roofline.  Unit = one LM iteration of one window: E x 520 + P x 360
+    algorithmic bytes (linearisation + Schur assembly + solve + back substitution and the error pass).  `achieved` is
+    measured in THIS run: bytes of all iterations of the call / the call's device span (HIP events on the library's stream).  The
+    dominant launch of an iteration (pair-wise Schur assembly, k_ba_schur_pairs_b) is quoted from the committed rocprofv3 summary of the
+    same calls (a recorded figure)."""
+    out = {}
+    P_, per_edge, per_point = 3000, 520, 360
+    try:
+        b = extra.get("ba_batch")
+        if b:
+            E_ = b["ba_residual_blocks_per_s"] * b["ms_per_call"] * 1e-3 / max(b["linearizations"], 1)       # edges per window (average)
+            nwin = 25
+            rounds = max(b["linearizations"] // nwin, 1)          # `linearizations` counts every window's; a launch advances all 25
+            by_iter = nwin * (E_ * per_edge + P_ * per_point)
+            it_ms = b["device_ms"] / rounds
+            ach = by_iter / (it_ms * 1e-3) / 1e9
+            dom_us, src = _kernel_avg_us("ba_batch_kernel_stats.csv", "k_ba_schur_pairs_b")
+            out["batched"] = {"workload": "25 windows x (20 + 4 KF, 3000 MP) in ONE eao_local_ba_batch call", "bound": "hbm", "unit": "GB/s",
+                              "algorithmic_bytes_per_iteration": int(by_iter), "iterations": rounds, "avg_iteration_ms": round(it_ms, 4),
+                              "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "frac": round(ach / HBM_PEAK_GBS, 4),
+                              "kernel": "k_ba_schur_pairs_b", "avg_launch_ms": None if dom_us is None else round(dom_us * 1e-3, 4),
+                              "kernel_frac": None if dom_us is None else round(by_iter / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              "kernel_source": src,
+                              "note": "achieved / frac: all four launches of an LM iteration, measured in this run; kernel_frac: the iteration's bytes against the "
+                                      "dominant launch alone (recorded rocprofv3 average) -- scattered 16-byte loads and fp64 arithmetic, not a streaming kernel"}
+        s1 = extra.get("ba")
+        if s1:
+            E_ = s1["ba_residual_blocks_per_s"] * s1["ms_per_lba_wall"] * 1e-3 / max(s1["linearizations_per_lba"], 1)
+            by_iter = E_ * per_edge + P_ * per_point
+            it_ms = s1["ms_per_lba_device"] / max(s1["linearizations_per_lba"], 1)
+            ach = by_iter / (it_ms * 1e-3) / 1e9
+            dom_us, src = _kernel_avg_us("ba_single_kernel_stats.csv", "k_ba_solve_tiles")
+            out["single_window"] = {"workload": "one LocalBundleAdjustment window (BASELINE configs[3])", "bound": "latency (one window is 9 MB and ~60 dependent launches)",
+                                    "unit": "GB/s", "algorithmic_bytes_per_iteration": int(by_iter), "iterations": s1["linearizations_per_lba"],
+                                    "avg_iteration_ms": round(it_ms, 4), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "frac": round(ach / HBM_PEAK_GBS, 4),
+                                    "kernel": "k_ba_solve_tiles", "avg_launch_ms": None if dom_us is None else round(dom_us * 1e-3, 4), "kernel_source": src}
+    except Exception as ex:  # noqa: BLE001
+        out["error"] = repr(ex)
+    return out
 
 
 def self_launch(n):
@@ -393,7 +484,7 @@ def measure_extra(E, synth, torch, dev):
             else:
                 h["bound"] = "valu (72 KB of traffic per pair: an HBM fraction says nothing here)"
             try:
-                sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+                sq = json.load(open(_profile("pmc_sq.json")))
                 kn = "k_hamming_matrix8" if mode == "matrix" else "k_hamming_best2_rows"
                 if kn in sq.get("kernels_extra", {}):
                     h["valu_frac"] = round(sq["kernels_extra"][kn]["SQ_INSTS_VALU"] / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS, 4)
@@ -615,7 +706,7 @@ def measure_extra(E, synth, torch, dev):
             extra["tracking_frame_device_ms"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
             extra["tracking_frame_device"] = {"keypoints": int(rT["n_keypoints"]), "map_points": len(XwT), "matches": int(rT["n_matches"]), "inliers": int(rT["n_inliers"]),
                                               "note": "eao_tracker_track_local_map: RGB-D stereo + grid + isInFrustum + SearchByProjection(points) + PoseOptimization on the device, one D2H; "
-                                                      "PoseOptimization's single-workgroup LM (4 x 10 iterations) is ~0.27 ms of it"}
+                                                      "PoseOptimization's single-workgroup LM (4 x 10 iterations) is ~0.12 ms of it"}
         except Exception as ex:  # noqa: BLE001
             extra["tracking_frame_device_error"] = repr(ex)
         # the Frame glue (isInFrustum over a 20 000-point local map) and a small-map BundleAdjustment (12 KF, 10 its)

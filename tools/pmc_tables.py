@@ -12,6 +12,7 @@ import re
 import sys
 
 O = sys.argv[1]
+R = sys.argv[2] if len(sys.argv) > 2 else "r02"        # round tag of the passes and of the files written
 
 
 def short(name):
@@ -32,8 +33,8 @@ def load(tag):
     return {k: dict({c: v / len(disp[k]) for c, v in acc[k].items()}, launches=len(disp[k])) for k in acc}
 
 
-a, b, h = load("r02_sq_a"), load("r02_sq_b"), load("r02_sq_h")
-fe, wr = load("r02_fetch"), load("r02_write")
+a, b, h = load(R + "_sq_a"), load(R + "_sq_b"), load(R + "_sq_h")
+fe, wr = load(R + "_fetch"), load(R + "_write")
 batch = int(os.environ.get("EAO_PMC_BATCH", "64"))
 steps = a.get("k_blur7", {}).get("launches", 1)         # one blur launch per bench step (timed and profiled alike)
 sq = {"_note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra (two passes); "
@@ -57,15 +58,15 @@ for name, row in stage.items():
 for k, v in h.items():
     if k.startswith("k_hamming"):
         sq["kernels_extra"][k.split("<")[0]] = {c: x for c, x in v.items()}
-json.dump(sq, open(os.path.join(O, "r02_pmc_sq.json"), "w"), indent=1)
+json.dump(sq, open(os.path.join(O, R + "_pmc_sq.json"), "w"), indent=1)
 cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS",
         "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]
-with open(os.path.join(O, "r02_pmc_sq.txt"), "w") as f:
-    f.write("# SQ counters per launch, 64-frame batch (tools/prof_r02.sh)\n")
+with open(os.path.join(O, R + "_pmc_sq.txt"), "w") as f:
+    f.write("# SQ counters per launch, 64-frame batch (tools/prof_round.sh)\n")
     f.write("kernel".ljust(22) + "".join(c.replace("SQ_", "").rjust(17) for c in cols) + "\n")
     for k, d in list(sq["kernels"].items()) + list(sq["kernels_extra"].items()):
         f.write(k[:22].ljust(22) + "".join(("%.4g" % d[c]).rjust(17) if c in d else "-".rjust(17) for c in cols) + "\n")
-print(open(os.path.join(O, "r02_pmc_sq.txt")).read())
+print(open(os.path.join(O, R + "_pmc_sq.txt")).read())
 # traffic
 tr = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
                "--no-extra; bytes = KiB counter x 1024, RAW counters.  MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half the bytes of a streaming read on gfx950 "
@@ -78,5 +79,5 @@ for st, kn in names.items():
     nl = sum(v["launches"] for k, v in fe.items() if k.startswith(kn))
     tr["kernels"][st] = {"kernel": kn, "launches_per_step": round(nl / steps, 2), "fetch_bytes_per_step": int(f_tot / steps), "write_bytes_per_step": int(w_tot / steps),
                          "hbm_bytes_per_step_corrected": int((2 * f_tot + w_tot) / steps)}
-json.dump(tr, open(os.path.join(O, "r02_pmc_traffic.json"), "w"), indent=1)
+json.dump(tr, open(os.path.join(O, R + "_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(tr["kernels"], indent=1))
