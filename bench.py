@@ -522,6 +522,40 @@ def measure_extra(E, synth, torch, dev):
         extra["orb_end_to_end_pcie"] = {"ms_per_64_frames": round(dtp * 1e3, 3), "kpts_per_s": round(sum(len(k) for k in kk) / dtp, 1),
                                         "note": "eao_orb_extract_batch: H2D of 19.7 MB of frames + extraction + D2H of 64 x cap x 60 B, pageable host memory"}
         del ext_h
+        # ... and through the STREAMING host API (eao_orb_stream_*): three pinned slots, asynchronous submit, the upload of batch
+        # k + 1 and the download of batch k - 1 overlap the extraction of batch k.  The frames are in the pinned slots already (a
+        # decoder / camera driver writes there directly); the variant that first copies 19.7 MB of pageable frames into the slot is
+        # reported beside it.
+        ext_s = E.ORBextractor(1000, 1.2, 8, 20, 7)
+        sl = ext_s.stream_create(640, 480, 64, 3)
+        for s_ in range(3):
+            sl[s_]["frames"][:] = fr64
+        for rep in range(2):
+            for s_ in range(3):
+                ext_s.stream_submit(s_)
+            for s_ in range(3):
+                ext_s.stream_wait(s_)
+        nb_ = 30
+
+        def pipeline(refill):
+            t0 = time.perf_counter()
+            kp = 0
+            for k in range(nb_ + 2):
+                if k < nb_:
+                    if refill:
+                        sl[k % 3]["frames"][:] = fr64
+                    ext_s.stream_submit(k % 3)
+                if k >= 2:
+                    ext_s.stream_wait((k - 2) % 3)
+                    kp += int(sl[(k - 2) % 3]["n"].sum())
+            return (time.perf_counter() - t0) / nb_, kp / nb_
+        dts, kps_ = pipeline(False)
+        dtr, _ = pipeline(True)
+        extra["orb_end_to_end_pcie_streaming"] = {"ms_per_64_frames": round(dts * 1e3, 3), "kpts_per_s": round(kps_ / dts, 1),
+                                                  "ms_per_64_frames_with_refill_memcpy": round(dtr * 1e3, 3), "slots": 3, "batches": nb_,
+                                                  "note": "eao_orb_stream_submit / _wait: H2D of 19.7 MB + extraction + D2H of 64 x cap x 60 B per batch on three streams, "
+                                                          "pinned slots owned by the handle; never `value`"}
+        del ext_s
     except Exception as ex:  # noqa: BLE001
         extra["orb_end_to_end_pcie_error"] = repr(ex)
     try:

@@ -23,6 +23,11 @@ class OrbCfg(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class OrbSlot(C.Structure):   # eao_orb_slot
+    _fields_ = [("frames", C.c_void_p), ("stride", C.c_int32), ("frame_stride", C.c_int64), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("n", C.c_void_p), ("cap", C.c_int32)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p), ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p),
                 ("u_right", C.c_void_p), ("descriptors", C.c_void_p), ("occupied", C.c_void_p),
@@ -76,6 +81,10 @@ SYMBOLS = {
     "eao_orb_extract": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, C.POINTER(_I)]),
     "eao_orb_extract_batch": (_I, [_P, _P, _I, _I, _I, C.c_int64, _I, _P, _P, _I, _P]),
     "eao_orb_extract_batch_device": (_I, [_P, _P, _I, _I, _I, C.c_int64, _I, _P, _P, _I, _P, _P]),
+    "eao_orb_stream_create": (_I, [_P, _I, _I, _I, _I]),
+    "eao_orb_stream_slot": (_I, [_P, _I, C.POINTER(OrbSlot)]),
+    "eao_orb_stream_submit": (_I, [_P, _I, _I]),
+    "eao_orb_stream_wait": (_I, [_P, _I]),
     "eao_orb_level": (_I, [_P, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
     "eao_orb_level_candidates": (_I, [_P, _I, _I, _P, _I, C.POINTER(_I)]),
     "eao_orb_set_profiling": (_I, [_P, _I]),

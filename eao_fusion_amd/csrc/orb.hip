@@ -1706,6 +1706,19 @@ struct eao_orb {
     GraphKey graphKey = {};
     std::vector<hipEvent_t> evs;   // kProfEvents events per profiled call, averaged by eao_orb_last_timing
     size_t evUsed = 0;
+    // streaming host API (eao_orb_stream_*): a ring of pinned input / output slots, three streams (upload, extraction, download)
+    struct StreamSlot {
+        unsigned char* pinIn = nullptr; unsigned char* pinOut = nullptr;      // pinned host memory: frames in, [counts | keypoints | descriptors] out
+        unsigned char* pinOutDev = nullptr;                                    // ... the output block as the device sees it (mapped)
+        unsigned char* dIn = nullptr; unsigned char* dOut = nullptr;           // their device twins
+        hipEvent_t evIn = nullptr, evDone = nullptr, evOut = nullptr;
+        int batch = 0;
+        bool submitted = false;
+    };
+    std::vector<StreamSlot> slots;
+    hipStream_t sUp = nullptr, sRun = nullptr, sDown = nullptr;
+    int sW = 0, sH = 0, sB = 0, sCap = 0, sPitch = 0;
+    size_t sInBytes = 0, sOutBytes = 0, sOffK = 0, sOffD = 0;
 };
 
 namespace {
@@ -1936,9 +1949,15 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
     if (!h->stream) {
         EAO_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         EAO_HIP(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
+        // (HIP maps its streams onto a handful of hardware queues, and streams that share one execute in submission order: only the
+        //  lanes the schedule can use get streams -- lane 0 unless EAO_ORB_LANES asks for more -- so that the streaming API's upload
+        //  stream does not end up behind the extraction's side stream)
+        const int lanesWanted = std::max(1, std::min(eao_orb::kLanes, getenv("EAO_ORB_LANES") ? atoi(getenv("EAO_ORB_LANES")) : 1));
         for (int i = 0; i < eao_orb::kLanes; i++) {
-            EAO_HIP(hipStreamCreateWithFlags(&h->laneMain[i], hipStreamNonBlocking));
-            EAO_HIP(hipStreamCreateWithFlags(&h->laneSide[i], hipStreamNonBlocking));
+            if (i < lanesWanted) {
+                EAO_HIP(hipStreamCreateWithFlags(&h->laneMain[i], hipStreamNonBlocking));
+                EAO_HIP(hipStreamCreateWithFlags(&h->laneSide[i], hipStreamNonBlocking));
+            }
             EAO_HIP(hipEventCreateWithFlags(&h->evFork[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evMid[i], hipEventDisableTiming));
@@ -2218,6 +2237,29 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
     return EAO_OK;
 }
 
+// The download of a streaming slot: 16 bytes per lane from HBM into MAPPED PINNED host memory, as a kernel.
+// (A hipMemcpyAsync on a third stream, waiting for the extraction's event, blocked the copy queue the next slot's upload sits in: with
+// three slots in flight upload, extraction and download ran one after the other, 0.94 ms per 64 frames; two slots hid it by accident.)
+__global__ __launch_bounds__(256) void k_stream_download(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+void stream_release(eao_orb* h) {
+    for (eao_orb::StreamSlot& sl : h->slots) {
+        if (sl.evOut && sl.submitted) (void)hipEventSynchronize(sl.evOut);
+        if (sl.pinIn) (void)hipHostFree(sl.pinIn);
+        if (sl.pinOut) (void)hipHostFree(sl.pinOut);
+        if (sl.dIn) (void)hipFree(sl.dIn);
+        if (sl.dOut) (void)hipFree(sl.dOut);
+        if (sl.evIn) (void)hipEventDestroy(sl.evIn);
+        if (sl.evOut) (void)hipEventDestroy(sl.evOut);
+        if (sl.evDone) (void)hipEventDestroy(sl.evDone);
+    }
+    h->slots.clear();
+    for (hipStream_t* q : {&h->sUp, &h->sRun, &h->sDown})
+        if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -2283,6 +2325,7 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
     if (h->pinOut) (void)hipHostFree(h->pinOut);
+    stream_release(h);
     if (h->evStart) (void)hipEventDestroy(h->evStart);
     if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
     delete h;
@@ -2391,6 +2434,94 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
 eao_status eao_orb_extract(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, eao_keypoint* kps,
                            uint8_t* desc, int32_t cap, int32_t* n) {
     return eao_orb_extract_batch(h, img, width, height, stride, 0, 1, kps, desc, cap, n);
+}
+
+// ---- streaming host API ------------------------------------------------------------------------------------------------
+// What a sequence reader / Tracking thread feeds are HOST images (src/Frame.cc:616-622 behind the Frame constructors,
+// src/Frame.cc:192-194).  eao_orb_extract_batch serves one call at a time from pageable memory: upload, extraction and download
+// follow each other (0.83 ms per 64 frames against 0.26 ms of extraction).  Here the handle owns a ring of PINNED slots: the
+// producer writes frames straight into a slot (a decoder's / camera driver's output buffer; cv::Mat can wrap it), submit() is
+// asynchronous, and the upload of slot k + 1 and the download of slot k - 1 overlap the extraction of slot k on three streams.
+// Results are identical to eao_orb_extract_batch's (tests/test_gpu_orb.py).
+eao_status eao_orb_stream_create(eao_orb* h, int32_t width, int32_t height, int32_t batch, int32_t nslots) {
+    EAO_REQUIRE(h && width > 0 && height > 0 && batch >= 1 && nslots >= 1 && nslots <= 8, "bad argument (1..8 slots)");
+    eao_status st = ensure(h, width, height, batch);
+    if (st) return st;
+    stream_release(h);
+    const Geom& g = h->geom;
+    h->sW = width; h->sH = height; h->sB = batch; h->sCap = g.totalKpCap; h->sPitch = g.L[0].pitch;
+    const size_t B = batch, cap = h->sCap;
+    h->sInBytes = B * (size_t)h->sPitch * height;
+    h->sOffK = (B * sizeof(int) + 255) & ~(size_t)255;
+    h->sOffD = (h->sOffK + B * cap * sizeof(eao_keypoint) + 255) & ~(size_t)255;
+    h->sOutBytes = (h->sOffD + B * cap * 32 + 15) & ~(size_t)15;
+    // Three plain streams.  HIP maps streams onto a few hardware queues and streams that share one run in submission order: with the
+    // handle's eight unused lane streams in the way the upload stream shared a queue with the extraction's side stream and the next
+    // slot's upload started ~100 us into the current extraction (0.50 ms per 64 frames instead of 0.42; the lane streams are now
+    // created on demand).  Stream PRIORITIES make it worse on this runtime (upload high: 0.44; download or extraction low: 0.83-0.88).
+    EAO_HIP(hipStreamCreateWithFlags(&h->sUp, hipStreamNonBlocking));
+    EAO_HIP(hipStreamCreateWithFlags(&h->sRun, hipStreamNonBlocking));
+    EAO_HIP(hipStreamCreateWithFlags(&h->sDown, hipStreamNonBlocking));
+    h->slots.resize(nslots);
+    for (eao_orb::StreamSlot& sl : h->slots) {
+        EAO_HIP(hipHostMalloc((void**)&sl.pinIn, h->sInBytes, hipHostMallocDefault));
+        EAO_HIP(hipHostMalloc((void**)&sl.pinOut, h->sOutBytes, hipHostMallocMapped));
+        EAO_HIP(hipHostGetDevicePointer((void**)&sl.pinOutDev, sl.pinOut, 0));
+        EAO_HIP(hipMalloc((void**)&sl.dIn, h->sInBytes));
+        EAO_HIP(hipMalloc((void**)&sl.dOut, h->sOutBytes));
+        EAO_HIP(hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming));
+        EAO_HIP(hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
+        EAO_HIP(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
+        std::memset(sl.pinOut, 0, h->sOutBytes);
+    }
+    return EAO_OK;
+}
+
+eao_status eao_orb_stream_slot(eao_orb* h, int32_t slot, eao_orb_slot* out) {
+    EAO_REQUIRE(h && out && slot >= 0 && slot < (int)h->slots.size(), "no such slot (eao_orb_stream_create first)");
+    const eao_orb::StreamSlot& sl = h->slots[slot];
+    out->frames = sl.pinIn; out->stride = h->sPitch; out->frame_stride = (int64_t)h->sPitch * h->sH;
+    out->n = (int32_t*)sl.pinOut; out->kps = (eao_keypoint*)(sl.pinOut + h->sOffK); out->desc = sl.pinOut + h->sOffD; out->cap = h->sCap;
+    return EAO_OK;
+}
+
+eao_status eao_orb_stream_submit(eao_orb* h, int32_t slot, int32_t batch) {
+    EAO_REQUIRE(h && slot >= 0 && slot < (int)h->slots.size(), "no such slot (eao_orb_stream_create first)");
+    EAO_REQUIRE(batch >= 1 && batch <= h->sB, "a slot holds 1..%d frames", h->sB);
+    eao_orb::StreamSlot& sl = h->slots[slot];
+    if (sl.submitted) EAO_HIP(hipEventSynchronize(sl.evOut));      // the slot's previous results must have left the device buffers
+    eao_status st = ensure(h, h->sW, h->sH, h->sB);
+    if (st) return st;
+    const size_t B = batch;
+    static const int envSkip = getenv("EAO_STREAM_SKIP") ? atoi(getenv("EAO_STREAM_SKIP")) : 0;      // diagnostic: 1 upload, 2 extraction, 4 download left out
+    if (!(envSkip & 1)) EAO_HIP(hipMemcpyAsync(sl.dIn, sl.pinIn, B * (size_t)h->sPitch * h->sH, hipMemcpyHostToDevice, h->sUp));
+    EAO_HIP(hipEventRecord(sl.evIn, h->sUp));
+    EAO_HIP(hipStreamWaitEvent(h->sRun, sl.evIn, 0));
+    if (!(envSkip & 2)) st = enqueue(h, sl.dIn, h->sPitch, (long long)h->sPitch * h->sH, batch, (eao_keypoint*)(sl.dOut + h->sOffK), sl.dOut + h->sOffD, h->sCap, (int*)sl.dOut, h->sRun);
+    if (st) return st;
+    // the download is a KERNEL (see k_stream_download) on a stream of its own behind the extraction's event: a few workgroups that
+    // store over PCIe beside the next slot's extraction; counts, keypoints and descriptors of the frames submitted lie in three ranges
+    EAO_HIP(hipEventRecord(sl.evDone, h->sRun));
+    EAO_HIP(hipStreamWaitEvent(h->sDown, sl.evDone, 0));
+    const size_t parts[3][2] = {{0, (B * sizeof(int) + 15) & ~(size_t)15}, {h->sOffK, B * (size_t)h->sCap * sizeof(eao_keypoint)}, {h->sOffD, B * (size_t)h->sCap * 32}};
+    for (int q = 0; q < 3 && !(envSkip & 4); q++) {
+        const size_t n16 = (parts[q][1] + 15) / 16;
+        const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 64);
+        hipLaunchKernelGGL(k_stream_download, dim3(grid), dim3(256), 0, h->sDown, reinterpret_cast<const uint4*>(sl.dOut + parts[q][0]),
+                           reinterpret_cast<uint4*>(sl.pinOutDev + parts[q][0]), n16);
+    }
+    EAO_HIP(hipEventRecord(sl.evOut, h->sDown));
+    sl.batch = batch; sl.submitted = true;
+    return EAO_OK;
+}
+
+eao_status eao_orb_stream_wait(eao_orb* h, int32_t slot) {
+    EAO_REQUIRE(h && slot >= 0 && slot < (int)h->slots.size(), "no such slot (eao_orb_stream_create first)");
+    eao_orb::StreamSlot& sl = h->slots[slot];
+    EAO_REQUIRE(sl.submitted, "slot %d was not submitted", slot);
+    EAO_HIP(hipEventSynchronize(sl.evOut));
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
 }
 
 eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which, int32_t* w, int32_t* hgt, uint8_t* dst) {

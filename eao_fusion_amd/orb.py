@@ -89,6 +89,31 @@ class ORBextractor:
                                                        d_desc, cap, d_n, stream))
         self._last_shape = (batch, height, width)
 
+    # --- streaming host API (eao_orb_stream_*): pinned slots, asynchronous submit, upload / extraction / download overlapped
+    def stream_create(self, width, height, batch, nslots=3):
+        _lib.check(self._L.eao_orb_stream_create(self._h, width, height, batch, nslots))
+        self._stream = (width, height, batch, nslots)
+        self._slots = []
+        for s in range(nslots):
+            sl = _lib.OrbSlot()
+            _lib.check(self._L.eao_orb_stream_slot(self._h, s, C.byref(sl)))
+            frames = np.ctypeslib.as_array(C.cast(sl.frames, C.POINTER(C.c_uint8)), shape=(batch, height, sl.stride))
+            kps = np.ctypeslib.as_array(C.cast(sl.kps, C.POINTER(C.c_uint8)), shape=(batch, sl.cap, 28)).view(KP_DTYPE).reshape(batch, sl.cap)
+            desc = np.ctypeslib.as_array(C.cast(sl.desc, C.POINTER(C.c_uint8)), shape=(batch, sl.cap, 32))
+            n = np.ctypeslib.as_array(C.cast(sl.n, C.POINTER(C.c_int32)), shape=(batch,))
+            self._slots.append(dict(frames=frames[:, :, :width], frames_pitched=frames, kps=kps, desc=desc, n=n, cap=int(sl.cap)))
+        return self._slots
+
+    def stream_submit(self, slot, batch=None):
+        _lib.check(self._L.eao_orb_stream_submit(self._h, slot, self._stream[2] if batch is None else batch))
+
+    def stream_wait(self, slot):
+        """Blocks until the slot's results are in its pinned arrays; returns per-frame (keypoints, descriptors) VIEWS into them."""
+        _lib.check(self._L.eao_orb_stream_wait(self._h, slot))
+        sl = self._slots[slot]
+        B = len(sl["n"])
+        return [sl["kps"][f, :sl["n"][f]] for f in range(B)], [sl["desc"][f, :sl["n"][f]] for f in range(B)]
+
     def set_profiling(self, on):
         _lib.check(self._L.eao_orb_set_profiling(self._h, 1 if on else 0))
 

@@ -87,6 +87,28 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
                                  int64_t frame_stride, int32_t batch, eao_keypoint* kps, uint8_t* desc, int32_t cap,
                                  int32_t* n);
 
+/* Streaming host API: what feeds Frame::ExtractORB are HOST images (reference src/Frame.cc:616-622, behind the Frame constructors
+ * :192-194), and a sequence reader has the next batch ready while this one is extracted.  The handle owns `nslots` slots of PINNED
+ * host memory: the producer writes up to `batch` frames into eao_orb_slot.frames (rows of `stride` bytes, frames `frame_stride`
+ * apart), eao_orb_stream_submit is ASYNCHRONOUS (upload -> extraction -> download on three streams, chained by events: the upload
+ * of one slot and the download of another overlap the extraction of a third), eao_orb_stream_wait blocks until the slot's results
+ * are in its pinned kps / desc / n arrays (frame f: kps + f * cap, desc + f * cap * 32, n[f]).  Results are those of
+ * eao_orb_extract_batch on the same frames.  A slot may be refilled once it has been waited for; submit on a slot that is still in
+ * flight waits for it first.  One producer thread per handle. */
+typedef struct {
+    uint8_t* frames;          /* pinned: batch x height rows of `stride` bytes */
+    int32_t stride;           /* row pitch of `frames` (>= width, a multiple of 64) */
+    int64_t frame_stride;     /* stride * height */
+    eao_keypoint* kps;        /* pinned: batch x cap */
+    uint8_t* desc;            /* pinned: batch x cap x 32 */
+    int32_t* n;               /* pinned: batch */
+    int32_t cap;              /* = eao_orb_max_keypoints */
+} eao_orb_slot;
+eao_status eao_orb_stream_create(eao_orb* h, int32_t width, int32_t height, int32_t batch, int32_t nslots);
+eao_status eao_orb_stream_slot(eao_orb* h, int32_t slot, eao_orb_slot* out);
+eao_status eao_orb_stream_submit(eao_orb* h, int32_t slot, int32_t batch);
+eao_status eao_orb_stream_wait(eao_orb* h, int32_t slot);
+
 /* Same, all pointers device-resident (HBM), asynchronous on `stream` (a hipStream_t; NULL = the null stream, exactly as the
  * Hamming entry points read it): whatever the caller enqueues on that stream afterwards is ordered behind the extraction.
  * The main chain of the call's kernels is enqueued on `stream` ITSELF (a private side stream of the handle, forked from and

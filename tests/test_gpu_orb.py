@@ -252,3 +252,35 @@ def test_device_api_alternating_streams(gpu, oracle):
         assert n == len(okps)
         assert np.array_equal(d_k[f].cpu().numpy()[0, :n].reshape(-1).view(gpu.KP_DTYPE), okps), "frame %d keypoints" % f
         assert np.array_equal(d_d[f].cpu().numpy()[0, :n], odesc), "frame %d descriptors" % f
+
+
+def test_streaming_host_api_equals_extract_batch(gpu):
+    """eao_orb_stream_*: pinned slots, asynchronous submit, three streams.  Five different batches through a ring of three slots
+    (the upload of one overlaps the extraction of another), submitted ahead of the waits and with a ragged last batch: every
+    frame's keypoints and descriptors equal eao_orb_extract_batch's, bit for bit; a slot can be refilled after its wait."""
+    ext = gpu.ORBextractor(1000, 1.2, 8, 20, 7)
+    ref = gpu.ORBextractor(1000, 1.2, 8, 20, 7)
+    B = 8
+    slots = ext.stream_create(640, 480, B, 3)
+    batches = [synth.synth_frames(B, seed0=4000 + 10 * k) for k in range(5)]
+    batches[3][2] = 77                     # a frame without corners
+    want = [ref.extract_batch(b) for b in batches]
+    sizes = [B, B, B, B, 5]                # the last batch is short
+    got = [None] * 5
+    for k in range(5 + 2):
+        if k < 5:
+            s = k % 3
+            if k >= 3:                      # the slot is reused: its previous results were collected two steps ago
+                assert got[k - 3] is not None
+            slots[s]["frames"][:sizes[k]] = batches[k][:sizes[k]]
+            ext.stream_submit(s, sizes[k])
+        if k >= 2:
+            j = k - 2
+            kk, dd = ext.stream_wait(j % 3)
+            got[j] = ([x.copy() for x in kk[:sizes[j]]], [x.copy() for x in dd[:sizes[j]]])
+    for k in range(5):
+        for f in range(sizes[k]):
+            assert np.array_equal(got[k][0][f], want[k][0][f]), "batch %d frame %d keypoints" % (k, f)
+            assert np.array_equal(got[k][1][f], want[k][1][f]), "batch %d frame %d descriptors" % (k, f)
+    with pytest.raises(gpu.EaoError):
+        ext.stream_submit(7, B)             # no such slot
