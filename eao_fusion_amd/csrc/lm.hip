@@ -34,7 +34,10 @@
 #include <vector>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -3724,6 +3727,17 @@ struct BALaunch {
 };
 
 // One window in flight: LocalBundleAdjustment / BundleAdjustment of one problem on one context (device arena + pinned mirrors).
+// The uploads of a batch group: window y of the launch is copied from its pinned host mirror (read over PCIe by the kernel itself) into
+// its device arena, 16 bytes per lane.  Both ends are 16-byte aligned (arena offsets are multiples of 256).
+struct BAUploadArgs { unsigned char* dst[8]; const unsigned char* src[8]; unsigned long long n16[8]; };
+__global__ __launch_bounds__(256) void k_ba_upload(BAUploadArgs A) {
+    const int w = blockIdx.y;
+    const uint4* __restrict__ s = reinterpret_cast<const uint4*>(A.src[w]);
+    uint4* __restrict__ d = reinterpret_cast<uint4*>(A.dst[w]);
+    const unsigned long long n = A.n16[w];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) d[i] = s[i];
+}
+
 struct BAJob {
     const eao_ba_problem* p = nullptr; const volatile uint8_t* stop = nullptr; eao_ba_result* r = nullptr;
     int mode = 0, robust = 1; const eao_ba_planes* pl = nullptr; float* planes_out = nullptr;
@@ -3742,7 +3756,11 @@ struct BAJob {
     bool batchable() const { return !trivial && chained && L.d.usePairs && L.d.solveTiles && !hasPl && !L.d.bigPath && D.nFree > 0 && D.nL > 0 && mode == 0; }
 
     // validation, arena, pinned mirror, upload (two copies on `s`), active structure.  No kernel is launched here.
-    eao_status prepare(hipStream_t s) {
+    // deferUpload (batches): NO call into the HIP runtime at all -- the pinned mirror is filled and [upSrc, upSrc + upBytes) is left
+    // for the group's leader, which moves every window of its group with ONE launch of k_ba_upload (the copies' enqueue calls
+    // serialise inside the runtime: 50 of them were most of a batch's 0.55 ms of set-up, and more host threads made it worse).
+    const unsigned char* upSrc = nullptr; unsigned char* upDst = nullptr; size_t upBytes = 0;
+    eao_status prepare(hipStream_t s, bool deferUpload = false) {
         eao::Range rg("lm: window set-up + upload");
         EAO_REQUIRE(p && r && r->cam_Tcw && r->points && (p->n_edges == 0 || r->edge_outlier || mode == 1), "null argument");
         EAO_REQUIRE(p->n_cams > 0 && p->n_points >= 0 && p->n_edges >= 0, "bad sizes");
@@ -3923,7 +3941,7 @@ struct BAJob {
             // The problem itself (observations, indices, initial state, flags) is on its way to the device while the host builds
             // the active structure below; the structure follows in a second copy.
             offSplit = (size_t)((unsigned char*)dcamIdx - a.base) & ~(size_t)255;
-            EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, offSplit - off0, hipMemcpyHostToDevice, s));
+            if (!deferUpload) EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, offSplit - off0, hipMemcpyHostToDevice, s));
             // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
             int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
             int* actCam = (int*)hostp(dactCam); int* actPt = (int*)hostp(dactPt);
@@ -4011,7 +4029,8 @@ struct BAJob {
         d.nPairsNZ = D.nPairsNZ; d.big = D.big;
         // the window record itself travels with the structure
         write_records((BADev*)hostp(dW));
-        EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));
+        if (!deferUpload) EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));
+        else { upSrc = c.pin + off0; upDst = a.base + off0; upBytes = (off1 - off0 + 15) & ~(size_t)15; }
         L.W = dW; L.nz = 1; L.s = s; L.seq = c.status->seq;
         c.status->ph[0].touched = c.status->ph[1].touched = 0;
         // map-scale runs (tens of milliseconds) are NOT enqueued speculatively when the caller can abort them: optimize() then
@@ -4190,6 +4209,51 @@ struct BABatchPool {
 };
 thread_local BABatchPool g_batch;
 constexpr int kBatchGroups = 4, kBatchGroupMin = 4;     // default number of window groups / fewest windows worth a group
+
+// The host threads of a batch call (window set-up workers, group leaders) are PERSISTENT: a call hands `count` tasks to the crew and
+// joins them.  Starting eight std::threads per call cost ~0.3 ms of a 2.9 ms batch (clone + first-touch of the thread's HIP state,
+// one after the other) -- which is why more set-up threads used to make a call slower.  The crew is per calling thread, grows on
+// demand and is never torn down (its threads sleep on a condition variable between calls and die with the process).
+struct HostCrew {
+    std::mutex m;
+    std::condition_variable wake, finished;
+    std::function<void(int)> fn;
+    int generation = 0, next = 0, count = 0, running = 0, threads = 0;
+    void body() {
+        int seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            wake.wait(lk, [&] { return generation != seen && next < count; });
+            while (next < count) {
+                const int i = next++;
+                running++;
+                lk.unlock();
+                fn(i);
+                lk.lock();
+                running--;
+            }
+            seen = generation;
+            if (running == 0) finished.notify_all();
+        }
+    }
+    // runs fn(0 .. n-1) on the crew (at least n threads, so tasks that wait for each other cannot starve) and fn0() on the caller
+    void run(int n, const std::function<void(int)>& f, const std::function<void()>& fn0) {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            while (threads < n) { std::thread(&HostCrew::body, this).detach(); threads++; }
+            fn = f; next = 0; count = n; generation++;
+        }
+        wake.notify_all();
+        fn0();
+        std::unique_lock<std::mutex> lk(m);
+        finished.wait(lk, [&] { return next >= count && running == 0; });
+        count = 0;
+    }
+};
+HostCrew& host_crew() {
+    static thread_local HostCrew* crew = new HostCrew();      // (leaked on purpose: its detached threads may outlive the caller's thread)
+    return *crew;
+}
 }  // namespace
 
 extern "C" {
@@ -4238,7 +4302,8 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     static const int envThreads = getenv("EAO_BA_BATCH_THREADS") ? atoi(getenv("EAO_BA_BATCH_THREADS")) : 0;
     static const int envGroups = getenv("EAO_BA_BATCH_GROUPS") ? atoi(getenv("EAO_BA_BATCH_GROUPS")) : 0;
     const int hw = (int)std::thread::hardware_concurrency();
-    const int nThreads = std::max(1, std::min(n, envThreads > 0 ? envThreads : std::min(8, std::max(1, hw / 2))));
+    // (set-up threads make no HIP call any more -- packing and counting only -- so they scale with the host's cores)
+    const int nThreads = std::max(1, std::min(n, envThreads > 0 ? envThreads : std::min(16, std::max(1, hw / 2))));
     const int G = std::max(1, std::min(std::min(envGroups > 0 ? envGroups : kBatchGroups, nThreads), n / kBatchGroupMin));
     while ((int)B.side.size() < G - 1) {
         hipStream_t q; hipEvent_t e;
@@ -4264,7 +4329,7 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
         (void)hipSetDevice(dev);
         for (int w = t; w < n; w += nThreads) {
             const int g = groupOfWindow(w);
-            stw[w] = jobs[w].prepare(streamOf(g));
+            stw[w] = jobs[w].prepare(streamOf(g), true);
             if (stw[w]) errw[w] = eao_last_error();
             prepared[g].fetch_add(1, std::memory_order_release);
         }
@@ -4279,6 +4344,20 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
             if (stw[w]) return;
         // the windows that share the batched enqueue (tile-solver path, something to optimise); the others -- windows beyond
         // 30 free keyframes, empty ones -- follow one by one on the same stream
+        {   // this group's uploads: one launch per eight windows (see BAJob::prepare)
+            BAUploadArgs U;
+            int k = 0;
+            auto flush = [&]() {
+                if (k) hipLaunchKernelGGL(k_ba_upload, dim3(48, k), dim3(256), 0, sg, U);
+                k = 0;
+            };
+            for (int w = w0; w < w1; w++) {
+                if (jobs[w].trivial || !jobs[w].upBytes) continue;
+                U.dst[k] = jobs[w].upDst; U.src[k] = jobs[w].upSrc; U.n16[k] = jobs[w].upBytes / 16;
+                if (++k == 8) flush();
+            }
+            flush();
+        }
         BALaunch& L = LG[g];
         L.s = sg; L.W = B.dW.p + 2 * w0; L.seq = 0; L.rot = w0 & 7;
         int first = -1, cnt = 0;
@@ -4326,14 +4405,8 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
             if (stw[w]) { errw[w] = eao_last_error(); return; }
         }
     };
-    {
-        std::vector<std::thread> th;
-        if (nThreads == 1 && G == 1) worker(0);          // (a batch of one: no thread is started)
-        else for (int t = 0; t < nThreads; t++) th.emplace_back(worker, t);
-        for (int g = 1; g < G; g++) th.emplace_back(groupWork, g);
-        groupWork(0);
-        for (auto& x : th) x.join();
-    }
+    if (nThreads == 1 && G == 1) { worker(0); groupWork(0); }          // (a batch of one: no thread is involved)
+    else host_crew().run(nThreads + G - 1, [&](int i) { if (i < nThreads) worker(i); else groupWork(i - nThreads + 1); }, [&] { groupWork(0); });
     bool failed = false;
     for (int w = 0; w < n; w++) failed = failed || stw[w];
     for (int g = 0; g < G; g++) failed = failed || stg[g];
