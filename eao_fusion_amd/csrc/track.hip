@@ -53,10 +53,12 @@ struct eao_tracker {
     float* dScale; float* dInvSigma2;
     unsigned char* res = nullptr;      // result block: device view of resPin, resBytes
     unsigned char* resPin = nullptr;
-    size_t resBytes = 0, listCap = 0;
+    size_t resBytes = 0, listCap = 0, assignLds = 0;
+    long long* dbg = nullptr;          // EAO_DEBUG_STAMPS: phase stamps of k_track_assign_edges (diagnostic runs only)
     ~eao_tracker() {
         if (pin) (void)hipHostFree(pin);
         if (resPin) (void)hipHostFree(resPin);
+        if (dbg) (void)hipFree(dbg);
         if (evIn) (void)hipEventDestroy(evIn);
         if (evOut) (void)hipEventDestroy(evOut);
         if (stream) (void)hipStreamDestroy(stream);
@@ -207,11 +209,14 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
 // ONE workgroup; occupancy and minq in LDS.  Converges in a handful of rounds (overlaps are local).
 constexpr int kAssignThreads = 1024;
 constexpr int kWalk = 4;              // candidate-list entries loaded together by the walks of the assignment step (8: no further gain)
-template <int PER>
-__device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
+constexpr int kLdsLists = 28 * 1024;  // candidate-list entries the assignment step can keep in LDS (112 KB of the CU's 160)
+// ListT: `const unsigned*` into HBM, or into the LDS copy of the whole (compact) candidate array -- every round walks every undecided
+// point's list three times, and each walk step was a dependent L2 round trip (8 rounds: 44.6 us for 1000 points; from LDS: see DESIGN.md)
+template <int PER, typename ListT>
+__device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query* __restrict__ q, ListT lists,
                                                   const int* __restrict__ segStart, const int* __restrict__ segCount,
                                                   const int* __restrict__ oct, unsigned char* occG, float nnratio,
-                                                  int* match, int* counts) {
+                                                  int* match, int* counts, long long* dbg = nullptr) {
     extern __shared__ int asm_[];
     int* minq = asm_;                                           // cap
     unsigned char* occ = reinterpret_cast<unsigned char*>(minq + cap);   // cap
@@ -219,24 +224,26 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
     __shared__ int s_left, s_nm;
     const int t = threadIdx.x;
     // PER = map points per thread: 4, 8 or 16 (local maps of up to 4096 / 8192 / 16384 points)
-    int st_[PER], cn_[PER];
+    int st_[PER], cn_[PER], mine[PER];      // mine: the point's match (written to memory once, after the rounds)
     bool open[PER];
     for (int i = t; i < cap; i += kAssignThreads) { occ[i] = occG[i]; octL[i] = (unsigned char)oct[i]; }
     if (t == 0) s_nm = 0;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int m = t + u * kAssignThreads;
-        open[u] = false; st_[u] = 0; cn_[u] = 0;
+        open[u] = false; st_[u] = 0; cn_[u] = 0; mine[u] = -1;
         if (m < nMp) {
-            match[m] = -1;
             if (q[m].active && segCount[m] > 0) { open[u] = true; st_[u] = segStart[m]; cn_[u] = segCount[m]; }
         }
     }
     __syncthreads();
+    long long ph[4] = {0, 0, 0, 0}, pt0 = dbg ? clock64() : 0;
+    auto lap = [&](int k) { if (dbg && t == 0) { const long long now = clock64(); ph[k] += now - pt0; pt0 = now; } };
     for (int round = 0; round < 4096; round++) {
         for (int i = t; i < cap; i += kAssignThreads) minq[i] = 0x7FFFFFFF;
         if (t == 0) s_left = 0;
         __syncthreads();
+        lap(0);
 #pragma unroll
         for (int u = 0; u < PER; u++)
             if (open[u]) {
@@ -253,64 +260,70 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
                 }
             }
         __syncthreads();
+        lap(1);
         int claim[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             claim[u] = -1;
             if (!open[u]) continue;
             const int m = t + u * kAssignThreads;
-            // upstream's scan over the candidates that are free (:83-115)
-            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            // upstream's scan over the candidates that are free (:83-115) -- and, in the SAME walk, the smallest distance among the
+            // candidates an earlier undecided point also lists: the decision is final iff that distance is beyond everything it looked
+            // at with an effect (the second best; every candidate when fewer than two are free).  One walk instead of two, and the three
+            // LDS reads a candidate needs (occupancy, octave, earliest undecided lister) are independent of each other.
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, earlierD = 0x7FFFFFFF;
             for (int k = 0; k < cn_[u]; k += kWalk) {
                 unsigned itw[kWalk];
 #pragma unroll
                 for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn_[u] ? lists[st_[u] + k + j] : 0u;
+                unsigned char oc[kWalk], ol[kWalk];
+                int mq[kWalk];
 #pragma unroll
-                for (int j = 0; j < kWalk; j++) {
-                    if (k + j >= cn_[u]) continue;
-                    const unsigned it = itw[j];
-                    const int i = (int)(it & 0xFFFF), d = (int)(it >> 16);
-                    if (occ[i]) continue;
-                    if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = octL[i]; bestIdx = i; }
-                    else if (d < bestDist2) { bestLevel2 = octL[i]; bestDist2 = d; }
-                }
-            }
-            // final? every candidate the decision looked at with an effect -- distance <= the second best (all of them when
-            // fewer than two are free) -- must not be listed by an earlier undecided point
-            bool fin = true;
-            for (int k = 0; k < cn_[u] && fin; k += kWalk) {
-                unsigned itw[kWalk];
-#pragma unroll
-                for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn_[u] ? lists[st_[u] + k + j] : 0u;
+                for (int j = 0; j < kWalk; j++) { const int i = (int)(itw[j] & 0xFFFF); oc[j] = occ[i]; ol[j] = octL[i]; mq[j] = minq[i]; }
 #pragma unroll
                 for (int j = 0; j < kWalk; j++) {
                     if (k + j >= cn_[u]) continue;
                     const int i = (int)(itw[j] & 0xFFFF), d = (int)(itw[j] >> 16);
-                    if (d <= bestDist2 && minq[i] < m) fin = false;
+                    if (mq[j] < m) earlierD = min(earlierD, d);
+                    if (oc[j]) continue;
+                    if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = ol[j]; bestIdx = i; }
+                    else if (d < bestDist2) { bestLevel2 = ol[j]; bestDist2 = d; }
                 }
             }
-            if (!fin) continue;
+            if (earlierD <= bestDist2) continue;        // not final yet
             open[u] = false;
             if (bestDist <= refc::TH_HIGH) {
                 if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
                 claim[u] = bestIdx;
-                match[m] = bestIdx;
+                mine[u] = bestIdx;
             }
         }
         __syncthreads();      // every decision of the round was taken from the same occupancy
-        int left = 0, nm = 0;
+        lap(2);
+        // (counts by ballot: a thousand lanes adding to one LDS word are served one after the other)
+        int wl = 0, wn = 0;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            if (claim[u] >= 0) { occ[claim[u]] = 1; nm++; }
-            left += open[u] ? 1 : 0;
+            if (claim[u] >= 0) occ[claim[u]] = 1;
+            wn += (int)__popcll(__ballot(claim[u] >= 0));
+            wl += (int)__popcll(__ballot(open[u]));
         }
-        if (left) atomicAdd(&s_left, left);
-        if (nm) atomicAdd(&s_nm, nm);
+        if ((t & 63) == 0) {
+            if (wl) atomicAdd(&s_left, wl);
+            if (wn) atomicAdd(&s_nm, wn);
+        }
         __syncthreads();
-        if (s_left == 0) break;
+        if (s_left == 0) { if (t == 0) counts[5] = round + 1; break; }
         __syncthreads();
+        lap(3);
     }
+    if (dbg && t == 0) { dbg[8] = ph[0]; dbg[9] = ph[1]; dbg[10] = ph[2]; dbg[11] = ph[3]; }
     for (int i = t; i < cap; i += kAssignThreads) occG[i] = occ[i];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int m = t + u * kAssignThreads;
+        if (m < nMp) match[m] = mine[u];
+    }
     if (t == 0) counts[3] = s_nm;
 }
 
@@ -368,18 +381,36 @@ __device__ __forceinline__ void track_edges_body(int nMp, int cap, const int* ma
 static_assert(kAssignThreads == kEdgeThreads, "one workgroup runs both steps");
 template <int PER>
 __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, int cap, const Query* __restrict__ q, const unsigned* __restrict__ lists,
-                                                                       const int* __restrict__ segStart, const int* __restrict__ segCount,
+                                                                       const int* __restrict__ segStart, const int* __restrict__ segCount, const int* __restrict__ cursor,
                                                                        const int* __restrict__ oct, unsigned char* occG, float nnratio, int* match, int* counts,
                                                                        int* kpMp, const float* __restrict__ kx, const float* __restrict__ ky,
                                                                        const float* __restrict__ ur, const float* __restrict__ mXw, const float* __restrict__ priorXw,
                                                                        const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl,
-                                                                       const float* __restrict__ dz, const unsigned char* __restrict__ inView, ResultBlock R) {
+                                                                       const float* __restrict__ dz, const unsigned char* __restrict__ inView, ResultBlock R,
+                                                                       long long* dbg) {
+    extern __shared__ unsigned char asm_raw[];
+    if (dbg && threadIdx.x == 0) dbg[0] = clock64();
     if (nMp > 0) {
-        track_assign_body<PER>(nMp, cap, q, lists, segStart, segCount, oct, occG, nnratio, match, counts);
+        {
+            // the candidate lists are ONE compact array (k_match_candidates fills it through an atomic cursor): when it fits, the
+            // workgroup copies it into LDS once (coalesced) and the rounds walk it there
+            const int total = *cursor;
+            unsigned* ldsLists = reinterpret_cast<unsigned*>(asm_raw + ((6 * (size_t)cap + 15) & ~(size_t)15));
+            if (total <= kLdsLists) {
+                for (int i = threadIdx.x; i < total; i += kAssignThreads) ldsLists[i] = lists[i];
+                __syncthreads();
+                if (dbg && threadIdx.x == 0) { dbg[1] = clock64(); dbg[7] = total; }
+                track_assign_body<PER, const unsigned*>(nMp, cap, q, ldsLists, segStart, segCount, oct, occG, nnratio, match, counts, dbg);
+            } else {
+                track_assign_body<PER, const unsigned* __restrict__>(nMp, cap, q, lists, segStart, segCount, oct, occG, nnratio, match, counts);
+            }
+        }
         __syncthreads();      // match[] is complete (and visible to the whole workgroup)
     }
+    if (dbg && threadIdx.x == 0) dbg[2] = clock64();
     track_edges_body(nMp, cap, match, kpMp, kx, ky, ur, oct, mXw, priorXw, invSigma2, E, edgeCap, counts, eOutl);
     __syncthreads();          // counts[2], kpMp[] are final
+    if (dbg && threadIdx.x == 0) dbg[3] = clock64();
     // everything the host needs except the pose and mvbOutlier, which PoseOptimization itself writes (by keypoint, through
     // the edge -> keypoint table): the block lies in mapped host memory
     const int t = threadIdx.x, n = counts[0];
@@ -392,6 +423,7 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
     }
     // Frame::isInFrustum(pMP, 0.5) of every local map point (workgroups 1.. of k_track_frame): the caller's visibility counters
     for (int m = t; m < nMp; m += kAssignThreads) R.inView[m] = inView[m];
+    if (dbg && threadIdx.x == 0) dbg[4] = clock64();
 }
 
 // everything the host needs, in one block: [SE3 | result ints | counts | kpMp | kpOutlier | uRight | depth]
@@ -451,6 +483,12 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
         hipEventCreateWithFlags(&h->evOut, hipEventDisableTiming) != hipSuccess) { delete h; eao::set_error("stream / event creation failed"); return EAO_ERR_NO_DEVICE; }
     h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C) + al256(12 * C)) + 4096;
     if (hipHostMalloc((void**)&h->pin, h->pinCap, hipHostMallocDefault) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
+    // the assignment workgroup's LDS: claims / occupancy / octaves by keypoint, then the staged candidate lists (beyond the default 64 KB)
+    if (getenv("EAO_DEBUG_STAMPS")) { EAO_HIP(hipMalloc((void**)&h->dbg, 128)); EAO_HIP(hipMemset(h->dbg, 0, 128)); }
+    h->assignLds = ((6 * C + 15) & ~(size_t)15) + 4 * (size_t)kLdsLists;
+    EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
+    EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
+    EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
     EAO_HIP(hipMemcpyAsync(h->dScale, h->scale.data(), 4 * (size_t)cfg->nlevels, hipMemcpyHostToDevice, h->stream));
     EAO_HIP(hipMemcpyAsync(h->dInvSigma2, h->invSigma2.data(), 4 * (size_t)cfg->nlevels, hipMemcpyHostToDevice, h->stream));
     EAO_HIP(hipStreamSynchronize(h->stream));
@@ -580,9 +618,9 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     unsigned char* rInView = r + ro; ro += al256((size_t)h->capMp);
     ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz, rInView};
     auto launch_assign = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), (size_t)C * 6, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->oct, h->occ,
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
                            nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
-                           h->inView, RB);
+                           h->inView, RB, h->dbg);
     };
     if (nMp <= 4 * kAssignThreads) launch_assign(k_track_assign_edges<4>);
     else if (nMp <= 8 * kAssignThreads) launch_assign(k_track_assign_edges<8>);
@@ -598,6 +636,15 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     // ---- the results are in host memory when the stream has drained
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
+    if (h->dbg) {
+        long long st[16];
+        EAO_HIP(hipMemcpy(st, h->dbg, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[eao track stamps]   rounds: init + reset %lld, claim walk %lld, decide %lld, commit %lld ticks\n", st[8], st[9], st[10], st[11]);
+        int rounds = 0;
+        EAO_HIP(hipMemcpy(&rounds, h->counts + 5, sizeof(int), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[eao track stamps] assign + edges: stage lists %lld (%lld entries), %d rounds %lld, edge list %lld, result block %lld ticks\n", st[1] - st[0], st[7], rounds,
+                st[2] - st[1], st[3] - st[2], st[4] - st[3]);
+    }
     const unsigned char* p = h->resPin;
     const int* oc = (const int*)(p + ((unsigned char*)rCounts - r));
     const int n = oc[0], nEdges = oc[2];
