@@ -711,6 +711,8 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     const bool stamp = P.dbg && t == 0;
     long long pa[6] = {0, 0, 0, 0, 0, 0}, pts = 0;
     auto lap = [&](int slot) { if (stamp) { const long long now = clock64(); pa[slot] += now - pts; pts = now; } };
+    const bool wstamp = P.dbg != nullptr;                // per-wave stamps: evaluation (heavy / light) and reduction tree of every wave
+    long long wH = 0, wL = 0, wT = 0, wt0 = 0;
     int ntrace = 0, iters = 0, npass = 0, nlight = 0;
     int pb = 0;                                          // parity of the pass in flight (which candidate buffer it reads)
     double* const mySys = s_sys[wv];
@@ -759,6 +761,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                 npass++;
                 double tot = 0;       // after the pass: lane q of every wave holds total q (heavy: 28 sums; light: chi2 of candidate q)
                 if (heavy) {
+                    if (wstamp) wt0 = clock64();
                     const SE3 T = s_cpose[pb][0];
                     const PoseRt Tm = pose_rt(T);
                     // ---- computeActiveErrors + activeRobustChi2 + buildSystem at T
@@ -849,15 +852,18 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                         }
                     }
                     lap(0);
+                    if (wstamp) { const long long now = clock64(); wH += now - wt0; wt0 = now; }
                     // ---- the wave's 28 totals (a wave without a level-0 edge contributes zeros without walking the tree)
                     if (__any(work)) {
                         const double ws = wave_transpose_sum32(acc);
                         if (lane < 32) red[wv * 32 + transpose_sum_index(lane)] = ws;
                     } else if (lane < 32) red[wv * 32 + lane] = 0;
+                    if (wstamp) wT += clock64() - wt0;
                 } else {
                     // ---- LIGHT pass: the robust chi2 of up to four candidate poses (computeActiveErrors + activeRobustChi2 of each, in
                     //      candidate order: the residuals every edge keeps are the LAST candidate's, as after upstream's last trial)
                     nlight++;
+                    if (wstamp) wt0 = clock64();
                     double chi[kPoseCand];
 #pragma unroll
                     for (int cnd = 0; cnd < kPoseCand; cnd++) {
@@ -885,6 +891,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                         }
                     }
                     lap(0);
+                    if (wstamp) wL += clock64() - wt0;
 #pragma unroll
                     for (int cnd = 0; cnd < kPoseCand; cnd++) {
                         if (cnd >= nb) continue;
@@ -1041,6 +1048,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     if (PLANES && t < M) P.planeOutlier[t] = s_pout[t];
     if (t == 0) { P.result[1] = iters; P.result[2] = ntrace; P.result[3] = npass | (nlight << 16); }
     if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
+    if (wstamp && lane == 0) { P.dbg[8 + wv] = wH; P.dbg[24 + wv] = wL; P.dbg[40 + wv] = wT; if (wv == 0) P.dbg[7] = nw; }
 }
 // MAXT = the launch's thread count bound: the four-wave classes are compiled for ONE wave per SIMD, i.e. with the SIMD's whole
 // register file (256 VGPRs + 256 AGPRs) per wave -- what does not fit the VGPRs is parked in AGPRs, not in scratch memory.
@@ -1051,10 +1059,12 @@ template <int EPT, bool PLANES, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_pose_optimization_batch(const PoseDev* __restrict__ W) {
     pose_lm_fused<EPT, PLANES>(W[blockIdx.x]);
 }
-// Launch geometry of the register kernels.  Measured (EAO_DEBUG_STAMPS, 1000 correspondences): an fp64 instruction occupies its SIMD
-// for ~8 cycles and two waves on one SIMD do not overlap -- so one wave per SIMD (four per workgroup) already saturates the CU's fp64
-// pipes, and every further wave only adds its own reduction tree.  Hence FOUR waves with up to four edges per thread for frames of
-// up to 1024 correspondences (edge i lives in thread i mod 256, slot i / 256), eight waves x four edges beyond.
+// Launch geometry of the register kernels.  A lone wave issues an fp64 instruction every 5.45 cycles, the SIMD's fp64 pipe takes one every
+// 4.3 (tools/ubench/f64_simd.hip, profiles/r03_ubench_f64.txt): one wave per SIMD (four per workgroup) is within 20 % of what the CU's
+// fp64 pipes can do, and the per-wave stamps of the evaluation say the same (tools/dbg_pose_waves.py, 1000 correspondences, 23 heavy
+// passes: four waves x 4 edges 114 k ticks; eight waves x 2 edges: waves 0-3 59 k, waves 4-7 -- the younger wave of every SIMD, served
+// when the older one has nothing to issue -- 108 k).  Every further wave adds its own reduction tree.  Hence FOUR waves with up to four
+// edges per thread for frames of up to 1024 correspondences (edge i lives in thread i mod 256, slot i / 256), eight waves x four edges beyond.
 constexpr int kPoseWaves4 = 256;
 inline int pose_threads(int n) { return n <= 4 * kPoseWaves4 ? std::min(kPoseWaves4, std::max(64, (n + 63) / 64 * 64)) : kPoseThreads; }
 inline int pose_ept(int n) { return n <= kPoseWaves4 ? 1 : (n <= 2 * kPoseWaves4 ? 2 : 4); }
@@ -3418,6 +3428,9 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
         long long st[64];
         EAO_HIP(hipMemcpy(st, P.dbg, sizeof(st), hipMemcpyDeviceToHost));
         fprintf(stderr, "[eao pose stamps] eval %lld tree + barrier %lld decide + solve + exp %lld clock64 ticks over %d LM iterations, %d passes (%d of them light)\n", st[0], st[1], st[2], res[1], res[3] & 0xFFFF, res[3] >> 16);
+        fprintf(stderr, "[eao pose stamps] per wave, heavy evaluation / light evaluation / tree:");
+        for (int w = 0; w < (int)st[7] && w < 16; w++) fprintf(stderr, "  w%d %lld / %lld / %lld", w, st[8 + w], st[24 + w], st[40 + w]);
+        fprintf(stderr, "\n");
     }
     se3_to_Tcw_f32(Tout, r->Tcw);
     r->n_inliers = n + M - res[0];
