@@ -2207,7 +2207,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(const BADev* __restr
 //   update   every live tile: C -= W_tile L_tile^T, ONE MFMA, operands = one LDS double per lane each
 // Measured on MI355X a lone wave issues one fp64 VALU instruction per 8 cycles whatever the dependences, so the cost
 // of a step is its instruction count on the longest wave: ~90 for the panel thread, ~10 per tile for the update.
-// L is archived row-packed in LDS; the back substitution L^T x = z walks it bottom-up in blocks of four.
+// L is archived row-packed in LDS; the back substitution L^T x = z walks it bottom-up in blocks of sixteen rows.
 constexpr int kTileMaxFree = 30;
 constexpr int kTileThreads = 1024;
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -2601,41 +2601,55 @@ __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(const BADev* __
     }
     if (stamp) { P.dbg[4] = clock64(); P.dbg[5] = wall_clock64(); P.dbg[10] = acc0; P.dbg[11] = acc1; P.dbg[12] = acc2; }
     __syncthreads();
-    // ---- L^T x = z bottom-up by ONE wave, no barriers: lane l keeps z(l), z(l + 64), z(l + 128) in registers; x(r) is
-    //      broadcast with a readlane, row r - 1 of L is fetched from LDS while row r is applied.  The products run over
-    //      whole registers: entries at and right of the diagonal only disturb z values that were consumed already.
-    if (wave == 0) {
-        const double* zrow = Lall + tile_lrow(g.n4);
-        double z0 = zrow[lane], z1 = zrow[lane + 64], z2 = zrow[lane + 128];   // slack + following arrays keep this in bounds
-        const double* lrow = Lall + tile_lrow(g.n4 - 1) + lane;
-        double p0 = lrow[0], p1 = lrow[64], p2 = lrow[128];
-        auto bcast = [](double v, int src) {
-            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    // ---- L^T x = z bottom-up in blocks of 16 rows.  Thread i keeps z(i) for the whole substitution.  The wave that holds a block's
+    //      rows solves its triangle: x(r) is broadcast with a readlane (and parked in lane r of `xv`: the products
+    //      run over the whole register, so entries at and right of the diagonal go on disturbing z values that were consumed already),
+    //      the block's 16 rows of L are fetched from LDS before the chain starts.  Rows held by LOWER waves take the block's 16
+    //      updates from the published x after a barrier, while the owner is already in its next block; blocks of wave 0 need no
+    //      barrier at all.  Every z(i) sees the same fused multiply-adds in the same order (r descending) as in a row-by-row sweep.
+    //      (Round 3: the sweep by one wave -- three registers of z, one row per step, 151 cycles per row -- took 18.1 k of the solver's
+    //      76 k cycles at 120 rows.)
+    {
+        auto bcast = [](int v, int src) { return __builtin_amdgcn_readlane(v, src); };
+        double z = 0, xv = 0;
+        if (wave <= ((g.n4 - 1) >> 6)) z = Lall[tile_lrow(g.n4) + t];      // (slack + the following arrays keep the padding lanes in bounds)
+        // one block of CNT rows [lo, lo + CNT): straight-line code per block size (n4 is a multiple of four: only the top block is short)
+        auto block = [&](auto cntTag, int lo) {
+            constexpr int CNT = decltype(cntTag)::value;
+            const int wB = lo >> 6;      // workgroup-uniform
+            double cL[CNT];
+            if (wave <= wB) {
+                const double* row = Lall + tile_lrow(lo + CNT - 1) + t;      // row lo + CNT - 1 - k, column t
+#pragma unroll
+                for (int k = 0; k < CNT; k++) { cL[k] = *row; row -= lo + CNT - 1 - k + 3; }      // tile_lrow(r) - tile_lrow(r - 1) = r + 3
+            }
+            if (wave == wB) {
+#pragma unroll
+                for (int k = 0; k < CNT; k++) {
+                    const int rl = (lo + CNT - 1 - k) & 63;
+                    const double xr = __hiloint2double(bcast(__double2hiint(z), rl), bcast(__double2loint(z), rl));
+                    xv = lane == rl ? z : xv;
+                    z = fma(-cL[k], xr, z);
+                }
+                const int lb = lo & 63;
+                if (lane >= lb && lane < lb + CNT) sx[lo + lane - lb] = xv;
+            }
+            if (wB > 0) {
+                __syncthreads();
+                if (wave < wB) {
+#pragma unroll
+                    for (int k = 0; k < CNT; k++) z = fma(-cL[k], sx[lo + CNT - 1 - k], z);
+                }
+            }
         };
-        int r = g.n4 - 1;
-        for (; r >= 128; r--) {
-            const double c0 = p0, c1 = p1, c2 = p2;
-            lrow -= r + 3;                         // tile_lrow(r) - tile_lrow(r - 1)
-            p0 = lrow[0]; p1 = lrow[64]; p2 = lrow[128];
-            const double xr = bcast(z2, r - 128);
-            sx[r] = xr;
-            z0 = fma(-c0, xr, z0); z1 = fma(-c1, xr, z1); z2 = fma(-c2, xr, z2);
+        int B = (g.n4 - 1) >> 4;
+        switch (g.n4 - (B << 4)) {      // rows of the top block
+            case 4: block(std::integral_constant<int, 4>(), B << 4); break;
+            case 8: block(std::integral_constant<int, 8>(), B << 4); break;
+            case 12: block(std::integral_constant<int, 12>(), B << 4); break;
+            default: block(std::integral_constant<int, 16>(), B << 4); break;
         }
-        for (; r >= 64; r--) {
-            const double c0 = p0, c1 = p1;
-            lrow -= r + 3;
-            p0 = lrow[0]; p1 = lrow[64];
-            const double xr = bcast(z1, r - 64);
-            sx[r] = xr;
-            z0 = fma(-c0, xr, z0); z1 = fma(-c1, xr, z1);
-        }
-        for (; r >= 0; r--) {
-            const double c0 = p0;
-            if (r > 0) { lrow -= r + 3; p0 = lrow[0]; }
-            const double xr = bcast(z0, r);
-            sx[r] = xr;
-            z0 = fma(-c0, xr, z0);
-        }
+        for (B--; B >= 0; B--) block(std::integral_constant<int, 16>(), B << 4);
     }
     __syncthreads();
     if (stamp) { P.dbg[6] = clock64(); P.dbg[7] = wall_clock64(); }
