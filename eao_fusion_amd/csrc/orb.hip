@@ -1378,7 +1378,10 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict__ g, ImgSrc s, const uint8_t* __restrict__ blur,
                                                          const unsigned* __restrict__ levelkps, const int* __restrict__ levelcnt,
                                                          eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                         int* __restrict__ nout, int cap, int f0, int nlevels) {
+                                                         int* __restrict__ nout, int cap, int f0, int nlevels, int lFirst, int lEnd, int writeN) {
+    // Levels [lFirst, lEnd) of every frame: blockIdx.x * 4 + wave counts the keypoints of THOSE levels; a launch over the lower levels may run
+    // while the upper levels' quad-trees are still at work (their counts are not read), the launch that covers the last level writes the
+    // frame's keypoint count (writeN).
     // (the wave index through readfirstlane: the compiler then KNOWS that the keypoint -- index, key, position, level --
     //  is wave-uniform, keeps it in SGPRs, loads it with scalar loads and addresses the two windows as SGPR base + 32-bit
     //  lane offset instead of per-lane 64-bit pointer arithmetic)
@@ -1396,8 +1399,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
         fy = (int)(xcd + 8 * (slot / gridDim.x));
         bx = (int)(slot % gridDim.x);
     }
-    int j = bx * 4 + wv;   // compact output index inside the frame
-    const int jout = j;
+    int j = bx * 4 + wv;   // compact output index inside the frame (relative to the first keypoint of level lFirst until the counts are known)
     const int f = fy + f0;
     // level of compact index j: the level counts are wave-uniform -- independent scalar loads and a running sum on the
     // scalar unit (the first version scanned them across lanes: four ds_bpermute round trips before anything else could start)
@@ -1406,16 +1408,18 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     //  was ~90 SALU instructions per wave, in a kernel that issues as many scalar as vector instructions -- one scalar unit per CU)
     int total, l, lbase;
     {
-        int inc = lane < nlevels ? levelcnt[f * nlevels + lane] : 0;
+        int inc = lane < lEnd ? levelcnt[f * nlevels + lane] : 0;
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);   // row_shr:1
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);   // row_shr:2
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);   // row_shr:4
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);   // row_shr:8
         total = __builtin_amdgcn_readlane(inc, 15);
-        l = (int)__popcll(__ballot(lane < nlevels && inc <= j));                // levels that end at or before j
+        if (lFirst > 0) j += __builtin_amdgcn_readlane(inc, lFirst - 1);
+        l = (int)__popcll(__ballot(lane < nlevels && inc <= j));                // levels that end at or before j (levels >= lEnd: the flat tail of the scan)
         lbase = l > 0 ? __builtin_amdgcn_readlane(inc, min(l, kMaxLevels) - 1) : 0;
     }
-    if (bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
+    const int jout = j;
+    if (writeN && bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
     if (l >= nlevels || jout >= cap) return;
     j -= lbase;
     const LevelGeom L = g->L[l];
@@ -1683,7 +1687,7 @@ struct eao_orb {
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
     bool evLastValid = false, capturing = false;   // evLastValid: a call has been enqueued on lastStream
     hipStream_t lastStream = nullptr;      // the stream of the previous call: compared, never dereferenced (its owner may have destroyed it)
-    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {};
+    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {}, evBlur[kLanes] = {}, evLow[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
     eao::DevBuf<uint8_t> d_pyr, d_blur, d_in;
@@ -1962,6 +1966,8 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
             EAO_HIP(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evMid[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
+            EAO_HIP(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming));
+            EAO_HIP(hipEventCreateWithFlags(&h->evLow[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evDone[i], hipEventDisableTiming));
         }
     }
@@ -2113,7 +2119,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
             }
             { eao::Range rg("orb: orientation + description"); hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
-                               h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels); }
+                               h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, 0, g.nlevels, 1); }
             if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
             if (!onCaller) {
                 EAO_HIP(hipEventRecord(h->evDone[i], ms));
@@ -2125,6 +2131,13 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             EAO_HIP(hipStreamWaitEvent(ss, h->evStart, 0));
             fast(ss, 0, cells0);
         }
+        bool blurOwn = false, splitOD = false;
+        auto orient = [&](hipStream_t str, int lFirst, int lEnd, int writeN) {
+            eao::Range rg("orb: orientation + description");
+            const int rangeCap = (lEnd < g.nlevels ? g.L[lEnd].kpBase : g.totalKpCap) - g.L[lFirst].kpBase;
+            hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, rangeCap), 4), nb), dim3(256), 0, str, h->d_geom.p, s, h->d_blur.p, h->d_levelkps.p,
+                               h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, lFirst, lEnd, writeN);
+        };
         for (int l = 1; l < g.nlevels; l++) {
             const int G4 = eao::cdiv(g.L[l].w, 4);
             // ONE-WAVE workgroups: the chain's small launches run beside FAST launches that fill every CU with one-wave workgroups;
@@ -2172,12 +2185,31 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             // it (64 frames: 0.2784 -> 0.2762 ms, 256 frames: 1.092 -> 1.071; measured the other way round before the resize
             // launches became one-wave workgroups, when the pyramid ended 20 us later).  EAO_ORB_BLUR_EARLY=0 restores the old point.
             static const int envBlurEarly = getenv("EAO_ORB_BLUR_EARLY") ? atoi(getenv("EAO_ORB_BLUR_EARLY")) : 1;
+            // Round 3, measured and NOT the default (EAO_ORB_BLUR_STREAM=1 switches it on, EAO_ORB_SPLIT=0 its second half off): the blur on a
+            // THIRD stream (the lane's own main stream, idle while the chain runs on the caller's), started when the pyramid ends, beside the
+            // upper levels' FAST instead of behind the side stream's quad-trees, and orientation + description of the LOWER levels on the side
+            // stream as soon as their quad-trees and the blur are done.  64 frames: 0.2570 ms per step as it is, 0.2631 with the blur on its own
+            // stream (it takes 75 us instead of 40 beside FAST and slows that down too), 0.2584 with the split launches on top: FAST, blur and
+            // description are all bound by the same VALUs, so moving them against each other buys nothing (tools/sweep_blur_stream.sh).
+            static const int envBlurStream = getenv("EAO_ORB_BLUR_STREAM") ? atoi(getenv("EAO_ORB_BLUR_STREAM")) : 0;
+            blurOwn = envBlurStream && envBlurEarly && onCaller && qtEarly && h->laneMain[i];
+            hipStream_t bs = blurOwn ? h->laneMain[i] : ss;
             if (envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
             fast(ms, early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
             if (!envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
-            EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
-            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
+            EAO_HIP(hipStreamWaitEvent(bs, h->evFork[i], 0));
+            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, bs, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
+            if (blurOwn) EAO_HIP(hipEventRecord(h->evBlur[i], bs));
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
+            // ... and orientation + description of the LOWER levels follow their quad-trees on the side stream as soon as the blur is
+            // done, beside the upper levels' quad-trees on the main stream (EAO_ORB_SPLIT=0: one launch for all levels at the end)
+            static const int envSplit = getenv("EAO_ORB_SPLIT") ? atoi(getenv("EAO_ORB_SPLIT")) : 1;
+            splitOD = blurOwn && envSplit;
+            if (splitOD) {
+                EAO_HIP(hipStreamWaitEvent(ss, h->evBlur[i], 0));
+                orient(ss, 0, mid, 0);
+                EAO_HIP(hipEventRecord(h->evLow[i], ss));
+            }
             if (early0 && !qtEarly) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
         }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
@@ -2185,9 +2217,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         // (the lower levels' quad-trees ran on the side stream, ahead of the blur: the wait for evJoin below covers them)
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
+        if (blurOwn) EAO_HIP(hipStreamWaitEvent(ms, h->evBlur[i], 0));
         if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
-        { eao::Range rg("orb: orientation + description"); hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, g.totalKpCap), 4), nb), dim3(256), 0, ms, h->d_geom.p, s,
-                           h->d_blur.p, h->d_levelkps.p, h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels); }
+        if (splitOD) {
+            orient(ms, mid, g.nlevels, 1);
+            EAO_HIP(hipStreamWaitEvent(ms, h->evLow[i], 0));
+        } else orient(ms, 0, g.nlevels, 1);
         if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
         if (!onCaller) {
             EAO_HIP(hipEventRecord(h->evDone[i], ms));
@@ -2322,6 +2357,8 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->evFast0[i]) (void)hipEventDestroy(h->evFast0[i]);
         if (h->evMid[i]) (void)hipEventDestroy(h->evMid[i]);
         if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
+        if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]);
+        if (h->evLow[i]) (void)hipEventDestroy(h->evLow[i]);
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
     if (h->pinOut) (void)hipHostFree(h->pinOut);
