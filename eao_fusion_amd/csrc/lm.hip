@@ -804,8 +804,8 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                         pose_accumulate_row<4>(acc, J2, wi, w * (info * eE[k][2]));
                     }
                     if (PLANES && M) {
-                        if (t < 13 * M) {
-                            const int p = t / 13, v = t - 13 * p;
+                        for (int pq = t; pq < 13 * M; pq += NT) {      // (a launch may have fewer threads than 13 M: 64 for a frame of 40 points)
+                            const int p = pq / 13, v = pq - 13 * p;
                             if (!(s_pflag[p] & 2)) {
                                 SE3 Tp = T;
                                 if (v) {
@@ -1078,7 +1078,7 @@ inline void launch_pose_registers(const PoseDev& P, int n, bool planes, hipStrea
         else hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseThreads>), dim3(1), b8, 0, s, P);
         return;
     }
-    const dim3 b(pose_threads(n));
+    const dim3 b(planes && n <= 4 * kPoseWaves4 ? std::max(pose_threads(n), std::min(kPoseWaves4, (13 * P.nPlanes + 63) / 64 * 64)) : pose_threads(n));
     switch (pose_class(n) + (planes ? 4 : 0)) {
         case 0: hipLaunchKernelGGL((k_pose_optimization<1, false, kPoseWaves4>), dim3(1), b, 0, s, P); break;
         case 1: hipLaunchKernelGGL((k_pose_optimization<2, false, kPoseWaves4>), dim3(1), b, 0, s, P); break;

@@ -169,6 +169,12 @@ def test_pose_optimization_parity(gpu, oracle, kw):
 
 @pytest.mark.parametrize("kw", [dict(n=300, seed=4200, n_planes=6), dict(n=12, seed=4201, n_planes=5, sigma=0.5, outlier_frac=0.0),
                                 dict(n=1500, seed=4202, n_planes=32), dict(n=40, seed=4203, n_planes=1, mono_frac=1.0),
+                                # fewer threads in the launch than 13 plane variants x planes (found by tools/sweep_pose.py: planes beyond the
+                                # launch's thread count were never evaluated)
+                                dict(n=54, seed=488437215, sigma=0.5, outlier_frac=0.1, mono_frac=0.0, n_planes=7),
+                                dict(n=34, seed=866062170, sigma=0.5, outlier_frac=0.0, mono_frac=1.0, n_planes=6),
+                                dict(n=27, seed=226023083, sigma=0.5, outlier_frac=0.3, mono_frac=0.3, n_planes=6),
+                                dict(n=100, seed=4204, n_planes=32), dict(n=700, seed=4205, n_planes=25),
                                 # beyond 2048 correspondences: the global-memory variant of the kernel carries the plane edges too
                                 dict(n=2600, seed=4204, n_planes=6), dict(n=3000, seed=4205, n_planes=32, mono_frac=0.5)])
 def test_pose_optimization_with_planes(gpu, oracle, kw):
