@@ -4515,7 +4515,7 @@ eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
     // frame as eight waves).  Waves without an edge leave a pass at once.
     P.devLo = -1; P.devHi = std::min(a.cap, 4 * kPoseWaves4);
     hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseWaves4>), dim3(1), dim3(kPoseWaves4), 0, s, P);
-    if (a.cap > 4 * kPoseWaves4) {
+    if (std::min(a.cap, a.maxEdges > 0 ? a.maxEdges : a.cap) > 4 * kPoseWaves4) {
         P.devLo = 4 * kPoseWaves4; P.devHi = a.cap;
         hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseThreads>), dim3(1), dim3(kPoseThreads), 0, s, P);
     }

@@ -541,6 +541,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     // without an event hand-over to a private stream and back (~10 us each on this runtime).  The handle's own stream only
     // carries the local-map uploads, which eao_tracker_set_local_map waits for.
     hipStream_t s = (hipStream_t)stream;
+    int nPrior = 0;
     if (prior_kp_map_point) {
         // Validated HERE: the kernels index the local map with these values.  An index beyond the uploaded map (e.g. a stale table
         // from before a smaller eao_tracker_set_local_map) is an error; a prior on an INACTIVE point is dropped -- the keypoint is free
@@ -553,6 +554,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
             EAO_REQUIRE(pm >= -2 && pm < nMp, "prior_kp_map_point[%d] = %d names no point of the local map (%d points)", k, (int)pm, nMp);
             if (pm >= 0 && !h->hActive[pm]) pm = -1;
             outside = outside || pm == -2;
+            nPrior += pm != -1;
             pr[k] = pm;
         }
         EAO_REQUIRE(!outside || prior_kp_Xw, "prior_kp_map_point holds -2 but prior_kp_Xw is NULL");
@@ -627,6 +629,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     else launch_assign(k_track_assign_edges<16>);
     eao::lm::PoseChainArgs PA;
     PA.nEdges = h->counts + 2; PA.cap = edgeCap;
+    PA.maxEdges = nMp + nPrior;        // every edge is a prior match or a new match, and new matches go to distinct local map points
     PA.Xw = h->eXw; PA.obs = h->eObs; PA.info = h->eInfo; PA.flags = h->eFlags; PA.err = h->eErr; PA.outlier = h->eOutl;
     std::memcpy(PA.Tcw0, Tcw_prior, 64);
     PA.fx = c.fx; PA.fy = c.fy; PA.cx = c.cx; PA.cy = c.cy; PA.bf = c.mbf;
