@@ -239,10 +239,46 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
     __syncthreads();
     long long ph[4] = {0, 0, 0, 0}, pt0 = dbg ? clock64() : 0;
     auto lap = [&](int k) { if (dbg && t == 0) { const long long now = clock64(); ph[k] += now - pt0; pt0 = now; } };
-    for (int round = 0; round < 4096; round++) {
-        for (int i = t; i < cap; i += kAssignThreads) minq[i] = 0x7FFFFFFF;
+    constexpr int kTagShift = 14, kPointMask = (1 << kTagShift) - 1;
+    static_assert(kPointMask >= 16384 - 1, "map-point indices must fit the key");
+    // upstream's scan over the candidates of point m that are free (:83-115) -- and, in the SAME walk, the smallest distance among the
+    // candidates an earlier undecided point also lists: the decision is final iff that distance is beyond everything it looked
+    // at with an effect (the second best; every candidate when fewer than two are free).  One walk instead of two, and the three
+    // LDS reads a candidate needs (occupancy, octave, earliest undecided lister) are independent of each other.
+    // Returns whether the decision is final; best = the keypoint the point takes (-1: none).
+    auto decide = [&](int m, int st, int cn, int& best) -> bool {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, earlierD = 0x7FFFFFFF;
+        for (int k = 0; k < cn; k += kWalk) {
+            unsigned itw[kWalk];
+#pragma unroll
+            for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn ? lists[st + k + j] : 0u;
+            unsigned char oc[kWalk], ol[kWalk];
+            int mq[kWalk];
+#pragma unroll
+            for (int j = 0; j < kWalk; j++) { const int i = (int)(itw[j] & 0xFFFF); oc[j] = occ[i]; ol[j] = octL[i]; mq[j] = minq[i]; }
+#pragma unroll
+            for (int j = 0; j < kWalk; j++) {
+                if (k + j >= cn) continue;
+                const int i = (int)(itw[j] & 0xFFFF), d = (int)(itw[j] >> 16);
+                if ((mq[j] & kPointMask) < m) earlierD = min(earlierD, d);
+                if (oc[j]) continue;
+                if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = ol[j]; bestIdx = i; }
+                else if (d < bestDist2) { bestLevel2 = ol[j]; bestDist2 = d; }
+            }
+        }
+        best = -1;
+        if (earlierD <= bestDist2) return false;
+        if (bestDist <= refc::TH_HIGH && !(bestLevel == bestLevel2 && bestDist > nnratio * bestDist2)) best = bestIdx;
+        return true;
+    };
+    // minq entries carry the round in their upper bits, counted DOWN: this round's claims are smaller than anything an earlier round left
+    // behind, so the array is never reset (a reset was a pass over `cap` entries and a barrier per round); every entry a decision reads
+    // has been claimed in the same round (at least by the point that reads it), i.e. its low 14 bits are this round's smallest lister.
+    for (int i = t; i < cap; i += kAssignThreads) minq[i] = 0x7FFFFFFF;
+    int tag = 0x1FFFF;
+    __syncthreads();
+    for (int round = 0; round < 4096; round++, tag--) {
         if (t == 0) s_left = 0;
-        __syncthreads();
         lap(0);
 #pragma unroll
         for (int u = 0; u < PER; u++)
@@ -256,7 +292,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
                     for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn_[u] ? lists[st_[u] + k + j] : 0u;
 #pragma unroll
                     for (int j = 0; j < kWalk; j++)
-                        if (k + j < cn_[u]) atomicMin(&minq[itw[j] & 0xFFFF], m);
+                        if (k + j < cn_[u]) atomicMin(&minq[itw[j] & 0xFFFF], (tag << kTagShift) | m);
                 }
             }
         __syncthreads();
@@ -266,37 +302,11 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
         for (int u = 0; u < PER; u++) {
             claim[u] = -1;
             if (!open[u]) continue;
-            const int m = t + u * kAssignThreads;
-            // upstream's scan over the candidates that are free (:83-115) -- and, in the SAME walk, the smallest distance among the
-            // candidates an earlier undecided point also lists: the decision is final iff that distance is beyond everything it looked
-            // at with an effect (the second best; every candidate when fewer than two are free).  One walk instead of two, and the three
-            // LDS reads a candidate needs (occupancy, octave, earliest undecided lister) are independent of each other.
-            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, earlierD = 0x7FFFFFFF;
-            for (int k = 0; k < cn_[u]; k += kWalk) {
-                unsigned itw[kWalk];
-#pragma unroll
-                for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn_[u] ? lists[st_[u] + k + j] : 0u;
-                unsigned char oc[kWalk], ol[kWalk];
-                int mq[kWalk];
-#pragma unroll
-                for (int j = 0; j < kWalk; j++) { const int i = (int)(itw[j] & 0xFFFF); oc[j] = occ[i]; ol[j] = octL[i]; mq[j] = minq[i]; }
-#pragma unroll
-                for (int j = 0; j < kWalk; j++) {
-                    if (k + j >= cn_[u]) continue;
-                    const int i = (int)(itw[j] & 0xFFFF), d = (int)(itw[j] >> 16);
-                    if (mq[j] < m) earlierD = min(earlierD, d);
-                    if (oc[j]) continue;
-                    if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = ol[j]; bestIdx = i; }
-                    else if (d < bestDist2) { bestLevel2 = ol[j]; bestDist2 = d; }
-                }
-            }
-            if (earlierD <= bestDist2) continue;        // not final yet
+            int best = -1;
+            if (!decide(t + u * kAssignThreads, st_[u], cn_[u], best)) continue;        // not final yet
             open[u] = false;
-            if (bestDist <= refc::TH_HIGH) {
-                if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
-                claim[u] = bestIdx;
-                mine[u] = bestIdx;
-            }
+            claim[u] = best;
+            mine[u] = best;
         }
         __syncthreads();      // every decision of the round was taken from the same occupancy
         lap(2);
@@ -313,7 +323,63 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
             if (wn) atomicAdd(&s_nm, wn);
         }
         __syncthreads();
+        if (dbg && t == 0 && round < 16) dbg[16 + round] = s_left;
         if (s_left == 0) { if (t == 0) counts[5] = round + 1; break; }
+        if (s_left <= 64) {
+            // ---- The undecided points halve from round to round (373, 182, 96, 52, 27, 12, 5 of 1000 on the benchmark frame) while a round of
+            //      the whole workgroup costs its five barriers and the reset of minq whatever is left (8 k cycles): the last 64 points are
+            //      handed to ONE wave, a lane each, which runs the SAME rounds with wavefront fences instead of workgroup barriers and resets
+            //      only the minq entries its lists name.
+            __shared__ int tM[64], tSt[64], tCn[64], tRes[64];
+            __shared__ int s_tail;
+            __syncthreads();
+            if (t == 0) s_tail = 0;
+            __syncthreads();
+            int slot[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                slot[u] = -1;
+                if (open[u]) {
+                    const int sl = atomicAdd(&s_tail, 1);
+                    slot[u] = sl; tM[sl] = t + u * kAssignThreads; tSt[sl] = st_[u]; tCn[sl] = cn_[u]; tRes[sl] = -1;
+                }
+            }
+            __syncthreads();
+            if (t < 64) {
+                const int nT = s_tail;
+                bool op = t < nT;
+                const int m = op ? tM[t] : 0, st = op ? tSt[t] : 0, cn = op ? tCn[t] : 0;
+                int res = -1, more = 0;
+                auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+                while (__any(op)) {
+                    more++;
+                    tag--;
+                    if (op)
+                        for (int k = 0; k < cn; k += kWalk) {
+                            unsigned itw[kWalk];
+#pragma unroll
+                            for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn ? lists[st + k + j] : 0u;
+#pragma unroll
+                            for (int j = 0; j < kWalk; j++)
+                                if (k + j < cn) atomicMin(&minq[itw[j] & 0xFFFF], (tag << kTagShift) | m);
+                        }
+                    wave_sync();
+                    int best = -1;
+                    const bool fin = op && decide(m, st, cn, best);
+                    wave_sync();          // every decision of the round was taken from the same occupancy
+                    if (fin) { op = false; res = best; if (best >= 0) occ[best] = 1; }
+                    wave_sync();
+                }
+                if (t < nT) tRes[t] = res;
+                const int nmw = (int)__popcll(__ballot(res >= 0));
+                if (t == 0) { s_nm += nmw; counts[5] = round + 1 + more; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if (slot[u] >= 0) mine[u] = tRes[slot[u]];
+            break;
+        }
         __syncthreads();
         lap(3);
     }
@@ -484,7 +550,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C) + al256(12 * C)) + 4096;
     if (hipHostMalloc((void**)&h->pin, h->pinCap, hipHostMallocDefault) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     // the assignment workgroup's LDS: claims / occupancy / octaves by keypoint, then the staged candidate lists (beyond the default 64 KB)
-    if (getenv("EAO_DEBUG_STAMPS")) { EAO_HIP(hipMalloc((void**)&h->dbg, 128)); EAO_HIP(hipMemset(h->dbg, 0, 128)); }
+    if (getenv("EAO_DEBUG_STAMPS")) { EAO_HIP(hipMalloc((void**)&h->dbg, 256)); EAO_HIP(hipMemset(h->dbg, 0, 256)); }
     h->assignLds = ((6 * C + 15) & ~(size_t)15) + 4 * (size_t)kLdsLists;
     EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
     EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
@@ -640,8 +706,11 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
     if (h->dbg) {
-        long long st[16];
+        long long st[32];
         EAO_HIP(hipMemcpy(st, h->dbg, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[eao track stamps]   points still undecided after each round:");
+        for (int k = 0; k < 16 && (k == 0 || st[16 + k - 1] > 0); k++) fprintf(stderr, " %lld", st[16 + k]);
+        fprintf(stderr, "\n");
         fprintf(stderr, "[eao track stamps]   rounds: init + reset %lld, claim walk %lld, decide %lld, commit %lld ticks\n", st[8], st[9], st[10], st[11]);
         int rounds = 0;
         EAO_HIP(hipMemcpy(&rounds, h->counts + 5, sizeof(int), hipMemcpyDeviceToHost));
