@@ -201,7 +201,8 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
 // Upstream walks the map points in index order; a keypoint assigned to an earlier point is skipped by every later one
 // (src/ORBmatcher.cc:87-89, 123).  A point's decision -- the two smallest (distance, list position) among its unoccupied
 // candidates, the TH_HIGH / ratio tests -- depends only on the occupancy of the candidates up to its second best.  Rounds:
-//   1. minq[k] = the smallest UNDECIDED point that lists keypoint k
+//   1. minq[k] = the smallest UNDECIDED point that lists keypoint k within TH_HIGH (a point can only ever take a keypoint at a distance
+//      <= TH_HIGH, so a more distant lister is no competitor: with every lister counted the rounds took 8 passes instead of 4 on the benchmark frame)
 //   2. every undecided point m decides from the claims that are final so far; it becomes final iff minq[k] >= m for every
 //      keypoint its decision depended on (no earlier undecided point can still take one of them) -- the smallest undecided
 //      point always does, and a claim never lands in the list of an earlier undecided point, so final decisions are exactly
@@ -216,17 +217,22 @@ template <int PER, typename ListT>
 __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query* __restrict__ q, ListT lists,
                                                   const int* __restrict__ segStart, const int* __restrict__ segCount,
                                                   const int* __restrict__ oct, unsigned char* occG, float nnratio,
-                                                  int* match, int* counts, long long* dbg = nullptr) {
+                                                  int* match, int* counts, int allListers, long long* dbg = nullptr) {
     extern __shared__ int asm_[];
     int* minq = asm_;                                           // cap
-    unsigned char* occ = reinterpret_cast<unsigned char*>(minq + cap);   // cap
-    unsigned char* octL = occ + cap;                            // cap: the keypoints' octaves (read per candidate in every round)
+    // own[k]: who holds keypoint k -- kFree, kPrior (occupied before the search: every point sees it) or the map point that claimed it, which
+    // only LATER points see: upstream walks the points in index order, so a claim by point p is invisible to every point before p.  (With a
+    // plain occupancy flag a point could only become final when no earlier undecided point listed its keypoint AT ALL -- an earlier point's
+    // second-best distance, hence its ratio test, would otherwise see the keypoint vanish.)
+    constexpr unsigned short kFree = 0xFFFF, kPrior = 0xFFFE;
+    unsigned short* own = reinterpret_cast<unsigned short*>(minq + cap);   // cap
+    unsigned char* octL = reinterpret_cast<unsigned char*>(own + cap);     // cap: the keypoints' octaves (read per candidate in every round)
     __shared__ int s_left, s_nm;
     const int t = threadIdx.x;
     // PER = map points per thread: 4, 8 or 16 (local maps of up to 4096 / 8192 / 16384 points)
     int st_[PER], cn_[PER], mine[PER];      // mine: the point's match (written to memory once, after the rounds)
     bool open[PER];
-    for (int i = t; i < cap; i += kAssignThreads) { occ[i] = occG[i]; octL[i] = (unsigned char)oct[i]; }
+    for (int i = t; i < cap; i += kAssignThreads) { own[i] = occG[i] ? kPrior : kFree; octL[i] = (unsigned char)oct[i]; }
     if (t == 0) s_nm = 0;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
@@ -239,6 +245,8 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
     __syncthreads();
     long long ph[4] = {0, 0, 0, 0}, pt0 = dbg ? clock64() : 0;
     auto lap = [&](int k) { if (dbg && t == 0) { const long long now = clock64(); ph[k] += now - pt0; pt0 = now; } };
+    const int listerBound = allListers ? 256 : refc::TH_HIGH;      // (debug A/B: EAO_TRACK_ALL_LISTERS=1 counts every lister)
+    int tag = 0x1FFFE;          // (the initial fill 0x7FFFFFFF reads as round 0x1FFFF: never the current one)
     constexpr int kTagShift = 14, kPointMask = (1 << kTagShift) - 1;
     static_assert(kPointMask >= 16384 - 1, "map-point indices must fit the key");
     // upstream's scan over the candidates of point m that are free (:83-115) -- and, in the SAME walk, the smallest distance among the
@@ -252,16 +260,17 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
             unsigned itw[kWalk];
 #pragma unroll
             for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn ? lists[st + k + j] : 0u;
-            unsigned char oc[kWalk], ol[kWalk];
+            unsigned char ol[kWalk];
+            unsigned short ow[kWalk];
             int mq[kWalk];
 #pragma unroll
-            for (int j = 0; j < kWalk; j++) { const int i = (int)(itw[j] & 0xFFFF); oc[j] = occ[i]; ol[j] = octL[i]; mq[j] = minq[i]; }
+            for (int j = 0; j < kWalk; j++) { const int i = (int)(itw[j] & 0xFFFF); ow[j] = own[i]; ol[j] = octL[i]; mq[j] = minq[i]; }
 #pragma unroll
             for (int j = 0; j < kWalk; j++) {
                 if (k + j >= cn) continue;
                 const int i = (int)(itw[j] & 0xFFFF), d = (int)(itw[j] >> 16);
-                if ((mq[j] & kPointMask) < m) earlierD = min(earlierD, d);
-                if (oc[j]) continue;
+                if ((mq[j] >> kTagShift) == tag && (mq[j] & kPointMask) < m) earlierD = min(earlierD, d);
+                if (ow[j] != kFree && (ow[j] == kPrior || (int)ow[j] < m)) continue;      // occupied when point m is reached
                 if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = ol[j]; bestIdx = i; }
                 else if (d < bestDist2) { bestLevel2 = ol[j]; bestDist2 = d; }
             }
@@ -275,7 +284,6 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
     // behind, so the array is never reset (a reset was a pass over `cap` entries and a barrier per round); every entry a decision reads
     // has been claimed in the same round (at least by the point that reads it), i.e. its low 14 bits are this round's smallest lister.
     for (int i = t; i < cap; i += kAssignThreads) minq[i] = 0x7FFFFFFF;
-    int tag = 0x1FFFF;
     __syncthreads();
     for (int round = 0; round < 4096; round++, tag--) {
         if (t == 0) s_left = 0;
@@ -292,7 +300,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
                     for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn_[u] ? lists[st_[u] + k + j] : 0u;
 #pragma unroll
                     for (int j = 0; j < kWalk; j++)
-                        if (k + j < cn_[u]) atomicMin(&minq[itw[j] & 0xFFFF], (tag << kTagShift) | m);
+                        if (k + j < cn_[u] && (int)(itw[j] >> 16) <= listerBound) atomicMin(&minq[itw[j] & 0xFFFF], (tag << kTagShift) | m);
                 }
             }
         __syncthreads();
@@ -314,7 +322,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
         int wl = 0, wn = 0;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            if (claim[u] >= 0) occ[claim[u]] = 1;
+            if (claim[u] >= 0) own[claim[u]] = (unsigned short)(t + u * kAssignThreads);
             wn += (int)__popcll(__ballot(claim[u] >= 0));
             wl += (int)__popcll(__ballot(open[u]));
         }
@@ -361,13 +369,13 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
                             for (int j = 0; j < kWalk; j++) itw[j] = k + j < cn ? lists[st + k + j] : 0u;
 #pragma unroll
                             for (int j = 0; j < kWalk; j++)
-                                if (k + j < cn) atomicMin(&minq[itw[j] & 0xFFFF], (tag << kTagShift) | m);
+                                if (k + j < cn && (int)(itw[j] >> 16) <= listerBound) atomicMin(&minq[itw[j] & 0xFFFF], (tag << kTagShift) | m);
                         }
                     wave_sync();
                     int best = -1;
                     const bool fin = op && decide(m, st, cn, best);
                     wave_sync();          // every decision of the round was taken from the same occupancy
-                    if (fin) { op = false; res = best; if (best >= 0) occ[best] = 1; }
+                    if (fin) { op = false; res = best; if (best >= 0) own[best] = (unsigned short)m; }
                     wave_sync();
                 }
                 if (t < nT) tRes[t] = res;
@@ -384,7 +392,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
         lap(3);
     }
     if (dbg && t == 0) { dbg[8] = ph[0]; dbg[9] = ph[1]; dbg[10] = ph[2]; dbg[11] = ph[3]; }
-    for (int i = t; i < cap; i += kAssignThreads) occG[i] = occ[i];
+    for (int i = t; i < cap; i += kAssignThreads) occG[i] = own[i] != kFree ? 1 : 0;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int m = t + u * kAssignThreads;
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
                                                                        const float* __restrict__ ur, const float* __restrict__ mXw, const float* __restrict__ priorXw,
                                                                        const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl,
                                                                        const float* __restrict__ dz, const unsigned char* __restrict__ inView, ResultBlock R,
-                                                                       long long* dbg) {
+                                                                       long long* dbg, int allListers) {
     extern __shared__ unsigned char asm_raw[];
     if (dbg && threadIdx.x == 0) dbg[0] = clock64();
     if (nMp > 0) {
@@ -461,14 +469,14 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
             // the candidate lists are ONE compact array (k_match_candidates fills it through an atomic cursor): when it fits, the
             // workgroup copies it into LDS once (coalesced) and the rounds walk it there
             const int total = *cursor;
-            unsigned* ldsLists = reinterpret_cast<unsigned*>(asm_raw + ((6 * (size_t)cap + 15) & ~(size_t)15));
+            unsigned* ldsLists = reinterpret_cast<unsigned*>(asm_raw + ((7 * (size_t)cap + 15) & ~(size_t)15));
             if (total <= kLdsLists) {
                 for (int i = threadIdx.x; i < total; i += kAssignThreads) ldsLists[i] = lists[i];
                 __syncthreads();
                 if (dbg && threadIdx.x == 0) { dbg[1] = clock64(); dbg[7] = total; }
-                track_assign_body<PER, const unsigned*>(nMp, cap, q, ldsLists, segStart, segCount, oct, occG, nnratio, match, counts, dbg);
+                track_assign_body<PER, const unsigned*>(nMp, cap, q, ldsLists, segStart, segCount, oct, occG, nnratio, match, counts, allListers, dbg);
             } else {
-                track_assign_body<PER, const unsigned* __restrict__>(nMp, cap, q, lists, segStart, segCount, oct, occG, nnratio, match, counts);
+                track_assign_body<PER, const unsigned* __restrict__>(nMp, cap, q, lists, segStart, segCount, oct, occG, nnratio, match, counts, allListers);
             }
         }
         __syncthreads();      // match[] is complete (and visible to the whole workgroup)
@@ -551,7 +559,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     if (hipHostMalloc((void**)&h->pin, h->pinCap, hipHostMallocDefault) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     // the assignment workgroup's LDS: claims / occupancy / octaves by keypoint, then the staged candidate lists (beyond the default 64 KB)
     if (getenv("EAO_DEBUG_STAMPS")) { EAO_HIP(hipMalloc((void**)&h->dbg, 256)); EAO_HIP(hipMemset(h->dbg, 0, 256)); }
-    h->assignLds = ((6 * C + 15) & ~(size_t)15) + 4 * (size_t)kLdsLists;
+    h->assignLds = ((7 * C + 15) & ~(size_t)15) + 4 * (size_t)kLdsLists;
     EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
     EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
     EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
@@ -685,10 +693,11 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
     unsigned char* rInView = r + ro; ro += al256((size_t)h->capMp);
     ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz, rInView};
+    static const int envAll = getenv("EAO_TRACK_ALL_LISTERS") ? atoi(getenv("EAO_TRACK_ALL_LISTERS")) : 0;
     auto launch_assign = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
                            nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
-                           h->inView, RB, h->dbg);
+                           h->inView, RB, h->dbg, envAll);
     };
     if (nMp <= 4 * kAssignThreads) launch_assign(k_track_assign_edges<4>);
     else if (nMp <= 8 * kAssignThreads) launch_assign(k_track_assign_edges<8>);

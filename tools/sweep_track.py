@@ -53,6 +53,9 @@ for it in range(N):
               and np.array_equal(got["kp_map_point"], want["kp_map_point"]) and got["n_edges"] == want["n_edges"] and got["n_inliers"] == want["n_inliers"]
               and np.array_equal(got["kp_outlier"], want["kp_outlier"]) and T._pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])[0])
         what = "matches %d / %d, edges %d / %d, inliers %d / %d" % (got["n_matches"], want["n_matches"], got["n_edges"], want["n_edges"], got["n_inliers"], want["n_inliers"])
+        if not ok and not np.array_equal(got["kp_map_point"], want["kp_map_point"]):
+            ks = np.nonzero(got["kp_map_point"] != want["kp_map_point"])[0]
+            what += "; mvpMapPoints differs at keypoints %s: got %s, oracle %s" % (ks[:6], got["kp_map_point"][ks[:6]], want["kp_map_point"][ks[:6]])
     except Exception as e:
         ok, what = False, "%s: %s" % (type(e).__name__, e)
     if not ok:
