@@ -482,6 +482,8 @@ struct PoseDev {
     double deltaPlane;
     GP<const int> scatterIdx;        // chained tracking: edge -> keypoint; the final outlier flags also land in scatterOut by keypoint
     GP<unsigned char> scatterOut;    // (null otherwise)
+    GP<int> done; int doneSeq;       // chained tracking: the LAST launch of the chain stores doneSeq here (mapped host memory) when everything
+                                     // the chain writes is visible to the host, which polls it instead of paying a stream synchronisation
 };
 
 constexpr int kPoseThreads = 512;
@@ -651,7 +653,10 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     const int NT = blockDim.x, nw = NT >> 6;
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = P.nDev ? min(*P.nDev, P.n) : P.n;
-    if (P.nDev && (n <= P.devLo || n > P.devHi)) return;      // another variant's frame (workgroup-uniform)
+    if (P.nDev && (n <= P.devLo || n > P.devHi)) {            // another variant's frame (workgroup-uniform)
+        if (P.done && t == 0) { __threadfence_system(); *P.done = P.doneSeq; }      // (the frame's own variant ran in front of this launch)
+        return;
+    }
     const float chi2Mono = refc::POSE_CHI2_MONO, chi2Stereo = refc::POSE_CHI2_STEREO;
     const Cam c = P.cam;
     double eX[EPT][3], eO[EPT][3], eI[EPT], eE[EPT][3];
@@ -1047,6 +1052,11 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
         }
     if (PLANES && t < M) P.planeOutlier[t] = s_pout[t];
     if (t == 0) { P.result[1] = iters; P.result[2] = ntrace; P.result[3] = npass | (nlight << 16); }
+    if (P.done) {      // every thread's stores (outlier flags by keypoint, the pose, the counts) before the flag
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0) { *P.done = P.doneSeq; }
+    }
     if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
     if (wstamp && lane == 0) { P.dbg[8 + wv] = wH; P.dbg[24 + wv] = wL; P.dbg[40 + wv] = wT; if (wv == 0) P.dbg[7] = nw; }
 }
@@ -3419,7 +3429,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     const bool zeroCopy = n <= 4 * kPoseThreads && M == 0 && !envUpload;      // (plane coefficients are re-read in every pass: uploaded)
     if (!zeroCopy) EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, off1 - off0, hipMemcpyHostToDevice, c.stream));
     PoseDev P;
-    P.nDev = nullptr; P.scatterIdx = nullptr; P.scatterOut = nullptr;
+    P.nDev = nullptr; P.scatterIdx = nullptr; P.scatterOut = nullptr; P.done = nullptr; P.doneSeq = 0;
     P.n = n; P.Xw = dXw; P.obs = dobs; P.info = dinfo; P.err = derr; P.flags = dflags; P.outlier = ooutl;
     if (zeroCopy) { P.Xw = (const double*)hostp(dXw); P.obs = (const double*)hostp(dobs); P.info = (const double*)hostp(dinfo); P.flags = (unsigned char*)hostp(dflags); }
     P.T0 = se3_from_Tcw_f32(p->Tcw);
@@ -4508,14 +4518,18 @@ eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
     P.cam.deltaMono = (float)std::sqrt(refc::POSE_HUBER2_MONO); P.cam.deltaStereo = (float)std::sqrt(refc::POSE_HUBER2_STEREO);
     P.Tout = (SE3*)a.outSE3; P.result = a.outResult; P.trace = a.outTrace;
     P.scatterIdx = a.scatterIdx; P.scatterOut = a.scatterOut;
+    P.done = nullptr; P.doneSeq = 0;
     P.nPlanes = 0; P.planes = nullptr; P.planeOutlier = nullptr; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
     P.dbg = nullptr;
     // The edge count lives on the device: one launch per geometry class the capacity admits (four waves up to 1024 edges, eight
     // beyond); each returns at its first instruction unless the frame's count falls in its range (a ~3 us launch, against running every
     // frame as eight waves).  Waves without an edge leave a pass at once.
+    const bool second = std::min(a.cap, a.maxEdges > 0 ? a.maxEdges : a.cap) > 4 * kPoseWaves4;
     P.devLo = -1; P.devHi = std::min(a.cap, 4 * kPoseWaves4);
+    if (!second) { P.done = a.done; P.doneSeq = a.doneSeq; }
     hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseWaves4>), dim3(1), dim3(kPoseWaves4), 0, s, P);
-    if (std::min(a.cap, a.maxEdges > 0 ? a.maxEdges : a.cap) > 4 * kPoseWaves4) {
+    if (second) {
+        P.done = a.done; P.doneSeq = a.doneSeq;
         P.devLo = 4 * kPoseWaves4; P.devHi = a.cap;
         hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseThreads>), dim3(1), dim3(kPoseThreads), 0, s, P);
     }

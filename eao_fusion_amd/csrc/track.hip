@@ -25,6 +25,8 @@
 //                    k_track_assign_edges -- a k_track_finish launch behind PoseOptimization until late in round 2)
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <atomic>
 #include <vector>
 
 #include "chain_internal.h"
@@ -54,6 +56,7 @@ struct eao_tracker {
     unsigned char* res = nullptr;      // result block: device view of resPin, resBytes
     unsigned char* resPin = nullptr;
     size_t resBytes = 0, listCap = 0, assignLds = 0;
+    int seq = 0;                       // call counter: the chain's last launch stores it in the result block's done word
     long long* dbg = nullptr;          // EAO_DEBUG_STAMPS: phase stamps of k_track_assign_edges (diagnostic runs only)
     ~eao_tracker() {
         if (pin) (void)hipHostFree(pin);
@@ -534,7 +537,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
                  oEX = take(24 * C), oEO = take(24 * C), oEI = take(8 * C), oEE = take(24 * C), oEF = take(C), oEOu = take(C), oEK = take(4 * C),
                  oSc = take(4 * 64), oIs = take(4 * 64), oCol = take(4 * ((size_t)cfg->grid_cols + 1));
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
-    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C) + al256(M);
+    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C) + al256(M) + 256;      // (+ the done word)
     if ((st = h->dev.reserve(off))) { delete h; return st; }
     unsigned char* b = h->dev.p;
     h->kx = (float*)(b + oKx); h->ky = (float*)(b + oKy); h->ang = (float*)(b + oAng); h->ur = (float*)(b + oUr); h->dz = (float*)(b + oDz);
@@ -550,7 +553,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     h->colStart = (int*)(b + oCol);
     // the result block is MAPPED PINNED HOST memory: the last kernels of the chain write it over PCIe (~30 KB) and the host reads it
     // after the one synchronisation -- no device-to-host copy behind the chain
-    if (hipHostMalloc((void**)&h->resPin, h->resBytes, hipHostMallocMapped) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
+    if (hipHostMalloc((void**)&h->resPin, h->resBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     std::memset(h->resPin, 0, h->resBytes);
     if (hipHostGetDevicePointer((void**)&h->res, h->resPin, 0) != hipSuccess) { delete h; eao::set_error("hipHostGetDevicePointer failed"); return EAO_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming) != hipSuccess ||
@@ -692,6 +695,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
     unsigned char* rInView = r + ro; ro += al256((size_t)h->capMp);
+    int* rDone = (int*)(r + ro); ro += 256;
     ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz, rInView};
     static const int envAll = getenv("EAO_TRACK_ALL_LISTERS") ? atoi(getenv("EAO_TRACK_ALL_LISTERS")) : 0;
     auto launch_assign = [&](auto kern) {
@@ -710,9 +714,23 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     PA.fx = c.fx; PA.fy = c.fy; PA.cx = c.cx; PA.cy = c.cy; PA.bf = c.mbf;
     PA.outSE3 = rSE3; PA.outResult = rRes; PA.outTrace = rTrace;
     PA.scatterIdx = h->eKp; PA.scatterOut = rOutl;      // mvbOutlier by keypoint, straight into the result block
+    // The results are in mapped host memory when the chain's last launch has stored this call's number in the done word: the host polls
+    // that word (the posted writes of the kernel arrive in order) instead of waiting for the runtime to notice the end of the stream --
+    // EAO_TRACK_POLL=0 goes back to hipStreamSynchronize, which is also what a call falls back to after 50 ms without the word.
+    static const int envPoll = getenv("EAO_TRACK_POLL") ? atoi(getenv("EAO_TRACK_POLL")) : 1;
+    const int seq = ++h->seq;
+    if (envPoll) { PA.done = rDone; PA.doneSeq = seq; }
     if ((st = eao::lm::enqueue_pose_device(PA, s))) return st;
-    // ---- the results are in host memory when the stream has drained
-    EAO_HIP(hipStreamSynchronize(s));
+    // ---- the results are in host memory when the done word says so (or when the stream has drained)
+    bool seen = false;
+    if (envPoll) {
+        const volatile int* done = reinterpret_cast<const volatile int*>(h->resPin + ((unsigned char*)rDone - r));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; !(seen = *done == seq); spins++)
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
     if (h->dbg) {
         long long st[32];

@@ -53,6 +53,11 @@ for it in range(N):
               and np.array_equal(got["kp_map_point"], want["kp_map_point"]) and got["n_edges"] == want["n_edges"] and got["n_inliers"] == want["n_inliers"]
               and np.array_equal(got["kp_outlier"], want["kp_outlier"]) and T._pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])[0])
         what = "matches %d / %d, edges %d / %d, inliers %d / %d" % (got["n_matches"], want["n_matches"], got["n_edges"], want["n_edges"], got["n_inliers"], want["n_inliers"])
+        if not ok:
+            pc = T._pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])
+            what += "; differing: %s; pose |d| %.3e vs update %.3e" % ([k for k, a, b in (("u_right", got["u_right"], want["u_right"]), ("depth", got["depth"], want["depth"]),
+                ("in_view", got["map_in_view"].astype(bool)[pj], want["in_view"][pj]), ("kp_map_point", got["kp_map_point"], want["kp_map_point"]),
+                ("kp_outlier", got["kp_outlier"], want["kp_outlier"])) if not np.array_equal(a, b)], pc[1], pc[2])
         if not ok and not np.array_equal(got["kp_map_point"], want["kp_map_point"]):
             ks = np.nonzero(got["kp_map_point"] != want["kp_map_point"])[0]
             what += "; mvpMapPoints differs at keypoints %s: got %s, oracle %s" % (ks[:6], got["kp_map_point"][ks[:6]], want["kp_map_point"][ks[:6]])
