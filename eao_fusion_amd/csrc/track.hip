@@ -85,9 +85,9 @@ constexpr int kFrameThreads = 1024;
 __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoint* __restrict__ kps, const int* __restrict__ nPtr, int cap,
                                                                const float* __restrict__ depth, int pitch, int W, int H, float mbf,
                                                                float minX, float minY, float invW, float invH, int cols, int rows, int npow2,
-                                                               int nMp, FrameArrays A, eao::frame::FrustumArgs FA) {
+                                                               int nMp, FrameArrays A, eao::frame::FrustumArgs FA, long long* dbg, int countingSort) {
     extern __shared__ unsigned tkeys[];
-    __shared__ int s_cnt;
+    __shared__ int s_cnt, s_maxc, s_wtot[kFrameThreads / 64];
     const int t = threadIdx.x;
     // Workgroups 1.. : Frame::isInFrustum over the local map points (independent of the keypoints) beside workgroup 0's frame
     // set-up -- as a launch of its own it cost 4.5 us plus a launch gap in front of every tracked frame's searches
@@ -96,9 +96,11 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
         if (m < FA.n) eao::frame::frustum_point(FA, m);
         return;
     }
+    if (dbg && t == 0) dbg[24] = clock64();
     const int n = min(max(*nPtr, 0), cap);
-    if (t == 0) { s_cnt = 0; *A.cursor = 0; }
+    if (t == 0) { s_cnt = 0; *A.cursor = 0; s_maxc = 0; }
     for (int m = t; m < nMp; m += kFrameThreads) A.mSkip[m] = 0;
+    if (countingSort) for (int c = t; c <= cols * rows; c += kFrameThreads) tkeys[npow2 + c] = 0;      // (the cell histogram of the counting sort below)
     __syncthreads();
     for (int i = t; i < npow2; i += kFrameThreads) {
         unsigned key = 0xFFFFFFFFu;
@@ -127,7 +129,65 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
         tkeys[i] = key;
     }
     __syncthreads();
-    if (npow2 >= 128 && npow2 <= 2 * kFrameThreads) {
+    if (dbg && t == 0) dbg[25] = clock64();
+    // ---- The keys (cell << 16 | keypoint) in ascending order = the keypoints cell by cell, by index inside a cell.  Cells hold a keypoint or two
+    //      (1100 keypoints over 3072 cells), so a COUNTING sort does it in five barrier phases: histogram of the cells (LDS atomics), exclusive scan
+    //      (three cells per thread, DPP wave scan, sixteen wave totals), scatter through per-cell cursors (arrival order), and every cell's few
+    //      entries put in index order by the thread that owns the cell.  The column starts of the walk lists ARE the scan.  (The bitonic network
+    //      below took 31 k of this workgroup's 46 k cycles for 2048 keys: 51 shuffle steps and 14 LDS steps with two barriers each.)  A cell with
+    //      more than 32 keypoints (or a grid beyond the LDS budget) sends the frame through the network instead.
+    const int cells = cols * rows;
+    bool counted = false;
+    const unsigned* sorted = tkeys;      // where the sorted keys end up
+    int inGrid = -1;                     // counting sort: the number of keypoints inside the grid (entries of `sorted` beyond it are not keys)
+    if (countingSort) {
+        unsigned* hist = tkeys + npow2;              // cells + 1 counters, then the scan
+        unsigned* outk = hist + cells + 1;           // npow2 sorted keys
+        for (int i = t; i < npow2; i += kFrameThreads) { const unsigned key = tkeys[i]; if (key != 0xFFFFFFFFu) atomicAdd(&hist[key >> 16], 1u); }
+        __syncthreads();
+        // exclusive scan over the cells: thread t owns cells [t * per, t * per + per)
+        const int per = (cells + kFrameThreads - 1) / kFrameThreads;
+        unsigned loc[8], sum = 0, mx = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int c = t * per + q; loc[q] = (q < per && c < cells) ? hist[c] : 0u; sum += loc[q]; mx = max(mx, loc[q]); }
+        unsigned inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)inc, d); if ((t & 63) >= d) inc += o; }
+        if ((t & 63) == 63) s_wtot[t >> 6] = (int)inc;
+        if (mx) atomicMax(&s_maxc, (int)mx);
+        __syncthreads();
+        unsigned base = inc - sum;
+        for (int w = 0; w < (t >> 6); w++) base += (unsigned)s_wtot[w];
+        if (s_maxc <= 32 && per <= 8) {
+            counted = true;
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const int c = t * per + q; if (q < per && c < cells) { hist[c] = base; base += loc[q]; } }
+            if (t == kFrameThreads - 1) hist[cells] = base;      // (the last thread's running sum = the number of keypoints inside the grid)
+            __syncthreads();
+            // scatter: outk[start(cell) + arrival], the cell's cursor = its start counted up (restored from the next cell's start afterwards)
+            for (int i = t; i < npow2; i += kFrameThreads) { const unsigned key = tkeys[i]; if (key != 0xFFFFFFFFu) outk[atomicAdd(&hist[key >> 16], 1u)] = key; }
+            __syncthreads();
+            // every cell's entries by index (insertion sort of <= 32 keys by the cell's owner); hist[c] now holds the cell's END
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int c = t * per + q;
+                if (q < per && c < cells && loc[q] > 1) {
+                    const unsigned e = hist[c], b = e - loc[q];
+                    for (unsigned a2 = b + 1; a2 < e; a2++) {
+                        const unsigned v = outk[a2];
+                        unsigned z = a2;
+                        while (z > b && outk[z - 1] > v) { outk[z] = outk[z - 1]; z--; }
+                        outk[z] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            inGrid = (int)hist[cells];
+            sorted = outk;
+        }
+    }
+    if (counted) {
+    } else if (npow2 >= 128 && npow2 <= 2 * kFrameThreads) {
         // Two keys per thread in REGISTERS (elements t and t + npow2 / 2, both exchange with thread t ^ j): the 51 of 66 steps
         // whose partner sits in the same wave are shuffles, the step j = npow2 / 2 is a swap of the thread's own pair, and
         // only the 14 steps with 64 <= j < npow2 / 2 go through LDS and a workgroup barrier (all 66 did: 30 us for 2048 keys).
@@ -175,9 +235,10 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
             __syncthreads();
         }
     }
+    if (dbg && t == 0) dbg[26] = clock64();
     int mine = 0;
     for (int i = t; i < npow2; i += kFrameThreads) {
-        const unsigned key = tkeys[i];
+        const unsigned key = (inGrid < 0 || i < inGrid) ? sorted[i] : 0xFFFFFFFFu;
         if (key != 0xFFFFFFFFu) {
             const int cell = (int)(key >> 16);
             A.order[i] = (int)(key & 0xFFFFu);
@@ -190,6 +251,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
     // first walk-list entry of every grid column (binary search over the sorted keys; keys of keypoints outside the grid are
     // 0xFFFFFFFF and sort behind every cell): a search window then walks its one or two columns, not the whole frame
     for (int cI = t; cI <= cols; cI += kFrameThreads) {
+        if (counted) { A.colStart[cI] = cI ? (int)tkeys[npow2 + cI * rows - 1] : 0; continue; }      // the END of the previous column's last cell (the scan, counted up by the scatter)
         const unsigned want = (unsigned)(cI * rows);
         int lo = 0, hi = npow2;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if ((tkeys[mid] >> 16) < want) lo = mid + 1; else hi = mid; }
@@ -197,6 +259,7 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
     }
     __syncthreads();
     if (t == 0) { A.counts[0] = n; A.counts[1] = s_cnt; A.counts[2] = 0; A.counts[3] = 0; A.counts[4] = 0; }
+    if (dbg && t == 0) dbg[27] = clock64();
 }
 
 // ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th), src/ORBmatcher.cc:51-81: the window of every point in view
@@ -664,8 +727,11 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
         F.inView = h->inView; F.projX = h->projX; F.projY = h->projY; F.projXR = h->projXR; F.viewCos = h->viewCos; F.level = h->level;
         eao::frame::fill_frustum_args(F, FA);
     }
-    hipLaunchKernelGGL(k_track_frame, dim3(1 + (nMp > 0 ? eao::cdiv(nMp, kFrameThreads) : 0)), dim3(kFrameThreads), (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth,
-                       depth_pitch, width, height, c.mbf, c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A, FA);
+    static const int envCount = getenv("EAO_TRACK_COUNTING_SORT") ? atoi(getenv("EAO_TRACK_COUNTING_SORT")) : 1;      // (A/B switch)
+    const size_t cells = (size_t)c.grid_cols * c.grid_rows, countLds = (2 * (size_t)npow2 + cells + 1) * 4;
+    const int countingSort = envCount && cells <= 8 * kFrameThreads && countLds <= 60 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(k_track_frame, dim3(1 + (nMp > 0 ? eao::cdiv(nMp, kFrameThreads) : 0)), dim3(kFrameThreads), countingSort ? countLds : (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth,
+                       depth_pitch, width, height, c.mbf, c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A, FA, h->dbg, countingSort);
     eao_status st;
     if (nMp > 0) {
         // the search windows are built by the candidate kernel itself (one wave per map point), which leaves them in h->q for the assignment
@@ -735,6 +801,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     if (h->dbg) {
         long long st[32];
         EAO_HIP(hipMemcpy(st, h->dbg, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[eao track stamps] frame set-up (workgroup 0): records + depth + keys %lld, sort %lld, order / cells / column starts %lld ticks\n", st[25] - st[24], st[26] - st[25], st[27] - st[26]);
         fprintf(stderr, "[eao track stamps]   points still undecided after each round:");
         for (int k = 0; k < 16 && (k == 0 || st[16 + k - 1] > 0); k++) fprintf(stderr, " %lld", st[16 + k]);
         fprintf(stderr, "\n");
