@@ -2319,6 +2319,9 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(const BADev* __
     if (first && bx == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
     const int cnt = P.pairCnt[bx];
     const int* pts = P.pairPts + (size_t)bx * P.nL;
+    const bool stampS = P.dbg && bx == 0 && t == 0;
+    long long sp0 = 0, sp1 = 0, sp2 = 0;
+    if (stampS) sp0 = clock64();
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; q++) acc[q] = 0;
@@ -2347,7 +2350,9 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(const BADev* __
             }
         }
     }
+    if (stampS) sp1 = clock64();
     block_sum_lds<42, kPairThreads>(acc, red, part);
+    if (stampS) { sp2 = clock64(); P.dbg[13] = sp1 - sp0; P.dbg[14] = sp2 - sp1; P.dbg[15] = cnt; }
     const TileGeom g = tile_geom(nF);
     if (t < 36) {
         const int r = t / 6, c = t - r * 6;
@@ -4181,6 +4186,7 @@ struct BAJob {
         if (D.dbg) {
             long long stt[16];
             EAO_HIP(hipMemcpy(stt, D.dbg, sizeof(stt), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[eao pair stamps] workgroup 0 (diagonal pair, %lld landmarks): loads + accumulation %lld, block sum of 42 values %lld shader-cycles\n", stt[15], stt[13], stt[14]);
             fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld / %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
                     stt[2] - stt[0], stt[4] - stt[2], stt[10], stt[11], stt[12], stt[6] - stt[4], stt[8] - stt[6], stt[3] - stt[1], stt[5] - stt[3], stt[7] - stt[5], stt[9] - stt[7]);
         }

@@ -939,21 +939,28 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
         // The candidates are in spatial order (cells row-major, corners row-major inside a cell), so neighbouring lanes mostly
         // hit the same (node, quadrant) bin: one LDS atomic per RUN of equal bins in the wave instead of one per candidate
         // (while the tree is shallow, thousands of atomics would otherwise queue on a handful of words).
-        for (int k0 = 0; k0 < M; k0 += kQT) {
-            const int k = k0 + t;
-            int bin = -1;
-            if (k < M) {
-                const int nd = nof[k];
-                const unsigned md = mid[nd];
-                if (md != kQtLeaf) bin = 4 * nd + quadrant_mid(keys[k], md);
-            }
-            const int prev = __builtin_amdgcn_update_dpp(-2, bin, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -2): VALU, not the LDS crossbar
-            const bool head = bin != prev;
-            const unsigned long long hm = __ballot(head);
-            if (head && bin >= 0) {
-                const unsigned long long rest = lane == 63 ? 0ull : (hm >> (lane + 1));
-                const int run = rest ? __ffsll((long long)rest) : 64 - lane;
-                atomicAdd(&childcnt[bin], run);
+        // (FOUR rows of kQT candidates per trip: node, key, split point of all four are fetched before any of them is used -- as one row
+        //  per trip the sweep was a chain of three dependent LDS reads and an atomic, twelve times over for level 0: 7 k cycles per pass)
+        for (int k0 = 0; k0 < M; k0 += 4 * kQT) {
+            int nd[4], bin[4];
+            unsigned ky[4], md[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int k = k0 + u * kQT + t; nd[u] = k < M ? (int)nof[k] : -1; ky[u] = k < M ? keys[k] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) md[u] = nd[u] >= 0 ? mid[nd[u]] : kQtLeaf;
+#pragma unroll
+            for (int u = 0; u < 4; u++) bin[u] = md[u] != kQtLeaf ? 4 * nd[u] + quadrant_mid(ky[u], md[u]) : -1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (k0 + u * kQT >= M) break;          // (uniform)
+                const int prev = __builtin_amdgcn_update_dpp(-2, bin[u], 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -2): VALU, not the LDS crossbar
+                const bool head = bin[u] != prev;
+                const unsigned long long hm = __ballot(head);
+                if (head && bin[u] >= 0) {
+                    const unsigned long long rest = lane == 63 ? 0ull : (hm >> (lane + 1));
+                    const int run = rest ? __ffsll((long long)rest) : 64 - lane;
+                    atomicAdd(&childcnt[bin[u]], run);
+                }
             }
         }
         __syncthreads();
