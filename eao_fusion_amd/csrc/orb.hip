@@ -150,14 +150,9 @@ inline void resize_coef_host(int d, double inv, int slimit, bool clampHi, int* o
     *wpair = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
 }
 
-__global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) {
+// one work item of a level: kResizeRows output rows x 4 output pixels of frame f
+__device__ __forceinline__ void resize_item(const ResizeArgs& A, const ImgSrc& s, int f, int item) {
     const ResizeLevel D = A.D, S = A.S;
-    const int bxi = blockIdx.x;
-    const int f = blockIdx.z + f0;
-    // work items = (group of kResizeRows output rows) x (4-pixel group), dealt to the lanes in one flat sequence: with a
-    // 256-pixel-wide block per row group the levels whose width is just above a multiple of 256 left up to half of the
-    // lanes idle (257 px -> two blocks; measured 240 -> 181 us for the seven launches of a 256-frame batch)
-    const int item = (bxi * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x;
     const int rg = (int)(((float)item + 0.5f) * A.invG);
     const int dyb = rg * kResizeRows;
     const int dx0 = (item - rg * A.G) * 4;
@@ -233,6 +228,28 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
                 o[i] = (uint8_t)min(max(v, 0), 255);
             }
         }
+    }
+}
+__global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) {
+    // work items = (group of kResizeRows output rows) x (4-pixel group), dealt to the lanes in one flat sequence: with a
+    // 256-pixel-wide block per row group the levels whose width is just above a multiple of 256 left up to half of the
+    // lanes idle (257 px -> two blocks; measured 240 -> 181 us for the seven launches of a 256-frame batch)
+    resize_item(A, s, blockIdx.z + f0, ((int)blockIdx.x * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x);
+}
+// The TOP of the pyramid in one launch: the upper levels are small (level 4 of a 640 x 480 frame is 309 x 231) and each is a resize of the one
+// below, so as launches of their own they are a chain of ~10 us steps on the step's critical path (pyramid -> FAST of the upper levels ->
+// their quad-trees -> description).  Here ONE workgroup per frame walks the levels first .. last in turn: all items of a level, a workgroup
+// barrier (the level it just wrote is the next one's source: same workgroup, global memory), the next level.  Same items, same arithmetic.
+constexpr int kResizeTopThreads = 1024, kResizeTopLevels = 6;
+struct ResizeTopArgs { int n; ResizeArgs L[kResizeTopLevels]; };
+__global__ __launch_bounds__(kResizeTopThreads) void k_resize_top(ResizeTopArgs T, ImgSrc s, int f0) {
+    const int f = blockIdx.x + f0;
+    for (int q = 0; q < T.n; q++) {
+        const ResizeArgs& A = T.L[q];
+        const int items = A.G * ((A.D.h + kResizeRows - 1) / kResizeRows);
+        for (int item = threadIdx.x; item < items; item += kResizeTopThreads) resize_item(A, s, f, item);
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -2139,6 +2156,8 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             fast(ss, 0, cells0);
         }
         bool blurOwn = false, splitOD = false;
+        ResizeTopArgs top;
+        top.n = 0;
         auto orient = [&](hipStream_t str, int lFirst, int lEnd, int writeN) {
             eao::Range rg("orb: orientation + description");
             const int rangeCap = (lEnd < g.nlevels ? g.L[lEnd].kpBase : g.totalKpCap) - g.L[lFirst].kpBase;
@@ -2160,6 +2179,16 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             ra.S = {g.L[l - 1].w, g.L[l - 1].h, g.L[l - 1].pitch, g.L[l - 1].off};
             ra.invX = 1. / ((double)g.L[l].w / g.L[l - 1].w); ra.invY = 1. / ((double)g.L[l].h / g.L[l - 1].h);
             ra.srcIsInput = l == 1; ra.pyrFrameBytes = g.pyrFrameBytes;
+            // levels topFrom .. nlevels-1 in ONE launch (k_resize_top), measured and NOT the default (EAO_ORB_TOP_FROM=3..6 switches it on): 64 frames,
+            // ms per step: off 0.2540, from level 3: 0.2736, 4: 0.2721, 5: 0.2657, 6: 0.2579 -- one workgroup per frame walks a level's items five
+            // deep where the chain's launches spread them over the chip; the launches it saves were cheaper (tools/sweep_top.sh)
+            static const int envTop = getenv("EAO_ORB_TOP_FROM") ? atoi(getenv("EAO_ORB_TOP_FROM")) : 0;
+            const int topFrom = (!prof && envTop >= 3 && envTop > mid - 1 && envTop < g.nlevels && g.nlevels - envTop <= kResizeTopLevels && nb >= 16) ? envTop : 0;
+            if (topFrom && l >= topFrom) {
+                top.L[top.n++] = ra;
+                if (l == g.nlevels - 1) { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_resize_top, dim3(nb), dim3(kResizeTopThreads), 0, ms, top, s, f0); }
+                continue;
+            }
             { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_resize, grid, block, 0, ms, ra, s, f0); }
             if (l == mid - 1) {
                 EAO_HIP(hipEventRecord(h->evMid[i], ms));
