@@ -1719,6 +1719,8 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
     const int cur = P.ctl[kCtlCur];
     const SE3* cams = P.camsBuf[cur];
     const double* pts = P.ptsBuf[cur];
+    const bool stampL = P.dbg && threadIdx.x == 0 && ((int)bx == 0 || (int)bx == ptBlocks);
+    const long long tl0 = stampL ? clock64() : 0;
     if ((int)bx < ptBlocks) {
         // role A: eight lanes per landmark, one edge per lane; Hll / bl are xor-tree sums over the lane group
         const int l = (bx * NT + threadIdx.x) >> 3, slot = threadIdx.x & 7;
@@ -1797,6 +1799,7 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
                 atomicMax((unsigned long long*)&P.lm[3], (unsigned long long)__double_as_longlong(m));
             }
         }
+        if (stampL) P.dbg[14] = clock64() - tl0;
     } else {
         const int ci = bx - ptBlocks;
         const int cam = P.actCam[ci];
@@ -1850,6 +1853,7 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
                 atomicMax((unsigned long long*)&P.lm[3], (unsigned long long)__double_as_longlong(m));
             }
         }
+        if (stampL) P.dbg[15] = clock64() - tl0;
     }
 }
 
@@ -2352,7 +2356,7 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_schur_pairs(const BADev* __
     }
     if (stampS) sp1 = clock64();
     block_sum_lds<42, kPairThreads>(acc, red, part);
-    if (stampS) { sp2 = clock64(); P.dbg[13] = sp1 - sp0; P.dbg[14] = sp2 - sp1; P.dbg[15] = cnt; }
+    if (stampS) { sp2 = clock64(); P.dbg[13] = ((sp1 - sp0) << 20) | (sp2 - sp1); }
     const TileGeom g = tile_geom(nF);
     if (t < 36) {
         const int r = t / 6, c = t - r * 6;
@@ -4186,7 +4190,8 @@ struct BAJob {
         if (D.dbg) {
             long long stt[16];
             EAO_HIP(hipMemcpy(stt, D.dbg, sizeof(stt), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[eao pair stamps] workgroup 0 (diagonal pair, %lld landmarks): loads + accumulation %lld, block sum of 42 values %lld shader-cycles\n", stt[15], stt[13], stt[14]);
+            fprintf(stderr, "[eao pair stamps] workgroup 0 (a diagonal pair): loads + accumulation %lld, block sum of 42 values %lld shader-cycles; linearisation: landmark workgroup 0 %lld, camera workgroup 0 %lld\n",
+                    stt[13] >> 20, stt[13] & 0xFFFFF, stt[14], stt[15]);
             fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld / %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
                     stt[2] - stt[0], stt[4] - stt[2], stt[10], stt[11], stt[12], stt[6] - stt[4], stt[8] - stt[6], stt[3] - stt[1], stt[5] - stt[3], stt[7] - stt[5], stt[9] - stt[7]);
         }
