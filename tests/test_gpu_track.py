@@ -318,3 +318,40 @@ def test_tracker_without_correspondences_keeps_the_prior():
     got = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), None, 0, 640, 480, cur["Tcw"], None, 1.0, 0.8, 0)
     assert got["n_matches"] == 0 and got["n_edges"] == 0 and got["n_inliers"] == 0
     assert np.array_equal(got["Tcw"], cur["Tcw"]) and (got["u_right"] == -1).all() and not got["kp_outlier"].any()
+
+
+def test_crowded_grid_cell_takes_the_sorting_network(oracle):
+    """The frame set-up orders the (cell, keypoint) keys by a counting sort when no grid cell holds more than 32 keypoints, by the bitonic
+    network otherwise: 70 keypoints moved into ONE cell (and 40 more onto one of its borders) must give the oracle chain's tables all the same."""
+    cur, kps, desc, depth, pts, prior = _scene(7130, n=700)
+    rng = np.random.default_rng(7130)
+    N = len(kps)
+    crowd = rng.choice(N, 110, replace=False)
+    kps["x"][crowd[:70]] = (205.0 + rng.uniform(0.5, 9.0, 70)).astype(np.float32)      # cell (20 or 21, 20) of the 64 x 48 grid: 10 px cells
+    kps["y"][crowd[:70]] = (203.0 + rng.uniform(0.5, 6.5, 70)).astype(np.float32)
+    kps["x"][crowd[70:]] = np.float32(215.0)                                              # exactly on a cell border (round half away from zero)
+    kps["y"][crowd[70:]] = (150.0 + rng.uniform(0, 100, 40)).astype(np.float32)
+    depth[kps["y"].astype(int), kps["x"].astype(int)] = rng.uniform(1.8, 6.2, N).astype(np.float32)
+    cur = dict(cur); cur["kp_x"], cur["kp_y"] = np.ascontiguousarray(kps["x"]), np.ascontiguousarray(kps["y"])
+    want = _chain(_OracleCalls(oracle), cur, kps, desc, depth, pts, prior, 5.0, 0.8)
+    cap = 2048
+    trk = _tracker(cur, cap, 2048)
+    trk.set_local_map(pts)
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+    got = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], prior, 5.0, 0.8,
+                              torch.cuda.current_stream().cuda_stream)
+    assert got["n_matches"] == want["n_matches"] and want["n_matches"] > 50
+    assert np.array_equal(got["kp_map_point"], want["kp_map_point"]) and np.array_equal(got["kp_outlier"], want["kp_outlier"])
+    assert np.array_equal(got["u_right"], want["u_right"]) and got["n_inliers"] == want["n_inliers"]
+
+
+def test_fallback_paths_of_the_chain():
+    """The chain's switchable paths (stream synchronisation instead of the polled done word, the sorting network instead of the counting sort,
+    every lister a competitor in the assignment rounds) against the oracle chain: a short randomised sweep in a process of its own, because the
+    switches are read once per process."""
+    import os, subprocess, sys
+    env = dict(os.environ, EAO_TRACK_POLL="0", EAO_TRACK_COUNTING_SORT="0", EAO_TRACK_ALL_LISTERS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "sweep_track.py"), "17", "16"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "tracker sweep: 16 frames, 0 mismatches" in out.stdout, out.stdout[-2000:]
