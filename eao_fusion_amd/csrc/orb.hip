@@ -1711,7 +1711,7 @@ struct eao_orb {
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
     bool evLastValid = false, capturing = false;   // evLastValid: a call has been enqueued on lastStream
     hipStream_t lastStream = nullptr;      // the stream of the previous call: compared, never dereferenced (its owner may have destroyed it)
-    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {}, evBlur[kLanes] = {}, evLow[kLanes] = {};
+    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {}, evBlur[kLanes] = {}, evLow[kLanes] = {}, evUp[kLanes] = {}, evUpDone[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
     eao::DevBuf<uint8_t> d_pyr, d_blur, d_in;
@@ -1992,6 +1992,8 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
             EAO_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evLow[i], hipEventDisableTiming));
+            EAO_HIP(hipEventCreateWithFlags(&h->evUp[i], hipEventDisableTiming));
+            EAO_HIP(hipEventCreateWithFlags(&h->evUpDone[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evDone[i], hipEventDisableTiming));
         }
     }
@@ -2155,6 +2157,14 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             EAO_HIP(hipStreamWaitEvent(ss, h->evStart, 0));
             fast(ss, 0, cells0);
         }
+        // Each FAST launch lasts about as long as its slowest cell-waves need, whatever its size (64 frames, each launch ALONE: level 0 36 us, levels 1-2
+        // 43 us, levels 3-7 44.5 us -- the upper levels' cells hold more corners): the upper levels' launch sits on the step's critical path behind the
+        // pyramid chain.  EAO_ORB_UP_SPLIT=l (measured, NOT the default) starts the FAST cells of levels mid .. l-1 on a third stream as soon as level l-1
+        // exists, so that only levels l .. wait for the end of the chain: 0.2626 ms per step without, 0.281 / 0.275 / 0.263 with l = 4 / 5 / 6 -- the two
+        // smaller launches last 46 and 34 us each: a launch is as long as its slowest cell-waves live (2-3 k instructions at a seventh of a SIMD's issue
+        // slots), so cutting one into two only adds a tail (tools/sweep_up.sh, tools/trace_fast_split.sh).
+        static const int envUp = getenv("EAO_ORB_UP_SPLIT") ? atoi(getenv("EAO_ORB_UP_SPLIT")) : 0;
+        const int upSplit = (!prof && onCaller && mid > 0 && qtEarly && h->laneMain[i] && envUp > mid && envUp < g.nlevels) ? envUp : 0;
         bool blurOwn = false, splitOD = false;
         ResizeTopArgs top;
         top.n = 0;
@@ -2190,6 +2200,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 continue;
             }
             { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_resize, grid, block, 0, ms, ra, s, f0); }
+            if (upSplit && l == upSplit - 1) {      // levels mid .. upSplit-1 exist: their FAST cells start on the third stream, beside the rest of the chain
+                EAO_HIP(hipEventRecord(h->evUp[i], ms));
+                EAO_HIP(hipStreamWaitEvent(h->laneMain[i], h->evUp[i], 0));
+                fast(h->laneMain[i], g.L[mid].cellBase, g.L[upSplit].cellBase);
+                EAO_HIP(hipEventRecord(h->evUpDone[i], h->laneMain[i]));
+            }
             if (l == mid - 1) {
                 EAO_HIP(hipEventRecord(h->evMid[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evMid[i], 0));
@@ -2213,7 +2229,9 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
             EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
             if (pe) EAO_HIP(hipEventRecord(ev[9], ms));
-            fast(ms, 0, g.totalCells);
+            static const int envSplitProf = getenv("EAO_FAST_SPLIT_PROF") ? atoi(getenv("EAO_FAST_SPLIT_PROF")) : 0;      // (diagnostic: the three launches of the chain schedule, each alone)
+            if (envSplitProf && g.nlevels > 3) { fast(ms, 0, cells0); fast(ms, cells0, g.L[3].cellBase); fast(ms, g.L[3].cellBase, g.totalCells); }
+            else fast(ms, 0, g.totalCells);
         } else {
             // The blur's fork point is the END OF THE PYRAMID, not the end of the main stream's FAST: on the side stream the blur
             // follows the quad-trees of the lower levels in stream order, which end when the main stream's FAST does, so the
@@ -2231,7 +2249,8 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             blurOwn = envBlurStream && envBlurEarly && onCaller && qtEarly && h->laneMain[i];
             hipStream_t bs = blurOwn ? h->laneMain[i] : ss;
             if (envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
-            fast(ms, early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
+            fast(ms, upSplit ? g.L[upSplit].cellBase : early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
+            if (upSplit) EAO_HIP(hipStreamWaitEvent(ms, h->evUpDone[i], 0));
             if (!envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
             EAO_HIP(hipStreamWaitEvent(bs, h->evFork[i], 0));
             { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, bs, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
@@ -2395,6 +2414,8 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
         if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]);
         if (h->evLow[i]) (void)hipEventDestroy(h->evLow[i]);
+        if (h->evUp[i]) (void)hipEventDestroy(h->evUp[i]);
+        if (h->evUpDone[i]) (void)hipEventDestroy(h->evUpDone[i]);
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
     if (h->pinOut) (void)hipHostFree(h->pinOut);
