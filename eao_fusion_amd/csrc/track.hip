@@ -247,7 +247,13 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
             mine++;
         }
     }
-    if (mine) atomicAdd(&s_cnt, mine);
+    // the number of keypoints inside the grid: the counting sort's scan has it; otherwise one LDS atomic per WAVE (a thousand lanes adding
+    // to one word are served one after the other: 4 k cycles)
+    if (counted) { if (t == 0) s_cnt = inGrid; }
+    else {
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        if ((t & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+    }
     // first walk-list entry of every grid column (binary search over the sorted keys; keys of keypoints outside the grid are
     // 0xFFFFFFFF and sort behind every cell): a search window then walks its one or two columns, not the whole frame
     for (int cI = t; cI <= cols; cI += kFrameThreads) {
