@@ -154,7 +154,8 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)inc, d); if ((t & 63) >= d) inc += o; }
         if ((t & 63) == 63) s_wtot[t >> 6] = (int)inc;
-        if (mx) atomicMax(&s_maxc, (int)mx);
+        for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d));
+        if ((t & 63) == 0 && mx) atomicMax(&s_maxc, (int)mx);      // (one LDS atomic per wave, not per thread)
         __syncthreads();
         unsigned base = inc - sum;
         for (int w = 0; w < (t >> 6); w++) base += (unsigned)s_wtot[w];
