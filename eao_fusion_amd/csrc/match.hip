@@ -85,6 +85,62 @@ __global__ __launch_bounds__(256) void k_match_candidates(FrameDev F, const Quer
     //  sweep instead of a walk over every keypoint of the frame -- 18 rounds for 1100 keypoints)
     int oBeg = 0, oEnd = F.nOrdered;
     if (any && F.colStart) { oBeg = F.colStart[x0]; oEnd = min(F.colStart[x1 + 1], F.nOrdered); }
+    // A window of one or two grid columns is at most four rounds of the wave: the candidates (index and distance) of such a window stay in the
+    // lanes' registers while the segment is reserved, and the second sweep -- three dependent loads per round all over again -- is left out.
+    if (any && oEnd - oBeg <= 4 * 64) {
+        int ci[4], cd[4], run = 0;
+        unsigned long long cm[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            ci[r] = -1; cd[r] = 0; cm[r] = 0;
+            const int o = oBeg + 64 * r + lane;
+            if (oBeg + 64 * r >= oEnd) continue;          // (uniform)
+            bool pass = false;
+            int i = 0;
+            if (o < oEnd) {
+                const int cx = F.cellx[o], cy = F.celly[o];
+                if (cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1) {
+                    i = F.order[o];
+                    const int oc = F.oct[i];
+                    bool ok = true;
+                    if (checkLevels) {
+                        if (oc < Q.minLevel) ok = false;
+                        if (Q.maxLevel >= 0 && oc > Q.maxLevel) ok = false;
+                    }
+                    if (ok) {
+                        const float dx = F.kx[i] - Q.x, dy = F.ky[i] - Q.y;
+                        ok = fabsf(dx) < Q.r && fabsf(dy) < Q.r;
+                    }
+                    if (ok) {
+                        const float u = F.ur[i];
+                        if (u > 0 && fabsf(Q.urRef - u) > Q.urTol) ok = false;
+                    }
+                    pass = ok;
+                }
+            }
+            cm[r] = __ballot(pass);
+            ci[r] = pass ? i : -1;
+            if (pass) cd[r] = dist256(d0, d1, F.desc[2 * i], F.desc[2 * i + 1]);
+            run += __popcll(cm[r]);
+        }
+        total = run;
+        if (lane == 0) {
+            base = total ? atomicAdd(cursor, total) : 0;
+            segStart[qi] = base;
+            segCount[qi] = total;
+        }
+        base = __shfl(base, 0);
+        int off = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (ci[r] >= 0) {
+                const int pos = base + off + __popcll(cm[r] & ((1ull << lane) - 1));
+                if (pos < outCap) out[pos] = ((unsigned)cd[r] << 16) | (unsigned)ci[r];
+            }
+            off += __popcll(cm[r]);
+        }
+        return;
+    }
     for (int sweep = 0; sweep < 2; sweep++) {
         int run = 0;
         if (any) {
