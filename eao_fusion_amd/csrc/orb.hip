@@ -1553,6 +1553,179 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     }
 }
 
+// (Measured option, see the launch site.)  KPW keypoints per WAVE, in three phases.  One wave per keypoint spends a third of its instructions on arithmetic that is the
+// same in all 64 lanes -- fastAtan2 of the two moments and, above all, cos / sin of the angle in double precision (upstream rounds a DOUBLE cosine
+// to float) -- and at 64 frames the kernel is the last one of the step, alone on a VALU-bound chip.  Here a wave (A) sums the moments of its KPW
+// keypoints one after the other and parks each pair in ONE LANE, (B) evaluates angle, cosine and sine of all of them lane-parallel, ONCE, and
+// (C) walks the keypoints again for the 256 steered tests.  The next keypoint's window is fetched while the current one is worked on.  Same
+// arithmetic per keypoint, expression for expression; results bit-identical (tests/test_gpu_orb.py compares every frame with the oracle).
+template <int KPW>
+__global__ __launch_bounds__(256) void k_orient_describe_multi(const Geom* __restrict__ g, ImgSrc s, const uint8_t* __restrict__ blur,
+                                                               const unsigned* __restrict__ levelkps, const int* __restrict__ levelcnt,
+                                                               eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                               int* __restrict__ nout, int cap, int f0, int nlevels, int lFirst, int lEnd, int writeN) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned pat[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const unsigned*>(c_pattern)[lane + 64 * k];
+    int bx = blockIdx.x, fy = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {      // frame f on XCD f % 8 (speed only)
+        const unsigned b = blockIdx.x + gridDim.x * blockIdx.y, xcd = b & 7, slot = b >> 3;
+        fy = (int)(xcd + 8 * (slot / gridDim.x));
+        bx = (int)(slot % gridDim.x);
+    }
+    const int f = fy + f0;
+    // level ends of the frame (lanes 0 .. nlevels-1, inclusive scan inside the 16-lane row)
+    int inc = lane < lEnd ? levelcnt[f * nlevels + lane] : 0;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);
+    const int total = __builtin_amdgcn_readlane(inc, 15);
+    if (writeN && bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
+    const int jfirst = (bx * 4 + wv) * KPW + (lFirst > 0 ? __builtin_amdgcn_readlane(inc, lFirst - 1) : 0);
+    const int nk = min(KPW, min(total, cap) - jfirst);      // keypoints of this wave (wave-uniform)
+    if (nk <= 0) return;
+    constexpr int kPR = 18, kPW = 10, kMR = 15, kMW = 9;
+    __shared__ unsigned patch[4][(2 * kPR + 1) * kPW];
+    __shared__ unsigned mpatch[4][(2 * kMR + 1) * kMW];
+    // (r, c) of the words a lane stages: the same for every keypoint
+    int mr_[5], mc_[5], pr_[6], pc_[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const int i = min(lane + 64 * k, (2 * kMR + 1) * kMW - 1); mr_[k] = (i * 7282) >> 16; mc_[k] = 4 * (i - mr_[k] * kMW); }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const int i = min(lane + 64 * k, (2 * kPR + 1) * kPW - 1); pr_[k] = (i * 6554) >> 16; pc_[k] = 4 * (i - pr_[k] * kPW); }
+    // keypoint q of the wave: level, key, position (wave-uniform)
+    auto locate = [&](int q, int& l, unsigned& key, int& cx, int& cy) {
+        const int j = jfirst + q;
+        l = (int)__popcll(__ballot(lane < nlevels && inc <= j));
+        const int lbase = l > 0 ? __builtin_amdgcn_readlane(inc, min(l, kMaxLevels) - 1) : 0;
+        key = levelkps[(long long)f * g->totalKpCap + g->L[l].kpBase + (j - lbase)];
+        cx = (int)(key & 0xFFF) + kMinBorder; cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
+    };
+    // ---- (A) moments
+    const int u = (lane & 31) - 15, half = lane >> 5, au = u < 0 ? -u : u;
+    int mm01 = 0, mm10 = 0, lq = 0;
+    unsigned keyq = 0;
+    unsigned mv[5];
+    int l, cx, cy, mph;
+    unsigned key;
+    bool aligned;
+    auto fetch_m = [&](int q) {
+        locate(q, l, key, cx, cy);
+        int pitch;
+        const uint8_t* img = level_ptr(g, s, l, f, &pitch);
+        aligned = ((((uintptr_t)img | (uintptr_t)pitch) & 3) == 0);
+        mph = (cx - kMR) & 3;
+        if (aligned) {
+            const uint8_t* mw = img + (cy - kMR) * pitch + (cx - kMR - mph);
+#pragma unroll
+            for (int k = 0; k < 5; k++) mv[k] = *reinterpret_cast<const unsigned*>(mw + (unsigned)(mr_[k] * pitch + mc_[k]));
+        }
+    };
+    fetch_m(0);
+    for (int q = 0; q < nk; q++) {
+        const int lc = l, mphc = mph;
+        const unsigned keyc = key;
+        if (aligned) {
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (lane + 64 * k < (2 * kMR + 1) * kMW) mpatch[wv][lane + 64 * k] = mv[k];
+        } else {      // (an unaligned caller image, level 0: byte loads)
+            int pitch;
+            const uint8_t* img = level_ptr(g, s, lc, f, &pitch);
+            uint8_t* mb = reinterpret_cast<uint8_t*>(mpatch[wv]);
+            for (int i = lane; i < (2 * kMR + 1) * (2 * kMR + 1); i += 64) {
+                const int r = i / (2 * kMR + 1), c = i - r * (2 * kMR + 1);
+                mb[r * (4 * kMW) + c + mphc] = img[(long long)(cy - kMR + r) * pitch + cx - kMR + c];
+            }
+        }
+        if (q + 1 < nk) fetch_m(q + 1);          // the next window travels while this one is summed
+        __builtin_amdgcn_wave_barrier();
+        int m10 = 0, m01 = 0;
+        if (u <= 15) {
+            const uint8_t* c0 = reinterpret_cast<const uint8_t*>(mpatch[wv]) + kMR * (4 * kMW) + kMR + mphc + u;
+            auto row = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int umLo = kUmaxTab[15 - k], umHi = kUmaxTab[k + 1];
+                const int v = half ? k + 1 : k - 15;
+                const int um = half ? umHi : umLo;
+                const int pix = c0[v * (4 * kMW)];
+                const int val = au <= um ? pix : 0;
+                m10 += u * val;
+                m01 += v * val;
+            };
+#define EAO_ROW(K) row(std::integral_constant<int, K>{});
+            EAO_ROW(0) EAO_ROW(1) EAO_ROW(2) EAO_ROW(3) EAO_ROW(4) EAO_ROW(5) EAO_ROW(6) EAO_ROW(7)
+            EAO_ROW(8) EAO_ROW(9) EAO_ROW(10) EAO_ROW(11) EAO_ROW(12) EAO_ROW(13) EAO_ROW(14) EAO_ROW(15)
+#undef EAO_ROW
+        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
+        if (lane == q) { mm01 = m01; mm10 = m10; lq = lc; keyq = keyc; }
+        __builtin_amdgcn_wave_barrier();          // (the window is overwritten in the next trip)
+    }
+    // ---- (B) angle, cosine, sine of the wave's keypoints, one per lane
+    const float angleL = fast_atan2_deg((float)mm01, (float)mm10);
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float aL, bL;
+    sincos_f32_via_f64(angleL * factorPI, &bL, &aL);
+    // ---- (C) steered BRIEF on the blurred level
+    unsigned pw[6];
+    int ph;
+    auto fetch_p = [&](int q) {
+        l = __builtin_amdgcn_readlane(lq, q);
+        key = (unsigned)__builtin_amdgcn_readlane((int)keyq, q);
+        cx = (int)(key & 0xFFF) + kMinBorder; cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
+        ph = (cx - kPR) & 3;
+        const int pitchB = g->L[l].pitch;
+        const uint8_t* bw = blur + (long long)f * g->pyrFrameBytes + g->L[l].off + (cy - kPR) * pitchB + (cx - kPR - ph);
+#pragma unroll
+        for (int k = 0; k < 6; k++) pw[k] = *reinterpret_cast<const unsigned*>(bw + (unsigned)(pr_[k] * pitchB + pc_[k]));
+    };
+    fetch_p(0);
+    for (int q = 0; q < nk; q++) {
+        const int lc = l, cxc = cx, cyc = cy, phc = ph;
+        const unsigned keyc = key;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (lane + 64 * k < (2 * kPR + 1) * kPW) patch[wv][lane + 64 * k] = pw[k];
+        if (q + 1 < nk) fetch_p(q + 1);
+        __builtin_amdgcn_wave_barrier();
+        const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angleL), q));
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aL), q));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bL), q));
+        const uint8_t* bc = reinterpret_cast<const uint8_t*>(patch[wv]) + kPR * (4 * kPW) + kPR + phc;
+        unsigned long long words[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float xa = (float)(signed char)(pat[k] & 0xFF), ya = (float)(signed char)((pat[k] >> 8) & 0xFF);
+            const float xb = (float)(signed char)((pat[k] >> 16) & 0xFF), yb = (float)(signed char)(pat[k] >> 24);
+            const int ra = __float2int_rn(xa * b + ya * a), ca = __float2int_rn(xa * a - ya * b);
+            const int rb = __float2int_rn(xb * b + yb * a), cb = __float2int_rn(xb * a - yb * b);
+            const int t0 = bc[ra * (4 * kPW) + ca], t1 = bc[rb * (4 * kPW) + cb];
+            words[k] = __ballot(t0 < t1);
+        }
+        if (lane == 0) {
+            const int jout = jfirst + q;
+            const LevelGeom L = g->L[lc];
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((long long)f * cap + jout) * 32);
+            d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+            eao_keypoint kp;
+            const float fxp = (float)cxc, fyp = (float)cyc;
+            kp.x = lc ? fxp * L.scale : fxp;
+            kp.y = lc ? fyp * L.scale : fyp;
+            kp.size = (float)L.scaledPatch;
+            kp.angle = angle;
+            kp.response = (float)(keyc >> 24);
+            kp.octave = lc;
+            kp.class_id = -1;
+            kps[(long long)f * cap + jout] = kp;
+        }
+        __builtin_amdgcn_wave_barrier();          // (the window is overwritten in the next trip)
+    }
+}
+
 // unpack (x, y, response) of the gathered FAST candidates for the stage tap
 __global__ void k_unpack_cand(const unsigned* __restrict__ keys, int n, float* __restrict__ xyr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2171,6 +2344,18 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         auto orient = [&](hipStream_t str, int lFirst, int lEnd, int writeN) {
             eao::Range rg("orb: orientation + description");
             const int rangeCap = (lEnd < g.nlevels ? g.L[lEnd].kpBase : g.totalKpCap) - g.L[lFirst].kpBase;
+            // EAO_ORB_KPW=4 / 8 / 16: several keypoints per wave, angle / cosine / sine of a wave's keypoints evaluated lane-parallel
+            // (k_orient_describe_multi).  Measured, NOT the default: 36 % fewer VALU instructions (2.79e7 -> 1.78e7 per 64 frames, SQ_INSTS_VALU) but
+            // 53.8 -> 50.9 us for the launch and no change of the step (0.2554 / 0.2545 ms): the launch is not bound by instruction issue after all.
+            static const int envKpw = getenv("EAO_ORB_KPW") ? atoi(getenv("EAO_ORB_KPW")) : 0;
+            const int kpw = envKpw;
+            auto multi = [&](auto kern, int KPW) {
+                hipLaunchKernelGGL(kern, dim3(eao::cdiv(std::min(cap, rangeCap), 4 * KPW), nb), dim3(256), 0, str, h->d_geom.p, s, h->d_blur.p, h->d_levelkps.p,
+                                   h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, lFirst, lEnd, writeN);
+            };
+            if (kpw == 4) { multi(k_orient_describe_multi<4>, 4); return; }
+            if (kpw == 8) { multi(k_orient_describe_multi<8>, 8); return; }
+            if (kpw == 16) { multi(k_orient_describe_multi<16>, 16); return; }
             hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, rangeCap), 4), nb), dim3(256), 0, str, h->d_geom.p, s, h->d_blur.p, h->d_levelkps.p,
                                h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, lFirst, lEnd, writeN);
         };
