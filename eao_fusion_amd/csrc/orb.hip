@@ -1553,17 +1553,20 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     }
 }
 
-// (Measured option, see the launch site.)  KPW keypoints per WAVE, in three phases.  One wave per keypoint spends a third of its instructions on arithmetic that is the
-// same in all 64 lanes -- fastAtan2 of the two moments and, above all, cos / sin of the angle in double precision (upstream rounds a DOUBLE cosine
-// to float) -- and at 64 frames the kernel is the last one of the step, alone on a VALU-bound chip.  Here a wave (A) sums the moments of its KPW
-// keypoints one after the other and parks each pair in ONE LANE, (B) evaluates angle, cosine and sine of all of them lane-parallel, ONCE, and
-// (C) walks the keypoints again for the 256 steered tests.  The next keypoint's window is fetched while the current one is worked on.  Same
-// arithmetic per keypoint, expression for expression; results bit-identical (tests/test_gpu_orb.py compares every frame with the oracle).
+// (Measured option, see the launch site.)  KPW keypoints per WAVE, in three phases.  One wave per keypoint spends a third of its instructions on
+// arithmetic that is the same in all 64 lanes -- fastAtan2 of the two moments and, above all, cos / sin of the angle in double precision (upstream
+// rounds a DOUBLE cosine to float) -- and half of the launch on the prologue of 66 000 waves.  Here a wave fetches the keys of its KPW keypoints
+// lane-parallel, (A) sums the moments of the keypoints one after the other and parks each pair in ONE LANE, (B) evaluates angle, cosine and sine of
+// all of them lane-parallel, ONCE, and (C) walks the keypoints again for the 256 steered tests.  The next keypoint's window is fetched while the current one is worked on.  Same arithmetic per keypoint, expression for expression; results bit-identical.
 template <int KPW>
 __global__ __launch_bounds__(256) void k_orient_describe_multi(const Geom* __restrict__ g, ImgSrc s, const uint8_t* __restrict__ blur,
                                                                const unsigned* __restrict__ levelkps, const int* __restrict__ levelcnt,
                                                                eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                                int* __restrict__ nout, int cap, int f0, int nlevels, int lFirst, int lEnd, int writeN) {
+    static_assert(KPW <= 64, "one lane per keypoint of the wave");
+    // KPW = 0: the launch has a FIXED number of workgroups per frame (gridDim.x) and a wave takes ceil(keypoints / waves) of them -- every wave of
+    // the launch then lives equally long and the launch can be sized to ONE round of the chip's wave slots (with a fixed KPW the 1056 waves an XCD
+    // gets for eight frames of 1000 keypoints fill its 512 slots 2.06 times: three rounds of 18 us for 31 us of arithmetic)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned pat[4];
 #pragma unroll
@@ -1583,68 +1586,79 @@ __global__ __launch_bounds__(256) void k_orient_describe_multi(const Geom* __res
     inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);
     const int total = __builtin_amdgcn_readlane(inc, 15);
     if (writeN && bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
-    const int jfirst = (bx * 4 + wv) * KPW + (lFirst > 0 ? __builtin_amdgcn_readlane(inc, lFirst - 1) : 0);
-    const int nk = min(KPW, min(total, cap) - jfirst);      // keypoints of this wave (wave-uniform)
+    const int jbase = lFirst > 0 ? __builtin_amdgcn_readlane(inc, lFirst - 1) : 0;
+    const int kpw = KPW ? KPW : (min(total, cap) - jbase + 4 * (int)gridDim.x - 1) / (4 * (int)gridDim.x);
+    const int jfirst = (bx * 4 + wv) * kpw + jbase;
+    const int nk = min(kpw, min(total, cap) - jfirst);      // keypoints of this wave (wave-uniform)
     if (nk <= 0) return;
     constexpr int kPR = 18, kPW = 10, kMR = 15, kMW = 9;
     __shared__ unsigned patch[4][(2 * kPR + 1) * kPW];
     __shared__ unsigned mpatch[4][(2 * kMR + 1) * kMW];
-    // (r, c) of the words a lane stages: the same for every keypoint
-    int mr_[5], mc_[5], pr_[6], pc_[6];
+    // ---- the wave's keys, lane q = keypoint q: level of compact index j (number of level ends at or before it), then the key
+    int lq = 0;
+    unsigned keyq = 0;
+    {
+        const int j = jfirst + min(lane, nk - 1);
+        int lbase = 0;
+        for (int lv = 0; lv < nlevels; lv++) { const int e = __builtin_amdgcn_readlane(inc, lv); if (e <= j) { lq = lv + 1; lbase = e; } }
+        lq = min(lq, nlevels - 1);
+        keyq = levelkps[(long long)f * g->totalKpCap + g->L[lq].kpBase + (j - lbase)];
+    }
+    // byte offsets (inside a window) of the words a lane stages: they depend on the level's pitch only, and a wave's keypoints are consecutive
+    // entries of the level-ordered list -- recomputed when the pitch changes (wave-uniform branch)
+    unsigned wOff[6];
+    int wPitch = -1;
+    auto m_offsets = [&](int pitch) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) { const int i = min(lane + 64 * k, (2 * kMR + 1) * kMW - 1); mr_[k] = (i * 7282) >> 16; mc_[k] = 4 * (i - mr_[k] * kMW); }
+        for (int k = 0; k < 5; k++) { const int i = min(lane + 64 * k, (2 * kMR + 1) * kMW - 1), r = (i * 7282) >> 16; wOff[k] = (unsigned)(r * pitch + 4 * (i - r * kMW)); }
+        wPitch = pitch;
+    };
+    auto p_offsets = [&](int pitch) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) { const int i = min(lane + 64 * k, (2 * kPR + 1) * kPW - 1); pr_[k] = (i * 6554) >> 16; pc_[k] = 4 * (i - pr_[k] * kPW); }
-    // keypoint q of the wave: level, key, position (wave-uniform)
-    auto locate = [&](int q, int& l, unsigned& key, int& cx, int& cy) {
-        const int j = jfirst + q;
-        l = (int)__popcll(__ballot(lane < nlevels && inc <= j));
-        const int lbase = l > 0 ? __builtin_amdgcn_readlane(inc, min(l, kMaxLevels) - 1) : 0;
-        key = levelkps[(long long)f * g->totalKpCap + g->L[l].kpBase + (j - lbase)];
+        for (int k = 0; k < 6; k++) { const int i = min(lane + 64 * k, (2 * kPR + 1) * kPW - 1), r = (i * 6554) >> 16; wOff[k] = (unsigned)(r * pitch + 4 * (i - r * kPW)); }
+        wPitch = pitch;
+    };
+    auto key_of = [&](int q, int& l, unsigned& key, int& cx, int& cy) {
+        l = __builtin_amdgcn_readlane(lq, q);
+        key = (unsigned)__builtin_amdgcn_readlane((int)keyq, q);
         cx = (int)(key & 0xFFF) + kMinBorder; cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
     };
     // ---- (A) moments
     const int u = (lane & 31) - 15, half = lane >> 5, au = u < 0 ? -u : u;
-    int mm01 = 0, mm10 = 0, lq = 0;
-    unsigned keyq = 0;
-    unsigned mv[5];
-    int l, cx, cy, mph;
-    unsigned key;
-    bool aligned;
-    auto fetch_m = [&](int q) {
-        locate(q, l, key, cx, cy);
+    int mm01 = 0, mm10 = 0;
+    auto fetch_m = [&](int q, unsigned (&mv)[5]) {      // (an unaligned caller image takes byte loads at staging time instead)
+        int l, cx, cy; unsigned key;
+        key_of(q, l, key, cx, cy);
         int pitch;
         const uint8_t* img = level_ptr(g, s, l, f, &pitch);
-        aligned = ((((uintptr_t)img | (uintptr_t)pitch) & 3) == 0);
-        mph = (cx - kMR) & 3;
-        if (aligned) {
-            const uint8_t* mw = img + (cy - kMR) * pitch + (cx - kMR - mph);
+        if ((((uintptr_t)img | (uintptr_t)pitch) & 3) == 0) {
+            const uint8_t* mw = img + (cy - kMR) * pitch + (cx - kMR - ((cx - kMR) & 3));
+            if (pitch != wPitch) m_offsets(pitch);
 #pragma unroll
-            for (int k = 0; k < 5; k++) mv[k] = *reinterpret_cast<const unsigned*>(mw + (unsigned)(mr_[k] * pitch + mc_[k]));
+            for (int k = 0; k < 5; k++) mv[k] = *reinterpret_cast<const unsigned*>(mw + wOff[k]);
         }
     };
-    fetch_m(0);
-    for (int q = 0; q < nk; q++) {
-        const int lc = l, mphc = mph;
-        const unsigned keyc = key;
-        if (aligned) {
+    auto moments = [&](int q, const unsigned (&mv)[5]) {
+        int l, cx, cy; unsigned key;
+        key_of(q, l, key, cx, cy);
+        int pitch;
+        const uint8_t* img = level_ptr(g, s, l, f, &pitch);
+        const int mph = (cx - kMR) & 3;
+        if ((((uintptr_t)img | (uintptr_t)pitch) & 3) == 0) {
 #pragma unroll
             for (int k = 0; k < 5; k++)
                 if (lane + 64 * k < (2 * kMR + 1) * kMW) mpatch[wv][lane + 64 * k] = mv[k];
-        } else {      // (an unaligned caller image, level 0: byte loads)
-            int pitch;
-            const uint8_t* img = level_ptr(g, s, lc, f, &pitch);
+        } else {
             uint8_t* mb = reinterpret_cast<uint8_t*>(mpatch[wv]);
             for (int i = lane; i < (2 * kMR + 1) * (2 * kMR + 1); i += 64) {
                 const int r = i / (2 * kMR + 1), c = i - r * (2 * kMR + 1);
-                mb[r * (4 * kMW) + c + mphc] = img[(long long)(cy - kMR + r) * pitch + cx - kMR + c];
+                mb[r * (4 * kMW) + c + mph] = img[(long long)(cy - kMR + r) * pitch + cx - kMR + c];
             }
         }
-        if (q + 1 < nk) fetch_m(q + 1);          // the next window travels while this one is summed
         __builtin_amdgcn_wave_barrier();
         int m10 = 0, m01 = 0;
         if (u <= 15) {
-            const uint8_t* c0 = reinterpret_cast<const uint8_t*>(mpatch[wv]) + kMR * (4 * kMW) + kMR + mphc + u;
+            const uint8_t* c0 = reinterpret_cast<const uint8_t*>(mpatch[wv]) + kMR * (4 * kMW) + kMR + mph + u;
             auto row = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 constexpr int umLo = kUmaxTab[15 - k], umHi = kUmaxTab[k + 1];
@@ -1662,8 +1676,19 @@ __global__ __launch_bounds__(256) void k_orient_describe_multi(const Geom* __res
         }
         m10 = wave_sum_i32(m10);
         m01 = wave_sum_i32(m01);
-        if (lane == q) { mm01 = m01; mm10 = m10; lq = lc; keyq = keyc; }
-        __builtin_amdgcn_wave_barrier();          // (the window is overwritten in the next trip)
+        if (lane == q) { mm01 = m01; mm10 = m10; }
+        __builtin_amdgcn_wave_barrier();          // (the window is overwritten by the next keypoint)
+    };
+    {
+        unsigned mvA[5] = {0, 0, 0, 0, 0};
+        fetch_m(0, mvA);
+        for (int q = 0; q < nk; q++) {
+            unsigned cur[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) cur[k] = mvA[k];
+            if (q + 1 < nk) fetch_m(q + 1, mvA);          // the next window travels while this one is summed
+            moments(q, cur);
+        }
     }
     // ---- (B) angle, cosine, sine of the wave's keypoints, one per lane
     const float angleL = fast_atan2_deg((float)mm01, (float)mm10);
@@ -1671,26 +1696,23 @@ __global__ __launch_bounds__(256) void k_orient_describe_multi(const Geom* __res
     float aL, bL;
     sincos_f32_via_f64(angleL * factorPI, &bL, &aL);
     // ---- (C) steered BRIEF on the blurred level
-    unsigned pw[6];
-    int ph;
-    auto fetch_p = [&](int q) {
-        l = __builtin_amdgcn_readlane(lq, q);
-        key = (unsigned)__builtin_amdgcn_readlane((int)keyq, q);
-        cx = (int)(key & 0xFFF) + kMinBorder; cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
-        ph = (cx - kPR) & 3;
+    wPitch = -1;
+    auto fetch_p = [&](int q, unsigned (&pw)[6]) {
+        int l, cx, cy; unsigned key;
+        key_of(q, l, key, cx, cy);
         const int pitchB = g->L[l].pitch;
-        const uint8_t* bw = blur + (long long)f * g->pyrFrameBytes + g->L[l].off + (cy - kPR) * pitchB + (cx - kPR - ph);
+        const uint8_t* bw = blur + (long long)f * g->pyrFrameBytes + g->L[l].off + (cy - kPR) * pitchB + (cx - kPR - ((cx - kPR) & 3));
+        if (pitchB != wPitch) p_offsets(pitchB);
 #pragma unroll
-        for (int k = 0; k < 6; k++) pw[k] = *reinterpret_cast<const unsigned*>(bw + (unsigned)(pr_[k] * pitchB + pc_[k]));
+        for (int k = 0; k < 6; k++) pw[k] = *reinterpret_cast<const unsigned*>(bw + wOff[k]);
     };
-    fetch_p(0);
-    for (int q = 0; q < nk; q++) {
-        const int lc = l, cxc = cx, cyc = cy, phc = ph;
-        const unsigned keyc = key;
+    auto describe = [&](int q, const unsigned (&pw)[6]) {
+        int lc, cxc, cyc; unsigned keyc;
+        key_of(q, lc, keyc, cxc, cyc);
+        const int phc = (cxc - kPR) & 3;
 #pragma unroll
         for (int k = 0; k < 6; k++)
             if (lane + 64 * k < (2 * kPR + 1) * kPW) patch[wv][lane + 64 * k] = pw[k];
-        if (q + 1 < nk) fetch_p(q + 1);
         __builtin_amdgcn_wave_barrier();
         const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angleL), q));
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aL), q));
@@ -1722,7 +1744,18 @@ __global__ __launch_bounds__(256) void k_orient_describe_multi(const Geom* __res
             kp.class_id = -1;
             kps[(long long)f * cap + jout] = kp;
         }
-        __builtin_amdgcn_wave_barrier();          // (the window is overwritten in the next trip)
+        __builtin_amdgcn_wave_barrier();          // (the window is overwritten by the next keypoint)
+    };
+    {
+        unsigned pwA[6] = {0, 0, 0, 0, 0, 0};
+        fetch_p(0, pwA);
+        for (int q = 0; q < nk; q++) {
+            unsigned cur[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cur[k] = pwA[k];
+            if (q + 1 < nk) fetch_p(q + 1, pwA);
+            describe(q, cur);
+        }
     }
 }
 
@@ -2353,6 +2386,13 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 hipLaunchKernelGGL(kern, dim3(eao::cdiv(std::min(cap, rangeCap), 4 * KPW), nb), dim3(256), 0, str, h->d_geom.p, s, h->d_blur.p, h->d_levelkps.p,
                                    h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, lFirst, lEnd, writeN);
             };
+            if (kpw == 1) {      // balanced: 16 workgroups per frame, ceil(keypoints / 64) keypoints per wave (up to 64: 4096 keypoints per frame)
+                if (std::min(cap, rangeCap) <= 4096) {
+                    hipLaunchKernelGGL(k_orient_describe_multi<0>, dim3(16, nb), dim3(256), 0, str, h->d_geom.p, s, h->d_blur.p, h->d_levelkps.p,
+                                       h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, lFirst, lEnd, writeN);
+                    return;
+                }
+            }
             if (kpw == 4) { multi(k_orient_describe_multi<4>, 4); return; }
             if (kpw == 8) { multi(k_orient_describe_multi<8>, 8); return; }
             if (kpw == 16) { multi(k_orient_describe_multi<16>, 16); return; }
