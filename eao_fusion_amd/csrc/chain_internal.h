@@ -9,10 +9,12 @@
 namespace eao {
 
 namespace lm {
-struct PoseChainArgs {            // every pointer is a device address (outSE3 / outResult / outTrace may be mapped host memory)
+struct PoseChainArgs {            // every pointer is a device address
     const int* nEdges; int cap;   // number of edges (device) and the capacity of the arrays
     int maxEdges = 0;             // what the host knows about the count (0: nothing beyond cap): launches for larger frames are left out
-    int* done = nullptr; int doneSeq = 0;   // optional: mapped host word that receives doneSeq when the chain's last launch has made its results visible
+    int* done = nullptr; int doneSeq = 0;   // mapped host word that receives doneSeq when the chain's last launch has made its results visible
+    const void* pubSrc = nullptr; void* pubDst = nullptr; int pubN16 = 0;   // ... after copying pubN16 x 16 bytes from the device block pubSrc (which every
+                                                                            // kernel of the chain writes) to its mapped host twin pubDst: one writer of host memory
     const double* Xw; const double* obs; const double* info; unsigned char* flags; double* err; unsigned char* outlier;
     float Tcw0[16]; float fx, fy, cx, cy, bf;
     void* outSE3; int* outResult; double* outTrace;

@@ -227,6 +227,214 @@ __global__ __launch_bounds__(256) void k_hamming_best2_seq(const uint4* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the distances on the MATRIX CORES.  popcount(a ^ b) = popcount(a) + popcount(b) - 2 popcount(a & b), and popcount(a & b) is
+// the dot product of the descriptors' bits spread to 0 / 1 bytes: v_mfma_i32_32x32x32_i8 takes 32 x 32 of those products over 32 bit positions
+// per instruction (eight instructions per 32 x 32 tile of distances, exact in i32) where the VALU path spends 16 v_xor / v_bcnt per distance.
+// A workgroup of four waves owns a block of 128 A rows x 128 B columns:
+//   B side   the block's 128 B descriptors are spread ONCE into LDS (byte k of a row = bit k, 272-byte row pitch: the lanes' 16-byte
+//            fragment reads fall on distinct banks) together with their popcounts;
+//   A side   wave w owns A rows 32 w .. 32 w + 31; lane (r = lane & 31, h = lane >> 5) spreads bits [32 kc + 16 h, + 16) of row r into the
+//            sixteen bytes of its operand fragment for step kc -- in registers, once per block (any bijection of the 256 bit positions onto the
+//            (kc, h, j) slots gives the same dot product as long as both sides use the same one; this one is the identity);
+//   product  D'[j][i] = sum_k Bspread[j][k] Aspread[i][k]: the B rows are the instruction's first operand, so an accumulator register
+//            holds four CONSECUTIVE columns j of ONE matrix row i = lane & 31 (reg 4 q + e <-> j = 8 q + 4 h + e): a lane packs them to
+//            four uint16 without any lane exchange.
+// Matrix mode stages the wave's 32 x 128 uint16 tile through LDS so that the global stores are 16 bytes per lane and 256 contiguous bytes per row
+// (the matrix is write-bound: 2 MB per 1000 x 1000 pair); best-2 mode never stores distances: the A side is spread to 0 / -1 bytes, so the
+// accumulator holds -popcount(a & b) and a key (distance << 20 | column) is ONE v_lshl_add on top of a per-column LDS word
+// (popcount(b_j) << 20 | j) -- two more instructions (v_med3_u32, v_min_u32) keep the lane's two smallest keys, i.e. upstream's
+// "if(d < best) ... else if(d < second)" scan in column order (src/ORBmatcher.cc:102-114: the first of equal distances wins).
+typedef int hm_v4i __attribute__((ext_vector_type(4)));
+typedef int hm_v16i __attribute__((ext_vector_type(16)));
+constexpr int kMB = 128;                 // block edge (A rows and B columns)
+constexpr int kMPitch = 272;             // bytes per spread row / per staged output row
+constexpr unsigned kKeyNone = (256u << 20) | 0xFFFFFu;
+
+__device__ __forceinline__ unsigned spread4(unsigned nib) { return __umul24(nib, 0x204081u) & 0x01010101u; }      // bit e of the nibble -> byte e (0 / 1)
+template <bool NEG>
+__device__ __forceinline__ hm_v4i spread16(unsigned half) {      // sixteen bits -> sixteen bytes (0 / 1, or 0 / -1)
+    unsigned w[4] = {spread4(half & 15u), spread4((half >> 4) & 15u), spread4((half >> 8) & 15u), spread4((half >> 12) & 15u)};
+    if (NEG) for (int q = 0; q < 4; q++) w[q] = (w[q] << 8) - w[q];      // 1 -> 0xFF per byte (no carries between bytes)
+    return hm_v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+}
+// thread t of 256 spreads half a descriptor (16 bytes = 128 bits) of B row (t >> 1) into the LDS image and leaves the row's popcount (or key base) behind
+__device__ __forceinline__ void spread_b_rows(unsigned char* sB, const uint4 v, int t) {
+    const unsigned dw[4] = {v.x, v.y, v.z, v.w};
+    unsigned char* dst = sB + (t >> 1) * kMPitch + (t & 1) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        *reinterpret_cast<hm_v4i*>(dst + 32 * q) = spread16<false>(dw[q] & 0xFFFFu);
+        *reinterpret_cast<hm_v4i*>(dst + 32 * q + 16) = spread16<false>(dw[q] >> 16);
+    }
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { unsigned d; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ void hm_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// full matrix: grid (column blocks, row blocks, pairs); nb % 8 == 0 and a 16-byte aligned D (else the popcount kernels above)
+__global__ __launch_bounds__(256, 2) void k_hamming_matrix_mfma(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,
+                                                                unsigned short* __restrict__ D) {
+    __shared__ __attribute__((aligned(16))) unsigned char sB[kMB * kMPitch];
+    __shared__ __attribute__((aligned(16))) unsigned char sOut[4][32 * kMPitch];
+    __shared__ __attribute__((aligned(16))) unsigned short sPb[kMB];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, h = lane >> 5;
+    const int pair = blockIdx.z;
+    A += (long long)pair * na * 2;
+    B += (long long)pair * nb * 2;
+    D += (long long)pair * na * nb;
+    const int i0 = blockIdx.y * kMB + 32 * wv, j0 = blockIdx.x * kMB;
+    {   // B side: 128 rows, two threads per row
+        const int j = j0 + (t >> 1);
+        const uint4 v = j < nb ? B[(long long)j * 2 + (t & 1)] : make_uint4(0, 0, 0, 0);
+        spread_b_rows(sB, v, t);
+        int pc = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        pc += __shfl_xor(pc, 1);
+        if (!(t & 1)) sPb[t >> 1] = (unsigned short)pc;
+    }
+    // A side: row i0 + r, the half-wave's sixteen bits of every dword
+    const int i = i0 + r;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (i < na) { a0 = A[(long long)i * 2]; a1 = A[(long long)i * 2 + 1]; }
+    const unsigned adw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    unsigned pa = 0;
+    hm_v4i af[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; kc++) { pa += __popc(adw[kc]); af[kc] = spread16<false>((adw[kc] >> (16 * h)) & 0xFFFFu); }
+    const unsigned paPk = pa | (pa << 16);
+    __syncthreads();
+    unsigned char* so = sOut[wv];
+#pragma unroll
+    for (int jt = 0; jt < 4; jt++) {
+        hm_v16i acc;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = 0;
+        const unsigned char* bsrc = sB + (jt * 32 + r) * kMPitch + 16 * h;
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+            const hm_v4i bf = *reinterpret_cast<const hm_v4i*>(bsrc + 32 * kc);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf, af[kc], acc, 0, 0, 0);
+        }
+        // reg 4 q + e: column jt * 32 + 8 q + 4 h + e of row r.  Pairs of uint16 in one dword: every intermediate stays below 2^16 and no half
+        // goes negative, so plain 32-bit arithmetic on the packed pairs is exact.
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int jc = jt * 32 + 8 * q + 4 * h;
+            const uint2 pb = *reinterpret_cast<const uint2*>(&sPb[jc]);
+            const unsigned lo = (paPk + pb.x) - (((unsigned)acc[4 * q] | ((unsigned)acc[4 * q + 1] << 16)) << 1);
+            const unsigned hi = (paPk + pb.y) - (((unsigned)acc[4 * q + 2] | ((unsigned)acc[4 * q + 3] << 16)) << 1);
+            *reinterpret_cast<uint2*>(so + r * kMPitch + jc * 2) = make_uint2(lo, hi);
+        }
+    }
+    hm_wave_sync();
+    // 32 rows x 256 bytes: sixteen lanes per row, 16 bytes each
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int row = p * 4 + (lane >> 4), ch = lane & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(so + row * kMPitch + ch * 16);
+        const int ii = i0 + row, jj = j0 + ch * 8;
+        if (ii < na && jj < nb) *reinterpret_cast<uint4*>(D + (long long)ii * nb + jj) = v;
+    }
+}
+
+// best / second-best per A row.  SEQ = false: `pairs` independent (A, B) sets as eao_hamming_best2_device lays them out; SEQ = true: the
+// consecutive frames of a device-resident batch (see k_hamming_best2_seq).  grid (row blocks, pairs or frames).
+struct Best2Src { const uint4* A; const uint4* B; int na, nb; const int* counts; const uint4* halo; int haloN; int cap; };
+template <bool SEQ>
+__global__ __launch_bounds__(256, 2) void k_hamming_best2_mfma(Best2Src S, eao_best2* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char sB[2][kMB * kMPitch];
+    __shared__ __attribute__((aligned(16))) unsigned sKb[2][kMB];      // per column: popcount << 20 | column (a huge word beyond nb)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, h = lane >> 5;
+    const uint4* A; const uint4* B; int na, nb; long long outBase;
+    if (SEQ) {
+        const int f = blockIdx.y;
+        A = f ? S.A + (long long)(f - 1) * S.cap * 2 : S.halo;
+        na = f ? min(S.counts[f - 1], S.cap) : S.haloN; nb = min(S.counts[f], S.cap);
+        B = S.A + (long long)f * S.cap * 2;
+        outBase = (long long)f * S.cap;
+        if (!A) return;
+    } else {
+        const int pair = blockIdx.y;
+        na = S.na; nb = S.nb;
+        A = S.A + (long long)pair * na * 2; B = S.B + (long long)pair * nb * 2;
+        outBase = (long long)pair * na;
+    }
+    const int ib = blockIdx.x * kMB;
+    if (ib >= na) return;                 // (workgroup-uniform)
+    const int i = ib + 32 * wv + r;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (i < na) { a0 = A[(long long)i * 2]; a1 = A[(long long)i * 2 + 1]; }
+    const unsigned adw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    unsigned pa = 0;
+    hm_v4i af[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; kc++) { pa += __popc(adw[kc]); af[kc] = spread16<true>((adw[kc] >> (16 * h)) & 0xFFFFu); }
+    const unsigned paS = pa << 20;
+    const int nChunks = (nb + kMB - 1) / kMB;
+    auto fetch = [&](int c) { const int j = c * kMB + (t >> 1); return j < nb ? B[(long long)j * 2 + (t & 1)] : make_uint4(0, 0, 0, 0); };
+    auto stage = [&](int c, const uint4 v) {
+        spread_b_rows(sB[c & 1], v, t);
+        int pc = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        pc += __shfl_xor(pc, 1);
+        const int j = c * kMB + (t >> 1);
+        if (!(t & 1)) sKb[c & 1][t >> 1] = j < nb ? ((unsigned)pc << 20) | (unsigned)j : 0x20000000u;
+    };
+    unsigned k1 = 0x7FFFFFFFu, k2 = 0x7FFFFFFFu;
+    if (nChunks > 0) stage(0, fetch(0));
+    __syncthreads();
+    for (int c = 0; c < nChunks; c++) {
+        const bool more = c + 1 < nChunks;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (more) nxt = fetch(c + 1);
+        const unsigned char* sb = sB[c & 1];
+        const unsigned* kb = sKb[c & 1];
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) {
+            hm_v16i acc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0;
+            const unsigned char* bsrc = sb + (jt * 32 + r) * kMPitch + 16 * h;
+#pragma unroll
+            for (int kc = 0; kc < 8; kc++) {
+                const hm_v4i bf = *reinterpret_cast<const hm_v4i*>(bsrc + 32 * kc);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf, af[kc], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 kq = *reinterpret_cast<const uint4*>(&kb[jt * 32 + 8 * q + 4 * h]);
+                const unsigned kbv[4] = {kq.x, kq.y, kq.z, kq.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    // acc = -popcount(a & b):  key = (pa + pb - 2 popcount(a & b)) << 20 | j
+                    const unsigned key = ((unsigned)acc[4 * q + e] << 21) + (kbv[e] + paS);
+                    k2 = umed3(key, k1, k2);      // (k1 <= k2 always: the median of the three is the new second smallest)
+                    k1 = min(k1, key);
+                }
+            }
+        }
+        if (more) stage(c + 1, nxt);
+        __syncthreads();
+    }
+    // the two half-waves hold the same rows: merge, then lanes 0..31 write
+    {
+        const unsigned o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
+        const unsigned n1 = min(k1, o1);
+        const unsigned n2 = min(max(k1, o1), min(k2, o2));
+        k1 = min(n1, kKeyNone); k2 = min(n2, kKeyNone);
+    }
+    if (h == 0 && i < na) {
+        eao_best2 res;
+        res.best = (int)(k1 >> 20);
+        res.second = (int)(k2 >> 20);
+        res.idx = k1 == kKeyNone ? -1 : (int)(k1 & 0xFFFFF);
+        res.idx2 = k2 == kKeyNone ? -1 : (int)(k2 & 0xFFFFF);
+        out[outBase + i] = res;
+    }
+}
+
+// EAO_HAMMING_MFMA: 0 = popcount kernels only, 1 (default) = matrix cores when the call holds at least 64 blocks of 128 rows, 2 = matrix
+// cores whenever the shapes allow.  Read on every call (the parity tests switch it inside one process).
+inline int hamming_mfma_mode() { const char* e = getenv("EAO_HAMMING_MFMA"); return e ? atoi(e) : 1; }
+
 struct Scratch {
     eao::DevBuf<uint8_t> a, b, mask;
     eao::DevBuf<unsigned short> d;
@@ -303,7 +511,13 @@ eao_status eao_hamming_matrix_device(const uint8_t* d_A, int32_t na, const uint8
     EAO_REQUIRE(((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_B & 15) == 0 && ((uintptr_t)d_D & 3) == 0, "descriptor arrays must be 16-byte aligned");
     eao_status st = eao::require_device();
     if (st) return st;
-    if ((nb & 7) == 0 && ((uintptr_t)d_D & 15) == 0 && !getenv("EAO_HAMMING_NARROW")) {
+    // matrix cores from 64 blocks of 128 x 128 on (a quarter of the chip); EAO_HAMMING_MFMA=0 keeps the popcount kernels (A/B runs)
+    const int envMfma = hamming_mfma_mode();
+    const long long blocks = (long long)eao::cdiv(nb, kMB) * eao::cdiv(na, kMB) * pairs;
+    if ((nb & 7) == 0 && ((uintptr_t)d_D & 15) == 0 && envMfma && (blocks >= 64 || envMfma > 1)) {
+        hipLaunchKernelGGL(k_hamming_matrix_mfma, dim3(eao::cdiv(nb, kMB), eao::cdiv(na, kMB), pairs), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_A, na,
+                           (const uint4*)d_B, nb, d_D);
+    } else if ((nb & 7) == 0 && ((uintptr_t)d_D & 15) == 0 && !getenv("EAO_HAMMING_NARROW")) {
         dim3 grid8(eao::cdiv(nb, 1024), eao::cdiv(na, kRowsPerBlock8), pairs);
         hipLaunchKernelGGL(k_hamming_matrix8, grid8, dim3(128), 0, (hipStream_t)stream, (const uint4*)d_A, na, (const uint4*)d_B, nb, d_D);
     } else {
@@ -321,7 +535,11 @@ eao_status eao_hamming_best2_device(const uint8_t* d_A, int32_t na, const uint8_
     EAO_REQUIRE(((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_B & 15) == 0, "descriptor arrays must be 16-byte aligned");
     eao_status st = eao::require_device();
     if (st) return st;
-    if (!d_mask && na >= 256 && !getenv("EAO_HAMMING_NARROW"))     // (few rows: one row per wave fills the chip better)
+    const int envMfma = hamming_mfma_mode();
+    if (!d_mask && envMfma && ((long long)eao::cdiv(na, kMB) * pairs >= 64 || envMfma > 1)) {      // matrix cores: enough row blocks to spread over the chip
+        Best2Src S{(const uint4*)d_A, (const uint4*)d_B, na, nb, nullptr, nullptr, 0, 0};
+        hipLaunchKernelGGL(k_hamming_best2_mfma<false>, dim3(eao::cdiv(na, kMB), pairs), dim3(256), 0, (hipStream_t)stream, S, d_out);
+    } else if (!d_mask && na >= 256 && !getenv("EAO_HAMMING_NARROW"))     // (few rows: one row per wave fills the chip better)
         hipLaunchKernelGGL(k_hamming_best2_rows, dim3(eao::cdiv(na, 4 * kB2Rows), pairs), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_A, na,
                            (const uint4*)d_B, nb, d_out);
     else
@@ -338,8 +556,13 @@ eao_status eao_hamming_best2_sequence_device(const uint8_t* d_desc, int32_t cap,
     EAO_REQUIRE(((uintptr_t)d_desc & 15) == 0 && ((uintptr_t)d_halo_desc & 15) == 0, "descriptor arrays must be 16-byte aligned");
     eao_status st = eao::require_device();
     if (st) return st;
-    hipLaunchKernelGGL(k_hamming_best2_seq, dim3(eao::cdiv(cap, 4 * kB2Rows), batch), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_desc, cap,
-                       d_counts, halo_n ? (const uint4*)d_halo_desc : nullptr, halo_n, d_out);
+    const int envMfma = hamming_mfma_mode();
+    if (envMfma && ((long long)eao::cdiv(cap, kMB) * batch >= 64 || envMfma > 1)) {
+        Best2Src S{(const uint4*)d_desc, nullptr, 0, 0, d_counts, halo_n ? (const uint4*)d_halo_desc : nullptr, halo_n, cap};
+        hipLaunchKernelGGL(k_hamming_best2_mfma<true>, dim3(eao::cdiv(cap, kMB), batch), dim3(256), 0, (hipStream_t)stream, S, d_out);
+    } else
+        hipLaunchKernelGGL(k_hamming_best2_seq, dim3(eao::cdiv(cap, 4 * kB2Rows), batch), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_desc, cap,
+                           d_counts, halo_n ? (const uint4*)d_halo_desc : nullptr, halo_n, d_out);
     EAO_HIP(hipGetLastError());
     return EAO_OK;
 }

@@ -484,7 +484,29 @@ struct PoseDev {
     GP<unsigned char> scatterOut;    // (null otherwise)
     GP<int> done; int doneSeq;       // chained tracking: the LAST launch of the chain stores doneSeq here (mapped host memory) when everything
                                      // the chain writes is visible to the host, which polls it instead of paying a stream synchronisation
+    // chained tracking: every kernel of the chain (this one included) writes its results into a DEVICE block; the chain's last launch -- and
+    // nobody else -- copies that block into its mapped host twin (pubN16 x 16 bytes), fences at system scope and only then stores the done
+    // word.  One writer, one fence: the host never depends on how stores of two different kernels to host memory are ordered.
+    GP<const uint4> pubSrc; GP<uint4> pubDst; int pubN16;
 };
+// the tail of the chain's last launch (every thread of the workgroup calls it; all of the workgroup's own stores to the device block are done)
+__device__ __forceinline__ void pose_publish(const PoseDev& P) {
+    if (!P.done) return;
+    __syncthreads();                                  // this workgroup's stores into the device block (other waves') are visible
+    const uint4* src = P.pubSrc; uint4* dst = P.pubDst;
+    for (int i = threadIdx.x; i < P.pubN16; i += blockDim.x) dst[i] = src[i];
+    __threadfence_system();                           // every thread: its stores have left the device ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // ... which is NOT yet "arrived in host memory, in order": the stores are posted PCIe writes, and with the single-writer copy and the
+        // fence alone the host still found one stale 16-byte piece of the block behind a fresh done word once in 10^5 calls
+        // (profiles/r04_track_poll_stress.txt) -- posted writes may pass each other (relaxed ordering), the word overtook a piece of
+        // the data.  A READ of the host block cannot pass posted writes and its completion cannot be returned before they are done
+        // (PCIe ordering: non-posted requests push posted ones), so the word is stored only after a load from the block has come back.
+        const int seen = __hip_atomic_load((int*)P.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the host zeroed it before the call)
+        if (seen != P.doneSeq) __hip_atomic_store((int*)P.done, P.doneSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 constexpr int kPoseThreads = 512;
 
@@ -654,7 +676,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = P.nDev ? min(*P.nDev, P.n) : P.n;
     if (P.nDev && (n <= P.devLo || n > P.devHi)) {            // another variant's frame (workgroup-uniform)
-        if (P.done && t == 0) { __threadfence_system(); *P.done = P.doneSeq; }      // (the frame's own variant ran in front of this launch)
+        pose_publish(P);      // (the frame's own variant ran in front of this launch and left its results in the device block)
         return;
     }
     const float chi2Mono = refc::POSE_CHI2_MONO, chi2Stereo = refc::POSE_CHI2_STEREO;
@@ -1052,11 +1074,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
         }
     if (PLANES && t < M) P.planeOutlier[t] = s_pout[t];
     if (t == 0) { P.result[1] = iters; P.result[2] = ntrace; P.result[3] = npass | (nlight << 16); }
-    if (P.done) {      // every thread's stores (outlier flags by keypoint, the pose, the counts) before the flag
-        __threadfence_system();
-        __syncthreads();
-        if (t == 0) { *P.done = P.doneSeq; }
-    }
+    pose_publish(P);         // (behind a barrier: the copy reads what other threads of this workgroup stored -- outlier flags by keypoint, the pose, the counts)
     if (stamp) for (int q = 0; q < 6; q++) P.dbg[q] = pa[q];
     if (wstamp && lane == 0) { P.dbg[8 + wv] = wH; P.dbg[24 + wv] = wL; P.dbg[40 + wv] = wT; if (wv == 0) P.dbg[7] = nw; }
 }
@@ -1392,7 +1410,12 @@ struct BADev {
     GP<double> bp;             // nFree*6
     GP<double> Hll;            // nL*9
     GP<double> bl;             // nL*3
-    GP<double> Hpl;            // E*18 (pose row block 6x3) for active edges with a free camera
+    GP<double> Hpl;            // E*18 (pose row block 6x3) for active edges with a free camera.  wmode = 1: the block is stored PRE-SCALED,
+                               // W = Hpl C^-T with C C^T = Hll + lambda I of its landmark (see ba_chol3), so that Hpl (Hll + lambda I)^-1 Hpl'^T = W W'^T
+    int wmode;                 // 1: windows on the matrix-core pair assembly (k_ba_schur_pairs_mfma): W / Tl / ul instead of Hpl / dinv3
+    GP<double> Tl;             // nL*6: T = C^-T (upper triangle 00 01 02 11 12 22) per landmark block   (wmode 1)
+    GP<double> ul;             // nL*3: u = C^-1 bl                                                     (wmode 1)
+    GP<int4> pairItems;        // per camera pair (i1 <= i2), nL slots: {edge (l, i1), edge (l, i2), l, 0} of the landmarks both observe, ascending (k_ba_pairs)
     GP<double> slab;           // chunks * nFree * (nFree*36 + 6): partial Schur rows
     GP<double> sys;            // n*(n+1): assembled Schur system (upper triangle + rhs column)
     GP<double> solveScratch;   // n*(n+1)+... doubles when the Schur system does not fit in LDS, else null
@@ -1709,8 +1732,10 @@ constexpr int kLinThreads = 1024;      // (batches: 512- and 256-thread workgrou
 // depend on the order, and non-negative doubles order like their bit patterns.
 // ctlOld != nullptr: the previous trial's decision has not been taken yet (bulk segment): see BADecision.  P.ctl / P.lm
 // are then the blocks this trial runs on (written by workgroup 0 here), ctlOld / lmOld the ones the previous trial ran on.
+// diagOnly (wmode 1, first linearisation of an optimize() call): only the largest diagonal entry is wanted -- lambda_0 must be known before
+// the landmarks' blocks can be stored pre-scaled, so that call runs the launch twice: once for the maximum, once for everything else.
 template <bool PL, int NT>
-__global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W, int wpar, int ptBlocks, int first) {
+__global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W, int wpar, int ptBlocks, int first, int diagOnly) {
     BA_WIN(P);
     if ((int)bx >= ptBlocks + P.nFree) return;      // (a batch is launched with the largest window's grid)
     __shared__ double red[(NT / 4) * 27], part[8 * 27];
@@ -1732,6 +1757,12 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
         int k = 0, end = 0;
         if (more) { k = P.ptStart[l] + slot; end = P.ptStart[l + 1]; }
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};   // upper triangle 00 01 02 11 12 22
+        const bool wm = !PL && P.wmode != 0;
+        double hx[18];            // wmode 1: the Hpl block of the lane's FIRST edge waits here for the landmark's Cholesky factor
+        int hxE = -1;
+        bool firstEdge = true;
+#pragma unroll
+        for (int q = 0; q < 18; q++) hx[q] = 0;
         while (e >= 0) {
             const unsigned char fl = P.eflag[e];
             if (!(fl & 2)) {
@@ -1766,14 +1797,23 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
 #pragma unroll
                     for (int j = i; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi[r] * A[r][j]; H[q++] += h; }
                 }
-                if (camFree) {
-                    double* Hx = &P.Hpl[(size_t)e * 18];
+                if (camFree && !diagOnly) {
+                    if (wm && firstEdge) {
+                        hxE = e;
 #pragma unroll
-                    for (int i = 0; i < 6; i++)
+                        for (int i = 0; i < 6; i++)
 #pragma unroll
-                        for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; Hx[i * 3 + j] = h; }
+                            for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; hx[i * 3 + j] = h; }
+                    } else {      // (wmode 1, a landmark with more than eight edges: unscaled for now, rescaled in place below)
+                        double* Hx = &P.Hpl[(size_t)e * 18];
+#pragma unroll
+                        for (int i = 0; i < 6; i++)
+#pragma unroll
+                            for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; Hx[i * 3 + j] = h; }
+                    }
                 }
             }
+            firstEdge = false;
             e = -1;
             if (more) {
                 k += 8;
@@ -1784,10 +1824,38 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
         for (int i = 0; i < 6; i++) H[i] = group8_sum(H[i]);
 #pragma unroll
         for (int i = 0; i < 3; i++) b[i] = group8_sum(b[i]);
-        if (live && slot == 0) {
+        if (live && slot == 0 && !diagOnly) {
             double* Ho = &P.Hll[(size_t)l * 9];
             Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
             for (int i = 0; i < 3; i++) P.bl[(size_t)l * 3 + i] = b[i];
+        }
+        if (wm && !diagOnly) {
+            // every lane of the group holds the landmark's sums: each factors M = Hll + lambda I itself and scales its own block(s)
+            const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
+            double T[6];
+            ba_chol3(H, lambda, T);
+            if (hxE >= 0) {
+                double* Wx = &P.Hpl[(size_t)hxE * 18];
+#pragma unroll
+                for (int i = 0; i < 6; i++) { double w0, w1, w2; ba_scale_row(T, hx[i * 3], hx[i * 3 + 1], hx[i * 3 + 2], w0, w1, w2); Wx[i * 3] = w0; Wx[i * 3 + 1] = w1; Wx[i * 3 + 2] = w2; }
+            }
+            if (more) {
+                for (int k2 = P.ptStart[l] + slot + 8; k2 < end; k2 += 8) {
+                    const int e2 = P.ptEdges[k2];
+                    if ((P.eflag[e2] & 2) || P.camIdx[P.ecam[e2]] < 0) continue;
+                    double* Wx = &P.Hpl[(size_t)e2 * 18];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { double w0, w1, w2; ba_scale_row(T, Wx[i * 3], Wx[i * 3 + 1], Wx[i * 3 + 2], w0, w1, w2); Wx[i * 3] = w0; Wx[i * 3 + 1] = w1; Wx[i * 3 + 2] = w2; }
+                }
+            }
+            if (live && slot == 0) {
+                double* To = &P.Tl[(size_t)l * 6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) To[i] = T[i];
+                P.ul[(size_t)l * 3] = T[0] * b[0];
+                P.ul[(size_t)l * 3 + 1] = T[1] * b[0] + T[3] * b[1];
+                P.ul[(size_t)l * 3 + 2] = T[2] * b[0] + T[4] * b[1] + T[5] * b[2];
+            }
         }
         if (first) {
             double m = (live && slot == 0) ? fmax(fmax(fabs(H[0]), fabs(H[3])), fabs(H[5])) : 0.0;
@@ -1843,9 +1911,11 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
         if (threadIdx.x == 0) {
             const double* sums = part;
             int q = 0;
-            for (int i = 0; i < 6; i++)
-                for (int j = i; j < 6; j++) { P.Hpp[(size_t)ci * 36 + i * 6 + j] = sums[q]; P.Hpp[(size_t)ci * 36 + j * 6 + i] = sums[q]; q++; }
-            for (int i = 0; i < 6; i++) P.bp[(size_t)ci * 6 + i] = sums[21 + i];
+            if (!diagOnly) {
+                for (int i = 0; i < 6; i++)
+                    for (int j = i; j < 6; j++) { P.Hpp[(size_t)ci * 36 + i * 6 + j] = sums[q]; P.Hpp[(size_t)ci * 36 + j * 6 + i] = sums[q]; q++; }
+                for (int i = 0; i < 6; i++) P.bp[(size_t)ci * 6 + i] = sums[21 + i];
+            }
             if (first) {
                 double m = 0;
                 q = 0;
@@ -1886,6 +1956,37 @@ __device__ inline void dinv3(const double* Hll, double lambda, double Di[9]) {
     Di[0] = c00 * id; Di[1] = (A[2] * A[7] - A[1] * A[8]) * id; Di[2] = (A[1] * A[5] - A[2] * A[4]) * id;
     Di[3] = c01 * id; Di[4] = (A[0] * A[8] - A[2] * A[6]) * id; Di[5] = (A[2] * A[3] - A[0] * A[5]) * id;
     Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+// wmode 1: instead of (Hll + lambda I)^-1 the landmark keeps the inverse Cholesky factor.  M = Hll + lambda I = C C^T (C lower), T = C^-T
+// (upper), so M^-1 = T T^T and   Hpl M^-1 Hpl'^T = (Hpl T)(Hpl' T)^T,   Hpl M^-1 bl = (Hpl T)(C^-1 bl),   x_l = T (C^-1 bl - sum (Hpl T)^T x_p):
+// every product the Schur complement needs is a plain inner product of pre-scaled blocks W = Hpl T -- what the matrix-core assembly
+// accumulates.  (block_solver.hpp:381-432 forms the same matrices through Eigen's 3x3 inverse(); the two differ in rounding only.)
+// H: upper triangle 00 01 02 11 12 22 of Hll.  1 / sqrt by v_rsq_f64 + two Newton steps (~1 ulp).
+__device__ __forceinline__ double ba_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(y * 0.5, e, y);
+}
+__device__ __forceinline__ void ba_chol3(const double H[6], double lambda, double T[6]) {
+    const double m00 = H[0] + lambda, m11 = H[3] + lambda, m22 = H[5] + lambda;
+    const double li00 = ba_rsqrt(m00);
+    const double c10 = H[1] * li00, c20 = H[2] * li00;
+    const double li11 = ba_rsqrt(m11 - c10 * c10);
+    const double c21 = (H[4] - c20 * c10) * li11;
+    const double li22 = ba_rsqrt(m22 - c20 * c20 - c21 * c21);
+    const double li10 = -(c10 * li00) * li11;
+    const double li21 = -(c21 * li11) * li22;
+    const double li20 = -(c20 * li00 + c21 * li10) * li22;
+    T[0] = li00; T[1] = li10; T[2] = li20; T[3] = li11; T[4] = li21; T[5] = li22;      // T[a][b] = C^-1[b][a]
+}
+// row (h0 h1 h2) of Hpl -> row of W = Hpl T
+__device__ __forceinline__ void ba_scale_row(const double T[6], double h0, double h1, double h2, double& w0, double& w1, double& w2) {
+    w0 = h0 * T[0];
+    w1 = h0 * T[1] + h1 * T[3];
+    w2 = h0 * T[2] + h1 * T[4] + h2 * T[5];
 }
 
 // grid (nFree, chunks), one workgroup per (free camera i1, chunk of its edge list).  Everything the accumulation needs is
@@ -3751,8 +3852,8 @@ struct BALaunch {
         int par = 0;
         for (int it = from; it < to; it++) {
             if (it != from && nL) par ^= 1;
-            if (d.hasPl) hipLaunchKernelGGL((k_ba_linearize<true, kLinThreads>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0);
-            else hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0);
+            if (d.hasPl) hipLaunchKernelGGL((k_ba_linearize<true, kLinThreads>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
+            else hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
             if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, W, wp(par));   // no Schur kernel to do it
             trial(par, 1, it == 0 && nF, it == to - 1 || !nL);      // (no landmark, no k_ba_backsub: k_ba_decide after every trial)
         }
@@ -4530,6 +4631,7 @@ eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
     P.Tout = (SE3*)a.outSE3; P.result = a.outResult; P.trace = a.outTrace;
     P.scatterIdx = a.scatterIdx; P.scatterOut = a.scatterOut;
     P.done = nullptr; P.doneSeq = 0;
+    P.pubSrc = (const uint4*)a.pubSrc; P.pubDst = (uint4*)a.pubDst; P.pubN16 = a.pubN16;
     P.nPlanes = 0; P.planes = nullptr; P.planeOutlier = nullptr; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
     P.dbg = nullptr;
     // The edge count lives on the device: one launch per geometry class the capacity admits (four waves up to 1024 edges, eight

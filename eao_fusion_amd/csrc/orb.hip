@@ -236,22 +236,6 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
     // lanes idle (257 px -> two blocks; measured 240 -> 181 us for the seven launches of a 256-frame batch)
     resize_item(A, s, blockIdx.z + f0, ((int)blockIdx.x * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x);
 }
-// The TOP of the pyramid in one launch: the upper levels are small (level 4 of a 640 x 480 frame is 309 x 231) and each is a resize of the one
-// below, so as launches of their own they are a chain of ~10 us steps on the step's critical path (pyramid -> FAST of the upper levels ->
-// their quad-trees -> description).  Here ONE workgroup per frame walks the levels first .. last in turn: all items of a level, a workgroup
-// barrier (the level it just wrote is the next one's source: same workgroup, global memory), the next level.  Same items, same arithmetic.
-constexpr int kResizeTopThreads = 1024, kResizeTopLevels = 6;
-struct ResizeTopArgs { int n; ResizeArgs L[kResizeTopLevels]; };
-__global__ __launch_bounds__(kResizeTopThreads) void k_resize_top(ResizeTopArgs T, ImgSrc s, int f0) {
-    const int f = blockIdx.x + f0;
-    for (int q = 0; q < T.n; q++) {
-        const ResizeArgs& A = T.L[q];
-        const int items = A.G * ((A.D.h + kResizeRows - 1) / kResizeRows);
-        for (int item = threadIdx.x; item < items; item += kResizeTopThreads) resize_item(A, s, f, item);
-        __threadfence_block();
-        __syncthreads();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------- fused pyramid
 // The whole pyramid of a frame in ONE launch.  Level l is a resize of level l - 1, so the seven launches of k_resize are a
@@ -1553,212 +1537,6 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
     }
 }
 
-// (Measured option, see the launch site.)  KPW keypoints per WAVE, in three phases.  One wave per keypoint spends a third of its instructions on
-// arithmetic that is the same in all 64 lanes -- fastAtan2 of the two moments and, above all, cos / sin of the angle in double precision (upstream
-// rounds a DOUBLE cosine to float) -- and half of the launch on the prologue of 66 000 waves.  Here a wave fetches the keys of its KPW keypoints
-// lane-parallel, (A) sums the moments of the keypoints one after the other and parks each pair in ONE LANE, (B) evaluates angle, cosine and sine of
-// all of them lane-parallel, ONCE, and (C) walks the keypoints again for the 256 steered tests.  The next keypoint's window is fetched while the current one is worked on.  Same arithmetic per keypoint, expression for expression; results bit-identical.
-template <int KPW>
-__global__ __launch_bounds__(256) void k_orient_describe_multi(const Geom* __restrict__ g, ImgSrc s, const uint8_t* __restrict__ blur,
-                                                               const unsigned* __restrict__ levelkps, const int* __restrict__ levelcnt,
-                                                               eao_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                               int* __restrict__ nout, int cap, int f0, int nlevels, int lFirst, int lEnd, int writeN) {
-    static_assert(KPW <= 64, "one lane per keypoint of the wave");
-    // KPW = 0: the launch has a FIXED number of workgroups per frame (gridDim.x) and a wave takes ceil(keypoints / waves) of them -- every wave of
-    // the launch then lives equally long and the launch can be sized to ONE round of the chip's wave slots (with a fixed KPW the 1056 waves an XCD
-    // gets for eight frames of 1000 keypoints fill its 512 slots 2.06 times: three rounds of 18 us for 31 us of arithmetic)
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned pat[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const unsigned*>(c_pattern)[lane + 64 * k];
-    int bx = blockIdx.x, fy = blockIdx.y;
-    if ((gridDim.y & 7) == 0) {      // frame f on XCD f % 8 (speed only)
-        const unsigned b = blockIdx.x + gridDim.x * blockIdx.y, xcd = b & 7, slot = b >> 3;
-        fy = (int)(xcd + 8 * (slot / gridDim.x));
-        bx = (int)(slot % gridDim.x);
-    }
-    const int f = fy + f0;
-    // level ends of the frame (lanes 0 .. nlevels-1, inclusive scan inside the 16-lane row)
-    int inc = lane < lEnd ? levelcnt[f * nlevels + lane] : 0;
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);
-    const int total = __builtin_amdgcn_readlane(inc, 15);
-    if (writeN && bx == 0 && threadIdx.x == 0) nout[f] = min(total, cap);
-    const int jbase = lFirst > 0 ? __builtin_amdgcn_readlane(inc, lFirst - 1) : 0;
-    const int kpw = KPW ? KPW : (min(total, cap) - jbase + 4 * (int)gridDim.x - 1) / (4 * (int)gridDim.x);
-    const int jfirst = (bx * 4 + wv) * kpw + jbase;
-    const int nk = min(kpw, min(total, cap) - jfirst);      // keypoints of this wave (wave-uniform)
-    if (nk <= 0) return;
-    constexpr int kPR = 18, kPW = 10, kMR = 15, kMW = 9;
-    __shared__ unsigned patch[4][(2 * kPR + 1) * kPW];
-    __shared__ unsigned mpatch[4][(2 * kMR + 1) * kMW];
-    // ---- the wave's keys, lane q = keypoint q: level of compact index j (number of level ends at or before it), then the key
-    int lq = 0;
-    unsigned keyq = 0;
-    {
-        const int j = jfirst + min(lane, nk - 1);
-        int lbase = 0;
-        for (int lv = 0; lv < nlevels; lv++) { const int e = __builtin_amdgcn_readlane(inc, lv); if (e <= j) { lq = lv + 1; lbase = e; } }
-        lq = min(lq, nlevels - 1);
-        keyq = levelkps[(long long)f * g->totalKpCap + g->L[lq].kpBase + (j - lbase)];
-    }
-    // byte offsets (inside a window) of the words a lane stages: they depend on the level's pitch only, and a wave's keypoints are consecutive
-    // entries of the level-ordered list -- recomputed when the pitch changes (wave-uniform branch)
-    unsigned wOff[6];
-    int wPitch = -1;
-    auto m_offsets = [&](int pitch) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) { const int i = min(lane + 64 * k, (2 * kMR + 1) * kMW - 1), r = (i * 7282) >> 16; wOff[k] = (unsigned)(r * pitch + 4 * (i - r * kMW)); }
-        wPitch = pitch;
-    };
-    auto p_offsets = [&](int pitch) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) { const int i = min(lane + 64 * k, (2 * kPR + 1) * kPW - 1), r = (i * 6554) >> 16; wOff[k] = (unsigned)(r * pitch + 4 * (i - r * kPW)); }
-        wPitch = pitch;
-    };
-    auto key_of = [&](int q, int& l, unsigned& key, int& cx, int& cy) {
-        l = __builtin_amdgcn_readlane(lq, q);
-        key = (unsigned)__builtin_amdgcn_readlane((int)keyq, q);
-        cx = (int)(key & 0xFFF) + kMinBorder; cy = (int)((key >> 12) & 0xFFF) + kMinBorder;
-    };
-    // ---- (A) moments
-    const int u = (lane & 31) - 15, half = lane >> 5, au = u < 0 ? -u : u;
-    int mm01 = 0, mm10 = 0;
-    auto fetch_m = [&](int q, unsigned (&mv)[5]) {      // (an unaligned caller image takes byte loads at staging time instead)
-        int l, cx, cy; unsigned key;
-        key_of(q, l, key, cx, cy);
-        int pitch;
-        const uint8_t* img = level_ptr(g, s, l, f, &pitch);
-        if ((((uintptr_t)img | (uintptr_t)pitch) & 3) == 0) {
-            const uint8_t* mw = img + (cy - kMR) * pitch + (cx - kMR - ((cx - kMR) & 3));
-            if (pitch != wPitch) m_offsets(pitch);
-#pragma unroll
-            for (int k = 0; k < 5; k++) mv[k] = *reinterpret_cast<const unsigned*>(mw + wOff[k]);
-        }
-    };
-    auto moments = [&](int q, const unsigned (&mv)[5]) {
-        int l, cx, cy; unsigned key;
-        key_of(q, l, key, cx, cy);
-        int pitch;
-        const uint8_t* img = level_ptr(g, s, l, f, &pitch);
-        const int mph = (cx - kMR) & 3;
-        if ((((uintptr_t)img | (uintptr_t)pitch) & 3) == 0) {
-#pragma unroll
-            for (int k = 0; k < 5; k++)
-                if (lane + 64 * k < (2 * kMR + 1) * kMW) mpatch[wv][lane + 64 * k] = mv[k];
-        } else {
-            uint8_t* mb = reinterpret_cast<uint8_t*>(mpatch[wv]);
-            for (int i = lane; i < (2 * kMR + 1) * (2 * kMR + 1); i += 64) {
-                const int r = i / (2 * kMR + 1), c = i - r * (2 * kMR + 1);
-                mb[r * (4 * kMW) + c + mph] = img[(long long)(cy - kMR + r) * pitch + cx - kMR + c];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        int m10 = 0, m01 = 0;
-        if (u <= 15) {
-            const uint8_t* c0 = reinterpret_cast<const uint8_t*>(mpatch[wv]) + kMR * (4 * kMW) + kMR + mph + u;
-            auto row = [&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                constexpr int umLo = kUmaxTab[15 - k], umHi = kUmaxTab[k + 1];
-                const int v = half ? k + 1 : k - 15;
-                const int um = half ? umHi : umLo;
-                const int pix = c0[v * (4 * kMW)];
-                const int val = au <= um ? pix : 0;
-                m10 += u * val;
-                m01 += v * val;
-            };
-#define EAO_ROW(K) row(std::integral_constant<int, K>{});
-            EAO_ROW(0) EAO_ROW(1) EAO_ROW(2) EAO_ROW(3) EAO_ROW(4) EAO_ROW(5) EAO_ROW(6) EAO_ROW(7)
-            EAO_ROW(8) EAO_ROW(9) EAO_ROW(10) EAO_ROW(11) EAO_ROW(12) EAO_ROW(13) EAO_ROW(14) EAO_ROW(15)
-#undef EAO_ROW
-        }
-        m10 = wave_sum_i32(m10);
-        m01 = wave_sum_i32(m01);
-        if (lane == q) { mm01 = m01; mm10 = m10; }
-        __builtin_amdgcn_wave_barrier();          // (the window is overwritten by the next keypoint)
-    };
-    {
-        unsigned mvA[5] = {0, 0, 0, 0, 0};
-        fetch_m(0, mvA);
-        for (int q = 0; q < nk; q++) {
-            unsigned cur[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) cur[k] = mvA[k];
-            if (q + 1 < nk) fetch_m(q + 1, mvA);          // the next window travels while this one is summed
-            moments(q, cur);
-        }
-    }
-    // ---- (B) angle, cosine, sine of the wave's keypoints, one per lane
-    const float angleL = fast_atan2_deg((float)mm01, (float)mm10);
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    float aL, bL;
-    sincos_f32_via_f64(angleL * factorPI, &bL, &aL);
-    // ---- (C) steered BRIEF on the blurred level
-    wPitch = -1;
-    auto fetch_p = [&](int q, unsigned (&pw)[6]) {
-        int l, cx, cy; unsigned key;
-        key_of(q, l, key, cx, cy);
-        const int pitchB = g->L[l].pitch;
-        const uint8_t* bw = blur + (long long)f * g->pyrFrameBytes + g->L[l].off + (cy - kPR) * pitchB + (cx - kPR - ((cx - kPR) & 3));
-        if (pitchB != wPitch) p_offsets(pitchB);
-#pragma unroll
-        for (int k = 0; k < 6; k++) pw[k] = *reinterpret_cast<const unsigned*>(bw + wOff[k]);
-    };
-    auto describe = [&](int q, const unsigned (&pw)[6]) {
-        int lc, cxc, cyc; unsigned keyc;
-        key_of(q, lc, keyc, cxc, cyc);
-        const int phc = (cxc - kPR) & 3;
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-            if (lane + 64 * k < (2 * kPR + 1) * kPW) patch[wv][lane + 64 * k] = pw[k];
-        __builtin_amdgcn_wave_barrier();
-        const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angleL), q));
-        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aL), q));
-        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bL), q));
-        const uint8_t* bc = reinterpret_cast<const uint8_t*>(patch[wv]) + kPR * (4 * kPW) + kPR + phc;
-        unsigned long long words[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float xa = (float)(signed char)(pat[k] & 0xFF), ya = (float)(signed char)((pat[k] >> 8) & 0xFF);
-            const float xb = (float)(signed char)((pat[k] >> 16) & 0xFF), yb = (float)(signed char)(pat[k] >> 24);
-            const int ra = __float2int_rn(xa * b + ya * a), ca = __float2int_rn(xa * a - ya * b);
-            const int rb = __float2int_rn(xb * b + yb * a), cb = __float2int_rn(xb * a - yb * b);
-            const int t0 = bc[ra * (4 * kPW) + ca], t1 = bc[rb * (4 * kPW) + cb];
-            words[k] = __ballot(t0 < t1);
-        }
-        if (lane == 0) {
-            const int jout = jfirst + q;
-            const LevelGeom L = g->L[lc];
-            unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((long long)f * cap + jout) * 32);
-            d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
-            eao_keypoint kp;
-            const float fxp = (float)cxc, fyp = (float)cyc;
-            kp.x = lc ? fxp * L.scale : fxp;
-            kp.y = lc ? fyp * L.scale : fyp;
-            kp.size = (float)L.scaledPatch;
-            kp.angle = angle;
-            kp.response = (float)(keyc >> 24);
-            kp.octave = lc;
-            kp.class_id = -1;
-            kps[(long long)f * cap + jout] = kp;
-        }
-        __builtin_amdgcn_wave_barrier();          // (the window is overwritten by the next keypoint)
-    };
-    {
-        unsigned pwA[6] = {0, 0, 0, 0, 0, 0};
-        fetch_p(0, pwA);
-        for (int q = 0; q < nk; q++) {
-            unsigned cur[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) cur[k] = pwA[k];
-            if (q + 1 < nk) fetch_p(q + 1, pwA);
-            describe(q, cur);
-        }
-    }
-}
-
 // unpack (x, y, response) of the gathered FAST candidates for the stage tap
 __global__ void k_unpack_cand(const unsigned* __restrict__ keys, int n, float* __restrict__ xyr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1917,7 +1695,7 @@ struct eao_orb {
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
     bool evLastValid = false, capturing = false;   // evLastValid: a call has been enqueued on lastStream
     hipStream_t lastStream = nullptr;      // the stream of the previous call: compared, never dereferenced (its owner may have destroyed it)
-    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {}, evBlur[kLanes] = {}, evLow[kLanes] = {}, evUp[kLanes] = {}, evUpDone[kLanes] = {};
+    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
     eao::DevBuf<uint8_t> d_pyr, d_blur, d_in;
@@ -2196,10 +1974,6 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
             EAO_HIP(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evMid[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
-            EAO_HIP(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming));
-            EAO_HIP(hipEventCreateWithFlags(&h->evLow[i], hipEventDisableTiming));
-            EAO_HIP(hipEventCreateWithFlags(&h->evUp[i], hipEventDisableTiming));
-            EAO_HIP(hipEventCreateWithFlags(&h->evUpDone[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evDone[i], hipEventDisableTiming));
         }
     }
@@ -2363,39 +2137,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             EAO_HIP(hipStreamWaitEvent(ss, h->evStart, 0));
             fast(ss, 0, cells0);
         }
-        // Each FAST launch lasts about as long as its slowest cell-waves need, whatever its size (64 frames, each launch ALONE: level 0 36 us, levels 1-2
-        // 43 us, levels 3-7 44.5 us -- the upper levels' cells hold more corners): the upper levels' launch sits on the step's critical path behind the
-        // pyramid chain.  EAO_ORB_UP_SPLIT=l (measured, NOT the default) starts the FAST cells of levels mid .. l-1 on a third stream as soon as level l-1
-        // exists, so that only levels l .. wait for the end of the chain: 0.2626 ms per step without, 0.281 / 0.275 / 0.263 with l = 4 / 5 / 6 -- the two
-        // smaller launches last 46 and 34 us each: a launch is as long as its slowest cell-waves live (2-3 k instructions at a seventh of a SIMD's issue
-        // slots), so cutting one into two only adds a tail (tools/sweep_up.sh, tools/trace_fast_split.sh).
-        static const int envUp = getenv("EAO_ORB_UP_SPLIT") ? atoi(getenv("EAO_ORB_UP_SPLIT")) : 0;
-        const int upSplit = (!prof && onCaller && mid > 0 && qtEarly && h->laneMain[i] && envUp > mid && envUp < g.nlevels) ? envUp : 0;
-        bool blurOwn = false, splitOD = false;
-        ResizeTopArgs top;
-        top.n = 0;
+        // (Round 3 measured four more schedule variants and a multi-keypoint description kernel here -- the upper levels' FAST split over a third
+        //  stream, the blur on its own stream with a split description, the top of the pyramid as one launch, several keypoints per wave -- none
+        //  faster than this schedule; they were removed in round 4, DESIGN.md section 5 keeps the measurements and the commits that hold the code.)
         auto orient = [&](hipStream_t str, int lFirst, int lEnd, int writeN) {
             eao::Range rg("orb: orientation + description");
             const int rangeCap = (lEnd < g.nlevels ? g.L[lEnd].kpBase : g.totalKpCap) - g.L[lFirst].kpBase;
-            // EAO_ORB_KPW=4 / 8 / 16: several keypoints per wave, angle / cosine / sine of a wave's keypoints evaluated lane-parallel
-            // (k_orient_describe_multi).  Measured, NOT the default: 36 % fewer VALU instructions (2.79e7 -> 1.78e7 per 64 frames, SQ_INSTS_VALU) but
-            // 53.8 -> 50.9 us for the launch and no change of the step (0.2554 / 0.2545 ms): the launch is not bound by instruction issue after all.
-            static const int envKpw = getenv("EAO_ORB_KPW") ? atoi(getenv("EAO_ORB_KPW")) : 0;
-            const int kpw = envKpw;
-            auto multi = [&](auto kern, int KPW) {
-                hipLaunchKernelGGL(kern, dim3(eao::cdiv(std::min(cap, rangeCap), 4 * KPW), nb), dim3(256), 0, str, h->d_geom.p, s, h->d_blur.p, h->d_levelkps.p,
-                                   h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, lFirst, lEnd, writeN);
-            };
-            if (kpw == 1) {      // balanced: 16 workgroups per frame, ceil(keypoints / 64) keypoints per wave (up to 64: 4096 keypoints per frame)
-                if (std::min(cap, rangeCap) <= 4096) {
-                    hipLaunchKernelGGL(k_orient_describe_multi<0>, dim3(16, nb), dim3(256), 0, str, h->d_geom.p, s, h->d_blur.p, h->d_levelkps.p,
-                                       h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, lFirst, lEnd, writeN);
-                    return;
-                }
-            }
-            if (kpw == 4) { multi(k_orient_describe_multi<4>, 4); return; }
-            if (kpw == 8) { multi(k_orient_describe_multi<8>, 8); return; }
-            if (kpw == 16) { multi(k_orient_describe_multi<16>, 16); return; }
             hipLaunchKernelGGL(k_orient_describe, dim3(eao::cdiv(std::min(cap, rangeCap), 4), nb), dim3(256), 0, str, h->d_geom.p, s, h->d_blur.p, h->d_levelkps.p,
                                h->d_levelcnt.p, d_kps, d_desc, d_n, cap, f0, g.nlevels, lFirst, lEnd, writeN);
         };
@@ -2414,23 +2161,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             ra.S = {g.L[l - 1].w, g.L[l - 1].h, g.L[l - 1].pitch, g.L[l - 1].off};
             ra.invX = 1. / ((double)g.L[l].w / g.L[l - 1].w); ra.invY = 1. / ((double)g.L[l].h / g.L[l - 1].h);
             ra.srcIsInput = l == 1; ra.pyrFrameBytes = g.pyrFrameBytes;
-            // levels topFrom .. nlevels-1 in ONE launch (k_resize_top), measured and NOT the default (EAO_ORB_TOP_FROM=3..6 switches it on): 64 frames,
-            // ms per step: off 0.2540, from level 3: 0.2736, 4: 0.2721, 5: 0.2657, 6: 0.2579 -- one workgroup per frame walks a level's items five
-            // deep where the chain's launches spread them over the chip; the launches it saves were cheaper (tools/sweep_top.sh)
-            static const int envTop = getenv("EAO_ORB_TOP_FROM") ? atoi(getenv("EAO_ORB_TOP_FROM")) : 0;
-            const int topFrom = (!prof && envTop >= 3 && envTop > mid - 1 && envTop < g.nlevels && g.nlevels - envTop <= kResizeTopLevels && nb >= 16) ? envTop : 0;
-            if (topFrom && l >= topFrom) {
-                top.L[top.n++] = ra;
-                if (l == g.nlevels - 1) { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_resize_top, dim3(nb), dim3(kResizeTopThreads), 0, ms, top, s, f0); }
-                continue;
-            }
             { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_resize, grid, block, 0, ms, ra, s, f0); }
-            if (upSplit && l == upSplit - 1) {      // levels mid .. upSplit-1 exist: their FAST cells start on the third stream, beside the rest of the chain
-                EAO_HIP(hipEventRecord(h->evUp[i], ms));
-                EAO_HIP(hipStreamWaitEvent(h->laneMain[i], h->evUp[i], 0));
-                fast(h->laneMain[i], g.L[mid].cellBase, g.L[upSplit].cellBase);
-                EAO_HIP(hipEventRecord(h->evUpDone[i], h->laneMain[i]));
-            }
             if (l == mid - 1) {
                 EAO_HIP(hipEventRecord(h->evMid[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evMid[i], 0));
@@ -2464,32 +2195,12 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             // it (64 frames: 0.2784 -> 0.2762 ms, 256 frames: 1.092 -> 1.071; measured the other way round before the resize
             // launches became one-wave workgroups, when the pyramid ended 20 us later).  EAO_ORB_BLUR_EARLY=0 restores the old point.
             static const int envBlurEarly = getenv("EAO_ORB_BLUR_EARLY") ? atoi(getenv("EAO_ORB_BLUR_EARLY")) : 1;
-            // Round 3, measured and NOT the default (EAO_ORB_BLUR_STREAM=1 switches it on, EAO_ORB_SPLIT=0 its second half off): the blur on a
-            // THIRD stream (the lane's own main stream, idle while the chain runs on the caller's), started when the pyramid ends, beside the
-            // upper levels' FAST instead of behind the side stream's quad-trees, and orientation + description of the LOWER levels on the side
-            // stream as soon as their quad-trees and the blur are done.  64 frames: 0.2570 ms per step as it is, 0.2631 with the blur on its own
-            // stream (it takes 75 us instead of 40 beside FAST and slows that down too), 0.2584 with the split launches on top: FAST, blur and
-            // description are all bound by the same VALUs, so moving them against each other buys nothing (tools/sweep_blur_stream.sh).
-            static const int envBlurStream = getenv("EAO_ORB_BLUR_STREAM") ? atoi(getenv("EAO_ORB_BLUR_STREAM")) : 0;
-            blurOwn = envBlurStream && envBlurEarly && onCaller && qtEarly && h->laneMain[i];
-            hipStream_t bs = blurOwn ? h->laneMain[i] : ss;
             if (envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
-            fast(ms, upSplit ? g.L[upSplit].cellBase : early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
-            if (upSplit) EAO_HIP(hipStreamWaitEvent(ms, h->evUpDone[i], 0));
+            fast(ms, early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
             if (!envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
-            EAO_HIP(hipStreamWaitEvent(bs, h->evFork[i], 0));
-            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, bs, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
-            if (blurOwn) EAO_HIP(hipEventRecord(h->evBlur[i], bs));
+            EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
+            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
-            // ... and orientation + description of the LOWER levels follow their quad-trees on the side stream as soon as the blur is
-            // done, beside the upper levels' quad-trees on the main stream (EAO_ORB_SPLIT=0: one launch for all levels at the end)
-            static const int envSplit = getenv("EAO_ORB_SPLIT") ? atoi(getenv("EAO_ORB_SPLIT")) : 1;
-            splitOD = blurOwn && envSplit;
-            if (splitOD) {
-                EAO_HIP(hipStreamWaitEvent(ss, h->evBlur[i], 0));
-                orient(ss, 0, mid, 0);
-                EAO_HIP(hipEventRecord(h->evLow[i], ss));
-            }
             if (early0 && !qtEarly) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
         }
         if (pe) EAO_HIP(hipEventRecord(ev[2], ms));
@@ -2497,12 +2208,8 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         // (the lower levels' quad-trees ran on the side stream, ahead of the blur: the wait for evJoin below covers them)
         if (pe) EAO_HIP(hipEventRecord(ev[3], ms));
         EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
-        if (blurOwn) EAO_HIP(hipStreamWaitEvent(ms, h->evBlur[i], 0));
         if (pe) EAO_HIP(hipEventRecord(ev[4], ms));
-        if (splitOD) {
-            orient(ms, mid, g.nlevels, 1);
-            EAO_HIP(hipStreamWaitEvent(ms, h->evLow[i], 0));
-        } else orient(ms, 0, g.nlevels, 1);
+        orient(ms, 0, g.nlevels, 1);
         if (pe) EAO_HIP(hipEventRecord(ev[5], ms));
         if (!onCaller) {
             EAO_HIP(hipEventRecord(h->evDone[i], ms));
@@ -2637,10 +2344,6 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->evFast0[i]) (void)hipEventDestroy(h->evFast0[i]);
         if (h->evMid[i]) (void)hipEventDestroy(h->evMid[i]);
         if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
-        if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]);
-        if (h->evLow[i]) (void)hipEventDestroy(h->evLow[i]);
-        if (h->evUp[i]) (void)hipEventDestroy(h->evUp[i]);
-        if (h->evUpDone[i]) (void)hipEventDestroy(h->evUpDone[i]);
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
     if (h->pinOut) (void)hipHostFree(h->pinOut);

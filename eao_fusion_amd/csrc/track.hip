@@ -55,6 +55,7 @@ struct eao_tracker {
     float* dScale; float* dInvSigma2;
     unsigned char* res = nullptr;      // result block: device view of resPin, resBytes
     unsigned char* resPin = nullptr;
+    unsigned char* resDev = nullptr;   // its DEVICE twin (same layout): every kernel of the chain writes here; the chain's last launch alone copies it to `res`
     size_t resBytes = 0, listCap = 0, assignLds = 0;
     int seq = 0;                       // call counter: the chain's last launch stores it in the result block's done word
     long long* dbg = nullptr;          // EAO_DEBUG_STAMPS: phase stamps of k_track_assign_edges (diagnostic runs only)
@@ -358,7 +359,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
     // has been claimed in the same round (at least by the point that reads it), i.e. its low 14 bits are this round's smallest lister.
     for (int i = t; i < cap; i += kAssignThreads) minq[i] = 0x7FFFFFFF;
     __syncthreads();
-    for (int round = 0; round < 4096; round++, tag--) {
+    for (int round = 0; round <= nMp; round++, tag--) {      // (every round finalises at least the smallest undecided point: at most nMp rounds)
         if (t == 0) s_left = 0;
         lap(0);
 #pragma unroll
@@ -608,8 +609,11 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
                  oSc = take(4 * 64), oIs = take(4 * 64), oCol = take(4 * ((size_t)cfg->grid_cols + 1));
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
     h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C) + al256(M) + 256;      // (+ the done word)
+    const size_t oRes = take(h->resBytes);
     if ((st = h->dev.reserve(off))) { delete h; return st; }
     unsigned char* b = h->dev.p;
+    h->resDev = b + oRes;
+    EAO_HIP(hipMemset(h->resDev, 0, h->resBytes));
     h->kx = (float*)(b + oKx); h->ky = (float*)(b + oKy); h->ang = (float*)(b + oAng); h->ur = (float*)(b + oUr); h->dz = (float*)(b + oDz);
     h->oct = (int*)(b + oOct); h->order = (int*)(b + oOrd); h->cellx = (unsigned short*)(b + oCx); h->celly = (unsigned short*)(b + oCy);
     h->counts = (int*)(b + oCnt); h->prior = (int*)(b + oPrior); h->priorXw = (float*)(b + oPriorX); h->kpMp = (int*)(b + oKpMp); h->occ = b + oOcc; h->kpOut = b + oKpOut;
@@ -621,8 +625,8 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     h->eXw = (double*)(b + oEX); h->eObs = (double*)(b + oEO); h->eInfo = (double*)(b + oEI); h->eErr = (double*)(b + oEE); h->eFlags = b + oEF;
     h->eOutl = b + oEOu; h->eKp = (int*)(b + oEK); h->dScale = (float*)(b + oSc); h->dInvSigma2 = (float*)(b + oIs);
     h->colStart = (int*)(b + oCol);
-    // the result block is MAPPED PINNED HOST memory: the last kernels of the chain write it over PCIe (~30 KB) and the host reads it
-    // after the one synchronisation -- no device-to-host copy behind the chain
+    // the result block is MAPPED PINNED HOST memory: the LAST kernel of the chain copies the device twin into it over PCIe (~30 KB) and the host
+    // reads it after the one synchronisation -- no device-to-host copy behind the chain
     if (hipHostMalloc((void**)&h->resPin, h->resBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     std::memset(h->resPin, 0, h->resBytes);
     if (hipHostGetDevicePointer((void**)&h->res, h->resPin, 0) != hipSuccess) { delete h; eao::set_error("hipHostGetDevicePointer failed"); return EAO_ERR_NO_DEVICE; }
@@ -756,8 +760,9 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     E.Xw = h->eXw; E.obs = h->eObs; E.info = h->eInfo; E.flags = h->eFlags; E.eKp = h->eKp;
     const int edgeCap = std::min(C, 2048);
     // result block layout
+    // (kernels write the DEVICE twin; the chain's last launch publishes it: see PoseDev::pubSrc, csrc/lm.hip)
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
-    unsigned char* r = h->res;
+    unsigned char* r = h->resDev;
     size_t ro = 0;
     void* rSE3 = r + ro; ro += se3;
     int* rRes = (int*)(r + ro); ro += al256(16);
@@ -767,8 +772,11 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     unsigned char* rOutl = r + ro; ro += al256(C);
     float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
-    unsigned char* rInView = r + ro; ro += al256((size_t)h->capMp);
-    int* rDone = (int*)(r + ro); ro += 256;
+    unsigned char* rInView = r + ro;
+    const size_t pubBytes = (ro + (size_t)std::max(nMp, 0) + 15) & ~(size_t)15;      // everything up to the last in-view flag
+    ro += al256((size_t)h->capMp);
+    const size_t oDone = ro; ro += 256;
+    int* rDone = (int*)(h->res + oDone);                                            // the done word itself only exists in host memory
     ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz, rInView};
     static const int envAll = getenv("EAO_TRACK_ALL_LISTERS") ? atoi(getenv("EAO_TRACK_ALL_LISTERS")) : 0;
     auto launch_assign = [&](auto kern) {
@@ -787,17 +795,21 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     PA.fx = c.fx; PA.fy = c.fy; PA.cx = c.cx; PA.cy = c.cy; PA.bf = c.mbf;
     PA.outSE3 = rSE3; PA.outResult = rRes; PA.outTrace = rTrace;
     PA.scatterIdx = h->eKp; PA.scatterOut = rOutl;      // mvbOutlier by keypoint, straight into the result block
-    // The results are in mapped host memory when the chain's last launch has stored this call's number in the done word: the host polls
-    // that word (the posted writes of the kernel arrive in order) instead of waiting for the runtime to notice the end of the stream --
-    // EAO_TRACK_POLL=0 goes back to hipStreamSynchronize, which is also what a call falls back to after 50 ms without the word.
+    // The results are in mapped host memory when the chain's last launch has stored this call's number in the done word: that launch is the
+    // ONLY writer of the host block -- it copies the device twin out, every thread fences at system scope, and behind a barrier one thread
+    // stores the word (round 4; until then two kernels wrote the host block and the host trusted the earlier kernel's posted writes to have
+    // landed when the later kernel's word arrived: one wrong frame in ~10^4).  The host polls the word instead of
+    // waiting for the runtime to notice the end of the stream; EAO_TRACK_POLL=0 goes back to hipStreamSynchronize, which is also what a
+    // call falls back to after 50 ms without the word.
     static const int envPoll = getenv("EAO_TRACK_POLL") ? atoi(getenv("EAO_TRACK_POLL")) : 1;
     const int seq = ++h->seq;
-    if (envPoll) { PA.done = rDone; PA.doneSeq = seq; }
+    *reinterpret_cast<volatile int*>(h->resPin + oDone) = 0;
+    PA.done = rDone; PA.doneSeq = seq; PA.pubSrc = h->resDev; PA.pubDst = h->res; PA.pubN16 = (int)(pubBytes / 16);
     if ((st = eao::lm::enqueue_pose_device(PA, s))) return st;
     // ---- the results are in host memory when the done word says so (or when the stream has drained)
     bool seen = false;
     if (envPoll) {
-        const volatile int* done = reinterpret_cast<const volatile int*>(h->resPin + ((unsigned char*)rDone - r));
+        const volatile int* done = reinterpret_cast<const volatile int*>(h->resPin + oDone);
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; !(seen = *done == seq); spins++)
             if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;

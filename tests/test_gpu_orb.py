@@ -284,15 +284,3 @@ def test_streaming_host_api_equals_extract_batch(gpu):
             assert np.array_equal(got[k][1][f], want[k][1][f]), "batch %d frame %d descriptors" % (k, f)
     with pytest.raises(gpu.EaoError):
         ext.stream_submit(7, B)             # no such slot
-
-
-def test_multi_keypoint_description_kernel_is_bit_exact():
-    """k_orient_describe_multi (EAO_ORB_KPW, a measured option: several keypoints per wave, trigonometry lane-parallel) against the oracle: a short
-    randomised sweep in a process of its own, because the switch is read once per process."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for kpw in ("8", "16"):
-        env = dict(os.environ, EAO_ORB_KPW=kpw)
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "sweep_orb.py"), "23", "6"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0, out.stderr[-2000:]
-        assert "sweep done: 6 configs, 0 mismatches" in out.stdout, out.stdout[-2000:]
