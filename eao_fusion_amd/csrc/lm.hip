@@ -1720,6 +1720,37 @@ __device__ inline void ba_commit(const BADecision& d, const double* lmOld, const
     st->seq = seq;
 }
 
+// wmode 1: instead of (Hll + lambda I)^-1 the landmark keeps the inverse Cholesky factor.  M = Hll + lambda I = C C^T (C lower), T = C^-T
+// (upper), so M^-1 = T T^T and   Hpl M^-1 Hpl'^T = (Hpl T)(Hpl' T)^T,   Hpl M^-1 bl = (Hpl T)(C^-1 bl),   x_l = T (C^-1 bl - sum (Hpl T)^T x_p):
+// every product the Schur complement needs is a plain inner product of pre-scaled blocks W = Hpl T -- what the matrix-core assembly
+// accumulates.  (block_solver.hpp:381-432 forms the same matrices through Eigen's 3x3 inverse(); the two differ in rounding only.)
+// H: upper triangle 00 01 02 11 12 22 of Hll.  1 / sqrt by v_rsq_f64 + two Newton steps (~1 ulp).
+__device__ __forceinline__ double ba_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(y * 0.5, e, y);
+}
+__device__ __forceinline__ void ba_chol3(const double H[6], double lambda, double T[6]) {
+    const double m00 = H[0] + lambda, m11 = H[3] + lambda, m22 = H[5] + lambda;
+    const double li00 = ba_rsqrt(m00);
+    const double c10 = H[1] * li00, c20 = H[2] * li00;
+    const double li11 = ba_rsqrt(m11 - c10 * c10);
+    const double c21 = (H[4] - c20 * c10) * li11;
+    const double li22 = ba_rsqrt(m22 - c20 * c20 - c21 * c21);
+    const double li10 = -(c10 * li00) * li11;
+    const double li21 = -(c21 * li11) * li22;
+    const double li20 = -(c20 * li00 + c21 * li10) * li22;
+    T[0] = li00; T[1] = li10; T[2] = li20; T[3] = li11; T[4] = li21; T[5] = li22;      // T[a][b] = C^-1[b][a]
+}
+// row (h0 h1 h2) of Hpl -> row of W = Hpl T
+__device__ __forceinline__ void ba_scale_row(const double T[6], double h0, double h1, double h2, double& w0, double& w1, double& w2) {
+    w0 = h0 * T[0];
+    w1 = h0 * T[1] + h1 * T[3];
+    w2 = h0 * T[2] + h1 * T[4] + h2 * T[5];
+}
+
 // role A: blocks [0, ptBlocks): eight lanes per landmark.  role B: blocks [ptBlocks, ptBlocks + nFree): one block per free
 // camera, one edge per thread; the 27 sums (21 of Hpp's upper triangle + 6 of bp) go through LDS in a fixed order: lane
 // quads first (DPP), then 27 x 8 column threads over 32 quad leaders each, then the last 8.  (Sixty-four-lane shuffle
@@ -1956,37 +1987,6 @@ __device__ inline void dinv3(const double* Hll, double lambda, double Di[9]) {
     Di[0] = c00 * id; Di[1] = (A[2] * A[7] - A[1] * A[8]) * id; Di[2] = (A[1] * A[5] - A[2] * A[4]) * id;
     Di[3] = c01 * id; Di[4] = (A[0] * A[8] - A[2] * A[6]) * id; Di[5] = (A[2] * A[3] - A[0] * A[5]) * id;
     Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-}
-
-// wmode 1: instead of (Hll + lambda I)^-1 the landmark keeps the inverse Cholesky factor.  M = Hll + lambda I = C C^T (C lower), T = C^-T
-// (upper), so M^-1 = T T^T and   Hpl M^-1 Hpl'^T = (Hpl T)(Hpl' T)^T,   Hpl M^-1 bl = (Hpl T)(C^-1 bl),   x_l = T (C^-1 bl - sum (Hpl T)^T x_p):
-// every product the Schur complement needs is a plain inner product of pre-scaled blocks W = Hpl T -- what the matrix-core assembly
-// accumulates.  (block_solver.hpp:381-432 forms the same matrices through Eigen's 3x3 inverse(); the two differ in rounding only.)
-// H: upper triangle 00 01 02 11 12 22 of Hll.  1 / sqrt by v_rsq_f64 + two Newton steps (~1 ulp).
-__device__ __forceinline__ double ba_rsqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-x * y, y, 1.0);
-    y = fma(y * 0.5, e, y);
-    e = fma(-x * y, y, 1.0);
-    return fma(y * 0.5, e, y);
-}
-__device__ __forceinline__ void ba_chol3(const double H[6], double lambda, double T[6]) {
-    const double m00 = H[0] + lambda, m11 = H[3] + lambda, m22 = H[5] + lambda;
-    const double li00 = ba_rsqrt(m00);
-    const double c10 = H[1] * li00, c20 = H[2] * li00;
-    const double li11 = ba_rsqrt(m11 - c10 * c10);
-    const double c21 = (H[4] - c20 * c10) * li11;
-    const double li22 = ba_rsqrt(m22 - c20 * c20 - c21 * c21);
-    const double li10 = -(c10 * li00) * li11;
-    const double li21 = -(c21 * li11) * li22;
-    const double li20 = -(c20 * li00 + c21 * li10) * li22;
-    T[0] = li00; T[1] = li10; T[2] = li20; T[3] = li11; T[4] = li21; T[5] = li22;      // T[a][b] = C^-1[b][a]
-}
-// row (h0 h1 h2) of Hpl -> row of W = Hpl T
-__device__ __forceinline__ void ba_scale_row(const double T[6], double h0, double h1, double h2, double& w0, double& w1, double& w2) {
-    w0 = h0 * T[0];
-    w1 = h0 * T[1] + h1 * T[3];
-    w2 = h0 * T[2] + h1 * T[4] + h2 * T[5];
 }
 
 // grid (nFree, chunks), one workgroup per (free camera i1, chunk of its edge list).  Everything the accumulation needs is
