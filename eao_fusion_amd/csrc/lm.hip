@@ -1415,7 +1415,7 @@ struct BADev {
     int wmode;                 // 1: windows on the matrix-core pair assembly (k_ba_schur_pairs_mfma): W / Tl / ul instead of Hpl / dinv3
     GP<double> Tl;             // nL*6: T = C^-T (upper triangle 00 01 02 11 12 22) per landmark block   (wmode 1)
     GP<double> ul;             // nL*3: u = C^-1 bl                                                     (wmode 1)
-    GP<int4> pairItems;        // per camera pair (i1 <= i2), nL slots: {edge (l, i1), edge (l, i2), l, 0} of the landmarks both observe, ascending (k_ba_pairs)
+    GP<int4> pairItems;        // per camera pair (i1 <= i2), nL slots: {144 * edge (l, i1), 144 * edge (l, i2), 24 * l, l} of the landmarks both observe, ascending (k_ba_pairs)
     GP<double> slab;           // chunks * nFree * (nFree*36 + 6): partial Schur rows
     GP<double> sys;            // n*(n+1): assembled Schur system (upper triangle + rhs column)
     GP<double> solveScratch;   // n*(n+1)+... doubles when the Schur system does not fit in LDS, else null
@@ -1763,10 +1763,14 @@ constexpr int kLinThreads = 1024;      // (batches: 512- and 256-thread workgrou
 // depend on the order, and non-negative doubles order like their bit patterns.
 // ctlOld != nullptr: the previous trial's decision has not been taken yet (bulk segment): see BADecision.  P.ctl / P.lm
 // are then the blocks this trial runs on (written by workgroup 0 here), ctlOld / lmOld the ones the previous trial ran on.
-// diagOnly (wmode 1, first linearisation of an optimize() call): only the largest diagonal entry is wanted -- lambda_0 must be known before
-// the landmarks' blocks can be stored pre-scaled, so that call runs the launch twice: once for the maximum, once for everything else.
-template <bool PL, int NT>
+// WM (wmode 1, point landmarks only): the blocks are stored pre-scaled, W = Hpl C^-T (ba_chol3), which needs the landmark's COMPLETE Hll before
+// the first block can be written: role A runs over its edges twice -- sums first, then the Jacobians again (a hundred instructions from the edge's
+// inputs, which are in L1 by then) for the blocks.  Holding the first pass's 6 x 3 block in registers instead spilled (128 VGPRs at 1024 threads).
+// diagOnly (WM, first linearisation of an optimize() call): only the largest diagonal entry is wanted -- lambda_0 must be known before
+// the blocks can be scaled, so that call runs the launch twice: once for the maximum, once for everything else.
+template <bool PL, int NT, bool WM>
 __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W, int wpar, int ptBlocks, int first, int diagOnly) {
+    static_assert(!(PL && WM), "pre-scaled blocks: point landmarks only");
     BA_WIN(P);
     if ((int)bx >= ptBlocks + P.nFree) return;      // (a batch is launched with the largest window's grid)
     __shared__ double red[(NT / 4) * 27], part[8 * 27];
@@ -1778,6 +1782,98 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
     const bool stampL = P.dbg && threadIdx.x == 0 && ((int)bx == 0 || (int)bx == ptBlocks);
     const long long tl0 = stampL ? clock64() : 0;
     if ((int)bx < ptBlocks) {
+        if constexpr (WM) {
+            const int l = (bx * NT + threadIdx.x) >> 3, slot = threadIdx.x & 7;
+            const bool live = l < P.nL;
+            const int4 rec = live ? P.slot[(size_t)l * 8 + slot] : make_int4(-1, 0, -1, 0);    // the lane's first edge (see BADev::slot)
+            const int pt = rec.w & 0x7FFFFFFF;
+            const bool more = rec.w < 0;          // a landmark with more than eight edges walks its list as before
+            const int kFirst = more ? P.ptStart[l] + slot : 0, end = more ? P.ptStart[l + 1] : 0;
+            auto each_edge = [&](auto&& body) {
+                int e = rec.x, cam = rec.y, ci = rec.z, k = kFirst;
+                while (e >= 0) {
+                    body(e, cam, ci);
+                    e = -1;
+                    if (more) {
+                        k += 8;
+                        if (k < end) { e = P.ptEdges[k]; cam = P.ecam[e]; ci = P.camIdx[cam]; }
+                    }
+                }
+            };
+            // robust weight and Jacobians of one edge, exactly as the classic role A forms them
+            auto edge_terms = [&](int e, int cam, double (&A)[3][3], double (&B)[3][6], double (&wi)[3], double (&omr)[3]) {
+                const unsigned char fl = P.eflag[e];
+                const bool stereo = fl & 1;
+                const double* er = &P.err[3 * e];
+                const double info = P.info[e];
+                double w = 1.0, r0;
+                ba_jacobians(P.cam, stereo, cams[cam], &pts[3 * pt], A, B);
+                if (fl & 4) huber(ba_chi2(er, info, stereo), stereo ? P.cam.deltaStereo : P.cam.deltaMono, r0, w);
+                for (int r = 0; r < 3; r++) { wi[r] = w * info; omr[r] = w * (-(info * er[r])); }
+            };
+            double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};   // upper triangle 00 01 02 11 12 22
+            each_edge([&](int e, int cam, int) {
+                if (P.eflag[e] & 2) return;
+                double A[3][3], B[3][6], wi[3], omr[3];
+                edge_terms(e, cam, A, B, wi, omr);
+                int q = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    double sb = 0;
+#pragma unroll
+                    for (int r = 0; r < 3; r++) sb += A[r][i] * omr[r];
+                    b[i] += sb;
+#pragma unroll
+                    for (int j = i; j < 3; j++) { double h = 0; for (int r = 0; r < 3; r++) h += A[r][i] * wi[r] * A[r][j]; H[q++] += h; }
+                }
+            });
+#pragma unroll
+            for (int i = 0; i < 6; i++) H[i] = group8_sum(H[i]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) b[i] = group8_sum(b[i]);
+            if (first) {
+                double m = (live && slot == 0) ? fmax(fmax(fabs(H[0]), fabs(H[3])), fabs(H[5])) : 0.0;
+                for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_down(m, d));
+                if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = m;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    for (int w = 1; w < NT / 64; w++) m = fmax(m, s_wmax[w]);
+                    atomicMax((unsigned long long*)&P.lm[3], (unsigned long long)__double_as_longlong(m));
+                }
+            }
+            if (!diagOnly) {
+                // every lane of the group holds the landmark's sums: each factors M = Hll + lambda I itself and scales its own block(s)
+                const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
+                double T[6];
+                ba_chol3(H, lambda, T);
+                each_edge([&](int e, int cam, int ci) {
+                    if (ci < 0 || (P.eflag[e] & 2)) return;
+                    double A[3][3], B[3][6], wi[3], omr[3];
+                    edge_terms(e, cam, A, B, wi, omr);
+                    double* Wx = &P.Hpl[(size_t)e * 18];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        double h[3];
+#pragma unroll
+                        for (int j = 0; j < 3; j++) { double v = 0; for (int r = 0; r < 3; r++) v += B[r][i] * wi[r] * A[r][j]; h[j] = v; }
+                        double w0, w1, w2;
+                        ba_scale_row(T, h[0], h[1], h[2], w0, w1, w2);
+                        Wx[i * 3] = w0; Wx[i * 3 + 1] = w1; Wx[i * 3 + 2] = w2;
+                    }
+                });
+                if (live && slot == 0) {
+                    double* Ho = &P.Hll[(size_t)l * 9];
+                    Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
+                    for (int i = 0; i < 3; i++) P.bl[(size_t)l * 3 + i] = b[i];
+                    double* To = &P.Tl[(size_t)l * 6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) To[i] = T[i];
+                    P.ul[(size_t)l * 3] = T[0] * b[0];
+                    P.ul[(size_t)l * 3 + 1] = T[1] * b[0] + T[3] * b[1];
+                    P.ul[(size_t)l * 3 + 2] = T[2] * b[0] + T[4] * b[1] + T[5] * b[2];
+                }
+            }
+        } else {
         // role A: eight lanes per landmark, one edge per lane; Hll / bl are xor-tree sums over the lane group
         const int l = (bx * NT + threadIdx.x) >> 3, slot = threadIdx.x & 7;
         const bool live = l < P.nL;
@@ -1788,12 +1884,6 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
         int k = 0, end = 0;
         if (more) { k = P.ptStart[l] + slot; end = P.ptStart[l + 1]; }
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};   // upper triangle 00 01 02 11 12 22
-        const bool wm = !PL && P.wmode != 0;
-        double hx[18];            // wmode 1: the Hpl block of the lane's FIRST edge waits here for the landmark's Cholesky factor
-        int hxE = -1;
-        bool firstEdge = true;
-#pragma unroll
-        for (int q = 0; q < 18; q++) hx[q] = 0;
         while (e >= 0) {
             const unsigned char fl = P.eflag[e];
             if (!(fl & 2)) {
@@ -1828,23 +1918,14 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
 #pragma unroll
                     for (int j = i; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += A[r][i] * wi[r] * A[r][j]; H[q++] += h; }
                 }
-                if (camFree && !diagOnly) {
-                    if (wm && firstEdge) {
-                        hxE = e;
+                if (camFree) {
+                    double* Hx = &P.Hpl[(size_t)e * 18];
 #pragma unroll
-                        for (int i = 0; i < 6; i++)
+                    for (int i = 0; i < 6; i++)
 #pragma unroll
-                            for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; hx[i * 3 + j] = h; }
-                    } else {      // (wmode 1, a landmark with more than eight edges: unscaled for now, rescaled in place below)
-                        double* Hx = &P.Hpl[(size_t)e * 18];
-#pragma unroll
-                        for (int i = 0; i < 6; i++)
-#pragma unroll
-                            for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; Hx[i * 3 + j] = h; }
-                    }
+                        for (int j = 0; j < 3; j++) { double h = 0; for (int r = 0; r < D; r++) h += B[r][i] * wi[r] * A[r][j]; Hx[i * 3 + j] = h; }
                 }
             }
-            firstEdge = false;
             e = -1;
             if (more) {
                 k += 8;
@@ -1855,38 +1936,10 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
         for (int i = 0; i < 6; i++) H[i] = group8_sum(H[i]);
 #pragma unroll
         for (int i = 0; i < 3; i++) b[i] = group8_sum(b[i]);
-        if (live && slot == 0 && !diagOnly) {
+        if (live && slot == 0) {
             double* Ho = &P.Hll[(size_t)l * 9];
             Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
             for (int i = 0; i < 3; i++) P.bl[(size_t)l * 3 + i] = b[i];
-        }
-        if (wm && !diagOnly) {
-            // every lane of the group holds the landmark's sums: each factors M = Hll + lambda I itself and scales its own block(s)
-            const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
-            double T[6];
-            ba_chol3(H, lambda, T);
-            if (hxE >= 0) {
-                double* Wx = &P.Hpl[(size_t)hxE * 18];
-#pragma unroll
-                for (int i = 0; i < 6; i++) { double w0, w1, w2; ba_scale_row(T, hx[i * 3], hx[i * 3 + 1], hx[i * 3 + 2], w0, w1, w2); Wx[i * 3] = w0; Wx[i * 3 + 1] = w1; Wx[i * 3 + 2] = w2; }
-            }
-            if (more) {
-                for (int k2 = P.ptStart[l] + slot + 8; k2 < end; k2 += 8) {
-                    const int e2 = P.ptEdges[k2];
-                    if ((P.eflag[e2] & 2) || P.camIdx[P.ecam[e2]] < 0) continue;
-                    double* Wx = &P.Hpl[(size_t)e2 * 18];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { double w0, w1, w2; ba_scale_row(T, Wx[i * 3], Wx[i * 3 + 1], Wx[i * 3 + 2], w0, w1, w2); Wx[i * 3] = w0; Wx[i * 3 + 1] = w1; Wx[i * 3 + 2] = w2; }
-                }
-            }
-            if (live && slot == 0) {
-                double* To = &P.Tl[(size_t)l * 6];
-#pragma unroll
-                for (int i = 0; i < 6; i++) To[i] = T[i];
-                P.ul[(size_t)l * 3] = T[0] * b[0];
-                P.ul[(size_t)l * 3 + 1] = T[1] * b[0] + T[3] * b[1];
-                P.ul[(size_t)l * 3 + 2] = T[2] * b[0] + T[4] * b[1] + T[5] * b[2];
-            }
         }
         if (first) {
             double m = (live && slot == 0) ? fmax(fmax(fabs(H[0]), fabs(H[3])), fabs(H[5])) : 0.0;
@@ -1897,6 +1950,7 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
                 for (int w = 1; w < NT / 64; w++) m = fmax(m, s_wmax[w]);
                 atomicMax((unsigned long long*)&P.lm[3], (unsigned long long)__double_as_longlong(m));
             }
+        }
         }
         if (stampL) P.dbg[14] = clock64() - tl0;
     } else {
@@ -1942,7 +1996,7 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
         if (threadIdx.x == 0) {
             const double* sums = part;
             int q = 0;
-            if (!diagOnly) {
+            if (!(WM && diagOnly)) {
                 for (int i = 0; i < 6; i++)
                     for (int j = i; j < 6; j++) { P.Hpp[(size_t)ci * 36 + i * 6 + j] = sums[q]; P.Hpp[(size_t)ci * 36 + j * 6 + i] = sums[q]; q++; }
                 for (int i = 0; i < 6; i++) P.bp[(size_t)ci * 6 + i] = sums[21 + i];
@@ -2368,11 +2422,13 @@ __global__ __launch_bounds__(256) void k_ba_pairs(const BADev* __restrict__ W, i
     while (rem >= nF - i1) { rem -= nF - i1; i1++; }
     const int i2 = i1 + rem;
     int* out = P.pairPts + (size_t)bx * P.nL;
+    int4* items = P.wmode ? P.pairItems + (size_t)bx * P.nL : nullptr;      // wmode 1: {edge (l, i1), edge (l, i2), l} instead of the bare landmark list
     if (t == 0) s_base = 0;
     __syncthreads();
     for (int l0 = 0; l0 < P.nL; l0 += 256) {
         const int l = l0 + t;
-        const bool hit = l < P.nL && P.table[(size_t)l * nF + i1] >= 0 && P.table[(size_t)l * nF + i2] >= 0;
+        const int e1 = l < P.nL ? P.table[(size_t)l * nF + i1] : -1, e2 = l < P.nL ? P.table[(size_t)l * nF + i2] : -1;
+        const bool hit = e1 >= 0 && e2 >= 0;
         // ordered compaction: waves in order, lanes in order
         __shared__ int s_w[4];
         const unsigned long long m = __ballot(hit);
@@ -2380,7 +2436,10 @@ __global__ __launch_bounds__(256) void k_ba_pairs(const BADev* __restrict__ W, i
         __syncthreads();
         int off = s_base;
         for (int w = 0; w < (t >> 6); w++) off += s_w[w];
-        if (hit) out[off + __popcll(m & ((1ull << lane) - 1))] = l;
+        if (hit) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1));
+            if (items) items[pos] = make_int4(e1 * 144, e2 * 144, l * 24, l); else out[pos] = l;      // byte offsets into Hpl (W) / ul, see k_ba_schur_pairs_mfma
+        }
         __syncthreads();
         if (t == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
@@ -2573,6 +2632,142 @@ __global__ __launch_bounds__(NT, 1024 / NT) void k_ba_schur_pairs_b(const BADev*
         } else if (diag) {
             const int r = 3 * h + q - 18;
             tile_store(P, g, g.n4, i1 * 6 + r, P.bp[i1 * 6 + r] - tot);   // right-hand side row
+        }
+    }
+}
+
+// (c) wmode 1 (round 4): the pair's block on the MATRIX CORES.  With the blocks stored pre-scaled (W = Hpl C^-T, see ba_chol3)
+//     S(i1, i2) = Hpp - sum_l W(i1, l) W(i2, l)^T   and   rhs(i1) = bp - sum_l W(i1, l) u_l
+//     are plain inner products over k = (landmark, component): a [6 x 3 n] by [3 n x 7] product per pair -- too thin for a GEMM tile, but exactly
+//     what v_mfma_f64_4x4x4_4b_f64 takes: FOUR independent 4 x 4 x 4 products per instruction, used as the four quadrants of an 8 x 8 output
+//     (rows 0..5 = the rows of W(i1), columns 0..5 = the rows of W(i2), column 6 = u_l on diagonal pairs; the rest is padding).  One
+//     instruction consumes one shared landmark (k = 0..2 its three components, k = 3 padding).  Lane maps of the instruction
+//     (tools/ubench/mfma_probe.hip -> profiles/r04_mfma_probe.txt):
+//       A: block (l >> 2) & 3, row l & 3, k = l >> 4      B: block (l >> 2) & 3, column l & 3, k = l >> 4      D: block (l >> 2) & 3, row l >> 4, column l & 3
+//     with block = 2 (row quadrant) + (column quadrant).
+//     What bounds every variant of this assembly is the path from L2 into the CU, not the arithmetic (a launch with the products removed takes as long
+//     as with them): the texture-address unit walks a wave's load quad by quad and line by line, so a load is only cheap when ALL its lanes carry
+//     16 useful bytes that fall on few lines.  Hence the fetch is shaped for the memory path, not for the instruction: a wave fetches the two blocks of
+//     SEVEN landmarks with two 16-byte-per-lane loads (lane 9 j + c: chunk c of landmark j's 144-byte block; ~15 cache lines per load), parks them in
+//     its own 2.4 KB of LDS, and reads each landmark's operands back in the instruction's layout (two 8-byte LDS reads with constant per-lane offsets;
+//     the padding lanes read a zero slot).  The first version -- operands loaded element-wise from global memory, 8 bytes per lane, 36 of 64 lanes useful,
+//     two loads per landmark -- took 105 us per 25 windows against the VALU kernel's 73: profiles/r04_ba_pair_ablation.txt.
+//     The loads of the next seven landmarks are in flight while the current seven are multiplied (eight VGPRs per stage); the records
+//     {144 * edge (l, i1), 144 * edge (l, i2), 24 * l} come as one small coalesced load two steps ahead and are handed to the lanes by ds_bpermute.
+//     A workgroup owns a pair: wave w takes the groups w, w + NW, ... of the pair's landmark list (four accumulators per wave, in turn), the
+//     partial sums are added in a fixed order -- no atomics, reproducible.  The list's last group is filled up with records of the ZERO block (block nEdges
+//     of the array, entry nL of u: k_ba_prepare clears them).  An edge the outlier pass switched off keeps its list entries: its W block is zero
+//     (k_ba_classify), its products vanish.
+constexpr int kPairG = 7;                       // landmarks per fetch
+constexpr int kPairSlot = 160;                  // LDS bytes per staged block: 144 data + a zero slot for the padding lanes
+constexpr int kPairWaveLds = 2 * kPairG * kPairSlot + kPairG * 32;      // A blocks, B blocks, u entries (24 + 8 bytes each)
+template <int NW>      // waves per pair: 4 in a batch (5 250 workgroups: throughput), 16 for a single window (210 workgroups: latency of the longest pair)
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 8 : 1) void k_ba_schur_pairs_mfma(const BADev* __restrict__ W, int wpar, int first) {
+    BA_WIN(P);
+    if ((int)bx >= P.nFree * (P.nFree + 1) / 2) return;
+    __shared__ double part[NW][64];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[NW][kPairWaveLds];
+    const int nF = P.nFree, t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // A launch of this kernel lasts (rounds of workgroups) x (a workgroup's chain of dependent memory round trips), not its arithmetic: everything a
+    // workgroup can ask for before it knows anything else is asked for at once -- halt flag, lambda, the pair's landmark count, the wave's FIRST
+    // group of records (wave w takes groups w, w + NW, ...: where they lie does not depend on the count) and, for the last step, its share of Hpp / bp.
+    int i1 = 0, rem = bx;
+    while (rem >= nF - i1) { rem -= nF - i1; i1++; }
+    const int i2 = i1 + rem;
+    const bool diag = i1 == i2;
+    const int blk = (lane >> 2) & 3, k = lane >> 4;
+    const int dR = 4 * (blk >> 1) + (lane >> 4), dC = 4 * (blk & 1) + (lane & 3);       // D: row of W(i1), column = row of W(i2) (6: the right-hand side)
+    const int* __restrict__ irec = reinterpret_cast<const int*>((const int4*)P.pairItems + (size_t)bx * P.nL);
+    const int recCap = 4 * P.nL;
+    auto load_rec = [&](int g) { const int o = g * (4 * kPairG) + lane; return lane < 4 * kPairG && o < recCap ? irec[o] : 0; };      // (inside the pair's nL slots whatever the count)
+    const int halt = P.ctl[kCtlHalt];
+    const double lm0 = P.lm[0], lm3 = P.lm[3];
+    const int cnt = P.pairCnt[bx];
+    int recRaw = load_rec(wave);
+    double hb = 0;
+    if (diag && wave == 0 && dR < 6) { if (dC < 6) hb = P.Hpp[(size_t)i1 * 36 + dR * 6 + dC]; else if (dC == 6) hb = P.bp[i1 * 6 + dR]; }
+    if (halt) return;
+    const double lambda = (first & 1) ? refc::LM_TAU * lm3 : lm0;
+    if ((first & 1) && bx == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
+    // ---- the instruction's view: which element of the 8 x 4 / 4 x 8 operands this lane supplies, as a byte offset into a staged block
+    const int aRow = 4 * (blk >> 1) + (lane & 3), bCol = 4 * (blk & 1) + (lane & 3);
+    const bool aOn = aRow < 6 && k < 3, bOn = bCol < 6 && k < 3, uOn = diag && bCol == 6 && k < 3;
+    unsigned char* const sA = stage[wave];
+    unsigned char* const sB = sA + kPairG * kPairSlot;
+    unsigned char* const sU = sB + kPairG * kPairSlot;
+    const unsigned char* const rdA = sA + (aOn ? (aRow * 3 + k) * 8 : 144);
+    const unsigned char* const rdB = bOn ? sB + (bCol * 3 + k) * 8 : (uOn ? sU + k * 8 : sB + 144);
+    const int rdBStep = (!bOn && uOn) ? 32 : kPairSlot;
+    // ---- the memory path's view: lane 9 j + c fetches 16-byte chunk c of landmark j's blocks (lane 63 idles); lanes 3 j + d fetch u_l[d]
+    const int fj = lane / 9, fc = lane - 9 * fj;
+    const bool fOn = lane < 9 * kPairG, fuOn = diag && lane < 3 * kPairG;
+    unsigned char* const wrA = sA + fj * kPairSlot + fc * 16;
+    unsigned char* const wrB = sB + fj * kPairSlot + fc * 16;
+    unsigned char* const wrU = sU + (lane / 3) * 32 + (lane % 3) * 8;
+    if (lane < kPairG) {      // the zero slots (never written again)
+        *reinterpret_cast<uint4*>(sA + lane * kPairSlot + 144) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(sB + lane * kPairSlot + 144) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<double*>(sU + lane * 32 + 24) = 0;
+    }
+    const char* const Wb = reinterpret_cast<const char*>((const double*)P.Hpl);
+    const char* const ub = reinterpret_cast<const char*>((const double*)P.ul);
+    const int nGall = (cnt + kPairG - 1) / kPairG;                    // groups of the pair; this wave: wave, wave + NW, ...
+    const int padRec = (lane & 3) == 2 ? P.nL * 24 : P.nEdges * 144;
+    auto fix_rec = [&](int raw, int g) { return lane < 4 * min(kPairG, cnt - g * kPairG) ? raw : padRec; };      // a short last group: the rest are zero-block records
+    struct Fetch { uint4 a, b; double u; };
+    auto fetch_data = [&](int rec) {
+        Fetch f;
+        f.a = make_uint4(0, 0, 0, 0); f.b = f.a; f.u = 0;
+        const unsigned oa = (unsigned)__shfl(rec, 4 * fj), ob = (unsigned)__shfl(rec, 4 * fj + 1);
+        if (fOn) {
+            f.a = *reinterpret_cast<const uint4*>(Wb + oa + fc * 16);
+            f.b = *reinterpret_cast<const uint4*>(Wb + ob + fc * 16);
+        }
+        if (diag) {
+            const unsigned ou = (unsigned)__shfl(rec, 4 * (lane / 3) + 2);
+            if (fuOn) f.u = *reinterpret_cast<const double*>(ub + ou + (lane % 3) * 8);
+        }
+        return f;
+    };
+    auto wave_fence = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    double acc[4] = {0, 0, 0, 0};
+    if (wave < nGall) {
+        Fetch cur = fetch_data(fix_rec(recRaw, wave));
+        int recN = wave + NW < nGall ? load_rec(wave + NW) : 0;
+        for (int g = wave; g < nGall; g += NW) {
+            // park group g (the reads of the group before it were issued ahead of these writes: LDS operations of a wave execute in order)
+            if (fOn) { *reinterpret_cast<uint4*>(wrA) = cur.a; *reinterpret_cast<uint4*>(wrB) = cur.b; }
+            if (fuOn) *reinterpret_cast<double*>(wrU) = cur.u;
+            // the next group's blocks on their way, the records of the one after it behind them
+            if (g + NW < nGall) {
+                cur = fetch_data(fix_rec(recN, g + NW));
+                if (g + 2 * NW < nGall) recN = load_rec(g + 2 * NW);
+            }
+            wave_fence();
+#pragma unroll
+            for (int j = 0; j < kPairG; j++) {
+                const double a = *reinterpret_cast<const double*>(rdA + j * kPairSlot);
+                const double b = *reinterpret_cast<const double*>(rdB + j * rdBStep);
+                acc[j & 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[j & 3], 0, 0, 0);
+            }
+            wave_fence();
+        }
+    }
+    part[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (t < 64) {
+        double tot = part[0][t];
+#pragma unroll
+        for (int w = 1; w < NW; w++) tot += part[w][t];
+        const TileGeom g = tile_geom(nF);
+        if (dR < 6 && dC < 6) {
+            if (!diag) {
+                tile_store(P, g, i2 * 6 + dC, i1 * 6 + dR, -tot);           // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
+            } else if (dC >= dR) {
+                tile_store(P, g, i1 * 6 + dC, i1 * 6 + dR, (hb + (dR == dC ? lambda : 0.0)) - tot);      // the upper-triangle value, mirrored into the lower tile
+            }
+        } else if (diag && dR < 6 && dC == 6) {
+            tile_store(P, g, g.n4, i1 * 6 + dR, hb - tot);                  // right-hand side row
         }
     }
 }
@@ -3209,19 +3404,31 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
         }
     });
     double bl[3] = {0, 0, 0}, Di[9], xl[3], np[3];
-    if (live) {
-        bl[0] = P.bl[(size_t)l * 3]; bl[1] = P.bl[(size_t)l * 3 + 1]; bl[2] = P.bl[(size_t)l * 3 + 2];
-        dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
+    const bool wm = !PL && P.wmode != 0;
+    if (live) { bl[0] = P.bl[(size_t)l * 3]; bl[1] = P.bl[(size_t)l * 3 + 1]; bl[2] = P.bl[(size_t)l * 3 + 2]; }
+    if (wm) {
+        // the edges' blocks are stored pre-scaled (W = Hpl C^-T):  x_l = T (u - sum W^T x_p),  T = C^-T, u = C^-1 bl  (see ba_chol3)
+        double T[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0};
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) T[i] = P.Tl[(size_t)l * 6 + i];
+            u[0] = P.ul[(size_t)l * 3]; u[1] = P.ul[(size_t)l * 3 + 1]; u[2] = P.ul[(size_t)l * 3 + 2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) cl[c] = u[c] + group8_sum(cl[c]);
+        xl[0] = T[0] * cl[0] + T[1] * cl[1] + T[2] * cl[2];
+        xl[1] = T[3] * cl[1] + T[4] * cl[2];
+        xl[2] = T[5] * cl[2];
     } else {
-        for (int i = 0; i < 9; i++) Di[i] = 0;
+        if (live) dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
+        else for (int i = 0; i < 9; i++) Di[i] = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) cl[c] = bl[c] + group8_sum(cl[c]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) xl[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) cl[c] = bl[c] + group8_sum(cl[c]);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        xl[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
-        np[i] = (live ? pts[3 * pt + i] : 0.0) + xl[i];
-    }
+    for (int i = 0; i < 3; i++) np[i] = (live ? pts[3 * pt + i] : 0.0) + xl[i];
     const bool isPl = PL && live && pt >= P.nPtsOnly;
     double npl[4] = {1, 0, 0, 0};
     if (isPl) plane_oplus(&P.plBuf[P.ctl[kCtlCur]][4 * (pt - P.nPtsOnly)], xl, npl);      // VertexPlane::oplusImpl
@@ -3347,7 +3554,14 @@ __global__ void k_ba_classify(const BADev* __restrict__ W, int wpar, int update)
         P.eflag[e] = (unsigned char)((fl | (bad ? 2 : 0)) & ~4);
         if (!bad && !(fl & 2)) P.ctl[kCtlAnyActive] = 1;     // somebody survives: the second optimize() has something to do
         const int l = P.ptIdx[P.ept[e]], ci = P.camIdx[P.ecam[e]];
-        if (bad && l >= 0 && ci >= 0) P.table[(size_t)l * P.nFree + ci] = -1;
+        if (bad && l >= 0 && ci >= 0) {
+            P.table[(size_t)l * P.nFree + ci] = -1;
+            if (P.wmode && !(fl & 2)) {      // the pair lists keep their entries: a switched-off edge contributes a zero block from now on
+                double* Wx = &P.Hpl[(size_t)e * 18];
+#pragma unroll
+                for (int q = 0; q < 18; q++) Wx[q] = 0;
+            }
+        }
     }
 }
 
@@ -3376,6 +3590,8 @@ __global__ __launch_bounds__(256) void k_ba_prepare(const BADev* __restrict__ W,
     if (idx < P.nCams) P.camsBuf[1][idx] = P.camsBuf[0][idx];
     if (idx < P.camStart[P.nFree]) P.camEdgeL[idx] = P.ptIdx[P.ept[P.camEdges[idx]]];
     if (idx == 0) *P.doneCnt = 0;
+    if (P.wmode && idx < 18) P.Hpl[(size_t)P.nEdges * 18 + idx] = 0;      // the zero block / zero u entry that pad the pair lists' last blocks
+    if (P.wmode && idx < 3) P.ul[(size_t)P.nL * 3 + idx] = 0;
 }
 
 // Results straight into pinned host memory: final state + the per-edge outlier flags.
@@ -3750,7 +3966,7 @@ namespace {
 // Launch geometry of one window -- or, field by field, the largest of a batch (every kernel guards its own window's sizes).
 struct BADims {
     int nF = 0, nL = 0, nP = 0, nC = 0, E = 0, nPl = 0;
-    bool hasPl = false, bigPath = false, usePairs = false, solveTiles = false, tiles3 = true, solveInLds = true;
+    bool hasPl = false, bigPath = false, usePairs = false, solveTiles = false, tiles3 = true, solveInLds = true, wmode = false;
     size_t tileLds = 0, solveLds = 0, schurLds = 0;
     int nPairsNZ = 0;          // map-scale path (never batched)
     double* big = nullptr;     // "
@@ -3820,6 +4036,9 @@ struct BALaunch {
             }
             for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
                 hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, W, wp(par), J);
+        } else if (nF && d.usePairs && d.solveTiles && d.wmode) {
+            if (nz > 1) hipLaunchKernelGGL(k_ba_schur_pairs_mfma<4>, dim3(nF * (nF + 1) / 2, 1, gz()), dim3(256), 0, s, W, wp(par), firstTrial ? 1 : 0);
+            else hipLaunchKernelGGL(k_ba_schur_pairs_mfma<16>, dim3(nF * (nF + 1) / 2, 1, 1), dim3(1024), 0, s, W, wp(par), firstTrial ? 1 : 0);
         } else if (nF && d.usePairs && d.solveTiles) {
             if (nz > 1) hipLaunchKernelGGL(k_ba_schur_pairs_b<kPairThreadsB>, dim3(nF * (nF + 1) / 2, 1, gz()), dim3(kPairThreadsB), 0, s, W, wp(par), firstTrial ? 1 : 0);
             else hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2, 1, 1), dim3(kPairThreads), 0, s, W, wp(par), firstTrial ? 1 : 0);
@@ -3838,6 +4057,14 @@ struct BALaunch {
         else if (nL) hipLaunchKernelGGL(k_ba_backsub<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par), decideHere, sqHere);
         if (withDecide) hipLaunchKernelGGL(k_ba_decide, dim3(1, 1, gz()), dim3(256), 0, s, W, wp(par), ++seq, bulk);
     }
+    // wmode 1, a host-stepped RETRIAL (lambda changed, state unchanged): the stored blocks carry the previous lambda's Cholesky factor, and the residuals
+    // array holds the rejected trial's -- both are rebuilt at the current state (the same values the rejected trial started from; upstream keeps
+    // its linearisation and only re-adds lambda, block_solver.hpp:564-589)
+    void relinearize() {
+        if (!d.wmode || !d.nL) return;
+        hipLaunchKernelGGL(k_ba_errors<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(0));
+        hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads, true>), dim3(linBlocks() + d.nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(0), linBlocks(), 0, 0);
+    }
     // iterations [from, to) of an optimize() call, one trial each, no host round trip
     void bulk(int from, int to, bool withErrors) {
         const int nF = d.nF, nL = d.nL, lb = linBlocks();
@@ -3852,8 +4079,13 @@ struct BALaunch {
         int par = 0;
         for (int it = from; it < to; it++) {
             if (it != from && nL) par ^= 1;
-            if (d.hasPl) hipLaunchKernelGGL((k_ba_linearize<true, kLinThreads>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
-            else hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
+            if (d.hasPl) hipLaunchKernelGGL((k_ba_linearize<true, kLinThreads, false>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
+            else if (d.wmode) {
+                // first linearisation of the call: lambda_0 (the largest diagonal entry) must be known before the blocks can be stored pre-scaled --
+                // one pass for the maximum, one for everything else
+                if (it == 0) hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads, true>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, 1, 1);
+                hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads, true>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
+            } else hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads, false>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
             if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, W, wp(par));   // no Schur kernel to do it
             trial(par, 1, it == 0 && nF, it == to - 1 || !nL);      // (no landmark, no k_ba_backsub: k_ba_decide after every trial)
         }
@@ -3965,6 +4197,7 @@ struct BAJob {
         need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
         need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
         need += (size_t)nP * 8 * sizeof(int4) + 256;
+        need += (size_t)nP * 9 * 8 + 2048 + 256;      // Tl, ul, the zero block
         need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
             need += (2 * (size_t)bg.RP * bg.RP + (size_t)bg.N * kBigNB) * 8;
@@ -3972,7 +4205,8 @@ struct BAJob {
         } else {
             need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
             need += (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
-            need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * 4;   // landmark lists of the camera pairs
+            need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * (4 + 16);   // landmark lists / item records of the camera pairs
+            need += (size_t)nP * 9 * 8 + 1024;
             need += (size_t)nC * (nC + 1) / 2 * 4;
         }
         if ((st = c.bytes.reserve(need))) return st;
@@ -4008,6 +4242,11 @@ struct BAJob {
         const int nPairsMax = nFreeIn * (nFreeIn + 1) / 2;
         D.pairCnt = a.take<int>(bigPath ? 1 : std::max(nPairsMax, 1));
         D.pairPts = a.take<int>(pairPath ? (size_t)nPairsMax * std::max(nP, 1) : 1);
+        static const bool envNoW = getenv("EAO_BA_WMODE") && !atoi(getenv("EAO_BA_WMODE"));      // (A/B switch: the VALU pair kernels)
+        const bool wmode = pairPath && !hasPl && !envNoW;
+        D.wmode = wmode ? 1 : 0;
+        D.pairItems = a.take<int4>(wmode ? (size_t)nPairsMax * std::max(nP, 1) : 1);
+        D.Tl = a.take<double>((size_t)std::max(nP, 1) * 6); D.ul = a.take<double>(((size_t)std::max(nP, 1) + 1) * 3);
         D.cls = a.take<unsigned char>(E);
         SE3* dcamsT = a.take<SE3>(nC);
         double* dptsT = a.take<double>((size_t)nP * 3);
@@ -4017,7 +4256,7 @@ struct BAJob {
         D.err = a.take<double>((size_t)E * 3);
         D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
         D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
-        D.Hpl = a.take<double>((size_t)E * 18);
+        D.Hpl = a.take<double>(((size_t)E + 1) * 18);      // (+ the zero block of k_ba_schur_pairs_mfma)
         double* dsolveScratch = a.take<double>(bigPath ? 8 : (size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
         D.sys = a.take<double>(bigPath ? 8 : std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
         D.slab = a.take<double>(bigPath ? 8 : (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
@@ -4157,6 +4396,8 @@ struct BAJob {
         d = BADims();
         d.nF = nF; d.nL = nL; d.nP = nP; d.nC = nC; d.E = E; d.nPl = nPl; d.hasPl = hasPl; d.bigPath = bigPath; d.chunks = chunks;
         d.usePairs = pairPath && nF > 0 && nL > 0;
+        d.wmode = D.wmode != 0 && d.usePairs;
+        if (!d.wmode) D.wmode = 0;
         const size_t ldHost = (size_t)((nF * 6 + 32) & ~31) + 1;
         d.solveLds = ((size_t)(nF * 6 + 6) * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
         if (d.solveLds > 150 * 1024) {   // system too large for LDS: S lives in (L2-resident) global scratch, M/xv stay in LDS
@@ -4238,6 +4479,7 @@ struct BAJob {
             bool accepted = S.accepted != 0;
             while (rho < 0 && qmax < refc::LM_MAX_TRIALS && !(stop && *stop)) {
                 if ((st = set_ctl(0, done, nBad))) return st;
+                L.relinearize();
                 L.trial(0, 0, false, true);
                 if ((st = wait_status(L.seq))) return st;
                 rho = c.status->rho; accepted = c.status->accepted != 0; curHost = c.status->cur;

@@ -114,7 +114,12 @@ def test_local_ba_rejected_trials(gpu, oracle, seed):
             assert err <= bound * upd, "%s: |gpu-cpu| %.3e vs update %.3e (band %.1e)" % (key, err, upd, CHAOTIC_BAND[seed])
         return
     assert list(r["iters"]) == list(o["iters"])
-    _check_trace(r, o, rel=1e-4, lam_rel=2e-3)      # monocular-only windows this far from the optimum are ill-conditioned: rounding differences grow
+    # monocular-only windows this far from the optimum are ill-conditioned: rounding differences grow.  lambda: 4e-3 since round 4 (2e-3 before) -- the
+    # pair assembly works on Cholesky-scaled blocks now (csrc/lm.hip, ba_chol3) where upstream and the oracle multiply by an explicit 3 x 3 inverse, so
+    # GPU and oracle differ in rounding from the first iteration on instead of from the first reordered sum: on seed 3037 the lambda of the 14th
+    # iteration moved from 1.45e-3 (explicit inverse) to 3.07e-3 (Cholesky) off the oracle's while chi2 agrees to 9e-8 and the final points to 8e-6 of the
+    # update (profiles/r04_lm_seed3037.txt); one float32 ulp on the inputs moves the ORACLE's own lambda by up to 8e-3 (profiles/r02_lm_trace_sensitivity.txt)
+    _check_trace(r, o, rel=1e-4, lam_rel=4e-3)
     _check_updates(r["poses"], o["poses"], p["poses"], "poses")
     _check_updates(r["points"], o["points"], p["points"], "points")
     assert np.array_equal(r["edge_outlier"], o["edge_outlier"])
