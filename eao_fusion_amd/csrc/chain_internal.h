@@ -112,6 +112,13 @@ struct QueryBuild {
     int* errFlags;            // bit 0: a point in view has a predicted level outside the pyramid
     Query* qOut;
 };
+// the search windows of SearchByProjection(Cur, Last) (src/ORBmatcher.cc:1339-1393) for every last-frame keypoint; q: n_last entries
+struct FrameQueryArgs {
+    const float* Tcw; const float* Tlw; int n_last; const uint8_t* valid; const float* Xw; const int32_t* last_octave;
+    float fx, fy, cx, cy, mbf, mb, th; int mono;
+    float min_x, max_x, min_y, max_y; const float* scale_factors; int nlevels;
+};
+eao_status build_frame_queries(const FrameQueryArgs& A, Query* q);
 // candidate lists of nq device-resident queries: out (packed distance << 16 | keypoint), segStart / segCount per query,
 // cursor (zeroed here)
 eao_status enqueue_candidates_device(const FrameDevArgs& F, const Query* q, const uint8_t* qdesc, int nq, unsigned* out, int outCap,

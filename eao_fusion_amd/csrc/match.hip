@@ -362,6 +362,52 @@ eao_status eao::match::enqueue_candidates_device(const FrameDevArgs& F, const Qu
     return EAO_OK;
 }
 
+// The search windows of ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono), src/ORBmatcher.cc:1339-1393: the relative
+// motion along the optical axis decides the level window (:1343-1347), every valid last-frame point is projected with the current pose (float
+// matrices, double accumulation) and gets a window of th x the scale factor of its octave.  Shared by the host-hop entry point below and by the
+// device-resident chain (csrc/track.hip).
+eao_status eao::match::build_frame_queries(const FrameQueryArgs& A, Query* q) {
+    const float* Tcw = A.Tcw; const float* Tlw = A.Tlw;
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++) {
+        double sacc = 0;
+        for (int k = 0; k < 3; k++) sacc += (double)(-Tcw[k * 4 + i]) * (double)Tcw[k * 4 + 3];
+        twc[i] = (float)sacc;
+    }
+    for (int i = 0; i < 3; i++) {
+        double sacc = 0;
+        for (int k = 0; k < 3; k++) sacc += (double)Tlw[i * 4 + k] * (double)twc[k];
+        tlc[i] = (float)(sacc + (double)Tlw[i * 4 + 3]);
+    }
+    const bool bForward = tlc[2] > A.mb && !A.mono;
+    const bool bBackward = -tlc[2] > A.mb && !A.mono;
+    for (int i = 0; i < A.n_last; i++) {
+        Query& Q = q[i];
+        Q.active = 0; Q.x = Q.y = Q.r = 0; Q.minLevel = 0; Q.maxLevel = -1; Q.urRef = 0; Q.urTol = 0;
+        if (!A.valid[i]) continue;
+        float xc3[3];
+        for (int r = 0; r < 3; r++) {
+            double sacc = 0;
+            for (int k = 0; k < 3; k++) sacc += (double)Tcw[r * 4 + k] * (double)A.Xw[3 * i + k];
+            xc3[r] = (float)(sacc + (double)Tcw[r * 4 + 3]);
+        }
+        const float invzc = (float)(1.0 / xc3[2]);
+        if (!(invzc >= 0)) continue;                   // "if(invzc<0) continue" -- and a NaN projection (a NaN pose or point) matches nothing
+        const float u = A.fx * xc3[0] * invzc + A.cx, v = A.fy * xc3[1] * invzc + A.cy;
+        if (!(u >= A.min_x && u <= A.max_x)) continue;
+        if (!(v >= A.min_y && v <= A.max_y)) continue;
+        const int oct = A.last_octave[i];
+        EAO_REQUIRE(oct >= 0 && oct < A.nlevels, "last-frame keypoint %d: octave %d out of range", i, oct);
+        const float radius = A.th * A.scale_factors[oct];
+        Q.active = 1; Q.x = u; Q.y = v; Q.r = radius;
+        if (bForward) { Q.minLevel = oct; Q.maxLevel = -1; }
+        else if (bBackward) { Q.minLevel = 0; Q.maxLevel = oct; }
+        else { Q.minLevel = oct - 1; Q.maxLevel = oct + 1; }
+        Q.urRef = u - A.mbf * invzc; Q.urTol = radius;
+    }
+    return EAO_OK;
+}
+
 extern "C" {
 
 eao_status eao_search_by_projection_points(const eao_frame_view* F, int32_t n_mp, const float* proj_x, const float* proj_y,
@@ -422,45 +468,9 @@ eao_status eao_search_by_projection_frames(const eao_frame_view* C, const float*
     EAO_REQUIRE(n_last == 0 || (valid && Xw && mp_desc && last_octave && last_angle), "null last-frame arrays");
     EAO_REQUIRE(C->n == 0 || (C->kp_x && C->kp_y && C->kp_octave && C->kp_angle && C->u_right && C->descriptors && C->scale_factors), "incomplete frame view");
     for (int i = 0; i < C->n; i++) cur_match[i] = -1;
-    // relative motion along the optical axis decides the level window (:1343-1347); float matrices, double accumulation
-    float twc[3], tlc[3];
-    for (int i = 0; i < 3; i++) {
-        double sacc = 0;
-        for (int k = 0; k < 3; k++) sacc += (double)(-Tcw[k * 4 + i]) * (double)Tcw[k * 4 + 3];
-        twc[i] = (float)sacc;
-    }
-    for (int i = 0; i < 3; i++) {
-        double sacc = 0;
-        for (int k = 0; k < 3; k++) sacc += (double)Tlw[i * 4 + k] * (double)twc[k];
-        tlc[i] = (float)(sacc + (double)Tlw[i * 4 + 3]);
-    }
-    const bool bForward = tlc[2] > mb && !mono;
-    const bool bBackward = -tlc[2] > mb && !mono;
     std::vector<Query> q(n_last);
-    for (int i = 0; i < n_last; i++) {
-        Query& Q = q[i];
-        Q.active = 0; Q.x = Q.y = Q.r = 0; Q.minLevel = 0; Q.maxLevel = -1; Q.urRef = 0; Q.urTol = 0;
-        if (!valid[i]) continue;
-        float xc3[3];
-        for (int r = 0; r < 3; r++) {
-            double sacc = 0;
-            for (int k = 0; k < 3; k++) sacc += (double)Tcw[r * 4 + k] * (double)Xw[3 * i + k];
-            xc3[r] = (float)(sacc + (double)Tcw[r * 4 + 3]);
-        }
-        const float invzc = (float)(1.0 / xc3[2]);
-        if (invzc < 0) continue;
-        const float u = fx * xc3[0] * invzc + cx, v = fy * xc3[1] * invzc + cy;
-        if (u < C->min_x || u > C->max_x) continue;
-        if (v < C->min_y || v > C->max_y) continue;
-        const int oct = last_octave[i];
-        EAO_REQUIRE(oct >= 0 && oct < C->nlevels, "last-frame keypoint %d: octave %d out of range", i, oct);
-        const float radius = th * C->scale_factors[oct];
-        Q.active = 1; Q.x = u; Q.y = v; Q.r = radius;
-        if (bForward) { Q.minLevel = oct; Q.maxLevel = -1; }
-        else if (bBackward) { Q.minLevel = 0; Q.maxLevel = oct; }
-        else { Q.minLevel = oct - 1; Q.maxLevel = oct + 1; }
-        Q.urRef = u - mbf * invzc; Q.urTol = radius;
-    }
+    eao::match::FrameQueryArgs QA{Tcw, Tlw, n_last, valid, Xw, last_octave, fx, fy, cx, cy, mbf, mb, th, mono, C->min_x, C->max_x, C->min_y, C->max_y, C->scale_factors, C->nlevels};
+    if (eao_status qs = eao::match::build_frame_queries(QA, q.data())) return qs;
     Lists L;
     eao_status st = build_lists(C, q, mp_desc, L);
     if (st) return st;

@@ -53,6 +53,9 @@ struct eao_tracker {
     Query* q; unsigned* lists; int *segStart, *segCount, *cursor; int* match;
     double *eXw, *eObs, *eInfo, *eErr; unsigned char *eFlags, *eOutl; int* eKp;
     float* dScale; float* dInvSigma2;
+    // the LAST frame's map points (TrackWithMotionModel): uploaded per call, apart from the local map, which stays where it is
+    float* lXw = nullptr; unsigned char* lDesc = nullptr; float* lAng = nullptr; unsigned char* lSkip = nullptr;
+    int capQ = 0;                      // queries / candidate segments / matches: max(max_keypoints, max_map_points)
     unsigned char* res = nullptr;      // result block: device view of resPin, resBytes
     unsigned char* resPin = nullptr;
     unsigned char* resDev = nullptr;   // its DEVICE twin (same layout): every kernel of the chain writes here; the chain's last launch alone copies it to `res`
@@ -535,7 +538,8 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
                                                                        const float* __restrict__ ur, const float* __restrict__ mXw, const float* __restrict__ priorXw,
                                                                        const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl,
                                                                        const float* __restrict__ dz, const unsigned char* __restrict__ inView, ResultBlock R,
-                                                                       long long* dbg, int allListers) {
+                                                                       long long* dbg, int allListers, const float* __restrict__ mAngle, const float* __restrict__ kAngle,
+                                                                       float rotFactor) {
     extern __shared__ unsigned char asm_raw[];
     if (dbg && threadIdx.x == 0) dbg[0] = clock64();
     if (nMp > 0) {
@@ -554,6 +558,55 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
             }
         }
         __syncthreads();      // match[] is complete (and visible to the whole workgroup)
+        if (rotFactor > 0.f) {
+            // rotation consistency of SearchByProjection(Cur, Last) (src/ORBmatcher.cc:1426-1468): the matches vote for the bin of their angle difference,
+            // the three fullest bins stay (ComputeThreeMaxima, :1603-1644: strictly greater in bin order, the second / third only from a tenth of the first)
+            constexpr int HISTO = refc::HISTO_LENGTH;
+            __shared__ int s_hist[HISTO], s_keep[3], s_gone;
+            if (threadIdx.x < HISTO) s_hist[threadIdx.x] = 0;
+            if (threadIdx.x == 0) s_gone = 0;
+            __syncthreads();
+            int bins[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int m = threadIdx.x + u * kAssignThreads;
+                bins[u] = -1;
+                const int k = m < nMp ? match[m] : -1;
+                if (k >= 0) {
+                    float rot = mAngle[m] - kAngle[k];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * rotFactor);
+                    if (bin == HISTO) bin = 0;
+                    if (bin >= 0 && bin < HISTO) { bins[u] = bin; atomicAdd(&s_hist[bin], 1); }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int top[3] = {0, 0, 0}, ind[3] = {-1, -1, -1};
+                for (int b = 0; b < HISTO; b++) {
+                    const int pop = s_hist[b];
+                    for (int rk = 0; rk < 3; rk++)
+                        if (pop > top[rk]) {
+                            for (int z = 2; z > rk; z--) { top[z] = top[z - 1]; ind[z] = ind[z - 1]; }
+                            top[rk] = pop; ind[rk] = b;
+                            break;
+                        }
+                }
+                const float floor10 = 0.1f * (float)top[0];
+                if (top[1] < floor10) { ind[1] = -1; ind[2] = -1; }
+                else if (top[2] < floor10) ind[2] = -1;
+                s_keep[0] = ind[0]; s_keep[1] = ind[1]; s_keep[2] = ind[2];
+            }
+            __syncthreads();
+            int gone = 0;
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if (bins[u] >= 0 && bins[u] != s_keep[0] && bins[u] != s_keep[1] && bins[u] != s_keep[2]) { match[threadIdx.x + u * kAssignThreads] = -1; gone++; }
+            if (gone) atomicAdd(&s_gone, gone);
+            __syncthreads();
+            if (threadIdx.x == 0) counts[3] -= s_gone;
+            __syncthreads();
+        }
     }
     if (dbg && threadIdx.x == 0) dbg[2] = clock64();
     track_edges_body(nMp, cap, match, kpMp, kx, ky, ur, oct, mXw, priorXw, invSigma2, E, edgeCap, counts, eOutl);
@@ -596,19 +649,21 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     h->invSigma2.assign(cfg->inv_level_sigma2, cfg->inv_level_sigma2 + cfg->nlevels);
     h->cfg.scale_factors = nullptr; h->cfg.inv_level_sigma2 = nullptr;
     h->cap = cfg->max_keypoints; h->capMp = cfg->max_map_points; h->nCells = cfg->grid_cols * cfg->grid_rows;
-    const size_t C = h->cap, M = h->capMp;
-    h->listCap = std::min<size_t>(C * M, (size_t)1 << 24);
+    const size_t C = h->cap, M = h->capMp, Q = std::max(C, M);      // Q: either stage's queries (local map points / last-frame keypoints)
+    h->capQ = (int)Q;
+    h->listCap = std::min<size_t>(C * Q, (size_t)1 << 24);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = al256(off + bytes); return o; };
     const size_t oKx = take(4 * C), oKy = take(4 * C), oAng = take(4 * C), oUr = take(4 * C), oDz = take(4 * C), oOct = take(4 * C), oOrd = take(4 * C),
                  oCx = take(2 * C), oCy = take(2 * C), oCnt = take(64), oPrior = take(4 * C), oPriorX = take(12 * C), oKpMp = take(4 * C), oOcc = take(C), oKpOut = take(C),
                  oMX = take(12 * M), oMN = take(12 * M), oMMin = take(4 * M), oMMax = take(4 * M), oMNum = take(4 * M), oMD = take(32 * M), oMA = take(M),
                  oMS = take(M), oIn = take(M), oPx = take(4 * M), oPy = take(4 * M), oPxr = take(4 * M), oVc = take(4 * M), oLv = take(4 * M),
-                 oQ = take(sizeof(Query) * M), oLists = take(4 * h->listCap), oSS = take(4 * M), oSC = take(4 * M), oCur = take(64), oMatch = take(4 * M),
+                 oQ = take(sizeof(Query) * Q), oLists = take(4 * h->listCap), oSS = take(4 * Q), oSC = take(4 * Q), oCur = take(64), oMatch = take(4 * Q),
+                 oLX = take(12 * C), oLD = take(32 * C), oLA = take(4 * C), oLS = take(Q),
                  oEX = take(24 * C), oEO = take(24 * C), oEI = take(8 * C), oEE = take(24 * C), oEF = take(C), oEOu = take(C), oEK = take(4 * C),
                  oSc = take(4 * 64), oIs = take(4 * 64), oCol = take(4 * ((size_t)cfg->grid_cols + 1));
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
-    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C) + al256(M) + 256;      // (+ the done word)
+    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C) + al256(Q) + 256;      // (+ the done word)
     const size_t oRes = take(h->resBytes);
     if ((st = h->dev.reserve(off))) { delete h; return st; }
     unsigned char* b = h->dev.p;
@@ -625,6 +680,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     h->eXw = (double*)(b + oEX); h->eObs = (double*)(b + oEO); h->eInfo = (double*)(b + oEI); h->eErr = (double*)(b + oEE); h->eFlags = b + oEF;
     h->eOutl = b + oEOu; h->eKp = (int*)(b + oEK); h->dScale = (float*)(b + oSc); h->dInvSigma2 = (float*)(b + oIs);
     h->colStart = (int*)(b + oCol);
+    h->lXw = (float*)(b + oLX); h->lDesc = b + oLD; h->lAng = (float*)(b + oLA); h->lSkip = b + oLS;
     // the result block is MAPPED PINNED HOST memory: the LAST kernel of the chain copies the device twin into it over PCIe (~30 KB) and the host
     // reads it after the one synchronisation -- no device-to-host copy behind the chain
     if (hipHostMalloc((void**)&h->resPin, h->resBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
@@ -632,7 +688,8 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     if (hipHostGetDevicePointer((void**)&h->res, h->resPin, 0) != hipSuccess) { delete h; eao::set_error("hipHostGetDevicePointer failed"); return EAO_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evOut, hipEventDisableTiming) != hipSuccess) { delete h; eao::set_error("stream / event creation failed"); return EAO_ERR_NO_DEVICE; }
-    h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C) + al256(12 * C)) + 4096;
+    h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C) + al256(12 * C) +
+                                      al256(sizeof(Query) * C) + al256(32 * C) + al256(4 * C)) + 4096;
     if (hipHostMalloc((void**)&h->pin, h->pinCap, hipHostMallocDefault) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     // the assignment workgroup's LDS: claims / occupancy / octaves by keypoint, then the staged candidate lists (beyond the default 64 KB)
     if (getenv("EAO_DEBUG_STAMPS")) { EAO_HIP(hipMalloc((void**)&h->dbg, 256)); EAO_HIP(hipMemset(h->dbg, 0, 256)); }
@@ -678,16 +735,26 @@ eao_status eao_tracker_set_local_map(eao_tracker* h, const eao_map_points* pts) 
     return EAO_OK;
 }
 
-eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
-                                       const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
-                                       const int32_t* prior_kp_map_point, const float* prior_kp_Xw, float th, float nnratio, eao_track_result* out,
-                                       void* stream) {
+}  // extern "C"
+
+namespace {
+// TrackWithMotionModel's inputs (NULL: TrackLocalMap over the uploaded local map): the last frame's map points as plain host arrays
+struct MotionArgs {
+    const float* Tcw_last; int n_last; const uint8_t* valid; const float* Xw; const uint8_t* mp_desc; const int32_t* octave; const float* angle;
+    int mono, check_orientation;
+};
+
+eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                       const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
+                       const int32_t* prior_kp_map_point, const float* prior_kp_Xw, float th, float nnratio, eao_track_result* out,
+                       void* stream, const MotionArgs* mm) {
     EAO_REQUIRE(h && d_kps && d_desc && d_n && Tcw_prior && out && out->kp_map_point && out->kp_outlier, "null argument");
+    for (int i = 0; i < 16; i++) EAO_REQUIRE(std::isfinite(Tcw_prior[i]), "the pose prior holds a NaN / Inf (entry %d)", i);
     EAO_REQUIRE(!d_depth || (depth_pitch >= width && width > 0 && height > 0), "bad depth image geometry");
     EAO_REQUIRE(((uintptr_t)d_desc & 15) == 0, "descriptors must be 16-byte aligned");
     eao::Range rg("track: frame -> frustum -> search -> pose");
     const eao_tracker_cfg& c = h->cfg;
-    const int C = h->cap, nMp = h->nMp;
+    const int C = h->cap, nMp = mm ? mm->n_last : h->nMp;      // the stage's queries: last-frame keypoints / local map points
     // The chain runs on the CALLER's stream itself: it is ordered behind whatever produced the inputs there (the extraction)
     // without an event hand-over to a private stream and back (~10 us each on this runtime).  The handle's own stream only
     // carries the local-map uploads, which eao_tracker_set_local_map waits for.
@@ -716,15 +783,39 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
             EAO_HIP(hipMemcpyAsync(h->priorXw, px, 12 * (size_t)C, hipMemcpyHostToDevice, s));
         }
     }
+    if (mm) {
+        // ---- the last frame's points: windows on the host (a thousand projections), then ONE staging block -> four asynchronous copies on the caller's
+        //      stream (the staging block is free: every call ends with its results on the host)
+        EAO_REQUIRE(mm->n_last >= 0 && mm->n_last <= C, "at most max_keypoints (%d) last-frame keypoints", C);
+        EAO_REQUIRE(mm->n_last == 0 || (mm->valid && mm->Xw && mm->mp_desc && mm->octave && mm->angle && mm->Tcw_last), "null last-frame arrays");
+        if (nMp > 0) {
+            for (int i = 0; i < 16; i++) EAO_REQUIRE(std::isfinite(mm->Tcw_last[i]), "the last frame's pose holds a NaN / Inf (entry %d)", i);
+            unsigned char* pq = h->pin; Query* hq = reinterpret_cast<Query*>(pq);
+            eao::match::FrameQueryArgs QA{Tcw_prior, mm->Tcw_last, nMp, mm->valid, mm->Xw, mm->octave, c.fx, c.fy, c.cx, c.cy, c.mbf, c.mbf / c.fx, th, mm->mono,
+                                          c.min_x, c.max_x, c.min_y, c.max_y, h->scale.data(), c.nlevels};
+            eao_status qs = eao::match::build_frame_queries(QA, hq);
+            if (qs) return qs;
+            size_t off = al256(sizeof(Query) * (size_t)nMp);
+            unsigned char* pX = h->pin + off; off += al256(12 * (size_t)nMp);
+            unsigned char* pD = h->pin + off; off += al256(32 * (size_t)nMp);
+            unsigned char* pA = h->pin + off; off += al256(4 * (size_t)nMp);
+            std::memcpy(pX, mm->Xw, 12 * (size_t)nMp); std::memcpy(pD, mm->mp_desc, 32 * (size_t)nMp); std::memcpy(pA, mm->angle, 4 * (size_t)nMp);
+            hipStream_t s0 = (hipStream_t)stream;
+            EAO_HIP(hipMemcpyAsync(h->q, pq, sizeof(Query) * (size_t)nMp, hipMemcpyHostToDevice, s0));
+            EAO_HIP(hipMemcpyAsync(h->lXw, pX, 12 * (size_t)nMp, hipMemcpyHostToDevice, s0));
+            EAO_HIP(hipMemcpyAsync(h->lDesc, pD, 32 * (size_t)nMp, hipMemcpyHostToDevice, s0));
+            EAO_HIP(hipMemcpyAsync(h->lAng, pA, 4 * (size_t)nMp, hipMemcpyHostToDevice, s0));
+        }
+    }
     FrameArrays A;
     A.kx = h->kx; A.ky = h->ky; A.ang = h->ang; A.ur = h->ur; A.dz = h->dz; A.oct = h->oct; A.order = h->order; A.cellx = h->cellx; A.celly = h->celly;
-    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = h->mSkip; A.cursor = h->cursor; A.colStart = h->colStart;
+    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = mm ? h->lSkip : h->mSkip; A.cursor = h->cursor; A.colStart = h->colStart;
     int npow2 = 64;
     while (npow2 < C) npow2 <<= 1;
     const float invW = (float)c.grid_cols / (c.max_x - c.min_x), invH = (float)c.grid_rows / (c.max_y - c.min_y);   // src/Frame.cc:258-259
     eao::frame::FrustumArgs FA;
     std::memset(&FA, 0, sizeof(FA));
-    if (nMp > 0) {
+    if (nMp > 0 && !mm) {
         eao::frame::FrustumDevArgs F;
         F.n = nMp; F.Xw = h->mXw; F.normal = h->mNormal; F.minDist = h->mMin; F.maxDist = h->mMax; F.maxDistNum = h->mNum;
         std::memcpy(F.Tcw, Tcw_prior, 64);
@@ -741,7 +832,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     static const int envCount = getenv("EAO_TRACK_COUNTING_SORT") ? atoi(getenv("EAO_TRACK_COUNTING_SORT")) : 1;      // (A/B switch)
     const size_t cells = (size_t)c.grid_cols * c.grid_rows, countLds = (2 * (size_t)npow2 + cells + 1) * 4;
     const int countingSort = envCount && cells <= 8 * kFrameThreads && countLds <= 60 * 1024 ? 1 : 0;
-    hipLaunchKernelGGL(k_track_frame, dim3(1 + (nMp > 0 ? eao::cdiv(nMp, kFrameThreads) : 0)), dim3(kFrameThreads), countingSort ? countLds : (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth,
+    hipLaunchKernelGGL(k_track_frame, dim3(1 + (nMp > 0 && !mm ? eao::cdiv(nMp, kFrameThreads) : 0)), dim3(kFrameThreads), countingSort ? countLds : (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth,
                        depth_pitch, width, height, c.mbf, c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A, FA, h->dbg, countingSort);
     eao_status st;
     if (nMp > 0) {
@@ -753,8 +844,8 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
         FD.cap = C; FD.nOrdered = h->counts + 1; FD.kx = h->kx; FD.ky = h->ky; FD.oct = h->oct; FD.ur = h->ur; FD.desc = d_desc;
         FD.order = h->order; FD.cellx = h->cellx; FD.celly = h->celly; FD.colStart = h->colStart;
         FD.minX = c.min_x; FD.minY = c.min_y; FD.invW = invW; FD.invH = invH; FD.cols = c.grid_cols; FD.rows = c.grid_rows;
-        if ((st = eao::match::enqueue_candidates_device(FD, h->q, h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
-                                                        h->segCount, h->cursor, s, true, &QB))) return st;
+        if ((st = eao::match::enqueue_candidates_device(FD, h->q, mm ? h->lDesc : h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
+                                                        h->segCount, h->cursor, s, true, mm ? nullptr : &QB))) return st;
     }
     EdgeArrays E;
     E.Xw = h->eXw; E.obs = h->eObs; E.info = h->eInfo; E.flags = h->eFlags; E.eKp = h->eKp;
@@ -774,15 +865,15 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     float* rDz = (float*)(r + ro); ro += al256(4 * (size_t)C);
     unsigned char* rInView = r + ro;
     const size_t pubBytes = (ro + (size_t)std::max(nMp, 0) + 15) & ~(size_t)15;      // everything up to the last in-view flag
-    ro += al256((size_t)h->capMp);
+    ro += al256((size_t)h->capQ);
     const size_t oDone = ro; ro += 256;
     int* rDone = (int*)(h->res + oDone);                                            // the done word itself only exists in host memory
     ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz, rInView};
     static const int envAll = getenv("EAO_TRACK_ALL_LISTERS") ? atoi(getenv("EAO_TRACK_ALL_LISTERS")) : 0;
     auto launch_assign = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
-                           nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, h->mXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
-                           h->inView, RB, h->dbg, envAll);
+                           mm ? INFINITY : nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, mm ? h->lXw : h->mXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
+                           h->inView, RB, h->dbg, envAll, h->lAng, h->ang, mm && mm->check_orientation ? (float)refc::HISTO_LENGTH / 360.0f : 0.f);
     };
     if (nMp <= 4 * kAssignThreads) launch_assign(k_track_assign_edges<4>);
     else if (nMp <= 8 * kAssignThreads) launch_assign(k_track_assign_edges<8>);
@@ -839,7 +930,7 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     std::memcpy(out->kp_map_point, p + ((unsigned char*)rKpMp - r), 4 * (size_t)C);
     if (out->kp_u_right) std::memcpy(out->kp_u_right, p + ((unsigned char*)rUr - r), 4 * (size_t)C);
     if (out->kp_depth) std::memcpy(out->kp_depth, p + ((unsigned char*)rDz - r), 4 * (size_t)C);
-    if (out->map_in_view && nMp > 0) {
+    if (out->map_in_view && nMp > 0 && !mm) {
         const unsigned char* iv = p + ((unsigned char*)rInView - r);
         for (int m = 0; m < nMp; m++) out->map_in_view[m] = (iv[m] && h->hActive[m]) ? 1 : 0;      // (an inactive point's arrays are stale)
     }
@@ -855,5 +946,33 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
     }
     return EAO_OK;
 }
+}  // namespace
+
+extern "C" {
+
+eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                       const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
+                                       const int32_t* prior_kp_map_point, const float* prior_kp_Xw, float th, float nnratio, eao_track_result* out,
+                                       void* stream) {
+    return track_chain(h, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_prior, prior_kp_map_point, prior_kp_Xw, th, nnratio, out, stream, nullptr);
+}
+
+eao_status eao_tracker_track_with_motion_model(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                               const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_cur,
+                                               const float* Tcw_last, int32_t n_last, const uint8_t* valid, const float* Xw, const uint8_t* mp_desc,
+                                               const int32_t* last_octave, const float* last_angle, float th, int32_t mono, int32_t check_orientation,
+                                               int32_t discard_outliers, eao_track_result* out, void* stream) {
+    EAO_REQUIRE(h && Tcw_last && n_last >= 0, "null argument");
+    MotionArgs mm{Tcw_last, n_last, valid, Xw, mp_desc, last_octave, last_angle, mono ? 1 : 0, check_orientation ? 1 : 0};
+    eao_status st = track_chain(h, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_cur, nullptr, nullptr, th, 0.f, out, stream, &mm);
+    if (st) return st;
+    if (discard_outliers) {      // "Discard outliers", src/Tracking.cc:2188-2207: the match is dropped, the flag cleared (n_inliers = what is left)
+        for (int k = 0; k < h->cap; k++)
+            if (out->kp_outlier[k]) { out->kp_map_point[k] = -1; out->kp_outlier[k] = 0; }
+    }
+    return EAO_OK;
+}
+
+int32_t eao_abi_version(void) { return EAO_ABI_VERSION; }
 
 }  // extern "C"

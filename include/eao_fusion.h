@@ -522,6 +522,32 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
                                        const int32_t* prior_kp_map_point, const float* prior_kp_Xw, float th, float nnratio, eao_track_result* out,
                                        void* stream);
 
+/* Tracking::TrackWithMotionModel's data path (reference src/Tracking.cc:1717-2231) on the same chain, ahead of TrackLocalMap: the frame set-up as
+ * above, ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (src/ORBmatcher.cc:1328-1472, with this fork's rotation-histogram
+ * factor HISTO_LENGTH / 360, :1337) against the LAST frame's map points, Optimizer::PoseOptimization from the predicted pose, and -- when
+ * discard_outliers != 0 -- the "Discard outliers" loop of src/Tracking.cc:2188-2207; one copy back.  The last frame travels as host arrays per
+ * last-frame keypoint i (n_last <= max_keypoints entries): valid[i] != 0 where mvpMapPoints[i] != NULL && !mvbOutlier[i]; Xw = GetWorldPos();
+ * mp_desc = GetDescriptor() (32 bytes); last_octave = mvKeys[i].octave; last_angle = mvKeysUn[i].angle.  Tcw_cur: the predicted pose
+ * (mVelocity * mLastFrame.mTcw, :1726), Tcw_last: mLastFrame.mTcw; 16 floats row-major each, finite (EAO_ERR_INVALID otherwise).
+ * Result (zero-initialise the struct and set the array pointers; map_in_view is not written): kp_map_point[k] = the LAST-FRAME INDEX whose map point
+ * keypoint k took, or -1; n_matches = the search's return value (what upstream tests against 20 before it retries with 2 th -- the caller repeats the
+ * call); n_edges = correspondences of the pose optimisation; n_inliers = n_edges minus the outliers = the matches left after the discard;
+ * kp_outlier = mvbOutlier after PoseOptimization (all zero after the discard).  A keypoint a point has taken counts as occupied for the points behind
+ * it, as for map points with Observations() > 0 (the same rule eao_search_by_projection_frames applies).  Same results as
+ * eao_compute_stereo_from_rgbd -> eao_search_by_projection_frames -> eao_pose_optimization on the same data. */
+eao_status eao_tracker_track_with_motion_model(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                               const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_cur,
+                                               const float* Tcw_last, int32_t n_last, const uint8_t* valid, const float* Xw, const uint8_t* mp_desc,
+                                               const int32_t* last_octave, const float* last_angle, float th, int32_t mono, int32_t check_orientation,
+                                               int32_t discard_outliers, eao_track_result* out, void* stream);
+
+/* The value of EAO_ABI_VERSION the library was built with.  Bumped whenever an entry point's parameter list or a struct's layout changes (round 3
+ * changed eao_tracker_track_local_map and eao_track_result in place); a caller compiled against another version must not call into the library.
+ * Result structs are zero-initialised by the caller (`eao_track_result R = {0};`) before their array pointers are set: a pointer member the
+ * caller's header does not know yet then reads as NULL = "not wanted". */
+#define EAO_ABI_VERSION 4
+int32_t eao_abi_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -355,3 +355,95 @@ def test_fallback_paths_of_the_chain():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "sweep_track.py"), "17", "16"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "tracker sweep: 16 frames, 0 mismatches" in out.stdout, out.stdout[-2000:]
+
+
+def _chain_motion(calls, search_frames, cur, kps, desc, depth, last, th, mono, discard=True):
+    """Tracking::TrackWithMotionModel's data path step by step (src/Tracking.cc:1717-2231): Frame::ComputeStereoFromRGBD, SearchByProjection(Cur, Last, th, bMono)
+    (src/ORBmatcher.cc:1328-1472), PoseOptimization over the matches from the predicted pose, the outlier discard (:2188-2207)."""
+    N = len(kps)
+    kx, ky = np.ascontiguousarray(kps["x"]), np.ascontiguousarray(kps["y"])
+    ur, dz = calls.stereo(kx, ky, kx, depth, cur["mbf"])
+    T = np.ascontiguousarray(cur["Tcw"], np.float32)
+    frame = dict(kp_x=kx, kp_y=ky, kp_octave=np.ascontiguousarray(kps["octave"]), kp_angle=np.ascontiguousarray(kps["angle"]), u_right=ur, descriptors=desc,
+                 occupied=None, min_x=np.float32(0), min_y=np.float32(0), max_x=np.float32(640), max_y=np.float32(480), scale_factors=cur["scale_factors"],
+                 Tcw=T, fx=cur["fx"], fy=cur["fy"], cx=cur["cx"], cy=cur["cy"], mbf=cur["mbf"], mb=cur["mb"])
+    nm, cur_match = search_frames(frame, last, th, mono)
+    ks = np.nonzero(cur_match >= 0)[0]
+    inv_sigma2 = (np.float32(1.0) / (cur["scale_factors"] * cur["scale_factors"])).astype(np.float32)
+    res = dict(n_matches=nm, kp_map_point=cur_match.copy(), u_right=ur, depth=dz, n_edges=len(ks))
+    if len(ks) < 3:
+        res.update(Tcw=T, n_inliers=0, kp_outlier=np.zeros(N, np.uint8))
+        return res
+    prob = dict(Tcw=T, points=np.ascontiguousarray(last["Xw"][cur_match[ks]], np.float32), obs=np.stack([kx[ks], ky[ks], ur[ks]], 1).astype(np.float32),
+                inv_sigma2=inv_sigma2[kps["octave"][ks]], fx=cur["fx"], fy=cur["fy"], cx=cur["cx"], cy=cur["cy"], bf=cur["mbf"])
+    r = calls.pose(prob)
+    outl = np.zeros(N, np.uint8)
+    outl[ks] = r["outlier"]
+    if discard:
+        res["kp_map_point"][outl != 0] = -1
+        outl[:] = 0
+    res.update(Tcw=r["Tcw"], n_inliers=r["n_inliers"], kp_outlier=outl)
+    return res
+
+
+@pytest.mark.parametrize("case", [dict(seed=7300), dict(seed=7301, th=7.0, mono_frac=0.0), dict(seed=7302, n=300, th=15.0, mono_frac=1.0, mono=True),
+                                  dict(seed=7303, n=1500, th=30.0), dict(seed=7304, n=900, moved=0.4), dict(seed=7305, n=900, moved=-0.4, discard=False),
+                                  dict(seed=7306, n=60, th=15.0), dict(seed=7307, n=2000, th=7.0, check=False)])
+def test_motion_model_stage_equals_the_oracle_chain(case, oracle):
+    """Round 4 (VERDICT r3 missing #3): eao_tracker_track_with_motion_model -- frame set-up, SearchByProjection(Cur, Last) with the rotation histogram of this fork
+    (factor HISTO_LENGTH / 360), PoseOptimization from the predicted pose, outlier discard -- against the same steps on the CPU oracle: every integer table bit
+    for bit (mvuRight / mvDepth, the greedy assignment after the rotation filter as LAST-FRAME indices, the search's return value, the edge count,
+    mvbOutlier, the matches left), the pose within the LM bound.  Forward / backward motion beyond the baseline switches the level windows (:1343-1347)."""
+    import eao_fusion_amd as E  # noqa: F401
+    kw = dict(seed=case["seed"], n=case.get("n", 900), mono_frac=case.get("mono_frac", 0.25))
+    cur, kps, desc, depth, pts, _ = _scene(**kw)
+    _, last, _ = synth.synth_tracking(n=kw["n"], seed=kw["seed"], mono_frac=0.0, occupied_frac=0.0)
+    if "moved" in case:      # the camera moved along its axis by more than the baseline: forward / backward level windows
+        cur = dict(cur); T = cur["Tcw"].copy(); T[2, 3] = -case["moved"]; cur["Tcw"] = T
+    th, mono, check, discard = case.get("th", 15.0), case.get("mono", False), case.get("check", True), case.get("discard", True)
+    if mono:
+        depth = np.zeros_like(depth)
+    oc = _OracleCalls(oracle)
+    want = _chain_motion(oc, lambda f, l, t, m: oracle.search_by_projection_frames(f, l, t, m, check), cur, kps, desc, depth, last, th, mono, discard)
+    cap = 2048 if len(kps) <= 2048 else 4096
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+    trk = _tracker(cur, cap, 2048)
+    got = trk.track_with_motion_model(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], last, th, mono, check, discard,
+                                      torch.cuda.current_stream().cuda_stream)
+    assert got["n_keypoints"] == len(kps)
+    assert np.array_equal(got["u_right"], want["u_right"]) and np.array_equal(got["depth"], want["depth"])
+    assert got["n_matches"] == want["n_matches"] and got["n_edges"] == want["n_edges"]
+    assert np.array_equal(got["kp_map_point"], want["kp_map_point"]), "matches (last-frame indices)"
+    assert np.array_equal(got["kp_outlier"], want["kp_outlier"]) and got["n_inliers"] == want["n_inliers"]
+    ok, err, upd = _pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])
+    assert ok, "pose |gpu - oracle| %.3e of update %.3e" % (err, upd)
+    if want["n_matches"] >= 20:
+        assert (got["kp_map_point"] >= 0).sum() > 0
+    # the stage leaves the uploaded local map alone: a TrackLocalMap call behind it gives what it gives without it
+    if "moved" in case:
+        return      # (this far along the axis the local map's predicted levels leave the pyramid: TrackLocalMap refuses, as it should)
+    trk.set_local_map(pts)
+    a = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], None, 1.0, 0.8, torch.cuda.current_stream().cuda_stream)
+    trk.track_with_motion_model(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], last, th, mono, check, discard,
+                                torch.cuda.current_stream().cuda_stream)
+    b = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], None, 1.0, 0.8, torch.cuda.current_stream().cuda_stream)
+    assert all(np.array_equal(a[k], b[k]) if isinstance(a[k], np.ndarray) else a[k] == b[k] for k in a)
+
+
+def test_motion_model_stage_rejects_bad_input():
+    cur, kps, desc, depth, pts, _ = _scene(seed=7310, n=200)
+    _, last, _ = synth.synth_tracking(n=200, seed=7310, mono_frac=0.0, occupied_frac=0.0)
+    import eao_fusion_amd as E
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, 1024)
+    trk = _tracker(cur, 1024, 64)
+    args = (d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480)
+    bad = cur["Tcw"].copy(); bad[1, 2] = np.nan
+    with pytest.raises(E.EaoError):
+        trk.track_with_motion_model(*args, bad, last, 15.0)
+    l2 = dict(last); l2["octave"] = last["octave"].copy(); l2["octave"][np.nonzero(last["valid"])[0][0]] = 9
+    with pytest.raises(E.EaoError):
+        trk.track_with_motion_model(*args, cur["Tcw"], l2, 15.0)
+    big = {k: (np.concatenate([v] * 8) if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == 200 else v) for k, v in last.items()}
+    with pytest.raises(E.EaoError):
+        trk.track_with_motion_model(*args, cur["Tcw"], big, 15.0)      # 1600 last-frame keypoints > max_keypoints 1024
+    assert E.load().eao_abi_version() == 4
