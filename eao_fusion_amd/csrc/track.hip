@@ -54,7 +54,7 @@ struct eao_tracker {
     double *eXw, *eObs, *eInfo, *eErr; unsigned char *eFlags, *eOutl; int* eKp;
     float* dScale; float* dInvSigma2;
     // the LAST frame's map points (TrackWithMotionModel): uploaded per call, apart from the local map, which stays where it is
-    float* lXw = nullptr; unsigned char* lDesc = nullptr; float* lAng = nullptr; unsigned char* lSkip = nullptr;
+    float* lXw = nullptr; unsigned char* lDesc = nullptr; float* lAng = nullptr; unsigned char* lSkip = nullptr; Query* lQ = nullptr;      // lQ | lXw | lDesc | lAng: ONE block, one copy
     int capQ = 0;                      // queries / candidate segments / matches: max(max_keypoints, max_map_points)
     unsigned char* res = nullptr;      // result block: device view of resPin, resBytes
     unsigned char* resPin = nullptr;
@@ -659,7 +659,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
                  oMX = take(12 * M), oMN = take(12 * M), oMMin = take(4 * M), oMMax = take(4 * M), oMNum = take(4 * M), oMD = take(32 * M), oMA = take(M),
                  oMS = take(M), oIn = take(M), oPx = take(4 * M), oPy = take(4 * M), oPxr = take(4 * M), oVc = take(4 * M), oLv = take(4 * M),
                  oQ = take(sizeof(Query) * Q), oLists = take(4 * h->listCap), oSS = take(4 * Q), oSC = take(4 * Q), oCur = take(64), oMatch = take(4 * Q),
-                 oLX = take(12 * C), oLD = take(32 * C), oLA = take(4 * C), oLS = take(Q),
+                 oLQ = take(sizeof(Query) * C), oLX = take(12 * C), oLD = take(32 * C), oLA = take(4 * C), oLS = take(Q),
                  oEX = take(24 * C), oEO = take(24 * C), oEI = take(8 * C), oEE = take(24 * C), oEF = take(C), oEOu = take(C), oEK = take(4 * C),
                  oSc = take(4 * 64), oIs = take(4 * 64), oCol = take(4 * ((size_t)cfg->grid_cols + 1));
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
@@ -680,7 +680,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     h->eXw = (double*)(b + oEX); h->eObs = (double*)(b + oEO); h->eInfo = (double*)(b + oEI); h->eErr = (double*)(b + oEE); h->eFlags = b + oEF;
     h->eOutl = b + oEOu; h->eKp = (int*)(b + oEK); h->dScale = (float*)(b + oSc); h->dInvSigma2 = (float*)(b + oIs);
     h->colStart = (int*)(b + oCol);
-    h->lXw = (float*)(b + oLX); h->lDesc = b + oLD; h->lAng = (float*)(b + oLA); h->lSkip = b + oLS;
+    h->lQ = (Query*)(b + oLQ); h->lXw = (float*)(b + oLX); h->lDesc = b + oLD; h->lAng = (float*)(b + oLA); h->lSkip = b + oLS;
     // the result block is MAPPED PINNED HOST memory: the LAST kernel of the chain copies the device twin into it over PCIe (~30 KB) and the host
     // reads it after the one synchronisation -- no device-to-host copy behind the chain
     if (hipHostMalloc((void**)&h->resPin, h->resBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
@@ -795,16 +795,10 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
                                           c.min_x, c.max_x, c.min_y, c.max_y, h->scale.data(), c.nlevels};
             eao_status qs = eao::match::build_frame_queries(QA, hq);
             if (qs) return qs;
-            size_t off = al256(sizeof(Query) * (size_t)nMp);
-            unsigned char* pX = h->pin + off; off += al256(12 * (size_t)nMp);
-            unsigned char* pD = h->pin + off; off += al256(32 * (size_t)nMp);
-            unsigned char* pA = h->pin + off; off += al256(4 * (size_t)nMp);
-            std::memcpy(pX, mm->Xw, 12 * (size_t)nMp); std::memcpy(pD, mm->mp_desc, 32 * (size_t)nMp); std::memcpy(pA, mm->angle, 4 * (size_t)nMp);
-            hipStream_t s0 = (hipStream_t)stream;
-            EAO_HIP(hipMemcpyAsync(h->q, pq, sizeof(Query) * (size_t)nMp, hipMemcpyHostToDevice, s0));
-            EAO_HIP(hipMemcpyAsync(h->lXw, pX, 12 * (size_t)nMp, hipMemcpyHostToDevice, s0));
-            EAO_HIP(hipMemcpyAsync(h->lDesc, pD, 32 * (size_t)nMp, hipMemcpyHostToDevice, s0));
-            EAO_HIP(hipMemcpyAsync(h->lAng, pA, 4 * (size_t)nMp, hipMemcpyHostToDevice, s0));
+            // the staging block mirrors the device block lQ | lXw | lDesc | lAng (offsets by CAPACITY, as eao_tracker_create laid them out): one copy
+            const size_t C2 = (size_t)C, oX = al256(sizeof(Query) * C2), oD = oX + al256(12 * C2), oA = oD + al256(32 * C2);
+            std::memcpy(h->pin + oX, mm->Xw, 12 * (size_t)nMp); std::memcpy(h->pin + oD, mm->mp_desc, 32 * (size_t)nMp); std::memcpy(h->pin + oA, mm->angle, 4 * (size_t)nMp);
+            EAO_HIP(hipMemcpyAsync(h->lQ, h->pin, oA + 4 * (size_t)nMp, hipMemcpyHostToDevice, (hipStream_t)stream));
         }
     }
     FrameArrays A;
@@ -844,7 +838,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
         FD.cap = C; FD.nOrdered = h->counts + 1; FD.kx = h->kx; FD.ky = h->ky; FD.oct = h->oct; FD.ur = h->ur; FD.desc = d_desc;
         FD.order = h->order; FD.cellx = h->cellx; FD.celly = h->celly; FD.colStart = h->colStart;
         FD.minX = c.min_x; FD.minY = c.min_y; FD.invW = invW; FD.invH = invH; FD.cols = c.grid_cols; FD.rows = c.grid_rows;
-        if ((st = eao::match::enqueue_candidates_device(FD, h->q, mm ? h->lDesc : h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
+        if ((st = eao::match::enqueue_candidates_device(FD, mm ? h->lQ : h->q, mm ? h->lDesc : h->mDesc, nMp, h->lists, (int)std::min(h->listCap, (size_t)0x7FFFFFFF), h->segStart,
                                                         h->segCount, h->cursor, s, true, mm ? nullptr : &QB))) return st;
     }
     EdgeArrays E;
@@ -871,7 +865,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz, rInView};
     static const int envAll = getenv("EAO_TRACK_ALL_LISTERS") ? atoi(getenv("EAO_TRACK_ALL_LISTERS")) : 0;
     auto launch_assign = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, h->q, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, mm ? h->lQ : h->q, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
                            mm ? INFINITY : nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, mm ? h->lXw : h->mXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
                            h->inView, RB, h->dbg, envAll, h->lAng, h->ang, mm && mm->check_orientation ? (float)refc::HISTO_LENGTH / 360.0f : 0.f);
     };

@@ -4,6 +4,7 @@
 //
 //   eaofusion::DeviceTracker trk(frame, maxKeypoints, maxMapPoints);      // once per camera (Frame statics: fx .. mbf, bounds, scale tables)
 //   trk.SetLocalMap(mvpLocalMapPoints);                                    // when Tracking::UpdateLocalMap changed the local map
+//   int nm = trk.TrackWithMotionModel(mCurrentFrame, mLastFrame, d_kps, d_desc, d_n, d_depth, depthPitch, w, h, th, bMono, stream, &nmatchesMap);   // round 4
 //   int nInliers = trk.TrackLocalMap(mCurrentFrame, d_kps, d_desc, d_n, d_depth, depthPitch, th, stream);
 //
 // TrackLocalMap replaces, for a distortion-free RGB-D / monocular camera, the sequence Frame::ComputeStereoFromRGBD +
@@ -110,7 +111,7 @@ public:
         float T[16];
         for (int r = 0; r < 4; r++)
             for (int c = 0; c < 4; c++) T[4 * r + c] = F.mTcw.template at<float>(r, c);
-        eao_track_result R;
+        eao_track_result R = {};      // (zero first: a member this header does not set reads as "not wanted", include/eao_fusion.h EAO_ABI_VERSION)
         R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data(); R.map_in_view = inView.data();
         detail::check(eao_tracker_track_local_map(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, T, prior.data(),
                                                   priorXw.empty() ? nullptr : priorXw.data(), th, nnratio, &R, stream),
@@ -132,6 +133,67 @@ public:
             for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[4 * r + c];
         F.SetPose(pose);
         return R.n_inliers;
+    }
+
+    // Tracking::TrackWithMotionModel's data path (src/Tracking.cc:1717-2231) for the frame the extractor just left on the device: the part of the Frame
+    // constructor after the extractor (mvuRight / mvDepth, the grid), ORBmatcher(0.9, true).SearchByProjection(Cur, Last, th, bMono), Optimizer::
+    // PoseOptimization(&Cur) and the "Discard outliers" loop, one copy back.  The caller has set Cur's predicted pose (SetPose(mVelocity * mLastFrame.mTcw),
+    // :1726) and cleared Cur.mvpMapPoints (:1729); it repeats the call with 2 * th when fewer than 20 matches come back (:1756-1760), exactly as upstream
+    // repeats the search.  Returns the search's nmatches minus the discarded outliers (upstream's `nmatches` at :2231); nmatchesMap counts the kept matches
+    // whose map point has observations (:2202-2203).  What upstream does between the search and the optimisation (object association, plane association) reads
+    // Cur.mvpMapPoints, which this call has filled by then only at its END -- a caller that needs them runs this stage with the host-hop calls instead.
+    template <class FrameT>
+    int TrackWithMotionModel(FrameT& Cur, const FrameT& Last, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth,
+                             int depthPitch, int width, int height, float th, bool bMono, void* stream, int* nmatchesMap = nullptr, int* nSearch = nullptr) {
+        using MapPointT = typename std::remove_pointer<typename std::decay<decltype(Cur.mvpMapPoints[0])>::type>::type;
+        if (Cur.N > cap_ || Last.N > cap_) throw std::runtime_error("DeviceTracker: a frame has more keypoints than maxKeypoints");
+        const size_t nl = (size_t)Last.N;
+        std::vector<uint8_t> valid(nl ? nl : 1, 0), desc(32 * (nl ? nl : 1), 0);
+        std::vector<float> Xw(3 * (nl ? nl : 1), 0.f), ang(nl ? nl : 1, 0.f);
+        std::vector<int32_t> oct(nl ? nl : 1, 0);
+        for (size_t i = 0; i < nl; i++) {
+            MapPointT* pMP = Last.mvpMapPoints[i];
+            oct[i] = Last.mvKeys[i].octave; ang[i] = Last.mvKeysUn[i].angle;
+            if (!pMP || Last.mvbOutlier[i]) continue;
+            valid[i] = 1;
+            const cv::Mat P = pMP->GetWorldPos(), D = pMP->GetDescriptor();
+            for (int a = 0; a < 3; a++) Xw[3 * i + a] = P.template at<float>(a);
+            std::memcpy(&desc[32 * i], D.template ptr<unsigned char>(0), 32);
+        }
+        float Tc[16], Tl[16];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) { Tc[4 * r + c] = Cur.mTcw.template at<float>(r, c); Tl[4 * r + c] = Last.mTcw.template at<float>(r, c); }
+        std::vector<int32_t> kpMp(cap_, -1);
+        std::vector<uint8_t> outl(cap_, 0);
+        std::vector<float> ur(cap_), dz(cap_);
+        eao_track_result R = {};
+        R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data();
+        detail::check(eao_tracker_track_with_motion_model(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, Tc, Tl, (int)nl, valid.data(), Xw.data(),
+                                                          desc.data(), oct.data(), ang.data(), th, bMono ? 1 : 0, 1, /* discard on this side */ 0, &R, stream),
+                      "eao_tracker_track_with_motion_model");
+        if (nSearch) *nSearch = R.n_matches;
+        Cur.mvuRight.assign(ur.begin(), ur.begin() + R.n_keypoints);
+        Cur.mvDepth.assign(dz.begin(), dz.begin() + R.n_keypoints);
+        cv::Mat pose(4, 4, CV_32F);
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[4 * r + c];
+        Cur.SetPose(pose);
+        int nmatches = R.n_matches, nMap = 0;
+        for (int k = 0; k < R.n_keypoints; k++) {      // "Discard outliers", src/Tracking.cc:2188-2207
+            Cur.mvbOutlier[k] = false;
+            if (kpMp[k] < 0) continue;
+            MapPointT* pMP = Last.mvpMapPoints[kpMp[k]];
+            if (outl[k]) {
+                pMP->mbTrackInView = false;
+                pMP->mnLastFrameSeen = Cur.mnId;
+                nmatches--;
+            } else {
+                Cur.mvpMapPoints[k] = pMP;
+                if (pMP->Observations() > 0) nMap++;
+            }
+        }
+        if (nmatchesMap) *nmatchesMap = nMap;
+        return nmatches;
     }
 
 private:

@@ -20,6 +20,10 @@ public:
     // buffers a maintainer keeps beside the extractor
     void TrackLocalMapOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch, int width,
                                int height, void* stream);
+    // ... and src/Tracking_TrackWithMotionModel.inc (round 4): the search + pose optimisation + outlier discard of Tracking::TrackWithMotionModel
+    bool TrackWithMotionModelOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch, int width,
+                                      int height, void* stream, const cv::Mat& predictedPose);
+    Frame mLastFrame;
     eaofusion::DeviceTracker* mpDeviceTracker = nullptr;
     int mSensor = System::RGBD;
     Frame mCurrentFrame;

@@ -47,6 +47,12 @@ void Tracking::TrackLocalMapOnDevice(const eao_keypoint* d_kps, const uint8_t* d
                                      int width, int height, void* stream) {
 #include "Tracking_TrackLocalMap.inc"
 }
+bool Tracking::TrackWithMotionModelOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch,
+                                            int width, int height, void* stream, const cv::Mat& predictedPose) {
+#include "Tracking_TrackWithMotionModel.inc"
+    (void)nmatches;
+    return nmatchesMap >= 10;      // :2230
+}
 }  // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;

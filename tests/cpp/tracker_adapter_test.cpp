@@ -16,6 +16,8 @@ struct MapPoint {
     bool bad = false, mbTrackInView = false;
     int nVisible = 0;
     long unsigned int mnLastFrameSeen = ~0ul;
+    int nObs = 1;
+    int Observations() { return nObs; }
     void IncreaseVisible(int n = 1) { nVisible += n; }
     bool isBad() { return bad; }
     cv::Mat GetWorldPos() { return pos.clone(); }
@@ -36,7 +38,7 @@ struct Frame {
     int mnScaleLevels = 8;
     std::vector<float> mvScaleFactors, mvInvLevelSigma2;
     cv::Mat mTcw;
-    std::vector<cv::KeyPoint> mvKeys;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     std::vector<float> mvuRight, mvDepth;
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<bool> mvbOutlier;
@@ -59,6 +61,7 @@ int main() {
     std::vector<MapPoint*> local;
     std::vector<float> depth((size_t)W * H, 0.f);
     std::vector<unsigned char> desc;
+    std::vector<int> seen;                 // keypoint k observes map point seen[k]
     for (int m = 0; m < M; m++) {
         MapPoint& p = pts[m];
         const float z = 2.f + 4.f * (float)rnd(), x = (float)(rnd() - 0.5) * z * 0.9f, y = (float)(rnd() - 0.5) * z * 0.7f;
@@ -77,6 +80,7 @@ int main() {
         if (u < 2 || u > W - 3 || v < 2 || v > H - 3) continue;
         cv::KeyPoint kp(u, v, 31.f, (float)(rnd() * 360.0), 50.f, oct);
         F.mvKeys.push_back(kp);
+        seen.push_back(m);
         for (int b = 0; b < 32; b++) desc.push_back((unsigned char)(p.desc.at<unsigned char>(0, b) ^ (rnd() < 0.1 ? 1 << (int)(rnd() * 8) : 0)));
         depth[(size_t)(int)v * W + (int)u] = rnd() < 0.2 ? 0.f : zc;
     }
@@ -156,7 +160,6 @@ int main() {
             return 2;
         }
     }
-    eao_tracker_destroy(h);
     int bad = 0, matched = 0;
     if (nIn != R.n_inliers) { fprintf(stderr, "inliers %d vs %d\n", nIn, R.n_inliers); bad++; }
     // SearchLocalPoints' bookkeeping (src/Tracking.cc:2590-2627)
@@ -179,6 +182,60 @@ int main() {
         matched += want ? 1 : 0;
     }
     for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) if (F.mTcw.at<float>(r, k) != R.Tcw[4 * r + k]) bad++;
+    // ---- TrackWithMotionModel (round 4): the LAST frame saw the same keypoints (every one with its map point, a few flagged as outliers, one a
+    //      temporal point without observations); the current frame enters with the predicted pose and empty matches.  Adapter vs a direct C-ABI call.
+    {
+        Frame Last = F2, Cur = F2;
+        Last.mvKeysUn = Last.mvKeys; Cur.mvKeysUn = Cur.mvKeys;
+        Last.mnId = 8; Cur.mnId = 9;
+        for (int k = 0; k < Last.N; k++) { Last.mvpMapPoints[k] = &pts[seen[k]]; Last.mvbOutlier[k] = (k % 17) == 0; }
+        Last.mvpMapPoints[2] = nullptr;
+        pts[seen[4]].nObs = 0;
+        Cur.mvpMapPoints.assign(Cur.N, nullptr); Cur.mvbOutlier.assign(Cur.N, false);
+        Cur.mTcw = F2.mTcw.clone(); Cur.mTcw.at<float>(0, 3) += 0.004f;
+        for (int k = 0; k < Cur.N; k++) Cur.mvKeysUn[k].angle = Cur.mvKeys[k].angle = std::fmod(Last.mvKeys[k].angle + 9.f, 360.f);
+        std::vector<eao_keypoint> ck(Cur.N);
+        for (int k = 0; k < Cur.N; k++) std::memcpy(&ck[k], &Cur.mvKeys[k], sizeof(eao_keypoint));
+        HIPCHK(hipMemcpy(d_kps, ck.data(), (size_t)Cur.N * sizeof(eao_keypoint), hipMemcpyHostToDevice));
+        Frame Cur2 = Cur;
+        int nMap = -1, nSearch = -1;
+        const int nm = trk.TrackWithMotionModel(Cur, Last, d_kps, d_desc, d_n, d_depth, W, W, H, 15.f, false, nullptr, &nMap, &nSearch);
+        // direct call, arrays by hand, the library's own discard
+        const int nl = Last.N;
+        std::vector<uint8_t> valid(nl, 0), ldesc(32 * (size_t)nl, 0), o2(cap, 0);
+        std::vector<float> lX(3 * (size_t)nl, 0.f), lang(nl);
+        std::vector<int32_t> loct(nl), k2(cap, -1);
+        for (int i = 0; i < nl; i++) {
+            loct[i] = Last.mvKeys[i].octave; lang[i] = Last.mvKeysUn[i].angle;
+            MapPoint* q = Last.mvpMapPoints[i];
+            if (!q || Last.mvbOutlier[i]) continue;
+            valid[i] = 1;
+            for (int a = 0; a < 3; a++) lX[3 * i + a] = q->pos.at<float>(a);
+            memcpy(&ldesc[32 * (size_t)i], q->desc.ptr<unsigned char>(0), 32);
+        }
+        float Tc[16], Tl[16];
+        for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) { Tc[4 * r + k] = Cur2.mTcw.at<float>(r, k); Tl[4 * r + k] = Last.mTcw.at<float>(r, k); }
+        eao_track_result R3 = {};
+        std::vector<float> ur3(cap), dz3(cap);
+        R3.kp_map_point = k2.data(); R3.kp_outlier = o2.data(); R3.kp_u_right = ur3.data(); R3.kp_depth = dz3.data();
+        if (eao_tracker_track_with_motion_model(h, d_kps, d_desc, d_n, d_depth, W, W, H, Tc, Tl, nl, valid.data(), lX.data(), ldesc.data(), loct.data(), lang.data(),
+                                                15.f, 0, 1, 1, &R3, nullptr) != EAO_OK) { fprintf(stderr, "%s\n", eao_last_error()); return 2; }
+        int kept = 0, withObs = 0, mmBad = 0;
+        for (int k = 0; k < Cur.N; k++) {
+            MapPoint* want = k2[k] >= 0 ? Last.mvpMapPoints[k2[k]] : nullptr;
+            if (Cur.mvpMapPoints[k] != want) mmBad++;
+            if (Cur.mvbOutlier[k]) mmBad++;
+            if (Cur.mvuRight[k] != ur3[k] || Cur.mvDepth[k] != dz3[k]) mmBad++;
+            if (want) { kept++; withObs += want->Observations() > 0 ? 1 : 0; }
+        }
+        for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) if (Cur.mTcw.at<float>(r, k) != R3.Tcw[4 * r + k]) mmBad++;
+        if (nm != kept || nm != R3.n_inliers || nMap != withObs || nSearch != R3.n_matches) { fprintf(stderr, "motion model counts: %d kept %d / %d, map %d / %d, search %d / %d\n", nm, kept, R3.n_inliers, nMap, withObs, nSearch, R3.n_matches); mmBad++; }
+        if (kept < 100) { fprintf(stderr, "motion model: only %d matches kept\n", kept); mmBad++; }
+        fprintf(stderr, "motion model: %d matches after the search, %d kept, %d with observations, %d disagreements\n", nSearch, kept, withObs, mmBad);
+        bad += mmBad;
+        pts[seen[4]].nObs = 1;
+    }
+    eao_tracker_destroy(h);
     fprintf(stderr, "%d keypoints, %d with a map point, %d inliers, %d disagreements\n", F.N, matched, nIn, bad);
     return (bad == 0 && matched > 100 && nIn > 50) ? 0 : 1;
 }

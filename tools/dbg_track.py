@@ -32,3 +32,14 @@ for i in range(105):
     if i >= 5: ts.append(time.perf_counter() - t0)
 ts = np.array(ts) * 1e3
 print("eao_tracker_track_local_map: min %.4f median %.4f ms (%d keypoints, %d matches, %d inliers)" % (ts.min(), np.median(ts), r["n_keypoints"], r["n_matches"], r["n_inliers"]))
+# the stage in front of it (round 4): TrackWithMotionModel's data path, and both stages back to back (what a tracked frame costs behind the extractor)
+ts, tb = [], []
+for i in range(105):
+    t0 = time.perf_counter()
+    m = trk.track_with_motion_model(dk.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddep.data_ptr(), 640, 640, 480, curT["Tcw"], lastT, 15.0, False, True, True, st)
+    t1 = time.perf_counter()
+    r = trk.track_local_map(dk.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddep.data_ptr(), 640, 640, 480, m["Tcw"], None, 3.0, 0.8, st)
+    if i >= 5: ts.append(t1 - t0); tb.append(time.perf_counter() - t0)
+ts, tb = np.array(ts) * 1e3, np.array(tb) * 1e3
+print("eao_tracker_track_with_motion_model: min %.4f median %.4f ms (%d matches, %d kept); motion model + local map back to back: min %.4f median %.4f ms per frame"
+      % (ts.min(), np.median(ts), m["n_matches"], m["n_inliers"], tb.min(), np.median(tb)))
