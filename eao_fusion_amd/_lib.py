@@ -100,6 +100,7 @@ SYMBOLS = {
     # the remaining guided searches: argument lists live in search.py (SEARCH_ARGTYPES), bound there
     "eao_search_by_projection_sim3": None, "eao_search_by_projection_kf": None, "eao_search_by_bow": None,
     "eao_search_for_triangulation": None, "eao_search_for_initialization": None, "eao_fuse_search": None, "eao_search_by_sim3": None,
+    "eao_search_for_triangulation_batch": None, "eao_fuse_search_batch": None,
     # f1, second half (the device-resident tracked frame): argument lists live in tracker.py
     "eao_tracker_create": None, "eao_tracker_destroy": None, "eao_tracker_set_local_map": None, "eao_tracker_track_local_map": None,
     "eao_tracker_track_with_motion_model": None, "eao_abi_version": (_I, []),

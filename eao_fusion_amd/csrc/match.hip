@@ -222,82 +222,118 @@ thread_local Ctx g_ctx;
 
 }  // namespace
 
-// uploads the frame + queries, runs the candidate kernel, downloads the compact lists
-eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L) {
+// uploads the frames + their queries, runs the candidate kernel once per frame, downloads the compact lists: ONE staging block, one upload, one
+// download and one synchronisation for all of them (round 4: the batched LocalMapping-side searches -- a single frame is a batch of one).
+// qdesc[f]: the query descriptors of frame f (nq[f] x 32 bytes); frames may share them (Fuse: the same map points into every target keyframe)
+eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs, const std::vector<Query>* qs, const uint8_t* const* qdescs, Lists* Ls) {
     Ctx& c = g_ctx;
     eao_status st = eao::require_device();
     if (st) return st;
     if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    const int n = F->n, nq = (int)q.size();
-    L.start.assign(nq, 0); L.count.assign(nq, 0); L.items.clear();
-    if (n == 0 || nq == 0) return EAO_OK;
-    EAO_REQUIRE(n < 65536, "at most 65535 keypoints per frame (indices are packed in 16 bits)");
-    // grid order: PosInGrid (src/Frame.cc:751-761) then cell column-major, insertion (= index) order inside a cell
-    struct Ord { int cx, cy, i; };
-    std::vector<Ord> ord;
-    ord.reserve(n);
-    for (int i = 0; i < n; i++) {
-        const int px = (int)std::round((F->kp_x[i] - F->min_x) * F->grid_inv_w);
-        const int py = (int)std::round((F->kp_y[i] - F->min_y) * F->grid_inv_h);
-        if (px < 0 || px >= F->grid_cols || py < 0 || py >= F->grid_rows) continue;
-        ord.push_back({px, py, i});
-    }
-    std::sort(ord.begin(), ord.end(), [](const Ord& a, const Ord& b) {
-        return a.cx != b.cx ? a.cx < b.cx : (a.cy != b.cy ? a.cy < b.cy : a.i < b.i);
-    });
-    const int no = (int)ord.size();
-    // one staging block: kx ky ur (float n) | oct (int n) | order (int no) | cellx celly (u16 no) | desc (32 n) | queries | qdesc
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t off = 0;
-    const size_t oKx = off; off = al(off + 4 * (size_t)n);
-    const size_t oKy = off; off = al(off + 4 * (size_t)n);
-    const size_t oUr = off; off = al(off + 4 * (size_t)n);
-    const size_t oOc = off; off = al(off + 4 * (size_t)n);
-    const size_t oOr = off; off = al(off + 4 * (size_t)std::max(no, 1));
-    const size_t oCx = off; off = al(off + 2 * (size_t)std::max(no, 1));
-    const size_t oCy = off; off = al(off + 2 * (size_t)std::max(no, 1));
-    const size_t oDe = off; off = al(off + 32 * (size_t)n);
-    const size_t oQ = off; off = al(off + sizeof(Query) * (size_t)nq);
-    const size_t oQd = off; off = al(off + 32 * (size_t)nq);
+    struct Ord { int cx, cy, i; };
+    struct Plan { int n, nq, no; size_t oKx, oKy, oUr, oOc, oOr, oCx, oCy, oDe, oQ, oQd, oOut, oMeta; size_t outCap; std::vector<Ord> ord; };
+    std::vector<Plan> plan(nf);
+    size_t off = 0, outOff = 0, metaOff = 0;
+    // shared query descriptors are staged once
+    std::vector<size_t> qdOff(nf, 0);
+    for (int f = 0; f < nf; f++) {
+        const eao_frame_view* F = Fs[f];
+        Plan& P = plan[f];
+        P.n = F->n; P.nq = (int)qs[f].size(); P.no = 0;
+        Ls[f].start.assign(P.nq, 0); Ls[f].count.assign(P.nq, 0); Ls[f].items.clear();
+        if (P.n == 0 || P.nq == 0) { P.n = 0; P.nq = 0; continue; }
+        EAO_REQUIRE(P.n < 65536, "at most 65535 keypoints per frame (indices are packed in 16 bits)");
+        // grid order: PosInGrid (src/Frame.cc:751-761) then cell column-major, insertion (= index) order inside a cell
+        P.ord.reserve(P.n);
+        for (int i = 0; i < P.n; i++) {
+            const int px = (int)std::round((F->kp_x[i] - F->min_x) * F->grid_inv_w);
+            const int py = (int)std::round((F->kp_y[i] - F->min_y) * F->grid_inv_h);
+            if (px < 0 || px >= F->grid_cols || py < 0 || py >= F->grid_rows) continue;
+            P.ord.push_back({px, py, i});
+        }
+        std::sort(P.ord.begin(), P.ord.end(), [](const Ord& a, const Ord& b) { return a.cx != b.cx ? a.cx < b.cx : (a.cy != b.cy ? a.cy < b.cy : a.i < b.i); });
+        P.no = (int)P.ord.size();
+        const size_t n = P.n, no = std::max(P.no, 1), nq = P.nq;
+        // per frame: kx ky ur (float n) | oct (int n) | order (int no) | cellx celly (u16 no) | desc (32 n) | queries | (qdesc unless shared with an earlier frame)
+        P.oKx = off; off = al(off + 4 * n);
+        P.oKy = off; off = al(off + 4 * n);
+        P.oUr = off; off = al(off + 4 * n);
+        P.oOc = off; off = al(off + 4 * n);
+        P.oOr = off; off = al(off + 4 * no);
+        P.oCx = off; off = al(off + 2 * no);
+        P.oCy = off; off = al(off + 2 * no);
+        P.oDe = off; off = al(off + 32 * n);
+        P.oQ = off; off = al(off + sizeof(Query) * nq);
+        int shared = -1;
+        for (int g = 0; g < f && shared < 0; g++) if (plan[g].nq == P.nq && qdescs[g] == qdescs[f]) shared = g;
+        if (shared >= 0) P.oQd = plan[shared].oQd;
+        else { P.oQd = off; off = al(off + 32 * nq); }
+        P.outCap = nq * no;
+        P.oOut = outOff; outOff += P.outCap;
+        P.oMeta = metaOff; metaOff += 2 * nq + 1;
+    }
+    if (off == 0) return EAO_OK;
+    EAO_REQUIRE(outOff < ((size_t)1 << 31), "candidate lists too large (%zu entries)", outOff);
     if ((st = c.host.resize(off))) return st;
     unsigned char* hb = c.host.data();
-    std::memcpy(hb + oKx, F->kp_x, 4 * (size_t)n); std::memcpy(hb + oKy, F->kp_y, 4 * (size_t)n);
-    std::memcpy(hb + oUr, F->u_right, 4 * (size_t)n); std::memcpy(hb + oOc, F->kp_octave, 4 * (size_t)n);
-    for (int k = 0; k < no; k++) {
-        ((int*)(hb + oOr))[k] = ord[k].i;
-        ((unsigned short*)(hb + oCx))[k] = (unsigned short)ord[k].cx;
-        ((unsigned short*)(hb + oCy))[k] = (unsigned short)ord[k].cy;
+    for (int f = 0; f < nf; f++) {
+        const eao_frame_view* F = Fs[f];
+        const Plan& P = plan[f];
+        if (!P.nq) continue;
+        const size_t n = P.n;
+        std::memcpy(hb + P.oKx, F->kp_x, 4 * n); std::memcpy(hb + P.oKy, F->kp_y, 4 * n);
+        std::memcpy(hb + P.oUr, F->u_right, 4 * n); std::memcpy(hb + P.oOc, F->kp_octave, 4 * n);
+        for (int k = 0; k < P.no; k++) {
+            ((int*)(hb + P.oOr))[k] = P.ord[k].i;
+            ((unsigned short*)(hb + P.oCx))[k] = (unsigned short)P.ord[k].cx;
+            ((unsigned short*)(hb + P.oCy))[k] = (unsigned short)P.ord[k].cy;
+        }
+        std::memcpy(hb + P.oDe, F->descriptors, 32 * n);
+        std::memcpy(hb + P.oQ, qs[f].data(), sizeof(Query) * (size_t)P.nq);
+        std::memcpy(hb + P.oQd, qdescs[f], 32 * (size_t)P.nq);
     }
-    std::memcpy(hb + oDe, F->descriptors, 32 * (size_t)n);
-    std::memcpy(hb + oQ, q.data(), sizeof(Query) * (size_t)nq);
-    std::memcpy(hb + oQd, qdesc, 32 * (size_t)nq);
     if ((st = c.dev.reserve(off))) return st;
-    const size_t outCap = (size_t)nq * std::max(no, 1);
-    if ((st = c.out.reserve(outCap * sizeof(unsigned)))) return st;
-    if ((st = c.meta.reserve((2 * (size_t)nq + 1) * sizeof(int)))) return st;
-    if ((st = c.metaDev.reserve(2 * (size_t)nq + 1))) return st;
+    if ((st = c.out.reserve(std::max(outOff, (size_t)1) * sizeof(unsigned)))) return st;
+    if ((st = c.meta.reserve(metaOff * sizeof(int)))) return st;
+    if ((st = c.metaDev.reserve(metaOff))) return st;
     hipStream_t s = c.stream;
     EAO_HIP(hipMemcpyAsync(c.dev.p, hb, off, hipMemcpyHostToDevice, s));
-    EAO_HIP(hipMemsetAsync(c.metaDev.p + 2 * (size_t)nq, 0, sizeof(int), s));   // cursor
+    EAO_HIP(hipMemsetAsync(c.metaDev.p, 0, metaOff * sizeof(int), s));   // (the cursors)
+    for (int f = 0; f < nf; f++) {
+        const eao_frame_view* F = Fs[f];
+        const Plan& P = plan[f];
+        if (!P.nq) continue;
+        FrameDev D;
+        D.nOrderedDev = nullptr;
+        D.n = P.n; D.nOrdered = P.no;
+        D.kx = (const float*)(c.dev.p + P.oKx); D.ky = (const float*)(c.dev.p + P.oKy); D.ur = (const float*)(c.dev.p + P.oUr);
+        D.oct = (const int*)(c.dev.p + P.oOc); D.order = (const int*)(c.dev.p + P.oOr);
+        D.cellx = (const unsigned short*)(c.dev.p + P.oCx); D.celly = (const unsigned short*)(c.dev.p + P.oCy); D.colStart = nullptr;
+        D.desc = (const uint4*)(c.dev.p + P.oDe);
+        D.minX = F->min_x; D.minY = F->min_y; D.invW = F->grid_inv_w; D.invH = F->grid_inv_h; D.cols = F->grid_cols; D.rows = F->grid_rows;
+        int* md = c.metaDev.p + P.oMeta;
+        hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(P.nq, 4)), dim3(256), 0, s, D, (const Query*)(c.dev.p + P.oQ),
+                           (const uint4*)(c.dev.p + P.oQd), P.nq, (unsigned*)c.out.p + P.oOut, (int)std::min(P.outCap, (size_t)0x7FFFFFFF), md,
+                           md + P.nq, md + 2 * (size_t)P.nq, eao::match::QueryBuild{});
+    }
     int* meta = (int*)c.meta.p;
-    FrameDev D;
-    D.nOrderedDev = nullptr;
-    D.n = n; D.nOrdered = no;
-    D.kx = (const float*)(c.dev.p + oKx); D.ky = (const float*)(c.dev.p + oKy); D.ur = (const float*)(c.dev.p + oUr);
-    D.oct = (const int*)(c.dev.p + oOc); D.order = (const int*)(c.dev.p + oOr);
-    D.cellx = (const unsigned short*)(c.dev.p + oCx); D.celly = (const unsigned short*)(c.dev.p + oCy); D.colStart = nullptr;
-    D.desc = (const uint4*)(c.dev.p + oDe);
-    D.minX = F->min_x; D.minY = F->min_y; D.invW = F->grid_inv_w; D.invH = F->grid_inv_h; D.cols = F->grid_cols; D.rows = F->grid_rows;
-    hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(nq, 4)), dim3(256), 0, s, D, (const Query*)(c.dev.p + oQ),
-                       (const uint4*)(c.dev.p + oQd), nq, (unsigned*)c.out.p, (int)std::min(outCap, (size_t)0x7FFFFFFF), c.metaDev.p,
-                       c.metaDev.p + nq, c.metaDev.p + 2 * (size_t)nq, eao::match::QueryBuild{});
-    EAO_HIP(hipMemcpyAsync(meta, c.metaDev.p, (2 * (size_t)nq + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipMemcpyAsync(meta, c.metaDev.p, metaOff * sizeof(int), hipMemcpyDeviceToHost, s));
     EAO_HIP(hipStreamSynchronize(s));
     EAO_HIP(hipGetLastError());
-    const int totalItems = meta[2 * (size_t)nq];
-    L.items.assign((const unsigned*)c.out.p, (const unsigned*)c.out.p + std::max(totalItems, 0));
-    for (int k = 0; k < nq; k++) { L.start[k] = meta[k]; L.count[k] = meta[nq + k]; }
+    for (int f = 0; f < nf; f++) {
+        const Plan& P = plan[f];
+        if (!P.nq) continue;
+        const int* m = meta + P.oMeta;
+        const int totalItems = m[2 * (size_t)P.nq];
+        const unsigned* o = (const unsigned*)c.out.p + P.oOut;
+        Ls[f].items.assign(o, o + std::max(totalItems, 0));
+        for (int k = 0; k < P.nq; k++) { Ls[f].start[k] = m[k]; Ls[f].count[k] = m[P.nq + k]; }
+    }
     return EAO_OK;
+}
+eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L) {
+    return build_lists_multi(1, &F, &q, &qdesc, &L);
 }
 
 namespace {

@@ -23,6 +23,8 @@ struct Lists {
 
 // uploads the frame + queries, runs the candidate kernel, downloads the compact lists
 eao_status build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L);
+// the same for nf frames in one upload / one synchronisation (frames may share their query descriptors: same pointer, same count)
+eao_status build_lists_multi(int nf, const eao_frame_view* const* Fs, const std::vector<Query>* qs, const uint8_t* const* qdescs, Lists* Ls);
 
 // Hamming distance of explicit pairs (ia[k] of set A, ib[k] of set B): the bag-of-words bucket searches
 eao_status pair_distances(const uint8_t* descA, int nA, const uint8_t* descB, int nB, const std::vector<int>& ia,

@@ -306,14 +306,15 @@ eao_status eao_search_by_bow(int32_t mode, int32_t n1, const uint8_t* desc1, con
     return EAO_OK;
 }
 
-eao_status eao_search_for_triangulation(const eao_frame_view* K1, const eao_feature_vector* fv1, const eao_frame_view* K2,
-                                        const eao_feature_vector* fv2, const float* F12, float ex, float ey,
-                                        int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
-    EAO_REQUIRE(view_ok(K1) && view_ok(K2) && F12 && match12 && nmatches && K2->level_sigma2, "bad argument");
-    EAO_REQUIRE(fv_ok(fv1, K1->n) && fv_ok(fv2, K2->n), "malformed feature vector");
+}  // extern "C"
+
+namespace {
+// SearchForTriangulation (src/ORBmatcher.cc:657-823) in two halves: every (keypoint of K1, keypoint of K2) pair of the common vocabulary nodes in visiting
+// order (ib shifted by `base2`: where K2's descriptors start in a concatenated array) ...
+void tri_pairs(const eao_frame_view* K1, const eao_feature_vector* fv1, const eao_frame_view* K2, const eao_feature_vector* fv2, int only_stereo, int base2,
+               std::vector<int>& ia, std::vector<int>& ib) {
     auto skip1 = [&](int i) { return (K1->occupied && K1->occupied[i]) || (only_stereo && !(K1->u_right[i] >= 0)); };
     auto skip2 = [&](int j) { return (K2->occupied && K2->occupied[j]) || (only_stereo && !(K2->u_right[j] >= 0)); };
-    std::vector<int> ia, ib;
     for_common_nodes(fv1, fv2, [&](int a, int b) {
         for (int p = fv1->node_start[a]; p < fv1->node_start[a + 1]; p++) {
             const int idx1 = (int)fv1->index[p];
@@ -321,13 +322,16 @@ eao_status eao_search_for_triangulation(const eao_frame_view* K1, const eao_feat
             for (int qx = fv2->node_start[b]; qx < fv2->node_start[b + 1]; qx++) {
                 const int idx2 = (int)fv2->index[qx];
                 if (skip2(idx2)) continue;
-                ia.push_back(idx1); ib.push_back(idx2);
+                ia.push_back(idx1); ib.push_back(base2 + idx2);
             }
         }
     });
-    std::vector<unsigned short> dist;
-    eao_status st = eao::match::pair_distances(K1->descriptors, K1->n, K2->descriptors, K2->n, ia, ib, dist);
-    if (st) return st;
+}
+// ... and the selection over their distances (`dist` points at this neighbour's first pair; returns how many it consumed)
+size_t tri_replay(const eao_frame_view* K1, const eao_feature_vector* fv1, const eao_frame_view* K2, const eao_feature_vector* fv2, const float* F12, float ex,
+                  float ey, int only_stereo, int check_orientation, const unsigned short* dist, int32_t* match12, int32_t* nmatches) {
+    auto skip1 = [&](int i) { return (K1->occupied && K1->occupied[i]) || (only_stereo && !(K1->u_right[i] >= 0)); };
+    auto skip2 = [&](int j) { return (K2->occupied && K2->occupied[j]) || (only_stereo && !(K2->u_right[j] >= 0)); };
     for (int i = 0; i < K1->n; i++) match12[i] = -1;
     RotHist hist(1.0f / HISTO_LENGTH);
     int nm = 0;
@@ -370,6 +374,54 @@ eao_status eao_search_for_triangulation(const eao_frame_view* K1, const eao_feat
     });
     if (check_orientation) hist.reject_minor([&](int k) { match12[k] = -1; nm--; });
     *nmatches = nm;
+    return cur;
+}
+bool octaves_ok(const eao_frame_view* K) {      // the replay indexes scale_factors / level_sigma2 with them
+    for (int i = 0; i < K->n; i++) if (K->kp_octave[i] < 0 || K->kp_octave[i] >= K->nlevels) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+eao_status eao_search_for_triangulation(const eao_frame_view* K1, const eao_feature_vector* fv1, const eao_frame_view* K2,
+                                        const eao_feature_vector* fv2, const float* F12, float ex, float ey,
+                                        int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
+    return eao_search_for_triangulation_batch(K1, fv1, 1, &K2, &fv2, F12, &ex, &ey, only_stereo, check_orientation, match12, nmatches);
+}
+
+/* LocalMapping::CreateNewMapPoints calls SearchForTriangulation once per neighbour keyframe (src/LocalMapping.cc:211-290: 10 or 20 of them per new
+ * keyframe): here ALL neighbours in one call -- the current keyframe's descriptors and every neighbour's travel to the device once, one launch computes
+ * the distances of every (neighbour, vocabulary-node) pair, one copy brings them back; the selection is replayed per neighbour exactly as in a single call. */
+eao_status eao_search_for_triangulation_batch(const eao_frame_view* K1, const eao_feature_vector* fv1, int32_t n_nb, const eao_frame_view* const* K2s,
+                                              const eao_feature_vector* const* fv2s, const float* F12s, const float* exs, const float* eys,
+                                              int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
+    EAO_REQUIRE(view_ok(K1) && n_nb >= 0 && (n_nb == 0 || (K2s && fv2s && F12s && exs && eys && match12 && nmatches)), "bad argument");
+    EAO_REQUIRE(fv_ok(fv1, K1->n), "malformed feature vector");
+    if (n_nb == 0) return EAO_OK;
+    std::vector<int> ia, ib;
+    std::vector<size_t> first(n_nb + 1, 0);
+    std::vector<uint8_t> descB;
+    int base2 = 0;
+    for (int k = 0; k < n_nb; k++) {
+        const eao_frame_view* K2 = K2s[k];
+        EAO_REQUIRE(view_ok(K2) && K2->level_sigma2 && fv_ok(fv2s[k], K2->n), "neighbour %d: bad frame view or feature vector", k);
+        EAO_REQUIRE(octaves_ok(K2), "neighbour %d: a keypoint's octave lies outside its %d levels", k, K2->nlevels);
+        for (int q = 0; q < 9; q++) EAO_REQUIRE(std::isfinite(F12s[9 * k + q]), "neighbour %d: F12 holds a NaN / Inf", k);
+        first[k] = ia.size();
+        tri_pairs(K1, fv1, K2, fv2s[k], only_stereo, base2, ia, ib);
+        descB.insert(descB.end(), K2->descriptors, K2->descriptors + 32 * (size_t)K2->n);
+        base2 += K2->n;
+    }
+    first[n_nb] = ia.size();
+    std::vector<unsigned short> dist;
+    eao_status st = eao::match::pair_distances(K1->descriptors, K1->n, descB.data(), base2, ia, ib, dist);
+    if (st) return st;
+    for (int k = 0; k < n_nb; k++) {
+        const size_t used = tri_replay(K1, fv1, K2s[k], fv2s[k], F12s + 9 * k, exs[k], eys[k], only_stereo, check_orientation, dist.data() + first[k],
+                                       match12 + (size_t)k * K1->n, nmatches + k);
+        if (used != first[k + 1] - first[k]) { eao::set_error("internal: neighbour %d consumed %zu of %zu pair distances", k, used, first[k + 1] - first[k]); return EAO_ERR_INTERNAL; }
+    }
     return EAO_OK;
 }
 
@@ -417,49 +469,72 @@ eao_status eao_search_for_initialization(int32_t n1, const int32_t* octave1, con
 
 eao_status eao_fuse_search(const eao_frame_view* KF, int32_t use_sim3, const float* pose, float fx, float fy, float cx, float cy,
                            float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused) {
-    EAO_REQUIRE(view_ok(KF) && pose && points_ok(pts, true) && best_kp && nfused && (use_sim3 || KF->inv_level_sigma2), "bad argument");
-    float Rcw[9], tcw[3], Ow[3];
-    if (use_sim3) decompose_sim3(pose, Rcw, tcw, Ow);
-    else { std::memcpy(Rcw, pose, 36); std::memcpy(tcw, pose + 9, 12); std::memcpy(Ow, pose + 12, 12); }
-    const int n = pts->n;
-    std::vector<Query> q(n, inactive());
-    std::vector<Shot> shot(n);
-    for (int i = 0; i < n; i++) {
-        best_kp[i] = -1;
-        if (!pts->active[i]) continue;
-        if (!shoot(KF, Rcw, tcw, Ow, fx, fy, cx, cy, pts, i, use_sim3 != 0, shot[i])) continue;
-        q[i] = window(shot[i].u, shot[i].v, th * KF->scale_factors[shot[i].level], -1, -1);
-    }
-    Lists L;
-    eao_status st = eao::match::build_lists(KF, q, pts->desc, L);
-    if (st) return st;
-    int nf = 0;
-    for (int i = 0; i < n; i++) {
-        if (!q[i].active || L.count[i] == 0) continue;
-        const Shot& s = shot[i];
-        const float ur = s.u - bf * s.invz;
-        int bestDist = use_sim3 ? INT_MAX : 256, bestIdx = -1;
-        for (int c = 0; c < L.count[i]; c++) {
-            const unsigned it = L.items[L.start[i] + c];
-            const int k = (int)(it & 0xFFFF), d = (int)(it >> 16);
-            const int kl = KF->kp_octave[k];
-            if (kl < s.level - 1 || kl > s.level) continue;
-            if (!use_sim3) {   // reprojection gates of the pose overload (src/ORBmatcher.cc:915-941)
-                const float exx = s.u - KF->kp_x[k], eyy = s.v - KF->kp_y[k];
-                if (KF->u_right[k] >= 0) {
-                    const float er = ur - KF->u_right[k];
-                    const float e2 = exx * exx + eyy * eyy + er * er;
-                    if (e2 * KF->inv_level_sigma2[kl] > refc::FUSE_CHI2_STEREO) continue;
-                } else {
-                    const float e2 = exx * exx + eyy * eyy;
-                    if (e2 * KF->inv_level_sigma2[kl] > refc::FUSE_CHI2_MONO) continue;
-                }
-            }
-            if (d < bestDist) { bestDist = d; bestIdx = k; }
+    return eao_fuse_search_batch(1, &KF, use_sim3, pose, fx, fy, cx, cy, bf, pts, th, best_kp, nfused);
+}
+
+/* LocalMapping::SearchInNeighbors fuses the current keyframe's map points into every target keyframe (src/LocalMapping.cc:458-520: Fuse(pKFi, vpMapPointMatches)
+ * per target): here the search half for ALL targets in one call -- the points' descriptors are staged once, every target's frame and windows go up in the same
+ * copy, one launch per target back to back, one synchronisation.  poses: 15 floats (use_sim3 = 0) or 16 (use_sim3 = 1) per target.  best_kp: n_kf x pts->n.
+ * As for the single call, replacing / adding observations is the caller's part, target by target in order; because an earlier target's fusions change the
+ * map (a point replaced, or merged into one that the next target already observes), the caller re-checks isBad() AND IsInKeyFrame(pKFi) before it uses a
+ * later target's candidate -- upstream's own two `continue`s at the head of Fuse's loop (src/ORBmatcher.cc:851-861). */
+eao_status eao_fuse_search_batch(int32_t n_kf, const eao_frame_view* const* KFs, int32_t use_sim3, const float* poses, float fx, float fy, float cx, float cy,
+                                 float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused) {
+    EAO_REQUIRE(n_kf >= 0 && (n_kf == 0 || (KFs && poses && best_kp && nfused)) && points_ok(pts, true), "bad argument");
+    if (n_kf == 0) return EAO_OK;
+    const int n = pts->n, plen = use_sim3 ? 16 : 15;
+    std::vector<std::vector<Query>> q(n_kf, std::vector<Query>(n, inactive()));
+    std::vector<std::vector<Shot>> shot(n_kf, std::vector<Shot>(n));
+    std::vector<const uint8_t*> qd(n_kf, pts->desc);
+    for (int f = 0; f < n_kf; f++) {
+        const eao_frame_view* KF = KFs[f];
+        EAO_REQUIRE(view_ok(KF) && (use_sim3 || KF->inv_level_sigma2), "target %d: bad frame view", f);
+        EAO_REQUIRE(octaves_ok(KF), "target %d: a keypoint's octave lies outside its %d levels", f, KF->nlevels);
+        const float* pose = poses + (size_t)plen * f;
+        for (int k = 0; k < plen; k++) EAO_REQUIRE(std::isfinite(pose[k]), "target %d: the pose holds a NaN / Inf", f);
+        float Rcw[9], tcw[3], Ow[3];
+        if (use_sim3) decompose_sim3(pose, Rcw, tcw, Ow);
+        else { std::memcpy(Rcw, pose, 36); std::memcpy(tcw, pose + 9, 12); std::memcpy(Ow, pose + 12, 12); }
+        for (int i = 0; i < n; i++) {
+            best_kp[(size_t)f * n + i] = -1;
+            if (!pts->active[i]) continue;
+            if (!shoot(KF, Rcw, tcw, Ow, fx, fy, cx, cy, pts, i, use_sim3 != 0, shot[f][i])) continue;
+            q[f][i] = window(shot[f][i].u, shot[f][i].v, th * KF->scale_factors[shot[f][i].level], -1, -1);
         }
-        if (bestDist <= TH_LOW) { best_kp[i] = bestIdx; nf++; }
     }
-    *nfused = nf;
+    std::vector<Lists> L(n_kf);
+    eao_status st = eao::match::build_lists_multi(n_kf, KFs, q.data(), qd.data(), L.data());
+    if (st) return st;
+    for (int f = 0; f < n_kf; f++) {
+        const eao_frame_view* KF = KFs[f];
+        int nf = 0;
+        for (int i = 0; i < n; i++) {
+            if (!q[f][i].active || L[f].count[i] == 0) continue;
+            const Shot& s = shot[f][i];
+            const float ur = s.u - bf * s.invz;
+            int bestDist = use_sim3 ? INT_MAX : 256, bestIdx = -1;
+            for (int c = 0; c < L[f].count[i]; c++) {
+                const unsigned it = L[f].items[L[f].start[i] + c];
+                const int k = (int)(it & 0xFFFF), d = (int)(it >> 16);
+                const int kl = KF->kp_octave[k];
+                if (kl < s.level - 1 || kl > s.level) continue;
+                if (!use_sim3) {   // reprojection gates of the pose overload (src/ORBmatcher.cc:915-941)
+                    const float exx = s.u - KF->kp_x[k], eyy = s.v - KF->kp_y[k];
+                    if (KF->u_right[k] >= 0) {
+                        const float er = ur - KF->u_right[k];
+                        const float e2 = exx * exx + eyy * eyy + er * er;
+                        if (e2 * KF->inv_level_sigma2[kl] > refc::FUSE_CHI2_STEREO) continue;
+                    } else {
+                        const float e2 = exx * exx + eyy * eyy;
+                        if (e2 * KF->inv_level_sigma2[kl] > refc::FUSE_CHI2_MONO) continue;
+                    }
+                }
+                if (d < bestDist) { bestDist = d; bestIdx = k; }
+            }
+            if (bestDist <= TH_LOW) { best_kp[(size_t)f * n + i] = bestIdx; nf++; }
+        }
+        nfused[f] = nf;
+    }
     return EAO_OK;
 }
 

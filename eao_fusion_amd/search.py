@@ -170,6 +170,47 @@ class Binding:
                                              float(s12), _p(R), _p(t), float(th)], out)
 
 
+class ProductBinding(Binding):
+    """... plus the two batched entry points of round 4 (LocalMapping::CreateNewMapPoints / SearchInNeighbors call a search once per neighbour keyframe): the
+    product only -- the checker has no batch form, the tests compare a batch with its single calls and those with the oracle."""
+
+    def __init__(self, lib, check):
+        super().__init__(lib, check)
+        lib.eao_search_for_triangulation_batch.restype = _I
+        lib.eao_search_for_triangulation_batch.argtypes = [_FR, _FV, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P]
+        lib.eao_fuse_search_batch.restype = _I
+        lib.eao_fuse_search_batch.argtypes = [_I, _P, _I, _P, _F, _F, _F, _F, _F, _MP, _F, _P, _P]
+
+    def search_for_triangulation_batch(self, k1, fv1, k2s, fv2s, F12s, exs, eys, only_stereo, check_orientation=True):
+        """Returns (nmatches[n_nb], match12[n_nb, n1])."""
+        v1, keep1 = frame_view(k1)
+        f1, kf1 = feature_vector(fv1)
+        views = [frame_view(k) for k in k2s]
+        fvs = [feature_vector(f) for f in fv2s]
+        nb = len(views)
+        vp = (C.POINTER(FrameView) * max(nb, 1))(*[C.pointer(v[0]) for v in views])
+        fp = (C.POINTER(FeatureVector) * max(nb, 1))(*[C.pointer(f[0]) for f in fvs])
+        F = np.ascontiguousarray(np.asarray(F12s, np.float32).reshape(nb, 9))
+        ex, ey = np.ascontiguousarray(exs, np.float32), np.ascontiguousarray(eys, np.float32)
+        out = np.full((nb, v1.n), -1, np.int32)
+        nm = np.zeros(nb, np.int32)
+        self.check(self.lib.eao_search_for_triangulation_batch(C.byref(v1), C.byref(f1), nb, C.cast(vp, _P), C.cast(fp, _P), _p(F), _p(ex), _p(ey),
+                                                               int(only_stereo), int(check_orientation), _p(out), _p(nm)))
+        return nm, out
+
+    def fuse_search_batch(self, kfs, use_sim3, poses, K, bf, pts, th):
+        """Returns (nfused[n_kf], best_kp[n_kf, n_points])."""
+        views = [frame_view(k) for k in kfs]
+        nk = len(views)
+        vp = (C.POINTER(FrameView) * max(nk, 1))(*[C.pointer(v[0]) for v in views])
+        m, k2 = map_points(pts)
+        ps = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(nk, -1))
+        out = np.full((nk, m.n), -1, np.int32)
+        nf = np.zeros(nk, np.int32)
+        self.check(self.lib.eao_fuse_search_batch(nk, C.cast(vp, _P), int(use_sim3), _p(ps), K[0], K[1], K[2], K[3], float(bf), C.byref(m), float(th), _p(out), _p(nf)))
+        return nf, out
+
+
 _binding = None
 
 
@@ -178,5 +219,5 @@ def product():
     global _binding
     if _binding is None:
         from . import _lib
-        _binding = Binding(_lib.load(), _lib.check)
+        _binding = ProductBinding(_lib.load(), _lib.check)
     return _binding

@@ -282,6 +282,14 @@ eao_status eao_search_for_triangulation(const eao_frame_view* K1, const eao_feat
                                         const eao_feature_vector* fv2, const float* F12, float ex, float ey,
                                         int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches);
 
+/* The same for ALL neighbour keyframes of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:211-290 calls SearchForTriangulation once per neighbour,
+ * 10 or 20 per new keyframe) in one call: one upload of K1 and of every neighbour, one launch, one copy back.  K2s / fv2s: n_nb pointers; F12s: 9 floats
+ * per neighbour; exs / eys: the epipoles; match12: n_nb x K1->n (row k = the single call's match12 against neighbour k), nmatches: n_nb.  Equal to n_nb
+ * single calls, entry for entry (tests/test_gpu_search.py). */
+eao_status eao_search_for_triangulation_batch(const eao_frame_view* K1, const eao_feature_vector* fv1, int32_t n_nb, const eao_frame_view* const* K2s,
+                                              const eao_feature_vector* const* fv2s, const float* F12s, const float* exs, const float* eys,
+                                              int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches);
+
 /* a15  SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) -- src/ORBmatcher.cc:405-520.
  * F1: n1 keypoints (octave, angle, descriptors); prev_matched: n1 x 2 floats, updated in place like vbPrevMatched. */
 eao_status eao_search_for_initialization(int32_t n1, const int32_t* octave1, const float* angle1, const uint8_t* desc1,
@@ -295,6 +303,14 @@ eao_status eao_search_for_initialization(int32_t n1, const int32_t* octave1, con
  * observation is the caller's part (it mutates the map), in index order, re-checking isBad() as upstream would. */
 eao_status eao_fuse_search(const eao_frame_view* KF, int32_t use_sim3, const float* pose, float fx, float fy, float cx, float cy,
                            float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused);
+
+/* The same points against ALL target keyframes of LocalMapping::SearchInNeighbors (src/LocalMapping.cc:458-520 calls Fuse once per target) in one call: the
+ * points travel once, every target's frame and windows in the same copy, one synchronisation.  KFs: n_kf pointers; poses: 15 (use_sim3 = 0) or 16 floats per
+ * target; best_kp: n_kf x pts->n; nfused: n_kf.  Equal to n_kf single calls ON THE SAME MAP STATE: an earlier target's fusions change the map, so the caller,
+ * applying the targets in order, re-checks isBad() and IsInKeyFrame(pKFi) (upstream's `continue`s, src/ORBmatcher.cc:851-861) before it uses a later
+ * target's candidate. */
+eao_status eao_fuse_search_batch(int32_t n_kf, const eao_frame_view* const* KFs, int32_t use_sim3, const float* poses, float fx, float fy, float cx, float cy,
+                                 float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused);
 
 /* a15  SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) -- src/ORBmatcher.cc:1102-1326.  pts1 / pts2: the map
  * points of the two keyframes by keypoint index (active = exists, not bad, not already matched); T1w / T2w: 16 floats.

@@ -128,3 +128,88 @@ def test_nothing_active(both, scene):
                  o.search_by_projection_sim3(scene["K2"], scene["Scw"], scene["K"], P, 10)) == 0
     assert _same(g.fuse_search(scene["K2"], 1, scene["Scw"], scene["K"], scene["bf"], P, 3.0),
                  o.fuse_search(scene["K2"], 1, scene["Scw"], scene["K"], scene["bf"], P, 3.0)) == 0
+
+
+def _neighbours(scene, n_nb):
+    """n_nb variants of K2 as neighbour keyframes: shifted keypoints, other occupancy, another fundamental matrix scale / epipole, one with an empty feature
+    vector overlap -- different work per neighbour, so a mixed-up slice of the shared distance array cannot pass."""
+    out = []
+    for k in range(n_nb):
+        k2 = dict(scene["K2"])
+        k2["kp_x"] = (scene["K2"]["kp_x"] + np.float32(0.25 * k)).astype(np.float32)
+        k2["occupied"] = ((scene["mp2"] >= 0) & (np.arange(len(scene["mp2"])) % (3 + k) == 0)).astype(np.uint8)
+        fv = dict(scene["fv2"])
+        if k == 2:
+            fv = dict(fv); fv["node_id"] = (fv["node_id"] + 100000).astype(np.uint32)      # no common vocabulary node with K1
+        if k % 2:
+            perm = np.random.default_rng(900 + k).permutation(len(k2["kp_x"]))              # another keypoint order (and descriptor order)
+            for key in ("kp_x", "kp_y", "kp_octave", "kp_angle", "u_right", "descriptors", "occupied"):
+                k2[key] = np.ascontiguousarray(k2[key][perm])
+            inv = np.argsort(perm)
+            fv = dict(fv); fv["index"] = inv[fv["index"]].astype(np.uint32)
+        F = (scene["F12"] * np.float32(1.0 + 0.01 * k)).astype(np.float32)
+        out.append((k2, fv, F, float(scene["ex"]) + k, float(scene["ey"]) - k))
+    return out
+
+
+@pytest.mark.parametrize("only_stereo", [0, 1])
+def test_search_for_triangulation_batch_equals_single_calls(both, scene, only_stereo):
+    """eao_search_for_triangulation_batch (LocalMapping::CreateNewMapPoints: one search per neighbour keyframe, src/LocalMapping.cc:211-290): row k of the batch
+    = the single call against neighbour k = the oracle's, entry for entry; 0, 1 and 7 neighbours."""
+    g, o = both
+    k1 = dict(scene["K1"])
+    k1["occupied"] = ((scene["mp1"] >= 0) & (np.arange(len(scene["mp1"])) % 2 == 0)).astype(np.uint8)
+    for n_nb in (7, 1, 0):
+        nb = _neighbours(scene, n_nb)
+        nm, m = g.search_for_triangulation_batch(k1, scene["fv1"], [x[0] for x in nb], [x[1] for x in nb], [x[2] for x in nb], [x[3] for x in nb],
+                                                 [x[4] for x in nb], only_stereo, True)
+        assert m.shape == (n_nb, len(k1["kp_x"]))
+        for k, (k2, fv, F, ex, ey) in enumerate(nb):
+            want = o.search_for_triangulation(k1, scene["fv1"], k2, fv, F, ex, ey, only_stereo, True)
+            single = g.search_for_triangulation(k1, scene["fv1"], k2, fv, F, ex, ey, only_stereo, True)
+            assert nm[k] == want[0] == single[0] and np.array_equal(m[k], want[1]) and np.array_equal(single[1], want[1]), "neighbour %d" % k
+        if n_nb == 7:
+            assert nm[2] == 0 and nm.sum() > 20
+
+
+@pytest.mark.parametrize("use_sim3", [0, 1])
+def test_fuse_search_batch_equals_single_calls(both, scene, use_sim3):
+    """eao_fuse_search_batch (LocalMapping::SearchInNeighbors: the same points into every target keyframe, src/LocalMapping.cc:458-520) against single calls and the oracle."""
+    g, o = both
+    kfs, poses = [], []
+    for k in range(5):
+        kf = dict(scene["K2"])
+        kf["kp_y"] = (scene["K2"]["kp_y"] + np.float32(0.5 * k)).astype(np.float32)
+        kfs.append(kf)
+        if use_sim3:
+            S = scene["Scw"].copy(); S[0, 3] += np.float32(0.002 * k)
+            poses.append(S.ravel())
+        else:
+            T = scene["T2w"].astype(np.float64).copy(); T[0, 3] += 0.002 * k
+            poses.append(np.concatenate([T[:3, :3].ravel(), T[:3, 3], -T[:3, :3].T @ T[:3, 3]]).astype(np.float32))
+    nf, best = g.fuse_search_batch(kfs, use_sim3, poses, scene["K"], scene["bf"], scene["points"], 3.0)
+    for k in range(5):
+        want = o.fuse_search(kfs[k], use_sim3, poses[k], scene["K"], scene["bf"], scene["points"], 3.0)
+        assert nf[k] == want[0] and np.array_equal(best[k], want[1]), "target %d" % k
+    assert nf.sum() > 30
+
+
+def test_searches_refuse_bad_input(both, scene):
+    """Negative cases of the host half: an octave beyond the frame's levels, NaN in a pose / fundamental matrix, a feature-vector index beyond
+    the frame -- EAO_ERR_INVALID (an exception here), never a fault."""
+    import eao_fusion_amd as E
+    g, _ = both
+    k2 = dict(scene["K2"]); k2["kp_octave"] = scene["K2"]["kp_octave"].copy(); k2["kp_octave"][5] = 8
+    with pytest.raises(E.EaoError):
+        g.search_for_triangulation(scene["K1"], scene["fv1"], k2, scene["fv2"], scene["F12"], scene["ex"], scene["ey"], 0, True)
+    Fn = scene["F12"].copy(); Fn[1, 1] = np.nan
+    with pytest.raises(E.EaoError):
+        g.search_for_triangulation(scene["K1"], scene["fv1"], scene["K2"], scene["fv2"], Fn, scene["ex"], scene["ey"], 0, True)
+    fv = dict(scene["fv2"]); fv["index"] = fv["index"].copy(); fv["index"][3] = len(scene["K2"]["kp_x"])
+    with pytest.raises(E.EaoError):
+        g.search_for_triangulation(scene["K1"], scene["fv1"], scene["K2"], fv, scene["F12"], scene["ex"], scene["ey"], 0, True)
+    Sn = scene["Scw"].copy(); Sn[2, 3] = np.inf
+    with pytest.raises(E.EaoError):
+        g.fuse_search(scene["K2"], 1, Sn, scene["K"], scene["bf"], scene["points"], 3.0)
+    with pytest.raises(E.EaoError):
+        g.fuse_search(k2, 1, scene["Scw"], scene["K"], scene["bf"], scene["points"], 3.0)
