@@ -39,9 +39,24 @@ VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4   # wave instructions / s: 256 CUs x 4 S
                                           # (tools/ubench/intops.hip; its output at 1 / 2 / 4 / 8 waves per SIMD: profiles/r03_ubench_intops.txt)
 
 
+def _source_sha(rel):
+    """sha256 (first 16 hex digits) of a kernel source file: what a committed counter file was captured from (a kernel edited after the
+    PMC pass would otherwise keep feeding stale instruction / byte counts into fractions that look live)."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def _fresh(pmc, rel):
+    """True when the committed counter file names the hash of today's kernel source (files older than round 4 carry none: stale by definition here)."""
+    return bool(pmc) and pmc.get("source_sha16", {}).get(rel) == _source_sha(rel)
+
+
 def _profile(name):
-    """The newest committed profile file of that name (profiles/r03_<name>, else r02_<name>): recorded figures the line quotes."""
-    for tag in ("r03", "r02"):
+    """The newest committed profile file of that name (profiles/r04_<name>, else r03_ / r02_<name>): recorded figures the line quotes."""
+    for tag in ("r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
         if os.path.exists(f):
             return f
@@ -147,6 +162,38 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
+    # ---- `value_cold` (VERDICT r3 next #8a): the timed loop above replays the SAME 64 frames -- 19.7 MB of input and the 60 MB pyramid stay in the
+    #      256 MB Infinity Cache, so none of its traffic is HBM traffic.  Here sixteen DISTINCT batches (the frames shifted by another offset each:
+    #      other corners, other keypoints; 315 MB of input) rotate through the same extractor, K steps, same barriers: every step's input comes from HBM.
+    cold = {}
+    try:
+        NB = 16
+        rot = [torch.roll(d_img, shifts=(5 * k, 9 * k), dims=(1, 2)).contiguous() for k in range(NB)]
+        for k in range(NB):
+            seq.extract(rot[k])
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        kp_cold = 0
+        for k in range(args.steps):
+            seq.extract(rot[k % NB])
+        torch.cuda.synchronize()
+        barrier()
+        tc1 = time.perf_counter()
+        for k in range(NB):      # (keypoints per step: one pass over the sixteen batches, outside the timed region)
+            seq.extract(rot[k])
+            kp_cold += int(d_n.to(torch.int64).sum().item())
+        v_cold, _kpc, el_cold = shard.aggregate_throughput(int(round(kp_cold / NB)) * args.steps, tc1 - tc0, device=dev)
+        cold = {"value_cold": round(v_cold, 1), "ms_per_step_cold": round(el_cold / args.steps * 1e3, 4), "distinct_batches": NB,
+                "input_MB": round(NB * B * W * H / 1e6, 1),
+                "note": "same extractor, K steps over 16 distinct 64-frame batches in rotation (the frames rolled by (5 k, 9 k) pixels): the input of a step is "
+                        "not in the 256 MB Infinity Cache when the step starts"}
+        del rot
+        seq.extract(d_img)
+        torch.cuda.synchronize()
+    except Exception as ex:  # noqa: BLE001
+        cold = {"value_cold_error": repr(ex)}
     # per-stage HIP-event timing: the same K steps again with events recorded between the kernels on the streams they
     # run on (profiled calls launch the kernels directly instead of replaying the captured hipGraph)
     ext.set_profiling(True)
@@ -184,7 +231,7 @@ def main():
     try:
         pmc_file = _profile("pmc_traffic.json")
         pmc = json.load(open(pmc_file))
-        if pmc.get("batch") == B and dom in pmc["kernels"]:
+        if pmc.get("batch") == B and dom in pmc["kernels"] and _fresh(pmc, "eao_fusion_amd/csrc/orb.hip"):
             k = pmc["kernels"][dom]
             traffic = int(2 * k["fetch_bytes_per_step"] + k["write_bytes_per_step"])   # all launches of the stage in one step
             traffic_note = "from the committed PMC passes (%s): 2 x FETCH_SIZE + WRITE_SIZE per step" % os.path.relpath(pmc_file, ROOT)
@@ -196,7 +243,7 @@ def main():
     try:
         sq = json.load(open(sq_file))
         kname = {"pyramid": "k_resize", "fast": "k_fast_cells", "quadtree": "k_quadtree", "blur": "k_blur7", "orient_describe": "k_orient_describe"}
-        if sq.get("batch") == B:
+        if sq.get("batch") == B and _fresh(sq, "eao_fusion_amd/csrc/orb.hip"):
             for st_, kn in kname.items():
                 if kn in sq["kernels"] and stage_ms.get(st_, 0) > 0:
                     insts = sq["kernels"][kn]["SQ_INSTS_VALU"] * sq["kernels"][kn].get("launches_per_step", 1)
@@ -210,17 +257,22 @@ def main():
               "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
               "valu_frac": valu.get(dom), "valu_frac_by_stage": valu,
               "pipeline_GBps": round(sum(stage_bytes.values()) / (stage_ms["total"] * 1e-3) / 1e9, 2)}
+    # roofline.frac is the HBM fraction SURVEY.md s8(d) defines (algorithmic bytes / launch time / 8 TB/s).  The kernel itself is bound by VALU issue
+    # (integer / packed byte arithmetic, no MFMA shape): that view -- wave instructions per launch from the committed SQ pass over the chip's
+    # measured issue rate -- sits beside it under roofline.valu, and is null when the committed pass was not captured from today's orb.hip.
+    roofline = dict(dict({"bound": "hbm"}, **hbm), **common)
+    roofline["limiter"] = "VALU issue (see roofline.valu): ~54 lane-instructions per pixel put FAST at the integer-issue ceiling, 12x above its HBM time"
     if valu.get(dom) is not None:
-        # The dominant kernel is VALU-ISSUE-bound (integer / packed byte arithmetic, no MFMA shape): its roofline is the chip's
-        # wave-instruction rate; the HBM fraction the contract names is kept beside it under "hbm".
         ginst = valu_insts[dom] / (stage_ms[dom] * 1e-3) / 1e9
-        roofline = dict({"bound": "valu", "achieved": round(ginst, 2), "peak": round(VALU_PEAK_WAVE_INSTS / 1e9, 1), "unit": "Gwave-inst/s",
-                         "frac": valu[dom], "hbm": hbm,
-                         "valu_note": "SQ_INSTS_VALU per launch (committed PMC pass, %s) / this run's launch time (HIP events on the kernel's stream) / 6.14e11 "
-                                      "wave-instructions/s (1024 SIMDs x 2.4 GHz / 4 cycles: profiles/r03_ubench_intops.txt); traffic = HBM bytes of the same "
-                                      "launch against algorithmic_bytes_per_launch" % os.path.relpath(sq_file, ROOT)}, **common)
+        roofline["valu"] = {"achieved": round(ginst, 2), "peak": round(VALU_PEAK_WAVE_INSTS / 1e9, 1), "unit": "Gwave-inst/s", "frac": valu[dom],
+                            "note": "SQ_INSTS_VALU per launch (committed PMC pass, %s) / this run's launch time (HIP events on the kernel's stream) / 6.14e11 "
+                                    "wave-instructions/s (1024 SIMDs x 2.4 GHz / 4 cycles: profiles/r04_ubench_intops.txt, with the fp32 rows beside the integer ones)"
+                                    % os.path.relpath(sq_file, ROOT)}
     else:
-        roofline = dict(dict({"bound": "hbm"}, **hbm), **common)
+        roofline["valu"] = None
+        roofline["valu_note"] = "no committed SQ pass captured from the current eao_fusion_amd/csrc/orb.hip (source hash differs): derived fields left out"
+    roofline["cache_note"] = ("the timed steps replay the same 64 frames: input + pyramid (80 MB) live in the 256 MB Infinity Cache and FETCH_SIZE counts those hits, "
+                              "so `traffic` is cache-side traffic, not HBM traffic; `value_cold` rotates 16 distinct batches")
 
     # every collective first (all ranks), the rank-0-only measurements afterwards: no rank waits inside RCCL for minutes
     gathered = {}
@@ -261,6 +313,7 @@ def main():
                        "frames_per_step": B * world, "keypoints_per_step": kp_total_step, "parallelism": "frames sharded per GPU, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }
+        out.update(cold)
         print(json.dumps(out))
     if seq_out and seq_out.get("allgather_ok") is False:
         print("[bench rank %d] the s8(e) all-gather returned payloads that differ from what the ranks sent" % rank, file=sys.stderr)
@@ -269,13 +322,34 @@ def main():
 
 
 def ba_roofline(extra):
-    """The BA half of the metric against the HBM roofline.  Unit = one LM iteration of one window: E x 520 + P x 360
-    algorithmic bytes (linearisation + Schur assembly + solve + back substitution and the error pass).  `achieved` is
-    measured in THIS run: bytes of all iterations of the call / the call's device span (HIP events on the library's stream).  The
-    dominant launch of an iteration (pair-wise Schur assembly, k_ba_schur_pairs_b) is quoted from the committed rocprofv3 summary of the
-    same calls (a recorded figure)."""
+    """The BA half of the metric against the HBM roofline.  Unit = one LM iteration of one window: E x 520 + P x 360 algorithmic bytes (SURVEY.md s8d:
+    linearisation + Schur assembly + solve + back substitution and the error pass).  `achieved` is measured in THIS run: bytes of all iterations of the
+    call / the call's device span (HIP events on the library's stream).  `traffic` = HBM-side bytes per LM iteration from the committed FETCH_SIZE /
+    WRITE_SIZE passes of the same calls (tools/prof_round.sh -> profiles/r04_ba_pmc_traffic.json; 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md
+    prescribes for gfx950), null when that file was not captured from today's lm.hip.  The dominant launch is named with its recorded average duration."""
     out = {}
     P_, per_edge, per_point = 3000, 520, 360
+    tr = None
+    try:
+        f = _profile("ba_pmc_traffic.json")
+        tr = json.load(open(f)) if f else None
+        if not _fresh(tr, "eao_fusion_amd/csrc/lm.hip"):
+            tr = None
+    except Exception:  # noqa: BLE001
+        tr = None
+
+    def dominant(csv_name, part):
+        """(kernel, avg_us) of the k_ba_* launch with the largest total time in a committed rocprofv3 summary"""
+        f = _profile(csv_name)
+        best = (None, None, 0.0)
+        if f:
+            for ln in open(f):
+                if ln.startswith("k_ba_") and not ln.startswith("k_ba_upload"):
+                    c = ln.strip().split(",")
+                    tot = float(c[-2])
+                    if tot > best[2]:
+                        best = (",".join(c[:-6]), float(c[-5]), tot)
+        return best[0], best[1], (os.path.relpath(f, ROOT) if f else None)
     try:
         b = extra.get("ba_batch")
         if b:
@@ -285,26 +359,31 @@ def ba_roofline(extra):
             by_iter = nwin * (E_ * per_edge + P_ * per_point)
             it_ms = b["device_ms"] / rounds
             ach = by_iter / (it_ms * 1e-3) / 1e9
-            dom_us, src = _kernel_avg_us("ba_batch_kernel_stats.csv", "k_ba_schur_pairs_b")
+            kn, dom_us, src = dominant("ba_batch_kernel_stats.csv", "batched")
+            t = (tr or {}).get("batched")
             out["batched"] = {"workload": "25 windows x (20 + 4 KF, 3000 MP) in ONE eao_local_ba_batch call", "bound": "hbm", "unit": "GB/s",
                               "algorithmic_bytes_per_iteration": int(by_iter), "iterations": rounds, "avg_iteration_ms": round(it_ms, 4),
                               "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "frac": round(ach / HBM_PEAK_GBS, 4),
-                              "kernel": "k_ba_schur_pairs_b", "avg_launch_ms": None if dom_us is None else round(dom_us * 1e-3, 4),
-                              "kernel_frac": None if dom_us is None else round(by_iter / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                              "kernel_source": src,
-                              "note": "achieved / frac: all four launches of an LM iteration, measured in this run; kernel_frac: the iteration's bytes against the "
-                                      "dominant launch alone (recorded rocprofv3 average) -- scattered 16-byte loads and fp64 arithmetic, not a streaming kernel"}
+                              "traffic": None if not t else int(t["hbm_bytes_per_iteration"]),
+                              "traffic_over_algorithmic": None if not t else round(t["hbm_bytes_per_iteration"] / by_iter, 3),
+                              "traffic_source": None if not t else "profiles/r04_ba_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE of the launches of one LM iteration)",
+                              "kernel": kn, "avg_launch_ms": None if dom_us is None else round(dom_us * 1e-3, 4), "kernel_source": src,
+                              "note": "achieved / frac: all launches of an LM iteration, measured in this run.  The launches are bound by the CUs' texture-address / L1 path, LDS and "
+                                      "dependent-launch latency (profiles/r04_ba_pair_ablation.txt), not by streaming"}
         s1 = extra.get("ba")
         if s1:
             E_ = s1["ba_residual_blocks_per_s"] * s1["ms_per_lba_wall"] * 1e-3 / max(s1["linearizations_per_lba"], 1)
             by_iter = E_ * per_edge + P_ * per_point
             it_ms = s1["ms_per_lba_device"] / max(s1["linearizations_per_lba"], 1)
             ach = by_iter / (it_ms * 1e-3) / 1e9
-            dom_us, src = _kernel_avg_us("ba_single_kernel_stats.csv", "k_ba_solve_tiles")
+            kn, dom_us, src = dominant("ba_single_kernel_stats.csv", "single")
+            t = (tr or {}).get("single_window")
             out["single_window"] = {"workload": "one LocalBundleAdjustment window (BASELINE configs[3])", "bound": "latency (one window is 9 MB and ~60 dependent launches)",
                                     "unit": "GB/s", "algorithmic_bytes_per_iteration": int(by_iter), "iterations": s1["linearizations_per_lba"],
                                     "avg_iteration_ms": round(it_ms, 4), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "frac": round(ach / HBM_PEAK_GBS, 4),
-                                    "kernel": "k_ba_solve_tiles", "avg_launch_ms": None if dom_us is None else round(dom_us * 1e-3, 4), "kernel_source": src}
+                                    "traffic": None if not t else int(t["hbm_bytes_per_iteration"]),
+                                    "traffic_over_algorithmic": None if not t else round(t["hbm_bytes_per_iteration"] / by_iter, 3),
+                                    "kernel": kn, "avg_launch_ms": None if dom_us is None else round(dom_us * 1e-3, 4), "kernel_source": src}
     except Exception as ex:  # noqa: BLE001
         out["error"] = repr(ex)
     return out
@@ -445,6 +524,49 @@ def measure_sequence(E, sequence, shard, torch, dist, dev, rank, world, seq, n_f
                     "all-gather of (keypoints, descriptors) of every frame and of every window's poses + points"}
 
 
+def search_cases(synth, n=1000):
+    """The nine guided searches of csrc/search.hip (rows a13-a15) on one synthetic two-keyframe scene, as (name, call(binding)) pairs -- the same calls time the
+    product (search.product()) in measure_extra and the oracle (oracle.search_binding()) in measure_cpu."""
+    sc = synth.synth_search_scene(n=n, seed=8300)
+    P = sc["points"]
+    ang = ((np.arange(len(P["active"])) * 37) % 360).astype(np.float32)
+    s1 = dict(descriptors=sc["K1"]["descriptors"], angle=sc["K1"]["kp_angle"], valid=(sc["mp1"] >= 0).astype(np.uint8), fv=sc["fv1"])
+    s2 = dict(descriptors=sc["K2"]["descriptors"], angle=sc["K2"]["kp_angle"], valid=(sc["mp2"] >= 0).astype(np.uint8), fv=sc["fv2"])
+    T = sc["T2w"].astype(np.float64)
+    pose15 = np.concatenate([T[:3, :3].ravel(), T[:3, 3], -T[:3, :3].T @ T[:3, 3]]).astype(np.float32)
+    pm = np.stack([sc["K1"]["kp_x"], sc["K1"]["kp_y"]], 1)
+
+    def pts_of(mp):
+        idx = np.maximum(mp, 0)
+        d = {k: np.ascontiguousarray(P[k][idx]) for k in ("Xw", "normal", "min_dist_inv", "max_dist_inv", "max_dist", "descriptors")}
+        d["active"] = ((mp >= 0) & (P["active"][idx] > 0)).astype(np.uint8)
+        return d
+    P1, P2 = pts_of(sc["mp1"]), pts_of(sc["mp2"])
+    cases = [
+        ("search_by_projection_sim3", lambda g: g.search_by_projection_sim3(sc["K2"], sc["Scw"], sc["K"], P, 10)),
+        ("search_by_projection_kf", lambda g: g.search_by_projection_kf(sc["K2"], sc["T2w"], sc["K"], P, ang, 15, 100, True)),
+        ("search_by_bow_kf_frame", lambda g: g.search_by_bow(0, s1, s2, 0.75, True)),
+        ("search_by_bow_kf_kf", lambda g: g.search_by_bow(1, s1, s2, 0.8, True)),
+        ("search_for_triangulation", lambda g: g.search_for_triangulation(sc["K1"], sc["fv1"], sc["K2"], sc["fv2"], sc["F12"], sc["ex"], sc["ey"], 0, True)),
+        ("search_for_initialization", lambda g: g.search_for_initialization(sc["K1"], sc["K2"], pm, 100, 0.9, True)),
+        ("fuse_search_pose", lambda g: g.fuse_search(sc["K2"], 0, pose15, sc["K"], sc["bf"], P, 3.0)),
+        ("fuse_search_sim3", lambda g: g.fuse_search(sc["K2"], 1, sc["Scw"], sc["K"], sc["bf"], P, 3.0)),
+        ("search_by_sim3", lambda g: g.search_by_sim3(sc["K1"], sc["T1w"], P1, sc["K2"], sc["T2w"], P2, sc["K"], 1.0, sc["R12"], sc["t12"], 7.5)),
+    ]
+    return sc, pose15, cases
+
+
+def time_calls(fn, reps=12, warm=2):
+    for _ in range(warm):
+        r = fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3, r
+
+
 def measure_extra(E, synth, torch, dev):
     """Hamming (configs[2]) and local BA (configs[3]) on GPU 0, outside the timed region."""
     extra = {}
@@ -476,18 +598,21 @@ def measure_extra(E, synth, torch, dev):
             byts = pairs * (2_064_000 if mode == "matrix" else 72_000)
             h = {"pair_distances_per_s": round(pairs * 1e6 / (ms * 1e-3), 1), "ms_per_launch": round(ms, 4), "pairs_per_launch": pairs,
                  "achieved_GBps": round(byts / (ms * 1e-3) / 1e9, 2)}
-            # 16 v_xor + 16 v_bcnt (with accumulate) per 256-bit distance, per lane: what the VALU must issue at the very least
-            dist_per_s = pairs * 1e6 / (ms * 1e-3)
-            h["valu_frac_min"] = round(dist_per_s * 16 / 64 / VALU_PEAK_WAVE_INSTS, 4)
+            # round 4: the distances come off the matrix cores (v_mfma_i32_32x32x32_i8 over 0 / 1 bytes, csrc/hamming.hip): 8 instructions of 32 cycles per
+            # 32 x 32 tile of distances -> the launch's matrix-core time at 2.4 GHz; the VALU spreads bits to bytes and (best-2) keeps the two smallest keys
+            h["kernel"] = "k_hamming_matrix_mfma" if mode == "matrix" else "k_hamming_best2_mfma"
+            h["mfma_time_frac"] = round((pairs * 1e6 / 1024.0) * 8 * 32 / (1024 * 2.4e9) / (ms * 1e-3), 4)
             if mode == "matrix":
                 h["frac_hbm"] = round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)     # write-bound: 2 B per distance
             else:
-                h["bound"] = "valu (72 KB of traffic per pair: an HBM fraction says nothing here)"
+                h["bound"] = "valu + matrix cores (72 KB of traffic per pair: an HBM fraction says nothing here)"
             try:
                 sq = json.load(open(_profile("pmc_sq.json")))
-                kn = "k_hamming_matrix8" if mode == "matrix" else "k_hamming_best2_rows"
-                if kn in sq.get("kernels_extra", {}):
-                    h["valu_frac"] = round(sq["kernels_extra"][kn]["SQ_INSTS_VALU"] / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS, 4)
+                if h["kernel"] in sq.get("kernels_extra", {}) and _fresh(sq, "eao_fusion_amd/csrc/hamming.hip"):
+                    ke = sq["kernels_extra"][h["kernel"]]
+                    h["valu_frac"] = round(ke["SQ_INSTS_VALU"] / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS, 4)
+                    if "SQ_VALU_MFMA_BUSY_CYCLES" in ke and "SQ_BUSY_CYCLES" in ke:
+                        h["mfma_busy_cycles_per_launch"] = ke["SQ_VALU_MFMA_BUSY_CYCLES"]
             except Exception:
                 pass
             extra["hamming_%s" % mode] = h
@@ -744,8 +869,48 @@ def measure_extra(E, synth, torch, dev):
                                               "timing": "median of 100 calls (through the Python mirror)", "ms_min_mean": [round(min(ttT) * 1e3, 4), round(float(np.mean(ttT)) * 1e3, 4)],
                                               "note": "eao_tracker_track_local_map: RGB-D stereo + grid + isInFrustum + SearchByProjection(points) + PoseOptimization on the device, "
                                                       "results in mapped host memory; PoseOptimization's single-workgroup LM (4 rounds) is ~0.135 ms of it"}
+            # the stage in front of it (round 4): TrackWithMotionModel's data path on the same handle, and both stages of a tracked frame back to back
+            for _ in range(5):
+                mT = trk.track_with_motion_model(dk.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddep.data_ptr(), 640, 640, 480, curT["Tcw"], lastT, 15.0, False, True, True, stT)
+            tmm, tbb = [], []
+            for _ in range(100):
+                t0 = time.perf_counter()
+                mT = trk.track_with_motion_model(dk.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddep.data_ptr(), 640, 640, 480, curT["Tcw"], lastT, 15.0, False, True, True, stT)
+                t1 = time.perf_counter()
+                trk.track_local_map(dk.data_ptr(), dd.data_ptr(), dn.data_ptr(), ddep.data_ptr(), 640, 640, 480, mT["Tcw"], None, 3.0, 0.8, stT)
+                tmm.append(t1 - t0); tbb.append(time.perf_counter() - t0)
+            extra["tracking_motion_model_device"] = {"ms_per_call": round(float(np.median(tmm)) * 1e3, 4), "matches": int(mT["n_matches"]), "kept_after_discard": int(mT["n_inliers"]),
+                                                     "ms_motion_model_plus_local_map": round(float(np.median(tbb)) * 1e3, 4),
+                                                     "note": "eao_tracker_track_with_motion_model: frame set-up + SearchByProjection(Cur, Last) with the rotation histogram + PoseOptimization + outlier "
+                                                             "discard on the device, one copy back; then eao_tracker_track_local_map from its pose (two calls, two copies: the local map of "
+                                                             "stage two depends on stage one's matches on the host, src/Tracking.cc:2233-2260)"}
         except Exception as ex:  # noqa: BLE001
             extra["tracking_frame_device_error"] = repr(ex)
+        # ---- rows a13-a15: the nine remaining guided searches, each timed at the Python mirror of its C entry point (host buffers in and out: upload, candidate /
+        #      pair-distance kernel, download, host replay) on a 1000-point two-keyframe scene; measure_cpu() times the oracle's counterpart beside each
+        try:
+            from eao_fusion_amd import search as SR
+            gS = SR.product()
+            scS, pose15S, casesS = search_cases(synth)
+            gsr = {}
+            for name, fn in casesS:
+                ms, r = time_calls(lambda: fn(gS))
+                gsr[name] = {"ms_per_call": round(ms, 4), "matches": int(r[0])}
+            # the batched LocalMapping-side entry points (round 4): 10 neighbour / target keyframes per call against 10 single calls
+            nbS = 10
+            k2s = [scS["K2"]] * nbS; fvs = [scS["fv2"]] * nbS
+            Fs = [scS["F12"]] * nbS; exs = [scS["ex"]] * nbS; eys = [scS["ey"]] * nbS
+            mb, _ = time_calls(lambda: gS.search_for_triangulation_batch(scS["K1"], scS["fv1"], k2s, fvs, Fs, exs, eys, 0, True), reps=8)
+            ms1, _ = time_calls(lambda: [gS.search_for_triangulation(scS["K1"], scS["fv1"], scS["K2"], scS["fv2"], scS["F12"], scS["ex"], scS["ey"], 0, True) for _ in range(nbS)], reps=8)
+            gsr["search_for_triangulation_batch"] = {"neighbours": nbS, "ms_per_call": round(mb, 4), "ms_ten_single_calls": round(ms1, 4)}
+            mb, _ = time_calls(lambda: gS.fuse_search_batch([scS["K2"]] * nbS, 0, [pose15S] * nbS, scS["K"], scS["bf"], scS["points"], 3.0), reps=8)
+            ms1, _ = time_calls(lambda: [gS.fuse_search(scS["K2"], 0, pose15S, scS["K"], scS["bf"], scS["points"], 3.0) for _ in range(nbS)], reps=8)
+            gsr["fuse_search_batch"] = {"targets": nbS, "ms_per_call": round(mb, 4), "ms_ten_single_calls": round(ms1, 4)}
+            gsr["note"] = ("median of 12 calls through the ctypes mirror (array wrapping included, ~0.02 ms); keypoints / map points: %d / %d; where a search loses to "
+                           "one CPU thread (extra.cpu_guided_searches) it is the upload + launch + download + host replay of a sub-millisecond problem" % (len(scS["K2"]["kp_x"]), len(scS["points"]["active"])))
+            extra["guided_searches"] = gsr
+        except Exception as ex:  # noqa: BLE001
+            extra["guided_searches_error"] = repr(ex)
         # the Frame glue (isInFrustum over a 20 000-point local map) and a small-map BundleAdjustment (12 KF, 10 its)
         from eao_fusion_amd import frame as FR
         rng = np.random.default_rng(11)
@@ -889,7 +1054,8 @@ def measure_cpu(frames, synth, extra):
             O.hamming_matrix(a, b)
             reps += 1
         dt = (time.perf_counter() - t0) / reps
-        ex["cpu_hamming_matrix"] = {"pair_distances_per_s": round(1e6 / dt, 1), "cores": 1, "kind": "port"}
+        ex["cpu_hamming_matrix"] = {"pair_distances_per_s": round(1e6 / dt, 1), "cores": 1, "kind": "port",
+                                    "note": "the reference's own SWAR bit count (src/ORBmatcher.cc:1649-1665), ~8x slower than a popcnt loop: faithful to the reference, not the best a CPU can do"}
         curf, lastf, mpsf = synth.synth_tracking()
         t0 = time.perf_counter()
         reps = 0
@@ -898,6 +1064,21 @@ def measure_cpu(frames, synth, extra):
             O.search_by_projection_frames(curf, lastf, 7.0, False, True)
             reps += 1
         ex["cpu_guided_matching"] = {"ms_per_frame_both_searches": round((time.perf_counter() - t0) / reps * 1e3, 3), "cores": 1, "kind": "port"}
+        # the nine remaining guided searches on the oracle (oracle/search_cpu.cpp, 1 thread), the same calls measure_extra() times on the product
+        try:
+            oS = O.search_binding()
+            _sc, _p15, casesS = search_cases(synth)
+            cs = {}
+            for name, fn in casesS:
+                ms, r = time_calls(lambda: fn(oS), reps=8)
+                g = extra.get("guided_searches", {}).get(name, {})
+                cs[name] = {"ms_per_call": round(ms, 4), "matches": int(r[0]),
+                            "gpu_over_cpu_time": None if "ms_per_call" not in g else round(g["ms_per_call"] / ms, 2)}
+            cs["note"] = ("oracle/search_cpu.cpp, 1 thread, median of 8 calls through its ctypes binding; gpu_over_cpu_time > 1: the product's call (upload + kernel + download + "
+                          "host replay) takes LONGER than one CPU thread on this 1000-point problem")
+            ex["cpu_guided_searches"] = cs
+        except Exception as e2:  # noqa: BLE001
+            ex["cpu_guided_searches_error"] = repr(e2)
         pp = synth.synth_pose()
         t0 = time.perf_counter()
         reps = 0

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void k_hamming_best2_seq(const uint4* __restri
 typedef int hm_v4i __attribute__((ext_vector_type(4)));
 typedef int hm_v16i __attribute__((ext_vector_type(16)));
 constexpr int kMB = 128;                 // block edge (A rows and B columns)
-constexpr int kMPitch = 272;             // bytes per spread row / per staged output row
+constexpr int kMPitch = 272;             // bytes per spread row
+constexpr int kOPitch = 144;             // bytes per staged output row: 64 columns x 2 bytes + 16 (16-byte aligned rows; 136 misaligns the 16-byte reads, 160 changes nothing)
 constexpr unsigned kKeyNone = (256u << 20) | 0xFFFFFu;
 
 __device__ __forceinline__ unsigned spread4(unsigned nib) { return __umul24(nib, 0x204081u) & 0x01010101u; }      // bit e of the nibble -> byte e (0 / 1)
@@ -272,10 +273,10 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { 
 __device__ __forceinline__ void hm_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // full matrix: grid (column blocks, row blocks, pairs); nb % 8 == 0 and a 16-byte aligned D (else the popcount kernels above)
-__global__ __launch_bounds__(256, 2) void k_hamming_matrix_mfma(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,
+__global__ __launch_bounds__(256, 3) void k_hamming_matrix_mfma(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,
                                                                 unsigned short* __restrict__ D) {
     __shared__ __attribute__((aligned(16))) unsigned char sB[kMB * kMPitch];
-    __shared__ __attribute__((aligned(16))) unsigned char sOut[4][32 * kMPitch];
+    __shared__ __attribute__((aligned(16))) unsigned char sOut[4][32 * kOPitch];      // 32 rows x 64 columns of uint16 per wave: two tiles at a time
     __shared__ __attribute__((aligned(16))) unsigned short sPb[kMB];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, h = lane >> 5;
     const int pair = blockIdx.z;
@@ -322,17 +323,21 @@ __global__ __launch_bounds__(256, 2) void k_hamming_matrix_mfma(const uint4* __r
             const uint2 pb = *reinterpret_cast<const uint2*>(&sPb[jc]);
             const unsigned lo = (paPk + pb.x) - (((unsigned)acc[4 * q] | ((unsigned)acc[4 * q + 1] << 16)) << 1);
             const unsigned hi = (paPk + pb.y) - (((unsigned)acc[4 * q + 2] | ((unsigned)acc[4 * q + 3] << 16)) << 1);
-            *reinterpret_cast<uint2*>(so + r * kMPitch + jc * 2) = make_uint2(lo, hi);
+            *reinterpret_cast<uint2*>(so + r * kOPitch + ((jt & 1) * 32 + 8 * q + 4 * h) * 2) = make_uint2(lo, hi);
         }
-    }
-    hm_wave_sync();
-    // 32 rows x 256 bytes: sixteen lanes per row, 16 bytes each
+        if (jt & 1) {
+            // two tiles = 32 rows x 128 bytes: eight lanes per row, 16 bytes each -- whole cache lines, 1 KB per store instruction.  (Staging all four
+            // tiles first cost 35 KB of LDS per workgroup on top of the 35 KB of spread rows: two workgroups per CU instead of three.)
+            hm_wave_sync();
 #pragma unroll
-    for (int p = 0; p < 8; p++) {
-        const int row = p * 4 + (lane >> 4), ch = lane & 15;
-        const uint4 v = *reinterpret_cast<const uint4*>(so + row * kMPitch + ch * 16);
-        const int ii = i0 + row, jj = j0 + ch * 8;
-        if (ii < na && jj < nb) *reinterpret_cast<uint4*>(D + (long long)ii * nb + jj) = v;
+            for (int p = 0; p < 4; p++) {
+                const int row = p * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(so + row * kOPitch + ch * 16);
+                const int ii = i0 + row, jj = j0 + (jt - 1) * 32 + ch * 8;
+                if (ii < na && jj < nb) *reinterpret_cast<uint4*>(D + (long long)ii * nb + jj) = v;
+            }
+            hm_wave_sync();
+        }
     }
 }
 

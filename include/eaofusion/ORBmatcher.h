@@ -266,6 +266,54 @@ public:
         return nm;
     }
 
+    // Round 4 -- ALL neighbour keyframes of LocalMapping::CreateNewMapPoints in one library call (src/LocalMapping.cc:211-290 calls SearchForTriangulation per
+    // neighbour inside its loop): vF12[k] is ComputeF12(pKF1, vpNeighKFs[k]) (:266), vvMatchedPairs[k] what the k-th single call would return.  The loop's own
+    // baseline test (:240-263) decides which neighbours the caller passes.
+    template <class KeyFrameT>
+    void SearchForTriangulationBatch(KeyFrameT* pKF1, const std::vector<KeyFrameT*>& vpNeighKFs, const std::vector<cv::Mat>& vF12,
+                                     std::vector<std::vector<std::pair<size_t, size_t> > >& vvMatchedPairs, const bool bOnlyStereo) {
+        const size_t nb = vpNeighKFs.size();
+        vvMatchedPairs.assign(nb, std::vector<std::pair<size_t, size_t> >());
+        if (!nb) return;
+        FrameArrays fa1;
+        eao_frame_view v1 = kfview(*pKF1, fa1);
+        for (int k = 0; k < v1.n; k++) fa1.occ[k] = pKF1->GetMapPoint(k) ? 1 : 0;
+        FeatVecArrays f1;
+        const eao_feature_vector fv1 = flatten(pKF1->mFeatVec, f1);
+        std::vector<FrameArrays> fa2(nb);
+        std::vector<FeatVecArrays> f2(nb);
+        std::vector<eao_frame_view> v2(nb);
+        std::vector<eao_feature_vector> fv2(nb);
+        std::vector<const eao_frame_view*> pv(nb);
+        std::vector<const eao_feature_vector*> pf(nb);
+        std::vector<float> Fm(9 * nb), ex(nb), ey(nb);
+        const cv::Mat Cw = pKF1->GetCameraCenter();
+        for (size_t q = 0; q < nb; q++) {
+            KeyFrameT* pKF2 = vpNeighKFs[q];
+            const cv::Mat R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();      // the epipole in the second image, as in the single call (:663-670)
+            float C2[3];
+            for (int r = 0; r < 3; r++) {
+                double acc = 0;
+                for (int k = 0; k < 3; k++) acc += (double)R2w.template at<float>(r, k) * (double)Cw.template at<float>(k);
+                C2[r] = (float)(acc + (double)t2w.template at<float>(r));
+            }
+            const float invz = 1.0f / C2[2];
+            ex[q] = pKF2->fx * C2[0] * invz + pKF2->cx; ey[q] = pKF2->fy * C2[1] * invz + pKF2->cy;
+            v2[q] = kfview(*pKF2, fa2[q]);
+            for (int k = 0; k < v2[q].n; k++) fa2[q].occ[k] = pKF2->GetMapPoint(k) ? 1 : 0;
+            fv2[q] = flatten(pKF2->mFeatVec, f2[q]);
+            pv[q] = &v2[q]; pf[q] = &fv2[q];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Fm[9 * q + r * 3 + c] = vF12[q].template at<float>(r, c);
+        }
+        std::vector<int32_t> m12(nb * (size_t)v1.n, -1), nm(nb, 0);
+        check(eao_search_for_triangulation_batch(&v1, &fv1, (int)nb, pv.data(), pf.data(), Fm.data(), ex.data(), ey.data(), bOnlyStereo ? 1 : 0,
+                                                 mbCheckOrientation ? 1 : 0, m12.data(), nm.data()), "eao_search_for_triangulation_batch");
+        for (size_t q = 0; q < nb; q++) {
+            vvMatchedPairs[q].reserve(nm[q]);
+            for (int i = 0; i < v1.n; i++) if (m12[q * v1.n + i] >= 0) vvMatchedPairs[q].push_back(std::make_pair((size_t)i, (size_t)m12[q * v1.n + i]));
+        }
+    }
+
     // reference :825-975 (LocalMapping::SearchInNeighbors).  The search runs for all points first; replacing / adding
     // observations then happens in index order exactly as upstream interleaves it, re-checking the entry conditions a
     // previous replacement may have changed.

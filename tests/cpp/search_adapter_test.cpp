@@ -174,6 +174,18 @@ int main(int argc, char** argv) {
         std::vector<int32_t> m12(A.N, -1);
         for (auto& p : pairs) m12[p.first] = (int32_t)p.second;
         wr(out, &n, 1); wr(out, m12.data(), m12.size());
+        // ... and the batched template (round 4): three neighbours (B, B again, A itself) in one call = three single calls
+        KeyFrame A2 = A;
+        std::vector<KeyFrame*> nb = {&B, &B, &A2};
+        std::vector<cv::Mat> vF = {mat(F12, 3, 3), mat(F12, 3, 3), mat(F12, 3, 3)};
+        std::vector<std::vector<std::pair<size_t, size_t> > > vv;
+        m75.SearchForTriangulationBatch(&A, nb, vF, vv, false);
+        for (size_t q = 0; q < nb.size(); q++) {
+            std::vector<std::pair<size_t, size_t> > one;
+            m75.SearchForTriangulation(&A, nb[q], vF[q], one, false);
+            if (one != vv[q]) { std::fprintf(stderr, "SearchForTriangulationBatch: neighbour %zu differs from its single call (%zu vs %zu pairs)\n", q, vv[q].size(), one.size()); return 3; }
+        }
+        if (vv[0] != pairs) { std::fprintf(stderr, "SearchForTriangulationBatch: neighbour 0 differs from the single call above\n"); return 3; }
     }
     // 4. SearchForInitialization
     {

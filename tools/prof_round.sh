@@ -3,7 +3,7 @@
 # behind the VALU roofline, the FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic, the per-kernel summaries of the BA calls behind
 # roofline.ba, and the VALU issue-rate micro-benchmark.
 #   bash tools/prof_round.sh r03   ->  gpurun_out/r03_*   (copy the summaries into profiles/ afterwards: tools/prof_round.sh does not)
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 rm -rf $O/${R}_stats $O/${R}_sq_a $O/${R}_sq_b $O/${R}_fetch $O/${R}_write $O/${R}_sq_h $O/${R}_ba_batch $O/${R}_ba_single
@@ -20,10 +20,16 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
     --output-format csv -d $O/${R}_sq_b -o b -- $BENCH > $O/${R}_sq_b.log 2>&1
 # ... and of the two Hamming kernels
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/${R}_sq_h -o h -- python3 tools/dbg_hamming.py > $O/${R}_sq_h.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS --output-format csv -d $O/${R}_sq_h -o h -- python3 tools/dbg_hamming.py > $O/${R}_sq_h.log 2>&1
 # 3. HBM-side traffic (separate passes: FETCH_SIZE and WRITE_SIZE do not fit one)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${R}_fetch -o f -- $BENCH > $O/${R}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${R}_write -o w -- $BENCH > $O/${R}_write.log 2>&1
+# 3b. ... and of the LM launches (round 4: roofline.ba.*.traffic): the 25-window batch in one group, and single windows
+rm -rf $O/${R}_ba_fetch $O/${R}_ba_write $O/${R}_ba1_fetch $O/${R}_ba1_write
+EAO_BA_BATCH_GROUPS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${R}_ba_fetch -o f -- python3 tools/dbg_ba_batch.py > $O/${R}_ba_fetch.log 2>&1
+EAO_BA_BATCH_GROUPS=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${R}_ba_write -o w -- python3 tools/dbg_ba_batch.py > $O/${R}_ba_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${R}_ba1_fetch -o f -- python3 tools/dbg_ba_cabi.py > $O/${R}_ba1_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${R}_ba1_write -o w -- python3 tools/dbg_ba_cabi.py > $O/${R}_ba1_write.log 2>&1
 python3 tools/pmc_tables.py $O $R
 # 4. the BA half: per-kernel durations of the 25-window batch and of the single window (the figures roofline.ba quotes)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_ba_batch -o s -- python3 tools/dbg_ba_batch.py > $O/${R}_ba_batch.log 2>&1
