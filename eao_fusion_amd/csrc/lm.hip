@@ -4603,7 +4603,7 @@ constexpr int kBatchGroups = 4, kBatchGroupMin = 4;     // default number of win
 
 // The host threads of a batch call (window set-up workers, group leaders) are PERSISTENT: a call hands `count` tasks to the crew and
 // joins them.  Starting eight std::threads per call cost ~0.3 ms of a 2.9 ms batch (clone + first-touch of the thread's HIP state,
-// one after the other) -- which is why more set-up threads used to make a call slower.  The crew is per calling thread, grows on
+// one after the other) -- which is why more set-up threads used to make a call slower.  The crew is process-wide, grows on
 // demand and is never torn down (its threads sleep on a condition variable between calls and die with the process).
 struct HostCrew {
     std::mutex m;
@@ -4628,7 +4628,9 @@ struct HostCrew {
         }
     }
     // runs fn(0 .. n-1) on the crew (at least n threads, so tasks that wait for each other cannot starve) and fn0() on the caller
+    std::mutex callMu;      // one batch call at a time uses the crew (calls from several host threads queue up here)
     void run(int n, const std::function<void(int)>& f, const std::function<void()>& fn0) {
+        std::lock_guard<std::mutex> oneCall(callMu);
         {
             std::unique_lock<std::mutex> lk(m);
             while (threads < n) { std::thread(&HostCrew::body, this).detach(); threads++; }
@@ -4642,7 +4644,11 @@ struct HostCrew {
     }
 };
 HostCrew& host_crew() {
-    static thread_local HostCrew* crew = new HostCrew();      // (leaked on purpose: its detached threads may outlive the caller's thread)
+    // ONE crew per process (round 4; it was one per calling thread: a pool of short-lived caller threads grew the process by ~19 sleeping threads per
+    // caller).  Its size is the largest thread count a call ever asked for (the set-up threads + group leaders of eao_local_ba_batch: about
+    // nineteen with the defaults); the threads sleep on a condition variable between calls and end with the process (detached: a static destructor
+    // that joined them would run after the HIP runtime's own teardown).
+    static HostCrew* crew = new HostCrew();
     return *crew;
 }
 }  // namespace

@@ -12,7 +12,7 @@
 //                       Hamming distance of the survivors and appends (index, distance) through ballot compaction, so
 //                       every query's list is already in upstream's candidate order.  Two sweeps (count, reserve a
 //                       segment with one atomic, fill) keep the output compact.
-// The host part of this file replays the assignment loops over those lists exactly as upstream runs them.
+// The assignment loops over those lists are replayed on the host exactly as upstream runs them: csrc/search.hip (a host-only translation unit since round 4).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -398,166 +398,3 @@ eao_status eao::match::enqueue_candidates_device(const FrameDevArgs& F, const Qu
     return EAO_OK;
 }
 
-// The search windows of ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono), src/ORBmatcher.cc:1339-1393: the relative
-// motion along the optical axis decides the level window (:1343-1347), every valid last-frame point is projected with the current pose (float
-// matrices, double accumulation) and gets a window of th x the scale factor of its octave.  Shared by the host-hop entry point below and by the
-// device-resident chain (csrc/track.hip).
-eao_status eao::match::build_frame_queries(const FrameQueryArgs& A, Query* q) {
-    const float* Tcw = A.Tcw; const float* Tlw = A.Tlw;
-    float twc[3], tlc[3];
-    for (int i = 0; i < 3; i++) {
-        double sacc = 0;
-        for (int k = 0; k < 3; k++) sacc += (double)(-Tcw[k * 4 + i]) * (double)Tcw[k * 4 + 3];
-        twc[i] = (float)sacc;
-    }
-    for (int i = 0; i < 3; i++) {
-        double sacc = 0;
-        for (int k = 0; k < 3; k++) sacc += (double)Tlw[i * 4 + k] * (double)twc[k];
-        tlc[i] = (float)(sacc + (double)Tlw[i * 4 + 3]);
-    }
-    const bool bForward = tlc[2] > A.mb && !A.mono;
-    const bool bBackward = -tlc[2] > A.mb && !A.mono;
-    for (int i = 0; i < A.n_last; i++) {
-        Query& Q = q[i];
-        Q.active = 0; Q.x = Q.y = Q.r = 0; Q.minLevel = 0; Q.maxLevel = -1; Q.urRef = 0; Q.urTol = 0;
-        if (!A.valid[i]) continue;
-        float xc3[3];
-        for (int r = 0; r < 3; r++) {
-            double sacc = 0;
-            for (int k = 0; k < 3; k++) sacc += (double)Tcw[r * 4 + k] * (double)A.Xw[3 * i + k];
-            xc3[r] = (float)(sacc + (double)Tcw[r * 4 + 3]);
-        }
-        const float invzc = (float)(1.0 / xc3[2]);
-        if (!(invzc >= 0)) continue;                   // "if(invzc<0) continue" -- and a NaN projection (a NaN pose or point) matches nothing
-        const float u = A.fx * xc3[0] * invzc + A.cx, v = A.fy * xc3[1] * invzc + A.cy;
-        if (!(u >= A.min_x && u <= A.max_x)) continue;
-        if (!(v >= A.min_y && v <= A.max_y)) continue;
-        const int oct = A.last_octave[i];
-        EAO_REQUIRE(oct >= 0 && oct < A.nlevels, "last-frame keypoint %d: octave %d out of range", i, oct);
-        const float radius = A.th * A.scale_factors[oct];
-        Q.active = 1; Q.x = u; Q.y = v; Q.r = radius;
-        if (bForward) { Q.minLevel = oct; Q.maxLevel = -1; }
-        else if (bBackward) { Q.minLevel = 0; Q.maxLevel = oct; }
-        else { Q.minLevel = oct - 1; Q.maxLevel = oct + 1; }
-        Q.urRef = u - A.mbf * invzc; Q.urTol = radius;
-    }
-    return EAO_OK;
-}
-
-extern "C" {
-
-eao_status eao_search_by_projection_points(const eao_frame_view* F, int32_t n_mp, const float* proj_x, const float* proj_y,
-                                           const float* proj_xr, const float* view_cos, const int32_t* pred_level,
-                                           const uint8_t* mp_desc, const uint8_t* skip, float th, float nnratio,
-                                           int32_t* match_kp, int32_t* nmatches) {
-    EAO_REQUIRE(F && match_kp && nmatches && n_mp >= 0, "null argument");
-    EAO_REQUIRE(n_mp == 0 || (proj_x && proj_y && proj_xr && view_cos && pred_level && mp_desc), "null map-point arrays");
-    EAO_REQUIRE(F->n == 0 || (F->kp_x && F->kp_y && F->kp_octave && F->u_right && F->descriptors && F->scale_factors), "incomplete frame view");
-    const bool bFactor = th != 1.0;
-    std::vector<Query> q(n_mp);
-    std::vector<float> rs(n_mp, 0.f);
-    for (int m = 0; m < n_mp; m++) {
-        Query& Q = q[m];
-        Q.active = !(skip && skip[m]);
-        const int lvl = pred_level[m];
-        if (Q.active) EAO_REQUIRE(lvl >= 0 && lvl < F->nlevels, "map point %d: predicted level %d out of range", m, lvl);
-        float r = view_cos[m] > refc::VIEWCOS_NARROW ? refc::RADIUS_NARROW : refc::RADIUS_WIDE;          // RadiusByViewingCos, :131-137
-        if (bFactor) r *= th;
-        rs[m] = Q.active ? r * F->scale_factors[lvl] : 0.f;
-        Q.x = proj_x[m]; Q.y = proj_y[m]; Q.r = rs[m];
-        Q.minLevel = lvl - 1; Q.maxLevel = lvl;
-        Q.urRef = proj_xr[m]; Q.urTol = rs[m];
-    }
-    Lists L;
-    eao_status st = build_lists(F, q, mp_desc, L);
-    if (st) return st;
-    std::vector<uint8_t> occ(F->n, 0);
-    if (F->occupied) std::memcpy(occ.data(), F->occupied, F->n);
-    int nm = 0;
-    for (int m = 0; m < n_mp; m++) {   // upstream's loop, :51-126
-        match_kp[m] = -1;
-        if (!q[m].active || L.count[m] == 0) continue;
-        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-        const unsigned* it = &L.items[L.start[m]];
-        for (int k = 0; k < L.count[m]; k++) {
-            const int i = (int)(it[k] & 0xFFFF), d = (int)(it[k] >> 16);
-            if (occ[i]) continue;
-            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = F->kp_octave[i]; bestIdx = i; }
-            else if (d < bestDist2) { bestLevel2 = F->kp_octave[i]; bestDist2 = d; }
-        }
-        if (bestDist <= refc::TH_HIGH) {
-            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
-            match_kp[m] = bestIdx;
-            occ[bestIdx] = 1;
-            nm++;
-        }
-    }
-    *nmatches = nm;
-    return EAO_OK;
-}
-
-eao_status eao_search_by_projection_frames(const eao_frame_view* C, const float* Tcw, const float* Tlw, int32_t n_last,
-                                           const uint8_t* valid, const float* Xw, const uint8_t* mp_desc, const int32_t* last_octave,
-                                           const float* last_angle, float fx, float fy, float cx, float cy, float mbf, float mb,
-                                           float th, int32_t mono, int32_t check_orientation, int32_t* cur_match, int32_t* nmatches) {
-    EAO_REQUIRE(C && Tcw && Tlw && cur_match && nmatches && n_last >= 0, "null argument");
-    EAO_REQUIRE(n_last == 0 || (valid && Xw && mp_desc && last_octave && last_angle), "null last-frame arrays");
-    EAO_REQUIRE(C->n == 0 || (C->kp_x && C->kp_y && C->kp_octave && C->kp_angle && C->u_right && C->descriptors && C->scale_factors), "incomplete frame view");
-    for (int i = 0; i < C->n; i++) cur_match[i] = -1;
-    std::vector<Query> q(n_last);
-    eao::match::FrameQueryArgs QA{Tcw, Tlw, n_last, valid, Xw, last_octave, fx, fy, cx, cy, mbf, mb, th, mono, C->min_x, C->max_x, C->min_y, C->max_y, C->scale_factors, C->nlevels};
-    if (eao_status qs = eao::match::build_frame_queries(QA, q.data())) return qs;
-    Lists L;
-    eao_status st = build_lists(C, q, mp_desc, L);
-    if (st) return st;
-    std::vector<uint8_t> occ(C->n, 0);
-    if (C->occupied) std::memcpy(occ.data(), C->occupied, C->n);
-    constexpr int HISTO = refc::HISTO_LENGTH;
-    std::vector<int> rotHist[HISTO];
-    const float factor = HISTO / 360.0f;          // this fork's histogram factor for this routine (:1337)
-    int nm = 0;
-    for (int i = 0; i < n_last; i++) {
-        if (!q[i].active || L.count[i] == 0) continue;
-        int bestDist = 256, bestIdx2 = -1;
-        const unsigned* it = &L.items[L.start[i]];
-        for (int k = 0; k < L.count[i]; k++) {
-            const int i2 = (int)(it[k] & 0xFFFF), d = (int)(it[k] >> 16);
-            if (occ[i2]) continue;
-            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
-        }
-        if (bestDist <= 100) {
-            cur_match[bestIdx2] = i;
-            occ[bestIdx2] = 1;
-            nm++;
-            if (check_orientation) {
-                float rot = last_angle[i] - C->kp_angle[bestIdx2];
-                if (rot < 0.0) rot += 360.0f;
-                int bin = (int)std::round(rot * factor);
-                if (bin == HISTO) bin = 0;
-                if (bin >= 0 && bin < HISTO) rotHist[bin].push_back(bestIdx2);
-            }
-        }
-    }
-    if (check_orientation) {   // keep the three fullest bins (ComputeThreeMaxima, :1603-1644)
-        int top[3] = {0, 0, 0}, ind[3] = {-1, -1, -1};
-        for (int b = 0; b < HISTO; b++) {
-            const int pop = (int)rotHist[b].size();
-            for (int rk = 0; rk < 3; rk++)
-                if (pop > top[rk]) {
-                    for (int z = 2; z > rk; z--) { top[z] = top[z - 1]; ind[z] = ind[z - 1]; }
-                    top[rk] = pop; ind[rk] = b;
-                    break;
-                }
-        }
-        const float floor10 = 0.1f * (float)top[0];
-        if (top[1] < floor10) { ind[1] = -1; ind[2] = -1; }
-        else if (top[2] < floor10) ind[2] = -1;
-        for (int b = 0; b < HISTO; b++)
-            if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int k : rotHist[b]) { cur_match[k] = -1; nm--; }
-    }
-    *nmatches = nm;
-    return EAO_OK;
-}
-
-}  // extern "C"

@@ -44,6 +44,12 @@ public:
     DeviceTracker(const DeviceTracker&) = delete;
     DeviceTracker& operator=(const DeviceTracker&) = delete;
 
+    // The handle's limits (4096 keypoints per frame, 16384 local map points at most, whatever the constructor asked for below that): a frame beyond them
+    // goes through the host-hop calls -- upstream's own SearchLocalPoints / PoseOptimization over the drop-in adapters -- as the INTEGRATION.md fragments do.
+    template <class FrameT> bool Fits(const FrameT& F) const { return F.N <= cap_; }
+    int MaxKeypoints() const { return cap_; }
+    int MaxMapPoints() const { return capMp_; }
+
     // Tracking::mvpLocalMapPoints -> HBM (kept until the next call).  Bad points stay in the arrays with active = 0.
     // Returns false -- and leaves the previous map in place -- when the local map is larger than maxMapPoints (the handle's
     // capacity, at most 16384): the caller then runs upstream's own SearchLocalPoints + PoseOptimization for this frame.

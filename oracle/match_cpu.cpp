@@ -205,3 +205,30 @@ int orc_search_by_projection_frames(const FrameView* C, const float* Tcw, const 
 }
 
 }  // extern "C"
+
+// ---- candidate lists for the HOST half of the product (round 4; tests/test_host_replay_cpu.py, tools/run_sanitizers.sh): what the product's candidate
+// kernel hands its host replay -- per query the keypoints of Frame::GetFeaturesInArea (src/Frame.cc:696-749) in the grid's visiting order, with the stereo
+// gate the searches apply inside their candidate loops (src/ORBmatcher.cc:95-100, 1405-1411: a keypoint with uRight > 0 whose |urRef - uRight| exceeds the
+// tolerance is skipped) and the Hamming distance to the query's descriptor, packed distance << 16 | keypoint.  This lets the product's host replay code
+// (eao_fusion_amd/csrc/search.hip compiled as plain C++ with sanitizers, tests/cpp/host_replay_provider.cpp as its list provider) run WITHOUT a GPU.
+// Query: the eight 4-byte fields of eao::match::Query (csrc/match_internal.h): x, y, r, minLevel, maxLevel, urRef, urTol, active.
+extern "C" int orc_candidate_lists(const FrameView* F, int nq, const void* queries, const uint8_t* qdesc, int32_t* start, int32_t* count, uint32_t* items,
+                                   int items_cap) {
+    struct Q { float x, y, r; int32_t minLevel, maxLevel; float urRef, urTol; int32_t active; };
+    const Q* q = (const Q*)queries;
+    const Grid g(*F);
+    int total = 0;
+    for (int k = 0; k < nq; k++) {
+        start[k] = total; count[k] = 0;
+        if (!q[k].active) continue;
+        for (int i : g.area(q[k].x, q[k].y, q[k].r, q[k].minLevel, q[k].maxLevel)) {
+            const float u = F->u_right[i];
+            if (u > 0 && std::fabs(q[k].urRef - u) > q[k].urTol) continue;
+            if (total >= items_cap) return -1;
+            items[total++] = ((uint32_t)dist256(qdesc + 32 * (size_t)k, F->descriptors + 32 * (size_t)i) << 16) | (uint32_t)i;
+            count[k]++;
+        }
+    }
+    return total;
+}
+extern "C" int orc_pair_distance(const uint8_t* a, const uint8_t* b) { return dist256(a, b); }

@@ -144,7 +144,7 @@ int main() {
     std::vector<uint8_t> inView(1024, 0);
     std::vector<uint8_t> outl(cap);
     std::vector<float> ur(cap), dz(cap);
-    eao_track_result R;
+    eao_track_result R = {};
     R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data(); R.map_in_view = inView.data();
     float T[16];
     for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) T[4 * r + k] = F2.mTcw.at<float>(r, k);

@@ -3,10 +3,13 @@
 # and driven by the whole non-GPU suite (golden vectors, oracle self-checks, numpy re-derivations, 240 quad-tree replays ...), and
 # the C++ adapters + every INTEGRATION.md snippet compiled with the same flags and -Werror=... off (compile + link only: running
 # them needs the GPU, and GPU / host-in-GPU-process sanitizer runs are not available on this pool).
-# Usage: bash tools/run_sanitizers.sh   -> profiles/r03_sanitizers_cpu.txt
+# Round 4: the HOST half of the product's guided searches (eao_fusion_amd/csrc/search.hip: per-query geometry + the selection loops of all eleven searches, driven
+# by caller-supplied indices) is part of the pass -- tests/test_host_replay_cpu.py builds it as plain C++ with the same flags (EAO_HOST_SAN=1) against the oracle's
+# candidate lists and runs the parity and the malformed-input cases under ASan + UBSan.
+# Usage: bash tools/run_sanitizers.sh   -> profiles/r04_sanitizers_cpu.txt
 set -u
 cd "$(dirname "$0")/.."
-OUT=profiles/r03_sanitizers_cpu.txt
+OUT=profiles/r04_sanitizers_cpu.txt
 TMP=$(mktemp -d)
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1"
 {
@@ -19,7 +22,7 @@ echo "== 2. python -m pytest tests -m 'not gpu' against the instrumented oracle 
 # (-O1 without -march=native: integer tables must still match the golden vectors bit for bit, fp64 LM results within 1e-9)
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-EAO_ORACLE_LIB=$TMP/liboracle_san.so python -m pytest tests -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -15
+EAO_HOST_SAN=1 EAO_ORACLE_LIB=$TMP/liboracle_san.so python -m pytest tests -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -15
 echo "pytest exit code: ${PIPESTATUS[0]}"
 echo "== 3. adapters + INTEGRATION.md snippets compiled with the sanitizer flags (compile + link)"
 python - <<PY
@@ -33,7 +36,7 @@ inc = ["-I", os.path.join(tree, "include"), "-I", os.path.join(tree, "src"), "-I
 link = ["-L", "eao_fusion_amd", "-leaofusion_hip", "-Wl,-rpath,/opt/rocm/lib", "-pthread"]
 san = "$SAN".split()
 jobs = [("integration_snippets_test", ["tests/cpp/integration_snippets_test.cpp"] + units, inc)]
-for t in ("adapter_test", "search_adapter_test", "frame_adapter_test"):
+for t in ("adapter_test", "search_adapter_test", "frame_adapter_test"):      # (tracker_adapter_test.cpp needs hipcc: device buffers)
     jobs.append((t, ["tests/cpp/%s.cpp" % t], ["-I", "include"]))
 bad = 0
 for name, srcs, incs in jobs:
