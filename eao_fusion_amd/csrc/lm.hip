@@ -1461,6 +1461,9 @@ struct BADev {
 // over the 8 XCDs in dispatch order, so with the plain (x = block, z = window) numbering the ~5 MB a window keeps re-reading
 // (Hpl blocks, residuals, the edge table) would be pulled into all eight L2s -- 25 windows are then fabric-bound (the pair
 // assembly alone moved 350 MB per launch).  Window w is served by XCD w % 8 only; the launch pads grid.z to a multiple of 8.
+// The windows of an INCOMPLETE last row of eight share all eight XCDs (slot x serves window x mod rem with the other slots of that residue, the
+// window's workgroups dealt round-robin among them): with 25 windows on 3 + 3 + ... + 4 the XCD that held four set the pace of every launch -- the
+// kernels took as long for 25 windows as for 32 (k_ba_linearize 53.7 / 55.3 us, 43.0 for 24; profiles/r04_ba_xcd_balance.txt).
 // wpar = block pair | rot << 4 | number of windows << 8 (rot: XCD of the group's first window -- the groups of a batch run
 // concurrently and together should load the XCDs evenly);  bx = this workgroup's block index inside its window.
 #define BA_WIN(P)                                                                                                   \
@@ -1469,8 +1472,15 @@ struct BADev {
         const unsigned nz_ = (unsigned)wpar >> 8;                                                                   \
         if (nz_ > 1) {                                                                                              \
             const unsigned b_ = blockIdx.x + gridDim.x * blockIdx.z, s_ = b_ >> 3;                                  \
-            wz_ = ((b_ - ((unsigned)wpar >> 4)) & 7) + 8 * (s_ / gridDim.x);      /* XCD x serves window (x - rot) mod 8 */  \
+            const unsigned xs_ = (b_ - ((unsigned)wpar >> 4)) & 7, row_ = s_ / gridDim.x;      /* XCD x: slot (x - rot) mod 8 */  \
+            const unsigned rem_ = nz_ & 7;                                                                          \
             bx = s_ % gridDim.x;                                                                                    \
+            wz_ = xs_ + 8 * row_;                                                                                   \
+            if (rem_ && row_ == (nz_ >> 3)) {      /* the incomplete last row: its rem_ windows over all eight slots */   \
+                const unsigned wq_ = xs_ % rem_, nsh_ = (8 - wq_ + rem_ - 1) / rem_;                                \
+                if (bx % nsh_ != xs_ / rem_) return;                                                                \
+                wz_ = 8 * row_ + wq_;                                                                               \
+            }                                                                                                       \
             if (wz_ >= nz_) return;                                                                                 \
         }                                                                                                           \
     }                                                                                                               \
@@ -2660,9 +2670,12 @@ __global__ __launch_bounds__(NT, 1024 / NT) void k_ba_schur_pairs_b(const BADev*
 //     (k_ba_classify), its products vanish.
 constexpr int kPairG = 7;                       // landmarks per fetch
 constexpr int kPairSlot = 160;                  // LDS bytes per staged block: 144 data + a zero slot for the padding lanes
-constexpr int kPairWaveLds = 2 * kPairG * kPairSlot + kPairG * 32;      // A blocks, B blocks, u entries (24 + 8 bytes each)
+constexpr int kPairWaveLds = 3 * kPairG * kPairSlot;      // A blocks, B blocks, u entries (24 bytes each, at the blocks' pitch: one immediate offset per landmark)
 template <int NW>      // waves per pair: 4 in a batch (5 250 workgroups: throughput), 16 for a single window (210 workgroups: latency of the longest pair)
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 8 : 1) void k_ba_schur_pairs_mfma(const BADev* __restrict__ W, int wpar, int first) {
+#ifndef EAO_PAIR_OCC
+#define EAO_PAIR_OCC 6
+#endif
+__global__ __launch_bounds__(64 * NW, NW == 4 ? EAO_PAIR_OCC : 1) void k_ba_schur_pairs_mfma(const BADev* __restrict__ W, int wpar, int first) {
     BA_WIN(P);
     if ((int)bx >= P.nFree * (P.nFree + 1) / 2) return;
     __shared__ double part[NW][64];
@@ -2697,17 +2710,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 8 : 1) void k_ba_schur_pairs_mfm
     unsigned char* const sU = sB + kPairG * kPairSlot;
     const unsigned char* const rdA = sA + (aOn ? (aRow * 3 + k) * 8 : 144);
     const unsigned char* const rdB = bOn ? sB + (bCol * 3 + k) * 8 : (uOn ? sU + k * 8 : sB + 144);
-    const int rdBStep = (!bOn && uOn) ? 32 : kPairSlot;
+    const unsigned rdA32 = (unsigned)reinterpret_cast<size_t>(rdA), rdB32 = (unsigned)reinterpret_cast<size_t>(rdB);      // LDS byte addresses
     // ---- the memory path's view: lane 9 j + c fetches 16-byte chunk c of landmark j's blocks (lane 63 idles); lanes 3 j + d fetch u_l[d]
     const int fj = lane / 9, fc = lane - 9 * fj;
     const bool fOn = lane < 9 * kPairG, fuOn = diag && lane < 3 * kPairG;
     unsigned char* const wrA = sA + fj * kPairSlot + fc * 16;
     unsigned char* const wrB = sB + fj * kPairSlot + fc * 16;
-    unsigned char* const wrU = sU + (lane / 3) * 32 + (lane % 3) * 8;
+    unsigned char* const wrU = sU + (lane / 3) * kPairSlot + (lane % 3) * 8;
     if (lane < kPairG) {      // the zero slots (never written again)
         *reinterpret_cast<uint4*>(sA + lane * kPairSlot + 144) = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(sB + lane * kPairSlot + 144) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<double*>(sU + lane * 32 + 24) = 0;
     }
     const char* const Wb = reinterpret_cast<const char*>((const double*)P.Hpl);
     const char* const ub = reinterpret_cast<const char*>((const double*)P.ul);
@@ -2744,12 +2756,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 8 : 1) void k_ba_schur_pairs_mfm
                 if (g + 2 * NW < nGall) recN = load_rec(g + 2 * NW);
             }
             wave_fence();
-#pragma unroll
-            for (int j = 0; j < kPairG; j++) {
-                const double a = *reinterpret_cast<const double*>(rdA + j * kPairSlot);
-                const double b = *reinterpret_cast<const double*>(rdB + j * rdBStep);
-                acc[j & 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[j & 3], 0, 0, 0);
-            }
+            // the operands: fourteen 8-byte reads, one instruction each.  (Left to the compiler they pair up into ds_read2_b64, which the LDS pipe serves at
+            // 8 - 10 cycles against 2 x 2.2 for the two plain reads -- tools/ubench/lds_ops.hip -- and this kernel runs at the pace of the CU's LDS pipe.)
+            double a0, a1, a2, a3, a4, a5, a6, b0, b1, b2, b3, b4, b5, b6;
+            static_assert(kPairG == 7 && kPairSlot == 160, "the immediate offsets below");
+            asm volatile("ds_read_b64 %0, %14\n ds_read_b64 %7, %15\n ds_read_b64 %1, %14 offset:160\n ds_read_b64 %8, %15 offset:160\n"
+                         "ds_read_b64 %2, %14 offset:320\n ds_read_b64 %9, %15 offset:320\n ds_read_b64 %3, %14 offset:480\n ds_read_b64 %10, %15 offset:480\n"
+                         "ds_read_b64 %4, %14 offset:640\n ds_read_b64 %11, %15 offset:640\n ds_read_b64 %5, %14 offset:800\n ds_read_b64 %12, %15 offset:800\n"
+                         "ds_read_b64 %6, %14 offset:960\n ds_read_b64 %13, %15 offset:960\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6)
+                         : "v"(rdA32), "v"(rdB32) : "memory");
+            acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, b2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a3, b3, acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, b4, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a5, b5, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a6, b6, acc[2], 0, 0, 0);
             wave_fence();
         }
     }
