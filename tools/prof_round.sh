@@ -41,5 +41,6 @@ python3 tools/summarize_rocprof.py "$f" $O/${R}_ba_single_kernel_stats.csv "pyth
 # 5. VALU issue rates at 1 / 2 / 4 / 8 waves per SIMD (bench.py's VALU_PEAK_WAVE_INSTS) and the fp64 pipes of one CU
 ./tools/ubench/intops_chip > $O/${R}_ubench_intops.txt 2>&1; head -8 $O/${R}_ubench_intops.txt
 ./tools/ubench/f64_simd > $O/${R}_ubench_f64.txt 2>&1
+./tools/ubench/lds_ops > $O/${R}_ubench_lds.txt 2>&1
 # 6. the default bench line itself
 python3 bench.py > $O/${R}_bench_line.json 2> $O/${R}_bench_line.err; tail -c 600 $O/${R}_bench_line.json; echo
