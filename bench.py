@@ -884,6 +884,31 @@ def measure_extra(E, synth, torch, dev):
                                                      "note": "eao_tracker_track_with_motion_model: frame set-up + SearchByProjection(Cur, Last) with the rotation histogram + PoseOptimization + outlier "
                                                              "discard on the device, one copy back; then eao_tracker_track_local_map from its pose (two calls, two copies: the local map of "
                                                              "stage two depends on stage one's matches on the host, src/Tracking.cc:2233-2260)"}
+            # ... and the other first stage (round 4): TrackReferenceKeyFrame's data path on a 1000-point keyframe / frame pair filed under 60 vocabulary nodes
+            scR = synth.synth_search_scene(n=1000, seed=8100, n_nodes=60)
+            K1R, K2R = scR["K1"], scR["K2"]
+            NR = len(K2R["kp_x"])
+            kR = np.zeros(NR, E.orb.KP_DTYPE)
+            kR["x"], kR["y"] = np.clip(K2R["kp_x"], 1, 638), np.clip(K2R["kp_y"], 1, 478)
+            kR["angle"], kR["octave"] = K2R["kp_angle"], K2R["kp_octave"]
+            mp1R = scR["mp1"]
+            kfR = dict(valid=(mp1R >= 0).astype(np.uint8), Xw=np.ascontiguousarray(scR["points"]["Xw"][np.maximum(mp1R, 0)], np.float32), descriptors=K1R["descriptors"],
+                       angle=K1R["kp_angle"], fv=scR["fv1"])
+            dkR = torch.zeros((2048, 28), dtype=torch.uint8, device=dev); dkR[:NR] = torch.from_numpy(kR.view(np.uint8).reshape(NR, 28)).to(dev)
+            ddR = torch.zeros((2048, 32), dtype=torch.uint8, device=dev); ddR[:NR] = torch.from_numpy(np.ascontiguousarray(K2R["descriptors"])).to(dev)
+            dnR = torch.tensor([NR], dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            fxR, fyR, cxR, cyR = scR["K"]
+            trkR = Tracker(fxR, fyR, cxR, cyR, scR["bf"], (0.0, 640.0, 0.0, 480.0), sfT, (np.float32(1) / (sfT * sfT)).astype(np.float32), float(np.log(np.float32(1.2))), 2048, 2048)
+            trr = []
+            for i in range(105):
+                t0 = time.perf_counter()
+                rR = trkR.track_reference_keyframe(dkR.data_ptr(), ddR.data_ptr(), dnR.data_ptr(), ddep.data_ptr(), 640, 640, 480, scR["T2w"], kfR, scR["fv2"], 0.7, True, True, stT)
+                if i >= 5: trr.append(time.perf_counter() - t0)
+            extra["tracking_reference_keyframe_device"] = {"ms_per_call": round(float(np.median(trr)) * 1e3, 4), "keyframe_keypoints": len(mp1R), "keypoints": NR,
+                                                           "matches": int(rR["n_matches"]), "kept_after_discard": int(rR["n_inliers"]),
+                                                           "note": "eao_tracker_track_reference_keyframe: frame set-up + SearchByBoW(KF, Frame) node by node + rotation histogram + PoseOptimization + "
+                                                                   "outlier discard on the device, one copy back (the frame's feature vector comes from DBoW2 on the host and is an input here)"}
         except Exception as ex:  # noqa: BLE001
             extra["tracking_frame_device_error"] = repr(ex)
         # ---- rows a13-a15: the nine remaining guided searches, each timed at the Python mirror of its C entry point (host buffers in and out: upload, candidate /

@@ -103,7 +103,7 @@ SYMBOLS = {
     "eao_search_for_triangulation_batch": None, "eao_fuse_search_batch": None,
     # f1, second half (the device-resident tracked frame): argument lists live in tracker.py
     "eao_tracker_create": None, "eao_tracker_destroy": None, "eao_tracker_set_local_map": None, "eao_tracker_track_local_map": None,
-    "eao_tracker_track_with_motion_model": None, "eao_abi_version": (_I, []),
+    "eao_tracker_track_with_motion_model": None, "eao_tracker_track_reference_keyframe": None, "eao_abi_version": (_I, []),
     # f1 (Frame glue): argument lists live in frame.py
     "eao_frame_is_in_frustum": None, "eao_assign_features_to_grid": None, "eao_compute_stereo_from_rgbd": None,
     "eao_distinctive_descriptors": (_I, [_I, _P, _P, _P]),

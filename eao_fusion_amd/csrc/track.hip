@@ -527,6 +527,65 @@ __device__ __forceinline__ void track_edges_body(int nMp, int cap, const int* ma
     }
 }
 
+// SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches), src/ORBmatcher.cc:159-288, for the chain of TrackReferenceKeyFrame: the features of the keyframe and of the
+// frame that fell into the same vocabulary node are compared node by node.  Upstream's order only matters INSIDE a node (a frame keypoint lies in one node, so
+// "if(vpMapPointMatches[realIdxF]) continue" :199-200 can only ever see keypoints taken by earlier keyframe features of the same node): a wave owns a node pair
+// and walks its keyframe features in order, the lanes share the frame side -- the two smallest (distance, list position) keys of the keypoints still free,
+// i.e. the scan's "first of equal distances wins" (:206-215), then "bestDist1<=TH_LOW" and the ratio test (:218-220).
+struct BowDev {
+    const int4* pairs;               // per common node: {first keyframe entry, count, first frame entry, count} (NULL: not this stage)
+    int nPairs;
+    const int* kfIdx; const int* fIdx;       // the nodes' index lists, common nodes only
+    const unsigned char* valid;      // by keyframe keypoint: its map point exists and is not bad (:183-189)
+    const uint4* kfDesc; const uint4* fDesc;
+    float nnratio;
+};
+__device__ __forceinline__ void track_bow_body(int nKf, const BowDev& B, int* match, int* counts) {
+    __shared__ int s_nmB;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int n = counts[0];
+    for (int m = t; m < nKf; m += kAssignThreads) match[m] = -1;
+    if (t == 0) s_nmB = 0;
+    __syncthreads();
+    int nm = 0, bad = 0;
+    for (int pi = wv; pi < B.nPairs; pi += kAssignThreads / 64) {
+        const int4 pr = B.pairs[pi];
+        unsigned long long taken = 0;      // bit j: list position lane + 64 j of this node's frame side was matched (<= 4096 keypoints: 64 per lane)
+        for (int a = 0; a < pr.y; a++) {
+            const int iKF = B.kfIdx[pr.x + a];      // (wave-uniform)
+            if (!B.valid[iKF]) continue;
+            const uint4 d0 = B.kfDesc[2 * (size_t)iKF], d1 = B.kfDesc[2 * (size_t)iKF + 1];
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;      // distance << 16 | list position
+            for (int p = lane, j = 0; p < pr.w; p += 64, j++) {
+                if ((taken >> j) & 1) continue;
+                const int iF = B.fIdx[pr.z + p];
+                if (iF >= n) { bad = 1; continue; }
+                const uint4 f0 = B.fDesc[2 * (size_t)iF], f1 = B.fDesc[2 * (size_t)iF + 1];
+                const unsigned d = __popc(d0.x ^ f0.x) + __popc(d0.y ^ f0.y) + __popc(d0.z ^ f0.z) + __popc(d0.w ^ f0.w) + __popc(d1.x ^ f1.x) + __popc(d1.y ^ f1.y) +
+                                   __popc(d1.z ^ f1.z) + __popc(d1.w ^ f1.w);
+                const unsigned key = (d << 16) | (unsigned)p;
+                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {      // the wave's two smallest keys (all distinct: the position is part of the key)
+                const unsigned o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+                const unsigned lo = min(k1, o1), hi = max(k1, o1);
+                k2 = min(hi, min(k2, o2)); k1 = lo;
+            }
+            const int best1 = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16), best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 16);
+            if (best1 <= refc::TH_LOW && (float)best1 < B.nnratio * (float)best2) {
+                const int p = (int)(k1 & 0xFFFFu);
+                if ((p & 63) == lane) taken |= 1ull << (p >> 6);
+                if (lane == 0) { match[iKF] = B.fIdx[pr.z + p]; nm++; }
+            }
+        }
+    }
+    if (lane == 0 && nm) atomicAdd(&s_nmB, nm);
+    if (bad) atomicOr(&counts[4], 8);      // a frame index beyond the keypoints the extractor left
+    __syncthreads();
+    if (t == 0) counts[3] = s_nmB;
+}
+
 // ONE launch for the greedy assignment and the edge list behind it (both are single-workgroup steps of 1024 threads; as two
 // launches the second one waited a launch gap for the first).  nMp = 0: no search ran, only the prior matches become edges.
 static_assert(kAssignThreads == kEdgeThreads, "one workgroup runs both steps");
@@ -539,11 +598,12 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
                                                                        const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl,
                                                                        const float* __restrict__ dz, const unsigned char* __restrict__ inView, ResultBlock R,
                                                                        long long* dbg, int allListers, const float* __restrict__ mAngle, const float* __restrict__ kAngle,
-                                                                       float rotFactor) {
+                                                                       float rotFactor, BowDev bow) {
     extern __shared__ unsigned char asm_raw[];
     if (dbg && threadIdx.x == 0) dbg[0] = clock64();
     if (nMp > 0) {
-        {
+        if (bow.pairs) track_bow_body(nMp, bow, match, counts);
+        else {
             // the candidate lists are ONE compact array (k_match_candidates fills it through an atomic cursor): when it fits, the
             // workgroup copies it into LDS once (coalesced) and the rounds walk it there
             const int total = *cursor;
@@ -744,17 +804,37 @@ struct MotionArgs {
     int mono, check_orientation;
 };
 
+// TrackReferenceKeyFrame's inputs: the reference keyframe's keypoints (map point present and good, position, descriptor, mvKeysUn angle) and the two
+// DBoW2 feature vectors (the frame's one comes from Frame::ComputeBoW on the host: the vocabulary tree is not part of this library)
+struct BowArgs {
+    int n_kf; const uint8_t* valid; const float* Xw; const uint8_t* kf_desc; const float* kf_angle;
+    const eao_feature_vector* fv_kf; const eao_feature_vector* fv_cur; int check_orientation;
+};
+
+eao_status check_feature_vector(const eao_feature_vector* fv, int n, const char* who) {
+    EAO_REQUIRE(fv && fv->n_nodes >= 0, "%s: null feature vector", who);
+    EAO_REQUIRE(fv->n_nodes == 0 || (fv->node_id && fv->node_start && fv->index), "%s: null feature-vector arrays", who);
+    if (fv->n_nodes) EAO_REQUIRE(fv->node_start[0] == 0, "%s: node_start[0] must be 0", who);
+    for (int i = 0; i < fv->n_nodes; i++) {
+        EAO_REQUIRE(i == 0 || fv->node_id[i] > fv->node_id[i - 1], "%s: node ids must ascend strictly (node %d)", who, i);
+        EAO_REQUIRE(fv->node_start[i + 1] >= fv->node_start[i], "%s: node_start must not decrease (node %d)", who, i);
+    }
+    EAO_REQUIRE(fv->n_nodes == 0 || fv->node_start[fv->n_nodes] <= n, "%s: %d indices for %d keypoints (a keypoint lies in ONE node)", who, fv->n_nodes ? fv->node_start[fv->n_nodes] : 0, n);
+    return EAO_OK;
+}
+
 eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
                        const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,
                        const int32_t* prior_kp_map_point, const float* prior_kp_Xw, float th, float nnratio, eao_track_result* out,
-                       void* stream, const MotionArgs* mm) {
+                       void* stream, const MotionArgs* mm, const BowArgs* bw = nullptr) {
     EAO_REQUIRE(h && d_kps && d_desc && d_n && Tcw_prior && out && out->kp_map_point && out->kp_outlier, "null argument");
     for (int i = 0; i < 16; i++) EAO_REQUIRE(std::isfinite(Tcw_prior[i]), "the pose prior holds a NaN / Inf (entry %d)", i);
     EAO_REQUIRE(!d_depth || (depth_pitch >= width && width > 0 && height > 0), "bad depth image geometry");
     EAO_REQUIRE(((uintptr_t)d_desc & 15) == 0, "descriptors must be 16-byte aligned");
     eao::Range rg("track: frame -> frustum -> search -> pose");
     const eao_tracker_cfg& c = h->cfg;
-    const int C = h->cap, nMp = mm ? mm->n_last : h->nMp;      // the stage's queries: last-frame keypoints / local map points
+    const int C = h->cap, nMp = bw ? bw->n_kf : mm ? mm->n_last : h->nMp;      // the stage's queries: keyframe keypoints / last-frame keypoints / local map points
+    const bool plain = !mm && !bw;
     // The chain runs on the CALLER's stream itself: it is ordered behind whatever produced the inputs there (the extraction)
     // without an event hand-over to a private stream and back (~10 us each on this runtime).  The handle's own stream only
     // carries the local-map uploads, which eao_tracker_set_local_map waits for.
@@ -801,15 +881,66 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
             EAO_HIP(hipMemcpyAsync(h->lQ, h->pin, oA + 4 * (size_t)nMp, hipMemcpyHostToDevice, (hipStream_t)stream));
         }
     }
+    BowDev BD;
+    std::memset(&BD, 0, sizeof(BD));
+    if (bw) {
+        // ---- the node pairs both feature vectors hold (the merge of :176-263), their index lists, the keyframe's arrays: ONE staging block, one copy.  The tables
+        //      take the place of the motion-model stage's windows (25 bytes per keypoint at most against the 32 of a window).
+        EAO_REQUIRE(bw->n_kf >= 0 && bw->n_kf <= C, "at most max_keypoints (%d) keyframe keypoints", C);
+        EAO_REQUIRE(bw->n_kf == 0 || (bw->valid && bw->Xw && bw->kf_desc && bw->kf_angle), "null keyframe arrays");
+        eao_status fs;
+        if ((fs = check_feature_vector(bw->fv_kf, bw->n_kf, "keyframe")) || (fs = check_feature_vector(bw->fv_cur, C, "frame"))) return fs;
+        if (nMp > 0) {
+            const eao_feature_vector &K = *bw->fv_kf, &F = *bw->fv_cur;
+            int nPairs = 0, nKI = 0, nFI = 0;
+            for (int a = 0, b = 0; a < K.n_nodes && b < F.n_nodes;) {
+                if (K.node_id[a] == F.node_id[b]) { nPairs++; nKI += K.node_start[a + 1] - K.node_start[a]; nFI += F.node_start[b + 1] - F.node_start[b]; a++; b++; }
+                else if (K.node_id[a] < F.node_id[b]) a++; else b++;
+            }
+            const size_t oKI = 16 * (size_t)nPairs, oFI = oKI + 4 * (size_t)nKI, oV = oFI + 4 * (size_t)nFI;
+            EAO_REQUIRE(oV + (size_t)C <= sizeof(Query) * (size_t)C, "feature vectors beyond the tracker's capacity");
+            int* hp = reinterpret_cast<int*>(h->pin);
+            int* hk = reinterpret_cast<int*>(h->pin + oKI);
+            int* hf = reinterpret_cast<int*>(h->pin + oFI);
+            unsigned char* seen = h->pin + oV;      // (first as the "index already listed" table of either side, then the valid flags)
+            std::memset(seen, 0, (size_t)C);
+            int kk = 0, ff = 0, pp = 0;
+            for (int a = 0, b = 0; a < K.n_nodes && b < F.n_nodes;) {
+                if (K.node_id[a] == F.node_id[b]) {
+                    hp[4 * pp] = kk; hp[4 * pp + 1] = K.node_start[a + 1] - K.node_start[a]; hp[4 * pp + 2] = ff; hp[4 * pp + 3] = F.node_start[b + 1] - F.node_start[b]; pp++;
+                    for (int i = K.node_start[a]; i < K.node_start[a + 1]; i++) {
+                        const uint32_t v = K.index[i];
+                        EAO_REQUIRE(v < (uint32_t)nMp, "keyframe feature-vector index %u beyond its %d keypoints", v, nMp);
+                        EAO_REQUIRE(!(seen[v] & 1), "keyframe keypoint %u is listed twice", v);
+                        seen[v] |= 1; hk[kk++] = (int)v;
+                    }
+                    for (int i = F.node_start[b]; i < F.node_start[b + 1]; i++) {
+                        const uint32_t v = F.index[i];
+                        EAO_REQUIRE(v < (uint32_t)C, "frame feature-vector index %u beyond max_keypoints", v);
+                        EAO_REQUIRE(!(seen[v] & 2), "frame keypoint %u is listed twice", v);
+                        seen[v] |= 2; hf[ff++] = (int)v;
+                    }
+                    a++; b++;
+                } else if (K.node_id[a] < F.node_id[b]) a++; else b++;
+            }
+            std::memcpy(h->pin + oV, bw->valid, (size_t)nMp);
+            const size_t C2 = (size_t)C, oX = al256(sizeof(Query) * C2), oD = oX + al256(12 * C2), oA = oD + al256(32 * C2);
+            std::memcpy(h->pin + oX, bw->Xw, 12 * (size_t)nMp); std::memcpy(h->pin + oD, bw->kf_desc, 32 * (size_t)nMp); std::memcpy(h->pin + oA, bw->kf_angle, 4 * (size_t)nMp);
+            EAO_HIP(hipMemcpyAsync(h->lQ, h->pin, oA + 4 * (size_t)nMp, hipMemcpyHostToDevice, s));
+            unsigned char* dq = reinterpret_cast<unsigned char*>(h->lQ);
+            BD.pairs = reinterpret_cast<const int4*>(dq); BD.nPairs = nPairs; BD.kfIdx = reinterpret_cast<const int*>(dq + oKI); BD.fIdx = reinterpret_cast<const int*>(dq + oFI);
+            BD.valid = dq + oV; BD.kfDesc = reinterpret_cast<const uint4*>(h->lDesc); BD.fDesc = reinterpret_cast<const uint4*>(d_desc); BD.nnratio = nnratio;
+        }
+    }
     FrameArrays A;
     A.kx = h->kx; A.ky = h->ky; A.ang = h->ang; A.ur = h->ur; A.dz = h->dz; A.oct = h->oct; A.order = h->order; A.cellx = h->cellx; A.celly = h->celly;
-    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = mm ? h->lSkip : h->mSkip; A.cursor = h->cursor; A.colStart = h->colStart;
+    A.counts = h->counts; A.prior = prior_kp_map_point ? h->prior : nullptr; A.kpMp = h->kpMp; A.occ = h->occ; A.mSkip = plain ? h->mSkip : h->lSkip; A.cursor = h->cursor; A.colStart = h->colStart;
     int npow2 = 64;
     while (npow2 < C) npow2 <<= 1;
     const float invW = (float)c.grid_cols / (c.max_x - c.min_x), invH = (float)c.grid_rows / (c.max_y - c.min_y);   // src/Frame.cc:258-259
     eao::frame::FrustumArgs FA;
     std::memset(&FA, 0, sizeof(FA));
-    if (nMp > 0 && !mm) {
+    if (nMp > 0 && plain) {
         eao::frame::FrustumDevArgs F;
         F.n = nMp; F.Xw = h->mXw; F.normal = h->mNormal; F.minDist = h->mMin; F.maxDist = h->mMax; F.maxDistNum = h->mNum;
         std::memcpy(F.Tcw, Tcw_prior, 64);
@@ -826,10 +957,10 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     static const int envCount = getenv("EAO_TRACK_COUNTING_SORT") ? atoi(getenv("EAO_TRACK_COUNTING_SORT")) : 1;      // (A/B switch)
     const size_t cells = (size_t)c.grid_cols * c.grid_rows, countLds = (2 * (size_t)npow2 + cells + 1) * 4;
     const int countingSort = envCount && cells <= 8 * kFrameThreads && countLds <= 60 * 1024 ? 1 : 0;
-    hipLaunchKernelGGL(k_track_frame, dim3(1 + (nMp > 0 && !mm ? eao::cdiv(nMp, kFrameThreads) : 0)), dim3(kFrameThreads), countingSort ? countLds : (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth,
+    hipLaunchKernelGGL(k_track_frame, dim3(1 + (nMp > 0 && plain ? eao::cdiv(nMp, kFrameThreads) : 0)), dim3(kFrameThreads), countingSort ? countLds : (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth,
                        depth_pitch, width, height, c.mbf, c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A, FA, h->dbg, countingSort);
     eao_status st;
-    if (nMp > 0) {
+    if (nMp > 0 && !bw) {
         // the search windows are built by the candidate kernel itself (one wave per map point), which leaves them in h->q for the assignment
         eao::match::QueryBuild QB;
         QB.active = h->mActive; QB.skip = h->mSkip; QB.inView = h->inView; QB.projX = h->projX; QB.projY = h->projY; QB.projXR = h->projXR;
@@ -865,9 +996,11 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     ResultBlock RB{rCounts, rKpMp, rOutl, rUr, rDz, rInView};
     static const int envAll = getenv("EAO_TRACK_ALL_LISTERS") ? atoi(getenv("EAO_TRACK_ALL_LISTERS")) : 0;
     auto launch_assign = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, mm ? h->lQ : h->q, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
-                           mm ? INFINITY : nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, mm ? h->lXw : h->mXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
-                           h->inView, RB, h->dbg, envAll, h->lAng, h->ang, mm && mm->check_orientation ? (float)refc::HISTO_LENGTH / 360.0f : 0.f);
+        // the rotation histogram's factor: this fork's HISTO_LENGTH / 360 in SearchByProjection(Cur, Last) (src/ORBmatcher.cc:1337), 1 / HISTO_LENGTH in SearchByBoW (:171)
+        const float rotFactor = mm && mm->check_orientation ? (float)refc::HISTO_LENGTH / 360.0f : bw && bw->check_orientation ? 1.0f / refc::HISTO_LENGTH : 0.f;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, plain ? h->q : h->lQ, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
+                           mm ? INFINITY : nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, plain ? h->mXw : h->lXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
+                           h->inView, RB, h->dbg, envAll, h->lAng, h->ang, rotFactor, BD);
     };
     if (nMp <= 4 * kAssignThreads) launch_assign(k_track_assign_edges<4>);
     else if (nMp <= 8 * kAssignThreads) launch_assign(k_track_assign_edges<8>);
@@ -920,11 +1053,12 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     const int n = oc[0], nEdges = oc[2];
     EAO_REQUIRE(!(oc[4] & 1), "a map point in view has a predicted level outside the pyramid (upstream would index mvScaleFactors out of range)");
     EAO_REQUIRE(!(oc[4] & 2), "more than %d correspondences: beyond the chained PoseOptimization's capacity", edgeCap);
+    EAO_REQUIRE(!(oc[4] & 8), "the frame's feature vector names a keypoint beyond the %d the extractor left", oc[0]);
     out->n_keypoints = n; out->n_matches = oc[3]; out->n_edges = nEdges;
     std::memcpy(out->kp_map_point, p + ((unsigned char*)rKpMp - r), 4 * (size_t)C);
     if (out->kp_u_right) std::memcpy(out->kp_u_right, p + ((unsigned char*)rUr - r), 4 * (size_t)C);
     if (out->kp_depth) std::memcpy(out->kp_depth, p + ((unsigned char*)rDz - r), 4 * (size_t)C);
-    if (out->map_in_view && nMp > 0 && !mm) {
+    if (out->map_in_view && nMp > 0 && plain) {
         const unsigned char* iv = p + ((unsigned char*)rInView - r);
         for (int m = 0; m < nMp; m++) out->map_in_view[m] = (iv[m] && h->hActive[m]) ? 1 : 0;      // (an inactive point's arrays are stale)
     }
@@ -961,6 +1095,22 @@ eao_status eao_tracker_track_with_motion_model(eao_tracker* h, const eao_keypoin
     eao_status st = track_chain(h, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_cur, nullptr, nullptr, th, 0.f, out, stream, &mm);
     if (st) return st;
     if (discard_outliers) {      // "Discard outliers", src/Tracking.cc:2188-2207: the match is dropped, the flag cleared (n_inliers = what is left)
+        for (int k = 0; k < h->cap; k++)
+            if (out->kp_outlier[k]) { out->kp_map_point[k] = -1; out->kp_outlier[k] = 0; }
+    }
+    return EAO_OK;
+}
+
+eao_status eao_tracker_track_reference_keyframe(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                                const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_last,
+                                                int32_t n_kf, const uint8_t* valid, const float* Xw, const uint8_t* kf_desc, const float* kf_angle,
+                                                const eao_feature_vector* fv_kf, const eao_feature_vector* fv_cur, float nnratio, int32_t check_orientation,
+                                                int32_t discard_outliers, eao_track_result* out, void* stream) {
+    EAO_REQUIRE(h && n_kf >= 0 && std::isfinite(nnratio), "null / bad argument");
+    BowArgs bw{n_kf, valid, Xw, kf_desc, kf_angle, fv_kf, fv_cur, check_orientation ? 1 : 0};
+    eao_status st = track_chain(h, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_last, nullptr, nullptr, 0.f, nnratio, out, stream, nullptr, &bw);
+    if (st) return st;
+    if (discard_outliers) {      // "Discard outliers", src/Tracking.cc:1593-1612
         for (int k = 0; k < h->cap; k++)
             if (out->kp_outlier[k]) { out->kp_map_point[k] = -1; out->kp_outlier[k] = 0; }
     }

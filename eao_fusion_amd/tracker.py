@@ -30,6 +30,8 @@ def _bind(L):
     L.eao_tracker_set_local_map.argtypes = [_P, C.POINTER(MapPoints)]
     L.eao_tracker_track_local_map.restype = _I
     L.eao_tracker_track_local_map.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _F, C.POINTER(TrackResult), _P]
+    L.eao_tracker_track_reference_keyframe.restype = _I
+    L.eao_tracker_track_reference_keyframe.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _F, _I, _I, C.POINTER(TrackResult), _P]
     L.eao_tracker_track_with_motion_model.restype = _I
     L.eao_tracker_track_with_motion_model.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _F, _I, _I, _I, C.POINTER(TrackResult), _P]
     return L
@@ -86,6 +88,31 @@ class Tracker:
         n = R.n_keypoints
         return dict(Tcw=np.array(R.Tcw, np.float32).reshape(4, 4), n_keypoints=n, n_matches=R.n_matches, n_edges=R.n_edges, n_inliers=R.n_inliers,
                     kp_map_point=kpmp[:n], kp_outlier=outl[:n], u_right=ur[:n], depth=dz[:n], map_in_view=inview[:self.n_mp])
+
+    def track_reference_keyframe(self, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_last, kf, fv_cur, nnratio=0.7, check_orientation=True,
+                                 discard_outliers=True, stream=0):
+        """Tracking::TrackReferenceKeyFrame's data path (src/Tracking.cc:1568-1631).  kf: dict(valid, Xw, descriptors, angle, fv) per keyframe keypoint, fv /
+        fv_cur: {node id: [keypoint indices]} (DBoW2::FeatureVector).  kp_map_point holds KEYFRAME keypoint indices."""
+        from .search import feature_vector
+        Tl = np.ascontiguousarray(Tcw_last, np.float32).reshape(4, 4)
+        valid = np.ascontiguousarray(kf["valid"], np.uint8)
+        Xw = np.ascontiguousarray(kf["Xw"], np.float32)
+        desc = np.ascontiguousarray(kf["descriptors"], np.uint8)
+        ang = np.ascontiguousarray(kf["angle"], np.float32)
+        f1, keep1 = feature_vector(kf["fv"])
+        f2, keep2 = feature_vector(fv_cur)
+        kpmp = np.full(self.cap, -1, np.int32)
+        outl = np.zeros(self.cap, np.uint8)
+        ur = np.zeros(self.cap, np.float32)
+        dz = np.zeros(self.cap, np.float32)
+        R = TrackResult()
+        R.kp_map_point, R.kp_outlier, R.kp_u_right, R.kp_depth = _lib.ptr(kpmp), _lib.ptr(outl), _lib.ptr(ur), _lib.ptr(dz)
+        _lib.check(self._L.eao_tracker_track_reference_keyframe(self._h, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, _lib.ptr(Tl), len(valid), _lib.ptr(valid),
+                                                               _lib.ptr(Xw), _lib.ptr(desc), _lib.ptr(ang), C.byref(f1), C.byref(f2), nnratio,
+                                                               1 if check_orientation else 0, 1 if discard_outliers else 0, C.byref(R), stream))
+        n = R.n_keypoints
+        return dict(Tcw=np.array(R.Tcw, np.float32).reshape(4, 4), n_keypoints=n, n_matches=R.n_matches, n_edges=R.n_edges, n_inliers=R.n_inliers,
+                    kp_map_point=kpmp[:n], kp_outlier=outl[:n], u_right=ur[:n], depth=dz[:n])
 
     def track_with_motion_model(self, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_cur, last, th, mono=False, check_orientation=True,
                                 discard_outliers=True, stream=0):

@@ -557,6 +557,24 @@ eao_status eao_tracker_track_with_motion_model(eao_tracker* h, const eao_keypoin
                                                const int32_t* last_octave, const float* last_angle, float th, int32_t mono, int32_t check_orientation,
                                                int32_t discard_outliers, eao_track_result* out, void* stream);
 
+/* Tracking::TrackReferenceKeyFrame's data path (reference src/Tracking.cc:1568-1631) on the same chain: the frame set-up as above,
+ * ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) (src/ORBmatcher.cc:159-288: ORBmatcher(0.7, true) at :1574, rotation-histogram factor
+ * 1 / HISTO_LENGTH :171), Optimizer::PoseOptimization from the last frame's pose (:1584-1590), and -- when discard_outliers != 0 -- the "Discard outliers" loop
+ * (:1593-1612); one copy back.  The reference keyframe travels as host arrays per keyframe keypoint i (n_kf <= max_keypoints entries): valid[i] != 0 where
+ * GetMapPointMatches()[i] != NULL && !isBad(); Xw = GetWorldPos(); kf_desc = pKF->mDescriptors.row(i); kf_angle = pKF->mvKeysUn[i].angle.  fv_kf = pKF->mFeatVec,
+ * fv_cur = mCurrentFrame.mFeatVec: the frame's own vector is what Frame::ComputeBoW (:1571) makes of its descriptors on the host -- DBoW2's vocabulary tree is
+ * not part of this library, so this stage costs the descriptors one trip to the host before the call.  A keypoint index lies in ONE node (DBoW2 files a feature
+ * under its single ancestor at levelsup); a vector that lists an index twice, out of range, or whose node ids do not ascend fails with EAO_ERR_INVALID before
+ * any kernel runs, an index of fv_cur beyond the *d_n keypoints the extractor left fails after the chain.  Tcw_last: mLastFrame.mTcw, 16 floats row-major, finite.
+ * Result as for eao_tracker_track_with_motion_model, with kp_map_point[k] = the KEYFRAME KEYPOINT INDEX whose map point frame keypoint k took, or -1, and n_matches =
+ * SearchByBoW's return value (what upstream tests against 15 / 10).  Same results as eao_compute_stereo_from_rgbd -> eao_search_by_bow(mode 0) ->
+ * eao_pose_optimization on the same data. */
+eao_status eao_tracker_track_reference_keyframe(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                                                const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_last,
+                                                int32_t n_kf, const uint8_t* valid, const float* Xw, const uint8_t* kf_desc, const float* kf_angle,
+                                                const eao_feature_vector* fv_kf, const eao_feature_vector* fv_cur, float nnratio, int32_t check_orientation,
+                                                int32_t discard_outliers, eao_track_result* out, void* stream);
+
 /* The value of EAO_ABI_VERSION the library was built with.  Bumped whenever an entry point's parameter list or a struct's layout changes (round 3
  * changed eao_tracker_track_local_map and eao_track_result in place); a caller compiled against another version must not call into the library.
  * Result structs are zero-initialised by the caller (`eao_track_result R = {0};`) before their array pointers are set: a pointer member the

@@ -5,6 +5,7 @@
 //   eaofusion::DeviceTracker trk(frame, maxKeypoints, maxMapPoints);      // once per camera (Frame statics: fx .. mbf, bounds, scale tables)
 //   trk.SetLocalMap(mvpLocalMapPoints);                                    // when Tracking::UpdateLocalMap changed the local map
 //   int nm = trk.TrackWithMotionModel(mCurrentFrame, mLastFrame, d_kps, d_desc, d_n, d_depth, depthPitch, w, h, th, bMono, stream, &nmatchesMap);   // round 4
+//   int nMap = trk.TrackReferenceKeyFrame(mCurrentFrame, mpReferenceKF, mLastFrame.mTcw, d_kps, d_desc, d_n, d_depth, depthPitch, w, h, stream, &nSearch);      // round 4
 //   int nInliers = trk.TrackLocalMap(mCurrentFrame, d_kps, d_desc, d_n, d_depth, depthPitch, th, stream);
 //
 // TrackLocalMap replaces, for a distortion-free RGB-D / monocular camera, the sequence Frame::ComputeStereoFromRGBD +
@@ -16,6 +17,7 @@
 #ifndef EAOFUSION_DEVICE_TRACKER_H
 #define EAOFUSION_DEVICE_TRACKER_H
 
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -202,7 +204,81 @@ public:
         return nmatches;
     }
 
+    // Tracking::TrackReferenceKeyFrame's data path (src/Tracking.cc:1568-1631) for the frame the extractor just left on the device: the part of the Frame
+    // constructor after the extractor, ORBmatcher(0.7, true).SearchByBoW(mpReferenceKF, Cur, vpMapPointMatches), Cur.SetPose(mLastFrame.mTcw),
+    // Optimizer::PoseOptimization(&Cur) and the "Discard outliers" loop, one copy back.  The caller has run Cur.ComputeBoW() (:1571: DBoW2 works on the host
+    // copy of the descriptors) and passes the last frame's pose.  Returns nmatchesMap (:1630 compares it with 10); nSearch = SearchByBoW's return value (:1580
+    // compares it with 10 -- below it the caller takes upstream's "return false" and ignores what this call filled in).  As with TrackWithMotionModel, what this
+    // fork does between the search and the optimisation (AssociatePlanesByBoundary, :1587) sees Cur.mvpMapPoints only after the call.
+    template <class KeyFrameT, class FrameT>
+    int TrackReferenceKeyFrame(FrameT& Cur, KeyFrameT* pRefKF, const cv::Mat& lastTcw, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
+                               const float* d_depth, int depthPitch, int width, int height, void* stream, int* nSearch = nullptr, float nnratio = 0.7f) {
+        using MapPointT = typename std::remove_pointer<typename std::decay<decltype(Cur.mvpMapPoints[0])>::type>::type;
+        const std::vector<MapPointT*> vpKF = pRefKF->GetMapPointMatches();
+        const size_t nk = vpKF.size();
+        if (Cur.N > cap_ || (int)nk > cap_) throw std::runtime_error("DeviceTracker: more keypoints than maxKeypoints");
+        std::vector<uint8_t> valid(nk ? nk : 1, 0), desc(32 * (nk ? nk : 1), 0);
+        std::vector<float> Xw(3 * (nk ? nk : 1), 0.f), ang(nk ? nk : 1, 0.f);
+        for (size_t i = 0; i < nk; i++) {
+            ang[i] = pRefKF->mvKeysUn[i].angle;
+            std::memcpy(&desc[32 * i], pRefKF->mDescriptors.ptr(i), 32);
+            MapPointT* pMP = vpKF[i];
+            if (!pMP || pMP->isBad()) continue;
+            valid[i] = 1;
+            const cv::Mat P = pMP->GetWorldPos();
+            for (int a = 0; a < 3; a++) Xw[3 * i + a] = P.template at<float>(a);
+        }
+        FeatVec fk, fc;
+        const eao_feature_vector fvK = flatten(pRefKF->mFeatVec, fk), fvC = flatten(Cur.mFeatVec, fc);
+        float Tl[16];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) Tl[4 * r + c] = lastTcw.template at<float>(r, c);
+        std::vector<int32_t> kpMp(cap_, -1);
+        std::vector<uint8_t> outl(cap_, 0);
+        std::vector<float> ur(cap_), dz(cap_);
+        eao_track_result R = {};
+        R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data();
+        detail::check(eao_tracker_track_reference_keyframe(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, Tl, (int)nk, valid.data(), Xw.data(), desc.data(),
+                                                           ang.data(), &fvK, &fvC, nnratio, 1, /* discard on this side */ 0, &R, stream),
+                      "eao_tracker_track_reference_keyframe");
+        if (nSearch) *nSearch = R.n_matches;
+        Cur.mvuRight.assign(ur.begin(), ur.begin() + R.n_keypoints);
+        Cur.mvDepth.assign(dz.begin(), dz.begin() + R.n_keypoints);
+        cv::Mat pose(4, 4, CV_32F);
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[4 * r + c];
+        Cur.SetPose(pose);
+        int nMap = 0;
+        for (int k = 0; k < R.n_keypoints; k++) {      // "Discard outliers", src/Tracking.cc:1593-1612
+            Cur.mvbOutlier[k] = false;
+            Cur.mvpMapPoints[k] = static_cast<MapPointT*>(NULL);
+            if (kpMp[k] < 0) continue;
+            MapPointT* pMP = vpKF[kpMp[k]];
+            if (outl[k]) {
+                pMP->mbTrackInView = false;
+                pMP->mnLastFrameSeen = Cur.mnId;
+            } else {
+                Cur.mvpMapPoints[k] = pMP;
+                if (pMP->Observations() > 0) nMap++;
+            }
+        }
+        return nMap;
+    }
+
 private:
+    struct FeatVec { std::vector<uint32_t> id, index; std::vector<int32_t> start; };
+    template <class FeatVecT>
+    static eao_feature_vector flatten(const FeatVecT& fv, FeatVec& a) {      // DBoW2::FeatureVector = std::map<node id, std::vector<keypoint index>>
+        a.id.clear(); a.index.clear(); a.start.assign(1, 0);
+        for (typename FeatVecT::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+            a.id.push_back((uint32_t)it->first);
+            for (size_t k = 0; k < it->second.size(); k++) a.index.push_back((uint32_t)it->second[k]);
+            a.start.push_back((int32_t)a.index.size());
+        }
+        eao_feature_vector f;
+        f.n_nodes = (int32_t)a.id.size(); f.node_id = a.id.data(); f.node_start = a.start.data(); f.index = a.index.data();
+        return f;
+    }
     eao_tracker* h_ = nullptr;
     int cap_, capMp_;
     std::vector<void*> map_;

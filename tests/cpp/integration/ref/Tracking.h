@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "Frame.h"
+#include "KeyFrame.h"
 #include "MapPoint.h"
 #include "ORBmatcher.h"
 #include "Optimizer.h"
@@ -23,7 +24,11 @@ public:
     // ... and src/Tracking_TrackWithMotionModel.inc (round 4): the search + pose optimisation + outlier discard of Tracking::TrackWithMotionModel
     bool TrackWithMotionModelOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch, int width,
                                       int height, void* stream, const cv::Mat& predictedPose);
+    // ... and src/Tracking_TrackReferenceKeyFrame.inc (round 4): everything of Tracking::TrackReferenceKeyFrame behind mCurrentFrame.ComputeBoW()
+    bool TrackReferenceKeyFrameOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch, int width,
+                                        int height, void* stream);
     Frame mLastFrame;
+    KeyFrame* mpReferenceKF = nullptr;
     eaofusion::DeviceTracker* mpDeviceTracker = nullptr;
     int mSensor = System::RGBD;
     Frame mCurrentFrame;

@@ -53,6 +53,10 @@ bool Tracking::TrackWithMotionModelOnDevice(const eao_keypoint* d_kps, const uin
     (void)nmatches;
     return nmatchesMap >= 10;      // :2230
 }
+bool Tracking::TrackReferenceKeyFrameOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch,
+                                              int width, int height, void* stream) {
+#include "Tracking_TrackReferenceKeyFrame.inc"
+}
 }  // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
 #include <vector>
 
 #include <eaofusion/DeviceTracker.h>
@@ -42,7 +44,16 @@ struct Frame {
     std::vector<float> mvuRight, mvDepth;
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<bool> mvbOutlier;
+    std::map<unsigned, std::vector<unsigned> > mFeatVec;      // DBoW2::FeatureVector
     void SetPose(cv::Mat T) { mTcw = T.clone(); }
+};
+
+struct KeyFrame {      // what TrackReferenceKeyFrame reads of the reference keyframe
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<cv::KeyPoint> mvKeysUn;
+    cv::Mat mDescriptors;
+    std::map<unsigned, std::vector<unsigned> > mFeatVec;
+    std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
 };
 float Frame::fx = 535.4f, Frame::fy = 539.2f, Frame::cx = 320.1f, Frame::cy = 247.6f;
 float Frame::mnMinX = 0.f, Frame::mnMaxX = 640.f, Frame::mnMinY = 0.f, Frame::mnMaxY = 480.f;
@@ -234,6 +245,74 @@ int main() {
         fprintf(stderr, "motion model: %d matches after the search, %d kept, %d with observations, %d disagreements\n", nSearch, kept, withObs, mmBad);
         bad += mmBad;
         pts[seen[4]].nObs = 1;
+    }
+    // ---- TrackReferenceKeyFrame (round 4): the reference keyframe saw the same points (descriptors a few bits off, its own keypoint order, one point bad, one
+    //      keypoint without a point); both feature vectors file a keypoint under (map point mod 37), a tenth of them elsewhere.  Adapter vs a direct C-ABI call.
+    {
+        Frame Cur = F2;
+        Cur.mvKeysUn = Cur.mvKeys; Cur.mnId = 11;
+        Cur.mvpMapPoints.assign(Cur.N, nullptr); Cur.mvbOutlier.assign(Cur.N, false);
+        std::vector<eao_keypoint> ck(Cur.N);
+        for (int k = 0; k < Cur.N; k++) std::memcpy(&ck[k], &Cur.mvKeys[k], sizeof(eao_keypoint));
+        HIPCHK(hipMemcpy(d_kps, ck.data(), (size_t)Cur.N * sizeof(eao_keypoint), hipMemcpyHostToDevice));
+        KeyFrame KF;
+        const int nk = Cur.N;
+        KF.mDescriptors = cv::Mat(nk, 32, CV_8U);
+        for (int i = 0; i < nk; i++) {
+            const int k = (int)(((long long)i * 11 + 3) % nk);      // keyframe keypoint i observes what frame keypoint k observes (its own keypoint order)
+            MapPoint* q = &pts[seen[k]];
+            KF.mvpMapPoints.push_back(i == 6 ? nullptr : q);
+            cv::KeyPoint kp = Cur.mvKeys[k]; kp.angle = std::fmod(kp.angle + 351.f, 360.f);
+            KF.mvKeysUn.push_back(kp);
+            for (int b = 0; b < 32; b++) KF.mDescriptors.ptr(i)[b] = (unsigned char)(q->desc.at<unsigned char>(0, b) ^ (rnd() < 0.08 ? 1 << (int)(rnd() * 8) : 0));
+            KF.mFeatVec[(unsigned)(rnd() < 0.1 ? (int)(rnd() * 37) : seen[k] % 37)].push_back((unsigned)i);
+        }
+        for (int k = 0; k < Cur.N; k++) Cur.mFeatVec[(unsigned)(rnd() < 0.1 ? (int)(rnd() * 37) : seen[k] % 37)].push_back((unsigned)k);
+        pts[seen[10]].nObs = 0;
+        cv::Mat lastT = F2.mTcw.clone(); lastT.at<float>(1, 3) += 0.006f;
+        int nSearch = -1;
+        const int nMap = trk.TrackReferenceKeyFrame(Cur, &KF, lastT, d_kps, d_desc, d_n, d_depth, W, W, H, nullptr, &nSearch);
+        // direct call, arrays by hand, the library's own discard
+        std::vector<uint8_t> valid(nk, 0), kdesc(32 * (size_t)nk, 0), o2(cap, 0);
+        std::vector<float> kX(3 * (size_t)nk, 0.f), kang(nk);
+        std::vector<int32_t> k2(cap, -1);
+        for (int i = 0; i < nk; i++) {
+            kang[i] = KF.mvKeysUn[i].angle;
+            memcpy(&kdesc[32 * (size_t)i], KF.mDescriptors.ptr(i), 32);
+            MapPoint* q = KF.mvpMapPoints[i];
+            if (!q || q->bad) continue;
+            valid[i] = 1;
+            for (int a = 0; a < 3; a++) kX[3 * i + a] = q->pos.at<float>(a);
+        }
+        auto flat = [](const std::map<unsigned, std::vector<unsigned> >& fv, std::vector<uint32_t>& id, std::vector<int32_t>& st, std::vector<uint32_t>& ix) {
+            st.assign(1, 0);
+            for (const auto& kv : fv) { id.push_back(kv.first); for (unsigned v : kv.second) ix.push_back(v); st.push_back((int32_t)ix.size()); }
+            eao_feature_vector f; f.n_nodes = (int32_t)id.size(); f.node_id = id.data(); f.node_start = st.data(); f.index = ix.data();
+            return f;
+        };
+        std::vector<uint32_t> idK, ixK, idC, ixC; std::vector<int32_t> stK, stC;
+        const eao_feature_vector fvK = flat(KF.mFeatVec, idK, stK, ixK), fvC = flat(Cur.mFeatVec, idC, stC, ixC);
+        float Tl[16];
+        for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) Tl[4 * r + k] = lastT.at<float>(r, k);
+        eao_track_result R4 = {};
+        std::vector<float> ur4(cap), dz4(cap);
+        R4.kp_map_point = k2.data(); R4.kp_outlier = o2.data(); R4.kp_u_right = ur4.data(); R4.kp_depth = dz4.data();
+        if (eao_tracker_track_reference_keyframe(h, d_kps, d_desc, d_n, d_depth, W, W, H, Tl, nk, valid.data(), kX.data(), kdesc.data(), kang.data(), &fvK, &fvC, 0.7f, 1, 1, &R4,
+                                                 nullptr) != EAO_OK) { fprintf(stderr, "%s\n", eao_last_error()); return 2; }
+        int kept = 0, withObs = 0, rkBad = 0;
+        for (int k = 0; k < Cur.N; k++) {
+            MapPoint* want = k2[k] >= 0 ? KF.mvpMapPoints[k2[k]] : nullptr;
+            if (Cur.mvpMapPoints[k] != want) rkBad++;
+            if (Cur.mvbOutlier[k]) rkBad++;
+            if (Cur.mvuRight[k] != ur4[k] || Cur.mvDepth[k] != dz4[k]) rkBad++;
+            if (want) { kept++; withObs += want->Observations() > 0 ? 1 : 0; }
+        }
+        for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) if (Cur.mTcw.at<float>(r, k) != R4.Tcw[4 * r + k]) rkBad++;
+        if (kept != R4.n_inliers || nMap != withObs || nSearch != R4.n_matches) { fprintf(stderr, "reference keyframe counts: kept %d / %d, map %d / %d, search %d / %d\n", kept, R4.n_inliers, nMap, withObs, nSearch, R4.n_matches); rkBad++; }
+        if (kept < 100) { fprintf(stderr, "reference keyframe: only %d matches kept\n", kept); rkBad++; }
+        fprintf(stderr, "reference keyframe: %d matches after the search, %d kept, %d with observations, %d disagreements\n", nSearch, kept, withObs, rkBad);
+        bad += rkBad;
+        pts[seen[10]].nObs = 1;
     }
     eao_tracker_destroy(h);
     fprintf(stderr, "%d keypoints, %d with a map point, %d inliers, %d disagreements\n", F.N, matched, nIn, bad);
