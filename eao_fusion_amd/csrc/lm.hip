@@ -4724,7 +4724,19 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     const int hw = (int)std::thread::hardware_concurrency();
     // (set-up threads make no HIP call any more -- packing and counting only -- so they scale with the host's cores)
     const int nThreads = std::max(1, std::min(n, envThreads > 0 ? envThreads : std::min(16, std::max(1, hw / 2))));
-    const int G = std::max(1, std::min(std::min(envGroups > 0 ? envGroups : kBatchGroups, nThreads), n / kBatchGroupMin));
+    // Groups hold WHOLE ROWS of eight windows where the batch has them (BA_WIN pins a window to an XCD row by row, and deals an incomplete row over all eight):
+    // 25 windows as 8 + 8 + 9 load every XCD with 3.125 windows, as 6 + 6 + 6 + 7 the fullest one with 3.5 (2.6 against 2.8 ms per call).
+    const int fullRows = n / 8, rest = n - 8 * fullRows;
+    const bool rowGroups = fullRows >= 1 && !getenv("EAO_BA_BATCH_EVEN");      // (A/B switch: the even split of rounds 2-3)
+    const bool restGroup = rowGroups && rest >= kBatchGroupMin;                // an incomplete row large enough to be a group of its own (else it joins the last group)
+    const int gWant = std::min(envGroups > 0 ? envGroups : kBatchGroups, nThreads);
+    const int G = std::max(1, rowGroups ? std::min(gWant, fullRows + (restGroup ? 1 : 0)) : std::min(gWant, n / kBatchGroupMin));
+    std::vector<int> gStart(G + 1, n);
+    for (int g = 0; g < G; g++) {
+        if (!rowGroups) gStart[g] = (int)((long long)n * g / G);
+        else if (restGroup && G > 1) gStart[g] = g == G - 1 ? 8 * fullRows : 8 * (int)((long long)fullRows * g / (G - 1));
+        else gStart[g] = 8 * (int)((long long)fullRows * g / G);
+    }
     while ((int)B.side.size() < G - 1) {
         hipStream_t q; hipEvent_t e;
         EAO_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
@@ -4743,7 +4755,7 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     // group is complete after one round; each group's leader then enqueues its chain while the workers carry on
     std::vector<std::atomic<int>> prepared(G);
     for (auto& a : prepared) a.store(0);
-    auto groupOfWindow = [&](int w) { int g = (int)(((long long)w * G) / n); while ((long long)n * (g + 1) / G <= w) g++; while ((long long)n * g / G > w) g--; return g; };
+    auto groupOfWindow = [&](int w) { int g = 0; while (gStart[g + 1] <= w) g++; return g; };
     auto streamOf = [&](int g) { return g == 0 ? B.stream : B.side[g - 1]; };
     auto worker = [&](int t) {
         (void)hipSetDevice(dev);
@@ -4756,7 +4768,7 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     };
     auto groupWork = [&](int g) {
         (void)hipSetDevice(dev);
-        const int w0 = (int)((long long)n * g / G), w1 = (int)((long long)n * (g + 1) / G);
+        const int w0 = gStart[g], w1 = gStart[g + 1];
         hipStream_t sg = streamOf(g);
         while (prepared[g].load(std::memory_order_acquire) < w1 - w0) std::this_thread::yield();    // (the workers above)
         msPrep[g] = since(tp0);
