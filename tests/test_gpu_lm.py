@@ -387,6 +387,21 @@ def test_local_ba_batch_equals_single_calls(gpu):
     assert _same_result(one[0], single[0])
 
 
+@pytest.mark.parametrize("n", [2, 7, 8, 9, 12, 17, 21])
+def test_local_ba_batch_placement_does_not_change_results(gpu, n, monkeypatch):
+    """Round 4: a batch's windows are pinned to XCDs row by row, the windows of an incomplete row of eight are dealt over all eight XCDs (BA_WIN), and the
+    window groups hold whole rows (8 + 8 + 9 for 25 windows).  None of it may change a bit: every batch size around the row boundaries against the even
+    split of rounds 2-3 (EAO_BA_BATCH_EVEN=1), one group, and a window's own single call (within the LM bound: a single window runs other kernels)."""
+    probs = [synth.synth_ba(n_free=4 + (w % 3), n_fixed=2, n_points=150 + 10 * (w % 5), seed=6400 + w) for w in range(n)]
+    rows = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
+    monkeypatch.setenv("EAO_BA_BATCH_EVEN", "1")
+    even = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
+    monkeypatch.delenv("EAO_BA_BATCH_EVEN")
+    assert all(_same_result(a, b) for a, b in zip(rows, even)), "row groups and the even split differ"
+    for w in (0, n - 1):
+        _close_result(rows[w], gpu.Optimizer.LocalBundleAdjustment(probs[w]), probs[w])
+
+
 def test_local_ba_batch_parity_configs4(gpu, oracle):
     """The 25 windows of BASELINE configs[4] (seeds 6000 + w) in one call; windows 0 and 24 against the fp64 oracle."""
     probs = [synth.synth_ba(seed=6000 + w) for w in range(25)]
