@@ -270,7 +270,15 @@ __device__ __forceinline__ void spread_b_rows(unsigned char* sB, const uint4 v, 
     }
 }
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { unsigned d; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ void hm_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// LDS hand-over between the lanes of ONE wave (its LDS operations execute in order: nothing to wait for).  The empty asm statements with a memory clobber keep the
+// COMPILER from moving LDS accesses across the point: the two sides park and fetch through different types (8-byte pairs in, 16-byte rows out), which do not alias in
+// its view, and a wavefront-scope fence lowers to no instruction at all (round 4: a hand-over of this shape in csrc/lm.hip was reordered by the scheduler).
+__device__ __forceinline__ void hm_wave_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // full matrix: grid (column blocks, row blocks, pairs); nb % 8 == 0 and a 16-byte aligned D (else the popcount kernels above)
 __global__ __launch_bounds__(256, 3) void k_hamming_matrix_mfma(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,

@@ -2741,7 +2741,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? EAO_PAIR_OCC : 1) void k_ba_schu
         }
         return f;
     };
-    auto wave_fence = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    auto wave_fence = [] { asm volatile("" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };      // (the clobbers: see hm_wave_sync, csrc/hamming.hip)
     double acc[4] = {0, 0, 0, 0};
     if (wave < nGall) {
         Fetch cur = fetch_data(fix_rec(recRaw, wave));

@@ -435,7 +435,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
                 bool op = t < nT;
                 const int m = op ? tM[t] : 0, st = op ? tSt[t] : 0, cn = op ? tCn[t] : 0;
                 int res = -1, more = 0;
-                auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+                auto wave_sync = [] { asm volatile("" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
                 while (__any(op)) {
                     more++;
                     tag--;
