@@ -349,6 +349,59 @@ public:
         return nFused;
     }
 
+    // Round 4 -- the points of LocalMapping::SearchInNeighbors against ALL its target keyframes in one library call (src/LocalMapping.cc:484-494 / :509-519 call
+    // Fuse once per target): the searches of every target run up front on the map as it is, then the targets are applied IN ORDER exactly as the single calls apply
+    // them -- a point that an earlier target's fusion made bad, or put into the keyframe at hand, is skipped as upstream's loop head would skip it (:851-861; a
+    // point's search does not depend on any other point's, so skipping is all that an earlier fusion can change).  Returns the sum of the targets' nFused; the
+    // per-target counts in *nFusedPerKF when given.  One camera for all targets (the batch entry point takes fx .. mbf once), as in the reference.
+    template <class KeyFrameT, class MapPointT>
+    int FuseBatch(const std::vector<KeyFrameT*>& vpTargetKFs, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0, std::vector<int>* nFusedPerKF = nullptr) {
+        const size_t nk = vpTargetKFs.size(), np = vpMapPoints.size();
+        if (nFusedPerKF) nFusedPerKF->assign(nk, 0);
+        if (!nk || !np) return 0;
+        PointArrays pa;
+        const eao_map_points mp = gather(vpMapPoints, pa, [&](MapPointT* p) { return p && !p->isBad(); });
+        std::vector<FrameArrays> fa(nk);
+        std::vector<eao_frame_view> v(nk);
+        std::vector<const eao_frame_view*> pv(nk);
+        std::vector<float> poses(15 * nk);
+        for (size_t q = 0; q < nk; q++) {
+            KeyFrameT* pKF = vpTargetKFs[q];
+            v[q] = kfview(*pKF, fa[q]); pv[q] = &v[q];
+            const cv::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
+            float* pose = &poses[15 * q];
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pose[r * 3 + c] = Rcw.template at<float>(r, c); pose[9 + r] = tcw.template at<float>(r); pose[12 + r] = Ow.template at<float>(r); }
+        }
+        KeyFrameT* k0 = vpTargetKFs[0];
+        std::vector<int32_t> best(nk * np, -1), nf(nk, 0);
+        check(eao_fuse_search_batch((int)nk, pv.data(), 0, poses.data(), k0->fx, k0->fy, k0->cx, k0->cy, k0->mbf, &mp, th, best.data(), nf.data()), "eao_fuse_search_batch");
+        int total = 0;
+        for (size_t q = 0; q < nk; q++) {
+            KeyFrameT* pKF = vpTargetKFs[q];
+            int nFused = 0;
+            for (size_t i = 0; i < np; i++) {
+                const int k = best[q * np + i];
+                if (k < 0) continue;
+                MapPointT* pMP = vpMapPoints[i];
+                if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+                MapPointT* pMPinKF = pKF->GetMapPoint(k);
+                if (pMPinKF) {
+                    if (!pMPinKF->isBad()) {
+                        if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                        else pMPinKF->Replace(pMP);
+                    }
+                } else {
+                    pMP->AddObservation(pKF, k);
+                    pKF->AddMapPoint(pMP, k);
+                }
+                nFused++;
+            }
+            if (nFusedPerKF) (*nFusedPerKF)[q] = nFused;
+            total += nFused;
+        }
+        return total;
+    }
+
     // reference :977-1100 (LoopClosing::SearchAndFuse)
     template <class KeyFrameT, class MapPointT>
     int Fuse(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints, float th, std::vector<MapPointT*>& vpReplacePoint) {

@@ -244,6 +244,55 @@ int main(int argc, char** argv) {
         for (auto& p : store) if (p.replacedBy) replaced++;
         wr(out, &n, 1); wr(out, &replaced, 1); wr(out, &addedN, 1);
     }
+    // 9b. FuseBatch (round 4): the same candidates against three target keyframes (K2, K1, K2 again -- the third target meets what the first one changed) in one
+    //     library call, against three Fuse calls in a row on an identical second world: per-target counts, every keyframe slot, every replacement
+    {
+        struct World {
+            std::vector<MapPoint> own, fresh;      // the keyframes' own points (copies of `store`) and the candidates (same geometry, in no keyframe)
+            KeyFrame T[3];
+            std::vector<MapPoint*> cand;
+        };
+        auto build = [&](World& w) {
+            w.own.assign(store.begin(), store.end());
+            w.fresh.assign(store.begin(), store.end());
+            for (auto& p : w.own) { p.obs.clear(); p.replacedBy = nullptr; }
+            w.T[0] = K2; w.T[1] = K1; w.T[2] = K2;
+            for (int q = 0; q < 3; q++) {
+                w.T[q].added.clear();
+                for (int k = 0; k < w.T[q].N; k++) {
+                    MapPoint*& p = w.T[q].mvpMapPoints[k];
+                    if (p) { p = &w.own[p - store.data()]; if (q != 2 || (k % 3)) p->AddObservation(&w.T[q], k); else p = nullptr; }      // (the third target starts with a third of its slots empty)
+                }
+            }
+            w.cand.resize(np);
+            static KeyFrame elsewhere[4];      // every second candidate is seen by four other keyframes: it wins the Observations() comparison and survives its fusions
+            for (int i = 0; i < np; i++) {
+                w.fresh[i].obs.clear(); w.fresh[i].replacedBy = nullptr; w.fresh[i].bad = !pact[i]; w.cand[i] = &w.fresh[i];
+                if (i % 2) for (int z = 0; z < 4; z++) w.fresh[i].AddObservation(&elsewhere[z], (size_t)i);
+            }
+        };
+        World wa, wb;
+        build(wa); build(wb);
+        int nSeq[3], total = 0;
+        for (int q = 0; q < 3; q++) { nSeq[q] = m75.Fuse(&wa.T[q], wa.cand, 3.0f); total += nSeq[q]; }
+        std::vector<KeyFrame*> targets = {&wb.T[0], &wb.T[1], &wb.T[2]};
+        std::vector<int> nBatch;
+        const int totalB = m75.FuseBatch(targets, wb.cand, 3.0f, &nBatch);
+        auto id = [&](World& w, MapPoint* p) -> long { if (!p) return -1; if (p >= w.own.data() && p < w.own.data() + w.own.size()) return p - w.own.data(); return 100000 + (p - w.fresh.data()); };
+        int diff = totalB != total;
+        for (int q = 0; q < 3; q++) {
+            if (nBatch[q] != nSeq[q]) diff++;
+            for (int k = 0; k < wa.T[q].N; k++) if (id(wa, wa.T[q].mvpMapPoints[k]) != id(wb, wb.T[q].mvpMapPoints[k])) diff++;
+            if (wa.T[q].added.size() != wb.T[q].added.size()) diff++;
+        }
+        for (int i = 0; i < np; i++) {
+            if (wa.fresh[i].bad != wb.fresh[i].bad || id(wa, wa.fresh[i].replacedBy) != id(wb, wb.fresh[i].replacedBy)) diff++;
+            if (wa.own[i].bad != wb.own[i].bad || id(wa, wa.own[i].replacedBy) != id(wb, wb.own[i].replacedBy)) diff++;
+            if (wa.fresh[i].obs.size() != wb.fresh[i].obs.size()) diff++;
+        }
+        if (diff || total < 100 || nSeq[2] == 0) { std::fprintf(stderr, "FuseBatch: %d differences from three Fuse calls (fused %d / %d: %d %d %d)\n", diff, totalB, total, nSeq[0], nSeq[1], nSeq[2]); return 3; }
+        std::fprintf(stderr, "FuseBatch: %d fused over three targets (%d %d %d), identical to three Fuse calls\n", total, nSeq[0], nSeq[1], nSeq[2]);
+    }
     // 10. MapPoint::ComputeDistinctiveDescriptors over the observations of each map point (K1 and K2 keypoints)
     {
         std::vector<std::vector<cv::Mat> > sets(np);
