@@ -1765,9 +1765,10 @@ __device__ __forceinline__ void ba_scale_row(const double T[6], double h0, doubl
 // camera, one edge per thread; the 27 sums (21 of Hpp's upper triangle + 6 of bp) go through LDS in a fixed order: lane
 // quads first (DPP), then 27 x 8 column threads over 32 quad leaders each, then the last 8.  (Sixty-four-lane shuffle
 // trees for the 27 values cost 6.4 us here; this costs about one.)
-constexpr int kLinThreads = 1024;      // (batches: 512- and 256-thread workgroups measured, no difference: 3.27 / 3.29 / 3.29 ms for 25 windows; again after
-                                       //  the flat -> global change: the launch alone 43.8 -> 37.6 us with 512, the four-group batch 2.94-2.98 ms either way,
-                                       //  one window 1.128 -> 1.143 ms -- and the role-B sum's tree depends on it, so ONE size serves both)
+constexpr int kLinThreads = 1024;      // workgroup size of a BATCH's linearisation (and of the classic, non-pre-scaled one).  Rounds 2-3 measured 512- and 256-thread
+                                       //  workgroups in batches without a difference (3.27 / 3.29 / 3.29 ms for 25 windows; the launch alone 43.8 -> 37.6 us with 512, the call
+                                       //  2.94-2.98 ms either way); round 4, pre-scaled blocks: a batch 48.9 us with 1024 against 51.8 with 512, ONE window 1.079 ms with 1024,
+                                       //  1.028 with 512, 1.062 with 256 -- BALaunch::lin_w picks.  (The role-B sum's tree depends on the size: last-bit differences only.)
 // first = 1 on the first linearisation of an optimize() call: the largest |diagonal entry| of Hpp / Hll (lambda_0 = 1e-5 x
 // that, optimization_algorithm_levenberg.cpp:166-180) is accumulated with one atomic max per workgroup -- a max does not
 // depend on the order, and non-negative doubles order like their bit patterns.
@@ -4036,6 +4037,19 @@ struct BALaunch {
     unsigned gz() const { return nz > 1 ? (unsigned)((nz + 7) & ~7) : 1u; }   // windows are dealt to the XCDs: grid.z padded to 8
     int ptBlocks() const { return eao::cdiv(std::max(d.nL, 1) * 8, 256); }       // eight lanes per landmark
     int linBlocks() const { return eao::cdiv(std::max(d.nL, 1) * 8, kLinThreads); }
+    // the pre-scaled-block linearisation: 1024-thread workgroups in a batch (48.9 us per 25 windows against 51.8 with 512), 512 / 256 for one window -- its 24 landmark
+    // workgroups of 1024 leave nine tenths of the chip idle (EAO_BA_LIN_THREADS for A/B runs; profiles/r04_ba_pair_ablation.txt)
+    template <int NT> void lin_launch(int par, int first, int diagOnly) const {
+        const int lb = eao::cdiv(std::max(d.nL, 1) * 8, NT);
+        hipLaunchKernelGGL((k_ba_linearize<false, NT, true>), dim3(lb + d.nF, 1, gz()), dim3(NT), 0, s, W, wp(par), lb, first, diagOnly);
+    }
+    void lin_w(int par, int first, int diagOnly) const {
+        static const int envLinT = getenv("EAO_BA_LIN_THREADS") ? atoi(getenv("EAO_BA_LIN_THREADS")) : 0;
+        const int nt = envLinT ? envLinT : (nz > 1 ? 1024 : 512);
+        if (nt == 256) lin_launch<256>(par, first, diagOnly);
+        else if (nt == 512) lin_launch<512>(par, first, diagOnly);
+        else lin_launch<kLinThreads>(par, first, diagOnly);
+    }
     void setup() const {      // device-side part of the set-up (once per window)
         hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(std::max(d.nL * d.nF, d.nL * 8), d.nP * 3), d.nC), d.E), d.nPl * 4), 256), 1, gz()), dim3(256), 0, s, W, wp(0));
         if (d.usePairs) {
@@ -4086,7 +4100,7 @@ struct BALaunch {
     void relinearize() {
         if (!d.wmode || !d.nL) return;
         hipLaunchKernelGGL(k_ba_errors<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(0));
-        hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads, true>), dim3(linBlocks() + d.nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(0), linBlocks(), 0, 0);
+        lin_w(0, 0, 0);
     }
     // iterations [from, to) of an optimize() call, one trial each, no host round trip
     void bulk(int from, int to, bool withErrors) {
@@ -4106,8 +4120,8 @@ struct BALaunch {
             else if (d.wmode) {
                 // first linearisation of the call: lambda_0 (the largest diagonal entry) must be known before the blocks can be stored pre-scaled --
                 // one pass for the maximum, one for everything else
-                if (it == 0) hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads, true>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, 1, 1);
-                hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads, true>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
+                if (it == 0) lin_w(par, 1, 1);
+                lin_w(par, it == 0 ? 1 : 0, 0);
             } else hipLaunchKernelGGL((k_ba_linearize<false, kLinThreads, false>), dim3(lb + nF, 1, gz()), dim3(kLinThreads), 0, s, W, wp(par), lb, it == 0 ? 1 : 0, 0);
             if (it == 0 && !nF) hipLaunchKernelGGL(k_ba_lambda_init, dim3(1), dim3(256), 0, s, W, wp(par));   // no Schur kernel to do it
             trial(par, 1, it == 0 && nF, it == to - 1 || !nL);      // (no landmark, no k_ba_backsub: k_ba_decide after every trial)
