@@ -216,6 +216,7 @@ struct Ctx {   // per-thread workspace, grow-only
     PinBuf out;              // candidate items, written by the kernel over PCIe (zero-copy), read after the stream sync
     eao::DevBuf<int> metaDev; // segStart[nq], segCount[nq], cursor (device: the cursor is an atomic)
     PinBuf meta;             // their pinned copy (asynchronous D2H in the same stream)
+    std::vector<int> cellOf, cellStart;      // scratch of the grid order's counting sort
     ~Ctx() { if (stream) (void)hipStreamDestroy(stream); }
 };
 thread_local Ctx g_ctx;
@@ -245,14 +246,23 @@ eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs
         if (P.n == 0 || P.nq == 0) { P.n = 0; P.nq = 0; continue; }
         EAO_REQUIRE(P.n < 65536, "at most 65535 keypoints per frame (indices are packed in 16 bits)");
         // grid order: PosInGrid (src/Frame.cc:751-761) then cell column-major, insertion (= index) order inside a cell
-        P.ord.reserve(P.n);
-        for (int i = 0; i < P.n; i++) {
-            const int px = (int)std::round((F->kp_x[i] - F->min_x) * F->grid_inv_w);
-            const int py = (int)std::round((F->kp_y[i] - F->min_y) * F->grid_inv_h);
-            if (px < 0 || px >= F->grid_cols || py < 0 || py >= F->grid_rows) continue;
-            P.ord.push_back({px, py, i});
+        // (a counting sort by cell -- the keypoints of a cell keep their index order: a comparison sort of a thousand records took a third of a whole search call)
+        {
+            const size_t nCells = (size_t)F->grid_cols * F->grid_rows;
+            std::vector<int>& cellOf = c.cellOf; std::vector<int>& cellStart = c.cellStart;
+            cellOf.resize(P.n); cellStart.assign(nCells + 1, 0);
+            for (int i = 0; i < P.n; i++) {
+                const int px = (int)std::round((F->kp_x[i] - F->min_x) * F->grid_inv_w);
+                const int py = (int)std::round((F->kp_y[i] - F->min_y) * F->grid_inv_h);
+                const bool in = px >= 0 && px < F->grid_cols && py >= 0 && py < F->grid_rows;
+                cellOf[i] = in ? px * F->grid_rows + py : -1;
+                if (in) cellStart[cellOf[i] + 1]++;
+            }
+            for (size_t q = 0; q < nCells; q++) cellStart[q + 1] += cellStart[q];
+            P.ord.resize(cellStart[nCells]);
+            for (int i = 0; i < P.n; i++)
+                if (cellOf[i] >= 0) P.ord[cellStart[cellOf[i]]++] = {cellOf[i] / F->grid_rows, cellOf[i] % F->grid_rows, i};
         }
-        std::sort(P.ord.begin(), P.ord.end(), [](const Ord& a, const Ord& b) { return a.cx != b.cx ? a.cx < b.cx : (a.cy != b.cy ? a.cy < b.cy : a.i < b.i); });
         P.no = (int)P.ord.size();
         const size_t n = P.n, no = std::max(P.no, 1), nq = P.nq;
         // per frame: kx ky ur (float n) | oct (int n) | order (int no) | cellx celly (u16 no) | desc (32 n) | queries | (qdesc unless shared with an earlier frame)
