@@ -566,3 +566,25 @@ def test_reference_keyframe_stage_rejects_bad_input():
     # and a good call still works afterwards
     got = trk.track_reference_keyframe(*args, cam["Tcw"], kf, sc["fv2"], 0.7, True, True, st)
     assert got["n_matches"] > 10
+
+
+def test_reference_keyframe_stage_degenerate_inputs(oracle):
+    """No common vocabulary node, empty feature vectors, a keyframe without keypoints: SearchByBoW returns 0, PoseOptimization has fewer than three
+    correspondences and leaves the pose alone (src/Optimizer.cc:453-454) -- and the handle works normally afterwards."""
+    sc, cam, kps, desc, depth, kf = _bow_case(7420, 300, 12)
+    cap = 2048
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+    trk = _tracker(cam, cap, 2048)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480)
+    empty = dict(node_id=np.zeros(0, np.uint32), node_start=np.zeros(1, np.int32), index=np.zeros(0, np.uint32))
+    far = dict(sc["fv2"]); far["node_id"] = (far["node_id"] + 100000).astype(np.uint32)
+    kf0 = dict(valid=np.zeros(0, np.uint8), Xw=np.zeros((0, 3), np.float32), descriptors=np.zeros((0, 32), np.uint8), angle=np.zeros(0, np.float32), fv=empty)
+    for k, fv in ((kf, far), (kf, empty), (dict(kf, fv=empty), sc["fv2"]), (kf0, sc["fv2"])):
+        got = trk.track_reference_keyframe(*args, cam["Tcw"], k, fv, 0.7, True, True, st)
+        assert got["n_keypoints"] == len(kps) and got["n_matches"] == 0 and got["n_edges"] == 0 and got["n_inliers"] == 0
+        assert (got["kp_map_point"] == -1).all() and not got["kp_outlier"].any()
+        assert np.array_equal(got["Tcw"], np.asarray(cam["Tcw"], np.float32))
+    want = _chain_bow(oracle, cam, kps, desc, depth, kf, sc["fv2"], 0.7, True, True)
+    got = trk.track_reference_keyframe(*args, cam["Tcw"], kf, sc["fv2"], 0.7, True, True, st)
+    assert got["n_matches"] == want["n_matches"] and np.array_equal(got["kp_map_point"], want["kp_map_point"])
