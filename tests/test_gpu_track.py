@@ -588,3 +588,22 @@ def test_reference_keyframe_stage_degenerate_inputs(oracle):
     want = _chain_bow(oracle, cam, kps, desc, depth, kf, sc["fv2"], 0.7, True, True)
     got = trk.track_reference_keyframe(*args, cam["Tcw"], kf, sc["fv2"], 0.7, True, True, st)
     assert got["n_matches"] == want["n_matches"] and np.array_equal(got["kp_map_point"], want["kp_map_point"])
+
+
+def test_motion_model_stage_without_last_frame_points():
+    """A last frame that holds no usable map point (or no keypoint at all): the search returns 0, the pose stays the prediction."""
+    cur, kps, desc, depth, pts, _ = _scene(seed=7330, n=300)
+    _, last, _ = synth.synth_tracking(n=300, seed=7330, mono_frac=0.0, occupied_frac=0.0)
+    cap = 2048
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+    trk = _tracker(cur, cap, 2048)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480)
+    none = dict(last, valid=np.zeros_like(last["valid"]))
+    empty = {k: (v[:0] if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == len(last["valid"]) else v) for k, v in last.items()}
+    for l in (none, empty):
+        got = trk.track_with_motion_model(*args, cur["Tcw"], l, 15.0, False, True, True, st)
+        assert got["n_keypoints"] == len(kps) and got["n_matches"] == 0 and got["n_edges"] == 0 and (got["kp_map_point"] == -1).all()
+        assert np.array_equal(got["Tcw"], np.asarray(cur["Tcw"], np.float32))
+    got = trk.track_with_motion_model(*args, cur["Tcw"], last, 15.0, False, True, True, st)
+    assert got["n_matches"] > 50
