@@ -16,13 +16,16 @@
 //                       (i2,r,c) accumulates its element of -sum_l Y_{i1,l} Hpl_{i2,l}^T through a dense point x camera
 //                       edge table (no atomics, fixed order)
 //      k_ba_reduce_*    sums the partial Schur slabs (many workgroups: one CU alone pulls too little from L2)
+//      k_ba_schur_pairs_mfma (round 4, the default of the tile-solver windows; k_ba_schur / k_ba_schur_pairs* are the older forms): the
+//                       linearisation leaves Cholesky-scaled blocks W = Hpl C^-T (C C^T = Hll + lambda I), ONE workgroup per camera pair adds
+//                       W(l, i1) W(l, i2)^T over the landmarks both observe on v_mfma_f64_4x4x4 (16-byte fetches staged through wave-private LDS)
 //      k_ba_solve_tiles the 6*nFree square system as register-resident 16x16 tiles: LDL^T in 4-column panels, trailing
 //                       update by v_mfma_f64_16x16x4_f64 (the ONE GEMM-shaped piece of the path), forward substitution
 //                       folded in as an extra matrix row, single-wave back substitution, pose update exp(dx)*T.
 //                       k_ba_solve (LDS / global scratch, 6-row panels, VALU) covers windows of more than 30 free keyframes
 //      k_ba_backsub     per point: x_l = Dinv (bl - Hpl^T x_p), new point, residuals + robust chi2 at the trial state
 //      k_ba_decide      fixed-order sums, rho, lambda / nu update; status lands in pinned host memory
-//  The Jacobian blocks are 6x6 / 6x3 / 3x3 (no MFMA shape fits): fp64 VALU + LDS, latency/bandwidth bound.  LM state
+//  The Jacobian blocks are 6x6 / 6x3 / 3x3: fp64 VALU + LDS, latency/bandwidth bound (the pair products are the exception: four 4x4x4 blocks).  LM state
 //  and control flow live on the device: the host enqueues all iterations of an optimize() call in bulk, syncs once, and
 //  replays an iteration trial by trial only when its first trial was rejected.
 #include <algorithm>
