@@ -28,6 +28,10 @@ class OrbSlot(C.Structure):   # eao_orb_slot
                 ("n", C.c_void_p), ("cap", C.c_int32)]
 
 
+class OrbLevelView(C.Structure):   # eao_orb_level_view
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("step", C.c_int32)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p), ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p),
                 ("u_right", C.c_void_p), ("descriptors", C.c_void_p), ("occupied", C.c_void_p),
@@ -86,6 +90,9 @@ SYMBOLS = {
     "eao_orb_stream_submit": (_I, [_P, _I, _I]),
     "eao_orb_stream_wait": (_I, [_P, _I]),
     "eao_orb_level": (_I, [_P, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
+    "eao_orb_pyramid": (_I, [_P, _I, _I, C.POINTER(OrbLevelView)]),
+    "eao_orb_set_keep_pyramid": (_I, [_P, _I]),
+    "eao_orb_extract_ref": (_I, [_P, _P, _I, _I, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I)]),
     "eao_orb_level_candidates": (_I, [_P, _I, _I, _P, _I, C.POINTER(_I)]),
     "eao_orb_set_profiling": (_I, [_P, _I]),
     "eao_orb_last_timing": (_I, [_P, _P]),

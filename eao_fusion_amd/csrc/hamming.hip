@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_hamming_best2_rows(const uint4* __restr
         const int r = i0 + (lane >> 1);
         sa[wv][lane] = r < na ? A[(long long)r * 2 + (lane & 1)] : make_uint4(0, 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();
+    eao::wave_sync();
     const unsigned none = (256u << 20) | 0xFFFFFu;
     unsigned k1[kB2Rows], k2[kB2Rows];
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_hamming_best2_seq(const uint4* __restri
         const int r = i0 + (lane >> 1);
         sa[wv][lane] = r < na ? A[(long long)r * 2 + (lane & 1)] : make_uint4(0, 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();
+    eao::wave_sync();
     const unsigned none = (256u << 20) | 0xFFFFFu;
     unsigned k1[kB2Rows], k2[kB2Rows];
 #pragma unroll
@@ -273,12 +273,7 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { 
 // LDS hand-over between the lanes of ONE wave (its LDS operations execute in order: nothing to wait for).  The empty asm statements with a memory clobber keep the
 // COMPILER from moving LDS accesses across the point: the two sides park and fetch through different types (8-byte pairs in, 16-byte rows out), which do not alias in
 // its view, and a wavefront-scope fence lowers to no instruction at all (round 4: a hand-over of this shape in csrc/lm.hip was reordered by the scheduler).
-__device__ __forceinline__ void hm_wave_sync() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
+__device__ __forceinline__ void hm_wave_sync() { eao::wave_sync(); }
 
 // full matrix: grid (column blocks, row blocks, pairs); nb % 8 == 0 and a 16-byte aligned D (else the popcount kernels above)
 __global__ __launch_bounds__(256, 3) void k_hamming_matrix_mfma(const uint4* __restrict__ A, int na, const uint4* __restrict__ B, int nb,

@@ -749,7 +749,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     double* const myEst = reinterpret_cast<double*>(&s_est[wv]);
     // solve (H + lambda I) x = b of THIS wave's copy of the system, x -> trial pose exp(x) * est, published as candidate `slot`
     auto solve_candidate = [&](int buf, int slot, double lambda) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");               // mySys / myEst were written by lanes of this wave
+        eao::wave_sync();               // mySys / myEst were written by lanes of this wave
         double A[36], b[6];
         int q = 0;
 #pragma unroll
@@ -767,7 +767,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
         if (lane == 0) { s_cpose[buf][slot] = trial; s_cscale[buf][slot] = sc; s_cok[buf][slot] = ok; }
     };
     auto copy7 = [&](double* dst, const double* src) {      // an SE3 between LDS records, by seven lanes of the calling wave
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        eao::wave_sync();
         if (lane < 7) dst[lane] = src[lane];
     };
     __syncthreads();
@@ -1030,7 +1030,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
             }
         }
         // ---- inlier / outlier classification of every edge (src/Optimizer.cc:554-621) at the round's estimate
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        eao::wave_sync();
         const SE3 fin = s_est[wv];
         const PoseRt finm = pose_rt(fin);
         double nbo = 0;
@@ -1746,12 +1746,16 @@ __device__ __forceinline__ double ba_rsqrt(double x) {
     return fma(y * 0.5, e, y);
 }
 __device__ __forceinline__ void ba_chol3(const double H[6], double lambda, double T[6]) {
-    const double m00 = H[0] + lambda, m11 = H[3] + lambda, m22 = H[5] + lambda;
+    // Pivots: Hll is a sum of J^T W J terms and lambda > 0, so every pivot is positive in exact arithmetic; for a landmark whose observations are (nearly)
+    // collinear the subtraction can cancel to <= 0, where v_rsq_f64 would return Inf / NaN and poison the whole window's Schur system.  A pivot is therefore
+    // kept at no less than one rounding unit of its diagonal entry -- the magnitude the cancellation noise has, and what upstream's explicit 3 x 3 inverse
+    // (finite, huge) amounts to; fmax leaves every healthy pivot bit for bit as it was.
+    const double m00 = fmax(H[0] + lambda, 2.2250738585072014e-308), m11 = H[3] + lambda, m22 = H[5] + lambda;
     const double li00 = ba_rsqrt(m00);
     const double c10 = H[1] * li00, c20 = H[2] * li00;
-    const double li11 = ba_rsqrt(m11 - c10 * c10);
+    const double li11 = ba_rsqrt(fmax(m11 - c10 * c10, fmax(m11 * 0x1p-53, 2.2250738585072014e-308)));
     const double c21 = (H[4] - c20 * c10) * li11;
-    const double li22 = ba_rsqrt(m22 - c20 * c20 - c21 * c21);
+    const double li22 = ba_rsqrt(fmax(m22 - c20 * c20 - c21 * c21, fmax(m22 * 0x1p-53, 2.2250738585072014e-308)));
     const double li10 = -(c10 * li00) * li11;
     const double li21 = -(c21 * li11) * li22;
     const double li20 = -(c20 * li00 + c21 * li10) * li22;
@@ -2745,7 +2749,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? EAO_PAIR_OCC : 1) void k_ba_schu
         }
         return f;
     };
-    auto wave_fence = [] { asm volatile("" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };      // (the clobbers: see hm_wave_sync, csrc/hamming.hip)
+    auto wave_fence = [] { eao::wave_sync(); };      // (csrc/common.h)
     double acc[4] = {0, 0, 0, 0};
     if (wave < nGall) {
         Fetch cur = fetch_data(fix_rec(recRaw, wave));

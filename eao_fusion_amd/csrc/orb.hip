@@ -786,7 +786,7 @@ __device__ __forceinline__ int wave_excl_scan(int* a, int n, int lane) {
         a[i] = run;
         run += x;
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    eao::wave_sync();
     return total;
 }
 
@@ -914,7 +914,7 @@ __device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* sm
     // fences, no workgroup barrier): as a sequence of block-wide steps it was ~20 barriers per pass with a handful of
     // instructions between them -- 43 k of level 0's 132 k cycles.  Four barriers per pass remain (six in a careful pass,
     // whose O(n^2) ranking stays block-wide).
-#define QT_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#define QT_WAVE_FENCE() eao::wave_sync()
     const int wv = t >> 6;
     for (int iter = 0; iter < 64 && !sh_done; iter++) {
         const int S = sh_S, phase = sh_phase;
@@ -1472,7 +1472,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
             mb[r * (4 * kMW) + c + mph] = img[(long long)(cy - kMR + r) * pitch + cx - kMR + c];
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    eao::wave_sync();
     // intensity centroid over the radius-15 disc: lanes 0..30 / 32..62 take column u, the halves split the rows
     const int u = (lane & 31) - 15, half = lane >> 5;
     int m10 = 0, m01 = 0;
@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Geom* __restrict_
 #pragma unroll
     for (int k = 0; k < 6; k++)
         if (lane + 64 * k < (2 * kPR + 1) * kPW) patch[wv][lane + 64 * k] = pw[k];
-    __builtin_amdgcn_wave_barrier();   // (one wave per keypoint: LDS writes of a wave are ordered before its later reads)
+    eao::wave_sync();   // (one wave per keypoint: LDS writes of a wave are ordered before its later reads)
     const uint8_t* bc = reinterpret_cast<const uint8_t*>(patch[wv]) + kPR * (4 * kPW) + kPR + ph;
     unsigned long long words[4];
 #pragma unroll
@@ -1709,6 +1709,12 @@ struct eao_orb {
     eao::DevBuf<uint8_t> d_desc;
     eao::DevBuf<float> d_xyr;
     eao::DevBuf<unsigned char> d_stereo;   // staging of eao_compute_stereo_matches
+    unsigned char* pinPyr = nullptr;       // eao_orb_pyramid: the bordered levels of one frame in mapped pinned host memory
+    size_t pinPyrCap = 0;
+    eao_orb_level_view pyrViews[kMaxLevels] = {};
+    int pyrFrame = -1, pyrBorder = -1;     // what pinPyr holds (of the last extraction; -1: nothing)
+    int autoPyrBorder = -1;                // >= 0: single-frame host-API extractions export the bordered pyramid in the same stream pass (eao_orb_set_keep_pyramid)
+    bool lastComplete = false;             // the last extraction was a synchronous host-API call: its products are final, nothing to wait for
     // last call (for stage taps)
     ImgSrc lastSrc{};
     int lastBatch = 0;
@@ -2013,7 +2019,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     eao::Range rAll("eao_orb_extract: enqueue");
     ImgSrc s;
     s.img0 = d_img; s.pitch0 = pitch0; s.fs0 = fs0; s.pyr = h->d_pyr.p;
-    h->lastSrc = s; h->lastBatch = batch;
+    h->lastSrc = s; h->lastBatch = batch; h->lastComplete = false; h->pyrFrame = -1;
     const bool prof = h->profiling;
     hipEvent_t* ev = nullptr;
     if (prof) {
@@ -2250,7 +2256,7 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
         (void)hipGraphDestroy(graph);
         h->graphKey = key;
     }
-    h->lastBatch = batch;
+    h->lastBatch = batch; h->lastComplete = false; h->pyrFrame = -1;
     // the same ordering rule as the direct path: the replayed launches use the handle's scratch
     if (h->evLastValid && h->lastStream != st) EAO_HIP(hipDeviceSynchronize());
     h->lastStream = st;
@@ -2264,6 +2270,40 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
 // three slots in flight upload, extraction and download ran one after the other, 0.94 ms per 64 frames; two slots hid it by accident.)
 __global__ __launch_bounds__(256) void k_stream_download(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// eao_orb_pyramid: every level of one frame WITH its BORDER_REFLECT_101 frame (what upstream keeps in mvImagePyramid, src/ORBextractor.cc:1113-1128), built by
+// ONE launch straight into mapped pinned host memory: a lane assembles 16 bytes of a bordered row (reflected coordinates, byte gathers out of the L2-resident
+// level) and stores them over PCIe.  ~1.3 MB per 640 x 480 frame; replaces 16 eao_orb_level calls + a per-pixel host loop in the adapter.
+struct PyrExportLevel { int w, h, srcPitch, srcOff, dstPitch, rowChunks, chunkBase; long long dstOff; };
+struct PyrExportArgs { int nlevels, border, totalChunks, pyrFrameBytes; PyrExportLevel L[kMaxLevels]; };
+__global__ __launch_bounds__(256) void k_pyramid_export(PyrExportArgs A, ImgSrc s, int frame, uint8_t* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= A.totalChunks) return;
+    int l = 0;
+    while (l + 1 < A.nlevels && idx >= A.L[l + 1].chunkBase) l++;
+    const PyrExportLevel& L = A.L[l];
+    const int r = idx - L.chunkBase, row = r / L.rowChunks, ch = r - row * L.rowChunks;
+    const uint8_t* src = l == 0 ? s.img0 + (long long)frame * s.fs0 : s.pyr + (long long)frame * A.pyrFrameBytes + L.srcOff;
+    const int pitch = l == 0 ? s.pitch0 : L.srcPitch;
+    int y = row - A.border;
+    y = y < 0 ? -y : (y >= L.h ? 2 * L.h - 2 - y : y);
+    y = min(max(y, 0), L.h - 1);
+    const uint8_t* srow = src + (long long)y * pitch;
+    unsigned w4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int x = ch * 16 + q * 4 + b - A.border;
+            x = x < 0 ? -x : (x >= L.w ? 2 * L.w - 2 - x : x);
+            x = min(max(x, 0), L.w - 1);       // (bytes of the row pitch beyond the right border)
+            v |= (unsigned)srow[x] << (8 * b);
+        }
+        w4[q] = v;
+    }
+    *reinterpret_cast<uint4*>(dst + L.dstOff + (long long)row * L.dstPitch + ch * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 }
 
 void stream_release(eao_orb* h) {
@@ -2280,6 +2320,54 @@ void stream_release(eao_orb* h) {
     h->slots.clear();
     for (hipStream_t* q : {&h->sUp, &h->sRun, &h->sDown})
         if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+}
+
+// Readers of the last extraction's products (pyramid levels, candidate taps, the stereo matcher).  After a host-API call (eao_orb_extract / _batch: what the
+// class-surface adapter makes) the products are final when the call returns -- nothing to wait for, and in particular no device-wide synchronise that would
+// make the Tracking thread wait for the LocalMapping thread's bundle adjustment.  Only after a DEVICE-API call on a caller's stream, which
+// the library must not touch again (its owner may have destroyed it, see enqueue_direct) and on which recording an event per call was measured at ~5 us, does
+// the reader drain the device.
+eao_status wait_last_extraction(eao_orb* h) {
+    if (!h->lastComplete) {
+        EAO_HIP(hipDeviceSynchronize());
+        h->lastComplete = true;
+    }
+    return EAO_OK;
+}
+
+// enqueue the export of frame `frame`'s bordered levels on the handle's stream (no synchronisation); fills h->pyrViews
+eao_status enqueue_pyramid_export(eao_orb* h, int frame, int border) {
+    const Geom& g = h->geom;
+    for (int l = 0; l < g.nlevels; l++) EAO_REQUIRE(border < g.L[l].w && border < g.L[l].h, "level %d is smaller than the border", l);
+    PyrExportArgs A;
+    A.nlevels = g.nlevels; A.border = border; A.pyrFrameBytes = g.pyrFrameBytes;
+    size_t off = 0;
+    int chunks = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        PyrExportLevel& L = A.L[l];
+        L.w = g.L[l].w; L.h = g.L[l].h; L.srcPitch = g.L[l].pitch; L.srcOff = g.L[l].off;
+        L.dstPitch = (L.w + 2 * border + 63) & ~63;
+        L.rowChunks = L.dstPitch / 16; L.chunkBase = chunks; L.dstOff = (long long)off;
+        chunks += L.rowChunks * (L.h + 2 * border);
+        off = (off + (size_t)L.dstPitch * (L.h + 2 * border) + 255) & ~(size_t)255;
+    }
+    A.totalChunks = chunks;
+    if (h->pinPyrCap < off) {
+        EAO_HIP(hipStreamSynchronize(h->stream));      // (a previous export may still be writing the old block)
+        if (h->pinPyr) (void)hipHostFree(h->pinPyr);
+        h->pinPyr = nullptr; h->pinPyrCap = 0;
+        EAO_HIP(hipHostMalloc((void**)&h->pinPyr, off, hipHostMallocMapped));
+        h->pinPyrCap = off;
+    }
+    unsigned char* dv = nullptr;
+    EAO_HIP(hipHostGetDevicePointer((void**)&dv, h->pinPyr, 0));
+    hipLaunchKernelGGL(k_pyramid_export, dim3(eao::cdiv(chunks, 256)), dim3(256), 0, h->stream, A, h->lastSrc, frame, dv);
+    for (int l = 0; l < g.nlevels; l++) {
+        h->pyrViews[l].data = h->pinPyr + A.L[l].dstOff + (size_t)border * A.L[l].dstPitch + border;
+        h->pyrViews[l].width = A.L[l].w; h->pyrViews[l].height = A.L[l].h; h->pyrViews[l].step = A.L[l].dstPitch;
+    }
+    h->pyrFrame = frame; h->pyrBorder = border;
+    return EAO_OK;
 }
 
 }  // namespace
@@ -2347,6 +2435,7 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
     if (h->pinOut) (void)hipHostFree(h->pinOut);
+    if (h->pinPyr) (void)hipHostFree(h->pinPyr);
     stream_release(h);
     if (h->evStart) (void)hipEventDestroy(h->evStart);
     if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
@@ -2435,6 +2524,7 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
         st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, batch, (eao_keypoint*)(dv + offK), dv + offD, cap, (int*)dv, h->stream);
         if (st) return st;
         EAO_HIP(hipStreamSynchronize(h->stream));
+        h->lastComplete = true;
         const int* hn = (const int*)h->pinOut;
         for (int f = 0; f < batch; f++) {
             const int nf = std::min(std::max(hn[f], 0), cap);
@@ -2450,6 +2540,7 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
     EAO_HIP(hipMemcpyAsync(kps, h->d_kps.p, B * cap * sizeof(eao_keypoint), hipMemcpyDeviceToHost, h->stream));
     EAO_HIP(hipMemcpyAsync(desc, h->d_desc.p, B * (size_t)cap * 32, hipMemcpyDeviceToHost, h->stream));
     EAO_HIP(hipStreamSynchronize(h->stream));
+    h->lastComplete = true;
     return EAO_OK;
 }
 
@@ -2562,8 +2653,64 @@ eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which
         src = (which ? h->d_blur.p : h->d_pyr.p) + (long long)frame * h->geom.pyrFrameBytes + L.off;
         pitch = L.pitch;
     }
-    EAO_HIP(hipDeviceSynchronize());   // the last extraction may have run on a caller-provided stream
-    EAO_HIP(hipMemcpy2D(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    eao_status st = wait_last_extraction(h);
+    if (st) return st;
+    EAO_HIP(hipMemcpy2DAsync(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost, h->stream));
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    return EAO_OK;
+}
+
+eao_status eao_orb_pyramid(eao_orb* h, int32_t frame, int32_t border, eao_orb_level_view* levels) {
+    EAO_REQUIRE(h && levels && h->geomValid && h->lastBatch > 0, "no extraction has run on this handle");
+    EAO_REQUIRE(frame >= 0 && frame < h->lastBatch && border >= 0 && border <= 64, "frame / border out of range");
+    if (!(h->lastComplete && h->pyrFrame == frame && h->pyrBorder == border)) {      // (else: exported behind the extraction itself, eao_orb_set_keep_pyramid)
+        eao_status st = wait_last_extraction(h);
+        if (!st) st = enqueue_pyramid_export(h, frame, border);
+        if (st) return st;
+        EAO_HIP(hipStreamSynchronize(h->stream));
+        EAO_HIP(hipGetLastError());
+    }
+    for (int l = 0; l < h->geom.nlevels; l++) levels[l] = h->pyrViews[l];
+    return EAO_OK;
+}
+
+eao_status eao_orb_set_keep_pyramid(eao_orb* h, int32_t border) {
+    EAO_REQUIRE(h && border >= -1 && border <= 64, "border: -1 (off) .. 64");
+    h->autoPyrBorder = border;
+    return EAO_OK;
+}
+
+eao_status eao_orb_extract_ref(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, const eao_keypoint** kps,
+                               const uint8_t** desc, int32_t* n) {
+    EAO_REQUIRE(h && kps && desc && n, "null argument");
+    *kps = nullptr; *desc = nullptr; *n = 0;
+    if (!img || width <= 0 || height <= 0) return EAO_OK;      // empty image, as eao_orb_extract
+    EAO_REQUIRE(stride >= width, "bad argument");
+    eao_status st = ensure(h, width, height, 1);
+    if (st) return st;
+    const Geom& g = h->geom;
+    const int cap = g.totalKpCap;
+    const size_t offK = 64, offD = offK + (size_t)cap * sizeof(eao_keypoint), outBytes = offD + (size_t)cap * 32;
+    if (h->pinOutCap < outBytes) {
+        if (h->pinOut) (void)hipHostFree(h->pinOut);
+        h->pinOut = nullptr; h->pinOutCap = 0;
+        EAO_HIP(hipHostMalloc((void**)&h->pinOut, outBytes, hipHostMallocMapped));
+        h->pinOutCap = outBytes;
+    }
+    unsigned char* dv = nullptr;
+    EAO_HIP(hipHostGetDevicePointer((void**)&dv, h->pinOut, 0));
+    if ((st = h->d_in.reserve((size_t)g.L[0].pitch * height))) return st;
+    const long long fs0 = (long long)g.L[0].pitch * height;
+    if (stride == g.L[0].pitch) EAO_HIP(hipMemcpyAsync(h->d_in.p, img, (size_t)fs0, hipMemcpyHostToDevice, h->stream));
+    else EAO_HIP(hipMemcpy2DAsync(h->d_in.p, g.L[0].pitch, img, stride, width, height, hipMemcpyHostToDevice, h->stream));
+    st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, 1, (eao_keypoint*)(dv + offK), dv + offD, cap, (int*)dv, h->stream);
+    if (st) return st;
+    if (h->autoPyrBorder >= 0 && (st = enqueue_pyramid_export(h, 0, h->autoPyrBorder))) return st;      // same stream, same synchronisation
+    EAO_HIP(hipStreamSynchronize(h->stream));
+    h->lastComplete = true;
+    *n = std::min(std::max(*(const int*)h->pinOut, 0), cap);
+    *kps = (const eao_keypoint*)(h->pinOut + offK);
+    *desc = h->pinOut + offD;
     return EAO_OK;
 }
 
@@ -2571,9 +2718,11 @@ eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, fl
     EAO_REQUIRE(h && n && h->geomValid && h->lastBatch > 0, "no extraction has run on this handle");
     EAO_REQUIRE(frame >= 0 && frame < h->lastBatch && level >= 0 && level < h->geom.nlevels, "frame/level out of range");
     const Geom& g = h->geom;
-    EAO_HIP(hipDeviceSynchronize());
+    eao_status st0 = wait_last_extraction(h);
+    if (st0) return st0;
     int cnt = 0;
-    EAO_HIP(hipMemcpy(&cnt, h->d_candcnt.p + frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    EAO_HIP(hipMemcpyAsync(&cnt, h->d_candcnt.p + frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    EAO_HIP(hipStreamSynchronize(h->stream));
     *n = cnt;
     if (!xyr || cnt == 0) return EAO_OK;
     const int m = std::min(cnt, cap);
@@ -2642,7 +2791,9 @@ eao_status eao_compute_stereo_matches(eao_orb* left, eao_orb* right, int32_t fra
     }
     for (int i = 0; i < nr; i++) EAO_REQUIRE(kps_r[i].octave >= 0 && kps_r[i].octave < g.nlevels, "right keypoint %d: octave out of range", i);
     if (nl == 0 || nr == 0) return EAO_OK;
-    EAO_HIP(hipDeviceSynchronize());   // the extractions may have run on caller-provided streams
+    eao_status stw = wait_last_extraction(left);     // (host-API extractions, what Frame's stereo constructor makes on its two threads, are final already)
+    if (!stw) stw = wait_last_extraction(right);
+    if (stw) return stw;
     eao::DevBuf<unsigned char>& buf = left->d_stereo;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off = 0;

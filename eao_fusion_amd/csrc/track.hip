@@ -435,7 +435,7 @@ __device__ __forceinline__ void track_assign_body(int nMp, int cap, const Query*
                 bool op = t < nT;
                 const int m = op ? tM[t] : 0, st = op ? tSt[t] : 0, cn = op ? tCn[t] : 0;
                 int res = -1, more = 0;
-                auto wave_sync = [] { asm volatile("" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
+                auto wave_sync = [] { eao::wave_sync(); };
                 while (__any(op)) {
                     more++;
                     tag--;
@@ -683,7 +683,9 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
         R.outl[i] = 0;
     }
     // Frame::isInFrustum(pMP, 0.5) of every local map point (workgroups 1.. of k_track_frame): the caller's visibility counters
-    for (int m = t; m < nMp; m += kAssignThreads) R.inView[m] = inView[m];
+    // (the motion-model / reference-keyframe stages pass inView = nullptr: their nMp counts last-frame / keyframe keypoints, which may exceed the
+    //  max_map_points the inView slice is sized for, and the host does not read the table there)
+    if (inView) for (int m = t; m < nMp; m += kAssignThreads) R.inView[m] = inView[m];
     if (dbg && threadIdx.x == 0) dbg[4] = clock64();
 }
 
@@ -1000,7 +1002,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
         const float rotFactor = mm && mm->check_orientation ? (float)refc::HISTO_LENGTH / 360.0f : bw && bw->check_orientation ? 1.0f / refc::HISTO_LENGTH : 0.f;
         hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, plain ? h->q : h->lQ, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
                            mm ? INFINITY : nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, plain ? h->mXw : h->lXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
-                           h->inView, RB, h->dbg, envAll, h->lAng, h->ang, rotFactor, BD);
+                           plain ? h->inView : nullptr, RB, h->dbg, envAll, h->lAng, h->ang, rotFactor, BD);
     };
     if (nMp <= 4 * kAssignThreads) launch_assign(k_track_assign_edges<4>);
     else if (nMp <= 8 * kAssignThreads) launch_assign(k_track_assign_edges<8>);

@@ -140,9 +140,36 @@ class ORBextractor:
 
     @property
     def mvImagePyramid(self):
-        """Level images of frame 0 of the last call with the reference's 19 px BORDER_REFLECT_101 frame
-        (src/ORBextractor.cc:1113-1128); the hot path itself never reads the border."""
-        return [np.pad(self.level_image(l), EDGE_THRESHOLD, mode="reflect") for l in range(self.nlevels)]
+        """Level images of frame 0 of the last call with the reference's 19 px BORDER_REFLECT_101 frame around them
+        (src/ORBextractor.cc:1113-1128), through eao_orb_pyramid: one launch into the handle's pinned block (the hot path itself
+        never reads the border).  Returned as copies of the bordered images."""
+        return self.image_pyramid(EDGE_THRESHOLD)
+
+    def image_pyramid(self, border, frame=0):
+        lv = (_lib.OrbLevelView * 16)()
+        _lib.check(self._L.eao_orb_pyramid(self._h, int(frame), int(border), lv))
+        out = []
+        for l in range(self.nlevels):
+            v = lv[l]
+            rows, cols = v.height + 2 * border, v.width + 2 * border
+            base = v.data - border * v.step - border
+            buf = (C.c_uint8 * (rows * v.step)).from_address(base)
+            out.append(np.frombuffer(buf, np.uint8).reshape(rows, v.step)[:, :cols].copy())
+        return out
+
+    def set_keep_pyramid(self, border):
+        _lib.check(self._L.eao_orb_set_keep_pyramid(self._h, int(border)))
+
+    def extract_ref(self, img):
+        """eao_orb_extract_ref: the class-surface adapter's call (results read in place from the handle's pinned block, copied here)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        kp, dp, n = C.c_void_p(), C.c_void_p(), C.c_int32()
+        _lib.check(self._L.eao_orb_extract_ref(self._h, _lib.ptr(img), img.shape[1], img.shape[0], img.strides[0], C.byref(kp), C.byref(dp), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        k = np.frombuffer((C.c_uint8 * (n.value * 28)).from_address(kp.value), KP_DTYPE).copy()
+        d = np.frombuffer((C.c_uint8 * (n.value * 32)).from_address(dp.value), np.uint8).reshape(n.value, 32).copy()
+        return k, d
 
 
 def compute_stereo_matches(ext_left, ext_right, kps_l, desc_l, kps_r, desc_r, mb, mbf, frame=0):

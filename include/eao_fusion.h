@@ -127,6 +127,28 @@ eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_
  * 7x7 Gaussian-blurred copy.  Either of w/h/dst may be NULL to query sizes only. */
 eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which, int32_t* w, int32_t* hgt, uint8_t* dst);
 
+/* ALL levels of frame `frame` of the last extraction in ONE call, each with a `border`-pixel BORDER_REFLECT_101 frame physically around it -- the form
+ * upstream keeps in mvImagePyramid (EDGE_THRESHOLD = 19: src/ORBextractor.cc:1113-1128; read by Frame::ComputeStereoMatches only, src/Frame.cc:846, 936-953).
+ * One launch writes the bordered levels into a pinned host block the handle owns; levels[l] (nlevels entries) receives the address of the level's pixel
+ * (0, 0) inside it, its size and its row pitch (rows -border .. height + border - 1 and columns -border .. width + border - 1 are addressable around it).
+ * The block is valid until the next eao_orb_pyramid call on the handle or its destruction.  After a host-API extraction (eao_orb_extract*) nothing but the
+ * handle's own stream is synchronised; after eao_orb_extract_batch_device on a caller's stream the device is drained first. */
+typedef struct {
+    uint8_t* data;            /* pixel (0, 0) of the level */
+    int32_t width, height;
+    int32_t step;             /* bytes per row */
+} eao_orb_level_view;
+eao_status eao_orb_pyramid(eao_orb* h, int32_t frame, int32_t border, eao_orb_level_view* levels);
+/* border >= 0: every eao_orb_extract_ref call also exports the frame's bordered pyramid behind the extraction, on the same stream and under the same single
+ * synchronisation, and the eao_orb_pyramid call that follows only hands out the views; -1 (the default): off. */
+eao_status eao_orb_set_keep_pyramid(eao_orb* h, int32_t border);
+
+/* eao_orb_extract without the copy into caller arrays: *kps / *desc point into the pinned block the device wrote the frame's results to (*n keypoints,
+ * *n x 32 descriptor bytes), valid until the next call on the handle.  What the class-surface adapter uses: its cv::KeyPoint vector and descriptor matrix
+ * are filled straight from there. */
+eao_status eao_orb_extract_ref(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, const eao_keypoint** kps,
+                               const uint8_t** desc, int32_t* n);
+
 /* Stage taps for parity tests (device -> host copies of intermediate products of the LAST extract call).
  * candidates: FAST corners of (frame, level) in reference order before the quad-tree, as (x, y, response)
  * float triples relative to the (16,16) level border origin; returns the count in *n (cap in triples). */
@@ -579,7 +601,7 @@ eao_status eao_tracker_track_reference_keyframe(eao_tracker* h, const eao_keypoi
  * changed eao_tracker_track_local_map and eao_track_result in place); a caller compiled against another version must not call into the library.
  * Result structs are zero-initialised by the caller (`eao_track_result R = {0};`) before their array pointers are set: a pointer member the
  * caller's header does not know yet then reads as NULL = "not wanted". */
-#define EAO_ABI_VERSION 4
+#define EAO_ABI_VERSION 5
 int32_t eao_abi_version(void);
 
 #ifdef __cplusplus

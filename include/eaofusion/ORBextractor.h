@@ -12,6 +12,7 @@
 #define ORBEXTRACTOR_H
 
 #include <cassert>
+#include <cstring>
 #include <list>
 #include <stdexcept>
 #include <string>
@@ -42,28 +43,48 @@ public:
     ORBextractor& operator=(const ORBextractor&) = delete;
 
     // Compute the ORB features and descriptors on an image; the mask is ignored, as upstream (include/ORBextractor.h:58).
+    // One library call; the results are copied ONCE, from the pinned block the device wrote them to into the caller's cv types.
     void operator()(cv::InputArray image_, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors_) {
         if (image_.empty()) return;
         cv::Mat image = image_.getMat();
         assert(image.type() == CV_8UC1);
-        int cap = 0;
-        check(eao_orb_max_keypoints(h_, image.cols, image.rows, &cap), "eao_orb_max_keypoints");
-        kp_.resize(cap);
-        desc_.resize((size_t)cap * 32);
-        int n = 0;
         static_assert(sizeof(cv::KeyPoint) == sizeof(eao_keypoint), "cv::KeyPoint must be the 28-byte POD the ABI mirrors");
-        check(eao_orb_extract(h_, image.ptr(0), image.cols, image.rows, (int)image.step, kp_.data(), desc_.data(), cap, &n), "eao_orb_extract");
-        keypoints.clear();
+        if (keepPyramid != keptPyramid_) {
+            check(eao_orb_set_keep_pyramid(h_, keepPyramid ? 19 : -1), "eao_orb_set_keep_pyramid");      // EDGE_THRESHOLD, src/ORBextractor.cc:67
+            keptPyramid_ = keepPyramid;
+        }
+        const eao_keypoint* kp = nullptr;
+        const uint8_t* desc = nullptr;
+        int n = 0;
+        check(eao_orb_extract_ref(h_, image.ptr(0), image.cols, image.rows, (int)image.step, &kp, &desc, &n), "eao_orb_extract_ref");
+        keypoints.resize((size_t)n);
         if (n == 0) {
             descriptors_.release();
         } else {
             descriptors_.create(n, 32, CV_8U);
             cv::Mat d = descriptors_.getMat();
-            for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc_[(size_t)i * 32], 32);
-            keypoints.resize(n);
-            std::memcpy((void*)keypoints.data(), kp_.data(), (size_t)n * sizeof(eao_keypoint));
+            if (d.isContinuous()) std::memcpy(d.ptr(0), desc, (size_t)n * 32);
+            else for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), desc + (size_t)i * 32, 32);
+            std::memcpy((void*)keypoints.data(), kp, (size_t)n * sizeof(eao_keypoint));
         }
-        refreshPyramid();
+        pyramidStale_ = true;
+        if (keepPyramid) ImagePyramid();
+    }
+
+    // mvImagePyramid of the frame extracted last, materialised ON DEMAND: upstream fills it in every call (src/ORBextractor.cc:1107-1131), but only
+    // Frame::ComputeStereoMatches ever reads it (src/Frame.cc:846, 936-953) -- and eaofusion::ComputeStereoMatches below does not need it either: it reads the
+    // pyramids where they are, on the device.  A caller that keeps upstream's ComputeStereoMatches sets keepPyramid = true once (Tracking's constructor, stereo
+    // sensor only) and finds the member filled after every call as before; anyone else calls ImagePyramid() when it wants the images.  Either way the levels come
+    // in ONE library call (eao_orb_pyramid): w x h views with the 19-pixel BORDER_REFLECT_101 frame physically around them, as upstream lays them out, inside a
+    // pinned block the extractor's handle owns -- valid until the next operator() call.
+    std::vector<cv::Mat>& ImagePyramid() {
+        if (pyramidStale_) {
+            eao_orb_level_view lv[16];
+            check(eao_orb_pyramid(h_, 0, 19, lv), "eao_orb_pyramid");
+            for (int l = 0; l < nlevels; l++) mvImagePyramid[l] = cv::Mat(lv[l].height, lv[l].width, CV_8UC1, lv[l].data, (size_t)lv[l].step);
+            pyramidStale_ = false;
+        }
+        return mvImagePyramid;
     }
 
     int inline GetLevels() { return nlevels; }
@@ -73,36 +94,15 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // Level images WITH the 19 px BORDER_REFLECT_101 frame, as upstream stores them (src/ORBextractor.cc:1113-1128).
-    // Only Frame::ComputeStereoMatches reads them (stereo sensor); set keepPyramid = false to skip the copy otherwise.
+    // Level images WITH the 19 px BORDER_REFLECT_101 frame around them, as upstream stores them (src/ORBextractor.cc:1113-1128): see ImagePyramid().
+    // keepPyramid = true fills the member in every operator() call (+ ~0.06 ms per 640 x 480 frame: one more launch behind the extraction, 1.3 MB over PCIe);
+    // the default leaves it to ImagePyramid().
     std::vector<cv::Mat> mvImagePyramid;
-    bool keepPyramid = true;
+    bool keepPyramid = false;
 
 protected:
     static void check(eao_status st, const char* what) {
         if (st != EAO_OK) throw std::runtime_error(std::string(what) + ": " + eao_last_error());
-    }
-    void refreshPyramid() {
-        if (!keepPyramid) return;
-        const int E = 19;
-        for (int l = 0; l < nlevels; l++) {
-            int w = 0, h = 0;
-            check(eao_orb_level(h_, 0, l, 0, &w, &h, nullptr), "eao_orb_level");
-            tight_.resize((size_t)w * h);
-            check(eao_orb_level(h_, 0, l, 0, nullptr, nullptr, tight_.data()), "eao_orb_level");
-            cv::Mat whole(h + 2 * E, w + 2 * E, CV_8UC1);
-            for (int y = -E; y < h + E; y++) {
-                const int sy = y < 0 ? -y : (y >= h ? 2 * h - 2 - y : y);
-                unsigned char* dst = whole.ptr(y + E);
-                const unsigned char* src = &tight_[(size_t)sy * w];
-                for (int x = -E; x < w + E; x++) dst[x + E] = src[x < 0 ? -x : (x >= w ? 2 * w - 2 - x : x)];
-            }
-#ifdef EAOFUSION_HAVE_OPENCV
-            mvImagePyramid[l] = whole(cv::Rect(E, E, w, h));   // w x h view with the border physically around it, as upstream
-#else
-            mvImagePyramid[l] = whole.roi(E, E, w, h);
-#endif
-        }
     }
 
     int nfeatures;
@@ -119,8 +119,7 @@ public:
 
 private:
     eao_orb* h_ = nullptr;
-    std::vector<eao_keypoint> kp_;
-    std::vector<unsigned char> desc_, tight_;
+    bool pyramidStale_ = true, keptPyramid_ = false;
 };
 
 }  // namespace ORB_SLAM2

@@ -118,8 +118,38 @@ int main(int argc, char** argv) {
     wr(out, &nk, 1);
     wr(out, keys.data(), keys.size());
     for (int i = 0; i < nk; i++) wr(out, descriptors.ptr(i), 32);
-    int32_t pyr0[3] = {extractor.mvImagePyramid[0].rows, extractor.mvImagePyramid[0].cols, (int32_t)extractor.mvImagePyramid[7].cols};
-    wr(out, pyr0, 3);
+    // mvImagePyramid on demand: every level a w x h view with the 19 px BORDER_REFLECT_101 frame physically around it (src/ORBextractor.cc:1113-1128) --
+    // checked pixel by pixel against the tight level images (eao_orb_level) reflected here
+    int32_t lazyEmpty = extractor.mvImagePyramid[0].empty() ? 1 : 0, borderMismatch = 0;
+    std::vector<cv::Mat>& pyrd = extractor.ImagePyramid();
+    for (int l = 0; l < 8; l++) {
+        int w = 0, h = 0;
+        eao_orb_level(extractor.handle(), 0, l, 0, &w, &h, nullptr);
+        std::vector<unsigned char> tight((size_t)w * h);
+        eao_orb_level(extractor.handle(), 0, l, 0, nullptr, nullptr, tight.data());
+        if (pyrd[l].cols != w || pyrd[l].rows != h) { borderMismatch++; continue; }
+        for (int y = -19; y < h + 19; y++) {
+            const int sy = y < 0 ? -y : (y >= h ? 2 * h - 2 - y : y);
+            const unsigned char* row = pyrd[l].data + (long)y * (long)pyrd[l].step;
+            for (int x = -19; x < w + 19; x++) {
+                const int sx = x < 0 ? -x : (x >= w ? 2 * w - 2 - x : x);
+                if (row[x] != tight[(size_t)sy * w + sx]) borderMismatch++;
+            }
+        }
+    }
+    int32_t pyr0[5] = {extractor.mvImagePyramid[0].rows, extractor.mvImagePyramid[0].cols, (int32_t)extractor.mvImagePyramid[7].cols, lazyEmpty, borderMismatch};
+    wr(out, pyr0, 5);
+    {   // keepPyramid = true: the member is filled by operator() itself, as upstream's is
+        ORB_SLAM2::ORBextractor eager(1000, 1.2f, 8, 20, 7);
+        eager.keepPyramid = true;
+        std::vector<cv::KeyPoint> k2;
+        cv::Mat d2;
+        eager(img, cv::Mat(), k2, d2);
+        int32_t same = (k2.size() == keys.size() && !eager.mvImagePyramid[3].empty() && eager.mvImagePyramid[3].cols == pyrd[3].cols) ? 1 : 0;
+        for (int y = -19; same && y < pyrd[3].rows + 19; y++)
+            if (std::memcmp(eager.mvImagePyramid[3].data + (long)y * (long)eager.mvImagePyramid[3].step - 19, pyrd[3].data + (long)y * (long)pyrd[3].step - 19, pyrd[3].cols + 38)) same = 0;
+        wr(out, &same, 1);
+    }
     int32_t dd = eaofusion::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1));
     wr(out, &dd, 1);
     cv::Mat empty;

@@ -113,7 +113,8 @@ int main() {
     F.N = (int)F.mvKeys.size();
     F.mvKeysUn = F.mvKeys;
     CHECK(F.N > 300 && (int)F.mvKeysRight.size() > 300, "ORBextractor: %d / %zu keypoints", F.N, F.mvKeysRight.size());
-    CHECK(exL.mvImagePyramid.size() == 8 && exL.mvImagePyramid[0].cols == W && exL.mvImagePyramid[0].rows == H, "mvImagePyramid");
+    CHECK(exL.mvImagePyramid.size() == 8 && exL.mvImagePyramid[0].empty(), "mvImagePyramid is filled on demand (keepPyramid = false)");
+    CHECK(exL.ImagePyramid()[0].cols == W && exL.mvImagePyramid[0].rows == H && exL.mvImagePyramid[7].cols == 179, "ImagePyramid()");
     scale_tables(F.mvScaleFactors, F.mvLevelSigma2, F.mvInvLevelSigma2);
     F.mfLogScaleFactor = std::log(1.2f);
     F.mbf = 40.f; F.mb = 40.f / Frame::fx;

@@ -54,13 +54,15 @@ def test_cpp_adapters_end_to_end(tmp_path):
     nk = int(take(np.int32, 1)[0])
     kps = take(E.KP_DTYPE, nk)
     desc = take(np.uint8, nk * 32).reshape(nk, 32)
-    pyr = take(np.int32, 3)
+    pyr = take(np.int32, 5)
+    eager_same = int(take(np.int32, 1)[0])
     dd = int(take(np.int32, 1)[0])
     untouched = int(take(np.int32, 1)[0])
     ext = E.ORBextractor(1000, 1.2, 8, 20, 7)
     k2, d2 = ext(img)
     assert np.array_equal(kps, k2) and np.array_equal(desc, d2)
-    assert list(pyr) == [480, 640, 179]               # mvImagePyramid[l] is the w x h view (border lives around it)
+    assert list(pyr) == [480, 640, 179, 1, 0]         # mvImagePyramid[l] is the w x h view (border lives around it); empty until asked for; 0 wrong border pixels
+    assert eager_same == 1                            # keepPyramid = true: filled by operator() itself
     assert dd == int(np.unpackbits(desc[0] ^ desc[1]).sum())
     assert untouched == 3
     # ---- ORBmatcher::SearchByProjection over the extractor's own keypoints: (almost) every point re-finds itself

@@ -116,14 +116,34 @@ def test_full_batch64_properties(gpu, oracle, B):
         assert np.array_equal(k1[f], okps) and np.array_equal(d1[f], odesc), "frame %d of %d" % (f, B)
 
 
-def test_mvImagePyramid_has_reference_border(gpu):
+def test_mvImagePyramid_has_reference_border(gpu, oracle):
+    """eao_orb_pyramid (one launch into the handle's pinned block) against the oracle's level images padded with numpy's BORDER_REFLECT_101, every level,
+    every pixel; then eao_orb_extract_ref (what the class-surface adapter calls) with the pyramid exported behind the extraction itself."""
     ext = gpu.ORBextractor(1000, 1.2, 8, 20, 7)
     img = synth.synth_frame(3)
-    ext(img)
+    k0, d0 = ext(img)
     pyr = ext.mvImagePyramid
     assert pyr[0].shape == (480 + 38, 640 + 38)
     assert np.array_equal(pyr[0][19:-19, 19:-19], img)
     assert np.array_equal(pyr[0][0, 19:-19], img[19])      # BORDER_REFLECT_101
+    ref = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    ref.extract(img)
+    for l in range(8):
+        assert np.array_equal(pyr[l], np.pad(ref.level_image(l), 19, mode="reflect")), "level %d" % l
+    for l, lv in enumerate(ext.image_pyramid(3)):             # another border width, asked for on demand
+        assert np.array_equal(lv, np.pad(ref.level_image(l), 3, mode="reflect")), "level %d, border 3" % l
+    ext.set_keep_pyramid(19)
+    img2 = synth.synth_frame(4)
+    k2, d2 = ext.extract_ref(img2)
+    ok2, od2 = ref.extract(img2)
+    assert np.array_equal(k2, ok2) and np.array_equal(d2, od2)
+    for l, lv in enumerate(ext.mvImagePyramid):              # exported in the extraction's own stream pass: the call only hands out views
+        assert np.array_equal(lv, np.pad(ref.level_image(l), 19, mode="reflect")), "level %d (kept)" % l
+    ext.set_keep_pyramid(-1)
+    k1, d1 = ext.extract_ref(img)
+    assert np.array_equal(k1, k0) and np.array_equal(d1, d0)
+    e, _ = ext.extract_ref(np.zeros((0, 0), np.uint8))
+    assert len(e) == 0
 
 
 def test_random_configurations(gpu, oracle):

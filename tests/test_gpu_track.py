@@ -446,7 +446,7 @@ def test_motion_model_stage_rejects_bad_input():
     big = {k: (np.concatenate([v] * 8) if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == 200 else v) for k, v in last.items()}
     with pytest.raises(E.EaoError):
         trk.track_with_motion_model(*args, cur["Tcw"], big, 15.0)      # 1600 last-frame keypoints > max_keypoints 1024
-    assert E.load().eao_abi_version() == 4
+    assert E.load().eao_abi_version() == 5
 
 
 def _bow_case(seed, n, n_nodes, flip=0.05, clutter=0.15, mono=False):

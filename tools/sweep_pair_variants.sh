@@ -22,3 +22,5 @@ PY
   call=$(python3 tools/dbg_ba_batch.py 2>&1 | grep "eao_local_ba_batch" | head -1 | sed 's/.*min \([0-9.]*\) median \([0-9.]*\).*/min \1 median \2 ms/')
   echo "$occ waves per SIMD: $line us; default call: $call" | tee -a $OUT
 done
+# leave the DEFAULT library installed (the loop above overwrote it with the last -DEAO_PAIR_OCC variant)
+rm -f $C/build/lm.o && make -C $C
