@@ -66,9 +66,11 @@ public:
     template <class FrameT, class MapPointT>
     int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3) {
         const int M = (int)vpMapPoints.size();
-        std::vector<float> px(M), py(M), pxr(M), vc(M);
-        std::vector<int32_t> lvl(M), match(M, -1);
-        std::vector<uint8_t> skip(M), desc((size_t)M * 32);
+        static thread_local std::vector<float> px, py, pxr, vc;
+        static thread_local std::vector<int32_t> lvl, match;
+        static thread_local std::vector<uint8_t> skip, desc;
+        static thread_local FrameArrays fa;
+        px.resize(M); py.resize(M); pxr.resize(M); vc.resize(M); lvl.resize(M); match.assign(M, -1); skip.resize(M); desc.resize((size_t)M * 32);
         for (int i = 0; i < M; i++) {
             MapPointT* pMP = vpMapPoints[i];
             skip[i] = (!pMP->mbTrackInView || pMP->isBad()) ? 1 : 0;
@@ -76,7 +78,6 @@ public:
             lvl[i] = pMP->mnTrackScaleLevel;
             if (!skip[i]) { const cv::Mat d = pMP->GetDescriptor(); std::memcpy(&desc[(size_t)i * 32], d.ptr(0), 32); }
         }
-        FrameArrays fa;
         const eao_frame_view v = view(F, fa);
         int nm = 0;
         check(eao_search_by_projection_points(&v, M, px.data(), py.data(), pxr.data(), vc.data(), lvl.data(), desc.data(), skip.data(),
@@ -89,9 +90,11 @@ public:
     template <class FrameT>
     int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono) {
         const int NL = LastFrame.N;
-        std::vector<uint8_t> valid(NL), desc((size_t)NL * 32);
-        std::vector<float> Xw((size_t)NL * 3), ang(NL);
-        std::vector<int32_t> oct(NL), cm(CurrentFrame.N, -1);
+        static thread_local std::vector<uint8_t> valid, desc;
+        static thread_local std::vector<float> Xw, ang;
+        static thread_local std::vector<int32_t> oct, cm;
+        static thread_local FrameArrays fa;
+        valid.resize(NL); desc.resize((size_t)NL * 32); Xw.resize((size_t)NL * 3); ang.resize(NL); oct.resize(NL); cm.assign(CurrentFrame.N, -1);
         for (int i = 0; i < NL; i++) {
             auto* pMP = LastFrame.mvpMapPoints[i];
             valid[i] = (pMP && !LastFrame.mvbOutlier[i]) ? 1 : 0;
@@ -104,7 +107,6 @@ public:
         }
         float Tc[16], Tl[16];
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { Tc[r * 4 + c] = CurrentFrame.mTcw.template at<float>(r, c); Tl[r * 4 + c] = LastFrame.mTcw.template at<float>(r, c); }
-        FrameArrays fa;
         const eao_frame_view v = view(CurrentFrame, fa);
         int nm = 0;
         check(eao_search_by_projection_frames(&v, Tc, Tl, NL, valid.data(), Xw.data(), desc.data(), oct.data(), ang.data(), CurrentFrame.fx,
@@ -166,19 +168,21 @@ public:
         const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
         vpMapPointMatches = std::vector<MapPointT*>(F.N, static_cast<MapPointT*>(NULL));
         const int n1 = (int)vpMapPointsKF.size(), n2 = F.N;
-        std::vector<uint8_t> valid1(n1), d1((size_t)n1 * 32), d2((size_t)n2 * 32);
-        std::vector<float> a1(n1), a2(n2);
+        static thread_local std::vector<uint8_t> valid1, d1, d2;
+        static thread_local std::vector<float> a1, a2;
+        static thread_local FeatVecArrays f1, f2;
+        valid1.resize(n1); a1.resize(n1); a2.resize(n2);
         for (int i = 0; i < n1; i++) {
             valid1[i] = (vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad()) ? 1 : 0;
             a1[i] = pKF->mvKeysUn[i].angle;
-            std::memcpy(&d1[(size_t)i * 32], pKF->mDescriptors.ptr(i), 32);
         }
-        for (int j = 0; j < n2; j++) { a2[j] = F.mvKeys[j].angle; std::memcpy(&d2[(size_t)j * 32], F.mDescriptors.ptr(j), 32); }
-        FeatVecArrays f1, f2;
+        for (int j = 0; j < n2; j++) a2[j] = F.mvKeys[j].angle;
+        const uint8_t* p1 = rows32(pKF->mDescriptors, n1, d1);
+        const uint8_t* p2 = rows32(F.mDescriptors, n2, d2);
         const eao_feature_vector fv1 = flatten(pKF->mFeatVec, f1), fv2 = flatten(F.mFeatVec, f2);
         std::vector<int32_t> m12(n1, -1);
         int nm = 0;
-        check(eao_search_by_bow(0, n1, d1.data(), a1.data(), valid1.data(), &fv1, n2, d2.data(), a2.data(), nullptr, &fv2, mfNNratio,
+        check(eao_search_by_bow(0, n1, p1, a1.data(), valid1.data(), &fv1, n2, p2, a2.data(), nullptr, &fv2, mfNNratio,
                                 mbCheckOrientation ? 1 : 0, m12.data(), &nm), "eao_search_by_bow");
         for (int i = 0; i < n1; i++) if (m12[i] >= 0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
         return nm;
@@ -559,6 +563,15 @@ protected:
         f.n_nodes = (int32_t)a.id.size(); f.node_id = a.id.data(); f.node_start = a.start.data(); f.index = a.index.data();
         return f;
     }
+    // n rows of 32 descriptor bytes as ONE block: the matrix itself when its rows are contiguous (Frame / KeyFrame::mDescriptors come out of one
+    // create(n, 32, CV_8U)), a packed copy in `pack` otherwise
+    static const uint8_t* rows32(const cv::Mat& D, int n, std::vector<uint8_t>& pack) {
+        if (n == 0) return nullptr;
+        if (D.isContinuous()) return D.ptr(0);
+        pack.resize((size_t)n * 32);
+        for (int i = 0; i < n; i++) std::memcpy(&pack[(size_t)i * 32], D.ptr(i), 32);
+        return pack.data();
+    }
     static void mat44(const cv::Mat& M, float* out) {
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[r * 4 + c] = M.at<float>(r, c);
     }
@@ -571,18 +584,18 @@ protected:
     template <class KeyFrameT>
     static eao_frame_view kfview(KeyFrameT& K, FrameArrays& a) {
         const int N = K.N;
-        a.x.resize(N); a.y.resize(N); a.ang.resize(N); a.ur.resize(N); a.oct.resize(N); a.occ.assign(N, 0); a.desc.resize((size_t)N * 32);
+        a.x.resize(N); a.y.resize(N); a.ang.resize(N); a.ur.resize(N); a.oct.resize(N); a.occ.assign(N, 0);
         for (int i = 0; i < N; i++) {
             a.x[i] = K.mvKeysUn[i].pt.x; a.y[i] = K.mvKeysUn[i].pt.y; a.ang[i] = K.mvKeysUn[i].angle; a.oct[i] = K.mvKeysUn[i].octave;
             a.ur[i] = K.mvuRight[i];
-            std::memcpy(&a.desc[(size_t)i * 32], K.mDescriptors.ptr(i), 32);
         }
+        const uint8_t* descPtr = rows32(K.mDescriptors, N, a.desc);
         a.sf.assign(K.mvScaleFactors.begin(), K.mvScaleFactors.end());
         a.s2.assign(K.mvLevelSigma2.begin(), K.mvLevelSigma2.end());
         a.is2.assign(K.mvInvLevelSigma2.begin(), K.mvInvLevelSigma2.end());
         eao_frame_view v;
         v.n = N; v.kp_x = a.x.data(); v.kp_y = a.y.data(); v.kp_octave = a.oct.data(); v.kp_angle = a.ang.data(); v.u_right = a.ur.data();
-        v.descriptors = a.desc.data(); v.occupied = a.occ.data();
+        v.descriptors = descPtr; v.occupied = a.occ.data();
         v.min_x = K.mnMinX; v.min_y = K.mnMinY; v.max_x = K.mnMaxX; v.max_y = K.mnMaxY;
         v.grid_inv_w = K.mfGridElementWidthInv; v.grid_inv_h = K.mfGridElementHeightInv;
         v.grid_cols = K.mnGridCols; v.grid_rows = K.mnGridRows;
@@ -594,17 +607,17 @@ protected:
     template <class FrameT>
     static eao_frame_view view(FrameT& F, FrameArrays& a) {
         const int N = F.N;
-        a.x.resize(N); a.y.resize(N); a.ang.resize(N); a.ur.resize(N); a.oct.resize(N); a.occ.resize(N); a.desc.resize((size_t)N * 32);
+        a.x.resize(N); a.y.resize(N); a.ang.resize(N); a.ur.resize(N); a.oct.resize(N); a.occ.resize(N);
         for (int i = 0; i < N; i++) {
             a.x[i] = F.mvKeysUn[i].pt.x; a.y[i] = F.mvKeysUn[i].pt.y; a.ang[i] = F.mvKeysUn[i].angle; a.oct[i] = F.mvKeysUn[i].octave;
             a.ur[i] = F.mvuRight[i];
             a.occ[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;
-            std::memcpy(&a.desc[(size_t)i * 32], F.mDescriptors.ptr(i), 32);
         }
+        const uint8_t* descPtr = rows32(F.mDescriptors, N, a.desc);
         a.sf.assign(F.mvScaleFactors.begin(), F.mvScaleFactors.end());
         eao_frame_view v;
         v.n = N; v.kp_x = a.x.data(); v.kp_y = a.y.data(); v.kp_octave = a.oct.data(); v.kp_angle = a.ang.data(); v.u_right = a.ur.data();
-        v.descriptors = a.desc.data(); v.occupied = a.occ.data();
+        v.descriptors = descPtr; v.occupied = a.occ.data();
         v.min_x = FrameT::mnMinX; v.min_y = FrameT::mnMinY; v.max_x = FrameT::mnMaxX; v.max_y = FrameT::mnMaxY;
         v.grid_inv_w = FrameT::mfGridElementWidthInv; v.grid_inv_h = FrameT::mfGridElementHeightInv;
         v.grid_cols = 64; v.grid_rows = 48;   // FRAME_GRID_COLS / FRAME_GRID_ROWS (include/Frame.h:89-90)

@@ -82,6 +82,7 @@ struct PoseJob {
 template <class MapPointT, class FrameT>
 bool gather_pose(FrameT* pFrame, PoseJob& j) {
     const int N = pFrame->N;
+    j.slot.reserve(N); j.Xw.reserve(3 * (size_t)N); j.obs.reserve(3 * (size_t)N); j.inv.reserve(N);
     {
         std::unique_lock<std::mutex> lock(MapPointT::mGlobalMutex);
         for (int i = 0; i < N; i++) {
@@ -150,112 +151,144 @@ std::vector<int> PoseOptimizationBatch(const std::vector<FrameT*>& frames) {
 }
 
 // ---- Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*) ------------------------------------------------
+// Round 5 (the class surface timed -- the first version of this walk cost 2.2 ms around a 1.04 ms library call on the 20 + 4 keyframe x
+// 3000 point window): every map point's observations are read ONCE (upstream copies the std::map twice per point, src/Optimizer.cc:722 and :836) into flat
+// per-thread arrays that also serve the fixed-camera pass, the edge pass and the write-back; the point -> index map is the rank of the point's mnId (one sort
+// of 3000 pairs, no tree with 15 000 look-ups); nothing is allocated per call after the first.  What remains is what the reference's own accessors cost -- a
+// mutex and a cv::Mat clone per GetWorldPos / GetPose, a std::map copy per GetObservations, SetWorldPos -- and tests/cpp/adapter_bench.cpp reports that floor.
+template <class KeyFrameT, class MapPointT>
+struct LbaScratch {
+    struct Obs { KeyFrameT* kf; size_t idx; };
+    struct CamRec { KeyFrameT* kf; bool fixed; bool local; };
+    std::vector<KeyFrameT*> localKFs, fixedKFs;
+    std::vector<MapPointT*> localMPs;
+    std::vector<Obs> obs;                 // all observations, point after point in localMPs order
+    std::vector<int32_t> obsStart;        // localMPs.size() + 1
+    std::vector<CamRec> cams;
+    std::vector<std::pair<unsigned long, int32_t> > order;
+    std::vector<int32_t> rank, eCam, ePt;
+    std::vector<float> camT, xyz, eObs, eInv, camOut, xyzOut;
+    std::vector<uint8_t> camFixed, erase;
+    std::vector<KeyFrameT*> eKF;
+    std::vector<MapPointT*> eMP, pts;
+};
+
 template <class MapPointT, class KeyFrameT, class MapT>
 void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
-    // the local window: this keyframe + its covisible ones; every map point they see; every other observer is fixed
-    std::list<KeyFrameT*> localKFs;
-    localKFs.push_back(pKF);
-    pKF->mnBALocalForKF = pKF->mnId;
+    static thread_local LbaScratch<KeyFrameT, MapPointT> S;
+    const unsigned long me = pKF->mnId;
+    // the local window: this keyframe + its covisible ones; every map point they see; every other observer is fixed (src/Optimizer.cc:680-738)
+    S.localKFs.clear(); S.fixedKFs.clear(); S.localMPs.clear(); S.obs.clear(); S.obsStart.assign(1, 0);
+    S.localKFs.push_back(pKF);
+    pKF->mnBALocalForKF = me;
     for (KeyFrameT* n : pKF->GetVectorCovisibleKeyFrames()) {
-        n->mnBALocalForKF = pKF->mnId;
-        if (!n->isBad()) localKFs.push_back(n);
+        n->mnBALocalForKF = me;
+        if (!n->isBad()) S.localKFs.push_back(n);
     }
-    std::list<MapPointT*> localMPs;
-    for (KeyFrameT* kf : localKFs)
+    for (KeyFrameT* kf : S.localKFs)
         for (MapPointT* mp : kf->GetMapPointMatches())
-            if (mp && !mp->isBad() && mp->mnBALocalForKF != pKF->mnId) {
-                localMPs.push_back(mp);
-                mp->mnBALocalForKF = pKF->mnId;
+            if (mp && !mp->isBad() && mp->mnBALocalForKF != me) {
+                S.localMPs.push_back(mp);
+                mp->mnBALocalForKF = me;
             }
-    std::list<KeyFrameT*> fixedKFs;
-    for (MapPointT* mp : localMPs) {
-        const std::map<KeyFrameT*, size_t> seenBy = mp->GetObservations();
+    const size_t nP = S.localMPs.size();
+    for (MapPointT* mp : S.localMPs) {
+        const std::map<KeyFrameT*, size_t> seenBy = mp->GetObservations();      // the ONE copy per point
         for (const auto& ob : seenBy) {
             KeyFrameT* kf = ob.first;
-            if (kf->mnBALocalForKF != pKF->mnId && kf->mnBAFixedForKF != pKF->mnId) {
-                kf->mnBAFixedForKF = pKF->mnId;
-                if (!kf->isBad()) fixedKFs.push_back(kf);
+            if (kf->mnBALocalForKF != me && kf->mnBAFixedForKF != me) {
+                kf->mnBAFixedForKF = me;
+                if (!kf->isBad()) S.fixedKFs.push_back(kf);
             }
+            S.obs.push_back({kf, ob.second});
         }
+        S.obsStart.push_back((int32_t)S.obs.size());
     }
     // flatten: cameras / points in ascending mnId (= g2o's vertex order), edges in the reference's insertion order
-    struct CamRec { KeyFrameT* kf; bool fixed; };
-    std::vector<CamRec> cams;
-    for (KeyFrameT* kf : localKFs) cams.push_back({kf, kf->mnId == 0});
-    for (KeyFrameT* kf : fixedKFs) cams.push_back({kf, true});
-    std::sort(cams.begin(), cams.end(), [](const CamRec& a, const CamRec& b) { return a.kf->mnId < b.kf->mnId; });
-    std::map<KeyFrameT*, int> camIndex;
-    for (size_t i = 0; i < cams.size(); i++) camIndex[cams[i].kf] = (int)i;
-    std::vector<MapPointT*> pts(localMPs.begin(), localMPs.end());
-    std::sort(pts.begin(), pts.end(), [](MapPointT* a, MapPointT* b) { return a->mnId < b->mnId; });
-    std::map<MapPointT*, int> ptIndex;
-    for (size_t i = 0; i < pts.size(); i++) ptIndex[pts[i]] = (int)i;
+    S.cams.clear();
+    for (KeyFrameT* kf : S.localKFs) S.cams.push_back({kf, kf->mnId == 0, true});
+    for (KeyFrameT* kf : S.fixedKFs) S.cams.push_back({kf, true, false});
+    std::sort(S.cams.begin(), S.cams.end(), [](const typename LbaScratch<KeyFrameT, MapPointT>::CamRec& a, const typename LbaScratch<KeyFrameT, MapPointT>::CamRec& b) { return a.kf->mnId < b.kf->mnId; });
+    const size_t nC = S.cams.size();
+    // camera index of a keyframe: the window holds a few dozen cameras -- a sorted array of (pointer, index) pairs, binary search
+    std::vector<std::pair<KeyFrameT*, int32_t> > camIndex(nC);      // (nC entries: a few hundred bytes)
+    for (size_t i = 0; i < nC; i++) camIndex[i] = std::make_pair(S.cams[i].kf, (int32_t)i);
+    std::sort(camIndex.begin(), camIndex.end());
+    auto cam_of = [&](KeyFrameT* kf) -> int32_t {
+        const auto it = std::lower_bound(camIndex.begin(), camIndex.end(), std::make_pair(kf, (int32_t)-1));
+        return (it != camIndex.end() && it->first == kf) ? it->second : -1;
+    };
+    // point index = rank of the point's mnId among the window's points
+    S.order.resize(nP);
+    for (size_t k = 0; k < nP; k++) S.order[k] = std::make_pair((unsigned long)S.localMPs[k]->mnId, (int32_t)k);
+    std::sort(S.order.begin(), S.order.end());
+    S.rank.resize(nP); S.pts.resize(nP);
+    for (size_t i = 0; i < nP; i++) { S.rank[S.order[i].second] = (int32_t)i; S.pts[i] = S.localMPs[S.order[i].second]; }
 
-    std::vector<float> camT(cams.size() * 16), xyz(pts.size() * 3), obs, inv;
-    std::vector<uint8_t> camFixed(cams.size());
-    std::vector<int32_t> eCam, ePt;
-    std::vector<KeyFrameT*> eKF;
-    std::vector<MapPointT*> eMP;
-    for (size_t i = 0; i < cams.size(); i++) {
-        const cv::Mat T = cams[i].kf->GetPose();
-        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) camT[i * 16 + r * 4 + c] = T.template at<float>(r, c);
-        camFixed[i] = cams[i].fixed ? 1 : 0;
+    S.camT.resize(nC * 16); S.camFixed.resize(nC); S.xyz.resize(nP * 3);
+    // isBad() of an observing keyframe (upstream asks it per EDGE, src/Optimizer.cc:843: 15 000 mutex round trips on this window) is asked once per CAMERA here
+    std::vector<uint8_t> camBad(nC);
+    for (size_t i = 0; i < nC; i++) {
+        camBad[i] = S.cams[i].kf->isBad() ? 1 : 0;
+        const cv::Mat T = S.cams[i].kf->GetPose();
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) S.camT[i * 16 + r * 4 + c] = T.template at<float>(r, c);
+        S.camFixed[i] = S.cams[i].fixed ? 1 : 0;
     }
-    for (size_t i = 0; i < pts.size(); i++) {
-        const cv::Mat P = pts[i]->GetWorldPos();
-        for (int k = 0; k < 3; k++) xyz[i * 3 + k] = P.template at<float>(k);
+    for (size_t i = 0; i < nP; i++) {
+        const cv::Mat P = S.pts[i]->GetWorldPos();
+        for (int k = 0; k < 3; k++) S.xyz[i * 3 + k] = P.template at<float>(k);
     }
-    float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy, bf = pKF->mbf;
-    for (MapPointT* mp : localMPs) {
-        const std::map<KeyFrameT*, size_t> seenBy = mp->GetObservations();
-        for (const auto& ob : seenBy) {
-            KeyFrameT* kf = ob.first;
-            if (kf->isBad()) continue;
-            auto ci = camIndex.find(kf);
-            if (ci == camIndex.end()) continue;   // upstream would dereference a null vertex here
+    const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy, bf = pKF->mbf;
+    S.eCam.clear(); S.ePt.clear(); S.eObs.clear(); S.eInv.clear(); S.eKF.clear(); S.eMP.clear();
+    for (size_t k = 0; k < nP; k++) {
+        MapPointT* mp = S.localMPs[k];
+        for (int32_t o = S.obsStart[k]; o < S.obsStart[k + 1]; o++) {
+            KeyFrameT* kf = S.obs[o].kf;
+            const int32_t ci = cam_of(kf);
+            if (ci < 0 || camBad[ci]) continue;   // a bad keyframe (upstream: `continue`); one outside the window: upstream would dereference a null vertex here
             // upstream copies the intrinsics into every edge from ITS keyframe (e->fx = pKFi->fx ..., src/Optimizer.cc:858-898); the
             // C-ABI carries one set per window, which is what this fork's single-camera Frame / KeyFrame statics amount to --
             // a window that mixes cameras is refused here rather than optimised with the wrong projection
             if (kf->fx != fx || kf->fy != fy || kf->cx != cx || kf->cy != cy || kf->mbf != bf)
                 throw std::runtime_error("eaofusion::LocalBundleAdjustment: keyframes of the window do not share fx, fy, cx, cy, mbf");
-            const cv::KeyPoint& kpUn = kf->mvKeysUn[ob.second];
-            eCam.push_back(ci->second); ePt.push_back(ptIndex[mp]);
-            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(kf->mvuRight[ob.second]);
-            inv.push_back(kf->mvInvLevelSigma2[kpUn.octave]);
-            eKF.push_back(kf); eMP.push_back(mp);
+            const size_t idx = S.obs[o].idx;
+            const cv::KeyPoint& kpUn = kf->mvKeysUn[idx];
+            S.eCam.push_back(ci); S.ePt.push_back(S.rank[k]);
+            S.eObs.push_back(kpUn.pt.x); S.eObs.push_back(kpUn.pt.y); S.eObs.push_back(kf->mvuRight[idx]);
+            S.eInv.push_back(kf->mvInvLevelSigma2[kpUn.octave]);
+            S.eKF.push_back(kf); S.eMP.push_back(mp);
         }
     }
     if (pbStopFlag && *pbStopFlag) return;
+    const size_t nE = S.eCam.size();
     eao_ba_problem P;
-    P.n_cams = (int)cams.size(); P.n_points = (int)pts.size(); P.n_edges = (int)eCam.size();
-    P.cam_Tcw = camT.data(); P.cam_fixed = camFixed.data(); P.points = xyz.data();
-    P.edge_cam = eCam.data(); P.edge_point = ePt.data(); P.edge_obs = obs.data(); P.edge_inv_sigma2 = inv.data();
+    P.n_cams = (int)nC; P.n_points = (int)nP; P.n_edges = (int)nE;
+    P.cam_Tcw = S.camT.data(); P.cam_fixed = S.camFixed.data(); P.points = S.xyz.data();
+    P.edge_cam = S.eCam.data(); P.edge_point = S.ePt.data(); P.edge_obs = S.eObs.data(); P.edge_inv_sigma2 = S.eInv.data();
     P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy; P.bf = bf; P.its_first = 5; P.its_second = 10;
-    std::vector<float> camOut(camT.size()), xyzOut(xyz.size());
-    std::vector<uint8_t> erase(std::max<size_t>(eCam.size(), 1));
+    S.camOut.resize(nC * 16); S.xyzOut.resize(nP * 3); S.erase.assign(std::max<size_t>(nE, 1), 0);
     eao_ba_result R;
-    R.cam_Tcw = camOut.data(); R.points = xyzOut.data(); R.edge_outlier = erase.data();
+    R.cam_Tcw = S.camOut.data(); R.points = S.xyzOut.data(); R.edge_outlier = S.erase.data();
     static_assert(sizeof(bool) == 1, "bool* abort flag is polled as a byte");
     check(eao_local_ba(&P, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), &R), "eao_local_ba");
     if (R.aborted) return;
 
     std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
-    for (size_t e = 0; e < eCam.size(); e++) {
-        if (!erase[e] || eMP[e]->isBad()) continue;
-        eKF[e]->EraseMapPointMatch(eMP[e]);
-        eMP[e]->EraseObservation(eKF[e]);
+    for (size_t e = 0; e < nE; e++) {
+        if (!S.erase[e] || S.eMP[e]->isBad()) continue;
+        S.eKF[e]->EraseMapPointMatch(S.eMP[e]);
+        S.eMP[e]->EraseObservation(S.eKF[e]);
     }
-    for (size_t i = 0; i < cams.size(); i++) {
-        if (cams[i].kf->mnBALocalForKF != pKF->mnId) continue;   // only local keyframes are written back
-        cv::Mat pose(4, 4, CV_32F);
-        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = camOut[i * 16 + r * 4 + c];
-        cams[i].kf->SetPose(pose);
+    cv::Mat pose(4, 4, CV_32F), pos(3, 1, CV_32F);      // (SetPose / SetWorldPos copy their argument, src/KeyFrame.cc:74-86, src/MapPoint.cc:68-73)
+    for (size_t i = 0; i < nC; i++) {
+        if (!S.cams[i].local) continue;   // only local keyframes are written back
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = S.camOut[i * 16 + r * 4 + c];
+        S.cams[i].kf->SetPose(pose);
     }
-    for (size_t i = 0; i < pts.size(); i++) {
-        cv::Mat pos(3, 1, CV_32F);
-        for (int k = 0; k < 3; k++) pos.template at<float>(k) = xyzOut[i * 3 + k];
-        pts[i]->SetWorldPos(pos);
-        pts[i]->UpdateNormalAndDepth();
+    for (size_t i = 0; i < nP; i++) {
+        for (int k = 0; k < 3; k++) pos.template at<float>(k) = S.xyzOut[i * 3 + k];
+        S.pts[i]->SetWorldPos(pos);
+        S.pts[i]->UpdateNormalAndDepth();
     }
 }
 

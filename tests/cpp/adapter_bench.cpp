@@ -31,7 +31,7 @@ struct Scope {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     ~Scope() { inside_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); }
 };
-template <class... A> eao_status orb_extract(A... a) { Scope s; return ::eao_orb_extract(a...); }
+template <class... A> eao_status orb_extract(A... a) { Scope s; return ::eao_orb_extract_ref(a...); }
 template <class... A> eao_status orb_pyramid(A... a) { Scope s; return ::eao_orb_pyramid(a...); }
 template <class... A> eao_status sbp_points(A... a) { Scope s; return ::eao_search_by_projection_points(a...); }
 template <class... A> eao_status sbp_frames(A... a) { Scope s; return ::eao_search_by_projection_frames(a...); }
@@ -39,7 +39,7 @@ template <class... A> eao_status sbow(A... a) { Scope s; return ::eao_search_by_
 template <class... A> eao_status pose(A... a) { Scope s; return ::eao_pose_optimization(a...); }
 template <class... A> eao_status lba(A... a) { Scope s; return ::eao_local_ba(a...); }
 }  // namespace cabi
-#define eao_orb_extract cabi::orb_extract
+#define eao_orb_extract_ref cabi::orb_extract
 #define eao_orb_pyramid cabi::orb_pyramid
 #define eao_search_by_projection_points cabi::sbp_points
 #define eao_search_by_projection_frames cabi::sbp_frames
@@ -49,7 +49,7 @@ template <class... A> eao_status lba(A... a) { Scope s; return ::eao_local_ba(a.
 #include <eaofusion/ORBextractor.h>
 #include <eaofusion/ORBmatcher.h>
 #include <eaofusion/OptimizerImpl.h>
-#undef eao_orb_extract
+#undef eao_orb_extract_ref
 #undef eao_orb_pyramid
 #undef eao_search_by_projection_points
 #undef eao_search_by_projection_frames
@@ -180,10 +180,7 @@ int main(int argc, char** argv) {
         Frame F;
         F.N = n; F.fx = K[0]; F.fy = K[1]; F.cx = K[2]; F.cy = K[3]; F.mbf = K[4];
         F.mvKeysUn.resize(n); F.mvuRight.resize(n); F.mvpMapPoints.resize(n); F.mvbOutlier.assign(n, false);
-        F.mvInvLevelSigma2.resize(8);
-        for (int l = 0; l < 8; l++) F.mvInvLevelSigma2[l] = 0;
-        // the information values come per edge; octave = the index of a table that holds them (one level per distinct value is not needed: n levels)
-        F.mvInvLevelSigma2.assign(inv.begin(), inv.end());
+        F.mvInvLevelSigma2.assign(inv.begin(), inv.end());      // the information values come per correspondence: keypoint i names "level" i of this table
         for (int i = 0; i < n; i++) {
             mps[i].mWorldPos = colN(&Xw[3 * (size_t)i], 3);
             F.mvKeysUn[i].pt.x = obs[3 * (size_t)i]; F.mvKeysUn[i].pt.y = obs[3 * (size_t)i + 1]; F.mvKeysUn[i].octave = i;
@@ -232,7 +229,33 @@ int main(int argc, char** argv) {
         };
         bool stop = false;
         const Stat s = measure(3, 15, build, [&] { eaofusion::LocalBundleAdjustment<MapPoint>(pKF, &stop, &map); });
-        std::snprintf(more, sizeof more, "\"keyframes\": %d, \"map_points\": %d, \"edges\": %d", nc, np, ne);
+        // What ANY implementation behind this signature pays to the reference's object model: exactly the accessor calls upstream's own function makes on this
+        // window (src/Optimizer.cc:680-738, 800-905, 1085-1137) -- GetVectorCovisibleKeyFrames, GetMapPointMatches, isBad, GetObservations twice per point,
+        // GetPose, GetWorldPos, SetPose, SetWorldPos, UpdateNormalAndDepth -- with nothing between them (no graph, no optimisation).
+        volatile double sink = 0;
+        auto floor_walk = [&] {
+            double acc = 0;
+            std::vector<KeyFrame*> local(1, pKF), fixedK;
+            pKF->mnBALocalForKF = pKF->mnId;
+            for (KeyFrame* n : pKF->GetVectorCovisibleKeyFrames()) { n->mnBALocalForKF = pKF->mnId; if (!n->isBad()) local.push_back(n); }
+            std::vector<MapPoint*> lm;
+            for (KeyFrame* k : local) for (MapPoint* m : k->GetMapPointMatches()) if (m && !m->isBad() && m->mnBALocalForKF != pKF->mnId) { lm.push_back(m); m->mnBALocalForKF = pKF->mnId; }
+            for (MapPoint* m : lm) { const std::map<KeyFrame*, size_t> o = m->GetObservations(); for (const auto& ob : o) if (ob.first->mnBALocalForKF != pKF->mnId && ob.first->mnBAFixedForKF != pKF->mnId) { ob.first->mnBAFixedForKF = pKF->mnId; if (!ob.first->isBad()) fixedK.push_back(ob.first); } }
+            for (KeyFrame* k : local) acc += k->GetPose().at<float>(0, 0);
+            for (KeyFrame* k : fixedK) acc += k->GetPose().at<float>(0, 0);
+            for (MapPoint* m : lm) {
+                acc += m->GetWorldPos().at<float>(0);
+                const std::map<KeyFrame*, size_t> o = m->GetObservations();
+                for (const auto& ob : o) if (!ob.first->isBad()) acc += ob.first->mvKeysUn[ob.second].pt.x + ob.first->mvuRight[ob.second];
+            }
+            std::unique_lock<std::mutex> lock(map.mMutexMapUpdate);
+            for (KeyFrame* k : local) { cv::Mat T = k->GetPose(); k->SetPose(T); }
+            for (MapPoint* m : lm) { cv::Mat X = m->GetWorldPos(); m->SetWorldPos(X); m->UpdateNormalAndDepth(); }
+            sink = acc;
+        };
+        const Stat fl = measure(3, 15, build, floor_walk);
+        std::snprintf(more, sizeof more, "\"keyframes\": %d, \"map_points\": %d, \"edges\": %d, \"reference_accessor_walk_ms\": %.4f, \"adapter_overhead_beyond_accessor_walk_ms\": %.4f", nc, np, ne,
+                      fl.call_ms, s.call_ms - s.cabi_ms - fl.call_ms);
         emit("local_bundle_adjustment", s, more);
     }
     // ------------------------------------------------------------------ the two SearchByProjection variants of the tracking loop
