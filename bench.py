@@ -383,6 +383,7 @@ def flat_scalars(roofline, extra):
         put("gs_%s_ms" % name, lambda n=name: gs[n]["ms_per_call"])
         put("gs_%s_over_cpu" % name, lambda n=name: cg[n]["gpu_over_cpu_time"])
         put("gs_%s_handles_ms" % name, lambda n=name: gs[n]["ms_per_call_handles"])
+        put("gs_%s_handles_over_cpu" % name, lambda n=name: cg[n]["gpu_handles_over_cpu_time"])
     put("gs_triangulation_batch10_ms", lambda: gs["search_for_triangulation_batch"]["ms_per_call"])
     put("gs_fuse_batch10_ms", lambda: gs["fuse_search_batch"]["ms_per_call"])
     put("gs_triangulation_batch10_handles_ms", lambda: gs["search_for_triangulation_batch"]["ms_per_call_handles"])
@@ -1000,6 +1001,31 @@ def measure_extra(E, synth, torch, dev):
             mb, _ = time_calls(lambda: gS.fuse_search_batch([scS["K2"]] * nbS, 0, [pose15S] * nbS, scS["K"], scS["bf"], scS["points"], 3.0), reps=8)
             ms1, _ = time_calls(lambda: [gS.fuse_search(scS["K2"], 0, pose15S, scS["K"], scS["bf"], scS["points"], 3.0) for _ in range(nbS)], reps=8)
             gsr["fuse_search_batch"] = {"targets": nbS, "ms_per_call": round(mb, 4), "ms_ten_single_calls": round(ms1, 4)}
+            # ---- round 5: the same searches through KEYFRAME HANDLES (eao_kf_*): the keyframes live in HBM (uploaded once, outside the timed calls -- a keyframe is
+            #      searched many times), the vocabulary-node searches and Fuse select on the device; per call: per-call flags / points up, two launches, one table back
+            try:
+                gH = SR.product_handles()
+                h1, h2 = gH.handle(scS["K1"], scS["fv1"]), gH.handle(scS["K2"], scS["fv2"])
+                v1S, v2S = (scS["mp1"] >= 0).astype(np.uint8), (scS["mp2"] >= 0).astype(np.uint8)
+                hc = [("search_by_bow_kf_frame", lambda: gH.search_by_bow_h(0, h1, v1S, h2, None, 0.75, True)),
+                      ("search_by_bow_kf_kf", lambda: gH.search_by_bow_h(1, h1, v1S, h2, v2S, 0.8, True)),
+                      ("search_for_triangulation", lambda: gH.search_for_triangulation_h(h1, [h2], [scS["F12"]], [scS["ex"]], [scS["ey"]], 0, True)),
+                      ("fuse_search_pose", lambda: gH.fuse_search_h([h2], 0, [pose15S], scS["K"], scS["bf"], scS["points"], 3.0)),
+                      ("fuse_search_sim3", lambda: gH.fuse_search_h([h2], 1, [scS["Scw"].ravel()], scS["K"], scS["bf"], scS["points"], 3.0))]
+                for name, fn in hc:
+                    ms, r = time_calls(fn)
+                    gsr[name]["ms_per_call_handles"] = round(ms, 4)
+                    gsr[name]["matches_handles"] = int(np.sum(r[0]))
+                for name, fn in casesS:      # the list-based searches: frame resident, host replay as before
+                    if "ms_per_call_handles" not in gsr[name]:
+                        ms, r = time_calls(lambda: fn(gH))
+                        gsr[name]["ms_per_call_handles"] = round(ms, 4)
+                mb, _ = time_calls(lambda: gH.search_for_triangulation_h(h1, [h2] * nbS, Fs, exs, eys, 0, True), reps=8)
+                gsr["search_for_triangulation_batch"]["ms_per_call_handles"] = round(mb, 4)
+                mb, _ = time_calls(lambda: gH.fuse_search_h([h2] * nbS, 0, [pose15S] * nbS, scS["K"], scS["bf"], scS["points"], 3.0), reps=8)
+                gsr["fuse_search_batch"]["ms_per_call_handles"] = round(mb, 4)
+            except Exception as ex:  # noqa: BLE001
+                gsr["handles_error"] = repr(ex)
             gsr["note"] = ("median of 12 calls through the ctypes mirror (array wrapping included, ~0.02 ms); keypoints / map points: %d / %d; where a search loses to "
                            "one CPU thread (extra.cpu_guided_searches) it is the upload + launch + download + host replay of a sub-millisecond problem" % (len(scS["K2"]["kp_x"]), len(scS["points"]["active"])))
             extra["guided_searches"] = gsr
@@ -1229,7 +1255,8 @@ def measure_cpu(frames, synth, extra):
                 ms, r = time_calls(lambda: fn(oS), reps=8)
                 g = extra.get("guided_searches", {}).get(name, {})
                 cs[name] = {"ms_per_call": round(ms, 4), "matches": int(r[0]),
-                            "gpu_over_cpu_time": None if "ms_per_call" not in g else round(g["ms_per_call"] / ms, 2)}
+                            "gpu_over_cpu_time": None if "ms_per_call" not in g else round(g["ms_per_call"] / ms, 2),
+                            "gpu_handles_over_cpu_time": None if "ms_per_call_handles" not in g else round(g["ms_per_call_handles"] / ms, 2)}
             cs["note"] = ("oracle/search_cpu.cpp, 1 thread, median of 8 calls through its ctypes binding; gpu_over_cpu_time > 1: the product's call (upload + kernel + download + "
                           "host replay) takes LONGER than one CPU thread on this 1000-point problem")
             ex["cpu_guided_searches"] = cs

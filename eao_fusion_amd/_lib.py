@@ -108,6 +108,10 @@ SYMBOLS = {
     "eao_search_by_projection_sim3": None, "eao_search_by_projection_kf": None, "eao_search_by_bow": None,
     "eao_search_for_triangulation": None, "eao_search_for_initialization": None, "eao_fuse_search": None, "eao_search_by_sim3": None,
     "eao_search_for_triangulation_batch": None, "eao_fuse_search_batch": None,
+    # keyframe handles (round 5): argument lists live in search.py (HandleBinding)
+    "eao_keyframe_create": None, "eao_keyframe_update_points": None, "eao_keyframe_destroy": None, "eao_keyframe_size": None,
+    "eao_kf_search_by_bow": None, "eao_kf_search_for_triangulation": None, "eao_kf_fuse_search": None, "eao_kf_search_by_projection_sim3": None,
+    "eao_kf_search_by_projection_kf": None, "eao_kf_search_for_initialization": None, "eao_kf_search_by_sim3": None,
     # f1, second half (the device-resident tracked frame): argument lists live in tracker.py
     "eao_tracker_create": None, "eao_tracker_destroy": None, "eao_tracker_set_local_map": None, "eao_tracker_track_local_map": None,
     "eao_tracker_track_with_motion_model": None, "eao_tracker_track_reference_keyframe": None, "eao_abi_version": (_I, []),

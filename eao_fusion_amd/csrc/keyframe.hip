@@ -1,0 +1,713 @@
+// keyframe.hip -- keyframe handles for MI355X (gfx950): upload once, search many.
+//
+// LocalMapping::CreateNewMapPoints and SearchInNeighbors (reference src/LocalMapping.cc:211-290, 458-520) and LoopClosing hit the SAME keyframes again and
+// again -- ten or twenty neighbours per new keyframe, the same neighbours for the next one.  The host-array entry points of csrc/search.hip upload every frame
+// with every call, put it into grid order on the host and replay the selection there; on a 1000-keypoint problem three of them were slower than ONE CPU thread
+// (VERDICT r4 weak #7).  An eao_keyframe owns what the searches read of a keyframe (or of a Frame that is a search target) in HBM: keypoints, octaves, angles,
+// uRight, descriptors, the grid order Frame / KeyFrame::GetFeaturesInArea walks (PosInGrid + counting sort, once), the DBoW2 feature vector, the occupancy
+// (GetMapPoint(k) != NULL) and the scale tables.  On top of it:
+//   * the vocabulary-node searches -- SearchByBoW (KF, Frame) / (KF, KF), src/ORBmatcher.cc:159-288, 522-655, and SearchForTriangulation, :657-823 with
+//     CheckDistEpipolarLine :140-157 -- run WHOLLY on the device: a wavefront per common vocabulary node walks the node's side-1 features in upstream's order,
+//     the lanes share the side-2 features (two smallest (distance, position) keys = "first of equal distances wins", the node-local "already matched" set as a
+//     per-lane bit mask -- a keypoint lies in ONE node, so upstream's greedy rule never reaches across nodes), a second small launch per problem applies the
+//     rotation histogram and writes the match table into mapped host memory: two launches and one synchronisation per call, whatever the number of neighbours;
+//   * the search half of Fuse (:825-975, 977-1100) likewise: a wavefront per (target keyframe, map point) projects the point, walks its grid window in the
+//     resident grid order and keeps the best gated candidate -- no candidate lists, no host replay (a point's search does not depend on other points');
+//   * the list-based searches (loop / relocalisation projection, initialisation, SearchBySim3) keep their host replay (csrc/search.hip) but take the frame from
+//     the handle: only the queries travel.
+// Results are those of the host-array entry points, entry for entry (tests/test_gpu_search.py runs every case through both and against the CPU restatement).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "match_internal.h"
+#include "search_internal.h"
+
+namespace {
+
+constexpr int TH_LOW = refc::TH_LOW, HISTO = refc::HISTO_LENGTH;
+constexpr int kMaxProb = 16;      // problems (neighbours / targets) per launch: their records travel in the kernel arguments
+
+struct KfDev {      // what the kernels read of one keyframe: device addresses inside the handle's block
+    int n, no, nNodes, nlevels;
+    const float* kx; const float* ky; const float* ur; const float* ang; const int* oct; const uint4* desc;
+    const int* order; const unsigned short* cellx; const unsigned short* celly; const int* colStart;
+    const unsigned char* occ;
+    const unsigned* nodeId; const int* nodeStart; const unsigned* index;
+    const float* sf; const float* s2; const float* is2;
+    float minX, minY, maxX, maxY, invW, invH, logScale;
+    int cols, rows;
+};
+
+__device__ __forceinline__ int dist256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- vocabulary-node searches
+struct NodeProb { const KfDev* k2; float F[9]; float ex, ey; };
+struct NodesArgs {
+    const KfDev* k1;
+    int nProb, onlyStereo;
+    float nnratio;
+    const unsigned char* valid1; const unsigned char* valid2;      // BoW: mapped host arrays (gathered once per wave); triangulation: unused
+    int2* match;                  // per (problem, side-1 keypoint): {generation stamp, side-2 keypoint}
+    int gen, n1;
+    NodeProb P[kMaxProb];
+};
+
+// MODE 0: SearchByBoW(KeyFrame*, Frame&), 1: SearchByBoW(KeyFrame*, KeyFrame*), 2: SearchForTriangulation
+template <int MODE>
+__global__ __launch_bounds__(256) void k_kf_nodes(NodesArgs A) {
+    const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + (threadIdx.x >> 6), pb = blockIdx.y;
+    const KfDev K1 = *A.k1;
+    if (a >= K1.nNodes) return;
+    const NodeProb& PB = A.P[pb];
+    const KfDev K2 = *PB.k2;
+    // the node of side 1 in side 2's vector (both ascending: std::map order; upstream's merge walk with lower_bound, :175-262)
+    const unsigned id = K1.nodeId[a];
+    int lo = 0, hi = K2.nNodes;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (K2.nodeId[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= K2.nNodes || K2.nodeId[lo] != id) return;
+    const int s1 = K1.nodeStart[a], c1 = K1.nodeStart[a + 1] - s1, s2 = K2.nodeStart[lo], c2 = K2.nodeStart[lo + 1] - s2;
+    if (c1 <= 0 || c2 <= 0) return;
+    // side 2, first 64 entries of the node in registers (a node rarely holds more; the rest is read from memory in every round)
+    int idx2 = -1, oct2 = 0;
+    uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0;
+    float x2 = 0, y2 = 0;
+    bool stereo2 = false, skip2 = true;
+    auto load2 = [&](int p, int& i2, uint4& g0, uint4& g1, float& xx, float& yy, int& oc, bool& st2) -> bool {      // false: upstream `continue`s at this entry
+        i2 = (int)K2.index[s2 + p];
+        bool skip;
+        if (MODE == 0) skip = false;
+        else if (MODE == 1) skip = !A.valid2[i2];
+        else skip = K2.occ[i2] || (A.onlyStereo && !(K2.ur[i2] >= 0));
+        if (skip) return false;
+        g0 = K2.desc[2 * (size_t)i2]; g1 = K2.desc[2 * (size_t)i2 + 1];
+        if (MODE == 2) { xx = K2.kx[i2]; yy = K2.ky[i2]; oc = K2.oct[i2]; st2 = K2.ur[i2] >= 0; }
+        return true;
+    };
+    if (lane < c2) skip2 = !load2(lane, idx2, f0, f1, x2, y2, oct2, stereo2);
+    unsigned long long taken = 0;      // bit j: list position lane + 64 j of the node's side 2 has been matched (BoW)
+    int matched = 0;
+    for (int a0 = 0; a0 < c1; a0 += 64) {
+        // side 1, 64 entries at a time: which of them upstream looks at (a ballot), their keypoint indices in the lanes
+        int myIdx1 = 0;
+        bool ok1 = false;
+        if (a0 + lane < c1) {
+            myIdx1 = (int)K1.index[s1 + a0 + lane];
+            if (MODE == 2) ok1 = !(K1.occ[myIdx1] || (A.onlyStereo && !(K1.ur[myIdx1] >= 0)));
+            else ok1 = A.valid1[myIdx1] != 0;
+        }
+        const unsigned long long m1 = __ballot(ok1);
+        const int cnt = min(64, c1 - a0);
+        for (int aa = 0; aa < cnt; aa++) {
+            if (!((m1 >> aa) & 1)) continue;
+            const int idx1 = __shfl(myIdx1, aa);
+            const uint4 d0 = K1.desc[2 * (size_t)idx1], d1 = K1.desc[2 * (size_t)idx1 + 1];
+            float la = 0, lb = 0, lc = 0, den = 0;
+            bool stereo1 = false;
+            if (MODE == 2) {      // the epipolar line of keypoint 1 in image 2 (CheckDistEpipolarLine, :140-157)
+                const float x1 = K1.kx[idx1], y1 = K1.ky[idx1];
+                stereo1 = K1.ur[idx1] >= 0;
+                la = x1 * PB.F[0] + y1 * PB.F[3] + PB.F[6];
+                lb = x1 * PB.F[1] + y1 * PB.F[4] + PB.F[7];
+                lc = x1 * PB.F[2] + y1 * PB.F[5] + PB.F[8];
+                den = la * la + lb * lb;
+            }
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+            auto offer = [&](int p, const uint4& g0, const uint4& g1, float xx, float yy, int oc, bool st2) {
+                const unsigned d = (unsigned)dist256(d0, d1, g0, g1);
+                unsigned key;
+                if (MODE == 2) {
+                    // upstream (:722-757): d <= TH_LOW and d <= the best so far, then the epipole and epipolar-line gates, then "best = this one" -- i.e. the smallest
+                    // distance among the gated candidates, the LAST of equal ones: position enters the key inverted
+                    if (d > (unsigned)TH_LOW) return;
+                    if (!stereo1 && !st2) {
+                        const float dex = PB.ex - xx, dey = PB.ey - yy;
+                        if (dex * dex + dey * dey < 100 * K2.sf[oc]) return;
+                    }
+                    const float num = la * xx + lb * yy + lc;
+                    if (den == 0) return;
+                    const float dsqr = num * num / den;
+                    if (!(dsqr < refc::EPIPOLAR_CHI2 * K2.s2[oc])) return;
+                    key = (d << 16) | (unsigned)(0xFFFF - p);
+                } else {
+                    key = (d << 16) | (unsigned)p;      // first of equal distances wins (strict '<' upstream, :206-215)
+                }
+                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+            };
+            if (!skip2 && !(taken & 1)) offer(lane, f0, f1, x2, y2, oct2, stereo2);
+            for (int p = lane + 64, j = 1; p < c2; p += 64, j++) {
+                if ((taken >> j) & 1) continue;
+                int i2, oc = 0; uint4 g0, g1; float xx = 0, yy = 0; bool st2 = false;
+                if (!load2(p, i2, g0, g1, xx, yy, oc, st2)) continue;
+                offer(p, g0, g1, xx, yy, oc, st2);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {      // the wave's two smallest keys (all distinct: the position is part of the key)
+                const unsigned o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+                const unsigned lo1 = min(k1, o1), hi1 = max(k1, o1);
+                k2 = min(hi1, min(k2, o2)); k1 = lo1;
+            }
+            if (k1 == 0xFFFFFFFFu) continue;
+            const int best1 = (int)(k1 >> 16), best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 16);
+            bool accept;
+            int p;
+            if (MODE == 2) { accept = true; p = 0xFFFF - (int)(k1 & 0xFFFFu); }
+            else {
+                p = (int)(k1 & 0xFFFFu);
+                accept = (MODE == 0 ? best1 <= TH_LOW : best1 < TH_LOW) && (float)best1 < A.nnratio * (float)best2;
+            }
+            if (!accept) continue;
+            if (MODE != 2 && (p & 63) == lane) taken |= 1ull << (p >> 6);      // (triangulation never consumes side 2: upstream does not set vbMatched2)
+            if (lane == 0) {
+                A.match[(size_t)pb * A.n1 + idx1] = make_int2(A.gen, (int)K2.index[s2 + p]);
+                matched++;
+            }
+        }
+    }
+    (void)matched;
+}
+
+// rotation histogram + ComputeThreeMaxima (src/ORBmatcher.cc:1603-1644) over a problem's matches, the table and its count into mapped host memory
+struct FinishArgs {
+    const KfDev* k1;
+    int nProb, n1, gen, checkOrientation;
+    const int2* match;
+    int* out;        // mapped host: nProb x n1
+    int* nm;         // mapped host: nProb
+    const KfDev* k2[kMaxProb];
+};
+__global__ __launch_bounds__(256) void k_kf_finish(FinishArgs A) {
+    __shared__ int s_hist[HISTO], s_keep[3], s_nm;
+    const int pb = blockIdx.x, t = threadIdx.x;
+    const float* ang1 = A.k1->ang;
+    const float* ang2 = A.k2[pb]->ang;
+    const float factor = 1.0f / HISTO;
+    if (t < HISTO) s_hist[t] = 0;
+    if (t == 0) { s_nm = 0; s_keep[0] = s_keep[1] = s_keep[2] = -1; }
+    __syncthreads();
+    const int2* M = A.match + (size_t)pb * A.n1;
+    auto bin_of = [&](int i, int m) {
+        float rot = ang1[i] - ang2[m];
+        if (rot < 0.0) rot += 360.0f;
+        int b = (int)roundf(rot * factor);
+        if (b == HISTO) b = 0;
+        return b;
+    };
+    if (A.checkOrientation) {
+        for (int i = t; i < A.n1; i += 256) {
+            const int2 e = M[i];
+            if (e.x != A.gen) continue;
+            const int b = bin_of(i, e.y);
+            if (b >= 0 && b < HISTO) atomicAdd(&s_hist[b], 1);
+        }
+        __syncthreads();
+        if (t == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < HISTO; i++) {
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
+        }
+        __syncthreads();
+    }
+    int kept = 0;
+    for (int i = t; i < A.n1; i += 256) {
+        const int2 e = M[i];
+        int m = e.x == A.gen ? e.y : -1;
+        if (m >= 0 && A.checkOrientation) {
+            const int b = bin_of(i, m);
+            if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) m = -1;
+        }
+        A.out[(size_t)pb * A.n1 + i] = m;
+        kept += m >= 0;
+    }
+    for (int o = 32; o >= 1; o >>= 1) kept += __shfl_xor(kept, o);
+    if ((t & 63) == 0 && kept) atomicAdd(&s_nm, kept);
+    __syncthreads();
+    if (t == 0) A.nm[pb] = s_nm;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- Fuse
+struct PtsDev { int n; const unsigned char* active; const float* Xw; const float* normal; const float* dmin; const float* dmax; const float* draw; const uint4* desc; };
+struct FuseTarget { const KfDev* k; float R[9], t[3], Ow[3]; };
+struct FuseArgs {
+    int nKf, useSim3;
+    float fx, fy, cx, cy, bf, th;
+    PtsDev P;
+    int* out;            // mapped host: nKf x P.n
+    FuseTarget T[kMaxProb];
+};
+// one wavefront per (target keyframe, map point): upstream's loop body (:851-971 / :1003-1096) up to "bestDist <= TH_LOW"
+__global__ __launch_bounds__(256) void k_kf_fuse(FuseArgs A) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6), f = blockIdx.y;
+    if (i >= A.P.n) return;
+    int* out = A.out + (size_t)f * A.P.n + i;
+    const FuseTarget& T = A.T[f];
+    const KfDev K = *T.k;
+    if (!A.P.active[i]) { if (lane == 0) *out = -1; return; }
+    // the projection with the range / viewing-angle tests (cv::Mat float semantics: A x + b accumulates in double and rounds once; cv::norm and Mat::dot
+    // accumulate in double) -- the same statements as shoot() in csrc/search.hip
+    const float X0 = A.P.Xw[3 * i], X1 = A.P.Xw[3 * i + 1], X2 = A.P.Xw[3 * i + 2];
+    float pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double s = (double)T.R[r * 3] * (double)X0 + (double)T.R[r * 3 + 1] * (double)X1 + (double)T.R[r * 3 + 2] * (double)X2;
+        pc[r] = (float)(1.0 * s + (double)T.t[r]);
+    }
+    bool ok = !(pc[2] < 0.0f);
+    float invz = 0, u = 0, v = 0;
+    int level = 0;
+    if (ok) {
+        invz = A.useSim3 ? (float)(1.0 / pc[2]) : 1 / pc[2];
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        u = A.fx * x + A.cx; v = A.fy * y + A.cy;
+        ok = u >= K.minX && u < K.maxX && v >= K.minY && v < K.maxY;      // KeyFrame::IsInImage
+    }
+    if (ok) {
+        const float PO0 = X0 - T.Ow[0], PO1 = X1 - T.Ow[1], PO2 = X2 - T.Ow[2];
+        const float dist = (float)sqrt((double)PO0 * PO0 + (double)PO1 * PO1 + (double)PO2 * PO2);
+        if (dist < A.P.dmin[i] || dist > A.P.dmax[i]) ok = false;
+        if (ok) {
+            const double dot = (double)PO0 * A.P.normal[3 * i] + (double)PO1 * A.P.normal[3 * i + 1] + (double)PO2 * A.P.normal[3 * i + 2];
+            if (dot < 0.5 * dist) ok = false;
+        }
+        if (ok) {      // MapPoint::PredictScale (src/MapPoint.cc:385-394): float log, float division, ceil -- the float logarithm as in frustum_point (chain_internal.h)
+            const float ratio = A.P.draw[i] / dist;
+            const float lg = (float)log((double)ratio);
+            level = (int)ceilf(lg / K.logScale);
+            ok = level >= 0 && level < K.nlevels;
+        }
+    }
+    if (!ok) { if (lane == 0) *out = -1; return; }
+    const float r = A.th * K.sf[level];
+    // KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:608-647), the float expressions as written upstream
+    const int x0 = max(0, (int)floorf((u - K.minX - r) * K.invW));
+    const int x1 = min(K.cols - 1, (int)ceilf((u - K.minX + r) * K.invW));
+    const int y0 = max(0, (int)floorf((v - K.minY - r) * K.invH));
+    const int y1 = min(K.rows - 1, (int)ceilf((v - K.minY + r) * K.invH));
+    if (x0 >= K.cols || x1 < 0 || y0 >= K.rows || y1 < 0) { if (lane == 0) *out = -1; return; }
+    const uint4 d0 = A.P.desc[2 * (size_t)i], d1 = A.P.desc[2 * (size_t)i + 1];
+    const float ur = u - A.bf * invz;
+    const int oBeg = K.colStart[x0], oEnd = min(K.colStart[x1 + 1], K.no);
+    unsigned best = 0xFFFFFFFFu;
+    for (int o0 = oBeg; o0 < oEnd; o0 += 64) {
+        const int o = o0 + lane;
+        if (o >= oEnd) continue;
+        const int cx = K.cellx[o], cy = K.celly[o];
+        if (cx < x0 || cx > x1 || cy < y0 || cy > y1) continue;
+        const int k = K.order[o];
+        const float kx = K.kx[k], ky = K.ky[k];
+        if (!(fabsf(kx - u) < r && fabsf(ky - v) < r)) continue;
+        const int kl = K.oct[k];
+        if (kl < level - 1 || kl > level) continue;
+        if (!A.useSim3) {      // reprojection gates of the pose overload (:915-941)
+            const float exx = u - kx, eyy = v - ky;
+            const float kur = K.ur[k];
+            if (kur >= 0) {
+                const float er = ur - kur;
+                const float e2 = exx * exx + eyy * eyy + er * er;
+                if (e2 * K.is2[kl] > refc::FUSE_CHI2_STEREO) continue;
+            } else {
+                const float e2 = exx * exx + eyy * eyy;
+                if (e2 * K.is2[kl] > refc::FUSE_CHI2_MONO) continue;
+            }
+        }
+        const unsigned d = (unsigned)dist256(d0, d1, K.desc[2 * (size_t)k], K.desc[2 * (size_t)k + 1]);
+        best = min(best, (d << 16) | (unsigned)o);      // candidates come in grid order: the first of equal distances wins (strict '<' upstream)
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = min(best, (unsigned)__shfl_xor(best, o));
+    if (lane == 0) *out = (best != 0xFFFFFFFFu && (int)(best >> 16) <= TH_LOW) ? K.order[best & 0xFFFFu] : -1;
+}
+
+// 16 bytes per lane from mapped pinned host memory into HBM, on the searches' own stream (an SDMA copy in front of a kernel costs a cross-engine hand-over)
+__global__ __launch_bounds__(256) void k_kf_upload(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+struct PinBuf {   // grow-only mapped pinned host buffer
+    unsigned char* p = nullptr; unsigned char* d = nullptr;
+    size_t n = 0;
+    eao_status reserve(size_t need) {
+        if (need <= n) return EAO_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; d = nullptr; n = 0;
+        const size_t cap = need + (need >> 2) + 4096;
+        EAO_HIP(hipHostMalloc((void**)&p, cap, hipHostMallocMapped));
+        EAO_HIP(hipHostGetDevicePointer((void**)&d, p, 0));
+        n = cap;
+        return EAO_OK;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+struct Ctx {   // per host thread, grow-only
+    hipStream_t stream = nullptr;
+    PinBuf in, out;
+    eao::DevBuf<int2> match;
+    eao::DevBuf<unsigned char> dev;
+    int gen = 0;
+    ~Ctx() { if (stream) (void)hipStreamDestroy(stream); }
+};
+thread_local Ctx g_kctx;
+
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+struct eao_keyframe {
+    // host copies: the list-based searches replay their selection over them, and the handle outlives the caller's arrays
+    std::vector<float> kx, ky, ang, ur, sf, s2, is2;
+    std::vector<int32_t> oct, nodeStart;
+    std::vector<uint8_t> desc, occ;
+    std::vector<uint32_t> nodeId, index;
+    eao_frame_view view;
+    eao_feature_vector fv;
+    bool hasFv = false, fvUnique = true;
+    unsigned char* dev = nullptr;      // one device block: [KfDev | arrays]
+    size_t oOcc = 0;
+    KfDev D;
+    eao::match::Resident res;
+};
+
+extern "C" {
+
+eao_status eao_keyframe_create(const eao_frame_view* F, const eao_feature_vector* fv, eao_keyframe** out) {
+    EAO_REQUIRE(F && out, "null argument");
+    *out = nullptr;
+    eao_status st = eao::require_device();
+    if (st) return st;
+    const int n = F->n;
+    EAO_REQUIRE(n >= 0 && n < 65536, "a keyframe holds 0..65535 keypoints (indices are packed in 16 bits)");
+    EAO_REQUIRE(n == 0 || (F->kp_x && F->kp_y && F->kp_octave && F->kp_angle && F->u_right && F->descriptors), "incomplete frame view");
+    EAO_REQUIRE(F->scale_factors && F->nlevels > 0 && F->nlevels <= 64 && F->grid_cols > 0 && F->grid_rows > 0 && (long long)F->grid_cols * F->grid_rows < (1 << 24), "bad geometry");
+    for (int i = 0; i < n; i++) {
+        EAO_REQUIRE(F->kp_octave[i] >= 0 && F->kp_octave[i] < F->nlevels, "keypoint %d: octave %d lies outside the %d levels", i, F->kp_octave[i], F->nlevels);
+        EAO_REQUIRE(std::isfinite(F->kp_x[i]) && std::isfinite(F->kp_y[i]), "keypoint %d: NaN / Inf coordinate", i);
+    }
+    if (fv) EAO_REQUIRE(eao::search::feature_vector_ok(fv, n), "malformed feature vector");
+    eao_keyframe* h = new eao_keyframe();
+    h->kx.assign(F->kp_x, F->kp_x + n); h->ky.assign(F->kp_y, F->kp_y + n); h->ang.assign(F->kp_angle, F->kp_angle + n); h->ur.assign(F->u_right, F->u_right + n);
+    h->oct.assign(F->kp_octave, F->kp_octave + n); h->desc.assign(F->descriptors, F->descriptors + 32 * (size_t)n);
+    h->occ.assign(n, 0);
+    if (F->occupied) h->occ.assign(F->occupied, F->occupied + n);
+    const int nl = F->nlevels;
+    h->sf.assign(F->scale_factors, F->scale_factors + nl);
+    h->s2.assign(nl, 0.f); h->is2.assign(nl, 0.f);
+    if (F->level_sigma2) h->s2.assign(F->level_sigma2, F->level_sigma2 + nl);
+    if (F->inv_level_sigma2) h->is2.assign(F->inv_level_sigma2, F->inv_level_sigma2 + nl);
+    h->view = *F;
+    h->view.kp_x = h->kx.data(); h->view.kp_y = h->ky.data(); h->view.kp_octave = h->oct.data(); h->view.kp_angle = h->ang.data(); h->view.u_right = h->ur.data();
+    h->view.descriptors = h->desc.data(); h->view.occupied = h->occ.data(); h->view.scale_factors = h->sf.data();
+    h->view.level_sigma2 = F->level_sigma2 ? h->s2.data() : nullptr; h->view.inv_level_sigma2 = F->inv_level_sigma2 ? h->is2.data() : nullptr;
+    int nn = 0;
+    if (fv) {
+        nn = fv->n_nodes;
+        h->hasFv = true;
+        h->nodeId.assign(fv->node_id, fv->node_id + nn);
+        h->nodeStart.assign(fv->node_start, fv->node_start + nn + 1);
+        h->index.assign(fv->index, fv->index + (nn ? fv->node_start[nn] : 0));
+        std::vector<uint8_t> seen(n, 0);      // DBoW2 files a feature under ONE node; a vector that lists a keypoint twice takes the host path (upstream's greedy rule would reach across nodes)
+        for (uint32_t k : h->index) { if (seen[k]) h->fvUnique = false; seen[k] = 1; }
+    }
+    if (h->nodeStart.empty()) h->nodeStart.assign(1, 0);
+    h->fv.n_nodes = nn; h->fv.node_id = h->nodeId.data(); h->fv.node_start = h->nodeStart.data(); h->fv.index = h->index.data();
+    // grid order: PosInGrid (src/Frame.cc:751-761 / KeyFrame's copy of the grid) then cell column-major, insertion (= index) order inside a cell
+    const int cols = F->grid_cols, rows = F->grid_rows;
+    const size_t nCells = (size_t)cols * rows;
+    std::vector<int> cellOf(n), cellStart(nCells + 1, 0);
+    for (int i = 0; i < n; i++) {
+        const int px = (int)std::round((F->kp_x[i] - F->min_x) * F->grid_inv_w);
+        const int py = (int)std::round((F->kp_y[i] - F->min_y) * F->grid_inv_h);
+        const bool in = px >= 0 && px < cols && py >= 0 && py < rows;
+        cellOf[i] = in ? px * rows + py : -1;
+        if (in) cellStart[cellOf[i] + 1]++;
+    }
+    for (size_t q = 0; q < nCells; q++) cellStart[q + 1] += cellStart[q];
+    const int no = cellStart[nCells];
+    std::vector<int> order(std::max(no, 1)), colStart(cols + 1);
+    std::vector<unsigned short> cellx(std::max(no, 1)), celly(std::max(no, 1));
+    for (int x = 0; x <= cols; x++) colStart[x] = cellStart[(size_t)std::min(x, cols) * rows];
+    {
+        std::vector<int> cur(cellStart.begin(), cellStart.end() - 1);
+        for (int i = 0; i < n; i++)
+            if (cellOf[i] >= 0) { const int o = cur[cellOf[i]]++; order[o] = i; cellx[o] = (unsigned short)(cellOf[i] / rows); celly[o] = (unsigned short)(cellOf[i] % rows); }
+    }
+    // one device block
+    const size_t n1 = std::max(n, 1), no1 = std::max(no, 1), nn1 = std::max(nn, 1), ni = std::max<size_t>(h->index.size(), 1);
+    size_t off = al256(sizeof(KfDev));
+    const size_t oKx = off; off = al256(off + 4 * n1);
+    const size_t oKy = off; off = al256(off + 4 * n1);
+    const size_t oUr = off; off = al256(off + 4 * n1);
+    const size_t oAn = off; off = al256(off + 4 * n1);
+    const size_t oOc = off; off = al256(off + 4 * n1);
+    const size_t oDe = off; off = al256(off + 32 * n1);
+    const size_t oOr = off; off = al256(off + 4 * no1);
+    const size_t oCx = off; off = al256(off + 2 * no1);
+    const size_t oCy = off; off = al256(off + 2 * no1);
+    const size_t oCs = off; off = al256(off + 4 * (size_t)(cols + 1));
+    const size_t oOcc = off; off = al256(off + n1);
+    const size_t oNi = off; off = al256(off + 4 * nn1);
+    const size_t oNs = off; off = al256(off + 4 * (nn1 + 1));
+    const size_t oIx = off; off = al256(off + 4 * ni);
+    const size_t oSf = off; off = al256(off + 4 * (size_t)nl);
+    const size_t oS2 = off; off = al256(off + 4 * (size_t)nl);
+    const size_t oI2 = off; off = al256(off + 4 * (size_t)nl);
+    std::vector<unsigned char> hb(off, 0);
+    if (hipMalloc((void**)&h->dev, off) != hipSuccess) { delete h; eao::set_error("hipMalloc of %zu bytes failed", off); return EAO_ERR_NO_DEVICE; }
+    unsigned char* dv = h->dev;
+    KfDev& D = h->D;
+    D.n = n; D.no = no; D.nNodes = nn; D.nlevels = nl;
+    D.kx = (const float*)(dv + oKx); D.ky = (const float*)(dv + oKy); D.ur = (const float*)(dv + oUr); D.ang = (const float*)(dv + oAn);
+    D.oct = (const int*)(dv + oOc); D.desc = (const uint4*)(dv + oDe); D.order = (const int*)(dv + oOr);
+    D.cellx = (const unsigned short*)(dv + oCx); D.celly = (const unsigned short*)(dv + oCy); D.colStart = (const int*)(dv + oCs);
+    D.occ = dv + oOcc; D.nodeId = (const unsigned*)(dv + oNi); D.nodeStart = (const int*)(dv + oNs); D.index = (const unsigned*)(dv + oIx);
+    D.sf = (const float*)(dv + oSf); D.s2 = (const float*)(dv + oS2); D.is2 = (const float*)(dv + oI2);
+    D.minX = F->min_x; D.minY = F->min_y; D.maxX = F->max_x; D.maxY = F->max_y; D.invW = F->grid_inv_w; D.invH = F->grid_inv_h; D.logScale = F->log_scale_factor;
+    D.cols = cols; D.rows = rows;
+    std::memcpy(hb.data(), &D, sizeof(D));
+    if (n) {
+        std::memcpy(&hb[oKx], h->kx.data(), 4 * (size_t)n); std::memcpy(&hb[oKy], h->ky.data(), 4 * (size_t)n); std::memcpy(&hb[oUr], h->ur.data(), 4 * (size_t)n);
+        std::memcpy(&hb[oAn], h->ang.data(), 4 * (size_t)n); std::memcpy(&hb[oOc], h->oct.data(), 4 * (size_t)n); std::memcpy(&hb[oDe], h->desc.data(), 32 * (size_t)n);
+        std::memcpy(&hb[oOcc], h->occ.data(), n);
+    }
+    if (no) { std::memcpy(&hb[oOr], order.data(), 4 * (size_t)no); std::memcpy(&hb[oCx], cellx.data(), 2 * (size_t)no); std::memcpy(&hb[oCy], celly.data(), 2 * (size_t)no); }
+    std::memcpy(&hb[oCs], colStart.data(), 4 * (size_t)(cols + 1));
+    if (nn) { std::memcpy(&hb[oNi], h->nodeId.data(), 4 * (size_t)nn); std::memcpy(&hb[oIx], h->index.data(), 4 * h->index.size()); }
+    std::memcpy(&hb[oNs], h->nodeStart.data(), 4 * h->nodeStart.size());
+    std::memcpy(&hb[oSf], h->sf.data(), 4 * (size_t)nl); std::memcpy(&hb[oS2], h->s2.data(), 4 * (size_t)nl); std::memcpy(&hb[oI2], h->is2.data(), 4 * (size_t)nl);
+    if (hipMemcpy(dv, hb.data(), off, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->dev); delete h; eao::set_error("upload of the keyframe failed"); return EAO_ERR_NO_DEVICE; }
+    h->oOcc = oOcc;
+    eao::match::Resident& R = h->res;
+    R.kx = D.kx; R.ky = D.ky; R.ur = D.ur; R.oct = D.oct; R.desc = (const uint8_t*)D.desc; R.order = D.order; R.cellx = D.cellx; R.celly = D.celly; R.colStart = D.colStart;
+    R.n = n; R.no = no;
+    *out = h;
+    return EAO_OK;
+}
+
+eao_status eao_keyframe_update_points(eao_keyframe* h, const uint8_t* occupied) {
+    EAO_REQUIRE(h, "null handle");
+    if (h->D.n == 0) return EAO_OK;
+    if (occupied) std::memcpy(h->occ.data(), occupied, h->D.n);
+    else std::fill(h->occ.begin(), h->occ.end(), 0);
+    EAO_HIP(hipMemcpy(h->dev + h->oOcc, h->occ.data(), h->D.n, hipMemcpyHostToDevice));
+    return EAO_OK;
+}
+
+void eao_keyframe_destroy(eao_keyframe* h) {
+    if (!h) return;
+    if (h->dev) (void)hipFree(h->dev);
+    delete h;
+}
+
+int32_t eao_keyframe_size(const eao_keyframe* h) { return h ? h->D.n : -1; }
+
+}  // extern "C"
+
+namespace {
+
+eao_status ctx_ready(Ctx& c) {
+    eao_status st = eao::require_device();
+    if (st) return st;
+    if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    return EAO_OK;
+}
+
+// the shared driver of the vocabulary-node searches: MODE as in k_kf_nodes; problems in chunks of kMaxProb per launch pair, ONE synchronisation
+eao_status run_nodes(int mode, const eao_keyframe* k1, int nProb, const eao_keyframe* const* k2s, const float* F12s, const float* exs, const float* eys,
+                     const uint8_t* valid1, const uint8_t* valid2, float nnratio, int onlyStereo, int checkOrientation, int32_t* match12, int32_t* nmatches) {
+    Ctx& c = g_kctx;
+    eao_status st = ctx_ready(c);
+    if (st) return st;
+    const int n1 = k1->D.n;
+    if (n1 == 0 || nProb == 0) { for (int p = 0; p < nProb; p++) nmatches[p] = 0; return EAO_OK; }
+    const size_t cells = (size_t)nProb * n1;
+    if (c.match.n < cells) {
+        if ((st = c.match.reserve(cells + (cells >> 2)))) return st;
+        EAO_HIP(hipMemsetAsync(c.match.p, 0, c.match.n * sizeof(int2), c.stream));      // (fresh memory may hold anything: no stamp of it may equal a generation)
+        c.gen = 0;
+    }
+    if (c.gen == 0x7FFFFFFF) { EAO_HIP(hipMemsetAsync(c.match.p, 0, c.match.n * sizeof(int2), c.stream)); c.gen = 0; }
+    c.gen++;
+    // mapped input block: the BoW validity flags; mapped output block: [counts | tables]
+    const size_t oV1 = 0, oV2 = al256((size_t)n1), inBytes = oV2 + al256(valid2 ? (size_t)k2s[0]->D.n : 1);
+    if ((st = c.in.reserve(inBytes))) return st;
+    if (valid1) std::memcpy(c.in.p + oV1, valid1, n1);
+    if (valid2) std::memcpy(c.in.p + oV2, valid2, k2s[0]->D.n);
+    const size_t oTab = al256(4 * (size_t)nProb);
+    if ((st = c.out.reserve(oTab + 4 * cells))) return st;
+    for (int p0 = 0; p0 < nProb; p0 += kMaxProb) {
+        const int np = std::min(kMaxProb, nProb - p0);
+        NodesArgs A;
+        A.k1 = (const KfDev*)k1->dev; A.nProb = np; A.onlyStereo = onlyStereo; A.nnratio = nnratio;
+        A.valid1 = valid1 ? c.in.d + oV1 : nullptr; A.valid2 = valid2 ? c.in.d + oV2 : nullptr;
+        A.match = c.match.p + (size_t)p0 * n1; A.gen = c.gen; A.n1 = n1;
+        FinishArgs B;
+        B.k1 = A.k1; B.nProb = np; B.n1 = n1; B.gen = c.gen; B.checkOrientation = checkOrientation; B.match = A.match;
+        B.out = (int*)(c.out.d + oTab) + (size_t)p0 * n1; B.nm = (int*)c.out.d + p0;
+        for (int q = 0; q < np; q++) {
+            A.P[q].k2 = (const KfDev*)k2s[p0 + q]->dev;
+            if (F12s) { std::memcpy(A.P[q].F, F12s + 9 * (size_t)(p0 + q), 36); A.P[q].ex = exs[p0 + q]; A.P[q].ey = eys[p0 + q]; }
+            else { std::memset(A.P[q].F, 0, 36); A.P[q].ex = A.P[q].ey = 0; }
+            B.k2[q] = A.P[q].k2;
+        }
+        const dim3 grid(eao::cdiv(std::max(k1->D.nNodes, 1), 4), np);
+        if (mode == 0) hipLaunchKernelGGL(k_kf_nodes<0>, grid, dim3(256), 0, c.stream, A);
+        else if (mode == 1) hipLaunchKernelGGL(k_kf_nodes<1>, grid, dim3(256), 0, c.stream, A);
+        else hipLaunchKernelGGL(k_kf_nodes<2>, grid, dim3(256), 0, c.stream, A);
+        hipLaunchKernelGGL(k_kf_finish, dim3(np), dim3(256), 0, c.stream, B);
+    }
+    EAO_HIP(hipStreamSynchronize(c.stream));
+    EAO_HIP(hipGetLastError());
+    std::memcpy(nmatches, c.out.p, 4 * (size_t)nProb);
+    std::memcpy(match12, c.out.p + oTab, 4 * cells);
+    return EAO_OK;
+}
+
+bool finite_n(const float* v, int n) {
+    for (int i = 0; i < n; i++) if (!std::isfinite(v[i])) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+eao_status eao_kf_search_by_bow(int32_t mode, const eao_keyframe* kf1, const uint8_t* valid1, const eao_keyframe* kf2, const uint8_t* valid2, float nnratio,
+                                int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
+    EAO_REQUIRE((mode == 0 || mode == 1) && kf1 && kf2 && match12 && nmatches, "bad argument");
+    EAO_REQUIRE(kf1->hasFv && kf2->hasFv, "both handles need their feature vector (eao_keyframe_create with fv)");
+    EAO_REQUIRE(kf1->D.n == 0 || valid1, "valid1 missing");
+    EAO_REQUIRE(mode == 0 || kf2->D.n == 0 || valid2, "valid2 missing (mode 1)");
+    if (!kf1->fvUnique || !kf2->fvUnique)      // a keypoint filed under two nodes: upstream's walk order matters across nodes -- the host replay keeps it
+        return eao_search_by_bow(mode, kf1->D.n, kf1->desc.data(), kf1->ang.data(), valid1, &kf1->fv, kf2->D.n, kf2->desc.data(), kf2->ang.data(), valid2, &kf2->fv,
+                                 nnratio, check_orientation, match12, nmatches);
+    return run_nodes(mode, kf1, 1, &kf2, nullptr, nullptr, nullptr, valid1, mode == 1 ? valid2 : nullptr, nnratio, 0, check_orientation, match12, nmatches);
+}
+
+eao_status eao_kf_search_for_triangulation(const eao_keyframe* kf1, int32_t n_nb, const eao_keyframe* const* kf2s, const float* F12s, const float* exs,
+                                           const float* eys, int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
+    EAO_REQUIRE(kf1 && n_nb >= 0 && (n_nb == 0 || (kf2s && F12s && exs && eys && match12 && nmatches)), "bad argument");
+    if (n_nb == 0) return EAO_OK;
+    EAO_REQUIRE(kf1->hasFv, "the handle needs its feature vector (eao_keyframe_create with fv)");
+    bool unique = kf1->fvUnique;
+    for (int k = 0; k < n_nb; k++) {
+        EAO_REQUIRE(kf2s[k] && kf2s[k]->hasFv && kf2s[k]->view.level_sigma2, "neighbour %d: no handle, no feature vector or no level_sigma2 in its view", k);
+        EAO_REQUIRE(finite_n(F12s + 9 * (size_t)k, 9) && std::isfinite(exs[k]) && std::isfinite(eys[k]), "neighbour %d: F12 / the epipole holds a NaN / Inf", k);
+        unique = unique && kf2s[k]->fvUnique;
+    }
+    if (!unique) {
+        std::vector<const eao_frame_view*> vs(n_nb);
+        std::vector<const eao_feature_vector*> fs(n_nb);
+        for (int k = 0; k < n_nb; k++) { vs[k] = &kf2s[k]->view; fs[k] = &kf2s[k]->fv; }
+        return eao_search_for_triangulation_batch(&kf1->view, &kf1->fv, n_nb, vs.data(), fs.data(), F12s, exs, eys, only_stereo, check_orientation, match12, nmatches);
+    }
+    return run_nodes(2, kf1, n_nb, kf2s, F12s, exs, eys, nullptr, nullptr, 0.f, only_stereo, check_orientation, match12, nmatches);
+}
+
+eao_status eao_kf_fuse_search(int32_t n_kf, const eao_keyframe* const* kfs, int32_t use_sim3, const float* poses, float fx, float fy, float cx, float cy, float bf,
+                              const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused) {
+    EAO_REQUIRE(n_kf >= 0 && (n_kf == 0 || (kfs && poses && best_kp && nfused)), "bad argument");
+    EAO_REQUIRE(pts && pts->n >= 0 && (pts->n == 0 || (pts->active && pts->Xw && pts->normal && pts->min_dist_inv && pts->max_dist_inv && pts->max_dist && pts->desc)),
+                "incomplete map points");
+    if (n_kf == 0) return EAO_OK;
+    const int n = pts->n, plen = use_sim3 ? 16 : 15;
+    for (int f = 0; f < n_kf; f++) {
+        EAO_REQUIRE(kfs[f] && (use_sim3 || kfs[f]->view.inv_level_sigma2), "target %d: no handle, or no inv_level_sigma2 in its view", f);
+        EAO_REQUIRE(finite_n(poses + (size_t)plen * f, plen), "target %d: the pose holds a NaN / Inf", f);
+        nfused[f] = 0;
+    }
+    if (n == 0) return EAO_OK;
+    Ctx& c = g_kctx;
+    eao_status st = ctx_ready(c);
+    if (st) return st;
+    // the points: one staging block in mapped memory, one upload kernel
+    const size_t N = n;
+    const size_t oAc = 0, oXw = al256(N), oNr = al256(oXw + 12 * N), oMn = al256(oNr + 12 * N), oMx = al256(oMn + 4 * N), oDr = al256(oMx + 4 * N), oDe = al256(oDr + 4 * N),
+                 bytes = al256(oDe + 32 * N);
+    if ((st = c.in.reserve(bytes))) return st;
+    if ((st = c.dev.reserve(bytes))) return st;
+    unsigned char* hb = c.in.p;
+    std::memcpy(hb + oAc, pts->active, N); std::memcpy(hb + oXw, pts->Xw, 12 * N); std::memcpy(hb + oNr, pts->normal, 12 * N);
+    std::memcpy(hb + oMn, pts->min_dist_inv, 4 * N); std::memcpy(hb + oMx, pts->max_dist_inv, 4 * N); std::memcpy(hb + oDr, pts->max_dist, 4 * N);
+    std::memcpy(hb + oDe, pts->desc, 32 * N);
+    if ((st = c.out.reserve(4 * N * (size_t)n_kf))) return st;
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_kf_upload, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 256)), dim3(256), 0, c.stream, (const uint4*)c.in.d, (uint4*)c.dev.p, n16);
+    for (int f0 = 0; f0 < n_kf; f0 += kMaxProb) {
+        const int nf = std::min(kMaxProb, n_kf - f0);
+        FuseArgs A;
+        A.nKf = nf; A.useSim3 = use_sim3; A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.bf = bf; A.th = th;
+        unsigned char* dv = c.dev.p;
+        A.P.n = n; A.P.active = dv + oAc; A.P.Xw = (const float*)(dv + oXw); A.P.normal = (const float*)(dv + oNr); A.P.dmin = (const float*)(dv + oMn);
+        A.P.dmax = (const float*)(dv + oMx); A.P.draw = (const float*)(dv + oDr); A.P.desc = (const uint4*)(dv + oDe);
+        A.out = (int*)c.out.d + (size_t)f0 * N;
+        for (int q = 0; q < nf; q++) {
+            FuseTarget& T = A.T[q];
+            T.k = (const KfDev*)kfs[f0 + q]->dev;
+            const float* pose = poses + (size_t)plen * (f0 + q);
+            if (use_sim3) {      // src/ORBmatcher.cc:980-986 (the same statements as decompose_sim3, csrc/search.hip)
+                const float scw = (float)std::sqrt((double)pose[0] * pose[0] + (double)pose[1] * pose[1] + (double)pose[2] * pose[2]);
+                for (int r = 0; r < 3; r++) { for (int cc = 0; cc < 3; cc++) T.R[r * 3 + cc] = pose[r * 4 + cc] / scw; T.t[r] = pose[r * 4 + 3] / scw; }
+                for (int i = 0; i < 3; i++) {
+                    double s = 0;
+                    for (int k = 0; k < 3; k++) s += (double)T.R[k * 3 + i] * (double)T.t[k];
+                    T.Ow[i] = (float)(-s);
+                }
+            } else { std::memcpy(T.R, pose, 36); std::memcpy(T.t, pose + 9, 12); std::memcpy(T.Ow, pose + 12, 12); }
+        }
+        hipLaunchKernelGGL(k_kf_fuse, dim3(eao::cdiv(n, 4), nf), dim3(256), 0, c.stream, A);
+    }
+    EAO_HIP(hipStreamSynchronize(c.stream));
+    EAO_HIP(hipGetLastError());
+    std::memcpy(best_kp, c.out.p, 4 * N * (size_t)n_kf);
+    for (int f = 0; f < n_kf; f++) {
+        int nf = 0;
+        const int32_t* b = best_kp + (size_t)f * N;
+        for (int i = 0; i < n; i++) nf += b[i] >= 0;
+        nfused[f] = nf;
+    }
+    return EAO_OK;
+}
+
+// ---- the list-based searches over a resident frame: the frame's view is the handle's host copy, its occupancy the caller's (it differs from search to search)
+eao_status eao_kf_search_by_projection_sim3(const eao_keyframe* kf, const uint8_t* occupied, const float* Scw, float fx, float fy, float cx, float cy,
+                                            const eao_map_points* pts, int32_t th, int32_t* kp_match, int32_t* nmatches) {
+    EAO_REQUIRE(kf, "null handle");
+    eao_frame_view v = kf->view;
+    v.occupied = occupied;
+    return eao::search::projection_sim3(&v, &kf->res, Scw, fx, fy, cx, cy, pts, th, kp_match, nmatches);
+}
+eao_status eao_kf_search_by_projection_kf(const eao_keyframe* cur, const uint8_t* occupied, const float* Tcw, float fx, float fy, float cx, float cy,
+                                          const eao_map_points* pts, const float* kf_angle, float th, int32_t orb_dist, int32_t check_orientation, int32_t* cur_match,
+                                          int32_t* nmatches) {
+    EAO_REQUIRE(cur, "null handle");
+    eao_frame_view v = cur->view;
+    v.occupied = occupied;
+    return eao::search::projection_kf(&v, &cur->res, Tcw, fx, fy, cx, cy, pts, kf_angle, th, orb_dist, check_orientation, cur_match, nmatches);
+}
+eao_status eao_kf_search_for_initialization(int32_t n1, const int32_t* octave1, const float* angle1, const uint8_t* desc1, const eao_keyframe* f2, float* prev_matched,
+                                            int32_t window, float nnratio, int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
+    EAO_REQUIRE(f2, "null handle");
+    return eao::search::initialization(n1, octave1, angle1, desc1, &f2->view, &f2->res, prev_matched, window, nnratio, check_orientation, match12, nmatches);
+}
+eao_status eao_kf_search_by_sim3(const eao_keyframe* k1, const float* T1w, const eao_map_points* pts1, const eao_keyframe* k2, const float* T2w,
+                                 const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12, const float* R12, const float* t12, float th,
+                                 int32_t* match12, int32_t* nfound) {
+    EAO_REQUIRE(k1 && k2, "null handle");
+    return eao::search::by_sim3(&k1->view, &k1->res, T1w, pts1, &k2->view, &k2->res, T2w, pts2, fx, fy, cx, cy, s12, R12, t12, th, match12, nfound);
+}
+
+}  // extern "C"

@@ -226,7 +226,8 @@ thread_local Ctx g_ctx;
 // uploads the frames + their queries, runs the candidate kernel once per frame, downloads the compact lists: ONE staging block, one upload, one
 // download and one synchronisation for all of them (round 4: the batched LocalMapping-side searches -- a single frame is a batch of one).
 // qdesc[f]: the query descriptors of frame f (nq[f] x 32 bytes); frames may share them (Fuse: the same map points into every target keyframe)
-eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs, const std::vector<Query>* qs, const uint8_t* const* qdescs, Lists* Ls) {
+eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs, const std::vector<Query>* qs, const uint8_t* const* qdescs, Lists* Ls,
+                                         const Resident* const* res) {
     Ctx& c = g_ctx;
     eao_status st = eao::require_device();
     if (st) return st;
@@ -245,6 +246,21 @@ eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs
         Ls[f].start.assign(P.nq, 0); Ls[f].count.assign(P.nq, 0); Ls[f].items.clear();
         if (P.n == 0 || P.nq == 0) { P.n = 0; P.nq = 0; continue; }
         EAO_REQUIRE(P.n < 65536, "at most 65535 keypoints per frame (indices are packed in 16 bits)");
+        const Resident* R = res ? res[f] : nullptr;
+        if (R) {      // the frame is on the device already, in grid order: only its queries (and their descriptors) travel
+            EAO_REQUIRE(R->n == P.n, "resident frame %d holds %d keypoints, the view %d", f, R->n, P.n);
+            P.no = R->no;
+            const size_t no = std::max(P.no, 1), nq = P.nq;
+            P.oQ = off; off = al(off + sizeof(Query) * nq);
+            int shared = -1;
+            for (int g = 0; g < f && shared < 0; g++) if (plan[g].nq == P.nq && qdescs[g] == qdescs[f]) shared = g;
+            if (shared >= 0) P.oQd = plan[shared].oQd;
+            else { P.oQd = off; off = al(off + 32 * nq); }
+            P.outCap = nq * no;
+            P.oOut = outOff; outOff += P.outCap;
+            P.oMeta = metaOff; metaOff += 2 * nq + 1;
+            continue;
+        }
         // grid order: PosInGrid (src/Frame.cc:751-761) then cell column-major, insertion (= index) order inside a cell
         // (a counting sort by cell -- the keypoints of a cell keep their index order: a comparison sort of a thousand records took a third of a whole search call)
         {
@@ -292,6 +308,11 @@ eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs
         const Plan& P = plan[f];
         if (!P.nq) continue;
         const size_t n = P.n;
+        if (res && res[f]) {
+            std::memcpy(hb + P.oQ, qs[f].data(), sizeof(Query) * (size_t)P.nq);
+            std::memcpy(hb + P.oQd, qdescs[f], 32 * (size_t)P.nq);
+            continue;
+        }
         std::memcpy(hb + P.oKx, F->kp_x, 4 * n); std::memcpy(hb + P.oKy, F->kp_y, 4 * n);
         std::memcpy(hb + P.oUr, F->u_right, 4 * n); std::memcpy(hb + P.oOc, F->kp_octave, 4 * n);
         for (int k = 0; k < P.no; k++) {
@@ -317,10 +338,15 @@ eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs
         FrameDev D;
         D.nOrderedDev = nullptr;
         D.n = P.n; D.nOrdered = P.no;
+        if (const Resident* R = res ? res[f] : nullptr) {
+            D.kx = R->kx; D.ky = R->ky; D.ur = R->ur; D.oct = R->oct; D.order = R->order; D.cellx = R->cellx; D.celly = R->celly; D.colStart = R->colStart;
+            D.desc = (const uint4*)R->desc;
+        } else {
         D.kx = (const float*)(c.dev.p + P.oKx); D.ky = (const float*)(c.dev.p + P.oKy); D.ur = (const float*)(c.dev.p + P.oUr);
         D.oct = (const int*)(c.dev.p + P.oOc); D.order = (const int*)(c.dev.p + P.oOr);
         D.cellx = (const unsigned short*)(c.dev.p + P.oCx); D.celly = (const unsigned short*)(c.dev.p + P.oCy); D.colStart = nullptr;
         D.desc = (const uint4*)(c.dev.p + P.oDe);
+        }
         D.minX = F->min_x; D.minY = F->min_y; D.invW = F->grid_inv_w; D.invH = F->grid_inv_h; D.cols = F->grid_cols; D.rows = F->grid_rows;
         int* md = c.metaDev.p + P.oMeta;
         hipLaunchKernelGGL(k_match_candidates, dim3(eao::cdiv(P.nq, 4)), dim3(256), 0, s, D, (const Query*)(c.dev.p + P.oQ),
@@ -342,8 +368,8 @@ eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs
     }
     return EAO_OK;
 }
-eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L) {
-    return build_lists_multi(1, &F, &q, &qdesc, &L);
+eao_status eao::match::build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L, const Resident* res) {
+    return build_lists_multi(1, &F, &q, &qdesc, &L, res ? &res : nullptr);
 }
 
 namespace {

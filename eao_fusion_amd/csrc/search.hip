@@ -23,6 +23,7 @@
 #include "common.h"
 #include "match_internal.h"
 #include "chain_internal.h"
+#include "search_internal.h"
 
 using eao::match::Lists;
 using eao::match::Query;
@@ -162,10 +163,10 @@ bool fv_ok(const eao_feature_vector* f, int n) {
 
 }  // namespace
 
-extern "C" {
+bool eao::search::feature_vector_ok(const eao_feature_vector* f, int n) { return fv_ok(f, n); }
 
-eao_status eao_search_by_projection_sim3(const eao_frame_view* KF, const float* Scw, float fx, float fy, float cx, float cy,
-                                         const eao_map_points* pts, int32_t th, int32_t* kp_match, int32_t* nmatches) {
+eao_status eao::search::projection_sim3(const eao_frame_view* KF, const match::Resident* res, const float* Scw, float fx, float fy, float cx, float cy,
+                                        const eao_map_points* pts, int32_t th, int32_t* kp_match, int32_t* nmatches) {
     EAO_REQUIRE(view_ok(KF) && Scw && points_ok(pts, true) && kp_match && nmatches, "bad argument");
     EAO_REQUIRE(finite_n(Scw, 16), "Scw holds a NaN / Inf");
     float Rcw[9], tcw[3], Ow[3];
@@ -181,7 +182,7 @@ eao_status eao_search_by_projection_sim3(const eao_frame_view* KF, const float* 
         q[i] = window(s.u, s.v, th * KF->scale_factors[s.level], -1, -1);
     }
     Lists L;
-    eao_status st = eao::match::build_lists(KF, q, pts->desc, L);
+    eao_status st = eao::match::build_lists(KF, q, pts->desc, L, res);
     if (st) return st;
     std::vector<uint8_t> occ(KF->n, 0);
     if (KF->occupied) std::memcpy(occ.data(), KF->occupied, KF->n);
@@ -204,9 +205,9 @@ eao_status eao_search_by_projection_sim3(const eao_frame_view* KF, const float* 
     return EAO_OK;
 }
 
-eao_status eao_search_by_projection_kf(const eao_frame_view* Cur, const float* Tcw, float fx, float fy, float cx, float cy,
-                                       const eao_map_points* pts, const float* kf_angle, float th, int32_t orb_dist,
-                                       int32_t check_orientation, int32_t* cur_match, int32_t* nmatches) {
+eao_status eao::search::projection_kf(const eao_frame_view* Cur, const match::Resident* res, const float* Tcw, float fx, float fy, float cx, float cy,
+                                      const eao_map_points* pts, const float* kf_angle, float th, int32_t orb_dist,
+                                      int32_t check_orientation, int32_t* cur_match, int32_t* nmatches) {
     EAO_REQUIRE(view_ok(Cur) && Tcw && points_ok(pts, false) && cur_match && nmatches && (pts->n == 0 || kf_angle), "bad argument");
     EAO_REQUIRE(finite_n(Tcw, 16), "Tcw holds a NaN / Inf");
     float Rcw[9], tcw[3], Ow[3];
@@ -231,7 +232,7 @@ eao_status eao_search_by_projection_kf(const eao_frame_view* Cur, const float* T
         q[i] = window(u, v, th * Cur->scale_factors[lvl], lvl - 1, lvl + 1);
     }
     Lists L;
-    eao_status st = eao::match::build_lists(Cur, q, pts->desc, L);
+    eao_status st = eao::match::build_lists(Cur, q, pts->desc, L, res);
     if (st) return st;
     std::vector<uint8_t> occ(Cur->n, 0);
     if (Cur->occupied) std::memcpy(occ.data(), Cur->occupied, Cur->n);
@@ -255,6 +256,18 @@ eao_status eao_search_by_projection_kf(const eao_frame_view* Cur, const float* T
     if (check_orientation) hist.reject_minor([&](int k) { cur_match[k] = -1; nm--; });
     *nmatches = nm;
     return EAO_OK;
+}
+
+extern "C" {
+
+eao_status eao_search_by_projection_sim3(const eao_frame_view* KF, const float* Scw, float fx, float fy, float cx, float cy,
+                                         const eao_map_points* pts, int32_t th, int32_t* kp_match, int32_t* nmatches) {
+    return eao::search::projection_sim3(KF, nullptr, Scw, fx, fy, cx, cy, pts, th, kp_match, nmatches);
+}
+eao_status eao_search_by_projection_kf(const eao_frame_view* Cur, const float* Tcw, float fx, float fy, float cx, float cy,
+                                       const eao_map_points* pts, const float* kf_angle, float th, int32_t orb_dist,
+                                       int32_t check_orientation, int32_t* cur_match, int32_t* nmatches) {
+    return eao::search::projection_kf(Cur, nullptr, Tcw, fx, fy, cx, cy, pts, kf_angle, th, orb_dist, check_orientation, cur_match, nmatches);
 }
 
 eao_status eao_search_by_bow(int32_t mode, int32_t n1, const uint8_t* desc1, const float* angle1, const uint8_t* valid1,
@@ -435,6 +448,13 @@ eao_status eao_search_for_triangulation_batch(const eao_frame_view* K1, const ea
 eao_status eao_search_for_initialization(int32_t n1, const int32_t* octave1, const float* angle1, const uint8_t* desc1,
                                          const eao_frame_view* F2, float* prev_matched, int32_t window_size, float nnratio,
                                          int32_t check_orientation, int32_t* match12, int32_t* nmatches) {
+    return eao::search::initialization(n1, octave1, angle1, desc1, F2, nullptr, prev_matched, window_size, nnratio, check_orientation, match12, nmatches);
+}
+}  // extern "C"
+
+eao_status eao::search::initialization(int32_t n1, const int32_t* octave1, const float* angle1, const uint8_t* desc1, const eao_frame_view* F2,
+                                       const match::Resident* res, float* prev_matched, int32_t window_size, float nnratio, int32_t check_orientation,
+                                       int32_t* match12, int32_t* nmatches) {
     EAO_REQUIRE(n1 >= 0 && view_ok(F2) && match12 && nmatches && (n1 == 0 || (octave1 && angle1 && desc1 && prev_matched)), "bad argument");
     std::vector<Query> q(n1, inactive());
     for (int i = 0; i < n1; i++) {
@@ -442,7 +462,7 @@ eao_status eao_search_for_initialization(int32_t n1, const int32_t* octave1, con
         q[i] = window(prev_matched[2 * i], prev_matched[2 * i + 1], (float)window_size, octave1[i], octave1[i]);
     }
     Lists L;
-    eao_status st = eao::match::build_lists(F2, q, desc1, L);
+    eao_status st = eao::match::build_lists(F2, q, desc1, L, res);
     if (st) return st;
     int nm = 0;
     for (int i = 0; i < n1; i++) match12[i] = -1;
@@ -473,6 +493,8 @@ eao_status eao_search_for_initialization(int32_t n1, const int32_t* octave1, con
     *nmatches = nm;
     return EAO_OK;
 }
+
+extern "C" {
 
 eao_status eao_fuse_search(const eao_frame_view* KF, int32_t use_sim3, const float* pose, float fx, float fy, float cx, float cy,
                            float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused) {
@@ -548,6 +570,14 @@ eao_status eao_fuse_search_batch(int32_t n_kf, const eao_frame_view* const* KFs,
 eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const eao_map_points* pts1, const eao_frame_view* K2,
                               const float* T2w, const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12,
                               const float* R12, const float* t12, float th, int32_t* match12, int32_t* nfound) {
+    return eao::search::by_sim3(K1, nullptr, T1w, pts1, K2, nullptr, T2w, pts2, fx, fy, cx, cy, s12, R12, t12, th, match12, nfound);
+}
+
+}  // extern "C"
+
+eao_status eao::search::by_sim3(const eao_frame_view* K1, const match::Resident* res1, const float* T1w, const eao_map_points* pts1, const eao_frame_view* K2,
+                                const match::Resident* res2, const float* T2w, const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12,
+                                const float* R12, const float* t12, float th, int32_t* match12, int32_t* nfound) {
     EAO_REQUIRE(view_ok(K1) && view_ok(K2) && T1w && T2w && points_ok(pts1, false) && points_ok(pts2, false) && R12 && t12 && match12 && nfound,
                 "bad argument");
     EAO_REQUIRE(finite_n(T1w, 16) && finite_n(T2w, 16) && finite_n(R12, 9) && finite_n(t12, 3) && std::isfinite(s12), "a pose / the sim3 holds a NaN / Inf");
@@ -560,7 +590,7 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
         for (int c = 0; c < 3; c++) { sR12[r * 3 + c] = s12 * R12[r * 3 + c]; sR21[r * 3 + c] = is12 * R12[c * 3 + r]; }
     affine3(sR21, t12, nullptr, -1.f, t21);
     auto one_way = [&](const eao_map_points* P, const float* Rw, const float* tw, const float* sR, const float* t,
-                       const eao_frame_view* K, std::vector<int>& out) -> eao_status {
+                       const eao_frame_view* K, const match::Resident* resK, std::vector<int>& out) -> eao_status {
         const int n = P->n;
         std::vector<Query> q(n, inactive());
         std::vector<int> level(n, 0);
@@ -582,7 +612,7 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
             q[i] = window(u, v, th * K->scale_factors[lvl], -1, -1);
         }
         Lists L;
-        eao_status st = eao::match::build_lists(K, q, P->desc, L);
+        eao_status st = eao::match::build_lists(K, q, P->desc, L, resK);
         if (st) return st;
         out.assign(n, -1);
         for (int i = 0; i < n; i++) {
@@ -599,9 +629,9 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
         return EAO_OK;
     };
     std::vector<int> m1, m2;
-    eao_status st = one_way(pts1, R1w, t1w, sR21, t21, K2, m1);
+    eao_status st = one_way(pts1, R1w, t1w, sR21, t21, K2, res2, m1);
     if (st) return st;
-    if ((st = one_way(pts2, R2w, t2w, sR12, t12, K1, m2))) return st;
+    if ((st = one_way(pts2, R2w, t2w, sR12, t12, K1, res1, m2))) return st;
     int nf = 0;
     for (int i1 = 0; i1 < pts1->n; i1++) {
         match12[i1] = -1;
@@ -611,8 +641,6 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
     *nfound = nf;
     return EAO_OK;
 }
-
-}  // extern "C"
 
 // ---- the two per-frame searches (moved here from match.hip in round 4: this file is the HOST half of every guided search -- no kernel, no HIP call --
 //      so that it also builds with g++ -fsanitize=address,undefined against a CPU list provider: tests/test_host_replay_cpu.py, tools/run_sanitizers.sh)

@@ -211,7 +211,171 @@ class ProductBinding(Binding):
         return nf, out
 
 
+class KeyFrameHandle:
+    """eao_keyframe: a frame dict (and its feature vector) uploaded once (include/eao_fusion.h, "keyframe handles")."""
+
+    def __init__(self, lib, check, frame, fv=None):
+        self.lib, self.check = lib, check
+        v, self._keep = frame_view(frame)
+        f = None
+        if fv is not None:
+            f, self._keepfv = feature_vector(fv)
+        self.h = _P()
+        check(lib.eao_keyframe_create(C.byref(v), None if f is None else C.byref(f), C.byref(self.h)))
+        self.n = v.n
+
+    def update_points(self, occupied):
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        self.check(self.lib.eao_keyframe_update_points(self.h, _p(occ)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.eao_keyframe_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class HandleBinding(ProductBinding):
+    """The same searches through keyframe handles (eao_kf_*).  The methods keep the host-array signatures -- a frame dict is turned into a handle on first use
+    and cached by the identity of its arrays -- so that the parity tests run every case through both bindings; handle() / the *_h methods are what a caller
+    that keeps its keyframes resident uses (and what bench.py times)."""
+
+    def __init__(self, lib, check):
+        super().__init__(lib, check)
+        K = _P
+        sigs = {
+            "eao_keyframe_create": [_FR, _FV, C.POINTER(_P)], "eao_keyframe_update_points": [K, _P], "eao_keyframe_size": [K],
+            "eao_kf_search_by_bow": [_I, K, _P, K, _P, _F, _I, _P, C.POINTER(_I)],
+            "eao_kf_search_for_triangulation": [K, _I, _P, _P, _P, _P, _I, _I, _P, _P],
+            "eao_kf_fuse_search": [_I, _P, _I, _P, _F, _F, _F, _F, _F, _MP, _F, _P, _P],
+            "eao_kf_search_by_projection_sim3": [K, _P, _P, _F, _F, _F, _F, _MP, _I, _P, C.POINTER(_I)],
+            "eao_kf_search_by_projection_kf": [K, _P, _P, _F, _F, _F, _F, _MP, _P, _F, _I, _I, _P, C.POINTER(_I)],
+            "eao_kf_search_for_initialization": [_I, _P, _P, _P, K, _P, _I, _F, _I, _P, C.POINTER(_I)],
+            "eao_kf_search_by_sim3": [K, _P, _MP, K, _P, _MP, _F, _F, _F, _F, _F, _P, _P, _F, _P, C.POINTER(_I)],
+        }
+        for name, args in sigs.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = _I, args
+        lib.eao_keyframe_destroy.restype, lib.eao_keyframe_destroy.argtypes = None, [K]
+        self._cache = {}
+
+    def handle(self, frame, fv=None):
+        """A handle of (frame, fv), cached while the dicts' arrays stay the same objects."""
+        key = tuple(id(frame.get(k)) for k in ("kp_x", "kp_y", "kp_octave", "kp_angle", "u_right", "descriptors", "occupied", "scale_factors", "level_sigma2",
+                                               "inv_level_sigma2")) + (None if fv is None else (id(fv["node_id"]), id(fv["node_start"]), id(fv["index"])),)
+        hit = self._cache.get(key)
+        if hit is None:
+            hit = (KeyFrameHandle(self.lib, self.check, frame, fv), frame, fv)      # (the dicts are kept alive: ids stay unique)
+            self._cache[key] = hit
+        return hit[0]
+
+    # ---- handle-level calls
+    def search_by_bow_h(self, mode, h1, valid1, h2, valid2, nnratio, check_orientation=True):
+        v1 = np.ascontiguousarray(valid1, np.uint8)
+        v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        out, n = np.full(h1.n, -1, np.int32), _I(0)
+        self.check(self.lib.eao_kf_search_by_bow(int(mode), h1.h, _p(v1), h2.h, _p(v2), float(nnratio), int(check_orientation), _p(out), C.byref(n)))
+        return int(n.value), out
+
+    def search_for_triangulation_h(self, h1, h2s, F12s, exs, eys, only_stereo, check_orientation=True):
+        nb = len(h2s)
+        hp = (_P * max(nb, 1))(*[h.h for h in h2s])
+        F = np.ascontiguousarray(np.asarray(F12s, np.float32).reshape(nb, 9))
+        ex, ey = np.ascontiguousarray(exs, np.float32), np.ascontiguousarray(eys, np.float32)
+        out, nm = np.full((nb, h1.n), -1, np.int32), np.zeros(nb, np.int32)
+        self.check(self.lib.eao_kf_search_for_triangulation(h1.h, nb, C.cast(hp, _P), _p(F), _p(ex), _p(ey), int(only_stereo), int(check_orientation), _p(out), _p(nm)))
+        return nm, out
+
+    def fuse_search_h(self, hs, use_sim3, poses, K, bf, pts, th):
+        nk = len(hs)
+        hp = (_P * max(nk, 1))(*[h.h for h in hs])
+        m, k2 = map_points(pts)
+        ps = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(nk, -1))
+        out, nf = np.full((nk, m.n), -1, np.int32), np.zeros(nk, np.int32)
+        self.check(self.lib.eao_kf_fuse_search(nk, C.cast(hp, _P), int(use_sim3), _p(ps), K[0], K[1], K[2], K[3], float(bf), C.byref(m), float(th), _p(out), _p(nf)))
+        return nf, out
+
+    # ---- the host-array signatures, routed through handles
+    def search_by_bow(self, mode, s1, s2, nnratio, check_orientation=True):
+        def as_frame(s):
+            n = len(s["descriptors"])
+            z = np.zeros(n, np.float32)
+            return dict(kp_x=z, kp_y=z, kp_octave=np.zeros(n, np.int32), kp_angle=s["angle"], u_right=z, descriptors=s["descriptors"], min_x=0.0, min_y=0.0, max_x=640.0,
+                        max_y=480.0, scale_factors=np.ones(1, np.float32))
+        key = (id(s1["descriptors"]), id(s1["fv"]["node_id"]), id(s2["descriptors"]), id(s2["fv"]["node_id"]))
+        hit = self._cache.get(("bow",) + key)
+        if hit is None:
+            f1, f2 = as_frame(s1), as_frame(s2)
+            hit = (self.handle(f1, s1["fv"]), self.handle(f2, s2["fv"]), s1, s2, f1, f2)
+            self._cache[("bow",) + key] = hit
+        return self.search_by_bow_h(mode, hit[0], s1["valid"], hit[1], s2.get("valid"), nnratio, check_orientation)
+
+    def search_for_triangulation(self, k1, fv1, k2, fv2, F12, ex, ey, only_stereo, check_orientation=True):
+        nm, out = self.search_for_triangulation_h(self.handle(k1, fv1), [self.handle(k2, fv2)], [F12], [ex], [ey], only_stereo, check_orientation)
+        return int(nm[0]), out[0]
+
+    def search_for_triangulation_batch(self, k1, fv1, k2s, fv2s, F12s, exs, eys, only_stereo, check_orientation=True):
+        return self.search_for_triangulation_h(self.handle(k1, fv1), [self.handle(k, f) for k, f in zip(k2s, fv2s)], F12s, exs, eys, only_stereo, check_orientation)
+
+    def fuse_search(self, kf, use_sim3, pose, K, bf, pts, th):
+        nf, out = self.fuse_search_h([self.handle(kf)], use_sim3, [np.asarray(pose, np.float32).ravel()], K, bf, pts, th)
+        return int(nf[0]), out[0]
+
+    def fuse_search_batch(self, kfs, use_sim3, poses, K, bf, pts, th):
+        return self.fuse_search_h([self.handle(k) for k in kfs], use_sim3, poses, K, bf, pts, th)
+
+    def search_by_projection_sim3(self, kf, Scw, K, pts, th):
+        h = self.handle(kf)
+        m, k2 = map_points(pts)
+        S = np.ascontiguousarray(Scw, np.float32)
+        occ = None if kf.get("occupied") is None else np.ascontiguousarray(kf["occupied"], np.uint8)
+        out, n = np.full(h.n, -1, np.int32), _I(0)
+        self.check(self.lib.eao_kf_search_by_projection_sim3(h.h, _p(occ), _p(S), K[0], K[1], K[2], K[3], C.byref(m), int(th), _p(out), C.byref(n)))
+        return int(n.value), out
+
+    def search_by_projection_kf(self, cur, Tcw, K, pts, kf_angle, th, orb_dist, check_orientation=True):
+        h = self.handle(cur)
+        m, k2 = map_points(pts)
+        T, ang = np.ascontiguousarray(Tcw, np.float32), np.ascontiguousarray(kf_angle, np.float32)
+        occ = None if cur.get("occupied") is None else np.ascontiguousarray(cur["occupied"], np.uint8)
+        out, n = np.full(h.n, -1, np.int32), _I(0)
+        self.check(self.lib.eao_kf_search_by_projection_kf(h.h, _p(occ), _p(T), K[0], K[1], K[2], K[3], C.byref(m), _p(ang), float(th), int(orb_dist), int(check_orientation),
+                                                           _p(out), C.byref(n)))
+        return int(n.value), out
+
+    def search_for_initialization(self, f1, f2, prev_matched, window, nnratio, check_orientation=True):
+        h2 = self.handle(f2)
+        o1, a1, d1 = np.ascontiguousarray(f1["kp_octave"], np.int32), np.ascontiguousarray(f1["kp_angle"], np.float32), np.ascontiguousarray(f1["descriptors"], np.uint8)
+        pm = np.array(prev_matched, np.float32, copy=True)
+        out, n = np.full(len(o1), -1, np.int32), _I(0)
+        self.check(self.lib.eao_kf_search_for_initialization(len(o1), _p(o1), _p(a1), _p(d1), h2.h, _p(pm), int(window), float(nnratio), int(check_orientation), _p(out), C.byref(n)))
+        return int(n.value), out, pm
+
+    def search_by_sim3(self, k1, T1w, pts1, k2, T2w, pts2, K, s12, R12, t12, th):
+        h1, h2 = self.handle(k1), self.handle(k2)
+        m1, km1 = map_points(pts1)
+        m2, km2 = map_points(pts2)
+        T1, T2 = np.ascontiguousarray(T1w, np.float32), np.ascontiguousarray(T2w, np.float32)
+        R, t = np.ascontiguousarray(R12, np.float32), np.ascontiguousarray(t12, np.float32)
+        out, n = np.full(m1.n, -1, np.int32), _I(0)
+        self.check(self.lib.eao_kf_search_by_sim3(h1.h, _p(T1), C.byref(m1), h2.h, _p(T2), C.byref(m2), K[0], K[1], K[2], K[3], float(s12), _p(R), _p(t), float(th), _p(out),
+                                                  C.byref(n)))
+        return int(n.value), out
+
+
 _binding = None
+_hbinding = None
+
+
+def product_handles():
+    """The searches through keyframe handles (eao_kf_*), bound to libeaofusion_hip.so."""
+    global _hbinding
+    if _hbinding is None:
+        from . import _lib
+        _hbinding = HandleBinding(_lib.load(), _lib.check)
+    return _hbinding
 
 
 def product():

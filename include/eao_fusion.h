@@ -342,6 +342,46 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
                               const float* T2w, const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12,
                               const float* R12, const float* t12, float th, int32_t* match12, int32_t* nfound);
 
+/* ---- keyframe handles (round 5): upload once, search many -------------------------------------------------------------------
+ * LocalMapping::CreateNewMapPoints / SearchInNeighbors (reference src/LocalMapping.cc:211-290, 458-520) and LoopClosing search the SAME keyframes again and
+ * again; the entry points above upload every frame with every call.  An eao_keyframe keeps what the guided searches read of a KeyFrame -- or of a Frame that is
+ * a search target -- in HBM: the view's keypoints / octaves / angles / uRight / descriptors, the grid order GetFeaturesInArea walks (built once), the scale
+ * tables, the DBoW2 feature vector (fv, may be NULL: the handle then serves the window searches only) and the occupancy view->occupied (NULL = none).  The
+ * arrays are copied: the caller's may go away.  A handle is immutable but for its occupancy; searches only read it, so any number of threads may search the
+ * same handle (each thread has its own stream and scratch).  `_kf` variants return exactly what their host-array counterparts above return on the same data. */
+typedef struct eao_keyframe eao_keyframe;
+eao_status eao_keyframe_create(const eao_frame_view* view, const eao_feature_vector* fv, eao_keyframe** out);
+/* occupied[k] != 0 where the keyframe holds a map point at keypoint k (GetMapPoint(k) != NULL) -- what SearchForTriangulation skips on both sides
+ * (src/ORBmatcher.cc:696-700, 712-716); NULL = no keypoint occupied.  Call it when map points were added to / erased from the keyframe. */
+eao_status eao_keyframe_update_points(eao_keyframe* kf, const uint8_t* occupied);
+void eao_keyframe_destroy(eao_keyframe* kf);
+int32_t eao_keyframe_size(const eao_keyframe* kf);      /* number of keypoints, -1 for NULL */
+
+/* a14 on handles, selection included ON THE DEVICE (a wavefront per common vocabulary node; two launches, one small copy back): arguments as
+ * eao_search_by_bow.  valid1 / valid2 change with the map and travel per call (n bytes each). */
+eao_status eao_kf_search_by_bow(int32_t mode, const eao_keyframe* kf1, const uint8_t* valid1, const eao_keyframe* kf2, const uint8_t* valid2, float nnratio,
+                                int32_t check_orientation, int32_t* match12, int32_t* nmatches);
+/* a15 on handles, all neighbours of LocalMapping::CreateNewMapPoints in one call, selection on the device: arguments as eao_search_for_triangulation_batch
+ * (n_nb = 1: the single search); the occupancy of both sides is the handles' (eao_keyframe_update_points).  match12: n_nb x size(kf1). */
+eao_status eao_kf_search_for_triangulation(const eao_keyframe* kf1, int32_t n_nb, const eao_keyframe* const* kf2s, const float* F12s, const float* exs,
+                                           const float* eys, int32_t only_stereo, int32_t check_orientation, int32_t* match12, int32_t* nmatches);
+/* a15 on handles, all targets of LocalMapping::SearchInNeighbors (or one: n_kf = 1) in one call: projection, window walk and gated best candidate per
+ * (target, point) on the device; arguments as eao_fuse_search_batch.  The points change from call to call and travel each time (70 bytes per point). */
+eao_status eao_kf_fuse_search(int32_t n_kf, const eao_keyframe* const* kfs, int32_t use_sim3, const float* poses, float fx, float fy, float cx, float cy,
+                              float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused);
+/* a13 / a15: the list-based searches with the searched frame taken from a handle (only the queries travel; the selection is replayed on the host as before).
+ * `occupied` replaces view->occupied of the host-array form (it differs from search to search: vpMatched, CurrentFrame.mvpMapPoints); NULL = none. */
+eao_status eao_kf_search_by_projection_sim3(const eao_keyframe* kf, const uint8_t* occupied, const float* Scw, float fx, float fy, float cx, float cy,
+                                            const eao_map_points* pts, int32_t th, int32_t* kp_match, int32_t* nmatches);
+eao_status eao_kf_search_by_projection_kf(const eao_keyframe* cur, const uint8_t* occupied, const float* Tcw, float fx, float fy, float cx, float cy,
+                                          const eao_map_points* pts, const float* kf_angle, float th, int32_t orb_dist, int32_t check_orientation,
+                                          int32_t* cur_match, int32_t* nmatches);
+eao_status eao_kf_search_for_initialization(int32_t n1, const int32_t* octave1, const float* angle1, const uint8_t* desc1, const eao_keyframe* f2,
+                                            float* prev_matched, int32_t window, float nnratio, int32_t check_orientation, int32_t* match12, int32_t* nmatches);
+eao_status eao_kf_search_by_sim3(const eao_keyframe* k1, const float* T1w, const eao_map_points* pts1, const eao_keyframe* k2, const float* T2w,
+                                 const eao_map_points* pts2, float fx, float fy, float cx, float cy, float s12, const float* R12, const float* t12, float th,
+                                 int32_t* match12, int32_t* nfound);
+
 /* ---- f1  Frame glue either side of the matcher ------------------------------------------------------------------ */
 
 /* What Frame::isInFrustum reads of the frame: mTcw (16 floats row-major: mRcw, mtcw), mOw, the static intrinsics and image

@@ -32,7 +32,7 @@ void range_push(const char*) {}
 void range_pop() {}
 
 namespace match {
-eao_status build_lists_multi(int nf, const eao_frame_view* const* Fs, const std::vector<Query>* qs, const uint8_t* const* qdescs, Lists* Ls) {
+eao_status build_lists_multi(int nf, const eao_frame_view* const* Fs, const std::vector<Query>* qs, const uint8_t* const* qdescs, Lists* Ls, const Resident* const*) {
     for (int f = 0; f < nf; f++) {
         const int nq = (int)qs[f].size(), n = Fs[f]->n;
         Ls[f].start.assign(nq, 0); Ls[f].count.assign(nq, 0); Ls[f].items.clear();
@@ -45,7 +45,7 @@ eao_status build_lists_multi(int nf, const eao_frame_view* const* Fs, const std:
     }
     return EAO_OK;
 }
-eao_status build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L) { return build_lists_multi(1, &F, &q, &qdesc, &L); }
+eao_status build_lists(const eao_frame_view* F, const std::vector<Query>& q, const uint8_t* qdesc, Lists& L, const Resident*) { return build_lists_multi(1, &F, &q, &qdesc, &L, nullptr); }
 eao_status pair_distances(const uint8_t* descA, int nA, const uint8_t* descB, int nB, const std::vector<int>& ia, const std::vector<int>& ib,
                           std::vector<unsigned short>& dist) {
     dist.assign(ia.size(), 0);

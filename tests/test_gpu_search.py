@@ -8,12 +8,14 @@ from eao_fusion_amd import search, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def both(oracle):
+@pytest.fixture(scope="module", params=["host arrays", "keyframe handles"])
+def both(request, oracle):
+    """Every case below runs twice: through the host-array entry points (eao_search_* / eao_fuse_search*) and through keyframe handles (eao_kf_*, round 5: frames
+    resident in HBM, the vocabulary-node searches and Fuse selected on the device) -- the same match tables as the oracle either way."""
     import torch  # noqa: F401  (first, so that the library resolves the same HIP runtime)
     import eao_fusion_amd as E
     assert E.load().eao_device_check() == 0, E.load().eao_last_error()
-    return search.product(), oracle.search_binding()
+    return (search.product() if request.param == "host arrays" else search.product_handles()), oracle.search_binding()
 
 
 @pytest.fixture(scope="module", params=[dict(), dict(n=1200, seed=8001, flip=0.09, mono_frac=0.6), dict(n=300, seed=8002, clutter=0.5, n_nodes=12)])
@@ -213,3 +215,43 @@ def test_searches_refuse_bad_input(both, scene):
         g.fuse_search(scene["K2"], 1, Sn, scene["K"], scene["bf"], scene["points"], 3.0)
     with pytest.raises(E.EaoError):
         g.fuse_search(k2, 1, scene["Scw"], scene["K"], scene["bf"], scene["points"], 3.0)
+
+
+def test_keyframe_handle_lifecycle(oracle):
+    """Handles are reusable across searches and calls, their occupancy can be replaced (eao_keyframe_update_points), big vocabulary nodes (more than 64 features on
+    either side: the in-register chunk and the memory rounds of the node kernel) and more neighbours than one launch carries (> 16) give the oracle's tables."""
+    import torch  # noqa: F401
+    g, o = search.product_handles(), oracle.search_binding()
+    sc = synth.synth_search_scene(n=1500, seed=8110, n_nodes=9)          # ~190 features per node
+    k1, k2 = dict(sc["K1"]), dict(sc["K2"])
+    h1, h2 = g.handle(k1, sc["fv1"]), g.handle(k2, sc["fv2"])
+    assert g.lib.eao_keyframe_size(h1.h) == len(k1["kp_x"])
+    s1 = dict(descriptors=k1["descriptors"], angle=k1["kp_angle"], valid=(sc["mp1"] >= 0).astype(np.uint8), fv=sc["fv1"])
+    s2 = dict(descriptors=k2["descriptors"], angle=k2["kp_angle"], valid=(sc["mp2"] >= 0).astype(np.uint8), fv=sc["fv2"])
+    for mode in (0, 1):
+        for rep in range(2):
+            got = g.search_by_bow_h(mode, h1, s1["valid"], h2, s2["valid"], 0.8, True)
+            want = o.search_by_bow(mode, s1, s2, 0.8, True)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[0] > 10
+    for rnd in range(3):
+        occ1 = (np.arange(len(k1["kp_x"])) % (2 + rnd) == 0).astype(np.uint8)
+        occ2 = (np.arange(len(k2["kp_x"])) % (3 + rnd) == 1).astype(np.uint8)
+        h1.update_points(occ1); h2.update_points(occ2 if rnd else None)
+        a, b = dict(k1), dict(k2)
+        a["occupied"], b["occupied"] = occ1, (occ2 if rnd else np.zeros_like(occ2))
+        nm, m = g.search_for_triangulation_h(h1, [h2] * 19, [sc["F12"]] * 19, [sc["ex"]] * 19, [sc["ey"]] * 19, 0, True)
+        want = o.search_for_triangulation(a, sc["fv1"], b, sc["fv2"], sc["F12"], sc["ex"], sc["ey"], 0, True)
+        assert all(nm[k] == want[0] and np.array_equal(m[k], want[1]) for k in range(19)), "round %d" % rnd
+    # a feature vector that files a keypoint under two nodes: the handle path hands over to the host replay (upstream's walk order matters across nodes)
+    fv = {k: v.copy() for k, v in sc["fv2"].items()}
+    fv["index"][fv["node_start"][1]] = fv["index"][fv["node_start"][0]]
+    hd = g.handle(k2, fv)
+    s2d = dict(s2); s2d["fv"] = fv
+    got = g.search_by_bow_h(0, h1, s1["valid"], hd, None, 0.8, True)
+    want = o.search_by_bow(0, s1, s2d, 0.8, True)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    T = sc["T2w"].astype(np.float64)
+    pose = np.concatenate([T[:3, :3].ravel(), T[:3, 3], -T[:3, :3].T @ T[:3, 3]]).astype(np.float32)
+    nf, best = g.fuse_search_h([h2] * 18, 0, [pose] * 18, sc["K"], sc["bf"], sc["points"], 3.0)
+    want = o.fuse_search(k2, 0, pose, sc["K"], sc["bf"], sc["points"], 3.0)
+    assert all(nf[k] == want[0] and np.array_equal(best[k], want[1]) for k in range(18)) and want[0] > 10
