@@ -17,7 +17,10 @@
 //     the handle: only the queries travel.
 // Results are those of the host-array entry points, entry for entry (tests/test_gpu_search.py runs every case through both and against the CPU restatement).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -46,34 +49,66 @@ __device__ __forceinline__ int dist256(const uint4 a0, const uint4 a1, const uin
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
+// Smallest value of the wave, on the VALU's data-parallel primitives: four row_shr steps leave lane 15 of every row of 16 with the row's minimum, row_bcast15 /
+// row_bcast31 carry it across the rows into lane 63, one v_readlane hands it to everybody.  (A shuffle butterfly -- six dependent ds_bpermute round trips per
+// key, ~150 cycles each -- made every step of the node walk 0.5 us: 976 ticks of 10 ns for 20 features, EAO_DEBUG_STAMPS.)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    constexpr int kId = (int)0xFFFFFFFFu;      // lanes without a source (row edges, rows outside the mask) read the identity
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(kId, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(kId, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(kId, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(kId, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(kId, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast15 into rows 1 and 3
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(kId, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ---------------------------------------------------------------------------------------------------------------- vocabulary-node searches
 struct NodeProb { const KfDev* k2; float F[9]; float ex, ey; };
 struct NodesArgs {
-    const KfDev* k1;
+    KfDev K1;                     // side 1 by value: one dependent load less at the head of every wave
     int nProb, onlyStereo;
     float nnratio;
     const unsigned char* valid1; const unsigned char* valid2;      // BoW: mapped host arrays (gathered once per wave); triangulation: unused
     int2* match;                  // per (problem, side-1 keypoint): {generation stamp, side-2 keypoint}
     int gen, n1;
     NodeProb P[kMaxProb];
+    // ONE problem (nProb == 1) whose side 1 has at most kPairCap nodes: side 2 travels by value too and the host has merged the two node-id lists already
+    // (pairB[a] = the node of side 2 with the id of side 1's node a, or -1) -- the wave's head loses its chain of dependent loads (struct, node id, six probes)
+    long long* dbg;               // EAO_DEBUG_STAMPS=1: shader-clock stamps of the wave that owns side-1 node 0 (diagnostic runs only)
+    int single;
+    KfDev K2v;
+    short pairB[512];
 };
+constexpr int kPairCap = 512;
 
 // MODE 0: SearchByBoW(KeyFrame*, Frame&), 1: SearchByBoW(KeyFrame*, KeyFrame*), 2: SearchForTriangulation
 template <int MODE>
 __global__ __launch_bounds__(256) void k_kf_nodes(NodesArgs A) {
     const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + (threadIdx.x >> 6), pb = blockIdx.y;
-    const KfDev K1 = *A.k1;
+    const KfDev& K1 = A.K1;
     if (a >= K1.nNodes) return;
+    const bool stamp = A.dbg && a == 0 && pb == 0 && lane == 0;
+    if (stamp) A.dbg[0] = wall_clock64();
     const NodeProb& PB = A.P[pb];
-    const KfDev K2 = *PB.k2;
-    // the node of side 1 in side 2's vector (both ascending: std::map order; upstream's merge walk with lower_bound, :175-262)
-    const unsigned id = K1.nodeId[a];
-    int lo = 0, hi = K2.nNodes;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (K2.nodeId[mid] < id) lo = mid + 1; else hi = mid;
+    KfDev K2;
+    int lo;
+    if (A.single) {
+        lo = A.pairB[a];
+        if (lo < 0) return;
+        K2 = A.K2v;
+    } else {
+        K2 = *PB.k2;
+        // the node of side 1 in side 2's vector (both ascending: std::map order; upstream's merge walk with lower_bound, :175-262)
+        const unsigned id = K1.nodeId[a];
+        lo = 0;
+        int hi = K2.nNodes;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (K2.nodeId[mid] < id) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= K2.nNodes || K2.nodeId[lo] != id) return;
     }
-    if (lo >= K2.nNodes || K2.nodeId[lo] != id) return;
     const int s1 = K1.nodeStart[a], c1 = K1.nodeStart[a + 1] - s1, s2 = K2.nodeStart[lo], c2 = K2.nodeStart[lo + 1] - s2;
     if (c1 <= 0 || c2 <= 0) return;
     // side 2, first 64 entries of the node in registers (a node rarely holds more; the rest is read from memory in every round)
@@ -92,29 +127,44 @@ __global__ __launch_bounds__(256) void k_kf_nodes(NodesArgs A) {
         if (MODE == 2) { xx = K2.kx[i2]; yy = K2.ky[i2]; oc = K2.oct[i2]; st2 = K2.ur[i2] >= 0; }
         return true;
     };
+    if (stamp) { A.dbg[1] = wall_clock64(); A.dbg[6] = c1; A.dbg[7] = c2; }
     if (lane < c2) skip2 = !load2(lane, idx2, f0, f1, x2, y2, oct2, stereo2);
+    if (A.dbg) __builtin_amdgcn_s_waitcnt(0);      // (diagnostic runs: the stamp below then includes the loads' latency)
+    if (stamp) { A.dbg[2] = wall_clock64() + (f0.x & 0); }
     unsigned long long taken = 0;      // bit j: list position lane + 64 j of the node's side 2 has been matched (BoW)
     int matched = 0;
     for (int a0 = 0; a0 < c1; a0 += 64) {
-        // side 1, 64 entries at a time: which of them upstream looks at (a ballot), their keypoint indices in the lanes
+        // side 1, 64 entries at a time: lane aa loads entry a0 + aa -- index, "does upstream look at it" (a ballot), descriptor, and for the triangulation its
+        // coordinates -- all 64 in flight at once; the walk below fetches them lane by lane with v_readlane (the walk's counter is wave-uniform).  Loading each
+        // descriptor when its turn came made every step of the walk a cache miss: 19.9 us per launch on the 1000-keypoint scene.
         int myIdx1 = 0;
         bool ok1 = false;
+        uint4 m0 = make_uint4(0, 0, 0, 0), m1d = m0;
+        float mx1 = 0, my1 = 0, mur1 = -1;
         if (a0 + lane < c1) {
             myIdx1 = (int)K1.index[s1 + a0 + lane];
-            if (MODE == 2) ok1 = !(K1.occ[myIdx1] || (A.onlyStereo && !(K1.ur[myIdx1] >= 0)));
+            if (MODE == 2) { mur1 = K1.ur[myIdx1]; ok1 = !(K1.occ[myIdx1] || (A.onlyStereo && !(mur1 >= 0))); }
             else ok1 = A.valid1[myIdx1] != 0;
+            if (ok1) {
+                m0 = K1.desc[2 * (size_t)myIdx1]; m1d = K1.desc[2 * (size_t)myIdx1 + 1];
+                if (MODE == 2) { mx1 = K1.kx[myIdx1]; my1 = K1.ky[myIdx1]; }
+            }
         }
         const unsigned long long m1 = __ballot(ok1);
+        if (A.dbg) __builtin_amdgcn_s_waitcnt(0);
+        if (stamp && a0 == 0) A.dbg[3] = wall_clock64() + (m0.x & 0);
         const int cnt = min(64, c1 - a0);
         for (int aa = 0; aa < cnt; aa++) {
             if (!((m1 >> aa) & 1)) continue;
-            const int idx1 = __shfl(myIdx1, aa);
-            const uint4 d0 = K1.desc[2 * (size_t)idx1], d1 = K1.desc[2 * (size_t)idx1 + 1];
+            const int idx1 = __builtin_amdgcn_readlane(myIdx1, aa);
+            uint4 d0, d1;
+            d0.x = __builtin_amdgcn_readlane(m0.x, aa); d0.y = __builtin_amdgcn_readlane(m0.y, aa); d0.z = __builtin_amdgcn_readlane(m0.z, aa); d0.w = __builtin_amdgcn_readlane(m0.w, aa);
+            d1.x = __builtin_amdgcn_readlane(m1d.x, aa); d1.y = __builtin_amdgcn_readlane(m1d.y, aa); d1.z = __builtin_amdgcn_readlane(m1d.z, aa); d1.w = __builtin_amdgcn_readlane(m1d.w, aa);
             float la = 0, lb = 0, lc = 0, den = 0;
             bool stereo1 = false;
             if (MODE == 2) {      // the epipolar line of keypoint 1 in image 2 (CheckDistEpipolarLine, :140-157)
-                const float x1 = K1.kx[idx1], y1 = K1.ky[idx1];
-                stereo1 = K1.ur[idx1] >= 0;
+                const float x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mx1), aa)), y1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my1), aa));
+                stereo1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mur1), aa)) >= 0;
                 la = x1 * PB.F[0] + y1 * PB.F[3] + PB.F[6];
                 lb = x1 * PB.F[1] + y1 * PB.F[4] + PB.F[7];
                 lc = x1 * PB.F[2] + y1 * PB.F[5] + PB.F[8];
@@ -149,13 +199,13 @@ __global__ __launch_bounds__(256) void k_kf_nodes(NodesArgs A) {
                 if (!load2(p, i2, g0, g1, xx, yy, oc, st2)) continue;
                 offer(p, g0, g1, xx, yy, oc, st2);
             }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {      // the wave's two smallest keys (all distinct: the position is part of the key)
-                const unsigned o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
-                const unsigned lo1 = min(k1, o1), hi1 = max(k1, o1);
-                k2 = min(hi1, min(k2, o2)); k1 = lo1;
+            // the wave's two smallest keys (all distinct: the position is part of the key): the minimum, then the minimum again with its owner's runner-up in its place
+            {
+                const unsigned b1 = wave_min_u32(k1);
+                if (b1 == 0xFFFFFFFFu) continue;
+                const unsigned b2 = (MODE == 2) ? 0xFFFFFFFFu : wave_min_u32(k1 == b1 ? k2 : k1);      // (the triangulation has no ratio test)
+                k1 = b1; k2 = b2;
             }
-            if (k1 == 0xFFFFFFFFu) continue;
             const int best1 = (int)(k1 >> 16), best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 16);
             bool accept;
             int p;
@@ -166,29 +216,37 @@ __global__ __launch_bounds__(256) void k_kf_nodes(NodesArgs A) {
             }
             if (!accept) continue;
             if (MODE != 2 && (p & 63) == lane) taken |= 1ull << (p >> 6);      // (triangulation never consumes side 2: upstream does not set vbMatched2)
+            // (the winner's keypoint index sits in lane p's register for the node's first 64 entries: a load here would stall every matching step of the walk
+            //  for a cache round trip -- 0.45 us per step, EAO_DEBUG_STAMPS)
+            const int win = p < 64 ? __builtin_amdgcn_readlane(idx2, p) : (int)K2.index[s2 + p];
             if (lane == 0) {
-                A.match[(size_t)pb * A.n1 + idx1] = make_int2(A.gen, (int)K2.index[s2 + p]);
+                A.match[(size_t)pb * A.n1 + idx1] = make_int2(A.gen, win);
                 matched++;
             }
         }
     }
     (void)matched;
+    if (stamp) A.dbg[4] = wall_clock64();
 }
 
 // rotation histogram + ComputeThreeMaxima (src/ORBmatcher.cc:1603-1644) over a problem's matches, the table and its count into mapped host memory
 struct FinishArgs {
-    const KfDev* k1;
+    const float* ang1;
     int nProb, n1, gen, checkOrientation;
     const int2* match;
     int* out;        // mapped host: nProb x n1
     int* nm;         // mapped host: nProb
-    const KfDev* k2[kMaxProb];
+    // the call's LAST finish launch publishes a done word the host polls (as the tracker's chain does, csrc/lm.hip pose_publish): every workgroup fences its
+    // stores to host memory at system scope, reads one of its own words back over PCIe (a read pushes posted writes) and takes a ticket; the last one stores
+    // the word.  done == nullptr: the host synchronises the stream instead.
+    int* ticket; int ticketLast; int* done; int doneSeq;
+    const float* ang2[kMaxProb];
 };
 __global__ __launch_bounds__(256) void k_kf_finish(FinishArgs A) {
     __shared__ int s_hist[HISTO], s_keep[3], s_nm;
     const int pb = blockIdx.x, t = threadIdx.x;
-    const float* ang1 = A.k1->ang;
-    const float* ang2 = A.k2[pb]->ang;
+    const float* ang1 = A.ang1;
+    const float* ang2 = A.ang2[pb];
     const float factor = 1.0f / HISTO;
     if (t < HISTO) s_hist[t] = 0;
     if (t == 0) { s_nm = 0; s_keep[0] = s_keep[1] = s_keep[2] = -1; }
@@ -201,13 +259,30 @@ __global__ __launch_bounds__(256) void k_kf_finish(FinishArgs A) {
         if (b == HISTO) b = 0;
         return b;
     };
-    if (A.checkOrientation) {
-        for (int i = t; i < A.n1; i += 256) {
+    // up to kFinPer x 256 keypoints: a thread's matches and their bins stay in registers between the vote and the verdict (one pass over memory)
+    constexpr int kFinPer = 8;
+    int mm[kFinPer], bb[kFinPer];
+    const bool inRegs = A.n1 <= kFinPer * 256;
+#pragma unroll
+    for (int u = 0; u < kFinPer; u++) {
+        const int i = t + 256 * u;
+        mm[u] = -1; bb[u] = -1;
+        if (inRegs && i < A.n1) {
             const int2 e = M[i];
-            if (e.x != A.gen) continue;
-            const int b = bin_of(i, e.y);
-            if (b >= 0 && b < HISTO) atomicAdd(&s_hist[b], 1);
+            if (e.x == A.gen) {
+                mm[u] = e.y;
+                if (A.checkOrientation) { bb[u] = bin_of(i, e.y); if (bb[u] >= 0 && bb[u] < HISTO) atomicAdd(&s_hist[bb[u]], 1); }
+            }
         }
+    }
+    if (A.checkOrientation) {
+        if (!inRegs)
+            for (int i = t; i < A.n1; i += 256) {
+                const int2 e = M[i];
+                if (e.x != A.gen) continue;
+                const int b = bin_of(i, e.y);
+                if (b >= 0 && b < HISTO) atomicAdd(&s_hist[b], 1);
+            }
         __syncthreads();
         if (t == 0) {
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -224,20 +299,41 @@ __global__ __launch_bounds__(256) void k_kf_finish(FinishArgs A) {
         __syncthreads();
     }
     int kept = 0;
-    for (int i = t; i < A.n1; i += 256) {
-        const int2 e = M[i];
-        int m = e.x == A.gen ? e.y : -1;
-        if (m >= 0 && A.checkOrientation) {
-            const int b = bin_of(i, m);
-            if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) m = -1;
+    if (inRegs) {
+#pragma unroll
+        for (int u = 0; u < kFinPer; u++) {
+            const int i = t + 256 * u;
+            if (i >= A.n1) continue;
+            int m = mm[u];
+            if (m >= 0 && A.checkOrientation && bb[u] != s_keep[0] && bb[u] != s_keep[1] && bb[u] != s_keep[2]) m = -1;
+            A.out[(size_t)pb * A.n1 + i] = m;
+            kept += m >= 0;
         }
-        A.out[(size_t)pb * A.n1 + i] = m;
-        kept += m >= 0;
+    } else {
+        for (int i = t; i < A.n1; i += 256) {
+            const int2 e = M[i];
+            int m = e.x == A.gen ? e.y : -1;
+            if (m >= 0 && A.checkOrientation) {
+                const int b = bin_of(i, m);
+                if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) m = -1;
+            }
+            A.out[(size_t)pb * A.n1 + i] = m;
+            kept += m >= 0;
+        }
     }
     for (int o = 32; o >= 1; o >>= 1) kept += __shfl_xor(kept, o);
     if ((t & 63) == 0 && kept) atomicAdd(&s_nm, kept);
     __syncthreads();
     if (t == 0) A.nm[pb] = s_nm;
+    if (A.done) {
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0) {
+            const int back = __hip_atomic_load(&A.nm[pb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (cannot pass this workgroup's posted writes)
+            const int tk = atomicAdd(A.ticket, 1);
+            if (tk == A.ticketLast && back == s_nm) __hip_atomic_store(A.done, A.doneSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- Fuse
@@ -358,6 +454,11 @@ struct Ctx {   // per host thread, grow-only
     PinBuf in, out;
     eao::DevBuf<int2> match;
     eao::DevBuf<unsigned char> dev;
+    eao::DevBuf<int> ticket;       // finish workgroups of all calls so far take their tickets here (a device counter that only grows)
+    int ticketNext = 0;
+    PinBuf doneWord;
+    long long* dbg = nullptr;
+    int seq = 0;
     int gen = 0;
     ~Ctx() { if (stream) (void)hipStreamDestroy(stream); }
 };
@@ -548,20 +649,49 @@ eao_status run_nodes(int mode, const eao_keyframe* k1, int nProb, const eao_keyf
     if (valid2) std::memcpy(c.in.p + oV2, valid2, k2s[0]->D.n);
     const size_t oTab = al256(4 * (size_t)nProb);
     if ((st = c.out.reserve(oTab + 4 * cells))) return st;
+    if (!c.ticket.p) {
+        if ((st = c.ticket.reserve(1))) return st;
+        EAO_HIP(hipMemsetAsync(c.ticket.p, 0, sizeof(int), c.stream));
+        c.ticketNext = 0;
+        if ((st = c.doneWord.reserve(64))) return st;
+    }
+    static const int envPoll = getenv("EAO_KF_POLL") ? atoi(getenv("EAO_KF_POLL")) : 1;      // 0: hipStreamSynchronize (A/B switch)
+    if (c.ticketNext > 0x70000000) { EAO_HIP(hipMemsetAsync(c.ticket.p, 0, sizeof(int), c.stream)); c.ticketNext = 0; }
+    const int seq = ++c.seq;
+    volatile int* doneHost = reinterpret_cast<volatile int*>(c.doneWord.p);
+    *doneHost = 0;
     for (int p0 = 0; p0 < nProb; p0 += kMaxProb) {
         const int np = std::min(kMaxProb, nProb - p0);
         NodesArgs A;
-        A.k1 = (const KfDev*)k1->dev; A.nProb = np; A.onlyStereo = onlyStereo; A.nnratio = nnratio;
+        A.K1 = k1->D; A.nProb = np; A.onlyStereo = onlyStereo; A.nnratio = nnratio;
         A.valid1 = valid1 ? c.in.d + oV1 : nullptr; A.valid2 = valid2 ? c.in.d + oV2 : nullptr;
         A.match = c.match.p + (size_t)p0 * n1; A.gen = c.gen; A.n1 = n1;
+        static const bool envStamps = getenv("EAO_DEBUG_STAMPS") && atoi(getenv("EAO_DEBUG_STAMPS"));
+        if (envStamps && !c.dbg) EAO_HIP(hipMalloc((void**)&c.dbg, 64 * sizeof(long long)));
+        A.dbg = c.dbg;
+        A.single = 0;
+        if (nProb == 1 && k1->D.nNodes <= kPairCap && k2s[0]->D.nNodes < 32768) {
+            A.single = 1;
+            A.K2v = k2s[0]->D;
+            const eao_keyframe* k2 = k2s[0];
+            int b = 0;
+            for (int a = 0; a < k1->D.nNodes; a++) {
+                while (b < k2->D.nNodes && k2->nodeId[b] < k1->nodeId[a]) b++;
+                A.pairB[a] = (short)((b < k2->D.nNodes && k2->nodeId[b] == k1->nodeId[a]) ? b : -1);
+            }
+        }
         FinishArgs B;
-        B.k1 = A.k1; B.nProb = np; B.n1 = n1; B.gen = c.gen; B.checkOrientation = checkOrientation; B.match = A.match;
+        B.ang1 = k1->D.ang; B.nProb = np; B.n1 = n1; B.gen = c.gen; B.checkOrientation = checkOrientation; B.match = A.match;
         B.out = (int*)(c.out.d + oTab) + (size_t)p0 * n1; B.nm = (int*)c.out.d + p0;
+        const bool lastChunk = p0 + np >= nProb;
+        B.ticket = c.ticket.p; B.done = nullptr; B.doneSeq = seq; B.ticketLast = -1;
+        if (envPoll && lastChunk) { B.done = (int*)c.doneWord.d; B.ticketLast = c.ticketNext + nProb - 1; }      // the last workgroup of the call's LAST launch: every earlier one has taken its ticket
+        else if (envPoll) { B.done = (int*)c.doneWord.d; B.doneSeq = 0; }                                            // (earlier chunks take tickets and confirm their stores; they never see ticketLast)
         for (int q = 0; q < np; q++) {
             A.P[q].k2 = (const KfDev*)k2s[p0 + q]->dev;
             if (F12s) { std::memcpy(A.P[q].F, F12s + 9 * (size_t)(p0 + q), 36); A.P[q].ex = exs[p0 + q]; A.P[q].ey = eys[p0 + q]; }
             else { std::memset(A.P[q].F, 0, 36); A.P[q].ex = A.P[q].ey = 0; }
-            B.k2[q] = A.P[q].k2;
+            B.ang2[q] = k2s[p0 + q]->D.ang;
         }
         const dim3 grid(eao::cdiv(std::max(k1->D.nNodes, 1), 4), np);
         if (mode == 0) hipLaunchKernelGGL(k_kf_nodes<0>, grid, dim3(256), 0, c.stream, A);
@@ -569,8 +699,22 @@ eao_status run_nodes(int mode, const eao_keyframe* k1, int nProb, const eao_keyf
         else hipLaunchKernelGGL(k_kf_nodes<2>, grid, dim3(256), 0, c.stream, A);
         hipLaunchKernelGGL(k_kf_finish, dim3(np), dim3(256), 0, c.stream, B);
     }
-    EAO_HIP(hipStreamSynchronize(c.stream));
+    bool seen = false;
+    if (envPoll) {
+        c.ticketNext += nProb;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; !(seen = *doneHost == seq); spins++)
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) EAO_HIP(hipStreamSynchronize(c.stream));
     EAO_HIP(hipGetLastError());
+    if (c.dbg) {
+        long long st[8];
+        EAO_HIP(hipMemcpy(st, c.dbg, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[eao kf nodes stamps] node 0 (%lld x %lld features): head %lld, side 2 in registers %lld, side 1 in registers %lld, walk %lld ticks of 10 ns\n", st[6], st[7],
+                st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3]);
+    }
     std::memcpy(nmatches, c.out.p, 4 * (size_t)nProb);
     std::memcpy(match12, c.out.p + oTab, 4 * cells);
     return EAO_OK;
@@ -605,7 +749,7 @@ eao_status eao_kf_search_for_triangulation(const eao_keyframe* kf1, int32_t n_nb
     bool unique = kf1->fvUnique;
     for (int k = 0; k < n_nb; k++) {
         EAO_REQUIRE(kf2s[k] && kf2s[k]->hasFv && kf2s[k]->view.level_sigma2, "neighbour %d: no handle, no feature vector or no level_sigma2 in its view", k);
-        EAO_REQUIRE(finite_n(F12s + 9 * (size_t)k, 9) && std::isfinite(exs[k]) && std::isfinite(eys[k]), "neighbour %d: F12 / the epipole holds a NaN / Inf", k);
+        EAO_REQUIRE(finite_n(F12s + 9 * (size_t)k, 9), "neighbour %d: F12 holds a NaN / Inf", k);      // (the epipole may: a keyframe against itself projects its own centre -- upstream's comparison with it is then false, here too)
         unique = unique && kf2s[k]->fvUnique;
     }
     if (!unique) {

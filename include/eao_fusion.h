@@ -330,7 +330,8 @@ eao_status eao_fuse_search(const eao_frame_view* KF, int32_t use_sim3, const flo
  * points travel once, every target's frame and windows in the same copy, one synchronisation.  KFs: n_kf pointers; poses: 15 (use_sim3 = 0) or 16 floats per
  * target; best_kp: n_kf x pts->n; nfused: n_kf.  Equal to n_kf single calls ON THE SAME MAP STATE: an earlier target's fusions change the map, so the caller,
  * applying the targets in order, re-checks isBad() and IsInKeyFrame(pKFi) (upstream's `continue`s, src/ORBmatcher.cc:851-861) before it uses a later
- * target's candidate. */
+ * target's candidate -- and searches again, against the remaining targets, every point whose DESCRIPTOR an applied fusion changed (pMPinKF->Replace(pMP) ends in
+ * pMP->ComputeDistinctiveDescriptors(), src/MapPoint.cc:177-215): eaofusion::ORBmatcher::FuseBatch does both. */
 eao_status eao_fuse_search_batch(int32_t n_kf, const eao_frame_view* const* KFs, int32_t use_sim3, const float* poses, float fx, float fy, float cx, float cy,
                                  float bf, const eao_map_points* pts, float th, int32_t* best_kp, int32_t* nfused);
 

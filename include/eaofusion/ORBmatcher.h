@@ -318,6 +318,39 @@ public:
         }
     }
 
+    // Round 5 -- the same call over KEYFRAME HANDLES (KeyFrameHandles further down: a keyframe is uploaded once and searched many times -- the neighbours of this
+    // new keyframe are mostly the neighbours of the next one): the whole search, selection included, runs on the device (eao_kf_search_for_triangulation).
+    template <class KeyFrameT>
+    void SearchForTriangulationBatch(const eao_keyframe* h1, KeyFrameT* pKF1, const std::vector<const eao_keyframe*>& h2s, const std::vector<KeyFrameT*>& vpNeighKFs,
+                                     const std::vector<cv::Mat>& vF12, std::vector<std::vector<std::pair<size_t, size_t> > >& vvMatchedPairs, const bool bOnlyStereo) {
+        const size_t nb = vpNeighKFs.size();
+        vvMatchedPairs.assign(nb, std::vector<std::pair<size_t, size_t> >());
+        if (!nb) return;
+        std::vector<float> Fm(9 * nb), ex(nb), ey(nb);
+        const cv::Mat Cw = pKF1->GetCameraCenter();
+        for (size_t q = 0; q < nb; q++) {
+            KeyFrameT* pKF2 = vpNeighKFs[q];
+            const cv::Mat R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();      // the epipole in the second image, as in the single call (:663-670)
+            float C2[3];
+            for (int r = 0; r < 3; r++) {
+                double acc = 0;
+                for (int k = 0; k < 3; k++) acc += (double)R2w.template at<float>(r, k) * (double)Cw.template at<float>(k);
+                C2[r] = (float)(acc + (double)t2w.template at<float>(r));
+            }
+            const float invz = 1.0f / C2[2];
+            ex[q] = pKF2->fx * C2[0] * invz + pKF2->cx; ey[q] = pKF2->fy * C2[1] * invz + pKF2->cy;
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Fm[9 * q + r * 3 + c] = vF12[q].template at<float>(r, c);
+        }
+        const int n1 = eao_keyframe_size(h1);
+        std::vector<int32_t> m12(nb * (size_t)n1, -1), nm(nb, 0);
+        check(eao_kf_search_for_triangulation(h1, (int)nb, h2s.data(), Fm.data(), ex.data(), ey.data(), bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, m12.data(), nm.data()),
+              "eao_kf_search_for_triangulation");
+        for (size_t q = 0; q < nb; q++) {
+            vvMatchedPairs[q].reserve(nm[q]);
+            for (int i = 0; i < n1; i++) if (m12[q * n1 + i] >= 0) vvMatchedPairs[q].push_back(std::make_pair((size_t)i, (size_t)m12[q * n1 + i]));
+        }
+    }
+
     // reference :825-975 (LocalMapping::SearchInNeighbors).  The search runs for all points first; replacing / adding
     // observations then happens in index order exactly as upstream interleaves it, re-checking the entry conditions a
     // previous replacement may have changed.
@@ -355,34 +388,54 @@ public:
 
     // Round 4 -- the points of LocalMapping::SearchInNeighbors against ALL its target keyframes in one library call (src/LocalMapping.cc:484-494 / :509-519 call
     // Fuse once per target): the searches of every target run up front on the map as it is, then the targets are applied IN ORDER exactly as the single calls apply
-    // them -- a point that an earlier target's fusion made bad, or put into the keyframe at hand, is skipped as upstream's loop head would skip it (:851-861; a
-    // point's search does not depend on any other point's, so skipping is all that an earlier fusion can change).  Returns the sum of the targets' nFused; the
+    // them -- a point that an earlier target's fusion made bad, or put into the keyframe at hand, is skipped as upstream's loop head would skip it (:851-861).
+    // Round 5: an earlier target's fusion can also change what a LATER target's search reads -- pMPinKF->Replace(pMP) ends in
+    // pMP->ComputeDistinctiveDescriptors() (src/MapPoint.cc:177-215), so the surviving candidate meets the next targets with a NEW descriptor.  The points a target
+    // leaves in that state are therefore searched again (they alone, against the remaining targets, one more library call per target that produced any -- with
+    // keyframe handles a few tens of microseconds) before the next target is applied: the result equals the single calls in a row, descriptor changes included
+    // (tests/cpp/search_adapter_test.cpp 9b, whose stand-in Replace now changes the survivor's descriptor).  Returns the sum of the targets' nFused; the
     // per-target counts in *nFusedPerKF when given.  One camera for all targets (the batch entry point takes fx .. mbf once), as in the reference.
+    // `handles` (may be NULL): the targets' keyframe handles -- the searches then run on frames resident in HBM (eao_kf_fuse_search) instead of uploading them.
     template <class KeyFrameT, class MapPointT>
-    int FuseBatch(const std::vector<KeyFrameT*>& vpTargetKFs, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0, std::vector<int>* nFusedPerKF = nullptr) {
+    int FuseBatch(const std::vector<KeyFrameT*>& vpTargetKFs, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0, std::vector<int>* nFusedPerKF = nullptr,
+                  const std::vector<const eao_keyframe*>* handles = nullptr) {
         const size_t nk = vpTargetKFs.size(), np = vpMapPoints.size();
         if (nFusedPerKF) nFusedPerKF->assign(nk, 0);
         if (!nk || !np) return 0;
-        PointArrays pa;
-        const eao_map_points mp = gather(vpMapPoints, pa, [&](MapPointT* p) { return p && !p->isBad(); });
-        std::vector<FrameArrays> fa(nk);
-        std::vector<eao_frame_view> v(nk);
-        std::vector<const eao_frame_view*> pv(nk);
+        std::vector<FrameArrays> fa(handles ? 0 : nk);
+        std::vector<eao_frame_view> v(handles ? 0 : nk);
+        std::vector<const eao_frame_view*> pv(handles ? 0 : nk);
         std::vector<float> poses(15 * nk);
         for (size_t q = 0; q < nk; q++) {
             KeyFrameT* pKF = vpTargetKFs[q];
-            v[q] = kfview(*pKF, fa[q]); pv[q] = &v[q];
+            if (!handles) { v[q] = kfview(*pKF, fa[q]); pv[q] = &v[q]; }
             const cv::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
             float* pose = &poses[15 * q];
             for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pose[r * 3 + c] = Rcw.template at<float>(r, c); pose[9 + r] = tcw.template at<float>(r); pose[12 + r] = Ow.template at<float>(r); }
         }
         KeyFrameT* k0 = vpTargetKFs[0];
-        std::vector<int32_t> best(nk * np, -1), nf(nk, 0);
-        check(eao_fuse_search_batch((int)nk, pv.data(), 0, poses.data(), k0->fx, k0->fy, k0->cx, k0->cy, k0->mbf, &mp, th, best.data(), nf.data()), "eao_fuse_search_batch");
+        // search `pts` against targets q0 .. nk-1; row q - q0 of `out` = target q
+        auto search = [&](const std::vector<MapPointT*>& pts, size_t q0, std::vector<int32_t>& out) {
+            PointArrays pa;
+            const eao_map_points mp = gather(pts, pa, [&](MapPointT* p) { return p && !p->isBad(); });
+            const size_t nt = nk - q0;
+            out.assign(nt * pts.size(), -1);
+            std::vector<int32_t> nf(nt, 0);
+            if (handles)
+                check(eao_kf_fuse_search((int)nt, handles->data() + q0, 0, &poses[15 * q0], k0->fx, k0->fy, k0->cx, k0->cy, k0->mbf, &mp, th, out.data(), nf.data()), "eao_kf_fuse_search");
+            else
+                check(eao_fuse_search_batch((int)nt, pv.data() + q0, 0, &poses[15 * q0], k0->fx, k0->fy, k0->cx, k0->cy, k0->mbf, &mp, th, out.data(), nf.data()), "eao_fuse_search_batch");
+        };
+        std::vector<int32_t> best;
+        search(vpMapPoints, 0, best);
         int total = 0;
+        std::vector<size_t> changed;            // candidates whose descriptor this target's fusions changed
+        std::vector<MapPointT*> sub;
+        std::vector<int32_t> again;
         for (size_t q = 0; q < nk; q++) {
             KeyFrameT* pKF = vpTargetKFs[q];
             int nFused = 0;
+            changed.clear();
             for (size_t i = 0; i < np; i++) {
                 const int k = best[q * np + i];
                 if (k < 0) continue;
@@ -392,7 +445,7 @@ public:
                 if (pMPinKF) {
                     if (!pMPinKF->isBad()) {
                         if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
-                        else pMPinKF->Replace(pMP);
+                        else { pMPinKF->Replace(pMP); changed.push_back(i); }      // pMP survives with a recomputed descriptor
                     }
                 } else {
                     pMP->AddObservation(pKF, k);
@@ -402,6 +455,13 @@ public:
             }
             if (nFusedPerKF) (*nFusedPerKF)[q] = nFused;
             total += nFused;
+            if (!changed.empty() && q + 1 < nk) {
+                sub.resize(changed.size());
+                for (size_t c = 0; c < changed.size(); c++) sub[c] = vpMapPoints[changed[c]];
+                search(sub, q + 1, again);
+                for (size_t t = q + 1; t < nk; t++)
+                    for (size_t c = 0; c < changed.size(); c++) best[t * np + changed[c]] = again[(t - q - 1) * changed.size() + c];
+            }
         }
         return total;
     }
@@ -519,6 +579,7 @@ public:
         else if (top[2] < floor10) { ind3 = -1; }
     }
 
+    friend class KeyFrameHandles;
 protected:
     struct FrameArrays { std::vector<float> x, y, ang, ur, sf, s2, is2; std::vector<int32_t> oct; std::vector<uint8_t> occ, desc; };
     struct PointArrays { std::vector<uint8_t> active, desc; std::vector<float> Xw, normal, dmin, dmax, draw; };
@@ -630,6 +691,51 @@ protected:
     }
     float mfNNratio;
     bool mbCheckOrientation;
+};
+
+// Keyframe handles for the LocalMapping / LoopClosing side (round 5): of(pKF) uploads a keyframe the first time it is asked for -- keypoints, descriptors, grid
+// order, feature vector, scale tables -- and hands out the resident handle afterwards; refresh(pKF) re-sends its occupancy (GetMapPoint(k) != NULL: what
+// SearchForTriangulation skips) after map points were added or erased; erase(pKF) when the keyframe is culled (KeyFrame::SetBadFlag).  One instance per thread
+// that searches (LocalMapping owns one); the handles themselves may be searched from several threads.
+class KeyFrameHandles {
+public:
+    KeyFrameHandles() {}
+    ~KeyFrameHandles() { for (auto& e : map_) eao_keyframe_destroy(e.second); }
+    KeyFrameHandles(const KeyFrameHandles&) = delete;
+    KeyFrameHandles& operator=(const KeyFrameHandles&) = delete;
+    template <class KeyFrameT>
+    const eao_keyframe* of(KeyFrameT* pKF) {
+        auto it = map_.find((const void*)pKF);
+        if (it != map_.end()) return it->second;
+        ORBmatcher::FrameArrays fa;
+        ORBmatcher::FeatVecArrays fv;
+        eao_frame_view v = ORBmatcher::kfview(*pKF, fa);
+        for (int k = 0; k < v.n; k++) fa.occ[k] = pKF->GetMapPoint(k) ? 1 : 0;
+        const eao_feature_vector f = ORBmatcher::flatten(pKF->mFeatVec, fv);
+        eao_keyframe* h = nullptr;
+        ORBmatcher::check(eao_keyframe_create(&v, &f, &h), "eao_keyframe_create");
+        map_[(const void*)pKF] = h;
+        return h;
+    }
+    template <class KeyFrameT>
+    void refresh(KeyFrameT* pKF) {
+        auto it = map_.find((const void*)pKF);
+        if (it == map_.end()) { (void)of(pKF); return; }
+        const int n = eao_keyframe_size(it->second);
+        std::vector<uint8_t> occ(n > 0 ? n : 1, 0);
+        for (int k = 0; k < n; k++) occ[k] = pKF->GetMapPoint(k) ? 1 : 0;
+        ORBmatcher::check(eao_keyframe_update_points(it->second, occ.data()), "eao_keyframe_update_points");
+    }
+    template <class KeyFrameT>
+    void erase(KeyFrameT* pKF) {
+        auto it = map_.find((const void*)pKF);
+        if (it == map_.end()) return;
+        eao_keyframe_destroy(it->second);
+        map_.erase(it);
+    }
+    size_t size() const { return map_.size(); }
+private:
+    std::map<const void*, eao_keyframe*> map_;
 };
 
 }  // namespace eaofusion

@@ -28,7 +28,14 @@ struct MapPoint {
     bool IsInKeyFrame(KeyFrame* kf) { return obs.count(kf) != 0; }
     int GetIndexInKeyFrame(KeyFrame* kf) { return obs.count(kf) ? (int)obs[kf] : -1; }
     void AddObservation(KeyFrame* kf, size_t idx) { obs[kf] = idx; }
-    void Replace(MapPoint* other) { bad = true; replacedBy = other; }
+    // upstream's Replace ends in pMP->ComputeDistinctiveDescriptors() (src/MapPoint.cc:177-215): the SURVIVOR's descriptor changes.  Here it takes over the absorbed
+    // point's descriptor with its bytes rotated by one -- a change later searches cannot miss (a stand-in that only marks the loser hides stale searches)
+    void Replace(MapPoint* other) {
+        bad = true; replacedBy = other;
+        cv::Mat d = descriptor.clone();
+        for (int k = 0; k < 32; k++) d.ptr(0)[k] = descriptor.ptr(0)[(k + 1) % 32];
+        other->descriptor = d;
+    }
     void SetDistances(float mn, float mx) { mfMinDistance = mn; mfMaxDistance = mx; }
 protected:
     float mfMinDistance = 0, mfMaxDistance = 0;
@@ -186,6 +193,24 @@ int main(int argc, char** argv) {
             if (one != vv[q]) { std::fprintf(stderr, "SearchForTriangulationBatch: neighbour %zu differs from its single call (%zu vs %zu pairs)\n", q, vv[q].size(), one.size()); return 3; }
         }
         if (vv[0] != pairs) { std::fprintf(stderr, "SearchForTriangulationBatch: neighbour 0 differs from the single call above\n"); return 3; }
+        // ... and over keyframe handles (round 5): resident frames, selection on the device; then after the keyframe gained a map point (refresh)
+        eaofusion::KeyFrameHandles H;
+        std::vector<const eao_keyframe*> hs = {H.of(nb[0]), H.of(nb[1]), H.of(nb[2])};
+        std::vector<std::vector<std::pair<size_t, size_t> > > vh;
+        m75.SearchForTriangulationBatch(H.of(&A), &A, hs, nb, vF, vh, false);
+        if (vh != vv) { std::fprintf(stderr, "SearchForTriangulationBatch over keyframe handles differs from the host-array batch\n"); return 3; }
+        if (H.size() != 3) { std::fprintf(stderr, "KeyFrameHandles: %zu handles for 3 distinct keyframes\n", H.size()); return 3; }
+        if (!pairs.empty()) {
+            static MapPoint extra;
+            A.mvpMapPoints[pairs[0].first] = &extra;      // the first matched keypoint of A now holds a map point: upstream skips it
+            H.refresh(&A);
+            m75.SearchForTriangulationBatch(H.of(&A), &A, hs, nb, vF, vh, false);
+            std::vector<std::pair<size_t, size_t> > one;
+            m75.SearchForTriangulation(&A, nb[0], vF[0], one, false);
+            if (vh[0] != one || (one.size() && one[0].first == pairs[0].first)) { std::fprintf(stderr, "KeyFrameHandles::refresh: the occupancy did not reach the device\n"); return 3; }
+            A.mvpMapPoints[pairs[0].first] = nullptr;
+        }
+        std::fprintf(stderr, "SearchForTriangulationBatch over keyframe handles: identical (%zu + %zu + %zu pairs)\n", vh[0].size(), vh[1].size(), vh[2].size());
     }
     // 4. SearchForInitialization
     {
@@ -232,6 +257,8 @@ int main(int argc, char** argv) {
         wr(out, &n, 1); wr(out, best.data(), best.size());
     }
     // 9. Fuse(KF, points, th) into K2 with its own points: replacements and additions
+    std::vector<cv::Mat> descBefore(np);      // (Replace changes the survivor's descriptor: the shared `store` gets its own back for the blocks below)
+    for (int i = 0; i < np; i++) descBefore[i] = store[i].descriptor.clone();
     {
         KeyFrame B = K2;
         for (int k = 0; k < B.N; k++) if (B.mvpMapPoints[k]) B.mvpMapPoints[k]->AddObservation(&B, k);
@@ -244,6 +271,7 @@ int main(int argc, char** argv) {
         for (auto& p : store) if (p.replacedBy) replaced++;
         wr(out, &n, 1); wr(out, &replaced, 1); wr(out, &addedN, 1);
     }
+    for (int i = 0; i < np; i++) store[i].descriptor = descBefore[i];
     // 9b. FuseBatch (round 4): the same candidates against three target keyframes (K2, K1, K2 again -- the third target meets what the first one changed) in one
     //     library call, against three Fuse calls in a row on an identical second world: per-target counts, every keyframe slot, every replacement
     {
@@ -278,6 +306,28 @@ int main(int argc, char** argv) {
         std::vector<KeyFrame*> targets = {&wb.T[0], &wb.T[1], &wb.T[2]};
         std::vector<int> nBatch;
         const int totalB = m75.FuseBatch(targets, wb.cand, 3.0f, &nBatch);
+        // ... and a third world through keyframe handles (frames resident on the device, eao_kf_fuse_search)
+        World wc;
+        build(wc);
+        {
+            eaofusion::KeyFrameHandles H;
+            std::vector<KeyFrame*> tc = {&wc.T[0], &wc.T[1], &wc.T[2]};
+            std::vector<const eao_keyframe*> hs = {H.of(tc[0]), H.of(tc[1]), H.of(tc[2])};
+            std::vector<int> nH;
+            const int totalH = m75.FuseBatch(tc, wc.cand, 3.0f, &nH, &hs);
+            int dh = totalH != total;
+            for (int q = 0; q < 3; q++) {
+                if (nH[q] != nSeq[q]) dh++;
+                for (int k = 0; k < wa.T[q].N; k++) {
+                    MapPoint* pa = wa.T[q].mvpMapPoints[k]; MapPoint* pc = wc.T[q].mvpMapPoints[k];
+                    const long ia = !pa ? -1 : (pa >= wa.own.data() && pa < wa.own.data() + wa.own.size()) ? pa - wa.own.data() : 100000 + (pa - wa.fresh.data());
+                    const long ic = !pc ? -1 : (pc >= wc.own.data() && pc < wc.own.data() + wc.own.size()) ? pc - wc.own.data() : 100000 + (pc - wc.fresh.data());
+                    if (ia != ic) dh++;
+                }
+            }
+            if (dh) { std::fprintf(stderr, "FuseBatch over keyframe handles: %d differences from three Fuse calls (%d / %d)\n", dh, totalH, total); return 3; }
+            std::fprintf(stderr, "FuseBatch over keyframe handles: identical to three Fuse calls (%zu handles)\n", H.size());
+        }
         auto id = [&](World& w, MapPoint* p) -> long { if (!p) return -1; if (p >= w.own.data() && p < w.own.data() + w.own.size()) return p - w.own.data(); return 100000 + (p - w.fresh.data()); };
         int diff = totalB != total;
         for (int q = 0; q < 3; q++) {
@@ -290,7 +340,9 @@ int main(int argc, char** argv) {
             if (wa.own[i].bad != wb.own[i].bad || id(wa, wa.own[i].replacedBy) != id(wb, wb.own[i].replacedBy)) diff++;
             if (wa.fresh[i].obs.size() != wb.fresh[i].obs.size()) diff++;
         }
-        if (diff || total < 100 || nSeq[2] == 0) { std::fprintf(stderr, "FuseBatch: %d differences from three Fuse calls (fused %d / %d: %d %d %d)\n", diff, totalB, total, nSeq[0], nSeq[1], nSeq[2]); return 3; }
+        // (the third target -- K2 again -- fuses nothing in EITHER world: the candidates that survived the first target carry their absorbed partners' rotated
+        //  descriptors by then.  A batch that searched all targets up front on the initial descriptors would fuse dozens there: that is the difference this block exists to catch.)
+        if (diff || total < 100 || nSeq[0] == 0 || nSeq[1] == 0) { std::fprintf(stderr, "FuseBatch: %d differences from three Fuse calls (fused %d / %d: %d %d %d)\n", diff, totalB, total, nSeq[0], nSeq[1], nSeq[2]); return 3; }
         std::fprintf(stderr, "FuseBatch: %d fused over three targets (%d %d %d), identical to three Fuse calls\n", total, nSeq[0], nSeq[1], nSeq[2]);
     }
     // 10. MapPoint::ComputeDistinctiveDescriptors over the observations of each map point (K1 and K2 keypoints)
