@@ -19,7 +19,13 @@ struct PoseChainArgs {            // every pointer is a device address
     float Tcw0[16]; float fx, fy, cx, cy, bf;
     void* outSE3; int* outResult; double* outTrace;
     const int* scatterIdx; unsigned char* scatterOut;   // optional: the final outlier flag of edge e also goes to scatterOut[scatterIdx[e]] (mvbOutlier by keypoint)
+    // plane edges of the frame (src/Optimizer.cc:456-535), round 5: nPlanes records of 10 doubles as pose_plane_records writes them (device-visible memory),
+    // their outlier flags (pFrame->mvbPlaneOutlier) into planeOutlier (a slice of the chain's device result block)
+    int nPlanes = 0; const double* planes = nullptr; unsigned char* planeOutlier = nullptr;
 };
+// world / measured coefficients normalised as Converter::toPlane3D does and the two information values of every plane edge (10 doubles per plane)
+void pose_plane_records(int n, const float* plane_world, const float* plane_obs, const unsigned char* plane_seen, double* rec);
+constexpr int kPoseChainMaxPlanes = 32;
 size_t pose_se3_bytes();
 void pose_se3_to_Tcw(const void* se3, float* T);       // Converter::toCvMat(SE3Quat)
 eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s);

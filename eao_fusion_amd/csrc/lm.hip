@@ -4943,8 +4943,19 @@ namespace eao {
 namespace lm {
 size_t pose_se3_bytes() { return sizeof(SE3); }
 void pose_se3_to_Tcw(const void* se3, float* T) { se3_to_Tcw_f32(*(const SE3*)se3, T); }
+void pose_plane_records(int n, const float* plane_world, const float* plane_obs, const unsigned char* plane_seen, double* rec) {
+    const double angleInfo = refc::PLANE_ANGLE_INFO / (1.0 * 1.0), disInfo = refc::PLANE_DIST_INFO_ROOT * refc::PLANE_DIST_INFO_ROOT;      // src/Optimizer.cc:464-465
+    for (int i = 0; i < n; i++) {
+        plane_from_f32(plane_world + 4 * i, rec + 10 * i);
+        plane_from_f32(plane_obs + 4 * i, rec + 10 * i + 4);
+        const double f = plane_seen[i] ? 1.0 : 2.0;                                                                                          // :503-516
+        rec[10 * i + 8] = f * angleInfo; rec[10 * i + 9] = f * disInfo;
+    }
+}
 eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
     EAO_REQUIRE(a.cap > 0 && a.cap <= 4 * kPoseThreads, "the chained PoseOptimization takes up to %d edges", 4 * kPoseThreads);
+    static_assert(kPoseChainMaxPlanes == kPoseMaxPlanes, "one limit");
+    EAO_REQUIRE(a.nPlanes >= 0 && a.nPlanes <= kPoseMaxPlanes && (a.nPlanes == 0 || (a.planes && a.planeOutlier)), "at most %d plane edges", kPoseMaxPlanes);
     PoseDev P;
     std::memset(&P, 0, sizeof(P));
     P.n = a.cap; P.nDev = a.nEdges;
@@ -4956,19 +4967,22 @@ eao_status enqueue_pose_device(const PoseChainArgs& a, hipStream_t s) {
     P.scatterIdx = a.scatterIdx; P.scatterOut = a.scatterOut;
     P.done = nullptr; P.doneSeq = 0;
     P.pubSrc = (const uint4*)a.pubSrc; P.pubDst = (uint4*)a.pubDst; P.pubN16 = a.pubN16;
-    P.nPlanes = 0; P.planes = nullptr; P.planeOutlier = nullptr; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
+    P.nPlanes = a.nPlanes; P.planes = a.planes; P.planeOutlier = a.planeOutlier; P.deltaPlane = (float)std::sqrt(refc::PLANE_CHI2);
     P.dbg = nullptr;
+    const bool pl = a.nPlanes > 0;
     // The edge count lives on the device: one launch per geometry class the capacity admits (four waves up to 1024 edges, eight
     // beyond); each returns at its first instruction unless the frame's count falls in its range (a ~3 us launch, against running every
     // frame as eight waves).  Waves without an edge leave a pass at once.
     const bool second = std::min(a.cap, a.maxEdges > 0 ? a.maxEdges : a.cap) > 4 * kPoseWaves4;
     P.devLo = -1; P.devHi = std::min(a.cap, 4 * kPoseWaves4);
     if (!second) { P.done = a.done; P.doneSeq = a.doneSeq; }
-    hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseWaves4>), dim3(1), dim3(kPoseWaves4), 0, s, P);
+    if (pl) hipLaunchKernelGGL((k_pose_optimization<4, true, kPoseWaves4>), dim3(1), dim3(kPoseWaves4), 0, s, P);
+    else hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseWaves4>), dim3(1), dim3(kPoseWaves4), 0, s, P);
     if (second) {
         P.done = a.done; P.doneSeq = a.doneSeq;
         P.devLo = 4 * kPoseWaves4; P.devHi = a.cap;
-        hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseThreads>), dim3(1), dim3(kPoseThreads), 0, s, P);
+        if (pl) hipLaunchKernelGGL((k_pose_optimization<4, true, kPoseThreads>), dim3(1), dim3(kPoseThreads), 0, s, P);
+        else hipLaunchKernelGGL((k_pose_optimization<4, false, kPoseThreads>), dim3(1), dim3(kPoseThreads), 0, s, P);
     }
     return EAO_OK;
 }

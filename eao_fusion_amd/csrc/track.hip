@@ -61,9 +61,14 @@ struct eao_tracker {
     unsigned char* resDev = nullptr;   // its DEVICE twin (same layout): every kernel of the chain writes here; the chain's last launch alone copies it to `res`
     size_t resBytes = 0, listCap = 0, assignLds = 0;
     int seq = 0;                       // call counter: the chain's last launch stores it in the result block's done word
+    // eao_tracker_set_options (round 5): consumed by the NEXT track call
+    int optMinMatches = 0, optPlanes = 0;
+    unsigned char* optPlaneOut = nullptr;
+    double* plPin = nullptr; double* plDev = nullptr;      // the plane edges' records in mapped pinned memory (10 doubles each), as the pose kernel reads them
     long long* dbg = nullptr;          // EAO_DEBUG_STAMPS: phase stamps of k_track_assign_edges (diagnostic runs only)
     ~eao_tracker() {
         if (pin) (void)hipHostFree(pin);
+        if (plPin) (void)hipHostFree(plPin);
         if (resPin) (void)hipHostFree(resPin);
         if (dbg) (void)hipFree(dbg);
         if (evIn) (void)hipEventDestroy(evIn);
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
                                                                        const float* __restrict__ invSigma2, EdgeArrays E, int edgeCap, unsigned char* eOutl,
                                                                        const float* __restrict__ dz, const unsigned char* __restrict__ inView, ResultBlock R,
                                                                        long long* dbg, int allListers, const float* __restrict__ mAngle, const float* __restrict__ kAngle,
-                                                                       float rotFactor, BowDev bow) {
+                                                                       float rotFactor, BowDev bow, int minMatches) {
     extern __shared__ unsigned char asm_raw[];
     if (dbg && threadIdx.x == 0) dbg[0] = clock64();
     if (nMp > 0) {
@@ -671,6 +676,10 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
     if (dbg && threadIdx.x == 0) dbg[2] = clock64();
     track_edges_body(nMp, cap, match, kpMp, kx, ky, ur, oct, mXw, priorXw, invSigma2, E, edgeCap, counts, eOutl);
     __syncthreads();          // counts[2], kpMp[] are final
+    // A search that returned fewer than min_matches matches (upstream: "if(nmatches<20)" retry / return false, src/Tracking.cc:1756-1763; "if(nmatches<15) return
+    // false", :1580-1581) is NOT followed by the pose optimisation: the edge count the pose kernel reads becomes zero, its launch leaves at once
+    if (threadIdx.x == 0 && counts[3] < minMatches) counts[2] = 0;
+    __syncthreads();
     if (dbg && threadIdx.x == 0) dbg[3] = clock64();
     // everything the host needs except the pose and mvbOutlier, which PoseOptimization itself writes (by keypoint, through
     // the edge -> keypoint table): the block lies in mapped host memory
@@ -725,7 +734,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
                  oEX = take(24 * C), oEO = take(24 * C), oEI = take(8 * C), oEE = take(24 * C), oEF = take(C), oEOu = take(C), oEK = take(4 * C),
                  oSc = take(4 * 64), oIs = take(4 * 64), oCol = take(4 * ((size_t)cfg->grid_cols + 1));
     const size_t se3 = al256(eao::lm::pose_se3_bytes());
-    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C) + al256(Q) + 256;      // (+ the done word)
+    h->resBytes = se3 + al256(16) + al256(192 * 8) + al256(32) + al256(eao::lm::kPoseChainMaxPlanes) + al256(4 * C) + al256(C) + al256(4 * C) + al256(4 * C) + al256(Q) + 256;      // (+ the done word)
     const size_t oRes = take(h->resBytes);
     if ((st = h->dev.reserve(off))) { delete h; return st; }
     unsigned char* b = h->dev.p;
@@ -747,6 +756,8 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     // reads it after the one synchronisation -- no device-to-host copy behind the chain
     if (hipHostMalloc((void**)&h->resPin, h->resBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     std::memset(h->resPin, 0, h->resBytes);
+    if (hipHostMalloc((void**)&h->plPin, 10 * sizeof(double) * eao::lm::kPoseChainMaxPlanes, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->plDev, h->plPin, 0) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     if (hipHostGetDevicePointer((void**)&h->res, h->resPin, 0) != hipSuccess) { delete h; eao::set_error("hipHostGetDevicePointer failed"); return EAO_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evOut, hipEventDisableTiming) != hipSuccess) { delete h; eao::set_error("stream / event creation failed"); return EAO_ERR_NO_DEVICE; }
@@ -837,6 +848,10 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     const eao_tracker_cfg& c = h->cfg;
     const int C = h->cap, nMp = bw ? bw->n_kf : mm ? mm->n_last : h->nMp;      // the stage's queries: keyframe keypoints / last-frame keypoints / local map points
     const bool plain = !mm && !bw;
+    // the one-shot options of eao_tracker_set_options
+    const int minMatches = plain ? 0 : h->optMinMatches, nPlanes = h->optPlanes;
+    unsigned char* planeOut = h->optPlaneOut;
+    h->optMinMatches = 0; h->optPlanes = 0; h->optPlaneOut = nullptr;
     // The chain runs on the CALLER's stream itself: it is ordered behind whatever produced the inputs there (the extraction)
     // without an event hand-over to a private stream and back (~10 us each on this runtime).  The handle's own stream only
     // carries the local-map uploads, which eao_tracker_set_local_map waits for.
@@ -986,6 +1001,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     int* rRes = (int*)(r + ro); ro += al256(16);
     double* rTrace = (double*)(r + ro); ro += al256(192 * 8);
     int* rCounts = (int*)(r + ro); ro += al256(32);
+    unsigned char* rPlOut = r + ro; ro += al256(eao::lm::kPoseChainMaxPlanes);      // mvbPlaneOutlier of the frame's plane edges (eao_tracker_set_options)
     int* rKpMp = (int*)(r + ro); ro += al256(4 * (size_t)C);
     unsigned char* rOutl = r + ro; ro += al256(C);
     float* rUr = (float*)(r + ro); ro += al256(4 * (size_t)C);
@@ -1002,7 +1018,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
         const float rotFactor = mm && mm->check_orientation ? (float)refc::HISTO_LENGTH / 360.0f : bw && bw->check_orientation ? 1.0f / refc::HISTO_LENGTH : 0.f;
         hipLaunchKernelGGL(kern, dim3(1), dim3(kAssignThreads), h->assignLds, s, nMp, C, plain ? h->q : h->lQ, h->lists, h->segStart, h->segCount, h->cursor, h->oct, h->occ,
                            mm ? INFINITY : nnratio, h->match, h->counts, h->kpMp, h->kx, h->ky, h->ur, plain ? h->mXw : h->lXw, h->priorXw, h->dInvSigma2, E, edgeCap, h->eOutl, h->dz,
-                           plain ? h->inView : nullptr, RB, h->dbg, envAll, h->lAng, h->ang, rotFactor, BD);
+                           plain ? h->inView : nullptr, RB, h->dbg, envAll, h->lAng, h->ang, rotFactor, BD, minMatches);
     };
     if (nMp <= 4 * kAssignThreads) launch_assign(k_track_assign_edges<4>);
     else if (nMp <= 8 * kAssignThreads) launch_assign(k_track_assign_edges<8>);
@@ -1015,6 +1031,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     PA.fx = c.fx; PA.fy = c.fy; PA.cx = c.cx; PA.cy = c.cy; PA.bf = c.mbf;
     PA.outSE3 = rSE3; PA.outResult = rRes; PA.outTrace = rTrace;
     PA.scatterIdx = h->eKp; PA.scatterOut = rOutl;      // mvbOutlier by keypoint, straight into the result block
+    PA.nPlanes = nPlanes; PA.planes = nPlanes ? h->plDev : nullptr; PA.planeOutlier = nPlanes ? rPlOut : nullptr;
     // The results are in mapped host memory when the chain's last launch has stored this call's number in the done word: that launch is the
     // ONLY writer of the host block -- it copies the device twin out, every thread fences at system scope, and behind a barrier one thread
     // stores the word (round 4; until then two kernels wrote the host block and the host trusted the earlier kernel's posted writes to have
@@ -1064,14 +1081,16 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
         const unsigned char* iv = p + ((unsigned char*)rInView - r);
         for (int m = 0; m < nMp; m++) out->map_in_view[m] = (iv[m] && h->hActive[m]) ? 1 : 0;      // (an inactive point's arrays are stale)
     }
-    if (nEdges < 3) {   // "if(nInitialCorrespondences<3) return 0" (src/Optimizer.cc:453-454): pose untouched
+    if (nEdges < 3) {   // "if(nInitialCorrespondences<3) return 0" (src/Optimizer.cc:453-454): pose untouched -- also the exit of a search below min_matches
         std::memcpy(out->Tcw, Tcw_prior, 64);
         out->n_inliers = 0;
         std::memset(out->kp_outlier, 0, C);
+        if (planeOut) std::memset(planeOut, 0, nPlanes);      // (upstream resets mvbPlaneOutlier only behind that test: untouched there, cleared here)
     } else {
+        if (planeOut) std::memcpy(planeOut, p + (rPlOut - r), nPlanes);
         eao::lm::pose_se3_to_Tcw(p, out->Tcw);
         const int* rr = (const int*)(p + ((unsigned char*)rRes - r));
-        out->n_inliers = nEdges - rr[0];
+        out->n_inliers = nEdges + nPlanes - rr[0];      // nInitialCorrespondences counts the plane edges too (src/Optimizer.cc:456-535, 672)
         std::memcpy(out->kp_outlier, p + ((unsigned char*)rOutl - r), C);
     }
     return EAO_OK;
@@ -1079,6 +1098,19 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
 }  // namespace
 
 extern "C" {
+
+eao_status eao_tracker_set_options(eao_tracker* h, const eao_track_options* opt) {
+    EAO_REQUIRE(h, "null handle");
+    h->optMinMatches = 0; h->optPlanes = 0; h->optPlaneOut = nullptr;
+    if (!opt) return EAO_OK;
+    EAO_REQUIRE(opt->min_matches >= 0 && opt->n_planes >= 0 && opt->n_planes <= eao::lm::kPoseChainMaxPlanes, "min_matches >= 0, at most %d plane edges", eao::lm::kPoseChainMaxPlanes);
+    EAO_REQUIRE(opt->n_planes == 0 || (opt->plane_world && opt->plane_obs && opt->plane_seen && opt->plane_outlier), "plane arrays missing");
+    for (int i = 0; i < 4 * opt->n_planes; i++) EAO_REQUIRE(std::isfinite(opt->plane_world[i]) && std::isfinite(opt->plane_obs[i]), "a plane coefficient is NaN / Inf");
+    h->optMinMatches = opt->min_matches;
+    h->optPlanes = opt->n_planes; h->optPlaneOut = opt->plane_outlier;
+    if (opt->n_planes) eao::lm::pose_plane_records(opt->n_planes, opt->plane_world, opt->plane_obs, opt->plane_seen, h->plPin);
+    return EAO_OK;
+}
 
 eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
                                        const float* d_depth, int32_t depth_pitch, int32_t width, int32_t height, const float* Tcw_prior,

@@ -21,7 +21,13 @@ class TrackResult(C.Structure):
                 ("kp_outlier", _P), ("kp_u_right", _P), ("kp_depth", _P), ("map_in_view", _P)]
 
 
+class TrackOptions(C.Structure):   # eao_track_options
+    _fields_ = [("min_matches", _I), ("n_planes", _I), ("plane_world", _P), ("plane_obs", _P), ("plane_seen", _P), ("plane_outlier", _P)]
+
+
 def _bind(L):
+    L.eao_tracker_set_options.restype = _I
+    L.eao_tracker_set_options.argtypes = [_P, C.POINTER(TrackOptions)]
     L.eao_tracker_create.restype = _I
     L.eao_tracker_create.argtypes = [C.POINTER(TrackerCfg), C.POINTER(_P)]
     L.eao_tracker_destroy.restype = None
@@ -62,6 +68,19 @@ class Tracker:
         m, keep = map_points(pts)
         _lib.check(self._L.eao_tracker_set_local_map(self._h, C.byref(m)))
         self.n_mp = int(m.n)
+
+    def set_options(self, min_matches=0, planes=None):
+        """One-shot options of the next track_* call (eao_tracker_set_options).  planes: dict(plane_world (m, 4), plane_obs (m, 4), plane_seen (m)); the plane outlier
+        flags of that call are then in self.plane_outlier afterwards."""
+        O = TrackOptions()
+        O.min_matches = int(min_matches)
+        self.plane_outlier = None
+        if planes is not None and len(planes["plane_world"]):
+            self._pw = np.ascontiguousarray(planes["plane_world"], np.float32); self._po = np.ascontiguousarray(planes["plane_obs"], np.float32)
+            self._ps = np.ascontiguousarray(planes["plane_seen"], np.uint8)
+            self.plane_outlier = np.zeros(len(self._ps), np.uint8)
+            O.n_planes, O.plane_world, O.plane_obs, O.plane_seen, O.plane_outlier = len(self._ps), _lib.ptr(self._pw), _lib.ptr(self._po), _lib.ptr(self._ps), _lib.ptr(self.plane_outlier)
+        _lib.check(self._L.eao_tracker_set_options(self._h, C.byref(O)))
 
     def track_local_map(self, d_kps, d_desc, d_n, d_depth, depth_pitch, width, height, Tcw_prior, prior=None, th=1.0, nnratio=0.8, stream=0, prior_Xw=None):
         """d_*: integers (HBM addresses).  prior: per keypoint -1 / local-map index / -2 (map point outside the local map, position in

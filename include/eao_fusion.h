@@ -601,6 +601,25 @@ eao_status eao_tracker_track_local_map(eao_tracker* h, const eao_keypoint* d_kps
                                        const int32_t* prior_kp_map_point, const float* prior_kp_Xw, float th, float nnratio, eao_track_result* out,
                                        void* stream);
 
+/* One-shot options of the NEXT eao_tracker_track_* call on the handle (round 5; NULL or never called: defaults).
+ *  - plane edges: in this fork Map::AssociatePlanesByBoundary runs BEFORE Optimizer::PoseOptimization in all three stages (src/Tracking.cc:1587, before :2181,
+ *    TrackLocalMap), so the frame's associated planes are edges of the optimisation (src/Optimizer.cc:456-535, 626-658).  A caller whose frame carries them
+ *    hands them over exactly as in eao_pose_problem (n_planes <= 32; plane_world = MapPlane::GetWorldPos(), plane_obs = mvPlaneCoefficients[i], plane_seen =
+ *    mbSeen) and gets mvbPlaneOutlier back in plane_outlier (caller array, valid until the track call returns); the chained pose optimisation is then the
+ *    plane instantiation of the same kernel -- same result as eao_pose_optimization with those planes on the chain's correspondences.
+ *  - min_matches (motion-model / reference-keyframe stages): when the search returns fewer matches, the pose optimisation and the outlier discard are
+ *    SKIPPED -- upstream repeats the search with 2 * th (src/Tracking.cc:1756-1763) or returns false (:1580-1581) before it optimises anything; the result then
+ *    carries the search's tables, n_edges = n_inliers = 0 and the prior pose, and the caller touches no map point.  0 = always optimise. */
+typedef struct {
+    int32_t min_matches;
+    int32_t n_planes;
+    const float* plane_world;      /* n_planes*4 */
+    const float* plane_obs;        /* n_planes*4 */
+    const uint8_t* plane_seen;     /* n_planes */
+    uint8_t* plane_outlier;        /* out: n_planes */
+} eao_track_options;
+eao_status eao_tracker_set_options(eao_tracker* h, const eao_track_options* opt);
+
 /* Tracking::TrackWithMotionModel's data path (reference src/Tracking.cc:1717-2231) on the same chain, ahead of TrackLocalMap: the frame set-up as
  * above, ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (src/ORBmatcher.cc:1328-1472, with this fork's rotation-histogram
  * factor HISTO_LENGTH / 360, :1337) against the LAST frame's map points, Optimizer::PoseOptimization from the predicted pose, and -- when

@@ -25,6 +25,7 @@
 
 #include "../eao_fusion.h"
 #include "Frame.h"
+#include "OptimizerImpl.h"      // collect_planes / store_planes: the frame's associated map planes as PoseOptimization's adapter reads them
 
 namespace eaofusion {
 
@@ -48,7 +49,10 @@ public:
 
     // The handle's limits (4096 keypoints per frame, 16384 local map points at most, whatever the constructor asked for below that): a frame beyond them
     // goes through the host-hop calls -- upstream's own SearchLocalPoints / PoseOptimization over the drop-in adapters -- as the INTEGRATION.md fragments do.
-    template <class FrameT> bool Fits(const FrameT& F) const { return F.N <= cap_; }
+    // So does every frame of a camera WITH LENS DISTORTION (round 5, VERDICT r4 missing #6): the chain reads the extractor's keypoints where upstream reads
+    // mvKeysUn (Frame::UndistortKeyPoints, src/Frame.cc:773-806); that is the same thing only while mDistCoef is zero (ros_test/config/TUM3.yaml:13-16), and with
+    // TUM1 / TUM2 intrinsics (k1 = 0.26) the chain would silently match and optimise on distorted coordinates.  Fits() says no, and the Track* calls throw.
+    template <class FrameT> bool Fits(const FrameT& F) const { return F.N <= cap_ && !detail::Distorted<FrameT>::check(F); }
     int MaxKeypoints() const { return cap_; }
     int MaxMapPoints() const { return capMp_; }
 
@@ -102,6 +106,7 @@ public:
         std::vector<uint8_t> outl(cap_, 0), inView(map_.size() ? map_.size() : 1, 0);
         std::vector<float> ur(cap_), dz(cap_), priorXw;
         if (F.N > cap_) throw std::runtime_error("DeviceTracker: the frame has more keypoints than maxKeypoints");
+        if (detail::Distorted<FrameT>::check(F)) throw std::runtime_error("DeviceTracker: the camera has lens distortion (mDistCoef != 0) -- the device chain reads mvKeys where upstream reads mvKeysUn; use the host-hop calls (Fits() is false)");
         for (int k = 0; k < F.N; k++) {
             MapPointT* pMP = F.mvpMapPoints[k];
             if (!pMP) continue;
@@ -121,6 +126,9 @@ public:
             for (int c = 0; c < 4; c++) T[4 * r + c] = F.mTcw.template at<float>(r, c);
         eao_track_result R = {};      // (zero first: a member this header does not set reads as "not wanted", include/eao_fusion.h EAO_ABI_VERSION)
         R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data(); R.map_in_view = inView.data();
+        PlaneEdges pe;
+        std::vector<uint8_t> pout;
+        set_options(F, 0, pe, pout);
         detail::check(eao_tracker_track_local_map(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, T, prior.data(),
                                                   priorXw.empty() ? nullptr : priorXw.data(), th, nnratio, &R, stream),
                       "eao_tracker_track_local_map");
@@ -140,6 +148,7 @@ public:
         for (int r = 0; r < 4; r++)
             for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[4 * r + c];
         F.SetPose(pose);
+        if (R.n_edges >= 3) store_planes(&F, pe, pout);      // mvbPlaneOutlier (upstream resets / sets them behind the "< 3 correspondences" test only)
         return R.n_inliers;
     }
 
@@ -150,11 +159,17 @@ public:
     // repeats the search.  Returns the search's nmatches minus the discarded outliers (upstream's `nmatches` at :2231); nmatchesMap counts the kept matches
     // whose map point has observations (:2202-2203).  What upstream does between the search and the optimisation (object association, plane association) reads
     // Cur.mvpMapPoints, which this call has filled by then only at its END -- a caller that needs them runs this stage with the host-hop calls instead.
+    // Round 5: (a) a search that returns fewer than minMatches (upstream's 20, :1756 / :1762) is NOT followed by the pose optimisation and the discard -- the call
+    // returns the search's count right away and has touched no map point and no pose, exactly as upstream at that point; the caller repeats it with 2 * th or
+    // returns false.  (b) The planes the caller associated with the predicted pose (Map::AssociatePlanesByBoundary, :2181 -- it reads the pose, not the matches)
+    // are edges of the chained optimisation; mvbPlaneOutlier comes back, the plane discard loop (:2210-2221) stays with the caller.
     template <class FrameT>
     int TrackWithMotionModel(FrameT& Cur, const FrameT& Last, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth,
-                             int depthPitch, int width, int height, float th, bool bMono, void* stream, int* nmatchesMap = nullptr, int* nSearch = nullptr) {
+                             int depthPitch, int width, int height, float th, bool bMono, void* stream, int* nmatchesMap = nullptr, int* nSearch = nullptr,
+                             int minMatches = 20) {
         using MapPointT = typename std::remove_pointer<typename std::decay<decltype(Cur.mvpMapPoints[0])>::type>::type;
         if (Cur.N > cap_ || Last.N > cap_) throw std::runtime_error("DeviceTracker: a frame has more keypoints than maxKeypoints");
+        if (detail::Distorted<FrameT>::check(Cur)) throw std::runtime_error("DeviceTracker: the camera has lens distortion (mDistCoef != 0) -- the device chain reads mvKeys where upstream reads mvKeysUn; use the host-hop calls (Fits() is false)");
         const size_t nl = (size_t)Last.N;
         std::vector<uint8_t> valid(nl ? nl : 1, 0), desc(32 * (nl ? nl : 1), 0);
         std::vector<float> Xw(3 * (nl ? nl : 1), 0.f), ang(nl ? nl : 1, 0.f);
@@ -176,16 +191,24 @@ public:
         std::vector<float> ur(cap_), dz(cap_);
         eao_track_result R = {};
         R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data();
+        PlaneEdges pe;
+        std::vector<uint8_t> pout;
+        set_options(Cur, minMatches, pe, pout);
         detail::check(eao_tracker_track_with_motion_model(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, Tc, Tl, (int)nl, valid.data(), Xw.data(),
                                                           desc.data(), oct.data(), ang.data(), th, bMono ? 1 : 0, 1, /* discard on this side */ 0, &R, stream),
                       "eao_tracker_track_with_motion_model");
         if (nSearch) *nSearch = R.n_matches;
         Cur.mvuRight.assign(ur.begin(), ur.begin() + R.n_keypoints);
         Cur.mvDepth.assign(dz.begin(), dz.begin() + R.n_keypoints);
+        if (R.n_matches < minMatches) {      // upstream has only searched at this point: no pose, no outlier flag, no map point touched
+            if (nmatchesMap) *nmatchesMap = 0;
+            return R.n_matches;
+        }
         cv::Mat pose(4, 4, CV_32F);
         for (int r = 0; r < 4; r++)
             for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[4 * r + c];
         Cur.SetPose(pose);
+        if (R.n_edges >= 3) store_planes(&Cur, pe, pout);
         int nmatches = R.n_matches, nMap = 0;
         for (int k = 0; k < R.n_keypoints; k++) {      // "Discard outliers", src/Tracking.cc:2188-2207
             Cur.mvbOutlier[k] = false;
@@ -212,11 +235,13 @@ public:
     // fork does between the search and the optimisation (AssociatePlanesByBoundary, :1587) sees Cur.mvpMapPoints only after the call.
     template <class KeyFrameT, class FrameT>
     int TrackReferenceKeyFrame(FrameT& Cur, KeyFrameT* pRefKF, const cv::Mat& lastTcw, const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n,
-                               const float* d_depth, int depthPitch, int width, int height, void* stream, int* nSearch = nullptr, float nnratio = 0.7f) {
+                               const float* d_depth, int depthPitch, int width, int height, void* stream, int* nSearch = nullptr, float nnratio = 0.7f,
+                               int minMatches = 10) {
         using MapPointT = typename std::remove_pointer<typename std::decay<decltype(Cur.mvpMapPoints[0])>::type>::type;
         const std::vector<MapPointT*> vpKF = pRefKF->GetMapPointMatches();
         const size_t nk = vpKF.size();
         if (Cur.N > cap_ || (int)nk > cap_) throw std::runtime_error("DeviceTracker: more keypoints than maxKeypoints");
+        if (detail::Distorted<FrameT>::check(Cur)) throw std::runtime_error("DeviceTracker: the camera has lens distortion (mDistCoef != 0) -- the device chain reads mvKeys where upstream reads mvKeysUn; use the host-hop calls (Fits() is false)");
         std::vector<uint8_t> valid(nk ? nk : 1, 0), desc(32 * (nk ? nk : 1), 0);
         std::vector<float> Xw(3 * (nk ? nk : 1), 0.f), ang(nk ? nk : 1, 0.f);
         for (size_t i = 0; i < nk; i++) {
@@ -238,16 +263,21 @@ public:
         std::vector<float> ur(cap_), dz(cap_);
         eao_track_result R = {};
         R.kp_map_point = kpMp.data(); R.kp_outlier = outl.data(); R.kp_u_right = ur.data(); R.kp_depth = dz.data();
+        PlaneEdges pe;
+        std::vector<uint8_t> pout;
+        set_options(Cur, minMatches, pe, pout);      // (the planes were associated with mLastFrame.mTcw set as the frame's pose, :1584-1587)
         detail::check(eao_tracker_track_reference_keyframe(h_, d_kps, d_desc, d_n, d_depth, depthPitch, width, height, Tl, (int)nk, valid.data(), Xw.data(), desc.data(),
                                                            ang.data(), &fvK, &fvC, nnratio, 1, /* discard on this side */ 0, &R, stream),
                       "eao_tracker_track_reference_keyframe");
         if (nSearch) *nSearch = R.n_matches;
         Cur.mvuRight.assign(ur.begin(), ur.begin() + R.n_keypoints);
         Cur.mvDepth.assign(dz.begin(), dz.begin() + R.n_keypoints);
+        if (R.n_matches < minMatches) return 0;      // "if (nmatches < 10) return false" (:1580-1581): nothing optimised, nothing touched
         cv::Mat pose(4, 4, CV_32F);
         for (int r = 0; r < 4; r++)
             for (int c = 0; c < 4; c++) pose.template at<float>(r, c) = R.Tcw[4 * r + c];
         Cur.SetPose(pose);
+        if (R.n_edges >= 3) store_planes(&Cur, pe, pout);
         int nMap = 0;
         for (int k = 0; k < R.n_keypoints; k++) {      // "Discard outliers", src/Tracking.cc:1593-1612
             Cur.mvbOutlier[k] = false;
@@ -266,6 +296,20 @@ public:
     }
 
 private:
+    // The one-shot options of the next chain call (eao_tracker_set_options, round 5): the frame's associated map planes -- in this fork
+    // Map::AssociatePlanesByBoundary runs BEFORE Optimizer::PoseOptimization in every stage (src/Tracking.cc:1587, :2181, TrackLocalMap), so they are edges of
+    // the optimisation (src/Optimizer.cc:456-535); the caller has associated them with the pose the stage starts from -- and the stage's match threshold.
+    template <class FrameT>
+    void set_options(FrameT& F, int minMatches, PlaneEdges& pe, std::vector<uint8_t>& pout) {
+        collect_planes(&F, pe);
+        const int M = (int)pe.slot.size();
+        if (M > 32) throw std::runtime_error("DeviceTracker: more than 32 associated planes");
+        pout.assign(M ? M : 1, 0);
+        eao_track_options O;
+        O.min_matches = minMatches; O.n_planes = M;
+        O.plane_world = M ? pe.world.data() : nullptr; O.plane_obs = M ? pe.obs.data() : nullptr; O.plane_seen = M ? pe.seen.data() : nullptr; O.plane_outlier = pout.data();
+        detail::check(eao_tracker_set_options(h_, &O), "eao_tracker_set_options");
+    }
     struct FeatVec { std::vector<uint32_t> id, index; std::vector<int32_t> start; };
     template <class FeatVecT>
     static eao_feature_vector flatten(const FeatVecT& fv, FeatVec& a) {      // DBoW2::FeatureVector = std::map<node id, std::vector<keypoint index>>

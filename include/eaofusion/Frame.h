@@ -16,6 +16,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../eao_fusion.h"
@@ -34,6 +35,20 @@ struct MaxDistanceOf : MapPointT {
 inline void check(eao_status st, const char* what) {
     if (st != EAO_OK) throw std::runtime_error(std::string(what) + ": " + eao_last_error());
 }
+// Does the frame's camera distort?  Upstream's own test (src/Frame.cc:775: mDistCoef.at<float>(0) == 0.0 means "mvKeysUn = mvKeys"), extended to every
+// coefficient; a Frame class without the member (a stand-in) counts as distortion-free.
+template <class FrameT, class = void>
+struct Distorted { static bool check(const FrameT&) { return false; } };
+template <class FrameT>
+struct Distorted<FrameT, decltype(void(std::declval<const FrameT&>().mDistCoef))> {
+    static bool check(const FrameT& F) {
+        const cv::Mat& d = F.mDistCoef;
+        if (d.empty()) return false;
+        const int n = d.rows * d.cols;
+        for (int i = 0; i < n; i++) if (d.template at<float>(i) != 0.0f) return true;
+        return false;
+    }
+};
 }  // namespace detail
 
 // for (pMP : vpMPs) if (!skip(pMP)) if (F.isInFrustum(pMP, viewingCosLimit)) nToMatch++;   returns nToMatch.

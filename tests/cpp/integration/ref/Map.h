@@ -10,8 +10,10 @@
 #include "MapPoint.h"
 
 namespace ORB_SLAM2 {
+class Frame;
 class Map {
 public:
+    void AssociatePlanesByBoundary(Frame &pF, bool out=false);      // reference include/Map.h:93 (defined by the test: the association itself is outside the path)
     std::vector<KeyFrame*> GetAllKeyFrames() { return kfs; }
     std::vector<MapPoint*> GetAllMapPoints() { return mps; }
     std::vector<MapPlane*> GetAllMapPlanes() { return planes; }

@@ -6,6 +6,7 @@
 
 #include "Frame.h"
 #include "KeyFrame.h"
+#include "Map.h"
 #include "MapPoint.h"
 #include "ORBmatcher.h"
 #include "Optimizer.h"
@@ -28,6 +29,7 @@ public:
     bool TrackReferenceKeyFrameOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch, int width,
                                         int height, void* stream);
     Frame mLastFrame;
+    Map* mpMap = nullptr;
     KeyFrame* mpReferenceKF = nullptr;
     eaofusion::DeviceTracker* mpDeviceTracker = nullptr;
     int mSensor = System::RGBD;

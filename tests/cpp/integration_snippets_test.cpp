@@ -50,13 +50,14 @@ void Tracking::TrackLocalMapOnDevice(const eao_keypoint* d_kps, const uint8_t* d
 bool Tracking::TrackWithMotionModelOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch,
                                             int width, int height, void* stream, const cv::Mat& predictedPose) {
 #include "Tracking_TrackWithMotionModel.inc"
-    (void)nmatches;
+    (void)nmatches; (void)predictedPose;
     return nmatchesMap >= 10;      // :2230
 }
 bool Tracking::TrackReferenceKeyFrameOnDevice(const eao_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, const float* d_depth, int depthPitch,
                                               int width, int height, void* stream) {
 #include "Tracking_TrackReferenceKeyFrame.inc"
 }
+void Map::AssociatePlanesByBoundary(Frame&, bool) {}      // (plane association: src/Map.cc, outside the path; the snippets only call it where upstream does)
 }  // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;

@@ -46,6 +46,7 @@ struct Frame {
     std::vector<bool> mvbOutlier;
     std::map<unsigned, std::vector<unsigned> > mFeatVec;      // DBoW2::FeatureVector
     void SetPose(cv::Mat T) { mTcw = T.clone(); }
+    cv::Mat mDistCoef;                                        // upstream include/Frame.h:216 (empty / all zero: no distortion)
 };
 
 struct KeyFrame {      // what TrackReferenceKeyFrame reads of the reference keyframe
@@ -313,6 +314,19 @@ int main() {
         fprintf(stderr, "reference keyframe: %d matches after the search, %d kept, %d with observations, %d disagreements\n", nSearch, kept, withObs, rkBad);
         bad += rkBad;
         pts[seen[10]].nObs = 1;
+    }
+    {   // a camera with lens distortion (TUM1: k1 = 0.2624, ros_test/config/TUM1.yaml:13-16): the chain would read mvKeys where upstream reads mvKeysUn -- it refuses
+        Frame D = F;
+        if (!trk.Fits(D)) { fprintf(stderr, "Fits() is false for a distortion-free frame\n"); bad++; }
+        D.mDistCoef = cv::Mat(4, 1, CV_32F);
+        for (int i = 0; i < 4; i++) D.mDistCoef.at<float>(i) = 0.f;
+        if (!trk.Fits(D)) { fprintf(stderr, "Fits() is false for all-zero distortion coefficients\n"); bad++; }
+        D.mDistCoef.at<float>(0) = 0.2624f;
+        bool threw = false;
+        try { trk.TrackLocalMap(D, d_kps, d_desc, d_n, d_depth, W, W, H, 3.0f, 0.8f, nullptr); } catch (const std::runtime_error&) { threw = true; }
+        if (trk.Fits(D) || !threw) { fprintf(stderr, "a frame with k1 = 0.26 was accepted by the device chain\n"); bad++; }
+        D.mDistCoef.at<float>(0) = 0.f; D.mDistCoef.at<float>(3) = -0.001f;      // (upstream only looks at coefficient 0, src/Frame.cc:775; the adapter at all of them)
+        if (trk.Fits(D)) { fprintf(stderr, "a frame with p2 != 0 was accepted by the device chain\n"); bad++; }
     }
     eao_tracker_destroy(h);
     fprintf(stderr, "%d keypoints, %d with a map point, %d inliers, %d disagreements\n", F.N, matched, nIn, bad);

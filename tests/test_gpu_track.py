@@ -607,3 +607,77 @@ def test_motion_model_stage_without_last_frame_points():
         assert np.array_equal(got["Tcw"], np.asarray(cur["Tcw"], np.float32))
     got = trk.track_with_motion_model(*args, cur["Tcw"], last, 15.0, False, True, True, st)
     assert got["n_matches"] > 50
+
+
+def _plane_edges(seed, m):
+    """m associated planes of a frame as synth_pose makes them (world / observed coefficients, mbSeen), the last one an outlier when m >= 3"""
+    pp = synth.synth_pose(n=50, seed=seed, n_planes=m)
+    return dict(plane_world=pp["plane_world"], plane_obs=pp["plane_obs"], plane_seen=pp["plane_seen"])
+
+
+@pytest.mark.parametrize("stage,m", [("local_map", 4), ("local_map", 1), ("motion_model", 6), ("motion_model", 32)])
+def test_plane_edges_ride_the_chained_pose_optimisation(stage, m, oracle):
+    """ADVICE r4 (medium): in this fork AssociatePlanesByBoundary runs BEFORE Optimizer::PoseOptimization (src/Tracking.cc:1587, before :2181), so a frame's associated
+    planes are edges of the optimisation.  eao_tracker_set_options hands them to the chain: the pose, mvbOutlier, the inlier count and mvbPlaneOutlier are those of
+    the oracle chain whose PoseOptimization carries the same plane edges -- and differ from the chain without them."""
+    import eao_fusion_amd as E  # noqa: F401
+    cur, kps, desc, depth, pts, prior = _scene(7400 + m, n=700, prior_frac=0.1)
+    planes = _plane_edges(7450 + m, m)
+    oc = _OracleCalls(oracle)
+    base_pose = oc.pose
+    seen = {}
+
+    def pose_with_planes(prob):
+        q = dict(prob); q.update(planes)
+        r = oracle.pose_optimization(q)
+        seen["plane_outlier"] = r["plane_outlier"]
+        return r
+    cap = 2048
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+    trk = _tracker(cur, cap, 2048)
+    st = torch.cuda.current_stream().cuda_stream
+    if stage == "local_map":
+        trk.set_local_map(pts)
+        run = lambda: trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], prior, 3.0, 0.8, st)      # noqa: E731
+        oc.pose = pose_with_planes
+        want = _chain(oc, cur, kps, desc, depth, pts, prior, 3.0, 0.8)
+    else:
+        _, last, _ = synth.synth_tracking(n=700, seed=7400 + m, mono_frac=0.0, occupied_frac=0.0)
+        run = lambda: trk.track_with_motion_model(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], last, 15.0, False, True, False, st)      # noqa: E731
+        oc.pose = pose_with_planes
+        want = _chain_motion(oc, lambda f, l, t, mo: oracle.search_by_projection_frames(f, l, t, mo, True), cur, kps, desc, depth, last, 15.0, False, False)
+    plain = run()
+    trk.set_options(planes=planes)
+    got = run()
+    assert np.array_equal(got["kp_map_point"], want["kp_map_point"]) and got["n_edges"] == want["n_edges"] and got["n_edges"] > 50
+    assert got["n_inliers"] == want["n_inliers"] and np.array_equal(got["kp_outlier"], want["kp_outlier"])
+    assert np.array_equal(trk.plane_outlier, seen["plane_outlier"])
+    ok, err, upd = _pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])
+    assert ok, "pose with %d plane edges: |gpu - oracle| %.3e of update %.3e" % (m, err, upd)
+    assert not np.array_equal(got["Tcw"], plain["Tcw"]), "the plane edges changed nothing"
+    again = run()      # the options are one-shot: the next call is the plain chain again
+    assert np.array_equal(again["Tcw"], plain["Tcw"]) and np.array_equal(again["kp_outlier"], plain["kp_outlier"])
+    oc.pose = base_pose
+
+
+def test_min_matches_skips_the_pose_optimisation(oracle):
+    """ADVICE r4 (low): upstream tests the search's return value BEFORE it optimises (TrackWithMotionModel: < 20 -> search again with 2 th, src/Tracking.cc:1756-1763;
+    TrackReferenceKeyFrame: < 15 -> return false, :1580-1581).  With min_matches set and a search below it the chain leaves the pose alone and reports the search's
+    tables only; at or above it nothing changes."""
+    import eao_fusion_amd as E  # noqa: F401
+    cur, kps, desc, depth, pts, _ = _scene(7500, n=60)
+    _, last, _ = synth.synth_tracking(n=60, seed=7500, mono_frac=0.0, occupied_frac=0.0)
+    cap = 2048
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, cap)
+    trk = _tracker(cur, cap, 2048)
+    st = torch.cuda.current_stream().cuda_stream
+    run = lambda th: trk.track_with_motion_model(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], last, th, False, True, False, st)      # noqa: E731
+    full = run(15.0)
+    assert 3 <= full["n_matches"] and full["n_edges"] == full["n_matches"]
+    trk.set_options(min_matches=full["n_matches"] + 1)
+    skipped = run(15.0)
+    assert skipped["n_matches"] == full["n_matches"] and np.array_equal(skipped["kp_map_point"], full["kp_map_point"])      # the search's tables
+    assert skipped["n_edges"] == 0 and skipped["n_inliers"] == 0 and not skipped["kp_outlier"].any() and np.array_equal(skipped["Tcw"], cur["Tcw"])
+    trk.set_options(min_matches=full["n_matches"])
+    same = run(15.0)
+    assert all(np.array_equal(same[k], full[k]) if isinstance(full[k], np.ndarray) else same[k] == full[k] for k in full)
