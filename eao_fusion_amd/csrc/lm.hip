@@ -1438,13 +1438,23 @@ struct BADev {
     GP<const double> pmeas;    // 4 per plane edge: the measured plane, normalised
     double deltaPlane, infoAngle, infoDist;
     // map-scale path (k_bal_*): dense lower-triangular system in HBM, panel workspace, factored diagonal blocks, pair CSR
-    GP<double> big;            // RP * RP
-    GP<double> bigL;           // RP * RP: the factor L (rows below each panel's diagonal block), row N = z
+    // Round 5: BLOCK-SPARSE.  The reference factors this system with a sparse LDL^T (SimplicialLDLT + AMD, solvers/linear_solver_eigen.h:95-112) because a
+    // map's covisibility is sparse; here the lower triangle lives as 64 x 64 TILES and only the tiles that the covisibility structure -- and the fill-in of its
+    // elimination, worked out on the host at tile level -- can ever make non-zero exist: bigTile[ti * bigT + tj] = the tile's slot in both pools, or -1.
+    // Memory and work follow the non-zero structure; a map in which every keyframe sees every other one keeps every tile and runs as before.
+    GP<double> big;            // bigTiles x 64 x 64: the working matrix (row-major inside a tile)
+    GP<double> bigL;           // bigTiles x 64 x 64: the factor L (rows below each panel's diagonal block); row N = z
     GP<double> bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks
     GP<int> bigFail;
+    GP<const int> bigTile;     // bigT * bigT
+    int bigT, bigTiles;
+    GP<const int> bigRowStart; // N / 32 + 1: per 32-column panel, its trailing tile rows that are live in the panel's tile column ...
+    GP<const int> bigRows;     // ... ascending; entry 0 is always the tile row of the NEXT diagonal block (its workgroup factors it on the spot)
     GP<const int> lpStart;     // nPairsNZ + 1
     GP<const int> lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
     GP<const int> lpPts;       // landmark blocks of each pair, ascending
+    GP<const int> lpE1;        // ... and the landmark's edges in camera i1 / i2 (the dense point x camera table of the window path would be
+    GP<const int> lpE2;        //     nP x nC ints: 400 MB for a 1000-keyframe map)
     int nPairsNZ;
     // per-window addresses every kernel finds HERE (the kernels take an array of windows and blockIdx.z, see BA_WIN)
     GP<int> ctl0;              // the two control blocks (8 ints each); a launch runs on ctl0 + 8 * par
@@ -3054,6 +3064,13 @@ __host__ __device__ inline BigGeom big_geom(int nF) {
     return g;
 }
 
+__device__ __forceinline__ int big_slot(const BADev& P, int ti, int tj) { return P.bigTile[ti * P.bigT + tj]; }
+__device__ __forceinline__ double* big_tile(double* pool, int slot) { return pool + ((size_t)slot << 12); }
+// element (r, c), c <= r, of a pool; the caller knows the tile exists
+__device__ __forceinline__ double* big_elem(const BADev& P, double* pool, int r, int c) {
+    return big_tile(pool, big_slot(P, r >> 6, c >> 6)) + ((r & 63) << 6) + (c & 63);
+}
+
 constexpr int kBigPairThreads = 512;   // (block_sum_lds needs 8 column threads per value)
 __global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(const BADev* __restrict__ W, int wpar, int first) {
     BA_WIN(P);
@@ -3061,14 +3078,13 @@ __global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(const BADev
     if (P.ctl[kCtlHalt]) return;
     const int nF = P.nFree, t = threadIdx.x;
     const BigGeom g = big_geom(nF);
-    const size_t ld = g.RP;
     const int i1 = P.lpPair[2 * bx], i2 = P.lpPair[2 * bx + 1];
     const bool diag = i1 == i2;
     const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
     if (bx == 0) {
         if (first && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
         if (t == 0) *P.bigFail = 0;
-        for (int r = g.n + t; r < g.N; r += kBigPairThreads) P.big[(size_t)r * ld + r] = 1.0;     // identity padding
+        for (int r = g.n + t; r < g.N; r += kBigPairThreads) *big_elem(P, P.big, r, r) = 1.0;     // identity padding
     }
     const int beg = P.lpStart[bx], cnt = P.lpStart[bx + 1] - beg;
     double acc[42];
@@ -3076,8 +3092,8 @@ __global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(const BADev
     for (int q = 0; q < 42; q++) acc[q] = 0;
     for (int k = t; k < cnt; k += kBigPairThreads) {
         const int l = P.lpPts[beg + k];
-        const int e1 = P.table[(size_t)l * nF + i1], e2 = P.table[(size_t)l * nF + i2];
-        if (e1 < 0 || e2 < 0) continue;                      // deactivated by the outlier pass
+        const int e1 = P.lpE1[beg + k], e2 = P.lpE2[beg + k];
+        if ((P.eflag[e1] | P.eflag[e2]) & 2) continue;       // deactivated by the outlier pass
         double Di[9];
         dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
         const double* B1 = &P.Hpl[(size_t)e1 * 18];
@@ -3104,11 +3120,11 @@ __global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(const BADev
     const double s = part[t];
     if (t < 36) {
         const int r = t / 6, c = t - r * 6;
-        if (!diag) P.big[(size_t)(i2 * 6 + c) * ld + i1 * 6 + r] = s;        // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
-        else if (c >= r) P.big[(size_t)(i1 * 6 + c) * ld + i1 * 6 + r] = s + P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+        if (!diag) *big_elem(P, P.big, i2 * 6 + c, i1 * 6 + r) = s;          // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
+        else if (c >= r) *big_elem(P, P.big, i1 * 6 + c, i1 * 6 + r) = s + P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
     } else if (diag) {
         const int r = t - 36;
-        P.big[(size_t)g.N * ld + i1 * 6 + r] = P.bp[i1 * 6 + r] - s;         // right-hand side row
+        *big_elem(P, P.big, g.N, i1 * 6 + r) = P.bp[i1 * 6 + r] - s;         // right-hand side row
     }
 }
 
@@ -3150,11 +3166,11 @@ __device__ inline void bal_store_diag_wave(const BADev& P, int kb, const double 
 __global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, int wpar) {
     BA_WIN(P);
     if (P.ctl[kCtlHalt]) return;
-    const size_t ld = big_geom(P.nFree).RP;
     const int i = threadIdx.x & 31;
+    const double* T0 = big_tile(P.big, big_slot(P, 0, 0));
     double row[kBigNB];
 #pragma unroll
-    for (int j = 0; j < kBigNB; j++) row[j] = P.big[(size_t)i * ld + j];
+    for (int j = 0; j < kBigNB; j++) row[j] = T0[i * 64 + j];
     const bool bad = bal_factor_diag_wave(row);
     bal_store_diag_wave(P, 0, row, bad);
 }
@@ -3167,7 +3183,7 @@ __global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, i
 // tile that still reads a and one that would overwrite it with l).  The tile that holds the NEXT diagonal block factors it on
 // the spot (one wavefront, see above), so the next launch starts from a finished L_kk.  The first version ran the row solves
 // as a launch of their own: two dependent launches per panel instead of one (12 + 13 us at 40 free keyframes).
-__global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, int wpar, int kb, int last) {
+__global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, int wpar, int kb, int last, int rowsOff) {
     BA_WIN(P);
     __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
@@ -3175,20 +3191,22 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
     __shared__ double da[kBigNB][kBigNB + 1];
     if (P.ctl[kCtlHalt]) return;
     const BigGeom g = big_geom(P.nFree);
-    const size_t ld = g.RP;
+    constexpr size_t ld = 64;                          // (inside a tile)
     const int k0 = kb * kBigNB, t = threadIdx.x;
-    const int tj0 = (k0 + kBigNB) >> 6;
-    const int tj = tj0 + bx, ti = tj0 + blockIdx.y;
+    // the workgroup's tile: (x, y) -> entries x, y of the panel's list of live tile rows (a dense system lists every trailing row)
+    const int* rows = P.bigRows + rowsOff;      // (= bigRowStart[kb]: the host passes it, one dependent load less at the head of every workgroup)
+    const int tj = rows[bx], ti = rows[blockIdx.y];
     if (ti < tj) return;
-    const int r0 = ti * 64, c0 = tj * 64;
-    double* S = P.big;
-    // panel rows of this tile: threads 0..63 the tile's rows (W), 64..127 its columns (L)
+    const int r0 = ti * 64, c0 = tj * 64, kc = k0 >> 6;
+    // panel rows of this tile: threads 0..63 the tile's rows (W), 64..127 its columns (L); a tile row that is dead in the panel's tile column (only ever the
+    // first list entry: the next diagonal block's row is always listed) contributes zeros
     const bool roleW = t < 64;
     const int prow = roleW ? r0 + t : c0 + (t - 64);
-    const bool act = t < 128 && prow >= k0 + kBigNB && prow <= g.N;      // rows of the panel itself / beyond the system: zero
+    const int pslot = big_slot(P, roleW ? ti : tj, kc);
+    const bool act = t < 128 && pslot >= 0 && prow >= k0 + kBigNB && prow <= g.N;      // rows of the panel itself / beyond the system: zero
     double w[kBigNB];
     if (act) {
-        const double* src = S + (size_t)prow * ld + k0;
+        const double* src = big_tile(P.big, pslot) + ((prow & 63) << 6) + (k0 & 63);
 #pragma unroll
         for (int c = 0; c < kBigNB; c++) w[c] = src[c];
     } else {
@@ -3197,7 +3215,7 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
     }
     const int tx = t & 15, ty = t >> 4;
     double c[4][4];
-    double* C = S + (size_t)(r0 + ty * 4) * ld + c0 + tx * 4;
+    double* C = big_tile(P.big, big_slot(P, ti, tj)) + (size_t)(ty * 4) * ld + tx * 4;      // (the host's symbolic elimination made sure the tile exists)
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -3219,7 +3237,7 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
 #pragma unroll
             for (int k = 0; k < kBigNB; k++) Wt[k][t] = w[k];
             if (bx == 0 && act) {
-                double* ldst = P.bigL + (size_t)prow * ld + k0;
+                double* ldst = big_tile(P.bigL, pslot) + ((prow & 63) << 6) + (k0 & 63);
 #pragma unroll
                 for (int k = 0; k < kBigNB; k++) ldst[k] = w[k] * a[k][k];
             }
@@ -3278,12 +3296,20 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
     __shared__ double part2[4][64];
     if (P.ctl[kCtlHalt]) return;
     const BigGeom g = big_geom(P.nFree);
-    const size_t ld = g.RP;
     const int n = g.n, N = g.N, t = threadIdx.x;
-    double* S = P.bigL;            // the archived factor (rows below each panel's diagonal block, z = row N)
+    double* S = P.bigL;            // the archived factor (rows below each panel's diagonal block, z = row N), as tiles
     const int J0 = J * kBigSB, w = min(kBigSB, N - J0);
-    double* z = S + (size_t)N * ld;
-    if (t < w) xl[t] = z[J0 + t];
+    auto zat = [&](int col) { return big_elem(P, S, N, col); };      // z = row N: its tile row is dense by construction
+    auto Lat = [&](int r, int col) -> double {                      // L(r, col), col < r: zero where the tile does not exist
+        const int sl = big_slot(P, r >> 6, col >> 6);
+        return sl < 0 ? 0.0 : big_tile(S, sl)[((r & 63) << 6) + (col & 63)];
+    };
+    if (J > 0 && bx > 0) {      // a column chunk in which none of the super-block's tile rows holds a tile has nothing to remove (workgroup-uniform; workgroup 0 also delivers x)
+        bool any = false;
+        for (int r = J0 >> 6; r <= (J0 + w - 1) >> 6; r++) any = any || big_slot(P, r, bx) >= 0;
+        if (!any) return;
+    }
+    if (t < w) xl[t] = *zat(J0 + t);
     {   // the super-block's (up to eight) factored diagonal blocks: 64 KB of LDS, every load of a thread in flight at once
         const double* Ld0 = P.bigDiag + (size_t)(J0 / kBigNB) * kBigNB * kBigNB;
         const int cnt = (w / kBigNB) * kBigNB * kBigNB;
@@ -3297,7 +3323,7 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
         if (b >= 0 && t < b * kBigNB) {
             const int cb = J0 + b * kBigNB;
 #pragma unroll
-            for (int i = 0; i < kBigNB; i++) dst[i] = S[(size_t)(cb + i) * ld + J0 + t];
+            for (int i = 0; i < kBigNB; i++) dst[i] = Lat(cb + i, J0 + t);
         }
     };
     auto do_block = [&](int b, double (&cur)[kBigNB], double (&nxt)[kBigNB]) {
@@ -3344,13 +3370,13 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
         for (int i0 = rg; i0 < w; i0 += 32) {      // (w is a multiple of 32) eight independent loads in flight
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = S[(size_t)(J0 + i0 + 4 * u) * ld + j];
+            for (int u = 0; u < 8; u++) v[u] = Lat(J0 + i0 + 4 * u, j);
 #pragma unroll
             for (int u = 0; u < 8; u++) acc = fma(v[u], xl[i0 + 4 * u], acc);
         }
         part2[rg][t & 63] = acc;
         __syncthreads();
-        if (rg == 0) z[j] -= (part2[0][t] + part2[1][t]) + (part2[2][t] + part2[3][t]);
+        if (rg == 0) *zat(j) -= (part2[0][t] + part2[1][t]) + (part2[2][t] + part2[3][t]);
         return;
     }
     __threadfence();
@@ -3586,7 +3612,7 @@ __global__ void k_ba_classify(const BADev* __restrict__ W, int wpar, int update)
         if (!bad && !(fl & 2)) P.ctl[kCtlAnyActive] = 1;     // somebody survives: the second optimize() has something to do
         const int l = P.ptIdx[P.ept[e]], ci = P.camIdx[P.ecam[e]];
         if (bad && l >= 0 && ci >= 0) {
-            P.table[(size_t)l * P.nFree + ci] = -1;
+            if (P.table) P.table[(size_t)l * P.nFree + ci] = -1;
             if (P.wmode && !(fl & 2)) {      // the pair lists keep their entries: a switched-off edge contributes a zero block from now on
                 double* Wx = &P.Hpl[(size_t)e * 18];
 #pragma unroll
@@ -3601,7 +3627,7 @@ __global__ void k_ba_classify(const BADev* __restrict__ W, int wpar, int update)
 __global__ __launch_bounds__(256) void k_ba_prepare(const BADev* __restrict__ W, int wpar) {
     BA_WIN(P);
     const int idx = bx * 256 + threadIdx.x;
-    if (idx < P.nL * P.nFree) {
+    if (P.table && idx < P.nL * P.nFree) {      // (the map-scale path has no table: its pair lists carry the edges)
         const int l = idx / P.nFree, ci = idx - l * P.nFree;
         int found = -1;
         for (int k = P.ptStart[l]; k < P.ptStart[l + 1]; k++) {
@@ -4001,6 +4027,8 @@ struct BADims {
     size_t tileLds = 0, solveLds = 0, schurLds = 0;
     int nPairsNZ = 0;          // map-scale path (never batched)
     double* big = nullptr;     // "
+    int bigTiles = 0;          // "
+    std::vector<int> bigRowCnt, bigRowOff; // " : live tile rows of every 32-column panel (the grid of its k_bal_step launch) and where its list starts
     BigGeom gB{};
     int chunks = kChunks;
     void merge(const BADims& o) {
@@ -4058,7 +4086,7 @@ struct BALaunch {
         else lin_launch<kLinThreads>(par, first, diagOnly);
     }
     void setup() const {      // device-side part of the set-up (once per window)
-        hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(std::max(d.nL * d.nF, d.nL * 8), d.nP * 3), d.nC), d.E), d.nPl * 4), 256), 1, gz()), dim3(256), 0, s, W, wp(0));
+        hipLaunchKernelGGL(k_ba_prepare, dim3(eao::cdiv(std::max(std::max(std::max(std::max(std::max(d.bigPath ? 0 : d.nL * d.nF, d.nL * 8), d.nP * 3), d.nC), d.E), d.nPl * 4), 256), 1, gz()), dim3(256), 0, s, W, wp(0));
         if (d.usePairs) {
             hipLaunchKernelGGL(k_ba_pairs, dim3(d.nF * (d.nF + 1) / 2, 1, gz()), dim3(256), 0, s, W, wp(0));
             hipLaunchKernelGGL(k_ba_tiles_init, dim3(tile_geom(d.nF).nTiles, 1, gz()), dim3(256), 0, s, W, wp(0));
@@ -4070,13 +4098,13 @@ struct BALaunch {
         const TileGeom tg = tile_geom(std::max(nF, 1));
         if (nF && d.bigPath) {
             const BigGeom gB = d.gB;
-            (void)hipMemsetAsync(d.big, 0, (size_t)gB.RP * gB.RP * sizeof(double), s);
+            (void)hipMemsetAsync(d.big, 0, ((size_t)d.bigTiles << 12) * sizeof(double), s);
             hipLaunchKernelGGL(k_bal_schur_pairs, dim3(d.nPairsNZ), dim3(kBigPairThreads), 0, s, W, wp(par), firstTrial ? 1 : 0);
-            const int nbk = gB.N / kBigNB, nT = gB.RP / 64;
+            const int nbk = gB.N / kBigNB;
             hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, W, wp(par));
             for (int kb = 0; kb < nbk; kb++) {
-                const int tj0 = (kb * kBigNB + kBigNB) >> 6;
-                hipLaunchKernelGGL(k_bal_step, dim3(nT - tj0, nT - tj0), dim3(256), 0, s, W, wp(par), kb, kb + 1 == nbk ? 1 : 0);
+                const int nr = d.bigRowCnt[kb];      // the panel's live tile rows (a dense system: every trailing one)
+                hipLaunchKernelGGL(k_bal_step, dim3(nr, nr), dim3(256), 0, s, W, wp(par), kb, kb + 1 == nbk ? 1 : 0, d.bigRowOff[kb]);
             }
             for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
                 hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, W, wp(par), J);
@@ -4236,16 +4264,70 @@ struct BAJob {
             lpPairsMax = std::min(lpEntries, (size_t)nFreeIn * (nFreeIn + 1) / 2);
             EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
         }
+        // ---- round 5: the TILE structure of the map-scale system.  Which 64 x 64 tiles of the lower triangle can ever be non-zero: the tiles a covisible camera pair's
+        //      6 x 6 block touches, the diagonal, the tile row of the right-hand side -- and the fill-in of the elimination, worked out here once at tile level
+        //      (eliminating tile column k joins every pair of tile rows that are live in it: the block form of the symbolic factorisation a sparse LDL^T starts
+        //      with, solvers/linear_solver_eigen.h:95-112; natural keyframe order -- consecutive keyframes are the covisible ones, which is what a fill-reducing
+        //      ordering would recover).  Memory and the launches' grids follow this structure.
+        static thread_local std::vector<int> tileMap, panelStart, panelRows;
+        int bigT = 0, bigTiles = 0;
+        if (bigPath) {
+            std::vector<int> fidx((size_t)nC, -1), cc((size_t)nC, 0);
+            for (int e = 0; e < E; e++) cc[edge_cam(e)]++;
+            int nFa = 0;
+            for (int i = 0; i < nC; i++) if (cc[i] && !p->cam_fixed[i]) fidx[i] = nFa++;
+            const BigGeom g = big_geom(std::max(nFa, 1));
+            bigT = g.RP / 64;
+            const int T = bigT, tN = g.N >> 6;
+            std::vector<unsigned char> live((size_t)T * T, 0);
+            {
+                const std::vector<int>& fc = c.scratch;      // free observers per landmark (counted above)
+                std::vector<int> off((size_t)nP + 1, 0), lst;
+                for (int i = 0; i < nP; i++) off[i + 1] = off[i] + fc[i];
+                lst.resize(off[nP]);
+                std::vector<int> cur(off.begin(), off.end() - 1);
+                for (int e = 0; e < E; e++) { const int f = fidx[edge_cam(e)]; if (f >= 0) lst[cur[edge_lm(e)]++] = f; }
+                for (int i = 0; i < nP; i++)
+                    for (int u = off[i]; u < off[i + 1]; u++)
+                        for (int v = u; v < off[i + 1]; v++) {
+                            const int lo = std::min(lst[u], lst[v]), hi = std::max(lst[u], lst[v]);
+                            const int r0 = (6 * hi) >> 6, r1 = (6 * hi + 5) >> 6, c0 = (6 * lo) >> 6, c1 = (6 * lo + 5) >> 6;
+                            live[(size_t)std::max(r0, c0) * T + std::min(r0, c0)] = 1; live[(size_t)std::max(r0, c1) * T + std::min(r0, c1)] = 1;
+                            live[(size_t)std::max(r1, c0) * T + std::min(r1, c0)] = 1; live[(size_t)std::max(r1, c1) * T + std::min(r1, c1)] = 1;
+                        }
+            }
+            for (int t = 0; t < T; t++) live[(size_t)t * T + t] = 1;
+            for (int t = 0; t <= tN; t++) live[(size_t)tN * T + t] = 1;      // the right-hand side row N (and the z it becomes) spans every column
+            std::vector<int> rws;
+            for (int k = 0; k < T; k++) {      // symbolic elimination
+                rws.clear();
+                for (int i = k + 1; i < T; i++) if (live[(size_t)i * T + k]) rws.push_back(i);
+                for (size_t a1 = 0; a1 < rws.size(); a1++)
+                    for (size_t b1 = 0; b1 <= a1; b1++) live[(size_t)rws[a1] * T + rws[b1]] = 1;
+            }
+            tileMap.assign((size_t)T * T, -1);
+            for (int i = 0; i < T; i++) for (int j = 0; j <= i; j++) if (live[(size_t)i * T + j]) tileMap[(size_t)i * T + j] = bigTiles++;
+            // per 32-column panel: the trailing tile rows that are live in the panel's tile column, the tile row of the next diagonal block first
+            const int nbk = g.N / kBigNB;
+            panelStart.assign((size_t)nbk + 1, 0); panelRows.clear();
+            for (int kb = 0; kb < nbk; kb++) {
+                const int kc = (kb * kBigNB) >> 6, tj0 = (kb * kBigNB + kBigNB) >> 6;
+                panelStart[kb] = (int)panelRows.size();
+                if (tj0 < T) panelRows.push_back(tj0);
+                for (int i = tj0 + 1; i < T; i++) if (live[(size_t)i * T + kc]) panelRows.push_back(i);
+            }
+            panelStart[nbk] = (int)panelRows.size();
+        }
         size_t need = 0;
         need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
-        need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (size_t)nP * nC * 4;
+        need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (bigPath ? 64 : (size_t)nP * nC * 4);
         need += (size_t)nC * (2 * sizeof(SE3) + 36 * 8 + 6 * 8 + 6 * 8 + 16);
         need += (size_t)nP * 8 * sizeof(int4) + 256;
         need += (size_t)nP * 9 * 8 + 2048 + 256;      // Tl, ul, the zero block
         need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
-            need += (2 * (size_t)bg.RP * bg.RP + (size_t)bg.N * kBigNB) * 8;
-            need += (lpEntries + 3 * lpPairsMax + 8) * 4;
+            need += (2 * ((size_t)bigTiles << 12) + (size_t)bg.N * kBigNB) * 8;
+            need += (3 * lpEntries + 3 * lpPairsMax + 8) * 4 + (tileMap.size() + panelStart.size() + panelRows.size() + 8) * 4 + 2048;
         } else {
             need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
             need += (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
@@ -4274,12 +4356,17 @@ struct BAJob {
         int* dlpStart = a.take<int>(bigPath ? lpPairsMax + 1 : 1);
         int* dlpPair = a.take<int>(bigPath ? 2 * lpPairsMax : 1);
         int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
+        int* dlpE1 = a.take<int>(bigPath ? lpEntries : 1);
+        int* dlpE2 = a.take<int>(bigPath ? lpEntries : 1);
+        int* dbigTile = a.take<int>(bigPath ? tileMap.size() : 1);
+        int* dbigRowStart = a.take<int>(bigPath ? panelStart.size() : 1);
+        int* dbigRows = a.take<int>(bigPath ? std::max<size_t>(panelRows.size(), 1) : 1);
         double* dpl0 = a.take<double>((size_t)nPl * 4 + 1);
         double* dpmeas = a.take<double>((size_t)Epl * 4 + 1);
         dW = a.take<BADev>(2);
         const size_t off1 = (a.off + 255) & ~(size_t)255;
         // ---- device-only part
-        int* dtable = a.take<int>((size_t)nP * nC);
+        int* dtable = bigPath ? nullptr : a.take<int>((size_t)nP * nC);      // (the map-scale path finds a landmark's edges in its pair lists)
         D.slot = a.take<int4>((size_t)std::max(nP, 1) * 8);
         D.camEdgeL = a.take<int>(E);
         const bool pairPath = !bigPath && nFreeIn > 0 && nFreeIn <= kTileMaxFree && !(solverEnv0 && !strcmp(solverEnv0, "lds")) && !getenv("EAO_BA_SLABS");
@@ -4304,11 +4391,12 @@ struct BAJob {
         double* dsolveScratch = a.take<double>(bigPath ? 8 : (size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
         D.sys = a.take<double>(bigPath ? 8 : std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
         D.slab = a.take<double>(bigPath ? 8 : (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
-        D.big = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
-        D.bigL = a.take<double>(bigPath ? (size_t)bg.RP * bg.RP : 8);
+        D.big = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
+        D.bigL = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
+        D.bigTile = dbigTile; D.bigT = bigT; D.bigTiles = bigTiles; D.bigRowStart = dbigRowStart; D.bigRows = dbigRows;
         D.bigDiag = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
         D.bigFail = a.take<int>(4);
-        D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpPts = dlpPts;
+        D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpPts = dlpPts; D.lpE1 = dlpE1; D.lpE2 = dlpE2;
         D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
         D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
         D.lm0 = a.take<double>(16);
@@ -4407,17 +4495,25 @@ struct BAJob {
                 // covisibility CSR: for every camera pair (i1 <= i2) sharing a landmark, the landmark blocks in ascending order
                 // (counting sort over the landmarks' observer lists; the diagonal pairs carry each camera's own landmarks)
                 int* lpStart = (int*)hostp(dlpStart); int* lpPair = (int*)hostp(dlpPair); int* lpPts = (int*)hostp(dlpPts);
-                static thread_local std::vector<int> pcnt, obs;
+                int* lpE1 = (int*)hostp(dlpE1); int* lpE2 = (int*)hostp(dlpE2);
+                EAO_REQUIRE(big_geom(nF).RP / 64 == bigT, "internal: tile structure built for another system size");
+                std::memcpy(hostp(dbigTile), tileMap.data(), tileMap.size() * sizeof(int));
+                std::memcpy(hostp(dbigRowStart), panelStart.data(), panelStart.size() * sizeof(int));
+                if (!panelRows.empty()) std::memcpy(hostp(dbigRows), panelRows.data(), panelRows.size() * sizeof(int));
+                static thread_local std::vector<int> pcnt, obs, obsE;
                 pcnt.assign((size_t)nF * (nF + 1) / 2, 0);
-                auto each_pair = [&](auto&& fn) {
+                auto each_pair = [&](auto&& fn) {      // fn(pair slot index, landmark, its edge in the pair's first camera, in its second)
                     for (int l = 0; l < nL; l++) {
-                        obs.clear();
-                        for (int k = ptStart[l]; k < ptStart[l + 1]; k++) { const int ci = camIdx[edge_cam(ptEdges[k])]; if (ci >= 0) obs.push_back(ci); }
+                        obs.clear(); obsE.clear();
+                        for (int k = ptStart[l]; k < ptStart[l + 1]; k++) { const int ci = camIdx[edge_cam(ptEdges[k])]; if (ci >= 0) { obs.push_back(ci); obsE.push_back(ptEdges[k]); } }
                         for (size_t u = 0; u < obs.size(); u++)
-                            for (size_t v = u; v < obs.size(); v++) fn(pair_index(std::min(obs[u], obs[v]), std::max(obs[u], obs[v]), nF), l);
+                            for (size_t v = u; v < obs.size(); v++) {
+                                const bool uFirst = obs[u] <= obs[v];
+                                fn(pair_index(std::min(obs[u], obs[v]), std::max(obs[u], obs[v]), nF), l, obsE[uFirst ? u : v], obsE[uFirst ? v : u]);
+                            }
                     }
                 };
-                each_pair([&](int pi, int) { pcnt[pi]++; });
+                each_pair([&](int pi, int, int, int) { pcnt[pi]++; });
                 int nz = 0, run = 0, pi = 0;
                 for (int i1 = 0; i1 < nF; i1++)
                     for (int i2 = i1; i2 < nF; i2++, pi++) {
@@ -4428,7 +4524,7 @@ struct BAJob {
                         run += cnt0; nz++;
                     }
                 lpStart[nz] = run;
-                each_pair([&](int pi2, int l) { lpPts[lpStart[pcnt[pi2]]++] = l; });
+                each_pair([&](int pi2, int l, int ea, int eb) { const int at = lpStart[pcnt[pi2]]++; lpPts[at] = l; lpE1[at] = ea; lpE2[at] = eb; });
                 for (int k = nz; k > 0; k--) lpStart[k] = lpStart[k - 1];   // cursors ended at the next pair's start: shift back
                 lpStart[0] = 0;
                 D.nPairsNZ = nz;
@@ -4458,7 +4554,9 @@ struct BAJob {
         d.tiles3 = tile_geom(std::max(nF, 1)).nTiles <= 3 * (kTileThreads / 64);
         d.schurLds = bigPath ? 0 : schur_lds_bytes(nF);
         d.gB = big_geom(std::max(nF, 1));
-        d.nPairsNZ = D.nPairsNZ; d.big = D.big;
+        d.nPairsNZ = D.nPairsNZ; d.big = D.big; d.bigTiles = bigTiles;
+        d.bigRowCnt.clear(); d.bigRowOff.clear();
+        if (bigPath) for (size_t kb = 0; kb + 1 < panelStart.size(); kb++) { d.bigRowCnt.push_back(panelStart[kb + 1] - panelStart[kb]); d.bigRowOff.push_back(panelStart[kb]); }
         // the window record itself travels with the structure
         write_records((BADev*)hostp(dW));
         if (!deferUpload) EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));

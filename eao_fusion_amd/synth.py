@@ -69,9 +69,12 @@ def _rot(rx, ry, rz):
 
 
 def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_frac=0.05, mono_frac=0.0,
-             rot_noise_deg=0.5, trans_noise=0.01, point_noise=0.02):
+             rot_noise_deg=0.5, trans_noise=0.01, point_noise=0.02, band=0):
     """Local-BA window.  Cameras on a 1 m arc facing a common volume; ids 0..n_fixed-1 fixed.
     Point i is observed by m_i = 2 + (i mod 7) cameras (i*7919 + j) mod n_cams.
+    band > 0 (round 5, a MAP instead of a window): the cameras follow a trajectory of n_cams / 24 m (the same 4 cm between neighbours), point i is observed by
+    m_i = 2 + (i mod (band - 1)) CONSECUTIVE cameras and lies in front of them -- every keyframe is covisible with its +-(band - 1) neighbours only, the
+    reduced camera system is a band matrix.
     Returns a dict of float32/int32 arrays shaped as the C-ABI wants them (eao_ba_problem):
       poses   (n_cams, 4, 4) f32 Tcw   (perturbed for free cameras)
       fixed   (n_cams,) u8
@@ -87,18 +90,31 @@ def synth_ba(n_free=20, n_fixed=4, n_points=3000, seed=3000, sigma=1.0, outlier_
     pts[:, 0] = rng.uniform(-0.3, 0.3, n_points) * pts[:, 2]   # inside every camera's frustum
     pts[:, 1] = rng.uniform(-0.25, 0.25, n_points) * pts[:, 2]
     poses = np.zeros((n_cams, 4, 4))
+    arc = max(1.0, n_cams / 24.0) if band else 1.0
+    centres = np.zeros((n_cams, 3))
     for c in range(n_cams):
         t = c / max(n_cams - 1, 1) - 0.5            # camera centres along a 1 m arc
-        centre = np.array([t, 0.05 * np.sin(6 * t), 0.1 * t * t])
-        Rwc = _rot(0.02 * np.sin(3 * t), -0.15 * t, 0.01 * t)   # look roughly at the volume centre
+        if band:      # a straight trajectory with a gentle weave: every camera looks along +z, its neighbours 4 cm to either side
+            centre = np.array([t * arc, 0.05 * np.sin(6 * t * arc), 0.02 * np.sin(2 * t * arc)])
+            Rwc = _rot(0.02 * np.sin(3 * t * arc), 0.03 * np.sin(5 * t * arc), 0.01 * np.sin(t * arc))
+        else:
+            centre = np.array([t, 0.05 * np.sin(6 * t), 0.1 * t * t])
+            Rwc = _rot(0.02 * np.sin(3 * t), -0.15 * t, 0.01 * t)   # look roughly at the volume centre
         Rcw = Rwc.T
+        centres[c] = centre
         poses[c, :3, :3] = Rcw
         poses[c, :3, 3] = -Rcw @ centre
         poses[c, 3, 3] = 1
     e_pt, e_cam = [], []
     for i in range(n_points):
-        m = 2 + (i % 7)
-        cams = sorted({(i * 7919 + j) % n_cams for j in range(m)})
+        if band:
+            m = min(2 + (i % max(1, band - 1)), n_cams)
+            c0 = (i * 7919) % (n_cams - m + 1)
+            cams = list(range(c0, c0 + m))
+            pts[i, 0] += centres[c0:c0 + m, 0].mean()          # in front of its observers
+        else:
+            m = 2 + (i % 7)
+            cams = sorted({(i * 7919 + j) % n_cams for j in range(m)})
         for c in cams:
             e_pt.append(i)
             e_cam.append(c)
