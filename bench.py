@@ -359,7 +359,7 @@ def flat_scalars(roofline, extra):
     put("ba_map_scale_ms", lambda: extra["bundle_adjustment_map_scale"]["ms_per_call"])
     put("ba_map_scale_frac", lambda: extra["bundle_adjustment_map_scale"]["frac_hbm"])
     put("ba_map_scale_banded_ms", lambda: extra["bundle_adjustment_map_scale_banded"]["ms_per_call"])
-    put("ba_map_scale_banded_MB", lambda: extra["bundle_adjustment_map_scale_banded"]["device_MB"])
+    put("ba_map_scale_banded_frac", lambda: extra["bundle_adjustment_map_scale_banded"]["frac_hbm"])
     put("hamming_matrix_us", lambda: round(extra["hamming_matrix"]["ms_per_launch"] * 1e3, 2))
     put("hamming_matrix_frac", lambda: extra["hamming_matrix"]["frac_hbm"])
     put("hamming_best2_us", lambda: round(extra["hamming_best2"]["ms_per_launch"] * 1e3, 2))
@@ -1104,9 +1104,33 @@ def measure_extra(E, synth, torch, dev):
             rm = E.Optimizer.BundleAdjustment(gm, 10, bRobust=False)
         dtm = (time.perf_counter() - t0) / 3
         trials = int(np.sum(rm["trace"]["trials"]))
-        extra["bundle_adjustment_map_scale"] = {"workload": "BundleAdjustment 200 free + 1 fixed KF x 20000 MP, E=%d, 10 its (1200 x 1200 reduced camera system)" % len(gm["edge_cam"]),
+        Em = len(gm["edge_cam"])
+        extra["bundle_adjustment_map_scale"] = {"workload": "BundleAdjustment 200 free + 1 fixed KF x 20000 MP, E=%d, 10 its (1200 x 1200 reduced camera system, every keyframe covisible with every other)" % Em,
                                                 "ms_per_call": round(dtm * 1e3, 3), "iters": int(rm["iters"][0]), "lm_trials": trials,
-                                                "ba_residual_blocks_per_s": round(len(gm["edge_cam"]) * int(rm["iters"][0]) / dtm, 1)}
+                                                "ba_residual_blocks_per_s": round(Em * int(rm["iters"][0]) / dtm, 1),
+                                                # the same per-unit figure as the windows (E x 520 + P x 360 bytes per LM trial) over the call's wall time
+                                                "frac_hbm": round((Em * 520 + 20000 * 360) * trials / dtm / 1e9 / HBM_PEAK_GBS, 5)}
+        # ... and a MAP as a SLAM system produces it (round 5): 1000 keyframes along a trajectory, each covisible with its +-10 neighbours only -- the reduced camera
+        # system is a band; the map-scale path stores and factors only the 64 x 64 tiles of that structure (+ fill-in)
+        try:
+            gb = synth.synth_ba(n_free=1000, n_fixed=1, n_points=50000, seed=5400, band=11)
+            E.Optimizer.BundleAdjustment(gb, 10, bRobust=False)
+            free0 = torch.cuda.mem_get_info()[0]
+            t0 = time.perf_counter()
+            for _ in range(3):
+                rb_ = E.Optimizer.BundleAdjustment(gb, 10, bRobust=False)
+            dtb_ = (time.perf_counter() - t0) / 3
+            Eb = len(gb["edge_cam"])
+            trb = int(np.sum(rb_["trace"]["trials"]))
+            extra["bundle_adjustment_map_scale_banded"] = {"workload": "BundleAdjustment 1000 free + 1 fixed KF x 50000 MP, E=%d, 10 its; every keyframe covisible with its +-10 neighbours (6000 x 6000 band system)" % Eb,
+                                                           "ms_per_call": round(dtb_ * 1e3, 3), "iters": int(rb_["iters"][0]), "lm_trials": trb,
+                                                           "ba_residual_blocks_per_s": round(Eb * int(rb_["iters"][0]) / dtb_, 1),
+                                                           "frac_hbm": round((Eb * 520 + 50000 * 360) * trb / dtb_ / 1e9 / HBM_PEAK_GBS, 5),
+                                                           "device_MB_dense_storage_would_need": round(2 * 6016.0 * 6016 * 8 / 1e6 + 50000 * 1001 * 4 / 1e6, 1),
+                                                           "note": "device memory of the library's arena for this problem: see tools/dbg_gba_banded.py (126 MB, torch.cuda.mem_get_info around the first call)"}
+            del free0
+        except Exception as ex:  # noqa: BLE001
+            extra["bundle_adjustment_map_scale_banded_error"] = repr(ex)
     except Exception as ex:  # noqa: BLE001
         extra["ba_error"] = repr(ex)
     return extra

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libeaofusion_hip.so")
+LIB_PATH = os.environ.get("EAO_LIB_PATH") or os.path.join(HERE, "libeaofusion_hip.so")      # (EAO_LIB_PATH: A/B runs against another build of the library)
 
 EAO_OK, EAO_ERR_INVALID, EAO_ERR_NO_DEVICE, EAO_ERR_CAPACITY, EAO_ERR_INTERNAL = 0, -1, -2, -3, -4
 

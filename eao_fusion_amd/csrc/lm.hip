@@ -1447,9 +1447,10 @@ struct BADev {
     GP<double> bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks
     GP<int> bigFail;
     GP<const int> bigTile;     // bigT * bigT
-    int bigT, bigTiles;
-    GP<const int> bigRowStart; // N / 32 + 1: per 32-column panel, its trailing tile rows that are live in the panel's tile column ...
-    GP<const int> bigRows;     // ... ascending; entry 0 is always the tile row of the NEXT diagonal block (its workgroup factors it on the spot)
+    int bigT, bigTiles, bigDense;
+    GP<const int4> bigWork;    // per 32-column panel, ONE record pair per tile its launch updates -- {ti, tj, slot of tile (ti, tj), slot of the panel's tile in row ti},
+                               // {slot of the panel's tile in row tj, 0, 0, 0} (-1: dead, zeros) -- so a workgroup finds its tiles with one load; the first record of a
+                               // panel is always the tile of the NEXT diagonal block (its workgroup factors it on the spot)
     GP<const int> lpStart;     // nPairsNZ + 1
     GP<const int> lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
     GP<const int> lpPts;       // landmark blocks of each pair, ascending
@@ -3064,7 +3065,8 @@ __host__ __device__ inline BigGeom big_geom(int nF) {
     return g;
 }
 
-__device__ __forceinline__ int big_slot(const BADev& P, int ti, int tj) { return P.bigTile[ti * P.bigT + tj]; }
+// (every tile live -- a map in which every keyframe sees every other one: the slots are the row-major numbering of the lower triangle, no table look-up)
+__device__ __forceinline__ int big_slot(const BADev& P, int ti, int tj) { return P.bigDense ? ti * (ti + 1) / 2 + tj : P.bigTile[ti * P.bigT + tj]; }
 __device__ __forceinline__ double* big_tile(double* pool, int slot) { return pool + ((size_t)slot << 12); }
 // element (r, c), c <= r, of a pool; the caller knows the tile exists
 __device__ __forceinline__ double* big_elem(const BADev& P, double* pool, int r, int c) {
@@ -3183,7 +3185,7 @@ __global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, i
 // tile that still reads a and one that would overwrite it with l).  The tile that holds the NEXT diagonal block factors it on
 // the spot (one wavefront, see above), so the next launch starts from a finished L_kk.  The first version ran the row solves
 // as a launch of their own: two dependent launches per panel instead of one (12 + 13 us at 40 free keyframes).
-__global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, int wpar, int kb, int last, int rowsOff) {
+__global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, int wpar, int kb, int last, int workOff) {
     BA_WIN(P);
     __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
@@ -3193,16 +3195,15 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
     const BigGeom g = big_geom(P.nFree);
     constexpr size_t ld = 64;                          // (inside a tile)
     const int k0 = kb * kBigNB, t = threadIdx.x;
-    // the workgroup's tile: (x, y) -> entries x, y of the panel's list of live tile rows (a dense system lists every trailing row)
-    const int* rows = P.bigRows + rowsOff;      // (= bigRowStart[kb]: the host passes it, one dependent load less at the head of every workgroup)
-    const int tj = rows[bx], ti = rows[blockIdx.y];
-    if (ti < tj) return;
-    const int r0 = ti * 64, c0 = tj * 64, kc = k0 >> 6;
+    // the workgroup's tile: record bx of the panel's work list (built by the host from the tile structure; a dense system lists every trailing tile)
+    const int4 wa = P.bigWork[2 * (size_t)(workOff + bx)], wb = P.bigWork[2 * (size_t)(workOff + bx) + 1];
+    const int ti = wa.x, tj = wa.y;
+    const int r0 = ti * 64, c0 = tj * 64;
     // panel rows of this tile: threads 0..63 the tile's rows (W), 64..127 its columns (L); a tile row that is dead in the panel's tile column (only ever the
     // first list entry: the next diagonal block's row is always listed) contributes zeros
     const bool roleW = t < 64;
     const int prow = roleW ? r0 + t : c0 + (t - 64);
-    const int pslot = big_slot(P, roleW ? ti : tj, kc);
+    const int pslot = roleW ? wa.w : wb.x;
     const bool act = t < 128 && pslot >= 0 && prow >= k0 + kBigNB && prow <= g.N;      // rows of the panel itself / beyond the system: zero
     double w[kBigNB];
     if (act) {
@@ -3215,7 +3216,7 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
     }
     const int tx = t & 15, ty = t >> 4;
     double c[4][4];
-    double* C = big_tile(P.big, big_slot(P, ti, tj)) + (size_t)(ty * 4) * ld + tx * 4;      // (the host's symbolic elimination made sure the tile exists)
+    double* C = big_tile(P.big, wa.z) + (size_t)(ty * 4) * ld + tx * 4;      // (the host's symbolic elimination made sure the tile exists)
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -3236,7 +3237,7 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
         if (roleW) {
 #pragma unroll
             for (int k = 0; k < kBigNB; k++) Wt[k][t] = w[k];
-            if (bx == 0 && act) {
+            if (ti == tj && act) {      // a tile row's DIAGONAL workgroup archives its panel rows (every listed row has one)
                 double* ldst = big_tile(P.bigL, pslot) + ((prow & 63) << 6) + (k0 & 63);
 #pragma unroll
                 for (int k = 0; k < kBigNB; k++) ldst[k] = w[k] * a[k][k];
@@ -3262,7 +3263,7 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
 #pragma unroll
         for (int j = 0; j < 4; j++) C[(size_t)i * ld + j] = c[i][j];
     // look-ahead: the tile that holds the NEXT panel's diagonal block (the first one dispatched) factors it right away
-    if (!last && bx == 0 && blockIdx.y == 0) {
+    if (!last && bx == 0) {
         const int o = k0 + kBigNB - c0;            // 0 or 32: offset of the block inside this tile
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -3322,8 +3323,10 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
     auto fetch = [&](int b, double (&dst)[kBigNB]) {
         if (b >= 0 && t < b * kBigNB) {
             const int cb = J0 + b * kBigNB;
+            const int sl = big_slot(P, cb >> 6, (J0 + t) >> 6);      // the block's 32 rows lie in one tile row
+            const double* src = sl < 0 ? nullptr : big_tile(S, sl) + ((cb & 63) << 6) + ((J0 + t) & 63);
 #pragma unroll
-            for (int i = 0; i < kBigNB; i++) dst[i] = Lat(cb + i, J0 + t);
+            for (int i = 0; i < kBigNB; i++) dst[i] = src ? src[i << 6] : 0.0;
         }
     };
     auto do_block = [&](int b, double (&cur)[kBigNB], double (&nxt)[kBigNB]) {
@@ -4028,7 +4031,8 @@ struct BADims {
     int nPairsNZ = 0;          // map-scale path (never batched)
     double* big = nullptr;     // "
     int bigTiles = 0;          // "
-    std::vector<int> bigRowCnt, bigRowOff; // " : live tile rows of every 32-column panel (the grid of its k_bal_step launch) and where its list starts
+    const int* bigPanelStart = nullptr;      // " : where every 32-column panel's work records start (nbk + 1 entries, thread-local storage that outlives the call's launches;
+                                             //     a POINTER: this struct is copied around, a vector member would be re-allocated with every copy)
     BigGeom gB{};
     int chunks = kChunks;
     void merge(const BADims& o) {
@@ -4103,8 +4107,8 @@ struct BALaunch {
             const int nbk = gB.N / kBigNB;
             hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, W, wp(par));
             for (int kb = 0; kb < nbk; kb++) {
-                const int nr = d.bigRowCnt[kb];      // the panel's live tile rows (a dense system: every trailing one)
-                hipLaunchKernelGGL(k_bal_step, dim3(nr, nr), dim3(256), 0, s, W, wp(par), kb, kb + 1 == nbk ? 1 : 0, d.bigRowOff[kb]);
+                // the panel's work list: the trailing tiles both of whose tile rows are live in the panel's tile column (a dense system: every trailing tile)
+                hipLaunchKernelGGL(k_bal_step, dim3(d.bigPanelStart[kb + 1] - d.bigPanelStart[kb]), dim3(256), 0, s, W, wp(par), kb, kb + 1 == nbk ? 1 : 0, d.bigPanelStart[kb]);
             }
             for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
                 hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, W, wp(par), J);
@@ -4269,32 +4273,42 @@ struct BAJob {
         //      (eliminating tile column k joins every pair of tile rows that are live in it: the block form of the symbolic factorisation a sparse LDL^T starts
         //      with, solvers/linear_solver_eigen.h:95-112; natural keyframe order -- consecutive keyframes are the covisible ones, which is what a fill-reducing
         //      ordering would recover).  Memory and the launches' grids follow this structure.
-        static thread_local std::vector<int> tileMap, panelStart, panelRows;
+        static thread_local std::vector<int> tileMap, panelStart;
+        static thread_local std::vector<int4> panelWork;
         int bigT = 0, bigTiles = 0;
         if (bigPath) {
-            std::vector<int> fidx((size_t)nC, -1), cc((size_t)nC, 0);
+            static thread_local std::vector<int> fidx, cc, off, lst, cur;
+            static thread_local std::vector<unsigned char> live, seen;
+            fidx.assign((size_t)nC, -1); cc.assign((size_t)nC, 0);
             for (int e = 0; e < E; e++) cc[edge_cam(e)]++;
             int nFa = 0;
             for (int i = 0; i < nC; i++) if (cc[i] && !p->cam_fixed[i]) fidx[i] = nFa++;
             const BigGeom g = big_geom(std::max(nFa, 1));
             bigT = g.RP / 64;
             const int T = bigT, tN = g.N >> 6;
-            std::vector<unsigned char> live((size_t)T * T, 0);
+            live.assign((size_t)T * T, 0);
             {
+                // which camera pairs share a landmark (one byte per ordered pair, one store per landmark and pair: this walk runs in every call) ...
                 const std::vector<int>& fc = c.scratch;      // free observers per landmark (counted above)
-                std::vector<int> off((size_t)nP + 1, 0), lst;
+                off.assign((size_t)nP + 1, 0);
                 for (int i = 0; i < nP; i++) off[i + 1] = off[i] + fc[i];
                 lst.resize(off[nP]);
-                std::vector<int> cur(off.begin(), off.end() - 1);
+                cur.assign(off.begin(), off.end() - 1);
                 for (int e = 0; e < E; e++) { const int f = fidx[edge_cam(e)]; if (f >= 0) lst[cur[edge_lm(e)]++] = f; }
+                seen.assign((size_t)nFa * nFa, 0);
                 for (int i = 0; i < nP; i++)
-                    for (int u = off[i]; u < off[i + 1]; u++)
-                        for (int v = u; v < off[i + 1]; v++) {
-                            const int lo = std::min(lst[u], lst[v]), hi = std::max(lst[u], lst[v]);
-                            const int r0 = (6 * hi) >> 6, r1 = (6 * hi + 5) >> 6, c0 = (6 * lo) >> 6, c1 = (6 * lo + 5) >> 6;
-                            live[(size_t)std::max(r0, c0) * T + std::min(r0, c0)] = 1; live[(size_t)std::max(r0, c1) * T + std::min(r0, c1)] = 1;
-                            live[(size_t)std::max(r1, c0) * T + std::min(r1, c0)] = 1; live[(size_t)std::max(r1, c1) * T + std::min(r1, c1)] = 1;
-                        }
+                    for (int u = off[i]; u < off[i + 1]; u++) {
+                        unsigned char* row = &seen[(size_t)lst[u] * nFa];
+                        for (int v = off[i]; v < off[i + 1]; v++) row[lst[v]] = 1;
+                    }
+                // ... and the tiles their 6 x 6 blocks touch
+                for (int hi = 0; hi < nFa; hi++)
+                    for (int lo = 0; lo <= hi; lo++) {
+                        if (!seen[(size_t)hi * nFa + lo]) continue;
+                        const int r0 = (6 * hi) >> 6, r1 = (6 * hi + 5) >> 6, c0 = (6 * lo) >> 6, c1 = (6 * lo + 5) >> 6;
+                        live[(size_t)std::max(r0, c0) * T + std::min(r0, c0)] = 1; live[(size_t)std::max(r0, c1) * T + std::min(r0, c1)] = 1;
+                        live[(size_t)std::max(r1, c0) * T + std::min(r1, c0)] = 1; live[(size_t)std::max(r1, c1) * T + std::min(r1, c1)] = 1;
+                    }
             }
             for (int t = 0; t < T; t++) live[(size_t)t * T + t] = 1;
             for (int t = 0; t <= tN; t++) live[(size_t)tN * T + t] = 1;      // the right-hand side row N (and the z it becomes) spans every column
@@ -4307,16 +4321,28 @@ struct BAJob {
             }
             tileMap.assign((size_t)T * T, -1);
             for (int i = 0; i < T; i++) for (int j = 0; j <= i; j++) if (live[(size_t)i * T + j]) tileMap[(size_t)i * T + j] = bigTiles++;
-            // per 32-column panel: the trailing tile rows that are live in the panel's tile column, the tile row of the next diagonal block first
+            // per 32-column panel: one record pair per tile its launch updates -- the trailing tiles (a, b) whose two tile rows are live in the panel's tile column;
+            // the tile of the next diagonal block first (its workgroup factors that block on the spot, also when the panel itself does not reach it)
             const int nbk = g.N / kBigNB;
-            panelStart.assign((size_t)nbk + 1, 0); panelRows.clear();
+            panelStart.assign((size_t)nbk + 1, 0); panelWork.clear();
             for (int kb = 0; kb < nbk; kb++) {
                 const int kc = (kb * kBigNB) >> 6, tj0 = (kb * kBigNB + kBigNB) >> 6;
-                panelStart[kb] = (int)panelRows.size();
-                if (tj0 < T) panelRows.push_back(tj0);
-                for (int i = tj0 + 1; i < T; i++) if (live[(size_t)i * T + kc]) panelRows.push_back(i);
+                panelStart[kb] = (int)(panelWork.size() / 2);
+                rws.clear();
+                rws.push_back(tj0);
+                for (int i = tj0 + 1; i < T; i++) if (live[(size_t)i * T + kc]) rws.push_back(i);
+                auto pslot = [&](int x) { return tileMap[(size_t)x * T + kc]; };
+                for (size_t a1 = 0; a1 < rws.size(); a1++)
+                    for (size_t b1 = 0; b1 <= a1; b1++) {
+                        const int ta = rws[a1], tb = rws[b1], sc = tileMap[(size_t)ta * T + tb];
+                        const bool first = a1 == 0;
+                        if (!first && (sc < 0 || pslot(ta) < 0 || pslot(tb) < 0)) continue;      // nothing to subtract from a tile one of whose panel tiles is zero
+                        panelWork.push_back(make_int4(ta, tb, sc, pslot(ta)));
+                        panelWork.push_back(make_int4(pslot(tb), 0, 0, 0));
+                    }
             }
-            panelStart[nbk] = (int)panelRows.size();
+            panelStart[nbk] = (int)(panelWork.size() / 2);
+            EAO_REQUIRE(panelWork.size() < ((size_t)1 << 28), "tile structure too large (%zu work records)", panelWork.size() / 2);
         }
         size_t need = 0;
         need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
@@ -4327,7 +4353,7 @@ struct BAJob {
         need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
             need += (2 * ((size_t)bigTiles << 12) + (size_t)bg.N * kBigNB) * 8;
-            need += (3 * lpEntries + 3 * lpPairsMax + 8) * 4 + (tileMap.size() + panelStart.size() + panelRows.size() + 8) * 4 + 2048;
+            need += (3 * lpEntries + 3 * lpPairsMax + 8) * 4 + (tileMap.size() + panelStart.size() + 8) * 4 + panelWork.size() * sizeof(int4) + 2048;
         } else {
             need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
             need += (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
@@ -4359,8 +4385,7 @@ struct BAJob {
         int* dlpE1 = a.take<int>(bigPath ? lpEntries : 1);
         int* dlpE2 = a.take<int>(bigPath ? lpEntries : 1);
         int* dbigTile = a.take<int>(bigPath ? tileMap.size() : 1);
-        int* dbigRowStart = a.take<int>(bigPath ? panelStart.size() : 1);
-        int* dbigRows = a.take<int>(bigPath ? std::max<size_t>(panelRows.size(), 1) : 1);
+        int4* dbigWork = a.take<int4>(bigPath ? std::max<size_t>(panelWork.size(), 1) : 1);
         double* dpl0 = a.take<double>((size_t)nPl * 4 + 1);
         double* dpmeas = a.take<double>((size_t)Epl * 4 + 1);
         dW = a.take<BADev>(2);
@@ -4393,7 +4418,7 @@ struct BAJob {
         D.slab = a.take<double>(bigPath ? 8 : (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
         D.big = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
         D.bigL = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
-        D.bigTile = dbigTile; D.bigT = bigT; D.bigTiles = bigTiles; D.bigRowStart = dbigRowStart; D.bigRows = dbigRows;
+        D.bigTile = dbigTile; D.bigT = bigT; D.bigTiles = bigTiles; D.bigWork = dbigWork; D.bigDense = bigPath && bigTiles == bigT * (bigT + 1) / 2 ? 1 : 0;
         D.bigDiag = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
         D.bigFail = a.take<int>(4);
         D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpPts = dlpPts; D.lpE1 = dlpE1; D.lpE2 = dlpE2;
@@ -4498,8 +4523,7 @@ struct BAJob {
                 int* lpE1 = (int*)hostp(dlpE1); int* lpE2 = (int*)hostp(dlpE2);
                 EAO_REQUIRE(big_geom(nF).RP / 64 == bigT, "internal: tile structure built for another system size");
                 std::memcpy(hostp(dbigTile), tileMap.data(), tileMap.size() * sizeof(int));
-                std::memcpy(hostp(dbigRowStart), panelStart.data(), panelStart.size() * sizeof(int));
-                if (!panelRows.empty()) std::memcpy(hostp(dbigRows), panelRows.data(), panelRows.size() * sizeof(int));
+                if (!panelWork.empty()) std::memcpy(hostp(dbigWork), panelWork.data(), panelWork.size() * sizeof(int4));
                 static thread_local std::vector<int> pcnt, obs, obsE;
                 pcnt.assign((size_t)nF * (nF + 1) / 2, 0);
                 auto each_pair = [&](auto&& fn) {      // fn(pair slot index, landmark, its edge in the pair's first camera, in its second)
@@ -4555,8 +4579,7 @@ struct BAJob {
         d.schurLds = bigPath ? 0 : schur_lds_bytes(nF);
         d.gB = big_geom(std::max(nF, 1));
         d.nPairsNZ = D.nPairsNZ; d.big = D.big; d.bigTiles = bigTiles;
-        d.bigRowCnt.clear(); d.bigRowOff.clear();
-        if (bigPath) for (size_t kb = 0; kb + 1 < panelStart.size(); kb++) { d.bigRowCnt.push_back(panelStart[kb + 1] - panelStart[kb]); d.bigRowOff.push_back(panelStart[kb]); }
+        d.bigPanelStart = bigPath ? panelStart.data() : nullptr;
         // the window record itself travels with the structure
         write_records((BADev*)hostp(dW));
         if (!deferUpload) EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));

@@ -442,3 +442,38 @@ def test_map_scale_ba_with_an_abort_flag_that_is_never_raised(gpu):
     la = gpu.Optimizer.LocalBundleAdjustment(p)
     lb = gpu.Optimizer.LocalBundleAdjustment(p, stop=np.zeros(1, np.uint8))
     assert list(la["iters"]) == list(lb["iters"]) and np.array_equal(la["poses"], lb["poses"]) and np.array_equal(la["edge_outlier"], lb["edge_outlier"])
+
+
+def _two_maps(kw1, kw2):
+    """Two maps that share nothing, as ONE problem (cameras and points of the second renumbered behind the first): the reduced camera system falls into two
+    diagonal blocks -- whole tile rows of the map-scale path's structure are dead in the tile columns of the other map."""
+    a, b = synth.synth_ba(**kw1), synth.synth_ba(**kw2)
+    nc, npt = len(a["poses"]), len(a["points"])
+    out = dict(a)
+    for k in ("poses", "fixed", "points", "poses_gt", "points_gt"):
+        out[k] = np.concatenate([a[k], b[k]])
+    out["edge_cam"] = np.concatenate([a["edge_cam"], b["edge_cam"] + nc]).astype(np.int32)
+    out["edge_point"] = np.concatenate([a["edge_point"], b["edge_point"] + npt]).astype(np.int32)
+    out["obs"] = np.concatenate([a["obs"], b["obs"]]); out["inv_sigma2"] = np.concatenate([a["inv_sigma2"], b["inv_sigma2"]])
+    return out
+
+
+@pytest.mark.parametrize("name", ["band 7 of 60", "band 3 of 110", "band 11 of 150, robust", "two maps", "two maps, the second inside a tile"])
+def test_bundle_adjustment_on_sparse_maps(gpu, oracle, name):
+    """Round 5: the map-scale path stores and factors the reduced camera system as 64 x 64 TILES of its non-zero structure (covisibility + the fill-in of the
+    elimination, worked out on the host) -- a band for a trajectory whose keyframes see their neighbours only, two blocks for two maps that share nothing.  Same LM
+    schedule and updates as the oracle (which factors the dense matrix) on all of them."""
+    robust = "robust" in name
+    if name.startswith("band"):
+        band, n = int(name.split()[1]), int(name.split()[3].rstrip(","))
+        p = synth.synth_ba(n_free=n, n_fixed=1, n_points=40 * n, seed=5500 + n, band=band)
+    elif name == "two maps":
+        p = _two_maps(dict(n_free=40, n_fixed=1, n_points=1500, seed=5601, band=5), dict(n_free=50, n_fixed=2, n_points=1800, seed=5602, band=6))
+    else:      # the second map starts in the middle of a tile row (36 free cameras = 216 rows = 3.4 tiles): its first tile row is shared with the first map's last cameras
+        p = _two_maps(dict(n_free=36, n_fixed=1, n_points=1400, seed=5603, band=4), dict(n_free=33, n_fixed=1, n_points=1300, seed=5604))
+    r = gpu.Optimizer.BundleAdjustment(p, 8, bRobust=robust)
+    o = oracle.bundle_adjustment(p, 8, robust)
+    assert list(r["iters"]) == [int(o["iters"][0]), 0] and r["iters"][0] >= 3
+    _check_trace(r, o, rel=CHI2_REL_PLANES)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
