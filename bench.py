@@ -55,8 +55,8 @@ def _fresh(pmc, rel):
 
 
 def _profile(name):
-    """The newest committed profile file of that name (profiles/r04_<name>, else r03_ / r02_<name>): recorded figures the line quotes."""
-    for tag in ("r04", "r03", "r02"):
+    """The newest committed profile file of that name (profiles/r05_<name>, else r04_ / r03_ / r02_<name>): recorded figures the line quotes."""
+    for tag in ("r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
         if os.path.exists(f):
             return f

@@ -12,17 +12,14 @@
 //  LocalBundleAdjustment : multi-workgroup kernels per LM trial, all reductions in a fixed order
 //      k_ba_linearize   role A (eight lanes per map point, one edge per lane): residual Jacobians, Hll/bl, per-edge 6x3
 //                       Hpl blocks; role B (one workgroup per free camera): Hpp/bp by a fixed-order tree over its edges
-//      k_ba_schur       one workgroup per (free camera, edge chunk): stages Y = Hpl (Hll+lambda I)^-1 in LDS, then thread
-//                       (i2,r,c) accumulates its element of -sum_l Y_{i1,l} Hpl_{i2,l}^T through a dense point x camera
-//                       edge table (no atomics, fixed order)
-//      k_ba_reduce_*    sums the partial Schur slabs (many workgroups: one CU alone pulls too little from L2)
-//      k_ba_schur_pairs_mfma (round 4, the default of the tile-solver windows; k_ba_schur / k_ba_schur_pairs* are the older forms): the
+//      k_ba_schur_pairs_mfma (round 4, the default of the tile-solver windows; k_ba_schur_pairs / _b, the VALU forms over unscaled blocks, serve windows with
+//                       plane landmarks; the slab assembly k_ba_schur + k_ba_reduce_* of round 1 was removed in round 5): the
 //                       linearisation leaves Cholesky-scaled blocks W = Hpl C^-T (C C^T = Hll + lambda I), ONE workgroup per camera pair adds
 //                       W(l, i1) W(l, i2)^T over the landmarks both observe on v_mfma_f64_4x4x4 (16-byte fetches staged through wave-private LDS)
 //      k_ba_solve_tiles the 6*nFree square system as register-resident 16x16 tiles: LDL^T in 4-column panels, trailing
 //                       update by v_mfma_f64_16x16x4_f64 (the ONE GEMM-shaped piece of the path), forward substitution
 //                       folded in as an extra matrix row, single-wave back substitution, pose update exp(dx)*T.
-//                       k_ba_solve (LDS / global scratch, 6-row panels, VALU) covers windows of more than 30 free keyframes
+//                       (windows of more than 30 free keyframes take the map-scale path k_bal_*; the single-workgroup LDS solver k_ba_solve is gone)
 //      k_ba_backsub     per point: x_l = Dinv (bl - Hpl^T x_p), new point, residuals + robust chi2 at the trial state
 //      k_ba_decide      fixed-order sums, rho, lambda / nu update; status lands in pinned host memory
 //  The Jacobian blocks are 6x6 / 6x3 / 3x3: fp64 VALU + LDS, latency/bandwidth bound (the pair products are the exception: four 4x4x4 blocks).  LM state
@@ -1419,9 +1416,7 @@ struct BADev {
     GP<double> Tl;             // nL*6: T = C^-T (upper triangle 00 01 02 11 12 22) per landmark block   (wmode 1)
     GP<double> ul;             // nL*3: u = C^-1 bl                                                     (wmode 1)
     GP<int4> pairItems;        // per camera pair (i1 <= i2), nL slots: {144 * edge (l, i1), 144 * edge (l, i2), 24 * l, l} of the landmarks both observe, ascending (k_ba_pairs)
-    GP<double> slab;           // chunks * nFree * (nFree*36 + 6): partial Schur rows
     GP<double> sys;            // n*(n+1): assembled Schur system (upper triangle + rhs column)
-    GP<double> solveScratch;   // n*(n+1)+... doubles when the Schur system does not fit in LDS, else null
     GP<int> doneCnt;           // workgroups of the running k_ba_backsub that have published their partial sums (zero between launches)
     GP<double> wgPart;         // their partial sums: 2 per workgroup
     GP<long long> dbg;         // optional phase stamps of k_ba_solve (diagnostic builds of the harness only)
@@ -1430,7 +1425,6 @@ struct BADev {
     GP<double> partChi;        // nL (robust chi2 of the point's edges at the last evaluated state)
     GP<double> partScale;      // nL
     GP<double> lm;             // [0] lambda [1] ni [2] currentChi [3] maxdiag
-    int chunks;
     // MapPlane vertices / EdgePlane edges of Optimizer::BundleAdjustment (src/Optimizer.cc:203-252): landmarks nPtsOnly.. are
     // planes (4 coefficients each, two state buffers like the points), edges nEdgesPt.. are plane edges (eflag bit3)
     int nPtsOnly, nEdgesPt;
@@ -1841,6 +1835,9 @@ __global__ __launch_bounds__(NT) void k_ba_linearize(const BADev* __restrict__ W
                 for (int r = 0; r < 3; r++) { wi[r] = w * info; omr[r] = w * (-(info * er[r])); }
             };
             double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};   // upper triangle 00 01 02 11 12 22
+            // (round 5, VERDICT r4 next #6b, measured and not kept: forming the unscaled block B^T (w Omega) A of the lane's first edge in THIS pass and keeping it
+            //  in registers until the landmark's Cholesky factor exists, instead of evaluating the edge's Jacobians a second time below -- 180 VGPRs, 1.030 ms against
+            //  1.030 ms per window; 70 spilled registers in the 1024-thread form of a batch, 3.34 ms against 2.62: profiles/r05_ba_pair_ablation.txt)
             each_edge([&](int e, int cam, int) {
                 if (P.eflag[e] & 2) return;
                 double A[3][3], B[3][6], wi[3], omr[3];
@@ -2070,328 +2067,6 @@ __device__ inline void dinv3(const double* Hll, double lambda, double Di[9]) {
     Di[0] = c00 * id; Di[1] = (A[2] * A[7] - A[1] * A[8]) * id; Di[2] = (A[1] * A[5] - A[2] * A[4]) * id;
     Di[3] = c01 * id; Di[4] = (A[0] * A[8] - A[2] * A[6]) * id; Di[5] = (A[2] * A[3] - A[0] * A[5]) * id;
     Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-}
-
-// grid (nFree, chunks), one workgroup per (free camera i1, chunk of its edge list).  Everything the accumulation needs is
-// staged in LDS first, with every global load of a batch in flight at once (the first version gathered the other
-// cameras' Hpl rows inside the accumulation loop: a chain of dependent L2 round trips, 30 us):
-//   stage    thread per (edge k, camera i2) slot: the point's entry of the (point x camera) edge table, then the 6x3
-//            block Hpl(i2, point) as nine 16-byte loads in flight, and bit k of the hit mask of i2;
-//            the LAST cnt threads, one per edge: Dinv of its point, Y = Hpl Dinv (18 doubles), Dinv bl (3)
-//   sums     thread per output, walking the set bits of its camera's hit mask:
-//            S(i1, i2)[r][c] -= sum_k Y_k[r][:] . Hpl(i2, k)[c][:]   and   coeff(i1) += Hpl(i1,k) (Dinv bl)_k
-// Every output is accumulated by ONE thread over the chunk's edges in list order: no atomics on data, reproducible.
-constexpr int kChunks = 12;            // partial Schur rows per free camera (fixed: the reduction loop is unrolled);
-                                       // 20 keyframes x 12 chunks = 240 workgroups: one round on 256 CUs
-constexpr int kSchurSlots = 640;       // (edge, camera) blocks staged per batch: 90 KB
-constexpr int kSchurMaxFree = 64;      // free keyframes per window
-constexpr int kSchurThreads = 1024;
-constexpr int kSchurMaxOut = (kSchurMaxFree * 36 + 6 + kSchurThreads - 1) / kSchurThreads;
-__host__ __device__ inline int schur_batch_edges(int nF) { return min(32, kSchurSlots / max(nF, 1)); }   // 32: one hit-mask word
-__global__ __launch_bounds__(kSchurThreads) void k_ba_schur(const BADev* __restrict__ W, int wpar, int first) {
-    BA_WIN(P);
-    extern __shared__ __attribute__((aligned(16))) double schurLds[];
-    if (P.ctl[kCtlHalt]) return;
-    const int i1 = bx, chunk = blockIdx.y, t = threadIdx.x;
-    const int nF = P.nFree, rowLen = nF * 36 + 6;
-    const int EB = schur_batch_edges(nF);
-    double* sB = schurLds;                                   // [EB * nF][18]
-    double* sY = sB + (size_t)kSchurSlots * 18;              // [EB][18]
-    double* sDb = sY + (size_t)EB * 18;                      // [EB][3]
-    unsigned* sMask = (unsigned*)(sDb + (size_t)EB * 3);     // [2][nF] hit masks over the batch's edges, by batch parity
-    const int beg = P.camStart[i1], end = P.camStart[i1 + 1];
-    const int per = (end - beg + P.chunks - 1) / P.chunks;
-    const int b0 = min(beg + chunk * per, end), total = min(per, end - b0);
-    // first trial of an optimize() call: lambda_0 from the maximum the linearisation just accumulated; workgroup (0,0)
-    // publishes it for the kernels that follow in the stream
-    const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
-    if (first && i1 == 0 && chunk == 0 && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
-    double acc[kSchurMaxOut];
-#pragma unroll
-    for (int o = 0; o < kSchurMaxOut; o++) acc[o] = 0;
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    if (t < 2 * nF) sMask[t] = 0;
-    __syncthreads();
-    const int sk = t / nF, si2 = t - sk * nF;                 // this thread's slot
-    int par = 0;
-    for (int base = 0; base < total; base += EB, par ^= 1) {
-        const int cnt = min(EB, total - base);
-        if (sk < cnt) {
-            const int e2 = P.table[(size_t)P.camEdgeL[b0 + base + sk] * nF + si2];
-            if (e2 >= 0) {
-                const v2d* src = (const v2d*)(P.Hpl + (size_t)e2 * 18);
-                v2d v[9];
-#pragma unroll
-                for (int i = 0; i < 9; i++) v[i] = src[i];
-                v2d* dst = (v2d*)(sB + (size_t)t * 18);
-#pragma unroll
-                for (int i = 0; i < 9; i++) dst[i] = v[i];
-                atomicOr(&sMask[par * nF + si2], 1u << sk);
-            }
-        }
-        const int yk = t - (kSchurThreads - cnt);
-        if (yk >= 0) {
-            const int e = P.camEdges[b0 + base + yk];
-            const int l = P.camEdgeL[b0 + base + yk];
-            const bool on = !(P.eflag[e] & 2);     // a deactivated edge stays in the list with a zero contribution
-            double Di[9];
-            dinv3(&P.Hll[(size_t)l * 9], lambda, Di);
-            const double* bl = &P.bl[(size_t)l * 3];
-            const double* Bi = &P.Hpl[(size_t)e * 18];
-#pragma unroll
-            for (int i = 0; i < 3; i++) sDb[yk * 3 + i] = on ? Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2] : 0.0;
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) sY[yk * 18 + r * 3 + c] = on ? Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c] : 0.0;
-        }
-        __syncthreads();
-        if (t < nF) sMask[(par ^ 1) * nF + t] = 0;            // the other parity's masks were last read before this barrier
-#pragma unroll
-        for (int o = 0; o < kSchurMaxOut; o++) {
-            const int q = t + o * kSchurThreads;
-            if (q >= rowLen) break;
-            double a = acc[o];
-            if (q < nF * 36) {
-                const int i2 = q / 36, r = (q % 36) / 6, c = q % 6;
-                if (i2 >= i1) {
-                    unsigned m = sMask[par * nF + i2];
-                    while (m) {
-                        const int k = __builtin_ctz(m);
-                        m &= m - 1;
-                        const double* Yv = &sY[k * 18 + r * 3];
-                        const double* Bj = &sB[(size_t)(k * nF + i2) * 18 + c * 3];
-                        a -= Yv[0] * Bj[0] + Yv[1] * Bj[1] + Yv[2] * Bj[2];
-                    }
-                }
-            } else {
-                const int r = q - nF * 36;
-                unsigned m = sMask[par * nF + i1];          // the camera's own edges: every list entry that is still active
-                while (m) {
-                    const int k = __builtin_ctz(m);
-                    m &= m - 1;
-                    const double* Bi = &sB[(size_t)(k * nF + i1) * 18 + r * 3];
-                    a += Bi[0] * sDb[k * 3] + Bi[1] * sDb[k * 3 + 1] + Bi[2] * sDb[k * 3 + 2];
-                }
-            }
-            acc[o] = a;
-        }
-        __syncthreads();
-    }
-    // partial slab of this chunk: dense n x n row-major (upper blocks) followed by the n coefficients
-    const int n = nF * 6;
-    double* slab = P.slab + (size_t)chunk * ((size_t)n * n + n);
-#pragma unroll
-    for (int o = 0; o < kSchurMaxOut; o++) {
-        const int q = t + o * kSchurThreads;
-        if (q < nF * 36) {
-            const int i2 = q / 36, r = (q % 36) / 6, c = q % 6;
-            if (i2 >= i1) slab[(size_t)(i1 * 6 + r) * n + i2 * 6 + c] = acc[o];
-        } else if (q < rowLen) {
-            slab[(size_t)n * n + i1 * 6 + (q - nF * 36)] = acc[o];
-        }
-    }
-}
-__host__ inline size_t schur_lds_bytes(int nF) {
-    const int EB = schur_batch_edges(nF);
-    return ((size_t)kSchurSlots * 18 + (size_t)EB * 21) * sizeof(double) + ((size_t)2 * nF) * sizeof(int) + 16;
-}
-
-// Sum the kChunks partial slabs in chunk order, add Hpp + lambda I and the right-hand side: one dense n x (n+1) system
-// (upper triangle) in global memory.  Many workgroups: a single CU can only pull ~10 B/clk from L2, so letting the
-// solver's lone workgroup read all slabs itself cost 16 us.
-__global__ __launch_bounds__(256) void k_ba_reduce_slabs(const BADev* __restrict__ W, int wpar) {
-    BA_WIN(P);
-    if (P.ctl[kCtlHalt]) return;
-    const int nF = P.nFree, n = nF * 6, ld = n + 1;
-    const size_t slabStride = (size_t)n * n + n;
-    const double lambda = P.lm[0];
-    const int idx = bx * 256 + threadIdx.x;
-    if (idx >= n * ld) return;
-    const int row = idx / ld, col = idx - row * ld;
-    double v = 0;
-    if (col == n) {
-        double co = 0;
-#pragma unroll
-        for (int ch = 0; ch < kChunks; ch++) co += P.slab[ch * slabStride + (size_t)n * n + row];
-        v = P.bp[row] - co;
-    } else {
-        const int i1 = row / 6, r = row - i1 * 6, i2 = col / 6, c = col - i2 * 6;
-        if (i2 >= i1) {
-            double part[kChunks];
-#pragma unroll
-            for (int ch = 0; ch < kChunks; ch++) part[ch] = P.slab[ch * slabStride + (size_t)row * n + col];
-            if (i1 == i2) v = P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
-#pragma unroll
-            for (int ch = 0; ch < kChunks; ch++) v += part[ch];
-        }
-    }
-    P.sys[idx] = v;
-}
-
-// One 512-thread workgroup: assemble Hschur = Hpp + lambda I + sum of slabs (upper triangle) in LDS, blocked
-// right-looking LDLT (6-row panels; the right-hand side rides along as an extra column; no pivoting, a zero pivot fails
-// like SimplicialLDLT), blocked back substitution, then exp(dx) * T for the free cameras.  n = 6*nFree <= 192.
-// The trailing update subtracts the six panel terms one after the other, i.e. exactly the scalar algorithm's operation order.
-constexpr int kSolveThreads = 512;   // 8 waves: 256 VGPRs per lane keep the panel's 6x6 working set out of scratch
-// IN_LDS = true: the system lives in LDS (up to 22 free keyframes); false: in L2-resident global scratch.  Two
-// instantiations so that each uses its own address space (a runtime-selected pointer would degrade to flat loads).
-template <bool IN_LDS>
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve(const BADev* __restrict__ W, int wpar) {
-    BA_WIN(P);
-    int* const solveOk = P.solveOk;
-    extern __shared__ double sm[];
-    const int nF = P.nFree, n = nF * 6, t = threadIdx.x;
-    const int ld = ((n + 32) & ~31) + 1;        // row stride: >= n + 1 (column n = right-hand side) and == 1 (mod 32) doubles, so a
-                                                // column walk (one row per lane) touches every LDS bank exactly once
-    double* S;                                  // n * ld
-    double* M;                                  // 6 * ld   multipliers of the current panel
-    if (IN_LDS) { S = sm; M = sm + (size_t)n * ld; }
-    else { S = P.solveScratch; M = sm; }
-    double* xv = M + (size_t)6 * ld;            // n   (LDS in both variants)
-    double* rd = xv + n;                        // n reciprocal pivots
-    __shared__ int s_fail;
-    if (P.ctl[kCtlHalt]) return;
-    if (t == 0) s_fail = 0;
-    if (P.dbg && t == 0) { P.dbg[0] = clock64(); P.dbg[1] = wall_clock64(); }
-    // the assembled system (k_ba_reduce_slabs): n x (n+1) row-major, upper triangle + right-hand side column
-    for (int idx = t; idx < n * (n + 1); idx += kSolveThreads) {
-        const int row = idx / (n + 1), col = idx - row * (n + 1);
-        S[(size_t)row * ld + col] = P.sys[idx];
-    }
-    for (int row = t; row < n; row += kSolveThreads) xv[row] = 0;
-    __syncthreads();
-    if (P.dbg && t == 0) { P.dbg[2] = clock64(); P.dbg[3] = wall_clock64(); }
-    long long accPanel = 0, accTrail = 0, tStamp = 0;
-    for (int jb = 0; jb < nF; jb++) {
-        const int j = jb * 6;
-        if (P.dbg && t == 0) tStamp = clock64();
-        // ---- panel: the thread owning column k (j <= k <= n) factorises the 6x6 diagonal block redundantly in registers
-        //      and retires its own column of the six panel rows; the other waves only take part in the barriers
-        const int k = j + t;
-        const bool active = k <= n;
-        double col[6], invd[6], l[6][6], a[6][6];
-        if (active) {
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c < 6; c++) a[r][c] = (c >= r) ? S[(size_t)(j + r) * ld + j + c] : 0.0;
-            bool bad = false;
-#pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const double dr = a[r][r];
-                if (dr == 0.0 || !isfinite(dr)) bad = true;
-                invd[r] = frcp(dr);
-#pragma unroll
-                for (int i = r + 1; i < 6; i++) {
-                    l[i][r] = a[r][i] * invd[r];
-#pragma unroll
-                    for (int c = i; c < 6; c++) a[i][c] -= l[i][r] * a[r][c];
-                }
-            }
-            if (bad) s_fail = 1;
-#pragma unroll
-            for (int r = 0; r < 6; r++) col[r] = S[(size_t)(j + r) * ld + k];
-        }
-        __syncthreads();           // every column has read the untouched diagonal block before anyone rewrites it
-        if (active) {
-            if (k >= j + 6) {
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int i = r + 1; i < 6; i++) col[i] -= l[i][r] * col[r];
-#pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    S[(size_t)(j + r) * ld + k] = col[r];
-                    if (k < n) M[(size_t)r * ld + k] = col[r] * invd[r];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-                    if (c == k - j) {
-#pragma unroll
-                        for (int r = 0; r <= c; r++) S[(size_t)(j + r) * ld + k] = a[r][c];
-                        rd[k] = invd[c];     // reciprocal pivot, reused by the back substitution
-                    }
-            }
-        }
-        __syncthreads();
-        if (P.dbg && t == 0) { const long long now = clock64(); accPanel += now - tStamp; tStamp = now; }
-        if (s_fail) break;
-        // ---- trailing update of rows i >= j+6: S(i,k) -= sum_r M(r,i) * S(j+r,k), r = 0..5 in order, k >= i (k == n: rhs).
-        //      Measured alternatives on MI355X (cycles of this phase summed over the 20 steps of a 120x120 system):
-        //        element per thread, 32-wide column strips (this code)            64 k
-        //        row per lane, panel values as LDS broadcast reads, 4 columns in flight   99 k
-        //        v_mfma_f64_16x16x4_f64 on 16x16 tiles, two tiles in flight per wave      81 k  (one tile: 95 k)
-        //      One workgroup alone on a CU cannot hide the ~64-cycle f64 MFMA / LDS latencies; the plain version wins.
-        {
-            const int tx = t & 31, ty = t >> 5;
-            for (int i = j + 6 + ty; i < n; i += kSolveThreads / 32) {
-                const double m0 = M[i], m1 = M[ld + i], m2 = M[2 * ld + i], m3 = M[3 * ld + i], m4 = M[4 * ld + i], m5 = M[5 * ld + i];
-                const int base = j + 6 + tx;
-                const int kfirst = i > base ? base + (((i - base + 31) >> 5) << 5) : base;
-                for (int kk = kfirst; kk <= n; kk += 32) {
-                    double v = S[(size_t)i * ld + kk];
-                    v = fma(-m0, S[(size_t)j * ld + kk], v);
-                    v = fma(-m1, S[(size_t)(j + 1) * ld + kk], v);
-                    v = fma(-m2, S[(size_t)(j + 2) * ld + kk], v);
-                    v = fma(-m3, S[(size_t)(j + 3) * ld + kk], v);
-                    v = fma(-m4, S[(size_t)(j + 4) * ld + kk], v);
-                    v = fma(-m5, S[(size_t)(j + 5) * ld + kk], v);
-                    S[(size_t)i * ld + kk] = v;
-                }
-            }
-        }
-        __syncthreads();
-        if (P.dbg && t == 0) accTrail += clock64() - tStamp;
-    }
-    if (P.dbg && t == 0) { P.dbg[4] = clock64(); P.dbg[5] = wall_clock64(); P.dbg[10] = accPanel; P.dbg[11] = accTrail; }
-    if (!s_fail) {
-        // ---- back substitution by 6-row blocks: x_i = (y_i - sum_{k>i} U(i,k) x_k) / d_i; only the threads that own a
-        //      row above the block (and wave 0, which publishes x) solve the 6x6 triangle
-        for (int jb = nF - 1; jb >= 0; jb--) {
-            const int j = jb * 6;
-            const bool need = t < j || t < 6;
-            double x[6];
-            if (need) {
-#pragma unroll
-                for (int r = 5; r >= 0; r--) {
-                    double v = S[(size_t)(j + r) * ld + n];
-#pragma unroll
-                    for (int c = r + 1; c < 6; c++) v -= S[(size_t)(j + r) * ld + j + c] * x[c];
-                    x[r] = v * rd[j + r];
-                }
-#pragma unroll
-                for (int r = 0; r < 6; r++) if (t == r) xv[j + r] = x[r];
-            }
-            __syncthreads();                    // all reads of the rhs column done before rows above are updated
-            if (t < j) {
-                double v = S[(size_t)t * ld + n];
-#pragma unroll
-                for (int c = 0; c < 6; c++) v -= S[(size_t)t * ld + j + c] * x[c];
-                S[(size_t)t * ld + n] = v;
-            }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    if (P.dbg && t == 0) { P.dbg[6] = clock64(); P.dbg[7] = wall_clock64(); }
-    for (int i = t; i < n; i += kSolveThreads) P.xp[i] = xv[i];
-    // trial cameras: exp(dx) * T for the free ones, copy for the others
-    const SE3* cams = cur_cams(P);
-    SE3* camsT = trial_cams(P);
-    for (int c = t; c < P.nCams; c += kSolveThreads) {
-        const int ci = P.camIdx[c];
-        if (ci >= 0) {
-            double u[6];
-            for (int q = 0; q < 6; q++) u[q] = xv[ci * 6 + q];
-            camsT[c] = se3_mul(se3_exp(u), cams[c]);
-        } else {
-            camsT[c] = cams[c];
-        }
-    }
-    if (t == 0) *solveOk = s_fail ? 0 : 1;
-    if (P.dbg && t == 0) { P.dbg[8] = clock64(); P.dbg[9] = wall_clock64(); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2814,41 +2489,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? EAO_PAIR_OCC : 1) void k_ba_schu
     }
 }
 
-// Sum the partial slabs straight into the solver's register layout: [tile][reg][lane].
-__global__ __launch_bounds__(256) void k_ba_reduce_tiles(const BADev* __restrict__ W, int wpar) {
-    BA_WIN(P);
-    if (P.ctl[kCtlHalt]) return;
-    const TileGeom g = tile_geom(P.nFree);
-    const int o = bx * 256 + threadIdx.x;
-    if (o >= g.nTiles * 256) return;
-    const int idx = o >> 8, reg = (o >> 6) & 3, lane = o & 63;
-    int ti, tj;
-    tile_of(g, idx, ti, tj);
-    const int row = ti * 16 + (lane >> 4) + 4 * reg, col = tj * 16 + (lane & 15);
-    const int n = g.n;
-    const size_t slabStride = (size_t)n * n + n;
-    double v = 0;
-    if (row < n) {
-        if (col <= row) {
-            double part[kChunks];
-#pragma unroll
-            for (int ch = 0; ch < kChunks; ch++) part[ch] = P.slab[ch * slabStride + (size_t)col * n + row];   // stored upper (col,row)
-            const int bi = row / 6;
-            if (bi == col / 6) v = P.Hpp[(size_t)bi * 36 + (col - bi * 6) * 6 + (row - bi * 6)] + (row == col ? P.lm[0] : 0.0);
-#pragma unroll
-            for (int ch = 0; ch < kChunks; ch++) v += part[ch];
-        }
-    } else if (row < g.n4) {
-        v = (col == row) ? 1.0 : 0.0;                       // identity padding up to a multiple of four
-    } else if (row == g.n4 && col < n) {
-        double co = 0;
-#pragma unroll
-        for (int ch = 0; ch < kChunks; ch++) co += P.slab[ch * slabStride + (size_t)n * n + col];
-        v = P.bp[col] - co;
-    }
-    P.sys[o] = v;
-}
-
 template <int TPW>
 __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(const BADev* __restrict__ W, int wpar) {
     BA_WIN(P);
@@ -3036,7 +2676,7 @@ __global__ __launch_bounds__(kTileThreads) void k_ba_solve_tiles(const BADev* __
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Map-scale path (more than kSchurMaxFree free keyframes: Optimizer::BundleAdjustment / GlobalBundleAdjustemnt over a whole
+// Map-scale path (more than kTileMaxFree free keyframes: Optimizer::BundleAdjustment / GlobalBundleAdjustemnt over a whole
 // map, src/Optimizer.cc:47-323, and oversized local windows).  The reduced camera system no longer fits one workgroup, so
 // it lives in HBM as a dense lower triangle and is factorised by the whole chip:
 //   layout   S: RP x RP doubles, row-major, only col <= row is meaningful.  Rows / columns 0..n-1 = the 6 nFree pose
@@ -4026,15 +3666,14 @@ namespace {
 // Launch geometry of one window -- or, field by field, the largest of a batch (every kernel guards its own window's sizes).
 struct BADims {
     int nF = 0, nL = 0, nP = 0, nC = 0, E = 0, nPl = 0;
-    bool hasPl = false, bigPath = false, usePairs = false, solveTiles = false, tiles3 = true, solveInLds = true, wmode = false;
-    size_t tileLds = 0, solveLds = 0, schurLds = 0;
+    bool hasPl = false, bigPath = false, usePairs = false, solveTiles = false, tiles3 = true, wmode = false;
+    size_t tileLds = 0;
     int nPairsNZ = 0;          // map-scale path (never batched)
     double* big = nullptr;     // "
     int bigTiles = 0;          // "
     const int* bigPanelStart = nullptr;      // " : where every 32-column panel's work records start (nbk + 1 entries, thread-local storage that outlives the call's launches;
                                              //     a POINTER: this struct is copied around, a vector member would be re-allocated with every copy)
     BigGeom gB{};
-    int chunks = kChunks;
     void merge(const BADims& o) {
         nF = std::max(nF, o.nF); nL = std::max(nL, o.nL); nP = std::max(nP, o.nP); nC = std::max(nC, o.nC); E = std::max(E, o.E);
         tiles3 = tiles3 && o.tiles3; tileLds = std::max(tileLds, o.tileLds);
@@ -4060,14 +3699,12 @@ struct BALaunch {
             }
             return EAO_OK;
         };
-        static std::atomic<int> aT3{0}, aT5{0}, aSolve{0}, aSchur{0}, aBack{0};
+        static std::atomic<int> aT3{0}, aT5{0}, aBack{0};
         eao_status st;
         if (d.solveTiles) {
             if (d.tiles3) { if ((st = raise((const void*)k_ba_solve_tiles<3>, aT3, d.tileLds))) return st; }
             else if ((st = raise((const void*)k_ba_solve_tiles<5>, aT5, d.tileLds))) return st;
         }
-        if (d.solveInLds && !d.solveTiles && !d.bigPath) { if ((st = raise((const void*)k_ba_solve<true>, aSolve, d.solveLds))) return st; }
-        if (d.nF && !d.bigPath) { if ((st = raise((const void*)k_ba_schur, aSchur, d.schurLds))) return st; }
         if (d.bigPath) { if ((st = raise((const void*)k_bal_backsolve, aBack, (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double)))) return st; }
         return EAO_OK;
     }
@@ -4099,7 +3736,6 @@ struct BALaunch {
     // one LM trial behind a linearisation: Schur assembly, solve, back substitution + residuals, (decision)
     void trial(int par, int bulk, bool firstTrial, bool withDecide) {
         const int nF = d.nF, nL = d.nL;
-        const TileGeom tg = tile_geom(std::max(nF, 1));
         if (nF && d.bigPath) {
             const BigGeom gB = d.gB;
             (void)hipMemsetAsync(d.big, 0, ((size_t)d.bigTiles << 12) * sizeof(double), s);
@@ -4118,16 +3754,13 @@ struct BALaunch {
         } else if (nF && d.usePairs && d.solveTiles) {
             if (nz > 1) hipLaunchKernelGGL(k_ba_schur_pairs_b<kPairThreadsB>, dim3(nF * (nF + 1) / 2, 1, gz()), dim3(kPairThreadsB), 0, s, W, wp(par), firstTrial ? 1 : 0);
             else hipLaunchKernelGGL(k_ba_schur_pairs, dim3(nF * (nF + 1) / 2, 1, 1), dim3(kPairThreads), 0, s, W, wp(par), firstTrial ? 1 : 0);
-        } else if (nF) {
-            hipLaunchKernelGGL(k_ba_schur, dim3(nF, d.chunks), dim3(kSchurThreads), d.schurLds, s, W, wp(par), firstTrial ? 1 : 0);
-            if (d.solveTiles) hipLaunchKernelGGL(k_ba_reduce_tiles, dim3(tg.nTiles), dim3(256), 0, s, W, wp(par));
-            else hipLaunchKernelGGL(k_ba_reduce_slabs, dim3(eao::cdiv(nF * 6 * (nF * 6 + 1), 256)), dim3(256), 0, s, W, wp(par));
         }
+        // (round 5: the slab assembly k_ba_schur + k_ba_reduce_* and the single-workgroup LDS / global-scratch solver k_ba_solve of rounds 1-2 are gone -- dominated
+        //  at every size by the pair assembly + register-tile solver up to 30 free keyframes and by the map-scale path beyond: 5.8 / 29 ms against 2.8 / 5.2 ms at
+        //  31 / 64 free keyframes; commit 2249a31 holds the code)
         if (d.bigPath) {}
         else if (d.solveTiles && d.tiles3) hipLaunchKernelGGL(k_ba_solve_tiles<3>, dim3(1, 1, gz()), dim3(kTileThreads), d.tileLds, s, W, wp(par));
         else if (d.solveTiles) hipLaunchKernelGGL(k_ba_solve_tiles<5>, dim3(1, 1, gz()), dim3(kTileThreads), d.tileLds, s, W, wp(par));
-        else if (d.solveInLds) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(kSolveThreads), d.solveLds, s, W, wp(par));
-        else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(kSolveThreads), d.solveLds, s, W, wp(par));
         const int decideHere = bulk && !withDecide ? 1 : 0, sqHere = decideHere ? ++seq : 0;      // (see k_ba_backsub)
         if (nL && d.hasPl) hipLaunchKernelGGL(k_ba_backsub<true>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par), decideHere, sqHere);
         else if (nL) hipLaunchKernelGGL(k_ba_backsub<false>, dim3(ptBlocks(), 1, gz()), dim3(256), 0, s, W, wp(par), decideHere, sqHere);
@@ -4246,7 +3879,6 @@ struct BAJob {
             EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nPo, "edge %d out of range", e);
         for (int e = 0; e < Epl; e++)
             EAO_REQUIRE(pl->pedge_cam[e] >= 0 && pl->pedge_cam[e] < nC && pl->pedge_plane[e] >= 0 && pl->pedge_plane[e] < nPl, "plane edge %d out of range", e);
-        const int chunks = kChunks;
         int nFreeIn = 0;
         for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
         EAO_REQUIRE(nFreeIn <= kBigMaxFree, "at most %d free keyframes in this build (got %d)", kBigMaxFree, nFreeIn);
@@ -4255,9 +3887,8 @@ struct BAJob {
         static const char* solverEnv0 = getenv("EAO_BA_SOLVER");
         // (measured, LocalBundleAdjustment wall time, tools/dbg_ba_sizes.py: the LDS / global-scratch single-workgroup solver with
         //  the slab assembly takes 5.8 ms at 31 free keyframes and 29 ms at 64, the map-scale path 3.6 and 6.9 ms -- so everything
-        //  beyond the register-tile solver goes there; EAO_BA_SOLVER=lds keeps the old path reachable up to 64 for A/B runs)
-        const bool wantLds0 = solverEnv0 && !strcmp(solverEnv0, "lds") && nFreeIn <= kSchurMaxFree;
-        const bool bigPath = (nFreeIn > kTileMaxFree && !wantLds0) || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
+        //  beyond the register-tile solver goes there; that older path was removed in round 5)
+        const bool bigPath = nFreeIn > kTileMaxFree || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
         const BigGeom bg = big_geom(std::max(nFreeIn, 1));
         size_t lpEntries = 0, lpPairsMax = 0;
         if (bigPath) {   // sizes of the pair CSR: sum over the points of m (m + 1) / 2, m = observers among the free keyframes
@@ -4356,7 +3987,6 @@ struct BAJob {
             need += (3 * lpEntries + 3 * lpPairsMax + 8) * 4 + (tileMap.size() + panelStart.size() + 8) * 4 + panelWork.size() * sizeof(int4) + 2048;
         } else {
             need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
-            need += (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6) * 8;
             need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * (4 + 16);   // landmark lists / item records of the camera pairs
             need += (size_t)nP * 9 * 8 + 1024;
             need += (size_t)nC * (nC + 1) / 2 * 4;
@@ -4364,7 +3994,7 @@ struct BAJob {
         if ((st = c.bytes.reserve(need))) return st;
         Arena a{c.bytes.p, c.bytes.n};
         std::memset(&D, 0, sizeof(D));
-        D.nCams = nC; D.nPts = nP; D.nEdges = E; D.chunks = chunks;
+        D.nCams = nC; D.nPts = nP; D.nEdges = E;
         D.cam.fx = p->fx; D.cam.fy = p->fy; D.cam.cx = p->cx; D.cam.cy = p->cy; D.cam.bf = p->bf; D.cam.bf_f = p->bf;
         D.cam.deltaMono = (float)std::sqrt(mode == 1 ? refc::GBA_HUBER2_MONO : refc::LBA_HUBER2_MONO);
         D.cam.deltaStereo = (float)std::sqrt(mode == 1 ? refc::GBA_HUBER2_STEREO : refc::LBA_HUBER2_STEREO);
@@ -4394,7 +4024,7 @@ struct BAJob {
         int* dtable = bigPath ? nullptr : a.take<int>((size_t)nP * nC);      // (the map-scale path finds a landmark's edges in its pair lists)
         D.slot = a.take<int4>((size_t)std::max(nP, 1) * 8);
         D.camEdgeL = a.take<int>(E);
-        const bool pairPath = !bigPath && nFreeIn > 0 && nFreeIn <= kTileMaxFree && !(solverEnv0 && !strcmp(solverEnv0, "lds")) && !getenv("EAO_BA_SLABS");
+        const bool pairPath = !bigPath && nFreeIn > 0 && nFreeIn <= kTileMaxFree;
         const int nPairsMax = nFreeIn * (nFreeIn + 1) / 2;
         D.pairCnt = a.take<int>(bigPath ? 1 : std::max(nPairsMax, 1));
         D.pairPts = a.take<int>(pairPath ? (size_t)nPairsMax * std::max(nP, 1) : 1);
@@ -4413,9 +4043,7 @@ struct BAJob {
         D.Hpp = a.take<double>((size_t)nC * 36); D.bp = a.take<double>((size_t)nC * 6);
         D.Hll = a.take<double>((size_t)nP * 9); D.bl = a.take<double>((size_t)nP * 3);
         D.Hpl = a.take<double>(((size_t)E + 1) * 18);      // (+ the zero block of k_ba_schur_pairs_mfma)
-        double* dsolveScratch = a.take<double>(bigPath ? 8 : (size_t)(nFreeIn * 6 + 6) * (nFreeIn * 6 + 34) + 8);
         D.sys = a.take<double>(bigPath ? 8 : std::max((size_t)(nFreeIn * 6) * (nFreeIn * 6 + 1), (size_t)tile_geom(std::max(nFreeIn, 1)).nTiles * 256) + 8);
-        D.slab = a.take<double>(bigPath ? 8 : (size_t)chunks * ((size_t)nC * 6 * nC * 6 + nC * 6));
         D.big = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
         D.bigL = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
         D.bigTile = dbigTile; D.bigT = bigT; D.bigTiles = bigTiles; D.bigWork = dbigWork; D.bigDense = bigPath && bigTiles == bigT * (bigT + 1) / 2 ? 1 : 0;
@@ -4558,25 +4186,14 @@ struct BAJob {
         const int nF = D.nFree, nL = D.nL;
         BADims& d = L.d;
         d = BADims();
-        d.nF = nF; d.nL = nL; d.nP = nP; d.nC = nC; d.E = E; d.nPl = nPl; d.hasPl = hasPl; d.bigPath = bigPath; d.chunks = chunks;
+        d.nF = nF; d.nL = nL; d.nP = nP; d.nC = nC; d.E = E; d.nPl = nPl; d.hasPl = hasPl; d.bigPath = bigPath;
         d.usePairs = pairPath && nF > 0 && nL > 0;
         d.wmode = D.wmode != 0 && d.usePairs;
         if (!d.wmode) D.wmode = 0;
-        const size_t ldHost = (size_t)((nF * 6 + 32) & ~31) + 1;
-        d.solveLds = ((size_t)(nF * 6 + 6) * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
-        if (d.solveLds > 150 * 1024) {   // system too large for LDS: S lives in (L2-resident) global scratch, M/xv stay in LDS
-            D.solveScratch = dsolveScratch;
-            d.solveLds = ((size_t)6 * ldHost + 2 * (size_t)nF * 6) * sizeof(double);
-        } else {
-            D.solveScratch = nullptr;
-        }
-        d.solveInLds = D.solveScratch == nullptr;
-        // solver choice: register tiles + MFMA up to kTileMaxFree free keyframes, else the LDS / global-scratch solver
-        const bool wantLds = solverEnv0 && !strcmp(solverEnv0, "lds");
-        d.solveTiles = !bigPath && nF > 0 && nF <= kTileMaxFree && !wantLds;
+        // solver choice: register tiles + MFMA up to kTileMaxFree free keyframes, the map-scale path beyond
+        d.solveTiles = !bigPath && nF > 0 && nF <= kTileMaxFree;
         d.tileLds = tile_solver_lds(std::max(nF, 1));
         d.tiles3 = tile_geom(std::max(nF, 1)).nTiles <= 3 * (kTileThreads / 64);
-        d.schurLds = bigPath ? 0 : schur_lds_bytes(nF);
         d.gB = big_geom(std::max(nF, 1));
         d.nPairsNZ = D.nPairsNZ; d.big = D.big; d.bigTiles = bigTiles;
         d.bigPanelStart = bigPath ? panelStart.data() : nullptr;

@@ -50,7 +50,7 @@ def _check_updates(new_gpu, new_cpu, old, what):
 
 @pytest.mark.parametrize("kw", [dict(), dict(n_free=5, n_fixed=2, n_points=300), dict(mono_frac=0.4, seed=3001),
                                 dict(n_free=3, n_fixed=0, n_points=120, seed=3002), dict(n_free=20, n_fixed=4, n_points=3000, sigma=0.0, outlier_frac=0.0),
-                                # 42 unknowns (padded to 44 by the tile solver), its 30-keyframe limit, and the LDS fallback beyond it
+                                # 42 unknowns (padded to 44 by the tile solver), its 30-keyframe limit, and the map-scale path beyond it
                                 dict(n_free=7, n_fixed=2, n_points=400, seed=3003), dict(n_free=30, n_fixed=3, n_points=1500, seed=3004),
                                 dict(n_free=34, n_fixed=2, n_points=1500, seed=3005)])
 def test_local_ba_parity(gpu, oracle, kw):

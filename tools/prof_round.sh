@@ -3,7 +3,7 @@
 # behind the VALU roofline, the FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic, the per-kernel summaries of the BA calls behind
 # roofline.ba, and the VALU issue-rate micro-benchmark.
 #   bash tools/prof_round.sh r03   ->  gpurun_out/r03_*   (copy the summaries into profiles/ afterwards: tools/prof_round.sh does not)
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 rm -rf $O/${R}_stats $O/${R}_sq_a $O/${R}_sq_b $O/${R}_fetch $O/${R}_write $O/${R}_sq_h $O/${R}_ba_batch $O/${R}_ba_single
