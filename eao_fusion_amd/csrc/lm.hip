@@ -756,12 +756,15 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
 #pragma unroll
         for (int a = 0; a < 6; a++) { b[a] = mySys[21 + a]; A[a * 7] += lambda; }
         double x[6] = {0, 0, 0, 0, 0, 0};
+        const long long q0 = stamp ? clock64() : 0;
         const int ok = ldlt6_solve(A, b, x) ? 1 : 0;
         double sc = 0;
 #pragma unroll
         for (int a = 0; a < 6; a++) sc += x[a] * (lambda * x[a] + b[a]);
+        const long long q1 = stamp ? clock64() : 0;
         const SE3 trial = se3_exp_mul(x, s_est[wv]);
         if (lane == 0) { s_cpose[buf][slot] = trial; s_cscale[buf][slot] = sc; s_cok[buf][slot] = ok; }
+        if (stamp) { const long long q2 = clock64(); pa[3] += q1 - q0; pa[4] += q2 - q1; pa[5] += 1; }
     };
     auto copy7 = [&](double* dst, const double* src) {      // an SE3 between LDS records, by seven lanes of the calling wave
         eao::wave_sync();
@@ -1438,7 +1441,8 @@ struct BADev {
     // Memory and work follow the non-zero structure; a map in which every keyframe sees every other one keeps every tile and runs as before.
     GP<double> big;            // bigTiles x 64 x 64: the working matrix (row-major inside a tile)
     GP<double> bigL;           // bigTiles x 64 x 64: the factor L (rows below each panel's diagonal block); row N = z
-    GP<double> bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks
+    GP<double> bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks (1 / d on the diagonal)
+    GP<double> bigLinv;        // (N / 32) * 32 * 32: their inverses as unit-lower blocks (k_bal_linv, for the back substitution)
     GP<int> bigFail;
     GP<const int> bigTile;     // bigT * bigT
     int bigT, bigTiles, bigDense;
@@ -1447,6 +1451,7 @@ struct BADev {
                                // panel is always the tile of the NEXT diagonal block (its workgroup factors it on the spot)
     GP<const int> lpStart;     // nPairsNZ + 1
     GP<const int> lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
+    GP<const int> lpOrder;     // nPairsNZ: the pairs with more than kBigPairLong entries first (four waves each), then the others (one wave each)
     GP<const int> lpPts;       // landmark blocks of each pair, ascending
     GP<const int> lpE1;        // ... and the landmark's edges in camera i1 / i2 (the dense point x camera table of the window path would be
     GP<const int> lpE2;        //     nP x nC ints: 400 MB for a 1000-keyframe map)
@@ -2713,26 +2718,33 @@ __device__ __forceinline__ double* big_elem(const BADev& P, double* pool, int r,
     return big_tile(pool, big_slot(P, r >> 6, c >> 6)) + ((r & 63) << 6) + (c & 63);
 }
 
-constexpr int kBigPairThreads = 512;   // (block_sum_lds needs 8 column threads per value)
-__global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(const BADev* __restrict__ W, int wpar, int first) {
+// Round 5: ONE WAVEFRONT per pair, FOUR for the long ones (rounds 3-4 ran 512 threads per pair: 192 VGPRs each, so ONE workgroup per CU, and a block-wide reduction
+// of 42 values per pair -- 90 us for the 1 593 pairs of the 200-keyframe benchmark map, six rounds of workgroups).  A pair's entries are a latency chain -- landmark
+// index -> edge flags -> three blocks -- of ~4 us per 64 of them: a covisible pair shares tens to a few hundred landmarks, a DIAGONAL pair carries every landmark its
+// keyframe sees; the host lists the long pairs first (lpOrder) and they get their own launch.  42 sums per pair: DPP tree per wave, the waves' totals through LDS in wave order.
+constexpr int kBigPairLong = 2048;
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bal_schur_pairs(const BADev* __restrict__ W, int wpar, int first, int pairOff) {
     BA_WIN(P);
-    __shared__ double red[(kBigPairThreads / 4) * 42], part[8 * 42];
+    __shared__ double red[NT / 64][42];
     if (P.ctl[kCtlHalt]) return;
     const int nF = P.nFree, t = threadIdx.x;
     const BigGeom g = big_geom(nF);
+    const bool lead = pairOff + (int)bx == 0;      // the first workgroup of the first launch also resets the trial's flags and padding
+    bx = P.lpOrder[pairOff + bx];
     const int i1 = P.lpPair[2 * bx], i2 = P.lpPair[2 * bx + 1];
     const bool diag = i1 == i2;
     const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
-    if (bx == 0) {
+    if (lead) {
         if (first && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
         if (t == 0) *P.bigFail = 0;
-        for (int r = g.n + t; r < g.N; r += kBigPairThreads) *big_elem(P, P.big, r, r) = 1.0;     // identity padding
+        for (int r = g.n + t; r < g.N; r += NT) *big_elem(P, P.big, r, r) = 1.0;     // identity padding
     }
     const int beg = P.lpStart[bx], cnt = P.lpStart[bx + 1] - beg;
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; q++) acc[q] = 0;
-    for (int k = t; k < cnt; k += kBigPairThreads) {
+    for (int k = t; k < cnt; k += NT) {
         const int l = P.lpPts[beg + k];
         const int e1 = P.lpE1[beg + k], e2 = P.lpE2[beg + k];
         if ((P.eflag[e1] | P.eflag[e2]) & 2) continue;       // deactivated by the outlier pass
@@ -2757,9 +2769,16 @@ __global__ __launch_bounds__(kBigPairThreads) void k_bal_schur_pairs(const BADev
             }
         }
     }
-    block_sum_lds<42, kBigPairThreads>(acc, red, part);
+#pragma unroll
+    for (int q = 0; q < 42; q++) {
+        const double ws = wave_sum_f64_lane63(acc[q]);
+        if ((t & 63) == 63) red[t >> 6][q] = ws;
+    }
+    __syncthreads();
     if (t >= 42) return;
-    const double s = part[t];
+    double s = 0;
+#pragma unroll
+    for (int wv = 0; wv < NT / 64; wv++) s += red[wv][t];
     if (t < 36) {
         const int r = t / 6, c = t - r * 6;
         if (!diag) *big_elem(P, P.big, i2 * 6 + c, i1 * 6 + r) = s;          // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
@@ -2793,28 +2812,114 @@ __device__ inline bool bal_factor_diag_wave(double (&row)[kBigNB]) {
     }
     return bad;
 }
+// ---- round 5: the same two serial pieces without v_readlane and without LDS broadcasts.  gfx90a+ gives 64-bit VALU operations ONE DPP control,
+// row_newbcast:K (lane K of every 16-lane row to the whole row), and v_fmac_f64 has a VOP2 encoding that takes it: one instruction is
+//      acc = fma(-x[lane K of my row], y, acc)
+// -- the broadcast FMA both pieces consist of (tools/ubench/dpp_f64.hip: result and rate on gfx950).  The compiler has no builtin for 64-bit DPP, so
+// these are inline assembly; its hazard recogniser does not look inside, hence the explicit wait states where a DPP source may just have been written
+// (VALU write -> DPP read of the same VGPR: 2 wait states; an EXEC write by a VALU compare -> DPP: 5).  Every lane of the wave must be active.
+#ifndef EAO_BAL_DPP
+#define EAO_BAL_DPP 1
+#endif
+template <int K> __device__ __forceinline__ void bal_fmac_nb(double& acc, double src, double y) {
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(y), "n"(K));
+}
+template <int K> __device__ __forceinline__ double bal_mov_nb(double src) {
+    double d;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(src), "n"(K));
+    return d;
+}
+template <int B, int... I, typename F> __device__ __forceinline__ void bal_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, B + I>{}), ...); }
+template <int B, int E, typename F> __device__ __forceinline__ void bal_static_for(F&& f) { if constexpr (E > B) bal_static_for_impl<B>(f, std::make_integer_sequence<int, E - B>{}); }
+
+// LDL^T of a 32 x 32 block, DPP form: the matrix lives in EVERY 16-lane row of the wave -- lane l holds rows l % 16 (X0: columns 0..15) and 16 + l % 16 (X1: columns
+// 0..31), four identical replicas -- so a_jp, the un-normalised column p at row j, is lane j % 16 of the register that holds column p, and the update
+// row[j] -= l_ip a_jp is ONE v_fmac_f64_dpp per row set (616 of them per block against 496 FMAs + 1 056 v_readlane).  The same products in the same order as
+// bal_factor_diag_wave: the factors agree bit for bit.  On return X0 / X1 [j] = L(row, j) below the diagonal and 1 / d on it.
+__device__ inline bool bal_factor_diag_dpp(double (&X0)[16], double (&X1)[kBigNB]) {
+    const int l16 = threadIdx.x & 15;
+    bool bad = false;
+    asm volatile("s_nop 4");
+    bal_static_for<0, kBigNB>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        asm volatile("s_nop 1");      // column p's last update may be the instruction before this one (pivot 30 -> 31)
+        double d;
+        if constexpr (p < 16) d = bal_mov_nb<p % 16>(X0[p]); else d = bal_mov_nb<p % 16>(X1[p]);
+        bad |= (d == 0.0 || !isfinite(d));
+        const double id = frcp(d);
+        double lip0 = 0;
+        if constexpr (p < 16) lip0 = X0[p] * id;
+        const double lip1 = X1[p] * id;
+        bal_static_for<p + 1, kBigNB>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < 16) { bal_fmac_nb<j % 16>(X0[j], X0[p], lip0); bal_fmac_nb<j % 16>(X1[j], X0[p], lip1); }
+            else if constexpr (p < 16) bal_fmac_nb<j % 16>(X1[j], X1[p], lip1);
+            else bal_fmac_nb<j % 16>(X1[j], X1[p], lip1);
+        });
+        if constexpr (p < 16) { X0[p] = l16 == p ? id : lip0; X1[p] = lip1; }
+        else X1[p] = l16 == p - 16 ? id : lip1;
+    });
+    return bad;
+}
+// rows l % 16 and 16 + l % 16 of the block at `src` (row stride ld doubles)
+__device__ __forceinline__ void bal_load_rows_dpp(const double* src, int ld, double (&X0)[16], double (&X1)[kBigNB]) {
+    const int l16 = threadIdx.x & 15;
+#pragma unroll
+    for (int j = 0; j < 16; j++) X0[j] = src[l16 * ld + j];
+#pragma unroll
+    for (int j = 0; j < kBigNB; j++) X1[j] = src[(16 + l16) * ld + j];
+}
+// (lanes 0..15 store their first row, lanes 16..31 -- an identical replica -- their second one)
+__device__ inline void bal_store_diag_dpp(double* bigDiag, int* bigFail, int kb, const double (&X0)[16], const double (&X1)[kBigNB], bool bad) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15;
+    double* Ld = bigDiag + (size_t)kb * kBigNB * kBigNB;
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < kBigNB; j++) Ld[l16 * kBigNB + j] = (j < 16 && j <= l16) ? X0[j < 16 ? j : 0] : 0.0;
+    } else if (lane < 32) {
+#pragma unroll
+        for (int j = 0; j < kBigNB; j++) Ld[(16 + l16) * kBigNB + j] = j <= 16 + l16 ? X1[j] : 0.0;
+    }
+    if (lane == 0 && bad) *bigFail = 1;
+}
+
 // the factored block as the panel / back-substitution kernels read it: unit-lower L below the diagonal, 1 / d ON it
-__device__ inline void bal_store_diag_wave(const BADev& P, int kb, const double (&row)[kBigNB], bool bad) {
+__device__ inline void bal_store_diag_wave(double* bigDiag, int* bigFail, int kb, const double (&row)[kBigNB], bool bad) {
     const int lane = threadIdx.x & 63;
     if (lane < kBigNB) {
-        double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB + lane * kBigNB;
+        double* Ld = bigDiag + (size_t)kb * kBigNB * kBigNB + lane * kBigNB;
 #pragma unroll
         for (int j = 0; j < kBigNB; j++) Ld[j] = j <= lane ? row[j] : 0.0;
     }
-    if (lane == 0 && bad) *P.bigFail = 1;
+    if (lane == 0 && bad) *bigFail = 1;
 }
+
+// The factorisation launches take what they need BY VALUE: the pool pointers, the halt flag's address and -- for the look-ahead workgroup, whose record is
+// the first of the panel's list -- the work record itself.  Read through the window record like the other LM kernels, a panel started with three
+// dependent round trips to memory (record -> work list -> tiles) before its first useful load; 38 launches per trial start with that chain.
+struct BigStepArgs {
+    double* big; double* bigL; double* bigDiag; int* bigFail; const int4* bigWork; const int* ctl; long long* dbg;
+    int N; int4 wa0; int wb0x;
+};
 
 // first diagonal block of a trial (the following ones are factored by the update kernel of the panel before them)
 __global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, int wpar) {
     BA_WIN(P);
     if (P.ctl[kCtlHalt]) return;
-    const int i = threadIdx.x & 31;
     const double* T0 = big_tile(P.big, big_slot(P, 0, 0));
+#if EAO_BAL_DPP
+    double X0[16], X1[kBigNB];
+    bal_load_rows_dpp(T0, 64, X0, X1);
+    const bool bad = bal_factor_diag_dpp(X0, X1);
+    bal_store_diag_dpp(P.bigDiag, P.bigFail, 0, X0, X1, bad);
+#else
+    const int i = threadIdx.x & 31;
     double row[kBigNB];
 #pragma unroll
     for (int j = 0; j < kBigNB; j++) row[j] = T0[i * 64 + j];
     const bool bad = bal_factor_diag_wave(row);
-    bal_store_diag_wave(P, 0, row, bad);
+    bal_store_diag_wave(P.bigDiag, P.bigFail, 0, row, bad);
+#endif
 }
 
 // One launch per 32-column panel: every 64 x 64 tile of the trailing lower triangle first solves the panel rows it needs ITSELF
@@ -2825,29 +2930,34 @@ __global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, i
 // tile that still reads a and one that would overwrite it with l).  The tile that holds the NEXT diagonal block factors it on
 // the spot (one wavefront, see above), so the next launch starts from a finished L_kk.  The first version ran the row solves
 // as a launch of their own: two dependent launches per panel instead of one (12 + 13 us at 40 free keyframes).
-__global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, int wpar, int kb, int last, int workOff) {
-    BA_WIN(P);
+__global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int last, int workOff) {
+    const unsigned bx = blockIdx.x;
     __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double a[kBigNB][kBigNB];
     __shared__ double da[kBigNB][kBigNB + 1];
-    if (P.ctl[kCtlHalt]) return;
-    const BigGeom g = big_geom(P.nFree);
     constexpr size_t ld = 64;                          // (inside a tile)
     const int k0 = kb * kBigNB, t = threadIdx.x;
-    // the workgroup's tile: record bx of the panel's work list (built by the host from the tile structure; a dense system lists every trailing tile)
-    const int4 wa = P.bigWork[2 * (size_t)(workOff + bx)], wb = P.bigWork[2 * (size_t)(workOff + bx) + 1];
+    // the workgroup's tile: record bx of the panel's work list (built by the host from the tile structure; a dense system lists every trailing tile).
+    // The halt flag travels with the record: one round trip to memory for both, not one behind the other (38 launches per trial start with this chain)
+    const int halted = A.ctl[kCtlHalt];
+    int4 wa = A.wa0;
+    int wbx = A.wb0x;
+    if (bx != 0) { wa = A.bigWork[2 * (size_t)(workOff + bx)]; wbx = A.bigWork[2 * (size_t)(workOff + bx) + 1].x; }
+    if (halted) return;
+    const bool stp = A.dbg && bx == 0 && t == 0 && kb == 2;      // phase stamps of the look-ahead workgroup of panel 2 (EAO_DEBUG_STAMPS)
+    if (stp) A.dbg[16] = clock64();
     const int ti = wa.x, tj = wa.y;
     const int r0 = ti * 64, c0 = tj * 64;
     // panel rows of this tile: threads 0..63 the tile's rows (W), 64..127 its columns (L); a tile row that is dead in the panel's tile column (only ever the
     // first list entry: the next diagonal block's row is always listed) contributes zeros
     const bool roleW = t < 64;
     const int prow = roleW ? r0 + t : c0 + (t - 64);
-    const int pslot = roleW ? wa.w : wb.x;
-    const bool act = t < 128 && pslot >= 0 && prow >= k0 + kBigNB && prow <= g.N;      // rows of the panel itself / beyond the system: zero
+    const int pslot = roleW ? wa.w : wbx;
+    const bool act = t < 128 && pslot >= 0 && prow >= k0 + kBigNB && prow <= A.N;      // rows of the panel itself / beyond the system: zero
     double w[kBigNB];
     if (act) {
-        const double* src = big_tile(P.big, pslot) + ((prow & 63) << 6) + (k0 & 63);
+        const double* src = big_tile(A.big, pslot) + ((prow & 63) << 6) + (k0 & 63);
 #pragma unroll
         for (int c = 0; c < kBigNB; c++) w[c] = src[c];
     } else {
@@ -2855,18 +2965,61 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
         for (int c = 0; c < kBigNB; c++) w[c] = 0.0;
     }
     const int tx = t & 15, ty = t >> 4;
+    const bool crit = !last && bx == 0;            // the look-ahead workgroup (see below): it walks its tile quadrant by quadrant
     double c[4][4];
-    double* C = big_tile(P.big, wa.z) + (size_t)(ty * 4) * ld + tx * 4;      // (the host's symbolic elimination made sure the tile exists)
+    double* const Ct = big_tile(A.big, wa.z);      // (the host's symbolic elimination made sure the tile exists)
+    double* C = Ct + (size_t)(ty * 4) * ld + tx * 4;
+    const int oq = k0 + kBigNB - c0;               // (look-ahead) 0 or 32: offset of the next diagonal block inside this tile
+    double accq[4];                                // (look-ahead) this thread's four entries of that block
+    if (!crit) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) c[i][j] = C[(size_t)i * ld + j];
+            for (int j = 0; j < 4; j++) c[i][j] = C[(size_t)i * ld + j];
+    } else {
+        const double* Cq = Ct + (size_t)(oq + (t >> 3)) * ld + oq + (t & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) accq[j] = Cq[j];
+    }
     {
-        const double* Ld = P.bigDiag + (size_t)kb * kBigNB * kBigNB;
+        const double* Ld = A.bigDiag + (size_t)kb * kBigNB * kBigNB;
         for (int idx = t; idx < kBigNB * kBigNB; idx += 256) a[idx >> 5][idx & 31] = Ld[idx];
     }
-    __syncthreads();
+#if EAO_BAL_DPP
+    // the row solves' coefficients in registers, every 16-lane row of the two solving waves a replica: lane l holds rows l % 16 and 16 + l % 16 of L_kk, so
+    // L(cc, q) is lane cc % 16 of register q -- a row_newbcast operand (see bal_fmac_nb) instead of an LDS broadcast read per FMA (8.5 k -> 3 k cycles per step)
+    double A0[15], A1[31];
     if (t < 128) {
+        const double* Ld = A.bigDiag + (size_t)kb * kBigNB * kBigNB + (t & 15) * kBigNB;
+#pragma unroll
+        for (int q = 0; q < 15; q++) A0[q] = Ld[q];
+#pragma unroll
+        for (int q = 0; q < 31; q++) A1[q] = Ld[16 * kBigNB + q];
+    }
+#endif
+    __syncthreads();
+    if (stp) A.dbg[17] = clock64();
+    if (t < 128) {
+#if EAO_BAL_DPP
+        // (every lane takes part: a row that is not `act` solves zeros)
+        asm volatile("s_nop 4");
+        // columns in PAIRS (c, c + 1): a dependent v_fmac_f64_dpp issues every 12 cycles, an independent one every 8.5 (tools/ubench/dpp_f64.hip), and
+        // the two chains only meet in the pair's last step; per column still the FMAs w[c] -= w[q] L(c, q) in ascending q
+        auto step = [&](auto ccc, auto qc) {
+            constexpr int cc = decltype(ccc)::value, q = decltype(qc)::value;
+            if constexpr (cc < 16) bal_fmac_nb<cc>(w[cc], A0[q], w[q]);
+            else bal_fmac_nb<cc - 16>(w[cc], A1[q], w[q]);
+        };
+        bal_static_for<0, kBigNB / 2>([&](auto hc) {
+            constexpr int c0 = 2 * decltype(hc)::value - 1;      // pairs (1, 2), (3, 4), ... (29, 30); column 31 alone
+            if constexpr (c0 < 0) {}
+            else if constexpr (c0 + 1 < kBigNB) {
+                bal_static_for<0, c0>([&](auto qc) { step(std::integral_constant<int, c0>{}, qc); step(std::integral_constant<int, c0 + 1>{}, qc); });
+                step(std::integral_constant<int, c0 + 1>{}, std::integral_constant<int, c0>{});
+            }
+        });
+        bal_static_for<0, kBigNB - 1>([&](auto qc) { step(std::integral_constant<int, kBigNB - 1>{}, qc); });
+#else
         if (act) {
 #pragma unroll
             for (int cc = 1; cc < kBigNB; cc++) {
@@ -2874,11 +3027,12 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
                 for (int q = 0; q < cc; q++) w[cc] = fma(-w[q], a[cc][q], w[cc]);
             }
         }
+#endif
         if (roleW) {
 #pragma unroll
             for (int k = 0; k < kBigNB; k++) Wt[k][t] = w[k];
             if (ti == tj && act) {      // a tile row's DIAGONAL workgroup archives its panel rows (every listed row has one)
-                double* ldst = big_tile(P.bigL, pslot) + ((prow & 63) << 6) + (k0 & 63);
+                double* ldst = big_tile(A.bigL, pslot) + ((prow & 63) << 6) + (k0 & 63);
 #pragma unroll
                 for (int k = 0; k < kBigNB; k++) ldst[k] = w[k] * a[k][k];
             }
@@ -2888,44 +3042,120 @@ __global__ __launch_bounds__(256) void k_bal_step(const BADev* __restrict__ W, i
         }
     }
     __syncthreads();
+    if (stp) A.dbg[18] = clock64();
+    if (!crit) {
 #pragma unroll 8
-    for (int k = 0; k < kBigNB; k++) {
-        double wv[4], lv[4];
+        for (int k = 0; k < kBigNB; k++) {
+            double wv[4], lv[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { wv[i] = Wt[k][ty * 4 + i]; lv[i] = Lt[k][tx * 4 + i]; }
+            for (int i = 0; i < 4; i++) { wv[i] = Wt[k][ty * 4 + i]; lv[i] = Lt[k][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) c[i][j] = fma(-wv[i], lv[j], c[i][j]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) c[i][j] = fma(-wv[i], lv[j], c[i][j]);
+            for (int j = 0; j < 4; j++) C[(size_t)i * ld + j] = c[i][j];
+        return;
     }
+    // look-ahead: the tile that holds the NEXT panel's diagonal block (the first one dispatched) factors it right away.  Only that 32 x 32 block is on the
+    // critical path of the whole factorisation, so it is updated FIRST, by all four waves (four outputs per thread); then wave 0 factors it while waves 1
+    // and 2 update the tile's two other quadrants below the diagonal in the shadow of the factorisation (the quadrant above it is read by nobody; when the block
+    // is the tile's lower-right quadrant the others are the panel's own rows and columns: no update at all).  The same FMAs per output as the full-tile loop.
+    {
+        const int o = oq;
+        {
+            const int qr = t >> 3, qc = (t & 7) * 4;
+            double (&acc)[4] = accq;
+#pragma unroll 8
+            for (int k = 0; k < kBigNB; k++) {
+                const double wv = Wt[k][o + qr];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) C[(size_t)i * ld + j] = c[i][j];
-    // look-ahead: the tile that holds the NEXT panel's diagonal block (the first one dispatched) factors it right away
-    if (!last && bx == 0) {
-        const int o = k0 + kBigNB - c0;            // 0 or 32: offset of the block inside this tile
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = ty * 4 + i - o, cc = tx * 4 + j - o;
-                if (r >= 0 && r < kBigNB && cc >= 0 && cc < kBigNB) da[r][cc] = c[i][j];
+                for (int j = 0; j < 4; j++) acc[j] = fma(-wv, Lt[k][o + qc + j], acc[j]);
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) da[qr][qc + j] = acc[j];
+        }
         __syncthreads();
+        if (stp) A.dbg[19] = clock64();
+        if (t >= 64 && t < 192 && o == 0) {
+            const int v = (t >> 6) - 1, lane = t & 63;          // wave 1: rows 32..63 x columns 0..31, wave 2: rows 32..63 x columns 32..63
+            const int rb = 32 + (lane >> 3) * 4, cb = v * 32 + (lane & 7) * 4;
+            double* Cq = Ct + (size_t)rb * ld + cb;
+            double q4[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) q4[i][j] = Cq[(size_t)i * ld + j];
+#pragma unroll 8
+            for (int k = 0; k < kBigNB; k++) {
+                double wv[4], lv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { wv[i] = Wt[k][rb + i]; lv[i] = Lt[k][cb + i]; }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) q4[i][j] = fma(-wv[i], lv[j], q4[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) Cq[(size_t)i * ld + j] = q4[i][j];
+        }
         if (t < 64) {
+#if EAO_BAL_DPP
+            double X0[16], X1[kBigNB];
+            bal_load_rows_dpp(&da[0][0], kBigNB + 1, X0, X1);
+            if (stp) A.dbg[20] = clock64();
+            const bool bad = bal_factor_diag_dpp(X0, X1);
+            if (stp) A.dbg[21] = clock64();
+            bal_store_diag_dpp(A.bigDiag, A.bigFail, kb + 1, X0, X1, bad);
+            if (stp) A.dbg[22] = clock64();
+#else
             double row[kBigNB];
 #pragma unroll
             for (int j = 0; j < kBigNB; j++) row[j] = da[t & 31][j];
             const bool bad = bal_factor_diag_wave(row);
-            bal_store_diag_wave(P, kb + 1, row, bad);
+            bal_store_diag_wave(A.bigDiag, A.bigFail, kb + 1, row, bad);
+#endif
         }
     }
 }
 
+// The inverses of the 32 x 32 unit-lower diagonal blocks, for the back substitution: one wavefront per pair of blocks (one launch behind the
+// factorisation), lane j of each half forward-substitutes column j of its block's inverse in registers (the coefficients as LDS broadcasts).
+// Out: bigLinv[block][r][c] = (L_bb^-1)(r, c).
+__global__ __launch_bounds__(64) void k_bal_linv(const BADev* __restrict__ W, int wpar, int nbk) {
+    BA_WIN(P);
+    __shared__ __attribute__((aligned(16))) double Ls[2 * kBigNB * kBigNB];
+    if (P.ctl[kCtlHalt]) return;
+    const int t = threadIdx.x, hb = t >> 5, j = t & 31, blk = min(2 * (int)bx + hb, nbk - 1);      // (an odd block count: the last wave's upper half repeats its lower one)
+    {
+        const double* Ld = P.bigDiag + (size_t)(2 * bx) * kBigNB * kBigNB;
+        const int cnt = min(2, nbk - 2 * (int)bx) * kBigNB * kBigNB / 2;
+        for (int idx = t; idx < cnt; idx += 64) reinterpret_cast<double2*>(Ls)[idx] = reinterpret_cast<const double2*>(Ld)[idx];
+    }
+    __syncthreads();
+    const double* L = Ls + (blk - 2 * (int)bx) * kBigNB * kBigNB;
+    double x[kBigNB];
+#pragma unroll
+    for (int i = 0; i < kBigNB; i++) x[i] = i == j ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < kBigNB - 1; m++) {
+#pragma unroll
+        for (int i = m + 1; i < kBigNB; i++) x[i] = fma(-L[i * kBigNB + m], x[m], x[i]);
+    }
+    double* dst = P.bigLinv + ((size_t)blk << 10);
+#pragma unroll
+    for (int i = 0; i < kBigNB; i++) dst[i * kBigNB + j] = x[i];
+}
+
 // Back substitution L^T x = z in super-blocks of 256 columns, one launch each, bottom-up.  Every workgroup solves the
 // super-block's own triangle redundantly (8 blocks of 32: column sums over the rows already solved split across the
-// waves, the 32 x 32 triangle by shuffles in wave 0), then removes the super-block's contribution from ITS 64 columns of z
+// waves; the 32 x 32 triangle is ONE product with the block's inverse from k_bal_linv -- 32 independent dot products instead of
+// the 31 dependent shuffle steps of rounds 3-4), then removes the super-block's contribution from ITS 64 columns of z
 // to the left: z_j -= sum_i L(i, j) x_i.  L is read once, by as many workgroups as there are column chunks; the last launch
 // (super-block 0) also applies exp(dx) * T.
 constexpr int kBigSB = 256;
@@ -2933,7 +3163,7 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
     BA_WIN(P);
     int* const solveOk = P.solveOk;
     __shared__ double xl[kBigSB];      // z of the super-block on entry, x on exit
-    extern __shared__ double sdiag[];  // (kBigSB / 32) x 32 x 32: the factored diagonal blocks of the super-block
+    extern __shared__ double sdiag[];  // (kBigSB / 32) x 32 x 32: the inverses of the super-block's unit-lower diagonal blocks
     __shared__ double part2[4][64];
     if (P.ctl[kCtlHalt]) return;
     const BigGeom g = big_geom(P.nFree);
@@ -2941,21 +3171,29 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
     double* S = P.bigL;            // the archived factor (rows below each panel's diagonal block, z = row N), as tiles
     const int J0 = J * kBigSB, w = min(kBigSB, N - J0);
     auto zat = [&](int col) { return big_elem(P, S, N, col); };      // z = row N: its tile row is dense by construction
-    auto Lat = [&](int r, int col) -> double {                      // L(r, col), col < r: zero where the tile does not exist
-        const int sl = big_slot(P, r >> 6, col >> 6);
-        return sl < 0 ? 0.0 : big_tile(S, sl)[((r & 63) << 6) + (col & 63)];
-    };
     if (J > 0 && bx > 0) {      // a column chunk in which none of the super-block's tile rows holds a tile has nothing to remove (workgroup-uniform; workgroup 0 also delivers x)
         bool any = false;
         for (int r = J0 >> 6; r <= (J0 + w - 1) >> 6; r++) any = any || big_slot(P, r, bx) >= 0;
         if (!any) return;
     }
+    const bool stb = P.dbg && bx == 0 && t == 0 && J == 1;      // phase stamps (EAO_DEBUG_STAMPS): super-block 1, workgroup 0
+    if (stb) P.dbg[24] = clock64();
     if (t < w) xl[t] = *zat(J0 + t);
-    {   // the super-block's (up to eight) factored diagonal blocks: 64 KB of LDS, every load of a thread in flight at once
-        const double* Ld0 = P.bigDiag + (size_t)(J0 / kBigNB) * kBigNB * kBigNB;
-        const int cnt = (w / kBigNB) * kBigNB * kBigNB;
-        for (int i = t; i < cnt; i += 256) sdiag[i] = Ld0[i];
+    {   // the super-block's (up to eight) inverted diagonal blocks: 64 KB of LDS, every load of a thread in flight at once
+        // (a fixed trip count: as a loop up to `cnt` this copy ran ONE load at a time -- 22 k cycles of a 60 k-cycle launch, EAO_DEBUG_STAMPS)
+        const double2* Ld0 = reinterpret_cast<const double2*>(P.bigLinv + (size_t)(J0 / kBigNB) * kBigNB * kBigNB);
+        const int cnt2 = (w / kBigNB) * kBigNB * kBigNB / 2;
+        double2 v[kBigSB / kBigNB * 2];
+#pragma unroll
+        for (int u = 0; u < kBigSB / kBigNB * 2; u++) v[u] = t + 256 * u < cnt2 ? Ld0[t + 256 * u] : make_double2(0, 0);
+#pragma unroll
+        for (int u = 0; u < kBigSB / kBigNB * 2; u++) reinterpret_cast<double2*>(sdiag)[t + 256 * u] = v[u];
     }
+    // this thread's column J0 + t: its tile in each of the super-block's (up to four) tile rows, looked up once
+    const int zsl = big_slot(P, N >> 6, (J0 + min(t, w - 1)) >> 6);      // (the z row's tile of that column: always there)
+    int mysl[kBigSB / 64];
+#pragma unroll
+    for (int r = 0; r < kBigSB / 64; r++) mysl[r] = (r << 6) < w ? big_slot(P, (J0 >> 6) + r, (J0 + min(t, w - 1)) >> 6) : -1;
     // the super-block's triangle, right-looking: the top block is solved by wave 0 (column c of L_kk in registers, the
     // solved entries handed down by v_readlane), then every thread owning a column to the left removes the block's 32 rows
     // from its z entry -- the 32 loads of a thread are independent of x, so they are in flight before the chain ends
@@ -2963,27 +3201,33 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
     auto fetch = [&](int b, double (&dst)[kBigNB]) {
         if (b >= 0 && t < b * kBigNB) {
             const int cb = J0 + b * kBigNB;
-            const int sl = big_slot(P, cb >> 6, (J0 + t) >> 6);      // the block's 32 rows lie in one tile row
-            const double* src = sl < 0 ? nullptr : big_tile(S, sl) + ((cb & 63) << 6) + ((J0 + t) & 63);
+            const int tr = b >> 1;                                   // the block's 32 rows lie in one tile row
+            const int sl = tr == 0 ? mysl[0] : tr == 1 ? mysl[1] : tr == 2 ? mysl[2] : mysl[3];
+            const double* src = big_tile(S, sl < 0 ? zsl : sl) + ((cb & 63) << 6) + ((J0 + t) & 63);      // (no tile: the z tile's bytes, masked below)
 #pragma unroll
-            for (int i = 0; i < kBigNB; i++) dst[i] = src ? src[i << 6] : 0.0;
+            for (int i = 0; i < kBigNB; i++) dst[i] = src[i << 6];
+            if (sl < 0) {
+#pragma unroll
+                for (int i = 0; i < kBigNB; i++) dst[i] = 0.0;
+            }
         }
     };
     auto do_block = [&](int b, double (&cur)[kBigNB], double (&nxt)[kBigNB]) {
         fetch(b - 1, nxt);
         __syncthreads();                 // xl[] of this block is final (initial load / previous block's updates)
-        if (t < 64) {
+        if (t < 64) {                    // x_b = L_bb^-T y_b: lane c sums column c of the inverse against y (zeros above the diagonal), four partial sums
             const int c = t & 31;
-            double v = xl[b * kBigNB + c];
-            const double* Ld = sdiag + (size_t)b * kBigNB * kBigNB;
-            double lc[kBigNB];
+            const double* Li = sdiag + (size_t)b * kBigNB * kBigNB + c;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-            for (int q = 0; q < kBigNB; q++) lc[q] = Ld[q * kBigNB + c];       // column c of L_kk (LDS)
-#pragma unroll
-            for (int q = kBigNB - 1; q >= 1; q--) {
-                const double xq = bal_readlane(v, q);
-                v = c < q ? fma(-lc[q], xq, v) : v;
+            for (int q = 0; q < kBigNB; q += 4) {
+                a0 = fma(Li[q * kBigNB], xl[b * kBigNB + q], a0);
+                a1 = fma(Li[(q + 1) * kBigNB], xl[b * kBigNB + q + 1], a1);
+                a2 = fma(Li[(q + 2) * kBigNB], xl[b * kBigNB + q + 2], a2);
+                a3 = fma(Li[(q + 3) * kBigNB], xl[b * kBigNB + q + 3], a3);
             }
+            const double v = (a0 + a1) + (a2 + a3);
+            eao::wave_sync();            // every lane has read y before any lane overwrites it
             if (t < 32) xl[b * kBigNB + t] = v;
         }
         __syncthreads();
@@ -2998,28 +3242,43 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
         double rowA[kBigNB], rowB[kBigNB];
         const int top = w / kBigNB - 1;
         fetch(top, rowA);
+        if (stb) P.dbg[25] = clock64();
         for (int b = top; b >= 0; b -= 2) {
             do_block(b, rowA, rowB);
             if (b - 1 >= 0) do_block(b - 1, rowB, rowA);
         }
     }
     __syncthreads();
+    if (stb) P.dbg[26] = clock64();
     if (bx == 0)
         for (int i = t; i < w; i += 256) if (J0 + i < n) P.xp[J0 + i] = xl[i];
     if (J > 0) {
         // this workgroup's 64 columns to the left of the super-block
+        // (rows rg, rg + 4, ... of the super-block, ALL 64 loads of a thread in flight at once behind four tile look-ups: in batches of eight, each behind its own
+        //  look-ups, this loop was 21 k cycles of a 60 k-cycle launch)
         const int j = bx * 64 + (t & 63), rg = t >> 6;
-        double acc = 0;
-        for (int i0 = rg; i0 < w; i0 += 32) {      // (w is a multiple of 32) eight independent loads in flight
-            double v[8];
+        // (a tile that does not exist reads the z tile instead and is masked afterwards: unconditional loads, no branch per load)
+        const double* const safe = big_tile(S, big_slot(P, N >> 6, bx)) + (t & 63);
+        const double* tl[kBigSB / 64];
+        bool ok[kBigSB / 64];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = Lat(J0 + i0 + 4 * u, j);
-#pragma unroll
-            for (int u = 0; u < 8; u++) acc = fma(v[u], xl[i0 + 4 * u], acc);
+        for (int r = 0; r < kBigSB / 64; r++) {
+            const int sl = (r << 6) < w ? big_slot(P, (J0 >> 6) + r, bx) : -1;
+            ok[r] = sl >= 0;
+            tl[r] = ok[r] ? big_tile(S, sl) + (t & 63) : safe;
         }
+        double v[kBigSB / 4];
+#pragma unroll
+        for (int m = 0; m < kBigSB / 4; m++) v[m] = tl[m >> 4][((rg + 4 * m) & 63) << 6];
+#pragma unroll
+        for (int m = 0; m < kBigSB / 4; m++) v[m] = (rg + 4 * m < w && ok[m >> 4]) ? v[m] : 0.0;
+        double acc = 0;
+#pragma unroll
+        for (int m = 0; m < kBigSB / 4; m++) { const int i = rg + 4 * m; if (i < w) acc = fma(v[m], xl[i], acc); }
         part2[rg][t & 63] = acc;
         __syncthreads();
         if (rg == 0) *zat(j) -= (part2[0][t] + part2[1][t]) + (part2[2][t] + part2[3][t]);
+        if (stb) P.dbg[27] = clock64();
         return;
     }
     __threadfence();
@@ -3477,7 +3736,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     if (P.dbg) {
         long long st[64];
         EAO_HIP(hipMemcpy(st, P.dbg, sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[eao pose stamps] eval %lld tree + barrier %lld decide + solve + exp %lld clock64 ticks over %d LM iterations, %d passes (%d of them light)\n", st[0], st[1], st[2], res[1], res[3] & 0xFFFF, res[3] >> 16);
+        fprintf(stderr, "[eao pose stamps] eval %lld tree + barrier %lld decide + solve + exp %lld clock64 ticks over %d LM iterations, %d passes (%d of them light); of the serial part, wave 0: 6 x 6 LDL^T + scale %lld, exp + compose + publish %lld ticks over %lld solves\n", st[0], st[1], st[2], res[1], res[3] & 0xFFFF, res[3] >> 16, st[3], st[4], st[5]);
         fprintf(stderr, "[eao pose stamps] per wave, heavy evaluation / light evaluation / tree:");
         for (int w = 0; w < (int)st[7] && w < 16; w++) fprintf(stderr, "  w%d %lld / %lld / %lld", w, st[8 + w], st[24 + w], st[40 + w]);
         fprintf(stderr, "\n");
@@ -3669,6 +3928,9 @@ struct BADims {
     bool hasPl = false, bigPath = false, usePairs = false, solveTiles = false, tiles3 = true, wmode = false;
     size_t tileLds = 0;
     int nPairsNZ = 0;          // map-scale path (never batched)
+    int nPairsLong = 0;        // " : how many of them take the four-wave kernel (listed first in lpOrder)
+    BigStepArgs bigArgs{};     // " : what k_bal_step takes by value (ctl / wa0 / wb0x filled per launch)
+    const int* bigCtl0 = nullptr; const int4* bigPanelWork = nullptr;      // " : the control blocks on the device; the host copy of the work records
     double* big = nullptr;     // "
     int bigTiles = 0;          // "
     const int* bigPanelStart = nullptr;      // " : where every 32-column panel's work records start (nbk + 1 entries, thread-local storage that outlives the call's launches;
@@ -3739,13 +4001,19 @@ struct BALaunch {
         if (nF && d.bigPath) {
             const BigGeom gB = d.gB;
             (void)hipMemsetAsync(d.big, 0, ((size_t)d.bigTiles << 12) * sizeof(double), s);
-            hipLaunchKernelGGL(k_bal_schur_pairs, dim3(d.nPairsNZ), dim3(kBigPairThreads), 0, s, W, wp(par), firstTrial ? 1 : 0);
+            if (d.nPairsLong) hipLaunchKernelGGL(k_bal_schur_pairs<256>, dim3(d.nPairsLong), dim3(256), 0, s, W, wp(par), firstTrial ? 1 : 0, 0);
+            if (d.nPairsNZ > d.nPairsLong) hipLaunchKernelGGL(k_bal_schur_pairs<64>, dim3(d.nPairsNZ - d.nPairsLong), dim3(64), 0, s, W, wp(par), firstTrial ? 1 : 0, d.nPairsLong);
             const int nbk = gB.N / kBigNB;
             hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, W, wp(par));
+            BigStepArgs A = d.bigArgs;
+            A.ctl = d.bigCtl0 + 8 * (par & 1);
             for (int kb = 0; kb < nbk; kb++) {
                 // the panel's work list: the trailing tiles both of whose tile rows are live in the panel's tile column (a dense system: every trailing tile)
-                hipLaunchKernelGGL(k_bal_step, dim3(d.bigPanelStart[kb + 1] - d.bigPanelStart[kb]), dim3(256), 0, s, W, wp(par), kb, kb + 1 == nbk ? 1 : 0, d.bigPanelStart[kb]);
+                const int4* rec = d.bigPanelWork + 2 * (size_t)d.bigPanelStart[kb];
+                A.wa0 = rec[0]; A.wb0x = rec[1].x;
+                hipLaunchKernelGGL(k_bal_step, dim3(d.bigPanelStart[kb + 1] - d.bigPanelStart[kb]), dim3(256), 0, s, A, kb, kb + 1 == nbk ? 1 : 0, d.bigPanelStart[kb]);
             }
+            hipLaunchKernelGGL(k_bal_linv, dim3(eao::cdiv(nbk, 2)), dim3(64), 0, s, W, wp(par), nbk);
             for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
                 hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, W, wp(par), J);
         } else if (nF && d.usePairs && d.solveTiles && d.wmode) {
@@ -3831,7 +4099,8 @@ struct BAJob {
     int mode = 0, robust = 1; const eao_ba_planes* pl = nullptr; float* planes_out = nullptr;
     LMContext* c = nullptr; LMTraceHost* tr = nullptr;
     int nPo = 0, nPl = 0, Ept = 0, Epl = 0, nC = 0, nP = 0, E = 0;
-    bool hasPl = false, trivial = false, chained = false, pollStop = false;
+    bool hasPl = false, trivial = false, chained = false, pollStop = false, lazy = false;
+    int nPairsLong = 0;        // map-scale path: the camera pairs that take the four-wave assembly kernel
     BADev D; BADev* dW = nullptr;
     BALaunch L;
     int curHost = 0;
@@ -3983,8 +4252,8 @@ struct BAJob {
         need += (size_t)nP * 9 * 8 + 2048 + 256;      // Tl, ul, the zero block
         need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
-            need += (2 * ((size_t)bigTiles << 12) + (size_t)bg.N * kBigNB) * 8;
-            need += (3 * lpEntries + 3 * lpPairsMax + 8) * 4 + (tileMap.size() + panelStart.size() + 8) * 4 + panelWork.size() * sizeof(int4) + 2048;
+            need += (2 * ((size_t)bigTiles << 12) + 2 * (size_t)bg.N * kBigNB) * 8;
+            need += (3 * lpEntries + 4 * lpPairsMax + 8) * 4 + (tileMap.size() + panelStart.size() + 8) * 4 + panelWork.size() * sizeof(int4) + 2048;
         } else {
             need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
             need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * (4 + 16);   // landmark lists / item records of the camera pairs
@@ -3992,6 +4261,9 @@ struct BAJob {
             need += (size_t)nC * (nC + 1) / 2 * 4;
         }
         if ((st = c.bytes.reserve(need))) return st;
+        if (bigPath && getenv("EAO_DEBUG_STAMPS"))
+            fprintf(stderr, "[eao map-scale arena] %.1f MB for this problem (%d x %d tile grid, %d live tiles = %.1f MB in the two pools, %zu work records), context arena %.1f MB\n",
+                    need / 1e6, bigT, bigT, bigTiles, 2.0 * bigTiles * 32768 / 1e6, panelWork.size() / 2, c.bytes.n / 1e6);
         Arena a{c.bytes.p, c.bytes.n};
         std::memset(&D, 0, sizeof(D));
         D.nCams = nC; D.nPts = nP; D.nEdges = E;
@@ -4011,6 +4283,7 @@ struct BAJob {
         int* dctl = a.take<int>(16);   // two control blocks: see BADecision
         int* dlpStart = a.take<int>(bigPath ? lpPairsMax + 1 : 1);
         int* dlpPair = a.take<int>(bigPath ? 2 * lpPairsMax : 1);
+        int* dlpOrder = a.take<int>(bigPath ? lpPairsMax : 1);
         int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
         int* dlpE1 = a.take<int>(bigPath ? lpEntries : 1);
         int* dlpE2 = a.take<int>(bigPath ? lpEntries : 1);
@@ -4048,15 +4321,16 @@ struct BAJob {
         D.bigL = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
         D.bigTile = dbigTile; D.bigT = bigT; D.bigTiles = bigTiles; D.bigWork = dbigWork; D.bigDense = bigPath && bigTiles == bigT * (bigT + 1) / 2 ? 1 : 0;
         D.bigDiag = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
+        D.bigLinv = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
         D.bigFail = a.take<int>(4);
-        D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpPts = dlpPts; D.lpE1 = dlpE1; D.lpE2 = dlpE2;
+        D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpOrder = dlpOrder; D.lpPts = dlpPts; D.lpE1 = dlpE1; D.lpE2 = dlpE2;
         D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
         D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
         D.lm0 = a.take<double>(16);
         D.solveOk = a.take<int>(4);
         D.doneCnt = a.take<int>(4);
         D.wgPart = a.take<double>(2 * (size_t)eao::cdiv(std::max(nP, 1) * 8, 256) + 2);
-        long long* ddbg = a.take<long long>(16);
+        long long* ddbg = a.take<long long>(32);
         D.dbg = getenv("EAO_DEBUG_STAMPS") ? ddbg : nullptr;
         EAO_REQUIRE(a.off <= a.cap, "internal: arena overflow");
         D.obs = dobs; D.info = dinfo; D.ecam = decam; D.ept = dept; D.eflag = dflag;
@@ -4180,6 +4454,14 @@ struct BAJob {
                 for (int k = nz; k > 0; k--) lpStart[k] = lpStart[k - 1];   // cursors ended at the next pair's start: shift back
                 lpStart[0] = 0;
                 D.nPairsNZ = nz;
+                nPairsLong = 0;
+                {   // launch order: long pairs first
+                    int* lpOrder = (int*)hostp(dlpOrder);
+                    int at = 0;
+                    for (int k = 0; k < nz; k++) if (lpStart[k + 1] - lpStart[k] > kBigPairLong) lpOrder[at++] = k;
+                    nPairsLong = at;
+                    for (int k = 0; k < nz; k++) if (lpStart[k + 1] - lpStart[k] <= kBigPairLong) lpOrder[at++] = k;
+                }
             }
         }
         // ---- launch geometry and solver choice of this window
@@ -4195,8 +4477,11 @@ struct BAJob {
         d.tileLds = tile_solver_lds(std::max(nF, 1));
         d.tiles3 = tile_geom(std::max(nF, 1)).nTiles <= 3 * (kTileThreads / 64);
         d.gB = big_geom(std::max(nF, 1));
-        d.nPairsNZ = D.nPairsNZ; d.big = D.big; d.bigTiles = bigTiles;
+        d.nPairsNZ = D.nPairsNZ; d.nPairsLong = nPairsLong; d.big = D.big; d.bigTiles = bigTiles;
         d.bigPanelStart = bigPath ? panelStart.data() : nullptr;
+        d.bigPanelWork = bigPath ? panelWork.data() : nullptr;
+        d.bigCtl0 = D.ctl0;
+        d.bigArgs = BigStepArgs{D.big, D.bigL, D.bigDiag, D.bigFail, D.bigWork, D.ctl0, D.dbg, d.gB.N, make_int4(0, 0, 0, 0), 0};
         // the window record itself travels with the structure
         write_records((BADev*)hostp(dW));
         if (!deferUpload) EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));
@@ -4206,7 +4491,11 @@ struct BAJob {
         // map-scale runs (tens of milliseconds) are NOT enqueued speculatively when the caller can abort them: optimize() then
         // submits one LM iteration at a time and reads *stop in between, like g2o's forceStopFlag
         pollStop = bigPath && stop != nullptr;
-        chained = E > 0 && (nF + nL) > 0 && !pollStop;
+        // ... and never more than two LM iterations ahead of the device otherwise (`lazy`, see optimize()): a map-scale iteration is ~50 launches, and
+        // everything enqueued behind a rejected trial drains as no-ops at the launch rate -- 1.5 of 14 ms on the 200-keyframe benchmark map when all ten
+        // iterations were enqueued up front
+        lazy = bigPath && !pollStop;
+        chained = E > 0 && (nF + nL) > 0 && !pollStop && !lazy;
         return EAO_OK;
     }
 
@@ -4237,7 +4526,23 @@ struct BAJob {
                 // ---- bulk segment: every remaining iteration, one trial each.  The control block is clean at the start of
                 //      an optimize() call (zeros from the upload / reset by the outlier pass); after a takeover it is rewritten.
                 if (done > 0 && (st = set_ctl(0, done, nBad))) return st;
-                L.bulk(done, pollStop ? std::min(iterations, done + 1) : iterations, needErrors);
+                if (lazy) {
+                    // one iteration per enqueue, the next one as soon as the decision of the one before the last has landed in the pinned status block.  The
+                    // poll is a pacing hint only: a stale read enqueues later (or one no-op iteration more), never something else -- what the host acts on is
+                    // read after the stream synchronisation below, as in the bulk path.
+                    volatile const int* pseq = &c.status->seq;
+                    volatile const int* pstat = &c.status->status;
+                    static thread_local std::vector<int> seqAt;
+                    seqAt.assign((size_t)iterations + 1, 0);
+                    for (int enq = done; enq < iterations; enq++) {
+                        if (enq - done >= 2) {
+                            while (*pseq - seqAt[enq - 2] < 0) { if (hipStreamQuery(L.s) != hipErrorNotReady) break; }
+                            if (*pstat != kStRunning) break;
+                        }
+                        L.bulk(enq, enq + 1, needErrors && enq == done);
+                        seqAt[enq] = L.seq;
+                    }
+                } else L.bulk(done, pollStop ? std::min(iterations, done + 1) : iterations, needErrors);
                 needErrors = false;
                 EAO_HIP(hipStreamSynchronize(L.s));
             }
@@ -4313,10 +4618,14 @@ struct BAJob {
         }
         EAO_HIP(hipGetLastError());
         if (D.dbg) {
-            long long stt[16];
+            long long stt[32];
             EAO_HIP(hipMemcpy(stt, D.dbg, sizeof(stt), hipMemcpyDeviceToHost));
             fprintf(stderr, "[eao pair stamps] workgroup 0 (a diagonal pair): loads + accumulation %lld, block sum of 42 values %lld shader-cycles; linearisation: landmark workgroup 0 %lld, camera workgroup 0 %lld\n",
                     stt[13] >> 20, stt[13] & 0xFFFFF, stt[14], stt[15]);
+            if (L.d.bigPath) fprintf(stderr, "[eao bal_backsolve stamps] super-block 1, workgroup 0: loads issued %lld, the 256-column triangle (8 blocks) %lld, removal from the columns to the left %lld shader-cycles\n",
+                                     stt[25] - stt[24], stt[26] - stt[25], stt[27] - stt[26]);
+            if (L.d.bigPath) fprintf(stderr, "[eao bal_step stamps] look-ahead workgroup of panel 2: prologue + loads + barrier %lld, row solves %lld, update %lld, tile to LDS and rows back %lld, 32 x 32 LDL^T %lld, store %lld shader-cycles\n",
+                                     stt[17] - stt[16], stt[18] - stt[17], stt[19] - stt[18], stt[20] - stt[19], stt[21] - stt[20], stt[22] - stt[21]);
             fprintf(stderr, "[eao solve stamps] assemble %lld factor %lld (panel %lld trailing %lld / %lld) backsub %lld tail %lld shader-cycles; wall(100MHz) %lld %lld %lld %lld\n",
                     stt[2] - stt[0], stt[4] - stt[2], stt[10], stt[11], stt[12], stt[6] - stt[4], stt[8] - stt[6], stt[3] - stt[1], stt[5] - stt[3], stt[7] - stt[5], stt[9] - stt[7]);
         }
