@@ -1441,7 +1441,7 @@ struct BADev {
     // Memory and work follow the non-zero structure; a map in which every keyframe sees every other one keeps every tile and runs as before.
     GP<double> big;            // bigTiles x 64 x 64: the working matrix (row-major inside a tile)
     GP<double> bigL;           // bigTiles x 64 x 64: the factor L (rows below each panel's diagonal block); row N = z
-    GP<double> bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks (1 / d on the diagonal)
+    GP<double> bigDiag;        // (N / 32) * 32 * 32: unit-lower diagonal blocks, column-major (1 / d on the diagonal)
     GP<double> bigLinv;        // (N / 32) * 32 * 32: their inverses as unit-lower blocks (k_bal_linv, for the back substitution)
     GP<int> bigFail;
     GP<const int> bigTile;     // bigT * bigT
@@ -1451,7 +1451,7 @@ struct BADev {
                                // panel is always the tile of the NEXT diagonal block (its workgroup factors it on the spot)
     GP<const int> lpStart;     // nPairsNZ + 1
     GP<const int> lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
-    GP<const int> lpOrder;     // nPairsNZ: the pairs with more than kBigPairLong entries first (four waves each), then the others (one wave each)
+    GP<const int> lpOrder;     // launch slots: the pairs with more than kBigPairLong entries first (four waves each), then the others (one wave each); -1 = idle slot
     GP<const int> lpPts;       // landmark blocks of each pair, ascending
     GP<const int> lpE1;        // ... and the landmark's edges in camera i1 / i2 (the dense point x camera table of the window path would be
     GP<const int> lpE2;        //     nP x nC ints: 400 MB for a 1000-keyframe map)
@@ -2731,7 +2731,11 @@ __global__ __launch_bounds__(NT) void k_bal_schur_pairs(const BADev* __restrict_
     const int nF = P.nFree, t = threadIdx.x;
     const BigGeom g = big_geom(nF);
     const bool lead = pairOff + (int)bx == 0;      // the first workgroup of the first launch also resets the trial's flags and padding
-    bx = P.lpOrder[pairOff + bx];
+    {
+        const int pi = P.lpOrder[pairOff + bx];
+        if (pi < 0) return;                        // (an idle slot of the XCD deal: never the first)
+        bx = pi;
+    }
     const int i1 = P.lpPair[2 * bx], i2 = P.lpPair[2 * bx + 1];
     const bool diag = i1 == i2;
     const double lambda = first ? refc::LM_TAU * P.lm[3] : P.lm[0];
@@ -2789,38 +2793,17 @@ __global__ __launch_bounds__(NT) void k_bal_schur_pairs(const BADev* __restrict_
     }
 }
 
-// LDL^T of a 32 x 32 block by ONE wavefront without LDS or barriers: lane i (and its mirror i + 32) holds row i in
-// registers (columns <= i meaningful).  Step p broadcasts the pivot and the un-normalised column p with v_readlane --
-// every index is a compile-time constant, so the rows stay in registers -- and every lane updates its row; what the lanes
-// compute above the diagonal is never read.  On return row[j] = L(i, j) for j < i and lane i's row[i] = 1 / d_i.
-// (The first version did the 32 steps with 256 threads on an LDS copy, one barrier per step: 18 us per block.)
-__device__ __forceinline__ double bal_readlane(double v, int lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-__device__ inline bool bal_factor_diag_wave(double (&row)[kBigNB]) {
-    const int lane = threadIdx.x & 31;
-    bool bad = false;
-#pragma unroll
-    for (int p = 0; p < kBigNB; p++) {
-        const double d = bal_readlane(row[p], p);
-        bad |= (d == 0.0 || !isfinite(d));
-        const double id = frcp(d);
-        const double lip = row[p] * id;
-#pragma unroll
-        for (int j = p + 1; j < kBigNB; j++) row[j] = fma(-lip, bal_readlane(row[p], j), row[j]);
-        row[p] = lane == p ? id : lip;
-    }
-    return bad;
-}
-// ---- round 5: the same two serial pieces without v_readlane and without LDS broadcasts.  gfx90a+ gives 64-bit VALU operations ONE DPP control,
+// The two serial pieces of a panel -- the row solves w = a L_kk^-T and the LDL^T of the next diagonal block -- are chains of broadcast FMAs: every lane needs
+// the same coefficient (row solve) or the pivot column's entry of row j (factorisation).  Rounds 3-4 fed them through LDS broadcast reads (a 32-column row solve:
+// 496 reads + FMAs on one thread per row, 8.5 k cycles) and v_readlane (the factorisation in one wavefront's registers, lane i = row i: 496 FMAs + 1 056 v_readlane,
+// 11.1 k cycles) -- 3.5 + 4.6 of a panel's 14 us (profiles/r05_bal_step_stamps.txt; commit 786e893 holds that code).
+// Round 5: gfx90a+ gives 64-bit VALU operations ONE DPP control,
 // row_newbcast:K (lane K of every 16-lane row to the whole row), and v_fmac_f64 has a VOP2 encoding that takes it: one instruction is
 //      acc = fma(-x[lane K of my row], y, acc)
 // -- the broadcast FMA both pieces consist of (tools/ubench/dpp_f64.hip: result and rate on gfx950).  The compiler has no builtin for 64-bit DPP, so
-// these are inline assembly; its hazard recogniser does not look inside, hence the explicit wait states where a DPP source may just have been written
-// (VALU write -> DPP read of the same VGPR: 2 wait states; an EXEC write by a VALU compare -> DPP: 5).  Every lane of the wave must be active.
-#ifndef EAO_BAL_DPP
-#define EAO_BAL_DPP 1
-#endif
+// these are inline assembly.  (The compiler's hazard recogniser does see them -- it puts `s_nop 0` between two dependent ones -- but the wait states a DPP source
+// needs behind a VALU write of the same VGPR (2) or a VALU write of EXEC (5) are spelled out where they can occur, and tools/isa_census.py --dpp-hazards checks
+// the compiled kernels for them.)  Every lane of the wave must be active.
 template <int K> __device__ __forceinline__ void bal_fmac_nb(double& acc, double src, double y) {
     asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(y), "n"(K));
 }
@@ -2835,7 +2818,7 @@ template <int B, int E, typename F> __device__ __forceinline__ void bal_static_f
 // LDL^T of a 32 x 32 block, DPP form: the matrix lives in EVERY 16-lane row of the wave -- lane l holds rows l % 16 (X0: columns 0..15) and 16 + l % 16 (X1: columns
 // 0..31), four identical replicas -- so a_jp, the un-normalised column p at row j, is lane j % 16 of the register that holds column p, and the update
 // row[j] -= l_ip a_jp is ONE v_fmac_f64_dpp per row set (616 of them per block against 496 FMAs + 1 056 v_readlane).  The same products in the same order as
-// bal_factor_diag_wave: the factors agree bit for bit.  On return X0 / X1 [j] = L(row, j) below the diagonal and 1 / d on it.
+// the v_readlane version of rounds 3-4: the factors agree bit for bit.  On return X0 / X1 [j] = L(row, j) below the diagonal and 1 / d on it.
 __device__ inline bool bal_factor_diag_dpp(double (&X0)[16], double (&X1)[kBigNB]) {
     const int l16 = threadIdx.x & 15;
     bool bad = false;
@@ -2869,28 +2852,26 @@ __device__ __forceinline__ void bal_load_rows_dpp(const double* src, int ld, dou
 #pragma unroll
     for (int j = 0; j < kBigNB; j++) X1[j] = src[(16 + l16) * ld + j];
 }
-// (lanes 0..15 store their first row, lanes 16..31 -- an identical replica -- their second one)
+// The factored block as the next panel's launch reads it, COLUMN-major: Ld[c][r] = L(r, c) below the diagonal, 1 / d on it, 0 above.  Every 16-lane row of the
+// wave holds the whole block, so lanes 0..31 write one column (rows 0..15 | 16..31) and lanes 32..63 the next one: 16 stores of 512 contiguous bytes.  (Row-major,
+// every lane wrote its own 256-byte row -- 32 partial lines per instruction; a store per pivot inside the factorisation loop costs more than it hides: 7.6 k + 0.9 k
+// cycles against 4.8 k + 2.3 k.)
 __device__ inline void bal_store_diag_dpp(double* bigDiag, int* bigFail, int kb, const double (&X0)[16], const double (&X1)[kBigNB], bool bad) {
     const int lane = threadIdx.x & 63, l16 = lane & 15;
-    double* Ld = bigDiag + (size_t)kb * kBigNB * kBigNB;
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < kBigNB; j++) Ld[l16 * kBigNB + j] = (j < 16 && j <= l16) ? X0[j < 16 ? j : 0] : 0.0;
-    } else if (lane < 32) {
-#pragma unroll
-        for (int j = 0; j < kBigNB; j++) Ld[(16 + l16) * kBigNB + j] = j <= 16 + l16 ? X1[j] : 0.0;
-    }
-    if (lane == 0 && bad) *bigFail = 1;
-}
-
-// the factored block as the panel / back-substitution kernels read it: unit-lower L below the diagonal, 1 / d ON it
-__device__ inline void bal_store_diag_wave(double* bigDiag, int* bigFail, int kb, const double (&row)[kBigNB], bool bad) {
-    const int lane = threadIdx.x & 63;
-    if (lane < kBigNB) {
-        double* Ld = bigDiag + (size_t)kb * kBigNB * kBigNB + lane * kBigNB;
-#pragma unroll
-        for (int j = 0; j < kBigNB; j++) Ld[j] = j <= lane ? row[j] : 0.0;
-    }
+    const bool up = lane & 16, odd = lane & 32;
+    double* Ld = bigDiag + (size_t)kb * kBigNB * kBigNB + (lane & 31) + (odd ? kBigNB : 0);
+    auto entry = [&](auto jc) {                       // L(row, j) as stored: this lane's row of the upper / lower half
+        constexpr int j = decltype(jc)::value;
+        double lo = 0.0;
+        if constexpr (j < 16) lo = j <= l16 ? X0[j] : 0.0;
+        const double hi = j <= 16 + l16 ? X1[j] : 0.0;
+        return up ? hi : lo;
+    };
+    bal_static_for<0, kBigNB / 2>([&](auto hc) {
+        constexpr int j = 2 * decltype(hc)::value;
+        const double e0 = entry(std::integral_constant<int, j>{}), e1 = entry(std::integral_constant<int, j + 1>{});
+        Ld[j * kBigNB] = odd ? e1 : e0;
+    });
     if (lane == 0 && bad) *bigFail = 1;
 }
 
@@ -2907,19 +2888,10 @@ __global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, i
     BA_WIN(P);
     if (P.ctl[kCtlHalt]) return;
     const double* T0 = big_tile(P.big, big_slot(P, 0, 0));
-#if EAO_BAL_DPP
     double X0[16], X1[kBigNB];
     bal_load_rows_dpp(T0, 64, X0, X1);
     const bool bad = bal_factor_diag_dpp(X0, X1);
     bal_store_diag_dpp(P.bigDiag, P.bigFail, 0, X0, X1, bad);
-#else
-    const int i = threadIdx.x & 31;
-    double row[kBigNB];
-#pragma unroll
-    for (int j = 0; j < kBigNB; j++) row[j] = T0[i * 64 + j];
-    const bool bad = bal_factor_diag_wave(row);
-    bal_store_diag_wave(P.bigDiag, P.bigFail, 0, row, bad);
-#endif
 }
 
 // One launch per 32-column panel: every 64 x 64 tile of the trailing lower triangle first solves the panel rows it needs ITSELF
@@ -2934,7 +2906,7 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
     const unsigned bx = blockIdx.x;
     __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
-    __shared__ __attribute__((aligned(16))) double a[kBigNB][kBigNB];
+    __shared__ double dv[kBigNB];                      // 1 / d of the panel's diagonal block
     __shared__ double da[kBigNB][kBigNB + 1];
     constexpr size_t ld = 64;                          // (inside a tile)
     const int k0 = kb * kBigNB, t = threadIdx.x;
@@ -2981,26 +2953,22 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
 #pragma unroll
         for (int j = 0; j < 4; j++) accq[j] = Cq[j];
     }
-    {
-        const double* Ld = A.bigDiag + (size_t)kb * kBigNB * kBigNB;
-        for (int idx = t; idx < kBigNB * kBigNB; idx += 256) a[idx >> 5][idx & 31] = Ld[idx];
-    }
-#if EAO_BAL_DPP
     // the row solves' coefficients in registers, every 16-lane row of the two solving waves a replica: lane l holds rows l % 16 and 16 + l % 16 of L_kk, so
-    // L(cc, q) is lane cc % 16 of register q -- a row_newbcast operand (see bal_fmac_nb) instead of an LDS broadcast read per FMA (8.5 k -> 3 k cycles per step)
+    // L(cc, q) is lane cc % 16 of register q -- a row_newbcast operand (see bal_fmac_nb) instead of an LDS broadcast read per FMA (8.5 k -> 5.3 k cycles per step)
     double A0[15], A1[31];
-    if (t < 128) {
-        const double* Ld = A.bigDiag + (size_t)kb * kBigNB * kBigNB + (t & 15) * kBigNB;
+    {
+        const double* Ld = A.bigDiag + (size_t)kb * kBigNB * kBigNB;      // column-major: Ld[c][r]
+        if (t < kBigNB) dv[t] = Ld[t * kBigNB + t];
+        if (t < 128) {
 #pragma unroll
-        for (int q = 0; q < 15; q++) A0[q] = Ld[q];
+            for (int q = 0; q < 15; q++) A0[q] = Ld[q * kBigNB + (t & 15)];
 #pragma unroll
-        for (int q = 0; q < 31; q++) A1[q] = Ld[16 * kBigNB + q];
+            for (int q = 0; q < 31; q++) A1[q] = Ld[q * kBigNB + 16 + (t & 15)];
+        }
     }
-#endif
     __syncthreads();
     if (stp) A.dbg[17] = clock64();
     if (t < 128) {
-#if EAO_BAL_DPP
         // (every lane takes part: a row that is not `act` solves zeros)
         asm volatile("s_nop 4");
         // columns in PAIRS (c, c + 1): a dependent v_fmac_f64_dpp issues every 12 cycles, an independent one every 8.5 (tools/ubench/dpp_f64.hip), and
@@ -3019,26 +2987,17 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
             }
         });
         bal_static_for<0, kBigNB - 1>([&](auto qc) { step(std::integral_constant<int, kBigNB - 1>{}, qc); });
-#else
-        if (act) {
-#pragma unroll
-            for (int cc = 1; cc < kBigNB; cc++) {
-#pragma unroll
-                for (int q = 0; q < cc; q++) w[cc] = fma(-w[q], a[cc][q], w[cc]);
-            }
-        }
-#endif
         if (roleW) {
 #pragma unroll
             for (int k = 0; k < kBigNB; k++) Wt[k][t] = w[k];
             if (ti == tj && act) {      // a tile row's DIAGONAL workgroup archives its panel rows (every listed row has one)
                 double* ldst = big_tile(A.bigL, pslot) + ((prow & 63) << 6) + (k0 & 63);
 #pragma unroll
-                for (int k = 0; k < kBigNB; k++) ldst[k] = w[k] * a[k][k];
+                for (int k = 0; k < kBigNB; k++) ldst[k] = w[k] * dv[k];
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < kBigNB; k++) Lt[k][t - 64] = w[k] * a[k][k];
+            for (int k = 0; k < kBigNB; k++) Lt[k][t - 64] = w[k] * dv[k];
         }
     }
     __syncthreads();
@@ -3105,7 +3064,6 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
                 for (int j = 0; j < 4; j++) Cq[(size_t)i * ld + j] = q4[i][j];
         }
         if (t < 64) {
-#if EAO_BAL_DPP
             double X0[16], X1[kBigNB];
             bal_load_rows_dpp(&da[0][0], kBigNB + 1, X0, X1);
             if (stp) A.dbg[20] = clock64();
@@ -3113,13 +3071,6 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
             if (stp) A.dbg[21] = clock64();
             bal_store_diag_dpp(A.bigDiag, A.bigFail, kb + 1, X0, X1, bad);
             if (stp) A.dbg[22] = clock64();
-#else
-            double row[kBigNB];
-#pragma unroll
-            for (int j = 0; j < kBigNB; j++) row[j] = da[t & 31][j];
-            const bool bad = bal_factor_diag_wave(row);
-            bal_store_diag_wave(A.bigDiag, A.bigFail, kb + 1, row, bad);
-#endif
         }
     }
 }
@@ -3138,14 +3089,14 @@ __global__ __launch_bounds__(64) void k_bal_linv(const BADev* __restrict__ W, in
         for (int idx = t; idx < cnt; idx += 64) reinterpret_cast<double2*>(Ls)[idx] = reinterpret_cast<const double2*>(Ld)[idx];
     }
     __syncthreads();
-    const double* L = Ls + (blk - 2 * (int)bx) * kBigNB * kBigNB;
+    const double* L = Ls + (blk - 2 * (int)bx) * kBigNB * kBigNB;      // column-major: L[c][r]
     double x[kBigNB];
 #pragma unroll
     for (int i = 0; i < kBigNB; i++) x[i] = i == j ? 1.0 : 0.0;
 #pragma unroll
     for (int m = 0; m < kBigNB - 1; m++) {
 #pragma unroll
-        for (int i = m + 1; i < kBigNB; i++) x[i] = fma(-L[i * kBigNB + m], x[m], x[i]);
+        for (int i = m + 1; i < kBigNB; i++) x[i] = fma(-L[m * kBigNB + i], x[m], x[i]);
     }
     double* dst = P.bigLinv + ((size_t)blk << 10);
 #pragma unroll
@@ -3197,7 +3148,7 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
     // the super-block's triangle, right-looking: the top block is solved by wave 0 (column c of L_kk in registers, the
     // solved entries handed down by v_readlane), then every thread owning a column to the left removes the block's 32 rows
     // from its z entry -- the 32 loads of a thread are independent of x, so they are in flight before the chain ends
-    // the rows a thread needs for block b - 1 are fetched while block b is being solved (two register buffers, A / B)
+    // the rows a thread needs for block b - 2 are requested while block b is being solved (three register buffers)
     auto fetch = [&](int b, double (&dst)[kBigNB]) {
         if (b >= 0 && t < b * kBigNB) {
             const int cb = J0 + b * kBigNB;
@@ -3213,7 +3164,7 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
         }
     };
     auto do_block = [&](int b, double (&cur)[kBigNB], double (&nxt)[kBigNB]) {
-        fetch(b - 1, nxt);
+        fetch(b - 2, nxt);
         __syncthreads();                 // xl[] of this block is final (initial load / previous block's updates)
         if (t < 64) {                    // x_b = L_bb^-T y_b: lane c sums column c of the inverse against y (zeros above the diagonal), four partial sums
             const int c = t & 31;
@@ -3239,13 +3190,16 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
         }
     };
     {
-        double rowA[kBigNB], rowB[kBigNB];
+        // (three register buffers: a block's rows are requested TWO blocks ahead -- one block of ~2 k cycles does not cover a load from the factor pool)
+        double rowA[kBigNB], rowB[kBigNB], rowC[kBigNB];
         const int top = w / kBigNB - 1;
         fetch(top, rowA);
+        fetch(top - 1, rowB);
         if (stb) P.dbg[25] = clock64();
-        for (int b = top; b >= 0; b -= 2) {
-            do_block(b, rowA, rowB);
+        for (int b = top; b >= 0; b -= 3) {
+            do_block(b, rowA, rowC);
             if (b - 1 >= 0) do_block(b - 1, rowB, rowA);
+            if (b - 2 >= 0) do_block(b - 2, rowC, rowB);
         }
     }
     __syncthreads();
@@ -3274,7 +3228,7 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
         for (int m = 0; m < kBigSB / 4; m++) v[m] = (rg + 4 * m < w && ok[m >> 4]) ? v[m] : 0.0;
         double acc = 0;
 #pragma unroll
-        for (int m = 0; m < kBigSB / 4; m++) { const int i = rg + 4 * m; if (i < w) acc = fma(v[m], xl[i], acc); }
+        for (int m = 0; m < kBigSB / 4; m++) { const int i = rg + 4 * m; const double xi = xl[i]; acc = fma(v[m], i < w ? xi : 0.0, acc); }      // (no branch per row; beyond w: 0 * 0)
         part2[rg][t & 63] = acc;
         __syncthreads();
         if (rg == 0) *zat(j) -= (part2[0][t] + part2[1][t]) + (part2[2][t] + part2[3][t]);
@@ -3928,7 +3882,7 @@ struct BADims {
     bool hasPl = false, bigPath = false, usePairs = false, solveTiles = false, tiles3 = true, wmode = false;
     size_t tileLds = 0;
     int nPairsNZ = 0;          // map-scale path (never batched)
-    int nPairsLong = 0;        // " : how many of them take the four-wave kernel (listed first in lpOrder)
+    int nPairsLong = 0, nPairsSlots = 0;        // " : launch slots of the four-wave kernel (first in lpOrder) / of both
     BigStepArgs bigArgs{};     // " : what k_bal_step takes by value (ctl / wa0 / wb0x filled per launch)
     const int* bigCtl0 = nullptr; const int4* bigPanelWork = nullptr;      // " : the control blocks on the device; the host copy of the work records
     double* big = nullptr;     // "
@@ -4002,7 +3956,7 @@ struct BALaunch {
             const BigGeom gB = d.gB;
             (void)hipMemsetAsync(d.big, 0, ((size_t)d.bigTiles << 12) * sizeof(double), s);
             if (d.nPairsLong) hipLaunchKernelGGL(k_bal_schur_pairs<256>, dim3(d.nPairsLong), dim3(256), 0, s, W, wp(par), firstTrial ? 1 : 0, 0);
-            if (d.nPairsNZ > d.nPairsLong) hipLaunchKernelGGL(k_bal_schur_pairs<64>, dim3(d.nPairsNZ - d.nPairsLong), dim3(64), 0, s, W, wp(par), firstTrial ? 1 : 0, d.nPairsLong);
+            if (d.nPairsSlots > d.nPairsLong) hipLaunchKernelGGL(k_bal_schur_pairs<64>, dim3(d.nPairsSlots - d.nPairsLong), dim3(64), 0, s, W, wp(par), firstTrial ? 1 : 0, d.nPairsLong);
             const int nbk = gB.N / kBigNB;
             hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, W, wp(par));
             BigStepArgs A = d.bigArgs;
@@ -4100,7 +4054,7 @@ struct BAJob {
     LMContext* c = nullptr; LMTraceHost* tr = nullptr;
     int nPo = 0, nPl = 0, Ept = 0, Epl = 0, nC = 0, nP = 0, E = 0;
     bool hasPl = false, trivial = false, chained = false, pollStop = false, lazy = false;
-    int nPairsLong = 0;        // map-scale path: the camera pairs that take the four-wave assembly kernel
+    int nPairsLong = 0, nPairsSlots = 0;      // map-scale path: launch slots (lpOrder) of the four-wave assembly kernel / of both kernels
     BADev D; BADev* dW = nullptr;
     BALaunch L;
     int curHost = 0;
@@ -4253,7 +4207,7 @@ struct BAJob {
         need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
             need += (2 * ((size_t)bigTiles << 12) + 2 * (size_t)bg.N * kBigNB) * 8;
-            need += (3 * lpEntries + 4 * lpPairsMax + 8) * 4 + (tileMap.size() + panelStart.size() + 8) * 4 + panelWork.size() * sizeof(int4) + 2048;
+            need += (3 * lpEntries + 5 * lpPairsMax + 72) * 4 + (tileMap.size() + panelStart.size() + 8) * 4 + panelWork.size() * sizeof(int4) + 2048;
         } else {
             need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
             need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * (4 + 16);   // landmark lists / item records of the camera pairs
@@ -4283,7 +4237,7 @@ struct BAJob {
         int* dctl = a.take<int>(16);   // two control blocks: see BADecision
         int* dlpStart = a.take<int>(bigPath ? lpPairsMax + 1 : 1);
         int* dlpPair = a.take<int>(bigPath ? 2 * lpPairsMax : 1);
-        int* dlpOrder = a.take<int>(bigPath ? lpPairsMax : 1);
+        int* dlpOrder = a.take<int>(bigPath ? 2 * lpPairsMax + 64 : 1);
         int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
         int* dlpE1 = a.take<int>(bigPath ? lpEntries : 1);
         int* dlpE2 = a.take<int>(bigPath ? lpEntries : 1);
@@ -4455,12 +4409,47 @@ struct BAJob {
                 lpStart[0] = 0;
                 D.nPairsNZ = nz;
                 nPairsLong = 0;
-                {   // launch order: long pairs first
+                {   // launch order: long pairs first; and inside each class the pairs are dealt to the eight XCDs by camera range -- workgroup b runs on XCD b % 8, a pair
+                    // list is sorted by its first camera, and the pairs of neighbouring cameras share their landmarks: dealt round-robin, every landmark's blocks were
+                    // pulled into all eight L2s (the assembly re-reads each block once per pair of its landmark: 570 MB per launch on the banded 1000-keyframe map);
+                    // with one contiguous camera range per XCD (equal shares of the entries) they stay in one or two.  A slot of -1 is an idle workgroup.
                     int* lpOrder = (int*)hostp(dlpOrder);
-                    int at = 0;
-                    for (int k = 0; k < nz; k++) if (lpStart[k + 1] - lpStart[k] > kBigPairLong) lpOrder[at++] = k;
-                    nPairsLong = at;
-                    for (int k = 0; k < nz; k++) if (lpStart[k + 1] - lpStart[k] <= kBigPairLong) lpOrder[at++] = k;
+                    const int kLong = getenv("EAO_BA_PAIR_LONG") ? atoi(getenv("EAO_BA_PAIR_LONG")) : kBigPairLong;      // (tests: the four-wave kernel on small maps)
+                    static thread_local std::vector<int> cls, grp[8];
+                    size_t at = 0;
+                    const size_t cap = 2 * (size_t)lpPairsMax + 64;
+                    bool fits = true;
+                    auto deal = [&](bool longOnes) -> int {
+                        cls.clear();
+                        long long tot = 0;
+                        for (int k = 0; k < nz; k++) if ((lpStart[k + 1] - lpStart[k] > kLong) == longOnes) { cls.push_back(k); tot += lpStart[k + 1] - lpStart[k]; }
+                        if (cls.empty()) return 0;
+                        for (auto& g8 : grp) g8.clear();
+                        long long run = 0;
+                        int x = 0, lastCam = -1;
+                        for (int k : cls) {      // a new XCD only at a camera boundary, once the running share of the entries is reached
+                            const int cam = lpPair[2 * k];
+                            if (cam != lastCam && x < 7 && run * 8 >= tot * (x + 1)) x++;
+                            lastCam = cam;
+                            grp[x].push_back(k);
+                            run += lpStart[k + 1] - lpStart[k];
+                        }
+                        size_t len = 0;
+                        for (auto& g8 : grp) len = std::max(len, g8.size());
+                        if (at + 8 * len > cap) { fits = false; return 0; }
+                        for (size_t sl = 0; sl < len; sl++)
+                            for (int q = 0; q < 8; q++) lpOrder[at++] = sl < grp[q].size() ? grp[q][sl] : -1;
+                        return (int)(8 * len);
+                    };
+                    nPairsLong = deal(true);
+                    nPairsSlots = nPairsLong + deal(false);
+                    if (!fits) {      // (one camera holds most of the pairs: plain order)
+                        at = 0;
+                        for (int k = 0; k < nz; k++) if (lpStart[k + 1] - lpStart[k] > kLong) lpOrder[at++] = k;
+                        nPairsLong = (int)at;
+                        for (int k = 0; k < nz; k++) if (lpStart[k + 1] - lpStart[k] <= kLong) lpOrder[at++] = k;
+                        nPairsSlots = (int)at;
+                    }
                 }
             }
         }
@@ -4477,7 +4466,7 @@ struct BAJob {
         d.tileLds = tile_solver_lds(std::max(nF, 1));
         d.tiles3 = tile_geom(std::max(nF, 1)).nTiles <= 3 * (kTileThreads / 64);
         d.gB = big_geom(std::max(nF, 1));
-        d.nPairsNZ = D.nPairsNZ; d.nPairsLong = nPairsLong; d.big = D.big; d.bigTiles = bigTiles;
+        d.nPairsNZ = D.nPairsNZ; d.nPairsLong = nPairsLong; d.nPairsSlots = nPairsSlots; d.big = D.big; d.bigTiles = bigTiles;
         d.bigPanelStart = bigPath ? panelStart.data() : nullptr;
         d.bigPanelWork = bigPath ? panelWork.data() : nullptr;
         d.bigCtl0 = D.ctl0;

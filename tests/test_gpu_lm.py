@@ -477,3 +477,18 @@ def test_bundle_adjustment_on_sparse_maps(gpu, oracle, name):
     _check_trace(r, o, rel=CHI2_REL_PLANES)
     _check_updates(r["poses"], o["poses"], p["poses"], "poses")
     _check_updates(r["points"], o["points"], p["points"], "points")
+
+
+@pytest.mark.parametrize("kw", [dict(n_free=80, n_fixed=1, n_points=3000, seed=5200), dict(n_free=60, n_fixed=1, n_points=2400, seed=5560, band=7)])
+def test_map_scale_assembly_with_four_wave_pairs(gpu, oracle, kw, monkeypatch):
+    """The Schur assembly of the map-scale path runs one wavefront per camera pair and FOUR for pairs with more than 2048 common landmarks (a keyframe's diagonal
+    pair on a dense map); EAO_BA_PAIR_LONG lowers the limit so that maps of test size take the four-wave kernel for most of their pairs and the one-wave kernel
+    for the rest -- both launches, the XCD deal of each class with its idle slots -- against the oracle."""
+    monkeypatch.setenv("EAO_BA_PAIR_LONG", "48")
+    p = synth.synth_ba(**kw)
+    r = gpu.Optimizer.BundleAdjustment(p, 8, bRobust=False)
+    o = oracle.bundle_adjustment(p, 8, False)
+    assert list(r["iters"]) == [int(o["iters"][0]), 0] and r["iters"][0] >= 3
+    _check_trace(r, o, rel=CHI2_REL_PLANES)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
