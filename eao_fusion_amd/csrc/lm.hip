@@ -561,10 +561,31 @@ __device__ __forceinline__ void pose_accumulate_row(double (&acc)[32], const dou
         }
     }
 }
-template <int M, int DIST>      // one halving step over ds_bpermute: M pairs (j, j + M), partner lane ^ DIST (every index a compile-time constant)
-__device__ __forceinline__ void transpose_sum_step(double (&v)[32], bool up) {
-#pragma unroll
-    for (int j = 0; j < M; j++) { const double keep = up ? v[j + M] : v[j], send = up ? v[j] : v[j + M]; v[j] = keep + __shfl_xor(send, DIST); }
+// Halving steps at lane distance 4 / 8 (inside a 16-lane DPP row) and 16 / 32 (across rows) WITHOUT selects or ds_bpermute (round 5; rounds 3-4 built `keep` / `send`
+// with four v_cndmask per pair and fetched `send` through two ds_bpermute round trips).  With A = v[j], B = v[j + M]: the lane whose distance bit is clear
+// wants A + A(partner), its partner B + B(partner).
+//   * distance 4 / 8: two bank-masked DPP moves per 32-bit half.  X = B overwritten with A(partner) in the banks whose bit is clear, Y = A overwritten with
+//     B(partner) in the banks whose bit is set; X + Y is `recv + keep` in the former and `keep + recv` in the latter -- the same sums as before (addition
+//     commutes), bit for bit.
+//   * distance 16 / 32: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows (upper half) of the first operand with the even rows (lower half)
+//     of the second -- after the swap of (A, B) every lane holds `keep` in one register and `recv` in the other.
+template <int CTRL_LO, int CTRL_HI, int BANK_LO>      // CTRL_LO: the control that reads lane + distance, CTRL_HI: lane - distance; BANK_LO: banks whose distance bit is clear
+__device__ __forceinline__ double dpp_halving_pair(double A, double B) {
+    const int al = __double2loint(A), ah = __double2hiint(A), bl = __double2loint(B), bh = __double2hiint(B);
+    const double X = __hiloint2double(__builtin_amdgcn_update_dpp(bh, ah, CTRL_LO, 0xF, BANK_LO, false), __builtin_amdgcn_update_dpp(bl, al, CTRL_LO, 0xF, BANK_LO, false));
+    const double Y = __hiloint2double(__builtin_amdgcn_update_dpp(ah, bh, CTRL_HI, 0xF, 0xF ^ BANK_LO, false), __builtin_amdgcn_update_dpp(al, bl, CTRL_HI, 0xF, 0xF ^ BANK_LO, false));
+    return X + Y;
+}
+template <bool ROW32>      // (A, B) -> keep + recv across DPP rows (distance 16) or wave halves (distance 32)
+__device__ __forceinline__ double swap_halving_pair(double A, double B) {
+    const int al = __double2loint(A), ah = __double2hiint(A), bl = __double2loint(B), bh = __double2hiint(B);
+    if constexpr (ROW32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap(al, bl, false, false), hi = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+        return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap(al, bl, false, false), hi = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+        return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
 }
 __device__ __forceinline__ double wave_transpose_sum32(double (&v)[32]) {
     const int lane = threadIdx.x & 63;
@@ -578,10 +599,12 @@ __device__ __forceinline__ double wave_transpose_sum32(double (&v)[32]) {
 #pragma unroll
         for (int j = 0; j < 8; j++) { const double keep = up ? v[j + 8] : v[j], send = up ? v[j] : v[j + 8]; v[j] = keep + dpp_quad_f64(send, true); }
     }
-    transpose_sum_step<4, 4>(v, lane & 4);
-    transpose_sum_step<2, 8>(v, lane & 8);
-    transpose_sum_step<1, 16>(v, lane & 16);
-    return v[0] + __shfl_xor(v[0], 32);
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = dpp_halving_pair<0x104, 0x114, 0x5>(v[j], v[j + 4]);      // row_shl:4 / row_shr:4, banks 0 and 2
+#pragma unroll
+    for (int j = 0; j < 2; j++) v[j] = dpp_halving_pair<0x128, 0x128, 0x3>(v[j], v[j + 2]);      // row_ror:8 either way, banks 0 and 1
+    v[0] = swap_halving_pair<false>(v[0], v[1]);
+    return swap_halving_pair<true>(v[0], v[0]);       // both halves of the wave hold the total
 }
 // which of the 32 values a lane holds after wave_transpose_sum32
 __device__ __forceinline__ int transpose_sum_index(int lane) {
@@ -653,16 +676,25 @@ __device__ __forceinline__ SE3 se3_exp_mul(const double u[6], const SE3& T) {
 // Same LM control flow as the round-2 kernel; the order of the 28 sums differs (a tree over lanes and waves instead of quads / columns /
 // segments), products are accumulated with fused multiply-adds, and exp(dx) goes through the quaternion directly.  The single call, the
 // batch and the tracker chain share this body and the same edge -> (thread, slot) map, so they agree bit for bit.
-constexpr int kPoseCand = 4;      // retrials evaluated per light pass
+constexpr int kPoseCand = 4;      // retrials evaluated per light pass (round 5, measured and not kept: a second batch of up to five -- two solves in wave 0 -- so that a run
+                                  // of nine rejections takes two light passes instead of three: the runs that close a round end on rho == 0 long before that, 36 -> 35 passes
+                                  // at 1000 correspondences, and the fifth candidate's registers slow every light pass: 0.182 -> 0.193 ms)
 template <int EPT, bool PLANES>
 __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     constexpr int kMaxWaves = kPoseThreads / 64;
-    __shared__ double red[kMaxWaves * 32];              // per-wave totals of a pass
+    __shared__ double red[2][kMaxWaves * 32];           // per-wave totals of a pass, double-buffered by pass parity (ONE barrier per heavy pass: a wave that is
+                                                        // a pass ahead writes the other buffer while slower waves still add this one up)
     __shared__ double s_sys[kMaxWaves][28];             // per wave: the linear system at the CURRENT estimate -- H (upper triangle, 21), b (6), chi2
-    __shared__ SE3 s_est[kMaxWaves];                    // per wave: the current (last accepted) estimate
-    // The candidate records are DOUBLE-BUFFERED by pass parity: a wave that has taken its decisions publishes the next pass's candidates
-    // while slower waves still read this pass's (nothing but barrier (A) separates the two)
-    __shared__ SE3 s_cpose[2][kPoseCand];               // the poses a pass evaluates
+    // Round 5: the first trial of an iteration is solved by EVERY wave for itself (same system, same instructions, same result -- a wave per SIMD, so the
+    // copies cost no time), which takes barrier (A) and the LDS round trips of the hand-over (publish, copy, read back) out of every heavy pass.  A wave keeps
+    // two pose records of its own: the current (last accepted) estimate in s_pose[wv][ei], the trial in the other one -- accepting the trial flips `ei`, nothing is
+    // copied -- and carries the trial's rotation matrix in registers into the next pass (the evaluation needs it there anyway).  (Holding the poses themselves
+    // in wave-uniform registers was measured first: 28 more SGPRs spill into VGPR lanes, +316 v_readlane in the kernel, 0.183 -> 0.191 ms.)  Only the poses of
+    // a LIGHT pass (retrials solved side by side, one per wave) still go through shared records:
+    // the candidate records are DOUBLE-BUFFERED by light-pass parity: a wave that has taken its decisions publishes the next light pass's candidates
+    // while slower waves still read this one's (nothing but barrier (A) separates the two)
+    __shared__ SE3 s_cpose[2][kPoseCand];               // the poses a light pass evaluates
+    __shared__ SE3 s_pose[kMaxWaves][2];                // per wave: estimate and trial (see above)
     __shared__ double s_cscale[2][kPoseCand];           // computeScale() of each: sum x (lambda x + b)
     __shared__ int s_cok[2][kPoseCand];                 // did its LDL^T succeed
     __shared__ double s_nb[kMaxWaves];
@@ -741,12 +773,15 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
     const bool wstamp = P.dbg != nullptr;                // per-wave stamps: evaluation (heavy / light) and reduction tree of every wave
     long long wH = 0, wL = 0, wT = 0, wt0 = 0;
     int ntrace = 0, iters = 0, npass = 0, nlight = 0;
-    int pb = 0;                                          // parity of the pass in flight (which candidate buffer it reads)
+    int pb = 0;                                          // parity of the light pass in flight (which candidate buffer it reads)
+    int rb = 0;                                          // parity of the pass in flight (which buffer of red[] it fills)
     double* const mySys = s_sys[wv];
-    double* const myEst = reinterpret_cast<double*>(&s_est[wv]);
-    // solve (H + lambda I) x = b of THIS wave's copy of the system, x -> trial pose exp(x) * est, published as candidate `slot`
-    auto solve_candidate = [&](int buf, int slot, double lambda) {
-        eao::wave_sync();               // mySys / myEst were written by lanes of this wave
+    int ei = 0;                                          // which of s_pose[wv][] holds the current estimate (wave-uniform)
+    int ci = 0;                                          // ... and which one the heavy pass in flight evaluates (ei: re-linearisation, ei ^ 1: a trial)
+    double cScale = 0; int cOk = 0;                      // computeScale() / the LDL^T's success of the trial in s_pose[wv][ei ^ 1]
+    // solve (H + lambda I) x = b of THIS wave's copy of the system, x -> trial pose exp(x) * est
+    auto solve_candidate = [&](double lambda, SE3& trialOut, double& scOut, int& okOut) {
+        eao::wave_sync();               // mySys / s_pose[wv] were written by lanes of this wave
         double A[36], b[6];
         int q = 0;
 #pragma unroll
@@ -762,13 +797,12 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
 #pragma unroll
         for (int a = 0; a < 6; a++) sc += x[a] * (lambda * x[a] + b[a]);
         const long long q1 = stamp ? clock64() : 0;
-        const SE3 trial = se3_exp_mul(x, s_est[wv]);
-        if (lane == 0) { s_cpose[buf][slot] = trial; s_cscale[buf][slot] = sc; s_cok[buf][slot] = ok; }
+        trialOut = se3_exp_mul(x, s_pose[wv][ei]);
+        scOut = sc; okOut = ok;
         if (stamp) { const long long q2 = clock64(); pa[3] += q1 - q0; pa[4] += q2 - q1; pa[5] += 1; }
     };
-    auto copy7 = [&](double* dst, const double* src) {      // an SE3 between LDS records, by seven lanes of the calling wave
-        eao::wave_sync();
-        if (lane < 7) dst[lane] = src[lane];
+    auto publish = [&](int buf, int slot, const SE3& T, double sc, int ok) {      // a light pass's candidate, by lane 0 of the calling wave
+        if (lane == 0) { s_cpose[buf][slot] = T; s_cscale[buf][slot] = sc; s_cok[buf][slot] = ok; }
     };
     __syncthreads();
     for (int round = 0; round < refc::POSE_ROUNDS; round++) {
@@ -776,24 +810,24 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
 #pragma unroll
         for (int k = 0; k < EPT; k++) any |= !(eF[k] & 2);
         if (PLANES && t < M) any |= !(s_pflag[t] & 2);
-        if (lane == 0) { s_est[wv] = P.T0; if (wv == 0) s_cpose[pb][0] = P.T0; }      // every round restarts from the frame's pose (src/Optimizer.cc:547)
-        const int active = __syncthreads_or(any);                                       // (also barrier (A) of the round's first pass)
+        if (lane == 0) s_pose[wv][ei] = P.T0;                                           // every round restarts from the frame's pose (src/Optimizer.cc:547)
+        ci = ei;
+        PoseRt Tm = pose_rt(P.T0);                                                      // rotation matrix + translation of the pose the next heavy pass evaluates
+        const int active = __syncthreads_or(any);
         if (active) {
             // ---- the LM of this optimize() call.  Every wave carries the SAME state (wave-uniform registers), derived from the same LDS
             //      totals by the same instructions; only the side effects (trace, result) are wave 0's.
             enum { kInit = 0, kTrial1 = 1, kRetry = 2, kRefresh = 3 };
             int phase = kInit, it = 0, qmax = 0, nbad = 0, nb = 1;      // nb: poses of the pass in flight
-            bool heavy = true;
+            bool heavy = true, needA = false;
             double lambda = 0, ni = 2, curChi = 0, iniChi = 0;
-            for (bool first = true;; first = false) {
-                if (!first) { __syncthreads(); pb ^= 1; }                                    // (A) the candidate poses are published
+            for (;;) {
+                if (needA) { __syncthreads(); pb ^= 1; }                                     // (A) the candidate poses of a light pass are published
                 if (stamp) pts = clock64();
                 npass++;
                 double tot = 0;       // after the pass: lane q of every wave holds total q (heavy: 28 sums; light: chi2 of candidate q)
                 if (heavy) {
                     if (wstamp) wt0 = clock64();
-                    const SE3 T = s_cpose[pb][0];
-                    const PoseRt Tm = pose_rt(T);
                     // ---- computeActiveErrors + activeRobustChi2 + buildSystem at T
                     double acc[32];
 #pragma unroll
@@ -834,6 +868,8 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                         pose_accumulate_row<4>(acc, J2, wi, w * (info * eE[k][2]));
                     }
                     if (PLANES && M) {
+                        eao::wave_sync();
+                        const SE3 T = s_pose[wv][ci];
                         for (int pq = t; pq < 13 * M; pq += NT) {      // (a launch may have fewer threads than 13 M: 64 for a frame of 40 points)
                             const int p = pq / 13, v = pq - 13 * p;
                             if (!(s_pflag[p] & 2)) {
@@ -886,8 +922,8 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                     // ---- the wave's 28 totals (a wave without a level-0 edge contributes zeros without walking the tree)
                     if (__any(work)) {
                         const double ws = wave_transpose_sum32(acc);
-                        if (lane < 32) red[wv * 32 + transpose_sum_index(lane)] = ws;
-                    } else if (lane < 32) red[wv * 32 + lane] = 0;
+                        if (lane < 32) red[rb][wv * 32 + transpose_sum_index(lane)] = ws;
+                    } else if (lane < 32) red[rb][wv * 32 + lane] = 0;
                     if (wstamp) wT += clock64() - wt0;
                 } else {
                     // ---- LIGHT pass: the robust chi2 of up to four candidate poses (computeActiveErrors + activeRobustChi2 of each, in
@@ -926,14 +962,15 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                     for (int cnd = 0; cnd < kPoseCand; cnd++) {
                         if (cnd >= nb) continue;
                         const double ws = wave_sum_f64_lane63(chi[cnd]);
-                        if (lane == 63) red[wv * 32 + cnd] = ws;
+                        if (lane == 63) red[rb][wv * 32 + cnd] = ws;
                     }
                 }
                 __syncthreads();                                                             // (B) red[] is complete
                 lap(1);
                 // ---- totals: lane q adds value q of the waves in wave order (every wave does, for itself)
                 if (lane < 28)
-                    for (int w = 0; w < nw; w++) tot += red[w * 32 + lane];
+                    for (int w = 0; w < nw; w++) tot += red[rb][w * 32 + lane];
+                rb ^= 1;
                 bool solve1 = false, done = false, toInit = false, toRefresh = false;
                 int refreshFrom = 0;
                 if (phase == kInit) {
@@ -961,9 +998,9 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                     int cnd = 0;
                     for (; cnd < nb; cnd++) {
                         const double chiT = lane_bcast_f64(tot, phase == kTrial1 ? 27 : cnd);
-                        const double tempChi = s_cok[pb][cnd] ? chiT : DBL_MAX;
+                        const double tempChi = (phase == kTrial1 ? cOk : s_cok[pb][cnd]) ? chiT : DBL_MAX;
                         r = curChi - tempChi;
-                        r /= s_cscale[pb][cnd] + 1e-3;
+                        r /= (phase == kTrial1 ? cScale : s_cscale[pb][cnd]) + 1e-3;
                         qmax++;
                         if (r > 0 && isfinite(tempChi)) {
                             const double y = 2 * r - 1;
@@ -972,8 +1009,13 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                             lambda *= fmax(1. / 3., alpha);
                             ni = 2;
                             curChi = tempChi;
-                            copy7(myEst, reinterpret_cast<const double*>(&s_cpose[pb][cnd]));      // est = this trial
-                            if (phase == kTrial1 && lane < 28) mySys[lane] = tot;               // its system is the next iteration's
+                            if (phase == kTrial1) {
+                                ei ^= 1;                                                        // est = this trial
+                                if (lane < 28) mySys[lane] = tot;                               // its system is the next iteration's
+                            } else {                                                            // est = this retrial (seven lanes copy the record)
+                                eao::wave_sync();
+                                if (lane < 7) reinterpret_cast<double*>(&s_pose[wv][ei])[lane] = reinterpret_cast<const double*>(&s_cpose[pb][cnd])[lane];
+                            }
                             accepted = true;
                             closed = true;
                             break;
@@ -986,10 +1028,13 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                         // every candidate was rejected with rho < 0 and trials remain: the next batch of retrials (their lambdas are known)
                         phase = kRetry; heavy = false;
                         nb = min(min(kPoseCand, nw), refc::LM_MAX_TRIALS - qmax);
+                        needA = true;
                         if (wv < nb) {
                             double lc = lambda, nc = ni;
                             for (int k = 0; k < wv; k++) { lc *= nc; nc *= 2; }
-                            solve_candidate(pb ^ 1, wv, lc);
+                            SE3 tr; double sc; int ok;
+                            solve_candidate(lc, tr, sc, ok);
+                            publish(pb ^ 1, wv, tr, sc, ok);
                         }
                     } else {
                         // ---- the iteration closes here
@@ -1016,14 +1061,20 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
                     }
                 }
                 if (solve1) {
-                    phase = kTrial1; heavy = true; nb = 1;
-                    if (wv == 0) solve_candidate(pb ^ 1, 0, lambda);
+                    phase = kTrial1; heavy = true; nb = 1; needA = false;
+                    SE3 tr;
+                    solve_candidate(lambda, tr, cScale, cOk);                               // every wave, for itself
+                    ci = ei ^ 1;
+                    if (lane == 0) s_pose[wv][ci] = tr;
+                    Tm = pose_rt(tr);
                 } else if (toInit) {
-                    phase = kInit; heavy = true; nb = 1;
-                    if (wv == 0) copy7(reinterpret_cast<double*>(&s_cpose[pb ^ 1][0]), myEst);
+                    phase = kInit; heavy = true; nb = 1; needA = false;
+                    eao::wave_sync();
+                    ci = ei;
+                    Tm = pose_rt(s_pose[wv][ei]);
                 } else if (toRefresh) {
-                    phase = kRefresh; heavy = false; nb = 1;
-                    if (wv == 0) copy7(reinterpret_cast<double*>(&s_cpose[pb ^ 1][0]), reinterpret_cast<const double*>(&s_cpose[pb][refreshFrom]));
+                    phase = kRefresh; heavy = false; nb = 1; needA = true;
+                    if (wv == 0) { const SE3 Tr = s_cpose[pb][refreshFrom]; publish(pb ^ 1, 0, Tr, 0, 1); }
                 }
                 lap(2);
                 if (done) break;
@@ -1031,7 +1082,7 @@ __device__ __forceinline__ void pose_lm_fused(const PoseDev& P) {
         }
         // ---- inlier / outlier classification of every edge (src/Optimizer.cc:554-621) at the round's estimate
         eao::wave_sync();
-        const SE3 fin = s_est[wv];
+        const SE3 fin = s_pose[wv][ei];
         const PoseRt finm = pose_rt(fin);
         double nbo = 0;
 #pragma unroll
