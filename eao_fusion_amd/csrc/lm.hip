@@ -4099,6 +4099,59 @@ __global__ __launch_bounds__(256) void k_ba_upload(BAUploadArgs A) {
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) d[i] = s[i];
 }
 
+// The host threads of a batch call (window set-up workers, group leaders) are PERSISTENT: a call hands `count` tasks to the crew and
+// joins them.  Starting eight std::threads per call cost ~0.3 ms of a 2.9 ms batch (clone + first-touch of the thread's HIP state,
+// one after the other) -- which is why more set-up threads used to make a call slower.  The crew is process-wide, grows on
+// demand and is never torn down (its threads sleep on a condition variable between calls and die with the process).
+thread_local bool t_inCrew = false;      // this thread belongs to the crew: a task must not hand work to the crew itself (one call at a time owns it)
+struct HostCrew {
+    std::mutex m;
+    std::condition_variable wake, finished;
+    std::function<void(int)> fn;
+    int generation = 0, next = 0, count = 0, running = 0, threads = 0;
+    void body() {
+        t_inCrew = true;
+        int seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            wake.wait(lk, [&] { return generation != seen && next < count; });
+            while (next < count) {
+                const int i = next++;
+                running++;
+                lk.unlock();
+                fn(i);
+                lk.lock();
+                running--;
+            }
+            seen = generation;
+            if (running == 0) finished.notify_all();
+        }
+    }
+    // runs fn(0 .. n-1) on the crew (at least n threads, so tasks that wait for each other cannot starve) and fn0() on the caller
+    std::mutex callMu;      // one batch call at a time uses the crew (calls from several host threads queue up here)
+    void run(int n, const std::function<void(int)>& f, const std::function<void()>& fn0) {
+        std::lock_guard<std::mutex> oneCall(callMu);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            while (threads < n) { std::thread(&HostCrew::body, this).detach(); threads++; }
+            fn = f; next = 0; count = n; generation++;
+        }
+        wake.notify_all();
+        fn0();
+        std::unique_lock<std::mutex> lk(m);
+        finished.wait(lk, [&] { return next >= count && running == 0; });
+        count = 0;
+    }
+};
+HostCrew& host_crew() {
+    // ONE crew per process (round 4; it was one per calling thread: a pool of short-lived caller threads grew the process by ~19 sleeping threads per
+    // caller, ADVICE r3).  Its size is the largest thread count a call ever asked for (the set-up threads + group leaders of eao_local_ba_batch: about
+    // nineteen with the defaults); the threads sleep on a condition variable between calls and end with the process (detached: a static destructor
+    // that joined them would run after the HIP runtime's own teardown).
+    static HostCrew* crew = new HostCrew();
+    return *crew;
+}
+
 struct BAJob {
     const eao_ba_problem* p = nullptr; const volatile uint8_t* stop = nullptr; eao_ba_result* r = nullptr;
     int mode = 0, robust = 1; const eao_ba_planes* pl = nullptr; float* planes_out = nullptr;
@@ -4132,6 +4185,10 @@ struct BAJob {
         LMContext& c = *this->c;
         eao_status st;
         tr->clear();
+        static const bool hostStamps = getenv("EAO_DEBUG_STAMPS") != nullptr;      // host phases of the set-up, in ms on stderr
+        const auto hs0 = std::chrono::steady_clock::now();
+        double hsT[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto hs_lap = [&](int k) { if (hostStamps) hsT[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count(); };
         nPo = p->n_points; nPl = pl ? pl->n_planes : 0; Ept = p->n_edges; Epl = pl ? pl->n_pedges : 0;
         nC = p->n_cams; nP = nPo + nPl; E = Ept + Epl;          // landmarks = points then planes, edges = point edges then plane edges
         hasPl = nPl > 0;
@@ -4165,14 +4222,26 @@ struct BAJob {
         const bool bigPath = nFreeIn > kTileMaxFree || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
         const BigGeom bg = big_geom(std::max(nFreeIn, 1));
         size_t lpEntries = 0, lpPairsMax = 0;
-        if (bigPath) {   // sizes of the pair CSR: sum over the points of m (m + 1) / 2, m = observers among the free keyframes
-            std::vector<int>& fc = c.scratch;
-            fc.assign((size_t)nP, 0);
-            for (int e = 0; e < E; e++) if (!p->cam_fixed[edge_cam(e)]) fc[edge_lm(e)]++;
-            for (int i = 0; i < nP; i++) lpEntries += (size_t)fc[i] * (fc[i] + 1) / 2;
-            lpPairsMax = std::min(lpEntries, (size_t)nFreeIn * (nFreeIn + 1) / 2);
-            EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
-        }
+        // ---- round 5: the covisibility structure of the map-scale path, CAMERA-MAJOR.  For every free camera i1 (ascending) the landmarks it observes in ascending
+        //      order, and for each of them its observers i2 >= i1: the pairs (i1, i2) of camera i1 are counted in a counter array of nF entries that stays in the
+        //      cache, come out sorted, and their entries are later written into ONE contiguous range per camera -- in ascending landmark order, which is the order the
+        //      assembly's fixed-order sums need.  (Rounds 3-5 walked the landmarks and scattered every (pair, landmark) entry through a counter per pair of the
+        //      whole nF (nF + 1) / 2 triangle, three times -- once into a byte matrix for the tile structure, once to count, once to fill: 9.8 + 2.4 ms of host time in
+        //      front of 26.7 ms of device time on the banded 1000-keyframe map.)  Same arrays as before, bit for bit.
+        //      Every landmark's observer list is sorted by camera, so a camera's partners i2 >= i1 in a landmark are the SUFFIX behind its own entry: no test per
+        //      observer (it failed half the time and mispredicted).  Both walks -- counting and filling -- are split over the host crew by camera ranges of equal
+        //      size taken from a shared counter (a camera's pairs and entries are its own: no two workers write the same word).
+        static thread_local std::vector<int> fidx, lmOff, lmCam, lmEdge, cmOff, cmLm, cmU, prA, prB, prStart, cmPairStart, pcur;
+        // workers for the two walks: the crew unless this thread is one of its own (a map-scale window inside a batch call), or the map is small
+        auto crew_for = [&](size_t work, int nChunks, const std::function<void(int)>& chunk) {
+            const int hw = (int)std::thread::hardware_concurrency();
+            static const int envT = getenv("EAO_BA_SETUP_THREADS") ? atoi(getenv("EAO_BA_SETUP_THREADS")) : 0;
+            const int nT = t_inCrew || work < 200000 ? 1 : std::max(1, std::min(envT > 0 ? envT : std::min(12, hw / 2), nChunks));
+            if (nT == 1) { for (int q = 0; q < nChunks; q++) chunk(q); return; }
+            std::atomic<int> next(0);
+            auto body = [&]() { for (int q; (q = next.fetch_add(1)) < nChunks;) chunk(q); };
+            host_crew().run(nT - 1, [&](int) { body(); }, body);
+        };
         // ---- round 5: the TILE structure of the map-scale system.  Which 64 x 64 tiles of the lower triangle can ever be non-zero: the tiles a covisible camera pair's
         //      6 x 6 block touches, the diagonal, the tile row of the right-hand side -- and the fill-in of the elimination, worked out here once at tile level
         //      (eliminating tile column k joins every pair of tile rows that are live in it: the block form of the symbolic factorisation a sparse LDL^T starts
@@ -4182,38 +4251,97 @@ struct BAJob {
         static thread_local std::vector<int4> panelWork;
         int bigT = 0, bigTiles = 0;
         if (bigPath) {
-            static thread_local std::vector<int> fidx, cc, off, lst, cur;
-            static thread_local std::vector<unsigned char> live, seen;
+            static thread_local std::vector<int> cc, cnt2, touched;
+            static thread_local std::vector<unsigned char> live;
+            // free cameras with at least one edge, in ascending order (the numbering the active structure below gives them: camIdx)
             fidx.assign((size_t)nC, -1); cc.assign((size_t)nC, 0);
+            lmOff.assign((size_t)nP + 1, 0);
             for (int e = 0; e < E; e++) cc[edge_cam(e)]++;
             int nFa = 0;
             for (int i = 0; i < nC; i++) if (cc[i] && !p->cam_fixed[i]) fidx[i] = nFa++;
+            // per landmark: its free observers and their edges, in edge order (the order of the active structure's ptEdges)
+            for (int e = 0; e < E; e++) if (fidx[edge_cam(e)] >= 0) lmOff[edge_lm(e) + 1]++;
+            for (int i = 0; i < nP; i++) {
+                const int m = lmOff[i + 1];
+                lpEntries += (size_t)m * (m + 1) / 2;
+                lmOff[i + 1] += lmOff[i];
+            }
+            EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
+            lmCam.resize(lmOff[nP]); lmEdge.resize(lmOff[nP]);
+            pcur.assign(lmOff.begin(), lmOff.end() - 1);
+            cmOff.assign((size_t)nFa + 1, 0);
+            for (int e = 0; e < E; e++) {
+                const int f = fidx[edge_cam(e)];
+                if (f < 0) continue;
+                const int at = pcur[edge_lm(e)]++;
+                lmCam[at] = f; lmEdge[at] = e; cmOff[f + 1]++;
+            }
+            for (int i = 0; i < nP; i++)           // observers by camera (insertion sort: a handful per landmark, mostly in order already)
+                for (int u = lmOff[i] + 1; u < lmOff[i + 1]; u++) {
+                    const int cf = lmCam[u], ce = lmEdge[u];
+                    int v = u;
+                    for (; v > lmOff[i] && lmCam[v - 1] > cf; v--) { lmCam[v] = lmCam[v - 1]; lmEdge[v] = lmEdge[v - 1]; }
+                    lmCam[v] = cf; lmEdge[v] = ce;
+                }
+            // per free camera: its landmarks in ascending order (a counting sort over the landmarks, walked in ascending order), each with the position of the
+            // camera's own entry in that landmark's list
+            for (int f = 0; f < nFa; f++) cmOff[f + 1] += cmOff[f];
+            cmLm.resize(cmOff[nFa]); cmU.resize(cmOff[nFa]);
+            pcur.assign(cmOff.begin(), cmOff.end() - 1);
+            for (int i = 0; i < nP; i++)
+                for (int u = lmOff[i]; u < lmOff[i + 1]; u++) { const int at = pcur[lmCam[u]]++; cmLm[at] = i; cmU[at] = u; }
+            hs_lap(5);
+            // the pairs of every camera and their entry counts: chunks of cameras, each into lists of its own, joined in camera order
+            constexpr int kChunkCams = 16;
+            const int nChunks = (nFa + kChunkCams - 1) / kChunkCams;
+            static thread_local std::vector<std::vector<int>> chB, chCnt;
+            chB.resize(nChunks); chCnt.resize(nChunks);
+            cmPairStart.assign((size_t)nFa + 1, 0);
+            {
+                int* const pairsOfCam = cmPairStart.data() + 1;
+                const int* const lmOffp = lmOff.data(); const int* const lmCamp = lmCam.data(); const int* const cmOffp = cmOff.data();
+                const int* const cmLmp = cmLm.data(); const int* const cmUp = cmU.data();
+                std::vector<int>* const chBp = chB.data(); std::vector<int>* const chCntp = chCnt.data();
+                crew_for(lpEntries, nChunks, [=](int q) {
+                    static thread_local std::vector<int> cnt2, touched;
+                    cnt2.assign((size_t)nFa, 0);
+                    std::vector<int>& oB = chBp[q]; std::vector<int>& oC = chCntp[q];
+                    oB.clear(); oC.clear();
+                    for (int i1 = q * kChunkCams; i1 < std::min(nFa, (q + 1) * kChunkCams); i1++) {
+                        touched.clear();
+                        for (int k = cmOffp[i1]; k < cmOffp[i1 + 1]; k++)
+                            for (int u = cmUp[k], ue = lmOffp[cmLmp[k] + 1]; u < ue; u++) { const int i2 = lmCamp[u]; if (cnt2[i2]++ == 0) touched.push_back(i2); }
+                        std::sort(touched.begin(), touched.end());
+                        for (int i2 : touched) { oB.push_back(i2); oC.push_back(cnt2[i2]); cnt2[i2] = 0; }
+                        pairsOfCam[i1] = (int)touched.size();
+                    }
+                });
+            }
+            hs_lap(6);
+            prA.clear(); prB.clear(); prStart.clear();
+            int run = 0;
+            for (int q = 0; q < nChunks; q++) {
+                size_t at = 0;
+                for (int i1 = q * kChunkCams; i1 < std::min(nFa, (q + 1) * kChunkCams); i1++) {
+                    const int np = cmPairStart[i1 + 1];
+                    for (int k = 0; k < np; k++, at++) { prA.push_back(i1); prB.push_back(chB[q][at]); prStart.push_back(run); run += chCnt[q][at]; }
+                    cmPairStart[i1 + 1] = (int)prA.size();
+                }
+            }
+            prStart.push_back(run);
+            EAO_REQUIRE((size_t)run == lpEntries, "internal: covisibility count mismatch (%d entries counted, %zu expected)", run, lpEntries);
+            lpPairsMax = prA.size();
+            hs_lap(7);
             const BigGeom g = big_geom(std::max(nFa, 1));
             bigT = g.RP / 64;
             const int T = bigT, tN = g.N >> 6;
             live.assign((size_t)T * T, 0);
-            {
-                // which camera pairs share a landmark (one byte per ordered pair, one store per landmark and pair: this walk runs in every call) ...
-                const std::vector<int>& fc = c.scratch;      // free observers per landmark (counted above)
-                off.assign((size_t)nP + 1, 0);
-                for (int i = 0; i < nP; i++) off[i + 1] = off[i] + fc[i];
-                lst.resize(off[nP]);
-                cur.assign(off.begin(), off.end() - 1);
-                for (int e = 0; e < E; e++) { const int f = fidx[edge_cam(e)]; if (f >= 0) lst[cur[edge_lm(e)]++] = f; }
-                seen.assign((size_t)nFa * nFa, 0);
-                for (int i = 0; i < nP; i++)
-                    for (int u = off[i]; u < off[i + 1]; u++) {
-                        unsigned char* row = &seen[(size_t)lst[u] * nFa];
-                        for (int v = off[i]; v < off[i + 1]; v++) row[lst[v]] = 1;
-                    }
-                // ... and the tiles their 6 x 6 blocks touch
-                for (int hi = 0; hi < nFa; hi++)
-                    for (int lo = 0; lo <= hi; lo++) {
-                        if (!seen[(size_t)hi * nFa + lo]) continue;
-                        const int r0 = (6 * hi) >> 6, r1 = (6 * hi + 5) >> 6, c0 = (6 * lo) >> 6, c1 = (6 * lo + 5) >> 6;
-                        live[(size_t)std::max(r0, c0) * T + std::min(r0, c0)] = 1; live[(size_t)std::max(r0, c1) * T + std::min(r0, c1)] = 1;
-                        live[(size_t)std::max(r1, c0) * T + std::min(r1, c0)] = 1; live[(size_t)std::max(r1, c1) * T + std::min(r1, c1)] = 1;
-                    }
+            // the tiles the pairs' 6 x 6 blocks touch
+            for (size_t k = 0; k < prA.size(); k++) {
+                const int lo = prA[k], hi = prB[k];
+                const int r0 = (6 * hi) >> 6, r1 = (6 * hi + 5) >> 6, c0 = (6 * lo) >> 6, c1 = (6 * lo + 5) >> 6;
+                live[(size_t)std::max(r0, c0) * T + std::min(r0, c0)] = 1; live[(size_t)std::max(r0, c1) * T + std::min(r0, c1)] = 1;
+                live[(size_t)std::max(r1, c0) * T + std::min(r1, c0)] = 1; live[(size_t)std::max(r1, c1) * T + std::min(r1, c1)] = 1;
             }
             for (int t = 0; t < T; t++) live[(size_t)t * T + t] = 1;
             for (int t = 0; t <= tN; t++) live[(size_t)tN * T + t] = 1;      // the right-hand side row N (and the z it becomes) spans every column
@@ -4249,6 +4377,7 @@ struct BAJob {
             panelStart[nbk] = (int)(panelWork.size() / 2);
             EAO_REQUIRE(panelWork.size() < ((size_t)1 << 28), "tile structure too large (%zu work records)", panelWork.size() / 2);
         }
+        hs_lap(0);
         size_t need = 0;
         need += (size_t)E * (3 * 4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 1 + 24 + 18 * 8);
         need += (size_t)nP * (3 + 3 + 9 + 3 + 3 + 1 + 1) * 8 + (size_t)nP * 16 + (bigPath ? 64 : (size_t)nP * nC * 4);
@@ -4391,6 +4520,7 @@ struct BAJob {
             // The problem itself (observations, indices, initial state, flags) is on its way to the device while the host builds
             // the active structure below; the structure follows in a second copy.
             offSplit = (size_t)((unsigned char*)dcamIdx - a.base) & ~(size_t)255;
+            hs_lap(1);
             if (!deferUpload) EAO_HIP(hipMemcpyAsync(a.base + off0, c.pin + off0, offSplit - off0, hipMemcpyHostToDevice, s));
             // ---- active structure: SparseOptimizer::initializeOptimization(level 0) + buildIndexMapping
             int* camIdx = (int*)hostp(dcamIdx); int* ptIdx = (int*)hostp(dptIdx);
@@ -4423,6 +4553,7 @@ struct BAJob {
                     camCnt[cam] = l;
                 }
             D.nFree = nF; D.nL = nL;
+            hs_lap(2);
             if (bigPath && nF > 0) {
                 // covisibility CSR: for every camera pair (i1 <= i2) sharing a landmark, the landmark blocks in ascending order
                 // (counting sort over the landmarks' observer lists; the diagonal pairs carry each camera's own landmarks)
@@ -4431,33 +4562,36 @@ struct BAJob {
                 EAO_REQUIRE(big_geom(nF).RP / 64 == bigT, "internal: tile structure built for another system size");
                 std::memcpy(hostp(dbigTile), tileMap.data(), tileMap.size() * sizeof(int));
                 if (!panelWork.empty()) std::memcpy(hostp(dbigWork), panelWork.data(), panelWork.size() * sizeof(int4));
-                static thread_local std::vector<int> pcnt, obs, obsE;
-                pcnt.assign((size_t)nF * (nF + 1) / 2, 0);
-                auto each_pair = [&](auto&& fn) {      // fn(pair slot index, landmark, its edge in the pair's first camera, in its second)
-                    for (int l = 0; l < nL; l++) {
-                        obs.clear(); obsE.clear();
-                        for (int k = ptStart[l]; k < ptStart[l + 1]; k++) { const int ci = camIdx[edge_cam(ptEdges[k])]; if (ci >= 0) { obs.push_back(ci); obsE.push_back(ptEdges[k]); } }
-                        for (size_t u = 0; u < obs.size(); u++)
-                            for (size_t v = u; v < obs.size(); v++) {
-                                const bool uFirst = obs[u] <= obs[v];
-                                fn(pair_index(std::min(obs[u], obs[v]), std::max(obs[u], obs[v]), nF), l, obsE[uFirst ? u : v], obsE[uFirst ? v : u]);
+                // (the pairs, their entry counts and every camera's landmark list were worked out above, before the arena was sized)
+                EAO_REQUIRE((int)cmPairStart.size() == nF + 1, "internal: covisibility structure built for another set of free keyframes");
+                const int nz = (int)prA.size();
+                for (int k = 0; k < nz; k++) { lpPair[2 * k] = prA[k]; lpPair[2 * k + 1] = prB[k]; }
+                std::memcpy(lpStart, prStart.data(), ((size_t)nz + 1) * sizeof(int));
+                const size_t nEnt = (size_t)prStart[nz];
+                const auto f0 = std::chrono::steady_clock::now();
+                {
+                    constexpr int kChunkCams = 16;
+                    const int nChunks = (nF + kChunkCams - 1) / kChunkCams;
+                    const int* const lmOffp = lmOff.data(); const int* const lmCamp = lmCam.data(); const int* const lmEdgep = lmEdge.data(); const int* const cmOffp = cmOff.data();
+                    const int* const cmLmp = cmLm.data(); const int* const cmUp = cmU.data(); const int* const prBp = prB.data(); const int* const prStartp = prStart.data();
+                    const int* const cmPairStartp = cmPairStart.data();
+                    crew_for(nEnt, nChunks, [=](int q) {
+                        static thread_local std::vector<int> cur;
+                        cur.resize((size_t)nF);
+                        for (int i1 = q * kChunkCams; i1 < std::min(nF, (q + 1) * kChunkCams); i1++) {
+                            for (int k = cmPairStartp[i1]; k < cmPairStartp[i1 + 1]; k++) cur[prBp[k]] = prStartp[k];      // fill cursors of camera i1's pairs
+                            for (int k = cmOffp[i1]; k < cmOffp[i1 + 1]; k++) {
+                                const int i = cmLmp[k], l = ptIdx[i], u0 = cmUp[k], e1 = lmEdgep[u0];
+                                for (int u = u0, ue = lmOffp[i + 1]; u < ue; u++) {
+                                    const int at = cur[lmCamp[u]]++;
+                                    lpPts[at] = l; lpE1[at] = e1; lpE2[at] = lmEdgep[u];
+                                }
                             }
-                    }
-                };
-                each_pair([&](int pi, int, int, int) { pcnt[pi]++; });
-                int nz = 0, run = 0, pi = 0;
-                for (int i1 = 0; i1 < nF; i1++)
-                    for (int i2 = i1; i2 < nF; i2++, pi++) {
-                        const int cnt0 = pcnt[pi];
-                        if (!cnt0) { pcnt[pi] = -1; continue; }
-                        lpPair[2 * nz] = i1; lpPair[2 * nz + 1] = i2; lpStart[nz] = run;
-                        pcnt[pi] = nz;            // the pair's slot; lpStart[slot] doubles as the fill cursor below
-                        run += cnt0; nz++;
-                    }
-                lpStart[nz] = run;
-                each_pair([&](int pi2, int l, int ea, int eb) { const int at = lpStart[pcnt[pi2]]++; lpPts[at] = l; lpE1[at] = ea; lpE2[at] = eb; });
-                for (int k = nz; k > 0; k--) lpStart[k] = lpStart[k - 1];   // cursors ended at the next pair's start: shift back
-                lpStart[0] = 0;
+                        }
+                    });
+                }
+                if (hostStamps) fprintf(stderr, "[eao map-scale host set-up] pair CSR fill: %zu entries, %d pairs, %.3f ms\n", nEnt, nz,
+                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count());
                 D.nPairsNZ = nz;
                 nPairsLong = 0;
                 {   // launch order: long pairs first; and inside each class the pairs are dealt to the eight XCDs by camera range -- workgroup b runs on XCD b % 8, a pair
@@ -4504,6 +4638,7 @@ struct BAJob {
                 }
             }
         }
+        hs_lap(3);
         // ---- launch geometry and solver choice of this window
         const int nF = D.nFree, nL = D.nL;
         BADims& d = L.d;
@@ -4536,6 +4671,13 @@ struct BAJob {
         // iterations were enqueued up front
         lazy = bigPath && !pollStop;
         chained = E > 0 && (nF + nL) > 0 && !pollStop && !lazy;
+        hs_lap(4);
+        if (hostStamps && bigPath)
+            fprintf(stderr, "[eao map-scale host set-up] observer / camera lists %.3f, pair counts %.3f, pair list %.3f, tiles + symbolic elimination + work records %.3f ms\n",
+                    hsT[5], hsT[6] - hsT[5], hsT[7] - hsT[6], hsT[0] - hsT[7]);
+        if (hostStamps && bigPath)
+            fprintf(stderr, "[eao map-scale host set-up] tile structure + symbolic elimination %.3f, arena + problem pack %.3f, active structure %.3f, pair CSR + launch order %.3f, records + upload enqueue %.3f ms (cumulative %.3f)\n",
+                    hsT[0], hsT[1] - hsT[0], hsT[2] - hsT[1], hsT[3] - hsT[2], hsT[4] - hsT[3], hsT[4]);
         return EAO_OK;
     }
 
@@ -4689,19 +4831,25 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     if (st) return st;
     BAJob j;
     j.p = p; j.stop = stop; j.r = r; j.mode = mode; j.robust = robust; j.pl = pl; j.planes_out = planes_out; j.c = &c; j.tr = &g_trace;
+    static const bool hostStamps = getenv("EAO_DEBUG_STAMPS") != nullptr;
+    const auto w0 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); };
     EAO_HIP(hipEventRecord(c.ev0, c.stream));
     if ((st = j.prepare(c.stream))) return st;
     if (j.trivial) return EAO_OK;
+    const double tPrep = ms();
     if ((st = j.L.attributes())) return st;
     j.L.setup();
     if (j.chained) {
         j.L.chain(mode, p->its_first, p->its_second);
         EAO_HIP(hipStreamSynchronize(c.stream));
     }
+    const double tSetup = ms();
     if ((st = j.complete())) return st;
     EAO_HIP(hipEventRecord(c.ev1, c.stream));
     EAO_HIP(hipStreamSynchronize(c.stream));
     EAO_HIP(hipEventElapsedTime(&g_trace.deviceMs, c.ev0, c.ev1));
+    if (hostStamps && j.L.d.bigPath) fprintf(stderr, "[eao map-scale wall] prepare %.3f, set-up launches (+ chain) %.3f, iterations + results %.3f ms; whole call %.3f ms\n", tPrep, tSetup - tPrep, ms() - tSetup, ms());
     return EAO_OK;
 }
 
@@ -4732,56 +4880,6 @@ struct BABatchPool {
 thread_local BABatchPool g_batch;
 constexpr int kBatchGroups = 4, kBatchGroupMin = 4;     // default number of window groups / fewest windows worth a group
 
-// The host threads of a batch call (window set-up workers, group leaders) are PERSISTENT: a call hands `count` tasks to the crew and
-// joins them.  Starting eight std::threads per call cost ~0.3 ms of a 2.9 ms batch (clone + first-touch of the thread's HIP state,
-// one after the other) -- which is why more set-up threads used to make a call slower.  The crew is process-wide, grows on
-// demand and is never torn down (its threads sleep on a condition variable between calls and die with the process).
-struct HostCrew {
-    std::mutex m;
-    std::condition_variable wake, finished;
-    std::function<void(int)> fn;
-    int generation = 0, next = 0, count = 0, running = 0, threads = 0;
-    void body() {
-        int seen = 0;
-        for (;;) {
-            std::unique_lock<std::mutex> lk(m);
-            wake.wait(lk, [&] { return generation != seen && next < count; });
-            while (next < count) {
-                const int i = next++;
-                running++;
-                lk.unlock();
-                fn(i);
-                lk.lock();
-                running--;
-            }
-            seen = generation;
-            if (running == 0) finished.notify_all();
-        }
-    }
-    // runs fn(0 .. n-1) on the crew (at least n threads, so tasks that wait for each other cannot starve) and fn0() on the caller
-    std::mutex callMu;      // one batch call at a time uses the crew (calls from several host threads queue up here)
-    void run(int n, const std::function<void(int)>& f, const std::function<void()>& fn0) {
-        std::lock_guard<std::mutex> oneCall(callMu);
-        {
-            std::unique_lock<std::mutex> lk(m);
-            while (threads < n) { std::thread(&HostCrew::body, this).detach(); threads++; }
-            fn = f; next = 0; count = n; generation++;
-        }
-        wake.notify_all();
-        fn0();
-        std::unique_lock<std::mutex> lk(m);
-        finished.wait(lk, [&] { return next >= count && running == 0; });
-        count = 0;
-    }
-};
-HostCrew& host_crew() {
-    // ONE crew per process (round 4; it was one per calling thread: a pool of short-lived caller threads grew the process by ~19 sleeping threads per
-    // caller, ADVICE r3).  Its size is the largest thread count a call ever asked for (the set-up threads + group leaders of eao_local_ba_batch: about
-    // nineteen with the defaults); the threads sleep on a condition variable between calls and end with the process (detached: a static destructor
-    // that joined them would run after the HIP runtime's own teardown).
-    static HostCrew* crew = new HostCrew();
-    return *crew;
-}
 }  // namespace
 
 extern "C" {
