@@ -4235,8 +4235,9 @@ struct BAJob {
         // workers for the two walks: the crew unless this thread is one of its own (a map-scale window inside a batch call), or the map is small
         auto crew_for = [&](size_t work, int nChunks, const std::function<void(int)>& chunk) {
             const int hw = (int)std::thread::hardware_concurrency();
-            static const int envT = getenv("EAO_BA_SETUP_THREADS") ? atoi(getenv("EAO_BA_SETUP_THREADS")) : 0;
-            const int nT = t_inCrew || work < 200000 ? 1 : std::max(1, std::min(envT > 0 ? envT : std::min(12, hw / 2), nChunks));
+            const char* envS = getenv("EAO_BA_SETUP_THREADS");      // (read per call: the tests force the crew onto small maps; 1 = never)
+            const int envT = envS ? atoi(envS) : 0;
+            const int nT = t_inCrew || (work < 200000 && envT <= 0) ? 1 : std::max(1, std::min(envT > 0 ? envT : std::min(12, hw / 2), nChunks));
             if (nT == 1) { for (int q = 0; q < nChunks; q++) chunk(q); return; }
             std::atomic<int> next(0);
             auto body = [&]() { for (int q; (q = next.fetch_add(1)) < nChunks;) chunk(q); };

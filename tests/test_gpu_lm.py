@@ -492,3 +492,26 @@ def test_map_scale_assembly_with_four_wave_pairs(gpu, oracle, kw, monkeypatch):
     _check_trace(r, o, rel=CHI2_REL_PLANES)
     _check_updates(r["poses"], o["poses"], p["poses"], "poses")
     _check_updates(r["points"], o["points"], p["points"], "points")
+
+
+@pytest.mark.parametrize("kw", [dict(n_free=110, n_fixed=1, n_points=4400, seed=5610, band=3), dict(n_free=70, n_fixed=2, n_points=2500, seed=5611)])
+def test_map_scale_set_up_on_the_host_crew(gpu, oracle, kw, monkeypatch):
+    """Round 5: the covisibility structure of the map-scale path (pairs of every camera, their landmark lists) is counted and filled camera by camera, on the
+    process-wide host crew for large maps.  EAO_BA_SETUP_THREADS forces the crew onto a map of test size: the device arrays -- hence the result -- must not depend on
+    how many workers built them, and a map-scale window INSIDE a batch call (whose set-up already runs on a crew thread) builds its structure on that thread alone."""
+    p = synth.synth_ba(**kw)
+    monkeypatch.setenv("EAO_BA_SETUP_THREADS", "1")
+    one = gpu.Optimizer.BundleAdjustment(p, 6, bRobust=False)
+    for nt in ("2", "5", "12"):
+        monkeypatch.setenv("EAO_BA_SETUP_THREADS", nt)
+        r = gpu.Optimizer.BundleAdjustment(p, 6, bRobust=False)
+        assert np.array_equal(r["poses"], one["poses"]) and np.array_equal(r["points"], one["points"]) and list(r["iters"]) == list(one["iters"]), nt
+    o = oracle.bundle_adjustment(p, 6, False)
+    assert list(one["iters"]) == [int(o["iters"][0]), 0]
+    _check_updates(one["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(one["points"], o["points"], p["points"], "points")
+    # the same map as a LocalBundleAdjustment window beside small windows in one batch call: equal to its own single call
+    probs = [synth.synth_ba(seed=6200), p, synth.synth_ba(seed=6201)]
+    single = gpu.Optimizer.LocalBundleAdjustment(p)
+    batch = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
+    assert _same_result(single, batch[1])
