@@ -113,10 +113,11 @@ SYMBOLS = {
     "eao_kf_search_by_bow": None, "eao_kf_search_for_triangulation": None, "eao_kf_fuse_search": None, "eao_kf_search_by_projection_sim3": None,
     "eao_kf_search_by_projection_kf": None, "eao_kf_search_for_initialization": None, "eao_kf_search_by_sim3": None,
     # f1, second half (the device-resident tracked frame): argument lists live in tracker.py
-    "eao_tracker_create": None, "eao_tracker_destroy": None, "eao_tracker_set_local_map": None, "eao_tracker_track_local_map": None, "eao_tracker_set_options": None,
+    "eao_tracker_create": None, "eao_tracker_destroy": None, "eao_tracker_set_local_map": None, "eao_tracker_track_local_map": None, "eao_tracker_set_options": None, "eao_tracker_set_distortion": None,
     "eao_tracker_track_with_motion_model": None, "eao_tracker_track_reference_keyframe": None, "eao_abi_version": (_I, []),
     # f1 (Frame glue): argument lists live in frame.py
-    "eao_frame_is_in_frustum": None, "eao_assign_features_to_grid": None, "eao_compute_stereo_from_rgbd": None,
+    "eao_frame_is_in_frustum": None, "eao_assign_features_to_grid": None, "eao_compute_stereo_from_rgbd": None, "eao_undistort_keypoints": None,
+    "eao_compute_image_bounds": None,
     "eao_distinctive_descriptors": (_I, [_I, _P, _P, _P]),
     "eao_compute_stereo_matches": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, C.c_float, C.c_float, _P, _P]),
     "eao_pose_optimization": (_I, [C.POINTER(PoseProblem), C.POINTER(PoseResult)]),

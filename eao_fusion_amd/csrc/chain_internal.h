@@ -41,6 +41,38 @@ struct FrustumDevArgs {           // Frame::isInFrustum over device-resident map
 };
 eao_status enqueue_frustum_device(const FrustumDevArgs& a, hipStream_t s);
 
+// Frame::UndistortKeyPoints (src/Frame.cc:773-806) = cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) of OpenCV 3.x
+// (modules/imgproc/src/undistort.cpp, cvUndistortPoints; the reference asks for "OpenCV 3.0" without pinning a release): every point is
+// normalised with K in double, the distortion model (k1 k2 p1 p2 [k3]) is inverted by FIVE fixed-point iterations, and the result is
+// projected with P = K and rounded to float.  The zero tilt / identity R / P = K factors of the library multiply by exact ones and
+// zeros and are left out.  Shared by k_undistort (csrc/frame.hip) and the tracker's frame set-up (csrc/track.hip).
+struct Distortion {
+    int on;                       // 0: mDistCoef.at<float>(0) == 0.0 -- upstream copies mvKeys (src/Frame.cc:775-779)
+    double fx, fy, cx, cy, ifx, ify;
+    double k1, k2, p1, p2, k3;
+};
+inline void fill_distortion(Distortion& D, float fx, float fy, float cx, float cy, const float* dist, int nCoef) {
+    D.on = dist && nCoef >= 4 && dist[0] != 0.0f ? 1 : 0;
+    D.fx = fx; D.fy = fy; D.cx = cx; D.cy = cy; D.ifx = 1. / (double)fx; D.ify = 1. / (double)fy;
+    D.k1 = dist && nCoef > 0 ? dist[0] : 0; D.k2 = dist && nCoef > 1 ? dist[1] : 0; D.p1 = dist && nCoef > 2 ? dist[2] : 0; D.p2 = dist && nCoef > 3 ? dist[3] : 0;
+    D.k3 = dist && nCoef > 4 ? dist[4] : 0;
+}
+__host__ __device__ __forceinline__ void undistort_point(const Distortion& D, float u, float v, float& uo, float& vo) {
+    double x = ((double)u - D.cx) * D.ifx, y = ((double)v - D.cy) * D.ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1.0 / (1 + ((D.k3 * r2 + D.k2) * r2 + D.k1) * r2);      // (k4 = k5 = k6 = 0: the rational model's numerator 1 + ((k6 r2 + k5) r2 + k4) r2 is exactly 1)
+        const double deltaX = 2 * D.p1 * x * y + D.p2 * (r2 + 2 * x * x);      // (+ s1 r2 + s2 r2^2 with s = 0: adds exact zeros)
+        const double deltaY = D.p1 * (r2 + 2 * y * y) + 2 * D.p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    uo = (float)(D.fx * x + D.cx);
+    vo = (float)(D.fy * y + D.cy);
+}
+eao_status enqueue_undistort_device(const Distortion& D, int n, const float* dx, const float* dy, float* ox, float* oy, hipStream_t s);
+
 // The kernel-side view of the same test, shared by k_is_in_frustum (csrc/frame.hip) and by the tracker's first launch
 // (csrc/track.hip), whose extra workgroups run it beside the single-workgroup frame set-up.
 struct FrustumArgs {

@@ -23,6 +23,16 @@ __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumArgs A) {
     eao::frame::frustum_point(A, i);
 }
 
+// Frame::UndistortKeyPoints, src/Frame.cc:773-806: one thread per keypoint (the arithmetic: undistort_point, chain_internal.h)
+__global__ __launch_bounds__(256) void k_undistort(eao::frame::Distortion D, int n, const float* __restrict__ x, const float* __restrict__ y,
+                                                   float* __restrict__ ox, float* __restrict__ oy) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float u = x[i], v = y[i];
+    if (D.on) eao::frame::undistort_point(D, u, v, u, v);
+    ox[i] = u; oy[i] = v;
+}
+
 // One workgroup.  keys[] (LDS) = cell << 16 | index for keypoints that fall into the grid, 0xFFFFFFFF for the others and
 // for the padding up to the next power of two; after the sort the items of a cell are in ascending index (= push_back)
 // order; cell_start[c] = first position whose cell is >= c (binary search over the sorted keys).
@@ -233,7 +243,56 @@ eao_status eao_compute_stereo_from_rgbd(int32_t n, const float* kp_x, const floa
     return EAO_OK;
 }
 
+eao_status eao_undistort_keypoints(int32_t n, const float* kp_x, const float* kp_y, float fx, float fy, float cx, float cy,
+                                   const float* dist_coef, int32_t n_coef, float* out_x, float* out_y) {
+    EAO_REQUIRE(n >= 0 && n_coef >= 0 && n_coef <= 5 && (n_coef == 0 || dist_coef) && fx != 0 && fy != 0, "bad argument");
+    if (n == 0) return EAO_OK;
+    EAO_REQUIRE(kp_x && kp_y && out_x && out_y, "null argument");
+    eao::frame::Distortion D;
+    eao::frame::fill_distortion(D, fx, fy, cx, cy, dist_coef, n_coef);
+    FCtx& c = g_fctx;
+    eao_status st = c.ready();
+    if (st) return st;
+    const size_t fN = al256(4 * (size_t)n), total = 4 * fN;
+    if ((st = c.pin(total))) return st;
+    if ((st = c.dev.reserve(total))) return st;
+    std::memcpy(c.host, kp_x, 4 * (size_t)n); std::memcpy(c.host + fN, kp_y, 4 * (size_t)n);
+    hipStream_t s = c.stream;
+    EAO_HIP(hipMemcpyAsync(c.dev.p, c.host, 2 * fN, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_undistort, dim3(eao::cdiv(n, 256)), dim3(256), 0, s, D, n, (const float*)c.dev.p, (const float*)(c.dev.p + fN), (float*)(c.dev.p + 2 * fN),
+                       (float*)(c.dev.p + 3 * fN));
+    EAO_HIP(hipMemcpyAsync(c.host + 2 * fN, c.dev.p + 2 * fN, 2 * fN, hipMemcpyDeviceToHost, s));
+    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(hipGetLastError());
+    std::memcpy(out_x, c.host + 2 * fN, 4 * (size_t)n); std::memcpy(out_y, c.host + 3 * fN, 4 * (size_t)n);
+    return EAO_OK;
+}
+
+eao_status eao_compute_image_bounds(int32_t cols, int32_t rows, float fx, float fy, float cx, float cy, const float* dist_coef, int32_t n_coef,
+                                    float* bounds) {
+    EAO_REQUIRE(cols > 0 && rows > 0 && bounds && n_coef >= 0 && n_coef <= 5 && (n_coef == 0 || dist_coef), "bad argument");
+    if (!(n_coef >= 1 && dist_coef[0] != 0.0f)) {      // src/Frame.cc:836-841
+        bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+        return EAO_OK;
+    }
+    // the four corners (0, 0), (cols, 0), (0, rows), (cols, rows) through the same kernel as the keypoints (:812-821)
+    const float x[4] = {0.0f, (float)cols, 0.0f, (float)cols}, y[4] = {0.0f, 0.0f, (float)rows, (float)rows};
+    float ux[4], uy[4];
+    eao_status st = eao_undistort_keypoints(4, x, y, fx, fy, cx, cy, dist_coef, n_coef, ux, uy);
+    if (st) return st;
+    float minX = std::min(ux[0], ux[2]), maxX = std::max(ux[1], ux[3]), minY = std::min(uy[0], uy[1]), maxY = std::max(uy[2], uy[3]);      // :823-826
+    bounds[0] = std::max(minX, 0.0f); bounds[1] = std::min(maxX, (float)cols); bounds[2] = std::max(minY, 0.0f); bounds[3] = std::min(maxY, (float)rows);   // :829-832
+    return EAO_OK;
+}
+
 }  // extern "C"
+
+eao_status eao::frame::enqueue_undistort_device(const Distortion& D, int n, const float* dx, const float* dy, float* ox, float* oy, hipStream_t s) {
+    if (n <= 0) return EAO_OK;
+    hipLaunchKernelGGL(k_undistort, dim3(eao::cdiv(n, 256)), dim3(256), 0, s, D, n, dx, dy, ox, oy);
+    EAO_HIP(hipGetLastError());
+    return EAO_OK;
+}
 
 // hook for the device-resident tracking chain (csrc/track.hip): the same kernel over arrays that already live on the device
 #include "chain_internal.h"

@@ -64,6 +64,7 @@ struct eao_tracker {
     // eao_tracker_set_options (round 5): consumed by the NEXT track call
     int optMinMatches = 0, optPlanes = 0;
     unsigned char* optPlaneOut = nullptr;
+    eao::frame::Distortion dist{};     // eao_tracker_set_distortion (persistent): dist.on = the frame set-up undistorts the keypoints first
     double* plPin = nullptr; double* plDev = nullptr;      // the plane edges' records in mapped pinned memory (10 doubles each), as the pose kernel reads them
     long long* dbg = nullptr;          // EAO_DEBUG_STAMPS: phase stamps of k_track_assign_edges (diagnostic runs only)
     ~eao_tracker() {
@@ -94,7 +95,8 @@ constexpr int kFrameThreads = 1024;
 __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoint* __restrict__ kps, const int* __restrict__ nPtr, int cap,
                                                                const float* __restrict__ depth, int pitch, int W, int H, float mbf,
                                                                float minX, float minY, float invW, float invH, int cols, int rows, int npow2,
-                                                               int nMp, FrameArrays A, eao::frame::FrustumArgs FA, long long* dbg, int countingSort) {
+                                                               int nMp, FrameArrays A, eao::frame::FrustumArgs FA, long long* dbg, int countingSort,
+                                                               eao::frame::Distortion D) {
     extern __shared__ unsigned tkeys[];
     __shared__ int s_cnt, s_maxc, s_wtot[kFrameThreads / 64];
     const int t = threadIdx.x;
@@ -115,16 +117,20 @@ __global__ __launch_bounds__(kFrameThreads) void k_track_frame(const eao_keypoin
         unsigned key = 0xFFFFFFFFu;
         if (i < n) {
             const eao_keypoint kp = kps[i];
-            A.kx[i] = kp.x; A.ky[i] = kp.y; A.ang[i] = kp.angle; A.oct[i] = kp.octave;
+            // mvKeysUn (Frame::UndistortKeyPoints, src/Frame.cc:773-806): what the grid, the searches and the pose edges read; the depth image is
+            // looked up at the DISTORTED keypoint (:1024-1029)
+            float ux = kp.x, uy = kp.y;
+            if (D.on) eao::frame::undistort_point(D, kp.x, kp.y, ux, uy);
+            A.kx[i] = ux; A.ky[i] = uy; A.ang[i] = kp.angle; A.oct[i] = kp.octave;
             float ur = -1.0f, dz = -1.0f;
             const int xi = (int)kp.x, yi = (int)kp.y;          // Mat::at<float>(float v, float u): truncation
             if (depth && xi >= 0 && xi < W && yi >= 0 && yi < H) {
                 const float d = depth[(size_t)yi * pitch + xi];
-                if (d > 0) { dz = d; ur = kp.x - mbf / d; }
+                if (d > 0) { dz = d; ur = ux - mbf / d; }
             }
             A.ur[i] = ur; A.dz[i] = dz;
-            const int px = (int)roundf((kp.x - minX) * invW);      // PosInGrid, src/Frame.cc:753-757
-            const int py = (int)roundf((kp.y - minY) * invH);
+            const int px = (int)roundf((ux - minX) * invW);      // PosInGrid, src/Frame.cc:753-757
+            const int py = (int)roundf((uy - minY) * invH);
             if (px >= 0 && px < cols && py >= 0 && py < rows) key = ((unsigned)(px * rows + py) << 16) | (unsigned)i;
             // mvpMapPoints as the caller hands it over: a keypoint that already has a map point is occupied, and that map
             // point is not searched again (Tracking::SearchLocalPoints: mnLastFrameSeen == frame id).  The host entry point
@@ -975,7 +981,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     const size_t cells = (size_t)c.grid_cols * c.grid_rows, countLds = (2 * (size_t)npow2 + cells + 1) * 4;
     const int countingSort = envCount && cells <= 8 * kFrameThreads && countLds <= 60 * 1024 ? 1 : 0;
     hipLaunchKernelGGL(k_track_frame, dim3(1 + (nMp > 0 && plain ? eao::cdiv(nMp, kFrameThreads) : 0)), dim3(kFrameThreads), countingSort ? countLds : (size_t)npow2 * 4, s, d_kps, d_n, C, d_depth,
-                       depth_pitch, width, height, c.mbf, c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A, FA, h->dbg, countingSort);
+                       depth_pitch, width, height, c.mbf, c.min_x, c.min_y, invW, invH, c.grid_cols, c.grid_rows, npow2, nMp, A, FA, h->dbg, countingSort, h->dist);
     eao_status st;
     if (nMp > 0 && !bw) {
         // the search windows are built by the candidate kernel itself (one wave per map point), which leaves them in h->q for the assignment
@@ -1109,6 +1115,13 @@ eao_status eao_tracker_set_options(eao_tracker* h, const eao_track_options* opt)
     h->optMinMatches = opt->min_matches;
     h->optPlanes = opt->n_planes; h->optPlaneOut = opt->plane_outlier;
     if (opt->n_planes) eao::lm::pose_plane_records(opt->n_planes, opt->plane_world, opt->plane_obs, opt->plane_seen, h->plPin);
+    return EAO_OK;
+}
+
+eao_status eao_tracker_set_distortion(eao_tracker* h, const float* dist_coef, int32_t n_coef) {
+    EAO_REQUIRE(h && n_coef >= 0 && n_coef <= 5 && (n_coef == 0 || dist_coef), "bad argument");
+    for (int i = 0; i < n_coef; i++) EAO_REQUIRE(std::isfinite(dist_coef[i]), "a distortion coefficient is NaN / Inf");
+    eao::frame::fill_distortion(h->dist, h->cfg.fx, h->cfg.fy, h->cfg.cx, h->cfg.cy, dist_coef, n_coef);
     return EAO_OK;
 }
 

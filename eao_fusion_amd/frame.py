@@ -34,6 +34,10 @@ class Binding:
         lib.eao_assign_features_to_grid.argtypes = [_I, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P]
         lib.eao_compute_stereo_from_rgbd.restype = _I
         lib.eao_compute_stereo_from_rgbd.argtypes = [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P]
+        lib.eao_undistort_keypoints.restype = _I
+        lib.eao_undistort_keypoints.argtypes = [_I, _P, _P, _F, _F, _F, _F, _P, _I, _P, _P]
+        lib.eao_compute_image_bounds.restype = _I
+        lib.eao_compute_image_bounds.argtypes = [_I, _I, _F, _F, _F, _F, _P, _I, _P]
 
     def _raw_is_in_frustum(self, m, keep, T, Ow, sc, limit, outs):
         F = FrustumFrame()
@@ -46,6 +50,27 @@ class Binding:
 
     def _raw_rgbd(self, n, kx, ky, ku, d, w, h, mbf, ur, dz):
         self.check(self.lib.eao_compute_stereo_from_rgbd(n, kx, ky, ku, d, w, h, w, 0, mbf, ur, dz))
+
+    def _raw_undistort(self, n, kx, ky, fx, fy, cx, cy, dist, nc, ox, oy):
+        self.check(self.lib.eao_undistort_keypoints(n, kx, ky, fx, fy, cx, cy, dist, nc, ox, oy))
+
+    def _raw_bounds(self, cols, rows, fx, fy, cx, cy, dist, nc, out):
+        self.check(self.lib.eao_compute_image_bounds(cols, rows, fx, fy, cx, cy, dist, nc, out))
+
+    def undistort_keypoints(self, kp_x, kp_y, fx, fy, cx, cy, dist_coef):
+        """Frame::UndistortKeyPoints (src/Frame.cc:773-806).  dist_coef: k1, k2, p1, p2[, k3].  Returns (x, y) of mvKeysUn."""
+        kx, ky = np.ascontiguousarray(kp_x, np.float32), np.ascontiguousarray(kp_y, np.float32)
+        d = np.ascontiguousarray(dist_coef, np.float32)
+        ox, oy = np.zeros(len(kx), np.float32), np.zeros(len(kx), np.float32)
+        self._raw_undistort(len(kx), _p(kx), _p(ky), float(fx), float(fy), float(cx), float(cy), _p(d) if len(d) else None, len(d), _p(ox), _p(oy))
+        return ox, oy
+
+    def compute_image_bounds(self, cols, rows, fx, fy, cx, cy, dist_coef):
+        """Frame::ComputeImageBounds (src/Frame.cc:808-842).  Returns float32 [mnMinX, mnMaxX, mnMinY, mnMaxY]."""
+        d = np.ascontiguousarray(dist_coef, np.float32)
+        out = np.zeros(4, np.float32)
+        self._raw_bounds(int(cols), int(rows), float(fx), float(fy), float(cx), float(cy), _p(d) if len(d) else None, len(d), _p(out))
+        return out
 
     def is_in_frustum(self, frame, pts, viewing_cos_limit=0.5):
         """frame: Tcw (4x4 f32), Ow (3), fx, fy, cx, cy, mbf, min_x, max_x, min_y, max_y, log_scale_factor.
@@ -102,3 +127,11 @@ def assign_features_to_grid(kp_x, kp_y, min_x, min_y, max_x, max_y, cols=64, row
 
 def compute_stereo_from_rgbd(kp_x, kp_y, kpu_x, depth, mbf):
     return product().compute_stereo_from_rgbd(kp_x, kp_y, kpu_x, depth, mbf)
+
+
+def undistort_keypoints(kp_x, kp_y, fx, fy, cx, cy, dist_coef):
+    return product().undistort_keypoints(kp_x, kp_y, fx, fy, cx, cy, dist_coef)
+
+
+def compute_image_bounds(cols, rows, fx, fy, cx, cy, dist_coef):
+    return product().compute_image_bounds(cols, rows, fx, fy, cx, cy, dist_coef)

@@ -28,6 +28,8 @@ class TrackOptions(C.Structure):   # eao_track_options
 def _bind(L):
     L.eao_tracker_set_options.restype = _I
     L.eao_tracker_set_options.argtypes = [_P, C.POINTER(TrackOptions)]
+    L.eao_tracker_set_distortion.restype = _I
+    L.eao_tracker_set_distortion.argtypes = [_P, _P, _I]
     L.eao_tracker_create.restype = _I
     L.eao_tracker_create.argtypes = [C.POINTER(TrackerCfg), C.POINTER(_P)]
     L.eao_tracker_destroy.restype = None
@@ -68,6 +70,13 @@ class Tracker:
         m, keep = map_points(pts)
         _lib.check(self._L.eao_tracker_set_local_map(self._h, C.byref(m)))
         self.n_mp = int(m.n)
+
+    def set_distortion(self, dist_coef):
+        """mDistCoef of the camera (k1, k2, p1, p2[, k3]); persistent.  With a non-zero k1 every track_* call undistorts the frame's keypoints on the device first
+        (Frame::UndistortKeyPoints); `bounds` of the constructor are then the undistorted image bounds (frame.compute_image_bounds)."""
+        d = np.ascontiguousarray(dist_coef, np.float32)
+        self._dist = d
+        _lib.check(self._L.eao_tracker_set_distortion(self._h, d.ctypes.data if len(d) else None, len(d)))
 
     def set_options(self, min_matches=0, planes=None):
         """One-shot options of the next track_* call (eao_tracker_set_options).  planes: dict(plane_world (m, 4), plane_obs (m, 4), plane_seen (m)); the plane outlier

@@ -419,6 +419,17 @@ eao_status eao_compute_stereo_from_rgbd(int32_t n, const float* kp_x, const floa
                                         int32_t width, int32_t height, int32_t pitch, int32_t depth_on_device, float mbf,
                                         float* u_right, float* out_depth);
 
+/* Frame::UndistortKeyPoints() -- src/Frame.cc:773-806: mvKeysUn[i].pt = cv::undistortPoints(mvKeys[i].pt, mK, mDistCoef, cv::Mat(), mK) (OpenCV 3.x:
+ * five fixed-point iterations of the inverse distortion model in double, result rounded to float).  dist_coef: mDistCoef as the reference fills it
+ * (src/Tracking.cc:90-101): k1, k2, p1, p2 and, with n_coef == 5, k3.  dist_coef[0] == 0 (or n_coef == 0): the coordinates are copied, as upstream copies
+ * mvKeys (:775-779).  One thread per keypoint on the device; host arrays in and out. */
+eao_status eao_undistort_keypoints(int32_t n, const float* kp_x, const float* kp_y, float fx, float fy, float cx, float cy,
+                                   const float* dist_coef, int32_t n_coef, float* out_x, float* out_y);
+/* Frame::ComputeImageBounds(imLeft) -- src/Frame.cc:808-842: bounds = { mnMinX, mnMaxX, mnMinY, mnMaxY } from the undistorted image corners, clamped to
+ * the image ("make sure it is inside image", :828-832). */
+eao_status eao_compute_image_bounds(int32_t cols, int32_t rows, float fx, float fy, float cx, float cy, const float* dist_coef, int32_t n_coef,
+                                    float* bounds);
+
 /* f4  Frame::ComputeStereoMatches() -- src/Frame.cc:841-1013.  `left` / `right` are the two extractor handles
  * (mpORBextractorLeft / Right) right after they extracted the stereo pair: the image pyramids of frame `frame` of their
  * last batch are still on the device and are read in place (the 19-px reflect-101 border of mvImagePyramid is evaluated
@@ -619,6 +630,11 @@ typedef struct {
     uint8_t* plane_outlier;        /* out: n_planes */
 } eao_track_options;
 eao_status eao_tracker_set_options(eao_tracker* h, const eao_track_options* opt);
+/* The camera's lens distortion (mDistCoef; round 5).  With a non-zero k1 the frame set-up of every eao_tracker_track_* call undistorts the keypoints on the
+ * device first (Frame::UndistortKeyPoints, as eao_undistort_keypoints): mvuRight, the grid, the searches and the pose edges then read mvKeysUn, the depth image
+ * is looked up at the DISTORTED keypoint -- upstream's own split (src/Frame.cc:1016-1037).  cfg.min_x .. max_y are the caller's mnMinX .. mnMaxY
+ * (eao_compute_image_bounds).  Persistent for the handle; n_coef == 0 or dist_coef[0] == 0: distortion-free (the default). */
+eao_status eao_tracker_set_distortion(eao_tracker* h, const float* dist_coef, int32_t n_coef);
 
 /* Tracking::TrackWithMotionModel's data path (reference src/Tracking.cc:1717-2231) on the same chain, ahead of TrackLocalMap: the frame set-up as
  * above, ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (src/ORBmatcher.cc:1328-1472, with this fork's rotation-histogram
@@ -661,7 +677,7 @@ eao_status eao_tracker_track_reference_keyframe(eao_tracker* h, const eao_keypoi
  * changed eao_tracker_track_local_map and eao_track_result in place); a caller compiled against another version must not call into the library.
  * Result structs are zero-initialised by the caller (`eao_track_result R = {0};`) before their array pointers are set: a pointer member the
  * caller's header does not know yet then reads as NULL = "not wanted". */
-#define EAO_ABI_VERSION 5
+#define EAO_ABI_VERSION 6
 int32_t eao_abi_version(void);
 
 #ifdef __cplusplus

@@ -12,6 +12,7 @@
 #ifndef EAOFUSION_FRAME_H
 #define EAOFUSION_FRAME_H
 
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -35,21 +36,43 @@ struct MaxDistanceOf : MapPointT {
 inline void check(eao_status st, const char* what) {
     if (st != EAO_OK) throw std::runtime_error(std::string(what) + ": " + eao_last_error());
 }
-// Does the frame's camera distort?  Upstream's own test (src/Frame.cc:775: mDistCoef.at<float>(0) == 0.0 means "mvKeysUn = mvKeys"), extended to every
-// coefficient; a Frame class without the member (a stand-in) counts as distortion-free.
+// mDistCoef of the frame as the C-ABI takes it (k1, k2, p1, p2[, k3]: src/Tracking.cc:90-101); a Frame class without the member (a stand-in) is distortion-free.
 template <class FrameT, class = void>
-struct Distorted { static bool check(const FrameT&) { return false; } };
+struct DistCoefOf { static int get(const FrameT&, float*) { return 0; } };
 template <class FrameT>
-struct Distorted<FrameT, decltype(void(std::declval<const FrameT&>().mDistCoef))> {
-    static bool check(const FrameT& F) {
+struct DistCoefOf<FrameT, decltype(void(std::declval<const FrameT&>().mDistCoef))> {
+    static int get(const FrameT& F, float* out) {
         const cv::Mat& d = F.mDistCoef;
-        if (d.empty()) return false;
-        const int n = d.rows * d.cols;
-        for (int i = 0; i < n; i++) if (d.template at<float>(i) != 0.0f) return true;
-        return false;
+        if (d.empty()) return 0;
+        const int n = std::min(5, d.rows * d.cols);
+        for (int i = 0; i < n; i++) out[i] = d.template at<float>(i);
+        return n;
     }
 };
 }  // namespace detail
+
+// Frame::UndistortKeyPoints() (src/Frame.cc:773-806) without OpenCV's undistortPoints: mvKeysUn = mvKeys with the undistorted coordinates
+// (eao_undistort_keypoints: one thread per keypoint on the device).
+template <class FrameT>
+void UndistortKeyPoints(FrameT& F) {
+    float d[5] = {0, 0, 0, 0, 0};
+    const int nc = detail::DistCoefOf<FrameT>::get(F, d);
+    F.mvKeysUn = F.mvKeys;
+    if (nc == 0 || d[0] == 0.0f) return;                               // :775-779
+    const size_t n = F.mvKeys.size();
+    std::vector<float> x(n), y(n), ux(n), uy(n);
+    for (size_t i = 0; i < n; i++) { x[i] = F.mvKeys[i].pt.x; y[i] = F.mvKeys[i].pt.y; }
+    detail::check(eao_undistort_keypoints((int)n, x.data(), y.data(), F.fx, F.fy, F.cx, F.cy, d, nc, ux.data(), uy.data()), "eao_undistort_keypoints");
+    for (size_t i = 0; i < n; i++) { F.mvKeysUn[i].pt.x = ux[i]; F.mvKeysUn[i].pt.y = uy[i]; }
+}
+// Frame::ComputeImageBounds(imLeft) (src/Frame.cc:808-842): mnMinX .. mnMaxY from the undistorted image corners.
+template <class FrameT>
+void ComputeImageBounds(FrameT& F, int cols, int rows) {
+    float d[5] = {0, 0, 0, 0, 0}, b[4];
+    const int nc = detail::DistCoefOf<FrameT>::get(F, d);
+    detail::check(eao_compute_image_bounds(cols, rows, F.fx, F.fy, F.cx, F.cy, d, nc, b), "eao_compute_image_bounds");
+    F.mnMinX = b[0]; F.mnMaxX = b[1]; F.mnMinY = b[2]; F.mnMaxY = b[3];
+}
 
 // for (pMP : vpMPs) if (!skip(pMP)) if (F.isInFrustum(pMP, viewingCosLimit)) nToMatch++;   returns nToMatch.
 // skip(pMP) holds the caller's own `continue`s (src/Tracking.cc:2615-2618: mnLastFrameSeen == mCurrentFrame.mnId, isBad()).

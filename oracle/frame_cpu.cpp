@@ -94,4 +94,52 @@ int orc_stereo_from_rgbd(int32_t n, const float* kp_x, const float* kp_y, const 
     return 0;
 }
 
+// Frame::UndistortKeyPoints, src/Frame.cc:773-806.  cv::undistortPoints(src, dst, mK, mDistCoef, cv::Mat(), mK) is third-party code (OpenCV; the reference
+// asks for "OpenCV 3.0" without pinning a release, ros_test/CMakeLists.txt:24): restated from the published algorithm of OpenCV 3.x's cvUndistortPoints
+// (modules/imgproc/src/undistort.cpp) -- K and the coefficients promoted to double, x = (u - cx) / fx as a product with 1 / fx, FIVE fixed-point iterations
+//     r2 = x^2 + y^2;  icdist = (1 + ((k6 r2 + k5) r2 + k4) r2) / (1 + ((k3 r2 + k2) r2 + k1) r2)
+//     dX = 2 p1 x y + p2 (r2 + 2 x^2) + s1 r2 + s2 r2^2;   dY = p1 (r2 + 2 y^2) + 2 p2 x y + s3 r2 + s4 r2^2
+//     x = (x0 - dX) icdist;  y = (y0 - dY) icdist
+// with k4 = k5 = k6 = s1..s4 = 0 for the reference's four or five coefficients, then xx = fx x + 0 y + cx (R = I, P = K: RR = K), divided by w = 1, to float.
+int orc_undistort_keypoints(int32_t n, const float* kp_x, const float* kp_y, float fxf, float fyf, float cxf, float cyf, const float* dist, int32_t n_coef,
+                            float* out_x, float* out_y) {
+    if (n_coef < 1 || dist[0] == 0.0f) {                                       // :775-779
+        for (int i = 0; i < n; i++) { out_x[i] = kp_x[i]; out_y[i] = kp_y[i]; }
+        return 0;
+    }
+    double k[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n_coef && i < 5; i++) k[i] = dist[i];                  // k1 k2 p1 p2 k3
+    const double fx = fxf, fy = fyf, cx = cxf, cy = cyf, ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; i++) {
+        double x = kp_x[i], y = kp_y[i];
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+        out_x[i] = (float)(xx * ww); out_y[i] = (float)(yy * ww);
+    }
+    return 0;
+}
+
+// Frame::ComputeImageBounds, src/Frame.cc:808-842.  bounds = mnMinX, mnMaxX, mnMinY, mnMaxY
+int orc_compute_image_bounds(int32_t cols, int32_t rows, float fx, float fy, float cx, float cy, const float* dist, int32_t n_coef, float* bounds) {
+    if (n_coef < 1 || dist[0] == 0.0f) { bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows; return 0; }
+    const float x[4] = {0.0f, (float)cols, 0.0f, (float)cols}, y[4] = {0.0f, 0.0f, (float)rows, (float)rows};
+    float ux[4], uy[4];
+    orc_undistort_keypoints(4, x, y, fx, fy, cx, cy, dist, n_coef, ux, uy);
+    bounds[0] = std::fmin(ux[0], ux[2]); bounds[1] = std::fmax(ux[1], ux[3]);
+    bounds[2] = std::fmin(uy[0], uy[1]); bounds[3] = std::fmax(uy[2], uy[3]);
+    bounds[0] = std::fmax(bounds[0], 0.0f); bounds[1] = std::fmin(bounds[1], (float)cols);
+    bounds[2] = std::fmax(bounds[2], 0.0f); bounds[3] = std::fmin(bounds[3], (float)rows);
+    return 0;
+}
+
 }  // extern "C"

@@ -417,6 +417,10 @@ def frame_binding():
             L.orc_assign_features_to_grid.argtypes = [_I, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P]
             L.orc_stereo_from_rgbd.restype = _I
             L.orc_stereo_from_rgbd.argtypes = [_I, _P, _P, _P, _P, _I, _F, _P, _P]
+            L.orc_undistort_keypoints.restype = _I
+            L.orc_undistort_keypoints.argtypes = [_I, _P, _P, _F, _F, _F, _F, _P, _I, _P, _P]
+            L.orc_compute_image_bounds.restype = _I
+            L.orc_compute_image_bounds.argtypes = [_I, _I, _F, _F, _F, _F, _P, _I, _P]
 
         def _raw_is_in_frustum(self, m, keep, T, Ow, sc, limit, outs):
             R = np.ascontiguousarray(T[:3, :3]); t = np.ascontiguousarray(T[:3, 3])
@@ -428,5 +432,11 @@ def frame_binding():
 
         def _raw_rgbd(self, n, kx, ky, ku, d, w, h, mbf, ur, dz):
             self.lib.orc_stereo_from_rgbd(n, kx, ky, ku, d, w, mbf, ur, dz)
+
+        def _raw_undistort(self, n, kx, ky, fx, fy, cx, cy, dist, nc, ox, oy):
+            self.lib.orc_undistort_keypoints(n, kx, ky, fx, fy, cx, cy, dist, nc, ox, oy)
+
+        def _raw_bounds(self, cols, rows, fx, fy, cx, cy, dist, nc, out):
+            self.lib.orc_compute_image_bounds(cols, rows, fx, fy, cx, cy, dist, nc, out)
 
     return _FrameOracle(lib())

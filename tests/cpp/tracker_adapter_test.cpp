@@ -315,18 +315,36 @@ int main() {
         bad += rkBad;
         pts[seen[10]].nObs = 1;
     }
-    {   // a camera with lens distortion (TUM1: k1 = 0.2624, ros_test/config/TUM1.yaml:13-16): the chain would read mvKeys where upstream reads mvKeysUn -- it refuses
+    {   // a camera with lens distortion (TUM1: ros_test/config/TUM1.yaml:13-17): the adapter hands mDistCoef to the handle, the chain undistorts the keypoints itself and
+        // reads mvKeysUn where upstream does -- mvuRight must be (undistorted column) - mbf / depth(at the DISTORTED pixel), with the undistortion of eaofusion::UndistortKeyPoints
         Frame D = F;
-        if (!trk.Fits(D)) { fprintf(stderr, "Fits() is false for a distortion-free frame\n"); bad++; }
-        D.mDistCoef = cv::Mat(4, 1, CV_32F);
-        for (int i = 0; i < 4; i++) D.mDistCoef.at<float>(i) = 0.f;
-        if (!trk.Fits(D)) { fprintf(stderr, "Fits() is false for all-zero distortion coefficients\n"); bad++; }
-        D.mDistCoef.at<float>(0) = 0.2624f;
-        bool threw = false;
-        try { trk.TrackLocalMap(D, d_kps, d_desc, d_n, d_depth, W, W, H, 3.0f, 0.8f, nullptr); } catch (const std::runtime_error&) { threw = true; }
-        if (trk.Fits(D) || !threw) { fprintf(stderr, "a frame with k1 = 0.26 was accepted by the device chain\n"); bad++; }
-        D.mDistCoef.at<float>(0) = 0.f; D.mDistCoef.at<float>(3) = -0.001f;      // (upstream only looks at coefficient 0, src/Frame.cc:775; the adapter at all of them)
-        if (trk.Fits(D)) { fprintf(stderr, "a frame with p2 != 0 was accepted by the device chain\n"); bad++; }
+        D.mDistCoef = cv::Mat(5, 1, CV_32F);
+        const float tum1[5] = {0.262383f, -0.953104f, -0.005358f, 0.002628f, 1.163314f};
+        for (int i = 0; i < 5; i++) D.mDistCoef.at<float>(i) = tum1[i];
+        eaofusion::UndistortKeyPoints(D);
+        float moved = 0.f;
+        for (int k = 0; k < D.N; k++) moved = std::max(moved, std::fabs(D.mvKeysUn[k].pt.x - D.mvKeys[k].pt.x));
+        if (!(moved > 1.0f)) { fprintf(stderr, "UndistortKeyPoints moved no keypoint (max %.3f px)\n", moved); bad++; }
+        eaofusion::DeviceTracker trkD(D, cap, 1024);
+        if (!trkD.Fits(D)) { fprintf(stderr, "Fits() is false for a distorted camera\n"); bad++; }
+        trkD.SetLocalMap(local);
+        for (int k = 0; k < D.N; k++) D.mvpMapPoints[k] = nullptr;
+        trkD.TrackLocalMap(D, d_kps, d_desc, d_n, d_depth, W, W, H, 3.0f, 0.8f, nullptr);
+        int dBad = 0, stereo = 0;
+        for (int k = 0; k < D.N; k++) {
+            const float dpt = depth[(size_t)(int)D.mvKeys[k].pt.y * W + (int)D.mvKeys[k].pt.x];
+            const float want = dpt > 0 ? D.mvKeysUn[k].pt.x - D.mbf / dpt : -1.0f;
+            if (D.mvuRight[k] != want) dBad++;
+            stereo += dpt > 0;
+        }
+        if (dBad || stereo < 100) { fprintf(stderr, "distorted camera: %d of %d mvuRight entries differ from the undistorted column - mbf / depth\n", dBad, D.N); bad++; }
+        Frame Z = F;                                              // k1 == 0: upstream copies mvKeys whatever the other coefficients say (src/Frame.cc:775-779)
+        Z.mDistCoef = cv::Mat(4, 1, CV_32F);
+        for (int i = 0; i < 4; i++) Z.mDistCoef.at<float>(i) = 0.f;
+        Z.mDistCoef.at<float>(3) = -0.001f;
+        eaofusion::UndistortKeyPoints(Z);
+        for (int k = 0; k < Z.N; k++) if (Z.mvKeysUn[k].pt.x != Z.mvKeys[k].pt.x || Z.mvKeysUn[k].pt.y != Z.mvKeys[k].pt.y) { bad++; break; }
+        fprintf(stderr, "distorted camera: keypoints moved by up to %.2f px, %d stereo entries checked, %d disagreements\n", moved, stereo, dBad);
     }
     eao_tracker_destroy(h);
     fprintf(stderr, "%d keypoints, %d with a map point, %d inliers, %d disagreements\n", F.N, matched, nIn, bad);

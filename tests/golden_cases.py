@@ -270,6 +270,29 @@ def _frame_glue(api):
     return out
 
 
+# the reference's own camera files: ros_test/config/TUM1.yaml:8-17, TUM2.yaml:8-17 (fx, fy, cx, cy | k1, k2, p1, p2, k3)
+TUM_CAMERAS = {"TUM1": ((517.306408, 516.469215, 318.643040, 255.313989), (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)),
+               "TUM2": ((520.908620, 521.007327, 325.141442, 249.701764), (0.231222, -0.784899, -0.003257, -0.000105, 0.917205))}
+
+
+def _undistort(api):
+    """Frame::UndistortKeyPoints / ComputeImageBounds with the reference's two distorted cameras: random keypoints, the image border, and the
+    four-coefficient form (k3 = 0: src/Tracking.cc:95-100 only appends a non-zero k3)."""
+    rng = np.random.default_rng(8900)
+    x = np.concatenate([rng.uniform(0, 640, 1500), np.linspace(0, 640, 33), np.zeros(9), np.full(9, 640.0)]).astype(np.float32)
+    y = np.concatenate([rng.uniform(0, 480, 1500), np.zeros(33), np.linspace(0, 480, 9), np.linspace(0, 480, 9)]).astype(np.float32)
+    out = {"in:points": _digest(x, y)}
+    for name, (K, D) in TUM_CAMERAS.items():
+        for nc in (4, 5):
+            ux, uy = api.frame.undistort_keypoints(x, y, *K, D[:nc])
+            out["%s_k%d_x" % (name, nc)], out["%s_k%d_y" % (name, nc)] = ux, uy
+            out["%s_k%d_bounds" % (name, nc)] = api.frame.compute_image_bounds(640, 480, *K, D[:nc])
+    ux, uy = api.frame.undistort_keypoints(x, y, *TUM_CAMERAS["TUM1"][0], (0.0, 0.1, 0.0, 0.0))      # k1 == 0: upstream copies mvKeys whatever the rest says
+    out["k1_zero_x"], out["k1_zero_y"] = ux, uy
+    out["k1_zero_bounds"] = api.frame.compute_image_bounds(640, 480, *TUM_CAMERAS["TUM1"][0], (0.0, 0.1, 0.0, 0.0))
+    return out
+
+
 def _distinct_and_stereo(api):
     rng = np.random.default_rng(78)
     sets = []
@@ -300,6 +323,7 @@ CASES = {
     "search_tracking": _tracking_searches,
     "search_guided": _guided_searches,
     "frame_glue": _frame_glue,
+    "undistort": _undistort,
     "distinct_and_stereo": _distinct_and_stereo,
 }
 

@@ -113,3 +113,23 @@ def test_stereo_from_rgbd(both):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     with pytest.raises(E.EaoError):     # cv::Mat::at would read out of bounds: refused
         g.compute_stereo_from_rgbd(np.array([640.5], np.float32), np.array([3], np.float32), np.array([640.5], np.float32), depth, 40.0)
+
+
+@pytest.mark.parametrize("cam", ["TUM1", "TUM2"])
+def test_undistort_keypoints(both, cam):
+    """Frame::UndistortKeyPoints / ComputeImageBounds on the device (k_undistort): the same floats as the oracle's restatement of cv::undistortPoints, for the
+    reference's two distorted cameras with four and five coefficients, keypoints inside, on and outside the image."""
+    from golden_cases import TUM_CAMERAS
+    g, o, E = both
+    K, D = TUM_CAMERAS[cam]
+    rng = np.random.default_rng(32)
+    for n in (5000, 257, 1, 0):
+        x = rng.uniform(-40, 680, n).astype(np.float32); y = rng.uniform(-40, 520, n).astype(np.float32)
+        for d in (D, D[:4], (0.0, 0.2, 0.0, 0.0), ()):
+            a, b = g.undistort_keypoints(x, y, *K, d), o.undistort_keypoints(x, y, *K, d)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for d in (D, D[:4], ()):
+        assert np.array_equal(g.compute_image_bounds(640, 480, *K, d), o.compute_image_bounds(640, 480, *K, d))
+        assert np.array_equal(g.compute_image_bounds(752, 480, *K, d), o.compute_image_bounds(752, 480, *K, d))
+    with pytest.raises(E.EaoError):
+        g.undistort_keypoints(np.zeros(3, np.float32), np.zeros(3, np.float32), 0.0, 500.0, 320.0, 240.0, D)

@@ -130,3 +130,57 @@ def test_stereo_from_rgbd(orc):
     assert np.array_equal(dz, np.where(ok, d, np.float32(-1)))
     assert np.array_equal(ur, np.where(ok, ku - np.float32(40.0) / np.where(ok, d, 1).astype(np.float32), np.float32(-1)))
     assert dz[-1] == -1 and ok.sum() > 300
+
+
+def _distort(xn, yn, D):
+    """the forward model cv::undistortPoints inverts (OpenCV calib3d documentation): normalised undistorted -> normalised distorted"""
+    k1, k2, p1, p2, k3 = (list(D) + [0.0])[:5]
+    r2 = xn * xn + yn * yn
+    rad = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    return xn * rad + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn), yn * rad + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn
+
+
+@pytest.mark.parametrize("cam", ["TUM1", "TUM2"])
+@pytest.mark.parametrize("nc", [4, 5])
+def test_undistort_keypoints(orc, cam, nc):
+    """Frame::UndistortKeyPoints = cv::undistortPoints(., mK, mDistCoef, Mat(), mK) with the reference's own distorted cameras (ros_test/config/TUM1.yaml,
+    TUM2.yaml): (1) an independent float64 numpy restatement of the five fixed-point iterations gives the same floats; (2) the forward distortion model
+    applied to the result lands back on the keypoint (the iteration has converged to a few thousandths of a pixel inside the image's inner disc)."""
+    from golden_cases import TUM_CAMERAS
+    (fx, fy, cx, cy), D = TUM_CAMERAS[cam]
+    D = D[:nc]
+    rng = np.random.default_rng(31)
+    x = rng.uniform(0, 640, 4000).astype(np.float32); y = rng.uniform(0, 480, 4000).astype(np.float32)
+    ux, uy = orc.undistort_keypoints(x, y, fx, fy, cx, cy, D)
+    fxd, fyd, cxd, cyd = (np.float64(np.float32(v)) for v in (fx, fy, cx, cy))
+    k = [np.float64(np.float32(v)) for v in (list(D) + [0.0])[:5]]
+    xn = (x.astype(np.float64) - cxd) * (1.0 / fxd); yn = (y.astype(np.float64) - cyd) * (1.0 / fyd)
+    x0, y0 = xn.copy(), yn.copy()
+    for _ in range(5):
+        r2 = xn * xn + yn * yn
+        ic = 1.0 / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+        dx = 2 * k[2] * xn * yn + k[3] * (r2 + 2 * xn * xn)
+        dy = k[2] * (r2 + 2 * yn * yn) + 2 * k[3] * xn * yn
+        xn, yn = (x0 - dx) * ic, (y0 - dy) * ic
+    assert np.array_equal(ux, (fxd * xn + cxd).astype(np.float32)) and np.array_equal(uy, (fyd * yn + cyd).astype(np.float32))
+    # round trip through the forward model, where the fixed point is well inside its basin (r < 0.45: three quarters of the image)
+    un, vn = (ux.astype(np.float64) - cxd) / fxd, (uy.astype(np.float64) - cyd) / fyd
+    xd, yd = _distort(un, vn, k)
+    inner = (x0 * x0 + y0 * y0) < 0.45 ** 2
+    assert inner.sum() > 2000
+    assert np.abs(xd * fxd + cxd - x)[inner].max() < 0.02 and np.abs(yd * fyd + cyd - y)[inner].max() < 0.02
+    assert np.abs(ux - x).max() > 1.0          # (the cameras do distort)
+
+
+def test_undistort_identity_and_bounds(orc):
+    from golden_cases import TUM_CAMERAS
+    K, D = TUM_CAMERAS["TUM1"]
+    x = np.array([0, 10.5, 639.25], np.float32); y = np.array([0, 200.75, 479.5], np.float32)
+    for d in ((), (0.0, 0.3, 0.01, 0.01), (0.0, 0.0, 0.0, 0.0, 0.5)):      # mDistCoef.at<float>(0) == 0.0: mvKeysUn = mvKeys (src/Frame.cc:775-779)
+        ux, uy = orc.undistort_keypoints(x, y, *K, d)
+        assert np.array_equal(ux, x) and np.array_equal(uy, y)
+        assert orc.compute_image_bounds(640, 480, *K, d).tolist() == [0.0, 640.0, 0.0, 480.0]
+    b = orc.compute_image_bounds(640, 480, *K, D)                           # src/Frame.cc:808-833
+    cx_, cy_ = orc.undistort_keypoints(np.array([0, 640, 0, 640], np.float32), np.array([0, 0, 480, 480], np.float32), *K, D)
+    want = [max(min(cx_[0], cx_[2]), 0), min(max(cx_[1], cx_[3]), 640), max(min(cy_[0], cy_[1]), 0), min(max(cy_[2], cy_[3]), 480)]
+    assert b.tolist() == [float(np.float32(v)) for v in want] and 0 < b[0] < 30 and 600 < b[1] < 640
