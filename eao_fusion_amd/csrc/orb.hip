@@ -119,6 +119,7 @@ struct ResizeArgs {
     int pyrFrameBytes;
     int G;                   // 4-pixel groups per output row, and its reciprocal (exact item / G by truncation, see QDIV)
     float invG;
+    int frameAffinity;       // frame f is served by XCD f % 8 (batches that are a multiple of 8; see k_resize)
 };
 
 __device__ __forceinline__ void resize_coef(int d, double inv, int slimit, bool clampHi, int* ofs, unsigned* wpair) {
@@ -234,7 +235,16 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
     // work items = (group of kResizeRows output rows) x (4-pixel group), dealt to the lanes in one flat sequence: with a
     // 256-pixel-wide block per row group the levels whose width is just above a multiple of 256 left up to half of the
     // lanes idle (257 px -> two blocks; measured 240 -> 181 us for the seven launches of a 256-frame batch)
-    resize_item(A, s, blockIdx.z + f0, ((int)blockIdx.x * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x);
+    // Round 5: frame -> XCD affinity as in k_fast_cells.  Workgroups are dealt round-robin over the 8 XCDs and every XCD has its own L2; in plain order the
+    // one-wave workgroups of adjacent row groups and of adjacent 256-pixel runs of a row land on different XCDs, and the source rows / cache lines they share
+    // are fetched into two L2s: 2 x FETCH_SIZE + WRITE_SIZE = 151 MB per 64-frame step against 100.5 MB algorithmic (profiles/r05_pmc_traffic.json; the factor 2
+    // holds for 4-byte loads too: profiles/r05_fetch_calib.txt).  With frame f on XCD f % 8 a line is fetched once.
+    int f = blockIdx.z, bx = blockIdx.x;
+    if (A.frameAffinity) {
+        const unsigned b = blockIdx.x + gridDim.x * blockIdx.z, xcd = b & 7, slot = b >> 3;
+        f = (int)(xcd + 8 * (slot / gridDim.x)); bx = (int)(slot % gridDim.x);
+    }
+    resize_item(A, s, f + f0, (bx * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------- fused pyramid
@@ -1297,11 +1307,16 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur, int f0, int src0Aligned) {
-    // (frame -> XCD affinity as in k_fast_cells was measured here and in k_resize: 0.152 vs 0.149 ms and 0.199 vs 0.194 ms at
-    //  batch 256 -- neither kernel re-reads enough across workgroups for it to matter; plain order kept)
-    const int lane = threadIdx.x & 31, f = blockIdx.y + f0;
-    const int bxi = blockIdx.x;
+__global__ __launch_bounds__(256) void k_blur7(const Geom* __restrict__ g, ImgSrc s, uint8_t* __restrict__ blur, int f0, int src0Aligned, int frameAffinity) {
+    // (frame -> XCD affinity as in k_fast_cells was measured here and in k_resize in round 1: 0.152 vs 0.149 ms and 0.199 vs 0.194 ms at batch 256, plain order kept.
+    //  Round 5 looks at the TRAFFIC: strips of 16 rows read 22, and a strip's neighbours run on other XCDs -- 149 MB per 64-frame step against 122 MB algorithmic.)
+    const int lane = threadIdx.x & 31;
+    int f = blockIdx.y, bxi = blockIdx.x;
+    if (frameAffinity) {
+        const unsigned b = blockIdx.x + gridDim.x * blockIdx.y, xcd = b & 7, slot = b >> 3;
+        f = (int)(xcd + 8 * (slot / gridDim.x)); bxi = (int)(slot % gridDim.x);
+    }
+    f += f0;
     int l = 0;
     while (l + 1 < g->nlevels && bxi >= g->L[l + 1].tileBase) l++;
     // (upstream blurs only levels that hold keypoints, :1081-1082; blurring all of them changes no output and removes
@@ -2058,6 +2073,10 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         // with the blur as before.  (Profiling runs keep the stages sequential so that each is timed alone.)
         const int cells0 = g.L[0].nCells;
         const bool early0 = !prof && g.nlevels > 1 && g.L[0].cellBase == 0 && cells0 < g.totalCells;
+        // frame -> XCD placement of the resize chain and of the blur (round 5; EAO_RESIZE_AFFINITY=0 / EAO_BLUR_AFFINITY=0: plain order)
+        static const int envRAff = getenv("EAO_RESIZE_AFFINITY") ? atoi(getenv("EAO_RESIZE_AFFINITY")) : 1;
+        static const int envBAff = getenv("EAO_BLUR_AFFINITY") ? atoi(getenv("EAO_BLUR_AFFINITY")) : 1;
+        const int resizeAff = envRAff && (nb & 7) == 0 ? 1 : 0, blurAff = envBAff && (nb & 7) == 0 ? 1 : 0;
         auto fast = [&](hipStream_t str, int first, int end) {
             eao::Range rg("orb: FAST cells");
             static const int envAff = getenv("EAO_FAST_AFFINITY") ? atoi(getenv("EAO_FAST_AFFINITY")) : 1;
@@ -2107,7 +2126,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 EAO_HIP(hipEventRecord(h->evFork[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
                 if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
-                { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
+                { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned, blurAff); }
                 if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
                 EAO_HIP(hipEventRecord(h->evJoin[i], ss));
                 EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
@@ -2124,7 +2143,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
                 { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_pyramid_fused, pgrid, dim3(kPyrThreads), h->pyrLds, ms, h->pyr, s, f0); }
                 EAO_HIP(hipEventRecord(h->evFork[i], ms));
                 EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
-                { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
+                { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned, blurAff); }
                 EAO_HIP(hipEventRecord(h->evJoin[i], ss));
                 fast(ms, cells0, g.totalCells);
                 quadtree(ms, 1, g.nlevels - 1);
@@ -2167,6 +2186,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             ra.S = {g.L[l - 1].w, g.L[l - 1].h, g.L[l - 1].pitch, g.L[l - 1].off};
             ra.invX = 1. / ((double)g.L[l].w / g.L[l - 1].w); ra.invY = 1. / ((double)g.L[l].h / g.L[l - 1].h);
             ra.srcIsInput = l == 1; ra.pyrFrameBytes = g.pyrFrameBytes;
+            ra.frameAffinity = resizeAff;
             { eao::Range rg("orb: pyramid"); hipLaunchKernelGGL(k_resize, grid, block, 0, ms, ra, s, f0); }
             if (l == mid - 1) {
                 EAO_HIP(hipEventRecord(h->evMid[i], ms));
@@ -2186,7 +2206,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             EAO_HIP(hipEventRecord(h->evFork[i], ms));
             EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
             if (pe) EAO_HIP(hipEventRecord(ev[6], ss));
-            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
+            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned, blurAff); }
             if (pe) EAO_HIP(hipEventRecord(ev[7], ss));
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
             EAO_HIP(hipStreamWaitEvent(ms, h->evJoin[i], 0));
@@ -2205,7 +2225,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
             fast(ms, early0 ? (mid ? g.L[mid].cellBase : cells0) : 0, g.totalCells);
             if (!envBlurEarly) EAO_HIP(hipEventRecord(h->evFork[i], ms));
             EAO_HIP(hipStreamWaitEvent(ss, h->evFork[i], 0));
-            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned); }
+            { eao::Range rg("orb: blur"); hipLaunchKernelGGL(k_blur7, dim3(g.totalTiles, nb), dim3(256), 0, ss, h->d_geom.p, s, h->d_blur.p, f0, src0Aligned, blurAff); }
             EAO_HIP(hipEventRecord(h->evJoin[i], ss));
             if (early0 && !qtEarly) EAO_HIP(hipStreamWaitEvent(ms, h->evFast0[i], 0));
         }

@@ -26,9 +26,8 @@ stage = {"pyramid": "k_resize", "fast": "k_fast_cells", "blur": "k_blur7", "quad
 # launches of the kernel per bench step (profiled + timed steps of the run: 1 warmup + 3 steps + 3 profiled calls ...): derive from blur (1 per step)
 steps = raw["k_blur7"]["launches_fetch"]
 out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 3 --warmup 1 "
-                "--no-cpu-baseline --no-extra; bytes = KiB counter * 1024.  RAW counters: the guide's x2 FETCH_SIZE "
-                "correction is calibrated for 16-B-per-lane streaming reads; these kernels read 4 or 12 B per lane, which is uncalibrated -- "
-                "self-check: k_blur7 reads and writes 243 MB algorithmically (batch x 950 532 px; + halo rows on the read side, + pitch padding on the write side).",
+                "--no-cpu-baseline --no-extra; bytes = KiB counter * 1024.  RAW counters: HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE "
+                "(MI355X_MICROARCH.md; the factor holds for 1-, 4- and 12-byte loads per lane as well: profiles/r05_fetch_calib.txt).",
        "batch": int(__import__("os").environ.get("EAO_PMC_BATCH", "64")), "kernels": {}}
 for st, k in stage.items():
     r = raw[k]
