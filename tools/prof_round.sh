@@ -44,3 +44,6 @@ python3 tools/summarize_rocprof.py "$f" $O/${R}_ba_single_kernel_stats.csv "pyth
 ./tools/ubench/lds_ops > $O/${R}_ubench_lds.txt 2>&1
 # 6. the default bench line itself
 python3 bench.py > $O/${R}_bench_line.json 2> $O/${R}_bench_line.err; tail -c 600 $O/${R}_bench_line.json; echo
+# 7. round-5 extras: pose / map-scale stamps and kernel summaries, FETCH_SIZE calibration by load width
+bash tools/prof_r05_pose_gba.sh > $O/${R}_extras.log 2>&1; tail -6 $O/${R}_extras.log | cut -c1-250
+bash tools/prof_fetch_calib.sh > /dev/null 2>&1; cat $O/r05_fetch_calib.txt
