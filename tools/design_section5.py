@@ -11,13 +11,16 @@ P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (R, name))
 
 
 def stats(path):
+    """kernel,calls,avg_us,min_us,max_us,total_ms,pct -- kernel names hold commas (template arguments), so the six numbers are split off from the right"""
     rows = {}
     if not os.path.exists(path):
         return rows
-    with open(path) as f:
-        lines = [ln for ln in f if not ln.startswith("#")]
-    for r in csv.DictReader(lines):
-        rows[r["kernel"]] = r
+    for ln in open(path):
+        if ln.startswith("#") or ln.startswith("kernel,"):
+            continue
+        parts = ln.rstrip("\n").rsplit(",", 6)
+        if len(parts) == 7:
+            rows[parts[0]] = dict(zip(("kernel", "calls", "avg_us", "min_us", "max_us", "total_ms", "pct"), parts))
     return rows
 
 
