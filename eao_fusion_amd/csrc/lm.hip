@@ -3595,6 +3595,12 @@ struct LMContext {  // per-thread device workspace, grow-only
     size_t pinOutCap = 0;
     eao::DevBuf<unsigned char> bytes;
     std::vector<int> scratch;     // host counters of the structure build (kept to avoid per-call allocation)
+    // map-scale path: where every 32-column panel's work records start / the records themselves, as the HOST reads them when it enqueues the panel launches --
+    // which, in a batch call, happens after every window has been prepared.  They belong to the window's context (round 5: as thread-local tables of the set-up
+    // worker they were overwritten by the next map-scale window the same worker prepared, and the first window ran with the second one's panels --
+    // tools/dbg_batch_two_maps.py, tests/test_gpu_lm.py::test_two_map_scale_windows_in_one_batch).
+    std::vector<int> bigPanelStart;
+    std::vector<int4> bigPanelWork;
     size_t used = 0;
     ~LMContext() {
         if (status) (void)hipHostFree(status);
@@ -4248,8 +4254,9 @@ struct BAJob {
         //      (eliminating tile column k joins every pair of tile rows that are live in it: the block form of the symbolic factorisation a sparse LDL^T starts
         //      with, solvers/linear_solver_eigen.h:95-112; natural keyframe order -- consecutive keyframes are the covisible ones, which is what a fill-reducing
         //      ordering would recover).  Memory and the launches' grids follow this structure.
-        static thread_local std::vector<int> tileMap, panelStart;
-        static thread_local std::vector<int4> panelWork;
+        static thread_local std::vector<int> tileMap;       // (consumed inside this function: copied into the pinned mirror below)
+        std::vector<int>& panelStart = c.bigPanelStart;     // (read by the launches of this window, long after this function has returned: the context's)
+        std::vector<int4>& panelWork = c.bigPanelWork;
         int bigT = 0, bigTiles = 0;
         if (bigPath) {
             static thread_local std::vector<int> cc, cnt2, touched;

@@ -515,3 +515,16 @@ def test_map_scale_set_up_on_the_host_crew(gpu, oracle, kw, monkeypatch):
     single = gpu.Optimizer.LocalBundleAdjustment(p)
     batch = gpu.Optimizer.LocalBundleAdjustmentBatch(probs)
     assert _same_result(single, batch[1])
+
+
+def test_two_map_scale_windows_in_one_batch(tmp_path):
+    """Round 5 regression: the host-side panel tables of a map-scale window (which panel launches which work records) were thread-local to the set-up worker; a second
+    map-scale window prepared by the SAME worker overwrote them before the first window's launches were enqueued, and the first window silently ran with the second
+    one's panels (wrong result, wrong iteration counts).  The worker count is read once per process, so the check runs in a process of its own with ONE set-up worker."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EAO_BA_BATCH_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg_batch_two_maps.py")], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln[:2] in ("A ", "S ", "B ")]
+    assert len(lines) == 3 and all(ln.endswith("identical") for ln in lines), out.stdout
