@@ -367,15 +367,19 @@ def test_fallback_paths_of_the_chain():
     assert "tracker sweep: 16 frames, 0 mismatches" in out.stdout, out.stdout[-2000:]
 
 
-def _chain_motion(calls, search_frames, cur, kps, desc, depth, last, th, mono, discard=True):
+def _chain_motion(calls, search_frames, cur, kps, desc, depth, last, th, mono, discard=True, dist=None):
     """Tracking::TrackWithMotionModel's data path step by step (src/Tracking.cc:1717-2231): Frame::ComputeStereoFromRGBD, SearchByProjection(Cur, Last, th, bMono)
     (src/ORBmatcher.cc:1328-1472), PoseOptimization over the matches from the predicted pose, the outlier discard (:2188-2207)."""
     N = len(kps)
-    kx, ky = np.ascontiguousarray(kps["x"]), np.ascontiguousarray(kps["y"])
-    ur, dz = calls.stereo(kx, ky, kx, depth, cur["mbf"])
+    kxd, kyd = np.ascontiguousarray(kps["x"]), np.ascontiguousarray(kps["y"])
+    kx, ky, bnd = kxd, kyd, np.array([0.0, 640.0, 0.0, 480.0], np.float32)
+    if dist is not None:      # Frame::UndistortKeyPoints / ComputeImageBounds in front of everything that reads mvKeysUn
+        kx, ky = calls.undistort(kxd, kyd, cur["fx"], cur["fy"], cur["cx"], cur["cy"], dist)
+        bnd = calls.bounds(640, 480, cur["fx"], cur["fy"], cur["cx"], cur["cy"], dist)
+    ur, dz = calls.stereo(kxd, kyd, kx, depth, cur["mbf"])
     T = np.ascontiguousarray(cur["Tcw"], np.float32)
     frame = dict(kp_x=kx, kp_y=ky, kp_octave=np.ascontiguousarray(kps["octave"]), kp_angle=np.ascontiguousarray(kps["angle"]), u_right=ur, descriptors=desc,
-                 occupied=None, min_x=np.float32(0), min_y=np.float32(0), max_x=np.float32(640), max_y=np.float32(480), scale_factors=cur["scale_factors"],
+                 occupied=None, min_x=np.float32(bnd[0]), min_y=np.float32(bnd[2]), max_x=np.float32(bnd[1]), max_y=np.float32(bnd[3]), scale_factors=cur["scale_factors"],
                  Tcw=T, fx=cur["fx"], fy=cur["fy"], cx=cur["cx"], cy=cur["cy"], mbf=cur["mbf"], mb=cur["mb"])
     nm, cur_match = search_frames(frame, last, th, mono)
     ks = np.nonzero(cur_match >= 0)[0]
@@ -750,3 +754,29 @@ def test_chain_with_a_distorted_camera(case, oracle):
     trk.set_distortion(())
     again = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], prior, th, nnratio, st)
     assert np.array_equal(again["u_right"], other["u_right"])
+
+
+@pytest.mark.parametrize("case", [dict(seed=7410, cam="TUM1"), dict(seed=7411, cam="TUM2", th=7.0)])
+def test_motion_model_stage_with_a_distorted_camera(case, oracle):
+    """The motion-model stage on the same frame set-up: SearchByProjection(Cur, Last) and the pose edges read the undistorted keypoints, the image bounds of the search
+    windows are the undistorted ones -- against the oracle chain with Frame::UndistortKeyPoints in front."""
+    from golden_cases import TUM_CAMERAS
+    D = np.asarray(TUM_CAMERAS[case["cam"]][1], np.float32)
+    cur, kps, desc, depth, pts, _ = _scene(case["seed"], n=900)
+    _, last, _ = synth.synth_tracking(n=900, seed=case["seed"], mono_frac=0.0, occupied_frac=0.0)
+    kps = _distort_keypoints(cur, kps, list(D.astype(np.float64)))
+    rng = np.random.default_rng(case["seed"])
+    depth[kps["y"].astype(int), kps["x"].astype(int)] = rng.uniform(1.8, 6.2, len(kps)).astype(np.float32)
+    th = case.get("th", 15.0)
+    oc = _OracleCalls(oracle)
+    want = _chain_motion(oc, lambda f, l, t, m: oracle.search_by_projection_frames(f, l, t, m, True), cur, kps, desc, depth, last, th, False, True, dist=D)
+    bnd = oc.bounds(640, 480, cur["fx"], cur["fy"], cur["cx"], cur["cy"], D)
+    d_kps, d_desc, d_n, d_depth = _device_buffers(kps, desc, depth, 2048)
+    trk = _tracker(cur, 2048, 2048, bnd, D)
+    got = trk.track_with_motion_model(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], last, th, False, True, True,
+                                      torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(got["u_right"], want["u_right"]) and np.array_equal(got["depth"], want["depth"])
+    assert got["n_matches"] == want["n_matches"] and want["n_matches"] > 100 and got["n_edges"] == want["n_edges"]
+    assert np.array_equal(got["kp_map_point"], want["kp_map_point"]) and got["n_inliers"] == want["n_inliers"]
+    ok, err, upd = _pose_close(got["Tcw"], want["Tcw"], cur["Tcw"])
+    assert ok, "pose |gpu - oracle| %.3e of update %.3e" % (err, upd)
