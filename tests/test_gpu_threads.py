@@ -63,3 +63,57 @@ def test_concurrent_entry_points():
     for t in ths:
         t.join()
     assert not errors, errors
+
+
+def test_concurrent_map_scale_batch_and_handle_calls(monkeypatch):
+    """Round 5's host-side machinery under concurrency: two threads run map-scale BundleAdjustment (their covisibility set-up is split over the ONE process-wide host
+    crew, forced onto these test-size maps), one runs eao_local_ba_batch (which owns the same crew for its set-up workers and group leaders), one runs the keyframe-handle
+    searches.  Every result must equal the single-threaded one bit for bit, whatever the interleaving."""
+    import torch  # noqa: F401
+    import eao_fusion_amd as E
+    from eao_fusion_amd import search
+    assert E.load().eao_device_check() == 0
+    monkeypatch.setenv("EAO_BA_SETUP_THREADS", "6")
+    mapA = synth.synth_ba(n_free=90, n_fixed=1, n_points=3600, seed=5620, band=5)
+    mapB = synth.synth_ba(n_free=64, n_fixed=2, n_points=2400, seed=5621)
+    wins = [synth.synth_ba(seed=6300 + w) for w in range(9)] + [synth.synth_ba(n_free=40, n_fixed=1, n_points=1500, seed=6310)]
+    sc = synth.synth_search_scene(n=500, seed=8310)
+
+    def ba_bytes(r):
+        return r["poses"].tobytes() + r["points"].tobytes() + bytes(list(r["iters"]))
+
+    def job_map_a():
+        return ba_bytes(E.Optimizer.BundleAdjustment(mapA, 6, bRobust=False))
+
+    def job_map_b():
+        return ba_bytes(E.Optimizer.BundleAdjustment(mapB, 6, bRobust=True))
+
+    def job_batch():
+        return b"".join(ba_bytes(r) + r["edge_outlier"].tobytes() for r in E.Optimizer.LocalBundleAdjustmentBatch(wins))
+
+    def job_handles():
+        g = search.product_handles()
+        s1 = dict(descriptors=sc["K1"]["descriptors"], angle=sc["K1"]["kp_angle"], valid=(sc["mp1"] >= 0).astype(np.uint8), fv=sc["fv1"])
+        s2 = dict(descriptors=sc["K2"]["descriptors"], angle=sc["K2"]["kp_angle"], valid=(sc["mp2"] >= 0).astype(np.uint8), fv=sc["fv2"])
+        n, m = g.search_by_bow(1, s1, s2, 0.75, True)
+        return m.tobytes() + bytes([n & 255])
+
+    jobs = [job_map_a, job_map_b, job_batch, job_handles]
+    expect = [j() for j in jobs]
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(5):
+                j = (i + rep) % len(jobs)
+                if jobs[j]() != expect[j]:
+                    errors.append("thread %d: job %s differs on repetition %d" % (i, jobs[j].__name__, rep))
+        except Exception as ex:  # noqa: BLE001
+            errors.append("thread %d: %r" % (i, ex))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
