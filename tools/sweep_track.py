@@ -1,6 +1,7 @@
 """Randomised parity sweep of the device-resident tracked frame (eao_tracker_track_local_map) against the CPU oracle's chain
 (ComputeStereoFromRGBD -> isInFrustum -> SearchByProjection(points) -> PoseOptimization): frame sizes, local-map sizes up to 16 384
-points, search radii, ratio thresholds, prior matches (on active, bad and foreign points), monocular fractions.  Integer tables bit for
+points, search radii, ratio thresholds, prior matches (on active, bad and foreign points), monocular fractions, and (round 5) a third of the frames through a camera
+with random lens distortion (Frame::UndistortKeyPoints on the chain).  Integer tables bit for
 bit, the pose within 1e-4 of the update.  Not part of the test suite: run by hand on a GPU box.
     python tools/sweep_track.py [seed] [cases]"""
 import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -39,10 +40,20 @@ for it in range(N):
         z = rng.uniform(2.0, 5.0, len(out))
         Xc = np.stack([(kps["x"][out] - cur["cx"]) * z / cur["fx"], (kps["y"][out] - cur["cy"]) * z / cur["fy"], z], 1)
         prior_Xw[out] = ((Xc - Tm[:3, 3]) @ Tm[:3, :3]).astype(np.float32)
+    dist, bnd = None, (0.0, 640.0, 0.0, 480.0)
+    if rng.random() < 0.34 and prior_Xw is None:      # a distorted camera: k1, k2, p1, p2 [, k3] around the reference's TUM1 / TUM2 values
+        dist = np.array([rng.uniform(0.05, 0.3), rng.uniform(-1.0, -0.1), rng.uniform(-0.006, 0.006), rng.uniform(-0.003, 0.003), rng.uniform(0.5, 1.2)], np.float32)
+        if rng.random() < 0.4: dist = dist[:4]
+        bnd = T._OracleCalls(O).bounds(640, 480, cur["fx"], cur["fy"], cur["cx"], cur["cy"], dist)
+        if not (bnd[1] - bnd[0] > 300 and bnd[3] - bnd[2] > 200):      # coefficients whose model folds over inside the image (no lens): a tamer draw
+            dist = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32) * np.float32(rng.uniform(0.3, 1.0))
+            bnd = T._OracleCalls(O).bounds(640, 480, cur["fx"], cur["fy"], cur["cx"], cur["cy"], dist)
+        kps = T._distort_keypoints(cur, kps, list(dist.astype(np.float64)) + [0.0] * (5 - len(dist)))
+        depth[kps["y"].astype(int), kps["x"].astype(int)] = rng.uniform(1.8, 6.2, len(kps)).astype(np.float32)
     try:
-        want = T._chain(T._OracleCalls(O), cur, kps, desc, depth, pts, prior, th, nnratio, prior_Xw)
+        want = T._chain(T._OracleCalls(O), cur, kps, desc, depth, pts, prior, th, nnratio, prior_Xw, dist=dist)
         cap = 2048
-        trk = T._tracker(cur, cap, 16384)
+        trk = T._tracker(cur, cap, 16384, bnd, dist)
         trk.set_local_map(pts)
         d_kps, d_desc, d_n, d_depth = T._device_buffers(kps, desc, depth, cap)
         got = trk.track_local_map(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_depth.data_ptr(), 640, 640, 480, cur["Tcw"], prior, th, nnratio,
