@@ -1,7 +1,7 @@
 """Randomised bit-exactness sweep of the guided searches (SearchByProjection sim3 / keyframe / frame-to-frame / points, SearchByBoW,
 SearchForTriangulation, SearchForInitialization, Fuse, SearchBySim3) against the CPU oracle over scene sizes, descriptor noise,
 clutter, monocular fractions, vocabulary sizes, radii and ratio thresholds.  Not part of the test suite: run by hand on a GPU box.
-    python tools/sweep_search.py [seed] [scenes]"""
+    python tools/sweep_search.py [seed] [scenes] [handles]      (handles: the same calls through keyframe handles, eao_kf_*, round 5)"""
 import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch  # noqa: F401
 import eao_fusion_amd as E
@@ -10,7 +10,7 @@ from oracle import oracle as O
 import test_gpu_search as T
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-g, o = search.product(), O.search_binding()
+g, o = (search.product_handles() if len(sys.argv) > 3 and sys.argv[3] == "handles" else search.product()), O.search_binding()
 bad = calls = 0
 def same(name, a, b, kw):
     global bad, calls
