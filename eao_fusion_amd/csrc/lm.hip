@@ -4193,7 +4193,7 @@ struct BAJob {
         tr->clear();
         static const bool hostStamps = getenv("EAO_DEBUG_STAMPS") != nullptr;      // host phases of the set-up, in ms on stderr
         const auto hs0 = std::chrono::steady_clock::now();
-        double hsT[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double hsT[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         auto hs_lap = [&](int k) { if (hostStamps) hsT[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs0).count(); };
         nPo = p->n_points; nPl = pl ? pl->n_planes : 0; Ept = p->n_edges; Epl = pl ? pl->n_pedges : 0;
         nC = p->n_cams; nP = nPo + nPl; E = Ept + Epl;          // landmarks = points then planes, edges = point edges then plane edges
@@ -4212,10 +4212,15 @@ struct BAJob {
             trivial = true;
             return EAO_OK;
         }
-        for (int e = 0; e < Ept; e++)
+        bool edgesByLandmark = true;      // the edge list is grouped landmark by landmark, ascending (what the adapters and every generator produce): ptEdges is then the identity
+        for (int e = 0, prev = 0; e < Ept; e++) {
             EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nPo, "edge %d out of range", e);
-        for (int e = 0; e < Epl; e++)
+            edgesByLandmark = edgesByLandmark && p->edge_point[e] >= prev; prev = p->edge_point[e];
+        }
+        for (int e = 0, prev = 0; e < Epl; e++) {
             EAO_REQUIRE(pl->pedge_cam[e] >= 0 && pl->pedge_cam[e] < nC && pl->pedge_plane[e] >= 0 && pl->pedge_plane[e] < nPl, "plane edge %d out of range", e);
+            edgesByLandmark = edgesByLandmark && pl->pedge_plane[e] >= prev; prev = pl->pedge_plane[e];
+        }
         int nFreeIn = 0;
         for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
         EAO_REQUIRE(nFreeIn <= kBigMaxFree, "at most %d free keyframes in this build (got %d)", kBigMaxFree, nFreeIn);
@@ -4268,22 +4273,30 @@ struct BAJob {
             int nFa = 0;
             for (int i = 0; i < nC; i++) if (cc[i] && !p->cam_fixed[i]) fidx[i] = nFa++;
             // per landmark: its free observers and their edges, in edge order (the order of the active structure's ptEdges)
-            for (int e = 0; e < E; e++) if (fidx[edge_cam(e)] >= 0) lmOff[edge_lm(e) + 1]++;
+            bool byLandmark = true;        // the edges come landmark by landmark (the adapters and every generator list them so): the observer lists are then a filtered copy
+            for (int e = 0, prev = 0; e < E; e++) { const int lmk = edge_lm(e); byLandmark = byLandmark && lmk >= prev; prev = lmk; if (fidx[edge_cam(e)] >= 0) lmOff[lmk + 1]++; }
             for (int i = 0; i < nP; i++) {
                 const int m = lmOff[i + 1];
                 lpEntries += (size_t)m * (m + 1) / 2;
                 lmOff[i + 1] += lmOff[i];
             }
             EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
+            hs_lap(8);
             lmCam.resize(lmOff[nP]); lmEdge.resize(lmOff[nP]);
-            pcur.assign(lmOff.begin(), lmOff.end() - 1);
             cmOff.assign((size_t)nFa + 1, 0);
-            for (int e = 0; e < E; e++) {
-                const int f = fidx[edge_cam(e)];
-                if (f < 0) continue;
-                const int at = pcur[edge_lm(e)]++;
-                lmCam[at] = f; lmEdge[at] = e; cmOff[f + 1]++;
+            if (byLandmark) {
+                int at = 0;
+                for (int e = 0; e < E; e++) { const int f = fidx[edge_cam(e)]; if (f >= 0) { lmCam[at] = f; lmEdge[at] = e; at++; cmOff[f + 1]++; } }
+            } else {
+                pcur.assign(lmOff.begin(), lmOff.end() - 1);
+                for (int e = 0; e < E; e++) {
+                    const int f = fidx[edge_cam(e)];
+                    if (f < 0) continue;
+                    const int at = pcur[edge_lm(e)]++;
+                    lmCam[at] = f; lmEdge[at] = e; cmOff[f + 1]++;
+                }
             }
+            hs_lap(9);
             for (int i = 0; i < nP; i++)           // observers by camera (insertion sort: a handful per landmark, mostly in order already)
                 for (int u = lmOff[i] + 1; u < lmOff[i + 1]; u++) {
                     const int cf = lmCam[u], ce = lmEdge[u];
@@ -4291,13 +4304,29 @@ struct BAJob {
                     for (; v > lmOff[i] && lmCam[v - 1] > cf; v--) { lmCam[v] = lmCam[v - 1]; lmEdge[v] = lmEdge[v - 1]; }
                     lmCam[v] = cf; lmEdge[v] = ce;
                 }
+            hs_lap(10);
             // per free camera: its landmarks in ascending order (a counting sort over the landmarks, walked in ascending order), each with the position of the
             // camera's own entry in that landmark's list
             for (int f = 0; f < nFa; f++) cmOff[f + 1] += cmOff[f];
             cmLm.resize(cmOff[nFa]); cmU.resize(cmOff[nFa]);
-            pcur.assign(cmOff.begin(), cmOff.end() - 1);
-            for (int i = 0; i < nP; i++)
-                for (int u = lmOff[i]; u < lmOff[i + 1]; u++) { const int at = pcur[lmCam[u]]++; cmLm[at] = i; cmU[at] = u; }
+            {   // (camera ranges on the crew: every worker walks all observer lists and files the entries of ITS cameras -- a camera's list is written by one worker, in landmark order)
+                const int nRanges = std::max(1, std::min(16, nFa / 32));
+                const int* const lmOffp = lmOff.data(); const int* const lmCamp = lmCam.data(); const int* const cmOffp = cmOff.data();
+                int* const cmLmp = cmLm.data(); int* const cmUp = cmU.data();
+                const int nPl_ = nP;
+                crew_for(lpEntries, nRanges, [=](int q) {
+                    const int f0 = (int)((long long)nFa * q / nRanges), f1 = (int)((long long)nFa * (q + 1) / nRanges);
+                    static thread_local std::vector<int> cur;
+                    cur.assign(cmOffp + f0, cmOffp + f1);
+                    for (int i = 0; i < nPl_; i++)
+                        for (int u = lmOffp[i]; u < lmOffp[i + 1]; u++) {
+                            const int f = lmCamp[u];
+                            if (f < f0 || f >= f1) continue;
+                            const int at = cur[f - f0]++;
+                            cmLmp[at] = i; cmUp[at] = u;
+                        }
+                });
+            }
             hs_lap(5);
             // the pairs of every camera and their entry counts: chunks of cameras, each into lists of its own, joined in camera order
             constexpr int kChunkCams = 16;
@@ -4547,10 +4576,18 @@ struct BAJob {
             for (int i = 0; i < nF; i++) camStart[i + 1] = camStart[i] + camCnt[actCam[i]];
             for (int i = 0; i < nL; i++) ptCnt[actPt[i]] = ptStart[i];         // counters become fill cursors
             for (int i = 0; i < nF; i++) camCnt[actCam[i]] = camStart[i];
-            for (int e = 0; e < E; e++) {
-                const int cam = edge_cam(e);
-                ptEdges[ptCnt[edge_lm(e)]++] = e;
-                if (camIdx[cam] >= 0) camEdges[camCnt[cam]++] = e;
+            if (edgesByLandmark) {      // (the landmarks' edge lists, concatenated in landmark order, ARE the edge list)
+                for (int e = 0; e < E; e++) {
+                    const int cam = edge_cam(e);
+                    ptEdges[e] = e;
+                    if (camIdx[cam] >= 0) camEdges[camCnt[cam]++] = e;
+                }
+            } else {
+                for (int e = 0; e < E; e++) {
+                    const int cam = edge_cam(e);
+                    ptEdges[ptCnt[edge_lm(e)]++] = e;
+                    if (camIdx[cam] >= 0) camEdges[camCnt[cam]++] = e;
+                }
             }
             // one edge per (camera, point) pair: the device's edge table has one slot per pair
             for (int i = 0; i < nC; i++) camCnt[i] = -1;                        // now: last point seen with this camera
@@ -4681,8 +4718,8 @@ struct BAJob {
         chained = E > 0 && (nF + nL) > 0 && !pollStop && !lazy;
         hs_lap(4);
         if (hostStamps && bigPath)
-            fprintf(stderr, "[eao map-scale host set-up] observer / camera lists %.3f, pair counts %.3f, pair list %.3f, tiles + symbolic elimination + work records %.3f ms\n",
-                    hsT[5], hsT[6] - hsT[5], hsT[7] - hsT[6], hsT[0] - hsT[7]);
+            fprintf(stderr, "[eao map-scale host set-up] observer / camera lists %.3f (counts %.3f, observer scatter %.3f, sort %.3f, camera scatter %.3f), pair counts %.3f, pair list %.3f, tiles + symbolic elimination + work records %.3f ms\n",
+                    hsT[5], hsT[8], hsT[9] - hsT[8], hsT[10] - hsT[9], hsT[5] - hsT[10], hsT[6] - hsT[5], hsT[7] - hsT[6], hsT[0] - hsT[7]);
         if (hostStamps && bigPath)
             fprintf(stderr, "[eao map-scale host set-up] tile structure + symbolic elimination %.3f, arena + problem pack %.3f, active structure %.3f, pair CSR + launch order %.3f, records + upload enqueue %.3f ms (cumulative %.3f)\n",
                     hsT[0], hsT[1] - hsT[0], hsT[2] - hsT[1], hsT[3] - hsT[2], hsT[4] - hsT[3], hsT[4]);

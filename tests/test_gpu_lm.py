@@ -528,3 +528,32 @@ def test_two_map_scale_windows_in_one_batch(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln[:2] in ("A ", "S ", "B ")]
     assert len(lines) == 3 and all(ln.endswith("identical") for ln in lines), out.stdout
+
+
+def _shuffle_edges(p, seed):
+    """the same problem with its edge list in random order (edge_cam / edge_point / obs / inv_sigma2 permuted together)"""
+    q = dict(p)
+    perm = np.random.default_rng(seed).permutation(len(p["edge_cam"]))
+    for k in ("edge_cam", "edge_point", "obs", "inv_sigma2"):
+        q[k] = np.ascontiguousarray(p[k][perm])
+    return q, perm
+
+
+@pytest.mark.parametrize("kw", [dict(n_free=6, n_fixed=2, n_points=400, seed=5700), dict(n_free=20, n_fixed=4, n_points=3000, seed=5701),
+                                dict(n_free=60, n_fixed=1, n_points=2400, seed=5702, band=7), dict(n_free=45, n_fixed=2, n_points=1800, seed=5703)])
+def test_edge_lists_in_any_order(gpu, oracle, kw):
+    """Round 5: the host set-up takes short cuts when the edge list comes landmark by landmark (what every generator and both adapters produce: the landmarks' edge
+    lists are then the edge list itself, the observer lists a filtered copy).  A caller may hand the edges over in ANY order: the general paths, against the oracle on the
+    same shuffled problem -- and, through the permutation, the same outlier table as the ordered problem gives."""
+    p = synth.synth_ba(**kw)
+    q, perm = _shuffle_edges(p, kw["seed"])
+    if kw["n_free"] > 30:
+        r, o = gpu.Optimizer.BundleAdjustment(q, 6, bRobust=False), oracle.bundle_adjustment(q, 6, False)
+        assert list(r["iters"]) == [int(o["iters"][0]), 0]
+    else:
+        r, o = gpu.Optimizer.LocalBundleAdjustment(q), oracle.local_ba(q)
+        assert list(r["iters"]) == list(o["iters"]) and np.array_equal(r["edge_outlier"], o["edge_outlier"])
+        ordered = gpu.Optimizer.LocalBundleAdjustment(p)
+        assert np.array_equal(r["edge_outlier"], ordered["edge_outlier"][perm])
+    _check_updates(r["poses"], o["poses"], q["poses"], "poses")
+    _check_updates(r["points"], o["points"], q["points"], "points")
