@@ -117,3 +117,52 @@ def test_concurrent_map_scale_batch_and_handle_calls(monkeypatch):
     for t in ths:
         t.join()
     assert not errors, errors
+
+
+def test_shared_keyframe_handles_across_threads(oracle):
+    """include/eao_fusion.h: "A handle is immutable but for its occupancy; searches only read it, so any number of threads may search the same handle (each thread has
+    its own stream and scratch)" -- LocalMapping creates the keyframes' handles, LoopClosing and Tracking search them.  Handles created on the MAIN thread, searched by
+    four other threads at once (vocabulary-node search, triangulation over 12 neighbours, fusion into 10 targets): every result equals the oracle's."""
+    import torch  # noqa: F401
+    from eao_fusion_amd import search
+    g, o = search.product_handles(), oracle.search_binding()
+    sc = synth.synth_search_scene(n=900, seed=8120, n_nodes=40)
+    k1, k2 = dict(sc["K1"]), dict(sc["K2"])
+    k1["occupied"] = ((sc["mp1"] >= 0) & (np.arange(len(sc["mp1"])) % 3 == 0)).astype(np.uint8)
+    k2["occupied"] = ((sc["mp2"] >= 0) & (np.arange(len(sc["mp2"])) % 4 == 1)).astype(np.uint8)
+    h1, h2 = g.handle(k1, sc["fv1"]), g.handle(k2, sc["fv2"])
+    h1.update_points(k1["occupied"]); h2.update_points(k2["occupied"])
+    s1 = dict(descriptors=k1["descriptors"], angle=k1["kp_angle"], valid=(sc["mp1"] >= 0).astype(np.uint8), fv=sc["fv1"])
+    s2 = dict(descriptors=k2["descriptors"], angle=k2["kp_angle"], valid=(sc["mp2"] >= 0).astype(np.uint8), fv=sc["fv2"])
+    want_bow = o.search_by_bow(1, s1, s2, 0.75, True)
+    want_tri = o.search_for_triangulation(k1, sc["fv1"], k2, sc["fv2"], sc["F12"], sc["ex"], sc["ey"], 0, True)
+    T = sc["T2w"].astype(np.float64)
+    pose = np.concatenate([T[:3, :3].ravel(), T[:3, 3], -T[:3, :3].T @ T[:3, 3]]).astype(np.float32)
+    want_fuse = o.fuse_search(k2, 0, pose, sc["K"], sc["bf"], sc["points"], 3.0)
+    assert want_bow[0] > 10 and want_tri[0] > 10 and want_fuse[0] > 10
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(8):
+                which = (i + rep) % 3
+                if which == 0:
+                    got = g.search_by_bow_h(1, h1, s1["valid"], h2, s2["valid"], 0.75, True)
+                    ok = got[0] == want_bow[0] and np.array_equal(got[1], want_bow[1])
+                elif which == 1:
+                    nm, m = g.search_for_triangulation_h(h1, [h2] * 12, [sc["F12"]] * 12, [sc["ex"]] * 12, [sc["ey"]] * 12, 0, True)
+                    ok = all(nm[k] == want_tri[0] and np.array_equal(m[k], want_tri[1]) for k in range(12))
+                else:
+                    nf, best = g.fuse_search_h([h2] * 10, 0, [pose] * 10, sc["K"], sc["bf"], sc["points"], 3.0)
+                    ok = all(nf[k] == want_fuse[0] and np.array_equal(best[k], want_fuse[1]) for k in range(10))
+                if not ok:
+                    errors.append("thread %d: search %d differs on repetition %d" % (i, which, rep))
+        except Exception as ex:  # noqa: BLE001
+            errors.append("thread %d: %r" % (i, ex))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
