@@ -4282,11 +4282,15 @@ struct BAJob {
             }
             EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
             hs_lap(8);
-            lmCam.resize(lmOff[nP]); lmEdge.resize(lmOff[nP]);
+            lmCam.resize((size_t)lmOff[nP] + 1); lmEdge.resize((size_t)lmOff[nP] + 1);      // (+ 1: the branch-free append writes one slot ahead)
             cmOff.assign((size_t)nFa + 1, 0);
             if (byLandmark) {
+                // (plain pointers and a branch-free append: the loop is a stream of 2 E loads and at most 2 E stores)
+                int* const lc = lmCam.data(); int* const le = lmEdge.data(); int* const co = cmOff.data() + 1; const int* const fi = fidx.data();
+                const int* const ecam = p->edge_cam; const int* const pcam = pl ? pl->pedge_cam : nullptr;
                 int at = 0;
-                for (int e = 0; e < E; e++) { const int f = fidx[edge_cam(e)]; if (f >= 0) { lmCam[at] = f; lmEdge[at] = e; at++; cmOff[f + 1]++; } }
+                for (int e = 0; e < Ept; e++) { const int f = fi[ecam[e]]; lc[at] = f; le[at] = e; const int ok = f >= 0; at += ok; if (ok) co[f]++; }
+                for (int e = Ept; e < E; e++) { const int f = fi[pcam[e - Ept]]; lc[at] = f; le[at] = e; const int ok = f >= 0; at += ok; if (ok) co[f]++; }
             } else {
                 pcur.assign(lmOff.begin(), lmOff.end() - 1);
                 for (int e = 0; e < E; e++) {
