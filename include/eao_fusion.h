@@ -353,7 +353,8 @@ eao_status eao_search_by_sim3(const eao_frame_view* K1, const float* T1w, const 
 typedef struct eao_keyframe eao_keyframe;
 eao_status eao_keyframe_create(const eao_frame_view* view, const eao_feature_vector* fv, eao_keyframe** out);
 /* occupied[k] != 0 where the keyframe holds a map point at keypoint k (GetMapPoint(k) != NULL) -- what SearchForTriangulation skips on both sides
- * (src/ORBmatcher.cc:696-700, 712-716); NULL = no keypoint occupied.  Call it when map points were added to / erased from the keyframe. */
+ * (src/ORBmatcher.cc:696-700, 712-716); NULL = no keypoint occupied.  Call it when map points were added to / erased from the keyframe -- from the thread that owns the
+ * keyframe's map points (LocalMapping), and not while another thread searches this handle: the update is the one writer, ordered by the caller like upstream's mMutexFeatures. */
 eao_status eao_keyframe_update_points(eao_keyframe* kf, const uint8_t* occupied);
 void eao_keyframe_destroy(eao_keyframe* kf);
 int32_t eao_keyframe_size(const eao_keyframe* kf);      /* number of keypoints, -1 for NULL */
