@@ -1,4 +1,5 @@
-"""Bit-for-bit A/B of the map-scale BundleAdjustment between two builds of the library (EAO_LIB_PATH selects one): poses, points and the LM trace of a few maps.
+"""(tools/ab_gba_job.sh runs the three steps below on the GPU box against gpurun_ab/libeaofusion_hip_head.so, a build of the previous commit.)
+Bit-for-bit A/B of the map-scale BundleAdjustment between two builds of the library (EAO_LIB_PATH selects one): poses, points and the LM trace of a few maps.
     EAO_LIB_PATH=gpurun_ab/libeaofusion_hip_head.so python tools/ab_gba_bits.py dump gpurun_out/gba_head.npz; python tools/ab_gba_bits.py dump gpurun_out/gba_new.npz
     python tools/ab_gba_bits.py cmp gpurun_out/gba_head.npz gpurun_out/gba_new.npz"""
 import sys, time; sys.path.insert(0, '.')

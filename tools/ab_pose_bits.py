@@ -1,4 +1,5 @@
-"""Bit-for-bit A/B of PoseOptimization between two builds of the library: dumps (pose, outlier table, LM trace) of a seeded set of problems over every launch
+"""(tools/ab_pose_job.sh runs the three steps below on the GPU box against gpurun_ab/libeaofusion_hip_head.so, a build of the previous commit.)
+Bit-for-bit A/B of PoseOptimization between two builds of the library: dumps (pose, outlier table, LM trace) of a seeded set of problems over every launch
 geometry to an .npz; run once per build (EAO_LIB_PATH selects it), then with both files to compare.
     EAO_LIB_PATH=gpurun_ab/libeaofusion_hip_head.so python tools/ab_pose_bits.py dump gpurun_out/pose_head.npz
     python tools/ab_pose_bits.py dump gpurun_out/pose_new.npz
