@@ -6,10 +6,10 @@
 # Round 4: the HOST half of the product's guided searches (eao_fusion_amd/csrc/search.hip: per-query geometry + the selection loops of all eleven searches, driven
 # by caller-supplied indices) is part of the pass -- tests/test_host_replay_cpu.py builds it as plain C++ with the same flags (EAO_HOST_SAN=1) against the oracle's
 # candidate lists and runs the parity and the malformed-input cases under ASan + UBSan.
-# Usage: bash tools/run_sanitizers.sh   -> profiles/r04_sanitizers_cpu.txt
+# Usage: bash tools/run_sanitizers.sh   [round]  -> profiles/<round>_sanitizers_cpu.txt (default r05)
 set -u
 cd "$(dirname "$0")/.."
-OUT=profiles/r04_sanitizers_cpu.txt
+OUT=profiles/${1:-r05}_sanitizers_cpu.txt
 TMP=$(mktemp -d)
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1"
 {
