@@ -14,4 +14,4 @@ bash tools/prof_pmc_traffic.sh > $O/traffic_aff.log 2>&1
 python3 -c "
 import json
 t = json.load(open('gpurun_out/pmc_traffic.json'))
-for k, v in t['kernels'].items(): print(k, v['kernel'], 'fetch %.1f MB write %.1f MB corrected %.1f MB' % (v['fetch_bytes_per_step'] / 1e6, v['write_bytes_per_step'] / 1e6, (2 * v['fetch_bytes_per_step'] + v['write_bytes_per_step']) / 1e6))"
+for k, v in t['kernels'].items(): print(k, v['kernel'], 'fetch %.1f MB write %.1f MB corrected %.1f MB' % (v['fetch_bytes_per_step'] / 1e6, v['write_bytes_per_step'] / 1e6, v['hbm_bytes_per_step_corrected'] / 1e6))"

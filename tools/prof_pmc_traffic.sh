@@ -34,7 +34,7 @@ for st, k in stage.items():
     f, w = r["fetch_KiB_per_launch"] * 1024, r["write_KiB_per_launch"] * 1024
     nl = r["launches_fetch"]
     out["kernels"][st] = {"kernel": k, "launches_per_step": round(nl / steps, 2), "fetch_bytes_per_step": int(f * nl / steps),
-                          "write_bytes_per_step": int(w * r["launches_write"] / steps), "hbm_bytes_per_step": int((f * nl + w * r["launches_write"]) / steps)}
+                          "write_bytes_per_step": int(w * r["launches_write"] / steps), "hbm_bytes_per_step_corrected": int((2 * f * nl + w * r["launches_write"]) / steps)}
 json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
 PY
