@@ -4213,13 +4213,21 @@ struct BAJob {
             return EAO_OK;
         }
         bool edgesByLandmark = true;      // the edge list is grouped landmark by landmark, ascending (what the adapters and every generator produce): ptEdges is then the identity
+        // ... and, in the same pass over the edges, the edge counts per camera and per landmark the active structure starts from
+        std::vector<int>& cnt = c.scratch;
+        cnt.assign((size_t)nC + nP, 0);
+        int* const camCnt = cnt.data(); int* const ptCnt = camCnt + nC;
         for (int e = 0, prev = 0; e < Ept; e++) {
-            EAO_REQUIRE(p->edge_cam[e] >= 0 && p->edge_cam[e] < nC && p->edge_point[e] >= 0 && p->edge_point[e] < nPo, "edge %d out of range", e);
-            edgesByLandmark = edgesByLandmark && p->edge_point[e] >= prev; prev = p->edge_point[e];
+            const int ec = p->edge_cam[e], ep = p->edge_point[e];
+            EAO_REQUIRE(ec >= 0 && ec < nC && ep >= 0 && ep < nPo, "edge %d out of range", e);
+            edgesByLandmark = edgesByLandmark && ep >= prev; prev = ep;
+            camCnt[ec]++; ptCnt[ep]++;
         }
         for (int e = 0, prev = 0; e < Epl; e++) {
-            EAO_REQUIRE(pl->pedge_cam[e] >= 0 && pl->pedge_cam[e] < nC && pl->pedge_plane[e] >= 0 && pl->pedge_plane[e] < nPl, "plane edge %d out of range", e);
-            edgesByLandmark = edgesByLandmark && pl->pedge_plane[e] >= prev; prev = pl->pedge_plane[e];
+            const int ec = pl->pedge_cam[e], ep = pl->pedge_plane[e];
+            EAO_REQUIRE(ec >= 0 && ec < nC && ep >= 0 && ep < nPl, "plane edge %d out of range", e);
+            edgesByLandmark = edgesByLandmark && ep >= prev; prev = ep;
+            camCnt[ec]++; ptCnt[nPo + ep]++;
         }
         int nFreeIn = 0;
         for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
@@ -4264,14 +4272,12 @@ struct BAJob {
         std::vector<int4>& panelWork = c.bigPanelWork;
         int bigT = 0, bigTiles = 0;
         if (bigPath) {
-            static thread_local std::vector<int> cc, cnt2, touched;
             static thread_local std::vector<unsigned char> live;
             // free cameras with at least one edge, in ascending order (the numbering the active structure below gives them: camIdx)
-            fidx.assign((size_t)nC, -1); cc.assign((size_t)nC, 0);
+            fidx.assign((size_t)nC, -1);
             lmOff.assign((size_t)nP + 1, 0);
-            for (int e = 0; e < E; e++) cc[edge_cam(e)]++;
             int nFa = 0;
-            for (int i = 0; i < nC; i++) if (cc[i] && !p->cam_fixed[i]) fidx[i] = nFa++;
+            for (int i = 0; i < nC; i++) if (camCnt[i] && !p->cam_fixed[i]) fidx[i] = nFa++;      // (camCnt: the validation pass)
             // per landmark: its free observers and their edges, in edge order (the order of the active structure's ptEdges)
             bool byLandmark = true;        // the edges come landmark by landmark (the adapters and every generator list them so): the observer lists are then a filtered copy
             for (int e = 0, prev = 0; e < E; e++) { const int lmk = edge_lm(e); byLandmark = byLandmark && lmk >= prev; prev = lmk; if (fidx[edge_cam(e)] >= 0) lmOff[lmk + 1]++; }
@@ -4568,10 +4574,7 @@ struct BAJob {
             int* actCam = (int*)hostp(dactCam); int* actPt = (int*)hostp(dactPt);
             int* ptStart = (int*)hostp(dptStart); int* ptEdges = (int*)hostp(dptEdges);
             int* camStart = (int*)hostp(dcamStart); int* camEdges = (int*)hostp(dcamEdges);
-            std::vector<int>& cnt = c.scratch;
-            cnt.assign((size_t)nC + nP, 0);
-            int* camCnt = cnt.data(); int* ptCnt = camCnt + nC;
-            for (int e = 0; e < E; e++) { camCnt[edge_cam(e)]++; ptCnt[edge_lm(e)]++; }
+            // (camCnt / ptCnt: counted with the validation pass above)
             int nF = 0, nL = 0;
             for (int i = 0; i < nC; i++) { camIdx[i] = -1; if (camCnt[i] && !p->cam_fixed[i]) { actCam[nF] = i; camIdx[i] = nF++; } }
             ptStart[0] = 0;
@@ -4580,12 +4583,18 @@ struct BAJob {
             for (int i = 0; i < nF; i++) camStart[i + 1] = camStart[i] + camCnt[actCam[i]];
             for (int i = 0; i < nL; i++) ptCnt[actPt[i]] = ptStart[i];         // counters become fill cursors
             for (int i = 0; i < nF; i++) camCnt[actCam[i]] = camStart[i];
-            if (edgesByLandmark) {      // (the landmarks' edge lists, concatenated in landmark order, ARE the edge list)
+            bool dupChecked = false;
+            if (edgesByLandmark) {      // (the landmarks' edge lists, concatenated in landmark order, ARE the edge list; the one-edge-per-pair test rides along)
+                static thread_local std::vector<int> camLast;
+                camLast.assign((size_t)nC, -1);
                 for (int e = 0; e < E; e++) {
-                    const int cam = edge_cam(e);
+                    const int cam = edge_cam(e), lmk = edge_lm(e);
                     ptEdges[e] = e;
                     if (camIdx[cam] >= 0) camEdges[camCnt[cam]++] = e;
+                    if (camLast[cam] == lmk) { eao::set_error("two edges join camera %d and point %d", cam, lmk); return EAO_ERR_INVALID; }
+                    camLast[cam] = lmk;
                 }
+                dupChecked = true;
             } else {
                 for (int e = 0; e < E; e++) {
                     const int cam = edge_cam(e);
@@ -4594,13 +4603,15 @@ struct BAJob {
                 }
             }
             // one edge per (camera, point) pair: the device's edge table has one slot per pair
-            for (int i = 0; i < nC; i++) camCnt[i] = -1;                        // now: last point seen with this camera
-            for (int l = 0; l < nL; l++)
-                for (int k = ptStart[l]; k < ptStart[l + 1]; k++) {
-                    const int cam = edge_cam(ptEdges[k]);
-                    if (camCnt[cam] == l) { eao::set_error("two edges join camera %d and point %d", cam, actPt[l]); return EAO_ERR_INVALID; }
-                    camCnt[cam] = l;
-                }
+            if (!dupChecked) {
+                for (int i = 0; i < nC; i++) camCnt[i] = -1;                        // now: last point seen with this camera
+                for (int l = 0; l < nL; l++)
+                    for (int k = ptStart[l]; k < ptStart[l + 1]; k++) {
+                        const int cam = edge_cam(ptEdges[k]);
+                        if (camCnt[cam] == l) { eao::set_error("two edges join camera %d and point %d", cam, actPt[l]); return EAO_ERR_INVALID; }
+                        camCnt[cam] = l;
+                    }
+            }
             D.nFree = nF; D.nL = nL;
             hs_lap(2);
             if (bigPath && nF > 0) {
