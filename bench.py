@@ -1098,15 +1098,19 @@ def measure_extra(E, synth, torch, dev):
         del ext1
         # map scale: more free keyframes than one workgroup factorises -> dense Schur system in HBM, panel / update LDL^T
         gm = synth.synth_ba(n_free=200, n_fixed=1, n_points=20000, seed=5300)
-        E.Optimizer.BundleAdjustment(gm, 10, bRobust=False)
-        t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(2):      # (the first call sizes the arena and the pinned mirrors, the second still grows the host crew and the set-up's scratch: steady state from the third)
+            E.Optimizer.BundleAdjustment(gm, 10, bRobust=False)
+        tsm = []
+        for _ in range(5):
+            t0 = time.perf_counter()
             rm = E.Optimizer.BundleAdjustment(gm, 10, bRobust=False)
-        dtm = (time.perf_counter() - t0) / 3
+            tsm.append(time.perf_counter() - t0)
+        dtm = float(np.median(tsm))
         trials = int(np.sum(rm["trace"]["trials"]))
         Em = len(gm["edge_cam"])
         extra["bundle_adjustment_map_scale"] = {"workload": "BundleAdjustment 200 free + 1 fixed KF x 20000 MP, E=%d, 10 its (1200 x 1200 reduced camera system; every point is seen by 2-8 consecutive keyframes, cyclically: 1 608 of 20 301 keyframe pairs are covisible, 74 of 210 tiles live after fill-in)" % Em,
-                                                "ms_per_call": round(dtm * 1e3, 3), "iters": int(rm["iters"][0]), "lm_trials": trials,
+                                                "ms_per_call": round(dtm * 1e3, 3), "ms_per_call_min_max": [round(min(tsm) * 1e3, 3), round(max(tsm) * 1e3, 3)], "timing": "median of 5 calls behind 2 warm-up calls",
+                                                "iters": int(rm["iters"][0]), "lm_trials": trials,
                                                 "ba_residual_blocks_per_s": round(Em * int(rm["iters"][0]) / dtm, 1),
                                                 # the same per-unit figure as the windows (E x 520 + P x 360 bytes per LM trial) over the call's wall time
                                                 "frac_hbm": round((Em * 520 + 20000 * 360) * trials / dtm / 1e9 / HBM_PEAK_GBS, 5)}
@@ -1114,16 +1118,20 @@ def measure_extra(E, synth, torch, dev):
         # system is a band; the map-scale path stores and factors only the 64 x 64 tiles of that structure (+ fill-in)
         try:
             gb = synth.synth_ba(n_free=1000, n_fixed=1, n_points=50000, seed=5400, band=11)
-            E.Optimizer.BundleAdjustment(gb, 10, bRobust=False)
+            for _ in range(2):
+                E.Optimizer.BundleAdjustment(gb, 10, bRobust=False)
             free0 = torch.cuda.mem_get_info()[0]
-            t0 = time.perf_counter()
-            for _ in range(3):
+            tsb = []
+            for _ in range(5):
+                t0 = time.perf_counter()
                 rb_ = E.Optimizer.BundleAdjustment(gb, 10, bRobust=False)
-            dtb_ = (time.perf_counter() - t0) / 3
+                tsb.append(time.perf_counter() - t0)
+            dtb_ = float(np.median(tsb))
             Eb = len(gb["edge_cam"])
             trb = int(np.sum(rb_["trace"]["trials"]))
             extra["bundle_adjustment_map_scale_banded"] = {"workload": "BundleAdjustment 1000 free + 1 fixed KF x 50000 MP, E=%d, 10 its; every keyframe covisible with its +-10 neighbours (6000 x 6000 band system)" % Eb,
-                                                           "ms_per_call": round(dtb_ * 1e3, 3), "iters": int(rb_["iters"][0]), "lm_trials": trb,
+                                                           "ms_per_call": round(dtb_ * 1e3, 3), "ms_per_call_min_max": [round(min(tsb) * 1e3, 3), round(max(tsb) * 1e3, 3)], "timing": "median of 5 calls behind 2 warm-up calls",
+                                                           "iters": int(rb_["iters"][0]), "lm_trials": trb,
                                                            "ba_residual_blocks_per_s": round(Eb * int(rb_["iters"][0]) / dtb_, 1),
                                                            "frac_hbm": round((Eb * 520 + 50000 * 360) * trb / dtb_ / 1e9 / HBM_PEAK_GBS, 5),
                                                            "device_MB_dense_storage_would_need": round(2 * 6016.0 * 6016 * 8 / 1e6 + 50000 * 1001 * 4 / 1e6, 1),
