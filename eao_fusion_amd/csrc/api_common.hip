@@ -50,6 +50,24 @@ eao_status require_device() {
     return cached;
 }
 
+hipError_t create_stream(hipStream_t* s, StreamClass c) {
+    static std::once_flag once;
+    static int prio[3] = {0, 0, 0};
+    static bool on = true;
+    std::call_once(once, [] {
+        const char* e = getenv("EAO_STREAM_PRIORITY");
+        if (e && !atoi(e)) { on = false; return; }
+        int least = 0, greatest = 0;      // numerically: greatest priority <= least priority
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); on = false; return; }
+        if (least == greatest) { on = false; return; }
+        prio[(int)StreamClass::Latency] = greatest;
+        prio[(int)StreamClass::Bulk] = least;
+        prio[(int)StreamClass::Background] = least - greatest >= 2 ? (least + greatest) / 2 : least;
+    });
+    if (!on) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio[(int)c]);
+}
+
 // roctx ranges around the stages of the hot path (SURVEY.md s5 "Tracing"): EAO_ROCTX=1 loads libroctx64 at the first range and
 // every later range shows up under `rocprofv3 --marker-trace`; without the variable a range is one predictable branch.
 namespace {

@@ -52,7 +52,7 @@ struct Distortion {
     double k1, k2, p1, p2, k3;
 };
 inline void fill_distortion(Distortion& D, float fx, float fy, float cx, float cy, const float* dist, int nCoef) {
-    D.on = dist && nCoef >= 4 && dist[0] != 0.0f ? 1 : 0;
+    D.on = dist && nCoef >= 1 && dist[0] != 0.0f ? 1 : 0;      // (coefficients the caller did not pass read as zero below -- a one- to three-coefficient camera is distorted too)
     D.fx = fx; D.fy = fy; D.cx = cx; D.cy = cy; D.ifx = 1. / (double)fx; D.ify = 1. / (double)fy;
     D.k1 = dist && nCoef > 0 ? dist[0] : 0; D.k2 = dist && nCoef > 1 ? dist[1] : 0; D.p1 = dist && nCoef > 2 ? dist[2] : 0; D.p2 = dist && nCoef > 3 ? dist[3] : 0;
     D.k3 = dist && nCoef > 4 ? dist[4] : 0;

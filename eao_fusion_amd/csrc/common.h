@@ -55,6 +55,18 @@ struct DevBuf {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Stream classes (round 6).  Upstream runs three threads at once on ONE device -- Tracking (per frame, real time), LocalMapping
+// (LocalBundleAdjustment, src/LocalMapping.cc:75) and LoopClosing's global BundleAdjustment thread (src/LoopClosing.cc:594; all started
+// in src/System.cc:98-138) -- so every stream the library creates says which of them it serves, and the HIP stream priority follows:
+//   Latency    -- extractor handles, the tracked-frame chain, PoseOptimization, the guided searches (a frame waits for each of them),
+//   Background -- LocalBundleAdjustment (one window and batches),
+//   Bulk       -- map-scale BundleAdjustment.
+// A priority class also has its own pool of hardware queues in the runtime, so a tracker stream no longer shares a queue with an LM
+// stream (beyond four streams of one class they do share: measured in round 2 on the batch groups).  EAO_STREAM_PRIORITY=0: every
+// stream at the default priority (the rounds 1-5 behaviour, for A/B runs).
+enum class StreamClass { Latency = 0, Background = 1, Bulk = 2 };
+hipError_t create_stream(hipStream_t* s, StreamClass c);
+
 #if defined(__HIPCC__)
 // THE hand-over point between the lanes of ONE wavefront through LDS (or through memory the wave alone touches): the
 // lanes' earlier stores are visible to the other lanes' later loads.  The hardware needs nothing for that -- a wave's

@@ -115,7 +115,7 @@ struct FCtx {   // per-thread workspace, grow-only
     eao_status ready() {
         eao_status st = eao::require_device();
         if (st) return st;
-        if (!stream) EAO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (!stream) EAO_HIP(eao::create_stream(&stream, eao::StreamClass::Latency));
         return EAO_OK;
     }
     ~FCtx() {

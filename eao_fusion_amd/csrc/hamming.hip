@@ -622,7 +622,7 @@ eao_status eao_distinctive_descriptors(int32_t n_sets, const int32_t* set_start,
     EAO_REQUIRE(set_start[0] == 0 && total >= 0 && (total == 0 || desc), "bad set table");
     for (int s2 = 0; s2 < n_sets; s2++) EAO_REQUIRE(set_start[s2 + 1] >= set_start[s2], "set table not ascending");
     DistinctScratch& c = g_distinct;
-    if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (!c.stream) EAO_HIP(eao::create_stream(&c.stream, eao::StreamClass::Background));
     if ((st = c.start.reserve((size_t)n_sets + 1))) return st;
     if ((st = c.desc.reserve(std::max((size_t)total, (size_t)1) * 32))) return st;
     if ((st = c.rowset.reserve(std::max(total, 1)))) return st;

@@ -522,6 +522,9 @@ eao_status eao_keyframe_create(const eao_frame_view* F, const eao_feature_vector
         h->index.assign(fv->index, fv->index + (nn ? fv->node_start[nn] : 0));
         std::vector<uint8_t> seen(n, 0);      // DBoW2 files a feature under ONE node; a vector that lists a keypoint twice takes the host path (upstream's greedy rule would reach across nodes)
         for (uint32_t k : h->index) { if (seen[k]) h->fvUnique = false; seen[k] = 1; }
+        //  k_kf_nodes marks side-2 entries already matched in ONE 64-bit mask per lane: 64 x 64 = 4096 entries of a node at most.  A node beyond that (DBoW2's
+        // level-4 nodes of a 1000-feature frame hold tens) takes the host path like a non-unique vector.
+        for (int a = 0; a < nn; a++) if (h->nodeStart[a + 1] - h->nodeStart[a] > 4096) h->fvUnique = false;
     }
     if (h->nodeStart.empty()) h->nodeStart.assign(1, 0);
     h->fv.n_nodes = nn; h->fv.node_id = h->nodeId.data(); h->fv.node_start = h->nodeStart.data(); h->fv.index = h->index.data();
@@ -622,7 +625,7 @@ namespace {
 eao_status ctx_ready(Ctx& c) {
     eao_status st = eao::require_device();
     if (st) return st;
-    if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (!c.stream) EAO_HIP(eao::create_stream(&c.stream, eao::StreamClass::Latency));
     return EAO_OK;
 }
 
@@ -700,6 +703,17 @@ eao_status run_nodes(int mode, const eao_keyframe* k1, int nProb, const eao_keyf
         hipLaunchKernelGGL(k_kf_finish, dim3(np), dim3(256), 0, c.stream, B);
     }
     bool seen = false;
+    //  a rejected launch would leave the device ticket counter behind ticketNext for the rest of the thread's life (every later call would spin out its
+    // 50 ms): on any launch error, and after a poll that timed out, the counter and its host twin start again from zero
+    const hipError_t launchErr = hipGetLastError();
+    if (launchErr != hipSuccess) {
+        (void)hipStreamSynchronize(c.stream);
+        (void)hipMemsetAsync(c.ticket.p, 0, sizeof(int), c.stream);
+        (void)hipStreamSynchronize(c.stream);
+        c.ticketNext = 0;
+        eao::set_error("keyframe search launch failed: %s", hipGetErrorString(launchErr));
+        return EAO_ERR_NO_DEVICE;
+    }
     if (envPoll) {
         c.ticketNext += nProb;
         const auto t0 = std::chrono::steady_clock::now();
@@ -707,7 +721,10 @@ eao_status run_nodes(int mode, const eao_keyframe* k1, int nProb, const eao_keyf
             if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
         std::atomic_thread_fence(std::memory_order_acquire);
     }
-    if (!seen) EAO_HIP(hipStreamSynchronize(c.stream));
+    if (!seen) {
+        EAO_HIP(hipStreamSynchronize(c.stream));
+        if (envPoll) { EAO_HIP(hipMemsetAsync(c.ticket.p, 0, sizeof(int), c.stream)); EAO_HIP(hipStreamSynchronize(c.stream)); c.ticketNext = 0; }
+    }
     EAO_HIP(hipGetLastError());
     if (c.dbg) {
         long long st[8];

@@ -3586,7 +3586,8 @@ struct LMTraceHost {
 thread_local LMTraceHost g_trace;
 
 struct LMContext {  // per-thread device workspace, grow-only
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                   // the stream of the call in progress: one of byClass[] (every call ends synchronised, so the next may take another)
+    hipStream_t byClass[3] = {nullptr, nullptr, nullptr};      // eao::StreamClass: PoseOptimization / LocalBundleAdjustment / map BundleAdjustment of this host thread
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     BAStatus* status = nullptr;   // pinned + mapped
     unsigned char* pin = nullptr; // pinned host mirror of the input part of the arena: ONE H2D copy per upload
@@ -3608,18 +3609,22 @@ struct LMContext {  // per-thread device workspace, grow-only
         if (pinOut) (void)hipHostFree(pinOut);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
+        for (hipStream_t q : byClass) if (q) (void)hipStreamDestroy(q);
     }
 };
 thread_local LMContext g_ctx;
 
-eao_status ctx_init(LMContext& c, bool ownStream = true) {
+eao_status ctx_init(LMContext& c, bool ownStream, eao::StreamClass cls) {
     eao_status st = eao::require_device();
     if (st) return st;
-    if (ownStream && !c.stream) {
-        EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-        EAO_HIP(hipEventCreate(&c.ev0));
-        EAO_HIP(hipEventCreate(&c.ev1));
+    if (ownStream) {
+        hipStream_t& q = c.byClass[(int)cls];
+        if (!q) EAO_HIP(eao::create_stream(&q, cls));
+        c.stream = q;
+        if (!c.ev0) {
+            EAO_HIP(hipEventCreate(&c.ev0));
+            EAO_HIP(hipEventCreate(&c.ev1));
+        }
     }
     if (!c.status) {
         EAO_HIP(hipHostMalloc((void**)&c.status, sizeof(BAStatus), hipHostMallocMapped));
@@ -3652,7 +3657,7 @@ eao_status eao_pose_optimization(const eao_pose_problem* p, eao_pose_result* r) 
     EAO_REQUIRE(M >= 0 && M <= kPoseMaxPlanes, "at most %d plane edges (got %d)", kPoseMaxPlanes, M);
     EAO_REQUIRE(M == 0 || (p->plane_world && p->plane_obs && p->plane_seen && r->plane_outlier), "plane arrays missing");
     LMContext& c = g_ctx;
-    eao_status st = ctx_init(c);
+    eao_status st = ctx_init(c, true, eao::StreamClass::Latency);
     if (st) return st;
     g_trace.clear();
     const int n = p->n;
@@ -3784,7 +3789,7 @@ eao_status eao_pose_optimization_batch(const eao_pose_problem* ps, int32_t nb, e
         EAO_REQUIRE(p->n_planes == 0 || (p->plane_world && p->plane_obs && p->plane_seen && r->plane_outlier), "plane arrays missing (problem %d)", b);
     }
     LMContext& c = g_ctx;
-    eao_status st = ctx_init(c);
+    eao_status st = ctx_init(c, true, eao::StreamClass::Latency);
     if (st) return st;
     std::vector<int> grp[8], single;      // register kernels by geometry class (pose_class) x (plane edges or not)
     for (int b = 0; b < nb; b++) {
@@ -4887,7 +4892,7 @@ struct BAJob {
 static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r, int mode, int robust,
                          const eao_ba_planes* pl = nullptr, float* planes_out = nullptr) {
     LMContext& c = g_ctx;
-    eao_status st = ctx_init(c);
+    eao_status st = ctx_init(c, true, mode == 0 ? eao::StreamClass::Background : eao::StreamClass::Bulk);
     if (st) return st;
     BAJob j;
     j.p = p; j.stop = stop; j.r = r; j.mode = mode; j.robust = robust; j.pl = pl; j.planes_out = planes_out; j.c = &c; j.tr = &g_trace;
@@ -4953,14 +4958,14 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     if (st) return st;
     BABatchPool& B = g_batch;
     if (!B.stream) {
-        EAO_HIP(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+        EAO_HIP(eao::create_stream(&B.stream, eao::StreamClass::Background));
         EAO_HIP(hipEventCreate(&B.ev0));
         EAO_HIP(hipEventCreate(&B.ev1));
     }
     while ((int)B.ctx.size() < n) B.ctx.emplace_back(new LMContext());
     if ((int)B.trace.size() < n) B.trace.resize(n);
     for (int w = 0; w < n; w++)
-        if ((st = ctx_init(*B.ctx[w], false))) return st;
+        if ((st = ctx_init(*B.ctx[w], false, eao::StreamClass::Background))) return st;
     if (B.hWCap < (size_t)n * 2) {
         if (B.hW) (void)hipHostFree(B.hW);
         B.hW = nullptr; B.hWCap = 0;
@@ -5005,7 +5010,7 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     }
     while ((int)B.side.size() < G - 1) {
         hipStream_t q; hipEvent_t e;
-        EAO_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        EAO_HIP(eao::create_stream(&q, eao::StreamClass::Background));
         EAO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         B.side.push_back(q); B.sideDone.push_back(e);
     }

@@ -231,7 +231,7 @@ eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs
     Ctx& c = g_ctx;
     eao_status st = eao::require_device();
     if (st) return st;
-    if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (!c.stream) EAO_HIP(eao::create_stream(&c.stream, eao::StreamClass::Latency));
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     struct Ord { int cx, cy, i; };
     struct Plan { int n, nq, no; size_t oKx, oKy, oUr, oOc, oOr, oCx, oCy, oDe, oQ, oQd, oOut, oMeta; size_t outCap; std::vector<Ord> ord; };
@@ -389,7 +389,7 @@ eao_status eao::match::pair_distances(const uint8_t* descA, int nA, const uint8_
     Ctx& c = g_ctx;
     eao_status st = eao::require_device();
     if (st) return st;
-    if (!c.stream) EAO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (!c.stream) EAO_HIP(eao::create_stream(&c.stream, eao::StreamClass::Latency));
     const size_t np = ia.size();
     dist.assign(np, 0);
     if (np == 0) return EAO_OK;

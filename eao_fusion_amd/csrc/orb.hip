@@ -1710,6 +1710,13 @@ struct eao_orb {
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
     bool evLastValid = false, capturing = false;   // evLastValid: a call has been enqueued on lastStream
     hipStream_t lastStream = nullptr;      // the stream of the previous call: compared, never dereferenced (its owner may have destroyed it)
+    // Round 6: ordering between calls that come in on DIFFERENT streams without draining the device (under the reference's concurrency a drain makes the
+    // Tracking thread wait for LocalMapping's whole bundle adjustment).  evLast is recorded behind a call's last kernel, a call on another stream waits for
+    // it ON THE DEVICE (hipStreamWaitEvent).  An event record between two calls costs the stream a few microseconds, so a handle that only ever sees one
+    // stream (the common case: the bench loop, one tracker) records nothing; the FIRST change of stream in a handle's life finds no event and drains once,
+    // from then on every call leaves its event.  EAO_ORB_LAST_EVENT=always records from the first call on (no drain ever), =never is the rounds 1-5 drain.
+    hipEvent_t evLast = nullptr;
+    bool everyCallEvent = false, evLastRecorded = false;
     hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {};
     eao::DevBuf<Geom> d_geom;
     eao::DevBuf<CellDesc> d_cells;
@@ -1976,20 +1983,34 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     return EAO_OK;
 }
 
+// EAO_ORB_LAST_EVENT: 0 = never (drain on a change of stream), 1 = adaptive (default), 2 = always
+int orb_last_event_mode() {
+    static const int mode = [] {
+        const char* e = getenv("EAO_ORB_LAST_EVENT");
+        if (!e) return 1;
+        if (!strcmp(e, "always")) return 2;
+        if (!strcmp(e, "never")) return 0;
+        return 1;
+    }();
+    return mode;
+}
+
 eao_status ensure(eao_orb* h, int W, int H, int batch) {
     eao_status st = eao::require_device();
     if (st) return st;
     if (!h->stream) {
-        EAO_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        EAO_HIP(eao::create_stream(&h->stream, eao::StreamClass::Latency));
         EAO_HIP(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
+        EAO_HIP(hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming));
+        h->everyCallEvent = orb_last_event_mode() == 2;
         // (HIP maps its streams onto a handful of hardware queues, and streams that share one execute in submission order: only the
         //  lanes the schedule can use get streams -- lane 0 unless EAO_ORB_LANES asks for more -- so that the streaming API's upload
         //  stream does not end up behind the extraction's side stream)
         const int lanesWanted = std::max(1, std::min(eao_orb::kLanes, getenv("EAO_ORB_LANES") ? atoi(getenv("EAO_ORB_LANES")) : 1));
         for (int i = 0; i < eao_orb::kLanes; i++) {
             if (i < lanesWanted) {
-                EAO_HIP(hipStreamCreateWithFlags(&h->laneMain[i], hipStreamNonBlocking));
-                EAO_HIP(hipStreamCreateWithFlags(&h->laneSide[i], hipStreamNonBlocking));
+                EAO_HIP(eao::create_stream(&h->laneMain[i], eao::StreamClass::Latency));
+                EAO_HIP(eao::create_stream(&h->laneSide[i], eao::StreamClass::Latency));
             }
             EAO_HIP(hipEventCreateWithFlags(&h->evFork[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
@@ -2027,6 +2048,16 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
     return EAO_OK;
 }
 
+// A call that comes in on another stream than the handle's previous call shares its pyramid / candidate scratch with it: it runs behind the previous
+// call's event on the device, or -- when that call left none (see eao_orb::evLast) -- behind a drain, after which every call of this handle leaves one.
+// The previous stream itself is never touched (its owner may have destroyed it).
+eao_status order_behind_last_call(eao_orb* h, hipStream_t st) {
+    if (h->evLastRecorded) EAO_HIP(hipStreamWaitEvent(st, h->evLast, 0));
+    else EAO_HIP(hipDeviceSynchronize());
+    if (orb_last_event_mode() != 0) h->everyCallEvent = true;
+    return EAO_OK;
+}
+
 // enqueue the whole pipeline for `batch` frames; level 0 is read from `src` (device memory)
 eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, int batch, eao_keypoint* d_kps,
                           uint8_t* d_desc, int cap, int* d_n, hipStream_t st, int lanes) {
@@ -2057,7 +2088,10 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     //  change of stream waits for the previous one on the host instead)
     //  (the previous stream may have been DESTROYED by its owner in the meantime -- a garbage-collected
     //  torch.cuda.Stream -- so its handle is never touched again: the rare change of stream drains the device instead)
-    if (h->evLastValid && !h->capturing && h->lastStream != st) EAO_HIP(hipDeviceSynchronize());
+    if (h->evLastValid && !h->capturing && h->lastStream != st) {
+        eao_status so = order_behind_last_call(h, st);
+        if (so) return so;
+    }
     if (!h->capturing) h->lastStream = st;
     EAO_HIP(hipEventRecord(h->evStart, st));
     for (int i = 0; i < lanes; i++) {
@@ -2245,6 +2279,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
     if (prof) EAO_HIP(hipEventRecord(ev[8], st));
     if (!h->capturing) {
         h->evLastValid = true;
+        if (h->everyCallEvent) { EAO_HIP(hipEventRecord(h->evLast, st)); h->evLastRecorded = true; }
     }
     EAO_HIP(hipGetLastError());
     return EAO_OK;
@@ -2278,10 +2313,14 @@ eao_status enqueue(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, 
     }
     h->lastBatch = batch; h->lastComplete = false; h->pyrFrame = -1;
     // the same ordering rule as the direct path: the replayed launches use the handle's scratch
-    if (h->evLastValid && h->lastStream != st) EAO_HIP(hipDeviceSynchronize());
+    if (h->evLastValid && h->lastStream != st) {
+        eao_status so = order_behind_last_call(h, st);
+        if (so) return so;
+    }
     h->lastStream = st;
     h->evLastValid = true;
     EAO_HIP(hipGraphLaunch(h->graphExec, st));
+    if (h->everyCallEvent) { EAO_HIP(hipEventRecord(h->evLast, st)); h->evLastRecorded = true; }
     return EAO_OK;
 }
 
@@ -2349,7 +2388,11 @@ void stream_release(eao_orb* h) {
 // the reader drain the device.
 eao_status wait_last_extraction(eao_orb* h) {
     if (!h->lastComplete) {
-        EAO_HIP(hipDeviceSynchronize());
+        if (h->evLastRecorded) EAO_HIP(hipEventSynchronize(h->evLast));      // (round 6: the call left its event)
+        else {
+            EAO_HIP(hipDeviceSynchronize());
+            if (orb_last_event_mode() != 0) h->everyCallEvent = true;           // this handle has readers behind device-API calls: later calls leave an event
+        }
         h->lastComplete = true;
     }
     return EAO_OK;
@@ -2458,6 +2501,7 @@ void eao_orb_destroy(eao_orb* h) {
     if (h->pinPyr) (void)hipHostFree(h->pinPyr);
     stream_release(h);
     if (h->evStart) (void)hipEventDestroy(h->evStart);
+    if (h->evLast) (void)hipEventDestroy(h->evLast);
     if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
     delete h;
 }
@@ -2592,9 +2636,9 @@ eao_status eao_orb_stream_create(eao_orb* h, int32_t width, int32_t height, int3
     // handle's eight unused lane streams in the way the upload stream shared a queue with the extraction's side stream and the next
     // slot's upload started ~100 us into the current extraction (0.50 ms per 64 frames instead of 0.42; the lane streams are now
     // created on demand).  Stream PRIORITIES make it worse on this runtime (upload high: 0.44; download or extraction low: 0.83-0.88).
-    EAO_HIP(hipStreamCreateWithFlags(&h->sUp, hipStreamNonBlocking));
-    EAO_HIP(hipStreamCreateWithFlags(&h->sRun, hipStreamNonBlocking));
-    EAO_HIP(hipStreamCreateWithFlags(&h->sDown, hipStreamNonBlocking));
+    EAO_HIP(eao::create_stream(&h->sUp, eao::StreamClass::Latency));
+    EAO_HIP(eao::create_stream(&h->sRun, eao::StreamClass::Latency));
+    EAO_HIP(eao::create_stream(&h->sDown, eao::StreamClass::Latency));
     h->slots.resize(nslots);
     for (eao_orb::StreamSlot& sl : h->slots) {
         EAO_HIP(hipHostMalloc((void**)&sl.pinIn, h->sInBytes, hipHostMallocDefault));

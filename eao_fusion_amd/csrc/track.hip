@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kAssignThreads) void k_track_assign_edges(int nMp, 
     if (dbg && threadIdx.x == 0) dbg[2] = clock64();
     track_edges_body(nMp, cap, match, kpMp, kx, ky, ur, oct, mXw, priorXw, invSigma2, E, edgeCap, counts, eOutl);
     __syncthreads();          // counts[2], kpMp[] are final
-    // A search that returned fewer than min_matches matches (upstream: "if(nmatches<20)" retry / return false, src/Tracking.cc:1756-1763; "if(nmatches<15) return
+    // A search that returned fewer than min_matches matches (upstream: "if(nmatches<20)" retry / return false, src/Tracking.cc:1756-1763; "if(nmatches<10) return
     // false", :1580-1581) is NOT followed by the pose optimisation: the edge count the pose kernel reads becomes zero, its launch leaves at once
     if (threadIdx.x == 0 && counts[3] < minMatches) counts[2] = 0;
     __syncthreads();
@@ -765,7 +765,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     if (hipHostMalloc((void**)&h->plPin, 10 * sizeof(double) * eao::lm::kPoseChainMaxPlanes, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->plDev, h->plPin, 0) != hipSuccess) { delete h; eao::set_error("pinned allocation failed"); return EAO_ERR_NO_DEVICE; }
     if (hipHostGetDevicePointer((void**)&h->res, h->resPin, 0) != hipSuccess) { delete h; eao::set_error("hipHostGetDevicePointer failed"); return EAO_ERR_NO_DEVICE; }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming) != hipSuccess ||
+    if (eao::create_stream(&h->stream, eao::StreamClass::Latency) != hipSuccess || hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evOut, hipEventDisableTiming) != hipSuccess) { delete h; eao::set_error("stream / event creation failed"); return EAO_ERR_NO_DEVICE; }
     h->pinCap = std::max(h->resBytes, al256(12 * M) * 2 + al256(4 * M) * 3 + al256(32 * M) + al256(M) + al256(4 * C) + al256(12 * C) +
                                       al256(sizeof(Query) * C) + al256(32 * C) + al256(4 * C)) + 4096;

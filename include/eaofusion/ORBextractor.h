@@ -73,8 +73,8 @@ public:
 
     // mvImagePyramid of the frame extracted last, materialised ON DEMAND: upstream fills it in every call (src/ORBextractor.cc:1107-1131), but only
     // Frame::ComputeStereoMatches ever reads it (src/Frame.cc:846, 936-953) -- and eaofusion::ComputeStereoMatches below does not need it either: it reads the
-    // pyramids where they are, on the device.  A caller that keeps upstream's ComputeStereoMatches sets keepPyramid = true once (Tracking's constructor, stereo
-    // sensor only) and finds the member filled after every call as before; anyone else calls ImagePyramid() when it wants the images.  Either way the levels come
+    // pyramids where they are, on the device.  A caller that keeps upstream's ComputeStereoMatches leaves keepPyramid at its default (true) and finds
+    // the member filled after every call as before; anyone else sets keepPyramid = false and calls ImagePyramid() when it wants the images.  Either way the levels come
     // in ONE library call (eao_orb_pyramid): w x h views with the 19-pixel BORDER_REFLECT_101 frame physically around them, as upstream lays them out, inside a
     // pinned block the extractor's handle owns -- valid until the next operator() call.
     std::vector<cv::Mat>& ImagePyramid() {
@@ -95,10 +95,12 @@ public:
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
     // Level images WITH the 19 px BORDER_REFLECT_101 frame around them, as upstream stores them (src/ORBextractor.cc:1113-1128): see ImagePyramid().
-    // keepPyramid = true fills the member in every operator() call (+ ~0.06 ms per 640 x 480 frame: one more launch behind the extraction, 1.3 MB over PCIe);
-    // the default leaves it to ImagePyramid().
+    // keepPyramid = true (the DEFAULT since round 6, ADVICE r5: an integrator who keeps upstream's Frame::ComputeStereoMatches must find the member filled
+    // without knowing about this flag) fills the member in every operator() call (+ ~0.02 ms per 640 x 480 frame: one more launch behind the extraction, 1.3 MB
+    // over PCIe); a caller that has replaced the stereo matcher or runs RGB-D / monocular sets it to false once and leaves the images to
+    // ImagePyramid().
     std::vector<cv::Mat> mvImagePyramid;
-    bool keepPyramid = false;
+    bool keepPyramid = true;
 
 protected:
     static void check(eao_status st, const char* what) {

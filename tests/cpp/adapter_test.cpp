@@ -111,6 +111,7 @@ int main(int argc, char** argv) {
     cv::Mat img(H, W, CV_8UC1);
     rd(in, img.data, (size_t)H * W);
     ORB_SLAM2::ORBextractor extractor(1000, 1.2f, 8, 20, 7);
+    extractor.keepPyramid = false;      // the on-demand form first (the default, keepPyramid = true, is the `eager` extractor below)
     std::vector<cv::KeyPoint> keys;
     cv::Mat descriptors;
     extractor(img, cv::Mat(), keys, descriptors);
@@ -139,9 +140,8 @@ int main(int argc, char** argv) {
     }
     int32_t pyr0[5] = {extractor.mvImagePyramid[0].rows, extractor.mvImagePyramid[0].cols, (int32_t)extractor.mvImagePyramid[7].cols, lazyEmpty, borderMismatch};
     wr(out, pyr0, 5);
-    {   // keepPyramid = true: the member is filled by operator() itself, as upstream's is
+    {   // keepPyramid = true, the default: the member is filled by operator() itself, as upstream's is
         ORB_SLAM2::ORBextractor eager(1000, 1.2f, 8, 20, 7);
-        eager.keepPyramid = true;
         std::vector<cv::KeyPoint> k2;
         cv::Mat d2;
         eager(img, cv::Mat(), k2, d2);

@@ -109,6 +109,13 @@ int main() {
     cv::Mat imL = synth_image(W, H, 0), imR = synth_image(W, H, -14);     // right image = left shifted by a 14 px disparity
     Frame F;
     F.mpORBextractorLeft = &exL; F.mpORBextractorRight = &exR;
+    {   // the drop-in default: upstream's member is filled by every call (a checkout that keeps Frame::ComputeStereoMatches reads it)
+        std::vector<cv::KeyPoint> k0; cv::Mat d0;
+        exL(imL, cv::Mat(), k0, d0);
+        CHECK(exL.keepPyramid && exL.mvImagePyramid.size() == 8 && exL.mvImagePyramid[0].cols == W && exL.mvImagePyramid[7].cols == 179, "mvImagePyramid is filled by operator() by default");
+    }
+    exL.keepPyramid = exR.keepPyramid = false;      // row 3b below replaces the stereo matcher: the pyramids stay on the device
+    for (auto& m : exL.mvImagePyramid) m = cv::Mat();
     (*F.mpORBextractorLeft)(imL, cv::Mat(), F.mvKeys, F.mDescriptors);        // Frame::ExtractORB, src/Frame.cc:616-622
     (*F.mpORBextractorRight)(imR, cv::Mat(), F.mvKeysRight, F.mDescriptorsRight);
     F.N = (int)F.mvKeys.size();

@@ -34,7 +34,8 @@ def fmt(v, nd=3):
 
 def main():
     line = json.load(open(P("bench_line.json")))
-    rf, ex = line["roofline"], line["extra"]
+    ex = line["extra"]
+    rf = dict(ex.get("flat", {}), **line["roofline"])      # (round 6: the driver-visible head of the record in `roofline`, the other flat figures in extra.flat)
     out = []
     w = out.append
     w("Source: `profiles/%s_bench_line.json` (`python bench.py`, default flags, HEAD of the round's last kernel edit).  Every row can be recomputed from the"
