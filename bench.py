@@ -49,6 +49,9 @@ def _source_sha(rel):
         return None
 
 
+LM_SOURCES = ("eao_fusion_amd/csrc/lm_internal.h", "eao_fusion_amd/csrc/lba.hip", "eao_fusion_amd/csrc/gba.hip", "eao_fusion_amd/csrc/lm_host.hip")      # (round 6: csrc/lm.hip split)
+
+
 def _fresh(pmc, rel):
     """True when the committed counter file names the hash of today's kernel source (files older than round 4 carry none: stale by definition here)."""
     return bool(pmc) and pmc.get("source_sha16", {}).get(rel) == _source_sha(rel)
@@ -56,7 +59,7 @@ def _fresh(pmc, rel):
 
 def _profile(name):
     """The newest committed profile file of that name (profiles/r05_<name>, else r04_ / r03_ / r02_<name>): recorded figures the line quotes."""
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
         if os.path.exists(f):
             return f
@@ -440,14 +443,14 @@ def ba_roofline(extra):
     linearisation + Schur assembly + solve + back substitution and the error pass).  `achieved` is measured in THIS run: bytes of all iterations of the
     call / the call's device span (HIP events on the library's stream).  `traffic` = HBM-side bytes per LM iteration from the committed FETCH_SIZE /
     WRITE_SIZE passes of the same calls (tools/prof_round.sh -> profiles/r04_ba_pmc_traffic.json; 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md
-    prescribes for gfx950), null when that file was not captured from today's lm.hip.  The dominant launch is named with its recorded average duration."""
+    prescribes for gfx950), null when that file was not captured from today's LM sources (lba.hip, gba.hip, lm_host.hip, lm_internal.h).  The dominant launch is named with its recorded average duration."""
     out = {}
     P_, per_edge, per_point = 3000, 520, 360
     tr = None
     try:
         f = _profile("ba_pmc_traffic.json")
         tr = json.load(open(f)) if f else None
-        if not _fresh(tr, "eao_fusion_amd/csrc/lm.hip"):
+        if not all(_fresh(tr, rel) for rel in LM_SOURCES):
             tr = None
     except Exception:  # noqa: BLE001
         tr = None

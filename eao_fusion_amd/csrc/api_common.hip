@@ -1,6 +1,7 @@
 // api_common.hip -- status/error plumbing and the device gate of the C-ABI (include/eao_fusion.h)
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -64,8 +65,24 @@ hipError_t create_stream(hipStream_t* s, StreamClass c) {
         prio[(int)StreamClass::Bulk] = least;
         prio[(int)StreamClass::Background] = least - greatest >= 2 ? (least + greatest) / 2 : least;
     });
+    // (Measured and not kept, profiles/r06_mixed_load_experiments.txt: leaving one or two compute units per XCD to the latency class with a CU mask on the
+    //  Background / Bulk streams -- hipExtStreamCreateWithCUMask -- made every class slower: LocalBundleAdjustment 2.14 -> 2.67 ms, the 25-window batch 2.8 -> 5.0 ms,
+    //  the tracked frame's p99 beside a looping LBA 0.87 -> 2.1 ms.)
     if (!on) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio[(int)c]);
+}
+
+hipError_t wait_latency(hipStream_t s) {
+    static const bool spin = !(getenv("EAO_SPIN_WAIT") && !atoi(getenv("EAO_SPIN_WAIT")));
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; it++) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) return e;
+            if ((it & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) break;
+        }
+    }
+    return hipStreamSynchronize(s);
 }
 
 // roctx ranges around the stages of the hot path (SURVEY.md s5 "Tracing"): EAO_ROCTX=1 loads libroctx64 at the first range and

@@ -66,6 +66,11 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // stream at the default priority (the rounds 1-5 behaviour, for A/B runs).
 enum class StreamClass { Latency = 0, Background = 1, Bulk = 2 };
 hipError_t create_stream(hipStream_t* s, StreamClass c);
+// The host's wait for a Latency-class stream: hipStreamSynchronize parks the thread on an interrupt, whose wake-up costs tens of microseconds and now and then
+// milliseconds (tests/cpp/mixed_load.cpp: the 7-10 ms maxima of the tracked frame beside a looping bundle adjustment disappear under HSA_ENABLE_INTERRUPT=0).  A frame
+// waits for each of these calls, so the caller's thread polls hipStreamQuery for up to 3 ms first (a Tracking thread has nothing else to do meanwhile; upstream's
+// computes the features on that core) and only then blocks.  EAO_SPIN_WAIT=0: always block.
+hipError_t wait_latency(hipStream_t s);
 
 #if defined(__HIPCC__)
 // THE hand-over point between the lanes of ONE wavefront through LDS (or through memory the wave alone touches): the

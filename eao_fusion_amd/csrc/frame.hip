@@ -175,7 +175,7 @@ eao_status eao_frame_is_in_frustum(const eao_frustum_frame* Fr, const eao_map_po
     A.viewCos = (float*)(c.dev.p + oCos); A.level = (int*)(c.dev.p + oLvl); A.inView = c.dev.p + oIn;
     hipLaunchKernelGGL(k_is_in_frustum, dim3(eao::cdiv(n, 256)), dim3(256), 0, s, A);
     EAO_HIP(hipMemcpyAsync(c.host + oU, c.dev.p + oU, total - oU, hipMemcpyDeviceToHost, s));
-    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(eao::wait_latency(s));
     EAO_HIP(hipGetLastError());
     std::memcpy(proj_x, c.host + oU, 4 * (size_t)n); std::memcpy(proj_y, c.host + oV, 4 * (size_t)n);
     std::memcpy(proj_xr, c.host + oUr, 4 * (size_t)n); std::memcpy(view_cos, c.host + oCos, 4 * (size_t)n);
@@ -207,7 +207,7 @@ eao_status eao_assign_features_to_grid(int32_t n, const float* kp_x, const float
     hipLaunchKernelGGL(k_grid_assign, dim3(1), dim3(kGridThreads), lds, s, n, (const float*)(c.dev.p + oX), (const float*)(c.dev.p + oY),
                        min_x, min_y, grid_inv_w, grid_inv_h, cols, rows, npow2, (int*)(c.dev.p + oS), (int*)(c.dev.p + oI));
     EAO_HIP(hipMemcpyAsync(c.host + oS, c.dev.p + oS, total - oS, hipMemcpyDeviceToHost, s));
-    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(eao::wait_latency(s));
     EAO_HIP(hipGetLastError());
     std::memcpy(cell_start, c.host + oS, 4 * (size_t)(nCells + 1));
     std::memcpy(items, c.host + oI, 4 * (size_t)cell_start[nCells]);
@@ -237,7 +237,7 @@ eao_status eao_compute_stereo_from_rgbd(int32_t n, const float* kp_x, const floa
     hipLaunchKernelGGL(k_stereo_from_rgbd, dim3(eao::cdiv(n, 256)), dim3(256), 0, s, n, (const float*)(c.dev.p + oX), (const float*)(c.dev.p + oY),
                        (const float*)(c.dev.p + oU), dDepth, pitch, mbf, (float*)(c.dev.p + oUr), (float*)(c.dev.p + oZ));
     EAO_HIP(hipMemcpyAsync(c.host + oUr, c.dev.p + oUr, total - oUr, hipMemcpyDeviceToHost, s));
-    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(eao::wait_latency(s));
     EAO_HIP(hipGetLastError());
     std::memcpy(u_right, c.host + oUr, 4 * (size_t)n); std::memcpy(out_depth, c.host + oZ, 4 * (size_t)n);
     return EAO_OK;
@@ -262,7 +262,7 @@ eao_status eao_undistort_keypoints(int32_t n, const float* kp_x, const float* kp
     hipLaunchKernelGGL(k_undistort, dim3(eao::cdiv(n, 256)), dim3(256), 0, s, D, n, (const float*)c.dev.p, (const float*)(c.dev.p + fN), (float*)(c.dev.p + 2 * fN),
                        (float*)(c.dev.p + 3 * fN));
     EAO_HIP(hipMemcpyAsync(c.host + 2 * fN, c.dev.p + 2 * fN, 2 * fN, hipMemcpyDeviceToHost, s));
-    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(eao::wait_latency(s));
     EAO_HIP(hipGetLastError());
     std::memcpy(out_x, c.host + 2 * fN, 4 * (size_t)n); std::memcpy(out_y, c.host + 3 * fN, 4 * (size_t)n);
     return EAO_OK;

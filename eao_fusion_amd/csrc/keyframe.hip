@@ -722,8 +722,8 @@ eao_status run_nodes(int mode, const eao_keyframe* k1, int nProb, const eao_keyf
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     if (!seen) {
-        EAO_HIP(hipStreamSynchronize(c.stream));
-        if (envPoll) { EAO_HIP(hipMemsetAsync(c.ticket.p, 0, sizeof(int), c.stream)); EAO_HIP(hipStreamSynchronize(c.stream)); c.ticketNext = 0; }
+        EAO_HIP(eao::wait_latency(c.stream));
+        if (envPoll) { EAO_HIP(hipMemsetAsync(c.ticket.p, 0, sizeof(int), c.stream)); EAO_HIP(eao::wait_latency(c.stream)); c.ticketNext = 0; }
     }
     EAO_HIP(hipGetLastError());
     if (c.dbg) {
@@ -831,7 +831,7 @@ eao_status eao_kf_fuse_search(int32_t n_kf, const eao_keyframe* const* kfs, int3
         }
         hipLaunchKernelGGL(k_kf_fuse, dim3(eao::cdiv(n, 4), nf), dim3(256), 0, c.stream, A);
     }
-    EAO_HIP(hipStreamSynchronize(c.stream));
+    EAO_HIP(eao::wait_latency(c.stream));
     EAO_HIP(hipGetLastError());
     std::memcpy(best_kp, c.out.p, 4 * N * (size_t)n_kf);
     for (int f = 0; f < n_kf; f++) {

@@ -355,7 +355,7 @@ eao_status eao::match::build_lists_multi(int nf, const eao_frame_view* const* Fs
     }
     int* meta = (int*)c.meta.p;
     EAO_HIP(hipMemcpyAsync(meta, c.metaDev.p, metaOff * sizeof(int), hipMemcpyDeviceToHost, s));
-    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(eao::wait_latency(s));
     EAO_HIP(hipGetLastError());
     for (int f = 0; f < nf; f++) {
         const Plan& P = plan[f];
@@ -410,7 +410,7 @@ eao_status eao::match::pair_distances(const uint8_t* descA, int nA, const uint8_
     if ((st = c.out.reserve(2 * np))) return st;
     hipLaunchKernelGGL(k_pair_distances, dim3(eao::cdiv((int)np, 256)), dim3(256), 0, s, (const uint4*)(c.dev.p + oA), (const uint4*)(c.dev.p + oB),
                        (const int2*)(c.dev.p + oP), (int)np, (unsigned short*)c.out.p);
-    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(eao::wait_latency(s));
     EAO_HIP(hipGetLastError());
     std::memcpy(dist.data(), c.out.p, 2 * np);
     return EAO_OK;

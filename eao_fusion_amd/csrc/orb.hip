@@ -1967,7 +1967,7 @@ eao_status build_geometry(eao_orb* h, int W, int H) {
     EAO_HIP(hipMemcpyAsync(h->d_geom.p, &g, sizeof(Geom), hipMemcpyHostToDevice, h->stream));
     { eao_status st = h->d_cells.reserve(h->cells.size()); if (st) return st; }
     EAO_HIP(hipMemcpyAsync(h->d_cells.p, h->cells.data(), h->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice, h->stream));
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(eao::wait_latency(h->stream));
     {   // per-function, process-wide state: only ever raised (another handle with a larger nfeatures may be in use)
         static std::atomic<int> cur{0};
         int have = cur.load();
@@ -2416,7 +2416,7 @@ eao_status enqueue_pyramid_export(eao_orb* h, int frame, int border) {
     }
     A.totalChunks = chunks;
     if (h->pinPyrCap < off) {
-        EAO_HIP(hipStreamSynchronize(h->stream));      // (a previous export may still be writing the old block)
+        EAO_HIP(eao::wait_latency(h->stream));      // (a previous export may still be writing the old block)
         if (h->pinPyr) (void)hipHostFree(h->pinPyr);
         h->pinPyr = nullptr; h->pinPyrCap = 0;
         EAO_HIP(hipHostMalloc((void**)&h->pinPyr, off, hipHostMallocMapped));
@@ -2587,7 +2587,7 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
         const size_t offK = (B * sizeof(int) + 63) & ~(size_t)63, offD = offK + B * (size_t)cap * sizeof(eao_keypoint);
         st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, batch, (eao_keypoint*)(dv + offK), dv + offD, cap, (int*)dv, h->stream);
         if (st) return st;
-        EAO_HIP(hipStreamSynchronize(h->stream));
+        EAO_HIP(eao::wait_latency(h->stream));
         h->lastComplete = true;
         const int* hn = (const int*)h->pinOut;
         for (int f = 0; f < batch; f++) {
@@ -2603,7 +2603,7 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
     EAO_HIP(hipMemcpyAsync(n, h->d_nout.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     EAO_HIP(hipMemcpyAsync(kps, h->d_kps.p, B * cap * sizeof(eao_keypoint), hipMemcpyDeviceToHost, h->stream));
     EAO_HIP(hipMemcpyAsync(desc, h->d_desc.p, B * (size_t)cap * 32, hipMemcpyDeviceToHost, h->stream));
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(eao::wait_latency(h->stream));
     h->lastComplete = true;
     return EAO_OK;
 }
@@ -2720,7 +2720,7 @@ eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which
     eao_status st = wait_last_extraction(h);
     if (st) return st;
     EAO_HIP(hipMemcpy2DAsync(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost, h->stream));
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(eao::wait_latency(h->stream));
     return EAO_OK;
 }
 
@@ -2731,7 +2731,7 @@ eao_status eao_orb_pyramid(eao_orb* h, int32_t frame, int32_t border, eao_orb_le
         eao_status st = wait_last_extraction(h);
         if (!st) st = enqueue_pyramid_export(h, frame, border);
         if (st) return st;
-        EAO_HIP(hipStreamSynchronize(h->stream));
+        EAO_HIP(eao::wait_latency(h->stream));
         EAO_HIP(hipGetLastError());
     }
     for (int l = 0; l < h->geom.nlevels; l++) levels[l] = h->pyrViews[l];
@@ -2770,7 +2770,7 @@ eao_status eao_orb_extract_ref(eao_orb* h, const uint8_t* img, int32_t width, in
     st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, 1, (eao_keypoint*)(dv + offK), dv + offD, cap, (int*)dv, h->stream);
     if (st) return st;
     if (h->autoPyrBorder >= 0 && (st = enqueue_pyramid_export(h, 0, h->autoPyrBorder))) return st;      // same stream, same synchronisation
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(eao::wait_latency(h->stream));
     h->lastComplete = true;
     *n = std::min(std::max(*(const int*)h->pinOut, 0), cap);
     *kps = (const eao_keypoint*)(h->pinOut + offK);
@@ -2786,7 +2786,7 @@ eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, fl
     if (st0) return st0;
     int cnt = 0;
     EAO_HIP(hipMemcpyAsync(&cnt, h->d_candcnt.p + frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(eao::wait_latency(h->stream));
     *n = cnt;
     if (!xyr || cnt == 0) return EAO_OK;
     const int m = std::min(cnt, cap);
@@ -2795,7 +2795,7 @@ eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, fl
     hipLaunchKernelGGL(k_unpack_cand, dim3(eao::cdiv(m, 256)), dim3(256), 0, h->stream,
                        h->d_cand.p + (long long)frame * g.totalCandCap + g.L[level].candBase, m, h->d_xyr.p);
     EAO_HIP(hipMemcpyAsync(xyr, h->d_xyr.p, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(eao::wait_latency(h->stream));
     return EAO_OK;
 }
 
@@ -2889,7 +2889,7 @@ eao_status eao_compute_stereo_matches(eao_orb* left, eao_orb* right, int32_t fra
     EAO_HIP(hipMemcpyAsync(u_right, A.uRight, 4 * (size_t)nl, hipMemcpyDeviceToHost, s));
     EAO_HIP(hipMemcpyAsync(depth, A.depth, 4 * (size_t)nl, hipMemcpyDeviceToHost, s));
     EAO_HIP(hipMemcpyAsync(sad.data(), A.sad, 4 * (size_t)nl, hipMemcpyDeviceToHost, s));
-    EAO_HIP(hipStreamSynchronize(s));
+    EAO_HIP(eao::wait_latency(s));
     EAO_HIP(hipGetLastError());
     // median-based rejection (src/Frame.cc:995-1012)
     std::vector<std::pair<int, int> > vDistIdx;

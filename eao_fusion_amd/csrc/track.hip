@@ -778,7 +778,7 @@ eao_status eao_tracker_create(const eao_tracker_cfg* cfg, eao_tracker** out) {
     EAO_HIP(hipFuncSetAttribute((const void*)k_track_assign_edges<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->assignLds));
     EAO_HIP(hipMemcpyAsync(h->dScale, h->scale.data(), 4 * (size_t)cfg->nlevels, hipMemcpyHostToDevice, h->stream));
     EAO_HIP(hipMemcpyAsync(h->dInvSigma2, h->invSigma2.data(), 4 * (size_t)cfg->nlevels, hipMemcpyHostToDevice, h->stream));
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(eao::wait_latency(h->stream));
     *out = h;
     return EAO_OK;
 }
@@ -806,11 +806,11 @@ eao_status eao_tracker_set_local_map(eao_tracker* h, const eao_map_points* pts) 
         return EAO_OK;
     };
     eao_status st;
-    EAO_HIP(hipStreamSynchronize(h->stream));      // the staging block may still feed the previous upload
+    EAO_HIP(eao::wait_latency(h->stream));      // the staging block may still feed the previous upload
     if ((st = put(h->mXw, pts->Xw, 12 * M)) || (st = put(h->mNormal, pts->normal, 12 * M)) || (st = put(h->mMin, pts->min_dist_inv, 4 * M)) ||
         (st = put(h->mMax, pts->max_dist_inv, 4 * M)) || (st = put(h->mNum, pts->max_dist, 4 * M)) || (st = put(h->mDesc, pts->desc, 32 * M)) ||
         (st = put(h->mActive, pts->active, M))) return st;
-    EAO_HIP(hipStreamSynchronize(h->stream));
+    EAO_HIP(eao::wait_latency(h->stream));
     return EAO_OK;
 }
 
@@ -1058,7 +1058,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
             if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
         std::atomic_thread_fence(std::memory_order_acquire);
     }
-    if (!seen) EAO_HIP(hipStreamSynchronize(s));
+    if (!seen) EAO_HIP(eao::wait_latency(s));
     EAO_HIP(hipGetLastError());
     if (h->dbg) {
         long long st[32];

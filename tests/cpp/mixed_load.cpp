@@ -28,9 +28,19 @@
 #include <vector>
 
 #include <eao_fusion.h>
+// (the LBA adapter's C-ABI call is routed through a wrapper that stamps its entry and exit: where in L's cycle -- accessor walk, C-ABI, write-back -- T's slow frames fall)
+namespace cabi {
+struct Span { double walk0, abi0, abi1, end; };
+static std::vector<Span> spans;              // thread L only
+static double t_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double abi0 = 0, abi1 = 0;
+template <class... A> eao_status lba(A... a) { abi0 = t_ms(); const eao_status st = ::eao_local_ba(a...); abi1 = t_ms(); return st; }
+}  // namespace cabi
+#define eao_local_ba cabi::lba
+#include <eaofusion/OptimizerImpl.h>
+#undef eao_local_ba
 #include <eaofusion/ORBextractor.h>
 #include <eaofusion/ORBmatcher.h>
-#include <eaofusion/OptimizerImpl.h>
 #include <eaofusion/DeviceTracker.h>
 
 // ---- stand-ins: the members the adapters touch, with upstream's locking / cloning behaviour (src/MapPoint.cc:68-91, 385-394; src/KeyFrame.cc:74-107, 268-300)
@@ -152,6 +162,7 @@ int main(int argc, char** argv) {
     if (argc < 4) return 2;
     const int nFrames = argc > 4 ? std::atoi(argv[4]) : 1200;
     const int periodUs = argc > 5 ? std::atoi(argv[5]) : 2000;
+    const int scenarioMask = argc > 6 ? std::atoi(argv[6]) : 15, variantMask = argc > 7 ? std::atoi(argv[7]) : 3;      // (diagnostic runs: a subset of the scenarios / variants)
     std::ifstream in(argv[1], std::ios::binary), inW(argv[2], std::ios::binary), inM(argv[3], std::ios::binary);
     if (!in || !inW || !inM) return 2;
     // ------------------------------------------------------------------ inputs (the layout of adapter_bench's problem.bin)
@@ -313,7 +324,7 @@ int main(int argc, char** argv) {
     };
 
     // ------------------------------------------------------------------ the three thread bodies
-    struct TOut { std::vector<double> total, extract, stageA, stageB; std::set<uint64_t> hashes; int late = 0; };
+    struct TOut { std::vector<double> total, extract, stageA, stageB, start; std::set<uint64_t> hashes; int late = 0; };
     std::atomic<bool> stopBg{false};
     auto runT = [&](int variant, TOut& out) {
         ORB_SLAM2::ORBextractor ex(1000, 1.2f, 8, 20, 7);
@@ -359,18 +370,21 @@ int main(int argc, char** argv) {
             }
             const double tot = ms_since(t0);
             h = fnv(h, descriptors.data, (size_t)descriptors.rows * 32);
-            if (f >= warm) { out.total.push_back(tot); out.extract.push_back(tE); out.stageA.push_back(tA); out.stageB.push_back(tB); }
+            if (f >= warm) { out.total.push_back(tot); out.extract.push_back(tE); out.stageA.push_back(tA); out.stageB.push_back(tB); out.start.push_back(cabi::t_ms() - tot); }
             out.hashes.insert(h);
         }
     };
-    struct BgOut { std::vector<double> ms; std::set<uint64_t> hashes; };
+    struct BgOut { std::vector<double> ms; std::set<uint64_t> hashes; std::atomic<int> calls{0}; };
     auto runL = [&](BgOut& out, int minCalls) {
         bool stop = false;
         for (int i = 0; !stopBg.load() || i < minCalls; i++) {
             buildWindow();
             const auto t0 = Clock::now();
+            const double w0 = cabi::t_ms();
             eaofusion::LocalBundleAdjustment<MapPoint>(pKF, &stop, &map);
             out.ms.push_back(ms_since(t0));
+            out.calls++;
+            cabi::spans.push_back(cabi::Span{w0, cabi::abi0, cabi::abi1, cabi::t_ms()});
             out.hashes.insert(windowHash());
         }
     };
@@ -381,6 +395,7 @@ int main(int argc, char** argv) {
             const auto t0 = Clock::now();
             EAOCHK(eao_local_ba_batch(P.data(), nWin, nullptr, R.data()));
             out.ms.push_back(ms_since(t0));
+            out.calls++;
             uint64_t h = 0; for (auto& w : wins) h ^= w.hash() * 1099511628211ull + (h << 7);
             out.hashes.insert(h);
         }
@@ -390,6 +405,7 @@ int main(int argc, char** argv) {
             const auto t0 = Clock::now();
             EAOCHK(eao_bundle_adjustment(&gmap.P, 0, nullptr, &gmap.R));
             out.ms.push_back(ms_since(t0));
+            out.calls++;
             out.hashes.insert(gmap.hash());
         }
     };
@@ -411,10 +427,12 @@ int main(int argc, char** argv) {
     bool identical = true;
     const char* vname[2] = {"device_chain", "class_surface"};
     for (int variant = 0; variant < 2; variant++) {
+        if (!(variantMask >> variant & 1)) continue;
         std::printf("  \"%s\": {\n", vname[variant]);
         std::set<uint64_t> ref;
         const char* sname[4] = {"idle", "beside_lba", "beside_lba_batch25", "beside_lba_and_map_ba"};
         for (int sc = 0; sc < 4; sc++) {
+            if (!(scenarioMask >> sc & 1)) { if (sc == 3) std::printf("    \"skipped\": true\n"); continue; }
             TOut T;
             BgOut L, LB, G;
             stopBg = false;
@@ -422,7 +440,11 @@ int main(int argc, char** argv) {
             if (sc == 1 || sc == 3) bg.emplace_back([&] { runL(L, 1); });
             if (sc == 2) bg.emplace_back([&] { runLB(LB, 1); });
             if (sc == 3) bg.emplace_back([&] { runG(G, 1); });
-            if (!bg.empty()) std::this_thread::sleep_for(std::chrono::milliseconds(30));      // the background jobs are in flight when the first frame arrives
+            // the background threads are long-lived in the reference (LocalMapping, LoopClosing): their first calls -- stream and arena creation, pinned mirrors -- are
+            // behind them when the first frame arrives
+            while ((sc == 1 || sc == 3) && L.calls < 2) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            while (sc == 2 && LB.calls < 2) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            while (sc == 3 && G.calls < 1) std::this_thread::sleep_for(std::chrono::milliseconds(1));
             runT(variant, T);
             stopBg = true;
             for (auto& t : bg) t.join();
@@ -434,9 +456,30 @@ int main(int argc, char** argv) {
                         stat_json(T.extract).c_str(), variant == 0 ? "motion_model_ms" : "search_last_frame_plus_pose_ms", stat_json(T.stageA).c_str(),
                         variant == 0 ? "local_map_ms" : "search_local_map_plus_pose_ms", stat_json(T.stageB).c_str(), T.late, same ? "true" : "false");
             if (!L.ms.empty()) std::printf(", \"lba_class_surface_ms\": %s", stat_json(L.ms).c_str());
+            if (sc == 1 && !cabi::spans.empty()) {
+                // where T's slow frames (beyond 1.25 x the median) START in thread L's cycle: [idle: L rebuilds its window | walk: the adapter reads the object graph |
+                // abi_first_third / rest: inside eao_local_ba (its first third holds the upload and the bulk enqueue) | write_back]; `all` = every frame, for the base rate
+                const double med = pct(T.total, 0.5);
+                int slow[5] = {0, 0, 0, 0, 0}, all[5] = {0, 0, 0, 0, 0};
+                for (size_t i = 0; i < T.total.size(); i++) {
+                    const double ts = T.start[i] + 0.5 * T.total[i];
+                    int ph = 0;
+                    for (const cabi::Span& sp : cabi::spans) {
+                        if (ts < sp.walk0 || ts > sp.end) continue;
+                        ph = ts < sp.abi0 ? 1 : ts < sp.abi0 + (sp.abi1 - sp.abi0) / 3 ? 2 : ts < sp.abi1 ? 3 : 4;
+                        break;
+                    }
+                    all[ph]++;
+                    if (T.total[i] > 1.25 * med) slow[ph]++;
+                }
+                std::printf(", \"slow_frames_by_lba_phase\": {\"idle\": [%d, %d], \"walk\": [%d, %d], \"abi_first_third\": [%d, %d], \"abi_rest\": [%d, %d], \"write_back\": [%d, %d], \"note\": \"[slow, all] frames whose midpoint falls in the phase\"}",
+                            slow[0], all[0], slow[1], all[1], slow[2], all[2], slow[3], all[3], slow[4], all[4]);
+            }
+            cabi::spans.clear();
             if (!LB.ms.empty()) std::printf(", \"lba_batch25_ms\": %s", stat_json(LB.ms).c_str());
             if (!G.ms.empty()) std::printf(", \"map_ba_ms\": %s", stat_json(G.ms).c_str());
             std::printf("}%s\n", sc == 3 ? "" : ",");
+            std::fflush(stdout);
         }
         std::printf("  },\n");
     }

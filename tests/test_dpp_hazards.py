@@ -1,6 +1,6 @@
-"""The map-scale factorisation's broadcast FMAs are hand-written 64-bit DPP instructions (inline assembly, csrc/lm.hip: v_fmac_f64_dpp / v_mov_b64_dpp with
+"""The map-scale factorisation's broadcast FMAs are hand-written 64-bit DPP instructions (inline assembly, csrc/gba.hip: v_fmac_f64_dpp / v_mov_b64_dpp with
 row_newbcast).  The hardware wants two wait states between a VALU write of a VGPR and a DPP read of it; a violation reads a stale value -- silently.  This compiles
-lm.hip for gfx950 (no GPU needed) and walks the instruction stream of every kernel that carries DPP instructions (tools/isa_census.py --dpp-hazards)."""
+gba.hip for gfx950 (no GPU needed) and walks the instruction stream of every kernel that carries DPP instructions (tools/isa_census.py --dpp-hazards)."""
 import os
 import subprocess
 import sys
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_no_dpp_read_right_behind_a_valu_write():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_census.py"), "--dpp-hazards", os.path.join(ROOT, "eao_fusion_amd", "csrc", "lm.hip"), "k_bal"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_census.py"), "--dpp-hazards", os.path.join(ROOT, "eao_fusion_amd", "csrc", "gba.hip"), "k_bal"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if "DPP instructions" in l]

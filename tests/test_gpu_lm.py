@@ -108,7 +108,7 @@ def test_local_ba_rejected_trials(gpu, oracle, seed):
         return
     assert list(r["iters"]) == list(o["iters"])
     # monocular-only windows this far from the optimum are ill-conditioned: rounding differences grow.  lambda: 4e-3 since round 4 (2e-3 before) -- the
-    # pair assembly works on Cholesky-scaled blocks now (csrc/lm.hip, ba_chol3) where upstream and the oracle multiply by an explicit 3 x 3 inverse, so
+    # pair assembly works on Cholesky-scaled blocks now (csrc/lba.hip, ba_chol3) where upstream and the oracle multiply by an explicit 3 x 3 inverse, so
     # GPU and oracle differ in rounding from the first iteration on instead of from the first reordered sum: on seed 3037 the lambda of the 14th
     # iteration moved from 1.45e-3 (explicit inverse) to 3.07e-3 (Cholesky) off the oracle's while chi2 agrees to 9e-8 and the final points to 8e-6 of the
     # update (profiles/r04_lm_seed3037.txt); one float32 ulp on the inputs moves the ORACLE's own lambda by up to 8e-3 (profiles/r02_lm_trace_sensitivity.txt)
@@ -254,7 +254,7 @@ def test_bundle_adjustment_parity(gpu, oracle, kw, its, robust):
                                            (dict(n_free=67, n_fixed=1, n_points=900, seed=5202, outlier_frac=0.0), 8, True)])
 def test_bundle_adjustment_map_scale(gpu, oracle, kw, its, robust):
     """More free keyframes than one workgroup factorises: the map-scale path (pair CSR from the host, dense lower
-    triangle in HBM, panel / update LDL^T across the chip, k_bal_* in csrc/lm.hip) against the same oracle."""
+    triangle in HBM, panel / update LDL^T across the chip, k_bal_* in csrc/gba.hip) against the same oracle."""
     p = synth.synth_ba(**kw)
     r = gpu.Optimizer.BundleAdjustment(p, its, bRobust=robust)
     o = oracle.bundle_adjustment(p, its, robust)

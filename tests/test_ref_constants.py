@@ -49,7 +49,7 @@ def _code_lines(path):
 
 
 CONSUMERS = {
-    "product": ["eao_fusion_amd/csrc/lm.hip", "eao_fusion_amd/csrc/match.hip", "eao_fusion_amd/csrc/search.hip", "eao_fusion_amd/csrc/track.hip",
+    "product": ["eao_fusion_amd/csrc/pose.hip", "eao_fusion_amd/csrc/lba.hip", "eao_fusion_amd/csrc/gba.hip", "eao_fusion_amd/csrc/lm_host.hip", "eao_fusion_amd/csrc/lm_internal.h", "eao_fusion_amd/csrc/match.hip", "eao_fusion_amd/csrc/search.hip", "eao_fusion_amd/csrc/track.hip",
                 "eao_fusion_amd/csrc/orb.hip", "eao_fusion_amd/csrc/chain_internal.h", "eao_fusion_amd/csrc/frame.hip", "eao_fusion_amd/csrc/hamming.hip"],
     "oracle": ["oracle/lm_cpu.cpp", "oracle/match_cpu.cpp", "oracle/search_cpu.cpp", "oracle/orb_cpu.cpp", "oracle/frame_cpu.cpp"],
 }
@@ -66,9 +66,13 @@ def test_no_literal_copies_beside_the_generated_header(who):
 
 
 @pytest.mark.parametrize("who,rel,names", [
-    ("product", "eao_fusion_amd/csrc/lm.hip", ["POSE_CHI2_MONO", "POSE_CHI2_STEREO", "POSE_ROUNDS", "POSE_ITS", "POSE_UNROBUST_ROUND", "POSE_HUBER2_MONO", "POSE_HUBER2_STEREO",
-                                               "LBA_CHI2_MONO", "LBA_CHI2_STEREO", "LBA_HUBER2_MONO", "LBA_HUBER2_STEREO", "GBA_HUBER2_MONO", "GBA_HUBER2_STEREO",
-                                               "PLANE_CHI2", "PLANE_ANGLE_INFO", "PLANE_DIST_INFO_ROOT", "LM_TAU", "LM_MAX_TRIALS"]),
+    # (round 6: csrc/lm.hip became pose.hip / lba.hip / gba.hip / lm_host.hip)
+    ("product", "eao_fusion_amd/csrc/pose.hip", ["POSE_CHI2_MONO", "POSE_CHI2_STEREO", "POSE_ROUNDS", "POSE_ITS", "POSE_UNROBUST_ROUND", "POSE_HUBER2_MONO", "POSE_HUBER2_STEREO",
+                                                 "PLANE_CHI2", "PLANE_ANGLE_INFO", "PLANE_DIST_INFO_ROOT", "LM_TAU", "LM_MAX_TRIALS"]),
+    ("product", "eao_fusion_amd/csrc/lba.hip", ["LBA_CHI2_MONO", "LBA_CHI2_STEREO", "LM_TAU"]),
+    ("product", "eao_fusion_amd/csrc/gba.hip", ["LM_TAU"]),
+    ("product", "eao_fusion_amd/csrc/lm_host.hip", ["LBA_HUBER2_MONO", "LBA_HUBER2_STEREO", "GBA_HUBER2_MONO", "GBA_HUBER2_STEREO", "PLANE_CHI2", "PLANE_ANGLE_INFO",
+                                                    "PLANE_DIST_INFO_ROOT", "LM_MAX_TRIALS"]),
     ("oracle", "oracle/lm_cpu.cpp", ["POSE_CHI2_MONO", "POSE_CHI2_STEREO", "POSE_ROUNDS", "POSE_ITS", "POSE_UNROBUST_ROUND", "POSE_HUBER2_MONO", "POSE_HUBER2_STEREO",
                                      "LBA_CHI2_MONO", "LBA_CHI2_STEREO", "LBA_HUBER2_MONO", "LBA_HUBER2_STEREO", "GBA_HUBER2_MONO", "GBA_HUBER2_STEREO",
                                      "PLANE_CHI2", "PLANE_ANGLE_INFO", "PLANE_DIST_INFO_ROOT", "LM_TAU", "LM_MAX_TRIALS", "LM_NI"]),

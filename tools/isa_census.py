@@ -2,8 +2,8 @@
 """Static ISA mix per kernel of one HIP source (gfx950): how many VALU / SALU / LDS / VMEM instructions, and how many of the
 VALU ones are 64-bit address arithmetic, integer multiplies, moves -- the census that found k_orient_describe's per-lane
 pointer arithmetic.  usage: python tools/isa_census.py eao_fusion_amd/csrc/orb.hip [name-filter]
-       python tools/isa_census.py --dpp-hazards eao_fusion_amd/csrc/lm.hip [name-filter]
---dpp-hazards: the hand-written 64-bit DPP instructions (inline assembly in csrc/lm.hip: v_fmac_f64_dpp / v_mov_b64_dpp with row_newbcast) need two wait states
+       python tools/isa_census.py --dpp-hazards eao_fusion_amd/csrc/gba.hip [name-filter]
+--dpp-hazards: the hand-written 64-bit DPP instructions (inline assembly in csrc/gba.hip: v_fmac_f64_dpp / v_mov_b64_dpp with row_newbcast) need two wait states
 between a VALU write of a VGPR and a DPP read of it; this walks every kernel's instruction stream and reports each DPP instruction whose broadcast source was
 written by a VALU instruction fewer than two wait states earlier, or that follows a VALU write of EXEC (v_cmpx) by fewer than five (an `s_nop N` counts N + 1).
 Exit code 1 if there is one."""
