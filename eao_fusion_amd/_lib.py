@@ -128,6 +128,7 @@ SYMBOLS = {
     "eao_bundle_adjustment_planes": (_I, [C.POINTER(BAProblem), C.POINTER(BAPlanes), _I, _P, C.POINTER(BAResult), _P]),
     "eao_last_lm_trace": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),
     "eao_last_lm_timing": (_I, [C.POINTER(C.c_float), C.POINTER(_I)]),
+    "eao_bundle_adjustment_plan": (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I]),
 }
 
 _lib = None

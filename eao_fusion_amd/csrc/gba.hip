@@ -42,8 +42,7 @@ __global__ __launch_bounds__(NT) void k_bal_schur_pairs(const BADev* __restrict_
     BA_WIN(P);
     __shared__ double red[NT / 64][42];
     if (P.ctl[kCtlHalt]) return;
-    const int nF = P.nFree, t = threadIdx.x;
-    const BigGeom g = big_geom(nF);
+    const int t = threadIdx.x, N = P.bigN;
     const bool lead = pairOff + (int)bx == 0;      // the first workgroup of the first launch also resets the trial's flags and padding
     {
         const int pi = P.lpOrder[pairOff + bx];
@@ -56,7 +55,7 @@ __global__ __launch_bounds__(NT) void k_bal_schur_pairs(const BADev* __restrict_
     if (lead) {
         if (first && t == 0) { P.lm[0] = lambda; P.lm[1] = 2; }
         if (t == 0) *P.bigFail = 0;
-        for (int r = g.n + t; r < g.N; r += NT) *big_elem(P, P.big, r, r) = 1.0;     // identity padding
+        for (int r = t; r < N; r += NT) if (P.bigRowCam[r] < 0) *big_elem(P, P.big, r, r) = 1.0;     // identity padding (behind every segment and the separator block)
     }
     const int beg = P.lpStart[bx], cnt = P.lpStart[bx + 1] - beg;
     double acc[42];
@@ -97,13 +96,16 @@ __global__ __launch_bounds__(NT) void k_bal_schur_pairs(const BADev* __restrict_
     double s = 0;
 #pragma unroll
     for (int wv = 0; wv < NT / 64; wv++) s += red[wv][t];
+    const int R1 = P.bigRow[i1], R2 = P.bigRow[i2];                          // the cameras' rows in the elimination order (round 6)
     if (t < 36) {
         const int r = t / 6, c = t - r * 6;
-        if (!diag) *big_elem(P, P.big, i2 * 6 + c, i1 * 6 + r) = s;          // lower element (row of i2, column of i1) = S(i1,i2)[r][c]
-        else if (c >= r) *big_elem(P, P.big, i1 * 6 + c, i1 * 6 + r) = s + P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
+        if (!diag) {      // the element of the LOWER triangle that holds S(i1,i2)[r][c] = S(i2,i1)[c][r]
+            if (R2 > R1) *big_elem(P, P.big, R2 + c, R1 + r) = s;
+            else *big_elem(P, P.big, R1 + r, R2 + c) = s;
+        } else if (c >= r) *big_elem(P, P.big, R1 + c, R1 + r) = s + P.Hpp[(size_t)i1 * 36 + r * 6 + c] + (r == c ? lambda : 0.0);
     } else if (diag) {
         const int r = t - 36;
-        *big_elem(P, P.big, g.N, i1 * 6 + r) = P.bp[i1 * 6 + r] - s;         // right-hand side row
+        *big_elem(P, P.big, N, R1 + r) = P.bp[i1 * 6 + r] - s;               // right-hand side row
     }
 }
 
@@ -190,15 +192,17 @@ __device__ inline void bal_store_diag_dpp(double* bigDiag, int* bigFail, int kb,
 }
 
 
-// first diagonal block of a trial (the following ones are factored by the update kernel of the panel before them)
-__global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, int wpar) {
+// the diagonal blocks of the panels nobody reaches before their launch -- the head of every segment -- straight from the assembled tiles (the others are
+// factored by the look-ahead workgroup of the last panel that updates them)
+__global__ __launch_bounds__(64) void k_bal_diag(const BADev* __restrict__ W, int wpar, int listOff) {
     BA_WIN(P);
     if (P.ctl[kCtlHalt]) return;
-    const double* T0 = big_tile(P.big, big_slot(P, 0, 0));
+    const int kb = P.bigDiagList[listOff + bx], tk = kb >> 1, oq = (kb & 1) * kBigNB;
+    const double* T0 = big_tile(P.big, big_slot(P, tk, tk)) + oq * 64 + oq;
     double X0[16], X1[kBigNB];
     bal_load_rows_dpp(T0, 64, X0, X1);
     const bool bad = bal_factor_diag_dpp(X0, X1);
-    bal_store_diag_dpp(P.bigDiag, P.bigFail, 0, X0, X1, bad);
+    bal_store_diag_dpp(P.bigDiag, P.bigFail, kb, X0, X1, bad);
 }
 
 // One launch per 32-column panel: every 64 x 64 tile of the trailing lower triangle first solves the panel rows it needs ITSELF
@@ -209,22 +213,22 @@ __global__ __launch_bounds__(64) void k_bal_diag0(const BADev* __restrict__ W, i
 // tile that still reads a and one that would overwrite it with l).  The tile that holds the NEXT diagonal block factors it on
 // the spot (one wavefront, see above), so the next launch starts from a finished L_kk.  The first version ran the row solves
 // as a launch of their own: two dependent launches per panel instead of one (12 + 13 us at 40 free keyframes).
-__global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int last, int workOff) {
+__global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int workOff) {
     const unsigned bx = blockIdx.x;
     __shared__ __attribute__((aligned(16))) double Wt[kBigNB][68];
     __shared__ __attribute__((aligned(16))) double Lt[kBigNB][68];
     __shared__ double dv[kBigNB];                      // 1 / d of the panel's diagonal block
     __shared__ double da[kBigNB][kBigNB + 1];
     constexpr size_t ld = 64;                          // (inside a tile)
-    const int k0 = kb * kBigNB, t = threadIdx.x;
-    // the workgroup's tile: record bx of the panel's work list (built by the host from the tile structure; a dense system lists every trailing tile).
-    // The halt flag travels with the record: one round trip to memory for both, not one behind the other (38 launches per trial start with this chain)
+    const int t = threadIdx.x;
+    // the workgroup's tile: record bx of the LAUNCH's work list (round 6: a launch holds the panels the schedule put side by side -- GbaPlan; the record names its panel).
+    // The halt flag travels with the record: one round trip to memory for both, not one behind the other (every launch of a trial starts with this chain)
     const int halted = A.ctl[kCtlHalt];
-    int4 wa = A.wa0;
-    int wbx = A.wb0x;
-    if (bx != 0) { wa = A.bigWork[2 * (size_t)(workOff + bx)]; wbx = A.bigWork[2 * (size_t)(workOff + bx) + 1].x; }
+    const int4 wa = A.bigWork[2 * (size_t)(workOff + bx)], wb = A.bigWork[2 * (size_t)(workOff + bx) + 1];
+    const int wbx = wb.x, kb = wb.y, flags = wb.z, nextKb = wb.w;
+    const int k0 = kb * kBigNB;
     if (halted) return;
-    const bool stp = A.dbg && bx == 0 && t == 0 && kb == 2;      // phase stamps of the look-ahead workgroup of panel 2 (EAO_DEBUG_STAMPS)
+    const bool stp = A.dbg && bx == 0 && t == 0 && (flags & 1) && kb == 2;      // phase stamps of the look-ahead workgroup of panel 2 (EAO_DEBUG_STAMPS)
     if (stp) A.dbg[16] = clock64();
     const int ti = wa.x, tj = wa.y;
     const int r0 = ti * 64, c0 = tj * 64;
@@ -244,11 +248,11 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
         for (int c = 0; c < kBigNB; c++) w[c] = 0.0;
     }
     const int tx = t & 15, ty = t >> 4;
-    const bool crit = !last && bx == 0;            // the look-ahead workgroup (see below): it walks its tile quadrant by quadrant
+    const bool crit = flags & 1;                   // a look-ahead workgroup (see below): it walks its tile quadrant by quadrant
     double c[4][4];
     double* const Ct = big_tile(A.big, wa.z);      // (the host's symbolic elimination made sure the tile exists)
     double* C = Ct + (size_t)(ty * 4) * ld + tx * 4;
-    const int oq = k0 + kBigNB - c0;               // (look-ahead) 0 or 32: offset of the next diagonal block inside this tile
+    const int oq = nextKb * kBigNB - c0;           // (look-ahead) 0 or 32: offset inside this tile of the diagonal block of panel nextKb, which this workgroup factors
     double accq[4];                                // (look-ahead) this thread's four entries of that block
     if (!crit) {
 #pragma unroll
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
         if (roleW) {
 #pragma unroll
             for (int k = 0; k < kBigNB; k++) Wt[k][t] = w[k];
-            if (ti == tj && act) {      // a tile row's DIAGONAL workgroup archives its panel rows (every listed row has one)
+            if ((flags & 2) && act) {   // ONE workgroup per (panel, tile row) archives the row's panel entries: the diagonal target's, or the z row's first listed one
                 double* ldst = big_tile(A.bigL, pslot) + ((prow & 63) << 6) + (k0 & 63);
 #pragma unroll
                 for (int k = 0; k < kBigNB; k++) ldst[k] = w[k] * dv[k];
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
     }
     __syncthreads();
     if (stp) A.dbg[18] = clock64();
+    if (flags & 4) return;      // (the right-hand side row's own tile: its record archives the panel's z entries, nothing is subtracted from scratch)
     if (!crit) {
 #pragma unroll 8
         for (int k = 0; k < kBigNB; k++) {
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int kb, int las
             if (stp) A.dbg[20] = clock64();
             const bool bad = bal_factor_diag_dpp(X0, X1);
             if (stp) A.dbg[21] = clock64();
-            bal_store_diag_dpp(A.bigDiag, A.bigFail, kb + 1, X0, X1, bad);
+            bal_store_diag_dpp(A.bigDiag, A.bigFail, nextKb, X0, X1, bad);
             if (stp) A.dbg[22] = clock64();
         }
     }
@@ -414,27 +419,28 @@ __global__ __launch_bounds__(64) void k_bal_linv(const BADev* __restrict__ W, in
 // super-block's own triangle redundantly (8 blocks of 32: column sums over the rows already solved split across the
 // waves; the 32 x 32 triangle is ONE product with the block's inverse from k_bal_linv -- 32 independent dot products instead of
 // the 31 dependent shuffle steps of rounds 3-4), then removes the super-block's contribution from ITS 64 columns of z
-// to the left: z_j -= sum_i L(i, j) x_i.  L is read once, by as many workgroups as there are column chunks; the last launch
-// (super-block 0) also applies exp(dx) * T.
-constexpr int kBigSB = 256;
-__global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__ W, int wpar, int J) {
+// to the left: z_j -= sum_i L(i, j) x_i.  L is read once, by as many workgroups as there are column chunks.
+// Round 6: a launch takes a LIST of super-blocks (blockIdx.y: the separator block's one by one, then one of every segment per launch -- GbaPlan::sb), each with
+// the range of column chunks to its left that hear from it (a segment's: its own columns only); exp(dx) * T moved into k_bal_apply behind the last launch.
+__global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__ W, int wpar, int sbOff) {
     BA_WIN(P);
-    int* const solveOk = P.solveOk;
     __shared__ double xl[kBigSB];      // z of the super-block on entry, x on exit
     extern __shared__ double sdiag[];  // (kBigSB / 32) x 32 x 32: the inverses of the super-block's unit-lower diagonal blocks
     __shared__ double part2[4][64];
     if (P.ctl[kCtlHalt]) return;
-    const BigGeom g = big_geom(P.nFree);
-    const int n = g.n, N = g.N, t = threadIdx.x;
+    const int N = P.bigN, t = threadIdx.x;
     double* S = P.bigL;            // the archived factor (rows below each panel's diagonal block, z = row N), as tiles
-    const int J0 = J * kBigSB, w = min(kBigSB, N - J0);
+    const int4 sbd = P.bigSB[sbOff + blockIdx.y];
+    const int J0 = sbd.x, w = sbd.y, chunk = sbd.z + (int)bx;      // this workgroup's column chunk of 64 (workgroup 0 also delivers x)
+    const bool hasLeft = chunk < sbd.w;
     auto zat = [&](int col) { return big_elem(P, S, N, col); };      // z = row N: its tile row is dense by construction
-    if (J > 0 && bx > 0) {      // a column chunk in which none of the super-block's tile rows holds a tile has nothing to remove (workgroup-uniform; workgroup 0 also delivers x)
+    if (bx > 0) {      // a column chunk in which none of the super-block's tile rows holds a tile has nothing to remove (workgroup-uniform)
+        if (!hasLeft) return;
         bool any = false;
-        for (int r = J0 >> 6; r <= (J0 + w - 1) >> 6; r++) any = any || big_slot(P, r, bx) >= 0;
+        for (int r = J0 >> 6; r <= (J0 + w - 1) >> 6; r++) any = any || big_slot(P, r, chunk) >= 0;
         if (!any) return;
     }
-    const bool stb = P.dbg && bx == 0 && t == 0 && J == 1;      // phase stamps (EAO_DEBUG_STAMPS): super-block 1, workgroup 0
+    const bool stb = P.dbg && bx == 0 && t == 0 && blockIdx.y == 0 && sbOff == 1;      // phase stamps (EAO_DEBUG_STAMPS): the second launch's first super-block, workgroup 0
     if (stb) P.dbg[24] = clock64();
     if (t < w) xl[t] = *zat(J0 + t);
     {   // the super-block's (up to eight) inverted diagonal blocks: 64 KB of LDS, every load of a thread in flight at once
@@ -512,19 +518,19 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
     __syncthreads();
     if (stb) P.dbg[26] = clock64();
     if (bx == 0)
-        for (int i = t; i < w; i += 256) if (J0 + i < n) P.xp[J0 + i] = xl[i];
-    if (J > 0) {
+        for (int i = t; i < w; i += 256) { const int nat = P.bigRowCam[J0 + i]; if (nat >= 0) P.xp[nat] = xl[i]; }      // (x in the cameras' natural order: what the landmarks' back substitution reads)
+    if (hasLeft) {
         // this workgroup's 64 columns to the left of the super-block
         // (rows rg, rg + 4, ... of the super-block, ALL 64 loads of a thread in flight at once behind four tile look-ups: in batches of eight, each behind its own
         //  look-ups, this loop was 21 k cycles of a 60 k-cycle launch)
-        const int j = bx * 64 + (t & 63), rg = t >> 6;
+        const int j = chunk * 64 + (t & 63), rg = t >> 6;
         // (a tile that does not exist reads the z tile instead and is masked afterwards: unconditional loads, no branch per load)
-        const double* const safe = big_tile(S, big_slot(P, N >> 6, bx)) + (t & 63);
+        const double* const safe = big_tile(S, big_slot(P, N >> 6, chunk)) + (t & 63);
         const double* tl[kBigSB / 64];
         bool ok[kBigSB / 64];
 #pragma unroll
         for (int r = 0; r < kBigSB / 64; r++) {
-            const int sl = (r << 6) < w ? big_slot(P, (J0 >> 6) + r, bx) : -1;
+            const int sl = (r << 6) < w ? big_slot(P, (J0 >> 6) + r, chunk) : -1;
             ok[r] = sl >= 0;
             tl[r] = ok[r] ? big_tile(S, sl) + (t & 63) : safe;
         }
@@ -540,13 +546,17 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
         __syncthreads();
         if (rg == 0) *zat(j) -= (part2[0][t] + part2[1][t]) + (part2[2][t] + part2[3][t]);
         if (stb) P.dbg[27] = clock64();
-        return;
     }
-    __threadfence();
-    __syncthreads();
+}
+
+// exp(dx) * T of every camera from the solved step (behind the last launch of the back substitution), and the solver's verdict
+__global__ __launch_bounds__(256) void k_bal_apply(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    if (P.ctl[kCtlHalt]) return;
+    const int t = threadIdx.x;
     const SE3* cams = cur_cams(P);
     SE3* camsT = trial_cams(P);
-    for (int cI = t; cI < P.nCams; cI += 256) {
+    for (int cI = t + 256 * (int)bx; cI < P.nCams; cI += 256 * (int)gridDim.x) {
         const int ci = P.camIdx[cI];
         if (ci >= 0) {
             double u[6];
@@ -556,10 +566,339 @@ __global__ __launch_bounds__(256) void k_bal_backsolve(const BADev* __restrict__
             camsT[cI] = cams[cI];
         }
     }
-    if (t == 0) *solveOk = *P.bigFail ? 0 : 1;
+    if (t == 0 && bx == 0) *P.solveOk = *P.bigFail ? 0 : 1;
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the ELIMINATION ORDER and LAUNCH SCHEDULE of the map-scale path.  The reference factors the reduced camera system with Eigen's
+// SimplicialLDLT behind an approximate-minimum-degree ordering (Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:95-112): its elimination tree is what lets independent
+// parts of the map factor independently.  Rounds 3-5 kept the natural keyframe order and ran ONE launch per 32-column panel, each waiting for the one before:
+// 188 dependent launches per LM trial on a 1000-keyframe trajectory (72 % of the call).  Here:
+//   order     one level of nested dissection on the covisibility graph.  The keyframes are laid out on a line (their natural order, or reverse Cuthill-McKee when that
+//             has the smaller bandwidth); P - 1 cuts of the line give P segments; a keyframe with a neighbour across a cut joins the SEPARATOR set (the smaller of the
+//             two sides' choices), so no covisibility edge links two segments.  Segments first, separators last; every segment and the separator block start on a
+//             64-row tile boundary (identity padding in between).  P minimises the estimated chain: longest segment's panels + the separator block's panels.
+//   symbolic  the tile-level fill-in of that order (as before: the block form of a sparse LDL^T's symbolic phase).
+//   schedule  panel k depends on panel j < k when j's panel rows reach k's tile row; two panels that share a tile row update a common tile.  List scheduling:
+//             a panel runs in the first launch behind all its dependencies in which no panel shares a tile row with it -- every launch takes one panel of every
+//             independent segment, so the chain is ~ N / (32 P) + (separator panels) launches long instead of N / 32.  All dependencies of a panel share its tile row,
+//             hence sit in DIFFERENT launches: the last one is unique, and its workgroup for the panel's diagonal tile factors the panel's 32 x 32 diagonal block on
+//             the spot (the look-ahead of round 4, now by the schedule's rule); panels without a dependency get theirs from one k_bal_diag launch.
+//   solve     back substitution bottom-up: the separator block in super-blocks of 256 columns (one launch each, every column to the left), then the segments'
+//             super-blocks level by level -- one launch per level for ALL segments (a segment's columns only hear from the separators and from itself).
+// A different order changes the rounding of the factorisation, nothing else (DESIGN.md section 2 already lists the Schur solver as "same factorisation up to rounding order").
+// Everything here is a pure function of the covisibility pattern: the plan is cached in the thread's context and reused while the pattern's hash stays the same.
+namespace {
+
+struct Csr { std::vector<int> off, adj; };
+
+void plan_adjacency(int n, const std::vector<int>& prA, const std::vector<int>& prB, Csr& g) {
+    g.off.assign((size_t)n + 1, 0);
+    for (size_t k = 0; k < prA.size(); k++) if (prA[k] != prB[k]) { g.off[prA[k] + 1]++; g.off[prB[k] + 1]++; }
+    for (int i = 0; i < n; i++) g.off[i + 1] += g.off[i];
+    g.adj.resize(g.off[n]);
+    std::vector<int> cur(g.off.begin(), g.off.end() - 1);
+    for (size_t k = 0; k < prA.size(); k++) if (prA[k] != prB[k]) { g.adj[cur[prA[k]]++] = prB[k]; g.adj[cur[prB[k]]++] = prA[k]; }
+}
+
+// reverse Cuthill-McKee over every component (start: a pseudo-peripheral vertex found by two sweeps from the component's vertex of smallest degree)
+void plan_rcm(int n, const Csr& g, std::vector<int>& order) {
+    order.clear();
+    std::vector<char> seen((size_t)n, 0);
+    std::vector<int> q, deg((size_t)n);
+    for (int i = 0; i < n; i++) deg[i] = g.off[i + 1] - g.off[i];
+    auto bfs = [&](int s, std::vector<int>& out, std::vector<char>& mark) {
+        out.clear(); out.push_back(s); mark[s] = 1;
+        std::vector<int> nb;
+        for (size_t h = 0; h < out.size(); h++) {
+            const int v = out[h];
+            nb.clear();
+            for (int e = g.off[v]; e < g.off[v + 1]; e++) if (!mark[g.adj[e]]) { mark[g.adj[e]] = 1; nb.push_back(g.adj[e]); }
+            std::sort(nb.begin(), nb.end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+            out.insert(out.end(), nb.begin(), nb.end());
+        }
+    };
+    std::vector<char> tmp((size_t)n, 0);
+    for (int s0 = 0; s0 < n; s0++) {
+        if (seen[s0]) continue;
+        // the component of s0, its vertex of smallest degree, two sweeps to the far end
+        std::vector<int> comp;
+        bfs(s0, comp, tmp);
+        int s = comp[0];
+        for (int v : comp) if (deg[v] < deg[s] || (deg[v] == deg[s] && v < s)) s = v;
+        for (int sweep = 0; sweep < 2; sweep++) {
+            for (int v : comp) tmp[v] = 0;
+            bfs(s, q, tmp);
+            s = q.back();
+        }
+        bfs(s, q, seen);
+        order.insert(order.end(), q.rbegin(), q.rend());
+    }
+}
+
+int plan_bandwidth(int n, const Csr& g, const std::vector<int>& pos) {
+    int bw = 0;
+    for (int v = 0; v < n; v++) for (int e = g.off[v]; e < g.off[v + 1]; e++) bw = std::max(bw, std::abs(pos[v] - pos[g.adj[e]]));
+    return bw;
+}
+
+inline int up64(int x) { return (x + 63) & ~63; }
+
+}  // namespace
+
+namespace eao {
+namespace lm {
+
+uint64_t gba_pattern_hash(int nFa, const std::vector<int>& prA, const std::vector<int>& prB) {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)nFa;
+    auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; h ^= h >> 29; };
+    mix(prA.size());
+    for (size_t k = 0; k < prA.size(); k++) mix(((uint64_t)(unsigned)prA[k] << 32) | (unsigned)prB[k]);
+    return h;
+}
+
+namespace {
+struct PlanGraph {      // what every candidate order of one pattern shares
+    int nFa = 0, rcm = 0, bandwidth = 0;
+    Csr g;
+    std::vector<int> line, pos, lo, hi;
+};
+void plan_for(const PlanGraph& G, const std::vector<int>& prA, const std::vector<int>& prB, int wantP, GbaPlan& pl);
+}  // namespace
+
+// forceP: 0 = choose, 1 = natural order, p > 1 = that many segments (the callers read EAO_BA_ND for it)
+void gba_build_plan(int nFa, const std::vector<int>& prA, const std::vector<int>& prB, int forceP, GbaPlan& pl) {
+    PlanGraph G;
+    G.nFa = nFa;
+    plan_adjacency(nFa, prA, prB, G.g);
+    // ---- the line the keyframes are laid out on
+    G.line.resize((size_t)nFa); G.pos.resize((size_t)nFa);
+    for (int i = 0; i < nFa; i++) G.line[i] = G.pos[i] = i;
+    const int bwNat = plan_bandwidth(nFa, G.g, G.pos);
+    if (nFa >= 64 && bwNat > 24) {
+        std::vector<int> rcm, rpos((size_t)nFa);
+        plan_rcm(nFa, G.g, rcm);
+        for (int i = 0; i < nFa; i++) rpos[rcm[i]] = i;
+        const int bwR = plan_bandwidth(nFa, G.g, rpos);
+        if (bwR * 5 < bwNat * 4) { G.line = rcm; G.pos = rpos; G.rcm = 1; }
+    }
+    G.bandwidth = G.rcm ? plan_bandwidth(nFa, G.g, G.pos) : bwNat;
+    // per vertex the reach of its neighbourhood along the line
+    G.lo.resize((size_t)nFa); G.hi.resize((size_t)nFa);
+    for (int v = 0; v < nFa; v++) {
+        int a = G.pos[v], b = G.pos[v];
+        for (int e = G.g.off[v]; e < G.g.off[v + 1]; e++) { a = std::min(a, G.pos[G.g.adj[e]]); b = std::max(b, G.pos[G.g.adj[e]]); }
+        G.lo[v] = a; G.hi[v] = b;
+    }
+    plan_for(G, prA, prB, 1, pl);
+    const int natural = (int)pl.launches.size();
+    if (forceP > 1) plan_for(G, prA, prB, std::min(forceP, std::max(1, nFa / 2)), pl);
+    else if (forceP == 0 && nFa >= 96) {
+        // the schedule itself is the estimate: a plan costs a fraction of a millisecond (0.23 ms at 1000 keyframes), so a handful of segment counts are built and
+        // the one with the fewest dependent launches -- factorisation + back substitution -- is kept (ties: fewer work records)
+        GbaPlan cand;
+        auto cost = [](const GbaPlan& q) { return (long long)(q.launches.size() + q.sbLaunches.size()) * 100000 + (long long)(q.work.size() / 2); };
+        for (int P : {4, 6, 8, 12, 16, 24, 32, 48}) {
+            if (nFa / P < 8) break;
+            plan_for(G, prA, prB, P, cand);
+            if (cost(cand) < cost(pl)) std::swap(pl, cand);
+        }
+        if (pl.P > 1 && (pl.launches.size() + pl.sbLaunches.size()) * 10 > (size_t)(natural + (pl.N + kBigSB - 1) / kBigSB) * 7) plan_for(G, prA, prB, 1, pl);      // (less than 30 % shorter: not worth the padding and the fill)
+    }
+    pl.chainNatural = natural;
+}
+
+namespace {
+void plan_for(const PlanGraph& G, const std::vector<int>& prA, const std::vector<int>& prB, int wantP, GbaPlan& pl) {
+    pl = GbaPlan();
+    const int nFa = G.nFa;
+    pl.nFa = nFa; pl.rcm = G.rcm; pl.bandwidth = G.bandwidth;
+    const std::vector<int>& line = G.line;
+    const std::vector<int>& pos = G.pos;
+    const std::vector<int>& lo = G.lo;
+    const std::vector<int>& hi = G.hi;
+    // (sep[v] = 1 + the cut v's separator group belongs to, 0 for a segment's keyframe.  Every group starts on a tile boundary of its own: two groups in one tile
+    //  row would make the segments to their left and right share that tile row -- the schedule could then never run them side by side)
+    std::vector<int> sepA, sepB, sep;
+    auto dissect = [&](int P, std::vector<int>& out, int& nSep) {
+        // cut i sits in front of line position cut[i]; side A: the vertex left of a cut with a neighbour at or behind it; side B: the mirror image
+        std::vector<int> cut;
+        for (int i = 1; i < P; i++) { const int c = (int)((long long)nFa * i / P); if (c > 0 && c < nFa && (cut.empty() || c > cut.back())) cut.push_back(c); }
+        sepA.assign((size_t)nFa, 0); sepB.assign((size_t)nFa, 0);
+        int nA = 0, nB = 0;
+        for (int v = 0; v < nFa; v++) {
+            const int p = pos[v];
+            const auto nx = std::upper_bound(cut.begin(), cut.end(), p);            // first cut behind p; the cuts <= p are [begin, nx)
+            if (nx != cut.end() && *nx <= hi[v]) { sepA[v] = 1 + (int)(nx - cut.begin()); nA++; }
+            if (nx != cut.begin() && *(nx - 1) > lo[v]) { sepB[v] = 1 + (int)(nx - 1 - cut.begin()); nB++; }
+        }
+        out = nA <= nB ? sepA : sepB;
+        nSep = std::min(nA, nB);
+        return cut;
+    };
+    std::vector<int> cut;
+    int nSep = 0;
+    if (wantP > 1) cut = dissect(wantP, sep, nSep);
+    else sep.assign((size_t)nFa, 0);
+    pl.P = (int)cut.size() + 1; pl.nSep = nSep;
+    // ---- rows: segments (64-aligned), then the separator block (64-aligned), N a multiple of 64 so that the right-hand side row has a tile row of its own
+    pl.rowOf.assign((size_t)nFa, -1);
+    pl.segStart.clear();
+    int row = 0;
+    {
+        size_t ci = 0;
+        bool open = false;
+        for (int p = 0; p < nFa; p++) {
+            while (ci < cut.size() && cut[ci] == p) { open = false; ci++; }
+            const int v = line[p];
+            if (sep[v]) continue;
+            if (!open) { row = up64(row); pl.segStart.push_back(row); open = true; }
+            pl.rowOf[v] = row; row += 6;
+        }
+    }
+    row = up64(row);
+    pl.sepStart = row;
+    // the separator groups, each from a tile boundary, in the order of a cyclic reduction of the chain they form once the segments are gone (every group is coupled
+    // to its two neighbours through the segments between them): the odd cuts first -- they do not see each other --, then every second of the rest, and so on.  With
+    // the groups in the order of their cuts the block is a chain of 2 (P - 1) dependent panels; this way its depth is logarithmic in P.
+    std::vector<int> gorder;
+    for (int step = 1; step <= (int)cut.size(); step *= 2)
+        for (int gq = step; gq <= (int)cut.size(); gq += 2 * step) gorder.push_back(gq);
+    static const bool envSepChain = getenv("EAO_BA_ND_SEP_CHAIN") != nullptr;      // (A/B: the separators in the order of their cuts)
+    if (envSepChain) { gorder.clear(); for (int gq = 1; gq <= (int)cut.size(); gq++) gorder.push_back(gq); }
+    for (int gq : gorder) {
+        row = up64(row);
+        for (int p = 0; p < nFa; p++) { const int v = line[p]; if (sep[v] == gq) { pl.rowOf[v] = row; row += 6; } }
+    }
+    pl.N = std::max(64, up64(row));
+    pl.segStart.push_back(pl.sepStart);      // (sentinel: segment s spans rows [segStart[s], segStart[s + 1]))
+    pl.rowCam.assign((size_t)pl.N, -1);
+    for (int v = 0; v < nFa; v++) for (int q = 0; q < 6; q++) pl.rowCam[pl.rowOf[v] + q] = v * 6 + q;
+    const int N = pl.N, tN = N >> 6, T = tN + 1;
+    pl.T = T; pl.RP = T * 64;
+    // ---- live tiles + fill-in
+    std::vector<unsigned char> live((size_t)T * T, 0);
+    auto mark = [&](int r, int c) { const int a = r >> 6, b = c >> 6; live[(size_t)std::max(a, b) * T + std::min(a, b)] = 1; };
+    for (size_t k = 0; k < prA.size(); k++) {
+        const int ra = pl.rowOf[prA[k]], rb = pl.rowOf[prB[k]];
+        mark(ra, rb); mark(ra + 5, rb); mark(ra, rb + 5); mark(ra + 5, rb + 5);
+    }
+    for (int t = 0; t < T; t++) live[(size_t)t * T + t] = 1;
+    for (int t = 0; t <= tN; t++) live[(size_t)tN * T + t] = 1;
+    std::vector<int> rws;
+    for (int k = 0; k < T; k++) {
+        rws.clear();
+        for (int i = k + 1; i < T; i++) if (live[(size_t)i * T + k]) rws.push_back(i);
+        for (size_t a1 = 0; a1 < rws.size(); a1++)
+            for (size_t b1 = 0; b1 <= a1; b1++) live[(size_t)rws[a1] * T + rws[b1]] = 1;
+    }
+    pl.tileMap.assign((size_t)T * T, -1);
+    pl.bigTiles = 0;
+    for (int i = 0; i < T; i++) for (int j = 0; j <= i; j++) if (live[(size_t)i * T + j]) pl.tileMap[(size_t)i * T + j] = pl.bigTiles++;
+    // ---- panels: the tile rows below each (rowsBelow), dependencies, launch indices
+    const int nbk = N / kBigNB;
+    pl.nbk = nbk;
+    std::vector<std::vector<int>> below((size_t)nbk);
+    for (int kb = 0; kb < nbk; kb++) {
+        const int kc = kb >> 1;
+        std::vector<int>& b = below[kb];
+        if (!(kb & 1)) b.push_back(kc);                                  // the second half of the panel's own tile
+        for (int i = kc + 1; i < T; i++) if (live[(size_t)i * T + kc]) b.push_back(i);
+    }
+    std::vector<int> launchOf((size_t)nbk, 0), provider((size_t)nbk, -1);
+    std::vector<std::vector<unsigned char>> used;                      // used[launch][tile row]
+    std::vector<int> lastAt((size_t)T, -1), lastWho((size_t)T, -1);    // per tile row: the latest launch that touches it, and its panel
+    for (int kb = 0; kb < nbk; kb++) {
+        const int tk = kb >> 1;
+        // every earlier panel that reaches tile row tk is a dependency; the latest of them is unique (they all share tk)
+        int t = lastAt[tk] + 1;
+        provider[kb] = lastWho[tk];
+        for (;; t++) {
+            if ((int)used.size() <= t) used.resize((size_t)t + 1, std::vector<unsigned char>((size_t)T, 0));
+            bool clash = false;
+            for (int r : below[kb]) if (r != tN && used[t][r]) { clash = true; break; }
+            if (!clash) break;
+        }
+        launchOf[kb] = t;
+        for (int r : below[kb]) if (r != tN) { used[t][r] = 1; if (t > lastAt[r]) { lastAt[r] = t; lastWho[r] = kb; } }
+    }
+    // (a panel whose tile row nobody reached before starts from the assembled block: its diagonal block comes from a k_bal_diag launch)
+    const int nLaunch = (int)used.size();
+    std::vector<std::vector<int>> byLaunch((size_t)nLaunch);
+    for (int kb = 0; kb < nbk; kb++) byLaunch[launchOf[kb]].push_back(kb);
+    // which (provider panel, tile) carries a look-ahead: panel kb's diagonal block is factored by its provider's workgroup for tile (tk, tk)
+    std::vector<std::vector<int>> looks((size_t)nbk);                  // looks[j] = panels whose diagonal block j's launch factors
+    for (int kb = 0; kb < nbk; kb++) if (provider[kb] >= 0) looks[provider[kb]].push_back(kb);
+    pl.work.clear(); pl.launches.clear(); pl.diagList.clear();
+    for (int t = 0; t < nLaunch; t++) {
+        GbaPlan::Launch L;
+        L.diagOff = (int)pl.diagList.size();
+        for (int kb : byLaunch[t]) if (provider[kb] < 0) pl.diagList.push_back(kb);
+        L.diagCnt = (int)pl.diagList.size() - L.diagOff;
+        L.off = (int)(pl.work.size() / 2);
+        // two passes: every panel's look-ahead records first (they are the chain's critical path: dispatched first), then the rest
+        for (int pass = 0; pass < 2; pass++)
+            for (int kb : byLaunch[t]) {
+                const int kc = kb >> 1;
+                const std::vector<int>& b = below[kb];
+                auto pslot = [&](int x) { return pl.tileMap[(size_t)x * T + kc]; };
+                for (size_t a1 = 0; a1 < b.size(); a1++)
+                    for (size_t b1 = 0; b1 <= a1; b1++) {
+                        const int ta = b[a1], tb = b[b1], sc = pl.tileMap[(size_t)ta * T + tb];
+                        if (sc < 0 || pslot(ta) < 0 || pslot(tb) < 0) continue;
+                        int next = -1;
+                        if (ta == tb) for (int k2 : looks[kb]) if ((k2 >> 1) == ta) next = k2;
+                        // the right-hand side row's own tile (tN, tN) is scratch: its record only exists to archive the panel's z entries, and only when no other
+                        // record of this panel has tile row tN as its row role
+                        const bool zOnly = ta == tN && tb == tN;
+                        if (zOnly && b.size() > 1) continue;
+                        if ((next >= 0) != (pass == 0)) continue;
+                        // archive: ONE record per (panel, tile row) stores the row's l entries -- the diagonal-target record, or for the z row the first listed one
+                        const bool archive = ta == tb ? true : (ta == tN && b1 == 0);
+                        const int flags = (next >= 0 ? 1 : 0) | (archive ? 2 : 0) | (zOnly ? 4 : 0);
+                        pl.work.push_back(make_int4(ta, tb, sc, pslot(ta)));
+                        pl.work.push_back(make_int4(pslot(tb), kb, flags, next));
+                    }
+            }
+        L.cnt = (int)(pl.work.size() / 2) - L.off;
+        pl.launches.push_back(L);
+    }
+    // ---- back substitution: separator super-blocks bottom-up (one launch each), then the segments' super-blocks level by level
+    pl.sb.clear(); pl.sbLaunches.clear();
+    auto add_launch = [&](int off) {
+        GbaPlan::SbLaunch s; s.off = off; s.cnt = (int)pl.sb.size() - off; s.maxChunks = 1;
+        for (int i = off; i < (int)pl.sb.size(); i++) s.maxChunks = std::max(s.maxChunks, pl.sb[i].w - pl.sb[i].z);
+        if (s.cnt) pl.sbLaunches.push_back(s);
+    };
+    if (N > pl.sepStart)
+        for (int J0 = pl.sepStart + (N - pl.sepStart - 1) / kBigSB * kBigSB; J0 >= pl.sepStart; J0 -= kBigSB) {
+            const int off = (int)pl.sb.size();
+            pl.sb.push_back(make_int4(J0, std::min(kBigSB, N - J0), 0, J0 >> 6));
+            add_launch(off);
+        }
+    const int nSeg = (int)pl.segStart.size() - 1;
+    int maxSb = 0;
+    for (int s = 0; s < nSeg; s++) maxSb = std::max(maxSb, (pl.segStart[s + 1] - pl.segStart[s] + kBigSB - 1) / kBigSB);
+    for (int lev = 0; lev < maxSb; lev++) {
+        const int off = (int)pl.sb.size();
+        for (int s = 0; s < nSeg; s++) {
+            const int r0 = pl.segStart[s], r1 = pl.segStart[s + 1] > r0 ? pl.segStart[s + 1] : r0;
+            // (the rows of a segment end at its padded length: [r0, next segment's start) may hold nothing but the alignment gap, which up64 already closed)
+            const int len = r1 - r0, nSb = (len + kBigSB - 1) / kBigSB, j = nSb - 1 - lev;
+            if (j < 0) continue;
+            const int J0 = r0 + j * kBigSB;
+            pl.sb.push_back(make_int4(J0, std::min(kBigSB, r1 - J0), r0 >> 6, J0 >> 6));
+        }
+        add_launch(off);
+    }
+    pl.chainEstimate = (int)(pl.launches.size() + pl.sbLaunches.size());
+}
+}  // namespace
+
+}  // namespace lm
+}  // namespace eao
 
 namespace eao {
 namespace lm {
@@ -581,23 +920,45 @@ void gba_enqueue_trial(const BALaunch& L, int par, bool firstTrial) {
     const BADev* W = L.W;
     hipStream_t s = L.s;
     auto wp = [&](int p) { return L.wp(p); };
-    const BigGeom gB = d.gB;
+    const GbaPlan& pl = *d.plan;
     (void)hipMemsetAsync(d.big, 0, ((size_t)d.bigTiles << 12) * sizeof(double), s);
     if (d.nPairsLong) hipLaunchKernelGGL(k_bal_schur_pairs<256>, dim3(d.nPairsLong), dim3(256), 0, s, W, wp(par), firstTrial ? 1 : 0, 0);
     if (d.nPairsSlots > d.nPairsLong) hipLaunchKernelGGL(k_bal_schur_pairs<64>, dim3(d.nPairsSlots - d.nPairsLong), dim3(64), 0, s, W, wp(par), firstTrial ? 1 : 0, d.nPairsLong);
-    const int nbk = gB.N / kBigNB;
-    hipLaunchKernelGGL(k_bal_diag0, dim3(1), dim3(64), 0, s, W, wp(par));
     BigStepArgs A = d.bigArgs;
     A.ctl = d.bigCtl0 + 8 * (par & 1);
-    for (int kb = 0; kb < nbk; kb++) {
-        // the panel's work list: the trailing tiles both of whose tile rows are live in the panel's tile column (a dense system: every trailing tile)
-        const int4* rec = d.bigPanelWork + 2 * (size_t)d.bigPanelStart[kb];
-        A.wa0 = rec[0]; A.wb0x = rec[1].x;
-        hipLaunchKernelGGL(k_bal_step, dim3(d.bigPanelStart[kb + 1] - d.bigPanelStart[kb]), dim3(256), 0, s, A, kb, kb + 1 == nbk ? 1 : 0, d.bigPanelStart[kb]);
+    // the factorisation: one launch per level of the schedule (GbaPlan::launches) -- the panels of independent segments side by side
+    for (const GbaPlan::Launch& Lq : pl.launches) {
+        if (Lq.diagCnt) hipLaunchKernelGGL(k_bal_diag, dim3(Lq.diagCnt), dim3(64), 0, s, W, wp(par), Lq.diagOff);
+        if (Lq.cnt) hipLaunchKernelGGL(k_bal_step, dim3(Lq.cnt), dim3(256), 0, s, A, Lq.off);
     }
-    hipLaunchKernelGGL(k_bal_linv, dim3(eao::cdiv(nbk, 2)), dim3(64), 0, s, W, wp(par), nbk);
-    for (int J = eao::cdiv(gB.N, kBigSB) - 1; J >= 0; J--)
-        hipLaunchKernelGGL(k_bal_backsolve, dim3(std::max(1, J * kBigSB / 64)), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, W, wp(par), J);
+    hipLaunchKernelGGL(k_bal_linv, dim3(eao::cdiv(pl.nbk, 2)), dim3(64), 0, s, W, wp(par), pl.nbk);
+    for (const GbaPlan::SbLaunch& Sq : pl.sbLaunches)
+        hipLaunchKernelGGL(k_bal_backsolve, dim3(Sq.maxChunks, Sq.cnt), dim3(256), (kBigSB / kBigNB) * kBigNB * kBigNB * sizeof(double), s, W, wp(par), Sq.off);
+    hipLaunchKernelGGL(k_bal_apply, dim3(eao::cdiv(std::max(d.nC, 1), 256)), dim3(256), 0, s, W, wp(par));
 }
 }  // namespace lm
 }  // namespace eao
+
+extern "C" {
+
+eao_status eao_bundle_adjustment_plan(int32_t n_free, int32_t n_pairs, const int32_t* pair_a, const int32_t* pair_b, int32_t force_segments, eao_gba_plan_info* info,
+                                      int32_t* row_of, int32_t* tile_map, int32_t cap_tile_map, int32_t* work, int32_t cap_work, int32_t* launches, int32_t cap_launches,
+                                      int32_t* diag_list, int32_t cap_diag, int32_t* sb, int32_t cap_sb, int32_t* sb_launches, int32_t cap_sb_launches) {
+    EAO_REQUIRE(n_free > 0 && n_free <= kBigMaxFree && n_pairs >= 0 && (n_pairs == 0 || (pair_a && pair_b)) && info, "bad argument");
+    std::vector<int> A(pair_a, pair_a + n_pairs), B(pair_b, pair_b + n_pairs);
+    for (int k = 0; k < n_pairs; k++) EAO_REQUIRE(A[k] >= 0 && A[k] <= B[k] && B[k] < n_free, "pair %d: (%d, %d) is not 0 <= a <= b < n_free", k, A[k], B[k]);
+    GbaPlan pl;
+    gba_build_plan(n_free, A, B, force_segments, pl);
+    *info = eao_gba_plan_info{pl.nFa, pl.N, pl.T, pl.nbk, pl.bigTiles, pl.P, pl.nSep, pl.sepStart, pl.rcm, pl.bandwidth, pl.chainNatural, pl.chainEstimate,
+                              (int32_t)pl.launches.size(), (int32_t)(pl.work.size() / 2), (int32_t)pl.diagList.size(), (int32_t)pl.sb.size(), (int32_t)pl.sbLaunches.size()};
+    if (row_of) std::memcpy(row_of, pl.rowOf.data(), pl.rowOf.size() * 4);
+    if (tile_map && cap_tile_map >= (int)pl.tileMap.size()) std::memcpy(tile_map, pl.tileMap.data(), pl.tileMap.size() * 4);
+    if (work && cap_work >= (int)(pl.work.size() / 2)) std::memcpy(work, pl.work.data(), pl.work.size() * sizeof(int4));
+    if (launches && cap_launches >= (int)pl.launches.size()) std::memcpy(launches, pl.launches.data(), pl.launches.size() * sizeof(GbaPlan::Launch));
+    if (diag_list && cap_diag >= (int)pl.diagList.size()) std::memcpy(diag_list, pl.diagList.data(), pl.diagList.size() * 4);
+    if (sb && cap_sb >= (int)pl.sb.size()) std::memcpy(sb, pl.sb.data(), pl.sb.size() * sizeof(int4));
+    if (sb_launches && cap_sb_launches >= (int)pl.sbLaunches.size()) std::memcpy(sb_launches, pl.sbLaunches.data(), pl.sbLaunches.size() * sizeof(GbaPlan::SbLaunch));
+    return EAO_OK;
+}
+
+}  // extern "C"

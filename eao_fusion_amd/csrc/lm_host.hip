@@ -182,7 +182,6 @@ struct BAJob {
         //  the slab assembly takes 5.8 ms at 31 free keyframes and 29 ms at 64, the map-scale path 3.6 and 6.9 ms -- so everything
         //  beyond the register-tile solver goes there; that older path was removed in round 5)
         const bool bigPath = nFreeIn > kTileMaxFree || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
-        const BigGeom bg = big_geom(std::max(nFreeIn, 1));
         size_t lpEntries = 0, lpPairsMax = 0;
         // ---- round 5: the covisibility structure of the map-scale path, CAMERA-MAJOR.  For every free camera i1 (ascending) the landmarks it observes in ascending
         //      order, and for each of them its observers i2 >= i1: the pairs (i1, i2) of camera i1 are counted in a counter array of nF entries that stays in the
@@ -205,17 +204,14 @@ struct BAJob {
             auto body = [&]() { for (int q; (q = next.fetch_add(1)) < nChunks;) chunk(q); };
             host_crew().run(nT - 1, [&](int) { body(); }, body);
         };
-        // ---- round 5: the TILE structure of the map-scale system.  Which 64 x 64 tiles of the lower triangle can ever be non-zero: the tiles a covisible camera pair's
-        //      6 x 6 block touches, the diagonal, the tile row of the right-hand side -- and the fill-in of the elimination, worked out here once at tile level
-        //      (eliminating tile column k joins every pair of tile rows that are live in it: the block form of the symbolic factorisation a sparse LDL^T starts
-        //      with, solvers/linear_solver_eigen.h:95-112; natural keyframe order -- consecutive keyframes are the covisible ones, which is what a fill-reducing
-        //      ordering would recover).  Memory and the launches' grids follow this structure.
-        static thread_local std::vector<int> tileMap;       // (consumed inside this function: copied into the pinned mirror below)
-        std::vector<int>& panelStart = c.bigPanelStart;     // (read by the launches of this window, long after this function has returned: the context's)
-        std::vector<int4>& panelWork = c.bigPanelWork;
+        // ---- the ORDER, TILE structure and launch SCHEDULE of the map-scale system (GbaPlan, gba.hip; round 5 built the tile structure here in natural keyframe order):
+        //      which 64 x 64 tiles of the lower triangle can ever be non-zero -- the tiles a covisible camera pair's 6 x 6 block touches in the elimination order, the
+        //      diagonal, the tile row of the right-hand side, and the fill-in of the elimination worked out at tile level (the block form of the symbolic factorisation a
+        //      sparse LDL^T starts with, solvers/linear_solver_eigen.h:95-112).  Memory and the launches' grids follow this structure.  The plan is a pure function of
+        //      the pair list; the context keeps it while the list's hash stays the same.
+        GbaPlan& plan = c.plan;             // (read by the launches of this window, long after this function has returned: the context's)
         int bigT = 0, bigTiles = 0;
         if (bigPath) {
-            static thread_local std::vector<unsigned char> live;
             // free cameras with at least one edge, in ascending order (the numbering the active structure below gives them: camIdx)
             fidx.assign((size_t)nC, -1);
             lmOff.assign((size_t)nP + 1, 0);
@@ -322,50 +318,19 @@ struct BAJob {
             EAO_REQUIRE((size_t)run == lpEntries, "internal: covisibility count mismatch (%d entries counted, %zu expected)", run, lpEntries);
             lpPairsMax = prA.size();
             hs_lap(7);
-            const BigGeom g = big_geom(std::max(nFa, 1));
-            bigT = g.RP / 64;
-            const int T = bigT, tN = g.N >> 6;
-            live.assign((size_t)T * T, 0);
-            // the tiles the pairs' 6 x 6 blocks touch
-            for (size_t k = 0; k < prA.size(); k++) {
-                const int lo = prA[k], hi = prB[k];
-                const int r0 = (6 * hi) >> 6, r1 = (6 * hi + 5) >> 6, c0 = (6 * lo) >> 6, c1 = (6 * lo + 5) >> 6;
-                live[(size_t)std::max(r0, c0) * T + std::min(r0, c0)] = 1; live[(size_t)std::max(r0, c1) * T + std::min(r0, c1)] = 1;
-                live[(size_t)std::max(r1, c0) * T + std::min(r1, c0)] = 1; live[(size_t)std::max(r1, c1) * T + std::min(r1, c1)] = 1;
+            {
+                const int forceP = getenv("EAO_BA_ND") ? atoi(getenv("EAO_BA_ND")) : 0;      // (read per call: A/B runs and the tests -- 1 = natural order, p > 1 = p segments)
+                const uint64_t key = gba_pattern_hash(nFa, prA, prB) ^ ((uint64_t)(unsigned)forceP << 48);
+                if (!plan.valid || plan.key != key || plan.nFa != nFa) {
+                    gba_build_plan(nFa, prA, prB, forceP, plan);
+                    plan.key = key; plan.valid = true;
+                    if (hostStamps) fprintf(stderr, "[eao map-scale plan] %d free keyframes (bandwidth %d%s): %d segment(s), %d separator keyframes, %d rows in %d tiles; %zu factorisation launches "
+                                            "(natural order: %d), %zu back-substitution launches, %zu work records\n", nFa, plan.bandwidth, plan.rcm ? ", reverse Cuthill-McKee line" : "", plan.P,
+                                            plan.nSep, plan.N, plan.bigTiles, plan.launches.size(), plan.chainNatural, plan.sbLaunches.size(), plan.work.size() / 2);
+                }
             }
-            for (int t = 0; t < T; t++) live[(size_t)t * T + t] = 1;
-            for (int t = 0; t <= tN; t++) live[(size_t)tN * T + t] = 1;      // the right-hand side row N (and the z it becomes) spans every column
-            std::vector<int> rws;
-            for (int k = 0; k < T; k++) {      // symbolic elimination
-                rws.clear();
-                for (int i = k + 1; i < T; i++) if (live[(size_t)i * T + k]) rws.push_back(i);
-                for (size_t a1 = 0; a1 < rws.size(); a1++)
-                    for (size_t b1 = 0; b1 <= a1; b1++) live[(size_t)rws[a1] * T + rws[b1]] = 1;
-            }
-            tileMap.assign((size_t)T * T, -1);
-            for (int i = 0; i < T; i++) for (int j = 0; j <= i; j++) if (live[(size_t)i * T + j]) tileMap[(size_t)i * T + j] = bigTiles++;
-            // per 32-column panel: one record pair per tile its launch updates -- the trailing tiles (a, b) whose two tile rows are live in the panel's tile column;
-            // the tile of the next diagonal block first (its workgroup factors that block on the spot, also when the panel itself does not reach it)
-            const int nbk = g.N / kBigNB;
-            panelStart.assign((size_t)nbk + 1, 0); panelWork.clear();
-            for (int kb = 0; kb < nbk; kb++) {
-                const int kc = (kb * kBigNB) >> 6, tj0 = (kb * kBigNB + kBigNB) >> 6;
-                panelStart[kb] = (int)(panelWork.size() / 2);
-                rws.clear();
-                rws.push_back(tj0);
-                for (int i = tj0 + 1; i < T; i++) if (live[(size_t)i * T + kc]) rws.push_back(i);
-                auto pslot = [&](int x) { return tileMap[(size_t)x * T + kc]; };
-                for (size_t a1 = 0; a1 < rws.size(); a1++)
-                    for (size_t b1 = 0; b1 <= a1; b1++) {
-                        const int ta = rws[a1], tb = rws[b1], sc = tileMap[(size_t)ta * T + tb];
-                        const bool first = a1 == 0;
-                        if (!first && (sc < 0 || pslot(ta) < 0 || pslot(tb) < 0)) continue;      // nothing to subtract from a tile one of whose panel tiles is zero
-                        panelWork.push_back(make_int4(ta, tb, sc, pslot(ta)));
-                        panelWork.push_back(make_int4(pslot(tb), 0, 0, 0));
-                    }
-            }
-            panelStart[nbk] = (int)(panelWork.size() / 2);
-            EAO_REQUIRE(panelWork.size() < ((size_t)1 << 28), "tile structure too large (%zu work records)", panelWork.size() / 2);
+            bigT = plan.T; bigTiles = plan.bigTiles;
+            EAO_REQUIRE(plan.work.size() < ((size_t)1 << 28), "tile structure too large (%zu work records)", plan.work.size() / 2);
         }
         hs_lap(0);
         size_t need = 0;
@@ -376,8 +341,8 @@ struct BAJob {
         need += (size_t)nP * 9 * 8 + 2048 + 256;      // Tl, ul, the zero block
         need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
-            need += (2 * ((size_t)bigTiles << 12) + 2 * (size_t)bg.N * kBigNB) * 8;
-            need += (3 * lpEntries + 5 * lpPairsMax + 72) * 4 + (tileMap.size() + panelStart.size() + 8) * 4 + panelWork.size() * sizeof(int4) + 2048;
+            need += (2 * ((size_t)bigTiles << 12) + 2 * (size_t)plan.N * kBigNB) * 8;
+            need += (3 * lpEntries + 5 * lpPairsMax + 72) * 4 + (plan.tileMap.size() + plan.rowOf.size() + plan.rowCam.size() + plan.diagList.size() + 8) * 4 + (plan.work.size() + plan.sb.size()) * sizeof(int4) + 4096;
         } else {
             need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
             need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * (4 + 16);   // landmark lists / item records of the camera pairs
@@ -387,7 +352,7 @@ struct BAJob {
         if ((st = c.bytes.reserve(need))) return st;
         if (bigPath && getenv("EAO_DEBUG_STAMPS"))
             fprintf(stderr, "[eao map-scale arena] %.1f MB for this problem (%d x %d tile grid, %d live tiles = %.1f MB in the two pools, %zu work records), context arena %.1f MB\n",
-                    need / 1e6, bigT, bigT, bigTiles, 2.0 * bigTiles * 32768 / 1e6, panelWork.size() / 2, c.bytes.n / 1e6);
+                    need / 1e6, bigT, bigT, bigTiles, 2.0 * bigTiles * 32768 / 1e6, plan.work.size() / 2, c.bytes.n / 1e6);
         Arena a{c.bytes.p, c.bytes.n};
         std::memset(&D, 0, sizeof(D));
         D.nCams = nC; D.nPts = nP; D.nEdges = E;
@@ -411,8 +376,12 @@ struct BAJob {
         int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
         int* dlpE1 = a.take<int>(bigPath ? lpEntries : 1);
         int* dlpE2 = a.take<int>(bigPath ? lpEntries : 1);
-        int* dbigTile = a.take<int>(bigPath ? tileMap.size() : 1);
-        int4* dbigWork = a.take<int4>(bigPath ? std::max<size_t>(panelWork.size(), 1) : 1);
+        int* dbigTile = a.take<int>(bigPath ? plan.tileMap.size() : 1);
+        int4* dbigWork = a.take<int4>(bigPath ? std::max<size_t>(plan.work.size(), 1) : 1);
+        int* dbigRow = a.take<int>(bigPath ? std::max<size_t>(plan.rowOf.size(), 1) : 1);
+        int* dbigRowCam = a.take<int>(bigPath ? std::max<size_t>(plan.rowCam.size(), 1) : 1);
+        int4* dbigSB = a.take<int4>(bigPath ? std::max<size_t>(plan.sb.size(), 1) : 1);
+        int* dbigDiagList = a.take<int>(bigPath ? std::max<size_t>(plan.diagList.size(), 1) : 1);
         double* dpl0 = a.take<double>((size_t)nPl * 4 + 1);
         double* dpmeas = a.take<double>((size_t)Epl * 4 + 1);
         dW = a.take<BADev>(2);
@@ -444,8 +413,9 @@ struct BAJob {
         D.big = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
         D.bigL = a.take<double>(bigPath ? ((size_t)bigTiles << 12) : 8);
         D.bigTile = dbigTile; D.bigT = bigT; D.bigTiles = bigTiles; D.bigWork = dbigWork; D.bigDense = bigPath && bigTiles == bigT * (bigT + 1) / 2 ? 1 : 0;
-        D.bigDiag = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
-        D.bigLinv = a.take<double>(bigPath ? (size_t)bg.N * kBigNB : 8);
+        D.bigDiag = a.take<double>(bigPath ? (size_t)plan.N * kBigNB : 8);
+        D.bigLinv = a.take<double>(bigPath ? (size_t)plan.N * kBigNB : 8);
+        D.bigN = bigPath ? plan.N : 0; D.bigRow = dbigRow; D.bigRowCam = dbigRowCam; D.bigSB = dbigSB; D.bigDiagList = dbigDiagList;
         D.bigFail = a.take<int>(4);
         D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpOrder = dlpOrder; D.lpPts = dlpPts; D.lpE1 = dlpE1; D.lpE2 = dlpE2;
         D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
@@ -562,9 +532,13 @@ struct BAJob {
                 // (counting sort over the landmarks' observer lists; the diagonal pairs carry each camera's own landmarks)
                 int* lpStart = (int*)hostp(dlpStart); int* lpPair = (int*)hostp(dlpPair); int* lpPts = (int*)hostp(dlpPts);
                 int* lpE1 = (int*)hostp(dlpE1); int* lpE2 = (int*)hostp(dlpE2);
-                EAO_REQUIRE(big_geom(nF).RP / 64 == bigT, "internal: tile structure built for another system size");
-                std::memcpy(hostp(dbigTile), tileMap.data(), tileMap.size() * sizeof(int));
-                if (!panelWork.empty()) std::memcpy(hostp(dbigWork), panelWork.data(), panelWork.size() * sizeof(int4));
+                EAO_REQUIRE(plan.valid && plan.nFa == nF && plan.T == bigT, "internal: tile structure built for another system size");
+                std::memcpy(hostp(dbigTile), plan.tileMap.data(), plan.tileMap.size() * sizeof(int));
+                if (!plan.work.empty()) std::memcpy(hostp(dbigWork), plan.work.data(), plan.work.size() * sizeof(int4));
+                std::memcpy(hostp(dbigRow), plan.rowOf.data(), plan.rowOf.size() * sizeof(int));
+                std::memcpy(hostp(dbigRowCam), plan.rowCam.data(), plan.rowCam.size() * sizeof(int));
+                if (!plan.sb.empty()) std::memcpy(hostp(dbigSB), plan.sb.data(), plan.sb.size() * sizeof(int4));
+                if (!plan.diagList.empty()) std::memcpy(hostp(dbigDiagList), plan.diagList.data(), plan.diagList.size() * sizeof(int));
                 // (the pairs, their entry counts and every camera's landmark list were worked out above, before the arena was sized)
                 EAO_REQUIRE((int)cmPairStart.size() == nF + 1, "internal: covisibility structure built for another set of free keyframes");
                 const int nz = (int)prA.size();
@@ -655,11 +629,11 @@ struct BAJob {
         d.tileLds = tile_solver_lds(std::max(nF, 1));
         d.tiles3 = tile_geom(std::max(nF, 1)).nTiles <= 3 * (kTileThreads / 64);
         d.gB = big_geom(std::max(nF, 1));
+        if (bigPath) { d.gB.N = plan.N; d.gB.RP = plan.RP; }
         d.nPairsNZ = D.nPairsNZ; d.nPairsLong = nPairsLong; d.nPairsSlots = nPairsSlots; d.big = D.big; d.bigTiles = bigTiles;
-        d.bigPanelStart = bigPath ? panelStart.data() : nullptr;
-        d.bigPanelWork = bigPath ? panelWork.data() : nullptr;
+        d.plan = bigPath ? &plan : nullptr;
         d.bigCtl0 = D.ctl0;
-        d.bigArgs = BigStepArgs{D.big, D.bigL, D.bigDiag, D.bigFail, D.bigWork, D.ctl0, D.dbg, d.gB.N, make_int4(0, 0, 0, 0), 0};
+        d.bigArgs = BigStepArgs{D.big, D.bigL, D.bigDiag, D.bigFail, D.bigWork, D.ctl0, D.dbg, d.gB.N};
         // the window record itself travels with the structure
         write_records((BADev*)hostp(dW));
         if (!deferUpload) EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));
@@ -676,10 +650,10 @@ struct BAJob {
         chained = E > 0 && (nF + nL) > 0 && !pollStop && !lazy;
         hs_lap(4);
         if (hostStamps && bigPath)
-            fprintf(stderr, "[eao map-scale host set-up] observer / camera lists %.3f (counts %.3f, observer scatter %.3f, sort %.3f, camera scatter %.3f), pair counts %.3f, pair list %.3f, tiles + symbolic elimination + work records %.3f ms\n",
+            fprintf(stderr, "[eao map-scale host set-up] observer / camera lists %.3f (counts %.3f, observer scatter %.3f, sort %.3f, camera scatter %.3f), pair counts %.3f, pair list %.3f, order + tiles + symbolic elimination + schedule (GbaPlan; cached per pattern) %.3f ms\n",
                     hsT[5], hsT[8], hsT[9] - hsT[8], hsT[10] - hsT[9], hsT[5] - hsT[10], hsT[6] - hsT[5], hsT[7] - hsT[6], hsT[0] - hsT[7]);
         if (hostStamps && bigPath)
-            fprintf(stderr, "[eao map-scale host set-up] tile structure + symbolic elimination %.3f, arena + problem pack %.3f, active structure %.3f, pair CSR + launch order %.3f, records + upload enqueue %.3f ms (cumulative %.3f)\n",
+            fprintf(stderr, "[eao map-scale host set-up] covisibility lists + pairs + plan %.3f, arena + problem pack %.3f, active structure %.3f, pair CSR + launch order %.3f, records + upload enqueue %.3f ms (cumulative %.3f)\n",
                     hsT[0], hsT[1] - hsT[0], hsT[2] - hsT[1], hsT[3] - hsT[2], hsT[4] - hsT[3], hsT[4]);
         return EAO_OK;
     }

@@ -119,9 +119,15 @@ struct BADev {
     GP<int> bigFail;
     GP<const int> bigTile;     // bigT * bigT
     int bigT, bigTiles, bigDense;
-    GP<const int4> bigWork;    // per 32-column panel, ONE record pair per tile its launch updates -- {ti, tj, slot of tile (ti, tj), slot of the panel's tile in row ti},
-                               // {slot of the panel's tile in row tj, 0, 0, 0} (-1: dead, zeros) -- so a workgroup finds its tiles with one load; the first record of a
-                               // panel is always the tile of the NEXT diagonal block (its workgroup factors it on the spot)
+    // round 6 (GbaPlan): the system's rows follow the elimination order -- segments, then the separator block, each on a 64-row tile boundary, identity padding between
+    int bigN;                  // rows / columns of the padded system (a multiple of 64); row bigN = the right-hand side, in a tile row of its own
+    GP<const int> bigRow;      // nFree: first row of free camera i's six unknowns
+    GP<const int> bigRowCam;   // bigN: the natural index (6 i + q) of the unknown a row holds, -1 for a padding row
+    GP<const int4> bigSB;      // super-blocks of the back substitution: {first column, width, first / end column chunk (of 64) to its left that hears from it}
+    GP<const int> bigDiagList; // panels whose diagonal block a k_bal_diag launch factors (no earlier panel reaches their tile row)
+    GP<const int4> bigWork;    // per LAUNCH of the factorisation (GbaPlan::launches), ONE record pair per tile it updates -- {ti, tj, slot of tile (ti, tj), slot of the panel's tile in row ti},
+                               // {slot of the panel's tile in row tj, panel, flags (1: factor panel `next`'s diagonal block on the spot, 2: archive tile row ti's l entries, 4: nothing but that), next};  (rounds 3-5: per panel)
+                               // so a workgroup finds its tiles with one load; a launch's look-ahead records come first
     GP<const int> lpStart;     // nPairsNZ + 1
     GP<const int> lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
     GP<const int> lpOrder;     // launch slots: the pairs with more than kBigPairLong entries first (four waves each), then the others (one wave each); -1 = idle slot
@@ -193,14 +199,31 @@ constexpr int kBigMaxFree = 2048;
 constexpr int kBigNB = 32;
 struct BigGeom { int n, N, RP; };
 constexpr int kBigPairLong = 2048;
+constexpr int kBigSB = 256;      // columns per super-block of the back substitution
 
-// The factorisation launches take what they need BY VALUE: the pool pointers, the halt flag's address and -- for the look-ahead workgroup, whose record is
-// the first of the panel's list -- the work record itself.  Read through the window record like the other LM kernels, a panel started with three
-// dependent round trips to memory (record -> work list -> tiles) before its first useful load; 38 launches per trial start with that chain.
+// The factorisation launches take what they need BY VALUE: the pool pointers, the halt flag's address, the work list.  Read through the window record like the
+// other LM kernels, a launch started with three dependent round trips to memory (record -> work list -> tiles) before its first useful load.
 struct BigStepArgs {
     double* big; double* bigL; double* bigDiag; int* bigFail; const int4* bigWork; const int* ctl; long long* dbg;
-    int N; int4 wa0; int wb0x;
+    int N;
 };
+
+// Elimination order, tile structure and launch schedule of the map-scale path (gba.hip: gba_build_plan): a pure function of the covisibility pattern, kept in the
+// thread's context and reused while the pattern's hash stays the same.
+struct GbaPlan {
+    uint64_t key = 0;
+    bool valid = false;
+    int nFa = 0, N = 0, T = 0, RP = 0, nbk = 0, bigTiles = 0;
+    int P = 1, nSep = 0, sepStart = 0, rcm = 0, bandwidth = 0, chainNatural = 0, chainEstimate = 0;
+    std::vector<int> rowOf, rowCam, segStart, tileMap, diagList;
+    std::vector<int4> work, sb;
+    struct Launch { int off, cnt, diagOff, diagCnt; };
+    struct SbLaunch { int off, cnt, maxChunks; };
+    std::vector<Launch> launches;
+    std::vector<SbLaunch> sbLaunches;
+};
+uint64_t gba_pattern_hash(int nFa, const std::vector<int>& prA, const std::vector<int>& prB);
+void gba_build_plan(int nFa, const std::vector<int>& prA, const std::vector<int>& prB, int forceP, GbaPlan& pl);
 
 struct LMTraceHost {
     std::vector<double> lambda, chi2;
@@ -226,8 +249,7 @@ struct LMContext {  // per-thread device workspace, grow-only
     // which, in a batch call, happens after every window has been prepared.  They belong to the window's context (round 5: as thread-local tables of the set-up
     // worker they were overwritten by the next map-scale window the same worker prepared, and the first window ran with the second one's panels --
     // tools/dbg_batch_two_maps.py, tests/test_gpu_lm.py::test_two_map_scale_windows_in_one_batch).
-    std::vector<int> bigPanelStart;
-    std::vector<int4> bigPanelWork;
+    GbaPlan plan;
     size_t used = 0;
     ~LMContext() {
         if (status) (void)hipHostFree(status);
@@ -262,11 +284,10 @@ struct BADims {
     int nPairsNZ = 0;          // map-scale path (never batched)
     int nPairsLong = 0, nPairsSlots = 0;        // " : launch slots of the four-wave kernel (first in lpOrder) / of both
     BigStepArgs bigArgs{};     // " : what k_bal_step takes by value (ctl / wa0 / wb0x filled per launch)
-    const int* bigCtl0 = nullptr; const int4* bigPanelWork = nullptr;      // " : the control blocks on the device; the host copy of the work records
+    const int* bigCtl0 = nullptr;              // " : the control blocks on the device
     double* big = nullptr;     // "
     int bigTiles = 0;          // "
-    const int* bigPanelStart = nullptr;      // " : where every 32-column panel's work records start (nbk + 1 entries, thread-local storage that outlives the call's launches;
-                                             //     a POINTER: this struct is copied around, a vector member would be re-allocated with every copy)
+    const GbaPlan* plan = nullptr;           // " : the launch schedule (the context's: it outlives the call's launches; a POINTER: this struct is copied around)
     BigGeom gB{};
     void merge(const BADims& o) {
         nF = std::max(nF, o.nF); nL = std::max(nL, o.nL); nP = std::max(nP, o.nP); nC = std::max(nC, o.nC); E = std::max(E, o.E);

@@ -547,6 +547,24 @@ typedef struct {
 eao_status eao_bundle_adjustment_planes(const eao_ba_problem* p, const eao_ba_planes* planes, int32_t robust, const volatile uint8_t* stop,
                                         eao_ba_result* r, float* planes_out /* n_planes*4: Converter::toCvMat(vPlane->estimate()) */);
 
+/* (diagnostic, host only -- needs no device) The elimination order, tile structure and launch schedule the map-scale path derives from a covisibility pattern
+ * (round 6; csrc/gba.hip gba_build_plan: one level of nested dissection of the keyframe graph, the block form of the symbolic phase of the reference's
+ * SimplicialLDLT + AMD ordering, Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:95-112).  pair_a[k] <= pair_b[k]: the covisible pairs of the n_free free keyframes,
+ * the diagonal pairs (i, i) included.  force_segments: 0 = the library's choice, 1 = natural order, p > 1 = p segments.  Arrays the caller passes as NULL (or whose
+ * capacity is too small) are left out; `info` always comes back, so a second call can size them.  tests/test_gba_plan.py replays the schedule on the CPU against a
+ * dense solve. */
+typedef struct {
+    int32_t n_free, n_rows /* N: padded system, a multiple of 64; row N = the right-hand side */, n_tile_rows /* T = N / 64 + 1 */, n_panels /* N / 32 */, n_tiles;
+    int32_t n_segments, n_separator, separator_start /* first row of the separator block */, rcm /* 1: the line is a reverse Cuthill-McKee order */, bandwidth;
+    int32_t chain_natural /* factorisation launches of the natural order */, chain_estimate /* this plan's launches, factorisation + back substitution */;
+    int32_t n_launches, n_work /* record pairs */, n_diag, n_sb, n_sb_launches;
+} eao_gba_plan_info;
+eao_status eao_bundle_adjustment_plan(int32_t n_free, int32_t n_pairs, const int32_t* pair_a, const int32_t* pair_b, int32_t force_segments, eao_gba_plan_info* info,
+                                      int32_t* row_of /* n_free */, int32_t* tile_map /* T * T */, int32_t cap_tile_map, int32_t* work /* 8 per record pair */, int32_t cap_work,
+                                      int32_t* launches /* 4 each: work offset, count, diag offset, count */, int32_t cap_launches, int32_t* diag_list, int32_t cap_diag,
+                                      int32_t* sb /* 4 each: first column, width, chunk lo, chunk hi */, int32_t cap_sb, int32_t* sb_launches /* 3 each: offset, count, grid.x */,
+                                      int32_t cap_sb_launches);
+
 /* LM trace of the last eao_local_ba / eao_pose_optimization call made by this thread (for parity tests):
  * up to cap entries of (lambda after the iteration, robust chi2, trials). Returns the count in *n. */
 eao_status eao_last_lm_trace(double* lambda, double* chi2, int32_t* trials, int32_t cap, int32_t* n);

@@ -36,3 +36,7 @@ CHAOTIC_BANDS_ALLOWED = 4
 CHI2_REL_PLANES = 1e-5
 # ---- the batched entry point against single calls of the same windows: chi2 after each optimize(), relative (the batch adds a landmark's terms in another order)
 CHI2_REL_BATCH_VS_SINGLE = 1e-4
+
+# ---- round 6: tests/test_gpu_lm_conditioning.py -- the five excursions of the round-5 sweeps (profiles/r05_sweeps.txt: one weakly constrained landmark each,
+#      1.1 - 1.9e-4 of the update) + 50 fresh draws.  A problem outside UPDATE_REL must lie inside the oracle's own one-ulp band, measured in the test; at most this many may.
+CONDITIONING_BANDED_MAX = 7

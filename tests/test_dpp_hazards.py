@@ -13,7 +13,7 @@ def test_no_dpp_read_right_behind_a_valu_write():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if "DPP instructions" in l]
-    assert any(l.startswith("k_bal_step") for l in lines) and any(l.startswith("k_bal_diag0") for l in lines), r.stdout
+    assert any(l.startswith("k_bal_step") for l in lines) and any(l.startswith("k_bal_diag") for l in lines), r.stdout
     for l in lines:
         assert l.rstrip().endswith(" 0 hazard violations"), l
         if l.startswith(("k_bal_step", "k_bal_diag0")):

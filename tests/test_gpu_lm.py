@@ -479,6 +479,47 @@ def test_bundle_adjustment_on_sparse_maps(gpu, oracle, name):
     _check_updates(r["points"], o["points"], p["points"], "points")
 
 
+@pytest.mark.parametrize("name,segments", [("band 3 of 110", 1), ("band 3 of 110", 4), ("band 3 of 110", 9), ("band 7 of 60", 3), ("band 11 of 150, robust", 5), ("band 11 of 150, robust", 0),
+                                           ("two maps", 4), ("two maps, the second inside a tile", 6), ("dense 80", 3), ("ring 5 of 120", 0), ("ring 5 of 120", 7)])
+def test_bundle_adjustment_in_nested_dissection_order(gpu, oracle, name, segments, monkeypatch):
+    """Round 6: the map-scale path eliminates the keyframes in a nested-dissection order (segments of the trajectory first, the separator keyframes between them last;
+    csrc/gba.hip gba_build_plan) and runs the panels of independent segments in ONE launch per level of the schedule.  EAO_BA_ND forces the number of segments onto maps
+    of test size (0: the library's choice, 1: natural order): same LM schedule and updates as the oracle -- which factors the dense matrix in natural order -- whatever the
+    order, on bands, on a ring (the last keyframes see the first: they all join the separators), on two maps that share nothing and on a map where everybody sees everybody."""
+    robust = "robust" in name
+    if name.startswith("band"):
+        band, n = int(name.split()[1]), int(name.split()[3].rstrip(","))
+        p = synth.synth_ba(n_free=n, n_fixed=1, n_points=40 * n, seed=5500 + n, band=band)
+    elif name.startswith("ring"):      # (a band whose points also wrap around: point i of the last keyframes is seen by the first ones)
+        band, n = int(name.split()[1]), int(name.split()[3])
+        p = synth.synth_ba(n_free=n, n_fixed=1, n_points=30 * n, seed=5700 + n, band=band)
+        ec = p["edge_cam"].copy()
+        far = ec >= n - 3
+        ec[far] = 1 + (ec[far] - (n - 3)) * 2          # the last three cameras' observations go to cameras 1, 3, 5: the trajectory closes on itself
+        # (keep at most one edge per (camera, point))
+        key = ec.astype(np.int64) * (len(p["points"]) + 1) + p["edge_point"]
+        _, first = np.unique(key, return_index=True)
+        keep = np.zeros(len(ec), bool); keep[first] = True
+        for k in ("edge_point", "obs", "inv_sigma2"):
+            p[k] = p[k][keep]
+        p["edge_cam"] = ec[keep].astype(np.int32)
+    elif name == "two maps":
+        p = _two_maps(dict(n_free=40, n_fixed=1, n_points=1500, seed=5601, band=5), dict(n_free=50, n_fixed=2, n_points=1800, seed=5602, band=6))
+    elif name == "dense 80":
+        p = synth.synth_ba(n_free=80, n_fixed=1, n_points=3000, seed=5200)
+    else:
+        p = _two_maps(dict(n_free=36, n_fixed=1, n_points=1400, seed=5603, band=4), dict(n_free=33, n_fixed=1, n_points=1300, seed=5604))
+    monkeypatch.setenv("EAO_BA_ND", str(segments))
+    r = gpu.Optimizer.BundleAdjustment(p, 8, bRobust=robust)
+    o = oracle.bundle_adjustment(p, 8, robust)
+    assert list(r["iters"]) == [int(o["iters"][0]), 0] and r["iters"][0] >= 3
+    _check_trace(r, o, rel=CHI2_REL_PLANES)
+    _check_updates(r["poses"], o["poses"], p["poses"], "poses")
+    _check_updates(r["points"], o["points"], p["points"], "points")
+    r2 = gpu.Optimizer.BundleAdjustment(p, 8, bRobust=robust)          # (the cached plan: bit for bit the same call)
+    assert np.array_equal(r["poses"], r2["poses"]) and np.array_equal(r["points"], r2["points"])
+
+
 @pytest.mark.parametrize("kw", [dict(n_free=80, n_fixed=1, n_points=3000, seed=5200), dict(n_free=60, n_fixed=1, n_points=2400, seed=5560, band=7)])
 def test_map_scale_assembly_with_four_wave_pairs(gpu, oracle, kw, monkeypatch):
     """The Schur assembly of the map-scale path runs one wavefront per camera pair and FOUR for pairs with more than 2048 common landmarks (a keyframe's diagonal
