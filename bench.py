@@ -425,6 +425,7 @@ def flat_scalars(roofline, extra):
         put(key, lambda c=call: cs[c]["call_ms"])
         put(key.replace("_ms", "_c_abi_ms"), lambda c=call: cs[c]["c_abi_ms"])
     put("cs_lba_overhead_frac", lambda: cs["local_bundle_adjustment"]["adapter_overhead_frac_of_c_abi"])
+    put("cs_lba_observations_ref_ms", lambda: cs["local_bundle_adjustment_with_accessors"]["call_ms"])
     gs, cg = extra.get("guided_searches", {}), extra.get("cpu_guided_searches", {})
     for name in ("search_by_bow_kf_frame", "search_by_bow_kf_kf", "search_for_triangulation", "fuse_search_pose"):
         put("gs_%s_ms" % name, lambda n=name: gs[n]["ms_per_call"])
@@ -1248,6 +1249,23 @@ def measure_class_surface(synth):
     if run.returncode != 0:
         return {"error": "adapter_bench rc %d: %s" % (run.returncode, (run.stdout + run.stderr)[-400:])}
     out = json.loads(run.stdout)
+    # the same LocalBundleAdjustment call over a MapPoint that carries the two allocation-free accessors (ForEachObservation,
+    # GetWorldPos(float*)) -- the adapter detects them; everything else in the stand-ins is unchanged
+    try:
+        exe2 = exe + "_edited"
+        cc2 = subprocess.run(["g++", "-O2", "-std=c++17", "-DEAOFUSION_FORCE_CV_COMPAT", "-DEAO_BENCH_EDITED_MAPPOINT", "-I", os.path.join(ROOT, "include"),
+                              os.path.join(ROOT, "tests", "cpp", "adapter_bench.cpp"), "-o", exe2, "-L", lib, "-leaofusion_hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-pthread"],
+                             capture_output=True, text=True)
+        if cc2.returncode == 0:
+            run2 = subprocess.run([exe2, prob, "lba"], capture_output=True, text=True, timeout=300)
+            if run2.returncode == 0:
+                out["local_bundle_adjustment_with_accessors"] = json.loads(run2.stdout)["local_bundle_adjustment"]
+            else:
+                out["local_bundle_adjustment_with_accessors"] = {"error": "rc %d: %s" % (run2.returncode, (run2.stdout + run2.stderr)[-300:])}
+        else:
+            out["local_bundle_adjustment_with_accessors"] = {"error": "g++: " + cc2.stderr[-300:]}
+    except Exception as ex:  # noqa: BLE001
+        out["local_bundle_adjustment_with_accessors"] = {"error": repr(ex)}
     out["note"] = ("tests/cpp/adapter_bench.cpp (g++ -O2, a process of its own): median wall time of each call through the reference's class signature, and the share of it inside the "
                    "C-ABI entry point the adapter makes (timed by a wrapper around that very call); adapter_overhead = flattening the object graph + writing the result back")
     return out

@@ -503,6 +503,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
     // only, every XCD walks its frames' cells in table order, so a cache line is fetched into one L2 and the load stays
     // balanced by construction -- 256-frame batch: FAST alone 0.540 -> 0.532 ms, the scheduled step 1.338 -> 1.301 ms (the
     // resize running beside FAST gets the fabric).  Speed only, never results.  EAO_FAST_AFFINITY=0 switches it off.
+    // (bits 8.. of the last argument: the phase after which a CENSUS run leaves the kernel -- EAO_FAST_STOP_AFTER, tools/prof_fast_census.sh; 0 in every other run)
+    const int stopAfter = frameAffinity >> 8;
+    frameAffinity &= 1;
     int cell = blockIdx.x, fy = blockIdx.y;
     if constexpr (kFastXcdRun > 0) {
         const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
@@ -568,6 +571,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
             tile[y * kTileStride + x + ph] = src[(long long)(c.y0 + y) * pitch + c.x0 + x];
         }
     }
+    if (stopAfter == 1) { if (lane == 0) cellcnt[slot] = 0; return; }      // census: launch + staging (an empty cell for the kernels behind)
     const int rw = tw + 2;
     const int scWords = (rw * (th_ + 2) + 3) >> 2;
     // (the geometry fields the loops need, read ONCE: the compiler re-loads g->x after every store it cannot tell apart)
@@ -669,6 +673,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
             }
         }
         __syncthreads();
+        if (stopAfter == 2) { if (lane == 0) cellcnt[slot] = 0; return; }  // census: ... + candidate test
         // ---- 2. arc value of the survivors in one polarity; corners go to the score map.  A survivor whose candidate test allows
         // both polarities and that is no dark corner is APPENDED to the work list with kSecond set and meets the bright
         // evaluation in a later lane of the same loop -- normally one of the lanes the last 64-entry round leaves idle (a
@@ -705,6 +710,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
             k0 = min(k0 + 64, nlist);      // (entries appended by a partial round start right behind it)
         }
         __syncthreads();
+        if (stopAfter == 3) { if (lane == 0) cellcnt[slot] = 0; return; }  // census: ... + arc values
         // ---- 3. NMS + ordered emission (a corner of score 0 is never kept: 0 > max(...) cannot hold, upstream the same)
         int total = 0;
         for (int k0 = 0; k0 < nwork; k0 += 64) {
@@ -2114,7 +2120,8 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         auto fast = [&](hipStream_t str, int first, int end) {
             eao::Range rg("orb: FAST cells");
             static const int envAff = getenv("EAO_FAST_AFFINITY") ? atoi(getenv("EAO_FAST_AFFINITY")) : 1;
-            const int aff = envAff && (nb & 7) == 0 ? 1 : 0;
+            static const int envStop = getenv("EAO_FAST_STOP_AFTER") ? atoi(getenv("EAO_FAST_STOP_AFTER")) : 0;      // (census runs only: results are garbage)
+            const int aff = (envAff && (nb & 7) == 0 ? 1 : 0) | envStop << 8;
             const bool whole = first == 0 && end == g.totalCells, narrow = g.fastStride == 48;
             auto* kern = whole ? (narrow ? k_fast_cells<true, 48> : k_fast_cells<true, kTileStrideWide>)
                                : (narrow ? k_fast_cells<false, 48> : k_fast_cells<false, kTileStrideWide>);

@@ -156,6 +156,30 @@ std::vector<int> PoseOptimizationBatch(const std::vector<FrameT*>& frames) {
 // per-thread arrays that also serve the fixed-camera pass, the edge pass and the write-back; the point -> index map is the rank of the point's mnId (one sort
 // of 3000 pairs, no tree with 15 000 look-ups); nothing is allocated per call after the first.  What remains is what the reference's own accessors cost -- a
 // mutex and a cv::Mat clone per GetWorldPos / GetPose, a std::map copy per GetObservations, SetWorldPos -- and tests/cpp/adapter_bench.cpp reports that floor.
+// Round 6 (OPTIONAL): half of this call's wall time at the class surface is the reference's object model -- GetObservations()
+// returns a COPY of a std::map (five nodes allocated and freed per map point), GetWorldPos() a cv::Mat clone.  A checkout that adds the two allocation-free accessors
+//     template <class F> void ForEachObservation(F&& f) { unique_lock<mutex> lock(mMutexFeatures); for (auto& o : mObservations) f(o.first, o.second); }
+//     void GetWorldPos(float* xyz) { unique_lock<mutex> lock(mMutexPos); for (int i = 0; i < 3; i++) xyz[i] = mWorldPos.at<float>(i); }
+// to include/MapPoint.h (beside :43 / src/MapPoint.cc:139) is detected here and the walk uses them; an unedited MapPoint takes upstream's accessors as before.  The
+// callback runs under the point's mMutexFeatures and only appends to a flat array (no other lock is taken inside it).
+namespace detail {
+template <class MP, class KF, class = void> struct HasForEachObservation : std::false_type {};
+template <class MP, class KF>
+struct HasForEachObservation<MP, KF, decltype(std::declval<MP&>().ForEachObservation(std::declval<void (*)(KF*, size_t)>()), void())> : std::true_type {};
+template <class MP, class = void> struct HasWorldPosOut : std::false_type {};
+template <class MP> struct HasWorldPosOut<MP, decltype(std::declval<MP&>().GetWorldPos(static_cast<float*>(nullptr)), void())> : std::true_type {};
+template <class KF, class MP, class F> void for_each_observation(MP* mp, F& f, std::true_type) { mp->ForEachObservation(f); }
+template <class KF, class MP, class F> void for_each_observation(MP* mp, F& f, std::false_type) {
+    const std::map<KF*, size_t> seenBy = mp->GetObservations();      // the ONE copy per point (upstream: two, src/Optimizer.cc:725, :836)
+    for (typename std::map<KF*, size_t>::const_iterator it = seenBy.begin(); it != seenBy.end(); ++it) f(it->first, it->second);
+}
+template <class MP> void world_pos(MP* mp, float* xyz, std::true_type) { mp->GetWorldPos(xyz); }
+template <class MP> void world_pos(MP* mp, float* xyz, std::false_type) {
+    const cv::Mat P = mp->GetWorldPos();
+    for (int k = 0; k < 3; k++) xyz[k] = P.template at<float>(k);
+}
+}  // namespace detail
+
 template <class KeyFrameT, class MapPointT>
 struct LbaScratch {
     struct Obs { KeyFrameT* kf; size_t idx; };
@@ -192,15 +216,19 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
                 mp->mnBALocalForKF = me;
             }
     const size_t nP = S.localMPs.size();
+    struct Append {
+        std::vector<typename LbaScratch<KeyFrameT, MapPointT>::Obs>* obs;
+        void operator()(KeyFrameT* kf, size_t idx) { typename LbaScratch<KeyFrameT, MapPointT>::Obs o = {kf, idx}; obs->push_back(o); }
+    } append = {&S.obs};
     for (MapPointT* mp : S.localMPs) {
-        const std::map<KeyFrameT*, size_t> seenBy = mp->GetObservations();      // the ONE copy per point
-        for (const auto& ob : seenBy) {
-            KeyFrameT* kf = ob.first;
+        const size_t first = S.obs.size();
+        detail::for_each_observation<KeyFrameT>(mp, append, detail::HasForEachObservation<MapPointT, KeyFrameT>());
+        for (size_t o = first; o < S.obs.size(); o++) {      // (outside the accessor: isBad() takes the keyframe's own mutex)
+            KeyFrameT* kf = S.obs[o].kf;
             if (kf->mnBALocalForKF != me && kf->mnBAFixedForKF != me) {
                 kf->mnBAFixedForKF = me;
                 if (!kf->isBad()) S.fixedKFs.push_back(kf);
             }
-            S.obs.push_back({kf, ob.second});
         }
         S.obsStart.push_back((int32_t)S.obs.size());
     }
@@ -234,10 +262,7 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) S.camT[i * 16 + r * 4 + c] = T.template at<float>(r, c);
         S.camFixed[i] = S.cams[i].fixed ? 1 : 0;
     }
-    for (size_t i = 0; i < nP; i++) {
-        const cv::Mat P = S.pts[i]->GetWorldPos();
-        for (int k = 0; k < 3; k++) S.xyz[i * 3 + k] = P.template at<float>(k);
-    }
+    for (size_t i = 0; i < nP; i++) detail::world_pos(S.pts[i], &S.xyz[i * 3], detail::HasWorldPosOut<MapPointT>());
     const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy, bf = pKF->mbf;
     S.eCam.clear(); S.ePt.clear(); S.eObs.clear(); S.eInv.clear(); S.eKF.clear(); S.eMP.clear();
     for (size_t k = 0; k < nP; k++) {

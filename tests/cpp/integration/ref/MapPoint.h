@@ -44,6 +44,13 @@ public:
     void UpdateNormalAndDepth() { normalUpdates++; }
     float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
     float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+    // the two allocation-free accessors, extracted verbatim from the snippet when the scratch checkout holds it
+#if defined(__has_include)
+#if __has_include("MapPoint_accessors.inc")
+#include "MapPoint_accessors.inc"
+#define EAO_TEST_MAPPOINT_HAS_ACCESSORS 1
+#endif
+#endif
 
     long unsigned int mnId = 0;
     long unsigned int mnBALocalForKF = ~0ul, mnBAGlobalForKF = 0;

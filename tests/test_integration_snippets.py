@@ -13,7 +13,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MARK = re.compile(r"<!-- snippet: (\S+) -->\n```cpp\n(.*?)```", re.S)
 EXPECTED = {"include/ORBextractor.h", "src/Optimizer_hip.cc", "src/Optimizer_hip_gba.cc", "src/ORBmatcher_hip.cc", "src/MapPoint_hip.cc",
-            "src/Frame_hip.cc", "src/Tracking_SearchLocalPoints.inc", "src/Tracking_TrackLocalMap.inc", "src/Tracking_TrackWithMotionModel.inc", "src/Tracking_TrackReferenceKeyFrame.inc"}
+            "src/Frame_hip.cc", "src/Tracking_SearchLocalPoints.inc", "src/Tracking_TrackLocalMap.inc", "src/Tracking_TrackWithMotionModel.inc", "src/Tracking_TrackReferenceKeyFrame.inc",
+            "include/MapPoint_accessors.inc"}
 
 
 def extract(dst):
