@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void k_bal_step(BigStepArgs A, int workOff) {
     // the workgroup's tile: record bx of the LAUNCH's work list (round 6: a launch holds the panels the schedule put side by side -- GbaPlan; the record names its panel).
     // The halt flag travels with the record: one round trip to memory for both, not one behind the other (every launch of a trial starts with this chain)
     const int halted = A.ctl[kCtlHalt];
-    const int4 wa = A.bigWork[2 * (size_t)(workOff + bx)], wb = A.bigWork[2 * (size_t)(workOff + bx) + 1];
+    int4 wa, wb;
+    if ((int)bx < A.nByValue) { wa = A.rec[2 * bx]; wb = A.rec[2 * bx + 1]; }      // (scalar loads from the kernel-argument segment: no round trip to the work list)
+    else { wa = A.bigWork[2 * (size_t)(workOff + bx)]; wb = A.bigWork[2 * (size_t)(workOff + bx) + 1]; }
     const int wbx = wb.x, kb = wb.y, flags = wb.z, nextKb = wb.w;
     const int k0 = kb * kBigNB;
     if (halted) return;
@@ -929,7 +931,11 @@ void gba_enqueue_trial(const BALaunch& L, int par, bool firstTrial) {
     // the factorisation: one launch per level of the schedule (GbaPlan::launches) -- the panels of independent segments side by side
     for (const GbaPlan::Launch& Lq : pl.launches) {
         if (Lq.diagCnt) hipLaunchKernelGGL(k_bal_diag, dim3(Lq.diagCnt), dim3(64), 0, s, W, wp(par), Lq.diagOff);
-        if (Lq.cnt) hipLaunchKernelGGL(k_bal_step, dim3(Lq.cnt), dim3(256), 0, s, A, Lq.off);
+        if (Lq.cnt) {
+            A.nByValue = std::min(Lq.cnt, kBigByValue);
+            std::memcpy(A.rec, pl.work.data() + 2 * (size_t)Lq.off, (size_t)A.nByValue * 2 * sizeof(int4));
+            hipLaunchKernelGGL(k_bal_step, dim3(Lq.cnt), dim3(256), 0, s, A, Lq.off);
+        }
     }
     hipLaunchKernelGGL(k_bal_linv, dim3(eao::cdiv(pl.nbk, 2)), dim3(64), 0, s, W, wp(par), pl.nbk);
     for (const GbaPlan::SbLaunch& Sq : pl.sbLaunches)

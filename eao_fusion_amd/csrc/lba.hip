@@ -1175,6 +1175,12 @@ __device__ inline void ba_decide_block(const BADev& P, const int* solveOk, BASta
     }
 }
 
+// a double made visible to every XCD before this thread goes on: an agent-scope atomic exchange whose result is waited for (see k_ba_backsub's memory model)
+__device__ __forceinline__ void publish_f64(double* p, double v) {
+    const unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old) : "memory");      // the returning form of the instruction: its completion is what orders it
+}
+
 // per landmark (eight lanes, one edge per lane): x_l = Dinv (bl - Hpl^T x_p); trial point; residuals + robust chi2 of
 // its edges at the trial state; scale partial
 template <bool PL>
@@ -1290,23 +1296,27 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
         double v[1] = {0};
         for (int i = threadIdx.x; i < P.nFree * 6; i += 256) { const double x = P.xp[i]; v[0] += x * (lambda * x + P.bp[i]); }
         block_sum<1, 256>(v, red, &out2[0]);
-        if (threadIdx.x == 0) __hip_atomic_store(&P.lm[4], out2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) publish_f64(&P.lm[4], out2[0]);
     }
     if (!decide) return;
     // The accept / reject decision of this trial, by the LAST workgroup of the window to get here (every other one has
     // published its partial sums by then): the next linearisation finds it in the other control block.  Leaving it to the
     // head of that launch instead -- every workgroup re-deriving it from the 2 nL partial sums -- cost each of its 1 100
     // workgroups (25 windows) 2.6 - 4 us of an 8 - 9 us life.
-    // Memory model: a workgroup publishes ITS partial sums (wgPart) with agent-scope atomic stores (written through, no L2
-    // write-back needed -- a __threadfence() here is a buffer_wbl2 per workgroup and made the launch 3x slower), waits for
-    // them (workgroup-scope release = s_waitcnt) and then takes its ticket; the last workgroup reads the partial sums with
-    // agent-scope atomic loads (they bypass its CU's L1).  The same goes for the camera part in lm[4].
+    // Memory model: a workgroup publishes ITS partial sums (wgPart) with agent-scope atomic EXCHANGES whose results it waits for, and only then takes its ticket; the
+    // last workgroup reads the partial sums with agent-scope atomic loads.  The same goes for the camera part in lm[4].
+    // (Round 6.  Rounds 2-5 published with agent-scope atomic STORES behind a workgroup-scope release -- no __threadfence(): its buffer_wbl2 per workgroup made the
+    //  launch 3x slower.  A written-through store is acknowledged before it has landed at the point where the eight XCDs' L2s meet, and the ticket -- an atomic on
+    //  another address -- can overtake it: beside another thread's bundle adjustment (a busy fabric) the last workgroup read ONE stale partial sum -- the previous
+    //  trial's -- in about one call of 10 000, an LM decision flipped, and the call returned one of a handful of wrong-but-repeatable results; never seen alone, nor
+    //  beside the extractor: tools/dbg_lba_beside_gba.py, tests/cpp/mixed_load.cpp's results_identical.  A read-modify-write atomic is performed AT that point and
+    //  returns only afterwards, so waiting for the exchange's result orders it before the ticket; two extra atomics per workgroup, no cache write-back.)
     __shared__ int s_last;
     __syncthreads();
     block_sum<2, 256>(mine, red, out2);         // this workgroup's 32 landmarks, fixed order
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&P.wgPart[2 * bx], out2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&P.wgPart[2 * bx + 1], out2[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish_f64(&P.wgPart[2 * bx], out2[0]);
+        publish_f64(&P.wgPart[2 * bx + 1], out2[1]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         s_last = __hip_atomic_fetch_add((int*)P.doneCnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     }
@@ -1320,7 +1330,10 @@ __global__ __launch_bounds__(256) void k_ba_backsub(const BADev* __restrict__ W,
     __syncthreads();
     block_sum<2, 256>(v, red, out2);
     if (threadIdx.x == 0) {
-        __hip_atomic_store((int*)P.doneCnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {   // (the counter back to zero for the next launch: an exchange as well -- performed where the next launch's tickets are counted)
+            const int was = __hip_atomic_exchange((int*)P.doneCnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(was) : "memory");
+        }
         const double camPart = __hip_atomic_load(&P.lm[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const BADecision d = ba_decision(P.lm, P.ctl, out2[0], camPart + out2[1], *P.solveOk, 1);
         ba_commit(d, P.lm, P.ctl, lmNext, ctlNext, P.status, seq, 1);

@@ -633,7 +633,7 @@ struct BAJob {
         d.nPairsNZ = D.nPairsNZ; d.nPairsLong = nPairsLong; d.nPairsSlots = nPairsSlots; d.big = D.big; d.bigTiles = bigTiles;
         d.plan = bigPath ? &plan : nullptr;
         d.bigCtl0 = D.ctl0;
-        d.bigArgs = BigStepArgs{D.big, D.bigL, D.bigDiag, D.bigFail, D.bigWork, D.ctl0, D.dbg, d.gB.N};
+        d.bigArgs = BigStepArgs{D.big, D.bigL, D.bigDiag, D.bigFail, D.bigWork, D.ctl0, D.dbg, d.gB.N, 0, {}};
         // the window record itself travels with the structure
         write_records((BADev*)hostp(dW));
         if (!deferUpload) EAO_HIP(hipMemcpyAsync(a.base + offSplit, c.pin + offSplit, off1 - offSplit, hipMemcpyHostToDevice, s));

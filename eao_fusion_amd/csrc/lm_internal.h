@@ -201,11 +201,14 @@ struct BigGeom { int n, N, RP; };
 constexpr int kBigPairLong = 2048;
 constexpr int kBigSB = 256;      // columns per super-block of the back substitution
 
-// The factorisation launches take what they need BY VALUE: the pool pointers, the halt flag's address, the work list.  Read through the window record like the
-// other LM kernels, a launch started with three dependent round trips to memory (record -> work list -> tiles) before its first useful load.
+// The factorisation launches take what they need BY VALUE: the pool pointers, the halt flag's address, the work list -- and the first kBigByValue record pairs of the
+// launch (its look-ahead workgroups come first in the list).  Read through the window record like the other LM kernels, a launch started with three dependent round
+// trips to memory (record -> work list -> tiles) before its first useful load.
+constexpr int kBigByValue = 8;      // the first records of a launch -- its look-ahead workgroups, the chain's critical path -- travel in the kernel arguments
 struct BigStepArgs {
     double* big; double* bigL; double* bigDiag; int* bigFail; const int4* bigWork; const int* ctl; long long* dbg;
-    int N;
+    int N, nByValue;
+    int4 rec[2 * kBigByValue];
 };
 
 // Elimination order, tile structure and launch schedule of the map-scale path (gba.hip: gba_build_plan): a pure function of the covisibility pattern, kept in the

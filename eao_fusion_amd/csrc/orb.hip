@@ -1714,6 +1714,12 @@ struct eao_orb {
     // (EAO_ORB_LANES, default 1: see the measurement note at enqueue())
     static constexpr int kLanes = 4;
     hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
+    // Round 6: the handle's private streams (its own main stream, the side stream of every call) take the priority of the stream the handle's FIRST call arrives on:
+    // a host-API call (ORBextractor::operator(), what the Tracking thread makes) arrives on no stream -> Latency class; a device-API call arrives on the caller's stream
+    // (PyTorch's default stream in bench.py) -> that stream's priority.  Measured (gpurun_out/r06g .. r06i, 64-frame step on PyTorch's default-priority stream): side
+    // stream at the same (default) priority 0.2553 ms; a Latency-class side stream beside it 0.2665 ms (FAST level 0 and the blur overtake the main chain's seven dependent
+    // resize launches); and a default-priority side stream created NEXT TO idle Latency-class streams of the same handle 0.43-0.64 ms, every stage twice as long -- one
+    // handle's streams are all of one priority.
     bool evLastValid = false, capturing = false;   // evLastValid: a call has been enqueued on lastStream
     hipStream_t lastStream = nullptr;      // the stream of the previous call: compared, never dereferenced (its owner may have destroyed it)
     // Round 6: ordering between calls that come in on DIFFERENT streams without draining the device (under the reference's concurrency a drain makes the
@@ -2001,11 +2007,22 @@ int orb_last_event_mode() {
     return mode;
 }
 
-eao_status ensure(eao_orb* h, int W, int H, int batch) {
+constexpr uintptr_t kNoCallerStream = ~(uintptr_t)0;      // a host-API call: the handle's streams are of the Latency class
+eao_status ensure(eao_orb* h, int W, int H, int batch, hipStream_t caller = (hipStream_t)kNoCallerStream) {
     eao_status st = eao::require_device();
     if (st) return st;
-    if (!h->stream) {
-        EAO_HIP(eao::create_stream(&h->stream, eao::StreamClass::Latency));
+    if (!h->stream && batch > 0) {      // (batch 0: a geometry query -- eao_orb_max_keypoints -- needs no stream, and must not decide the handle's priority)
+        // the priority of the handle's streams: see eao_orb (round 6)
+        int least = 0, greatest = 0, p = 0;
+        const bool follow = (uintptr_t)caller != kNoCallerStream && !(getenv("EAO_STREAM_PRIORITY") && !atoi(getenv("EAO_STREAM_PRIORITY"))) &&
+                            hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && hipStreamGetPriority(caller, &p) == hipSuccess;
+        (void)hipGetLastError();
+        auto make = [&](hipStream_t* q) -> hipError_t {
+            if ((uintptr_t)caller == kNoCallerStream) return eao::create_stream(q, eao::StreamClass::Latency);
+            if (!follow || p == 0) return hipStreamCreateWithFlags(q, hipStreamNonBlocking);
+            return hipStreamCreateWithPriority(q, hipStreamNonBlocking, p);
+        };
+        EAO_HIP(make(&h->stream));
         EAO_HIP(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
         EAO_HIP(hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming));
         h->everyCallEvent = orb_last_event_mode() == 2;
@@ -2015,8 +2032,8 @@ eao_status ensure(eao_orb* h, int W, int H, int batch) {
         const int lanesWanted = std::max(1, std::min(eao_orb::kLanes, getenv("EAO_ORB_LANES") ? atoi(getenv("EAO_ORB_LANES")) : 1));
         for (int i = 0; i < eao_orb::kLanes; i++) {
             if (i < lanesWanted) {
-                EAO_HIP(eao::create_stream(&h->laneMain[i], eao::StreamClass::Latency));
-                EAO_HIP(eao::create_stream(&h->laneSide[i], eao::StreamClass::Latency));
+                EAO_HIP(make(&h->laneMain[i]));
+                EAO_HIP(make(&h->laneSide[i]));
             }
             EAO_HIP(hipEventCreateWithFlags(&h->evFork[i], hipEventDisableTiming));
             EAO_HIP(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
@@ -2106,6 +2123,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         // back, which put two cross-stream event hops (~25 us on PyTorch's bundled HIP 7.0 runtime) between consecutive calls.
         const bool onCaller = lanes == 1;
         hipStream_t ms = onCaller ? st : h->laneMain[i], ss = h->laneSide[i];
+
         const bool pe = prof && i == 0;
         if (!onCaller) EAO_HIP(hipStreamWaitEvent(ms, h->evStart, 0));
         // Level 0 IS the input image: its FAST cells (a third of all cells) do not wait for the pyramid.  Outside profiling
@@ -2538,7 +2556,7 @@ eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_
                                         int32_t* d_n, void* stream) {
     EAO_REQUIRE(h && d_img && d_kps && d_desc && d_n, "null argument");
     EAO_REQUIRE(width > 0 && height > 0 && stride >= width && batch >= 1, "bad image geometry");
-    eao_status st = ensure(h, width, height, batch);
+    eao_status st = ensure(h, width, height, batch, (hipStream_t)stream);
     if (st) return st;
     if (cap < h->geom.totalKpCap) {
         eao::set_error("cap %d < eao_orb_max_keypoints %d", cap, h->geom.totalKpCap);

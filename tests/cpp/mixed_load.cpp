@@ -452,9 +452,14 @@ int main(int argc, char** argv) {
             const bool same = T.hashes == ref && T.hashes.size() == 1 && (L.hashes.empty() || L.hashes == Lalone.hashes) && (LB.hashes.empty() || LB.hashes == LBalone.hashes) &&
                               (G.hashes.empty() || G.hashes == Galone.hashes);
             identical = identical && same;
+            char why[256];
+            std::snprintf(why, sizeof why, "\"distinct_results\": {\"frames\": %zu, \"frames_equal_idle\": %s, \"lba\": %zu, \"lba_equal_alone\": %s, \"lba_batch\": %zu, \"lba_batch_equal_alone\": %s, \"map_ba\": %zu, \"map_ba_equal_alone\": %s}",
+                          T.hashes.size(), T.hashes == ref ? "true" : "false", L.hashes.size(), L.hashes.empty() || L.hashes == Lalone.hashes ? "true" : "false", LB.hashes.size(),
+                          LB.hashes.empty() || LB.hashes == LBalone.hashes ? "true" : "false", G.hashes.size(), G.hashes.empty() || G.hashes == Galone.hashes ? "true" : "false");
             std::printf("    \"%s\": {\"frame_ms\": %s, \"extract_ms\": %s, \"%s\": %s, \"%s\": %s, \"late_frames\": %d, \"results_identical\": %s", sname[sc], stat_json(T.total).c_str(),
                         stat_json(T.extract).c_str(), variant == 0 ? "motion_model_ms" : "search_last_frame_plus_pose_ms", stat_json(T.stageA).c_str(),
                         variant == 0 ? "local_map_ms" : "search_local_map_plus_pose_ms", stat_json(T.stageB).c_str(), T.late, same ? "true" : "false");
+            std::printf(", %s", why);
             if (!L.ms.empty()) std::printf(", \"lba_class_surface_ms\": %s", stat_json(L.ms).c_str());
             if (sc == 1 && !cabi::spans.empty()) {
                 // where T's slow frames (beyond 1.25 x the median) START in thread L's cycle: [idle: L rebuilds its window | walk: the adapter reads the object graph |

@@ -166,3 +166,40 @@ def test_shared_keyframe_handles_across_threads(oracle):
     for t in ths:
         t.join()
     assert not errors, errors
+
+
+def test_three_threads_of_bundle_adjustment_return_identical_results():
+    """Round 6 (tests/cpp/mixed_load.cpp found it: `results_identical` false in 3 of 16 scenarios): LocalBundleAdjustment beside ANOTHER thread's bundle adjustment returned, about
+    once in 10 000 calls, one of a handful of wrong-but-repeatable results -- the last workgroup of k_ba_backsub summed a stale partial chi2 (published with an agent-scope
+    atomic STORE that the ticket overtook on a busy fabric) and an LM decision flipped; never alone, never beside the extractor.  The partial sums are now published with
+    returning atomic exchanges (csrc/lba.hip).  This test runs the reference's mix for a few seconds -- LocalMapping's LBA loop, a second LBA loop on another window, LoopClosing's
+    map-scale BundleAdjustment -- and demands bit-identical results throughout; the long form is tools/dbg_lba_beside_gba.py (minutes, 10^5 calls)."""
+    import time
+    import torch  # noqa: F401
+    import eao_fusion_amd as E
+    assert E.load().eao_device_check() == 0
+    pa, pb = synth.synth_ba(), synth.synth_ba(seed=6007)
+    g = synth.synth_ba(n_free=200, n_fixed=1, n_points=8000, seed=5405, band=9)
+    jobs = {"lba_a": lambda: E.Optimizer.LocalBundleAdjustment(pa), "lba_b": lambda: E.Optimizer.LocalBundleAdjustment(pb),
+            "map_ba": lambda: E.Optimizer.BundleAdjustment(g, 10, bRobust=False)}
+    key = lambda r: r["poses"].tobytes() + r["points"].tobytes() + r["edge_outlier"].tobytes()      # noqa: E731
+    want = {k: key(j()) for k, j in jobs.items()}
+    errors, counts = [], {k: 0 for k in jobs}
+    t_end = time.perf_counter() + 6.0
+
+    def worker(k):
+        try:
+            while time.perf_counter() < t_end:
+                if key(jobs[k]()) != want[k]:
+                    errors.append("%s: call %d differs" % (k, counts[k]))
+                counts[k] += 1
+        except Exception as ex:  # noqa: BLE001
+            errors.append("%s: %r" % (k, ex))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in jobs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    assert counts["lba_a"] > 500 and counts["map_ba"] > 50, counts
