@@ -672,42 +672,54 @@ void plan_for(const PlanGraph& G, const std::vector<int>& prA, const std::vector
 
 // forceP: 0 = choose, 1 = natural order, p > 1 = that many segments (the callers read EAO_BA_ND for it)
 void gba_build_plan(int nFa, const std::vector<int>& prA, const std::vector<int>& prB, int forceP, GbaPlan& pl) {
-    PlanGraph G;
-    G.nFa = nFa;
-    plan_adjacency(nFa, prA, prB, G.g);
-    // ---- the line the keyframes are laid out on
-    G.line.resize((size_t)nFa); G.pos.resize((size_t)nFa);
-    for (int i = 0; i < nFa; i++) G.line[i] = G.pos[i] = i;
-    const int bwNat = plan_bandwidth(nFa, G.g, G.pos);
-    if (nFa >= 64 && bwNat > 24) {
-        std::vector<int> rcm, rpos((size_t)nFa);
-        plan_rcm(nFa, G.g, rcm);
-        for (int i = 0; i < nFa; i++) rpos[rcm[i]] = i;
-        const int bwR = plan_bandwidth(nFa, G.g, rpos);
-        if (bwR * 5 < bwNat * 4) { G.line = rcm; G.pos = rpos; G.rcm = 1; }
+    // ---- the lines the keyframes can be laid out on: their natural order, and reverse Cuthill-McKee when that narrows the band.  A loop that closes on itself (the
+    //      last keyframes see the first) is the case where the wider line wins: on the natural line only the first few keyframes reach across every cut (they join the
+    //      separators once), while RCM folds the ring and doubles the band at every cut -- so both lines are tried and the plans decide.
+    PlanGraph G[2];
+    int nLines = 1;
+    auto reach = [&](PlanGraph& g) {      // per vertex the reach of its neighbourhood along the line
+        g.lo.resize((size_t)nFa); g.hi.resize((size_t)nFa);
+        for (int v = 0; v < nFa; v++) {
+            int a = g.pos[v], b = g.pos[v];
+            for (int e = g.g.off[v]; e < g.g.off[v + 1]; e++) { a = std::min(a, g.pos[g.g.adj[e]]); b = std::max(b, g.pos[g.g.adj[e]]); }
+            g.lo[v] = a; g.hi[v] = b;
+        }
+    };
+    G[0].nFa = nFa;
+    plan_adjacency(nFa, prA, prB, G[0].g);
+    G[0].line.resize((size_t)nFa); G[0].pos.resize((size_t)nFa);
+    for (int i = 0; i < nFa; i++) G[0].line[i] = G[0].pos[i] = i;
+    G[0].bandwidth = plan_bandwidth(nFa, G[0].g, G[0].pos);
+    reach(G[0]);
+    if (nFa >= 64 && G[0].bandwidth > 24) {
+        G[1].nFa = nFa; G[1].g = G[0].g; G[1].rcm = 1;
+        plan_rcm(nFa, G[1].g, G[1].line);
+        G[1].pos.resize((size_t)nFa);
+        for (int i = 0; i < nFa; i++) G[1].pos[G[1].line[i]] = i;
+        G[1].bandwidth = plan_bandwidth(nFa, G[1].g, G[1].pos);
+        if (G[1].bandwidth * 5 < G[0].bandwidth * 4) { reach(G[1]); nLines = 2; }
     }
-    G.bandwidth = G.rcm ? plan_bandwidth(nFa, G.g, G.pos) : bwNat;
-    // per vertex the reach of its neighbourhood along the line
-    G.lo.resize((size_t)nFa); G.hi.resize((size_t)nFa);
-    for (int v = 0; v < nFa; v++) {
-        int a = G.pos[v], b = G.pos[v];
-        for (int e = G.g.off[v]; e < G.g.off[v + 1]; e++) { a = std::min(a, G.pos[G.g.adj[e]]); b = std::max(b, G.pos[G.g.adj[e]]); }
-        G.lo[v] = a; G.hi[v] = b;
-    }
-    plan_for(G, prA, prB, 1, pl);
+    plan_for(G[0], prA, prB, 1, pl);
     const int natural = (int)pl.launches.size();
-    if (forceP > 1) plan_for(G, prA, prB, std::min(forceP, std::max(1, nFa / 2)), pl);
-    else if (forceP == 0 && nFa >= 96) {
+    auto cost = [](const GbaPlan& q) { return (long long)(q.launches.size() + q.sbLaunches.size()) * 100000 + (long long)(q.work.size() / 2); };
+    GbaPlan cand;
+    if (forceP > 1) {
+        const int P = std::min(forceP, std::max(1, nFa / 2));
+        plan_for(G[0], prA, prB, P, pl);
+        if (nLines == 2) { plan_for(G[1], prA, prB, P, cand); if (cost(cand) < cost(pl)) std::swap(pl, cand); }
+    } else if (forceP == 0 && nFa >= 96) {
         // the schedule itself is the estimate: a plan costs a fraction of a millisecond (0.23 ms at 1000 keyframes), so a handful of segment counts are built and
         // the one with the fewest dependent launches -- factorisation + back substitution -- is kept (ties: fewer work records)
-        GbaPlan cand;
-        auto cost = [](const GbaPlan& q) { return (long long)(q.launches.size() + q.sbLaunches.size()) * 100000 + (long long)(q.work.size() / 2); };
-        for (int P : {4, 6, 8, 12, 16, 24, 32, 48}) {
-            if (nFa / P < 8) break;
-            plan_for(G, prA, prB, P, cand);
-            if (cost(cand) < cost(pl)) std::swap(pl, cand);
-        }
-        if (pl.P > 1 && (pl.launches.size() + pl.sbLaunches.size()) * 10 > (size_t)(natural + (pl.N + kBigSB - 1) / kBigSB) * 7) plan_for(G, prA, prB, 1, pl);      // (less than 30 % shorter: not worth the padding and the fill)
+        for (int li = 0; li < nLines; li++)
+            for (int P : {4, 6, 8, 12, 16, 24, 32, 48}) {
+                if (nFa / P < 8) break;
+                plan_for(G[li], prA, prB, P, cand);
+                if (cost(cand) < cost(pl)) std::swap(pl, cand);
+            }
+        if (pl.P > 1 && (pl.launches.size() + pl.sbLaunches.size()) * 10 > (size_t)(natural + (pl.N + kBigSB - 1) / kBigSB) * 7) plan_for(G[0], prA, prB, 1, pl);      // (less than 30 % shorter: not worth the padding and the fill)
+    } else if (nLines == 2) {      // natural order asked for, or a small map: the narrower line as before
+        plan_for(G[1], prA, prB, 1, cand);
+        if (forceP != 1 && cost(cand) < cost(pl)) std::swap(pl, cand);
     }
     pl.chainNatural = natural;
 }

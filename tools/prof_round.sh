@@ -3,7 +3,7 @@
 # behind the VALU roofline, the FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic, the per-kernel summaries of the BA calls behind
 # roofline.ba, and the VALU issue-rate micro-benchmark.
 #   bash tools/prof_round.sh r03   ->  gpurun_out/r03_*   (copy the summaries into profiles/ afterwards: tools/prof_round.sh does not)
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 rm -rf $O/${R}_stats $O/${R}_sq_a $O/${R}_sq_b $O/${R}_fetch $O/${R}_write $O/${R}_sq_h $O/${R}_ba_batch $O/${R}_ba_single
@@ -44,6 +44,15 @@ python3 tools/summarize_rocprof.py "$f" $O/${R}_ba_single_kernel_stats.csv "pyth
 ./tools/ubench/lds_ops > $O/${R}_ubench_lds.txt 2>&1
 # 6. the default bench line itself
 python3 bench.py > $O/${R}_bench_line.json 2> $O/${R}_bench_line.err; tail -c 600 $O/${R}_bench_line.json; echo
-# 7. round-5 extras: pose / map-scale stamps and kernel summaries, FETCH_SIZE calibration by load width
-bash tools/prof_r05_pose_gba.sh > $O/${R}_extras.log 2>&1; tail -6 $O/${R}_extras.log | cut -c1-250
-bash tools/prof_fetch_calib.sh > /dev/null 2>&1; cat $O/r05_fetch_calib.txt
+# 7. the map-scale BundleAdjustment benchmarks: host-phase stamps, the plan line, rocprofv3 kernel summaries (fresh directories: this step removes nothing)
+G=$O/${R}_gba_$$; GB=$O/${R}_gbab_$$
+rocprofv3 --kernel-trace --stats --output-format csv -d $G -o s -- python3 tools/dbg_gba.py > $O/${R}_gba.log 2>&1
+f=$(find $G -name "*kernel_stats.csv" | head -1); python3 tools/summarize_rocprof.py "$f" $O/${R}_gba_kernel_stats.csv "python3 tools/dbg_gba.py (200 KF x 20000 MP, 3 calls)" | head -14
+EAO_DBG_ORACLE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GB -o s -- python3 tools/dbg_gba_banded.py > $O/${R}_gbab.log 2>&1
+f=$(find $GB -name "*kernel_stats.csv" | head -1); python3 tools/summarize_rocprof.py "$f" $O/${R}_gba_banded_kernel_stats.csv "EAO_DBG_ORACLE=0 python3 tools/dbg_gba_banded.py (1000 KF x 50000 MP band 11, 3 calls)" | head -14
+EAO_DEBUG_STAMPS=1 EAO_DBG_ORACLE=0 python3 tools/dbg_gba_banded.py 2>&1 | grep -E 'map-scale plan|host set-up|map-scale wall|banded GBA' | cut -c1-420 > $O/${R}_gba_banded_host_stamps.txt
+EAO_BA_ND=1 EAO_DEBUG_STAMPS=1 EAO_DBG_ORACLE=0 python3 tools/dbg_gba_banded.py 2>&1 | grep -E 'map-scale plan|map-scale wall|banded GBA' | cut -c1-420 > $O/${R}_gba_banded_natural_order.txt
+EAO_DEBUG_STAMPS=1 EAO_DBG_ORACLE=0 python3 tools/dbg_gba.py 2>&1 | grep -E 'map-scale plan|host set-up|map-scale wall|^GBA' | cut -c1-420 > $O/${R}_gba_host_stamps.txt
+tail -3 $O/${R}_gba_host_stamps.txt $O/${R}_gba_banded_host_stamps.txt | cut -c1-300
+# 8. the GPU suite's log
+python3 -m pytest tests -m gpu -q > $O/${R}_gputests.log 2>&1; tail -3 $O/${R}_gputests.log

@@ -25,6 +25,9 @@ for it in range(N):
     mode = int(rng.integers(0, 3))
     if "band" in kw: mode = int(rng.integers(0, 2)); os.environ["EAO_BA_SETUP_THREADS"] = str(int(rng.choice([1, 3, 8])))      # (the set-up on 1 / 3 / 8 workers of the host crew)
     else: os.environ.pop("EAO_BA_SETUP_THREADS", None)
+    # (round 6) the map-scale path's elimination order: the library's choice, natural order, or a forced number of segments (read per call)
+    if kw["n_free"] > 30: os.environ["EAO_BA_ND"] = str(int(rng.choice([0, 0, 1, 2, 3, 5, 8]))); kw_nd = os.environ["EAO_BA_ND"]
+    else: os.environ.pop("EAO_BA_ND", None); kw_nd = "-"
     try:
         if mode == 0:
             r, o = E.Optimizer.LocalBundleAdjustment(p), O.local_ba(p)
@@ -42,7 +45,7 @@ for it in range(N):
         ok = False; print("   exception", repr(ex))
     if not ok:
         bad += 1
-        print("MISMATCH mode %d %s" % (mode, kw), flush=True)
+        print("MISMATCH mode %d %s EAO_BA_ND=%s" % (mode, kw, kw_nd), flush=True)
         try:      # what differs, and how far the ORACLE itself moves when the input points move by one float32 ulp (an ill-conditioned landmark amplifies the last bit)
             def rel(a, b, old):
                 upd = max(np.abs(b.astype(np.float64) - old.astype(np.float64)).max(), 1e-6)
