@@ -49,7 +49,7 @@ def _source_sha(rel):
         return None
 
 
-LM_SOURCES = ("eao_fusion_amd/csrc/lm_internal.h", "eao_fusion_amd/csrc/lba.hip", "eao_fusion_amd/csrc/gba.hip", "eao_fusion_amd/csrc/lm_host.hip")      # (round 6: csrc/lm.hip split)
+LM_SOURCES = ("eao_fusion_amd/csrc/lm_internal.h", "eao_fusion_amd/csrc/lba.hip", "eao_fusion_amd/csrc/gba.hip")      # (round 6: csrc/lm.hip split; the KERNEL sources -- lm_host.hip is host code + the PCIe copy kernel)
 
 
 def _fresh(pmc, rel):

@@ -53,9 +53,9 @@ def main():
         ("tracked frame: motion model + local map", "%.4f ms (%.4f + %.4f)" % (rf["track_frame_ms"], rf["track_motion_model_ms"], rf["track_local_map_ms"]), "— (0.487)", "`eao_tracker_*`, polled done word"),
         ("Hamming 1000 × 1000 matrix (×64 pairs)", "%.1f µs, frac %.3f" % (rf["hamming_matrix_us"], rf["hamming_matrix_frac"]), "—", "`eao_hamming_matrix_device`"),
     ]
-    for k in ("search_by_bow_kf_frame", "search_by_bow_kf_kf", "search_for_triangulation", "fuse_search_pose"):
-        rows.append(("`%s` (keyframe handles)" % k, "%.4f ms = %.2f× one CPU thread (per-call upload form: %.4f ms = %.2f×)" % (
-            rf["gs_%s_handles_ms" % k], rf["gs_%s_handles_over_cpu" % k], rf["gs_%s_ms" % k], rf["gs_%s_over_cpu" % k]), "—", "ctypes mirror, median of 12"))
+    rows.append(("guided searches on keyframe handles: `search_by_bow` kf-frame / kf-kf, `search_for_triangulation`, `fuse_search`", " / ".join("%.4f" % rf["gs_%s_handles_ms" % k] for k in
+                 ("search_by_bow_kf_frame", "search_by_bow_kf_kf", "search_for_triangulation", "fuse_search_pose")) + " ms = " + " / ".join("%.2f" % rf["gs_%s_handles_over_cpu" % k] for k in
+                 ("search_by_bow_kf_frame", "search_by_bow_kf_kf", "search_for_triangulation", "fuse_search_pose")) + " × one CPU thread", "—", "ctypes mirror, median of 12"))
     rows += [
         ("`search_for_triangulation_batch` (10 neighbours, handles)", "%.4f ms (upload form %.3f)" % (rf["gs_triangulation_batch10_handles_ms"], rf["gs_triangulation_batch10_ms"]), "—", "″"),
         ("`fuse_search_batch` (10 targets, handles)", "%.4f ms (upload form %.3f)" % (rf["gs_fuse_batch10_handles_ms"], rf["gs_fuse_batch10_ms"]), "—", "″"),
@@ -98,7 +98,7 @@ def main():
       " 64-frame batches with the single-frame and 256-frame calls of the extras, the stage events of the table above are the 64-frame figures):\n" % R)
     w("| Kernel | calls | avg µs | min µs | max µs | % of GPU time |")
     w("|---|---|---|---|---|---|")
-    for name, r in list(ks.items())[:16]:
+    for name, r in list(ks.items())[:8]:
         w("| `%s` | %s | %s | %s | %s | %.1f |" % (name, r["calls"], r["avg_us"], r["min_us"], r["max_us"], float(r["pct"])))
     # ---- traffic
     if os.path.exists(P("pmc_traffic.json")):
