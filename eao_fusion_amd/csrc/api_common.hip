@@ -1,6 +1,7 @@
 // api_common.hip -- status/error plumbing and the device gate of the C-ABI (include/eao_fusion.h)
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -72,7 +73,18 @@ hipError_t create_stream(hipStream_t* s, StreamClass c) {
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio[(int)c]);
 }
 
+namespace {
+std::atomic<long long> g_latencyStampNs{0};
+long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+void note_latency_call() { g_latencyStampNs.store(now_ns(), std::memory_order_relaxed); }
+bool latency_caller_alive() {
+    const long long t = g_latencyStampNs.load(std::memory_order_relaxed);
+    return t != 0 && now_ns() - t < 100000000ll;
+}
+
 hipError_t wait_latency(hipStream_t s) {
+    note_latency_call();
     static const bool spin = !(getenv("EAO_SPIN_WAIT") && !atoi(getenv("EAO_SPIN_WAIT")));
     if (spin) {
         const auto t0 = std::chrono::steady_clock::now();

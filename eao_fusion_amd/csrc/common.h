@@ -71,6 +71,12 @@ hipError_t create_stream(hipStream_t* s, StreamClass c);
 // waits for each of these calls, so the caller's thread polls hipStreamQuery for up to 3 ms first (a Tracking thread has nothing else to do meanwhile; upstream's
 // computes the features on that core) and only then blocks.  EAO_SPIN_WAIT=0: always block.
 hipError_t wait_latency(hipStream_t s);
+// A latency-class call is in progress / was made moments ago (stamped by wait_latency and by the tracked-frame chain's poll): eao_local_ba_batch deals its windows to TWO
+// stream groups instead of four while a frame-rate caller is alive in the process.  Measured (tests/cpp/mixed_load.cpp, gpurun_out/r06n): four groups keep every CU's
+// register file occupied without a gap, and the tracker's full-register-file workgroups wait for the batch's whole busy period (tracked frame p50 1.65 / p99 3.2 ms against
+// 0.77 idle); with two groups 1.08 / 1.64 ms, the batch 2.87 -> 3.13 ms per call.  No latency-class call within the last 100 ms: four groups, as in the benchmark.
+void note_latency_call();
+bool latency_caller_alive();
 
 #if defined(__HIPCC__)
 // THE hand-over point between the lanes of ONE wavefront through LDS (or through memory the wave alone touches): the

@@ -912,7 +912,8 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
     const int fullRows = n / 8, rest = n - 8 * fullRows;
     const bool rowGroups = fullRows >= 1 && !getenv("EAO_BA_BATCH_EVEN");      // (A/B switch: the even split of rounds 2-3)
     const bool restGroup = rowGroups && rest >= kBatchGroupMin;                // an incomplete row large enough to be a group of its own (else it joins the last group)
-    const int gWant = std::min(envGroups > 0 ? envGroups : kBatchGroups, nThreads);
+    // (two groups while a frame-rate caller is alive in the process: common.h, note_latency_call)
+    const int gWant = std::min(envGroups > 0 ? envGroups : (eao::latency_caller_alive() ? 2 : kBatchGroups), nThreads);
     const int G = std::max(1, rowGroups ? std::min(gWant, fullRows + (restGroup ? 1 : 0)) : std::min(gWant, n / kBatchGroupMin));
     std::vector<int> gStart(G + 1, n);
     for (int g = 0; g < G; g++) {

@@ -1051,6 +1051,7 @@ eao_status track_chain(eao_tracker* h, const eao_keypoint* d_kps, const uint8_t*
     if ((st = eao::lm::enqueue_pose_device(PA, s))) return st;
     // ---- the results are in host memory when the done word says so (or when the stream has drained)
     bool seen = false;
+    eao::note_latency_call();
     if (envPoll) {
         const volatile int* done = reinterpret_cast<const volatile int*>(h->resPin + oDone);
         const auto t0 = std::chrono::steady_clock::now();
