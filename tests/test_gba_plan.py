@@ -209,6 +209,64 @@ def test_random_graphs_and_components():
             replay(get_plan(n, pairs, force), pairs, seed=100 + trial)
 
 
+def check_structure(pl):
+    """the schedule's contracts alone (no matrix): usable on maps too large for a dense replay"""
+    info, tm = pl["info"], pl["tile_map"]
+    N, tN = info.n_rows, info.n_rows // 64
+    have = set()
+    for (off, cnt, doff, dcnt) in pl["launches"]:
+        for kb in pl["diag"][doff:doff + dcnt]:
+            assert int(kb) not in have
+            have.add(int(kb))
+        recs = pl["work"][off:off + cnt]
+        targets = [int(r[2]) for r in recs if not (r[6] & 4)]
+        assert len(targets) == len(set(targets))
+        reads = set((int(t_), 32 * int(r[5])) for r in recs for t_ in (r[0], r[1]))
+        rows_read = {}
+        for (t_, k0_) in reads:
+            rows_read.setdefault(t_, []).append(k0_)
+        new = set()
+        for (ti, tj, sc, sw, sl, kb, flags, nxt) in recs:
+            kc = kb // 2
+            assert int(kb) in have and tm[ti, tj] == sc and sc >= 0 and tm[ti, kc] == sw and sw >= 0 and tm[tj, kc] == sl and sl >= 0
+            if not (flags & 4):
+                c_lo = max(64 * int(tj), 32 * int(kb) + 32)
+                assert not any(c_lo <= k0_ < 64 * int(tj) + 64 for k0_ in rows_read.get(int(ti), []))
+            if flags & 1:
+                assert ti == tj and nxt // 2 == ti and int(nxt) not in have and int(nxt) not in new
+                new.add(int(nxt))
+        have |= new
+    assert have == set(range(N // 32))
+    cols = np.zeros(N, int)
+    for (off, cnt, _gx) in pl["sb_launches"]:
+        for (J0, w, lo, hi) in pl["sb"][off:off + cnt]:
+            assert (cols[J0:J0 + w] == 0).all() and 64 * hi <= J0 and lo <= hi
+            cols[J0:J0 + w] = 1
+    assert cols.all()
+
+
+def test_large_maps_keep_the_contracts():
+    """2000 keyframes on a band with 40 loop closures, and 1500 keyframes of a random sparse graph in shuffled order: the schedule's contracts hold (no dense replay at this size)"""
+    rng = np.random.default_rng(11)
+    pairs = set(band_pairs(2000, 8))
+    for _ in range(40):
+        i, j = sorted(int(x) for x in rng.integers(0, 2000, 2))
+        pairs.add((i, j))
+    pl = get_plan(2000, sorted(pairs))
+    check_structure(pl)
+    assert pl["info"].n_launches < pl["info"].chain_natural // 3
+    perm = rng.permutation(1500)
+    pairs = set((i, i) for i in range(1500))
+    for a in range(1500):
+        for k in range(1, 6):
+            if a + k < 1500:
+                i, j = int(perm[a]), int(perm[a + k])
+                pairs.add((min(i, j), max(i, j)))
+    pl = get_plan(1500, sorted(pairs))
+    check_structure(pl)
+    assert pl["info"].rcm == 1 and pl["info"].n_launches < pl["info"].chain_natural      # (shuffled ids: the natural line is useless, reverse Cuthill-McKee finds the trajectory)
+
+
 def test_a_trajectory_gets_a_short_chain():
     """1000 keyframes, each covisible with its +-10 neighbours (bench.py's banded map): the factorisation's chain of dependent launches falls from 188 panels to a few dozen"""
     pl = get_plan(1000, band_pairs(1000, 10))
