@@ -218,63 +218,147 @@ struct BAJob {
             int nFa = 0;
             for (int i = 0; i < nC; i++) if (camCnt[i] && !p->cam_fixed[i]) fidx[i] = nFa++;      // (camCnt: the validation pass)
             // per landmark: its free observers and their edges, in edge order (the order of the active structure's ptEdges)
-            bool byLandmark = true;        // the edges come landmark by landmark (the adapters and every generator list them so): the observer lists are then a filtered copy
-            for (int e = 0, prev = 0; e < E; e++) { const int lmk = edge_lm(e); byLandmark = byLandmark && lmk >= prev; prev = lmk; if (fidx[edge_cam(e)] >= 0) lmOff[lmk + 1]++; }
-            for (int i = 0; i < nP; i++) {
-                const int m = lmOff[i + 1];
-                lpEntries += (size_t)m * (m + 1) / 2;
-                lmOff[i + 1] += lmOff[i];
-            }
-            EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
-            hs_lap(8);
-            lmCam.resize((size_t)lmOff[nP] + 1); lmEdge.resize((size_t)lmOff[nP] + 1);      // (+ 1: the branch-free append writes one slot ahead)
-            cmOff.assign((size_t)nFa + 1, 0);
-            if (byLandmark) {
-                // (plain pointers and a branch-free append: the loop is a stream of 2 E loads and at most 2 E stores)
-                int* const lc = lmCam.data(); int* const le = lmEdge.data(); int* const co = cmOff.data() + 1; const int* const fi = fidx.data();
-                const int* const ecam = p->edge_cam; const int* const pcam = pl ? pl->pedge_cam : nullptr;
-                int at = 0;
-                for (int e = 0; e < Ept; e++) { const int f = fi[ecam[e]]; lc[at] = f; le[at] = e; const int ok = f >= 0; at += ok; if (ok) co[f]++; }
-                for (int e = Ept; e < E; e++) { const int f = fi[pcam[e - Ept]]; lc[at] = f; le[at] = e; const int ok = f >= 0; at += ok; if (ok) co[f]++; }
-            } else {
-                pcur.assign(lmOff.begin(), lmOff.end() - 1);
-                for (int e = 0; e < E; e++) {
-                    const int f = fidx[edge_cam(e)];
-                    if (f < 0) continue;
-                    const int at = pcur[edge_lm(e)]++;
-                    lmCam[at] = f; lmEdge[at] = e; cmOff[f + 1]++;
+            // ---- round 6: the observer lists and the camera lists in TWO PARALLEL PASSES over landmark ranges (the serial walks below took 2.3 of the 4.8 ms of host
+            //      set-up in front of the 1000-keyframe map's 7.5 ms of device time).  With the edges listed landmark by landmark (what the adapters and every
+            //      generator produce; no plane edges) a landmark's edges are contiguous, so a chunk of the edge list cut at landmark boundaries owns its landmarks:
+            //      pass 1 counts every landmark's free observers and the chunk's entries per camera; pass 2 writes the observer lists (sorted by camera) and files every
+            //      entry under its camera at the position the chunks before it left -- a camera's list comes out in ascending landmark order, the same arrays as the
+            //      serial walk, element for element (tests/test_gpu_lm.py::test_map_scale_set_up_on_the_host_crew).  1000-keyframe map: lists 2.25 -> 1.0 ms, the call 12.4 -> 11.6 ms.
+            const int envSetupT = getenv("EAO_BA_SETUP_THREADS") ? atoi(getenv("EAO_BA_SETUP_THREADS")) : 0;      // (1: the serial walks; n > 1: the parallel passes on any map -- the tests)
+            const bool parallelLists = edgesByLandmark && Epl == 0 && !t_inCrew && envSetupT != 1 && (Ept >= 200000 || envSetupT > 1);      // (a crew hand-over costs ~0.1 ms: at 100 000 edges the two passes gain nothing -- measured on the 200-keyframe map)
+            if (parallelLists) {
+                const int Q = 48;
+                static thread_local std::vector<int> cb, cl, chunkFree, camCntQ;
+                static thread_local std::vector<long long> chunkEnt;
+                cb.assign(Q + 1, Ept); cl.assign(Q + 1, nP);
+                const int* const ecam = p->edge_cam; const int* const ept = p->edge_point;
+                for (int q = 0; q < Q; q++) {      // chunk q = edges [cb[q], cb[q + 1]) = landmarks [cl[q], cl[q + 1]); boundaries moved forward to a landmark boundary
+                    int e = (int)((long long)Ept * q / Q);
+                    while (e > 0 && e < Ept && ept[e] == ept[e - 1]) e++;
+                    cb[q] = std::min(e, Ept);
+                    cl[q] = q == 0 ? 0 : (cb[q] < Ept ? ept[cb[q]] : nP);
                 }
-            }
-            hs_lap(9);
-            for (int i = 0; i < nP; i++)           // observers by camera (insertion sort: a handful per landmark, mostly in order already)
-                for (int u = lmOff[i] + 1; u < lmOff[i + 1]; u++) {
-                    const int cf = lmCam[u], ce = lmEdge[u];
-                    int v = u;
-                    for (; v > lmOff[i] && lmCam[v - 1] > cf; v--) { lmCam[v] = lmCam[v - 1]; lmEdge[v] = lmEdge[v - 1]; }
-                    lmCam[v] = cf; lmEdge[v] = ce;
-                }
-            hs_lap(10);
-            // per free camera: its landmarks in ascending order (a counting sort over the landmarks, walked in ascending order), each with the position of the
-            // camera's own entry in that landmark's list
-            for (int f = 0; f < nFa; f++) cmOff[f + 1] += cmOff[f];
-            cmLm.resize(cmOff[nFa]); cmU.resize(cmOff[nFa]);
-            {   // (camera ranges on the crew: every worker walks all observer lists and files the entries of ITS cameras -- a camera's list is written by one worker, in landmark order)
-                const int nRanges = std::max(1, std::min(16, nFa / 32));
-                const int* const lmOffp = lmOff.data(); const int* const lmCamp = lmCam.data(); const int* const cmOffp = cmOff.data();
-                int* const cmLmp = cmLm.data(); int* const cmUp = cmU.data();
-                const int nPl_ = nP;
-                crew_for(lpEntries, nRanges, [=](int q) {
-                    const int f0 = (int)((long long)nFa * q / nRanges), f1 = (int)((long long)nFa * (q + 1) / nRanges);
-                    static thread_local std::vector<int> cur;
-                    cur.assign(cmOffp + f0, cmOffp + f1);
-                    for (int i = 0; i < nPl_; i++)
-                        for (int u = lmOffp[i]; u < lmOffp[i + 1]; u++) {
-                            const int f = lmCamp[u];
-                            if (f < f0 || f >= f1) continue;
-                            const int at = cur[f - f0]++;
-                            cmLmp[at] = i; cmUp[at] = u;
+                for (int q = Q - 1; q > 0; q--) cb[q] = std::max(cb[q], cb[q - 1]);      // (monotone; an empty chunk is harmless)
+                cb[0] = 0; cl[0] = 0;
+                for (int q = 1; q < Q; q++) cl[q] = cb[q] < Ept ? ept[cb[q]] : nP;
+                chunkFree.assign(Q, 0); chunkEnt.assign(Q, 0); camCntQ.assign((size_t)Q * nFa, 0);
+                lmOff.assign((size_t)nP + 1, 0);
+                {
+                    const int* const fi = fidx.data(); int* const cfp = chunkFree.data(); long long* const cep = chunkEnt.data();
+                    int* const ccq = camCntQ.data(); const int* const cbp = cb.data();
+                    const int nFa_ = nFa;
+                    crew_for((size_t)Ept * 8, Q, [=](int q) {
+                        int* const cc = ccq + (size_t)q * nFa_;
+                        int freeN = 0; long long ent = 0;
+                        for (int e = cbp[q]; e < cbp[q + 1];) {
+                            const int lmk = ept[e];
+                            int m = 0;
+                            for (; e < cbp[q + 1] && ept[e] == lmk; e++) { const int f = fi[ecam[e]]; if (f >= 0) { m++; cc[f]++; } }
+                            freeN += m; ent += (long long)m * (m + 1) / 2;
                         }
-                });
+                        cfp[q] = freeN; cep[q] = ent;
+                    });
+                }
+                // chunk bases; per camera the start of its list and, per chunk, where the chunk's entries go
+                static thread_local std::vector<int> chunkBase;
+                chunkBase.assign(Q + 1, 0);
+                for (int q = 0; q < Q; q++) { chunkBase[q + 1] = chunkBase[q] + chunkFree[q]; lpEntries += (size_t)chunkEnt[q]; }
+                EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
+                hs_lap(8);
+                const int total = chunkBase[Q];
+                lmCam.resize((size_t)total + 1); lmEdge.resize((size_t)total + 1);
+                cmOff.assign((size_t)nFa + 1, 0);
+                for (int f = 0; f < nFa; f++) {
+                    int run = 0;
+                    for (int q = 0; q < Q; q++) { const int c0 = camCntQ[(size_t)q * nFa + f]; camCntQ[(size_t)q * nFa + f] = run; run += c0; }      // counts become offsets inside the camera's list
+                    cmOff[f + 1] = cmOff[f] + run;
+                }
+                cmLm.resize(cmOff[nFa]); cmU.resize(cmOff[nFa]);
+                hs_lap(9);
+                {
+                    int* const lmOffp = lmOff.data(); int* const lc = lmCam.data(); int* const le = lmEdge.data(); const int* const fi = fidx.data();
+                    int* const ccq = camCntQ.data(); const int* const cbp = cb.data(); const int* const clp = cl.data(); const int* const basep = chunkBase.data();
+                    const int* const cmOffp = cmOff.data(); int* const cmLmp = cmLm.data(); int* const cmUp = cmU.data();
+                    const int nFa_ = nFa;
+                    crew_for((size_t)Ept * 8, Q, [=](int q) {
+                        int* const cc = ccq + (size_t)q * nFa_;
+                        int at = basep[q], e = cbp[q];
+                        const int lEnd = clp[q + 1];
+                        for (int lmk = clp[q]; lmk < lEnd; lmk++) {
+                            lmOffp[lmk] = at;      // (a landmark without edges: an empty list)
+                            const int first = at;
+                            for (; e < cbp[q + 1] && ept[e] == lmk; e++) { const int f = fi[ecam[e]]; if (f >= 0) { lc[at] = f; le[at] = e; at++; } }
+                            for (int u = first + 1; u < at; u++) {      // observers by camera (insertion sort: a handful per landmark, mostly in order already)
+                                const int cf = lc[u], ce = le[u];
+                                int v = u;
+                                for (; v > first && lc[v - 1] > cf; v--) { lc[v] = lc[v - 1]; le[v] = le[v - 1]; }
+                                lc[v] = cf; le[v] = ce;
+                            }
+                            for (int u = first; u < at; u++) { const int f = lc[u], pos = cmOffp[f] + cc[f]++; cmLmp[pos] = lmk; cmUp[pos] = u; }
+                        }
+                    });
+                    lmOff[nP] = total;
+                }
+                hs_lap(10);
+            } else {
+                bool byLandmark = true;        // the edges come landmark by landmark (the adapters and every generator list them so): the observer lists are then a filtered copy
+                for (int e = 0, prev = 0; e < E; e++) { const int lmk = edge_lm(e); byLandmark = byLandmark && lmk >= prev; prev = lmk; if (fidx[edge_cam(e)] >= 0) lmOff[lmk + 1]++; }
+                for (int i = 0; i < nP; i++) {
+                    const int m = lmOff[i + 1];
+                    lpEntries += (size_t)m * (m + 1) / 2;
+                    lmOff[i + 1] += lmOff[i];
+                }
+                EAO_REQUIRE(lpEntries < ((size_t)1 << 31), "covisibility structure too large (%zu pair entries)", lpEntries);
+                hs_lap(8);
+                lmCam.resize((size_t)lmOff[nP] + 1); lmEdge.resize((size_t)lmOff[nP] + 1);      // (+ 1: the branch-free append writes one slot ahead)
+                cmOff.assign((size_t)nFa + 1, 0);
+                if (byLandmark) {
+                    // (plain pointers and a branch-free append: the loop is a stream of 2 E loads and at most 2 E stores)
+                    int* const lc = lmCam.data(); int* const le = lmEdge.data(); int* const co = cmOff.data() + 1; const int* const fi = fidx.data();
+                    const int* const ecam = p->edge_cam; const int* const pcam = pl ? pl->pedge_cam : nullptr;
+                    int at = 0;
+                    for (int e = 0; e < Ept; e++) { const int f = fi[ecam[e]]; lc[at] = f; le[at] = e; const int ok = f >= 0; at += ok; if (ok) co[f]++; }
+                    for (int e = Ept; e < E; e++) { const int f = fi[pcam[e - Ept]]; lc[at] = f; le[at] = e; const int ok = f >= 0; at += ok; if (ok) co[f]++; }
+                } else {
+                    pcur.assign(lmOff.begin(), lmOff.end() - 1);
+                    for (int e = 0; e < E; e++) {
+                        const int f = fidx[edge_cam(e)];
+                        if (f < 0) continue;
+                        const int at = pcur[edge_lm(e)]++;
+                        lmCam[at] = f; lmEdge[at] = e; cmOff[f + 1]++;
+                    }
+                }
+                hs_lap(9);
+                for (int i = 0; i < nP; i++)           // observers by camera (insertion sort: a handful per landmark, mostly in order already)
+                    for (int u = lmOff[i] + 1; u < lmOff[i + 1]; u++) {
+                        const int cf = lmCam[u], ce = lmEdge[u];
+                        int v = u;
+                        for (; v > lmOff[i] && lmCam[v - 1] > cf; v--) { lmCam[v] = lmCam[v - 1]; lmEdge[v] = lmEdge[v - 1]; }
+                        lmCam[v] = cf; lmEdge[v] = ce;
+                    }
+                hs_lap(10);
+                // per free camera: its landmarks in ascending order (a counting sort over the landmarks, walked in ascending order), each with the position of the
+                // camera's own entry in that landmark's list
+                for (int f = 0; f < nFa; f++) cmOff[f + 1] += cmOff[f];
+                cmLm.resize(cmOff[nFa]); cmU.resize(cmOff[nFa]);
+                {   // (camera ranges on the crew: every worker walks all observer lists and files the entries of ITS cameras -- a camera's list is written by one worker, in landmark order)
+                    const int nRanges = std::max(1, std::min(16, nFa / 32));
+                    const int* const lmOffp = lmOff.data(); const int* const lmCamp = lmCam.data(); const int* const cmOffp = cmOff.data();
+                    int* const cmLmp = cmLm.data(); int* const cmUp = cmU.data();
+                    const int nPl_ = nP;
+                    crew_for(lpEntries, nRanges, [=](int q) {
+                        const int f0 = (int)((long long)nFa * q / nRanges), f1 = (int)((long long)nFa * (q + 1) / nRanges);
+                        static thread_local std::vector<int> cur;
+                        cur.assign(cmOffp + f0, cmOffp + f1);
+                        for (int i = 0; i < nPl_; i++)
+                            for (int u = lmOffp[i]; u < lmOffp[i + 1]; u++) {
+                                const int f = lmCamp[u];
+                                if (f < f0 || f >= f1) continue;
+                                const int at = cur[f - f0]++;
+                                cmLmp[at] = i; cmUp[at] = u;
+                            }
+                    });
+                }
             }
             hs_lap(5);
             // the pairs of every camera and their entry counts: chunks of cameras, each into lists of its own, joined in camera order
