@@ -58,12 +58,51 @@ struct HostCrew {
     std::condition_variable wake, finished;
     std::function<void(int)> fn;
     int generation = 0, next = 0, count = 0, running = 0, threads = 0;
+    // ---- SESSIONS (round 6): the set-up of a map-scale BundleAdjustment is a dozen short parallel passes (0.05 - 0.3 ms each) with serial joints in between.  Handing each
+    //      pass over through the condition variable cost ~0.1 ms per pass -- as much as the pass saved on the 200-keyframe map.  A session wakes the crew ONCE; its threads
+    //      then poll one word for the passes of that set-up (claiming chunks with a compare-and-swap on it: sequence number, chunk count and next chunk in one 64-bit
+    //      word, so a thread that is late can never take a chunk of a later pass) and go back to sleep when the session closes.  The caller works on every pass itself
+    //      and waits only for chunks somebody claimed: a crew thread that never wakes costs nothing but its share.
+    int sessionSeq = 0;                          // (under m)
+    std::atomic<int> sessionOpen{0};
+    std::atomic<uint64_t> passWord{0};           // seq << 40 | chunks << 20 | next chunk
+    std::atomic<int> passDone{0};
+    const std::function<void(int)>* passFn = nullptr;
+    uint64_t passSeq = 0;
+    static void cpu_relax() { __builtin_ia32_pause(); }
+    bool claim_chunks(uint64_t seq) {            // chunks of pass `seq` until none is left (or the pass is over); true if the word still belongs to that pass
+        for (;;) {
+            uint64_t w = passWord.load(std::memory_order_acquire);
+            if ((w >> 40) != seq) return false;
+            const int nx = (int)(w & 0xFFFFF), n = (int)((w >> 20) & 0xFFFFF);
+            if (nx >= n) return true;
+            if (!passWord.compare_exchange_weak(w, w + 1, std::memory_order_acq_rel)) continue;
+            (*passFn)(nx);
+            passDone.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void spin_session() {
+        const auto t0 = std::chrono::steady_clock::now();
+        dbgJoined++;
+        for (int it = 0; sessionOpen.load(std::memory_order_acquire); it++) {
+            const uint64_t w = passWord.load(std::memory_order_acquire);
+            if ((int)(w & 0xFFFFF) < (int)((w >> 20) & 0xFFFFF)) claim_chunks(w >> 40);
+            else cpu_relax();
+            if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;      // (a set-up takes a few milliseconds)
+        }
+    }
     void body() {
         t_inCrew = true;
-        int seen = 0;
+        int seen = 0, seenSession = 0;
         for (;;) {
             std::unique_lock<std::mutex> lk(m);
-            wake.wait(lk, [&] { return generation != seen && next < count; });
+            wake.wait(lk, [&] { return (generation != seen && next < count) || sessionSeq != seenSession; });
+            if (sessionSeq != seenSession) {
+                seenSession = sessionSeq;
+                lk.unlock();
+                spin_session();
+                continue;
+            }
             while (next < count) {
                 const int i = next++;
                 running++;
@@ -90,6 +129,48 @@ struct HostCrew {
         std::unique_lock<std::mutex> lk(m);
         finished.wait(lk, [&] { return next >= count && running == 0; });
         count = 0;
+    }
+    // a session: false when another call owns the crew (the caller then runs its passes alone)
+    bool session_begin(int nThreads) {
+        if (!callMu.try_lock()) return false;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            while (threads < nThreads) { std::thread(&HostCrew::body, this).detach(); threads++; }
+            sessionOpen.store(1, std::memory_order_release);
+            sessionSeq++;
+            dbgJoined = 0; dbgT0 = std::chrono::steady_clock::now();
+        }
+        wake.notify_all();
+        return true;
+    }
+    void session_end() {
+        sessionOpen.store(0, std::memory_order_release);
+        callMu.unlock();
+    }
+    std::atomic<int> dbgJoined{0};
+    std::chrono::steady_clock::time_point dbgT0;
+    void session_pass(int nChunks, const std::function<void(int)>& chunk) {      // (the session's owner only)
+        static const bool dbg = getenv("EAO_DEBUG_CREW") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::atomic<int> mine{0};
+        std::function<void(int)> wrapped;
+        if (dbg) {
+            wrapped = [&](int q) { if (!t_inCrew) mine++; chunk(q); };
+            session_pass_(nChunks, wrapped);
+            fprintf(stderr, "[crew] pass of %d chunks: %.3f ms (at %.3f since session start), caller ran %d, %d crew threads in the session so far\n", nChunks,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), std::chrono::duration<double, std::milli>(t0 - dbgT0).count(), mine.load(), dbgJoined.load());
+            return;
+        }
+        session_pass_(nChunks, chunk);
+    }
+    void session_pass_(int nChunks, const std::function<void(int)>& chunk) {
+        passFn = &chunk;
+        passDone.store(0, std::memory_order_relaxed);
+        passSeq = (passSeq + 1) & 0xFFFFFF;
+        if (passSeq == 0) passSeq = 1;
+        passWord.store((passSeq << 40) | ((uint64_t)nChunks << 20), std::memory_order_release);
+        claim_chunks(passSeq);
+        while (passDone.load(std::memory_order_acquire) < nChunks) cpu_relax();
     }
 };
 HostCrew& host_crew() {
@@ -156,22 +237,6 @@ struct BAJob {
             return EAO_OK;
         }
         bool edgesByLandmark = true;      // the edge list is grouped landmark by landmark, ascending (what the adapters and every generator produce): ptEdges is then the identity
-        // ... and, in the same pass over the edges, the edge counts per camera and per landmark the active structure starts from
-        std::vector<int>& cnt = c.scratch;
-        cnt.assign((size_t)nC + nP, 0);
-        int* const camCnt = cnt.data(); int* const ptCnt = camCnt + nC;
-        for (int e = 0, prev = 0; e < Ept; e++) {
-            const int ec = p->edge_cam[e], ep = p->edge_point[e];
-            EAO_REQUIRE(ec >= 0 && ec < nC && ep >= 0 && ep < nPo, "edge %d out of range", e);
-            edgesByLandmark = edgesByLandmark && ep >= prev; prev = ep;
-            camCnt[ec]++; ptCnt[ep]++;
-        }
-        for (int e = 0, prev = 0; e < Epl; e++) {
-            const int ec = pl->pedge_cam[e], ep = pl->pedge_plane[e];
-            EAO_REQUIRE(ec >= 0 && ec < nC && ep >= 0 && ep < nPl, "plane edge %d out of range", e);
-            edgesByLandmark = edgesByLandmark && ep >= prev; prev = ep;
-            camCnt[ec]++; ptCnt[nPo + ep]++;
-        }
         int nFreeIn = 0;
         for (int i = 0; i < nC; i++) nFreeIn += p->cam_fixed[i] ? 0 : 1;
         EAO_REQUIRE(nFreeIn <= kBigMaxFree, "at most %d free keyframes in this build (got %d)", kBigMaxFree, nFreeIn);
@@ -182,6 +247,97 @@ struct BAJob {
         //  the slab assembly takes 5.8 ms at 31 free keyframes and 29 ms at 64, the map-scale path 3.6 and 6.9 ms -- so everything
         //  beyond the register-tile solver goes there; that older path was removed in round 5)
         const bool bigPath = nFreeIn > kTileMaxFree || (nFreeIn > 0 && solverEnv0 && !strcmp(solverEnv0, "big"));
+        // ---- round 6: the set-up of a map-scale call runs as a SESSION of the host crew (HostCrew: one wake-up, then passes handed over through one polled word):
+        //      validation + counts, the observer / camera lists, the pair counts, the problem pack and the pair lists are each a pass over landmark or camera ranges.
+        //      EAO_BA_SETUP_THREADS: 1 = the serial walks, n > 1 = a session of n threads on any map (the tests), unset = a session from 20 000 edges on.
+        const int envSetupT = getenv("EAO_BA_SETUP_THREADS") ? atoi(getenv("EAO_BA_SETUP_THREADS")) : 0;      // (read per call)
+        struct SessionGuard {
+            bool open = false;
+            ~SessionGuard() { if (open) host_crew().session_end(); }
+        } session;
+        if (bigPath && !t_inCrew && envSetupT != 1 && (Ept >= 20000 || envSetupT > 1)) {
+            const int hw = (int)std::thread::hardware_concurrency();
+            const int nT = envSetupT > 1 ? envSetupT : std::max(2, std::min(12, hw / 2));
+            session.open = host_crew().session_begin(nT - 1);
+        }
+        // ... and, in the same pass over the edges, the edge counts per camera and per landmark the active structure starts from
+        std::vector<int>& cnt = c.scratch;
+        cnt.assign((size_t)nC + nP, 0);
+        int* const camCnt = cnt.data(); int* const ptCnt = camCnt + nC;
+        // ---- the parallel form of that pass (sessions; no plane edges): chunks of the edge list cut at landmark boundaries.  Every chunk validates its edges, checks that
+        //      the landmarks ascend, counts each landmark's edges (a landmark's run belongs to one chunk) and its own edges per camera, looks for a camera that appears
+        //      twice in a landmark, and counts what the covisibility structure needs (free observers, pair entries).  Anything unexpected -- an index out of range, a
+        //      landmark out of order -- and the serial pass below runs instead (and words the error).
+        constexpr int kQ = 48;
+        static thread_local std::vector<int> cb, cl, chunkFree, camCntQ, camLastQ, chunkBad, cmE;
+        static thread_local std::vector<long long> chunkEnt;
+        bool countedInChunks = false;
+        if (session.open && Epl == 0 && Ept > 0) {
+            const int* const ecam = p->edge_cam; const int* const ept = p->edge_point; const uint8_t* const fixedp = p->cam_fixed;
+            cb.assign(kQ + 1, Ept);
+            for (int q = 0; q < kQ; q++) {      // chunk q = edges [cb[q], cb[q + 1]); boundaries moved forward to the end of a run of equal landmarks
+                int e = (int)((long long)Ept * q / kQ);
+                while (e > 0 && e < Ept && ept[e] == ept[e - 1]) e++;
+                cb[q] = std::min(e, Ept);
+            }
+            cb[0] = 0;
+            for (int q = 1; q <= kQ; q++) cb[q] = std::max(cb[q], cb[q - 1]);      // (monotone; an empty chunk is harmless)
+            chunkFree.assign(kQ, 0); chunkEnt.assign(kQ, 0); chunkBad.assign(2 * kQ, -1);
+            camCntQ.assign((size_t)kQ * nC, 0); camLastQ.assign((size_t)kQ * nC, -1);
+            {
+                int* const cfp = chunkFree.data(); long long* const cep = chunkEnt.data(); int* const ccq = camCntQ.data(); int* const clq = camLastQ.data();
+                const int* const cbp = cb.data(); int* const bad = chunkBad.data();
+                const int nC_ = nC, nPo_ = nPo;
+                host_crew().session_pass(kQ, [=](int q) {
+                    int* const cc = ccq + (size_t)q * nC_; int* const last = clq + (size_t)q * nC_;
+                    int freeN = 0; long long ent = 0;
+                    const int e1 = cbp[q + 1];
+                    int prev = cbp[q] > 0 ? ept[cbp[q] - 1] : -1;
+                    for (int e = cbp[q]; e < e1;) {
+                        const int lmk = ept[e];
+                        if (lmk <= prev || lmk >= nPo_) { bad[2 * q] = -2; return; }
+                        int m = 0, run = 0;
+                        for (; e < e1 && ept[e] == lmk; e++, run++) {
+                            const int ec = ecam[e];
+                            if ((unsigned)ec >= (unsigned)nC_) { bad[2 * q] = -2; return; }
+                            if (last[ec] == lmk && bad[2 * q] == -1) { bad[2 * q] = ec; bad[2 * q + 1] = lmk; }
+                            last[ec] = lmk;
+                            cc[ec]++;
+                            m += fixedp[ec] ? 0 : 1;
+                        }
+                        __atomic_store_n(&ptCnt[lmk], run, __ATOMIC_RELAXED);      // (a landmark out of order could be written by two chunks: the serial pass then starts over)
+                        freeN += m; ent += (long long)m * (m + 1) / 2;
+                        prev = lmk;
+                    }
+                    cfp[q] = freeN; cep[q] = ent;
+                });
+            }
+            countedInChunks = true;
+            for (int q = 0; q < kQ; q++) countedInChunks = countedInChunks && chunkBad[2 * q] != -2;
+            if (countedInChunks) {
+                for (int q = 0; q < kQ; q++)
+                    if (chunkBad[2 * q] >= 0) { eao::set_error("two edges join camera %d and point %d", chunkBad[2 * q], chunkBad[2 * q + 1]); return EAO_ERR_INVALID; }
+                for (int i = 0; i < nC; i++) {      // a camera's count; per chunk: where the chunk's edges go inside the camera's list
+                    int run = 0;
+                    for (int q = 0; q < kQ; q++) { const int c0 = camCntQ[(size_t)q * nC + i]; camCntQ[(size_t)q * nC + i] = run; run += c0; }
+                    camCnt[i] = run;
+                }
+            } else std::fill(cnt.begin(), cnt.end(), 0);
+        }
+        if (!countedInChunks) {
+            for (int e = 0, prev = 0; e < Ept; e++) {
+                const int ec = p->edge_cam[e], ep = p->edge_point[e];
+                EAO_REQUIRE(ec >= 0 && ec < nC && ep >= 0 && ep < nPo, "edge %d out of range", e);
+                edgesByLandmark = edgesByLandmark && ep >= prev; prev = ep;
+                camCnt[ec]++; ptCnt[ep]++;
+            }
+            for (int e = 0, prev = 0; e < Epl; e++) {
+                const int ec = pl->pedge_cam[e], ep = pl->pedge_plane[e];
+                EAO_REQUIRE(ec >= 0 && ec < nC && ep >= 0 && ep < nPl, "plane edge %d out of range", e);
+                edgesByLandmark = edgesByLandmark && ep >= prev; prev = ep;
+                camCnt[ec]++; ptCnt[nPo + ep]++;
+            }
+        }
         size_t lpEntries = 0, lpPairsMax = 0;
         // ---- round 5: the covisibility structure of the map-scale path, CAMERA-MAJOR.  For every free camera i1 (ascending) the landmarks it observes in ascending
         //      order, and for each of them its observers i2 >= i1: the pairs (i1, i2) of camera i1 are counted in a counter array of nF entries that stays in the
@@ -195,10 +351,9 @@ struct BAJob {
         static thread_local std::vector<int> fidx, lmOff, lmCam, lmEdge, cmOff, cmLm, cmU, prA, prB, prStart, cmPairStart, pcur;
         // workers for the two walks: the crew unless this thread is one of its own (a map-scale window inside a batch call), or the map is small
         auto crew_for = [&](size_t work, int nChunks, const std::function<void(int)>& chunk) {
+            if (session.open) { host_crew().session_pass(nChunks, chunk); return; }
             const int hw = (int)std::thread::hardware_concurrency();
-            const char* envS = getenv("EAO_BA_SETUP_THREADS");      // (read per call: the tests force the crew onto small maps; 1 = never)
-            const int envT = envS ? atoi(envS) : 0;
-            const int nT = t_inCrew || (work < 200000 && envT <= 0) ? 1 : std::max(1, std::min(envT > 0 ? envT : std::min(12, hw / 2), nChunks));
+            const int nT = t_inCrew || envSetupT == 1 || (work < 200000 && envSetupT <= 0) ? 1 : std::max(1, std::min(envSetupT > 0 ? envSetupT : std::min(12, hw / 2), nChunks));
             if (nT == 1) { for (int q = 0; q < nChunks; q++) chunk(q); return; }
             std::atomic<int> next(0);
             auto body = [&]() { for (int q; (q = next.fetch_add(1)) < nChunks;) chunk(q); };
@@ -218,47 +373,20 @@ struct BAJob {
             int nFa = 0;
             for (int i = 0; i < nC; i++) if (camCnt[i] && !p->cam_fixed[i]) fidx[i] = nFa++;      // (camCnt: the validation pass)
             // per landmark: its free observers and their edges, in edge order (the order of the active structure's ptEdges)
-            // ---- round 6: the observer lists and the camera lists in TWO PARALLEL PASSES over landmark ranges (the serial walks below took 2.3 of the 4.8 ms of host
+            // ---- round 6: the observer lists and the camera lists in PARALLEL PASSES over landmark ranges (the serial walks below took 2.3 of the 4.8 ms of host
             //      set-up in front of the 1000-keyframe map's 7.5 ms of device time).  With the edges listed landmark by landmark (what the adapters and every
             //      generator produce; no plane edges) a landmark's edges are contiguous, so a chunk of the edge list cut at landmark boundaries owns its landmarks:
-            //      pass 1 counts every landmark's free observers and the chunk's entries per camera; pass 2 writes the observer lists (sorted by camera) and files every
-            //      entry under its camera at the position the chunks before it left -- a camera's list comes out in ascending landmark order, the same arrays as the
-            //      serial walk, element for element (tests/test_gpu_lm.py::test_map_scale_set_up_on_the_host_crew).  1000-keyframe map: lists 2.25 -> 1.0 ms, the call 12.4 -> 11.6 ms.
-            const int envSetupT = getenv("EAO_BA_SETUP_THREADS") ? atoi(getenv("EAO_BA_SETUP_THREADS")) : 0;      // (1: the serial walks; n > 1: the parallel passes on any map -- the tests)
-            const bool parallelLists = edgesByLandmark && Epl == 0 && !t_inCrew && envSetupT != 1 && (Ept >= 200000 || envSetupT > 1);      // (a crew hand-over costs ~0.1 ms: at 100 000 edges the two passes gain nothing -- measured on the 200-keyframe map)
+            //      the validation pass above has counted every chunk's free observers, pair entries and edges per camera; the pass here writes the observer lists
+            //      (sorted by camera) and files every entry under its camera at the position the chunks before it left -- a camera's list comes out in ascending
+            //      landmark order, the same arrays as the serial walk, element for element (tests/test_gpu_lm.py::test_map_scale_set_up_on_the_host_crew), and the
+            //      camera's edge list of the active structure (camEdges) with it.
+            const bool parallelLists = countedInChunks;
             if (parallelLists) {
-                const int Q = 48;
-                static thread_local std::vector<int> cb, cl, chunkFree, camCntQ;
-                static thread_local std::vector<long long> chunkEnt;
-                cb.assign(Q + 1, Ept); cl.assign(Q + 1, nP);
+                const int Q = kQ;
                 const int* const ecam = p->edge_cam; const int* const ept = p->edge_point;
-                for (int q = 0; q < Q; q++) {      // chunk q = edges [cb[q], cb[q + 1]) = landmarks [cl[q], cl[q + 1]); boundaries moved forward to a landmark boundary
-                    int e = (int)((long long)Ept * q / Q);
-                    while (e > 0 && e < Ept && ept[e] == ept[e - 1]) e++;
-                    cb[q] = std::min(e, Ept);
-                    cl[q] = q == 0 ? 0 : (cb[q] < Ept ? ept[cb[q]] : nP);
-                }
-                for (int q = Q - 1; q > 0; q--) cb[q] = std::max(cb[q], cb[q - 1]);      // (monotone; an empty chunk is harmless)
-                cb[0] = 0; cl[0] = 0;
+                cl.assign(Q + 1, nP);
+                cl[0] = 0;
                 for (int q = 1; q < Q; q++) cl[q] = cb[q] < Ept ? ept[cb[q]] : nP;
-                chunkFree.assign(Q, 0); chunkEnt.assign(Q, 0); camCntQ.assign((size_t)Q * nFa, 0);
-                lmOff.assign((size_t)nP + 1, 0);
-                {
-                    const int* const fi = fidx.data(); int* const cfp = chunkFree.data(); long long* const cep = chunkEnt.data();
-                    int* const ccq = camCntQ.data(); const int* const cbp = cb.data();
-                    const int nFa_ = nFa;
-                    crew_for((size_t)Ept * 8, Q, [=](int q) {
-                        int* const cc = ccq + (size_t)q * nFa_;
-                        int freeN = 0; long long ent = 0;
-                        for (int e = cbp[q]; e < cbp[q + 1];) {
-                            const int lmk = ept[e];
-                            int m = 0;
-                            for (; e < cbp[q + 1] && ept[e] == lmk; e++) { const int f = fi[ecam[e]]; if (f >= 0) { m++; cc[f]++; } }
-                            freeN += m; ent += (long long)m * (m + 1) / 2;
-                        }
-                        cfp[q] = freeN; cep[q] = ent;
-                    });
-                }
                 // chunk bases; per camera the start of its list and, per chunk, where the chunk's entries go
                 static thread_local std::vector<int> chunkBase;
                 chunkBase.assign(Q + 1, 0);
@@ -268,20 +396,22 @@ struct BAJob {
                 const int total = chunkBase[Q];
                 lmCam.resize((size_t)total + 1); lmEdge.resize((size_t)total + 1);
                 cmOff.assign((size_t)nFa + 1, 0);
-                for (int f = 0; f < nFa; f++) {
-                    int run = 0;
-                    for (int q = 0; q < Q; q++) { const int c0 = camCntQ[(size_t)q * nFa + f]; camCntQ[(size_t)q * nFa + f] = run; run += c0; }      // counts become offsets inside the camera's list
-                    cmOff[f + 1] = cmOff[f] + run;
-                }
-                cmLm.resize(cmOff[nFa]); cmU.resize(cmOff[nFa]);
+                for (int i = 0; i < nC; i++) if (fidx[i] >= 0) cmOff[fidx[i] + 1] = camCnt[i];
+                for (int f = 0; f < nFa; f++) cmOff[f + 1] += cmOff[f];
+                cmLm.resize(cmOff[nFa]); cmU.resize(cmOff[nFa]); cmE.resize(cmOff[nFa]);
                 hs_lap(9);
                 {
                     int* const lmOffp = lmOff.data(); int* const lc = lmCam.data(); int* const le = lmEdge.data(); const int* const fi = fidx.data();
                     int* const ccq = camCntQ.data(); const int* const cbp = cb.data(); const int* const clp = cl.data(); const int* const basep = chunkBase.data();
-                    const int* const cmOffp = cmOff.data(); int* const cmLmp = cmLm.data(); int* const cmUp = cmU.data();
+                    const int* const cmOffp = cmOff.data(); int* const cmLmp = cmLm.data(); int* const cmUp = cmU.data(); int* const cmEp = cmE.data();
                     const int nFa_ = nFa;
+                    static thread_local std::vector<int> ccF;      // per chunk and free camera: where the chunk's entries go inside the camera's list (camCntQ, renumbered)
+                    ccF.resize((size_t)Q * nFa);
+                    for (int q = 0; q < Q; q++)
+                        for (int i = 0; i < nC; i++) if (fidx[i] >= 0) ccF[(size_t)q * nFa + fidx[i]] = ccq[(size_t)q * nC + i];
+                    int* const ccFp = ccF.data();
                     crew_for((size_t)Ept * 8, Q, [=](int q) {
-                        int* const cc = ccq + (size_t)q * nFa_;
+                        int* const cc = ccFp + (size_t)q * nFa_;
                         int at = basep[q], e = cbp[q];
                         const int lEnd = clp[q + 1];
                         for (int lmk = clp[q]; lmk < lEnd; lmk++) {
@@ -294,7 +424,7 @@ struct BAJob {
                                 for (; v > first && lc[v - 1] > cf; v--) { lc[v] = lc[v - 1]; le[v] = le[v - 1]; }
                                 lc[v] = cf; le[v] = ce;
                             }
-                            for (int u = first; u < at; u++) { const int f = lc[u], pos = cmOffp[f] + cc[f]++; cmLmp[pos] = lmk; cmUp[pos] = u; }
+                            for (int u = first; u < at; u++) { const int f = lc[u], pos = cmOffp[f] + cc[f]++; cmLmp[pos] = lmk; cmUp[pos] = u; cmEp[pos] = le[u]; }
                         }
                     });
                     lmOff[nP] = total;
@@ -362,7 +492,7 @@ struct BAJob {
             }
             hs_lap(5);
             // the pairs of every camera and their entry counts: chunks of cameras, each into lists of its own, joined in camera order
-            constexpr int kChunkCams = 16;
+            constexpr int kChunkCams = 4;
             const int nChunks = (nFa + kChunkCams - 1) / kChunkCams;
             static thread_local std::vector<std::vector<int>> chB, chCnt;
             chB.resize(nChunks); chCnt.resize(nChunks);
@@ -538,10 +668,23 @@ struct BAJob {
         auto hostp = [&](const void* dev) { return c.pin + ((const unsigned char*)dev - a.base); };
         size_t offSplit = off0;
         {
-            std::memcpy(hostp(dobs), p->edge_obs, (size_t)Ept * 12);
-            std::memcpy(hostp(dinfo), p->edge_inv_sigma2, (size_t)Ept * 4);
-            std::memcpy(hostp(decam), p->edge_cam, (size_t)Ept * 4);
-            std::memcpy(hostp(dept), p->edge_point, (size_t)Ept * 4);
+            unsigned char* const hf = (unsigned char*)hostp(dflag);      // edge flags: bit0 stereo, bit2 robust kernel present (bit1 = level 1 is only ever set on the device)
+            double* const hp = (double*)hostp(dpts);
+            {
+                unsigned char* const hobs = hostp(dobs); unsigned char* const hinfo = hostp(dinfo); unsigned char* const hecam = hostp(decam); unsigned char* const hept = hostp(dept);
+                const eao_ba_problem* const pp = p;
+                const int Ept_ = Ept, nPo_ = nPo; const unsigned char rb = robust ? 4 : 0;
+                const int nPack = session.open ? 16 : 1;
+                crew_for(0, nPack, [=](int q) {
+                    const size_t e0 = (size_t)Ept_ * q / nPack, e1 = (size_t)Ept_ * (q + 1) / nPack;
+                    std::memcpy(hobs + e0 * 12, pp->edge_obs + e0 * 3, (e1 - e0) * 12);
+                    std::memcpy(hinfo + e0 * 4, pp->edge_inv_sigma2 + e0, (e1 - e0) * 4);
+                    std::memcpy(hecam + e0 * 4, pp->edge_cam + e0, (e1 - e0) * 4);
+                    std::memcpy(hept + e0 * 4, pp->edge_point + e0, (e1 - e0) * 4);
+                    for (size_t e = e0; e < e1; e++) hf[e] = (unsigned char)((!(pp->edge_obs[3 * e + 2] < 0) ? 1 : 0) | rb);
+                    for (size_t i = (size_t)nPo_ * 3 * q / nPack, i1 = (size_t)nPo_ * 3 * (q + 1) / nPack; i < i1; i++) hp[i] = pp->points[i];
+                });
+            }
             if (hasPl) {
                 std::memset(hostp(dobs) + (size_t)Ept * 12, 0, (size_t)Epl * 12);
                 std::memset(hostp(dinfo) + (size_t)Ept * 4, 0, (size_t)Epl * 4);
@@ -553,12 +696,7 @@ struct BAJob {
             }
             SE3* hc = (SE3*)hostp(dcams);
             for (int i = 0; i < nC; i++) hc[i] = se3_from_Tcw_f32(p->cam_Tcw + 16 * i);
-            double* hp = (double*)hostp(dpts);
-            for (size_t i = 0; i < (size_t)nPo * 3; i++) hp[i] = p->points[i];
             for (size_t i = (size_t)nPo * 3; i < (size_t)nP * 3; i++) hp[i] = 0;
-            // edge flags: bit0 stereo, bit2 robust kernel present (bit1 = level 1 is only ever set on the device)
-            unsigned char* hf = (unsigned char*)hostp(dflag);
-            for (int e = 0; e < Ept; e++) hf[e] = (unsigned char)((!(p->edge_obs[3 * e + 2] < 0) ? 1 : 0) | (robust ? 4 : 0));
             for (int e = Ept; e < E; e++) hf[e] = 8 | 4;      // EdgePlane: always a Huber kernel (:246-248)
             std::memset(hostp(dctl), 0, 16 * sizeof(int));
             // The problem itself (observations, indices, initial state, flags) is on its way to the device while the host builds
@@ -581,7 +719,17 @@ struct BAJob {
             for (int i = 0; i < nL; i++) ptCnt[actPt[i]] = ptStart[i];         // counters become fill cursors
             for (int i = 0; i < nF; i++) camCnt[actCam[i]] = camStart[i];
             bool dupChecked = false;
-            if (edgesByLandmark) {      // (the landmarks' edge lists, concatenated in landmark order, ARE the edge list; the one-edge-per-pair test rides along)
+            if (countedInChunks && bigPath) {      // (sessions: the duplicate test rode along with the validation pass, a camera's edges came with its landmark list -- cmE)
+                EAO_REQUIRE((int)cmE.size() == camStart[nF], "internal: camera edge lists built for another set of free keyframes");
+                const int* const cmEp = cmE.data();
+                const int E_ = E, tot = camStart[nF];
+                crew_for((size_t)E, 16, [=](int q) {
+                    for (int e = (int)((long long)E_ * q / 16), e1 = (int)((long long)E_ * (q + 1) / 16); e < e1; e++) ptEdges[e] = e;
+                    const int k0 = (int)((long long)tot * q / 16), k1 = (int)((long long)tot * (q + 1) / 16);
+                    std::memcpy(camEdges + k0, cmEp + k0, (size_t)(k1 - k0) * sizeof(int));
+                });
+                dupChecked = true;
+            } else if (edgesByLandmark) {      // (the landmarks' edge lists, concatenated in landmark order, ARE the edge list; the one-edge-per-pair test rides along)
                 static thread_local std::vector<int> camLast;
                 camLast.assign((size_t)nC, -1);
                 for (int e = 0; e < E; e++) {
@@ -631,7 +779,7 @@ struct BAJob {
                 const size_t nEnt = (size_t)prStart[nz];
                 const auto f0 = std::chrono::steady_clock::now();
                 {
-                    constexpr int kChunkCams = 16;
+                    constexpr int kChunkCams = 4;
                     const int nChunks = (nF + kChunkCams - 1) / kChunkCams;
                     const int* const lmOffp = lmOff.data(); const int* const lmCamp = lmCam.data(); const int* const lmEdgep = lmEdge.data(); const int* const cmOffp = cmOff.data();
                     const int* const cmLmp = cmLm.data(); const int* const cmUp = cmU.data(); const int* const prBp = prB.data(); const int* const prStartp = prStart.data();
