@@ -37,6 +37,38 @@ __device__ __forceinline__ double* big_elem(const BADev& P, double* pool, int r,
 // of 42 values per pair -- 90 us for the 1 593 pairs of the 200-keyframe benchmark map, six rounds of workgroups).  A pair's entries are a latency chain -- landmark
 // index -> edge flags -> three blocks -- of ~4 us per 64 of them: a covisible pair shares tens to a few hundred landmarks, a DIAGONAL pair carries every landmark its
 // keyframe sees; the host lists the long pairs first (lpOrder) and they get their own launch.  42 sums per pair: DPP tree per wave, the waves' totals through LDS in wave order.
+// round 6: the ENTRIES of the pair lists, written on the device.  For pair (i1, i2) the landmarks both cameras observe, in ascending order, each with its edge in
+// either camera: the host used to file them pair by pair (0.4 - 1.0 ms of the set-up on its crew, then 4 - 17 MB over PCIe in front of the first launch); it now sends the
+// observer lists it builds anyway (per landmark the free observers sorted by camera, per camera its landmarks in ascending order: four ints per edge) and one wave per pair
+// walks camera i1's landmarks 64 at a time, looks for i2 behind i1's own entry in each landmark's list and places the hits by their rank in the ballot -- the order the
+// host's walk produced, entry for entry (the assembly sums a pair's landmarks in list order).
+__global__ __launch_bounds__(256) void k_bal_pair_fill(const BADev* __restrict__ W, int wpar) {
+    BA_WIN(P);
+    const int lane = threadIdx.x & 63;
+    const int pair = (int)bx * 4 + (threadIdx.x >> 6);
+    if (pair >= P.nPairsNZ) return;
+    const int i1 = P.lpPair[2 * pair], i2 = P.lpPair[2 * pair + 1];
+    int at = P.lpStart[pair];
+    const int k1 = P.cmOff[i1 + 1];
+    for (int kb = P.cmOff[i1]; kb < k1; kb += 64) {
+        const int k = kb + lane;
+        int found = -1, lmk = 0, u0 = 0;
+        if (k < k1) {
+            lmk = P.cmLm[k]; u0 = P.cmU[k];
+            for (int u = u0, ue = P.lmOff[lmk + 1]; u < ue; u++) {
+                const int cam = P.lmCam[u];
+                if (cam >= i2) { if (cam == i2) found = u; break; }
+            }
+        }
+        const unsigned long long hits = __ballot(found >= 0);
+        if (found >= 0) {
+            const int pos = at + __popcll(hits & ((1ull << lane) - 1ull));
+            P.lpPts[pos] = P.ptIdx[lmk]; P.lpE1[pos] = P.lmEdge[u0]; P.lpE2[pos] = P.lmEdge[found];
+        }
+        at += __popcll(hits);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_bal_schur_pairs(const BADev* __restrict__ W, int wpar, int first, int pairOff) {
     BA_WIN(P);
@@ -929,6 +961,9 @@ eao_status gba_attributes() {
 }
 
 // one LM trial of a map-scale window behind its linearisation: memset of the working tiles, pair assembly, the panel factorisation, back substitution
+void gba_enqueue_pair_fill(const BALaunch& L) {
+    if (L.d.nPairsNZ > 0) hipLaunchKernelGGL(k_bal_pair_fill, dim3(eao::cdiv(L.d.nPairsNZ, 4), 1, 1), dim3(256), 0, L.s, L.W, L.wp(0));
+}
 void gba_enqueue_trial(const BALaunch& L, int par, bool firstTrial) {
     const BADims& d = L.d;
     const BADev* W = L.W;

@@ -1487,6 +1487,7 @@ void BALaunch::setup() const {      // device-side part of the set-up (once per 
         hipLaunchKernelGGL(k_ba_pairs, dim3(d.nF * (d.nF + 1) / 2, 1, gz()), dim3(256), 0, s, W, wp(0));
         hipLaunchKernelGGL(k_ba_tiles_init, dim3(tile_geom(d.nF).nTiles, 1, gz()), dim3(256), 0, s, W, wp(0));
     }
+    if (d.bigPath) gba_enqueue_pair_fill(*this);
 }
 // one LM trial behind a linearisation: Schur assembly, solve, back substitution + residuals, (decision)
 void BALaunch::trial(int par, int bulk, bool firstTrial, bool withDecide) {

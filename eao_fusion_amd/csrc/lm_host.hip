@@ -556,7 +556,7 @@ struct BAJob {
         need += 128 * 256 + (size_t)nPl * 4 * 8 * 2 + (size_t)Epl * 4 * 8 + 2 * sizeof(BADev) + (size_t)nP + 1024;     // (+ k_ba_backsub's workgroup sums)
         if (bigPath) {
             need += (2 * ((size_t)bigTiles << 12) + 2 * (size_t)plan.N * kBigNB) * 8;
-            need += (3 * lpEntries + 5 * lpPairsMax + 72) * 4 + (plan.tileMap.size() + plan.rowOf.size() + plan.rowCam.size() + plan.diagList.size() + 8) * 4 + (plan.work.size() + plan.sb.size()) * sizeof(int4) + 4096;
+            need += (3 * lpEntries + 5 * lpPairsMax + 72 + 4 * (lmCam.size() + 2) + (size_t)nP + nC + 16) * 4 + (plan.tileMap.size() + plan.rowOf.size() + plan.rowCam.size() + plan.diagList.size() + 8) * 4 + (plan.work.size() + plan.sb.size()) * sizeof(int4) + 4096;
         } else {
             need += 2 * ((size_t)(nC * 6 + 6) * (nC * 6 + 34) + 8) * 8;
             need += (size_t)nC * (nC + 1) / 2 * ((size_t)nP + 64) * (4 + 16);   // landmark lists / item records of the camera pairs
@@ -587,9 +587,9 @@ struct BAJob {
         int* dlpStart = a.take<int>(bigPath ? lpPairsMax + 1 : 1);
         int* dlpPair = a.take<int>(bigPath ? 2 * lpPairsMax : 1);
         int* dlpOrder = a.take<int>(bigPath ? 2 * lpPairsMax + 64 : 1);
-        int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);
-        int* dlpE1 = a.take<int>(bigPath ? lpEntries : 1);
-        int* dlpE2 = a.take<int>(bigPath ? lpEntries : 1);
+        const size_t nObs = bigPath ? lmCam.size() : 1;      // (observer list entries + 1)
+        int* dlmOff = a.take<int>(bigPath ? (size_t)nP + 1 : 1); int* dlmCam = a.take<int>(nObs); int* dlmEdge = a.take<int>(nObs);
+        int* dcmOff = a.take<int>(bigPath ? cmOff.size() : 1); int* dcmLm = a.take<int>(nObs); int* dcmU = a.take<int>(nObs);
         int* dbigTile = a.take<int>(bigPath ? plan.tileMap.size() : 1);
         int4* dbigWork = a.take<int4>(bigPath ? std::max<size_t>(plan.work.size(), 1) : 1);
         int* dbigRow = a.take<int>(bigPath ? std::max<size_t>(plan.rowOf.size(), 1) : 1);
@@ -602,6 +602,9 @@ struct BAJob {
         const size_t off1 = (a.off + 255) & ~(size_t)255;
         // ---- device-only part
         int* dtable = bigPath ? nullptr : a.take<int>((size_t)nP * nC);      // (the map-scale path finds a landmark's edges in its pair lists)
+        int* dlpPts = a.take<int>(bigPath ? lpEntries : 1);                  // (filled by k_bal_pair_fill)
+        int* dlpE1 = a.take<int>(bigPath ? lpEntries : 1);
+        int* dlpE2 = a.take<int>(bigPath ? lpEntries : 1);
         D.slot = a.take<int4>((size_t)std::max(nP, 1) * 8);
         D.camEdgeL = a.take<int>(E);
         const bool pairPath = !bigPath && nFreeIn > 0 && nFreeIn <= kTileMaxFree;
@@ -632,6 +635,7 @@ struct BAJob {
         D.bigN = bigPath ? plan.N : 0; D.bigRow = dbigRow; D.bigRowCam = dbigRowCam; D.bigSB = dbigSB; D.bigDiagList = dbigDiagList;
         D.bigFail = a.take<int>(4);
         D.lpStart = dlpStart; D.lpPair = dlpPair; D.lpOrder = dlpOrder; D.lpPts = dlpPts; D.lpE1 = dlpE1; D.lpE2 = dlpE2;
+        D.lmOff = dlmOff; D.lmCam = dlmCam; D.lmEdge = dlmEdge; D.cmOff = dcmOff; D.cmLm = dcmLm; D.cmU = dcmU;
         D.xp = a.take<double>((size_t)nC * 6); D.xl = a.take<double>((size_t)nP * 3);
         D.partChi = a.take<double>(nP); D.partScale = a.take<double>(nP);
         D.lm0 = a.take<double>(16);
@@ -762,8 +766,7 @@ struct BAJob {
             if (bigPath && nF > 0) {
                 // covisibility CSR: for every camera pair (i1 <= i2) sharing a landmark, the landmark blocks in ascending order
                 // (counting sort over the landmarks' observer lists; the diagonal pairs carry each camera's own landmarks)
-                int* lpStart = (int*)hostp(dlpStart); int* lpPair = (int*)hostp(dlpPair); int* lpPts = (int*)hostp(dlpPts);
-                int* lpE1 = (int*)hostp(dlpE1); int* lpE2 = (int*)hostp(dlpE2);
+                int* lpStart = (int*)hostp(dlpStart); int* lpPair = (int*)hostp(dlpPair);
                 EAO_REQUIRE(plan.valid && plan.nFa == nF && plan.T == bigT, "internal: tile structure built for another system size");
                 std::memcpy(hostp(dbigTile), plan.tileMap.data(), plan.tileMap.size() * sizeof(int));
                 if (!plan.work.empty()) std::memcpy(hostp(dbigWork), plan.work.data(), plan.work.size() * sizeof(int4));
@@ -776,31 +779,21 @@ struct BAJob {
                 const int nz = (int)prA.size();
                 for (int k = 0; k < nz; k++) { lpPair[2 * k] = prA[k]; lpPair[2 * k + 1] = prB[k]; }
                 std::memcpy(lpStart, prStart.data(), ((size_t)nz + 1) * sizeof(int));
-                const size_t nEnt = (size_t)prStart[nz];
-                const auto f0 = std::chrono::steady_clock::now();
+                // the observer lists travel instead of the pairs' entries (k_bal_pair_fill writes those on the device: see there)
+                EAO_REQUIRE((int)lmOff.size() == nP + 1 && (int)cmOff.size() == nF + 1 && lmCam.size() == nObs && cmLm.size() + 1 == nObs, "internal: observer lists built for another problem");
                 {
-                    constexpr int kChunkCams = 4;
-                    const int nChunks = (nF + kChunkCams - 1) / kChunkCams;
-                    const int* const lmOffp = lmOff.data(); const int* const lmCamp = lmCam.data(); const int* const lmEdgep = lmEdge.data(); const int* const cmOffp = cmOff.data();
-                    const int* const cmLmp = cmLm.data(); const int* const cmUp = cmU.data(); const int* const prBp = prB.data(); const int* const prStartp = prStart.data();
-                    const int* const cmPairStartp = cmPairStart.data();
-                    crew_for(nEnt, nChunks, [=](int q) {
-                        static thread_local std::vector<int> cur;
-                        cur.resize((size_t)nF);
-                        for (int i1 = q * kChunkCams; i1 < std::min(nF, (q + 1) * kChunkCams); i1++) {
-                            for (int k = cmPairStartp[i1]; k < cmPairStartp[i1 + 1]; k++) cur[prBp[k]] = prStartp[k];      // fill cursors of camera i1's pairs
-                            for (int k = cmOffp[i1]; k < cmOffp[i1 + 1]; k++) {
-                                const int i = cmLmp[k], l = ptIdx[i], u0 = cmUp[k], e1 = lmEdgep[u0];
-                                for (int u = u0, ue = lmOffp[i + 1]; u < ue; u++) {
-                                    const int at = cur[lmCamp[u]]++;
-                                    lpPts[at] = l; lpE1[at] = e1; lpE2[at] = lmEdgep[u];
-                                }
-                            }
-                        }
+                    int* const hLmOff = (int*)hostp(dlmOff); int* const hLmCam = (int*)hostp(dlmCam); int* const hLmEdge = (int*)hostp(dlmEdge);
+                    int* const hCmOff = (int*)hostp(dcmOff); int* const hCmLm = (int*)hostp(dcmLm); int* const hCmU = (int*)hostp(dcmU);
+                    const int* const lmOffp = lmOff.data(); const int* const lmCamp = lmCam.data(); const int* const lmEdgep = lmEdge.data();
+                    const int* const cmOffp = cmOff.data(); const int* const cmLmp = cmLm.data(); const int* const cmUp = cmU.data();
+                    const size_t nO = nObs - 1, nPp = (size_t)nP + 1, nFp = (size_t)nF + 1;
+                    const int nCopy = session.open ? 12 : 1;
+                    crew_for(0, nCopy, [=](int q) {
+                        auto part = [&](int* dst, const int* src, size_t n) { const size_t i0 = n * q / nCopy, i1 = n * (q + 1) / nCopy; std::memcpy(dst + i0, src + i0, (i1 - i0) * sizeof(int)); };
+                        part(hLmOff, lmOffp, nPp); part(hLmCam, lmCamp, nO); part(hLmEdge, lmEdgep, nO);
+                        part(hCmOff, cmOffp, nFp); part(hCmLm, cmLmp, nO); part(hCmU, cmUp, nO);
                     });
                 }
-                if (hostStamps) fprintf(stderr, "[eao map-scale host set-up] pair CSR fill: %zu entries, %d pairs, %.3f ms\n", nEnt, nz,
-                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count());
                 D.nPairsNZ = nz;
                 nPairsLong = 0;
                 {   // launch order: long pairs first; and inside each class the pairs are dealt to the eight XCDs by camera range -- workgroup b runs on XCD b % 8, a pair

@@ -131,9 +131,15 @@ struct BADev {
     GP<const int> lpStart;     // nPairsNZ + 1
     GP<const int> lpPair;      // 2 * nPairsNZ: (i1, i2), i1 <= i2
     GP<const int> lpOrder;     // launch slots: the pairs with more than kBigPairLong entries first (four waves each), then the others (one wave each); -1 = idle slot
-    GP<const int> lpPts;       // landmark blocks of each pair, ascending
-    GP<const int> lpE1;        // ... and the landmark's edges in camera i1 / i2 (the dense point x camera table of the window path would be
-    GP<const int> lpE2;        //     nP x nC ints: 400 MB for a 1000-keyframe map)
+    GP<int> lpPts;             // landmark blocks of each pair, ascending
+    GP<int> lpE1;              // ... and the landmark's edges in camera i1 / i2 (the dense point x camera table of the window path would be
+    GP<int> lpE2;              //     nP x nC ints: 400 MB for a 1000-keyframe map).  Written by k_bal_pair_fill from the observer lists below
+    GP<const int> lmOff;       // nPts + 1: per landmark its FREE observers, sorted by free-camera block ...
+    GP<const int> lmCam;       // ... the block
+    GP<const int> lmEdge;      // ... the edge
+    GP<const int> cmOff;       // nFree + 1: per free camera its landmarks, ascending ...
+    GP<const int> cmLm;        // ... the landmark (point index)
+    GP<const int> cmU;         // ... the position of the camera's own entry in that landmark's observer list
     int nPairsNZ;
     // per-window addresses every kernel finds HERE (the kernels take an array of windows and blockIdx.z, see BA_WIN)
     GP<int> ctl0;              // the two control blocks (8 ints each); a launch runs on ctl0 + 8 * par
@@ -325,6 +331,7 @@ struct BALaunch {      // (member functions: lba.hip -- they launch its kernels;
 // gba.hip: the dynamic-LDS limit of its back substitution; assembly + factorisation + back substitution of one trial of a map-scale window (BALaunch::trial)
 eao_status gba_attributes();
 void gba_enqueue_trial(const BALaunch& L, int par, bool firstTrial);
+void gba_enqueue_pair_fill(const BALaunch& L);
 
 }  // namespace lm
 }  // namespace eao
