@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <list>
+#include <cstdint>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -183,32 +185,85 @@ template <class MP> void world_pos(MP* mp, float* xyz, std::false_type) {
 template <class KeyFrameT, class MapPointT>
 struct LbaScratch {
     struct Obs { KeyFrameT* kf; size_t idx; };
-    struct CamRec { KeyFrameT* kf; bool fixed; bool local; };
-    std::vector<KeyFrameT*> localKFs, fixedKFs;
+    struct CamRec { KeyFrameT* kf; bool fixed; bool local; int32_t slot; };
+    std::vector<KeyFrameT*> localKFs, fixedKFs, slotKF;
     std::vector<MapPointT*> localMPs;
     std::vector<Obs> obs;                 // all observations, point after point in localMPs order
+    std::vector<int32_t> obsSlot;         // ... and the slot of each observation's keyframe (-1: a bad keyframe)
     std::vector<int32_t> obsStart;        // localMPs.size() + 1
     std::vector<CamRec> cams;
-    std::vector<std::pair<unsigned long, int32_t> > order;
-    std::vector<int32_t> rank, eCam, ePt;
+    std::vector<std::pair<unsigned long, int32_t> > order, orderTmp;
+    std::vector<int32_t> rank, eCam, ePt, slotCam;
     std::vector<float> camT, xyz, eObs, eInv, camOut, xyzOut;
-    std::vector<uint8_t> camFixed, erase;
-    std::vector<KeyFrameT*> eKF;
-    std::vector<MapPointT*> eMP, pts;
+    std::vector<uint8_t> camFixed, camBad, erase;
+    std::vector<MapPointT*> pts;
+    // keyframe -> slot: the window holds a few dozen keyframes, every observation asks once.  Open addressing over a power of two, rebuilt per call.
+    std::vector<std::pair<KeyFrameT*, int32_t> > table;
+    size_t tableMask = 0, tableUsed = 0;
+    static size_t hash_of(const void* p) { return (size_t)(((uintptr_t)p >> 4) * (uintptr_t)0x9E3779B97F4A7C15ull >> 40); }
+    void table_reset(size_t cap) {
+        table.assign(cap, std::make_pair((KeyFrameT*)nullptr, (int32_t)0));
+        tableMask = cap - 1; tableUsed = 0;
+    }
+    std::pair<KeyFrameT*, int32_t>* table_find(KeyFrameT* kf) {      // the keyframe's entry, or the empty one it would take
+        size_t h = hash_of(kf) & tableMask;
+        while (table[h].first && table[h].first != kf) h = (h + 1) & tableMask;
+        return &table[h];
+    }
+    void table_insert(KeyFrameT* kf, int32_t slot) {
+        if (2 * (tableUsed + 1) > table.size()) {
+            std::vector<std::pair<KeyFrameT*, int32_t> > old;
+            old.swap(table);
+            table_reset(old.size() * 2);
+            for (size_t i = 0; i < old.size(); i++) if (old[i].first) { *table_find(old[i].first) = old[i]; tableUsed++; }
+        }
+        std::pair<KeyFrameT*, int32_t>* e = table_find(kf);
+        if (!e->first) tableUsed++;
+        e->first = kf; e->second = slot;
+    }
 };
+
+namespace detail {
+// order[i] = (id, k) sorted by id: least-significant-digit radix sort over the id RANGE of the window (map point ids of one window lie close together: two passes of
+// eleven bits; a comparison sort of 3000 pairs was a tenth of the adapter's walk)
+inline void sort_by_id(std::vector<std::pair<unsigned long, int32_t> >& v, std::vector<std::pair<unsigned long, int32_t> >& tmp) {
+    const size_t n = v.size();
+    if (n < 64) { std::sort(v.begin(), v.end()); return; }
+    unsigned long lo = v[0].first, hi = v[0].first;
+    for (size_t i = 1; i < n; i++) { lo = std::min(lo, v[i].first); hi = std::max(hi, v[i].first); }
+    tmp.resize(n);
+    size_t count[2048];
+    for (int shift = 0; shift < 64 && ((hi - lo) >> shift) != 0; shift += 11) {
+        std::memset(count, 0, sizeof(count));
+        for (size_t i = 0; i < n; i++) count[((v[i].first - lo) >> shift) & 2047]++;
+        size_t run = 0;
+        for (int d = 0; d < 2048; d++) { const size_t c = count[d]; count[d] = run; run += c; }
+        for (size_t i = 0; i < n; i++) tmp[count[((v[i].first - lo) >> shift) & 2047]++] = v[i];
+        v.swap(tmp);
+    }
+    // (equal ids cannot occur -- one MapPoint, one id; the sort is stable in k anyway)
+}
+}  // namespace detail
 
 template <class MapPointT, class KeyFrameT, class MapT>
 void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
-    static thread_local LbaScratch<KeyFrameT, MapPointT> S;
+    typedef LbaScratch<KeyFrameT, MapPointT> Scratch;
+    static thread_local Scratch S;
     const unsigned long me = pKF->mnId;
-    // the local window: this keyframe + its covisible ones; every map point they see; every other observer is fixed (src/Optimizer.cc:680-738)
-    S.localKFs.clear(); S.fixedKFs.clear(); S.localMPs.clear(); S.obs.clear(); S.obsStart.assign(1, 0);
+    // the local window: this keyframe + its covisible ones; every map point they see; every other observer is fixed (src/Optimizer.cc:680-738).
+    // Every keyframe the walk meets gets a SLOT (local ones first, fixed ones as their first observation turns up; -1 = bad): the observations carry the slot, and
+    // the edge pass below turns it into the camera index with one table look-up (it was a binary search over the window's cameras per edge).
+    S.localKFs.clear(); S.fixedKFs.clear(); S.slotKF.clear(); S.localMPs.clear(); S.obs.clear(); S.obsSlot.clear(); S.obsStart.assign(1, 0);
+    S.table_reset(256);
     S.localKFs.push_back(pKF);
     pKF->mnBALocalForKF = me;
+    S.table_insert(pKF, 0); S.slotKF.push_back(pKF);
     for (KeyFrameT* n : pKF->GetVectorCovisibleKeyFrames()) {
         n->mnBALocalForKF = me;
-        if (!n->isBad()) S.localKFs.push_back(n);
+        if (!n->isBad()) { S.localKFs.push_back(n); S.table_insert(n, (int32_t)S.slotKF.size()); S.slotKF.push_back(n); }
+        else S.table_insert(n, -1);
     }
+    const size_t nLocal = S.localKFs.size();
     for (KeyFrameT* kf : S.localKFs)
         for (MapPointT* mp : kf->GetMapPointMatches())
             if (mp && mp->mnBALocalForKF != me && !mp->isBad()) {      // (the mark first: isBad() takes two mutexes, and four of five visits find the point marked already)
@@ -216,76 +271,88 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
                 mp->mnBALocalForKF = me;
             }
     const size_t nP = S.localMPs.size();
+    // (the callback runs under the point's mutex: it looks the keyframe's slot up and appends -- a keyframe it has not met yet is entered after the accessor has returned,
+    //  because isBad() takes the keyframe's own mutex)
     struct Append {
-        std::vector<typename LbaScratch<KeyFrameT, MapPointT>::Obs>* obs;
-        void operator()(KeyFrameT* kf, size_t idx) { typename LbaScratch<KeyFrameT, MapPointT>::Obs o = {kf, idx}; obs->push_back(o); }
-    } append = {&S.obs};
+        Scratch* S;
+        bool unknown;
+        void operator()(KeyFrameT* kf, size_t idx) {
+            typename Scratch::Obs o = {kf, idx};
+            S->obs.push_back(o);
+            const std::pair<KeyFrameT*, int32_t>* e = S->table_find(kf);
+            S->obsSlot.push_back(e->first ? e->second : -2);
+            unknown = unknown || !e->first;
+        }
+    } append = {&S, false};
     for (MapPointT* mp : S.localMPs) {
         const size_t first = S.obs.size();
         detail::for_each_observation<KeyFrameT>(mp, append, detail::HasForEachObservation<MapPointT, KeyFrameT>());
-        for (size_t o = first; o < S.obs.size(); o++) {      // (outside the accessor: isBad() takes the keyframe's own mutex)
-            KeyFrameT* kf = S.obs[o].kf;
-            if (kf->mnBALocalForKF != me && kf->mnBAFixedForKF != me) {
+        if (append.unknown) {
+            append.unknown = false;
+            for (size_t o = first; o < S.obs.size(); o++) {
+                if (S.obsSlot[o] != -2) continue;
+                KeyFrameT* kf = S.obs[o].kf;
+                const std::pair<KeyFrameT*, int32_t>* e = S.table_find(kf);
+                if (e->first) { S.obsSlot[o] = e->second; continue; }      // (twice in one point's map: cannot happen, but costs nothing)
                 kf->mnBAFixedForKF = me;
-                if (!kf->isBad()) S.fixedKFs.push_back(kf);
+                int32_t slot = -1;
+                if (!kf->isBad()) { slot = (int32_t)S.slotKF.size(); S.slotKF.push_back(kf); S.fixedKFs.push_back(kf); }
+                S.table_insert(kf, slot);
+                S.obsSlot[o] = slot;
             }
         }
         S.obsStart.push_back((int32_t)S.obs.size());
     }
     // flatten: cameras / points in ascending mnId (= g2o's vertex order), edges in the reference's insertion order
     S.cams.clear();
-    for (KeyFrameT* kf : S.localKFs) S.cams.push_back({kf, kf->mnId == 0, true});
-    for (KeyFrameT* kf : S.fixedKFs) S.cams.push_back({kf, true, false});
-    std::sort(S.cams.begin(), S.cams.end(), [](const typename LbaScratch<KeyFrameT, MapPointT>::CamRec& a, const typename LbaScratch<KeyFrameT, MapPointT>::CamRec& b) { return a.kf->mnId < b.kf->mnId; });
+    for (size_t i = 0; i < S.slotKF.size(); i++) { typename Scratch::CamRec c = {S.slotKF[i], i >= nLocal || S.slotKF[i]->mnId == 0, i < nLocal, (int32_t)i}; S.cams.push_back(c); }
+    std::sort(S.cams.begin(), S.cams.end(), [](const typename Scratch::CamRec& a, const typename Scratch::CamRec& b) { return a.kf->mnId < b.kf->mnId; });
     const size_t nC = S.cams.size();
-    // camera index of a keyframe: the window holds a few dozen cameras -- a sorted array of (pointer, index) pairs, binary search
-    std::vector<std::pair<KeyFrameT*, int32_t> > camIndex(nC);      // (nC entries: a few hundred bytes)
-    for (size_t i = 0; i < nC; i++) camIndex[i] = std::make_pair(S.cams[i].kf, (int32_t)i);
-    std::sort(camIndex.begin(), camIndex.end());
-    auto cam_of = [&](KeyFrameT* kf) -> int32_t {
-        const auto it = std::lower_bound(camIndex.begin(), camIndex.end(), std::make_pair(kf, (int32_t)-1));
-        return (it != camIndex.end() && it->first == kf) ? it->second : -1;
-    };
+    S.slotCam.resize(nC);
+    for (size_t i = 0; i < nC; i++) S.slotCam[S.cams[i].slot] = (int32_t)i;
     // point index = rank of the point's mnId among the window's points
     S.order.resize(nP);
     for (size_t k = 0; k < nP; k++) S.order[k] = std::make_pair((unsigned long)S.localMPs[k]->mnId, (int32_t)k);
-    std::sort(S.order.begin(), S.order.end());
+    detail::sort_by_id(S.order, S.orderTmp);
     S.rank.resize(nP); S.pts.resize(nP);
     for (size_t i = 0; i < nP; i++) { S.rank[S.order[i].second] = (int32_t)i; S.pts[i] = S.localMPs[S.order[i].second]; }
 
-    S.camT.resize(nC * 16); S.camFixed.resize(nC); S.xyz.resize(nP * 3);
+    S.camT.resize(nC * 16); S.camFixed.resize(nC); S.camBad.resize(nC); S.xyz.resize(nP * 3);
+    const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy, bf = pKF->mbf;
     // isBad() of an observing keyframe (upstream asks it per EDGE, src/Optimizer.cc:843: 15 000 mutex round trips on this window) is asked once per CAMERA here
-    std::vector<uint8_t> camBad(nC);
     for (size_t i = 0; i < nC; i++) {
-        camBad[i] = S.cams[i].kf->isBad() ? 1 : 0;
-        const cv::Mat T = S.cams[i].kf->GetPose();
+        KeyFrameT* kf = S.cams[i].kf;
+        S.camBad[i] = kf->isBad() ? 1 : 0;
+        const cv::Mat T = kf->GetPose();
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) S.camT[i * 16 + r * 4 + c] = T.template at<float>(r, c);
         S.camFixed[i] = S.cams[i].fixed ? 1 : 0;
+        // upstream copies the intrinsics into every edge from ITS keyframe (e->fx = pKFi->fx ..., src/Optimizer.cc:858-898); the
+        // C-ABI carries one set per window, which is what this fork's single-camera Frame / KeyFrame statics amount to --
+        // a window that mixes cameras is refused here rather than optimised with the wrong projection
+        if (!S.camBad[i] && (kf->fx != fx || kf->fy != fy || kf->cx != cx || kf->cy != cy || kf->mbf != bf))
+            throw std::runtime_error("eaofusion::LocalBundleAdjustment: keyframes of the window do not share fx, fy, cx, cy, mbf");
     }
     for (size_t i = 0; i < nP; i++) detail::world_pos(S.pts[i], &S.xyz[i * 3], detail::HasWorldPosOut<MapPointT>());
-    const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy, bf = pKF->mbf;
-    S.eCam.clear(); S.ePt.clear(); S.eObs.clear(); S.eInv.clear(); S.eKF.clear(); S.eMP.clear();
+    const size_t nObs = S.obs.size();
+    S.eCam.resize(nObs); S.ePt.resize(nObs); S.eObs.resize(nObs * 3); S.eInv.resize(nObs);
+    size_t nE = 0;
     for (size_t k = 0; k < nP; k++) {
-        MapPointT* mp = S.localMPs[k];
+        const int32_t pt = S.rank[k];
         for (int32_t o = S.obsStart[k]; o < S.obsStart[k + 1]; o++) {
+            const int32_t slot = S.obsSlot[o];
+            if (slot < 0) continue;               // a bad keyframe (upstream: `continue`)
+            const int32_t ci = S.slotCam[slot];
+            if (S.camBad[ci]) continue;
             KeyFrameT* kf = S.obs[o].kf;
-            const int32_t ci = cam_of(kf);
-            if (ci < 0 || camBad[ci]) continue;   // a bad keyframe (upstream: `continue`); one outside the window: upstream would dereference a null vertex here
-            // upstream copies the intrinsics into every edge from ITS keyframe (e->fx = pKFi->fx ..., src/Optimizer.cc:858-898); the
-            // C-ABI carries one set per window, which is what this fork's single-camera Frame / KeyFrame statics amount to --
-            // a window that mixes cameras is refused here rather than optimised with the wrong projection
-            if (kf->fx != fx || kf->fy != fy || kf->cx != cx || kf->cy != cy || kf->mbf != bf)
-                throw std::runtime_error("eaofusion::LocalBundleAdjustment: keyframes of the window do not share fx, fy, cx, cy, mbf");
             const size_t idx = S.obs[o].idx;
             const cv::KeyPoint& kpUn = kf->mvKeysUn[idx];
-            S.eCam.push_back(ci); S.ePt.push_back(S.rank[k]);
-            S.eObs.push_back(kpUn.pt.x); S.eObs.push_back(kpUn.pt.y); S.eObs.push_back(kf->mvuRight[idx]);
-            S.eInv.push_back(kf->mvInvLevelSigma2[kpUn.octave]);
-            S.eKF.push_back(kf); S.eMP.push_back(mp);
+            S.eCam[nE] = ci; S.ePt[nE] = pt;
+            S.eObs[3 * nE] = kpUn.pt.x; S.eObs[3 * nE + 1] = kpUn.pt.y; S.eObs[3 * nE + 2] = kf->mvuRight[idx];
+            S.eInv[nE] = kf->mvInvLevelSigma2[kpUn.octave];
+            nE++;
         }
     }
     if (pbStopFlag && *pbStopFlag) return;
-    const size_t nE = S.eCam.size();
     eao_ba_problem P;
     P.n_cams = (int)nC; P.n_points = (int)nP; P.n_edges = (int)nE;
     P.cam_Tcw = S.camT.data(); P.cam_fixed = S.camFixed.data(); P.points = S.xyz.data();
@@ -300,9 +367,12 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
 
     std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
     for (size_t e = 0; e < nE; e++) {
-        if (!S.erase[e] || S.eMP[e]->isBad()) continue;
-        S.eKF[e]->EraseMapPointMatch(S.eMP[e]);
-        S.eMP[e]->EraseObservation(S.eKF[e]);
+        if (!S.erase[e]) continue;
+        MapPointT* mp = S.pts[S.ePt[e]];
+        if (mp->isBad()) continue;
+        KeyFrameT* kf = S.cams[S.eCam[e]].kf;
+        kf->EraseMapPointMatch(mp);
+        mp->EraseObservation(kf);
     }
     cv::Mat pose(4, 4, CV_32F), pos(3, 1, CV_32F);      // (SetPose / SetWorldPos copy their argument, src/KeyFrame.cc:74-86, src/MapPoint.cc:68-73)
     for (size_t i = 0; i < nC; i++) {

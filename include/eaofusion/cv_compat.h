@@ -71,7 +71,10 @@ public:
         for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * elemSize());
         return m;
     }
-    void copyTo(Mat& dst) const { dst = clone(); }
+    void copyTo(Mat& dst) const {      // (OpenCV: dst.create(size, type) keeps a buffer of the right shape, then the rows are copied)
+        if (dst.data == nullptr || dst.rows != rows || dst.cols != cols || dst.type_ != type_ || dst.data == data) { if (dst.data != data || dst.data == nullptr) dst = clone(); return; }
+        for (int y = 0; y < rows; y++) std::memcpy(dst.data + (size_t)y * dst.step, data + (size_t)y * step, (size_t)cols * elemSize());
+    }
     static Mat zeros(int r, int c, int type) { Mat m(r, c, type); std::memset(m.data, 0, (size_t)r * m.step); return m; }
     static Mat eye(int r, int c, int type) {
         Mat m = zeros(r, c, type);
