@@ -1740,6 +1740,8 @@ struct eao_orb {
     eao::DevBuf<eao_keypoint> d_kps;
     unsigned char* pinOut = nullptr;       // mapped pinned host memory: results of small host-API calls land here directly
     size_t pinOutCap = 0;
+    unsigned char* pinUp = nullptr;        // pinned staging of small host-API uploads (upload_frames)
+    size_t pinUpCap = 0;
     eao::DevBuf<uint8_t> d_desc;
     eao::DevBuf<float> d_xyr;
     eao::DevBuf<unsigned char> d_stereo;   // staging of eao_compute_stereo_matches
@@ -2458,6 +2460,39 @@ eao_status enqueue_pyramid_export(eao_orb* h, int frame, int border) {
     return EAO_OK;
 }
 
+// The caller's frames (pageable memory) to h->d_in in the device pitch.  Small uploads -- the per-frame calls -- go through a pinned staging buffer of the handle: the
+// runtime's own path for pageable memory registers the caller's pages with the driver for the duration of the copy, and a registered range that the kernel touches
+// meanwhile (another thread's munmap, page migration) has the driver take every queue of the process off the GPU for a millisecond or more -- one tracked frame in a
+// thousand took 6 - 12 ms beside a looping LocalBundleAdjustment.  The staging copy costs ~15 us per 640 x 480 frame.  EAO_ORB_PINNED_IN=0: the runtime's path (A/B runs).
+constexpr size_t kPinnedInMax = 8u << 20;
+eao_status upload_frames(eao_orb* h, const uint8_t* img, int width, int height, int stride, long long frame_stride, int batch) {
+    const Geom& g = h->geom;
+    const long long fs0 = (long long)g.L[0].pitch * height;
+    const size_t bytes = (size_t)batch * (size_t)fs0;
+    static const bool envNoPinned = getenv("EAO_ORB_PINNED_IN") && !atoi(getenv("EAO_ORB_PINNED_IN"));
+    if (bytes <= kPinnedInMax && !envNoPinned) {
+        if (h->pinUpCap < bytes) {
+            if (h->pinUp) (void)hipHostFree(h->pinUp);
+            h->pinUp = nullptr; h->pinUpCap = 0;
+            EAO_HIP(hipHostMalloc((void**)&h->pinUp, bytes, hipHostMallocDefault));
+            h->pinUpCap = bytes;
+        }
+        if (stride == g.L[0].pitch && (batch == 1 || frame_stride == fs0)) std::memcpy(h->pinUp, img, bytes);
+        else
+            for (int f = 0; f < batch; f++)
+                for (int y = 0; y < height; y++) std::memcpy(h->pinUp + f * fs0 + (size_t)y * g.L[0].pitch, img + (long long)f * frame_stride + (size_t)y * stride, (size_t)width);
+        EAO_HIP(hipMemcpyAsync(h->d_in.p, h->pinUp, bytes, hipMemcpyHostToDevice, h->stream));
+        return EAO_OK;
+    }
+    if (stride == g.L[0].pitch && (batch == 1 || frame_stride == fs0)) {     // contiguous frames: one linear copy
+        EAO_HIP(hipMemcpyAsync(h->d_in.p, img, bytes, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int f = 0; f < batch; f++)
+            EAO_HIP(hipMemcpy2DAsync(h->d_in.p + f * fs0, g.L[0].pitch, img + (long long)f * frame_stride, stride, width, height, hipMemcpyHostToDevice, h->stream));
+    }
+    return EAO_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2523,6 +2558,7 @@ void eao_orb_destroy(eao_orb* h) {
         if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
     }
     if (h->pinOut) (void)hipHostFree(h->pinOut);
+    if (h->pinUp) (void)hipHostFree(h->pinUp);
     if (h->pinPyr) (void)hipHostFree(h->pinPyr);
     stream_release(h);
     if (h->evStart) (void)hipEventDestroy(h->evStart);
@@ -2588,13 +2624,7 @@ eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, 
     if ((st = h->d_desc.reserve(B * (size_t)cap * 32))) return st;
     if ((st = h->d_nout.reserve(B))) return st;
     const long long fs0 = (long long)g.L[0].pitch * height;
-    if (stride == g.L[0].pitch && (batch == 1 || frame_stride == fs0)) {     // contiguous frames: one linear copy
-        EAO_HIP(hipMemcpyAsync(h->d_in.p, img, B * (size_t)fs0, hipMemcpyHostToDevice, h->stream));
-    } else {
-        for (int f = 0; f < batch; f++)
-            EAO_HIP(hipMemcpy2DAsync(h->d_in.p + f * fs0, g.L[0].pitch, img + (long long)f * frame_stride, stride, width, height,
-                                     hipMemcpyHostToDevice, h->stream));
-    }
+    if ((st = upload_frames(h, img, width, height, stride, frame_stride, batch))) return st;
     // Small calls (the per-frame latency path): the last kernel writes keypoints, descriptors and counts straight into mapped
     // pinned host memory -- ~70 KB per frame over PCIe -- and the rows that exist are copied to the caller's (pageable) arrays
     // after the one synchronisation: three pageable device-to-host copies (~15 us each) gone.  Large batches keep the DMA path.
@@ -2790,8 +2820,7 @@ eao_status eao_orb_extract_ref(eao_orb* h, const uint8_t* img, int32_t width, in
     EAO_HIP(hipHostGetDevicePointer((void**)&dv, h->pinOut, 0));
     if ((st = h->d_in.reserve((size_t)g.L[0].pitch * height))) return st;
     const long long fs0 = (long long)g.L[0].pitch * height;
-    if (stride == g.L[0].pitch) EAO_HIP(hipMemcpyAsync(h->d_in.p, img, (size_t)fs0, hipMemcpyHostToDevice, h->stream));
-    else EAO_HIP(hipMemcpy2DAsync(h->d_in.p, g.L[0].pitch, img, stride, width, height, hipMemcpyHostToDevice, h->stream));
+    if ((st = upload_frames(h, img, width, height, stride, 0, 1))) return st;
     st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, 1, (eao_keypoint*)(dv + offK), dv + offD, cap, (int*)dv, h->stream);
     if (st) return st;
     if (h->autoPyrBorder >= 0 && (st = enqueue_pyramid_export(h, 0, h->autoPyrBorder))) return st;      // same stream, same synchronisation
