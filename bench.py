@@ -52,6 +52,9 @@ def _source_sha(rel):
 LM_SOURCES = ("eao_fusion_amd/csrc/lm_internal.h", "eao_fusion_amd/csrc/lba.hip", "eao_fusion_amd/csrc/gba.hip")      # (round 6: csrc/lm.hip split; the KERNEL sources -- lm_host.hip is host code + the PCIe copy kernel)
 
 
+ORB_SOURCES = ("eao_fusion_amd/csrc/orb.hip", "eao_fusion_amd/csrc/orb_internal.h")      # (round 6: csrc/orb.hip split; the pyramid / FAST / blur / description kernels and the records they read)
+
+
 def _fresh(pmc, rel):
     """True when the committed counter file names the hash of today's kernel source (files older than round 4 carry none: stale by definition here)."""
     return bool(pmc) and pmc.get("source_sha16", {}).get(rel) == _source_sha(rel)
@@ -234,7 +237,7 @@ def main():
     try:
         pmc_file = _profile("pmc_traffic.json")
         pmc = json.load(open(pmc_file))
-        if pmc.get("batch") == B and dom in pmc["kernels"] and _fresh(pmc, "eao_fusion_amd/csrc/orb.hip"):
+        if pmc.get("batch") == B and dom in pmc["kernels"] and all(_fresh(pmc, rel) for rel in ORB_SOURCES):
             k = pmc["kernels"][dom]
             traffic = int(2 * k["fetch_bytes_per_step"] + k["write_bytes_per_step"])   # all launches of the stage in one step
             traffic_note = "from the committed PMC passes (%s): 2 x FETCH_SIZE + WRITE_SIZE per step" % os.path.relpath(pmc_file, ROOT)
@@ -246,7 +249,7 @@ def main():
     try:
         sq = json.load(open(sq_file))
         kname = {"pyramid": "k_resize", "fast": "k_fast_cells", "quadtree": "k_quadtree", "blur": "k_blur7", "orient_describe": "k_orient_describe"}
-        if sq.get("batch") == B and _fresh(sq, "eao_fusion_amd/csrc/orb.hip"):
+        if sq.get("batch") == B and all(_fresh(sq, rel) for rel in ORB_SOURCES):
             for st_, kn in kname.items():
                 if kn in sq["kernels"] and stage_ms.get(st_, 0) > 0:
                     insts = sq["kernels"][kn]["SQ_INSTS_VALU"] * sq["kernels"][kn].get("launches_per_step", 1)

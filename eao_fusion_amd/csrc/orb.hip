@@ -20,80 +20,15 @@
 //
 // Float semantics: this file is compiled with -ffp-contract=off (see Makefile): the reference's float
 // expressions are rounded op by op.
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <vector>
+#include "orb_internal.h"
 
-#include "common.h"
+using namespace eao::orb;
 
 namespace {
-
-constexpr int kMaxLevels = 16;
-constexpr int kEdge = refc::EDGE_THRESHOLD;
-constexpr int kMinBorder = kEdge - 3;  // 16
-constexpr int kTile = 72;              // max FAST sub-image edge (cell <= 60 px + 6)
-// (tested region of a cell = sub-image minus the 3 px FAST margin on every side: at most 66 x 66)
-constexpr int kTileStrideWide = 80;    // LDS row stride of the widest tile: 72 + up to 3 bytes of alignment phase, multiple of 4
-constexpr int kMaxIni = 16;
-constexpr size_t kPinnedOutMax = 1 << 20;   // host-API calls whose results fit go through mapped pinned memory (eao_orb_extract_batch)
-constexpr int kFastXcdRun = 0;         // 0 = plain workgroup -> cell order (see k_fast_cells)
 
 __constant__ __align__(16) signed char c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
-
-struct LevelGeom {
-    int w, h, pitch, off;      // level image; off = byte offset inside one frame's pyramid block
-    int cellBase, nCells;      // FAST cells of this level inside the per-frame cell table
-    int quota;                 // mnFeaturesPerLevel
-    int nIni, boxH;            // initial quad-tree nodes; maxBorderY - minBorderY
-    float hX;
-    int listCap;               // node-list / keypoint capacity of this level
-    int kpBase;                // first keypoint slot of this level inside a frame
-    int candBase, candCap;     // candidate scratch of this level inside a frame
-    int tileBase, tilesX;      // blur: first workgroup of this level, 128-px strips per row of strips
-    long long nodeOff;         // k_quadtree, global node lists: byte offset of this level inside a frame's workspace
-    int scaledPatch;
-    float scale;
-};
-
-struct Geom {
-    int nlevels, W, H;
-    int totalCells, cellCap;
-    int totalKpCap, totalCandCap, totalTiles;
-    int pyrFrameBytes;
-    int iniTh, minTh;
-    int scanCap;               // LDS scan workspace entries for k_quadtree
-    int qtLdsCand, qtKeysOff;  // k_quadtree: candidates (key + node index) that fit in LDS, byte offset of the keys
-    int qtNodesGlobal;         // the node lists do not fit in LDS (thousands of features on one level): global workspace instead
-    long long qtNodeFrameBytes;
-    int fastMaxTested, fastTileBytes, fastLdsBytes, fastStride;   // k_fast_cells dynamic LDS carve-up
-    int umax[16];
-    LevelGeom L[kMaxLevels];
-};
-
-struct CellDesc {
-    short level, x0, y0, sw, sh, offX, offY, pad;
-};
-
-struct ImgSrc {  // level-0 source (caller's frames) + internal pyramid
-    const uint8_t* img0;
-    int pitch0;
-    long long fs0;
-    uint8_t* pyr;
-};
-
-__device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const ImgSrc& s, int l, int f, int* pitch) {
-    if (l == 0) {
-        *pitch = s.pitch0;
-        return s.img0 + (long long)f * s.fs0;
-    }
-    *pitch = g->L[l].pitch;
-    return s.pyr + (long long)f * g->pyrFrameBytes + g->L[l].off;
-}
 
 // ---------------------------------------------------------------------------------------------- resize
 // Source bytes S[sx], S[sx+1] of the four output pixels of a lane all lie inside three aligned words of the source
@@ -136,20 +71,6 @@ __device__ __forceinline__ void resize_coef(int d, double inv, int slimit, bool 
     *wpair = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
 }
 
-// the same on the host (k_pyramid_fused reads tables built with it): lrintf rounds to nearest even like v_cvt_i32_f32
-inline void resize_coef_host(int d, double inv, int slimit, bool clampHi, int* ofs, unsigned* wpair) {
-    float fr = (float)(((double)d + 0.5) * inv - 0.5);
-    int o = (int)std::floor(fr);
-    fr -= (float)o;
-    if (clampHi) {
-        if (o < 0) { fr = 0; o = 0; }
-        if (o >= slimit - 1) { fr = 0; o = slimit - 1; }
-    }
-    const int w0 = std::min(std::max((int)std::lrintf((1.f - fr) * 2048.f), -32768), 32767);
-    const int w1 = std::min(std::max((int)std::lrintf(fr * 2048.f), -32768), 32767);
-    *ofs = o;
-    *wpair = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
-}
 
 // one work item of a level: kResizeRows output rows x 4 output pixels of frame f
 __device__ __forceinline__ void resize_item(const ResizeArgs& A, const ImgSrc& s, int f, int item) {
@@ -255,32 +176,6 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, ImgSrc s, int f0) 
 // tile every level exactly), plus the one-pixel right / bottom fringe the next level's interpolation reaches into, which it
 // recomputes instead of waiting for its neighbour.  The tiles of all levels live in LDS; only owned pixels go to HBM.
 // Same arithmetic as k_resize, pixel by pixel (OpenCV's 11-bit fixed point; the coefficients come from resize_coef).
-constexpr int kPyrTW = 128, kPyrTH = 32;      // the level-1 tile of a workgroup
-constexpr int kPyrThreads = 256;
-struct PyrLevel { int w, h, pitch, off; double invX, invY; int ldsOff, ldsW, ldsH; int coefXOff, coefYOff; };   // ldsW x ldsH: capacity of the level's tile
-struct PyrArgs {
-    int nlevels, tilesX, tilesY, pyrFrameBytes;
-    int coefOff;                      // LDS offset of the coefficient tables (xofs, xw, yofs, yw: 4 x coefCap ints)
-    int coefCap;
-    PyrLevel L[kMaxLevels];           // L[0]: the input image (ldsOff / ldsW / ldsH: its staged source region)
-    const int4* ranges;               // [level][tilesX + tilesY]: (own0, own1, req0, req1) of a tile column / tile row (device)
-    const int2* coefX;                // per level: (source offset, weight pair) of every column / row (device)
-    const int2* coefY;
-};
-// first destination index whose clamped source offset is >= bound (destinations 0 .. dn): the ownership boundary
-__host__ __device__ inline int pyr_src_ofs(int d, double inv, int sn) {
-    float fr = (float)(((double)d + 0.5) * inv - 0.5);
-    int o = (int)floorf(fr);
-    return o < 0 ? 0 : (o > sn - 1 ? sn - 1 : o);
-}
-__host__ __device__ inline int pyr_first_at_least(int bound, double inv, int sn, int dn) {
-    if (bound <= 0) return 0;
-    int d = (int)((double)bound / inv);          // estimate, then walk (the offset function is monotone)
-    d = d < 0 ? 0 : (d > dn ? dn : d);
-    while (d > 0 && pyr_src_ofs(d - 1, inv, sn) >= bound) d--;
-    while (d < dn && pyr_src_ofs(d, inv, sn) < bound) d++;
-    return d;
-}
 struct PyrRange { int x0, x1, y0, y1; };        // [x0, x1) x [y0, y1)
 __global__ __launch_bounds__(kPyrThreads) void k_pyramid_fused(PyrArgs A, ImgSrc s, int f0) {
     extern __shared__ __align__(16) unsigned char psm[];
@@ -738,444 +633,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Geom* __restrict__ g, c
 #undef QDIV
 }
 
-// ---------------------------------------------------------------------------------------------- quad-tree
-// Threads per quad-tree workgroup: a template parameter.  The candidate sweeps scale with it, the block scans and barriers get
-// dearer: 1024 threads are faster while the launch is latency-bound (one frame: device step 0.124 -> 0.105 ms, eight frames 0.143 ->
-// 0.129), 256 when many workgroups compete for the CUs (64 frames: 0.323 vs 0.339 ms).
-constexpr int kQTSmall = 1024, kQTLarge = 256;
-// In-place exclusive scan of a[0..n) by the whole kQT-thread block; returns the total.  Caller guarantees a[]
-// is fully written and visible (barrier) before the call; the function ends with a barrier.
-constexpr int kQtNodeInts = 2 + 2 + 2 + 4 + 4 + 5;   // per list entry next to its two boxes: cnt, crk, mid (x2 each), childcnt, childpos (x4), five work arrays
-template <int kQT>
-__device__ int block_excl_scan(int* a, int n, int* wtmp) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int per = (n + kQT - 1) / kQT;
-    const int b = min(t * per, n), e = min(b + per, n);
-    int ssum = 0;
-    for (int i = b; i < e; i++) ssum += a[i];
-    // inclusive scan over the wave on the VALU (DPP row shifts inside the rows of 16, then the row broadcasts 15 / 31) instead
-    // of six ds_bpermute round trips: the quad-tree calls this scan some thirty times per level, each on its critical path
-    int v = ssum;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2 and 3
-    __syncthreads();  // protect wtmp from the previous call's readers
-    if (lane == 63) wtmp[wv] = v;
-    __syncthreads();
-    int woff = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kQT / 64; w++) {
-        const int x = wtmp[w];
-        if (w < wv) woff += x;
-        total += x;
-    }
-    int run = woff + v - ssum;
-    for (int i = b; i < e; i++) {
-        const int x = a[i];
-        a[i] = run;
-        run += x;
-    }
-    __syncthreads();
-    return total;
-}
-
-// The same exclusive scan by ONE wave, in place, without a workgroup barrier (the caller fences at wavefront scope).
-__device__ __forceinline__ int wave_excl_scan(int* a, int n, int lane) {
-    const int per = (n + 63) >> 6;
-    const int b = min(lane * per, n), e = min(b + per, n);
-    int ssum = 0;
-    for (int i = b; i < e; i++) ssum += a[i];
-    int v = ssum;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2 and 3
-    const int total = __builtin_amdgcn_readlane(v, 63);
-    int run = v - ssum;
-    for (int i = b; i < e; i++) {
-        const int x = a[i];
-        a[i] = run;
-        run += x;
-    }
-    eao::wave_sync();
-    return total;
-}
-
-constexpr unsigned kQtLeaf = 0xFFFFFFFFu;          // mid of an entry that holds one key (every key then maps to quadrant 0)
-__device__ __forceinline__ unsigned box_mid(short4 bx) {
-    return (unsigned)(bx.x + ((bx.z - bx.x + 1) >> 1)) | ((unsigned)(bx.y + ((bx.w - bx.y + 1) >> 1)) << 16);
-}
-__device__ __forceinline__ int quadrant_mid(unsigned key, unsigned mid) {
-    const unsigned x = key & 0xFFF, y = (key >> 12) & 0xFFF;
-    return (x < (mid & 0xFFFFu) ? 0 : 1) + (y < (mid >> 16) ? 0 : 2);
-}
-__device__ __forceinline__ int quadrant(unsigned key, short4 bx) {
-    const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
-    const int mx = bx.x + ((bx.z - bx.x + 1) >> 1);   // UL.x + ceil((UR.x-UL.x)/2)
-    const int my = bx.y + ((bx.w - bx.y + 1) >> 1);
-    return (x < mx ? 0 : 1) + (y < my ? 0 : 2);
-}
-
-// One workgroup per (level, frame).  List entries are (box, count, creation rank); `nodeof[k]` is the list
-// position of candidate k's node.  Every pass (a) histograms children of all multi-key nodes, (b) picks the set
-// of nodes that upstream would split in this pass and their processing order, (c) lays out the new list exactly
-// as upstream's push_front/erase sequence would leave it.
-struct QtArgs {
-    const Geom* g; const unsigned* cellcand; const int* cellcnt; unsigned* levelkps; int* levelcnt; int f, l, M;
-    long long* dbg;
-    unsigned* candOut;   // global copy of the gathered candidates (read back by eao_orb_level_candidates)
-};
-
-// The candidate keys and their node index live in LDS when the level's M candidates fit the launch's LDS budget
-// (g->qtLdsCand; always at the default 1000-feature settings), else in the global scratch arrays: the body is inlined
-// once per placement.
-template <int kQT, class KeyPtr, class NofPtr>
-__device__ __forceinline__ void quadtree_body(const QtArgs& A, unsigned char* smem, int* wtmp, int* shv, KeyPtr keys, NofPtr nof) {
-    const Geom* __restrict__ g = A.g;
-    int& sh_S = shv[0]; int& sh_phase = shv[1]; int& sh_done = shv[2]; int& sh_rstar = shv[3]; int& sh_nexp = shv[4];
-    long long* dbg = A.dbg;
-    // (phase stamps of diagnostic runs, thread 0 only, kept in LDS: as per-thread registers they cost 22 VGPRs of a kernel that
-    //  spills at 1024 threads)
-    __shared__ long long dacc[11];
-    if (dbg && threadIdx.x == 0) { for (int i = 0; i < 10; i++) dacc[i] = 0; dacc[10] = clock64(); }
-#define QSTAMP(i) do { if (dbg && threadIdx.x == 0) { const long long now_ = clock64(); dacc[i] += now_ - dacc[10]; dacc[10] = now_; } } while (0)
-    const int t = threadIdx.x, lane = t & 63;
-    const int l = A.l, f = A.f, M = A.M;
-    const LevelGeom L = g->L[l];
-    const int LC = L.listCap, N = L.quota;
-    // ---- LDS carve-up
-    short4* box0 = reinterpret_cast<short4*>(smem);
-    short4* box1 = box0 + LC;
-    int* cnt0 = reinterpret_cast<int*>(box1 + LC);
-    int* cnt1 = cnt0 + LC;
-    int* crk0 = cnt1 + LC;
-    int* crk1 = crk0 + LC;
-    unsigned* mid0 = reinterpret_cast<unsigned*>(crk1 + LC);   // split point of a multi-key entry (mx | my << 16), kQtLeaf otherwise
-    unsigned* mid1 = mid0 + LC;
-    int* childcnt = reinterpret_cast<int*>(mid1 + LC);          // 4 per entry
-    int* childpos = childcnt + 4 * LC;  // 4 per entry
-    unsigned long long* rkey = reinterpret_cast<unsigned long long*>(childpos);   // sort keys of a careful pass (before childpos is filled)
-    int* newpos = childpos + 4 * LC;
-    int* order = newpos + LC;
-    int* vlist = order + LC;
-    int* procRank = vlist + LC;
-    int* scanB = procRank + LC;
-    int* scanA = scanB + LC;            // g->scanCap entries (>= LC and >= nCells); holds the exclusive cell prefix on entry
-
-    // ---- gather this level's candidates in upstream order: cells row-major, corners row-major inside a cell.  One
-    // thread per cell, sixteen independent loads in flight (a cell holds a handful of corners).
-    const long long cslot = (long long)f * g->totalCells + L.cellBase;
-    for (int c = t; c < L.nCells; c += kQT) {
-        const int o = scanA[c], n = (c + 1 < L.nCells ? scanA[c + 1] : M) - o;
-        const unsigned* srcc = A.cellcand + (cslot + c) * g->cellCap;
-        // (sixteen loads in flight: a cell of the benchmark frames holds ~11 corners, so one memory round trip instead of three)
-        for (int j0 = 0; j0 < n; j0 += 16) {
-            unsigned v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = srcc[min(j0 + u, n - 1)];
-#pragma unroll
-            for (int u = 0; u < 16; u++)
-                if (j0 + u < n) { keys[o + j0 + u] = v[u]; A.candOut[o + j0 + u] = v[u]; }
-        }
-    }
-    __syncthreads();
-    // ---- initial nodes
-    const int nIni = L.nIni;
-    if (t < nIni) {
-        box0[t] = make_short4((short)(int)(L.hX * (float)t), 0, (short)(int)(L.hX * (float)(t + 1)), (short)L.boxH);
-        cnt0[t] = 0;
-        crk0[t] = t;
-    }
-    __syncthreads();
-    for (int k0 = 0; k0 < M; k0 += kQT) {   // (every candidate lands in one of <= 16 nodes: count by ballot, not by 3000 atomics on one word)
-        const int k = k0 + t;
-        int ini = -1;
-        if (k < M) {
-            ini = min((int)((float)(keys[k] & 0xFFF) / L.hX), nIni - 1);
-            nof[k] = (unsigned short)ini;
-        }
-        for (int i = 0; i < nIni; i++) {
-            const unsigned long long m = __ballot(ini == i);
-            if (m && (t & 63) == 0) atomicAdd(&cnt0[i], __popcll(m));
-        }
-    }
-    __syncthreads();
-    if (t == 0) {  // drop empty initial nodes (nIni <= 16)
-        int S = 0;
-        for (int i = 0; i < nIni; i++) {
-            newpos[i] = S;
-            if (cnt0[i] > 0) { box0[S] = box0[i]; cnt0[S] = cnt0[i]; crk0[S] = S; mid0[S] = cnt0[i] > 1 ? box_mid(box0[i]) : kQtLeaf; S++; }
-        }
-        sh_S = S; sh_phase = 0; sh_done = 0;
-    }
-    __syncthreads();
-    if (nIni > 1) {
-        for (int k = t; k < M; k += kQT) nof[k] = (unsigned short)newpos[nof[k]];
-        __syncthreads();
-    }
-
-    QSTAMP(0);
-    int diters = 0;
-    short4* box = box0; short4* nbox = box1;
-    unsigned* mid = mid0; unsigned* nmid = mid1;
-    int* cnt = cnt0; int* ncnt = cnt1;
-    int* crk = crk0; int* ncrk = crk1;
-    // Every pass: two sweeps over the M candidates by the whole workgroup (child histograms, re-homing) and, between them, the
-    // list logic over the S <= N nodes.  The list logic runs in WAVE 0 ALONE, wave-synchronously (DPP scans, wavefront-scope
-    // fences, no workgroup barrier): as a sequence of block-wide steps it was ~20 barriers per pass with a handful of
-    // instructions between them -- 43 k of level 0's 132 k cycles.  Four barriers per pass remain (six in a careful pass,
-    // whose O(n^2) ranking stays block-wide).
-#define QT_WAVE_FENCE() eao::wave_sync()
-    const int wv = t >> 6;
-    for (int iter = 0; iter < 64 && !sh_done; iter++) {
-        const int S = sh_S, phase = sh_phase;
-        // (1) reset of the per-node scratch (everyone) ...
-        for (int i = t; i < S; i += kQT) {
-            procRank[i] = -1;
-            childcnt[4 * i] = 0; childcnt[4 * i + 1] = 0; childcnt[4 * i + 2] = 0; childcnt[4 * i + 3] = 0;
-        }
-        if (t == 0) { sh_rstar = 0x7FFFFFFF; sh_nexp = 0; }
-        __syncthreads();
-        // ... and the multi-key entries in list order (wave 0, beside the other waves' share of the histogram sweep)
-        int nCand = 0;
-        if (wv == 0) {
-            for (int i = lane; i < S; i += 64) scanA[i] = cnt[i] > 1 ? 1 : 0;
-            QT_WAVE_FENCE();
-            nCand = wave_excl_scan(scanA, S, lane);
-            for (int i = lane; i < S; i += 64)
-                if (cnt[i] > 1) vlist[scanA[i]] = i;
-            QT_WAVE_FENCE();
-        }
-        QSTAMP(1);
-        // (2) child histograms of every candidate
-        // The candidates are in spatial order (cells row-major, corners row-major inside a cell), so neighbouring lanes mostly
-        // hit the same (node, quadrant) bin: one LDS atomic per RUN of equal bins in the wave instead of one per candidate
-        // (while the tree is shallow, thousands of atomics would otherwise queue on a handful of words).
-        // (FOUR rows of kQT candidates per trip: node, key, split point of all four are fetched before any of them is used -- as one row
-        //  per trip the sweep was a chain of three dependent LDS reads and an atomic, twelve times over for level 0: 7 k cycles per pass)
-        for (int k0 = 0; k0 < M; k0 += 4 * kQT) {
-            int nd[4], bin[4];
-            unsigned ky[4], md[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int k = k0 + u * kQT + t; nd[u] = k < M ? (int)nof[k] : -1; ky[u] = k < M ? keys[k] : 0u; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) md[u] = nd[u] >= 0 ? mid[nd[u]] : kQtLeaf;
-#pragma unroll
-            for (int u = 0; u < 4; u++) bin[u] = md[u] != kQtLeaf ? 4 * nd[u] + quadrant_mid(ky[u], md[u]) : -1;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (k0 + u * kQT >= M) break;          // (uniform)
-                const int prev = __builtin_amdgcn_update_dpp(-2, bin[u], 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -2): VALU, not the LDS crossbar
-                const bool head = bin[u] != prev;
-                const unsigned long long hm = __ballot(head);
-                if (head && bin[u] >= 0) {
-                    const unsigned long long rest = lane == 63 ? 0ull : (hm >> (lane + 1));
-                    const int run = rest ? __ffsll((long long)rest) : 64 - lane;
-                    atomicAdd(&childcnt[bin[u]], run);
-                }
-            }
-        }
-        __syncthreads();
-        QSTAMP(2);
-        // (3) processing order: list order (full pass) or (size, creation rank) descending (careful pass)
-        if (phase == 1) {
-            // rank by (size, creation rank) descending, block-wide: the two sort fields are packed into one 64-bit key per node
-            // (size << 32 | creation rank; the pairs are unique) and laid out densely (childpos is free here, 8-byte aligned),
-            // so that the counting loop is one broadcast LDS read and one compare per node.  When there are fewer nodes than
-            // threads, 2 / 4 / ... adjacent lanes share a node's loop and add their counts with DPP shuffles.
-            if (wv == 0) {
-                for (int j = lane; j < nCand; j += 64) { const int me = vlist[j]; rkey[j] = ((unsigned long long)(unsigned)cnt[me] << 32) | (unsigned)crk[me]; }
-                if (lane == 0) sh_nexp = nCand;         // (nCand lives in wave 0's registers: hand it to the others; reset below)
-            }
-            __syncthreads();
-            const int nC2 = sh_nexp;
-            int sl = 1;
-            while (2 * sl * nC2 <= kQT && sl < 16) sl *= 2;
-            for (int j0 = 0; j0 < nC2; j0 += kQT / sl) {
-                const int j = j0 + t / sl, part = t & (sl - 1);
-                int r = 0;
-                if (j < nC2) {
-                    const unsigned long long mk = rkey[j];
-#pragma unroll 8
-                    for (int u = part; u < nC2; u += sl) r += rkey[u] > mk;
-                }
-                for (int d = sl >> 1; d >= 1; d >>= 1) r += __shfl_xor(r, d);
-                if (j < nC2 && part == 0) order[r] = vlist[j];
-            }
-            __syncthreads();
-            if (t == 0) sh_nexp = 0;
-        }
-        QSTAMP(3);
-        if (wv == 0) {
-            if (phase == 0) {
-                for (int j = lane; j < nCand; j += 64) order[j] = vlist[j];
-                QT_WAVE_FENCE();
-            }
-            // (4) growth prefix in processing order; the careful pass stops at the first prefix reaching N
-            for (int r = lane; r < nCand; r += 64) {
-                const int i = order[r];
-                scanA[r] = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
-            }
-            QT_WAVE_FENCE();
-            wave_excl_scan(scanA, nCand, lane);
-            int rstar = 0x7FFFFFFF;
-            if (phase == 1) {
-                for (int r = lane; r < nCand; r += 64) {
-                    const int i = order[r];
-                    const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
-                    if (S + scanA[r] + ne - (r + 1) >= N) rstar = min(rstar, r);
-                }
-                for (int d = 32; d >= 1; d >>= 1) rstar = min(rstar, __shfl_xor(rstar, d));
-            }
-            QSTAMP(4);
-            const int nProc = (phase == 1 && rstar != 0x7FFFFFFF) ? rstar + 1 : nCand;
-            int totalChildren = 0;
-            if (nProc > 0) {
-                const int i = order[nProc - 1];
-                totalChildren = scanA[nProc - 1] + (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
-            }
-            for (int r = lane; r < nProc; r += 64) procRank[order[r]] = r;
-            QT_WAVE_FENCE();
-            for (int i = lane; i < S; i += 64) scanB[i] = procRank[i] < 0 ? 1 : 0;
-            QT_WAVE_FENCE();
-            wave_excl_scan(scanB, S, lane);
-            QSTAMP(5);
-            // (5) new list: children of the LAST processed node first (each as n4,n3,n2,n1), untouched entries after
-            int myexp = 0;
-            for (int i = lane; i < S; i += 64) {
-                const int r = procRank[i];
-                if (r < 0) {
-                    const int p = totalChildren + scanB[i];
-                    nbox[p] = box[i]; ncnt[p] = cnt[i]; ncrk[p] = crk[i]; nmid[p] = mid[i];
-                    childpos[4 * i] = p; childpos[4 * i + 1] = p; childpos[4 * i + 2] = p; childpos[4 * i + 3] = p;   // (every key of an untouched entry moves with it)
-                } else {
-                    const short4 b = box[i];
-                    const short mx = (short)(b.x + ((b.z - b.x + 1) >> 1)), my = (short)(b.y + ((b.w - b.y + 1) >> 1));
-                    const int ne = (childcnt[4 * i] > 0) + (childcnt[4 * i + 1] > 0) + (childcnt[4 * i + 2] > 0) + (childcnt[4 * i + 3] > 0);
-                    int p = totalChildren - (scanA[r] + ne);
-                    for (int q = 3; q >= 0; q--) {
-                        const int c = childcnt[4 * i + q];
-                        if (c > 0) {
-                            short4 nb;
-                            nb.x = (q & 1) ? mx : b.x; nb.z = (q & 1) ? b.z : mx;
-                            nb.y = (q & 2) ? my : b.y; nb.w = (q & 2) ? b.w : my;
-                            nbox[p] = nb; ncnt[p] = c; ncrk[p] = 4 * r + q; nmid[p] = c > 1 ? box_mid(nb) : kQtLeaf;
-                            childpos[4 * i + q] = p;
-                            p++;
-                            myexp += c > 1;
-                        }
-                    }
-                }
-            }
-            for (int d = 32; d >= 1; d >>= 1) myexp += __shfl_xor(myexp, d);
-            // (7) upstream's termination tests (src/ORBextractor.cc:660-737)
-            if (lane == 0) {
-                const int S2 = totalChildren + S - nProc;
-                sh_S = S2;
-                if (S2 >= N || S2 == S) sh_done = 1;
-                else if (phase == 0 && S2 + 3 * myexp > N) sh_phase = 1;
-            }
-        }
-        __syncthreads();
-        QSTAMP(6);
-        // (6) re-home the candidates
-        for (int k = t; k < M; k += kQT) {
-            const int nd = nof[k];
-            nof[k] = (unsigned short)childpos[4 * nd + quadrant_mid(keys[k], mid[nd])];
-        }
-        __syncthreads();
-        QSTAMP(7);
-        diters++;
-        short4* tb = box; box = nbox; nbox = tb;
-        unsigned* tm = mid; mid = nmid; nmid = tm;
-        int* ti = cnt; cnt = ncnt; ncnt = ti;
-        ti = crk; crk = ncrk; ncrk = ti;
-    }
-#undef QT_WAVE_FENCE
-    // ---- best response per node, first candidate wins ties (strict '>' at src/ORBextractor.cc:752)
-    const int S = sh_S;
-    unsigned* best = reinterpret_cast<unsigned*>(scanB);
-    for (int i = t; i < S; i += kQT) best[i] = 0;
-    __syncthreads();
-    for (int k = t; k < M; k += kQT) atomicMax(&best[nof[k]], ((keys[k] >> 24) << 20) | (0xFFFFFu - (unsigned)k));
-    __syncthreads();
-    unsigned* out = A.levelkps + (long long)f * g->totalKpCap + L.kpBase;
-    for (int i = t; i < S; i += kQT) {
-        const unsigned k = 0xFFFFFu - (best[i] & 0xFFFFFu);
-        out[i] = keys[k];
-    }
-    if (t == 0) A.levelcnt[f * g->nlevels + l] = S;
-    QSTAMP(8);
-    if (dbg && t == 0 && A.dbg) {
-        long long* o = dbg + 16 * l;
-        for (int i = 0; i < 9; i++) o[i] = dacc[i];
-        o[9] = diters; o[10] = M; o[11] = S;
-    }
-#undef QSTAMP
-}
-
-template <int kQT>
-__device__ __noinline__ void quadtree_global(const Geom* __restrict__ g, const unsigned* cellcand, const int* cellcnt, unsigned* cand, unsigned short* nodeof,
-                                             unsigned* levelkps, int* levelcnt, int* candcnt, int f, int l, unsigned char* base, long long* dbg, int* wtmp, int* shv) {
-    const int t = threadIdx.x;
-    const LevelGeom L = g->L[l];
-    int* scanA = reinterpret_cast<int*>(base + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * kQtNodeInts));
-    const long long cslot = (long long)f * g->totalCells + L.cellBase;
-    for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
-    __syncthreads();
-    const int M = block_excl_scan<kQT>(scanA, L.nCells, wtmp);
-    if (t == 0) candcnt[f * g->nlevels + l] = M;
-    if (M == 0) {
-        if (t == 0) levelcnt[f * g->nlevels + l] = 0;
-        return;
-    }
-    QtArgs A = {g, cellcand, cellcnt, levelkps, levelcnt, f, l, M, dbg, cand + (long long)f * g->totalCandCap + L.candBase};
-    quadtree_body<kQT>(A, base, wtmp, shv, cand + (long long)f * g->totalCandCap + L.candBase, nodeof + (long long)f * g->totalCandCap + L.candBase);
-}
-
-template <int kQT>
-__global__ __launch_bounds__(kQT, kQT == 256 ? 4 : 1) void k_quadtree(const Geom* __restrict__ g, const unsigned* __restrict__ cellcand,
-                                                  const int* __restrict__ cellcnt, unsigned* __restrict__ cand,
-                                                  unsigned short* __restrict__ nodeof, unsigned* __restrict__ levelkps,
-                                                  int* __restrict__ levelcnt, int* __restrict__ candcnt, int f0, long long* dbg, int l0,
-                                                  unsigned char* __restrict__ qtnodes) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int wtmp[kQT / 64];
-    __shared__ int shv[8];
-    const int t = threadIdx.x;
-    // level-major dispatch (frames fastest): the long level-0 workgroups of EVERY frame start first and the short top levels
-    // fill the gaps behind them -- with the levels of a frame dispatched together the last frames' level 0 was the tail
-    const int l = blockIdx.y + l0, f = blockIdx.x + f0;   // the launch covers levels l0 .. l0 + gridDim.y - 1
-    const LevelGeom L = g->L[l];
-    if (g->qtNodesGlobal) {   // node lists too large for LDS: the same algorithm over a global workspace (slower, never refused)
-        quadtree_global<kQT>(g, cellcand, cellcnt, cand, nodeof, levelkps, levelcnt, candcnt, f, l, qtnodes + (long long)f * g->qtNodeFrameBytes + L.nodeOff,
-                        (dbg && f == f0) ? dbg : nullptr, wtmp, shv);
-        return;
-    }
-    int* scanA = reinterpret_cast<int*>(smem + (size_t)L.listCap * (2 * sizeof(short4) + sizeof(int) * kQtNodeInts));
-    const long long cslot = (long long)f * g->totalCells + L.cellBase;
-    for (int i = t; i < L.nCells; i += kQT) scanA[i] = cellcnt[cslot + i];
-    __syncthreads();
-    const int M = block_excl_scan<kQT>(scanA, L.nCells, wtmp);
-    if (t == 0) candcnt[f * g->nlevels + l] = M;
-    if (M == 0) {
-        if (t == 0) levelcnt[f * g->nlevels + l] = 0;
-        return;
-    }
-    QtArgs A = {g, cellcand, cellcnt, levelkps, levelcnt, f, l, M, (dbg && f == f0) ? dbg : nullptr, cand + (long long)f * g->totalCandCap + L.candBase};
-    if (M <= g->qtLdsCand) {
-        unsigned* keysL = reinterpret_cast<unsigned*>(smem + g->qtKeysOff);
-        quadtree_body<kQT>(A, smem, wtmp, shv, keysL, reinterpret_cast<unsigned short*>(keysL + g->qtLdsCand));
-    } else {
-        quadtree_body<kQT>(A, smem, wtmp, shv, cand + (long long)f * g->totalCandCap + L.candBase, nodeof + (long long)f * g->totalCandCap + L.candBase);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- blur
 __device__ __forceinline__ int reflect101(int p, int len) {
     while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
@@ -1190,9 +647,6 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // Borders: in waves that touch the left / right image edge each lane carries three v_perm selectors (built once) that
 // rebuild the reflect-101 window from the words it could load in bounds; rows reflect through their index.  An
 // unaligned caller image (level 0 only) takes a byte-wise variant of the same loop.
-constexpr int kBlurRows = 16;    // output rows per strip
-constexpr int kBlurSegW = 128;   // strip width
-constexpr int kBlurStripsPerWg = 8;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned udot2(unsigned a, unsigned b, unsigned c) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
@@ -1569,19 +1023,8 @@ __global__ void k_unpack_cand(const unsigned* __restrict__ keys, int n, float* _
     }
 }
 
-inline int cv_round(double v) { return (int)std::lrint(v); }
 
 }  // namespace
-
-// ================================================================================================= host
-constexpr size_t kProfEvents = 10;
-struct GraphKey {
-    const void* img; int pitch0; long long fs0; int batch; void* kps; void* desc; int cap; void* n; int lanes;
-    bool operator==(const GraphKey& o) const {
-        return img == o.img && pitch0 == o.pitch0 && fs0 == o.fs0 && batch == o.batch && kps == o.kps && desc == o.desc && cap == o.cap && n == o.n && lanes == o.lanes;
-    }
-};
-
 
 // ---------------------------------------------------------------------------------------------- stereo matching
 // Frame::ComputeStereoMatches (src/Frame.cc:841-1013): one wavefront per left keypoint.
@@ -1692,396 +1135,8 @@ __global__ __launch_bounds__(256) void k_stereo_match(const Geom* __restrict__ g
     if (lane == 0) { A.uRight[iL] = outU; A.depth[iL] = outD; A.sad[iL] = outS; }
 }
 
-struct eao_orb {
-    eao_orb_cfg cfg;
-    std::vector<float> scale, invScale, sigma2, invSigma2;
-    std::vector<int> quota;
-    int umax[16];
-    // geometry of the current (W, H)
-    Geom geom;
-    bool geomValid = false;
-    int batchCap = 0;
-    std::vector<CellDesc> cells;
-    size_t quadLds = 0;
-    eao::DevBuf<int4> d_pyrRanges;
-    eao::DevBuf<int2> d_pyrCoef;
-    PyrArgs pyr;               // the fused pyramid launch of this geometry
-    size_t pyrLds = 0;
-    bool pyrFused = false;
-    // device state
-    hipStream_t stream = nullptr;
-    // up to kLanes sub-batches can run as independent pipelines, each on its own (main, side) stream pair
-    // (EAO_ORB_LANES, default 1: see the measurement note at enqueue())
-    static constexpr int kLanes = 4;
-    hipStream_t laneMain[kLanes] = {}, laneSide[kLanes] = {};
-    // Round 6: the handle's private streams (its own main stream, the side stream of every call) take the priority of the stream the handle's FIRST call arrives on:
-    // a host-API call (ORBextractor::operator(), what the Tracking thread makes) arrives on no stream -> Latency class; a device-API call arrives on the caller's stream
-    // (PyTorch's default stream in bench.py) -> that stream's priority.  Measured (gpurun_out/r06g .. r06i, 64-frame step on PyTorch's default-priority stream): side
-    // stream at the same (default) priority 0.2553 ms; a Latency-class side stream beside it 0.2665 ms (FAST level 0 and the blur overtake the main chain's seven dependent
-    // resize launches); and a default-priority side stream created NEXT TO idle Latency-class streams of the same handle 0.43-0.64 ms, every stage twice as long -- one
-    // handle's streams are all of one priority.
-    bool evLastValid = false, capturing = false;   // evLastValid: a call has been enqueued on lastStream
-    hipStream_t lastStream = nullptr;      // the stream of the previous call: compared, never dereferenced (its owner may have destroyed it)
-    // Round 6: ordering between calls that come in on DIFFERENT streams without draining the device (under the reference's concurrency a drain makes the
-    // Tracking thread wait for LocalMapping's whole bundle adjustment).  evLast is recorded behind a call's last kernel, a call on another stream waits for
-    // it ON THE DEVICE (hipStreamWaitEvent).  An event record between two calls costs the stream a few microseconds, so a handle that only ever sees one
-    // stream (the common case: the bench loop, one tracker) records nothing; the FIRST change of stream in a handle's life finds no event and drains once,
-    // from then on every call leaves its event.  EAO_ORB_LAST_EVENT=always records from the first call on (no drain ever), =never is the rounds 1-5 drain.
-    hipEvent_t evLast = nullptr;
-    bool everyCallEvent = false, evLastRecorded = false;
-    hipEvent_t evStart = nullptr, evFork[kLanes] = {}, evJoin[kLanes] = {}, evDone[kLanes] = {}, evFast0[kLanes] = {}, evMid[kLanes] = {};
-    eao::DevBuf<Geom> d_geom;
-    eao::DevBuf<CellDesc> d_cells;
-    eao::DevBuf<uint8_t> d_pyr, d_blur, d_in;
-    eao::DevBuf<unsigned> d_cellcand, d_cand, d_levelkps;
-    eao::DevBuf<unsigned short> d_nodeof;
-    eao::DevBuf<unsigned char> d_qtnodes;   // global node lists (only when they do not fit in LDS)
-    eao::DevBuf<int> d_cellcnt, d_levelcnt, d_candcnt, d_nout;
-    eao::DevBuf<eao_keypoint> d_kps;
-    unsigned char* pinOut = nullptr;       // mapped pinned host memory: results of small host-API calls land here directly
-    size_t pinOutCap = 0;
-    unsigned char* pinUp = nullptr;        // pinned staging of small host-API uploads (upload_frames)
-    size_t pinUpCap = 0;
-    eao::DevBuf<uint8_t> d_desc;
-    eao::DevBuf<float> d_xyr;
-    eao::DevBuf<unsigned char> d_stereo;   // staging of eao_compute_stereo_matches
-    unsigned char* pinPyr = nullptr;       // eao_orb_pyramid: the bordered levels of one frame in mapped pinned host memory
-    size_t pinPyrCap = 0;
-    eao_orb_level_view pyrViews[kMaxLevels] = {};
-    int pyrFrame = -1, pyrBorder = -1;     // what pinPyr holds (of the last extraction; -1: nothing)
-    int autoPyrBorder = -1;                // >= 0: single-frame host-API extractions export the bordered pyramid in the same stream pass (eao_orb_set_keep_pyramid)
-    bool lastComplete = false;             // the last extraction was a synchronous host-API call: its products are final, nothing to wait for
-    // last call (for stage taps)
-    ImgSrc lastSrc{};
-    int lastBatch = 0;
-    bool profiling = false;
-    long long* d_dbg = nullptr;   // EAO_DEBUG_STAMPS: per-level phase cycles of k_quadtree (diagnostic runs only)
-    hipGraphExec_t graphExec = nullptr;
-    GraphKey graphKey = {};
-    std::vector<hipEvent_t> evs;   // kProfEvents events per profiled call, averaged by eao_orb_last_timing
-    size_t evUsed = 0;
-    // streaming host API (eao_orb_stream_*): a ring of pinned input / output slots, three streams (upload, extraction, download)
-    struct StreamSlot {
-        unsigned char* pinIn = nullptr; unsigned char* pinOut = nullptr;      // pinned host memory: frames in, [counts | keypoints | descriptors] out
-        unsigned char* pinOutDev = nullptr;                                    // ... the output block as the device sees it (mapped)
-        unsigned char* dIn = nullptr; unsigned char* dOut = nullptr;           // their device twins
-        hipEvent_t evIn = nullptr, evDone = nullptr, evOut = nullptr;
-        int batch = 0;
-        bool submitted = false;
-    };
-    std::vector<StreamSlot> slots;
-    hipStream_t sUp = nullptr, sRun = nullptr, sDown = nullptr;
-    int sW = 0, sH = 0, sB = 0, sCap = 0, sPitch = 0;
-    size_t sInBytes = 0, sOutBytes = 0, sOffK = 0, sOffD = 0;
-};
-
-namespace {
-
-eao_status build_geometry(eao_orb* h, int W, int H) {
-    const eao_orb_cfg& c = h->cfg;
-    Geom& g = h->geom;
-    std::memset(&g, 0, sizeof(g));
-    g.nlevels = c.nlevels; g.W = W; g.H = H;
-    g.iniTh = c.ini_th_fast; g.minTh = c.min_th_fast;
-    for (int i = 0; i < 16; i++) g.umax[i] = h->umax[i];
-    h->cells.clear();
-    int off = 0, kpBase = 0, candBase = 0, tileBase = 0, maxCell = 0, scanCap = 0, maxList = 0, maxSw = 0, maxSh = 0;
-    // first pass: level sizes and the largest FAST cell (fixes cellCap)
-    for (int l = 0; l < c.nlevels; l++) {
-        LevelGeom& L = g.L[l];
-        const float s = h->invScale[l];
-        L.w = cv_round((float)W * s);   // reference src/ORBextractor.cc:1111-1112
-        L.h = cv_round((float)H * s);
-        EAO_REQUIRE(L.w < 4096 && L.h < 4096, "level %d is %dx%d: coordinates are packed in 12 bits", l, L.w, L.h);
-        const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
-        const float width = (float)(maxBX - kMinBorder), height = (float)(maxBY - kMinBorder);
-        const int nCols = (int)(width / (float)refc::FAST_CELL), nRows = (int)(height / (float)refc::FAST_CELL);
-        EAO_REQUIRE(nCols >= 1 && nRows >= 1, "level %d (%dx%d) is smaller than one 30 px FAST cell plus borders", l, L.w, L.h);
-        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
-        EAO_REQUIRE(wCell + 6 <= kTile && hCell + 6 <= kTile, "FAST cell %dx%d exceeds the LDS tile", wCell, hCell);
-        maxCell = std::max(maxCell, ((wCell + 1) / 2) * ((hCell + 1) / 2));
-    }
-    g.cellCap = maxCell;  // 3x3 NMS with strict '>' keeps at most one corner per 2x2 block
-    for (int l = 0; l < c.nlevels; l++) {
-        LevelGeom& L = g.L[l];
-        L.pitch = (L.w + 63) & ~63;
-        L.off = off;
-        off += ((L.pitch * ((L.h + kBlurRows - 1) / kBlurRows * kBlurRows)) + 255) & ~255;   // (padding rows: see k_blur7)
-        const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
-        const float width = (float)(maxBX - kMinBorder), height = (float)(maxBY - kMinBorder);
-        const int nCols = (int)(width / (float)refc::FAST_CELL), nRows = (int)(height / (float)refc::FAST_CELL);
-        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
-        L.cellBase = (int)h->cells.size();
-        for (int i = 0; i < nRows; i++) {   // reference src/ORBextractor.cc:789-806
-            const float iniY = (float)(kMinBorder + i * hCell);
-            float maxY = iniY + hCell + 6;
-            if (iniY >= maxBY - 3) continue;
-            if (maxY > maxBY) maxY = (float)maxBY;
-            for (int j = 0; j < nCols; j++) {
-                const float iniX = (float)(kMinBorder + j * wCell);
-                float maxX = iniX + wCell + 6;
-                if (iniX >= maxBX - 6) continue;
-                if (maxX > maxBX) maxX = (float)maxBX;
-                CellDesc cd;
-                cd.level = (short)l; cd.x0 = (short)iniX; cd.y0 = (short)iniY;
-                cd.sw = (short)((int)maxX - (int)iniX); cd.sh = (short)((int)maxY - (int)iniY);
-                cd.offX = (short)(j * wCell); cd.offY = (short)(i * hCell); cd.pad = 0;
-                maxSw = std::max(maxSw, (int)cd.sw); maxSh = std::max(maxSh, (int)cd.sh);
-                h->cells.push_back(cd);
-            }
-        }
-        L.nCells = (int)h->cells.size() - L.cellBase;
-        L.quota = h->quota[l];
-        L.boxH = maxBY - kMinBorder;
-        L.nIni = (int)std::round((float)(maxBX - kMinBorder) / (float)(maxBY - kMinBorder));  // :543
-        EAO_REQUIRE(L.nIni >= 1 && L.nIni <= kMaxIni, "level %d aspect ratio gives %d initial quad-tree nodes (supported 1..%d)", l, L.nIni, kMaxIni);
-        L.hX = (float)(maxBX - kMinBorder) / (float)L.nIni;
-        L.listCap = std::max(L.quota + 3, 4 * L.nIni) + 1;
-        EAO_REQUIRE(L.listCap < 65535, "quota too large");
-        L.kpBase = kpBase; kpBase += L.listCap;
-        L.candBase = candBase; L.candCap = L.nCells * g.cellCap; candBase += L.candCap;
-        EAO_REQUIRE(L.candCap < (1 << 20), "level %d can hold %d FAST candidates; the quad-tree packs indices in 20 bits", l, L.candCap);
-        L.tilesX = eao::cdiv(L.w, kBlurSegW);
-        L.tileBase = tileBase; tileBase += eao::cdiv(L.tilesX * eao::cdiv(L.h, kBlurRows), kBlurStripsPerWg);
-        L.scale = h->scale[l];
-        L.scaledPatch = (int)(refc::PATCH_SIZE * h->scale[l]);
-        scanCap = std::max(scanCap, std::max(L.listCap, L.nCells));
-        maxList = std::max(maxList, L.listCap);
-    }
-    g.totalCells = (int)h->cells.size();
-    g.totalKpCap = kpBase;
-    g.totalCandCap = candBase;
-    g.totalTiles = tileBase;
-    g.pyrFrameBytes = off;
-    // ---- fused pyramid: tile capacities by running the kernel's own range rules over every tile (host and device evaluate
-    //      the same float / double expressions; -ffp-contract=off on both sides)
-    {
-        PyrArgs& P = h->pyr;
-        std::memset(&P, 0, sizeof(P));
-        h->pyrFused = false;
-        static const bool envChain = getenv("EAO_ORB_PYRAMID") && !strcmp(getenv("EAO_ORB_PYRAMID"), "chain");
-        if (c.nlevels > 1 && !envChain) {
-            P.nlevels = c.nlevels; P.pyrFrameBytes = g.pyrFrameBytes;
-            for (int l = 0; l < c.nlevels; l++) {
-                P.L[l].w = g.L[l].w; P.L[l].h = g.L[l].h; P.L[l].pitch = g.L[l].pitch; P.L[l].off = g.L[l].off;
-                if (l) { P.L[l].invX = 1. / ((double)g.L[l].w / g.L[l - 1].w); P.L[l].invY = 1. / ((double)g.L[l].h / g.L[l - 1].h); }
-            }
-            P.tilesX = eao::cdiv(g.L[1].w, kPyrTW); P.tilesY = eao::cdiv(g.L[1].h, kPyrTH);
-            std::vector<int> capW(c.nlevels, 1), capH(c.nlevels, 1);
-            const int nT = P.tilesX + P.tilesY;
-            std::vector<int4> table((size_t)c.nlevels * nT, make_int4(0, 0, 0, 0));
-            auto axis = [&](int tiles, int T, bool isX, std::vector<int>& capv) {
-                for (int b = 0; b < tiles; b++) {
-                    const int col = isX ? b : P.tilesX + b;
-                    std::vector<int> o0(c.nlevels), o1(c.nlevels);
-                    int b0 = std::min(b * T, isX ? g.L[1].w : g.L[1].h), b1 = std::min((b + 1) * T, isX ? g.L[1].w : g.L[1].h);
-                    o0[1] = b0; o1[1] = b1;
-                    for (int l = 2; l < c.nlevels; l++) {
-                        const double inv = isX ? P.L[l].invX : P.L[l].invY;
-                        const int sn = isX ? g.L[l - 1].w : g.L[l - 1].h, dn = isX ? g.L[l].w : g.L[l].h;
-                        b0 = pyr_first_at_least(b0, inv, sn, dn); b1 = pyr_first_at_least(b1, inv, sn, dn);
-                        o0[l] = b0; o1[l] = b1;
-                    }
-                    int r0 = o0[c.nlevels - 1], r1 = o1[c.nlevels - 1];
-                    capv[c.nlevels - 1] = std::max(capv[c.nlevels - 1], r1 - r0);
-                    for (int l = 1; l < c.nlevels; l++) { table[(size_t)l * nT + col].x = o0[l]; table[(size_t)l * nT + col].y = o1[l]; }
-                    table[(size_t)(c.nlevels - 1) * nT + col].z = r0; table[(size_t)(c.nlevels - 1) * nT + col].w = r1;
-                    for (int l = c.nlevels - 1; l >= 1; l--) {
-                        int q0 = l > 1 ? o0[l - 1] : 0x7FFFFFFF, q1 = l > 1 ? o1[l - 1] : 0;
-                        if (r1 > r0) {
-                            const double inv = isX ? P.L[l].invX : P.L[l].invY;
-                            const int sn = isX ? g.L[l - 1].w : g.L[l - 1].h;
-                            q0 = std::min(q0, pyr_src_ofs(r0, inv, sn));
-                            q1 = std::max(q1, std::min(pyr_src_ofs(r1 - 1, inv, sn) + 1, sn - 1) + 1);
-                        }
-                        if (q0 > q1) q0 = q1 = 0;
-                        capv[l - 1] = std::max(capv[l - 1], q1 - q0);
-                        table[(size_t)(l - 1) * nT + col].z = q0; table[(size_t)(l - 1) * nT + col].w = q1;
-                        r0 = q0; r1 = q1;
-                    }
-                }
-            };
-            axis(P.tilesX, kPyrTW, true, capW);
-            axis(P.tilesY, kPyrTH, false, capH);
-            size_t lds = 0;
-            int coefCap = 1;
-            for (int l = 0; l < c.nlevels; l++) {
-                P.L[l].ldsW = ((capW[l] + 3) & ~3) + 16; P.L[l].ldsH = capH[l] + 1;     // (+ slack: staging origin, three-word reads past the last pixel)
-                P.L[l].ldsOff = (int)lds;
-                lds += ((size_t)P.L[l].ldsW * P.L[l].ldsH + 15) & ~(size_t)15;
-                coefCap = std::max(coefCap, std::max(capW[l], capH[l]));
-            }
-            coefCap = (coefCap + 7) & ~3;
-            P.coefOff = (int)lds; P.coefCap = coefCap;
-            lds += (size_t)coefCap * 16;
-            h->pyrLds = lds;
-            // (extreme level counts, and scale factors beyond 2 -- four pixels then read more than three source words -- keep
-            //  the chain of k_resize launches)
-            h->pyrFused = lds <= 64 * 1024 && h->cfg.scale_factor <= 2.0f;
-            for (int l = 1; l < c.nlevels; l++)
-                if (P.L[l].invX > 2.0 || P.L[l].invY > 2.0) h->pyrFused = false;
-            if (h->pyrFused) {
-                std::vector<int2> cxv, cyv;
-                for (int l = 1; l < c.nlevels; l++) {
-                    P.L[l].coefXOff = (int)cxv.size(); P.L[l].coefYOff = (int)cyv.size();
-                    for (int d = 0; d < g.L[l].w; d++) { int o; unsigned w2; resize_coef_host(d, P.L[l].invX, g.L[l - 1].w, true, &o, &w2); cxv.push_back(make_int2(o, (int)w2)); }
-                    for (int d = 0; d < g.L[l].h; d++) { int o; unsigned w2; resize_coef_host(d, P.L[l].invY, g.L[l - 1].h, false, &o, &w2); cyv.push_back(make_int2(o, (int)w2)); }
-                }
-                eao_status st2 = h->d_pyrRanges.reserve(table.size());
-                if (st2) return st2;
-                if ((st2 = h->d_pyrCoef.reserve(cxv.size() + cyv.size()))) return st2;
-                EAO_HIP(hipMemcpy(h->d_pyrRanges.p, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice));
-                EAO_HIP(hipMemcpy(h->d_pyrCoef.p, cxv.data(), cxv.size() * sizeof(int2), hipMemcpyHostToDevice));
-                EAO_HIP(hipMemcpy(h->d_pyrCoef.p + cxv.size(), cyv.data(), cyv.size() * sizeof(int2), hipMemcpyHostToDevice));
-                P.ranges = h->d_pyrRanges.p;
-                P.coefX = h->d_pyrCoef.p; P.coefY = h->d_pyrCoef.p + cxv.size();
-            }
-        }
-    }
-    g.scanCap = scanCap;
-    g.fastMaxTested = std::max(1, (maxSw - 6) * (maxSh - 6));
-    // tile | work list u16[maxT] (+ the second list, stacked from its end) | score map | 16-word survivor-position table
-    g.fastStride = maxSw + 3 <= 48 ? 48 : kTileStrideWide;
-    g.fastTileBytes = ((maxSh * g.fastStride) + 15) & ~15;
-    g.fastLdsBytes = g.fastTileBytes + ((2 * g.fastMaxTested + 15) & ~15) + ((((maxSw - 4) * (maxSh - 4)) + 15) & ~15) + 64;
-    // k_quadtree dynamic LDS: 2 short4 + 2 cnt + 2 crk + 4 childcnt + 4 childpos + newpos/order/vlist/procRank/scanB per entry + scanA
-    h->quadLds = (size_t)maxList * (2 * sizeof(short4) + sizeof(int) * kQtNodeInts) + (size_t)scanCap * sizeof(int);
-    g.qtNodesGlobal = 0; g.qtNodeFrameBytes = 0;
-    if (h->quadLds > 100 * 1024) {   // (thousands of features on one level: upstream takes any N, src/ORBextractor.cc:539)
-        g.qtNodesGlobal = 1;
-        long long noff = 0;
-        for (int l = 0; l < c.nlevels; l++) {
-            g.L[l].nodeOff = noff;
-            noff += (((long long)g.L[l].listCap * (2 * sizeof(short4) + sizeof(int) * kQtNodeInts) + (long long)scanCap * sizeof(int)) + 255) & ~255LL;
-        }
-        g.qtNodeFrameBytes = noff;
-        h->quadLds = 0;
-    }
-    // candidate keys (4 B) + node indices (2 B) in LDS while two workgroups still fit a CU
-    h->quadLds = (h->quadLds + 15) & ~(size_t)15;
-    g.qtKeysOff = (int)h->quadLds;
-    // Capacity: about four candidates per requested feature (the 640 x 480 benchmark frames leave ~3100 candidates on level 0
-    // for 1000 features; a level that holds more falls back to the global arrays).  With the level-major dispatch the
-    // smaller footprint pays: three workgroups per CU instead of two -- k_quadtree alone 210 -> 169 us at batch 256 (8192 ->
-    // 4096 candidates; 3200: 143 us, but then the blur beside it is the longer of the two).
-    static const size_t kQtLdsCandEnv = getenv("EAO_QT_LDS_CAND") ? (size_t)atoi(getenv("EAO_QT_LDS_CAND")) : 0;
-    const size_t kQtLdsCand = kQtLdsCandEnv ? kQtLdsCandEnv : std::min<size_t>(8192, std::max<size_t>(2048, ((size_t)h->cfg.nfeatures * 4 + 63) & ~(size_t)63));
-    g.qtLdsCand = (int)std::min<size_t>(kQtLdsCand, h->quadLds < 76 * 1024 ? (76 * 1024 - h->quadLds) / 6 : 0) & ~7;
-    h->quadLds += (size_t)g.qtLdsCand * 6;
-    if (g.qtNodesGlobal) { g.qtLdsCand = 0; h->quadLds = 0; }     // (everything in the global workspace)
-    // the blur kernel hard-codes the taps; make sure the published construction gives them
-    {
-        float cf[7]; double sum = 0;
-        for (int i = 0; i < 7; i++) { double x = i - 3; cf[i] = (float)std::exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
-        const int expect[7] = {18, 34, 49, 55, 49, 34, 18};
-        for (int i = 0; i < 7; i++)
-            if (cv_round((double)(float)(cf[i] * (1. / sum)) * 256.0) != expect[i]) { eao::set_error("gaussian taps mismatch"); return EAO_ERR_INTERNAL; }
-    }
-    { eao_status st = h->d_geom.reserve(1); if (st) return st; }
-    EAO_HIP(hipMemcpyAsync(h->d_geom.p, &g, sizeof(Geom), hipMemcpyHostToDevice, h->stream));
-    { eao_status st = h->d_cells.reserve(h->cells.size()); if (st) return st; }
-    EAO_HIP(hipMemcpyAsync(h->d_cells.p, h->cells.data(), h->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice, h->stream));
-    EAO_HIP(eao::wait_latency(h->stream));
-    {   // per-function, process-wide state: only ever raised (another handle with a larger nfeatures may be in use)
-        static std::atomic<int> cur{0};
-        int have = cur.load();
-        while ((int)h->quadLds > have) {
-            EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree<kQTSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
-            EAO_HIP(hipFuncSetAttribute((const void*)k_quadtree<kQTLarge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->quadLds));
-            if (cur.compare_exchange_weak(have, (int)h->quadLds)) break;
-        }
-    }
-    h->geomValid = true;
-    h->batchCap = 0;
-    if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
-    return EAO_OK;
-}
-
-// EAO_ORB_LAST_EVENT: 0 = never (drain on a change of stream), 1 = adaptive (default), 2 = always
-int orb_last_event_mode() {
-    static const int mode = [] {
-        const char* e = getenv("EAO_ORB_LAST_EVENT");
-        if (!e) return 1;
-        if (!strcmp(e, "always")) return 2;
-        if (!strcmp(e, "never")) return 0;
-        return 1;
-    }();
-    return mode;
-}
-
-constexpr uintptr_t kNoCallerStream = ~(uintptr_t)0;      // a host-API call: the handle's streams are of the Latency class
-eao_status ensure(eao_orb* h, int W, int H, int batch, hipStream_t caller = (hipStream_t)kNoCallerStream) {
-    eao_status st = eao::require_device();
-    if (st) return st;
-    if (!h->stream && batch > 0) {      // (batch 0: a geometry query -- eao_orb_max_keypoints -- needs no stream, and must not decide the handle's priority)
-        // the priority of the handle's streams: see eao_orb (round 6)
-        int least = 0, greatest = 0, p = 0;
-        const bool follow = (uintptr_t)caller != kNoCallerStream && !(getenv("EAO_STREAM_PRIORITY") && !atoi(getenv("EAO_STREAM_PRIORITY"))) &&
-                            hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && hipStreamGetPriority(caller, &p) == hipSuccess;
-        (void)hipGetLastError();
-        auto make = [&](hipStream_t* q) -> hipError_t {
-            if ((uintptr_t)caller == kNoCallerStream) return eao::create_stream(q, eao::StreamClass::Latency);
-            if (!follow || p == 0) return hipStreamCreateWithFlags(q, hipStreamNonBlocking);
-            return hipStreamCreateWithPriority(q, hipStreamNonBlocking, p);
-        };
-        EAO_HIP(make(&h->stream));
-        EAO_HIP(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
-        EAO_HIP(hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming));
-        h->everyCallEvent = orb_last_event_mode() == 2;
-        // (HIP maps its streams onto a handful of hardware queues, and streams that share one execute in submission order: only the
-        //  lanes the schedule can use get streams -- lane 0 unless EAO_ORB_LANES asks for more -- so that the streaming API's upload
-        //  stream does not end up behind the extraction's side stream)
-        const int lanesWanted = std::max(1, std::min(eao_orb::kLanes, getenv("EAO_ORB_LANES") ? atoi(getenv("EAO_ORB_LANES")) : 1));
-        for (int i = 0; i < eao_orb::kLanes; i++) {
-            if (i < lanesWanted) {
-                EAO_HIP(make(&h->laneMain[i]));
-                EAO_HIP(make(&h->laneSide[i]));
-            }
-            EAO_HIP(hipEventCreateWithFlags(&h->evFork[i], hipEventDisableTiming));
-            EAO_HIP(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
-            EAO_HIP(hipEventCreateWithFlags(&h->evMid[i], hipEventDisableTiming));
-            EAO_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
-            EAO_HIP(hipEventCreateWithFlags(&h->evDone[i], hipEventDisableTiming));
-        }
-    }
-    if (!h->d_dbg && getenv("EAO_DEBUG_STAMPS")) {
-        EAO_HIP(hipMalloc(&h->d_dbg, 16 * kMaxLevels * sizeof(long long)));
-        EAO_HIP(hipMemset(h->d_dbg, 0, 16 * kMaxLevels * sizeof(long long)));
-    }
-    if (!h->geomValid || h->geom.W != W || h->geom.H != H) {
-        st = build_geometry(h, W, H);
-        if (st) return st;
-    }
-    if (batch > h->batchCap) {
-        const Geom& g = h->geom;
-        const size_t B = batch;
-#define RES(buf, cnt) do { st = h->buf.reserve(cnt); if (st) return st; } while (0)
-        RES(d_pyr, B * g.pyrFrameBytes);
-        RES(d_blur, B * g.pyrFrameBytes);
-        RES(d_cellcand, B * (size_t)g.totalCells * g.cellCap);
-        RES(d_cellcnt, B * g.totalCells);
-        RES(d_cand, B * (size_t)g.totalCandCap);
-        RES(d_nodeof, B * (size_t)g.totalCandCap);
-        if (g.qtNodesGlobal) RES(d_qtnodes, B * (size_t)g.qtNodeFrameBytes);
-        RES(d_levelkps, B * (size_t)g.totalKpCap);
-        RES(d_levelcnt, B * g.nlevels);
-        RES(d_candcnt, B * g.nlevels);
-#undef RES
-        h->batchCap = batch;
-        if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }   // buffers moved
-    }
-    return EAO_OK;
-}
-
-// A call that comes in on another stream than the handle's previous call shares its pyramid / candidate scratch with it: it runs behind the previous
-// call's event on the device, or -- when that call left none (see eao_orb::evLast) -- behind a drain, after which every call of this handle leaves one.
-// The previous stream itself is never touched (its owner may have destroyed it).
-eao_status order_behind_last_call(eao_orb* h, hipStream_t st) {
-    if (h->evLastRecorded) EAO_HIP(hipStreamWaitEvent(st, h->evLast, 0));
-    else EAO_HIP(hipDeviceSynchronize());
-    if (orb_last_event_mode() != 0) h->everyCallEvent = true;
-    return EAO_OK;
-}
+namespace eao {
+namespace orb {
 
 // enqueue the whole pipeline for `batch` frames; level 0 is read from `src` (device memory)
 eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long long fs0, int batch, eao_keypoint* d_kps,
@@ -2165,10 +1220,7 @@ eao_status enqueue_direct(eao_orb* h, const uint8_t* d_img, int pitch0, long lon
         const int src0Aligned = ((((uintptr_t)s.img0 | (uintptr_t)s.pitch0 | (uintptr_t)(batch > 1 ? s.fs0 : 0)) & 3) == 0) ? 1 : 0;
         auto quadtree = [&](hipStream_t str, int lFirst, int nLev) {
             eao::Range rg("orb: quad-tree");
-            if (nb < 36) hipLaunchKernelGGL(k_quadtree<kQTSmall>, dim3(nb, nLev), dim3(kQTSmall), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
-                               h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst, h->d_qtnodes.p);
-            else hipLaunchKernelGGL(k_quadtree<kQTLarge>, dim3(nb, nLev), dim3(kQTLarge), h->quadLds, str, h->d_geom.p, h->d_cellcand.p, h->d_cellcnt.p, h->d_cand.p,
-                               h->d_nodeof.p, h->d_levelkps.p, h->d_levelcnt.p, h->d_candcnt.p, f0, h->d_dbg, lFirst, h->d_qtnodes.p);
+            launch_quadtree(h, str, nb, f0, lFirst, nLev);
         };
         // Measured (device-resident step, ms): batch 1: 0.117 fused vs 0.142 chain, 8: 0.136 / 0.160, 32: 0.231 / 0.235, 64: 0.353 /
         // 0.309 -- small batches are bound by the chain of dependent launches, large ones by the VALU, where the fused kernel's
@@ -2392,39 +1444,6 @@ __global__ __launch_bounds__(256) void k_pyramid_export(PyrExportArgs A, ImgSrc 
     *reinterpret_cast<uint4*>(dst + L.dstOff + (long long)row * L.dstPitch + ch * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 }
 
-void stream_release(eao_orb* h) {
-    for (eao_orb::StreamSlot& sl : h->slots) {
-        if (sl.evOut && sl.submitted) (void)hipEventSynchronize(sl.evOut);
-        if (sl.pinIn) (void)hipHostFree(sl.pinIn);
-        if (sl.pinOut) (void)hipHostFree(sl.pinOut);
-        if (sl.dIn) (void)hipFree(sl.dIn);
-        if (sl.dOut) (void)hipFree(sl.dOut);
-        if (sl.evIn) (void)hipEventDestroy(sl.evIn);
-        if (sl.evOut) (void)hipEventDestroy(sl.evOut);
-        if (sl.evDone) (void)hipEventDestroy(sl.evDone);
-    }
-    h->slots.clear();
-    for (hipStream_t* q : {&h->sUp, &h->sRun, &h->sDown})
-        if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
-}
-
-// Readers of the last extraction's products (pyramid levels, candidate taps, the stereo matcher).  After a host-API call (eao_orb_extract / _batch: what the
-// class-surface adapter makes) the products are final when the call returns -- nothing to wait for, and in particular no device-wide synchronise that would
-// make the Tracking thread wait for the LocalMapping thread's bundle adjustment.  Only after a DEVICE-API call on a caller's stream, which
-// the library must not touch again (its owner may have destroyed it, see enqueue_direct) and on which recording an event per call was measured at ~5 us, does
-// the reader drain the device.
-eao_status wait_last_extraction(eao_orb* h) {
-    if (!h->lastComplete) {
-        if (h->evLastRecorded) EAO_HIP(hipEventSynchronize(h->evLast));      // (round 6: the call left its event)
-        else {
-            EAO_HIP(hipDeviceSynchronize());
-            if (orb_last_event_mode() != 0) h->everyCallEvent = true;           // this handle has readers behind device-API calls: later calls leave an event
-        }
-        h->lastComplete = true;
-    }
-    return EAO_OK;
-}
-
 // enqueue the export of frame `frame`'s bordered levels on the handle's stream (no synchronisation); fills h->pyrViews
 eao_status enqueue_pyramid_export(eao_orb* h, int frame, int border) {
     const Geom& g = h->geom;
@@ -2460,262 +1479,11 @@ eao_status enqueue_pyramid_export(eao_orb* h, int frame, int border) {
     return EAO_OK;
 }
 
-// The caller's frames (pageable memory) to h->d_in in the device pitch.  Small uploads -- the per-frame calls -- go through a pinned staging buffer of the handle: the
-// runtime's own path for pageable memory registers the caller's pages with the driver for the duration of the copy, and a registered range that the kernel touches
-// meanwhile (another thread's munmap, page migration) has the driver take every queue of the process off the GPU for a millisecond or more -- one tracked frame in a
-// thousand took 6 - 12 ms beside a looping LocalBundleAdjustment.  The staging copy costs ~15 us per 640 x 480 frame.  EAO_ORB_PINNED_IN=0: the runtime's path (A/B runs).
-constexpr size_t kPinnedInMax = 8u << 20;
-eao_status upload_frames(eao_orb* h, const uint8_t* img, int width, int height, int stride, long long frame_stride, int batch) {
-    const Geom& g = h->geom;
-    const long long fs0 = (long long)g.L[0].pitch * height;
-    const size_t bytes = (size_t)batch * (size_t)fs0;
-    static const bool envNoPinned = getenv("EAO_ORB_PINNED_IN") && !atoi(getenv("EAO_ORB_PINNED_IN"));
-    if (bytes <= kPinnedInMax && !envNoPinned) {
-        if (h->pinUpCap < bytes) {
-            if (h->pinUp) (void)hipHostFree(h->pinUp);
-            h->pinUp = nullptr; h->pinUpCap = 0;
-            EAO_HIP(hipHostMalloc((void**)&h->pinUp, bytes, hipHostMallocDefault));
-            h->pinUpCap = bytes;
-        }
-        if (stride == g.L[0].pitch && (batch == 1 || frame_stride == fs0)) std::memcpy(h->pinUp, img, bytes);
-        else
-            for (int f = 0; f < batch; f++)
-                for (int y = 0; y < height; y++) std::memcpy(h->pinUp + f * fs0 + (size_t)y * g.L[0].pitch, img + (long long)f * frame_stride + (size_t)y * stride, (size_t)width);
-        EAO_HIP(hipMemcpyAsync(h->d_in.p, h->pinUp, bytes, hipMemcpyHostToDevice, h->stream));
-        return EAO_OK;
-    }
-    if (stride == g.L[0].pitch && (batch == 1 || frame_stride == fs0)) {     // contiguous frames: one linear copy
-        EAO_HIP(hipMemcpyAsync(h->d_in.p, img, bytes, hipMemcpyHostToDevice, h->stream));
-    } else {
-        for (int f = 0; f < batch; f++)
-            EAO_HIP(hipMemcpy2DAsync(h->d_in.p + f * fs0, g.L[0].pitch, img + (long long)f * frame_stride, stride, width, height, hipMemcpyHostToDevice, h->stream));
-    }
-    return EAO_OK;
-}
-
-}  // namespace
+}  // namespace orb
+}  // namespace eao
 
 extern "C" {
 
-eao_status eao_orb_create(const eao_orb_cfg* cfg, eao_orb** out) {
-    EAO_REQUIRE(cfg && out, "null argument");
-    EAO_REQUIRE(cfg->nlevels >= 1 && cfg->nlevels <= kMaxLevels, "nlevels must be in 1..%d", kMaxLevels);
-    EAO_REQUIRE(cfg->nfeatures >= 1 && cfg->scale_factor > 1.0f, "need nfeatures >= 1 and scale_factor > 1");
-    eao_status st = eao::require_device();
-    if (st) return st;
-    eao_orb* h = new eao_orb();
-    h->cfg = *cfg;
-    const int nl = cfg->nlevels;
-    const double scaleFactor = cfg->scale_factor;  // the reference keeps this member as a double (include/ORBextractor.h:97)
-    h->scale.resize(nl); h->sigma2.resize(nl); h->invScale.resize(nl); h->invSigma2.resize(nl); h->quota.resize(nl);
-    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
-    for (int i = 1; i < nl; i++) {
-        h->scale[i] = (float)(h->scale[i - 1] * scaleFactor);
-        h->sigma2[i] = h->scale[i] * h->scale[i];
-    }
-    for (int i = 0; i < nl; i++) {
-        h->invScale[i] = 1.0f / h->scale[i];
-        h->invSigma2[i] = 1.0f / h->sigma2[i];
-    }
-    const float factor = (float)(1.0f / scaleFactor);
-    float desired = cfg->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
-    int sum = 0;
-    for (int l = 0; l < nl - 1; l++) {
-        h->quota[l] = cv_round(desired);
-        sum += h->quota[l];
-        desired *= factor;
-    }
-    h->quota[nl - 1] = std::max(cfg->nfeatures - sum, 0);
-    {   // end of each row of the radius-15 disc (reference src/ORBextractor.cc:455-469)
-        const int vmax = (int)std::floor(15 * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(15 * std::sqrt(2.f) / 2);
-        for (int v = 0; v <= vmax; ++v) h->umax[v] = cv_round(std::sqrt(225.0 - v * v));
-        for (int v = 15, v0 = 0; v >= vmin; --v) {
-            while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
-            h->umax[v] = v0;
-            ++v0;
-        }
-    }
-    {
-        const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-        for (int i = 0; i < 16; i++)
-            if (h->umax[i] != expect[i]) { delete h; eao::set_error("umax table mismatch"); return EAO_ERR_INTERNAL; }
-    }
-    *out = h;
-    return EAO_OK;
-}
-
-void eao_orb_destroy(eao_orb* h) {
-    if (!h) return;
-    for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    for (int i = 0; i < eao_orb::kLanes; i++) {
-        if (h->laneMain[i]) { (void)hipStreamSynchronize(h->laneMain[i]); (void)hipStreamDestroy(h->laneMain[i]); }
-        if (h->laneSide[i]) { (void)hipStreamSynchronize(h->laneSide[i]); (void)hipStreamDestroy(h->laneSide[i]); }
-        if (h->evFork[i]) (void)hipEventDestroy(h->evFork[i]);
-        if (h->evFast0[i]) (void)hipEventDestroy(h->evFast0[i]);
-        if (h->evMid[i]) (void)hipEventDestroy(h->evMid[i]);
-        if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
-        if (h->evDone[i]) (void)hipEventDestroy(h->evDone[i]);
-    }
-    if (h->pinOut) (void)hipHostFree(h->pinOut);
-    if (h->pinUp) (void)hipHostFree(h->pinUp);
-    if (h->pinPyr) (void)hipHostFree(h->pinPyr);
-    stream_release(h);
-    if (h->evStart) (void)hipEventDestroy(h->evStart);
-    if (h->evLast) (void)hipEventDestroy(h->evLast);
-    if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
-    delete h;
-}
-
-eao_status eao_orb_tables(const eao_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* fpl) {
-    EAO_REQUIRE(h, "null handle");
-    for (int i = 0; i < h->cfg.nlevels; i++) {
-        if (scale) scale[i] = h->scale[i];
-        if (inv_scale) inv_scale[i] = h->invScale[i];
-        if (sigma2) sigma2[i] = h->sigma2[i];
-        if (inv_sigma2) inv_sigma2[i] = h->invSigma2[i];
-        if (fpl) fpl[i] = h->quota[i];
-    }
-    return EAO_OK;
-}
-
-eao_status eao_orb_max_keypoints(eao_orb* h, int32_t width, int32_t height, int32_t* cap) {
-    EAO_REQUIRE(h && cap, "null argument");
-    eao_status st = ensure(h, width, height, 0);
-    if (st) return st;
-    *cap = h->geom.totalKpCap;
-    return EAO_OK;
-}
-
-eao_status eao_orb_extract_batch_device(eao_orb* h, const uint8_t* d_img, int32_t width, int32_t height, int32_t stride,
-                                        int64_t frame_stride, int32_t batch, eao_keypoint* d_kps, uint8_t* d_desc, int32_t cap,
-                                        int32_t* d_n, void* stream) {
-    EAO_REQUIRE(h && d_img && d_kps && d_desc && d_n, "null argument");
-    EAO_REQUIRE(width > 0 && height > 0 && stride >= width && batch >= 1, "bad image geometry");
-    eao_status st = ensure(h, width, height, batch, (hipStream_t)stream);
-    if (st) return st;
-    if (cap < h->geom.totalKpCap) {
-        eao::set_error("cap %d < eao_orb_max_keypoints %d", cap, h->geom.totalKpCap);
-        return EAO_ERR_CAPACITY;
-    }
-    // exactly the caller's stream: NULL is the (legacy) null stream, as in the Hamming entry points -- torch's default stream
-    // among others; work the caller enqueues behind this call on that stream is ordered behind the extraction
-    return enqueue(h, d_img, stride, frame_stride, batch, d_kps, d_desc, cap, d_n, (hipStream_t)stream);
-}
-
-eao_status eao_orb_extract_batch(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, int64_t frame_stride,
-                                 int32_t batch, eao_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n) {
-    EAO_REQUIRE(h && n, "null argument");
-    if (!img || width <= 0 || height <= 0) {  // empty image: outputs untouched (reference :1046-1047)
-        for (int f = 0; f < std::max(batch, 0); f++) n[f] = 0;
-        return EAO_OK;
-    }
-    EAO_REQUIRE(kps && desc && stride >= width && batch >= 1, "bad argument");
-    eao_status st = ensure(h, width, height, batch);
-    if (st) return st;
-    const Geom& g = h->geom;
-    if (cap < g.totalKpCap) {
-        eao::set_error("cap %d < eao_orb_max_keypoints %d", cap, g.totalKpCap);
-        return EAO_ERR_CAPACITY;
-    }
-    const size_t B = batch;
-    if ((st = h->d_in.reserve(B * (size_t)g.L[0].pitch * height))) return st;
-    if ((st = h->d_kps.reserve(B * (size_t)cap))) return st;
-    if ((st = h->d_desc.reserve(B * (size_t)cap * 32))) return st;
-    if ((st = h->d_nout.reserve(B))) return st;
-    const long long fs0 = (long long)g.L[0].pitch * height;
-    if ((st = upload_frames(h, img, width, height, stride, frame_stride, batch))) return st;
-    // Small calls (the per-frame latency path): the last kernel writes keypoints, descriptors and counts straight into mapped
-    // pinned host memory -- ~70 KB per frame over PCIe -- and the rows that exist are copied to the caller's (pageable) arrays
-    // after the one synchronisation: three pageable device-to-host copies (~15 us each) gone.  Large batches keep the DMA path.
-    const size_t outBytes = B * sizeof(int) + 64 + B * (size_t)cap * (sizeof(eao_keypoint) + 32);
-    static const bool envNoPinned = getenv("EAO_ORB_PINNED_OUT") && !atoi(getenv("EAO_ORB_PINNED_OUT"));      // (A/B switch)
-    if (outBytes <= kPinnedOutMax && !envNoPinned) {
-        if (h->pinOutCap < outBytes) {
-            if (h->pinOut) (void)hipHostFree(h->pinOut);
-            h->pinOut = nullptr; h->pinOutCap = 0;
-            EAO_HIP(hipHostMalloc((void**)&h->pinOut, outBytes, hipHostMallocMapped));
-            h->pinOutCap = outBytes;
-        }
-        unsigned char* dv = nullptr;
-        EAO_HIP(hipHostGetDevicePointer((void**)&dv, h->pinOut, 0));
-        const size_t offK = (B * sizeof(int) + 63) & ~(size_t)63, offD = offK + B * (size_t)cap * sizeof(eao_keypoint);
-        st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, batch, (eao_keypoint*)(dv + offK), dv + offD, cap, (int*)dv, h->stream);
-        if (st) return st;
-        EAO_HIP(eao::wait_latency(h->stream));
-        h->lastComplete = true;
-        const int* hn = (const int*)h->pinOut;
-        for (int f = 0; f < batch; f++) {
-            const int nf = std::min(std::max(hn[f], 0), cap);
-            n[f] = nf;
-            std::memcpy(kps + (size_t)f * cap, h->pinOut + offK + (size_t)f * cap * sizeof(eao_keypoint), (size_t)nf * sizeof(eao_keypoint));
-            std::memcpy(desc + (size_t)f * cap * 32, h->pinOut + offD + (size_t)f * cap * 32, (size_t)nf * 32);
-        }
-        return EAO_OK;
-    }
-    st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, batch, h->d_kps.p, h->d_desc.p, cap, h->d_nout.p, h->stream);
-    if (st) return st;
-    EAO_HIP(hipMemcpyAsync(n, h->d_nout.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    EAO_HIP(hipMemcpyAsync(kps, h->d_kps.p, B * cap * sizeof(eao_keypoint), hipMemcpyDeviceToHost, h->stream));
-    EAO_HIP(hipMemcpyAsync(desc, h->d_desc.p, B * (size_t)cap * 32, hipMemcpyDeviceToHost, h->stream));
-    EAO_HIP(eao::wait_latency(h->stream));
-    h->lastComplete = true;
-    return EAO_OK;
-}
-
-eao_status eao_orb_extract(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, eao_keypoint* kps,
-                           uint8_t* desc, int32_t cap, int32_t* n) {
-    return eao_orb_extract_batch(h, img, width, height, stride, 0, 1, kps, desc, cap, n);
-}
-
-// ---- streaming host API ------------------------------------------------------------------------------------------------
-// What a sequence reader / Tracking thread feeds are HOST images (src/Frame.cc:616-622 behind the Frame constructors,
-// src/Frame.cc:192-194).  eao_orb_extract_batch serves one call at a time from pageable memory: upload, extraction and download
-// follow each other (0.83 ms per 64 frames against 0.26 ms of extraction).  Here the handle owns a ring of PINNED slots: the
-// producer writes frames straight into a slot (a decoder's / camera driver's output buffer; cv::Mat can wrap it), submit() is
-// asynchronous, and the upload of slot k + 1 and the download of slot k - 1 overlap the extraction of slot k on three streams.
-// Results are identical to eao_orb_extract_batch's (tests/test_gpu_orb.py).
-eao_status eao_orb_stream_create(eao_orb* h, int32_t width, int32_t height, int32_t batch, int32_t nslots) {
-    EAO_REQUIRE(h && width > 0 && height > 0 && batch >= 1 && nslots >= 1 && nslots <= 8, "bad argument (1..8 slots)");
-    eao_status st = ensure(h, width, height, batch);
-    if (st) return st;
-    stream_release(h);
-    const Geom& g = h->geom;
-    h->sW = width; h->sH = height; h->sB = batch; h->sCap = g.totalKpCap; h->sPitch = g.L[0].pitch;
-    const size_t B = batch, cap = h->sCap;
-    h->sInBytes = B * (size_t)h->sPitch * height;
-    h->sOffK = (B * sizeof(int) + 255) & ~(size_t)255;
-    h->sOffD = (h->sOffK + B * cap * sizeof(eao_keypoint) + 255) & ~(size_t)255;
-    h->sOutBytes = (h->sOffD + B * cap * 32 + 15) & ~(size_t)15;
-    // Three plain streams.  HIP maps streams onto a few hardware queues and streams that share one run in submission order: with the
-    // handle's eight unused lane streams in the way the upload stream shared a queue with the extraction's side stream and the next
-    // slot's upload started ~100 us into the current extraction (0.50 ms per 64 frames instead of 0.42; the lane streams are now
-    // created on demand).  Stream PRIORITIES make it worse on this runtime (upload high: 0.44; download or extraction low: 0.83-0.88).
-    EAO_HIP(eao::create_stream(&h->sUp, eao::StreamClass::Latency));
-    EAO_HIP(eao::create_stream(&h->sRun, eao::StreamClass::Latency));
-    EAO_HIP(eao::create_stream(&h->sDown, eao::StreamClass::Latency));
-    h->slots.resize(nslots);
-    for (eao_orb::StreamSlot& sl : h->slots) {
-        EAO_HIP(hipHostMalloc((void**)&sl.pinIn, h->sInBytes, hipHostMallocDefault));
-        EAO_HIP(hipHostMalloc((void**)&sl.pinOut, h->sOutBytes, hipHostMallocMapped));
-        EAO_HIP(hipHostGetDevicePointer((void**)&sl.pinOutDev, sl.pinOut, 0));
-        EAO_HIP(hipMalloc((void**)&sl.dIn, h->sInBytes));
-        EAO_HIP(hipMalloc((void**)&sl.dOut, h->sOutBytes));
-        EAO_HIP(hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming));
-        EAO_HIP(hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
-        EAO_HIP(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
-        std::memset(sl.pinOut, 0, h->sOutBytes);
-    }
-    return EAO_OK;
-}
-
-eao_status eao_orb_stream_slot(eao_orb* h, int32_t slot, eao_orb_slot* out) {
-    EAO_REQUIRE(h && out && slot >= 0 && slot < (int)h->slots.size(), "no such slot (eao_orb_stream_create first)");
-    const eao_orb::StreamSlot& sl = h->slots[slot];
-    out->frames = sl.pinIn; out->stride = h->sPitch; out->frame_stride = (int64_t)h->sPitch * h->sH;
-    out->n = (int32_t*)sl.pinOut; out->kps = (eao_keypoint*)(sl.pinOut + h->sOffK); out->desc = sl.pinOut + h->sOffD; out->cap = h->sCap;
-    return EAO_OK;
-}
 
 eao_status eao_orb_stream_submit(eao_orb* h, int32_t slot, int32_t batch) {
     EAO_REQUIRE(h && slot >= 0 && slot < (int)h->slots.size(), "no such slot (eao_orb_stream_create first)");
@@ -2747,91 +1515,6 @@ eao_status eao_orb_stream_submit(eao_orb* h, int32_t slot, int32_t batch) {
     return EAO_OK;
 }
 
-eao_status eao_orb_stream_wait(eao_orb* h, int32_t slot) {
-    EAO_REQUIRE(h && slot >= 0 && slot < (int)h->slots.size(), "no such slot (eao_orb_stream_create first)");
-    eao_orb::StreamSlot& sl = h->slots[slot];
-    EAO_REQUIRE(sl.submitted, "slot %d was not submitted", slot);
-    EAO_HIP(hipEventSynchronize(sl.evOut));
-    EAO_HIP(hipGetLastError());
-    return EAO_OK;
-}
-
-eao_status eao_orb_level(eao_orb* h, int32_t frame, int32_t level, int32_t which, int32_t* w, int32_t* hgt, uint8_t* dst) {
-    EAO_REQUIRE(h && h->geomValid && h->lastBatch > 0, "no extraction has run on this handle");
-    EAO_REQUIRE(frame >= 0 && frame < h->lastBatch && level >= 0 && level < h->geom.nlevels, "frame/level out of range");
-    const LevelGeom& L = h->geom.L[level];
-    if (w) *w = L.w;
-    if (hgt) *hgt = L.h;
-    if (!dst) return EAO_OK;
-    const uint8_t* src;
-    int pitch;
-    if (which == 0 && level == 0) {
-        src = h->lastSrc.img0 + (long long)frame * h->lastSrc.fs0;
-        pitch = h->lastSrc.pitch0;
-    } else {
-        src = (which ? h->d_blur.p : h->d_pyr.p) + (long long)frame * h->geom.pyrFrameBytes + L.off;
-        pitch = L.pitch;
-    }
-    eao_status st = wait_last_extraction(h);
-    if (st) return st;
-    EAO_HIP(hipMemcpy2DAsync(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost, h->stream));
-    EAO_HIP(eao::wait_latency(h->stream));
-    return EAO_OK;
-}
-
-eao_status eao_orb_pyramid(eao_orb* h, int32_t frame, int32_t border, eao_orb_level_view* levels) {
-    EAO_REQUIRE(h && levels && h->geomValid && h->lastBatch > 0, "no extraction has run on this handle");
-    EAO_REQUIRE(frame >= 0 && frame < h->lastBatch && border >= 0 && border <= 64, "frame / border out of range");
-    if (!(h->lastComplete && h->pyrFrame == frame && h->pyrBorder == border)) {      // (else: exported behind the extraction itself, eao_orb_set_keep_pyramid)
-        eao_status st = wait_last_extraction(h);
-        if (!st) st = enqueue_pyramid_export(h, frame, border);
-        if (st) return st;
-        EAO_HIP(eao::wait_latency(h->stream));
-        EAO_HIP(hipGetLastError());
-    }
-    for (int l = 0; l < h->geom.nlevels; l++) levels[l] = h->pyrViews[l];
-    return EAO_OK;
-}
-
-eao_status eao_orb_set_keep_pyramid(eao_orb* h, int32_t border) {
-    EAO_REQUIRE(h && border >= -1 && border <= 64, "border: -1 (off) .. 64");
-    h->autoPyrBorder = border;
-    return EAO_OK;
-}
-
-eao_status eao_orb_extract_ref(eao_orb* h, const uint8_t* img, int32_t width, int32_t height, int32_t stride, const eao_keypoint** kps,
-                               const uint8_t** desc, int32_t* n) {
-    EAO_REQUIRE(h && kps && desc && n, "null argument");
-    *kps = nullptr; *desc = nullptr; *n = 0;
-    if (!img || width <= 0 || height <= 0) return EAO_OK;      // empty image, as eao_orb_extract
-    EAO_REQUIRE(stride >= width, "bad argument");
-    eao_status st = ensure(h, width, height, 1);
-    if (st) return st;
-    const Geom& g = h->geom;
-    const int cap = g.totalKpCap;
-    const size_t offK = 64, offD = offK + (size_t)cap * sizeof(eao_keypoint), outBytes = offD + (size_t)cap * 32;
-    if (h->pinOutCap < outBytes) {
-        if (h->pinOut) (void)hipHostFree(h->pinOut);
-        h->pinOut = nullptr; h->pinOutCap = 0;
-        EAO_HIP(hipHostMalloc((void**)&h->pinOut, outBytes, hipHostMallocMapped));
-        h->pinOutCap = outBytes;
-    }
-    unsigned char* dv = nullptr;
-    EAO_HIP(hipHostGetDevicePointer((void**)&dv, h->pinOut, 0));
-    if ((st = h->d_in.reserve((size_t)g.L[0].pitch * height))) return st;
-    const long long fs0 = (long long)g.L[0].pitch * height;
-    if ((st = upload_frames(h, img, width, height, stride, 0, 1))) return st;
-    st = enqueue(h, h->d_in.p, g.L[0].pitch, fs0, 1, (eao_keypoint*)(dv + offK), dv + offD, cap, (int*)dv, h->stream);
-    if (st) return st;
-    if (h->autoPyrBorder >= 0 && (st = enqueue_pyramid_export(h, 0, h->autoPyrBorder))) return st;      // same stream, same synchronisation
-    EAO_HIP(eao::wait_latency(h->stream));
-    h->lastComplete = true;
-    *n = std::min(std::max(*(const int*)h->pinOut, 0), cap);
-    *kps = (const eao_keypoint*)(h->pinOut + offK);
-    *desc = h->pinOut + offD;
-    return EAO_OK;
-}
-
 eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, float* xyr, int32_t cap, int32_t* n) {
     EAO_REQUIRE(h && n && h->geomValid && h->lastBatch > 0, "no extraction has run on this handle");
     EAO_REQUIRE(frame >= 0 && frame < h->lastBatch && level >= 0 && level < h->geom.nlevels, "frame/level out of range");
@@ -2850,45 +1533,6 @@ eao_status eao_orb_level_candidates(eao_orb* h, int32_t frame, int32_t level, fl
                        h->d_cand.p + (long long)frame * g.totalCandCap + g.L[level].candBase, m, h->d_xyr.p);
     EAO_HIP(hipMemcpyAsync(xyr, h->d_xyr.p, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     EAO_HIP(eao::wait_latency(h->stream));
-    return EAO_OK;
-}
-
-int32_t eao_orb_lanes(int32_t batch) { return batch < eao_orb::kLanes ? (batch > 0 ? batch : 1) : eao_orb::kLanes; }
-
-eao_status eao_orb_set_profiling(eao_orb* h, int32_t on) {
-    EAO_REQUIRE(h, "null handle");
-    h->profiling = on != 0;
-    h->evUsed = 0;
-    return EAO_OK;
-}
-
-eao_status eao_orb_last_timing(eao_orb* h, float ms[6]) {
-    EAO_REQUIRE(h && ms && h->evUsed >= kProfEvents, "no profiled call since eao_orb_set_profiling(h, 1)");
-    const size_t calls = h->evUsed / kProfEvents;
-    EAO_HIP(hipEventSynchronize(h->evs[h->evUsed - kProfEvents + 8]));   // ev[8] of the last call
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (size_t c = 0; c < calls; c++) {
-        hipEvent_t* ev = &h->evs[c * kProfEvents];
-        float t;
-        // stage intervals of slice 0 (one of the concurrently running sub-batches)
-        EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[1])); acc[0] += t;   // pyramid
-        EAO_HIP(hipEventElapsedTime(&t, ev[9], ev[2])); acc[1] += t;   // FAST (after the blur of a profiled call)
-        EAO_HIP(hipEventElapsedTime(&t, ev[2], ev[3])); acc[2] += t;   // quad-tree
-        EAO_HIP(hipEventElapsedTime(&t, ev[6], ev[7])); acc[3] += t;   // blur, side stream
-        EAO_HIP(hipEventElapsedTime(&t, ev[4], ev[5])); acc[4] += t;   // orientation + description
-        EAO_HIP(hipEventElapsedTime(&t, ev[0], ev[8])); acc[5] += t;   // whole batch
-    }
-    for (int i = 0; i < 6; i++) ms[i] = (float)(acc[i] / calls);
-    h->evUsed = 0;
-    if (h->d_dbg) {
-        long long st[16 * kMaxLevels];
-        EAO_HIP(hipMemcpy(st, h->d_dbg, sizeof(st), hipMemcpyDeviceToHost));
-        for (int l = 0; l < h->geom.nlevels; l++) {
-            const long long* o = st + 16 * l;
-            fprintf(stderr, "[eao quadtree stamps] level %d: M %lld S %lld passes %lld | setup %lld | multi-scan %lld hist %lld order %lld growth %lld rank %lld newlist %lld rehome %lld tail %lld | final %lld cycles\n",
-                    l, o[10], o[11], o[9], o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], 0LL, o[8]);
-        }
-    }
     return EAO_OK;
 }
 
@@ -2959,5 +1603,4 @@ eao_status eao_compute_stereo_matches(eao_orb* left, eao_orb* right, int32_t fra
     }
     return EAO_OK;
 }
-
 }  // extern "C"

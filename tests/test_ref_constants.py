@@ -50,7 +50,7 @@ def _code_lines(path):
 
 CONSUMERS = {
     "product": ["eao_fusion_amd/csrc/pose.hip", "eao_fusion_amd/csrc/lba.hip", "eao_fusion_amd/csrc/gba.hip", "eao_fusion_amd/csrc/lm_host.hip", "eao_fusion_amd/csrc/lm_internal.h", "eao_fusion_amd/csrc/match.hip", "eao_fusion_amd/csrc/search.hip", "eao_fusion_amd/csrc/track.hip",
-                "eao_fusion_amd/csrc/orb.hip", "eao_fusion_amd/csrc/chain_internal.h", "eao_fusion_amd/csrc/frame.hip", "eao_fusion_amd/csrc/hamming.hip"],
+                "eao_fusion_amd/csrc/orb.hip", "eao_fusion_amd/csrc/orb_internal.h", "eao_fusion_amd/csrc/orb_host.hip", "eao_fusion_amd/csrc/orb_quadtree.hip", "eao_fusion_amd/csrc/chain_internal.h", "eao_fusion_amd/csrc/frame.hip", "eao_fusion_amd/csrc/hamming.hip"],
     "oracle": ["oracle/lm_cpu.cpp", "oracle/match_cpu.cpp", "oracle/search_cpu.cpp", "oracle/orb_cpu.cpp", "oracle/frame_cpu.cpp"],
 }
 # literals that can only be one of the reference's constants (a bare 10 or 100 can be anything; these cannot)
@@ -82,7 +82,9 @@ def test_no_literal_copies_beside_the_generated_header(who):
                                                    "RADIUS_WIDE"]),
     ("oracle", "oracle/search_cpu.cpp", ["TH_HIGH", "TH_LOW", "HISTO_LENGTH", "EPIPOLAR_CHI2", "FUSE_CHI2_MONO", "FUSE_CHI2_STEREO"]),
     ("product", "eao_fusion_amd/csrc/track.hip", ["TH_HIGH", "HISTO_LENGTH"]),
-    ("product", "eao_fusion_amd/csrc/orb.hip", ["TH_HIGH", "EDGE_THRESHOLD", "FAST_CELL", "PATCH_SIZE"]),
+    ("product", "eao_fusion_amd/csrc/orb.hip", ["TH_HIGH"]),
+    ("product", "eao_fusion_amd/csrc/orb_internal.h", ["EDGE_THRESHOLD"]),
+    ("product", "eao_fusion_amd/csrc/orb_host.hip", ["FAST_CELL", "PATCH_SIZE"]),
     ("oracle", "oracle/orb_cpu.cpp", ["TH_HIGH", "EDGE_THRESHOLD", "FAST_CELL", "PATCH_SIZE", "HALF_PATCH_SIZE"]),
 ])
 def test_consumers_name_the_constants(who, rel, names):

@@ -39,7 +39,7 @@ def sha16(rel):
     return hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest()[:16]
 
 
-SRC = {rel: sha16(rel) for rel in ("eao_fusion_amd/csrc/orb.hip", "eao_fusion_amd/csrc/hamming.hip", "eao_fusion_amd/csrc/lm_internal.h", "eao_fusion_amd/csrc/lba.hip", "eao_fusion_amd/csrc/gba.hip", "eao_fusion_amd/csrc/lm_host.hip")}      # what bench.py checks before it derives anything
+SRC = {rel: sha16(rel) for rel in ("eao_fusion_amd/csrc/orb.hip", "eao_fusion_amd/csrc/orb_internal.h", "eao_fusion_amd/csrc/hamming.hip", "eao_fusion_amd/csrc/lm_internal.h", "eao_fusion_amd/csrc/lba.hip", "eao_fusion_amd/csrc/gba.hip", "eao_fusion_amd/csrc/lm_host.hip")}      # what bench.py checks before it derives anything
 a, b, h = load(R + "_sq_a"), load(R + "_sq_b"), load(R + "_sq_h")
 fe, wr = load(R + "_fetch"), load(R + "_write")
 batch = int(os.environ.get("EAO_PMC_BATCH", "64"))
