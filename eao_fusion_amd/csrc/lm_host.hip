@@ -1042,8 +1042,13 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     const double tPrep = ms();
     if ((st = j.L.attributes())) return st;
     j.L.setup();
+    static const bool wallStamps = getenv("EAO_BA_WALL_STAMPS") != nullptr;
+    static const bool spin = getenv("EAO_BA_SPIN") && atoi(getenv("EAO_BA_SPIN"));
+    double tEnq = 0;
     if (j.chained) {
         j.L.chain(mode, p->its_first, p->its_second);
+        tEnq = ms();
+        if (spin) while (hipStreamQuery(c.stream) == hipErrorNotReady) {}
         EAO_HIP(hipStreamSynchronize(c.stream));
     }
     const double tSetup = ms();
@@ -1051,6 +1056,7 @@ static eao_status ba_run(const eao_ba_problem* p, const volatile uint8_t* stop, 
     EAO_HIP(hipEventRecord(c.ev1, c.stream));
     EAO_HIP(hipStreamSynchronize(c.stream));
     EAO_HIP(hipEventElapsedTime(&g_trace.deviceMs, c.ev0, c.ev1));
+    if (wallStamps && !j.L.d.bigPath) fprintf(stderr, "[eao window wall] prepare %.3f, enqueue %.3f, wait %.3f, takeovers + results %.3f ms; whole call %.3f ms\n", tPrep, tEnq - tPrep, tSetup - tEnq, ms() - tSetup, ms());
     if (hostStamps && j.L.d.bigPath) fprintf(stderr, "[eao map-scale wall] prepare %.3f, set-up launches (+ chain) %.3f, iterations + results %.3f ms; whole call %.3f ms\n", tPrep, tSetup - tPrep, ms() - tSetup, ms());
     return EAO_OK;
 }

@@ -40,9 +40,24 @@ template <class... A> eao_status sbp_frames(A... a) { Scope s; return ::eao_sear
 template <class... A> eao_status sbow(A... a) { Scope s; return ::eao_search_by_bow(a...); }
 template <class... A> eao_status pose(A... a) { Scope s; return ::eao_pose_optimization(a...); }
 static bool stub_lba = false;      // `adapter_bench problem.bin lba-walk`: the library call replaced by an identity result -- the adapter's own walk, timed on a box without a GPU
+static int lba_points = 0, lba_edges = 0;      // what the adapter handed over: the points the LOCAL keyframes see (upstream's window), a little less than the generator's map
 inline eao_status lba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r) {
+    lba_points = p->n_points; lba_edges = p->n_edges;
     Scope s;
     if (!stub_lba) return ::eao_local_ba(p, stop, r);
+    if (const char* dump = std::getenv("EAO_WALK_DUMP")) {      // tests/test_adapter_walk_cpu.py: the problem the adapter hands to the library, once
+        static bool done = false;
+        if (!done) {
+            done = true;
+            std::ofstream f(dump, std::ios::binary);
+            const int32_t hdr[3] = {p->n_cams, p->n_points, p->n_edges};
+            f.write((const char*)hdr, sizeof hdr);
+            f.write((const char*)p->cam_Tcw, sizeof(float) * 16 * (size_t)p->n_cams); f.write((const char*)p->cam_fixed, (size_t)p->n_cams);
+            f.write((const char*)p->points, sizeof(float) * 3 * (size_t)p->n_points);
+            f.write((const char*)p->edge_cam, sizeof(int32_t) * (size_t)p->n_edges); f.write((const char*)p->edge_point, sizeof(int32_t) * (size_t)p->n_edges);
+            f.write((const char*)p->edge_obs, sizeof(float) * 3 * (size_t)p->n_edges); f.write((const char*)p->edge_inv_sigma2, sizeof(float) * (size_t)p->n_edges);
+        }
+    }
     std::memcpy(r->cam_Tcw, p->cam_Tcw, sizeof(float) * 16 * (size_t)p->n_cams);
     std::memcpy(r->points, p->points, sizeof(float) * 3 * (size_t)p->n_points);
     std::memset(r->edge_outlier, 0, (size_t)p->n_edges);
@@ -174,7 +189,7 @@ int main(int argc, char** argv) {
     g_lbaOnly = cabi::stub_lba || (argc > 2 && std::string(argv[2]) == "lba");
     std::ifstream in(argv[1], std::ios::binary);
     if (!in) return 2;
-    char more[256];
+    char more[384];
     std::printf("{\n");
     // ------------------------------------------------------------------ ORBextractor::operator(), as Frame::ExtractORB calls it
     int32_t H, W;
@@ -281,8 +296,8 @@ int main(int argc, char** argv) {
             sink = acc;
         };
         const Stat fl = measure(3, 15, build, floor_walk);
-        std::snprintf(more, sizeof more, "\"keyframes\": %d, \"map_points\": %d, \"edges\": %d, \"reference_accessor_walk_ms\": %.4f, \"adapter_overhead_beyond_accessor_walk_ms\": %.4f", nc, np, ne,
-                      fl.call_ms, s.call_ms - s.cabi_ms - fl.call_ms);
+        std::snprintf(more, sizeof more, "\"keyframes\": %d, \"map_points\": %d, \"edges\": %d, \"window_points\": %d, \"window_edges\": %d, \"reference_accessor_walk_ms\": %.4f, \"adapter_overhead_beyond_accessor_walk_ms\": %.4f", nc, np, ne,
+                      cabi::lba_points, cabi::lba_edges, fl.call_ms, s.call_ms - s.cabi_ms - fl.call_ms);
         emit("local_bundle_adjustment", s, more);
         g_inLba = false;
     }

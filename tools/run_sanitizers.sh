@@ -6,10 +6,10 @@
 # Round 4: the HOST half of the product's guided searches (eao_fusion_amd/csrc/search.hip: per-query geometry + the selection loops of all eleven searches, driven
 # by caller-supplied indices) is part of the pass -- tests/test_host_replay_cpu.py builds it as plain C++ with the same flags (EAO_HOST_SAN=1) against the oracle's
 # candidate lists and runs the parity and the malformed-input cases under ASan + UBSan.
-# Usage: bash tools/run_sanitizers.sh   [round]  -> profiles/<round>_sanitizers_cpu.txt (default r05)
+# Usage: bash tools/run_sanitizers.sh   [round]  -> profiles/<round>_sanitizers_cpu.txt (default r06)
 set -u
 cd "$(dirname "$0")/.."
-OUT=profiles/${1:-r05}_sanitizers_cpu.txt
+OUT=profiles/${1:-r06}_sanitizers_cpu.txt
 TMP=$(mktemp -d)
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1"
 {
@@ -50,5 +50,17 @@ for name, srcs, incs in jobs:
 sys.exit(bad)
 PY
 echo "compile exit code: $?"
+echo "== 4. the LocalBundleAdjustment adapter's walk RUN under ASan + UBSan (tests/cpp/adapter_bench.cpp lba-walk: the library call replaced by an identity result -- no GPU needed), unedited MapPoint and the row-2c accessors"
+python - <<PY
+import sys; sys.path.insert(0, ".")
+import bench
+from eao_fusion_amd import synth
+bench.class_surface_problem("$TMP/problem.bin", synth)
+PY
+for V in "" "-DEAO_BENCH_EDITED_MAPPOINT"; do
+  g++ -std=c++17 -DEAOFUSION_FORCE_CV_COMPAT $V $SAN -I include tests/cpp/adapter_bench.cpp -o $TMP/adapter_bench_san -L eao_fusion_amd -leaofusion_hip -Wl,-rpath,$PWD/eao_fusion_amd -Wl,-rpath,/opt/rocm/lib -pthread 2>&1 | grep -E "error|warning" | head -5
+  ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 $TMP/adapter_bench_san $TMP/problem.bin lba-walk | grep -o '"call_ms": [0-9.]*' | head -1
+  echo "adapter_bench lba-walk ${V:-(unedited MapPoint)} exit code: ${PIPESTATUS[0]}"
+done
 } 2>&1 | tee $OUT
 rm -rf $TMP
