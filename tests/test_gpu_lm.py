@@ -558,6 +558,31 @@ def test_map_scale_set_up_on_the_host_crew(gpu, oracle, kw, monkeypatch):
     assert _same_result(single, batch[1])
 
 
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_map_scale_set_up_refuses_bad_edge_lists_the_same_way_on_any_crew(gpu, threads, monkeypatch):
+    """Round 6: the validation pass of a map-scale call runs in chunks on a crew session.  What it refuses -- an index out of range, two edges between one camera and one
+    point -- and the words it refuses them with must not depend on the crew; an edge list that is NOT grouped by landmark falls back to the serial walks and gives the
+    result of its ordered twin (edge order only permutes the sums inside one landmark's and one camera's lists: same bits is not promised, the same LM trace is)."""
+    monkeypatch.setenv("EAO_BA_SETUP_THREADS", threads)
+    p = synth.synth_ba(n_free=45, n_fixed=2, n_points=1800, seed=5750)
+    bad = dict(p); ec = p["edge_cam"].copy(); ec[1234] = len(p["poses"]); bad["edge_cam"] = ec
+    with pytest.raises(Exception, match="edge 1234 out of range"):
+        gpu.Optimizer.BundleAdjustment(bad, 3, bRobust=False)
+    bad = dict(p); ep = p["edge_point"].copy(); ep[0] = -1; bad["edge_point"] = ep
+    with pytest.raises(Exception, match="edge 0 out of range"):
+        gpu.Optimizer.BundleAdjustment(bad, 3, bRobust=False)
+    e = 4321
+    dup = dict(p)
+    for k in ("edge_cam", "edge_point", "obs", "inv_sigma2"):
+        dup[k] = np.ascontiguousarray(np.insert(p[k], e + 1, p[k][e], axis=0))
+    with pytest.raises(Exception, match="two edges join camera %d and point %d" % (p["edge_cam"][e], p["edge_point"][e])):
+        gpu.Optimizer.BundleAdjustment(dup, 3, bRobust=False)
+    q, _ = _shuffle_edges(p, 5750)
+    a, b = gpu.Optimizer.BundleAdjustment(p, 4, bRobust=False), gpu.Optimizer.BundleAdjustment(q, 4, bRobust=False)
+    assert list(a["iters"]) == list(b["iters"]) and list(a["trace"]["trials"]) == list(b["trace"]["trials"])
+    assert np.allclose(a["points"], b["points"], rtol=0, atol=1e-5) and np.allclose(a["poses"], b["poses"], rtol=0, atol=1e-5)
+
+
 def test_two_map_scale_windows_in_one_batch(tmp_path):
     """Round 5 regression: the host-side panel tables of a map-scale window (which panel launches which work records) were thread-local to the set-up worker; a second
     map-scale window prepared by the SAME worker overwrote them before the first window's launches were enqueued, and the first window silently ran with the second

@@ -53,6 +53,6 @@ f=$(find $GB -name "*kernel_stats.csv" | head -1); python3 tools/summarize_rocpr
 EAO_DEBUG_STAMPS=1 EAO_DBG_ORACLE=0 python3 tools/dbg_gba_banded.py 2>&1 | grep -E 'map-scale plan|host set-up|map-scale wall|banded GBA' | cut -c1-420 > $O/${R}_gba_banded_host_stamps.txt
 EAO_BA_ND=1 EAO_DEBUG_STAMPS=1 EAO_DBG_ORACLE=0 python3 tools/dbg_gba_banded.py 2>&1 | grep -E 'map-scale plan|map-scale wall|banded GBA' | cut -c1-420 > $O/${R}_gba_banded_natural_order.txt
 EAO_DEBUG_STAMPS=1 EAO_DBG_ORACLE=0 python3 tools/dbg_gba.py 2>&1 | grep -E 'map-scale plan|host set-up|map-scale wall|^GBA' | cut -c1-420 > $O/${R}_gba_host_stamps.txt
-tail -3 $O/${R}_gba_host_stamps.txt $O/${R}_gba_banded_host_stamps.txt | cut -c1-300
+tail -n 3 $O/${R}_gba_host_stamps.txt $O/${R}_gba_banded_host_stamps.txt | cut -c1-300
 # 8. the GPU suite's log
 python3 -m pytest tests -m gpu -q > $O/${R}_gputests.log 2>&1; tail -3 $O/${R}_gputests.log
