@@ -580,7 +580,8 @@ def test_map_scale_set_up_refuses_bad_edge_lists_the_same_way_on_any_crew(gpu, t
     q, _ = _shuffle_edges(p, 5750)
     a, b = gpu.Optimizer.BundleAdjustment(p, 4, bRobust=False), gpu.Optimizer.BundleAdjustment(q, 4, bRobust=False)
     assert list(a["iters"]) == list(b["iters"]) and list(a["trace"]["trials"]) == list(b["trace"]["trials"])
-    assert np.allclose(a["points"], b["points"], rtol=0, atol=1e-5) and np.allclose(a["poses"], b["poses"], rtol=0, atol=1e-5)
+    _check_updates(b["poses"], a["poses"], p["poses"], "poses")
+    _check_updates(b["points"], a["points"], p["points"], "points")
 
 
 def test_two_map_scale_windows_in_one_batch(tmp_path):
