@@ -62,5 +62,8 @@ for V in "" "-DEAO_BENCH_EDITED_MAPPOINT"; do
   ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 $TMP/adapter_bench_san $TMP/problem.bin lba-walk | grep -o '"call_ms": [0-9.]*' | head -1
   echo "adapter_bench lba-walk ${V:-(unedited MapPoint)} exit code: ${PIPESTATUS[0]}"
 done
+echo "== 5. the host crew (eao_fusion_amd/csrc/host_crew.h: batch runs + polled sessions) under ThreadSanitizer (tests/cpp/host_crew_test.cpp)"
+g++ -std=c++17 -O1 -g -fsanitize=thread -pthread tests/cpp/host_crew_test.cpp -o $TMP/host_crew_tsan && TSAN_OPTIONS=halt_on_error=1 $TMP/host_crew_tsan
+echo "host_crew_test (TSan) exit code: $?"
 } 2>&1 | tee $OUT
 rm -rf $TMP
