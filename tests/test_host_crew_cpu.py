@@ -12,6 +12,7 @@ def test_host_crew_sessions_under_thread_sanitizer(tmp_path):
     cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", os.path.join(ROOT, "tests", "cpp", "host_crew_test.cpp"), "-o", exe],
                         capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr[-3000:]
-    run = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")}      # (tools/run_sanitizers.sh runs the suite under a preloaded ASan runtime: not in a TSan process)
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(env, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
     assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-4000:]
     assert "every chunk once" in run.stdout and "ThreadSanitizer" not in run.stderr
