@@ -66,6 +66,24 @@ def test_batch_matches_single_and_oracle(gpu, oracle):
         assert np.array_equal(desc[f], odesc), "frame %d descriptors" % f
 
 
+def test_host_batch_with_rows_narrower_than_the_device_pitch(gpu, oracle):
+    """Round 6: small host-API uploads are staged through a pinned buffer of the handle, row by row when the caller's stride is not the device pitch (752 px rows, 768 B
+    pitch) -- a batch of such frames against the oracle and against its own single-frame calls; then a batch too large for the staging buffer (the runtime's 2-D copy)."""
+    imgs = np.stack([synth.synth_frame(2100 + f, w=752, h=480, n_rect=250, n_small=1200) for f in range(3)])
+    ext = gpu.ORBextractor(800, 1.2, 8, 20, 7)
+    orc = oracle.OrbOracle(800, 1.2, 8, 20, 7)
+    kps, desc = ext.extract_batch(imgs)
+    for f in range(len(imgs)):
+        okps, odesc = orc.extract(imgs[f])
+        assert np.array_equal(kps[f], okps) and np.array_equal(desc[f], odesc), "frame %d" % f
+        k1, d1 = ext(imgs[f])
+        assert np.array_equal(k1, kps[f]) and np.array_equal(d1, desc[f]), "frame %d alone" % f
+    big = np.stack([imgs[f % 3] for f in range(24)])      # 24 x 768 x 480 B = 8.8 MB: beyond the staging buffer
+    kb, db = ext.extract_batch(big)
+    for f in range(len(big)):
+        assert np.array_equal(kb[f], kps[f % 3]) and np.array_equal(db[f], desc[f % 3]), "frame %d of the large batch" % f
+
+
 @pytest.mark.parametrize("cfg,shape", [((500, 1.2, 8, 20, 7), (480, 640)), ((2000, 1.2, 8, 20, 7), (376, 1241)),
                                        ((1200, 1.1, 4, 15, 5), (480, 752)), ((300, 1.5, 3, 30, 10), (240, 320))])
 def test_other_configurations(gpu, oracle, cfg, shape):
