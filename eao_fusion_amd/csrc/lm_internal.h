@@ -201,7 +201,7 @@ struct BAStatus {            // pinned host memory, written by k_ba_decide / k_b
 constexpr int kTileMaxFree = 30;
 constexpr int kTileThreads = 1024;
 struct TileGeom { int n, n4, R, Tr, Tc, nTiles; };
-constexpr int kBigMaxFree = 2048;
+constexpr int kBigMaxFree = 8192;
 constexpr int kBigNB = 32;
 struct BigGeom { int n, N, RP; };
 constexpr int kBigPairLong = 2048;

@@ -528,8 +528,8 @@ eao_status eao_local_ba_batch(const eao_ba_problem* problems, int32_t n, const v
  * ONE optimize(p->its_first) call (its_second is ignored), Huber kernels (delta sqrt(5.99) / sqrt(7.815), :94-95) only
  * when robust != 0, no outlier pass: r->edge_outlier may be NULL and comes back all zero, r->iters[1] = 0.
  * Up to 30 free keyframes run on the register-tile solver of eao_local_ba; beyond that (whole maps after a loop
- * closure, up to 2048 free keyframes) the reduced camera system is a dense lower triangle in HBM factorised by the whole
- * chip (csrc/lm.hip, k_bal_*); oversized windows of eao_local_ba take the same path. */
+ * closure, up to 8192 free keyframes) the reduced camera system is kept as block-sparse 64 x 64 tiles in HBM, in a nested-dissection
+ * order, and factorised by the whole chip (csrc/gba.hip, k_bal_*); oversized windows of eao_local_ba take the same path. */
 eao_status eao_bundle_adjustment(const eao_ba_problem* p, int32_t robust, const volatile uint8_t* stop, eao_ba_result* r);
 
 /* The MapPlane vertices / EdgePlane edges of the same function (src/Optimizer.cc:203-252; src/g2oAddition/VertexPlane.h,

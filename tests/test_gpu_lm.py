@@ -584,6 +584,26 @@ def test_map_scale_set_up_refuses_bad_edge_lists_the_same_way_on_any_crew(gpu, t
     _check_updates(b["points"], a["points"], p["points"], "points")
 
 
+def test_bundle_adjustment_beyond_2048_keyframes(gpu, monkeypatch):
+    """Round 6: the map-scale path takes up to 8192 free keyframes (2048 until then -- a limit nothing in the kernels needed).  No dense oracle at that size: a 2304-keyframe band
+    in the nested-dissection order the library chooses against the SAME map in natural keyframe order (the chain of rounds 3-5: another elimination order, another
+    rounding, the same system -- both orders are held to the oracle on smaller maps above), the LM schedule and the update bar; and the limit itself, loudly."""
+    p = synth.synth_ba(n_free=2304, n_fixed=1, n_points=36000, seed=5760, band=9)
+    a = gpu.Optimizer.BundleAdjustment(p, 4, bRobust=False)
+    monkeypatch.setenv("EAO_BA_ND", "1")
+    b = gpu.Optimizer.BundleAdjustment(p, 4, bRobust=False)
+    monkeypatch.delenv("EAO_BA_ND")
+    assert list(a["iters"]) == list(b["iters"]) == [4, 0] and list(a["trace"]["trials"]) == list(b["trace"]["trials"])
+    assert np.all(np.isfinite(a["poses"])) and np.all(np.isfinite(a["points"]))
+    assert a["trace"]["chi2"][-1] < a["trace"]["chi2"][0]
+    _check_updates(a["poses"], b["poses"], p["poses"], "poses")
+    _check_updates(a["points"], b["points"], p["points"], "points")
+    big = dict(p)
+    big["poses"] = np.ascontiguousarray(np.tile(p["poses"][:1], (8200, 1, 1))); big["fixed"] = np.zeros(8200, np.uint8)
+    with pytest.raises(Exception, match="at most 8192 free keyframes"):
+        gpu.Optimizer.BundleAdjustment(big, 1, bRobust=False)
+
+
 def test_two_map_scale_windows_in_one_batch(tmp_path):
     """Round 5 regression: the host-side panel tables of a map-scale window (which panel launches which work records) were thread-local to the set-up worker; a second
     map-scale window prepared by the SAME worker overwrote them before the first window's launches were enqueued, and the first window silently ran with the second
