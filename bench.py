@@ -429,6 +429,9 @@ def flat_scalars(roofline, extra):
         put(key.replace("_ms", "_c_abi_ms"), lambda c=call: cs[c]["c_abi_ms"])
     put("cs_lba_overhead_frac", lambda: cs["local_bundle_adjustment"]["adapter_overhead_frac_of_c_abi"])
     put("cs_lba_observations_ref_ms", lambda: cs["local_bundle_adjustment_with_accessors"]["call_ms"])
+    put("cs_map_ba_ms", lambda: cs["bundle_adjustment_map"]["call_ms"])
+    put("cs_map_ba_c_abi_ms", lambda: cs["bundle_adjustment_map"]["c_abi_ms"])
+    put("cs_map_ba_observations_ref_ms", lambda: cs["bundle_adjustment_map_with_accessors"]["call_ms"])
     gs, cg = extra.get("guided_searches", {}), extra.get("cpu_guided_searches", {})
     for name in ("search_by_bow_kf_frame", "search_by_bow_kf_kf", "search_for_triangulation", "fuse_search_pose"):
         put("gs_%s_ms" % name, lambda n=name: gs[n]["ms_per_call"])
@@ -1269,6 +1272,17 @@ def measure_class_surface(synth):
             out["local_bundle_adjustment_with_accessors"] = {"error": "g++: " + cc2.stderr[-300:]}
     except Exception as ex:  # noqa: BLE001
         out["local_bundle_adjustment_with_accessors"] = {"error": repr(ex)}
+    # Optimizer::BundleAdjustment over a whole map at the class surface (LoopClosing's call with its abort flag): the 1000-keyframe band, unedited MapPoint and row 2c's
+    try:
+        gmap = os.path.join(tmp, "map.bin")
+        if not os.path.exists(gmap):
+            mixed_load_inputs(tmp, synth)
+        for key, binary in (("bundle_adjustment_map", exe), ("bundle_adjustment_map_with_accessors", exe + "_edited")):
+            if os.path.exists(binary):
+                rg = subprocess.run([binary, gmap, "gba"], capture_output=True, text=True, timeout=300)
+                out[key] = json.loads(rg.stdout)["bundle_adjustment_map"] if rg.returncode == 0 else {"error": "rc %d: %s" % (rg.returncode, (rg.stdout + rg.stderr)[-300:])}
+    except Exception as ex:  # noqa: BLE001
+        out["bundle_adjustment_map"] = {"error": repr(ex)}
     out["note"] = ("tests/cpp/adapter_bench.cpp (g++ -O2, a process of its own): median wall time of each call through the reference's class signature, and the share of it inside the "
                    "C-ABI entry point the adapter makes (timed by a wrapper around that very call); adapter_overhead = flattening the object graph + writing the result back")
     return out

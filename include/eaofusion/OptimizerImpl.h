@@ -24,6 +24,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -210,6 +211,7 @@ struct LbaScratch {
         while (table[h].first && table[h].first != kf) h = (h + 1) & tableMask;
         return &table[h];
     }
+    const std::pair<KeyFrameT*, int32_t>* table_find(KeyFrameT* kf) const { return const_cast<LbaScratch*>(this)->table_find(kf); }
     void table_insert(KeyFrameT* kf, int32_t slot) {
         if (2 * (tableUsed + 1) > table.size()) {
             std::vector<std::pair<KeyFrameT*, int32_t> > old;
@@ -395,19 +397,30 @@ void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
 template <class MapPointT, class KeyFrameT, class MapPlaneT>
 void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<MapPointT*>& vpMP, const std::vector<MapPlaneT*>& vpMPl,
                       int nIterations = 5, bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true) {
-    // cameras / points in ascending mnId (g2o's vertex order); edges in upstream's insertion order (vpMP order, then the
-    // observation map's order)
+    // cameras / points in ascending mnId (g2o's vertex order).  Edges: point after point in ascending mnId, a point's observations in its map's order -- upstream walks
+    // vpMP, which Map::GetAllMapPoints() fills from a std::set<MapPoint*>: the order of the allocator's addresses, nothing a result may depend on; the ascending order
+    // is what lets the library's map-scale set-up run its parallel passes (csrc/lm_host.hip).
+    // Round 6: this walk was two std::map look-ups per edge, a map copy per point and three allocations per vertex -- ~0.4 us per edge in front of a 9 ms device call on a
+    // 1000-keyframe map; it now shares LocalBundleAdjustment's pieces (pointer table, id sort, the optional accessors of INTEGRATION.md row 2c).
+    typedef LbaScratch<KeyFrameT, MapPointT> Scratch;
+    static thread_local Scratch S;
     std::vector<KeyFrameT*> cams;
     for (KeyFrameT* kf : vpKFs) if (!kf->isBad()) cams.push_back(kf);
     std::sort(cams.begin(), cams.end(), [](KeyFrameT* a, KeyFrameT* b) { return a->mnId < b->mnId; });
     if (cams.empty()) return;
-    std::map<KeyFrameT*, int> camIndex;
-    for (size_t i = 0; i < cams.size(); i++) camIndex[cams[i]] = (int)i;
+    size_t cap = 256;
+    while (cap < 4 * cams.size()) cap *= 2;
+    S.table_reset(cap);
+    for (size_t i = 0; i < cams.size(); i++) S.table_insert(cams[i], (int32_t)i);
+    S.order.clear();
     std::vector<MapPointT*> pts;
-    for (MapPointT* mp : vpMP) if (!mp->isBad()) pts.push_back(mp);
-    std::sort(pts.begin(), pts.end(), [](MapPointT* a, MapPointT* b) { return a->mnId < b->mnId; });
-    std::map<MapPointT*, int> ptIndex;
-    for (size_t i = 0; i < pts.size(); i++) ptIndex[pts[i]] = (int)i;
+    for (MapPointT* mp : vpMP) if (!mp->isBad()) { S.order.push_back(std::make_pair((unsigned long)mp->mnId, (int32_t)pts.size())); pts.push_back(mp); }
+    detail::sort_by_id(S.order, S.orderTmp);
+    {
+        std::vector<MapPointT*> sorted(pts.size());
+        for (size_t i = 0; i < pts.size(); i++) sorted[i] = pts[S.order[i].second];
+        pts.swap(sorted);
+    }
     std::vector<float> camT(cams.size() * 16), xyz(pts.size() * 3), obs, inv;
     std::vector<uint8_t> camFixed(cams.size()), included(pts.size(), 0);
     std::vector<int32_t> eCam, ePt;
@@ -416,25 +429,59 @@ void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<Ma
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) camT[i * 16 + r * 4 + c] = T.template at<float>(r, c);
         camFixed[i] = cams[i]->mnId == 0 ? 1 : 0;                       // :91
     }
-    for (size_t i = 0; i < pts.size(); i++) {
-        const cv::Mat P = pts[i]->GetWorldPos();
-        for (int k = 0; k < 3; k++) xyz[i * 3 + k] = P.template at<float>(k);
+    // The read side of the walk -- a lock, a position and a std::map of observations per map point, a keypoint per observation: pointer chasing through the whole map,
+    // 30 ms on a 1000-keyframe map where the device call takes 9 -- runs on a few threads, each over a contiguous range of the (sorted) points: every accessor takes the
+    // object's own mutex exactly as on one thread, the keyframe table is read-only by now, and the ranges' edge lists are joined in order.
+    struct Append {
+        std::vector<typename Scratch::Obs>* obs;
+        void operator()(KeyFrameT* kf, size_t idx) { typename Scratch::Obs o = {kf, idx}; obs->push_back(o); }
+    };
+    struct Part { std::vector<int32_t> eCam, ePt; std::vector<float> obs, inv; std::vector<typename Scratch::Obs> seen; };
+    const size_t nPts = pts.size();
+    const int nWalk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::thread::hardware_concurrency() / 2), nPts / 4096));      // (a thread per 4096 points: starting one costs ~50 us)
+    std::vector<Part> parts((size_t)nWalk);
+    const Scratch* const table = &S;      // (S is thread_local: a helper thread must look the keyframes up in the CALLER's table, not in its own empty one)
+    auto walk = [&, table](int t) {
+        Part& Q = parts[(size_t)t];
+        const size_t i0 = nPts * (size_t)t / (size_t)nWalk, i1 = nPts * (size_t)(t + 1) / (size_t)nWalk;
+        Q.eCam.reserve((i1 - i0) * 7); Q.ePt.reserve((i1 - i0) * 7); Q.obs.reserve((i1 - i0) * 21); Q.inv.reserve((i1 - i0) * 7);
+        Append append = {&Q.seen};
+        for (size_t i = i0; i < i1; i++) {
+            detail::world_pos(pts[i], &xyz[i * 3], detail::HasWorldPosOut<MapPointT>());
+            Q.seen.clear();
+            detail::for_each_observation<KeyFrameT>(pts[i], append, detail::HasForEachObservation<MapPointT, KeyFrameT>());
+            for (size_t o = 0; o < Q.seen.size(); o++) {      // (outside the accessor: isBad() takes the keyframe's own mutex)
+                KeyFrameT* kf = Q.seen[o].kf;
+                const std::pair<KeyFrameT*, int32_t>* e = table->table_find(kf);
+                if (!e->first) continue;                                    // a keyframe outside vpKFs, or a bad one (:124; asked once per keyframe above, not once per
+                                                                            // edge: 325 000 round trips through a thousand mutexes, from several threads at once)
+                const size_t idx = Q.seen[o].idx;
+                const cv::KeyPoint& kpUn = kf->mvKeysUn[idx];
+                Q.eCam.push_back(e->second); Q.ePt.push_back((int32_t)i);
+                Q.obs.push_back(kpUn.pt.x); Q.obs.push_back(kpUn.pt.y); Q.obs.push_back(kf->mvuRight[idx]);
+                Q.inv.push_back(kf->mvInvLevelSigma2[kpUn.octave]);
+                included[i] = 1;                                            // nEdges != 0, :193-201
+            }
+        }
+    };
+    if (nWalk == 1) walk(0);
+    else {
+        std::vector<std::thread> helpers;
+        for (int t = 1; t < nWalk; t++) helpers.emplace_back(walk, t);
+        walk(0);
+        for (std::thread& h : helpers) h.join();
     }
-    for (MapPointT* mp : vpMP) {
-        if (mp->isBad()) continue;
-        const std::map<KeyFrameT*, size_t> seenBy = mp->GetObservations();
-        for (const auto& ob : seenBy) {
-            KeyFrameT* kf = ob.first;
-            if (kf->isBad()) continue;                                  // :124
-            auto ci = camIndex.find(kf);
-            if (ci == camIndex.end()) continue;                         // a keyframe outside vpKFs: upstream has no vertex for it
-            const cv::KeyPoint& kpUn = kf->mvKeysUn[ob.second];
-            eCam.push_back(ci->second); ePt.push_back(ptIndex[mp]);
-            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(kf->mvuRight[ob.second]);
-            inv.push_back(kf->mvInvLevelSigma2[kpUn.octave]);
-            included[ptIndex[mp]] = 1;                                  // nEdges != 0, :193-201
+    if (nWalk == 1) { eCam.swap(parts[0].eCam); ePt.swap(parts[0].ePt); obs.swap(parts[0].obs); inv.swap(parts[0].inv); }
+    else {
+        size_t nE = 0;
+        for (const Part& Q : parts) nE += Q.eCam.size();
+        eCam.reserve(nE); ePt.reserve(nE); obs.reserve(nE * 3); inv.reserve(nE);
+        for (const Part& Q : parts) {
+            eCam.insert(eCam.end(), Q.eCam.begin(), Q.eCam.end()); ePt.insert(ePt.end(), Q.ePt.begin(), Q.ePt.end());
+            obs.insert(obs.end(), Q.obs.begin(), Q.obs.end()); inv.insert(inv.end(), Q.inv.begin(), Q.inv.end());
         }
     }
+    auto cam_index = [&](KeyFrameT* kf) -> int32_t { const std::pair<KeyFrameT*, int32_t>* e = S.table_find(kf); return e->first ? e->second : -1; };
     // map planes (:210-252), in ascending mnId like their vertex ids
     std::vector<MapPlaneT*> planes;
     for (MapPlaneT* pl : vpMPl) if (pl && !pl->isBad()) planes.push_back(pl);
@@ -448,10 +495,10 @@ void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<Ma
         for (const auto& ob : seenBy) {
             KeyFrameT* kf = ob.first;
             if (kf->isBad()) continue;                                  // :231
-            auto ci = camIndex.find(kf);
-            if (ci == camIndex.end()) continue;                         // optimizer.vertex(pKFi->mnId) == NULL, :234-235
+            const int32_t ci = cam_index(kf);
+            if (ci < 0) continue;                                       // optimizer.vertex(pKFi->mnId) == NULL, :234-235
             const cv::Mat& c = kf->mvPlaneCoefficients[ob.second];
-            plEdgePlane.push_back((int32_t)i); plEdgeCam.push_back(ci->second);
+            plEdgePlane.push_back((int32_t)i); plEdgeCam.push_back(ci);
             for (int k = 0; k < 4; k++) plObs.push_back(c.template at<float>(k));
         }
     }
@@ -470,8 +517,8 @@ void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<Ma
     static_assert(sizeof(bool) == 1, "bool* abort flag is polled as a byte");
     check(eao_bundle_adjustment_planes(&P, planes.empty() ? nullptr : &PL, bRobust ? 1 : 0, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), &R,
                                        plOut.data()), "eao_bundle_adjustment_planes");
+    cv::Mat T(4, 4, CV_32F), X(3, 1, CV_32F);                           // (SetPose / SetWorldPos / copyTo copy their argument)
     for (size_t i = 0; i < cams.size(); i++) {                          // :258-275
-        cv::Mat T(4, 4, CV_32F);
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.template at<float>(r, c) = camOut[i * 16 + r * 4 + c];
         if (nLoopKF == 0) {
             cams[i]->SetPose(T);
@@ -483,7 +530,6 @@ void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<Ma
     }
     for (size_t i = 0; i < pts.size(); i++) {                           // :277-300
         if (!included[i]) continue;
-        cv::Mat X(3, 1, CV_32F);
         for (int k = 0; k < 3; k++) X.template at<float>(k) = xyzOut[i * 3 + k];
         if (nLoopKF == 0) {
             pts[i]->SetWorldPos(X);

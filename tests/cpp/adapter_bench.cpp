@@ -40,11 +40,7 @@ template <class... A> eao_status sbp_frames(A... a) { Scope s; return ::eao_sear
 template <class... A> eao_status sbow(A... a) { Scope s; return ::eao_search_by_bow(a...); }
 template <class... A> eao_status pose(A... a) { Scope s; return ::eao_pose_optimization(a...); }
 static bool stub_lba = false;      // `adapter_bench problem.bin lba-walk`: the library call replaced by an identity result -- the adapter's own walk, timed on a box without a GPU
-static int lba_points = 0, lba_edges = 0;      // what the adapter handed over: the points the LOCAL keyframes see (upstream's window), a little less than the generator's map
-inline eao_status lba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r) {
-    lba_points = p->n_points; lba_edges = p->n_edges;
-    Scope s;
-    if (!stub_lba) return ::eao_local_ba(p, stop, r);
+inline void dump_problem(const eao_ba_problem* p) {
     if (const char* dump = std::getenv("EAO_WALK_DUMP")) {      // tests/test_adapter_walk_cpu.py: the problem the adapter hands to the library, once
         static bool done = false;
         if (!done) {
@@ -58,13 +54,32 @@ inline eao_status lba(const eao_ba_problem* p, const volatile uint8_t* stop, eao
             f.write((const char*)p->edge_obs, sizeof(float) * 3 * (size_t)p->n_edges); f.write((const char*)p->edge_inv_sigma2, sizeof(float) * (size_t)p->n_edges);
         }
     }
+}
+static int lba_points = 0, lba_edges = 0;      // what the adapter handed over: the points the LOCAL keyframes see (upstream's window), a little less than the generator's map
+inline eao_status lba(const eao_ba_problem* p, const volatile uint8_t* stop, eao_ba_result* r) {
+    lba_points = p->n_points; lba_edges = p->n_edges;
+    Scope s;
+    if (!stub_lba) return ::eao_local_ba(p, stop, r);
+    dump_problem(p);
     std::memcpy(r->cam_Tcw, p->cam_Tcw, sizeof(float) * 16 * (size_t)p->n_cams);
     std::memcpy(r->points, p->points, sizeof(float) * 3 * (size_t)p->n_points);
     std::memset(r->edge_outlier, 0, (size_t)p->n_edges);
     r->aborted = 0; r->iters[0] = r->iters[1] = 0; r->chi2[0] = r->chi2[1] = 0;
     return EAO_OK;
 }
+static int gba_points = 0, gba_edges = 0;
+inline eao_status gba(const eao_ba_problem* p, const eao_ba_planes* pl, int32_t robust, const volatile uint8_t* stop, eao_ba_result* r, float* planes_out) {
+    gba_points = p->n_points; gba_edges = p->n_edges;
+    Scope s;
+    if (!stub_lba) return ::eao_bundle_adjustment_planes(p, pl, robust, stop, r, planes_out);
+    dump_problem(p);
+    std::memcpy(r->cam_Tcw, p->cam_Tcw, sizeof(float) * 16 * (size_t)p->n_cams);
+    std::memcpy(r->points, p->points, sizeof(float) * 3 * (size_t)p->n_points);
+    r->aborted = 0; r->iters[0] = r->iters[1] = 0; r->chi2[0] = r->chi2[1] = 0;
+    return EAO_OK;
+}
 }  // namespace cabi
+#define eao_bundle_adjustment_planes cabi::gba
 #define eao_orb_extract_ref cabi::orb_extract
 #define eao_orb_pyramid cabi::orb_pyramid
 #define eao_search_by_projection_points cabi::sbp_points
@@ -82,6 +97,7 @@ inline eao_status lba(const eao_ba_problem* p, const volatile uint8_t* stop, eao
 #undef eao_search_by_bow
 #undef eao_pose_optimization
 #undef eao_local_ba
+#undef eao_bundle_adjustment_planes
 
 // ---- stand-ins: the members the adapters touch, with upstream's locking / cloning behaviour (src/MapPoint.cc:68-91, 385-394; src/KeyFrame.cc:74-107, 268-300)
 struct KeyFrame;
@@ -107,6 +123,17 @@ struct MapPoint {
 #endif
     void EraseObservation(KeyFrame* kf) { std::unique_lock<std::mutex> l(mMutexFeatures); mObservations.erase(kf); }
     void UpdateNormalAndDepth() {}
+    cv::Mat mPosGBA;                              // Optimizer::BundleAdjustment with nLoopKF != 0
+    long unsigned int mnBAGlobalForKF = 0;
+};
+struct MapPlane {                                 // (the map of the bench holds none: the members Optimizer::BundleAdjustment's template names)
+    long unsigned int mnId = 0, mnBAGlobalForKF = 0;
+    cv::Mat mWorldPos, mPosGBA;
+    std::map<KeyFrame*, int> mObservations;
+    bool isBad() { return false; }
+    cv::Mat GetWorldPos() { return mWorldPos.clone(); }
+    void SetWorldPos(const cv::Mat& p) { p.copyTo(mWorldPos); }
+    std::map<KeyFrame*, int> GetObservations() { return mObservations; }
 };
 std::mutex MapPoint::mGlobalMutex;
 
@@ -121,6 +148,9 @@ struct KeyFrame {
     std::map<unsigned, std::vector<unsigned> > mFeatVec;
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<KeyFrame*> mvpOrderedConnectedKeyFrames;
+    std::vector<cv::Mat> mvPlaneCoefficients;
+    cv::Mat mTcwGBA;
+    long unsigned int mnBAGlobalForKF = 0;
     bool isBad() { std::unique_lock<std::mutex> l(mMutexConnections); return false; }
     cv::Mat GetPose() { std::unique_lock<std::mutex> l(mMutexPose); return Tcw.clone(); }
     void SetPose(const cv::Mat& T) { std::unique_lock<std::mutex> l(mMutexPose); T.copyTo(Tcw); }
@@ -183,8 +213,72 @@ static void emit(const char* name, const Stat& s, const char* more, bool last = 
                 s.call_ms - s.cabi_ms, s.cabi_ms > 0 ? (s.call_ms - s.cabi_ms) / s.cabi_ms : 0.0, more[0] ? ", " : "", more, last ? "" : ",");
 }
 
+// `adapter_bench <map.bin> gba` (or gba-walk: the library call replaced by an identity result): the whole-map call alone
+static int map_section(const char* path) {
+    // ------------------------------------------------------------------ Optimizer::BundleAdjustment(vpKFs, vpMP, vpMPl, 10, &stop, nLoopKF, false) over a whole map
+    // (argv[3] = the flat map of bench.py's mixed_load_inputs: LoopClosing::RunGlobalBundleAdjustment's call, src/LoopClosing.cc:594 -> src/Optimizer.cc:47-323)
+    {
+        std::ifstream mf(path, std::ios::binary);
+        if (!mf) return 2;
+        int32_t hdr[5];
+        rd(mf, hdr, 5);
+        const int nc = hdr[0], np = hdr[1], ne = hdr[2];
+        const std::vector<float> poses = rdv<float>(mf, 16 * (size_t)nc);
+        const std::vector<uint8_t> fixed = rdv<uint8_t>(mf, nc);
+        const std::vector<float> pts = rdv<float>(mf, 3 * (size_t)np);
+        const std::vector<int32_t> ecam = rdv<int32_t>(mf, ne), ept = rdv<int32_t>(mf, ne);
+        const std::vector<float> obs = rdv<float>(mf, 3 * (size_t)ne), inv = rdv<float>(mf, ne);
+        float K[5];
+        rd(mf, K, 5);
+        std::vector<KeyFrame> kfs(nc);
+        std::vector<MapPoint> mps(np);
+        std::vector<KeyFrame*> vk; std::vector<MapPoint*> vm; std::vector<MapPlane*> vpl;
+        auto build = [&] {
+            for (int c = 0; c < nc; c++) {
+                KeyFrame& k = kfs[c];
+                k.mnId = fixed[c] ? 0 : (unsigned long)c + 1;      // (upstream fixes the keyframe with mnId 0, src/Optimizer.cc:91)
+                k.fx = K[0]; k.fy = K[1]; k.cx = K[2]; k.cy = K[3]; k.mbf = K[4];
+                k.Tcw = mat44(&poses[16 * (size_t)c]);
+                k.mvKeysUn.clear(); k.mvuRight.clear(); k.mvInvLevelSigma2.clear();
+            }
+            for (int p = 0; p < np; p++) { mps[p].mnId = p; mps[p].mWorldPos = colN(&pts[3 * (size_t)p], 3); mps[p].mObservations.clear(); }
+            for (int e = 0; e < ne; e++) {
+                KeyFrame& k = kfs[ecam[e]];
+                cv::KeyPoint kp;
+                kp.pt.x = obs[3 * (size_t)e]; kp.pt.y = obs[3 * (size_t)e + 1]; kp.octave = (int)k.mvKeysUn.size();
+                mps[ept[e]].mObservations[&k] = k.mvKeysUn.size();
+                k.mvKeysUn.push_back(kp); k.mvuRight.push_back(obs[3 * (size_t)e + 2]); k.mvInvLevelSigma2.push_back(inv[e]);
+            }
+            vk.clear(); vm.clear();
+            for (int c = 0; c < nc; c++) vk.push_back(&kfs[c]);
+            for (int p = 0; p < np; p++) vm.push_back(&mps[(size_t)((long long)p * 7919 % np)]);      // (Map::GetAllMapPoints: the order of a std::set of pointers -- any order)
+        };
+        bool stop = false;
+        std::vector<double> tc, ti;
+        for (int r = 0; r < 2 + 5; r++) {
+            build();
+            cabi::inside_ns = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            eaofusion::BundleAdjustment(vk, vm, vpl, 10, &stop, 0, false);
+            const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+            if (r >= 2) { tc.push_back(ns); ti.push_back(cabi::inside_ns); }
+        }
+        std::sort(tc.begin(), tc.end()); std::sort(ti.begin(), ti.end());
+        const Stat s = {tc[tc.size() / 2] * 1e-6, ti[ti.size() / 2] * 1e-6};
+        char more[384];
+        std::snprintf(more, sizeof more, "\"keyframes\": %d, \"map_points\": %d, \"edges\": %d, \"problem_points\": %d, \"problem_edges\": %d", nc, np, ne, cabi::gba_points, cabi::gba_edges);
+        std::printf("{\n  \"bundle_adjustment_map\": {\"call_ms\": %.4f, \"c_abi_ms\": %.4f, \"adapter_overhead_ms\": %.4f, %s}\n}\n", s.call_ms, s.cabi_ms, s.call_ms - s.cabi_ms, more);
+    }
+    return 0;
+
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
+    if (argc > 2 && (std::string(argv[2]) == "gba" || std::string(argv[2]) == "gba-walk")) {
+        cabi::stub_lba = std::string(argv[2]) == "gba-walk";
+        return map_section(argv[1]);
+    }
     cabi::stub_lba = argc > 2 && std::string(argv[2]) == "lba-walk";
     g_lbaOnly = cabi::stub_lba || (argc > 2 && std::string(argv[2]) == "lba");
     std::ifstream in(argv[1], std::ios::binary);
