@@ -11,12 +11,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("edited", [False, True], ids=["upstream_accessors", "row_2c_accessors"])
-def test_map_adapter_flattens_the_map_in_ascending_order(tmp_path, edited):
+@pytest.mark.parametrize("edited,n_points,tsan", [(False, 2500, False), (True, 2500, False), (True, 13000, True)],
+                         ids=["upstream_accessors", "row_2c_accessors", "three_walk_threads_under_tsan"])
+def test_map_adapter_flattens_the_map_in_ascending_order(tmp_path, edited, n_points, tsan):
+    """(third case: 13 000 map points = three threads on the read side of the walk, the binary built with -fsanitize=thread: the stand-ins lock as upstream's classes do, the
+    adapter must not add a race of its own)"""
     import sys
     sys.path.insert(0, ROOT)
     from eao_fusion_amd import synth
-    p = synth.synth_ba(n_free=60, n_fixed=1, n_points=2500, seed=5770, band=7)
+    p = synth.synth_ba(n_free=60, n_fixed=1, n_points=n_points, seed=5770, band=7)
     path = str(tmp_path / "map.bin")
     with open(path, "wb") as f:
         f.write(struct.pack("<iiiii", len(p["poses"]), len(p["points"]), len(p["edge_cam"]), 10, 0))
@@ -25,13 +28,14 @@ def test_map_adapter_flattens_the_map_in_ascending_order(tmp_path, edited):
         f.write(np.asarray([p[k] for k in ("fx", "fy", "cx", "cy", "bf")], np.float32).tobytes())
     exe = str(tmp_path / "adapter_bench")
     lib = os.path.join(ROOT, "eao_fusion_amd")
-    cc = subprocess.run(["g++", "-O1", "-std=c++17", "-DEAOFUSION_FORCE_CV_COMPAT"] + (["-DEAO_BENCH_EDITED_MAPPOINT"] if edited else []) +
+    cc = subprocess.run(["g++", "-O1", "-std=c++17", "-DEAOFUSION_FORCE_CV_COMPAT"] + (["-DEAO_BENCH_EDITED_MAPPOINT"] if edited else []) + (["-g", "-fsanitize=thread"] if tsan else []) +
                         ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_bench.cpp"), "-o", exe, "-L", lib, "-leaofusion_hip",
                          "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-pthread"], capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr[-2000:]
     dump = str(tmp_path / "walk.bin")
-    run = subprocess.run([exe, path, "gba-walk"], capture_output=True, text=True, env=dict(os.environ, EAO_WALK_DUMP=dump), timeout=300)
-    assert run.returncode == 0, run.stdout[-500:] + run.stderr[-1500:]
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")} if tsan else dict(os.environ)
+    run = subprocess.run([exe, path, "gba-walk"], capture_output=True, text=True, env=dict(env, EAO_WALK_DUMP=dump, TSAN_OPTIONS="halt_on_error=1"), timeout=600)
+    assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr, run.stdout[-500:] + run.stderr[-3000:]
     raw = open(dump, "rb").read()
     nc, npt, ne = np.frombuffer(raw, np.int32, 3)
     off = 12
