@@ -328,8 +328,8 @@ def test_bundle_adjustment_with_planes(gpu, oracle, kw, pk, its, robust):
 
 
 def test_bundle_adjustment_limits(gpu):
-    p = synth.synth_ba(n_free=2049, n_fixed=1, n_points=60, seed=5104)
-    with pytest.raises(gpu.EaoError):            # beyond the map-scale path's 2048 free keyframes: refused, not approximated
+    p = synth.synth_ba(n_free=8193, n_fixed=1, n_points=60, seed=5104)
+    with pytest.raises(gpu.EaoError):            # beyond the map-scale path's 8192 free keyframes (2048 until round 6): refused, not approximated
         gpu.Optimizer.BundleAdjustment(p, 10, bRobust=False)
     p = synth.synth_ba(n_free=4, n_fixed=1, n_points=100, seed=5105)
     r = gpu.Optimizer.BundleAdjustment(p, 10, stop=np.array([1], np.uint8))
