@@ -69,6 +69,17 @@ typename std::enable_if<has_planes<FrameT>::value>::type store_planes(FrameT* pF
 template <class FrameT>
 typename std::enable_if<!has_planes<FrameT>::value>::type store_planes(FrameT*, const PlaneEdges&, const std::vector<uint8_t>&) {}
 
+// the world position of a map point without a cv::Mat clone when the checkout carries the optional accessor of INTEGRATION.md row 2c (GetWorldPos(float*)), upstream's otherwise
+namespace detail {
+template <class MP, class = void> struct HasWorldPosOut : std::false_type {};
+template <class MP> struct HasWorldPosOut<MP, decltype(std::declval<MP&>().GetWorldPos(static_cast<float*>(nullptr)), void())> : std::true_type {};
+template <class MP> void world_pos(MP* mp, float* xyz, std::true_type) { mp->GetWorldPos(xyz); }
+template <class MP> void world_pos(MP* mp, float* xyz, std::false_type) {
+    const cv::Mat P = mp->GetWorldPos();
+    for (int k = 0; k < 3; k++) xyz[k] = P.template at<float>(k);
+}
+}  // namespace detail
+
 // ---- Optimizer::PoseOptimization(Frame*) --------------------------------------------------------------------
 // The flattened problem of one frame and what is needed to write its result back.
 struct PoseJob {
@@ -93,9 +104,10 @@ bool gather_pose(FrameT* pFrame, PoseJob& j) {
             if (!pMP) continue;
             pFrame->mvbOutlier[i] = false;
             const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
-            const cv::Mat P = pMP->GetWorldPos();
+            float xyz[3];
+            detail::world_pos(pMP, xyz, detail::HasWorldPosOut<MapPointT>());
             j.slot.push_back(i);
-            j.Xw.push_back(P.template at<float>(0)); j.Xw.push_back(P.template at<float>(1)); j.Xw.push_back(P.template at<float>(2));
+            j.Xw.push_back(xyz[0]); j.Xw.push_back(xyz[1]); j.Xw.push_back(xyz[2]);
             j.obs.push_back(kpUn.pt.x); j.obs.push_back(kpUn.pt.y); j.obs.push_back(pFrame->mvuRight[i]);   // < 0 => monocular edge
             j.inv.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
         }
@@ -127,7 +139,8 @@ int store_pose(FrameT* pFrame, const PoseJob& j) {
 
 template <class MapPointT, class FrameT>
 int PoseOptimization(FrameT* pFrame) {
-    PoseJob j;
+    static thread_local PoseJob j;      // (its vectors keep their capacity: nothing is allocated per frame after the first)
+    j.slot.clear(); j.Xw.clear(); j.obs.clear(); j.inv.clear(); j.pe.slot.clear(); j.pe.world.clear(); j.pe.obs.clear(); j.pe.seen.clear();
     if (!gather_pose<MapPointT>(pFrame, j)) return 0;
     check(eao_pose_optimization(&j.P, &j.R), "eao_pose_optimization");
     return store_pose(pFrame, j);
@@ -169,17 +182,10 @@ namespace detail {
 template <class MP, class KF, class = void> struct HasForEachObservation : std::false_type {};
 template <class MP, class KF>
 struct HasForEachObservation<MP, KF, decltype(std::declval<MP&>().ForEachObservation(std::declval<void (*)(KF*, size_t)>()), void())> : std::true_type {};
-template <class MP, class = void> struct HasWorldPosOut : std::false_type {};
-template <class MP> struct HasWorldPosOut<MP, decltype(std::declval<MP&>().GetWorldPos(static_cast<float*>(nullptr)), void())> : std::true_type {};
 template <class KF, class MP, class F> void for_each_observation(MP* mp, F& f, std::true_type) { mp->ForEachObservation(f); }
 template <class KF, class MP, class F> void for_each_observation(MP* mp, F& f, std::false_type) {
     const std::map<KF*, size_t> seenBy = mp->GetObservations();      // the ONE copy per point (upstream: two, src/Optimizer.cc:725, :836)
     for (typename std::map<KF*, size_t>::const_iterator it = seenBy.begin(); it != seenBy.end(); ++it) f(it->first, it->second);
-}
-template <class MP> void world_pos(MP* mp, float* xyz, std::true_type) { mp->GetWorldPos(xyz); }
-template <class MP> void world_pos(MP* mp, float* xyz, std::false_type) {
-    const cv::Mat P = mp->GetWorldPos();
-    for (int k = 0; k < 3; k++) xyz[k] = P.template at<float>(k);
 }
 }  // namespace detail
 
