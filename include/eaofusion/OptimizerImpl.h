@@ -406,8 +406,8 @@ void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<Ma
     // cameras / points in ascending mnId (g2o's vertex order).  Edges: point after point in ascending mnId, a point's observations in its map's order -- upstream walks
     // vpMP, which Map::GetAllMapPoints() fills from a std::set<MapPoint*>: the order of the allocator's addresses, nothing a result may depend on; the ascending order
     // is what lets the library's map-scale set-up run its parallel passes (csrc/lm_host.hip).
-    // Round 6: this walk was two std::map look-ups per edge, a map copy per point and three allocations per vertex -- ~0.4 us per edge in front of a 9 ms device call on a
-    // 1000-keyframe map; it now shares LocalBundleAdjustment's pieces (pointer table, id sort, the optional accessors of INTEGRATION.md row 2c).
+    // Round 6: this walk was two std::map look-ups per edge, a map copy per point and three allocations per vertex -- 89 ms in front of a 12 ms library call on a
+    // 1000-keyframe map (101 ms in all; 27 ms now); it now shares LocalBundleAdjustment's pieces (pointer table, id sort, the optional accessors of INTEGRATION.md row 2c).
     typedef LbaScratch<KeyFrameT, MapPointT> Scratch;
     static thread_local Scratch S;
     std::vector<KeyFrameT*> cams;

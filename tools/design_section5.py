@@ -66,7 +66,7 @@ def main():
         ("... over a `MapPoint` with the two optional accessors (INTEGRATION.md row 2c)", "%.3f ms (C-ABI %.3f)" % (
             rf["cs_lba_observations_ref_ms"], ex["class_surface"]["local_bundle_adjustment_with_accessors"]["c_abi_ms"]), "≤ 1.3 with the edit", "″, built with `-DEAO_BENCH_EDITED_MAPPOINT`"),
         ("class surface `Optimizer::BundleAdjustment`, 1000 KF × 50 k MP map with LoopClosing's abort flag", "%.1f ms (C-ABI %.2f)" % (
-            rf.get("cs_map_ba_ms", float("nan")), rf.get("cs_map_ba_c_abi_ms", float("nan"))), "— (the walk alone was 150 ms)", "`adapter_bench <map.bin> gba`"),
+            rf.get("cs_map_ba_ms", float("nan")), rf.get("cs_map_ba_c_abi_ms", float("nan"))), "— (101 ms with round 5's adapter)", "`adapter_bench <map.bin> gba`"),
         ("class surface `SearchByProjection` ×2 / `SearchByBoW`", "%.4f / %.4f / %.4f ms (C-ABI %.4f / %.4f / %.4f)" % (
             rf["cs_sbp_local_map_ms"], rf["cs_sbp_last_frame_ms"], rf["cs_sbow_ms"], rf["cs_sbp_local_map_c_abi_ms"], rf["cs_sbp_last_frame_c_abi_ms"], rf["cs_sbow_c_abi_ms"]), "—", "″"),
     ]
