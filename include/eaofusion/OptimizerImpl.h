@@ -24,6 +24,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -473,8 +474,12 @@ void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<Ma
     if (nWalk == 1) walk(0);
     else {
         std::vector<std::thread> helpers;
-        for (int t = 1; t < nWalk; t++) helpers.emplace_back(walk, t);
+        int started = 1;
+        for (; started < nWalk; started++) {
+            try { helpers.emplace_back(walk, started); } catch (const std::system_error&) { break; }      // (no thread to be had: the caller walks the remaining ranges itself)
+        }
         walk(0);
+        for (int t = started; t < nWalk; t++) walk(t);
         for (std::thread& h : helpers) h.join();
     }
     if (nWalk == 1) { eCam.swap(parts[0].eCam); ePt.swap(parts[0].ePt); obs.swap(parts[0].obs); inv.swap(parts[0].inv); }
