@@ -320,6 +320,8 @@ CASES = {
     "lba_small_mono": _lba_case(n_free=5, n_fixed=2, n_points=300, mono_frac=0.4, seed=3001),
     "gba_points": _gba_case(0, 10, False, n_free=6, n_fixed=3, n_points=400, seed=3100, mono_frac=0.2),
     "gba_planes": _gba_case(4, 10, True, n_free=6, n_fixed=3, n_points=400, seed=3100, mono_frac=0.2),
+    # round 6: a map beyond the register-tile solver -- 60 keyframes on a band, the map-scale path (block-sparse tiles, nested-dissection order) against the oracle's dense solve
+    "gba_map_band60": _gba_case(0, 6, False, n_free=60, n_fixed=1, n_points=2400, seed=5780, band=7),
     "search_tracking": _tracking_searches,
     "search_guided": _guided_searches,
     "frame_glue": _frame_glue,
